@@ -1,0 +1,200 @@
+/*
+ * remd_hip.h — C ABI of libremd_hip.so, the MI355X (gfx950) replica-exchange engine.
+ *
+ * This is the drop-in boundary for ONE hot path of choderalab/openmmtools: the
+ * replica-exchange iteration  mix -> propagate -> u_kl
+ * (reference: openmmtools/multistate/multistatesampler.py:766-804).
+ * The reference has no FFI; its narrowest seam is the three overridable hooks
+ *   MultiStateSampler._mix_replicas        (multistatesampler.py:1500, replicaexchange.py:255, sams.py:395)
+ *   MultiStateSampler._propagate_replicas  (multistatesampler.py:1287)
+ *   MultiStateSampler._compute_energies    (multistatesampler.py:1436)
+ * plus the ContextCache attributes (multistatesampler.py:1755-1764).  Each entry point
+ * below names the reference interface it replaces.  See INTEGRATION.md for the ctypes
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; remd_last_error() gives text
+ *   - plain pointers and sizes only; host pointers unless the name starts with d_
+ *   - units: nm, ps, amu, kJ/mol, elementary charge (OpenMM's md_unit_system)
+ *   - one handle per GPU / rank; a handle is not thread-safe, distinct handles are
+ *   - all kernels are launched on the stream given at creation (NULL = default stream)
+ *   - random numbers: counter-based Philox4x32-10, key = seed, counters documented
+ *     per entry point (DESIGN.md "RNG stream spec"); results do not depend on how
+ *     replicas are sharded over ranks
+ */
+#ifndef REMD_HIP_H
+#define REMD_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct remd_ctx* remd_handle;
+
+/* nonbonded methods (mirror openmm.NonbondedForce enum subset the configs use) */
+#define REMD_NB_NONE            0
+#define REMD_NB_CUTOFF_PERIODIC 1   /* reaction field */
+#define REMD_NB_PME             2
+
+/* mixing schemes (replicaexchange.py:265-283, sams.py:410-417) */
+#define REMD_MIX_NONE           0
+#define REMD_MIX_SWAP_ALL       1
+#define REMD_MIX_SWAP_NEIGHBORS 2
+#define REMD_MIX_SAMS_GLOBAL    3
+
+/*
+ * Flat description of an openmm.System restricted to the force classes the five
+ * benchmark test systems use (testsystems.py:685-840, 1872-2030, 3465-3527,
+ * 3789-3857, 3863-3923).  All arrays are host memory, read during remd_set_system.
+ */
+typedef struct remd_system_desc {
+    int32_t n_atoms;
+    const double* mass;             /* [N] amu                                           */
+
+    /* CustomExternalForce of testsystems.HarmonicOscillator (testsystems.py:779-786):
+       U = K/2 ((x-x0)^2 + y^2 + z^2) + U0 on the listed atoms                           */
+    int32_t n_ext;
+    const int32_t* ext_atoms;       /* [n_ext]                                           */
+    double ext_K, ext_x0, ext_U0;
+
+    /* HarmonicBondForce / HarmonicAngleForce / PeriodicTorsionForce                     */
+    int32_t n_bonds;    const int32_t* bond_atoms;    const double* bond_params;    /* [n][2]; [n][2] = r0, k            */
+    int32_t n_angles;   const int32_t* angle_atoms;   const double* angle_params;   /* [n][3]; [n][2] = theta0, k        */
+    int32_t n_torsions; const int32_t* torsion_atoms; const double* torsion_params; /* [n][4]; [n][3] = n, phase, k      */
+
+    /* NonbondedForce                                                                     */
+    int32_t nb_method;              /* REMD_NB_*                                         */
+    double cutoff;                  /* nm                                                */
+    double switch_distance;         /* nm, <= 0: no switching function                   */
+    double rf_dielectric;           /* reaction-field solvent dielectric (78.3)          */
+    double ewald_alpha;             /* 1/nm (PME)                                        */
+    int32_t pme_grid[3];            /* PME mesh (each a product of 2,3,5; <= 256)        */
+    int32_t use_dispersion_correction;
+    const double* charge;           /* [N] e                                             */
+    const double* sigma;            /* [N] nm                                            */
+    const double* epsilon;          /* [N] kJ/mol                                        */
+    int32_t n_exceptions;
+    const int32_t* exception_atoms; /* [n][2]                                            */
+    const double* exception_params; /* [n][3] = chargeProd, sigma, epsilon               */
+
+    /* constraints: rigid 3-site waters (SETTLE) and X-H clusters (SHAKE)                */
+    int32_t n_settle;
+    const int32_t* settle_atoms;    /* [n][3] = O, H1, H2                                */
+    double settle_dOH, settle_dHH;  /* nm                                                */
+    int32_t n_shake;
+    const int32_t* shake_atoms;     /* [n][4] = heavy, h1, h2|-1, h3|-1                  */
+    const double* shake_dist;       /* [n][3] nm                                         */
+
+    int32_t cmm_frequency;          /* CMMotionRemover frequency in steps, 0 = absent    */
+
+    /* AbsoluteAlchemicalFactory region (alchemy.py:417-427, 1356-1390): soft-core LJ on
+       alchemical/non-alchemical pairs; alchemical atoms must be uncharged or use PME
+       'exact' treatment (charge scaling by lambda_electrostatics)                       */
+    int32_t n_alch;
+    const int32_t* alch_atoms;      /* [n_alch]                                          */
+    double softcore_alpha, softcore_a, softcore_b, softcore_c;
+} remd_system_desc;
+
+/* ---- lifetime -------------------------------------------------------------------- */
+/* Replaces cache.ContextCache construction (cache.py:313-346): one batched device-state
+   pool per GPU.  stream: a hipStream_t (as void*) or NULL.                              */
+int  remd_create(remd_handle* out, int device, void* stream);
+int  remd_destroy(remd_handle h);
+const char* remd_last_error(remd_handle h);   /* h may be NULL: last global error         */
+int  remd_version(void);
+
+/* ---- set-up (reference: MultiStateSampler._pre_write_create, multistatesampler.py:836-926) */
+int  remd_set_system(remd_handle h, const remd_system_desc* desc);
+
+/* K thermodynamic states: beta [1/(kJ/mol)], lambda_sterics, lambda_electrostatics, and an
+   additive potential-energy constant per state in kJ/mol (e.g. the lambda-dependent
+   long-range correction of the alchemical CustomNonbondedForce).  Arrays may be NULL
+   (lambda = 1, const = 0).  Reference: states.py:1908-1917 (reduced potential),
+   paralleltempering.py:206-215, states.py:911-992.                                      */
+int  remd_set_states(remd_handle h, int K, const double* beta,
+                     const double* lambda_sterics, const double* lambda_electrostatics,
+                     const double* energy_const);
+
+/* LangevinIntegrator (integrators.py:1071-1158) as used by
+   mcmc.LangevinSplittingDynamicsMove (mcmc.py:1280-1316): splitting string of V/R/O tokens. */
+int  remd_set_integrator(remd_handle h, const char* splitting, double timestep_ps,
+                         double collision_rate_invps, int n_steps,
+                         int reassign_velocities, double constraint_tolerance);
+
+/* Replicas r_begin .. r_begin+R_local-1 of R_global live on this handle.
+   x, v: [R_local][N][3] (v may be NULL -> zero); box: [R_local][3] orthorhombic edge
+   lengths; labels: [R_global] state index of every replica.
+   Reference: SamplerState.apply_to_context (states.py:2257-2279).                       */
+int  remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local,
+                       const double* x, const double* v, const double* box,
+                       const int64_t* labels);
+int  remd_set_labels(remd_handle h, const int64_t* labels /*[R_global]*/);
+int  remd_seed(remd_handle h, uint64_t seed);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* Replaces MultiStateSampler._propagate_replicas (multistatesampler.py:1287-1337) and
+   BaseIntegratorMove.apply (mcmc.py:668-776) for every local replica at once: optional
+   Maxwell-Boltzmann velocity reassignment, n_steps of the splitting, NaN flag per replica.
+   nan_flags: host [R_local] or NULL.                                                     */
+int  remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags);
+
+/* Replaces MultiStateSampler._compute_energies / _compute_replica_energies
+   (multistatesampler.py:1436-1494; paralleltempering.py:175-215): rows r_begin.. of the
+   reduced-potential matrix.  d_ukl_rows: DEVICE [R_local][K] f64, or NULL to use the
+   handle's own full [R_global][K] matrix (rows written in place).  ukl_host: host
+   [R_local][K] copy or NULL.  potential_host: host [R_local] kJ/mol or NULL.            */
+int  remd_compute_energies(remd_handle h, double* d_ukl_rows, double* ukl_host,
+                           double* potential_host);
+
+/* Device address of the handle's own [R_global][K] u_kl matrix (for RCCL all-gather
+   through torch.distributed on an aliasing tensor).                                     */
+int  remd_ukl_device_ptr(remd_handle h, double** d_ukl);
+
+/* Replaces ReplicaExchangeSampler._mix_replicas (replicaexchange.py:255-292),
+   _mix_all_replicas_numba (:294-349), _mix_neighboring_replicas (:366-380) and
+   SAMSSampler._global_jump (sams.py:477-501).
+   d_ukl: DEVICE [R][ld] (first K columns are the sampled states; ld >= K, 0 means K) or
+   NULL = the handle's own matrix.  labels: host [R] in/out.
+   n_accepted / n_proposed: host [K][K], overwritten (the reference zeroes them per call).
+   log_weights: host [K] (SAMS) or NULL.  sams_log_P: host [R][K] out (SAMS) or NULL.    */
+int  remd_mix(remd_handle h, int scheme, int64_t iteration, int R, int K,
+              const double* d_ukl, int ld, int64_t* labels,
+              int64_t* n_accepted, int64_t* n_proposed,
+              const double* log_weights, double* sams_log_P);
+
+/* Stand-alone mixing on a host u_kl (copied to the device first): what a caller that
+   only wants the Gibbs swap kernel binds (the reference's test_mixing.py:11-46 shape).  */
+int  remd_mix_host(remd_handle h, int scheme, int64_t iteration, int R, int K,
+                   const double* ukl_host, int64_t* labels,
+                   int64_t* n_accepted, int64_t* n_proposed,
+                   const double* log_weights, double* sams_log_P, int64_t n_attempts);
+
+/* ---- snapshots / test hooks --------------------------------------------------------- */
+/* Replaces SamplerState.update_from_context (mcmc.py:731-773, states.py:2431-2490).
+   Any pointer may be NULL.  x, v: [R_local][N][3]; potential, kinetic: [R_local].       */
+int  remd_get_replicas(remd_handle h, double* x, double* v, double* potential, double* kinetic);
+/* forces in kJ/mol/nm, [R_local][N][3] (evaluates them first)                           */
+int  remd_get_forces(remd_handle h, double* f);
+/* run a splitting string once per call on all local replicas with explicit step counter
+   (test hook: single V / R / O substeps).                                               */
+int  remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t first_step, int n_steps);
+int  remd_sync(remd_handle h);
+
+/* timing of the last remd_propagate / compute_energies / mix on the handle's stream,
+   measured with hipEvents (ms)                                                           */
+int  remd_last_timing(remd_handle h, double* propagate_ms, double* energies_ms, double* mix_ms);
+
+/* dominant-kernel accounting for bench.py's roofline object: number of launches and
+   summed duration (ms, hipEvent-bracketed) of the named kernel class since the last reset.
+   Only collected when profiling is enabled (adds event overhead).                        */
+int  remd_profile_enable(remd_handle h, int on);
+int  remd_profile_get(remd_handle h, const char* kernel_class, int64_t* n_launches, double* total_ms);
+int  remd_profile_reset(remd_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REMD_HIP_H */

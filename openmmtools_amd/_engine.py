@@ -1,0 +1,295 @@
+"""ctypes binding of libremd_hip.so (the C ABI in include/remd_hip.h) and the HipEngine wrapper.
+
+This is the product path.  There is deliberately NO CPU fallback: if the shared library is
+missing, or no gfx950 device is visible, construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libremd_hip.so')
+
+MIX_SCHEMES = {None: 0, 'none': 0, 'swap-all': 1, 'swap-neighbors': 2, 'sams-global-jump': 3}
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class RemdSystemDesc(C.Structure):
+    _fields_ = [
+        ('n_atoms', C.c_int32), ('mass', c_double_p),
+        ('n_ext', C.c_int32), ('ext_atoms', c_int32_p),
+        ('ext_K', C.c_double), ('ext_x0', C.c_double), ('ext_U0', C.c_double),
+        ('n_bonds', C.c_int32), ('bond_atoms', c_int32_p), ('bond_params', c_double_p),
+        ('n_angles', C.c_int32), ('angle_atoms', c_int32_p), ('angle_params', c_double_p),
+        ('n_torsions', C.c_int32), ('torsion_atoms', c_int32_p), ('torsion_params', c_double_p),
+        ('nb_method', C.c_int32), ('cutoff', C.c_double), ('switch_distance', C.c_double),
+        ('rf_dielectric', C.c_double), ('ewald_alpha', C.c_double), ('pme_grid', C.c_int32 * 3),
+        ('use_dispersion_correction', C.c_int32),
+        ('charge', c_double_p), ('sigma', c_double_p), ('epsilon', c_double_p),
+        ('n_exceptions', C.c_int32), ('exception_atoms', c_int32_p), ('exception_params', c_double_p),
+        ('n_settle', C.c_int32), ('settle_atoms', c_int32_p), ('settle_dOH', C.c_double), ('settle_dHH', C.c_double),
+        ('n_shake', C.c_int32), ('shake_atoms', c_int32_p), ('shake_dist', c_double_p),
+        ('cmm_frequency', C.c_int32),
+        ('n_alch', C.c_int32), ('alch_atoms', c_int32_p),
+        ('softcore_alpha', C.c_double), ('softcore_a', C.c_double), ('softcore_b', C.c_double), ('softcore_c', C.c_double),
+    ]
+
+
+EXPORTS = [
+    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_states',
+    'remd_set_integrator', 'remd_set_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
+    'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
+    'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
+    'remd_profile_get', 'remd_profile_reset',
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libremd_hip.so and declare every prototype of include/remd_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.remd_create.argtypes = [C.POINTER(vp), C.c_int, vp]
+    lib.remd_destroy.argtypes = [vp]
+    lib.remd_last_error.argtypes = [vp]
+    lib.remd_last_error.restype = C.c_char_p
+    lib.remd_version.argtypes = []
+    lib.remd_set_system.argtypes = [vp, C.POINTER(RemdSystemDesc)]
+    lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
+    lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
+    lib.remd_set_replicas.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]
+    lib.remd_set_labels.argtypes = [vp, c_int64_p]
+    lib.remd_seed.argtypes = [vp, C.c_uint64]
+    lib.remd_propagate.argtypes = [vp, C.c_int64, c_int32_p]
+    lib.remd_compute_energies.argtypes = [vp, vp, c_double_p, c_double_p]
+    lib.remd_ukl_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    lib.remd_mix.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, vp, C.c_int, c_int64_p, c_int64_p, c_int64_p,
+                             c_double_p, c_double_p]
+    lib.remd_mix_host.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, c_double_p, c_int64_p, c_int64_p,
+                                  c_int64_p, c_double_p, c_double_p, C.c_int64]
+    lib.remd_get_replicas.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
+    lib.remd_get_forces.argtypes = [vp, c_double_p]
+    lib.remd_step.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64, C.c_int]
+    lib.remd_sync.argtypes = [vp]
+    lib.remd_last_timing.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+    lib.remd_profile_enable.argtypes = [vp, C.c_int]
+    lib.remd_profile_get.argtypes = [vp, C.c_char_p, c_int64_p, c_double_p]
+    lib.remd_profile_reset.argtypes = [vp]
+    for name in EXPORTS:
+        if name not in ('remd_last_error',):
+            getattr(lib, name).restype = C.c_int
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_int32_p)
+
+
+def _lp(a):
+    return None if a is None else a.ctypes.data_as(c_int64_p)
+
+
+def build_desc(d):
+    """Turn the dict from system.system_to_desc into a RemdSystemDesc (+ keep-alive list)."""
+    keep = []
+
+    def f64(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        keep.append(a)
+        return _dp(a)
+
+    def i32(a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        keep.append(a)
+        return _ip(a)
+
+    s = RemdSystemDesc()
+    s.n_atoms = int(d['n_atoms']); s.mass = f64(d['mass'])
+    s.n_ext = int(d['n_ext']); s.ext_atoms = i32(d['ext_atoms'])
+    s.ext_K, s.ext_x0, s.ext_U0 = float(d['ext_K']), float(d['ext_x0']), float(d['ext_U0'])
+    s.n_bonds = len(d['bond_atoms']); s.bond_atoms = i32(d['bond_atoms']); s.bond_params = f64(d['bond_params'])
+    s.n_angles = len(d['angle_atoms']); s.angle_atoms = i32(d['angle_atoms']); s.angle_params = f64(d['angle_params'])
+    s.n_torsions = len(d['torsion_atoms']); s.torsion_atoms = i32(d['torsion_atoms']); s.torsion_params = f64(d['torsion_params'])
+    s.nb_method = int(d['nb_method']); s.cutoff = float(d['cutoff']); s.switch_distance = float(d['switch_distance'])
+    s.rf_dielectric = float(d['rf_dielectric']); s.ewald_alpha = float(d['ewald_alpha'])
+    for k in range(3):
+        s.pme_grid[k] = int(d['pme_grid'][k])
+    s.use_dispersion_correction = int(d['use_dispersion_correction'])
+    s.charge = f64(d['charge']); s.sigma = f64(d['sigma']); s.epsilon = f64(d['epsilon'])
+    s.n_exceptions = len(d['exception_atoms']); s.exception_atoms = i32(d['exception_atoms'])
+    s.exception_params = f64(d['exception_params'])
+    s.n_settle = len(d['settle_atoms']); s.settle_atoms = i32(d['settle_atoms'])
+    s.settle_dOH, s.settle_dHH = float(d['settle_dOH']), float(d['settle_dHH'])
+    s.n_shake = len(d['shake_atoms']); s.shake_atoms = i32(d['shake_atoms']); s.shake_dist = f64(d['shake_dist'])
+    s.cmm_frequency = int(d['cmm_frequency'])
+    s.n_alch = len(d['alch_atoms']); s.alch_atoms = i32(d['alch_atoms'])
+    s.softcore_alpha, s.softcore_a, s.softcore_b, s.softcore_c = [float(v) for v in d['softcore']]
+    return s, keep
+
+
+class HipEngine:
+    """One libremd_hip.so handle = the batched device-state pool of one GPU (replaces cache.ContextCache,
+    openmmtools/cache.py:378-461, for the replica-exchange hot path)."""
+
+    is_device = True
+
+    def __init__(self, device=0, stream=None, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.h = C.c_void_p()
+        rc = self.lib.remd_create(C.byref(self.h), int(device), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise RuntimeError('remd_create failed (%d): %s' % (rc, self.lib.remd_last_error(None).decode()))
+        self.device = device
+        self.N = self.K = self.R = self.R_global = self.r_begin = 0
+        self._keep = None
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.remd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed (%d): %s' % (what, rc, self.lib.remd_last_error(self.h).decode()))
+
+    # ---- set-up ---------------------------------------------------------------------
+    def set_system(self, desc_dict):
+        s, keep = build_desc(desc_dict)
+        self._check(self.lib.remd_set_system(self.h, C.byref(s)), 'remd_set_system')
+        self.N = int(desc_dict['n_atoms'])
+
+    def set_states(self, beta, lambda_sterics=None, lambda_electrostatics=None, energy_const=None):
+        beta = np.ascontiguousarray(beta, dtype=np.float64)
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+                for a in (lambda_sterics, lambda_electrostatics, energy_const)]
+        self._check(self.lib.remd_set_states(self.h, len(beta), _dp(beta), *[_dp(a) for a in arrs]), 'remd_set_states')
+        self.K = len(beta)
+
+    def set_integrator(self, splitting, timestep, collision_rate, n_steps, reassign_velocities=True,
+                       constraint_tolerance=1e-8):
+        self._check(self.lib.remd_set_integrator(self.h, splitting.encode(), float(timestep), float(collision_rate),
+                                                 int(n_steps), int(bool(reassign_velocities)),
+                                                 float(constraint_tolerance)), 'remd_set_integrator')
+
+    def set_replicas(self, R_global, r_begin, x, v, box, labels):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        R_local = x.shape[0]
+        v = None if v is None else np.ascontiguousarray(v, dtype=np.float64)
+        box = np.ascontiguousarray(box, dtype=np.float64).reshape(R_local, 3)
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        assert x.shape == (R_local, self.N, 3) and labels.shape == (R_global,)
+        self._check(self.lib.remd_set_replicas(self.h, int(R_global), int(r_begin), R_local, _dp(x), _dp(v),
+                                               _dp(box), _lp(labels)), 'remd_set_replicas')
+        self.R, self.R_global, self.r_begin = R_local, int(R_global), int(r_begin)
+
+    def set_labels(self, labels):
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        self._check(self.lib.remd_set_labels(self.h, _lp(labels)), 'remd_set_labels')
+
+    def seed(self, seed):
+        self._check(self.lib.remd_seed(self.h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)), 'remd_seed')
+
+    # ---- hot path ----------------------------------------------------------------------
+    def propagate(self, iteration):
+        flags = np.zeros(self.R, dtype=np.int32)
+        self._check(self.lib.remd_propagate(self.h, int(iteration), _ip(flags)), 'remd_propagate')
+        return flags
+
+    def compute_energies(self, d_rows=None, want_host=True, want_potential=False):
+        """Rows [R_local, K] of u_kl.  d_rows: device pointer (int) or None for the handle's matrix."""
+        ukl = np.empty((self.R, self.K), dtype=np.float64) if want_host else None
+        pot = np.empty(self.R, dtype=np.float64) if want_potential else None
+        self._check(self.lib.remd_compute_energies(self.h, C.c_void_p(d_rows) if d_rows else None, _dp(ukl), _dp(pot)),
+                    'remd_compute_energies')
+        return (ukl, pot) if want_potential else ukl
+
+    def ukl_device_ptr(self):
+        p = C.c_void_p()
+        self._check(self.lib.remd_ukl_device_ptr(self.h, C.byref(p)), 'remd_ukl_device_ptr')
+        return p.value
+
+    def mix(self, scheme, iteration, labels, d_ukl=None, R=None, K=None, ld=0, log_weights=None):
+        R = self.R_global if R is None else R
+        K = self.K if K is None else K
+        labels = np.ascontiguousarray(labels, dtype=np.int64).copy()
+        nacc = np.zeros((K, K), dtype=np.int64)
+        nprop = np.zeros((K, K), dtype=np.int64)
+        sid = MIX_SCHEMES[scheme]
+        logw = None if log_weights is None else np.ascontiguousarray(log_weights, dtype=np.float64)
+        logP = np.zeros((R, K), dtype=np.float64) if sid == 3 else None
+        self._check(self.lib.remd_mix(self.h, sid, int(iteration), R, K, C.c_void_p(d_ukl) if d_ukl else None,
+                                      int(ld), _lp(labels), _lp(nacc), _lp(nprop), _dp(logw), _dp(logP)), 'remd_mix')
+        return labels, nacc, nprop, logP
+
+    def mix_host(self, scheme, iteration, ukl, labels, log_weights=None, n_attempts=-1):
+        ukl = np.ascontiguousarray(ukl, dtype=np.float64)
+        R, K = ukl.shape
+        labels = np.ascontiguousarray(labels, dtype=np.int64).copy()
+        nacc = np.zeros((K, K), dtype=np.int64)
+        nprop = np.zeros((K, K), dtype=np.int64)
+        sid = MIX_SCHEMES[scheme]
+        logw = None if log_weights is None else np.ascontiguousarray(log_weights, dtype=np.float64)
+        logP = np.zeros((R, K), dtype=np.float64) if sid == 3 else None
+        self._check(self.lib.remd_mix_host(self.h, sid, int(iteration), R, K, _dp(ukl), _lp(labels), _lp(nacc),
+                                           _lp(nprop), _dp(logw), _dp(logP), int(n_attempts)), 'remd_mix_host')
+        return labels, nacc, nprop, logP
+
+    # ---- snapshots / hooks ---------------------------------------------------------------
+    def get_replicas(self, positions=True, velocities=True, potential=False, kinetic=False):
+        x = np.empty((self.R, self.N, 3)) if positions else None
+        v = np.empty((self.R, self.N, 3)) if velocities else None
+        u = np.empty(self.R) if potential else None
+        k = np.empty(self.R) if kinetic else None
+        self._check(self.lib.remd_get_replicas(self.h, _dp(x), _dp(v), _dp(u), _dp(k)), 'remd_get_replicas')
+        return x, v, u, k
+
+    def get_forces(self):
+        f = np.empty((self.R, self.N, 3))
+        self._check(self.lib.remd_get_forces(self.h, _dp(f)), 'remd_get_forces')
+        return f
+
+    def step(self, splitting, iteration=0, first_step=0, n_steps=1):
+        self._check(self.lib.remd_step(self.h, splitting.encode(), int(iteration), int(first_step), int(n_steps)),
+                    'remd_step')
+
+    def sync(self):
+        self._check(self.lib.remd_sync(self.h), 'remd_sync')
+
+    def last_timing(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.lib.remd_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(propagate_ms=a.value, energies_ms=b.value, mix_ms=c.value)
+
+    def profile_enable(self, on=True):
+        self.lib.remd_profile_enable(self.h, int(bool(on)))
+
+    def profile_reset(self):
+        self.lib.remd_profile_reset(self.h)
+
+    def profile_get(self, name):
+        n, ms = C.c_int64(), C.c_double()
+        self.lib.remd_profile_get(self.h, name.encode(), C.byref(n), C.byref(ms))
+        return n.value, ms.value

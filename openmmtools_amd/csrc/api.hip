@@ -1,0 +1,421 @@
+// C ABI of libremd_hip.so (see include/remd_hip.h for the contract and reference citations).
+#include "remd_internal.h"
+#include <cstring>
+#include <cmath>
+#include <mutex>
+
+int remd_check_finite(remd_ctx* h);
+int remd_assemble_ukl(remd_ctx* h, double* d_rows);
+void remd_free_constraints(remd_ctx* h);
+
+static std::mutex g_err_mutex;
+static std::string g_last_error;
+
+void remd_set_global_error(const std::string& s) { std::lock_guard<std::mutex> l(g_err_mutex); g_last_error = s; }
+int remd_fail(remd_ctx* h, int code, const std::string& msg) { if (h) h->err = msg; remd_set_global_error(msg); return code; }
+
+template <typename T> static void dfree(T*& p) { if (p) { hipFree(p); p = nullptr; } }
+
+template <typename T>
+static int upload(remd_ctx* h, T*& dptr, const std::vector<T>& host)
+{
+    dfree(dptr);
+    if (host.empty()) return 0;
+    REMD_CHECK(h, hipMalloc(&dptr, sizeof(T) * host.size()));
+    REMD_CHECK(h, hipMemcpy(dptr, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" {
+
+int remd_version(void) { return 1; }
+
+const char* remd_last_error(remd_handle h)
+{
+    if (h) return h->err.c_str();
+    std::lock_guard<std::mutex> l(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_last_error;
+    return copy.c_str();
+}
+
+int remd_create(remd_handle* out, int device, void* stream)
+{
+    if (!out) return remd_fail(nullptr, -1, "remd_create: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return remd_fail(nullptr, -2, std::string("remd_create: no HIP device available (") + hipGetErrorString(e) + ")");
+    if (device < 0 || device >= n) return remd_fail(nullptr, -1, "remd_create: bad device index");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return remd_fail(nullptr, -2, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    remd_ctx* h = new remd_ctx();
+    h->device = device;
+    h->stream = (hipStream_t)stream;
+    hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+    *out = h;
+    return 0;
+}
+
+int remd_destroy(remd_handle h)
+{
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    remd_pme_destroy(h);
+    remd_free_constraints(h);
+    dfree(h->d_invmass); dfree(h->d_mass); dfree(h->d_ext_atoms);
+    dfree(h->d_bond_atoms); dfree(h->d_bond_params); dfree(h->d_angle_atoms); dfree(h->d_angle_params);
+    dfree(h->d_torsion_atoms); dfree(h->d_torsion_params);
+    dfree(h->d_nbparam); dfree(h->d_exclmask); dfree(h->d_exc_atoms); dfree(h->d_exc_params); dfree(h->d_excl_pairs);
+    dfree(h->d_alch_atoms);
+    dfree(h->d_beta); dfree(h->d_lam_s); dfree(h->d_lam_e); dfree(h->d_econst);
+    dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_pos_ref); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels);
+    dfree(h->d_ukl); dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
+    dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    delete h;
+    return 0;
+}
+
+int remd_seed(remd_handle h, uint64_t seed) { if (!h) return -1; h->seed = seed; return 0; }
+
+int remd_set_system(remd_handle h, const remd_system_desc* d)
+{
+    if (!h || !d) return remd_fail(h, -1, "remd_set_system: NULL argument");
+    if (d->n_atoms <= 0 || !d->mass) return remd_fail(h, -1, "remd_set_system: n_atoms/mass missing");
+    hipSetDevice(h->device);
+    h->N = d->n_atoms;
+    h->Npad = (d->n_atoms + 63) / 64 * 64;
+    std::vector<float> im(h->Npad, 0.f), m(h->Npad, 0.f);
+    h->total_mass = 0;
+    for (int i = 0; i < h->N; ++i) {
+        if (!(d->mass[i] > 0)) return remd_fail(h, -3, "massless particles are not supported");
+        m[i] = (float)d->mass[i]; im[i] = (float)(1.0 / d->mass[i]); h->total_mass += d->mass[i];
+    }
+    int rc;
+    if ((rc = upload(h, h->d_invmass, im))) return rc;
+    if ((rc = upload(h, h->d_mass, m))) return rc;
+    h->n_ext = d->n_ext; h->ext_K = d->ext_K; h->ext_x0 = d->ext_x0; h->ext_U0 = d->ext_U0;
+    {
+        std::vector<int> ea(d->ext_atoms, d->ext_atoms + d->n_ext);
+        if ((rc = upload(h, h->d_ext_atoms, ea))) return rc;
+    }
+    h->cmm_frequency = d->cmm_frequency;
+    if ((rc = remd_build_constraints(h, d))) return rc;
+    if ((rc = remd_build_nonbonded(h, d))) return rc;
+    h->has_system = true;
+    h->forces_valid = false;
+    return 0;
+}
+
+int remd_set_states(remd_handle h, int K, const double* beta, const double* lam_s, const double* lam_e, const double* econst)
+{
+    if (!h || K <= 0 || !beta) return remd_fail(h, -1, "remd_set_states: bad arguments");
+    hipSetDevice(h->device);
+    h->K = K;
+    h->beta.assign(beta, beta + K);
+    h->lam_s.assign(K, 1.0); h->lam_e.assign(K, 1.0); h->econst.assign(K, 0.0);
+    if (lam_s) h->lam_s.assign(lam_s, lam_s + K);
+    if (lam_e) h->lam_e.assign(lam_e, lam_e + K);
+    if (econst) h->econst.assign(econst, econst + K);
+    for (int k = 0; k < K; ++k) if (!(h->beta[k] > 0)) return remd_fail(h, -1, "remd_set_states: beta must be > 0");
+    int rc;
+    if ((rc = upload(h, h->d_beta, h->beta))) return rc;
+    if ((rc = upload(h, h->d_lam_s, h->lam_s))) return rc;
+    if ((rc = upload(h, h->d_lam_e, h->lam_e))) return rc;
+    if ((rc = upload(h, h->d_econst, h->econst))) return rc;
+    dfree(h->d_ukl);
+    if (h->R_global > 0) {
+        REMD_CHECK(h, hipMalloc(&h->d_ukl, sizeof(double) * (size_t)h->R_global * K));
+        REMD_CHECK(h, hipMemset(h->d_ukl, 0, sizeof(double) * (size_t)h->R_global * K));
+    }
+    return 0;
+}
+
+int remd_set_integrator(remd_handle h, const char* splitting, double dt, double gamma, int n_steps,
+                        int reassign, double tol)
+{
+    if (!h) return -1;
+    if (!(dt > 0) || n_steps < 0 || gamma < 0) return remd_fail(h, -1, "remd_set_integrator: bad parameters");
+    int rc = remd_parse_splitting(h, splitting, h->tokens, h->nV, h->nR, h->nO);
+    if (rc) return rc;
+    h->splitting = splitting; h->dt = dt; h->gamma = gamma; h->n_steps = n_steps; h->reassign = reassign;
+    h->constraint_tol = tol > 0 ? tol : 1e-8;
+    h->has_integrator = true;
+    return 0;
+}
+
+int remd_set_labels(remd_handle h, const int64_t* labels)
+{
+    if (!h || !labels || h->R_global <= 0) return remd_fail(h, -1, "remd_set_labels: replicas not set");
+    for (int r = 0; r < h->R_global; ++r)
+        if (labels[r] < 0 || (h->K > 0 && labels[r] >= h->K)) return remd_fail(h, -1, "remd_set_labels: label out of range");
+    h->labels.assign(labels, labels + h->R_global);
+    REMD_CHECK(h, hipMemcpyAsync(h->d_labels, h->labels.data(), sizeof(int64_t) * h->R_global, hipMemcpyHostToDevice, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, const double* x, const double* v,
+                      const double* box, const int64_t* labels)
+{
+    if (!h || !h->has_system) return remd_fail(h, -1, "remd_set_replicas: call remd_set_system first");
+    if (R_global <= 0 || R_local <= 0 || r_begin < 0 || r_begin + R_local > R_global || !x || !labels)
+        return remd_fail(h, -1, "remd_set_replicas: bad arguments");
+    hipSetDevice(h->device);
+    const bool realloc = (R_local != h->R) || (R_global != h->R_global) || !h->d_pos;
+    h->R_global = R_global; h->r_begin = r_begin; h->R = R_local;
+    const size_t n = (size_t)R_local * h->Npad;
+    if (realloc) {
+        dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels); dfree(h->d_ukl);
+        dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
+        REMD_CHECK(h, hipMalloc(&h->d_pos, sizeof(float4) * n));
+        REMD_CHECK(h, hipMalloc(&h->d_vel, sizeof(float4) * n));
+        REMD_CHECK(h, hipMalloc(&h->d_force, sizeof(long long) * 3 * n));
+        REMD_CHECK(h, hipMalloc(&h->d_box, sizeof(float) * 4 * R_local));
+        REMD_CHECK(h, hipMalloc(&h->d_labels, sizeof(int64_t) * R_global));
+        REMD_CHECK(h, hipMalloc(&h->d_potential, sizeof(double) * R_local));
+        REMD_CHECK(h, hipMalloc(&h->d_kinetic, sizeof(double) * R_local));
+        REMD_CHECK(h, hipMalloc(&h->d_nan, sizeof(int) * R_local));
+        REMD_CHECK(h, hipMalloc(&h->d_cmm, sizeof(long long) * 4 * R_local));
+        h->n_epart = 8 + 4 * ((h->Npad + 255) / 256) + 64;
+        REMD_CHECK(h, hipMalloc(&h->d_epart, sizeof(double) * (size_t)h->n_epart * R_local));
+        if (h->K > 0) {
+            REMD_CHECK(h, hipMalloc(&h->d_ukl, sizeof(double) * (size_t)R_global * h->K));
+            REMD_CHECK(h, hipMemset(h->d_ukl, 0, sizeof(double) * (size_t)R_global * h->K));
+        }
+    }
+    std::vector<float4> hp(n, make_float4(0, 0, 0, 0)), hv(n, make_float4(0, 0, 0, 0));
+    for (int r = 0; r < R_local; ++r)
+        for (int i = 0; i < h->N; ++i) {
+            const double* p = x + ((size_t)r * h->N + i) * 3;
+            hp[(size_t)r * h->Npad + i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+            if (v) {
+                const double* w = v + ((size_t)r * h->N + i) * 3;
+                hv[(size_t)r * h->Npad + i] = make_float4((float)w[0], (float)w[1], (float)w[2], 0.f);
+            }
+        }
+    // padding atoms are parked far apart so that they never interact
+    for (int r = 0; r < R_local; ++r)
+        for (int i = h->N; i < h->Npad; ++i) hp[(size_t)r * h->Npad + i] = make_float4(1e6f + 10.f * i, 1e6f, 1e6f, 0.f);
+    std::vector<float> hb(4 * (size_t)R_local, 0.f);
+    h->box_host.assign(3 * (size_t)R_local, 0.0);
+    for (int r = 0; r < R_local; ++r) for (int k = 0; k < 3; ++k) {
+        const double L = box ? box[3 * r + k] : 0.0;
+        hb[4 * r + k] = (float)L; h->box_host[3 * r + k] = L;
+    }
+    REMD_CHECK(h, hipMemcpy(h->d_pos, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    REMD_CHECK(h, hipMemcpy(h->d_vel, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    REMD_CHECK(h, hipMemcpy(h->d_box, hb.data(), sizeof(float) * 4 * R_local, hipMemcpyHostToDevice));
+    h->forces_valid = false;
+    if (h->nb_method == REMD_NB_PME) { int rc = remd_pme_setup(h); if (rc) return rc; }
+    return remd_set_labels(h, labels);
+}
+
+int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
+{
+    if (!h || !h->has_system || !h->has_integrator || h->R <= 0 || h->K <= 0)
+        return remd_fail(h, -1, "remd_propagate: system/states/integrator/replicas not all set");
+    hipSetDevice(h->device);
+    hipEventRecord(h->ev0, h->stream);
+    int rc;
+    if (h->reassign) { if ((rc = remd_assign_velocities(h, iteration))) return rc; }
+    if ((rc = remd_run_steps(h, h->tokens, h->nV, h->nR, h->nO, iteration, 0, h->n_steps))) return rc;
+    if ((rc = remd_check_finite(h))) return rc;
+    hipEventRecord(h->ev1, h->stream);
+    std::vector<int> flags(h->R, 0);
+    REMD_CHECK(h, hipMemcpyAsync(flags.data(), h->d_nan, sizeof(int) * h->R, hipMemcpyDeviceToHost, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_prop = ms;
+    if (nan_flags) for (int r = 0; r < h->R; ++r) nan_flags[r] = flags[r];
+    return 0;
+}
+
+int remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t first_step, int n_steps)
+{
+    if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return remd_fail(h, -1, "remd_step: not set up");
+    hipSetDevice(h->device);
+    std::vector<char> tokens; int nV, nR, nO;
+    // a test-hook splitting may consist of a single substep: count with the configured integrator
+    std::string s(splitting ? splitting : "");
+    tokens.clear();
+    for (char c : s) { if (c == ' ') continue; c = (char)toupper(c); if (c != 'V' && c != 'R' && c != 'O') return remd_fail(h, -3, "remd_step: token must be V, R or O"); tokens.push_back(c); }
+    nV = h->nV; nR = h->nR; nO = h->nO;
+    int rc = remd_run_steps(h, tokens, nV, nR, nO, iteration, first_step, n_steps);
+    if (rc) return rc;
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int remd_ukl_device_ptr(remd_handle h, double** d_ukl)
+{
+    if (!h || !d_ukl || !h->d_ukl) return remd_fail(h, -1, "remd_ukl_device_ptr: states/replicas not set");
+    *d_ukl = h->d_ukl;
+    return 0;
+}
+
+int remd_compute_energies(remd_handle h, double* d_ukl_rows, double* ukl_host, double* potential_host)
+{
+    if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return remd_fail(h, -1, "remd_compute_energies: not set up");
+    hipSetDevice(h->device);
+    hipEventRecord(h->ev0, h->stream);
+    int rc;
+    if ((rc = remd_compute_forces(h, true))) return rc;
+    double* rows = d_ukl_rows ? d_ukl_rows : h->d_ukl + (size_t)h->r_begin * h->K;
+    if ((rc = remd_assemble_ukl(h, rows))) return rc;
+    hipEventRecord(h->ev1, h->stream);
+    if (ukl_host) REMD_CHECK(h, hipMemcpyAsync(ukl_host, rows, sizeof(double) * (size_t)h->R * h->K, hipMemcpyDeviceToHost, h->stream));
+    if (potential_host) REMD_CHECK(h, hipMemcpyAsync(potential_host, h->d_potential, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_energy = ms;
+    return 0;
+}
+
+static int ensure_mix_buffers(remd_ctx* h, int R, int K)
+{
+    if (h->stats_K != K || !h->d_nacc) {
+        dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw);
+        REMD_CHECK(h, hipMalloc(&h->d_nacc, sizeof(unsigned long long) * (size_t)K * K));
+        REMD_CHECK(h, hipMalloc(&h->d_nprop, sizeof(unsigned long long) * (size_t)K * K));
+        REMD_CHECK(h, hipMalloc(&h->d_logw, sizeof(double) * K));
+        h->stats_K = K;
+    }
+    if (h->ukl_tmp_n < (size_t)R * K) {
+        dfree(h->d_ukl_tmp); dfree(h->d_logP);
+        REMD_CHECK(h, hipMalloc(&h->d_ukl_tmp, sizeof(double) * (size_t)R * K));
+        REMD_CHECK(h, hipMalloc(&h->d_logP, sizeof(double) * (size_t)R * K));
+        h->ukl_tmp_n = (size_t)R * K;
+    }
+    return 0;
+}
+
+static int mix_common(remd_ctx* h, int scheme, int64_t iteration, int R, int K, int ld, const double* d_ukl, int64_t* labels,
+                      int64_t* n_accepted, int64_t* n_proposed, const double* log_weights, double* sams_log_P,
+                      int64_t n_attempts, int64_t* d_labels)
+{
+    int rc;
+    hipEventRecord(h->ev0, h->stream);
+    REMD_CHECK(h, hipMemcpyAsync(d_labels, labels, sizeof(int64_t) * R, hipMemcpyHostToDevice, h->stream));
+    if (log_weights) REMD_CHECK(h, hipMemcpyAsync(h->d_logw, log_weights, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
+    if ((rc = remd_mix_launch(h, scheme, iteration, R, K, ld, d_ukl, d_labels, h->d_nacc, h->d_nprop,
+                              log_weights ? h->d_logw : nullptr, h->d_logP, n_attempts))) return rc;
+    REMD_CHECK(h, hipMemcpyAsync(labels, d_labels, sizeof(int64_t) * R, hipMemcpyDeviceToHost, h->stream));
+    if (n_accepted) REMD_CHECK(h, hipMemcpyAsync(n_accepted, h->d_nacc, sizeof(int64_t) * (size_t)K * K, hipMemcpyDeviceToHost, h->stream));
+    if (n_proposed) REMD_CHECK(h, hipMemcpyAsync(n_proposed, h->d_nprop, sizeof(int64_t) * (size_t)K * K, hipMemcpyDeviceToHost, h->stream));
+    if (sams_log_P && scheme == REMD_MIX_SAMS_GLOBAL)
+        REMD_CHECK(h, hipMemcpyAsync(sams_log_P, h->d_logP, sizeof(double) * (size_t)R * K, hipMemcpyDeviceToHost, h->stream));
+    hipEventRecord(h->ev1, h->stream);
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_mix = ms;
+    return 0;
+}
+
+int remd_mix(remd_handle h, int scheme, int64_t iteration, int R, int K, const double* d_ukl, int ld, int64_t* labels,
+             int64_t* n_accepted, int64_t* n_proposed, const double* log_weights, double* sams_log_P)
+{
+    if (!h || !labels || R <= 0 || K <= 0) return remd_fail(h, -1, "remd_mix: bad arguments");
+    hipSetDevice(h->device);
+    if (!d_ukl) {
+        if (!h->d_ukl || R != h->R_global || K > h->K) return remd_fail(h, -1, "remd_mix: handle has no matching u_kl matrix");
+        d_ukl = h->d_ukl; ld = h->K;
+    }
+    int rc = ensure_mix_buffers(h, R, K);
+    if (rc) return rc;
+    int64_t* d_labels = nullptr;
+    bool own = false;
+    if (h->d_labels && R == h->R_global) d_labels = h->d_labels;
+    else { REMD_CHECK(h, hipMalloc(&d_labels, sizeof(int64_t) * R)); own = true; }
+    rc = mix_common(h, scheme, iteration, R, K, ld, d_ukl, labels, n_accepted, n_proposed, log_weights, sams_log_P, -1, d_labels);
+    if (own) hipFree(d_labels);
+    if (!rc && !own) h->labels.assign(labels, labels + R);
+    return rc;
+}
+
+int remd_mix_host(remd_handle h, int scheme, int64_t iteration, int R, int K, const double* ukl_host, int64_t* labels,
+                  int64_t* n_accepted, int64_t* n_proposed, const double* log_weights, double* sams_log_P,
+                  int64_t n_attempts)
+{
+    if (!h || !labels || !ukl_host || R <= 0 || K <= 0) return remd_fail(h, -1, "remd_mix_host: bad arguments");
+    hipSetDevice(h->device);
+    int rc = ensure_mix_buffers(h, R, K);
+    if (rc) return rc;
+    REMD_CHECK(h, hipMemcpyAsync(h->d_ukl_tmp, ukl_host, sizeof(double) * (size_t)R * K, hipMemcpyHostToDevice, h->stream));
+    int64_t* d_labels = nullptr;
+    REMD_CHECK(h, hipMalloc(&d_labels, sizeof(int64_t) * R));
+    rc = mix_common(h, scheme, iteration, R, K, K, h->d_ukl_tmp, labels, n_accepted, n_proposed, log_weights, sams_log_P,
+                    n_attempts, d_labels);
+    hipFree(d_labels);
+    return rc;
+}
+
+int remd_get_replicas(remd_handle h, double* x, double* v, double* potential, double* kinetic)
+{
+    if (!h || h->R <= 0) return remd_fail(h, -1, "remd_get_replicas: no replicas");
+    hipSetDevice(h->device);
+    const size_t n = (size_t)h->R * h->Npad;
+    std::vector<float4> buf(n);
+    if (x) {
+        REMD_CHECK(h, hipMemcpyAsync(buf.data(), h->d_pos, sizeof(float4) * n, hipMemcpyDeviceToHost, h->stream));
+        REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        for (int r = 0; r < h->R; ++r) for (int i = 0; i < h->N; ++i) {
+            const float4 p = buf[(size_t)r * h->Npad + i]; double* o = x + ((size_t)r * h->N + i) * 3;
+            o[0] = p.x; o[1] = p.y; o[2] = p.z;
+        }
+    }
+    if (v) {
+        REMD_CHECK(h, hipMemcpyAsync(buf.data(), h->d_vel, sizeof(float4) * n, hipMemcpyDeviceToHost, h->stream));
+        REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        for (int r = 0; r < h->R; ++r) for (int i = 0; i < h->N; ++i) {
+            const float4 p = buf[(size_t)r * h->Npad + i]; double* o = v + ((size_t)r * h->N + i) * 3;
+            o[0] = p.x; o[1] = p.y; o[2] = p.z;
+        }
+    }
+    if (potential) {
+        int rc = remd_compute_forces(h, true); if (rc) return rc;
+        REMD_CHECK(h, hipMemcpyAsync(potential, h->d_potential, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (kinetic) {
+        int rc = remd_kinetic_energy(h); if (rc) return rc;
+        REMD_CHECK(h, hipMemcpyAsync(kinetic, h->d_kinetic, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
+    }
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int remd_get_forces(remd_handle h, double* f)
+{
+    if (!h || h->R <= 0 || !f) return remd_fail(h, -1, "remd_get_forces: bad arguments");
+    hipSetDevice(h->device);
+    int rc = remd_compute_forces(h, false); if (rc) return rc;
+    const size_t n = (size_t)h->R * 3 * h->Npad;
+    std::vector<long long> buf(n);
+    REMD_CHECK(h, hipMemcpyAsync(buf.data(), h->d_force, sizeof(long long) * n, hipMemcpyDeviceToHost, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < h->R; ++r) for (int i = 0; i < h->N; ++i) for (int k = 0; k < 3; ++k)
+        f[((size_t)r * h->N + i) * 3 + k] = (double)buf[((size_t)r * 3 + k) * h->Npad + i] / REMD_FORCE_SCALE;
+    return 0;
+}
+
+int remd_sync(remd_handle h) { if (!h) return -1; hipSetDevice(h->device); REMD_CHECK(h, hipStreamSynchronize(h->stream)); return 0; }
+
+int remd_last_timing(remd_handle h, double* p, double* e, double* m)
+{
+    if (!h) return -1;
+    if (p) *p = h->t_prop; if (e) *e = h->t_energy; if (m) *m = h->t_mix;
+    return 0;
+}
+
+int remd_profile_enable(remd_handle h, int on) { if (!h) return -1; h->profiling = on != 0; return 0; }
+int remd_profile_reset(remd_handle h) { if (!h) return -1; h->prof.clear(); return 0; }
+int remd_profile_get(remd_handle h, const char* name, int64_t* n, double* ms)
+{
+    if (!h || !name) return -1;
+    auto it = h->prof.find(name);
+    if (n) *n = it == h->prof.end() ? 0 : it->second.n;
+    if (ms) *ms = it == h->prof.end() ? 0.0 : it->second.ms;
+    return 0;
+}
+
+} // extern "C"

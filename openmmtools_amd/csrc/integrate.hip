@@ -1,0 +1,532 @@
+// Langevin splitting integrator kernels (gfx950): V / R / O substeps, constraints,
+// Maxwell-Boltzmann velocity draw, kinetic-energy reduction, CM-motion removal.
+//
+// Reference semantics (restated):
+//   openmmtools/integrators.py:1404-1423  R: x += (dt/n_R) v ; constrain x ; v += (x - x1)/(dt/n_R) ; constrain v
+//   openmmtools/integrators.py:1425-1446  V: v += (dt/n_V) f/m ; constrain v
+//   openmmtools/integrators.py:1448-1460  O: v = a v + b sigma xi ; constrain v,  a = exp(-gamma h), b = sqrt(1-a^2),
+//                                            h = dt/max(1,n_O) (:1142-1146), sigma = sqrt(kT/m) (:1314)
+//   openmmtools/mcmc.py:710-711           setVelocitiesToTemperature (+ velocity constraints)
+//   openmmtools/integrators.py:1313       addUpdateContextState (CMMotionRemover acts here, once per step)
+//
+// Design: one thread owns one *constraint unit* (a rigid water, an X-H cluster, or a free
+// atom), keeps its <= 4 atoms' x and v in registers and runs the whole chain of substeps
+// between two force evaluations without touching HBM in between.  All replicas of the
+// rank are covered by one launch (blockIdx.y = replica).
+#include "remd_internal.h"
+#include "rng.h"
+
+#define UNIT_FREE   0
+#define UNIT_SETTLE 1
+#define UNIT_SHAKE  2
+#define MAX_TOK 24
+
+struct chain_prog {
+    int n;                 // tokens in this chain
+    char tok[MAX_TOK];     // 'V','R','O','C' (C = subtract centre-of-mass velocity)
+    int o_index[MAX_TOK];  // for 'O': index of this O inside the step program
+    long long step[MAX_TOK]; // global step counter of each token (for the O noise counter)
+    float hV, hR;          // dt/n_V, dt/n_R
+    float a, b;            // OU coefficients
+    int nO;
+    int accumulate_momentum;  // after the chain, add sum(m v) into d_cmm
+};
+
+struct settle_const { float mO, mH, ra, rb, rc, dOH, dHH; };
+
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+// Analytic SETTLE (Miyamoto & Kollman 1992) in coordinates relative to the old O position:
+// p0[] old (constrained) positions relative to A0 (p0[0] = 0), p1[] unconstrained new
+// positions relative to A0.  Returns constrained new positions (relative to A0) in p1.
+__device__ __forceinline__ void settle_positions(const settle_const& sc, const float3* p0, float3* p1)
+{
+    const float3 b0 = p0[1], c0 = p0[2];
+    const float M = sc.mO + 2.f * sc.mH;
+    const float3 d0 = (p1[0] * sc.mO + p1[1] * sc.mH + p1[2] * sc.mH) * (1.f / M);
+    const float3 a1 = p1[0] - d0, b1 = p1[1] - d0, c1 = p1[2] - d0;
+    float3 Z = cross3(b0, c0);
+    float3 X = cross3(a1, Z);
+    float3 Y = cross3(Z, X);
+    X = X * rsqrtf(dot3(X, X)); Y = Y * rsqrtf(dot3(Y, Y)); Z = Z * rsqrtf(dot3(Z, Z));
+    const float xb0 = dot3(X, b0), yb0 = dot3(Y, b0);
+    const float xc0 = dot3(X, c0), yc0 = dot3(Y, c0);
+    const float za1 = dot3(Z, a1);
+    const float xb1 = dot3(X, b1), yb1 = dot3(Y, b1), zb1 = dot3(Z, b1);
+    const float xc1 = dot3(X, c1), yc1 = dot3(Y, c1), zc1 = dot3(Z, c1);
+    const float sinphi = za1 / sc.ra;
+    const float cosphi = sqrtf(fmaxf(0.f, 1.f - sinphi * sinphi));
+    const float sinpsi = (zb1 - zc1) / (2.f * sc.rc * cosphi);
+    const float cospsi = sqrtf(fmaxf(0.f, 1.f - sinpsi * sinpsi));
+    const float ya2 = sc.ra * cosphi;
+    const float xb2 = -sc.rc * cospsi;
+    const float yb2 = -sc.rb * cosphi - sc.rc * sinpsi * sinphi;
+    const float yc2 = -sc.rb * cosphi + sc.rc * sinpsi * sinphi;
+    const float alpha = xb2 * (xb0 - xc0) + yb0 * yb2 + yc0 * yc2;
+    const float beta  = xb2 * (yc0 - yb0) + xb0 * yb2 + xc0 * yc2;
+    const float gamma = xb0 * yb1 - xb1 * yb0 + xc0 * yc1 - xc1 * yc0;
+    const float al2be2 = alpha * alpha + beta * beta;
+    const float sintheta = (alpha * gamma - beta * sqrtf(fmaxf(0.f, al2be2 - gamma * gamma))) / al2be2;
+    const float costheta = sqrtf(fmaxf(0.f, 1.f - sintheta * sintheta));
+    const float xa3 = -ya2 * sintheta, ya3 = ya2 * costheta, za3 = za1;
+    const float xb3 = xb2 * costheta - yb2 * sintheta, yb3 = xb2 * sintheta + yb2 * costheta, zb3 = zb1;
+    const float xc3 = -xb2 * costheta - yc2 * sintheta, yc3 = -xb2 * sintheta + yc2 * costheta, zc3 = zc1;
+    p1[0] = X * xa3 + Y * ya3 + Z * za3 + d0;
+    p1[1] = X * xb3 + Y * yb3 + Z * zb3 + d0;
+    p1[2] = X * xc3 + Y * yc3 + Z * zc3 + d0;
+}
+
+// Analytic velocity constraint for a rigid triangle: remove the relative velocity along the
+// three bonds by solving the 3x3 Lagrange-multiplier system (Cramer's rule).
+__device__ __forceinline__ void settle_velocities(float imA, float imB, float imC, const float3* p, float3* v)
+{
+    float3 eAB = p[1] - p[0], eBC = p[2] - p[1], eCA = p[0] - p[2];
+    eAB = eAB * rsqrtf(dot3(eAB, eAB)); eBC = eBC * rsqrtf(dot3(eBC, eBC)); eCA = eCA * rsqrtf(dot3(eCA, eCA));
+    const float dAB = dot3(v[1] - v[0], eAB), dBC = dot3(v[2] - v[1], eBC), dCA = dot3(v[0] - v[2], eCA);
+    const float cAB_BC = dot3(eAB, eBC), cAB_CA = dot3(eAB, eCA), cBC_CA = dot3(eBC, eCA);
+    const float m00 = imA + imB,        m01 = -cAB_BC * imB,  m02 = -cAB_CA * imA;
+    const float m10 = -cAB_BC * imB,    m11 = imB + imC,      m12 = -cBC_CA * imC;
+    const float m20 = -cAB_CA * imA,    m21 = -cBC_CA * imC,  m22 = imC + imA;
+    const float det = m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
+    const float idet = 1.f / det;
+    const float tAB = (dAB * (m11 * m22 - m12 * m21) - m01 * (dBC * m22 - m12 * dCA) + m02 * (dBC * m21 - m11 * dCA)) * idet;
+    const float tBC = (m00 * (dBC * m22 - m12 * dCA) - dAB * (m10 * m22 - m12 * m20) + m02 * (m10 * dCA - dBC * m20)) * idet;
+    const float tCA = (m00 * (m11 * dCA - dBC * m21) - m01 * (m10 * dCA - dBC * m20) + dAB * (m10 * m21 - m11 * m20)) * idet;
+    v[0] = v[0] + (eAB * tAB - eCA * tCA) * imA;
+    v[1] = v[1] + (eBC * tBC - eAB * tAB) * imB;
+    v[2] = v[2] + (eCA * tCA - eBC * tBC) * imC;
+}
+
+// SHAKE for a star cluster (central atom 0 bonded to atoms 1..n-1): p0 old constrained
+// positions, p1 unconstrained new positions (both relative to the old central atom).
+__device__ __forceinline__ void shake_positions(int n, const float* im, const float* d, float tol,
+                                                const float3* p0, float3* p1)
+{
+    for (int it = 0; it < 60; ++it) {
+        bool conv = true;
+        for (int k = 1; k < n; ++k) {
+            const float3 r0 = p0[k] - p0[0];
+            const float3 r = p1[k] - p1[0];
+            const float d2 = d[k - 1] * d[k - 1];
+            const float diff = d2 - dot3(r, r);
+            if (fabsf(diff) > 2.f * tol * d2) {
+                conv = false;
+                const float lam = diff / (2.f * (im[0] + im[k]) * dot3(r, r0));
+                p1[0] = p1[0] - r0 * (lam * im[0]);
+                p1[k] = p1[k] + r0 * (lam * im[k]);
+            }
+        }
+        if (conv) break;
+    }
+}
+
+__device__ __forceinline__ void shake_velocities(int n, const float* im, float tol, const float3* p, float3* v)
+{
+    for (int it = 0; it < 60; ++it) {
+        bool conv = true;
+        for (int k = 1; k < n; ++k) {
+            const float3 r = p[k] - p[0];
+            const float r2 = dot3(r, r);
+            const float rv = dot3(r, v[k] - v[0]);
+            // converged when the bond-length rate is below tol (1/ps, relative)
+            if (fabsf(rv) > tol * r2) {
+                conv = false;
+                const float lam = rv / (r2 * (im[0] + im[k]));
+                v[0] = v[0] + r * (lam * im[0]);
+                v[k] = v[k] - r * (lam * im[k]);
+            }
+        }
+        if (conv) break;
+    }
+}
+
+struct unit_regs {
+    int type, n;
+    int idx[4];
+    float3 x[4];     // absolute positions
+    float3 v[4];
+    float im[4];
+    float d[3];
+};
+
+__device__ __forceinline__ void constrain_v(const unit_regs& u, const settle_const& sc, float tol, float3* v, const float3* x)
+{
+    if (u.type == UNIT_SETTLE) {
+        float3 p[3] = { f3(0, 0, 0), x[1] - x[0], x[2] - x[0] };
+        settle_velocities(u.im[0], u.im[1], u.im[2], p, v);
+    } else if (u.type == UNIT_SHAKE) {
+        float3 p[4];
+        for (int k = 0; k < u.n; ++k) p[k] = x[k] - x[0];
+        shake_velocities(u.n, u.im, tol, p, v);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict__ unit_atoms,
+                            const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist,
+                            settle_const sc, float tol,
+                            int Npad, float4* __restrict__ pos, float4* __restrict__ vel,
+                            const long long* __restrict__ force, const float* __restrict__ invmass,
+                            const int64_t* __restrict__ labels, const double* __restrict__ beta,
+                            int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass)
+{
+    const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    float3 mom = f3(0, 0, 0);
+    if (uidx < n_units) {
+        unit_regs u;
+        const int4 a4 = unit_atoms[uidx];
+        u.idx[0] = a4.x; u.idx[1] = a4.y; u.idx[2] = a4.z; u.idx[3] = a4.w;
+        u.type = unit_type[uidx];
+        u.n = (a4.y < 0) ? 1 : (a4.z < 0) ? 2 : (a4.w < 0) ? 3 : 4;
+        float4* P = pos + (size_t)r * Npad;
+        float4* V = vel + (size_t)r * Npad;
+        const long long* F = force + (size_t)r * 3 * Npad;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < u.n) {
+            const float4 p = P[u.idx[k]], w = V[u.idx[k]];
+            u.x[k] = f3(p.x, p.y, p.z); u.v[k] = f3(w.x, w.y, w.z);
+            u.im[k] = invmass[u.idx[k]];
+        }
+        if (u.type == UNIT_SHAKE) for (int k = 0; k < 3; ++k) u.d[k] = shake_dist[uidx * 3 + k];
+        const float kT = (float)(1.0 / beta[labels[r_begin + r]]);
+        const uint32_t rg = (uint32_t)(r_begin + r);
+
+        for (int t = 0; t < prog.n; ++t) {
+            const char tok = prog.tok[t];
+            if (tok == 'V') {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (k < u.n) {
+                    const float s = prog.hV * u.im[k] * (1.0f / 4294967296.0f);
+                    u.v[k].x += s * (float)F[u.idx[k]];
+                    u.v[k].y += s * (float)F[Npad + u.idx[k]];
+                    u.v[k].z += s * (float)F[2 * Npad + u.idx[k]];
+                }
+                constrain_v(u, sc, tol, u.v, u.x);
+            } else if (tok == 'R') {
+                if (u.type == UNIT_FREE) {
+                    u.x[0] = u.x[0] + u.v[0] * prog.hR;
+                } else {
+                    // relative coordinates (origin = old position of atom 0) keep fp32 precision
+                    float3 p0[4], p1[4], q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < u.n) {
+                        p0[k] = u.x[k] - u.x[0];
+                        p1[k] = p0[k] + u.v[k] * prog.hR;
+                        q[k] = p1[k];
+                    }
+                    if (u.type == UNIT_SETTLE) settle_positions(sc, p0, p1);
+                    else shake_positions(u.n, u.im, u.d, tol, p0, p1);
+                    const float ih = 1.f / prog.hR;
+                    const float3 org = u.x[0];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < u.n) {
+                        u.v[k] = u.v[k] + (p1[k] - q[k]) * ih;          // integrators.py:1417
+                        u.x[k] = org + p1[k];
+                    }
+                    constrain_v(u, sc, tol, u.v, u.x);
+                }
+            } else if (tok == 'O') {
+                const uint64_t cnt = (uint64_t)prog.step[t] * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (k < u.n) {
+                    philox4 w = remd_philox(seed, REMD_STREAM_OU, (uint32_t)u.idx[k], rg, cnt);
+                    const float r1 = sqrtf(-2.f * __logf(remd_u23(w.w[0])));
+                    const float r2 = sqrtf(-2.f * __logf(remd_u23(w.w[2])));
+                    float s1, c1, s2, c2;
+                    __sincosf(6.2831853071795865f * remd_u23(w.w[1]), &s1, &c1);
+                    __sincosf(6.2831853071795865f * remd_u23(w.w[3]), &s2, &c2);
+                    const float sig = prog.b * sqrtf(kT * u.im[k]);
+                    u.v[k].x = prog.a * u.v[k].x + sig * (r1 * c1);
+                    u.v[k].y = prog.a * u.v[k].y + sig * (r1 * s1);
+                    u.v[k].z = prog.a * u.v[k].z + sig * (r2 * c2);
+                    (void)s2;
+                }
+                constrain_v(u, sc, tol, u.v, u.x);
+            } else if (tok == 'C') {
+                // CMMotionRemover: v -= P/M with P accumulated by the previous chain
+                const long long* c = cmm + (size_t)r * 4;
+                const float sx = (float)c[0] * (1.0f / 4294967296.0f) * inv_total_mass;
+                const float sy = (float)c[1] * (1.0f / 4294967296.0f) * inv_total_mass;
+                const float sz = (float)c[2] * (1.0f / 4294967296.0f) * inv_total_mass;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (k < u.n) { u.v[k].x -= sx; u.v[k].y -= sy; u.v[k].z -= sz; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < u.n) {
+            P[u.idx[k]] = make_float4(u.x[k].x, u.x[k].y, u.x[k].z, 0.f);
+            V[u.idx[k]] = make_float4(u.v[k].x, u.v[k].y, u.v[k].z, 0.f);
+            if (prog.accumulate_momentum) {
+                const float m = 1.f / u.im[k];
+                mom = mom + u.v[k] * m;
+            }
+        }
+    }
+    if (prog.accumulate_momentum) {
+        // wavefront shuffle reduction, one fixed-point atomic per wave (deterministic sum)
+        for (int off = 32; off > 0; off >>= 1) {
+            mom.x += __shfl_xor(mom.x, off); mom.y += __shfl_xor(mom.y, off); mom.z += __shfl_xor(mom.z, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + (size_t)r * 4);
+            atomicAdd(&c[0], (unsigned long long)(long long)((double)mom.x * 4294967296.0));
+            atomicAdd(&c[1], (unsigned long long)(long long)((double)mom.y * 4294967296.0));
+            atomicAdd(&c[2], (unsigned long long)(long long)((double)mom.z * 4294967296.0));
+        }
+    }
+}
+
+// Maxwell-Boltzmann velocities (mcmc.py:710-711): v = sqrt(kT/m) xi, then velocity constraints.
+__global__ __launch_bounds__(256)
+void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
+                              const unsigned char* __restrict__ unit_type, settle_const sc, float tol,
+                              int Npad, const float4* __restrict__ pos, float4* __restrict__ vel,
+                              const float* __restrict__ invmass, const int64_t* __restrict__ labels,
+                              const double* __restrict__ beta, int r_begin, uint64_t seed, int64_t iteration)
+{
+    const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (uidx >= n_units) return;
+    unit_regs u;
+    const int4 a4 = unit_atoms[uidx];
+    u.idx[0] = a4.x; u.idx[1] = a4.y; u.idx[2] = a4.z; u.idx[3] = a4.w;
+    u.type = unit_type[uidx];
+    u.n = (a4.y < 0) ? 1 : (a4.z < 0) ? 2 : (a4.w < 0) ? 3 : 4;
+    const float4* P = pos + (size_t)r * Npad;
+    float4* V = vel + (size_t)r * Npad;
+    const float kT = (float)(1.0 / beta[labels[r_begin + r]]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < u.n) {
+        const float4 p = P[u.idx[k]];
+        u.x[k] = f3(p.x, p.y, p.z);
+        u.im[k] = invmass[u.idx[k]];
+        philox4 w = remd_philox(seed, REMD_STREAM_VELOCITY, (uint32_t)u.idx[k], (uint32_t)(r_begin + r), (uint64_t)iteration);
+        const float r1 = sqrtf(-2.f * __logf(remd_u23(w.w[0])));
+        const float r2 = sqrtf(-2.f * __logf(remd_u23(w.w[2])));
+        float s1, c1, s2, c2;
+        __sincosf(6.2831853071795865f * remd_u23(w.w[1]), &s1, &c1);
+        __sincosf(6.2831853071795865f * remd_u23(w.w[3]), &s2, &c2);
+        const float sig = sqrtf(kT * u.im[k]);
+        u.v[k] = f3(sig * r1 * c1, sig * r1 * s1, sig * r2 * c2);
+        (void)s2;
+    }
+    constrain_v(u, sc, tol, u.v, u.x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < u.n) V[u.idx[k]] = make_float4(u.v[k].x, u.v[k].y, u.v[k].z, 0.f);
+}
+
+// KE = sum 1/2 m v^2 per replica: per-lane partial -> wave shuffle -> LDS -> one value per block,
+// blocks of one replica are summed in fixed order by the last stage (deterministic).
+__global__ __launch_bounds__(256)
+void kinetic_energy_kernel(int N, int Npad, const float4* __restrict__ vel, const float* __restrict__ mass,
+                           double* __restrict__ ke)
+{
+    __shared__ double s_part[4];
+    const int r = blockIdx.x;
+    const float4* V = vel + (size_t)r * Npad;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float4 v = V[i];
+        acc += 0.5 * (double)mass[i] * ((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ke[r] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ void check_finite_kernel(int N, int Npad, const float4* __restrict__ pos, const float4* __restrict__ vel, int* __restrict__ nan_flag)
+{
+    const int r = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float4 p = pos[(size_t)r * Npad + i], v = vel[(size_t)r * Npad + i];
+    const float s = p.x + p.y + p.z + v.x + v.y + v.z;
+    if (!isfinite(s)) nan_flag[r] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct unit_tables {
+    int n_units = 0;
+    int4* d_atoms = nullptr; unsigned char* d_type = nullptr; float* d_dist = nullptr;
+    settle_const sc{};
+};
+static std::map<remd_ctx*, unit_tables> g_units;
+
+int remd_build_constraints(remd_ctx* h, const remd_system_desc* d)
+{
+    unit_tables& ut = g_units[h];
+    if (ut.d_atoms) { hipFree(ut.d_atoms); hipFree(ut.d_type); hipFree(ut.d_dist); ut = unit_tables(); }
+    const int N = d->n_atoms;
+    std::vector<char> used(N, 0);
+    std::vector<int4> atoms; std::vector<unsigned char> type; std::vector<float> dist;
+    for (int s = 0; s < d->n_settle; ++s) {
+        const int* a = d->settle_atoms + 3 * s;
+        atoms.push_back(make_int4(a[0], a[1], a[2], -1)); type.push_back(UNIT_SETTLE);
+        dist.push_back(0); dist.push_back(0); dist.push_back(0);
+        for (int k = 0; k < 3; ++k) { if (a[k] < 0 || a[k] >= N || used[a[k]]) return remd_fail(h, -3, "bad SETTLE triple"); used[a[k]] = 1; }
+    }
+    for (int s = 0; s < d->n_shake; ++s) {
+        const int* a = d->shake_atoms + 4 * s;
+        atoms.push_back(make_int4(a[0], a[1], a[2], a[3])); type.push_back(UNIT_SHAKE);
+        for (int k = 0; k < 3; ++k) dist.push_back((float)d->shake_dist[3 * s + k]);
+        for (int k = 0; k < 4; ++k) if (a[k] >= 0) { if (a[k] >= N || used[a[k]]) return remd_fail(h, -3, "bad SHAKE cluster"); used[a[k]] = 1; }
+    }
+    for (int i = 0; i < N; ++i) if (!used[i]) {
+        atoms.push_back(make_int4(i, -1, -1, -1)); type.push_back(UNIT_FREE);
+        dist.push_back(0); dist.push_back(0); dist.push_back(0);
+    }
+    ut.n_units = (int)atoms.size();
+    REMD_CHECK(h, hipMalloc(&ut.d_atoms, sizeof(int4) * ut.n_units));
+    REMD_CHECK(h, hipMalloc(&ut.d_type, ut.n_units));
+    REMD_CHECK(h, hipMalloc(&ut.d_dist, sizeof(float) * 3 * ut.n_units));
+    REMD_CHECK(h, hipMemcpy(ut.d_atoms, atoms.data(), sizeof(int4) * ut.n_units, hipMemcpyHostToDevice));
+    REMD_CHECK(h, hipMemcpy(ut.d_type, type.data(), ut.n_units, hipMemcpyHostToDevice));
+    REMD_CHECK(h, hipMemcpy(ut.d_dist, dist.data(), sizeof(float) * 3 * ut.n_units, hipMemcpyHostToDevice));
+    h->n_settle = d->n_settle; h->n_shake = d->n_shake;
+    int n_con = 3 * d->n_settle;
+    for (int s = 0; s < d->n_shake; ++s) for (int k = 1; k < 4; ++k) if (d->shake_atoms[4 * s + k] >= 0) n_con++;
+    h->n_dof = 3 * N - n_con - (d->cmm_frequency > 0 ? 3 : 0);
+    if (d->n_settle > 0) {
+        const int* a = d->settle_atoms;
+        const double mO = d->mass[a[0]], mH = d->mass[a[1]];
+        const double rc = 0.5 * d->settle_dHH;
+        const double t = sqrt(d->settle_dOH * d->settle_dOH - rc * rc);
+        const double ra = 2.0 * mH * t / (mO + 2.0 * mH);
+        ut.sc.mO = (float)mO; ut.sc.mH = (float)mH; ut.sc.ra = (float)ra; ut.sc.rb = (float)(t - ra);
+        ut.sc.rc = (float)rc; ut.sc.dOH = (float)d->settle_dOH; ut.sc.dHH = (float)d->settle_dHH;
+    }
+    return 0;
+}
+
+void remd_free_constraints(remd_ctx* h)
+{
+    auto it = g_units.find(h);
+    if (it == g_units.end()) return;
+    if (it->second.d_atoms) { hipFree(it->second.d_atoms); hipFree(it->second.d_type); hipFree(it->second.d_dist); }
+    g_units.erase(it);
+}
+
+int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO)
+{
+    // integrators.py:1474-1537: space-separated, case-insensitive V/R/O tokens.  Force-group
+    // suffixes (V0, V1: multiple-time-step) and Metropolization braces are not supported.
+    tokens.clear(); nV = nR = nO = 0;
+    std::string s(splitting ? splitting : "");
+    size_t i = 0;
+    while (i < s.size()) {
+        while (i < s.size() && s[i] == ' ') ++i;
+        if (i >= s.size()) break;
+        size_t j = i; while (j < s.size() && s[j] != ' ') ++j;
+        std::string tok = s.substr(i, j - i);
+        for (auto& c : tok) c = (char)toupper(c);
+        if (tok == "V" || tok == "V0") { tokens.push_back('V'); nV++; }
+        else if (tok == "R") { tokens.push_back('R'); nR++; }
+        else if (tok == "O") { tokens.push_back('O'); nO++; }
+        else return remd_fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V R O)");
+        i = j;
+    }
+    if (tokens.empty()) return remd_fail(h, -3, "empty splitting string");
+    if (nR == 0 || nV == 0) return remd_fail(h, -3, "splitting needs at least one R and one V (integrators.py:1376-1385)");
+    return 0;
+}
+
+static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog)
+{
+    remd_prof_scope ps(h, "integrate_chain");
+    dim3 grid((ut.n_units + 255) / 256, h->R);
+    hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
+                       ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
+                       h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
+                       (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0));
+}
+
+// Runs n_steps of the token program.  Tokens are grouped into chains that need no new
+// force evaluation; a 'V' after an 'R' forces a force evaluation first.
+int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
+                   int64_t iteration, int64_t first_step, int n_steps)
+{
+    const unit_tables& ut = g_units[h];
+    if (ut.n_units == 0) return remd_fail(h, -3, "no system set");
+    chain_prog base{};
+    base.hV = (float)(h->dt / (nV > 0 ? nV : 1));
+    base.hR = (float)(h->dt / (nR > 0 ? nR : 1));
+    const double hO = h->dt / (nO > 0 ? nO : 1);                 // integrators.py:1142
+    base.a = (float)exp(-h->gamma * hO);                         // :1143
+    base.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO));       // :1146
+    base.nO = nO > 0 ? nO : 1;
+    chain_prog cur = base; cur.n = 0;
+    auto flush = [&](bool accumulate) {
+        if (cur.n == 0 && !accumulate) return;
+        cur.accumulate_momentum = accumulate ? 1 : 0;
+        launch_chain(h, ut, cur);
+        cur = base; cur.n = 0;
+    };
+    auto push = [&](char tok, int oidx, long long step) {
+        if (cur.n == MAX_TOK) flush(false);
+        cur.tok[cur.n] = tok; cur.o_index[cur.n] = oidx; cur.step[cur.n] = step; cur.n++;
+    };
+    for (int s = 0; s < n_steps; ++s) {
+        const long long gstep = (long long)iteration * (long long)h->n_steps + first_step + s;
+        // integrators.py:1313 addUpdateContextState: CMMotionRemover fires at the top of a step
+        if (h->cmm_frequency > 0 && ((first_step + s) % h->cmm_frequency) == 0) {
+            bool pending_reads_cmm = false;
+            for (int t = 0; t < cur.n; ++t) pending_reads_cmm |= (cur.tok[t] == 'C');
+            if (pending_reads_cmm) flush(false);   // it must see the previous accumulators
+            hipMemsetAsync(h->d_cmm, 0, sizeof(long long) * 4 * h->R, h->stream);
+            flush(true);                        // finishes pending tokens and accumulates sum(m v)
+            push('C', 0, gstep);
+        }
+        int oidx = 0;
+        for (char tok : tokens) {
+            if (tok == 'V' && !h->forces_valid) {
+                flush(false);
+                int rc = remd_compute_forces(h, false);
+                if (rc) return rc;
+            }
+            push(tok, tok == 'O' ? oidx : 0, gstep);
+            if (tok == 'O') oidx++;
+            if (tok == 'R') h->forces_valid = false;
+        }
+    }
+    flush(false);
+    REMD_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int remd_assign_velocities(remd_ctx* h, int64_t iteration)
+{
+    const unit_tables& ut = g_units[h];
+    remd_prof_scope ps(h, "assign_velocities");
+    dim3 grid((ut.n_units + 255) / 256, h->R);
+    hipLaunchKernelGGL(assign_velocities_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc,
+                       (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_invmass, h->d_labels,
+                       h->d_beta, h->r_begin, h->seed, iteration);
+    REMD_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int remd_kinetic_energy(remd_ctx* h)
+{
+    remd_prof_scope ps(h, "kinetic_energy");
+    hipLaunchKernelGGL(kinetic_energy_kernel, dim3(h->R), dim3(256), 0, h->stream, h->N, h->Npad, h->d_vel, h->d_mass, h->d_kinetic);
+    REMD_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+int remd_check_finite(remd_ctx* h)
+{
+    REMD_CHECK(h, hipMemsetAsync(h->d_nan, 0, sizeof(int) * h->R, h->stream));
+    dim3 grid((h->N + 255) / 256, h->R);
+    hipLaunchKernelGGL(check_finite_kernel, grid, dim3(256), 0, h->stream, h->N, h->Npad, h->d_pos, h->d_vel, h->d_nan);
+    REMD_CHECK(h, hipGetLastError());
+    return 0;
+}

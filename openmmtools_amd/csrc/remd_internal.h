@@ -1,0 +1,152 @@
+// Internal declarations of libremd_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/remd_hip.h"
+
+#define REMD_KB 0.00831446261815324   // kJ/mol/K  (BOLTZMANN_CONSTANT_kB * AVOGADRO_CONSTANT_NA)
+#define REMD_ONE_4PI_EPS0 138.93545764438198
+
+struct remd_error { int code; std::string msg; };
+
+// fixed-point scale of the force accumulators (deterministic integer atomics)
+#define REMD_FORCE_SCALE 4294967296.0   // 2^32
+
+struct remd_profile_entry { int64_t n = 0; double ms = 0.0; };
+
+struct remd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    uint64_t seed = 0;
+
+    // ---- system -------------------------------------------------------------------
+    int N = 0;            // atoms
+    int Npad = 0;         // atoms padded to a multiple of 64
+    bool has_system = false;
+    float* d_invmass = nullptr;        // [Npad]  (0 for padding)
+    float* d_mass = nullptr;           // [Npad]
+    double total_mass = 0.0;
+    // harmonic external force
+    int n_ext = 0; int* d_ext_atoms = nullptr; double ext_K = 0, ext_x0 = 0, ext_U0 = 0;
+    // bonded
+    int n_bonds = 0, n_angles = 0, n_torsions = 0;
+    int* d_bond_atoms = nullptr; float* d_bond_params = nullptr;
+    int* d_angle_atoms = nullptr; float* d_angle_params = nullptr;
+    int* d_torsion_atoms = nullptr; float* d_torsion_params = nullptr;
+    // nonbonded
+    int nb_method = REMD_NB_NONE;
+    double cutoff = 0, switch_dist = -1, rf_dielectric = 78.3, ewald_alpha = 0;
+    int grid[3] = {0, 0, 0};
+    int use_disp = 0;
+    double disp_coeff = 0;             // E_lrc = disp_coeff / V for the non-alchemical system
+    float4* d_nbparam = nullptr;       // [Npad] (q, sigma/2, 2*sqrt(eps), alch flag)
+    unsigned long long* d_exclmask = nullptr; // [Npad][EXCL_WORDS] window exclusion bit masks
+    int excl_window = 0;               // atoms j in [i-excl_window, i+excl_window] are mask-addressable
+    int n_exceptions = 0;              // 1-4 style exceptions with non-zero params
+    int* d_exc_atoms = nullptr; float* d_exc_params = nullptr;   // [n][2], [n][3]
+    int n_excl_pairs = 0;              // all excluded pairs (for the PME exclusion correction)
+    int* d_excl_pairs = nullptr;       // [n][2]
+    double self_energy = 0;            // PME self term (kJ/mol), lambda_elec = 1
+    // constraints
+    int n_settle = 0; int* d_settle_atoms = nullptr; double settle_dOH = 0, settle_dHH = 0;
+    int n_shake = 0;  int* d_shake_atoms = nullptr; float* d_shake_dist = nullptr;
+    int n_groups = 0; int* d_group_first = nullptr;   // constraint groups (molecule-like units)
+    int* d_free_atoms = nullptr; int n_free = 0;      // atoms in no constraint
+    int cmm_frequency = 0;
+    int n_dof = 0;
+    // alchemy
+    int n_alch = 0; int* d_alch_atoms = nullptr;
+    double sc_alpha = 0.5, sc_a = 1, sc_b = 1, sc_c = 6;
+
+    // ---- states ---------------------------------------------------------------------
+    int K = 0;
+    std::vector<double> beta, lam_s, lam_e, econst;
+    double* d_beta = nullptr; double* d_lam_s = nullptr; double* d_lam_e = nullptr; double* d_econst = nullptr;
+
+    // ---- integrator -----------------------------------------------------------------
+    std::string splitting = "V R O R V";
+    std::vector<char> tokens;          // parsed 'V','R','O'
+    int nV = 0, nR = 0, nO = 0;
+    double dt = 0.001, gamma = 1.0, constraint_tol = 1e-8;
+    int n_steps = 1; int reassign = 1;
+    bool has_integrator = false;
+
+    // ---- replicas -------------------------------------------------------------------
+    int R_global = 0, r_begin = 0, R = 0;     // R = local replicas
+    float4* d_pos = nullptr;           // [R][Npad] xyz + pad
+    float4* d_vel = nullptr;           // [R][Npad] xyz + pad
+    float4* d_pos_ref = nullptr;       // [R][Npad] reference (constrained) positions for SHAKE/SETTLE
+    long long* d_force = nullptr;      // [R][3][Npad] fixed point
+    float* d_box = nullptr;            // [R][4] lx, ly, lz, pad
+    std::vector<double> box_host;      // [R][3]
+    int64_t* d_labels = nullptr;       // [R_global]
+    std::vector<int64_t> labels;
+    double* d_ukl = nullptr;           // [R_global][K]
+    double* d_potential = nullptr;     // [R]
+    double* d_epart = nullptr; int n_epart = 0;   // per-replica per-block energy partials
+    double* d_kinetic = nullptr;       // [R]
+    int* d_nan = nullptr;              // [R]
+    long long* d_cmm = nullptr;        // [R][4] fixed-point momentum accumulators
+    bool forces_valid = false;
+
+    // ---- PME ------------------------------------------------------------------------
+    void* pme = nullptr;               // opaque (pme.hip)
+
+    // ---- mixing scratch ----------------------------------------------------------------
+    unsigned long long* d_nacc = nullptr; unsigned long long* d_nprop = nullptr; int stats_K = 0;
+    double* d_logw = nullptr; double* d_logP = nullptr; double* d_ukl_tmp = nullptr; size_t ukl_tmp_n = 0;
+
+    // ---- timing / profiling -------------------------------------------------------------
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double t_prop = 0, t_energy = 0, t_mix = 0;
+    bool profiling = false;
+    std::map<std::string, remd_profile_entry> prof;
+};
+
+#define REMD_CHECK(h, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e); remd_set_global_error((h)->err); return -2; } } while (0)
+
+void remd_set_global_error(const std::string& s);
+int remd_fail(remd_ctx* h, int code, const std::string& msg);
+
+// profiling wrapper: brackets a launch with events when profiling is on
+struct remd_prof_scope {
+    remd_ctx* h; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    remd_prof_scope(remd_ctx* h_, const char* n) : h(h_), name(n) {
+        if (h->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, h->stream); }
+    }
+    ~remd_prof_scope() {
+        if (h->profiling) {
+            hipEventRecord(b, h->stream); hipEventSynchronize(b);
+            float ms = 0; hipEventElapsedTime(&ms, a, b);
+            auto& e = h->prof[name]; e.n += 1; e.ms += ms;
+            hipEventDestroy(a); hipEventDestroy(b);
+        }
+    }
+};
+
+// ---- mix.hip --------------------------------------------------------------------------
+int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, int ld, const double* d_ukl,
+                    int64_t* d_labels, unsigned long long* d_nacc, unsigned long long* d_nprop,
+                    const double* d_logw, double* d_logP, int64_t n_attempts);
+
+// ---- integrate.hip ----------------------------------------------------------------------
+int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO);
+int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
+                   int64_t iteration, int64_t first_step, int n_steps);
+int remd_assign_velocities(remd_ctx* h, int64_t iteration);
+int remd_kinetic_energy(remd_ctx* h);
+
+// ---- forces.hip -------------------------------------------------------------------------
+int remd_compute_forces(remd_ctx* h, bool with_energy);   // fills d_force (and d_potential when with_energy)
+int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d);
+int remd_build_constraints(remd_ctx* h, const remd_system_desc* d);
+
+// ---- pme.hip ----------------------------------------------------------------------------
+int remd_pme_setup(remd_ctx* h);
+int remd_pme_destroy(remd_ctx* h);
+int remd_pme_forces(remd_ctx* h, bool with_energy, double* d_energy /*[R]*/);

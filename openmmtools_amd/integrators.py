@@ -1,0 +1,114 @@
+"""Langevin splitting integrators as parameter carriers for the device engine.
+
+Mirrors openmmtools/integrators.py: LangevinIntegrator (:1015-1557), VVVRIntegrator (:2125),
+BAOABIntegrator (:2152), GeodesicBAOABIntegrator (:2194).  The reference builds an OpenMM
+CustomIntegrator step program; here the splitting string is parsed with the same rules
+(:1474-1537, sanity check :1337-1402) and handed to libremd_hip.so, whose integrate_chain
+kernel executes the V/R/O substeps (csrc/integrate.hip).
+"""
+import math
+from . import unit, constants
+
+
+class LangevinIntegrator:
+    def __init__(self, temperature=298.0 * unit.kelvin, collision_rate=1.0 / unit.picoseconds,
+                 timestep=1.0 * unit.femtoseconds, splitting="V R O R V", constraint_tolerance=1e-8,
+                 measure_shadow_work=False, measure_heat=False):
+        if measure_shadow_work or measure_heat:
+            raise NotImplementedError('heat / shadow-work accumulators are not implemented (SURVEY 8(f) #3)')
+        self._temperature = float(temperature)
+        self._gamma = float(collision_rate)
+        self._timestep = float(timestep)
+        self._constraint_tolerance = float(constraint_tolerance)
+        self._splitting = splitting
+        self._ORV_counts, self._mts, self._force_group_nV = self._parse_splitting_string(splitting)
+
+    # ---- reference API ---------------------------------------------------------------
+    def getStepSize(self):
+        return self._timestep
+
+    def getTemperature(self):
+        return self._temperature
+
+    def setTemperature(self, temperature):
+        self._temperature = float(temperature)
+
+    def getConstraintTolerance(self):
+        return self._constraint_tolerance
+
+    @property
+    def kT(self):
+        return constants.kB * self._temperature
+
+    @property
+    def is_metropolized(self):
+        return False
+
+    @property
+    def splitting(self):
+        return self._splitting
+
+    @property
+    def collision_rate(self):
+        return self._gamma
+
+    @property
+    def a(self):
+        """integrators.py:1142-1143."""
+        h = self._timestep / max(1, self._ORV_counts['O'])
+        return math.exp(-self._gamma * h)
+
+    @property
+    def b(self):
+        """integrators.py:1146."""
+        h = self._timestep / max(1, self._ORV_counts['O'])
+        return math.sqrt(1.0 - math.exp(-2.0 * self._gamma * h))
+
+    # ---- parsing (integrators.py:1337-1402, 1474-1537) --------------------------------------
+    @staticmethod
+    def _sanity_check(splitting):
+        tokens = splitting.split(' ')
+        if '{' in splitting or '}' in splitting:
+            raise NotImplementedError('Metropolized splittings ("{ }") are not implemented (GHMC is out of scope)')
+        for t in tokens:
+            if t == '':
+                raise ValueError('Invalid step name: splitting has repeated or trailing spaces')
+            if t[0] not in 'ORV':
+                raise ValueError("Invalid step name '%s' used; valid step names are R, V, O" % t)
+            if t[0] != 'V' and len(t) > 1:
+                raise ValueError("Invalid step name '%s'" % t)
+            if t[0] == 'V' and len(t) > 1 and not t[1:].isdigit():
+                raise ValueError("Invalid force group in step '%s'" % t)
+        if 'R' not in tokens:
+            raise ValueError('Must have at least one R step')
+        if not any(t[0] == 'V' for t in tokens):
+            raise ValueError('Must have at least one V step')
+
+    def _parse_splitting_string(self, splitting_string):
+        splitting_string = splitting_string.upper()
+        self._sanity_check(splitting_string)
+        steps = splitting_string.split(' ')
+        counts = {s: sum(1 for t in steps if t[0] == s) for s in 'ORV'}
+        groups = set(t[1:] for t in steps if t[0] == 'V' and len(t) > 1)
+        mts = len(groups) > 1
+        if mts:
+            raise NotImplementedError('multiple-time-step splittings (V0 V1 ...) are not implemented')
+        return counts, mts, {'0': counts['V']}
+
+
+class VVVRIntegrator(LangevinIntegrator):
+    def __init__(self, *args, **kwargs):
+        kwargs['splitting'] = "O V R V O"       # integrators.py:2149
+        super().__init__(*args, **kwargs)
+
+
+class BAOABIntegrator(LangevinIntegrator):
+    def __init__(self, *args, **kwargs):
+        kwargs['splitting'] = "V R O R V"       # integrators.py:2190
+        super().__init__(*args, **kwargs)
+
+
+class GeodesicBAOABIntegrator(LangevinIntegrator):
+    def __init__(self, *args, K_r=2, **kwargs):
+        kwargs['splitting'] = " ".join(["V"] + ["R"] * K_r + ["O"] + ["R"] * K_r + ["V"])   # :2237-2238
+        super().__init__(*args, **kwargs)

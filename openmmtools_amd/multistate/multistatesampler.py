@@ -1,0 +1,346 @@
+"""MultiStateSampler: the replica-exchange iteration loop driving the device engine.
+
+Mirrors openmmtools/multistate/multistatesampler.py (class :63): ``create`` (:537-609,
+_pre_write_create :836-926), ``run`` (:724-804: mix -> propagate -> energies), ``equilibrate``
+(:649-722: propagate -> energies -> mix), and the three hooks the engine replaces:
+``_mix_replicas`` (:1500-1517), ``_propagate_replicas`` (:1287-1337), ``_compute_energies``
+(:1436-1494).  Storage (MultiStateReporter), online analysis and minimization are out of
+scope; ``storage`` is accepted and ignored unless it offers ``write_iteration``.
+"""
+import copy
+import time
+import logging
+import numpy as np
+
+from .. import mcmc, unit
+from ..system import system_to_desc
+from .utils import SimulationNaNError
+from .comm import SingleProcessComm
+
+logger = logging.getLogger(__name__)
+
+
+class MultiStateSampler:
+    def __init__(self, mcmc_moves=None, number_of_iterations=1, locality=None,
+                 online_analysis_interval=None, engine=None, seed=0xC0FFEE, comm=None):
+        if locality is not None:
+            raise NotImplementedError('only global neighborhoods (locality=None) are implemented')
+        if mcmc_moves is None:
+            # multistatesampler.py:224-227
+            self._mcmc_moves = mcmc.LangevinDynamicsMove(timestep=2.0 * unit.femtosecond,
+                                                         collision_rate=5.0 / unit.picosecond,
+                                                         n_steps=500, reassign_velocities=True,
+                                                         n_restart_attempts=6)
+        else:
+            self._mcmc_moves = copy.deepcopy(mcmc_moves)
+        self.number_of_iterations = number_of_iterations
+        self.locality = locality
+        self.online_analysis_interval = online_analysis_interval
+        self._engine = engine
+        self._seed = int(seed)
+        self._comm = comm if comm is not None else SingleProcessComm()
+        self._thermodynamic_states = None
+        self._unsampled_states = None
+        self._sampler_states = None
+        self._replica_thermodynamic_states = None
+        self._iteration = None
+        self._energy_thermodynamic_states = None
+        self._neighborhoods = None
+        self._energy_unsampled_states = None
+        self._n_accepted_matrix = None
+        self._n_proposed_matrix = None
+        self._reporter = None
+        self._timing_data = dict()
+        self._sampler_states_stale = False
+        self._device_ukl = None          # torch tensor [R, K_total] (multi-rank or device mixing)
+        self.verify_labels = False
+
+    # ---- properties (multistatesampler.py:301-436) ----------------------------------------
+    @property
+    def n_states(self):
+        return 0 if self._thermodynamic_states is None else len(self._thermodynamic_states)
+
+    @property
+    def n_replicas(self):
+        return 0 if self._sampler_states is None else len(self._sampler_states)
+
+    @property
+    def iteration(self):
+        return self._iteration
+
+    @property
+    def mcmc_moves(self):
+        return copy.deepcopy(self._mcmc_moves)
+
+    @property
+    def thermodynamic_states(self):
+        return self._thermodynamic_states
+
+    @property
+    def sampler_states(self):
+        self._sync_sampler_states()
+        return self._sampler_states
+
+    @property
+    def replica_thermodynamic_states(self):
+        return self._replica_thermodynamic_states
+
+    @property
+    def energy_thermodynamic_states(self):
+        return self._energy_thermodynamic_states
+
+    @property
+    def is_completed(self):
+        return self._iteration >= self.number_of_iterations
+
+    @property
+    def engine(self):
+        return self._engine
+
+    # ---- create ---------------------------------------------------------------------------
+    @classmethod
+    def _default_initial_thermodynamic_states(cls, thermodynamic_states, sampler_states):
+        """multistatesampler.py:1117-1143."""
+        n_thermo, n_sampler = len(thermodynamic_states), len(sampler_states)
+        thermo_indices = np.arange(n_thermo, dtype=int)
+        initial = np.zeros(n_sampler, dtype=int)
+        loops = n_sampler // n_thermo
+        n_looped = n_thermo * loops
+        initial[:n_looped] = np.tile(thermo_indices, loops)
+        initial[n_looped:] = np.linspace(0, n_thermo - 1, n_sampler - n_looped, dtype=int)
+        return initial
+
+    def create(self, thermodynamic_states, sampler_states, storage=None, initial_thermodynamic_states=None,
+               unsampled_thermodynamic_states=None, metadata=None):
+        if self._thermodynamic_states is not None:
+            raise RuntimeError('Cannot invoke create() on an already initialized sampler')   # :572-574
+        if hasattr(sampler_states, 'positions'):
+            sampler_states = [sampler_states]
+        self._pre_write_create(thermodynamic_states, sampler_states, storage,
+                               initial_thermodynamic_states=initial_thermodynamic_states,
+                               unsampled_thermodynamic_states=unsampled_thermodynamic_states, metadata=metadata)
+        self._reporter = storage if hasattr(storage, 'write_iteration') else None
+        self._initialize_engine()
+
+    def _pre_write_create(self, thermodynamic_states, sampler_states, storage, initial_thermodynamic_states=None,
+                          unsampled_thermodynamic_states=None, metadata=None):
+        """multistatesampler.py:836-926."""
+        is_periodic = thermodynamic_states[0].is_periodic
+        for ts in thermodynamic_states:
+            if ts.is_periodic != is_periodic:
+                raise Exception('Thermodynamic states contain a mixture of systems with and without '
+                                'periodic boundary conditions.')
+        if is_periodic:
+            for ss in sampler_states:
+                if ss.box_vectors is None:
+                    raise Exception('All sampler states must have box_vectors defined if the system is periodic.')
+        n_particles = thermodynamic_states[0].n_particles
+        for the_states in (thermodynamic_states, sampler_states):
+            for state in the_states:
+                if state.n_particles != n_particles:
+                    raise ValueError('All ThermodynamicStates and SamplerStates must have the same number '
+                                     'of particles')
+        self._metadata = dict(metadata) if metadata else {}
+        self._thermodynamic_states = copy.deepcopy(list(thermodynamic_states))
+        self._unsampled_states = copy.deepcopy(list(unsampled_thermodynamic_states or []))
+        self._sampler_states = [copy.deepcopy(s) for s in sampler_states]
+        if initial_thermodynamic_states is None:
+            initial_thermodynamic_states = self._default_initial_thermodynamic_states(thermodynamic_states,
+                                                                                      sampler_states)
+        self._replica_thermodynamic_states = np.array(initial_thermodynamic_states, np.int64)
+        for replica_id, state_id in enumerate(self._replica_thermodynamic_states):
+            ss = self._sampler_states[replica_id]
+            if ss.box_vectors is None:
+                ss.box_vectors = self._thermodynamic_states[state_id].system.getDefaultPeriodicBoxVectors()
+        if isinstance(self._mcmc_moves, mcmc.MCMCMove):
+            self._mcmc_moves = [copy.deepcopy(self._mcmc_moves) for _ in range(self.n_states)]
+        elif len(self._mcmc_moves) != self.n_states:
+            raise RuntimeError('The number of MCMCMoves ({}) and ThermodynamicStates ({}) must be the same.'.format(
+                len(self._mcmc_moves), self.n_states))
+        self._iteration = 0
+        K, R = self.n_states, self.n_replicas
+        self._n_accepted_matrix = np.zeros([K, K], np.int64)
+        self._n_proposed_matrix = np.zeros([K, K], np.int64)
+        self._energy_thermodynamic_states = np.zeros([R, K], np.float64)
+        self._neighborhoods = np.zeros([R, K], 'i1')
+        self._energy_unsampled_states = np.zeros([R, len(self._unsampled_states)], np.float64)
+
+    def _engine_move(self):
+        """All states must share one Langevin recipe (one batched launch covers every replica)."""
+        m0 = self._mcmc_moves[0]
+        if not isinstance(m0, mcmc.LangevinSplittingDynamicsMove):
+            raise NotImplementedError('the device engine propagates with Langevin(Splitting)DynamicsMove only')
+        key0 = (m0.timestep, m0.collision_rate, m0.n_steps, m0.reassign_velocities, m0.splitting)
+        for m in self._mcmc_moves[1:]:
+            if (m.timestep, m.collision_rate, m.n_steps, m.reassign_velocities, m.splitting) != key0:
+                raise NotImplementedError('per-state MCMC moves must be identical for batched propagation')
+        return m0
+
+    def _state_energy_constants(self, states):
+        """Additive per-state potential constants (e.g. lambda-dependent long-range corrections)."""
+        return np.zeros(len(states))
+
+    def _initialize_engine(self):
+        if self._engine is None:
+            from .._engine import HipEngine
+            self._engine = HipEngine()          # raises if libremd_hip.so / a GPU is missing: no CPU fallback
+        eng = self._engine
+        all_states = list(self._thermodynamic_states) + list(self._unsampled_states)
+        ref = all_states[0]
+        for s in all_states[1:]:
+            if not s.is_state_compatible(ref):
+                raise NotImplementedError('all thermodynamic states must share one System (differing only in '
+                                          'temperature and lambda parameters)')
+        box0 = self._sampler_states[0].box_edges if ref.is_periodic else None
+        desc = system_to_desc(ref.system, box=box0)
+        eng.set_system(desc)
+        beta = np.array([s.beta for s in all_states])
+        lam_s = np.array([s.lambda_sterics for s in all_states], dtype=np.float64)
+        lam_e = np.array([s.lambda_electrostatics for s in all_states], dtype=np.float64)
+        eng.set_states(beta, lam_s, lam_e, self._state_energy_constants(all_states))
+        move = self._engine_move()
+        eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
+                           move.reassign_velocities, move.constraint_tolerance)
+        eng.seed(self._seed)
+        R = self.n_replicas
+        self._r_begin, self._r_count = self._comm.partition(R)
+        sl = slice(self._r_begin, self._r_begin + self._r_count)
+        x = np.stack([s.positions for s in self._sampler_states[sl]])
+        have_v = all(s.velocities is not None for s in self._sampler_states[sl])
+        v = np.stack([s.velocities for s in self._sampler_states[sl]]) if have_v else None
+        if ref.is_periodic:
+            box = np.stack([s.box_edges for s in self._sampler_states[sl]])
+        else:
+            box = np.zeros((self._r_count, 3))
+        eng.set_replicas(R, self._r_begin, x, v, box, self._replica_thermodynamic_states)
+        self._K_total = len(all_states)
+
+    # ---- run / equilibrate ------------------------------------------------------------------
+    def equilibrate(self, n_iterations, mcmc_moves=None):
+        """multistatesampler.py:649-722: propagate -> energies -> mix, iteration counter untouched."""
+        if mcmc_moves is not None:
+            raise NotImplementedError('equilibrate() with a different move set')
+        if self._iteration == 0 and not self._energies_computed():
+            self._compute_energies()
+        for it in range(1, 1 + n_iterations):
+            self._equil_iteration = it
+            self._propagate_replicas(rng_iteration=-it)
+            self._compute_energies()
+            self._replica_thermodynamic_states = self._mix_replicas(rng_iteration=-it)
+        self._check_nan_energy()
+
+    def _energies_computed(self):
+        return bool(self._neighborhoods.any())
+
+    def run(self, n_iterations=None):
+        """multistatesampler.py:724-804."""
+        if self._thermodynamic_states is None:
+            raise RuntimeError('call create() first')
+        if self._iteration == 0 and not self._energies_computed():
+            self._compute_energies()                                   # :738-753
+            self._check_nan_energy()
+        if n_iterations is None:
+            iteration_limit = self.number_of_iterations
+        else:
+            iteration_limit = min(self._iteration + n_iterations, self.number_of_iterations)
+        t_run = time.time()
+        while self._iteration < iteration_limit:                       # :766
+            t0 = time.time()
+            self._iteration += 1                                       # :768
+            self._replica_thermodynamic_states = self._mix_replicas()  # :776
+            t1 = time.time()
+            self._propagate_replicas()                                 # :779
+            t2 = time.time()
+            self._compute_energies()                                   # :782
+            t3 = time.time()
+            self._report_iteration()                                   # :785
+            self._update_timing(t0, t1, t2, t3, t_run)                 # :793
+            self._check_nan_energy()                                   # :804
+
+    def _update_timing(self, t0, t1, t2, t3, t_run):
+        """multistatesampler.py:1766-1803 (subset)."""
+        d = self._timing_data
+        d['iteration_seconds'] = t3 - t0
+        d['mixing_seconds'] = t1 - t0
+        d['propagation_seconds'] = t2 - t1
+        d['energy_seconds'] = t3 - t2
+        n = d.get('n_timed', 0) + 1
+        d['n_timed'] = n
+        d['average_seconds_per_iteration'] = (time.time() - t_run) / n if n else 0.0
+        move = self._mcmc_moves[0]
+        ns_per_iter = move.timestep * move.n_steps * 1e-3 * self.n_replicas
+        d['ns_per_day'] = ns_per_iter / d['iteration_seconds'] * 86400.0 if d['iteration_seconds'] > 0 else 0.0
+
+    def _report_iteration(self):
+        if self._reporter is not None:
+            self._reporter.write_iteration(self)
+
+    # ---- the three hooks ---------------------------------------------------------------------
+    def _mix_replicas(self, rng_iteration=None):
+        """multistatesampler.py:1500-1517: the base class does not mix."""
+        self._n_accepted_matrix[:, :] = 0
+        self._n_proposed_matrix[:, :] = 0
+        return self._replica_thermodynamic_states
+
+    def _propagate_replicas(self, rng_iteration=None):
+        """multistatesampler.py:1287-1337 for every local replica in one device call."""
+        it = self._iteration if rng_iteration is None else rng_iteration
+        self._engine.set_labels(self._replica_thermodynamic_states)
+        flags = self._engine.propagate(it)
+        self._sampler_states_stale = True
+        if np.any(flags):
+            bad = (np.nonzero(flags)[0] + self._r_begin).tolist()
+            raise SimulationNaNError('Propagating replicas {} resulted in a NaN!'.format(bad))
+        for move in self._mcmc_moves:
+            move.statistics = dict(n_attempts=move.statistics.get('n_attempts', 0) + 1)
+
+    def _compute_energies(self):
+        """multistatesampler.py:1436-1494: fill u_kl for all replicas (global neighborhoods)."""
+        K, U = self.n_states, len(self._unsampled_states)
+        if self._comm.world_size == 1:
+            rows = self._engine.compute_energies()
+            full = rows
+        else:
+            full = self._gather_rows()
+        full = np.asarray(full)
+        self._energy_thermodynamic_states[:, :] = full[:, :K]
+        if U:
+            self._energy_unsampled_states[:, :] = full[:, K:]
+        self._neighborhoods[:, :] = 1                                   # :1441-1444 with locality None
+
+    def _gather_rows(self):
+        """Multi-rank: each rank computes its [R_local, K_total] rows; RCCL/gloo all-gather."""
+        import torch
+        eng = self._engine
+        Kt = self._K_total
+        if getattr(eng, 'is_device', False):
+            if self._device_ukl is None:
+                dev = torch.device('cuda', eng.device)
+                self._device_rows = torch.empty((self._r_count, Kt), dtype=torch.float64, device=dev)
+                self._device_ukl = torch.empty((self.n_replicas, Kt), dtype=torch.float64, device=dev)
+            eng.compute_energies(d_rows=self._device_rows.data_ptr(), want_host=False)
+            self._comm.all_gather_rows(self._device_rows, self.n_replicas, out=self._device_ukl)
+            torch.cuda.synchronize(self._device_ukl.device)
+            return self._device_ukl.cpu().numpy()
+        rows = torch.from_numpy(np.ascontiguousarray(eng.compute_energies()))
+        full = self._comm.all_gather_rows(rows, self.n_replicas)
+        self._host_ukl_full = full.numpy()
+        return self._host_ukl_full
+
+    def _check_nan_energy(self):
+        """multistatesampler.py:1049-1081."""
+        diag = self._energy_thermodynamic_states[np.arange(self.n_replicas), self._replica_thermodynamic_states]
+        bad = np.nonzero(np.isnan(diag))[0]
+        if len(bad):
+            raise SimulationNaNError('NaN encountered in energies of replicas {} at their current states'.format(bad.tolist()))
+
+    def _sync_sampler_states(self):
+        """D2H snapshot of the local replicas (mcmc.py:731-773; reporter read point multistatesampler.py:1217)."""
+        if not self._sampler_states_stale:
+            return
+        x, v, _, _ = self._engine.get_replicas(positions=True, velocities=True)
+        for k in range(self._r_count):
+            s = self._sampler_states[self._r_begin + k]
+            s.positions = x[k].copy()
+            s.velocities = v[k].copy()
+        self._sampler_states_stale = False

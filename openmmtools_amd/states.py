@@ -1,0 +1,190 @@
+"""ThermodynamicState / SamplerState: the input contract of the replica-exchange engine.
+
+Mirrors the parts of openmmtools/states.py the hot path touches:
+  ThermodynamicState   states.py:331-1930  (system, temperature, pressure, beta, reduced potential
+                       algebra :1908-1917, compatibility :994-1050)
+  SamplerState         states.py:1933-2521 (positions, velocities, box_vectors, cached energies)
+  CompoundThermodynamicState + GlobalParameterState (lambda_sterics / lambda_electrostatics)
+                       states.py:2524-3046, alchemy.AlchemicalState alchemy.py:86-410
+Quantities are md-unit floats / numpy arrays (see unit.py).
+"""
+import copy
+import numpy as np
+from . import constants
+
+
+class ThermodynamicState:
+    def __init__(self, system, temperature, pressure=None):
+        self._system = system
+        self.temperature = temperature
+        self.pressure = pressure
+        if pressure is not None:
+            raise NotImplementedError('NPT (pressure) states are outside the engine\'s current scope (SURVEY 8(f) #3)')
+
+    @property
+    def system(self):
+        return self._system
+
+    def get_system(self):
+        return self._system
+
+    @property
+    def temperature(self):
+        return self._temperature
+
+    @temperature.setter
+    def temperature(self, value):
+        value = float(value)
+        if not value > 0:
+            raise ValueError('temperature must be positive')
+        self._temperature = value
+
+    @property
+    def kT(self):
+        return constants.kB * self._temperature
+
+    @property
+    def beta(self):
+        return 1.0 / (constants.kB * self._temperature)
+
+    @property
+    def n_particles(self):
+        return self._system.getNumParticles()
+
+    @property
+    def is_periodic(self):
+        return self._system.usesPeriodicBoundaryConditions()
+
+    @property
+    def default_box_vectors(self):
+        return self._system.getDefaultPeriodicBoxVectors()
+
+    # lambda parameters: a plain ThermodynamicState is the fully interacting end state
+    lambda_sterics = 1.0
+    lambda_electrostatics = 1.0
+
+    @staticmethod
+    def _compute_reduced_potential(potential_energy, temperature, volume=None, pressure=None):
+        """states.py:1908-1917: u = beta (U + p V); energies per mole, so N_A is already folded in."""
+        beta = 1.0 / (constants.kB * temperature)
+        reduced = potential_energy
+        if pressure is not None:
+            reduced = reduced + pressure * volume
+        return beta * reduced
+
+    def reduced_potential(self, sampler_state_or_energy):
+        """Reduced potential of a SamplerState with a cached potential energy, or of an energy in kJ/mol."""
+        if isinstance(sampler_state_or_energy, SamplerState):
+            energy = sampler_state_or_energy.potential_energy
+            volume = sampler_state_or_energy.volume
+            if energy is None:
+                raise ValueError('SamplerState has no cached potential energy')
+        else:
+            energy, volume = float(sampler_state_or_energy), None
+        return self._compute_reduced_potential(energy, self._temperature, volume, self.pressure)
+
+    def is_state_compatible(self, other):
+        """states.py:994-1050: same standard system and same ensemble."""
+        return (self._system is other._system or self._system.fingerprint() == other._system.fingerprint()) \
+            and (self.pressure is None) == (other.pressure is None)
+
+    def __deepcopy__(self, memo):
+        # Systems are treated as immutable once wrapped (the reference deep-copies and re-hashes)
+        new = copy.copy(self)
+        return new
+
+
+class AlchemicalState:
+    """lambda_sterics / lambda_electrostatics carrier (alchemy.py:86-410, only these two)."""
+
+    def __init__(self, lambda_sterics=1.0, lambda_electrostatics=1.0):
+        self.lambda_sterics = float(lambda_sterics)
+        self.lambda_electrostatics = float(lambda_electrostatics)
+
+    @classmethod
+    def from_system(cls, system):
+        if getattr(system, 'alchemical_region', None) is None:
+            raise ValueError('system has no alchemical region')
+        return cls()
+
+
+class CompoundThermodynamicState(ThermodynamicState):
+    """states.py:2524-3046 restricted to one AlchemicalState composable state."""
+
+    def __init__(self, thermodynamic_state, composable_states):
+        super().__init__(thermodynamic_state.system, thermodynamic_state.temperature, thermodynamic_state.pressure)
+        if len(composable_states) != 1 or not isinstance(composable_states[0], AlchemicalState):
+            raise NotImplementedError('only a single AlchemicalState composable state is supported')
+        self._alch = copy.copy(composable_states[0])
+
+    @property
+    def lambda_sterics(self):
+        return self._alch.lambda_sterics
+
+    @lambda_sterics.setter
+    def lambda_sterics(self, v):
+        self._alch.lambda_sterics = float(v)
+
+    @property
+    def lambda_electrostatics(self):
+        return self._alch.lambda_electrostatics
+
+    @lambda_electrostatics.setter
+    def lambda_electrostatics(self, v):
+        self._alch.lambda_electrostatics = float(v)
+
+    def __deepcopy__(self, memo):
+        new = copy.copy(self)
+        new._alch = copy.copy(self._alch)
+        return new
+
+
+class SamplerState:
+    def __init__(self, positions, velocities=None, box_vectors=None):
+        self.positions = np.array(positions, dtype=np.float64).reshape(-1, 3)
+        self.velocities = None if velocities is None else np.array(velocities, dtype=np.float64).reshape(-1, 3)
+        self.box_vectors = None if box_vectors is None else np.array(box_vectors, dtype=np.float64).reshape(3, 3)
+        self.potential_energy = None
+        self.kinetic_energy = None
+
+    @property
+    def n_particles(self):
+        return self.positions.shape[0]
+
+    @property
+    def volume(self):
+        if self.box_vectors is None:
+            return None
+        return float(abs(np.linalg.det(self.box_vectors)))
+
+    @property
+    def box_edges(self):
+        """Orthorhombic edge lengths; triclinic boxes are not supported by the engine."""
+        if self.box_vectors is None:
+            return None
+        off = self.box_vectors - np.diag(np.diag(self.box_vectors))
+        if np.abs(off).max() > 1e-9:
+            raise NotImplementedError('triclinic periodic boxes are not supported')
+        return np.diag(self.box_vectors).copy()
+
+    def __getstate__(self):
+        return dict(positions=self.positions, velocities=self.velocities, box_vectors=self.box_vectors,
+                    potential_energy=self.potential_energy, kinetic_energy=self.kinetic_energy)
+
+    def __setstate__(self, s):
+        self.__dict__.update(s)
+
+
+def group_by_compatibility(states):
+    """states.py:186-217."""
+    groups, indices = [], []
+    for i, s in enumerate(states):
+        for g, idx in zip(groups, indices):
+            if s.is_state_compatible(g[0]):
+                g.append(s)
+                idx.append(i)
+                break
+        else:
+            groups.append([s])
+            indices.append([i])
+    return groups, indices

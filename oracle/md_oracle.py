@@ -1,0 +1,252 @@
+"""md_oracle.py — TEST INFRASTRUCTURE ONLY (CPU oracle, f64 numpy).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product path (openmmtools_amd/_engine.py -> libremd_hip.so) never does.
+
+Restates, in double precision and the simplest possible form, the arithmetic the hot path
+performs per replica:
+
+  * Langevin splitting substeps   openmmtools/integrators.py:1404-1460 (R, V, O), constants
+                                  :1139-1149, sigma = sqrt(kT/m) :1314, step program :1309-1317
+  * velocity reassignment         openmmtools/mcmc.py:710-711
+  * reduced potential             openmmtools/states.py:1908-1917; PT shortcut
+                                  openmmtools/multistate/paralleltempering.py:206-215
+  * potential energy / forces of the benchmark systems as OpenMM defines them for the Systems
+    built in openmmtools/testsystems.py:779-786 (harmonic well), :1957-2017 (LJ fluid with
+    switching function and dispersion correction), :3496-3527 (Amber explicit solvent: bonds,
+    angles, torsions, LJ + PME Coulomb with exclusions/exceptions), and the alchemical soft-core
+    forms of openmmtools/alchemy/alchemy.py:1356-1390.
+  * constraints by plain iterative SHAKE / RATTLE to 1e-12 (the device uses analytic SETTLE for
+    waters, so agreement is a real cross-check, not the same code twice).
+
+PARITY PINNING: the force/energy arithmetic lives in OpenMM (not vendored in /root/reference,
+CI pins 8.2.0 / 8.3.1, .github/workflows/CI.yml:31-43) and no reference test pins an absolute
+energy or trajectory, so absolute-energy parity is UNPINNED against the reference.
+What pins this oracle: closed forms (harmonic well, two-particle LJ, analytic long-range
+correction integral), direct Ewald summation for the PME path, finite-difference force checks,
+and the statistical known answers the reference tests use (tests/test_oracle_md.py).
+
+Random numbers: Philox4x32-10 with the stream layout of openmmtools_amd/csrc/rng.h, restated
+here with numpy uint64 arithmetic and checked against the Random123 known-answer vectors.
+"""
+import math
+import numpy as np
+
+KB = 0.008314462618153242          # kJ/mol/K  (openmmtools/constants.py:7)
+ONE_4PI_EPS0 = 138.93545764438198  # openmmtools/constants.py:12-14
+
+STREAM_SWAP_ALL, STREAM_NEIGHBOR, STREAM_SAMS, STREAM_VELOCITY, STREAM_OU = 1, 2, 3, 4, 5
+
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = 0x9E3779B9, 0xBB67AE85
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10; all inputs broadcastable integer arrays; returns 4 uint32 arrays."""
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint64) & _MASK for c in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)) & _MASK
+        n1 = p1 & _MASK
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)) & _MASK
+        n3 = p0 & _MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def draw(seed, stream, a, b, t):
+    """counter = (a, b, (u32)t, stream ^ ((u32)(t>>32) << 8)), key = seed."""
+    t = int(t) & 0xFFFFFFFFFFFFFFFF
+    c3 = (stream ^ (((t >> 32) & 0xFFFFFFFF) << 8)) & 0xFFFFFFFF
+    return philox4x32_10(a, b, t & 0xFFFFFFFF, c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+
+
+def u23(w):
+    """((w >> 9) + 0.5) / 2^23, the 23-bit uniform the device uses for Box-Muller."""
+    return ((np.asarray(w, dtype=np.uint64) >> np.uint64(9)).astype(np.float64) + 0.5) / 8388608.0
+
+
+def gaussians3(seed, stream, atoms, replica, t):
+    """Three N(0,1) per atom: Box-Muller on words (0,1) -> (n0, n1) and (2,3) -> n2 (cos branch)."""
+    w0, w1, w2, w3 = draw(seed, stream, np.asarray(atoms), replica, t)
+    r1 = np.sqrt(-2.0 * np.log(u23(w0)))
+    r2 = np.sqrt(-2.0 * np.log(u23(w2)))
+    a1 = 2.0 * np.pi * u23(w1)
+    a2 = 2.0 * np.pi * u23(w3)
+    return np.stack([r1 * np.cos(a1), r1 * np.sin(a1), r2 * np.cos(a2)], axis=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# potential energy and forces
+# ---------------------------------------------------------------------------------------------
+
+class OracleSystem:
+    """f64 energy/force evaluation for a system description dict (openmmtools_amd.system.system_to_desc)."""
+
+    def __init__(self, desc):
+        self.d = desc
+        self.N = int(desc['n_atoms'])
+        self.mass = np.asarray(desc['mass'], dtype=np.float64)
+        self.constraints = self._constraint_list()
+
+    def _constraint_list(self):
+        d = self.d
+        cons = []
+        for (o, h1, h2) in np.asarray(d['settle_atoms']).reshape(-1, 3):
+            cons += [(o, h1, d['settle_dOH']), (o, h2, d['settle_dOH']), (h1, h2, d['settle_dHH'])]
+        for atoms, dist in zip(np.asarray(d['shake_atoms']).reshape(-1, 4), np.asarray(d['shake_dist']).reshape(-1, 3)):
+            for k in range(1, 4):
+                if atoms[k] >= 0:
+                    cons.append((atoms[0], atoms[k], dist[k - 1]))
+        return cons
+
+    # each term returns (energy, forces[N,3])
+    def ext(self, x):
+        d = self.d
+        f = np.zeros_like(x)
+        e = 0.0
+        if d['n_ext'] > 0:
+            idx = np.asarray(d['ext_atoms'])
+            K, x0, U0 = d['ext_K'], d['ext_x0'], d['ext_U0']
+            dx = x[idx].copy()
+            dx[:, 0] -= x0
+            e = float(0.5 * K * np.sum(dx * dx) + U0 * len(idx))    # testsystems.py:779
+            f[idx] = -K * dx
+        return e, f
+
+    def energy_forces(self, x, box=None, lambda_sterics=1.0, lambda_electrostatics=1.0, forces=True):
+        e, f = self.ext(x)
+        for term in getattr(self, 'extra_terms', []):
+            et, ft = term(x, box, lambda_sterics, lambda_electrostatics)
+            e += et
+            f += ft
+        return e, f
+
+    def potential(self, x, box=None, **kw):
+        return self.energy_forces(x, box, **kw)[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# constraints: iterative SHAKE (positions) and RATTLE (velocities), f64, tolerance 1e-12
+# ---------------------------------------------------------------------------------------------
+
+def shake(cons, invm, x_old, x_new, tol=1e-12, max_iter=500):
+    """Move x_new along the OLD bond vectors until every |r|^2 matches d^2 (relative tol)."""
+    x = x_new.copy()
+    for _ in range(max_iter):
+        worst = 0.0
+        for (i, j, dist) in cons:
+            r = x[j] - x[i]
+            diff = dist * dist - r @ r
+            worst = max(worst, abs(diff) / (dist * dist))
+            if abs(diff) > tol * dist * dist:
+                r0 = x_old[j] - x_old[i]
+                lam = diff / (2.0 * (invm[i] + invm[j]) * (r @ r0))
+                x[i] -= lam * invm[i] * r0
+                x[j] += lam * invm[j] * r0
+        if worst < tol:
+            break
+    return x
+
+
+def rattle(cons, invm, x, v, tol=1e-12, max_iter=500):
+    """Remove the velocity components along the constraints."""
+    v = v.copy()
+    for _ in range(max_iter):
+        worst = 0.0
+        for (i, j, dist) in cons:
+            r = x[j] - x[i]
+            rv = r @ (v[j] - v[i])
+            worst = max(worst, abs(rv) / (dist * dist))
+            lam = rv / ((r @ r) * (invm[i] + invm[j]))
+            v[i] += lam * invm[i] * r
+            v[j] -= lam * invm[j] * r
+        if worst < tol:
+            break
+    return v
+
+
+# ---------------------------------------------------------------------------------------------
+# Langevin splitting integrator (integrators.py:1309-1317, 1404-1460)
+# ---------------------------------------------------------------------------------------------
+
+class OracleLangevin:
+    def __init__(self, system, splitting, timestep, collision_rate, n_steps, seed, cmm_frequency=None):
+        self.s = system
+        self.tokens = splitting.upper().split()
+        self.nV = sum(t[0] == 'V' for t in self.tokens)
+        self.nR = self.tokens.count('R')
+        self.nO = self.tokens.count('O')
+        self.dt, self.gamma, self.n_steps, self.seed = float(timestep), float(collision_rate), int(n_steps), int(seed)
+        h = self.dt / max(1, self.nO)
+        self.a = math.exp(-self.gamma * h)                         # integrators.py:1143
+        self.b = math.sqrt(1.0 - math.exp(-2.0 * self.gamma * h))  # :1146
+        self.cmm = system.d['cmm_frequency'] if cmm_frequency is None else cmm_frequency
+
+    def assign_velocities(self, x, kT, replica, iteration):
+        """mcmc.py:710-711: Maxwell-Boltzmann draw, then velocity constraints."""
+        s = self.s
+        xi = gaussians3(self.seed, STREAM_VELOCITY, np.arange(s.N), replica, iteration)
+        v = np.sqrt(kT / s.mass)[:, None] * xi
+        if s.constraints:
+            v = rattle(s.constraints, 1.0 / s.mass, x, v)
+        return v
+
+    def run(self, x, v, box, kT, replica, iteration, first_step=0, n_steps=None, tokens=None,
+            lambda_sterics=1.0, lambda_electrostatics=1.0):
+        s = self.s
+        invm = 1.0 / s.mass
+        tokens = self.tokens if tokens is None else tokens
+        n_steps = self.n_steps if n_steps is None else n_steps
+        x, v = x.copy(), v.copy()
+        f = None
+        for step in range(n_steps):
+            gstep = iteration * self.n_steps + first_step + step
+            if self.cmm and ((first_step + step) % self.cmm) == 0:
+                p = (s.mass[:, None] * v).sum(axis=0)                # CMMotionRemover at the top of a step
+                v -= p / s.mass.sum()
+            oidx = 0
+            for tok in tokens:
+                if tok[0] == 'V':
+                    if f is None:
+                        f = s.energy_forces(x, box, lambda_sterics, lambda_electrostatics)[1]
+                    v = v + (self.dt / self.nV) * f * invm[:, None]                 # :1440-1442
+                    if s.constraints:
+                        v = rattle(s.constraints, invm, x, v)
+                elif tok == 'R':
+                    h = self.dt / self.nR
+                    x1 = x + h * v                                                  # :1414
+                    if s.constraints:
+                        xc = shake(s.constraints, invm, x, x1)                      # :1416
+                        v = v + (xc - x1) / h                                       # :1417
+                        x = xc
+                        v = rattle(s.constraints, invm, x, v)                       # :1418
+                    else:
+                        x = x1
+                    f = None
+                elif tok == 'O':
+                    cnt = gstep * max(1, self.nO) + oidx
+                    xi = gaussians3(self.seed, STREAM_OU, np.arange(s.N), replica, cnt)
+                    v = self.a * v + self.b * np.sqrt(kT * invm)[:, None] * xi      # :1455
+                    if s.constraints:
+                        v = rattle(s.constraints, invm, x, v)
+                    oidx += 1
+        return x, v
+
+
+def kinetic_energy(mass, v):
+    return float(0.5 * np.sum(mass[:, None] * v * v))
+
+
+def reduced_potential_matrix(potentials, betas, energy_const=None, alch=None):
+    """u[r, l] = beta_l (U_r + const_l + alch[r, l])  (states.py:1908-1917, paralleltempering.py:206-215)."""
+    U = np.asarray(potentials, dtype=np.float64)[:, None]
+    tot = U + (0.0 if energy_const is None else np.asarray(energy_const)[None, :])
+    if alch is not None:
+        tot = tot + alch
+    return np.asarray(betas)[None, :] * tot

@@ -1,0 +1,112 @@
+"""OracleEngine: the Python engine interface (openmmtools_amd._engine.HipEngine) backed by the CPU
+oracle.  TEST INFRASTRUCTURE ONLY — lets the host-side sampler logic, the sharding and the
+collectives be exercised on a GPU-less box (gloo, world_size 2) and serves as the checker in the
+GPU parity tests.  Never imported by the product package."""
+import numpy as np
+import oracle
+from oracle import md_oracle as mo
+
+
+class OracleEngine:
+    is_device = False
+
+    def __init__(self, system_factory=None):
+        self.system_factory = system_factory or mo.OracleSystem
+        self.seed_value = 0
+
+    def set_system(self, desc):
+        self.desc = desc
+        self.sys = self.system_factory(desc)
+        self.N = self.sys.N
+
+    def set_states(self, beta, lambda_sterics=None, lambda_electrostatics=None, energy_const=None):
+        self.beta = np.array(beta, dtype=np.float64)
+        self.K = len(self.beta)
+        self.lam_s = np.ones(self.K) if lambda_sterics is None else np.array(lambda_sterics, dtype=np.float64)
+        self.lam_e = np.ones(self.K) if lambda_electrostatics is None else np.array(lambda_electrostatics, dtype=np.float64)
+        self.econst = np.zeros(self.K) if energy_const is None else np.array(energy_const, dtype=np.float64)
+
+    def set_integrator(self, splitting, timestep, collision_rate, n_steps, reassign_velocities=True,
+                       constraint_tolerance=1e-8):
+        self.integ_args = (splitting, timestep, collision_rate, n_steps)
+        self.reassign = reassign_velocities
+
+    def set_replicas(self, R_global, r_begin, x, v, box, labels):
+        self.R_global, self.r_begin = R_global, r_begin
+        self.x = np.array(x, dtype=np.float64)
+        self.R = self.x.shape[0]
+        self.v = np.zeros_like(self.x) if v is None else np.array(v, dtype=np.float64)
+        self.box = np.array(box, dtype=np.float64).reshape(self.R, 3)
+        self.labels = np.array(labels, dtype=np.int64)
+
+    def set_labels(self, labels):
+        self.labels = np.array(labels, dtype=np.int64)
+
+    def seed(self, seed):
+        self.seed_value = int(seed)
+
+    def _integrator(self):
+        s, dt, g, n = self.integ_args
+        return mo.OracleLangevin(self.sys, s, dt, g, n, self.seed_value)
+
+    def _box(self, r):
+        return self.box[r] if self.box[r].any() else None
+
+    def propagate(self, iteration):
+        integ = self._integrator()
+        flags = np.zeros(self.R, dtype=np.int32)
+        for r in range(self.R):
+            rg = self.r_begin + r
+            k = self.labels[rg]
+            kT = 1.0 / self.beta[k]
+            if self.reassign:
+                self.v[r] = integ.assign_velocities(self.x[r], kT, rg, iteration)
+            self.x[r], self.v[r] = integ.run(self.x[r], self.v[r], self._box(r), kT, rg, iteration,
+                                             lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
+            if not (np.isfinite(self.x[r]).all() and np.isfinite(self.v[r]).all()):
+                flags[r] = 1
+        return flags
+
+    def step(self, splitting, iteration=0, first_step=0, n_steps=1):
+        integ = self._integrator()
+        for r in range(self.R):
+            rg = self.r_begin + r
+            k = self.labels[rg]
+            self.x[r], self.v[r] = integ.run(self.x[r], self.v[r], self._box(r), 1.0 / self.beta[k], rg, iteration,
+                                             first_step=first_step, n_steps=n_steps,
+                                             tokens=[c for c in splitting.upper() if c != ' '],
+                                             lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
+
+    def potentials(self):
+        return np.array([self.sys.potential(self.x[r], self._box(r)) for r in range(self.R)])
+
+    def compute_energies(self, d_rows=None, want_host=True, want_potential=False):
+        U = self.potentials()
+        if hasattr(self.sys, 'state_energies'):
+            rows = np.stack([self.beta * (self.sys.state_energies(self.x[r], self._box(r), self.lam_s, self.lam_e)
+                                          + self.econst) for r in range(self.R)])
+        else:
+            rows = mo.reduced_potential_matrix(U, self.beta, self.econst)
+        self._rows = rows
+        return (rows, U) if want_potential else rows
+
+    def mix(self, scheme, iteration, labels, d_ukl=None, R=None, K=None, ld=0, log_weights=None):
+        # single-rank path: the engine's own rows are the full matrix
+        return self.mix_host(scheme, iteration, self._rows[:, :(K or self.K)], labels, log_weights=log_weights)
+
+    def mix_host(self, scheme, iteration, ukl, labels, log_weights=None, n_attempts=-1):
+        return oracle.mix(scheme, self.seed_value, iteration, ukl, labels, log_weights=log_weights, n_attempts=n_attempts)
+
+    def get_replicas(self, positions=True, velocities=True, potential=False, kinetic=False):
+        u = self.potentials() if potential else None
+        k = np.array([mo.kinetic_energy(self.sys.mass, self.v[r]) for r in range(self.R)]) if kinetic else None
+        return self.x.copy(), self.v.copy(), u, k
+
+    def get_forces(self):
+        return np.stack([self.sys.energy_forces(self.x[r], self._box(r))[1] for r in range(self.R)])
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass

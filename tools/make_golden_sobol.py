@@ -1,0 +1,16 @@
+"""Generates tests/golden/sobol_512x3.npy from the reference's own Sobol module.
+
+Run in the build container only (needs /root/reference):  python tools/make_golden_sobol.py
+The reference builds LennardJonesFluid positions with sobol.i4_sobol_generate(3, N, 1)
+(openmmtools/testsystems.py:280); openmmtools_amd.testsystems re-implements the generator and
+tests/test_testsystems.py checks it against this fixture.
+"""
+import importlib.util
+import numpy as np
+
+spec = importlib.util.spec_from_file_location('ref_sobol', '/root/reference/openmmtools/sobol.py')
+mod = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mod)
+pts = np.array(mod.i4_sobol_generate(3, 512, 1))      # [3, 512]
+np.save('tests/golden/sobol_512x3.npy', pts.astype(np.float64))
+print(pts[:, :6].T)
