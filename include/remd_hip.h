@@ -182,6 +182,9 @@ int  remd_get_forces(remd_handle h, double* f);
    (test hook: single V / R / O substeps).                                               */
 int  remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t first_step, int n_steps);
 int  remd_sync(remd_handle h);
+/* test hook: in-place unnormalised 3-D complex FFT of a host array [nx][ny][nz][2] on the
+   in-tree mixed-radix FFT that the PME reciprocal pass uses                             */
+int  remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inverse);
 
 /* timing of the last remd_propagate / compute_energies / mix on the handle's stream,
    measured with hipEvents (ms)                                                           */

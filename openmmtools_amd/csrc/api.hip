@@ -6,6 +6,9 @@
 
 int remd_check_finite(remd_ctx* h);
 int remd_assemble_ukl(remd_ctx* h, double* d_rows);
+int remd_nb_required_epart(remd_ctx* h);
+void remd_free_nonbonded(remd_ctx* h);
+int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
 void remd_free_constraints(remd_ctx* h);
 
 static std::mutex g_err_mutex;
@@ -64,6 +67,7 @@ int remd_destroy(remd_handle h)
     hipStreamSynchronize(h->stream);
     remd_pme_destroy(h);
     remd_free_constraints(h);
+    remd_free_nonbonded(h);
     dfree(h->d_invmass); dfree(h->d_mass); dfree(h->d_ext_atoms);
     dfree(h->d_bond_atoms); dfree(h->d_bond_params); dfree(h->d_angle_atoms); dfree(h->d_angle_params);
     dfree(h->d_torsion_atoms); dfree(h->d_torsion_params);
@@ -180,7 +184,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         REMD_CHECK(h, hipMalloc(&h->d_kinetic, sizeof(double) * R_local));
         REMD_CHECK(h, hipMalloc(&h->d_nan, sizeof(int) * R_local));
         REMD_CHECK(h, hipMalloc(&h->d_cmm, sizeof(long long) * 4 * R_local));
-        h->n_epart = 8 + 4 * ((h->Npad + 255) / 256) + 64;
+        h->n_epart = remd_nb_required_epart(h);
         REMD_CHECK(h, hipMalloc(&h->d_epart, sizeof(double) * (size_t)h->n_epart * R_local));
         if (h->K > 0) {
             REMD_CHECK(h, hipMalloc(&h->d_ukl, sizeof(double) * (size_t)R_global * h->K));
@@ -396,6 +400,13 @@ int remd_get_forces(remd_handle h, double* f)
     for (int r = 0; r < h->R; ++r) for (int i = 0; i < h->N; ++i) for (int k = 0; k < 3; ++k)
         f[((size_t)r * h->N + i) * 3 + k] = (double)buf[((size_t)r * 3 + k) * h->Npad + i] / REMD_FORCE_SCALE;
     return 0;
+}
+
+int remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inverse)
+{
+    if (!h || !data) return remd_fail(h, -1, "remd_test_fft3d: bad arguments");
+    hipSetDevice(h->device);
+    return remd_test_fft3d_impl(h, nx, ny, nz, data, inverse);
 }
 
 int remd_sync(remd_handle h) { if (!h) return -1; hipSetDevice(h->device); REMD_CHECK(h, hipStreamSynchronize(h->stream)); return 0; }

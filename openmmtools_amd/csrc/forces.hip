@@ -1,13 +1,26 @@
-// Force / potential-energy kernels (gfx950): harmonic external force, bonded terms,
-// nonbonded direct space.  Forces accumulate in 64-bit fixed point (deterministic integer
-// atomics, scale 2^32); energies are written as per-block f64 partials that are summed in a
-// fixed order by reduce_energy_kernel (bit-reproducible).
+// Force / potential-energy kernels (gfx950): harmonic external force, bonded terms, nonbonded
+// direct space (LJ + switching function, reaction-field or Ewald-direct Coulomb, soft-core
+// alchemical sterics), exceptions, Ewald exclusion correction.
 //
-// Functional forms restated from the reference:
+// Forces accumulate in 64-bit fixed point (integer atomics => bit-reproducible sums, scale 2^32);
+// energies are written as per-block f64 partials and summed in a fixed order.
+//
+// Functional forms restated from the reference's system builders / OpenMM semantics:
 //   testsystems.HarmonicOscillator      testsystems.py:779-786   U = K/2 ((x-x0)^2+y^2+z^2) + U0
-//   NonbondedForce / bonded terms       OpenMM semantics as built by testsystems.py:1957-2017,
-//                                       3496-3527 (see oracle/md_oracle.py for the f64 restatement)
+//   NonbondedForce (LJ fluid)           testsystems.py:1978-2000 CutoffPeriodic, switch, dispersion correction
+//   Amber explicit solvent              testsystems.py:3504-3517 PME, HBonds, rigid water, switch
+//   alchemical soft-core sterics        alchemy/alchemy.py:1383-1388 (softcore_c = 6 closed form)
+// The f64 restatement used for parity is oracle/md_oracle.py.
+//
+// Nonbonded design: one wavefront owns 64 consecutive atoms i (lane = atom); the j loop walks a
+// slice of all atoms with wave-uniform addresses (scalar loads, no LDS traffic); the full i x j
+// matrix is evaluated (each pair twice), so every lane sums its own force in a fixed order and no
+// atomics are needed inside the loop.  Exclusions are a per-atom bit window over j - i, consulted
+// only in tiles that overlap the window.  The grid is (i tiles) x (j slices) x (replicas).
 #include "remd_internal.h"
+#include <cmath>
+#include <algorithm>
+#include <set>
 
 #define EP_EXT      0
 #define EP_BOND     1
@@ -19,12 +32,63 @@
 #define EP_CONST    7
 #define EP_NB0      8      // first nonbonded block slot
 
+#define NB_LJ_ONLY 0
+#define NB_RF      1
+#define NB_EWALD   2
+
+#define MAX_EXCL_WORDS 8
+
+struct nb_params {
+    float rc, rc2, rs, inv_sw;        // cutoff, cutoff^2, switching distance (<0: none), 1/(rc-rs)
+    float krf, crf;                   // reaction field
+    float alpha, two_alpha_sqrtpi;    // Ewald
+    int excl_words;                   // 64-bit words of the exclusion window per atom
+    int n_jsplit;
+};
+
+struct nb_tables {
+    nb_params p{};
+    int method = NB_LJ_ONLY;
+    bool has_alch = false;
+    float4* d_param = nullptr;            // [Npad] (q*sqrt(k_e), sigma/2, 2*sqrt(eps), alchemical flag)
+    unsigned long long* d_mask = nullptr; // [Npad][excl_words]
+    int n_exc = 0; int* d_exc_atoms = nullptr; float* d_exc_params = nullptr;     // nonzero exceptions
+    int n_excl = 0; int* d_excl_atoms = nullptr; float* d_excl_qq = nullptr;      // all excluded pairs (Ewald correction)
+    float* d_rep_lam = nullptr;           // [R][4] per replica: lambda_s^a, alpha (1-lambda_s)^b, lambda_e, pad
+    int rep_lam_R = 0;
+    std::vector<double> state_lam_a, state_sc;   // per state, for the alchemical u_kl kernel
+    double* d_state_lam = nullptr;        // [K][2]
+    double* d_alch_ukl = nullptr;         // [R][K]
+    int alch_R = 0, alch_K = 0;
+    double disp_coeff = 0.0;              // E_disp = disp_coeff / V
+    double self_energy = 0.0;             // Ewald self term, kJ/mol
+    double net_charge_term = 0.0;         // neutralising-plasma coefficient: E = coeff / V
+    std::vector<double> charge;           // original charges
+    std::vector<char> is_alch;
+};
+static std::map<remd_ctx*, nb_tables> g_nb;
+
 __device__ __forceinline__ void add_force(long long* __restrict__ F, int Npad, int i, float fx, float fy, float fz)
 {
     unsigned long long* U = reinterpret_cast<unsigned long long*>(F);
     atomicAdd(&U[i],            (unsigned long long)(long long)((double)fx * REMD_FORCE_SCALE));
     atomicAdd(&U[Npad + i],     (unsigned long long)(long long)((double)fy * REMD_FORCE_SCALE));
     atomicAdd(&U[2 * Npad + i], (unsigned long long)(long long)((double)fz * REMD_FORCE_SCALE));
+}
+
+__device__ __forceinline__ double wave_sum(double e)
+{
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+    return e;
+}
+
+// block of 256 threads: deterministic sum, result valid in thread 0
+__device__ __forceinline__ double block_sum_256(double e, double* s_part)
+{
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    return s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
 template <bool ENERGY>
@@ -43,9 +107,356 @@ void ext_force_kernel(int n_ext, const int* __restrict__ ext_atoms, float K, flo
         if (ENERGY) e += 0.5 * (double)K * ((double)dx * dx + (double)p.y * p.y + (double)p.z * p.z) + U0;
     }
     if (ENERGY) {
-        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+        e = wave_sum(e);
         if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_EXT] = e;
     }
+}
+
+// ---- bonded terms -----------------------------------------------------------------------------
+__device__ __forceinline__ float3 ld3(const float4* P, int i) { const float4 p = P[i]; return make_float3(p.x, p.y, p.z); }
+__device__ __forceinline__ float3 sub3(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 scl3(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float3 add3(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float dotf(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 crs3(float3 a, float3 b) {
+    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+template <bool ENERGY>
+__global__ __launch_bounds__(256)
+void bond_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ params, int Npad,
+                 const float4* __restrict__ pos, long long* __restrict__ force, double* __restrict__ epart, int n_epart)
+{
+    __shared__ double s_part[4];
+    const int r = blockIdx.x;
+    const float4* P = pos + (size_t)r * Npad;
+    long long* F = force + (size_t)r * 3 * Npad;
+    double e = 0.0;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int i = atoms[2 * t], j = atoms[2 * t + 1];
+        const float r0 = params[2 * t], k = params[2 * t + 1];
+        const float3 d = sub3(ld3(P, j), ld3(P, i));
+        const float len = sqrtf(dotf(d, d));
+        const float dl = len - r0;
+        const float fs = k * dl / len;               // F_i = +fs * d, F_j = -fs * d
+        add_force(F, Npad, i, fs * d.x, fs * d.y, fs * d.z);
+        add_force(F, Npad, j, -fs * d.x, -fs * d.y, -fs * d.z);
+        if (ENERGY) e += 0.5 * (double)k * (double)dl * (double)dl;
+    }
+    if (ENERGY) { e = block_sum_256(e, s_part); if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_BOND] = e; }
+}
+
+template <bool ENERGY>
+__global__ __launch_bounds__(256)
+void angle_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ params, int Npad,
+                  const float4* __restrict__ pos, long long* __restrict__ force, double* __restrict__ epart, int n_epart)
+{
+    __shared__ double s_part[4];
+    const int r = blockIdx.x;
+    const float4* P = pos + (size_t)r * Npad;
+    long long* F = force + (size_t)r * 3 * Npad;
+    double e = 0.0;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int a = atoms[3 * t], b = atoms[3 * t + 1], c = atoms[3 * t + 2];
+        const float th0 = params[2 * t], k = params[2 * t + 1];
+        const float3 v0 = sub3(ld3(P, a), ld3(P, b));     // b -> a
+        const float3 v1 = sub3(ld3(P, c), ld3(P, b));     // b -> c
+        const float3 cp = crs3(v0, v1);
+        const float rp = fmaxf(sqrtf(dotf(cp, cp)), 1e-6f);
+        const float r20 = dotf(v0, v0), r21 = dotf(v1, v1);
+        const float dt = dotf(v0, v1);
+        const float cosine = fminf(fmaxf(dt * rsqrtf(r20 * r21), -1.f), 1.f);
+        const float theta = acosf(cosine);
+        const float dth = theta - th0;
+        const float dEdth = k * dth;
+        // dtheta/dx_a = (v0 x cp) / (|v0|^2 |cp|),  dtheta/dx_c = (cp x v1) / (|v1|^2 |cp|)
+        const float3 fa = scl3(crs3(v0, cp), -dEdth / (r20 * rp));
+        const float3 fc = scl3(crs3(cp, v1), -dEdth / (r21 * rp));
+        add_force(F, Npad, a, fa.x, fa.y, fa.z);
+        add_force(F, Npad, c, fc.x, fc.y, fc.z);
+        add_force(F, Npad, b, -(fa.x + fc.x), -(fa.y + fc.y), -(fa.z + fc.z));
+        if (ENERGY) e += 0.5 * (double)k * (double)dth * (double)dth;
+    }
+    if (ENERGY) { e = block_sum_256(e, s_part); if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_ANGLE] = e; }
+}
+
+template <bool ENERGY>
+__global__ __launch_bounds__(256)
+void torsion_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ params, int Npad,
+                    const float4* __restrict__ pos, long long* __restrict__ force, double* __restrict__ epart, int n_epart)
+{
+    __shared__ double s_part[4];
+    const int r = blockIdx.x;
+    const float4* P = pos + (size_t)r * Npad;
+    long long* F = force + (size_t)r * 3 * Npad;
+    double e = 0.0;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int a1 = atoms[4 * t], a2 = atoms[4 * t + 1], a3 = atoms[4 * t + 2], a4 = atoms[4 * t + 3];
+        const float per = params[3 * t], phase = params[3 * t + 1], k = params[3 * t + 2];
+        const float3 p1 = ld3(P, a1), p2 = ld3(P, a2), p3 = ld3(P, a3), p4 = ld3(P, a4);
+        const float3 b1 = sub3(p2, p1), b2 = sub3(p3, p2), b3 = sub3(p4, p3);
+        const float3 m = crs3(b1, b2), nn = crs3(b2, b3);
+        const float m2 = fmaxf(dotf(m, m), 1e-12f), n2 = fmaxf(dotf(nn, nn), 1e-12f);
+        const float lb2 = sqrtf(dotf(b2, b2));
+        // IUPAC dihedral: phi = atan2(|b2| b1.(b2 x b3), (b1 x b2).(b2 x b3))
+        const float phi = atan2f(lb2 * dotf(b1, nn), dotf(m, nn));
+        const float arg = per * phi - phase;
+        const float dEdphi = -k * per * sinf(arg);
+        // gradient of phi (Blondel & Karplus 1996)
+        const float3 g1 = scl3(m, -lb2 / m2);
+        const float3 g4 = scl3(nn, lb2 / n2);
+        const float s12 = dotf(b1, b2) / (lb2 * lb2), s32 = dotf(b3, b2) / (lb2 * lb2);
+        const float3 g2 = add3(scl3(g1, -(1.f + s12)), scl3(g4, s32));     // = -g1 - s12 g1 + s32 g4
+        const float3 g3 = add3(scl3(g4, -(1.f + s32)), scl3(g1, s12));
+        add_force(F, Npad, a1, -dEdphi * g1.x, -dEdphi * g1.y, -dEdphi * g1.z);
+        add_force(F, Npad, a2, -dEdphi * g2.x, -dEdphi * g2.y, -dEdphi * g2.z);
+        add_force(F, Npad, a3, -dEdphi * g3.x, -dEdphi * g3.y, -dEdphi * g3.z);
+        add_force(F, Npad, a4, -dEdphi * g4.x, -dEdphi * g4.y, -dEdphi * g4.z);
+        if (ENERGY) e += (double)k * (1.0 + (double)cosf(arg));
+    }
+    if (ENERGY) { e = block_sum_256(e, s_part); if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_TORSION] = e; }
+}
+
+// ---- nonbonded pair arithmetic -------------------------------------------------------------------
+__device__ __forceinline__ void switch_fn(const nb_params& p, float r, float& U, float& dUdr)
+{
+    if (p.rs >= 0.f && r > p.rs) {
+        const float x = (r - p.rs) * p.inv_sw;
+        const float S = 1.f + x * x * x * (-10.f + x * (15.f - 6.f * x));
+        const float dS = x * x * (-30.f + x * (60.f - 30.f * x)) * p.inv_sw;
+        dUdr = S * dUdr + U * dS;
+        U *= S;
+    }
+}
+
+// returns energy, writes dU/dr / r  (so that F_i = fr * (xj - xi))
+template <int METHOD, bool ALCH>
+__device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, float4 pi, float4 pj,
+                                                  float lam_a, float sc, float& fr, bool energy_skip_na, float& e_out)
+{
+    const float inv_r = rsqrtf(r2);
+    const float r = r2 * inv_r;
+    const float sig = pi.y + pj.y, eps4 = pi.z * pj.z;
+    float U = 0.f, dUdr = 0.f;
+    bool na = false;
+    if (eps4 != 0.f) {
+        if (ALCH && (pi.w != pj.w)) {
+            // soft-core (alchemy.py:1383-1388 with softcore_c = 6): x = 1/(alpha(1-l)^b + (r/sigma)^6)
+            na = true;
+            const float is2 = 1.f / (sig * sig);
+            const float t = r2 * r2 * r2 * is2 * is2 * is2;
+            const float x = 1.f / (sc + t);
+            U = lam_a * eps4 * x * (x - 1.f);
+            dUdr = lam_a * eps4 * (2.f * x - 1.f) * (-x * x * 6.f * t * inv_r);
+        } else {
+            const float s2 = sig * sig * inv_r * inv_r;
+            const float s6 = s2 * s2 * s2;
+            U = eps4 * s6 * (s6 - 1.f);
+            dUdr = eps4 * s6 * (6.f - 12.f * s6) * inv_r;
+        }
+        switch_fn(p, r, U, dUdr);
+    }
+    float Uc = 0.f, dUc = 0.f;
+    if (METHOD != NB_LJ_ONLY) {
+        const float qq = pi.x * pj.x;
+        if (METHOD == NB_EWALD) {
+            const float ar = p.alpha * r;
+            const float erfc_ar = erfcf(ar);
+            const float ex = __expf(-ar * ar);
+            Uc = qq * erfc_ar * inv_r;
+            dUc = -qq * (erfc_ar * inv_r + p.two_alpha_sqrtpi * ex) * inv_r;
+        } else {
+            Uc = qq * (inv_r + p.krf * r2 - p.crf);
+            dUc = qq * (2.f * p.krf * r - inv_r * inv_r);
+        }
+    }
+    fr = (dUdr + dUc) * inv_r;
+    e_out = ((ALCH && na && energy_skip_na) ? 0.f : U) + Uc;
+    return e_out;
+}
+
+template <int METHOD, bool ENERGY, bool ALCH>
+__global__ __launch_bounds__(64)
+void nonbonded_kernel(nb_params p, int N, int Npad, const float4* __restrict__ pos,
+                      const float4* __restrict__ param, const unsigned long long* __restrict__ mask,
+                      const float* __restrict__ box, const float* __restrict__ rep_lam,
+                      long long* __restrict__ force, double* __restrict__ epart, int n_epart)
+{
+    const int lane = threadIdx.x;
+    const int i0 = blockIdx.x * 64;
+    const int i = i0 + lane;
+    const int js = blockIdx.y;
+    const int r = blockIdx.z;
+    const float4* __restrict__ P = pos + (size_t)r * Npad;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
+    float lam_a = 1.f, sc = 0.f, lam_e = 1.f;
+    if (ALCH) { lam_a = rep_lam[4 * r]; sc = rep_lam[4 * r + 1]; lam_e = rep_lam[4 * r + 2]; }
+    const bool active = i < N;
+    const float4 xi = P[active ? i : 0];
+    float4 pi = param[active ? i : 0];
+    if (ALCH && pi.w != 0.f) pi.x *= lam_e;
+    unsigned long long mk[MAX_EXCL_WORDS];
+#pragma unroll
+    for (int w = 0; w < MAX_EXCL_WORDS; ++w) mk[w] = (w < p.excl_words) ? mask[(size_t)(active ? i : 0) * p.excl_words + w] : 0ull;
+    const int half = 32 * p.excl_words;
+
+    const int ntile = (N + 63) / 64;
+    const int tps = (ntile + p.n_jsplit - 1) / p.n_jsplit;
+    const int t0 = js * tps, t1 = min(ntile, t0 + tps);
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    double e = 0.0;
+    for (int tile = t0; tile < t1; ++tile) {
+        const int jb = tile * 64;
+        const int je = min(jb + 64, N);
+        const bool near = (jb + 63 >= i0 - half) && (jb <= i0 + 63 + half);
+        for (int j = jb; j < je; ++j) {
+            const float4 xj = P[j];                 // wave-uniform address -> scalar load
+            float4 pj = param[j];
+            float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+            dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            bool in = active && (r2 < p.rc2);
+            if (near) {
+                const int d = j - i + half;
+                if (d >= 0 && d < 2 * half) in = in && !((mk[d >> 6] >> (d & 63)) & 1ull);
+            }
+            if (in) {
+                if (ALCH && pj.w != 0.f) pj.x *= lam_e;
+                float fr, ee;
+                pair_interaction<METHOD, ALCH>(p, r2, pi, pj, lam_a, sc, fr, ENERGY, ee);
+                fx += fr * dx; fy += fr * dy; fz += fr * dz;
+                if (ENERGY) e += 0.5 * (double)ee;
+            }
+        }
+    }
+    if (active) {
+        long long* F = force + (size_t)r * 3 * Npad;
+        if (p.n_jsplit == 1) {
+            F[i] += (long long)((double)fx * REMD_FORCE_SCALE);
+            F[Npad + i] += (long long)((double)fy * REMD_FORCE_SCALE);
+            F[2 * Npad + i] += (long long)((double)fz * REMD_FORCE_SCALE);
+        } else {
+            add_force(F, Npad, i, fx, fy, fz);
+        }
+    }
+    if (ENERGY) {
+        e = wave_sum(e);
+        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + blockIdx.x * gridDim.y + js] = e;
+    }
+}
+
+// 1-4 style exceptions with non-zero parameters: plain Coulomb + LJ, no cutoff, no switch
+template <bool ENERGY>
+__global__ __launch_bounds__(256)
+void exception_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ params, int Npad,
+                      const float4* __restrict__ pos, const float* __restrict__ box,
+                      long long* __restrict__ force, double* __restrict__ epart, int n_epart)
+{
+    __shared__ double s_part[4];
+    const int r = blockIdx.x;
+    const float4* P = pos + (size_t)r * Npad;
+    long long* F = force + (size_t)r * 3 * Npad;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    double e = 0.0;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int i = atoms[2 * t], j = atoms[2 * t + 1];
+        const float qq = params[3 * t], sig = params[3 * t + 1], eps = params[3 * t + 2];
+        float3 d = sub3(ld3(P, j), ld3(P, i));
+        if (Lx > 0.f) { d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz); }
+        const float r2 = dotf(d, d);
+        const float inv_r = rsqrtf(r2);
+        const float s2 = sig * sig * inv_r * inv_r, s6 = s2 * s2 * s2;
+        const float U = 4.f * eps * s6 * (s6 - 1.f) + qq * inv_r;
+        const float dUdr = 4.f * eps * s6 * (6.f - 12.f * s6) * inv_r - qq * inv_r * inv_r;
+        const float fr = dUdr * inv_r;
+        add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
+        add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
+        if (ENERGY) e += (double)U;
+    }
+    if (ENERGY) { e = block_sum_256(e, s_part); if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_EXCEPT] = e; }
+}
+
+// Ewald correction for excluded pairs: the reciprocal sum contains them, so subtract qq erf(alpha r)/r
+template <bool ENERGY>
+__global__ __launch_bounds__(256)
+void ewald_exclusion_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ qq_arr, float alpha,
+                            float two_alpha_sqrtpi, int Npad, const float4* __restrict__ pos, const float* __restrict__ box,
+                            long long* __restrict__ force, double* __restrict__ epart, int n_epart)
+{
+    __shared__ double s_part[4];
+    const int r = blockIdx.x;
+    const float4* P = pos + (size_t)r * Npad;
+    long long* F = force + (size_t)r * 3 * Npad;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    double e = 0.0;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int i = atoms[2 * t], j = atoms[2 * t + 1];
+        const float qq = qq_arr[t];
+        float3 d = sub3(ld3(P, j), ld3(P, i));
+        d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz);
+        const float r2 = dotf(d, d);
+        const float inv_r = rsqrtf(r2);
+        const float rr = r2 * inv_r;
+        const float ar = alpha * rr;
+        const float erf_ar = erff(ar);
+        const float U = -qq * erf_ar * inv_r;
+        const float dUdr = -qq * (two_alpha_sqrtpi * __expf(-ar * ar) * inv_r - erf_ar * inv_r * inv_r);
+        const float fr = dUdr * inv_r;
+        add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
+        add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
+        if (ENERGY) e += (double)U;
+    }
+    if (ENERGY) { e = block_sum_256(e, s_part); if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_EXCLCORR] = e; }
+}
+
+// per-replica constants: dispersion correction, Ewald self energy, neutralising background
+__global__ void const_energy_kernel(int R, double disp_coeff, double self_e, double plasma_coeff,
+                                    const float* __restrict__ box, double* __restrict__ epart, int n_epart)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
+    double e = self_e;
+    if (V > 0) e += (disp_coeff + plasma_coeff) / V;
+    epart[(size_t)r * n_epart + EP_CONST] = e;
+}
+
+// alchemical/non-alchemical soft-core pair energies for every state lambda: alch[r][k]
+__global__ __launch_bounds__(256)
+void alch_ukl_kernel(nb_params p, int N, int Npad, int n_alch, const int* __restrict__ alch_atoms,
+                     const float4* __restrict__ pos, const float4* __restrict__ param, const float* __restrict__ box,
+                     int K, const double* __restrict__ state_lam /*[K][2]*/, double* __restrict__ out /*[R][K]*/)
+{
+    __shared__ double s_part[4];
+    const int k = blockIdx.x, r = blockIdx.y;
+    const float4* P = pos + (size_t)r * Npad;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const float lam_a = (float)state_lam[2 * k], sc = (float)state_lam[2 * k + 1];
+    double e = 0.0;
+    const int total = n_alch * N;
+    for (int t = threadIdx.x; t < total; t += 256) {
+        const int a = alch_atoms[t / N], j = t % N;
+        const float4 pj = param[j];
+        if (pj.w != 0.f) continue;                       // alchemical/alchemical pairs are not lambda-controlled
+        const float4 pa = param[a];
+        const float4 xa = P[a], xj = P[j];
+        float dx = xj.x - xa.x, dy = xj.y - xa.y, dz = xj.z - xa.z;
+        dx -= Lx * rintf(dx / Lx); dy -= Ly * rintf(dy / Ly); dz -= Lz * rintf(dz / Lz);
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 >= p.rc2) continue;
+        const float sig = pa.y + pj.y, eps4 = pa.z * pj.z;
+        if (eps4 == 0.f) continue;
+        const float inv_r = rsqrtf(r2), rr = r2 * inv_r;
+        const float is2 = 1.f / (sig * sig);
+        const float tt = r2 * r2 * r2 * is2 * is2 * is2;
+        const float x = 1.f / (sc + tt);
+        float U = lam_a * eps4 * x * (x - 1.f), dU = 0.f;
+        switch_fn(p, rr, U, dU);
+        e += (double)U;
+    }
+    e = block_sum_256(e, s_part);
+    if (threadIdx.x == 0) out[(size_t)r * K + k] = e;
 }
 
 // sums the partial slots of each replica in fixed order: lane-strided, then xor-shuffle tree
@@ -55,13 +466,12 @@ void reduce_energy_kernel(int n_epart, const double* __restrict__ epart, double*
     const int r = blockIdx.x;
     double e = 0.0;
     for (int t = threadIdx.x; t < n_epart; t += 64) e += epart[(size_t)r * n_epart + t];
-    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+    e = wave_sum(e);
     if (threadIdx.x == 0) potential[r] = e;
 }
 
 // u_kl rows (states.py:1908-1917 with pressure=None; paralleltempering.py:206-215):
-//   u[r][l] = beta_l * (U_r + econst_l)          when all states share the Hamiltonian.
-// The lambda-dependent part (alchemical states) is added by the alchemical kernel.
+//   u[r][l] = beta_l * (U_r + E_alch[r][l] + econst_l)
 __global__ void assemble_ukl_kernel(int R, int K, const double* __restrict__ potential,
                                     const double* __restrict__ beta, const double* __restrict__ econst,
                                     const double* __restrict__ alch /*[R][K] or null*/,
@@ -75,12 +485,230 @@ __global__ void assemble_ukl_kernel(int R, int K, const double* __restrict__ pot
     ukl_rows[t] = beta[l] * U;
 }
 
+// ---------------------------------------------------------------------------------------------------
+template <typename T> static void dfree(T*& p) { if (p) { hipFree(p); p = nullptr; } }
+template <typename T>
+static int upload(remd_ctx* h, T*& dptr, const std::vector<T>& host)
+{
+    dfree(dptr);
+    if (host.empty()) return 0;
+    REMD_CHECK(h, hipMalloc(&dptr, sizeof(T) * host.size()));
+    REMD_CHECK(h, hipMemcpy(dptr, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void remd_free_nonbonded(remd_ctx* h)
+{
+    auto it = g_nb.find(h);
+    if (it == g_nb.end()) return;
+    nb_tables& t = it->second;
+    dfree(t.d_param); dfree(t.d_mask); dfree(t.d_exc_atoms); dfree(t.d_exc_params); dfree(t.d_excl_atoms); dfree(t.d_excl_qq);
+    dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
+    g_nb.erase(it);
+}
+
+// long-range dispersion correction coefficient (E = coeff / V), OpenMM NonbondedForce convention:
+// averages over the N(N+1)/2 multiset of particle pairs (self pairs included), switching-region
+// integral included.  `eps` already has alchemical atoms zeroed when the system is alchemical.
+static double dispersion_coefficient(int N, const std::vector<double>& sigma, const std::vector<double>& eps,
+                                     double rc, double rs)
+{
+    std::map<std::pair<double, double>, long long> classes;
+    for (int i = 0; i < N; ++i) classes[{sigma[i], eps[i]}]++;
+    std::vector<std::pair<std::pair<double, double>, long long>> cl(classes.begin(), classes.end());
+    auto integral_switch = [&](double sig) {
+        // energy removed by the switch: int_{rs}^{rc} (1 - S(r)) (sig^12/r^12 - sig^6/r^6) r^2 dr, composite Simpson (f64)
+        if (!(rs >= 0) || rs >= rc) return 0.0;
+        const int n = 4000; const double hstep = (rc - rs) / n;
+        auto f = [&](double r) {
+            const double x = (r - rs) / (rc - rs);
+            const double S = 1.0 + x * x * x * (-10.0 + x * (15.0 - 6.0 * x));
+            const double s6 = pow(sig / r, 6);
+            return (1.0 - S) * (s6 * s6 - s6) * r * r;
+        };
+        double acc = f(rs) + f(rc);
+        for (int k = 1; k < n; ++k) acc += f(rs + k * hstep) * ((k & 1) ? 4.0 : 2.0);
+        return acc * hstep / 3.0;
+    };
+    double sum1 = 0, sum2 = 0, sum3 = 0;
+    for (size_t a = 0; a < cl.size(); ++a)
+        for (size_t b = a; b < cl.size(); ++b) {
+            const double count = (a == b) ? 0.5 * (double)cl[a].second * (double)(cl[a].second + 1)
+                                          : (double)cl[a].second * (double)cl[b].second;
+            const double sig = 0.5 * (cl[a].first.first + cl[b].first.first);
+            const double e = sqrt(cl[a].first.second * cl[b].first.second);
+            if (e == 0.0) continue;
+            const double s6 = pow(sig, 6);
+            sum1 += count * e * s6 * s6;
+            sum2 += count * e * s6;
+            sum3 += count * e * integral_switch(sig);
+        }
+    const double npairs = 0.5 * (double)N * (double)(N + 1);
+    sum1 /= npairs; sum2 /= npairs; sum3 /= npairs;
+    return 8.0 * N * (double)N * M_PI * (sum1 / (9.0 * pow(rc, 9)) - sum2 / (3.0 * pow(rc, 3)) + sum3);
+}
+
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
 {
-    (void)d;
+    remd_free_nonbonded(h);
     h->nb_method = d->nb_method;
-    if (d->nb_method != REMD_NB_NONE) return remd_fail(h, -4, "nonbonded forces not built into this libremd_hip.so yet");
+    // bonded tables live in the context
+    {
+        std::vector<int> ba(d->bond_atoms, d->bond_atoms + 2 * (size_t)d->n_bonds);
+        std::vector<float> bp(2 * (size_t)d->n_bonds);
+        for (size_t k = 0; k < bp.size(); ++k) bp[k] = (float)d->bond_params[k];
+        std::vector<int> aa(d->angle_atoms, d->angle_atoms + 3 * (size_t)d->n_angles);
+        std::vector<float> ap(2 * (size_t)d->n_angles);
+        for (size_t k = 0; k < ap.size(); ++k) ap[k] = (float)d->angle_params[k];
+        std::vector<int> ta(d->torsion_atoms, d->torsion_atoms + 4 * (size_t)d->n_torsions);
+        std::vector<float> tp(3 * (size_t)d->n_torsions);
+        for (size_t k = 0; k < tp.size(); ++k) tp[k] = (float)d->torsion_params[k];
+        int rc;
+        if ((rc = upload(h, h->d_bond_atoms, ba)) || (rc = upload(h, h->d_bond_params, bp)) ||
+            (rc = upload(h, h->d_angle_atoms, aa)) || (rc = upload(h, h->d_angle_params, ap)) ||
+            (rc = upload(h, h->d_torsion_atoms, ta)) || (rc = upload(h, h->d_torsion_params, tp))) return rc;
+        h->n_bonds = d->n_bonds; h->n_angles = d->n_angles; h->n_torsions = d->n_torsions;
+        for (int k = 0; k < 2 * d->n_bonds; ++k) if (ba[k] < 0 || ba[k] >= d->n_atoms) return remd_fail(h, -3, "bond atom index out of range");
+        for (int k = 0; k < 3 * d->n_angles; ++k) if (aa[k] < 0 || aa[k] >= d->n_atoms) return remd_fail(h, -3, "angle atom index out of range");
+        for (int k = 0; k < 4 * d->n_torsions; ++k) if (ta[k] < 0 || ta[k] >= d->n_atoms) return remd_fail(h, -3, "torsion atom index out of range");
+    }
+    h->n_alch = d->n_alch;
+    if (d->nb_method == REMD_NB_NONE) return 0;
+    if (d->nb_method != REMD_NB_CUTOFF_PERIODIC && d->nb_method != REMD_NB_PME) return remd_fail(h, -3, "unknown nonbonded method");
+    if (!d->charge || !d->sigma || !d->epsilon) return remd_fail(h, -1, "nonbonded parameter arrays missing");
+    if (!(d->cutoff > 0)) return remd_fail(h, -1, "cutoff must be positive");
+    const int N = d->n_atoms;
+    nb_tables& t = g_nb[h];
+    t.is_alch.assign(N, 0);
+    for (int a = 0; a < d->n_alch; ++a) {
+        if (d->alch_atoms[a] < 0 || d->alch_atoms[a] >= N) return remd_fail(h, -3, "alchemical atom index out of range");
+        t.is_alch[d->alch_atoms[a]] = 1;
+    }
+    t.has_alch = d->n_alch > 0;
+    if (t.has_alch && d->softcore_c != 6.0) return remd_fail(h, -3, "only softcore_c = 6 is implemented");
+    h->sc_alpha = d->softcore_alpha; h->sc_a = d->softcore_a; h->sc_b = d->softcore_b; h->sc_c = d->softcore_c;
+    {
+        std::vector<int> al(d->alch_atoms, d->alch_atoms + d->n_alch);
+        int rc = upload(h, h->d_alch_atoms, al); if (rc) return rc;
+    }
+    bool any_charge = false;
+    t.charge.assign(d->charge, d->charge + N);
+    for (int i = 0; i < N; ++i) any_charge |= (d->charge[i] != 0.0);
+    t.method = !any_charge ? NB_LJ_ONLY : (d->nb_method == REMD_NB_PME ? NB_EWALD : NB_RF);
+    if (d->nb_method == REMD_NB_PME && !any_charge) t.method = NB_LJ_ONLY;
+    const double sqk = sqrt(REMD_ONE_4PI_EPS0);
+    std::vector<float4> prm(h->Npad, make_float4(0, 0, 0, 0));
+    for (int i = 0; i < N; ++i)
+        prm[i] = make_float4((float)(d->charge[i] * sqk), (float)(0.5 * d->sigma[i]), (float)(2.0 * sqrt(d->epsilon[i])),
+                             t.is_alch[i] ? 1.f : 0.f);
+    int rc;
+    if ((rc = upload(h, t.d_param, prm))) return rc;
+    // exclusion window
+    int maxd = 0;
+    for (int e = 0; e < d->n_exceptions; ++e) {
+        const int i = d->exception_atoms[2 * e], j = d->exception_atoms[2 * e + 1];
+        if (i < 0 || j < 0 || i >= N || j >= N || i == j) return remd_fail(h, -3, "bad exception pair");
+        maxd = std::max(maxd, std::abs(i - j));
+    }
+    int words = std::max(1, (maxd + 32) / 32);          // window [-32w, 32w) must contain +-maxd
+    if (words > MAX_EXCL_WORDS) return remd_fail(h, -3, "exclusions span more than 255 atom indices (not supported yet)");
+    std::vector<unsigned long long> mk((size_t)h->Npad * words, 0ull);
+    auto setbit = [&](int i, int j) { const int dd = j - i + 32 * words; mk[(size_t)i * words + (dd >> 6)] |= 1ull << (dd & 63); };
+    for (int i = 0; i < N; ++i) setbit(i, i);
+    std::vector<int> exc_atoms, excl_atoms; std::vector<float> exc_params, excl_qq;
+    for (int e = 0; e < d->n_exceptions; ++e) {
+        const int i = d->exception_atoms[2 * e], j = d->exception_atoms[2 * e + 1];
+        setbit(i, j); setbit(j, i);
+        const double qq = d->exception_params[3 * e], sg = d->exception_params[3 * e + 1], ep = d->exception_params[3 * e + 2];
+        if (qq != 0.0 || ep != 0.0) {
+            if (t.is_alch[i] || t.is_alch[j]) return remd_fail(h, -3, "non-zero exceptions on alchemical atoms are not implemented yet");
+            exc_atoms.push_back(i); exc_atoms.push_back(j);
+            exc_params.push_back((float)(qq * REMD_ONE_4PI_EPS0)); exc_params.push_back((float)sg); exc_params.push_back((float)ep);
+        }
+        if (d->charge[i] != 0.0 && d->charge[j] != 0.0) {
+            excl_atoms.push_back(i); excl_atoms.push_back(j);
+            excl_qq.push_back((float)(d->charge[i] * d->charge[j] * REMD_ONE_4PI_EPS0));
+        }
+    }
+    if ((rc = upload(h, t.d_mask, mk))) return rc;
+    t.n_exc = (int)exc_params.size() / 3;
+    if ((rc = upload(h, t.d_exc_atoms, exc_atoms)) || (rc = upload(h, t.d_exc_params, exc_params))) return rc;
+    t.n_excl = (t.method == NB_EWALD) ? (int)excl_qq.size() : 0;
+    if ((rc = upload(h, t.d_excl_atoms, excl_atoms)) || (rc = upload(h, t.d_excl_qq, excl_qq))) return rc;
+
+    nb_params& p = t.p;
+    p.rc = (float)d->cutoff; p.rc2 = (float)(d->cutoff * d->cutoff);
+    p.rs = (d->switch_distance > 0 && d->switch_distance < d->cutoff) ? (float)d->switch_distance : -1.f;
+    p.inv_sw = p.rs >= 0 ? (float)(1.0 / (d->cutoff - d->switch_distance)) : 0.f;
+    const double eps_s = d->rf_dielectric;
+    p.krf = (float)((eps_s - 1.0) / (2.0 * eps_s + 1.0) / pow(d->cutoff, 3));
+    p.crf = (float)(3.0 * eps_s / (2.0 * eps_s + 1.0) / d->cutoff);
+    p.alpha = (float)d->ewald_alpha; p.two_alpha_sqrtpi = (float)(2.0 * d->ewald_alpha / sqrt(M_PI));
+    p.excl_words = words;
+    const int ntile = (N + 63) / 64;
+    p.n_jsplit = std::max(1, std::min(ntile, 4));
+    h->cutoff = d->cutoff; h->switch_dist = d->switch_distance; h->ewald_alpha = d->ewald_alpha;
+    for (int k = 0; k < 3; ++k) h->grid[k] = d->pme_grid[k];
+
+    // dispersion correction of the (possibly alchemically modified) NonbondedForce
+    t.disp_coeff = 0.0;
+    if (d->use_dispersion_correction) {
+        std::vector<double> sg(d->sigma, d->sigma + N), ep(d->epsilon, d->epsilon + N);
+        for (int i = 0; i < N; ++i) if (t.is_alch[i]) ep[i] = 0.0;     // alchemy.py: alchemical atoms carry eps = 0 in the NonbondedForce
+        t.disp_coeff = dispersion_coefficient(N, sg, ep, d->cutoff, p.rs >= 0 ? d->switch_distance : -1.0);
+    }
+    t.self_energy = 0.0; t.net_charge_term = 0.0;
+    if (t.method == NB_EWALD) {
+        double q2 = 0, qs = 0;
+        for (int i = 0; i < N; ++i) { q2 += d->charge[i] * d->charge[i]; qs += d->charge[i]; }
+        t.self_energy = -REMD_ONE_4PI_EPS0 * d->ewald_alpha / sqrt(M_PI) * q2;
+        t.net_charge_term = -REMD_ONE_4PI_EPS0 * M_PI * qs * qs / (2.0 * d->ewald_alpha * d->ewald_alpha);
+    }
     return 0;
+}
+
+// per-replica lambda parameters follow the replica's current state label
+static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
+{
+    if (!t.has_alch) return 0;
+    if (t.rep_lam_R != h->R) { dfree(t.d_rep_lam); REMD_CHECK(h, hipMalloc(&t.d_rep_lam, sizeof(float) * 4 * h->R)); t.rep_lam_R = h->R; }
+    std::vector<float> rl(4 * (size_t)h->R, 0.f);
+    for (int r = 0; r < h->R; ++r) {
+        const int64_t k = h->labels.empty() ? 0 : h->labels[h->r_begin + r];
+        const double ls = h->lam_s.empty() ? 1.0 : h->lam_s[k], le = h->lam_e.empty() ? 1.0 : h->lam_e[k];
+        rl[4 * r] = (float)pow(ls, h->sc_a);
+        rl[4 * r + 1] = (float)(h->sc_alpha * pow(1.0 - ls, h->sc_b));
+        rl[4 * r + 2] = (float)le;
+    }
+    REMD_CHECK(h, hipMemcpyAsync(t.d_rep_lam, rl.data(), sizeof(float) * rl.size(), hipMemcpyHostToDevice, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+template <int METHOD, bool ENERGY>
+static void launch_nb(remd_ctx* h, nb_tables& t)
+{
+    const int ntile = (h->N + 63) / 64;
+    dim3 grid(ntile, t.p.n_jsplit, h->R);
+    if (t.has_alch)
+        hipLaunchKernelGGL((nonbonded_kernel<METHOD, ENERGY, true>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, h->d_pos,
+                           t.d_param, t.d_mask, h->d_box, t.d_rep_lam, h->d_force, h->d_epart, h->n_epart);
+    else
+        hipLaunchKernelGGL((nonbonded_kernel<METHOD, ENERGY, false>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, h->d_pos,
+                           t.d_param, t.d_mask, h->d_box, (const float*)nullptr, h->d_force, h->d_epart, h->n_epart);
+}
+
+const float* remd_nb_rep_lam(remd_ctx* h)
+{
+    auto it = g_nb.find(h);
+    return (it != g_nb.end() && it->second.has_alch) ? it->second.d_rep_lam : nullptr;
+}
+const float4* remd_nb_param(remd_ctx* h) { return g_nb[h].d_param; }
+
+int remd_nb_required_epart(remd_ctx* h)
+{
+    const int ntile = (h->Npad + 63) / 64;
+    return EP_NB0 + ntile * 4 + 8;
 }
 
 int remd_compute_forces(remd_ctx* h, bool with_energy)
@@ -88,18 +716,65 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
     REMD_CHECK(h, hipMemsetAsync(h->d_force, 0, sizeof(long long) * 3 * (size_t)h->Npad * h->R, h->stream));
     if (with_energy)
         REMD_CHECK(h, hipMemsetAsync(h->d_epart, 0, sizeof(double) * (size_t)h->n_epart * h->R, h->stream));
+    const int R = h->R;
+#define LAUNCH_E(kern, ...) do { if (with_energy) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
     if (h->n_ext > 0) {
         remd_prof_scope ps(h, "ext_force");
+        LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
+                 h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
+    }
+    if (h->n_bonds > 0) {
+        remd_prof_scope ps(h, "bonded");
+        LAUNCH_E(bond_kernel, dim3(R), dim3(256), 0, h->stream, h->n_bonds, h->d_bond_atoms, h->d_bond_params, h->Npad,
+                 h->d_pos, h->d_force, h->d_epart, h->n_epart);
+    }
+    if (h->n_angles > 0) {
+        remd_prof_scope ps(h, "bonded");
+        LAUNCH_E(angle_kernel, dim3(R), dim3(256), 0, h->stream, h->n_angles, h->d_angle_atoms, h->d_angle_params, h->Npad,
+                 h->d_pos, h->d_force, h->d_epart, h->n_epart);
+    }
+    if (h->n_torsions > 0) {
+        remd_prof_scope ps(h, "bonded");
+        LAUNCH_E(torsion_kernel, dim3(R), dim3(256), 0, h->stream, h->n_torsions, h->d_torsion_atoms, h->d_torsion_params, h->Npad,
+                 h->d_pos, h->d_force, h->d_epart, h->n_epart);
+    }
+    if (h->nb_method != REMD_NB_NONE) {
+        nb_tables& t = g_nb[h];
+        int rc = update_replica_lambdas(h, t);
+        if (rc) return rc;
+        {
+            remd_prof_scope ps(h, "nonbonded");
+            if (with_energy) {
+                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, true>(h, t);
+                else if (t.method == NB_RF) launch_nb<NB_RF, true>(h, t);
+                else launch_nb<NB_EWALD, true>(h, t);
+            } else {
+                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, false>(h, t);
+                else if (t.method == NB_RF) launch_nb<NB_RF, false>(h, t);
+                else launch_nb<NB_EWALD, false>(h, t);
+            }
+        }
+        if (t.n_exc > 0) {
+            remd_prof_scope ps(h, "exceptions");
+            LAUNCH_E(exception_kernel, dim3(R), dim3(256), 0, h->stream, t.n_exc, t.d_exc_atoms, t.d_exc_params, h->Npad,
+                     h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);
+        }
+        if (t.n_excl > 0) {
+            remd_prof_scope ps(h, "exceptions");
+            LAUNCH_E(ewald_exclusion_kernel, dim3(R), dim3(256), 0, h->stream, t.n_excl, t.d_excl_atoms, t.d_excl_qq, t.p.alpha,
+                     t.p.two_alpha_sqrtpi, h->Npad, h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);
+        }
+        if (t.method == NB_EWALD) {
+            rc = remd_pme_forces(h, with_energy, nullptr);
+            if (rc) return rc;
+        }
         if (with_energy)
-            hipLaunchKernelGGL(ext_force_kernel<true>, dim3(h->R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms,
-                               (float)h->ext_K, (float)h->ext_x0, h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
-        else
-            hipLaunchKernelGGL(ext_force_kernel<false>, dim3(h->R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms,
-                               (float)h->ext_K, (float)h->ext_x0, h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
+            hipLaunchKernelGGL(const_energy_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, t.disp_coeff, t.self_energy,
+                               t.net_charge_term, h->d_box, h->d_epart, h->n_epart);
     }
-    if (with_energy) {
-        hipLaunchKernelGGL(reduce_energy_kernel, dim3(h->R), dim3(64), 0, h->stream, h->n_epart, h->d_epart, h->d_potential);
-    }
+#undef LAUNCH_E
+    if (with_energy)
+        hipLaunchKernelGGL(reduce_energy_kernel, dim3(R), dim3(64), 0, h->stream, h->n_epart, h->d_epart, h->d_potential);
     REMD_CHECK(h, hipGetLastError());
     h->forces_valid = true;
     return 0;
@@ -108,8 +783,30 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
 int remd_assemble_ukl(remd_ctx* h, double* d_rows)
 {
     const int n = h->R * h->K;
+    const double* alch = nullptr;
+    auto it = g_nb.find(h);
+    if (it != g_nb.end() && it->second.has_alch && h->nb_method != REMD_NB_NONE) {
+        nb_tables& t = it->second;
+        if (t.alch_R != h->R || t.alch_K != h->K) {
+            dfree(t.d_alch_ukl); dfree(t.d_state_lam);
+            REMD_CHECK(h, hipMalloc(&t.d_alch_ukl, sizeof(double) * (size_t)n));
+            REMD_CHECK(h, hipMalloc(&t.d_state_lam, sizeof(double) * 2 * h->K));
+            t.alch_R = h->R; t.alch_K = h->K;
+        }
+        std::vector<double> sl(2 * (size_t)h->K);
+        for (int k = 0; k < h->K; ++k) {
+            sl[2 * k] = pow(h->lam_s[k], h->sc_a);
+            sl[2 * k + 1] = h->sc_alpha * pow(1.0 - h->lam_s[k], h->sc_b);
+        }
+        REMD_CHECK(h, hipMemcpyAsync(t.d_state_lam, sl.data(), sizeof(double) * sl.size(), hipMemcpyHostToDevice, h->stream));
+        REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        remd_prof_scope ps(h, "alch_ukl");
+        hipLaunchKernelGGL(alch_ukl_kernel, dim3(h->K, h->R), dim3(256), 0, h->stream, t.p, h->N, h->Npad, h->n_alch,
+                           h->d_alch_atoms, h->d_pos, t.d_param, h->d_box, h->K, t.d_state_lam, t.d_alch_ukl);
+        alch = t.d_alch_ukl;
+    }
     hipLaunchKernelGGL(assemble_ukl_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K,
-                       h->d_potential, h->d_beta, h->d_econst, (const double*)nullptr, d_rows);
+                       h->d_potential, h->d_beta, h->d_econst, alch, d_rows);
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }

@@ -177,8 +177,18 @@ class MultiStateSampler:
         return m0
 
     def _state_energy_constants(self, states):
-        """Additive per-state potential constants (e.g. lambda-dependent long-range corrections)."""
-        return np.zeros(len(states))
+        """Additive per-state potential constants: the lambda-dependent long-range correction of the
+        alchemical CustomNonbondedForces (alchemy.py:1786-1789), constant in NVT."""
+        from ..system import NonbondedForce
+        from ..alchemy import alchemical_long_range_constants
+        system = states[0].system
+        if getattr(system, 'alchemical_region', None) is None:
+            return np.zeros(len(states))
+        nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)]
+        if not nb or not nb[0].usesPeriodicBoundaryConditions():
+            return np.zeros(len(states))
+        volume = self._sampler_states[0].volume
+        return alchemical_long_range_constants(system, nb[0], [s.lambda_sterics for s in states], volume)
 
     def _initialize_engine(self):
         if self._engine is None:

@@ -1,0 +1,319 @@
+"""forcefield.py — TEST INFRASTRUCTURE ONLY (CPU oracle, f64).
+
+Potential energy of the benchmark systems written once, in double precision, as a
+differentiable torch expression; forces come from autograd, so they are the exact gradient of
+the restated energy and are independent of the hand-derived force formulas in
+openmmtools_amd/csrc/forces.hip and pme.hip.
+
+What is restated (OpenMM semantics of the Systems the reference builds — OpenMM itself is not
+vendored under /root/reference, so absolute parity with it is UNPINNED; see md_oracle.py):
+  * HarmonicBondForce / HarmonicAngleForce / PeriodicTorsionForce:
+        E = k/2 (r-r0)^2,  k/2 (theta-theta0)^2,  k (1 + cos(n phi - phi0))
+  * NonbondedForce, CutoffPeriodic or PME (testsystems.py:1978-2000, 3504-3517):
+        LJ 4 eps ((s/r)^12 - (s/r)^6), Lorentz-Berthelot mixing, switching function
+        S = 1 - 10 x^3 + 15 x^4 - 6 x^5 on [r_switch, r_cut] applied to LJ only,
+        Coulomb k_e q q (1/r + k_rf r^2 - c_rf)      (reaction field, eps_solvent = 78.3)
+        or      k_e q q erfc(alpha r)/r              (Ewald direct space)
+        exceptions: plain k_e qq/r + LJ without cutoff; excluded pairs get the Ewald correction
+        -k_e q q erf(alpha r)/r; self energy -k_e alpha/sqrt(pi) sum q^2;
+        reciprocal space by smooth PME (Essmann 1995), order 5, same mesh as the device;
+        isotropic long-range dispersion correction with the switching-region integral.
+  * alchemical soft-core sterics between alchemical and non-alchemical atoms
+    (alchemy/alchemy.py:1383-1388): U = l^a 4 eps x (x-1), x = (s/r_eff)^6,
+    r_eff = s (alpha (1-l)^b + (r/s)^c)^(1/c); alchemical/alchemical pairs keep full LJ
+    (annihilate_sterics=False, alchemy.py:421); alchemical charges scale with
+    lambda_electrostatics (exact PME treatment, alchemy.py:1675-1680).
+"""
+import math
+import numpy as np
+import torch
+from scipy.spatial import cKDTree
+from scipy import integrate
+
+from .md_oracle import OracleSystem, ONE_4PI_EPS0
+
+torch.set_default_dtype(torch.float64)
+PME_ORDER = 5
+
+
+def _bspline_weights(f, order=PME_ORDER):
+    """w[..., j] = M_order(f + j), j = 0..order-1 (mesh index k0 - j); differentiable in f."""
+    a = [f, 1.0 - f] + [torch.zeros_like(f)] * (order - 2)
+    for m in range(3, order + 1):
+        new = []
+        for j in range(order):
+            if j < m:
+                cur = a[j] if j < m - 1 else torch.zeros_like(f)
+                prev = a[j - 1] if j > 0 else torch.zeros_like(f)
+                new.append(((f + j) * cur + (m - f - j) * prev) / (m - 1))
+            else:
+                new.append(torch.zeros_like(f))
+        a = new
+    return torch.stack(a, dim=-1)
+
+
+def _bspline_moduli(n, order=PME_ORDER):
+    def M(o, u):
+        if o == 2:
+            return 0.0 if (u < 0 or u > 2) else 1.0 - abs(u - 1.0)
+        return u / (o - 1) * M(o - 1, u) + (o - u) / (o - 1) * M(o - 1, u - 1.0)
+    w = np.array([M(order, k + 1.0) for k in range(order - 1)])
+    m = np.arange(n)
+    arg = 2.0 * np.pi * np.outer(m, np.arange(order - 1)) / n
+    bm = (w * np.cos(arg)).sum(1) ** 2 + (w * np.sin(arg)).sum(1) ** 2
+    for i in range(n):
+        if bm[i] < 1e-7:
+            bm[i] = 0.5 * (bm[(i - 1) % n] + bm[(i + 1) % n])
+    return bm
+
+
+def dispersion_coefficient(sigma, epsilon, rc, rs):
+    """E_disp = coeff / V, OpenMM NonbondedForce convention (average over the N(N+1)/2 pair multiset)."""
+    N = len(sigma)
+    classes = {}
+    for s, e in zip(sigma, epsilon):
+        classes[(s, e)] = classes.get((s, e), 0) + 1
+    cl = sorted(classes.items())
+    s1 = s2 = s3 = 0.0
+    for a in range(len(cl)):
+        for b in range(a, len(cl)):
+            (sa, ea), na = cl[a]
+            (sb, eb), nb = cl[b]
+            count = na * (na + 1) / 2.0 if a == b else na * nb
+            sig, eps = 0.5 * (sa + sb), math.sqrt(ea * eb)
+            if eps == 0.0:
+                continue
+            s1 += count * eps * sig ** 12
+            s2 += count * eps * sig ** 6
+            if rs is not None and 0 <= rs < rc:
+                def f(r):
+                    x = (r - rs) / (rc - rs)
+                    S = 1.0 - 10.0 * x ** 3 + 15.0 * x ** 4 - 6.0 * x ** 5
+                    return (1.0 - S) * ((sig / r) ** 12 - (sig / r) ** 6) * r * r
+                s3 += count * eps * integrate.quad(f, rs, rc, epsabs=0, epsrel=1e-12)[0]
+    npairs = N * (N + 1) / 2.0
+    return 8.0 * N * N * math.pi * (s1 / npairs / (9.0 * rc ** 9) - s2 / npairs / (3.0 * rc ** 3) + s3 / npairs)
+
+
+class ForceFieldOracle(OracleSystem):
+    def __init__(self, desc):
+        super().__init__(desc)
+        d = desc
+        self.q = torch.tensor(np.asarray(d['charge'], dtype=np.float64))
+        self.sig = torch.tensor(np.asarray(d['sigma'], dtype=np.float64))
+        self.eps = torch.tensor(np.asarray(d['epsilon'], dtype=np.float64))
+        self.is_alch = np.zeros(self.N, dtype=bool)
+        self.is_alch[np.asarray(d['alch_atoms'], dtype=int)] = True
+        self.alch_t = torch.tensor(self.is_alch)
+        exc = np.asarray(d['exception_atoms']).reshape(-1, 2)
+        self.excluded = set((min(i, j), max(i, j)) for i, j in exc)
+        self.exc_atoms = exc
+        self.exc_params = np.asarray(d['exception_params'], dtype=np.float64).reshape(-1, 3)
+        self.method = int(d['nb_method'])
+        self.rc = float(d['cutoff'])
+        self.rs = float(d['switch_distance']) if d['switch_distance'] > 0 else None
+        self.alpha = float(d['ewald_alpha'])
+        self.grid = [int(g) for g in d['pme_grid']]
+        self.has_charge = bool(np.any(np.asarray(d['charge']) != 0.0))
+        eps_for_disp = np.where(self.is_alch, 0.0, np.asarray(d['epsilon'], dtype=np.float64))
+        self.disp_coeff = dispersion_coefficient(list(np.asarray(d['sigma'])), list(eps_for_disp), self.rc, self.rs) \
+            if (self.method and d['use_dispersion_correction']) else 0.0
+        self.sc = d.get('softcore', (0.5, 1.0, 1.0, 6.0))
+        self._bm = [torch.tensor(_bspline_moduli(n)) for n in self.grid] if self.method == 2 else None
+
+    # ---- pair list (numpy) ---------------------------------------------------------------------
+    def _pairs(self, x, box):
+        xw = np.mod(x, box)
+        xw = np.where(xw >= box, 0.0, xw)
+        tree = cKDTree(xw, boxsize=box)
+        pairs = tree.query_pairs(self.rc, output_type='ndarray')
+        if len(self.excluded):
+            key = pairs[:, 0].astype(np.int64) * self.N + pairs[:, 1]
+            ex = np.array([a * self.N + b for a, b in self.excluded], dtype=np.int64)
+            pairs = pairs[~np.isin(key, ex)]
+        return pairs
+
+    @staticmethod
+    def _min_image(d, box_t):
+        return d - box_t * torch.round(d / box_t)
+
+    def _switch(self, r):
+        if self.rs is None:
+            return torch.ones_like(r)
+        x = torch.clamp((r - self.rs) / (self.rc - self.rs), 0.0, 1.0)
+        return 1.0 - 10.0 * x ** 3 + 15.0 * x ** 4 - 6.0 * x ** 5
+
+    # ---- energy terms (torch) --------------------------------------------------------------------
+    def _bonded(self, x):
+        d = self.d
+        e = x.new_zeros(())
+        ba = np.asarray(d['bond_atoms']).reshape(-1, 2)
+        if len(ba):
+            bp = torch.tensor(np.asarray(d['bond_params'], dtype=np.float64).reshape(-1, 2))
+            r = (x[ba[:, 1]] - x[ba[:, 0]]).norm(dim=1)
+            e = e + (0.5 * bp[:, 1] * (r - bp[:, 0]) ** 2).sum()
+        aa = np.asarray(d['angle_atoms']).reshape(-1, 3)
+        if len(aa):
+            ap = torch.tensor(np.asarray(d['angle_params'], dtype=np.float64).reshape(-1, 2))
+            v0, v1 = x[aa[:, 0]] - x[aa[:, 1]], x[aa[:, 2]] - x[aa[:, 1]]
+            cos = (v0 * v1).sum(1) / (v0.norm(dim=1) * v1.norm(dim=1))
+            th = torch.acos(torch.clamp(cos, -1.0, 1.0))
+            e = e + (0.5 * ap[:, 1] * (th - ap[:, 0]) ** 2).sum()
+        ta = np.asarray(d['torsion_atoms']).reshape(-1, 4)
+        if len(ta):
+            tp = torch.tensor(np.asarray(d['torsion_params'], dtype=np.float64).reshape(-1, 3))
+            b1, b2, b3 = x[ta[:, 1]] - x[ta[:, 0]], x[ta[:, 2]] - x[ta[:, 1]], x[ta[:, 3]] - x[ta[:, 2]]
+            m, n = torch.linalg.cross(b1, b2), torch.linalg.cross(b2, b3)
+            phi = torch.atan2(b2.norm(dim=1) * (b1 * n).sum(1), (m * n).sum(1))
+            e = e + (tp[:, 2] * (1.0 + torch.cos(tp[:, 0] * phi - tp[:, 1]))).sum()
+        return e
+
+    def _pair_terms(self, x, box_t, pairs, lam_s, lam_e, include_na=True, only_na=False):
+        i, j = pairs[:, 0], pairs[:, 1]
+        dv = self._min_image(x[j] - x[i], box_t)
+        r = dv.norm(dim=1)
+        sig = 0.5 * (self.sig[i] + self.sig[j])
+        eps = torch.sqrt(self.eps[i] * self.eps[j])
+        na = self.alch_t[i] != self.alch_t[j]
+        alpha_sc, a, b, c = self.sc
+        lj = 4.0 * eps * ((sig / r) ** 12 - (sig / r) ** 6)
+        reff = sig * (alpha_sc * (1.0 - lam_s) ** b + (r / sig) ** c) ** (1.0 / c)
+        xsc = (sig / reff) ** 6
+        sc = (lam_s ** a) * 4.0 * eps * xsc * (xsc - 1.0)
+        S = self._switch(r)
+        if only_na:
+            return (torch.where(na, sc, torch.zeros_like(sc)) * S).sum()
+        sterics = torch.where(na, sc if include_na else torch.zeros_like(sc), lj) * S
+        e = sterics.sum()
+        if self.has_charge:
+            q = torch.where(self.alch_t, self.q * lam_e, self.q)
+            qq = ONE_4PI_EPS0 * q[i] * q[j]
+            if self.method == 2:
+                e = e + (qq * torch.erfc(self.alpha * r) / r).sum()
+            else:
+                eps_s = self.d['rf_dielectric']
+                krf = (eps_s - 1.0) / (2.0 * eps_s + 1.0) / self.rc ** 3
+                crf = 3.0 * eps_s / (2.0 * eps_s + 1.0) / self.rc
+                e = e + (qq * (1.0 / r + krf * r * r - crf)).sum()
+        return e
+
+    def _exceptions(self, x, box_t, lam_e):
+        e = x.new_zeros(())
+        if len(self.exc_atoms) == 0:
+            return e
+        i, j = self.exc_atoms[:, 0], self.exc_atoms[:, 1]
+        p = torch.tensor(self.exc_params)
+        dv = x[j] - x[i]
+        if box_t is not None:
+            dv = self._min_image(dv, box_t)
+        r = dv.norm(dim=1)
+        nz = (p[:, 0] != 0) | (p[:, 2] != 0)
+        sr6 = torch.where(nz, (p[:, 1] / r) ** 6, torch.zeros_like(r))
+        e = e + (torch.where(nz, ONE_4PI_EPS0 * p[:, 0] / r, torch.zeros_like(r)) + 4.0 * p[:, 2] * sr6 * (sr6 - 1.0)).sum()
+        if self.method == 2 and self.has_charge:
+            q = torch.where(self.alch_t, self.q * lam_e, self.q)
+            e = e - (ONE_4PI_EPS0 * q[i] * q[j] * torch.erf(self.alpha * r) / r).sum()
+        return e
+
+    def pme_reciprocal(self, x, box_t, q):
+        """Smooth PME reciprocal energy: E = 1/2 sum_m G(m) |S(m)|^2, G = k_e exp(-pi^2 m^2/alpha^2) B(m) / (pi V m^2)."""
+        n = self.grid
+        u = [(x[:, k] / box_t[k] - torch.floor(x[:, k] / box_t[k])) * n[k] for k in range(3)]
+        k0 = [torch.floor(uk).detach().long() for uk in u]
+        w = [_bspline_weights(uk - kk) for uk, kk in zip(u, k0)]          # [N, 5] each
+        off = torch.arange(PME_ORDER)
+        idx = [torch.remainder(kk[:, None] - off[None, :], nk) for kk, nk in zip(k0, n)]
+        lin = (idx[0][:, :, None, None] * n[1] + idx[1][:, None, :, None]) * n[2] + idx[2][:, None, None, :]
+        val = q[:, None, None, None] * w[0][:, :, None, None] * w[1][:, None, :, None] * w[2][:, None, None, :]
+        Q = torch.zeros(n[0] * n[1] * n[2], dtype=x.dtype).index_add(0, lin.reshape(-1), val.reshape(-1)).reshape(n)
+        S = torch.fft.fftn(Q)
+        m = [torch.fft.fftfreq(nk, d=1.0 / nk) / box_t[k] for k, nk in enumerate(n)]
+        msq = m[0][:, None, None] ** 2 + m[1][None, :, None] ** 2 + m[2][None, None, :] ** 2
+        V = box_t[0] * box_t[1] * box_t[2]
+        B = 1.0 / (self._bm[0][:, None, None] * self._bm[1][None, :, None] * self._bm[2][None, None, :])
+        msq_safe = torch.where(msq > 0, msq, torch.ones_like(msq))
+        G = torch.where(msq > 0, ONE_4PI_EPS0 * torch.exp(-math.pi ** 2 * msq_safe / self.alpha ** 2) * B / (math.pi * V * msq_safe),
+                        torch.zeros_like(msq))
+        return 0.5 * (G * (S.real ** 2 + S.imag ** 2)).sum()
+
+    def energy_torch(self, x, box, lam_s=1.0, lam_e=1.0, include_na=True):
+        d = self.d
+        e = x.new_zeros(())
+        if d['n_ext'] > 0:
+            idx = np.asarray(d['ext_atoms'])
+            dx = x[idx] - torch.tensor([d['ext_x0'], 0.0, 0.0])
+            e = e + 0.5 * d['ext_K'] * (dx * dx).sum() + d['ext_U0'] * len(idx)
+        e = e + self._bonded(x)
+        if self.method:
+            box_t = torch.tensor(np.asarray(box, dtype=np.float64))
+            pairs = self._pairs(x.detach().numpy(), np.asarray(box, dtype=np.float64))
+            if len(pairs):
+                e = e + self._pair_terms(x, box_t, pairs, lam_s, lam_e, include_na=include_na)
+            e = e + self._exceptions(x, box_t, lam_e)
+            V = float(np.prod(box))
+            e = e + self.disp_coeff / V
+            if self.method == 2 and self.has_charge:
+                q = torch.where(self.alch_t, self.q * lam_e, self.q)
+                e = e + self.pme_reciprocal(x, box_t, q)
+                e = e - ONE_4PI_EPS0 * self.alpha / math.sqrt(math.pi) * (q * q).sum()
+                e = e - ONE_4PI_EPS0 * math.pi * q.sum() ** 2 / (2.0 * self.alpha ** 2 * V)
+        return e
+
+    def energy_forces(self, x, box=None, lambda_sterics=1.0, lambda_electrostatics=1.0, forces=True):
+        xt = torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=forces)
+        e = self.energy_torch(xt, box, lambda_sterics, lambda_electrostatics)
+        if not forces:
+            return float(e.detach()), None
+        if e.requires_grad:
+            (g,) = torch.autograd.grad(e, xt)
+            return float(e.detach()), -g.numpy()
+        return float(e.detach()), np.zeros_like(np.asarray(x, dtype=np.float64))
+
+    def potential(self, x, box=None, lambda_sterics=1.0, lambda_electrostatics=1.0):
+        return self.energy_forces(x, box, lambda_sterics, lambda_electrostatics, forces=False)[0]
+
+    def state_energies(self, x, box, lam_s, lam_e):
+        """Potential at every state's (lambda_sterics, lambda_electrostatics) for one configuration."""
+        xt = torch.tensor(np.asarray(x, dtype=np.float64))
+        if not self.is_alch.any() or not self.method:
+            return np.full(len(lam_s), float(self.energy_torch(xt, box)))
+        if self.has_charge and np.any(np.asarray(lam_e) != 1.0):
+            return np.array([float(self.energy_torch(xt, box, ls, le)) for ls, le in zip(lam_s, lam_e)])
+        base = float(self.energy_torch(xt, box, 1.0, 1.0, include_na=False))
+        box_t = torch.tensor(np.asarray(box, dtype=np.float64))
+        pairs = self._pairs(np.asarray(x, dtype=np.float64), np.asarray(box, dtype=np.float64))
+        return np.array([base + float(self._pair_terms(xt, box_t, pairs, ls, 1.0, only_na=True)) for ls in lam_s])
+
+
+def ewald_direct_sum(x, q, box, alpha, rc_real=None, kmax=12):
+    """Plain Ewald summation in f64 (real space over nearest images within L/2, reciprocal to |k| <= kmax),
+    including self and neutralising terms; used only to pin the PME oracle on small systems."""
+    x = np.asarray(x, dtype=np.float64); q = np.asarray(q, dtype=np.float64); box = np.asarray(box, dtype=np.float64)
+    N = len(q)
+    V = box.prod()
+    e_real = 0.0
+    shifts = [np.array([a, b, c]) * box for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]
+    for i in range(N):
+        for j in range(i + 1, N):
+            for s in shifts:
+                r = np.linalg.norm(x[j] - x[i] + s)
+                e_real += q[i] * q[j] * math.erfc(alpha * r) / r
+        for s in shifts:
+            if np.any(s != 0):
+                r = np.linalg.norm(s)
+                e_real += 0.5 * q[i] * q[i] * math.erfc(alpha * r) / r
+    e_rec = 0.0
+    rng = range(-kmax, kmax + 1)
+    for a in rng:
+        for b in rng:
+            for c in rng:
+                if a == b == c == 0:
+                    continue
+                m = np.array([a, b, c]) / box
+                msq = m @ m
+                S = np.sum(q * np.exp(2j * np.pi * (x @ m)))
+                e_rec += math.exp(-math.pi ** 2 * msq / alpha ** 2) / msq * abs(S) ** 2
+    e_rec *= 1.0 / (2.0 * math.pi * V)
+    e_self = -alpha / math.sqrt(math.pi) * np.sum(q * q)
+    e_bg = -math.pi * q.sum() ** 2 / (2.0 * alpha ** 2 * V)
+    return ONE_4PI_EPS0 * (e_real + e_rec + e_self + e_bg)

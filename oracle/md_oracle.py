@@ -135,37 +135,67 @@ class OracleSystem:
 # constraints: iterative SHAKE (positions) and RATTLE (velocities), f64, tolerance 1e-12
 # ---------------------------------------------------------------------------------------------
 
+def _color_constraints(cons):
+    """Group constraints into colours whose members share no atom (vectorised Gauss-Seidel sweeps)."""
+    colours = []
+    for c in cons:
+        for col in colours:
+            if c[0] not in col['atoms'] and c[1] not in col['atoms']:
+                col['atoms'].update((c[0], c[1]))
+                col['list'].append(c)
+                break
+        else:
+            colours.append({'atoms': {c[0], c[1]}, 'list': [c]})
+    out = []
+    for col in colours:
+        a = np.array(col['list'], dtype=np.float64)
+        out.append((a[:, 0].astype(int), a[:, 1].astype(int), a[:, 2]))
+    return out
+
+
+_colour_cache = {}
+
+
+def _colours(cons):
+    key = id(cons)
+    if key not in _colour_cache:
+        _colour_cache[key] = _color_constraints(cons)
+    return _colour_cache[key]
+
+
 def shake(cons, invm, x_old, x_new, tol=1e-12, max_iter=500):
-    """Move x_new along the OLD bond vectors until every |r|^2 matches d^2 (relative tol)."""
+    """Iterative SHAKE: move x_new along the OLD bond vectors until every |r|^2 matches d^2 (relative tol).
+    Constraints of one colour share no atoms and are updated together (plain Gauss-Seidel otherwise)."""
     x = x_new.copy()
+    cols = _colours(cons)
     for _ in range(max_iter):
         worst = 0.0
-        for (i, j, dist) in cons:
+        for (i, j, dist) in cols:
             r = x[j] - x[i]
-            diff = dist * dist - r @ r
-            worst = max(worst, abs(diff) / (dist * dist))
-            if abs(diff) > tol * dist * dist:
-                r0 = x_old[j] - x_old[i]
-                lam = diff / (2.0 * (invm[i] + invm[j]) * (r @ r0))
-                x[i] -= lam * invm[i] * r0
-                x[j] += lam * invm[j] * r0
+            diff = dist * dist - np.einsum('ij,ij->i', r, r)
+            worst = max(worst, float(np.max(np.abs(diff) / (dist * dist))))
+            r0 = x_old[j] - x_old[i]
+            lam = diff / (2.0 * (invm[i] + invm[j]) * np.einsum('ij,ij->i', r, r0))
+            x[i] -= (lam * invm[i])[:, None] * r0
+            x[j] += (lam * invm[j])[:, None] * r0
         if worst < tol:
             break
     return x
 
 
 def rattle(cons, invm, x, v, tol=1e-12, max_iter=500):
-    """Remove the velocity components along the constraints."""
+    """Iterative RATTLE velocity stage: remove the velocity components along the constraints."""
     v = v.copy()
+    cols = _colours(cons)
     for _ in range(max_iter):
         worst = 0.0
-        for (i, j, dist) in cons:
+        for (i, j, dist) in cols:
             r = x[j] - x[i]
-            rv = r @ (v[j] - v[i])
-            worst = max(worst, abs(rv) / (dist * dist))
-            lam = rv / ((r @ r) * (invm[i] + invm[j]))
-            v[i] += lam * invm[i] * r
-            v[j] -= lam * invm[j] * r
+            rv = np.einsum('ij,ij->i', r, v[j] - v[i])
+            worst = max(worst, float(np.max(np.abs(rv) / (dist * dist))))
+            lam = rv / (np.einsum('ij,ij->i', r, r) * (invm[i] + invm[j]))
+            v[i] += (lam * invm[i])[:, None] * r
+            v[j] -= (lam * invm[j])[:, None] * r
         if worst < tol:
             break
     return v

@@ -1,0 +1,157 @@
+"""GPU parity of the force-field kernels (csrc/forces.hip, pme.hip, SETTLE/SHAKE in integrate.hip) against the
+f64 oracle, through the C ABI.  Tolerances: u_kl / potential 1e-5 relative (north_star); forces to the
+reference's own cross-platform bar of 0.06 kcal/mol/A RMSE = 2.5 kJ/mol/nm (scripts/test_openmm_platforms.py:154-155),
+in practice ~1e-4 relative; FFT vs numpy to fp32 round-off."""
+import numpy as np
+import pytest
+from openmmtools_amd import testsystems as ts, alchemy
+from openmmtools_amd.system import system_to_desc
+from oracle import md_oracle as mo
+from oracle.forcefield import ForceFieldOracle
+from oracle_engine import OracleEngine
+
+pytestmark = pytest.mark.gpu
+KB = 0.008314462618153242
+SEED = 0xC0FFEE
+
+
+@pytest.mark.parametrize('shape', [(8, 8, 8), (16, 24, 40), (72, 80, 80), (96, 120, 128), (144, 8, 16)])
+def test_fft3d_matches_numpy(hip_engine_factory, shape):
+    eng = hip_engine_factory()
+    rng = np.random.default_rng(sum(shape))
+    a = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(np.complex64)
+    ref = np.fft.fftn(a.astype(np.complex128))
+    got = eng.test_fft3d(a)
+    assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
+    back = eng.test_fft3d(got, inverse=True) / np.prod(shape)
+    assert np.abs(back - a).max() < 1e-5 * np.abs(a).max()
+
+
+def _engine_for(eng, system, positions, R=2, temperature=300.0, lam_s=None, jitter=0.0, splitting='V R O R V',
+                dt=0.001, n_steps=5, labels=None, econst=None):
+    desc = system_to_desc(system)
+    eng.set_system(desc)
+    K = R if lam_s is None else len(lam_s)
+    eng.set_states(np.full(K, 1.0 / (KB * temperature)), lam_s, None, econst)
+    eng.set_integrator(splitting, dt, 1.0, n_steps, True, 1e-8)
+    eng.seed(SEED)
+    rng = np.random.default_rng(3)
+    x = np.stack([positions + jitter * rng.normal(size=positions.shape) * (r > 0) for r in range(R)])
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (R, 1))
+    eng.set_replicas(R, 0, x, None, box, np.arange(R) % K if labels is None else labels)
+    return desc, x, box
+
+
+def test_lj_fluid_energy_and_forces(hip_engine_factory):
+    """BASELINE config 2 system: LennardJonesFluid(512), CutoffPeriodic + switch + dispersion correction."""
+    lj = ts.LennardJonesFluid(nparticles=512)
+    eng = hip_engine_factory()
+    desc, x, box = _engine_for(eng, lj.system, lj.positions, R=2, jitter=0.01)
+    ff = ForceFieldOracle(desc)
+    rows, U = eng.compute_energies(want_potential=True)
+    f = eng.get_forces()
+    xd = eng.get_replicas()[0]
+    for r in range(2):
+        e_ref, f_ref = ff.energy_forces(xd[r], box[r])
+        assert np.isclose(U[r], e_ref, rtol=1e-5), (U[r], e_ref)
+        assert np.abs(f[r] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
+        assert np.isclose(rows[r, 0], e_ref / (KB * 300.0), rtol=1e-5)
+
+
+def test_lj_fluid_alchemical_ukl(hip_engine_factory):
+    """16 lambda_sterics states on atoms 0-9 (tests/test_alchemy.py:1864-1866): u_kl rows from one pass."""
+    lj = ts.LennardJonesFluid(nparticles=512)
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(10))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, region)
+    lam = np.linspace(1.0, 0.0, 16)
+    nb = [f for f in system.getForces() if hasattr(f, 'particles') and hasattr(f, 'exceptions')][0]
+    V = np.prod(np.diag(system.getDefaultPeriodicBoxVectors()))
+    econst = alchemy.alchemical_long_range_constants(system, nb, lam, V)
+    assert econst[0] < 0 and abs(econst[-1]) < abs(econst[0])       # tail shrinks as the atoms decouple
+    eng = hip_engine_factory()
+    desc, x, box = _engine_for(eng, system, lj.positions, R=3, lam_s=lam, jitter=0.01, labels=[0, 7, 15],
+                               econst=econst)
+    ff = ForceFieldOracle(desc)
+    rows = eng.compute_energies()
+    xd = eng.get_replicas()[0]
+    beta = 1.0 / (KB * 300.0)
+    for r in range(3):
+        ref = beta * (ff.state_energies(xd[r], box[r], lam, np.ones(16)) + econst)
+        assert np.allclose(rows[r], ref, rtol=1e-5), np.abs(rows[r] / ref - 1).max()
+    # forces at each replica's own lambda
+    f = eng.get_forces()
+    for r, k in enumerate([0, 7, 15]):
+        f_ref = ff.energy_forces(xd[r], box[r], lambda_sterics=lam[k])[1]
+        assert np.abs(f[r] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
+
+
+@pytest.fixture(scope='module')
+def alanine():
+    al = ts.AlanineDipeptideExplicit()
+    return al, system_to_desc(al.system)
+
+
+def test_alanine_energy_and_forces(hip_engine_factory, alanine):
+    """BASELINE config 3 system: bonded + LJ + PME (direct, reciprocal, exclusions, self) + dispersion."""
+    al, _ = alanine
+    eng = hip_engine_factory()
+    desc, x, box = _engine_for(eng, al.system, al.positions, R=2, jitter=0.002)
+    ff = ForceFieldOracle(desc)
+    rows, U = eng.compute_energies(want_potential=True)
+    f = eng.get_forces()
+    xd = eng.get_replicas()[0]
+    for r in range(2):
+        e_ref, f_ref = ff.energy_forces(xd[r], box[r])
+        assert np.isclose(U[r], e_ref, rtol=1e-5), (U[r], e_ref, U[r] - e_ref)
+        rmse = np.sqrt(((f[r] - f_ref) ** 2).sum(axis=1).mean())
+        assert rmse < 2.5, rmse                                    # 0.06 kcal/mol/A in kJ/mol/nm
+        assert np.abs(f[r] - f_ref).max() < 1e-3 * np.abs(f_ref).max()
+
+
+def test_alanine_constraints_and_substeps(hip_engine_factory, alanine):
+    """SETTLE (analytic) / SHAKE clusters on the device vs iterative f64 SHAKE/RATTLE in the oracle."""
+    al, desc = alanine
+    eng, ora = hip_engine_factory(), OracleEngine(ForceFieldOracle)
+    _engine_for(eng, al.system, al.positions, R=1, splitting='V R R O R R V', dt=0.002)
+    _engine_for(ora, al.system, al.positions, R=1, splitting='V R R O R R V', dt=0.002)
+    eng.propagate_zero = None
+    # velocities: Maxwell-Boltzmann + velocity constraints
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 0, True, 1e-8)
+    ora.set_integrator('V R R O R R V', 0.002, 1.0, 0, True, 1e-8)
+    eng.propagate(1)
+    ora.propagate(1)
+    xg, vg, _, _ = eng.get_replicas()
+    assert np.abs(vg - ora.v).max() < 5e-5 * np.abs(ora.v).max() + 1e-5
+    cons = ora.sys.constraints
+    i, j, dist = np.array([c[0] for c in cons]), np.array([c[1] for c in cons]), np.array([c[2] for c in cons])
+    rel_v = np.einsum('ij,ij->i', xg[0][j] - xg[0][i], vg[0][j] - vg[0][i])
+    assert np.abs(rel_v).max() < 2e-5
+    ora.x, ora.v = xg.copy(), vg.copy()
+    for tok in ('R', 'V', 'O', 'R', 'R', 'V'):
+        eng.step(tok, iteration=1, first_step=0)
+        ora.step(tok, iteration=1, first_step=0)
+        xg, vg, _, _ = eng.get_replicas()
+        assert np.abs(xg - ora.x).max() < 2e-6, (tok, np.abs(xg - ora.x).max())
+        assert np.abs(vg - ora.v).max() < 3e-3 * np.abs(ora.v).max() / 10 + 2e-4, (tok, np.abs(vg - ora.v).max())
+        d = np.linalg.norm(xg[0][j] - xg[0][i], axis=1)
+        assert np.abs(d - dist).max() < 2e-6, (tok, np.abs(d - dist).max())
+        ora.x, ora.v = xg.copy(), vg.copy()
+
+
+def test_alanine_short_trajectory(hip_engine_factory, alanine):
+    """10 g-BAOAB steps at 2 fs with CM-motion removal: device fp32 vs oracle f64, same Philox stream."""
+    al, desc = alanine
+    eng, ora = hip_engine_factory(), OracleEngine(ForceFieldOracle)
+    _engine_for(eng, al.system, al.positions, R=1, splitting='V R R O R R V', dt=0.002, n_steps=10)
+    _engine_for(ora, al.system, al.positions, R=1, splitting='V R R O R R V', dt=0.002, n_steps=10)
+    assert not eng.propagate(3).any()
+    ora.propagate(3)
+    xg, vg, _, _ = eng.get_replicas()
+    assert np.abs(xg - ora.x).max() < 5e-5                      # nm, after 10 steps
+    assert np.sqrt(((vg - ora.v) ** 2).mean()) < 2e-3 * np.sqrt((ora.v ** 2).mean())
+    m = np.asarray(desc['mass'])
+    p = (m[:, None] * vg[0]).sum(0) / m.sum()
+    assert np.abs(p).max() < 5e-3                                 # CM velocity stays ~0 (thermal kicks only)
+    U_dev = eng.compute_energies(want_potential=True)[1]
+    U_ora = ora.potentials()
+    assert np.allclose(U_dev, U_ora, rtol=2e-4)
