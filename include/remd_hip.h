@@ -181,6 +181,10 @@ int  remd_get_forces(remd_handle h, double* f);
 /* run a splitting string once per call on all local replicas with explicit step counter
    (test hook: single V / R / O substeps).                                               */
 int  remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t first_step, int n_steps);
+/* test hook: potential-energy components per local replica, out[R_local][9] =
+   {external, bonds, angles, torsions, exceptions, Ewald exclusion correction, PME reciprocal,
+    constants (dispersion + Ewald self + background), nonbonded direct}                  */
+int  remd_get_energy_components(remd_handle h, double* out);
 int  remd_sync(remd_handle h);
 /* test hook: in-place unnormalised 3-D complex FFT of a host array [nx][ny][nz][2] on the
    in-tree mixed-radix FFT that the PME reciprocal pass uses                             */

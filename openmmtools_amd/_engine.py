@@ -43,7 +43,7 @@ EXPORTS = [
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
-    'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d',
+    'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components',
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def load_library(path=None):
     lib.remd_get_forces.argtypes = [vp, c_double_p]
     lib.remd_step.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64, C.c_int]
     lib.remd_sync.argtypes = [vp]
+    lib.remd_get_energy_components.argtypes = [vp, c_double_p]
     lib.remd_test_fft3d.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.remd_last_timing.argtypes = [vp, c_double_p, c_double_p, c_double_p]
     lib.remd_profile_enable.argtypes = [vp, C.c_int]
@@ -275,6 +276,13 @@ class HipEngine:
     def step(self, splitting, iteration=0, first_step=0, n_steps=1):
         self._check(self.lib.remd_step(self.h, splitting.encode(), int(iteration), int(first_step), int(n_steps)),
                     'remd_step')
+
+    def energy_components(self):
+        names = ['external', 'bonds', 'angles', 'torsions', 'exceptions', 'ewald_exclusions', 'pme_reciprocal',
+                 'constants', 'nonbonded_direct']
+        out = np.zeros((self.R, 9))
+        self._check(self.lib.remd_get_energy_components(self.h, _dp(out)), 'remd_get_energy_components')
+        return [dict(zip(names, row)) for row in out]
 
     def test_fft3d(self, data, inverse=False):
         a = np.ascontiguousarray(data, dtype=np.complex64).copy()

@@ -409,6 +409,22 @@ int remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inve
     return remd_test_fft3d_impl(h, nx, ny, nz, data, inverse);
 }
 
+int remd_get_energy_components(remd_handle h, double* out)
+{
+    if (!h || !out || h->R <= 0) return remd_fail(h, -1, "remd_get_energy_components: bad arguments");
+    hipSetDevice(h->device);
+    int rc = remd_compute_forces(h, true); if (rc) return rc;
+    std::vector<double> ep((size_t)h->n_epart * h->R);
+    REMD_CHECK(h, hipMemcpyAsync(ep.data(), h->d_epart, sizeof(double) * ep.size(), hipMemcpyDeviceToHost, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < h->R; ++r) {
+        for (int k = 0; k < 8; ++k) out[9 * r + k] = ep[(size_t)r * h->n_epart + k];
+        double nb = 0; for (int k = 8; k < h->n_epart; ++k) nb += ep[(size_t)r * h->n_epart + k];
+        out[9 * r + 8] = nb;
+    }
+    return 0;
+}
+
 int remd_sync(remd_handle h) { if (!h) return -1; hipSetDevice(h->device); REMD_CHECK(h, hipStreamSynchronize(h->stream)); return 0; }
 
 int remd_last_timing(remd_handle h, double* p, double* e, double* m)

@@ -161,7 +161,7 @@ void fft_pass_kernel(fft_plan pl, float2* __restrict__ grid, size_t rep_stride, 
         float2* other = (res == bufA) ? bufB : bufA;
         const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
         const double V = (double)Lx * Ly * Lz;
-        const float pref = (float)(REMD_ONE_4PI_EPS0 / (M_PI * V));
+        const float pref = (float)(1.0 / (M_PI * V));      // charges already carry sqrt(k_e)
         const float fac = (float)(M_PI * M_PI) / (alpha * alpha);
         const int l = l0 + line;
         double e_acc = 0.0;
