@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py — REMD iterations/s on the BASELINE.json headline workload.
+
+A "step" is one replica-exchange iteration (mix -> propagate -> u_kl, the loop body of
+openmmtools/multistate/multistatesampler.py:766-804 with storage/analysis excluded) of
+ParallelTemperingSampler on testsystems.AlanineDipeptideExplicit: 24 replicas per GPU,
+temperatures logspace(300 K, 600 K), g-BAOAB "V R R O R R V", 2 fs, 500 MD steps per iteration,
+velocities reassigned each iteration, Philox seed 0xC0FFEE.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Weak scaling: every rank owns 24 replicas of one 24*N-replica ensemble; the only data-path
+collective is the RCCL all-gather of u_kl rows.  `value` counts 24-replica-iteration units:
+(R_total / 24) * iterations / s, so that N = 1 is exactly the BASELINE metric.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+REPLICAS_PER_GPU = 24
+MD_STEPS = 500
+SEED = 0xC0FFEE
+# algorithmic work of the direct-space nonbonded kernel: ~210 pairs/atom inside the
+# 1 nm cutoff x ~48 flop/pair (LJ + switch + erfc Coulomb)  =>  10 kflop / atom / force evaluation
+FLOP_PER_ATOM_NONBONDED = 1.0e4
+FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector peak = f32-input MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+def build_sampler(n_replicas, engine, comm, md_steps):
+    from openmmtools_amd import testsystems, states, mcmc, unit
+    from openmmtools_amd.multistate import ParallelTemperingSampler
+    ts = testsystems.AlanineDipeptideExplicit()
+    thermo = states.ThermodynamicState(ts.system, 300.0 * unit.kelvin)
+    sstate = states.SamplerState(ts.positions, box_vectors=ts.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=md_steps, reassign_velocities=True,
+                                              splitting='V R R O R R V')
+    sampler = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=10 ** 9, engine=engine, seed=SEED,
+                                       comm=comm)
+    sampler.create(thermo, [sstate], storage=None, min_temperature=300.0 * unit.kelvin,
+                   max_temperature=600.0 * unit.kelvin, n_temperatures=n_replicas)
+    return sampler, ts
+
+
+def cpu_baseline(md_steps_sample=8):
+    """The f64 oracle ("port") on the host: a bounded sample of the same workload (one replica, a few
+    g-BAOAB steps + one energy evaluation), extrapolated to 24 replicas x 500 steps per iteration."""
+    from openmmtools_amd import testsystems
+    from openmmtools_amd.system import system_to_desc
+    from oracle import md_oracle as mo
+    from oracle.forcefield import ForceFieldOracle
+    ts = testsystems.AlanineDipeptideExplicit()
+    desc = system_to_desc(ts.system)
+    ff = ForceFieldOracle(desc)
+    box = np.diag(ts.system.getDefaultPeriodicBoxVectors())
+    integ = mo.OracleLangevin(ff, 'V R R O R R V', 0.002, 1.0, md_steps_sample, SEED)
+    kT = mo.KB * 300.0
+    t0 = time.time()
+    v = integ.assign_velocities(ts.positions, kT, 0, 1)
+    x, v = integ.run(ts.positions, v, box, kT, 0, 1)
+    t_steps = time.time() - t0
+    t0 = time.time()
+    ff.potential(x, box)
+    t_energy = time.time() - t0
+    per_iter = REPLICAS_PER_GPU * (MD_STEPS * t_steps / md_steps_sample + t_energy)
+    return dict(value=1.0 / per_iter, unit='iterations/s', cores=1, kind='port',
+                sample='1 replica x %d g-BAOAB steps + 1 energy evaluation of AlanineDipeptideExplicit with the f64 '
+                       'torch/numpy oracle (%.1f s), extrapolated to 24 replicas x %d steps' %
+                       (md_steps_sample, t_steps + t_energy, MD_STEPS))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--md-steps', type=int, default=MD_STEPS, help='MD steps per iteration (500 = BASELINE)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                             '--master-addr 127.0.0.1 --master-port 29511 bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        from openmmtools_amd.multistate.comm import TorchDistributedComm
+        comm = TorchDistributedComm()
+
+    from openmmtools_amd._engine import HipEngine
+    stream = torch.cuda.current_stream().cuda_stream
+    engine = HipEngine(device=local_rank, stream=stream)
+    n_replicas = REPLICAS_PER_GPU * world
+    sampler, ts = build_sampler(n_replicas, engine, comm, args.md_steps)
+    n_atoms = ts.system.getNumParticles()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sampler.run(args.warmup)
+    engine.profile_reset()
+    engine.profile_enable(True)            # asynchronous HIP events around the dominant kernel class only
+    sync()
+    t0 = time.perf_counter()
+    sampler.run(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    engine.profile_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        it_per_s = args.steps / elapsed
+        value = it_per_s * (n_replicas / REPLICAS_PER_GPU)
+        n_launch, ms = engine.profile_get('nonbonded')
+        roof = None
+        if n_launch > 0:
+            flops = FLOP_PER_ATOM_NONBONDED * n_atoms * REPLICAS_PER_GPU
+            avg_ms = ms / n_launch
+            achieved = flops / (avg_ms * 1e-3) / 1e12
+            roof = dict(kernel='nonbonded_kernel', bound='mfma', achieved=achieved, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=achieved / FP32_PEAK_TFLOPS, traffic=None, launches=n_launch, avg_launch_ms=avg_ms,
+                        note='fp32 VALU kernel; peak = FP32 vector rate = f32-input MFMA rate (157.3 TFLOP/s); '
+                             'algorithmic work = 10 kflop/atom (SURVEY 8(d))')
+        out = dict(metric='REMD iterations/s (propagate+u_kl+mix), 24-replica AlanineDipeptideExplicit per GPU',
+                   value=value, unit='iterations/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='f32', data='synthetic',
+                   config=dict(workload='testsystems.AlanineDipeptideExplicit (2269 atoms, PME) parallel tempering, '
+                                        'logspace(300K,600K), g-BAOAB V R R O R R V 2 fs, %d MD steps/iteration, swap-all'
+                                        % args.md_steps,
+                               replicas_per_gpu=REPLICAS_PER_GPU, replicas_total=n_replicas, md_steps=args.md_steps,
+                               parallelism='replica-sharded x%d' % world, seed=SEED),
+                   timing=dict(sampler._timing_data), roofline=roof)
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out, default=float))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

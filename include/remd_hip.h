@@ -194,10 +194,13 @@ int  remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inv
    measured with hipEvents (ms)                                                           */
 int  remd_last_timing(remd_handle h, double* propagate_ms, double* energies_ms, double* mix_ms);
 
-/* dominant-kernel accounting for bench.py's roofline object: number of launches and
-   summed duration (ms, hipEvent-bracketed) of the named kernel class since the last reset.
-   Only collected when profiling is enabled (adds event overhead).                        */
+/* per-kernel-class accounting for bench.py's roofline object: HIP events are recorded on the
+   handle's stream around each launch (no synchronisation at launch time) and resolved when
+   queried.  on = 1: only the class set with remd_profile_filter (default "nonbonded");
+   on = 2: every class ("integrate_chain", "nonbonded", "pme_fft", "pme_spread", "pme_gather",
+   "bonded", "exceptions", "mix_swap_all", ...).                                           */
 int  remd_profile_enable(remd_handle h, int on);
+int  remd_profile_filter(remd_handle h, const char* kernel_class);
 int  remd_profile_get(remd_handle h, const char* kernel_class, int64_t* n_launches, double* total_ms);
 int  remd_profile_reset(remd_handle h);
 

@@ -43,7 +43,7 @@ EXPORTS = [
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
-    'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components',
+    'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
 ]
 
 _lib = None
@@ -88,6 +88,7 @@ def load_library(path=None):
     lib.remd_profile_enable.argtypes = [vp, C.c_int]
     lib.remd_profile_get.argtypes = [vp, C.c_char_p, c_int64_p, c_double_p]
     lib.remd_profile_reset.argtypes = [vp]
+    lib.remd_profile_filter.argtypes = [vp, C.c_char_p]
     for name in EXPORTS:
         if name not in ('remd_last_error',):
             getattr(lib, name).restype = C.c_int
@@ -299,8 +300,10 @@ class HipEngine:
         self.lib.remd_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))
         return dict(propagate_ms=a.value, energies_ms=b.value, mix_ms=c.value)
 
-    def profile_enable(self, on=True):
-        self.lib.remd_profile_enable(self.h, int(bool(on)))
+    def profile_enable(self, on=1, kernel_class=None):
+        if kernel_class is not None:
+            self.lib.remd_profile_filter(self.h, kernel_class.encode())
+        self.lib.remd_profile_enable(self.h, int(on))
 
     def profile_reset(self):
         self.lib.remd_profile_reset(self.h)

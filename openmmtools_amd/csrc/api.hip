@@ -434,11 +434,24 @@ int remd_last_timing(remd_handle h, double* p, double* e, double* m)
     return 0;
 }
 
-int remd_profile_enable(remd_handle h, int on) { if (!h) return -1; h->profiling = on != 0; return 0; }
-int remd_profile_reset(remd_handle h) { if (!h) return -1; h->prof.clear(); return 0; }
+static void resolve_profile(remd_ctx* h)
+{
+    for (auto& p : h->prof_pending) {
+        hipEventSynchronize(p.b);
+        float ms = 0; hipEventElapsedTime(&ms, p.a, p.b);
+        auto& e = h->prof[p.name]; e.n += 1; e.ms += ms;
+        hipEventDestroy(p.a); hipEventDestroy(p.b);
+    }
+    h->prof_pending.clear();
+}
+
+int remd_profile_enable(remd_handle h, int on) { if (!h) return -1; h->profiling = on < 0 ? 0 : (on > 2 ? 2 : on); return 0; }
+int remd_profile_filter(remd_handle h, const char* kernel_class) { if (!h || !kernel_class) return -1; h->prof_filter = kernel_class; return 0; }
+int remd_profile_reset(remd_handle h) { if (!h) return -1; resolve_profile(h); h->prof.clear(); return 0; }
 int remd_profile_get(remd_handle h, const char* name, int64_t* n, double* ms)
 {
     if (!h || !name) return -1;
+    resolve_profile(h);
     auto it = h->prof.find(name);
     if (n) *n = it == h->prof.end() ? 0 : it->second.n;
     if (ms) *ms = it == h->prof.end() ? 0.0 : it->second.ms;

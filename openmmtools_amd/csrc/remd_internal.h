@@ -103,7 +103,10 @@ struct remd_ctx {
     // ---- timing / profiling -------------------------------------------------------------
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double t_prop = 0, t_energy = 0, t_mix = 0;
-    bool profiling = false;
+    int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes
+    std::string prof_filter = "nonbonded";
+    struct pending_t { std::string name; hipEvent_t a, b; };
+    std::vector<pending_t> prof_pending;
     std::map<std::string, remd_profile_entry> prof;
 };
 
@@ -113,18 +116,19 @@ struct remd_ctx {
 void remd_set_global_error(const std::string& s);
 int remd_fail(remd_ctx* h, int code, const std::string& msg);
 
-// profiling wrapper: brackets a launch with events when profiling is on
+// profiling wrapper: brackets a launch with HIP events recorded on the handle's stream.  Nothing is
+// synchronised at launch time; the pairs are resolved in remd_profile_get().  Level 1 records only
+// the class named by prof_filter (bench.py: the dominant kernel), level 2 records every class.
 struct remd_prof_scope {
-    remd_ctx* h; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    remd_ctx* h; const char* name; hipEvent_t a = nullptr; bool on = false;
     remd_prof_scope(remd_ctx* h_, const char* n) : h(h_), name(n) {
-        if (h->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, h->stream); }
+        on = h->profiling == 2 || (h->profiling == 1 && h->prof_filter == n);
+        if (on) { hipEventCreate(&a); hipEventRecord(a, h->stream); }
     }
     ~remd_prof_scope() {
-        if (h->profiling) {
-            hipEventRecord(b, h->stream); hipEventSynchronize(b);
-            float ms = 0; hipEventElapsedTime(&ms, a, b);
-            auto& e = h->prof[name]; e.n += 1; e.ms += ms;
-            hipEventDestroy(a); hipEventDestroy(b);
+        if (on) {
+            hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, h->stream);
+            h->prof_pending.push_back({name, a, b});
         }
     }
 };
