@@ -109,7 +109,7 @@ __device__ __forceinline__ void settle_velocities(float imA, float imB, float im
 __device__ __forceinline__ void shake_positions(int n, const float* im, const float* d, float tol,
                                                 const float3* p0, float3* p1)
 {
-    for (int it = 0; it < 60; ++it) {
+    for (int it = 0; it < 24; ++it) {
         bool conv = true;
         for (int k = 1; k < n; ++k) {
             const float3 r0 = p0[k] - p0[0];
@@ -129,14 +129,15 @@ __device__ __forceinline__ void shake_positions(int n, const float* im, const fl
 
 __device__ __forceinline__ void shake_velocities(int n, const float* im, float tol, const float3* p, float3* v)
 {
-    for (int it = 0; it < 60; ++it) {
+    // converged when the bond-length rate is below tol relative to |r| |v| (fp32 noise floor ~1e-7 |r||v|)
+    for (int it = 0; it < 16; ++it) {
         bool conv = true;
         for (int k = 1; k < n; ++k) {
             const float3 r = p[k] - p[0];
+            const float3 dv = v[k] - v[0];
             const float r2 = dot3(r, r);
-            const float rv = dot3(r, v[k] - v[0]);
-            // converged when the bond-length rate is below tol (1/ps, relative)
-            if (fabsf(rv) > tol * r2) {
+            const float rv = dot3(r, dv);
+            if (rv * rv > tol * tol * r2 * (dot3(v[k], v[k]) + dot3(v[0], v[0]) + 1e-12f)) {
                 conv = false;
                 const float lam = rv / (r2 * (im[0] + im[k]));
                 v[0] = v[0] + r * (lam * im[0]);
@@ -168,7 +169,7 @@ __device__ __forceinline__ void constrain_v(const unit_regs& u, const settle_con
     }
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64)
 void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict__ unit_atoms,
                             const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist,
                             settle_const sc, float tol,
@@ -180,12 +181,13 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     float3 mom = f3(0, 0, 0);
-    if (uidx < n_units) {
+    const bool live = uidx < n_units && unit_atoms[uidx < n_units ? uidx : 0].x >= 0;   // padding units do nothing
+    if (live) {
         unit_regs u;
         const int4 a4 = unit_atoms[uidx];
         u.idx[0] = a4.x; u.idx[1] = a4.y; u.idx[2] = a4.z; u.idx[3] = a4.w;
         u.type = unit_type[uidx];
-        u.n = (a4.y < 0) ? 1 : (a4.z < 0) ? 2 : (a4.w < 0) ? 3 : 4;
+        u.n = (a4.x < 0) ? 0 : (a4.y < 0) ? 1 : (a4.z < 0) ? 2 : (a4.w < 0) ? 3 : 4;   // n = 0: padding unit
         float4* P = pos + (size_t)r * Npad;
         float4* V = vel + (size_t)r * Npad;
         const long long* F = force + (size_t)r * 3 * Npad;
@@ -212,7 +214,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                 constrain_v(u, sc, tol, u.v, u.x);
             } else if (tok == 'R') {
                 if (u.type == UNIT_FREE) {
-                    u.x[0] = u.x[0] + u.v[0] * prog.hR;
+                    if (u.n > 0) u.x[0] = u.x[0] + u.v[0] * prog.hR;
                 } else {
                     // relative coordinates (origin = old position of atom 0) keep fp32 precision
                     float3 p0[4], p1[4], q[4];
@@ -285,7 +287,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
 }
 
 // Maxwell-Boltzmann velocities (mcmc.py:710-711): v = sqrt(kT/m) xi, then velocity constraints.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64)
 void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
                               const unsigned char* __restrict__ unit_type, settle_const sc, float tol,
                               int Npad, const float4* __restrict__ pos, float4* __restrict__ vel,
@@ -297,9 +299,10 @@ void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
     if (uidx >= n_units) return;
     unit_regs u;
     const int4 a4 = unit_atoms[uidx];
+    if (a4.x < 0) return;
     u.idx[0] = a4.x; u.idx[1] = a4.y; u.idx[2] = a4.z; u.idx[3] = a4.w;
     u.type = unit_type[uidx];
-    u.n = (a4.y < 0) ? 1 : (a4.z < 0) ? 2 : (a4.w < 0) ? 3 : 4;
+    u.n = (a4.x < 0) ? 0 : (a4.y < 0) ? 1 : (a4.z < 0) ? 2 : (a4.w < 0) ? 3 : 4;
     const float4* P = pos + (size_t)r * Npad;
     float4* V = vel + (size_t)r * Npad;
     const float kT = (float)(1.0 / beta[labels[r_begin + r]]);
@@ -374,12 +377,18 @@ int remd_build_constraints(remd_ctx* h, const remd_system_desc* d)
         dist.push_back(0); dist.push_back(0); dist.push_back(0);
         for (int k = 0; k < 3; ++k) { if (a[k] < 0 || a[k] >= N || used[a[k]]) return remd_fail(h, -3, "bad SETTLE triple"); used[a[k]] = 1; }
     }
+    while (atoms.size() % 64) { atoms.push_back(make_int4(-1, -1, -1, -1)); type.push_back(UNIT_SETTLE); dist.push_back(0); dist.push_back(0); dist.push_back(0); }
     for (int s = 0; s < d->n_shake; ++s) {
         const int* a = d->shake_atoms + 4 * s;
         atoms.push_back(make_int4(a[0], a[1], a[2], a[3])); type.push_back(UNIT_SHAKE);
         for (int k = 0; k < 3; ++k) dist.push_back((float)d->shake_dist[3 * s + k]);
         for (int k = 0; k < 4; ++k) if (a[k] >= 0) { if (a[k] >= N || used[a[k]]) return remd_fail(h, -3, "bad SHAKE cluster"); used[a[k]] = 1; }
     }
+    auto pad64 = [&](unsigned char ty) {
+        // units of one kind fill whole wavefronts: no wave mixes SETTLE, SHAKE and free-atom code paths
+        while (atoms.size() % 64) { atoms.push_back(make_int4(-1, -1, -1, -1)); type.push_back(ty); dist.push_back(0); dist.push_back(0); dist.push_back(0); }
+    };
+    pad64(UNIT_SHAKE);
     for (int i = 0; i < N; ++i) if (!used[i]) {
         atoms.push_back(make_int4(i, -1, -1, -1)); type.push_back(UNIT_FREE);
         dist.push_back(0); dist.push_back(0); dist.push_back(0);
@@ -442,8 +451,8 @@ int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& 
 static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog)
 {
     remd_prof_scope ps(h, "integrate_chain");
-    dim3 grid((ut.n_units + 255) / 256, h->R);
-    hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
+    dim3 grid((ut.n_units + 63) / 64, h->R);
+    hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(64), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0));
@@ -506,8 +515,8 @@ int remd_assign_velocities(remd_ctx* h, int64_t iteration)
 {
     const unit_tables& ut = g_units[h];
     remd_prof_scope ps(h, "assign_velocities");
-    dim3 grid((ut.n_units + 255) / 256, h->R);
-    hipLaunchKernelGGL(assign_velocities_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc,
+    dim3 grid((ut.n_units + 63) / 64, h->R);
+    hipLaunchKernelGGL(assign_velocities_kernel, grid, dim3(64), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc,
                        (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_invmass, h->d_labels,
                        h->d_beta, h->r_begin, h->seed, iteration);
     REMD_CHECK(h, hipGetLastError());

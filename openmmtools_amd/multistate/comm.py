@@ -64,8 +64,14 @@ class TorchDistributedComm:
         if len(set(self._counts)) == 1:
             self.dist.all_gather_into_tensor(out, rows.contiguous(), group=self.group)
         else:
-            chunks = [out[b:b + c] for b, c in zip(self._begins, self._counts)]
-            self.dist.all_gather(chunks, rows.contiguous(), group=self.group)
+            # ragged blocks: pad every rank's block to the largest one, gather, then compact
+            cmax = max(self._counts)
+            send = torch.zeros((cmax, K), dtype=rows.dtype, device=rows.device)
+            send[:rows.shape[0]] = rows
+            recv = torch.empty((self.world_size * cmax, K), dtype=rows.dtype, device=rows.device)
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+            for r, (b, c) in enumerate(zip(self._begins, self._counts)):
+                out[b:b + c] = recv[r * cmax:r * cmax + c]
         return out
 
     def broadcast_labels(self, labels):

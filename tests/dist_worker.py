@@ -1,0 +1,55 @@
+"""Worker for tests/test_distributed_cpu.py: runs the sharded sampler under torch.distributed (gloo)."""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def build(sampler_kind, engine, comm, n_iter):
+    from openmmtools_amd import testsystems, states, mcmc, unit
+    from openmmtools_amd.multistate import ParallelTemperingSampler, SAMSSampler
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0)
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=25, reassign_velocities=True, splitting='V R O R V')
+    if sampler_kind == 'pt':
+        s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm)
+        s.create(ts, [ss], min_temperature=300.0, max_temperature=600.0, n_temperatures=5)
+    else:
+        sts = [states.ThermodynamicState(ho.system, T) for T in np.linspace(300.0, 500.0, 6)]
+        s = SAMSSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm,
+                        flatness_criteria='minimum-visits')
+        s.create(sts, [ss] * 4)
+    s.verify_labels = True
+    return s
+
+
+def run(sampler_kind, comm, n_iter=6):
+    from oracle_engine import OracleEngine
+    s = build(sampler_kind, OracleEngine(), comm, n_iter)
+    history = []
+    for _ in range(n_iter):
+        s.run(1)
+        history.append((s.replica_thermodynamic_states.copy(), s.energy_thermodynamic_states.copy(),
+                        s._n_accepted_matrix.copy(), s._n_proposed_matrix.copy()))
+    x = np.stack([st.positions for st in s.sampler_states])
+    return history, x, (s._r_begin, s._r_count)
+
+
+if __name__ == '__main__':
+    import torch.distributed as dist
+    from openmmtools_amd.multistate.comm import TorchDistributedComm
+    kind, out = sys.argv[1], sys.argv[2]
+    dist.init_process_group('gloo')
+    comm = TorchDistributedComm()
+    history, x, (b, c) = run(kind, comm)
+    np.savez(os.path.join(out, 'rank%d.npz' % comm.rank),
+             labels=np.stack([h[0] for h in history]), ukl=np.stack([h[1] for h in history]),
+             nacc=np.stack([h[2] for h in history]), nprop=np.stack([h[3] for h in history]),
+             x_local=x[b:b + c], r_begin=b, r_count=c)
+    dist.barrier()
+    dist.destroy_process_group()
