@@ -1,12 +1,13 @@
 // Smooth particle-mesh Ewald reciprocal space (Essmann et al. 1995), batched over replicas (gfx950).
 //
-// Pipeline per force evaluation, all replicas at once:
-//   memset(grid) -> spread (order-5 B-splines, 64-bit fixed-point atomics => reproducible charges)
-//   -> FFT z (reads the fixed-point mesh, writes complex f32 in place) -> FFT y
-//   -> fused x pass: forward FFT, multiply by the influence function (+ energy), inverse FFT
-//   -> inverse FFT y -> inverse FFT z -> gather forces (125 mesh points per atom).
-// The 1-D FFTs are in-tree mixed-radix (2,3,4,5) Stockham transforms in LDS; each workgroup
-// transforms FFT_B = 8 adjacent lines so that strided passes still move 64-byte segments.
+// Pipeline per force evaluation, all replicas at once (3 FFT launches):
+//   memset(mesh) -> spread (order-5 B-splines, 32-bit fixed-point atomics => reproducible charge mesh)
+//   -> z forward: 8 real lines per workgroup -> half spectrum, stored kz-major as planes spec[kz][x][y]
+//   -> xy fused: one (kz, replica) plane resident in LDS (2 x nx x ny x 8 B <= 160 KiB on gfx950):
+//      forward y, forward x, influence function (+ energy), inverse x, inverse y — one read + one write per point
+//   -> z inverse: Hermitian completion in LDS, real potential mesh -> gather forces (125 points per atom).
+// Meshes whose plane exceeds the LDS fall back to separate strided passes.  The 1-D FFTs are in-tree
+// mixed-radix (2,3,4,5) Stockham transforms.
 //
 // Reference semantics: OpenMM NonbondedForce PME as configured by testsystems.py:3504-3517
 // (ewaldErrorTolerance 1e-5, cutoff 1 nm).  f64 restatement: oracle/md_oracle.py (pme_reciprocal),
@@ -14,6 +15,7 @@
 #include "remd_internal.h"
 #include <cmath>
 #include <vector>
+#include <type_traits>
 
 #define PME_ORDER 5
 #define FFT_B 8
@@ -24,7 +26,10 @@ struct pme_state {
     int n[3] = {0, 0, 0};
     int R = 0;
     size_t npts = 0;
-    float2* d_grid = nullptr;          // [R][nx][ny][nz] complex f32 (aliased as int64 fixed point during spreading)
+    int* d_mesh = nullptr;             // [R][nx][ny][nz] 32-bit fixed-point charge mesh; reused as the float potential mesh
+    float2* d_grid = nullptr;          // [R][nz/2+1][nx][ny] half spectrum, kz-major (or the full complex grid of the test hook)
+    int nzc = 0; size_t nspec = 0; size_t xy_lds = 0; bool xy_fused = false;
+    int* d_col_count = nullptr; int* d_col_start = nullptr; int* d_cursor = nullptr; int* d_atom_col = nullptr; int* d_col_atoms = nullptr;
     float2* d_tw[3] = {nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i k / n)
     float* d_bmod[3] = {nullptr, nullptr, nullptr};  // |b(m)|^-2 ... stored as B-spline moduli squared inverse
     int nrad[3] = {0, 0, 0}; int radix[3][8];
@@ -37,7 +42,10 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-struct fft_plan { int n; int nrad; int radix[8]; };
+// mnb[s] / mNs[s]: ceil(2^32 / d) for d = n/radix[s] and d = Ns(s): exact unsigned division of indices < 2^16
+struct fft_plan { int n; int nrad; int radix[8]; unsigned mnb[8]; unsigned mNs[8]; };
+__host__ __device__ __forceinline__ unsigned fft_magic(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ int fft_div(int x, unsigned magic, int d) { return d == 1 ? x : (int)__umulhi((unsigned)x, magic); }
 
 // butterflies; SIGN = -1 forward, +1 inverse
 template <int SIGN>
@@ -76,141 +84,54 @@ __device__ __forceinline__ void bfly5(float2* v)
     v[2] = make_float2(p2.x - q2.y, p2.y + q2.x); v[3] = make_float2(p2.x + q2.y, p2.y - q2.x);
 }
 
-// Stockham mixed-radix FFT of FFT_B lines of length n held in LDS (layout [line][n]).
-// bufA holds the input; the result ends in the returned buffer.  tw[k] = exp(-2 pi i k / n).
+// ---- generic strided-line Stockham FFT in LDS ---------------------------------------------------------
+// nlines lines of length n; element e of line l sits at buf[l*ls + e*es].  Consecutive threads take the
+// unit-stride index (lines when ls == 1, butterflies when es == 1) so LDS accesses stay conflict-light.
 template <int SIGN>
-__device__ float2* fft_lds(const fft_plan& pl, float2* bufA, float2* bufB, const float2* __restrict__ tw, int line, int t)
+__device__ float2* fft_lines_lds(const fft_plan& pl, float2* src, float2* dst, int nlines, int ls, int es,
+                                 const float2* __restrict__ tw, int tid, int nthreads)
 {
     const int n = pl.n;
-    float2* src = bufA + line * n;
-    float2* dst = bufB + line * n;
+    const unsigned mlines = fft_magic((unsigned)nlines);
     int Ns = 1;
     for (int s = 0; s < pl.nrad; ++s) {
         const int Rx = pl.radix[s];
         const int nb = n / Rx;
-        for (int j = t; j < nb; j += FFT_T) {
-            const int k = j % Ns;
-            const int tstep = k * (n / (Ns * Rx));            // twiddle index increment per r
+        const int total = nlines * nb;
+        const int tstride = n / (Ns * Rx);
+        const unsigned mnb = pl.mnb[s], mNs = pl.mNs[s];
+        for (int idx = tid; idx < total; idx += nthreads) {
+            int l, j;
+            if (ls == 1) { j = fft_div(idx, mlines, nlines); l = idx - j * nlines; }
+            else { l = fft_div(idx, mnb, nb); j = idx - l * nb; }
+            const int jq = fft_div(j, mNs, Ns);
+            const int k = j - jq * Ns;
+            const int tstep = k * tstride;                  // tstep * r < n for every r < Rx: no modulo needed
+            const float2* S = src + l * ls;
             float2 v[5];
 #pragma unroll
             for (int r = 0; r < 5; ++r) if (r < Rx) {
-                float2 w = tw[(tstep * r) % n];
-                if (SIGN > 0) w.y = -w.y;
-                v[r] = cmul(src[j + r * nb], w);
+                v[r] = S[(j + r * nb) * es];
+                if (s > 0 && r > 0) {                       // first stage (Ns = 1) and r = 0: twiddle = 1
+                    float2 w = tw[tstep * r];
+                    if (SIGN > 0) w.y = -w.y;
+                    v[r] = cmul(v[r], w);
+                }
             }
             if (Rx == 2) bfly2<SIGN>(v); else if (Rx == 3) bfly3<SIGN>(v); else if (Rx == 4) bfly4<SIGN>(v); else bfly5<SIGN>(v);
-            const int d0 = (j / Ns) * Ns * Rx + k;
+            const int d0 = jq * Ns * Rx + k;
+            float2* D = dst + l * ls;
 #pragma unroll
-            for (int r = 0; r < 5; ++r) if (r < Rx) dst[d0 + r * Ns] = v[r];
+            for (int r = 0; r < 5; ++r) if (r < Rx) D[(d0 + r * Ns) * es] = v[r];
         }
         __syncthreads();
         float2* tmp = src; src = dst; dst = tmp;
         Ns *= Rx;
     }
-    return src - line * n;
+    return src;
 }
 
-// MODE 0: plain pass.  MODE 1: first forward pass, input is the int64 fixed-point mesh.
-// MODE 2: fused x pass: forward, influence function (+ energy), inverse.
-// line addressing: element e of line l is at  base(l) + e * es, lines l0..l0+FFT_B-1 are adjacent (stride ls).
-template <int SIGN, int MODE>
-__global__ __launch_bounds__(FFT_B * FFT_T)
-void fft_pass_kernel(fft_plan pl, float2* __restrict__ grid, size_t rep_stride, int es, int lines_per_rep,
-                     int line_div, size_t line_hi_stride, int contiguous, const float2* __restrict__ tw,
-                     // MODE 2 extras
-                     const float* __restrict__ bm0, const float* __restrict__ bm1, const float* __restrict__ bm2,
-                     int n1, int n2, const float* __restrict__ box, float alpha, int with_energy,
-                     double* __restrict__ energy, int n_eblk)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n = pl.n;
-    float2* bufA = reinterpret_cast<float2*>(smem);
-    float2* bufB = bufA + FFT_B * n;
-    const int r = blockIdx.y;
-    const int l0 = blockIdx.x * FFT_B;
-    float2* G = grid + (size_t)r * rep_stride;
-    const int tid = threadIdx.x;
-    // line l -> base offset
-    auto base = [&](int l) -> size_t { return (size_t)(l / line_div) * line_hi_stride + (size_t)(l % line_div) * (contiguous ? (size_t)n : 1); };
-    // load
-    if (contiguous) {
-        for (int idx = tid; idx < FFT_B * n; idx += FFT_B * FFT_T) {
-            const int b = idx / n, e = idx % n;
-            const int l = l0 + b;
-            float2 v = make_float2(0.f, 0.f);
-            if (l < lines_per_rep) {
-                if (MODE == 1) {
-                    const long long q = reinterpret_cast<const long long*>(G)[base(l) + e];
-                    v.x = (float)((double)q * (1.0 / PME_FIXED_SCALE));
-                } else v = G[base(l) + e];
-            }
-            bufA[b * n + e] = v;
-        }
-    } else {
-        for (int idx = tid; idx < FFT_B * n; idx += FFT_B * FFT_T) {
-            const int e = idx / FFT_B, b = idx % FFT_B;
-            const int l = l0 + b;
-            bufA[b * n + e] = (l < lines_per_rep) ? G[base(l) + (size_t)e * es] : make_float2(0.f, 0.f);
-        }
-    }
-    __syncthreads();
-    const int line = tid / FFT_T, t = tid % FFT_T;
-    float2* res = fft_lds<SIGN>(pl, bufA, bufB, tw, line, t);
-    if (MODE == 2) {
-        // lines of the x pass are indexed l = k1 * n2 + k2 (k1 along y, k2 along z); element e = k0 along x
-        float2* other = (res == bufA) ? bufB : bufA;
-        const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-        const double V = (double)Lx * Ly * Lz;
-        const float pref = (float)(1.0 / (M_PI * V));      // charges already carry sqrt(k_e)
-        const float fac = (float)(M_PI * M_PI) / (alpha * alpha);
-        const int l = l0 + line;
-        double e_acc = 0.0;
-        if (l < lines_per_rep) {
-            const int k1 = l / n2, k2 = l % n2;
-            const int m1 = (k1 <= n1 / 2) ? k1 : k1 - n1, m2 = (k2 <= n2 / 2) ? k2 : k2 - n2;
-            const float my = m1 / Ly, mz = m2 / Lz;
-            for (int e = t; e < n; e += FFT_T) {
-                const int m0 = (e <= n / 2) ? e : e - n;
-                const float mx = m0 / Lx;
-                const float msq = mx * mx + my * my + mz * mz;
-                float g = 0.f;
-                if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bm0[e] * bm1[k1] * bm2[k2]);
-                const float2 s = res[line * n + e];
-                if (with_energy) e_acc += 0.5 * (double)g * ((double)s.x * s.x + (double)s.y * s.y);
-                res[line * n + e] = make_float2(s.x * g, s.y * g);
-            }
-        }
-        __syncthreads();
-        if (with_energy) {
-            // deterministic block reduction: wave shuffle then fixed-order sum over waves
-            double* s_e = reinterpret_cast<double*>(other);   // scratch (the inverse pass overwrites it later)
-            for (int off = 32; off > 0; off >>= 1) e_acc += __shfl_xor(e_acc, off);
-            if ((tid & 63) == 0) s_e[tid >> 6] = e_acc;
-            __syncthreads();
-            if (tid == 0) {
-                double tot = 0.0;
-                for (int w = 0; w < (FFT_B * FFT_T) / 64; ++w) tot += s_e[w];
-                energy[(size_t)r * n_eblk + blockIdx.x] = tot;
-            }
-            __syncthreads();
-        }
-        res = fft_lds<+1>(pl, res, other, tw, line, t);
-    }
-    // store
-    if (contiguous) {
-        for (int idx = tid; idx < FFT_B * n; idx += FFT_B * FFT_T) {
-            const int b = idx / n, e = idx % n;
-            const int l = l0 + b;
-            if (l < lines_per_rep) G[base(l) + e] = res[b * n + e];
-        }
-    } else {
-        for (int idx = tid; idx < FFT_B * n; idx += FFT_B * FFT_T) {
-            const int e = idx / FFT_B, b = idx % FFT_B;
-            const int l = l0 + b;
-            if (l < lines_per_rep) G[base(l) + (size_t)e * es] = res[b * n + e];
-        }
-    }
-}
+#define PME_MESH_SCALE 16777216.0f     // 2^24: 32-bit fixed-point charge mesh, |sum| < 128
 
 // order-5 cardinal B-spline weights and derivatives: w[j] = M5(f + j), d[j] = M5'(f + j), j = 0..4,
 // belonging to mesh index k0 - j.
@@ -237,50 +158,287 @@ __device__ __forceinline__ void bspline5(float f, float* w, float* d)
     }
 }
 
-__global__ __launch_bounds__(128)
-void pme_spread_kernel(int N, int Npad, int nx, int ny, int nz, size_t rep_stride, const float4* __restrict__ pos,
-                       const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                       long long* __restrict__ mesh)
+// ---- atom binning by mesh column ------------------------------------------------------------------------
+// column of atom i = (kx, ky) = integer part of its scaled fractional x, y coordinate.  The fused spread + z-FFT
+// kernel walks, for its 8 lines, the atoms of the 5 x 12 columns whose order-5 stencils can reach them.
+__device__ __forceinline__ void pme_scaled(const float4 x, const float* __restrict__ box4, int nx, int ny, int nz,
+                                           float& ux, float& uy, float& uz, int& kx, int& ky, int& kz)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (i >= N) return;
-    const float4 pr = param[i];
-    float q = pr.x;                                          // charge * sqrt(k_e)
-    if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
-    if (q == 0.f) return;
-    const float4 x = pos[(size_t)r * Npad + i];
-    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-    float fx = x.x / Lx, fy = x.y / Ly, fz = x.z / Lz;
+    float fx = x.x / box4[0], fy = x.y / box4[1], fz = x.z / box4[2];
     fx -= floorf(fx); fy -= floorf(fy); fz -= floorf(fz);
-    float ux = fx * nx, uy = fy * ny, uz = fz * nz;
-    int kx = (int)ux, ky = (int)uy, kz = (int)uz;
-    float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
-    bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
-    if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
-    unsigned long long* M = reinterpret_cast<unsigned long long*>(mesh + (size_t)r * rep_stride);
-#pragma unroll
+    ux = fx * nx; uy = fy * ny; uz = fz * nz;
+    kx = (int)ux; ky = (int)uy; kz = (int)uz;
+}
+
+__global__ __launch_bounds__(256)
+void pme_bin_count_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __restrict__ pos,
+                          const float* __restrict__ box, int* __restrict__ col_count /*[R][nx*ny+1]*/, int* __restrict__ atom_col)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (i >= N) return;
+    float ux, uy, uz; int kx, ky, kz;
+    pme_scaled(pos[(size_t)r * Npad + i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+    if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny;
+    const int c = kx * ny + ky;
+    atom_col[(size_t)r * Npad + i] = c;
+    atomicAdd(&col_count[(size_t)r * (nx * ny + 1) + c], 1);
+}
+
+// exclusive scan of the column counts of one replica (one workgroup per replica); also resets the fill cursors
+__global__ __launch_bounds__(1024)
+void pme_bin_scan_kernel(int ncol, int* __restrict__ col_count, int* __restrict__ col_start, int* __restrict__ cursor)
+{
+    __shared__ int s_part[1024];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    int* cnt = col_count + (size_t)r * (ncol + 1);
+    int* st = col_start + (size_t)r * (ncol + 1);
+    int* cur = cursor + (size_t)r * (ncol + 1);
+    const int per = (ncol + 1023) / 1024;
+    const int b = tid * per, e = min(ncol, b + per);
+    int sum = 0;
+    for (int c = b; c < e; ++c) sum += cnt[c];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan (integers: order-independent)
+        int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = (tid > 0) ? s_part[tid - 1] : 0;
+    for (int c = b; c < e; ++c) { st[c] = run; cur[c] = run; run += cnt[c]; cnt[c] = 0; }
+    if (tid == 1023) st[ncol] = s_part[1023];
+}
+
+__global__ __launch_bounds__(256)
+void pme_bin_fill_kernel(int N, int Npad, int ncol, const int* __restrict__ atom_col, int* __restrict__ cursor,
+                         int* __restrict__ col_atoms)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (i >= N) return;
+    const int c = atom_col[(size_t)r * Npad + i];
+    const int slot = atomicAdd(&cursor[(size_t)r * (ncol + 1) + c], 1);
+    col_atoms[(size_t)r * Npad + slot] = i;             // order inside a column is irrelevant: integer accumulation
+}
+
+// fused spreading + forward z FFT.  Workgroup = FFT_B lines (x, y0..y0+7).  Charges are accumulated in LDS as
+// 32-bit fixed point (order-independent => bit-reproducible), converted to complex f32 and transformed.
+__global__ __launch_bounds__(256)
+void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const float4* __restrict__ pos,
+                            const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
+                            const int* __restrict__ col_start, const int* __restrict__ col_atoms,
+                            float2* __restrict__ spec, const float2* tw)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nz = pl.n, nzc = nz / 2 + 1;
+    float2* bufA = reinterpret_cast<float2*>(smem);
+    float2* bufB = bufA + nl * nz;
+    int* acc = reinterpret_cast<int*>(bufB);            // nl * nz ints, reuses the second FFT buffer
+    float2* s_tw = bufB + nl * nz;
+    for (int idx = threadIdx.x; idx < nz; idx += 256) s_tw[idx] = tw[idx];
+    tw = s_tw;
+    const int r = blockIdx.y, tid = threadIdx.x;
+    const int l0 = blockIdx.x * nl;
+    const int x = l0 / ny, y0 = l0 % ny;
+    const int ncol = nx * ny;
+    for (int idx = tid; idx < nl * nz; idx += 256) acc[idx] = 0;
+    __syncthreads();
+    const int* cs = col_start + (size_t)r * (ncol + 1);
+    const int* ca = col_atoms + (size_t)r * Npad;
+    const float4* P = pos + (size_t)r * Npad;
+    // candidate columns: kx in {x .. x+4} (stencil index a = kx - x), ky in [y0, y0 + nl + 3]
     for (int a = 0; a < 5; ++a) {
-        int ix = kx - a; if (ix < 0) ix += nx;
-        const float qa = q * wx[a];
+        int kxc = x + a; if (kxc >= nx) kxc -= nx;
+        for (int seg = 0; seg < 2; ++seg) {
+            // ky range [y0, y0+nl+4) split at the periodic wrap
+            int kb = y0, ke = y0 + nl + 4;
+            if (seg == 0) ke = min(ke, ny); else { if (ke <= ny) break; kb = 0; ke -= ny; }
+            const int abeg = cs[kxc * ny + kb], aend = cs[kxc * ny + ke];
+            for (int t = abeg + tid; t < aend; t += 256) {
+                const int i = ca[t];
+                const float4 pr = param[i];
+                float q = pr.x;
+                if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
+                if (q == 0.f) continue;
+                float ux, uy, uz; int kx, ky, kz;
+                pme_scaled(P[i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+                float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
+                bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
+                if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+                float wa = 0.f;
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            int iy = ky - b; if (iy < 0) iy += ny;
-            const float qab = qa * wy[b];
-            const size_t row = ((size_t)ix * ny + iy) * nz;
+                for (int k = 0; k < 5; ++k) if (k == a) wa = wx[k];
+                const float qa = q * wa * PME_MESH_SCALE;
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                int iz = kz - c; if (iz < 0) iz += nz;
-                atomicAdd(&M[row + iz], (unsigned long long)(long long)((double)(qab * wz[c]) * PME_FIXED_SCALE));
+                for (int b = 0; b < 5; ++b) {
+                    int iy = ky - b; if (iy < 0) iy += ny;
+                    const int lb = iy - y0;                      // line inside this workgroup?
+                    if (lb < 0 || lb >= nl) continue;
+                    const float qab = qa * wy[b];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        int iz = kz - c; if (iz < 0) iz += nz;
+                        atomicAdd(&acc[lb * nz + iz], __float2int_rn(qab * wz[c]));
+                    }
+                }
             }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nl * nz; idx += 256)
+        bufA[idx] = make_float2((float)acc[idx] * (1.0f / PME_MESH_SCALE), 0.f);
+    __syncthreads();
+    float2* res = fft_lines_lds<-1>(pl, bufA, bufB, nl, nz, 1, tw, tid, 256);
+    float2* S = spec + (size_t)r * nzc * nx * ny;
+    for (int idx = tid; idx < nl * nzc; idx += 256) {
+        const int kz = idx / nl, b = idx % nl;
+        S[((size_t)kz * nx + x) * ny + y0 + b] = res[b * nz + kz];
+    }
+}
+
+// inverse z: half spectrum -> FFT_B real lines (Hermitian completion in LDS), written as float mesh[x][y][z]
+__global__ __launch_bounds__(256)
+void pme_zinv_kernel(fft_plan pl, int nl, int nx, int ny, const float2* __restrict__ spec, float* __restrict__ mesh,
+                     const float2* tw)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nz = pl.n, nzc = nz / 2 + 1;
+    float2* bufA = reinterpret_cast<float2*>(smem);
+    float2* bufB = bufA + nl * nz;
+    float2* s_tw = bufB + nl * nz;
+    for (int idx = threadIdx.x; idx < nz; idx += 256) s_tw[idx] = tw[idx];
+    tw = s_tw;
+    const int r = blockIdx.y, tid = threadIdx.x;
+    const int l0 = blockIdx.x * nl;
+    const int x = l0 / ny, y0 = l0 % ny;
+    const float2* S = spec + (size_t)r * nzc * nx * ny;
+    for (int idx = tid; idx < nl * nzc; idx += 256) {
+        const int kz = idx / nl, b = idx % nl;
+        const float2 v = S[((size_t)kz * nx + x) * ny + y0 + b];
+        bufA[b * nz + kz] = v;
+        if (kz > 0 && kz < nz - kz) bufA[b * nz + nz - kz] = make_float2(v.x, -v.y);
+    }
+    __syncthreads();
+    float2* res = fft_lines_lds<+1>(pl, bufA, bufB, nl, nz, 1, tw, tid, 256);
+    float* M = mesh + (size_t)r * nx * ny * nz + (size_t)l0 * nz;
+    for (int idx = tid; idx < nl * nz; idx += 256) M[idx] = res[idx].x;
+}
+
+// one (kz, replica) plane resident in LDS: forward y, forward x, influence function (+ energy), inverse x, inverse y
+#define XY_THREADS 1024
+__global__ __launch_bounds__(XY_THREADS)
+void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict__ spec,
+                         const float2* twx, const float2* twy,
+                         const float* __restrict__ bmx, const float* __restrict__ bmy, const float* __restrict__ bmz,
+                         const float* __restrict__ box, float alpha, int with_energy, double* __restrict__ energy, int n_eblk)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nx = plx.n, ny = ply.n, nzc = nz / 2 + 1;
+    const int np = nx * ny;
+    float2* bufA = reinterpret_cast<float2*>(smem);
+    float2* bufB = bufA + np;
+    float2* s_twx = bufB + np;                           // twiddle tables staged in LDS
+    float2* s_twy = s_twx + nx;
+    const int kz = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    float2* P = spec + ((size_t)r * nzc + kz) * np;
+    for (int idx = tid; idx < np; idx += XY_THREADS) bufA[idx] = P[idx];
+    for (int idx = tid; idx < nx; idx += XY_THREADS) s_twx[idx] = twx[idx];
+    for (int idx = tid; idx < ny; idx += XY_THREADS) s_twy[idx] = twy[idx];
+    twx = s_twx; twy = s_twy;
+    __syncthreads();
+    float2* res = fft_lines_lds<-1>(ply, bufA, bufB, nx, ny, 1, twy, tid, XY_THREADS);          // along y
+    float2* oth = (res == bufA) ? bufB : bufA;
+    res = fft_lines_lds<-1>(plx, res, oth, ny, 1, ny, twx, tid, XY_THREADS);                    // along x
+    oth = (res == bufA) ? bufB : bufA;
+    {
+        const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+        const double V = (double)Lx * Ly * Lz;
+        const float pref = (float)(1.0 / (M_PI * V));               // charges already carry sqrt(k_e)
+        const float fac = (float)(M_PI * M_PI) / (alpha * alpha);
+        const float mz = kz / Lz;                                   // kz <= nz/2
+        const float bz = bmz[kz];
+        const float wz = (kz == 0 || 2 * kz == nz) ? 1.f : 2.f;     // Hermitian half: weight of the mirrored plane
+        double e_acc = 0.0;
+        for (int idx = tid; idx < np; idx += XY_THREADS) {
+            const int kx = idx / ny, ky = idx - kx * ny;
+            const int m0 = (kx <= nx / 2) ? kx : kx - nx, m1 = (ky <= ny / 2) ? ky : ky - ny;
+            const float mx = m0 / Lx, my = m1 / Ly;
+            const float msq = mx * mx + my * my + mz * mz;
+            float g = 0.f;
+            if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
+            const float2 sv = res[idx];
+            if (with_energy) e_acc += 0.5 * (double)(wz * g) * ((double)sv.x * sv.x + (double)sv.y * sv.y);
+            res[idx] = make_float2(sv.x * g, sv.y * g);
+        }
+        __syncthreads();
+        if (with_energy) {
+            double* s_e = reinterpret_cast<double*>(oth);
+            for (int off = 32; off > 0; off >>= 1) e_acc += __shfl_xor(e_acc, off);
+            if ((tid & 63) == 0) s_e[tid >> 6] = e_acc;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < XY_THREADS / 64; ++w) tot += s_e[w];
+                energy[(size_t)r * n_eblk + kz] = tot;
+            }
+            __syncthreads();
+        }
+    }
+    res = fft_lines_lds<+1>(plx, res, oth, ny, 1, ny, twx, tid, XY_THREADS);
+    oth = (res == bufA) ? bufB : bufA;
+    res = fft_lines_lds<+1>(ply, res, oth, nx, ny, 1, twy, tid, XY_THREADS);
+    for (int idx = tid; idx < np; idx += XY_THREADS) P[idx] = res[idx];
+}
+
+// MODE 0: plain pass.  (kept for the 3-D FFT test hook and as the fall-back for planes larger than the LDS)
+template <int SIGN, int MODE>
+__global__ __launch_bounds__(FFT_B * FFT_T)
+void fft_pass_kernel(fft_plan pl, float2* __restrict__ grid, size_t rep_stride, int es, int lines_per_rep,
+                     int line_div, size_t line_hi_stride, int contiguous, const float2* __restrict__ tw)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = pl.n;
+    float2* bufA = reinterpret_cast<float2*>(smem);
+    float2* bufB = bufA + FFT_B * n;
+    const int r = blockIdx.y;
+    const int l0 = blockIdx.x * FFT_B;
+    float2* G = grid + (size_t)r * rep_stride;
+    const int tid = threadIdx.x;
+    auto base = [&](int l) -> size_t { return (size_t)(l / line_div) * line_hi_stride + (size_t)(l % line_div) * (contiguous ? (size_t)n : 1); };
+    if (contiguous) {
+        for (int idx = tid; idx < FFT_B * n; idx += FFT_B * FFT_T) {
+            const int b = idx / n, e = idx % n;
+            const int l = l0 + b;
+            bufA[b * n + e] = (l < lines_per_rep) ? G[base(l) + e] : make_float2(0.f, 0.f);
+        }
+    } else {
+        for (int idx = tid; idx < FFT_B * n; idx += FFT_B * FFT_T) {
+            const int e = idx / FFT_B, b = idx % FFT_B;
+            const int l = l0 + b;
+            bufA[b * n + e] = (l < lines_per_rep) ? G[base(l) + (size_t)e * es] : make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    float2* res = fft_lines_lds<SIGN>(pl, bufA, bufB, FFT_B, n, 1, tw, tid, FFT_B * FFT_T);
+    if (contiguous) {
+        for (int idx = tid; idx < FFT_B * n; idx += FFT_B * FFT_T) {
+            const int b = idx / n, e = idx % n;
+            const int l = l0 + b;
+            if (l < lines_per_rep) G[base(l) + e] = res[b * n + e];
+        }
+    } else {
+        for (int idx = tid; idx < FFT_B * n; idx += FFT_B * FFT_T) {
+            const int e = idx / FFT_B, b = idx % FFT_B;
+            const int l = l0 + b;
+            if (l < lines_per_rep) G[base(l) + (size_t)e * es] = res[b * n + e];
         }
     }
 }
 
 __global__ __launch_bounds__(128)
-void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, size_t rep_stride, const float4* __restrict__ pos,
+void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __restrict__ pos,
                        const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                       const float2* __restrict__ mesh, long long* __restrict__ force)
+                       const float* __restrict__ mesh, long long* __restrict__ force)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
@@ -298,7 +456,7 @@ void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, size_t rep_strid
     float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
     bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
     if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
-    const float2* M = mesh + (size_t)r * rep_stride;
+    const float* M = mesh + (size_t)r * nx * ny * nz;
     float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
@@ -311,7 +469,7 @@ void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, size_t rep_strid
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
                 int iz = kz - c; if (iz < 0) iz += nz;
-                const float phi = M[row + iz].x;
+                const float phi = M[row + iz];
                 sx += wz[c] * phi; sz += dz[c] * phi;
             }
             gx += dx[a] * wy[b] * sx; gy += wx[a] * dy[b] * sx; gz += wx[a] * wy[b] * sz;
@@ -323,6 +481,41 @@ void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, size_t rep_strid
     F[i] += (long long)((double)Fx * REMD_FORCE_SCALE);
     F[Npad + i] += (long long)((double)Fy * REMD_FORCE_SCALE);
     F[2 * Npad + i] += (long long)((double)Fz * REMD_FORCE_SCALE);
+}
+
+// fall-back influence-function pass for meshes whose (x,y) plane does not fit the LDS
+__global__ __launch_bounds__(256)
+void pme_influence_kernel(int nx, int ny, int nz, float2* __restrict__ spec, const float* __restrict__ bmx,
+                          const float* __restrict__ bmy, const float* __restrict__ bmz, const float* __restrict__ box,
+                          float alpha, int with_energy, double* __restrict__ energy, int n_eblk)
+{
+    __shared__ double s_e[4];
+    const int kz = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, nzc = nz / 2 + 1, np = nx * ny;
+    float2* P = spec + ((size_t)r * nzc + kz) * np;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const double V = (double)Lx * Ly * Lz;
+    const float pref = (float)(1.0 / (M_PI * V));
+    const float fac = (float)(M_PI * M_PI) / (alpha * alpha);
+    const float mz = kz / Lz, bz = bmz[kz];
+    const float wz = (kz == 0 || 2 * kz == nz) ? 1.f : 2.f;
+    double e_acc = 0.0;
+    for (int idx = tid; idx < np; idx += 256) {
+        const int kx = idx / ny, ky = idx - kx * ny;
+        const int m0 = (kx <= nx / 2) ? kx : kx - nx, m1 = (ky <= ny / 2) ? ky : ky - ny;
+        const float mx = m0 / Lx, my = m1 / Ly;
+        const float msq = mx * mx + my * my + mz * mz;
+        float g = 0.f;
+        if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
+        const float2 sv = P[idx];
+        if (with_energy) e_acc += 0.5 * (double)(wz * g) * ((double)sv.x * sv.x + (double)sv.y * sv.y);
+        P[idx] = make_float2(sv.x * g, sv.y * g);
+    }
+    if (with_energy) {
+        for (int off = 32; off > 0; off >>= 1) e_acc += __shfl_xor(e_acc, off);
+        if ((tid & 63) == 0) s_e[tid >> 6] = e_acc;
+        __syncthreads();
+        if (tid == 0) energy[(size_t)r * n_eblk + kz] = s_e[0] + s_e[1] + s_e[2] + s_e[3];
+    }
 }
 
 __global__ void pme_energy_reduce_kernel(int n_eblk, const double* __restrict__ e, double* __restrict__ epart, int n_epart, int slot)
@@ -357,6 +550,9 @@ int remd_pme_destroy(remd_ctx* h)
     pme_state* s = (pme_state*)h->pme;
     if (!s) return 0;
     if (s->d_grid) hipFree(s->d_grid);
+    if (s->d_mesh) hipFree(s->d_mesh);
+    if (s->d_col_count) hipFree(s->d_col_count); if (s->d_col_start) hipFree(s->d_col_start); if (s->d_cursor) hipFree(s->d_cursor);
+    if (s->d_atom_col) hipFree(s->d_atom_col); if (s->d_col_atoms) hipFree(s->d_col_atoms);
     for (int k = 0; k < 3; ++k) { if (s->d_tw[k]) hipFree(s->d_tw[k]); if (s->d_bmod[k]) hipFree(s->d_bmod[k]); }
     if (s->d_energy) hipFree(s->d_energy);
     delete s;
@@ -364,7 +560,20 @@ int remd_pme_destroy(remd_ctx* h)
     return 0;
 }
 
-int remd_pme_setup(remd_ctx* h)
+static fft_plan make_plan(pme_state* s, int axis)
+{
+    fft_plan pl; pl.n = s->n[axis]; pl.nrad = s->nrad[axis];
+    int Ns = 1;
+    for (int k = 0; k < 8; ++k) {
+        pl.radix[k] = s->radix[axis][k];
+        pl.mnb[k] = pl.mNs[k] = 0;
+        if (k < pl.nrad) { pl.mnb[k] = fft_magic((unsigned)(pl.n / pl.radix[k])); pl.mNs[k] = fft_magic((unsigned)Ns); Ns *= pl.radix[k]; }
+    }
+    return pl;
+}
+
+// full_complex: allocate the [R][nx][ny][nz] complex grid of the FFT test hook instead of the PME buffers
+static int pme_setup_impl(remd_ctx* h, bool full_complex)
 {
     remd_pme_destroy(h);
     pme_state* s = new pme_state();
@@ -376,7 +585,21 @@ int remd_pme_setup(remd_ctx* h)
     }
     s->R = h->R;
     s->npts = (size_t)s->n[0] * s->n[1] * s->n[2];
-    REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->npts * s->R));
+    s->nzc = s->n[2] / 2 + 1;
+    s->nspec = (size_t)s->nzc * s->n[0] * s->n[1];
+    if (full_complex) {
+        REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->npts * s->R));
+    } else {
+        REMD_CHECK(h, hipMalloc(&s->d_mesh, sizeof(int) * s->npts * s->R));
+        REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->nspec * s->R));
+        const size_t nc = (size_t)s->n[0] * s->n[1] + 1;
+        REMD_CHECK(h, hipMalloc(&s->d_col_count, sizeof(int) * nc * s->R));
+        REMD_CHECK(h, hipMalloc(&s->d_col_start, sizeof(int) * nc * s->R));
+        REMD_CHECK(h, hipMalloc(&s->d_cursor, sizeof(int) * nc * s->R));
+        REMD_CHECK(h, hipMalloc(&s->d_atom_col, sizeof(int) * (size_t)h->Npad * s->R));
+        REMD_CHECK(h, hipMalloc(&s->d_col_atoms, sizeof(int) * (size_t)h->Npad * s->R));
+        REMD_CHECK(h, hipMemset(s->d_col_count, 0, sizeof(int) * nc * s->R));
+    }
     for (int k = 0; k < 3; ++k) {
         const int n = s->n[k];
         std::vector<float2> tw(n);
@@ -399,26 +622,28 @@ int remd_pme_setup(remd_ctx* h)
         REMD_CHECK(h, hipMalloc(&s->d_bmod[k], sizeof(float) * n));
         REMD_CHECK(h, hipMemcpy(s->d_bmod[k], bm.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     }
-    s->n_eblk = (s->n[1] * s->n[2] + FFT_B - 1) / FFT_B;
+    s->n_eblk = s->nzc;
     REMD_CHECK(h, hipMalloc(&s->d_energy, sizeof(double) * (size_t)s->n_eblk * s->R));
+    s->xy_lds = sizeof(float2) * (2 * (size_t)s->n[0] * s->n[1] + s->n[0] + s->n[1]);
+    s->xy_fused = s->xy_lds <= 160 * 1024;
+    if (s->xy_fused)
+        REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return 0;
 }
 
-template <int SIGN, int MODE>
-static void launch_pass(remd_ctx* h, pme_state* s, int axis, bool with_energy)
+int remd_pme_setup(remd_ctx* h) { return pme_setup_impl(h, false); }
+
+template <int SIGN>
+static void launch_pass(remd_ctx* h, pme_state* s, float2* data, size_t rep_stride, int axis_n_index, int es, int lines,
+                        int line_div, size_t hi, int contiguous)
 {
-    const int nx = s->n[0], ny = s->n[1], nz = s->n[2];
-    fft_plan pl; pl.n = s->n[axis]; pl.nrad = s->nrad[axis];
-    for (int k = 0; k < 8; ++k) pl.radix[k] = s->radix[axis][k];
-    int es, lines, line_div, contiguous; size_t hi;
-    if (axis == 2) { es = 1; lines = nx * ny; line_div = lines; hi = 0; contiguous = 1; }
-    else if (axis == 1) { es = nz; lines = nx * nz; line_div = nz; hi = (size_t)ny * nz; contiguous = 0; }
-    else { es = ny * nz; lines = ny * nz; line_div = lines; hi = 0; contiguous = 0; }
+    fft_plan pl = make_plan(s, axis_n_index);
     dim3 grid((lines + FFT_B - 1) / FFT_B, s->R);
     const size_t lds = sizeof(float2) * 2 * FFT_B * pl.n;
-    hipLaunchKernelGGL((fft_pass_kernel<SIGN, MODE>), grid, dim3(FFT_B * FFT_T), lds, h->stream, pl, s->d_grid, s->npts, es, lines,
-                       line_div, hi, contiguous, s->d_tw[axis], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], ny, nz, h->d_box,
-                       (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);
+    hipLaunchKernelGGL((fft_pass_kernel<SIGN, 0>), grid, dim3(FFT_B * FFT_T), lds, h->stream, pl, data, rep_stride, es, lines,
+                       line_div, hi, contiguous, s->d_tw[axis_n_index]);
 }
 
 const float* remd_nb_rep_lam(remd_ctx* h);
@@ -428,28 +653,47 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, double* d_energy)
 {
     (void)d_energy;
     pme_state* s = (pme_state*)h->pme;
-    if (!s || s->R != h->R) { int rc = remd_pme_setup(h); if (rc) return rc; s = (pme_state*)h->pme; }
+    if (!s || s->R != h->R || !s->d_mesh) { int rc = remd_pme_setup(h); if (rc) return rc; s = (pme_state*)h->pme; }
     const int nx = s->n[0], ny = s->n[1], nz = s->n[2];
     const float* rep_lam = remd_nb_rep_lam(h);
     const float4* param = remd_nb_param(h);
-    REMD_CHECK(h, hipMemsetAsync(s->d_grid, 0, sizeof(float2) * s->npts * s->R, h->stream));
+    const int ncol = nx * ny;
     {
-        remd_prof_scope ps(h, "pme_spread");
-        hipLaunchKernelGGL(pme_spread_kernel, dim3((h->N + 127) / 128, h->R), dim3(128), 0, h->stream, h->N, h->Npad, nx, ny, nz,
-                           s->npts, h->d_pos, param, h->d_box, rep_lam, reinterpret_cast<long long*>(s->d_grid));
+        remd_prof_scope ps(h, "pme_bin");
+        const dim3 agrid((h->N + 255) / 256, h->R);
+        hipLaunchKernelGGL(pme_bin_count_kernel, agrid, dim3(256), 0, h->stream, h->N, h->Npad, nx, ny, nz, h->d_pos, h->d_box,
+                           s->d_col_count, s->d_atom_col);
+        hipLaunchKernelGGL(pme_bin_scan_kernel, dim3(h->R), dim3(1024), 0, h->stream, ncol, s->d_col_count, s->d_col_start, s->d_cursor);
+        hipLaunchKernelGGL(pme_bin_fill_kernel, agrid, dim3(256), 0, h->stream, h->N, h->Npad, ncol, s->d_atom_col, s->d_cursor, s->d_col_atoms);
     }
     {
         remd_prof_scope ps(h, "pme_fft");
-        launch_pass<-1, 1>(h, s, 2, false);
-        launch_pass<-1, 0>(h, s, 1, false);
-        launch_pass<-1, 2>(h, s, 0, with_energy);
-        launch_pass<+1, 0>(h, s, 1, false);
-        launch_pass<+1, 0>(h, s, 2, false);
+        int nl = 8;                                   // lines per workgroup: the largest divisor of ny that is <= 32
+        for (int c = 8; c <= 32; ++c) if (ny % c == 0) nl = c;
+        const size_t zlds = sizeof(float2) * (2 * nl * nz + nz);
+        const dim3 zgrid(nx * ny / nl, s->R);
+        hipLaunchKernelGGL(pme_spread_zfwd_kernel, zgrid, dim3(256), zlds, h->stream, make_plan(s, 2), nl, nx, ny, h->Npad, h->d_pos,
+                           param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
+        if (s->xy_fused) {
+            hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(XY_THREADS), s->xy_lds, h->stream, make_plan(s, 0), make_plan(s, 1),
+                               nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
+                               (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);
+        } else {
+            // spec layout [kz][x][y]: y lines contiguous, x lines strided by ny
+            launch_pass<-1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
+            launch_pass<-1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
+            hipLaunchKernelGGL(pme_influence_kernel, dim3(s->nzc, s->R), dim3(256), 0, h->stream, nx, ny, nz, s->d_grid, s->d_bmod[0],
+                               s->d_bmod[1], s->d_bmod[2], h->d_box, (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);
+            launch_pass<+1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
+            launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
+        }
+        hipLaunchKernelGGL(pme_zinv_kernel, zgrid, dim3(256), zlds, h->stream, make_plan(s, 2), nl, nx, ny, s->d_grid,
+                           reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
     }
     {
         remd_prof_scope ps(h, "pme_gather");
         hipLaunchKernelGGL(pme_gather_kernel, dim3((h->N + 127) / 128, h->R), dim3(128), 0, h->stream, h->N, h->Npad, nx, ny, nz,
-                           s->npts, h->d_pos, param, h->d_box, rep_lam, s->d_grid, h->d_force);
+                           h->d_pos, param, h->d_box, rep_lam, reinterpret_cast<const float*>(s->d_mesh), h->d_force);
     }
     if (with_energy)
         hipLaunchKernelGGL(pme_energy_reduce_kernel, dim3(h->R), dim3(64), 0, h->stream, s->n_eblk, s->d_energy, h->d_epart,
@@ -458,21 +702,24 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, double* d_energy)
     return 0;
 }
 
-// test hook: in-place 3-D complex FFT of a host array [nx][ny][nz] (interleaved re, im)
+// test hook: in-place 3-D complex FFT of a host array [nx][ny][nz] (interleaved re, im) on the strided-pass kernels
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse)
 {
-    pme_state saved_dummy;
-    (void)saved_dummy;
     pme_state* old = (pme_state*)h->pme;
     const int oldgrid[3] = { h->grid[0], h->grid[1], h->grid[2] };
     const int oldR = h->R;
     h->pme = nullptr; h->grid[0] = nx; h->grid[1] = ny; h->grid[2] = nz; h->R = 1;
-    int rc = remd_pme_setup(h);
+    int rc = pme_setup_impl(h, true);
     if (!rc) {
         pme_state* s = (pme_state*)h->pme;
         hipMemcpy(s->d_grid, data, sizeof(float2) * s->npts, hipMemcpyHostToDevice);
-        if (!inverse) { launch_pass<-1, 0>(h, s, 2, false); launch_pass<-1, 0>(h, s, 1, false); launch_pass<-1, 0>(h, s, 0, false); }
-        else { launch_pass<+1, 0>(h, s, 0, false); launch_pass<+1, 0>(h, s, 1, false); launch_pass<+1, 0>(h, s, 2, false); }
+        auto all = [&](auto tag) {
+            constexpr int SG = decltype(tag)::value;
+            launch_pass<SG>(h, s, s->d_grid, s->npts, 2, 1, nx * ny, nx * ny, 0, 1);
+            launch_pass<SG>(h, s, s->d_grid, s->npts, 1, nz, nx * nz, nz, (size_t)ny * nz, 0);
+            launch_pass<SG>(h, s, s->d_grid, s->npts, 0, ny * nz, ny * nz, ny * nz, 0, 0);
+        };
+        if (!inverse) all(std::integral_constant<int, -1>()); else all(std::integral_constant<int, +1>());
         hipStreamSynchronize(h->stream);
         hipMemcpy(data, s->d_grid, sizeof(float2) * s->npts, hipMemcpyDeviceToHost);
         if (hipGetLastError() != hipSuccess) rc = remd_fail(h, -2, "fft test launch failed");
