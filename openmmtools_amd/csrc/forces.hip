@@ -21,6 +21,8 @@
 #include <cmath>
 #include <algorithm>
 #include <set>
+#include <cstdlib>
+#include <cstdio>
 
 #define EP_EXT      0
 #define EP_BOND     1
@@ -65,6 +67,19 @@ struct nb_tables {
     double net_charge_term = 0.0;         // neutralising-plasma coefficient: E = coeff / V
     std::vector<double> charge;           // original charges
     std::vector<char> is_alch;
+    // spatial ordering: exclusion/constraint-connected groups (molecules) stay contiguous, groups are ordered
+    // along a Morton curve of their cells every resort_interval force evaluations
+    int n_groups = 0; int* d_grp_first = nullptr; int* d_grp_size = nullptr;
+    int* d_order = nullptr;               // [R][Npad] sorted slot -> atom (-1: padding)
+    float4* d_spos = nullptr;             // [R][Npad] positions in sorted order (refreshed every evaluation)
+    float4* d_sparam = nullptr;           // [R][Npad]
+    unsigned long long* d_smask = nullptr;// [R][Npad][excl_words]
+    float4* d_tile_c = nullptr; float4* d_tile_h = nullptr;   // [R][ntile] bounding-box centre / half extent
+    float4* d_partial = nullptr; size_t partial_n = 0;      // [R][n_jsplit][Npad] nonbonded force partials
+    // 8-atom cluster pair lists (sorted slot space): lane = (i atom, j atom) of an 8 x 8 cluster pair
+    float4* d_cl_c = nullptr; float4* d_cl_h = nullptr;     // [R][ncl] cluster bounding boxes
+    unsigned short* d_cl_list = nullptr; int* d_cl_count = nullptr; int cl_cap = 0; bool clusters = true;
+    int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 20; bool sorting = true;
 };
 static std::map<remd_ctx*, nb_tables> g_nb;
 
@@ -230,7 +245,7 @@ __device__ __forceinline__ void switch_fn(const nb_params& p, float r, float& U,
 }
 
 // returns energy, writes dU/dr / r  (so that F_i = fr * (xj - xi))
-template <int METHOD, bool ALCH>
+template <int METHOD, bool ALCH, bool FAST_ERFC>
 __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, float4 pi, float4 pj,
                                                   float lam_a, float sc, float& fr, bool energy_skip_na, float& e_out)
 {
@@ -261,8 +276,15 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
         const float qq = pi.x * pj.x;
         if (METHOD == NB_EWALD) {
             const float ar = p.alpha * r;
-            const float erfc_ar = erfcf(ar);
             const float ex = __expf(-ar * ar);
+            float erfc_ar;
+            if (FAST_ERFC) {
+                // Abramowitz & Stegun 7.1.26 (|abs err| < 1.5e-7): force-only evaluations; energies use erfcf
+                const float t = __frcp_rn(1.f + 0.3275911f * ar);
+                erfc_ar = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f)))) * ex;
+            } else {
+                erfc_ar = erfcf(ar);
+            }
             Uc = qq * erfc_ar * inv_r;
             dUc = -qq * (erfc_ar * inv_r + p.two_alpha_sqrtpi * ex) * inv_r;
         } else {
@@ -275,24 +297,298 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
     return e_out;
 }
 
+// ---- spatial ordering ------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned morton3(unsigned x, unsigned y, unsigned z)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) m |= ((x >> b) & 1u) << (3 * b) | ((y >> b) & 1u) << (3 * b + 1) | ((z >> b) & 1u) << (3 * b + 2);
+    return m;
+}
+
+// one workgroup per replica: rank the groups by (Morton cell of the group's first atom, group index), then
+// lay their atoms out contiguously.  Keys are unique, so the order is deterministic.
+__global__ __launch_bounds__(1024)
+void sort_groups_kernel(int G, int N, int Npad, const int* __restrict__ grp_first, const int* __restrict__ grp_size,
+                        const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* key = reinterpret_cast<unsigned*>(smem);       // [G]
+    int* r_first = reinterpret_cast<int*>(key + G);          // [G] by rank
+    int* r_size = r_first + G;                               // [G] by rank
+    int* r_off = r_size + G;                                 // [G] by rank (exclusive scan)
+    __shared__ int s_part[1024];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const int ncx = max(1, min(63, (int)(Lx / cell))), ncy = max(1, min(63, (int)(Ly / cell))), ncz = max(1, min(63, (int)(Lz / cell)));
+    for (int g = tid; g < G; g += 1024) {
+        const float4 x = pos[(size_t)r * Npad + grp_first[g]];
+        float fx = x.x / Lx, fy = x.y / Ly, fz = x.z / Lz;
+        fx -= floorf(fx); fy -= floorf(fy); fz -= floorf(fz);
+        const unsigned cx = min(ncx - 1, (int)(fx * ncx)), cy = min(ncy - 1, (int)(fy * ncy)), cz = min(ncz - 1, (int)(fz * ncz));
+        key[g] = (morton3(cx, cy, cz) << 13) | (unsigned)g;
+    }
+    __syncthreads();
+    for (int g = tid; g < G; g += 1024) {
+        const unsigned k = key[g];
+        int rank = 0;
+        for (int o = 0; o < G; ++o) rank += (key[o] < k) ? 1 : 0;
+        r_first[rank] = grp_first[g];
+        r_size[rank] = grp_size[g];
+    }
+    __syncthreads();
+    const int per = (G + 1023) / 1024;
+    const int b = min(G, tid * per), e = min(G, b + per);
+    int sum = 0;
+    for (int k = b; k < e; ++k) sum += r_size[k];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = (tid > 0) ? s_part[tid - 1] : 0;
+    for (int k = b; k < e; ++k) { r_off[k] = run; run += r_size[k]; }
+    __syncthreads();
+    int* O = order + (size_t)r * Npad;
+    for (int k = tid; k < G; k += 1024) {
+        const int st = r_off[k], f = r_first[k], n = r_size[k];
+        for (int a = 0; a < n; ++a) O[st + a] = f + a;
+    }
+    for (int k = N + tid; k < Npad; k += 1024) O[k] = -1;
+}
+
+__global__ __launch_bounds__(256)
+void gather_params_kernel(int Npad, int words, const int* __restrict__ order, const float4* __restrict__ param,
+                          const unsigned long long* __restrict__ mask, float4* __restrict__ sparam,
+                          unsigned long long* __restrict__ smask)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (k >= Npad) return;
+    const int o = order[(size_t)r * Npad + k];
+    sparam[(size_t)r * Npad + k] = (o >= 0) ? param[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < words; ++w)
+        smask[((size_t)r * Npad + k) * words + w] = (o >= 0) ? mask[(size_t)o * words + w] : 0ull;
+}
+
+// positions into sorted order + bounding box of every 64-atom tile (relative to the tile's first atom, minimum image)
+__global__ __launch_bounds__(64)
+void gather_positions_kernel(int Npad, const int* __restrict__ order, const float4* __restrict__ pos,
+                             const float* __restrict__ box, float4* __restrict__ spos, float4* __restrict__ tile_c,
+                             float4* __restrict__ tile_h, float4* __restrict__ cl_c, float4* __restrict__ cl_h)
+{
+    const int tile = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const int k = tile * 64 + lane;
+    const int o = order[(size_t)r * Npad + k];
+    const float4 x = (o >= 0) ? pos[(size_t)r * Npad + o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    spos[(size_t)r * Npad + k] = x;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const float x0 = __shfl(x.x, 0), y0 = __shfl(x.y, 0), z0 = __shfl(x.z, 0);   // lane 0 of a tile is always a real atom
+    float dx = x.x - x0, dy = x.y - y0, dz = x.z - z0;
+    dx -= Lx * rintf(dx / Lx); dy -= Ly * rintf(dy / Ly); dz -= Lz * rintf(dz / Lz);
+    if (o < 0) { dx = dy = dz = 0.f; }
+    float lox = dx, hix = dx, loy = dy, hiy = dy, loz = dz, hiz = dz;
+    for (int off = 32; off > 0; off >>= 1) {
+        lox = fminf(lox, __shfl_xor(lox, off)); hix = fmaxf(hix, __shfl_xor(hix, off));
+        loy = fminf(loy, __shfl_xor(loy, off)); hiy = fmaxf(hiy, __shfl_xor(hiy, off));
+        loz = fminf(loz, __shfl_xor(loz, off)); hiz = fmaxf(hiz, __shfl_xor(hiz, off));
+    }
+    if (lane == 0) {
+        const int nt = gridDim.x;
+        tile_c[(size_t)r * nt + tile] = make_float4(x0 + 0.5f * (lox + hix), y0 + 0.5f * (loy + hiy), z0 + 0.5f * (loz + hiz), 0.f);
+        tile_h[(size_t)r * nt + tile] = make_float4(0.5f * (hix - lox), 0.5f * (hiy - loy), 0.5f * (hiz - loz), 0.f);
+    }
+    if (cl_c) {
+        // 8-atom clusters: same construction inside each group of 8 lanes (relative to the group's first atom)
+        const int g0 = lane & ~7;
+        const float cx0 = __shfl(x.x, g0), cy0 = __shfl(x.y, g0), cz0 = __shfl(x.z, g0);
+        const int o0 = __shfl(o, g0);
+        float ex = x.x - cx0, ey = x.y - cy0, ez = x.z - cz0;
+        ex -= Lx * rintf(ex / Lx); ey -= Ly * rintf(ey / Ly); ez -= Lz * rintf(ez / Lz);
+        if (o < 0) { ex = ey = ez = 0.f; }
+        float ax = ex, bx2 = ex, ay = ey, by2 = ey, az = ez, bz2 = ez;
+        for (int off = 4; off > 0; off >>= 1) {
+            ax = fminf(ax, __shfl_xor(ax, off)); bx2 = fmaxf(bx2, __shfl_xor(bx2, off));
+            ay = fminf(ay, __shfl_xor(ay, off)); by2 = fmaxf(by2, __shfl_xor(by2, off));
+            az = fminf(az, __shfl_xor(az, off)); bz2 = fmaxf(bz2, __shfl_xor(bz2, off));
+        }
+        if ((lane & 7) == 0) {
+            const int ncl = gridDim.x * 8;
+            const int c = tile * 8 + (lane >> 3);
+            // an empty (all-padding) cluster is parked far away with a negative extent so that it never pairs
+            cl_c[(size_t)r * ncl + c] = (o0 >= 0) ? make_float4(cx0 + 0.5f * (ax + bx2), cy0 + 0.5f * (ay + by2), cz0 + 0.5f * (az + bz2), 0.f)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            cl_h[(size_t)r * ncl + c] = (o0 >= 0) ? make_float4(0.5f * (bx2 - ax), 0.5f * (by2 - ay), 0.5f * (bz2 - az), 0.f)
+                                                  : make_float4(-1e9f, -1e9f, -1e9f, 0.f);
+        }
+    }
+}
+
+// neighbour list of 8-atom clusters: one wavefront per i cluster tests every j cluster (bounding boxes, minimum
+// image) and appends the hits in ascending order (ballot + popcount => deterministic).
+__global__ __launch_bounds__(64)
+void build_cluster_list_kernel(int ncl, int cap, float rc2, const float4* __restrict__ cl_c, const float4* __restrict__ cl_h,
+                               const float* __restrict__ box, unsigned short* __restrict__ list, int* __restrict__ count)
+{
+    const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const float4 ci = cl_c[(size_t)r * ncl + ic], hi = cl_h[(size_t)r * ncl + ic];
+    unsigned short* L = list + ((size_t)r * ncl + ic) * cap;
+    int n = 0;
+    for (int base = 0; base < ncl; base += 64) {
+        const int jc = base + lane;
+        bool hit = false;
+        if (jc < ncl) {
+            const float4 cj = cl_c[(size_t)r * ncl + jc], hj = cl_h[(size_t)r * ncl + jc];
+            float bx = cj.x - ci.x, by = cj.y - ci.y, bz = cj.z - ci.z;
+            bx -= Lx * rintf(bx / Lx); by -= Ly * rintf(by / Ly); bz -= Lz * rintf(bz / Lz);
+            bx = fmaxf(0.f, fabsf(bx) - hi.x - hj.x); by = fmaxf(0.f, fabsf(by) - hi.y - hj.y); bz = fmaxf(0.f, fabsf(bz) - hi.z - hj.z);
+            hit = (hi.x >= 0.f) && (bx * bx + by * by + bz * bz <= rc2);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int slot = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < cap) L[slot] = (unsigned short)jc;
+        }
+        n += __popcll(m);
+    }
+    if (lane == 0) count[(size_t)r * ncl + ic] = n;       // n > cap is detected on the host side (fallback)
+}
+
+// 8 x 8 cluster-pair kernel: lane = (ii = lane >> 3, jj = lane & 7).  Every lane evaluates its own atom pair, so
+// the arithmetic is straight-line (no wave-level branching); i forces are reduced over the 8 j lanes at the end.
 template <int METHOD, bool ENERGY, bool ALCH>
 __global__ __launch_bounds__(64)
-void nonbonded_kernel(nb_params p, int N, int Npad, const float4* __restrict__ pos,
-                      const float4* __restrict__ param, const unsigned long long* __restrict__ mask,
-                      const float* __restrict__ box, const float* __restrict__ rep_lam,
-                      long long* __restrict__ force, double* __restrict__ epart, int n_epart)
+void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, const float4* __restrict__ spos,
+                              const float4* __restrict__ sparam, const unsigned long long* __restrict__ smask,
+                              const int* __restrict__ order, const unsigned short* __restrict__ list,
+                              const int* __restrict__ count, const float* __restrict__ box, const float* __restrict__ rep_lam,
+                              long long* __restrict__ force, double* __restrict__ epart, int n_epart)
 {
-    const int lane = threadIdx.x;
-    const int i0 = blockIdx.x * 64;
-    const int i = i0 + lane;
-    const int js = blockIdx.y;
-    const int r = blockIdx.z;
-    const float4* __restrict__ P = pos + (size_t)r * Npad;
+    const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const int ii = lane >> 3, jj = lane & 7;
+    const int i = ic * 8 + ii;
+    const float4* __restrict__ P = spos + (size_t)r * Npad;
+    const float4* __restrict__ prm = sparam + (size_t)r * Npad;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
     float lam_a = 1.f, sc = 0.f, lam_e = 1.f;
     if (ALCH) { lam_a = rep_lam[4 * r]; sc = rep_lam[4 * r + 1]; lam_e = rep_lam[4 * r + 2]; }
-    const bool active = i < N;
+    const bool iact = i < N;
+    const float4 xi = P[iact ? i : 0];
+    float4 pi = prm[iact ? i : 0];
+    if (ALCH && pi.w != 0.f) pi.x *= lam_e;
+    unsigned long long mk[MAX_EXCL_WORDS];
+#pragma unroll
+    for (int w = 0; w < MAX_EXCL_WORDS; ++w)
+        mk[w] = (w < p.excl_words) ? smask[((size_t)r * Npad + (iact ? i : 0)) * p.excl_words + w] : 0ull;
+    const int half = 32 * p.excl_words;
+    const unsigned short* L = list + ((size_t)r * ncl + ic) * cap;
+    const int n = min(count[(size_t)r * ncl + ic], cap);
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    double e = 0.0;
+    // one cluster pair: every lane evaluates its own (i atom, j atom) pair
+    auto pair_step = [&](int jc, const float4 xj, float4 pj) {
+        const int j = jc * 8 + jj;
+        float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+        dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        bool in = iact && (j < N) && (r2 < p.rc2);
+        if (abs(jc - ic) * 8 < half + 8) {                   // wave-uniform: exclusions only live near the diagonal
+            const int d = j - i + half;
+            if (d >= 0 && d < 2 * half) {
+                unsigned long long m = 0ull;
+#pragma unroll
+                for (int w = 0; w < MAX_EXCL_WORDS; ++w) if ((d >> 6) == w) m = mk[w];
+                in = in && !((m >> (d & 63)) & 1ull);
+            }
+        }
+        if (!__any(in)) return;                              // no atom pair of this cluster pair is inside the cutoff
+        if (ALCH && pj.w != 0.f) pj.x *= lam_e;
+        float fr, ee;
+        // evaluated for every lane (r2 clamped for masked pairs), result discarded unless `in`
+        pair_interaction<METHOD, ALCH, !ENERGY>(p, in ? r2 : p.rc2, pi, pj, lam_a, sc, fr, ENERGY, ee);
+        fr = in ? fr : 0.f;
+        fx += fr * dx; fy += fr * dy; fz += fr * dz;
+        if (ENERGY) e += in ? 0.5 * (double)ee : 0.0;
+    };
+    // The j atoms of 8 cluster pairs at a time go through LDS: each lane fetches one atom (position + parameters)
+    // of the NEXT batch into registers before the current batch is processed, and the registers are written to
+    // LDS only afterwards, so the global-load latency hides behind 8 cluster pairs of arithmetic.
+    __shared__ float4 s_x[2][64];
+    __shared__ float4 s_p[2][64];
+    const int lc = lane >> 3;
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = min(64, n - base);                       // list entries in this 64-chunk
+        const int my_jc = (lane < cnt) ? (int)L[base + lane] : 0;
+        int jsrc = __shfl(my_jc, min(lc, cnt - 1));
+        float4 gx = P[jsrc * 8 + jj], gp = prm[jsrc * 8 + jj];
+        int buf = 0;
+        for (int sub = 0; sub < cnt; sub += 8) {
+            s_x[buf][lane] = gx; s_p[buf][lane] = gp;
+            __syncthreads();
+            if (sub + 8 < cnt) {                                 // prefetch the next batch
+                jsrc = __shfl(my_jc, min(sub + 8 + lc, cnt - 1));
+                gx = P[jsrc * 8 + jj]; gp = prm[jsrc * 8 + jj];
+            }
+            const int nb = min(8, cnt - sub);
+#pragma unroll 2
+            for (int c = 0; c < nb; ++c) {
+                const int jc = __builtin_amdgcn_readlane(my_jc, sub + c);
+                pair_step(jc, s_x[buf][c * 8 + jj], s_p[buf][c * 8 + jj]);
+            }
+            buf ^= 1;
+        }
+    }
+    // reduce over the 8 j lanes of each i atom
+    for (int off = 4; off > 0; off >>= 1) { fx += __shfl_xor(fx, off); fy += __shfl_xor(fy, off); fz += __shfl_xor(fz, off); }
+    if (iact && jj == 0) {
+        long long* F = force + (size_t)r * 3 * Npad;
+        const int io = order[(size_t)r * Npad + i];
+        F[io] += (long long)((double)fx * REMD_FORCE_SCALE);
+        F[Npad + io] += (long long)((double)fy * REMD_FORCE_SCALE);
+        F[2 * Npad + io] += (long long)((double)fz * REMD_FORCE_SCALE);
+    }
+    if (ENERGY) {
+        e = wave_sum(e);
+        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + ic] = e;
+    }
+}
+
+
+// Workgroup = 4 wavefronts = 4 consecutive i tiles of one replica sharing one stream of j atoms: the j
+// positions/parameters are staged through LDS in chunks of NB_CHUNK atoms with coalesced 16-byte loads and
+// read back with wave-uniform (broadcast) ds_read_b128, so the inner loop never waits on global memory.
+#define NB_CHUNK 128
+#define NB_WAVES 4
+template <int METHOD, bool ENERGY, bool ALCH>
+__global__ __launch_bounds__(64 * NB_WAVES)
+void nonbonded_kernel(nb_params p, int N, int Npad, const float4* __restrict__ pos,
+                      const float4* __restrict__ param_all, const unsigned long long* __restrict__ mask_all,
+                      const int* __restrict__ order, const float4* __restrict__ tile_c, const float4* __restrict__ tile_h,
+                      const float* __restrict__ box, const float* __restrict__ rep_lam,
+                      float4* __restrict__ partial, double* __restrict__ epart, int n_epart, int ntile)
+{
+    __shared__ float4 s_pos[NB_CHUNK];
+    __shared__ float4 s_prm[NB_CHUNK];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int itile = blockIdx.x * NB_WAVES + wave;
+    const int i0 = itile * 64;
+    const int i = i0 + lane;
+    const int js = blockIdx.y;
+    const int r = blockIdx.z;
+    // pos / param / mask are per-replica arrays in sorted (spatially ordered) slot space when order != nullptr
+    const float4* __restrict__ P = pos + (size_t)r * Npad;
+    const float4* __restrict__ param = order ? param_all + (size_t)r * Npad : param_all;
+    const unsigned long long* __restrict__ mask = order ? mask_all + (size_t)r * Npad * p.excl_words : mask_all;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
+    float lam_a = 1.f, sc = 0.f, lam_e = 1.f;
+    if (ALCH) { lam_a = rep_lam[4 * r]; sc = rep_lam[4 * r + 1]; lam_e = rep_lam[4 * r + 2]; }
+    const bool active = (itile < ntile) && (i < N);
     const float4 xi = P[active ? i : 0];
     float4 pi = param[active ? i : 0];
     if (ALCH && pi.w != 0.f) pi.x *= lam_e;
@@ -301,49 +597,84 @@ void nonbonded_kernel(nb_params p, int N, int Npad, const float4* __restrict__ p
     for (int w = 0; w < MAX_EXCL_WORDS; ++w) mk[w] = (w < p.excl_words) ? mask[(size_t)(active ? i : 0) * p.excl_words + w] : 0ull;
     const int half = 32 * p.excl_words;
 
-    const int ntile = (N + 63) / 64;
     const int tps = (ntile + p.n_jsplit - 1) / p.n_jsplit;
     const int t0 = js * tps, t1 = min(ntile, t0 + tps);
+    const int jbeg = t0 * 64, jend = min(t1 * 64, N);
+    float4 ci = make_float4(0.f, 0.f, 0.f, 0.f), hi = ci;
+    const bool cull = order != nullptr && itile < ntile;
+    if (cull) { ci = tile_c[(size_t)r * ntile + itile]; hi = tile_h[(size_t)r * ntile + itile]; }
     float fx = 0.f, fy = 0.f, fz = 0.f;
     double e = 0.0;
-    for (int tile = t0; tile < t1; ++tile) {
-        const int jb = tile * 64;
-        const int je = min(jb + 64, N);
-        const bool near = (jb + 63 >= i0 - half) && (jb <= i0 + 63 + half);
-        for (int j = jb; j < je; ++j) {
-            const float4 xj = P[j];                 // wave-uniform address -> scalar load
-            float4 pj = param[j];
-            float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
-            dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
-            const float r2 = dx * dx + dy * dy + dz * dz;
-            bool in = active && (r2 < p.rc2);
-            if (near) {
-                const int d = j - i + half;
-                if (d >= 0 && d < 2 * half) in = in && !((mk[d >> 6] >> (d & 63)) & 1ull);
+    for (int cb = jbeg; cb < jend; cb += NB_CHUNK) {
+        __syncthreads();                                     // previous chunk fully consumed
+        {
+            const int jj = min(cb + (tid & (NB_CHUNK - 1)), jend - 1);
+            if (tid < NB_CHUNK) s_pos[tid] = P[jj]; else s_prm[tid - NB_CHUNK] = param[jj];
+        }
+        __syncthreads();
+        const int cn = min(NB_CHUNK, jend - cb);
+        for (int tb = 0; tb < cn; tb += 64) {                // the chunk holds up to two j tiles
+            const int jb = cb + tb;
+            const int tn = min(64, cn - tb);
+            const bool near = (jb + 63 >= i0 - half) && (jb <= i0 + 63 + half);
+            if (cull) {
+                // tile-level cull: minimum distance between the two bounding boxes (minimum image) beyond the cutoff
+                const int jt = jb >> 6;
+                const float4 cj = tile_c[(size_t)r * ntile + jt], hj = tile_h[(size_t)r * ntile + jt];
+                float bx = cj.x - ci.x, by = cj.y - ci.y, bz = cj.z - ci.z;
+                bx -= Lx * rintf(bx * iLx); by -= Ly * rintf(by * iLy); bz -= Lz * rintf(bz * iLz);
+                bx = fmaxf(0.f, fabsf(bx) - hi.x - hj.x); by = fmaxf(0.f, fabsf(by) - hi.y - hj.y); bz = fmaxf(0.f, fabsf(bz) - hi.z - hj.z);
+                if (bx * bx + by * by + bz * bz > p.rc2) continue;
             }
-            if (in) {
-                if (ALCH && pj.w != 0.f) pj.x *= lam_e;
-                float fr, ee;
-                pair_interaction<METHOD, ALCH>(p, r2, pi, pj, lam_a, sc, fr, ENERGY, ee);
-                fx += fr * dx; fy += fr * dy; fz += fr * dz;
-                if (ENERGY) e += 0.5 * (double)ee;
+#pragma unroll 4
+            for (int u = 0; u < tn; ++u) {
+                const int j = jb + u;
+                const float4 xj = s_pos[tb + u];             // same address in every lane: LDS broadcast
+                float4 pj = s_prm[tb + u];
+                float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+                dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                bool in = active && (r2 < p.rc2);
+                if (near) {
+                    const int d = j - i + half;
+                    if (d >= 0 && d < 2 * half) in = in && !((mk[d >> 6] >> (d & 63)) & 1ull);
+                }
+                if (in) {
+                    if (ALCH && pj.w != 0.f) pj.x *= lam_e;
+                    float fr, ee;
+                    pair_interaction<METHOD, ALCH, !ENERGY>(p, r2, pi, pj, lam_a, sc, fr, ENERGY, ee);
+                    fx += fr * dx; fy += fr * dy; fz += fr * dz;
+                    if (ENERGY) e += 0.5 * (double)ee;
+                }
             }
         }
     }
     if (active) {
-        long long* F = force + (size_t)r * 3 * Npad;
-        if (p.n_jsplit == 1) {
-            F[i] += (long long)((double)fx * REMD_FORCE_SCALE);
-            F[Npad + i] += (long long)((double)fy * REMD_FORCE_SCALE);
-            F[2 * Npad + i] += (long long)((double)fz * REMD_FORCE_SCALE);
-        } else {
-            add_force(F, Npad, i, fx, fy, fz);
-        }
+        // every (i tile, j slice) wave owns one row of the partial-force buffer: plain coalesced stores, no atomics;
+        // nb_reduce_kernel folds the slices into the fixed-point accumulator in a fixed order
+        const int io = order ? order[(size_t)r * Npad + i] : i;      // back to the atom's own slot
+        partial[((size_t)r * p.n_jsplit + js) * Npad + io] = make_float4(fx, fy, fz, 0.f);
     }
     if (ENERGY) {
         e = wave_sum(e);
-        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + blockIdx.x * gridDim.y + js] = e;
+        if (lane == 0 && itile < ntile) epart[(size_t)r * n_epart + EP_NB0 + itile * p.n_jsplit + js] = e;
     }
+}
+
+__global__ __launch_bounds__(256)
+void nb_reduce_kernel(int N, int Npad, int nsplit, const float4* __restrict__ partial, long long* __restrict__ force)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (i >= N) return;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float4 f = partial[((size_t)r * nsplit + s) * Npad + i];
+        fx += f.x; fy += f.y; fz += f.z;
+    }
+    long long* F = force + (size_t)r * 3 * Npad;
+    F[i] += (long long)((double)fx * REMD_FORCE_SCALE);
+    F[Npad + i] += (long long)((double)fy * REMD_FORCE_SCALE);
+    F[2 * Npad + i] += (long long)((double)fz * REMD_FORCE_SCALE);
 }
 
 // 1-4 style exceptions with non-zero parameters: plain Coulomb + LJ, no cutoff, no switch
@@ -504,6 +835,8 @@ void remd_free_nonbonded(remd_ctx* h)
     nb_tables& t = it->second;
     dfree(t.d_param); dfree(t.d_mask); dfree(t.d_exc_atoms); dfree(t.d_exc_params); dfree(t.d_excl_atoms); dfree(t.d_excl_qq);
     dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
+    dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sparam); dfree(t.d_smask);
+    dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
     g_nb.erase(it);
 }
 
@@ -646,9 +979,44 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     p.alpha = (float)d->ewald_alpha; p.two_alpha_sqrtpi = (float)(2.0 * d->ewald_alpha / sqrt(M_PI));
     p.excl_words = words;
     const int ntile = (N + 63) / 64;
-    p.n_jsplit = std::max(1, std::min(ntile, 4));
+    {
+        const char* env = getenv("REMD_NB_JSPLIT");
+        int want = env ? atoi(env) : 4;
+        p.n_jsplit = std::max(1, std::min(std::min(ntile, 16), want));
+    }
     h->cutoff = d->cutoff; h->switch_dist = d->switch_distance; h->ewald_alpha = d->ewald_alpha;
     for (int k = 0; k < 3; ++k) h->grid[k] = d->pme_grid[k];
+
+    // groups: connected components of exclusions + constraints, made contiguous in index space
+    {
+        std::vector<int> parent(N);
+        for (int i = 0; i < N; ++i) parent[i] = i;
+        auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+        auto unite = [&](int a, int b) { a = find(a); b = find(b); if (a != b) parent[std::max(a, b)] = std::min(a, b); };
+        for (int e = 0; e < d->n_exceptions; ++e) unite(d->exception_atoms[2 * e], d->exception_atoms[2 * e + 1]);
+        for (int w = 0; w < d->n_settle; ++w) { unite(d->settle_atoms[3 * w], d->settle_atoms[3 * w + 1]); unite(d->settle_atoms[3 * w], d->settle_atoms[3 * w + 2]); }
+        for (int c = 0; c < d->n_shake; ++c) for (int k = 1; k < 4; ++k) if (d->shake_atoms[4 * c + k] >= 0) unite(d->shake_atoms[4 * c], d->shake_atoms[4 * c + k]);
+        // the root is the smallest index of a component; extend every component to the span [root, max member]
+        std::vector<int> hi(N);
+        for (int i = 0; i < N; ++i) hi[i] = i;
+        for (int i = 0; i < N; ++i) { const int rt = find(i); hi[rt] = std::max(hi[rt], i); }
+        std::vector<int> first, size;
+        int i = 0;
+        while (i < N) {
+            int end = hi[find(i)];
+            for (int k = i; k <= end; ++k) end = std::max(end, hi[find(k)]);   // merge interleaved components
+            first.push_back(i); size.push_back(end - i + 1);
+            i = end + 1;
+        }
+        t.n_groups = (int)first.size();
+        if ((rc = upload(h, t.d_grp_first, first)) || (rc = upload(h, t.d_grp_size, size))) return rc;
+        const char* env = getenv("REMD_NB_SORT");
+        t.sorting = !(env && atoi(env) == 0);
+        const char* env3 = getenv("REMD_NB_CLUSTERS");
+        t.clusters = !(env3 && atoi(env3) == 0);
+        const char* env2 = getenv("REMD_NB_RESORT");
+        if (env2) t.resort_interval = std::max(1, atoi(env2));
+    }
 
     // dispersion correction of the (possibly alchemically modified) NonbondedForce
     t.disp_coeff = 0.0;
@@ -685,17 +1053,100 @@ static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
     return 0;
 }
 
+static int ensure_sorted(remd_ctx* h, nb_tables& t)
+{
+    if (!t.sorting || t.n_groups <= 0 || t.n_groups >= 8192) return 0;
+    const int ntile = (h->N + 63) / 64;
+    if (t.sort_R != h->R) {
+        dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sparam); dfree(t.d_smask); dfree(t.d_tile_c); dfree(t.d_tile_h);
+        const size_t n = (size_t)h->R * h->Npad;
+        REMD_CHECK(h, hipMalloc(&t.d_order, sizeof(int) * n));
+        REMD_CHECK(h, hipMalloc(&t.d_spos, sizeof(float4) * n));
+        REMD_CHECK(h, hipMalloc(&t.d_sparam, sizeof(float4) * n));
+        REMD_CHECK(h, hipMalloc(&t.d_smask, sizeof(unsigned long long) * n * t.p.excl_words));
+        REMD_CHECK(h, hipMalloc(&t.d_tile_c, sizeof(float4) * (size_t)h->R * ntile));
+        REMD_CHECK(h, hipMalloc(&t.d_tile_h, sizeof(float4) * (size_t)h->R * ntile));
+        dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
+        const int ncl = ntile * 8;
+        t.cl_cap = std::min(ncl, 1024);
+        REMD_CHECK(h, hipMalloc(&t.d_cl_c, sizeof(float4) * (size_t)h->R * ncl));
+        REMD_CHECK(h, hipMalloc(&t.d_cl_h, sizeof(float4) * (size_t)h->R * ncl));
+        REMD_CHECK(h, hipMalloc(&t.d_cl_list, sizeof(unsigned short) * (size_t)h->R * ncl * t.cl_cap));
+        REMD_CHECK(h, hipMalloc(&t.d_cl_count, sizeof(int) * (size_t)h->R * ncl));
+        t.sort_R = h->R; t.evals_since_sort = 1 << 30;
+    }
+    if (t.evals_since_sort >= t.resort_interval) {
+        remd_prof_scope ps(h, "nb_sort");
+        const size_t lds = sizeof(int) * 4 * (size_t)t.n_groups;
+        hipLaunchKernelGGL(sort_groups_kernel, dim3(h->R), dim3(1024), lds, h->stream, t.n_groups, h->N, h->Npad, t.d_grp_first,
+                           t.d_grp_size, h->d_pos, h->d_box, 0.45f, t.d_order);
+        hipLaunchKernelGGL(gather_params_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.p.excl_words,
+                           t.d_order, t.d_param, t.d_mask, t.d_sparam, t.d_smask);
+        t.evals_since_sort = 0;
+    }
+    t.evals_since_sort++;
+    {
+        remd_prof_scope ps(h, "nb_gather");
+        const bool cl = t.clusters && ntile * 8 < 65536;
+        hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, t.d_order, h->d_pos, h->d_box,
+                           t.d_spos, t.d_tile_c, t.d_tile_h, cl ? t.d_cl_c : (float4*)nullptr, cl ? t.d_cl_h : (float4*)nullptr);
+        if (cl) {
+            const int ncl = ntile * 8;
+            hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl, h->R), dim3(64), 0, h->stream, ncl, t.cl_cap, t.p.rc2, t.d_cl_c,
+                               t.d_cl_h, h->d_box, t.d_cl_list, t.d_cl_count);
+            if (t.evals_since_sort == 1 && (t.cl_cap < ncl || getenv("REMD_DEBUG"))) {
+                // capacity check once per re-sort (the only host synchronisation of this path)
+                std::vector<int> cnt((size_t)h->R * ncl);
+                REMD_CHECK(h, hipMemcpyAsync(cnt.data(), t.d_cl_count, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, h->stream));
+                REMD_CHECK(h, hipStreamSynchronize(h->stream));
+                int mx = 0; for (int c : cnt) mx = std::max(mx, c);
+                if (getenv("REMD_DEBUG")) {
+                    double mean = 0; for (int c : cnt) mean += c; mean /= cnt.size();
+                    std::vector<float4> hh((size_t)h->R * ncl);
+                    hipMemcpy(hh.data(), t.d_cl_h, sizeof(float4) * hh.size(), hipMemcpyDeviceToHost);
+                    double hx = 0; int nh = 0; for (auto& v : hh) if (v.x >= 0) { hx += v.x + v.y + v.z; nh++; }
+                    fprintf(stderr, "[remd] cluster list: ncl %d mean neighbours %.1f max %d cap %d mean half-extent %.3f nm\n", ncl, mean, mx, t.cl_cap, hx / (3.0 * nh));
+                }
+                if (mx > t.cl_cap) t.clusters = false;        // fall back to the tile kernel
+            }
+        }
+    }
+    return 0;
+}
+
 template <int METHOD, bool ENERGY>
 static void launch_nb(remd_ctx* h, nb_tables& t)
 {
     const int ntile = (h->N + 63) / 64;
-    dim3 grid(ntile, t.p.n_jsplit, h->R);
+    if (t.sorting && t.clusters && t.d_order && t.d_cl_list && t.n_groups > 0 && t.n_groups < 8192 && ntile * 8 < 65536) {
+        const int ncl = ntile * 8;
+        dim3 grid(ncl, h->R);
+        if (t.has_alch)
+            hipLaunchKernelGGL((nonbonded_cluster_kernel<METHOD, ENERGY, true>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl,
+                               t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box, t.d_rep_lam,
+                               h->d_force, h->d_epart, h->n_epart);
+        else
+            hipLaunchKernelGGL((nonbonded_cluster_kernel<METHOD, ENERGY, false>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl,
+                               t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box,
+                               (const float*)nullptr, h->d_force, h->d_epart, h->n_epart);
+        return;
+    }
+    dim3 grid((ntile + NB_WAVES - 1) / NB_WAVES, t.p.n_jsplit, h->R);
+    const size_t need = (size_t)h->R * t.p.n_jsplit * h->Npad;
+    if (t.partial_n < need) { dfree(t.d_partial); if (hipMalloc(&t.d_partial, sizeof(float4) * need) != hipSuccess) return; t.partial_n = need; }
+    const bool sorted = t.sorting && t.d_order && t.n_groups > 0 && t.n_groups < 8192;
+    const float4* P = sorted ? t.d_spos : h->d_pos;
+    const float4* prm = sorted ? t.d_sparam : t.d_param;
+    const unsigned long long* mk = sorted ? t.d_smask : t.d_mask;
+    const int* ord = sorted ? t.d_order : nullptr;
     if (t.has_alch)
-        hipLaunchKernelGGL((nonbonded_kernel<METHOD, ENERGY, true>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, h->d_pos,
-                           t.d_param, t.d_mask, h->d_box, t.d_rep_lam, h->d_force, h->d_epart, h->n_epart);
+        hipLaunchKernelGGL((nonbonded_kernel<METHOD, ENERGY, true>), grid, dim3(64 * NB_WAVES), 0, h->stream, t.p, h->N, h->Npad, P,
+                           prm, mk, ord, t.d_tile_c, t.d_tile_h, h->d_box, t.d_rep_lam, t.d_partial, h->d_epart, h->n_epart, ntile);
     else
-        hipLaunchKernelGGL((nonbonded_kernel<METHOD, ENERGY, false>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, h->d_pos,
-                           t.d_param, t.d_mask, h->d_box, (const float*)nullptr, h->d_force, h->d_epart, h->n_epart);
+        hipLaunchKernelGGL((nonbonded_kernel<METHOD, ENERGY, false>), grid, dim3(64 * NB_WAVES), 0, h->stream, t.p, h->N, h->Npad, P,
+                           prm, mk, ord, t.d_tile_c, t.d_tile_h, h->d_box, (const float*)nullptr, t.d_partial, h->d_epart, h->n_epart, ntile);
+    hipLaunchKernelGGL(nb_reduce_kernel, dim3((h->N + 255) / 256, h->R), dim3(256), 0, h->stream, h->N, h->Npad, t.p.n_jsplit,
+                       t.d_partial, h->d_force);
 }
 
 const float* remd_nb_rep_lam(remd_ctx* h)
@@ -708,7 +1159,7 @@ const float4* remd_nb_param(remd_ctx* h) { return g_nb[h].d_param; }
 int remd_nb_required_epart(remd_ctx* h)
 {
     const int ntile = (h->Npad + 63) / 64;
-    return EP_NB0 + ntile * 4 + 8;
+    return EP_NB0 + ntile * 16 + 8;
 }
 
 int remd_compute_forces(remd_ctx* h, bool with_energy)
@@ -742,6 +1193,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         nb_tables& t = g_nb[h];
         int rc = update_replica_lambdas(h, t);
         if (rc) return rc;
+        if ((rc = ensure_sorted(h, t))) return rc;
         {
             remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {

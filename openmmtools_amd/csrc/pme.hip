@@ -89,7 +89,7 @@ __device__ __forceinline__ void bfly5(float2* v)
 // unit-stride index (lines when ls == 1, butterflies when es == 1) so LDS accesses stay conflict-light.
 template <int SIGN>
 __device__ float2* fft_lines_lds(const fft_plan& pl, float2* src, float2* dst, int nlines, int ls, int es,
-                                 const float2* __restrict__ tw, int tid, int nthreads)
+                                 const float2* __restrict__ tw, int tid, int nthreads, bool lines_fastest = false)
 {
     const int n = pl.n;
     const unsigned mlines = fft_magic((unsigned)nlines);
@@ -102,7 +102,7 @@ __device__ float2* fft_lines_lds(const fft_plan& pl, float2* src, float2* dst, i
         const unsigned mnb = pl.mnb[s], mNs = pl.mNs[s];
         for (int idx = tid; idx < total; idx += nthreads) {
             int l, j;
-            if (ls == 1) { j = fft_div(idx, mlines, nlines); l = idx - j * nlines; }
+            if (ls == 1 || lines_fastest) { j = fft_div(idx, mlines, nlines); l = idx - j * nlines; }
             else { l = fft_div(idx, mnb, nb); j = idx - l * nb; }
             const int jq = fft_div(j, mNs, Ns);
             const int k = j - jq * Ns;
@@ -335,20 +335,23 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nx = plx.n, ny = ply.n, nzc = nz / 2 + 1;
     const int np = nx * ny;
+    const int PS = ny + 1;                                // padded row stride: bank-conflict-free column access
+    const int npp = nx * PS;
     float2* bufA = reinterpret_cast<float2*>(smem);
-    float2* bufB = bufA + np;
-    float2* s_twx = bufB + np;                           // twiddle tables staged in LDS
+    float2* bufB = bufA + npp;
+    float2* s_twx = bufB + npp;                          // twiddle tables staged in LDS
     float2* s_twy = s_twx + nx;
     const int kz = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
     float2* P = spec + ((size_t)r * nzc + kz) * np;
-    for (int idx = tid; idx < np; idx += XY_THREADS) bufA[idx] = P[idx];
+    const unsigned mny = fft_magic((unsigned)ny);
+    for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); bufA[idx + x] = P[idx]; }   // x*PS + y
     for (int idx = tid; idx < nx; idx += XY_THREADS) s_twx[idx] = twx[idx];
     for (int idx = tid; idx < ny; idx += XY_THREADS) s_twy[idx] = twy[idx];
     twx = s_twx; twy = s_twy;
     __syncthreads();
-    float2* res = fft_lines_lds<-1>(ply, bufA, bufB, nx, ny, 1, twy, tid, XY_THREADS);          // along y
+    float2* res = fft_lines_lds<-1>(ply, bufA, bufB, nx, PS, 1, twy, tid, XY_THREADS, true);    // along y
     float2* oth = (res == bufA) ? bufB : bufA;
-    res = fft_lines_lds<-1>(plx, res, oth, ny, 1, ny, twx, tid, XY_THREADS);                    // along x
+    res = fft_lines_lds<-1>(plx, res, oth, ny, 1, PS, twx, tid, XY_THREADS, true);              // along x
     oth = (res == bufA) ? bufB : bufA;
     {
         const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
@@ -360,15 +363,15 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
         const float wz = (kz == 0 || 2 * kz == nz) ? 1.f : 2.f;     // Hermitian half: weight of the mirrored plane
         double e_acc = 0.0;
         for (int idx = tid; idx < np; idx += XY_THREADS) {
-            const int kx = idx / ny, ky = idx - kx * ny;
+            const int kx = fft_div(idx, mny, ny), ky = idx - kx * ny;
             const int m0 = (kx <= nx / 2) ? kx : kx - nx, m1 = (ky <= ny / 2) ? ky : ky - ny;
             const float mx = m0 / Lx, my = m1 / Ly;
             const float msq = mx * mx + my * my + mz * mz;
             float g = 0.f;
             if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
-            const float2 sv = res[idx];
+            const float2 sv = res[idx + kx];                    // kx*PS + ky
             if (with_energy) e_acc += 0.5 * (double)(wz * g) * ((double)sv.x * sv.x + (double)sv.y * sv.y);
-            res[idx] = make_float2(sv.x * g, sv.y * g);
+            res[idx + kx] = make_float2(sv.x * g, sv.y * g);
         }
         __syncthreads();
         if (with_energy) {
@@ -384,10 +387,10 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
             __syncthreads();
         }
     }
-    res = fft_lines_lds<+1>(plx, res, oth, ny, 1, ny, twx, tid, XY_THREADS);
+    res = fft_lines_lds<+1>(plx, res, oth, ny, 1, PS, twx, tid, XY_THREADS, true);
     oth = (res == bufA) ? bufB : bufA;
-    res = fft_lines_lds<+1>(ply, res, oth, nx, ny, 1, twy, tid, XY_THREADS);
-    for (int idx = tid; idx < np; idx += XY_THREADS) P[idx] = res[idx];
+    res = fft_lines_lds<+1>(ply, res, oth, nx, PS, 1, twy, tid, XY_THREADS, true);
+    for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); P[idx] = res[idx + x]; }
 }
 
 // MODE 0: plain pass.  (kept for the 3-D FFT test hook and as the fall-back for planes larger than the LDS)
@@ -624,7 +627,7 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     }
     s->n_eblk = s->nzc;
     REMD_CHECK(h, hipMalloc(&s->d_energy, sizeof(double) * (size_t)s->n_eblk * s->R));
-    s->xy_lds = sizeof(float2) * (2 * (size_t)s->n[0] * s->n[1] + s->n[0] + s->n[1]);
+    s->xy_lds = sizeof(float2) * (2 * (size_t)s->n[0] * (s->n[1] + 1) + s->n[0] + s->n[1]);
     s->xy_fused = s->xy_lds <= 160 * 1024;
     if (s->xy_fused)
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
