@@ -104,14 +104,16 @@ __device__ __forceinline__ void settle_velocities(float imA, float imB, float im
     v[2] = v[2] + (eCA * tCA - eBC * tBC) * imC;
 }
 
-// SHAKE for a star cluster (central atom 0 bonded to atoms 1..n-1): p0 old constrained
-// positions, p1 unconstrained new positions (both relative to the old central atom).
-__device__ __forceinline__ void shake_positions(int n, const float* im, const float* d, float tol,
-                                                const float3* p0, float3* p1)
+// SHAKE for a star cluster (central atom 0 bonded to atoms 1..NAT-1): p0 old constrained positions, p1
+// unconstrained new positions (both relative to the old central atom).  NAT is a compile-time constant so that
+// every array lives in registers (no scratch).
+template <int NAT>
+__device__ __forceinline__ void shake_positions(const float* im, const float* d, float tol, const float3* p0, float3* p1)
 {
     for (int it = 0; it < 24; ++it) {
         bool conv = true;
-        for (int k = 1; k < n; ++k) {
+#pragma unroll
+        for (int k = 1; k < NAT; ++k) {
             const float3 r0 = p0[k] - p0[0];
             const float3 r = p1[k] - p1[0];
             const float d2 = d[k - 1] * d[k - 1];
@@ -127,12 +129,14 @@ __device__ __forceinline__ void shake_positions(int n, const float* im, const fl
     }
 }
 
-__device__ __forceinline__ void shake_velocities(int n, const float* im, float tol, const float3* p, float3* v)
+template <int NAT>
+__device__ __forceinline__ void shake_velocities(const float* im, float tol, const float3* p, float3* v)
 {
     // converged when the bond-length rate is below tol relative to |r| |v| (fp32 noise floor ~1e-7 |r||v|)
     for (int it = 0; it < 16; ++it) {
         bool conv = true;
-        for (int k = 1; k < n; ++k) {
+#pragma unroll
+        for (int k = 1; k < NAT; ++k) {
             const float3 r = p[k] - p[0];
             const float3 dv = v[k] - v[0];
             const float r2 = dot3(r, r);
@@ -148,28 +152,112 @@ __device__ __forceinline__ void shake_velocities(int n, const float* im, float t
     }
 }
 
-struct unit_regs {
-    int type, n;
-    int idx[4];
-    float3 x[4];     // absolute positions
-    float3 v[4];
-    float im[4];
-    float d[3];
-};
-
-__device__ __forceinline__ void constrain_v(const unit_regs& u, const settle_const& sc, float tol, float3* v, const float3* x)
+template <int TYPE, int NAT>
+__device__ __forceinline__ void constrain_v(const settle_const& sc, const float* im, float tol, float3* v, const float3* x)
 {
-    if (u.type == UNIT_SETTLE) {
+    if (TYPE == UNIT_SETTLE) {
         float3 p[3] = { f3(0, 0, 0), x[1] - x[0], x[2] - x[0] };
-        settle_velocities(u.im[0], u.im[1], u.im[2], p, v);
-    } else if (u.type == UNIT_SHAKE) {
-        float3 p[4];
-        for (int k = 0; k < u.n; ++k) p[k] = x[k] - x[0];
-        shake_velocities(u.n, u.im, tol, p, v);
+        settle_velocities(im[0], im[1], im[2], p, v);
+    } else if (TYPE == UNIT_SHAKE) {
+        float3 p[NAT];
+#pragma unroll
+        for (int k = 0; k < NAT; ++k) p[k] = x[k] - x[0];
+        shake_velocities<NAT>(im, tol, p, v);
     }
 }
 
-__global__ __launch_bounds__(64)
+__device__ __forceinline__ float3 gaussian3(uint64_t seed, uint32_t stream, uint32_t atom, uint32_t replica, uint64_t t)
+{
+    philox4 w = remd_philox(seed, stream, atom, replica, t);
+    const float r1 = sqrtf(-2.f * __logf(remd_u23(w.w[0])));
+    const float r2 = sqrtf(-2.f * __logf(remd_u23(w.w[2])));
+    float s1, c1, s2, c2;
+    __sincosf(6.2831853071795865f * remd_u23(w.w[1]), &s1, &c1);
+    __sincosf(6.2831853071795865f * remd_u23(w.w[3]), &s2, &c2);
+    (void)s2;
+    return f3(r1 * c1, r1 * s1, r2 * c2);
+}
+
+// the whole chain of substeps for one constraint unit, everything in registers
+template <int TYPE, int NAT>
+__device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* idx, const float* dist, const settle_const& sc,
+                                          float tol, int Npad, float4* __restrict__ P, float4* __restrict__ V,
+                                          const long long* __restrict__ F, const float* __restrict__ invmass, float kT,
+                                          uint32_t rg, uint64_t seed, const long long* __restrict__ cmm_r, float inv_total_mass)
+{
+    float3 x[NAT], v[NAT];
+    float im[NAT];
+#pragma unroll
+    for (int k = 0; k < NAT; ++k) {
+        const float4 p = P[idx[k]], w = V[idx[k]];
+        x[k] = f3(p.x, p.y, p.z); v[k] = f3(w.x, w.y, w.z);
+        im[k] = invmass[idx[k]];
+    }
+    for (int t = 0; t < prog.n; ++t) {
+        const char tok = prog.tok[t];
+        if (tok == 'V') {
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) {
+                const float s = prog.hV * im[k] * (1.0f / 4294967296.0f);
+                v[k].x += s * (float)F[idx[k]];
+                v[k].y += s * (float)F[Npad + idx[k]];
+                v[k].z += s * (float)F[2 * Npad + idx[k]];
+            }
+            constrain_v<TYPE, NAT>(sc, im, tol, v, x);
+        } else if (tok == 'R') {
+            if (TYPE == UNIT_FREE) {
+                x[0] = x[0] + v[0] * prog.hR;
+            } else {
+                // relative coordinates (origin = old position of atom 0) keep fp32 precision
+                float3 p0[NAT], p1[NAT], q[NAT];
+#pragma unroll
+                for (int k = 0; k < NAT; ++k) {
+                    p0[k] = x[k] - x[0];
+                    p1[k] = p0[k] + v[k] * prog.hR;
+                    q[k] = p1[k];
+                }
+                if (TYPE == UNIT_SETTLE) settle_positions(sc, p0, p1);
+                else shake_positions<NAT>(im, dist, tol, p0, p1);
+                const float ih = 1.f / prog.hR;
+                const float3 org = x[0];
+#pragma unroll
+                for (int k = 0; k < NAT; ++k) {
+                    v[k] = v[k] + (p1[k] - q[k]) * ih;          // integrators.py:1417
+                    x[k] = org + p1[k];
+                }
+                constrain_v<TYPE, NAT>(sc, im, tol, v, x);
+            }
+        } else if (tok == 'O') {
+            const uint64_t cnt = (uint64_t)prog.step[t] * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) {
+                const float3 xi = gaussian3(seed, REMD_STREAM_OU, (uint32_t)idx[k], rg, cnt);
+                const float sig = prog.b * sqrtf(kT * im[k]);
+                v[k].x = prog.a * v[k].x + sig * xi.x;
+                v[k].y = prog.a * v[k].y + sig * xi.y;
+                v[k].z = prog.a * v[k].z + sig * xi.z;
+            }
+            constrain_v<TYPE, NAT>(sc, im, tol, v, x);
+        } else if (tok == 'C') {
+            // CMMotionRemover: v -= P/M with P accumulated by the previous chain
+            const float sx = (float)cmm_r[0] * (1.0f / 4294967296.0f) * inv_total_mass;
+            const float sy = (float)cmm_r[1] * (1.0f / 4294967296.0f) * inv_total_mass;
+            const float sz = (float)cmm_r[2] * (1.0f / 4294967296.0f) * inv_total_mass;
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) { v[k].x -= sx; v[k].y -= sy; v[k].z -= sz; }
+        }
+    }
+    float3 mom = f3(0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NAT; ++k) {
+        P[idx[k]] = make_float4(x[k].x, x[k].y, x[k].z, 0.f);
+        V[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
+        mom = mom + v[k] * (1.f / im[k]);
+    }
+    return mom;
+}
+
+__global__ __launch_bounds__(256)
 void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict__ unit_atoms,
                             const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist,
                             settle_const sc, float tol,
@@ -181,99 +269,28 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     float3 mom = f3(0, 0, 0);
-    const bool live = uidx < n_units && unit_atoms[uidx < n_units ? uidx : 0].x >= 0;   // padding units do nothing
-    if (live) {
-        unit_regs u;
-        const int4 a4 = unit_atoms[uidx];
-        u.idx[0] = a4.x; u.idx[1] = a4.y; u.idx[2] = a4.z; u.idx[3] = a4.w;
-        u.type = unit_type[uidx];
-        u.n = (a4.x < 0) ? 0 : (a4.y < 0) ? 1 : (a4.z < 0) ? 2 : (a4.w < 0) ? 3 : 4;   // n = 0: padding unit
+    const int4 a4 = (uidx < n_units) ? unit_atoms[uidx] : make_int4(-1, -1, -1, -1);
+    if (a4.x >= 0) {                                            // padding units do nothing
+        const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
+        const int type = unit_type[uidx];
+        float dist[3] = { 0.f, 0.f, 0.f };
+        if (type == UNIT_SHAKE) { dist[0] = shake_dist[uidx * 3]; dist[1] = shake_dist[uidx * 3 + 1]; dist[2] = shake_dist[uidx * 3 + 2]; }
         float4* P = pos + (size_t)r * Npad;
         float4* V = vel + (size_t)r * Npad;
         const long long* F = force + (size_t)r * 3 * Npad;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < u.n) {
-            const float4 p = P[u.idx[k]], w = V[u.idx[k]];
-            u.x[k] = f3(p.x, p.y, p.z); u.v[k] = f3(w.x, w.y, w.z);
-            u.im[k] = invmass[u.idx[k]];
-        }
-        if (u.type == UNIT_SHAKE) for (int k = 0; k < 3; ++k) u.d[k] = shake_dist[uidx * 3 + k];
         const float kT = (float)(1.0 / beta[labels[r_begin + r]]);
         const uint32_t rg = (uint32_t)(r_begin + r);
-
-        for (int t = 0; t < prog.n; ++t) {
-            const char tok = prog.tok[t];
-            if (tok == 'V') {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (k < u.n) {
-                    const float s = prog.hV * u.im[k] * (1.0f / 4294967296.0f);
-                    u.v[k].x += s * (float)F[u.idx[k]];
-                    u.v[k].y += s * (float)F[Npad + u.idx[k]];
-                    u.v[k].z += s * (float)F[2 * Npad + u.idx[k]];
-                }
-                constrain_v(u, sc, tol, u.v, u.x);
-            } else if (tok == 'R') {
-                if (u.type == UNIT_FREE) {
-                    if (u.n > 0) u.x[0] = u.x[0] + u.v[0] * prog.hR;
-                } else {
-                    // relative coordinates (origin = old position of atom 0) keep fp32 precision
-                    float3 p0[4], p1[4], q[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (k < u.n) {
-                        p0[k] = u.x[k] - u.x[0];
-                        p1[k] = p0[k] + u.v[k] * prog.hR;
-                        q[k] = p1[k];
-                    }
-                    if (u.type == UNIT_SETTLE) settle_positions(sc, p0, p1);
-                    else shake_positions(u.n, u.im, u.d, tol, p0, p1);
-                    const float ih = 1.f / prog.hR;
-                    const float3 org = u.x[0];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (k < u.n) {
-                        u.v[k] = u.v[k] + (p1[k] - q[k]) * ih;          // integrators.py:1417
-                        u.x[k] = org + p1[k];
-                    }
-                    constrain_v(u, sc, tol, u.v, u.x);
-                }
-            } else if (tok == 'O') {
-                const uint64_t cnt = (uint64_t)prog.step[t] * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (k < u.n) {
-                    philox4 w = remd_philox(seed, REMD_STREAM_OU, (uint32_t)u.idx[k], rg, cnt);
-                    const float r1 = sqrtf(-2.f * __logf(remd_u23(w.w[0])));
-                    const float r2 = sqrtf(-2.f * __logf(remd_u23(w.w[2])));
-                    float s1, c1, s2, c2;
-                    __sincosf(6.2831853071795865f * remd_u23(w.w[1]), &s1, &c1);
-                    __sincosf(6.2831853071795865f * remd_u23(w.w[3]), &s2, &c2);
-                    const float sig = prog.b * sqrtf(kT * u.im[k]);
-                    u.v[k].x = prog.a * u.v[k].x + sig * (r1 * c1);
-                    u.v[k].y = prog.a * u.v[k].y + sig * (r1 * s1);
-                    u.v[k].z = prog.a * u.v[k].z + sig * (r2 * c2);
-                    (void)s2;
-                }
-                constrain_v(u, sc, tol, u.v, u.x);
-            } else if (tok == 'C') {
-                // CMMotionRemover: v -= P/M with P accumulated by the previous chain
-                const long long* c = cmm + (size_t)r * 4;
-                const float sx = (float)c[0] * (1.0f / 4294967296.0f) * inv_total_mass;
-                const float sy = (float)c[1] * (1.0f / 4294967296.0f) * inv_total_mass;
-                const float sz = (float)c[2] * (1.0f / 4294967296.0f) * inv_total_mass;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (k < u.n) { u.v[k].x -= sx; u.v[k].y -= sy; u.v[k].z -= sz; }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < u.n) {
-            P[u.idx[k]] = make_float4(u.x[k].x, u.x[k].y, u.x[k].z, 0.f);
-            V[u.idx[k]] = make_float4(u.v[k].x, u.v[k].y, u.v[k].z, 0.f);
-            if (prog.accumulate_momentum) {
-                const float m = 1.f / u.im[k];
-                mom = mom + u.v[k] * m;
-            }
-        }
+        const long long* cr = cmm + (size_t)r * 4;
+#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, invmass, kT, rg, seed, cr, inv_total_mass)
+        if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
+        else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
+        else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
+        else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
+        else RUN(UNIT_SHAKE, 4);
+#undef RUN
     }
     if (prog.accumulate_momentum) {
-        // wavefront shuffle reduction, one fixed-point atomic per wave (deterministic sum)
+        // wavefront shuffle reduction, one fixed-point atomic per wave (integer => order-independent sum)
         for (int off = 32; off > 0; off >>= 1) {
             mom.x += __shfl_xor(mom.x, off); mom.y += __shfl_xor(mom.y, off); mom.z += __shfl_xor(mom.z, off);
         }
@@ -287,7 +304,28 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
 }
 
 // Maxwell-Boltzmann velocities (mcmc.py:710-711): v = sqrt(kT/m) xi, then velocity constraints.
-__global__ __launch_bounds__(64)
+template <int TYPE, int NAT>
+__device__ __forceinline__ void assign_unit(const int* idx, const settle_const& sc, float tol, const float4* __restrict__ P,
+                                            float4* __restrict__ V, const float* __restrict__ invmass, float kT, uint32_t rg,
+                                            uint64_t seed, int64_t iteration)
+{
+    float3 x[NAT], v[NAT];
+    float im[NAT];
+#pragma unroll
+    for (int k = 0; k < NAT; ++k) {
+        const float4 p = P[idx[k]];
+        x[k] = f3(p.x, p.y, p.z);
+        im[k] = invmass[idx[k]];
+        const float3 xi = gaussian3(seed, REMD_STREAM_VELOCITY, (uint32_t)idx[k], rg, (uint64_t)iteration);
+        const float sig = sqrtf(kT * im[k]);
+        v[k] = xi * sig;
+    }
+    constrain_v<TYPE, NAT>(sc, im, tol, v, x);
+#pragma unroll
+    for (int k = 0; k < NAT; ++k) V[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
+}
+
+__global__ __launch_bounds__(256)
 void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
                               const unsigned char* __restrict__ unit_type, settle_const sc, float tol,
                               int Npad, const float4* __restrict__ pos, float4* __restrict__ vel,
@@ -297,33 +335,19 @@ void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (uidx >= n_units) return;
-    unit_regs u;
     const int4 a4 = unit_atoms[uidx];
     if (a4.x < 0) return;
-    u.idx[0] = a4.x; u.idx[1] = a4.y; u.idx[2] = a4.z; u.idx[3] = a4.w;
-    u.type = unit_type[uidx];
-    u.n = (a4.x < 0) ? 0 : (a4.y < 0) ? 1 : (a4.z < 0) ? 2 : (a4.w < 0) ? 3 : 4;
+    const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
+    const int type = unit_type[uidx];
     const float4* P = pos + (size_t)r * Npad;
     float4* V = vel + (size_t)r * Npad;
     const float kT = (float)(1.0 / beta[labels[r_begin + r]]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (k < u.n) {
-        const float4 p = P[u.idx[k]];
-        u.x[k] = f3(p.x, p.y, p.z);
-        u.im[k] = invmass[u.idx[k]];
-        philox4 w = remd_philox(seed, REMD_STREAM_VELOCITY, (uint32_t)u.idx[k], (uint32_t)(r_begin + r), (uint64_t)iteration);
-        const float r1 = sqrtf(-2.f * __logf(remd_u23(w.w[0])));
-        const float r2 = sqrtf(-2.f * __logf(remd_u23(w.w[2])));
-        float s1, c1, s2, c2;
-        __sincosf(6.2831853071795865f * remd_u23(w.w[1]), &s1, &c1);
-        __sincosf(6.2831853071795865f * remd_u23(w.w[3]), &s2, &c2);
-        const float sig = sqrtf(kT * u.im[k]);
-        u.v[k] = f3(sig * r1 * c1, sig * r1 * s1, sig * r2 * c2);
-        (void)s2;
-    }
-    constrain_v(u, sc, tol, u.v, u.x);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (k < u.n) V[u.idx[k]] = make_float4(u.v[k].x, u.v[k].y, u.v[k].z, 0.f);
+    const uint32_t rg = (uint32_t)(r_begin + r);
+    if (type == UNIT_SETTLE) assign_unit<UNIT_SETTLE, 3>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
+    else if (type == UNIT_FREE) assign_unit<UNIT_FREE, 1>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
+    else if (a4.z < 0) assign_unit<UNIT_SHAKE, 2>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
+    else if (a4.w < 0) assign_unit<UNIT_SHAKE, 3>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
+    else assign_unit<UNIT_SHAKE, 4>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
 }
 
 // KE = sum 1/2 m v^2 per replica: per-lane partial -> wave shuffle -> LDS -> one value per block,
@@ -451,8 +475,8 @@ int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& 
 static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog)
 {
     remd_prof_scope ps(h, "integrate_chain");
-    dim3 grid((ut.n_units + 63) / 64, h->R);
-    hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(64), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
+    dim3 grid((ut.n_units + 255) / 256, h->R);
+    hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0));
@@ -515,8 +539,8 @@ int remd_assign_velocities(remd_ctx* h, int64_t iteration)
 {
     const unit_tables& ut = g_units[h];
     remd_prof_scope ps(h, "assign_velocities");
-    dim3 grid((ut.n_units + 63) / 64, h->R);
-    hipLaunchKernelGGL(assign_velocities_kernel, grid, dim3(64), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc,
+    dim3 grid((ut.n_units + 255) / 256, h->R);
+    hipLaunchKernelGGL(assign_velocities_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc,
                        (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_invmass, h->d_labels,
                        h->d_beta, h->r_begin, h->seed, iteration);
     REMD_CHECK(h, hipGetLastError());
