@@ -232,6 +232,103 @@ void torsion_kernel(int n, const int* __restrict__ atoms, const float* __restric
     if (ENERGY) { e = block_sum_256(e, s_part); if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_TORSION] = e; }
 }
 
+// All short "listed" terms of one force evaluation in a single launch (force-only path): harmonic bonds, angles,
+// periodic torsions, non-zero exceptions and the Ewald exclusion correction.  One term per thread.
+struct listed_tables {
+    int n_bonds, n_angles, n_torsions, n_exc, n_excl;
+    const int *bond_atoms, *angle_atoms, *torsion_atoms, *exc_atoms, *excl_atoms;
+    const float *bond_params, *angle_params, *torsion_params, *exc_params, *excl_qq;
+    float alpha, two_alpha_sqrtpi;
+};
+
+__global__ __launch_bounds__(256)
+void listed_forces_kernel(listed_tables T, int Npad, const float4* __restrict__ pos, const float* __restrict__ box,
+                          long long* __restrict__ force)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    const float4* P = pos + (size_t)r * Npad;
+    long long* F = force + (size_t)r * 3 * Npad;
+    if (t < T.n_bonds) {
+        const int i = T.bond_atoms[2 * t], j = T.bond_atoms[2 * t + 1];
+        const float r0 = T.bond_params[2 * t], k = T.bond_params[2 * t + 1];
+        const float3 d = sub3(ld3(P, j), ld3(P, i));
+        const float len = sqrtf(dotf(d, d));
+        const float fs = k * (len - r0) / len;
+        add_force(F, Npad, i, fs * d.x, fs * d.y, fs * d.z);
+        add_force(F, Npad, j, -fs * d.x, -fs * d.y, -fs * d.z);
+        return;
+    }
+    t -= T.n_bonds;
+    if (t < T.n_angles) {
+        const int a = T.angle_atoms[3 * t], b = T.angle_atoms[3 * t + 1], c = T.angle_atoms[3 * t + 2];
+        const float th0 = T.angle_params[2 * t], k = T.angle_params[2 * t + 1];
+        const float3 v0 = sub3(ld3(P, a), ld3(P, b)), v1 = sub3(ld3(P, c), ld3(P, b));
+        const float3 cp = crs3(v0, v1);
+        const float rp = fmaxf(sqrtf(dotf(cp, cp)), 1e-6f);
+        const float r20 = dotf(v0, v0), r21 = dotf(v1, v1);
+        const float cosine = fminf(fmaxf(dotf(v0, v1) * rsqrtf(r20 * r21), -1.f), 1.f);
+        const float dEdth = k * (acosf(cosine) - th0);
+        const float3 fa = scl3(crs3(v0, cp), -dEdth / (r20 * rp));
+        const float3 fc = scl3(crs3(cp, v1), -dEdth / (r21 * rp));
+        add_force(F, Npad, a, fa.x, fa.y, fa.z);
+        add_force(F, Npad, c, fc.x, fc.y, fc.z);
+        add_force(F, Npad, b, -(fa.x + fc.x), -(fa.y + fc.y), -(fa.z + fc.z));
+        return;
+    }
+    t -= T.n_angles;
+    if (t < T.n_torsions) {
+        const int a1 = T.torsion_atoms[4 * t], a2 = T.torsion_atoms[4 * t + 1], a3 = T.torsion_atoms[4 * t + 2], a4 = T.torsion_atoms[4 * t + 3];
+        const float per = T.torsion_params[3 * t], phase = T.torsion_params[3 * t + 1], k = T.torsion_params[3 * t + 2];
+        const float3 p1 = ld3(P, a1), p2 = ld3(P, a2), p3 = ld3(P, a3), p4 = ld3(P, a4);
+        const float3 b1 = sub3(p2, p1), b2 = sub3(p3, p2), b3 = sub3(p4, p3);
+        const float3 m = crs3(b1, b2), nn = crs3(b2, b3);
+        const float m2 = fmaxf(dotf(m, m), 1e-12f), n2 = fmaxf(dotf(nn, nn), 1e-12f);
+        const float lb2 = sqrtf(dotf(b2, b2));
+        const float phi = atan2f(lb2 * dotf(b1, nn), dotf(m, nn));
+        const float dEdphi = -k * per * sinf(per * phi - phase);
+        const float3 g1 = scl3(m, -lb2 / m2);
+        const float3 g4 = scl3(nn, lb2 / n2);
+        const float s12 = dotf(b1, b2) / (lb2 * lb2), s32 = dotf(b3, b2) / (lb2 * lb2);
+        const float3 g2 = add3(scl3(g1, -(1.f + s12)), scl3(g4, s32));
+        const float3 g3 = add3(scl3(g4, -(1.f + s32)), scl3(g1, s12));
+        add_force(F, Npad, a1, -dEdphi * g1.x, -dEdphi * g1.y, -dEdphi * g1.z);
+        add_force(F, Npad, a2, -dEdphi * g2.x, -dEdphi * g2.y, -dEdphi * g2.z);
+        add_force(F, Npad, a3, -dEdphi * g3.x, -dEdphi * g3.y, -dEdphi * g3.z);
+        add_force(F, Npad, a4, -dEdphi * g4.x, -dEdphi * g4.y, -dEdphi * g4.z);
+        return;
+    }
+    t -= T.n_torsions;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    if (t < T.n_exc) {
+        const int i = T.exc_atoms[2 * t], j = T.exc_atoms[2 * t + 1];
+        const float qq = T.exc_params[3 * t], sig = T.exc_params[3 * t + 1], eps = T.exc_params[3 * t + 2];
+        float3 d = sub3(ld3(P, j), ld3(P, i));
+        if (Lx > 0.f) { d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz); }
+        const float r2 = dotf(d, d);
+        const float inv_r = rsqrtf(r2);
+        const float s2 = sig * sig * inv_r * inv_r, s6 = s2 * s2 * s2;
+        const float fr = (4.f * eps * s6 * (6.f - 12.f * s6) * inv_r - qq * inv_r * inv_r) * inv_r;
+        add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
+        add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
+        return;
+    }
+    t -= T.n_exc;
+    if (t < T.n_excl) {
+        const int i = T.excl_atoms[2 * t], j = T.excl_atoms[2 * t + 1];
+        const float qq = T.excl_qq[t];
+        float3 d = sub3(ld3(P, j), ld3(P, i));
+        d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz);
+        const float r2 = dotf(d, d);
+        const float inv_r = rsqrtf(r2);
+        const float ar = T.alpha * r2 * inv_r;
+        const float erf_ar = erff(ar);
+        const float fr = -qq * (T.two_alpha_sqrtpi * __expf(-ar * ar) * inv_r - erf_ar * inv_r * inv_r) * inv_r;
+        add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
+        add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
+    }
+}
+
 // ---- nonbonded pair arithmetic -------------------------------------------------------------------
 __device__ __forceinline__ void switch_fn(const nb_params& p, float r, float& U, float& dUdr)
 {
@@ -1174,17 +1271,38 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
                  h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
     }
-    if (h->n_bonds > 0) {
+    const bool merged = !with_energy;      // force-only evaluations: every listed term in one launch
+    if (merged) {
+        listed_tables T{};
+        T.n_bonds = h->n_bonds; T.n_angles = h->n_angles; T.n_torsions = h->n_torsions;
+        T.bond_atoms = h->d_bond_atoms; T.bond_params = h->d_bond_params;
+        T.angle_atoms = h->d_angle_atoms; T.angle_params = h->d_angle_params;
+        T.torsion_atoms = h->d_torsion_atoms; T.torsion_params = h->d_torsion_params;
+        auto it = g_nb.find(h);
+        if (it != g_nb.end() && h->nb_method != REMD_NB_NONE) {
+            nb_tables& t = it->second;
+            T.n_exc = t.n_exc; T.exc_atoms = t.d_exc_atoms; T.exc_params = t.d_exc_params;
+            T.n_excl = t.n_excl; T.excl_atoms = t.d_excl_atoms; T.excl_qq = t.d_excl_qq;
+            T.alpha = t.p.alpha; T.two_alpha_sqrtpi = t.p.two_alpha_sqrtpi;
+        }
+        const int total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
+        if (total > 0) {
+            remd_prof_scope ps(h, "bonded");
+            hipLaunchKernelGGL(listed_forces_kernel, dim3((total + 255) / 256, R), dim3(256), 0, h->stream, T, h->Npad, h->d_pos,
+                               h->d_box, h->d_force);
+        }
+    }
+    if (!merged && h->n_bonds > 0) {
         remd_prof_scope ps(h, "bonded");
         LAUNCH_E(bond_kernel, dim3(R), dim3(256), 0, h->stream, h->n_bonds, h->d_bond_atoms, h->d_bond_params, h->Npad,
                  h->d_pos, h->d_force, h->d_epart, h->n_epart);
     }
-    if (h->n_angles > 0) {
+    if (!merged && h->n_angles > 0) {
         remd_prof_scope ps(h, "bonded");
         LAUNCH_E(angle_kernel, dim3(R), dim3(256), 0, h->stream, h->n_angles, h->d_angle_atoms, h->d_angle_params, h->Npad,
                  h->d_pos, h->d_force, h->d_epart, h->n_epart);
     }
-    if (h->n_torsions > 0) {
+    if (!merged && h->n_torsions > 0) {
         remd_prof_scope ps(h, "bonded");
         LAUNCH_E(torsion_kernel, dim3(R), dim3(256), 0, h->stream, h->n_torsions, h->d_torsion_atoms, h->d_torsion_params, h->Npad,
                  h->d_pos, h->d_force, h->d_epart, h->n_epart);
@@ -1206,12 +1324,12 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
                 else launch_nb<NB_EWALD, false>(h, t);
             }
         }
-        if (t.n_exc > 0) {
+        if (!merged && t.n_exc > 0) {
             remd_prof_scope ps(h, "exceptions");
             LAUNCH_E(exception_kernel, dim3(R), dim3(256), 0, h->stream, t.n_exc, t.d_exc_atoms, t.d_exc_params, h->Npad,
                      h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);
         }
-        if (t.n_excl > 0) {
+        if (!merged && t.n_excl > 0) {
             remd_prof_scope ps(h, "exceptions");
             LAUNCH_E(ewald_exclusion_kernel, dim3(R), dim3(256), 0, h->stream, t.n_excl, t.d_excl_atoms, t.d_excl_qq, t.p.alpha,
                      t.p.two_alpha_sqrtpi, h->Npad, h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);

@@ -33,16 +33,19 @@ __global__ __launch_bounds__(64)
 void mix_swap_all_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
                          const double* __restrict__ g_ukl, int64_t* __restrict__ g_labels,
                          unsigned long long* __restrict__ g_nacc, unsigned long long* __restrict__ g_nprop,
-                         int64_t n_attempts, int ukl_in_lds)
+                         int64_t n_attempts, int ukl_in_lds, int stats_in_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* s_u = reinterpret_cast<double*>(smem);
-    int* s_lab = reinterpret_cast<int*>(smem + (ukl_in_lds ? (size_t)R * K * sizeof(double) : 0));
+    volatile int* s_lab = reinterpret_cast<int*>(smem + (ukl_in_lds ? (size_t)R * K * sizeof(double) : 0));
+    unsigned* s_nprop = reinterpret_cast<unsigned*>(const_cast<int*>(s_lab) + ((R + 1) & ~1));   // [K*K] when stats_in_lds
+    unsigned* s_nacc = s_nprop + K * K;
     const int lane = threadIdx.x;
 
     if (ukl_in_lds)
         for (int t = lane; t < R * K; t += 64) s_u[t] = g_ukl[(size_t)(t / K) * ld + (t % K)];
     for (int t = lane; t < R; t += 64) s_lab[t] = (int)g_labels[t];
+    if (stats_in_lds) for (int t = lane; t < 2 * K * K; t += 64) s_nprop[t] = 0u;
     __syncthreads();
     const double* U = ukl_in_lds ? s_u : g_ukl;
     const int ldu = ukl_in_lds ? K : ld;
@@ -59,8 +62,8 @@ void mix_swap_all_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
         unsigned long long dep = 0ull;
 #pragma unroll 8
         for (int m = 0; m < 64; ++m) {
-            const int im = __shfl(i, m);
-            const int jm = __shfl(j, m);
+            const int im = __builtin_amdgcn_readlane(i, m);
+            const int jm = __builtin_amdgcn_readlane(j, m);
             const bool c = (m < lane) && (im == i || im == j || jm == i || jm == j);
             dep |= (unsigned long long)c << m;
         }
@@ -70,21 +73,27 @@ void mix_swap_all_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
             if (ready) {
                 const int si = s_lab[i], sj = s_lab[j];                                  // :328-329
                 const double log_p = mix_logp(U, ldu, i, j, si, sj);                     // :332-336
-                atomicAdd(&g_nprop[(size_t)si * K + sj], 1ull);                          // :339
-                atomicAdd(&g_nprop[(size_t)sj * K + si], 1ull);                          // :340
-                if (log_p >= 0.0 || u < remd_exp_det(log_p)) {                           // :343
-                    s_lab[i] = sj;                                                       // :345
-                    s_lab[j] = si;                                                       // :346
-                    atomicAdd(&g_nacc[(size_t)si * K + sj], 1ull);                       // :348
-                    atomicAdd(&g_nacc[(size_t)sj * K + si], 1ull);                       // :349
+                const bool acc = log_p >= 0.0 || u < remd_exp_det(log_p);                // :343
+                if (acc) { s_lab[i] = sj; s_lab[j] = si; }                               // :345-346
+                if (stats_in_lds) {
+                    atomicAdd(&s_nprop[si * K + sj], 1u); atomicAdd(&s_nprop[sj * K + si], 1u);          // :339-340
+                    if (acc) { atomicAdd(&s_nacc[si * K + sj], 1u); atomicAdd(&s_nacc[sj * K + si], 1u); }   // :348-349
+                } else {
+                    atomicAdd(&g_nprop[(size_t)si * K + sj], 1ull); atomicAdd(&g_nprop[(size_t)sj * K + si], 1ull);
+                    if (acc) { atomicAdd(&g_nacc[(size_t)si * K + sj], 1ull); atomicAdd(&g_nacc[(size_t)sj * K + si], 1ull); }
                 }
             }
-            __syncthreads();
+            // single wavefront: LDS operations retire in program order, so the next round's label reads see this
+            // round's writes; only the compiler must not move them (volatile labels + scheduling barrier).  No
+            // s_waitcnt vmcnt here: the fire-and-forget global counter atomics must not stall the chain.
+            __builtin_amdgcn_wave_barrier();
             done |= __ballot(ready);
         }
     }
     __syncthreads();
     for (int t = lane; t < R; t += 64) g_labels[t] = (int64_t)s_lab[t];
+    if (stats_in_lds)
+        for (int t = lane; t < K * K; t += 64) { g_nprop[t] = s_nprop[t]; g_nacc[t] = s_nacc[t]; }
 }
 
 // replicaexchange.py:366-380 — neighbouring STATE pairs (s, s+1), s = offset, offset+2, ...
@@ -186,14 +195,18 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         if (R != K) return remd_fail(h, -3, "swap-all requires n_replicas == n_states");
         if (n_attempts < 0) n_attempts = (int64_t)R * R * R;                                   // :269
         size_t ukl_bytes = (size_t)R * K * sizeof(double);
+        const size_t lab_bytes = sizeof(int) * (size_t)((R + 1) & ~1);
+        const size_t stat_bytes = sizeof(unsigned) * 2 * (size_t)K * K;
+        // counters (32-bit: <= 2 R^3 per entry) live in LDS when everything fits in 160 KB, else global atomics
         int in_lds = ukl_bytes <= MIX_MAX_LDS_UKL;
-        size_t lds = (in_lds ? ukl_bytes : 0) + sizeof(int) * R;
+        int stats_lds = ((in_lds ? ukl_bytes : 0) + lab_bytes + stat_bytes <= 156 * 1024) && (2.0 * (double)n_attempts < 4.0e9);
+        size_t lds = (in_lds ? ukl_bytes : 0) + lab_bytes + (stats_lds ? stat_bytes : 0);
         lds = (lds + 15) & ~(size_t)15;
         REMD_CHECK(h, hipFuncSetAttribute((const void*)mix_swap_all_kernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         remd_prof_scope ps(h, "mix_swap_all");
         hipLaunchKernelGGL(mix_swap_all_kernel, dim3(1), dim3(64), lds, h->stream,
-                           h->seed, iteration, R, K, ld, d_ukl, d_labels, d_nacc, d_nprop, n_attempts, in_lds);
+                           h->seed, iteration, R, K, ld, d_ukl, d_labels, d_nacc, d_nprop, n_attempts, in_lds, stats_lds);
     } else if (scheme == REMD_MIX_SWAP_NEIGHBORS) {
         if (R != K) return remd_fail(h, -3, "swap-neighbors requires n_replicas == n_states");
         size_t lds = sizeof(int) * (size_t)(R + K);

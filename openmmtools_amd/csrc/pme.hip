@@ -28,7 +28,7 @@ struct pme_state {
     size_t npts = 0;
     int* d_mesh = nullptr;             // [R][nx][ny][nz] 32-bit fixed-point charge mesh; reused as the float potential mesh
     float2* d_grid = nullptr;          // [R][nz/2+1][nx][ny] half spectrum, kz-major (or the full complex grid of the test hook)
-    int nzc = 0; size_t nspec = 0; size_t xy_lds = 0; bool xy_fused = false;
+    int nzc = 0; size_t nspec = 0; size_t xy_lds = 0; bool xy_fused = false; int xy_threads = 512;
     int* d_col_count = nullptr; int* d_col_start = nullptr; int* d_cursor = nullptr; int* d_atom_col = nullptr; int* d_col_atoms = nullptr;
     float2* d_tw[3] = {nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i k / n)
     float* d_bmod[3] = {nullptr, nullptr, nullptr};  // |b(m)|^-2 ... stored as B-spline moduli squared inverse
@@ -131,6 +131,74 @@ __device__ float2* fft_lines_lds(const fft_plan& pl, float2* src, float2* dst, i
     return src;
 }
 
+// ---- in-place variant: every thread keeps its share of the points in registers across the barrier, so only ONE
+// LDS image of the data is needed (half the footprint of the ping-pong version => more workgroups per CU).
+template <int SIGN, int RX> __device__ __forceinline__ void bfly(float2* v)
+{
+    if (RX == 2) bfly2<SIGN>(v); else if (RX == 3) bfly3<SIGN>(v); else if (RX == 4) bfly4<SIGN>(v); else bfly5<SIGN>(v);
+}
+
+template <int SIGN, int RX, int PPT>
+__device__ __forceinline__ void fft_stage_inplace(float2* buf, int n, int nlines, int ls, int es, int Ns, int s,
+                                                  unsigned mlines, unsigned mnb, unsigned mNs,
+                                                  const float2* __restrict__ tw, int tid, int nthreads, bool lines_fastest)
+{
+    constexpr int NB = (PPT + RX - 1) / RX;
+    float2 v[NB][RX];
+    int dst[NB];
+    const int nb = n / RX;
+    const int total = nlines * nb;
+    const int tstride = n / (Ns * RX);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int idx = tid + b * nthreads;
+        dst[b] = -1;
+        if (idx < total) {
+            int l, j;
+            if (ls == 1 || lines_fastest) { j = fft_div(idx, mlines, nlines); l = idx - j * nlines; }
+            else { l = fft_div(idx, mnb, nb); j = idx - l * nb; }
+            const int jq = fft_div(j, mNs, Ns);
+            const int k = j - jq * Ns;
+            const int tstep = k * tstride;
+            const float2* S = buf + l * ls;
+#pragma unroll
+            for (int r = 0; r < RX; ++r) {
+                v[b][r] = S[(j + r * nb) * es];
+                if (s > 0 && r > 0) {
+                    float2 w = tw[tstep * r];
+                    if (SIGN > 0) w.y = -w.y;
+                    v[b][r] = cmul(v[b][r], w);
+                }
+            }
+            bfly<SIGN, RX>(v[b]);
+            dst[b] = l * ls + (jq * Ns * RX + k) * es;
+        }
+    }
+    __syncthreads();                                         // every input of this stage is in registers
+#pragma unroll
+    for (int b = 0; b < NB; ++b) if (dst[b] >= 0) {
+#pragma unroll
+        for (int r = 0; r < RX; ++r) buf[dst[b] + r * Ns * es] = v[b][r];
+    }
+    __syncthreads();
+}
+
+template <int SIGN, int PPT>
+__device__ void fft_lines_inplace(const fft_plan& pl, float2* buf, int nlines, int ls, int es,
+                                  const float2* __restrict__ tw, int tid, int nthreads, bool lines_fastest)
+{
+    const unsigned mlines = fft_magic((unsigned)nlines);
+    int Ns = 1;
+    for (int s = 0; s < pl.nrad; ++s) {
+        const int Rx = pl.radix[s];
+        if (Rx == 4) fft_stage_inplace<SIGN, 4, PPT>(buf, pl.n, nlines, ls, es, Ns, s, mlines, pl.mnb[s], pl.mNs[s], tw, tid, nthreads, lines_fastest);
+        else if (Rx == 5) fft_stage_inplace<SIGN, 5, PPT>(buf, pl.n, nlines, ls, es, Ns, s, mlines, pl.mnb[s], pl.mNs[s], tw, tid, nthreads, lines_fastest);
+        else if (Rx == 3) fft_stage_inplace<SIGN, 3, PPT>(buf, pl.n, nlines, ls, es, Ns, s, mlines, pl.mnb[s], pl.mNs[s], tw, tid, nthreads, lines_fastest);
+        else fft_stage_inplace<SIGN, 2, PPT>(buf, pl.n, nlines, ls, es, Ns, s, mlines, pl.mnb[s], pl.mNs[s], tw, tid, nthreads, lines_fastest);
+        Ns *= Rx;
+    }
+}
+
 #define PME_MESH_SCALE 16777216.0f     // 2^24: 32-bit fixed-point charge mesh, |sum| < 128
 
 // order-5 cardinal B-spline weights and derivatives: w[j] = M5(f + j), d[j] = M5'(f + j), j = 0..4,
@@ -221,40 +289,41 @@ void pme_bin_fill_kernel(int N, int Npad, int ncol, const int* __restrict__ atom
     col_atoms[(size_t)r * Npad + slot] = i;             // order inside a column is irrelevant: integer accumulation
 }
 
-// fused spreading + forward z FFT.  Workgroup = FFT_B lines (x, y0..y0+7).  Charges are accumulated in LDS as
-// 32-bit fixed point (order-independent => bit-reproducible), converted to complex f32 and transformed.
-__global__ __launch_bounds__(256)
+#define Z_THREADS 512
+#define Z_PPT 12             // points per thread in registers: nl * nz <= Z_PPT * Z_THREADS
+
+// fused spreading + forward z FFT.  Workgroup = nl lines (x, y0..y0+nl-1), nl a divisor of ny (the whole row when it
+// fits).  Charges are accumulated in LDS as 32-bit fixed point (order-independent => bit-reproducible), converted to
+// complex f32 and transformed in place; the half spectrum is written kz-major in runs of nl points.
+__global__ __launch_bounds__(Z_THREADS)
 void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const float4* __restrict__ pos,
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms,
                             float2* __restrict__ spec, const float2* tw)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nz = pl.n, nzc = nz / 2 + 1;
-    float2* bufA = reinterpret_cast<float2*>(smem);
-    float2* bufB = bufA + nl * nz;
-    int* acc = reinterpret_cast<int*>(bufB);            // nl * nz ints, reuses the second FFT buffer
-    float2* s_tw = bufB + nl * nz;
-    for (int idx = threadIdx.x; idx < nz; idx += 256) s_tw[idx] = tw[idx];
-    tw = s_tw;
+    const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz + 1;
+    float2* buf = reinterpret_cast<float2*>(smem);          // [nl][PZ]
+    float2* s_tw = buf + nl * PZ;                           // [nz]
+    int* acc = reinterpret_cast<int*>(s_tw + nz);           // [nl][nz]
     const int r = blockIdx.y, tid = threadIdx.x;
     const int l0 = blockIdx.x * nl;
     const int x = l0 / ny, y0 = l0 % ny;
     const int ncol = nx * ny;
-    for (int idx = tid; idx < nl * nz; idx += 256) acc[idx] = 0;
+    for (int idx = tid; idx < nl * nz; idx += Z_THREADS) acc[idx] = 0;
+    for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     __syncthreads();
     const int* cs = col_start + (size_t)r * (ncol + 1);
     const int* ca = col_atoms + (size_t)r * Npad;
     const float4* P = pos + (size_t)r * Npad;
-    // candidate columns: kx in {x .. x+4} (stencil index a = kx - x), ky in [y0, y0 + nl + 3]
+    // candidate columns: kx in {x .. x+4} (stencil index a = kx - x), ky in [y0, y0 + nl + 3] (periodic)
     for (int a = 0; a < 5; ++a) {
         int kxc = x + a; if (kxc >= nx) kxc -= nx;
         for (int seg = 0; seg < 2; ++seg) {
-            // ky range [y0, y0+nl+4) split at the periodic wrap
-            int kb = y0, ke = y0 + nl + 4;
+            int kb = y0, ke = min(y0 + nl + 4, y0 + ny);        // never more than one full period
             if (seg == 0) ke = min(ke, ny); else { if (ke <= ny) break; kb = 0; ke -= ny; }
             const int abeg = cs[kxc * ny + kb], aend = cs[kxc * ny + ke];
-            for (int t = abeg + tid; t < aend; t += 256) {
+            for (int t = abeg + tid; t < aend; t += Z_THREADS) {
                 const int i = ca[t];
                 const float4 pr = param[i];
                 float q = pr.x;
@@ -285,48 +354,57 @@ void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < nl * nz; idx += 256)
-        bufA[idx] = make_float2((float)acc[idx] * (1.0f / PME_MESH_SCALE), 0.f);
+    const unsigned mnz = fft_magic((unsigned)nz);
+    for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
+        const int l = fft_div(idx, mnz, nz);
+        buf[idx + l] = make_float2((float)acc[idx] * (1.0f / PME_MESH_SCALE), 0.f);     // l*PZ + z
+    }
     __syncthreads();
-    float2* res = fft_lines_lds<-1>(pl, bufA, bufB, nl, nz, 1, tw, tid, 256);
+    fft_lines_inplace<-1, Z_PPT>(pl, buf, nl, PZ, 1, s_tw, tid, Z_THREADS, true);
     float2* S = spec + (size_t)r * nzc * nx * ny;
-    for (int idx = tid; idx < nl * nzc; idx += 256) {
-        const int kz = idx / nl, b = idx % nl;
-        S[((size_t)kz * nx + x) * ny + y0 + b] = res[b * nz + kz];
+    const unsigned mnl = fft_magic((unsigned)nl);
+    for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
+        const int kz = fft_div(idx, mnl, nl), b = idx - kz * nl;
+        S[((size_t)kz * nx + x) * ny + y0 + b] = buf[b * PZ + kz];
     }
 }
 
-// inverse z: half spectrum -> FFT_B real lines (Hermitian completion in LDS), written as float mesh[x][y][z]
-__global__ __launch_bounds__(256)
+// inverse z: half spectrum -> nl real lines (Hermitian completion in LDS), written as float mesh[x][y][z]
+__global__ __launch_bounds__(Z_THREADS)
 void pme_zinv_kernel(fft_plan pl, int nl, int nx, int ny, const float2* __restrict__ spec, float* __restrict__ mesh,
                      const float2* tw)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nz = pl.n, nzc = nz / 2 + 1;
-    float2* bufA = reinterpret_cast<float2*>(smem);
-    float2* bufB = bufA + nl * nz;
-    float2* s_tw = bufB + nl * nz;
-    for (int idx = threadIdx.x; idx < nz; idx += 256) s_tw[idx] = tw[idx];
-    tw = s_tw;
+    const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz + 1;
+    float2* buf = reinterpret_cast<float2*>(smem);
+    float2* s_tw = buf + nl * PZ;
     const int r = blockIdx.y, tid = threadIdx.x;
     const int l0 = blockIdx.x * nl;
     const int x = l0 / ny, y0 = l0 % ny;
+    for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     const float2* S = spec + (size_t)r * nzc * nx * ny;
-    for (int idx = tid; idx < nl * nzc; idx += 256) {
-        const int kz = idx / nl, b = idx % nl;
+    const unsigned mnl = fft_magic((unsigned)nl);
+    for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
+        const int kz = fft_div(idx, mnl, nl), b = idx - kz * nl;
         const float2 v = S[((size_t)kz * nx + x) * ny + y0 + b];
-        bufA[b * nz + kz] = v;
-        if (kz > 0 && kz < nz - kz) bufA[b * nz + nz - kz] = make_float2(v.x, -v.y);
+        buf[b * PZ + kz] = v;
+        if (kz > 0 && kz < nz - kz) buf[b * PZ + nz - kz] = make_float2(v.x, -v.y);
     }
     __syncthreads();
-    float2* res = fft_lines_lds<+1>(pl, bufA, bufB, nl, nz, 1, tw, tid, 256);
+    fft_lines_inplace<+1, Z_PPT>(pl, buf, nl, PZ, 1, s_tw, tid, Z_THREADS, true);
     float* M = mesh + (size_t)r * nx * ny * nz + (size_t)l0 * nz;
-    for (int idx = tid; idx < nl * nz; idx += 256) M[idx] = res[idx].x;
+    const unsigned mnz = fft_magic((unsigned)nz);
+    for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
+        const int l = fft_div(idx, mnz, nz);
+        M[idx] = buf[idx + l].x;
+    }
 }
 
-// one (kz, replica) plane resident in LDS: forward y, forward x, influence function (+ energy), inverse x, inverse y
-#define XY_THREADS 1024
-__global__ __launch_bounds__(XY_THREADS)
+// one (kz, replica) plane resident in LDS: forward y, forward x, influence function (+ energy), inverse x, inverse y.
+// In-place stages: LDS = nx (ny+1) 8 B (52 KB for 80 x 80) => three workgroups per CU overlap their load / FFT / store.
+#define XY_MAX_THREADS 1024
+#define XY_PPT 13            // points per thread held in registers: nx * ny <= XY_PPT * XY_THREADS
+__global__ __launch_bounds__(XY_MAX_THREADS)
 void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict__ spec,
                          const float2* twx, const float2* twy,
                          const float* __restrict__ bmx, const float* __restrict__ bmy, const float* __restrict__ bmz,
@@ -337,22 +415,29 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
     const int np = nx * ny;
     const int PS = ny + 1;                                // padded row stride: bank-conflict-free column access
     const int npp = nx * PS;
-    float2* bufA = reinterpret_cast<float2*>(smem);
-    float2* bufB = bufA + npp;
-    float2* s_twx = bufB + npp;                          // twiddle tables staged in LDS
+    float2* buf = reinterpret_cast<float2*>(smem);
+    float2* s_twx = buf + npp;                           // twiddle tables staged in LDS
     float2* s_twy = s_twx + nx;
+    double* s_e = reinterpret_cast<double*>(s_twy + ny);
     const int kz = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    const int XY_THREADS = blockDim.x;                   // 512 (two workgroups per CU) or 1024 for larger planes
     float2* P = spec + ((size_t)r * nzc + kz) * np;
     const unsigned mny = fft_magic((unsigned)ny);
-    for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); bufA[idx + x] = P[idx]; }   // x*PS + y
+    {
+        // 16-byte global loads (two complex points), rows are even-length
+        const float4* P4 = reinterpret_cast<const float4*>(P);
+        for (int idx = tid; idx < np / 2; idx += XY_THREADS) {
+            const float4 q = P4[idx];
+            const int e = 2 * idx, x = fft_div(e, mny, ny);
+            buf[e + x] = make_float2(q.x, q.y); buf[e + x + 1] = make_float2(q.z, q.w);
+        }
+    }
     for (int idx = tid; idx < nx; idx += XY_THREADS) s_twx[idx] = twx[idx];
     for (int idx = tid; idx < ny; idx += XY_THREADS) s_twy[idx] = twy[idx];
     twx = s_twx; twy = s_twy;
     __syncthreads();
-    float2* res = fft_lines_lds<-1>(ply, bufA, bufB, nx, PS, 1, twy, tid, XY_THREADS, true);    // along y
-    float2* oth = (res == bufA) ? bufB : bufA;
-    res = fft_lines_lds<-1>(plx, res, oth, ny, 1, PS, twx, tid, XY_THREADS, true);              // along x
-    oth = (res == bufA) ? bufB : bufA;
+    fft_lines_inplace<-1, XY_PPT>(ply, buf, nx, PS, 1, twy, tid, XY_THREADS, true);     // along y
+    fft_lines_inplace<-1, XY_PPT>(plx, buf, ny, 1, PS, twx, tid, XY_THREADS, true);     // along x
     {
         const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
         const double V = (double)Lx * Ly * Lz;
@@ -369,13 +454,11 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
             const float msq = mx * mx + my * my + mz * mz;
             float g = 0.f;
             if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
-            const float2 sv = res[idx + kx];                    // kx*PS + ky
+            const float2 sv = buf[idx + kx];                    // kx*PS + ky
             if (with_energy) e_acc += 0.5 * (double)(wz * g) * ((double)sv.x * sv.x + (double)sv.y * sv.y);
-            res[idx + kx] = make_float2(sv.x * g, sv.y * g);
+            buf[idx + kx] = make_float2(sv.x * g, sv.y * g);
         }
-        __syncthreads();
         if (with_energy) {
-            double* s_e = reinterpret_cast<double*>(oth);
             for (int off = 32; off > 0; off >>= 1) e_acc += __shfl_xor(e_acc, off);
             if ((tid & 63) == 0) s_e[tid >> 6] = e_acc;
             __syncthreads();
@@ -384,13 +467,19 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
                 for (int w = 0; w < XY_THREADS / 64; ++w) tot += s_e[w];
                 energy[(size_t)r * n_eblk + kz] = tot;
             }
-            __syncthreads();
+        }
+        __syncthreads();
+    }
+    fft_lines_inplace<+1, XY_PPT>(plx, buf, ny, 1, PS, twx, tid, XY_THREADS, true);
+    fft_lines_inplace<+1, XY_PPT>(ply, buf, nx, PS, 1, twy, tid, XY_THREADS, true);
+    {
+        float4* P4 = reinterpret_cast<float4*>(P);
+        for (int idx = tid; idx < np / 2; idx += XY_THREADS) {
+            const int e = 2 * idx, x = fft_div(e, mny, ny);
+            const float2 a = buf[e + x], c = buf[e + x + 1];
+            P4[idx] = make_float4(a.x, a.y, c.x, c.y);
         }
     }
-    res = fft_lines_lds<+1>(plx, res, oth, ny, 1, PS, twx, tid, XY_THREADS, true);
-    oth = (res == bufA) ? bufB : bufA;
-    res = fft_lines_lds<+1>(ply, res, oth, nx, PS, 1, twy, tid, XY_THREADS, true);
-    for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); P[idx] = res[idx + x]; }
 }
 
 // MODE 0: plain pass.  (kept for the 3-D FFT test hook and as the fall-back for planes larger than the LDS)
@@ -627,8 +716,9 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     }
     s->n_eblk = s->nzc;
     REMD_CHECK(h, hipMalloc(&s->d_energy, sizeof(double) * (size_t)s->n_eblk * s->R));
-    s->xy_lds = sizeof(float2) * (2 * (size_t)s->n[0] * (s->n[1] + 1) + s->n[0] + s->n[1]);
-    s->xy_fused = s->xy_lds <= 160 * 1024;
+    s->xy_lds = sizeof(float2) * ((size_t)s->n[0] * (s->n[1] + 1) + s->n[0] + s->n[1]) + 128;
+    s->xy_threads = ((size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * 512) ? 512 : 1024;
+    s->xy_fused = (size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * s->xy_threads && s->xy_lds <= 160 * 1024;
     if (s->xy_fused)
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
     REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -671,14 +761,14 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, double* d_energy)
     }
     {
         remd_prof_scope ps(h, "pme_fft");
-        int nl = 8;                                   // lines per workgroup: the largest divisor of ny that is <= 32
-        for (int c = 8; c <= 32; ++c) if (ny % c == 0) nl = c;
-        const size_t zlds = sizeof(float2) * (2 * nl * nz + nz);
+        int nl = 1;                                   // lines per workgroup: largest divisor of ny whose points fit the registers
+        for (int c = 1; c <= ny; ++c) if (ny % c == 0 && c * nz <= Z_PPT * Z_THREADS) nl = c;
+        const size_t zlds = sizeof(float2) * ((size_t)nl * (nz + 1) + nz) + sizeof(int) * (size_t)nl * nz;
         const dim3 zgrid(nx * ny / nl, s->R);
-        hipLaunchKernelGGL(pme_spread_zfwd_kernel, zgrid, dim3(256), zlds, h->stream, make_plan(s, 2), nl, nx, ny, h->Npad, h->d_pos,
+        hipLaunchKernelGGL(pme_spread_zfwd_kernel, zgrid, dim3(Z_THREADS), zlds, h->stream, make_plan(s, 2), nl, nx, ny, h->Npad, h->d_pos,
                            param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
         if (s->xy_fused) {
-            hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(XY_THREADS), s->xy_lds, h->stream, make_plan(s, 0), make_plan(s, 1),
+            hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, h->stream, make_plan(s, 0), make_plan(s, 1),
                                nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
                                (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);
         } else {
@@ -690,7 +780,8 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, double* d_energy)
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         }
-        hipLaunchKernelGGL(pme_zinv_kernel, zgrid, dim3(256), zlds, h->stream, make_plan(s, 2), nl, nx, ny, s->d_grid,
+        const size_t zlds_inv = sizeof(float2) * ((size_t)nl * (nz + 1) + nz);
+        hipLaunchKernelGGL(pme_zinv_kernel, zgrid, dim3(Z_THREADS), zlds_inv, h->stream, make_plan(s, 2), nl, nx, ny, s->d_grid,
                            reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
     }
     {
