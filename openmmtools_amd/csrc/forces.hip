@@ -55,6 +55,10 @@ struct nb_tables {
     float4* d_param = nullptr;            // [Npad] (q*sqrt(k_e), sigma/2, 2*sqrt(eps), alchemical flag)
     unsigned long long* d_mask = nullptr; // [Npad][excl_words]
     int n_exc = 0; int* d_exc_atoms = nullptr; float* d_exc_params = nullptr;     // nonzero exceptions
+    int* d_exc_alch = nullptr; int* d_excl_alch = nullptr;   // number of alchemical atoms in each pair (0, 1, 2)
+    double lam_e_override = -1.0;         // >= 0: evaluate every replica at this lambda_electrostatics (u_kl probes)
+    double self_nn = 0, self_aa = 0, q_n = 0, q_a = 0;   // Ewald self / net-charge pieces (non-alchemical, alchemical)
+    double* d_probe = nullptr; int probe_R = 0;            // [3][R] potentials at lambda_e = 0, 1/2, 1
     int n_excl = 0; int* d_excl_atoms = nullptr; float* d_excl_qq = nullptr;      // all excluded pairs (Ewald correction)
     float* d_rep_lam = nullptr;           // [R][4] per replica: lambda_s^a, alpha (1-lambda_s)^b, lambda_e, pad
     int rep_lam_R = 0;
@@ -238,6 +242,7 @@ struct listed_tables {
     int n_bonds, n_angles, n_torsions, n_exc, n_excl;
     const int *bond_atoms, *angle_atoms, *torsion_atoms, *exc_atoms, *excl_atoms;
     const float *bond_params, *angle_params, *torsion_params, *exc_params, *excl_qq;
+    const int *exc_alch, *excl_alch; const float* rep_lam;
     float alpha, two_alpha_sqrtpi;
 };
 
@@ -302,7 +307,9 @@ void listed_forces_kernel(listed_tables T, int Npad, const float4* __restrict__ 
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     if (t < T.n_exc) {
         const int i = T.exc_atoms[2 * t], j = T.exc_atoms[2 * t + 1];
-        const float qq = T.exc_params[3 * t], sig = T.exc_params[3 * t + 1], eps = T.exc_params[3 * t + 2];
+        float qq = T.exc_params[3 * t];
+        const float sig = T.exc_params[3 * t + 1], eps = T.exc_params[3 * t + 2];
+        if (T.rep_lam && T.exc_alch[t] > 0) qq *= T.rep_lam[4 * r + 2];      // alchemy.py:1964-1966 exception offset
         float3 d = sub3(ld3(P, j), ld3(P, i));
         if (Lx > 0.f) { d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz); }
         const float r2 = dotf(d, d);
@@ -316,7 +323,8 @@ void listed_forces_kernel(listed_tables T, int Npad, const float4* __restrict__ 
     t -= T.n_exc;
     if (t < T.n_excl) {
         const int i = T.excl_atoms[2 * t], j = T.excl_atoms[2 * t + 1];
-        const float qq = T.excl_qq[t];
+        float qq = T.excl_qq[t];
+        if (T.rep_lam) { const float le = T.rep_lam[4 * r + 2]; const int na = T.excl_alch[t]; qq *= (na == 2) ? le * le : (na == 1) ? le : 1.f; }
         float3 d = sub3(ld3(P, j), ld3(P, i));
         d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz);
         const float r2 = dotf(d, d);
@@ -777,7 +785,8 @@ void nb_reduce_kernel(int N, int Npad, int nsplit, const float4* __restrict__ pa
 // 1-4 style exceptions with non-zero parameters: plain Coulomb + LJ, no cutoff, no switch
 template <bool ENERGY>
 __global__ __launch_bounds__(256)
-void exception_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ params, int Npad,
+void exception_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ params,
+                      const int* __restrict__ alch, const float* __restrict__ rep_lam, int Npad,
                       const float4* __restrict__ pos, const float* __restrict__ box,
                       long long* __restrict__ force, double* __restrict__ epart, int n_epart)
 {
@@ -789,7 +798,9 @@ void exception_kernel(int n, const int* __restrict__ atoms, const float* __restr
     double e = 0.0;
     for (int t = threadIdx.x; t < n; t += 256) {
         const int i = atoms[2 * t], j = atoms[2 * t + 1];
-        const float qq = params[3 * t], sig = params[3 * t + 1], eps = params[3 * t + 2];
+        float qq = params[3 * t];
+        const float sig = params[3 * t + 1], eps = params[3 * t + 2];
+        if (rep_lam && alch[t] > 0) qq *= rep_lam[4 * r + 2];
         float3 d = sub3(ld3(P, j), ld3(P, i));
         if (Lx > 0.f) { d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz); }
         const float r2 = dotf(d, d);
@@ -808,7 +819,8 @@ void exception_kernel(int n, const int* __restrict__ atoms, const float* __restr
 // Ewald correction for excluded pairs: the reciprocal sum contains them, so subtract qq erf(alpha r)/r
 template <bool ENERGY>
 __global__ __launch_bounds__(256)
-void ewald_exclusion_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ qq_arr, float alpha,
+void ewald_exclusion_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ qq_arr,
+                            const int* __restrict__ alch, const float* __restrict__ rep_lam, float alpha,
                             float two_alpha_sqrtpi, int Npad, const float4* __restrict__ pos, const float* __restrict__ box,
                             long long* __restrict__ force, double* __restrict__ epart, int n_epart)
 {
@@ -820,7 +832,8 @@ void ewald_exclusion_kernel(int n, const int* __restrict__ atoms, const float* _
     double e = 0.0;
     for (int t = threadIdx.x; t < n; t += 256) {
         const int i = atoms[2 * t], j = atoms[2 * t + 1];
-        const float qq = qq_arr[t];
+        float qq = qq_arr[t];
+        if (rep_lam) { const float le = rep_lam[4 * r + 2]; const int na = alch[t]; qq *= (na == 2) ? le * le : (na == 1) ? le : 1.f; }
         float3 d = sub3(ld3(P, j), ld3(P, i));
         d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz);
         const float r2 = dotf(d, d);
@@ -838,15 +851,19 @@ void ewald_exclusion_kernel(int n, const int* __restrict__ atoms, const float* _
     if (ENERGY) { e = block_sum_256(e, s_part); if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_EXCLCORR] = e; }
 }
 
-// per-replica constants: dispersion correction, Ewald self energy, neutralising background
-__global__ void const_energy_kernel(int R, double disp_coeff, double self_e, double plasma_coeff,
+// per-replica constants: dispersion correction, Ewald self energy, neutralising background.  Alchemical charges
+// scale with lambda_electrostatics (exact PME treatment, alchemy.py:1897-1899): self = nn + l^2 aa, Q = Qn + l Qa.
+__global__ void const_energy_kernel(int R, double disp_coeff, double self_nn, double self_aa, double q_n, double q_a,
+                                    double plasma_pref, const float* __restrict__ rep_lam,
                                     const float* __restrict__ box, double* __restrict__ epart, int n_epart)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
-    double e = self_e;
-    if (V > 0) e += (disp_coeff + plasma_coeff) / V;
+    const double le = rep_lam ? (double)rep_lam[4 * r + 2] : 1.0;
+    const double Q = q_n + le * q_a;
+    double e = self_nn + le * le * self_aa;
+    if (V > 0) e += (disp_coeff + plasma_pref * Q * Q) / V;
     epart[(size_t)r * n_epart + EP_CONST] = e;
 }
 
@@ -931,6 +948,7 @@ void remd_free_nonbonded(remd_ctx* h)
     if (it == g_nb.end()) return;
     nb_tables& t = it->second;
     dfree(t.d_param); dfree(t.d_mask); dfree(t.d_exc_atoms); dfree(t.d_exc_params); dfree(t.d_excl_atoms); dfree(t.d_excl_qq);
+    dfree(t.d_exc_alch); dfree(t.d_excl_alch); dfree(t.d_probe);
     dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
     dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sparam); dfree(t.d_smask);
     dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
@@ -1045,26 +1063,32 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     std::vector<unsigned long long> mk((size_t)h->Npad * words, 0ull);
     auto setbit = [&](int i, int j) { const int dd = j - i + 32 * words; mk[(size_t)i * words + (dd >> 6)] |= 1ull << (dd & 63); };
     for (int i = 0; i < N; ++i) setbit(i, i);
-    std::vector<int> exc_atoms, excl_atoms; std::vector<float> exc_params, excl_qq;
+    std::vector<int> exc_atoms, excl_atoms, exc_alch, excl_alch; std::vector<float> exc_params, excl_qq;
     for (int e = 0; e < d->n_exceptions; ++e) {
         const int i = d->exception_atoms[2 * e], j = d->exception_atoms[2 * e + 1];
         setbit(i, j); setbit(j, i);
         const double qq = d->exception_params[3 * e], sg = d->exception_params[3 * e + 1], ep = d->exception_params[3 * e + 2];
         if (qq != 0.0 || ep != 0.0) {
-            if (t.is_alch[i] || t.is_alch[j]) return remd_fail(h, -3, "non-zero exceptions on alchemical atoms are not implemented yet");
+            // alchemy.py:1964-1990: electrostatic exceptions touching the region scale with lambda_electrostatics;
+            // alchemical/alchemical sterics exceptions stay at full strength (annihilate_sterics=False); a sterics
+            // exception between an alchemical and a non-alchemical atom would need the soft-core CustomBondForce.
+            if ((t.is_alch[i] != t.is_alch[j]) && ep != 0.0)
+                return remd_fail(h, -3, "sterics exceptions between alchemical and non-alchemical atoms are not implemented");
+            exc_alch.push_back((int)t.is_alch[i] + (int)t.is_alch[j]);
             exc_atoms.push_back(i); exc_atoms.push_back(j);
             exc_params.push_back((float)(qq * REMD_ONE_4PI_EPS0)); exc_params.push_back((float)sg); exc_params.push_back((float)ep);
         }
         if (d->charge[i] != 0.0 && d->charge[j] != 0.0) {
+            excl_alch.push_back((int)t.is_alch[i] + (int)t.is_alch[j]);
             excl_atoms.push_back(i); excl_atoms.push_back(j);
             excl_qq.push_back((float)(d->charge[i] * d->charge[j] * REMD_ONE_4PI_EPS0));
         }
     }
     if ((rc = upload(h, t.d_mask, mk))) return rc;
     t.n_exc = (int)exc_params.size() / 3;
-    if ((rc = upload(h, t.d_exc_atoms, exc_atoms)) || (rc = upload(h, t.d_exc_params, exc_params))) return rc;
+    if ((rc = upload(h, t.d_exc_atoms, exc_atoms)) || (rc = upload(h, t.d_exc_params, exc_params)) || (rc = upload(h, t.d_exc_alch, exc_alch))) return rc;
     t.n_excl = (t.method == NB_EWALD) ? (int)excl_qq.size() : 0;
-    if ((rc = upload(h, t.d_excl_atoms, excl_atoms)) || (rc = upload(h, t.d_excl_qq, excl_qq))) return rc;
+    if ((rc = upload(h, t.d_excl_atoms, excl_atoms)) || (rc = upload(h, t.d_excl_qq, excl_qq)) || (rc = upload(h, t.d_excl_alch, excl_alch))) return rc;
 
     nb_params& p = t.p;
     p.rc = (float)d->cutoff; p.rc2 = (float)(d->cutoff * d->cutoff);
@@ -1122,12 +1146,17 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         for (int i = 0; i < N; ++i) if (t.is_alch[i]) ep[i] = 0.0;     // alchemy.py: alchemical atoms carry eps = 0 in the NonbondedForce
         t.disp_coeff = dispersion_coefficient(N, sg, ep, d->cutoff, p.rs >= 0 ? d->switch_distance : -1.0);
     }
-    t.self_energy = 0.0; t.net_charge_term = 0.0;
+    t.self_energy = 0.0; t.net_charge_term = 0.0; t.self_nn = t.self_aa = t.q_n = t.q_a = 0.0;
     if (t.method == NB_EWALD) {
-        double q2 = 0, qs = 0;
-        for (int i = 0; i < N; ++i) { q2 += d->charge[i] * d->charge[i]; qs += d->charge[i]; }
-        t.self_energy = -REMD_ONE_4PI_EPS0 * d->ewald_alpha / sqrt(M_PI) * q2;
-        t.net_charge_term = -REMD_ONE_4PI_EPS0 * M_PI * qs * qs / (2.0 * d->ewald_alpha * d->ewald_alpha);
+        double q2n = 0, q2a = 0;
+        for (int i = 0; i < N; ++i) {
+            if (t.is_alch[i]) { q2a += d->charge[i] * d->charge[i]; t.q_a += d->charge[i]; }
+            else { q2n += d->charge[i] * d->charge[i]; t.q_n += d->charge[i]; }
+        }
+        const double pref = -REMD_ONE_4PI_EPS0 * d->ewald_alpha / sqrt(M_PI);
+        t.self_nn = pref * q2n; t.self_aa = pref * q2a;
+        t.self_energy = t.self_nn + t.self_aa;
+        t.net_charge_term = -REMD_ONE_4PI_EPS0 * M_PI / (2.0 * d->ewald_alpha * d->ewald_alpha);   // times Q^2 / V
     }
     return 0;
 }
@@ -1140,7 +1169,8 @@ static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
     std::vector<float> rl(4 * (size_t)h->R, 0.f);
     for (int r = 0; r < h->R; ++r) {
         const int64_t k = h->labels.empty() ? 0 : h->labels[h->r_begin + r];
-        const double ls = h->lam_s.empty() ? 1.0 : h->lam_s[k], le = h->lam_e.empty() ? 1.0 : h->lam_e[k];
+        const double ls = h->lam_s.empty() ? 1.0 : h->lam_s[k];
+        const double le = t.lam_e_override >= 0.0 ? t.lam_e_override : (h->lam_e.empty() ? 1.0 : h->lam_e[k]);
         rl[4 * r] = (float)pow(ls, h->sc_a);
         rl[4 * r + 1] = (float)(h->sc_alpha * pow(1.0 - ls, h->sc_b));
         rl[4 * r + 2] = (float)le;
@@ -1271,6 +1301,10 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
                  h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
     }
+    if (h->nb_method != REMD_NB_NONE) {      // per-replica lambdas must be current before ANY kernel reads them
+        int rc0 = update_replica_lambdas(h, g_nb[h]);
+        if (rc0) return rc0;
+    }
     const bool merged = !with_energy;      // force-only evaluations: every listed term in one launch
     if (merged) {
         listed_tables T{};
@@ -1284,6 +1318,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
             T.n_exc = t.n_exc; T.exc_atoms = t.d_exc_atoms; T.exc_params = t.d_exc_params;
             T.n_excl = t.n_excl; T.excl_atoms = t.d_excl_atoms; T.excl_qq = t.d_excl_qq;
             T.alpha = t.p.alpha; T.two_alpha_sqrtpi = t.p.two_alpha_sqrtpi;
+            T.exc_alch = t.d_exc_alch; T.excl_alch = t.d_excl_alch; T.rep_lam = t.has_alch ? t.d_rep_lam : nullptr;
         }
         const int total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
         if (total > 0) {
@@ -1326,12 +1361,14 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         }
         if (!merged && t.n_exc > 0) {
             remd_prof_scope ps(h, "exceptions");
-            LAUNCH_E(exception_kernel, dim3(R), dim3(256), 0, h->stream, t.n_exc, t.d_exc_atoms, t.d_exc_params, h->Npad,
+            LAUNCH_E(exception_kernel, dim3(R), dim3(256), 0, h->stream, t.n_exc, t.d_exc_atoms, t.d_exc_params, t.d_exc_alch,
+                     t.has_alch ? t.d_rep_lam : (const float*)nullptr, h->Npad,
                      h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);
         }
         if (!merged && t.n_excl > 0) {
             remd_prof_scope ps(h, "exceptions");
-            LAUNCH_E(ewald_exclusion_kernel, dim3(R), dim3(256), 0, h->stream, t.n_excl, t.d_excl_atoms, t.d_excl_qq, t.p.alpha,
+            LAUNCH_E(ewald_exclusion_kernel, dim3(R), dim3(256), 0, h->stream, t.n_excl, t.d_excl_atoms, t.d_excl_qq, t.d_excl_alch,
+                     t.has_alch ? t.d_rep_lam : (const float*)nullptr, t.p.alpha,
                      t.p.two_alpha_sqrtpi, h->Npad, h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);
         }
         if (t.method == NB_EWALD) {
@@ -1339,8 +1376,9 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
             if (rc) return rc;
         }
         if (with_energy)
-            hipLaunchKernelGGL(const_energy_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, t.disp_coeff, t.self_energy,
-                               t.net_charge_term, h->d_box, h->d_epart, h->n_epart);
+            hipLaunchKernelGGL(const_energy_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, t.disp_coeff, t.self_nn, t.self_aa,
+                               t.q_n, t.q_a, t.net_charge_term, t.has_alch ? t.d_rep_lam : (const float*)nullptr, h->d_box,
+                               h->d_epart, h->n_epart);
     }
 #undef LAUNCH_E
     if (with_energy)
@@ -1350,11 +1388,31 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
     return 0;
 }
 
+// u_kl with lambda_electrostatics states: every Coulomb term is bilinear in the charges and alchemical charges scale
+// linearly, so U(lambda_e) = a + b l + c l^2 EXACTLY; three energy passes at l = 0, 1/2, 1 determine a, b, c per replica.
+__global__ void assemble_ukl_poly_kernel(int R, int K, const double* __restrict__ probe /*[3][R]*/,
+                                         const double* __restrict__ beta, const double* __restrict__ econst,
+                                         const double* __restrict__ lam_e, const double* __restrict__ alch,
+                                         double* __restrict__ ukl_rows)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R * K) return;
+    const int r = t / K, l = t % K;
+    const double P0 = probe[r], Ph = probe[R + r], P1 = probe[2 * R + r];
+    const double c = 2.0 * (P1 - P0) - 4.0 * (Ph - P0);
+    const double b = (P1 - P0) - c;
+    const double le = lam_e[l];
+    double U = P0 + b * le + c * le * le + econst[l];
+    if (alch) U += alch[t];
+    ukl_rows[t] = beta[l] * U;
+}
+
 int remd_assemble_ukl(remd_ctx* h, double* d_rows)
 {
     const int n = h->R * h->K;
     const double* alch = nullptr;
     auto it = g_nb.find(h);
+    bool poly = false;
     if (it != g_nb.end() && it->second.has_alch && h->nb_method != REMD_NB_NONE) {
         nb_tables& t = it->second;
         if (t.alch_R != h->R || t.alch_K != h->K) {
@@ -1370,10 +1428,32 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
         }
         REMD_CHECK(h, hipMemcpyAsync(t.d_state_lam, sl.data(), sizeof(double) * sl.size(), hipMemcpyHostToDevice, h->stream));
         REMD_CHECK(h, hipStreamSynchronize(h->stream));
-        remd_prof_scope ps(h, "alch_ukl");
-        hipLaunchKernelGGL(alch_ukl_kernel, dim3(h->K, h->R), dim3(256), 0, h->stream, t.p, h->N, h->Npad, h->n_alch,
-                           h->d_alch_atoms, h->d_pos, t.d_param, h->d_box, h->K, t.d_state_lam, t.d_alch_ukl);
+        {
+            remd_prof_scope ps(h, "alch_ukl");
+            hipLaunchKernelGGL(alch_ukl_kernel, dim3(h->K, h->R), dim3(256), 0, h->stream, t.p, h->N, h->Npad, h->n_alch,
+                               h->d_alch_atoms, h->d_pos, t.d_param, h->d_box, h->K, t.d_state_lam, t.d_alch_ukl);
+        }
         alch = t.d_alch_ukl;
+        // lambda_electrostatics states need the polynomial only when alchemical atoms carry charge
+        bool lam_e_varies = false;
+        for (int k = 0; k < h->K; ++k) lam_e_varies |= (h->lam_e[k] != h->lam_e[0]) || (h->lam_e[k] != 1.0);
+        poly = lam_e_varies && (t.self_aa != 0.0);
+        if (poly) {
+            if (t.probe_R != h->R) { dfree(t.d_probe); REMD_CHECK(h, hipMalloc(&t.d_probe, sizeof(double) * 3 * h->R)); t.probe_R = h->R; }
+            const double probes[3] = { 0.0, 0.5, 1.0 };
+            for (int q = 0; q < 3; ++q) {
+                t.lam_e_override = probes[q];
+                int rc = remd_compute_forces(h, true);
+                t.lam_e_override = -1.0;
+                if (rc) return rc;
+                REMD_CHECK(h, hipMemcpyAsync(t.d_probe + (size_t)q * h->R, h->d_potential, sizeof(double) * h->R, hipMemcpyDeviceToDevice, h->stream));
+            }
+            h->forces_valid = false;        // the last pass used a probe lambda, not the replicas' own
+            hipLaunchKernelGGL(assemble_ukl_poly_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K, t.d_probe,
+                               h->d_beta, h->d_econst, h->d_lam_e, alch, d_rows);
+            REMD_CHECK(h, hipGetLastError());
+            return 0;
+        }
     }
     hipLaunchKernelGGL(assemble_ukl_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K,
                        h->d_potential, h->d_beta, h->d_econst, alch, d_rows);

@@ -209,7 +209,11 @@ class ForceFieldOracle(OracleSystem):
         r = dv.norm(dim=1)
         nz = (p[:, 0] != 0) | (p[:, 2] != 0)
         sr6 = torch.where(nz, (p[:, 1] / r) ** 6, torch.zeros_like(r))
-        e = e + (torch.where(nz, ONE_4PI_EPS0 * p[:, 0] / r, torch.zeros_like(r)) + 4.0 * p[:, 2] * sr6 * (sr6 - 1.0)).sum()
+        # exact PME treatment: electrostatic exceptions touching the alchemical region scale with lambda_electrostatics
+        # (exception parameter offset, alchemy.py:1964-1966)
+        any_alch = torch.tensor(self.is_alch[i] | self.is_alch[j])
+        qq = torch.where(any_alch, p[:, 0] * lam_e, p[:, 0])
+        e = e + (torch.where(nz, ONE_4PI_EPS0 * qq / r, torch.zeros_like(r)) + 4.0 * p[:, 2] * sr6 * (sr6 - 1.0)).sum()
         if self.method == 2 and self.has_charge:
             q = torch.where(self.alch_t, self.q * lam_e, self.q)
             e = e - (ONE_4PI_EPS0 * q[i] * q[j] * torch.erf(self.alpha * r) / r).sum()

@@ -155,3 +155,67 @@ def test_alanine_short_trajectory(hip_engine_factory, alanine):
     U_dev = eng.compute_energies(want_potential=True)[1]
     U_ora = ora.potentials()
     assert np.allclose(U_dev, U_ora, rtol=2e-4)
+
+
+@pytest.mark.parametrize('system_cls,R', [(ts.HostGuestExplicit, 2), (ts.DHFRExplicit, 1)])
+def test_large_systems_energy_forces_and_propagation(hip_engine_factory, system_cls, R):
+    """BASELINE config 4 / 5 systems (CB7:B2 host-guest, 4491 atoms, 96^3 mesh; DHFR, 23558 atoms, 144^3 mesh):
+    energy within 1e-5 relative, force RMSE within the cross-platform bar, and a short g-BAOAB run keeps every
+    constraint and stays finite."""
+    tsys = system_cls()
+    eng = hip_engine_factory()
+    desc, x, box = _engine_for(eng, tsys.system, tsys.positions, R=R, jitter=0.001, splitting='V R R O R R V',
+                               dt=0.002, n_steps=10)
+    ff = ForceFieldOracle(desc)
+    U = eng.compute_energies(want_potential=True)[1]
+    f = eng.get_forces()
+    xd = eng.get_replicas()[0]
+    for r in range(R):
+        e_ref, f_ref = ff.energy_forces(xd[r], box[r])
+        assert np.isclose(U[r], e_ref, rtol=1e-5), (U[r], e_ref)
+        rmse = np.sqrt(((f[r] - f_ref) ** 2).sum(axis=1).mean())
+        assert rmse < 2.5, rmse
+    assert not eng.propagate(1).any()
+    xg, vg, _, _ = eng.get_replicas()
+    cons = mo.OracleSystem(desc).constraints
+    i, j, dist = np.array([c[0] for c in cons]), np.array([c[1] for c in cons]), np.array([c[2] for c in cons])
+    for r in range(R):
+        d = np.linalg.norm(xg[r][j] - xg[r][i], axis=1)
+        assert np.abs(d - dist).max() < 5e-6
+    assert np.isfinite(eng.compute_energies()).all()
+
+
+def test_hostguest_alchemical_electrostatics_and_sterics_ukl(hip_engine_factory):
+    """BASELINE config 4 state family on CB7:B2 (alchemical guest = atoms 126-155, tests/test_alchemy.py:1873-1875):
+    lambda_electrostatics 1 -> 0 with exact PME treatment (charge offsets, alchemy.py:1897-1899), then lambda_sterics
+    1 -> 0 (soft core).  The device fits U(lambda_e) = a + b l + c l^2 from three energy passes; the oracle
+    recomputes every state from scratch."""
+    hg = ts.HostGuestExplicit()
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(hg.system, region)
+    lam_e = np.array([1.0, 0.5, 0.25, 0.0, 0.0, 0.0, 0.0])
+    lam_s = np.array([1.0, 1.0, 1.0, 1.0, 0.6, 0.2, 0.0])
+    K = len(lam_e)
+    eng = hip_engine_factory()
+    desc = system_to_desc(system)
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 300.0)
+    eng.set_states(np.full(K, beta), lam_s, lam_e, None)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 5, True, 1e-8)
+    eng.seed(SEED)
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (2, 1))
+    x = np.stack([hg.positions, hg.positions + 0.001 * np.random.default_rng(0).normal(size=hg.positions.shape)])
+    labels = np.array([1, 5])
+    eng.set_replicas(2, 0, x, None, box, labels)
+    rows = eng.compute_energies()
+    xd = eng.get_replicas()[0]
+    ff = ForceFieldOracle(desc)
+    for r in range(2):
+        ref = beta * ff.state_energies(xd[r], box[r], lam_s, lam_e)
+        assert np.allclose(rows[r], ref, rtol=1e-5), np.abs(rows[r] / ref - 1).max()
+        assert abs((rows[r, 0] - rows[r, 3]) - (ref[0] - ref[3])) < 0.05 * K      # differences survive to << 1 kT
+    f = eng.get_forces()
+    for r, k in enumerate(labels):
+        f_ref = ff.energy_forces(xd[r], box[r], lambda_sterics=lam_s[k], lambda_electrostatics=lam_e[k])[1]
+        assert np.sqrt(((f[r] - f_ref) ** 2).sum(axis=1).mean()) < 2.5
+    assert not eng.propagate(1).any()
