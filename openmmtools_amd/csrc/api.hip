@@ -3,6 +3,7 @@
 #include <cstring>
 #include <cmath>
 #include <mutex>
+#include <cstdlib>
 
 int remd_check_finite(remd_ctx* h);
 int remd_assemble_ukl(remd_ctx* h, double* d_rows);
@@ -56,6 +57,15 @@ int remd_create(remd_handle* out, int device, void* stream)
     h->device = device;
     h->stream = (hipStream_t)stream;
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+    {
+        // the reciprocal-space chain is the longer critical path: give its stream the highest priority
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess)
+            hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+    }
+    hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    { const char* env = getenv("REMD_OVERLAP"); h->overlap = !(env && atoi(env) == 0); }
     *out = h;
     return 0;
 }
@@ -77,6 +87,9 @@ int remd_destroy(remd_handle h)
     dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_pos_ref); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels);
     dfree(h->d_ukl); dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     delete h;

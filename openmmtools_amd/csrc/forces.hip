@@ -650,11 +650,8 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
     // reduce over the 8 j lanes of each i atom
     for (int off = 4; off > 0; off >>= 1) { fx += __shfl_xor(fx, off); fy += __shfl_xor(fy, off); fz += __shfl_xor(fz, off); }
     if (iact && jj == 0) {
-        long long* F = force + (size_t)r * 3 * Npad;
-        const int io = order[(size_t)r * Npad + i];
-        F[io] += (long long)((double)fx * REMD_FORCE_SCALE);
-        F[Npad + io] += (long long)((double)fy * REMD_FORCE_SCALE);
-        F[2 * Npad + io] += (long long)((double)fz * REMD_FORCE_SCALE);
+        // integer atomics: the PME gather may be adding to the same atom on the other stream
+        add_force(force + (size_t)r * 3 * Npad, Npad, order[(size_t)r * Npad + i], fx, fy, fz);
     }
     if (ENERGY) {
         e = wave_sum(e);
@@ -776,10 +773,7 @@ void nb_reduce_kernel(int N, int Npad, int nsplit, const float4* __restrict__ pa
         const float4 f = partial[((size_t)r * nsplit + s) * Npad + i];
         fx += f.x; fy += f.y; fz += f.z;
     }
-    long long* F = force + (size_t)r * 3 * Npad;
-    F[i] += (long long)((double)fx * REMD_FORCE_SCALE);
-    F[Npad + i] += (long long)((double)fy * REMD_FORCE_SCALE);
-    F[2 * Npad + i] += (long long)((double)fz * REMD_FORCE_SCALE);
+    add_force(force + (size_t)r * 3 * Npad, Npad, i, fx, fy, fz);
 }
 
 // 1-4 style exceptions with non-zero parameters: plain Coulomb + LJ, no cutoff, no switch
@@ -1301,9 +1295,20 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
                  h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
     }
+    bool pme_forked = false;
     if (h->nb_method != REMD_NB_NONE) {      // per-replica lambdas must be current before ANY kernel reads them
-        int rc0 = update_replica_lambdas(h, g_nb[h]);
+        nb_tables& t0 = g_nb[h];
+        int rc0 = update_replica_lambdas(h, t0);
         if (rc0) return rc0;
+        if (t0.method == NB_EWALD && h->overlap && h->stream2) {
+            // fork: the reciprocal-space pipeline runs on the second stream while this one does the direct space
+            hipEventRecord(h->ev_fork, h->stream);
+            hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
+            rc0 = remd_pme_forces(h, with_energy, h->stream2);
+            if (rc0) return rc0;
+            hipEventRecord(h->ev_join, h->stream2);
+            pme_forked = true;
+        }
     }
     const bool merged = !with_energy;      // force-only evaluations: every listed term in one launch
     if (merged) {
@@ -1372,8 +1377,8 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
                      t.p.two_alpha_sqrtpi, h->Npad, h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);
         }
         if (t.method == NB_EWALD) {
-            rc = remd_pme_forces(h, with_energy, nullptr);
-            if (rc) return rc;
+            if (pme_forked) hipStreamWaitEvent(h->stream, h->ev_join, 0);       // join
+            else { rc = remd_pme_forces(h, with_energy, h->stream); if (rc) return rc; }
         }
         if (with_energy)
             hipLaunchKernelGGL(const_energy_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, t.disp_coeff, t.self_nn, t.self_aa,

@@ -28,6 +28,7 @@ struct pme_state {
     size_t npts = 0;
     int* d_mesh = nullptr;             // [R][nx][ny][nz] 32-bit fixed-point charge mesh; reused as the float potential mesh
     float2* d_grid = nullptr;          // [R][nz/2+1][nx][ny] half spectrum, kz-major (or the full complex grid of the test hook)
+    hipStream_t stream = nullptr;      // stream of the current remd_pme_forces call
     int nzc = 0; size_t nspec = 0; size_t xy_lds = 0; bool xy_fused = false; int xy_threads = 512;
     int* d_col_count = nullptr; int* d_col_start = nullptr; int* d_cursor = nullptr; int* d_atom_col = nullptr; int* d_col_atoms = nullptr;
     float2* d_tw[3] = {nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i k / n)
@@ -569,10 +570,11 @@ void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __
     }
     // dE/dx = q * dtheta/du * du/dx, du/dx = n / L
     const float Fx = -q * gx * nx / Lx, Fy = -q * gy * ny / Ly, Fz = -q * gz * nz / Lz;
-    long long* F = force + (size_t)r * 3 * Npad;
-    F[i] += (long long)((double)Fx * REMD_FORCE_SCALE);
-    F[Npad + i] += (long long)((double)Fy * REMD_FORCE_SCALE);
-    F[2 * Npad + i] += (long long)((double)Fz * REMD_FORCE_SCALE);
+    // integer atomics: the direct-space kernels add to the same accumulators concurrently on another stream
+    unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
+    atomicAdd(&F[i], (unsigned long long)(long long)((double)Fx * REMD_FORCE_SCALE));
+    atomicAdd(&F[Npad + i], (unsigned long long)(long long)((double)Fy * REMD_FORCE_SCALE));
+    atomicAdd(&F[2 * Npad + i], (unsigned long long)(long long)((double)Fz * REMD_FORCE_SCALE));
 }
 
 // fall-back influence-function pass for meshes whose (x,y) plane does not fit the LDS
@@ -735,62 +737,62 @@ static void launch_pass(remd_ctx* h, pme_state* s, float2* data, size_t rep_stri
     fft_plan pl = make_plan(s, axis_n_index);
     dim3 grid((lines + FFT_B - 1) / FFT_B, s->R);
     const size_t lds = sizeof(float2) * 2 * FFT_B * pl.n;
-    hipLaunchKernelGGL((fft_pass_kernel<SIGN, 0>), grid, dim3(FFT_B * FFT_T), lds, h->stream, pl, data, rep_stride, es, lines,
+    hipLaunchKernelGGL((fft_pass_kernel<SIGN, 0>), grid, dim3(FFT_B * FFT_T), lds, s->stream ? s->stream : h->stream, pl, data, rep_stride, es, lines,
                        line_div, hi, contiguous, s->d_tw[axis_n_index]);
 }
 
 const float* remd_nb_rep_lam(remd_ctx* h);
 const float4* remd_nb_param(remd_ctx* h);
 
-int remd_pme_forces(remd_ctx* h, bool with_energy, double* d_energy)
+int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
 {
-    (void)d_energy;
     pme_state* s = (pme_state*)h->pme;
     if (!s || s->R != h->R || !s->d_mesh) { int rc = remd_pme_setup(h); if (rc) return rc; s = (pme_state*)h->pme; }
+    s->stream = st;
     const int nx = s->n[0], ny = s->n[1], nz = s->n[2];
     const float* rep_lam = remd_nb_rep_lam(h);
     const float4* param = remd_nb_param(h);
     const int ncol = nx * ny;
     {
-        remd_prof_scope ps(h, "pme_bin");
+        remd_prof_scope ps(h, "pme_bin", st);
         const dim3 agrid((h->N + 255) / 256, h->R);
-        hipLaunchKernelGGL(pme_bin_count_kernel, agrid, dim3(256), 0, h->stream, h->N, h->Npad, nx, ny, nz, h->d_pos, h->d_box,
+        hipLaunchKernelGGL(pme_bin_count_kernel, agrid, dim3(256), 0, st, h->N, h->Npad, nx, ny, nz, h->d_pos, h->d_box,
                            s->d_col_count, s->d_atom_col);
-        hipLaunchKernelGGL(pme_bin_scan_kernel, dim3(h->R), dim3(1024), 0, h->stream, ncol, s->d_col_count, s->d_col_start, s->d_cursor);
-        hipLaunchKernelGGL(pme_bin_fill_kernel, agrid, dim3(256), 0, h->stream, h->N, h->Npad, ncol, s->d_atom_col, s->d_cursor, s->d_col_atoms);
+        hipLaunchKernelGGL(pme_bin_scan_kernel, dim3(h->R), dim3(1024), 0, st, ncol, s->d_col_count, s->d_col_start, s->d_cursor);
+        hipLaunchKernelGGL(pme_bin_fill_kernel, agrid, dim3(256), 0, st, h->N, h->Npad, ncol, s->d_atom_col, s->d_cursor, s->d_col_atoms);
     }
     {
-        remd_prof_scope ps(h, "pme_fft");
+        remd_prof_scope ps(h, "pme_fft", st);
         int nl = 1;                                   // lines per workgroup: largest divisor of ny whose points fit the registers
         for (int c = 1; c <= ny; ++c) if (ny % c == 0 && c * nz <= Z_PPT * Z_THREADS) nl = c;
         const size_t zlds = sizeof(float2) * ((size_t)nl * (nz + 1) + nz) + sizeof(int) * (size_t)nl * nz;
         const dim3 zgrid(nx * ny / nl, s->R);
-        hipLaunchKernelGGL(pme_spread_zfwd_kernel, zgrid, dim3(Z_THREADS), zlds, h->stream, make_plan(s, 2), nl, nx, ny, h->Npad, h->d_pos,
+        hipLaunchKernelGGL(pme_spread_zfwd_kernel, zgrid, dim3(Z_THREADS), zlds, st, make_plan(s, 2), nl, nx, ny, h->Npad, h->d_pos,
                            param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
         if (s->xy_fused) {
-            hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, h->stream, make_plan(s, 0), make_plan(s, 1),
+            hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
                                (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);
         } else {
             // spec layout [kz][x][y]: y lines contiguous, x lines strided by ny
             launch_pass<-1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
             launch_pass<-1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
-            hipLaunchKernelGGL(pme_influence_kernel, dim3(s->nzc, s->R), dim3(256), 0, h->stream, nx, ny, nz, s->d_grid, s->d_bmod[0],
+            hipLaunchKernelGGL(pme_influence_kernel, dim3(s->nzc, s->R), dim3(256), 0, st, nx, ny, nz, s->d_grid, s->d_bmod[0],
                                s->d_bmod[1], s->d_bmod[2], h->d_box, (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         }
         const size_t zlds_inv = sizeof(float2) * ((size_t)nl * (nz + 1) + nz);
-        hipLaunchKernelGGL(pme_zinv_kernel, zgrid, dim3(Z_THREADS), zlds_inv, h->stream, make_plan(s, 2), nl, nx, ny, s->d_grid,
+        hipLaunchKernelGGL(pme_zinv_kernel, zgrid, dim3(Z_THREADS), zlds_inv, st, make_plan(s, 2), nl, nx, ny, s->d_grid,
                            reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
     }
     {
-        remd_prof_scope ps(h, "pme_gather");
-        hipLaunchKernelGGL(pme_gather_kernel, dim3((h->N + 127) / 128, h->R), dim3(128), 0, h->stream, h->N, h->Npad, nx, ny, nz,
+        remd_prof_scope ps(h, "pme_gather", st);
+        hipLaunchKernelGGL(pme_gather_kernel, dim3((h->N + 127) / 128, h->R), dim3(128), 0, st, h->N, h->Npad, nx, ny, nz,
                            h->d_pos, param, h->d_box, rep_lam, reinterpret_cast<const float*>(s->d_mesh), h->d_force);
     }
     if (with_energy)
-        hipLaunchKernelGGL(pme_energy_reduce_kernel, dim3(h->R), dim3(64), 0, h->stream, s->n_eblk, s->d_energy, h->d_epart,
+        hipLaunchKernelGGL(pme_energy_reduce_kernel, dim3(h->R), dim3(64), 0, st, s->n_eblk, s->d_energy, h->d_epart,
                            h->n_epart, 6 /*EP_PME*/);
     REMD_CHECK(h, hipGetLastError());
     return 0;

@@ -102,6 +102,8 @@ struct remd_ctx {
 
     // ---- timing / profiling -------------------------------------------------------------
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // second stream: the PME reciprocal pipeline (LDS / latency bound) overlaps the direct-space kernels (VALU bound)
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true;
     double t_prop = 0, t_energy = 0, t_mix = 0;
     int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes
     std::string prof_filter = "nonbonded";
@@ -120,14 +122,15 @@ int remd_fail(remd_ctx* h, int code, const std::string& msg);
 // synchronised at launch time; the pairs are resolved in remd_profile_get().  Level 1 records only
 // the class named by prof_filter (bench.py: the dominant kernel), level 2 records every class.
 struct remd_prof_scope {
-    remd_ctx* h; const char* name; hipEvent_t a = nullptr; bool on = false;
-    remd_prof_scope(remd_ctx* h_, const char* n) : h(h_), name(n) {
+    remd_ctx* h; const char* name; hipEvent_t a = nullptr; bool on = false; hipStream_t st;
+    remd_prof_scope(remd_ctx* h_, const char* n, hipStream_t stream = (hipStream_t)-1) : h(h_), name(n) {
+        st = (stream == (hipStream_t)-1) ? h->stream : stream;     // events go on the stream the kernel is launched on
         on = h->profiling == 2 || (h->profiling == 1 && h->prof_filter == n);
-        if (on) { hipEventCreate(&a); hipEventRecord(a, h->stream); }
+        if (on) { hipEventCreate(&a); hipEventRecord(a, st); }
     }
     ~remd_prof_scope() {
         if (on) {
-            hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, h->stream);
+            hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, st);
             h->prof_pending.push_back({name, a, b});
         }
     }
@@ -153,4 +156,4 @@ int remd_build_constraints(remd_ctx* h, const remd_system_desc* d);
 // ---- pme.hip ----------------------------------------------------------------------------
 int remd_pme_setup(remd_ctx* h);
 int remd_pme_destroy(remd_ctx* h);
-int remd_pme_forces(remd_ctx* h, bool with_energy, double* d_energy /*[R]*/);
+int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st);

@@ -307,7 +307,7 @@ class MultiStateSampler:
     def _compute_energies(self):
         """multistatesampler.py:1436-1494: fill u_kl for all replicas (global neighborhoods)."""
         K, U = self.n_states, len(self._unsampled_states)
-        if self._comm.world_size == 1:
+        if isinstance(self._comm, SingleProcessComm):
             rows = self._engine.compute_energies()
             full = rows
         else:

@@ -7,6 +7,7 @@ validation (:220-234), round-robin tiling of sampler states (:239-253) and ``_mi
 """
 import numpy as np
 from .multistatesampler import MultiStateSampler
+from .comm import SingleProcessComm
 
 
 class ReplicaExchangeSampler(MultiStateSampler):
@@ -56,10 +57,11 @@ class ReplicaExchangeSampler(MultiStateSampler):
         eng = self._engine
         labels_in = self._replica_thermodynamic_states
         K = self.n_states
-        if self._comm.world_size > 1 and getattr(eng, 'is_device', False) and self._device_ukl is not None:
+        distributed = not isinstance(self._comm, SingleProcessComm)
+        if distributed and getattr(eng, 'is_device', False) and self._device_ukl is not None:
             out = eng.mix(scheme, it, labels_in, d_ukl=self._device_ukl.data_ptr(), R=self.n_replicas, K=K,
                           ld=self._K_total, log_weights=log_weights)
-        elif self._comm.world_size > 1:
+        elif distributed:
             out = eng.mix_host(scheme, it, self._host_ukl_full[:, :K], labels_in, log_weights=log_weights)
         else:
             out = eng.mix(scheme, it, labels_in, R=self.n_replicas, K=K, ld=self._K_total, log_weights=log_weights)
