@@ -239,55 +239,38 @@ __device__ __forceinline__ void pme_scaled(const float4 x, const float* __restri
     kx = (int)ux; ky = (int)uy; kz = (int)uz;
 }
 
-__global__ __launch_bounds__(256)
-void pme_bin_count_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __restrict__ pos,
-                          const float* __restrict__ box, int* __restrict__ col_count /*[R][nx*ny+1]*/, int* __restrict__ atom_col)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (i >= N) return;
-    float ux, uy, uz; int kx, ky, kz;
-    pme_scaled(pos[(size_t)r * Npad + i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
-    if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny;
-    const int c = kx * ny + ky;
-    atom_col[(size_t)r * Npad + i] = c;
-    atomicAdd(&col_count[(size_t)r * (nx * ny + 1) + c], 1);
-}
-
-// exclusive scan of the column counts of one replica (one workgroup per replica); also resets the fill cursors
+// bin atoms by their mesh column kx (one workgroup per replica, everything in LDS): the fused spread + z-FFT
+// workgroup of row x walks the atoms of bins kx = x .. x+4.  The order inside a bin is irrelevant because the
+// charges are accumulated as integers.
 __global__ __launch_bounds__(1024)
-void pme_bin_scan_kernel(int ncol, int* __restrict__ col_count, int* __restrict__ col_start, int* __restrict__ cursor)
+void pme_bin_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __restrict__ pos, const float* __restrict__ box,
+                    int* __restrict__ bin_start /*[R][nx+1]*/, int* __restrict__ bin_atoms /*[R][Npad]*/)
 {
-    __shared__ int s_part[1024];
+    __shared__ int s_cnt[257], s_start[257], s_cur[256];
     const int r = blockIdx.x, tid = threadIdx.x;
-    int* cnt = col_count + (size_t)r * (ncol + 1);
-    int* st = col_start + (size_t)r * (ncol + 1);
-    int* cur = cursor + (size_t)r * (ncol + 1);
-    const int per = (ncol + 1023) / 1024;
-    const int b = tid * per, e = min(ncol, b + per);
-    int sum = 0;
-    for (int c = b; c < e; ++c) sum += cnt[c];
-    s_part[tid] = sum;
+    for (int k = tid; k <= nx; k += 1024) s_cnt[k] = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan (integers: order-independent)
-        int v = (tid >= off) ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    for (int i = tid; i < N; i += 1024) {
+        float ux, uy, uz; int kx, ky, kz;
+        pme_scaled(pos[(size_t)r * Npad + i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+        if (kx >= nx) kx -= nx;
+        atomicAdd(&s_cnt[kx], 1);
     }
-    int run = (tid > 0) ? s_part[tid - 1] : 0;
-    for (int c = b; c < e; ++c) { st[c] = run; cur[c] = run; run += cnt[c]; cnt[c] = 0; }
-    if (tid == 1023) st[ncol] = s_part[1023];
-}
-
-__global__ __launch_bounds__(256)
-void pme_bin_fill_kernel(int N, int Npad, int ncol, const int* __restrict__ atom_col, int* __restrict__ cursor,
-                         int* __restrict__ col_atoms)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (i >= N) return;
-    const int c = atom_col[(size_t)r * Npad + i];
-    const int slot = atomicAdd(&cursor[(size_t)r * (ncol + 1) + c], 1);
-    col_atoms[(size_t)r * Npad + slot] = i;             // order inside a column is irrelevant: integer accumulation
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int k = 0; k < nx; ++k) { s_start[k] = run; s_cur[k] = run; run += s_cnt[k]; }
+        s_start[nx] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 1024) {
+        float ux, uy, uz; int kx, ky, kz;
+        pme_scaled(pos[(size_t)r * Npad + i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+        if (kx >= nx) kx -= nx;
+        const int slot = atomicAdd(&s_cur[kx], 1);
+        bin_atoms[(size_t)r * Npad + slot] = i;
+    }
+    for (int k = tid; k <= nx; k += 1024) bin_start[(size_t)r * (nx + 1) + k] = s_start[k];
 }
 
 #define Z_THREADS 512
@@ -303,53 +286,48 @@ void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const
                             float2* __restrict__ spec, const float2* tw)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz + 1;
+    const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz | 1;
     float2* buf = reinterpret_cast<float2*>(smem);          // [nl][PZ]
     float2* s_tw = buf + nl * PZ;                           // [nz]
     int* acc = reinterpret_cast<int*>(s_tw + nz);           // [nl][nz]
     const int r = blockIdx.y, tid = threadIdx.x;
     const int l0 = blockIdx.x * nl;
     const int x = l0 / ny, y0 = l0 % ny;
-    const int ncol = nx * ny;
     for (int idx = tid; idx < nl * nz; idx += Z_THREADS) acc[idx] = 0;
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     __syncthreads();
-    const int* cs = col_start + (size_t)r * (ncol + 1);
+    const int* cs = col_start + (size_t)r * (nx + 1);
     const int* ca = col_atoms + (size_t)r * Npad;
     const float4* P = pos + (size_t)r * Npad;
-    // candidate columns: kx in {x .. x+4} (stencil index a = kx - x), ky in [y0, y0 + nl + 3] (periodic)
+    // candidate atoms: mesh column kx in {x .. x+4} (stencil index a = kx - x); the y stencil is tested per atom
     for (int a = 0; a < 5; ++a) {
         int kxc = x + a; if (kxc >= nx) kxc -= nx;
-        for (int seg = 0; seg < 2; ++seg) {
-            int kb = y0, ke = min(y0 + nl + 4, y0 + ny);        // never more than one full period
-            if (seg == 0) ke = min(ke, ny); else { if (ke <= ny) break; kb = 0; ke -= ny; }
-            const int abeg = cs[kxc * ny + kb], aend = cs[kxc * ny + ke];
-            for (int t = abeg + tid; t < aend; t += Z_THREADS) {
-                const int i = ca[t];
-                const float4 pr = param[i];
-                float q = pr.x;
-                if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
-                if (q == 0.f) continue;
-                float ux, uy, uz; int kx, ky, kz;
-                pme_scaled(P[i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
-                float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
-                bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
-                if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
-                float wa = 0.f;
+        const int abeg = cs[kxc], aend = cs[kxc + 1];
+        for (int t = abeg + tid; t < aend; t += Z_THREADS) {
+            const int i = ca[t];
+            const float4 pr = param[i];
+            float q = pr.x;
+            if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
+            if (q == 0.f) continue;
+            float ux, uy, uz; int kx, ky, kz;
+            pme_scaled(P[i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+            float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
+            bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
+            if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+            float wa = 0.f;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) if (k == a) wa = wx[k];
-                const float qa = q * wa * PME_MESH_SCALE;
+            for (int k = 0; k < 5; ++k) if (k == a) wa = wx[k];
+            const float qa = q * wa * PME_MESH_SCALE;
 #pragma unroll
-                for (int b = 0; b < 5; ++b) {
-                    int iy = ky - b; if (iy < 0) iy += ny;
-                    const int lb = iy - y0;                      // line inside this workgroup?
-                    if (lb < 0 || lb >= nl) continue;
-                    const float qab = qa * wy[b];
+            for (int b = 0; b < 5; ++b) {
+                int iy = ky - b; if (iy < 0) iy += ny;
+                const int lb = iy - y0;                      // line inside this workgroup?
+                if (lb < 0 || lb >= nl) continue;
+                const float qab = qa * wy[b];
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        int iz = kz - c; if (iz < 0) iz += nz;
-                        atomicAdd(&acc[lb * nz + iz], __float2int_rn(qab * wz[c]));
-                    }
+                for (int c = 0; c < 5; ++c) {
+                    int iz = kz - c; if (iz < 0) iz += nz;
+                    atomicAdd(&acc[lb * nz + iz], __float2int_rn(qab * wz[c]));
                 }
             }
         }
@@ -358,7 +336,7 @@ void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const
     const unsigned mnz = fft_magic((unsigned)nz);
     for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
         const int l = fft_div(idx, mnz, nz);
-        buf[idx + l] = make_float2((float)acc[idx] * (1.0f / PME_MESH_SCALE), 0.f);     // l*PZ + z
+        buf[idx + l * (PZ - nz)] = make_float2((float)acc[idx] * (1.0f / PME_MESH_SCALE), 0.f);     // l*PZ + z
     }
     __syncthreads();
     fft_lines_inplace<-1, Z_PPT>(pl, buf, nl, PZ, 1, s_tw, tid, Z_THREADS, true);
@@ -376,7 +354,7 @@ void pme_zinv_kernel(fft_plan pl, int nl, int nx, int ny, const float2* __restri
                      const float2* tw)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz + 1;
+    const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz | 1;
     float2* buf = reinterpret_cast<float2*>(smem);
     float2* s_tw = buf + nl * PZ;
     const int r = blockIdx.y, tid = threadIdx.x;
@@ -397,7 +375,7 @@ void pme_zinv_kernel(fft_plan pl, int nl, int nx, int ny, const float2* __restri
     const unsigned mnz = fft_magic((unsigned)nz);
     for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
         const int l = fft_div(idx, mnz, nz);
-        M[idx] = buf[idx + l].x;
+        M[idx] = buf[idx + l * (PZ - nz)].x;
     }
 }
 
@@ -414,7 +392,7 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nx = plx.n, ny = ply.n, nzc = nz / 2 + 1;
     const int np = nx * ny;
-    const int PS = ny + 1;                                // padded row stride: bank-conflict-free column access
+    const int PS = ny | 1;                                // odd row stride: bank-conflict-free column access
     const int npp = nx * PS;
     float2* buf = reinterpret_cast<float2*>(smem);
     float2* s_twx = buf + npp;                           // twiddle tables staged in LDS
@@ -424,15 +402,8 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
     const int XY_THREADS = blockDim.x;                   // 512 (two workgroups per CU) or 1024 for larger planes
     float2* P = spec + ((size_t)r * nzc + kz) * np;
     const unsigned mny = fft_magic((unsigned)ny);
-    {
-        // 16-byte global loads (two complex points), rows are even-length
-        const float4* P4 = reinterpret_cast<const float4*>(P);
-        for (int idx = tid; idx < np / 2; idx += XY_THREADS) {
-            const float4 q = P4[idx];
-            const int e = 2 * idx, x = fft_div(e, mny, ny);
-            buf[e + x] = make_float2(q.x, q.y); buf[e + x + 1] = make_float2(q.z, q.w);
-        }
-    }
+    const int pad = PS - ny;                               // 0 or 1
+    for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); buf[idx + x * pad] = P[idx]; }   // x*PS + y
     for (int idx = tid; idx < nx; idx += XY_THREADS) s_twx[idx] = twx[idx];
     for (int idx = tid; idx < ny; idx += XY_THREADS) s_twy[idx] = twy[idx];
     twx = s_twx; twy = s_twy;
@@ -455,9 +426,9 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
             const float msq = mx * mx + my * my + mz * mz;
             float g = 0.f;
             if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
-            const float2 sv = buf[idx + kx];                    // kx*PS + ky
+            const float2 sv = buf[idx + kx * pad];              // kx*PS + ky
             if (with_energy) e_acc += 0.5 * (double)(wz * g) * ((double)sv.x * sv.x + (double)sv.y * sv.y);
-            buf[idx + kx] = make_float2(sv.x * g, sv.y * g);
+            buf[idx + kx * pad] = make_float2(sv.x * g, sv.y * g);
         }
         if (with_energy) {
             for (int off = 32; off > 0; off >>= 1) e_acc += __shfl_xor(e_acc, off);
@@ -473,14 +444,7 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
     }
     fft_lines_inplace<+1, XY_PPT>(plx, buf, ny, 1, PS, twx, tid, XY_THREADS, true);
     fft_lines_inplace<+1, XY_PPT>(ply, buf, nx, PS, 1, twy, tid, XY_THREADS, true);
-    {
-        float4* P4 = reinterpret_cast<float4*>(P);
-        for (int idx = tid; idx < np / 2; idx += XY_THREADS) {
-            const int e = 2 * idx, x = fft_div(e, mny, ny);
-            const float2 a = buf[e + x], c = buf[e + x + 1];
-            P4[idx] = make_float4(a.x, a.y, c.x, c.y);
-        }
-    }
+    for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); P[idx] = buf[idx + x * pad]; }
 }
 
 // MODE 0: plain pass.  (kept for the 3-D FFT test hook and as the fall-back for planes larger than the LDS)
@@ -674,8 +638,8 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     h->pme = s;
     for (int k = 0; k < 3; ++k) {
         s->n[k] = h->grid[k];
-        if (s->n[k] < 8 || s->n[k] > 256 || (s->n[k] % FFT_B) != 0 || !factorize(s->n[k], s->radix[k], s->nrad[k]))
-            return remd_fail(h, -3, "PME mesh sizes must be multiples of 8 with factors 2,3,5 and <= 256");
+        if (s->n[k] < 6 || s->n[k] > 256 || !factorize(s->n[k], s->radix[k], s->nrad[k]))
+            return remd_fail(h, -3, "PME mesh sizes must be products of 2, 3, 5 between 6 and 256");
     }
     s->R = h->R;
     s->npts = (size_t)s->n[0] * s->n[1] * s->n[2];
@@ -686,13 +650,8 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     } else {
         REMD_CHECK(h, hipMalloc(&s->d_mesh, sizeof(int) * s->npts * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->nspec * s->R));
-        const size_t nc = (size_t)s->n[0] * s->n[1] + 1;
-        REMD_CHECK(h, hipMalloc(&s->d_col_count, sizeof(int) * nc * s->R));
-        REMD_CHECK(h, hipMalloc(&s->d_col_start, sizeof(int) * nc * s->R));
-        REMD_CHECK(h, hipMalloc(&s->d_cursor, sizeof(int) * nc * s->R));
-        REMD_CHECK(h, hipMalloc(&s->d_atom_col, sizeof(int) * (size_t)h->Npad * s->R));
+        REMD_CHECK(h, hipMalloc(&s->d_col_start, sizeof(int) * (size_t)(s->n[0] + 1) * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_atoms, sizeof(int) * (size_t)h->Npad * s->R));
-        REMD_CHECK(h, hipMemset(s->d_col_count, 0, sizeof(int) * nc * s->R));
     }
     for (int k = 0; k < 3; ++k) {
         const int n = s->n[k];
@@ -718,7 +677,7 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     }
     s->n_eblk = s->nzc;
     REMD_CHECK(h, hipMalloc(&s->d_energy, sizeof(double) * (size_t)s->n_eblk * s->R));
-    s->xy_lds = sizeof(float2) * ((size_t)s->n[0] * (s->n[1] + 1) + s->n[0] + s->n[1]) + 128;
+    s->xy_lds = sizeof(float2) * ((size_t)s->n[0] * (s->n[1] | 1) + s->n[0] + s->n[1]) + 128;
     s->xy_threads = ((size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * 512) ? 512 : 1024;
     s->xy_fused = (size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * s->xy_threads && s->xy_lds <= 160 * 1024;
     if (s->xy_fused)
@@ -752,20 +711,16 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
     const int nx = s->n[0], ny = s->n[1], nz = s->n[2];
     const float* rep_lam = remd_nb_rep_lam(h);
     const float4* param = remd_nb_param(h);
-    const int ncol = nx * ny;
     {
         remd_prof_scope ps(h, "pme_bin", st);
-        const dim3 agrid((h->N + 255) / 256, h->R);
-        hipLaunchKernelGGL(pme_bin_count_kernel, agrid, dim3(256), 0, st, h->N, h->Npad, nx, ny, nz, h->d_pos, h->d_box,
-                           s->d_col_count, s->d_atom_col);
-        hipLaunchKernelGGL(pme_bin_scan_kernel, dim3(h->R), dim3(1024), 0, st, ncol, s->d_col_count, s->d_col_start, s->d_cursor);
-        hipLaunchKernelGGL(pme_bin_fill_kernel, agrid, dim3(256), 0, st, h->N, h->Npad, ncol, s->d_atom_col, s->d_cursor, s->d_col_atoms);
+        hipLaunchKernelGGL(pme_bin_kernel, dim3(h->R), dim3(1024), 0, st, h->N, h->Npad, nx, ny, nz, h->d_pos, h->d_box,
+                           s->d_col_start, s->d_col_atoms);
     }
     {
         remd_prof_scope ps(h, "pme_fft", st);
         int nl = 1;                                   // lines per workgroup: largest divisor of ny whose points fit the registers
         for (int c = 1; c <= ny; ++c) if (ny % c == 0 && c * nz <= Z_PPT * Z_THREADS) nl = c;
-        const size_t zlds = sizeof(float2) * ((size_t)nl * (nz + 1) + nz) + sizeof(int) * (size_t)nl * nz;
+        const size_t zlds = sizeof(float2) * ((size_t)nl * (nz | 1) + nz) + sizeof(int) * (size_t)nl * nz;
         const dim3 zgrid(nx * ny / nl, s->R);
         hipLaunchKernelGGL(pme_spread_zfwd_kernel, zgrid, dim3(Z_THREADS), zlds, st, make_plan(s, 2), nl, nx, ny, h->Npad, h->d_pos,
                            param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
@@ -782,7 +737,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         }
-        const size_t zlds_inv = sizeof(float2) * ((size_t)nl * (nz + 1) + nz);
+        const size_t zlds_inv = sizeof(float2) * ((size_t)nl * (nz | 1) + nz);
         hipLaunchKernelGGL(pme_zinv_kernel, zgrid, dim3(Z_THREADS), zlds_inv, st, make_plan(s, 2), nl, nx, ny, s->d_grid,
                            reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
     }

@@ -273,15 +273,14 @@ def ewald_parameters(cutoff, tolerance, box):
     """alpha and mesh size from the Ewald error tolerance.
 
     alpha = sqrt(-ln(2 tol))/r_c (the formula the reference quotes at alchemy.py:1528-1532);
-    mesh >= 2 alpha L / (3 tol^(1/5)) per axis, rounded up to a multiple of 8 that is a product of
-    2, 3, 5 (the radices of the in-tree FFT).
+    mesh >= 2 alpha L / (3 tol^(1/5)) per axis, rounded up to a product of 2, 3, 5 (the radices of the
+    in-tree FFT).
     """
     alpha = math.sqrt(-math.log(2.0 * tolerance)) / cutoff
     grid = []
     for L in box:
         n = int(math.ceil(2.0 * alpha * L / (3.0 * tolerance ** 0.2)))
         n = max(n, 6)
-        n = (n + 7) // 8 * 8                 # the in-tree FFT transforms 8 adjacent lines per workgroup
         while True:
             m = n
             for p in (2, 3, 5):
@@ -289,7 +288,7 @@ def ewald_parameters(cutoff, tolerance, box):
                     m //= p
             if m == 1:
                 break
-            n += 8
+            n += 1
         grid.append(n)
     return alpha, grid
 
