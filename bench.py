@@ -35,6 +35,21 @@ FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector peak = f32-
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic_bytes(kernel):
+    """HBM-side bytes per launch of `kernel`, measured offline with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    (separate passes, FETCH doubled per MI355X_MICROARCH.md) on this same workload; profiles/README.md has the recipe.
+    None when no measurement is committed."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+        if kernel in table:
+            return float(table[kernel]['hbm_mb_corrected']) * 1.0e6
+    except Exception:
+        pass
+    return None
+
+
 def build_sampler(n_replicas, engine, comm, md_steps):
     from openmmtools_amd import testsystems, states, mcmc, unit
     from openmmtools_amd.multistate import ParallelTemperingSampler
@@ -51,7 +66,7 @@ def build_sampler(n_replicas, engine, comm, md_steps):
     return sampler, ts
 
 
-def cpu_baseline(md_steps_sample=12):
+def cpu_baseline(md_steps_sample=60):
     """The f64 oracle ("port") on the host: a bounded sample of the same workload (one replica, a few
     g-BAOAB steps + one energy evaluation), extrapolated to 24 replicas x 500 steps per iteration."""
     from openmmtools_amd import testsystems
@@ -145,7 +160,8 @@ def main():
             avg_ms = ms / n_launch
             achieved = flops / (avg_ms * 1e-3) / 1e12
             roof = dict(kernel='nonbonded_cluster_kernel', bound='mfma', achieved=achieved, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=achieved / FP32_PEAK_TFLOPS, traffic=None, launches=n_launch, avg_launch_ms=avg_ms,
+                        frac=achieved / FP32_PEAK_TFLOPS, traffic=pmc_traffic_bytes('nonbonded_cluster_kernel'),
+                        launches=n_launch, avg_launch_ms=avg_ms,
                         note='fp32 VALU kernel; peak = FP32 vector rate = f32-input MFMA rate (157.3 TFLOP/s); '
                              'algorithmic work = 10 kflop/atom (SURVEY 8(d))')
         out = dict(metric='REMD iterations/s (propagate+u_kl+mix), 24-replica AlanineDipeptideExplicit per GPU',
