@@ -196,7 +196,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         REMD_CHECK(h, hipMalloc(&h->d_potential, sizeof(double) * R_local));
         REMD_CHECK(h, hipMalloc(&h->d_kinetic, sizeof(double) * R_local));
         REMD_CHECK(h, hipMalloc(&h->d_nan, sizeof(int) * R_local));
-        REMD_CHECK(h, hipMalloc(&h->d_cmm, sizeof(long long) * 4 * R_local));
+        REMD_CHECK(h, hipMalloc(&h->d_cmm, sizeof(long long) * 4 * 2 * R_local));
         h->n_epart = remd_nb_required_epart(h);
         REMD_CHECK(h, hipMalloc(&h->d_epart, sizeof(double) * (size_t)h->n_epart * R_local));
         if (h->K > 0) {
@@ -226,7 +226,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     REMD_CHECK(h, hipMemcpy(h->d_pos, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     REMD_CHECK(h, hipMemcpy(h->d_vel, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     REMD_CHECK(h, hipMemcpy(h->d_box, hb.data(), sizeof(float) * 4 * R_local, hipMemcpyHostToDevice));
-    h->forces_valid = false;
+    h->forces_valid = false; h->force_zeroed = false;
     if (h->nb_method == REMD_NB_PME) { int rc = remd_pme_setup(h); if (rc) return rc; }
     return remd_set_labels(h, labels);
 }

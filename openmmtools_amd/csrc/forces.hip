@@ -37,6 +37,8 @@
 #define NB_LJ_ONLY 0
 #define NB_RF      1
 #define NB_EWALD   2
+#define NB_EWALD_NOLJ 3   // Coulomb only: the LJ-active atoms are handled by a second, much shorter cluster list
+#define NB_RF_NOLJ    4
 
 #define MAX_EXCL_WORDS 8
 
@@ -83,6 +85,14 @@ struct nb_tables {
     // 8-atom cluster pair lists (sorted slot space): lane = (i atom, j atom) of an 8 x 8 cluster pair
     float4* d_cl_c = nullptr; float4* d_cl_h = nullptr;     // [R][ncl] cluster bounding boxes
     unsigned short* d_cl_list = nullptr; int* d_cl_count = nullptr; int cl_cap = 0; bool clusters = true;
+    // LJ-active sub-system (atoms with eps != 0; 1/3 of a TIP3P box): own sorted order, clusters and pair list, so
+    // that the main cluster kernel is Coulomb-only
+    bool lj_split = false; int NL = 0, NLpad = 0, lj_words = 1, lj_cap = 0;
+    int* d_lj_ord = nullptr;              // [Npad] atom -> LJ ordinal (-1: no LJ)
+    unsigned long long* d_lj_mask = nullptr;   // [NLpad][lj_words] exclusion window in LJ-ordinal space
+    int* d_lj_order = nullptr; float4* d_lj_spos = nullptr; float4* d_lj_sparam = nullptr; unsigned long long* d_lj_smask = nullptr;
+    float4* d_lj_tile_c = nullptr; float4* d_lj_tile_h = nullptr; float4* d_lj_cl_c = nullptr; float4* d_lj_cl_h = nullptr;
+    unsigned short* d_lj_list = nullptr; int* d_lj_count = nullptr;
     int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 20; bool sorting = true;
 };
 static std::map<remd_ctx*, nb_tables> g_nb;
@@ -359,7 +369,7 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
     const float sig = pi.y + pj.y, eps4 = pi.z * pj.z;
     float U = 0.f, dUdr = 0.f;
     bool na = false;
-    if (eps4 != 0.f) {
+    if (METHOD <= NB_EWALD && eps4 != 0.f) {
         if (ALCH && (pi.w != pj.w)) {
             // soft-core (alchemy.py:1383-1388 with softcore_c = 6): x = 1/(alpha(1-l)^b + (r/sigma)^6)
             na = true;
@@ -379,7 +389,7 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
     float Uc = 0.f, dUc = 0.f;
     if (METHOD != NB_LJ_ONLY) {
         const float qq = pi.x * pj.x;
-        if (METHOD == NB_EWALD) {
+        if (METHOD == NB_EWALD || METHOD == NB_EWALD_NOLJ) {
             const float ar = p.alpha * r;
             const float ex = __expf(-ar * ar);
             float erfc_ar;
@@ -478,16 +488,56 @@ void gather_params_kernel(int Npad, int words, const int* __restrict__ order, co
         smask[((size_t)r * Npad + k) * words + w] = (o >= 0) ? mask[(size_t)o * words + w] : 0ull;
 }
 
+// LJ-active atoms in the order of the sorted slots (one workgroup per replica): flags -> exclusive scan -> compaction;
+// parameters and exclusion windows are gathered from the LJ-ordinal tables built on the host.
+__global__ __launch_bounds__(1024)
+void compact_lj_kernel(int N, int Npad, int NL, int NLpad, int words, const int* __restrict__ order, const int* __restrict__ lj_ord,
+                       const float4* __restrict__ param, const unsigned long long* __restrict__ lj_mask,
+                       int* __restrict__ lj_order, float4* __restrict__ lj_sparam, unsigned long long* __restrict__ lj_smask)
+{
+    __shared__ int s_part[1024];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int* O = order + (size_t)r * Npad;
+    const int per = (N + 1023) / 1024;
+    const int b = min(N, tid * per), e = min(N, b + per);
+    int cnt = 0;
+    for (int k = b; k < e; ++k) cnt += (lj_ord[O[k]] >= 0) ? 1 : 0;
+    s_part[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int slot = (tid > 0) ? s_part[tid - 1] : 0;
+    for (int k = b; k < e; ++k) {
+        const int a = O[k];
+        const int ord = lj_ord[a];
+        if (ord >= 0) {
+            lj_order[(size_t)r * NLpad + slot] = a;
+            lj_sparam[(size_t)r * NLpad + slot] = param[a];
+            for (int w = 0; w < words; ++w) lj_smask[((size_t)r * NLpad + slot) * words + w] = lj_mask[(size_t)ord * words + w];
+            ++slot;
+        }
+    }
+    for (int k = NL + tid; k < NLpad; k += 1024) {
+        lj_order[(size_t)r * NLpad + k] = -1;
+        lj_sparam[(size_t)r * NLpad + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < words; ++w) lj_smask[((size_t)r * NLpad + k) * words + w] = 0ull;
+    }
+}
+
 // positions into sorted order + bounding box of every 64-atom tile (relative to the tile's first atom, minimum image)
 __global__ __launch_bounds__(64)
-void gather_positions_kernel(int Npad, const int* __restrict__ order, const float4* __restrict__ pos,
+void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ order, const float4* __restrict__ pos,
                              const float* __restrict__ box, float4* __restrict__ spos, float4* __restrict__ tile_c,
                              float4* __restrict__ tile_h, float4* __restrict__ cl_c, float4* __restrict__ cl_h)
 {
     const int tile = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
     const int k = tile * 64 + lane;
     const int o = order[(size_t)r * Npad + k];
-    const float4 x = (o >= 0) ? pos[(size_t)r * Npad + o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 x = (o >= 0) ? pos[(size_t)r * Npad_pos + o] : make_float4(0.f, 0.f, 0.f, 0.f);
     spos[(size_t)r * Npad + k] = x;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const float x0 = __shfl(x.x, 0), y0 = __shfl(x.y, 0), z0 = __shfl(x.z, 0);   // lane 0 of a tile is always a real atom
@@ -570,7 +620,7 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
                               const float4* __restrict__ sparam, const unsigned long long* __restrict__ smask,
                               const int* __restrict__ order, const unsigned short* __restrict__ list,
                               const int* __restrict__ count, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                              long long* __restrict__ force, double* __restrict__ epart, int n_epart)
+                              long long* __restrict__ force, int Npad_force, double* __restrict__ epart, int n_epart, int ep_off)
 {
     const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
     const int ii = lane >> 3, jj = lane & 7;
@@ -590,8 +640,13 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
     for (int w = 0; w < MAX_EXCL_WORDS; ++w)
         mk[w] = (w < p.excl_words) ? smask[((size_t)r * Npad + (iact ? i : 0)) * p.excl_words + w] : 0ull;
     const int half = 32 * p.excl_words;
-    const unsigned short* L = list + ((size_t)r * ncl + ic) * cap;
-    const int n = min(count[(size_t)r * ncl + ic], cap);
+    // gridDim.z wavefronts share the neighbour list of one i cluster (contiguous slices; forces are merged by the
+    // integer atomics at the end), used for the short LJ sub-system lists to expose more parallelism
+    const int n_all = min(count[(size_t)r * ncl + ic], cap);
+    const int per = (n_all + gridDim.z - 1) / gridDim.z;
+    const int l_beg = min(n_all, (int)blockIdx.z * per);
+    const unsigned short* L = list + ((size_t)r * ncl + ic) * cap + l_beg;
+    const int n = min(per, n_all - l_beg);
     float fx = 0.f, fy = 0.f, fz = 0.f;
     double e = 0.0;
     // one cluster pair: every lane evaluates its own (i atom, j atom) pair
@@ -651,11 +706,11 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
     for (int off = 4; off > 0; off >>= 1) { fx += __shfl_xor(fx, off); fy += __shfl_xor(fy, off); fz += __shfl_xor(fz, off); }
     if (iact && jj == 0) {
         // integer atomics: the PME gather may be adding to the same atom on the other stream
-        add_force(force + (size_t)r * 3 * Npad, Npad, order[(size_t)r * Npad + i], fx, fy, fz);
+        add_force(force + (size_t)r * 3 * Npad_force, Npad_force, order[(size_t)r * Npad + i], fx, fy, fz);
     }
     if (ENERGY) {
         e = wave_sum(e);
-        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + ic] = e;
+        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + ep_off + ic * gridDim.z + blockIdx.z] = e;
     }
 }
 
@@ -946,6 +1001,8 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
     dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sparam); dfree(t.d_smask);
     dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
+    dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
+    dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
     g_nb.erase(it);
 }
 
@@ -1133,6 +1190,35 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         if (env2) t.resort_interval = std::max(1, atoi(env2));
     }
 
+    // LJ-active sub-system: worthwhile when charges exist and most atoms carry no LJ (TIP3P hydrogens)
+    {
+        std::vector<int> ord(h->Npad, -1);
+        int NL = 0;
+        for (int i = 0; i < N; ++i) if (d->epsilon[i] != 0.0) ord[i] = NL++;
+        const char* env = getenv("REMD_NB_LJSPLIT");
+        t.lj_split = any_charge && NL > 0 && NL * 10 <= N * 6 && !(env && atoi(env) == 0);
+        if (t.lj_split) {
+            t.NL = NL; t.NLpad = (NL + 63) / 64 * 64;
+            int maxd_lj = 0;
+            for (int e = 0; e < d->n_exceptions; ++e) {
+                const int a = ord[d->exception_atoms[2 * e]], b2 = ord[d->exception_atoms[2 * e + 1]];
+                if (a >= 0 && b2 >= 0) maxd_lj = std::max(maxd_lj, std::abs(a - b2));
+            }
+            t.lj_words = std::max(1, (maxd_lj + 32) / 32);
+            if (t.lj_words > MAX_EXCL_WORDS) t.lj_split = false;
+        }
+        if (t.lj_split) {
+            std::vector<unsigned long long> lm((size_t)t.NLpad * t.lj_words, 0ull);
+            auto setb = [&](int a, int b2) { const int dd = b2 - a + 32 * t.lj_words; lm[(size_t)a * t.lj_words + (dd >> 6)] |= 1ull << (dd & 63); };
+            for (int a = 0; a < t.NL; ++a) setb(a, a);
+            for (int e = 0; e < d->n_exceptions; ++e) {
+                const int a = ord[d->exception_atoms[2 * e]], b2 = ord[d->exception_atoms[2 * e + 1]];
+                if (a >= 0 && b2 >= 0) { setb(a, b2); setb(b2, a); }
+            }
+            if ((rc = upload(h, t.d_lj_ord, ord)) || (rc = upload(h, t.d_lj_mask, lm))) return rc;
+        }
+    }
+
     // dispersion correction of the (possibly alchemically modified) NonbondedForce
     t.disp_coeff = 0.0;
     if (d->use_dispersion_correction) {
@@ -1194,6 +1280,23 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         REMD_CHECK(h, hipMalloc(&t.d_cl_h, sizeof(float4) * (size_t)h->R * ncl));
         REMD_CHECK(h, hipMalloc(&t.d_cl_list, sizeof(unsigned short) * (size_t)h->R * ncl * t.cl_cap));
         REMD_CHECK(h, hipMalloc(&t.d_cl_count, sizeof(int) * (size_t)h->R * ncl));
+        if (t.lj_split) {
+            dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask); dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h);
+            dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
+            const size_t nl = (size_t)h->R * t.NLpad;
+            const int ncl_lj = t.NLpad / 8;
+            t.lj_cap = std::min(ncl_lj, 1024);
+            REMD_CHECK(h, hipMalloc(&t.d_lj_order, sizeof(int) * nl));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_spos, sizeof(float4) * nl));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_sparam, sizeof(float4) * nl));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_smask, sizeof(unsigned long long) * nl * t.lj_words));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_tile_c, sizeof(float4) * (size_t)h->R * (t.NLpad / 64)));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_tile_h, sizeof(float4) * (size_t)h->R * (t.NLpad / 64)));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_cl_c, sizeof(float4) * (size_t)h->R * ncl_lj));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_cl_h, sizeof(float4) * (size_t)h->R * ncl_lj));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_list, sizeof(unsigned short) * (size_t)h->R * ncl_lj * t.lj_cap));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_count, sizeof(int) * (size_t)h->R * ncl_lj));
+        }
         t.sort_R = h->R; t.evals_since_sort = 1 << 30;
     }
     if (t.evals_since_sort >= t.resort_interval) {
@@ -1203,18 +1306,28 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
                            t.d_grp_size, h->d_pos, h->d_box, 0.45f, t.d_order);
         hipLaunchKernelGGL(gather_params_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.p.excl_words,
                            t.d_order, t.d_param, t.d_mask, t.d_sparam, t.d_smask);
+        if (t.lj_split)
+            hipLaunchKernelGGL(compact_lj_kernel, dim3(h->R), dim3(1024), 0, h->stream, h->N, h->Npad, t.NL, t.NLpad, t.lj_words, t.d_order,
+                               t.d_lj_ord, t.d_param, t.d_lj_mask, t.d_lj_order, t.d_lj_sparam, t.d_lj_smask);
         t.evals_since_sort = 0;
     }
     t.evals_since_sort++;
     {
         remd_prof_scope ps(h, "nb_gather");
         const bool cl = t.clusters && ntile * 8 < 65536;
-        hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, t.d_order, h->d_pos, h->d_box,
+        hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, h->Npad, t.d_order, h->d_pos, h->d_box,
                            t.d_spos, t.d_tile_c, t.d_tile_h, cl ? t.d_cl_c : (float4*)nullptr, cl ? t.d_cl_h : (float4*)nullptr);
         if (cl) {
             const int ncl = ntile * 8;
             hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl, h->R), dim3(64), 0, h->stream, ncl, t.cl_cap, t.p.rc2, t.d_cl_c,
                                t.d_cl_h, h->d_box, t.d_cl_list, t.d_cl_count);
+            if (t.lj_split) {
+                const int ntile_lj = t.NLpad / 64, ncl_lj = t.NLpad / 8;
+                hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
+                                   h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
+                hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl_lj, h->R), dim3(64), 0, h->stream, ncl_lj, t.lj_cap, t.p.rc2,
+                                   t.d_lj_cl_c, t.d_lj_cl_h, h->d_box, t.d_lj_list, t.d_lj_count);
+            }
             if (t.evals_since_sort == 1 && (t.cl_cap < ncl || getenv("REMD_DEBUG"))) {
                 // capacity check once per re-sort (the only host synchronisation of this path)
                 std::vector<int> cnt((size_t)h->R * ncl);
@@ -1241,15 +1354,29 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
     const int ntile = (h->N + 63) / 64;
     if (t.sorting && t.clusters && t.d_order && t.d_cl_list && t.n_groups > 0 && t.n_groups < 8192 && ntile * 8 < 65536) {
         const int ncl = ntile * 8;
-        dim3 grid(ncl, h->R);
-        if (t.has_alch)
-            hipLaunchKernelGGL((nonbonded_cluster_kernel<METHOD, ENERGY, true>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl,
-                               t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box, t.d_rep_lam,
-                               h->d_force, h->d_epart, h->n_epart);
-        else
-            hipLaunchKernelGGL((nonbonded_cluster_kernel<METHOD, ENERGY, false>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl,
-                               t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box,
-                               (const float*)nullptr, h->d_force, h->d_epart, h->n_epart);
+        static int main_split = getenv("REMD_NB_MAINSPLIT") ? std::max(1, std::min(4, atoi(getenv("REMD_NB_MAINSPLIT")))) : 4;
+        dim3 grid(ncl, h->R, main_split);
+        const float* rl = t.has_alch ? t.d_rep_lam : (const float*)nullptr;
+        const bool split = t.lj_split && t.d_lj_list && (METHOD == NB_EWALD || METHOD == NB_RF);
+        constexpr int MAIN = (METHOD == NB_EWALD) ? NB_EWALD_NOLJ : (METHOD == NB_RF) ? NB_RF_NOLJ : METHOD;
+#define LAUNCH_CL(M, ALCHF) hipLaunchKernelGGL((nonbonded_cluster_kernel<M, ENERGY, ALCHF>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl, \
+            t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box, rl, h->d_force, h->Npad, h->d_epart, h->n_epart, 0)
+        if (split) { if (t.has_alch) LAUNCH_CL(MAIN, true); else LAUNCH_CL(MAIN, false); }
+        else { if (t.has_alch) LAUNCH_CL(METHOD, true); else LAUNCH_CL(METHOD, false); }
+#undef LAUNCH_CL
+        if (split) {
+            nb_params pl = t.p; pl.excl_words = t.lj_words;
+            const int ncl_lj = t.NLpad / 8;
+            dim3 g2(ncl_lj, h->R, 4);
+            if (t.has_alch)
+                hipLaunchKernelGGL((nonbonded_cluster_kernel<NB_LJ_ONLY, ENERGY, true>), g2, dim3(64), 0, h->stream, pl, t.NL, t.NLpad, ncl_lj,
+                                   t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_smask, t.d_lj_order, t.d_lj_list, t.d_lj_count, h->d_box, rl,
+                                   h->d_force, h->Npad, h->d_epart, h->n_epart, ncl * 4);
+            else
+                hipLaunchKernelGGL((nonbonded_cluster_kernel<NB_LJ_ONLY, ENERGY, false>), g2, dim3(64), 0, h->stream, pl, t.NL, t.NLpad, ncl_lj,
+                                   t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_smask, t.d_lj_order, t.d_lj_list, t.d_lj_count, h->d_box, rl,
+                                   h->d_force, h->Npad, h->d_epart, h->n_epart, ncl * 4);
+        }
         return;
     }
     dim3 grid((ntile + NB_WAVES - 1) / NB_WAVES, t.p.n_jsplit, h->R);
@@ -1280,12 +1407,14 @@ const float4* remd_nb_param(remd_ctx* h) { return g_nb[h].d_param; }
 int remd_nb_required_epart(remd_ctx* h)
 {
     const int ntile = (h->Npad + 63) / 64;
-    return EP_NB0 + ntile * 16 + 8;
+    return EP_NB0 + ntile * 8 * 4 + 8 + ntile * 8 * 4;  // up to 4 slices per main cluster + 4 per LJ-sub-system cluster
 }
 
 int remd_compute_forces(remd_ctx* h, bool with_energy)
 {
-    REMD_CHECK(h, hipMemsetAsync(h->d_force, 0, sizeof(long long) * 3 * (size_t)h->Npad * h->R, h->stream));
+    if (!h->force_zeroed)
+        REMD_CHECK(h, hipMemsetAsync(h->d_force, 0, sizeof(long long) * 3 * (size_t)h->Npad * h->R, h->stream));
+    h->force_zeroed = false;
     if (with_energy)
         REMD_CHECK(h, hipMemsetAsync(h->d_epart, 0, sizeof(double) * (size_t)h->n_epart * h->R, h->stream));
     const int R = h->R;

@@ -29,7 +29,9 @@ struct chain_prog {
     float hV, hR;          // dt/n_V, dt/n_R
     float a, b;            // OU coefficients
     int nO;
-    int accumulate_momentum;  // after the chain, add sum(m v) into d_cmm
+    int accumulate_momentum;  // after the chain, add sum(m v) into cmm buffer cmm_w
+    int cmm_w, cmm_r;         // double-buffered momentum accumulators: 'C' reads cmm_r and clears the other one
+    int zero_force;           // the chain ends with stale forces (an R after its last V): clear them for the next evaluation
 };
 
 struct settle_const { float mO, mH, ra, rb, rc, dOH, dHH; };
@@ -182,7 +184,7 @@ __device__ __forceinline__ float3 gaussian3(uint64_t seed, uint32_t stream, uint
 template <int TYPE, int NAT>
 __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* idx, const float* dist, const settle_const& sc,
                                           float tol, int Npad, float4* __restrict__ P, float4* __restrict__ V,
-                                          const long long* __restrict__ F, const float* __restrict__ invmass, float kT,
+                                          const long long* F, long long* Fw, const float* __restrict__ invmass, float kT,
                                           uint32_t rg, uint64_t seed, const long long* __restrict__ cmm_r, float inv_total_mass)
 {
     float3 x[NAT], v[NAT];
@@ -253,6 +255,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
         P[idx[k]] = make_float4(x[k].x, x[k].y, x[k].z, 0.f);
         V[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
         mom = mom + v[k] * (1.f / im[k]);
+        if (prog.zero_force) { Fw[idx[k]] = 0; Fw[Npad + idx[k]] = 0; Fw[2 * Npad + idx[k]] = 0; }
     }
     return mom;
 }
@@ -262,13 +265,18 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist,
                             settle_const sc, float tol,
                             int Npad, float4* __restrict__ pos, float4* __restrict__ vel,
-                            const long long* __restrict__ force, const float* __restrict__ invmass,
+                            long long* force, const float* __restrict__ invmass,
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass)
 {
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     float3 mom = f3(0, 0, 0);
+    if (uidx == 0 && prog.cmm_r >= 0) {
+        // this chain consumes accumulator cmm_r: clear the OTHER buffer (its sum was consumed one step ago)
+        long long* o = cmm + ((size_t)(1 - prog.cmm_r) * gridDim.y + r) * 4;
+        o[0] = 0; o[1] = 0; o[2] = 0;
+    }
     const int4 a4 = (uidx < n_units) ? unit_atoms[uidx] : make_int4(-1, -1, -1, -1);
     if (a4.x >= 0) {                                            // padding units do nothing
         const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
@@ -278,10 +286,11 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         float4* P = pos + (size_t)r * Npad;
         float4* V = vel + (size_t)r * Npad;
         const long long* F = force + (size_t)r * 3 * Npad;
+        long long* Fw = force + (size_t)r * 3 * Npad;
         const float kT = (float)(1.0 / beta[labels[r_begin + r]]);
         const uint32_t rg = (uint32_t)(r_begin + r);
-        const long long* cr = cmm + (size_t)r * 4;
-#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, invmass, kT, rg, seed, cr, inv_total_mass)
+        const long long* cr = cmm + ((size_t)prog.cmm_r * gridDim.y + r) * 4;
+#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass)
         if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
         else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
         else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
@@ -295,7 +304,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
             mom.x += __shfl_xor(mom.x, off); mom.y += __shfl_xor(mom.y, off); mom.z += __shfl_xor(mom.z, off);
         }
         if ((threadIdx.x & 63) == 0) {
-            unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + (size_t)r * 4);
+            unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + ((size_t)prog.cmm_w * gridDim.y + r) * 4);
             atomicAdd(&c[0], (unsigned long long)(long long)((double)mom.x * 4294967296.0));
             atomicAdd(&c[1], (unsigned long long)(long long)((double)mom.y * 4294967296.0));
             atomicAdd(&c[2], (unsigned long long)(long long)((double)mom.z * 4294967296.0));
@@ -496,10 +505,20 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     base.a = (float)exp(-h->gamma * hO);                         // :1143
     base.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO));       // :1146
     base.nO = nO > 0 ? nO : 1;
+    base.cmm_r = -1; base.cmm_w = 0; base.zero_force = 0;
     chain_prog cur = base; cur.n = 0;
+    int cmm_w = 0;                     // accumulator the next momentum sum goes to
+    bool zeroed_by_chain = false;
     auto flush = [&](bool accumulate) {
         if (cur.n == 0 && !accumulate) return;
         cur.accumulate_momentum = accumulate ? 1 : 0;
+        cur.cmm_w = cmm_w;
+        // forces are stale after an R that follows the chain's last V: let the chain clear them (saves a memset)
+        bool seenR = false, staleAtEnd = false;
+        for (int t = 0; t < cur.n; ++t) { if (cur.tok[t] == 'R') seenR = true; if (cur.tok[t] == 'V') seenR = false; }
+        staleAtEnd = seenR;
+        cur.zero_force = staleAtEnd ? 1 : 0;
+        if (staleAtEnd) zeroed_by_chain = true;
         launch_chain(h, ut, cur);
         cur = base; cur.n = 0;
     };
@@ -507,21 +526,26 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         if (cur.n == MAX_TOK) flush(false);
         cur.tok[cur.n] = tok; cur.o_index[cur.n] = oidx; cur.step[cur.n] = step; cur.n++;
     };
+    if (h->cmm_frequency > 0)
+        hipMemsetAsync(h->d_cmm, 0, sizeof(long long) * 4 * 2 * h->R, h->stream);      // both accumulators, once per call
     for (int s = 0; s < n_steps; ++s) {
         const long long gstep = (long long)iteration * (long long)h->n_steps + first_step + s;
         // integrators.py:1313 addUpdateContextState: CMMotionRemover fires at the top of a step
         if (h->cmm_frequency > 0 && ((first_step + s) % h->cmm_frequency) == 0) {
             bool pending_reads_cmm = false;
             for (int t = 0; t < cur.n; ++t) pending_reads_cmm |= (cur.tok[t] == 'C');
-            if (pending_reads_cmm) flush(false);   // it must see the previous accumulators
-            hipMemsetAsync(h->d_cmm, 0, sizeof(long long) * 4 * h->R, h->stream);
-            flush(true);                        // finishes pending tokens and accumulates sum(m v)
+            if (pending_reads_cmm) flush(false);   // it must see its own accumulator before the next sum starts
+            flush(true);                        // finishes pending tokens and accumulates sum(m v) into buffer cmm_w
             push('C', 0, gstep);
+            cur.cmm_r = cmm_w;                  // this chain subtracts P/M from that buffer and clears the other one
+            cmm_w = 1 - cmm_w;
         }
         int oidx = 0;
         for (char tok : tokens) {
             if (tok == 'V' && !h->forces_valid) {
                 flush(false);
+                h->force_zeroed = zeroed_by_chain;
+                zeroed_by_chain = false;
                 int rc = remd_compute_forces(h, false);
                 if (rc) return rc;
             }
@@ -531,6 +555,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         }
     }
     flush(false);
+    h->force_zeroed = zeroed_by_chain;
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }

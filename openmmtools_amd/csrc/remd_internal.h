@@ -90,8 +90,9 @@ struct remd_ctx {
     double* d_epart = nullptr; int n_epart = 0;   // per-replica per-block energy partials
     double* d_kinetic = nullptr;       // [R]
     int* d_nan = nullptr;              // [R]
-    long long* d_cmm = nullptr;        // [R][4] fixed-point momentum accumulators
+    long long* d_cmm = nullptr;        // [2][R][4] double-buffered fixed-point momentum accumulators
     bool forces_valid = false;
+    bool force_zeroed = false;         // the last integrator chain already cleared d_force (skip the memset)
 
     // ---- PME ------------------------------------------------------------------------
     void* pme = nullptr;               // opaque (pme.hip)
