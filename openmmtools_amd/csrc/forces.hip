@@ -620,9 +620,15 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
                               const float4* __restrict__ sparam, const unsigned long long* __restrict__ smask,
                               const int* __restrict__ order, const unsigned short* __restrict__ list,
                               const int* __restrict__ count, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                              long long* __restrict__ force, int Npad_force, double* __restrict__ epart, int n_epart, int ep_off)
+                              long long* __restrict__ force, int Npad_force, double* __restrict__ epart, int n_epart, int ep_off,
+                              int R, int nsplit)
 {
-    const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    // persistent form: the grid may be smaller than the number of (cluster, replica, slice) work items so that this
+    // VALU-bound kernel never takes more than its share of the wave slots (the PME workgroups need 8 at a time)
+    const int lane = threadIdx.x;
+    const int n_items = ncl * R * nsplit;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int ic = item % ncl, r = (item / ncl) % R, zsl = item / (ncl * R);
     const int ii = lane >> 3, jj = lane & 7;
     const int i = ic * 8 + ii;
     const float4* __restrict__ P = spos + (size_t)r * Npad;
@@ -643,8 +649,8 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
     // gridDim.z wavefronts share the neighbour list of one i cluster (contiguous slices; forces are merged by the
     // integer atomics at the end), used for the short LJ sub-system lists to expose more parallelism
     const int n_all = min(count[(size_t)r * ncl + ic], cap);
-    const int per = (n_all + gridDim.z - 1) / gridDim.z;
-    const int l_beg = min(n_all, (int)blockIdx.z * per);
+    const int per = (n_all + nsplit - 1) / nsplit;
+    const int l_beg = min(n_all, zsl * per);
     const unsigned short* L = list + ((size_t)r * ncl + ic) * cap + l_beg;
     const int n = min(per, n_all - l_beg);
     float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -677,17 +683,20 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
     // The j atoms of 8 cluster pairs at a time go through LDS: each lane fetches one atom (position + parameters)
     // of the NEXT batch into registers before the current batch is processed, and the registers are written to
     // LDS only afterwards, so the global-load latency hides behind 8 cluster pairs of arithmetic.
-    __shared__ float4 s_x[2][64];
-    __shared__ float4 s_p[2][64];
+    // (single buffer: one wavefront per workgroup, LDS operations retire in program order, so the next batch's
+    // writes cannot overtake this batch's reads; 2 KB per wavefront keeps LDS free for the PME workgroups that
+    // share the CU)
+    __shared__ float4 s_x[64];
+    __shared__ float4 s_p[64];
     const int lc = lane >> 3;
     for (int base = 0; base < n; base += 64) {
         const int cnt = min(64, n - base);                       // list entries in this 64-chunk
         const int my_jc = (lane < cnt) ? (int)L[base + lane] : 0;
         int jsrc = __shfl(my_jc, min(lc, cnt - 1));
         float4 gx = P[jsrc * 8 + jj], gp = prm[jsrc * 8 + jj];
-        int buf = 0;
         for (int sub = 0; sub < cnt; sub += 8) {
-            s_x[buf][lane] = gx; s_p[buf][lane] = gp;
+            __syncthreads();
+            s_x[lane] = gx; s_p[lane] = gp;
             __syncthreads();
             if (sub + 8 < cnt) {                                 // prefetch the next batch
                 jsrc = __shfl(my_jc, min(sub + 8 + lc, cnt - 1));
@@ -697,9 +706,8 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
 #pragma unroll 2
             for (int c = 0; c < nb; ++c) {
                 const int jc = __builtin_amdgcn_readlane(my_jc, sub + c);
-                pair_step(jc, s_x[buf][c * 8 + jj], s_p[buf][c * 8 + jj]);
+                pair_step(jc, s_x[c * 8 + jj], s_p[c * 8 + jj]);
             }
-            buf ^= 1;
         }
     }
     // reduce over the 8 j lanes of each i atom
@@ -710,8 +718,9 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
     }
     if (ENERGY) {
         e = wave_sum(e);
-        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + ep_off + ic * gridDim.z + blockIdx.z] = e;
+        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + ep_off + ic * nsplit + zsl] = e;
     }
+    }   // work items
 }
 
 
@@ -1355,27 +1364,34 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
     if (t.sorting && t.clusters && t.d_order && t.d_cl_list && t.n_groups > 0 && t.n_groups < 8192 && ntile * 8 < 65536) {
         const int ncl = ntile * 8;
         static int main_split = getenv("REMD_NB_MAINSPLIT") ? std::max(1, std::min(4, atoi(getenv("REMD_NB_MAINSPLIT")))) : 4;
-        dim3 grid(ncl, h->R, main_split);
+        // wave budget: when the PME pipeline runs concurrently, cap the direct-space kernels at 16 waves per CU
+        static int persist = getenv("REMD_NB_PERSIST") ? atoi(getenv("REMD_NB_PERSIST")) : 16;
+        int ncu = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) ncu = prop.multiProcessorCount; }
+        const bool cap_waves = h->overlap && h->stream2 && t.method == NB_EWALD && persist > 0;
+        const int n_items = ncl * h->R * main_split;
+        dim3 grid(cap_waves ? std::min(n_items, ncu * persist) : n_items);
         const float* rl = t.has_alch ? t.d_rep_lam : (const float*)nullptr;
         const bool split = t.lj_split && t.d_lj_list && (METHOD == NB_EWALD || METHOD == NB_RF);
         constexpr int MAIN = (METHOD == NB_EWALD) ? NB_EWALD_NOLJ : (METHOD == NB_RF) ? NB_RF_NOLJ : METHOD;
 #define LAUNCH_CL(M, ALCHF) hipLaunchKernelGGL((nonbonded_cluster_kernel<M, ENERGY, ALCHF>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl, \
-            t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box, rl, h->d_force, h->Npad, h->d_epart, h->n_epart, 0)
+            t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box, rl, h->d_force, h->Npad, h->d_epart, h->n_epart, 0, \
+            h->R, main_split)
         if (split) { if (t.has_alch) LAUNCH_CL(MAIN, true); else LAUNCH_CL(MAIN, false); }
         else { if (t.has_alch) LAUNCH_CL(METHOD, true); else LAUNCH_CL(METHOD, false); }
 #undef LAUNCH_CL
         if (split) {
             nb_params pl = t.p; pl.excl_words = t.lj_words;
             const int ncl_lj = t.NLpad / 8;
-            dim3 g2(ncl_lj, h->R, 4);
+            const int n_items2 = ncl_lj * h->R * 4;
+            dim3 g2(cap_waves ? std::min(n_items2, ncu * persist) : n_items2);
             if (t.has_alch)
                 hipLaunchKernelGGL((nonbonded_cluster_kernel<NB_LJ_ONLY, ENERGY, true>), g2, dim3(64), 0, h->stream, pl, t.NL, t.NLpad, ncl_lj,
                                    t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_smask, t.d_lj_order, t.d_lj_list, t.d_lj_count, h->d_box, rl,
-                                   h->d_force, h->Npad, h->d_epart, h->n_epart, ncl * 4);
+                                   h->d_force, h->Npad, h->d_epart, h->n_epart, ncl * 4, h->R, 4);
             else
                 hipLaunchKernelGGL((nonbonded_cluster_kernel<NB_LJ_ONLY, ENERGY, false>), g2, dim3(64), 0, h->stream, pl, t.NL, t.NLpad, ncl_lj,
                                    t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_smask, t.d_lj_order, t.d_lj_list, t.d_lj_count, h->d_box, rl,
-                                   h->d_force, h->Npad, h->d_epart, h->n_epart, ncl * 4);
+                                   h->d_force, h->Npad, h->d_epart, h->n_epart, ncl * 4, h->R, 4);
         }
         return;
     }

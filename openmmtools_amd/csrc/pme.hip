@@ -246,6 +246,7 @@ __global__ __launch_bounds__(1024)
 void pme_bin_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __restrict__ pos, const float* __restrict__ box,
                     int* __restrict__ bin_start /*[R][nx+1]*/, int* __restrict__ bin_atoms /*[R][Npad]*/)
 {
+    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     __shared__ int s_cnt[257], s_start[257], s_cur[256];
     const int r = blockIdx.x, tid = threadIdx.x;
     for (int k = tid; k <= nx; k += 1024) s_cnt[k] = 0;
@@ -285,11 +286,12 @@ void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms,
                             float2* __restrict__ spec, const float2* tw)
 {
+    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz | 1;
     float2* buf = reinterpret_cast<float2*>(smem);          // [nl][PZ]
     float2* s_tw = buf + nl * PZ;                           // [nz]
-    int* acc = reinterpret_cast<int*>(s_tw + nz);           // [nl][nz]
+    int* acc = reinterpret_cast<int*>(buf);                 // [nl][nz] aliases buf: converted through registers below
     const int r = blockIdx.y, tid = threadIdx.x;
     const int l0 = blockIdx.x * nl;
     const int x = l0 / ny, y0 = l0 % ny;
@@ -334,9 +336,18 @@ void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const
     }
     __syncthreads();
     const unsigned mnz = fft_magic((unsigned)nz);
-    for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
-        const int l = fft_div(idx, mnz, nz);
-        buf[idx + l * (PZ - nz)] = make_float2((float)acc[idx] * (1.0f / PME_MESH_SCALE), 0.f);     // l*PZ + z
+    {
+        // acc and buf share LDS: every thread first pulls its share of the integer mesh into registers, then all
+        // threads write the complex image (nl * nz <= Z_PPT * Z_THREADS)
+        float val[Z_PPT];
+#pragma unroll
+        for (int q = 0; q < Z_PPT; ++q) { const int idx = tid + q * Z_THREADS; val[q] = (idx < nl * nz) ? (float)acc[idx] * (1.0f / PME_MESH_SCALE) : 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Z_PPT; ++q) {
+            const int idx = tid + q * Z_THREADS;
+            if (idx < nl * nz) { const int l = fft_div(idx, mnz, nz); buf[idx + l * (PZ - nz)] = make_float2(val[q], 0.f); }   // l*PZ + z
+        }
     }
     __syncthreads();
     fft_lines_inplace<-1, Z_PPT>(pl, buf, nl, PZ, 1, s_tw, tid, Z_THREADS, true);
@@ -353,6 +364,7 @@ __global__ __launch_bounds__(Z_THREADS)
 void pme_zinv_kernel(fft_plan pl, int nl, int nx, int ny, const float2* __restrict__ spec, float* __restrict__ mesh,
                      const float2* tw)
 {
+    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz | 1;
     float2* buf = reinterpret_cast<float2*>(smem);
@@ -389,6 +401,7 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
                          const float* __restrict__ bmx, const float* __restrict__ bmy, const float* __restrict__ bmz,
                          const float* __restrict__ box, float alpha, int with_energy, double* __restrict__ energy, int n_eblk)
 {
+    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nx = plx.n, ny = ply.n, nzc = nz / 2 + 1;
     const int np = nx * ny;
@@ -497,6 +510,7 @@ void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __
                        const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                        const float* __restrict__ mesh, long long* __restrict__ force)
 {
+    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (i >= N) return;
@@ -720,7 +734,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
         remd_prof_scope ps(h, "pme_fft", st);
         int nl = 1;                                   // lines per workgroup: largest divisor of ny whose points fit the registers
         for (int c = 1; c <= ny; ++c) if (ny % c == 0 && c * nz <= Z_PPT * Z_THREADS) nl = c;
-        const size_t zlds = sizeof(float2) * ((size_t)nl * (nz | 1) + nz) + sizeof(int) * (size_t)nl * nz;
+        const size_t zlds = sizeof(float2) * ((size_t)nl * (nz | 1) + nz);
         const dim3 zgrid(nx * ny / nl, s->R);
         hipLaunchKernelGGL(pme_spread_zfwd_kernel, zgrid, dim3(Z_THREADS), zlds, st, make_plan(s, 2), nl, nx, ny, h->Npad, h->d_pos,
                            param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
