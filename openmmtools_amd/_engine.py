@@ -58,6 +58,13 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise RuntimeError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                            '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 + libhsa-runtime64 (used for the RCCL
+    # all-gather), and a process that initialises the system ROCm runtime first leaves torch with "No HIP GPUs are
+    # available".  Loading torch first makes libremd_hip.so's NEEDED libamdhip64.so.7 resolve to the already loaded copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.remd_create.argtypes = [C.POINTER(vp), C.c_int, vp]

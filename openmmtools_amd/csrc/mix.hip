@@ -5,13 +5,19 @@
 //   swap-neighbors  replicaexchange.py:366-380
 //   SAMS global     openmmtools/multistate/sams.py:477-501
 //
-// The swap-all loop is a serial dependency chain.  It is parallelised *exactly*: attempts
-// that touch disjoint replica slots commute (label writes are disjoint, the count
-// increments are integer adds), so a wavefront draws 64 consecutive attempts from the
-// counter-based Philox stream, builds for every lane the bit mask of EARLIER lanes that
-// share a replica with it, and then retires lanes in dependency order: a lane fires as
-// soon as all its earlier conflicting lanes have fired.  The result is bit-identical to
-// the sequential loop (tests/test_mix_parity.py against oracle/mix_oracle.c).
+// The swap-all loop is a serial dependency chain.  It is parallelised *exactly* by speculation: a workgroup
+// draws a window of blockDim.x consecutive attempts from the counter-based Philox stream; every attempt keeps a
+// provisional accept/reject decision.  Per replica slot the window's attempts form an ordered chain (ordinal =
+// number of earlier attempts of the window touching the slot, from occupancy bit masks), and one 32-bit word per
+// slot holds the provisionally ACCEPTED attempts of its chain.  The label an attempt sees in slot s is found by
+// hopping backwards: nearest earlier accepted attempt of the chain (one masked count-leading-zeros) -> its
+// partner slot -> ... until no accepted attempt is left, which names the slot whose window-start label arrives.
+// All attempts re-evaluate in sweeps until no decision changes; the dependency is triangular (attempt t only
+// depends on t' < t), so the fixed point is unique and equals the sequential result, and attempt t is final
+// after at most t+1 sweeps (in practice 2-4 sweeps at replica-exchange acceptance rates).  Then every attempt
+// adds its counts and every slot resolves its new label.  The result is bit-identical to the sequential loop
+// (tests/test_mix_parity.py against oracle/mix_oracle.c).  The window scales with R (conflict density ~4/R per
+// attempt pair) and is cut short where a slot would collect more than 32 attempts.
 #include "remd_internal.h"
 #include "rng.h"
 
@@ -29,71 +35,159 @@ __device__ __forceinline__ double mix_logp(const double* __restrict__ U, int ld,
     return __dadd_rn(b, e_jj);
 }
 
-__global__ __launch_bounds__(64)
+#define MIX_CHAIN 32      // attempts of one window per replica slot (bits of the accepted word)
+
+// workgroup barrier ordering LDS traffic only: the fire-and-forget global counter atomics must not be waited for
+__device__ __forceinline__ void mix_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// number of window positions < t set in this slot's occupancy mask
+__device__ __forceinline__ int mix_ordinal(const unsigned long long* touch_r, int t)
+{
+    int n = 0;
+    const int wi = t >> 6;
+    for (int q = 0; q < wi; ++q) n += __popcll(touch_r[q]);
+    if (t & 63) n += __popcll(touch_r[wi] & ((1ull << (t & 63)) - 1ull));
+    return n;
+}
+
+// slot whose window-start label sits in `slot` just before the chain position `ord` of that slot; `m` = the slot's
+// accepted word already masked to positions < ord (loaded by the caller so that two walks can overlap their first read)
+__device__ __forceinline__ int mix_origin(const unsigned* accb, const unsigned* chain, int slot, unsigned m)
+{
+    while (m) {
+        const unsigned e = chain[slot * MIX_CHAIN + 31 - __clz((int)m)];    // nearest earlier accepted swap: go to its partner
+        slot = (int)(e & 0xffffu);
+        const int ord = (int)(e >> 16);
+        m = accb[slot] & ((1u << ord) - 1u);       // ord < 32 for every chain entry
+    }
+    return slot;
+}
+__device__ __forceinline__ unsigned mix_below(int ord) { return ord >= 32 ? 0xffffffffu : ((1u << ord) - 1u); }
+
+// No volatile LDS accesses here (they compile to serialised flat loads).  Every cross-thread hand-over is
+// separated by a workgroup barrier, and reads that race with a same-sweep decision update are harmless: the
+// update raises the changed flag, so another sweep follows.
+template <bool UKL_LDS>
+__global__ __launch_bounds__(1024)
 void mix_swap_all_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
                          const double* __restrict__ g_ukl, int64_t* __restrict__ g_labels,
                          unsigned long long* __restrict__ g_nacc, unsigned long long* __restrict__ g_nprop,
-                         int64_t n_attempts, int ukl_in_lds, int stats_in_lds)
+                         int64_t n_attempts, int stats_in_lds, long long* __restrict__ g_dbg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, W = blockDim.x, nw = W >> 6;
+    long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t0 = clock64(), w0 = wall_clock64();
+#define MIX_TICK(slot) do { if (g_dbg) { long long t1 = clock64(); dbg[slot] += t1 - t0; t0 = t1; } } while (0)
+    const int Rpad = (R + 1) & ~1;
     double* s_u = reinterpret_cast<double*>(smem);
-    volatile int* s_lab = reinterpret_cast<int*>(smem + (ukl_in_lds ? (size_t)R * K * sizeof(double) : 0));
-    unsigned* s_nprop = reinterpret_cast<unsigned*>(const_cast<int*>(s_lab) + ((R + 1) & ~1));   // [K*K] when stats_in_lds
+    unsigned long long* s_touch = reinterpret_cast<unsigned long long*>(smem + (UKL_LDS ? (size_t)R * K * sizeof(double) : 0));   // [R][nw]
+    unsigned* s_chain = reinterpret_cast<unsigned*>(s_touch + (size_t)R * nw);   // [R][32]: partner slot | partner ordinal << 16
+    unsigned* s_accb = s_chain + (size_t)R * MIX_CHAIN;                          // [R] accepted attempts of the slot's chain
+    int* s_lab = reinterpret_cast<int*>(s_accb + Rpad);                          // [2][Rpad]
+    int* s_flag = s_lab + 2 * Rpad;          // [0..2] rotating "a decision changed" flags, [3] effective window length
+    unsigned* s_nprop = reinterpret_cast<unsigned*>(s_flag + 4);                 // [K*K] when stats_in_lds
     unsigned* s_nacc = s_nprop + K * K;
-    const int lane = threadIdx.x;
 
-    if (ukl_in_lds)
-        for (int t = lane; t < R * K; t += 64) s_u[t] = g_ukl[(size_t)(t / K) * ld + (t % K)];
-    for (int t = lane; t < R; t += 64) s_lab[t] = (int)g_labels[t];
-    if (stats_in_lds) for (int t = lane; t < 2 * K * K; t += 64) s_nprop[t] = 0u;
+    if (UKL_LDS)
+        for (int t = tid; t < R * K; t += W) s_u[t] = g_ukl[(size_t)(t / K) * ld + (t % K)];
+    for (int t = tid; t < R; t += W) s_lab[t] = (int)g_labels[t];
+    for (int t = tid; t < R * nw; t += W) s_touch[t] = 0ull;
+    if (tid < 4) s_flag[tid] = 0;
+    if (stats_in_lds) for (int t = tid; t < 2 * K * K; t += W) s_nprop[t] = 0u;
     __syncthreads();
-    const double* U = ukl_in_lds ? s_u : g_ukl;
-    const int ldu = ukl_in_lds ? K : ld;
+    const int ldu = UKL_LDS ? K : ld;
+    int sweep = 0;      // running sweep counter: selects the rotating flag slot
+    int cur_lab = 0;    // which half of s_lab holds the labels at window start
 
-    for (int64_t base = 0; base < n_attempts; base += 64) {
-        const int64_t k = base + lane;
-        const bool valid = k < n_attempts;
+    MIX_TICK(0);
+    for (int64_t base = 0; base < n_attempts;) {
+        const int64_t k = base + tid;
+        const bool active = k < n_attempts;
         philox4 w = remd_philox(seed, REMD_STREAM_SWAP_ALL, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), (uint64_t)iteration);
         const int i = (int)remd_mulhi32(w.w[0], (uint32_t)R);     // randint(R), replicaexchange.py:324
         const int j = (int)remd_mulhi32(w.w[1], (uint32_t)R);     // :325
         const double u = remd_u53(w.w[2], w.w[3]);
+        const int* lab0 = s_lab + cur_lab * Rpad;
+        int* lab1 = s_lab + (cur_lab ^ 1) * Rpad;
 
-        // dependency mask over earlier lanes of this batch
-        unsigned long long dep = 0ull;
-#pragma unroll 8
-        for (int m = 0; m < 64; ++m) {
-            const int im = __builtin_amdgcn_readlane(i, m);
-            const int jm = __builtin_amdgcn_readlane(j, m);
-            const bool c = (m < lane) && (im == i || im == j || jm == i || jm == j);
-            dep |= (unsigned long long)c << m;
+        if (active) {
+            atomicOr(&s_touch[(size_t)i * nw + (tid >> 6)], 1ull << (tid & 63));
+            atomicOr(&s_touch[(size_t)j * nw + (tid >> 6)], 1ull << (tid & 63));
         }
-        unsigned long long done = ~__ballot(valid);
-        while (done != ~0ull) {
-            const bool ready = !((done >> lane) & 1ull) && ((dep & ~done) == 0ull);
-            if (ready) {
-                const int si = s_lab[i], sj = s_lab[j];                                  // :328-329
-                const double log_p = mix_logp(U, ldu, i, j, si, sj);                     // :332-336
-                const bool acc = log_p >= 0.0 || u < remd_exp_det(log_p);                // :343
-                if (acc) { s_lab[i] = sj; s_lab[j] = si; }                               // :345-346
-                if (stats_in_lds) {
-                    atomicAdd(&s_nprop[si * K + sj], 1u); atomicAdd(&s_nprop[sj * K + si], 1u);          // :339-340
-                    if (acc) { atomicAdd(&s_nacc[si * K + sj], 1u); atomicAdd(&s_nacc[sj * K + si], 1u); }   // :348-349
-                } else {
-                    atomicAdd(&g_nprop[(size_t)si * K + sj], 1ull); atomicAdd(&g_nprop[(size_t)sj * K + si], 1ull);
-                    if (acc) { atomicAdd(&g_nacc[(size_t)si * K + sj], 1ull); atomicAdd(&g_nacc[(size_t)sj * K + si], 1ull); }
+        for (int r = tid; r < R; r += W) s_accb[r] = 0u;
+        if (tid == 0) s_flag[3] = W;
+        mix_barrier();
+        int ord_i = 0, ord_j = 0;
+        if (active) {
+            const unsigned long long* ti = s_touch + (size_t)i * nw;
+            const unsigned long long* tj = s_touch + (size_t)j * nw;
+            const int wi = tid >> 6;
+            const unsigned long long low = (1ull << (tid & 63)) - 1ull;
+            for (int q = 0; q < wi; ++q) { ord_i += __popcll(ti[q]); ord_j += __popcll(tj[q]); }
+            ord_i += __popcll(ti[wi] & low); ord_j += __popcll(tj[wi] & low);
+            if (ord_i >= MIX_CHAIN || ord_j >= MIX_CHAIN) atomicMin(&s_flag[3], tid);
+        }
+        mix_barrier();
+        const int weff = s_flag[3];          // >= 1: the first attempt of a window always has ordinal 0
+        const bool live = active && tid < weff;
+        if (live && i != j) {
+            s_chain[i * MIX_CHAIN + ord_i] = (unsigned)j | ((unsigned)ord_j << 16);
+            s_chain[j * MIX_CHAIN + ord_j] = (unsigned)i | ((unsigned)ord_i << 16);
+        }
+        mix_barrier();
+        MIX_TICK(1);
+
+        bool acc = false;
+        int a_seen = -1, b_seen = -1, si = 0, sj = 0;
+        for (;; ++sweep) {
+            if (live) {
+                const unsigned ma = s_accb[i] & mix_below(ord_i), mb = s_accb[j] & mix_below(ord_j);
+                const int a = mix_origin(s_accb, s_chain, i, ma);
+                const int b = mix_origin(s_accb, s_chain, j, mb);
+                if (a != a_seen || b != b_seen) {
+                    a_seen = a; b_seen = b;
+                    si = lab0[a]; sj = lab0[b];                                          // :328-329
+                    const double log_p = UKL_LDS ? mix_logp(s_u, ldu, i, j, si, sj) : mix_logp(g_ukl, ldu, i, j, si, sj);   // :332-336
+                    const bool nacc = log_p >= 0.0 || u < remd_exp_det(log_p);           // :343
+                    if (nacc != acc) {
+                        acc = nacc;
+                        if (i != j) {
+                            atomicXor(&s_accb[i], 1u << ord_i); atomicXor(&s_accb[j], 1u << ord_j);
+                            s_flag[sweep % 3] = 1;
+                        }
+                    }
                 }
             }
-            // single wavefront: LDS operations retire in program order, so the next round's label reads see this
-            // round's writes; only the compiler must not move them (volatile labels + scheduling barrier).  No
-            // s_waitcnt vmcnt here: the fire-and-forget global counter atomics must not stall the chain.
-            __builtin_amdgcn_wave_barrier();
-            done |= __ballot(ready);
+            if (tid == 0) s_flag[(sweep + 1) % 3] = 0;
+            mix_barrier();
+            dbg[5] += 1;
+            if (!s_flag[sweep % 3]) { ++sweep; break; }
         }
+        MIX_TICK(2);
+        // decisions are final: counts (:339-340, :348-349) and the labels after the window (:345-346)
+        if (live) {
+            if (stats_in_lds) {
+                atomicAdd(&s_nprop[si * K + sj], 1u); atomicAdd(&s_nprop[sj * K + si], 1u);
+                if (acc) { atomicAdd(&s_nacc[si * K + sj], 1u); atomicAdd(&s_nacc[sj * K + si], 1u); }
+            } else {
+                atomicAdd(&g_nprop[(size_t)si * K + sj], 1ull); atomicAdd(&g_nprop[(size_t)sj * K + si], 1ull);
+                if (acc) { atomicAdd(&g_nacc[(size_t)si * K + sj], 1ull); atomicAdd(&g_nacc[(size_t)sj * K + si], 1ull); }
+            }
+        }
+        for (int r = tid; r < R; r += W)
+            lab1[r] = lab0[mix_origin(s_accb, s_chain, r, s_accb[r] & mix_below(mix_ordinal(s_touch + (size_t)r * nw, weff)))];
+        mix_barrier();
+        for (int t = tid; t < R * nw; t += W) s_touch[t] = 0ull;
+        cur_lab ^= 1;
+        base += weff;
+        mix_barrier();
+        MIX_TICK(3);
     }
-    __syncthreads();
-    for (int t = lane; t < R; t += 64) g_labels[t] = (int64_t)s_lab[t];
+    if (g_dbg && tid == 0) { for (int q = 0; q < 8; ++q) g_dbg[q] = dbg[q]; g_dbg[6] = wall_clock64() - w0; }
+    for (int t = tid; t < R; t += W) g_labels[t] = (int64_t)s_lab[cur_lab * Rpad + t];
     if (stats_in_lds)
-        for (int t = lane; t < K * K; t += 64) { g_nprop[t] = s_nprop[t]; g_nacc[t] = s_nacc[t]; }
+        for (int t = tid; t < K * K; t += W) { g_nprop[t] = s_nprop[t]; g_nacc[t] = s_nacc[t]; }
 }
 
 // replicaexchange.py:366-380 — neighbouring STATE pairs (s, s+1), s = offset, offset+2, ...
@@ -195,18 +289,39 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         if (R != K) return remd_fail(h, -3, "swap-all requires n_replicas == n_states");
         if (n_attempts < 0) n_attempts = (int64_t)R * R * R;                                   // :269
         size_t ukl_bytes = (size_t)R * K * sizeof(double);
-        const size_t lab_bytes = sizeof(int) * (size_t)((R + 1) & ~1);
+        if (R > 32767) return remd_fail(h, -3, "swap-all supports at most 32767 replicas");
+        // window = 6R attempts (conflict probability between two attempts ~4/R), whole wavefronts, <= 768 threads (measured optimum)
+        static int force_waves = getenv("REMD_MIX_WAVES") ? atoi(getenv("REMD_MIX_WAVES")) : 0;
+        int waves = force_waves > 0 ? force_waves : (4 * R + 63) / 64;
+        waves = std::max(1, std::min(16, waves));
+        static int per_r = getenv("REMD_MIX_WINDOW") ? std::max(1, atoi(getenv("REMD_MIX_WINDOW"))) : 6;
+        static int max_waves = getenv("REMD_MIX_MAXWAVES") ? std::max(1, std::min(16, atoi(getenv("REMD_MIX_MAXWAVES")))) : 12;
+        if (force_waves <= 0) waves = std::max(1, std::min(max_waves, (per_r * R + 63) / 64));
+        while (waves > 1 && (size_t)R * waves * 8 > 64 * 1024) --waves;      // occupancy masks [R][waves] u64
+        const size_t Rp = (size_t)((R + 1) & ~1);
+        const size_t work_bytes = 8 * (size_t)R * waves + 4 * (size_t)R * 32 + 4 * Rp + 8 * Rp + 16;
         const size_t stat_bytes = sizeof(unsigned) * 2 * (size_t)K * K;
-        // counters (32-bit: <= 2 R^3 per entry) live in LDS when everything fits in 160 KB, else global atomics
-        int in_lds = ukl_bytes <= MIX_MAX_LDS_UKL;
-        int stats_lds = ((in_lds ? ukl_bytes : 0) + lab_bytes + stat_bytes <= 156 * 1024) && (2.0 * (double)n_attempts < 4.0e9);
-        size_t lds = (in_lds ? ukl_bytes : 0) + lab_bytes + (stats_lds ? stat_bytes : 0);
+        // u_kl, then the counters (32-bit: <= 2 R^3 per entry), live in LDS when they fit in 160 KB; else global memory
+        int in_lds = ukl_bytes + work_bytes <= 156 * 1024;
+        int stats_lds = ((in_lds ? ukl_bytes : 0) + work_bytes + stat_bytes <= 156 * 1024) && (2.0 * (double)n_attempts < 4.0e9);
+        size_t lds = (in_lds ? ukl_bytes : 0) + work_bytes + (stats_lds ? stat_bytes : 0);
         lds = (lds + 15) & ~(size_t)15;
-        REMD_CHECK(h, hipFuncSetAttribute((const void*)mix_swap_all_kernel,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 160 * 1024) return remd_fail(h, -3, "swap-all working set does not fit in LDS");
+        auto kern = in_lds ? mix_swap_all_kernel<true> : mix_swap_all_kernel<false>;
+        REMD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         remd_prof_scope ps(h, "mix_swap_all");
-        hipLaunchKernelGGL(mix_swap_all_kernel, dim3(1), dim3(64), lds, h->stream,
-                           h->seed, iteration, R, K, ld, d_ukl, d_labels, d_nacc, d_nprop, n_attempts, in_lds, stats_lds);
+        static long long* d_dbg = nullptr;
+        static const bool debug = getenv("REMD_MIX_DEBUG") != nullptr;
+        if (debug && !d_dbg) REMD_CHECK(h, hipMalloc(&d_dbg, 8 * sizeof(long long)));
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), lds, h->stream,
+                           h->seed, iteration, R, K, ld, d_ukl, d_labels, d_nacc, d_nprop, n_attempts, stats_lds, d_dbg);
+        if (debug) {
+            long long hd[8];
+            REMD_CHECK(h, hipStreamSynchronize(h->stream));
+            REMD_CHECK(h, hipMemcpy(hd, d_dbg, sizeof(hd), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[mix] R=%d waves=%d lds=%zu ukl_lds=%d stats_lds=%d cycles: setup %lld window-prep %lld sweeps %lld finalize %lld "
+                    "n_sweeps %lld wall(100MHz ticks) %lld\n", R, waves, lds, in_lds, stats_lds, hd[0], hd[1], hd[2], hd[3], hd[5], hd[6]);
+        }
     } else if (scheme == REMD_MIX_SWAP_NEIGHBORS) {
         if (R != K) return remd_fail(h, -3, "swap-neighbors requires n_replicas == n_states");
         size_t lds = sizeof(int) * (size_t)(R + K);

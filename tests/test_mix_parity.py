@@ -43,6 +43,42 @@ def test_swap_all_full_r128(hip_engine_factory):
         assert np.array_equal(a, b)
 
 
+def test_swap_all_r192_ukl_in_global_memory(hip_engine_factory):
+    """8 GPUs x 24 replicas (bench.py weak scaling): u_kl (295 KB) no longer fits in LDS; PT-like low acceptance."""
+    eng = hip_engine_factory()
+    eng.seed(SEED)
+    R = 192
+    rng = np.random.default_rng(6)
+    kT = 0.0083145 * np.geomspace(300.0, 600.0, R)
+    u = np.outer(-30000.0 + 0.5 * kT * 4500 + rng.normal(size=R) * np.sqrt(2250.0) * kT, 1.0 / kT)
+    labels = rng.permutation(R).astype(np.int64)
+    got = eng.mix_host('swap-all', 2, u, labels, n_attempts=1500000)
+    ref = oracle.mix('swap-all', SEED, 2, u, labels, n_attempts=1500000)
+    for a, b in zip(got[:3], ref[:3]):
+        assert np.array_equal(a, b)
+    assert 0.01 < got[1].sum() / got[2].sum() < 0.3
+
+
+@pytest.mark.parametrize('R', [3, 8, 48, 96])
+def test_swap_all_speculation_stress(hip_engine_factory, R):
+    """Cases that stress the speculative window: every swap accepted (u = 0, longest accepted chains), duplicate
+    labels (swaps that do not change anything), and windows cut short by crowded replica slots (small R)."""
+    eng = hip_engine_factory()
+    eng.seed(SEED + R)
+    rng = np.random.default_rng(100 + R)
+    cases = [(np.zeros((R, R)), rng.permutation(R)),
+             (_ukl(R, R, 1.0, rng), rng.integers(0, R, R)),                 # duplicates allowed by the kernel contract
+             (_ukl(R, R, 0.2, rng), np.arange(R))]
+    for u, labels in cases:
+        labels = labels.astype(np.int64)
+        for it in (0, 3):
+            got = eng.mix_host('swap-all', it, u, labels)
+            ref = oracle.mix('swap-all', SEED + R, it, u, labels)
+            for a, b in zip(got[:3], ref[:3]):
+                assert np.array_equal(a, b)
+            labels = got[0]
+
+
 def test_swap_all_edge_cases(hip_engine_factory):
     eng = hip_engine_factory()
     eng.seed(1)
