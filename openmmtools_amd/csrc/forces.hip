@@ -364,7 +364,9 @@ template <int METHOD, bool ALCH, bool FAST_ERFC>
 __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, float4 pi, float4 pj,
                                                   float lam_a, float sc, float& fr, bool energy_skip_na, float& e_out)
 {
-    const float inv_r = rsqrtf(r2);
+    // hardware v_rsq_f32 / v_rcp_f32 (1 ulp) instead of the libm wrappers: r2 is never denormal here and the
+    // denormal/IEEE-division guards cost a sixth of this VALU-bound loop
+    const float inv_r = __builtin_amdgcn_rsqf(r2);
     const float r = r2 * inv_r;
     const float sig = pi.y + pj.y, eps4 = pi.z * pj.z;
     float U = 0.f, dUdr = 0.f;
@@ -395,7 +397,7 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
             float erfc_ar;
             if (FAST_ERFC) {
                 // Abramowitz & Stegun 7.1.26 (|abs err| < 1.5e-7): force-only evaluations; energies use erfcf
-                const float t = __frcp_rn(1.f + 0.3275911f * ar);
+                const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ar);
                 erfc_ar = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f)))) * ex;
             } else {
                 erfc_ar = erfcf(ar);
@@ -589,6 +591,7 @@ void build_cluster_list_kernel(int ncl, int cap, float rc2, const float4* __rest
 {
     const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
     const float4 ci = cl_c[(size_t)r * ncl + ic], hi = cl_h[(size_t)r * ncl + ic];
     unsigned short* L = list + ((size_t)r * ncl + ic) * cap;
     int n = 0;
@@ -598,7 +601,7 @@ void build_cluster_list_kernel(int ncl, int cap, float rc2, const float4* __rest
         if (jc < ncl) {
             const float4 cj = cl_c[(size_t)r * ncl + jc], hj = cl_h[(size_t)r * ncl + jc];
             float bx = cj.x - ci.x, by = cj.y - ci.y, bz = cj.z - ci.z;
-            bx -= Lx * rintf(bx / Lx); by -= Ly * rintf(by / Ly); bz -= Lz * rintf(bz / Lz);
+            bx -= Lx * rintf(bx * iLx); by -= Ly * rintf(by * iLy); bz -= Lz * rintf(bz * iLz);
             bx = fmaxf(0.f, fabsf(bx) - hi.x - hj.x); by = fmaxf(0.f, fabsf(by) - hi.y - hj.y); bz = fmaxf(0.f, fabsf(bz) - hi.z - hj.z);
             hit = (hi.x >= 0.f) && (bx * bx + by * by + bz * bz <= rc2);
         }

@@ -22,6 +22,8 @@
 #define FFT_T 32
 #define PME_FIXED_SCALE 68719476736.0      // 2^36
 
+struct fft_sched { const uint2* tab; int off[8]; };   // see fft_stage_sched
+
 struct pme_state {
     int n[3] = {0, 0, 0};
     int R = 0;
@@ -36,7 +38,9 @@ struct pme_state {
     int nrad[3] = {0, 0, 0}; int radix[3][8];
     double* d_energy = nullptr;        // [R][n_eblk]
     int n_eblk = 0;
-    float4* d_q = nullptr;             // unused
+    fft_sched sch_x, sch_y, sch_z;     // butterfly schedules of the in-place passes (xy planes; z lines for (sch_nl, sch_zt))
+    uint2* d_sched[3] = {nullptr, nullptr, nullptr};
+    int sch_nl = 0, sch_zt = 0;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -139,63 +143,65 @@ template <int SIGN, int RX> __device__ __forceinline__ void bfly(float2* v)
     if (RX == 2) bfly2<SIGN>(v); else if (RX == 3) bfly3<SIGN>(v); else if (RX == 4) bfly4<SIGN>(v); else bfly5<SIGN>(v);
 }
 
+// Butterfly schedule of one in-place pass, precomputed on the host (build_sched): the index arithmetic of a
+// mixed-radix stage (two divisions by non-constant sizes, five multiplies) is the same for every workgroup and
+// every call, and on the VALU it cost more than the floating-point butterflies themselves.  Entry of butterfly
+// (stage s, slot b, thread t) at tab[off[s] + b * nthreads + t]: x = first input element | first output element << 16
+// (0xffffffff: idle), y = twiddle step.
+
 template <int SIGN, int RX, int PPT>
-__device__ __forceinline__ void fft_stage_inplace(float2* buf, int n, int nlines, int ls, int es, int Ns, int s,
-                                                  unsigned mlines, unsigned mnb, unsigned mNs,
-                                                  const float2* __restrict__ tw, int tid, int nthreads, bool lines_fastest)
+__device__ __forceinline__ void fft_stage_sched(float2* buf, const uint2* __restrict__ tab, int in_stride, int out_stride,
+                                                bool twiddle, const float2* __restrict__ tw, int tid, int nthreads)
 {
     constexpr int NB = (PPT + RX - 1) / RX;
     float2 v[NB][RX];
     int dst[NB];
-    const int nb = n / RX;
-    const int total = nlines * nb;
-    const int tstride = n / (Ns * RX);
+    uint2 e[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) e[b] = tab[b * nthreads + tid];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int idx = tid + b * nthreads;
         dst[b] = -1;
-        if (idx < total) {
-            int l, j;
-            if (ls == 1 || lines_fastest) { j = fft_div(idx, mlines, nlines); l = idx - j * nlines; }
-            else { l = fft_div(idx, mnb, nb); j = idx - l * nb; }
-            const int jq = fft_div(j, mNs, Ns);
-            const int k = j - jq * Ns;
-            const int tstep = k * tstride;
-            const float2* S = buf + l * ls;
+        if (e[b].x != 0xffffffffu) {
+            const float2* S = buf + (e[b].x & 0xffffu);
+            const int tstep = (int)e[b].y;
 #pragma unroll
             for (int r = 0; r < RX; ++r) {
-                v[b][r] = S[(j + r * nb) * es];
-                if (s > 0 && r > 0) {
+                v[b][r] = S[r * in_stride];
+                if (twiddle && r > 0) {
                     float2 w = tw[tstep * r];
                     if (SIGN > 0) w.y = -w.y;
                     v[b][r] = cmul(v[b][r], w);
                 }
             }
             bfly<SIGN, RX>(v[b]);
-            dst[b] = l * ls + (jq * Ns * RX + k) * es;
+            dst[b] = (int)(e[b].x >> 16);
         }
     }
     __syncthreads();                                         // every input of this stage is in registers
 #pragma unroll
     for (int b = 0; b < NB; ++b) if (dst[b] >= 0) {
 #pragma unroll
-        for (int r = 0; r < RX; ++r) buf[dst[b] + r * Ns * es] = v[b][r];
+        for (int r = 0; r < RX; ++r) buf[dst[b] + r * out_stride] = v[b][r];
     }
     __syncthreads();
 }
 
+// in-place FFT of nlines lines (element e of line l at buf[l*ls + e*es]); every thread keeps its share of the points in
+// registers across the barrier, so only ONE LDS image of the data is needed
 template <int SIGN, int PPT>
-__device__ void fft_lines_inplace(const fft_plan& pl, float2* buf, int nlines, int ls, int es,
-                                  const float2* __restrict__ tw, int tid, int nthreads, bool lines_fastest)
+__device__ void fft_lines_inplace(const fft_plan& pl, const fft_sched& sc, float2* buf, int es,
+                                  const float2* __restrict__ tw, int tid, int nthreads)
 {
-    const unsigned mlines = fft_magic((unsigned)nlines);
     int Ns = 1;
     for (int s = 0; s < pl.nrad; ++s) {
         const int Rx = pl.radix[s];
-        if (Rx == 4) fft_stage_inplace<SIGN, 4, PPT>(buf, pl.n, nlines, ls, es, Ns, s, mlines, pl.mnb[s], pl.mNs[s], tw, tid, nthreads, lines_fastest);
-        else if (Rx == 5) fft_stage_inplace<SIGN, 5, PPT>(buf, pl.n, nlines, ls, es, Ns, s, mlines, pl.mnb[s], pl.mNs[s], tw, tid, nthreads, lines_fastest);
-        else if (Rx == 3) fft_stage_inplace<SIGN, 3, PPT>(buf, pl.n, nlines, ls, es, Ns, s, mlines, pl.mnb[s], pl.mNs[s], tw, tid, nthreads, lines_fastest);
-        else fft_stage_inplace<SIGN, 2, PPT>(buf, pl.n, nlines, ls, es, Ns, s, mlines, pl.mnb[s], pl.mNs[s], tw, tid, nthreads, lines_fastest);
+        const int in_stride = (pl.n / Rx) * es, out_stride = Ns * es;
+        const uint2* tab = sc.tab + sc.off[s];
+        if (Rx == 4) fft_stage_sched<SIGN, 4, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else if (Rx == 5) fft_stage_sched<SIGN, 5, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else if (Rx == 3) fft_stage_sched<SIGN, 3, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else fft_stage_sched<SIGN, 2, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
         Ns *= Rx;
     }
 }
@@ -274,14 +280,14 @@ void pme_bin_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __res
     for (int k = tid; k <= nx; k += 1024) bin_start[(size_t)r * (nx + 1) + k] = s_start[k];
 }
 
-#define Z_THREADS 512
-#define Z_PPT 12             // points per thread in registers: nl * nz <= Z_PPT * Z_THREADS
+#define Z_PPT 12             // points per thread in registers: nl * nz <= Z_PPT * ZT (ZT = workgroup size, 256 or 512)
 
 // fused spreading + forward z FFT.  Workgroup = nl lines (x, y0..y0+nl-1), nl a divisor of ny (the whole row when it
 // fits).  Charges are accumulated in LDS as 32-bit fixed point (order-independent => bit-reproducible), converted to
 // complex f32 and transformed in place; the half spectrum is written kz-major in runs of nl points.
+template <int Z_THREADS>
 __global__ __launch_bounds__(Z_THREADS)
-void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const float4* __restrict__ pos,
+void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, int Npad, const float4* __restrict__ pos,
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms,
                             float2* __restrict__ spec, const float2* tw)
@@ -350,7 +356,7 @@ void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const
         }
     }
     __syncthreads();
-    fft_lines_inplace<-1, Z_PPT>(pl, buf, nl, PZ, 1, s_tw, tid, Z_THREADS, true);
+    fft_lines_inplace<-1, Z_PPT>(pl, sc, buf, 1, s_tw, tid, Z_THREADS);
     float2* S = spec + (size_t)r * nzc * nx * ny;
     const unsigned mnl = fft_magic((unsigned)nl);
     for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
@@ -360,8 +366,9 @@ void pme_spread_zfwd_kernel(fft_plan pl, int nl, int nx, int ny, int Npad, const
 }
 
 // inverse z: half spectrum -> nl real lines (Hermitian completion in LDS), written as float mesh[x][y][z]
+template <int Z_THREADS>
 __global__ __launch_bounds__(Z_THREADS)
-void pme_zinv_kernel(fft_plan pl, int nl, int nx, int ny, const float2* __restrict__ spec, float* __restrict__ mesh,
+void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const float2* __restrict__ spec, float* __restrict__ mesh,
                      const float2* tw)
 {
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
@@ -382,7 +389,7 @@ void pme_zinv_kernel(fft_plan pl, int nl, int nx, int ny, const float2* __restri
         if (kz > 0 && kz < nz - kz) buf[b * PZ + nz - kz] = make_float2(v.x, -v.y);
     }
     __syncthreads();
-    fft_lines_inplace<+1, Z_PPT>(pl, buf, nl, PZ, 1, s_tw, tid, Z_THREADS, true);
+    fft_lines_inplace<+1, Z_PPT>(pl, sc, buf, 1, s_tw, tid, Z_THREADS);
     float* M = mesh + (size_t)r * nx * ny * nz + (size_t)l0 * nz;
     const unsigned mnz = fft_magic((unsigned)nz);
     for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
@@ -396,7 +403,7 @@ void pme_zinv_kernel(fft_plan pl, int nl, int nx, int ny, const float2* __restri
 #define XY_MAX_THREADS 1024
 #define XY_PPT 13            // points per thread held in registers: nx * ny <= XY_PPT * XY_THREADS
 __global__ __launch_bounds__(XY_MAX_THREADS)
-void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict__ spec,
+void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched scy, int nz, float2* __restrict__ spec,
                          const float2* twx, const float2* twy,
                          const float* __restrict__ bmx, const float* __restrict__ bmy, const float* __restrict__ bmz,
                          const float* __restrict__ box, float alpha, int with_energy, double* __restrict__ energy, int n_eblk)
@@ -421,8 +428,8 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
     for (int idx = tid; idx < ny; idx += XY_THREADS) s_twy[idx] = twy[idx];
     twx = s_twx; twy = s_twy;
     __syncthreads();
-    fft_lines_inplace<-1, XY_PPT>(ply, buf, nx, PS, 1, twy, tid, XY_THREADS, true);     // along y
-    fft_lines_inplace<-1, XY_PPT>(plx, buf, ny, 1, PS, twx, tid, XY_THREADS, true);     // along x
+    fft_lines_inplace<-1, XY_PPT>(ply, scy, buf, 1, twy, tid, XY_THREADS);      // along y
+    fft_lines_inplace<-1, XY_PPT>(plx, scx, buf, PS, twx, tid, XY_THREADS);     // along x
     {
         const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
         const double V = (double)Lx * Ly * Lz;
@@ -455,8 +462,8 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, int nz, float2* __restrict_
         }
         __syncthreads();
     }
-    fft_lines_inplace<+1, XY_PPT>(plx, buf, ny, 1, PS, twx, tid, XY_THREADS, true);
-    fft_lines_inplace<+1, XY_PPT>(ply, buf, nx, PS, 1, twy, tid, XY_THREADS, true);
+    fft_lines_inplace<+1, XY_PPT>(plx, scx, buf, PS, twx, tid, XY_THREADS);
+    fft_lines_inplace<+1, XY_PPT>(ply, scy, buf, 1, twy, tid, XY_THREADS);
     for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); P[idx] = buf[idx + x * pad]; }
 }
 
@@ -627,6 +634,7 @@ int remd_pme_destroy(remd_ctx* h)
     if (s->d_atom_col) hipFree(s->d_atom_col); if (s->d_col_atoms) hipFree(s->d_col_atoms);
     for (int k = 0; k < 3; ++k) { if (s->d_tw[k]) hipFree(s->d_tw[k]); if (s->d_bmod[k]) hipFree(s->d_bmod[k]); }
     if (s->d_energy) hipFree(s->d_energy);
+    for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
     delete s;
     h->pme = nullptr;
     return 0;
@@ -642,6 +650,42 @@ static fft_plan make_plan(pme_state* s, int axis)
         if (k < pl.nrad) { pl.mnb[k] = fft_magic((unsigned)(pl.n / pl.radix[k])); pl.mNs[k] = fft_magic((unsigned)Ns); Ns *= pl.radix[k]; }
     }
     return pl;
+}
+
+// host mirror of the index arithmetic of one in-place pass (element e of line l at l*ls + e*es, consecutive threads
+// take consecutive lines): fills the butterfly schedule read by fft_stage_sched
+static int build_sched(remd_ctx* h, pme_state* s, int axis, int nlines, int ls, int es, int nthreads, int ppt,
+                       fft_sched* out, uint2** d_tab)
+{
+    const int n = s->n[axis];
+    std::vector<uint2> tab;
+    int Ns = 1;
+    for (int st = 0; st < s->nrad[axis]; ++st) {
+        const int Rx = s->radix[axis][st];
+        const int NB = (ppt + Rx - 1) / Rx;
+        const int nb = n / Rx, total = nlines * nb, tstride = n / (Ns * Rx);
+        if ((long long)NB * nthreads < total) return remd_fail(h, -3, "PME FFT pass does not fit the workgroup registers");
+        out->off[st] = (int)tab.size();
+        for (int b = 0; b < NB; ++b)
+            for (int t = 0; t < nthreads; ++t) {
+                const int idx = t + b * nthreads;
+                uint2 e = make_uint2(0xffffffffu, 0u);
+                if (idx < total) {
+                    const int j = idx / nlines, l = idx % nlines;
+                    const int jq = j / Ns, k = j % Ns;
+                    const int src = l * ls + j * es, dst = l * ls + (jq * Ns * Rx + k) * es;
+                    if (src > 0xffff || dst + (Rx - 1) * Ns * es > 0xffff) return remd_fail(h, -3, "PME plane too large for the FFT schedule");
+                    e = make_uint2((unsigned)src | ((unsigned)dst << 16), (unsigned)(k * tstride));
+                }
+                tab.push_back(e);
+            }
+        Ns *= Rx;
+    }
+    if (*d_tab) { hipFree(*d_tab); *d_tab = nullptr; }
+    REMD_CHECK(h, hipMalloc(d_tab, sizeof(uint2) * tab.size()));
+    REMD_CHECK(h, hipMemcpy(*d_tab, tab.data(), sizeof(uint2) * tab.size(), hipMemcpyHostToDevice));
+    out->tab = *d_tab;
+    return 0;
 }
 
 // full_complex: allocate the [R][nx][ny][nz] complex grid of the FFT test hook instead of the PME buffers
@@ -693,11 +737,19 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     REMD_CHECK(h, hipMalloc(&s->d_energy, sizeof(double) * (size_t)s->n_eblk * s->R));
     s->xy_lds = sizeof(float2) * ((size_t)s->n[0] * (s->n[1] | 1) + s->n[0] + s->n[1]) + 128;
     s->xy_threads = ((size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * 512) ? 512 : 1024;
+    if (getenv("REMD_PME_XYT")) s->xy_threads = std::max(s->xy_threads, std::min(1024, atoi(getenv("REMD_PME_XYT"))));
     s->xy_fused = (size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * s->xy_threads && s->xy_lds <= 160 * 1024;
-    if (s->xy_fused)
+    if (s->xy_fused && !full_complex) {
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
-    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const int PS = s->n[1] | 1;
+        int rc = build_sched(h, s, 1, s->n[0], PS, 1, s->xy_threads, XY_PPT, &s->sch_y, &s->d_sched[1]);      // along y: lines = x rows
+        if (!rc) rc = build_sched(h, s, 0, s->n[1], 1, PS, s->xy_threads, XY_PPT, &s->sch_x, &s->d_sched[0]);  // along x: lines = y columns
+        if (rc) return rc;
+    }
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return 0;
 }
 
@@ -732,15 +784,28 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
     }
     {
         remd_prof_scope ps(h, "pme_fft", st);
-        int nl = 1;                                   // lines per workgroup: largest divisor of ny whose points fit the registers
-        for (int c = 1; c <= ny; ++c) if (ny % c == 0 && c * nz <= Z_PPT * Z_THREADS) nl = c;
+        // lines per workgroup: a divisor of ny whose points fit the registers of the workgroup
+        static const int zt_env = getenv("REMD_PME_ZT") ? atoi(getenv("REMD_PME_ZT")) : 512;
+        static const int nl_cap = getenv("REMD_PME_NL") ? atoi(getenv("REMD_PME_NL")) : 1 << 30;
+        const int ZT = zt_env == 256 ? 256 : 512;
+        int nl = 1;
+        for (int c = 1; c <= ny && c <= nl_cap; ++c) if (ny % c == 0 && c * nz <= Z_PPT * ZT) nl = c;
         const size_t zlds = sizeof(float2) * ((size_t)nl * (nz | 1) + nz);
         const dim3 zgrid(nx * ny / nl, s->R);
-        hipLaunchKernelGGL(pme_spread_zfwd_kernel, zgrid, dim3(Z_THREADS), zlds, st, make_plan(s, 2), nl, nx, ny, h->Npad, h->d_pos,
-                           param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
+        if (s->sch_nl != nl || s->sch_zt != ZT) {
+            int rc = build_sched(h, s, 2, nl, nz | 1, 1, ZT, Z_PPT, &s->sch_z, &s->d_sched[2]);
+            if (rc) return rc;
+            s->sch_nl = nl; s->sch_zt = ZT;
+        }
+        if (ZT == 256)
+            hipLaunchKernelGGL(pme_spread_zfwd_kernel<256>, zgrid, dim3(256), zlds, st, make_plan(s, 2), s->sch_z, nl, nx, ny, h->Npad, h->d_pos,
+                               param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
+        else
+            hipLaunchKernelGGL(pme_spread_zfwd_kernel<512>, zgrid, dim3(512), zlds, st, make_plan(s, 2), s->sch_z, nl, nx, ny, h->Npad, h->d_pos,
+                               param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
         if (s->xy_fused) {
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
-                               nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
+                               s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
                                (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);
         } else {
             // spec layout [kz][x][y]: y lines contiguous, x lines strided by ny
@@ -752,8 +817,12 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         }
         const size_t zlds_inv = sizeof(float2) * ((size_t)nl * (nz | 1) + nz);
-        hipLaunchKernelGGL(pme_zinv_kernel, zgrid, dim3(Z_THREADS), zlds_inv, st, make_plan(s, 2), nl, nx, ny, s->d_grid,
-                           reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
+        if (ZT == 256)
+            hipLaunchKernelGGL(pme_zinv_kernel<256>, zgrid, dim3(256), zlds_inv, st, make_plan(s, 2), s->sch_z, nl, nx, ny, s->d_grid,
+                               reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
+        else
+            hipLaunchKernelGGL(pme_zinv_kernel<512>, zgrid, dim3(512), zlds_inv, st, make_plan(s, 2), s->sch_z, nl, nx, ny, s->d_grid,
+                               reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
     }
     {
         remd_prof_scope ps(h, "pme_gather", st);
