@@ -307,12 +307,16 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
     const int* cs = col_start + (size_t)r * (nx + 1);
     const int* ca = col_atoms + (size_t)r * Npad;
     const float4* P = pos + (size_t)r * Npad;
-    // candidate atoms: mesh column kx in {x .. x+4} (stencil index a = kx - x); the y stencil is tested per atom
-    for (int a = 0; a < 5; ++a) {
-        int kxc = x + a; if (kxc >= nx) kxc -= nx;
-        const int abeg = cs[kxc], aend = cs[kxc + 1];
-        for (int t = abeg + tid; t < aend; t += Z_THREADS) {
-            const int i = ca[t];
+    // candidate atoms: mesh column kx in {x .. x+4} (stencil index a = kx - x); the y stencil is tested per atom.  The
+    // columns are consecutive in the binned atom array (two runs when they wrap), so all candidates are taken in ONE
+    // pass: one dependent chain of global loads (bin -> atom -> position) per workgroup instead of five.
+    {
+        const int xe = x + 5;
+        const int beg0 = cs[x], end0 = cs[xe <= nx ? xe : nx];
+        const int beg1 = cs[0], end1 = (xe <= nx) ? beg1 : cs[xe - nx];
+        const int n0 = end0 - beg0, ntot = n0 + (end1 - beg1);
+        for (int t = tid; t < ntot; t += Z_THREADS) {
+            const int i = ca[t < n0 ? beg0 + t : beg1 + (t - n0)];
             const float4 pr = param[i];
             float q = pr.x;
             if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
@@ -321,7 +325,8 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
             pme_scaled(P[i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
             float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
             bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
-            if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+            if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+            int a = kx - x; if (a < 0) a += nx;              // 0..4 by construction of the bins
             float wa = 0.f;
 #pragma unroll
             for (int k = 0; k < 5; ++k) if (k == a) wa = wx[k];
