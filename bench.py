@@ -43,8 +43,10 @@ def pmc_traffic_bytes(kernel):
     try:
         with open(path) as fh:
             table = json.load(fh)
-        if kernel in table:
-            return float(table[kernel]['hbm_mb_corrected']) * 1.0e6
+        # one force evaluation launches the Coulomb and the LJ sub-system instantiation (force-only, non-alchemical)
+        hits = [v for k, v in table.items() if kernel in k and ('<' not in k or k.rstrip().endswith('false, false>'))]
+        if hits:
+            return sum(float(v['hbm_mb_corrected']) for v in hits) * 1.0e6
     except Exception:
         pass
     return None
