@@ -58,10 +58,12 @@ int remd_create(remd_handle* out, int device, void* stream)
     h->stream = (hipStream_t)stream;
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     {
-        // the reciprocal-space chain is the longer critical path: give its stream the highest priority
+        // second stream: carries the direct-space kernels while the (longer) reciprocal-space chain stays on the main one
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess)
+        const char* pe = getenv("REMD_S2_PRIO");
+        const int prio = (pe && !strcmp(pe, "lo")) ? lo : (pe && !strcmp(pe, "mid")) ? (lo + hi) / 2 : hi;
+        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio) != hipSuccess)
             hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
     }
     hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);

@@ -1443,18 +1443,29 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
                  h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
     }
-    bool pme_forked = false;
+    bool pme_forked = false, swapped = false;
+    struct unswap { remd_ctx* h; bool* on; ~unswap() { if (*on) std::swap(h->stream, h->stream2); } } guard{h, &swapped};
     if (h->nb_method != REMD_NB_NONE) {      // per-replica lambdas must be current before ANY kernel reads them
         nb_tables& t0 = g_nb[h];
         int rc0 = update_replica_lambdas(h, t0);
         if (rc0) return rc0;
         if (t0.method == NB_EWALD && h->overlap && h->stream2) {
-            // fork: the reciprocal-space pipeline runs on the second stream while this one does the direct space
+            // fork: the reciprocal-space pipeline is the longer branch, so IT stays on the main stream directly behind the
+            // integrator chain (no cross-stream event latency on the critical path); the direct-space launches below go
+            // to the second stream (h->stream is swapped until the join) and absorb the event wait in their slack
+            static const bool pme_on_main = !(getenv("REMD_PME_MAIN") && atoi(getenv("REMD_PME_MAIN")) == 0);
             hipEventRecord(h->ev_fork, h->stream);
             hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
-            rc0 = remd_pme_forces(h, with_energy, h->stream2);
-            if (rc0) return rc0;
-            hipEventRecord(h->ev_join, h->stream2);
+            if (pme_on_main) {
+                rc0 = remd_pme_forces(h, with_energy, h->stream);
+                if (rc0) return rc0;
+                std::swap(h->stream, h->stream2);
+                swapped = true;
+            } else {
+                rc0 = remd_pme_forces(h, with_energy, h->stream2);
+                if (rc0) return rc0;
+                hipEventRecord(h->ev_join, h->stream2);
+            }
             pme_forked = true;
         }
     }
@@ -1525,7 +1536,10 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
                      t.p.two_alpha_sqrtpi, h->Npad, h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);
         }
         if (t.method == NB_EWALD) {
-            if (pme_forked) hipStreamWaitEvent(h->stream, h->ev_join, 0);       // join
+            if (pme_forked) {                                                   // join
+                if (swapped) { hipEventRecord(h->ev_join, h->stream); std::swap(h->stream, h->stream2); swapped = false; }
+                hipStreamWaitEvent(h->stream, h->ev_join, 0);
+            }
             else { rc = remd_pme_forces(h, with_energy, h->stream); if (rc) return rc; }
         }
         if (with_energy)
