@@ -124,6 +124,13 @@ int  remd_set_integrator(remd_handle h, const char* splitting, double timestep_p
                          double collision_rate_invps, int n_steps,
                          int reassign_velocities, double constraint_tolerance);
 
+/* BaseIntegratorMove.n_restart_attempts (mcmc.py:668-776, retry loop :706-759): when a replica
+   holds a NaN after remd_propagate's MD steps, its pre-propagate positions/velocities are
+   restored and the move is repeated (fresh noise: the Philox counters carry the attempt
+   number) up to n more times; replicas that were fine keep the result of the attempt in which
+   they first succeeded.  nan_flags report the replicas that failed every attempt.  Default 0. */
+int  remd_set_restart_attempts(remd_handle h, int n_restart_attempts);
+
 /* Replicas r_begin .. r_begin+R_local-1 of R_global live on this handle.
    x, v: [R_local][N][3] (v may be NULL -> zero); box: [R_local][3] orthorhombic edge
    lengths; labels: [R_global] state index of every replica.

@@ -44,6 +44,7 @@ EXPORTS = [
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
+    'remd_set_restart_attempts',
 ]
 
 _lib = None
@@ -75,6 +76,7 @@ def load_library(path=None):
     lib.remd_set_system.argtypes = [vp, C.POINTER(RemdSystemDesc)]
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
+    lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
     lib.remd_set_replicas.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]
     lib.remd_set_labels.argtypes = [vp, c_int64_p]
     lib.remd_seed.argtypes = [vp, C.c_uint64]
@@ -203,6 +205,10 @@ class HipEngine:
         self._check(self.lib.remd_set_integrator(self.h, splitting.encode(), float(timestep), float(collision_rate),
                                                  int(n_steps), int(bool(reassign_velocities)),
                                                  float(constraint_tolerance)), 'remd_set_integrator')
+
+    def set_restart_attempts(self, n):
+        """mcmc.py:706-759: retries of a move whose result holds a NaN (restored start state, fresh noise)."""
+        self._check(self.lib.remd_set_restart_attempts(self.h, int(n)), 'remd_set_restart_attempts')
 
     def set_replicas(self, R_global, r_begin, x, v, box, labels):
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -88,6 +88,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_beta); dfree(h->d_lam_s); dfree(h->d_lam_e); dfree(h->d_econst);
     dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_pos_ref); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels);
     dfree(h->d_ukl); dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
+    dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -233,6 +234,13 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     return remd_set_labels(h, labels);
 }
 
+int remd_set_restart_attempts(remd_handle h, int n)
+{
+    if (!h || n < 0) return remd_fail(h, -1, "remd_set_restart_attempts: bad arguments");
+    h->n_restart_attempts = n;
+    return 0;
+}
+
 int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
 {
     if (!h || !h->has_system || !h->has_integrator || h->R <= 0 || h->K <= 0)
@@ -240,12 +248,45 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     hipSetDevice(h->device);
     hipEventRecord(h->ev0, h->stream);
     int rc;
-    if (h->reassign) { if ((rc = remd_assign_velocities(h, iteration))) return rc; }
-    if ((rc = remd_run_steps(h, h->tokens, h->nV, h->nR, h->nO, iteration, 0, h->n_steps))) return rc;
-    if ((rc = remd_check_finite(h))) return rc;
-    hipEventRecord(h->ev1, h->stream);
+    const int attempts = h->n_restart_attempts;
+    const size_t seg = (size_t)h->Npad, bytes = sizeof(float4) * seg * h->R;
+    if (attempts > 0) {
+        // mcmc.py:700-703: the state the move starts from is what a failed attempt is reset to
+        if (!h->d_snap_pos) {
+            REMD_CHECK(h, hipMalloc(&h->d_snap_pos, bytes)); REMD_CHECK(h, hipMalloc(&h->d_snap_vel, bytes));
+            REMD_CHECK(h, hipMalloc(&h->d_fin_pos, bytes)); REMD_CHECK(h, hipMalloc(&h->d_fin_vel, bytes));
+        }
+        REMD_CHECK(h, hipMemcpyAsync(h->d_snap_pos, h->d_pos, bytes, hipMemcpyDeviceToDevice, h->stream));
+        REMD_CHECK(h, hipMemcpyAsync(h->d_snap_vel, h->d_vel, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
     std::vector<int> flags(h->R, 0);
-    REMD_CHECK(h, hipMemcpyAsync(flags.data(), h->d_nan, sizeof(int) * h->R, hipMemcpyDeviceToHost, h->stream));
+    std::vector<char> pending(h->R, 1);
+    for (int a = 0;; ++a) {
+        // the attempt number rides in the high bits of the iteration counter => fresh velocities and OU noise
+        const int64_t it = iteration + ((int64_t)a << 40);
+        if (h->reassign) { if ((rc = remd_assign_velocities(h, it))) return rc; }
+        if ((rc = remd_run_steps(h, h->tokens, h->nV, h->nR, h->nO, it, 0, h->n_steps))) return rc;
+        if ((rc = remd_check_finite(h))) return rc;
+        REMD_CHECK(h, hipMemcpyAsync(flags.data(), h->d_nan, sizeof(int) * h->R, hipMemcpyDeviceToHost, h->stream));
+        REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        int n_bad = 0;
+        for (int r = 0; r < h->R; ++r) if (pending[r] && flags[r]) ++n_bad;
+        if (a == 0 && (n_bad == 0 || attempts == 0)) break;              // the normal case: nothing to restore
+        const bool last = (n_bad == 0) || (a == attempts);
+        for (int r = 0; r < h->R; ++r) {
+            if (!pending[r] || (flags[r] && !last)) continue;             // (a replica that failed for good keeps its NaN state)
+            REMD_CHECK(h, hipMemcpyAsync(h->d_fin_pos + r * seg, h->d_pos + r * seg, sizeof(float4) * seg, hipMemcpyDeviceToDevice, h->stream));
+            REMD_CHECK(h, hipMemcpyAsync(h->d_fin_vel + r * seg, h->d_vel + r * seg, sizeof(float4) * seg, hipMemcpyDeviceToDevice, h->stream));
+            if (!flags[r]) pending[r] = 0;
+        }
+        const float4* src_p = last ? h->d_fin_pos : h->d_snap_pos;
+        const float4* src_v = last ? h->d_fin_vel : h->d_snap_vel;
+        REMD_CHECK(h, hipMemcpyAsync(h->d_pos, src_p, bytes, hipMemcpyDeviceToDevice, h->stream));
+        REMD_CHECK(h, hipMemcpyAsync(h->d_vel, src_v, bytes, hipMemcpyDeviceToDevice, h->stream));
+        h->forces_valid = false; h->force_zeroed = false;
+        if (last) { for (int r = 0; r < h->R; ++r) flags[r] = pending[r] ? 1 : 0; break; }
+    }
+    hipEventRecord(h->ev1, h->stream);
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
     float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_prop = ms;
     if (nan_flags) for (int r = 0; r < h->R; ++r) nan_flags[r] = flags[r];
@@ -295,7 +336,8 @@ int remd_compute_energies(remd_handle h, double* d_ukl_rows, double* ukl_host, d
 static int ensure_mix_buffers(remd_ctx* h, int R, int K)
 {
     if (h->stats_K != K || !h->d_nacc) {
-        dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw);
+        dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel);
+    dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw);
         REMD_CHECK(h, hipMalloc(&h->d_nacc, sizeof(unsigned long long) * (size_t)K * K));
         REMD_CHECK(h, hipMalloc(&h->d_nprop, sizeof(unsigned long long) * (size_t)K * K));
         REMD_CHECK(h, hipMalloc(&h->d_logw, sizeof(double) * K));

@@ -211,6 +211,7 @@ class MultiStateSampler:
         move = self._engine_move()
         eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
                            move.reassign_velocities, move.constraint_tolerance)
+        eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
         eng.seed(self._seed)
         R = self.n_replicas
         self._r_begin, self._r_count = self._comm.partition(R)

@@ -31,6 +31,9 @@ class OracleEngine:
         self.integ_args = (splitting, timestep, collision_rate, n_steps)
         self.reassign = reassign_velocities
 
+    def set_restart_attempts(self, n):
+        self.n_restart_attempts = int(n)
+
     def set_replicas(self, R_global, r_begin, x, v, box, labels):
         self.R_global, self.r_begin = R_global, r_begin
         self.x = np.array(x, dtype=np.float64)
@@ -59,12 +62,17 @@ class OracleEngine:
             rg = self.r_begin + r
             k = self.labels[rg]
             kT = 1.0 / self.beta[k]
-            if self.reassign:
-                self.v[r] = integ.assign_velocities(self.x[r], kT, rg, iteration)
-            self.x[r], self.v[r] = integ.run(self.x[r], self.v[r], self._box(r), kT, rg, iteration,
-                                             lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
-            if not (np.isfinite(self.x[r]).all() and np.isfinite(self.v[r]).all()):
-                flags[r] = 1
+            x0, v0 = self.x[r].copy(), self.v[r].copy()
+            # mcmc.py:706-759: a NaN result restores the start state and repeats the move with fresh noise (the attempt
+            # number rides in the high bits of the iteration counter, as in remd_propagate)
+            for attempt in range(getattr(self, 'n_restart_attempts', 0) + 1):
+                it = iteration + (attempt << 40)
+                v = integ.assign_velocities(x0, kT, rg, it) if self.reassign else v0
+                self.x[r], self.v[r] = integ.run(x0, v, self._box(r), kT, rg, it,
+                                                 lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
+                flags[r] = 0 if (np.isfinite(self.x[r]).all() and np.isfinite(self.v[r]).all()) else 1
+                if not flags[r]:
+                    break
         return flags
 
     def step(self, splitting, iteration=0, first_step=0, n_steps=1):

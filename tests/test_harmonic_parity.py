@@ -134,3 +134,30 @@ def test_equipartition_statistics(hip_engine_factory):
     expect = 1.5 * KB * 300.0
     sem = U.std() / np.sqrt(len(U) / 2.0)
     assert abs(U.mean() - expect) < 6.0 * sem, (U.mean(), expect, sem)
+
+
+def test_nan_restart_bookkeeping(hip_engine_factory):
+    """remd_set_restart_attempts (mcmc.py:706-759): a replica that fails every attempt is flagged, and the replicas
+    that were fine keep exactly the result of their first (successful) attempt although the batch was re-run."""
+    clean, eng = hip_engine_factory(), hip_engine_factory()
+    R = 4
+    rng = np.random.default_rng(1)
+    x = rng.normal(scale=0.01, size=(R, 1, 3))
+    _setup(clean, R=R, x=x)
+    flags = clean.propagate(5)
+    assert not flags.any()
+    xc, vc, _, _ = clean.get_replicas()
+    xbad = x.copy()
+    xbad[2] = np.nan
+    _setup(eng, R=R, x=xbad)
+    eng.set_restart_attempts(3)
+    flags = eng.propagate(5)
+    assert flags.tolist() == [0, 0, 1, 0]
+    xg, vg, _, _ = eng.get_replicas()
+    for r in (0, 1, 3):
+        assert np.array_equal(xg[r], xc[r]) and np.array_equal(vg[r], vc[r])
+    assert not np.isfinite(xg[2]).all()
+    # the state stays usable: energies of the healthy replicas are finite, the next propagate flags the same replica
+    u = eng.compute_energies()
+    assert np.isfinite(u[[0, 1, 3]]).all()
+    assert eng.propagate(6).tolist() == [0, 0, 1, 0]

@@ -118,3 +118,58 @@ def test_reduced_potential_algebra():
     assert np.isclose(ts.reduced_potential(ss), 12.5 / (0.008314462618153242 * 300.0))
     with pytest.raises(NotImplementedError):
         states.ThermodynamicState(ho.system, 300.0, pressure=1.0 * unit.atmosphere)
+
+
+def test_nan_restart_attempts_follow_the_reference_protocol():
+    """mcmc.py:706-759: a move that ends in NaN is repeated from its start state with fresh noise up to
+    n_restart_attempts times; a replica that keeps failing raises SimulationNaNError
+    (multistate/utils.py:51).  The oracle engine's integrator is patched to fail on chosen attempts."""
+    from oracle import md_oracle as mo
+    from openmmtools_amd.multistate.utils import SimulationNaNError
+    ho, ts, ss = _ho_states(3)
+    calls = []
+    real_run = mo.OracleLangevin.run
+
+    def make(failing):
+        def run(self, x, v, box, kT, replica, iteration, **kw):
+            attempt = iteration >> 40
+            calls.append((replica, attempt))
+            xo, vo = real_run(self, x, v, box, kT, replica, iteration, **kw)
+            if (replica, attempt) in failing:
+                xo = xo * np.nan
+            return xo, vo
+        return run
+
+    def sampler(n_restart):
+        move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                                  n_steps=5, reassign_velocities=True, splitting='V R O R V',
+                                                  n_restart_attempts=n_restart)
+        s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=1, engine=OracleEngine(), seed=3)
+        s.create(ts, [ss], min_temperature=300.0, max_temperature=600.0, n_temperatures=3)
+        return s
+
+    try:
+        # replica 1 fails twice, succeeds on the third attempt; the others run once
+        mo.OracleLangevin.run = make({(1, 0), (1, 1)})
+        s = sampler(4)
+        s.run()
+        assert [c for c in calls if c[0] == 1] == [(1, 0), (1, 1), (1, 2)]
+        assert [c for c in calls if c[0] == 0] == [(0, 0)] and [c for c in calls if c[0] == 2] == [(2, 0)]
+        assert np.isfinite(np.stack([st.positions for st in s.sampler_states])).all()
+        # the retried replica used different noise: its result differs from a clean run, the others are identical
+        mo.OracleLangevin.run = real_run
+        clean = sampler(4)
+        clean.run()
+        xa = np.stack([st.positions for st in s.sampler_states])
+        xb = np.stack([st.positions for st in clean.sampler_states])
+        moved = [not np.array_equal(xa[r], xb[r]) for r in range(3)]
+        assert sum(moved) == 1
+        # attempts exhausted -> the error of the reference
+        calls.clear()
+        mo.OracleLangevin.run = make({(2, a) for a in range(8)})
+        s = sampler(2)
+        with pytest.raises(SimulationNaNError):
+            s.run()
+        assert [c for c in calls if c[0] == 2] == [(2, 0), (2, 1), (2, 2)]
+    finally:
+        mo.OracleLangevin.run = real_run
