@@ -36,6 +36,9 @@ class SingleProcessComm:
     def broadcast_labels(self, labels):
         return labels
 
+    def gather_objects(self, obj):
+        return [obj]
+
     def barrier(self):
         pass
 
@@ -81,6 +84,13 @@ class TorchDistributedComm:
         t = torch.as_tensor(np.asarray(labels, dtype=np.int64), device=dev)
         self.dist.broadcast(t, src=0, group=self.group)
         return t.cpu().numpy()
+
+    def gather_objects(self, obj):
+        """Host-side gather to rank 0 (checkpoint snapshots only; the reference gathers every replica's pickled
+        SamplerState on every iteration, multistatesampler.py:1303-1311).  Returns the list on rank 0, None elsewhere."""
+        out = [None] * self.world_size if self.rank == 0 else None
+        self.dist.gather_object(obj, out, dst=0, group=self.group)
+        return out
 
     def barrier(self):
         self.dist.barrier(group=self.group)

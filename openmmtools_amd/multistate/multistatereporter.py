@@ -1,0 +1,311 @@
+"""Storage of a multistate simulation: the write path that follows the timed iteration, and the read path
+``from_storage`` / analysis need.
+
+Mirrors openmmtools/multistate/multistatereporter.py (class :69): one *analysis* store written every
+iteration — energies f8[iter, R, K] + neighborhoods i1 + unsampled f8[iter, R, U] (``write_energies``
+:865-929), replica state indices i4[iter, R] (:797-815), accepted / proposed i4[iter, K, K]
+(``write_mixing_statistics`` :957-999), timestamps (:1001-1018), last good iteration (:1072-1092), online
+logZ / weights for SAMS (:1167-1252) — and one *checkpoint* store written every ``checkpoint_interval``
+iterations (default 50, :131) with positions / velocities as **f4** and box vectors
+(``_write_sampler_states_to_given_file`` :1654-1737).
+
+The reference writes NetCDF4; netCDF4 is not available in this environment, so the container is
+a directory of append-only little-endian record files (record i = iteration i, O(1) per iteration, overwritable
+on resume) plus one ``.npz`` per checkpoint; variable names, dtypes and shapes are the reference's.  Only the
+caller's rank 0 writes (the reference: ``@mpiplus.on_single_node(0)``).
+"""
+import json
+import os
+import pickle
+import time
+
+import numpy as np
+
+
+class _RecordFile:
+    """Fixed-size records, record index = iteration."""
+
+    def __init__(self, path, dtype, shape):
+        self.path, self.dtype, self.shape = path, np.dtype(dtype).newbyteorder('<'), tuple(int(s) for s in shape)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    def write(self, index, array):
+        a = np.ascontiguousarray(array, dtype=self.dtype).reshape(self.shape)
+        mode = 'r+b' if os.path.exists(self.path) else 'w+b'
+        with open(self.path, mode) as fh:
+            fh.seek(index * self.nbytes)
+            fh.write(a.tobytes())
+
+    def count(self):
+        if not os.path.exists(self.path) or self.nbytes == 0:
+            return 0
+        return os.path.getsize(self.path) // self.nbytes
+
+    def read(self, index=slice(None)):
+        n = self.count()
+        if self.nbytes == 0:
+            data = np.zeros((n,) + self.shape, self.dtype)
+        else:
+            data = np.fromfile(self.path, dtype=self.dtype, count=n * int(np.prod(self.shape))).reshape((n,) + self.shape)
+        return data[index]
+
+
+class MultiStateReporter:
+    """multistatereporter.py:69.  ``storage`` is a path; the analysis store is ``<storage>`` (a directory), the
+    checkpoint store ``<storage stem>_checkpoint`` beside it (the reference: ``<name>.nc`` and
+    ``<name>_checkpoint.nc``, :176-199)."""
+
+    def __init__(self, storage, open_mode=None, checkpoint_interval=50, checkpoint_storage=None,
+                 analysis_particle_indices=()):
+        self._storage_analysis = str(storage)
+        stem = self._storage_analysis[:-3] if self._storage_analysis.endswith('.nc') else self._storage_analysis
+        self._storage_checkpoint = str(checkpoint_storage) if checkpoint_storage else stem + '_checkpoint'
+        self._checkpoint_interval = int(checkpoint_interval)
+        self._analysis_particle_indices = tuple(int(i) for i in analysis_particle_indices)
+        self._files = {}
+        self._meta = None
+        self._open_mode = None
+        if open_mode is not None:
+            self.open(open_mode)
+
+    # ---- life cycle (:240-330) -----------------------------------------------------------------------------
+    @property
+    def filepath(self):
+        return self._storage_analysis
+
+    @property
+    def checkpoint_interval(self):
+        return self._checkpoint_interval
+
+    def storage_exists(self):
+        return os.path.exists(os.path.join(self._storage_analysis, 'meta.json'))
+
+    def is_open(self):
+        return self._open_mode is not None
+
+    def open(self, mode='r'):
+        if mode not in ('r', 'w', 'a'):
+            raise ValueError("open mode must be 'r', 'w' or 'a'")
+        if mode == 'r' and not self.storage_exists():
+            raise IOError('no storage at {}'.format(self._storage_analysis))
+        if mode == 'w':
+            for d in (self._storage_analysis, self._storage_checkpoint):
+                if os.path.isdir(d):
+                    for f in os.listdir(d):
+                        os.remove(os.path.join(d, f))
+        if mode in ('w', 'a'):
+            os.makedirs(self._storage_analysis, exist_ok=True)
+            os.makedirs(self._storage_checkpoint, exist_ok=True)
+        self._open_mode = mode
+        self._meta = None
+        if self.storage_exists():
+            with open(os.path.join(self._storage_analysis, 'meta.json')) as fh:
+                self._meta = json.load(fh)
+            self._checkpoint_interval = int(self._meta.get('checkpoint_interval', self._checkpoint_interval))
+            self._declare()
+
+    def close(self):
+        self._open_mode = None
+
+    def sync(self):
+        pass                                   # every write is flushed when its file is closed
+
+    def _require_write(self):
+        if self._open_mode not in ('w', 'a'):
+            raise IOError('storage is not open for writing')
+
+    def _declare(self):
+        m = self._meta
+        R, K, U = m['n_replicas'], m['n_states'], m['n_unsampled']
+        d = self._storage_analysis
+        self._files = {
+            'energies': _RecordFile(os.path.join(d, 'energies.f8'), 'f8', (R, K)),                # :889-892
+            'neighborhoods': _RecordFile(os.path.join(d, 'neighborhoods.i1'), 'i1', (R, K)),      # :893-897
+            'unsampled_energies': _RecordFile(os.path.join(d, 'unsampled_energies.f8'), 'f8', (R, U)),
+            'states': _RecordFile(os.path.join(d, 'states.i4'), 'i4', (R,)),                      # :806
+            'accepted': _RecordFile(os.path.join(d, 'accepted.i4'), 'i4', (K, K)),                # :982-989
+            'proposed': _RecordFile(os.path.join(d, 'proposed.i4'), 'i4', (K, K)),
+            'timestamp': _RecordFile(os.path.join(d, 'timestamp.f8'), 'f8', ()),
+            'logZ': _RecordFile(os.path.join(d, 'logZ.f8'), 'f8', (K,)),                          # online data, SAMS
+            'log_weights': _RecordFile(os.path.join(d, 'log_weights.f8'), 'f8', (K,)),
+        }
+
+    def initialize(self, n_replicas, n_states, n_unsampled, n_atoms):
+        """Dimensions of the record variables (the reference creates them lazily on first write)."""
+        self._require_write()
+        self._meta = dict(n_replicas=int(n_replicas), n_states=int(n_states), n_unsampled=int(n_unsampled),
+                          n_atoms=int(n_atoms), checkpoint_interval=self._checkpoint_interval,
+                          format='openmmtools_amd-records-1', created=time.time())
+        with open(os.path.join(self._storage_analysis, 'meta.json'), 'w') as fh:
+            json.dump(self._meta, fh)
+        self._declare()
+
+    # ---- states, moves, options, metadata (:476-690; serialised with pickle instead of YAML/XML) -------------
+    def _write_object(self, name, obj):
+        self._require_write()
+        with open(os.path.join(self._storage_analysis, name + '.pkl'), 'wb') as fh:
+            pickle.dump(obj, fh)
+
+    def _read_object(self, name):
+        with open(os.path.join(self._storage_analysis, name + '.pkl'), 'rb') as fh:
+            return pickle.load(fh)
+
+    def write_thermodynamic_states(self, thermodynamic_states, unsampled_states):
+        self._write_object('thermodynamic_states', (list(thermodynamic_states), list(unsampled_states)))
+
+    def read_thermodynamic_states(self):
+        return self._read_object('thermodynamic_states')
+
+    def write_mcmc_moves(self, mcmc_moves):
+        self._write_object('mcmc_moves', list(mcmc_moves))
+
+    def read_mcmc_moves(self):
+        return self._read_object('mcmc_moves')
+
+    def write_dict(self, name, data):
+        self._write_object(name, dict(data))
+
+    def read_dict(self, name):
+        return self._read_object(name)
+
+    # ---- per-iteration analysis data -----------------------------------------------------------------------
+    def write_energies(self, energy_thermodynamic_states, energy_neighborhoods, energy_unsampled_states, iteration):
+        """:865-929."""
+        self._require_write()
+        self._files['energies'].write(iteration, energy_thermodynamic_states)
+        self._files['neighborhoods'].write(iteration, energy_neighborhoods)
+        self._files['unsampled_energies'].write(iteration, energy_unsampled_states)
+
+    def read_energies(self, iteration=slice(None)):
+        """:817-863 -> (energy_thermodynamic_states, neighborhoods, energy_unsampled_states)."""
+        e = self._files['energies'].read(iteration)
+        fu = self._files['unsampled_energies']
+        eu = fu.read(iteration) if fu.nbytes else np.zeros(e.shape[:-1] + (0,), fu.dtype)    # no unsampled states: empty records
+        return e, self._files['neighborhoods'].read(iteration), eu
+
+    def write_replica_thermodynamic_states(self, state_indices, iteration):
+        """:797-815."""
+        self._require_write()
+        self._files['states'].write(iteration, state_indices)
+
+    def read_replica_thermodynamic_states(self, iteration=slice(None)):
+        """:775-795."""
+        return self._files['states'].read(iteration).astype(np.int64)
+
+    def write_mixing_statistics(self, n_accepted_matrix, n_proposed_matrix, iteration):
+        """:957-999 (stored as i4, like the reference)."""
+        self._require_write()
+        self._files['accepted'].write(iteration, n_accepted_matrix)
+        self._files['proposed'].write(iteration, n_proposed_matrix)
+
+    def read_mixing_statistics(self, iteration=slice(None)):
+        """:931-955."""
+        return self._files['accepted'].read(iteration), self._files['proposed'].read(iteration)
+
+    def write_timestamp(self, iteration):
+        """:1001-1018."""
+        self._require_write()
+        self._files['timestamp'].write(iteration, time.time())
+
+    def read_timestamp(self, iteration=slice(None)):
+        return self._files['timestamp'].read(iteration)
+
+    def write_online_data_dynamic_and_static(self, iteration, **kwargs):
+        """:1167-1252 (the variables SAMS writes: logZ, log_weights)."""
+        self._require_write()
+        for k, v in kwargs.items():
+            if k in self._files and v is not None:
+                self._files[k].write(iteration, v)
+            elif v is not None and iteration % self._checkpoint_interval == 0:
+                self._write_object('online_%s_%09d' % (k, iteration), v)     # small python objects: checkpoint iterations only
+
+    def read_online_data_if_present(self, iteration):
+        out = {}
+        for k in ('logZ', 'log_weights'):
+            if self._files[k].count() > iteration:
+                out[k] = self._files[k].read(iteration)
+        suffix = '_%09d.pkl' % iteration
+        for f in os.listdir(self._storage_analysis):
+            if f.startswith('online_') and f.endswith(suffix):
+                out[f[len('online_'):-len(suffix)]] = self._read_object(f[:-4])
+        return out or None
+
+    def write_last_iteration(self, iteration):
+        """:1072-1092: marks the last iteration all of whose data is on disk."""
+        self._require_write()
+        tmp = os.path.join(self._storage_analysis, 'last_iteration.json.tmp')
+        with open(tmp, 'w') as fh:
+            json.dump(dict(last_iteration=int(iteration)), fh)
+        os.replace(tmp, os.path.join(self._storage_analysis, 'last_iteration.json'))
+
+    def read_last_iteration(self, last_checkpoint=True):
+        """:1020-1070: the last good iteration, or (default) the last one with a checkpoint at or below it."""
+        path = os.path.join(self._storage_analysis, 'last_iteration.json')
+        if not os.path.exists(path):
+            return None
+        with open(path) as fh:
+            last = int(json.load(fh)['last_iteration'])
+        if not last_checkpoint:
+            return last
+        cps = [c for c in self.read_checkpoint_iterations() if c <= last]
+        return max(cps) if cps else None
+
+    # ---- checkpoints (:1597-1737) --------------------------------------------------------------------------
+    def _checkpoint_path(self, iteration):
+        return os.path.join(self._storage_checkpoint, 'iteration_%09d.npz' % iteration)
+
+    def read_checkpoint_iterations(self):
+        if not os.path.isdir(self._storage_checkpoint):
+            return []
+        return sorted(int(f[10:19]) for f in os.listdir(self._storage_checkpoint) if f.startswith('iteration_') and f.endswith('.npz'))
+
+    def write_sampler_states(self, sampler_states, iteration):
+        """:1094-1115: only on checkpoint iterations; positions / velocities as f4 (:1621-1632), box f4."""
+        self._require_write()
+        if iteration % self._checkpoint_interval != 0:
+            return False
+        x = np.stack([np.asarray(s.positions, dtype=np.float64) for s in sampler_states]).astype('<f4')
+        v = np.stack([np.zeros_like(np.asarray(s.positions, dtype=np.float64)) if s.velocities is None
+                      else np.asarray(s.velocities, dtype=np.float64) for s in sampler_states]).astype('<f4')
+        has_box = all(s.box_vectors is not None for s in sampler_states)
+        box = np.stack([np.asarray(s.box_vectors, dtype=np.float64) for s in sampler_states]).astype('<f4') if has_box \
+            else np.zeros((len(sampler_states), 3, 3), '<f4')
+        tmp = self._checkpoint_path(iteration) + '.tmp.npz'
+        np.savez(tmp, positions=x, velocities=v, box_vectors=box, has_box=np.array(has_box))
+        os.replace(tmp, self._checkpoint_path(iteration))
+        return True
+
+    def read_sampler_states(self, iteration, analysis_particles_only=False):
+        """:1117-1165: None when ``iteration`` is not a checkpoint iteration."""
+        path = self._checkpoint_path(iteration)
+        if not os.path.exists(path):
+            return None
+        from .. import states
+        with np.load(path) as d:
+            x, v, box, has_box = d['positions'], d['velocities'], d['box_vectors'], bool(d['has_box'])
+        return [states.SamplerState(x[r].astype(np.float64), velocities=v[r].astype(np.float64),
+                                    box_vectors=box[r].astype(np.float64) if has_box else None) for r in range(len(x))]
+
+    # ---- the sampler's hook: what MultiStateSampler._report_iteration does (multistatesampler.py:1189-1222) --
+    def write_iteration(self, sampler):
+        if getattr(sampler, '_comm', None) is not None and sampler._comm.rank != 0:
+            if sampler._iteration % self._checkpoint_interval == 0:
+                sampler._gather_sampler_states()          # collective: every rank takes part
+            return
+        it = sampler._iteration
+        if self._meta is None:
+            self.initialize(sampler.n_replicas, sampler.n_states, len(sampler._unsampled_states),
+                            sampler._thermodynamic_states[0].n_particles)
+        if it % self._checkpoint_interval == 0:
+            sampler._gather_sampler_states()
+            self.write_sampler_states(sampler._sampler_states, it)                                  # :1217
+        self.write_replica_thermodynamic_states(sampler._replica_thermodynamic_states, it)          # :1218
+        self.write_mcmc_moves(sampler._mcmc_moves)                                                  # :1219
+        self.write_energies(sampler._energy_thermodynamic_states, sampler._neighborhoods,
+                            sampler._energy_unsampled_states, it)                                   # :1220
+        self.write_mixing_statistics(sampler._n_accepted_matrix, sampler._n_proposed_matrix, it)    # :1221
+        online = sampler._online_data() if hasattr(sampler, '_online_data') else None
+        if online:
+            self.write_online_data_dynamic_and_static(it, **online)
+        self.write_timestamp(it)                                                                    # :1202
+        self.write_last_iteration(it)                                                               # :1207

@@ -4,10 +4,12 @@ Mirrors openmmtools/multistate/multistatesampler.py (class :63): ``create`` (:53
 _pre_write_create :836-926), ``run`` (:724-804: mix -> propagate -> energies), ``equilibrate``
 (:649-722: propagate -> energies -> mix), and the three hooks the engine replaces:
 ``_mix_replicas`` (:1500-1517), ``_propagate_replicas`` (:1287-1337), ``_compute_energies``
-(:1436-1494).  Storage (MultiStateReporter), online analysis and minimization are out of
-scope; ``storage`` is accepted and ignored unless it offers ``write_iteration``.
+(:1436-1494).  ``storage`` (a path or a MultiStateReporter) receives every iteration's energies, state
+indices and mixing statistics plus f4 checkpoints (multistatereporter.py); ``from_storage`` resumes from the
+last complete checkpoint.  Online analysis and minimization are out of scope.
 """
 import copy
+import os
 import time
 import logging
 import numpy as np
@@ -119,8 +121,91 @@ class MultiStateSampler:
         self._pre_write_create(thermodynamic_states, sampler_states, storage,
                                initial_thermodynamic_states=initial_thermodynamic_states,
                                unsampled_thermodynamic_states=unsampled_thermodynamic_states, metadata=metadata)
-        self._reporter = storage if hasattr(storage, 'write_iteration') else None
+        self._initialize_reporter(storage)
         self._initialize_engine()
+
+    def _initialize_reporter(self, storage):
+        """multistatesampler.py:1169-1187: a path or a MultiStateReporter; states, moves, options and metadata are
+        stored at creation, iteration 0 (initial energies) by the first run()."""
+        from .multistatereporter import MultiStateReporter
+        if storage is None:
+            self._reporter = None
+            return
+        rep = MultiStateReporter(storage) if isinstance(storage, (str, bytes, os.PathLike)) else storage
+        self._reporter = rep if hasattr(rep, 'write_iteration') else None
+        if self._reporter is None or not isinstance(rep, MultiStateReporter) or self._comm.rank != 0:
+            return
+        if not rep.is_open() or rep._open_mode == 'r':
+            rep.open('w')
+        rep.initialize(self.n_replicas, self.n_states, len(self._unsampled_states), self._thermodynamic_states[0].n_particles)
+        rep.write_thermodynamic_states(self._thermodynamic_states, self._unsampled_states)
+        rep.write_mcmc_moves(self._mcmc_moves)
+        rep.write_dict('options', self._options())
+        rep.write_dict('metadata', self._metadata)
+
+    def _options(self):
+        """What from_storage needs to rebuild the sampler (multistatesampler.py:1145-1167 _store_options)."""
+        return dict(cls=type(self).__name__, module=type(self).__module__, number_of_iterations=self.number_of_iterations,
+                    seed=self._seed, kwargs=self._ctor_kwargs())
+
+    def _ctor_kwargs(self):
+        return {}
+
+    @classmethod
+    def from_storage(cls, storage, engine=None, comm=None):
+        """multistatesampler.py:263-299 + _restore_sampler_from_reporter (:956-1047): resume from the last checkpoint
+        iteration whose data is complete."""
+        import importlib
+        from .multistatereporter import MultiStateReporter
+        rep = MultiStateReporter(storage) if isinstance(storage, (str, bytes, os.PathLike)) else storage
+        if not rep.is_open():
+            rep.open('a')
+        it = rep.read_last_iteration(last_checkpoint=True)
+        if it is None:
+            raise IOError('storage {} holds no complete checkpoint'.format(rep.filepath))
+        opts = rep.read_dict('options')
+        klass = getattr(importlib.import_module(opts['module']), opts['cls'])
+        if not issubclass(klass, cls):
+            raise TypeError('storage was written by {}, not a {}'.format(opts['cls'], cls.__name__))
+        moves = rep.read_mcmc_moves()
+        s = klass(mcmc_moves=moves, number_of_iterations=opts['number_of_iterations'], engine=engine, seed=opts['seed'],
+                  comm=comm, **opts['kwargs'])
+        thermo, unsampled = rep.read_thermodynamic_states()
+        sampler_states = rep.read_sampler_states(it)
+        labels = rep.read_replica_thermodynamic_states(it)
+        s._pre_write_create(thermo, sampler_states, None, initial_thermodynamic_states=labels,
+                            unsampled_thermodynamic_states=unsampled, metadata=rep.read_dict('metadata'))
+        s._mcmc_moves = moves
+        s._iteration = int(it)
+        e, nb, eu = rep.read_energies(it)
+        s._energy_thermodynamic_states[:, :] = e
+        s._neighborhoods[:, :] = nb
+        s._energy_unsampled_states[:, :] = eu
+        acc, prop = rep.read_mixing_statistics(it)
+        s._n_accepted_matrix[:, :] = acc
+        s._n_proposed_matrix[:, :] = prop
+        s._restore_online(rep.read_online_data_if_present(it))
+        s._reporter = rep
+        s._initialize_engine()
+        s._mix_from_stored_energies = True
+        return s
+
+    def _restore_online(self, data):
+        pass
+
+    def _gather_sampler_states(self):
+        """Checkpoint read point (multistatesampler.py:1217): device -> host for the local block, then (multi-rank) a
+        host gather of the blocks to rank 0.  Collective: every rank calls it on checkpoint iterations."""
+        self._sync_sampler_states()
+        if self._comm.world_size == 1:
+            return
+        mine = [(s.positions, s.velocities) for s in self._sampler_states[self._r_begin:self._r_begin + self._r_count]]
+        blocks = self._comm.gather_objects((self._r_begin, mine))
+        if blocks is not None:
+            for begin, block in blocks:
+                for k, (x, v) in enumerate(block):
+                    self._sampler_states[begin + k].positions = x
+                    self._sampler_states[begin + k].velocities = v
 
     def _pre_write_create(self, thermodynamic_states, sampler_states, storage, initial_thermodynamic_states=None,
                           unsampled_thermodynamic_states=None, metadata=None):
@@ -250,6 +335,8 @@ class MultiStateSampler:
         if self._iteration == 0 and not self._energies_computed():
             self._compute_energies()                                   # :738-753
             self._check_nan_energy()
+            if self._reporter is not None:
+                self._reporter.write_iteration(self)                   # iteration 0: initial states and energies
         if n_iterations is None:
             iteration_limit = self.number_of_iterations
         else:

@@ -15,6 +15,9 @@ class ReplicaExchangeSampler(MultiStateSampler):
         super().__init__(**kwargs)
         self.replica_mixing_scheme = replica_mixing_scheme
 
+    def _ctor_kwargs(self):
+        return dict(replica_mixing_scheme=self._replica_mixing_scheme)
+
     @property
     def replica_mixing_scheme(self):
         return self._replica_mixing_scheme
@@ -58,7 +61,13 @@ class ReplicaExchangeSampler(MultiStateSampler):
         labels_in = self._replica_thermodynamic_states
         K = self.n_states
         distributed = not isinstance(self._comm, SingleProcessComm)
-        if distributed and getattr(eng, 'is_device', False) and self._device_ukl is not None:
+        if getattr(self, '_mix_from_stored_energies', False):
+            # first mix after from_storage: the reference mixes with the energies read back from storage
+            # (multistatesampler.py:1003-1020), not with energies recomputed from the f4 checkpoint positions
+            self._mix_from_stored_energies = False
+            out = eng.mix_host(scheme, it, np.ascontiguousarray(self._energy_thermodynamic_states[:, :K]), labels_in,
+                               log_weights=log_weights)
+        elif distributed and getattr(eng, 'is_device', False) and self._device_ukl is not None:
             out = eng.mix(scheme, it, labels_in, d_ukl=self._device_ukl.data_ptr(), R=self.n_replicas, K=K,
                           ld=self._K_total, log_weights=log_weights)
         elif distributed:

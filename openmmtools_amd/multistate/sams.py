@@ -41,6 +41,28 @@ class SAMSSampler(ReplicaExchangeSampler):
         self._cached_state_histogram = None
         self._gamma = None
 
+    def _ctor_kwargs(self):
+        return dict(log_target_probabilities=self.log_target_probabilities, state_update_scheme=self.state_update_scheme,
+                    update_stages=self.update_stages, flatness_criteria=self.flatness_criteria,
+                    flatness_threshold=self.flatness_threshold, weight_update_method=self.weight_update_method,
+                    gamma0=self.gamma0, logZ_guess=self.logZ_guess)
+
+    def _online_data(self):
+        """sams.py:618, :681: logZ and log_weights go to storage every iteration; stage bookkeeping with them."""
+        return dict(logZ=self._logZ, log_weights=self.log_weights,
+                    sams_state=dict(stage=self._stage, t0=self._t0, histogram=self._cached_state_histogram.copy(),
+                                    iteration=self._iteration))
+
+    def _restore_online(self, data):
+        if not data:
+            return
+        self._logZ = np.array(data['logZ'], np.float64)
+        self._update_log_weights()
+        st = data.get('sams_state')
+        if st and st.get('iteration') == self._iteration:
+            self._stage, self._t0 = st['stage'], st['t0']
+            self._cached_state_histogram = np.array(st['histogram'])
+
     def _initialize_stage(self):
         """sams.py:291-296."""
         self._t0 = 0

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
-def build(sampler_kind, engine, comm, n_iter):
+def build(sampler_kind, engine, comm, n_iter, storage=None):
     from openmmtools_amd import testsystems, states, mcmc, unit
     from openmmtools_amd.multistate import ParallelTemperingSampler, SAMSSampler
     ho = testsystems.HarmonicOscillator()
@@ -18,19 +18,21 @@ def build(sampler_kind, engine, comm, n_iter):
                                               n_steps=25, reassign_velocities=True, splitting='V R O R V')
     if sampler_kind == 'pt':
         s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm)
-        s.create(ts, [ss], min_temperature=300.0, max_temperature=600.0, n_temperatures=5)
+        s.create(ts, [ss], storage=storage, min_temperature=300.0, max_temperature=600.0, n_temperatures=5)
     else:
         sts = [states.ThermodynamicState(ho.system, T) for T in np.linspace(300.0, 500.0, 6)]
         s = SAMSSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm,
                         flatness_criteria='minimum-visits')
-        s.create(sts, [ss] * 4)
+        s.create(sts, [ss] * 4, storage=storage)
     s.verify_labels = True
     return s
 
 
-def run(sampler_kind, comm, n_iter=6):
+def run(sampler_kind, comm, n_iter=6, storage_dir=None):
     from oracle_engine import OracleEngine
-    s = build(sampler_kind, OracleEngine(), comm, n_iter)
+    from openmmtools_amd.multistate import MultiStateReporter
+    storage = MultiStateReporter(os.path.join(storage_dir, 'store'), checkpoint_interval=2) if storage_dir else None
+    s = build(sampler_kind, OracleEngine(), comm, n_iter, storage)
     history = []
     for _ in range(n_iter):
         s.run(1)
@@ -46,7 +48,7 @@ if __name__ == '__main__':
     kind, out = sys.argv[1], sys.argv[2]
     dist.init_process_group('gloo')
     comm = TorchDistributedComm()
-    history, x, (b, c) = run(kind, comm)
+    history, x, (b, c) = run(kind, comm, storage_dir=out)
     np.savez(os.path.join(out, 'rank%d.npz' % comm.rank),
              labels=np.stack([h[0] for h in history]), ukl=np.stack([h[1] for h in history]),
              nacc=np.stack([h[2] for h in history]), nprop=np.stack([h[3] for h in history]),

@@ -22,7 +22,8 @@ def test_block_partition():
 def test_sharded_run_equals_single_process(tmp_path, kind):
     import dist_worker
     from openmmtools_amd.multistate.comm import SingleProcessComm
-    ref_hist, ref_x, _ = dist_worker.run(kind, SingleProcessComm())
+    os.makedirs(tmp_path / 'single')
+    ref_hist, ref_x, _ = dist_worker.run(kind, SingleProcessComm(), storage_dir=str(tmp_path / 'single'))
     port = 29600 + (os.getpid() % 200) + (0 if kind == 'pt' else 1)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(HERE, 'dist_worker.py'), kind,
@@ -40,3 +41,14 @@ def test_sharded_run_equals_single_process(tmp_path, kind):
     got = np.concatenate([z['x_local'] for z in ranks])
     assert np.array_equal(got, ref_x)
     assert int(ranks[0]['r_begin']) == 0 and int(ranks[1]['r_begin']) == int(ranks[0]['r_count'])
+    # storage: rank 0 alone writes; the checkpoint gathers both ranks' blocks and equals the single-process store
+    from openmmtools_amd.multistate import MultiStateReporter
+    a = MultiStateReporter(os.path.join(tmp_path, 'store'), open_mode='r')
+    b = MultiStateReporter(os.path.join(tmp_path, 'single', 'store'), open_mode='r')
+    assert a.read_checkpoint_iterations() == b.read_checkpoint_iterations() == [0, 2, 4, 6]
+    for it in (2, 6):
+        xa = np.stack([s.positions for s in a.read_sampler_states(it)])
+        xb = np.stack([s.positions for s in b.read_sampler_states(it)])
+        assert np.array_equal(xa, xb)
+    assert np.array_equal(a.read_energies()[0], b.read_energies()[0])
+    assert np.array_equal(a.read_replica_thermodynamic_states(), b.read_replica_thermodynamic_states())

@@ -161,3 +161,39 @@ def test_nan_restart_bookkeeping(hip_engine_factory):
     u = eng.compute_energies()
     assert np.isfinite(u[[0, 1, 3]]).all()
     assert eng.propagate(6).tolist() == [0, 0, 1, 0]
+
+
+def test_storage_and_resume_on_device(hip_engine_factory, tmp_path):
+    """SURVEY 8(f) row 1 on the device engine: every iteration's u_kl / labels / statistics reach storage, checkpoints
+    hold the f4 snapshot read back from the GPU, and from_storage continues; the first mix after the resume uses the
+    stored energies (multistatesampler.py:1003-1020), checked against the sequential oracle on that matrix."""
+    import oracle
+    from openmmtools_amd.multistate import MultiStateReporter
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0)
+    ss = states.SamplerState(ho.positions)
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=20, reassign_velocities=True, splitting='V R O R V')
+    path = str(tmp_path / 'run.nc')
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=7, engine=hip_engine_factory(), seed=SEED)
+    s.create(ts, [ss], storage=MultiStateReporter(path, checkpoint_interval=2), min_temperature=300.0,
+             max_temperature=600.0, n_temperatures=6)
+    for it in range(1, 5):
+        s.run(1)
+        e = MultiStateReporter(path, open_mode='r').read_energies(it)[0]
+        assert np.array_equal(e, s.energy_thermodynamic_states)
+    x4 = np.stack([st.positions for st in s.sampler_states])
+    rd = MultiStateReporter(path, open_mode='r')
+    assert rd.read_checkpoint_iterations() == [0, 2, 4]
+    cp = np.stack([c.positions for c in rd.read_sampler_states(4)])
+    assert np.array_equal(cp, x4.astype(np.float32).astype(np.float64))
+    e4, lab4 = rd.read_energies(4)[0], rd.read_replica_thermodynamic_states(4)
+    r = ParallelTemperingSampler.from_storage(path, engine=hip_engine_factory())
+    assert r.iteration == 4
+    r.run(1)
+    ref = oracle.mix('swap-all', SEED, 5, e4, lab4)
+    assert np.array_equal(r.replica_thermodynamic_states, ref[0])
+    assert np.array_equal(r._n_accepted_matrix, ref[1]) and np.array_equal(r._n_proposed_matrix, ref[2])
+    r.run()
+    assert r.iteration == 7 and np.isfinite(r.energy_thermodynamic_states).all()
+    assert MultiStateReporter(path, open_mode='r').read_energies()[0].shape == (8, 6, 6)

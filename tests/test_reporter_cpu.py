@@ -1,0 +1,126 @@
+"""Storage write path and resume (openmmtools/multistate/multistatereporter.py, from_storage
+multistatesampler.py:263-299).  The reference's own storage tests check that what is read back equals what the sampler
+held (tests/test_sampling.py:1139-1231 stored energies / states, :1380-1460 resume)."""
+import numpy as np
+import pytest
+from openmmtools_amd import testsystems, states, mcmc, unit
+from openmmtools_amd.multistate import (ParallelTemperingSampler, ReplicaExchangeSampler, SAMSSampler,
+                                        MultiStateReporter, MultiStateSampler)
+from oracle_engine import OracleEngine
+
+
+def _move(n=10):
+    return mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=n, reassign_velocities=True, splitting='V R O R V')
+
+
+def _pt(tmp_path, n_iter, interval=2, storage=True):
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0)
+    ss = states.SamplerState(ho.positions)
+    rep = MultiStateReporter(str(tmp_path / 'pt.nc'), checkpoint_interval=interval) if storage else None
+    s = ParallelTemperingSampler(mcmc_moves=_move(), number_of_iterations=n_iter, engine=OracleEngine(), seed=11)
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=600.0, n_temperatures=4)
+    return s, rep
+
+
+def test_every_iteration_is_stored_with_reference_dtypes(tmp_path):
+    s, rep = _pt(tmp_path, 5)
+    seen = []
+    for _ in range(5):
+        s.run(1)
+        seen.append((s.energy_thermodynamic_states.copy(), s.replica_thermodynamic_states.copy(),
+                     s._n_accepted_matrix.copy(), s._n_proposed_matrix.copy()))
+    r = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r')
+    e, nb, eu = r.read_energies()
+    assert e.shape == (6, 4, 4) and e.dtype == np.dtype('<f8') and nb.dtype == np.dtype('i1') and eu.shape == (6, 4, 0)
+    st = r.read_replica_thermodynamic_states()
+    acc, prop = r.read_mixing_statistics()
+    assert acc.dtype == np.dtype('<i4') and acc.shape == (6, 4, 4)
+    for it, (ue, lab, a, p) in enumerate(seen, start=1):
+        assert np.array_equal(e[it], ue) and np.array_equal(st[it], lab)
+        assert np.array_equal(acc[it], a) and np.array_equal(prop[it], p)
+    assert np.all(nb == 1) and np.isfinite(e[0]).all()            # iteration 0 = initial energies
+    assert r.read_last_iteration(last_checkpoint=False) == 5
+    assert r.read_checkpoint_iterations() == [0, 2, 4] and r.read_last_iteration() == 4
+    assert r.read_sampler_states(3) is None                        # not a checkpoint iteration
+    cp = r.read_sampler_states(4)
+    assert len(cp) == 4 and cp[0].positions.shape == (1, 3)
+    assert np.all(np.diff(r.read_timestamp()) >= 0)
+
+
+def test_checkpoint_positions_are_float32_of_the_sampler_state(tmp_path):
+    s, rep = _pt(tmp_path, 2, interval=1)
+    s.run()
+    x = np.stack([st.positions for st in s.sampler_states])
+    cp = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_sampler_states(2)
+    xs = np.stack([c.positions for c in cp])
+    assert np.array_equal(xs, x.astype(np.float32).astype(np.float64))
+    assert not np.array_equal(xs, x)                               # f4 on disk (multistatereporter.py:1621-1632)
+
+
+def test_resume_from_storage_continues_the_same_markov_chain(tmp_path):
+    """A run interrupted after a checkpoint and resumed with from_storage gives exactly the stored-precision
+    continuation: labels, statistics and energies of the later iterations equal those of a sampler restarted from
+    the same f4 checkpoint by hand."""
+    s, rep = _pt(tmp_path, 6, interval=2)
+    s.run(4)                                                       # iterations 1..4, checkpoint at 4
+    del s
+    r = ParallelTemperingSampler.from_storage(str(tmp_path / 'pt.nc'), engine=OracleEngine())
+    assert r.iteration == 4 and r.number_of_iterations == 6 and type(r) is ParallelTemperingSampler
+    assert np.array_equal(r.replica_thermodynamic_states,
+                          MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_replica_thermodynamic_states(4))
+    r.run()
+    assert r.iteration == 6 and r.is_completed
+    rd = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r')
+    e, _, _ = rd.read_energies()
+    assert e.shape[0] == 7 and rd.read_last_iteration(last_checkpoint=False) == 6
+    # the resumed chain is a deterministic function of the checkpoint: a second resume reproduces it bit for bit
+    import shutil
+    shutil.copytree(str(tmp_path / 'pt.nc'), str(tmp_path / 'copy.nc'))
+    shutil.copytree(str(tmp_path / 'pt_checkpoint'), str(tmp_path / 'copy_checkpoint'))
+    rc = MultiStateReporter(str(tmp_path / 'copy.nc'), open_mode='a')
+    rc.write_last_iteration(4)
+    r2 = ParallelTemperingSampler.from_storage(rc, engine=OracleEngine())
+    r2.run()
+    e2, _, _ = MultiStateReporter(str(tmp_path / 'copy.nc'), open_mode='r').read_energies()
+    assert np.array_equal(e2[5:], e[5:])
+    with pytest.raises(TypeError):
+        SAMSSampler.from_storage(str(tmp_path / 'pt.nc'), engine=OracleEngine())
+
+
+def test_sams_online_data_and_resume(tmp_path):
+    ho = testsystems.HarmonicOscillator()
+    tss = [states.ThermodynamicState(ho.system, T) for T in (300.0, 350.0, 400.0)]
+    ss = states.SamplerState(ho.positions)
+    rep = MultiStateReporter(str(tmp_path / 'sams'), checkpoint_interval=3)
+    s = SAMSSampler(mcmc_moves=_move(5), number_of_iterations=9, engine=OracleEngine(), seed=2)
+    s.create(tss, [ss], storage=rep)
+    s.run(6)
+    logZ6, hist6 = s._logZ.copy(), s._state_histogram.copy()
+    rd = MultiStateReporter(str(tmp_path / 'sams'), open_mode='r')
+    online = rd.read_online_data_if_present(6)
+    assert np.array_equal(online['logZ'], logZ6) and np.array_equal(online['sams_state']['histogram'], hist6)
+    r = MultiStateSampler.from_storage(str(tmp_path / 'sams'), engine=OracleEngine())
+    assert type(r) is SAMSSampler and r.iteration == 6
+    assert np.array_equal(r._logZ, logZ6) and np.array_equal(r._state_histogram, hist6)
+    r.run()
+    assert r.iteration == 9
+    # sams.py:381-393 / tests/test_sampling.py:2757-2787: the histogram equals np.histogram of the stored labels
+    lab = MultiStateReporter(str(tmp_path / 'sams'), open_mode='r').read_replica_thermodynamic_states()
+    counts = np.bincount(lab[1:, 0], minlength=3)             # iteration 0 is the initial state, not a visited one
+    assert np.array_equal(r._state_histogram, counts)
+
+
+def test_storage_path_string_and_write_mode_guard(tmp_path):
+    ho = testsystems.HarmonicOscillator()
+    ts = [states.ThermodynamicState(ho.system, T) for T in (300.0, 400.0)]
+    s = ReplicaExchangeSampler(mcmc_moves=_move(3), number_of_iterations=2, engine=OracleEngine(), seed=5)
+    s.create(ts, [states.SamplerState(ho.positions)], storage=str(tmp_path / 'rex'))
+    s.run()
+    r = MultiStateReporter(str(tmp_path / 'rex'), open_mode='r')
+    assert r.read_energies()[0].shape == (3, 2, 2)
+    with pytest.raises(IOError):
+        r.write_last_iteration(1)
+    with pytest.raises(IOError):
+        MultiStateReporter(str(tmp_path / 'missing'), open_mode='r')
