@@ -155,11 +155,13 @@ def main():
     if rank == 0:
         it_per_s = args.steps / elapsed
         value = it_per_s * (n_replicas / REPLICAS_PER_GPU)
+        # one force evaluation = the Coulomb launch (class 'nonbonded') + the LJ sub-system launch ('nonbonded_lj')
         n_launch, ms = engine.profile_get('nonbonded')
+        n_lj, ms_lj = engine.profile_get('nonbonded_lj')
         roof = None
         if n_launch > 0:
             flops = FLOP_PER_ATOM_NONBONDED * n_atoms * REPLICAS_PER_GPU
-            avg_ms = ms / n_launch
+            avg_ms = (ms + ms_lj) / n_launch
             achieved = flops / (avg_ms * 1e-3) / 1e12
             roof = dict(kernel='nonbonded_cluster_kernel', bound='mfma', achieved=achieved, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=achieved / FP32_PEAK_TFLOPS, traffic=pmc_traffic_bytes('nonbonded_cluster_kernel'),

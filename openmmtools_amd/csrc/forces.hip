@@ -1272,10 +1272,24 @@ static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
     return 0;
 }
 
-static int ensure_sorted(remd_ctx* h, nb_tables& t)
+// phase 1: (re-sort,) gather and neighbour list of the main system; phase 2: the same for the LJ sub-system; 3: both.
+// Split so that the long Coulomb pair kernel can be launched before the LJ lists and the listed terms are built.
+static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
 {
     if (!t.sorting || t.n_groups <= 0 || t.n_groups >= 8192) return 0;
     const int ntile = (h->N + 63) / 64;
+    if (!(phase & 1)) {
+        const bool cl2 = t.clusters && ntile * 8 < 65536;
+        if (cl2 && t.lj_split && t.sort_R == h->R) {
+            remd_prof_scope ps(h, "nb_gather");
+            const int ntile_lj = t.NLpad / 64, ncl_lj = t.NLpad / 8;
+            hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
+                               h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
+            hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl_lj, h->R), dim3(64), 0, h->stream, ncl_lj, t.lj_cap, t.p.rc2,
+                               t.d_lj_cl_c, t.d_lj_cl_h, h->d_box, t.d_lj_list, t.d_lj_count);
+        }
+        return 0;
+    }
     if (t.sort_R != h->R) {
         dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sparam); dfree(t.d_smask); dfree(t.d_tile_c); dfree(t.d_tile_h);
         const size_t n = (size_t)h->R * h->Npad;
@@ -1333,7 +1347,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
             const int ncl = ntile * 8;
             hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl, h->R), dim3(64), 0, h->stream, ncl, t.cl_cap, t.p.rc2, t.d_cl_c,
                                t.d_cl_h, h->d_box, t.d_cl_list, t.d_cl_count);
-            if (t.lj_split) {
+            if (t.lj_split && (phase & 2)) {
                 const int ntile_lj = t.NLpad / 64, ncl_lj = t.NLpad / 8;
                 hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
                                    h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
@@ -1361,7 +1375,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
 }
 
 template <int METHOD, bool ENERGY>
-static void launch_nb(remd_ctx* h, nb_tables& t)
+static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
 {
     const int ntile = (h->N + 63) / 64;
     if (t.sorting && t.clusters && t.d_order && t.d_cl_list && t.n_groups > 0 && t.n_groups < 8192 && ntile * 8 < 65536) {
@@ -1369,7 +1383,8 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
         static int main_split = getenv("REMD_NB_MAINSPLIT") ? std::max(1, std::min(4, atoi(getenv("REMD_NB_MAINSPLIT")))) : 4;
         // wave budget: when the PME pipeline runs concurrently, cap the direct-space kernels at 16 waves per CU
         static int persist = getenv("REMD_NB_PERSIST") ? atoi(getenv("REMD_NB_PERSIST")) : 16;
-        int ncu = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) ncu = prop.multiProcessorCount; }
+        static int ncu = 0;
+        if (!ncu) { hipDeviceProp_t prop; ncu = (hipGetDeviceProperties(&prop, h->device) == hipSuccess) ? prop.multiProcessorCount : 256; }
         const bool cap_waves = h->overlap && h->stream2 && t.method == NB_EWALD && persist > 0;
         const int n_items = ncl * h->R * main_split;
         dim3 grid(cap_waves ? std::min(n_items, ncu * persist) : n_items);
@@ -1379,10 +1394,12 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
 #define LAUNCH_CL(M, ALCHF) hipLaunchKernelGGL((nonbonded_cluster_kernel<M, ENERGY, ALCHF>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl, \
             t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box, rl, h->d_force, h->Npad, h->d_epart, h->n_epart, 0, \
             h->R, main_split)
-        if (split) { if (t.has_alch) LAUNCH_CL(MAIN, true); else LAUNCH_CL(MAIN, false); }
-        else { if (t.has_alch) LAUNCH_CL(METHOD, true); else LAUNCH_CL(METHOD, false); }
+        if (phase & 1) {
+            if (split) { if (t.has_alch) LAUNCH_CL(MAIN, true); else LAUNCH_CL(MAIN, false); }
+            else { if (t.has_alch) LAUNCH_CL(METHOD, true); else LAUNCH_CL(METHOD, false); }
+        }
 #undef LAUNCH_CL
-        if (split) {
+        if (split && (phase & 2)) {
             nb_params pl = t.p; pl.excl_words = t.lj_words;
             const int ncl_lj = t.NLpad / 8;
             const int n_items2 = ncl_lj * h->R * 4;
@@ -1398,6 +1415,7 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
         }
         return;
     }
+    if (!(phase & 1)) return;
     dim3 grid((ntile + NB_WAVES - 1) / NB_WAVES, t.p.n_jsplit, h->R);
     const size_t need = (size_t)h->R * t.p.n_jsplit * h->Npad;
     if (t.partial_n < need) { dfree(t.d_partial); if (hipMalloc(&t.d_partial, sizeof(float4) * need) != hipSuccess) return; t.partial_n = need; }
@@ -1470,6 +1488,19 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         }
     }
     const bool merged = !with_energy;      // force-only evaluations: every listed term in one launch
+    // Launch order of a force-only evaluation: the long Coulomb pair kernel goes first (its lists are two small
+    // kernels), so that it overlaps the whole mesh pipeline; listed terms and the LJ sub-system follow behind it.
+    bool main_launched = false;
+    if (merged && h->nb_method != REMD_NB_NONE) {
+        nb_tables& t = g_nb[h];
+        int rc = ensure_sorted(h, t, 1);
+        if (rc) return rc;
+        remd_prof_scope ps(h, "nonbonded");
+        if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, false>(h, t, 1);
+        else if (t.method == NB_RF) launch_nb<NB_RF, false>(h, t, 1);
+        else launch_nb<NB_EWALD, false>(h, t, 1);
+        main_launched = true;
+    }
     if (merged) {
         listed_tables T{};
         T.n_bonds = h->n_bonds; T.n_angles = h->n_angles; T.n_torsions = h->n_torsions;
@@ -1510,17 +1541,18 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         nb_tables& t = g_nb[h];
         int rc = update_replica_lambdas(h, t);
         if (rc) return rc;
-        if ((rc = ensure_sorted(h, t))) return rc;
+        const int phase = main_launched ? 2 : 3;
+        if ((rc = ensure_sorted(h, t, phase))) return rc;
         {
-            remd_prof_scope ps(h, "nonbonded");
+            remd_prof_scope ps(h, phase == 2 ? "nonbonded_lj" : "nonbonded");
             if (with_energy) {
-                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, true>(h, t);
-                else if (t.method == NB_RF) launch_nb<NB_RF, true>(h, t);
-                else launch_nb<NB_EWALD, true>(h, t);
+                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, true>(h, t, phase);
+                else if (t.method == NB_RF) launch_nb<NB_RF, true>(h, t, phase);
+                else launch_nb<NB_EWALD, true>(h, t, phase);
             } else {
-                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, false>(h, t);
-                else if (t.method == NB_RF) launch_nb<NB_RF, false>(h, t);
-                else launch_nb<NB_EWALD, false>(h, t);
+                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, false>(h, t, phase);
+                else if (t.method == NB_RF) launch_nb<NB_RF, false>(h, t, phase);
+                else launch_nb<NB_EWALD, false>(h, t, phase);
             }
         }
         if (!merged && t.n_exc > 0) {

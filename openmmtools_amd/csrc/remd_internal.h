@@ -129,7 +129,7 @@ struct remd_prof_scope {
     remd_ctx* h; const char* name; hipEvent_t a = nullptr; bool on = false; hipStream_t st;
     remd_prof_scope(remd_ctx* h_, const char* n, hipStream_t stream = (hipStream_t)-1) : h(h_), name(n) {
         st = (stream == (hipStream_t)-1) ? h->stream : stream;     // events go on the stream the kernel is launched on
-        on = h->profiling == 2 || (h->profiling == 1 && h->prof_filter == n);
+        on = h->profiling == 2 || (h->profiling == 1 && std::string(n).rfind(h->prof_filter, 0) == 0);
         if (on) { hipEventCreate(&a); hipEventRecord(a, st); }
     }
     ~remd_prof_scope() {
