@@ -1382,10 +1382,10 @@ static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
         const int ncl = ntile * 8;
         static int main_split = getenv("REMD_NB_MAINSPLIT") ? std::max(1, std::min(4, atoi(getenv("REMD_NB_MAINSPLIT")))) : 4;
         // wave budget: when the PME pipeline runs concurrently, cap the direct-space kernels at 16 waves per CU
-        static int persist = getenv("REMD_NB_PERSIST") ? atoi(getenv("REMD_NB_PERSIST")) : 16;
+        static int persist = getenv("REMD_NB_PERSIST") ? atoi(getenv("REMD_NB_PERSIST")) : 0;
         static int ncu = 0;
         if (!ncu) { hipDeviceProp_t prop; ncu = (hipGetDeviceProperties(&prop, h->device) == hipSuccess) ? prop.multiProcessorCount : 256; }
-        const bool cap_waves = h->overlap && h->stream2 && t.method == NB_EWALD && persist > 0;
+        const bool cap_waves = h->pme_concurrent && persist > 0;
         const int n_items = ncl * h->R * main_split;
         dim3 grid(cap_waves ? std::min(n_items, ncu * persist) : n_items);
         const float* rl = t.has_alch ? t.d_rep_lam : (const float*)nullptr;
@@ -1487,6 +1487,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
             pme_forked = true;
         }
     }
+    h->pme_concurrent = pme_forked;
     const bool merged = !with_energy;      // force-only evaluations: every listed term in one launch
     // Launch order of a force-only evaluation: the long Coulomb pair kernel goes first (its lists are two small
     // kernels), so that it overlaps the whole mesh pipeline; listed terms and the LJ sub-system follow behind it.

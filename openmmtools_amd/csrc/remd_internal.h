@@ -107,7 +107,7 @@ struct remd_ctx {
     // ---- timing / profiling -------------------------------------------------------------
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream: the PME reciprocal pipeline (LDS / latency bound) overlaps the direct-space kernels (VALU bound)
-    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true;
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true; bool pme_concurrent = false;
     double t_prop = 0, t_energy = 0, t_mix = 0;
     int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes
     std::string prof_filter = "nonbonded";
