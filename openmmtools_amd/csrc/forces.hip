@@ -1475,7 +1475,9 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
             hipEventRecord(h->ev_fork, h->stream);
             hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
             if (pme_on_main) {
-                rc0 = remd_pme_forces(h, with_energy, h->stream);
+                // everything up to the inverse z FFT now; the gather is enqueued behind the join (below), so that the
+                // cross-stream wait sits in front of the last mesh kernel instead of between it and the integrator
+                rc0 = remd_pme_forces(h, with_energy, h->stream, 1);
                 if (rc0) return rc0;
                 std::swap(h->stream, h->stream2);
                 swapped = true;
@@ -1570,8 +1572,10 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         }
         if (t.method == NB_EWALD) {
             if (pme_forked) {                                                   // join
+                const bool gather_pending = swapped;
                 if (swapped) { hipEventRecord(h->ev_join, h->stream); std::swap(h->stream, h->stream2); swapped = false; }
                 hipStreamWaitEvent(h->stream, h->ev_join, 0);
+                if (gather_pending) { rc = remd_pme_forces(h, with_energy, h->stream, 2); if (rc) return rc; }
             }
             else { rc = remd_pme_forces(h, with_energy, h->stream); if (rc) return rc; }
         }

@@ -774,7 +774,7 @@ static void launch_pass(remd_ctx* h, pme_state* s, float2* data, size_t rep_stri
 const float* remd_nb_rep_lam(remd_ctx* h);
 const float4* remd_nb_param(remd_ctx* h);
 
-int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
+int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
 {
     pme_state* s = (pme_state*)h->pme;
     if (!s || s->R != h->R || !s->d_mesh) { int rc = remd_pme_setup(h); if (rc) return rc; s = (pme_state*)h->pme; }
@@ -782,6 +782,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
     const int nx = s->n[0], ny = s->n[1], nz = s->n[2];
     const float* rep_lam = remd_nb_rep_lam(h);
     const float4* param = remd_nb_param(h);
+    if (part & 1) {
     {
         remd_prof_scope ps(h, "pme_bin", st);
         hipLaunchKernelGGL(pme_bin_kernel, dim3(h->R), dim3(1024), 0, st, h->N, h->Npad, nx, ny, nz, h->d_pos, h->d_box,
@@ -829,6 +830,8 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st)
             hipLaunchKernelGGL(pme_zinv_kernel<512>, zgrid, dim3(512), zlds_inv, st, make_plan(s, 2), s->sch_z, nl, nx, ny, s->d_grid,
                                reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
     }
+    }   // part 1
+    if (!(part & 2)) { REMD_CHECK(h, hipGetLastError()); return 0; }
     {
         remd_prof_scope ps(h, "pme_gather", st);
         hipLaunchKernelGGL(pme_gather_kernel, dim3((h->N + 127) / 128, h->R), dim3(128), 0, st, h->N, h->Npad, nx, ny, nz,

@@ -160,4 +160,4 @@ int remd_build_constraints(remd_ctx* h, const remd_system_desc* d);
 // ---- pme.hip ----------------------------------------------------------------------------
 int remd_pme_setup(remd_ctx* h);
 int remd_pme_destroy(remd_ctx* h);
-int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st);
+int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part = 3);   // part 1: bin .. inverse z, part 2: gather (+ energy)
