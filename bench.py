@@ -114,12 +114,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
                              '--master-addr 127.0.0.1 --master-port 29511 bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    if os.environ.get('REMD_BENCH_SHARE_GPU'):       # functional test of the N > 1 flow on a one-GPU box (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('REMD_BENCH_BACKEND', 'nccl')     # "nccl" is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         from openmmtools_amd.multistate.comm import TorchDistributedComm
         comm = TorchDistributedComm()
 
@@ -148,7 +154,7 @@ def main():
     engine.profile_enable(False)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
