@@ -45,6 +45,13 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
     return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 
+// One wavefront per SIMD at best (a few hundred waves per launch): the chain kernel is bound by the LATENCY of its
+// dependent arithmetic, so the 1-ulp hardware reciprocal / square root / reciprocal square root replace the IEEE
+// expansions (~10 dependent instructions each) of '/', sqrtf and rsqrtf; fp32 SETTLE is ~1e-7 relative either way.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 // Analytic SETTLE (Miyamoto & Kollman 1992) in coordinates relative to the old O position:
 // p0[] old (constrained) positions relative to A0 (p0[0] = 0), p1[] unconstrained new
 // positions relative to A0.  Returns constrained new positions (relative to A0) in p1.
@@ -52,21 +59,21 @@ __device__ __forceinline__ void settle_positions(const settle_const& sc, const f
 {
     const float3 b0 = p0[1], c0 = p0[2];
     const float M = sc.mO + 2.f * sc.mH;
-    const float3 d0 = (p1[0] * sc.mO + p1[1] * sc.mH + p1[2] * sc.mH) * (1.f / M);
+    const float3 d0 = (p1[0] * sc.mO + p1[1] * sc.mH + p1[2] * sc.mH) * frcp(M);
     const float3 a1 = p1[0] - d0, b1 = p1[1] - d0, c1 = p1[2] - d0;
     float3 Z = cross3(b0, c0);
     float3 X = cross3(a1, Z);
     float3 Y = cross3(Z, X);
-    X = X * rsqrtf(dot3(X, X)); Y = Y * rsqrtf(dot3(Y, Y)); Z = Z * rsqrtf(dot3(Z, Z));
+    X = X * frsq(dot3(X, X)); Y = Y * frsq(dot3(Y, Y)); Z = Z * frsq(dot3(Z, Z));
     const float xb0 = dot3(X, b0), yb0 = dot3(Y, b0);
     const float xc0 = dot3(X, c0), yc0 = dot3(Y, c0);
     const float za1 = dot3(Z, a1);
     const float xb1 = dot3(X, b1), yb1 = dot3(Y, b1), zb1 = dot3(Z, b1);
     const float xc1 = dot3(X, c1), yc1 = dot3(Y, c1), zc1 = dot3(Z, c1);
-    const float sinphi = za1 / sc.ra;
-    const float cosphi = sqrtf(fmaxf(0.f, 1.f - sinphi * sinphi));
-    const float sinpsi = (zb1 - zc1) / (2.f * sc.rc * cosphi);
-    const float cospsi = sqrtf(fmaxf(0.f, 1.f - sinpsi * sinpsi));
+    const float sinphi = za1 * frcp(sc.ra);
+    const float cosphi = fsqrt(fmaxf(0.f, 1.f - sinphi * sinphi));
+    const float sinpsi = (zb1 - zc1) * frcp(2.f * sc.rc * cosphi);
+    const float cospsi = fsqrt(fmaxf(0.f, 1.f - sinpsi * sinpsi));
     const float ya2 = sc.ra * cosphi;
     const float xb2 = -sc.rc * cospsi;
     const float yb2 = -sc.rb * cosphi - sc.rc * sinpsi * sinphi;
@@ -75,8 +82,8 @@ __device__ __forceinline__ void settle_positions(const settle_const& sc, const f
     const float beta  = xb2 * (yc0 - yb0) + xb0 * yb2 + xc0 * yc2;
     const float gamma = xb0 * yb1 - xb1 * yb0 + xc0 * yc1 - xc1 * yc0;
     const float al2be2 = alpha * alpha + beta * beta;
-    const float sintheta = (alpha * gamma - beta * sqrtf(fmaxf(0.f, al2be2 - gamma * gamma))) / al2be2;
-    const float costheta = sqrtf(fmaxf(0.f, 1.f - sintheta * sintheta));
+    const float sintheta = (alpha * gamma - beta * fsqrt(fmaxf(0.f, al2be2 - gamma * gamma))) * frcp(al2be2);
+    const float costheta = fsqrt(fmaxf(0.f, 1.f - sintheta * sintheta));
     const float xa3 = -ya2 * sintheta, ya3 = ya2 * costheta, za3 = za1;
     const float xb3 = xb2 * costheta - yb2 * sintheta, yb3 = xb2 * sintheta + yb2 * costheta, zb3 = zb1;
     const float xc3 = -xb2 * costheta - yc2 * sintheta, yc3 = -xb2 * sintheta + yc2 * costheta, zc3 = zc1;
@@ -90,14 +97,14 @@ __device__ __forceinline__ void settle_positions(const settle_const& sc, const f
 __device__ __forceinline__ void settle_velocities(float imA, float imB, float imC, const float3* p, float3* v)
 {
     float3 eAB = p[1] - p[0], eBC = p[2] - p[1], eCA = p[0] - p[2];
-    eAB = eAB * rsqrtf(dot3(eAB, eAB)); eBC = eBC * rsqrtf(dot3(eBC, eBC)); eCA = eCA * rsqrtf(dot3(eCA, eCA));
+    eAB = eAB * frsq(dot3(eAB, eAB)); eBC = eBC * frsq(dot3(eBC, eBC)); eCA = eCA * frsq(dot3(eCA, eCA));
     const float dAB = dot3(v[1] - v[0], eAB), dBC = dot3(v[2] - v[1], eBC), dCA = dot3(v[0] - v[2], eCA);
     const float cAB_BC = dot3(eAB, eBC), cAB_CA = dot3(eAB, eCA), cBC_CA = dot3(eBC, eCA);
     const float m00 = imA + imB,        m01 = -cAB_BC * imB,  m02 = -cAB_CA * imA;
     const float m10 = -cAB_BC * imB,    m11 = imB + imC,      m12 = -cBC_CA * imC;
     const float m20 = -cAB_CA * imA,    m21 = -cBC_CA * imC,  m22 = imC + imA;
     const float det = m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
-    const float idet = 1.f / det;
+    const float idet = frcp(det);
     const float tAB = (dAB * (m11 * m22 - m12 * m21) - m01 * (dBC * m22 - m12 * dCA) + m02 * (dBC * m21 - m11 * dCA)) * idet;
     const float tBC = (m00 * (dBC * m22 - m12 * dCA) - dAB * (m10 * m22 - m12 * m20) + m02 * (m10 * dCA - dBC * m20)) * idet;
     const float tCA = (m00 * (m11 * dCA - dBC * m21) - m01 * (m10 * dCA - dBC * m20) + dAB * (m10 * m21 - m11 * m20)) * idet;
@@ -122,7 +129,7 @@ __device__ __forceinline__ void shake_positions(const float* im, const float* d,
             const float diff = d2 - dot3(r, r);
             if (fabsf(diff) > 2.f * tol * d2) {
                 conv = false;
-                const float lam = diff / (2.f * (im[0] + im[k]) * dot3(r, r0));
+                const float lam = diff * frcp(2.f * (im[0] + im[k]) * dot3(r, r0));
                 p1[0] = p1[0] - r0 * (lam * im[0]);
                 p1[k] = p1[k] + r0 * (lam * im[k]);
             }
@@ -145,7 +152,7 @@ __device__ __forceinline__ void shake_velocities(const float* im, float tol, con
             const float rv = dot3(r, dv);
             if (rv * rv > tol * tol * r2 * (dot3(v[k], v[k]) + dot3(v[0], v[0]) + 1e-12f)) {
                 conv = false;
-                const float lam = rv / (r2 * (im[0] + im[k]));
+                const float lam = rv * frcp(r2 * (im[0] + im[k]));
                 v[0] = v[0] + r * (lam * im[0]);
                 v[k] = v[k] - r * (lam * im[k]);
             }
@@ -171,8 +178,8 @@ __device__ __forceinline__ void constrain_v(const settle_const& sc, const float*
 __device__ __forceinline__ float3 gaussian3(uint64_t seed, uint32_t stream, uint32_t atom, uint32_t replica, uint64_t t)
 {
     philox4 w = remd_philox(seed, stream, atom, replica, t);
-    const float r1 = sqrtf(-2.f * __logf(remd_u23(w.w[0])));
-    const float r2 = sqrtf(-2.f * __logf(remd_u23(w.w[2])));
+    const float r1 = fsqrt(-2.f * __logf(remd_u23(w.w[0])));
+    const float r2 = fsqrt(-2.f * __logf(remd_u23(w.w[2])));
     float s1, c1, s2, c2;
     __sincosf(6.2831853071795865f * remd_u23(w.w[1]), &s1, &c1);
     __sincosf(6.2831853071795865f * remd_u23(w.w[3]), &s2, &c2);
@@ -220,7 +227,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                 }
                 if (TYPE == UNIT_SETTLE) settle_positions(sc, p0, p1);
                 else shake_positions<NAT>(im, dist, tol, p0, p1);
-                const float ih = 1.f / prog.hR;
+                const float ih = frcp(prog.hR);
                 const float3 org = x[0];
 #pragma unroll
                 for (int k = 0; k < NAT; ++k) {
@@ -234,7 +241,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
 #pragma unroll
             for (int k = 0; k < NAT; ++k) {
                 const float3 xi = gaussian3(seed, REMD_STREAM_OU, (uint32_t)idx[k], rg, cnt);
-                const float sig = prog.b * sqrtf(kT * im[k]);
+                const float sig = prog.b * fsqrt(kT * im[k]);
                 v[k].x = prog.a * v[k].x + sig * xi.x;
                 v[k].y = prog.a * v[k].y + sig * xi.y;
                 v[k].z = prog.a * v[k].z + sig * xi.z;
@@ -254,7 +261,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
     for (int k = 0; k < NAT; ++k) {
         P[idx[k]] = make_float4(x[k].x, x[k].y, x[k].z, 0.f);
         V[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
-        mom = mom + v[k] * (1.f / im[k]);
+        mom = mom + v[k] * frcp(im[k]);
         if (prog.zero_force) { Fw[idx[k]] = 0; Fw[Npad + idx[k]] = 0; Fw[2 * Npad + idx[k]] = 0; }
     }
     return mom;
@@ -287,7 +294,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         float4* V = vel + (size_t)r * Npad;
         const long long* F = force + (size_t)r * 3 * Npad;
         long long* Fw = force + (size_t)r * 3 * Npad;
-        const float kT = (float)(1.0 / beta[labels[r_begin + r]]);
+        const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
         const uint32_t rg = (uint32_t)(r_begin + r);
         const long long* cr = cmm + ((size_t)prog.cmm_r * gridDim.y + r) * 4;
 #define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass)
@@ -326,7 +333,7 @@ __device__ __forceinline__ void assign_unit(const int* idx, const settle_const& 
         x[k] = f3(p.x, p.y, p.z);
         im[k] = invmass[idx[k]];
         const float3 xi = gaussian3(seed, REMD_STREAM_VELOCITY, (uint32_t)idx[k], rg, (uint64_t)iteration);
-        const float sig = sqrtf(kT * im[k]);
+        const float sig = fsqrt(kT * im[k]);
         v[k] = xi * sig;
     }
     constrain_v<TYPE, NAT>(sc, im, tol, v, x);
@@ -350,7 +357,7 @@ void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
     const int type = unit_type[uidx];
     const float4* P = pos + (size_t)r * Npad;
     float4* V = vel + (size_t)r * Npad;
-    const float kT = (float)(1.0 / beta[labels[r_begin + r]]);
+    const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
     const uint32_t rg = (uint32_t)(r_begin + r);
     if (type == UNIT_SETTLE) assign_unit<UNIT_SETTLE, 3>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
     else if (type == UNIT_FREE) assign_unit<UNIT_FREE, 1>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
