@@ -520,12 +520,15 @@ void fft_pass_kernel(fft_plan pl, float2* __restrict__ grid, size_t rep_stride, 
 __global__ __launch_bounds__(128)
 void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __restrict__ pos,
                        const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                       const float* __restrict__ mesh, long long* __restrict__ force)
+                       const float* __restrict__ mesh, long long* __restrict__ force, const int* __restrict__ col_atoms)
 {
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
-    if (i >= N) return;
+    if (t >= N) return;
+    // atoms in the order of the spreading bins (sorted by mesh column kx): the lanes of a wavefront then read the same
+    // one or two x slabs of the potential mesh (21.6 KB each), which stay in L1 instead of being re-fetched from L2
+    const int i = col_atoms[(size_t)r * Npad + t];
     const float4 pr = param[i];
     float q = pr.x;
     if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
@@ -835,7 +838,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
     {
         remd_prof_scope ps(h, "pme_gather", st);
         hipLaunchKernelGGL(pme_gather_kernel, dim3((h->N + 127) / 128, h->R), dim3(128), 0, st, h->N, h->Npad, nx, ny, nz,
-                           h->d_pos, param, h->d_box, rep_lam, reinterpret_cast<const float*>(s->d_mesh), h->d_force);
+                           h->d_pos, param, h->d_box, rep_lam, reinterpret_cast<const float*>(s->d_mesh), h->d_force, s->d_col_atoms);
     }
     if (with_energy)
         hipLaunchKernelGGL(pme_energy_reduce_kernel, dim3(h->R), dim3(64), 0, st, s->n_eblk, s->d_energy, h->d_epart,
