@@ -1491,10 +1491,12 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
     }
     h->pme_concurrent = pme_forked;
     const bool merged = !with_energy;      // force-only evaluations: every listed term in one launch
-    // Launch order of a force-only evaluation: the long Coulomb pair kernel goes first (its lists are two small
-    // kernels), so that it overlaps the whole mesh pipeline; listed terms and the LJ sub-system follow behind it.
+    // Launch order of a force-only evaluation (measured, bench.py): listed terms -> both lists -> Coulomb pair kernel
+    // -> LJ pair kernel gives 6.77 it/s with the packed z transforms; launching the Coulomb kernel ahead of the listed
+    // terms and the LJ lists (REMD_NB_EARLY=1) makes it collide with the XY FFT pass instead of the spreading: 6.22.
     bool main_launched = false;
-    if (merged && h->nb_method != REMD_NB_NONE) {
+    static const bool nb_early = getenv("REMD_NB_EARLY") && atoi(getenv("REMD_NB_EARLY")) != 0;
+    if (merged && nb_early && h->nb_method != REMD_NB_NONE) {
         nb_tables& t = g_nb[h];
         int rc = ensure_sorted(h, t, 1);
         if (rc) return rc;

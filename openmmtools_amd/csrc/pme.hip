@@ -25,7 +25,7 @@
 struct fft_sched { const uint2* tab; int off[8]; };   // see fft_stage_sched
 
 struct pme_state {
-    int n[3] = {0, 0, 0};
+    int n[4] = {0, 0, 0, 0};           // mesh dimensions; n[3] = nz / 2 (length of the packed real-to-complex z transform)
     int R = 0;
     size_t npts = 0;
     int* d_mesh = nullptr;             // [R][nx][ny][nz] 32-bit fixed-point charge mesh; reused as the float potential mesh
@@ -33,9 +33,10 @@ struct pme_state {
     hipStream_t stream = nullptr;      // stream of the current remd_pme_forces call
     int nzc = 0; size_t nspec = 0; size_t xy_lds = 0; bool xy_fused = false; int xy_threads = 512;
     int* d_col_count = nullptr; int* d_col_start = nullptr; int* d_cursor = nullptr; int* d_atom_col = nullptr; int* d_col_atoms = nullptr;
-    float2* d_tw[3] = {nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i k / n)
+    float2* d_tw[4] = {nullptr, nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i k / n)
     float* d_bmod[3] = {nullptr, nullptr, nullptr};  // |b(m)|^-2 ... stored as B-spline moduli squared inverse
-    int nrad[3] = {0, 0, 0}; int radix[3][8];
+    int nrad[4] = {0, 0, 0, 0}; int radix[4][8];
+    bool z_half = false;               // nz even: z transforms run as nz/2-point complex FFTs of packed real pairs
     double* d_energy = nullptr;        // [R][n_eblk]
     int n_eblk = 0;
     fft_sched sch_x, sch_y, sch_z;     // butterfly schedules of the in-place passes (xy planes; z lines for (sch_nl, sch_zt))
@@ -285,24 +286,31 @@ void pme_bin_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __res
 // fused spreading + forward z FFT.  Workgroup = nl lines (x, y0..y0+nl-1), nl a divisor of ny (the whole row when it
 // fits).  Charges are accumulated in LDS as 32-bit fixed point (order-independent => bit-reproducible), converted to
 // complex f32 and transformed in place; the half spectrum is written kz-major in runs of nl points.
-template <int Z_THREADS>
+// HALF (nz even): the real lines are packed as nz/2 complex numbers z[n] = x[2n] + i x[2n+1], transformed with an
+// nz/2-point FFT (pl, sc describe THAT transform) and untangled into the half spectrum while it is written out:
+//   X[k] = (Z[k] + conj Z[M-k]) / 2 - (i/2) W^k (Z[k] - conj Z[M-k]),  W = exp(-2 pi i / nz),  M = nz/2,  Z[M] = Z[0].
+// Half the butterflies and half the LDS of the plain complex transform (four workgroups per CU instead of three).
+template <int Z_THREADS, bool HALF>
 __global__ __launch_bounds__(Z_THREADS)
 void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, int Npad, const float4* __restrict__ pos,
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms,
-                            float2* __restrict__ spec, const float2* tw)
+                            float2* __restrict__ spec, const float2* tw, const float2* tw_half)
 {
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz | 1;
+    const int M = pl.n;                                     // length of the FFT that is run
+    const int nz = HALF ? 2 * M : M, nzc = nz / 2 + 1, PZ = HALF ? ((M + 1) | 1) : (nz | 1);
     float2* buf = reinterpret_cast<float2*>(smem);          // [nl][PZ]
-    float2* s_tw = buf + nl * PZ;                           // [nz]
+    float2* s_tw = buf + nl * PZ;                           // [nz] twiddles of the full length
+    float2* s_twh = s_tw + nz;                              // [M] twiddles of the half length (HALF only)
     int* acc = reinterpret_cast<int*>(buf);                 // [nl][nz] aliases buf: converted through registers below
     const int r = blockIdx.y, tid = threadIdx.x;
     const int l0 = blockIdx.x * nl;
     const int x = l0 / ny, y0 = l0 % ny;
     for (int idx = tid; idx < nl * nz; idx += Z_THREADS) acc[idx] = 0;
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
+    if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
     __syncthreads();
     const int* cs = col_start + (size_t)r * (nx + 1);
     const int* ca = col_atoms + (size_t)r * Npad;
@@ -346,60 +354,106 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
         }
     }
     __syncthreads();
-    const unsigned mnz = fft_magic((unsigned)nz);
+    const unsigned mM = fft_magic((unsigned)M);
     {
         // acc and buf share LDS: every thread first pulls its share of the integer mesh into registers, then all
-        // threads write the complex image (nl * nz <= Z_PPT * Z_THREADS)
-        float val[Z_PPT];
+        // threads write the complex image (nl * M <= Z_PPT * Z_THREADS)
+        float2 val[Z_PPT];
 #pragma unroll
-        for (int q = 0; q < Z_PPT; ++q) { const int idx = tid + q * Z_THREADS; val[q] = (idx < nl * nz) ? (float)acc[idx] * (1.0f / PME_MESH_SCALE) : 0.f; }
+        for (int q = 0; q < Z_PPT; ++q) {
+            const int idx = tid + q * Z_THREADS;             // complex point: line l = idx / M, element n = idx % M
+            val[q] = make_float2(0.f, 0.f);
+            if (idx < nl * M) {
+                if (HALF) { const int2 w = reinterpret_cast<const int2*>(acc)[idx]; val[q] = make_float2((float)w.x * (1.0f / PME_MESH_SCALE), (float)w.y * (1.0f / PME_MESH_SCALE)); }
+                else val[q].x = (float)acc[idx] * (1.0f / PME_MESH_SCALE);
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < Z_PPT; ++q) {
             const int idx = tid + q * Z_THREADS;
-            if (idx < nl * nz) { const int l = fft_div(idx, mnz, nz); buf[idx + l * (PZ - nz)] = make_float2(val[q], 0.f); }   // l*PZ + z
+            if (idx < nl * M) { const int l = fft_div(idx, mM, M); buf[idx + l * (PZ - M)] = val[q]; }   // l*PZ + n
         }
     }
     __syncthreads();
-    fft_lines_inplace<-1, Z_PPT>(pl, sc, buf, 1, s_tw, tid, Z_THREADS);
+    fft_lines_inplace<-1, Z_PPT>(pl, sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
     float2* S = spec + (size_t)r * nzc * nx * ny;
     const unsigned mnl = fft_magic((unsigned)nl);
     for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
         const int kz = fft_div(idx, mnl, nl), b = idx - kz * nl;
-        S[((size_t)kz * nx + x) * ny + y0 + b] = buf[b * PZ + kz];
+        float2 X;
+        if (HALF) {
+            const float2 Zk = buf[b * PZ + (kz == M ? 0 : kz)], Zm = buf[b * PZ + (kz == 0 ? 0 : M - kz)];
+            const float2 E = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));          // (Z[k] + conj Z[M-k]) / 2
+            const float2 O = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));         // -(i/2) (Z[k] - conj Z[M-k])
+            X = cadd(E, cmul(s_tw[kz], O));
+        } else {
+            X = buf[b * PZ + kz];
+        }
+        S[((size_t)kz * nx + x) * ny + y0 + b] = X;
     }
 }
 
 // inverse z: half spectrum -> nl real lines (Hermitian completion in LDS), written as float mesh[x][y][z]
-template <int Z_THREADS>
+// HALF: Z'[k] = (X[k] + conj X[M-k]) + i conj(W^k) (X[k] - conj X[M-k]), k < M = nz/2; the M-point inverse FFT of Z'
+// holds the real line as pairs (x[2n], x[2n+1]).
+template <int Z_THREADS, bool HALF>
 __global__ __launch_bounds__(Z_THREADS)
 void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const float2* __restrict__ spec, float* __restrict__ mesh,
-                     const float2* tw)
+                     const float2* tw, const float2* tw_half)
 {
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nz = pl.n, nzc = nz / 2 + 1, PZ = nz | 1;
+    const int M = pl.n;
+    const int nz = HALF ? 2 * M : M, nzc = nz / 2 + 1, PZ = HALF ? ((M + 1) | 1) : (nz | 1);
     float2* buf = reinterpret_cast<float2*>(smem);
     float2* s_tw = buf + nl * PZ;
+    float2* s_twh = s_tw + nz;
     const int r = blockIdx.y, tid = threadIdx.x;
     const int l0 = blockIdx.x * nl;
     const int x = l0 / ny, y0 = l0 % ny;
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
+    if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
     const float2* S = spec + (size_t)r * nzc * nx * ny;
     const unsigned mnl = fft_magic((unsigned)nl);
     for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
         const int kz = fft_div(idx, mnl, nl), b = idx - kz * nl;
         const float2 v = S[((size_t)kz * nx + x) * ny + y0 + b];
-        buf[b * PZ + kz] = v;
-        if (kz > 0 && kz < nz - kz) buf[b * PZ + nz - kz] = make_float2(v.x, -v.y);
+        buf[b * PZ + kz] = v;                                 // HALF: slot M = nz/2 exists (PZ >= M + 1)
+        if (!HALF && kz > 0 && kz < nz - kz) buf[b * PZ + nz - kz] = make_float2(v.x, -v.y);
     }
     __syncthreads();
-    fft_lines_inplace<+1, Z_PPT>(pl, sc, buf, 1, s_tw, tid, Z_THREADS);
-    float* M = mesh + (size_t)r * nx * ny * nz + (size_t)l0 * nz;
-    const unsigned mnz = fft_magic((unsigned)nz);
-    for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
-        const int l = fft_div(idx, mnz, nz);
-        M[idx] = buf[idx + l * (PZ - nz)].x;
+    if (HALF) {
+        // in place: the pair (k, M - k) is owned by one thread
+        for (int idx = tid; idx < nl * (M / 2 + 1); idx += Z_THREADS) {
+            const int k = fft_div(idx, mnl, nl), b = idx - k * nl;
+            const float2 Xk = buf[b * PZ + k], Xm = buf[b * PZ + M - k];
+            const float2 A = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);              // X[k] + conj X[M-k]
+            const float2 B = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);              // X[k] - conj X[M-k]
+            const float2 w = s_tw[k];                                             // W^k
+            const float2 t = cmul(make_float2(w.x, -w.y), B);                     // conj(W^k) B
+            buf[b * PZ + k] = make_float2(A.x - t.y, A.y + t.x);                  // A + i t
+            if (k != 0 && k != M - k) {
+                const float2 u = cmul(w, make_float2(B.x, -B.y));                 // W^k conj(B)
+                buf[b * PZ + M - k] = make_float2(A.x - u.y, -A.y + u.x);         // conj(A) + i u
+            }
+        }
+        __syncthreads();
+    }
+    fft_lines_inplace<+1, Z_PPT>(pl, sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
+    float* Mesh = mesh + (size_t)r * nx * ny * nz + (size_t)l0 * nz;
+    const unsigned mM = fft_magic((unsigned)M);
+    if (HALF) {
+        float2* M2 = reinterpret_cast<float2*>(Mesh);          // nz even: the line start is 8-byte aligned
+        for (int idx = tid; idx < nl * M; idx += Z_THREADS) {
+            const int l = fft_div(idx, mM, M);
+            M2[idx] = buf[idx + l * (PZ - M)];                 // (x[2n], x[2n+1])
+        }
+    } else {
+        for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
+            const int l = fft_div(idx, mM, M);
+            Mesh[idx] = buf[idx + l * (PZ - nz)].x;
+        }
     }
 }
 
@@ -640,7 +694,8 @@ int remd_pme_destroy(remd_ctx* h)
     if (s->d_mesh) hipFree(s->d_mesh);
     if (s->d_col_count) hipFree(s->d_col_count); if (s->d_col_start) hipFree(s->d_col_start); if (s->d_cursor) hipFree(s->d_cursor);
     if (s->d_atom_col) hipFree(s->d_atom_col); if (s->d_col_atoms) hipFree(s->d_col_atoms);
-    for (int k = 0; k < 3; ++k) { if (s->d_tw[k]) hipFree(s->d_tw[k]); if (s->d_bmod[k]) hipFree(s->d_bmod[k]); }
+    for (int k = 0; k < 4; ++k) if (s->d_tw[k]) hipFree(s->d_tw[k]);
+    for (int k = 0; k < 3; ++k) if (s->d_bmod[k]) hipFree(s->d_bmod[k]);
     if (s->d_energy) hipFree(s->d_energy);
     for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
     delete s;
@@ -707,6 +762,9 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         if (s->n[k] < 6 || s->n[k] > 256 || !factorize(s->n[k], s->radix[k], s->nrad[k]))
             return remd_fail(h, -3, "PME mesh sizes must be products of 2, 3, 5 between 6 and 256");
     }
+    s->n[3] = s->n[2] / 2;
+    s->z_half = (s->n[2] % 2 == 0) && s->n[3] >= 3 && factorize(s->n[3], s->radix[3], s->nrad[3]) &&
+                !(getenv("REMD_PME_ZHALF") && atoi(getenv("REMD_PME_ZHALF")) == 0);
     s->R = h->R;
     s->npts = (size_t)s->n[0] * s->n[1] * s->n[2];
     s->nzc = s->n[2] / 2 + 1;
@@ -718,6 +776,13 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->nspec * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_start, sizeof(int) * (size_t)(s->n[0] + 1) * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_atoms, sizeof(int) * (size_t)h->Npad * s->R));
+    }
+    if (s->z_half) {
+        const int n = s->n[3];
+        std::vector<float2> tw(n);
+        for (int j = 0; j < n; ++j) tw[j] = make_float2((float)cos(2.0 * M_PI * j / n), (float)(-sin(2.0 * M_PI * j / n)));
+        REMD_CHECK(h, hipMalloc(&s->d_tw[3], sizeof(float2) * n));
+        REMD_CHECK(h, hipMemcpy(s->d_tw[3], tw.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
     }
     for (int k = 0; k < 3; ++k) {
         const int n = s->n[k];
@@ -754,10 +819,11 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         if (!rc) rc = build_sched(h, s, 0, s->n[1], 1, PS, s->xy_threads, XY_PPT, &s->sch_x, &s->d_sched[0]);  // along x: lines = y columns
         if (rc) return rc;
     }
-    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define Z_LDS_ATTR(ZT, HF) \
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel<ZT, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel<ZT, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    Z_LDS_ATTR(512, false) Z_LDS_ATTR(256, false) Z_LDS_ATTR(512, true) Z_LDS_ATTR(256, true)
+#undef Z_LDS_ATTR
     return 0;
 }
 
@@ -797,21 +863,23 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         static const int zt_env = getenv("REMD_PME_ZT") ? atoi(getenv("REMD_PME_ZT")) : 512;
         static const int nl_cap = getenv("REMD_PME_NL") ? atoi(getenv("REMD_PME_NL")) : 1 << 30;
         const int ZT = zt_env == 256 ? 256 : 512;
+        const bool half = s->z_half;
+        const int zaxis = half ? 3 : 2;                  // the transform that is run: nz/2 packed points or nz points
+        const int M = s->n[zaxis], PZ = half ? ((M + 1) | 1) : (nz | 1);
         int nl = 1;
-        for (int c = 1; c <= ny && c <= nl_cap; ++c) if (ny % c == 0 && c * nz <= Z_PPT * ZT) nl = c;
-        const size_t zlds = sizeof(float2) * ((size_t)nl * (nz | 1) + nz);
+        for (int c = 1; c <= ny && c <= nl_cap; ++c) if (ny % c == 0 && c * M <= Z_PPT * ZT) nl = c;
+        const size_t zlds = sizeof(float2) * ((size_t)nl * PZ + nz + (half ? M : 0));
         const dim3 zgrid(nx * ny / nl, s->R);
         if (s->sch_nl != nl || s->sch_zt != ZT) {
-            int rc = build_sched(h, s, 2, nl, nz | 1, 1, ZT, Z_PPT, &s->sch_z, &s->d_sched[2]);
+            int rc = build_sched(h, s, zaxis, nl, PZ, 1, ZT, Z_PPT, &s->sch_z, &s->d_sched[2]);
             if (rc) return rc;
             s->sch_nl = nl; s->sch_zt = ZT;
         }
-        if (ZT == 256)
-            hipLaunchKernelGGL(pme_spread_zfwd_kernel<256>, zgrid, dim3(256), zlds, st, make_plan(s, 2), s->sch_z, nl, nx, ny, h->Npad, h->d_pos,
-                               param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
-        else
-            hipLaunchKernelGGL(pme_spread_zfwd_kernel<512>, zgrid, dim3(512), zlds, st, make_plan(s, 2), s->sch_z, nl, nx, ny, h->Npad, h->d_pos,
-                               param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid, s->d_tw[2]);
+#define LAUNCH_Z(KERN, ZTT, HF, ...) hipLaunchKernelGGL((KERN<ZTT, HF>), zgrid, dim3(ZTT), zlds, st, make_plan(s, zaxis), s->sch_z, nl, nx, ny, __VA_ARGS__)
+#define DISPATCH_Z(KERN, ...) do { if (ZT == 256) { if (half) LAUNCH_Z(KERN, 256, true, __VA_ARGS__); else LAUNCH_Z(KERN, 256, false, __VA_ARGS__); } \
+                                   else { if (half) LAUNCH_Z(KERN, 512, true, __VA_ARGS__); else LAUNCH_Z(KERN, 512, false, __VA_ARGS__); } } while (0)
+        DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid,
+                   s->d_tw[2], s->d_tw[3]);
         if (s->xy_fused) {
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
@@ -825,13 +893,9 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         }
-        const size_t zlds_inv = sizeof(float2) * ((size_t)nl * (nz | 1) + nz);
-        if (ZT == 256)
-            hipLaunchKernelGGL(pme_zinv_kernel<256>, zgrid, dim3(256), zlds_inv, st, make_plan(s, 2), s->sch_z, nl, nx, ny, s->d_grid,
-                               reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
-        else
-            hipLaunchKernelGGL(pme_zinv_kernel<512>, zgrid, dim3(512), zlds_inv, st, make_plan(s, 2), s->sch_z, nl, nx, ny, s->d_grid,
-                               reinterpret_cast<float*>(s->d_mesh), s->d_tw[2]);
+        DISPATCH_Z(pme_zinv_kernel, s->d_grid, reinterpret_cast<float*>(s->d_mesh), s->d_tw[2], s->d_tw[3]);
+#undef DISPATCH_Z
+#undef LAUNCH_Z
     }
     }   // part 1
     if (!(part & 2)) { REMD_CHECK(h, hipGetLastError()); return 0; }
