@@ -674,11 +674,12 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
                 in = in && !((m >> (d & 63)) & 1ull);
             }
         }
-        if (!__any(in)) return;                              // no atom pair of this cluster pair is inside the cutoff
+        if (__builtin_amdgcn_ballot_w64(in) == 0ull) return;  // no atom pair of this cluster pair is inside the cutoff (scalar test)
         if (ALCH && pj.w != 0.f) pj.x *= lam_e;
         float fr, ee;
-        // evaluated for every lane (r2 clamped for masked pairs), result discarded unless `in`
-        pair_interaction<METHOD, ALCH, !ENERGY>(p, in ? r2 : p.rc2, pi, pj, lam_a, sc, fr, ENERGY, ee);
+        // evaluated for every lane (r2 clamped to the cutoff for far pairs; excluded pairs, even r2 = 0, produce
+        // garbage that the selects below discard), result kept only where `in`
+        pair_interaction<METHOD, ALCH, !ENERGY>(p, fminf(r2, p.rc2), pi, pj, lam_a, sc, fr, ENERGY, ee);
         fr = in ? fr : 0.f;
         fx += fr * dx; fy += fr * dy; fz += fr * dz;
         if (ENERGY) e += in ? 0.5 * (double)ee : 0.0;

@@ -460,7 +460,7 @@ void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const fl
 // one (kz, replica) plane resident in LDS: forward y, forward x, influence function (+ energy), inverse x, inverse y.
 // In-place stages: LDS = nx (ny+1) 8 B (52 KB for 80 x 80) => three workgroups per CU overlap their load / FFT / store.
 #define XY_MAX_THREADS 1024
-#define XY_PPT 13            // points per thread held in registers: nx * ny <= XY_PPT * XY_THREADS
+#define XY_PPT 15            // points per thread held in registers: nx * ny <= XY_PPT * XY_THREADS
 __global__ __launch_bounds__(XY_MAX_THREADS)
 void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched scy, int nz, float2* __restrict__ spec,
                          const float2* twx, const float2* twy,
@@ -809,8 +809,27 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     s->n_eblk = s->nzc;
     REMD_CHECK(h, hipMalloc(&s->d_energy, sizeof(double) * (size_t)s->n_eblk * s->R));
     s->xy_lds = sizeof(float2) * ((size_t)s->n[0] * (s->n[1] | 1) + s->n[0] + s->n[1]) + 128;
-    s->xy_threads = ((size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * 512) ? 512 : 1024;
-    if (getenv("REMD_PME_XYT")) s->xy_threads = std::max(s->xy_threads, std::min(1024, atoi(getenv("REMD_PME_XYT"))));
+    // workgroup size of the XY kernel: every stage issues ceil(butterflies / threads) butterfly slots per thread,
+    // masked-off slots still cost issue cycles, so pick the wavefront count that wastes the fewest (75 x 75: 384 threads
+    // run 1125 radix-5 and 1875 radix-3 butterflies in 3 and 5 full slots; 512 threads would idle a quarter of them)
+    {
+        const long long np = (long long)s->n[0] * s->n[1];
+        long long best_cost = -1; int best_t = 1024;
+        for (int t = 256; t <= 1024; t += 64) {
+            if (np > (long long)XY_PPT * t) continue;
+            long long cost = 0; bool ok = true;
+            for (int ax = 0; ax < 2 && ok; ++ax)
+                for (int st = 0; st < s->nrad[ax]; ++st) {
+                    const int rx = s->radix[ax][st];
+                    const long long nbf = np / rx, slots = (nbf + t - 1) / t;
+                    if (slots > (XY_PPT + rx - 1) / rx) ok = false;
+                    cost += slots * t * rx;                    // issued lane-points of this stage
+                }
+            if (ok && (best_cost < 0 || cost < best_cost)) { best_cost = cost; best_t = t; }
+        }
+        s->xy_threads = best_t;
+        if (getenv("REMD_PME_XYT")) s->xy_threads = std::max(256, std::min(1024, atoi(getenv("REMD_PME_XYT"))));
+    }
     s->xy_fused = (size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * s->xy_threads && s->xy_lds <= 160 * 1024;
     if (s->xy_fused && !full_complex) {
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
@@ -860,12 +879,14 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
     {
         remd_prof_scope ps(h, "pme_fft", st);
         // lines per workgroup: a divisor of ny whose points fit the registers of the workgroup
-        static const int zt_env = getenv("REMD_PME_ZT") ? atoi(getenv("REMD_PME_ZT")) : 512;
+        static const int zt_env = getenv("REMD_PME_ZT") ? atoi(getenv("REMD_PME_ZT")) : 0;
         static const int nl_cap = getenv("REMD_PME_NL") ? atoi(getenv("REMD_PME_NL")) : 1 << 30;
-        const int ZT = zt_env == 256 ? 256 : 512;
         const bool half = s->z_half;
         const int zaxis = half ? 3 : 2;                  // the transform that is run: nz/2 packed points or nz points
         const int M = s->n[zaxis], PZ = half ? ((M + 1) | 1) : (nz | 1);
+        // 256 threads when a whole mesh row still fits their registers (fuller butterfly slots, 8 workgroups per CU;
+        // measured 6.75 -> 6.95 it/s on the 75 x 75 x 72 mesh), else 512
+        const int ZT = zt_env == 256 ? 256 : zt_env == 512 ? 512 : ((long long)ny * M <= (long long)Z_PPT * 256 ? 256 : 512);
         int nl = 1;
         for (int c = 1; c <= ny && c <= nl_cap; ++c) if (ny % c == 0 && c * M <= Z_PPT * ZT) nl = c;
         const size_t zlds = sizeof(float2) * ((size_t)nl * PZ + nz + (half ? M : 0));
