@@ -902,6 +902,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid,
                    s->d_tw[2], s->d_tw[3]);
         if (s->xy_fused) {
+            remd_prof_scope pxy(h, "pme_xy", st);
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
                                (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);

@@ -129,7 +129,15 @@ struct remd_prof_scope {
     remd_ctx* h; const char* name; hipEvent_t a = nullptr; bool on = false; hipStream_t st;
     remd_prof_scope(remd_ctx* h_, const char* n, hipStream_t stream = (hipStream_t)-1) : h(h_), name(n) {
         st = (stream == (hipStream_t)-1) ? h->stream : stream;     // events go on the stream the kernel is launched on
-        on = h->profiling == 2 || (h->profiling == 1 && std::string(n).rfind(h->prof_filter, 0) == 0);
+        on = h->profiling == 2;
+        if (h->profiling == 1) {                       // filter: '|'-separated class-name prefixes
+            const std::string nm(n), &f = h->prof_filter;
+            for (size_t b = 0; b <= f.size() && !on; ) {
+                size_t e = f.find('|', b); if (e == std::string::npos) e = f.size();
+                on = e > b && nm.compare(0, e - b, f, b, e - b) == 0;
+                b = e + 1;
+            }
+        }
         if (on) { hipEventCreate(&a); hipEventRecord(a, st); }
     }
     ~remd_prof_scope() {
