@@ -229,6 +229,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     REMD_CHECK(h, hipMemcpy(h->d_pos, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     REMD_CHECK(h, hipMemcpy(h->d_vel, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     REMD_CHECK(h, hipMemcpy(h->d_box, hb.data(), sizeof(float) * 4 * R_local, hipMemcpyHostToDevice));
+    h->box_version++;
     h->forces_valid = false; h->force_zeroed = false;
     if (h->nb_method == REMD_NB_PME) { int rc = remd_pme_setup(h); if (rc) return rc; }
     return remd_set_labels(h, labels);

@@ -36,6 +36,7 @@ struct pme_state {
     float2* d_tw[4] = {nullptr, nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i k / n)
     float* d_bmod[3] = {nullptr, nullptr, nullptr};  // |b(m)|^-2 ... stored as B-spline moduli squared inverse
     int nrad[4] = {0, 0, 0, 0}; int radix[4][8];
+    float* d_infl = nullptr; int infl_version = -1;   // influence function [R][nz/2+1][nx][ny], rebuilt when a box changes
     bool z_half = false;               // nz even: z transforms run as nz/2-point complex FFTs of packed real pairs
     double* d_energy = nullptr;        // [R][n_eblk]
     int n_eblk = 0;
@@ -457,6 +458,32 @@ void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const fl
     }
 }
 
+// Influence function G(kx, ky, kz) = exp(-pi^2 m^2 / alpha^2) / (pi V m^2 |b_x b_y b_z|^2) of every replica's box, laid out
+// like the half spectrum.  It only depends on the box, so it is tabulated when a box changes (NVT: once) instead of being
+// recomputed (~45 VALU instructions per mesh point incl. an IEEE division and an exp) in every XY pass.
+__global__ __launch_bounds__(256)
+void pme_influence_table_kernel(int nx, int ny, int nz, const float* __restrict__ bmx, const float* __restrict__ bmy,
+                                const float* __restrict__ bmz, const float* __restrict__ box, float alpha, float* __restrict__ infl)
+{
+    const int kz = blockIdx.x, r = blockIdx.y, nzc = nz / 2 + 1, np = nx * ny;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const double V = (double)Lx * Ly * Lz;
+    const float pref = (float)(1.0 / (M_PI * V));               // charges already carry sqrt(k_e)
+    const float fac = (float)(M_PI * M_PI) / (alpha * alpha);
+    const float mz = kz / Lz;                                   // kz <= nz/2
+    const float bz = bmz[kz];
+    float* G = infl + ((size_t)r * nzc + kz) * np;
+    for (int idx = threadIdx.x; idx < np; idx += blockDim.x) {
+        const int kx = idx / ny, ky = idx - kx * ny;
+        const int m0 = (kx <= nx / 2) ? kx : kx - nx, m1 = (ky <= ny / 2) ? ky : ky - ny;
+        const float mx = m0 / Lx, my = m1 / Ly;
+        const float msq = mx * mx + my * my + mz * mz;
+        float g = 0.f;
+        if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
+        G[idx] = g;
+    }
+}
+
 // one (kz, replica) plane resident in LDS: forward y, forward x, influence function (+ energy), inverse x, inverse y.
 // In-place stages: LDS = nx (ny+1) 8 B (52 KB for 80 x 80) => three workgroups per CU overlap their load / FFT / store.
 #define XY_MAX_THREADS 1024
@@ -465,7 +492,8 @@ __global__ __launch_bounds__(XY_MAX_THREADS)
 void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched scy, int nz, float2* __restrict__ spec,
                          const float2* twx, const float2* twy,
                          const float* __restrict__ bmx, const float* __restrict__ bmy, const float* __restrict__ bmz,
-                         const float* __restrict__ box, float alpha, int with_energy, double* __restrict__ energy, int n_eblk)
+                         const float* __restrict__ box, float alpha, int with_energy, double* __restrict__ energy, int n_eblk,
+                         const float* __restrict__ infl)
 {
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -490,21 +518,12 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
     fft_lines_inplace<-1, XY_PPT>(ply, scy, buf, 1, twy, tid, XY_THREADS);      // along y
     fft_lines_inplace<-1, XY_PPT>(plx, scx, buf, PS, twx, tid, XY_THREADS);     // along x
     {
-        const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-        const double V = (double)Lx * Ly * Lz;
-        const float pref = (float)(1.0 / (M_PI * V));               // charges already carry sqrt(k_e)
-        const float fac = (float)(M_PI * M_PI) / (alpha * alpha);
-        const float mz = kz / Lz;                                   // kz <= nz/2
-        const float bz = bmz[kz];
         const float wz = (kz == 0 || 2 * kz == nz) ? 1.f : 2.f;     // Hermitian half: weight of the mirrored plane
+        const float* __restrict__ G = infl + ((size_t)r * nzc + kz) * np;
         double e_acc = 0.0;
         for (int idx = tid; idx < np; idx += XY_THREADS) {
-            const int kx = fft_div(idx, mny, ny), ky = idx - kx * ny;
-            const int m0 = (kx <= nx / 2) ? kx : kx - nx, m1 = (ky <= ny / 2) ? ky : ky - ny;
-            const float mx = m0 / Lx, my = m1 / Ly;
-            const float msq = mx * mx + my * my + mz * mz;
-            float g = 0.f;
-            if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
+            const int kx = fft_div(idx, mny, ny);
+            const float g = G[idx];
             const float2 sv = buf[idx + kx * pad];              // kx*PS + ky
             if (with_energy) e_acc += 0.5 * (double)(wz * g) * ((double)sv.x * sv.x + (double)sv.y * sv.y);
             buf[idx + kx * pad] = make_float2(sv.x * g, sv.y * g);
@@ -697,6 +716,7 @@ int remd_pme_destroy(remd_ctx* h)
     for (int k = 0; k < 4; ++k) if (s->d_tw[k]) hipFree(s->d_tw[k]);
     for (int k = 0; k < 3; ++k) if (s->d_bmod[k]) hipFree(s->d_bmod[k]);
     if (s->d_energy) hipFree(s->d_energy);
+    if (s->d_infl) hipFree(s->d_infl);
     for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
     delete s;
     h->pme = nullptr;
@@ -902,10 +922,16 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid,
                    s->d_tw[2], s->d_tw[3]);
         if (s->xy_fused) {
+            if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
+            if (s->infl_version != h->box_version) {
+                hipLaunchKernelGGL(pme_influence_table_kernel, dim3(s->nzc, s->R), dim3(256), 0, st, nx, ny, nz, s->d_bmod[0], s->d_bmod[1],
+                                   s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl);
+                s->infl_version = h->box_version;
+            }
             remd_prof_scope pxy(h, "pme_xy", st);
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
-                               (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk);
+                               (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl);
         } else {
             // spec layout [kz][x][y]: y lines contiguous, x lines strided by ny
             launch_pass<-1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);

@@ -79,6 +79,7 @@ struct remd_ctx {
     int R_global = 0, r_begin = 0, R = 0;     // R = local replicas
     float4* d_pos = nullptr;           // [R][Npad] xyz + pad
     float4* d_vel = nullptr;           // [R][Npad] xyz + pad
+    int box_version = 0;               // bumped whenever the box edges on the device change (PME influence table)
     int n_restart_attempts = 0;        // mcmc.py:706-759
     float4* d_snap_pos = nullptr; float4* d_snap_vel = nullptr;   // pre-propagate state (restart attempts)
     float4* d_fin_pos = nullptr; float4* d_fin_vel = nullptr;     // first successful result of every replica
