@@ -131,6 +131,15 @@ int  remd_set_integrator(remd_handle h, const char* splitting, double timestep_p
    they first succeeded.  nan_flags report the replicas that failed every attempt.  Default 0. */
 int  remd_set_restart_attempts(remd_handle h, int n_restart_attempts);
 
+/* MultiStateSampler.minimize (multistatesampler.py:611-647; _minimize_replica :1351-1434) with the reference's
+   FIREMinimizationIntegrator (integrators.py:2290-2469, default parameters: timestep 1 fs, alpha 0.1, dt_max 10 fs,
+   f_inc 1.1, f_dec 0.5, f_alpha 0.99, N_min 5): every local replica is minimised at its current state's Hamiltonian.
+   tolerance: kJ/mol/nm (converged when |f| / n_dof <= tolerance, as the reference tests it); max_iterations = 0: until
+   every replica has converged (polled every 50 steps), else exactly that many FIRE steps.  Velocities are zeroed first.
+   converged: [R_local] flags (may be NULL); n_iterations: steps taken (may be NULL).                                  */
+int  remd_minimize(remd_handle h, double tolerance_kj_per_mol_nm, int max_iterations,
+                   int32_t* converged, int32_t* n_iterations);
+
 /* Replicas r_begin .. r_begin+R_local-1 of R_global live on this handle.
    x, v: [R_local][N][3] (v may be NULL -> zero); box: [R_local][3] orthorhombic edge
    lengths; labels: [R_global] state index of every replica.

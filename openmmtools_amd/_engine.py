@@ -44,7 +44,7 @@ EXPORTS = [
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
-    'remd_set_restart_attempts',
+    'remd_set_restart_attempts', 'remd_minimize',
 ]
 
 _lib = None
@@ -77,6 +77,7 @@ def load_library(path=None):
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
+    lib.remd_minimize.argtypes = [vp, C.c_double, C.c_int, c_int32_p, c_int32_p]
     lib.remd_set_replicas.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]
     lib.remd_set_labels.argtypes = [vp, c_int64_p]
     lib.remd_seed.argtypes = [vp, C.c_uint64]
@@ -209,6 +210,15 @@ class HipEngine:
     def set_restart_attempts(self, n):
         """mcmc.py:706-759: retries of a move whose result holds a NaN (restored start state, fresh noise)."""
         self._check(self.lib.remd_set_restart_attempts(self.h, int(n)), 'remd_set_restart_attempts')
+
+    def minimize(self, tolerance=1.0, max_iterations=0):
+        """FIRE minimisation of every local replica (multistatesampler.py:611-647).  tolerance in kJ/mol/nm.
+        Returns (converged flags, FIRE steps taken)."""
+        conv = np.zeros(self.R, dtype=np.int32)
+        n = C.c_int32(0)
+        self._check(self.lib.remd_minimize(self.h, float(tolerance), int(max_iterations), conv.ctypes.data_as(c_int32_p),
+                                           C.byref(n)), 'remd_minimize')
+        return conv, n.value
 
     def set_replicas(self, R_global, r_begin, x, v, box, labels):
         x = np.ascontiguousarray(x, dtype=np.float64)

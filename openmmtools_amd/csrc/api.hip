@@ -294,6 +294,14 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     return 0;
 }
 
+int remd_minimize(remd_handle h, double tolerance, int max_iterations, int32_t* converged, int32_t* n_iterations)
+{
+    if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return remd_fail(h, -1, "remd_minimize: system/states/replicas not all set");
+    if (!(tolerance >= 0) || max_iterations < 0) return remd_fail(h, -1, "remd_minimize: bad arguments");
+    hipSetDevice(h->device);
+    return remd_minimize_impl(h, tolerance, max_iterations, converged, n_iterations);
+}
+
 int remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t first_step, int n_steps)
 {
     if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return remd_fail(h, -1, "remd_step: not set up");

@@ -595,3 +595,269 @@ int remd_check_finite(remd_ctx* h)
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FIRE minimisation (MultiStateSampler.minimize, multistatesampler.py:611-647, _minimize_replica :1351-1434, with the
+// reference's FIREMinimizationIntegrator, integrators.py:2290-2469), all local replicas at once.  One reference step:
+//   converged if |f| / ndof <= ftol (:2377-2386);  x0 = x, v0 = v, E0 = U(x) (:2392-2394);
+//   v += dt/2 f/m;  x += dt v;  constrain x;  v += dt/2 f(x_new)/m + (x - x1)/dt;  constrain v (:2397-2402);
+//   dE = U(x_new) - E0;  P = f.v;  v = (1 - alpha) v + alpha f/|f| |v| (:2404-2421);
+//   restart (x = x0, v = v0, P = -1) unless dE < 0 (:2423-2431);  converged if dt <= 1e-5 timestep (:2433-2437);
+//   P > 0: N_neg += 1, beyond N_min: dt = min(dt f_inc, dt_max), alpha *= f_alpha (:2439-2449);
+//   P < 0: N_neg = 0, dt *= f_dec, v = 0, alpha = alpha_start (:2451-2458).
+// Three kernels around one energy + force evaluation per step; the per-replica scalars are double buffered.
+struct fire_rep { float dt, alpha; int n_neg, converged; double E, f2; };     // E, f2 = U and sum f^2 at the current x
+struct fire_consts { float dt_max, f_inc, f_dec, alpha0, f_alpha, dt_min, ftol, ndof; int n_min; };
+
+template <int TYPE, int NAT>
+__device__ __forceinline__ void fire_move_unit(const int* idx, const float* dist, const settle_const& sc, float tol, int Npad,
+                                               float4* __restrict__ P, float4* __restrict__ V, const long long* __restrict__ F,
+                                               float4* __restrict__ X0, float4* __restrict__ V0, long long* __restrict__ F0,
+                                               const float* __restrict__ invmass, float dt)
+{
+    float3 x[NAT], v[NAT];
+    float im[NAT];
+#pragma unroll
+    for (int k = 0; k < NAT; ++k) {
+        const float4 p = P[idx[k]], w = V[idx[k]];
+        X0[idx[k]] = p; V0[idx[k]] = w;
+        const long long fx = F[idx[k]], fy = F[Npad + idx[k]], fz = F[2 * Npad + idx[k]];
+        F0[idx[k]] = fx; F0[Npad + idx[k]] = fy; F0[2 * Npad + idx[k]] = fz;
+        x[k] = f3(p.x, p.y, p.z); v[k] = f3(w.x, w.y, w.z);
+        im[k] = invmass[idx[k]];
+        const float s = 0.5f * dt * im[k] * (1.0f / 4294967296.0f);
+        v[k].x += s * (float)fx; v[k].y += s * (float)fy; v[k].z += s * (float)fz;
+    }
+    if (TYPE == UNIT_FREE) {
+        x[0] = x[0] + v[0] * dt;
+    } else {
+        float3 p0[NAT], p1[NAT], q[NAT];
+#pragma unroll
+        for (int k = 0; k < NAT; ++k) { p0[k] = x[k] - x[0]; p1[k] = p0[k] + v[k] * dt; q[k] = p1[k]; }
+        if (TYPE == UNIT_SETTLE) settle_positions(sc, p0, p1);
+        else shake_positions<NAT>(im, dist, tol, p0, p1);
+        const float ih = frcp(dt);
+        const float3 org = x[0];
+#pragma unroll
+        for (int k = 0; k < NAT; ++k) { v[k] = v[k] + (p1[k] - q[k]) * ih; x[k] = org + p1[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < NAT; ++k) {
+        P[idx[k]] = make_float4(x[k].x, x[k].y, x[k].z, 0.f);
+        V[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void fire_move_kernel(int n_units, const int4* __restrict__ unit_atoms, const unsigned char* __restrict__ unit_type,
+                      const float* __restrict__ shake_dist, settle_const sc, float tol, int Npad, float4* __restrict__ pos,
+                      float4* __restrict__ vel, const long long* __restrict__ force, float4* __restrict__ x0,
+                      float4* __restrict__ v0, long long* __restrict__ f0, const float* __restrict__ invmass,
+                      const fire_rep* __restrict__ state)
+{
+    const int uidx = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    const fire_rep s = state[r];
+    if (s.converged || uidx >= n_units) return;
+    const int4 a4 = unit_atoms[uidx];
+    if (a4.x < 0) return;
+    const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
+    const int type = unit_type[uidx];
+    float dist[3] = { 0.f, 0.f, 0.f };
+    if (type == UNIT_SHAKE) { dist[0] = shake_dist[uidx * 3]; dist[1] = shake_dist[uidx * 3 + 1]; dist[2] = shake_dist[uidx * 3 + 2]; }
+    const size_t o = (size_t)r * Npad, of = (size_t)r * 3 * Npad;
+#define RUN(TY, NA) fire_move_unit<TY, NA>(idx, dist, sc, tol, Npad, pos + o, vel + o, force + of, x0 + o, v0 + o, f0 + of, invmass, s.dt)
+    if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
+    else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
+    else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
+    else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
+    else RUN(UNIT_SHAKE, 4);
+#undef RUN
+}
+
+// second half kick with the new forces, velocity constraints, and the per-workgroup partial sums of f.f, v.v, f.v
+template <int TYPE, int NAT>
+__device__ __forceinline__ void fire_finish_unit(const int* idx, const settle_const& sc, float tol, int Npad,
+                                                 const float4* __restrict__ P, float4* __restrict__ V, const long long* __restrict__ F,
+                                                 const float* __restrict__ invmass, float dt, bool kick, double* sums)
+{
+    float3 x[NAT], v[NAT], f[NAT];
+    float im[NAT];
+#pragma unroll
+    for (int k = 0; k < NAT; ++k) {
+        const float4 p = P[idx[k]], w = V[idx[k]];
+        x[k] = f3(p.x, p.y, p.z); v[k] = f3(w.x, w.y, w.z);
+        im[k] = invmass[idx[k]];
+        f[k] = f3((float)F[idx[k]] * (1.0f / 4294967296.0f), (float)F[Npad + idx[k]] * (1.0f / 4294967296.0f),
+                  (float)F[2 * Npad + idx[k]] * (1.0f / 4294967296.0f));
+        if (kick) v[k] = v[k] + f[k] * (0.5f * dt * im[k]);
+    }
+    if (kick) {
+        constrain_v<TYPE, NAT>(sc, im, tol, v, x);
+#pragma unroll
+        for (int k = 0; k < NAT; ++k) V[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NAT; ++k) { sums[0] += (double)dot3(f[k], f[k]); sums[1] += (double)dot3(v[k], v[k]); sums[2] += (double)dot3(f[k], v[k]); }
+}
+
+__global__ __launch_bounds__(256)
+void fire_finish_kernel(int n_units, const int4* __restrict__ unit_atoms, const unsigned char* __restrict__ unit_type,
+                        settle_const sc, float tol, int Npad, const float4* __restrict__ pos, float4* __restrict__ vel,
+                        const long long* __restrict__ force, const float* __restrict__ invmass,
+                        const fire_rep* __restrict__ state, int kick, double* __restrict__ partial /*[R][gridDim.x][3]*/)
+{
+    const int uidx = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    const fire_rep s = state[r];
+    double sums[3] = { 0.0, 0.0, 0.0 };
+    const int4 a4 = (uidx < n_units) ? unit_atoms[uidx] : make_int4(-1, -1, -1, -1);
+    if (a4.x >= 0 && !(s.converged && kick)) {
+        const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
+        const int type = unit_type[uidx];
+        const size_t o = (size_t)r * Npad, of = (size_t)r * 3 * Npad;
+#define RUN(TY, NA) fire_finish_unit<TY, NA>(idx, sc, tol, Npad, pos + o, vel + o, force + of, invmass, s.dt, kick != 0, sums)
+        if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
+        else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
+        else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
+        else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
+        else RUN(UNIT_SHAKE, 4);
+#undef RUN
+    }
+    __shared__ double s_part[4][3];
+    for (int q = 0; q < 3; ++q) {
+        double v = sums[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_part[w][threadIdx.x];         // fixed order => reproducible
+        partial[((size_t)r * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = v;
+    }
+}
+
+// scalar FIRE logic of every replica (computed redundantly by every thread from the partial sums) + the per-atom update
+__global__ __launch_bounds__(256)
+void fire_update_kernel(int n_units, const int4* __restrict__ unit_atoms, int Npad, float4* __restrict__ pos, float4* __restrict__ vel,
+                        long long* __restrict__ force, const float4* __restrict__ x0, const float4* __restrict__ v0,
+                        const long long* __restrict__ f0, const double* __restrict__ potential, const double* __restrict__ partial,
+                        int nblk, fire_consts c, const fire_rep* __restrict__ cur, fire_rep* __restrict__ nxt, int init)
+{
+    const int uidx = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    const fire_rep s = cur[r];
+    double f2 = 0.0, v2 = 0.0, fv = 0.0;
+    for (int b = 0; b < nblk; ++b) { f2 += partial[((size_t)r * nblk + b) * 3]; v2 += partial[((size_t)r * nblk + b) * 3 + 1]; fv += partial[((size_t)r * nblk + b) * 3 + 2]; }
+    fire_rep n = s;
+    if (init) {
+        // before the first step: forces and energy at the start positions, convergence test of the first step (:2377-2386)
+        n.E = potential[r]; n.f2 = f2;
+        n.converged = (sqrt(f2) / (double)c.ndof <= (double)c.ftol) ? 1 : 0;
+        if (uidx == 0) nxt[r] = n;
+        return;
+    }
+    if (s.converged) { if (uidx == 0) nxt[r] = s; return; }
+    const double E_new = potential[r];
+    const bool restart = !(E_new - s.E < 0.0);                                   // :2423-2427, NaN-safe
+    const float fmag = (float)sqrt(f2), vmag = (float)sqrt(v2);
+    const float P = restart ? -1.f : (float)fv;
+    const int4 a4 = (uidx < n_units) ? unit_atoms[uidx] : make_int4(-1, -1, -1, -1);
+    if (a4.x >= 0) {
+        const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
+        const size_t o = (size_t)r * Npad, of = (size_t)r * 3 * Npad;
+        for (int k = 0; k < 4; ++k) {
+            const int i = idx[k];
+            if (i < 0) break;
+            if (restart) {
+                pos[o + i] = x0[o + i];
+                force[of + i] = f0[of + i]; force[of + Npad + i] = f0[of + Npad + i]; force[of + 2 * Npad + i] = f0[of + 2 * Npad + i];
+            }
+            float4 w = restart ? v0[o + i] : vel[o + i];
+            if (!restart && fmag > 0.f) {
+                const float sf = s.alpha * vmag / fmag * (1.0f / 4294967296.0f);    // alpha |v| / |f| on the fixed-point force
+                w.x = (1.f - s.alpha) * w.x + sf * (float)force[of + i];
+                w.y = (1.f - s.alpha) * w.y + sf * (float)force[of + Npad + i];
+                w.z = (1.f - s.alpha) * w.z + sf * (float)force[of + 2 * Npad + i];
+            }
+            if (P < 0.f) w = make_float4(0.f, 0.f, 0.f, 0.f);                     // :2455
+            vel[o + i] = w;
+        }
+    }
+    if (uidx == 0) {
+        if (!restart) { n.E = E_new; n.f2 = f2; }
+        if (s.dt <= c.dt_min) n.converged = 1;                                    // :2433-2437
+        if (P > 0.f) {
+            n.n_neg = s.n_neg + 1;
+            if (n.n_neg > c.n_min) { n.dt = fminf(s.dt * c.f_inc, c.dt_max); n.alpha = s.alpha * c.f_alpha; }
+        }
+        if (P < 0.f) { n.n_neg = 0; n.dt = s.dt * c.f_dec; n.alpha = c.alpha0; }
+        // convergence test at the top of the next step (:2377-2386), on the forces the next step starts from
+        if (sqrt(n.f2) / (double)c.ndof <= (double)c.ftol) n.converged = 1;
+        nxt[r] = n;
+    }
+}
+
+int remd_minimize_impl(remd_ctx* h, double tolerance, int max_iterations, int32_t* converged_out, int32_t* n_iter_out)
+{
+    const unit_tables& ut = g_units[h];
+    if (ut.n_units == 0) return remd_fail(h, -3, "no system set");
+    const int R = h->R, Npad = h->Npad;
+    const dim3 grid((ut.n_units + 255) / 256, R);
+    const int nblk = (int)grid.x;
+    float4 *x0 = nullptr, *v0 = nullptr; long long* f0 = nullptr; double* partial = nullptr; fire_rep* st = nullptr;
+    REMD_CHECK(h, hipMalloc(&x0, sizeof(float4) * (size_t)R * Npad));
+    REMD_CHECK(h, hipMalloc(&v0, sizeof(float4) * (size_t)R * Npad));
+    REMD_CHECK(h, hipMalloc(&f0, sizeof(long long) * 3 * (size_t)R * Npad));
+    REMD_CHECK(h, hipMalloc(&partial, sizeof(double) * 3 * (size_t)R * nblk));
+    REMD_CHECK(h, hipMalloc(&st, sizeof(fire_rep) * 2 * (size_t)R));
+    auto cleanup = [&]() { hipFree(x0); hipFree(v0); hipFree(f0); hipFree(partial); hipFree(st); };
+    const float timestep = 0.001f;                               // 1 fs (integrators.py:2318)
+    fire_consts c{};
+    c.dt_max = 0.010f; c.f_inc = 1.1f; c.f_dec = 0.5f; c.alpha0 = 0.1f; c.f_alpha = 0.99f; c.n_min = 5;
+    c.dt_min = 1.0e-5f * timestep; c.ftol = (float)tolerance; c.ndof = 3.0f * (float)h->N;
+    std::vector<fire_rep> init(2 * (size_t)R);
+    for (auto& s : init) { s.dt = timestep; s.alpha = c.alpha0; s.n_neg = 0; s.converged = 0; s.E = 0.0; s.f2 = 0.0; }
+    REMD_CHECK(h, hipMemcpyAsync(st, init.data(), sizeof(fire_rep) * init.size(), hipMemcpyHostToDevice, h->stream));
+    // "velocities should be set to zero before using this integrator" (integrators.py:2341)
+    REMD_CHECK(h, hipMemsetAsync(h->d_vel, 0, sizeof(float4) * (size_t)R * Npad, h->stream));
+    const float tol = (float)fmax(h->constraint_tol, 1e-6);
+    int cur = 0, rc = 0, it = 0;
+    h->forces_valid = false; h->force_zeroed = false;
+    if ((rc = remd_compute_forces(h, true))) { cleanup(); return rc; }
+    hipLaunchKernelGGL(fire_finish_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc, tol, Npad, h->d_pos,
+                       h->d_vel, h->d_force, h->d_invmass, st, 0, partial);
+    hipLaunchKernelGGL(fire_update_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, Npad, h->d_pos, h->d_vel, h->d_force,
+                       x0, v0, f0, h->d_potential, partial, nblk, c, st, st + R, 1);
+    cur = 1;
+    std::vector<fire_rep> host(R);
+    const int limit = max_iterations > 0 ? max_iterations : 200000;
+    bool all_done = false;
+    while (it < limit && !all_done) {
+        const int chunk = std::min(50, limit - it);              // the reference polls 'converged' every 50 steps (:1407-1409)
+        for (int k = 0; k < chunk; ++k, ++it) {
+            fire_rep* S = st + (size_t)cur * R;
+            fire_rep* Nx = st + (size_t)(1 - cur) * R;
+            hipLaunchKernelGGL(fire_move_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.d_dist, ut.sc, tol,
+                               Npad, h->d_pos, h->d_vel, h->d_force, x0, v0, f0, h->d_invmass, S);
+            h->forces_valid = false; h->force_zeroed = false;
+            if ((rc = remd_compute_forces(h, true))) { cleanup(); return rc; }
+            hipLaunchKernelGGL(fire_finish_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc, tol, Npad,
+                               h->d_pos, h->d_vel, h->d_force, h->d_invmass, S, 1, partial);
+            hipLaunchKernelGGL(fire_update_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, Npad, h->d_pos, h->d_vel,
+                               h->d_force, x0, v0, f0, h->d_potential, partial, nblk, c, S, Nx, 0);
+            cur = 1 - cur;
+        }
+        hipMemcpyAsync(host.data(), st + (size_t)cur * R, sizeof(fire_rep) * R, hipMemcpyDeviceToHost, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { cleanup(); return remd_fail(h, -2, "minimize: device error"); }
+        all_done = true;
+        for (int r = 0; r < R; ++r) all_done = all_done && host[r].converged;
+        if (max_iterations > 0) all_done = false;               // a fixed number of steps was asked for
+    }
+    hipMemcpyAsync(host.data(), st + (size_t)cur * R, sizeof(fire_rep) * R, hipMemcpyDeviceToHost, h->stream);
+    hipStreamSynchronize(h->stream);
+    if (converged_out) for (int r = 0; r < R; ++r) converged_out[r] = host[r].converged;
+    if (n_iter_out) *n_iter_out = it;
+    h->forces_valid = false; h->force_zeroed = false;
+    cleanup();
+    REMD_CHECK(h, hipGetLastError());
+    return 0;
+}

@@ -162,6 +162,7 @@ int remd_assign_velocities(remd_ctx* h, int64_t iteration);
 int remd_kinetic_energy(remd_ctx* h);
 
 // ---- forces.hip -------------------------------------------------------------------------
+int remd_minimize_impl(remd_ctx* h, double tolerance, int max_iterations, int32_t* converged, int32_t* n_iterations);
 int remd_compute_forces(remd_ctx* h, bool with_energy);   // fills d_force (and d_potential when with_energy)
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d);
 int remd_build_constraints(remd_ctx* h, const remd_system_desc* d);

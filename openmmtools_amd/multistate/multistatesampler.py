@@ -312,6 +312,21 @@ class MultiStateSampler:
         self._K_total = len(all_states)
 
     # ---- run / equilibrate ------------------------------------------------------------------
+    def minimize(self, tolerance=1.0 * unit.kilojoules_per_mole / unit.nanometers, max_iterations=0):
+        """multistatesampler.py:611-647: FIRE-minimise every replica at its current state (one batched device call per
+        rank instead of one Context per replica), store the minimised positions in the sampler states and in storage."""
+        if self._thermodynamic_states is None or self.n_replicas == 0:
+            raise RuntimeError('Cannot minimize replicas. The simulation must be created first.')     # :629-630
+        self._engine.set_labels(self._replica_thermodynamic_states)
+        converged, n_steps = self._engine.minimize(float(tolerance), int(max_iterations))
+        self._sampler_states_stale = True
+        self._neighborhoods[:, :] = 0                     # energies are stale: run() recomputes them at iteration 0
+        self._gather_sampler_states()
+        if self._reporter is not None and hasattr(self._reporter, 'write_sampler_states') and self._comm.rank == 0 \
+                and getattr(self._reporter, '_meta', None) is not None:
+            self._reporter.write_sampler_states(self._sampler_states, self._iteration)                 # :647
+        return converged, n_steps
+
     def equilibrate(self, n_iterations, mcmc_moves=None):
         """multistatesampler.py:649-722: propagate -> energies -> mix, iteration counter untouched."""
         if mcmc_moves is not None:

@@ -280,3 +280,66 @@ def reduced_potential_matrix(potentials, betas, energy_const=None, alch=None):
     if alch is not None:
         tot = tot + alch
     return np.asarray(betas)[None, :] * tot
+
+
+class OracleFIRE:
+    """f64 restatement of the reference's FIREMinimizationIntegrator (openmmtools/integrators.py:2290-2469), one replica at
+    a time, as MultiStateSampler._minimize_replica drives it (multistatesampler.py:1351-1434).  TEST INFRASTRUCTURE ONLY."""
+
+    def __init__(self, system, tolerance=0.0, timestep=0.001, alpha=0.1, dt_max=0.010, f_inc=1.1, f_dec=0.5, f_alpha=0.99,
+                 n_min=5):
+        self.s = system
+        self.ftol, self.timestep, self.alpha0 = float(tolerance), float(timestep), float(alpha)
+        self.dt_max, self.f_inc, self.f_dec, self.f_alpha, self.n_min = dt_max, f_inc, f_dec, f_alpha, int(n_min)
+
+    def minimize(self, x, box=None, max_iterations=0, lambda_sterics=1.0, lambda_electrostatics=1.0, history=None):
+        s = self.s
+        invm = 1.0 / s.mass
+        x = np.array(x, dtype=np.float64)
+        v = np.zeros_like(x)                                         # :2341
+        dt, alpha, n_neg, converged = self.timestep, self.alpha0, 0, False
+        ndof = 3 * s.N
+        ef = lambda y: s.energy_forces(y, box, lambda_sterics, lambda_electrostatics)
+        E, f = ef(x)
+        it = 0
+        limit = max_iterations if max_iterations > 0 else 200000
+        while it < limit:
+            if np.sqrt((f * f).sum()) / ndof <= self.ftol:           # :2377-2386
+                converged = True
+            if converged:
+                if max_iterations == 0:
+                    break
+                it += 1
+                continue
+            x0, v0, E0, f0 = x, v, E, f                              # :2392-2394
+            v = v + 0.5 * dt * f * invm[:, None]                     # :2397
+            x1 = x + dt * v                                          # :2398-2399
+            xn = shake(s.constraints, invm, x, x1) if s.constraints else x1      # :2400
+            En, fn = ef(xn)
+            v = v + 0.5 * dt * fn * invm[:, None] + (xn - x1) / dt   # :2401
+            if s.constraints:
+                v = rattle(s.constraints, invm, xn, v)               # :2402
+            dE = En - E0                                             # :2404
+            fmag, vmag = np.sqrt((fn * fn).sum()), np.sqrt((v * v).sum())        # :2408-2413
+            P = float((fn * v).sum())                                # :2416
+            if fmag > 0:
+                v = (1.0 - alpha) * v + alpha * (fn / fmag) * vmag   # :2421
+            x, E, f = xn, En, fn
+            if not (dE < 0):                                         # :2423-2431
+                x, v, E, f, P = x0, v0, E0, f0, -1.0
+            if dt <= 1.0e-5 * self.timestep:                         # :2433-2437
+                converged = True
+            if P > 0:                                                # :2439-2449
+                n_neg += 1
+                if n_neg > self.n_min:
+                    dt = min(dt * self.f_inc, self.dt_max)
+                    alpha *= self.f_alpha
+            if P < 0:                                                # :2451-2458
+                n_neg = 0
+                dt *= self.f_dec
+                v = np.zeros_like(v)
+                alpha = self.alpha0
+            it += 1
+            if history is not None:
+                history.append((E, dt, alpha, n_neg))
+        return x, v, E, converged, it

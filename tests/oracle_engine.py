@@ -75,6 +75,18 @@ class OracleEngine:
                     break
         return flags
 
+    def minimize(self, tolerance=1.0, max_iterations=0):
+        fire = mo.OracleFIRE(self.sys, tolerance=tolerance)
+        conv = np.zeros(self.R, dtype=np.int32)
+        n_it = 0
+        for r in range(self.R):
+            k = self.labels[self.r_begin + r]
+            self.x[r], self.v[r], _, c, it = fire.minimize(self.x[r], self._box(r), max_iterations,
+                                                           lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
+            conv[r] = int(c)
+            n_it = max(n_it, it)
+        return conv, n_it
+
     def step(self, splitting, iteration=0, first_step=0, n_steps=1):
         integ = self._integrator()
         for r in range(self.R):
