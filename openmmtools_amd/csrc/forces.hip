@@ -1302,7 +1302,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
         REMD_CHECK(h, hipMalloc(&t.d_tile_h, sizeof(float4) * (size_t)h->R * ntile));
         dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
         const int ncl = ntile * 8;
-        t.cl_cap = std::min(ncl, 1024);
+        t.cl_cap = std::min(ncl, 4096);     // whole row for systems up to 32k atoms: a cluster that straddles a large molecule can neighbour half the box
         REMD_CHECK(h, hipMalloc(&t.d_cl_c, sizeof(float4) * (size_t)h->R * ncl));
         REMD_CHECK(h, hipMalloc(&t.d_cl_h, sizeof(float4) * (size_t)h->R * ncl));
         REMD_CHECK(h, hipMalloc(&t.d_cl_list, sizeof(unsigned short) * (size_t)h->R * ncl * t.cl_cap));
@@ -1312,7 +1312,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
             dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
             const size_t nl = (size_t)h->R * t.NLpad;
             const int ncl_lj = t.NLpad / 8;
-            t.lj_cap = std::min(ncl_lj, 1024);
+            t.lj_cap = std::min(ncl_lj, 4096);
             REMD_CHECK(h, hipMalloc(&t.d_lj_order, sizeof(int) * nl));
             REMD_CHECK(h, hipMalloc(&t.d_lj_spos, sizeof(float4) * nl));
             REMD_CHECK(h, hipMalloc(&t.d_lj_sparam, sizeof(float4) * nl));
