@@ -131,6 +131,15 @@ int  remd_set_integrator(remd_handle h, const char* splitting, double timestep_p
    they first succeeded.  nan_flags report the replicas that failed every attempt.  Default 0. */
 int  remd_set_restart_attempts(remd_handle h, int n_restart_attempts);
 
+/* NPT states.  The reference's ThermodynamicState with a pressure adds an openmm.MonteCarloBarostat (frequency 25) to the
+   System (states.py:1177-1181, 893-898); it fires inside the integrator's updateContextState step
+   (integrators.py:1313).  pressure: [K] per state in kJ/mol/nm^3 (bar x 0.06022140857), or NULL / frequency 0 to switch
+   the barostat off.  The volume moves follow OpenMM's MonteCarloBarostatImpl (molecule-centre scaling, adaptive volume
+   step); u_kl gains beta_l p_l V_r (states.py:1913-1914).  Boxes change: read them back with remd_get_boxes.          */
+int  remd_set_barostat(remd_handle h, int K, const double* pressure, int frequency);
+int  remd_get_boxes(remd_handle h, double* box /*[R_local][3]*/);
+int  remd_get_barostat_stats(remd_handle h, double* volume_scale /*[R_local]*/, int64_t* n_attempted, int64_t* n_accepted);
+
 /* MultiStateSampler.minimize (multistatesampler.py:611-647; _minimize_replica :1351-1434) with the reference's
    FIREMinimizationIntegrator (integrators.py:2290-2469, default parameters: timestep 1 fs, alpha 0.1, dt_max 10 fs,
    f_inc 1.1, f_dec 0.5, f_alpha 0.99, N_min 5): every local replica is minimised at its current state's Hamiltonian.

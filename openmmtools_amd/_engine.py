@@ -44,7 +44,7 @@ EXPORTS = [
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
-    'remd_set_restart_attempts', 'remd_minimize',
+    'remd_set_restart_attempts', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
 ]
 
 _lib = None
@@ -78,6 +78,9 @@ def load_library(path=None):
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
     lib.remd_minimize.argtypes = [vp, C.c_double, C.c_int, c_int32_p, c_int32_p]
+    lib.remd_set_barostat.argtypes = [vp, C.c_int, c_double_p, C.c_int]
+    lib.remd_get_boxes.argtypes = [vp, c_double_p]
+    lib.remd_get_barostat_stats.argtypes = [vp, c_double_p, c_int64_p, c_int64_p]
     lib.remd_set_replicas.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]
     lib.remd_set_labels.argtypes = [vp, c_int64_p]
     lib.remd_seed.argtypes = [vp, C.c_uint64]
@@ -210,6 +213,25 @@ class HipEngine:
     def set_restart_attempts(self, n):
         """mcmc.py:706-759: retries of a move whose result holds a NaN (restored start state, fresh noise)."""
         self._check(self.lib.remd_set_restart_attempts(self.h, int(n)), 'remd_set_restart_attempts')
+
+    def set_barostat(self, pressure, frequency=25):
+        """Monte Carlo barostat of the NPT states (states.py:1177-1181): pressure per state in kJ/mol/nm^3, or None."""
+        if pressure is None:
+            self._check(self.lib.remd_set_barostat(self.h, 0, None, 0), 'remd_set_barostat')
+            return
+        p = np.ascontiguousarray(pressure, dtype=np.float64)
+        self._check(self.lib.remd_set_barostat(self.h, len(p), _dp(p), int(frequency)), 'remd_set_barostat')
+
+    def get_boxes(self):
+        box = np.zeros((self.R, 3), dtype=np.float64)
+        self._check(self.lib.remd_get_boxes(self.h, _dp(box)), 'remd_get_boxes')
+        return box
+
+    def barostat_stats(self):
+        vs = np.zeros(self.R); na = np.zeros(self.R, np.int64); nc = np.zeros(self.R, np.int64)
+        self._check(self.lib.remd_get_barostat_stats(self.h, _dp(vs), na.ctypes.data_as(c_int64_p), nc.ctypes.data_as(c_int64_p)),
+                    'remd_get_barostat_stats')
+        return vs, na, nc
 
     def minimize(self, tolerance=1.0, max_iterations=0):
         """FIRE minimisation of every local replica (multistatesampler.py:611-647).  tolerance in kJ/mol/nm.

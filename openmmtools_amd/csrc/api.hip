@@ -88,6 +88,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_beta); dfree(h->d_lam_s); dfree(h->d_lam_e); dfree(h->d_econst);
     dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_pos_ref); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels);
     dfree(h->d_ukl); dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
+    dfree(h->d_pressure); dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
     dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
@@ -190,6 +191,9 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     const size_t n = (size_t)R_local * h->Npad;
     if (realloc) {
         dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels); dfree(h->d_ukl);
+        // per-replica scratch of the barostat and of the restart attempts is sized by R_local as well
+        dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
+        dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel);
         dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
         REMD_CHECK(h, hipMalloc(&h->d_pos, sizeof(float4) * n));
         REMD_CHECK(h, hipMalloc(&h->d_vel, sizeof(float4) * n));
@@ -294,6 +298,48 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     return 0;
 }
 
+int remd_set_barostat(remd_handle h, int K, const double* pressure, int frequency)
+{
+    if (!h) return -1;
+    hipSetDevice(h->device);
+    if (!pressure || frequency <= 0) { h->baro_frequency = 0; return 0; }
+    if (K != h->K) return remd_fail(h, -1, "remd_set_barostat: K differs from remd_set_states");
+    std::vector<double> p(pressure, pressure + K);
+    for (double v : p) if (!(v == v)) return remd_fail(h, -1, "remd_set_barostat: NaN pressure");
+    int rc = upload(h, h->d_pressure, p);
+    if (rc) return rc;
+    h->baro_frequency = frequency;
+    return 0;
+}
+
+int remd_get_boxes(remd_handle h, double* box)
+{
+    if (!h || !box || h->R <= 0 || !h->d_box) return remd_fail(h, -1, "remd_get_boxes: replicas not set");
+    hipSetDevice(h->device);
+    std::vector<float> hb(4 * (size_t)h->R);
+    REMD_CHECK(h, hipMemcpyAsync(hb.data(), h->d_box, sizeof(float) * hb.size(), hipMemcpyDeviceToHost, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < h->R; ++r) for (int k = 0; k < 3; ++k) box[3 * r + k] = hb[4 * r + k];
+    return 0;
+}
+
+int remd_get_barostat_stats(remd_handle h, double* volume_scale, int64_t* n_attempted, int64_t* n_accepted)
+{
+    if (!h || h->R <= 0) return remd_fail(h, -1, "remd_get_barostat_stats: replicas not set");
+    hipSetDevice(h->device);
+    std::vector<double> st(8 * (size_t)h->R, 0.0);
+    if (h->d_baro) {
+        REMD_CHECK(h, hipMemcpyAsync(st.data(), h->d_baro, sizeof(double) * st.size(), hipMemcpyDeviceToHost, h->stream));
+        REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    }
+    for (int r = 0; r < h->R; ++r) {
+        if (volume_scale) volume_scale[r] = st[8 * r];
+        if (n_attempted) n_attempted[r] = (int64_t)st[8 * r + 3];
+        if (n_accepted) n_accepted[r] = (int64_t)st[8 * r + 4];
+    }
+    return 0;
+}
+
 int remd_minimize(remd_handle h, double tolerance, int max_iterations, int32_t* converged, int32_t* n_iterations)
 {
     if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return remd_fail(h, -1, "remd_minimize: system/states/replicas not all set");
@@ -345,8 +391,7 @@ int remd_compute_energies(remd_handle h, double* d_ukl_rows, double* ukl_host, d
 static int ensure_mix_buffers(remd_ctx* h, int R, int K)
 {
     if (h->stats_K != K || !h->d_nacc) {
-        dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel);
-    dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw);
+        dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw);
         REMD_CHECK(h, hipMalloc(&h->d_nacc, sizeof(unsigned long long) * (size_t)K * K));
         REMD_CHECK(h, hipMalloc(&h->d_nprop, sizeof(unsigned long long) * (size_t)K * K));
         REMD_CHECK(h, hipMalloc(&h->d_logw, sizeof(double) * K));

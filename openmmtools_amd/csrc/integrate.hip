@@ -547,6 +547,14 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             cur.cmm_r = cmm_w;                  // this chain subtracts P/M from that buffer and clears the other one
             cmm_w = 1 - cmm_w;
         }
+        // Monte Carlo barostat (NPT states): acts in the same updateContextState slot, every baro_frequency-th step
+        if (h->baro_frequency > 0 && (++h->baro_steps % h->baro_frequency) == 0) {
+            flush(false);
+            h->force_zeroed = zeroed_by_chain;
+            zeroed_by_chain = false;
+            int rc = remd_barostat_attempt(h);
+            if (rc) return rc;
+        }
         int oidx = 0;
         for (char tok : tokens) {
             if (tok == 'V' && !h->forces_valid) {

@@ -79,6 +79,11 @@ struct remd_ctx {
     int R_global = 0, r_begin = 0, R = 0;     // R = local replicas
     float4* d_pos = nullptr;           // [R][Npad] xyz + pad
     float4* d_vel = nullptr;           // [R][Npad] xyz + pad
+    // Monte Carlo barostat (OpenMM MonteCarloBarostat as the reference's NPT ThermodynamicState adds it, states.py:1177-1181)
+    int baro_frequency = 0; long long baro_steps = 0, baro_attempts = 0;
+    double* d_pressure = nullptr;      // [K] kJ/mol/nm^3 (bar * N_A * 1e-25)
+    double* d_baro = nullptr;          // [R][8]: volumeScale, attempted, accepted (adaptation window), total attempted, total accepted, dV, newV, oldV
+    float* d_box_old = nullptr; float4* d_baro_x0 = nullptr; long long* d_baro_f0 = nullptr; double* d_baro_U0 = nullptr; int* d_baro_acc = nullptr;
     int box_version = 0;               // bumped whenever the box edges on the device change (PME influence table)
     int n_restart_attempts = 0;        // mcmc.py:706-759
     float4* d_snap_pos = nullptr; float4* d_snap_vel = nullptr;   // pre-propagate state (restart attempts)
@@ -162,6 +167,7 @@ int remd_assign_velocities(remd_ctx* h, int64_t iteration);
 int remd_kinetic_energy(remd_ctx* h);
 
 // ---- forces.hip -------------------------------------------------------------------------
+int remd_barostat_attempt(remd_ctx* h);
 int remd_minimize_impl(remd_ctx* h, double tolerance, int max_iterations, int32_t* converged, int32_t* n_iterations);
 int remd_compute_forces(remd_ctx* h, bool with_energy);   // fills d_force (and d_potential when with_energy)
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d);

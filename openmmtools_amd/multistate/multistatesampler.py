@@ -297,6 +297,17 @@ class MultiStateSampler:
         eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
                            move.reassign_velocities, move.constraint_tolerance)
         eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
+        pressures = [s.pressure for s in all_states]
+        if any(p is not None for p in pressures):
+            if any(p is None for p in pressures):
+                raise ValueError('NPT and NVT thermodynamic states cannot be mixed')
+            if np.any(lam_s != 1.0) or np.any(lam_e != 1.0):
+                raise NotImplementedError('NPT with alchemical states (volume-dependent long-range constants)')
+            eng.set_barostat(np.array(pressures, dtype=np.float64), all_states[0].barostat_frequency)
+            self._npt = True
+        else:
+            eng.set_barostat(None)
+            self._npt = False
         eng.seed(self._seed)
         R = self.n_replicas
         self._r_begin, self._r_count = self._comm.partition(R)
@@ -456,4 +467,8 @@ class MultiStateSampler:
             s = self._sampler_states[self._r_begin + k]
             s.positions = x[k].copy()
             s.velocities = v[k].copy()
+        if getattr(self, '_npt', False):                                # the barostat rescales the boxes on the device
+            boxes = self._engine.get_boxes()
+            for k in range(self._r_count):
+                self._sampler_states[self._r_begin + k].box_vectors = np.diag(boxes[k])
         self._sampler_states_stale = False

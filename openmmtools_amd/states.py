@@ -17,9 +17,12 @@ class ThermodynamicState:
     def __init__(self, system, temperature, pressure=None):
         self._system = system
         self.temperature = temperature
-        self.pressure = pressure
-        if pressure is not None:
-            raise NotImplementedError('NPT (pressure) states are outside the engine\'s current scope (SURVEY 8(f) #3)')
+        # NPT: the reference adds an openmm.MonteCarloBarostat (frequency 25) to the System (states.py:1177-1181); here the
+        # pressure (kJ/mol/nm^3, i.e. `p * unit.bar`) and the frequency are handed to the engine's barostat
+        self.pressure = None if pressure is None else float(pressure)
+        self.barostat_frequency = 25
+        if pressure is not None and not system.usesPeriodicBoundaryConditions():
+            raise ValueError('pressure is specified but the system is not periodic')          # states.py:1156-1158
 
     @property
     def system(self):

@@ -228,18 +228,30 @@ class OracleLangevin:
         return v
 
     def run(self, x, v, box, kT, replica, iteration, first_step=0, n_steps=None, tokens=None,
-            lambda_sterics=1.0, lambda_electrostatics=1.0):
+            lambda_sterics=1.0, lambda_electrostatics=1.0, barostat=None):
+        """barostat: None or dict(obj=OracleBarostat, pressure=p, frequency=f, steps_done=n, attempts_done=m); when given the
+        (possibly rescaled) box is returned as a third value."""
         s = self.s
         invm = 1.0 / s.mass
         tokens = self.tokens if tokens is None else tokens
         n_steps = self.n_steps if n_steps is None else n_steps
         x, v = x.copy(), v.copy()
         f = None
+        baro_steps = barostat['steps_done'] if barostat else 0
+        baro_attempt = barostat['attempts_done'] if barostat else 0
         for step in range(n_steps):
             gstep = iteration * self.n_steps + first_step + step
             if self.cmm and ((first_step + step) % self.cmm) == 0:
                 p = (s.mass[:, None] * v).sum(axis=0)                # CMMotionRemover at the top of a step
                 v -= p / s.mass.sum()
+            if barostat:
+                baro_steps += 1
+                if baro_steps % barostat['frequency'] == 0:          # MonteCarloBarostatImpl: every frequency-th step
+                    x, box, _ = barostat['obj'].attempt(x, box, kT, barostat['pressure'], replica, baro_attempt,
+                                                        lambda_sterics=lambda_sterics,
+                                                        lambda_electrostatics=lambda_electrostatics)
+                    baro_attempt += 1
+                    f = None
             oidx = 0
             for tok in tokens:
                 if tok[0] == 'V':
@@ -266,6 +278,8 @@ class OracleLangevin:
                     if s.constraints:
                         v = rattle(s.constraints, invm, x, v)
                     oidx += 1
+        if barostat:
+            return x, v, box
         return x, v
 
 
@@ -343,3 +357,86 @@ class OracleFIRE:
             if history is not None:
                 history.append((E, dt, alpha, n_neg))
         return x, v, E, converged, it
+
+
+# ---------------------------------------------------------------------------------------------
+# Monte Carlo barostat: f64 restatement of OpenMM's MonteCarloBarostatImpl::updateContextState (the NPT machinery the
+# reference relies on, openmmtools/states.py:1177-1181; integrators.py:1313).  TEST INFRASTRUCTURE ONLY.
+# ---------------------------------------------------------------------------------------------
+STREAM_BAROSTAT = 6
+
+
+def molecules_from_desc(desc):
+    """Connected components over exceptions (1-2, 1-3, 1-4 ... pairs), bonds and constraints; the device uses the same
+    union (forces.hip: remd_build_nonbonded groups).  Returns a list of atom-index arrays."""
+    n = int(desc['n_atoms'])
+    parent = list(range(n))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    def union(a, b):
+        ra, rb = find(int(a)), find(int(b))
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
+    for key, width in (('exception_atoms', 2), ('bond_atoms', 2)):
+        arr = np.asarray(desc.get(key, []), dtype=int).reshape(-1, width)
+        for a, b in arr:
+            union(a, b)
+    for (o, h1, h2) in np.asarray(desc['settle_atoms'], dtype=int).reshape(-1, 3):
+        union(o, h1); union(o, h2)
+    for atoms in np.asarray(desc['shake_atoms'], dtype=int).reshape(-1, 4):
+        for k in range(1, 4):
+            if atoms[k] >= 0:
+                union(atoms[0], atoms[k])
+    groups = {}
+    for a in range(n):
+        groups.setdefault(find(a), []).append(a)
+    return [np.array(g) for g in groups.values()]
+
+
+def u53(hi, lo):
+    return float(((int(hi) << 21) | (int(lo) >> 11)) / 9007199254740992.0)
+
+
+class OracleBarostat:
+    def __init__(self, system, seed, molecules):
+        self.s, self.seed, self.mols = system, int(seed), molecules
+        self.state = {}          # replica -> [volume_scale, attempted, accepted, total_attempted, total_accepted]
+
+    def attempt(self, x, box, kT, pressure, replica, attempt, **lam):
+        st = self.state.setdefault(replica, [0.0, 0, 0, 0, 0])
+        box = np.asarray(box, dtype=np.float64)
+        U0 = self.s.potential(x, box, **lam)
+        V = float(np.prod(box))
+        if st[0] <= 0.0:
+            st[0] = 0.01 * V
+        w = draw(self.seed, STREAM_BAROSTAT, 0, replica, attempt)
+        dV = st[0] * 2.0 * (u53(w[2], w[3]) - 0.5)
+        newV = V + dV
+        scale = (newV / V) ** (1.0 / 3.0)
+        xn = x.copy()
+        for m in self.mols:
+            c = x[m].mean(axis=0)
+            cw = c - np.floor(c / box) * box
+            xn[m] += cw * (scale - 1.0) - (c - cw)
+        boxn = box * scale
+        U1 = self.s.potential(xn, boxn, **lam)
+        wgt = U1 - U0 + pressure * dV - len(self.mols) * kT * np.log(newV / V)
+        q = draw(self.seed, STREAM_BAROSTAT, 1, replica, attempt)
+        reject = (not (wgt <= 0.0)) and (not (u53(q[2], q[3]) <= np.exp(-wgt / kT)))
+        if reject:
+            xn, boxn = x, box
+        else:
+            st[2] += 1; st[4] += 1
+        st[1] += 1; st[3] += 1
+        if st[1] >= 10:
+            Vc = float(np.prod(boxn))
+            if st[2] < 0.25 * st[1]:
+                st[0] /= 1.1; st[1] = 0; st[2] = 0
+            elif st[2] > 0.75 * st[1]:
+                st[0] = min(st[0] * 1.1, Vc * 0.3); st[1] = 0; st[2] = 0
+        return xn, boxn, (not reject)

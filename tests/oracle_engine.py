@@ -31,6 +31,16 @@ class OracleEngine:
         self.integ_args = (splitting, timestep, collision_rate, n_steps)
         self.reassign = reassign_velocities
 
+    def set_barostat(self, pressure, frequency=25):
+        self.pressure = None if pressure is None else np.array(pressure, dtype=np.float64)
+        self.baro_frequency = int(frequency)
+        self._baro = None
+        self._baro_steps = 0
+        self._baro_attempts = 0
+
+    def get_boxes(self):
+        return self.box.copy()
+
     def set_restart_attempts(self, n):
         self.n_restart_attempts = int(n)
 
@@ -68,11 +78,23 @@ class OracleEngine:
             for attempt in range(getattr(self, 'n_restart_attempts', 0) + 1):
                 it = iteration + (attempt << 40)
                 v = integ.assign_velocities(x0, kT, rg, it) if self.reassign else v0
-                self.x[r], self.v[r] = integ.run(x0, v, self._box(r), kT, rg, it,
-                                                 lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
+                if getattr(self, 'pressure', None) is not None:
+                    if self._baro is None:
+                        self._baro = mo.OracleBarostat(self.sys, self.seed_value, mo.molecules_from_desc(self.sys.d))
+                    baro = dict(obj=self._baro, pressure=self.pressure[k], frequency=self.baro_frequency,
+                                steps_done=self._baro_steps, attempts_done=self._baro_attempts)
+                    self.x[r], self.v[r], self.box[r] = integ.run(x0, v, self._box(r), kT, rg, it, lambda_sterics=self.lam_s[k],
+                                                                  lambda_electrostatics=self.lam_e[k], barostat=baro)
+                else:
+                    self.x[r], self.v[r] = integ.run(x0, v, self._box(r), kT, rg, it,
+                                                     lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
                 flags[r] = 0 if (np.isfinite(self.x[r]).all() and np.isfinite(self.v[r]).all()) else 1
                 if not flags[r]:
                     break
+        if getattr(self, 'pressure', None) is not None:
+            n = integ.n_steps
+            self._baro_attempts += (self._baro_steps + n) // self.baro_frequency - self._baro_steps // self.baro_frequency
+            self._baro_steps += n
         return flags
 
     def minimize(self, tolerance=1.0, max_iterations=0):
@@ -107,6 +129,8 @@ class OracleEngine:
                                           + self.econst) for r in range(self.R)])
         else:
             rows = mo.reduced_potential_matrix(U, self.beta, self.econst)
+        if getattr(self, 'pressure', None) is not None:                        # states.py:1913-1914: + beta_l p_l V_r
+            rows = rows + self.beta[None, :] * self.pressure[None, :] * np.prod(self.box, axis=1)[:, None]
         self._rows = rows
         return (rows, U) if want_potential else rows
 

@@ -1,0 +1,124 @@
+"""GPU: NPT states = Monte Carlo barostat inside the Langevin step (forces.hip: baro_* kernels, remd_set_barostat) and
+the beta p V term of u_kl, against the f64 oracle restatement of OpenMM's MonteCarloBarostatImpl (the machinery the
+reference's NPT ThermodynamicState relies on, states.py:1177-1181)."""
+import numpy as np
+import pytest
+from openmmtools_amd import testsystems as ts, states, mcmc, unit
+from openmmtools_amd.system import system_to_desc
+from openmmtools_amd.multistate import ParallelTemperingSampler
+from oracle import md_oracle as mo
+from oracle.forcefield import ForceFieldOracle
+from oracle_engine import OracleEngine
+
+pytestmark = pytest.mark.gpu
+KB = 0.008314462618153242
+
+
+def _setup(eng, system, x, T, pressure, n_steps, seed=11, dt=0.002):
+    R = len(x)
+    desc = system_to_desc(system)
+    eng.set_system(desc)
+    eng.set_states(1.0 / (KB * np.asarray(T, dtype=np.float64)))
+    eng.set_integrator('V R O R V', dt, 1.0, n_steps, True, 1e-8)
+    eng.set_barostat(np.full(R, pressure), 25)
+    eng.seed(seed)
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (R, 1))
+    eng.set_replicas(R, 0, x, None, box, np.arange(R))
+    return desc, box
+
+
+def test_barostat_tracks_the_oracle_on_the_lj_fluid(hip_engine_factory):
+    lj = ts.LennardJonesFluid(nparticles=216)
+    R = 3
+    rng = np.random.default_rng(1)
+    x = np.stack([lj.positions + 0.005 * rng.normal(size=lj.positions.shape) for _ in range(R)])
+    T = [110.0, 120.0, 130.0]
+    p = 40.0 * unit.bar
+    eng, ora = hip_engine_factory(), OracleEngine(ForceFieldOracle)
+    _setup(eng, lj.system, x, T, p, 50)
+    _setup(ora, lj.system, x, T, p, 50)
+    V0 = np.prod(eng.get_boxes(), axis=1)
+    for it in range(2):                                        # 2 x 50 steps = 4 volume moves per replica
+        assert not eng.propagate(it).any()
+        ora.propagate(it)
+        Vd, Vo = np.prod(eng.get_boxes(), axis=1), np.prod(ora.get_boxes(), axis=1)
+        assert np.allclose(Vd, Vo, rtol=2e-5), (it, Vd, Vo)
+    assert np.all(Vd != V0)
+    vs, na, nc = eng.barostat_stats()
+    assert na.tolist() == [4, 4, 4]
+    assert nc.tolist() == [ora._baro.state[r][4] for r in range(R)]
+    # u_kl rows include beta_l p_l V_r; energies evaluated by the oracle on the device's positions and boxes
+    xg, _, _, _ = eng.get_replicas()
+    rows = eng.compute_energies()
+    sysm = ForceFieldOracle(system_to_desc(lj.system))
+    beta = 1.0 / (KB * np.array(T))
+    boxes = eng.get_boxes()
+    for r in range(R):
+        U = sysm.potential(xg[r], boxes[r])
+        expect = beta * (U + p * np.prod(boxes[r]))
+        assert np.allclose(rows[r], expect, rtol=1e-5, atol=1e-4)
+
+
+def test_ideal_gas_volume_distribution_on_device(hip_engine_factory):
+    """eps = 0, q = 0: P(V) ~ V^N exp(-beta p V)  =>  <V> = (N + 1) kT / p  (and the same for the oracle, CPU test)."""
+    N, T, p = 64, 300.0, 30.0 * unit.bar
+    lj = ts.LennardJonesFluid(nparticles=N, epsilon=0.0)
+    R = 8
+    x = np.tile(lj.positions, (R, 1, 1))
+    eng = hip_engine_factory()
+    _setup(eng, lj.system, x, [T] * R, p, 25, dt=0.001)
+    vols = []
+    for it in range(700):
+        assert not eng.propagate(it).any()
+        if it >= 200:
+            vols.append(np.prod(eng.get_boxes(), axis=1))
+    vols = np.array(vols)
+    expect = (N + 1) * KB * T / p
+    mean = vols.mean()
+    sem = vols.std() / np.sqrt(vols.size / 15.0)
+    assert abs(mean - expect) < 5 * sem + 0.01 * expect, (mean, expect, sem)
+    rel = vols.std() / mean
+    assert 0.8 / np.sqrt(N + 1) < rel < 1.25 / np.sqrt(N + 1)          # Gamma(N + 1) distribution: sigma / mean = (N + 1)^-1/2
+    vs, na, nc = eng.barostat_stats()
+    assert np.all(na == 700) and np.all((nc / na > 0.2) & (nc / na < 0.9))      # adaptation aims at 25-75 % per 10-move window
+
+
+def test_alanine_npt_keeps_molecules_rigid(hip_engine_factory):
+    al = ts.AlanineDipeptideExplicit()
+    R = 2
+    x = np.stack([al.positions, al.positions])
+    eng = hip_engine_factory()
+    desc, box0 = _setup(eng, al.system, x, [300.0, 310.0], 1.0 * unit.bar, 100)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 100, True, 1e-8)
+    assert not eng.propagate(0).any()
+    boxes = eng.get_boxes()
+    assert np.all(np.abs(boxes / box0 - 1.0) < 0.02) and np.any(boxes != box0)
+    xg, _, ug, _ = eng.get_replicas(potential=True)
+    cons = mo.OracleSystem(desc).constraints
+    for (i, j, d0) in cons[:600]:
+        assert abs(np.linalg.norm(xg[0][i] - xg[0][j]) - d0) < 3e-6
+    sysm = ForceFieldOracle(desc)
+    U = sysm.potential(xg[1], boxes[1])
+    assert np.isclose(ug[1], U, rtol=1e-5), (ug[1], U)
+    vs, na, nc = eng.barostat_stats()
+    assert na.tolist() == [4, 4]
+
+
+def test_sampler_npt_on_device(hip_engine_factory):
+    lj = ts.LennardJonesFluid(nparticles=216)
+    tstate = states.ThermodynamicState(lj.system, 120.0, pressure=40.0 * unit.bar)
+    ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=50, reassign_velocities=True, splitting='V R O R V')
+    res = []
+    for engine in (hip_engine_factory(), OracleEngine(ForceFieldOracle)):
+        s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=2, engine=engine, seed=9)
+        s.create(tstate, [ss], min_temperature=110.0, max_temperature=130.0, n_temperatures=3)
+        s.run()
+        s._sampler_states_stale = True
+        s._sync_sampler_states()
+        res.append((s.replica_thermodynamic_states.copy(), np.array([st.volume for st in s.sampler_states]),
+                    s.energy_thermodynamic_states.copy()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.allclose(res[0][1], res[1][1], rtol=5e-5)
+    assert np.allclose(res[0][2], res[1][2], rtol=2e-4, atol=2e-3)
