@@ -36,6 +36,7 @@ struct pme_state {
     float2* d_tw[4] = {nullptr, nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i k / n)
     float* d_bmod[3] = {nullptr, nullptr, nullptr};  // |b(m)|^-2 ... stored as B-spline moduli squared inverse
     int nrad[4] = {0, 0, 0, 0}; int radix[4][8];
+    int xs_sw = 0;                      // y-slab width of pme_x_fused_kernel (planes that do not fit the LDS)
     float* d_infl = nullptr; int infl_version = -1;   // influence function [R][nz/2+1][nx][ny], rebuilt when a box changes
     bool z_half = false;               // nz even: z transforms run as nz/2-point complex FFTs of packed real pairs
     double* d_energy = nullptr;        // [R][n_eblk]
@@ -545,6 +546,53 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
     for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); P[idx] = buf[idx + x * pad]; }
 }
 
+// Planes too large for the LDS-resident XY pass (144 x 144 complex = 162 KB + tables): the two y passes stay separate
+// (contiguous lines), but forward x, influence function (+ energy) and inverse x are fused on a slab of `sw` y columns
+// resident in LDS — three sweeps over the half spectrum instead of five.
+#define XS_THREADS 256
+__global__ __launch_bounds__(XS_THREADS)
+void pme_x_fused_kernel(fft_plan plx, fft_sched scx, int ny, int nz, int sw, float2* __restrict__ spec, const float2* twx,
+                        int with_energy, double* __restrict__ energy, int n_eblk, const float* __restrict__ infl)
+{
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nx = plx.n, nzc = nz / 2 + 1, nslab = ny / sw, PS = sw | 1;
+    float2* buf = reinterpret_cast<float2*>(smem);           // [nx][PS]
+    float2* s_twx = buf + nx * PS;
+    double* s_e = reinterpret_cast<double*>(s_twx + nx + (nx & 1));
+    const int kz = blockIdx.x / nslab, slab = blockIdx.x - kz * nslab, r = blockIdx.y, tid = threadIdx.x;
+    const int y0 = slab * sw;
+    float2* P = spec + ((size_t)r * nzc + kz) * nx * ny;
+    const float* __restrict__ G = infl + ((size_t)r * nzc + kz) * nx * ny;
+    const unsigned msw = fft_magic((unsigned)sw);
+    for (int idx = tid; idx < nx * sw; idx += XS_THREADS) { const int x = fft_div(idx, msw, sw), yy = idx - x * sw; buf[x * PS + yy] = P[x * ny + y0 + yy]; }
+    for (int idx = tid; idx < nx; idx += XS_THREADS) s_twx[idx] = twx[idx];
+    __syncthreads();
+    fft_lines_inplace<-1, XY_PPT>(plx, scx, buf, PS, s_twx, tid, XS_THREADS);
+    const float wz = (kz == 0 || 2 * kz == nz) ? 1.f : 2.f;
+    double e_acc = 0.0;
+    for (int idx = tid; idx < nx * sw; idx += XS_THREADS) {
+        const int kx = fft_div(idx, msw, sw), yy = idx - kx * sw;
+        const float g = G[kx * ny + y0 + yy];
+        const float2 sv = buf[kx * PS + yy];
+        if (with_energy) e_acc += 0.5 * (double)(wz * g) * ((double)sv.x * sv.x + (double)sv.y * sv.y);
+        buf[kx * PS + yy] = make_float2(sv.x * g, sv.y * g);
+    }
+    if (with_energy) {
+        for (int off = 32; off > 0; off >>= 1) e_acc += __shfl_xor(e_acc, off);
+        if ((tid & 63) == 0) s_e[tid >> 6] = e_acc;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < XS_THREADS / 64; ++w) tot += s_e[w];
+            energy[(size_t)r * n_eblk + blockIdx.x] = tot;
+        }
+    }
+    __syncthreads();
+    fft_lines_inplace<+1, XY_PPT>(plx, scx, buf, PS, s_twx, tid, XS_THREADS);
+    for (int idx = tid; idx < nx * sw; idx += XS_THREADS) { const int x = fft_div(idx, msw, sw), yy = idx - x * sw; P[x * ny + y0 + yy] = buf[x * PS + yy]; }
+}
+
 // MODE 0: plain pass.  (kept for the 3-D FFT test hook and as the fall-back for planes larger than the LDS)
 template <int SIGN, int MODE>
 __global__ __launch_bounds__(FFT_B * FFT_T)
@@ -851,6 +899,19 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         if (getenv("REMD_PME_XYT")) s->xy_threads = std::max(256, std::min(1024, atoi(getenv("REMD_PME_XYT"))));
     }
     s->xy_fused = (size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * s->xy_threads && s->xy_lds <= 160 * 1024;
+    if (!s->xy_fused && !full_complex) {
+        // widest divisor of ny whose slab fits the registers of 256 threads and ~40 KB of LDS
+        for (int c = 1; c <= s->n[1]; ++c)
+            if (s->n[1] % c == 0 && (long long)s->n[0] * c <= (long long)XY_PPT * XS_THREADS && (size_t)s->n[0] * (c | 1) * 8 <= 40 * 1024) s->xs_sw = c;
+        if (s->xs_sw > 0) {
+            int rc = build_sched(h, s, 0, s->xs_sw, 1, s->xs_sw | 1, XS_THREADS, XY_PPT, &s->sch_x, &s->d_sched[0]);
+            if (rc) return rc;
+            s->n_eblk = s->nzc * (s->n[1] / s->xs_sw);
+            hipFree(s->d_energy); s->d_energy = nullptr;
+            REMD_CHECK(h, hipMalloc(&s->d_energy, sizeof(double) * (size_t)s->n_eblk * s->R));
+            REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_x_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        }
+    }
     if (s->xy_fused && !full_complex) {
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
         const int PS = s->n[1] | 1;
@@ -921,17 +982,27 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
                                    else { if (half) LAUNCH_Z(KERN, 512, true, __VA_ARGS__); else LAUNCH_Z(KERN, 512, false, __VA_ARGS__); } } while (0)
         DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid,
                    s->d_tw[2], s->d_tw[3]);
-        if (s->xy_fused) {
+        if (s->xy_fused || s->xs_sw > 0) {
             if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
             if (s->infl_version != h->box_version) {
                 hipLaunchKernelGGL(pme_influence_table_kernel, dim3(s->nzc, s->R), dim3(256), 0, st, nx, ny, nz, s->d_bmod[0], s->d_bmod[1],
                                    s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl);
                 s->infl_version = h->box_version;
             }
+        }
+        if (s->xy_fused) {
             remd_prof_scope pxy(h, "pme_xy", st);
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
                                (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl);
+        } else if (s->xs_sw > 0) {
+            // spec layout [kz][x][y]: y passes on contiguous lines, then the fused x pass on LDS-resident y slabs
+            launch_pass<-1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
+            const int PS = s->xs_sw | 1;
+            const size_t lds = sizeof(float2) * ((size_t)nx * PS + nx + 2) + 64;
+            hipLaunchKernelGGL(pme_x_fused_kernel, dim3(s->nzc * (ny / s->xs_sw), s->R), dim3(XS_THREADS), lds, st, make_plan(s, 0), s->sch_x,
+                               ny, nz, s->xs_sw, s->d_grid, s->d_tw[0], with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl);
+            launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         } else {
             // spec layout [kz][x][y]: y lines contiguous, x lines strided by ny
             launch_pass<-1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
