@@ -588,30 +588,48 @@ void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ ord
 // image) and appends the hits in ascending order (ballot + popcount => deterministic).
 __global__ __launch_bounds__(64)
 void build_cluster_list_kernel(int ncl, int cap, float rc2, const float4* __restrict__ cl_c, const float4* __restrict__ cl_h,
+                               const float4* __restrict__ tile_c, const float4* __restrict__ tile_h,
                                const float* __restrict__ box, unsigned short* __restrict__ list, int* __restrict__ count)
 {
+    // two levels: the 64-atom tile boxes (8 clusters each) are tested first, then the clusters of the hit tiles, eight
+    // tiles per pass; tiles and clusters are visited in ascending order, so the list is the same as a flat scan's
+    __shared__ int s_tiles[64];
     const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const int ntile = ncl >> 3;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
     const float4 ci = cl_c[(size_t)r * ncl + ic], hi = cl_h[(size_t)r * ncl + ic];
     unsigned short* L = list + ((size_t)r * ncl + ic) * cap;
+    auto near = [&](const float4 cj, const float4 hj) {
+        float bx = cj.x - ci.x, by = cj.y - ci.y, bz = cj.z - ci.z;
+        bx -= Lx * rintf(bx * iLx); by -= Ly * rintf(by * iLy); bz -= Lz * rintf(bz * iLz);
+        bx = fmaxf(0.f, fabsf(bx) - hi.x - hj.x); by = fmaxf(0.f, fabsf(by) - hi.y - hj.y); bz = fmaxf(0.f, fabsf(bz) - hi.z - hj.z);
+        return (hi.x >= 0.f) && (bx * bx + by * by + bz * bz <= rc2);
+    };
     int n = 0;
-    for (int base = 0; base < ncl; base += 64) {
-        const int jc = base + lane;
-        bool hit = false;
-        if (jc < ncl) {
-            const float4 cj = cl_c[(size_t)r * ncl + jc], hj = cl_h[(size_t)r * ncl + jc];
-            float bx = cj.x - ci.x, by = cj.y - ci.y, bz = cj.z - ci.z;
-            bx -= Lx * rintf(bx * iLx); by -= Ly * rintf(by * iLy); bz -= Lz * rintf(bz * iLz);
-            bx = fmaxf(0.f, fabsf(bx) - hi.x - hj.x); by = fmaxf(0.f, fabsf(by) - hi.y - hj.y); bz = fmaxf(0.f, fabsf(bz) - hi.z - hj.z);
-            hit = (hi.x >= 0.f) && (bx * bx + by * by + bz * bz <= rc2);
+    for (int tbase = 0; tbase < ntile; tbase += 64) {
+        const int jt = tbase + lane;
+        const bool thit = (jt < ntile) && near(tile_c[(size_t)r * ntile + jt], tile_h[(size_t)r * ntile + jt]);
+        const unsigned long long tm = __ballot(thit);
+        const int nhit = __popcll(tm);
+        __syncthreads();                                   // (one wavefront: orders the LDS reuse between chunks)
+        if (thit) s_tiles[__popcll(tm & ((1ull << lane) - 1ull))] = jt;
+        __syncthreads();
+        for (int q = 0; q < nhit; q += 8) {
+            const int g = q + (lane >> 3);
+            bool hit = false;
+            int jc = 0;
+            if (g < nhit) {
+                jc = s_tiles[g] * 8 + (lane & 7);
+                hit = near(cl_c[(size_t)r * ncl + jc], cl_h[(size_t)r * ncl + jc]);   // empty clusters carry a negative extent
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int slot = n + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < cap) L[slot] = (unsigned short)jc;
+            }
+            n += __popcll(m);
         }
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const int slot = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (slot < cap) L[slot] = (unsigned short)jc;
-        }
-        n += __popcll(m);
     }
     if (lane == 0) count[(size_t)r * ncl + ic] = n;       // n > cap is detected on the host side (fallback)
 }
@@ -1291,7 +1309,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
             hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
                                h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
             hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl_lj, h->R), dim3(64), 0, h->stream, ncl_lj, t.lj_cap, t.p.rc2,
-                               t.d_lj_cl_c, t.d_lj_cl_h, h->d_box, t.d_lj_list, t.d_lj_count);
+                               t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, h->d_box, t.d_lj_list, t.d_lj_count);
         }
         return 0;
     }
@@ -1351,13 +1369,13 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
         if (cl) {
             const int ncl = ntile * 8;
             hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl, h->R), dim3(64), 0, h->stream, ncl, t.cl_cap, t.p.rc2, t.d_cl_c,
-                               t.d_cl_h, h->d_box, t.d_cl_list, t.d_cl_count);
+                               t.d_cl_h, t.d_tile_c, t.d_tile_h, h->d_box, t.d_cl_list, t.d_cl_count);
             if (t.lj_split && (phase & 2)) {
                 const int ntile_lj = t.NLpad / 64, ncl_lj = t.NLpad / 8;
                 hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
                                    h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
                 hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl_lj, h->R), dim3(64), 0, h->stream, ncl_lj, t.lj_cap, t.p.rc2,
-                                   t.d_lj_cl_c, t.d_lj_cl_h, h->d_box, t.d_lj_list, t.d_lj_count);
+                                   t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, h->d_box, t.d_lj_list, t.d_lj_count);
             }
             if (t.evals_since_sort == 1 && (t.cl_cap < ncl || getenv("REMD_DEBUG"))) {
                 // capacity check once per re-sort (the only host synchronisation of this path)
