@@ -147,3 +147,15 @@ def test_sams_global_jump_parity(hip_engine_factory, R, K):
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
         assert np.allclose(got[3], ref[3], rtol=0, atol=1e-12)      # log P_k: libm log differs by <= ulps
         labels = got[0]
+
+
+def test_device_reproduces_the_committed_golden_vectors(hip_engine_factory):
+    """tests/golden/mix_reference_arith.json: transcription of replicaexchange.py:294-349 / :382-406 (tools/make_golden_mix.py)."""
+    import json, os
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'mix_reference_arith.json')
+    for c in json.load(open(path))['cases']:
+        eng = hip_engine_factory()
+        eng.seed(c['seed'])
+        got = eng.mix_host('swap-all', c['iteration'], np.array(c['u_kl']), np.array(c['labels_in'], dtype=np.int64))
+        assert got[0].tolist() == c['labels_out']
+        assert got[1].tolist() == c['n_accepted'] and got[2].tolist() == c['n_proposed']

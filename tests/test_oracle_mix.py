@@ -139,3 +139,15 @@ def test_sams_global_jump_properties():
     for r in range(R):
         _, p = scipy.stats.chisquare(cnt[r], 3000 * np.exp(ref[r]))
         assert p > 1e-4
+
+
+def test_golden_mixing_vectors():
+    """tests/golden/mix_reference_arith.json (tools/make_golden_mix.py): the pure-Python transcription of
+    replicaexchange.py:294-349 / :382-406 on this repository's Philox draws, committed as a fixture."""
+    import json, os
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'mix_reference_arith.json')
+    for c in json.load(open(path))['cases']:
+        u = np.array(c['u_kl'])
+        lab, nacc, nprop, _ = oracle.mix('swap-all', c['seed'], c['iteration'], u, np.array(c['labels_in'], dtype=np.int64))
+        assert lab.tolist() == c['labels_out']
+        assert nacc.tolist() == c['n_accepted'] and nprop.tolist() == c['n_proposed']
