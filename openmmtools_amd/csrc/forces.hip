@@ -96,7 +96,7 @@ struct nb_tables {
     unsigned short* d_lj_list = nullptr; int* d_lj_count = nullptr;
     int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 20; bool sorting = true;
 };
-static std::map<remd_ctx*, nb_tables> g_nb;
+static handle_table<nb_tables> g_nb;
 
 __device__ __forceinline__ void add_force(long long* __restrict__ F, int Npad, int i, float fx, float fy, float fz)
 {
@@ -1028,9 +1028,9 @@ static int upload(remd_ctx* h, T*& dptr, const std::vector<T>& host)
 
 void remd_free_nonbonded(remd_ctx* h)
 {
-    auto it = g_nb.find(h);
-    if (it == g_nb.end()) return;
-    nb_tables& t = it->second;
+    nb_tables* it = g_nb.find(h);
+    if (!it) return;
+    nb_tables& t = *it;
     dfree(t.d_param); dfree(t.d_mask); dfree(t.d_exc_atoms); dfree(t.d_exc_params); dfree(t.d_excl_atoms); dfree(t.d_excl_qq);
     dfree(t.d_exc_alch); dfree(t.d_excl_alch); dfree(t.d_probe);
     dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
@@ -1038,7 +1038,7 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
-    g_nb.erase(it);
+    g_nb.erase(h);
 }
 
 // long-range dispersion correction coefficient (E = coeff / V), OpenMM NonbondedForce convention:
@@ -1459,8 +1459,8 @@ static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
 
 const float* remd_nb_rep_lam(remd_ctx* h)
 {
-    auto it = g_nb.find(h);
-    return (it != g_nb.end() && it->second.has_alch) ? it->second.d_rep_lam : nullptr;
+    nb_tables* it = g_nb.find(h);
+    return (it && it->has_alch) ? it->d_rep_lam : nullptr;
 }
 const float4* remd_nb_param(remd_ctx* h) { return g_nb[h].d_param; }
 
@@ -1535,9 +1535,9 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         T.bond_atoms = h->d_bond_atoms; T.bond_params = h->d_bond_params;
         T.angle_atoms = h->d_angle_atoms; T.angle_params = h->d_angle_params;
         T.torsion_atoms = h->d_torsion_atoms; T.torsion_params = h->d_torsion_params;
-        auto it = g_nb.find(h);
-        if (it != g_nb.end() && h->nb_method != REMD_NB_NONE) {
-            nb_tables& t = it->second;
+        nb_tables* it = g_nb.find(h);
+        if (it && h->nb_method != REMD_NB_NONE) {
+            nb_tables& t = *it;
             T.n_exc = t.n_exc; T.exc_atoms = t.d_exc_atoms; T.exc_params = t.d_exc_params;
             T.n_excl = t.n_excl; T.excl_atoms = t.d_excl_atoms; T.excl_qq = t.d_excl_qq;
             T.alpha = t.p.alpha; T.two_alpha_sqrtpi = t.p.two_alpha_sqrtpi;
@@ -1705,9 +1705,9 @@ void baro_restore_kernel(int N, int Npad, const int* __restrict__ accepted, floa
 
 int remd_barostat_attempt(remd_ctx* h)
 {
-    auto it = g_nb.find(h);
-    if (it == g_nb.end() || it->second.n_groups <= 0) return remd_fail(h, -3, "barostat: the system has no molecule table (needs a NonbondedForce)");
-    nb_tables& t = it->second;
+    nb_tables* it = g_nb.find(h);
+    if (!it || it->n_groups <= 0) return remd_fail(h, -3, "barostat: the system has no molecule table (needs a NonbondedForce)");
+    nb_tables& t = *it;
     const int R = h->R, Npad = h->Npad;
     if (!h->d_baro) {
         REMD_CHECK(h, hipMalloc(&h->d_baro, sizeof(double) * 8 * R)); REMD_CHECK(h, hipMemset(h->d_baro, 0, sizeof(double) * 8 * R));
@@ -1765,10 +1765,10 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
 {
     const int n = h->R * h->K;
     const double* alch = nullptr;
-    auto it = g_nb.find(h);
+    nb_tables* it = g_nb.find(h);
     bool poly = false;
-    if (it != g_nb.end() && it->second.has_alch && h->nb_method != REMD_NB_NONE) {
-        nb_tables& t = it->second;
+    if (it && it->has_alch && h->nb_method != REMD_NB_NONE) {
+        nb_tables& t = *it;
         if (t.alch_R != h->R || t.alch_K != h->K) {
             dfree(t.d_alch_ukl); dfree(t.d_state_lam);
             REMD_CHECK(h, hipMalloc(&t.d_alch_ukl, sizeof(double) * (size_t)n));

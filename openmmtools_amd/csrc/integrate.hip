@@ -402,7 +402,7 @@ struct unit_tables {
     int4* d_atoms = nullptr; unsigned char* d_type = nullptr; float* d_dist = nullptr;
     settle_const sc{};
 };
-static std::map<remd_ctx*, unit_tables> g_units;
+static handle_table<unit_tables> g_units;
 
 int remd_build_constraints(remd_ctx* h, const remd_system_desc* d)
 {
@@ -458,10 +458,10 @@ int remd_build_constraints(remd_ctx* h, const remd_system_desc* d)
 
 void remd_free_constraints(remd_ctx* h)
 {
-    auto it = g_units.find(h);
-    if (it == g_units.end()) return;
-    if (it->second.d_atoms) { hipFree(it->second.d_atoms); hipFree(it->second.d_type); hipFree(it->second.d_dist); }
-    g_units.erase(it);
+    unit_tables* it = g_units.find(h);
+    if (!it) return;
+    if (it->d_atoms) { hipFree(it->d_atoms); hipFree(it->d_type); hipFree(it->d_dist); }
+    g_units.erase(h);
 }
 
 int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO)

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <mutex>
+#include <map>
 #include <vector>
 #include <map>
 #include "../../include/remd_hip.h"
@@ -131,6 +133,18 @@ int remd_fail(remd_ctx* h, int code, const std::string& msg);
 // profiling wrapper: brackets a launch with HIP events recorded on the handle's stream.  Nothing is
 // synchronised at launch time; the pairs are resolved in remd_profile_get().  Level 1 records only
 // the class named by prof_filter (bench.py: the dominant kernel), level 2 records every class.
+// Per-handle side tables (defined in the .hip files that own them).  Distinct handles may be used from distinct threads
+// (include/remd_hip.h): look-ups and insertions are serialised, and std::map never moves its elements, so a reference
+// obtained here stays valid until the handle itself is destroyed.
+template <typename T>
+struct handle_table {
+    std::mutex m;
+    std::map<remd_ctx*, T> map;
+    T& operator[](remd_ctx* h) { std::lock_guard<std::mutex> l(m); return map[h]; }
+    T* find(remd_ctx* h) { std::lock_guard<std::mutex> l(m); auto it = map.find(h); return it == map.end() ? nullptr : &it->second; }
+    void erase(remd_ctx* h) { std::lock_guard<std::mutex> l(m); map.erase(h); }
+};
+
 struct remd_prof_scope {
     remd_ctx* h; const char* name; hipEvent_t a = nullptr; bool on = false; hipStream_t st;
     remd_prof_scope(remd_ctx* h_, const char* n, hipStream_t stream = (hipStream_t)-1) : h(h_), name(n) {
