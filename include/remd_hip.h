@@ -138,6 +138,9 @@ int  remd_set_restart_attempts(remd_handle h, int n_restart_attempts);
    step); u_kl gains beta_l p_l V_r (states.py:1913-1914).  Boxes change: read them back with remd_get_boxes.          */
 int  remd_set_barostat(remd_handle h, int K, const double* pressure, int frequency);
 int  remd_get_boxes(remd_handle h, double* box /*[R_local][3]*/);
+/* The per-state energy constants of remd_set_states are long-range corrections ~ 1/V (alchemy.py:1786-1789); with a
+   barostat they must follow the box: pass the volume (nm^3) they were evaluated at, 0 = volume independent (default). */
+int  remd_set_energy_const_volume(remd_handle h, double reference_volume);
 int  remd_get_barostat_stats(remd_handle h, double* volume_scale /*[R_local]*/, int64_t* n_attempted, int64_t* n_accepted);
 
 /* MultiStateSampler.minimize (multistatesampler.py:611-647; _minimize_replica :1351-1434) with the reference's

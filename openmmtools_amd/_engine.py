@@ -45,6 +45,7 @@ EXPORTS = [
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
+    'remd_set_energy_const_volume',
 ]
 
 _lib = None
@@ -80,6 +81,7 @@ def load_library(path=None):
     lib.remd_minimize.argtypes = [vp, C.c_double, C.c_int, c_int32_p, c_int32_p]
     lib.remd_set_barostat.argtypes = [vp, C.c_int, c_double_p, C.c_int]
     lib.remd_get_boxes.argtypes = [vp, c_double_p]
+    lib.remd_set_energy_const_volume.argtypes = [vp, C.c_double]
     lib.remd_get_barostat_stats.argtypes = [vp, c_double_p, c_int64_p, c_int64_p]
     lib.remd_set_replicas.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]
     lib.remd_set_labels.argtypes = [vp, c_int64_p]
@@ -221,6 +223,10 @@ class HipEngine:
             return
         p = np.ascontiguousarray(pressure, dtype=np.float64)
         self._check(self.lib.remd_set_barostat(self.h, len(p), _dp(p), int(frequency)), 'remd_set_barostat')
+
+    def set_energy_const_volume(self, volume):
+        """The energy constants of set_states scale as volume / V with the replica's box (NPT + alchemical states)."""
+        self._check(self.lib.remd_set_energy_const_volume(self.h, float(volume)), 'remd_set_energy_const_volume')
 
     def get_boxes(self):
         box = np.zeros((self.R, 3), dtype=np.float64)

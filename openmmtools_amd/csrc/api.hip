@@ -312,6 +312,13 @@ int remd_set_barostat(remd_handle h, int K, const double* pressure, int frequenc
     return 0;
 }
 
+int remd_set_energy_const_volume(remd_handle h, double reference_volume)
+{
+    if (!h || !(reference_volume >= 0.0)) return remd_fail(h, -1, "remd_set_energy_const_volume: bad arguments");
+    h->econst_vref = reference_volume;
+    return 0;
+}
+
 int remd_get_boxes(remd_handle h, double* box)
 {
     if (!h || !box || h->R <= 0 || !h->d_box) return remd_fail(h, -1, "remd_get_boxes: replicas not set");

@@ -1003,14 +1003,16 @@ __global__ void assemble_ukl_kernel(int R, int K, const double* __restrict__ pot
                                     const double* __restrict__ beta, const double* __restrict__ econst,
                                     const double* __restrict__ alch /*[R][K] or null*/,
                                     const double* __restrict__ pressure /*[K] or null*/, const float* __restrict__ box,
-                                    double* __restrict__ ukl_rows)
+                                    double econst_vref, double* __restrict__ ukl_rows)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R * K) return;
     const int r = t / K, l = t % K;
-    double U = potential[r] + econst[l];
+    const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
+    // the per-state constants are long-range corrections ~ 1/V quoted at the volume econst_vref (0: volume independent)
+    double U = potential[r] + econst[l] * ((econst_vref > 0.0 && V > 0.0) ? econst_vref / V : 1.0);
     if (alch) U += alch[t];
-    if (pressure) U += pressure[l] * ((double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2]);
+    if (pressure) U += pressure[l] * V;
     ukl_rows[t] = beta[l] * U;
 }
 
@@ -1667,6 +1669,7 @@ void baro_scale_kernel(int n_mol, const int* __restrict__ first, const int* __re
 __global__ void baro_decide_kernel(int R, int r_begin, uint64_t seed, long long attempt, int n_mol, const double* __restrict__ U_old,
                                    const double* __restrict__ U_new, const int64_t* __restrict__ labels,
                                    const double* __restrict__ beta, const double* __restrict__ pressure,
+                                   const double* __restrict__ econst, double econst_vref,
                                    float* __restrict__ box, const float* __restrict__ box_old, double* __restrict__ st,
                                    int* __restrict__ accepted)
 {
@@ -1675,7 +1678,9 @@ __global__ void baro_decide_kernel(int R, int r_begin, uint64_t seed, long long 
     double* S = st + (size_t)r * 8;
     const int k = (int)labels[r_begin + r];
     const double kT = 1.0 / beta[k];
-    const double w = U_new[r] - U_old[r] + pressure[k] * S[5] - (double)n_mol * kT * log(S[6] / S[7]);
+    // + the current state's long-range constant ~ 1/V (alchemical sterics correction), which d_potential does not carry
+    const double dlr = (econst_vref > 0.0) ? econst[k] * econst_vref * (1.0 / S[6] - 1.0 / S[7]) : 0.0;
+    const double w = U_new[r] - U_old[r] + dlr + pressure[k] * S[5] - (double)n_mol * kT * log(S[6] / S[7]);
     const philox4 q = remd_philox(seed, REMD_STREAM_BAROSTAT, 1u, (uint32_t)(r_begin + r), (uint64_t)attempt);
     const bool reject = !(w <= 0.0) && !(remd_u53(q.w[2], q.w[3]) <= exp(-w / kT));     // NaN energies reject
     accepted[r] = reject ? 0 : 1;
@@ -1732,7 +1737,7 @@ int remd_barostat_attempt(remd_ctx* h)
     h->force_zeroed = false;
     if ((rc = remd_compute_forces(h, true))) return rc;                         // U' and forces of the scaled configuration
     hipLaunchKernelGGL(baro_decide_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, h->r_begin, h->seed, attempt, t.n_groups,
-                       h->d_baro_U0, h->d_potential, h->d_labels, h->d_beta, h->d_pressure, h->d_box, h->d_box_old, h->d_baro,
+                       h->d_baro_U0, h->d_potential, h->d_labels, h->d_beta, h->d_pressure, h->d_econst, h->econst_vref, h->d_box, h->d_box_old, h->d_baro,
                        h->d_baro_acc);
     hipLaunchKernelGGL(baro_restore_kernel, dim3((h->N + 255) / 256, R), dim3(256), 0, h->stream, h->N, Npad, h->d_baro_acc, h->d_pos,
                        h->d_baro_x0, h->d_force, h->d_baro_f0, h->d_potential, h->d_baro_U0);
@@ -1747,7 +1752,8 @@ int remd_barostat_attempt(remd_ctx* h)
 __global__ void assemble_ukl_poly_kernel(int R, int K, const double* __restrict__ probe /*[3][R]*/,
                                          const double* __restrict__ beta, const double* __restrict__ econst,
                                          const double* __restrict__ lam_e, const double* __restrict__ alch,
-                                         double* __restrict__ ukl_rows)
+                                         const double* __restrict__ pressure /*[K] or null*/, const float* __restrict__ box,
+                                         double econst_vref, double* __restrict__ ukl_rows)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R * K) return;
@@ -1756,8 +1762,10 @@ __global__ void assemble_ukl_poly_kernel(int R, int K, const double* __restrict_
     const double c = 2.0 * (P1 - P0) - 4.0 * (Ph - P0);
     const double b = (P1 - P0) - c;
     const double le = lam_e[l];
-    double U = P0 + b * le + c * le * le + econst[l];
+    const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
+    double U = P0 + b * le + c * le * le + econst[l] * ((econst_vref > 0.0 && V > 0.0) ? econst_vref / V : 1.0);
     if (alch) U += alch[t];
+    if (pressure) U += pressure[l] * V;
     ukl_rows[t] = beta[l] * U;
 }
 
@@ -1804,13 +1812,14 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
             }
             h->forces_valid = false;        // the last pass used a probe lambda, not the replicas' own
             hipLaunchKernelGGL(assemble_ukl_poly_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K, t.d_probe,
-                               h->d_beta, h->d_econst, h->d_lam_e, alch, d_rows);
+                               h->d_beta, h->d_econst, h->d_lam_e, alch, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr,
+                               h->d_box, h->econst_vref, d_rows);
             REMD_CHECK(h, hipGetLastError());
             return 0;
         }
     }
     hipLaunchKernelGGL(assemble_ukl_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K,
-                       h->d_potential, h->d_beta, h->d_econst, alch, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr, h->d_box, d_rows);
+                       h->d_potential, h->d_beta, h->d_econst, alch, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr, h->d_box, h->econst_vref, d_rows);
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }

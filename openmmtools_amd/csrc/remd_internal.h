@@ -83,6 +83,7 @@ struct remd_ctx {
     float4* d_vel = nullptr;           // [R][Npad] xyz + pad
     // Monte Carlo barostat (OpenMM MonteCarloBarostat as the reference's NPT ThermodynamicState adds it, states.py:1177-1181)
     int baro_frequency = 0; long long baro_steps = 0, baro_attempts = 0;
+    double econst_vref = 0.0;          // volume at which the per-state energy constants were evaluated (they scale as 1/V); 0: constant
     double* d_pressure = nullptr;      // [K] kJ/mol/nm^3 (bar * N_A * 1e-25)
     double* d_baro = nullptr;          // [R][8]: volumeScale, attempted, accepted (adaptation window), total attempted, total accepted, dV, newV, oldV
     float* d_box_old = nullptr; float4* d_baro_x0 = nullptr; long long* d_baro_f0 = nullptr; double* d_baro_U0 = nullptr; int* d_baro_acc = nullptr;

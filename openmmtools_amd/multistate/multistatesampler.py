@@ -301,12 +301,13 @@ class MultiStateSampler:
         if any(p is not None for p in pressures):
             if any(p is None for p in pressures):
                 raise ValueError('NPT and NVT thermodynamic states cannot be mixed')
-            if np.any(lam_s != 1.0) or np.any(lam_e != 1.0):
-                raise NotImplementedError('NPT with alchemical states (volume-dependent long-range constants)')
             eng.set_barostat(np.array(pressures, dtype=np.float64), all_states[0].barostat_frequency)
+            # the alchemical long-range constants were evaluated at the first sampler state's volume and scale as 1/V
+            eng.set_energy_const_volume(self._sampler_states[0].volume if np.any(self._state_energy_constants(all_states) != 0.0) else 0.0)
             self._npt = True
         else:
             eng.set_barostat(None)
+            eng.set_energy_const_volume(0.0)
             self._npt = False
         eng.seed(self._seed)
         R = self.n_replicas

@@ -248,6 +248,7 @@ class OracleLangevin:
                 baro_steps += 1
                 if baro_steps % barostat['frequency'] == 0:          # MonteCarloBarostatImpl: every frequency-th step
                     x, box, _ = barostat['obj'].attempt(x, box, kT, barostat['pressure'], replica, baro_attempt,
+                                                        long_range=barostat.get('long_range', 0.0),
                                                         lambda_sterics=lambda_sterics,
                                                         lambda_electrostatics=lambda_electrostatics)
                     baro_attempt += 1
@@ -407,7 +408,8 @@ class OracleBarostat:
         self.s, self.seed, self.mols = system, int(seed), molecules
         self.state = {}          # replica -> [volume_scale, attempted, accepted, total_attempted, total_accepted]
 
-    def attempt(self, x, box, kT, pressure, replica, attempt, **lam):
+    def attempt(self, x, box, kT, pressure, replica, attempt, long_range=0.0, **lam):
+        """long_range: coefficient c of a state constant c / V that the potential does not carry (alchemical sterics LRC)."""
         st = self.state.setdefault(replica, [0.0, 0, 0, 0, 0])
         box = np.asarray(box, dtype=np.float64)
         U0 = self.s.potential(x, box, **lam)
@@ -425,7 +427,7 @@ class OracleBarostat:
             xn[m] += cw * (scale - 1.0) - (c - cw)
         boxn = box * scale
         U1 = self.s.potential(xn, boxn, **lam)
-        wgt = U1 - U0 + pressure * dV - len(self.mols) * kT * np.log(newV / V)
+        wgt = U1 - U0 + long_range * (1.0 / newV - 1.0 / V) + pressure * dV - len(self.mols) * kT * np.log(newV / V)
         q = draw(self.seed, STREAM_BAROSTAT, 1, replica, attempt)
         reject = (not (wgt <= 0.0)) and (not (u53(q[2], q[3]) <= np.exp(-wgt / kT)))
         if reject:

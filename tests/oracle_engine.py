@@ -38,6 +38,9 @@ class OracleEngine:
         self._baro_steps = 0
         self._baro_attempts = 0
 
+    def set_energy_const_volume(self, volume):
+        self.econst_vref = float(volume)
+
     def get_boxes(self):
         return self.box.copy()
 
@@ -81,8 +84,10 @@ class OracleEngine:
                 if getattr(self, 'pressure', None) is not None:
                     if self._baro is None:
                         self._baro = mo.OracleBarostat(self.sys, self.seed_value, mo.molecules_from_desc(self.sys.d))
+                    vref = getattr(self, 'econst_vref', 0.0)
                     baro = dict(obj=self._baro, pressure=self.pressure[k], frequency=self.baro_frequency,
-                                steps_done=self._baro_steps, attempts_done=self._baro_attempts)
+                                steps_done=self._baro_steps, attempts_done=self._baro_attempts,
+                                long_range=(self.econst[k] * vref) if vref > 0 else 0.0)
                     self.x[r], self.v[r], self.box[r] = integ.run(x0, v, self._box(r), kT, rg, it, lambda_sterics=self.lam_s[k],
                                                                   lambda_electrostatics=self.lam_e[k], barostat=baro)
                 else:
@@ -124,11 +129,13 @@ class OracleEngine:
 
     def compute_energies(self, d_rows=None, want_host=True, want_potential=False):
         U = self.potentials()
+        vref = getattr(self, 'econst_vref', 0.0)
+        scale = [(vref / np.prod(self.box[r])) if vref > 0 else 1.0 for r in range(self.R)]      # constants ~ 1/V
         if hasattr(self.sys, 'state_energies'):
             rows = np.stack([self.beta * (self.sys.state_energies(self.x[r], self._box(r), self.lam_s, self.lam_e)
-                                          + self.econst) for r in range(self.R)])
+                                          + self.econst * scale[r]) for r in range(self.R)])
         else:
-            rows = mo.reduced_potential_matrix(U, self.beta, self.econst)
+            rows = np.stack([self.beta * (U[r] + self.econst * scale[r]) for r in range(self.R)])
         if getattr(self, 'pressure', None) is not None:                        # states.py:1913-1914: + beta_l p_l V_r
             rows = rows + self.beta[None, :] * self.pressure[None, :] * np.prod(self.box, axis=1)[:, None]
         self._rows = rows

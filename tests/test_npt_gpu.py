@@ -122,3 +122,43 @@ def test_sampler_npt_on_device(hip_engine_factory):
     assert np.array_equal(res[0][0], res[1][0])
     assert np.allclose(res[0][1], res[1][1], rtol=5e-5)
     assert np.allclose(res[0][2], res[1][2], rtol=2e-4, atol=2e-3)
+
+
+def test_npt_with_alchemical_states_tracks_the_oracle(hip_engine_factory):
+    """NPT + lambda_sterics states (production free-energy mode): the per-state long-range constants scale as 1/V with each
+    replica's box, both in u_kl and in the barostat's acceptance."""
+    from openmmtools_amd import alchemy
+    from openmmtools_amd.system import NonbondedForce
+    lj = ts.LennardJonesFluid(nparticles=216)
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(10))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, region)
+    nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
+    lam = np.array([1.0, 0.6, 0.3, 0.0])
+    R = len(lam)
+    V0 = float(np.prod(np.diag(system.getDefaultPeriodicBoxVectors())))
+    econst = alchemy.alchemical_long_range_constants(system, nb, lam, V0)
+    assert np.any(econst != 0.0)
+    p = 40.0 * unit.bar
+    x = np.tile(lj.positions, (R, 1, 1))
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (R, 1))
+    engines = []
+    for eng in (hip_engine_factory(), OracleEngine(ForceFieldOracle)):
+        eng.set_system(system_to_desc(system))
+        eng.set_states(np.full(R, 1.0 / (KB * 120.0)), lam, None, econst)
+        eng.set_integrator('V R O R V', 0.002, 1.0, 50, True, 1e-8)
+        eng.set_barostat(np.full(R, p), 25)
+        eng.set_energy_const_volume(V0)
+        eng.seed(21)
+        eng.set_replicas(R, 0, x, None, box, np.arange(R))
+        engines.append(eng)
+    dev, ora = engines
+    for it in range(2):
+        assert not dev.propagate(it).any()
+        ora.propagate(it)
+    Vd, Vo = np.prod(dev.get_boxes(), axis=1), np.prod(ora.get_boxes(), axis=1)
+    assert np.allclose(Vd, Vo, rtol=3e-5), (Vd, Vo)
+    assert np.all(Vd != V0)
+    # u_kl of the device against the oracle evaluated on the device's own configuration
+    xg, _, _, _ = dev.get_replicas()
+    ora.x, ora.box = xg.copy(), dev.get_boxes()
+    assert np.allclose(dev.compute_energies(), ora.compute_energies(), rtol=1e-5, atol=2e-4)
