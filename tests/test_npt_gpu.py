@@ -162,3 +162,46 @@ def test_npt_with_alchemical_states_tracks_the_oracle(hip_engine_factory):
     xg, _, _, _ = dev.get_replicas()
     ora.x, ora.box = xg.copy(), dev.get_boxes()
     assert np.allclose(dev.compute_energies(), ora.compute_energies(), rtol=1e-5, atol=2e-4)
+
+
+def test_hostguest_npt_alchemical_production_mode(hip_engine_factory):
+    """CB7:B2 host-guest, lambda_electrostatics + lambda_sterics states, NPT at 1 bar (the production free-energy ensemble):
+    50 g-BAOAB steps with two volume moves per replica on the device, then u_kl = beta_l (U(l) + c_l V0/V + p V) against
+    the oracle evaluated on the device's configuration and boxes."""
+    from openmmtools_amd import alchemy
+    from openmmtools_amd.system import NonbondedForce
+    hg = ts.HostGuestExplicit()
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(hg.system, region)
+    lam_e = np.array([1.0, 0.5, 0.0, 0.0])
+    lam_s = np.array([1.0, 1.0, 1.0, 0.4])
+    K = len(lam_e)
+    nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
+    box0 = np.diag(system.getDefaultPeriodicBoxVectors())
+    V0 = float(np.prod(box0))
+    econst = alchemy.alchemical_long_range_constants(system, nb, lam_s, V0)
+    p = 1.0 * unit.bar
+    eng = hip_engine_factory()
+    desc = system_to_desc(system)
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 300.0)
+    eng.set_states(np.full(K, beta), lam_s, lam_e, econst)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 50, True, 1e-8)
+    eng.set_barostat(np.full(K, p), 25)
+    eng.set_energy_const_volume(V0)
+    eng.seed(5)
+    labels = np.array([1, 3])
+    x = np.stack([hg.positions, hg.positions])
+    eng.set_replicas(2, 0, x, None, np.tile(box0, (2, 1)), labels)
+    assert not eng.propagate(0).any()
+    boxes = eng.get_boxes()
+    assert np.any(boxes != box0) and np.all(np.abs(boxes / box0 - 1.0) < 0.02)
+    _, na, _ = eng.barostat_stats()
+    assert na.tolist() == [2, 2]
+    rows = eng.compute_energies()
+    xd = eng.get_replicas()[0]
+    ff = ForceFieldOracle(desc)
+    for r in range(2):
+        V = float(np.prod(boxes[r]))
+        ref = beta * (ff.state_energies(xd[r], boxes[r], lam_s, lam_e) + econst * V0 / V + p * V)
+        assert np.allclose(rows[r], ref, rtol=1e-5), np.abs(rows[r] / ref - 1).max()
