@@ -63,3 +63,28 @@ def test_sampler_npt_on_oracle_engine_changes_volumes_and_ukl():
     expect = beta[None, :] * (U[:, None] + 30.0 * unit.bar * np.prod(eng.box, axis=1)[:, None])
     assert np.allclose(s.energy_thermodynamic_states, expect, rtol=1e-12)
     assert eng._baro_attempts == 4 and eng._baro_steps == 100
+
+
+def test_sampler_npt_with_alchemical_states_passes_the_reference_volume():
+    """ReplicaExchangeSampler over lambda_sterics states at constant pressure: the engine receives the pressures, the
+    barostat frequency and the volume at which the long-range constants were evaluated."""
+    from openmmtools_amd import alchemy
+    lj = testsystems.LennardJonesFluid(nparticles=64)
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(4))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, region)
+    ths = [states.CompoundThermodynamicState(states.ThermodynamicState(system, 120.0, pressure=20.0 * unit.bar),
+                                             [states.AlchemicalState(lambda_sterics=l)]) for l in (1.0, 0.5, 0.0)]
+    ss = states.SamplerState(lj.positions, box_vectors=system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, n_steps=25, reassign_velocities=True)
+    from openmmtools_amd.multistate import ReplicaExchangeSampler
+    eng = OracleEngine(ForceFieldOracle)
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=1, engine=eng, seed=2)
+    s.create(ths, [ss])
+    assert np.allclose(eng.pressure, 20.0 * unit.bar) and eng.baro_frequency == 25
+    assert np.isclose(eng.econst_vref, ss.volume) and np.any(eng.econst != 0.0)
+    s.run()
+    V = np.prod(eng.box, axis=1)
+    expect = eng.beta[None, :] * (np.stack([eng.sys.state_energies(eng.x[r], eng.box[r], eng.lam_s, eng.lam_e) for r in range(3)])
+                                  + eng.econst[None, :] * ss.volume / V[:, None] + 20.0 * unit.bar * V[:, None])
+    assert np.allclose(s.energy_thermodynamic_states, expect, rtol=1e-12)
+    assert eng._baro_attempts == 1
