@@ -89,7 +89,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_pos_ref); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels);
     dfree(h->d_ukl); dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
     dfree(h->d_pressure); dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
-    dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel);
+    dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -193,7 +193,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels); dfree(h->d_ukl);
         // per-replica scratch of the barostat and of the restart attempts is sized by R_local as well
         dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
-        dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel);
+        dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
         dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
         REMD_CHECK(h, hipMalloc(&h->d_pos, sizeof(float4) * n));
         REMD_CHECK(h, hipMalloc(&h->d_vel, sizeof(float4) * n));
@@ -260,7 +260,9 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         if (!h->d_snap_pos) {
             REMD_CHECK(h, hipMalloc(&h->d_snap_pos, bytes)); REMD_CHECK(h, hipMalloc(&h->d_snap_vel, bytes));
             REMD_CHECK(h, hipMalloc(&h->d_fin_pos, bytes)); REMD_CHECK(h, hipMalloc(&h->d_fin_vel, bytes));
+            REMD_CHECK(h, hipMalloc(&h->d_snap_box, sizeof(float) * 4 * h->R)); REMD_CHECK(h, hipMalloc(&h->d_fin_box, sizeof(float) * 4 * h->R));
         }
+        REMD_CHECK(h, hipMemcpyAsync(h->d_snap_box, h->d_box, sizeof(float) * 4 * h->R, hipMemcpyDeviceToDevice, h->stream));
         REMD_CHECK(h, hipMemcpyAsync(h->d_snap_pos, h->d_pos, bytes, hipMemcpyDeviceToDevice, h->stream));
         REMD_CHECK(h, hipMemcpyAsync(h->d_snap_vel, h->d_vel, bytes, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -282,12 +284,15 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
             if (!pending[r] || (flags[r] && !last)) continue;             // (a replica that failed for good keeps its NaN state)
             REMD_CHECK(h, hipMemcpyAsync(h->d_fin_pos + r * seg, h->d_pos + r * seg, sizeof(float4) * seg, hipMemcpyDeviceToDevice, h->stream));
             REMD_CHECK(h, hipMemcpyAsync(h->d_fin_vel + r * seg, h->d_vel + r * seg, sizeof(float4) * seg, hipMemcpyDeviceToDevice, h->stream));
+            REMD_CHECK(h, hipMemcpyAsync(h->d_fin_box + 4 * r, h->d_box + 4 * r, sizeof(float) * 4, hipMemcpyDeviceToDevice, h->stream));
             if (!flags[r]) pending[r] = 0;
         }
         const float4* src_p = last ? h->d_fin_pos : h->d_snap_pos;
         const float4* src_v = last ? h->d_fin_vel : h->d_snap_vel;
         REMD_CHECK(h, hipMemcpyAsync(h->d_pos, src_p, bytes, hipMemcpyDeviceToDevice, h->stream));
         REMD_CHECK(h, hipMemcpyAsync(h->d_vel, src_v, bytes, hipMemcpyDeviceToDevice, h->stream));
+        REMD_CHECK(h, hipMemcpyAsync(h->d_box, last ? h->d_fin_box : h->d_snap_box, sizeof(float) * 4 * h->R, hipMemcpyDeviceToDevice, h->stream));
+        h->box_version++;
         h->forces_valid = false; h->force_zeroed = false;
         if (last) { for (int r = 0; r < h->R; ++r) flags[r] = pending[r] ? 1 : 0; break; }
     }

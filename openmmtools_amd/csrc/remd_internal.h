@@ -91,6 +91,7 @@ struct remd_ctx {
     int n_restart_attempts = 0;        // mcmc.py:706-759
     float4* d_snap_pos = nullptr; float4* d_snap_vel = nullptr;   // pre-propagate state (restart attempts)
     float4* d_fin_pos = nullptr; float4* d_fin_vel = nullptr;     // first successful result of every replica
+    float* d_snap_box = nullptr; float* d_fin_box = nullptr;      // boxes move under the barostat: same treatment
     float4* d_pos_ref = nullptr;       // [R][Npad] reference (constrained) positions for SHAKE/SETTLE
     long long* d_force = nullptr;      // [R][3][Npad] fixed point
     float* d_box = nullptr;            // [R][4] lx, ly, lz, pad
