@@ -219,3 +219,19 @@ def test_hostguest_alchemical_electrostatics_and_sterics_ukl(hip_engine_factory)
         f_ref = ff.energy_forces(xd[r], box[r], lambda_sterics=lam_s[k], lambda_electrostatics=lam_e[k])[1]
         assert np.sqrt(((f[r] - f_ref) ** 2).sum(axis=1).mean()) < 2.5
     assert not eng.propagate(1).any()
+
+
+def test_alanine_propagation_is_bit_reproducible(hip_engine_factory):
+    """Forces are accumulated as 64-bit fixed point (integer atomics), the mesh charges as 32-bit fixed point, energies
+    in fixed-order partial sums, and every random stream is counter based: two runs of the same propagate on two streams
+    must agree bit for bit (positions, velocities, u_kl), whatever the order in which workgroups and atomics retire."""
+    al = ts.AlanineDipeptideExplicit()
+    out = []
+    for _ in range(2):
+        eng = hip_engine_factory()
+        _engine_for(eng, al.system, al.positions, R=3, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=25)
+        assert not eng.propagate(4).any()
+        x, v, _, _ = eng.get_replicas()
+        out.append((x, v, eng.compute_energies()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
