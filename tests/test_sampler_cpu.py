@@ -173,3 +173,26 @@ def test_nan_restart_attempts_follow_the_reference_protocol():
         assert [c for c in calls if c[0] == 2] == [(2, 0), (2, 1), (2, 2)]
     finally:
         mo.OracleLangevin.run = real_run
+
+
+def test_unsampled_states_energies(tmp_path):
+    """multistatesampler.py:1436-1456, :923-926: energies of every replica at the unsampled states ([R, U], never mixed into)."""
+    from openmmtools_amd.multistate import ReplicaExchangeSampler, MultiStateReporter
+    ho = testsystems.HarmonicOscillator()
+    sampled = [states.ThermodynamicState(ho.system, T) for T in (300.0, 350.0, 400.0)]
+    unsampled = [states.ThermodynamicState(ho.system, T) for T in (250.0, 500.0)]
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=10, reassign_velocities=True)
+    eng = OracleEngine()
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=3, engine=eng, seed=4)
+    s.create(sampled, [states.SamplerState(ho.positions + 0.01)], storage=MultiStateReporter(str(tmp_path / 'u'), checkpoint_interval=1),
+             unsampled_thermodynamic_states=unsampled)
+    s.run()
+    assert s.energy_thermodynamic_states.shape == (3, 3) and s._energy_unsampled_states.shape == (3, 2)
+    U = eng.potentials()
+    beta_u = np.array([t.beta for t in unsampled])
+    assert np.allclose(s._energy_unsampled_states, U[:, None] * beta_u[None, :], rtol=1e-13)
+    assert s._n_proposed_matrix.shape == (3, 3) and sorted(s.replica_thermodynamic_states) == [0, 1, 2]
+    e, nb, eu = MultiStateReporter(str(tmp_path / 'u'), open_mode='r').read_energies()
+    assert eu.shape == (4, 3, 2) and np.array_equal(eu[3], s._energy_unsampled_states)
+    r = ReplicaExchangeSampler.from_storage(str(tmp_path / 'u'), engine=OracleEngine())
+    assert len(r._unsampled_states) == 2 and r._energy_unsampled_states.shape == (3, 2)

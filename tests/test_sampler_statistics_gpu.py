@@ -95,3 +95,37 @@ def test_sams_sampler_runs_on_device_and_flattens(hip_engine_factory):
     assert s._state_histogram.min() > 0.1 * s._state_histogram.sum() / 4
     f_exact = -1.5 * np.log(T / T[0])
     assert np.abs((s._logZ - s._logZ[0]) - (-(f_exact - f_exact[0]))).max() < 0.5     # logZ = -f, loose SAMS bar
+
+
+def test_unsampled_states_on_device(hip_engine_factory):
+    """Unsampled end states ride along in the device u_kl rows (leading dimension K + U); only the K sampled columns are
+    mixed (multistatesampler.py:1436-1456)."""
+    from openmmtools_amd import alchemy
+    from openmmtools_amd.multistate import ReplicaExchangeSampler
+    from openmmtools_amd.system import system_to_desc
+    from oracle.forcefield import ForceFieldOracle
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(10))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, region)
+
+    def st(l):
+        return states.CompoundThermodynamicState(states.ThermodynamicState(system, 120.0), [states.AlchemicalState(lambda_sterics=l)])
+    sampled, unsampled = [st(l) for l in (0.8, 0.6, 0.4, 0.2)], [st(1.0), st(0.0)]
+    ss = states.SamplerState(lj.positions, box_vectors=system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=20, reassign_velocities=True, splitting='V R O R V')
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=2, engine=hip_engine_factory(), seed=6)
+    s.create(sampled, [ss], unsampled_thermodynamic_states=unsampled)
+    s.run()
+    assert s._energy_unsampled_states.shape == (4, 2) and s._n_proposed_matrix.sum() == 2 * 4 ** 3
+    s._sampler_states_stale = True
+    s._sync_sampler_states()
+    ff = ForceFieldOracle(system_to_desc(system))
+    lam = np.array([0.8, 0.6, 0.4, 0.2, 1.0, 0.0])
+    econst = s._state_energy_constants(sampled + unsampled)
+    beta = sampled[0].beta
+    box = np.diag(system.getDefaultPeriodicBoxVectors())
+    for r in range(4):
+        ref = beta * (ff.state_energies(s.sampler_states[r].positions, box, lam, np.ones(6)) + econst)
+        got = np.concatenate([s.energy_thermodynamic_states[r], s._energy_unsampled_states[r]])
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-4)
