@@ -4,14 +4,15 @@ ints) on the (i, j, u) sequence of this repository's Philox stream spec.  The re
 here (it needs numba / openmm / mpiplus), so the transcription is the pinned golden vector; the C oracle and the
 HIP kernel must both reproduce it bit for bit (tests/test_oracle_mix.py, tests/test_mix_parity.py).
 
-usage: python tools/make_golden_mix.py
+usage: python tests/golden/make_golden_mix.py   (test infrastructure: the only place outside tests/ proper, smoke() and
+bench.py's cpu_baseline leg that touches oracle/ is this fixture generator, which lives under tests/)
 """
 import json
 import math
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import md_oracle as mo
@@ -50,5 +51,5 @@ if __name__ == '__main__':
     cases = [case(4, 0xC0FFEE, 0, 3.0), case(9, 12345, 7, 2.0), case(24, 0xC0FFEE, 3, 3.0)]
     out = os.path.join(ROOT, 'tests', 'golden', 'mix_reference_arith.json')
     with open(out, 'w') as fh:
-        json.dump(dict(generator='tools/make_golden_mix.py', cases=cases), fh)
+        json.dump(dict(generator='tests/golden/make_golden_mix.py', cases=cases), fh)
     print('wrote', out, os.path.getsize(out), 'bytes')

@@ -1,6 +1,6 @@
 """Generates tests/golden/sobol_512x3.npy from the reference's own Sobol module.
 
-Run in the build container only (needs /root/reference):  python tools/make_golden_sobol.py
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden_sobol.py
 The reference builds LennardJonesFluid positions with sobol.i4_sobol_generate(3, N, 1)
 (openmmtools/testsystems.py:280); openmmtools_amd.testsystems re-implements the generator and
 tests/test_testsystems.py checks it against this fixture.

@@ -150,7 +150,7 @@ def test_sams_global_jump_parity(hip_engine_factory, R, K):
 
 
 def test_device_reproduces_the_committed_golden_vectors(hip_engine_factory):
-    """tests/golden/mix_reference_arith.json: transcription of replicaexchange.py:294-349 / :382-406 (tools/make_golden_mix.py)."""
+    """tests/golden/mix_reference_arith.json: transcription of replicaexchange.py:294-349 / :382-406 (tests/golden/make_golden_mix.py)."""
     import json, os
     path = os.path.join(os.path.dirname(__file__), 'golden', 'mix_reference_arith.json')
     for c in json.load(open(path))['cases']:

@@ -142,7 +142,7 @@ def test_sams_global_jump_properties():
 
 
 def test_golden_mixing_vectors():
-    """tests/golden/mix_reference_arith.json (tools/make_golden_mix.py): the pure-Python transcription of
+    """tests/golden/mix_reference_arith.json (tests/golden/make_golden_mix.py): the pure-Python transcription of
     replicaexchange.py:294-349 / :382-406 on this repository's Philox draws, committed as a fixture."""
     import json, os
     path = os.path.join(os.path.dirname(__file__), 'golden', 'mix_reference_arith.json')
