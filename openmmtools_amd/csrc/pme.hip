@@ -22,7 +22,7 @@
 #define FFT_T 32
 #define PME_FIXED_SCALE 68719476736.0      // 2^36
 
-struct fft_sched { const uint2* tab; int off[8]; };   // see fft_stage_sched
+struct fft_sched { const uint2* tab; int off[8]; int wave_local; };   // see fft_stage_sched
 
 struct pme_state {
     int n[4] = {0, 0, 0, 0};           // mesh dimensions; n[3] = nz / 2 (length of the packed real-to-complex z transform)
@@ -152,7 +152,9 @@ template <int SIGN, int RX> __device__ __forceinline__ void bfly(float2* v)
 // (stage s, slot b, thread t) at tab[off[s] + b * nthreads + t]: x = first input element | first output element << 16
 // (0xffffffff: idle), y = twiddle step.
 
-template <int SIGN, int RX, int PPT>
+// WL (wave-local schedule): every wavefront owns whole lines, so the read -> write hand-over of a stage only involves
+// its own lanes — LDS operations of one wavefront retire in order — and no workgroup barrier is needed inside a pass.
+template <int SIGN, int RX, int PPT, bool WL>
 __device__ __forceinline__ void fft_stage_sched(float2* buf, const uint2* __restrict__ tab, int in_stride, int out_stride,
                                                 bool twiddle, const float2* __restrict__ tw, int tid, int nthreads)
 {
@@ -181,31 +183,45 @@ __device__ __forceinline__ void fft_stage_sched(float2* buf, const uint2* __rest
             dst[b] = (int)(e[b].x >> 16);
         }
     }
-    __syncthreads();                                         // every input of this stage is in registers
+    if (WL) __builtin_amdgcn_wave_barrier(); else __syncthreads();      // every input of this stage is in registers
 #pragma unroll
     for (int b = 0; b < NB; ++b) if (dst[b] >= 0) {
 #pragma unroll
         for (int r = 0; r < RX; ++r) buf[dst[b] + r * out_stride] = v[b][r];
     }
-    __syncthreads();
+    if (WL) __builtin_amdgcn_wave_barrier(); else __syncthreads();
 }
 
 // in-place FFT of nlines lines (element e of line l at buf[l*ls + e*es]); every thread keeps its share of the points in
 // registers across the barrier, so only ONE LDS image of the data is needed
-template <int SIGN, int PPT>
-__device__ void fft_lines_inplace(const fft_plan& pl, const fft_sched& sc, float2* buf, int es,
-                                  const float2* __restrict__ tw, int tid, int nthreads)
+template <int SIGN, int PPT, bool WL>
+__device__ __forceinline__ void fft_lines_stages(const fft_plan& pl, const fft_sched& sc, float2* buf, int es,
+                                                 const float2* __restrict__ tw, int tid, int nthreads)
 {
     int Ns = 1;
     for (int s = 0; s < pl.nrad; ++s) {
         const int Rx = pl.radix[s];
         const int in_stride = (pl.n / Rx) * es, out_stride = Ns * es;
         const uint2* tab = sc.tab + sc.off[s];
-        if (Rx == 4) fft_stage_sched<SIGN, 4, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
-        else if (Rx == 5) fft_stage_sched<SIGN, 5, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
-        else if (Rx == 3) fft_stage_sched<SIGN, 3, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
-        else fft_stage_sched<SIGN, 2, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        if (Rx == 4) fft_stage_sched<SIGN, 4, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else if (Rx == 5) fft_stage_sched<SIGN, 5, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else if (Rx == 3) fft_stage_sched<SIGN, 3, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else fft_stage_sched<SIGN, 2, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
         Ns *= Rx;
+    }
+}
+
+// in-place FFT of nlines lines (element e of line l at buf[l*ls + e*es]); every thread keeps its share of the points in
+// registers across the barrier, so only ONE LDS image of the data is needed
+template <int SIGN, int PPT>
+__device__ __forceinline__ void fft_lines_inplace(const fft_plan& pl, const fft_sched& sc, float2* buf, int es,
+                                  const float2* __restrict__ tw, int tid, int nthreads)
+{
+    if (sc.wave_local) {
+        fft_lines_stages<SIGN, PPT, true>(pl, sc, buf, es, tw, tid, nthreads);
+        __syncthreads();                                     // the next pass regroups the lines
+    } else {
+        fft_lines_stages<SIGN, PPT, false>(pl, sc, buf, es, tw, tid, nthreads);
     }
 }
 
@@ -786,30 +802,55 @@ static fft_plan make_plan(pme_state* s, int axis)
 // host mirror of the index arithmetic of one in-place pass (element e of line l at l*ls + e*es, consecutive threads
 // take consecutive lines): fills the butterfly schedule read by fft_stage_sched
 static int build_sched(remd_ctx* h, pme_state* s, int axis, int nlines, int ls, int es, int nthreads, int ppt,
-                       fft_sched* out, uint2** d_tab)
+                       fft_sched* out, uint2** d_tab, bool want_wave_local = false)
 {
     const int n = s->n[axis];
+    const int nwaves = nthreads / 64;
+    // wave-local mapping: wavefront w owns the contiguous lines [w, w+1) * lines_per_wave; feasible when every wavefront's butterflies fit its slots
+    bool wl = want_wave_local && nwaves >= 1 && getenv("REMD_PME_WAVELOCAL") && atoi(getenv("REMD_PME_WAVELOCAL")) != 0;
+    const int lines_per_wave = (nlines + nwaves - 1) / nwaves;
+    for (int st = 0; st < s->nrad[axis] && wl; ++st) {
+        const int Rx = s->radix[axis][st];
+        if ((long long)lines_per_wave * (n / Rx) > (long long)((ppt + Rx - 1) / Rx) * 64) wl = false;
+    }
+    out->wave_local = wl ? 1 : 0;
     std::vector<uint2> tab;
     int Ns = 1;
     for (int st = 0; st < s->nrad[axis]; ++st) {
         const int Rx = s->radix[axis][st];
         const int NB = (ppt + Rx - 1) / Rx;
         const int nb = n / Rx, total = nlines * nb, tstride = n / (Ns * Rx);
-        if ((long long)NB * nthreads < total) return remd_fail(h, -3, "PME FFT pass does not fit the workgroup registers");
+        if (!wl && (long long)NB * nthreads < total) return remd_fail(h, -3, "PME FFT pass does not fit the workgroup registers");
         out->off[st] = (int)tab.size();
-        for (int b = 0; b < NB; ++b)
-            for (int t = 0; t < nthreads; ++t) {
-                const int idx = t + b * nthreads;
-                uint2 e = make_uint2(0xffffffffu, 0u);
-                if (idx < total) {
-                    const int j = idx / nlines, l = idx % nlines;
-                    const int jq = j / Ns, k = j % Ns;
-                    const int src = l * ls + j * es, dst = l * ls + (jq * Ns * Rx + k) * es;
-                    if (src > 0xffff || dst + (Rx - 1) * Ns * es > 0xffff) return remd_fail(h, -3, "PME plane too large for the FFT schedule");
-                    e = make_uint2((unsigned)src | ((unsigned)dst << 16), (unsigned)(k * tstride));
+        const size_t base = tab.size();
+        tab.resize(base + (size_t)NB * nthreads, make_uint2(0xffffffffu, 0u));
+        auto entry = [&](int l, int j) {
+            const int jq = j / Ns, k = j % Ns;
+            const int src = l * ls + j * es, dst = l * ls + (jq * Ns * Rx + k) * es;
+            return make_uint2((unsigned)src | ((unsigned)dst << 16), (unsigned)(k * tstride));
+        };
+        if ((nlines - 1) * ls + (n - 1) * es > 0xffff) return remd_fail(h, -3, "PME plane too large for the FFT schedule");
+        if (wl) {
+            for (int w = 0; w < nwaves; ++w) {
+                std::vector<int> mine;
+                for (int l = w * lines_per_wave; l < std::min(nlines, (w + 1) * lines_per_wave); ++l) mine.push_back(l);
+                const int cnt = (int)mine.size() * nb;
+                if (mine.empty()) continue;
+                for (int k = 0; k < cnt; ++k) {
+                    // consecutive lanes walk the unit-stride direction: lines when ls == 1, butterflies when es == 1
+                    int l, j;
+                    if (ls == 1) { j = k / (int)mine.size(); l = mine[k % mine.size()]; }
+                    else { l = mine[k / nb]; j = k % nb; }
+                    tab[base + (size_t)(k / 64) * nthreads + w * 64 + (k % 64)] = entry(l, j);
                 }
-                tab.push_back(e);
             }
+        } else {
+            for (int b = 0; b < NB; ++b)
+                for (int t = 0; t < nthreads; ++t) {
+                    const int idx = t + b * nthreads;
+                    if (idx < total) tab[base + (size_t)b * nthreads + t] = entry(idx % nlines, idx / nlines);
+                }
+        }
         Ns *= Rx;
     }
     if (*d_tab) { hipFree(*d_tab); *d_tab = nullptr; }
@@ -883,18 +924,25 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     {
         const long long np = (long long)s->n[0] * s->n[1];
         long long best_cost = -1; int best_t = 1024;
-        for (int t = 256; t <= 1024; t += 64) {
-            if (np > (long long)XY_PPT * t) continue;
-            long long cost = 0; bool ok = true;
-            for (int ax = 0; ax < 2 && ok; ++ax)
-                for (int st = 0; st < s->nrad[ax]; ++st) {
-                    const int rx = s->radix[ax][st];
-                    const long long nbf = np / rx, slots = (nbf + t - 1) / t;
-                    if (slots > (XY_PPT + rx - 1) / rx) ok = false;
-                    cost += slots * t * rx;                    // issued lane-points of this stage
-                }
-            if (ok && (best_cost < 0 || cost < best_cost)) { best_cost = cost; best_t = t; }
-        }
+        // REMD_PME_WAVELOCAL=1: standalone XY pass 64 -> 60 us (24 x alanine), but no end-to-end gain next to the pair kernels: default off
+        const bool try_wl = getenv("REMD_PME_WAVELOCAL") && atoi(getenv("REMD_PME_WAVELOCAL")) != 0;
+        for (int pass = try_wl ? 0 : 1; pass < 2 && best_cost < 0; ++pass)       // pass 0: wave-local schedules, 1: global
+            for (int t = 256; t <= 1024; t += 64) {
+                if (np > (long long)XY_PPT * t) continue;
+                long long cost = 0; bool ok = true;
+                for (int ax = 0; ax < 2 && ok; ++ax)
+                    for (int st = 0; st < s->nrad[ax]; ++st) {
+                        const int rx = s->radix[ax][st];
+                        long long slots;
+                        if (pass == 0) {
+                            const long long lpw = (s->n[1 - ax] + t / 64 - 1) / (t / 64);     // lines of the busiest wavefront
+                            slots = (lpw * (s->n[ax] / rx) + 63) / 64;
+                        } else slots = (np / rx + t - 1) / t;
+                        if (slots > (XY_PPT + rx - 1) / rx) ok = false;
+                        cost += slots * t * rx;                    // issued lane-points of this stage
+                    }
+                if (ok && (best_cost < 0 || cost < best_cost)) { best_cost = cost; best_t = t; }
+            }
         s->xy_threads = best_t;
         if (getenv("REMD_PME_XYT")) s->xy_threads = std::max(256, std::min(1024, atoi(getenv("REMD_PME_XYT"))));
     }
@@ -915,8 +963,8 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     if (s->xy_fused && !full_complex) {
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
         const int PS = s->n[1] | 1;
-        int rc = build_sched(h, s, 1, s->n[0], PS, 1, s->xy_threads, XY_PPT, &s->sch_y, &s->d_sched[1]);      // along y: lines = x rows
-        if (!rc) rc = build_sched(h, s, 0, s->n[1], 1, PS, s->xy_threads, XY_PPT, &s->sch_x, &s->d_sched[0]);  // along x: lines = y columns
+        int rc = build_sched(h, s, 1, s->n[0], PS, 1, s->xy_threads, XY_PPT, &s->sch_y, &s->d_sched[1], true);      // along y: lines = x rows
+        if (!rc) rc = build_sched(h, s, 0, s->n[1], 1, PS, s->xy_threads, XY_PPT, &s->sch_x, &s->d_sched[0], true);  // along x: lines = y columns
         if (rc) return rc;
     }
 #define Z_LDS_ATTR(ZT, HF) \
