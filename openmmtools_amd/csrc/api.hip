@@ -1,4 +1,5 @@
 // C ABI of libremd_hip.so (see include/remd_hip.h for the contract and reference citations).
+#include <chrono>
 #include "remd_internal.h"
 #include <cstring>
 #include <cmath>
@@ -272,10 +273,19 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         // the attempt number rides in the high bits of the iteration counter => fresh velocities and OU noise
         const int64_t it = iteration + ((int64_t)a << 40);
         if (h->reassign) { if ((rc = remd_assign_velocities(h, it))) return rc; }
+        static const bool time_enqueue = getenv("REMD_TIME_ENQUEUE") != nullptr;
+        const auto tq0 = std::chrono::steady_clock::now();
         if ((rc = remd_run_steps(h, h->tokens, h->nV, h->nR, h->nO, it, 0, h->n_steps))) return rc;
+        const auto tq1 = std::chrono::steady_clock::now();
         if ((rc = remd_check_finite(h))) return rc;
         REMD_CHECK(h, hipMemcpyAsync(flags.data(), h->d_nan, sizeof(int) * h->R, hipMemcpyDeviceToHost, h->stream));
         REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        if (time_enqueue) {
+            // diagnostic: host time spent enqueueing the MD steps vs the time until the device finished them
+            const auto tq2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[remd] propagate: %d steps enqueued in %.2f ms, device done %.2f ms after the last enqueue\n", h->n_steps,
+                    std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(tq2 - tq1).count());
+        }
         int n_bad = 0;
         for (int r = 0; r < h->R; ++r) if (pending[r] && flags[r]) ++n_bad;
         if (a == 0 && (n_bad == 0 || attempts == 0)) break;              // the normal case: nothing to restore

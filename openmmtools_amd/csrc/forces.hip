@@ -49,6 +49,7 @@ struct nb_params {
     float alpha, two_alpha_sqrtpi;    // Ewald
     int excl_words;                   // 64-bit words of the exclusion window per atom
     int n_jsplit;
+    int dbg;                          // REMD_SCI_DBG timing experiments (results are wrong when set)
 };
 
 struct nb_tables {
@@ -94,6 +95,11 @@ struct nb_tables {
     int* d_lj_order = nullptr; float4* d_lj_spos = nullptr; float4* d_lj_sparam = nullptr; unsigned long long* d_lj_smask = nullptr;
     float4* d_lj_tile_c = nullptr; float4* d_lj_tile_h = nullptr; float4* d_lj_cl_c = nullptr; float4* d_lj_cl_h = nullptr;
     unsigned short* d_lj_list = nullptr; int* d_lj_count = nullptr;
+    // Newton's-third-law path: per-tile union lists (jc | imask << 16) and near-diagonal exclusion words
+    bool n3l = true; int sci_split = 16;
+    unsigned int* d_sci_list = nullptr; int* d_sci_count = nullptr; unsigned long long* d_excl = nullptr; int excl_W = 0;
+    long long* d_sforce = nullptr; long long* d_lj_sforce = nullptr;   // [R][3][Npad] / [R][3][NLpad] forces in sorted slot space
+    unsigned int* d_lj_sci_list = nullptr; int* d_lj_sci_count = nullptr; unsigned long long* d_lj_excl = nullptr; int lj_excl_W = 0;
     int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 20; bool sorting = true;
 };
 static handle_table<nb_tables> g_nb;
@@ -747,6 +753,265 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
 }
 
 
+// ---- Newton's-third-law path: super-cluster ("sci") lists -----------------------------------------------------------
+// One list per 64-atom tile (= 8 consecutive i clusters): the ascending union of the j clusters that neighbour any of
+// them, each entry carrying the 8-bit mask of the i clusters it pairs with.  Only cluster pairs with jc >= ic are listed,
+// so every atom pair is evaluated once; the kernel accumulates the reaction on the j atoms in registers across the
+// (up to 8) i clusters of an entry and adds it with one reduction + 8 integer atomics per entry.  Forces go to an
+// accumulator in SORTED slot space, where the 8 atoms of a cluster are one aligned 64-byte line (the L2 atomic units
+// are limited by line requests: scattering to the atoms' own slots costs 3-4 lines per cluster and made this kernel
+// 93 us instead of ~55); scatter_sorted_forces_kernel folds it into the per-atom accumulator afterwards.
+
+// sorted-slot force accumulator -> per-atom accumulator (integer atomics: the PME gather may be adding on the other
+// stream); the slot is cleared for the next evaluation
+__global__ __launch_bounds__(256)
+void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, long long* __restrict__ sforce_a,
+                                  int Npad_b, const int* __restrict__ order_b, long long* __restrict__ sforce_b,
+                                  long long* __restrict__ force, int Npad_force)
+{
+    int k = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    const bool second = k >= Npad_a;                      // main system slots first, then the LJ sub-system's
+    if (second) k -= Npad_a;
+    const int Npad_s = second ? Npad_b : Npad_a;
+    if (k >= Npad_s) return;
+    long long* S = (second ? sforce_b : sforce_a) + (size_t)r * 3 * Npad_s;
+    const int o = (second ? order_b : order_a)[(size_t)r * Npad_s + k];
+    unsigned long long* U = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad_force);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long long v = S[(size_t)c * Npad_s + k];
+        if (v != 0) { S[(size_t)c * Npad_s + k] = 0; if (o >= 0) atomicAdd(&U[(size_t)c * Npad_force + o], (unsigned long long)v); }
+    }
+}
+
+// exclusion bits of the near-diagonal cluster pairs (ic, ic + dj), dj < W: bit (ii*8 + jj) set = pair not evaluated.
+// Folded in: the exclusion windows, the self pairs and the lower triangle of the diagonal cluster pair.
+// Rebuilt with the spatial order (every resort_interval evaluations), not with the lists.
+__global__ __launch_bounds__(64)
+void build_excl_kernel(int Npad, int ncl, int W, int words, const unsigned long long* __restrict__ smask,
+                       unsigned long long* __restrict__ excl)
+{
+    const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const int ii = lane >> 3, jj = lane & 7;
+    const int half = 32 * words;
+    const int i = ic * 8 + ii;
+    for (int dj = 0; dj < W; ++dj) {
+        const int j = (ic + dj) * 8 + jj;
+        const int d = j - i + half;
+        bool ex = (dj == 0 && jj <= ii);
+        if (d >= 0 && d < 2 * half) ex = ex || ((smask[((size_t)r * Npad + i) * words + (d >> 6)] >> (d & 63)) & 1ull);
+        const unsigned long long m = __ballot(ex);
+        if (lane == 0) excl[((size_t)r * ncl + ic) * W + dj] = m;
+    }
+}
+
+__global__ __launch_bounds__(64)
+void build_sci_list_kernel(int ncl, int cap, float rc2, const float4* __restrict__ cl_c, const float4* __restrict__ cl_h,
+                           const float4* __restrict__ tile_c, const float4* __restrict__ tile_h,
+                           const float* __restrict__ box, unsigned int* __restrict__ list, int* __restrict__ count)
+{
+    __shared__ int s_tiles[64];
+    __shared__ float4 s_ci[8], s_hi[8];
+    const int T = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const int ntile = ncl >> 3;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
+    if (lane < 8) { s_ci[lane] = cl_c[(size_t)r * ncl + T * 8 + lane]; s_hi[lane] = cl_h[(size_t)r * ncl + T * 8 + lane]; }
+    const float4 ct = tile_c[(size_t)r * ntile + T], ht = tile_h[(size_t)r * ntile + T];
+    auto near = [&](const float4 ci, const float4 hi, const float4 cj, const float4 hj) {
+        float bx = cj.x - ci.x, by = cj.y - ci.y, bz = cj.z - ci.z;
+        bx -= Lx * rintf(bx * iLx); by -= Ly * rintf(by * iLy); bz -= Lz * rintf(bz * iLz);
+        bx = fmaxf(0.f, fabsf(bx) - hi.x - hj.x); by = fmaxf(0.f, fabsf(by) - hi.y - hj.y); bz = fmaxf(0.f, fabsf(bz) - hi.z - hj.z);
+        return (hi.x >= 0.f) && (bx * bx + by * by + bz * bz <= rc2);
+    };
+    unsigned int* L = list + ((size_t)r * ntile + T) * cap;
+    int n = 0;
+    for (int tbase = T; tbase < ntile; tbase += 64) {
+        const int jt = tbase + lane;
+        const bool thit = (jt < ntile) && near(ct, ht, tile_c[(size_t)r * ntile + jt], tile_h[(size_t)r * ntile + jt]);
+        const unsigned long long tm = __ballot(thit);
+        const int nhit = __popcll(tm);
+        __syncthreads();                                   // (one wavefront: orders the LDS reuse between chunks)
+        if (thit) s_tiles[__popcll(tm & ((1ull << lane) - 1ull))] = jt;
+        __syncthreads();
+        for (int q = 0; q < nhit; q += 8) {                // 8 hit tiles = 64 j clusters per pass, one per lane
+            const int g = q + (lane >> 3);
+            unsigned int imask = 0u;
+            int jc = 0;
+            if (g < nhit) {
+                jc = s_tiles[g] * 8 + (lane & 7);
+                const float4 cj = cl_c[(size_t)r * ncl + jc], hj = cl_h[(size_t)r * ncl + jc];   // empty clusters carry a negative extent
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    if (jc >= T * 8 + s && near(s_ci[s], s_hi[s], cj, hj)) imask |= 1u << s;
+            }
+            const unsigned long long m = __ballot(imask != 0u);
+            if (imask != 0u) {
+                const int slot = n + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < cap) L[slot] = (unsigned int)jc | (imask << 16);
+            }
+            n += __popcll(m);
+        }
+    }
+    if (lane == 0) count[(size_t)r * ntile + T] = n;      // n > cap is detected on the host side (fallback)
+}
+
+// lane = (ii = lane >> 3, jj = lane & 7): the lane holds atom ii of all 8 i clusters of its tile in registers and, per
+// list entry, atom jj of the j cluster.
+#define SCI_NW 4
+// NW wavefronts per workgroup take consecutive slices of one tile's list and merge their i forces through LDS (fixed
+// order), so the i atoms are flushed once per workgroup.
+template <int METHOD, bool ENERGY, bool ALCH, int NW>
+// 4 wavefronts per SIMD (<= 128 VGPRs) for the hot variants; the rarely used ones that would spill keep 3
+#define SCI_RELAXED (METHOD == NB_RF || METHOD == NB_EWALD || (METHOD == NB_LJ_ONLY && ALCH))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SCI_RELAXED ? 2 : 4, SCI_RELAXED ? 3 : 4)))
+void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const float4* __restrict__ spos,
+                          const float4* __restrict__ sparam, const unsigned long long* __restrict__ excl, int W,
+                          const unsigned int* __restrict__ list,
+                          const int* __restrict__ count, const float* __restrict__ box, const float* __restrict__ rep_lam,
+                          long long* __restrict__ force, int Npad_force, double* __restrict__ epart, int n_epart, int ep_off,
+                          int R, int nsplit)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ntile = ncl >> 3;
+    const int item = blockIdx.x;
+    const int T = item % ntile, r = (item / ntile) % R, zsl = (item / (ntile * R)) * NW + wv;
+    const int ii = lane >> 3, jj = lane & 7;
+    const float4* __restrict__ P = spos + (size_t)r * Npad;
+    const float4* __restrict__ prm = sparam + (size_t)r * Npad;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
+    float lam_a = 1.f, sc = 0.f, lam_e = 1.f;
+    if (ALCH) { lam_a = rep_lam[4 * r]; sc = rep_lam[4 * r + 1]; lam_e = rep_lam[4 * r + 2]; }
+    const int c_last = (N - 1) >> 3;                         // the only cluster that can mix real and padding atoms
+
+    const int n_all = min(count[(size_t)r * ntile + T], cap);
+    const int per = (n_all + nsplit - 1) / nsplit;
+    const int l_beg = min(n_all, zsl * per);
+    const int n = max(0, min(per, n_all - l_beg));
+    if (NW == 1 && n <= 0) return;
+    const unsigned int* L = list + ((size_t)r * ntile + T) * cap + l_beg;
+
+    float4 xi[8], pi[8];
+    float fix[8], fiy[8], fiz[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int i = (T * 8 + s) * 8 + ii;
+        xi[s] = P[i]; pi[s] = prm[i];
+        if (ALCH && pi[s].w != 0.f) pi[s].x *= lam_e;
+        fix[s] = fiy[s] = fiz[s] = 0.f;
+    }
+    // exclusion words of this tile's near-diagonal pairs: lane s*8 + dj holds excl[ic_s][dj] (W <= 8), read back with readlane
+    unsigned int ex_lo = 0u, ex_hi = 0u;
+    if (W <= 8 && jj < W) {
+        const unsigned long long m = excl[((size_t)r * ncl + T * 8 + ii) * W + jj];
+        ex_lo = (unsigned int)m; ex_hi = (unsigned int)(m >> 32);
+    }
+    double e = 0.0;
+    // j forces of 8 consecutive entries are parked in the lane group ii = entry & 7 and flushed together: 3 full-width
+    // atomic instructions per 8 entries.  (Loads and atomics share one in-order wait counter, so every atomic issued
+    // inside the entry loop makes the wait for the next prefetched j atoms a full L2 round trip.)
+    float qfx = 0.f, qfy = 0.f, qfz = 0.f;
+    int qj = 0;
+
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = min(64, n - base);                       // list entries in this 64-chunk
+        const unsigned int my_ent = (lane < cnt) ? L[base + lane] : 0u;
+        int jn = (int)(__builtin_amdgcn_readlane(my_ent, 0) & 0xffffu);
+        float4 gx = P[jn * 8 + jj], gp = prm[jn * 8 + jj];
+        for (int k = 0; k < cnt; ++k) {
+            const unsigned int ent = __builtin_amdgcn_readlane(my_ent, k);
+            const int jc = (int)(ent & 0xffffu);
+            const unsigned int imask = ent >> 16;
+            const float4 xj = gx;
+            float4 pj = gp;
+            // prefetch the next entry's j atoms behind this entry's arithmetic (unconditional: the last entry of a chunk
+            // re-reads itself, which keeps the loop free of a branch the register allocator would pin copies to)
+            jn = (int)(__builtin_amdgcn_readlane(my_ent, min(k + 1, cnt - 1)) & 0xffffu);
+            gx = P[jn * 8 + jj]; gp = prm[jn * 8 + jj];
+            if (ALCH && pj.w != 0.f) pj.x *= lam_e;
+            const int j = jc * 8 + jj;
+            float fjx = 0.f, fjy = 0.f, fjz = 0.f;
+            bool touched = false;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (!((imask >> s) & 1u)) continue;              // wave-uniform
+                const int ic = T * 8 + s;
+                float dx = xj.x - xi[s].x, dy = xj.y - xi[s].y, dz = xj.z - xi[s].z;
+                dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                bool in = r2 < p.rc2;
+                const int dj = jc - ic;
+                if (dj < W) {                                    // wave-uniform: exclusions (and the diagonal) live here
+                    unsigned long long m;
+                    if (W <= 8) m = (unsigned long long)__builtin_amdgcn_readlane(ex_lo, s * 8 + dj)
+                                  | ((unsigned long long)__builtin_amdgcn_readlane(ex_hi, s * 8 + dj) << 32);
+                    else m = excl[((size_t)r * ncl + ic) * W + dj];
+                    in = in && !((m >> lane) & 1ull);
+                }
+                if (jc == c_last || ic == c_last) in = in && (j < N) && (ic * 8 + ii < N);
+                if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;   // no atom pair of this cluster pair is inside the cutoff
+                touched = true;
+                float fr, ee;
+                // evaluated for every lane (r2 clamped to the cutoff for far pairs; excluded pairs, even r2 = 0, produce
+                // garbage that the selects below discard), result kept only where `in`
+                pair_interaction<METHOD, ALCH, !ENERGY>(p, fminf(r2, p.rc2), pi[s], pj, lam_a, sc, fr, ENERGY, ee);
+                fr = in ? fr : 0.f;
+                const float tx = fr * dx, ty = fr * dy, tz = fr * dz;
+                fix[s] += tx; fiy[s] += ty; fiz[s] += tz;
+                fjx -= tx; fjy -= ty; fjz -= tz;
+                if (ENERGY) e += in ? (double)ee : 0.0;
+            }
+            if (touched && !(p.dbg & 2)) {
+                // reaction on the j atoms: all-reduce over the 8 ii lanes (every lane ends up with the total of its jj)
+                fjx += __shfl_xor(fjx, 8); fjy += __shfl_xor(fjy, 8); fjz += __shfl_xor(fjz, 8);
+                fjx += __shfl_xor(fjx, 16); fjy += __shfl_xor(fjy, 16); fjz += __shfl_xor(fjz, 16);
+                fjx += __shfl_xor(fjx, 32); fjy += __shfl_xor(fjy, 32); fjz += __shfl_xor(fjz, 32);
+            }
+            const int eb = k & 7;
+            if (ii == eb) { qfx = fjx; qfy = fjy; qfz = fjz; qj = j; }
+            if (eb == 7 || k + 1 == cnt) {
+                // lane group ii holds entry (k & ~7) + ii: 8 lanes = one 64-byte line of the sorted accumulator
+                if (ii <= eb && !(p.dbg & 1)) add_force(force + (size_t)r * 3 * Npad_force, Npad_force, qj, qfx, qfy, qfz);
+            }
+        }
+    }
+    // i forces: reduce-scatter over the 8 jj lanes (7 exchanges per component); afterwards lane (ii, jj) holds the
+    // total of atom ii of cluster s = jj, so all 64 lanes issue one atomic triple
+    auto reduce_scatter = [&](float (&v)[8]) {
+        float a[4], b[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float send = (jj & 4) ? v[q] : v[q + 4], keep = (jj & 4) ? v[q + 4] : v[q];
+            a[q] = keep + __shfl_xor(send, 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float send = (jj & 2) ? a[q] : a[q + 2], keep = (jj & 2) ? a[q + 2] : a[q];
+            b[q] = keep + __shfl_xor(send, 2);
+        }
+        const float send = (jj & 1) ? b[0] : b[1], keep = (jj & 1) ? b[1] : b[0];
+        return keep + __shfl_xor(send, 1);
+    };
+    float fx = reduce_scatter(fix), fy = reduce_scatter(fiy), fz = reduce_scatter(fiz);
+    if (NW > 1) {
+        __shared__ float s_f[NW][3][64];
+        s_f[wv][0][lane] = fx; s_f[wv][1][lane] = fy; s_f[wv][2][lane] = fz;
+        __syncthreads();
+        if (wv == 0) {
+            fx = s_f[0][0][lane]; fy = s_f[0][1][lane]; fz = s_f[0][2][lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { fx += s_f[w][0][lane]; fy += s_f[w][1][lane]; fz += s_f[w][2][lane]; }
+        }
+    }
+    if (wv == 0 && !(p.dbg & 4)) add_force(force + (size_t)r * 3 * Npad_force, Npad_force, (T * 8 + jj) * 8 + ii, fx, fy, fz);
+    if (ENERGY) {
+        e = wave_sum(e);
+        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + ep_off + T * nsplit + zsl] = e;
+    }
+}
+
 // Workgroup = 4 wavefronts = 4 consecutive i tiles of one replica sharing one stream of j atoms: the j
 // positions/parameters are staged through LDS in chunks of NB_CHUNK atoms with coalesced 16-byte loads and
 // read back with wave-uniform (broadcast) ds_read_b128, so the inner loop never waits on global memory.
@@ -1040,6 +1305,8 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
+    dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
+    dfree(t.d_sforce); dfree(t.d_lj_sforce);
     g_nb.erase(h);
 }
 
@@ -1187,6 +1454,7 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     p.crf = (float)(3.0 * eps_s / (2.0 * eps_s + 1.0) / d->cutoff);
     p.alpha = (float)d->ewald_alpha; p.two_alpha_sqrtpi = (float)(2.0 * d->ewald_alpha / sqrt(M_PI));
     p.excl_words = words;
+    p.dbg = getenv("REMD_SCI_DBG") ? atoi(getenv("REMD_SCI_DBG")) : 0;
     const int ntile = (N + 63) / 64;
     {
         const char* env = getenv("REMD_NB_JSPLIT");
@@ -1223,6 +1491,8 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         t.sorting = !(env && atoi(env) == 0);
         const char* env3 = getenv("REMD_NB_CLUSTERS");
         t.clusters = !(env3 && atoi(env3) == 0);
+        if (getenv("REMD_NB_N3L")) t.n3l = atoi(getenv("REMD_NB_N3L")) != 0;
+        if (getenv("REMD_NB_SCISPLIT")) t.sci_split = std::max(1, std::min(16, atoi(getenv("REMD_NB_SCISPLIT"))));
         const char* env2 = getenv("REMD_NB_RESORT");
         if (env2) t.resort_interval = std::max(1, atoi(env2));
     }
@@ -1299,6 +1569,21 @@ static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
 
 // phase 1: (re-sort,) gather and neighbour list of the main system; phase 2: the same for the LJ sub-system; 3: both.
 // Split so that the long Coulomb pair kernel can be launched before the LJ lists and the listed terms are built.
+// cluster pair lists of one (sub-)system: per-tile union lists on the Newton's-third-law path, per-cluster lists otherwise
+static void launch_list_build(remd_ctx* h, nb_tables& t, bool lj)
+{
+    const int ncl = lj ? t.NLpad / 8 : ((h->N + 63) / 64) * 8;
+    const int cap = lj ? t.lj_cap : t.cl_cap;
+    const float4* cc = lj ? t.d_lj_cl_c : t.d_cl_c; const float4* ch = lj ? t.d_lj_cl_h : t.d_cl_h;
+    const float4* tc = lj ? t.d_lj_tile_c : t.d_tile_c; const float4* th = lj ? t.d_lj_tile_h : t.d_tile_h;
+    if (t.n3l && (lj ? t.d_lj_sci_list : t.d_sci_list))
+        hipLaunchKernelGGL(build_sci_list_kernel, dim3(ncl / 8, h->R), dim3(64), 0, h->stream, ncl, cap, t.p.rc2, cc, ch, tc, th, h->d_box,
+                           lj ? t.d_lj_sci_list : t.d_sci_list, lj ? t.d_lj_sci_count : t.d_sci_count);
+    else
+        hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl, h->R), dim3(64), 0, h->stream, ncl, cap, t.p.rc2, cc, ch, tc, th, h->d_box,
+                           lj ? t.d_lj_list : t.d_cl_list, lj ? t.d_lj_count : t.d_cl_count);
+}
+
 static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
 {
     if (!t.sorting || t.n_groups <= 0 || t.n_groups >= 8192) return 0;
@@ -1307,11 +1592,10 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
         const bool cl2 = t.clusters && ntile * 8 < 65536;
         if (cl2 && t.lj_split && t.sort_R == h->R) {
             remd_prof_scope ps(h, "nb_gather");
-            const int ntile_lj = t.NLpad / 64, ncl_lj = t.NLpad / 8;
+            const int ntile_lj = t.NLpad / 64;
             hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
                                h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
-            hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl_lj, h->R), dim3(64), 0, h->stream, ncl_lj, t.lj_cap, t.p.rc2,
-                               t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, h->d_box, t.d_lj_list, t.d_lj_count);
+            launch_list_build(h, t, true);
         }
         return 0;
     }
@@ -1331,6 +1615,16 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
         REMD_CHECK(h, hipMalloc(&t.d_cl_h, sizeof(float4) * (size_t)h->R * ncl));
         REMD_CHECK(h, hipMalloc(&t.d_cl_list, sizeof(unsigned short) * (size_t)h->R * ncl * t.cl_cap));
         REMD_CHECK(h, hipMalloc(&t.d_cl_count, sizeof(int) * (size_t)h->R * ncl));
+        dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_sforce); dfree(t.d_lj_sforce);
+        dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
+        if (t.n3l) {
+            t.excl_W = 4 * t.p.excl_words + 1;
+            REMD_CHECK(h, hipMalloc(&t.d_sci_list, sizeof(unsigned int) * (size_t)h->R * ntile * t.cl_cap));
+            REMD_CHECK(h, hipMalloc(&t.d_sci_count, sizeof(int) * (size_t)h->R * ntile));
+            REMD_CHECK(h, hipMalloc(&t.d_excl, sizeof(unsigned long long) * (size_t)h->R * ncl * t.excl_W));
+            REMD_CHECK(h, hipMalloc(&t.d_sforce, sizeof(long long) * n * 3));
+            REMD_CHECK(h, hipMemsetAsync(t.d_sforce, 0, sizeof(long long) * n * 3, h->stream));
+        }
         if (t.lj_split) {
             dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask); dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h);
             dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
@@ -1347,6 +1641,14 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
             REMD_CHECK(h, hipMalloc(&t.d_lj_cl_h, sizeof(float4) * (size_t)h->R * ncl_lj));
             REMD_CHECK(h, hipMalloc(&t.d_lj_list, sizeof(unsigned short) * (size_t)h->R * ncl_lj * t.lj_cap));
             REMD_CHECK(h, hipMalloc(&t.d_lj_count, sizeof(int) * (size_t)h->R * ncl_lj));
+            if (t.n3l) {
+                t.lj_excl_W = 4 * t.lj_words + 1;
+                REMD_CHECK(h, hipMalloc(&t.d_lj_sci_list, sizeof(unsigned int) * (size_t)h->R * (ncl_lj / 8) * t.lj_cap));
+                REMD_CHECK(h, hipMalloc(&t.d_lj_sci_count, sizeof(int) * (size_t)h->R * (ncl_lj / 8)));
+                REMD_CHECK(h, hipMalloc(&t.d_lj_excl, sizeof(unsigned long long) * (size_t)h->R * ncl_lj * t.lj_excl_W));
+                REMD_CHECK(h, hipMalloc(&t.d_lj_sforce, sizeof(long long) * nl * 3));
+                REMD_CHECK(h, hipMemsetAsync(t.d_lj_sforce, 0, sizeof(long long) * nl * 3, h->stream));
+            }
         }
         t.sort_R = h->R; t.evals_since_sort = 1 << 30;
     }
@@ -1360,6 +1662,13 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
         if (t.lj_split)
             hipLaunchKernelGGL(compact_lj_kernel, dim3(h->R), dim3(1024), 0, h->stream, h->N, h->Npad, t.NL, t.NLpad, t.lj_words, t.d_order,
                                t.d_lj_ord, t.d_param, t.d_lj_mask, t.d_lj_order, t.d_lj_sparam, t.d_lj_smask);
+        if (t.n3l && t.d_excl) {
+            hipLaunchKernelGGL(build_excl_kernel, dim3(ntile * 8, h->R), dim3(64), 0, h->stream, h->Npad, ntile * 8, t.excl_W, t.p.excl_words,
+                               t.d_smask, t.d_excl);
+            if (t.lj_split && t.d_lj_excl)
+                hipLaunchKernelGGL(build_excl_kernel, dim3(t.NLpad / 8, h->R), dim3(64), 0, h->stream, t.NLpad, t.NLpad / 8, t.lj_excl_W,
+                                   t.lj_words, t.d_lj_smask, t.d_lj_excl);
+        }
         t.evals_since_sort = 0;
     }
     t.evals_since_sort++;
@@ -1370,19 +1679,18 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
                            t.d_spos, t.d_tile_c, t.d_tile_h, cl ? t.d_cl_c : (float4*)nullptr, cl ? t.d_cl_h : (float4*)nullptr);
         if (cl) {
             const int ncl = ntile * 8;
-            hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl, h->R), dim3(64), 0, h->stream, ncl, t.cl_cap, t.p.rc2, t.d_cl_c,
-                               t.d_cl_h, t.d_tile_c, t.d_tile_h, h->d_box, t.d_cl_list, t.d_cl_count);
+            launch_list_build(h, t, false);
             if (t.lj_split && (phase & 2)) {
-                const int ntile_lj = t.NLpad / 64, ncl_lj = t.NLpad / 8;
+                const int ntile_lj = t.NLpad / 64;
                 hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
                                    h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
-                hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl_lj, h->R), dim3(64), 0, h->stream, ncl_lj, t.lj_cap, t.p.rc2,
-                                   t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, h->d_box, t.d_lj_list, t.d_lj_count);
+                launch_list_build(h, t, true);
             }
             if (t.evals_since_sort == 1 && (t.cl_cap < ncl || getenv("REMD_DEBUG"))) {
                 // capacity check once per re-sort (the only host synchronisation of this path)
-                std::vector<int> cnt((size_t)h->R * ncl);
-                REMD_CHECK(h, hipMemcpyAsync(cnt.data(), t.d_cl_count, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, h->stream));
+                const bool sci = t.n3l && t.d_sci_list;
+                std::vector<int> cnt((size_t)h->R * (sci ? ntile : ncl));
+                REMD_CHECK(h, hipMemcpyAsync(cnt.data(), sci ? t.d_sci_count : t.d_cl_count, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, h->stream));
                 REMD_CHECK(h, hipStreamSynchronize(h->stream));
                 int mx = 0; for (int c : cnt) mx = std::max(mx, c);
                 if (getenv("REMD_DEBUG")) {
@@ -1391,6 +1699,13 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
                     hipMemcpy(hh.data(), t.d_cl_h, sizeof(float4) * hh.size(), hipMemcpyDeviceToHost);
                     double hx = 0; int nh = 0; for (auto& v : hh) if (v.x >= 0) { hx += v.x + v.y + v.z; nh++; }
                     fprintf(stderr, "[remd] cluster list: ncl %d mean neighbours %.1f max %d cap %d mean half-extent %.3f nm\n", ncl, mean, mx, t.cl_cap, hx / (3.0 * nh));
+                }
+                if (getenv("REMD_DEBUG") && sci) {
+                    std::vector<unsigned int> ll((size_t)ntile * t.cl_cap);
+                    hipMemcpy(ll.data(), t.d_sci_list, sizeof(unsigned int) * ll.size(), hipMemcpyDeviceToHost);
+                    double ne = 0, nb = 0;
+                    for (int T = 0; T < ntile; ++T) for (int k = 0; k < std::min(cnt[T], t.cl_cap); ++k) { ne += 1; nb += __builtin_popcount(ll[(size_t)T * t.cl_cap + k] >> 16); }
+                    fprintf(stderr, "[remd] sci list (replica 0): %d tiles, %.1f entries per tile, %.2f i clusters per entry\n", ntile, ne / ntile, nb / std::max(1.0, ne));
                 }
                 if (mx > t.cl_cap) t.clusters = false;        // fall back to the tile kernel
             }
@@ -1419,12 +1734,41 @@ static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
 #define LAUNCH_CL(M, ALCHF) hipLaunchKernelGGL((nonbonded_cluster_kernel<M, ENERGY, ALCHF>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl, \
             t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box, rl, h->d_force, h->Npad, h->d_epart, h->n_epart, 0, \
             h->R, main_split)
-        if (phase & 1) {
+        const bool sci = t.n3l && t.d_sci_list && t.d_excl && t.d_sforce && (!split || (t.d_lj_sci_list && t.d_lj_excl && t.d_lj_sforce));
+        const int ssplit = std::max(SCI_NW, std::min(16, t.sci_split / SCI_NW * SCI_NW));
+#define LAUNCH_SCI(M, ALCHF) hipLaunchKernelGGL((nonbonded_sci_kernel<M, ENERGY, ALCHF, SCI_NW>), dim3(ntile * h->R * (ssplit / SCI_NW)), dim3(64 * SCI_NW), 0, h->stream, t.p, \
+            h->N, h->Npad, ncl, t.cl_cap, t.d_spos, t.d_sparam, t.d_excl, t.excl_W, t.d_sci_list, t.d_sci_count, h->d_box, rl, \
+            t.d_sforce, h->Npad, h->d_epart, h->n_epart, 0, h->R, ssplit)
+        if ((phase & 1) && sci) {
+            if (split) { if (t.has_alch) LAUNCH_SCI(MAIN, true); else LAUNCH_SCI(MAIN, false); }
+            else { if (t.has_alch) LAUNCH_SCI(METHOD, true); else LAUNCH_SCI(METHOD, false); }
+            if (!(split && (phase & 2)))                  // otherwise folded together with the LJ sub-system's below
+                hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.d_order,
+                                   t.d_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
+        } else if (phase & 1) {
             if (split) { if (t.has_alch) LAUNCH_CL(MAIN, true); else LAUNCH_CL(MAIN, false); }
             else { if (t.has_alch) LAUNCH_CL(METHOD, true); else LAUNCH_CL(METHOD, false); }
         }
 #undef LAUNCH_CL
-        if (split && (phase & 2)) {
+#undef LAUNCH_SCI
+        if (split && (phase & 2) && sci) {
+            const int ncl_lj = t.NLpad / 8, ntile_lj = t.NLpad / 64;
+            const int ls = ssplit;
+            if (t.has_alch)
+                hipLaunchKernelGGL((nonbonded_sci_kernel<NB_LJ_ONLY, ENERGY, true, SCI_NW>), dim3(ntile_lj * h->R * (ls / SCI_NW)), dim3(64 * SCI_NW), 0, h->stream, t.p, t.NL,
+                                   t.NLpad, ncl_lj, t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl, t.lj_excl_W, t.d_lj_sci_list,
+                                   t.d_lj_sci_count, h->d_box, rl, t.d_lj_sforce, t.NLpad, h->d_epart, h->n_epart, ncl * 4, h->R, ls);
+            else
+                hipLaunchKernelGGL((nonbonded_sci_kernel<NB_LJ_ONLY, ENERGY, false, SCI_NW>), dim3(ntile_lj * h->R * (ls / SCI_NW)), dim3(64 * SCI_NW), 0, h->stream, t.p, t.NL,
+                                   t.NLpad, ncl_lj, t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl, t.lj_excl_W, t.d_lj_sci_list,
+                                   t.d_lj_sci_count, h->d_box, rl, t.d_lj_sforce, t.NLpad, h->d_epart, h->n_epart, ncl * 4, h->R, ls);
+            if (phase & 1)
+                hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
+                                   t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
+            else
+                hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, t.NLpad, t.d_lj_order,
+                                   t.d_lj_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
+        } else if (split && (phase & 2)) {
             nb_params pl = t.p; pl.excl_words = t.lj_words;
             const int ncl_lj = t.NLpad / 8;
             const int n_items2 = ncl_lj * h->R * 4;
