@@ -886,12 +886,12 @@ void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const 
     if (ALCH) { lam_a = rep_lam[4 * r]; sc = rep_lam[4 * r + 1]; lam_e = rep_lam[4 * r + 2]; }
     const int c_last = (N - 1) >> 3;                         // the only cluster that can mix real and padding atoms
 
+    // slice zsl takes the entries zsl, zsl + nsplit, ...: the near-diagonal entries (most i clusters per entry) come first
+    // in a list, so contiguous slices would be unevenly loaded
     const int n_all = min(count[(size_t)r * ntile + T], cap);
-    const int per = (n_all + nsplit - 1) / nsplit;
-    const int l_beg = min(n_all, zsl * per);
-    const int n = max(0, min(per, n_all - l_beg));
+    const int n = (n_all - zsl + nsplit - 1) / nsplit;
     if (NW == 1 && n <= 0) return;
-    const unsigned int* L = list + ((size_t)r * ntile + T) * cap + l_beg;
+    const unsigned int* L = list + ((size_t)r * ntile + T) * cap + zsl;
 
     float4 xi[8], pi[8];
     float fix[8], fiy[8], fiz[8];
@@ -917,7 +917,7 @@ void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const 
 
     for (int base = 0; base < n; base += 64) {
         const int cnt = min(64, n - base);                       // list entries in this 64-chunk
-        const unsigned int my_ent = (lane < cnt) ? L[base + lane] : 0u;
+        const unsigned int my_ent = (lane < cnt) ? L[(size_t)(base + lane) * nsplit] : 0u;
         int jn = (int)(__builtin_amdgcn_readlane(my_ent, 0) & 0xffffu);
         float4 gx = P[jn * 8 + jj], gp = prm[jn * 8 + jj];
         for (int k = 0; k < cnt; ++k) {
