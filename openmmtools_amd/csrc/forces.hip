@@ -942,6 +942,7 @@ void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const 
                 dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
                 const float r2 = dx * dx + dy * dy + dz * dz;
                 bool in = r2 < p.rc2;
+                const float r2c = in ? r2 : p.rc2;               // clamp for the lanes beyond the cutoff (one select; fminf costs three ops)
                 const int dj = jc - ic;
                 if (dj < W) {                                    // wave-uniform: exclusions (and the diagonal) live here
                     unsigned long long m;
@@ -956,7 +957,7 @@ void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const 
                 float fr, ee;
                 // evaluated for every lane (r2 clamped to the cutoff for far pairs; excluded pairs, even r2 = 0, produce
                 // garbage that the selects below discard), result kept only where `in`
-                pair_interaction<METHOD, ALCH, !ENERGY>(p, fminf(r2, p.rc2), pi[s], pj, lam_a, sc, fr, ENERGY, ee);
+                pair_interaction<METHOD, ALCH, !ENERGY>(p, r2c, pi[s], pj, lam_a, sc, fr, ENERGY, ee);
                 fr = in ? fr : 0.f;
                 const float tx = fr * dx, ty = fr * dy, tz = fr * dz;
                 fix[s] += tx; fiy[s] += ty; fiz[s] += tz;

@@ -235,3 +235,21 @@ def test_alanine_propagation_is_bit_reproducible(hip_engine_factory):
         out.append((x, v, eng.compute_energies()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize('system_cls', [ts.AlanineDipeptideExplicit, ts.HostGuestExplicit])
+def test_newton3_lists_match_full_lists(hip_engine_factory, monkeypatch, system_cls):
+    """The direct-space sum runs on per-tile union lists with every cluster pair listed once (Newton's third law, sci
+    kernel); REMD_NB_N3L=0 selects the older per-cluster full lists.  Same pairs, same per-pair arithmetic: forces
+    agree to the order of summation (fixed-point accumulation, fp32 partial sums), energies to their f64 sums."""
+    tsys = system_cls()
+    res = []
+    for n3l in ('1', '0'):
+        monkeypatch.setenv('REMD_NB_N3L', n3l)
+        eng = hip_engine_factory()
+        _engine_for(eng, tsys.system, tsys.positions, R=2, jitter=0.002)
+        U = eng.compute_energies(want_potential=True)[1]
+        res.append((eng.get_forces(), U))
+    (f1, u1), (f0, u0) = res
+    assert np.abs(f1 - f0).max() < 2e-5 * np.abs(f0).max()
+    assert np.allclose(u1, u0, rtol=1e-9, atol=1e-6)
