@@ -49,7 +49,6 @@ struct nb_params {
     float alpha, two_alpha_sqrtpi;    // Ewald
     int excl_words;                   // 64-bit words of the exclusion window per atom
     int n_jsplit;
-    int dbg;                          // REMD_SCI_DBG timing experiments (results are wrong when set)
 };
 
 struct nb_tables {
@@ -538,12 +537,12 @@ void compact_lj_kernel(int N, int Npad, int NL, int NLpad, int words, const int*
 }
 
 // positions into sorted order + bounding box of every 64-atom tile (relative to the tile's first atom, minimum image)
-__global__ __launch_bounds__(64)
-void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ order, const float4* __restrict__ pos,
-                             const float* __restrict__ box, float4* __restrict__ spos, float4* __restrict__ tile_c,
-                             float4* __restrict__ tile_h, float4* __restrict__ cl_c, float4* __restrict__ cl_h)
+__device__ __forceinline__
+void gather_positions_body(int tile, int nt, int r, int lane, int Npad, int Npad_pos, const int* __restrict__ order,
+                           const float4* __restrict__ pos, const float* __restrict__ box, float4* __restrict__ spos,
+                           float4* __restrict__ tile_c, float4* __restrict__ tile_h, float4* __restrict__ cl_c,
+                           float4* __restrict__ cl_h)
 {
-    const int tile = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
     const int k = tile * 64 + lane;
     const int o = order[(size_t)r * Npad + k];
     const float4 x = (o >= 0) ? pos[(size_t)r * Npad_pos + o] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -560,7 +559,6 @@ void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ ord
         loz = fminf(loz, __shfl_xor(loz, off)); hiz = fmaxf(hiz, __shfl_xor(hiz, off));
     }
     if (lane == 0) {
-        const int nt = gridDim.x;
         tile_c[(size_t)r * nt + tile] = make_float4(x0 + 0.5f * (lox + hix), y0 + 0.5f * (loy + hiy), z0 + 0.5f * (loz + hiz), 0.f);
         tile_h[(size_t)r * nt + tile] = make_float4(0.5f * (hix - lox), 0.5f * (hiy - loy), 0.5f * (hiz - loz), 0.f);
     }
@@ -579,7 +577,7 @@ void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ ord
             az = fminf(az, __shfl_xor(az, off)); bz2 = fmaxf(bz2, __shfl_xor(bz2, off));
         }
         if ((lane & 7) == 0) {
-            const int ncl = gridDim.x * 8;
+            const int ncl = nt * 8;
             const int c = tile * 8 + (lane >> 3);
             // an empty (all-padding) cluster is parked far away with a negative extent so that it never pairs
             cl_c[(size_t)r * ncl + c] = (o0 >= 0) ? make_float4(cx0 + 0.5f * (ax + bx2), cy0 + 0.5f * (ay + by2), cz0 + 0.5f * (az + bz2), 0.f)
@@ -588,6 +586,26 @@ void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ ord
                                                   : make_float4(-1e9f, -1e9f, -1e9f, 0.f);
         }
     }
+}
+
+__global__ __launch_bounds__(64)
+void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ order, const float4* __restrict__ pos,
+                             const float* __restrict__ box, float4* __restrict__ spos, float4* __restrict__ tile_c,
+                             float4* __restrict__ tile_h, float4* __restrict__ cl_c, float4* __restrict__ cl_h)
+{
+    gather_positions_body(blockIdx.x, gridDim.x, blockIdx.y, threadIdx.x, Npad, Npad_pos, order, pos, box, spos, tile_c, tile_h, cl_c, cl_h);
+}
+
+// main system (first nt_a tiles of the grid) and LJ sub-system in one launch: one dependent launch less per evaluation
+struct gather_args { int Npad; const int* order; float4* spos; float4* tile_c; float4* tile_h; float4* cl_c; float4* cl_h; };
+__global__ __launch_bounds__(64)
+void gather_positions2_kernel(int nt_a, gather_args a, gather_args b, int Npad_pos, const float4* __restrict__ pos,
+                              const float* __restrict__ box)
+{
+    const bool second = (int)blockIdx.x >= nt_a;
+    const gather_args& g = second ? b : a;
+    gather_positions_body(second ? blockIdx.x - nt_a : blockIdx.x, second ? gridDim.x - nt_a : nt_a, blockIdx.y, threadIdx.x, g.Npad, Npad_pos,
+                          g.order, pos, box, g.spos, g.tile_c, g.tile_h, g.cl_c, g.cl_h);
 }
 
 // neighbour list of 8-atom clusters: one wavefront per i cluster tests every j cluster (bounding boxes, minimum
@@ -806,14 +824,13 @@ void build_excl_kernel(int Npad, int ncl, int W, int words, const unsigned long 
     }
 }
 
-__global__ __launch_bounds__(64)
-void build_sci_list_kernel(int ncl, int cap, float rc2, const float4* __restrict__ cl_c, const float4* __restrict__ cl_h,
-                           const float4* __restrict__ tile_c, const float4* __restrict__ tile_h,
-                           const float* __restrict__ box, unsigned int* __restrict__ list, int* __restrict__ count)
+__device__ __forceinline__
+void build_sci_list_body(int T, int r, int lane, int ncl, int cap, float rc2, const float4* __restrict__ cl_c,
+                         const float4* __restrict__ cl_h, const float4* __restrict__ tile_c, const float4* __restrict__ tile_h,
+                         const float* __restrict__ box, unsigned int* __restrict__ list, int* __restrict__ count)
 {
     __shared__ int s_tiles[64];
     __shared__ float4 s_ci[8], s_hi[8];
-    const int T = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
     const int ntile = ncl >> 3;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
@@ -857,25 +874,45 @@ void build_sci_list_kernel(int ncl, int cap, float rc2, const float4* __restrict
     if (lane == 0) count[(size_t)r * ntile + T] = n;      // n > cap is detected on the host side (fallback)
 }
 
+__global__ __launch_bounds__(64)
+void build_sci_list_kernel(int ncl, int cap, float rc2, const float4* __restrict__ cl_c, const float4* __restrict__ cl_h,
+                           const float4* __restrict__ tile_c, const float4* __restrict__ tile_h,
+                           const float* __restrict__ box, unsigned int* __restrict__ list, int* __restrict__ count)
+{
+    build_sci_list_body(blockIdx.x, blockIdx.y, threadIdx.x, ncl, cap, rc2, cl_c, cl_h, tile_c, tile_h, box, list, count);
+}
+
+struct sci_list_args { int ncl, cap; const float4* cl_c; const float4* cl_h; const float4* tile_c; const float4* tile_h; unsigned int* list; int* count; };
+__global__ __launch_bounds__(64)
+void build_sci_list2_kernel(int nt_a, sci_list_args a, sci_list_args b, float rc2, const float* __restrict__ box)
+{
+    const bool second = (int)blockIdx.x >= nt_a;
+    const sci_list_args& g = second ? b : a;
+    build_sci_list_body(second ? blockIdx.x - nt_a : blockIdx.x, blockIdx.y, threadIdx.x, g.ncl, g.cap, rc2, g.cl_c, g.cl_h, g.tile_c, g.tile_h,
+                        box, g.list, g.count);
+}
+
 // lane = (ii = lane >> 3, jj = lane & 7): the lane holds atom ii of all 8 i clusters of its tile in registers and, per
 // list entry, atom jj of the j cluster.
 #define SCI_NW 4
 // NW wavefronts per workgroup take consecutive slices of one tile's list and merge their i forces through LDS (fixed
 // order), so the i atoms are flushed once per workgroup.
+struct sci_args {
+    int N, Npad, ncl, cap, W, Npad_force, ep_off, nsplit;
+    const float4* spos; const float4* sparam; const unsigned long long* excl; const unsigned int* list; const int* count;
+    long long* force;
+};
 template <int METHOD, bool ENERGY, bool ALCH, int NW>
-// 4 wavefronts per SIMD (<= 128 VGPRs) for the hot variants; the rarely used ones that would spill keep 3
-#define SCI_RELAXED (METHOD == NB_RF || METHOD == NB_EWALD || (METHOD == NB_LJ_ONLY && ALCH))
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SCI_RELAXED ? 2 : 4, SCI_RELAXED ? 3 : 4)))
-void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const float4* __restrict__ spos,
-                          const float4* __restrict__ sparam, const unsigned long long* __restrict__ excl, int W,
-                          const unsigned int* __restrict__ list,
-                          const int* __restrict__ count, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                          long long* __restrict__ force, int Npad_force, double* __restrict__ epart, int n_epart, int ep_off,
-                          int R, int nsplit)
+__device__ __forceinline__
+void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const float* __restrict__ box,
+                        const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R)
 {
+    const int N = a.N, Npad = a.Npad, ncl = a.ncl, cap = a.cap, W = a.W, Npad_force = a.Npad_force, ep_off = a.ep_off, nsplit = a.nsplit;
+    const float4* __restrict__ spos = a.spos; const float4* __restrict__ sparam = a.sparam;
+    const unsigned long long* __restrict__ excl = a.excl; const unsigned int* __restrict__ list = a.list;
+    const int* __restrict__ count = a.count; long long* __restrict__ force = a.force;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntile = ncl >> 3;
-    const int item = blockIdx.x;
     const int T = item % ntile, r = (item / ntile) % R, zsl = (item / (ntile * R)) * NW + wv;
     const int ii = lane >> 3, jj = lane & 7;
     const float4* __restrict__ P = spos + (size_t)r * Npad;
@@ -964,7 +1001,7 @@ void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const 
                 fjx -= tx; fjy -= ty; fjz -= tz;
                 if (ENERGY) e += in ? (double)ee : 0.0;
             }
-            if (touched && !(p.dbg & 2)) {
+            if (touched) {
                 // reaction on the j atoms: all-reduce over the 8 ii lanes (every lane ends up with the total of its jj)
                 fjx += __shfl_xor(fjx, 8); fjy += __shfl_xor(fjy, 8); fjz += __shfl_xor(fjz, 8);
                 fjx += __shfl_xor(fjx, 16); fjy += __shfl_xor(fjy, 16); fjz += __shfl_xor(fjz, 16);
@@ -974,7 +1011,7 @@ void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const 
             if (ii == eb) { qfx = fjx; qfy = fjy; qfz = fjz; qj = j; }
             if (eb == 7 || k + 1 == cnt) {
                 // lane group ii holds entry (k & ~7) + ii: 8 lanes = one 64-byte line of the sorted accumulator
-                if (ii <= eb && !(p.dbg & 1)) add_force(force + (size_t)r * 3 * Npad_force, Npad_force, qj, qfx, qfy, qfz);
+                if (ii <= eb) add_force(force + (size_t)r * 3 * Npad_force, Npad_force, qj, qfx, qfy, qfz);
             }
         }
     }
@@ -1006,11 +1043,32 @@ void nonbonded_sci_kernel(nb_params p, int N, int Npad, int ncl, int cap, const 
             for (int w = 1; w < NW; ++w) { fx += s_f[w][0][lane]; fy += s_f[w][1][lane]; fz += s_f[w][2][lane]; }
         }
     }
-    if (wv == 0 && !(p.dbg & 4)) add_force(force + (size_t)r * 3 * Npad_force, Npad_force, (T * 8 + jj) * 8 + ii, fx, fy, fz);
+    if (wv == 0) add_force(force + (size_t)r * 3 * Npad_force, Npad_force, (T * 8 + jj) * 8 + ii, fx, fy, fz);
     if (ENERGY) {
         e = wave_sum(e);
         if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + ep_off + T * nsplit + zsl] = e;
     }
+}
+
+// 4 wavefronts per SIMD (<= 128 VGPRs) for the hot variants; the rarely used ones that would spill keep 3
+#define SCI_RELAXED(M) (M == NB_RF || M == NB_EWALD || (M == NB_LJ_ONLY && ALCH))
+template <int METHOD, bool ENERGY, bool ALCH, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SCI_RELAXED(METHOD) ? 2 : 4, SCI_RELAXED(METHOD) ? 3 : 4)))
+void nonbonded_sci_kernel(nb_params p, sci_args a, const float* __restrict__ box, const float* __restrict__ rep_lam,
+                          double* __restrict__ epart, int n_epart, int R)
+{
+    nonbonded_sci_body<METHOD, ENERGY, ALCH, NW>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R);
+}
+
+// main (Coulomb-only) system and LJ sub-system in one launch: the short LJ work items fill the tail of the main ones
+template <int METHOD_A, int METHOD_B, bool ENERGY, bool ALCH, int NW>
+__global__ __launch_bounds__(64 * NW)
+__attribute__((amdgpu_waves_per_eu((SCI_RELAXED(METHOD_A) || SCI_RELAXED(METHOD_B)) ? 2 : 4, (SCI_RELAXED(METHOD_A) || SCI_RELAXED(METHOD_B)) ? 3 : 4)))
+void nonbonded_sci2_kernel(nb_params p, sci_args a, sci_args b, int n_items_a, const float* __restrict__ box,
+                           const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R)
+{
+    if ((int)blockIdx.x < n_items_a) nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R);
+    else nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW>(p, b, blockIdx.x - n_items_a, box, rep_lam, epart, n_epart, R);
 }
 
 // Workgroup = 4 wavefronts = 4 consecutive i tiles of one replica sharing one stream of j atoms: the j
@@ -1455,7 +1513,6 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     p.crf = (float)(3.0 * eps_s / (2.0 * eps_s + 1.0) / d->cutoff);
     p.alpha = (float)d->ewald_alpha; p.two_alpha_sqrtpi = (float)(2.0 * d->ewald_alpha / sqrt(M_PI));
     p.excl_words = words;
-    p.dbg = getenv("REMD_SCI_DBG") ? atoi(getenv("REMD_SCI_DBG")) : 0;
     const int ntile = (N + 63) / 64;
     {
         const char* env = getenv("REMD_NB_JSPLIT");
@@ -1676,12 +1733,23 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
     {
         remd_prof_scope ps(h, "nb_gather");
         const bool cl = t.clusters && ntile * 8 < 65536;
+        const bool fused = cl && t.lj_split && (phase & 2) && t.n3l && t.d_sci_list && t.d_lj_sci_list;
+        if (fused) {
+            // main system + LJ sub-system in one gather launch and one list launch
+            const int ntile_lj = t.NLpad / 64;
+            gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h};
+            gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h};
+            hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
+            sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
+            sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};
+            hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb, t.p.rc2, h->d_box);
+        } else
         hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, h->Npad, t.d_order, h->d_pos, h->d_box,
                            t.d_spos, t.d_tile_c, t.d_tile_h, cl ? t.d_cl_c : (float4*)nullptr, cl ? t.d_cl_h : (float4*)nullptr);
         if (cl) {
             const int ncl = ntile * 8;
-            launch_list_build(h, t, false);
-            if (t.lj_split && (phase & 2)) {
+            if (!fused) launch_list_build(h, t, false);
+            if (!fused && t.lj_split && (phase & 2)) {
                 const int ntile_lj = t.NLpad / 64;
                 hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
                                    h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
@@ -1737,38 +1805,43 @@ static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
             h->R, main_split)
         const bool sci = t.n3l && t.d_sci_list && t.d_excl && t.d_sforce && (!split || (t.d_lj_sci_list && t.d_lj_excl && t.d_lj_sforce));
         const int ssplit = std::max(SCI_NW, std::min(16, t.sci_split / SCI_NW * SCI_NW));
-#define LAUNCH_SCI(M, ALCHF) hipLaunchKernelGGL((nonbonded_sci_kernel<M, ENERGY, ALCHF, SCI_NW>), dim3(ntile * h->R * (ssplit / SCI_NW)), dim3(64 * SCI_NW), 0, h->stream, t.p, \
-            h->N, h->Npad, ncl, t.cl_cap, t.d_spos, t.d_sparam, t.d_excl, t.excl_W, t.d_sci_list, t.d_sci_count, h->d_box, rl, \
-            t.d_sforce, h->Npad, h->d_epart, h->n_epart, 0, h->R, ssplit)
+        sci_args sa{h->N, h->Npad, ncl, t.cl_cap, t.excl_W, h->Npad, 0, ssplit, t.d_spos, t.d_sparam, t.d_excl, t.d_sci_list, t.d_sci_count, t.d_sforce};
+        sci_args sb{};
+        if (split) sb = sci_args{t.NL, t.NLpad, t.NLpad / 8, t.lj_cap, t.lj_excl_W, t.NLpad, ncl * 4, ssplit, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl,
+                                 t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce};
+        const int items_a = ntile * h->R * (ssplit / SCI_NW), items_b = split ? (t.NLpad / 64) * h->R * (ssplit / SCI_NW) : 0;
+#define LAUNCH_SCI(M, ALCHF) hipLaunchKernelGGL((nonbonded_sci_kernel<M, ENERGY, ALCHF, SCI_NW>), dim3(items_a), dim3(64 * SCI_NW), 0, h->stream, t.p, sa, \
+            h->d_box, rl, h->d_epart, h->n_epart, h->R)
+#define LAUNCH_SCI2(ALCHF) hipLaunchKernelGGL((nonbonded_sci2_kernel<MAIN, NB_LJ_ONLY, ENERGY, ALCHF, SCI_NW>), dim3(items_a + items_b), dim3(64 * SCI_NW), 0, \
+            h->stream, t.p, sa, sb, items_a, h->d_box, rl, h->d_epart, h->n_epart, h->R)
+        if (sci && split && phase == 3) {
+            // one launch for both systems, one scatter for both sorted accumulators
+            if (t.has_alch) LAUNCH_SCI2(true); else LAUNCH_SCI2(false);
+            hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
+                               t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
+            return;
+        }
         if ((phase & 1) && sci) {
             if (split) { if (t.has_alch) LAUNCH_SCI(MAIN, true); else LAUNCH_SCI(MAIN, false); }
             else { if (t.has_alch) LAUNCH_SCI(METHOD, true); else LAUNCH_SCI(METHOD, false); }
-            if (!(split && (phase & 2)))                  // otherwise folded together with the LJ sub-system's below
-                hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.d_order,
-                                   t.d_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
+            hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.d_order,
+                               t.d_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
         } else if (phase & 1) {
             if (split) { if (t.has_alch) LAUNCH_CL(MAIN, true); else LAUNCH_CL(MAIN, false); }
             else { if (t.has_alch) LAUNCH_CL(METHOD, true); else LAUNCH_CL(METHOD, false); }
         }
 #undef LAUNCH_CL
 #undef LAUNCH_SCI
+#undef LAUNCH_SCI2
         if (split && (phase & 2) && sci) {
-            const int ncl_lj = t.NLpad / 8, ntile_lj = t.NLpad / 64;
-            const int ls = ssplit;
             if (t.has_alch)
-                hipLaunchKernelGGL((nonbonded_sci_kernel<NB_LJ_ONLY, ENERGY, true, SCI_NW>), dim3(ntile_lj * h->R * (ls / SCI_NW)), dim3(64 * SCI_NW), 0, h->stream, t.p, t.NL,
-                                   t.NLpad, ncl_lj, t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl, t.lj_excl_W, t.d_lj_sci_list,
-                                   t.d_lj_sci_count, h->d_box, rl, t.d_lj_sforce, t.NLpad, h->d_epart, h->n_epart, ncl * 4, h->R, ls);
+                hipLaunchKernelGGL((nonbonded_sci_kernel<NB_LJ_ONLY, ENERGY, true, SCI_NW>), dim3(items_b), dim3(64 * SCI_NW), 0, h->stream, t.p, sb,
+                                   h->d_box, rl, h->d_epart, h->n_epart, h->R);
             else
-                hipLaunchKernelGGL((nonbonded_sci_kernel<NB_LJ_ONLY, ENERGY, false, SCI_NW>), dim3(ntile_lj * h->R * (ls / SCI_NW)), dim3(64 * SCI_NW), 0, h->stream, t.p, t.NL,
-                                   t.NLpad, ncl_lj, t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl, t.lj_excl_W, t.d_lj_sci_list,
-                                   t.d_lj_sci_count, h->d_box, rl, t.d_lj_sforce, t.NLpad, h->d_epart, h->n_epart, ncl * 4, h->R, ls);
-            if (phase & 1)
-                hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
-                                   t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
-            else
-                hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, t.NLpad, t.d_lj_order,
-                                   t.d_lj_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
+                hipLaunchKernelGGL((nonbonded_sci_kernel<NB_LJ_ONLY, ENERGY, false, SCI_NW>), dim3(items_b), dim3(64 * SCI_NW), 0, h->stream, t.p, sb,
+                                   h->d_box, rl, h->d_epart, h->n_epart, h->R);
+            hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, t.NLpad, t.d_lj_order,
+                               t.d_lj_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
         } else if (split && (phase & 2)) {
             nb_params pl = t.p; pl.excl_words = t.lj_words;
             const int ncl_lj = t.NLpad / 8;
