@@ -1,0 +1,315 @@
+"""Free-energy analysis of a stored multistate simulation: what ``MultiStateSampler._offline_analysis`` needs.
+
+The reference runs ``MultiStateSamplerAnalyzer`` (openmmtools/multistate/multistateanalyzer.py:1164) on the
+reporter's energies and hands them to **pymbar** (a dependency that is not vendored in the reference tree and not
+installed here; ``devtools/conda-envs/test_env.yaml:14`` lists it unpinned, i.e. pymbar 4).  This module restates the
+published algorithms the analyzer relies on, in plain numpy:
+
+* ``statistical_inefficiency`` / ``subsample_correlated_data`` — pymbar.timeseries (Chodera et al., JCTC 3, 26 (2007);
+  integrated autocorrelation time summed until the normalised fluctuation autocorrelation function first crosses zero,
+  ``mintime = 3``, optional ``fast`` increments);
+* ``get_equilibration_data_per_sample`` — openmmtools/multistate/utils.py:107-190 (automated equilibration detection of
+  Chodera, JCTC 12, 1799 (2016) on at most ``max_subset`` time origins);
+* ``MBAR`` — Shirts & Chodera, J. Chem. Phys. 129, 124105 (2008): self-consistent / Newton solution of eq. 11 for the
+  dimensionless free energies and the asymptotic covariance of eq. 8 / D6 (SVD form) for their uncertainties;
+* ``MultiStateSamplerAnalyzer`` — the analyzer's pipeline for global neighbourhoods: effective-energy timeseries
+  (multistateanalyzer.py:1414-1478), equilibration data (:2026-2088), decorrelated u_ln / N_l assembly with the
+  unsampled states at the end points (:1479-1545), free energy differences (:1919-2003).
+
+Parity: unpinned against pymbar itself (absent); pinned against the analytical free energies of harmonic oscillators,
+the reference's own acceptance test (tests/test_sampling.py:100-300), in tests/test_analysis_cpu.py.
+"""
+import numpy as np
+
+
+# ---- timeseries ------------------------------------------------------------------------------------------------
+def statistical_inefficiency(A_n, fast=False, mintime=3):
+    """g = 1 + 2 tau of the stationary timeseries ``A_n`` (>= 1).  pymbar.timeseries.statistical_inefficiency."""
+    A = np.asarray(A_n, dtype=np.float64)
+    N = A.size
+    dA = A - A.mean()
+    sigma2 = np.mean(dA * dA)
+    if sigma2 == 0.0:
+        raise ValueError('sample covariance is zero: cannot compute the statistical inefficiency')
+    g = 1.0
+    t, increment = 1, 1
+    while t < N - 1:
+        C = np.dot(dA[:N - t], dA[t:]) / (float(N - t) * sigma2)
+        if C <= 0.0 and t > mintime:
+            break
+        g += 2.0 * C * (1.0 - float(t) / float(N)) * float(increment)
+        t += increment
+        if fast:
+            increment += 1
+    return max(g, 1.0)
+
+
+def subsample_correlated_data(A_t, g=None, fast=False, conservative=False):
+    """Indices of an (approximately) uncorrelated subset: every ``g``-th sample, rounded (pymbar.timeseries)."""
+    T = len(A_t)
+    if g is None:
+        g = statistical_inefficiency(A_t, fast=fast)
+    if conservative:
+        stride = int(np.ceil(g))
+        return list(range(0, T, stride))
+    indices, n = [], 0
+    while int(round(n * g)) < T:
+        t = int(round(n * g))
+        if n == 0 or t != indices[-1]:
+            indices.append(t)
+        n += 1
+    return indices
+
+
+def get_equilibration_data_per_sample(timeseries_to_analyze, fast=True, max_subset=100):
+    """(i_t, g_i, n_effective_i) on at most ``max_subset`` evenly spaced time origins (multistate/utils.py:107-190)."""
+    series = np.array(timeseries_to_analyze)
+    time_size = series.size
+    set_size = time_size - 1
+    if max_subset is None or set_size < max_subset:
+        max_subset = set_size
+    if max_subset == 0:
+        max_subset = 1
+    if series.std() == 0.0 or max_subset == 1:
+        return (np.arange(max_subset, dtype=int), np.array([1] * max_subset),
+                np.arange(time_size, time_size - max_subset, -1))
+    g_i = np.ones([max_subset], np.float32)
+    n_effective_i = np.ones([max_subset], np.float32)
+    counter = np.arange(max_subset)
+    i_t = np.floor(counter * time_size / max_subset).astype(int)
+    for i, t in enumerate(i_t):
+        try:
+            g_i[i] = statistical_inefficiency(series[t:], fast=fast)
+        except Exception:
+            g_i[i] = (time_size - t + 1)
+        n_effective_i[i] = (time_size - t + 1) / g_i[i]
+    return i_t, g_i, n_effective_i
+
+
+# ---- MBAR --------------------------------------------------------------------------------------------------------
+def _logsumexp(a, axis=None, b=None):
+    a = np.asarray(a, dtype=np.float64)
+    amax = np.max(a, axis=axis, keepdims=True)
+    amax = np.where(np.isfinite(amax), amax, 0.0)
+    e = np.exp(a - amax)
+    if b is not None:
+        e = e * b
+    s = np.sum(e, axis=axis, keepdims=True)
+    out = np.log(s) + amax
+    return np.squeeze(out, axis=axis) if axis is not None else float(out.reshape(()))
+
+
+class ParameterError(Exception):
+    """Raised when the estimator cannot be computed from the data it was given (pymbar.utils.ParameterError)."""
+
+
+class MBAR:
+    """Multistate Bennett acceptance ratio estimator.
+
+    ``u_kn[k, n]`` is the reduced potential of sample ``n`` evaluated in state ``k``; ``N_k[k]`` the number of samples
+    drawn from state ``k`` (0 for unsampled states).  Solves  f_i = -ln sum_n exp(-u_in) / sum_k N_k exp(f_k - u_kn)
+    (eq. 11) with f_0 = 0.
+    """
+
+    def __init__(self, u_kn, N_k, initial_f_k=None, relative_tolerance=1.0e-12, maximum_iterations=10000):
+        self.u_kn = np.array(u_kn, dtype=np.float64)
+        self.N_k = np.array(N_k, dtype=np.int64)
+        K, N = self.u_kn.shape
+        if self.N_k.shape != (K,) or int(self.N_k.sum()) != N:
+            raise ParameterError('N_k must have one entry per state and sum to the number of samples')
+        if not np.all(np.isfinite(self.u_kn[self.N_k > 0])):
+            raise ParameterError('non-finite reduced potentials in a sampled state')
+        self.K, self.N = K, N
+        f = np.zeros(K) if initial_f_k is None else np.array(initial_f_k, dtype=np.float64) - float(np.asarray(initial_f_k)[0])
+        self.f_k = self._solve(f, relative_tolerance, maximum_iterations)
+        self._log_W = None
+
+    # log of the mixture denominator per sample: ln sum_k N_k exp(f_k - u_kn)
+    def _log_denominator(self, f_k):
+        s = self.N_k > 0
+        return _logsumexp(f_k[s, None] - self.u_kn[s, :], axis=0, b=self.N_k[s, None].astype(np.float64))
+
+    def _solve(self, f_k, rtol, maxiter):
+        s = np.flatnonzero(self.N_k > 0)
+        if s.size == 0:
+            raise ParameterError('no sampled state')
+        u = self.u_kn[s]
+        Nk = self.N_k[s].astype(np.float64)
+        f = f_k[s] - f_k[s][0]
+
+        def objective_parts(f):
+            log_den = _logsumexp(f[:, None] - u, axis=0, b=Nk[:, None])
+            log_W = f[:, None] - u - log_den[None, :]                     # [Ks, N]
+            return log_den, log_W
+
+        # a few self-consistent sweeps bring any starting point into Newton's basin
+        for _ in range(5):
+            log_den, _ = objective_parts(f)
+            f_new = -_logsumexp(-u - log_den[None, :], axis=1)
+            f = f_new - f_new[0]
+        for _ in range(maxiter):
+            log_den, log_W = objective_parts(f)
+            W = np.exp(log_W)
+            g = Nk * (W.sum(axis=1) - 1.0)                                # gradient of the convex objective
+            H = np.diag(Nk * W.sum(axis=1)) - (Nk[:, None] * Nk[None, :]) * (W @ W.T)
+            if s.size > 1:
+                try:
+                    step = np.zeros_like(f)
+                    step[1:] = np.linalg.solve(H[1:, 1:], g[1:])
+                except np.linalg.LinAlgError:
+                    step = np.zeros_like(f)
+                    step[1:] = np.linalg.lstsq(H[1:, 1:], g[1:], rcond=None)[0]
+            else:
+                step = np.zeros_like(f)
+            phi0 = log_den.sum() - np.dot(Nk, f)
+            scale = 1.0
+            while True:                                                   # backtrack: the objective must not increase
+                f_try = f - scale * step
+                phi = objective_parts(f_try)[0].sum() - np.dot(Nk, f_try)
+                if phi <= phi0 + 1e-12 * abs(phi0) or scale < 1e-6:
+                    break
+                scale *= 0.5
+            delta = np.max(np.abs(f_try - f))
+            f = f_try
+            if delta <= rtol * max(1.0, np.max(np.abs(f))):
+                break
+        else:
+            raise ParameterError('MBAR did not converge')
+        if not np.all(np.isfinite(f)):
+            raise ParameterError('MBAR produced non-finite free energies')
+        out = np.zeros(self.K)
+        out[s] = f
+        # unsampled states: one application of eq. 11 with the converged denominator
+        log_den = _logsumexp(f[:, None] - u, axis=0, b=Nk[:, None])
+        uns = np.flatnonzero(self.N_k == 0)
+        if uns.size:
+            out[uns] = -_logsumexp(-self.u_kn[uns] - log_den[None, :], axis=1)
+        return out - out[0]
+
+    @property
+    def log_W_nk(self):
+        if self._log_W is None:
+            log_den = self._log_denominator(self.f_k)
+            self._log_W = (self.f_k[:, None] - self.u_kn - log_den[None, :]).T          # [N, K]
+        return self._log_W
+
+    def _theta(self):
+        """Asymptotic covariance of the f_k (eq. 8), SVD form:  Theta = V S (I - S V^T N V S)^+ S V^T  with
+        W = U S V^T — only the K x K Gram matrix W^T W is needed."""
+        W = np.exp(self.log_W_nk)
+        G = W.T @ W
+        evals, V = np.linalg.eigh(G)
+        evals = np.clip(evals, 0.0, None)
+        S = np.sqrt(evals)
+        M = np.eye(self.K) - (S[:, None] * (V.T @ (self.N_k[:, None].astype(np.float64) * V))) * S[None, :]
+        return (V * S[None, :]) @ np.linalg.pinv(M, rcond=1e-10) @ (V * S[None, :]).T
+
+    def compute_free_energy_differences(self):
+        """(Delta_f_ij, dDelta_f_ij) with Delta_f_ij[i, j] = f_j - f_i (pymbar's convention)."""
+        f = self.f_k
+        Delta = f[None, :] - f[:, None]
+        Theta = self._theta()
+        d2 = np.diag(Theta)[:, None] + np.diag(Theta)[None, :] - 2.0 * Theta
+        d2 = np.where(np.abs(d2) < 1e-14, 0.0, d2)
+        with np.errstate(invalid='ignore'):
+            dDelta = np.sqrt(d2)                     # NaN where the estimate of the variance is negative (under-sampling)
+        np.fill_diagonal(dDelta, 0.0)
+        return Delta, dDelta
+
+
+# ---- the analyzer pipeline (global neighbourhoods) --------------------------------------------------------------
+class MultiStateSamplerAnalyzer:
+    """Free energies from a ``MultiStateReporter`` (multistateanalyzer.py:1164; global neighbourhoods only)."""
+
+    def __init__(self, reporter, n_equilibration_iterations=None, statistical_inefficiency=None, max_subset=100,
+                 max_n_iterations=None, use_full_trajectory=False, analysis_kwargs=None):
+        if statistical_inefficiency is not None and n_equilibration_iterations is None:
+            raise Exception('Cannot specify statistical_inefficiency without n_equilibration_iterations, because '
+                            'otherwise n_equilibration_iterations cannot be computed for the given '
+                            'statistical_inefficiency.')                                     # :1209-1213
+        self._reporter = reporter
+        self._n_equilibration_iterations = n_equilibration_iterations
+        self._statistical_inefficiency = statistical_inefficiency
+        self._max_subset = max_subset
+        self._max_n_iterations = max_n_iterations
+        self.use_full_trajectory = use_full_trajectory
+        self._kwargs = dict(analysis_kwargs or {})
+        self._equilibration_data = None
+        self._mbar = None
+
+    def _read_energies(self):
+        """[replica, state, iteration] arrays like the reference's ``_read_energies`` (:1353-1412)."""
+        e, nb, eu = self._reporter.read_energies()
+        states = self._reporter.read_replica_thermodynamic_states()
+        n = e.shape[0] if self._max_n_iterations is None else min(e.shape[0], self._max_n_iterations + 1)
+        return (np.moveaxis(e[:n], 0, -1), np.moveaxis(eu[:n], 0, -1), np.moveaxis(nb[:n], 0, -1),
+                np.moveaxis(states[:n], 0, -1))
+
+    @staticmethod
+    def get_effective_energy_timeseries(energies, replica_state_indices):
+        """u_n[iteration] = sum over replicas of the reduced potential in the state the replica occupies (:1462-1472)."""
+        n_replicas, _, n_iterations = energies.shape
+        u_n = np.zeros([n_iterations], np.float64)
+        rep = np.arange(n_replicas)
+        for it in range(n_iterations):
+            u_n[it] = np.sum(energies[rep, replica_state_indices[:, it], it])
+        return u_n
+
+    def _get_equilibration_data(self, energies=None, replica_state_indices=None):
+        """(n_equilibration_iterations, statistical_inefficiency, n_effective_max), :2026-2088."""
+        if energies is None:
+            energies, _, _, replica_state_indices = self._read_energies()
+        if self._n_equilibration_iterations is not None and self._statistical_inefficiency is not None:
+            n_eq, g_t = self._n_equilibration_iterations, self._statistical_inefficiency
+            n_eff = (energies.shape[-1] - 1 - n_eq + 1) / g_t
+        else:
+            u_n = self.get_effective_energy_timeseries(energies, replica_state_indices)
+            t0 = self._n_equilibration_iterations if self._n_equilibration_iterations is not None else 1   # drop iteration 0
+            i_t, g_i, n_effective_i = get_equilibration_data_per_sample(u_n[t0:], max_subset=self._max_subset)
+            n_eff = n_effective_i.max()
+            i_max = n_effective_i.argmax()
+            n_eq = int(i_t[i_max] + t0)
+            g_t = self._statistical_inefficiency if self._statistical_inefficiency is not None else float(g_i[i_max])
+        self._equilibration_data = (n_eq, g_t, n_eff)
+        return self._equilibration_data
+
+    @property
+    def n_equilibration_iterations(self):
+        return (self._equilibration_data or self._get_equilibration_data())[0]
+
+    @property
+    def statistical_inefficiency(self):
+        return (self._equilibration_data or self._get_equilibration_data())[1]
+
+    def _compute_mbar_decorrelated_energies(self):
+        """(u_ln, N_l) with the unsampled states at the two end points (:1479-1545)."""
+        e, eu, nb, states = self._read_energies()
+        n_eq, g_t, _ = self._get_equilibration_data(e, states)
+        if not self.use_full_trajectory:
+            e, eu, states = e[..., n_eq:], eu[..., n_eq:], states[..., n_eq:]
+            idx = subsample_correlated_data(np.zeros(e.shape[-1]), g=g_t)
+            e, eu, states = e[..., idx], eu[..., idx], states[..., idx]
+        n_replicas, n_sampled, n_it = e.shape
+        n_uns = eu.shape[1]
+        n_total = n_sampled + n_uns
+        first = int(n_uns / 2.0)
+        last = n_total - first
+        u_ln = np.zeros([n_total, n_it * n_replicas])
+        N_l = np.zeros([n_total], dtype=int)
+        u_ln[first:last, :] = np.concatenate([e[k] for k in range(n_replicas)], axis=1)      # kln' -> ln (:1027-1034)
+        uniq, counts = np.unique(states, return_counts=True)
+        N_l[first:last][uniq] = counts
+        if n_uns > 0:
+            u_ln[[0, -1], :] = np.concatenate([eu[k] for k in range(n_replicas)], axis=1)
+        return u_ln, N_l
+
+    @property
+    def mbar(self):
+        if self._mbar is None:
+            u_ln, N_l = self._compute_mbar_decorrelated_energies()
+            self._mbar = MBAR(u_ln, N_l, initial_f_k=self._kwargs.get('initial_f_k'))
+        return self._mbar
+
+    def get_free_energy(self):
+        """(Delta_f_ij, dDelta_f_ij) in kT between all (unsampled + sampled) states (:1958-2003)."""
+        return self.mbar.compute_free_energy_differences()

@@ -39,6 +39,9 @@ class SingleProcessComm:
     def gather_objects(self, obj):
         return [obj]
 
+    def broadcast_object(self, obj):
+        return obj
+
     def barrier(self):
         pass
 
@@ -91,6 +94,12 @@ class TorchDistributedComm:
         out = [None] * self.world_size if self.rank == 0 else None
         self.dist.gather_object(obj, out, dst=0, group=self.group)
         return out
+
+    def broadcast_object(self, obj):
+        """Small host object from rank 0 to every rank (the offline analysis' error estimate, which decides completion)."""
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]
 
     def barrier(self):
         self.dist.barrier(group=self.group)

@@ -128,6 +128,10 @@ class MultiStateReporter:
             'timestamp': _RecordFile(os.path.join(d, 'timestamp.f8'), 'f8', ()),
             'logZ': _RecordFile(os.path.join(d, 'logZ.f8'), 'f8', (K,)),                          # online data, SAMS
             'log_weights': _RecordFile(os.path.join(d, 'log_weights.f8'), 'f8', (K,)),
+            # online / offline free energy estimates (multistatesampler.py:1602-1605, 1662-1664)
+            'f_k': _RecordFile(os.path.join(d, 'f_k.f8'), 'f8', (K,)),
+            'f_k_offline': _RecordFile(os.path.join(d, 'f_k_offline.f8'), 'f8', (K + U,)),
+            'free_energy': _RecordFile(os.path.join(d, 'free_energy.f8'), 'f8', (2,)),
         }
 
     def initialize(self, n_replicas, n_states, n_unsampled, n_atoms):
@@ -218,6 +222,37 @@ class MultiStateReporter:
                 self._files[k].write(iteration, v)
             elif v is not None and iteration % self._checkpoint_interval == 0:
                 self._write_object('online_%s_%09d' % (k, iteration), v)     # small python objects: checkpoint iterations only
+
+    def write_online_analysis_data(self, iteration, **kwargs):
+        """:1305-1339: 1-D numeric online-analysis variables, per iteration (``iteration`` None: the static copy, which
+        here is simply the latest record)."""
+        if iteration is None:
+            return
+        self.write_online_data_dynamic_and_static(iteration, **kwargs)
+
+    def read_online_analysis_data(self, iteration, *keys):
+        """:1236-1303: {key: value} at ``iteration`` (None: the most recent record).  KeyError for an unknown variable,
+        IndexError when nothing was written at that iteration — the two exceptions the sampler's reader handles."""
+        out = {}
+        for k in keys:
+            if k not in self._files:
+                raise KeyError(k)
+            n = self._files[k].count()
+            if n == 0:
+                raise ValueError('no {} in storage'.format(k))
+            idx = n - 1 if iteration is None else int(iteration)
+            if idx >= n or idx < 0:
+                raise IndexError(idx)
+            out[k] = self._files[k].read(idx)
+        return out
+
+    def write_current_statistics(self, data):
+        """:1353-1375: appends one YAML document per call to ``<storage stem>_real_time_analysis.yaml``."""
+        self._require_write()
+        import yaml
+        stem = self._storage_analysis[:-3] if self._storage_analysis.endswith('.nc') else self._storage_analysis
+        with open(stem + '_real_time_analysis.yaml', 'a') as fh:
+            fh.write(yaml.dump([data], sort_keys=False))
 
     def read_online_data_if_present(self, iteration):
         out = {}

@@ -24,9 +24,18 @@ logger = logging.getLogger(__name__)
 
 class MultiStateSampler:
     def __init__(self, mcmc_moves=None, number_of_iterations=1, locality=None,
-                 online_analysis_interval=None, engine=None, seed=0xC0FFEE, comm=None):
+                 online_analysis_interval=200, online_analysis_target_error=0.0,
+                 online_analysis_minimum_iterations=200, engine=None, seed=0xC0FFEE, comm=None):
         if locality is not None:
             raise NotImplementedError('only global neighborhoods (locality=None) are implemented')
+        # multistatesampler.py:478-501
+        if online_analysis_interval is not None and (type(online_analysis_interval) != int or online_analysis_interval < 1):
+            raise ValueError('online_analysis_interval must be an integer >=1 or None')
+        if online_analysis_interval is not None:
+            if online_analysis_target_error < 0:
+                raise ValueError('online_analysis_target_error must be a float >= 0')
+            if type(online_analysis_minimum_iterations) is not int or online_analysis_minimum_iterations < 0:
+                raise ValueError('online_analysis_minimum_iterations must be an integer >= 0')
         if mcmc_moves is None:
             # multistatesampler.py:224-227
             self._mcmc_moves = mcmc.LangevinDynamicsMove(timestep=2.0 * unit.femtosecond,
@@ -38,6 +47,10 @@ class MultiStateSampler:
         self.number_of_iterations = number_of_iterations
         self.locality = locality
         self.online_analysis_interval = online_analysis_interval
+        self.online_analysis_target_error = online_analysis_target_error
+        self.online_analysis_minimum_iterations = online_analysis_minimum_iterations
+        self._last_mbar_f_k = None                # :246-247
+        self._last_err_free_energy = None
         self._engine = engine
         self._seed = int(seed)
         self._comm = comm if comm is not None else SingleProcessComm()
@@ -145,8 +158,12 @@ class MultiStateSampler:
 
     def _options(self):
         """What from_storage needs to rebuild the sampler (multistatesampler.py:1145-1167 _store_options)."""
+        kwargs = dict(online_analysis_interval=self.online_analysis_interval,
+                      online_analysis_target_error=self.online_analysis_target_error,
+                      online_analysis_minimum_iterations=self.online_analysis_minimum_iterations)
+        kwargs.update(self._ctor_kwargs())
         return dict(cls=type(self).__name__, module=type(self).__module__, number_of_iterations=self.number_of_iterations,
-                    seed=self._seed, kwargs=self._ctor_kwargs())
+                    seed=self._seed, kwargs=kwargs)
 
     def _ctor_kwargs(self):
         return {}
@@ -185,6 +202,11 @@ class MultiStateSampler:
         s._n_accepted_matrix[:, :] = acc
         s._n_proposed_matrix[:, :] = prop
         s._restore_online(rep.read_online_data_if_present(it))
+        if s.online_analysis_interval is not None:                              # :991-995
+            last_f_k, last_free_energy = cls._read_last_free_energy(rep, it)
+            if last_f_k is not None:
+                s._last_mbar_f_k = np.array(last_f_k, dtype=np.float64)
+                s._last_err_free_energy = float(last_free_energy[1])
         s._reporter = rep
         s._initialize_engine()
         s._mix_from_stored_energies = True
@@ -369,7 +391,7 @@ class MultiStateSampler:
         else:
             iteration_limit = min(self._iteration + n_iterations, self.number_of_iterations)
         t_run = time.time()
-        while self._iteration < iteration_limit:                       # :766
+        while not self._is_completed(iteration_limit):                 # :766
             t0 = time.time()
             self._iteration += 1                                       # :768
             self._replica_thermodynamic_states = self._mix_replicas()  # :776
@@ -379,6 +401,7 @@ class MultiStateSampler:
             self._compute_energies()                                   # :782
             t3 = time.time()
             self._report_iteration()                                   # :785
+            self._update_analysis()                                    # :788
             self._update_timing(t0, t1, t2, t3, t_run)                 # :793
             self._check_nan_energy()                                   # :804
 
@@ -399,6 +422,107 @@ class MultiStateSampler:
     def _report_iteration(self):
         if self._reporter is not None:
             self._reporter.write_iteration(self)
+
+    # ---- completion and online / offline analysis (multistatesampler.py:526-528, 1519-1735) ----------------------
+    @property
+    def is_completed(self):
+        return self._is_completed()
+
+    def _is_completed(self, iteration_limit=None):
+        if iteration_limit is None:
+            iteration_limit = self.number_of_iterations
+        return self._is_completed_static(iteration_limit, self._iteration, self._last_err_free_energy,
+                                         self.online_analysis_target_error)
+
+    @staticmethod
+    def _is_completed_static(iteration_limit, iteration, last_err_free_energy, online_analysis_target_error):
+        """:1720-1730: the iteration limit, or the statistical error target of the online analysis."""
+        return bool(iteration >= iteration_limit or (last_err_free_energy is not None and
+                                                     last_err_free_energy <= online_analysis_target_error))
+
+    def _update_analysis(self):
+        """:1677-1694: the stochastic-approximation estimate every iteration, MBAR every online_analysis_interval."""
+        if self.online_analysis_interval is None:
+            return
+        self._last_err_free_energy = self._online_analysis()
+        if self._iteration % self.online_analysis_interval == 0:
+            err = self._offline_analysis()
+            if err is not None:
+                self._last_err_free_energy = err
+
+    def _online_analysis(self, gamma0=1.0):
+        """:1625-1675.  logZ_k += gamma * P(k | x_r) / pi_k over the replicas (pi_k = 1, gamma = gamma0 / (iteration + 1)),
+        then anchored at state 0.  Replicated on every rank from the replicated u_kl (the reference: rank 0 + broadcast)."""
+        gamma = gamma0 / float(self._iteration + 1)
+        if self._last_mbar_f_k is None:
+            self._last_mbar_f_k = np.zeros([self.n_states], np.float64)
+        logZ = -self._last_mbar_f_k
+        u = self._energy_thermodynamic_states
+        # log P_k = -u_k - logsumexp(-u): global neighbourhoods, zero log weights (:1647-1653)
+        m = np.max(-u, axis=1, keepdims=True)
+        log_P = -u - (m + np.log(np.sum(np.exp(-u - m), axis=1, keepdims=True)))
+        P = np.exp(log_P)
+        for r in range(self.n_replicas):                     # sequential accumulation, the reference's order
+            logZ += gamma * P[r]
+        logZ[:] -= logZ[0]
+        self._last_mbar_f_k = -logZ
+        free_energy = self._last_mbar_f_k[-1] - self._last_mbar_f_k[0]
+        self._last_err_free_energy = np.inf
+        if self._reporter is not None and self._comm.rank == 0:
+            self._reporter.write_online_data_dynamic_and_static(self._iteration, f_k=self._last_mbar_f_k,
+                                                                free_energy=(free_energy, self._last_err_free_energy))
+        return self._last_err_free_energy
+
+    def _offline_analysis(self):
+        """:1522-1620: MBAR on the stored, equilibrated and decorrelated energies; needs a reporter.  Returns the standard
+        error of f_last - f_first in kT, or None when the estimate cannot be computed yet (under-sampled)."""
+        if self.locality is not None:
+            raise Exception('Cannot use MBAR with non-global locality.')
+        if self._reporter is None:
+            return None
+        from .analysis import MultiStateSamplerAnalyzer, ParameterError
+        if not hasattr(self, '_last_mbar_f_k_offline'):
+            self._last_mbar_f_k_offline = np.zeros(self.n_states + len(self._unsampled_states))
+        err = None
+        if self._comm.rank == 0:
+            analysis = MultiStateSamplerAnalyzer(self._reporter, analysis_kwargs={'initial_f_k': self._last_mbar_f_k_offline})
+            try:
+                mbar = analysis.mbar
+                free_energy, err_free_energy = analysis.get_free_energy()
+                n_eq, g_t = analysis.n_equilibration_iterations, analysis.statistical_inefficiency
+            except (ParameterError, ValueError, np.linalg.LinAlgError) as e:
+                logger.debug('MBAR could not be computed: %s', e)
+            else:
+                self._last_mbar_f_k_offline = mbar.f_k
+                fe, err = float(free_energy[0, -1]), float(err_free_energy[0, -1])
+                if np.isnan(err):
+                    err = np.inf                                            # :1585-1586
+                self._reporter.write_online_data_dynamic_and_static(self._iteration, f_k_offline=self._last_mbar_f_k_offline,
+                                                                    free_energy=(fe, err))
+                self._reporter.write_current_statistics({
+                    'iteration': int(self._iteration),
+                    'percent_complete': float(self._iteration * 100 / self.number_of_iterations),
+                    'mbar_analysis': {'free_energy_in_kT': fe, 'standard_error_in_kT': float(err),
+                                      'number_of_uncorrelated_samples': float(analysis._equilibration_data[-1]),
+                                      'n_equilibrium_iterations': int(n_eq), 'statistical_inefficiency': float(g_t)},
+                    'timing_data': {k: float(v) for k, v in self._timing_data.items()}})
+        if self._comm.world_size > 1:
+            err = self._comm.broadcast_object(err)
+        return err
+
+    @staticmethod
+    def _read_last_free_energy(reporter, iteration):
+        """:1696-1718: the most recent stored (f_k, (free_energy, error)) at or before ``iteration``."""
+        last_f_k = last_free_energy = None
+        for index in range(iteration, 0, -1):
+            try:
+                data = reporter.read_online_analysis_data(index, 'f_k', 'free_energy')
+                last_f_k, last_free_energy = data['f_k'], data['free_energy']
+            except (IndexError, KeyError, ValueError):
+                break
+            if not np.all(last_f_k == 0):
+                break
+        return last_f_k, last_free_energy
 
     # ---- the three hooks ---------------------------------------------------------------------
     def _mix_replicas(self, rng_iteration=None):
