@@ -169,3 +169,28 @@ def test_offline_mbar_on_a_parallel_tempering_run_matches_the_analytical_free_en
     import os, yaml
     docs = yaml.safe_load(open(str(tmp_path / 'x' / 'store') + '_real_time_analysis.yaml'))
     assert docs[-1]['iteration'] == 240 and abs(docs[-1]['mbar_analysis']['free_energy_in_kT'] - fe) < 1e-12
+
+
+def test_offline_mbar_reports_free_energies_relative_to_the_unsampled_end_states(tmp_path):
+    """With two unsampled states they take the end points of the MBAR state list (multistateanalyzer.py:1517-1536) and the
+    reported free energy is f(last unsampled) - f(first unsampled), here -3/2 ln(700 / 250)."""
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=5.0 / unit.picosecond,
+                                              n_steps=40, reassign_velocities=True, splitting='V R O R V')
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=200, engine=OracleEngine(), seed=5,
+                                 online_analysis_interval=200)
+    rep = MultiStateReporter(str(tmp_path / 'store'), checkpoint_interval=100)
+    unsampled = [states.ThermodynamicState(ho.system, T * unit.kelvin) for T in (250.0, 700.0)]
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=600.0, n_temperatures=4,
+             unsampled_thermodynamic_states=unsampled)
+    s.run()
+    a = an.MultiStateSamplerAnalyzer(rep)
+    u_ln, N_l = a._compute_mbar_decorrelated_energies()
+    assert u_ln.shape[0] == 6 and N_l[0] == 0 and N_l[-1] == 0 and N_l[1:-1].sum() == u_ln.shape[1]
+    D, dD = a.get_free_energy()
+    exact = -1.5 * np.log(700.0 / 250.0)
+    assert abs(D[0, -1] - exact) < 6.0 * dD[0, -1] and 0.0 < dD[0, -1] < 0.5
+    fe, err = rep.read_online_analysis_data(None, 'free_energy')['free_energy']
+    assert fe == D[0, -1] and err == dD[0, -1] and len(rep.read_online_analysis_data(None, 'f_k_offline')['f_k_offline']) == 6
