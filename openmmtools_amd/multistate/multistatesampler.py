@@ -8,6 +8,7 @@ _pre_write_create :836-926), ``run`` (:724-804: mix -> propagate -> energies), `
 indices and mixing statistics plus f4 checkpoints (multistatereporter.py); ``from_storage`` resumes from the
 last complete checkpoint.  Online analysis and minimization are out of scope.
 """
+import collections
 import copy
 import os
 import time
@@ -105,12 +106,67 @@ class MultiStateSampler:
         return self._energy_thermodynamic_states
 
     @property
-    def is_completed(self):
-        return self._iteration >= self.number_of_iterations
+    def is_periodic(self):
+        """multistatesampler.py:431-436."""
+        if self._sampler_states is None:
+            return None
+        return self._thermodynamic_states[0].is_periodic
+
+    @property
+    def metadata(self):
+        """:519-523."""
+        return copy.deepcopy(getattr(self, '_metadata', None))
+
+    @property
+    def options(self):
+        """What is stored for ``from_storage`` / ``read_status`` (:1145-1167)."""
+        o = self._options()
+        flat = dict(number_of_iterations=o['number_of_iterations'])
+        flat.update(o['kwargs'])
+        return flat
 
     @property
     def engine(self):
         return self._engine
+
+    def __repr__(self):
+        return '<instance of {}>'.format(self.__class__.__name__)
+
+    class Status(collections.namedtuple('Status', ['iteration', 'target_error', 'is_completed'])):
+        """:301-305."""
+
+    @classmethod
+    def read_status(cls, storage):
+        """:307-358: (iteration, target_error, is_completed) from the storage alone, without building the sampler."""
+        from .multistatereporter import MultiStateReporter
+        rep = MultiStateReporter(storage) if isinstance(storage, (str, bytes, os.PathLike)) else storage
+        was_open = rep.is_open()
+        if not was_open:
+            rep.open('r')
+        try:
+            opts = rep.read_dict('options')
+            kw = opts['kwargs']
+            iteration = rep.read_last_iteration(last_checkpoint=False) or 0     # nothing reported yet: iteration 0
+            target_error = last_err = None
+            if kw.get('online_analysis_interval') is not None and kw.get('online_analysis_target_error', 0.0) != 0.0:
+                target_error = kw['online_analysis_target_error']
+                try:
+                    last_err = float(cls._read_last_free_energy(rep, iteration)[1][1])
+                except TypeError:
+                    last_err = np.inf                                      # no free energy stored yet
+        finally:
+            if not was_open:
+                rep.close()
+        done = cls._is_completed_static(opts['number_of_iterations'], iteration, last_err, kw.get('online_analysis_target_error', 0.0))
+        return cls.Status(iteration=iteration, target_error=target_error, is_completed=done)
+
+    def extend(self, n_iterations):
+        """:806-822: like run(), but raises ``number_of_iterations`` when needed (and stores the new value)."""
+        if self._iteration + n_iterations > self.number_of_iterations:
+            self.number_of_iterations = self._iteration + n_iterations
+            if self._reporter is not None and self._comm.rank == 0:
+                self._reporter.write_dict('options', self._options())
+        self.run(n_iterations)
 
     # ---- create ---------------------------------------------------------------------------
     @classmethod

@@ -194,3 +194,28 @@ def test_offline_mbar_reports_free_energies_relative_to_the_unsampled_end_states
     assert abs(D[0, -1] - exact) < 6.0 * dD[0, -1] and 0.0 < dD[0, -1] < 0.5
     fe, err = rep.read_online_analysis_data(None, 'free_energy')['free_energy']
     assert fe == D[0, -1] and err == dD[0, -1] and len(rep.read_online_analysis_data(None, 'f_k_offline')['f_k_offline']) == 6
+
+
+def test_extend_read_status_and_stored_options(tmp_path):
+    """multistatesampler.py:307-358 (read_status), :806-822 (extend), :1145-1167 (stored options)."""
+    (tmp_path / 'a').mkdir(); (tmp_path / 'b').mkdir()
+    s, rep = _pt_sampler(tmp_path / 'a', 2, online_analysis_interval=1)
+    assert s.is_periodic is False and repr(s) == '<instance of ParallelTemperingSampler>' and s.metadata == {}
+    s.run()
+    assert s.iteration == 2 and s.is_completed
+    st = ParallelTemperingSampler.read_status(rep)
+    assert st == (2, None, True) and st.iteration == 2 and st.target_error is None
+    s.run(3)                                              # run() never passes number_of_iterations ...
+    assert s.iteration == 2
+    s.extend(2)                                           # ... extend() does, and stores the new limit
+    assert s.iteration == 4 and s.number_of_iterations == 4 and s.options['number_of_iterations'] == 4
+    assert ParallelTemperingSampler.read_status(str(tmp_path / 'a' / 'store')) == (4, None, True)
+    resumed = ParallelTemperingSampler.from_storage(rep, engine=OracleEngine())
+    assert resumed.number_of_iterations == 4 and resumed.options == s.options
+    # a statistical-error stopping condition shows up in the status
+    s2, rep2 = _pt_sampler(tmp_path / 'b', 5, online_analysis_interval=1, online_analysis_target_error=np.inf)
+    # nothing estimated yet: the error defaults to inf, which meets an infinite target (the reference's trap, :343-346)
+    assert ParallelTemperingSampler.read_status(rep2) == (0, np.inf, True)
+    s2.run()
+    st2 = ParallelTemperingSampler.read_status(rep2)
+    assert st2.iteration == s2.iteration < 5 and st2.target_error == np.inf and st2.is_completed
