@@ -339,6 +339,13 @@ class MultiStateSampler:
                 raise NotImplementedError('per-state MCMC moves must be identical for batched propagation')
         return m0
 
+    def _program_engine_move(self):
+        move = self._engine_move()
+        eng = self._engine
+        eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
+                           move.reassign_velocities, move.constraint_tolerance)
+        eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
+
     def _state_energy_constants(self, states):
         """Additive per-state potential constants: the lambda-dependent long-range correction of the
         alchemical CustomNonbondedForces (alchemy.py:1786-1789), constant in NVT."""
@@ -371,10 +378,7 @@ class MultiStateSampler:
         lam_s = np.array([s.lambda_sterics for s in all_states], dtype=np.float64)
         lam_e = np.array([s.lambda_electrostatics for s in all_states], dtype=np.float64)
         eng.set_states(beta, lam_s, lam_e, self._state_energy_constants(all_states))
-        move = self._engine_move()
-        eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
-                           move.reassign_velocities, move.constraint_tolerance)
-        eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
+        self._program_engine_move()
         pressures = [s.pressure for s in all_states]
         if any(p is not None for p in pressures):
             if any(p is None for p in pressures):
@@ -419,16 +423,38 @@ class MultiStateSampler:
 
     def equilibrate(self, n_iterations, mcmc_moves=None):
         """multistatesampler.py:649-722: propagate -> energies -> mix, iteration counter untouched."""
-        if mcmc_moves is not None:
-            raise NotImplementedError('equilibrate() with a different move set')
-        if self._iteration == 0 and not self._energies_computed():
-            self._compute_energies()
-        for it in range(1, 1 + n_iterations):
-            self._equil_iteration = it
-            self._propagate_replicas(rng_iteration=-it)
-            self._compute_energies()
-            self._replica_thermodynamic_states = self._mix_replicas(rng_iteration=-it)
-        self._check_nan_energy()
+        if self._thermodynamic_states is None:
+            raise RuntimeError('Cannot equilibrate replicas. The simulation must be created first.')
+        production_moves = self._mcmc_moves
+        if mcmc_moves is not None:                                       # :655-670: temporary equilibration moves
+            if isinstance(mcmc_moves, mcmc.MCMCMove):
+                mcmc_moves = [copy.deepcopy(mcmc_moves) for _ in range(self.n_states)]
+            elif len(mcmc_moves) != self.n_states:
+                raise RuntimeError('The number of MCMCMoves ({}) and ThermodynamicStates ({}) for equilibration'
+                                   ' must be the same.'.format(len(mcmc_moves), self.n_states))
+            self._mcmc_moves = list(mcmc_moves)
+            try:
+                self._program_engine_move()
+            except Exception:
+                self._mcmc_moves = production_moves
+                raise
+        try:
+            if self._iteration == 0 and not self._energies_computed():
+                self._compute_energies()
+            for it in range(1, 1 + n_iterations):
+                self._equil_iteration = it
+                self._propagate_replicas(rng_iteration=-it)
+                self._compute_energies()
+                self._replica_thermodynamic_states = self._mix_replicas(rng_iteration=-it)
+            self._check_nan_energy()
+        finally:
+            if self._mcmc_moves is not production_moves:                 # :716-717: restore the production moves
+                self._mcmc_moves = production_moves
+                self._program_engine_move()
+        if self._reporter is not None:                                   # :720-721: update the stored positions
+            self._gather_sampler_states()
+            if self._comm.rank == 0:
+                self._reporter.write_sampler_states(self._sampler_states, self._iteration)
 
     def _energies_computed(self):
         return bool(self._neighborhoods.any())

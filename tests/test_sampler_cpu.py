@@ -196,3 +196,35 @@ def test_unsampled_states_energies(tmp_path):
     assert eu.shape == (4, 3, 2) and np.array_equal(eu[3], s._energy_unsampled_states)
     r = ReplicaExchangeSampler.from_storage(str(tmp_path / 'u'), engine=OracleEngine())
     assert len(r._unsampled_states) == 2 and r._energy_unsampled_states.shape == (3, 2)
+
+
+def test_equilibrate_with_temporary_moves_restores_the_production_moves(tmp_path):
+    """multistatesampler.py:649-722: equilibration runs propagate -> energies -> mix with its own MCMCMoves, leaves the
+    iteration counter alone, restores the production moves and updates the stored positions."""
+    ho, ts, ss = _ho_states(3)
+    prod = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=10, reassign_velocities=True, splitting='V R O R V')
+    equil = mcmc.LangevinSplittingDynamicsMove(timestep=0.5 * unit.femtosecond, collision_rate=20.0 / unit.picosecond,
+                                               n_steps=7, reassign_velocities=True, splitting='V R O R V')
+    from openmmtools_amd.multistate import MultiStateReporter
+    eng = OracleEngine()
+    s = ParallelTemperingSampler(mcmc_moves=prod, number_of_iterations=2, engine=eng, seed=3)
+    rep = MultiStateReporter(str(tmp_path / 'store'), checkpoint_interval=1)
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=400.0, n_temperatures=3)
+    assert eng.integ_args == ('V R O R V', 0.001, 1.0, 10)
+    seen = []
+    orig = eng.propagate
+    eng.propagate = lambda it: (seen.append(eng.integ_args), orig(it))[1]
+    s.equilibrate(2, mcmc_moves=equil)
+    assert seen == [('V R O R V', 0.0005, 20.0, 7)] * 2 and s.iteration == 0
+    assert eng.integ_args == ('V R O R V', 0.001, 1.0, 10) and s.mcmc_moves[0].n_steps == 10
+    x_eq = np.stack([st.positions for st in s.sampler_states])
+    stored = rep.read_sampler_states(0)
+    assert stored is not None and np.allclose(np.stack([st.positions for st in stored]), x_eq, atol=1e-6)   # f4 checkpoint
+    with pytest.raises(RuntimeError):
+        s.equilibrate(1, mcmc_moves=[equil, equil])                # one move per state or a single move
+    with pytest.raises(NotImplementedError):
+        s.equilibrate(1, mcmc_moves=mcmc.MCMCMove())               # the engine propagates with Langevin moves only
+    assert eng.integ_args == ('V R O R V', 0.001, 1.0, 10)
+    s.run()
+    assert s.iteration == 2 and seen[-1] == ('V R O R V', 0.001, 1.0, 10)
