@@ -90,6 +90,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_pos_ref); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels);
     dfree(h->d_ukl); dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
     dfree(h->d_pressure); dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
+    dfree(h->d_mix_log);
     dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }

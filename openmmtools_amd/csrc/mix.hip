@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024)
 void mix_swap_all_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
                          const double* __restrict__ g_ukl, int64_t* __restrict__ g_labels,
                          unsigned long long* __restrict__ g_nacc, unsigned long long* __restrict__ g_nprop,
-                         int64_t n_attempts, int stats_in_lds, long long* __restrict__ g_dbg)
+                         int64_t n_attempts, int stats_in_lds, long long* __restrict__ g_dbg, unsigned int* __restrict__ g_log)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, W = blockDim.x, nw = W >> 6;
@@ -170,6 +170,11 @@ void mix_swap_all_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
             if (stats_in_lds) {
                 atomicAdd(&s_nprop[si * K + sj], 1u); atomicAdd(&s_nprop[sj * K + si], 1u);
                 if (acc) { atomicAdd(&s_nacc[si * K + sj], 1u); atomicAdd(&s_nacc[sj * K + si], 1u); }
+            } else if (g_log) {
+                // counters too large for LDS (R > ~128): one coalesced store per attempt instead of 2-4 global atomics from
+                // this single CU (which also sat in front of the next window's u_kl loads in the in-order wait counter);
+                // mix_stats_from_log_kernel builds the K x K matrices afterwards on the whole chip
+                g_log[k] = (unsigned)si | ((unsigned)sj << 15) | (acc ? (1u << 30) : 0u) | (1u << 31);
             } else {
                 atomicAdd(&g_nprop[(size_t)si * K + sj], 1ull); atomicAdd(&g_nprop[(size_t)sj * K + si], 1ull);
                 if (acc) { atomicAdd(&g_nacc[(size_t)si * K + sj], 1ull); atomicAdd(&g_nacc[(size_t)sj * K + si], 1ull); }
@@ -276,6 +281,20 @@ void sams_global_jump_kernel(uint64_t seed, int64_t iteration, int R, int K, int
     }
 }
 
+// proposed / accepted state-pair counts (replicaexchange.py:339-340, 348-349) from the attempt log of mix_swap_all_kernel
+__global__ __launch_bounds__(256)
+void mix_stats_from_log_kernel(int64_t n_attempts, const unsigned int* __restrict__ log, int K,
+                               unsigned long long* __restrict__ g_nacc, unsigned long long* __restrict__ g_nprop)
+{
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n_attempts; k += (int64_t)gridDim.x * 256) {
+        const unsigned int e = log[k];
+        if (!(e >> 31)) continue;
+        const int si = (int)(e & 0x7fffu), sj = (int)((e >> 15) & 0x7fffu);
+        atomicAdd(&g_nprop[(size_t)si * K + sj], 1ull); atomicAdd(&g_nprop[(size_t)sj * K + si], 1ull);
+        if ((e >> 30) & 1u) { atomicAdd(&g_nacc[(size_t)si * K + sj], 1ull); atomicAdd(&g_nacc[(size_t)sj * K + si], 1ull); }
+    }
+}
+
 int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, int ld, const double* d_ukl,
                     int64_t* d_labels, unsigned long long* d_nacc, unsigned long long* d_nprop,
                     const double* d_logw, double* d_logP, int64_t n_attempts)
@@ -313,8 +332,21 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         static long long* d_dbg = nullptr;
         static const bool debug = getenv("REMD_MIX_DEBUG") != nullptr;
         if (debug && !d_dbg) REMD_CHECK(h, hipMalloc(&d_dbg, 8 * sizeof(long long)));
+        unsigned int* d_log = nullptr;
+        static const bool use_log = !(getenv("REMD_MIX_LOG") && atoi(getenv("REMD_MIX_LOG")) == 0);
+        if (!stats_lds && use_log && (size_t)n_attempts * sizeof(unsigned int) <= ((size_t)1 << 30)) {
+            if (h->mix_log_n < (size_t)n_attempts) {
+                if (h->d_mix_log) { hipFree(h->d_mix_log); h->d_mix_log = nullptr; h->mix_log_n = 0; }
+                REMD_CHECK(h, hipMalloc(&h->d_mix_log, sizeof(unsigned int) * (size_t)n_attempts));
+                h->mix_log_n = (size_t)n_attempts;
+            }
+            d_log = h->d_mix_log;
+        }
         hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), lds, h->stream,
-                           h->seed, iteration, R, K, ld, d_ukl, d_labels, d_nacc, d_nprop, n_attempts, stats_lds, d_dbg);
+                           h->seed, iteration, R, K, ld, d_ukl, d_labels, d_nacc, d_nprop, n_attempts, stats_lds, d_dbg, d_log);
+        if (d_log)
+            hipLaunchKernelGGL(mix_stats_from_log_kernel, dim3((unsigned)std::min<int64_t>(4096, (n_attempts + 255) / 256)), dim3(256), 0, h->stream,
+                               n_attempts, d_log, K, d_nacc, d_nprop);
         if (debug) {
             long long hd[8];
             REMD_CHECK(h, hipStreamSynchronize(h->stream));
