@@ -245,14 +245,33 @@ class MultiStateSamplerAnalyzer:
         return (np.moveaxis(e[:n], 0, -1), np.moveaxis(eu[:n], 0, -1), np.moveaxis(nb[:n], 0, -1),
                 np.moveaxis(states[:n], 0, -1))
 
-    @staticmethod
-    def get_effective_energy_timeseries(energies, replica_state_indices):
-        """u_n[iteration] = sum over replicas of the reduced potential in the state the replica occupies (:1462-1472)."""
+    @property
+    def has_log_weights(self):
+        """True when the storage holds per-iteration logZ / log_weights (SAMS), :898-909."""
+        try:
+            self._reporter.read_online_analysis_data(0, 'logZ', 'log_weights')
+            return True
+        except (ValueError, IndexError, KeyError):
+            return False
+
+    def get_effective_energy_timeseries(self, energies, replica_state_indices):
+        """u_n[iteration] = sum over replicas of the reduced potential in the state the replica occupies (:1462-1472);
+        with SAMS weights, the expanded-ensemble correction -sum log_w[state] + logsumexp(-f + log_w) per iteration
+        (:1446-1470, f = the last online logZ estimate)."""
         n_replicas, _, n_iterations = energies.shape
         u_n = np.zeros([n_iterations], np.float64)
         rep = np.arange(n_replicas)
+        log_weights = f_l = None
+        if self.has_log_weights:
+            lw = self._reporter._files['log_weights'].read()          # [iteration, state]
+            if lw.shape[0] >= n_iterations:
+                log_weights = lw[:n_iterations].T
+                f_l = -self._reporter.read_online_analysis_data(None, 'logZ')['logZ']
         for it in range(n_iterations):
-            u_n[it] = np.sum(energies[rep, replica_state_indices[:, it], it])
+            states = replica_state_indices[:, it]
+            u_n[it] = np.sum(energies[rep, states, it])
+            if log_weights is not None:
+                u_n[it] += -np.sum(log_weights[states, it]) + _logsumexp(-f_l + log_weights[:, it])
         return u_n
 
     def _get_equilibration_data(self, energies=None, replica_state_indices=None):
@@ -265,6 +284,9 @@ class MultiStateSamplerAnalyzer:
         else:
             u_n = self.get_effective_energy_timeseries(energies, replica_state_indices)
             t0 = self._n_equilibration_iterations if self._n_equilibration_iterations is not None else 1   # drop iteration 0
+            t0_sams = self._sams_t0()                                     # :2068-2076: only the asymptotically optimal SAMS stage
+            if t0_sams is not None:
+                t0 = max(t0, t0_sams)
             i_t, g_i, n_effective_i = get_equilibration_data_per_sample(u_n[t0:], max_subset=self._max_subset)
             n_eff = n_effective_i.max()
             i_max = n_effective_i.argmax()
@@ -272,6 +294,16 @@ class MultiStateSamplerAnalyzer:
             g_t = self._statistical_inefficiency if self._statistical_inefficiency is not None else float(g_i[i_max])
         self._equilibration_data = (n_eq, g_t, n_eff)
         return self._equilibration_data
+
+    def _sams_t0(self):
+        """Start of SAMS' second stage when the storage records one (written with the online data at checkpoints)."""
+        try:
+            last = self._reporter.read_last_iteration(last_checkpoint=True)
+            data = self._reporter.read_online_data_if_present(last) if last is not None else None
+            st = (data or {}).get('sams_state')
+            return int(st['t0']) if st and st.get('stage', 0) == 1 and st.get('t0', 0) > 0 else None
+        except Exception:
+            return None
 
     @property
     def n_equilibration_iterations(self):

@@ -219,3 +219,38 @@ def test_extend_read_status_and_stored_options(tmp_path):
     s2.run()
     st2 = ParallelTemperingSampler.read_status(rep2)
     assert st2.iteration == s2.iteration < 5 and st2.target_error == np.inf and st2.is_completed
+
+
+def test_analyzer_on_a_sams_run_uses_the_expanded_ensemble_timeseries(tmp_path):
+    """SAMS storage carries per-iteration logZ / log_weights: the effective-energy timeseries gets the expanded-ensemble
+    correction (multistateanalyzer.py:1446-1470) and equilibration starts no earlier than SAMS' second stage (:2068-2076);
+    MBAR on the expanded-ensemble samples still has to recover -3/2 ln(T_j / T_i), and SAMS' own logZ should agree."""
+    from openmmtools_amd.multistate import SAMSSampler
+    ho = testsystems.HarmonicOscillator()
+    T = np.linspace(300.0, 500.0, 5)
+    sts = [states.ThermodynamicState(ho.system, t * unit.kelvin) for t in T]
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=5.0 / unit.picosecond,
+                                              n_steps=40, reassign_velocities=True, splitting='V R O R V')
+    s = SAMSSampler(mcmc_moves=move, number_of_iterations=300, engine=OracleEngine(), seed=21,
+                    flatness_criteria='minimum-visits', online_analysis_interval=None)
+    rep = MultiStateReporter(str(tmp_path / 'store'), checkpoint_interval=50)
+    s.create(sts, [ss] * 2, storage=rep)
+    s.run()
+    a = an.MultiStateSamplerAnalyzer(rep)
+    assert a.has_log_weights and a._sams_t0() is not None and a._sams_t0() >= 1
+    e, eu, nb, st = a._read_energies()
+    plain = np.array([e[np.arange(2), st[:, it], it].sum() for it in range(e.shape[-1])])
+    u_n = a.get_effective_energy_timeseries(e, st)
+    assert u_n.shape == plain.shape and not np.allclose(u_n, plain)
+    n_eq, g, n_eff = a._get_equilibration_data()
+    assert n_eq >= a._sams_t0()
+    D, dD = a.get_free_energy()
+    exact = -1.5 * np.log(T[None, :] / T[:, None])
+    assert np.all(np.abs(D - exact)[dD > 0] < 6.0 * dD[dD > 0])
+    assert abs((-s._logZ[-1] + s._logZ[0]) - exact[0, -1]) < 0.5          # SAMS' online estimate, loosely
+    # a plain parallel-tempering store has no weights
+    (tmp_path / 'p').mkdir()
+    s2, rep2 = _pt_sampler(tmp_path / 'p', 3, online_analysis_interval=None)
+    s2.run()
+    assert not an.MultiStateSamplerAnalyzer(rep2).has_log_weights
