@@ -17,7 +17,8 @@ def build(sampler_kind, engine, comm, n_iter, storage=None):
     move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
                                               n_steps=25, reassign_velocities=True, splitting='V R O R V')
     if sampler_kind == 'pt':
-        s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm)
+        s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm,
+                                     online_analysis_interval=3)       # MBAR on rank 0 at iterations 3 and 6, error broadcast
         s.create(ts, [ss], storage=storage, min_temperature=300.0, max_temperature=600.0, n_temperatures=5)
     else:
         sts = [states.ThermodynamicState(ho.system, T) for T in np.linspace(300.0, 500.0, 6)]
@@ -34,11 +35,14 @@ def run(sampler_kind, comm, n_iter=6, storage_dir=None):
     storage = MultiStateReporter(os.path.join(storage_dir, 'store'), checkpoint_interval=2) if storage_dir else None
     s = build(sampler_kind, OracleEngine(), comm, n_iter, storage)
     history = []
+    analysis = []
     for _ in range(n_iter):
         s.run(1)
         history.append((s.replica_thermodynamic_states.copy(), s.energy_thermodynamic_states.copy(),
                         s._n_accepted_matrix.copy(), s._n_proposed_matrix.copy()))
+        analysis.append(np.append(s._last_mbar_f_k, s._last_err_free_energy))
     x = np.stack([st.positions for st in s.sampler_states])
+    run.last_analysis = np.stack(analysis)          # [iteration, K + 1]: online f_k and the current error estimate
     return history, x, (s._r_begin, s._r_count)
 
 
@@ -52,6 +56,6 @@ if __name__ == '__main__':
     np.savez(os.path.join(out, 'rank%d.npz' % comm.rank),
              labels=np.stack([h[0] for h in history]), ukl=np.stack([h[1] for h in history]),
              nacc=np.stack([h[2] for h in history]), nprop=np.stack([h[3] for h in history]),
-             x_local=x[b:b + c], r_begin=b, r_count=c)
+             x_local=x[b:b + c], r_begin=b, r_count=c, analysis=run.last_analysis)
     dist.barrier()
     dist.destroy_process_group()

@@ -24,6 +24,7 @@ def test_sharded_run_equals_single_process(tmp_path, kind):
     from openmmtools_amd.multistate.comm import SingleProcessComm
     os.makedirs(tmp_path / 'single')
     ref_hist, ref_x, _ = dist_worker.run(kind, SingleProcessComm(), storage_dir=str(tmp_path / 'single'))
+    ref_analysis = dist_worker.run.last_analysis.copy()
     port = 29600 + (os.getpid() % 200) + (0 if kind == 'pt' else 1)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(HERE, 'dist_worker.py'), kind,
@@ -37,6 +38,9 @@ def test_sharded_run_equals_single_process(tmp_path, kind):
             assert np.array_equal(z['labels'][it], labels)
             assert np.array_equal(z['ukl'][it], ukl)       # bit-identical f64 rows after the all-gather
             assert np.array_equal(z['nacc'][it], nacc) and np.array_equal(z['nprop'][it], nprop)
+    # online analysis: replicated stochastic-approximation estimate; the MBAR error (rank 0, iterations 3 and 6) is broadcast
+    for z in ranks:
+        assert np.array_equal(z['analysis'], ref_analysis, equal_nan=True)
     # positions never leave their rank: each rank's block equals the matching block of the reference run
     got = np.concatenate([z['x_local'] for z in ranks])
     assert np.array_equal(got, ref_x)
