@@ -142,6 +142,11 @@ int  remd_get_boxes(remd_handle h, double* box /*[R_local][3]*/);
    barostat they must follow the box: pass the volume (nm^3) they were evaluated at, 0 = volume independent (default). */
 int  remd_set_energy_const_volume(remd_handle h, double reference_volume);
 int  remd_get_barostat_stats(remd_handle h, double* volume_scale /*[R_local]*/, int64_t* n_attempted, int64_t* n_accepted);
+/* mcmc.py:1597-1700 MonteCarloBarostatMove: n_attempts volume moves of every local replica outside the integrator (the
+   reference runs a DummyIntegrator for n_attempts steps with the barostat's frequency temporarily set to 1).  Same
+   move, same random stream and attempt counter as the in-integrator barostat; velocities are not touched.  Needs
+   remd_set_barostat (returns -3 otherwise).  Returns after the moves have completed.                                  */
+int  remd_barostat_attempts(remd_handle h, int n_attempts);
 
 /* MultiStateSampler.minimize (multistatesampler.py:611-647; _minimize_replica :1351-1434) with the reference's
    FIREMinimizationIntegrator (integrators.py:2290-2469, default parameters: timestep 1 fs, alpha 0.1, dt_max 10 fs,

@@ -45,6 +45,7 @@ EXPORTS = [
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
+    'remd_barostat_attempts',
     'remd_set_energy_const_volume',
 ]
 
@@ -83,6 +84,7 @@ def load_library(path=None):
     lib.remd_get_boxes.argtypes = [vp, c_double_p]
     lib.remd_set_energy_const_volume.argtypes = [vp, C.c_double]
     lib.remd_get_barostat_stats.argtypes = [vp, c_double_p, c_int64_p, c_int64_p]
+    lib.remd_barostat_attempts.argtypes = [vp, C.c_int]
     lib.remd_set_replicas.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]
     lib.remd_set_labels.argtypes = [vp, c_int64_p]
     lib.remd_seed.argtypes = [vp, C.c_uint64]
@@ -232,6 +234,10 @@ class HipEngine:
         box = np.zeros((self.R, 3), dtype=np.float64)
         self._check(self.lib.remd_get_boxes(self.h, _dp(box)), 'remd_get_boxes')
         return box
+
+    def barostat_attempts(self, n_attempts):
+        """mcmc.py:1597-1700 MonteCarloBarostatMove: n volume moves of every local replica outside the integrator."""
+        self._check(self.lib.remd_barostat_attempts(self.h, int(n_attempts)), 'remd_barostat_attempts')
 
     def barostat_stats(self):
         vs = np.zeros(self.R); na = np.zeros(self.R, np.int64); nc = np.zeros(self.R, np.int64)

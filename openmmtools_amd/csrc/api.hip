@@ -346,6 +346,21 @@ int remd_get_boxes(remd_handle h, double* box)
     return 0;
 }
 
+int remd_barostat_attempts(remd_handle h, int n_attempts)
+{
+    if (!h) return -1;
+    if (n_attempts < 0) return remd_fail(h, -1, "remd_barostat_attempts: negative n_attempts");
+    if (h->R <= 0 || !h->d_pos) return remd_fail(h, -1, "remd_barostat_attempts: replicas not set");
+    if (h->baro_frequency <= 0 || !h->d_pressure) return remd_fail(h, -3, "remd_barostat_attempts: no barostat (remd_set_barostat)");
+    hipSetDevice(h->device);
+    for (int a = 0; a < n_attempts; ++a) {
+        int rc = remd_barostat_attempt(h);
+        if (rc) return rc;
+    }
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int remd_get_barostat_stats(remd_handle h, double* volume_scale, int64_t* n_attempted, int64_t* n_accepted)
 {
     if (!h || h->R <= 0) return remd_fail(h, -1, "remd_get_barostat_stats: replicas not set");

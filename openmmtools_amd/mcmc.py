@@ -1,7 +1,7 @@
 """Langevin MCMC moves as the sampler's propagation recipe.
 
-Mirrors openmmtools/mcmc.py: BaseIntegratorMove (:603-807), LangevinDynamicsMove (:1066-1172),
-LangevinSplittingDynamicsMove (:1180-1316).  In the reference ``apply`` pushes one replica
+Mirrors openmmtools/mcmc.py: SequenceMove (:350-440), BaseIntegratorMove (:603-807), LangevinDynamicsMove (:1066-1172),
+LangevinSplittingDynamicsMove (:1180-1316), MonteCarloBarostatMove (:1597-1700).  In the reference ``apply`` pushes one replica
 through an OpenMM Context (:668-776); here a move only carries the parameters and the
 multistate sampler propagates *all* replicas in one batched device call
 (_engine.HipEngine.propagate -> remd_propagate).
@@ -11,6 +11,29 @@ from . import unit, integrators
 
 class MCMCMove:
     pass
+
+
+class SequenceMove(MCMCMove):
+    """mcmc.py:350-440: the moves are applied in order, once per iteration."""
+
+    def __init__(self, move_list, **kwargs):
+        self.move_list = list(move_list)
+
+    @property
+    def statistics(self):
+        return [getattr(m, 'statistics', None) for m in self.move_list]
+
+    @statistics.setter
+    def statistics(self, value):
+        for m, v in zip(self.move_list, value):
+            if hasattr(m, 'statistics'):
+                m.statistics = v
+
+    def __iter__(self):
+        return iter(self.move_list)
+
+    def __len__(self):
+        return len(self.move_list)
 
 
 class IntegratorMoveError(Exception):
@@ -54,3 +77,19 @@ class LangevinDynamicsMove(LangevinSplittingDynamicsMove):
         super().__init__(timestep=timestep, collision_rate=collision_rate, n_steps=n_steps,
                          reassign_velocities=reassign_velocities, splitting="V R O R V",
                          constraint_tolerance=constraint_tolerance, **kwargs)
+
+
+class MonteCarloBarostatMove(BaseIntegratorMove):
+    """mcmc.py:1597-1700: ``n_attempts`` Monte Carlo volume moves (the reference steps a DummyIntegrator ``n_attempts`` times
+    with the state's MonteCarloBarostat at frequency 1).  The thermodynamic state must carry a pressure."""
+
+    def __init__(self, n_attempts=5, **kwargs):
+        super().__init__(n_steps=n_attempts, **kwargs)
+
+    @property
+    def n_attempts(self):
+        return self.n_steps
+
+    @n_attempts.setter
+    def n_attempts(self, value):
+        self.n_steps = int(value)

@@ -328,23 +328,50 @@ class MultiStateSampler:
         self._neighborhoods = np.zeros([R, K], 'i1')
         self._energy_unsampled_states = np.zeros([R, len(self._unsampled_states)], np.float64)
 
-    def _engine_move(self):
-        """All states must share one Langevin recipe (one batched launch covers every replica)."""
-        m0 = self._mcmc_moves[0]
-        if not isinstance(m0, mcmc.LangevinSplittingDynamicsMove):
-            raise NotImplementedError('the device engine propagates with Langevin(Splitting)DynamicsMove only')
-        key0 = (m0.timestep, m0.collision_rate, m0.n_steps, m0.reassign_velocities, m0.splitting)
-        for m in self._mcmc_moves[1:]:
-            if (m.timestep, m.collision_rate, m.n_steps, m.reassign_velocities, m.splitting) != key0:
+    @staticmethod
+    def _flatten(move):
+        if isinstance(move, mcmc.SequenceMove):
+            out = []
+            for m in move.move_list:
+                out.extend(MultiStateSampler._flatten(m))
+            return out
+        return [move]
+
+    @staticmethod
+    def _move_key(m):
+        if isinstance(m, mcmc.MonteCarloBarostatMove):
+            return ('barostat', m.n_attempts)
+        if isinstance(m, mcmc.LangevinSplittingDynamicsMove):
+            return ('langevin', m.timestep, m.collision_rate, m.n_steps, m.reassign_velocities, m.splitting)
+        raise NotImplementedError('the device engine propagates with Langevin(Splitting)DynamicsMove and '
+                                  'MonteCarloBarostatMove (alone or in a SequenceMove) only')
+
+    def _engine_program(self):
+        """The per-iteration recipe of every replica: the flattened move sequence of state 0, which all states must share
+        (one batched launch covers every replica).  At most one Langevin move (the engine holds one integrator program)."""
+        prog = self._flatten(self._mcmc_moves[0])
+        keys = [self._move_key(m) for m in prog]
+        for other in self._mcmc_moves[1:]:
+            if [self._move_key(m) for m in self._flatten(other)] != keys:
                 raise NotImplementedError('per-state MCMC moves must be identical for batched propagation')
-        return m0
+        if sum(1 for k in keys if k[0] == 'langevin') > 1:
+            raise NotImplementedError('more than one Langevin move per iteration')
+        return prog
+
+    def _engine_move(self):
+        """The Langevin move of the program (None for a barostat-only recipe)."""
+        for m in self._engine_program():
+            if isinstance(m, mcmc.LangevinSplittingDynamicsMove):
+                return m
+        return None
 
     def _program_engine_move(self):
         move = self._engine_move()
         eng = self._engine
-        eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
-                           move.reassign_velocities, move.constraint_tolerance)
-        eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
+        if move is not None:
+            eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
+                               move.reassign_velocities, move.constraint_tolerance)
+            eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
 
     def _state_energy_constants(self, states):
         """Additive per-state potential constants: the lambda-dependent long-range correction of the
@@ -497,8 +524,8 @@ class MultiStateSampler:
         n = d.get('n_timed', 0) + 1
         d['n_timed'] = n
         d['average_seconds_per_iteration'] = (time.time() - t_run) / n if n else 0.0
-        move = self._mcmc_moves[0]
-        ns_per_iter = move.timestep * move.n_steps * 1e-3 * self.n_replicas
+        move = self._engine_move()
+        ns_per_iter = (move.timestep * move.n_steps * 1e-3 * self.n_replicas) if move is not None else 0.0
         d['ns_per_day'] = ns_per_iter / d['iteration_seconds'] * 86400.0 if d['iteration_seconds'] > 0 else 0.0
 
     def _report_iteration(self):
@@ -617,13 +644,21 @@ class MultiStateSampler:
         """multistatesampler.py:1287-1337 for every local replica in one device call."""
         it = self._iteration if rng_iteration is None else rng_iteration
         self._engine.set_labels(self._replica_thermodynamic_states)
-        flags = self._engine.propagate(it)
-        self._sampler_states_stale = True
-        if np.any(flags):
-            bad = (np.nonzero(flags)[0] + self._r_begin).tolist()
-            raise SimulationNaNError('Propagating replicas {} resulted in a NaN!'.format(bad))
-        for move in self._mcmc_moves:
-            move.statistics = dict(n_attempts=move.statistics.get('n_attempts', 0) + 1)
+        for move in self._engine_program():                      # SequenceMove: in order, once per iteration (mcmc.py:406-424)
+            if isinstance(move, mcmc.MonteCarloBarostatMove):
+                if not getattr(self, '_npt', False):
+                    raise RuntimeError('Requested a MonteCarloBarostat move on a system at constant volume')   # mcmc.py:1673-1676
+                self._engine.barostat_attempts(move.n_attempts)
+                self._sampler_states_stale = True
+                continue
+            flags = self._engine.propagate(it)
+            self._sampler_states_stale = True
+            if np.any(flags):
+                bad = (np.nonzero(flags)[0] + self._r_begin).tolist()
+                raise SimulationNaNError('Propagating replicas {} resulted in a NaN!'.format(bad))
+        for state_move in self._mcmc_moves:
+            for move in self._flatten(state_move):
+                move.statistics = dict(n_attempts=move.statistics.get('n_attempts', 0) + 1)
 
     def _compute_energies(self):
         """multistatesampler.py:1436-1494: fill u_kl for all replicas (global neighborhoods)."""

@@ -102,6 +102,23 @@ class OracleEngine:
             self._baro_steps += n
         return flags
 
+    def barostat_attempts(self, n_attempts):
+        """remd_barostat_attempts: n volume moves per replica outside the integrator, same attempt counter."""
+        if getattr(self, 'pressure', None) is None:
+            raise RuntimeError('remd_barostat_attempts: no barostat (remd_set_barostat)')
+        if self._baro is None:
+            self._baro = mo.OracleBarostat(self.sys, self.seed_value, mo.molecules_from_desc(self.sys.d))
+        vref = getattr(self, 'econst_vref', 0.0)
+        for a in range(int(n_attempts)):
+            for r in range(self.R):
+                rg = self.r_begin + r
+                k = self.labels[rg]
+                lr = (self.econst[k] * vref) if vref > 0 else 0.0
+                self.x[r], self.box[r], _ = self._baro.attempt(self.x[r], self._box(r), 1.0 / self.beta[k], self.pressure[k], rg,
+                                                               self._baro_attempts, long_range=lr,
+                                                               lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
+            self._baro_attempts += 1
+
     def minimize(self, tolerance=1.0, max_iterations=0):
         fire = mo.OracleFIRE(self.sys, tolerance=tolerance)
         conv = np.zeros(self.R, dtype=np.int32)

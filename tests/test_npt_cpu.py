@@ -88,3 +88,51 @@ def test_sampler_npt_with_alchemical_states_passes_the_reference_volume():
                                   + eng.econst[None, :] * ss.volume / V[:, None] + 20.0 * unit.bar * V[:, None])
     assert np.allclose(s.energy_thermodynamic_states, expect, rtol=1e-12)
     assert eng._baro_attempts == 1
+
+
+def test_monte_carlo_barostat_move_in_a_sequence_move():
+    """mcmc.py:1597-1700 + SequenceMove (:350-440): n_attempts volume moves outside the integrator, then the Langevin
+    move; the barostat keeps firing inside the integrator too (it is part of the NPT state), all on one attempt counter."""
+    lj = testsystems.LennardJonesFluid(nparticles=64)
+    ts = states.ThermodynamicState(lj.system, 120.0, pressure=30.0 * unit.bar)
+    ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+    langevin = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                                  n_steps=25, reassign_velocities=True, splitting='V R O R V')
+    baro = mcmc.MonteCarloBarostatMove(n_attempts=3)
+    assert baro.n_attempts == 3 and baro.n_steps == 3
+    seq = mcmc.SequenceMove([baro, langevin])
+    eng = OracleEngine(ForceFieldOracle)
+    s = ParallelTemperingSampler(mcmc_moves=seq, number_of_iterations=2, engine=eng, seed=3)
+    s.create(ts, [ss], min_temperature=120.0, max_temperature=150.0, n_temperatures=2)
+    calls = []
+    orig_b, orig_p = eng.barostat_attempts, eng.propagate
+    eng.barostat_attempts = lambda n: (calls.append(('barostat', n)), orig_b(n))[1]
+    eng.propagate = lambda it: (calls.append(('langevin', it)), orig_p(it))[1]
+    s.run()
+    assert calls == [('barostat', 3), ('langevin', 1), ('barostat', 3), ('langevin', 2)]
+    assert eng._baro_attempts == 2 * 3 + 2 * 1 and eng._baro_steps == 50      # 3 explicit + 1 in-integrator per iteration
+    assert eng.integ_args[3] == 25
+    stats = s.mcmc_moves[0].statistics
+    assert stats[0]['n_attempts'] == 2 and stats[1]['n_attempts'] == 2
+    # the explicit moves alone, against the oracle barostat driven by hand
+    eng2 = OracleEngine(ForceFieldOracle)
+    s2 = ParallelTemperingSampler(mcmc_moves=mcmc.MonteCarloBarostatMove(n_attempts=4), number_of_iterations=1, engine=eng2, seed=3)
+    s2.create(ts, [ss], min_temperature=120.0, max_temperature=150.0, n_temperatures=2)
+    s2.run()
+    ref = mo.OracleBarostat(eng2.sys, 3, mo.molecules_from_desc(eng2.sys.d))
+    for r in range(2):
+        x, box = np.asarray(lj.positions, dtype=np.float64), np.diag(lj.system.getDefaultPeriodicBoxVectors()).astype(float)
+        k = int(s2.replica_thermodynamic_states[r])
+        for a in range(4):
+            x, box, _ = ref.attempt(x, box, 1.0 / s2.thermodynamic_states[k].beta, 30.0 * unit.bar, r, a)
+        assert np.allclose(eng2.box[r], box, rtol=1e-12) and np.allclose(eng2.x[r], x, atol=1e-12)
+    # a barostat move needs a barostated state; unknown moves are refused
+    nvt = states.ThermodynamicState(lj.system, 120.0)
+    s3 = ParallelTemperingSampler(mcmc_moves=mcmc.SequenceMove([baro, langevin]), number_of_iterations=1,
+                                  engine=OracleEngine(ForceFieldOracle), seed=3)
+    s3.create(nvt, [ss], min_temperature=120.0, max_temperature=150.0, n_temperatures=2)
+    with pytest.raises(RuntimeError, match='MonteCarloBarostat'):
+        s3.run()
+    with pytest.raises(NotImplementedError):
+        ParallelTemperingSampler(mcmc_moves=mcmc.SequenceMove([langevin, langevin]), engine=OracleEngine(ForceFieldOracle)
+                                 ).create(ts, [ss], min_temperature=120.0, max_temperature=150.0, n_temperatures=2)

@@ -205,3 +205,32 @@ def test_hostguest_npt_alchemical_production_mode(hip_engine_factory):
         V = float(np.prod(boxes[r]))
         ref = beta * (ff.state_energies(xd[r], boxes[r], lam_s, lam_e) + econst * V0 / V + p * V)
         assert np.allclose(rows[r], ref, rtol=1e-5), np.abs(rows[r] / ref - 1).max()
+
+
+def test_barostat_attempts_outside_the_integrator_track_the_oracle(hip_engine_factory):
+    """remd_barostat_attempts (MonteCarloBarostatMove, mcmc.py:1597-1700): explicit volume moves share the move, the random
+    stream and the attempt counter with the in-integrator barostat."""
+    lj = ts.LennardJonesFluid(nparticles=216)
+    R = 2
+    rng = np.random.default_rng(5)
+    x = np.stack([lj.positions + 0.005 * rng.normal(size=lj.positions.shape) for _ in range(R)])
+    T = [110.0, 125.0]
+    p = 40.0 * unit.bar
+    eng, ora = hip_engine_factory(), OracleEngine(ForceFieldOracle)
+    _setup(eng, lj.system, x, T, p, 25)
+    _setup(ora, lj.system, x, T, p, 25)
+    V0 = np.prod(eng.get_boxes(), axis=1)
+    eng.barostat_attempts(3); ora.barostat_attempts(3)
+    Vd, Vo = np.prod(eng.get_boxes(), axis=1), np.prod(ora.get_boxes(), axis=1)
+    assert np.allclose(Vd, Vo, rtol=2e-5) and np.all(Vd != V0)
+    assert np.abs(eng.get_replicas()[0] - ora.x).max() < 2e-5
+    assert not eng.propagate(0).any()                          # 25 steps: in-integrator attempt number 3 follows
+    ora.propagate(0)
+    assert np.allclose(np.prod(eng.get_boxes(), axis=1), np.prod(ora.get_boxes(), axis=1), rtol=2e-5)
+    assert eng.barostat_stats()[1].tolist() == [4, 4]
+    nvt = hip_engine_factory()
+    desc = system_to_desc(lj.system)
+    nvt.set_system(desc); nvt.set_states(1.0 / (KB * np.array(T)))
+    nvt.set_replicas(R, 0, x, None, np.tile(np.diag(lj.system.getDefaultPeriodicBoxVectors()), (R, 1)), np.arange(R))
+    with pytest.raises(RuntimeError):
+        nvt.barostat_attempts(1)
