@@ -19,6 +19,8 @@ published algorithms the analyzer relies on, in plain numpy:
 Parity: unpinned against pymbar itself (absent); pinned against the analytical free energies of harmonic oscillators,
 the reference's own acceptance test (tests/test_sampling.py:100-300), in tests/test_analysis_cpu.py.
 """
+import collections
+
 import numpy as np
 
 
@@ -38,6 +40,36 @@ def statistical_inefficiency(A_n, fast=False, mintime=3):
         if C <= 0.0 and t > mintime:
             break
         g += 2.0 * C * (1.0 - float(t) / float(N)) * float(increment)
+        t += increment
+        if fast:
+            increment += 1
+    return max(g, 1.0)
+
+
+def statistical_inefficiency_multiple(A_kn, fast=False, mintime=3):
+    """One statistical inefficiency from several timeseries of the same observable (pymbar.timeseries): the fluctuation
+    autocorrelation function is averaged over the series before it is integrated."""
+    series = [np.asarray(a, dtype=np.float64) for a in A_kn]
+    N_k = np.array([a.size for a in series])
+    Nmax, N = int(N_k.max()), int(N_k.sum())
+    mu = sum(a.sum() for a in series) / float(N)
+    dA = [a - mu for a in series]
+    sigma2 = sum((d * d).sum() for d in dA) / float(N)
+    if sigma2 == 0.0:
+        raise ValueError('sample covariance is zero: cannot compute the statistical inefficiency')
+    g = 1.0
+    t, increment = 1, 1
+    while t < Nmax - 1:
+        num, den = 0.0, 0
+        for d in dA:
+            if t >= d.size:
+                continue
+            x = d[:d.size - t] * d[t:]
+            num += x.sum(); den += x.size
+        C = (num / float(den)) / sigma2
+        if C <= 0.0 and t > mintime:
+            break
+        g += 2.0 * C * (1.0 - float(t) / N_k.mean()) * float(increment)
         t += increment
         if fast:
             increment += 1
@@ -341,6 +373,32 @@ class MultiStateSamplerAnalyzer:
             u_ln, N_l = self._compute_mbar_decorrelated_energies()
             self._mbar = MBAR(u_ln, N_l, initial_f_k=self._kwargs.get('initial_f_k'))
         return self._mbar
+
+    MixingStatistics = collections.namedtuple('MixingStatistics', ['transition_matrix', 'eigenvalues', 'statistical_inefficiency'])
+
+    def generate_mixing_statistics(self, number_equilibrated=None):
+        """(transition_matrix, eigenvalues sorted from greatest to least, statistical inefficiency of the replicas' state
+        indices) from the stored state trajectory (:1243-1303; symmetrised empirical transition counts)."""
+        if number_equilibrated is None:
+            number_equilibrated = self.n_equilibration_iterations
+        states = self._reporter.read_replica_thermodynamic_states()
+        if self._max_n_iterations is not None:
+            states = states[:self._max_n_iterations + 1]
+        n_iter, n_replicas = states.shape
+        n_states = int(self._reporter._meta['n_states'])
+        n_ij = np.zeros([n_states, n_states], np.int64)
+        for it in range(number_equilibrated, n_iter - 1):
+            np.add.at(n_ij, (states[it], states[it + 1]), 1)
+        t_ij = np.zeros([n_states, n_states], np.float64)
+        for i in range(n_states):
+            den = float(n_ij[i, :].sum() + n_ij[:, i].sum())
+            if den > 0:
+                t_ij[i, :] = (n_ij[i, :] + n_ij[:, i]) / den
+            else:
+                t_ij[i, i] = 1.0
+        mu = -np.sort(-np.linalg.eigvals(t_ij))
+        g = statistical_inefficiency_multiple(np.transpose(states[number_equilibrated:]))
+        return self.MixingStatistics(transition_matrix=t_ij, eigenvalues=mu, statistical_inefficiency=g)
 
     def get_free_energy(self):
         """(Delta_f_ij, dDelta_f_ij) in kT between all (unsampled + sampled) states (:1958-2003)."""

@@ -254,3 +254,36 @@ def test_analyzer_on_a_sams_run_uses_the_expanded_ensemble_timeseries(tmp_path):
     s2, rep2 = _pt_sampler(tmp_path / 'p', 3, online_analysis_interval=None)
     s2.run()
     assert not an.MultiStateSamplerAnalyzer(rep2).has_log_weights
+
+
+def test_mixing_statistics_from_the_stored_state_trajectory(tmp_path):
+    """multistateanalyzer.py:1243-1303: symmetrised transition counts, eigenvalues in descending order, state-index
+    statistical inefficiency."""
+    (tmp_path / 'm').mkdir()
+    s, rep = _pt_sampler(tmp_path / 'm', 60, online_analysis_interval=None)
+    s.run()
+    a = an.MultiStateSamplerAnalyzer(rep)
+    ms = a.generate_mixing_statistics(number_equilibrated=1)
+    T = ms.transition_matrix
+    assert T.shape == (4, 4) and np.allclose(T.sum(axis=1), 1.0) and np.all(T >= 0)
+    assert np.isclose(ms.eigenvalues[0].real, 1.0) and np.all(np.diff(ms.eigenvalues.real) <= 1e-12)
+    assert abs(ms.eigenvalues[1]) < 1.0 and ms.statistical_inefficiency >= 1.0
+    states = rep.read_replica_thermodynamic_states()
+    n = np.zeros((4, 4))
+    for it in range(1, states.shape[0] - 1):
+        for r in range(4):
+            n[states[it, r], states[it + 1, r]] += 1
+    i = 2
+    assert np.allclose(T[i], (n[i] + n[:, i]) / (n[i].sum() + n[:, i].sum()))
+    # default: the automatically detected equilibration
+    assert a.generate_mixing_statistics().transition_matrix.shape == (4, 4)
+    # several series of one AR(1) process share one inefficiency
+    rng = np.random.default_rng(9)
+    series = []
+    for _ in range(6):
+        x = np.zeros(5000); e = rng.normal(size=5000)
+        for t in range(1, 5000):
+            x[t] = 0.6 * x[t - 1] + e[t]
+        series.append(x)
+    g = an.statistical_inefficiency_multiple(series)
+    assert abs(g - 4.0) < 0.5
