@@ -589,7 +589,7 @@ class MultiStateSampler:
             raise Exception('Cannot use MBAR with non-global locality.')
         if self._reporter is None:
             return None
-        from .analysis import MultiStateSamplerAnalyzer, ParameterError
+        from .analysis import MultiStateSamplerAnalyzer
         if not hasattr(self, '_last_mbar_f_k_offline'):
             self._last_mbar_f_k_offline = np.zeros(self.n_states + len(self._unsampled_states))
         err = None
@@ -599,8 +599,8 @@ class MultiStateSampler:
                 mbar = analysis.mbar
                 free_energy, err_free_energy = analysis.get_free_energy()
                 n_eq, g_t = analysis.n_equilibration_iterations, analysis.statistical_inefficiency
-            except (ParameterError, ValueError, np.linalg.LinAlgError) as e:
-                logger.debug('MBAR could not be computed: %s', e)
+            except Exception as e:            # under-sampled data must not stop a running simulation (:1566-1575 traps pymbar's ParameterError)
+                logger.debug('MBAR could not be computed: %s: %s', type(e).__name__, e)
             else:
                 self._last_mbar_f_k_offline = mbar.f_k
                 fe, err = float(free_energy[0, -1]), float(err_free_energy[0, -1])
