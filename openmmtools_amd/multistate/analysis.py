@@ -225,16 +225,59 @@ class MBAR:
             self._log_W = (self.f_k[:, None] - self.u_kn - log_den[None, :]).T          # [N, K]
         return self._log_W
 
-    def _theta(self):
-        """Asymptotic covariance of the f_k (eq. 8), SVD form:  Theta = V S (I - S V^T N V S)^+ S V^T  with
-        W = U S V^T — only the K x K Gram matrix W^T W is needed."""
-        W = np.exp(self.log_W_nk)
+    @staticmethod
+    def _theta_of(W, N_k):
+        """Asymptotic covariance (eq. 8), SVD form:  Theta = V S (I - S V^T N V S)^+ S V^T  with W = U S V^T — only
+        the Gram matrix W^T W is needed.  ``W`` may carry extra columns with N_k = 0 (unsampled or observable-weighted
+        states)."""
         G = W.T @ W
         evals, V = np.linalg.eigh(G)
         evals = np.clip(evals, 0.0, None)
         S = np.sqrt(evals)
-        M = np.eye(self.K) - (S[:, None] * (V.T @ (self.N_k[:, None].astype(np.float64) * V))) * S[None, :]
+        M = np.eye(W.shape[1]) - (S[:, None] * (V.T @ (np.asarray(N_k, dtype=np.float64)[:, None] * V))) * S[None, :]
         return (V * S[None, :]) @ np.linalg.pinv(M, rcond=1e-10) @ (V * S[None, :]).T
+
+    def _theta(self):
+        return self._theta_of(np.exp(self.log_W_nk), self.N_k)
+
+    def compute_entropy_and_enthalpy(self):
+        """Reduced enthalpy <u_i>_i and entropy s_i = <u_i>_i - f_i differences with their uncertainties
+        (pymbar's compute_entropy_and_enthalpy; section IV of the MBAR paper: each <u_i>_i is the ratio of the
+        normalisation constants of an extra, u-weighted state and of state i, so its error follows from the covariance
+        of the augmented set of free energies).  Returns a dict with Delta_f, dDelta_f, Delta_u, dDelta_u, Delta_s,
+        dDelta_s; Delta_x[i, j] = x_j - x_i."""
+        K = self.K
+        log_W = self.log_W_nk                                         # [N, K]
+        u = self.u_kn.T                                               # [N, K]
+        shift = u.min() - 1.0                                         # observable made positive for the logarithm
+        A = u - shift
+        log_WA_raw = log_W + np.log(A)
+        log_cA = _logsumexp(log_WA_raw, axis=0)                       # ln <A>_i (shifted)
+        W_aug = np.concatenate([np.exp(log_W), np.exp(log_WA_raw - log_cA[None, :])], axis=1)
+        Theta = self._theta_of(W_aug, np.concatenate([self.N_k, np.zeros(K, dtype=np.int64)]))
+        A_i = np.exp(log_cA)
+        u_i = A_i + shift
+        # x = (f_0..f_{K-1}, u_0..u_{K-1}) is linear in the augmented free energies: du_i = <A>_i (df_i - df_{K+i})
+        J = np.zeros((2 * K, 2 * K))
+        J[:K, :K] = np.eye(K)
+        J[K:, :K] = np.diag(A_i)
+        J[K:, K:] = -np.diag(A_i)
+        C = J @ Theta @ J.T
+
+        def diff_and_err(value, L):                                   # value_j - value_i and its error; L maps x -> value
+            cov = L @ C @ L.T
+            d2 = np.diag(cov)[:, None] + np.diag(cov)[None, :] - 2.0 * cov
+            d2 = np.where(np.abs(d2) < 1e-14, 0.0, d2)
+            with np.errstate(invalid='ignore'):
+                err = np.sqrt(d2)
+            np.fill_diagonal(err, 0.0)
+            return value[None, :] - value[:, None], err
+        Lf = np.concatenate([np.eye(K), np.zeros((K, K))], axis=1)
+        Lu = np.concatenate([np.zeros((K, K)), np.eye(K)], axis=1)
+        Df, dDf = diff_and_err(self.f_k, Lf)
+        Du, dDu = diff_and_err(u_i, Lu)
+        Ds, dDs = diff_and_err(u_i - self.f_k, Lu - Lf)
+        return dict(Delta_f=Df, dDelta_f=dDf, Delta_u=Du, dDelta_u=dDu, Delta_s=Ds, dDelta_s=dDs)
 
     def compute_free_energy_differences(self):
         """(Delta_f_ij, dDelta_f_ij) with Delta_f_ij[i, j] = f_j - f_i (pymbar's convention)."""
@@ -399,6 +442,16 @@ class MultiStateSamplerAnalyzer:
         mu = -np.sort(-np.linalg.eigvals(t_ij))
         g = statistical_inefficiency_multiple(np.transpose(states[number_equilibrated:]))
         return self.MixingStatistics(transition_matrix=t_ij, eigenvalues=mu, statistical_inefficiency=g)
+
+    def get_enthalpy(self):
+        """(Delta_u_ij, dDelta_u_ij) of the reduced enthalpy <u_i>_i, :1988-2005."""
+        r = self.mbar.compute_entropy_and_enthalpy()
+        return r['Delta_u'], r['dDelta_u']
+
+    def get_entropy(self):
+        """(Delta_s_ij, dDelta_s_ij) of the reduced entropy s_i = <u_i>_i - f_i, :2007-2024."""
+        r = self.mbar.compute_entropy_and_enthalpy()
+        return r['Delta_s'], r['dDelta_s']
 
     def get_free_energy(self):
         """(Delta_f_ij, dDelta_f_ij) in kT between all (unsampled + sampled) states (:1958-2003)."""

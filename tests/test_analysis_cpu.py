@@ -287,3 +287,29 @@ def test_mixing_statistics_from_the_stored_state_trajectory(tmp_path):
         series.append(x)
     g = an.statistical_inefficiency_multiple(series)
     assert abs(g - 4.0) < 0.5
+
+
+def test_mbar_enthalpy_and_entropy_of_harmonic_oscillators():
+    """tests/test_sampling.py:404-437: Delta H and Delta S within 6 standard errors.  For u_k = |x|^2 / (2 sigma_k^2) in
+    3-D, <u_k>_k = 3/2 for every k (equipartition), so Delta_u = 0 and Delta_s = -Delta_f; the reported errors are compared
+    with the scatter over repetitions, and the free-energy part agrees with compute_free_energy_differences."""
+    sigmas = [1.0 + 0.2 * k for k in range(7)]
+    sampled = [1, 2, 3, 4, 5]
+    rng = np.random.default_rng(12)
+    du, ddu, ds, dds = [], [], [], []
+    for rep in range(16):
+        u_kn, N_k, f_exact = _harmonic_samples(sigmas, sampled, 400, rng)
+        mbar = an.MBAR(u_kn, N_k)
+        r = mbar.compute_entropy_and_enthalpy()
+        D, dD = mbar.compute_free_energy_differences()
+        assert np.allclose(r['Delta_f'], D) and np.allclose(r['dDelta_f'], dD, atol=1e-10)
+        exact_f = f_exact[None, :] - f_exact[:, None]
+        for key, dkey, exact in (('Delta_u', 'dDelta_u', np.zeros((7, 7))), ('Delta_s', 'dDelta_s', -exact_f)):
+            nz = r[dkey] > 0
+            assert np.all(np.abs(r[key] - exact)[nz] / r[dkey][nz] < 6.0), key
+            assert np.allclose(r[key], -r[key].T)
+        du.append(r['Delta_u'][1, 5]); ddu.append(r['dDelta_u'][1, 5]); ds.append(r['Delta_s'][1, 5]); dds.append(r['dDelta_s'][1, 5])
+    assert 0.5 < np.mean(ddu) / np.std(du, ddof=1) < 2.0
+    assert 0.5 < np.mean(dds) / np.std(ds, ddof=1) < 2.0
+    # identity Delta_s = Delta_u - Delta_f holds for the estimates themselves
+    assert np.allclose(r['Delta_s'], r['Delta_u'] - r['Delta_f'], atol=1e-12)
