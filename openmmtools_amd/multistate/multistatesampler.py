@@ -27,8 +27,8 @@ class MultiStateSampler:
     def __init__(self, mcmc_moves=None, number_of_iterations=1, locality=None,
                  online_analysis_interval=200, online_analysis_target_error=0.0,
                  online_analysis_minimum_iterations=200, engine=None, seed=0xC0FFEE, comm=None):
-        if locality is not None:
-            raise NotImplementedError('only global neighborhoods (locality=None) are implemented')
+        if locality is not None and ((type(locality) != int) or (locality <= 0)):      # :504-508
+            raise ValueError('locality must be an int > 0')
         # multistatesampler.py:478-501
         if online_analysis_interval is not None and (type(online_analysis_interval) != int or online_analysis_interval < 1):
             raise ValueError('online_analysis_interval must be an integer >=1 or None')
@@ -214,7 +214,7 @@ class MultiStateSampler:
 
     def _options(self):
         """What from_storage needs to rebuild the sampler (multistatesampler.py:1145-1167 _store_options)."""
-        kwargs = dict(online_analysis_interval=self.online_analysis_interval,
+        kwargs = dict(locality=self.locality, online_analysis_interval=self.online_analysis_interval,
                       online_analysis_target_error=self.online_analysis_target_error,
                       online_analysis_minimum_iterations=self.online_analysis_minimum_iterations)
         kwargs.update(self._ctor_kwargs())
@@ -567,12 +567,19 @@ class MultiStateSampler:
             self._last_mbar_f_k = np.zeros([self.n_states], np.float64)
         logZ = -self._last_mbar_f_k
         u = self._energy_thermodynamic_states
-        # log P_k = -u_k - logsumexp(-u): global neighbourhoods, zero log weights (:1647-1653)
-        m = np.max(-u, axis=1, keepdims=True)
-        log_P = -u - (m + np.log(np.sum(np.exp(-u - m), axis=1, keepdims=True)))
-        P = np.exp(log_P)
-        for r in range(self.n_replicas):                     # sequential accumulation, the reference's order
-            logZ += gamma * P[r]
+        if self.locality is None:
+            # log P_k = -u_k - logsumexp(-u): global neighbourhoods, zero log weights (:1647-1653)
+            m = np.max(-u, axis=1, keepdims=True)
+            log_P = -u - (m + np.log(np.sum(np.exp(-u - m), axis=1, keepdims=True)))
+            P = np.exp(log_P)
+            for r in range(self.n_replicas):                 # sequential accumulation, the reference's order
+                logZ += gamma * P[r]
+        else:
+            for r, state in enumerate(self._replica_thermodynamic_states):
+                nb = self._neighborhood(state)
+                lp = -u[r, nb]
+                lp = lp - (lp.max() + np.log(np.sum(np.exp(lp - lp.max()))))
+                logZ[nb] += gamma * np.exp(lp)
         logZ[:] -= logZ[0]
         self._last_mbar_f_k = -logZ
         free_energy = self._last_mbar_f_k[-1] - self._last_mbar_f_k[0]
@@ -669,10 +676,26 @@ class MultiStateSampler:
         else:
             full = self._gather_rows()
         full = np.asarray(full)
-        self._energy_thermodynamic_states[:, :] = full[:, :K]
         if U:
             self._energy_unsampled_states[:, :] = full[:, K:]
-        self._neighborhoods[:, :] = 1                                   # :1441-1444 with locality None
+        if self.locality is None:
+            self._energy_thermodynamic_states[:, :] = full[:, :K]
+            self._neighborhoods[:, :] = 1                               # :1441-1444: global neighbourhoods
+            return
+        # local neighbourhoods (:1441-1458): only the energies of the states within +-locality of a replica's state are
+        # refreshed and flagged; the device computes whole rows anyway, so this is a mask on what is kept
+        self._neighborhoods[:, :] = 0
+        for r, state in enumerate(self._replica_thermodynamic_states):
+            nb = self._neighborhood(state)
+            self._neighborhoods[r, nb] = 1
+            self._energy_thermodynamic_states[r, nb] = full[r, nb]
+
+    def _neighborhood(self, state_index):
+        """:1263-1281."""
+        if self.locality is None:
+            return list(range(0, self.n_states))
+        state_index = int(state_index)
+        return list(range(max(0, state_index - self.locality), min(self.n_states, state_index + self.locality + 1)))
 
     def _gather_rows(self):
         """Multi-rank: each rank computes its [R_local, K_total] rows; RCCL/gloo all-gather."""

@@ -228,3 +228,41 @@ def test_equilibrate_with_temporary_moves_restores_the_production_moves(tmp_path
     assert eng.integ_args == ('V R O R V', 0.001, 1.0, 10)
     s.run()
     assert s.iteration == 2 and seen[-1] == ('V R O R V', 0.001, 1.0, 10)
+
+
+def test_local_neighborhoods_mask_energies_and_online_analysis(tmp_path):
+    """multistatesampler.py:1263-1281, 1441-1458, 1644-1653: with ``locality`` only the energies of states within
+    +-locality of a replica's current state are refreshed and flagged (the rest keep their previous values), the
+    online estimate only touches those states, mixing must be swap-neighbors and MBAR is refused."""
+    from openmmtools_amd.multistate import MultiStateReporter
+    ho, ts, ss = _ho_states(6)
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=10, reassign_velocities=True, splitting='V R O R V')
+    with pytest.raises(ValueError):
+        ParallelTemperingSampler(mcmc_moves=move, locality=0, engine=OracleEngine())
+    with pytest.raises(ValueError):
+        ParallelTemperingSampler(mcmc_moves=move, locality=2, replica_mixing_scheme='swap-all', engine=OracleEngine())
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=3, engine=OracleEngine(), seed=4, locality=1,
+                                 replica_mixing_scheme='swap-neighbors', online_analysis_interval=50)
+    rep = MultiStateReporter(str(tmp_path / 'store'), checkpoint_interval=10)
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=600.0, n_temperatures=6)
+    assert s._neighborhood(0) == [0, 1] and s._neighborhood(3) == [2, 3, 4] and s._neighborhood(5) == [4, 5]
+    prev = None
+    for it in range(3):
+        s.run(1)
+        nb = s._neighborhoods.astype(bool)
+        states_now = s.replica_thermodynamic_states
+        for r in range(6):
+            assert np.flatnonzero(nb[r]).tolist() == s._neighborhood(states_now[r])
+        full = s._engine.compute_energies()
+        assert np.allclose(s.energy_thermodynamic_states[nb], full[nb], rtol=1e-13)
+        if prev is not None:
+            assert np.array_equal(s.energy_thermodynamic_states[~nb], prev[~nb])       # stale entries are left alone
+        prev = s.energy_thermodynamic_states.copy()
+        assert np.abs(np.diff(np.sort(states_now))).max() == 1                          # still a permutation
+    e, stored_nb, _ = rep.read_energies()
+    assert np.array_equal(stored_nb[-1].astype(bool), nb)
+    assert s._last_mbar_f_k is not None and np.isfinite(s._last_mbar_f_k).all() and s._last_mbar_f_k[0] == 0.0
+    with pytest.raises(Exception, match='non-global locality'):
+        s._offline_analysis()
+    assert s.options['locality'] == 1
