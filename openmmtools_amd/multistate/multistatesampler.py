@@ -500,9 +500,11 @@ class MultiStateSampler:
         else:
             iteration_limit = min(self._iteration + n_iterations, self.number_of_iterations)
         t_run = time.time()
+        run_initial_iteration = self._iteration
         while not self._is_completed(iteration_limit):                 # :766
             t0 = time.time()
             self._iteration += 1                                       # :768
+            logger.info('Iteration %d/%s', self._iteration, iteration_limit)
             self._replica_thermodynamic_states = self._mix_replicas()  # :776
             t1 = time.time()
             self._propagate_replicas()                                 # :779
@@ -511,22 +513,38 @@ class MultiStateSampler:
             t3 = time.time()
             self._report_iteration()                                   # :785
             self._update_analysis()                                    # :788
-            self._update_timing(t0, t1, t2, t3, t_run)                 # :793
+            self._update_timing(t0, t1, t2, t3, t_run, run_initial_iteration, iteration_limit)   # :793
+            logger.info('Iteration took %.3fs.', self._timing_data['iteration_seconds'])
+            if 'estimated_time_remaining' in self._timing_data:
+                logger.info('Estimated completion in %s, at %s (consuming total wall clock time %s).',
+                            self._timing_data['estimated_time_remaining'], self._timing_data['estimated_localtime_finish_date'],
+                            self._timing_data['estimated_total_time'])
             self._check_nan_energy()                                   # :804
 
-    def _update_timing(self, t0, t1, t2, t3, t_run):
-        """multistatesampler.py:1766-1803 (subset)."""
+    def _update_timing(self, t0, t1, t2, t3, t_run, run_initial_iteration=None, iteration_limit=None):
+        """multistatesampler.py:1766-1803: per-iteration and average wall time, completion estimate, ns/day over all
+        replicas' dynamic moves (plus the mix / propagate / energy split of the iteration, which the reference only logs)."""
+        import datetime
         d = self._timing_data
         d['iteration_seconds'] = t3 - t0
         d['mixing_seconds'] = t1 - t0
         d['propagation_seconds'] = t2 - t1
         d['energy_seconds'] = t3 - t2
-        n = d.get('n_timed', 0) + 1
+        n = (self._iteration - run_initial_iteration) if run_initial_iteration is not None else d.get('n_timed', 0) + 1
         d['n_timed'] = n
-        d['average_seconds_per_iteration'] = (time.time() - t_run) / n if n else 0.0
-        move = self._engine_move()
-        ns_per_iter = (move.timestep * move.n_steps * 1e-3 * self.n_replicas) if move is not None else 0.0
-        d['ns_per_day'] = ns_per_iter / d['iteration_seconds'] * 86400.0 if d['iteration_seconds'] > 0 else 0.0
+        d['average_seconds_per_iteration'] = (time.time() - t_run) / n if n > 0 else 0.0
+        if iteration_limit is not None and np.isfinite(iteration_limit):
+            remaining = datetime.timedelta(seconds=d['average_seconds_per_iteration'] * (iteration_limit - self._iteration))
+            d['estimated_time_remaining'] = str(remaining)
+            d['estimated_localtime_finish_date'] = (datetime.datetime.now() + remaining).strftime('%Y-%b-%d-%H:%M:%S')
+            d['estimated_total_time'] = str(datetime.timedelta(seconds=d['average_seconds_per_iteration'] * iteration_limit))
+        ns_per_iter = 0.0
+        for state_move in self._mcmc_moves:                                # one (possibly composite) move per replica
+            for move in self._flatten(state_move):
+                if hasattr(move, 'timestep') and hasattr(move, 'n_steps'):
+                    ns_per_iter += move.timestep * 1e-3 * move.n_steps      # timestep in ps
+        avg = d['average_seconds_per_iteration']
+        d['ns_per_day'] = ns_per_iter / (avg / 86400.0) if avg > 0 else 0.0
 
     def _report_iteration(self):
         if self._reporter is not None:
@@ -621,7 +639,7 @@ class MultiStateSampler:
                     'mbar_analysis': {'free_energy_in_kT': fe, 'standard_error_in_kT': float(err),
                                       'number_of_uncorrelated_samples': float(analysis._equilibration_data[-1]),
                                       'n_equilibrium_iterations': int(n_eq), 'statistical_inefficiency': float(g_t)},
-                    'timing_data': {k: float(v) for k, v in self._timing_data.items()}})
+                    'timing_data': {k: (v if isinstance(v, str) else float(v)) for k, v in self._timing_data.items()}})
         if self._comm.world_size > 1:
             err = self._comm.broadcast_object(err)
         return err

@@ -266,3 +266,22 @@ def test_local_neighborhoods_mask_energies_and_online_analysis(tmp_path):
     with pytest.raises(Exception, match='non-global locality'):
         s._offline_analysis()
     assert s.options['locality'] == 1
+
+
+def test_timing_data_fields():
+    """multistatesampler.py:1766-1803: average over the iterations of THIS run() call, completion estimate, ns/day over the
+    dynamic moves of all states."""
+    ho, ts, ss = _ho_states(3)
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
+                                              n_steps=10, reassign_velocities=True, splitting='V R O R V')
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=4, engine=OracleEngine(), seed=1)
+    s.create(ts, [ss], min_temperature=300.0, max_temperature=400.0, n_temperatures=3)
+    s.run(2)
+    d = dict(s._timing_data)
+    assert d['n_timed'] == 2 and d['average_seconds_per_iteration'] > 0 and d['iteration_seconds'] > 0
+    for k in ('estimated_time_remaining', 'estimated_localtime_finish_date', 'estimated_total_time'):
+        assert isinstance(d[k], str)
+    # 3 states x 10 steps x 2 fs = 6e-5 ns per iteration
+    assert np.isclose(d['ns_per_day'], 6e-5 / (d['average_seconds_per_iteration'] / 86400.0), rtol=1e-12)
+    s.run()                                               # a second run() averages over its own two iterations
+    assert s.iteration == 4 and s._timing_data['n_timed'] == 2

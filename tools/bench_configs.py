@@ -33,7 +33,7 @@ def run(name, sampler, n_iter, warm=1):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_iter
     print(json.dumps(dict(config=name, iterations_per_s=1.0 / dt, ms_per_iteration=1e3 * dt, replicas=sampler.n_replicas,
-                          states=sampler.n_states, timing={k: float(v) for k, v in sampler._timing_data.items()})), flush=True)
+                          states=sampler.n_states, timing={k: (v if isinstance(v, str) else float(v)) for k, v in sampler._timing_data.items()})), flush=True)
 
 
 def main():
