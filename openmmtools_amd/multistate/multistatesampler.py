@@ -16,6 +16,7 @@ import logging
 import numpy as np
 
 from .. import mcmc, unit
+from ..utils import with_timer
 from ..system import system_to_desc
 from .utils import SimulationNaNError
 from .comm import SingleProcessComm
@@ -433,6 +434,7 @@ class MultiStateSampler:
         self._K_total = len(all_states)
 
     # ---- run / equilibrate ------------------------------------------------------------------
+    @with_timer('Minimizing all replicas')
     def minimize(self, tolerance=1.0 * unit.kilojoules_per_mole / unit.nanometers, max_iterations=0):
         """multistatesampler.py:611-647: FIRE-minimise every replica at its current state (one batched device call per
         rank instead of one Context per replica), store the minimised positions in the sampler states and in storage."""
@@ -546,6 +548,7 @@ class MultiStateSampler:
         avg = d['average_seconds_per_iteration']
         d['ns_per_day'] = ns_per_iter / (avg / 86400.0) if avg > 0 else 0.0
 
+    @with_timer('Writing iteration information to storage')
     def _report_iteration(self):
         if self._reporter is not None:
             self._reporter.write_iteration(self)
@@ -577,6 +580,7 @@ class MultiStateSampler:
             if err is not None:
                 self._last_err_free_energy = err
 
+    @with_timer('Computing online free energy estimate')
     def _online_analysis(self, gamma0=1.0):
         """:1625-1675.  logZ_k += gamma * P(k | x_r) / pi_k over the replicas (pi_k = 1, gamma = gamma0 / (iteration + 1)),
         then anchored at state 0.  Replicated on every rank from the replicated u_kl (the reference: rank 0 + broadcast)."""
@@ -607,6 +611,7 @@ class MultiStateSampler:
                                                                 free_energy=(free_energy, self._last_err_free_energy))
         return self._last_err_free_energy
 
+    @with_timer('Computing offline free energy estimate')
     def _offline_analysis(self):
         """:1522-1620: MBAR on the stored, equilibrated and decorrelated energies; needs a reporter.  Returns the standard
         error of f_last - f_first in kT, or None when the estimate cannot be computed yet (under-sampled)."""
@@ -665,6 +670,7 @@ class MultiStateSampler:
         self._n_proposed_matrix[:, :] = 0
         return self._replica_thermodynamic_states
 
+    @with_timer('Propagating all replicas')
     def _propagate_replicas(self, rng_iteration=None):
         """multistatesampler.py:1287-1337 for every local replica in one device call."""
         it = self._iteration if rng_iteration is None else rng_iteration
@@ -685,6 +691,7 @@ class MultiStateSampler:
             for move in self._flatten(state_move):
                 move.statistics = dict(n_attempts=move.statistics.get('n_attempts', 0) + 1)
 
+    @with_timer('Computing energy matrix')
     def _compute_energies(self):
         """multistatesampler.py:1436-1494: fill u_kl for all replicas (global neighborhoods)."""
         K, U = self.n_states, len(self._unsampled_states)

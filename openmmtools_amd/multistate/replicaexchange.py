@@ -8,6 +8,7 @@ validation (:220-234), round-robin tiling of sampler states (:239-253) and ``_mi
 import numpy as np
 from .multistatesampler import MultiStateSampler
 from .comm import SingleProcessComm
+from ..utils import time_it
 
 
 class ReplicaExchangeSampler(MultiStateSampler):
@@ -49,7 +50,8 @@ class ReplicaExchangeSampler(MultiStateSampler):
             self._n_accepted_matrix[:, :] = 0
             self._n_proposed_matrix[:, :] = 0
             return self._replica_thermodynamic_states
-        labels, nacc, nprop = self._device_mix(self._replica_mixing_scheme, it)
+        with time_it('Mixing of replicas'):                                   # replicaexchange.py:265
+            labels, nacc, nprop = self._device_mix(self._replica_mixing_scheme, it)
         self._n_accepted_matrix[:, :] = nacc[:K, :K]
         self._n_proposed_matrix[:, :] = nprop[:K, :K]
         n_prop = self._n_proposed_matrix.sum()
