@@ -67,6 +67,12 @@ class TorchDistributedComm:
         K = rows.shape[1]
         if out is None:
             out = torch.empty((n_replicas, K), dtype=rows.dtype, device=rows.device)
+        if rows.is_cuda and self.dist.get_backend(self.group) != 'nccl':
+            # a host-only backend (gloo: several ranks sharing one GPU in the tests, or a CPU fabric): stage the
+            # <= 128 KiB of rows through host memory; the gathered matrix still ends up on the device for the mix
+            full = self.all_gather_rows(rows.cpu(), n_replicas)
+            out.copy_(full)
+            return out
         if len(set(self._counts)) == 1:
             self.dist.all_gather_into_tensor(out, rows.contiguous(), group=self.group)
         else:

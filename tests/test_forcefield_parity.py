@@ -253,3 +253,81 @@ def test_newton3_lists_match_full_lists(hip_engine_factory, monkeypatch, system_
     (f1, u1), (f0, u0) = res
     assert np.abs(f1 - f0).max() < 2e-5 * np.abs(f0).max()
     assert np.allclose(u1, u0, rtol=1e-9, atol=1e-6)
+
+
+def test_config4_all_64_alchemical_states_ukl(hip_engine_factory):
+    """BASELINE config 4 AT ITS STATED SIZE: CB7:B2 with the full 64-state ladder (lambda_electrostatics 1 -> 0 over 32
+    states, then lambda_sterics 1 -> 0 over 32) — every column of two replicas' u_kl rows against
+    the oracle, which recomputes each state from scratch (reduced_potential_at_states, states.py:911-992).  The device
+    fits U(lambda_e) from three mesh passes and evaluates the soft-core pairs for all lambda_s in one pass; this is the
+    check that the fit and the one-pass evaluation hold on all 64 states, not on a 7-state sample."""
+    hg = ts.HostGuestExplicit()
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(hg.system, region)
+    lam_e = np.concatenate([np.linspace(1.0, 0.0, 32), np.zeros(32)])
+    lam_s = np.concatenate([np.ones(32), np.linspace(1.0, 0.0, 32)])
+    K = 64
+    nb = [f for f in system.getForces() if hasattr(f, 'particles') and hasattr(f, 'exceptions')][0]
+    V = np.prod(np.diag(system.getDefaultPeriodicBoxVectors()))
+    econst = alchemy.alchemical_long_range_constants(system, nb, lam_s, V)
+    eng = hip_engine_factory()
+    desc = system_to_desc(system)
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 300.0)
+    eng.set_states(np.full(K, beta), lam_s, lam_e, econst)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 5, True, 1e-8)
+    eng.seed(SEED)
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (2, 1))
+    x = np.stack([hg.positions, hg.positions + 0.001 * np.random.default_rng(0).normal(size=hg.positions.shape)])
+    labels = np.array([10, 50])
+    eng.set_replicas(2, 0, x, None, box, labels)
+    rows = eng.compute_energies()
+    assert rows.shape == (2, 64)
+    xd = eng.get_replicas()[0]
+    ff = ForceFieldOracle(desc)
+    for r in range(2):
+        ref = beta * (ff.state_energies(xd[r], box[r], lam_s, lam_e) + econst)
+        assert np.allclose(rows[r], ref, rtol=1e-5), np.abs(rows[r] / ref - 1).max()
+        # what mixing consumes are differences between neighbouring states: they must survive the cancellation
+        d_dev, d_ref = np.diff(rows[r]), np.diff(ref)
+        assert np.abs(d_dev - d_ref).max() < 0.05, np.abs(d_dev - d_ref).max()
+
+
+def test_config5_dhfr_128_state_sams_row_and_jump(hip_engine_factory):
+    """BASELINE config 5 AT ITS STATED SHAPE: DHFR (23 558 atoms) with a 128-state ladder (temperatures, BASELINE.md
+    section 4 leaves the ladder to us: geomspace 300-400 K) and the SAMS global jump.  Two replicas: the 128-column u_kl
+    rows against the oracle's potential, then one remd_mix(SAMS) on the device matrix against the C oracle's jump
+    (which the reference-executed fixture pins) on the same rows — labels and count matrices bit-exact."""
+    import oracle
+    dh = ts.DHFRExplicit()
+    K = 128
+    T = np.geomspace(300.0, 400.0, K)
+    beta = 1.0 / (KB * T)
+    eng = hip_engine_factory()
+    desc = system_to_desc(dh.system)
+    eng.set_system(desc)
+    eng.set_states(beta, None, None, None)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 5, True, 1e-8)
+    eng.seed(SEED)
+    R = 2
+    box = np.tile(np.diag(dh.system.getDefaultPeriodicBoxVectors()), (R, 1))
+    x = np.stack([dh.positions, dh.positions + 0.001 * np.random.default_rng(1).normal(size=dh.positions.shape)])
+    labels = np.array([3, 100], dtype=np.int64)
+    eng.set_replicas(R, 0, x, None, box, labels)
+    rows, U = eng.compute_energies(want_potential=True)
+    assert rows.shape == (R, K)
+    ff = ForceFieldOracle(desc)
+    xd = eng.get_replicas()[0]
+    for r in range(R):
+        e_ref = ff.potential(xd[r], box[r])
+        assert np.isclose(U[r], e_ref, rtol=1e-5), (U[r], e_ref)
+        assert np.allclose(rows[r], beta * e_ref, rtol=1e-5)
+        assert np.allclose(rows[r], beta * U[r], rtol=1e-14)        # paralleltempering.py:206-215 outer product
+    # the jump: energies this large make the categorical draw degenerate unless the weights compensate (as SAMS's
+    # adapted weights do): log_w = +u of a reference replica, so that log P spans a few kT across the ladder
+    logw = rows[0] + np.linspace(0.0, 3.0, K)
+    got = eng.mix('sams-global-jump', 7, labels, R=R, K=K, log_weights=logw)
+    ref = oracle.mix('sams-global-jump', SEED, 7, rows, labels, log_weights=logw)
+    assert np.array_equal(got[0], ref[0])
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    assert np.allclose(got[3], ref[3], rtol=0, atol=1e-9)      # log P of O(1e5)-sized arguments: 1e-9 absolute
