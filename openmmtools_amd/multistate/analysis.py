@@ -316,7 +316,12 @@ class MultiStateSamplerAnalyzer:
         """[replica, state, iteration] arrays like the reference's ``_read_energies`` (:1353-1412)."""
         e, nb, eu = self._reporter.read_energies()
         states = self._reporter.read_replica_thermodynamic_states()
-        n = e.shape[0] if self._max_n_iterations is None else min(e.shape[0], self._max_n_iterations + 1)
+        # records beyond the last completely written iteration are stale (a resume from an earlier checkpoint leaves the
+        # abandoned branch's records behind): the reference caps at the last good iteration (multistateanalyzer.py:1353-1412)
+        last = self._reporter.read_last_iteration(last_checkpoint=False)
+        n = e.shape[0] if last is None else min(e.shape[0], int(last) + 1)
+        if self._max_n_iterations is not None:
+            n = min(n, self._max_n_iterations + 1)
         return (np.moveaxis(e[:n], 0, -1), np.moveaxis(eu[:n], 0, -1), np.moveaxis(nb[:n], 0, -1),
                 np.moveaxis(states[:n], 0, -1))
 

@@ -50,6 +50,20 @@ class _RecordFile:
         return data[index]
 
 
+class _RestrictedUnpickler(pickle.Unpickler):
+    """The stored objects are this package's own state / move / System classes plus numpy arrays and builtin containers;
+    nothing else may be constructed when a storage directory is opened (the reference stores YAML / XML, data only)."""
+    _MODULES = ('openmmtools_amd', 'numpy', 'collections', 'copyreg')
+    _BUILTINS = {'dict', 'list', 'tuple', 'set', 'frozenset', 'int', 'float', 'complex', 'str', 'bytes', 'bytearray', 'bool',
+                 'slice', 'range', 'object'}
+
+    def find_class(self, module, name):
+        root = module.split('.')[0]
+        if root in self._MODULES or (module == 'builtins' and name in self._BUILTINS):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError('storage refers to %s.%s, which is not a class this package stores' % (module, name))
+
+
 class MultiStateReporter:
     """multistatereporter.py:69.  ``storage`` is a path; the analysis store is ``<storage>`` (a directory), the
     checkpoint store ``<storage stem>_checkpoint`` beside it (the reference: ``<name>.nc`` and
@@ -89,10 +103,12 @@ class MultiStateReporter:
         if mode == 'r' and not self.storage_exists():
             raise IOError('no storage at {}'.format(self._storage_analysis))
         if mode == 'w':
+            # start a fresh store: remove only the files THIS format owns (never the contents of an unrelated directory)
             for d in (self._storage_analysis, self._storage_checkpoint):
                 if os.path.isdir(d):
                     for f in os.listdir(d):
-                        os.remove(os.path.join(d, f))
+                        if self._owns(f):
+                            os.remove(os.path.join(d, f))
         if mode in ('w', 'a'):
             os.makedirs(self._storage_analysis, exist_ok=True)
             os.makedirs(self._storage_checkpoint, exist_ok=True)
@@ -103,6 +119,13 @@ class MultiStateReporter:
                 self._meta = json.load(fh)
             self._checkpoint_interval = int(self._meta.get('checkpoint_interval', self._checkpoint_interval))
             self._declare()
+
+    _OWNED_SUFFIXES = ('.f8', '.f4', '.i1', '.i4', '.pkl', '.json', '.yaml', '.npz')
+
+    @classmethod
+    def _owns(cls, filename):
+        """File names this container writes: typed record files, pickled objects, meta.json, the real-time YAML."""
+        return filename.endswith(cls._OWNED_SUFFIXES)
 
     def close(self):
         self._open_mode = None
@@ -152,7 +175,7 @@ class MultiStateReporter:
 
     def _read_object(self, name):
         with open(os.path.join(self._storage_analysis, name + '.pkl'), 'rb') as fh:
-            return pickle.load(fh)
+            return _RestrictedUnpickler(fh).load()
 
     def write_thermodynamic_states(self, thermodynamic_states, unsampled_states):
         self._write_object('thermodynamic_states', (list(thermodynamic_states), list(unsampled_states)))

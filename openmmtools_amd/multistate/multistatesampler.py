@@ -193,6 +193,11 @@ class MultiStateSampler:
                                unsampled_thermodynamic_states=unsampled_thermodynamic_states, metadata=metadata)
         self._initialize_reporter(storage)
         self._initialize_engine()
+        self._iteration0_energies_reported = False
+        # multistatesampler.py:588-609 (_initialize_reporter -> _report_iteration): iteration 0 -- initial positions, state
+        # indices, zeroed energies -- is on disk from creation on (SAMS counts the initial states in its histogram here,
+        # sams.py:381-393); run() rewrites the energies of iteration 0 (:738-753)
+        self._report_iteration()
 
     def _initialize_reporter(self, storage):
         """multistatesampler.py:1169-1187: a path or a MultiStateReporter; states, moves, options and metadata are
@@ -205,6 +210,9 @@ class MultiStateSampler:
         self._reporter = rep if hasattr(rep, 'write_iteration') else None
         if self._reporter is None or not isinstance(rep, MultiStateReporter) or self._comm.rank != 0:
             return
+        if rep.storage_exists():
+            # multistatesampler.py:588: never write over an existing simulation
+            raise RuntimeError('Storage file {} already exists; cowardly refusing to overwrite.'.format(rep.filepath))
         if not rep.is_open() or rep._open_mode == 'r':
             rep.open('w')
         rep.initialize(self.n_replicas, self.n_states, len(self._unsampled_states), self._thermodynamic_states[0].n_particles)
@@ -238,6 +246,8 @@ class MultiStateSampler:
         if it is None:
             raise IOError('storage {} holds no complete checkpoint'.format(rep.filepath))
         opts = rep.read_dict('options')
+        if not str(opts['module']).startswith('openmmtools_amd.'):
+            raise TypeError('storage names a sampler class outside this package: {}'.format(opts['module']))
         klass = getattr(importlib.import_module(opts['module']), opts['cls'])
         if not issubclass(klass, cls):
             raise TypeError('storage was written by {}, not a {}'.format(opts['cls'], cls.__name__))
@@ -492,11 +502,15 @@ class MultiStateSampler:
         """multistatesampler.py:724-804."""
         if self._thermodynamic_states is None:
             raise RuntimeError('call create() first')
-        if self._iteration == 0 and not self._energies_computed():
-            self._compute_energies()                                   # :738-753
+        if self._iteration == 0 and not getattr(self, '_iteration0_energies_reported', False):
+            # :738-753: at iteration 0 the starting energies (of the minimised / equilibrated structures) are ALWAYS
+            # computed and written, whatever equilibrate() or minimize() did before
+            if not self._energies_computed():
+                self._compute_energies()
             self._check_nan_energy()
             if self._reporter is not None:
-                self._reporter.write_iteration(self)                   # iteration 0: initial states and energies
+                self._reporter.write_iteration(self)                   # iteration 0 again, now with the starting energies
+            self._iteration0_energies_reported = True
         if n_iterations is None:
             iteration_limit = self.number_of_iterations
         else:

@@ -49,7 +49,10 @@ class SAMSSampler(ReplicaExchangeSampler):
 
     def _online_data(self):
         """sams.py:618, :681: logZ and log_weights go to storage every iteration; stage bookkeeping with them."""
-        return dict(logZ=self._logZ, log_weights=self.log_weights,
+        # sams.py:618: the stored log_weights of iteration n are the ones the mix of iteration n USED (written before the
+        # update); logZ is the post-update estimate (:381-383) and is what a resume rebuilds the weights from
+        used = getattr(self, '_log_weights_used', None)
+        return dict(logZ=self._logZ, log_weights=self.log_weights if used is None else used,
                     sams_state=dict(stage=self._stage, t0=self._t0, histogram=self._cached_state_histogram.copy(),
                                     iteration=self._iteration))
 
@@ -98,6 +101,7 @@ class SAMSSampler(ReplicaExchangeSampler):
         """sams.py:395-437."""
         it = self._iteration if rng_iteration is None else rng_iteration
         K = self.n_states
+        self._log_weights_used = np.array(self.log_weights, np.float64)
         labels, nacc, nprop = self._device_mix('sams-global-jump', it, log_weights=self.log_weights)
         self._n_accepted_matrix[:, :] = nacc[:K, :K]
         self._n_proposed_matrix[:, :] = nprop[:K, :K]

@@ -296,6 +296,7 @@ def sams_trajectory(R, K, seed, n_iterations, update_stages, flatness_criteria, 
     _, RefSAMS = make_reference_classes(rnd)
     s = RefSAMS(real_np.zeros((R, K)), labels, log_target, gamma0, update_stages, flatness_criteria, flatness_threshold,
                 weight_update_method)
+    s.report()              # create() reports iteration 0 (multistatesampler.py:588-609): the initial states are counted
     frames = []
     for it in range(n_iterations):
         u = f_true[None, :] + rng.normal(scale=1.0, size=(R, K))      # -ln of unnormalised densities + noise

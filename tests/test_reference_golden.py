@@ -97,6 +97,7 @@ def _make_sams(c, engine):
     s._update_log_weights()
     s._cached_state_histogram = np.zeros(K, dtype=int)
     s._replica_thermodynamic_states = np.array(c['frames'][0]['labels_in'], dtype=np.int64)
+    s._report_iteration()          # create() reports iteration 0: SAMS counts the initial states (sams.py:381-393)
     return s
 
 

@@ -108,7 +108,7 @@ def test_sams_online_data_and_resume(tmp_path):
     assert r.iteration == 9
     # sams.py:381-393 / tests/test_sampling.py:2757-2787: the histogram equals np.histogram of the stored labels
     lab = MultiStateReporter(str(tmp_path / 'sams'), open_mode='r').read_replica_thermodynamic_states()
-    counts = np.bincount(lab[1:, 0], minlength=3)             # iteration 0 is the initial state, not a visited one
+    counts = np.bincount(lab[:, 0], minlength=3)              # every stored iteration, the initial one included (reference)
     assert np.array_equal(r._state_histogram, counts)
 
 
@@ -124,3 +124,51 @@ def test_storage_path_string_and_write_mode_guard(tmp_path):
         r.write_last_iteration(1)
     with pytest.raises(IOError):
         MultiStateReporter(str(tmp_path / 'missing'), open_mode='r')
+
+
+def test_create_equilibrate_run_resume_keeps_iteration_zero(tmp_path):
+    """multistatesampler.py:588-609, 738-753: iteration 0 is reported at create() and its energies are rewritten by the
+    first run() whatever happened in between; a resume before the next checkpoint must find the initial permutation."""
+    s, rep = _pt(tmp_path, 4, interval=10)
+    r0 = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r')
+    assert r0.read_last_iteration(last_checkpoint=False) == 0            # on disk right after create()
+    assert r0.read_replica_thermodynamic_states(0).tolist() == [0, 1, 2, 3]
+    s.equilibrate(2)
+    labels_after_equil = s.replica_thermodynamic_states.copy()
+    s.run(3)                                                             # no checkpoint after iteration 0 (interval 10)
+    rd = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r')
+    e, nb, _ = rd.read_energies()
+    assert np.all(nb[0] == 1) and np.isfinite(e[0]).all() and np.abs(e[0]).sum() > 0
+    assert np.array_equal(rd.read_replica_thermodynamic_states(0), labels_after_equil)
+    x0 = np.stack([c.positions for c in rd.read_sampler_states(0)])
+    assert np.abs(x0).sum() > 0                                          # the equilibrated positions, not the initial zeros
+    del s
+    r = ParallelTemperingSampler.from_storage(str(tmp_path / 'pt.nc'), engine=OracleEngine())
+    assert r.iteration == 0
+    assert np.array_equal(r.replica_thermodynamic_states, labels_after_equil)
+    assert sorted(r.replica_thermodynamic_states.tolist()) == [0, 1, 2, 3]
+    r.run(2)
+    assert r.iteration == 2 and sorted(r.replica_thermodynamic_states.tolist()) == [0, 1, 2, 3]
+
+
+def test_create_refuses_to_overwrite_and_open_w_spares_foreign_files(tmp_path):
+    s, rep = _pt(tmp_path, 2)
+    s.run(1)
+    with pytest.raises(RuntimeError, match='refusing to overwrite'):
+        _pt(tmp_path, 2)                                                 # multistatesampler.py:588
+    d = tmp_path / 'other'
+    d.mkdir()
+    (d / 'notes.txt').write_text('mine')
+    (d / 'energies.f8').write_bytes(b'')
+    MultiStateReporter(str(d), open_mode='w')
+    assert (d / 'notes.txt').read_text() == 'mine' and not (d / 'energies.f8').exists()
+
+
+def test_storage_objects_are_unpickled_with_a_whitelist(tmp_path):
+    import pickle, subprocess
+    s, rep = _pt(tmp_path, 2)
+    s.run(1)
+    with open(str(tmp_path / 'pt.nc' / 'metadata.pkl'), 'wb') as fh:
+        pickle.dump(subprocess.Popen, fh)                               # a class reference the format never stores
+    with pytest.raises(pickle.UnpicklingError):
+        MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_dict('metadata')

@@ -81,7 +81,7 @@ def test_sams_histogram_and_weights():
                     flatness_criteria='minimum-visits')
     s.create(sts, [ss], storage=None)
     assert s.n_replicas == 1 and s.n_states == 5
-    seen = []
+    seen = [int(s.replica_thermodynamic_states[0])]        # create() reported iteration 0 (sams.py:381-393 counts it)
     orig_report = s._report_iteration
 
     def rec():
