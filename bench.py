@@ -10,9 +10,17 @@ velocities reassigned each iteration, Philox seed 0xC0FFEE (BASELINE.md section 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Weak scaling: every rank owns 24 replicas of one 24*N-replica ensemble; the only data-path
+Default (weak scaling): every rank owns 24 replicas of one 24*N-replica ensemble; the only data-path
 collective is the RCCL all-gather of u_kl rows.  `value` counts 24-replica-iteration units:
 (R_total / 24) * iterations / s, so that N = 1 is exactly the BASELINE metric.
+
+    --replicas-total T    strong scaling: ONE T-replica ensemble block-sharded over the N ranks
+                          (T = 24: the BASELINE metric as written, "24-replica ..., 1/2/4/8 GPU";
+                           T = 128: the north_star efficiency target, "1->8 GPUs at 128 replicas").
+                          `value` keeps the same unit (T / 24 * iterations / s), `scaling` = "strong".
+
+cpu_baseline: the same iteration through the same C ABI on oracle/_build/libremd_cpu.so (f64, OpenMP over
+replicas, all host cores), timed on a bounded sample (fewer MD steps per iteration, scaled to 500).
 """
 import argparse
 import json
@@ -34,7 +42,6 @@ FLOP_PER_ATOM_NONBONDED = 1.0e4
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector peak = f32-input MFMA peak
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PME_MESH = (75, 75, 72)           # AlanineDipeptideExplicit at ewaldErrorTolerance 1e-5 (system.ewald_parameters)
-HBM_PEAK_GBS = 8000.0
 
 
 def pmc_traffic_bytes(kernel):
@@ -70,33 +77,48 @@ def build_sampler(n_replicas, engine, comm, md_steps):
     return sampler, ts
 
 
-def cpu_baseline(md_steps_sample=60):
-    """The f64 oracle ("port") on the host: a bounded sample of the same workload (one replica, a few
-    g-BAOAB steps + one energy evaluation), extrapolated to 24 replicas x 500 steps per iteration."""
-    from openmmtools_amd import testsystems
-    from openmmtools_amd.system import system_to_desc
-    from oracle import md_oracle as mo
-    from oracle.forcefield import ForceFieldOracle
-    import torch
-    torch.set_num_threads(1)                      # a scalar port: one host core, stated in the result
-    ts = testsystems.AlanineDipeptideExplicit()
-    desc = system_to_desc(ts.system)
-    ff = ForceFieldOracle(desc)
-    box = np.diag(ts.system.getDefaultPeriodicBoxVectors())
-    integ = mo.OracleLangevin(ff, 'V R R O R R V', 0.002, 1.0, md_steps_sample, SEED)
-    kT = mo.KB * 300.0
-    t0 = time.time()
-    v = integ.assign_velocities(ts.positions, kT, 0, 1)
-    x, v = integ.run(ts.positions, v, box, kT, 0, 1)
-    t_steps = time.time() - t0
-    t0 = time.time()
-    ff.potential(x, box)
-    t_energy = time.time() - t0
-    per_iter = REPLICAS_PER_GPU * (MD_STEPS * t_steps / md_steps_sample + t_energy)
-    return dict(value=1.0 / per_iter, unit='iterations/s', cores=1, kind='port',
-                sample='1 replica x %d g-BAOAB steps + 1 energy evaluation of AlanineDipeptideExplicit with the f64 '
-                       'torch/numpy oracle (%.1f s), extrapolated to 24 replicas x %d steps' %
-                       (md_steps_sample, t_steps + t_energy, MD_STEPS))
+def cpu_baseline(n_replicas=REPLICAS_PER_GPU, budget_s=15.0):
+    """The CPU baseline BASELINE.md section 3 names: the same mix -> propagate -> u_kl iteration of the same 24-replica
+    parallel-tempering ensemble, through the same C ABI (include/remd_hip.h) implemented on the CPU by
+    oracle/_build/libremd_cpu.so (f64, cell/Verlet-list direct space, smooth PME with an in-tree FFT, SETTLE/SHAKE,
+    OpenMP over replicas as the reference's mpiplus path distributes replicas over ranks).  Bounded sample: a probe of 2
+    MD steps sizes the sample so that the timed iteration costs about `budget_s` seconds on this box; the propagation
+    time is scaled linearly to 500 steps, mixing and the energy matrix are timed in full."""
+    import oracle
+    from openmmtools_amd._engine import HipEngine          # the ctypes binding; here it loads the CPU library
+    lib_path = os.path.join(os.path.dirname(os.path.abspath(oracle.__file__)), '_build', 'libremd_cpu.so')
+    if not os.path.exists(lib_path):
+        oracle.build()
+
+    def make(md_steps):
+        eng = HipEngine(lib_path=lib_path)
+        eng.is_device = False
+        sampler, _ = build_sampler(n_replicas, eng, None, md_steps)
+        return sampler, eng
+
+    s, eng = make(2)
+    threads = int(eng.lib.remd_cpu_num_threads())
+    t0 = time.perf_counter()
+    s.run(1)                                                # builds lists, meshes, FFT tables; times 2 steps
+    probe = time.perf_counter() - t0
+    per_step = max(1e-4, float(s._timing_data['propagation_seconds']) / 2.0)
+    eng.close()
+    k = int(max(2, min(MD_STEPS, budget_s / per_step)))
+    s, eng = make(k)
+    s.run(1)                                                # warm-up iteration (iteration 0 energies, first lists)
+    t0 = time.perf_counter()
+    s.run(1)
+    sample_s = time.perf_counter() - t0
+    td = s._timing_data
+    t_mix, t_prop, t_en = float(td['mixing_seconds']), float(td['propagation_seconds']), float(td['energy_seconds'])
+    per_iter = t_mix + t_prop * (MD_STEPS / float(k)) + t_en
+    eng.close()
+    return dict(value=1.0 / per_iter, unit='iterations/s', cores=min(threads, n_replicas), kind='port',
+                threads_available=threads, seconds_per_iteration=per_iter,
+                sample='one full mix -> propagate -> u_kl iteration of the %d-replica AlanineDipeptideExplicit ensemble on '
+                       'libremd_cpu.so (same C ABI, f64, OpenMP over replicas) with %d of %d MD steps (%.1f s measured; '
+                       'propagation scaled x%.1f, mixing %.4f s and energy matrix %.3f s in full; probe %.1f s)' %
+                       (n_replicas, k, MD_STEPS, sample_s, MD_STEPS / float(k), t_mix, t_en, probe))
 
 
 def main():
@@ -106,6 +128,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--md-steps', type=int, default=MD_STEPS, help='MD steps per iteration (500 = BASELINE)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--replicas-total', type=int, default=0,
+                    help='strong scaling: one ensemble of this many replicas sharded over the ranks (24 = the BASELINE '
+                         'metric as written, 128 = the north_star efficiency target); 0 = weak scaling, 24 per GPU')
     args = ap.parse_args()
 
     import torch
@@ -134,8 +159,12 @@ def main():
     from openmmtools_amd._engine import HipEngine
     stream = torch.cuda.current_stream().cuda_stream
     engine = HipEngine(device=local_rank, stream=stream)
-    n_replicas = REPLICAS_PER_GPU * world
+    strong = args.replicas_total > 0
+    n_replicas = args.replicas_total if strong else REPLICAS_PER_GPU * world
+    if n_replicas < world:
+        raise SystemExit('--replicas-total must be at least the number of ranks')
     sampler, ts = build_sampler(n_replicas, engine, comm, args.md_steps)
+    n_local = sampler._r_count                  # replicas on this rank (block partition, comm.py)
     n_atoms = ts.system.getNumParticles()
 
     def sync():
@@ -169,7 +198,7 @@ def main():
         n_xy, ms_xy = engine.profile_get('pme_xy')
         roof_nb = roof_xy = None
         if n_launch > 0:
-            flops = FLOP_PER_ATOM_NONBONDED * n_atoms * REPLICAS_PER_GPU
+            flops = FLOP_PER_ATOM_NONBONDED * n_atoms * n_local
             avg_ms = (ms + ms_lj) / n_launch
             achieved = flops / (avg_ms * 1e-3) / 1e12
             roof_nb = dict(kernel='nonbonded_sci2_kernel', bound='mfma', achieved=achieved, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
@@ -183,7 +212,7 @@ def main():
             # algorithmic bytes (SURVEY 8(d) "grid traffic 8 B x G per pass"): the half spectrum [nz/2+1][nx][ny] complex f32 of
             # every replica is read once and written once by the plane-resident XY pass
             nx, ny, nz = PME_MESH
-            nbytes = 2.0 * 8.0 * (nz // 2 + 1) * nx * ny * REPLICAS_PER_GPU
+            nbytes = 2.0 * 8.0 * (nz // 2 + 1) * nx * ny * n_local
             avg_ms = ms_xy / n_xy
             achieved = nbytes / (avg_ms * 1e-3) / 1e9
             roof_xy = dict(kernel='pme_xy_fused_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
@@ -197,17 +226,21 @@ def main():
         cands.sort(key=lambda r: -r['total_ms'])
         roof = cands[0] if cands else None
         roof2 = cands[1] if len(cands) > 1 else None
-        out = dict(metric='REMD iterations/s (propagate+u_kl+mix), 24-replica AlanineDipeptideExplicit per GPU',
+        out = dict(metric='REMD iterations/s (propagate+u_kl+mix), 24-replica AlanineDipeptideExplicit' +
+                          (' per GPU' if not strong else ' units, one %d-replica ensemble over all GPUs' % n_replicas),
                    value=value, unit='iterations/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='strong' if strong else 'weak',
+                   vs_baseline=None,
                    dtype='f32', data='synthetic',
                    config=dict(workload='testsystems.AlanineDipeptideExplicit (2269 atoms, PME) parallel tempering, '
                                         'logspace(300K,600K), g-BAOAB V R R O R R V 2 fs, %d MD steps/iteration, swap-all'
                                         % args.md_steps,
-                               replicas_per_gpu=REPLICAS_PER_GPU, replicas_total=n_replicas, md_steps=args.md_steps,
+                               replicas_per_gpu=(n_replicas / float(world)), replicas_total=n_replicas, md_steps=args.md_steps,
+                               mode=('strong: one %d-replica ensemble' % n_replicas) if strong else 'weak: 24 replicas per GPU',
                                parallelism='replica-sharded x%d' % world, seed=SEED),
                    timing=dict(sampler._timing_data), roofline=roof, roofline_secondary=roof2)
         if not args.no_cpu_baseline and world == 1:
+            engine.close()
             out['cpu_baseline'] = cpu_baseline()
         else:
             out['cpu_baseline'] = None

@@ -1,0 +1,1334 @@
+/*
+ * remd_cpu.cpp — libremd_cpu.so: the CPU implementation of include/remd_hip.h.
+ *
+ * TEST INFRASTRUCTURE AND CPU BASELINE ONLY.  It lives under oracle/, is never imported by the product package
+ * (openmmtools_amd loads libremd_hip.so or raises), and exists for two purposes (SURVEY.md 8(b) last line, 8(d);
+ * BASELINE.md section 3):
+ *   1. the CPU baseline timed beside the MI355X numbers in bench.py (`cpu_baseline`): the same replica-exchange
+ *      iteration  mix -> propagate -> u_kl  (openmmtools/multistate/multistatesampler.py:766-804) through the same
+ *      C ABI, f64, OpenMP over replicas — the shape of the reference's own CPU path, which distributes replicas over
+ *      mpiplus ranks one replica at a time (multistatesampler.py:1296-1297, 1448-1449);
+ *   2. a second, compiled checker for the ABI: the -m "not gpu" tests drive it with the very ctypes class the GPU tests
+ *      use and compare it with the f64 Python oracle.
+ *
+ * Algorithms (each restated from the same reference lines as the HIP kernels; the Python oracle oracle/md_oracle.py /
+ * oracle/forcefield.py is the independent statement they are both tested against):
+ *   Langevin splitting V/R/O           openmmtools/integrators.py:1404-1460, constants :1139-1149
+ *   velocity reassignment              openmmtools/mcmc.py:710-711
+ *   NaN restart attempts               openmmtools/mcmc.py:706-759
+ *   reduced potential / u_kl           openmmtools/states.py:1908-1917, 911-992; paralleltempering.py:206-215
+ *   mixing                             oracle/mix_oracle.c (replicaexchange.py:294-406, sams.py:477-501), linked in
+ *   forces: harmonic bond / angle, periodic torsion, LJ + switch, reaction field or Ewald direct + smooth PME
+ *   (order 5) + exclusion correction + self/background terms, 1-4 exceptions, dispersion correction, soft-core
+ *   alchemical sterics and lambda-scaled alchemical charges (alchemy.py:1379-1388, 1675-1680)
+ *   constraints: iterative SHAKE / RATTLE per rigid cluster to 1e-12 (the HIP engine uses analytic SETTLE)
+ * Exact Verlet lists (cutoff + skin, rebuilt when an atom has moved skin/2), cell-list construction.
+ *
+ * Not implemented on the CPU (return -3): the Monte Carlo barostat and FIRE minimisation entry points.
+ */
+#include "../../include/remd_hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+extern "C" {
+void oracle_draw(uint64_t seed, uint32_t stream, uint32_t a, uint32_t b, uint64_t t, uint32_t* out);
+void oracle_mix_swap_all(uint64_t seed, int64_t iteration, int R, int K, const double* u_kl, int64_t* labels, int64_t* n_acc,
+                         int64_t* n_prop, int64_t n_attempts);
+void oracle_mix_swap_neighbors(uint64_t seed, int64_t iteration, int R, int K, const double* u_kl, int64_t* labels,
+                               int64_t* n_acc, int64_t* n_prop);
+void oracle_sams_global_jump(uint64_t seed, int64_t iteration, int R, int K, const double* u_kl, const double* log_w,
+                             int64_t* labels, int64_t* n_acc, int64_t* n_prop, double* log_P);
+}
+
+namespace {
+
+constexpr double ONE_4PI_EPS0 = 138.93545764438198;     // openmmtools/constants.py:12-14
+constexpr double PI = 3.14159265358979323846;
+constexpr int PME_ORDER = 5;
+constexpr double SKIN = 0.12;                            // nm, Verlet buffer
+constexpr double CONSTRAINT_TOL = 1e-12;
+typedef std::complex<double> cplx;
+
+// ------------------------------------------------------------------------------------------------------------------
+// mixed-radix complex FFT (2, 3, 4, 5 and a generic butterfly), decimation in time, out of place
+// ------------------------------------------------------------------------------------------------------------------
+struct FFT1D {
+    int n = 0;
+    std::vector<int> factors;      // (radix, remaining) pairs
+    std::vector<cplx> tw;          // exp(-2 pi i k / n)
+    std::vector<cplx> scratch;
+    explicit FFT1D(int n_) : n(n_) {
+        int m = n, p = 4;
+        while (m > 1) {
+            while (m % p) { if (p == 4) p = 2; else if (p == 2) p = 3; else p += 2; if (p * p > m) p = m; }
+            m /= p; factors.push_back(p); factors.push_back(m);
+        }
+        tw.resize(n);
+        for (int k = 0; k < n; ++k) tw[k] = cplx(cos(-2.0 * PI * k / n), sin(-2.0 * PI * k / n));
+        scratch.resize(n);
+    }
+    void bfly_generic(cplx* out, size_t fstride, int m, int p) {
+        std::vector<cplx> s(p);
+        for (int u = 0; u < m; ++u) {
+            int k = u;
+            for (int q = 0; q < p; ++q) { s[q] = out[k]; k += m; }
+            k = u;
+            for (int q1 = 0; q1 < p; ++q1) {
+                size_t twidx = 0;
+                cplx acc = s[0];
+                for (int q = 1; q < p; ++q) { twidx += fstride * k; if (twidx >= (size_t)n) twidx %= n; acc += s[q] * tw[twidx]; }
+                out[k] = acc; k += m;
+            }
+        }
+    }
+    void bfly2(cplx* out, size_t fstride, int m) {
+        for (int k = 0; k < m; ++k) { const cplx t = out[k + m] * tw[k * fstride]; out[k + m] = out[k] - t; out[k] += t; }
+    }
+    void bfly3(cplx* out, size_t fstride, int m) {
+        const double s3 = tw[fstride * m].imag();          // -sin(2 pi / 3)
+        for (int k = 0; k < m; ++k) {
+            const cplx a = out[k + m] * tw[k * fstride], b = out[k + 2 * m] * tw[2 * k * fstride];
+            const cplx sum = a + b, dif = (a - b) * s3;
+            const cplx h = out[k] - 0.5 * sum;
+            out[k] += sum;
+            out[k + m] = cplx(h.real() - dif.imag(), h.imag() + dif.real());
+            out[k + 2 * m] = cplx(h.real() + dif.imag(), h.imag() - dif.real());
+        }
+    }
+    void bfly4(cplx* out, size_t fstride, int m) {
+        for (int k = 0; k < m; ++k) {
+            const cplx a = out[k], b = out[k + m] * tw[k * fstride], c = out[k + 2 * m] * tw[2 * k * fstride],
+                       d = out[k + 3 * m] * tw[3 * k * fstride];
+            const cplx t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+            const cplx jt3(t3.imag(), -t3.real());          // -i * t3
+            out[k] = t0 + t2; out[k + 2 * m] = t0 - t2;
+            out[k + m] = t1 + jt3; out[k + 3 * m] = t1 - jt3;
+        }
+    }
+    void bfly5(cplx* out, size_t fstride, int m) {
+        const cplx ya = tw[fstride * m], yb = tw[2 * fstride * m];
+        for (int k = 0; k < m; ++k) {
+            const cplx s0 = out[k], s1 = out[k + m] * tw[k * fstride], s2 = out[k + 2 * m] * tw[2 * k * fstride],
+                       s3 = out[k + 3 * m] * tw[3 * k * fstride], s4 = out[k + 4 * m] * tw[4 * k * fstride];
+            const cplx s7 = s1 + s4, s10 = s1 - s4, s8 = s2 + s3, s9 = s2 - s3;
+            out[k] = s0 + s7 + s8;
+            const cplx s5(s0.real() + s7.real() * ya.real() + s8.real() * yb.real(), s0.imag() + s7.imag() * ya.real() + s8.imag() * yb.real());
+            const cplx s6(s10.imag() * ya.imag() + s9.imag() * yb.imag(), -s10.real() * ya.imag() - s9.real() * yb.imag());
+            out[k + m] = s5 - s6; out[k + 4 * m] = s5 + s6;
+            const cplx s11(s0.real() + s7.real() * yb.real() + s8.real() * ya.real(), s0.imag() + s7.imag() * yb.real() + s8.imag() * ya.real());
+            const cplx s12(-s10.imag() * yb.imag() + s9.imag() * ya.imag(), s10.real() * yb.imag() - s9.real() * ya.imag());
+            out[k + 2 * m] = s11 + s12; out[k + 3 * m] = s11 - s12;
+        }
+    }
+    void work(cplx* out, const cplx* in, size_t fstride, const int* f) {
+        const int p = f[0], m = f[1];
+        if (m == 1) for (int k = 0; k < p; ++k) out[k] = in[k * fstride];
+        else for (int k = 0; k < p; ++k) work(out + (size_t)k * m, in + k * fstride, fstride * p, f + 2);
+        switch (p) {
+            case 2: bfly2(out, fstride, m); break;
+            case 3: bfly3(out, fstride, m); break;
+            case 4: bfly4(out, fstride, m); break;
+            case 5: bfly5(out, fstride, m); break;
+            default: bfly_generic(out, fstride, m, p);
+        }
+    }
+    // forward: sum x e^{-2 pi i jk/n}; inverse: e^{+...}, both unnormalised.  in and out must not alias.
+    void transform(const cplx* in, cplx* out, bool inverse) {
+        if (n == 1) { out[0] = in[0]; return; }
+        if (!inverse) { work(out, in, 1, factors.data()); return; }
+        for (int k = 0; k < n; ++k) scratch[k] = std::conj(in[k]);
+        work(out, scratch.data(), 1, factors.data());
+        for (int k = 0; k < n; ++k) out[k] = std::conj(out[k]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// random numbers: stream layout of openmmtools_amd/csrc/rng.h (DESIGN.md "RNG stream spec")
+// ------------------------------------------------------------------------------------------------------------------
+inline double u23(uint32_t w) { return ((double)(w >> 9) + 0.5) / 8388608.0; }
+inline void gaussians3(uint64_t seed, uint32_t stream, int atom, int replica, uint64_t t, double g[3])
+{
+    uint32_t w[4];
+    oracle_draw(seed, stream, (uint32_t)atom, (uint32_t)replica, t, w);
+    const double r1 = sqrt(-2.0 * log(u23(w[0]))), r2 = sqrt(-2.0 * log(u23(w[2])));
+    const double a1 = 2.0 * PI * u23(w[1]), a2 = 2.0 * PI * u23(w[3]);
+    g[0] = r1 * cos(a1); g[1] = r1 * sin(a1); g[2] = r2 * cos(a2);
+}
+
+struct Cluster { int n_atoms; int atoms[4]; int nc; int ci[3], cj[3]; double d[3]; int settle; };   // local indices in ci/cj; settle: rigid 3-site water
+
+// ------------------------------------------------------------------------------------------------------------------
+// system description (copied from remd_system_desc)
+// ------------------------------------------------------------------------------------------------------------------
+struct System {
+    int N = 0;
+    std::vector<double> mass, invm;
+    std::vector<int> ext_atoms; double ext_K = 0, ext_x0 = 0, ext_U0 = 0;
+    std::vector<int> bond_atoms, angle_atoms, torsion_atoms, exc_atoms;
+    std::vector<double> bond_params, angle_params, torsion_params, exc_params;
+    int method = 0; double rc = 0, rs = -1, rf_eps = 78.3, alpha = 0; int grid[3] = {0, 0, 0}; int use_disp = 0;
+    std::vector<double> q, sig, eps;
+    std::vector<char> alch;
+    bool has_charge = false, has_alch = false;
+    double sc_alpha = 0.5, sc_a = 1, sc_b = 1, sc_c = 6;
+    std::vector<Cluster> clusters;
+    int cmm = 0;
+    double total_mass = 0, disp_coeff = 0;
+    std::vector<std::vector<int>> excl;           // per atom, sorted partner list (exceptions are excluded from the pair loop)
+    std::vector<double> bmod[3];                  // B-spline moduli of the PME mesh
+    int n_dof = 0;
+    double settle_ra = 0, settle_rb = 0, settle_rc = 0, settle_dHH = 0, settle_mO = 0, settle_mH = 0;
+};
+
+double M_spline(int o, double u) {                // cardinal B-spline of order o at u
+    if (o == 2) return (u < 0 || u > 2) ? 0.0 : 1.0 - fabs(u - 1.0);
+    return u / (o - 1) * M_spline(o - 1, u) + (o - u) / (o - 1) * M_spline(o - 1, u - 1.0);
+}
+
+std::vector<double> bspline_moduli(int n) {
+    std::vector<double> w(PME_ORDER - 1), bm(n);
+    for (int k = 0; k < PME_ORDER - 1; ++k) w[k] = M_spline(PME_ORDER, k + 1.0);
+    for (int m = 0; m < n; ++m) {
+        double c = 0, s = 0;
+        for (int k = 0; k < PME_ORDER - 1; ++k) { const double a = 2.0 * PI * m * k / n; c += w[k] * cos(a); s += w[k] * sin(a); }
+        bm[m] = c * c + s * s;
+    }
+    for (int i = 0; i < n; ++i) if (bm[i] < 1e-7) bm[i] = 0.5 * (bm[(i - 1 + n) % n] + bm[(i + 1) % n]);
+    return bm;
+}
+
+double disp_switch_integral(double sig, double rs, double rc) {
+    // int_rs^rc (1 - S(r)) ((sig/r)^12 - (sig/r)^6) r^2 dr   with composite Simpson, 4096 intervals (error ~ h^4 f'''' << 1e-13)
+    const int n = 4096; const double h = (rc - rs) / n;
+    auto f = [&](double r) {
+        const double x = (r - rs) / (rc - rs);
+        const double S = 1.0 - 10.0 * x * x * x + 15.0 * x * x * x * x - 6.0 * x * x * x * x * x;
+        const double s6 = pow(sig / r, 6);
+        return (1.0 - S) * (s6 * s6 - s6) * r * r;
+    };
+    double acc = f(rs) + f(rc);
+    for (int i = 1; i < n; ++i) acc += f(rs + i * h) * ((i & 1) ? 4.0 : 2.0);
+    return acc * h / 3.0;
+}
+
+double dispersion_coefficient(const System& s) {
+    // E_disp = coeff / V, OpenMM NonbondedForce convention (average over the N(N+1)/2 pair multiset); alchemical atoms
+    // carry no dispersion correction in the NonbondedForce (their sterics live in the custom forces, alchemy.py:1786-1789)
+    std::map<std::pair<double, double>, double> classes;
+    for (int i = 0; i < s.N; ++i) classes[{s.sig[i], s.alch[i] ? 0.0 : s.eps[i]}] += 1.0;
+    std::vector<std::pair<std::pair<double, double>, double>> cl(classes.begin(), classes.end());
+    double s1 = 0, s2 = 0, s3 = 0;
+    for (size_t a = 0; a < cl.size(); ++a) for (size_t b = a; b < cl.size(); ++b) {
+        const double na = cl[a].second, nb = cl[b].second;
+        const double count = (a == b) ? na * (na + 1) / 2.0 : na * nb;
+        const double sg = 0.5 * (cl[a].first.first + cl[b].first.first), ep = sqrt(cl[a].first.second * cl[b].first.second);
+        if (ep == 0.0) continue;
+        s1 += count * ep * pow(sg, 12); s2 += count * ep * pow(sg, 6);
+        if (s.rs >= 0 && s.rs < s.rc) s3 += count * ep * disp_switch_integral(sg, s.rs, s.rc);
+    }
+    const double npairs = (double)s.N * (s.N + 1) / 2.0, N = s.N;
+    return 8.0 * N * N * PI * (s1 / npairs / (9.0 * pow(s.rc, 9)) - s2 / npairs / (3.0 * pow(s.rc, 3)) + s3 / npairs);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one replica: state, neighbour list, PME work space
+// ------------------------------------------------------------------------------------------------------------------
+struct Replica {
+    std::vector<double> x, v, f;                  // [N][3]
+    double box[3] = {0, 0, 0};
+    bool f_valid = false;
+    // Verlet list
+    std::vector<double> x_list; double box_list[3] = {0, 0, 0};
+    std::vector<int> pair_i, pair_j;              // i < j, not excluded, within rc + skin at build time
+    bool list_valid = false;
+    // PME
+    std::vector<double> Q, phi;
+    std::vector<cplx> H;
+    int pme_nthreads = 1;
+};
+
+struct Timers { double list = 0, pairs = 0, bonded = 0, exc = 0, pme = 0; };
+static Timers g_timers;
+static const bool g_time = getenv("REMD_CPU_TIMERS") != nullptr;
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Energy { double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; double total() const { double t = 0; for (double v : c) t += v; return t; } };
+
+inline double min_image(double d, double L) { return d - L * nearbyint(d / L); }
+
+void build_list(const System& s, Replica& r)
+{
+    const int N = s.N;
+    const double rl = s.rc + SKIN, rl2 = rl * rl;
+    r.pair_i.clear(); r.pair_j.clear();
+    r.x_list = r.x; for (int k = 0; k < 3; ++k) r.box_list[k] = r.box[k];
+    int nc[3]; double cs[3];
+    for (int k = 0; k < 3; ++k) { nc[k] = std::max(1, (int)floor(r.box[k] / rl)); cs[k] = r.box[k] / nc[k]; }
+    const int ncell = nc[0] * nc[1] * nc[2];
+    std::vector<int> head(ncell + 1, 0), cell(N), order(N);
+    for (int i = 0; i < N; ++i) {
+        int c[3];
+        for (int k = 0; k < 3; ++k) {
+            double u = r.x[3 * i + k] / r.box[k]; u -= floor(u);
+            c[k] = std::min(nc[k] - 1, (int)(u * nc[k]));
+        }
+        cell[i] = (c[0] * nc[1] + c[1]) * nc[2] + c[2];
+        head[cell[i] + 1]++;
+    }
+    for (int c = 0; c < ncell; ++c) head[c + 1] += head[c];
+    { std::vector<int> pos(head.begin(), head.end() - 1); for (int i = 0; i < N; ++i) order[pos[cell[i]]++] = i; }
+    std::vector<int> nbr;
+    for (int cx = 0; cx < nc[0]; ++cx) for (int cy = 0; cy < nc[1]; ++cy) for (int cz = 0; cz < nc[2]; ++cz) {
+        const int c0 = (cx * nc[1] + cy) * nc[2] + cz;
+        // each unordered pair of neighbouring cells once; with fewer than 3 cells along a dimension the -1 / +1 images
+        // coincide, so the neighbour set is made unique first
+        nbr.clear();
+        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) for (int dz = -1; dz <= 1; ++dz) {
+            const int c1 = (((cx + dx + nc[0]) % nc[0]) * nc[1] + (cy + dy + nc[1]) % nc[1]) * nc[2] + (cz + dz + nc[2]) % nc[2];
+            if (c1 >= c0) nbr.push_back(c1);
+        }
+        std::sort(nbr.begin(), nbr.end());
+        nbr.erase(std::unique(nbr.begin(), nbr.end()), nbr.end());
+        for (int c1 : nbr) {
+            for (int a = head[c0]; a < head[c0 + 1]; ++a) {
+                const int i = order[a];
+                for (int b = (c1 == c0 ? a + 1 : head[c1]); b < head[c1 + 1]; ++b) {
+                    const int j = order[b];
+                    double d2 = 0; for (int k = 0; k < 3; ++k) { const double d = min_image(r.x[3 * j + k] - r.x[3 * i + k], r.box[k]); d2 += d * d; }
+                    if (d2 >= rl2) continue;
+                    const int lo = std::min(i, j), hi = std::max(i, j);
+                    if (std::binary_search(s.excl[lo].begin(), s.excl[lo].end(), hi)) continue;
+                    r.pair_i.push_back(lo); r.pair_j.push_back(hi);
+                }
+            }
+        }
+    }
+    r.list_valid = true;
+}
+
+void ensure_list(const System& s, Replica& r)
+{
+    bool ok = r.list_valid && (int)r.x_list.size() == 3 * s.N;
+    if (ok) for (int k = 0; k < 3; ++k) if (r.box_list[k] != r.box[k]) ok = false;
+    if (ok) {
+        const double lim = 0.25 * SKIN * SKIN;
+        for (int i = 0; i < s.N && ok; ++i) {
+            double d2 = 0; for (int k = 0; k < 3; ++k) { const double d = r.x[3 * i + k] - r.x_list[3 * i + k]; d2 += d * d; }
+            if (!(d2 < lim)) ok = false;             // also catches NaN
+        }
+    }
+    if (!ok) build_list(s, r);
+}
+
+inline void bspline(double f, double w[PME_ORDER], double dw[PME_ORDER])
+{
+    // w[j] = M_5(f + j), dw[j] = M_4(f + j) - M_4(f + j - 1); recursion of oracle/forcefield.py:_bspline_weights
+    double a[PME_ORDER] = {f, 1.0 - f, 0, 0, 0}, b[PME_ORDER];
+    for (int m = 3; m <= PME_ORDER; ++m) {
+        if (m == PME_ORDER) for (int j = 0; j < PME_ORDER; ++j) dw[j] = a[j] - (j > 0 ? a[j - 1] : 0.0);
+        for (int j = 0; j < PME_ORDER; ++j) {
+            if (j < m) {
+                const double cur = (j < m - 1) ? a[j] : 0.0, prev = (j > 0) ? a[j - 1] : 0.0;
+                b[j] = ((f + j) * cur + (m - f - j) * prev) / (m - 1);
+            } else b[j] = 0.0;
+        }
+        for (int j = 0; j < PME_ORDER; ++j) a[j] = b[j];
+    }
+    for (int j = 0; j < PME_ORDER; ++j) w[j] = a[j];
+}
+
+struct FFTSet { std::unique_ptr<FFT1D> f[3]; };
+
+// smooth PME reciprocal energy (and forces when f != nullptr) for charges qv
+double pme_reciprocal(const System& s, Replica& r, const std::vector<double>& qv, double* f, FFTSet& fft)
+{
+    const int nx = s.grid[0], ny = s.grid[1], nz = s.grid[2], nzh = nz / 2 + 1;
+    const size_t G = (size_t)nx * ny * nz, GH = (size_t)nx * ny * nzh;
+    r.Q.assign(G, 0.0); r.H.resize(GH);
+    const int N = s.N;
+    const int n[3] = {nx, ny, nz};
+    // spread
+    for (int i = 0; i < N; ++i) {
+        if (qv[i] == 0.0) continue;
+        double w[3][PME_ORDER], dw[3][PME_ORDER]; int k0[3];
+        for (int k = 0; k < 3; ++k) {
+            double u = r.x[3 * i + k] / r.box[k]; u = (u - floor(u)) * n[k];
+            k0[k] = (int)floor(u);
+            bspline(u - k0[k], w[k], dw[k]);
+        }
+        for (int a = 0; a < PME_ORDER; ++a) {
+            const int ix = ((k0[0] - a) % nx + nx) % nx;
+            for (int b = 0; b < PME_ORDER; ++b) {
+                const int iy = ((k0[1] - b) % ny + ny) % ny;
+                const double wab = qv[i] * w[0][a] * w[1][b];
+                double* row = &r.Q[((size_t)ix * ny + iy) * nz];
+                for (int c = 0; c < PME_ORDER; ++c) row[((k0[2] - c) % nz + nz) % nz] += wab * w[2][c];
+            }
+        }
+    }
+    // forward transform: z (real input, keep the half spectrum), then y, then x
+    std::vector<cplx> lin(std::max(std::max(nx, ny), nz)), lout(lin.size());
+    for (int ix = 0; ix < nx; ++ix) for (int iy = 0; iy < ny; ++iy) {
+        const double* row = &r.Q[((size_t)ix * ny + iy) * nz];
+        for (int k = 0; k < nz; ++k) lin[k] = cplx(row[k], 0.0);
+        fft.f[2]->transform(lin.data(), lout.data(), false);
+        cplx* h = &r.H[((size_t)ix * ny + iy) * nzh];
+        for (int k = 0; k < nzh; ++k) h[k] = lout[k];
+    }
+    for (int ix = 0; ix < nx; ++ix) for (int kz = 0; kz < nzh; ++kz) {
+        for (int iy = 0; iy < ny; ++iy) lin[iy] = r.H[((size_t)ix * ny + iy) * nzh + kz];
+        fft.f[1]->transform(lin.data(), lout.data(), false);
+        for (int iy = 0; iy < ny; ++iy) r.H[((size_t)ix * ny + iy) * nzh + kz] = lout[iy];
+    }
+    const double V = r.box[0] * r.box[1] * r.box[2];
+    double energy = 0.0;
+    for (int iy = 0; iy < ny; ++iy) for (int kz = 0; kz < nzh; ++kz) {
+        for (int ix = 0; ix < nx; ++ix) lin[ix] = r.H[((size_t)ix * ny + iy) * nzh + kz];
+        fft.f[0]->transform(lin.data(), lout.data(), false);
+        // influence function G(m) = k_e exp(-pi^2 m^2 / alpha^2) / (pi V m^2 b(m)), applied in place (x is the last pass)
+        const double my = (iy <= ny / 2 ? iy : iy - ny) / r.box[1], mz = kz / r.box[2];
+        const double wz = (kz == 0 || (nz % 2 == 0 && kz == nz / 2)) ? 1.0 : 2.0;
+        for (int ix = 0; ix < nx; ++ix) {
+            const double mx = (ix <= nx / 2 ? ix : ix - nx) / r.box[0];
+            const double m2 = mx * mx + my * my + mz * mz;
+            double g = 0.0;
+            if (m2 > 0) g = ONE_4PI_EPS0 * exp(-PI * PI * m2 / (s.alpha * s.alpha)) / (s.bmod[0][ix] * s.bmod[1][iy] * s.bmod[2][kz] * PI * V * m2);
+            energy += 0.5 * wz * g * std::norm(lout[ix]);
+            lout[ix] *= g;
+        }
+        if (f) {
+            fft.f[0]->transform(lout.data(), lin.data(), true);
+            for (int ix = 0; ix < nx; ++ix) r.H[((size_t)ix * ny + iy) * nzh + kz] = lin[ix];
+        }
+    }
+    if (!f) return energy;
+    // inverse y, then z with Hermitian completion -> real potential mesh phi = sum_m G S e^{+2 pi i m r / n}
+    for (int ix = 0; ix < nx; ++ix) for (int kz = 0; kz < nzh; ++kz) {
+        for (int iy = 0; iy < ny; ++iy) lin[iy] = r.H[((size_t)ix * ny + iy) * nzh + kz];
+        fft.f[1]->transform(lin.data(), lout.data(), true);
+        for (int iy = 0; iy < ny; ++iy) r.H[((size_t)ix * ny + iy) * nzh + kz] = lout[iy];
+    }
+    r.phi.resize(G);
+    for (int ix = 0; ix < nx; ++ix) for (int iy = 0; iy < ny; ++iy) {
+        const cplx* h = &r.H[((size_t)ix * ny + iy) * nzh];
+        for (int k = 0; k < nzh; ++k) lin[k] = h[k];
+        for (int k = nzh; k < nz; ++k) lin[k] = std::conj(h[nz - k]);
+        fft.f[2]->transform(lin.data(), lout.data(), true);
+        double* row = &r.phi[((size_t)ix * ny + iy) * nz];
+        for (int k = 0; k < nz; ++k) row[k] = lout[k].real();
+    }
+    // gather: F_i = -q_i sum dtheta/dx phi
+    for (int i = 0; i < N; ++i) {
+        if (qv[i] == 0.0) continue;
+        double w[3][PME_ORDER], dw[3][PME_ORDER]; int k0[3];
+        for (int k = 0; k < 3; ++k) {
+            double u = r.x[3 * i + k] / r.box[k]; u = (u - floor(u)) * n[k];
+            k0[k] = (int)floor(u);
+            bspline(u - k0[k], w[k], dw[k]);
+        }
+        double g[3] = {0, 0, 0};
+        for (int a = 0; a < PME_ORDER; ++a) {
+            const int ix = ((k0[0] - a) % nx + nx) % nx;
+            for (int b = 0; b < PME_ORDER; ++b) {
+                const int iy = ((k0[1] - b) % ny + ny) % ny;
+                const double* row = &r.phi[((size_t)ix * ny + iy) * nz];
+                double s0 = 0, s1 = 0;
+                for (int c = 0; c < PME_ORDER; ++c) { const double p = row[((k0[2] - c) % nz + nz) % nz]; s0 += w[2][c] * p; s1 += dw[2][c] * p; }
+                g[0] += dw[0][a] * w[1][b] * s0; g[1] += w[0][a] * dw[1][b] * s0; g[2] += w[0][a] * w[1][b] * s1;
+            }
+        }
+        for (int k = 0; k < 3; ++k) f[3 * i + k] -= qv[i] * g[k] * n[k] / r.box[k];
+    }
+    return energy;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// potential energy and forces of one replica at (lambda_sterics, lambda_electrostatics)
+//   parts: which contributions to evaluate (the u_kl assembly re-evaluates only what a lambda changes)
+// ------------------------------------------------------------------------------------------------------------------
+enum { PART_BONDED = 1, PART_STERICS = 2, PART_SOFTCORE = 4, PART_ELEC = 8, PART_ALL = 15 };
+
+Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double* f, FFTSet& fft, int parts = PART_ALL)
+{
+    Energy E;
+    const int N = s.N;
+    const double* x = r.x.data();
+    if (f) std::fill(f, f + 3 * N, 0.0);
+    const bool periodic = s.method != 0;
+    auto delta = [&](int i, int j, double d[3]) {
+        for (int k = 0; k < 3; ++k) { d[k] = x[3 * j + k] - x[3 * i + k]; if (periodic) d[k] = min_image(d[k], r.box[k]); }
+    };
+    if (parts & PART_BONDED) {
+        if (!s.ext_atoms.empty()) {                                   // testsystems.py:779-786
+            for (int i : s.ext_atoms) {
+                const double dx[3] = {x[3 * i] - s.ext_x0, x[3 * i + 1], x[3 * i + 2]};
+                E.c[0] += 0.5 * s.ext_K * (dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]) + s.ext_U0;
+                if (f) for (int k = 0; k < 3; ++k) f[3 * i + k] -= s.ext_K * dx[k];
+            }
+        }
+        for (size_t b = 0; b < s.bond_atoms.size() / 2; ++b) {
+            const int i = s.bond_atoms[2 * b], j = s.bond_atoms[2 * b + 1];
+            const double r0 = s.bond_params[2 * b], k = s.bond_params[2 * b + 1];
+            double d[3] = {x[3 * j] - x[3 * i], x[3 * j + 1] - x[3 * i + 1], x[3 * j + 2] - x[3 * i + 2]};
+            const double rr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            E.c[1] += 0.5 * k * (rr - r0) * (rr - r0);
+            if (f) { const double g = k * (rr - r0) / rr; for (int c = 0; c < 3; ++c) { f[3 * i + c] += g * d[c]; f[3 * j + c] -= g * d[c]; } }
+        }
+        for (size_t a = 0; a < s.angle_atoms.size() / 3; ++a) {
+            const int i = s.angle_atoms[3 * a], j = s.angle_atoms[3 * a + 1], k = s.angle_atoms[3 * a + 2];
+            const double th0 = s.angle_params[2 * a], ka = s.angle_params[2 * a + 1];
+            double v0[3], v1[3];
+            for (int c = 0; c < 3; ++c) { v0[c] = x[3 * i + c] - x[3 * j + c]; v1[c] = x[3 * k + c] - x[3 * j + c]; }
+            const double n0 = sqrt(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]), n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
+            double cs = (v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2]) / (n0 * n1);
+            cs = std::max(-1.0, std::min(1.0, cs));
+            const double th = acos(cs);
+            E.c[2] += 0.5 * ka * (th - th0) * (th - th0);
+            if (f) {
+                const double sn = sqrt(std::max(1e-30, 1.0 - cs * cs));
+                const double dEdth = ka * (th - th0);
+                // d theta / d r_i = -(v1/n1 - cs v0/n0) / (n0 sin)
+                for (int c = 0; c < 3; ++c) {
+                    const double gi = -(v1[c] / n1 - cs * v0[c] / n0) / (n0 * sn), gk = -(v0[c] / n0 - cs * v1[c] / n1) / (n1 * sn);
+                    f[3 * i + c] -= dEdth * gi; f[3 * k + c] -= dEdth * gk; f[3 * j + c] += dEdth * (gi + gk);
+                }
+            }
+        }
+        for (size_t t = 0; t < s.torsion_atoms.size() / 4; ++t) {
+            const int a0 = s.torsion_atoms[4 * t], a1 = s.torsion_atoms[4 * t + 1], a2 = s.torsion_atoms[4 * t + 2], a3 = s.torsion_atoms[4 * t + 3];
+            const double per = s.torsion_params[3 * t], phase = s.torsion_params[3 * t + 1], kt = s.torsion_params[3 * t + 2];
+            double b1[3], b2[3], b3[3], m[3], n[3];
+            for (int c = 0; c < 3; ++c) { b1[c] = x[3 * a1 + c] - x[3 * a0 + c]; b2[c] = x[3 * a2 + c] - x[3 * a1 + c]; b3[c] = x[3 * a3 + c] - x[3 * a2 + c]; }
+            m[0] = b1[1] * b2[2] - b1[2] * b2[1]; m[1] = b1[2] * b2[0] - b1[0] * b2[2]; m[2] = b1[0] * b2[1] - b1[1] * b2[0];
+            n[0] = b2[1] * b3[2] - b2[2] * b3[1]; n[1] = b2[2] * b3[0] - b2[0] * b3[2]; n[2] = b2[0] * b3[1] - b2[1] * b3[0];
+            const double b2n = sqrt(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]);
+            const double phi = atan2(b2n * (b1[0] * n[0] + b1[1] * n[1] + b1[2] * n[2]), m[0] * n[0] + m[1] * n[1] + m[2] * n[2]);
+            E.c[3] += kt * (1.0 + cos(per * phi - phase));
+            if (f) {
+                const double dEdphi = -kt * per * sin(per * phi - phase);
+                const double m2 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2], n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                const double b1b2 = b1[0] * b2[0] + b1[1] * b2[1] + b1[2] * b2[2], b3b2 = b3[0] * b2[0] + b3[1] * b2[1] + b3[2] * b2[2];
+                // Blondel & Karplus: dphi/dr0 = -|b2| m / m^2 ; dphi/dr3 = |b2| n / n^2
+                for (int c = 0; c < 3; ++c) {
+                    const double g0 = -b2n / m2 * m[c], g3 = b2n / n2 * n[c];
+                    const double g1 = (-1.0 - b1b2 / (b2n * b2n)) * g0 + (b3b2 / (b2n * b2n)) * g3;      // d phi / d r1
+                    const double g2 = -(g0 + g1 + g3);
+                    f[3 * a0 + c] -= dEdphi * g0; f[3 * a1 + c] -= dEdphi * g1; f[3 * a2 + c] -= dEdphi * g2; f[3 * a3 + c] -= dEdphi * g3;
+                }
+            }
+        }
+    }
+    if (!periodic) return E;
+    const double V = r.box[0] * r.box[1] * r.box[2];
+    // charges at this lambda_electrostatics (exact PME treatment: alchemical charges scale, alchemy.py:1675-1680)
+    std::vector<double> qv;
+    const bool elec = (parts & PART_ELEC) && s.has_charge;
+    if (elec) { qv.resize(N); for (int i = 0; i < N; ++i) qv[i] = s.alch[i] ? s.q[i] * lam_e : s.q[i]; }
+    // ---- pair loop -------------------------------------------------------------------------------------------
+    if (parts & (PART_STERICS | PART_SOFTCORE | PART_ELEC)) {
+        double tt0 = g_time ? now_ms() : 0;
+        ensure_list(s, r);
+        if (g_time) { const double t1 = now_ms(); g_timers.list += t1 - tt0; tt0 = t1; }
+        const double rc2 = s.rc * s.rc;
+        const double krf = (s.rf_eps - 1.0) / (2.0 * s.rf_eps + 1.0) / (s.rc * s.rc * s.rc), crf = 3.0 * s.rf_eps / (2.0 * s.rf_eps + 1.0) / s.rc;
+        const double two_a_sqrtpi = 2.0 * s.alpha / sqrt(PI);
+        const bool sw = s.rs >= 0 && s.rs < s.rc;
+        const double one_m_l = 1.0 - lam_s, la = pow(lam_s, s.sc_a), lb = s.sc_alpha * pow(one_m_l, s.sc_b);
+        double e_lj = 0, e_el = 0;
+        const size_t np = r.pair_i.size();
+        for (size_t p = 0; p < np; ++p) {
+            const int i = r.pair_i[p], j = r.pair_j[p];
+            double d[3]; delta(i, j, d);
+            const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            if (r2 >= rc2) continue;
+            const double rr = sqrt(r2);
+            double fr = 0.0;                                       // -dE/dr / r  (force on j = fr * d)
+            const double ep = sqrt(s.eps[i] * s.eps[j]);
+            const bool na = s.has_alch && (s.alch[i] != s.alch[j]);
+            if (ep != 0.0 && ((na && (parts & PART_SOFTCORE)) || (!na && (parts & PART_STERICS)))) {
+                const double sg = 0.5 * (s.sig[i] + s.sig[j]);
+                double e, dedr;
+                if (!na) {
+                    const double s2 = sg * sg / r2, s6 = s2 * s2 * s2;
+                    e = 4.0 * ep * (s6 * s6 - s6); dedr = 4.0 * ep * (-12.0 * s6 * s6 + 6.0 * s6) / rr;
+                } else {
+                    // alchemy.py:1383-1388: U = l^a 4 eps x (x - 1), x = (sigma / r_eff)^6, r_eff = sigma (alpha (1-l)^b + (r/sigma)^c)^(1/c)
+                    const double rs_c = pow(rr / sg, s.sc_c);
+                    const double base = lb + rs_c;
+                    const double xs = pow(base, -6.0 / s.sc_c);
+                    e = la * 4.0 * ep * xs * (xs - 1.0);
+                    const double dxdr = (-6.0 / s.sc_c) * pow(base, -6.0 / s.sc_c - 1.0) * s.sc_c * rs_c / rr;
+                    dedr = la * 4.0 * ep * (2.0 * xs - 1.0) * dxdr;
+                }
+                if (sw && rr > s.rs) {
+                    const double t = (rr - s.rs) / (s.rc - s.rs);
+                    const double S = 1.0 - 10.0 * t * t * t + 15.0 * t * t * t * t - 6.0 * t * t * t * t * t;
+                    const double dS = (-30.0 * t * t + 60.0 * t * t * t - 30.0 * t * t * t * t) / (s.rc - s.rs);
+                    dedr = dedr * S + e * dS; e *= S;
+                }
+                e_lj += e; fr -= dedr / rr;
+            }
+            if (elec) {
+                const double qq = ONE_4PI_EPS0 * qv[i] * qv[j];
+                if (qq != 0.0) {
+                    if (s.method == REMD_NB_PME) {
+                        const double ar = s.alpha * rr, ec = erfc(ar);
+                        e_el += qq * ec / rr;
+                        fr += qq * (ec / rr + two_a_sqrtpi * exp(-ar * ar)) / r2;
+                    } else {
+                        e_el += qq * (1.0 / rr + krf * r2 - crf);
+                        fr += qq * (1.0 / (rr * r2) - 2.0 * krf);
+                    }
+                }
+            }
+            if (f && fr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * j + k] += fr * d[k]; f[3 * i + k] -= fr * d[k]; }
+        }
+        E.c[8] += e_lj + e_el;
+        if (g_time) g_timers.pairs += now_ms() - tt0;
+    }
+    // ---- exceptions (no cutoff) and the Ewald correction of every excluded pair ------------------------------------------
+    if (parts & (PART_STERICS | PART_ELEC)) {
+        const size_t ne = s.exc_atoms.size() / 2;
+        const double two_a_sqrtpi = 2.0 * s.alpha / sqrt(PI);
+        for (size_t e = 0; e < ne; ++e) {
+            const int i = s.exc_atoms[2 * e], j = s.exc_atoms[2 * e + 1];
+            const double qq0 = s.exc_params[3 * e], sg = s.exc_params[3 * e + 1], ep = s.exc_params[3 * e + 2];
+            double d[3]; delta(i, j, d);
+            const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], rr = sqrt(r2);
+            double fr = 0.0;
+            if ((parts & PART_STERICS) && ep != 0.0) {
+                const double s2 = sg * sg / r2, s6 = s2 * s2 * s2;
+                E.c[4] += 4.0 * ep * s6 * (s6 - 1.0);
+                fr += 4.0 * ep * (12.0 * s6 * s6 - 6.0 * s6) / r2;
+            }
+            if (parts & PART_ELEC) {
+                if (qq0 != 0.0) {
+                    // exception charge products that touch the alchemical region scale with lambda_e (alchemy.py:1964-1966)
+                    const double qq = ONE_4PI_EPS0 * ((s.has_alch && (s.alch[i] || s.alch[j])) ? qq0 * lam_e : qq0);
+                    E.c[4] += qq / rr; fr += qq / (rr * r2);
+                }
+                if (elec && s.method == REMD_NB_PME) {
+                    const double qq = ONE_4PI_EPS0 * qv[i] * qv[j];
+                    if (qq != 0.0) {
+                        const double ar = s.alpha * rr, ef = erf(ar);
+                        E.c[5] -= qq * ef / rr;
+                        fr -= qq * (ef / rr - two_a_sqrtpi * exp(-ar * ar)) / r2;
+                    }
+                }
+            }
+            if (f && fr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * j + k] += fr * d[k]; f[3 * i + k] -= fr * d[k]; }
+        }
+    }
+    if (parts & PART_STERICS) E.c[7] += s.disp_coeff / V;
+    if (elec && s.method == REMD_NB_PME) {
+        const double tp0 = g_time ? now_ms() : 0;
+        E.c[6] += pme_reciprocal(s, r, qv, f, fft);
+        if (g_time) g_timers.pme += now_ms() - tp0;
+        double q2 = 0, qs = 0; for (int i = 0; i < N; ++i) { q2 += qv[i] * qv[i]; qs += qv[i]; }
+        E.c[7] -= ONE_4PI_EPS0 * s.alpha / sqrt(PI) * q2;
+        E.c[7] -= ONE_4PI_EPS0 * PI * qs * qs / (2.0 * s.alpha * s.alpha * V);
+    }
+    return E;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// constraints: iterative SHAKE (positions along the old bond vectors) and RATTLE (velocities), per rigid cluster
+// ------------------------------------------------------------------------------------------------------------------
+// analytic SETTLE for a rigid three-site water (Miyamoto & Kollman, J. Comput. Chem. 13, 952 (1992)): the constrained
+// positions that iterated SHAKE converges to, in closed form.  a = O, b = H1, c = H2.
+inline void settle_water(const System& s, const int* at, const double* x_old, double* x_new)
+{
+    const double mO = s.settle_mO, mH = s.settle_mH, M = mO + 2.0 * mH;
+    const double ra = s.settle_ra, rb = s.settle_rb, rc = s.settle_rc;
+    const double *a0 = x_old + 3 * at[0], *b0 = x_old + 3 * at[1], *c0 = x_old + 3 * at[2];
+    double *a1 = x_new + 3 * at[0], *b1 = x_new + 3 * at[1], *c1 = x_new + 3 * at[2];
+    double xb0[3], xc0[3], com[3], xa1[3], xb1[3], xc1[3];
+    for (int k = 0; k < 3; ++k) {
+        xb0[k] = b0[k] - a0[k]; xc0[k] = c0[k] - a0[k];
+        com[k] = (mO * a1[k] + mH * (b1[k] + c1[k])) / M;
+        xa1[k] = a1[k] - com[k]; xb1[k] = b1[k] - com[k]; xc1[k] = c1[k] - com[k];
+    }
+    auto cross = [](const double* u, const double* v, double* w) { w[0] = u[1] * v[2] - u[2] * v[1]; w[1] = u[2] * v[0] - u[0] * v[2]; w[2] = u[0] * v[1] - u[1] * v[0]; };
+    auto dot = [](const double* u, const double* v) { return u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; };
+    double Z[3], X[3], Y[3];
+    cross(xb0, xc0, Z); cross(xa1, Z, X); cross(Z, X, Y);
+    const double nz = 1.0 / sqrt(dot(Z, Z)), nx = 1.0 / sqrt(dot(X, X)), ny = 1.0 / sqrt(dot(Y, Y));
+    for (int k = 0; k < 3; ++k) { Z[k] *= nz; X[k] *= nx; Y[k] *= ny; }
+    const double xb0d = dot(X, xb0), yb0d = dot(Y, xb0), xc0d = dot(X, xc0), yc0d = dot(Y, xc0);
+    const double za1d = dot(Z, xa1), xb1d = dot(X, xb1), yb1d = dot(Y, xb1), zb1d = dot(Z, xb1), xc1d = dot(X, xc1), yc1d = dot(Y, xc1), zc1d = dot(Z, xc1);
+    const double sinphi = za1d / ra, cosphi = sqrt(1.0 - sinphi * sinphi);
+    const double sinpsi = (zb1d - zc1d) / (2.0 * rc * cosphi), cospsi = sqrt(1.0 - sinpsi * sinpsi);
+    const double ya2d = ra * cosphi, xb2d = -rc * cospsi;
+    const double yb2d = -rb * cosphi - rc * sinpsi * sinphi, yc2d = -rb * cosphi + rc * sinpsi * sinphi;
+    const double alpha = xb2d * (xb0d - xc0d) + yb0d * yb2d + yc0d * yc2d;
+    const double beta = xb2d * (yc0d - yb0d) + xb0d * yb2d + xc0d * yc2d;
+    const double gamma = xb0d * yb1d - xb1d * yb0d + xc0d * yc1d - xc1d * yc0d;
+    const double al2be2 = alpha * alpha + beta * beta;
+    const double sintheta = (alpha * gamma - beta * sqrt(al2be2 - gamma * gamma)) / al2be2, costheta = sqrt(1.0 - sintheta * sintheta);
+    const double xa3d = -ya2d * sintheta, ya3d = ya2d * costheta, za3d = za1d;
+    const double xb3d = xb2d * costheta - yb2d * sintheta, yb3d = xb2d * sintheta + yb2d * costheta, zb3d = zb1d;
+    const double xc3d = -xb2d * costheta - yc2d * sintheta, yc3d = -xb2d * sintheta + yc2d * costheta, zc3d = zc1d;
+    for (int k = 0; k < 3; ++k) {
+        a1[k] = com[k] + X[k] * xa3d + Y[k] * ya3d + Z[k] * za3d;
+        b1[k] = com[k] + X[k] * xb3d + Y[k] * yb3d + Z[k] * zb3d;
+        c1[k] = com[k] + X[k] * xc3d + Y[k] * yc3d + Z[k] * zc3d;
+    }
+}
+
+// positions: SETTLE for the waters, iterated SHAKE (along the old bond vectors) for the X-H clusters
+void shake(const System& s, const double* x_old, double* x_new)
+{
+    for (const Cluster& c : s.clusters) {
+        if (c.settle) { settle_water(s, c.atoms, x_old, x_new); continue; }
+        for (int iter = 0; iter < 500; ++iter) {
+            double worst = 0;
+            for (int q = 0; q < c.nc; ++q) {
+                const int i = c.atoms[c.ci[q]], j = c.atoms[c.cj[q]];
+                double rn[3], ro[3], r2 = 0, dot = 0;
+                for (int k = 0; k < 3; ++k) { rn[k] = x_new[3 * j + k] - x_new[3 * i + k]; ro[k] = x_old[3 * j + k] - x_old[3 * i + k]; r2 += rn[k] * rn[k]; dot += rn[k] * ro[k]; }
+                const double diff = c.d[q] * c.d[q] - r2;
+                worst = std::max(worst, fabs(diff) / (c.d[q] * c.d[q]));
+                const double lam = diff / (2.0 * (s.invm[i] + s.invm[j]) * dot);
+                for (int k = 0; k < 3; ++k) { x_new[3 * i + k] -= lam * s.invm[i] * ro[k]; x_new[3 * j + k] += lam * s.invm[j] * ro[k]; }
+            }
+            if (!(worst >= CONSTRAINT_TOL)) break;
+        }
+    }
+}
+
+// velocities (RATTLE): the Lagrange multipliers of a cluster's <= 3 constraints solve a small LINEAR system -- exact, no
+// iteration.  Constraint q = (i, j): r_q . (v_j - v_i) = 0 after  v_i += invm_i sum_q' (+-) lam_q' r_q'.
+void rattle(const System& s, const double* x, double* v)
+{
+    for (const Cluster& c : s.clusters) {
+        const int n = c.nc;
+        double r[3][3], A[3][3], b[3], lam[3];
+        for (int q = 0; q < n; ++q) {
+            const int i = c.atoms[c.ci[q]], j = c.atoms[c.cj[q]];
+            b[q] = 0;
+            for (int k = 0; k < 3; ++k) { r[q][k] = x[3 * j + k] - x[3 * i + k]; b[q] += r[q][k] * (v[3 * j + k] - v[3 * i + k]); }
+        }
+        for (int q = 0; q < n; ++q) for (int p = 0; p < n; ++p) {
+            // effect of lam_p (v_ip += lam invm r_p, v_jp -= lam invm r_p) on r_q . (v_jq - v_iq)
+            const int iq = c.ci[q], jq = c.cj[q], ip = c.ci[p], jp = c.cj[p];
+            double coef = 0;
+            if (jq == jp) coef -= s.invm[c.atoms[jp]];
+            if (jq == ip) coef += s.invm[c.atoms[ip]];
+            if (iq == jp) coef += s.invm[c.atoms[jp]];
+            if (iq == ip) coef -= s.invm[c.atoms[ip]];
+            A[q][p] = coef * (r[q][0] * r[p][0] + r[q][1] * r[p][1] + r[q][2] * r[p][2]);
+        }
+        // solve A lam = -b by Gaussian elimination with partial pivoting (n <= 3)
+        double Mx[3][4];
+        for (int q = 0; q < n; ++q) { for (int p = 0; p < n; ++p) Mx[q][p] = A[q][p]; Mx[q][n] = -b[q]; }
+        for (int col = 0; col < n; ++col) {
+            int piv = col;
+            for (int q = col + 1; q < n; ++q) if (fabs(Mx[q][col]) > fabs(Mx[piv][col])) piv = q;
+            if (piv != col) for (int p = 0; p <= n; ++p) std::swap(Mx[col][p], Mx[piv][p]);
+            for (int q = col + 1; q < n; ++q) { const double fct = Mx[q][col] / Mx[col][col]; for (int p = col; p <= n; ++p) Mx[q][p] -= fct * Mx[col][p]; }
+        }
+        for (int q = n - 1; q >= 0; --q) { double acc = Mx[q][n]; for (int p = q + 1; p < n; ++p) acc -= Mx[q][p] * lam[p]; lam[q] = acc / Mx[q][q]; }
+        for (int q = 0; q < n; ++q) {
+            const int i = c.atoms[c.ci[q]], j = c.atoms[c.cj[q]];
+            for (int k = 0; k < 3; ++k) { v[3 * i + k] += lam[q] * s.invm[i] * r[q][k]; v[3 * j + k] -= lam[q] * s.invm[j] * r[q][k]; }
+        }
+    }
+}
+
+} // namespace
+
+// ----------------------------------------------------------------------------------------------------------------------
+// the handle
+// ----------------------------------------------------------------------------------------------------------------------
+struct remd_ctx {
+    std::string err;
+    System sys;
+    bool has_system = false, has_integrator = false;
+    int K = 0;
+    std::vector<double> beta, lam_s, lam_e, econst;
+    double econst_vref = 0.0;
+    std::vector<char> tokens; int nV = 0, nR = 0, nO = 0;
+    double dt = 0, gamma = 0; int n_steps = 0, reassign = 0, n_restart_attempts = 0;
+    int R = 0, R_global = 0, r_begin = 0;
+    std::vector<Replica> reps;
+    std::vector<int64_t> labels;
+    std::vector<double> ukl;                   // [R_global][K]
+    std::vector<double> potential;
+    uint64_t seed = 0;
+    std::vector<FFTSet> fft;                   // one per OpenMP thread
+    double t_prop = 0, t_energy = 0, t_mix = 0;
+    int n_threads = 1;
+};
+
+static std::mutex g_err_mutex;
+static std::string g_last_error;
+static int fail(remd_ctx* h, int code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    std::lock_guard<std::mutex> l(g_err_mutex); g_last_error = msg;
+    return code;
+}
+
+static int parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO)
+{
+    tokens.clear(); nV = nR = nO = 0;
+    std::string s(splitting ? splitting : "");
+    size_t i = 0;
+    while (i < s.size()) {
+        while (i < s.size() && s[i] == ' ') ++i;
+        if (i >= s.size()) break;
+        size_t j = i; while (j < s.size() && s[j] != ' ') ++j;
+        std::string tok = s.substr(i, j - i);
+        for (auto& c : tok) c = (char)toupper(c);
+        if (tok == "V" || tok == "V0") { tokens.push_back('V'); nV++; }
+        else if (tok == "R") { tokens.push_back('R'); nR++; }
+        else if (tok == "O") { tokens.push_back('O'); nO++; }
+        else return fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V R O)");
+        i = j;
+    }
+    if (tokens.empty()) return fail(h, -3, "empty splitting string");
+    if (nR == 0 || nV == 0) return fail(h, -3, "splitting needs at least one R and one V (integrators.py:1376-1385)");
+    return 0;
+}
+
+static FFTSet& thread_fft(remd_ctx* h)
+{
+    int t = 0;
+#ifdef _OPENMP
+    t = omp_get_thread_num();
+#endif
+    FFTSet& f = h->fft[t];
+    if (h->sys.method == REMD_NB_PME && !f.f[0]) for (int k = 0; k < 3; ++k) f.f[k].reset(new FFT1D(h->sys.grid[k]));
+    return f;
+}
+
+static void ensure_forces(remd_ctx* h, int r)
+{
+    Replica& rep = h->reps[r];
+    if (rep.f_valid) return;
+    const int64_t k = h->labels[h->r_begin + r];
+    evaluate(h->sys, rep, h->lam_s[k], h->lam_e[k], rep.f.data(), thread_fft(h));
+    rep.f_valid = true;
+}
+
+// integrators.py:1309-1317, 1404-1460 for one replica (cf. oracle/md_oracle.py:OracleLangevin.run)
+static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int nV, int nR, int nO, int64_t iteration,
+                      int64_t first_step, int n_steps)
+{
+    const System& s = h->sys;
+    Replica& rep = h->reps[r];
+    const int N = s.N, rg = h->r_begin + r;
+    const double kT = 1.0 / h->beta[h->labels[rg]];
+    const double hV = h->dt / std::max(1, nV), hR = h->dt / std::max(1, nR), hO = h->dt / std::max(1, nO);
+    const double a = exp(-h->gamma * hO), b = sqrt(1.0 - exp(-2.0 * h->gamma * hO));      // integrators.py:1143, 1146
+    const bool cons = !s.clusters.empty();
+    std::vector<double> x1;
+    if (cons) x1.resize(3 * N);
+    double* x = rep.x.data(); double* v = rep.v.data();
+    for (int st = 0; st < n_steps; ++st) {
+        const int64_t gstep = iteration * (int64_t)h->n_steps + first_step + st;
+        if (s.cmm > 0 && ((first_step + st) % s.cmm) == 0) {              // CMMotionRemover at the top of a step (:1313)
+            double p[3] = {0, 0, 0};
+            for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) p[k] += s.mass[i] * v[3 * i + k];
+            for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) v[3 * i + k] -= p[k] / s.total_mass;
+        }
+        int oidx = 0;
+        for (char tok : tokens) {
+            if (tok == 'V') {
+                ensure_forces(h, r);
+                const double* f = rep.f.data();
+                for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) v[3 * i + k] += hV * f[3 * i + k] * s.invm[i];   // :1440-1442
+                if (cons) rattle(s, x, v);
+            } else if (tok == 'R') {
+                if (cons) {
+                    for (int i = 0; i < 3 * N; ++i) x1[i] = x[i] + hR * v[i];                                            // :1414
+                    std::vector<double> xc(x1);
+                    shake(s, x, xc.data());                                                                              // :1416
+                    for (int i = 0; i < 3 * N; ++i) { v[i] += (xc[i] - x1[i]) / hR; x[i] = xc[i]; }                        // :1417
+                    rattle(s, x, v);                                                                                     // :1418
+                } else for (int i = 0; i < 3 * N; ++i) x[i] += hR * v[i];
+                rep.f_valid = false;
+            } else {
+                const uint64_t cnt = (uint64_t)gstep * (uint64_t)std::max(1, nO) + (uint64_t)oidx;
+                for (int i = 0; i < N; ++i) {
+                    double g[3]; gaussians3(h->seed, 5u, i, rg, cnt, g);
+                    const double sg = b * sqrt(kT * s.invm[i]);
+                    for (int k = 0; k < 3; ++k) v[3 * i + k] = a * v[3 * i + k] + sg * g[k];                             // :1455
+                }
+                if (cons) rattle(s, x, v);
+                oidx++;
+            }
+        }
+    }
+}
+
+static void assign_velocities(remd_ctx* h, int r, int64_t iteration)
+{
+    const System& s = h->sys;
+    Replica& rep = h->reps[r];
+    const int rg = h->r_begin + r;
+    const double kT = 1.0 / h->beta[h->labels[rg]];
+    for (int i = 0; i < s.N; ++i) {                                       // mcmc.py:710-711
+        double g[3]; gaussians3(h->seed, 4u, i, rg, (uint64_t)iteration, g);
+        const double sg = sqrt(kT * s.invm[i]);
+        for (int k = 0; k < 3; ++k) rep.v[3 * i + k] = sg * g[k];
+    }
+    if (!s.clusters.empty()) rattle(s, rep.x.data(), rep.v.data());
+}
+
+static bool finite_state(const Replica& rep)
+{
+    for (double a : rep.x) if (!std::isfinite(a)) return false;
+    for (double a : rep.v) if (!std::isfinite(a)) return false;
+    return true;
+}
+
+// u_kl row of one replica (states.py:911-992, 1908-1917); returns the potential at the replica's own state
+static double ukl_row(remd_ctx* h, int r, double* row)
+{
+    const System& s = h->sys;
+    Replica& rep = h->reps[r];
+    FFTSet& fft = thread_fft(h);
+    const int K = h->K;
+    const int64_t own = h->labels[h->r_begin + r];
+    const double V = rep.box[0] * rep.box[1] * rep.box[2];
+    const double cscale = (h->econst_vref > 0 && V > 0) ? h->econst_vref / V : 1.0;
+    bool lam_varies = false;
+    for (int k = 0; k < K; ++k) if (h->lam_s[k] != h->lam_s[0] || h->lam_e[k] != h->lam_e[0]) lam_varies = true;
+    if (!s.has_alch || !lam_varies) {
+        // one energy per replica serves every state (paralleltempering.py:206-215)
+        const double U = evaluate(s, rep, h->lam_s[own], h->lam_e[own], nullptr, fft).total();
+        for (int k = 0; k < K; ++k) row[k] = h->beta[k] * (U + h->econst[k] * cscale);
+        return U;
+    }
+    // alchemical states: only the soft-core pairs depend on lambda_sterics; the electrostatic energy is an exact quadratic
+    // in lambda_electrostatics (charges and exception charge products are linear in it) -> three evaluations
+    const double base = evaluate(s, rep, 1.0, 1.0, nullptr, fft, PART_BONDED | PART_STERICS).total();
+    double el[3] = {0, 0, 0};
+    if (s.has_charge) for (int q = 0; q < 3; ++q) el[q] = evaluate(s, rep, 1.0, 0.5 * q, nullptr, fft, PART_ELEC).total();
+    const double c0 = el[0], c2 = 2.0 * (el[2] - 2.0 * el[1] + el[0]), c1 = el[2] - el[0] - c2;
+    std::map<double, double> sc;
+    double U_own = 0;
+    for (int k = 0; k < K; ++k) {
+        auto it = sc.find(h->lam_s[k]);
+        if (it == sc.end()) it = sc.emplace(h->lam_s[k], evaluate(s, rep, h->lam_s[k], 1.0, nullptr, fft, PART_SOFTCORE).total()).first;
+        const double le = h->lam_e[k];
+        const double U = base + it->second + c0 + c1 * le + c2 * le * le;
+        row[k] = h->beta[k] * (U + h->econst[k] * cscale);
+        if (k == own) U_own = U;
+    }
+    return U_own;
+}
+
+extern "C" {
+
+int remd_version(void) { return 1; }
+
+const char* remd_last_error(remd_handle h)
+{
+    if (h) return h->err.c_str();
+    std::lock_guard<std::mutex> l(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_last_error;
+    return copy.c_str();
+}
+
+int remd_create(remd_handle* out, int device, void* stream)
+{
+    (void)device; (void)stream;
+    if (!out) return fail(nullptr, -1, "remd_create: out is NULL");
+    remd_ctx* h = new remd_ctx();
+#ifdef _OPENMP
+    h->n_threads = omp_get_max_threads();
+#endif
+    h->fft.resize(std::max(256, h->n_threads));
+    *out = h;
+    return 0;
+}
+
+int remd_destroy(remd_handle h)
+{
+    if (g_time) fprintf(stderr, "[remd_cpu] ms: list %.1f pairs %.1f pme %.1f\n", g_timers.list, g_timers.pairs, g_timers.pme);
+    delete h; return 0;
+}
+int remd_seed(remd_handle h, uint64_t seed) { if (!h) return -1; h->seed = seed; return 0; }
+
+int remd_set_system(remd_handle h, const remd_system_desc* d)
+{
+    if (!h || !d) return fail(h, -1, "remd_set_system: NULL argument");
+    if (d->n_atoms <= 0 || !d->mass) return fail(h, -1, "remd_set_system: n_atoms/mass missing");
+    System s;
+    const int N = s.N = d->n_atoms;
+    s.mass.assign(d->mass, d->mass + N); s.invm.resize(N);
+    for (int i = 0; i < N; ++i) {
+        if (!(s.mass[i] > 0)) return fail(h, -3, "massless particles are not supported");
+        s.invm[i] = 1.0 / s.mass[i]; s.total_mass += s.mass[i];
+    }
+    s.ext_atoms.assign(d->ext_atoms, d->ext_atoms + d->n_ext); s.ext_K = d->ext_K; s.ext_x0 = d->ext_x0; s.ext_U0 = d->ext_U0;
+    s.bond_atoms.assign(d->bond_atoms, d->bond_atoms + 2 * (size_t)d->n_bonds); s.bond_params.assign(d->bond_params, d->bond_params + 2 * (size_t)d->n_bonds);
+    s.angle_atoms.assign(d->angle_atoms, d->angle_atoms + 3 * (size_t)d->n_angles); s.angle_params.assign(d->angle_params, d->angle_params + 2 * (size_t)d->n_angles);
+    s.torsion_atoms.assign(d->torsion_atoms, d->torsion_atoms + 4 * (size_t)d->n_torsions); s.torsion_params.assign(d->torsion_params, d->torsion_params + 3 * (size_t)d->n_torsions);
+    s.method = d->nb_method; s.rc = d->cutoff; s.rs = d->switch_distance > 0 ? d->switch_distance : -1.0;
+    s.rf_eps = d->rf_dielectric; s.alpha = d->ewald_alpha; s.use_disp = d->use_dispersion_correction;
+    for (int k = 0; k < 3; ++k) s.grid[k] = d->pme_grid[k];
+    s.q.assign(N, 0.0); s.sig.assign(N, 1.0); s.eps.assign(N, 0.0); s.alch.assign(N, 0);
+    if (s.method) {
+        if (!d->charge || !d->sigma || !d->epsilon) return fail(h, -1, "remd_set_system: nonbonded parameters missing");
+        s.q.assign(d->charge, d->charge + N); s.sig.assign(d->sigma, d->sigma + N); s.eps.assign(d->epsilon, d->epsilon + N);
+    }
+    for (double q : s.q) if (q != 0.0) s.has_charge = true;
+    for (int a = 0; a < d->n_alch; ++a) { s.alch[d->alch_atoms[a]] = 1; s.has_alch = true; }
+    s.sc_alpha = d->softcore_alpha; s.sc_a = d->softcore_a; s.sc_b = d->softcore_b; s.sc_c = d->softcore_c;
+    s.exc_atoms.assign(d->exception_atoms, d->exception_atoms + 2 * (size_t)d->n_exceptions);
+    s.exc_params.assign(d->exception_params, d->exception_params + 3 * (size_t)d->n_exceptions);
+    s.excl.assign(N, {});
+    for (int e = 0; e < d->n_exceptions; ++e) {
+        const int i = std::min(s.exc_atoms[2 * e], s.exc_atoms[2 * e + 1]), j = std::max(s.exc_atoms[2 * e], s.exc_atoms[2 * e + 1]);
+        s.excl[i].push_back(j);
+    }
+    for (auto& v : s.excl) std::sort(v.begin(), v.end());
+    int n_con = 0;
+    for (int w = 0; w < d->n_settle; ++w) {
+        Cluster c{}; c.n_atoms = 3; for (int k = 0; k < 3; ++k) c.atoms[k] = d->settle_atoms[3 * w + k];
+        c.nc = 3; c.ci[0] = 0; c.cj[0] = 1; c.d[0] = d->settle_dOH; c.ci[1] = 0; c.cj[1] = 2; c.d[1] = d->settle_dOH; c.ci[2] = 1; c.cj[2] = 2; c.d[2] = d->settle_dHH;
+        c.settle = 1;
+        s.clusters.push_back(c); n_con += 3;
+    }
+    for (int w = 0; w < d->n_shake; ++w) {
+        Cluster c{}; c.n_atoms = 1; c.atoms[0] = d->shake_atoms[4 * w]; c.nc = 0;
+        for (int k = 1; k < 4; ++k) if (d->shake_atoms[4 * w + k] >= 0) {
+            c.atoms[c.n_atoms] = d->shake_atoms[4 * w + k]; c.ci[c.nc] = 0; c.cj[c.nc] = c.n_atoms; c.d[c.nc] = d->shake_dist[3 * w + k - 1];
+            c.n_atoms++; c.nc++; n_con++;
+        }
+        s.clusters.push_back(c);
+    }
+    if (d->n_settle > 0) {
+        // Miyamoto & Kollman geometry constants of the rigid water (all waters share masses and distances)
+        const int* a = d->settle_atoms;
+        s.settle_mO = d->mass[a[0]]; s.settle_mH = d->mass[a[1]];
+        s.settle_rc = 0.5 * d->settle_dHH;
+        const double t = sqrt(d->settle_dOH * d->settle_dOH - s.settle_rc * s.settle_rc);
+        s.settle_ra = 2.0 * s.settle_mH * t / (s.settle_mO + 2.0 * s.settle_mH); s.settle_rb = t - s.settle_ra; s.settle_dHH = d->settle_dHH;
+        for (int w = 0; w < d->n_settle; ++w)
+            if (d->mass[a[3 * w]] != s.settle_mO || d->mass[a[3 * w + 1]] != s.settle_mH || d->mass[a[3 * w + 2]] != s.settle_mH)
+                return fail(h, -3, "remd_set_system: SETTLE waters must share one set of masses");
+    }
+    s.cmm = d->cmm_frequency;
+    s.n_dof = 3 * N - n_con - (s.cmm > 0 ? 3 : 0);
+    if (s.method == REMD_NB_PME) {
+        for (int k = 0; k < 3; ++k) { if (s.grid[k] < PME_ORDER) return fail(h, -1, "remd_set_system: PME mesh too small"); s.bmod[k] = bspline_moduli(s.grid[k]); }
+    }
+    s.disp_coeff = (s.method && s.use_disp) ? dispersion_coefficient(s) : 0.0;
+    h->sys = std::move(s);
+    for (auto& f : h->fft) for (int k = 0; k < 3; ++k) f.f[k].reset();
+    h->has_system = true;
+    for (auto& r : h->reps) { r.f_valid = false; r.list_valid = false; }
+    return 0;
+}
+
+int remd_set_states(remd_handle h, int K, const double* beta, const double* lam_s, const double* lam_e, const double* econst)
+{
+    if (!h || K <= 0 || !beta) return fail(h, -1, "remd_set_states: bad arguments");
+    for (int k = 0; k < K; ++k) if (!(beta[k] > 0)) return fail(h, -1, "remd_set_states: beta must be > 0");
+    h->K = K;
+    h->beta.assign(beta, beta + K);
+    h->lam_s.assign(K, 1.0); h->lam_e.assign(K, 1.0); h->econst.assign(K, 0.0);
+    if (lam_s) h->lam_s.assign(lam_s, lam_s + K);
+    if (lam_e) h->lam_e.assign(lam_e, lam_e + K);
+    if (econst) h->econst.assign(econst, econst + K);
+    h->ukl.assign((size_t)std::max(0, h->R_global) * K, 0.0);
+    for (auto& r : h->reps) r.f_valid = false;
+    return 0;
+}
+
+int remd_set_integrator(remd_handle h, const char* splitting, double dt, double gamma, int n_steps, int reassign, double tol)
+{
+    (void)tol;                                     // the f64 solver always iterates to 1e-12
+    if (!h) return -1;
+    if (!(dt > 0) || n_steps < 0 || gamma < 0) return fail(h, -1, "remd_set_integrator: bad parameters");
+    int rc = parse_splitting(h, splitting, h->tokens, h->nV, h->nR, h->nO);
+    if (rc) return rc;
+    h->dt = dt; h->gamma = gamma; h->n_steps = n_steps; h->reassign = reassign; h->has_integrator = true;
+    return 0;
+}
+
+int remd_set_restart_attempts(remd_handle h, int n)
+{
+    if (!h || n < 0) return fail(h, -1, "remd_set_restart_attempts: bad arguments");
+    h->n_restart_attempts = n;
+    return 0;
+}
+
+int remd_set_barostat(remd_handle h, int K, const double* pressure, int frequency)
+{
+    (void)K;
+    if (!h) return -1;
+    if (!pressure || frequency <= 0) return 0;     // switching it off is fine
+    return fail(h, -3, "libremd_cpu: the Monte Carlo barostat is not implemented in the CPU baseline");
+}
+int remd_get_boxes(remd_handle h, double* box)
+{
+    if (!h || !box || h->R <= 0) return fail(h, -1, "remd_get_boxes: replicas not set");
+    for (int r = 0; r < h->R; ++r) for (int k = 0; k < 3; ++k) box[3 * r + k] = h->reps[r].box[k];
+    return 0;
+}
+int remd_set_energy_const_volume(remd_handle h, double v) { if (!h || !(v >= 0)) return fail(h, -1, "remd_set_energy_const_volume: bad arguments"); h->econst_vref = v; return 0; }
+int remd_get_barostat_stats(remd_handle h, double* vs, int64_t* na, int64_t* nc)
+{
+    if (!h || h->R <= 0) return fail(h, -1, "remd_get_barostat_stats: replicas not set");
+    for (int r = 0; r < h->R; ++r) { if (vs) vs[r] = 0; if (na) na[r] = 0; if (nc) nc[r] = 0; }
+    return 0;
+}
+int remd_barostat_attempts(remd_handle h, int n) { (void)n; return fail(h, -3, "remd_barostat_attempts: no barostat (remd_set_barostat)"); }
+int remd_minimize(remd_handle h, double tol, int maxit, int32_t* conv, int32_t* nit)
+{
+    (void)tol; (void)maxit; (void)conv; (void)nit;
+    return fail(h, -3, "libremd_cpu: FIRE minimisation is not implemented in the CPU baseline");
+}
+
+int remd_set_labels(remd_handle h, const int64_t* labels)
+{
+    if (!h || !labels || h->R_global <= 0) return fail(h, -1, "remd_set_labels: replicas not set");
+    for (int r = 0; r < h->R_global; ++r)
+        if (labels[r] < 0 || (h->K > 0 && labels[r] >= h->K)) return fail(h, -1, "remd_set_labels: label out of range");
+    bool changed = h->labels.size() != (size_t)h->R_global;
+    for (int r = 0; r < h->R_global && !changed; ++r) if (h->labels[r] != labels[r]) changed = true;
+    h->labels.assign(labels, labels + h->R_global);
+    if (changed && h->sys.has_alch) for (auto& r : h->reps) r.f_valid = false;     // forces depend on the state's lambdas
+    return 0;
+}
+
+int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, const double* x, const double* v, const double* box,
+                      const int64_t* labels)
+{
+    if (!h || !h->has_system) return fail(h, -1, "remd_set_replicas: call remd_set_system first");
+    if (R_global <= 0 || R_local <= 0 || r_begin < 0 || r_begin + R_local > R_global || !x || !labels)
+        return fail(h, -1, "remd_set_replicas: bad arguments");
+    const int N = h->sys.N;
+    h->R_global = R_global; h->r_begin = r_begin; h->R = R_local;
+    h->reps.assign(R_local, Replica());
+    for (int r = 0; r < R_local; ++r) {
+        Replica& rep = h->reps[r];
+        rep.x.assign(x + (size_t)r * 3 * N, x + (size_t)(r + 1) * 3 * N);
+        if (v) rep.v.assign(v + (size_t)r * 3 * N, v + (size_t)(r + 1) * 3 * N); else rep.v.assign(3 * (size_t)N, 0.0);
+        rep.f.assign(3 * (size_t)N, 0.0);
+        for (int k = 0; k < 3; ++k) rep.box[k] = box ? box[3 * r + k] : 0.0;
+        if (h->sys.method && !(rep.box[0] > 0 && rep.box[1] > 0 && rep.box[2] > 0)) return fail(h, -1, "remd_set_replicas: periodic system needs a box");
+        if (h->sys.method) for (int k = 0; k < 3; ++k) if (rep.box[k] < 2.0 * h->sys.rc) return fail(h, -1, "remd_set_replicas: box smaller than twice the cutoff");
+    }
+    h->ukl.assign((size_t)R_global * std::max(0, h->K), 0.0);
+    h->potential.assign(R_local, 0.0);
+    h->labels.clear();
+    return remd_set_labels(h, labels);
+}
+
+int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
+{
+    if (!h || !h->has_system || !h->has_integrator || h->R <= 0 || h->K <= 0)
+        return fail(h, -1, "remd_propagate: system/states/integrator/replicas not all set");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int R = h->R;
+    std::vector<int> flags(R, 0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int r = 0; r < R; ++r) {
+        Replica& rep = h->reps[r];
+        const std::vector<double> x0 = rep.x, v0 = rep.v;
+        for (int a = 0; a <= h->n_restart_attempts; ++a) {             // mcmc.py:706-759
+            const int64_t it = iteration + ((int64_t)a << 40);
+            if (a > 0) { rep.x = x0; rep.v = v0; rep.f_valid = false; }
+            if (h->reassign) assign_velocities(h, r, it);
+            run_steps(h, r, h->tokens, h->nV, h->nR, h->nO, it, 0, h->n_steps);
+            flags[r] = finite_state(rep) ? 0 : 1;
+            if (!flags[r]) break;
+        }
+    }
+    h->t_prop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (nan_flags) for (int r = 0; r < R; ++r) nan_flags[r] = flags[r];
+    return 0;
+}
+
+int remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t first_step, int n_steps)
+{
+    if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return fail(h, -1, "remd_step: not set up");
+    std::vector<char> tokens;
+    for (const char* c = splitting ? splitting : ""; *c; ++c) {
+        if (*c == ' ') continue;
+        const char t = (char)toupper(*c);
+        if (t != 'V' && t != 'R' && t != 'O') return fail(h, -3, "remd_step: token must be V, R or O");
+        tokens.push_back(t);
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int r = 0; r < h->R; ++r) run_steps(h, r, tokens, h->nV, h->nR, h->nO, iteration, first_step, n_steps);
+    return 0;
+}
+
+int remd_ukl_device_ptr(remd_handle h, double** d_ukl)
+{
+    if (!h || !d_ukl || h->ukl.empty()) return fail(h, -1, "remd_ukl_device_ptr: states/replicas not set");
+    *d_ukl = h->ukl.data();
+    return 0;
+}
+
+int remd_compute_energies(remd_handle h, double* d_rows, double* ukl_host, double* potential_host)
+{
+    if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return fail(h, -1, "remd_compute_energies: not set up");
+    const auto t0 = std::chrono::steady_clock::now();
+    if (h->ukl.size() != (size_t)h->R_global * h->K) h->ukl.assign((size_t)h->R_global * h->K, 0.0);
+    double* rows = d_rows ? d_rows : h->ukl.data() + (size_t)h->r_begin * h->K;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int r = 0; r < h->R; ++r) h->potential[r] = ukl_row(h, r, rows + (size_t)r * h->K);
+    h->t_energy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ukl_host) memcpy(ukl_host, rows, sizeof(double) * (size_t)h->R * h->K);
+    if (potential_host) memcpy(potential_host, h->potential.data(), sizeof(double) * h->R);
+    return 0;
+}
+
+static int mix_impl(remd_ctx* h, int scheme, int64_t iteration, int R, int K, const double* u, int ld, int64_t* labels,
+                    int64_t* nacc, int64_t* nprop, const double* logw, double* logP, int64_t n_attempts)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<double> uc((size_t)R * K);
+    for (int r = 0; r < R; ++r) memcpy(&uc[(size_t)r * K], u + (size_t)r * ld, sizeof(double) * K);
+    std::vector<int64_t> a((size_t)K * K, 0), p((size_t)K * K, 0);
+    std::vector<double> lp;
+    switch (scheme) {
+        case REMD_MIX_NONE: break;
+        case REMD_MIX_SWAP_ALL: oracle_mix_swap_all(h->seed, iteration, R, K, uc.data(), labels, a.data(), p.data(), n_attempts); break;
+        case REMD_MIX_SWAP_NEIGHBORS: oracle_mix_swap_neighbors(h->seed, iteration, R, K, uc.data(), labels, a.data(), p.data()); break;
+        case REMD_MIX_SAMS_GLOBAL:
+            if (!logw) return fail(h, -1, "remd_mix: SAMS needs log_weights");
+            lp.resize((size_t)R * K);
+            oracle_sams_global_jump(h->seed, iteration, R, K, uc.data(), logw, labels, a.data(), p.data(), lp.data());
+            if (logP) memcpy(logP, lp.data(), sizeof(double) * lp.size());
+            break;
+        default: return fail(h, -1, "remd_mix: unknown scheme");
+    }
+    if (nacc) memcpy(nacc, a.data(), sizeof(int64_t) * a.size());
+    if (nprop) memcpy(nprop, p.data(), sizeof(int64_t) * p.size());
+    h->t_mix = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int remd_mix(remd_handle h, int scheme, int64_t iteration, int R, int K, const double* d_ukl, int ld, int64_t* labels,
+             int64_t* nacc, int64_t* nprop, const double* logw, double* logP)
+{
+    if (!h || !labels || R <= 0 || K <= 0) return fail(h, -1, "remd_mix: bad arguments");
+    if (!d_ukl) {
+        if (h->ukl.empty() || R != h->R_global || K > h->K) return fail(h, -1, "remd_mix: handle has no matching u_kl matrix");
+        d_ukl = h->ukl.data(); ld = h->K;
+    }
+    if (ld <= 0) ld = K;
+    int rc = mix_impl(h, scheme, iteration, R, K, d_ukl, ld, labels, nacc, nprop, logw, logP, -1);
+    if (!rc && R == h->R_global && !h->labels.empty()) rc = remd_set_labels(h, labels);
+    return rc;
+}
+
+int remd_mix_host(remd_handle h, int scheme, int64_t iteration, int R, int K, const double* ukl, int64_t* labels, int64_t* nacc,
+                  int64_t* nprop, const double* logw, double* logP, int64_t n_attempts)
+{
+    if (!h || !labels || !ukl || R <= 0 || K <= 0) return fail(h, -1, "remd_mix_host: bad arguments");
+    return mix_impl(h, scheme, iteration, R, K, ukl, K, labels, nacc, nprop, logw, logP, n_attempts);
+}
+
+int remd_get_replicas(remd_handle h, double* x, double* v, double* potential, double* kinetic)
+{
+    if (!h || h->R <= 0) return fail(h, -1, "remd_get_replicas: no replicas");
+    const int N = h->sys.N;
+    for (int r = 0; r < h->R; ++r) {
+        if (x) memcpy(x + (size_t)r * 3 * N, h->reps[r].x.data(), sizeof(double) * 3 * N);
+        if (v) memcpy(v + (size_t)r * 3 * N, h->reps[r].v.data(), sizeof(double) * 3 * N);
+        if (kinetic) { double ke = 0; for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) ke += 0.5 * h->sys.mass[i] * h->reps[r].v[3 * i + k] * h->reps[r].v[3 * i + k]; kinetic[r] = ke; }
+    }
+    if (potential) {
+        if (h->K <= 0) return fail(h, -1, "remd_get_replicas: states not set");
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int r = 0; r < h->R; ++r) {
+            const int64_t k = h->labels[h->r_begin + r];
+            potential[r] = evaluate(h->sys, h->reps[r], h->lam_s[k], h->lam_e[k], nullptr, thread_fft(h)).total();
+        }
+    }
+    return 0;
+}
+
+int remd_get_forces(remd_handle h, double* f)
+{
+    if (!h || h->R <= 0 || !f || h->K <= 0) return fail(h, -1, "remd_get_forces: bad arguments");
+    const int N = h->sys.N;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int r = 0; r < h->R; ++r) { h->reps[r].f_valid = false; ensure_forces(h, r); memcpy(f + (size_t)r * 3 * N, h->reps[r].f.data(), sizeof(double) * 3 * N); }
+    return 0;
+}
+
+int remd_get_energy_components(remd_handle h, double* out)
+{
+    if (!h || !out || h->R <= 0 || h->K <= 0) return fail(h, -1, "remd_get_energy_components: bad arguments");
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int r = 0; r < h->R; ++r) {
+        const int64_t k = h->labels[h->r_begin + r];
+        const Energy E = evaluate(h->sys, h->reps[r], h->lam_s[k], h->lam_e[k], nullptr, thread_fft(h));
+        for (int c = 0; c < 9; ++c) out[9 * r + c] = E.c[c];
+    }
+    return 0;
+}
+
+int remd_sync(remd_handle h) { return h ? 0 : -1; }
+
+int remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inverse)
+{
+    if (!h || !data || nx <= 0 || ny <= 0 || nz <= 0) return fail(h, -1, "remd_test_fft3d: bad arguments");
+    const int n[3] = {nx, ny, nz};
+    std::vector<cplx> a((size_t)nx * ny * nz);
+    for (size_t i = 0; i < a.size(); ++i) a[i] = cplx(data[2 * i], data[2 * i + 1]);
+    const size_t stride[3] = {(size_t)ny * nz, (size_t)nz, 1};
+    for (int dim = 0; dim < 3; ++dim) {
+        FFT1D fft(n[dim]);
+        std::vector<cplx> lin(n[dim]), lout(n[dim]);
+        const int d1 = (dim + 1) % 3, d2 = (dim + 2) % 3;
+        for (int p = 0; p < n[d1]; ++p) for (int q = 0; q < n[d2]; ++q) {
+            const size_t base = p * stride[d1] + q * stride[d2];
+            for (int k = 0; k < n[dim]; ++k) lin[k] = a[base + k * stride[dim]];
+            fft.transform(lin.data(), lout.data(), inverse != 0);
+            for (int k = 0; k < n[dim]; ++k) a[base + k * stride[dim]] = lout[k];
+        }
+    }
+    for (size_t i = 0; i < a.size(); ++i) { data[2 * i] = (float)a[i].real(); data[2 * i + 1] = (float)a[i].imag(); }
+    return 0;
+}
+
+int remd_last_timing(remd_handle h, double* p, double* e, double* m)
+{
+    if (!h) return -1;
+    if (p) *p = h->t_prop; if (e) *e = h->t_energy; if (m) *m = h->t_mix;
+    return 0;
+}
+
+int remd_profile_enable(remd_handle h, int on) { (void)on; return h ? 0 : -1; }
+int remd_profile_filter(remd_handle h, const char* c) { (void)c; return h ? 0 : -1; }
+int remd_profile_reset(remd_handle h) { return h ? 0 : -1; }
+int remd_profile_get(remd_handle h, const char* name, int64_t* n, double* ms) { (void)name; if (!h) return -1; if (n) *n = 0; if (ms) *ms = 0; return 0; }
+
+/* CPU-library extension used by bench.py's cpu_baseline leg: threads OpenMP will use over replicas */
+int remd_cpu_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+} // extern "C"
