@@ -318,7 +318,13 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         if (force_waves <= 0) waves = std::max(1, std::min(max_waves, (per_r * R + 63) / 64));
         while (waves > 1 && (size_t)R * waves * 8 > 64 * 1024) --waves;      // occupancy masks [R][waves] u64
         const size_t Rp = (size_t)((R + 1) & ~1);
-        const size_t work_bytes = 8 * (size_t)R * waves + 4 * (size_t)R * 32 + 4 * Rp + 8 * Rp + 16;
+        auto work_for = [&](int wv) { return 8 * (size_t)R * wv + 4 * (size_t)R * 32 + 4 * Rp + 8 * Rp + 16; };
+        // a slightly shorter window (>= 5R attempts) that lets u_kl stay in LDS beats a longer one reading it from L2
+        // (R = 128: 10 wavefronts, 21.9 ms instead of 25.0 ms with 12; measured, tools/mix_microbench.py)
+        if (force_waves <= 0 && ukl_bytes + work_for(waves) > 156 * 1024)
+            for (int wv = waves - 1; wv >= std::max(1, (5 * R + 63) / 64); --wv)
+                if (ukl_bytes + work_for(wv) <= 156 * 1024) { waves = wv; break; }
+        const size_t work_bytes = work_for(waves);
         const size_t stat_bytes = sizeof(unsigned) * 2 * (size_t)K * K;
         // u_kl, then the counters (32-bit: <= 2 R^3 per entry), live in LDS when they fit in 160 KB; else global memory
         int in_lds = ukl_bytes + work_bytes <= 156 * 1024;

@@ -159,3 +159,4 @@ def test_device_reproduces_the_committed_golden_vectors(hip_engine_factory):
         got = eng.mix_host('swap-all', c['iteration'], np.array(c['u_kl']), np.array(c['labels_in'], dtype=np.int64))
         assert got[0].tolist() == c['labels_out']
         assert got[1].tolist() == c['n_accepted'] and got[2].tolist() == c['n_proposed']
+
