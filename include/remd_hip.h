@@ -119,7 +119,11 @@ int  remd_set_states(remd_handle h, int K, const double* beta,
                      const double* energy_const);
 
 /* LangevinIntegrator (integrators.py:1071-1158) as used by
-   mcmc.LangevinSplittingDynamicsMove (mcmc.py:1280-1316): splitting string of V/R/O tokens. */
+   mcmc.LangevinSplittingDynamicsMove (mcmc.py:1280-1316): splitting string of V/R/O tokens.
+   constraint_tolerance (reference default 1e-8, integrators.py:1073): rigid waters are solved analytically (SETTLE) and
+   do not depend on it; the iterative X-H cluster solver works on the fp32 state and stops at
+   max(constraint_tolerance, 1e-6) relative -- a smaller request is honoured as 1e-6, the floor of fp32 coordinates
+   (<= 0 selects the default 1e-8, i.e. 1e-6 effective).  libremd_cpu.so (f64) always iterates to 1e-12.                  */
 int  remd_set_integrator(remd_handle h, const char* splitting, double timestep_ps,
                          double collision_rate_invps, int n_steps,
                          int reassign_velocities, double constraint_tolerance);

@@ -53,8 +53,8 @@ class LangevinSplittingDynamicsMove(BaseIntegratorMove):
                  n_steps=1000, reassign_velocities=False, splitting="V R O R V", constraint_tolerance=1.0e-8,
                  measure_shadow_work=False, measure_heat=False, **kwargs):
         super().__init__(n_steps=n_steps, reassign_velocities=reassign_velocities, **kwargs)
-        self.timestep = float(timestep)
-        self.collision_rate = float(collision_rate)
+        self.timestep = float(unit.to_md(timestep))                 # ps; float or openmm.unit.Quantity
+        self.collision_rate = float(unit.to_md(collision_rate))     # 1/ps
         self.splitting = splitting
         self.constraint_tolerance = float(constraint_tolerance)
         if measure_shadow_work or measure_heat:

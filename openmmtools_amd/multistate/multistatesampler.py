@@ -380,6 +380,11 @@ class MultiStateSampler:
         move = self._engine_move()
         eng = self._engine
         if move is not None:
+            if getattr(eng, 'is_device', False) and move.constraint_tolerance < 1e-6 and not getattr(self, '_warned_tolerance', False):
+                # include/remd_hip.h: the fp32 state bounds what the iterative X-H solver can reach (SETTLE waters are analytic)
+                logger.warning('constraint_tolerance %g is below the fp32 floor of the device state; X-H clusters are '
+                               'constrained to 1e-6 relative, rigid waters analytically', move.constraint_tolerance)
+                self._warned_tolerance = True
             eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
                                move.reassign_velocities, move.constraint_tolerance)
             eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
@@ -451,7 +456,7 @@ class MultiStateSampler:
         if self._thermodynamic_states is None or self.n_replicas == 0:
             raise RuntimeError('Cannot minimize replicas. The simulation must be created first.')     # :629-630
         self._engine.set_labels(self._replica_thermodynamic_states)
-        converged, n_steps = self._engine.minimize(float(tolerance), int(max_iterations))
+        converged, n_steps = self._engine.minimize(float(unit.to_md(tolerance)), int(max_iterations))
         self._sampler_states_stale = True
         self._neighborhoods[:, :] = 0                     # energies are stale: run() recomputes them at iteration 0
         self._gather_sampler_states()

@@ -11,6 +11,7 @@ Quantities are md-unit floats / numpy arrays (see unit.py).
 import copy
 import numpy as np
 from . import constants
+from .unit import to_md
 
 
 class ThermodynamicState:
@@ -19,7 +20,7 @@ class ThermodynamicState:
         self.temperature = temperature
         # NPT: the reference adds an openmm.MonteCarloBarostat (frequency 25) to the System (states.py:1177-1181); here the
         # pressure (kJ/mol/nm^3, i.e. `p * unit.bar`) and the frequency are handed to the engine's barostat
-        self.pressure = None if pressure is None else float(pressure)
+        self.pressure = None if pressure is None else float(to_md(pressure))     # Quantity -> kJ/mol/nm^3 (md units)
         self.barostat_frequency = 25
         if pressure is not None and not system.usesPeriodicBoundaryConditions():
             raise ValueError('pressure is specified but the system is not periodic')          # states.py:1156-1158
@@ -37,7 +38,7 @@ class ThermodynamicState:
 
     @temperature.setter
     def temperature(self, value):
-        value = float(value)
+        value = float(to_md(value))                    # float kelvin or an openmm.unit.Quantity
         if not value > 0:
             raise ValueError('temperature must be positive')
         self._temperature = value
@@ -144,9 +145,12 @@ class CompoundThermodynamicState(ThermodynamicState):
 
 class SamplerState:
     def __init__(self, positions, velocities=None, box_vectors=None):
-        self.positions = np.array(positions, dtype=np.float64).reshape(-1, 3)
-        self.velocities = None if velocities is None else np.array(velocities, dtype=np.float64).reshape(-1, 3)
-        self.box_vectors = None if box_vectors is None else np.array(box_vectors, dtype=np.float64).reshape(3, 3)
+        # plain arrays in nm / nm ps^-1, or openmm.unit.Quantity of arrays / Vec3 lists (states.py:1975-2010)
+        self.positions = np.array(to_md(positions), dtype=np.float64).reshape(-1, 3)
+        self.velocities = None if velocities is None else np.array(to_md(velocities), dtype=np.float64).reshape(-1, 3)
+        if box_vectors is not None and not hasattr(box_vectors, 'value_in_unit_system'):
+            box_vectors = [to_md(b) for b in box_vectors] if isinstance(box_vectors, (list, tuple)) else box_vectors
+        self.box_vectors = None if box_vectors is None else np.array(to_md(box_vectors), dtype=np.float64).reshape(3, 3)
         self.potential_energy = None
         self.kinetic_energy = None
 

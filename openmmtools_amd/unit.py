@@ -27,3 +27,28 @@ atmosphere = atmospheres = 1.01325 * bar
 # angles
 radian = radians = 1.0
 degree = degrees = 0.017453292519943295
+
+
+def to_md(value):
+    """A plain number / array in OpenMM's md_unit_system (nm, ps, amu, kJ/mol, K, e; pressure kJ/mol/nm^3) from either
+    a plain number (taken as already being in those units: the floats this module's unit constants produce) or anything
+    that behaves like ``openmm.unit.Quantity`` -- i.e. offers ``value_in_unit_system`` -- which is what a caller that
+    builds its states with the reference's own objects passes (openmmtools/states.py:1908-1917 strips units the same
+    way).  The unit system object is looked up next to the Quantity's class, so no import of openmm is needed here."""
+    if hasattr(value, 'value_in_unit_system'):
+        import importlib
+        import sys
+        mod = sys.modules.get(type(value).__module__)
+        md = None
+        for name in (type(value).__module__, type(value).__module__.rsplit('.', 1)[0], 'openmm.unit', 'simtk.unit'):
+            try:
+                m = sys.modules.get(name) or importlib.import_module(name)
+            except ImportError:
+                continue
+            md = getattr(m, 'md_unit_system', None)
+            if md is not None:
+                break
+        if md is None:
+            raise TypeError('cannot find md_unit_system for a %s' % type(value).__name__)
+        return value.value_in_unit_system(md)
+    return value
