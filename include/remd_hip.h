@@ -17,7 +17,8 @@
  *   - plain pointers and sizes only; host pointers unless the name starts with d_
  *   - units: nm, ps, amu, kJ/mol, elementary charge (OpenMM's md_unit_system)
  *   - one handle per GPU / rank; a handle is not thread-safe, distinct handles are
- *   - all kernels are launched on the stream given at creation (NULL = default stream)
+ *   - all kernels are launched on the stream given at creation (NULL = a private non-blocking stream owned by the
+ *     handle; entry points that return results synchronise it before they return)
  *   - random numbers: counter-based Philox4x32-10, key = seed, counters documented
  *     per entry point (DESIGN.md "RNG stream spec"); results do not depend on how
  *     replicas are sharded over ranks
@@ -100,7 +101,7 @@ typedef struct remd_system_desc {
 
 /* ---- lifetime -------------------------------------------------------------------- */
 /* Replaces cache.ContextCache construction (cache.py:313-346): one batched device-state
-   pool per GPU.  stream: a hipStream_t (as void*) or NULL.                              */
+   pool per GPU.  stream: a hipStream_t (as void*; must be capturable, i.e. not the legacy default stream) or NULL.                              */
 int  remd_create(remd_handle* out, int device, void* stream);
 int  remd_destroy(remd_handle h);
 const char* remd_last_error(remd_handle h);   /* h may be NULL: last global error         */

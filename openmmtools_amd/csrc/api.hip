@@ -57,6 +57,12 @@ int remd_create(remd_handle* out, int device, void* stream)
     remd_ctx* h = new remd_ctx();
     h->device = device;
     h->stream = (hipStream_t)stream;
+    if (!h->stream) {
+        // NULL: a private non-blocking stream (the legacy default stream cannot be captured into a graph, and every entry point
+        // that hands results to the caller synchronises before it returns, so nothing relies on default-stream ordering)
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return remd_fail(nullptr, -2, "hipStreamCreate failed"); }
+        h->owns_stream = true;
+    }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     {
         // second stream: carries the direct-space kernels while the (longer) reciprocal-space chain stays on the main one
@@ -78,6 +84,7 @@ int remd_destroy(remd_handle h)
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    remd_free_step_graph(h);
     remd_pme_destroy(h);
     remd_free_constraints(h);
     remd_free_nonbonded(h);
@@ -94,6 +101,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -130,6 +138,7 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
     if ((rc = remd_build_nonbonded(h, d))) return rc;
     h->has_system = true;
     h->forces_valid = false;
+    h->graph_epoch++;
     return 0;
 }
 
@@ -144,6 +153,7 @@ int remd_set_states(remd_handle h, int K, const double* beta, const double* lam_
     if (lam_e) h->lam_e.assign(lam_e, lam_e + K);
     if (econst) h->econst.assign(econst, econst + K);
     for (int k = 0; k < K; ++k) if (!(h->beta[k] > 0)) return remd_fail(h, -1, "remd_set_states: beta must be > 0");
+    h->graph_epoch++;
     int rc;
     if ((rc = upload(h, h->d_beta, h->beta))) return rc;
     if ((rc = upload(h, h->d_lam_s, h->lam_s))) return rc;
@@ -152,7 +162,7 @@ int remd_set_states(remd_handle h, int K, const double* beta, const double* lam_
     dfree(h->d_ukl);
     if (h->R_global > 0) {
         REMD_CHECK(h, hipMalloc(&h->d_ukl, sizeof(double) * (size_t)h->R_global * K));
-        REMD_CHECK(h, hipMemset(h->d_ukl, 0, sizeof(double) * (size_t)h->R_global * K));
+        REMD_CHECK(h, hipMemsetAsync(h->d_ukl, 0, sizeof(double) * (size_t)h->R_global * K, h->stream));
     }
     return 0;
 }
@@ -167,6 +177,7 @@ int remd_set_integrator(remd_handle h, const char* splitting, double dt, double 
     h->splitting = splitting; h->dt = dt; h->gamma = gamma; h->n_steps = n_steps; h->reassign = reassign;
     h->constraint_tol = tol > 0 ? tol : 1e-8;
     h->has_integrator = true;
+    h->graph_epoch++;
     return 0;
 }
 
@@ -210,7 +221,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         REMD_CHECK(h, hipMalloc(&h->d_epart, sizeof(double) * (size_t)h->n_epart * R_local));
         if (h->K > 0) {
             REMD_CHECK(h, hipMalloc(&h->d_ukl, sizeof(double) * (size_t)R_global * h->K));
-            REMD_CHECK(h, hipMemset(h->d_ukl, 0, sizeof(double) * (size_t)R_global * h->K));
+            REMD_CHECK(h, hipMemsetAsync(h->d_ukl, 0, sizeof(double) * (size_t)R_global * h->K, h->stream));
         }
     }
     std::vector<float4> hp(n, make_float4(0, 0, 0, 0)), hv(n, make_float4(0, 0, 0, 0));
@@ -236,6 +247,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     REMD_CHECK(h, hipMemcpy(h->d_vel, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     REMD_CHECK(h, hipMemcpy(h->d_box, hb.data(), sizeof(float) * 4 * R_local, hipMemcpyHostToDevice));
     h->box_version++;
+    h->graph_epoch++;
     h->forces_valid = false; h->force_zeroed = false;
     if (h->nb_method == REMD_NB_PME) { int rc = remd_pme_setup(h); if (rc) return rc; }
     return remd_set_labels(h, labels);
@@ -325,6 +337,7 @@ int remd_set_barostat(remd_handle h, int K, const double* pressure, int frequenc
     int rc = upload(h, h->d_pressure, p);
     if (rc) return rc;
     h->baro_frequency = frequency;
+    h->graph_epoch++;
     return 0;
 }
 

@@ -100,6 +100,7 @@ struct nb_tables {
     long long* d_sforce = nullptr; long long* d_lj_sforce = nullptr;   // [R][3][Npad] / [R][3][NLpad] forces in sorted slot space
     unsigned int* d_lj_sci_list = nullptr; int* d_lj_sci_count = nullptr; unsigned long long* d_lj_excl = nullptr; int lj_excl_W = 0;
     int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 20; bool sorting = true;
+    std::vector<float> rep_lam_host;      // what d_rep_lam holds
 };
 static handle_table<nb_tables> g_nb;
 
@@ -1610,7 +1611,7 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
 static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
 {
     if (!t.has_alch) return 0;
-    if (t.rep_lam_R != h->R) { dfree(t.d_rep_lam); REMD_CHECK(h, hipMalloc(&t.d_rep_lam, sizeof(float) * 4 * h->R)); t.rep_lam_R = h->R; }
+    if (t.rep_lam_R != h->R) { dfree(t.d_rep_lam); REMD_CHECK(h, hipMalloc(&t.d_rep_lam, sizeof(float) * 4 * h->R)); t.rep_lam_R = h->R; t.rep_lam_host.clear(); }
     std::vector<float> rl(4 * (size_t)h->R, 0.f);
     for (int r = 0; r < h->R; ++r) {
         const int64_t k = h->labels.empty() ? 0 : h->labels[h->r_begin + r];
@@ -1620,8 +1621,12 @@ static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
         rl[4 * r + 1] = (float)(h->sc_alpha * pow(1.0 - ls, h->sc_b));
         rl[4 * r + 2] = (float)le;
     }
+    // uploaded only when something changed (labels after a mix, a lambda override of the u_kl passes): the steady state of the
+    // MD loop has no host copy and no synchronisation per force evaluation (and can be captured into a graph)
+    if (rl == t.rep_lam_host) return 0;
     REMD_CHECK(h, hipMemcpyAsync(t.d_rep_lam, rl.data(), sizeof(float) * rl.size(), hipMemcpyHostToDevice, h->stream));
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    t.rep_lam_host = rl;
     return 0;
 }
 
@@ -1890,6 +1895,20 @@ int remd_nb_required_epart(remd_ctx* h)
     return EP_NB0 + ntile * 8 * 4 + 8 + ntile * 8 * 4;  // up to 4 slices per main cluster + 4 per LJ-sub-system cluster
 }
 
+// used by the captured MD step (integrate.hip): is the next force evaluation a re-sorting one, and the bookkeeping of an
+// evaluation that was replayed from the graph instead of enqueued here
+int remd_nb_resort_due(remd_ctx* h)
+{
+    nb_tables* t = g_nb.find(h);
+    if (!t || h->nb_method == REMD_NB_NONE || !t->sorting || t->n_groups <= 0 || t->n_groups >= 8192) return 0;
+    return (t->sort_R != h->R || t->evals_since_sort >= t->resort_interval) ? 1 : 0;
+}
+void remd_nb_note_evaluation(remd_ctx* h)
+{
+    nb_tables* t = g_nb.find(h);
+    if (t && h->nb_method != REMD_NB_NONE) t->evals_since_sort++;
+}
+
 int remd_compute_forces(remd_ctx* h, bool with_energy)
 {
     if (!h->force_zeroed)
@@ -2133,7 +2152,7 @@ int remd_barostat_attempt(remd_ctx* h)
     nb_tables& t = *it;
     const int R = h->R, Npad = h->Npad;
     if (!h->d_baro) {
-        REMD_CHECK(h, hipMalloc(&h->d_baro, sizeof(double) * 8 * R)); REMD_CHECK(h, hipMemset(h->d_baro, 0, sizeof(double) * 8 * R));
+        REMD_CHECK(h, hipMalloc(&h->d_baro, sizeof(double) * 8 * R)); REMD_CHECK(h, hipMemsetAsync(h->d_baro, 0, sizeof(double) * 8 * R, h->stream));
         REMD_CHECK(h, hipMalloc(&h->d_box_old, sizeof(float) * 4 * R));
         REMD_CHECK(h, hipMalloc(&h->d_baro_x0, sizeof(float4) * (size_t)R * Npad));
         REMD_CHECK(h, hipMalloc(&h->d_baro_f0, sizeof(long long) * 3 * (size_t)R * Npad));

@@ -25,13 +25,17 @@ struct chain_prog {
     int n;                 // tokens in this chain
     char tok[MAX_TOK];     // 'V','R','O','C' (C = subtract centre-of-mass velocity)
     int o_index[MAX_TOK];  // for 'O': index of this O inside the step program
-    long long step[MAX_TOK]; // global step counter of each token (for the O noise counter)
+    long long step[MAX_TOK]; // step of each token RELATIVE to the step counter on the device (ctr[0]) when the chain runs: 0 = the
+                           // step the launching loop body belongs to, -1 = a token left pending by the previous body
     float hV, hR;          // dt/n_V, dt/n_R
     float a, b;            // OU coefficients
     int nO;
     int accumulate_momentum;  // after the chain, add sum(m v) into cmm buffer cmm_w
     int cmm_w, cmm_r;         // double-buffered momentum accumulators: 'C' reads cmm_r and clears the other one
     int zero_force;           // the chain ends with stale forces (an R after its last V): clear them for the next evaluation
+    int use_ctr;              // 1: steps are relative to the counters on the device (graph mode); 0: absolute (eager launches)
+    int body_idx;             // loop-body index (ctr[1]) this program was built for: the momentum double buffer alternates per
+                              // body, so a replayed (graph) launch shifts cmm_w / cmm_r by the parity of ctr[1] - body_idx
 };
 
 struct settle_const { float mO, mH, ra, rb, rc, dOH, dHH; };
@@ -192,7 +196,8 @@ template <int TYPE, int NAT>
 __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* idx, const float* dist, const settle_const& sc,
                                           float tol, int Npad, float4* __restrict__ P, float4* __restrict__ V,
                                           const long long* F, long long* Fw, const float* __restrict__ invmass, float kT,
-                                          uint32_t rg, uint64_t seed, const long long* __restrict__ cmm_r, float inv_total_mass)
+                                          uint32_t rg, uint64_t seed, const long long* __restrict__ cmm_r, float inv_total_mass,
+                                          long long gstep_base)
 {
     float3 x[NAT], v[NAT];
     float im[NAT];
@@ -237,7 +242,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                 constrain_v<TYPE, NAT>(sc, im, tol, v, x);
             }
         } else if (tok == 'O') {
-            const uint64_t cnt = (uint64_t)prog.step[t] * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
+            const uint64_t cnt = (uint64_t)(gstep_base + prog.step[t]) * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
 #pragma unroll
             for (int k = 0; k < NAT; ++k) {
                 const float3 xi = gaussian3(seed, REMD_STREAM_OU, (uint32_t)idx[k], rg, cnt);
@@ -274,14 +279,21 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             int Npad, float4* __restrict__ pos, float4* __restrict__ vel,
                             long long* force, const float* __restrict__ invmass,
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
-                            int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass)
+                            int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
+                            const long long* __restrict__ ctr)
 {
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     float3 mom = f3(0, 0, 0);
-    if (uidx == 0 && prog.cmm_r >= 0) {
+    // ctr[0]: global step index of the loop body this launch belongs to; ctr[1]: index of that body inside the current
+    // run (remd_run_steps).  Both live on the device so that a captured step (hipGraph) can be replayed unchanged.
+    // (ctr == NULL: eager launches carry absolute steps and buffer indices in `prog`, nothing to look up)
+    const long long gstep_base = ctr ? ctr[0] : 0ll;
+    const int flip = ctr ? (int)((ctr[1] - (long long)prog.body_idx) & 1) : 0;
+    const int cmm_r_eff = prog.cmm_r >= 0 ? (prog.cmm_r ^ flip) : -1, cmm_w_eff = prog.cmm_w ^ flip;
+    if (uidx == 0 && cmm_r_eff >= 0) {
         // this chain consumes accumulator cmm_r: clear the OTHER buffer (its sum was consumed one step ago)
-        long long* o = cmm + ((size_t)(1 - prog.cmm_r) * gridDim.y + r) * 4;
+        long long* o = cmm + ((size_t)(1 - cmm_r_eff) * gridDim.y + r) * 4;
         o[0] = 0; o[1] = 0; o[2] = 0;
     }
     const int4 a4 = (uidx < n_units) ? unit_atoms[uidx] : make_int4(-1, -1, -1, -1);
@@ -296,8 +308,8 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         long long* Fw = force + (size_t)r * 3 * Npad;
         const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
         const uint32_t rg = (uint32_t)(r_begin + r);
-        const long long* cr = cmm + ((size_t)prog.cmm_r * gridDim.y + r) * 4;
-#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass)
+        const long long* cr = cmm + ((size_t)max(cmm_r_eff, 0) * gridDim.y + r) * 4;
+#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, gstep_base)
         if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
         else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
         else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
@@ -311,7 +323,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
             mom.x += __shfl_xor(mom.x, off); mom.y += __shfl_xor(mom.y, off); mom.z += __shfl_xor(mom.z, off);
         }
         if ((threadIdx.x & 63) == 0) {
-            unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + ((size_t)prog.cmm_w * gridDim.y + r) * 4);
+            unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + ((size_t)cmm_w_eff * gridDim.y + r) * 4);
             atomicAdd(&c[0], (unsigned long long)(long long)((double)mom.x * 4294967296.0));
             atomicAdd(&c[1], (unsigned long long)(long long)((double)mom.y * 4294967296.0));
             atomicAdd(&c[2], (unsigned long long)(long long)((double)mom.z * 4294967296.0));
@@ -488,18 +500,32 @@ int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& 
     return 0;
 }
 
-static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog)
+static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog)   // prog.use_ctr selects the counter look-up
 {
     remd_prof_scope ps(h, "integrate_chain");
     dim3 grid((ut.n_units + 255) / 256, h->R);
     hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
-                       (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0));
+                       (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr);
 }
+
+__global__ void ctr_set_kernel(long long* ctr, long long gstep, long long body) { ctr[0] = gstep; ctr[1] = body; }
+__global__ void ctr_tick_kernel(long long* ctr) { ctr[0] += 1; ctr[1] += 1; }
 
 // Runs n_steps of the token program.  Tokens are grouped into chains that need no new
 // force evaluation; a 'V' after an 'R' forces a force evaluation first.
+//
+// One loop body = one MD step's launches (the chain(s) around the centre-of-mass removal, the force evaluation on two
+// streams, the step-counter tick).  From the third step on every body enqueues the same launches with the same
+// arguments -- what changes from step to step (the global step index in the noise counters, which momentum
+// accumulator is written / read) is read from two counters ON THE DEVICE -- so the body is captured once into a hipGraph
+// (stream capture across the fork / join of the two streams) and replayed with ONE launch per step; the steps on which
+// the atoms are re-sorted, the barostat fires or kernels are being timed run eagerly.  Results are bit-identical either
+// way (same kernels, same arguments, integer accumulation).  Opt-in with REMD_GRAPH=1 (see below: no gain measured).
+int remd_nb_resort_due(remd_ctx* h);
+void remd_nb_note_evaluation(remd_ctx* h);
+
 int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
                    int64_t iteration, int64_t first_step, int n_steps)
 {
@@ -516,17 +542,32 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     chain_prog cur = base; cur.n = 0;
     int cmm_w = 0;                     // accumulator the next momentum sum goes to
     bool zeroed_by_chain = false;
+    const long long gstep0 = (long long)iteration * (long long)h->n_steps + first_step;
+    // ---- graph eligibility (opt-in: measured on ROCm 7.2 / MI355X a replayed step is no faster than its eager launches --
+    // the floor of a step is the dependent chain of kernels, not the host -- see DESIGN.md) ------------------------------
+    const bool graph_env = getenv("REMD_GRAPH") && atoi(getenv("REMD_GRAPH")) != 0;      // read per call: the parity test switches it
+    static const int prof_sample = getenv("REMD_GRAPH_PROF_BODIES") ? atoi(getenv("REMD_GRAPH_PROF_BODIES")) : 24;
+    const bool graph_ok = graph_env && h->profiling != 2 && h->baro_frequency == 0 && h->cmm_frequency <= 1 && n_steps >= 6;
+    if (graph_ok) {
+        if (!h->d_ctr) REMD_CHECK(h, hipMalloc(&h->d_ctr, 2 * sizeof(long long)));
+        hipLaunchKernelGGL(ctr_set_kernel, dim3(1), dim3(1), 0, h->stream, h->d_ctr, gstep0, 0ll);
+    }
+    int body = 0;                      // index of the loop body being enqueued (== ctr[1] when its kernels run)
     auto flush = [&](bool accumulate) {
         if (cur.n == 0 && !accumulate) return;
         cur.accumulate_momentum = accumulate ? 1 : 0;
         cur.cmm_w = cmm_w;
+        cur.body_idx = body;
         // forces are stale after an R that follows the chain's last V: let the chain clear them (saves a memset)
         bool seenR = false, staleAtEnd = false;
         for (int t = 0; t < cur.n; ++t) { if (cur.tok[t] == 'R') seenR = true; if (cur.tok[t] == 'V') seenR = false; }
         staleAtEnd = seenR;
         cur.zero_force = staleAtEnd ? 1 : 0;
         if (staleAtEnd) zeroed_by_chain = true;
-        launch_chain(h, ut, cur);
+        chain_prog out = cur;
+        out.use_ctr = graph_ok ? 1 : 0;
+        if (graph_ok) for (int t = 0; t < out.n; ++t) out.step[t] -= gstep0 + body;    // absolute step -> relative to this body's counter
+        launch_chain(h, ut, out);
         cur = base; cur.n = 0;
     };
     auto push = [&](char tok, int oidx, long long step) {
@@ -535,8 +576,8 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     };
     if (h->cmm_frequency > 0)
         hipMemsetAsync(h->d_cmm, 0, sizeof(long long) * 4 * 2 * h->R, h->stream);      // both accumulators, once per call
-    for (int s = 0; s < n_steps; ++s) {
-        const long long gstep = (long long)iteration * (long long)h->n_steps + first_step + s;
+    auto run_body = [&](int s) -> int {
+        const long long gstep = gstep0 + s;
         // integrators.py:1313 addUpdateContextState: CMMotionRemover fires at the top of a step
         if (h->cmm_frequency > 0 && ((first_step + s) % h->cmm_frequency) == 0) {
             bool pending_reads_cmm = false;
@@ -568,11 +609,59 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             if (tok == 'O') oidx++;
             if (tok == 'R') h->forces_valid = false;
         }
+        if (graph_ok) hipLaunchKernelGGL(ctr_tick_kernel, dim3(1), dim3(1), 0, h->stream, h->d_ctr);
+        return 0;
+    };
+    const int first_graph_body = 2 + (h->profiling == 1 ? prof_sample : 0);   // timed launches (HIP events) are sampled eagerly
+    std::string key(tokens.begin(), tokens.end());
+    key += "|" + std::to_string(h->graph_epoch) + "|" + std::to_string(h->R) + "|" + std::to_string((long long)(uintptr_t)h->stream);
+    struct snap { std::string tok; bool fz, fv, zc; int cmm_w; };
+    auto take = [&]() { return snap{std::string(cur.tok, cur.tok + cur.n), h->force_zeroed, h->forces_valid, zeroed_by_chain, cmm_w}; };
+    for (int s = 0; s < n_steps; ++s, ++body) {
+        bool done = false;
+        if (graph_ok && s >= first_graph_body && !remd_nb_resort_due(h)) {
+            if (h->step_graph_exec && h->step_graph_key == key) {
+                // replay: one launch; then advance the host-side state exactly as the captured body did
+                REMD_CHECK(h, hipGraphLaunch(h->step_graph_exec, h->stream));
+                for (int t = 0; t < cur.n; ++t) cur.step[t] += 1;
+                if (h->cmm_frequency > 0) cmm_w = 1 - cmm_w;
+                remd_nb_note_evaluation(h);
+                done = true;
+            } else if (h->step_graph_key != key + "!") {
+                const snap before = take();
+                if (h->step_graph_exec) { hipGraphExecDestroy(h->step_graph_exec); h->step_graph_exec = nullptr; }
+                if (h->step_graph) { hipGraphDestroy(h->step_graph); h->step_graph = nullptr; }
+                REMD_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+                const int rc = run_body(s);
+                hipGraph_t g = nullptr;
+                const hipError_t e = hipStreamEndCapture(h->stream, &g);
+                if (rc) { if (g) hipGraphDestroy(g); return rc; }
+                if (e != hipSuccess || !g) return remd_fail(h, -2, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+                h->step_graph = g;
+                REMD_CHECK(h, hipGraphInstantiate(&h->step_graph_exec, g, nullptr, nullptr, 0));
+                REMD_CHECK(h, hipGraphLaunch(h->step_graph_exec, h->stream));      // capture recorded the body, this runs it
+                const snap after = take();
+                // reusable only if the body left the host-side state as it found it (steady state of the step program)
+                const bool steady = before.tok == after.tok && before.fz == after.fz && before.fv == after.fv && before.zc == after.zc &&
+                                    (h->cmm_frequency > 0 ? after.cmm_w == 1 - before.cmm_w : after.cmm_w == before.cmm_w);
+                h->step_graph_key = steady ? key : key + "!";                      // "!": do not try again for this program
+                done = true;
+            }
+        }
+        if (!done) { int rc = run_body(s); if (rc) return rc; }
     }
     flush(false);
     h->force_zeroed = zeroed_by_chain;
     REMD_CHECK(h, hipGetLastError());
     return 0;
+}
+
+void remd_free_step_graph(remd_ctx* h)
+{
+    if (h->step_graph_exec) { hipGraphExecDestroy(h->step_graph_exec); h->step_graph_exec = nullptr; }
+    if (h->step_graph) { hipGraphDestroy(h->step_graph); h->step_graph = nullptr; }
+    h->step_graph_key.clear();
+    if (h->d_ctr) { hipFree(h->d_ctr); h->d_ctr = nullptr; }
 }
 
 int remd_assign_velocities(remd_ctx* h, int64_t iteration)

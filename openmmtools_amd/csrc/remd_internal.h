@@ -21,7 +21,7 @@ struct remd_profile_entry { int64_t n = 0; double ms = 0.0; };
 
 struct remd_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; bool owns_stream = false;
     std::string err;
     uint64_t seed = 0;
 
@@ -108,6 +108,11 @@ struct remd_ctx {
     bool forces_valid = false;
     bool force_zeroed = false;         // the last integrator chain already cleared d_force (skip the memset)
 
+    // ---- step counters on the device + the captured MD step (integrate.hip: remd_run_steps) ---------
+    long long* d_ctr = nullptr;        // [0] global step index of the current loop body, [1] body index inside the current run
+    hipGraph_t step_graph = nullptr; hipGraphExec_t step_graph_exec = nullptr; std::string step_graph_key;
+    unsigned long long graph_epoch = 0;   // bumped by everything that changes buffers / programs a captured step refers to
+
     // ---- PME ------------------------------------------------------------------------
     void* pme = nullptr;               // opaque (pme.hip)
 
@@ -182,6 +187,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                    int64_t iteration, int64_t first_step, int n_steps);
 int remd_assign_velocities(remd_ctx* h, int64_t iteration);
 int remd_kinetic_energy(remd_ctx* h);
+void remd_free_step_graph(remd_ctx* h);
 
 // ---- forces.hip -------------------------------------------------------------------------
 int remd_barostat_attempt(remd_ctx* h);

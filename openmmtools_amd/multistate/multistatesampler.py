@@ -380,7 +380,8 @@ class MultiStateSampler:
         move = self._engine_move()
         eng = self._engine
         if move is not None:
-            if getattr(eng, 'is_device', False) and move.constraint_tolerance < 1e-6 and not getattr(self, '_warned_tolerance', False):
+            has_constraints = self._thermodynamic_states[0].system.getNumConstraints() > 0
+            if getattr(eng, 'is_device', False) and has_constraints and move.constraint_tolerance < 1e-6 and not getattr(self, '_warned_tolerance', False):
                 # include/remd_hip.h: the fp32 state bounds what the iterative X-H solver can reach (SETTLE waters are analytic)
                 logger.warning('constraint_tolerance %g is below the fp32 floor of the device state; X-H clusters are '
                                'constrained to 1e-6 relative, rigid waters analytically', move.constraint_tolerance)

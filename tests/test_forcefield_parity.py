@@ -331,3 +331,26 @@ def test_config5_dhfr_128_state_sams_row_and_jump(hip_engine_factory):
     assert np.array_equal(got[0], ref[0])
     assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
     assert np.allclose(got[3], ref[3], rtol=0, atol=1e-9)      # log P of O(1e5)-sized arguments: 1e-9 absolute
+
+
+@pytest.mark.parametrize('system_name,splitting,dt,n_steps', [('alanine', 'V R R O R R V', 0.002, 60), ('alanine', 'O V R V O', 0.001, 45),
+                                                              ('lj', 'V R O R V', 0.001, 50)])
+def test_captured_step_graph_equals_eager_launches(hip_engine_factory, monkeypatch, system_name, splitting, dt, n_steps):
+    """remd_run_steps captures the steady-state MD step (two chain launches, the force evaluation forked over two streams,
+    the device step-counter tick) into a hipGraph and replays it; the step index of the noise counters and the
+    momentum double buffer are read from counters on the device.  Replayed and eagerly launched runs must agree bit
+    for bit (positions, velocities, u_kl), across the re-sort cadence (every 20 evaluations run eagerly) and for a
+    second propagate that reuses the captured graph."""
+    tsys = ts.AlanineDipeptideExplicit() if system_name == 'alanine' else ts.LennardJonesFluid(nparticles=512)
+    out = []
+    for graph in ('0', '1'):
+        monkeypatch.setenv('REMD_GRAPH', graph)
+        eng = hip_engine_factory()
+        _engine_for(eng, tsys.system, tsys.positions, R=3, jitter=0.002, splitting=splitting, dt=dt, n_steps=n_steps)
+        assert not eng.propagate(4).any()
+        assert not eng.propagate(5).any()
+        x, v, _, _ = eng.get_replicas()
+        out.append((x, v, eng.compute_energies()))
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])

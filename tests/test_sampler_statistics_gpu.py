@@ -82,7 +82,7 @@ def test_sams_sampler_runs_on_device_and_flattens(hip_engine_factory):
     s = SAMSSampler(mcmc_moves=move, number_of_iterations=600, engine=hip_engine_factory(), seed=7, gamma0=1.0,
                     flatness_criteria='minimum-visits')
     s.create(sts, [ss, ss], storage=None)
-    seen = []
+    seen = [int(x) for x in s.replica_thermodynamic_states]     # create() reported iteration 0 (sams.py:381-393 counts it)
     orig = s._report_iteration
 
     def rec():
