@@ -117,51 +117,97 @@ __device__ __forceinline__ void settle_velocities(float imA, float imB, float im
     v[2] = v[2] + (eCA * tCA - eBC * tBC) * imC;
 }
 
-// SHAKE for a star cluster (central atom 0 bonded to atoms 1..NAT-1): p0 old constrained positions, p1
-// unconstrained new positions (both relative to the old central atom).  NAT is a compile-time constant so that
-// every array lives in registers (no scratch).
-template <int NAT>
-__device__ __forceinline__ void shake_positions(const float* im, const float* d, float tol, const float3* p0, float3* p1)
+// K x K linear solve (K <= 3: the constraints of one X-H star cluster), Cramer's rule, everything in registers
+template <int K>
+__device__ __forceinline__ void solve_small(const float (&A)[3][3], const float (&b)[3], float (&x)[3])
 {
-    for (int it = 0; it < 24; ++it) {
-        bool conv = true;
-#pragma unroll
-        for (int k = 1; k < NAT; ++k) {
-            const float3 r0 = p0[k] - p0[0];
-            const float3 r = p1[k] - p1[0];
-            const float d2 = d[k - 1] * d[k - 1];
-            const float diff = d2 - dot3(r, r);
-            if (fabsf(diff) > 2.f * tol * d2) {
-                conv = false;
-                const float lam = diff * frcp(2.f * (im[0] + im[k]) * dot3(r, r0));
-                p1[0] = p1[0] - r0 * (lam * im[0]);
-                p1[k] = p1[k] + r0 * (lam * im[k]);
-            }
-        }
-        if (conv) break;
+    if (K == 1) {
+        x[0] = b[0] * frcp(A[0][0]); x[1] = 0.f; x[2] = 0.f;
+    } else if (K == 2) {
+        const float idet = frcp(A[0][0] * A[1][1] - A[0][1] * A[1][0]);
+        x[0] = (b[0] * A[1][1] - A[0][1] * b[1]) * idet;
+        x[1] = (A[0][0] * b[1] - b[0] * A[1][0]) * idet;
+        x[2] = 0.f;
+    } else {
+        const float c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][0] * A[2][2] - A[1][2] * A[2][0], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+        const float idet = frcp(A[0][0] * c00 - A[0][1] * c01 + A[0][2] * c02);
+        x[0] = (b[0] * c00 - A[0][1] * (b[1] * A[2][2] - A[1][2] * b[2]) + A[0][2] * (b[1] * A[2][1] - A[1][1] * b[2])) * idet;
+        x[1] = (A[0][0] * (b[1] * A[2][2] - A[1][2] * b[2]) - b[0] * c01 + A[0][2] * (A[1][0] * b[2] - b[1] * A[2][0])) * idet;
+        x[2] = (A[0][0] * (A[1][1] * b[2] - b[1] * A[2][1]) - A[0][1] * (A[1][0] * b[2] - b[1] * A[2][0]) + b[0] * c02) * idet;
     }
 }
 
+// Position constraints of a star cluster (central atom 0 bonded to atoms 1..NAT-1): p0 old constrained positions, p1
+// unconstrained new positions (both relative to the old central atom).  The SHAKE displacements act along the OLD bond
+// vectors r0_q with one multiplier per bond; instead of Gauss-Seidel sweeps over the bonds (6-10 sweeps, data dependent,
+// and the one wavefront holding the solute's clusters used to set the duration of the whole integrator launch) the K x K
+// system  |s_q + sum_p B_qp lam_p r0_p|^2 = d_q^2,  B_qp = 1/m_0 + delta_qp / m_q,  is solved by Newton iterations with the
+// exact Jacobian (quadratic convergence: a half step moves bond lengths by < 1 %, so two iterations reach fp32 round-off; three
+// are done), a fixed number of them so that the wave never diverges.
+// NAT is a compile-time constant so that every array lives in registers (no scratch).
 template <int NAT>
-__device__ __forceinline__ void shake_velocities(const float* im, float tol, const float3* p, float3* v)
+__device__ __forceinline__ void shake_positions(const float* im, const float* d, float /*tol*/, const float3* p0, float3* p1)
 {
-    // converged when the bond-length rate is below tol relative to |r| |v| (fp32 noise floor ~1e-7 |r||v|)
-    for (int it = 0; it < 16; ++it) {
-        bool conv = true;
+    constexpr int K = NAT - 1;
+    float3 r0[3], sv[3];
+    float lam[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 1; k < NAT; ++k) {
-            const float3 r = p[k] - p[0];
-            const float3 dv = v[k] - v[0];
-            const float r2 = dot3(r, r);
-            const float rv = dot3(r, dv);
-            if (rv * rv > tol * tol * r2 * (dot3(v[k], v[k]) + dot3(v[0], v[0]) + 1e-12f)) {
-                conv = false;
-                const float lam = rv * frcp(r2 * (im[0] + im[k]));
-                v[0] = v[0] + r * (lam * im[0]);
-                v[k] = v[k] - r * (lam * im[k]);
+    for (int q = 0; q < 3; ++q) {
+        r0[q] = q < K ? p0[q + 1] - p0[0] : f3(0, 0, 0);
+        sv[q] = q < K ? p1[q + 1] - p1[0] : f3(0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        float3 acc = f3(0, 0, 0);                                   // im0 * sum_p lam_p r0_p (the central atom's share)
+#pragma unroll
+        for (int p = 0; p < K; ++p) acc = acc + r0[p] * (lam[p] * im[0]);
+        float J[3][3], g[3], dl[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q < K) {
+                const float3 cur = sv[q] + acc + r0[q] * (lam[q] * im[q + 1]);
+                g[q] = d[q] * d[q] - dot3(cur, cur);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) J[q][p] = p < K ? 2.f * dot3(cur, r0[p]) * (im[0] + (p == q ? im[q + 1] : 0.f)) : 0.f;
+            } else {
+                g[q] = 0.f;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) J[q][p] = p == q ? 1.f : 0.f;
             }
         }
-        if (conv) break;
+        solve_small<K>(J, g, dl);
+#pragma unroll
+        for (int q = 0; q < K; ++q) lam[q] += dl[q];
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        p1[0] = p1[0] - r0[q] * (lam[q] * im[0]);
+        p1[q + 1] = p1[q + 1] + r0[q] * (lam[q] * im[q + 1]);
+    }
+}
+
+// Velocity constraints of a star cluster: the multipliers solve a K x K LINEAR system exactly (no iteration):
+//   sum_p (1/m_0 r_q.r_p + delta_qp r_q.r_q / m_q) mu_p = r_q . (v_q - v_0)
+template <int NAT>
+__device__ __forceinline__ void shake_velocities(const float* im, float /*tol*/, const float3* p, float3* v)
+{
+    constexpr int K = NAT - 1;
+    float3 r[3];
+    float A[3][3], b[3], mu[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r[q] = q < K ? p[q + 1] - p[0] : f3(0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        b[q] = q < K ? dot3(r[q], v[q + 1] - v[0]) : 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+            A[q][pp] = (q < K && pp < K) ? dot3(r[q], r[pp]) * (im[0] + (pp == q ? im[q + 1] : 0.f)) : (pp == q ? 1.f : 0.f);
+    }
+    solve_small<K>(A, b, mu);
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        v[0] = v[0] + r[q] * (mu[q] * im[0]);
+        v[q + 1] = v[q + 1] - r[q] * (mu[q] * im[q + 1]);
     }
 }
 
