@@ -176,7 +176,7 @@ def main():
 
     sampler.run(args.warmup)
     engine.profile_reset()
-    engine.profile_enable(True, 'nonbonded|pme_xy')   # asynchronous HIP events around the two heaviest kernel classes only
+    engine.profile_enable(True, 'nonbonded|pme_xy|integrate_chain')   # asynchronous HIP events around the heaviest kernel classes only
     sync()
     t0 = time.perf_counter()
     sampler.run(args.steps)
@@ -221,6 +221,18 @@ def main():
                            note='forward y, forward x, influence function, inverse x, inverse y on an LDS-resident plane: one read + '
                                 'one write of the half spectrum; in practice VALU/LDS-issue bound (mixed-radix butterflies), and it '
                                 'shares the chip with the pair kernel on the other stream')
+        # the integrator chain against its own roof (fused bound 64 B/atom: read x, v, f, 1/m, write x, v)
+        n_ch, ms_ch = engine.profile_get('integrate_chain')
+        roof_ch = None
+        if n_ch > 0:
+            avg_ms = ms_ch / n_ch
+            achieved = 64.0 * n_atoms * n_local / (avg_ms * 1e-3) / 1e9
+            roof_ch = dict(kernel='integrate_chain_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                           frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic_bytes('integrate_chain_kernel'), launches=n_ch,
+                           avg_launch_ms=avg_ms, total_ms=ms_ch,
+                           note='two launches per MD step (split at the centre-of-mass reduction); one thread per rigid water / '
+                                'X-H cluster / free atom with x, v in registers: 96 workgroups, bound by the latency of the '
+                                'dependent SETTLE / RATTLE arithmetic, not by HBM')
         # the contract asks for the dominant kernel: the class with the larger accumulated time in the timed region
         cands = [r for r in (roof_nb, roof_xy) if r]
         cands.sort(key=lambda r: -r['total_ms'])
@@ -238,7 +250,17 @@ def main():
                                replicas_per_gpu=(n_replicas / float(world)), replicas_total=n_replicas, md_steps=args.md_steps,
                                mode=('strong: one %d-replica ensemble' % n_replicas) if strong else 'weak: 24 replicas per GPU',
                                parallelism='replica-sharded x%d' % world, seed=SEED),
-                   timing=dict(sampler._timing_data), roofline=roof, roofline_secondary=roof2)
+                   timing=dict(sampler._timing_data), roofline=roof, roofline_secondary=roof2, roofline_integrator=roof_ch)
+        try:
+            # achievable roofs of THIS box (STREAM triad past the Infinity Cache, FMA chains), SURVEY 8(d)
+            out['measured_roofs'] = engine.roof_microbench()
+            if roof and roof['unit'] == 'TFLOP/s':
+                roof['frac_of_measured_pk_fma'] = roof['achieved'] / out['measured_roofs']['pk_fma_f32_tflop_per_s']
+            for r_ in (roof, roof2, roof_ch):
+                if r_ and r_['unit'] == 'GB/s':
+                    r_['frac_of_measured_stream'] = r_['achieved'] / out['measured_roofs']['stream_triad_gb_per_s']
+        except Exception as exc:                      # a measurement extra: never fail the bench line for it
+            out['measured_roofs'] = dict(error=str(exc))
         if not args.no_cpu_baseline and world == 1:
             engine.close()
             out['cpu_baseline'] = cpu_baseline()

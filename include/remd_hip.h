@@ -242,6 +242,11 @@ int  remd_profile_filter(remd_handle h, const char* kernel_class);
 int  remd_profile_get(remd_handle h, const char* kernel_class, int64_t* n_launches, double* total_ms);
 int  remd_profile_reset(remd_handle h);
 
+/* measurement hook: the achievable roofs of the box the benchmark runs on -- STREAM triad on 3 x 512 MiB
+   (GB/s), independent v_fma_f32 chains and v_pk_fma_f32 chains (TFLOP/s).  Any pointer may be NULL.  bench.py reports
+   them beside the spec peaks; the reference has no counterpart.                                                          */
+int  remd_roof_microbench(remd_handle h, double* stream_gb_per_s, double* fma_tflop_per_s, double* pk_fma_tflop_per_s);
+
 #ifdef __cplusplus
 }
 #endif

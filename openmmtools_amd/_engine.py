@@ -46,7 +46,7 @@ EXPORTS = [
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
-    'remd_set_energy_const_volume',
+    'remd_set_energy_const_volume', 'remd_roof_microbench',
 ]
 
 _lib = None
@@ -106,6 +106,7 @@ def load_library(path=None):
     lib.remd_profile_get.argtypes = [vp, C.c_char_p, c_int64_p, c_double_p]
     lib.remd_profile_reset.argtypes = [vp]
     lib.remd_profile_filter.argtypes = [vp, C.c_char_p]
+    lib.remd_roof_microbench.argtypes = [vp, c_double_p, c_double_p, c_double_p]
     for name in EXPORTS:
         if name not in ('remd_last_error',):
             getattr(lib, name).restype = C.c_int
@@ -356,6 +357,12 @@ class HipEngine:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         self.lib.remd_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))
         return dict(propagate_ms=a.value, energies_ms=b.value, mix_ms=c.value)
+
+    def roof_microbench(self):
+        """Achievable roofs of this box: STREAM triad GB/s, v_fma_f32 and v_pk_fma_f32 TFLOP/s (include/remd_hip.h)."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.lib.remd_roof_microbench(self.h, C.byref(a), C.byref(b), C.byref(c)), 'remd_roof_microbench')
+        return dict(stream_triad_gb_per_s=a.value, fma_f32_tflop_per_s=b.value, pk_fma_f32_tflop_per_s=c.value)
 
     def profile_enable(self, on=1, kernel_class=None):
         if kernel_class is not None:

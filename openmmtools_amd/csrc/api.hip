@@ -73,7 +73,8 @@ int remd_create(remd_handle* out, int device, void* stream)
         if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio) != hipSuccess)
             hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
     }
-    hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    { const unsigned evf = (getenv("REMD_EVENT_SYSFENCE") ? 0u : hipEventReleaseToDevice) | hipEventDisableTiming;   // device-scope release: no system-scope cache write-back per fork / join
+      hipEventCreateWithFlags(&h->ev_fork, evf); hipEventCreateWithFlags(&h->ev_join, evf); }
     { const char* env = getenv("REMD_OVERLAP"); h->overlap = !(env && atoi(env) == 0); }
     *out = h;
     return 0;

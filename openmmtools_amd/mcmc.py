@@ -37,7 +37,47 @@ class SequenceMove(MCMCMove):
 
 
 class IntegratorMoveError(Exception):
-    """mcmc.py:538-600 (the NaN error raised after n_restart_attempts)."""
+    """mcmc.py:538-600: raised when a NaN is found after applying a move (after ``n_restart_attempts`` retries), carrying what
+    is needed to reproduce it.  ``context``: dict(system=System, thermodynamic_state=..., positions, velocities, box) --
+    the stand-in for the openmm.Context the reference keeps."""
+
+    def __init__(self, message, move, context=None):
+        super().__init__(message)
+        self.move = move
+        self.context = context
+
+    def serialize_error(self, path_files_prefix):
+        """mcmc.py:556-600: ``<prefix>-move.json`` (the move's parameters), ``<prefix>-system.xml`` (the serialised System, OpenMM
+        document layout), ``<prefix>-integrator.json`` (the Langevin program the engine ran) and ``<prefix>-state.npz``
+        (positions, velocities, box of the failed replica).  Existing files are overwritten."""
+        import json
+        import os
+        import numpy as np
+        directory_path = os.path.dirname(path_files_prefix)
+        if directory_path and not os.path.exists(directory_path):
+            os.makedirs(directory_path)
+        mv = {k: (v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)) for k, v in vars(self.move).items()}
+        mv['class'] = type(self.move).__name__
+        with open(path_files_prefix + '-move.json', 'w') as f:
+            json.dump(mv, f)
+        ctx = self.context or {}
+        if ctx.get('system') is not None:
+            try:
+                from . import system_xml
+                with open(path_files_prefix + '-system.xml', 'w') as f:
+                    f.write(system_xml.to_xml(ctx["system"], pressure=getattr(ctx.get("thermodynamic_state"), "pressure", None), temperature=getattr(ctx.get("thermodynamic_state"), "temperature", None)))
+            except Exception as exc:                       # a System the XML writer does not cover: say so instead of failing the dump
+                with open(path_files_prefix + '-system.xml', 'w') as f:
+                    f.write('<!-- System not serialisable: %s -->\n' % exc)
+        ts = ctx.get('thermodynamic_state')
+        integ = dict(kind='LangevinIntegrator', splitting=getattr(self.move, 'splitting', None), timestep_ps=getattr(self.move, 'timestep', None),
+                     collision_rate_per_ps=getattr(self.move, 'collision_rate', None), n_steps=getattr(self.move, 'n_steps', None),
+                     temperature_K=getattr(ts, 'temperature', None), pressure=getattr(ts, 'pressure', None),
+                     lambda_sterics=getattr(ts, 'lambda_sterics', None), lambda_electrostatics=getattr(ts, 'lambda_electrostatics', None))
+        with open(path_files_prefix + '-integrator.json', 'w') as f:
+            json.dump(integ, f)
+        arrays = {k: np.asarray(ctx[k]) for k in ('positions', 'velocities', 'box', 'positions_before', 'velocities_before') if ctx.get(k) is not None}
+        np.savez(path_files_prefix + '-state.npz', **arrays)
 
 
 class BaseIntegratorMove(MCMCMove):

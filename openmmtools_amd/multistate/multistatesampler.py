@@ -705,11 +705,36 @@ class MultiStateSampler:
             flags = self._engine.propagate(it)
             self._sampler_states_stale = True
             if np.any(flags):
-                bad = (np.nonzero(flags)[0] + self._r_begin).tolist()
-                raise SimulationNaNError('Propagating replicas {} resulted in a NaN!'.format(bad))
+                self._dump_nan_errors(np.nonzero(flags)[0], move)
         for state_move in self._mcmc_moves:
             for move in self._flatten(state_move):
                 move.statistics = dict(n_attempts=move.statistics.get('n_attempts', 0) + 1)
+
+    def _dump_nan_errors(self, bad_local, move):
+        """multistatesampler.py:1324-1334: save the NaN-ing replica (state, System, move) under ``nan-error-logs/`` next to
+        the storage before aborting with SimulationNaNError."""
+        x, v, _, _ = self._engine.get_replicas()
+        try:
+            boxes = self._engine.get_boxes()
+        except Exception:
+            boxes = None
+        base = os.path.dirname(os.path.abspath(self._reporter.filepath)) if self._reporter is not None else os.getcwd()
+        output_dir = os.path.join(base, 'nan-error-logs')
+        bad_global = []
+        for rl in bad_local:
+            replica_id = int(rl) + self._r_begin
+            state_id = int(self._replica_thermodynamic_states[replica_id])
+            before = self._sampler_states[replica_id]            # last state synchronised to the host (start of the iteration at best)
+            err = mcmc.IntegratorMoveError('NaN after %s' % type(move).__name__, move, context=dict(
+                system=self._thermodynamic_states[state_id].system, thermodynamic_state=self._thermodynamic_states[state_id],
+                positions=x[rl], velocities=v[rl], box=None if boxes is None else boxes[rl],
+                positions_before=before.positions, velocities_before=before.velocities))
+            err.serialize_error(os.path.join(output_dir, 'iteration{}-replica{}-state{}'.format(self._iteration, replica_id, state_id)))
+            bad_global.append(replica_id)
+        message = ('Propagating replicas {} resulted in a NaN!\nThe state of the system and integrator before the error were saved'
+                   ' in {}').format(bad_global, output_dir)
+        logger.critical(message)
+        raise SimulationNaNError(message)
 
     @with_timer('Computing energy matrix')
     def _compute_energies(self):

@@ -1321,6 +1321,12 @@ int remd_profile_filter(remd_handle h, const char* c) { (void)c; return h ? 0 : 
 int remd_profile_reset(remd_handle h) { return h ? 0 : -1; }
 int remd_profile_get(remd_handle h, const char* name, int64_t* n, double* ms) { (void)name; if (!h) return -1; if (n) *n = 0; if (ms) *ms = 0; return 0; }
 
+int remd_roof_microbench(remd_handle h, double* a, double* b, double* c)
+{
+    (void)a; (void)b; (void)c;
+    return fail(h, -3, "libremd_cpu: the roof microbenchmarks are GPU measurements (not implemented on the CPU)");
+}
+
 /* CPU-library extension used by bench.py's cpu_baseline leg: threads OpenMP will use over replicas */
 int remd_cpu_num_threads(void)
 {

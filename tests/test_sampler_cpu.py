@@ -168,8 +168,22 @@ def test_nan_restart_attempts_follow_the_reference_protocol():
         calls.clear()
         mo.OracleLangevin.run = make({(2, a) for a in range(8)})
         s = sampler(2)
-        with pytest.raises(SimulationNaNError):
-            s.run()
+        import os, json, tempfile
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)                      # no storage: the dump goes next to the working directory
+            try:
+                with pytest.raises(SimulationNaNError, match='nan-error-logs'):
+                    s.run()
+            finally:
+                os.chdir(cwd)
+            # multistatesampler.py:1324-1334, mcmc.py:556-600: the NaN-ing replica's move, System, integrator and state are saved
+            prefix = os.path.join(tmp, 'nan-error-logs', 'iteration1-replica2-state%d' % int(s.replica_thermodynamic_states[2]))
+            assert json.load(open(prefix + '-move.json'))['class'] == 'LangevinSplittingDynamicsMove'
+            assert json.load(open(prefix + '-integrator.json'))['splitting'] == 'V R O R V'
+            assert '<System' in open(prefix + '-system.xml').read()
+            st = np.load(prefix + '-state.npz')
+            assert np.isnan(st['positions']).all() and np.isfinite(st['positions_before']).all()
         assert [c for c in calls if c[0] == 2] == [(2, 0), (2, 1), (2, 2)]
     finally:
         mo.OracleLangevin.run = real_run

@@ -1,0 +1,55 @@
+"""Per-kernel roofline table ("report each kernel's own HBM fraction"): joins the rocprofv3 kernel-trace
+summary (average duration per launch) with the PMC traffic table (FETCH_SIZE x 2 + WRITE_SIZE per launch, separate
+passes) and the algorithmic bytes per launch of the headline workload (24 replicas x 2269 atoms, 75 x 75 x 72 mesh).
+
+usage: python tools/kernel_roofs.py <kernel_stats.md> <pmc_traffic.json> [--stream GBs] > profiles/rNN_x_kernel_roofs.md"""
+import json
+import sys
+
+R, N, NPAD = 24, 2269, 2304
+NX, NY, NZ = 75, 75, 72
+HALF = (NZ // 2 + 1) * NX * NY * R            # complex points of the half spectrum, all replicas
+REAL = NX * NY * NZ * R
+# algorithmic bytes per launch (what the kernel must move at least once) and the SURVEY 8(d) row they come from
+ALGO = {
+    'integrate_chain_kernel': (64.0 * N * R, 'fused V/R/O bound: read x, v, f, 1/m; write x, v = 64 B/atom'),
+    'pme_spread_zfwd': (16.0 * N * R + 8.0 * HALF, 'read x, q per atom; write the half spectrum (8 B/point)'),
+    'pme_xy_fused_kernel': (16.0 * HALF + 4.0 * HALF, 'read + write the half spectrum, read the influence table'),
+    'pme_zinv': (8.0 * HALF + 4.0 * REAL, 'read the half spectrum, write the real potential mesh'),
+    'pme_gather_kernel': (4.0 * REAL + 40.0 * N * R, 'read the potential mesh once; x, q in, 24 B/atom of force atomics out'),
+    'nonbonded_sci2_kernel': (28.0 * N * R, 'x, q, sigma, eps in; f out = 28 B/atom (the kernel is FP32-VALU bound, 10 kflop/atom)'),
+    'scatter_sorted_forces_kernel': (2 * 24.0 * NPAD * R, 'read the sorted accumulator, add into the per-atom accumulator'),
+    'gather_positions2_kernel': (2 * 16.0 * NPAD * R + 16.0 * NPAD * R, 'x in, sorted x out (+ cluster boxes)'),
+    'listed_forces_kernel': (0.0, 'latency bound (~2300 terms per replica)'),
+    'build_sci_list2_kernel': (0.0, 'latency bound'),
+    'pme_bin_kernel': (16.0 * N * R + 4.0 * N * R, 'x in, bin lists out'),
+}
+
+
+def main():
+    stats, pmc = sys.argv[1], sys.argv[2]
+    stream = float(sys.argv[sys.argv.index('--stream') + 1]) if '--stream' in sys.argv else None
+    traffic = json.load(open(pmc))
+    rows = []
+    for line in open(stats):
+        if not line.startswith('|') or line.startswith('| kernel') or line.startswith('|---'):
+            continue
+        c = [x.strip() for x in line.strip().strip('|').split('|')]
+        name, calls, avg_us = c[0], int(c[1]), float(c[3])
+        key = [k for k in ALGO if k in name]
+        if not key or calls < 100:
+            continue
+        algo, why = ALGO[key[0]]
+        pm = [v for k, v in traffic.items() if key[0] in k]
+        pmc_mb = pm[0]['hbm_mb_corrected'] if pm else float('nan')
+        rows.append((name[:46], calls, avg_us, algo / 1e6, pmc_mb, algo / (avg_us * 1e-6) / 1e9, pmc_mb * 1e6 / (avg_us * 1e-6) / 1e9, why))
+    print('| kernel | launches | avg us | algorithmic MB / launch | PMC HBM-side MB / launch | algorithmic GB/s | frac of 8 TB/s' +
+          (' | frac of measured STREAM (%.0f GB/s)' % stream if stream else '') + ' | PMC GB/s | algorithmic bytes counted |')
+    print('|---|---|---|---|---|---|---|' + ('---|' if stream else '') + '---|---|')
+    for n, calls, us, amb, pmb, ag, pg, why in rows:
+        print('| %s | %d | %.1f | %.2f | %.2f | %.0f | %.3f |' % (n, calls, us, amb, pmb, ag, ag / 8000.0) +
+              (' %.3f |' % (ag / stream) if stream else '') + ' %.0f | %s |' % (pg, why))
+
+
+if __name__ == '__main__':
+    main()
