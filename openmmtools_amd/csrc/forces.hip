@@ -101,6 +101,7 @@ struct nb_tables {
     unsigned int* d_lj_sci_list = nullptr; int* d_lj_sci_count = nullptr; unsigned long long* d_lj_excl = nullptr; int lj_excl_W = 0;
     int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 20; bool sorting = true;
     std::vector<float> rep_lam_host;      // what d_rep_lam holds
+    float sort_cell = getenv("REMD_NB_CELL") ? (float)atof(getenv("REMD_NB_CELL")) : 0.45f;   // Morton cell edge (nm) of the molecule sort
 };
 static handle_table<nb_tables> g_nb;
 
@@ -1719,7 +1720,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
         remd_prof_scope ps(h, "nb_sort");
         const size_t lds = sizeof(int) * 4 * (size_t)t.n_groups;
         hipLaunchKernelGGL(sort_groups_kernel, dim3(h->R), dim3(1024), lds, h->stream, t.n_groups, h->N, h->Npad, t.d_grp_first,
-                           t.d_grp_size, h->d_pos, h->d_box, 0.45f, t.d_order);
+                           t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order);
         hipLaunchKernelGGL(gather_params_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.p.excl_words,
                            t.d_order, t.d_param, t.d_mask, t.d_sparam, t.d_smask);
         if (t.lj_split)

@@ -24,7 +24,8 @@
  *   constraints: iterative SHAKE / RATTLE per rigid cluster to 1e-12 (the HIP engine uses analytic SETTLE)
  * Exact Verlet lists (cutoff + skin, rebuilt when an atom has moved skin/2), cell-list construction.
  *
- * Not implemented on the CPU (return -3): the Monte Carlo barostat and FIRE minimisation entry points.
+ * The Monte Carlo barostat (remd_set_barostat / remd_barostat_attempts) and FIRE minimisation (remd_minimize) follow the same
+ * restatements as the Python oracle (OracleBarostat, OracleFIRE); only remd_roof_microbench (a GPU measurement) returns -3.
  */
 #include "../../include/remd_hip.h"
 
@@ -191,6 +192,7 @@ struct System {
     std::vector<std::vector<int>> excl;           // per atom, sorted partner list (exceptions are excluded from the pair loop)
     std::vector<double> bmod[3];                  // B-spline moduli of the PME mesh
     int n_dof = 0;
+    std::vector<std::vector<int>> molecules;      // connected components over exceptions, bonds, constraints (barostat scaling units)
     double settle_ra = 0, settle_rb = 0, settle_rc = 0, settle_dHH = 0, settle_mO = 0, settle_mH = 0;
 };
 
@@ -251,6 +253,7 @@ struct Replica {
     std::vector<double> x, v, f;                  // [N][3]
     double box[3] = {0, 0, 0};
     bool f_valid = false;
+    double baro[5] = {0, 0, 0, 0, 0};             // volume scale, attempted, accepted (adaptation window), total attempted, total accepted
     // Verlet list
     std::vector<double> x_list; double box_list[3] = {0, 0, 0};
     std::vector<int> pair_i, pair_j;              // i < j, not excluded, within rc + skin at build time
@@ -761,6 +764,7 @@ struct remd_ctx {
     int K = 0;
     std::vector<double> beta, lam_s, lam_e, econst;
     double econst_vref = 0.0;
+    std::vector<double> pressure; int baro_frequency = 0; long long baro_steps = 0, baro_attempts = 0;
     std::vector<char> tokens; int nV = 0, nR = 0, nO = 0;
     double dt = 0, gamma = 0; int n_steps = 0, reassign = 0, n_restart_attempts = 0;
     int R = 0, R_global = 0, r_begin = 0;
@@ -825,9 +829,11 @@ static void ensure_forces(remd_ctx* h, int r)
     rep.f_valid = true;
 }
 
+static void barostat_attempt(remd_ctx* h, int r, long long attempt);
+
 // integrators.py:1309-1317, 1404-1460 for one replica (cf. oracle/md_oracle.py:OracleLangevin.run)
 static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int nV, int nR, int nO, int64_t iteration,
-                      int64_t first_step, int n_steps)
+                      int64_t first_step, int n_steps, bool with_barostat = false)
 {
     const System& s = h->sys;
     Replica& rep = h->reps[r];
@@ -845,6 +851,13 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
             double p[3] = {0, 0, 0};
             for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) p[k] += s.mass[i] * v[3 * i + k];
             for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) v[3 * i + k] -= p[k] / s.total_mass;
+        }
+        if (with_barostat && h->baro_frequency > 0 && ((h->baro_steps + st + 1) % h->baro_frequency) == 0) {
+            // MonteCarloBarostat: every frequency-th step, in the same updateContextState slot (integrators.py:1313); the attempt
+            // counter is the handle's (shared by all replicas: they attempt in lock step)
+            const long long attempt = h->baro_attempts + (h->baro_steps + st + 1) / h->baro_frequency - h->baro_steps / h->baro_frequency - 1;
+            barostat_attempt(h, r, attempt);
+            x = rep.x.data();
         }
         int oidx = 0;
         for (char tok : tokens) {
@@ -912,7 +925,7 @@ static double ukl_row(remd_ctx* h, int r, double* row)
     if (!s.has_alch || !lam_varies) {
         // one energy per replica serves every state (paralleltempering.py:206-215)
         const double U = evaluate(s, rep, h->lam_s[own], h->lam_e[own], nullptr, fft).total();
-        for (int k = 0; k < K; ++k) row[k] = h->beta[k] * (U + h->econst[k] * cscale);
+        for (int k = 0; k < K; ++k) row[k] = h->beta[k] * (U + h->econst[k] * cscale + (h->pressure.empty() ? 0.0 : h->pressure[k] * V));   // states.py:1913-1914
         return U;
     }
     // alchemical states: only the soft-core pairs depend on lambda_sterics; the electrostatic energy is an exact quadratic
@@ -928,10 +941,108 @@ static double ukl_row(remd_ctx* h, int r, double* row)
         if (it == sc.end()) it = sc.emplace(h->lam_s[k], evaluate(s, rep, h->lam_s[k], 1.0, nullptr, fft, PART_SOFTCORE).total()).first;
         const double le = h->lam_e[k];
         const double U = base + it->second + c0 + c1 * le + c2 * le * le;
-        row[k] = h->beta[k] * (U + h->econst[k] * cscale);
+        row[k] = h->beta[k] * (U + h->econst[k] * cscale + (h->pressure.empty() ? 0.0 : h->pressure[k] * V));
         if (k == own) U_own = U;
     }
     return U_own;
+}
+
+
+// One Monte Carlo volume move of one replica: OpenMM's MonteCarloBarostatImpl::updateContextState restated (cf.
+// oracle/md_oracle.py:OracleBarostat): dV = scale * 2 (u - 1/2); every molecule's centre (arithmetic mean, wrapped into the
+// box) is scaled by s = (V'/V)^(1/3) together with the box; w = U' - U + c (1/V' - 1/V) + p dV - N_mol kT ln(V'/V); reject if
+// w > 0 and u' > exp(-w / kT); after >= 10 attempts the volume step adapts (/ 1.1 below 25 %, x 1.1 capped at 0.3 V above 75 %).
+static void barostat_attempt(remd_ctx* h, int r, long long attempt)
+{
+    const System& s = h->sys;
+    Replica& rep = h->reps[r];
+    FFTSet& fft = thread_fft(h);
+    const int rg = h->r_begin + r, N = s.N;
+    const int64_t k = h->labels[rg];
+    const double kT = 1.0 / h->beta[k], p = h->pressure[k];
+    const double c_lr = h->econst_vref > 0 ? h->econst[k] * h->econst_vref : 0.0;
+    const double U0 = evaluate(s, rep, h->lam_s[k], h->lam_e[k], nullptr, fft).total();
+    const double V = rep.box[0] * rep.box[1] * rep.box[2];
+    if (rep.baro[0] <= 0.0) rep.baro[0] = 0.01 * V;
+    uint32_t w[4];
+    oracle_draw(h->seed, 6u, 0u, (uint32_t)rg, (uint64_t)attempt, w);
+    auto u53 = [](uint32_t hi, uint32_t lo) { return (double)(((uint64_t)hi << 21) | (uint64_t)(lo >> 11)) / 9007199254740992.0; };
+    const double dV = rep.baro[0] * 2.0 * (u53(w[2], w[3]) - 0.5);
+    const double newV = V + dV, scale = cbrt(newV / V);
+    const std::vector<double> x0 = rep.x;
+    const double box0[3] = {rep.box[0], rep.box[1], rep.box[2]};
+    for (const auto& m : s.molecules) {
+        double c[3] = {0, 0, 0};
+        for (int a : m) for (int q = 0; q < 3; ++q) c[q] += x0[3 * a + q];
+        for (int q = 0; q < 3; ++q) {
+            c[q] /= (double)m.size();
+            const double cw = c[q] - floor(c[q] / box0[q]) * box0[q];
+            const double shift = cw * (scale - 1.0) - (c[q] - cw);
+            for (int a : m) rep.x[3 * a + q] = x0[3 * a + q] + shift;
+        }
+    }
+    for (int q = 0; q < 3; ++q) rep.box[q] = box0[q] * scale;
+    rep.list_valid = false;
+    const double U1 = evaluate(s, rep, h->lam_s[k], h->lam_e[k], nullptr, fft).total();
+    const double wgt = U1 - U0 + c_lr * (1.0 / newV - 1.0 / V) + p * dV - (double)s.molecules.size() * kT * log(newV / V);
+    oracle_draw(h->seed, 6u, 1u, (uint32_t)rg, (uint64_t)attempt, w);
+    const bool reject = !(wgt <= 0.0) && !(u53(w[2], w[3]) <= exp(-wgt / kT));
+    if (reject) { rep.x = x0; for (int q = 0; q < 3; ++q) rep.box[q] = box0[q]; rep.list_valid = false; }
+    else { rep.baro[2] += 1; rep.baro[4] += 1; }
+    rep.baro[1] += 1; rep.baro[3] += 1;
+    rep.f_valid = false;
+    (void)N;
+    if (rep.baro[1] >= 10) {
+        const double Vc = rep.box[0] * rep.box[1] * rep.box[2];
+        if (rep.baro[2] < 0.25 * rep.baro[1]) { rep.baro[0] /= 1.1; rep.baro[1] = 0; rep.baro[2] = 0; }
+        else if (rep.baro[2] > 0.75 * rep.baro[1]) { rep.baro[0] = std::min(rep.baro[0] * 1.1, Vc * 0.3); rep.baro[1] = 0; rep.baro[2] = 0; }
+    }
+}
+
+// FIREMinimizationIntegrator (openmmtools/integrators.py:2290-2469) for one replica, cf. oracle/md_oracle.py:OracleFIRE
+static void fire_minimize(remd_ctx* h, int r, double ftol, int max_iterations, int* converged_out, int* iters_out)
+{
+    const System& s = h->sys;
+    Replica& rep = h->reps[r];
+    FFTSet& fft = thread_fft(h);
+    const int N = s.N;
+    const int64_t k = h->labels[h->r_begin + r];
+    const double timestep = 0.001, alpha0 = 0.1, dt_max = 0.010, f_inc = 1.1, f_dec = 0.5, f_alpha = 0.99; const int n_min = 5;
+    std::vector<double> x = rep.x, v(3 * (size_t)N, 0.0), f(3 * (size_t)N), x0, v0, f0, x1(3 * (size_t)N), fn(3 * (size_t)N);   // :2341
+    double dt = timestep, alpha = alpha0; int n_neg = 0; bool converged = false;
+    const double ndof = 3.0 * N;
+    const bool cons = !s.clusters.empty();
+    auto ef = [&](const std::vector<double>& y, double* fo) { rep.x = y; rep.list_valid = rep.list_valid; return evaluate(s, rep, h->lam_s[k], h->lam_e[k], fo, fft).total(); };
+    double E = ef(x, f.data());
+    int it = 0;
+    const int limit = max_iterations > 0 ? max_iterations : 200000;
+    while (it < limit) {
+        double f2 = 0; for (double a : f) f2 += a * a;
+        if (sqrt(f2) / ndof <= ftol) converged = true;                                   // :2377-2386
+        if (converged) { if (max_iterations == 0) break; ++it; continue; }
+        x0 = x; v0 = v; f0 = f; const double E0 = E;                                     // :2392-2394
+        for (int i = 0; i < N; ++i) for (int q = 0; q < 3; ++q) v[3 * i + q] += 0.5 * dt * f[3 * i + q] * s.invm[i];   // :2397
+        for (int i = 0; i < 3 * N; ++i) x1[i] = x[i] + dt * v[i];                        // :2398-2399
+        std::vector<double> xn = x1;
+        if (cons) shake(s, x.data(), xn.data());                                         // :2400
+        const double En = ef(xn, fn.data());
+        for (int i = 0; i < N; ++i) for (int q = 0; q < 3; ++q)
+            v[3 * i + q] += 0.5 * dt * fn[3 * i + q] * s.invm[i] + (xn[3 * i + q] - x1[3 * i + q]) / dt;   // :2401
+        if (cons) rattle(s, xn.data(), v.data());                                        // :2402
+        const double dE = En - E0;                                                       // :2404
+        double fmag = 0, vmag = 0, P = 0;
+        for (int i = 0; i < 3 * N; ++i) { fmag += fn[i] * fn[i]; vmag += v[i] * v[i]; P += fn[i] * v[i]; }   // :2408-2416
+        fmag = sqrt(fmag); vmag = sqrt(vmag);
+        if (fmag > 0) for (int i = 0; i < 3 * N; ++i) v[i] = (1.0 - alpha) * v[i] + alpha * (fn[i] / fmag) * vmag;   // :2421
+        x = xn; E = En; f = fn;
+        if (!(dE < 0)) { x = x0; v = v0; E = E0; f = f0; P = -1.0; }                     // :2423-2431
+        if (dt <= 1.0e-5 * timestep) converged = true;                                   // :2433-2437
+        if (P > 0) { n_neg += 1; if (n_neg > n_min) { dt = std::min(dt * f_inc, dt_max); alpha *= f_alpha; } }   // :2439-2449
+        if (P < 0) { n_neg = 0; dt *= f_dec; std::fill(v.begin(), v.end(), 0.0); alpha = alpha0; }               // :2451-2458
+        ++it;
+    }
+    rep.x = x; rep.v = v; rep.f_valid = false; rep.list_valid = false;
+    *converged_out = converged ? 1 : 0; *iters_out = it;
 }
 
 extern "C" {
@@ -1033,6 +1144,18 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
         for (int k = 0; k < 3; ++k) { if (s.grid[k] < PME_ORDER) return fail(h, -1, "remd_set_system: PME mesh too small"); s.bmod[k] = bspline_moduli(s.grid[k]); }
     }
     s.disp_coeff = (s.method && s.use_disp) ? dispersion_coefficient(s) : 0.0;
+    {   // molecules = connected components over exceptions, bonds and constraints (what the barostat scales as units)
+        std::vector<int> parent(N);
+        for (int i = 0; i < N; ++i) parent[i] = i;
+        auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+        auto unite = [&](int a, int b) { const int ra = find(a), rb = find(b); if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb); };
+        for (int e = 0; e < d->n_exceptions; ++e) unite(d->exception_atoms[2 * e], d->exception_atoms[2 * e + 1]);
+        for (int b2 = 0; b2 < d->n_bonds; ++b2) unite(d->bond_atoms[2 * b2], d->bond_atoms[2 * b2 + 1]);
+        for (const Cluster& c : s.clusters) for (int q = 1; q < c.n_atoms; ++q) unite(c.atoms[0], c.atoms[q]);
+        std::map<int, std::vector<int>> groups;
+        for (int i = 0; i < N; ++i) groups[find(i)].push_back(i);
+        for (auto& g : groups) s.molecules.push_back(g.second);
+    }
     h->sys = std::move(s);
     for (auto& f : h->fft) for (int k = 0; k < 3; ++k) f.f[k].reset();
     h->has_system = true;
@@ -1075,10 +1198,13 @@ int remd_set_restart_attempts(remd_handle h, int n)
 
 int remd_set_barostat(remd_handle h, int K, const double* pressure, int frequency)
 {
-    (void)K;
     if (!h) return -1;
-    if (!pressure || frequency <= 0) return 0;     // switching it off is fine
-    return fail(h, -3, "libremd_cpu: the Monte Carlo barostat is not implemented in the CPU baseline");
+    if (!pressure || frequency <= 0) { h->baro_frequency = 0; h->pressure.clear(); return 0; }
+    if (K != h->K) return fail(h, -1, "remd_set_barostat: K differs from remd_set_states");
+    for (int k = 0; k < K; ++k) if (!(pressure[k] == pressure[k])) return fail(h, -1, "remd_set_barostat: NaN pressure");
+    h->pressure.assign(pressure, pressure + K);
+    h->baro_frequency = frequency;
+    return 0;
 }
 int remd_get_boxes(remd_handle h, double* box)
 {
@@ -1090,14 +1216,33 @@ int remd_set_energy_const_volume(remd_handle h, double v) { if (!h || !(v >= 0))
 int remd_get_barostat_stats(remd_handle h, double* vs, int64_t* na, int64_t* nc)
 {
     if (!h || h->R <= 0) return fail(h, -1, "remd_get_barostat_stats: replicas not set");
-    for (int r = 0; r < h->R; ++r) { if (vs) vs[r] = 0; if (na) na[r] = 0; if (nc) nc[r] = 0; }
+    for (int r = 0; r < h->R; ++r) { if (vs) vs[r] = h->reps[r].baro[0]; if (na) na[r] = (int64_t)h->reps[r].baro[3]; if (nc) nc[r] = (int64_t)h->reps[r].baro[4]; }
     return 0;
 }
-int remd_barostat_attempts(remd_handle h, int n) { (void)n; return fail(h, -3, "remd_barostat_attempts: no barostat (remd_set_barostat)"); }
+int remd_barostat_attempts(remd_handle h, int n)
+{
+    if (!h) return -1;
+    if (n < 0) return fail(h, -1, "remd_barostat_attempts: negative n_attempts");
+    if (h->R <= 0) return fail(h, -1, "remd_barostat_attempts: replicas not set");
+    if (h->baro_frequency <= 0 || h->pressure.empty()) return fail(h, -3, "remd_barostat_attempts: no barostat (remd_set_barostat)");
+    for (int a = 0; a < n; ++a) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int r = 0; r < h->R; ++r) barostat_attempt(h, r, h->baro_attempts);
+        h->baro_attempts += 1;
+    }
+    return 0;
+}
 int remd_minimize(remd_handle h, double tol, int maxit, int32_t* conv, int32_t* nit)
 {
-    (void)tol; (void)maxit; (void)conv; (void)nit;
-    return fail(h, -3, "libremd_cpu: FIRE minimisation is not implemented in the CPU baseline");
+    if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return fail(h, -1, "remd_minimize: system/states/replicas not all set");
+    if (!(tol >= 0) || maxit < 0) return fail(h, -1, "remd_minimize: bad arguments");
+    std::vector<int> c(h->R, 0), n(h->R, 0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int r = 0; r < h->R; ++r) fire_minimize(h, r, tol, maxit, &c[r], &n[r]);
+    int mx = 0;
+    for (int r = 0; r < h->R; ++r) { if (conv) conv[r] = c[r]; mx = std::max(mx, n[r]); }
+    if (nit) *nit = mx;
+    return 0;
 }
 
 int remd_set_labels(remd_handle h, const int64_t* labels)
@@ -1147,14 +1292,19 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     for (int r = 0; r < R; ++r) {
         Replica& rep = h->reps[r];
         const std::vector<double> x0 = rep.x, v0 = rep.v;
+        const double box0[3] = {rep.box[0], rep.box[1], rep.box[2]};
         for (int a = 0; a <= h->n_restart_attempts; ++a) {             // mcmc.py:706-759
             const int64_t it = iteration + ((int64_t)a << 40);
-            if (a > 0) { rep.x = x0; rep.v = v0; rep.f_valid = false; }
+            if (a > 0) { rep.x = x0; rep.v = v0; for (int q = 0; q < 3; ++q) rep.box[q] = box0[q]; rep.f_valid = false; rep.list_valid = false; }
             if (h->reassign) assign_velocities(h, r, it);
-            run_steps(h, r, h->tokens, h->nV, h->nR, h->nO, it, 0, h->n_steps);
+            run_steps(h, r, h->tokens, h->nV, h->nR, h->nO, it, 0, h->n_steps, true);
             flags[r] = finite_state(rep) ? 0 : 1;
             if (!flags[r]) break;
         }
+    }
+    if (h->baro_frequency > 0) {
+        h->baro_attempts += (h->baro_steps + h->n_steps) / h->baro_frequency - h->baro_steps / h->baro_frequency;
+        h->baro_steps += h->n_steps;
     }
     h->t_prop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (nan_flags) for (int r = 0; r < R; ++r) nan_flags[r] = flags[r];

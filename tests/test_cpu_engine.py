@@ -175,15 +175,64 @@ def test_cpu_sampler_equals_python_oracle_engine(cpu_engine_factory):
         assert np.allclose(ua, ub, rtol=1e-9, atol=1e-12)
 
 
-def test_cpu_library_exports_the_whole_abi_and_refuses_what_it_lacks(cpu_engine_factory):
+def test_cpu_barostat_tracks_the_python_oracle(cpu_engine_factory):
+    """NPT: Monte Carlo barostat inside the Langevin step (frequency 5 here) and explicit volume moves; boxes, volumes and
+    the beta p V term of u_kl against OracleEngine on the same Philox stream."""
+    lj = ts.LennardJonesFluid(nparticles=216)
+    desc = system_to_desc(lj.system)
+    R = 2
+    beta = np.full(R, 1.0 / (KB * 120.0))
+    p = np.full(R, 30.0 * unit.bar)
+    box = np.tile(np.diag(lj.system.getDefaultPeriodicBoxVectors()), (R, 1))
+    x = np.stack([lj.positions, lj.positions + 0.002 * np.random.default_rng(1).normal(size=lj.positions.shape)])
+    engines = []
+    for eng in (cpu_engine_factory(), OracleEngine(ForceFieldOracle)):
+        eng.set_system(desc)
+        eng.set_states(beta)
+        eng.set_integrator('V R O R V', 0.002, 1.0, 12, True, 1e-8)
+        eng.set_barostat(p, 5)
+        eng.set_energy_const_volume(0.0)
+        eng.seed(SEED)
+        eng.set_replicas(R, 0, x, None, box, np.arange(R))
+        assert not eng.propagate(1).any()
+        eng.barostat_attempts(3)
+        engines.append(eng)
+    cpu, ora = engines
+    assert np.allclose(cpu.get_boxes(), ora.get_boxes(), rtol=1e-10)
+    assert not np.allclose(cpu.get_boxes(), box)                       # some move was accepted
+    assert np.allclose(cpu.get_replicas()[0], ora.get_replicas()[0], atol=1e-8)
+    rows_c, rows_o = cpu.compute_energies(), ora.compute_energies()
+    assert np.allclose(rows_c, rows_o, rtol=1e-9)
+    vs, na, nc = cpu.barostat_stats()
+    assert na.tolist() == [5, 5] and (nc <= na).all() and (vs > 0).all()
+
+
+def test_cpu_fire_minimiser_tracks_the_python_oracle(cpu_engine_factory):
+    """remd_minimize on the CPU library = OracleFIRE (integrators.py:2290-2469) step for step: 25 FIRE steps of a jittered
+    LJ fluid and of alanine dipeptide with constraints."""
+    for system, n_it, jitter in ((ts.LennardJonesFluid(nparticles=216), 25, 0.003), (ts.AlanineDipeptideExplicit(), 8, 0.0)):
+        desc = system_to_desc(system.system)
+        x = (system.positions + jitter * np.random.default_rng(2).normal(size=system.positions.shape))[None]
+        box = np.diag(system.system.getDefaultPeriodicBoxVectors())[None]
+        out = []
+        for eng in (cpu_engine_factory(), OracleEngine(ForceFieldOracle)):
+            eng.set_system(desc)
+            eng.set_states(np.array([1.0 / (KB * 300.0)]))
+            eng.set_integrator('V R O R V', 0.001, 1.0, 1, True, 1e-8)
+            eng.seed(SEED)
+            eng.set_replicas(1, 0, x, None, box, np.zeros(1, dtype=np.int64))
+            conv, n = eng.minimize(tolerance=0.0, max_iterations=n_it)
+            out.append((eng.get_replicas()[0], n))
+        assert out[0][1] == out[1][1] == n_it
+        assert np.abs(out[0][0] - out[1][0]).max() < 1e-7
+        assert np.abs(out[0][0] - x).max() > 1e-5                       # it moved
+
+
+def test_cpu_library_exports_the_whole_abi(cpu_engine_factory):
     from openmmtools_amd._engine import EXPORTS
     eng = cpu_engine_factory()
     for name in EXPORTS:
         assert hasattr(eng.lib, name), name
     assert eng.lib.remd_cpu_num_threads() >= 1
-    lj = ts.LennardJonesFluid(nparticles=216)
-    _setup(eng, lj.system, lj.positions, R=1)
-    with pytest.raises(RuntimeError, match='not implemented'):
-        eng.minimize()
-    with pytest.raises(RuntimeError, match='not implemented'):
-        eng.set_barostat(np.array([0.06]), 25)
+    with pytest.raises(RuntimeError, match='GPU measurement'):
+        eng.roof_microbench()
