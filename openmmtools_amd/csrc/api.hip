@@ -412,7 +412,8 @@ int remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t f
     nV = h->nV; nR = h->nR; nO = h->nO;
     int rc = remd_run_steps(h, tokens, nV, nR, nO, iteration, first_step, n_steps);
     if (rc) return rc;
-    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    static const bool nosync = getenv("REMD_STEP_NOSYNC") != nullptr;      // experiment hook: interleaving several handles from one thread
+    if (!nosync) REMD_CHECK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

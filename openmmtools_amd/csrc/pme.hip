@@ -44,6 +44,7 @@ struct pme_state {
     fft_sched sch_x, sch_y, sch_z;     // butterfly schedules of the in-place passes (xy planes; z lines for (sch_nl, sch_zt))
     uint2* d_sched[3] = {nullptr, nullptr, nullptr};
     int sch_nl = 0, sch_zt = 0;
+    bool gather_fused = false;         // the inverse z launch already added the forces (pme_zinv_gather_kernel)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -472,6 +473,110 @@ void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const fl
             const int l = fft_div(idx, mM, M);
             Mesh[idx] = buf[idx + l * (PZ - nz)].x;
         }
+    }
+}
+
+// inverse z + force gather in one launch.  After the inverse z transforms a workgroup holds the real potential of its mesh
+// row(s) x in LDS; the atoms whose 5-point x stencil touches that row are exactly the ones of bins kx = x .. x+4 (the
+// candidates of the spreading pass), so each of them takes ITS SHARE of the force from this row here -- 25 LDS reads --
+// and adds it to the fixed-point accumulators.  An atom gets its force from five workgroups (15 integer atomics instead
+// of 3; sums are order independent), and the real potential mesh (4 B / point written, then 125 reads per atom from L2) and
+// one dependent launch on the critical path of a step disappear.
+template <int Z_THREADS, bool HALF>
+__global__ __launch_bounds__(Z_THREADS)
+void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const float2* __restrict__ spec,
+                            const float2* tw, const float2* tw_half, int Npad, const float4* __restrict__ pos,
+                            const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
+                            const int* __restrict__ col_start, const int* __restrict__ col_atoms, long long* __restrict__ force)
+{
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = pl.n;
+    const int nz = HALF ? 2 * M : M, nzc = nz / 2 + 1, PZ = HALF ? ((M + 1) | 1) : (nz | 1);
+    float2* buf = reinterpret_cast<float2*>(smem);
+    float2* s_tw = buf + nl * PZ;
+    float2* s_twh = s_tw + nz;
+    const int r = blockIdx.y, tid = threadIdx.x;
+    const int l0 = blockIdx.x * nl;
+    const int x = l0 / ny, y0 = l0 % ny;
+    for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
+    if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
+    const float2* S = spec + (size_t)r * nzc * nx * ny;
+    const unsigned mnl = fft_magic((unsigned)nl);
+    for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
+        const int kz = fft_div(idx, mnl, nl), b = idx - kz * nl;
+        const float2 v = S[((size_t)kz * nx + x) * ny + y0 + b];
+        buf[b * PZ + kz] = v;
+        if (!HALF && kz > 0 && kz < nz - kz) buf[b * PZ + nz - kz] = make_float2(v.x, -v.y);
+    }
+    __syncthreads();
+    if (HALF) {
+        for (int idx = tid; idx < nl * (M / 2 + 1); idx += Z_THREADS) {
+            const int k = fft_div(idx, mnl, nl), b = idx - k * nl;
+            const float2 Xk = buf[b * PZ + k], Xm = buf[b * PZ + M - k];
+            const float2 A = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);
+            const float2 B = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);
+            const float2 w = s_tw[k];
+            const float2 t = cmul(make_float2(w.x, -w.y), B);
+            buf[b * PZ + k] = make_float2(A.x - t.y, A.y + t.x);
+            if (k != 0 && k != M - k) {
+                const float2 u = cmul(w, make_float2(B.x, -B.y));
+                buf[b * PZ + M - k] = make_float2(A.x - u.y, -A.y + u.x);
+            }
+        }
+        __syncthreads();
+    }
+    fft_lines_inplace<+1, Z_PPT>(pl, sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
+    // potential of line l at z: HALF keeps the real line as pairs (x[2n], x[2n+1]) = consecutive floats; else the real parts
+    const float* phi = reinterpret_cast<const float*>(buf);
+    const int zs = HALF ? 1 : 2, ls = 2 * PZ;
+    const int* cs = col_start + (size_t)r * (nx + 1);
+    const int* ca = col_atoms + (size_t)r * Npad;
+    const float4* P = pos + (size_t)r * Npad;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
+    const int xe = x + 5;
+    const int beg0 = cs[x], end0 = cs[xe <= nx ? xe : nx];
+    const int beg1 = cs[0], end1 = (xe <= nx) ? beg1 : cs[xe - nx];
+    const int n0 = end0 - beg0, ntot = n0 + (end1 - beg1);
+    for (int t = tid; t < ntot; t += Z_THREADS) {
+        const int i = ca[t < n0 ? beg0 + t : beg1 + (t - n0)];
+        const float4 pr = param[i];
+        float q = pr.x;
+        if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
+        if (q == 0.f) continue;
+        float ux, uy, uz; int kx, ky, kz;
+        pme_scaled(P[i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+        float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
+        bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
+        if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+        int a = kx - x; if (a < 0) a += nx;              // 0..4 by construction of the bins
+        float wxa = 0.f, dxa = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (k == a) { wxa = wx[k]; dxa = dx[k]; }
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            int iy = ky - b; if (iy < 0) iy += ny;
+            const int lb = iy - y0;
+            if (lb < 0 || lb >= nl) continue;
+            any = true;
+            float sx = 0.f, sz = 0.f;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                int iz = kz - c; if (iz < 0) iz += nz;
+                const float p = phi[lb * ls + iz * zs];
+                sx += wz[c] * p; sz += dz[c] * p;
+            }
+            gx += wy[b] * sx; gy += dy[b] * sx; gz += wy[b] * sz;
+        }
+        if (!any) continue;
+        // dE/dx = q * dtheta/du * du/dx, du/dx = n / L
+        const float Fx = -q * dxa * gx * nx / Lx, Fy = -q * wxa * gy * ny / Ly, Fz = -q * wxa * gz * nz / Lz;
+        atomicAdd(&F[i], (unsigned long long)(long long)((double)Fx * REMD_FORCE_SCALE));
+        atomicAdd(&F[Npad + i], (unsigned long long)(long long)((double)Fy * REMD_FORCE_SCALE));
+        atomicAdd(&F[2 * Npad + i], (unsigned long long)(long long)((double)Fz * REMD_FORCE_SCALE));
     }
 }
 
@@ -1060,13 +1165,21 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         }
-        DISPATCH_Z(pme_zinv_kernel, s->d_grid, reinterpret_cast<float*>(s->d_mesh), s->d_tw[2], s->d_tw[3]);
+        static const bool fuse_gather = !(getenv("REMD_PME_FUSEGATHER") && atoi(getenv("REMD_PME_FUSEGATHER")) == 0);
+        s->gather_fused = fuse_gather;
+        if (fuse_gather) {
+            remd_prof_scope pzg(h, "pme_zinv_gather", st);
+            DISPATCH_Z(pme_zinv_gather_kernel, s->d_grid, s->d_tw[2], s->d_tw[3], h->Npad, h->d_pos, param, h->d_box, rep_lam,
+                       s->d_col_start, s->d_col_atoms, h->d_force);
+        } else {
+            DISPATCH_Z(pme_zinv_kernel, s->d_grid, reinterpret_cast<float*>(s->d_mesh), s->d_tw[2], s->d_tw[3]);
+        }
 #undef DISPATCH_Z
 #undef LAUNCH_Z
     }
     }   // part 1
     if (!(part & 2)) { REMD_CHECK(h, hipGetLastError()); return 0; }
-    {
+    if (!s->gather_fused) {
         remd_prof_scope ps(h, "pme_gather", st);
         hipLaunchKernelGGL(pme_gather_kernel, dim3((h->N + 127) / 128, h->R), dim3(128), 0, st, h->N, h->Npad, nx, ny, nz,
                            h->d_pos, param, h->d_box, rep_lam, reinterpret_cast<const float*>(s->d_mesh), h->d_force, s->d_col_atoms);
