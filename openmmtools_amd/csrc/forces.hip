@@ -108,9 +108,9 @@ static handle_table<nb_tables> g_nb;
 __device__ __forceinline__ void add_force(long long* __restrict__ F, int Npad, int i, float fx, float fy, float fz)
 {
     unsigned long long* U = reinterpret_cast<unsigned long long*>(F);
-    atomicAdd(&U[i],            (unsigned long long)(long long)((double)fx * REMD_FORCE_SCALE));
-    atomicAdd(&U[Npad + i],     (unsigned long long)(long long)((double)fy * REMD_FORCE_SCALE));
-    atomicAdd(&U[2 * Npad + i], (unsigned long long)(long long)((double)fz * REMD_FORCE_SCALE));
+    atomicAdd(&U[i],            remd_f2fix(fx));
+    atomicAdd(&U[Npad + i],     remd_f2fix(fy));
+    atomicAdd(&U[2 * Npad + i], remd_f2fix(fz));
 }
 
 __device__ __forceinline__ double wave_sum(double e)
@@ -417,7 +417,8 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
             dUc = qq * (2.f * p.krf * r - inv_r * inv_r);
         }
     }
-    fr = (dUdr + dUc) * inv_r;
+    // (x + 0.f cannot be folded without nsz: name the sum the variant has)
+    fr = (METHOD == NB_LJ_ONLY ? dUdr : METHOD > NB_EWALD ? dUc : dUdr + dUc) * inv_r;
     e_out = ((ALCH && na && energy_skip_na) ? 0.f : U) + Uc;
     return e_out;
 }
@@ -894,6 +895,38 @@ void build_sci_list2_kernel(int nt_a, sci_list_args a, sci_list_args b, float rc
                         box, g.list, g.count);
 }
 
+// all-reduce over the lanes that differ in bit 3 / 4 / 5 of the lane id without the LDS crossbar (ds_bpermute: address
+// arithmetic + a round trip per exchange): a row rotation by 8 (DPP) and the gfx950 row / half swaps
+__device__ __forceinline__ float allsum_x8(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float allsum_x16(float v)
+{
+    float a = v, b = v;        // odd rows of a <-> even rows of b
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float allsum_x32(float v)
+{
+    float a = v, b = v;        // upper half of a <-> lower half of b
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// v where bit `lane` of the wave-uniform mask is set, else 0: one v_cndmask on the scalar mask
+__device__ __forceinline__ float keep_where(unsigned long long m, float v)
+{
+    float o;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(m));
+    return o;
+}
+__device__ __forceinline__ float min_sv(float s_uniform, float v)
+{
+    float o;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(o) : "s"(s_uniform), "v"(v));
+    return o;
+}
+
 // lane = (ii = lane >> 3, jj = lane & 7): the lane holds atom ii of all 8 i clusters of its tile in registers and, per
 // list entry, atom jj of the j cluster.
 #define SCI_NW 4
@@ -924,6 +957,7 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
     float lam_a = 1.f, sc = 0.f, lam_e = 1.f;
     if (ALCH) { lam_a = rep_lam[4 * r]; sc = rep_lam[4 * r + 1]; lam_e = rep_lam[4 * r + 2]; }
     const int c_last = (N - 1) >> 3;                         // the only cluster that can mix real and padding atoms
+    const unsigned long long valid_j = __builtin_amdgcn_ballot_w64(c_last * 8 + jj < N), valid_i = __builtin_amdgcn_ballot_w64(c_last * 8 + ii < N);
 
     // slice zsl takes the entries zsl, zsl + nsplit, ...: the near-diagonal entries (most i clusters per entry) come first
     // in a list, so contiguous slices would be unevenly loaded
@@ -980,34 +1014,40 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 float dx = xj.x - xi[s].x, dy = xj.y - xi[s].y, dz = xj.z - xi[s].z;
                 dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
                 const float r2 = dx * dx + dy * dy + dz * dz;
-                bool in = r2 < p.rc2;
-                const float r2c = in ? r2 : p.rc2;               // clamp for the lanes beyond the cutoff (one select; fminf costs three ops)
+                // which lane pairs count is wave-uniform data (cutoff ballot, exclusion word, padding masks): scalar unit
+                unsigned long long in = __builtin_amdgcn_ballot_w64(r2 < p.rc2);
+                const float r2c = min_sv(p.rc2, r2);             // lanes beyond the cutoff evaluate at the cutoff
                 const int dj = jc - ic;
                 if (dj < W) {                                    // wave-uniform: exclusions (and the diagonal) live here
                     unsigned long long m;
-                    if (W <= 8) m = (unsigned long long)__builtin_amdgcn_readlane(ex_lo, s * 8 + dj)
-                                  | ((unsigned long long)__builtin_amdgcn_readlane(ex_hi, s * 8 + dj) << 32);
-                    else m = excl[((size_t)r * ncl + ic) * W + dj];
-                    in = in && !((m >> lane) & 1ull);
+                    // (readlane returns int: without the unsigned cast bit 31 of the low word would smear over lanes 32..63)
+                    if (W <= 8) m = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(ex_lo, s * 8 + dj)
+                                  | ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(ex_hi, s * 8 + dj) << 32);
+                    else {
+                        const unsigned long long mv = excl[((size_t)r * ncl + ic) * W + dj];
+                        m = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)mv)
+                          | ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(mv >> 32)) << 32);
+                    }
+                    in &= ~m;
                 }
-                if (jc == c_last || ic == c_last) in = in && (j < N) && (ic * 8 + ii < N);
-                if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;   // no atom pair of this cluster pair is inside the cutoff
+                if (jc == c_last) in &= valid_j;
+                if (ic == c_last) in &= valid_i;
+                if (in == 0ull) continue;                        // no atom pair of this cluster pair is inside the cutoff
                 touched = true;
                 float fr, ee;
-                // evaluated for every lane (r2 clamped to the cutoff for far pairs; excluded pairs, even r2 = 0, produce
-                // garbage that the selects below discard), result kept only where `in`
+                // evaluated for every lane (excluded pairs, even r2 = 0, produce garbage that the select below discards)
                 pair_interaction<METHOD, ALCH, !ENERGY>(p, r2c, pi[s], pj, lam_a, sc, fr, ENERGY, ee);
-                fr = in ? fr : 0.f;
+                fr = keep_where(in, fr);
                 const float tx = fr * dx, ty = fr * dy, tz = fr * dz;
                 fix[s] += tx; fiy[s] += ty; fiz[s] += tz;
                 fjx -= tx; fjy -= ty; fjz -= tz;
-                if (ENERGY) e += in ? (double)ee : 0.0;
+                if (ENERGY) e += ((in >> lane) & 1ull) ? (double)ee : 0.0;
             }
             if (touched) {
                 // reaction on the j atoms: all-reduce over the 8 ii lanes (every lane ends up with the total of its jj)
-                fjx += __shfl_xor(fjx, 8); fjy += __shfl_xor(fjy, 8); fjz += __shfl_xor(fjz, 8);
-                fjx += __shfl_xor(fjx, 16); fjy += __shfl_xor(fjy, 16); fjz += __shfl_xor(fjz, 16);
-                fjx += __shfl_xor(fjx, 32); fjy += __shfl_xor(fjy, 32); fjz += __shfl_xor(fjz, 32);
+                fjx = allsum_x8(fjx); fjy = allsum_x8(fjy); fjz = allsum_x8(fjz);
+                fjx = allsum_x16(fjx); fjy = allsum_x16(fjy); fjz = allsum_x16(fjz);
+                fjx = allsum_x32(fjx); fjy = allsum_x32(fjy); fjz = allsum_x32(fjz);
             }
             const int eb = k & 7;
             if (ii == eb) { qfx = fjx; qfy = fjy; qfz = fjz; qj = j; }

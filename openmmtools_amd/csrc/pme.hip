@@ -574,9 +574,9 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
         if (!any) continue;
         // dE/dx = q * dtheta/du * du/dx, du/dx = n / L
         const float Fx = -q * dxa * gx * nx / Lx, Fy = -q * wxa * gy * ny / Ly, Fz = -q * wxa * gz * nz / Lz;
-        atomicAdd(&F[i], (unsigned long long)(long long)((double)Fx * REMD_FORCE_SCALE));
-        atomicAdd(&F[Npad + i], (unsigned long long)(long long)((double)Fy * REMD_FORCE_SCALE));
-        atomicAdd(&F[2 * Npad + i], (unsigned long long)(long long)((double)Fz * REMD_FORCE_SCALE));
+        atomicAdd(&F[i], remd_f2fix(Fx));
+        atomicAdd(&F[Npad + i], remd_f2fix(Fy));
+        atomicAdd(&F[2 * Npad + i], remd_f2fix(Fz));
     }
 }
 
@@ -807,9 +807,9 @@ void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __
     const float Fx = -q * gx * nx / Lx, Fy = -q * gy * ny / Ly, Fz = -q * gz * nz / Lz;
     // integer atomics: the direct-space kernels add to the same accumulators concurrently on another stream
     unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
-    atomicAdd(&F[i], (unsigned long long)(long long)((double)Fx * REMD_FORCE_SCALE));
-    atomicAdd(&F[Npad + i], (unsigned long long)(long long)((double)Fy * REMD_FORCE_SCALE));
-    atomicAdd(&F[2 * Npad + i], (unsigned long long)(long long)((double)Fz * REMD_FORCE_SCALE));
+    atomicAdd(&F[i], remd_f2fix(Fx));
+    atomicAdd(&F[Npad + i], remd_f2fix(Fy));
+    atomicAdd(&F[2 * Npad + i], remd_f2fix(Fz));
 }
 
 // fall-back influence-function pass for meshes whose (x,y) plane does not fit the LDS

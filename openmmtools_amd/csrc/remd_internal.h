@@ -17,6 +17,19 @@ struct remd_error { int code; std::string msg; };
 // fixed-point scale of the force accumulators (deterministic integer atomics)
 #define REMD_FORCE_SCALE 4294967296.0   // 2^32
 
+// (unsigned long long)(long long)((double)f * 2^32), i.e. truncation toward zero, bit for bit, without the f64 conversion
+// chain the cast expands to (8 double-rate instructions per component): |f| = floor + fraction is exact in f32, the
+// fraction times 2^32 is exact, and the two halves are converted separately.  |f| >= 2^31 saturates as before.
+__device__ __forceinline__ unsigned long long remd_f2fix(float f)
+{
+    const float a = fabsf(f);
+    const float hi_f = floorf(a);
+    const unsigned int lo = (unsigned int)((a - hi_f) * 4294967296.f);
+    const unsigned int hi = (unsigned int)(int)hi_f;
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    return f < 0.f ? 0ull - v : v;
+}
+
 struct remd_profile_entry { int64_t n = 0; double ms = 0.0; };
 
 struct remd_ctx {

@@ -85,6 +85,35 @@ def test_lj_fluid_alchemical_ukl(hip_engine_factory):
         assert np.abs(f[r] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
 
 
+def test_exclusion_word_with_high_lane_bits(hip_engine_factory):
+    """8-atom groups whose exclusions include (slot 3, slot 7) of a cluster: bit 31 of the diagonal cluster pair's 64-bit
+    exclusion word is set.  (The word is read as two 32-bit halves; a signed low half once smeared that bit over lanes
+    32..63 and silently dropped the pairs of i atoms 4..7.)  Also (0, 4) and the chain (k, k+1)."""
+    from openmmtools_amd.system import NonbondedForce
+    lj = ts.LennardJonesFluid(nparticles=512)
+    nb = [f for f in lj.system.getForces() if isinstance(f, NonbondedForce)][0]
+    for g in range(64):
+        for k in range(7):
+            nb.addException(8 * g + k, 8 * g + k + 1, 0.0, 0.1, 0.0)
+        nb.addException(8 * g + 3, 8 * g + 7, 0.0, 0.1, 0.0)
+        nb.addException(8 * g, 8 * g + 4, 0.0, 0.1, 0.0)
+    # every group a compact 2 x 2 x 2 cube (0.38 nm edge), so that its non-excluded pairs (4,6), (4,7), (5,7) ... carry force
+    L = float(np.diag(lj.system.getDefaultPeriodicBoxVectors())[0])
+    cube = 0.38 * np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=float)
+    centres = (L / 4.0) * np.array([[a, b, c] for a in range(4) for b in range(4) for c in range(4)], dtype=float) + 0.3
+    positions = (centres[:, None, :] + cube[None, :, :]).reshape(512, 3)
+    eng = hip_engine_factory()
+    desc, x, box = _engine_for(eng, lj.system, positions, R=2, jitter=0.01)
+    ff = ForceFieldOracle(desc)
+    U = eng.compute_energies(want_potential=True)[1]
+    f = eng.get_forces()
+    xd = eng.get_replicas()[0]
+    for r in range(2):
+        e_ref, f_ref = ff.energy_forces(xd[r], box[r])
+        assert np.isclose(U[r], e_ref, rtol=1e-5), (U[r], e_ref)
+        assert np.abs(f[r] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
+
+
 @pytest.fixture(scope='module')
 def alanine():
     al = ts.AlanineDipeptideExplicit()
