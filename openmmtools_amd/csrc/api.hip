@@ -11,6 +11,7 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows);
 int remd_nb_required_epart(remd_ctx* h);
 void remd_free_nonbonded(remd_ctx* h);
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
+int remd_test_xy_mfma_impl(remd_ctx* h, int n, int nplanes, float* data, int mode);
 void remd_free_constraints(remd_ctx* h);
 
 static std::mutex g_err_mutex;
@@ -76,6 +77,10 @@ int remd_create(remd_handle* out, int device, void* stream)
     { const unsigned evf = (getenv("REMD_EVENT_SYSFENCE") ? 0u : hipEventReleaseToDevice) | hipEventDisableTiming;   // device-scope release: no system-scope cache write-back per fork / join
       hipEventCreateWithFlags(&h->ev_fork, evf); hipEventCreateWithFlags(&h->ev_join, evf); }
     { const char* env = getenv("REMD_OVERLAP"); h->overlap = !(env && atoi(env) == 0); }
+    h->sync_events = getenv("REMD_SYNC_EVENTS") && atoi(getenv("REMD_SYNC_EVENTS")) != 0;
+    if (hipMalloc(&h->d_sync, 4 * sizeof(unsigned int)) != hipSuccess || hipMemset(h->d_sync, 0, 4 * sizeof(unsigned int)) != hipSuccess) {
+        delete h; return remd_fail(nullptr, -2, "remd_create: hipMalloc failed");
+    }
     *out = h;
     return 0;
 }
@@ -103,6 +108,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
+    if (h->d_sync) hipFree(h->d_sync);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -293,7 +299,10 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         const auto tq1 = std::chrono::steady_clock::now();
         if ((rc = remd_check_finite(h))) return rc;
         REMD_CHECK(h, hipMemcpyAsync(flags.data(), h->d_nan, sizeof(int) * h->R, hipMemcpyDeviceToHost, h->stream));
+        unsigned int spin_out = 0;
+        REMD_CHECK(h, hipMemcpyAsync(&spin_out, h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
         REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        if (spin_out) return remd_fail(h, -2, "remd_propagate: a cross-stream wait on the device ran out (fork / join flag never arrived)");
         if (time_enqueue) {
             // diagnostic: host time spent enqueueing the MD steps vs the time until the device finished them
             const auto tq2 = std::chrono::steady_clock::now();
@@ -571,6 +580,13 @@ int remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inve
     if (!h || !data) return remd_fail(h, -1, "remd_test_fft3d: bad arguments");
     hipSetDevice(h->device);
     return remd_test_fft3d_impl(h, nx, ny, nz, data, inverse);
+}
+
+int remd_test_xy_mfma(remd_handle h, int n, int nplanes, float* data, int mode)
+{
+    if (!h || !data || n <= 0 || nplanes <= 0) return remd_fail(h, -1, "remd_test_xy_mfma: bad arguments");
+    hipSetDevice(h->device);
+    return remd_test_xy_mfma_impl(h, n, nplanes, data, mode);
 }
 
 int remd_get_energy_components(remd_handle h, double* out)

@@ -105,6 +105,23 @@ struct nb_tables {
 };
 static handle_table<nb_tables> g_nb;
 
+// cross-stream dependencies without the command processor (see remd_ctx::d_sync): one lane polls a flag in device memory
+__global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq, unsigned int* spin_out)
+{
+    if (threadIdx.x == 0) {
+        long long n = 0;
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++n > (1ll << 25)) { atomicExch(spin_out, 1u); break; }       // seconds: something upstream died; say so instead of hanging
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__global__ void remd_signal_kernel(unsigned int* flag, unsigned int seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void add_force(long long* __restrict__ F, int Npad, int i, float fx, float fy, float fz)
 {
     unsigned long long* U = reinterpret_cast<unsigned long long*>(F);
@@ -1975,8 +1992,15 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
             // integrator chain (no cross-stream event latency on the critical path); the direct-space launches below go
             // to the second stream (h->stream is swapped until the join) and absorb the event wait in their slack
             static const bool pme_on_main = !(getenv("REMD_PME_MAIN") && atoi(getenv("REMD_PME_MAIN")) == 0);
-            hipEventRecord(h->ev_fork, h->stream);
-            hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
+            const bool flags = pme_on_main && !h->sync_events && !h->capturing;
+            if (flags) {
+                // the binning kernel (first launch of remd_pme_forces) stores the fork flag; the second stream polls it
+                h->fork_seq_pending = ++h->sync_seq;
+                hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream2, h->d_sync, h->sync_seq, h->d_sync + 2);
+            } else {
+                hipEventRecord(h->ev_fork, h->stream);
+                hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
+            }
             if (pme_on_main) {
                 // everything up to the inverse z FFT now; the gather is enqueued behind the join (below), so that the
                 // cross-stream wait sits in front of the last mesh kernel instead of between it and the integrator
@@ -2078,8 +2102,14 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         if (t.method == NB_EWALD) {
             if (pme_forked) {                                                   // join
                 const bool gather_pending = swapped;
-                if (swapped) { hipEventRecord(h->ev_join, h->stream); std::swap(h->stream, h->stream2); swapped = false; }
-                hipStreamWaitEvent(h->stream, h->ev_join, 0);
+                if (swapped && !h->sync_events && !h->capturing) {
+                    hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
+                    std::swap(h->stream, h->stream2); swapped = false;
+                    hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq, h->d_sync + 2);
+                } else {
+                    if (swapped) { hipEventRecord(h->ev_join, h->stream); std::swap(h->stream, h->stream2); swapped = false; }
+                    hipStreamWaitEvent(h->stream, h->ev_join, 0);
+                }
                 if (gather_pending) { rc = remd_pme_forces(h, with_energy, h->stream, 2); if (rc) return rc; }
             }
             else { rc = remd_pme_forces(h, with_energy, h->stream); if (rc) return rc; }

@@ -678,7 +678,9 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                 if (h->step_graph_exec) { hipGraphExecDestroy(h->step_graph_exec); h->step_graph_exec = nullptr; }
                 if (h->step_graph) { hipGraphDestroy(h->step_graph); h->step_graph = nullptr; }
                 REMD_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+                h->capturing = true;                 // cross-stream dependencies as events: capture follows them into the second stream
                 const int rc = run_body(s);
+                h->capturing = false;
                 hipGraph_t g = nullptr;
                 const hipError_t e = hipStreamEndCapture(h->stream, &g);
                 if (rc) { if (g) hipGraphDestroy(g); return rc; }

@@ -24,6 +24,10 @@
 
 struct fft_sched { const uint2* tab; int off[8]; int wave_local; };   // see fft_stage_sched
 
+int remd_dftmm_build_table(remd_ctx* h, int n, void** d_table);
+void remd_dftmm_launch_xy(hipStream_t st, int n, int nplanes, int nzc, int nz, float2* spec, const void* table, const float* infl,
+                          const float* gbound, int with_energy, double* energy, int n_eblk, int mode);
+
 struct pme_state {
     int n[4] = {0, 0, 0, 0};           // mesh dimensions; n[3] = nz / 2 (length of the packed real-to-complex z transform)
     int R = 0;
@@ -37,6 +41,7 @@ struct pme_state {
     float* d_bmod[3] = {nullptr, nullptr, nullptr};  // |b(m)|^-2 ... stored as B-spline moduli squared inverse
     int nrad[4] = {0, 0, 0, 0}; int radix[4][8];
     int xs_sw = 0;                      // y-slab width of pme_x_fused_kernel (planes that do not fit the LDS)
+    float* d_gmax = nullptr;           // [R][nz/2+1] largest influence value of a plane (a-priori scale of the matrix-core XY pass)
     float* d_infl = nullptr; int infl_version = -1;   // influence function [R][nz/2+1][nx][ny], rebuilt when a box changes
     bool z_half = false;               // nz even: z transforms run as nz/2-point complex FFTs of packed real pairs
     double* d_energy = nullptr;        // [R][n_eblk]
@@ -44,6 +49,7 @@ struct pme_state {
     fft_sched sch_x, sch_y, sch_z;     // butterfly schedules of the in-place passes (xy planes; z lines for (sch_nl, sch_zt))
     uint2* d_sched[3] = {nullptr, nullptr, nullptr};
     int sch_nl = 0, sch_zt = 0;
+    void* d_dftmm = nullptr; bool xy_mfma = false;    // matrix-core XY pass (dft_mfma.hip): LDS image of the DFT matrix
     bool gather_fused = false;         // the inverse z launch already added the forces (pme_zinv_gather_kernel)
 };
 
@@ -270,8 +276,12 @@ __device__ __forceinline__ void pme_scaled(const float4 x, const float* __restri
 // charges are accumulated as integers.
 __global__ __launch_bounds__(1024)
 void pme_bin_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __restrict__ pos, const float* __restrict__ box,
-                    int* __restrict__ bin_start /*[R][nx+1]*/, int* __restrict__ bin_atoms /*[R][Npad]*/)
+                    int* __restrict__ bin_start /*[R][nx+1]*/, int* __restrict__ bin_atoms /*[R][Npad]*/,
+                    unsigned int* fork_flag, unsigned int fork_seq)
 {
+    // this launch sits directly behind the integrator on the main stream: its start publishes "positions are final" to the
+    // direct-space kernels polling on the second stream (remd_ctx::d_sync)
+    if (fork_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(fork_flag, fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     __shared__ int s_cnt[257], s_start[257], s_cur[256];
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -585,8 +595,11 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
 // recomputed (~45 VALU instructions per mesh point incl. an IEEE division and an exp) in every XY pass.
 __global__ __launch_bounds__(256)
 void pme_influence_table_kernel(int nx, int ny, int nz, const float* __restrict__ bmx, const float* __restrict__ bmy,
-                                const float* __restrict__ bmz, const float* __restrict__ box, float alpha, float* __restrict__ infl)
+                                const float* __restrict__ bmz, const float* __restrict__ box, float alpha, float* __restrict__ infl,
+                                float* __restrict__ gmax /* [R][nzc] largest value of each plane, or NULL */)
 {
+    __shared__ float s_gm[4];
+    float gm = 0.f;
     const int kz = blockIdx.x, r = blockIdx.y, nzc = nz / 2 + 1, np = nx * ny;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const double V = (double)Lx * Ly * Lz;
@@ -603,6 +616,13 @@ void pme_influence_table_kernel(int nx, int ny, int nz, const float* __restrict_
         float g = 0.f;
         if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
         G[idx] = g;
+        gm = fmaxf(gm, g);
+    }
+    if (gmax) {
+        for (int off = 32; off > 0; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off));
+        if ((threadIdx.x & 63) == 0) s_gm[threadIdx.x >> 6] = gm;
+        __syncthreads();
+        if (threadIdx.x == 0) gmax[(size_t)r * nzc + kz] = fmaxf(fmaxf(s_gm[0], s_gm[1]), fmaxf(s_gm[2], s_gm[3]));
     }
 }
 
@@ -886,6 +906,8 @@ int remd_pme_destroy(remd_ctx* h)
     for (int k = 0; k < 3; ++k) if (s->d_bmod[k]) hipFree(s->d_bmod[k]);
     if (s->d_energy) hipFree(s->d_energy);
     if (s->d_infl) hipFree(s->d_infl);
+    if (s->d_dftmm) hipFree(s->d_dftmm);
+    if (s->d_gmax) hipFree(s->d_gmax);
     for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
     delete s;
     h->pme = nullptr;
@@ -1065,6 +1087,12 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
             REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_x_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         }
     }
+    // square planes up to 80 x 80: the XY pass as matrix products on the MFMA pipes (dft_mfma.hip), REMD_PME_XY_MFMA=1.
+    // Opt-in: parity-green and as accurate as the FFT, but 89 us stand-alone against the FFT kernel's 67 (its 154 KB of LDS
+    // allow one workgroup per CU, so the 80 MB of plane traffic are not overlapped with the products)
+    s->xy_mfma = !full_complex && s->n[0] == s->n[1] && s->n[0] <= 80 && s->xy_fused
+                 && getenv("REMD_PME_XY_MFMA") && atoi(getenv("REMD_PME_XY_MFMA")) != 0;
+    if (s->xy_mfma) { int rc = remd_dftmm_build_table(h, s->n[0], &s->d_dftmm); if (rc) return rc; }
     if (s->xy_fused && !full_complex) {
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
         const int PS = s->n[1] | 1;
@@ -1108,7 +1136,8 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
     {
         remd_prof_scope ps(h, "pme_bin", st);
         hipLaunchKernelGGL(pme_bin_kernel, dim3(h->R), dim3(1024), 0, st, h->N, h->Npad, nx, ny, nz, h->d_pos, h->d_box,
-                           s->d_col_start, s->d_col_atoms);
+                           s->d_col_start, s->d_col_atoms, h->fork_seq_pending ? h->d_sync : (unsigned int*)nullptr, h->fork_seq_pending);
+        h->fork_seq_pending = 0;
     }
     {
         remd_prof_scope ps(h, "pme_fft", st);
@@ -1137,13 +1166,18 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
                    s->d_tw[2], s->d_tw[3]);
         if (s->xy_fused || s->xs_sw > 0) {
             if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
+            if (!s->d_gmax) REMD_CHECK(h, hipMalloc(&s->d_gmax, sizeof(float) * s->nzc * s->R));
             if (s->infl_version != h->box_version) {
                 hipLaunchKernelGGL(pme_influence_table_kernel, dim3(s->nzc, s->R), dim3(256), 0, st, nx, ny, nz, s->d_bmod[0], s->d_bmod[1],
-                                   s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl);
+                                   s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl, s->d_gmax);
                 s->infl_version = h->box_version;
             }
         }
-        if (s->xy_fused) {
+        if (s->xy_mfma) {
+            remd_prof_scope pxy(h, "pme_xy", st);
+            remd_dftmm_launch_xy(st, nx, s->nzc * s->R, s->nzc, nz, s->d_grid, s->d_dftmm, s->d_infl, s->d_gmax, with_energy ? 1 : 0, s->d_energy,
+                                 s->n_eblk, 0);
+        } else if (s->xy_fused) {
             remd_prof_scope pxy(h, "pme_xy", st);
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,

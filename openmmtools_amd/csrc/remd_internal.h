@@ -136,6 +136,11 @@ struct remd_ctx {
     // ---- timing / profiling -------------------------------------------------------------
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream: the PME reciprocal pipeline (LDS / latency bound) overlaps the direct-space kernels (VALU bound)
+    // fork / join of the two streams by flags in device memory ([0] fork, [1] join, [2] a spin ran out): the first mesh kernel
+    // publishes the fork, a one-wavefront kernel at the head of the second stream waits for it, and the mirror image at the
+    // join -- an event record / wait costs ~6 us of command-processor latency on the critical path, twice per step.
+    // REMD_SYNC_EVENTS=1 (and graph capture, which needs events to see the second stream) keep the events.
+    unsigned int* d_sync = nullptr; unsigned int sync_seq = 0; unsigned int fork_seq_pending = 0; bool sync_events = false, capturing = false;
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true; bool pme_concurrent = false;
     double t_prop = 0, t_energy = 0, t_mix = 0;
     int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes
