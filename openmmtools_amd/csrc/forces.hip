@@ -117,6 +117,12 @@ __global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+void remd_launch_join_wait(remd_ctx* h)      // a deferred join nobody consumed: wait for it now
+{
+    if (!h->join_deferred) return;
+    hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->join_deferred, h->d_sync + 2);
+    h->join_deferred = 0;
+}
 __global__ void remd_signal_kernel(unsigned int* flag, unsigned int seq)
 {
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -2105,7 +2111,8 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
                 if (swapped && !h->sync_events && !h->capturing) {
                     hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
                     std::swap(h->stream, h->stream2); swapped = false;
-                    hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq, h->d_sync + 2);
+                    if (h->defer_join_ok && !with_energy) h->join_deferred = h->sync_seq;
+                    else hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq, h->d_sync + 2);
                 } else {
                     if (swapped) { hipEventRecord(h->ev_join, h->stream); std::swap(h->stream, h->stream2); swapped = false; }
                     hipStreamWaitEvent(h->stream, h->ev_join, 0);

@@ -326,8 +326,20 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             long long* force, const float* __restrict__ invmass,
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
-                            const long long* __restrict__ ctr)
+                            const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq)
 {
+    if (join_flag) {
+        // the forces of the direct-space stream: poll its "done" flag here instead of behind a cross-stream event (remd_ctx::d_sync)
+        if (threadIdx.x == 0) {
+            long long n = 0;
+            while ((int)(__hip_atomic_load(join_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++n > (1ll << 25)) { atomicExch(join_flag + 1, 1u); break; }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     float3 mom = f3(0, 0, 0);
@@ -553,7 +565,9 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
     hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
-                       (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr);
+                       (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr,
+                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred);
+    h->join_deferred = 0;
 }
 
 __global__ void ctr_set_kernel(long long* ctr, long long gstep, long long body) { ctr[0] = gstep; ctr[1] = body; }
@@ -570,6 +584,7 @@ __global__ void ctr_tick_kernel(long long* ctr) { ctr[0] += 1; ctr[1] += 1; }
 // the atoms are re-sorted, the barostat fires or kernels are being timed run eagerly.  Results are bit-identical either
 // way (same kernels, same arguments, integer accumulation).  Opt-in with REMD_GRAPH=1 (see below: no gain measured).
 int remd_nb_resort_due(remd_ctx* h);
+void remd_launch_join_wait(remd_ctx* h);
 void remd_nb_note_evaluation(remd_ctx* h);
 
 int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
@@ -648,7 +663,9 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                 flush(false);
                 h->force_zeroed = zeroed_by_chain;
                 zeroed_by_chain = false;
+                h->defer_join_ok = true;            // the next main-stream launch is the chain holding this V
                 int rc = remd_compute_forces(h, false);
+                h->defer_join_ok = false;
                 if (rc) return rc;
             }
             push(tok, tok == 'O' ? oidx : 0, gstep);
@@ -666,6 +683,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     for (int s = 0; s < n_steps; ++s, ++body) {
         bool done = false;
         if (graph_ok && s >= first_graph_body && !remd_nb_resort_due(h)) {
+            remd_launch_join_wait(h);          // an eager body's deferred join: the graph's first chain does not poll for it
             if (h->step_graph_exec && h->step_graph_key == key) {
                 // replay: one launch; then advance the host-side state exactly as the captured body did
                 REMD_CHECK(h, hipGraphLaunch(h->step_graph_exec, h->stream));
@@ -699,6 +717,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         if (!done) { int rc = run_body(s); if (rc) return rc; }
     }
     flush(false);
+    remd_launch_join_wait(h);
     h->force_zeroed = zeroed_by_chain;
     REMD_CHECK(h, hipGetLastError());
     return 0;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
 #include <string>
 #include <mutex>
 #include <map>
@@ -141,10 +143,15 @@ struct remd_ctx {
     // join -- an event record / wait costs ~6 us of command-processor latency on the critical path, twice per step.
     // REMD_SYNC_EVENTS=1 (and graph capture, which needs events to see the second stream) keep the events.
     unsigned int* d_sync = nullptr; unsigned int sync_seq = 0; unsigned int fork_seq_pending = 0; bool sync_events = false, capturing = false;
+    // remd_run_steps: the launch that follows a force evaluation on the main stream is always an integrator chain, so the
+    // join is polled in that kernel's prologue (join_deferred = sequence number to wait for) instead of a kernel of its own
+    bool defer_join_ok = false; unsigned int join_deferred = 0;
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true; bool pme_concurrent = false;
     double t_prop = 0, t_energy = 0, t_mix = 0;
     int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes
     std::string prof_filter = "nonbonded";
+    int prof_every = getenv("REMD_PROF_EVERY") ? std::max(1, atoi(getenv("REMD_PROF_EVERY"))) : 16;   // level 1: sample every n-th launch of a class
+    std::map<const char*, long> prof_seen;
     struct pending_t { std::string name; hipEvent_t a, b; };
     std::vector<pending_t> prof_pending;
     std::map<std::string, remd_profile_entry> prof;
@@ -183,6 +190,9 @@ struct remd_prof_scope {
                 on = e > b && nm.compare(0, e - b, f, b, e - b) == 0;
                 b = e + 1;
             }
+            // sampled: every prof_every-th launch of a class (an event pair costs host time and, on the main stream, ~12 us of
+            // command-processor latency on the critical path of a step: timing every launch slows what it measures)
+            if (on) on = (h->prof_seen[n]++ % h->prof_every) == 0;
         }
         if (on) { hipEventCreate(&a); hipEventRecord(a, st); }
     }
