@@ -12,6 +12,7 @@ int remd_nb_required_epart(remd_ctx* h);
 void remd_free_nonbonded(remd_ctx* h);
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
 int remd_test_xy_mfma_impl(remd_ctx* h, int n, int nplanes, float* data, int mode);
+void remd_nb_tune_resolve(remd_ctx* h);
 void remd_free_constraints(remd_ctx* h);
 
 static std::mutex g_err_mutex;
@@ -302,6 +303,7 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         unsigned int spin_out = 0;
         REMD_CHECK(h, hipMemcpyAsync(&spin_out, h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
         REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        remd_nb_tune_resolve(h);
         if (spin_out) return remd_fail(h, -2, "remd_propagate: a cross-stream wait on the device ran out (fork / join flag never arrived)");
         if (time_enqueue) {
             // diagnostic: host time spent enqueueing the MD steps vs the time until the device finished them

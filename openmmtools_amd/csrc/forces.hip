@@ -101,6 +101,14 @@ struct nb_tables {
     unsigned int* d_lj_sci_list = nullptr; int* d_lj_sci_count = nullptr; unsigned long long* d_lj_excl = nullptr; int lj_excl_W = 0;
     int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 20; bool sorting = true;
     std::vector<float> rep_lam_host;      // what d_rep_lam holds
+    unsigned int* d_queue = nullptr;      // item queues of the resident-workgroup pair kernel: [0] Coulomb, [1] LJ, [2] workgroups done
+    // How many workgroups of the pair kernel stay resident next to the mesh kernels (0 = one per item) is a balance between
+    // the two streams that depends on the system (24 x alanine dipeptide: 2 per CU is 4 % faster than one per item, 8 x
+    // host-guest: 7 % slower), so it is measured: during the first long remd_run_steps the candidates take turns over
+    // segments of TUNE_SEG real MD steps timed with events; results are bit-identical under every choice (fixed-point sums).
+    struct tune_seg { int cand; hipEvent_t a, b; };
+    std::vector<tune_seg> tune_segs; int tune_state = 0 /* 0 measuring, 1 awaiting resolve, 2 done */, tune_left = 0, tune_next = 0;
+    int nb_grid = 0;                      // current choice (workgroups; 0 = one per item)
     float sort_cell = getenv("REMD_NB_CELL") ? (float)atof(getenv("REMD_NB_CELL")) : 0.45f;   // Morton cell edge (nm) of the molecule sort
 };
 static handle_table<nb_tables> g_nb;
@@ -1129,11 +1137,39 @@ void nonbonded_sci_kernel(nb_params p, sci_args a, const float* __restrict__ box
 template <int METHOD_A, int METHOD_B, bool ENERGY, bool ALCH, int NW>
 __global__ __launch_bounds__(64 * NW)
 __attribute__((amdgpu_waves_per_eu((SCI_RELAXED(METHOD_A) || SCI_RELAXED(METHOD_B)) ? 2 : 4, (SCI_RELAXED(METHOD_A) || SCI_RELAXED(METHOD_B)) ? 3 : 4)))
-void nonbonded_sci2_kernel(nb_params p, sci_args a, sci_args b, int n_items_a, const float* __restrict__ box,
+void nonbonded_sci2_kernel(nb_params p, sci_args a, sci_args b, int n_items_a, int n_items, unsigned int* queue, const float* __restrict__ box,
                            const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R)
 {
-    if ((int)blockIdx.x < n_items_a) nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R);
-    else nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW>(p, b, blockIdx.x - n_items_a, box, rep_lam, epart, n_epart, R);
+    if (!queue) {
+        if ((int)blockIdx.x < n_items_a) nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R);
+        else nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW>(p, b, blockIdx.x - n_items_a, box, rep_lam, epart, n_epart, R);
+        return;
+    }
+    // gridDim.x < n_items: a resident set of workgroups pulls items from two queues (Coulomb items first, then the short LJ
+    // items).  The grid size bounds the share of a CU's wave slots and registers this kernel holds while the mesh kernels of
+    // the other stream want them: with one workgroup per item the XY pass got 30 % of its work done next to this kernel and
+    // needed a 47 us tail of its own.  Forces are fixed-point sums and energy partials are per item, so the order in which
+    // items are pulled does not change a bit of the result.
+    __shared__ int s_item;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = (int)atomicAdd(&queue[0], 1u);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= n_items_a) break;
+        nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW>(p, a, item, box, rep_lam, epart, n_epart, R);
+        __syncthreads();                 // s_item and the merge buffer are reused
+    }
+    __syncthreads();
+    for (;;) {
+        if (threadIdx.x == 0) s_item = (int)atomicAdd(&queue[1], 1u);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= n_items - n_items_a) break;
+        nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW>(p, b, item, box, rep_lam, epart, n_epart, R);
+        __syncthreads();
+    }
+    // the last workgroup to leave rewinds the queues for the next launch (everybody has seen them run dry by then)
+    if (threadIdx.x == 0 && atomicAdd(&queue[2], 1u) == gridDim.x - 1) { queue[0] = 0u; queue[1] = 0u; queue[2] = 0u; }
 }
 
 // Workgroup = 4 wavefronts = 4 consecutive i tiles of one replica sharing one stream of j atoms: the j
@@ -1430,7 +1466,8 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
     dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
-    dfree(t.d_sforce); dfree(t.d_lj_sforce);
+    dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue);
+    for (auto& sg : t.tune_segs) { if (sg.a) hipEventDestroy(sg.a); if (sg.b) hipEventDestroy(sg.b); }
     g_nb.erase(h);
 }
 
@@ -1751,6 +1788,10 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
             REMD_CHECK(h, hipMalloc(&t.d_excl, sizeof(unsigned long long) * (size_t)h->R * ncl * t.excl_W));
             REMD_CHECK(h, hipMalloc(&t.d_sforce, sizeof(long long) * n * 3));
             REMD_CHECK(h, hipMemsetAsync(t.d_sforce, 0, sizeof(long long) * n * 3, h->stream));
+            if (!t.d_queue) {
+                REMD_CHECK(h, hipMalloc(&t.d_queue, 4 * sizeof(unsigned int)));
+                REMD_CHECK(h, hipMemsetAsync(t.d_queue, 0, 4 * sizeof(unsigned int), h->stream));
+            }
         }
         if (t.lj_split) {
             dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask); dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h);
@@ -1881,8 +1922,13 @@ static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
         const int items_a = ntile * h->R * (ssplit / SCI_NW), items_b = split ? (t.NLpad / 64) * h->R * (ssplit / SCI_NW) : 0;
 #define LAUNCH_SCI(M, ALCHF) hipLaunchKernelGGL((nonbonded_sci_kernel<M, ENERGY, ALCHF, SCI_NW>), dim3(items_a), dim3(64 * SCI_NW), 0, h->stream, t.p, sa, \
             h->d_box, rl, h->d_epart, h->n_epart, h->R)
-#define LAUNCH_SCI2(ALCHF) hipLaunchKernelGGL((nonbonded_sci2_kernel<MAIN, NB_LJ_ONLY, ENERGY, ALCHF, SCI_NW>), dim3(items_a + items_b), dim3(64 * SCI_NW), 0, \
-            h->stream, t.p, sa, sb, items_a, h->d_box, rl, h->d_epart, h->n_epart, h->R)
+        static const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
+        const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
+        const int sci2_grid = (h->pme_concurrent && persist_grid > 0) ? std::min(items_a + items_b, persist_grid)
+                            : cap_waves ? std::min(items_a + items_b, ncu * persist) : items_a + items_b;
+#define LAUNCH_SCI2(ALCHF) hipLaunchKernelGGL((nonbonded_sci2_kernel<MAIN, NB_LJ_ONLY, ENERGY, ALCHF, SCI_NW>), dim3(sci2_grid), dim3(64 * SCI_NW), 0, \
+            h->stream, t.p, sa, sb, items_a, items_a + items_b, sci2_grid < items_a + items_b ? t.d_queue : (unsigned int*)nullptr, h->d_box, rl, \
+            h->d_epart, h->n_epart, h->R)
         if (sci && split && phase == 3) {
             // one launch for both systems, one scatter for both sorted accumulators
             if (t.has_alch) LAUNCH_SCI2(true); else LAUNCH_SCI2(false);
@@ -1966,6 +2012,57 @@ int remd_nb_resort_due(remd_ctx* h)
     nb_tables* t = g_nb.find(h);
     if (!t || h->nb_method == REMD_NB_NONE || !t->sorting || t->n_groups <= 0 || t->n_groups >= 8192) return 0;
     return (t->sort_R != h->R || t->evals_since_sort >= t->resort_interval) ? 1 : 0;
+}
+#define TUNE_SEG 40                       // two re-sorts per segment
+static const int g_tune_cands[4] = {0, 3 * 256, 5 * 128, 2 * 256};      // workgroups: one per item, 3 / 2.5 / 2 per CU (256 CUs)
+// called at the top of every eagerly launched MD step of remd_run_steps
+void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call)
+{
+    nb_tables* tp = g_nb.find(h);
+    if (!tp || h->nb_method == REMD_NB_NONE) return;
+    nb_tables& t = *tp;
+    static const bool fixed = getenv("REMD_NB_PERSIST_GRID") || getenv("REMD_NB_PERSIST");
+    if (fixed || t.tune_state != 0 || !h->pme_concurrent || h->profiling == 2) return;
+    if (t.tune_left == 0) {
+        hipEvent_t boundary = nullptr;
+        if (!t.tune_segs.empty() && !t.tune_segs.back().b) {            // close the open segment
+            hipEventCreate(&boundary); hipEventRecord(boundary, h->stream);
+            t.tune_segs.back().b = boundary;
+        }
+        if (t.tune_next == 8) { t.tune_state = 1; t.nb_grid = 0; return; }      // two rounds of four candidates measured
+        if (steps_left_in_call < TUNE_SEG) { t.nb_grid = 0; return; }           // resume in a later call
+        nb_tables::tune_seg sg{g_tune_cands[t.tune_next & 3], nullptr, nullptr};
+        hipEventCreate(&sg.a); hipEventRecord(sg.a, h->stream);                // (each segment owns its pair of events)
+        t.tune_segs.push_back(sg);
+        t.nb_grid = sg.cand;
+        t.tune_next++;
+        t.tune_left = TUNE_SEG;
+    }
+    t.tune_left--;
+}
+// after the stream has been synchronised: pick the fastest candidate
+void remd_nb_tune_resolve(remd_ctx* h)
+{
+    nb_tables* tp = g_nb.find(h);
+    if (!tp || tp->tune_state != 1) return;
+    nb_tables& t = *tp;
+    double ms[4] = {0, 0, 0, 0};
+    bool ok = true;
+    for (auto& sg : t.tune_segs) {
+        float e = 0.f;
+        if (!sg.a || !sg.b || hipEventElapsedTime(&e, sg.a, sg.b) != hipSuccess) { ok = false; (void)hipGetLastError(); }
+        for (int c = 0; c < 4; ++c) if (g_tune_cands[c] == sg.cand) ms[c] += e;
+        if (sg.a) hipEventDestroy(sg.a);
+        if (sg.b) hipEventDestroy(sg.b);
+    }
+    t.tune_segs.clear();
+    int best = 0;
+    for (int c = 1; c < 4; ++c) if (ok && ms[c] < ms[best] * 0.995) best = c;     // ties go to the simpler launch
+    t.nb_grid = ok ? g_tune_cands[best] : 0;
+    t.tune_state = 2;
+    if (getenv("REMD_NB_TUNE_VERBOSE"))
+        fprintf(stderr, "[remd] pair-kernel residency: one per item %.2f ms, 3/CU %.2f, 2.5/CU %.2f, 2/CU %.2f per %d steps -> %d workgroups\n",
+                ms[0], ms[1], ms[2], ms[3], 2 * TUNE_SEG, t.nb_grid);
 }
 void remd_nb_note_evaluation(remd_ctx* h)
 {

@@ -585,6 +585,7 @@ __global__ void ctr_tick_kernel(long long* ctr) { ctr[0] += 1; ctr[1] += 1; }
 // way (same kernels, same arguments, integer accumulation).  Opt-in with REMD_GRAPH=1 (see below: no gain measured).
 int remd_nb_resort_due(remd_ctx* h);
 void remd_launch_join_wait(remd_ctx* h);
+void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call);
 void remd_nb_note_evaluation(remd_ctx* h);
 
 int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
@@ -714,7 +715,10 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                 done = true;
             }
         }
-        if (!done) { int rc = run_body(s); if (rc) return rc; }
+        if (!done) {
+            if (!graph_ok) remd_nb_tune_step(h, n_steps - s);
+            int rc = run_body(s); if (rc) return rc;
+        }
     }
     flush(false);
     remd_launch_join_wait(h);

@@ -266,6 +266,24 @@ def test_alanine_propagation_is_bit_reproducible(hip_engine_factory):
     assert np.array_equal(out[0][2], out[1][2])
 
 
+def test_resident_pair_workgroups_do_not_change_a_bit(hip_engine_factory, monkeypatch):
+    """The pair kernel either launches one workgroup per work item or keeps a resident set that pulls items from a queue
+    (REMD_NB_PERSIST_GRID, chosen by timing at run time): forces are fixed-point sums, so positions and velocities after a
+    propagation are bit-identical under every choice, and so are the forces themselves."""
+    al = ts.AlanineDipeptideExplicit()
+    out = []
+    for grid in ('0', '96', '512'):
+        monkeypatch.setenv('REMD_NB_PERSIST_GRID', grid)
+        eng = hip_engine_factory()
+        _engine_for(eng, al.system, al.positions, R=3, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=25)
+        f = eng.get_forces()
+        eng.propagate(0)
+        x, v = eng.get_replicas()[:2]
+        out.append((f, x, v))
+    for f, x, v in out[1:]:
+        assert np.array_equal(f, out[0][0]) and np.array_equal(x, out[0][1]) and np.array_equal(v, out[0][2])
+
+
 @pytest.mark.parametrize('system_cls', [ts.AlanineDipeptideExplicit, ts.HostGuestExplicit])
 def test_newton3_lists_match_full_lists(hip_engine_factory, monkeypatch, system_cls):
     """The direct-space sum runs on per-tile union lists with every cluster pair listed once (Newton's third law, sci
