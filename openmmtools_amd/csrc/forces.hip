@@ -109,6 +109,7 @@ struct nb_tables {
     struct tune_seg { int cand; hipEvent_t a, b; };
     std::vector<tune_seg> tune_segs; int tune_state = 0 /* 0 measuring, 1 awaiting resolve, 2 done */, tune_left = 0, tune_next = 0;
     int nb_grid = 0;                      // current choice (workgroups; 0 = one per item)
+    bool defer_scatter = false, scatter_pending = false;   // the caller launches direct_tail_kernel instead of the scatter
     float sort_cell = getenv("REMD_NB_CELL") ? (float)atof(getenv("REMD_NB_CELL")) : 0.45f;   // Morton cell edge (nm) of the molecule sort
 };
 static handle_table<nb_tables> g_nb;
@@ -295,12 +296,10 @@ struct listed_tables {
     float alpha, two_alpha_sqrtpi;
 };
 
-__global__ __launch_bounds__(256)
-void listed_forces_kernel(listed_tables T, int Npad, const float4* __restrict__ pos, const float* __restrict__ box,
-                          long long* __restrict__ force)
+__device__ __forceinline__
+void listed_forces_body(const listed_tables& T, int Npad, const float4* __restrict__ pos, const float* __restrict__ box,
+                        long long* __restrict__ force, int t, int r)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
     const float4* P = pos + (size_t)r * Npad;
     long long* F = force + (size_t)r * 3 * Npad;
     if (t < T.n_bonds) {
@@ -384,6 +383,13 @@ void listed_forces_kernel(listed_tables T, int Npad, const float4* __restrict__ 
         add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
         add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
     }
+}
+
+__global__ __launch_bounds__(256)
+void listed_forces_kernel(listed_tables T, int Npad, const float4* __restrict__ pos, const float* __restrict__ box,
+                          long long* __restrict__ force)
+{
+    listed_forces_body(T, Npad, pos, box, force, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
 
 // ---- nonbonded pair arithmetic -------------------------------------------------------------------
@@ -816,13 +822,11 @@ void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, co
 
 // sorted-slot force accumulator -> per-atom accumulator (integer atomics: the PME gather may be adding on the other
 // stream); the slot is cleared for the next evaluation
-__global__ __launch_bounds__(256)
-void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, long long* __restrict__ sforce_a,
-                                  int Npad_b, const int* __restrict__ order_b, long long* __restrict__ sforce_b,
-                                  long long* __restrict__ force, int Npad_force)
+__device__ __forceinline__
+void scatter_sorted_forces_body(int Npad_a, const int* __restrict__ order_a, long long* __restrict__ sforce_a,
+                                int Npad_b, const int* __restrict__ order_b, long long* __restrict__ sforce_b,
+                                long long* __restrict__ force, int Npad_force, int k, int r)
 {
-    int k = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
     const bool second = k >= Npad_a;                      // main system slots first, then the LJ sub-system's
     if (second) k -= Npad_a;
     const int Npad_s = second ? Npad_b : Npad_a;
@@ -834,6 +838,41 @@ void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, l
     for (int c = 0; c < 3; ++c) {
         const long long v = S[(size_t)c * Npad_s + k];
         if (v != 0) { S[(size_t)c * Npad_s + k] = 0; if (o >= 0) atomicAdd(&U[(size_t)c * Npad_force + o], (unsigned long long)v); }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, long long* __restrict__ sforce_a,
+                                  int Npad_b, const int* __restrict__ order_b, long long* __restrict__ sforce_b,
+                                  long long* __restrict__ force, int Npad_force)
+{
+    scatter_sorted_forces_body(Npad_a, order_a, sforce_a, Npad_b, order_b, sforce_b, force, Npad_force, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+}
+
+// the tail of the direct-space stream of a force-only evaluation in ONE launch: sorted-slot scatter (blocks < n_scatter),
+// every listed term (the rest), and -- by the last block to finish -- the "direct-space forces are complete" flag the
+// integrator on the main stream polls (remd_ctx::d_sync).  Three dependent launches of ~6 us each otherwise.
+struct scatter_args { int Npad_a; const int* order_a; long long* sforce_a; int Npad_b; const int* order_b; long long* sforce_b; };
+__global__ __launch_bounds__(256)
+void direct_tail_kernel(scatter_args sc, int n_scatter, listed_tables T, int Npad, const float4* __restrict__ pos,
+                        const float* __restrict__ box, long long* __restrict__ force, unsigned int* join_flag, unsigned int join_seq,
+                        unsigned int* done)
+{
+    if ((int)blockIdx.x < n_scatter)
+        scatter_sorted_forces_body(sc.Npad_a, sc.order_a, sc.sforce_a, sc.Npad_b, sc.order_b, sc.sforce_b, force, Npad,
+                                   blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+    else
+        listed_forces_body(T, Npad, pos, box, force, (blockIdx.x - n_scatter) * 256 + threadIdx.x, blockIdx.y);
+    if (join_flag) {
+        // the block's force atomics (device scope: performed at the coherence point) are acknowledged at the barrier's
+        // s_waitcnt; a __threadfence() per block (L2 write-back + invalidate, ~3.5 us each) would cost more than the launches saved
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1) {
+                *done = 0u;
+                __hip_atomic_store(join_flag, join_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -1932,6 +1971,7 @@ static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
         if (sci && split && phase == 3) {
             // one launch for both systems, one scatter for both sorted accumulators
             if (t.has_alch) LAUNCH_SCI2(true); else LAUNCH_SCI2(false);
+            if (t.defer_scatter) { t.scatter_pending = true; return; }
             hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
                                t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
             return;
@@ -2139,6 +2179,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
     // listed terms BEHIND the pair kernel (REMD_LISTED_LATE=0: in front): the pair kernel then starts 20 us earlier and shares
     // the spreading pass's idle vector units instead of fighting the XY pass for them (118.9 -> 116.8 ms per 500 steps)
     static const bool listed_late = !(getenv("REMD_LISTED_LATE") && atoi(getenv("REMD_LISTED_LATE")) == 0);
+    bool join_signalled = false;
     auto launch_listed = [&]() {
     {
         listed_tables T{};
@@ -2155,7 +2196,17 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
             T.exc_alch = t.d_exc_alch; T.excl_alch = t.d_excl_alch; T.rep_lam = t.has_alch ? t.d_rep_lam : nullptr;
         }
         const int total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
-        if (total > 0) {
+        if (it && it->scatter_pending) {
+            nb_tables& t = *it;
+            t.scatter_pending = false;
+            const int n_scatter = (h->Npad + t.NLpad + 255) / 256;
+            const bool sig = swapped && !h->sync_events && !h->capturing;       // this launch is the last of the direct-space stream
+            remd_prof_scope ps(h, "bonded");
+            hipLaunchKernelGGL(direct_tail_kernel, dim3(n_scatter + (total + 255) / 256, R), dim3(256), 0, h->stream,
+                               scatter_args{h->Npad, t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce}, n_scatter, T, h->Npad, h->d_pos,
+                               h->d_box, h->d_force, sig ? h->d_sync + 1 : (unsigned int*)nullptr, h->sync_seq, t.d_queue + 3);
+            join_signalled = sig;
+        } else if (total > 0) {
             remd_prof_scope ps(h, "bonded");
             hipLaunchKernelGGL(listed_forces_kernel, dim3((total + 255) / 256, R), dim3(256), 0, h->stream, T, h->Npad, h->d_pos,
                                h->d_box, h->d_force);
@@ -2184,6 +2235,11 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         if (rc) return rc;
         const int phase = main_launched ? 2 : 3;
         if ((rc = ensure_sorted(h, t, phase))) return rc;
+        // REMD_TAIL_FUSE=1: scatter + listed terms + join flag in one launch.  Measured: worth 1 ms per 500 steps when the direct-space
+        // stream is the longer branch (pair kernel at < 2 workgroups per CU), nothing at the tuned balance (111.3 vs 110.9 ms): opt-in
+        static const bool tail_fuse = getenv("REMD_TAIL_FUSE") && atoi(getenv("REMD_TAIL_FUSE")) != 0;
+        t.defer_scatter = tail_fuse && merged && listed_late && phase == 3;       // the scatter rides in the listed-terms launch
+        t.scatter_pending = false;
         {
             remd_prof_scope ps(h, phase == 2 ? "nonbonded_lj" : "nonbonded");
             if (with_energy) {
@@ -2213,7 +2269,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
             if (pme_forked) {                                                   // join
                 const bool gather_pending = swapped;
                 if (swapped && !h->sync_events && !h->capturing) {
-                    hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
+                    if (!join_signalled) hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
                     std::swap(h->stream, h->stream2); swapped = false;
                     if (h->defer_join_ok && !with_energy) h->join_deferred = h->sync_seq;
                     else hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq, h->d_sync + 2);

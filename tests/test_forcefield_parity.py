@@ -272,8 +272,9 @@ def test_resident_pair_workgroups_do_not_change_a_bit(hip_engine_factory, monkey
     propagation are bit-identical under every choice, and so are the forces themselves."""
     al = ts.AlanineDipeptideExplicit()
     out = []
-    for grid in ('0', '96', '512'):
+    for grid, fuse in (('0', '0'), ('96', '0'), ('512', '1'), ('0', '1')):
         monkeypatch.setenv('REMD_NB_PERSIST_GRID', grid)
+        monkeypatch.setenv('REMD_TAIL_FUSE', fuse)       # scatter + listed terms + join flag in one launch
         eng = hip_engine_factory()
         _engine_for(eng, al.system, al.positions, R=3, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=25)
         f = eng.get_forces()
