@@ -99,7 +99,7 @@ struct nb_tables {
     unsigned int* d_sci_list = nullptr; int* d_sci_count = nullptr; unsigned long long* d_excl = nullptr; int excl_W = 0;
     long long* d_sforce = nullptr; long long* d_lj_sforce = nullptr;   // [R][3][Npad] / [R][3][NLpad] forces in sorted slot space
     unsigned int* d_lj_sci_list = nullptr; int* d_lj_sci_count = nullptr; unsigned long long* d_lj_excl = nullptr; int lj_excl_W = 0;
-    int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 20; bool sorting = true;
+    int sort_R = 0; int evals_since_sort = 1 << 30; int resort_interval = 40; bool sorting = true;
     std::vector<float> rep_lam_host;      // what d_rep_lam holds
     unsigned int* d_queue = nullptr;      // item queues of the resident-workgroup pair kernel: [0] Coulomb, [1] LJ, [2] workgroups done
     // How many workgroups of the pair kernel stay resident next to the mesh kernels (0 = one per item) is a balance between
@@ -2053,7 +2053,7 @@ int remd_nb_resort_due(remd_ctx* h)
     if (!t || h->nb_method == REMD_NB_NONE || !t->sorting || t->n_groups <= 0 || t->n_groups >= 8192) return 0;
     return (t->sort_R != h->R || t->evals_since_sort >= t->resort_interval) ? 1 : 0;
 }
-#define TUNE_SEG 40                       // two re-sorts per segment
+#define TUNE_SEG 40                       // one re-sort of the spatial order per segment (resort_interval)
 static const int g_tune_cands[4] = {0, 3 * 256, 5 * 128, 2 * 256};      // workgroups: one per item, 3 / 2.5 / 2 per CU (256 CUs)
 // called at the top of every eagerly launched MD step of remd_run_steps
 void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call)
