@@ -207,7 +207,9 @@ def main():
                            note='fp32 VALU kernel; peak = FP32 vector rate = f32-input MFMA rate (157.3 TFLOP/s); '
                                 'algorithmic work = 10 kflop/atom (SURVEY 8(d)); one launch evaluates the Coulomb system and the LJ '
                                 'sub-system (every pair once: Newton\'s third law on per-tile union lists); the timed scope also '
-                                'holds the 7 us sorted-slot force scatter')
+                                'holds the 7 us sorted-slot force scatter.  The duration is the one next to the mesh kernels of the '
+                                'other stream: the launch keeps a tuned number of workgroups resident (2 per CU here) so that the XY '
+                                'pass is not starved, which stretches this launch and shortens the step (stand-alone: 0.075 ms)')
         if n_xy > 0:
             # algorithmic bytes (SURVEY 8(d) "grid traffic 8 B x G per pass"): the half spectrum [nz/2+1][nx][ny] complex f32 of
             # every replica is read once and written once by the plane-resident XY pass
