@@ -26,7 +26,7 @@ struct fft_sched { const uint2* tab; int off[8]; int wave_local; };   // see fft
 
 int remd_dftmm_build_table(remd_ctx* h, int n, void** d_table);
 void remd_dftmm_launch_xy(hipStream_t st, int n, int nplanes, int nzc, int nz, float2* spec, const void* table, const float* infl,
-                          const float* gbound, int with_energy, double* energy, int n_eblk, int mode);
+                          const float* gbound, int with_energy, double* energy, int n_eblk, int mode, long long* tdbg = nullptr);
 
 struct pme_state {
     int n[4] = {0, 0, 0, 0};           // mesh dimensions; n[3] = nz / 2 (length of the packed real-to-complex z transform)
@@ -1054,7 +1054,10 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         // REMD_PME_WAVELOCAL=1: standalone XY pass 64 -> 60 us (24 x alanine), but no end-to-end gain next to the pair kernels: default off
         const bool try_wl = getenv("REMD_PME_WAVELOCAL") && atoi(getenv("REMD_PME_WAVELOCAL")) != 0;
         for (int pass = try_wl ? 0 : 1; pass < 2 && best_cost < 0; ++pass)       // pass 0: wave-local schedules, 1: global
-            for (int t = 256; t <= 1024; t += 64) {
+            // multiples of 256 threads only: the dispatcher reserves ceil(waves / 4) wave slots on EVERY SIMD for a workgroup
+            // (tools/probes/occupancy_probe.hip), so a 6-wavefront workgroup occupies the slots of 8; next to the pair kernel's
+            // resident workgroups 512 threads beat the 384 that waste the fewest butterfly slots (108.3 vs 110.2 ms per 500 steps)
+            for (int t = 256; t <= 1024; t += 256) {
                 if (np > (long long)XY_PPT * t) continue;
                 long long cost = 0; bool ok = true;
                 for (int ax = 0; ax < 2 && ok; ++ax)
