@@ -304,6 +304,7 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         REMD_CHECK(h, hipMemcpyAsync(&spin_out, h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
         REMD_CHECK(h, hipStreamSynchronize(h->stream));
         remd_nb_tune_resolve(h);
+        if (spin_out == 2) return remd_fail(h, -2, "remd_propagate: more atoms in one PME mesh column than the chain-binned layout holds (REMD_PME_CHAINBIN=0 selects the binning launch)");
         if (spin_out) return remd_fail(h, -2, "remd_propagate: a cross-stream wait on the device ran out (fork / join flag never arrived)");
         if (time_enqueue) {
             // diagnostic: host time spent enqueueing the MD steps vs the time until the device finished them

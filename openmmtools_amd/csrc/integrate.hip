@@ -243,7 +243,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                                           float tol, int Npad, float4* __restrict__ P, float4* __restrict__ V,
                                           const long long* F, long long* Fw, const float* __restrict__ invmass, float kT,
                                           uint32_t rg, uint64_t seed, const long long* __restrict__ cmm_r, float inv_total_mass,
-                                          long long gstep_base)
+                                          long long gstep_base, const remd_chain_bins& bins, int r)
 {
     float3 x[NAT], v[NAT];
     float im[NAT];
@@ -314,6 +314,17 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
         V[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
         mom = mom + v[k] * frcp(im[k]);
         if (prog.zero_force) { Fw[idx[k]] = 0; Fw[Npad + idx[k]] = 0; Fw[2 * Npad + idx[k]] = 0; }
+        if (bins.count) {
+            // these positions are final for the force evaluation that follows: bin the atom by its PME mesh column here, so
+            // that no binning launch sits between the integrator and the spreading pass (the order inside a bin is
+            // irrelevant: charges and forces are fixed-point sums)
+            float u; int kx;
+            remd_pme_scaled1(x[k].x, bins.box[4 * r], bins.nx, u, kx);
+            if (kx >= bins.nx) kx -= bins.nx;
+            const int slot = atomicAdd(&bins.count[(size_t)r * bins.nx + kx], 1);
+            if (slot < bins.cap) bins.atoms[((size_t)r * bins.nx + kx) * bins.cap + slot] = idx[k];
+            else atomicExch(bins.err, 2u);
+        }
     }
     return mom;
 }
@@ -326,7 +337,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             long long* force, const float* __restrict__ invmass,
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
-                            const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq)
+                            const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins)
 {
     if (join_flag) {
         // the forces of the direct-space stream: poll its "done" flag here instead of behind a cross-stream event (remd_ctx::d_sync)
@@ -367,7 +378,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
         const uint32_t rg = (uint32_t)(r_begin + r);
         const long long* cr = cmm + ((size_t)max(cmm_r_eff, 0) * gridDim.y + r) * 4;
-#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, gstep_base)
+#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, gstep_base, bins, r)
         if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
         else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
         else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
@@ -558,16 +569,19 @@ int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& 
     return 0;
 }
 
-static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog)   // prog.use_ctr selects the counter look-up
+remd_chain_bins remd_pme_chain_bins(remd_ctx* h);
+static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog, bool bin_for_pme = false)   // prog.use_ctr selects the counter look-up
 {
+    const remd_chain_bins bins = (bin_for_pme && !h->capturing && prog.use_ctr == 0) ? remd_pme_chain_bins(h) : remd_chain_bins();
     remd_prof_scope ps(h, "integrate_chain");
     dim3 grid((ut.n_units + 255) / 256, h->R);
     hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr,
-                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred);
+                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins);
     h->join_deferred = 0;
+    if (bins.count) h->cbins_ready = true;
 }
 
 __global__ void ctr_set_kernel(long long* ctr, long long gstep, long long body) { ctr[0] = gstep; ctr[1] = body; }
@@ -615,7 +629,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         hipLaunchKernelGGL(ctr_set_kernel, dim3(1), dim3(1), 0, h->stream, h->d_ctr, gstep0, 0ll);
     }
     int body = 0;                      // index of the loop body being enqueued (== ctr[1] when its kernels run)
-    auto flush = [&](bool accumulate) {
+    auto flush = [&](bool accumulate, bool bin_for_pme = false) {      // bin_for_pme: a force evaluation follows this launch directly
         if (cur.n == 0 && !accumulate) return;
         cur.accumulate_momentum = accumulate ? 1 : 0;
         cur.cmm_w = cmm_w;
@@ -629,7 +643,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         chain_prog out = cur;
         out.use_ctr = graph_ok ? 1 : 0;
         if (graph_ok) for (int t = 0; t < out.n; ++t) out.step[t] -= gstep0 + body;    // absolute step -> relative to this body's counter
-        launch_chain(h, ut, out);
+        launch_chain(h, ut, out, bin_for_pme);
         cur = base; cur.n = 0;
     };
     auto push = [&](char tok, int oidx, long long step) {
@@ -661,7 +675,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         int oidx = 0;
         for (char tok : tokens) {
             if (tok == 'V' && !h->forces_valid) {
-                flush(false);
+                flush(false, true);
                 h->force_zeroed = zeroed_by_chain;
                 zeroed_by_chain = false;
                 h->defer_join_ok = true;            // the next main-stream launch is the chain holding this V

@@ -49,6 +49,9 @@ struct pme_state {
     fft_sched sch_x, sch_y, sch_z;     // butterfly schedules of the in-place passes (xy planes; z lines for (sch_nl, sch_zt))
     uint2* d_sched[3] = {nullptr, nullptr, nullptr};
     int sch_nl = 0, sch_zt = 0;
+    // bins filled by the integrator chain's epilogue (no binning launch on the critical path): count[2][R][nx] double buffered by
+    // evaluation parity (the spreading pass zeroes the other one), atoms[R][nx][cbin_cap]; cbin_use: this evaluation reads them
+    int* d_cbin_count = nullptr; int* d_cbin_atoms = nullptr; int cbin_cap = 0, cbin_parity = 0; bool cbin_use = false;
     void* d_dftmm = nullptr; bool xy_mfma = false;    // matrix-core XY pass (dft_mfma.hip): LDS image of the DFT matrix
     bool gather_fused = false;         // the inverse z launch already added the forces (pme_zinv_gather_kernel)
 };
@@ -265,10 +268,41 @@ __device__ __forceinline__ void bspline5(float f, float* w, float* d)
 __device__ __forceinline__ void pme_scaled(const float4 x, const float* __restrict__ box4, int nx, int ny, int nz,
                                            float& ux, float& uy, float& uz, int& kx, int& ky, int& kz)
 {
-    float fx = x.x / box4[0], fy = x.y / box4[1], fz = x.z / box4[2];
-    fx -= floorf(fx); fy -= floorf(fy); fz -= floorf(fz);
-    ux = fx * nx; uy = fy * ny; uz = fz * nz;
-    kx = (int)ux; ky = (int)uy; kz = (int)uz;
+    remd_pme_scaled1(x.x, box4[0], nx, ux, kx);
+    remd_pme_scaled1(x.y, box4[1], ny, uy, ky);
+    remd_pme_scaled1(x.z, box4[2], nz, uz, kz);
+}
+
+// The atoms a mesh row x can receive charge from / give force to: those of the five bins kx = x .. x+4 (mod nx).  Two
+// layouts of the bins: compact (pme_bin_kernel: start[nx+1] + one atom array, the five bins are at most two contiguous
+// runs) or capped (binned by the integrator chain's epilogue: count[nx] + atoms[nx][cap], five runs).
+struct pme_cand { int n[5]; int base[5]; int ntot; };
+__device__ __forceinline__ pme_cand pme_candidates(const int* __restrict__ cs, int x, int nx, int cap)
+{
+    pme_cand c;
+    if (cap > 0) {
+        c.ntot = 0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            int kx = x + b; if (kx >= nx) kx -= nx;
+            c.n[b] = min(cs[kx], cap); c.base[b] = kx * cap; c.ntot += c.n[b];
+        }
+    } else {
+        const int xe = x + 5;
+        const int beg0 = cs[x], end0 = cs[xe <= nx ? xe : nx];
+        const int beg1 = cs[0], end1 = (xe <= nx) ? beg1 : cs[xe - nx];
+        c.n[0] = end0 - beg0; c.base[0] = beg0; c.n[1] = end1 - beg1; c.base[1] = beg1;
+        c.n[2] = c.n[3] = c.n[4] = 0; c.base[2] = c.base[3] = c.base[4] = 0;
+        c.ntot = c.n[0] + c.n[1];
+    }
+    return c;
+}
+__device__ __forceinline__ int pme_cand_atom(const pme_cand& c, const int* __restrict__ ca, int t)
+{
+    int base = c.base[0];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) if (t >= c.n[b]) { t -= c.n[b]; base = c.base[b + 1]; } else break;
+    return ca[base + t];
 }
 
 // bin atoms by their mesh column kx (one workgroup per replica, everything in LDS): the fused spread + z-FFT
@@ -324,7 +358,8 @@ __global__ __launch_bounds__(Z_THREADS)
 void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, int Npad, const float4* __restrict__ pos,
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms,
-                            float2* __restrict__ spec, const float2* tw, const float2* tw_half)
+                            float2* __restrict__ spec, const float2* tw, const float2* tw_half,
+                            int bin_cap, int* __restrict__ zero_count, unsigned int* fork_flag, unsigned int fork_seq)
 {
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -341,19 +376,19 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
     __syncthreads();
-    const int* cs = col_start + (size_t)r * (nx + 1);
-    const int* ca = col_atoms + (size_t)r * Npad;
+    const int* cs = col_start + (size_t)r * (bin_cap > 0 ? nx : nx + 1);
+    const int* ca = col_atoms + (size_t)r * (bin_cap > 0 ? (size_t)nx * bin_cap : (size_t)Npad);
     const float4* P = pos + (size_t)r * Npad;
-    // candidate atoms: mesh column kx in {x .. x+4} (stencil index a = kx - x); the y stencil is tested per atom.  The
-    // columns are consecutive in the binned atom array (two runs when they wrap), so all candidates are taken in ONE
-    // pass: one dependent chain of global loads (bin -> atom -> position) per workgroup instead of five.
+    if (zero_count && blockIdx.x == 0) for (int k = tid; k < nx; k += Z_THREADS) zero_count[(size_t)r * nx + k] = 0;   // the bins of the NEXT evaluation
+    if (fork_flag && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)             // (no binning launch in front: this one publishes the fork)
+        __hip_atomic_store(fork_flag, fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // candidate atoms: mesh column kx in {x .. x+4} (stencil index a = kx - x); the y stencil is tested per atom.  All
+    // candidates are taken in ONE pass: one dependent chain of global loads (bin -> atom -> position) per workgroup.
     {
-        const int xe = x + 5;
-        const int beg0 = cs[x], end0 = cs[xe <= nx ? xe : nx];
-        const int beg1 = cs[0], end1 = (xe <= nx) ? beg1 : cs[xe - nx];
-        const int n0 = end0 - beg0, ntot = n0 + (end1 - beg1);
+        const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
+        const int ntot = cnd.ntot;
         for (int t = tid; t < ntot; t += Z_THREADS) {
-            const int i = ca[t < n0 ? beg0 + t : beg1 + (t - n0)];
+            const int i = pme_cand_atom(cnd, ca, t);
             const float4 pr = param[i];
             float q = pr.x;
             if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
@@ -497,7 +532,8 @@ __global__ __launch_bounds__(Z_THREADS)
 void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const float2* __restrict__ spec,
                             const float2* tw, const float2* tw_half, int Npad, const float4* __restrict__ pos,
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                            const int* __restrict__ col_start, const int* __restrict__ col_atoms, long long* __restrict__ force)
+                            const int* __restrict__ col_start, const int* __restrict__ col_atoms, long long* __restrict__ force,
+                            int bin_cap)
 {
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -540,17 +576,15 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
     // potential of line l at z: HALF keeps the real line as pairs (x[2n], x[2n+1]) = consecutive floats; else the real parts
     const float* phi = reinterpret_cast<const float*>(buf);
     const int zs = HALF ? 1 : 2, ls = 2 * PZ;
-    const int* cs = col_start + (size_t)r * (nx + 1);
-    const int* ca = col_atoms + (size_t)r * Npad;
+    const int* cs = col_start + (size_t)r * (bin_cap > 0 ? nx : nx + 1);
+    const int* ca = col_atoms + (size_t)r * (bin_cap > 0 ? (size_t)nx * bin_cap : (size_t)Npad);
     const float4* P = pos + (size_t)r * Npad;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
-    const int xe = x + 5;
-    const int beg0 = cs[x], end0 = cs[xe <= nx ? xe : nx];
-    const int beg1 = cs[0], end1 = (xe <= nx) ? beg1 : cs[xe - nx];
-    const int n0 = end0 - beg0, ntot = n0 + (end1 - beg1);
+    const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
+    const int ntot = cnd.ntot;
     for (int t = tid; t < ntot; t += Z_THREADS) {
-        const int i = ca[t < n0 ? beg0 + t : beg1 + (t - n0)];
+        const int i = pme_cand_atom(cnd, ca, t);
         const float4 pr = param[i];
         float q = pr.x;
         if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
@@ -907,6 +941,7 @@ int remd_pme_destroy(remd_ctx* h)
     if (s->d_energy) hipFree(s->d_energy);
     if (s->d_infl) hipFree(s->d_infl);
     if (s->d_dftmm) hipFree(s->d_dftmm);
+    if (s->d_cbin_count) hipFree(s->d_cbin_count); if (s->d_cbin_atoms) hipFree(s->d_cbin_atoms);
     if (s->d_gmax) hipFree(s->d_gmax);
     for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
     delete s;
@@ -1012,6 +1047,13 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->nspec * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_start, sizeof(int) * (size_t)(s->n[0] + 1) * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_atoms, sizeof(int) * (size_t)h->Npad * s->R));
+        if (!full_complex && !(getenv("REMD_PME_CHAINBIN") && atoi(getenv("REMD_PME_CHAINBIN")) == 0)) {
+            // four times the mean occupancy of a mesh column (x bins are 1 / nx of a homogeneous box): overflow is detected
+            s->cbin_cap = std::min(h->Npad, std::max(64, 4 * ((h->N + s->n[0] - 1) / s->n[0])));
+            REMD_CHECK(h, hipMalloc(&s->d_cbin_count, sizeof(int) * 2 * (size_t)s->R * s->n[0]));
+            REMD_CHECK(h, hipMemset(s->d_cbin_count, 0, sizeof(int) * 2 * (size_t)s->R * s->n[0]));
+            REMD_CHECK(h, hipMalloc(&s->d_cbin_atoms, sizeof(int) * (size_t)s->R * s->n[0] * s->cbin_cap));
+        }
     }
     if (s->z_half) {
         const int n = s->n[3];
@@ -1136,6 +1178,10 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
     const float* rep_lam = remd_nb_rep_lam(h);
     const float4* param = remd_nb_param(h);
     if (part & 1) {
+    // bins from the integrator chain (h->cbins_ready: the chain launched just before this evaluation filled buffer cbin_parity)
+    s->cbin_use = h->cbins_ready && s->d_cbin_count && !(getenv("REMD_PME_FUSEGATHER") && atoi(getenv("REMD_PME_FUSEGATHER")) == 0);
+    h->cbins_ready = false;
+    if (!s->cbin_use)
     {
         remd_prof_scope ps(h, "pme_bin", st);
         hipLaunchKernelGGL(pme_bin_kernel, dim3(h->R), dim3(1024), 0, st, h->N, h->Npad, nx, ny, nz, h->d_pos, h->d_box,
@@ -1165,8 +1211,17 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
 #define LAUNCH_Z(KERN, ZTT, HF, ...) hipLaunchKernelGGL((KERN<ZTT, HF>), zgrid, dim3(ZTT), zlds, st, make_plan(s, zaxis), s->sch_z, nl, nx, ny, __VA_ARGS__)
 #define DISPATCH_Z(KERN, ...) do { if (ZT == 256) { if (half) LAUNCH_Z(KERN, 256, true, __VA_ARGS__); else LAUNCH_Z(KERN, 256, false, __VA_ARGS__); } \
                                    else { if (half) LAUNCH_Z(KERN, 512, true, __VA_ARGS__); else LAUNCH_Z(KERN, 512, false, __VA_ARGS__); } } while (0)
-        DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, s->d_col_start, s->d_col_atoms, s->d_grid,
-                   s->d_tw[2], s->d_tw[3]);
+        // bins: compact arrays of the binning launch, or the capped ones the integrator chain filled (buffer cbin_parity; this
+        // pass zeroes the other buffer for the next evaluation and, with no binning launch in front, publishes the fork)
+        const int* bin_cs = s->cbin_use ? s->d_cbin_count + (size_t)s->cbin_parity * s->R * nx : s->d_col_start;
+        const int* bin_ca = s->cbin_use ? s->d_cbin_atoms : s->d_col_atoms;
+        const int bin_cap = s->cbin_use ? s->cbin_cap : 0;
+        int* bin_zero = s->cbin_use ? s->d_cbin_count + (size_t)(1 - s->cbin_parity) * s->R * nx : (int*)nullptr;
+        unsigned int* fflag = (s->cbin_use && h->fork_seq_pending) ? h->d_sync : (unsigned int*)nullptr;
+        const unsigned int fseq = h->fork_seq_pending;
+        if (s->cbin_use) { h->fork_seq_pending = 0; }
+        DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, bin_cs, bin_ca, s->d_grid,
+                   s->d_tw[2], s->d_tw[3], bin_cap, bin_zero, fflag, fseq);
         if (s->xy_fused || s->xs_sw > 0) {
             if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
             if (!s->d_gmax) REMD_CHECK(h, hipMalloc(&s->d_gmax, sizeof(float) * s->nzc * s->R));
@@ -1207,7 +1262,8 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         if (fuse_gather) {
             remd_prof_scope pzg(h, "pme_zinv_gather", st);
             DISPATCH_Z(pme_zinv_gather_kernel, s->d_grid, s->d_tw[2], s->d_tw[3], h->Npad, h->d_pos, param, h->d_box, rep_lam,
-                       s->d_col_start, s->d_col_atoms, h->d_force);
+                       bin_cs, bin_ca, h->d_force, bin_cap);
+            if (s->cbin_use) s->cbin_parity ^= 1;          // the next chain fills the buffer this evaluation has just zeroed
         } else {
             DISPATCH_Z(pme_zinv_kernel, s->d_grid, reinterpret_cast<float*>(s->d_mesh), s->d_tw[2], s->d_tw[3]);
         }
@@ -1229,6 +1285,18 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
 }
 
 // test hook: in-place 3-D complex FFT of a host array [nx][ny][nz] (interleaved re, im) on the strided-pass kernels
+// bins for the NEXT force evaluation, to be filled by the integrator chain that finalises the positions (integrate.hip)
+remd_chain_bins remd_pme_chain_bins(remd_ctx* h)
+{
+    remd_chain_bins b;
+    pme_state* s = (pme_state*)h->pme;
+    static const bool fuse_gather = !(getenv("REMD_PME_FUSEGATHER") && atoi(getenv("REMD_PME_FUSEGATHER")) == 0);
+    if (!s || !s->d_cbin_count || s->R != h->R || !fuse_gather || !h->pme_concurrent) return b;
+    b.nx = s->n[0]; b.cap = s->cbin_cap; b.count = s->d_cbin_count + (size_t)s->cbin_parity * s->R * s->n[0]; b.atoms = s->d_cbin_atoms;
+    b.box = h->d_box; b.err = h->d_sync + 2;
+    return b;
+}
+
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse)
 {
     pme_state* old = (pme_state*)h->pme;

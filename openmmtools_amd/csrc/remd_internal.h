@@ -19,6 +19,20 @@ struct remd_error { int code; std::string msg; };
 // fixed-point scale of the force accumulators (deterministic integer atomics)
 #define REMD_FORCE_SCALE 4294967296.0   // 2^32
 
+// scaled fractional mesh coordinate u in [0, n) of a position component and its integer part: ONE definition, because the PME
+// spreading pass recomputes the mesh column of an atom that was binned elsewhere (pme_bin_kernel or the integrator chain's
+// epilogue) and the two must agree bit for bit
+__device__ __forceinline__ void remd_pme_scaled1(float x, float L, int n, float& u, int& k)
+{
+    float f = x / L;
+    f -= floorf(f);
+    u = f * n;
+    k = (int)u;
+}
+// what the integrator chain needs to bin the atoms it has just moved by mesh column kx (pme.hip owns the arrays):
+// count[r][nx] (zero on entry) and atoms[r][nx][cap]; NULL count = no binning
+struct remd_chain_bins { int nx = 0, cap = 0; int* count = nullptr; int* atoms = nullptr; const float* box = nullptr; unsigned int* err = nullptr; };
+
 // (unsigned long long)(long long)((double)f * 2^32), i.e. truncation toward zero, bit for bit, without the f64 conversion
 // chain the cast expands to (8 double-rate instructions per component): |f| = floor + fraction is exact in f32, the
 // fraction times 2^32 is exact, and the two halves are converted separately.  |f| >= 2^31 saturates as before.
@@ -146,6 +160,7 @@ struct remd_ctx {
     // remd_run_steps: the launch that follows a force evaluation on the main stream is always an integrator chain, so the
     // join is polled in that kernel's prologue (join_deferred = sequence number to wait for) instead of a kernel of its own
     bool defer_join_ok = false; unsigned int join_deferred = 0;
+    bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true; bool pme_concurrent = false;
     double t_prop = 0, t_energy = 0, t_mix = 0;
     int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes

@@ -266,6 +266,24 @@ def test_alanine_propagation_is_bit_reproducible(hip_engine_factory):
     assert np.array_equal(out[0][2], out[1][2])
 
 
+def test_bins_from_the_integrator_chain_do_not_change_a_bit(hip_engine_factory, monkeypatch):
+    """Inside remd_run_steps the integrator chain that finalises the positions also bins the atoms by PME mesh column
+    (REMD_PME_CHAINBIN, default on), replacing the binning launch; the order of atoms inside a bin differs from run to run,
+    charges and forces are fixed-point sums: bit-identical trajectories either way."""
+    al = ts.AlanineDipeptideExplicit()
+    out = []
+    for flag in ('1', '0', '1'):
+        monkeypatch.setenv('REMD_PME_CHAINBIN', flag)
+        eng = hip_engine_factory()
+        _engine_for(eng, al.system, al.positions, R=3, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=30)
+        eng.propagate(0)
+        eng.propagate(1)
+        x, v = eng.get_replicas()[:2]
+        out.append((x, v))
+    for x, v in out[1:]:
+        assert np.array_equal(x, out[0][0]) and np.array_equal(v, out[0][1])
+
+
 def test_resident_pair_workgroups_do_not_change_a_bit(hip_engine_factory, monkeypatch):
     """The pair kernel either launches one workgroup per work item or keeps a resident set that pulls items from a queue
     (REMD_NB_PERSIST_GRID, chosen by timing at run time): forces are fixed-point sums, so positions and velocities after a
