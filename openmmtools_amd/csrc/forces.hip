@@ -2054,7 +2054,8 @@ int remd_nb_resort_due(remd_ctx* h)
     return (t->sort_R != h->R || t->evals_since_sort >= t->resort_interval) ? 1 : 0;
 }
 #define TUNE_SEG 40                       // one re-sort of the spatial order per segment (resort_interval)
-static const int g_tune_cands[4] = {0, 3 * 256, 5 * 128, 2 * 256};      // workgroups: one per item, 3 / 2.5 / 2 per CU (256 CUs)
+#define TUNE_NC 6
+static const int g_tune_cands[TUNE_NC] = {0, 768, 704, 640, 576, 512};      // workgroups: one per item, 3 ... 2 per CU (256 CUs) in steps of 1/4
 // called at the top of every eagerly launched MD step of remd_run_steps
 void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call)
 {
@@ -2069,9 +2070,9 @@ void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call)
             hipEventCreate(&boundary); hipEventRecord(boundary, h->stream);
             t.tune_segs.back().b = boundary;
         }
-        if (t.tune_next == 8) { t.tune_state = 1; t.nb_grid = 0; return; }      // two rounds of four candidates measured
+        if (t.tune_next == 2 * TUNE_NC) { t.tune_state = 1; t.nb_grid = 0; return; }      // two rounds of the candidates measured
         if (steps_left_in_call < TUNE_SEG) { t.nb_grid = 0; return; }           // resume in a later call
-        nb_tables::tune_seg sg{g_tune_cands[t.tune_next & 3], nullptr, nullptr};
+        nb_tables::tune_seg sg{g_tune_cands[t.tune_next % TUNE_NC], nullptr, nullptr};
         hipEventCreate(&sg.a); hipEventRecord(sg.a, h->stream);                // (each segment owns its pair of events)
         t.tune_segs.push_back(sg);
         t.nb_grid = sg.cand;
@@ -2086,23 +2087,26 @@ void remd_nb_tune_resolve(remd_ctx* h)
     nb_tables* tp = g_nb.find(h);
     if (!tp || tp->tune_state != 1) return;
     nb_tables& t = *tp;
-    double ms[4] = {0, 0, 0, 0};
+    double ms[TUNE_NC] = {0};
     bool ok = true;
     for (auto& sg : t.tune_segs) {
         float e = 0.f;
         if (!sg.a || !sg.b || hipEventElapsedTime(&e, sg.a, sg.b) != hipSuccess) { ok = false; (void)hipGetLastError(); }
-        for (int c = 0; c < 4; ++c) if (g_tune_cands[c] == sg.cand) ms[c] += e;
+        for (int c = 0; c < TUNE_NC; ++c) if (g_tune_cands[c] == sg.cand) ms[c] += e;
         if (sg.a) hipEventDestroy(sg.a);
         if (sg.b) hipEventDestroy(sg.b);
     }
     t.tune_segs.clear();
     int best = 0;
-    for (int c = 1; c < 4; ++c) if (ok && ms[c] < ms[best] * 0.995) best = c;     // ties go to the simpler launch
+    for (int c = 1; c < TUNE_NC; ++c) if (ok && ms[c] < ms[best] * 0.995) best = c;     // ties go to the earlier candidate
     t.nb_grid = ok ? g_tune_cands[best] : 0;
     t.tune_state = 2;
     if (getenv("REMD_NB_TUNE_VERBOSE"))
-        fprintf(stderr, "[remd] pair-kernel residency: one per item %.2f ms, 3/CU %.2f, 2.5/CU %.2f, 2/CU %.2f per %d steps -> %d workgroups\n",
-                ms[0], ms[1], ms[2], ms[3], 2 * TUNE_SEG, t.nb_grid);
+    {
+        fprintf(stderr, "[remd] pair-kernel residency, ms per %d steps:", 2 * TUNE_SEG);
+        for (int c = 0; c < TUNE_NC; ++c) fprintf(stderr, " %d: %.2f", g_tune_cands[c], ms[c]);
+        fprintf(stderr, " -> %d workgroups\n", t.nb_grid);
+    }
 }
 void remd_nb_note_evaluation(remd_ctx* h)
 {
