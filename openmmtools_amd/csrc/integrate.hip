@@ -322,7 +322,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
             remd_pme_scaled1(x[k].x, bins.box[4 * r], bins.nx, u, kx);
             if (kx >= bins.nx) kx -= bins.nx;
             const int slot = atomicAdd(&bins.count[(size_t)r * bins.nx + kx], 1);
-            if (slot < bins.cap) bins.atoms[((size_t)r * bins.nx + kx) * bins.cap + slot] = idx[k];
+            if (slot < bins.cap) bins.atoms[((size_t)r * bins.nx + kx) * bins.cap + slot] = make_float4(x[k].x, x[k].y, x[k].z, __int_as_float(idx[k]));
             else atomicExch(bins.err, 2u);
         }
     }

@@ -51,7 +51,7 @@ struct pme_state {
     int sch_nl = 0, sch_zt = 0;
     // bins filled by the integrator chain's epilogue (no binning launch on the critical path): count[2][R][nx] double buffered by
     // evaluation parity (the spreading pass zeroes the other one), atoms[R][nx][cbin_cap]; cbin_use: this evaluation reads them
-    int* d_cbin_count = nullptr; int* d_cbin_atoms = nullptr; int cbin_cap = 0, cbin_parity = 0; bool cbin_use = false;
+    int* d_cbin_count = nullptr; float4* d_cbin_atoms = nullptr; int cbin_cap = 0, cbin_parity = 0; bool cbin_use = false;
     void* d_dftmm = nullptr; bool xy_mfma = false;    // matrix-core XY pass (dft_mfma.hip): LDS image of the DFT matrix
     bool gather_fused = false;         // the inverse z launch already added the forces (pme_zinv_gather_kernel)
 };
@@ -297,12 +297,17 @@ __device__ __forceinline__ pme_cand pme_candidates(const int* __restrict__ cs, i
     }
     return c;
 }
-__device__ __forceinline__ int pme_cand_atom(const pme_cand& c, const int* __restrict__ ca, int t)
+// atom index and position of candidate t: capped bins hold float4(x, y, z, index), compact ones indices into pos[]
+__device__ __forceinline__ int pme_cand_atom(const pme_cand& c, const int* __restrict__ ca, int t, bool capped,
+                                             const float4* __restrict__ P, float4& xi)
 {
     int base = c.base[0];
 #pragma unroll
     for (int b = 0; b < 4; ++b) if (t >= c.n[b]) { t -= c.n[b]; base = c.base[b + 1]; } else break;
-    return ca[base + t];
+    if (capped) { xi = reinterpret_cast<const float4*>(ca)[base + t]; return __float_as_int(xi.w); }
+    const int i = ca[base + t];
+    xi = P[i];
+    return i;
 }
 
 // bin atoms by their mesh column kx (one workgroup per replica, everything in LDS): the fused spread + z-FFT
@@ -377,7 +382,7 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
     if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
     __syncthreads();
     const int* cs = col_start + (size_t)r * (bin_cap > 0 ? nx : nx + 1);
-    const int* ca = col_atoms + (size_t)r * (bin_cap > 0 ? (size_t)nx * bin_cap : (size_t)Npad);
+    const int* ca = col_atoms + (size_t)r * (bin_cap > 0 ? (size_t)nx * bin_cap * 4 : (size_t)Npad);     // capped entries are float4
     const float4* P = pos + (size_t)r * Npad;
     if (zero_count && blockIdx.x == 0) for (int k = tid; k < nx; k += Z_THREADS) zero_count[(size_t)r * nx + k] = 0;   // the bins of the NEXT evaluation
     if (fork_flag && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)             // (no binning launch in front: this one publishes the fork)
@@ -388,13 +393,14 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
         const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
         const int ntot = cnd.ntot;
         for (int t = tid; t < ntot; t += Z_THREADS) {
-            const int i = pme_cand_atom(cnd, ca, t);
+            float4 xi;
+            const int i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi);
             const float4 pr = param[i];
             float q = pr.x;
             if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
             if (q == 0.f) continue;
             float ux, uy, uz; int kx, ky, kz;
-            pme_scaled(P[i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+            pme_scaled(xi, box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
             float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
             bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
             if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
@@ -577,20 +583,21 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
     const float* phi = reinterpret_cast<const float*>(buf);
     const int zs = HALF ? 1 : 2, ls = 2 * PZ;
     const int* cs = col_start + (size_t)r * (bin_cap > 0 ? nx : nx + 1);
-    const int* ca = col_atoms + (size_t)r * (bin_cap > 0 ? (size_t)nx * bin_cap : (size_t)Npad);
+    const int* ca = col_atoms + (size_t)r * (bin_cap > 0 ? (size_t)nx * bin_cap * 4 : (size_t)Npad);
     const float4* P = pos + (size_t)r * Npad;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
     const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
     const int ntot = cnd.ntot;
     for (int t = tid; t < ntot; t += Z_THREADS) {
-        const int i = pme_cand_atom(cnd, ca, t);
+        float4 xi;
+        const int i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi);
         const float4 pr = param[i];
         float q = pr.x;
         if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
         if (q == 0.f) continue;
         float ux, uy, uz; int kx, ky, kz;
-        pme_scaled(P[i], box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+        pme_scaled(xi, box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
         float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
         bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
         if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
@@ -1052,7 +1059,7 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
             s->cbin_cap = std::min(h->Npad, std::max(64, 4 * ((h->N + s->n[0] - 1) / s->n[0])));
             REMD_CHECK(h, hipMalloc(&s->d_cbin_count, sizeof(int) * 2 * (size_t)s->R * s->n[0]));
             REMD_CHECK(h, hipMemset(s->d_cbin_count, 0, sizeof(int) * 2 * (size_t)s->R * s->n[0]));
-            REMD_CHECK(h, hipMalloc(&s->d_cbin_atoms, sizeof(int) * (size_t)s->R * s->n[0] * s->cbin_cap));
+            REMD_CHECK(h, hipMalloc(&s->d_cbin_atoms, sizeof(float4) * (size_t)s->R * s->n[0] * s->cbin_cap));
         }
     }
     if (s->z_half) {
@@ -1214,7 +1221,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         // bins: compact arrays of the binning launch, or the capped ones the integrator chain filled (buffer cbin_parity; this
         // pass zeroes the other buffer for the next evaluation and, with no binning launch in front, publishes the fork)
         const int* bin_cs = s->cbin_use ? s->d_cbin_count + (size_t)s->cbin_parity * s->R * nx : s->d_col_start;
-        const int* bin_ca = s->cbin_use ? s->d_cbin_atoms : s->d_col_atoms;
+        const int* bin_ca = s->cbin_use ? reinterpret_cast<const int*>(s->d_cbin_atoms) : s->d_col_atoms;
         const int bin_cap = s->cbin_use ? s->cbin_cap : 0;
         int* bin_zero = s->cbin_use ? s->d_cbin_count + (size_t)(1 - s->cbin_parity) * s->R * nx : (int*)nullptr;
         unsigned int* fflag = (s->cbin_use && h->fork_seq_pending) ? h->d_sync : (unsigned int*)nullptr;
