@@ -110,6 +110,7 @@ int remd_destroy(remd_handle h)
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     if (h->d_sync) hipFree(h->d_sync);
+    if (h->d_chain_sync) hipFree(h->d_chain_sync);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -304,6 +305,7 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         REMD_CHECK(h, hipMemcpyAsync(&spin_out, h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
         REMD_CHECK(h, hipStreamSynchronize(h->stream));
         remd_nb_tune_resolve(h);
+        if (spin_out == 3) return remd_fail(h, -2, "remd_propagate: the integrator chain's momentum barrier ran out (REMD_CHAIN_MERGE=0 selects two launches)");
         if (spin_out == 2) return remd_fail(h, -2, "remd_propagate: more atoms in one PME mesh column than the chain-binned layout holds (REMD_PME_CHAINBIN=0 selects the binning launch)");
         if (spin_out) return remd_fail(h, -2, "remd_propagate: a cross-stream wait on the device ran out (fork / join flag never arrived)");
         if (time_enqueue) {

@@ -36,7 +36,12 @@ struct chain_prog {
     int use_ctr;              // 1: steps are relative to the counters on the device (graph mode); 0: absolute (eager launches)
     int body_idx;             // loop-body index (ctr[1]) this program was built for: the momentum double buffer alternates per
                               // body, so a replayed (graph) launch shifts cmm_w / cmm_r by the parity of ctr[1] - body_idx
+    int m_buf;                // token 'M' (inside a chain): add sum(m v) into momentum buffer m_buf, then wait until every workgroup
+    unsigned int m_epoch;     // of the replica has done so (m_epoch-th barrier of this handle): the 'C' that follows reads the sum
 };
+
+// state of one constraint unit between the segments of a chain (registers)
+struct unit_regs { float3 x[4], v[4]; float im[4]; };
 
 struct settle_const { float mO, mH, ra, rb, rc, dOH, dHH; };
 
@@ -243,17 +248,20 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                                           float tol, int Npad, float4* __restrict__ P, float4* __restrict__ V,
                                           const long long* F, long long* Fw, const float* __restrict__ invmass, float kT,
                                           uint32_t rg, uint64_t seed, const long long* __restrict__ cmm_r, float inv_total_mass,
-                                          long long gstep_base, const remd_chain_bins& bins, int r)
+                                          long long gstep_base, const remd_chain_bins& bins, int r,
+                                          unit_regs& S, int t0, int t1, bool first, bool last)
 {
-    float3 x[NAT], v[NAT];
-    float im[NAT];
+    float3 (&x)[4] = S.x; float3 (&v)[4] = S.v;
+    float (&im)[4] = S.im;
+    if (first) {
 #pragma unroll
-    for (int k = 0; k < NAT; ++k) {
-        const float4 p = P[idx[k]], w = V[idx[k]];
-        x[k] = f3(p.x, p.y, p.z); v[k] = f3(w.x, w.y, w.z);
-        im[k] = invmass[idx[k]];
+        for (int k = 0; k < NAT; ++k) {
+            const float4 p = P[idx[k]], w = V[idx[k]];
+            x[k] = f3(p.x, p.y, p.z); v[k] = f3(w.x, w.y, w.z);
+            im[k] = invmass[idx[k]];
+        }
     }
-    for (int t = 0; t < prog.n; ++t) {
+    for (int t = t0; t < t1; ++t) {
         const char tok = prog.tok[t];
         if (tok == 'V') {
 #pragma unroll
@@ -299,15 +307,17 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
             }
             constrain_v<TYPE, NAT>(sc, im, tol, v, x);
         } else if (tok == 'C') {
-            // CMMotionRemover: v -= P/M with P accumulated by the previous chain
-            const float sx = (float)cmm_r[0] * (1.0f / 4294967296.0f) * inv_total_mass;
-            const float sy = (float)cmm_r[1] * (1.0f / 4294967296.0f) * inv_total_mass;
-            const float sz = (float)cmm_r[2] * (1.0f / 4294967296.0f) * inv_total_mass;
+            // CMMotionRemover: v -= P/M with P accumulated by the previous chain or by the 'M' token in front (read at the
+            // coherence point: other workgroups added to it by atomics during this launch)
+            const float sx = (float)__hip_atomic_load(&cmm_r[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
+            const float sy = (float)__hip_atomic_load(&cmm_r[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
+            const float sz = (float)__hip_atomic_load(&cmm_r[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
 #pragma unroll
             for (int k = 0; k < NAT; ++k) { v[k].x -= sx; v[k].y -= sy; v[k].z -= sz; }
         }
     }
     float3 mom = f3(0, 0, 0);
+    if (!last) return mom;
 #pragma unroll
     for (int k = 0; k < NAT; ++k) {
         P[idx[k]] = make_float4(x[k].x, x[k].y, x[k].z, 0.f);
@@ -337,7 +347,8 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             long long* force, const float* __restrict__ invmass,
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
-                            const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins)
+                            const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
+                            unsigned int* chain_sync, unsigned int* chain_sync_err)
 {
     if (join_flag) {
         // the forces of the direct-space stream: poll its "done" flag here instead of behind a cross-stream event (remd_ctx::d_sync)
@@ -366,25 +377,65 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         o[0] = 0; o[1] = 0; o[2] = 0;
     }
     const int4 a4 = (uidx < n_units) ? unit_atoms[uidx] : make_int4(-1, -1, -1, -1);
-    if (a4.x >= 0) {                                            // padding units do nothing
-        const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
-        const int type = unit_type[uidx];
-        float dist[3] = { 0.f, 0.f, 0.f };
-        if (type == UNIT_SHAKE) { dist[0] = shake_dist[uidx * 3]; dist[1] = shake_dist[uidx * 3 + 1]; dist[2] = shake_dist[uidx * 3 + 2]; }
-        float4* P = pos + (size_t)r * Npad;
-        float4* V = vel + (size_t)r * Npad;
-        const long long* F = force + (size_t)r * 3 * Npad;
-        long long* Fw = force + (size_t)r * 3 * Npad;
-        const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
-        const uint32_t rg = (uint32_t)(r_begin + r);
-        const long long* cr = cmm + ((size_t)max(cmm_r_eff, 0) * gridDim.y + r) * 4;
-#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, gstep_base, bins, r)
-        if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
-        else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
-        else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
-        else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
-        else RUN(UNIT_SHAKE, 4);
+    const bool active = a4.x >= 0;                              // padding units do nothing (but take part in the 'M' barrier)
+    const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
+    const int type = active ? unit_type[uidx] : UNIT_FREE;
+    float dist[3] = { 0.f, 0.f, 0.f };
+    if (active && type == UNIT_SHAKE) { dist[0] = shake_dist[uidx * 3]; dist[1] = shake_dist[uidx * 3 + 1]; dist[2] = shake_dist[uidx * 3 + 2]; }
+    float4* P = pos + (size_t)r * Npad;
+    float4* V = vel + (size_t)r * Npad;
+    const long long* F = force + (size_t)r * 3 * Npad;
+    long long* Fw = force + (size_t)r * 3 * Npad;
+    const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
+    const uint32_t rg = (uint32_t)(r_begin + r);
+    const long long* cr = cmm + ((size_t)max(cmm_r_eff, 0) * gridDim.y + r) * 4;
+    unit_regs S;
+    // segments of the token program, split at 'M' (momentum sum + barrier over the replica's workgroups)
+    for (int t0 = 0;;) {
+        int t1 = t0;
+        while (t1 < prog.n && prog.tok[t1] != 'M') ++t1;
+        const bool first = t0 == 0, last = t1 == prog.n;
+        if (active) {
+#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, gstep_base, bins, r, S, t0, t1, first, last)
+            if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
+            else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
+            else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
+            else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
+            else RUN(UNIT_SHAKE, 4);
 #undef RUN
+        }
+        if (last) break;
+        {
+            // 'M': sum(m v) of the velocities as they are now into buffer m_buf; every workgroup of this replica arrives at a
+            // counter in device memory and waits for the others (all of them are resident: the launcher checks the grid size)
+            float3 pm = f3(0, 0, 0);
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (idx[k] >= 0) pm = pm + S.v[k] * frcp(S.im[k]);
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                pm.x += __shfl_xor(pm.x, off); pm.y += __shfl_xor(pm.y, off); pm.z += __shfl_xor(pm.z, off);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + ((size_t)(prog.m_buf ^ flip) * gridDim.y + r) * 4);
+                atomicAdd(&c[0], (unsigned long long)(long long)((double)pm.x * 4294967296.0));
+                atomicAdd(&c[1], (unsigned long long)(long long)((double)pm.y * 4294967296.0));
+                atomicAdd(&c[2], (unsigned long long)(long long)((double)pm.z * 4294967296.0));
+            }
+            __syncthreads();                                    // (s_waitcnt: this workgroup's atomics are acknowledged)
+            if (threadIdx.x == 0) {
+                unsigned int* arrive = chain_sync + r;
+                atomicAdd(arrive, 1u);
+                const unsigned int target = prog.m_epoch * gridDim.x;
+                long long n = 0;
+                while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++n > (1ll << 25)) { atomicExch(chain_sync_err, 3u); break; }
+                }
+            }
+            __syncthreads();
+        }
+        t0 = t1 + 1;
     }
     if (prog.accumulate_momentum) {
         // wavefront shuffle reduction, one fixed-point atomic per wave (integer => order-independent sum)
@@ -579,7 +630,7 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr,
-                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins);
+                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2);
     h->join_deferred = 0;
     if (bins.count) h->cbins_ready = true;
 }
@@ -628,6 +679,20 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         if (!h->d_ctr) REMD_CHECK(h, hipMalloc(&h->d_ctr, 2 * sizeof(long long)));
         hipLaunchKernelGGL(ctr_set_kernel, dim3(1), dim3(1), 0, h->stream, h->d_ctr, gstep0, 0ll);
     }
+    // the centre-of-mass motion remover needs sum(m v) over the whole replica between two tokens of a step: either two launches
+    // (the first ends with the sum) or one launch with a barrier over the replica's workgroups in device memory ('M' token) --
+    // every workgroup of the grid must then be resident at once, hence the bound on the grid
+    const bool merge_env = !(getenv("REMD_CHAIN_MERGE") && atoi(getenv("REMD_CHAIN_MERGE")) == 0);
+    const long long chain_blocks = (long long)((ut.n_units + 255) / 256) * h->R;
+    const bool merge_cmm = merge_env && !graph_ok && chain_blocks <= 1024 && h->profiling != 2;
+    const long long sync_key = (long long)h->R * 1000003ll + ut.n_units;
+    if (merge_cmm && (!h->d_chain_sync || h->chain_sync_key != sync_key)) {      // counters count arrivals of THIS grid shape
+        if (h->d_chain_sync) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_chain_sync); h->d_chain_sync = nullptr; }
+        h->chain_sync_key = sync_key;
+        REMD_CHECK(h, hipMalloc(&h->d_chain_sync, sizeof(unsigned int) * h->R));
+        REMD_CHECK(h, hipMemsetAsync(h->d_chain_sync, 0, sizeof(unsigned int) * h->R, h->stream));
+        h->chain_sync_epoch = 0;
+    }
     int body = 0;                      // index of the loop body being enqueued (== ctr[1] when its kernels run)
     auto flush = [&](bool accumulate, bool bin_for_pme = false) {      // bin_for_pme: a force evaluation follows this launch directly
         if (cur.n == 0 && !accumulate) return;
@@ -659,7 +724,13 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             bool pending_reads_cmm = false;
             for (int t = 0; t < cur.n; ++t) pending_reads_cmm |= (cur.tok[t] == 'C');
             if (pending_reads_cmm) flush(false);   // it must see its own accumulator before the next sum starts
-            flush(true);                        // finishes pending tokens and accumulates sum(m v) into buffer cmm_w
+            if (merge_cmm && cur.n > 0 && cur.n + 2 <= MAX_TOK) {
+                // ONE launch: pending tokens, 'M' (sum(m v) into buffer cmm_w + barrier over the replica's workgroups), 'C', ...
+                push('M', 0, gstep);
+                cur.m_buf = cmm_w; cur.m_epoch = ++h->chain_sync_epoch;
+            } else {
+                flush(true);                    // finishes pending tokens and accumulates sum(m v) into buffer cmm_w
+            }
             push('C', 0, gstep);
             cur.cmm_r = cmm_w;                  // this chain subtracts P/M from that buffer and clears the other one
             cmm_w = 1 - cmm_w;

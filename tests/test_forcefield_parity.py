@@ -272,8 +272,9 @@ def test_bins_from_the_integrator_chain_do_not_change_a_bit(hip_engine_factory, 
     charges and forces are fixed-point sums: bit-identical trajectories either way."""
     al = ts.AlanineDipeptideExplicit()
     out = []
-    for flag in ('1', '0', '1'):
+    for flag, merge in (('1', '1'), ('0', '1'), ('1', '0'), ('0', '0')):
         monkeypatch.setenv('REMD_PME_CHAINBIN', flag)
+        monkeypatch.setenv('REMD_CHAIN_MERGE', merge)     # centre-of-mass sum by a barrier inside ONE chain launch, or two launches
         eng = hip_engine_factory()
         _engine_for(eng, al.system, al.positions, R=3, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=30)
         eng.propagate(0)
