@@ -241,9 +241,11 @@ def main():
             roof_ch = dict(kernel='integrate_chain_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                            frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic_bytes('integrate_chain_kernel'), launches=n_ch,
                            avg_launch_ms=avg_ms, total_ms=ms_ch,
-                           note='two launches per MD step (split at the centre-of-mass reduction); one thread per rigid water / '
-                                'X-H cluster / free atom with x, v in registers: 96 workgroups, bound by the latency of the '
-                                'dependent SETTLE / RATTLE arithmetic, not by HBM')
+                           note='one launch per MD step: V | sum(m v) + barrier over the replica\'s workgroups | C V R R O R R | PME '
+                                'binning; its prologue polls the direct-space stream\'s "forces complete" flag, so the duration '
+                                'includes that wait and the barrier; one thread per rigid water / X-H cluster / free atom with '
+                                'x, v in registers: 216 workgroups, bound by the latency of the dependent SETTLE / RATTLE '
+                                'arithmetic, not by HBM')
         # the contract asks for the dominant kernel: the class with the larger accumulated time in the timed region
         cands = [r for r in (roof_nb, roof_xy) if r]
         cands.sort(key=lambda r: -r['total_ms'])
