@@ -74,6 +74,7 @@ int remd_create(remd_handle* out, int device, void* stream)
         const int prio = (pe && !strcmp(pe, "lo")) ? lo : (pe && !strcmp(pe, "mid")) ? (lo + hi) / 2 : hi;
         if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio) != hipSuccess)
             hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+        if (getenv("REMD_LISTED_STREAM") && atoi(getenv("REMD_LISTED_STREAM")) != 0) hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking);
     }
     { const unsigned evf = (getenv("REMD_EVENT_SYSFENCE") ? 0u : hipEventReleaseToDevice) | hipEventDisableTiming;   // device-scope release: no system-scope cache write-back per fork / join
       hipEventCreateWithFlags(&h->ev_fork, evf); hipEventCreateWithFlags(&h->ev_join, evf); }
@@ -108,6 +109,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     if (h->d_sync) hipFree(h->d_sync);
     if (h->d_chain_sync) hipFree(h->d_chain_sync);

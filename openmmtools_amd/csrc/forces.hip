@@ -115,11 +115,12 @@ struct nb_tables {
 static handle_table<nb_tables> g_nb;
 
 // cross-stream dependencies without the command processor (see remd_ctx::d_sync): one lane polls a flag in device memory
-__global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq, unsigned int* spin_out)
+__global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq, unsigned int* spin_out, const unsigned int* flag2 = nullptr)
 {
     if (threadIdx.x == 0) {
         long long n = 0;
-        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0 ||
+               (flag2 && (int)(__hip_atomic_load(flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0)) {
             __builtin_amdgcn_s_sleep(4);
             if (++n > (1ll << 25)) { atomicExch(spin_out, 1u); break; }       // seconds: something upstream died; say so instead of hanging
         }
@@ -129,7 +130,8 @@ __global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq
 void remd_launch_join_wait(remd_ctx* h)      // a deferred join nobody consumed: wait for it now
 {
     if (!h->join_deferred) return;
-    hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->join_deferred, h->d_sync + 2);
+    hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->join_deferred, h->d_sync + 2,
+                       h->listed_on_s3 ? h->d_sync + 3 : (const unsigned int*)nullptr);
     h->join_deferred = 0;
 }
 __global__ void remd_signal_kernel(unsigned int* flag, unsigned int seq)
@@ -2217,6 +2219,17 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         }
     }
     };
+    // REMD_LISTED_STREAM=1: the listed terms on a third stream right behind the fork (experiment: takes them off the direct-space tail)
+    h->listed_on_s3 = false;
+    if (merged && listed_late && h->stream3 && pme_forked && swapped && !h->sync_events && !h->capturing) {
+        hipStream_t keep = h->stream;
+        h->stream = h->stream3;
+        hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream3, h->d_sync, h->sync_seq, h->d_sync + 2);
+        launch_listed();
+        hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream3, h->d_sync + 3, h->sync_seq);
+        h->stream = keep;
+        h->listed_on_s3 = true;
+    }
     if (merged && !listed_late) launch_listed();
     if (!merged && h->n_bonds > 0) {
         remd_prof_scope ps(h, "bonded");
@@ -2256,7 +2269,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
                 else launch_nb<NB_EWALD, false>(h, t, phase);
             }
         }
-        if (merged && listed_late) launch_listed();
+        if (merged && listed_late && !h->listed_on_s3) launch_listed();
         if (!merged && t.n_exc > 0) {
             remd_prof_scope ps(h, "exceptions");
             LAUNCH_E(exception_kernel, dim3(R), dim3(256), 0, h->stream, t.n_exc, t.d_exc_atoms, t.d_exc_params, t.d_exc_alch,
@@ -2276,7 +2289,8 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
                     if (!join_signalled) hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
                     std::swap(h->stream, h->stream2); swapped = false;
                     if (h->defer_join_ok && !with_energy) h->join_deferred = h->sync_seq;
-                    else hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq, h->d_sync + 2);
+                    else hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq, h->d_sync + 2,
+                                            h->listed_on_s3 ? h->d_sync + 3 : (const unsigned int*)nullptr);
                 } else {
                     if (swapped) { hipEventRecord(h->ev_join, h->stream); std::swap(h->stream, h->stream2); swapped = false; }
                     hipStreamWaitEvent(h->stream, h->ev_join, 0);

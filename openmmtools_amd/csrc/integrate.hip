@@ -348,13 +348,14 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
                             const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
-                            unsigned int* chain_sync, unsigned int* chain_sync_err)
+                            unsigned int* chain_sync, unsigned int* chain_sync_err, const unsigned int* join_flag2)
 {
     if (join_flag) {
         // the forces of the direct-space stream: poll its "done" flag here instead of behind a cross-stream event (remd_ctx::d_sync)
         if (threadIdx.x == 0) {
             long long n = 0;
-            while ((int)(__hip_atomic_load(join_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0) {
+            while ((int)(__hip_atomic_load(join_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0 ||
+                   (join_flag2 && (int)(__hip_atomic_load(join_flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0)) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++n > (1ll << 25)) { atomicExch(join_flag + 1, 1u); break; }
             }
@@ -630,7 +631,8 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr,
-                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2);
+                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2,
+                       (h->join_deferred && h->listed_on_s3) ? h->d_sync + 3 : (const unsigned int*)nullptr);
     h->join_deferred = 0;
     if (bins.count) h->cbins_ready = true;
 }

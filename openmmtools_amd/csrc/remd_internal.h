@@ -163,6 +163,7 @@ struct remd_ctx {
     bool defer_join_ok = false; unsigned int join_deferred = 0;
     unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
+    hipStream_t stream3 = nullptr; bool listed_on_s3 = false;    // third stream: the listed terms of a force-only evaluation (joins through d_sync[3])
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true; bool pme_concurrent = false;
     double t_prop = 0, t_energy = 0, t_mix = 0;
     int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes
