@@ -534,7 +534,7 @@ void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const fl
 // of 3; sums are order independent), and the real potential mesh (4 B / point written, then 125 reads per atom from L2) and
 // one dependent launch on the critical path of a step disappear.
 template <int Z_THREADS, bool HALF>
-__global__ __launch_bounds__(Z_THREADS)
+__global__ __launch_bounds__(Z_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const float2* __restrict__ spec,
                             const float2* tw, const float2* tw_half, int Npad, const float4* __restrict__ pos,
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
