@@ -375,8 +375,10 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
     float2* s_twh = s_tw + nz;                              // [M] twiddles of the half length (HALF only)
     int* acc = reinterpret_cast<int*>(buf);                 // [nl][nz] aliases buf: converted through registers below
     const int r = blockIdx.y, tid = threadIdx.x;
-    const int l0 = blockIdx.x * nl;
-    const int x = l0 / ny, y0 = l0 % ny;
+    // a mesh row x is covered by ceil(ny / nl) workgroups of nl lines (the last one may hang over the end of the row)
+    const int nbpr = (ny + nl - 1) / nl;
+    const int x = blockIdx.x / nbpr, y0 = (blockIdx.x - x * nbpr) * nl;
+    const int l0 = x * ny + y0;
     for (int idx = tid; idx < nl * nz; idx += Z_THREADS) acc[idx] = 0;
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
@@ -460,7 +462,7 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
         } else {
             X = buf[b * PZ + kz];
         }
-        S[((size_t)kz * nx + x) * ny + y0 + b] = X;
+        if (y0 + b < ny) S[((size_t)kz * nx + x) * ny + y0 + b] = X;
     }
 }
 
@@ -480,15 +482,17 @@ void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const fl
     float2* s_tw = buf + nl * PZ;
     float2* s_twh = s_tw + nz;
     const int r = blockIdx.y, tid = threadIdx.x;
-    const int l0 = blockIdx.x * nl;
-    const int x = l0 / ny, y0 = l0 % ny;
+    // a mesh row x is covered by ceil(ny / nl) workgroups of nl lines (the last one may hang over the end of the row)
+    const int nbpr = (ny + nl - 1) / nl;
+    const int x = blockIdx.x / nbpr, y0 = (blockIdx.x - x * nbpr) * nl;
+    const int l0 = x * ny + y0;
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
     const float2* S = spec + (size_t)r * nzc * nx * ny;
     const unsigned mnl = fft_magic((unsigned)nl);
     for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
         const int kz = fft_div(idx, mnl, nl), b = idx - kz * nl;
-        const float2 v = S[((size_t)kz * nx + x) * ny + y0 + b];
+        const float2 v = (y0 + b < ny) ? S[((size_t)kz * nx + x) * ny + y0 + b] : make_float2(0.f, 0.f);
         buf[b * PZ + kz] = v;                                 // HALF: slot M = nz/2 exists (PZ >= M + 1)
         if (!HALF && kz > 0 && kz < nz - kz) buf[b * PZ + nz - kz] = make_float2(v.x, -v.y);
     }
@@ -549,15 +553,17 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
     float2* s_tw = buf + nl * PZ;
     float2* s_twh = s_tw + nz;
     const int r = blockIdx.y, tid = threadIdx.x;
-    const int l0 = blockIdx.x * nl;
-    const int x = l0 / ny, y0 = l0 % ny;
+    // a mesh row x is covered by ceil(ny / nl) workgroups of nl lines (the last one may hang over the end of the row)
+    const int nbpr = (ny + nl - 1) / nl;
+    const int x = blockIdx.x / nbpr, y0 = (blockIdx.x - x * nbpr) * nl;
+    const int l0 = x * ny + y0;
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
     const float2* S = spec + (size_t)r * nzc * nx * ny;
     const unsigned mnl = fft_magic((unsigned)nl);
     for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
         const int kz = fft_div(idx, mnl, nl), b = idx - kz * nl;
-        const float2 v = S[((size_t)kz * nx + x) * ny + y0 + b];
+        const float2 v = (y0 + b < ny) ? S[((size_t)kz * nx + x) * ny + y0 + b] : make_float2(0.f, 0.f);
         buf[b * PZ + kz] = v;
         if (!HALF && kz > 0 && kz < nz - kz) buf[b * PZ + nz - kz] = make_float2(v.x, -v.y);
     }
@@ -1208,8 +1214,11 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         const int ZT = zt_env == 256 ? 256 : zt_env == 512 ? 512 : ((long long)ny * M <= (long long)Z_PPT * 256 ? 256 : 512);
         int nl = 1;
         for (int c = 1; c <= ny && c <= nl_cap; ++c) if (ny % c == 0 && c * M <= Z_PPT * ZT) nl = c;
+        // REMD_PME_NLX: any number of lines per workgroup (the last workgroup of a row hangs over its end); fused gather path only
+        static const int nlx = getenv("REMD_PME_NLX") ? atoi(getenv("REMD_PME_NLX")) : 0;
+        if (nlx > 0 && nlx * M <= Z_PPT * ZT && nlx <= ny) nl = nlx;
         const size_t zlds = sizeof(float2) * ((size_t)nl * PZ + nz + (half ? M : 0));
-        const dim3 zgrid(nx * ny / nl, s->R);
+        const dim3 zgrid(nx * ((ny + nl - 1) / nl), s->R);
         if (s->sch_nl != nl || s->sch_zt != ZT) {
             int rc = build_sched(h, s, zaxis, nl, PZ, 1, ZT, Z_PPT, &s->sch_z, &s->d_sched[2]);
             if (rc) return rc;

@@ -47,5 +47,6 @@ int main()
         run<64>(waves, 0); run<96>(waves, 0); run<128>(waves, 0); run<136>(waves, 0); run<144>(waves, 0); run<152>(waves, 0); run<160>(waves, 0); run<168>(waves, 0);
     }
     run<64>(5, 51328); run<64>(6, 46328); run<64>(4, 6148);
+    for (int lds : {23064, 22776, 22528, 22016, 21504, 20480}) run<64>(4, lds);    // the z passes of the 75 x 75 x 72 mesh: 6, 7 or 8 per CU?
     return 0;
 }
