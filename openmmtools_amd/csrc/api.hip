@@ -13,6 +13,7 @@ void remd_free_nonbonded(remd_ctx* h);
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
 int remd_test_xy_mfma_impl(remd_ctx* h, int n, int nplanes, float* data, int mode);
 void remd_nb_tune_resolve(remd_ctx* h);
+static int remd_check_device_flags(remd_ctx* h, const char* where);
 void remd_free_constraints(remd_ctx* h);
 
 static std::mutex g_err_mutex;
@@ -388,7 +389,7 @@ int remd_barostat_attempts(remd_handle h, int n_attempts)
         if (rc) return rc;
     }
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return remd_check_device_flags(h, "remd_barostat_attempts");
 }
 
 int remd_get_barostat_stats(remd_handle h, double* volume_scale, int64_t* n_attempted, int64_t* n_accepted)
@@ -454,7 +455,7 @@ int remd_compute_energies(remd_handle h, double* d_ukl_rows, double* ukl_host, d
     if (potential_host) REMD_CHECK(h, hipMemcpyAsync(potential_host, h->d_potential, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
     float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_energy = ms;
-    return 0;
+    return remd_check_device_flags(h, "remd_compute_energies");
 }
 
 static int ensure_mix_buffers(remd_ctx* h, int R, int K)
@@ -579,6 +580,18 @@ int remd_get_forces(remd_handle h, double* f)
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
     for (int r = 0; r < h->R; ++r) for (int i = 0; i < h->N; ++i) for (int k = 0; k < 3; ++k)
         f[((size_t)r * h->N + i) * 3 + k] = (double)buf[((size_t)r * 3 + k) * h->Npad + i] / REMD_FORCE_SCALE;
+    return remd_check_device_flags(h, "remd_get_forces");
+}
+
+// the device reports what it cannot raise: a cross-stream poll or the chain's barrier that ran out, an overfull PME bin
+// (d_sync[2], sticky).  Called behind the stream synchronisation of every entry point that evaluates forces.
+static int remd_check_device_flags(remd_ctx* h, const char* where)
+{
+    unsigned int f = 0;
+    REMD_CHECK(h, hipMemcpy(&f, h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost));
+    if (f == 3) return remd_fail(h, -2, std::string(where) + ": the integrator chain's momentum barrier ran out (REMD_CHAIN_MERGE=0 selects two launches)");
+    if (f == 2) return remd_fail(h, -2, std::string(where) + ": more atoms in one PME mesh column than the chain-binned layout holds (REMD_PME_CHAINBIN=0 selects the binning launch)");
+    if (f) return remd_fail(h, -2, std::string(where) + ": a cross-stream wait on the device ran out (fork / join flag never arrived)");
     return 0;
 }
 
