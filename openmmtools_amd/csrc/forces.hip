@@ -95,7 +95,9 @@ struct nb_tables {
     float4* d_lj_tile_c = nullptr; float4* d_lj_tile_h = nullptr; float4* d_lj_cl_c = nullptr; float4* d_lj_cl_h = nullptr;
     unsigned short* d_lj_list = nullptr; int* d_lj_count = nullptr;
     // Newton's-third-law path: per-tile union lists (jc | imask << 16) and near-diagonal exclusion words
-    bool n3l = true; int sci_split = 12;     // list slices per tile (3 workgroups of 4 wavefronts): measured optimum for the headline config (8: 7.71, 12: 7.76, 16: 7.62 it/s)
+    bool n3l = true; int sci_split = 8;      // list slices per tile (2 workgroups of 4 wavefronts).  Round 1, one workgroup per item: 8: 7.71, 12: 7.76, 16: 7.62 it/s;
+                                             // round 2, resident workgroups pulling items: 8: 105.9, 12: 106.55, 16: 111.0 ms per 500 steps.  ONE value for every launch
+                                             // mode: the slices' fp32 partial sums make the forces depend on it bit-wise, and the mode is chosen by timing
     unsigned int* d_sci_list = nullptr; int* d_sci_count = nullptr; unsigned long long* d_excl = nullptr; int excl_W = 0;
     long long* d_sforce = nullptr; long long* d_lj_sforce = nullptr;   // [R][3][Npad] / [R][3][NLpad] forces in sorted slot space
     unsigned int* d_lj_sci_list = nullptr; int* d_lj_sci_count = nullptr; unsigned long long* d_lj_excl = nullptr; int lj_excl_W = 0;
