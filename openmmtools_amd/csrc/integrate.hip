@@ -332,8 +332,11 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
             remd_pme_scaled1(x[k].x, bins.box[4 * r], bins.nx, u, kx);
             if (kx >= bins.nx) kx -= bins.nx;
             const int slot = atomicAdd(&bins.count[(size_t)r * bins.nx + kx], 1);
-            if (slot < bins.cap) bins.atoms[((size_t)r * bins.nx + kx) * bins.cap + slot] = make_float4(x[k].x, x[k].y, x[k].z, __int_as_float(idx[k]));
-            else atomicExch(bins.err, 2u);
+            if (slot < bins.cap) {
+                const size_t e = ((size_t)r * bins.nx + kx) * bins.cap + slot;
+                bins.atoms[e] = make_float4(x[k].x, x[k].y, x[k].z, __int_as_float(idx[k]));
+                if (bins.q) bins.q[e] = bins.param[idx[k]].x;        // (state-independent charges only, see remd_pme_chain_bins)
+            } else atomicExch(bins.err, 2u);
         }
     }
     return mom;

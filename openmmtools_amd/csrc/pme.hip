@@ -51,6 +51,7 @@ struct pme_state {
     int sch_nl = 0, sch_zt = 0;
     // bins filled by the integrator chain's epilogue (no binning launch on the critical path): count[2][R][nx] double buffered by
     // evaluation parity (the spreading pass zeroes the other one), atoms[R][nx][cbin_cap]; cbin_use: this evaluation reads them
+    float* d_cbin_q = nullptr;
     int* d_cbin_count = nullptr; float4* d_cbin_atoms = nullptr; int cbin_cap = 0, cbin_parity = 0; bool cbin_use = false;
     void* d_dftmm = nullptr; bool xy_mfma = false;    // matrix-core XY pass (dft_mfma.hip): LDS image of the DFT matrix
     bool gather_fused = false;         // the inverse z launch already added the forces (pme_zinv_gather_kernel)
@@ -297,16 +298,27 @@ __device__ __forceinline__ pme_cand pme_candidates(const int* __restrict__ cs, i
     }
     return c;
 }
-// atom index and position of candidate t: capped bins hold float4(x, y, z, index), compact ones indices into pos[]
+// atom index, position and effective charge of candidate t: capped bins hold float4(x, y, z, index) + a charge array (both
+// loads independent), compact ones indices into pos[] / param[]
 __device__ __forceinline__ int pme_cand_atom(const pme_cand& c, const int* __restrict__ ca, int t, bool capped,
-                                             const float4* __restrict__ P, float4& xi)
+                                             const float4* __restrict__ P, float4& xi, const float* __restrict__ cq,
+                                             const float4* __restrict__ param, const float* __restrict__ rep_lam, int r, float& q)
 {
     int base = c.base[0];
 #pragma unroll
     for (int b = 0; b < 4; ++b) if (t >= c.n[b]) { t -= c.n[b]; base = c.base[b + 1]; } else break;
-    if (capped) { xi = reinterpret_cast<const float4*>(ca)[base + t]; return __float_as_int(xi.w); }
-    const int i = ca[base + t];
-    xi = P[i];
+    int i;
+    if (capped) {
+        xi = reinterpret_cast<const float4*>(ca)[base + t];
+        i = __float_as_int(xi.w);
+        if (cq) { q = cq[base + t]; return i; }
+    } else {
+        i = ca[base + t];
+        xi = P[i];
+    }
+    const float4 pr = param[i];
+    q = pr.x;
+    if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
     return i;
 }
 
@@ -364,7 +376,8 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms,
                             float2* __restrict__ spec, const float2* tw, const float2* tw_half,
-                            int bin_cap, int* __restrict__ zero_count, unsigned int* fork_flag, unsigned int fork_seq)
+                            int bin_cap, int* __restrict__ zero_count, unsigned int* fork_flag, unsigned int fork_seq,
+                            const float* __restrict__ bin_q)
 {
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -395,11 +408,8 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
         const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
         const int ntot = cnd.ntot;
         for (int t = tid; t < ntot; t += Z_THREADS) {
-            float4 xi;
-            const int i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi);
-            const float4 pr = param[i];
-            float q = pr.x;
-            if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
+            float4 xi; float q;
+            pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi, bin_q ? bin_q + (size_t)r * nx * bin_cap : (const float*)nullptr, param, rep_lam, r, q);
             if (q == 0.f) continue;
             float ux, uy, uz; int kx, ky, kz;
             pme_scaled(xi, box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
@@ -543,7 +553,7 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
                             const float2* tw, const float2* tw_half, int Npad, const float4* __restrict__ pos,
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms, long long* __restrict__ force,
-                            int bin_cap)
+                            int bin_cap, const float* __restrict__ bin_q)
 {
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -596,11 +606,8 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
     const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
     const int ntot = cnd.ntot;
     for (int t = tid; t < ntot; t += Z_THREADS) {
-        float4 xi;
-        const int i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi);
-        const float4 pr = param[i];
-        float q = pr.x;
-        if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
+        float4 xi; float q;
+        const int i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi, bin_q ? bin_q + (size_t)r * nx * bin_cap : (const float*)nullptr, param, rep_lam, r, q);
         if (q == 0.f) continue;
         float ux, uy, uz; int kx, ky, kz;
         pme_scaled(xi, box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
@@ -954,7 +961,7 @@ int remd_pme_destroy(remd_ctx* h)
     if (s->d_energy) hipFree(s->d_energy);
     if (s->d_infl) hipFree(s->d_infl);
     if (s->d_dftmm) hipFree(s->d_dftmm);
-    if (s->d_cbin_count) hipFree(s->d_cbin_count); if (s->d_cbin_atoms) hipFree(s->d_cbin_atoms);
+    if (s->d_cbin_count) hipFree(s->d_cbin_count); if (s->d_cbin_atoms) hipFree(s->d_cbin_atoms); if (s->d_cbin_q) hipFree(s->d_cbin_q);
     if (s->d_gmax) hipFree(s->d_gmax);
     for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
     delete s;
@@ -1066,6 +1073,7 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
             REMD_CHECK(h, hipMalloc(&s->d_cbin_count, sizeof(int) * 2 * (size_t)s->R * s->n[0]));
             REMD_CHECK(h, hipMemset(s->d_cbin_count, 0, sizeof(int) * 2 * (size_t)s->R * s->n[0]));
             REMD_CHECK(h, hipMalloc(&s->d_cbin_atoms, sizeof(float4) * (size_t)s->R * s->n[0] * s->cbin_cap));
+            REMD_CHECK(h, hipMalloc(&s->d_cbin_q, sizeof(float) * (size_t)s->R * s->n[0] * s->cbin_cap));
         }
     }
     if (s->z_half) {
@@ -1237,7 +1245,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         const unsigned int fseq = h->fork_seq_pending;
         if (s->cbin_use) { h->fork_seq_pending = 0; }
         DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, bin_cs, bin_ca, s->d_grid,
-                   s->d_tw[2], s->d_tw[3], bin_cap, bin_zero, fflag, fseq);
+                   s->d_tw[2], s->d_tw[3], bin_cap, bin_zero, fflag, fseq, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr);
         if (s->xy_fused || s->xs_sw > 0) {
             if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
             if (!s->d_gmax) REMD_CHECK(h, hipMalloc(&s->d_gmax, sizeof(float) * s->nzc * s->R));
@@ -1278,7 +1286,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         if (fuse_gather) {
             remd_prof_scope pzg(h, "pme_zinv_gather", st);
             DISPATCH_Z(pme_zinv_gather_kernel, s->d_grid, s->d_tw[2], s->d_tw[3], h->Npad, h->d_pos, param, h->d_box, rep_lam,
-                       bin_cs, bin_ca, h->d_force, bin_cap);
+                       bin_cs, bin_ca, h->d_force, bin_cap, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr);
             if (s->cbin_use) s->cbin_parity ^= 1;          // the next chain fills the buffer this evaluation has just zeroed
         } else {
             DISPATCH_Z(pme_zinv_kernel, s->d_grid, reinterpret_cast<float*>(s->d_mesh), s->d_tw[2], s->d_tw[3]);
@@ -1310,6 +1318,10 @@ remd_chain_bins remd_pme_chain_bins(remd_ctx* h)
     if (!s || !s->d_cbin_count || s->R != h->R || !fuse_gather || !h->pme_concurrent) return b;
     b.nx = s->n[0]; b.cap = s->cbin_cap; b.count = s->d_cbin_count + (size_t)s->cbin_parity * s->R * s->n[0]; b.atoms = s->d_cbin_atoms;
     b.box = h->d_box; b.err = h->d_sync + 2;
+    // charges ride in the bins only when they do not depend on the replica's state: the chain runs before the evaluation
+    // that refreshes the per-replica lambdas
+    b.param = remd_nb_param(h);
+    b.q = (b.param && !remd_nb_rep_lam(h)) ? s->d_cbin_q : nullptr;
     return b;
 }
 

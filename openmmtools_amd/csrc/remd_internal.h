@@ -32,7 +32,9 @@ __device__ __forceinline__ void remd_pme_scaled1(float x, float L, int n, float&
 // what the integrator chain needs to bin the atoms it has just moved by mesh column kx (pme.hip owns the arrays):
 // count[r][nx] (zero on entry) and atoms[r][nx][cap]; NULL count = no binning
 // (an entry is the atom's position with its index in .w: the spreading pass then needs no second dependent load for it)
-struct remd_chain_bins { int nx = 0, cap = 0; int* count = nullptr; float4* atoms = nullptr; const float* box = nullptr; unsigned int* err = nullptr; };
+// (and its effective charge in a parallel array: no dependent load of the per-atom parameters either)
+struct remd_chain_bins { int nx = 0, cap = 0; int* count = nullptr; float4* atoms = nullptr; const float* box = nullptr; unsigned int* err = nullptr;
+                         float* q = nullptr; const float4* param = nullptr; const float* rep_lam = nullptr; };
 
 // (unsigned long long)(long long)((double)f * 2^32), i.e. truncation toward zero, bit for bit, without the f64 conversion
 // chain the cast expands to (8 double-rate instructions per component): |f| = floor + fraction is exact in f32, the
