@@ -95,9 +95,7 @@ struct nb_tables {
     float4* d_lj_tile_c = nullptr; float4* d_lj_tile_h = nullptr; float4* d_lj_cl_c = nullptr; float4* d_lj_cl_h = nullptr;
     unsigned short* d_lj_list = nullptr; int* d_lj_count = nullptr;
     // Newton's-third-law path: per-tile union lists (jc | imask << 16) and near-diagonal exclusion words
-    bool n3l = true; int sci_split = 8;      // list slices per tile (2 workgroups of 4 wavefronts).  Round 1, one workgroup per item: 8: 7.71, 12: 7.76, 16: 7.62 it/s;
-                                             // round 2, resident workgroups pulling items: 8: 105.9, 12: 106.55, 16: 111.0 ms per 500 steps.  ONE value for every launch
-                                             // mode: the slices' fp32 partial sums make the forces depend on it bit-wise, and the mode is chosen by timing
+    bool n3l = true; int sci_split = 12;     // list slices per tile (workgroups of 4 wavefronts); set per system in remd_build_nonbonded
     unsigned int* d_sci_list = nullptr; int* d_sci_count = nullptr; unsigned long long* d_excl = nullptr; int excl_W = 0;
     long long* d_sforce = nullptr; long long* d_lj_sforce = nullptr;   // [R][3][Npad] / [R][3][NLpad] forces in sorted slot space
     unsigned int* d_lj_sci_list = nullptr; int* d_lj_sci_count = nullptr; unsigned long long* d_lj_excl = nullptr; int lj_excl_W = 0;
@@ -1695,6 +1693,10 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         const char* env3 = getenv("REMD_NB_CLUSTERS");
         t.clusters = !(env3 && atoi(env3) == 0);
         if (getenv("REMD_NB_N3L")) t.n3l = atoi(getenv("REMD_NB_N3L")) != 0;
+        // 8 slices where the mesh stream runs beside the pair kernel (its launch may become a resident set pulling items: 105.9 vs
+        // 106.55 ms per 500 steps on the headline config), 12 elsewhere (LJ fluid, one workgroup per item: 66.6 vs 63.3 it/s).
+        // Fixed per system, never per launch mode: the slices' fp32 partial sums enter the forces bit-wise.
+        t.sci_split = (t.method == NB_EWALD && h->overlap && h->stream2) ? 8 : 12;
         if (getenv("REMD_NB_SCISPLIT")) t.sci_split = std::max(1, std::min(16, atoi(getenv("REMD_NB_SCISPLIT"))));
         const char* env2 = getenv("REMD_NB_RESORT");
         if (env2) t.resort_interval = std::max(1, atoi(env2));
