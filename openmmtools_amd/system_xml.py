@@ -7,8 +7,11 @@ below restate OpenMM's serialization proxies (SystemProxy, HarmonicBondForceProx
 PeriodicTorsionForceProxy, NonbondedForceProxy, CustomExternalForceProxy, CMMotionRemoverProxy,
 MonteCarloBarostatProxy; OpenMM 8 writes ``version`` 1-4 of them).  **External knowledge — OpenMM is not in
 /root/reference and not installed here**: the reader is written to be tolerant (unknown attributes are ignored,
-optional blocks may be missing) and is pinned only by round trips through the writer in this module and by a hand-written
-document in tests/test_system_xml_cpu.py; re-verify against a file produced by OpenMM when one is available.
+optional blocks may be missing).  Pinned by round trips through the writer in this module, a hand-written document
+(tests/test_system_xml_cpu.py) and — round 3 — **a document written by OpenMM 7.7 itself**: the System of
+AlanineDipeptideExplicit stored in the reference's data/reporter-examples/alanine_dipeptide_legacy.nc
+(tests/golden/openmm_alanine_fixture.npz, tests/test_openmm_fixture.py) parses to exactly the description this
+package builds from the Amber files.
 
 Forces outside the hot path's scope (GBSA, CustomNonbonded, CustomBond, ... and NonbondedForce parameter offsets /
 non-default PME) raise ``NotImplementedError`` naming the force, like ``system_to_desc`` does.
@@ -175,6 +178,11 @@ def from_xml(text_or_path):
         elif kind == 'MonteCarloBarostat':
             barostat = dict(pressure=float(e.get('pressure')), temperature=float(e.get('temperature', '300')),
                             frequency=int(e.get('frequency', '25')))
+            continue
+        elif kind == 'AndersenThermostat':
+            # the reference's *standard system* keeps an AndersenThermostat as the marker of "this state has a
+            # thermostat" (states.py:1447-1490, 1100-1180); its temperature lives on the ThermodynamicState and the
+            # Langevin integrator does the thermostatting, so the force itself carries nothing for the engine
             continue
         else:
             raise NotImplementedError('unsupported OpenMM force %s' % kind)

@@ -1,0 +1,173 @@
+"""Floating-point parity against numbers PRODUCED BY OPENMM, on the headline system.
+
+tests/golden/openmm_alanine_fixture.npz is extracted (tests/golden/make_golden_from_openmm_fixture.py) from the store the
+reference ships for its own resume test (openmmtools/data/reporter-examples/alanine_dipeptide_legacy{,_checkpoint}.nc,
+tests/test_sampling.py:2943-2990): the System XML OpenMM 7.7 serialised for testsystems.AlanineDipeptideExplicit, three
+frames of positions (f4) and the reduced potentials u_kl = beta_l U(x) (states.py:1908-1917) OpenMM computed for them
+at 20 temperatures.  Checked here:
+
+  * the Amber -> System conversion of this package (openmmtools_amd/amber.py via tools/convert_amber.py) equals
+    OpenMM's AmberPrmtopFile.createSystem result field by field (masses, constraints, bonds, angles, torsions with k != 0,
+    charges, sigma where epsilon != 0, epsilon, all 2345 exceptions, cutoff / switch / tolerance / dispersion flag);
+  * the f64 oracle (oracle/forcefield.py) and libremd_cpu.so reproduce OpenMM's u_kl on all 3 x 20 entries to 5e-6
+    relative (measured 1.3e-6: f4 positions + OpenMM's single-precision arithmetic are the residual);
+  * (-m gpu) remd_compute_energies through the C ABI reproduces OpenMM's u_kl to north_star's 1e-5 relative — against
+    OpenMM's numbers, not against this repository's oracle.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from openmmtools_amd import system_xml, testsystems as ts
+from openmmtools_amd.system import system_to_desc
+from openmmtools_amd._engine import HipEngine
+from oracle.forcefield import ForceFieldOracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KB = 0.008314462618153242            # kJ/mol/K, openmm.unit.MOLAR_GAS_CONSTANT_R (constants.py)
+CPU_LIB = os.path.join(os.path.dirname(os.path.abspath(oracle.__file__)), '_build', 'libremd_cpu.so')
+
+
+@pytest.fixture(scope='module')
+def fixture():
+    z = np.load(os.path.join(HERE, 'golden', 'openmm_alanine_fixture.npz'))
+    xml = zlib.decompress(z['system_xml_zlib'].tobytes()).decode()
+    system, barostat = system_xml.from_xml(xml)
+    assert barostat is None
+    return dict(z=z, xml=xml, system=system, desc=system_to_desc(system))
+
+
+def test_fixture_is_what_the_reference_test_describes(fixture):
+    z = fixture['z']
+    assert z['positions'].shape == (3, 2269, 3) and z['positions'].dtype == np.float32
+    assert z['energies'].shape == (3, 20)
+    # the legacy store (2022) carries the OLDER exponential ladder T_i = T_min + (T_max - T_min)(e^{i/(n-1)} - 1)/(e - 1),
+    # not the np.logspace of today's paralleltempering.py:162 — the states are stored, so nothing depends on the rule
+    n = 20
+    ladder = [300.0 + (600.0 - 300.0) * (np.exp(float(i) / float(n - 1)) - 1.0) / (np.e - 1.0) for i in range(n)]
+    assert np.allclose(z['temperatures'], ladder, rtol=1e-12)
+    assert 'LangevinSplittingDynamicsMove' in str(z['mcmc_move0'])
+    # one replica, so u_kl rows obey u[l] * T_l = const (paralleltempering.py:206-215)
+    U = z['energies'] * KB * z['temperatures'][None, :]
+    assert np.abs(U / U[:, :1] - 1).max() < 1e-12
+
+
+def test_openmm_system_equals_this_packages_amber_conversion(fixture):
+    """OpenMM's createSystem(PME, 1.0 nm, HBonds, rigidWater) + the testsystem's switch (testsystems.py:3496-3527) vs
+    AlanineDipeptideExplicit() of this package: a wrong 1-4 scale factor, torsion phase or charge constant fails here."""
+    a = fixture['desc']
+    b = system_to_desc(ts.AlanineDipeptideExplicit().system)
+    assert a['n_atoms'] == b['n_atoms'] == 2269
+    assert np.array_equal(a['mass'], b['mass'])
+    for key in ('nb_method', 'cutoff', 'use_dispersion_correction', 'rf_dielectric', 'cmm_frequency'):
+        assert a[key] == b[key], key
+    assert abs(a['switch_distance'] - b['switch_distance']) < 1e-12
+    assert a['ewald_alpha'] == b['ewald_alpha'] and list(a['pme_grid']) == list(b['pme_grid'])
+    # constraints: 749 rigid waters + 12 X-H in 6 clusters = 2259
+    assert np.array_equal(a['settle_atoms'], b['settle_atoms']) and len(a['settle_atoms']) == 749
+    assert a['settle_dOH'] == pytest.approx(b['settle_dOH'], abs=1e-9) and a['settle_dHH'] == pytest.approx(b['settle_dHH'], abs=1e-9)
+    assert np.array_equal(a['shake_atoms'], b['shake_atoms'])
+    assert np.allclose(a['shake_dist'], b['shake_dist'], atol=1e-9)
+    assert 3 * len(a['settle_atoms']) + (a['shake_atoms'][:, 1:] >= 0).sum() == 2259
+    # listed terms
+    for name, nat in (('bond', 2), ('angle', 3)):
+        assert np.array_equal(a[name + '_atoms'], b[name + '_atoms']), name
+        assert np.allclose(a[name + '_params'], b[name + '_params'], rtol=1e-9, atol=0), name
+    keep = a['torsion_params'][:, 2] != 0.0            # OpenMM keeps the prmtop's zero-k terms; they carry no energy
+    assert keep.sum() == 32 and len(keep) == 52
+
+    def tors(d, mask=None):
+        at, pr = d['torsion_atoms'], d['torsion_params']
+        if mask is not None:
+            at, pr = at[mask], pr[mask]
+        return sorted((tuple(int(x) for x in t), int(p[0]), round(float(p[1]), 9), round(float(p[2]), 9)) for t, p in zip(at, pr))
+    assert tors(a, keep) == tors(b)
+    # particles
+    assert np.array_equal(a['charge'], b['charge'])
+    assert np.array_equal(a['epsilon'], b['epsilon'])
+    on = a['epsilon'] != 0.0
+    assert np.allclose(a['sigma'][on], b['sigma'][on], rtol=1e-12)
+    assert abs(a['charge'].sum()) < 1e-9
+
+    def exc(d):
+        out = {}
+        for (i, j), p in zip(d['exception_atoms'], d['exception_params']):
+            out[(min(int(i), int(j)), max(int(i), int(j)))] = p
+        return out
+    ea, eb = exc(a), exc(b)
+    assert len(ea) == len(eb) == 2345 and set(ea) == set(eb)
+    n14 = 0
+    for pair, p in ea.items():
+        q = eb[pair]
+        assert p[0] == pytest.approx(q[0], rel=1e-9, abs=1e-12), pair            # chargeProd (1-4: q q / 1.2)
+        assert p[2] == pytest.approx(q[2], rel=1e-9, abs=1e-12), pair            # epsilon   (1-4: sqrt(e e) / 2)
+        if p[2] != 0.0:
+            assert p[1] == pytest.approx(q[1], rel=1e-9), pair
+        n14 += (p[0] != 0.0 or p[2] != 0.0)
+    assert n14 == 41                                                              # the solute's 1-4 pairs
+    assert np.allclose(np.diag(fixture['system'].getDefaultPeriodicBoxVectors()),
+                       np.diag(ts.AlanineDipeptideExplicit().system.getDefaultPeriodicBoxVectors()), atol=2e-7)
+
+
+def _frames(fixture):
+    z = fixture['z']
+    x = z['positions'].astype(np.float64)
+    box = np.stack([np.diag(b).astype(np.float64) for b in z['box_vectors']])
+    beta = 1.0 / (KB * z['temperatures'])
+    return x, box, beta, z['energies']
+
+
+def test_oracle_reproduces_openmm_reduced_potentials(fixture):
+    x, box, beta, u_openmm = _frames(fixture)
+    ff = ForceFieldOracle(fixture['desc'])
+    worst = 0.0
+    for it in range(3):
+        u = ff.potential(x[it], box[it]) * beta
+        worst = max(worst, np.abs(u / u_openmm[it] - 1.0).max())
+    assert worst < 5e-6, worst
+
+
+def _engine_rows(eng, fixture):
+    x, box, beta, u_openmm = _frames(fixture)
+    eng.set_system(fixture['desc'])
+    eng.set_states(beta)
+    eng.set_integrator('V R O R V', 0.001, 1.0, 1, False, 1e-6)
+    eng.seed(1)
+    eng.set_replicas(3, 0, x, None, box, np.zeros(3, dtype=np.int64))
+    return eng.compute_energies(), u_openmm
+
+
+def test_cpu_library_reproduces_openmm_reduced_potentials(fixture):
+    """libremd_cpu.so (the timed CPU baseline and second checker) against OpenMM's own numbers."""
+    if not os.path.exists(CPU_LIB):
+        oracle.build()
+    eng = HipEngine(lib_path=CPU_LIB)
+    try:
+        rows, u_openmm = _engine_rows(eng, fixture)
+    finally:
+        eng.close()
+    assert rows.shape == (3, 20)
+    assert np.abs(rows / u_openmm - 1.0).max() < 5e-6, np.abs(rows / u_openmm - 1.0).max()
+
+
+@pytest.mark.gpu
+def test_hip_engine_reproduces_openmm_reduced_potentials(hip_engine_factory, fixture):
+    """north_star: 'within 1e-5 relative on u_kl' — checked against the reference's (OpenMM's) numbers on config 3's
+    system: remd_set_system from OpenMM's XML, remd_compute_energies on OpenMM's frames, K = 20 temperatures."""
+    eng = hip_engine_factory()
+    rows, u_openmm = _engine_rows(eng, fixture)
+    assert rows.shape == (3, 20)
+    err = np.abs(rows / u_openmm - 1.0).max()
+    assert err < 1e-5, err
+
+
+@pytest.mark.gpu
+def test_hip_engine_from_amber_files_reproduces_openmm_too(hip_engine_factory, fixture):
+    """Same frames through the description this package builds from the prmtop (the product's own input path)."""
+    eng = hip_engine_factory()
+    own = dict(fixture, desc=system_to_desc(ts.AlanineDipeptideExplicit().system))
+    rows, u_openmm = _engine_rows(eng, own)
+    assert np.abs(rows / u_openmm - 1.0).max() < 1e-5
