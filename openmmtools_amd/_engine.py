@@ -57,7 +57,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or os.environ.get('REMD_HIP_LIB') or LIB_PATH        # REMD_HIP_LIB: A/B runs against another build of the same ABI
+    path = path or LIB_PATH        # another build of the same ABI only by an explicit lib_path (tests, tools): no environment hook
     if not os.path.exists(path):
         raise RuntimeError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                            '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)

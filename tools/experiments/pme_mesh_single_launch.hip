@@ -1,3 +1,23 @@
+// EXPERIMENT (round 3) -- NOT COMPILED INTO THE PRODUCT.  pme.hip with the reciprocal-space pipeline as ONE launch
+// (pme_mesh_kernel, REMD_PME_MESH1): row items (spread -> z -> y transform on the (y, z) slab of a mesh row), column items
+// (x transform, influence function, inverse x for all kz of one ky) and inverse row items (y, z inverse, force gather), all
+// 256 threads / 23.7 KB of LDS / 70 VGPRs, items waiting on per-replica arrival counters inside the launch (block-index
+// order, epoch counters, 16-byte write-through (sc1) spectrum stores through a buffer descriptor, one agent-scope acquire per
+// consuming workgroup).  Parity-green (forces within 1e-6 of the three-launch path: the influence table and the transforms
+// are the same expressions, contracted differently in the different kernels) and SLOWER:
+//     24 x alanine dipeptide, stand-alone: 197 us per evaluation against 30 + 67 + 45 = 142 us for the three launches;
+//     overlapped with the direct-space stream: 160.3 ms per 500 steps against 106.5 ms.
+// Why (in-kernel wall-clock stamps, REMD_MESH_TIMES=1; rocprofv3 SQ counters, tools/pmc_mesh.sh):
+//   * the same instruction work (30.4 M VALU wavefront-instructions per evaluation against 33.1 M for the three kernels) but
+//     twice the wavefront-cycles (625 M against 298 M): waves wait;
+//   * a write-through store is complete only when the fabric has it: 7 us of drain in front of every arrival even on an idle
+//     chip (plain stores + one agent-scope release fence: 20 us); an item of B / C holds its LDS and wave slots for 11 - 16 us
+//     until its replica's rows / columns are through -- a quarter of the slot-time;
+//   * per-workgroup times are throughput bound, not latency bound: 15 / 13 / 12 us (A / B / C) with 900 workgroups resident
+//     become 40 / 50 / 30 us with 1536; the "second round" of the old launches costs less than the slots lost to waiting;
+//   * without the acquire the consumer reads the previous evaluation's lines from its own XCD's L2 (garbage energies): sc1
+//     stores alone are not a hand-off on this chip.
+// Kept for the record of what was measured; see DESIGN.md section 7c.
 // Smooth particle-mesh Ewald reciprocal space (Essmann et al. 1995), batched over replicas (gfx950).
 //
 // Pipeline per force evaluation, all replicas at once (3 FFT launches):
@@ -14,6 +34,7 @@
 // itself pinned against direct Ewald summation.
 #include "remd_internal.h"
 #include <cmath>
+#include <cstring>
 #include <vector>
 #include <type_traits>
 
@@ -28,6 +49,18 @@ int remd_dftmm_build_table(remd_ctx* h, int n, void** d_table);
 void remd_dftmm_launch_xy(hipStream_t st, int n, int nplanes, int nzc, int nz, float2* spec, const void* table, const float* infl,
                           const float* gbound, int with_energy, double* energy, int n_eblk, int mode, long long* tdbg = nullptr);
 
+// (device-resident constants of the single-launch mesh pipeline, see pme_mesh_kernel)
+struct fft_plan_s { int n; int nrad; int radix[8]; };
+struct fft_sched_s { const uint2* tab; int off[8]; };
+struct mesh_const {
+    fft_plan_s plz, ply, plx; fft_sched_s scz, scy, scx;
+    int nx, ny, Npad, R, n_eblk, pad0;
+    const float4* pos; const float4* param; const float* box; const float* rep_lam;
+    float2* spec; const float2* twz; const float2* twzh; const float2* twy; const float2* twx;
+    const float* infl; double* energy; long long* force;
+    unsigned int* sync;            // [r] rows of replica r through A, [R + r] columns through B: monotonic, a launch waits for epoch * count
+    unsigned int* err;
+};
 struct pme_state {
     int n[4] = {0, 0, 0, 0};           // mesh dimensions; n[3] = nz / 2 (length of the packed real-to-complex z transform)
     int R = 0;
@@ -55,6 +88,11 @@ struct pme_state {
     int* d_cbin_count = nullptr; float4* d_cbin_atoms = nullptr; int cbin_cap = 0, cbin_parity = 0; bool cbin_use = false;
     void* d_dftmm = nullptr; bool xy_mfma = false;    // matrix-core XY pass (dft_mfma.hip): LDS image of the DFT matrix
     bool gather_fused = false;         // the inverse z launch already added the forces (pme_zinv_gather_kernel)
+    // single-launch mesh pipeline (pme_mesh_kernel): spectrum as row slabs [R][nx][ky][kz], influence table [R][ky][kx][kz]
+    bool mesh1 = false; int mesh_zt = 256; size_t mesh_lds = 0;
+    fft_sched sch_y2, sch_x2, sch_z2; uint2* d_sched2[3] = {nullptr, nullptr, nullptr};
+    unsigned int* d_mesh_sync = nullptr; unsigned int mesh_epoch = 0;
+    mesh_const* d_mesh_const = nullptr; mesh_const mesh_const_host;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -205,15 +243,20 @@ __device__ __forceinline__ void fft_stage_sched(float2* buf, const uint2* __rest
 
 // in-place FFT of nlines lines (element e of line l at buf[l*ls + e*es]); every thread keeps its share of the points in
 // registers across the barrier, so only ONE LDS image of the data is needed
-template <int SIGN, int PPT, bool WL>
-__device__ __forceinline__ void fft_lines_stages(const fft_plan& pl, const fft_sched& sc, float2* buf, int es,
+// plans and schedules are passed as pointers (kernel-argument structs or the constant address space): pl->radix[s] is
+// indexed at run time, which a by-value copy would turn into a private (scratch) array
+__device__ __forceinline__ int fft_sched_wave_local(const fft_sched* sc) { return sc->wave_local; }
+__device__ __forceinline__ int fft_sched_wave_local(const __attribute__((address_space(4))) fft_sched_s*) { return 0; }
+template <int SIGN, int PPT, bool WL, typename PLAN, typename SCHED>
+__device__ __forceinline__ void fft_lines_stages(PLAN pl, SCHED sc, float2* buf, int es,
                                                  const float2* __restrict__ tw, int tid, int nthreads)
 {
     int Ns = 1;
-    for (int s = 0; s < pl.nrad; ++s) {
-        const int Rx = pl.radix[s];
-        const int in_stride = (pl.n / Rx) * es, out_stride = Ns * es;
-        const uint2* tab = sc.tab + sc.off[s];
+    const int n = pl->n, nrad = pl->nrad;
+    for (int s = 0; s < nrad; ++s) {
+        const int Rx = pl->radix[s];
+        const int in_stride = (n / Rx) * es, out_stride = Ns * es;
+        const uint2* tab = sc->tab + sc->off[s];
         if (Rx == 4) fft_stage_sched<SIGN, 4, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
         else if (Rx == 5) fft_stage_sched<SIGN, 5, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
         else if (Rx == 3) fft_stage_sched<SIGN, 3, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
@@ -224,11 +267,11 @@ __device__ __forceinline__ void fft_lines_stages(const fft_plan& pl, const fft_s
 
 // in-place FFT of nlines lines (element e of line l at buf[l*ls + e*es]); every thread keeps its share of the points in
 // registers across the barrier, so only ONE LDS image of the data is needed
-template <int SIGN, int PPT>
-__device__ __forceinline__ void fft_lines_inplace(const fft_plan& pl, const fft_sched& sc, float2* buf, int es,
+template <int SIGN, int PPT, typename PLAN, typename SCHED>
+__device__ __forceinline__ void fft_lines_inplace(PLAN pl, SCHED sc, float2* buf, int es,
                                   const float2* __restrict__ tw, int tid, int nthreads)
 {
-    if (sc.wave_local) {
+    if (fft_sched_wave_local(sc)) {
         fft_lines_stages<SIGN, PPT, true>(pl, sc, buf, es, tw, tid, nthreads);
         __syncthreads();                                     // the next pass regroups the lines
     } else {
@@ -458,7 +501,7 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
         }
     }
     __syncthreads();
-    fft_lines_inplace<-1, Z_PPT>(pl, sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
+    fft_lines_inplace<-1, Z_PPT>(&pl, &sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
     float2* S = spec + (size_t)r * nzc * nx * ny;
     const unsigned mnl = fft_magic((unsigned)nl);
     for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
@@ -524,7 +567,7 @@ void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const fl
         }
         __syncthreads();
     }
-    fft_lines_inplace<+1, Z_PPT>(pl, sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
+    fft_lines_inplace<+1, Z_PPT>(&pl, &sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
     float* Mesh = mesh + (size_t)r * nx * ny * nz + (size_t)l0 * nz;
     const unsigned mM = fft_magic((unsigned)M);
     if (HALF) {
@@ -594,7 +637,7 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
         }
         __syncthreads();
     }
-    fft_lines_inplace<+1, Z_PPT>(pl, sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
+    fft_lines_inplace<+1, Z_PPT>(&pl, &sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
     // potential of line l at z: HALF keeps the real line as pairs (x[2n], x[2n+1]) = consecutive floats; else the real parts
     const float* phi = reinterpret_cast<const float*>(buf);
     const int zs = HALF ? 1 : 2, ls = 2 * PZ;
@@ -644,6 +687,448 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
     }
 }
 
+// ---- the whole mesh pipeline as ONE launch of uniform workgroups (round 3) ----------------------------------------------
+// A 3-D transform of the real charge mesh does not need an (x, y) plane in one workgroup: the workgroup that spreads the
+// charges of mesh row x holds the whole real (y, z) slab of that row in LDS, so it runs BOTH the (packed real-to-complex) z
+// transform and the y transform on it and writes the slab [ky][kz] of the half spectrum; what is left is a 1-D transform
+// along x, which a workgroup runs for all kz of one ky (a slab [x][kz] of exactly the same size) together with the
+// influence function and the inverse x transform; the inverse row pass mirrors the first.  Three phases of items
+//     A (r, x)  : spread -> z forward -> y forward                      -> spec[r][x][ky][kz]
+//     B (r, ky) : x forward -> influence function (+ energy) -> x inverse   (in place)
+//     C (r, x)  : y inverse -> z inverse -> force gather from the slab in LDS
+// with the same shape (ZT threads, ny x (nz/2+1) complex points in LDS, <= 64 VGPRs), so they live in ONE kernel and ONE
+// launch: a workgroup draws a ticket (its item: all A items, then all B, then all C, replica-major), and an item of B / C
+// waits on a per-replica arrival counter of the phase in front of it.  Tickets are drawn in the order workgroups start,
+// so an item only ever waits for items that are already running or done: no assumption about dispatch order, no
+// deadlock.  What this buys: (1) no workgroup needs a 45 KB plane any more (888 planes on 768 LDS slots made the XY pass
+// run two rounds, every launch); (2) the tail of a phase (1800 rows on 1536 slots) is filled by the next phase's items of
+// the replicas that are already complete instead of idling the chip; (3) two dependent launches fewer per step.
+// The arithmetic of every 1-D transform, the untangling and the influence product is the three-launch path's, so forces
+// are bit-identical to it (fixed-point sums; tests/test_forcefield_parity.py::test_mesh_single_launch_equals_three_launches).
+// Hand-off between workgroups inside the launch (MI355X: per-XCD L2s are not coherent): the spectrum is stored and loaded
+// with agent-scope relaxed atomics (sc1: write-through / L1-bypassing), every storing wave drains its stores before the
+// barrier in front of the arrival, the consumer polls with one lane (cdna_hip_programming.md, guideline 16 form R1).
+// what does not change from launch to launch lives in device memory and is read through the constant address space (scalar
+// loads where they are needed): as kernel arguments the three plans and schedules were preloaded into ~100 SGPRs, the
+// overflow went to VGPRs and the kernel needed 114 of them
+struct mesh_args {
+    const mesh_const* c;
+    const int* col_start; const int* col_atoms; const float* bin_q; int* zero_count;
+    int bin_cap, with_energy;
+    unsigned int epoch, fork_seq; unsigned int* fork_flag;
+    long long* tdbg;               // REMD_MESH_TIMES: [grid][4] wall-clock stamps (start, wait over, end) or NULL
+};
+typedef const __attribute__((address_space(4))) mesh_const* mesh_const_ptr;
+#ifndef MESH_WPE
+#define MESH_WPE 6         // minimum wavefronts per SIMD the register allocation is held to (0: none)
+#endif
+#ifndef MESH_SLEEP
+#define MESH_SLEEP 2
+#endif
+#ifndef MESH_GATHER_UNROLL
+#define MESH_GATHER_UNROLL 1   // the y loop of the force gather stays rolled: 68 instead of 98 VGPRs
+#endif
+#ifndef MESH_FENCE
+#define MESH_FENCE 1       // bit 0: agent-scope acquire behind a wait (needed: the reader's L2 may hold the line from the
+                           // previous evaluation; measured: garbage without it), bit 1: release before an arrival (plain stores)
+#endif
+#ifndef MESH_IO
+#define MESH_IO 1          // 0: plain loads / stores (timing experiments only: NOT coherent across XCDs), 1: 8-byte sc1
+#endif
+typedef unsigned int mesh_u32x4 __attribute__((ext_vector_type(4)));
+// spectrum traffic between workgroups: 16-byte accesses through a buffer descriptor; stores are write-through (sc1: the bytes
+// leave the XCD's L2, nothing to write back at the arrival; 8-byte sc1 stores are one fabric write per lane and measured
+// 2x slower per item), loads are plain behind the reader's agent-scope acquire
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mesh_rsrc(const void* base, unsigned int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void mesh_st2(__amdgpu_buffer_rsrc_t rs, unsigned int byte_off, float2 a, float2 b)
+{
+    mesh_u32x4 v = { __float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x), __float_as_uint(b.y) };
+#if MESH_IO == 0
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 0);
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16);      // aux 16 = sc1
+#endif
+}
+__device__ __forceinline__ mesh_u32x4 mesh_ld2(__amdgpu_buffer_rsrc_t rs, unsigned int byte_off)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+}
+__device__ __forceinline__ void mesh_wait(const unsigned int* cnt, unsigned int target, unsigned int* err, int tid)
+{
+    if (tid == 0) {
+        long long n = 0;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(MESH_SLEEP);
+            if (++n > (1ll << 24)) { atomicExch(err, 3u); break; }       // something upstream died: say so instead of hanging
+        }
+#if MESH_FENCE & 1
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void mesh_arrive(unsigned int* cnt, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) {
+#if MESH_FENCE & 2
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// the three item kinds (inlined: as real calls the argument block went through 672 bytes of scratch per lane)
+template <int ZT>
+__device__ __forceinline__ long long mesh_rows_fwd(const mesh_args& a, int it, int ticket, long long* ts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const mesh_const_ptr c = (mesh_const_ptr)a.c;
+    const int M = c->plz.n, nz = 2 * M, nzc = M + 1, PZ = (M + 1) | 1;
+    const int nx = c->nx, ny = c->ny, nmax = nx > ny ? nx : ny;
+    float2* buf = reinterpret_cast<float2*>(smem);          // [ny or nx][PZ]
+    float2* s_tw = buf + nmax * PZ;                         // [nz] twiddles of the full z length (untangling)
+    float2* s_twh = s_tw + nz;                              // [M] twiddles of the packed z transform
+    float2* s_twl = s_twh + M;                              // [nmax] twiddles of the y (A, C) or x (B) transform
+    double* s_e = reinterpret_cast<double*>(s_twl + nmax + (nmax & 1));
+    const int tid = threadIdx.x;
+    const int nzp = nzc + (nzc & 1), hp = nzp / 2;          // global rows are padded to an even number of complex points: 16-byte pairs
+    const unsigned mM = fft_magic((unsigned)M), mhp = fft_magic((unsigned)hp);
+    constexpr int PAIRS = (Z_PPT + 1) / 2 + 1;               // 16-byte pairs per thread (the pad column adds a few)
+    (void)s_e; (void)mM; (void)s_tw; (void)s_twh;
+    long long t_wait = 0;
+    const int r = it / nx, x = it - r * nx;
+    const int nl = ny;
+    for (int idx = tid; idx < nz; idx += ZT) s_tw[idx] = c->twz[idx];
+    for (int idx = tid; idx < M; idx += ZT) s_twh[idx] = c->twzh[idx];
+    for (int idx = tid; idx < ny; idx += ZT) s_twl[idx] = c->twy[idx];
+    const int* cs = a.col_start + (size_t)r * (a.bin_cap > 0 ? nx : nx + 1);
+    const int* ca = a.col_atoms + (size_t)r * (a.bin_cap > 0 ? (size_t)nx * a.bin_cap * 4 : (size_t)c->Npad);
+    const float* cq = a.bin_q ? a.bin_q + (size_t)r * nx * a.bin_cap : (const float*)nullptr;
+    const float4* P = c->pos + (size_t)r * c->Npad;
+    const __amdgpu_buffer_rsrc_t rs = mesh_rsrc(c->spec + ((size_t)r * nx + x) * ny * nzp, (unsigned)(ny * nzp * sizeof(float2)));   // this row's slab [ky][nzp]
+    const unsigned mnl = fft_magic((unsigned)nl);
+    int* acc = reinterpret_cast<int*>(buf);             // [nl][nz] aliases buf: converted through registers below
+    for (int idx = tid; idx < nl * nz; idx += ZT) acc[idx] = 0;
+    if (a.zero_count && x == 0) for (int k = tid; k < nx; k += ZT) a.zero_count[(size_t)r * nx + k] = 0;   // the bins of the NEXT evaluation
+    if (a.fork_flag && ticket == 0 && tid == 0)             // positions are final: the direct-space stream may start
+        __hip_atomic_store(a.fork_flag, a.fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    {
+        const pme_cand cnd = pme_candidates(cs, x, nx, a.bin_cap);
+        const int ntot = cnd.ntot;
+        for (int t = tid; t < ntot; t += ZT) {
+            float4 xi; float q;
+            pme_cand_atom(cnd, ca, t, a.bin_cap > 0, P, xi, cq, c->param, c->rep_lam, r, q);
+            if (q == 0.f) continue;
+            float ux, uy, uz; int kx, ky, kz;
+            pme_scaled(xi, c->box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+            float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
+            bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
+            if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+            int s = kx - x; if (s < 0) s += nx;              // 0..4 by construction of the bins
+            float wa = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (k == s) wa = wx[k];
+            const float qa = q * wa * PME_MESH_SCALE;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                int iy = ky - b; if (iy < 0) iy += ny;
+                const float qab = qa * wy[b];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    int iz = kz - c; if (iz < 0) iz += nz;
+                    atomicAdd(&acc[iy * nz + iz], __float2int_rn(qab * wz[c]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (a.tdbg) ts[0] = (long long)wall_clock64();           // charges spread
+    {
+        float2 val[Z_PPT];
+#pragma unroll
+        for (int q = 0; q < Z_PPT; ++q) {
+            const int idx = tid + q * ZT;                    // complex point: line l = idx / M, element n = idx % M
+            val[q] = make_float2(0.f, 0.f);
+            if (idx < nl * M) { const int2 w = reinterpret_cast<const int2*>(acc)[idx]; val[q] = make_float2((float)w.x * (1.0f / PME_MESH_SCALE), (float)w.y * (1.0f / PME_MESH_SCALE)); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Z_PPT; ++q) {
+            const int idx = tid + q * ZT;
+            if (idx < nl * M) { const int l = fft_div(idx, mM, M); buf[idx + l * (PZ - M)] = val[q]; }   // l*PZ + n
+        }
+    }
+    __syncthreads();
+    fft_lines_inplace<-1, Z_PPT>(&c->plz, &c->scz, buf, 1, s_twh, tid, ZT);
+    // untangle in place: the pair (k, M - k) is owned by one thread; X[M] goes to the slot behind the line
+    for (int idx = tid; idx < nl * (M / 2 + 1); idx += ZT) {
+        const int k = fft_div(idx, mnl, nl), b = idx - k * nl;
+        const int km = (k == 0) ? 0 : M - k;
+        const float2 Zk = buf[b * PZ + k], Zm = buf[b * PZ + km];
+        const float2 E = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));          // (Z[k] + conj Z[M-k]) / 2
+        const float2 O = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));         // -(i/2) (Z[k] - conj Z[M-k])
+        buf[b * PZ + k] = cadd(E, cmul(s_tw[k], O));
+        if (k == 0) {
+            buf[b * PZ + M] = cadd(E, cmul(s_tw[M], O));
+        } else if (k != km) {
+            const float2 E2 = make_float2(0.5f * (Zm.x + Zk.x), 0.5f * (Zm.y - Zk.y));
+            const float2 O2 = make_float2(0.5f * (Zm.y + Zk.y), -0.5f * (Zm.x - Zk.x));
+            buf[b * PZ + km] = cadd(E2, cmul(s_tw[km], O2));
+        }
+    }
+    __syncthreads();
+    fft_lines_inplace<-1, Z_PPT>(&c->ply, &c->scy, buf, PZ, s_twl, tid, ZT);       // along y: nzc lines, element stride PZ
+    if (a.tdbg) ts[1] = (long long)wall_clock64();           // transforms done
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        // pair p = (ky, kz = 2 j), contiguous in the slab; no branches around the memory operations: a pair beyond the slab is
+        // out of the descriptor's range (dropped by the hardware), its LDS reads are clamped
+        const int p = tid + q * ZT, pc = min(p, ny * hp - 1);
+        const int ky = fft_div(pc, mhp, hp), kz = 2 * (pc - ky * hp);
+        const float2 v0 = buf[ky * PZ + kz], v1t = buf[ky * PZ + min(kz + 1, nzc - 1)];
+        const float2 v1 = (kz + 1 < nzc) ? v1t : make_float2(0.f, 0.f);
+        mesh_st2(rs, (unsigned)p * 16u, v0, v1);
+    }
+    mesh_arrive(c->sync + r, tid);
+    return t_wait;
+}
+
+template <int ZT>
+__device__ __forceinline__ long long mesh_rows_inv(const mesh_args& a, int it, long long* ts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const mesh_const_ptr c = (mesh_const_ptr)a.c;
+    const int M = c->plz.n, nz = 2 * M, nzc = M + 1, PZ = (M + 1) | 1;
+    const int nx = c->nx, ny = c->ny, nmax = nx > ny ? nx : ny;
+    float2* buf = reinterpret_cast<float2*>(smem);          // [ny or nx][PZ]
+    float2* s_tw = buf + nmax * PZ;                         // [nz] twiddles of the full z length (untangling)
+    float2* s_twh = s_tw + nz;                              // [M] twiddles of the packed z transform
+    float2* s_twl = s_twh + M;                              // [nmax] twiddles of the y (A, C) or x (B) transform
+    double* s_e = reinterpret_cast<double*>(s_twl + nmax + (nmax & 1));
+    const int tid = threadIdx.x;
+    const int nzp = nzc + (nzc & 1), hp = nzp / 2;          // global rows are padded to an even number of complex points: 16-byte pairs
+    const unsigned mM = fft_magic((unsigned)M), mhp = fft_magic((unsigned)hp);
+    constexpr int PAIRS = (Z_PPT + 1) / 2 + 1;               // 16-byte pairs per thread (the pad column adds a few)
+    (void)s_e; (void)mM; (void)s_tw; (void)s_twh;
+    long long t_wait = 0;
+    const int r = it / nx, x = it - r * nx;
+    const int nl = ny;
+    for (int idx = tid; idx < nz; idx += ZT) s_tw[idx] = c->twz[idx];
+    for (int idx = tid; idx < M; idx += ZT) s_twh[idx] = c->twzh[idx];
+    for (int idx = tid; idx < ny; idx += ZT) s_twl[idx] = c->twy[idx];
+    const int* cs = a.col_start + (size_t)r * (a.bin_cap > 0 ? nx : nx + 1);
+    const int* ca = a.col_atoms + (size_t)r * (a.bin_cap > 0 ? (size_t)nx * a.bin_cap * 4 : (size_t)c->Npad);
+    const float* cq = a.bin_q ? a.bin_q + (size_t)r * nx * a.bin_cap : (const float*)nullptr;
+    const float4* P = c->pos + (size_t)r * c->Npad;
+    const __amdgpu_buffer_rsrc_t rs = mesh_rsrc(c->spec + ((size_t)r * nx + x) * ny * nzp, (unsigned)(ny * nzp * sizeof(float2)));   // this row's slab [ky][nzp]
+    const unsigned mnl = fft_magic((unsigned)nl);
+    mesh_wait(c->sync + c->R + r, a.epoch * (unsigned)ny, c->err, tid);
+    if (a.tdbg) t_wait = (long long)wall_clock64();
+    {
+        // all loads of a thread in flight at once (a load per loop trip would pay the memory latency Z_PPT times)
+        mesh_u32x4 val[PAIRS];
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) val[q] = mesh_ld2(rs, (unsigned)(tid + q * ZT) * 16u);     // beyond the slab: out of range, reads 0
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            const int p = tid + q * ZT;
+            if (p < ny * hp) {
+                const int ky = fft_div(p, mhp, hp), kz = 2 * (p - ky * hp);
+                buf[ky * PZ + kz] = make_float2(__uint_as_float(val[q].x), __uint_as_float(val[q].y));
+                if (kz + 1 < nzc) buf[ky * PZ + kz + 1] = make_float2(__uint_as_float(val[q].z), __uint_as_float(val[q].w));
+            }
+        }
+    }
+    __syncthreads();
+    if (a.tdbg) ts[0] = (long long)wall_clock64();           // slab loaded
+    fft_lines_inplace<+1, Z_PPT>(&c->ply, &c->scy, buf, PZ, s_twl, tid, ZT);
+    for (int idx = tid; idx < nl * (M / 2 + 1); idx += ZT) {
+        const int k = fft_div(idx, mnl, nl), b = idx - k * nl;
+        const float2 Xk = buf[b * PZ + k], Xm = buf[b * PZ + M - k];
+        const float2 A = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);
+        const float2 B = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);
+        const float2 w = s_tw[k];
+        const float2 t = cmul(make_float2(w.x, -w.y), B);
+        buf[b * PZ + k] = make_float2(A.x - t.y, A.y + t.x);
+        if (k != 0 && k != M - k) {
+            const float2 u = cmul(w, make_float2(B.x, -B.y));
+            buf[b * PZ + M - k] = make_float2(A.x - u.y, -A.y + u.x);
+        }
+    }
+    __syncthreads();
+    fft_lines_inplace<+1, Z_PPT>(&c->plz, &c->scz, buf, 1, s_twh, tid, ZT);
+    if (a.tdbg) ts[1] = (long long)wall_clock64();           // transforms done
+    const float* phi = reinterpret_cast<const float*>(buf);         // the real line as pairs (x[2n], x[2n+1]) = consecutive floats
+    const int ls = 2 * PZ;
+    const float Lx = c->box[4 * r], Ly = c->box[4 * r + 1], Lz = c->box[4 * r + 2];
+    unsigned long long* F = reinterpret_cast<unsigned long long*>(c->force + (size_t)r * 3 * c->Npad);
+    const pme_cand cnd = pme_candidates(cs, x, nx, a.bin_cap);
+    const int ntot = cnd.ntot;
+    for (int t = tid; t < ntot; t += ZT) {
+        float4 xi; float q;
+        const int i = pme_cand_atom(cnd, ca, t, a.bin_cap > 0, P, xi, cq, c->param, c->rep_lam, r, q);
+        if (q == 0.f) continue;
+        float ux, uy, uz; int kx, ky, kz;
+        pme_scaled(xi, c->box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+        float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
+        bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
+        if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+        int s = kx - x; if (s < 0) s += nx;
+        float wxa = 0.f, dxa = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (k == s) { wxa = wx[k]; dxa = dx[k]; }
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll MESH_GATHER_UNROLL
+        for (int b = 0; b < 5; ++b) {
+            int iy = ky - b; if (iy < 0) iy += ny;
+            float sx = 0.f, sz = 0.f;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                int iz = kz - c; if (iz < 0) iz += nz;
+                const float p = phi[iy * ls + iz];
+                sx += wz[c] * p; sz += dz[c] * p;
+            }
+            gx += wy[b] * sx; gy += dy[b] * sx; gz += wy[b] * sz;
+        }
+        const float Fx = -q * dxa * gx * nx / Lx, Fy = -q * wxa * gy * ny / Ly, Fz = -q * wxa * gz * nz / Lz;
+        atomicAdd(&F[i], remd_f2fix(Fx));
+        atomicAdd(&F[c->Npad + i], remd_f2fix(Fy));
+        atomicAdd(&F[2 * c->Npad + i], remd_f2fix(Fz));
+    }
+    return t_wait;
+}
+
+template <int ZT>
+__device__ __forceinline__ long long mesh_cols(const mesh_args& a, int it, long long* ts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const mesh_const_ptr c = (mesh_const_ptr)a.c;
+    const int M = c->plz.n, nz = 2 * M, nzc = M + 1, PZ = (M + 1) | 1;
+    const int nx = c->nx, ny = c->ny, nmax = nx > ny ? nx : ny;
+    float2* buf = reinterpret_cast<float2*>(smem);          // [ny or nx][PZ]
+    float2* s_tw = buf + nmax * PZ;                         // [nz] twiddles of the full z length (untangling)
+    float2* s_twh = s_tw + nz;                              // [M] twiddles of the packed z transform
+    float2* s_twl = s_twh + M;                              // [nmax] twiddles of the y (A, C) or x (B) transform
+    double* s_e = reinterpret_cast<double*>(s_twl + nmax + (nmax & 1));
+    const int tid = threadIdx.x;
+    const int nzp = nzc + (nzc & 1), hp = nzp / 2;          // global rows are padded to an even number of complex points: 16-byte pairs
+    const unsigned mM = fft_magic((unsigned)M), mhp = fft_magic((unsigned)hp);
+    constexpr int PAIRS = (Z_PPT + 1) / 2 + 1;               // 16-byte pairs per thread (the pad column adds a few)
+    (void)s_e; (void)mM; (void)s_tw; (void)s_twh;
+    long long t_wait = 0;
+    // ---- column items: all kz of one ky; slab [x][kz] ------------------------------------------------------------
+    const int r = it / ny, ky = it - r * ny;
+    for (int idx = tid; idx < nx; idx += ZT) s_twl[idx] = c->twx[idx];
+    mesh_wait(c->sync + r, a.epoch * (unsigned)nx, c->err, tid);
+    if (a.tdbg) t_wait = (long long)wall_clock64();
+    // element (x, kz) of this column at byte ((x * ny + ky) * nzp + kz) * 8 of the replica's spectrum
+    const __amdgpu_buffer_rsrc_t rs = mesh_rsrc(c->spec + (size_t)r * nx * ny * nzp, (unsigned)((size_t)nx * ny * nzp * sizeof(float2)));
+    const unsigned mnzc = fft_magic((unsigned)nzc);
+    {
+        mesh_u32x4 val[PAIRS];
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            const int p = tid + q * ZT;
+            const int kx = fft_div(p, mhp, hp), j = p - kx * hp;
+            val[q] = mesh_ld2(rs, p < nx * hp ? (unsigned)(((kx * ny + ky) * nzp + 2 * j) * 8) : 0xfffffff0u);     // out of range: reads 0
+        }
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            const int p = tid + q * ZT;
+            if (p < nx * hp) {
+                const int kx = fft_div(p, mhp, hp), kz = 2 * (p - kx * hp);
+                buf[kx * PZ + kz] = make_float2(__uint_as_float(val[q].x), __uint_as_float(val[q].y));
+                if (kz + 1 < nzc) buf[kx * PZ + kz + 1] = make_float2(__uint_as_float(val[q].z), __uint_as_float(val[q].w));
+            }
+        }
+    }
+    __syncthreads();
+    if (a.tdbg) ts[0] = (long long)wall_clock64();           // slab loaded
+    fft_lines_inplace<-1, Z_PPT>(&c->plx, &c->scx, buf, PZ, s_twl, tid, ZT);
+    {
+        const float* __restrict__ G = c->infl + ((size_t)r * ny + ky) * nx * nzc;       // [r][ky][kx][kz]
+        double e_acc = 0.0;
+        float gv[Z_PPT];
+#pragma unroll
+        for (int q = 0; q < Z_PPT; ++q) { const int idx = tid + q * ZT; gv[q] = G[min(idx, nx * nzc - 1)]; }
+#pragma unroll
+        for (int q = 0; q < Z_PPT; ++q) {
+            const int idx = tid + q * ZT;
+            if (idx < nx * nzc) {
+                const int kx = fft_div(idx, mnzc, nzc), kz = idx - kx * nzc;
+                const float g = gv[q];
+                const float2 sv = buf[kx * PZ + kz];
+                if (a.with_energy) {
+                    const float wz = (kz == 0 || kz == M) ? 1.f : 2.f;          // Hermitian half: weight of the mirrored plane
+                    e_acc += 0.5 * (double)(wz * g) * ((double)sv.x * sv.x + (double)sv.y * sv.y);
+                }
+                buf[kx * PZ + kz] = make_float2(sv.x * g, sv.y * g);
+            }
+        }
+        if (a.with_energy) {
+            for (int off = 32; off > 0; off >>= 1) e_acc += __shfl_xor(e_acc, off);
+            if ((tid & 63) == 0) s_e[tid >> 6] = e_acc;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < ZT / 64; ++w) tot += s_e[w];
+                c->energy[(size_t)r * c->n_eblk + ky] = tot;
+            }
+        }
+        __syncthreads();
+    }
+    fft_lines_inplace<+1, Z_PPT>(&c->plx, &c->scx, buf, PZ, s_twl, tid, ZT);
+    if (a.tdbg) ts[1] = (long long)wall_clock64();           // transforms done
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const int p = tid + q * ZT, pc = min(p, nx * hp - 1);
+        const int kx = fft_div(pc, mhp, hp), kz = 2 * (pc - kx * hp);
+        const float2 v0 = buf[kx * PZ + kz], v1t = buf[kx * PZ + min(kz + 1, nzc - 1)];
+        const float2 v1 = (kz + 1 < nzc) ? v1t : make_float2(0.f, 0.f);
+        mesh_st2(rs, p < nx * hp ? (unsigned)(((kx * ny + ky) * nzp + kz) * 8) : 0xfffffff0u, v0, v1);
+    }
+    mesh_arrive(c->sync + c->R + r, tid);
+    return t_wait;
+}
+
+template <int ZT>
+__global__ __launch_bounds__(ZT)
+#if MESH_WPE
+__attribute__((amdgpu_waves_per_eu(MESH_WPE, 8)))
+#endif
+void pme_mesh_kernel(mesh_args a)
+{
+    __builtin_amdgcn_s_setprio(3);
+    // item = block index: all A items, then all B, then all C, replica-major.  An item of B / C waits only for items with a
+    // LOWER index; the dispatcher hands out workgroups in index order, so those are running or done (the spins are bounded
+    // and report through the error flag instead of hanging should that ever not hold)
+    const int ticket = (int)blockIdx.x;
+    const mesh_const_ptr c = (mesh_const_ptr)a.c;
+    const int nA = c->R * c->nx, nB = c->R * c->ny;
+    long long t_start = 0, t_wait = 0; long long ts[2] = {0, 0};
+    if (a.tdbg) t_start = (long long)wall_clock64();
+#ifdef MESH_ONLY
+    if (MESH_ONLY == 1) t_wait = mesh_rows_fwd<ZT>(a, ticket, ticket, ts);
+    if (MESH_ONLY == 2) t_wait = mesh_cols<ZT>(a, ticket - nA, ts);
+    if (MESH_ONLY == 3) t_wait = mesh_rows_inv<ZT>(a, ticket - nA - nB, ts);
+#else
+    if (ticket < nA) t_wait = mesh_rows_fwd<ZT>(a, ticket, ticket, ts);
+    else if (ticket < nA + nB) t_wait = mesh_cols<ZT>(a, ticket - nA, ts);
+    else t_wait = mesh_rows_inv<ZT>(a, ticket - nA - nB, ts);
+#endif
+    if (a.tdbg && threadIdx.x == 0) {
+        long long* T = a.tdbg + 6 * (size_t)blockIdx.x;
+        T[0] = t_start; T[1] = t_wait ? t_wait : t_start; T[2] = (long long)wall_clock64(); T[3] = ts[0]; T[4] = ts[1]; T[5] = 0;
+    }
+}
+
 // Influence function G(kx, ky, kz) = exp(-pi^2 m^2 / alpha^2) / (pi V m^2 |b_x b_y b_z|^2) of every replica's box, laid out
 // like the half spectrum.  It only depends on the box, so it is tabulated when a box changes (NVT: once) instead of being
 // recomputed (~45 VALU instructions per mesh point incl. an IEEE division and an exp) in every XY pass.
@@ -680,6 +1165,30 @@ void pme_influence_table_kernel(int nx, int ny, int nz, const float* __restrict_
     }
 }
 
+// the same table laid out for the single-launch pipeline: [R][ky][kx][kz] (one contiguous run per column item)
+__global__ __launch_bounds__(256)
+void pme_influence_table2_kernel(int nx, int ny, int nz, const float* __restrict__ bmx, const float* __restrict__ bmy,
+                                 const float* __restrict__ bmz, const float* __restrict__ box, float alpha, float* __restrict__ infl)
+{
+    const int ky = blockIdx.x, r = blockIdx.y, nzc = nz / 2 + 1;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const double V = (double)Lx * Ly * Lz;
+    const float pref = (float)(1.0 / (M_PI * V));
+    const float fac = (float)(M_PI * M_PI) / (alpha * alpha);
+    const int m1 = (ky <= ny / 2) ? ky : ky - ny;
+    const float my = m1 / Ly;
+    float* G = infl + ((size_t)r * ny + ky) * nx * nzc;
+    for (int idx = threadIdx.x; idx < nx * nzc; idx += blockDim.x) {
+        const int kx = idx / nzc, kz = idx - kx * nzc;
+        const int m0 = (kx <= nx / 2) ? kx : kx - nx;
+        const float mx = m0 / Lx, mz = kz / Lz;
+        const float msq = mx * mx + my * my + mz * mz;
+        float g = 0.f;
+        if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bmz[kz]);
+        G[idx] = g;
+    }
+}
+
 // one (kz, replica) plane resident in LDS: forward y, forward x, influence function (+ energy), inverse x, inverse y.
 // In-place stages: LDS = nx (ny+1) 8 B (52 KB for 80 x 80) => three workgroups per CU overlap their load / FFT / store.
 #define XY_MAX_THREADS 1024
@@ -711,8 +1220,8 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
     for (int idx = tid; idx < ny; idx += XY_THREADS) s_twy[idx] = twy[idx];
     twx = s_twx; twy = s_twy;
     __syncthreads();
-    fft_lines_inplace<-1, XY_PPT>(ply, scy, buf, 1, twy, tid, XY_THREADS);      // along y
-    fft_lines_inplace<-1, XY_PPT>(plx, scx, buf, PS, twx, tid, XY_THREADS);     // along x
+    fft_lines_inplace<-1, XY_PPT>(&ply, &scy, buf, 1, twy, tid, XY_THREADS);      // along y
+    fft_lines_inplace<-1, XY_PPT>(&plx, &scx, buf, PS, twx, tid, XY_THREADS);     // along x
     {
         const float wz = (kz == 0 || 2 * kz == nz) ? 1.f : 2.f;     // Hermitian half: weight of the mirrored plane
         const float* __restrict__ G = infl + ((size_t)r * nzc + kz) * np;
@@ -736,8 +1245,8 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
         }
         __syncthreads();
     }
-    fft_lines_inplace<+1, XY_PPT>(plx, scx, buf, PS, twx, tid, XY_THREADS);
-    fft_lines_inplace<+1, XY_PPT>(ply, scy, buf, 1, twy, tid, XY_THREADS);
+    fft_lines_inplace<+1, XY_PPT>(&plx, &scx, buf, PS, twx, tid, XY_THREADS);
+    fft_lines_inplace<+1, XY_PPT>(&ply, &scy, buf, 1, twy, tid, XY_THREADS);
     for (int idx = tid; idx < np; idx += XY_THREADS) { const int x = fft_div(idx, mny, ny); P[idx] = buf[idx + x * pad]; }
 }
 
@@ -763,7 +1272,7 @@ void pme_x_fused_kernel(fft_plan plx, fft_sched scx, int ny, int nz, int sw, flo
     for (int idx = tid; idx < nx * sw; idx += XS_THREADS) { const int x = fft_div(idx, msw, sw), yy = idx - x * sw; buf[x * PS + yy] = P[x * ny + y0 + yy]; }
     for (int idx = tid; idx < nx; idx += XS_THREADS) s_twx[idx] = twx[idx];
     __syncthreads();
-    fft_lines_inplace<-1, XY_PPT>(plx, scx, buf, PS, s_twx, tid, XS_THREADS);
+    fft_lines_inplace<-1, XY_PPT>(&plx, &scx, buf, PS, s_twx, tid, XS_THREADS);
     const float wz = (kz == 0 || 2 * kz == nz) ? 1.f : 2.f;
     double e_acc = 0.0;
     for (int idx = tid; idx < nx * sw; idx += XS_THREADS) {
@@ -784,7 +1293,7 @@ void pme_x_fused_kernel(fft_plan plx, fft_sched scx, int ny, int nz, int sw, flo
         }
     }
     __syncthreads();
-    fft_lines_inplace<+1, XY_PPT>(plx, scx, buf, PS, s_twx, tid, XS_THREADS);
+    fft_lines_inplace<+1, XY_PPT>(&plx, &scx, buf, PS, s_twx, tid, XS_THREADS);
     for (int idx = tid; idx < nx * sw; idx += XS_THREADS) { const int x = fft_div(idx, msw, sw), yy = idx - x * sw; P[x * ny + y0 + yy] = buf[x * PS + yy]; }
 }
 
@@ -964,6 +1473,9 @@ int remd_pme_destroy(remd_ctx* h)
     if (s->d_cbin_count) hipFree(s->d_cbin_count); if (s->d_cbin_atoms) hipFree(s->d_cbin_atoms); if (s->d_cbin_q) hipFree(s->d_cbin_q);
     if (s->d_gmax) hipFree(s->d_gmax);
     for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
+    for (int k = 0; k < 3; ++k) if (s->d_sched2[k]) hipFree(s->d_sched2[k]);
+    if (s->d_mesh_sync) hipFree(s->d_mesh_sync);
+    if (s->d_mesh_const) hipFree(s->d_mesh_const);
     delete s;
     h->pme = nullptr;
     return 0;
@@ -1064,7 +1576,8 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->npts * s->R));
     } else {
         REMD_CHECK(h, hipMalloc(&s->d_mesh, sizeof(int) * s->npts * s->R));
-        REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->nspec * s->R));
+        // (the single-launch pipeline pads the kz rows of its slabs to an even number of points)
+        REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * (size_t)s->n[0] * s->n[1] * (s->nzc + (s->nzc & 1)) * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_start, sizeof(int) * (size_t)(s->n[0] + 1) * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_atoms, sizeof(int) * (size_t)h->Npad * s->R));
         if (!full_complex && !(getenv("REMD_PME_CHAINBIN") && atoi(getenv("REMD_PME_CHAINBIN")) == 0)) {
@@ -1166,6 +1679,30 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         if (!rc) rc = build_sched(h, s, 0, s->n[1], 1, PS, s->xy_threads, XY_PPT, &s->sch_x, &s->d_sched[0], true);  // along x: lines = y columns
         if (rc) return rc;
     }
+    // single-launch pipeline: the whole row (ny lines) and a whole column slab fit the registers of one workgroup
+    if (!full_complex && s->z_half && !(getenv("REMD_PME_MESH1") && atoi(getenv("REMD_PME_MESH1")) == 0)) {
+        const int M = s->n[3], nzc = M + 1, PZ = (M + 1) | 1, nmax = std::max(s->n[0], s->n[1]);
+        const long long need = std::max((long long)s->n[1] * M, (long long)nmax * nzc);
+        const int zt = need <= (long long)Z_PPT * 256 ? 256 : 512;
+        if (need <= (long long)Z_PPT * zt && (long long)nmax * PZ <= 0xffff) {
+            s->mesh_zt = zt;
+            s->mesh_lds = sizeof(float2) * ((size_t)nmax * PZ + s->n[2] + M + nmax + (nmax & 1)) + sizeof(double) * (zt / 64) + 16;
+            int rc = build_sched(h, s, 3, s->n[1], PZ, 1, zt, Z_PPT, &s->sch_z2, &s->d_sched2[2]);                 // z: ny lines of M points
+            if (!rc) rc = build_sched(h, s, 1, nzc, 1, PZ, zt, Z_PPT, &s->sch_y2, &s->d_sched2[1]);               // y: nzc lines, stride PZ
+            if (!rc) rc = build_sched(h, s, 0, nzc, 1, PZ, zt, Z_PPT, &s->sch_x2, &s->d_sched2[0]);               // x: the same shape
+            if (rc) return rc;
+            REMD_CHECK(h, hipMalloc(&s->d_mesh_sync, sizeof(unsigned int) * 2 * (size_t)s->R));
+            REMD_CHECK(h, hipMemset(s->d_mesh_sync, 0, sizeof(unsigned int) * 2 * (size_t)s->R));
+            REMD_CHECK(h, hipMalloc(&s->d_mesh_const, sizeof(mesh_const)));
+            memset(&s->mesh_const_host, 0xff, sizeof(mesh_const));
+            REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_mesh_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_mesh_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            s->mesh1 = true;
+            s->n_eblk = s->n[1];
+            hipFree(s->d_energy); s->d_energy = nullptr;
+            REMD_CHECK(h, hipMalloc(&s->d_energy, sizeof(double) * (size_t)s->n_eblk * s->R));
+        }
+    }
 #define Z_LDS_ATTR(ZT, HF) \
     REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel<ZT, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
     REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel<ZT, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1211,7 +1748,74 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
                            s->d_col_start, s->d_col_atoms, h->fork_seq_pending ? h->d_sync : (unsigned int*)nullptr, h->fork_seq_pending);
         h->fork_seq_pending = 0;
     }
-    {
+    if (s->mesh1) {
+        remd_prof_scope ps(h, "pme_mesh", st);
+        if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
+        if (s->infl_version != h->box_version) {
+            hipLaunchKernelGGL(pme_influence_table2_kernel, dim3(ny, s->R), dim3(256), 0, st, nx, ny, nz, s->d_bmod[0], s->d_bmod[1],
+                               s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl);
+            s->infl_version = h->box_version;
+        }
+        mesh_const mc;
+        memset(&mc, 0, sizeof(mc));
+        auto slim = [&](int axis) { fft_plan_s q; q.n = s->n[axis]; q.nrad = s->nrad[axis]; for (int k = 0; k < 8; ++k) q.radix[k] = k < s->nrad[axis] ? s->radix[axis][k] : 0; return q; };
+        auto slims = [&](const fft_sched& f) { fft_sched_s q; q.tab = f.tab; for (int k = 0; k < 8; ++k) q.off[k] = f.off[k]; return q; };
+        mc.plz = slim(3); mc.ply = slim(1); mc.plx = slim(0);
+        mc.scz = slims(s->sch_z2); mc.scy = slims(s->sch_y2); mc.scx = slims(s->sch_x2);
+        mc.nx = nx; mc.ny = ny; mc.Npad = h->Npad; mc.R = s->R; mc.n_eblk = s->n_eblk;
+        mc.pos = h->d_pos; mc.param = param; mc.box = h->d_box; mc.rep_lam = rep_lam;
+        mc.spec = s->d_grid; mc.twz = s->d_tw[2]; mc.twzh = s->d_tw[3]; mc.twy = s->d_tw[1]; mc.twx = s->d_tw[0];
+        mc.infl = s->d_infl; mc.energy = s->d_energy; mc.force = h->d_force;
+        mc.sync = s->d_mesh_sync; mc.err = h->d_sync + 2;
+        if (memcmp(&mc, &s->mesh_const_host, sizeof(mc)) != 0) {           // first launch, or a buffer moved
+            s->mesh_const_host = mc;
+            REMD_CHECK(h, hipMemcpyAsync(s->d_mesh_const, &s->mesh_const_host, sizeof(mc), hipMemcpyHostToDevice, st));
+        }
+        mesh_args a;
+        a.c = s->d_mesh_const;
+        a.bin_cap = s->cbin_use ? s->cbin_cap : 0; a.with_energy = with_energy ? 1 : 0;
+        a.col_start = s->cbin_use ? s->d_cbin_count + (size_t)s->cbin_parity * s->R * nx : s->d_col_start;
+        a.col_atoms = s->cbin_use ? reinterpret_cast<const int*>(s->d_cbin_atoms) : s->d_col_atoms;
+        a.bin_q = (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr;
+        a.zero_count = s->cbin_use ? s->d_cbin_count + (size_t)(1 - s->cbin_parity) * s->R * nx : (int*)nullptr;
+        a.epoch = ++s->mesh_epoch;
+        a.fork_flag = (s->cbin_use && h->fork_seq_pending) ? h->d_sync : (unsigned int*)nullptr;
+        a.fork_seq = h->fork_seq_pending;
+        if (s->cbin_use) h->fork_seq_pending = 0;
+        const dim3 grid((unsigned)(s->R * (2 * nx + ny)));
+        a.tdbg = nullptr;
+        static const bool want_times = getenv("REMD_MESH_TIMES") != nullptr;
+        static int n_launch = 0;
+        long long* d_t = nullptr;
+        if (want_times && ++n_launch == 200) { hipMalloc(&d_t, sizeof(long long) * 6 * grid.x); a.tdbg = d_t; }
+        if (s->mesh_zt == 256) hipLaunchKernelGGL(pme_mesh_kernel<256>, grid, dim3(256), s->mesh_lds, st, a);
+        else hipLaunchKernelGGL(pme_mesh_kernel<512>, grid, dim3(512), s->mesh_lds, st, a);
+        if (d_t) {
+            hipStreamSynchronize(st);
+            std::vector<long long> T(6 * (size_t)grid.x);
+            hipMemcpy(T.data(), d_t, sizeof(long long) * T.size(), hipMemcpyDeviceToHost);
+            hipFree(d_t);
+            long long t0 = T[0];
+            for (size_t b = 0; b < grid.x; ++b) t0 = std::min(t0, T[6 * b]);
+            const int nA = s->R * nx, nB = s->R * ny;
+            const char* names[3] = {"A rows fwd", "B columns", "C rows inv"};
+            for (int ph = 0; ph < 3; ++ph) {
+                const size_t b0 = ph == 0 ? 0 : ph == 1 ? nA : nA + nB, b1 = ph == 0 ? nA : ph == 1 ? nA + nB : grid.x;
+                double s_start = 0, s_wait = 0, s_work = 0, s_p1 = 0, s_p2 = 0, s_p3 = 0; long long first = 1ll << 62, last_start = 0, last_end = 0;
+                for (size_t b = b0; b < b1; ++b) {
+                    const long long* t = &T[6 * b];
+                    s_start += (t[0] - t0); s_wait += (t[1] - t[0]); s_work += (t[2] - t[1]);
+                    s_p1 += (t[3] - t[1]); s_p2 += (t[4] - t[3]); s_p3 += (t[2] - t[4]);
+                    first = std::min(first, t[0] - t0); last_start = std::max(last_start, t[0] - t0); last_end = std::max(last_end, t[2] - t0);
+                }
+                const double n = (double)(b1 - b0), tick = 0.01;     // wall_clock64: 100 MHz
+                fprintf(stderr, "[mesh] %-11s %5d items: first start %7.2f us, last start %7.2f, last end %7.2f; mean wait %6.2f us, mean work %6.2f us = %5.2f (spread | load) + %5.2f (transforms) + %5.2f (store + drain | gather)\n",
+                        names[ph], (int)n, first * tick, last_start * tick, last_end * tick, s_wait / n * tick, s_work / n * tick, s_p1 / n * tick, s_p2 / n * tick, s_p3 / n * tick);
+            }
+        }
+        s->gather_fused = true;
+        if (s->cbin_use) s->cbin_parity ^= 1;          // the next chain fills the buffer this evaluation has just zeroed
+    } else {
         remd_prof_scope ps(h, "pme_fft", st);
         // lines per workgroup: a divisor of ny whose points fit the registers of the workgroup
         static const int zt_env = getenv("REMD_PME_ZT") ? atoi(getenv("REMD_PME_ZT")) : 0;

@@ -8,7 +8,7 @@ KB = 0.008314462618153242
 al = ts.AlanineDipeptideExplicit()
 box = np.diag(al.system.getDefaultPeriodicBoxVectors())
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-eng = HipEngine()
+eng = HipEngine(lib_path=os.environ.get("AB_LIB") or None)
 eng.set_system(system_to_desc(al.system)); eng.set_states(np.full(R, 1 / (KB * 300.0)))
 eng.set_integrator('V R R O R R V', 0.002, 1.0, 200, True, 1e-8)
 eng.set_replicas(R, 0, np.tile(al.positions, (R, 1, 1)), None, np.tile(box, (R, 1)), np.arange(R))
