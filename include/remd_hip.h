@@ -121,10 +121,13 @@ int  remd_set_states(remd_handle h, int K, const double* beta,
 
 /* LangevinIntegrator (integrators.py:1071-1158) as used by
    mcmc.LangevinSplittingDynamicsMove (mcmc.py:1280-1316): splitting string of V/R/O tokens.
-   constraint_tolerance (reference default 1e-8, integrators.py:1073): rigid waters are solved analytically (SETTLE) and
-   do not depend on it; the iterative X-H cluster solver works on the fp32 state and stops at
-   max(constraint_tolerance, 1e-6) relative -- a smaller request is honoured as 1e-6, the floor of fp32 coordinates
-   (<= 0 selects the default 1e-8, i.e. 1e-6 effective).  libremd_cpu.so (f64) always iterates to 1e-12.                  */
+   constraint_tolerance (reference default 1e-8, integrators.py:1073): NOT an iteration threshold in libremd_hip.so.  Rigid
+   waters are solved analytically (SETTLE).  X-H star clusters (<= 3 hydrogens on one heavy atom) get a fixed amount of work:
+   positions by three Newton iterations on the K x K system of Lagrange multipliers (quadratic convergence from the
+   unconstrained step: residual at the fp32 round-off of the coordinates, ~1e-6 relative to the bond length, after two),
+   velocities by one exact K x K linear solve.  The value is accepted for interface parity and ignored by both solvers; a
+   request below 1e-6 cannot be met by fp32 coordinates and the host classes say so once.  tests/test_forcefield_parity.py
+   (test_alanine_constraints_and_substeps) bounds the residual.  libremd_cpu.so (f64) iterates to 1e-12.                  */
 int  remd_set_integrator(remd_handle h, const char* splitting, double timestep_ps,
                          double collision_rate_invps, int n_steps,
                          int reassign_velocities, double constraint_tolerance);

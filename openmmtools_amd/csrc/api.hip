@@ -272,6 +272,29 @@ int remd_set_restart_attempts(remd_handle h, int n)
     return 0;
 }
 
+// The device reports what it cannot raise through a sticky word (d_sync[2]): a wait polled on the device that ran out (1), an
+// overfull capped PME bin (2), the integrator chain's momentum barrier (3).  A raised flag is cleared and the mechanism behind it
+// switched off for this handle (events instead of polled flags, two chain launches instead of the barrier, the binning launch
+// instead of capped bins), so that the handle keeps working; `retry` says whether the caller runs the work again itself (then
+// this is not an error yet).
+int remd_recover_device_flag(remd_ctx* h, unsigned int f, const char* where, bool retry)
+{
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) REMD_CHECK(h, hipStreamSynchronize(h->stream2));
+    REMD_CHECK(h, hipMemset(h->d_sync + 2, 0, sizeof(unsigned int)));
+    h->join_deferred = 0; h->cbins_ready = false;
+    std::string what;
+    if (f == 2) { h->no_chain_bins = true; what = "more atoms in one PME mesh column than the chain-binned layout holds; using the binning launch from now on"; }
+    else if (f == 3) { h->no_device_waits = true; what = "the integrator chain's momentum barrier ran out; using two chain launches from now on"; }
+    else { h->no_device_waits = true; h->sync_events = true; what = "a wait polled on the device ran out (fork / join flag never arrived); using events from now on"; }
+    if (retry) {
+        static bool warned = false;
+        if (!warned) { fprintf(stderr, "[remd] %s: %s (the work is run again)\n", where, what.c_str()); warned = true; }
+        return 0;
+    }
+    return remd_fail(h, -2, std::string(where) + ": " + what);
+}
+
 int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
 {
     if (!h || !h->has_system || !h->has_integrator || h->R <= 0 || h->K <= 0)
@@ -281,8 +304,10 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     int rc;
     const int attempts = h->n_restart_attempts;
     const size_t seg = (size_t)h->Npad, bytes = sizeof(float4) * seg * h->R;
-    if (attempts > 0) {
-        // mcmc.py:700-703: the state the move starts from is what a failed attempt is reset to
+    int device_retry = 0;
+    {
+        // mcmc.py:700-703: the state the move starts from is what a failed attempt is reset to (and what a propagation whose
+        // device-side waits failed is run again from)
         if (!h->d_snap_pos) {
             REMD_CHECK(h, hipMalloc(&h->d_snap_pos, bytes)); REMD_CHECK(h, hipMalloc(&h->d_snap_vel, bytes));
             REMD_CHECK(h, hipMalloc(&h->d_fin_pos, bytes)); REMD_CHECK(h, hipMalloc(&h->d_fin_vel, bytes));
@@ -308,9 +333,21 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         REMD_CHECK(h, hipMemcpyAsync(&spin_out, h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
         REMD_CHECK(h, hipStreamSynchronize(h->stream));
         remd_nb_tune_resolve(h);
-        if (spin_out == 3) return remd_fail(h, -2, "remd_propagate: the integrator chain's momentum barrier ran out (REMD_CHAIN_MERGE=0 selects two launches)");
-        if (spin_out == 2) return remd_fail(h, -2, "remd_propagate: more atoms in one PME mesh column than the chain-binned layout holds (REMD_PME_CHAINBIN=0 selects the binning launch)");
-        if (spin_out) return remd_fail(h, -2, "remd_propagate: a cross-stream wait on the device ran out (fork / join flag never arrived)");
+        if (spin_out) {
+            // a poll on the device ran out or a capped PME bin overflowed: this propagation's forces cannot be trusted.  The
+            // state it started from is still there (snapshot above), so the handle drops the mechanism that failed and the
+            // attempt is run again with the same random streams -- once.
+            const int rc2 = remd_recover_device_flag(h, spin_out, "remd_propagate", device_retry == 0);
+            if (rc2) return rc2;
+            ++device_retry;
+            REMD_CHECK(h, hipMemcpyAsync(h->d_pos, h->d_snap_pos, bytes, hipMemcpyDeviceToDevice, h->stream));
+            REMD_CHECK(h, hipMemcpyAsync(h->d_vel, h->d_snap_vel, bytes, hipMemcpyDeviceToDevice, h->stream));
+            REMD_CHECK(h, hipMemcpyAsync(h->d_box, h->d_snap_box, sizeof(float) * 4 * h->R, hipMemcpyDeviceToDevice, h->stream));
+            h->box_version++;
+            h->forces_valid = false; h->force_zeroed = false;
+            --a;
+            continue;
+        }
         if (time_enqueue) {
             // diagnostic: host time spent enqueueing the MD steps vs the time until the device finished them
             const auto tq2 = std::chrono::steady_clock::now();
@@ -589,9 +626,7 @@ static int remd_check_device_flags(remd_ctx* h, const char* where)
 {
     unsigned int f = 0;
     REMD_CHECK(h, hipMemcpy(&f, h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost));
-    if (f == 3) return remd_fail(h, -2, std::string(where) + ": the integrator chain's momentum barrier ran out (REMD_CHAIN_MERGE=0 selects two launches)");
-    if (f == 2) return remd_fail(h, -2, std::string(where) + ": more atoms in one PME mesh column than the chain-binned layout holds (REMD_PME_CHAINBIN=0 selects the binning launch)");
-    if (f) return remd_fail(h, -2, std::string(where) + ": a cross-stream wait on the device ran out (fork / join flag never arrived)");
+    if (f) return remd_recover_device_flag(h, f, where, false);
     return 0;
 }
 

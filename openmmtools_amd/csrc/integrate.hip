@@ -689,7 +689,10 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     // every workgroup of the grid must then be resident at once, hence the bound on the grid
     const bool merge_env = !(getenv("REMD_CHAIN_MERGE") && atoi(getenv("REMD_CHAIN_MERGE")) == 0);
     const long long chain_blocks = (long long)((ut.n_units + 255) / 256) * h->R;
-    const bool merge_cmm = merge_env && !graph_ok && chain_blocks <= 1024 && h->profiling != 2;
+    // (the same bound holds for the join polled in the chain's prologue: spinning workgroups of a grid larger than the chip
+    // holds at once could keep the direct-space stream's last launches from ever being dispatched)
+    const bool device_waits_ok = chain_blocks <= 1024 && !h->no_device_waits;
+    const bool merge_cmm = merge_env && !graph_ok && device_waits_ok && h->profiling != 2;
     const long long sync_key = (long long)h->R * 1000003ll + ut.n_units;
     if (merge_cmm && (!h->d_chain_sync || h->chain_sync_key != sync_key)) {      // counters count arrivals of THIS grid shape
         if (h->d_chain_sync) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_chain_sync); h->d_chain_sync = nullptr; }
@@ -754,7 +757,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                 flush(false, true);
                 h->force_zeroed = zeroed_by_chain;
                 zeroed_by_chain = false;
-                h->defer_join_ok = true;            // the next main-stream launch is the chain holding this V
+                h->defer_join_ok = device_waits_ok;   // the next main-stream launch is the chain holding this V
                 int rc = remd_compute_forces(h, false);
                 h->defer_join_ok = false;
                 if (rc) return rc;

@@ -1070,6 +1070,7 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         if (!full_complex && !(getenv("REMD_PME_CHAINBIN") && atoi(getenv("REMD_PME_CHAINBIN")) == 0)) {
             // four times the mean occupancy of a mesh column (x bins are 1 / nx of a homogeneous box): overflow is detected
             s->cbin_cap = std::min(h->Npad, std::max(64, 4 * ((h->N + s->n[0] - 1) / s->n[0])));
+            if (getenv("REMD_PME_CBIN_CAP")) s->cbin_cap = std::max(1, atoi(getenv("REMD_PME_CBIN_CAP")));      // test hook: provoke the overflow path
             REMD_CHECK(h, hipMalloc(&s->d_cbin_count, sizeof(int) * 2 * (size_t)s->R * s->n[0]));
             REMD_CHECK(h, hipMemset(s->d_cbin_count, 0, sizeof(int) * 2 * (size_t)s->R * s->n[0]));
             REMD_CHECK(h, hipMalloc(&s->d_cbin_atoms, sizeof(float4) * (size_t)s->R * s->n[0] * s->cbin_cap));
@@ -1317,7 +1318,7 @@ remd_chain_bins remd_pme_chain_bins(remd_ctx* h)
     remd_chain_bins b;
     pme_state* s = (pme_state*)h->pme;
     static const bool fuse_gather = !(getenv("REMD_PME_FUSEGATHER") && atoi(getenv("REMD_PME_FUSEGATHER")) == 0);
-    if (!s || !s->d_cbin_count || s->R != h->R || !fuse_gather || !h->pme_concurrent) return b;
+    if (!s || !s->d_cbin_count || s->R != h->R || !fuse_gather || !h->pme_concurrent || h->no_chain_bins) return b;
     b.nx = s->n[0]; b.cap = s->cbin_cap; b.count = s->d_cbin_count + (size_t)s->cbin_parity * s->R * s->n[0]; b.atoms = s->d_cbin_atoms;
     b.box = h->d_box; b.err = h->d_sync + 2;
     // charges ride in the bins only when they do not depend on the replica's state: the chain runs before the evaluation

@@ -163,6 +163,9 @@ struct remd_ctx {
     // remd_run_steps: the launch that follows a force evaluation on the main stream is always an integrator chain, so the
     // join is polled in that kernel's prologue (join_deferred = sequence number to wait for) instead of a kernel of its own
     bool defer_join_ok = false; unsigned int join_deferred = 0;
+    // set when a wait polled on the device ran out / a capped PME bin overflowed: the handle falls back to events, two chain
+    // launches and the binning launch (api.hip: remd_recover_device_flag) instead of staying dead behind a sticky flag
+    bool no_device_waits = false, no_chain_bins = false;
     unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
     hipStream_t stream3 = nullptr; bool listed_on_s3 = false;    // third stream: the listed terms of a force-only evaluation (joins through d_sync[3])

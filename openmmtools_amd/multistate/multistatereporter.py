@@ -17,6 +17,7 @@ caller's rank 0 writes (the reference: ``@mpiplus.on_single_node(0)``).
 import json
 import os
 import pickle
+import re
 import time
 
 import numpy as np
@@ -52,16 +53,37 @@ class _RecordFile:
 
 class _RestrictedUnpickler(pickle.Unpickler):
     """The stored objects are this package's own state / move / System classes plus numpy arrays and builtin containers;
-    nothing else may be constructed when a storage directory is opened (the reference stores YAML / XML, data only)."""
-    _MODULES = ('openmmtools_amd', 'numpy', 'collections', 'copyreg')
+    nothing else may be constructed when a storage directory is opened (the reference stores YAML / XML, data only).
+
+    ``find_class`` resolves ``name`` with getattr, and from protocol 4 on a dotted name walks attributes (``os.system`` reached
+    through any module that imports os), so: no dotted names; from this package only classes DEFINED in this package; from
+    numpy only the array / dtype / scalar constructors a pickled array needs (a whole-package whitelist admits gadgets such as
+    numpy.testing._private.utils.runstring)."""
     _BUILTINS = {'dict', 'list', 'tuple', 'set', 'frozenset', 'int', 'float', 'complex', 'str', 'bytes', 'bytearray', 'bool',
                  'slice', 'range', 'object'}
+    _NUMPY = {('numpy', 'ndarray'), ('numpy', 'dtype'),
+              ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+              ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+              ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer')}
+    _NUMPY_SCALARS = {'bool_', 'int8', 'int16', 'int32', 'int64', 'uint8', 'uint16', 'uint32', 'uint64', 'float16', 'float32',
+                      'float64', 'complex64', 'complex128', 'str_', 'bytes_'}
+    _OTHER = {('collections', 'OrderedDict'), ('copyreg', '_reconstructor')}
 
     def find_class(self, module, name):
-        root = module.split('.')[0]
-        if root in self._MODULES or (module == 'builtins' and name in self._BUILTINS):
+        refuse = pickle.UnpicklingError('storage refers to %s.%s, which is not a class this package stores' % (module, name))
+        if '.' in name:
+            raise refuse
+        if module == 'builtins':
+            if name in self._BUILTINS:
+                return super().find_class(module, name)
+            raise refuse
+        if (module, name) in self._NUMPY or (module, name) in self._OTHER or (module == 'numpy' and name in self._NUMPY_SCALARS):
             return super().find_class(module, name)
-        raise pickle.UnpicklingError('storage refers to %s.%s, which is not a class this package stores' % (module, name))
+        if module == 'openmmtools_amd' or module.startswith('openmmtools_amd.'):
+            obj = super().find_class(module, name)
+            if isinstance(obj, type) and (obj.__module__ == 'openmmtools_amd' or obj.__module__.startswith('openmmtools_amd.')):
+                return obj
+        raise refuse
 
 
 class MultiStateReporter:
@@ -120,12 +142,16 @@ class MultiStateReporter:
             self._checkpoint_interval = int(self._meta.get('checkpoint_interval', self._checkpoint_interval))
             self._declare()
 
-    _OWNED_SUFFIXES = ('.f8', '.f4', '.i1', '.i4', '.pkl', '.json', '.yaml', '.npz')
+    _OWNED_NAMES = re.compile(
+        r'^(meta\.json|last_iteration\.json(\.tmp)?|(thermodynamic_states|mcmc_moves|options|metadata)\.pkl|online_\w+_\d{9}\.pkl|'
+        r'(energies|unsampled_energies|timestamp|logZ|log_weights|f_k|f_k_offline|free_energy)\.f8|neighborhoods\.i1|'
+        r'(states|accepted|proposed)\.i4|iteration_\d{9}(\.tmp)?\.npz)$')
 
     @classmethod
     def _owns(cls, filename):
-        """File names this container writes: typed record files, pickled objects, meta.json, the real-time YAML."""
-        return filename.endswith(cls._OWNED_SUFFIXES)
+        """Exactly the file names this container writes (typed record files, the four pickled objects, per-checkpoint online data,
+        meta / last-iteration JSON, checkpoint npz) -- not every *.json / *.pkl / *.npz a user may keep in the same directory."""
+        return cls._OWNED_NAMES.match(filename) is not None
 
     def close(self):
         self._open_mode = None

@@ -52,6 +52,20 @@ if __name__ == '__main__':
     kind, out = sys.argv[1], sys.argv[2]
     dist.init_process_group('gloo')
     comm = TorchDistributedComm()
+    if kind == 'exists':
+        # the store under <out>/store was created by the test: create() must refuse on EVERY rank, before any collective
+        from oracle_engine import OracleEngine
+        from openmmtools_amd.multistate import MultiStateReporter
+        try:
+            build('pt', OracleEngine(), comm, 2, MultiStateReporter(os.path.join(out, 'store'), checkpoint_interval=2))
+            verdict = 'created'
+        except RuntimeError as e:
+            verdict = 'refused' if 'refusing to overwrite' in str(e) else 'other: %s' % e
+        with open(os.path.join(out, 'exists_rank%d.txt' % comm.rank), 'w') as fh:
+            fh.write(verdict)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0)
     history, x, (b, c) = run(kind, comm, storage_dir=out)
     np.savez(os.path.join(out, 'rank%d.npz' % comm.rank),
              labels=np.stack([h[0] for h in history]), ukl=np.stack([h[1] for h in history]),

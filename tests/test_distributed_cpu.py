@@ -56,3 +56,18 @@ def test_sharded_run_equals_single_process(tmp_path, kind):
         assert np.array_equal(xa, xb)
     assert np.array_equal(a.read_energies()[0], b.read_energies()[0])
     assert np.array_equal(a.read_replica_thermodynamic_states(), b.read_replica_thermodynamic_states())
+
+
+def test_existing_storage_is_refused_on_every_rank(tmp_path):
+    """the 'storage already exists' error used to be raised on rank 0 only; the other ranks went on into the
+    collectives of create() and hung.  The check is broadcast now: both ranks refuse (and the job ends)."""
+    import dist_worker
+    from openmmtools_amd.multistate.comm import SingleProcessComm
+    dist_worker.run('pt', SingleProcessComm(), n_iter=1, storage_dir=str(tmp_path))          # leaves <tmp>/store behind
+    port = 29850 + (os.getpid() % 100)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(HERE, 'dist_worker.py'), 'exists', str(tmp_path)]
+    res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS='1'), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    for r in range(2):
+        assert open(os.path.join(tmp_path, 'exists_rank%d.txt' % r)).read() == 'refused'

@@ -285,6 +285,29 @@ def test_bins_from_the_integrator_chain_do_not_change_a_bit(hip_engine_factory, 
         assert np.array_equal(x, out[0][0]) and np.array_equal(v, out[0][1])
 
 
+def test_overfull_mesh_bins_fall_back_to_the_binning_launch(hip_engine_factory, monkeypatch):
+    """the bins the integrator chain fills for the PME passes are capped (4 x the mean occupancy of a mesh column); a
+    density the cap does not hold (slab, droplet, vacuum layer) used to leave a sticky error flag and a dead handle.  Now the
+    propagation is run again from its start state with the binning launch (no cap) and the handle stays on it: same
+    trajectory, bit for bit, as a run that never used the capped bins.  The overflow is provoked with a cap of 8 atoms."""
+    al = ts.AlanineDipeptideExplicit()
+    out = []
+    for cap, chainbin in (('8', '1'), (None, '0')):
+        if cap is None:
+            monkeypatch.delenv('REMD_PME_CBIN_CAP', raising=False)
+        else:
+            monkeypatch.setenv('REMD_PME_CBIN_CAP', cap)
+        monkeypatch.setenv('REMD_PME_CHAINBIN', chainbin)
+        eng = hip_engine_factory()
+        _engine_for(eng, al.system, al.positions, R=3, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=30)
+        assert not eng.propagate(0).any()              # first call: overflow -> recovery inside remd_propagate
+        assert not eng.propagate(1).any()              # the handle keeps working
+        x, v = eng.get_replicas()[:2]
+        out.append((x, v, eng.compute_energies()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
+
+
 def test_resident_pair_workgroups_do_not_change_a_bit(hip_engine_factory, monkeypatch):
     """The pair kernel either launches one workgroup per work item or keeps a resident set that pulls items from a queue
     (REMD_NB_PERSIST_GRID, chosen by timing at run time): forces are fixed-point sums, so positions and velocities after a

@@ -160,8 +160,13 @@ def test_create_refuses_to_overwrite_and_open_w_spares_foreign_files(tmp_path):
     d.mkdir()
     (d / 'notes.txt').write_text('mine')
     (d / 'energies.f8').write_bytes(b'')
+    # a user's own *.json / *.yaml / *.npz / *.pkl in a directory without meta.json are not this format's files
+    for name in ('config.json', 'protocol.yaml', 'frames.npz', 'model.pkl', 'energies.f8.bak'):
+        (d / name).write_text('keep')
     MultiStateReporter(str(d), open_mode='w')
     assert (d / 'notes.txt').read_text() == 'mine' and not (d / 'energies.f8').exists()
+    for name in ('config.json', 'protocol.yaml', 'frames.npz', 'model.pkl', 'energies.f8.bak'):
+        assert (d / name).read_text() == 'keep'
 
 
 def test_storage_objects_are_unpickled_with_a_whitelist(tmp_path):
@@ -172,3 +177,57 @@ def test_storage_objects_are_unpickled_with_a_whitelist(tmp_path):
         pickle.dump(subprocess.Popen, fh)                               # a class reference the format never stores
     with pytest.raises(pickle.UnpicklingError):
         MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_dict('metadata')
+    # from protocol 4 on STACK_GLOBAL hands find_class a dotted name that getattr walks ('os.system' through any
+    # module of this package that imports os); and a whole-numpy whitelist admits exec gadgets
+    marker = tmp_path / 'pwned'
+    def stack_global(module, name, arg=None):
+        """protocol-4 pickle: push module and (possibly dotted) name, STACK_GLOBAL, optionally call with one string argument"""
+        def u(t):
+            return b'\x8c' + bytes([len(t)]) + t.encode()
+        out = b'\x80\x04' + u(module) + u(name) + b'\x93'
+        if arg is not None:
+            out += u(arg) + b'\x85R'
+        return out + b'.'
+    payloads = [
+        stack_global('openmmtools_amd.multistate.multistatereporter', 'os.system', 'touch %s' % marker),
+        stack_global('openmmtools_amd.multistate.multistatereporter', 'os'),
+        pickle.dumps(subprocess.check_call),
+        stack_global('numpy.testing._private.utils', 'runstring'),
+        stack_global('numpy', 'load'),
+        stack_global('builtins', 'eval', '1'),
+    ]
+    for payload in payloads:
+        with open(str(tmp_path / 'pt.nc' / 'metadata.pkl'), 'wb') as fh:
+            fh.write(payload)
+        with pytest.raises(pickle.UnpicklingError):
+            MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_dict('metadata')
+    assert not marker.exists()
+    # what the format does store still loads: this package's classes, numpy arrays and scalars, builtin containers
+    import numpy as np
+    rep2 = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='a')
+    rep2.write_dict('metadata', dict(a=np.arange(3.0), b=np.float64(2.5), c=[1, (2, 3)], d={'x': None}))
+    back = rep2.read_dict('metadata')
+    assert np.array_equal(back['a'], np.arange(3.0)) and back['b'] == 2.5 and back['c'] == [1, (2, 3)]
+    assert len(rep2.read_thermodynamic_states()[0]) == 4 and len(rep2.read_mcmc_moves()) == 4
+
+
+class _UserSampler(ParallelTemperingSampler):
+    """a sampler class defined outside the package, as a user's script would"""
+
+
+def test_a_users_subclass_resumes_through_its_own_from_storage(tmp_path):
+    """from_storage refused every sampler class whose module is not under openmmtools_amd.  A subclass resumes through
+    ITS OWN from_storage (the caller supplies the class; nothing named in the storage is imported); any other foreign name is
+    still refused."""
+    ho = testsystems.HarmonicOscillator()
+    ts_ = states.ThermodynamicState(ho.system, 300.0)
+    ss = states.SamplerState(ho.positions)
+    rep = MultiStateReporter(str(tmp_path / 'u.nc'), checkpoint_interval=1)
+    s = _UserSampler(mcmc_moves=_move(), number_of_iterations=4, engine=OracleEngine(), seed=11)
+    s.create(ts_, [ss], storage=rep, min_temperature=300.0, max_temperature=600.0, n_temperatures=3)
+    s.run(2)
+    r = _UserSampler.from_storage(str(tmp_path / 'u.nc'), engine=OracleEngine())
+    assert type(r) is _UserSampler and r.iteration == 2
+    r.run(1)
+    with pytest.raises(TypeError, match='resume with that class'):
+        ParallelTemperingSampler.from_storage(str(tmp_path / 'u.nc'), engine=OracleEngine())
