@@ -283,9 +283,11 @@ int remd_recover_device_flag(remd_ctx* h, unsigned int f, const char* where, boo
     if (h->stream2) REMD_CHECK(h, hipStreamSynchronize(h->stream2));
     REMD_CHECK(h, hipMemset(h->d_sync + 2, 0, sizeof(unsigned int)));
     h->join_deferred = 0; h->cbins_ready = false;
+    remd_nb_invalidate_sort(h);
     std::string what;
     if (f == 2) { h->no_chain_bins = true; what = "more atoms in one PME mesh column than the chain-binned layout holds; using the binning launch from now on"; }
     else if (f == 3) { h->no_device_waits = true; what = "the integrator chain's momentum barrier ran out; using two chain launches from now on"; }
+    else if (f == 4) { h->no_resident = true; what = "more neighbours per atom than the resident small-system kernel's list holds; using the regular launches from now on"; }
     else { h->no_device_waits = true; h->sync_events = true; what = "a wait polled on the device ran out (fork / join flag never arrived); using events from now on"; }
     if (retry) {
         static bool warned = false;

@@ -35,21 +35,9 @@
 #define EP_CONST    7
 #define EP_NB0      8      // first nonbonded block slot
 
-#define NB_LJ_ONLY 0
-#define NB_RF      1
-#define NB_EWALD   2
-#define NB_EWALD_NOLJ 3   // Coulomb only: the LJ-active atoms are handled by a second, much shorter cluster list
-#define NB_RF_NOLJ    4
+#include "pair_math.h"
 
 #define MAX_EXCL_WORDS 8
-
-struct nb_params {
-    float rc, rc2, rs, inv_sw;        // cutoff, cutoff^2, switching distance (<0: none), 1/(rc-rs)
-    float krf, crf;                   // reaction field
-    float alpha, two_alpha_sqrtpi;    // Ewald
-    int excl_words;                   // 64-bit words of the exclusion window per atom
-    int n_jsplit;
-};
 
 struct nb_tables {
     nb_params p{};
@@ -392,74 +380,6 @@ void listed_forces_kernel(listed_tables T, int Npad, const float4* __restrict__ 
                           long long* __restrict__ force)
 {
     listed_forces_body(T, Npad, pos, box, force, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
-}
-
-// ---- nonbonded pair arithmetic -------------------------------------------------------------------
-__device__ __forceinline__ void switch_fn(const nb_params& p, float r, float& U, float& dUdr)
-{
-    if (p.rs >= 0.f && r > p.rs) {
-        const float x = (r - p.rs) * p.inv_sw;
-        const float S = 1.f + x * x * x * (-10.f + x * (15.f - 6.f * x));
-        const float dS = x * x * (-30.f + x * (60.f - 30.f * x)) * p.inv_sw;
-        dUdr = S * dUdr + U * dS;
-        U *= S;
-    }
-}
-
-// returns energy, writes dU/dr / r  (so that F_i = fr * (xj - xi))
-template <int METHOD, bool ALCH, bool FAST_ERFC>
-__device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, float4 pi, float4 pj,
-                                                  float lam_a, float sc, float& fr, bool energy_skip_na, float& e_out)
-{
-    // hardware v_rsq_f32 / v_rcp_f32 (1 ulp) instead of the libm wrappers: r2 is never denormal here and the
-    // denormal/IEEE-division guards cost a sixth of this VALU-bound loop
-    const float inv_r = __builtin_amdgcn_rsqf(r2);
-    const float r = r2 * inv_r;
-    const float sig = pi.y + pj.y, eps4 = pi.z * pj.z;
-    float U = 0.f, dUdr = 0.f;
-    bool na = false;
-    if (METHOD <= NB_EWALD && eps4 != 0.f) {
-        if (ALCH && (pi.w != pj.w)) {
-            // soft-core (alchemy.py:1383-1388 with softcore_c = 6): x = 1/(alpha(1-l)^b + (r/sigma)^6)
-            na = true;
-            const float is2 = 1.f / (sig * sig);
-            const float t = r2 * r2 * r2 * is2 * is2 * is2;
-            const float x = 1.f / (sc + t);
-            U = lam_a * eps4 * x * (x - 1.f);
-            dUdr = lam_a * eps4 * (2.f * x - 1.f) * (-x * x * 6.f * t * inv_r);
-        } else {
-            const float s2 = sig * sig * inv_r * inv_r;
-            const float s6 = s2 * s2 * s2;
-            U = eps4 * s6 * (s6 - 1.f);
-            dUdr = eps4 * s6 * (6.f - 12.f * s6) * inv_r;
-        }
-        switch_fn(p, r, U, dUdr);
-    }
-    float Uc = 0.f, dUc = 0.f;
-    if (METHOD != NB_LJ_ONLY) {
-        const float qq = pi.x * pj.x;
-        if (METHOD == NB_EWALD || METHOD == NB_EWALD_NOLJ) {
-            const float ar = p.alpha * r;
-            const float ex = __expf(-ar * ar);
-            float erfc_ar;
-            if (FAST_ERFC) {
-                // Abramowitz & Stegun 7.1.26 (|abs err| < 1.5e-7): force-only evaluations; energies use erfcf
-                const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ar);
-                erfc_ar = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f)))) * ex;
-            } else {
-                erfc_ar = erfcf(ar);
-            }
-            Uc = qq * erfc_ar * inv_r;
-            dUc = -qq * (erfc_ar * inv_r + p.two_alpha_sqrtpi * ex) * inv_r;
-        } else {
-            Uc = qq * (inv_r + p.krf * r2 - p.crf);
-            dUc = qq * (2.f * p.krf * r - inv_r * inv_r);
-        }
-    }
-    // (x + 0.f cannot be folded without nsz: name the sum the variant has)
-    fr = (METHOD == NB_LJ_ONLY ? dUdr : METHOD > NB_EWALD ? dUc : dUdr + dUc) * inv_r;
-    e_out = ((ALCH && na && energy_skip_na) ? 0.f : U) + Uc;
-    return e_out;
 }
 
 // ---- spatial ordering ------------------------------------------------------------------------------
@@ -2113,6 +2033,28 @@ void remd_nb_tune_resolve(remd_ctx* h)
         for (int c = 0; c < TUNE_NC; ++c) fprintf(stderr, " %d: %.2f", g_tune_cands[c], ms[c]);
         fprintf(stderr, " -> %d workgroups\n", t.nb_grid);
     }
+}
+// the next force evaluation re-sorts the molecules (a propagation that is run again after a device-side failure starts in the
+// sort phase a fresh handle would have: bit-identical trajectories; the resident small-system path moves atoms without
+// evaluations being counted)
+void remd_nb_invalidate_sort(remd_ctx* h)
+{
+    nb_tables* t = g_nb.find(h);
+    if (t) t->evals_since_sort = 1 << 30;
+}
+// what the resident small-system kernel (integrate.hip) needs from the nonbonded tables: pair constants, per-atom parameters in
+// ATOM order, the per-replica lambdas (refreshed here when the labels changed).  ok = 0: this system is not one it covers.
+int remd_nb_resident_info(remd_ctx* h, int* ok, int* method, int* has_alch, nb_params* p, const float4** param, const float** rep_lam)
+{
+    *ok = 0; *method = -1; *has_alch = 0; *param = nullptr; *rep_lam = nullptr;
+    if (h->nb_method == REMD_NB_NONE) { *ok = 1; return 0; }              // e.g. the harmonic oscillator: external force only
+    nb_tables* t = g_nb.find(h);
+    if (!t || t->method != NB_LJ_ONLY || t->n_exc != 0 || t->n_excl != 0 || h->n_exceptions != 0) return 0;
+    int rc = update_replica_lambdas(h, *t);
+    if (rc) return rc;
+    *ok = 1; *method = t->method; *has_alch = t->has_alch ? 1 : 0; *p = t->p; *param = t->d_param;
+    *rep_lam = t->has_alch ? t->d_rep_lam : nullptr;
+    return 0;
 }
 void remd_nb_note_evaluation(remd_ctx* h)
 {

@@ -15,6 +15,7 @@
 // rank are covered by one launch (blockIdx.y = replica).
 #include "remd_internal.h"
 #include "rng.h"
+#include "pair_math.h"
 
 #define UNIT_FREE   0
 #define UNIT_SETTLE 1
@@ -643,6 +644,233 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
 __global__ void ctr_set_kernel(long long* ctr, long long gstep, long long body) { ctr[0] = gstep; ctr[1] = body; }
 __global__ void ctr_tick_kernel(long long* ctr) { ctr[0] += 1; ctr[1] += 1; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident small-system path (round 3).  For systems of up to 1024 atoms without constraints, mesh or listed terms (the
+// reference's HarmonicOscillator and LennardJonesFluid test systems: BASELINE configs 1 and 2) an MD step of the regular path
+// is a chain of ~8 dependent launches of a few microseconds each and the GPU idles in between (LJ fluid, 16 replicas: 30 us
+// per step for 8 k atoms).  mcmc.py:700-719 is ONE integrator.step(n_steps) per move, so the MI355X-first shape of that is
+// ONE launch per propagation: a workgroup owns a replica, a thread owns an atom (x, v, f, 1/m and the pair parameters stay in
+// registers for all n_steps), positions and a Verlet list live in LDS:
+//   * neighbour list: all pairs inside r_c + skin, FULL list (every pair from both sides: no atomics, every atom sums its
+//     forces in list order -- deterministic), rebuilt by an all-pairs pass over the LDS positions whenever any atom has moved
+//     more than skin / 2 since the last build (a workgroup vote at every evaluation): the list is a superset of the pairs
+//     inside r_c at all times, the cutoff test in the force loop is exact;
+//   * force evaluation where the splitting string needs one (a V after an R), with the pair arithmetic of the regular
+//     kernels (pair_math.h: LJ + switch, soft-core for alchemical / non-alchemical pairs at the replica's lambda);
+//   * V / R / O / centre-of-mass removal as in the chain kernel, same Philox streams (atom, global replica, global O-substep
+//     counter): the trajectories follow the regular path to fp32 summation order.
+// Two workgroup barriers per force evaluation, nothing else between steps.
+struct resident_prog {
+    int n; char tok[MAX_TOK]; int o_index[MAX_TOK];
+    float hV, hR, a, b; int nO;
+    int n_steps, cmm_frequency; long long gstep0, first_step;
+    int dbg;               // REMD_RESIDENT_DBG (timing experiments): 1 no pair loop, 2 no noise, 4 one list build only, 8 count rebuilds into err[1]
+};
+struct resident_sys {
+    int N, Npad, method, alch, n_ext, list_cap;
+    nb_params p;
+    float skin, ext_K, ext_x0, inv_total_mass;
+    const float4* param; const float* rep_lam; const int* ext_atoms; const float* invmass; const float* box;
+    const int64_t* labels; const double* beta; int r_begin; uint64_t seed;
+    unsigned int* err;
+};
+
+#ifndef RES_UNROLL
+#define RES_UNROLL 4
+#endif
+template <bool ALCH>
+__global__ __launch_bounds__(1024)
+void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__ pos, float4* __restrict__ vel)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = S.N, T = blockDim.x, tid = threadIdx.x, r = blockIdx.x, nw = T >> 6;
+    float4* s_pos = reinterpret_cast<float4*>(smem);                      // [T] positions (w: unused)
+    float4* s_par = s_pos + T;                                            // [T] pair parameters of every atom
+    float* s_red = reinterpret_cast<float*>(s_par + T);                   // [16][4] wavefront partial sums
+    int* s_vote = reinterpret_cast<int*>(s_red + 63);                     // "somebody left its skin / 2 sphere" (last word of the partial sums' block)
+    unsigned short* s_cnt = reinterpret_cast<unsigned short*>(s_red + 64);// [T] list lengths
+    unsigned short* s_list = s_cnt + T;                                   // [cap][T] neighbour j of slot k of atom i at [k * T + i]
+    const bool active = tid < N;
+    float4* P = pos + (size_t)r * S.Npad;
+    float4* V = vel + (size_t)r * S.Npad;
+    float3 x = f3(0, 0, 0), v = f3(0, 0, 0), f = f3(0, 0, 0), xref = f3(0, 0, 0);
+    float im = 0.f;
+    float4 par = make_float4(0, 0, 0, 0);
+    if (active) {
+        const float4 p4 = P[tid], v4 = V[tid];
+        x = f3(p4.x, p4.y, p4.z); v = f3(v4.x, v4.y, v4.z);
+        im = S.invmass[tid];
+        if (S.method >= 0) par = S.param[tid];
+    }
+    s_par[tid] = par;
+    bool ext = false;
+    for (int k = 0; k < S.n_ext; ++k) ext |= (S.ext_atoms[k] == tid);
+    const float Lx = S.box[4 * r], Ly = S.box[4 * r + 1], Lz = S.box[4 * r + 2];
+    const float iLx = Lx > 0.f ? 1.f / Lx : 0.f, iLy = Ly > 0.f ? 1.f / Ly : 0.f, iLz = Lz > 0.f ? 1.f / Lz : 0.f;
+    float lam_a = 1.f, sc = 0.f;
+    if (ALCH) { lam_a = S.rep_lam[4 * r]; sc = S.rep_lam[4 * r + 1]; }
+    const float kT = frcp((float)S.beta[S.labels[S.r_begin + r]]);
+    const uint32_t rg = (uint32_t)(S.r_begin + r);
+    const float rl = S.p.rc + S.skin, rl2 = rl * rl, half_skin2 = 0.25f * S.skin * S.skin;
+    bool have_list = false, forces_valid = false;
+    if (tid == 0) *s_vote = 0;
+    __syncthreads();
+
+    auto evaluate = [&]() {
+        // publish the positions; rebuild the list if any atom has left its skin / 2 sphere
+        const float3 d = x - xref;
+        const int moved = (!have_list || (active && dot3(d, d) > half_skin2)) ? 1 : 0;
+        s_pos[tid] = make_float4(x.x, x.y, x.z, 0.f);
+        // the vote rides on the barrier that publishes the positions (a word in LDS; __syncthreads_or costs two more barriers)
+        if ((prog.dbg & 4) ? !have_list : moved) *s_vote = 1;
+        __syncthreads();
+        const int rebuild = *s_vote;
+        f = f3(0, 0, 0);
+        if (S.method >= 0) {
+            if (rebuild) {
+                int n = 0;
+                if (active) {
+                    for (int j = 0; j < N; ++j) {                        // wave-uniform j: LDS broadcast reads
+                        const float4 q = s_pos[j];
+                        float dx = q.x - x.x, dy = q.y - x.y, dz = q.z - x.z;
+                        dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        if (r2 < rl2 && j != tid) {
+                            if (n < S.list_cap) s_list[n * T + tid] = (unsigned short)j;
+                            ++n;
+                        }
+                    }
+                    if (n > S.list_cap) { atomicExch(S.err, 4u); n = S.list_cap; }
+                    xref = x;
+                }
+                s_cnt[tid] = (unsigned short)n;
+                have_list = true;
+            }
+            if (active && !(prog.dbg & 1)) {
+                // four neighbours per trip: their index, position and parameter reads are all issued before the first is used (a
+                // read per trip made the loop a chain of three dependent LDS round trips per neighbour)
+                const int n = s_cnt[tid];
+                for (int k = 0; k < n; k += RES_UNROLL) {
+                    int j[RES_UNROLL]; float4 q[RES_UNROLL], pj[RES_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < RES_UNROLL; ++u) j[u] = s_list[min(k + u, n - 1) * T + tid];
+#pragma unroll
+                    for (int u = 0; u < RES_UNROLL; ++u) { q[u] = s_pos[j[u]]; pj[u] = s_par[j[u]]; }
+#pragma unroll
+                    for (int u = 0; u < RES_UNROLL; ++u) {
+                        float dx = q[u].x - x.x, dy = q[u].y - x.y, dz = q[u].z - x.z;
+                        dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        if (r2 < S.p.rc2 && k + u < n) {
+                            float fr, ee;
+                            pair_interaction<NB_LJ_ONLY, ALCH, true>(S.p, r2, par, pj[u], lam_a, sc, fr, false, ee);
+                            f.x += fr * dx; f.y += fr * dy; f.z += fr * dz;       // F_i = fr * (x_j - x_i)
+                        }
+                    }
+                }
+            }
+        }
+        if (ext) { f.x -= S.ext_K * (x.x - S.ext_x0); f.y -= S.ext_K * x.y; f.z -= S.ext_K * x.z; }
+        __syncthreads();                                     // everybody is done with s_pos (and the vote) before the next publication
+        if (tid == 0) *s_vote = 0;
+        forces_valid = true;
+    };
+
+    for (int s = 0; s < prog.n_steps; ++s) {
+        const long long gstep = prog.gstep0 + s;
+        if (prog.cmm_frequency > 0 && ((prog.first_step + s) % prog.cmm_frequency) == 0) {
+            // integrators.py:1313: CMMotionRemover at the top of a step: v -= sum(m v) / M; fixed-order sums (deterministic)
+            float3 pm = active ? v * frcp(im) : f3(0, 0, 0);
+            for (int off = 32; off > 0; off >>= 1) { pm.x += __shfl_xor(pm.x, off); pm.y += __shfl_xor(pm.y, off); pm.z += __shfl_xor(pm.z, off); }
+            if ((tid & 63) == 0) { s_red[4 * (tid >> 6)] = pm.x; s_red[4 * (tid >> 6) + 1] = pm.y; s_red[4 * (tid >> 6) + 2] = pm.z; }
+            __syncthreads();
+            float3 tot = f3(0, 0, 0);
+            for (int w = 0; w < nw; ++w) tot = tot + f3(s_red[4 * w], s_red[4 * w + 1], s_red[4 * w + 2]);
+            __syncthreads();
+            if (active) v = v - tot * S.inv_total_mass;
+        }
+        for (int t = 0; t < prog.n; ++t) {
+            const char tok = prog.tok[t];
+            if (tok == 'V') {
+                if (!forces_valid) evaluate();
+                v = v + f * (prog.hV * im);
+            } else if (tok == 'R') {
+                x = x + v * prog.hR;
+                forces_valid = false;
+            } else {
+                const uint64_t cnt = (uint64_t)gstep * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
+                const float3 xi = (prog.dbg & 2) ? f3(0.1f, 0.2f, 0.3f) : gaussian3(S.seed, REMD_STREAM_OU, (uint32_t)tid, rg, cnt);
+                const float sig = prog.b * fsqrt(kT * im);
+                v = f3(prog.a * v.x + sig * xi.x, prog.a * v.y + sig * xi.y, prog.a * v.z + sig * xi.z);
+            }
+        }
+    }
+    if (active) {
+        P[tid] = make_float4(x.x, x.y, x.z, 0.f);
+        V[tid] = make_float4(v.x, v.y, v.z, 0.f);
+    }
+}
+
+void remd_launch_join_wait(remd_ctx* h);
+int remd_nb_resident_info(remd_ctx* h, int* ok, int* method, int* has_alch, nb_params* p, const float4** param, const float** rep_lam);
+void remd_nb_invalidate_sort(remd_ctx* h);
+
+// returns 1 when the propagation was run by the resident kernel, 0 when the system / request is not one it covers, < 0 on error
+static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
+                                   int64_t iteration, int64_t first_step, int n_steps)
+{
+    const bool enabled = !(getenv("REMD_RESIDENT") && atoi(getenv("REMD_RESIDENT")) == 0);      // read per call: the parity tests switch it
+    if (!enabled || h->no_resident) return 0;
+    if (h->N > 1024 || h->n_settle > 0 || h->n_shake > 0 || h->n_bonds > 0 || h->n_angles > 0 || h->n_torsions > 0) return 0;
+    if (h->baro_frequency > 0 || h->profiling == 2 || h->capturing || (int)tokens.size() > MAX_TOK || n_steps < 1) return 0;
+    int ok = 0, method = -1, alch = 0; nb_params p{}; const float4* param = nullptr; const float* rep_lam = nullptr;
+    int rc = remd_nb_resident_info(h, &ok, &method, &alch, &p, &param, &rep_lam);
+    if (rc) return rc;
+    if (!ok) return 0;
+    resident_sys S{};
+    S.N = h->N; S.Npad = h->Npad; S.method = method; S.alch = alch; S.n_ext = h->n_ext; S.p = p;
+    // skin: a fifth of the cutoff, at most what keeps r_c + skin inside half the smallest box edge (minimum image)
+    double lmin = 1e30;
+    for (int r = 0; r < h->R; ++r) for (int k = 0; k < 3; ++k) lmin = std::min(lmin, h->box_host.size() >= (size_t)3 * (r + 1) ? h->box_host[3 * r + k] : 1e30);
+    const double skin_frac = getenv("REMD_RESIDENT_SKIN") ? atof(getenv("REMD_RESIDENT_SKIN")) : 0.2;
+    S.skin = method >= 0 ? (float)std::max(0.0, std::min(skin_frac * p.rc, 0.5 * lmin - p.rc - 1e-3)) : 0.f;
+    if (method >= 0 && !(0.5 * lmin > p.rc)) return 0;
+    S.ext_K = (float)h->ext_K; S.ext_x0 = (float)h->ext_x0; S.inv_total_mass = (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0);
+    S.param = param; S.rep_lam = rep_lam; S.ext_atoms = h->d_ext_atoms; S.invmass = h->d_invmass; S.box = h->d_box;
+    S.labels = h->d_labels; S.beta = h->d_beta; S.r_begin = h->r_begin; S.seed = h->seed; S.err = h->d_sync + 2;
+    const int T = std::max(64, (h->N + 63) / 64 * 64);
+    // list capacity from the LDS that is left: positions + parameters (32 B per thread), partial sums, counts
+    const size_t fixed = (size_t)T * 32 + 64 * sizeof(float) + (size_t)T * 2;
+    const size_t lds_max = 144 * 1024;
+    S.list_cap = method >= 0 ? (int)std::min<size_t>(128, (lds_max - fixed) / ((size_t)T * 2)) : 0;
+    if (getenv("REMD_RESIDENT_CAP")) S.list_cap = std::max(1, std::min(S.list_cap, atoi(getenv("REMD_RESIDENT_CAP"))));      // test hook: provoke the overflow path
+    if (method >= 0 && S.list_cap < 16 && !getenv("REMD_RESIDENT_CAP")) return 0;
+    const size_t lds = fixed + (size_t)S.list_cap * T * 2;
+    resident_prog prog{};
+    prog.n = (int)tokens.size();
+    int oidx = 0;
+    for (int t = 0; t < prog.n; ++t) { prog.tok[t] = tokens[t]; prog.o_index[t] = tokens[t] == 'O' ? oidx++ : 0; }
+    prog.hV = (float)(h->dt / (nV > 0 ? nV : 1)); prog.hR = (float)(h->dt / (nR > 0 ? nR : 1));
+    const double hO = h->dt / (nO > 0 ? nO : 1);
+    prog.a = (float)exp(-h->gamma * hO); prog.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO)); prog.nO = nO > 0 ? nO : 1;
+    prog.n_steps = n_steps; prog.cmm_frequency = h->cmm_frequency;
+    prog.gstep0 = (long long)iteration * (long long)h->n_steps + first_step; prog.first_step = first_step;
+    prog.dbg = getenv("REMD_RESIDENT_DBG") ? atoi(getenv("REMD_RESIDENT_DBG")) : 0;
+    remd_launch_join_wait(h);
+    remd_prof_scope ps(h, "resident_md");
+    if (alch) {
+        REMD_CHECK(h, hipFuncSetAttribute((const void*)resident_md_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        hipLaunchKernelGGL(resident_md_kernel<true>, dim3(h->R), dim3(T), lds, h->stream, prog, S, h->d_pos, h->d_vel);
+    } else {
+        REMD_CHECK(h, hipFuncSetAttribute((const void*)resident_md_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        hipLaunchKernelGGL(resident_md_kernel<false>, dim3(h->R), dim3(T), lds, h->stream, prog, S, h->d_pos, h->d_vel);
+    }
+    REMD_CHECK(h, hipGetLastError());
+    h->forces_valid = false; h->force_zeroed = false;
+    remd_nb_invalidate_sort(h);            // the atoms moved n_steps without the regular path's evaluation counter seeing it
+    return 1;
+}
+
 // Runs n_steps of the token program.  Tokens are grouped into chains that need no new
 // force evaluation; a 'V' after an 'R' forces a force evaluation first.
 //
@@ -663,6 +891,10 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
 {
     const unit_tables& ut = g_units[h];
     if (ut.n_units == 0) return remd_fail(h, -3, "no system set");
+    {
+        const int rr = remd_run_steps_resident(h, tokens, nV, nR, nO, iteration, first_step, n_steps);
+        if (rr != 0) return rr < 0 ? rr : 0;
+    }
     chain_prog base{};
     base.hV = (float)(h->dt / (nV > 0 ? nV : 1));
     base.hR = (float)(h->dt / (nR > 0 ? nR : 1));

@@ -165,7 +165,7 @@ struct remd_ctx {
     bool defer_join_ok = false; unsigned int join_deferred = 0;
     // set when a wait polled on the device ran out / a capped PME bin overflowed: the handle falls back to events, two chain
     // launches and the binning launch (api.hip: remd_recover_device_flag) instead of staying dead behind a sticky flag
-    bool no_device_waits = false, no_chain_bins = false;
+    bool no_device_waits = false, no_chain_bins = false, no_resident = false;
     unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
     hipStream_t stream3 = nullptr; bool listed_on_s3 = false;    // third stream: the listed terms of a force-only evaluation (joins through d_sync[3])
@@ -243,6 +243,7 @@ void remd_free_step_graph(remd_ctx* h);
 // ---- forces.hip -------------------------------------------------------------------------
 int remd_barostat_attempt(remd_ctx* h);
 int remd_minimize_impl(remd_ctx* h, double tolerance, int max_iterations, int32_t* converged, int32_t* n_iterations);
+void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluation re-sorts the molecules
 int remd_compute_forces(remd_ctx* h, bool with_energy);   // fills d_force (and d_potential when with_energy)
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d);
 int remd_build_constraints(remd_ctx* h, const remd_system_desc* d);

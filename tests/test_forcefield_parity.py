@@ -85,6 +85,60 @@ def test_lj_fluid_alchemical_ukl(hip_engine_factory):
         assert np.abs(f[r] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
 
 
+def _lj_alchemical(eng, n_steps, dt, R=3, splitting='V R O R V'):
+    lj = ts.LennardJonesFluid(nparticles=512)
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(10))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, region)
+    lam = np.linspace(1.0, 0.0, 16)
+    _engine_for(eng, system, lj.positions, R=R, lam_s=lam, jitter=0.01, labels=[0, 7, 15][:R], splitting=splitting, dt=dt, n_steps=n_steps)
+
+
+@pytest.mark.parametrize('splitting,dt,n_steps', [('V R O R V', 0.001, 60), ('V R R O R R V', 0.001, 600), ('O V R V O', 0.002, 100)])
+def test_resident_small_system_kernel_follows_the_regular_launches(hip_engine_factory, monkeypatch, splitting, dt, n_steps):
+    """Round 3: systems without constraints, mesh or listed terms of up to 1024 atoms (BASELINE configs 1 and 2) are propagated by
+    ONE launch per move (resident_md_kernel: a workgroup per replica, an atom per thread, x / v / f in registers for all n_steps,
+    Verlet list in LDS rebuilt when an atom leaves its skin / 2 sphere) instead of ~8 dependent launches per MD step.  Same pair
+    arithmetic, same Philox streams: the trajectory follows the regular path to fp32 summation order, through list rebuilds
+    (600 steps move the fastest atoms several skins) and for the lambda of each replica's state."""
+    out = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('REMD_RESIDENT', flag)
+        eng = hip_engine_factory()
+        _lj_alchemical(eng, n_steps, dt, splitting=splitting)
+        assert not eng.propagate(3).any()
+        x, v = eng.get_replicas()[:2]
+        out.append((x, v, eng.compute_energies()))
+    (xa, va, ua), (xb, vb, ub) = out
+    moved = np.abs(xb - ts.LennardJonesFluid(nparticles=512).positions[None]).max()
+    assert moved > (0.15 if n_steps == 600 else 0.01)                  # the long case outruns the skin: rebuilds happened
+    # fp32 summation order differs between the paths; a collision amplifies that (600 steps: the worst atom 4e-4 nm, the median
+    # 1e-7 nm), so the bulk is held tightly and the outliers loosely
+    dx, dv = np.abs(xa - xb), np.abs(va - vb)
+    assert np.median(dx) < 2e-6 and np.median(dv) < 2e-5, (np.median(dx), np.median(dv))
+    assert dx.max() < (5e-3 if n_steps > 100 else 5e-5), dx.max()
+    assert dv.max() < (5e-2 if n_steps > 100 else 5e-4), dv.max()
+    assert np.allclose(ua, ub, rtol=1e-3 if n_steps > 100 else 2e-5, atol=1e-2 if n_steps > 100 else 1e-4)
+
+
+def test_resident_kernel_list_overflow_falls_back_to_the_regular_launches(hip_engine_factory, monkeypatch):
+    """A neighbour list that does not fit the kernel's LDS budget raises the device flag; the propagation is run again from its
+    start state by the regular launches and the handle stays on them: bit-identical to a handle that never used the kernel."""
+    out = []
+    for cap, flag in (('2', '1'), (None, '0')):
+        if cap is None:
+            monkeypatch.delenv('REMD_RESIDENT_CAP', raising=False)
+        else:
+            monkeypatch.setenv('REMD_RESIDENT_CAP', cap)
+        monkeypatch.setenv('REMD_RESIDENT', flag)
+        eng = hip_engine_factory()
+        _lj_alchemical(eng, 40, 0.001)
+        assert not eng.propagate(0).any()
+        assert not eng.propagate(1).any()
+        x, v = eng.get_replicas()[:2]
+        out.append((x, v))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_exclusion_word_with_high_lane_bits(hip_engine_factory):
     """8-atom groups whose exclusions include (slot 3, slot 7) of a cluster: bit 31 of the diagonal cluster pair's 64-bit
     exclusion word is set.  (The word is read as two 32-bit halves; a signed low half once smeared that bit over lanes
