@@ -676,8 +676,33 @@ struct resident_sys {
 };
 
 #ifndef RES_UNROLL
-#define RES_UNROLL 4
+#define RES_UNROLL 2
 #endif
+#define RES_FSCALE 8192.f       // LDS force accumulators: 32-bit fixed point, 2^-13 kJ/mol/nm (|F| < 2.6e5 kJ/mol/nm: r > 0.19 nm for argon)
+
+// LJ + switch of one pair without branches: the soft-core form  x = 1 / (sc + (r / sigma)^6),  U = lam eps4 x (x - 1)  IS
+// Lennard-Jones for sc = 0, lam = 1 (alchemy.py:1383-1388 with softcore_c = 6), so alchemical / non-alchemical pairs differ from
+// the rest only in two selected constants; the switching polynomial is evaluated at x clamped to [0, 1].  Hardware reciprocals
+// (1 ulp).  Returns dU/dr / r, so that F_i = fr * (x_j - x_i).
+template <bool ALCH>
+__device__ __forceinline__ float resident_pair(const nb_params& p, float r2, float4 pi, float4 pj, float lam_a, float sc)
+{
+    const float inv_r = __builtin_amdgcn_rsqf(r2), r = r2 * inv_r;
+    const float sig = pi.y + pj.y, eps4 = pi.z * pj.z;
+    const bool soft = ALCH && (pi.w != pj.w);
+    const float lam = soft ? lam_a : 1.f, s0 = soft ? sc : 0.f;
+    const float is2 = __builtin_amdgcn_rcpf(sig * sig);
+    const float q2 = r2 * is2, t = q2 * q2 * q2;
+    const float x = __builtin_amdgcn_rcpf(s0 + t);
+    float U = lam * eps4 * x * (x - 1.f);
+    float dUdr = lam * eps4 * (2.f * x - 1.f) * (-x * x * 6.f * t * inv_r);
+    const float xs = fminf(fmaxf((r - p.rs) * p.inv_sw, 0.f), 1.f);          // no switch: inv_sw = 0
+    const float Sw = 1.f + xs * xs * xs * (-10.f + xs * (15.f - 6.f * xs));
+    const float dS = xs * xs * (-30.f + xs * (60.f - 30.f * xs)) * p.inv_sw;
+    dUdr = Sw * dUdr + U * dS;
+    return dUdr * inv_r;
+}
+
 template <bool ALCH>
 __global__ __launch_bounds__(1024)
 void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__ pos, float4* __restrict__ vel)
@@ -686,10 +711,12 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
     const int N = S.N, T = blockDim.x, tid = threadIdx.x, r = blockIdx.x, nw = T >> 6;
     float4* s_pos = reinterpret_cast<float4*>(smem);                      // [T] positions (w: unused)
     float4* s_par = s_pos + T;                                            // [T] pair parameters of every atom
-    float* s_red = reinterpret_cast<float*>(s_par + T);                   // [16][4] wavefront partial sums
-    int* s_vote = reinterpret_cast<int*>(s_red + 63);                     // "somebody left its skin / 2 sphere" (last word of the partial sums' block)
-    unsigned short* s_cnt = reinterpret_cast<unsigned short*>(s_red + 64);// [T] list lengths
-    unsigned short* s_list = s_cnt + T;                                   // [cap][T] neighbour j of slot k of atom i at [k * T + i]
+    float* s_red = reinterpret_cast<float*>(s_par + T);                   // [16][4] wavefront partial sums; the last words:
+    int* s_vote = reinterpret_cast<int*>(s_red + 60);                     // [2] "somebody left its skin / 2 sphere", by evaluation parity
+    int* s_np = reinterpret_cast<int*>(s_red + 62);                       // pairs in the list
+    int* s_f = reinterpret_cast<int*>(s_red + 64);                        // [3][T] fixed-point force accumulators
+    unsigned long long* s_fl = reinterpret_cast<unsigned long long*>(s_f + 3 * T + (T & 1));   // [3][T] the same in 64 bits: contributions too large for the fast path
+    unsigned int* s_pairs = reinterpret_cast<unsigned int*>(s_fl + 3 * T); // [cap] i | j << 16, i < j
     const bool active = tid < N;
     float4* P = pos + (size_t)r * S.Npad;
     float4* V = vel + (size_t)r * S.Npad;
@@ -703,6 +730,8 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
         if (S.method >= 0) par = S.param[tid];
     }
     s_par[tid] = par;
+    s_f[tid] = 0; s_f[T + tid] = 0; s_f[2 * T + tid] = 0;
+    s_fl[tid] = 0ull; s_fl[T + tid] = 0ull; s_fl[2 * T + tid] = 0ull;
     bool ext = false;
     for (int k = 0; k < S.n_ext; ++k) ext |= (S.ext_atoms[k] == tid);
     const float Lx = S.box[4 * r], Ly = S.box[4 * r + 1], Lz = S.box[4 * r + 2];
@@ -713,66 +742,96 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
     const uint32_t rg = (uint32_t)(S.r_begin + r);
     const float rl = S.p.rc + S.skin, rl2 = rl * rl, half_skin2 = 0.25f * S.skin * S.skin;
     bool have_list = false, forces_valid = false;
-    if (tid == 0) *s_vote = 0;
+    int n_eval = 0;
+    if (tid == 0) { s_vote[0] = 0; s_vote[1] = 0; *s_np = 0; }
     __syncthreads();
 
     auto evaluate = [&]() {
-        // publish the positions; rebuild the list if any atom has left its skin / 2 sphere
+        // publish the positions; rebuild the list if any atom has left its skin / 2 sphere.  The vote rides on the barrier that
+        // publishes the positions (two words used in turn: the one of the next evaluation is cleared behind this barrier)
         const float3 d = x - xref;
-        const int moved = (!have_list || (active && dot3(d, d) > half_skin2)) ? 1 : 0;
+        const bool moved = !have_list || (active && dot3(d, d) > half_skin2);
+        const int par_e = n_eval & 1;
         s_pos[tid] = make_float4(x.x, x.y, x.z, 0.f);
-        // the vote rides on the barrier that publishes the positions (a word in LDS; __syncthreads_or costs two more barriers)
-        if ((prog.dbg & 4) ? !have_list : moved) *s_vote = 1;
+        if ((prog.dbg & 4) ? !have_list : moved) s_vote[par_e] = 1;
         __syncthreads();
-        const int rebuild = *s_vote;
+        const int rebuild = s_vote[par_e];
+        if (tid == 0) s_vote[par_e ^ 1] = 0;
+        ++n_eval;
         f = f3(0, 0, 0);
         if (S.method >= 0) {
             if (rebuild) {
-                int n = 0;
+                if (tid == 0) *s_np = 0;
+                __syncthreads();
                 if (active) {
                     for (int j = 0; j < N; ++j) {                        // wave-uniform j: LDS broadcast reads
                         const float4 q = s_pos[j];
                         float dx = q.x - x.x, dy = q.y - x.y, dz = q.z - x.z;
                         dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
                         const float r2 = dx * dx + dy * dy + dz * dz;
-                        if (r2 < rl2 && j != tid) {
-                            if (n < S.list_cap) s_list[n * T + tid] = (unsigned short)j;
-                            ++n;
+                        if (r2 < rl2 && j > tid) {                       // every pair once; the order of the list does not matter
+                            const int slot = atomicAdd(s_np, 1);         // (forces are integer sums)
+                            if (slot < S.list_cap) s_pairs[slot] = (unsigned int)tid | ((unsigned int)j << 16);
                         }
                     }
-                    if (n > S.list_cap) { atomicExch(S.err, 4u); n = S.list_cap; }
                     xref = x;
                 }
-                s_cnt[tid] = (unsigned short)n;
                 have_list = true;
+                __syncthreads();
+                if (tid == 0 && *s_np > S.list_cap) atomicExch(S.err, 4u);
             }
-            if (active && !(prog.dbg & 1)) {
-                // four neighbours per trip: their index, position and parameter reads are all issued before the first is used (a
-                // read per trip made the loop a chain of three dependent LDS round trips per neighbour)
-                const int n = s_cnt[tid];
-                for (int k = 0; k < n; k += RES_UNROLL) {
-                    int j[RES_UNROLL]; float4 q[RES_UNROLL], pj[RES_UNROLL];
+            if (!(prog.dbg & 1)) {
+                // a thread takes pairs tid, tid + T, ...: the same number for every lane (an atom-per-lane loop runs as long as the
+                // busiest atom of the wavefront: 16 slots for 10 neighbours on average), RES_UNROLL pairs per trip with all their
+                // LDS reads in flight
+                const int np = min(*s_np, S.list_cap);
+                for (int k = tid; k < np; k += RES_UNROLL * T) {
+                    unsigned int w[RES_UNROLL]; float4 qi[RES_UNROLL], qj[RES_UNROLL], pi[RES_UNROLL], pj[RES_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < RES_UNROLL; ++u) j[u] = s_list[min(k + u, n - 1) * T + tid];
-#pragma unroll
-                    for (int u = 0; u < RES_UNROLL; ++u) { q[u] = s_pos[j[u]]; pj[u] = s_par[j[u]]; }
+                    for (int u = 0; u < RES_UNROLL; ++u) w[u] = s_pairs[min(k + u * T, np - 1)];
 #pragma unroll
                     for (int u = 0; u < RES_UNROLL; ++u) {
-                        float dx = q[u].x - x.x, dy = q[u].y - x.y, dz = q[u].z - x.z;
+                        const int i = w[u] & 0xffffu, j = w[u] >> 16;
+                        qi[u] = s_pos[i]; qj[u] = s_pos[j]; pi[u] = s_par[i]; pj[u] = s_par[j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < RES_UNROLL; ++u) {
+                        const int i = w[u] & 0xffffu, j = w[u] >> 16;
+                        float dx = qj[u].x - qi[u].x, dy = qj[u].y - qi[u].y, dz = qj[u].z - qi[u].z;
                         dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
                         const float r2 = dx * dx + dy * dy + dz * dz;
-                        if (r2 < S.p.rc2 && k + u < n) {
-                            float fr, ee;
-                            pair_interaction<NB_LJ_ONLY, ALCH, true>(S.p, r2, par, pj[u], lam_a, sc, fr, false, ee);
-                            f.x += fr * dx; f.y += fr * dy; f.z += fr * dz;       // F_i = fr * (x_j - x_i)
+                        if (r2 < S.p.rc2 && k + u * T < np) {
+                            const float fr = resident_pair<ALCH>(S.p, r2, pi[u], pj[u], lam_a, sc) * RES_FSCALE;
+                            const float ax = fr * dx, ay = fr * dy, az = fr * dz;                                    // F_i = fr (x_j - x_i)
+                            if (fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fabsf(az)) < 134217728.f) {                       // 2^27: sixteen of them fit 32 bits
+                                const int fx = __float2int_rn(ax), fy = __float2int_rn(ay), fz = __float2int_rn(az);
+                                atomicAdd(&s_f[i], fx); atomicAdd(&s_f[T + i], fy); atomicAdd(&s_f[2 * T + i], fz);
+                                atomicAdd(&s_f[j], -fx); atomicAdd(&s_f[T + j], -fy); atomicAdd(&s_f[2 * T + j], -fz);
+                            } else {
+                                // a pair deep inside the repulsive core (an unminimised start): 64-bit accumulators, rare and slow
+                                const long long fx = (long long)ax, fy = (long long)ay, fz = (long long)az;
+                                atomicAdd(&s_fl[i], (unsigned long long)fx); atomicAdd(&s_fl[T + i], (unsigned long long)fy); atomicAdd(&s_fl[2 * T + i], (unsigned long long)fz);
+                                atomicAdd(&s_fl[j], (unsigned long long)(-fx)); atomicAdd(&s_fl[T + j], (unsigned long long)(-fy)); atomicAdd(&s_fl[2 * T + j], (unsigned long long)(-fz));
+                            }
                         }
                     }
                 }
             }
+            __syncthreads();                                 // every pair is in; nobody reads s_pos any more
+            {
+                const long long lx = (long long)s_fl[tid], ly = (long long)s_fl[T + tid], lz = (long long)s_fl[2 * T + tid];
+                f = f3((float)s_f[tid], (float)s_f[T + tid], (float)s_f[2 * T + tid]);
+                if (lx | ly | lz) {
+                    f = f + f3((float)lx, (float)ly, (float)lz);
+                    s_fl[tid] = 0ull; s_fl[T + tid] = 0ull; s_fl[2 * T + tid] = 0ull;
+                }
+                f = f * (1.f / RES_FSCALE);
+            }
+            s_f[tid] = 0; s_f[T + tid] = 0; s_f[2 * T + tid] = 0;      // (the next accumulation starts behind the next publication barrier)
+        } else {
+            __syncthreads();
         }
         if (ext) { f.x -= S.ext_K * (x.x - S.ext_x0); f.y -= S.ext_K * x.y; f.z -= S.ext_K * x.z; }
-        __syncthreads();                                     // everybody is done with s_pos (and the vote) before the next publication
-        if (tid == 0) *s_vote = 0;
         forces_valid = true;
     };
 
@@ -782,10 +841,10 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
             // integrators.py:1313: CMMotionRemover at the top of a step: v -= sum(m v) / M; fixed-order sums (deterministic)
             float3 pm = active ? v * frcp(im) : f3(0, 0, 0);
             for (int off = 32; off > 0; off >>= 1) { pm.x += __shfl_xor(pm.x, off); pm.y += __shfl_xor(pm.y, off); pm.z += __shfl_xor(pm.z, off); }
-            if ((tid & 63) == 0) { s_red[4 * (tid >> 6)] = pm.x; s_red[4 * (tid >> 6) + 1] = pm.y; s_red[4 * (tid >> 6) + 2] = pm.z; }
+            if ((tid & 63) == 0) { s_red[3 * (tid >> 6)] = pm.x; s_red[3 * (tid >> 6) + 1] = pm.y; s_red[3 * (tid >> 6) + 2] = pm.z; }
             __syncthreads();
             float3 tot = f3(0, 0, 0);
-            for (int w = 0; w < nw; ++w) tot = tot + f3(s_red[4 * w], s_red[4 * w + 1], s_red[4 * w + 2]);
+            for (int w = 0; w < nw; ++w) tot = tot + f3(s_red[3 * w], s_red[3 * w + 1], s_red[3 * w + 2]);
             __syncthreads();
             if (active) v = v - tot * S.inv_total_mass;
         }
@@ -839,13 +898,13 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
     S.param = param; S.rep_lam = rep_lam; S.ext_atoms = h->d_ext_atoms; S.invmass = h->d_invmass; S.box = h->d_box;
     S.labels = h->d_labels; S.beta = h->d_beta; S.r_begin = h->r_begin; S.seed = h->seed; S.err = h->d_sync + 2;
     const int T = std::max(64, (h->N + 63) / 64 * 64);
-    // list capacity from the LDS that is left: positions + parameters (32 B per thread), partial sums, counts
-    const size_t fixed = (size_t)T * 32 + 64 * sizeof(float) + (size_t)T * 2;
+    // pair-list capacity from the LDS that is left: positions + parameters (32 B per thread), partial sums / flags, force accumulators
+    const size_t fixed = (size_t)T * 32 + 64 * sizeof(float) + (size_t)T * 12 + 8 + (size_t)T * 24;
     const size_t lds_max = 144 * 1024;
-    S.list_cap = method >= 0 ? (int)std::min<size_t>(128, (lds_max - fixed) / ((size_t)T * 2)) : 0;
+    S.list_cap = method >= 0 ? (int)std::min<size_t>(32768, (lds_max - fixed) / 4) : 0;
     if (getenv("REMD_RESIDENT_CAP")) S.list_cap = std::max(1, std::min(S.list_cap, atoi(getenv("REMD_RESIDENT_CAP"))));      // test hook: provoke the overflow path
-    if (method >= 0 && S.list_cap < 16 && !getenv("REMD_RESIDENT_CAP")) return 0;
-    const size_t lds = fixed + (size_t)S.list_cap * T * 2;
+    if (method >= 0 && S.list_cap < 4 * h->N && !getenv("REMD_RESIDENT_CAP")) return 0;
+    const size_t lds = fixed + (size_t)S.list_cap * 4;
     resident_prog prog{};
     prog.n = (int)tokens.size();
     int oidx = 0;
