@@ -352,7 +352,8 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
                             const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
-                            unsigned int* chain_sync, unsigned int* chain_sync_err, const unsigned int* join_flag2)
+                            unsigned int* chain_sync, unsigned int* chain_sync_err, const unsigned int* join_flag2,
+                            unsigned long long* own_time)
 {
     if (join_flag) {
         // the forces of the direct-space stream: poll its "done" flag here instead of behind a cross-stream event (remd_ctx::d_sync)
@@ -367,6 +368,9 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    // profiling: this launch's OWN time, from "forces complete" seen to the end, for workgroup (0, 0) (the launch duration a
+    // profiler reports also holds the wait for the direct-space stream in the prologue)
+    const unsigned long long own_t0 = own_time ? wall_clock64() : 0ull;
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     float3 mom = f3(0, 0, 0);
@@ -453,6 +457,10 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
             atomicAdd(&c[1], (unsigned long long)(long long)((double)mom.y * 4294967296.0));
             atomicAdd(&c[2], (unsigned long long)(long long)((double)mom.z * 4294967296.0));
         }
+    }
+    if (own_time && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        atomicAdd(&own_time[0], wall_clock64() - own_t0);
+        atomicAdd(&own_time[1], 1ull);
     }
 }
 
@@ -636,7 +644,8 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr,
                        h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2,
-                       (h->join_deferred && h->listed_on_s3) ? h->d_sync + 3 : (const unsigned int*)nullptr);
+                       (h->join_deferred && h->listed_on_s3) ? h->d_sync + 3 : (const unsigned int*)nullptr,
+                       (h->profiling == 2 || (h->profiling == 1 && h->prof_filter.find("integrate_chain") != std::string::npos)) ? h->d_chain_own : (unsigned long long*)nullptr);
     h->join_deferred = 0;
     if (bins.count) h->cbins_ready = true;
 }

@@ -166,6 +166,7 @@ struct remd_ctx {
     // set when a wait polled on the device ran out / a capped PME bin overflowed: the handle falls back to events, two chain
     // launches and the binning launch (api.hip: remd_recover_device_flag) instead of staying dead behind a sticky flag
     bool no_device_waits = false, no_chain_bins = false, no_resident = false;
+    unsigned long long* d_chain_own = nullptr;   // [2] profiling: sum of (end - flag seen) wall-clock ticks of workgroup (0, 0), launches
     unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
     hipStream_t stream3 = nullptr; bool listed_on_s3 = false;    // third stream: the listed terms of a force-only evaluation (joins through d_sync[3])

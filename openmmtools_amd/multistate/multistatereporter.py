@@ -86,6 +86,18 @@ class _RestrictedUnpickler(pickle.Unpickler):
         raise refuse
 
 
+def _reference_read(method):
+    """Reading methods answer from the reference's own netCDF4 store when the reporter was opened on one (read-only)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        if self._ref is not None:
+            return getattr(self._ref, method.__name__)(*args, **kwargs)
+        return method(self, *args, **kwargs)
+    return wrapper
+
+
 class MultiStateReporter:
     """multistatereporter.py:69.  ``storage`` is a path; the analysis store is ``<storage>`` (a directory), the
     checkpoint store ``<storage stem>_checkpoint`` beside it (the reference: ``<name>.nc`` and
@@ -101,6 +113,7 @@ class MultiStateReporter:
         self._files = {}
         self._meta = None
         self._open_mode = None
+        self._ref = None                  # a ReferenceStoreReader when `storage` is a netCDF4 file written by the reference
         if open_mode is not None:
             self.open(open_mode)
 
@@ -114,7 +127,12 @@ class MultiStateReporter:
         return self._checkpoint_interval
 
     def storage_exists(self):
-        return os.path.exists(os.path.join(self._storage_analysis, 'meta.json'))
+        from ._reference_store import is_reference_store
+        return is_reference_store(self._storage_analysis) or os.path.exists(os.path.join(self._storage_analysis, 'meta.json'))
+
+    @property
+    def is_reference_store(self):
+        return self._ref is not None
 
     def is_open(self):
         return self._open_mode is not None
@@ -122,6 +140,17 @@ class MultiStateReporter:
     def open(self, mode='r'):
         if mode not in ('r', 'w', 'a'):
             raise ValueError("open mode must be 'r', 'w' or 'a'")
+        from ._reference_store import is_reference_store, ReferenceStoreReader
+        if is_reference_store(self._storage_analysis):
+            # a store written by the reference itself (netCDF4): readable through libhdf5, never written (multistatereporter.py
+            # of the reference owns that format); a simulation resumed from it reports into a store of this package's own
+            if mode == 'w':
+                raise IOError('{} is a netCDF4 store written by the reference: it can be read and resumed from, not overwritten'.format(self._storage_analysis))
+            ckpt = self._storage_checkpoint if os.path.isfile(self._storage_checkpoint) else None
+            self._ref = ReferenceStoreReader(self._storage_analysis, ckpt)
+            self._checkpoint_interval = self._ref.checkpoint_interval
+            self._open_mode = 'r'
+            return
         if mode == 'r' and not self.storage_exists():
             raise IOError('no storage at {}'.format(self._storage_analysis))
         if mode == 'w':
@@ -160,6 +189,8 @@ class MultiStateReporter:
         pass                                   # every write is flushed when its file is closed
 
     def _require_write(self):
+        if self._ref is not None:
+            raise IOError('a store written by the reference is read-only here')
         if self._open_mode not in ('w', 'a'):
             raise IOError('storage is not open for writing')
 
@@ -206,18 +237,21 @@ class MultiStateReporter:
     def write_thermodynamic_states(self, thermodynamic_states, unsampled_states):
         self._write_object('thermodynamic_states', (list(thermodynamic_states), list(unsampled_states)))
 
+    @_reference_read
     def read_thermodynamic_states(self):
         return self._read_object('thermodynamic_states')
 
     def write_mcmc_moves(self, mcmc_moves):
         self._write_object('mcmc_moves', list(mcmc_moves))
 
+    @_reference_read
     def read_mcmc_moves(self):
         return self._read_object('mcmc_moves')
 
     def write_dict(self, name, data):
         self._write_object(name, dict(data))
 
+    @_reference_read
     def read_dict(self, name):
         return self._read_object(name)
 
@@ -229,6 +263,7 @@ class MultiStateReporter:
         self._files['neighborhoods'].write(iteration, energy_neighborhoods)
         self._files['unsampled_energies'].write(iteration, energy_unsampled_states)
 
+    @_reference_read
     def read_energies(self, iteration=slice(None)):
         """:817-863 -> (energy_thermodynamic_states, neighborhoods, energy_unsampled_states)."""
         e = self._files['energies'].read(iteration)
@@ -241,6 +276,7 @@ class MultiStateReporter:
         self._require_write()
         self._files['states'].write(iteration, state_indices)
 
+    @_reference_read
     def read_replica_thermodynamic_states(self, iteration=slice(None)):
         """:775-795."""
         return self._files['states'].read(iteration).astype(np.int64)
@@ -251,6 +287,7 @@ class MultiStateReporter:
         self._files['accepted'].write(iteration, n_accepted_matrix)
         self._files['proposed'].write(iteration, n_proposed_matrix)
 
+    @_reference_read
     def read_mixing_statistics(self, iteration=slice(None)):
         """:931-955."""
         return self._files['accepted'].read(iteration), self._files['proposed'].read(iteration)
@@ -260,6 +297,7 @@ class MultiStateReporter:
         self._require_write()
         self._files['timestamp'].write(iteration, time.time())
 
+    @_reference_read
     def read_timestamp(self, iteration=slice(None)):
         return self._files['timestamp'].read(iteration)
 
@@ -279,6 +317,7 @@ class MultiStateReporter:
             return
         self.write_online_data_dynamic_and_static(iteration, **kwargs)
 
+    @_reference_read
     def read_online_analysis_data(self, iteration, *keys):
         """:1236-1303: {key: value} at ``iteration`` (None: the most recent record).  KeyError for an unknown variable,
         IndexError when nothing was written at that iteration — the two exceptions the sampler's reader handles."""
@@ -303,6 +342,7 @@ class MultiStateReporter:
         with open(stem + '_real_time_analysis.yaml', 'a') as fh:
             fh.write(yaml.dump([data], sort_keys=False))
 
+    @_reference_read
     def read_online_data_if_present(self, iteration):
         out = {}
         for k in ('logZ', 'log_weights'):
@@ -322,6 +362,7 @@ class MultiStateReporter:
             json.dump(dict(last_iteration=int(iteration)), fh)
         os.replace(tmp, os.path.join(self._storage_analysis, 'last_iteration.json'))
 
+    @_reference_read
     def read_last_iteration(self, last_checkpoint=True):
         """:1020-1070: the last good iteration, or (default) the last one with a checkpoint at or below it."""
         path = os.path.join(self._storage_analysis, 'last_iteration.json')
@@ -338,6 +379,7 @@ class MultiStateReporter:
     def _checkpoint_path(self, iteration):
         return os.path.join(self._storage_checkpoint, 'iteration_%09d.npz' % iteration)
 
+    @_reference_read
     def read_checkpoint_iterations(self):
         if not os.path.isdir(self._storage_checkpoint):
             return []
@@ -359,6 +401,7 @@ class MultiStateReporter:
         os.replace(tmp, self._checkpoint_path(iteration))
         return True
 
+    @_reference_read
     def read_sampler_states(self, iteration, analysis_particles_only=False):
         """:1117-1165: None when ``iteration`` is not a checkpoint iteration."""
         path = self._checkpoint_path(iteration)

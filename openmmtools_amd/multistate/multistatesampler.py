@@ -238,9 +238,16 @@ class MultiStateSampler:
         return {}
 
     @classmethod
-    def from_storage(cls, storage, engine=None, comm=None):
+    def from_storage(cls, storage, engine=None, comm=None, continue_in=None, seed=None):
         """multistatesampler.py:263-299 + _restore_sampler_from_reporter (:956-1047): resume from the last checkpoint
-        iteration whose data is complete."""
+        iteration whose data is complete.
+
+        ``storage`` may also be a netCDF4 store WRITTEN BY THE REFERENCE (opened read-only through libhdf5, _reference_store.py):
+        states, moves, options, the last checkpoint (zero velocities for legacy files, as tests/test_sampling.py:2975-2983
+        asserts), energies and statistics are restored as the reference restores them and the run continues on the device.
+        The reference's file is never written: ``continue_in`` names a new store of this package's format that receives the
+        history read so far and every further iteration (None: the resumed sampler reports nowhere); ``seed`` is this
+        engine's Philox key (the reference's random streams cannot be continued)."""
         import importlib
         from .multistatereporter import MultiStateReporter
         rep = MultiStateReporter(storage) if isinstance(storage, (str, bytes, os.PathLike)) else storage
@@ -249,6 +256,8 @@ class MultiStateSampler:
         it = rep.read_last_iteration(last_checkpoint=True)
         if it is None:
             raise IOError('storage {} holds no complete checkpoint'.format(rep.filepath))
+        if rep.is_reference_store:
+            return cls._from_reference_store(rep, it, engine, comm, continue_in, seed)
         opts = rep.read_dict('options')
         if str(opts['module']).startswith('openmmtools_amd.'):
             klass = getattr(importlib.import_module(opts['module']), opts['cls'])
@@ -284,6 +293,70 @@ class MultiStateSampler:
         s._reporter = rep
         s._initialize_engine()
         s._mix_from_stored_energies = True
+        return s
+
+    @classmethod
+    def _from_reference_store(cls, rep, it, engine, comm, continue_in, seed):
+        import inspect
+        from .multistatereporter import MultiStateReporter
+        opts = dict(rep.read_dict('options'))
+        accepted = set()
+        for klass in cls.__mro__:
+            if klass is object:
+                continue
+            accepted |= set(inspect.signature(klass.__init__).parameters)
+        kwargs = {k: v for k, v in opts.items() if k in accepted and k not in ('mcmc_moves', 'number_of_iterations')}
+        dropped = sorted(k for k in opts if k not in accepted)
+        if dropped:
+            logger.warning('options of the reference store not understood by %s and ignored: %s', cls.__name__, dropped)
+        moves = rep.read_mcmc_moves()
+        n_iter = opts.get('number_of_iterations', 1)
+        s = cls(mcmc_moves=moves, number_of_iterations=float('inf') if n_iter is None else n_iter, engine=engine,
+                seed=0xC0FFEE if seed is None else seed, comm=comm, **kwargs)
+        thermo, unsampled = rep.read_thermodynamic_states()
+        sampler_states = rep.read_sampler_states(it)
+        labels = np.asarray(rep.read_replica_thermodynamic_states(it), dtype=np.int64)
+        s._pre_write_create(thermo, sampler_states, None, initial_thermodynamic_states=labels,
+                            unsampled_thermodynamic_states=unsampled, metadata=rep.read_dict('metadata'))
+        s._mcmc_moves = moves
+        s._iteration = int(it)
+        e, nb, eu = rep.read_energies(it)
+        s._energy_thermodynamic_states[:, :] = e
+        s._neighborhoods[:, :] = nb
+        s._energy_unsampled_states[:, :] = eu
+        acc, prop = rep.read_mixing_statistics(it)
+        s._n_accepted_matrix[:, :] = acc
+        s._n_proposed_matrix[:, :] = prop
+        s._restore_online(rep.read_online_data_if_present(it))
+        s._iteration0_energies_reported = True
+        s._reporter = None
+        s._initialize_engine()
+        s._mix_from_stored_energies = True
+        if continue_in is not None:
+            new = MultiStateReporter(continue_in) if isinstance(continue_in, (str, bytes, os.PathLike)) else continue_in
+            if s._comm.broadcast_object(bool(new.storage_exists()) if s._comm.rank == 0 else None):
+                raise RuntimeError('Storage file {} already exists; cowardly refusing to overwrite.'.format(new.filepath))
+            new._checkpoint_interval = rep.checkpoint_interval
+            if s._comm.rank == 0:
+                new.open('w')
+                new.initialize(s.n_replicas, s.n_states, len(unsampled), thermo[0].n_particles)
+                new.write_thermodynamic_states(thermo, unsampled)
+                new.write_mcmc_moves(moves)
+                new.write_dict('options', s._options())
+                new.write_dict('metadata', s._metadata)
+                E, NB, EU = rep.read_energies(slice(0, it + 1))
+                ST = rep.read_replica_thermodynamic_states(slice(0, it + 1))
+                ACC, PROP = rep.read_mixing_statistics(slice(0, it + 1))
+                for k in range(it + 1):                                  # the history the reference wrote, iteration by iteration
+                    new.write_replica_thermodynamic_states(ST[k], k)
+                    new.write_energies(E[k], NB[k], EU[k], k)
+                    new.write_mixing_statistics(ACC[k], PROP[k], k)
+                    new.write_timestamp(k)
+                    ck = rep.read_sampler_states(k)
+                    if ck is not None:
+                        new.write_sampler_states(ck, k)
+                new.write_last_iteration(it)
+            s._reporter = new
         return s
 
     def _restore_online(self, data):
