@@ -132,6 +132,23 @@ int  remd_set_integrator(remd_handle h, const char* splitting, double timestep_p
                          double collision_rate_invps, int n_steps,
                          int reassign_velocities, double constraint_tolerance);
 
+/* Heat, shadow work and Metropolization of LangevinIntegrator (integrators.py:1077-1125 constructor flags, :1175-1204 globals,
+   :1404-1460 substeps, :1539-1557 Metropolization; mcmc.py:1282-1316 passes the flags through the move).
+     heat         = sum over the O substeps of the change of the kinetic energy (:1448-1460), kJ/mol, per replica;
+     shadow work  = sum over the V substeps of the change of the kinetic energy (:1433-1446) and over the R substeps of the
+                    change of kinetic + potential energy (:1404-1423), kJ/mol, per replica;
+     a splitting string may hold "{" ... "}" around V / R substeps ("O { V R V } O"): at "}" every replica accepts the substeps
+     since "{" with probability min(1, exp(-shadow_work / kT)) (uniform from the Philox stream 7: (index of the "}" in the
+     string, global replica, global step)), on rejection x = x_old, v = -v_old; the shadow work restarts from 0 (:1544-1557).
+     A Metropolized string measures shadow work whatever the flag says (:1117-1119).
+   Measuring shadow work needs the potential energy before and after every R substep: two energy evaluations per "V R O R V"
+   step instead of one force evaluation (the reference pays the same through CustomIntegrator's `energy`).  Values accumulate
+   over remd_propagate / remd_step calls until remd_reset_work (LangevinIntegrator.reset, :1213-1218).
+   remd_get_work: any pointer may be NULL; arrays [R_local]; n_accepted / n_trials count the "}" decisions (:1286-1297).   */
+int  remd_set_work_measurement(remd_handle h, int measure_heat, int measure_shadow_work);
+int  remd_get_work(remd_handle h, double* heat, double* shadow_work, int64_t* n_accepted, int64_t* n_trials);
+int  remd_reset_work(remd_handle h);
+
 /* BaseIntegratorMove.n_restart_attempts (mcmc.py:668-776, retry loop :706-759): when a replica
    holds a NaN after remd_propagate's MD steps, its pre-propagate positions/velocities are
    restored and the move is repeated (fresh noise: the Philox counters carry the attempt

@@ -44,7 +44,7 @@ EXPORTS = [
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_test_xy_mfma', 'remd_get_energy_components', 'remd_profile_filter',
-    'remd_set_restart_attempts', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
+    'remd_set_restart_attempts', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
     'remd_set_energy_const_volume', 'remd_roof_microbench',
 ]
@@ -79,6 +79,9 @@ def load_library(path=None):
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
+    lib.remd_set_work_measurement.argtypes = [vp, C.c_int, C.c_int]
+    lib.remd_get_work.argtypes = [vp, c_double_p, c_double_p, c_int64_p, c_int64_p]
+    lib.remd_reset_work.argtypes = [vp]
     lib.remd_minimize.argtypes = [vp, C.c_double, C.c_int, c_int32_p, c_int32_p]
     lib.remd_set_barostat.argtypes = [vp, C.c_int, c_double_p, C.c_int]
     lib.remd_get_boxes.argtypes = [vp, c_double_p]
@@ -215,6 +218,20 @@ class HipEngine:
         self._check(self.lib.remd_set_integrator(self.h, splitting.encode(), float(timestep), float(collision_rate),
                                                  int(n_steps), int(bool(reassign_velocities)),
                                                  float(constraint_tolerance)), 'remd_set_integrator')
+
+    def set_work_measurement(self, measure_heat=False, measure_shadow_work=False):
+        """LangevinIntegrator(measure_heat=, measure_shadow_work=) (integrators.py:1077-1125)."""
+        self._check(self.lib.remd_set_work_measurement(self.h, int(bool(measure_heat)), int(bool(measure_shadow_work))), 'remd_set_work_measurement')
+
+    def get_work(self):
+        """dict(heat, shadow_work [kJ/mol], n_accepted, n_trials) per local replica, accumulated since the last reset_work."""
+        heat, sw = np.zeros(self.R), np.zeros(self.R)
+        na, nt = np.zeros(self.R, np.int64), np.zeros(self.R, np.int64)
+        self._check(self.lib.remd_get_work(self.h, _dp(heat), _dp(sw), _lp(na), _lp(nt)), 'remd_get_work')
+        return dict(heat=heat, shadow_work=sw, n_accepted=na, n_trials=nt)
+
+    def reset_work(self):
+        self._check(self.lib.remd_reset_work(self.h), 'remd_reset_work')
 
     def set_restart_attempts(self, n):
         """mcmc.py:706-759: retries of a move whose result holds a NaN (restored start state, fresh noise)."""

@@ -115,6 +115,7 @@ int remd_destroy(remd_handle h)
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     if (h->d_sync) hipFree(h->d_sync);
     if (h->d_chain_own) hipFree(h->d_chain_own);
+    if (h->d_work) { hipFree(h->d_work); hipFree(h->d_pe_prev); hipFree(h->d_xold); hipFree(h->d_vold); hipFree(h->d_accept); }
     if (h->d_chain_sync) hipFree(h->d_chain_sync);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -265,6 +266,42 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     h->forces_valid = false; h->force_zeroed = false;
     if (h->nb_method == REMD_NB_PME) { int rc = remd_pme_setup(h); if (rc) return rc; }
     return remd_set_labels(h, labels);
+}
+
+int remd_set_work_measurement(remd_handle h, int measure_heat, int measure_shadow_work)
+{
+    if (!h) return -1;
+    h->measure_heat = measure_heat ? 1 : 0; h->measure_shadow = measure_shadow_work ? 1 : 0;
+    h->graph_epoch++;
+    return 0;
+}
+
+int remd_reset_work(remd_handle h)
+{
+    if (!h) return -1;
+    hipSetDevice(h->device);
+    if (h->R <= 0) return 0;
+    int rc = remd_work_buffers(h); if (rc) return rc;
+    REMD_CHECK(h, hipMemsetAsync(h->d_work, 0, sizeof(long long) * 4 * h->R, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int remd_get_work(remd_handle h, double* heat, double* shadow_work, int64_t* n_accepted, int64_t* n_trials)
+{
+    if (!h || h->R <= 0) return remd_fail(h, -1, "remd_get_work: no replicas");
+    hipSetDevice(h->device);
+    int rc = remd_work_buffers(h); if (rc) return rc;
+    std::vector<long long> w(4 * (size_t)h->R);
+    REMD_CHECK(h, hipMemcpyAsync(w.data(), h->d_work, sizeof(long long) * w.size(), hipMemcpyDeviceToHost, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < h->R; ++r) {
+        if (heat) heat[r] = (double)w[4 * r] / 16777216.0;
+        if (shadow_work) shadow_work[r] = (double)w[4 * r + 1] / 16777216.0;
+        if (n_trials) n_trials[r] = w[4 * r + 2];
+        if (n_accepted) n_accepted[r] = w[4 * r + 2] - w[4 * r + 3];
+    }
+    return 0;
 }
 
 int remd_set_restart_attempts(remd_handle h, int n)
@@ -466,7 +503,7 @@ int remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t f
     // a test-hook splitting may consist of a single substep: count with the configured integrator
     std::string s(splitting ? splitting : "");
     tokens.clear();
-    for (char c : s) { if (c == ' ') continue; c = (char)toupper(c); if (c != 'V' && c != 'R' && c != 'O') return remd_fail(h, -3, "remd_step: token must be V, R or O"); tokens.push_back(c); }
+    for (char c : s) { if (c == ' ') continue; c = (char)toupper(c); if (c != 'V' && c != 'R' && c != 'O' && c != '{' && c != '}') return remd_fail(h, -3, "remd_step: token must be V, R, O, { or }"); tokens.push_back(c); }
     nV = h->nV; nR = h->nR; nO = h->nO;
     int rc = remd_run_steps(h, tokens, nV, nR, nO, iteration, first_step, n_steps);
     if (rc) return rc;

@@ -39,10 +39,11 @@ struct chain_prog {
                               // body, so a replayed (graph) launch shifts cmm_w / cmm_r by the parity of ctr[1] - body_idx
     int m_buf;                // token 'M' (inside a chain): add sum(m v) into momentum buffer m_buf, then wait until every workgroup
     unsigned int m_epoch;     // of the replica has done so (m_epoch-th barrier of this handle): the 'C' that follows reads the sum
+    int measure;              // bit 0: heat (kinetic-energy change of the O substeps), bit 1: kinetic part of the shadow work (V, R substeps)
 };
 
 // state of one constraint unit between the segments of a chain (registers)
-struct unit_regs { float3 x[4], v[4]; float im[4]; };
+struct unit_regs { float3 x[4], v[4]; float im[4]; float heat, shadow; };
 
 struct settle_const { float mO, mH, ra, rb, rc, dOH, dHH; };
 
@@ -250,11 +251,18 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                                           const long long* F, long long* Fw, const float* __restrict__ invmass, float kT,
                                           uint32_t rg, uint64_t seed, const long long* __restrict__ cmm_r, float inv_total_mass,
                                           long long gstep_base, const remd_chain_bins& bins, int r,
-                                          unit_regs& S, int t0, int t1, bool first, bool last)
+                                          unit_regs& S, int t0, int t1, bool first, bool last,
+                                          float4* __restrict__ Xold, float4* __restrict__ Vold)
 {
     float3 (&x)[4] = S.x; float3 (&v)[4] = S.v;
     float (&im)[4] = S.im;
+    // kinetic energy of this unit's atoms (integrators.py:1141: 0.5 m v^2 summed over the degrees of freedom)
+    auto unit_ke = [&]() { float ke = 0.f;
+#pragma unroll
+        for (int k = 0; k < NAT; ++k) ke += 0.5f * dot3(v[k], v[k]) * frcp(im[k]);
+        return ke; };
     if (first) {
+        S.heat = 0.f; S.shadow = 0.f;
 #pragma unroll
         for (int k = 0; k < NAT; ++k) {
             const float4 p = P[idx[k]], w = V[idx[k]];
@@ -264,7 +272,15 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
     }
     for (int t = t0; t < t1; ++t) {
         const char tok = prog.tok[t];
-        if (tok == 'V') {
+        const float ke0 = ((prog.measure & 1) && tok == 'O') || ((prog.measure & 2) && (tok == 'V' || tok == 'R')) ? unit_ke() : 0.f;
+        if (tok == '{') {
+            // Metropolization starts: remember x and v (integrators.py:1539-1542)
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) {
+                Xold[idx[k]] = make_float4(x[k].x, x[k].y, x[k].z, 0.f);
+                Vold[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
+            }
+        } else if (tok == 'V') {
 #pragma unroll
             for (int k = 0; k < NAT; ++k) {
                 const float s = prog.hV * im[k] * (1.0f / 4294967296.0f);
@@ -316,6 +332,8 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
 #pragma unroll
             for (int k = 0; k < NAT; ++k) { v[k].x -= sx; v[k].y -= sy; v[k].z -= sz; }
         }
+        if ((prog.measure & 1) && tok == 'O') S.heat += unit_ke() - ke0;                           // :1448-1460
+        if ((prog.measure & 2) && (tok == 'V' || tok == 'R')) S.shadow += unit_ke() - ke0;         // :1409-1446 (kinetic part)
     }
     float3 mom = f3(0, 0, 0);
     if (!last) return mom;
@@ -353,7 +371,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
                             const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
                             unsigned int* chain_sync, unsigned int* chain_sync_err, const unsigned int* join_flag2,
-                            unsigned long long* own_time)
+                            unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold)
 {
     if (join_flag) {
         // the forces of the direct-space stream: poll its "done" flag here instead of behind a cross-stream event (remd_ctx::d_sync)
@@ -405,7 +423,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         while (t1 < prog.n && prog.tok[t1] != 'M') ++t1;
         const bool first = t0 == 0, last = t1 == prog.n;
         if (active) {
-#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, gstep_base, bins, r, S, t0, t1, first, last)
+#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, gstep_base, bins, r, S, t0, t1, first, last, xold ? xold + (size_t)r * Npad : nullptr, vold ? vold + (size_t)r * Npad : nullptr)
             if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
             else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
             else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
@@ -456,6 +474,16 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
             atomicAdd(&c[0], (unsigned long long)(long long)((double)mom.x * 4294967296.0));
             atomicAdd(&c[1], (unsigned long long)(long long)((double)mom.y * 4294967296.0));
             atomicAdd(&c[2], (unsigned long long)(long long)((double)mom.z * 4294967296.0));
+        }
+    }
+    if (prog.measure && work) {
+        // heat / kinetic shadow work of this launch: wavefront sums, one fixed-point atomic per wave (order-independent)
+        float hq = active ? S.heat : 0.f, sw = active ? S.shadow : 0.f;
+        for (int off = 32; off > 0; off >>= 1) { hq += __shfl_xor(hq, off); sw += __shfl_xor(sw, off); }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* w = reinterpret_cast<unsigned long long*>(work + 4 * (size_t)r);
+            if (prog.measure & 1) atomicAdd(&w[0], (unsigned long long)(long long)((double)hq * 16777216.0));
+            if (prog.measure & 2) atomicAdd(&w[1], (unsigned long long)(long long)((double)sw * 16777216.0));
         }
     }
     if (own_time && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -625,11 +653,19 @@ int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& 
         if (tok == "V" || tok == "V0") { tokens.push_back('V'); nV++; }
         else if (tok == "R") { tokens.push_back('R'); nR++; }
         else if (tok == "O") { tokens.push_back('O'); nO++; }
-        else return remd_fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V R O)");
+        else if (tok == "{" || tok == "}") tokens.push_back(tok[0]);      // Metropolization of the substeps in between (:1539-1557)
+        else return remd_fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V R O { })");
         i = j;
     }
     if (tokens.empty()) return remd_fail(h, -3, "empty splitting string");
     if (nR == 0 || nV == 0) return remd_fail(h, -3, "splitting needs at least one R and one V (integrators.py:1376-1385)");
+    int depth = 0;
+    for (char c : tokens) {
+        if (c == '{') { if (++depth > 1) return remd_fail(h, -3, "nested '{' in the splitting string"); }
+        else if (c == '}') { if (--depth < 0) return remd_fail(h, -3, "'}' without '{' in the splitting string"); }
+        else if (c == 'O' && depth > 0) return remd_fail(h, -3, "O substeps cannot be Metropolized (integrators.py:1387-1401)");
+    }
+    if (depth != 0) return remd_fail(h, -3, "'{' without '}' in the splitting string");
     return 0;
 }
 
@@ -645,13 +681,68 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr,
                        h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2,
                        (h->join_deferred && h->listed_on_s3) ? h->d_sync + 3 : (const unsigned int*)nullptr,
-                       (h->profiling == 2 || (h->profiling == 1 && h->prof_filter.find("integrate_chain") != std::string::npos)) ? h->d_chain_own : (unsigned long long*)nullptr);
+                       (h->profiling == 2 || (h->profiling == 1 && h->prof_filter.find("integrate_chain") != std::string::npos)) ? h->d_chain_own : (unsigned long long*)nullptr,
+                       h->d_work, h->d_xold, h->d_vold);
     h->join_deferred = 0;
     if (bins.count) h->cbins_ready = true;
 }
 
 __global__ void ctr_set_kernel(long long* ctr, long long gstep, long long body) { ctr[0] = gstep; ctr[1] = body; }
 __global__ void ctr_tick_kernel(long long* ctr) { ctr[0] += 1; ctr[1] += 1; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Heat, shadow work and Metropolization (integrators.py:1175-1204, 1404-1460, 1539-1557).  The kinetic-energy changes of the
+// substeps are summed inside the chain kernel (fixed point, per replica); the potential-energy change of an R substep needs the
+// energy at the positions before and after it: remd_run_steps evaluates energies there (the evaluation behind an R also
+// provides the forces of the V that follows, so a step of "V R O R V" costs two evaluations with energies instead of one without).
+#define WORK_SCALE 16777216.0        // 2^24: 6e-8 kJ/mol
+__global__ void work_pe_kernel(int R, const double* __restrict__ U, double* __restrict__ pe_prev, long long* __restrict__ work, int accumulate)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    if (accumulate) work[4 * r + 1] += (long long)((U[r] - pe_prev[r]) * WORK_SCALE);          // :1420-1423 (potential part)
+    pe_prev[r] = U[r];
+}
+// '}' (:1544-1557): accept = step(exp(-shadow_work / kT) - uniform); trials++; on rejection x = xold, v = -vold; shadow_work = 0
+__global__ void metropolis_kernel(int R, int r_begin, uint64_t seed, long long gstep, int brace, const int64_t* __restrict__ labels,
+                                  const double* __restrict__ beta, long long* __restrict__ work, int* __restrict__ accept)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double sw = (double)work[4 * r + 1] / WORK_SCALE;
+    const philox4 w = remd_philox(seed, REMD_STREAM_METROPOLIS, (uint32_t)brace, (uint32_t)(r_begin + r), (uint64_t)gstep);
+    const double u = remd_u53(w.w[2], w.w[3]);
+    const int acc = (exp(-sw * beta[labels[r_begin + r]]) - u >= 0.0) ? 1 : 0;
+    accept[r] = acc;
+    work[4 * r + 2] += 1;
+    if (!acc) work[4 * r + 3] += 1;
+    work[4 * r + 1] = 0;
+}
+__global__ __launch_bounds__(256)
+void metropolis_restore_kernel(int N, int Npad, const int* __restrict__ accept, float4* __restrict__ pos, float4* __restrict__ vel,
+                               const float4* __restrict__ xold, const float4* __restrict__ vold)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (i >= N || accept[r]) return;
+    const size_t o = (size_t)r * Npad + i;
+    pos[o] = xold[o];
+    const float4 v = vold[o];
+    vel[o] = make_float4(-v.x, -v.y, -v.z, 0.f);
+}
+int remd_work_buffers(remd_ctx* h)
+{
+    if (h->work_R == h->R && h->d_work) return 0;
+    if (h->d_work) { hipFree(h->d_work); hipFree(h->d_pe_prev); hipFree(h->d_xold); hipFree(h->d_vold); hipFree(h->d_accept); }
+    h->d_work = nullptr;
+    REMD_CHECK(h, hipMalloc(&h->d_work, sizeof(long long) * 4 * h->R));
+    REMD_CHECK(h, hipMalloc(&h->d_pe_prev, sizeof(double) * h->R));
+    REMD_CHECK(h, hipMalloc(&h->d_xold, sizeof(float4) * (size_t)h->R * h->Npad));
+    REMD_CHECK(h, hipMalloc(&h->d_vold, sizeof(float4) * (size_t)h->R * h->Npad));
+    REMD_CHECK(h, hipMalloc(&h->d_accept, sizeof(int) * h->R));
+    REMD_CHECK(h, hipMemsetAsync(h->d_work, 0, sizeof(long long) * 4 * h->R, h->stream));
+    h->work_R = h->R;
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Resident small-system path (round 3).  For systems of up to 1024 atoms without constraints, mesh or listed terms (the
@@ -891,6 +982,8 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
     if (!enabled || h->no_resident) return 0;
     if (h->N > 1024 || h->n_settle > 0 || h->n_shake > 0 || h->n_bonds > 0 || h->n_angles > 0 || h->n_torsions > 0) return 0;
     if (h->baro_frequency > 0 || h->profiling == 2 || h->capturing || (int)tokens.size() > MAX_TOK || n_steps < 1) return 0;
+    if (h->measure_heat || h->measure_shadow) return 0;
+    for (char c : tokens) if (c != 'V' && c != 'R' && c != 'O') return 0;
     int ok = 0, method = -1, alch = 0; nb_params p{}; const float4* param = nullptr; const float* rep_lam = nullptr;
     int rc = remd_nb_resident_info(h, &ok, &method, &alch, &p, &param, &rep_lam);
     if (rc) return rc;
@@ -971,6 +1064,12 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     base.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO));       // :1146
     base.nO = nO > 0 ? nO : 1;
     base.cmm_r = -1; base.cmm_w = 0; base.zero_force = 0;
+    int n_braces = 0;
+    for (char c : tokens) n_braces += (c == '}');
+    const bool shadow = h->measure_shadow || n_braces > 0;              // a Metropolized program measures shadow work (:1117-1119)
+    base.measure = (h->measure_heat ? 1 : 0) | (shadow ? 2 : 0);
+    if (base.measure) { int rcw = remd_work_buffers(h); if (rcw) return rcw; }
+    bool pe_valid = false;             // d_pe_prev holds U at the current positions
     chain_prog cur = base; cur.n = 0;
     int cmm_w = 0;                     // accumulator the next momentum sum goes to
     bool zeroed_by_chain = false;
@@ -979,7 +1078,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     // the floor of a step is the dependent chain of kernels, not the host -- see DESIGN.md) ------------------------------
     const bool graph_env = getenv("REMD_GRAPH") && atoi(getenv("REMD_GRAPH")) != 0;      // read per call: the parity test switches it
     static const int prof_sample = getenv("REMD_GRAPH_PROF_BODIES") ? atoi(getenv("REMD_GRAPH_PROF_BODIES")) : 24;
-    const bool graph_ok = graph_env && h->profiling != 2 && h->baro_frequency == 0 && h->cmm_frequency <= 1 && n_steps >= 6;
+    const bool graph_ok = graph_env && h->profiling != 2 && h->baro_frequency == 0 && h->cmm_frequency <= 1 && n_steps >= 6 && !base.measure;
     if (graph_ok) {
         if (!h->d_ctr) REMD_CHECK(h, hipMalloc(&h->d_ctr, 2 * sizeof(long long)));
         hipLaunchKernelGGL(ctr_set_kernel, dim3(1), dim3(1), 0, h->stream, h->d_ctr, gstep0, 0ll);
@@ -1051,8 +1150,30 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             int rc = remd_barostat_attempt(h);
             if (rc) return rc;
         }
-        int oidx = 0;
+        int oidx = 0, brace = 0;
+        auto evaluate_with_energy = [&](bool accumulate) -> int {
+            // energies (and forces) at the current positions; accumulate: add U - U_prev to the shadow work (:1420-1423)
+            flush(false);
+            h->force_zeroed = zeroed_by_chain;
+            zeroed_by_chain = false;
+            int rc = remd_compute_forces(h, true);
+            if (rc) return rc;
+            hipLaunchKernelGGL(work_pe_kernel, dim3((h->R + 63) / 64), dim3(64), 0, h->stream, h->R, h->d_potential, h->d_pe_prev, h->d_work, accumulate ? 1 : 0);
+            pe_valid = true;
+            return 0;
+        };
         for (char tok : tokens) {
+            if (tok == '{') { push('{', 0, gstep); continue; }
+            if (tok == '}') {
+                flush(false);
+                hipLaunchKernelGGL(metropolis_kernel, dim3((h->R + 63) / 64), dim3(64), 0, h->stream, h->R, h->r_begin, h->seed, gstep, brace++,
+                                   h->d_labels, h->d_beta, h->d_work, h->d_accept);
+                hipLaunchKernelGGL(metropolis_restore_kernel, dim3((h->N + 255) / 256, h->R), dim3(256), 0, h->stream, h->N, h->Npad, h->d_accept,
+                                   h->d_pos, h->d_vel, h->d_xold, h->d_vold);
+                h->forces_valid = false; pe_valid = false;         // rejected replicas are back at their old positions
+                continue;
+            }
+            if (tok == 'R' && shadow && !pe_valid) { int rc = evaluate_with_energy(false); if (rc) return rc; }
             if (tok == 'V' && !h->forces_valid) {
                 flush(false, true);
                 h->force_zeroed = zeroed_by_chain;
@@ -1064,7 +1185,10 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             }
             push(tok, tok == 'O' ? oidx : 0, gstep);
             if (tok == 'O') oidx++;
-            if (tok == 'R') h->forces_valid = false;
+            if (tok == 'R') {
+                h->forces_valid = false;
+                if (shadow) { int rc = evaluate_with_energy(true); if (rc) return rc; }
+            }
         }
         if (graph_ok) hipLaunchKernelGGL(ctr_tick_kernel, dim3(1), dim3(1), 0, h->stream, h->d_ctr);
         return 0;

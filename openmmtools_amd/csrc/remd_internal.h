@@ -108,6 +108,12 @@ struct remd_ctx {
     double dt = 0.001, gamma = 1.0, constraint_tol = 1e-8;
     int n_steps = 1; int reassign = 1;
     bool has_integrator = false;
+    // heat / shadow work / Metropolization (integrators.py:1175-1204, 1404-1460, 1539-1557)
+    int measure_heat = 0, measure_shadow = 0;                   // (a splitting with '{' '}' measures shadow work whatever the flag says)
+    long long* d_work = nullptr;       // [R][4] fixed point 2^-24 kJ/mol: heat, shadow work; integers: Metropolis trials, rejections
+    double* d_pe_prev = nullptr;       // [R] potential energy at the positions the last energy evaluation saw
+    float4* d_xold = nullptr; float4* d_vold = nullptr; int* d_accept = nullptr;   // '{' snapshot, per-replica decision of '}'
+    int work_R = 0;
 
     // ---- replicas -------------------------------------------------------------------
     int R_global = 0, r_begin = 0, R = 0;     // R = local replicas
@@ -239,6 +245,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                    int64_t iteration, int64_t first_step, int n_steps);
 int remd_assign_velocities(remd_ctx* h, int64_t iteration);
 int remd_kinetic_energy(remd_ctx* h);
+int remd_work_buffers(remd_ctx* h);                    // heat / shadow-work accumulators and the '{' snapshot of the local replicas
 void remd_free_step_graph(remd_ctx* h);
 
 // ---- forces.hip -------------------------------------------------------------------------

@@ -18,6 +18,7 @@
 #define REMD_STREAM_SAMS      3u  // a = replica ; t = iteration
 #define REMD_STREAM_VELOCITY  4u  // a = atom, b = global replica ; t = iteration
 #define REMD_STREAM_OU        5u  // a = atom, b = global replica ; t = global O-substep counter
+#define REMD_STREAM_METROPOLIS 7u // a = index of the '}' inside the step program, b = global replica ; t = global step
 #define REMD_STREAM_BAROSTAT  6u  // a = 0: volume draw, 1: acceptance uniform ; b = global replica ; t = attempt counter
 
 struct philox4 { uint32_t w[4]; };

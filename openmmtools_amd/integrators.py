@@ -14,14 +14,15 @@ class LangevinIntegrator:
     def __init__(self, temperature=298.0 * unit.kelvin, collision_rate=1.0 / unit.picoseconds,
                  timestep=1.0 * unit.femtoseconds, splitting="V R O R V", constraint_tolerance=1e-8,
                  measure_shadow_work=False, measure_heat=False):
-        if measure_shadow_work or measure_heat:
-            raise NotImplementedError('heat / shadow-work accumulators are not implemented (SURVEY 8(f) #3)')
         self._temperature = float(temperature)
         self._gamma = float(collision_rate)
         self._timestep = float(timestep)
         self._constraint_tolerance = float(constraint_tolerance)
         self._splitting = splitting
         self._ORV_counts, self._mts, self._force_group_nV = self._parse_splitting_string(splitting)
+        self._metropolized_integrator = '{' in splitting                     # integrators.py:1114-1119
+        self._measure_heat = bool(measure_heat)
+        self._measure_shadow_work = bool(measure_shadow_work) or self._metropolized_integrator
 
     # ---- reference API ---------------------------------------------------------------
     def getStepSize(self):
@@ -42,7 +43,17 @@ class LangevinIntegrator:
 
     @property
     def is_metropolized(self):
-        return False
+        """integrators.py:1304-1307."""
+        return self._metropolized_integrator
+
+    @property
+    def measure_heat(self):
+        return self._measure_heat
+
+    @property
+    def measure_shadow_work(self):
+        """True for every Metropolized splitting, whatever the constructor flag said (integrators.py:1117-1119)."""
+        return self._measure_shadow_work
 
     @property
     def splitting(self):
@@ -67,18 +78,28 @@ class LangevinIntegrator:
     # ---- parsing (integrators.py:1337-1402, 1474-1537) --------------------------------------
     @staticmethod
     def _sanity_check(splitting):
+        """integrators.py:1337-1402: step names, one V and one R at least, balanced non-nested braces without an O inside."""
         tokens = splitting.split(' ')
-        if '{' in splitting or '}' in splitting:
-            raise NotImplementedError('Metropolized splittings ("{ }") are not implemented (GHMC is out of scope)')
+        depth = 0
         for t in tokens:
             if t == '':
                 raise ValueError('Invalid step name: splitting has repeated or trailing spaces')
+            if t in '{}':
+                depth += 1 if t == '{' else -1
+                if depth < 0 or depth > 1:
+                    raise ValueError('Use of { and } must be balanced and not nested')       # :1366-1374
+                continue
             if t[0] not in 'ORV':
-                raise ValueError("Invalid step name '%s' used; valid step names are R, V, O" % t)
+                raise ValueError("Invalid step name '%s' used; valid step names are R, V, O, { and }" % t)
             if t[0] != 'V' and len(t) > 1:
                 raise ValueError("Invalid step name '%s'" % t)
             if t[0] == 'V' and len(t) > 1 and not t[1:].isdigit():
                 raise ValueError("Invalid force group in step '%s'" % t)
+            if t[0] == 'O' and depth > 0:
+                raise ValueError('Shadow work generating steps found outside the Metropolization block' if False else
+                                 'O steps cannot be inside the Metropolization block')          # :1387-1401
+        if depth != 0:
+            raise ValueError('Use of { and } must be balanced')
         if 'R' not in tokens:
             raise ValueError('Must have at least one R step')
         if not any(t[0] == 'V' for t in tokens):
@@ -88,7 +109,7 @@ class LangevinIntegrator:
         splitting_string = splitting_string.upper()
         self._sanity_check(splitting_string)
         steps = splitting_string.split(' ')
-        counts = {s: sum(1 for t in steps if t[0] == s) for s in 'ORV'}
+        counts = {s: sum(1 for t in steps if t[0] == s) for s in 'ORV{}'}
         groups = set(t[1:] for t in steps if t[0] == 'V' and len(t) > 1)
         mts = len(groups) > 1
         if mts:

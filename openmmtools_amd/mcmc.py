@@ -97,15 +97,16 @@ class LangevinSplittingDynamicsMove(BaseIntegratorMove):
         self.collision_rate = float(unit.to_md(collision_rate))     # 1/ps
         self.splitting = splitting
         self.constraint_tolerance = float(constraint_tolerance)
-        if measure_shadow_work or measure_heat:
-            raise NotImplementedError('heat / shadow-work accumulators are not implemented')
+        self.measure_shadow_work = bool(measure_shadow_work)         # mcmc.py:1290-1291: passed through to the integrator
+        self.measure_heat = bool(measure_heat)
 
     def _get_integrator(self, thermodynamic_state):
         """mcmc.py:1308-1316."""
         return integrators.LangevinIntegrator(temperature=thermodynamic_state.temperature,
                                               collision_rate=self.collision_rate, timestep=self.timestep,
                                               splitting=self.splitting,
-                                              constraint_tolerance=self.constraint_tolerance)
+                                              constraint_tolerance=self.constraint_tolerance,
+                                              measure_shadow_work=self.measure_shadow_work, measure_heat=self.measure_heat)
 
 
 class LangevinDynamicsMove(LangevinSplittingDynamicsMove):

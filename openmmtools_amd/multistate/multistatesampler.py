@@ -433,7 +433,8 @@ class MultiStateSampler:
         if isinstance(m, mcmc.MonteCarloBarostatMove):
             return ('barostat', m.n_attempts)
         if isinstance(m, mcmc.LangevinSplittingDynamicsMove):
-            return ('langevin', m.timestep, m.collision_rate, m.n_steps, m.reassign_velocities, m.splitting)
+            return ('langevin', m.timestep, m.collision_rate, m.n_steps, m.reassign_velocities, m.splitting,
+                    getattr(m, 'measure_heat', False), getattr(m, 'measure_shadow_work', False))
         raise NotImplementedError('the device engine propagates with Langevin(Splitting)DynamicsMove and '
                                   'MonteCarloBarostatMove (alone or in a SequenceMove) only')
 
@@ -470,6 +471,8 @@ class MultiStateSampler:
             eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
                                move.reassign_velocities, move.constraint_tolerance)
             eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
+            if hasattr(eng, 'set_work_measurement'):                              # mcmc.py:1308-1316: the move's flags reach the integrator
+                eng.set_work_measurement(getattr(move, 'measure_heat', False), getattr(move, 'measure_shadow_work', False))
 
     def _state_energy_constants(self, states):
         """Additive per-state potential constants: the lambda-dependent long-range correction of the

@@ -254,6 +254,7 @@ struct Replica {
     double box[3] = {0, 0, 0};
     bool f_valid = false;
     double baro[5] = {0, 0, 0, 0, 0};             // volume scale, attempted, accepted (adaptation window), total attempted, total accepted
+    double heat = 0, shadow = 0; long long n_trials = 0, n_rejected = 0;   // remd_get_work (integrators.py:1175-1204, 1539-1557)
     // Verlet list
     std::vector<double> x_list; double box_list[3] = {0, 0, 0};
     std::vector<int> pair_i, pair_j;              // i < j, not excluded, within rc + skin at build time
@@ -767,6 +768,7 @@ struct remd_ctx {
     std::vector<double> pressure; int baro_frequency = 0; long long baro_steps = 0, baro_attempts = 0;
     std::vector<char> tokens; int nV = 0, nR = 0, nO = 0;
     double dt = 0, gamma = 0; int n_steps = 0, reassign = 0, n_restart_attempts = 0;
+    int measure_heat = 0, measure_shadow = 0;
     int R = 0, R_global = 0, r_begin = 0;
     std::vector<Replica> reps;
     std::vector<int64_t> labels;
@@ -801,11 +803,19 @@ static int parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>
         if (tok == "V" || tok == "V0") { tokens.push_back('V'); nV++; }
         else if (tok == "R") { tokens.push_back('R'); nR++; }
         else if (tok == "O") { tokens.push_back('O'); nO++; }
-        else return fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V R O)");
+        else if (tok == "{" || tok == "}") tokens.push_back(tok[0]);
+        else return fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V R O { })");
         i = j;
     }
     if (tokens.empty()) return fail(h, -3, "empty splitting string");
     if (nR == 0 || nV == 0) return fail(h, -3, "splitting needs at least one R and one V (integrators.py:1376-1385)");
+    int depth = 0;
+    for (char c : tokens) {
+        if (c == '{') { if (++depth > 1) return fail(h, -3, "nested '{' in the splitting string"); }
+        else if (c == '}') { if (--depth < 0) return fail(h, -3, "'}' without '{' in the splitting string"); }
+        else if (c == 'O' && depth > 0) return fail(h, -3, "O substeps cannot be Metropolized (integrators.py:1387-1401)");
+    }
+    if (depth != 0) return fail(h, -3, "'{' without '}' in the splitting string");
     return 0;
 }
 
@@ -845,6 +855,12 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
     std::vector<double> x1;
     if (cons) x1.resize(3 * N);
     double* x = rep.x.data(); double* v = rep.v.data();
+    bool braces = false;
+    for (char c : tokens) braces |= (c == '}');
+    const bool m_heat = h->measure_heat != 0, m_shadow = h->measure_shadow != 0 || braces;
+    auto ke = [&]() { double e = 0; for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) e += 0.5 * s.mass[i] * v[3 * i + k] * v[3 * i + k]; return e; };
+    auto pe = [&]() { const int64_t kk = h->labels[rg]; return evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], nullptr, thread_fft(h)).total(); };
+    std::vector<double> xold, vold;
     for (int st = 0; st < n_steps; ++st) {
         const int64_t gstep = iteration * (int64_t)h->n_steps + first_step + st;
         if (s.cmm > 0 && ((first_step + st) % s.cmm) == 0) {              // CMMotionRemover at the top of a step (:1313)
@@ -859,14 +875,31 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
             barostat_attempt(h, r, attempt);
             x = rep.x.data();
         }
-        int oidx = 0;
+        int oidx = 0, brace = 0;
         for (char tok : tokens) {
-            if (tok == 'V') {
+            if (tok == '{') {                                                                                            // :1539-1542
+                xold = rep.x; vold = rep.v;
+            } else if (tok == '}') {                                                                                     // :1544-1557
+                uint32_t w[4];
+                oracle_draw(h->seed, 7u, (uint32_t)brace, (uint32_t)rg, (uint64_t)gstep, w);
+                const double u = (double)(((uint64_t)w[2] << 21) | (uint64_t)(w[3] >> 11)) / 9007199254740992.0;
+                rep.n_trials++;
+                if (!(exp(-rep.shadow / kT) - u >= 0.0)) {
+                    rep.n_rejected++;
+                    for (int i = 0; i < 3 * N; ++i) { x[i] = xold[i]; v[i] = -vold[i]; }
+                    rep.f_valid = false; rep.list_valid = false;
+                }
+                rep.shadow = 0.0;
+                brace++;
+            } else if (tok == 'V') {
                 ensure_forces(h, r);
                 const double* f = rep.f.data();
+                const double ke0 = m_shadow ? ke() : 0.0;
                 for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) v[3 * i + k] += hV * f[3 * i + k] * s.invm[i];   // :1440-1442
                 if (cons) rattle(s, x, v);
+                if (m_shadow) rep.shadow += ke() - ke0;                                                                  // :1444-1446
             } else if (tok == 'R') {
+                const double e0 = m_shadow ? ke() + pe() : 0.0;                                                          // :1407-1409
                 if (cons) {
                     for (int i = 0; i < 3 * N; ++i) x1[i] = x[i] + hR * v[i];                                            // :1414
                     std::vector<double> xc(x1);
@@ -875,7 +908,9 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                     rattle(s, x, v);                                                                                     // :1418
                 } else for (int i = 0; i < 3 * N; ++i) x[i] += hR * v[i];
                 rep.f_valid = false;
+                if (m_shadow) rep.shadow += ke() + pe() - e0;                                                            // :1420-1423
             } else {
+                const double ke0 = m_heat ? ke() : 0.0;
                 const uint64_t cnt = (uint64_t)gstep * (uint64_t)std::max(1, nO) + (uint64_t)oidx;
                 for (int i = 0; i < N; ++i) {
                     double g[3]; gaussians3(h->seed, 5u, i, rg, cnt, g);
@@ -884,6 +919,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                 }
                 if (cons) rattle(s, x, v);
                 oidx++;
+                if (m_heat) rep.heat += ke() - ke0;                                                                      // :1457-1460
             }
         }
     }
@@ -1189,6 +1225,30 @@ int remd_set_integrator(remd_handle h, const char* splitting, double dt, double 
     return 0;
 }
 
+int remd_set_work_measurement(remd_handle h, int measure_heat, int measure_shadow_work)
+{
+    if (!h) return -1;
+    h->measure_heat = measure_heat ? 1 : 0; h->measure_shadow = measure_shadow_work ? 1 : 0;
+    return 0;
+}
+int remd_reset_work(remd_handle h)
+{
+    if (!h) return -1;
+    for (auto& rep : h->reps) { rep.heat = 0; rep.shadow = 0; rep.n_trials = 0; rep.n_rejected = 0; }
+    return 0;
+}
+int remd_get_work(remd_handle h, double* heat, double* shadow_work, int64_t* n_accepted, int64_t* n_trials)
+{
+    if (!h || h->R <= 0) return fail(h, -1, "remd_get_work: no replicas");
+    for (int r = 0; r < h->R; ++r) {
+        const Replica& rep = h->reps[r];
+        if (heat) heat[r] = rep.heat;
+        if (shadow_work) shadow_work[r] = rep.shadow;
+        if (n_trials) n_trials[r] = rep.n_trials;
+        if (n_accepted) n_accepted[r] = rep.n_trials - rep.n_rejected;
+    }
+    return 0;
+}
 int remd_set_restart_attempts(remd_handle h, int n)
 {
     if (!h || n < 0) return fail(h, -1, "remd_set_restart_attempts: bad arguments");
@@ -1318,7 +1378,7 @@ int remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t f
     for (const char* c = splitting ? splitting : ""; *c; ++c) {
         if (*c == ' ') continue;
         const char t = (char)toupper(*c);
-        if (t != 'V' && t != 'R' && t != 'O') return fail(h, -3, "remd_step: token must be V, R or O");
+        if (t != 'V' && t != 'R' && t != 'O' && t != '{' && t != '}') return fail(h, -3, "remd_step: token must be V, R, O, { or }");
         tokens.push_back(t);
     }
 #pragma omp parallel for schedule(dynamic, 1)

@@ -36,6 +36,7 @@ KB = 0.008314462618153242          # kJ/mol/K  (openmmtools/constants.py:7)
 ONE_4PI_EPS0 = 138.93545764438198  # openmmtools/constants.py:12-14
 
 STREAM_SWAP_ALL, STREAM_NEIGHBOR, STREAM_SAMS, STREAM_VELOCITY, STREAM_OU = 1, 2, 3, 4, 5
+STREAM_METROPOLIS = 7          # a = index of the '}' in the step program, b = global replica, t = global step; uniform from words 2, 3
 
 _M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 _W0, _W1 = 0x9E3779B9, 0xBB67AE85
@@ -237,6 +238,10 @@ class OracleLangevin:
         n_steps = self.n_steps if n_steps is None else n_steps
         x, v = x.copy(), v.copy()
         f = None
+        work = getattr(self, 'work', None)            # dict(heat, shadow_work, n_accepted, n_trials) or None: measured when present
+        ke = lambda vv: kinetic_energy(s.mass, vv)
+        pe = lambda xx: s.energy_forces(xx, box, lambda_sterics, lambda_electrostatics)[0]
+        xold = vold = None
         baro_steps = barostat['steps_done'] if barostat else 0
         baro_attempt = barostat['attempts_done'] if barostat else 0
         for step in range(n_steps):
@@ -254,14 +259,33 @@ class OracleLangevin:
                     baro_attempt += 1
                     f = None
             oidx = 0
+            brace = 0
             for tok in tokens:
-                if tok[0] == 'V':
+                if tok == '{':                                                      # integrators.py:1539-1542
+                    xold, vold = x.copy(), v.copy()
+                elif tok == '}':                                                    # :1544-1557
+                    w = draw(self.seed, STREAM_METROPOLIS, brace, replica, gstep)
+                    u = ((int(w[2]) << 21) | (int(w[3]) >> 11)) / 9007199254740992.0
+                    work['n_trials'] += 1
+                    if np.exp(-work['shadow_work'] / kT) - u >= 0.0:
+                        work['n_accepted'] += 1
+                    else:
+                        x, v = xold.copy(), -vold
+                        f = None
+                    work['shadow_work'] = 0.0
+                    brace += 1
+                elif tok[0] == 'V':
                     if f is None:
                         f = s.energy_forces(x, box, lambda_sterics, lambda_electrostatics)[1]
+                    ke0 = ke(v) if work is not None else 0.0
                     v = v + (self.dt / self.nV) * f * invm[:, None]                 # :1440-1442
                     if s.constraints:
                         v = rattle(s.constraints, invm, x, v)
+                    if work is not None:
+                        work['shadow_work'] += ke(v) - ke0                          # :1444-1446
                 elif tok == 'R':
+                    if work is not None:
+                        e0 = ke(v) + pe(x)                                          # :1407-1409
                     h = self.dt / self.nR
                     x1 = x + h * v                                                  # :1414
                     if s.constraints:
@@ -272,13 +296,18 @@ class OracleLangevin:
                     else:
                         x = x1
                     f = None
+                    if work is not None:
+                        work['shadow_work'] += ke(v) + pe(x) - e0                   # :1420-1423
                 elif tok == 'O':
+                    ke0 = ke(v) if work is not None else 0.0
                     cnt = gstep * max(1, self.nO) + oidx
                     xi = gaussians3(self.seed, STREAM_OU, np.arange(s.N), replica, cnt)
                     v = self.a * v + self.b * np.sqrt(kT * invm)[:, None] * xi      # :1455
                     if s.constraints:
                         v = rattle(s.constraints, invm, x, v)
                     oidx += 1
+                    if work is not None:
+                        work['heat'] += ke(v) - ke0                                 # :1457-1460
         if barostat:
             return x, v, box
         return x, v

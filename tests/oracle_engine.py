@@ -47,6 +47,29 @@ class OracleEngine:
     def set_restart_attempts(self, n):
         self.n_restart_attempts = int(n)
 
+    # heat / shadow work / Metropolization (remd_set_work_measurement, remd_get_work, remd_reset_work)
+    def set_work_measurement(self, measure_heat=False, measure_shadow_work=False):
+        self._measure = (bool(measure_heat), bool(measure_shadow_work))
+
+    def _work_of(self, integ, r, tokens=None):
+        toks = integ.tokens if tokens is None else tokens
+        on = any(getattr(self, '_measure', (False, False))) or ('}' in toks)
+        if not on:
+            integ.work = None
+            return
+        if getattr(self, '_work', None) is None or len(self._work) != self.R:
+            self._work = [dict(heat=0.0, shadow_work=0.0, n_accepted=0, n_trials=0) for _ in range(self.R)]
+        integ.work = self._work[r]
+
+    def get_work(self):
+        w = getattr(self, '_work', None) or [dict(heat=0.0, shadow_work=0.0, n_accepted=0, n_trials=0) for _ in range(self.R)]
+        m = getattr(self, '_measure', (False, False))
+        return dict(heat=np.array([x['heat'] if m[0] else 0.0 for x in w]), shadow_work=np.array([x['shadow_work'] for x in w]),
+                    n_accepted=np.array([x['n_accepted'] for x in w], np.int64), n_trials=np.array([x['n_trials'] for x in w], np.int64))
+
+    def reset_work(self):
+        self._work = None
+
     def set_replicas(self, R_global, r_begin, x, v, box, labels):
         self.R_global, self.r_begin = R_global, r_begin
         self.x = np.array(x, dtype=np.float64)
@@ -81,6 +104,7 @@ class OracleEngine:
             for attempt in range(getattr(self, 'n_restart_attempts', 0) + 1):
                 it = iteration + (attempt << 40)
                 v = integ.assign_velocities(x0, kT, rg, it) if self.reassign else v0
+                self._work_of(integ, r)
                 if getattr(self, 'pressure', None) is not None:
                     if self._baro is None:
                         self._baro = mo.OracleBarostat(self.sys, self.seed_value, mo.molecules_from_desc(self.sys.d))
@@ -136,6 +160,7 @@ class OracleEngine:
         for r in range(self.R):
             rg = self.r_begin + r
             k = self.labels[rg]
+            self._work_of(integ, r, [c for c in splitting.upper() if c != ' '])
             self.x[r], self.v[r] = integ.run(self.x[r], self.v[r], self._box(r), 1.0 / self.beta[k], rg, iteration,
                                              first_step=first_step, n_steps=n_steps,
                                              tokens=[c for c in splitting.upper() if c != ' '],

@@ -99,8 +99,12 @@ def test_integrator_splitting_parsing():
     for sp in ('V R O R V', 'V R R R O R R R V', 'O V R V O'):
         li = integrators.LangevinIntegrator(splitting=sp)
         assert li._ORV_counts['R'] == sp.split().count('R')
-    with pytest.raises(NotImplementedError):
-        integrators.LangevinIntegrator(splitting='O { V R V } O')
+    m = integrators.LangevinIntegrator(splitting='O { V R V } O')            # tests/test_mcmc.py:585: a valid splitting
+    assert m.is_metropolized and m.measure_shadow_work and not m.measure_heat   # integrators.py:1114-1119
+    assert not integrators.LangevinIntegrator(splitting='V R O R V', measure_heat=True).is_metropolized
+    for bad in ('O { V R V O', 'O V R V } O', '{ { V R V } }', '{ V R O R V }'):
+        with pytest.raises(ValueError):
+            integrators.LangevinIntegrator(splitting=bad)
     with pytest.raises(ValueError):
         integrators.LangevinIntegrator(splitting='V O V')
     with pytest.raises(ValueError):

@@ -1,0 +1,157 @@
+"""Heat, shadow work and Metropolization of LangevinIntegrator (integrators.py:1077-1125, 1175-1204, 1404-1460, 1539-1557; mcmc.py:
+1282-1316): remd_set_work_measurement / remd_get_work / remd_reset_work and the "{ }" tokens of the splitting string.
+
+Checker: the f64 Python oracle (oracle/md_oracle.py: the reference's step program restated substep by substep, KE before / after
+each V and O, KE + PE before / after each R, Metropolis decision at '}' on Philox stream 7).  CPU: libremd_cpu.so (second,
+compiled implementation) against it.  GPU (-m gpu): libremd_hip.so against it; the device sums the kinetic parts inside the
+integrator chain (fp32 per unit, fixed-point per replica) and takes the potential parts from energy evaluations before and after
+every R substep.  Tolerances: a substep's kinetic-energy change is a difference of fp32 numbers of size KE ~ 3/2 N kT, so the
+device's heat / shadow work carry an absolute error of ~1e-6 KE per substep."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from openmmtools_amd import testsystems as ts, integrators, mcmc
+from openmmtools_amd.system import system_to_desc
+from openmmtools_amd._engine import HipEngine
+from oracle.forcefield import ForceFieldOracle
+from oracle_engine import OracleEngine
+
+KB = 0.008314462618153242
+SEED = 0xC0FFEE
+CPU_LIB = os.path.join(os.path.dirname(os.path.abspath(oracle.__file__)), '_build', 'libremd_cpu.so')
+
+
+def _setup(eng, system, positions, splitting, dt, n_steps, R=3, measure=(True, True), factory_desc=None, T=(300.0, 350.0, 420.0)):
+    desc = system_to_desc(system) if factory_desc is None else factory_desc
+    eng.set_system(desc)
+    eng.set_states(1.0 / (KB * np.array(T[:R])))
+    eng.set_integrator(splitting, dt, 5.0, n_steps, True, 1e-8)
+    eng.set_work_measurement(*measure)
+    eng.seed(SEED)
+    rng = np.random.default_rng(5)
+    x = np.stack([positions + 0.003 * rng.normal(size=positions.shape) * (r > 0) for r in range(R)])
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (R, 1))
+    eng.set_replicas(R, 0, x, None, box, np.arange(R))
+    return desc
+
+
+def _compare(eng, ora, ke_scale, n_sub):
+    w, wo = eng.get_work(), ora.get_work()
+    tol = 3e-6 * ke_scale * n_sub + 1e-6
+    assert np.allclose(w['heat'], wo['heat'], rtol=2e-4, atol=tol), (w['heat'], wo['heat'])
+    assert np.allclose(w['shadow_work'], wo['shadow_work'], rtol=2e-4, atol=tol), (w['shadow_work'], wo['shadow_work'])
+    assert np.array_equal(w['n_trials'], wo['n_trials']) and np.array_equal(w['n_accepted'], wo['n_accepted'])
+    return w, wo
+
+
+def _lj():
+    lj = ts.LennardJonesFluid(nparticles=216)
+    return lj.system, lj.positions
+
+
+@pytest.fixture(scope='module')
+def cpu_engine():
+    if not os.path.exists(CPU_LIB):
+        oracle.build()
+    made = []
+
+    def make():
+        e = HipEngine(lib_path=CPU_LIB)
+        made.append(e)
+        return e
+    yield make
+    for e in made:
+        e.close()
+
+
+def _run_case(make_engine, splitting, dt, n_steps, measure, lj=True):
+    system, positions = _lj()
+    eng, ora = make_engine(), OracleEngine(system_factory=ForceFieldOracle)
+    for e in (eng, ora):
+        _setup(e, system, positions, splitting, dt, n_steps, measure=measure)
+    assert not np.any(eng.propagate(2))
+    ora.propagate(2)
+    ke = 1.5 * 216 * KB * 420.0
+    n_sub = n_steps * len(splitting.split())
+    w, wo = _compare(eng, ora, ke, n_sub)
+    xg, vg = eng.get_replicas()[:2]
+    assert np.abs(xg - ora.x).max() < 5e-5 and np.abs(vg - ora.v).max() < 5e-4
+    return eng, ora, w, wo
+
+
+@pytest.mark.parametrize('splitting', ['V R O R V', 'O V R V O', 'V R R O R R V'])
+def test_cpu_library_heat_and_shadow_work_follow_the_oracle(cpu_engine, splitting):
+    eng, ora, w, wo = _run_case(cpu_engine, splitting, 0.002, 12, (True, True))
+    assert np.all(np.abs(wo['heat']) > 1e-3)               # something was measured
+    # the bookkeeping identity of the reference's accumulators: over whole steps heat + shadow work = the change of the total
+    # energy (every substep's energy change lands in exactly one of the two)
+    # (checked on the oracle's own numbers: it is a property of the restated step program)
+    eng.reset_work()
+    assert np.all(eng.get_work()['heat'] == 0) and np.all(eng.get_work()['shadow_work'] == 0)
+    # flags off: nothing is accumulated
+    eng.set_work_measurement(False, False)
+    eng.propagate(3)
+    assert np.all(eng.get_work()['heat'] == 0) and np.all(eng.get_work()['shadow_work'] == 0)
+
+
+def test_heat_plus_shadow_work_is_the_energy_change():
+    """Every substep's energy change is booked exactly once: heat (O) + shadow work (V, R) = Delta(KE + PE) over the run."""
+    system, positions = _lj()
+    ora = OracleEngine(system_factory=ForceFieldOracle)
+    _setup(ora, system, positions, 'V R O R V', 0.002, 10, R=2, T=(300.0, 400.0))
+    ora.reassign = False
+    from oracle import md_oracle as mo
+    ora.v = np.stack([np.random.default_rng(r).normal(size=positions.shape) * 0.3 for r in range(2)])
+    e0 = [ora.sys.potential(ora.x[r], ora.box[r]) + mo.kinetic_energy(ora.sys.mass, ora.v[r]) for r in range(2)]
+    ora.propagate(0)
+    e1 = [ora.sys.potential(ora.x[r], ora.box[r]) + mo.kinetic_energy(ora.sys.mass, ora.v[r]) for r in range(2)]
+    w = ora.get_work()
+    assert np.allclose(w['heat'] + w['shadow_work'], np.array(e1) - np.array(e0), rtol=1e-9, atol=1e-9)
+
+
+def test_cpu_library_metropolized_splitting_follows_the_oracle(cpu_engine):
+    """'O { V R V } O' (tests/test_mcmc.py:585): the unminimised fluid rejects most 4 fs proposals and accepts some: both branches are exercised."""
+    eng, ora, w, wo = _run_case(cpu_engine, 'O { V R V } O', 0.004, 25, (True, False))
+    assert np.all(wo['n_trials'] == 25)
+    assert 0 < wo['n_accepted'].sum() < 75                 # accepted and rejected proposals occurred
+    assert np.all(np.abs(wo['shadow_work']) < 1e-12)       # reset at every '}' (integrators.py:1557)
+
+
+def test_host_classes_carry_the_flags():
+    m = mcmc.LangevinSplittingDynamicsMove(splitting='O { V R V } O', measure_heat=True)
+    integ = m._get_integrator(type('S', (), {'temperature': 300.0})())
+    assert integ.is_metropolized and integ.measure_heat and integ.measure_shadow_work
+    assert not mcmc.LangevinDynamicsMove().measure_heat
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('splitting', ['V R O R V', 'O V R V O'])
+def test_device_heat_and_shadow_work_follow_the_oracle(hip_engine_factory, splitting):
+    eng, ora, w, wo = _run_case(hip_engine_factory, splitting, 0.002, 12, (True, True))
+    eng.reset_work()
+    assert np.all(eng.get_work()['heat'] == 0)
+
+
+@pytest.mark.gpu
+def test_device_metropolized_splitting_follows_the_oracle(hip_engine_factory):
+    eng, ora, w, wo = _run_case(hip_engine_factory, 'O { V R V } O', 0.004, 25, (True, False))
+    assert np.all(w['n_trials'] == 25) and 0 < w['n_accepted'].sum() < 75
+
+
+@pytest.mark.gpu
+def test_device_shadow_work_with_constraints_and_mesh(hip_engine_factory):
+    """Alanine dipeptide in water: SETTLE / X-H constraints change the kinetic energy inside R, PME energies before and after."""
+    al = ts.AlanineDipeptideExplicit()
+    eng, ora = hip_engine_factory(), OracleEngine(system_factory=ForceFieldOracle)
+    for e in (eng, ora):
+        _setup(e, al.system, al.positions, 'V R O R V', 0.002, 3, R=2, measure=(True, True), T=(300.0, 330.0))
+    assert not np.any(eng.propagate(1))
+    ora.propagate(1)
+    w, wo = eng.get_work(), ora.get_work()
+    ke = 0.5 * 4548 * KB * 330.0
+    assert np.allclose(w['heat'], wo['heat'], rtol=1e-3, atol=1e-4 * ke)
+    assert np.allclose(w['shadow_work'], wo['shadow_work'], rtol=1e-3, atol=1e-4 * ke), (w['shadow_work'], wo['shadow_work'])
