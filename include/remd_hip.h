@@ -247,9 +247,6 @@ int  remd_sync(remd_handle h);
 /* test hook: in-place unnormalised 3-D complex FFT of a host array [nx][ny][nz][2] on the
    in-tree mixed-radix FFT that the PME reciprocal pass uses                             */
 int  remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inverse);
-/* test hook: the matrix-core XY pass of the PME mesh (csrc/dft_mfma.hip) on `nplanes` host planes [n][n][2], n <= 80,
-   in place.  mode 1: forward 2-D DFT (output [kx][ky]); mode 0: forward then inverse (= n^2 x input)        */
-int  remd_test_xy_mfma(remd_handle h, int n, int nplanes, float* data, int mode);
 
 /* timing of the last remd_propagate / compute_energies / mix on the handle's stream,
    measured with hipEvents (ms)                                                           */

@@ -43,7 +43,7 @@ EXPORTS = [
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
-    'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_test_xy_mfma', 'remd_get_energy_components', 'remd_profile_filter',
+    'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
     'remd_set_energy_const_volume', 'remd_roof_microbench',
@@ -104,7 +104,6 @@ def load_library(path=None):
     lib.remd_sync.argtypes = [vp]
     lib.remd_get_energy_components.argtypes = [vp, c_double_p]
     lib.remd_test_fft3d.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
-    lib.remd_test_xy_mfma.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.remd_last_timing.argtypes = [vp, c_double_p, c_double_p, c_double_p]
     lib.remd_profile_enable.argtypes = [vp, C.c_int]
     lib.remd_profile_get.argtypes = [vp, C.c_char_p, c_int64_p, c_double_p]
@@ -366,15 +365,6 @@ class HipEngine:
         nx, ny, nz = a.shape
         self._check(self.lib.remd_test_fft3d(self.h, nx, ny, nz, a.view(np.float32).ctypes.data_as(C.POINTER(C.c_float)),
                                              int(bool(inverse))), 'remd_test_fft3d')
-        return a
-
-    def test_xy_mfma(self, planes, mode=1):
-        """planes [p][n][n] complex64 through the matrix-core XY pass (mode 1: forward 2-D DFT; 0: forward + inverse)."""
-        a = np.ascontiguousarray(planes, dtype=np.complex64).copy()
-        p, n, n2 = a.shape
-        assert n == n2
-        self._check(self.lib.remd_test_xy_mfma(self.h, n, p, a.view(np.float32).ctypes.data_as(C.POINTER(C.c_float)), int(mode)),
-                    'remd_test_xy_mfma')
         return a
 
     def sync(self):

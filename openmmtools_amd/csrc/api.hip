@@ -11,7 +11,6 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows);
 int remd_nb_required_epart(remd_ctx* h);
 void remd_free_nonbonded(remd_ctx* h);
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
-int remd_test_xy_mfma_impl(remd_ctx* h, int n, int nplanes, float* data, int mode);
 void remd_nb_tune_resolve(remd_ctx* h);
 static int remd_check_device_flags(remd_ctx* h, const char* where);
 void remd_free_constraints(remd_ctx* h);
@@ -71,13 +70,10 @@ int remd_create(remd_handle* out, int device, void* stream)
         // second stream: carries the direct-space kernels while the (longer) reciprocal-space chain stays on the main one
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char* pe = getenv("REMD_S2_PRIO");
-        const int prio = (pe && !strcmp(pe, "lo")) ? lo : (pe && !strcmp(pe, "mid")) ? (lo + hi) / 2 : hi;
-        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio) != hipSuccess)
+        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess)
             hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
-        if (getenv("REMD_LISTED_STREAM") && atoi(getenv("REMD_LISTED_STREAM")) != 0) hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking);
     }
-    { const unsigned evf = (getenv("REMD_EVENT_SYSFENCE") ? 0u : hipEventReleaseToDevice) | hipEventDisableTiming;   // device-scope release: no system-scope cache write-back per fork / join
+    { const unsigned evf = hipEventReleaseToDevice | hipEventDisableTiming;   // device-scope release: no system-scope cache write-back per fork / join
       hipEventCreateWithFlags(&h->ev_fork, evf); hipEventCreateWithFlags(&h->ev_join, evf); }
     { const char* env = getenv("REMD_OVERLAP"); h->overlap = !(env && atoi(env) == 0); }
     h->sync_events = getenv("REMD_SYNC_EVENTS") && atoi(getenv("REMD_SYNC_EVENTS")) != 0;
@@ -94,7 +90,6 @@ int remd_destroy(remd_handle h)
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    remd_free_step_graph(h);
     remd_pme_destroy(h);
     remd_free_constraints(h);
     remd_free_nonbonded(h);
@@ -111,7 +106,6 @@ int remd_destroy(remd_handle h)
     dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
-    if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     if (h->d_sync) hipFree(h->d_sync);
     if (h->d_chain_own) hipFree(h->d_chain_own);
@@ -153,7 +147,6 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
     if ((rc = remd_build_nonbonded(h, d))) return rc;
     h->has_system = true;
     h->forces_valid = false;
-    h->graph_epoch++;
     return 0;
 }
 
@@ -168,7 +161,6 @@ int remd_set_states(remd_handle h, int K, const double* beta, const double* lam_
     if (lam_e) h->lam_e.assign(lam_e, lam_e + K);
     if (econst) h->econst.assign(econst, econst + K);
     for (int k = 0; k < K; ++k) if (!(h->beta[k] > 0)) return remd_fail(h, -1, "remd_set_states: beta must be > 0");
-    h->graph_epoch++;
     int rc;
     if ((rc = upload(h, h->d_beta, h->beta))) return rc;
     if ((rc = upload(h, h->d_lam_s, h->lam_s))) return rc;
@@ -192,7 +184,6 @@ int remd_set_integrator(remd_handle h, const char* splitting, double dt, double 
     h->splitting = splitting; h->dt = dt; h->gamma = gamma; h->n_steps = n_steps; h->reassign = reassign;
     h->constraint_tol = tol > 0 ? tol : 1e-8;
     h->has_integrator = true;
-    h->graph_epoch++;
     return 0;
 }
 
@@ -262,7 +253,6 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     REMD_CHECK(h, hipMemcpy(h->d_vel, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     REMD_CHECK(h, hipMemcpy(h->d_box, hb.data(), sizeof(float) * 4 * R_local, hipMemcpyHostToDevice));
     h->box_version++;
-    h->graph_epoch++;
     h->forces_valid = false; h->force_zeroed = false;
     if (h->nb_method == REMD_NB_PME) { int rc = remd_pme_setup(h); if (rc) return rc; }
     return remd_set_labels(h, labels);
@@ -272,7 +262,6 @@ int remd_set_work_measurement(remd_handle h, int measure_heat, int measure_shado
 {
     if (!h) return -1;
     h->measure_heat = measure_heat ? 1 : 0; h->measure_shadow = measure_shadow_work ? 1 : 0;
-    h->graph_epoch++;
     return 0;
 }
 
@@ -364,10 +353,7 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         // the attempt number rides in the high bits of the iteration counter => fresh velocities and OU noise
         const int64_t it = iteration + ((int64_t)a << 40);
         if (h->reassign) { if ((rc = remd_assign_velocities(h, it))) return rc; }
-        static const bool time_enqueue = getenv("REMD_TIME_ENQUEUE") != nullptr;
-        const auto tq0 = std::chrono::steady_clock::now();
         if ((rc = remd_run_steps(h, h->tokens, h->nV, h->nR, h->nO, it, 0, h->n_steps))) return rc;
-        const auto tq1 = std::chrono::steady_clock::now();
         if ((rc = remd_check_finite(h))) return rc;
         REMD_CHECK(h, hipMemcpyAsync(flags.data(), h->d_nan, sizeof(int) * h->R, hipMemcpyDeviceToHost, h->stream));
         unsigned int spin_out = 0;
@@ -388,12 +374,6 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
             h->forces_valid = false; h->force_zeroed = false;
             --a;
             continue;
-        }
-        if (time_enqueue) {
-            // diagnostic: host time spent enqueueing the MD steps vs the time until the device finished them
-            const auto tq2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "[remd] propagate: %d steps enqueued in %.2f ms, device done %.2f ms after the last enqueue\n", h->n_steps,
-                    std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(tq2 - tq1).count());
         }
         int n_bad = 0;
         for (int r = 0; r < h->R; ++r) if (pending[r] && flags[r]) ++n_bad;
@@ -433,7 +413,6 @@ int remd_set_barostat(remd_handle h, int K, const double* pressure, int frequenc
     int rc = upload(h, h->d_pressure, p);
     if (rc) return rc;
     h->baro_frequency = frequency;
-    h->graph_epoch++;
     return 0;
 }
 
@@ -507,8 +486,7 @@ int remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t f
     nV = h->nV; nR = h->nR; nO = h->nO;
     int rc = remd_run_steps(h, tokens, nV, nR, nO, iteration, first_step, n_steps);
     if (rc) return rc;
-    static const bool nosync = getenv("REMD_STEP_NOSYNC") != nullptr;      // experiment hook: interleaving several handles from one thread
-    if (!nosync) REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -678,12 +656,6 @@ int remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inve
     return remd_test_fft3d_impl(h, nx, ny, nz, data, inverse);
 }
 
-int remd_test_xy_mfma(remd_handle h, int n, int nplanes, float* data, int mode)
-{
-    if (!h || !data || n <= 0 || nplanes <= 0) return remd_fail(h, -1, "remd_test_xy_mfma: bad arguments");
-    hipSetDevice(h->device);
-    return remd_test_xy_mfma_impl(h, n, nplanes, data, mode);
-}
 
 int remd_get_energy_components(remd_handle h, double* out)
 {

@@ -12,11 +12,11 @@
 //   alchemical soft-core sterics        alchemy/alchemy.py:1383-1388 (softcore_c = 6 closed form)
 // The f64 restatement used for parity is oracle/md_oracle.py.
 //
-// Nonbonded design: one wavefront owns 64 consecutive atoms i (lane = atom); the j loop walks a
-// slice of all atoms with wave-uniform addresses (scalar loads, no LDS traffic); the full i x j
-// matrix is evaluated (each pair twice), so every lane sums its own force in a fixed order and no
-// atomics are needed inside the loop.  Exclusions are a per-atom bit window over j - i, consulted
-// only in tiles that overlap the window.  The grid is (i tiles) x (j slices) x (replicas).
+// Nonbonded design: atoms are kept in a spatial (Morton) order of whole molecules; 8-atom clusters of that order are
+// paired through per-tile union lists with every cluster pair listed once (nonbonded_sci_kernel, Newton's third law);
+// a list that outgrows its capacity, or a system without sortable molecules, runs on the 64-atom tile kernel
+// (nonbonded_kernel: lane = atom i, wave-uniform j stream, each pair from both sides, exclusions as a bit window).
+// The Monte Carlo barostat lives in barostat.hip, the pair arithmetic in pair_math.h.
 #include "remd_internal.h"
 #include "rng.h"
 #include <cmath>
@@ -73,7 +73,7 @@ struct nb_tables {
     float4* d_partial = nullptr; size_t partial_n = 0;      // [R][n_jsplit][Npad] nonbonded force partials
     // 8-atom cluster pair lists (sorted slot space): lane = (i atom, j atom) of an 8 x 8 cluster pair
     float4* d_cl_c = nullptr; float4* d_cl_h = nullptr;     // [R][ncl] cluster bounding boxes
-    unsigned short* d_cl_list = nullptr; int* d_cl_count = nullptr; int cl_cap = 0; bool clusters = true;
+    int cl_cap = 0; bool clusters = true;
     // LJ-active sub-system (atoms with eps != 0; 1/3 of a TIP3P box): own sorted order, clusters and pair list, so
     // that the main cluster kernel is Coulomb-only
     bool lj_split = false; int NL = 0, NLpad = 0, lj_words = 1, lj_cap = 0;
@@ -81,9 +81,8 @@ struct nb_tables {
     unsigned long long* d_lj_mask = nullptr;   // [NLpad][lj_words] exclusion window in LJ-ordinal space
     int* d_lj_order = nullptr; float4* d_lj_spos = nullptr; float4* d_lj_sparam = nullptr; unsigned long long* d_lj_smask = nullptr;
     float4* d_lj_tile_c = nullptr; float4* d_lj_tile_h = nullptr; float4* d_lj_cl_c = nullptr; float4* d_lj_cl_h = nullptr;
-    unsigned short* d_lj_list = nullptr; int* d_lj_count = nullptr;
     // Newton's-third-law path: per-tile union lists (jc | imask << 16) and near-diagonal exclusion words
-    bool n3l = true; int sci_split = 12;     // list slices per tile (workgroups of 4 wavefronts); set per system in remd_build_nonbonded
+    int sci_split = 12;     // list slices per tile (workgroups of 4 wavefronts); set per system in remd_build_nonbonded
     unsigned int* d_sci_list = nullptr; int* d_sci_count = nullptr; unsigned long long* d_excl = nullptr; int excl_W = 0;
     long long* d_sforce = nullptr; long long* d_lj_sforce = nullptr;   // [R][3][Npad] / [R][3][NLpad] forces in sorted slot space
     unsigned int* d_lj_sci_list = nullptr; int* d_lj_sci_count = nullptr; unsigned long long* d_lj_excl = nullptr; int lj_excl_W = 0;
@@ -97,18 +96,16 @@ struct nb_tables {
     struct tune_seg { int cand; hipEvent_t a, b; };
     std::vector<tune_seg> tune_segs; int tune_state = 0 /* 0 measuring, 1 awaiting resolve, 2 done */, tune_left = 0, tune_next = 0;
     int nb_grid = 0;                      // current choice (workgroups; 0 = one per item)
-    bool defer_scatter = false, scatter_pending = false;   // the caller launches direct_tail_kernel instead of the scatter
-    float sort_cell = getenv("REMD_NB_CELL") ? (float)atof(getenv("REMD_NB_CELL")) : 0.45f;   // Morton cell edge (nm) of the molecule sort
+    float sort_cell = 0.45f;              // Morton cell edge (nm) of the molecule sort
 };
 static handle_table<nb_tables> g_nb;
 
 // cross-stream dependencies without the command processor (see remd_ctx::d_sync): one lane polls a flag in device memory
-__global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq, unsigned int* spin_out, const unsigned int* flag2 = nullptr)
+__global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq, unsigned int* spin_out)
 {
     if (threadIdx.x == 0) {
         long long n = 0;
-        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0 ||
-               (flag2 && (int)(__hip_atomic_load(flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0)) {
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
             __builtin_amdgcn_s_sleep(4);
             if (++n > (1ll << 25)) { atomicExch(spin_out, 1u); break; }       // seconds: something upstream died; say so instead of hanging
         }
@@ -118,8 +115,7 @@ __global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq
 void remd_launch_join_wait(remd_ctx* h)      // a deferred join nobody consumed: wait for it now
 {
     if (!h->join_deferred) return;
-    hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->join_deferred, h->d_sync + 2,
-                       h->listed_on_s3 ? h->d_sync + 3 : (const unsigned int*)nullptr);
+    hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->join_deferred, h->d_sync + 2);
     h->join_deferred = 0;
 }
 __global__ void remd_signal_kernel(unsigned int* flag, unsigned int seq)
@@ -570,169 +566,6 @@ void gather_positions2_kernel(int nt_a, gather_args a, gather_args b, int Npad_p
                           g.order, pos, box, g.spos, g.tile_c, g.tile_h, g.cl_c, g.cl_h);
 }
 
-// neighbour list of 8-atom clusters: one wavefront per i cluster tests every j cluster (bounding boxes, minimum
-// image) and appends the hits in ascending order (ballot + popcount => deterministic).
-__global__ __launch_bounds__(64)
-void build_cluster_list_kernel(int ncl, int cap, float rc2, const float4* __restrict__ cl_c, const float4* __restrict__ cl_h,
-                               const float4* __restrict__ tile_c, const float4* __restrict__ tile_h,
-                               const float* __restrict__ box, unsigned short* __restrict__ list, int* __restrict__ count)
-{
-    // two levels: the 64-atom tile boxes (8 clusters each) are tested first, then the clusters of the hit tiles, eight
-    // tiles per pass; tiles and clusters are visited in ascending order, so the list is the same as a flat scan's
-    __shared__ int s_tiles[64];
-    const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
-    const int ntile = ncl >> 3;
-    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-    const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
-    const float4 ci = cl_c[(size_t)r * ncl + ic], hi = cl_h[(size_t)r * ncl + ic];
-    unsigned short* L = list + ((size_t)r * ncl + ic) * cap;
-    auto near = [&](const float4 cj, const float4 hj) {
-        float bx = cj.x - ci.x, by = cj.y - ci.y, bz = cj.z - ci.z;
-        bx -= Lx * rintf(bx * iLx); by -= Ly * rintf(by * iLy); bz -= Lz * rintf(bz * iLz);
-        bx = fmaxf(0.f, fabsf(bx) - hi.x - hj.x); by = fmaxf(0.f, fabsf(by) - hi.y - hj.y); bz = fmaxf(0.f, fabsf(bz) - hi.z - hj.z);
-        return (hi.x >= 0.f) && (bx * bx + by * by + bz * bz <= rc2);
-    };
-    int n = 0;
-    for (int tbase = 0; tbase < ntile; tbase += 64) {
-        const int jt = tbase + lane;
-        const bool thit = (jt < ntile) && near(tile_c[(size_t)r * ntile + jt], tile_h[(size_t)r * ntile + jt]);
-        const unsigned long long tm = __ballot(thit);
-        const int nhit = __popcll(tm);
-        __syncthreads();                                   // (one wavefront: orders the LDS reuse between chunks)
-        if (thit) s_tiles[__popcll(tm & ((1ull << lane) - 1ull))] = jt;
-        __syncthreads();
-        for (int q = 0; q < nhit; q += 8) {
-            const int g = q + (lane >> 3);
-            bool hit = false;
-            int jc = 0;
-            if (g < nhit) {
-                jc = s_tiles[g] * 8 + (lane & 7);
-                hit = near(cl_c[(size_t)r * ncl + jc], cl_h[(size_t)r * ncl + jc]);   // empty clusters carry a negative extent
-            }
-            const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const int slot = n + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < cap) L[slot] = (unsigned short)jc;
-            }
-            n += __popcll(m);
-        }
-    }
-    if (lane == 0) count[(size_t)r * ncl + ic] = n;       // n > cap is detected on the host side (fallback)
-}
-
-// 8 x 8 cluster-pair kernel: lane = (ii = lane >> 3, jj = lane & 7).  Every lane evaluates its own atom pair, so
-// the arithmetic is straight-line (no wave-level branching); i forces are reduced over the 8 j lanes at the end.
-template <int METHOD, bool ENERGY, bool ALCH>
-__global__ __launch_bounds__(64)
-void nonbonded_cluster_kernel(nb_params p, int N, int Npad, int ncl, int cap, const float4* __restrict__ spos,
-                              const float4* __restrict__ sparam, const unsigned long long* __restrict__ smask,
-                              const int* __restrict__ order, const unsigned short* __restrict__ list,
-                              const int* __restrict__ count, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                              long long* __restrict__ force, int Npad_force, double* __restrict__ epart, int n_epart, int ep_off,
-                              int R, int nsplit)
-{
-    // persistent form: the grid may be smaller than the number of (cluster, replica, slice) work items so that this
-    // VALU-bound kernel never takes more than its share of the wave slots (the PME workgroups need 8 at a time)
-    const int lane = threadIdx.x;
-    const int n_items = ncl * R * nsplit;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int ic = item % ncl, r = (item / ncl) % R, zsl = item / (ncl * R);
-    const int ii = lane >> 3, jj = lane & 7;
-    const int i = ic * 8 + ii;
-    const float4* __restrict__ P = spos + (size_t)r * Npad;
-    const float4* __restrict__ prm = sparam + (size_t)r * Npad;
-    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-    const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
-    float lam_a = 1.f, sc = 0.f, lam_e = 1.f;
-    if (ALCH) { lam_a = rep_lam[4 * r]; sc = rep_lam[4 * r + 1]; lam_e = rep_lam[4 * r + 2]; }
-    const bool iact = i < N;
-    const float4 xi = P[iact ? i : 0];
-    float4 pi = prm[iact ? i : 0];
-    if (ALCH && pi.w != 0.f) pi.x *= lam_e;
-    unsigned long long mk[MAX_EXCL_WORDS];
-#pragma unroll
-    for (int w = 0; w < MAX_EXCL_WORDS; ++w)
-        mk[w] = (w < p.excl_words) ? smask[((size_t)r * Npad + (iact ? i : 0)) * p.excl_words + w] : 0ull;
-    const int half = 32 * p.excl_words;
-    // gridDim.z wavefronts share the neighbour list of one i cluster (contiguous slices; forces are merged by the
-    // integer atomics at the end), used for the short LJ sub-system lists to expose more parallelism
-    const int n_all = min(count[(size_t)r * ncl + ic], cap);
-    const int per = (n_all + nsplit - 1) / nsplit;
-    const int l_beg = min(n_all, zsl * per);
-    const unsigned short* L = list + ((size_t)r * ncl + ic) * cap + l_beg;
-    const int n = min(per, n_all - l_beg);
-    float fx = 0.f, fy = 0.f, fz = 0.f;
-    double e = 0.0;
-    // one cluster pair: every lane evaluates its own (i atom, j atom) pair
-    auto pair_step = [&](int jc, const float4 xj, float4 pj) {
-        const int j = jc * 8 + jj;
-        float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
-        dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
-        const float r2 = dx * dx + dy * dy + dz * dz;
-        bool in = iact && (j < N) && (r2 < p.rc2);
-        if (abs(jc - ic) * 8 < half + 8) {                   // wave-uniform: exclusions only live near the diagonal
-            const int d = j - i + half;
-            if (d >= 0 && d < 2 * half) {
-                unsigned long long m = 0ull;
-#pragma unroll
-                for (int w = 0; w < MAX_EXCL_WORDS; ++w) if ((d >> 6) == w) m = mk[w];
-                in = in && !((m >> (d & 63)) & 1ull);
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(in) == 0ull) return;  // no atom pair of this cluster pair is inside the cutoff (scalar test)
-        if (ALCH && pj.w != 0.f) pj.x *= lam_e;
-        float fr, ee;
-        // evaluated for every lane (r2 clamped to the cutoff for far pairs; excluded pairs, even r2 = 0, produce
-        // garbage that the selects below discard), result kept only where `in`
-        pair_interaction<METHOD, ALCH, !ENERGY>(p, fminf(r2, p.rc2), pi, pj, lam_a, sc, fr, ENERGY, ee);
-        fr = in ? fr : 0.f;
-        fx += fr * dx; fy += fr * dy; fz += fr * dz;
-        if (ENERGY) e += in ? 0.5 * (double)ee : 0.0;
-    };
-    // The j atoms of 8 cluster pairs at a time go through LDS: each lane fetches one atom (position + parameters)
-    // of the NEXT batch into registers before the current batch is processed, and the registers are written to
-    // LDS only afterwards, so the global-load latency hides behind 8 cluster pairs of arithmetic.
-    // (single buffer: one wavefront per workgroup, LDS operations retire in program order, so the next batch's
-    // writes cannot overtake this batch's reads; 2 KB per wavefront keeps LDS free for the PME workgroups that
-    // share the CU)
-    __shared__ float4 s_x[64];
-    __shared__ float4 s_p[64];
-    const int lc = lane >> 3;
-    for (int base = 0; base < n; base += 64) {
-        const int cnt = min(64, n - base);                       // list entries in this 64-chunk
-        const int my_jc = (lane < cnt) ? (int)L[base + lane] : 0;
-        int jsrc = __shfl(my_jc, min(lc, cnt - 1));
-        float4 gx = P[jsrc * 8 + jj], gp = prm[jsrc * 8 + jj];
-        for (int sub = 0; sub < cnt; sub += 8) {
-            __syncthreads();
-            s_x[lane] = gx; s_p[lane] = gp;
-            __syncthreads();
-            if (sub + 8 < cnt) {                                 // prefetch the next batch
-                jsrc = __shfl(my_jc, min(sub + 8 + lc, cnt - 1));
-                gx = P[jsrc * 8 + jj]; gp = prm[jsrc * 8 + jj];
-            }
-            const int nb = min(8, cnt - sub);
-#pragma unroll 2
-            for (int c = 0; c < nb; ++c) {
-                const int jc = __builtin_amdgcn_readlane(my_jc, sub + c);
-                pair_step(jc, s_x[c * 8 + jj], s_p[c * 8 + jj]);
-            }
-        }
-    }
-    // reduce over the 8 j lanes of each i atom
-    for (int off = 4; off > 0; off >>= 1) { fx += __shfl_xor(fx, off); fy += __shfl_xor(fy, off); fz += __shfl_xor(fz, off); }
-    if (iact && jj == 0) {
-        // integer atomics: the PME gather may be adding to the same atom on the other stream
-        add_force(force + (size_t)r * 3 * Npad_force, Npad_force, order[(size_t)r * Npad + i], fx, fy, fz);
-    }
-    if (ENERGY) {
-        e = wave_sum(e);
-        if (lane == 0) epart[(size_t)r * n_epart + EP_NB0 + ep_off + ic * nsplit + zsl] = e;
-    }
-    }   // work items
-}
-
-
 // ---- Newton's-third-law path: super-cluster ("sci") lists -----------------------------------------------------------
 // One list per 64-atom tile (= 8 consecutive i clusters): the ascending union of the j clusters that neighbour any of
 // them, each entry carrying the 8-bit mask of the i clusters it pairs with.  Only cluster pairs with jc >= ic are listed,
@@ -771,36 +604,6 @@ void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, l
     scatter_sorted_forces_body(Npad_a, order_a, sforce_a, Npad_b, order_b, sforce_b, force, Npad_force, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
 }
 
-// the tail of the direct-space stream of a force-only evaluation in ONE launch: sorted-slot scatter (blocks < n_scatter),
-// every listed term (the rest), and -- by the last block to finish -- the "direct-space forces are complete" flag the
-// integrator on the main stream polls (remd_ctx::d_sync).  Three dependent launches of ~6 us each otherwise.
-struct scatter_args { int Npad_a; const int* order_a; long long* sforce_a; int Npad_b; const int* order_b; long long* sforce_b; };
-__global__ __launch_bounds__(256)
-void direct_tail_kernel(scatter_args sc, int n_scatter, listed_tables T, int Npad, const float4* __restrict__ pos,
-                        const float* __restrict__ box, long long* __restrict__ force, unsigned int* join_flag, unsigned int join_seq,
-                        unsigned int* done)
-{
-    if ((int)blockIdx.x < n_scatter)
-        scatter_sorted_forces_body(sc.Npad_a, sc.order_a, sc.sforce_a, sc.Npad_b, sc.order_b, sc.sforce_b, force, Npad,
-                                   blockIdx.x * 256 + threadIdx.x, blockIdx.y);
-    else
-        listed_forces_body(T, Npad, pos, box, force, (blockIdx.x - n_scatter) * 256 + threadIdx.x, blockIdx.y);
-    if (join_flag) {
-        // the block's force atomics (device scope: performed at the coherence point) are acknowledged at the barrier's
-        // s_waitcnt; a __threadfence() per block (L2 write-back + invalidate, ~3.5 us each) would cost more than the launches saved
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1) {
-                *done = 0u;
-                __hip_atomic_store(join_flag, join_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
-// exclusion bits of the near-diagonal cluster pairs (ic, ic + dj), dj < W: bit (ii*8 + jj) set = pair not evaluated.
-// Folded in: the exclusion windows, the self pairs and the lower triangle of the diagonal cluster pair.
-// Rebuilt with the spatial order (every resort_interval evaluations), not with the lists.
 __global__ __launch_bounds__(64)
 void build_excl_kernel(int Npad, int ncl, int W, int words, const unsigned long long* __restrict__ smask,
                        unsigned long long* __restrict__ excl)
@@ -1423,9 +1226,9 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_exc_alch); dfree(t.d_excl_alch); dfree(t.d_probe);
     dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
     dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sparam); dfree(t.d_smask);
-    dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
+    dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h);
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
-    dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
+    dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h);
     dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
     dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue);
     for (auto& sg : t.tune_segs) { if (sg.a) hipEventDestroy(sg.a); if (sg.b) hipEventDestroy(sg.b); }
@@ -1578,9 +1381,7 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     p.excl_words = words;
     const int ntile = (N + 63) / 64;
     {
-        const char* env = getenv("REMD_NB_JSPLIT");
-        int want = env ? atoi(env) : 4;
-        p.n_jsplit = std::max(1, std::min(std::min(ntile, 16), want));
+        p.n_jsplit = std::max(1, std::min(std::min(ntile, 16), 4));
     }
     h->cutoff = d->cutoff; h->switch_dist = d->switch_distance; h->ewald_alpha = d->ewald_alpha;
     for (int k = 0; k < 3; ++k) h->grid[k] = d->pme_grid[k];
@@ -1608,18 +1409,12 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         }
         t.n_groups = (int)first.size();
         if ((rc = upload(h, t.d_grp_first, first)) || (rc = upload(h, t.d_grp_size, size))) return rc;
-        const char* env = getenv("REMD_NB_SORT");
-        t.sorting = !(env && atoi(env) == 0);
-        const char* env3 = getenv("REMD_NB_CLUSTERS");
-        t.clusters = !(env3 && atoi(env3) == 0);
-        if (getenv("REMD_NB_N3L")) t.n3l = atoi(getenv("REMD_NB_N3L")) != 0;
+        t.sorting = true;
+        t.clusters = !getenv("REMD_NB_TILES");        // test hook: the 64-atom tile kernel a list overflow falls back to
         // 8 slices where the mesh stream runs beside the pair kernel (its launch may become a resident set pulling items: 105.9 vs
         // 106.55 ms per 500 steps on the headline config), 12 elsewhere (LJ fluid, one workgroup per item: 66.6 vs 63.3 it/s).
         // Fixed per system, never per launch mode: the slices' fp32 partial sums enter the forces bit-wise.
         t.sci_split = (t.method == NB_EWALD && h->overlap && h->stream2) ? 8 : 12;
-        if (getenv("REMD_NB_SCISPLIT")) t.sci_split = std::max(1, std::min(16, atoi(getenv("REMD_NB_SCISPLIT"))));
-        const char* env2 = getenv("REMD_NB_RESORT");
-        if (env2) t.resort_interval = std::max(1, atoi(env2));
     }
 
     // LJ-active sub-system: worthwhile when charges exist and most atoms carry no LJ (TIP3P hydrogens)
@@ -1627,8 +1422,7 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         std::vector<int> ord(h->Npad, -1);
         int NL = 0;
         for (int i = 0; i < N; ++i) if (d->epsilon[i] != 0.0) ord[i] = NL++;
-        const char* env = getenv("REMD_NB_LJSPLIT");
-        t.lj_split = any_charge && NL > 0 && NL * 10 <= N * 6 && !(env && atoi(env) == 0);
+        t.lj_split = any_charge && NL > 0 && NL * 10 <= N * 6;
         if (t.lj_split) {
             t.NL = NL; t.NLpad = (NL + 63) / 64 * 64;
             int maxd_lj = 0;
@@ -1688,7 +1482,7 @@ static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
         rl[4 * r + 2] = (float)le;
     }
     // uploaded only when something changed (labels after a mix, a lambda override of the u_kl passes): the steady state of the
-    // MD loop has no host copy and no synchronisation per force evaluation (and can be captured into a graph)
+    // MD loop has no host copy and no synchronisation per force evaluation
     if (rl == t.rep_lam_host) return 0;
     REMD_CHECK(h, hipMemcpyAsync(t.d_rep_lam, rl.data(), sizeof(float) * rl.size(), hipMemcpyHostToDevice, h->stream));
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
@@ -1696,38 +1490,22 @@ static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
     return 0;
 }
 
-// phase 1: (re-sort,) gather and neighbour list of the main system; phase 2: the same for the LJ sub-system; 3: both.
-// Split so that the long Coulomb pair kernel can be launched before the LJ lists and the listed terms are built.
-// cluster pair lists of one (sub-)system: per-tile union lists on the Newton's-third-law path, per-cluster lists otherwise
+// per-tile union lists of one (sub-)system
 static void launch_list_build(remd_ctx* h, nb_tables& t, bool lj)
 {
     const int ncl = lj ? t.NLpad / 8 : ((h->N + 63) / 64) * 8;
-    const int cap = lj ? t.lj_cap : t.cl_cap;
-    const float4* cc = lj ? t.d_lj_cl_c : t.d_cl_c; const float4* ch = lj ? t.d_lj_cl_h : t.d_cl_h;
-    const float4* tc = lj ? t.d_lj_tile_c : t.d_tile_c; const float4* th = lj ? t.d_lj_tile_h : t.d_tile_h;
-    if (t.n3l && (lj ? t.d_lj_sci_list : t.d_sci_list))
-        hipLaunchKernelGGL(build_sci_list_kernel, dim3(ncl / 8, h->R), dim3(64), 0, h->stream, ncl, cap, t.p.rc2, cc, ch, tc, th, h->d_box,
-                           lj ? t.d_lj_sci_list : t.d_sci_list, lj ? t.d_lj_sci_count : t.d_sci_count);
-    else
-        hipLaunchKernelGGL(build_cluster_list_kernel, dim3(ncl, h->R), dim3(64), 0, h->stream, ncl, cap, t.p.rc2, cc, ch, tc, th, h->d_box,
-                           lj ? t.d_lj_list : t.d_cl_list, lj ? t.d_lj_count : t.d_cl_count);
+    hipLaunchKernelGGL(build_sci_list_kernel, dim3(ncl / 8, h->R), dim3(64), 0, h->stream, ncl, lj ? t.lj_cap : t.cl_cap, t.p.rc2,
+                       lj ? t.d_lj_cl_c : t.d_cl_c, lj ? t.d_lj_cl_h : t.d_cl_h, lj ? t.d_lj_tile_c : t.d_tile_c, lj ? t.d_lj_tile_h : t.d_tile_h,
+                       h->d_box, lj ? t.d_lj_sci_list : t.d_sci_list, lj ? t.d_lj_sci_count : t.d_sci_count);
 }
 
-static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
+// sorted order (refreshed every resort_interval evaluations), sorted positions + bounding boxes and the super-cluster
+// lists (every evaluation) of the cluster-pair path
+static int ensure_sorted(remd_ctx* h, nb_tables& t)
 {
     if (!t.sorting || t.n_groups <= 0 || t.n_groups >= 8192) return 0;
     const int ntile = (h->N + 63) / 64;
-    if (!(phase & 1)) {
-        const bool cl2 = t.clusters && ntile * 8 < 65536;
-        if (cl2 && t.lj_split && t.sort_R == h->R) {
-            remd_prof_scope ps(h, "nb_gather");
-            const int ntile_lj = t.NLpad / 64;
-            hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
-                               h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
-            launch_list_build(h, t, true);
-        }
-        return 0;
-    }
+    const bool cl = t.clusters && ntile * 8 < 65536;
     if (t.sort_R != h->R) {
         dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sparam); dfree(t.d_smask); dfree(t.d_tile_c); dfree(t.d_tile_h);
         const size_t n = (size_t)h->R * h->Npad;
@@ -1737,16 +1515,14 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
         REMD_CHECK(h, hipMalloc(&t.d_smask, sizeof(unsigned long long) * n * t.p.excl_words));
         REMD_CHECK(h, hipMalloc(&t.d_tile_c, sizeof(float4) * (size_t)h->R * ntile));
         REMD_CHECK(h, hipMalloc(&t.d_tile_h, sizeof(float4) * (size_t)h->R * ntile));
-        dfree(t.d_cl_c); dfree(t.d_cl_h); dfree(t.d_cl_list); dfree(t.d_cl_count);
-        const int ncl = ntile * 8;
-        t.cl_cap = std::min(ncl, 4096);     // whole row for systems up to 32k atoms: a cluster that straddles a large molecule can neighbour half the box
-        REMD_CHECK(h, hipMalloc(&t.d_cl_c, sizeof(float4) * (size_t)h->R * ncl));
-        REMD_CHECK(h, hipMalloc(&t.d_cl_h, sizeof(float4) * (size_t)h->R * ncl));
-        REMD_CHECK(h, hipMalloc(&t.d_cl_list, sizeof(unsigned short) * (size_t)h->R * ncl * t.cl_cap));
-        REMD_CHECK(h, hipMalloc(&t.d_cl_count, sizeof(int) * (size_t)h->R * ncl));
+        dfree(t.d_cl_c); dfree(t.d_cl_h);
         dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_sforce); dfree(t.d_lj_sforce);
         dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
-        if (t.n3l) {
+        const int ncl = ntile * 8;
+        t.cl_cap = std::min(ncl, 4096);     // whole row for systems up to 32k atoms: a cluster that straddles a large molecule can neighbour half the box
+        if (cl) {
+            REMD_CHECK(h, hipMalloc(&t.d_cl_c, sizeof(float4) * (size_t)h->R * ncl));
+            REMD_CHECK(h, hipMalloc(&t.d_cl_h, sizeof(float4) * (size_t)h->R * ncl));
             t.excl_W = 4 * t.p.excl_words + 1;
             REMD_CHECK(h, hipMalloc(&t.d_sci_list, sizeof(unsigned int) * (size_t)h->R * ntile * t.cl_cap));
             REMD_CHECK(h, hipMalloc(&t.d_sci_count, sizeof(int) * (size_t)h->R * ntile));
@@ -1758,9 +1534,9 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
                 REMD_CHECK(h, hipMemsetAsync(t.d_queue, 0, 4 * sizeof(unsigned int), h->stream));
             }
         }
-        if (t.lj_split) {
+        if (cl && t.lj_split) {
             dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask); dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h);
-            dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h); dfree(t.d_lj_list); dfree(t.d_lj_count);
+            dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h);
             const size_t nl = (size_t)h->R * t.NLpad;
             const int ncl_lj = t.NLpad / 8;
             t.lj_cap = std::min(ncl_lj, 4096);
@@ -1772,19 +1548,16 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
             REMD_CHECK(h, hipMalloc(&t.d_lj_tile_h, sizeof(float4) * (size_t)h->R * (t.NLpad / 64)));
             REMD_CHECK(h, hipMalloc(&t.d_lj_cl_c, sizeof(float4) * (size_t)h->R * ncl_lj));
             REMD_CHECK(h, hipMalloc(&t.d_lj_cl_h, sizeof(float4) * (size_t)h->R * ncl_lj));
-            REMD_CHECK(h, hipMalloc(&t.d_lj_list, sizeof(unsigned short) * (size_t)h->R * ncl_lj * t.lj_cap));
-            REMD_CHECK(h, hipMalloc(&t.d_lj_count, sizeof(int) * (size_t)h->R * ncl_lj));
-            if (t.n3l) {
-                t.lj_excl_W = 4 * t.lj_words + 1;
-                REMD_CHECK(h, hipMalloc(&t.d_lj_sci_list, sizeof(unsigned int) * (size_t)h->R * (ncl_lj / 8) * t.lj_cap));
-                REMD_CHECK(h, hipMalloc(&t.d_lj_sci_count, sizeof(int) * (size_t)h->R * (ncl_lj / 8)));
-                REMD_CHECK(h, hipMalloc(&t.d_lj_excl, sizeof(unsigned long long) * (size_t)h->R * ncl_lj * t.lj_excl_W));
-                REMD_CHECK(h, hipMalloc(&t.d_lj_sforce, sizeof(long long) * nl * 3));
-                REMD_CHECK(h, hipMemsetAsync(t.d_lj_sforce, 0, sizeof(long long) * nl * 3, h->stream));
-            }
+            t.lj_excl_W = 4 * t.lj_words + 1;
+            REMD_CHECK(h, hipMalloc(&t.d_lj_sci_list, sizeof(unsigned int) * (size_t)h->R * (ncl_lj / 8) * t.lj_cap));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_sci_count, sizeof(int) * (size_t)h->R * (ncl_lj / 8)));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_excl, sizeof(unsigned long long) * (size_t)h->R * ncl_lj * t.lj_excl_W));
+            REMD_CHECK(h, hipMalloc(&t.d_lj_sforce, sizeof(long long) * nl * 3));
+            REMD_CHECK(h, hipMemsetAsync(t.d_lj_sforce, 0, sizeof(long long) * nl * 3, h->stream));
         }
         t.sort_R = h->R; t.evals_since_sort = 1 << 30;
     }
+    const bool split = cl && t.lj_split;
     if (t.evals_since_sort >= t.resort_interval) {
         remd_prof_scope ps(h, "nb_sort");
         const size_t lds = sizeof(int) * 4 * (size_t)t.n_groups;
@@ -1792,154 +1565,94 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t, int phase = 3)
                            t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order);
         hipLaunchKernelGGL(gather_params_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.p.excl_words,
                            t.d_order, t.d_param, t.d_mask, t.d_sparam, t.d_smask);
-        if (t.lj_split)
+        if (split)
             hipLaunchKernelGGL(compact_lj_kernel, dim3(h->R), dim3(1024), 0, h->stream, h->N, h->Npad, t.NL, t.NLpad, t.lj_words, t.d_order,
                                t.d_lj_ord, t.d_param, t.d_lj_mask, t.d_lj_order, t.d_lj_sparam, t.d_lj_smask);
-        if (t.n3l && t.d_excl) {
+        if (cl) {
             hipLaunchKernelGGL(build_excl_kernel, dim3(ntile * 8, h->R), dim3(64), 0, h->stream, h->Npad, ntile * 8, t.excl_W, t.p.excl_words,
                                t.d_smask, t.d_excl);
-            if (t.lj_split && t.d_lj_excl)
+            if (split)
                 hipLaunchKernelGGL(build_excl_kernel, dim3(t.NLpad / 8, h->R), dim3(64), 0, h->stream, t.NLpad, t.NLpad / 8, t.lj_excl_W,
                                    t.lj_words, t.d_lj_smask, t.d_lj_excl);
         }
         t.evals_since_sort = 0;
     }
     t.evals_since_sort++;
-    {
-        remd_prof_scope ps(h, "nb_gather");
-        const bool cl = t.clusters && ntile * 8 < 65536;
-        const bool fused = cl && t.lj_split && (phase & 2) && t.n3l && t.d_sci_list && t.d_lj_sci_list;
-        if (fused) {
-            // main system + LJ sub-system in one gather launch and one list launch
-            const int ntile_lj = t.NLpad / 64;
-            gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h};
-            gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h};
-            hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
-            sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
-            sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};
-            hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb, t.p.rc2, h->d_box);
-        } else
+    remd_prof_scope ps(h, "nb_gather");
+    if (split) {
+        // main system + LJ sub-system in one gather launch and one list launch
+        const int ntile_lj = t.NLpad / 64;
+        gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h};
+        gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h};
+        hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
+        sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
+        sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};
+        hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb, t.p.rc2, h->d_box);
+    } else {
         hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, h->Npad, t.d_order, h->d_pos, h->d_box,
                            t.d_spos, t.d_tile_c, t.d_tile_h, cl ? t.d_cl_c : (float4*)nullptr, cl ? t.d_cl_h : (float4*)nullptr);
-        if (cl) {
-            const int ncl = ntile * 8;
-            if (!fused) launch_list_build(h, t, false);
-            if (!fused && t.lj_split && (phase & 2)) {
-                const int ntile_lj = t.NLpad / 64;
-                hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile_lj, h->R), dim3(64), 0, h->stream, t.NLpad, h->Npad, t.d_lj_order,
-                                   h->d_pos, h->d_box, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h);
-                launch_list_build(h, t, true);
-            }
-            if (t.evals_since_sort == 1 && (t.cl_cap < ncl || getenv("REMD_DEBUG"))) {
-                // capacity check once per re-sort (the only host synchronisation of this path)
-                const bool sci = t.n3l && t.d_sci_list;
-                std::vector<int> cnt((size_t)h->R * (sci ? ntile : ncl));
-                REMD_CHECK(h, hipMemcpyAsync(cnt.data(), sci ? t.d_sci_count : t.d_cl_count, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, h->stream));
-                REMD_CHECK(h, hipStreamSynchronize(h->stream));
-                int mx = 0; for (int c : cnt) mx = std::max(mx, c);
-                if (getenv("REMD_DEBUG")) {
-                    double mean = 0; for (int c : cnt) mean += c; mean /= cnt.size();
-                    std::vector<float4> hh((size_t)h->R * ncl);
-                    hipMemcpy(hh.data(), t.d_cl_h, sizeof(float4) * hh.size(), hipMemcpyDeviceToHost);
-                    double hx = 0; int nh = 0; for (auto& v : hh) if (v.x >= 0) { hx += v.x + v.y + v.z; nh++; }
-                    fprintf(stderr, "[remd] cluster list: ncl %d mean neighbours %.1f max %d cap %d mean half-extent %.3f nm\n", ncl, mean, mx, t.cl_cap, hx / (3.0 * nh));
-                }
-                if (getenv("REMD_DEBUG") && sci) {
-                    std::vector<unsigned int> ll((size_t)ntile * t.cl_cap);
-                    hipMemcpy(ll.data(), t.d_sci_list, sizeof(unsigned int) * ll.size(), hipMemcpyDeviceToHost);
-                    double ne = 0, nb = 0;
-                    for (int T = 0; T < ntile; ++T) for (int k = 0; k < std::min(cnt[T], t.cl_cap); ++k) { ne += 1; nb += __builtin_popcount(ll[(size_t)T * t.cl_cap + k] >> 16); }
-                    fprintf(stderr, "[remd] sci list (replica 0): %d tiles, %.1f entries per tile, %.2f i clusters per entry\n", ntile, ne / ntile, nb / std::max(1.0, ne));
-                }
-                if (mx > t.cl_cap) t.clusters = false;        // fall back to the tile kernel
-            }
+        if (cl) launch_list_build(h, t, false);
+    }
+    static const bool debug = getenv("REMD_DEBUG") != nullptr;
+    if (cl && t.evals_since_sort == 1 && (t.cl_cap < ntile * 8 || debug)) {
+        // capacity check once per re-sort (the only host synchronisation of this path)
+        std::vector<int> cnt((size_t)h->R * ntile);
+        REMD_CHECK(h, hipMemcpyAsync(cnt.data(), t.d_sci_count, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, h->stream));
+        REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        int mx = 0; for (int c : cnt) mx = std::max(mx, c);
+        if (debug) {
+            std::vector<unsigned int> ll((size_t)ntile * t.cl_cap);
+            hipMemcpy(ll.data(), t.d_sci_list, sizeof(unsigned int) * ll.size(), hipMemcpyDeviceToHost);
+            double ne = 0, nb = 0;
+            for (int T = 0; T < ntile; ++T) for (int k = 0; k < std::min(cnt[T], t.cl_cap); ++k) { ne += 1; nb += __builtin_popcount(ll[(size_t)T * t.cl_cap + k] >> 16); }
+            fprintf(stderr, "[remd] sci list (replica 0): %d tiles, %.1f entries per tile (max %d, cap %d), %.2f i clusters per entry\n",
+                    ntile, ne / ntile, mx, t.cl_cap, nb / std::max(1.0, ne));
         }
+        if (mx > t.cl_cap) t.clusters = false;        // fall back to the tile kernel
     }
     return 0;
 }
 
+// direct-space launch: the Newton's-third-law cluster-pair kernel over the super-cluster lists (main system and, for the
+// Ewald / reaction-field methods, the LJ-only sub-system in the same launch), or the all-tile kernel when the system has no
+// sortable groups or a list outgrew its capacity
 template <int METHOD, bool ENERGY>
-static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
+static void launch_nb(remd_ctx* h, nb_tables& t)
 {
     const int ntile = (h->N + 63) / 64;
-    if (t.sorting && t.clusters && t.d_order && t.d_cl_list && t.n_groups > 0 && t.n_groups < 8192 && ntile * 8 < 65536) {
+    if (t.sorting && t.clusters && t.d_order && t.d_sci_list && t.n_groups > 0 && t.n_groups < 8192 && ntile * 8 < 65536) {
         const int ncl = ntile * 8;
-        static int main_split = getenv("REMD_NB_MAINSPLIT") ? std::max(1, std::min(4, atoi(getenv("REMD_NB_MAINSPLIT")))) : 4;
-        // wave budget: when the PME pipeline runs concurrently, cap the direct-space kernels at 16 waves per CU
-        static int persist = getenv("REMD_NB_PERSIST") ? atoi(getenv("REMD_NB_PERSIST")) : 0;
-        static int ncu = 0;
-        if (!ncu) { hipDeviceProp_t prop; ncu = (hipGetDeviceProperties(&prop, h->device) == hipSuccess) ? prop.multiProcessorCount : 256; }
-        const bool cap_waves = h->pme_concurrent && persist > 0;
-        const int n_items = ncl * h->R * main_split;
-        dim3 grid(cap_waves ? std::min(n_items, ncu * persist) : n_items);
         const float* rl = t.has_alch ? t.d_rep_lam : (const float*)nullptr;
-        const bool split = t.lj_split && t.d_lj_list && (METHOD == NB_EWALD || METHOD == NB_RF);
+        const bool split = t.lj_split && t.d_lj_sci_list && (METHOD == NB_EWALD || METHOD == NB_RF);
         constexpr int MAIN = (METHOD == NB_EWALD) ? NB_EWALD_NOLJ : (METHOD == NB_RF) ? NB_RF_NOLJ : METHOD;
-#define LAUNCH_CL(M, ALCHF) hipLaunchKernelGGL((nonbonded_cluster_kernel<M, ENERGY, ALCHF>), grid, dim3(64), 0, h->stream, t.p, h->N, h->Npad, ncl, \
-            t.cl_cap, t.d_spos, t.d_sparam, t.d_smask, t.d_order, t.d_cl_list, t.d_cl_count, h->d_box, rl, h->d_force, h->Npad, h->d_epart, h->n_epart, 0, \
-            h->R, main_split)
-        const bool sci = t.n3l && t.d_sci_list && t.d_excl && t.d_sforce && (!split || (t.d_lj_sci_list && t.d_lj_excl && t.d_lj_sforce));
         const int ssplit = std::max(SCI_NW, std::min(16, t.sci_split / SCI_NW * SCI_NW));
         sci_args sa{h->N, h->Npad, ncl, t.cl_cap, t.excl_W, h->Npad, 0, ssplit, t.d_spos, t.d_sparam, t.d_excl, t.d_sci_list, t.d_sci_count, t.d_sforce};
-        sci_args sb{};
-        if (split) sb = sci_args{t.NL, t.NLpad, t.NLpad / 8, t.lj_cap, t.lj_excl_W, t.NLpad, ncl * 4, ssplit, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl,
-                                 t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce};
-        const int items_a = ntile * h->R * (ssplit / SCI_NW), items_b = split ? (t.NLpad / 64) * h->R * (ssplit / SCI_NW) : 0;
-#define LAUNCH_SCI(M, ALCHF) hipLaunchKernelGGL((nonbonded_sci_kernel<M, ENERGY, ALCHF, SCI_NW>), dim3(items_a), dim3(64 * SCI_NW), 0, h->stream, t.p, sa, \
-            h->d_box, rl, h->d_epart, h->n_epart, h->R)
-        static const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
-        const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
-        const int sci2_grid = (h->pme_concurrent && persist_grid > 0) ? std::min(items_a + items_b, persist_grid)
-                            : cap_waves ? std::min(items_a + items_b, ncu * persist) : items_a + items_b;
-#define LAUNCH_SCI2(ALCHF) hipLaunchKernelGGL((nonbonded_sci2_kernel<MAIN, NB_LJ_ONLY, ENERGY, ALCHF, SCI_NW>), dim3(sci2_grid), dim3(64 * SCI_NW), 0, \
-            h->stream, t.p, sa, sb, items_a, items_a + items_b, sci2_grid < items_a + items_b ? t.d_queue : (unsigned int*)nullptr, h->d_box, rl, \
-            h->d_epart, h->n_epart, h->R)
-        if (sci && split && phase == 3) {
-            // one launch for both systems, one scatter for both sorted accumulators
+        const int items_a = ntile * h->R * (ssplit / SCI_NW);
+        if (split) {
+            // one launch for both systems, one scatter for both sorted accumulators; the launch is either one workgroup per
+            // work item or a resident set pulling items from a queue (t.nb_grid, chosen by timing: remd_nb_tune_step)
+            sci_args sb{t.NL, t.NLpad, t.NLpad / 8, t.lj_cap, t.lj_excl_W, t.NLpad, ncl * 4, ssplit, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl,
+                        t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce};
+            const int items = items_a + (t.NLpad / 64) * h->R * (ssplit / SCI_NW);
+            static const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
+            const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
+            const int grid = (h->pme_concurrent && persist_grid > 0) ? std::min(items, persist_grid) : items;
+#define LAUNCH_SCI2(ALCHF) hipLaunchKernelGGL((nonbonded_sci2_kernel<MAIN, NB_LJ_ONLY, ENERGY, ALCHF, SCI_NW>), dim3(grid), dim3(64 * SCI_NW), 0, \
+            h->stream, t.p, sa, sb, items_a, items, grid < items ? t.d_queue : (unsigned int*)nullptr, h->d_box, rl, h->d_epart, h->n_epart, h->R)
             if (t.has_alch) LAUNCH_SCI2(true); else LAUNCH_SCI2(false);
-            if (t.defer_scatter) { t.scatter_pending = true; return; }
+#undef LAUNCH_SCI2
             hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
                                t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
             return;
         }
-        if ((phase & 1) && sci) {
-            if (split) { if (t.has_alch) LAUNCH_SCI(MAIN, true); else LAUNCH_SCI(MAIN, false); }
-            else { if (t.has_alch) LAUNCH_SCI(METHOD, true); else LAUNCH_SCI(METHOD, false); }
-            hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.d_order,
-                               t.d_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
-        } else if (phase & 1) {
-            if (split) { if (t.has_alch) LAUNCH_CL(MAIN, true); else LAUNCH_CL(MAIN, false); }
-            else { if (t.has_alch) LAUNCH_CL(METHOD, true); else LAUNCH_CL(METHOD, false); }
-        }
-#undef LAUNCH_CL
+#define LAUNCH_SCI(ALCHF) hipLaunchKernelGGL((nonbonded_sci_kernel<METHOD, ENERGY, ALCHF, SCI_NW>), dim3(items_a), dim3(64 * SCI_NW), 0, h->stream, t.p, sa, \
+            h->d_box, rl, h->d_epart, h->n_epart, h->R)
+        if (t.has_alch) LAUNCH_SCI(true); else LAUNCH_SCI(false);
 #undef LAUNCH_SCI
-#undef LAUNCH_SCI2
-        if (split && (phase & 2) && sci) {
-            if (t.has_alch)
-                hipLaunchKernelGGL((nonbonded_sci_kernel<NB_LJ_ONLY, ENERGY, true, SCI_NW>), dim3(items_b), dim3(64 * SCI_NW), 0, h->stream, t.p, sb,
-                                   h->d_box, rl, h->d_epart, h->n_epart, h->R);
-            else
-                hipLaunchKernelGGL((nonbonded_sci_kernel<NB_LJ_ONLY, ENERGY, false, SCI_NW>), dim3(items_b), dim3(64 * SCI_NW), 0, h->stream, t.p, sb,
-                                   h->d_box, rl, h->d_epart, h->n_epart, h->R);
-            hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, t.NLpad, t.d_lj_order,
-                               t.d_lj_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
-        } else if (split && (phase & 2)) {
-            nb_params pl = t.p; pl.excl_words = t.lj_words;
-            const int ncl_lj = t.NLpad / 8;
-            const int n_items2 = ncl_lj * h->R * 4;
-            dim3 g2(cap_waves ? std::min(n_items2, ncu * persist) : n_items2);
-            if (t.has_alch)
-                hipLaunchKernelGGL((nonbonded_cluster_kernel<NB_LJ_ONLY, ENERGY, true>), g2, dim3(64), 0, h->stream, pl, t.NL, t.NLpad, ncl_lj,
-                                   t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_smask, t.d_lj_order, t.d_lj_list, t.d_lj_count, h->d_box, rl,
-                                   h->d_force, h->Npad, h->d_epart, h->n_epart, ncl * 4, h->R, 4);
-            else
-                hipLaunchKernelGGL((nonbonded_cluster_kernel<NB_LJ_ONLY, ENERGY, false>), g2, dim3(64), 0, h->stream, pl, t.NL, t.NLpad, ncl_lj,
-                                   t.lj_cap, t.d_lj_spos, t.d_lj_sparam, t.d_lj_smask, t.d_lj_order, t.d_lj_list, t.d_lj_count, h->d_box, rl,
-                                   h->d_force, h->Npad, h->d_epart, h->n_epart, ncl * 4, h->R, 4);
-        }
+        hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.d_order,
+                           t.d_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);
         return;
     }
-    if (!(phase & 1)) return;
     dim3 grid((ntile + NB_WAVES - 1) / NB_WAVES, t.p.n_jsplit, h->R);
     const size_t need = (size_t)h->R * t.p.n_jsplit * h->Npad;
     if (t.partial_n < need) { dfree(t.d_partial); if (hipMalloc(&t.d_partial, sizeof(float4) * need) != hipSuccess) return; t.partial_n = need; }
@@ -1958,6 +1671,14 @@ static void launch_nb(remd_ctx* h, nb_tables& t, int phase = 3)
                        t.d_partial, h->d_force);
 }
 
+int remd_nb_molecules(remd_ctx* h, const int** first, const int** size)
+{
+    nb_tables* it = g_nb.find(h);
+    if (!it || it->n_groups <= 0) return 0;
+    *first = it->d_grp_first; *size = it->d_grp_size;
+    return it->n_groups;
+}
+
 const float* remd_nb_rep_lam(remd_ctx* h)
 {
     nb_tables* it = g_nb.find(h);
@@ -1971,14 +1692,6 @@ int remd_nb_required_epart(remd_ctx* h)
     return EP_NB0 + ntile * 8 * 4 + 8 + ntile * 8 * 4;  // up to 4 slices per main cluster + 4 per LJ-sub-system cluster
 }
 
-// used by the captured MD step (integrate.hip): is the next force evaluation a re-sorting one, and the bookkeeping of an
-// evaluation that was replayed from the graph instead of enqueued here
-int remd_nb_resort_due(remd_ctx* h)
-{
-    nb_tables* t = g_nb.find(h);
-    if (!t || h->nb_method == REMD_NB_NONE || !t->sorting || t->n_groups <= 0 || t->n_groups >= 8192) return 0;
-    return (t->sort_R != h->R || t->evals_since_sort >= t->resort_interval) ? 1 : 0;
-}
 #define TUNE_SEG 40                       // one re-sort of the spatial order per segment (resort_interval)
 #define TUNE_NC 6
 static const int g_tune_cands[TUNE_NC] = {0, 768, 704, 640, 576, 512};      // workgroups: one per item, 3 ... 2 per CU (256 CUs) in steps of 1/4
@@ -1988,7 +1701,7 @@ void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call)
     nb_tables* tp = g_nb.find(h);
     if (!tp || h->nb_method == REMD_NB_NONE) return;
     nb_tables& t = *tp;
-    static const bool fixed = getenv("REMD_NB_PERSIST_GRID") || getenv("REMD_NB_PERSIST");
+    static const bool fixed = getenv("REMD_NB_PERSIST_GRID") != nullptr;
     if (fixed || t.tune_state != 0 || !h->pme_concurrent || h->profiling == 2) return;
     if (t.tune_left == 0) {
         hipEvent_t boundary = nullptr;
@@ -2056,11 +1769,6 @@ int remd_nb_resident_info(remd_ctx* h, int* ok, int* method, int* has_alch, nb_p
     *rep_lam = t->has_alch ? t->d_rep_lam : nullptr;
     return 0;
 }
-void remd_nb_note_evaluation(remd_ctx* h)
-{
-    nb_tables* t = g_nb.find(h);
-    if (t && h->nb_method != REMD_NB_NONE) t->evals_since_sort++;
-}
 
 int remd_compute_forces(remd_ctx* h, bool with_energy)
 {
@@ -2076,107 +1784,37 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
                  h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
     }
-    bool pme_forked = false, swapped = false;
+    // Two branches between the integrator chains.  The reciprocal-space pipeline is the longer one, so IT stays on the main
+    // stream directly behind the integrator; the direct-space launches go to the second stream (h->stream is swapped until
+    // the join).  Fork and join are flags in device memory polled by kernels (remd_ctx::d_sync), or events when a handle has
+    // fallen back to them (REMD_SYNC_EVENTS=1 / api.hip: remd_recover_device_flag).  Measured alternatives that lost their
+    // A/B and were removed in round 3 (numbers in DESIGN.md 7b): the mesh branch on the second stream, the pair kernel ahead
+    // of the listed terms, the listed terms in front of the pair kernel or on a third stream, scatter + listed terms + join
+    // flag in one launch.
+    bool forked = false, swapped = false;
     struct unswap { remd_ctx* h; bool* on; ~unswap() { if (*on) std::swap(h->stream, h->stream2); } } guard{h, &swapped};
     if (h->nb_method != REMD_NB_NONE) {      // per-replica lambdas must be current before ANY kernel reads them
         nb_tables& t0 = g_nb[h];
         int rc0 = update_replica_lambdas(h, t0);
         if (rc0) return rc0;
         if (t0.method == NB_EWALD && h->overlap && h->stream2) {
-            // fork: the reciprocal-space pipeline is the longer branch, so IT stays on the main stream directly behind the
-            // integrator chain (no cross-stream event latency on the critical path); the direct-space launches below go
-            // to the second stream (h->stream is swapped until the join) and absorb the event wait in their slack
-            static const bool pme_on_main = !(getenv("REMD_PME_MAIN") && atoi(getenv("REMD_PME_MAIN")) == 0);
-            const bool flags = pme_on_main && !h->sync_events && !h->capturing;
-            if (flags) {
-                // the binning kernel (first launch of remd_pme_forces) stores the fork flag; the second stream polls it
+            if (!h->sync_events) {
+                // the first mesh launch (binning kernel, or the spreading pass when the chain binned the atoms) stores the
+                // fork flag; a one-wavefront kernel at the head of the second stream polls it
                 h->fork_seq_pending = ++h->sync_seq;
                 hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream2, h->d_sync, h->sync_seq, h->d_sync + 2);
             } else {
                 hipEventRecord(h->ev_fork, h->stream);
                 hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
             }
-            if (pme_on_main) {
-                // everything up to the inverse z FFT now; the gather is enqueued behind the join (below), so that the
-                // cross-stream wait sits in front of the last mesh kernel instead of between it and the integrator
-                rc0 = remd_pme_forces(h, with_energy, h->stream, 1);
-                if (rc0) return rc0;
-                std::swap(h->stream, h->stream2);
-                swapped = true;
-            } else {
-                rc0 = remd_pme_forces(h, with_energy, h->stream2);
-                if (rc0) return rc0;
-                hipEventRecord(h->ev_join, h->stream2);
-            }
-            pme_forked = true;
+            rc0 = remd_pme_forces(h, with_energy, h->stream, 1);        // everything up to the inverse z transform + gather
+            if (rc0) return rc0;
+            std::swap(h->stream, h->stream2);
+            swapped = true; forked = true;
         }
     }
-    h->pme_concurrent = pme_forked;
+    h->pme_concurrent = forked;
     const bool merged = !with_energy;      // force-only evaluations: every listed term in one launch
-    // Launch order of a force-only evaluation (measured, bench.py): listed terms -> both lists -> Coulomb pair kernel
-    // -> LJ pair kernel gives 6.77 it/s with the packed z transforms; launching the Coulomb kernel ahead of the listed
-    // terms and the LJ lists (REMD_NB_EARLY=1) makes it collide with the XY FFT pass instead of the spreading: 6.22.
-    bool main_launched = false;
-    static const bool nb_early = getenv("REMD_NB_EARLY") && atoi(getenv("REMD_NB_EARLY")) != 0;
-    if (merged && nb_early && h->nb_method != REMD_NB_NONE) {
-        nb_tables& t = g_nb[h];
-        int rc = ensure_sorted(h, t, 1);
-        if (rc) return rc;
-        remd_prof_scope ps(h, "nonbonded");
-        if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, false>(h, t, 1);
-        else if (t.method == NB_RF) launch_nb<NB_RF, false>(h, t, 1);
-        else launch_nb<NB_EWALD, false>(h, t, 1);
-        main_launched = true;
-    }
-    // listed terms BEHIND the pair kernel (REMD_LISTED_LATE=0: in front): the pair kernel then starts 20 us earlier and shares
-    // the spreading pass's idle vector units instead of fighting the XY pass for them (118.9 -> 116.8 ms per 500 steps)
-    static const bool listed_late = !(getenv("REMD_LISTED_LATE") && atoi(getenv("REMD_LISTED_LATE")) == 0);
-    bool join_signalled = false;
-    auto launch_listed = [&]() {
-    {
-        listed_tables T{};
-        T.n_bonds = h->n_bonds; T.n_angles = h->n_angles; T.n_torsions = h->n_torsions;
-        T.bond_atoms = h->d_bond_atoms; T.bond_params = h->d_bond_params;
-        T.angle_atoms = h->d_angle_atoms; T.angle_params = h->d_angle_params;
-        T.torsion_atoms = h->d_torsion_atoms; T.torsion_params = h->d_torsion_params;
-        nb_tables* it = g_nb.find(h);
-        if (it && h->nb_method != REMD_NB_NONE) {
-            nb_tables& t = *it;
-            T.n_exc = t.n_exc; T.exc_atoms = t.d_exc_atoms; T.exc_params = t.d_exc_params;
-            T.n_excl = t.n_excl; T.excl_atoms = t.d_excl_atoms; T.excl_qq = t.d_excl_qq;
-            T.alpha = t.p.alpha; T.two_alpha_sqrtpi = t.p.two_alpha_sqrtpi;
-            T.exc_alch = t.d_exc_alch; T.excl_alch = t.d_excl_alch; T.rep_lam = t.has_alch ? t.d_rep_lam : nullptr;
-        }
-        const int total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
-        if (it && it->scatter_pending) {
-            nb_tables& t = *it;
-            t.scatter_pending = false;
-            const int n_scatter = (h->Npad + t.NLpad + 255) / 256;
-            const bool sig = swapped && !h->sync_events && !h->capturing;       // this launch is the last of the direct-space stream
-            remd_prof_scope ps(h, "bonded");
-            hipLaunchKernelGGL(direct_tail_kernel, dim3(n_scatter + (total + 255) / 256, R), dim3(256), 0, h->stream,
-                               scatter_args{h->Npad, t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce}, n_scatter, T, h->Npad, h->d_pos,
-                               h->d_box, h->d_force, sig ? h->d_sync + 1 : (unsigned int*)nullptr, h->sync_seq, t.d_queue + 3);
-            join_signalled = sig;
-        } else if (total > 0) {
-            remd_prof_scope ps(h, "bonded");
-            hipLaunchKernelGGL(listed_forces_kernel, dim3((total + 255) / 256, R), dim3(256), 0, h->stream, T, h->Npad, h->d_pos,
-                               h->d_box, h->d_force);
-        }
-    }
-    };
-    // REMD_LISTED_STREAM=1: the listed terms on a third stream right behind the fork (experiment: takes them off the direct-space tail)
-    h->listed_on_s3 = false;
-    if (merged && listed_late && h->stream3 && pme_forked && swapped && !h->sync_events && !h->capturing) {
-        hipStream_t keep = h->stream;
-        h->stream = h->stream3;
-        hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream3, h->d_sync, h->sync_seq, h->d_sync + 2);
-        launch_listed();
-        hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream3, h->d_sync + 3, h->sync_seq);
-        h->stream = keep;
-        h->listed_on_s3 = true;
-    }
-    if (merged && !listed_late) launch_listed();
     if (!merged && h->n_bonds > 0) {
         remd_prof_scope ps(h, "bonded");
         LAUNCH_E(bond_kernel, dim3(R), dim3(256), 0, h->stream, h->n_bonds, h->d_bond_atoms, h->d_bond_params, h->Npad,
@@ -2192,30 +1830,48 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         LAUNCH_E(torsion_kernel, dim3(R), dim3(256), 0, h->stream, h->n_torsions, h->d_torsion_atoms, h->d_torsion_params, h->Npad,
                  h->d_pos, h->d_force, h->d_epart, h->n_epart);
     }
-    if (h->nb_method != REMD_NB_NONE) {
+    // listed terms of a force-only evaluation: ONE launch, behind the pair kernel (it then starts 20 us earlier, next to the
+    // spreading pass: 118.9 -> 116.8 ms per 500 steps)
+    auto launch_listed = [&]() {
+        listed_tables T{};
+        T.n_bonds = h->n_bonds; T.n_angles = h->n_angles; T.n_torsions = h->n_torsions;
+        T.bond_atoms = h->d_bond_atoms; T.bond_params = h->d_bond_params;
+        T.angle_atoms = h->d_angle_atoms; T.angle_params = h->d_angle_params;
+        T.torsion_atoms = h->d_torsion_atoms; T.torsion_params = h->d_torsion_params;
+        nb_tables* it = g_nb.find(h);
+        if (it && h->nb_method != REMD_NB_NONE) {
+            nb_tables& t = *it;
+            T.n_exc = t.n_exc; T.exc_atoms = t.d_exc_atoms; T.exc_params = t.d_exc_params;
+            T.n_excl = t.n_excl; T.excl_atoms = t.d_excl_atoms; T.excl_qq = t.d_excl_qq;
+            T.alpha = t.p.alpha; T.two_alpha_sqrtpi = t.p.two_alpha_sqrtpi;
+            T.exc_alch = t.d_exc_alch; T.excl_alch = t.d_excl_alch; T.rep_lam = t.has_alch ? t.d_rep_lam : nullptr;
+        }
+        const int total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
+        if (total > 0) {
+            remd_prof_scope ps(h, "bonded");
+            hipLaunchKernelGGL(listed_forces_kernel, dim3((total + 255) / 256, R), dim3(256), 0, h->stream, T, h->Npad, h->d_pos,
+                               h->d_box, h->d_force);
+        }
+    };
+    if (h->nb_method == REMD_NB_NONE) {
+        if (merged) launch_listed();
+    } else {
         nb_tables& t = g_nb[h];
-        int rc = update_replica_lambdas(h, t);
+        int rc = ensure_sorted(h, t);
         if (rc) return rc;
-        const int phase = main_launched ? 2 : 3;
-        if ((rc = ensure_sorted(h, t, phase))) return rc;
-        // REMD_TAIL_FUSE=1: scatter + listed terms + join flag in one launch.  Measured: worth 1 ms per 500 steps when the direct-space
-        // stream is the longer branch (pair kernel at < 2 workgroups per CU), nothing at the tuned balance (111.3 vs 110.9 ms): opt-in
-        static const bool tail_fuse = getenv("REMD_TAIL_FUSE") && atoi(getenv("REMD_TAIL_FUSE")) != 0;
-        t.defer_scatter = tail_fuse && merged && listed_late && phase == 3;       // the scatter rides in the listed-terms launch
-        t.scatter_pending = false;
         {
-            remd_prof_scope ps(h, phase == 2 ? "nonbonded_lj" : "nonbonded");
+            remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {
-                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, true>(h, t, phase);
-                else if (t.method == NB_RF) launch_nb<NB_RF, true>(h, t, phase);
-                else launch_nb<NB_EWALD, true>(h, t, phase);
+                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, true>(h, t);
+                else if (t.method == NB_RF) launch_nb<NB_RF, true>(h, t);
+                else launch_nb<NB_EWALD, true>(h, t);
             } else {
-                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, false>(h, t, phase);
-                else if (t.method == NB_RF) launch_nb<NB_RF, false>(h, t, phase);
-                else launch_nb<NB_EWALD, false>(h, t, phase);
+                if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, false>(h, t);
+                else if (t.method == NB_RF) launch_nb<NB_RF, false>(h, t);
+                else launch_nb<NB_EWALD, false>(h, t);
             }
         }
-        if (merged && listed_late && !h->listed_on_s3) launch_listed();
+        if (merged) launch_listed();
         if (!merged && t.n_exc > 0) {
             remd_prof_scope ps(h, "exceptions");
             LAUNCH_E(exception_kernel, dim3(R), dim3(256), 0, h->stream, t.n_exc, t.d_exc_atoms, t.d_exc_params, t.d_exc_alch,
@@ -2229,19 +1885,20 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
                      t.p.two_alpha_sqrtpi, h->Npad, h->d_pos, h->d_box, h->d_force, h->d_epart, h->n_epart);
         }
         if (t.method == NB_EWALD) {
-            if (pme_forked) {                                                   // join
-                const bool gather_pending = swapped;
-                if (swapped && !h->sync_events && !h->capturing) {
-                    if (!join_signalled) hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
+            if (forked) {                                                       // join
+                if (!h->sync_events) {
+                    hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
                     std::swap(h->stream, h->stream2); swapped = false;
+                    // inside remd_run_steps the launch that follows on the main stream is an integrator chain: it polls the
+                    // flag in its prologue (no kernel of its own for the wait)
                     if (h->defer_join_ok && !with_energy) h->join_deferred = h->sync_seq;
-                    else hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq, h->d_sync + 2,
-                                            h->listed_on_s3 ? h->d_sync + 3 : (const unsigned int*)nullptr);
+                    else hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq, h->d_sync + 2);
                 } else {
-                    if (swapped) { hipEventRecord(h->ev_join, h->stream); std::swap(h->stream, h->stream2); swapped = false; }
+                    hipEventRecord(h->ev_join, h->stream);
+                    std::swap(h->stream, h->stream2); swapped = false;
                     hipStreamWaitEvent(h->stream, h->ev_join, 0);
                 }
-                if (gather_pending) { rc = remd_pme_forces(h, with_energy, h->stream, 2); if (rc) return rc; }
+                rc = remd_pme_forces(h, with_energy, h->stream, 2); if (rc) return rc;        // (the energy reduction of the mesh part)
             }
             else { rc = remd_pme_forces(h, with_energy, h->stream); if (rc) return rc; }
         }
@@ -2255,134 +1912,6 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         hipLaunchKernelGGL(reduce_energy_kernel, dim3(R), dim3(64), 0, h->stream, h->n_epart, h->d_epart, h->d_potential);
     REMD_CHECK(h, hipGetLastError());
     h->forces_valid = true;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Monte Carlo barostat: what an NPT ThermodynamicState means in the reference (states.py:1177-1181 adds an
-// openmm.MonteCarloBarostat, frequency 25, to the System; it fires inside LangevinIntegrator's addUpdateContextState step,
-// integrators.py:1313).  The algorithm is OpenMM's MonteCarloBarostatImpl::updateContextState, restated: every
-// `frequency` steps  dV = volumeScale * 2 (u - 1/2);  every molecule's centre (arithmetic mean, wrapped into the box) is
-// scaled by s = (V'/V)^(1/3) together with the box;  w = U' - U + p dV - N_mol kT ln(V'/V);  reject (restore) if w > 0 and
-// u' > exp(-w / kT);  after >= 10 attempts volumeScale /= 1.1 below 25 % acceptance, *= 1.1 (capped at 0.3 V) above 75 %.
-// All local replicas attempt at once, each with its own state's p and kT and its own Philox draws.
-__global__ void baro_draw_kernel(int R, int r_begin, uint64_t seed, long long attempt, float* __restrict__ box,
-                                 float* __restrict__ box_old, double* __restrict__ st)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    double* S = st + (size_t)r * 8;
-    const double Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-    const double V = Lx * Ly * Lz;
-    if (S[0] <= 0.0) S[0] = 0.01 * V;                                   // initial volumeScale (MonteCarloBarostatImpl::initialize)
-    const philox4 w = remd_philox(seed, REMD_STREAM_BAROSTAT, 0u, (uint32_t)(r_begin + r), (uint64_t)attempt);
-    const double dV = S[0] * 2.0 * (remd_u53(w.w[2], w.w[3]) - 0.5);
-    const double newV = V + dV;
-    const double scale = cbrt(newV / V);
-    S[5] = dV; S[6] = newV; S[7] = V;
-    box_old[4 * r] = box[4 * r]; box_old[4 * r + 1] = box[4 * r + 1]; box_old[4 * r + 2] = box[4 * r + 2];
-    box[4 * r] = (float)(Lx * scale); box[4 * r + 1] = (float)(Ly * scale); box[4 * r + 2] = (float)(Lz * scale);
-}
-
-// one thread per molecule (contiguous atom range): centre -> wrapped centre -> scaled centre (OpenMM scalePositions)
-__global__ __launch_bounds__(256)
-void baro_scale_kernel(int n_mol, const int* __restrict__ first, const int* __restrict__ size, int Npad,
-                       float4* __restrict__ pos, const float* __restrict__ box_old, const double* __restrict__ st)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (g >= n_mol) return;
-    const double* S = st + (size_t)r * 8;
-    const float scale = (float)cbrt(S[6] / S[7]);
-    float4* P = pos + (size_t)r * Npad;
-    const int a0 = first[g], n = size[g];
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    for (int k = 0; k < n; ++k) { const float4 p = P[a0 + k]; cx += p.x; cy += p.y; cz += p.z; }
-    const float inv = 1.f / (float)n;
-    cx *= inv; cy *= inv; cz *= inv;
-    const float Lx = box_old[4 * r], Ly = box_old[4 * r + 1], Lz = box_old[4 * r + 2];
-    const float wx = cx - floorf(cx / Lx) * Lx, wy = cy - floorf(cy / Ly) * Ly, wz = cz - floorf(cz / Lz) * Lz;
-    const float dx = wx * (scale - 1.f) - (cx - wx), dy = wy * (scale - 1.f) - (cy - wy), dz = wz * (scale - 1.f) - (cz - wz);
-    for (int k = 0; k < n; ++k) { float4 p = P[a0 + k]; p.x += dx; p.y += dy; p.z += dz; P[a0 + k] = p; }
-}
-
-__global__ void baro_decide_kernel(int R, int r_begin, uint64_t seed, long long attempt, int n_mol, const double* __restrict__ U_old,
-                                   const double* __restrict__ U_new, const int64_t* __restrict__ labels,
-                                   const double* __restrict__ beta, const double* __restrict__ pressure,
-                                   const double* __restrict__ econst, double econst_vref,
-                                   float* __restrict__ box, const float* __restrict__ box_old, double* __restrict__ st,
-                                   int* __restrict__ accepted)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    double* S = st + (size_t)r * 8;
-    const int k = (int)labels[r_begin + r];
-    const double kT = 1.0 / beta[k];
-    // + the current state's long-range constant ~ 1/V (alchemical sterics correction), which d_potential does not carry
-    const double dlr = (econst_vref > 0.0) ? econst[k] * econst_vref * (1.0 / S[6] - 1.0 / S[7]) : 0.0;
-    const double w = U_new[r] - U_old[r] + dlr + pressure[k] * S[5] - (double)n_mol * kT * log(S[6] / S[7]);
-    const philox4 q = remd_philox(seed, REMD_STREAM_BAROSTAT, 1u, (uint32_t)(r_begin + r), (uint64_t)attempt);
-    const bool reject = !(w <= 0.0) && !(remd_u53(q.w[2], q.w[3]) <= exp(-w / kT));     // NaN energies reject
-    accepted[r] = reject ? 0 : 1;
-    if (reject) { box[4 * r] = box_old[4 * r]; box[4 * r + 1] = box_old[4 * r + 1]; box[4 * r + 2] = box_old[4 * r + 2]; }
-    else { S[2] += 1.0; S[4] += 1.0; }
-    S[1] += 1.0; S[3] += 1.0;
-    if (S[1] >= 10.0) {
-        const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
-        if (S[2] < 0.25 * S[1]) { S[0] /= 1.1; S[1] = 0.0; S[2] = 0.0; }
-        else if (S[2] > 0.75 * S[1]) { S[0] = fmin(S[0] * 1.1, V * 0.3); S[1] = 0.0; S[2] = 0.0; }
-    }
-}
-
-__global__ __launch_bounds__(256)
-void baro_restore_kernel(int N, int Npad, const int* __restrict__ accepted, float4* __restrict__ pos, const float4* __restrict__ x0,
-                         long long* __restrict__ force, const long long* __restrict__ f0, double* __restrict__ potential,
-                         const double* __restrict__ U0)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (accepted[r]) return;
-    if (i == 0) potential[r] = U0[r];
-    if (i >= N) return;
-    const size_t o = (size_t)r * Npad, of = (size_t)r * 3 * Npad;
-    pos[o + i] = x0[o + i];
-    force[of + i] = f0[of + i]; force[of + Npad + i] = f0[of + Npad + i]; force[of + 2 * Npad + i] = f0[of + 2 * Npad + i];
-}
-
-int remd_barostat_attempt(remd_ctx* h)
-{
-    nb_tables* it = g_nb.find(h);
-    if (!it || it->n_groups <= 0) return remd_fail(h, -3, "barostat: the system has no molecule table (needs a NonbondedForce)");
-    nb_tables& t = *it;
-    const int R = h->R, Npad = h->Npad;
-    if (!h->d_baro) {
-        REMD_CHECK(h, hipMalloc(&h->d_baro, sizeof(double) * 8 * R)); REMD_CHECK(h, hipMemsetAsync(h->d_baro, 0, sizeof(double) * 8 * R, h->stream));
-        REMD_CHECK(h, hipMalloc(&h->d_box_old, sizeof(float) * 4 * R));
-        REMD_CHECK(h, hipMalloc(&h->d_baro_x0, sizeof(float4) * (size_t)R * Npad));
-        REMD_CHECK(h, hipMalloc(&h->d_baro_f0, sizeof(long long) * 3 * (size_t)R * Npad));
-        REMD_CHECK(h, hipMalloc(&h->d_baro_U0, sizeof(double) * R));
-        REMD_CHECK(h, hipMalloc(&h->d_baro_acc, sizeof(int) * R));
-    }
-    int rc;
-    h->force_zeroed = false;
-    if ((rc = remd_compute_forces(h, true))) return rc;                         // U and forces of the current configuration
-    REMD_CHECK(h, hipMemcpyAsync(h->d_baro_U0, h->d_potential, sizeof(double) * R, hipMemcpyDeviceToDevice, h->stream));
-    REMD_CHECK(h, hipMemcpyAsync(h->d_baro_f0, h->d_force, sizeof(long long) * 3 * (size_t)R * Npad, hipMemcpyDeviceToDevice, h->stream));
-    REMD_CHECK(h, hipMemcpyAsync(h->d_baro_x0, h->d_pos, sizeof(float4) * (size_t)R * Npad, hipMemcpyDeviceToDevice, h->stream));
-    const long long attempt = h->baro_attempts++;
-    hipLaunchKernelGGL(baro_draw_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, h->r_begin, h->seed, attempt, h->d_box,
-                       h->d_box_old, h->d_baro);
-    hipLaunchKernelGGL(baro_scale_kernel, dim3((t.n_groups + 255) / 256, R), dim3(256), 0, h->stream, t.n_groups, t.d_grp_first,
-                       t.d_grp_size, Npad, h->d_pos, h->d_box_old, h->d_baro);
-    h->box_version++;
-    h->force_zeroed = false;
-    if ((rc = remd_compute_forces(h, true))) return rc;                         // U' and forces of the scaled configuration
-    hipLaunchKernelGGL(baro_decide_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, h->r_begin, h->seed, attempt, t.n_groups,
-                       h->d_baro_U0, h->d_potential, h->d_labels, h->d_beta, h->d_pressure, h->d_econst, h->econst_vref, h->d_box, h->d_box_old, h->d_baro,
-                       h->d_baro_acc);
-    hipLaunchKernelGGL(baro_restore_kernel, dim3((h->N + 255) / 256, R), dim3(256), 0, h->stream, h->N, Npad, h->d_baro_acc, h->d_pos,
-                       h->d_baro_x0, h->d_force, h->d_baro_f0, h->d_potential, h->d_baro_U0);
-    h->box_version++;
-    h->forces_valid = true; h->force_zeroed = false;
-    REMD_CHECK(h, hipGetLastError());
     return 0;
 }
 

@@ -26,17 +26,13 @@ struct chain_prog {
     int n;                 // tokens in this chain
     char tok[MAX_TOK];     // 'V','R','O','C' (C = subtract centre-of-mass velocity)
     int o_index[MAX_TOK];  // for 'O': index of this O inside the step program
-    long long step[MAX_TOK]; // step of each token RELATIVE to the step counter on the device (ctr[0]) when the chain runs: 0 = the
-                           // step the launching loop body belongs to, -1 = a token left pending by the previous body
+    long long step[MAX_TOK]; // global step index of each token (a chain may hold tokens left pending by the previous step)
     float hV, hR;          // dt/n_V, dt/n_R
     float a, b;            // OU coefficients
     int nO;
     int accumulate_momentum;  // after the chain, add sum(m v) into cmm buffer cmm_w
     int cmm_w, cmm_r;         // double-buffered momentum accumulators: 'C' reads cmm_r and clears the other one
     int zero_force;           // the chain ends with stale forces (an R after its last V): clear them for the next evaluation
-    int use_ctr;              // 1: steps are relative to the counters on the device (graph mode); 0: absolute (eager launches)
-    int body_idx;             // loop-body index (ctr[1]) this program was built for: the momentum double buffer alternates per
-                              // body, so a replayed (graph) launch shifts cmm_w / cmm_r by the parity of ctr[1] - body_idx
     int m_buf;                // token 'M' (inside a chain): add sum(m v) into momentum buffer m_buf, then wait until every workgroup
     unsigned int m_epoch;     // of the replica has done so (m_epoch-th barrier of this handle): the 'C' that follows reads the sum
     int measure;              // bit 0: heat (kinetic-energy change of the O substeps), bit 1: kinetic part of the shadow work (V, R substeps)
@@ -250,7 +246,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                                           float tol, int Npad, float4* __restrict__ P, float4* __restrict__ V,
                                           const long long* F, long long* Fw, const float* __restrict__ invmass, float kT,
                                           uint32_t rg, uint64_t seed, const long long* __restrict__ cmm_r, float inv_total_mass,
-                                          long long gstep_base, const remd_chain_bins& bins, int r,
+                                          const remd_chain_bins& bins, int r,
                                           unit_regs& S, int t0, int t1, bool first, bool last,
                                           float4* __restrict__ Xold, float4* __restrict__ Vold)
 {
@@ -313,7 +309,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                 constrain_v<TYPE, NAT>(sc, im, tol, v, x);
             }
         } else if (tok == 'O') {
-            const uint64_t cnt = (uint64_t)(gstep_base + prog.step[t]) * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
+            const uint64_t cnt = (uint64_t)prog.step[t] * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
 #pragma unroll
             for (int k = 0; k < NAT; ++k) {
                 const float3 xi = gaussian3(seed, REMD_STREAM_OU, (uint32_t)idx[k], rg, cnt);
@@ -369,16 +365,15 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             long long* force, const float* __restrict__ invmass,
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
-                            const long long* __restrict__ ctr, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
-                            unsigned int* chain_sync, unsigned int* chain_sync_err, const unsigned int* join_flag2,
+                            unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
+                            unsigned int* chain_sync, unsigned int* chain_sync_err,
                             unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold)
 {
     if (join_flag) {
         // the forces of the direct-space stream: poll its "done" flag here instead of behind a cross-stream event (remd_ctx::d_sync)
         if (threadIdx.x == 0) {
             long long n = 0;
-            while ((int)(__hip_atomic_load(join_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0 ||
-                   (join_flag2 && (int)(__hip_atomic_load(join_flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0)) {
+            while ((int)(__hip_atomic_load(join_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++n > (1ll << 25)) { atomicExch(join_flag + 1, 1u); break; }
             }
@@ -392,12 +387,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     float3 mom = f3(0, 0, 0);
-    // ctr[0]: global step index of the loop body this launch belongs to; ctr[1]: index of that body inside the current
-    // run (remd_run_steps).  Both live on the device so that a captured step (hipGraph) can be replayed unchanged.
-    // (ctr == NULL: eager launches carry absolute steps and buffer indices in `prog`, nothing to look up)
-    const long long gstep_base = ctr ? ctr[0] : 0ll;
-    const int flip = ctr ? (int)((ctr[1] - (long long)prog.body_idx) & 1) : 0;
-    const int cmm_r_eff = prog.cmm_r >= 0 ? (prog.cmm_r ^ flip) : -1, cmm_w_eff = prog.cmm_w ^ flip;
+    const int cmm_r_eff = prog.cmm_r, cmm_w_eff = prog.cmm_w;
     if (uidx == 0 && cmm_r_eff >= 0) {
         // this chain consumes accumulator cmm_r: clear the OTHER buffer (its sum was consumed one step ago)
         long long* o = cmm + ((size_t)(1 - cmm_r_eff) * gridDim.y + r) * 4;
@@ -423,7 +413,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         while (t1 < prog.n && prog.tok[t1] != 'M') ++t1;
         const bool first = t0 == 0, last = t1 == prog.n;
         if (active) {
-#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, gstep_base, bins, r, S, t0, t1, first, last, xold ? xold + (size_t)r * Npad : nullptr, vold ? vold + (size_t)r * Npad : nullptr)
+#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, bins, r, S, t0, t1, first, last, xold ? xold + (size_t)r * Npad : nullptr, vold ? vold + (size_t)r * Npad : nullptr)
             if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
             else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
             else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
@@ -444,7 +434,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                 pm.x += __shfl_xor(pm.x, off); pm.y += __shfl_xor(pm.y, off); pm.z += __shfl_xor(pm.z, off);
             }
             if ((threadIdx.x & 63) == 0) {
-                unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + ((size_t)(prog.m_buf ^ flip) * gridDim.y + r) * 4);
+                unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + ((size_t)prog.m_buf * gridDim.y + r) * 4);
                 atomicAdd(&c[0], (unsigned long long)(long long)((double)pm.x * 4294967296.0));
                 atomicAdd(&c[1], (unsigned long long)(long long)((double)pm.y * 4294967296.0));
                 atomicAdd(&c[2], (unsigned long long)(long long)((double)pm.z * 4294967296.0));
@@ -670,25 +660,21 @@ int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& 
 }
 
 remd_chain_bins remd_pme_chain_bins(remd_ctx* h);
-static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog, bool bin_for_pme = false)   // prog.use_ctr selects the counter look-up
+static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog, bool bin_for_pme = false)
 {
-    const remd_chain_bins bins = (bin_for_pme && !h->capturing && prog.use_ctr == 0) ? remd_pme_chain_bins(h) : remd_chain_bins();
+    const remd_chain_bins bins = bin_for_pme ? remd_pme_chain_bins(h) : remd_chain_bins();
     remd_prof_scope ps(h, "integrate_chain");
     dim3 grid((ut.n_units + 255) / 256, h->R);
     hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
-                       (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0), prog.use_ctr ? h->d_ctr : (const long long*)nullptr,
+                       (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0),
                        h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2,
-                       (h->join_deferred && h->listed_on_s3) ? h->d_sync + 3 : (const unsigned int*)nullptr,
                        (h->profiling == 2 || (h->profiling == 1 && h->prof_filter.find("integrate_chain") != std::string::npos)) ? h->d_chain_own : (unsigned long long*)nullptr,
                        h->d_work, h->d_xold, h->d_vold);
     h->join_deferred = 0;
     if (bins.count) h->cbins_ready = true;
 }
-
-__global__ void ctr_set_kernel(long long* ctr, long long gstep, long long body) { ctr[0] = gstep; ctr[1] = body; }
-__global__ void ctr_tick_kernel(long long* ctr) { ctr[0] += 1; ctr[1] += 1; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Heat, shadow work and Metropolization (integrators.py:1175-1204, 1404-1460, 1539-1557).  The kinetic-energy changes of the
@@ -764,7 +750,6 @@ struct resident_prog {
     int n; char tok[MAX_TOK]; int o_index[MAX_TOK];
     float hV, hR, a, b; int nO;
     int n_steps, cmm_frequency; long long gstep0, first_step;
-    int dbg;               // REMD_RESIDENT_DBG (timing experiments): 1 no pair loop, 2 no noise, 4 one list build only, 8 count rebuilds into err[1]
 };
 struct resident_sys {
     int N, Npad, method, alch, n_ext, list_cap;
@@ -853,7 +838,7 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
         const bool moved = !have_list || (active && dot3(d, d) > half_skin2);
         const int par_e = n_eval & 1;
         s_pos[tid] = make_float4(x.x, x.y, x.z, 0.f);
-        if ((prog.dbg & 4) ? !have_list : moved) s_vote[par_e] = 1;
+        if (moved) s_vote[par_e] = 1;
         __syncthreads();
         const int rebuild = s_vote[par_e];
         if (tid == 0) s_vote[par_e ^ 1] = 0;
@@ -880,7 +865,7 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
                 __syncthreads();
                 if (tid == 0 && *s_np > S.list_cap) atomicExch(S.err, 4u);
             }
-            if (!(prog.dbg & 1)) {
+            {
                 // a thread takes pairs tid, tid + T, ...: the same number for every lane (an atom-per-lane loop runs as long as the
                 // busiest atom of the wavefront: 16 slots for 10 neighbours on average), RES_UNROLL pairs per trip with all their
                 // LDS reads in flight
@@ -958,7 +943,7 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
                 forces_valid = false;
             } else {
                 const uint64_t cnt = (uint64_t)gstep * (uint64_t)prog.nO + (uint64_t)prog.o_index[t];
-                const float3 xi = (prog.dbg & 2) ? f3(0.1f, 0.2f, 0.3f) : gaussian3(S.seed, REMD_STREAM_OU, (uint32_t)tid, rg, cnt);
+                const float3 xi = gaussian3(S.seed, REMD_STREAM_OU, (uint32_t)tid, rg, cnt);
                 const float sig = prog.b * fsqrt(kT * im);
                 v = f3(prog.a * v.x + sig * xi.x, prog.a * v.y + sig * xi.y, prog.a * v.z + sig * xi.z);
             }
@@ -981,7 +966,7 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
     const bool enabled = !(getenv("REMD_RESIDENT") && atoi(getenv("REMD_RESIDENT")) == 0);      // read per call: the parity tests switch it
     if (!enabled || h->no_resident) return 0;
     if (h->N > 1024 || h->n_settle > 0 || h->n_shake > 0 || h->n_bonds > 0 || h->n_angles > 0 || h->n_torsions > 0) return 0;
-    if (h->baro_frequency > 0 || h->profiling == 2 || h->capturing || (int)tokens.size() > MAX_TOK || n_steps < 1) return 0;
+    if (h->baro_frequency > 0 || h->profiling == 2 || (int)tokens.size() > MAX_TOK || n_steps < 1) return 0;
     if (h->measure_heat || h->measure_shadow) return 0;
     for (char c : tokens) if (c != 'V' && c != 'R' && c != 'O') return 0;
     int ok = 0, method = -1, alch = 0; nb_params p{}; const float4* param = nullptr; const float* rep_lam = nullptr;
@@ -993,8 +978,7 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
     // skin: a fifth of the cutoff, at most what keeps r_c + skin inside half the smallest box edge (minimum image)
     double lmin = 1e30;
     for (int r = 0; r < h->R; ++r) for (int k = 0; k < 3; ++k) lmin = std::min(lmin, h->box_host.size() >= (size_t)3 * (r + 1) ? h->box_host[3 * r + k] : 1e30);
-    const double skin_frac = getenv("REMD_RESIDENT_SKIN") ? atof(getenv("REMD_RESIDENT_SKIN")) : 0.2;
-    S.skin = method >= 0 ? (float)std::max(0.0, std::min(skin_frac * p.rc, 0.5 * lmin - p.rc - 1e-3)) : 0.f;
+    S.skin = method >= 0 ? (float)std::max(0.0, std::min(0.2 * p.rc, 0.5 * lmin - p.rc - 1e-3)) : 0.f;
     if (method >= 0 && !(0.5 * lmin > p.rc)) return 0;
     S.ext_K = (float)h->ext_K; S.ext_x0 = (float)h->ext_x0; S.inv_total_mass = (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0);
     S.param = param; S.rep_lam = rep_lam; S.ext_atoms = h->d_ext_atoms; S.invmass = h->d_invmass; S.box = h->d_box;
@@ -1016,7 +1000,6 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
     prog.a = (float)exp(-h->gamma * hO); prog.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO)); prog.nO = nO > 0 ? nO : 1;
     prog.n_steps = n_steps; prog.cmm_frequency = h->cmm_frequency;
     prog.gstep0 = (long long)iteration * (long long)h->n_steps + first_step; prog.first_step = first_step;
-    prog.dbg = getenv("REMD_RESIDENT_DBG") ? atoi(getenv("REMD_RESIDENT_DBG")) : 0;
     remd_launch_join_wait(h);
     remd_prof_scope ps(h, "resident_md");
     if (alch) {
@@ -1035,17 +1018,11 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
 // Runs n_steps of the token program.  Tokens are grouped into chains that need no new
 // force evaluation; a 'V' after an 'R' forces a force evaluation first.
 //
-// One loop body = one MD step's launches (the chain(s) around the centre-of-mass removal, the force evaluation on two
-// streams, the step-counter tick).  From the third step on every body enqueues the same launches with the same
-// arguments -- what changes from step to step (the global step index in the noise counters, which momentum
-// accumulator is written / read) is read from two counters ON THE DEVICE -- so the body is captured once into a hipGraph
-// (stream capture across the fork / join of the two streams) and replayed with ONE launch per step; the steps on which
-// the atoms are re-sorted, the barostat fires or kernels are being timed run eagerly.  Results are bit-identical either
-// way (same kernels, same arguments, integer accumulation).  Opt-in with REMD_GRAPH=1 (see below: no gain measured).
-int remd_nb_resort_due(remd_ctx* h);
+// One loop body = one MD step's launches: the chain(s) around the centre-of-mass removal and the force evaluation on two streams.
+// (Round 2 also captured the body into a hipGraph and replayed it: bit-identical and no faster on ROCm 7.2 -- the floor of a step is
+// the dependent chain of kernels, not the host -- so the capture path was removed in round 3; DESIGN.md section 7b has the numbers.)
 void remd_launch_join_wait(remd_ctx* h);
 void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call);
-void remd_nb_note_evaluation(remd_ctx* h);
 
 int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
                    int64_t iteration, int64_t first_step, int n_steps)
@@ -1074,15 +1051,6 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     int cmm_w = 0;                     // accumulator the next momentum sum goes to
     bool zeroed_by_chain = false;
     const long long gstep0 = (long long)iteration * (long long)h->n_steps + first_step;
-    // ---- graph eligibility (opt-in: measured on ROCm 7.2 / MI355X a replayed step is no faster than its eager launches --
-    // the floor of a step is the dependent chain of kernels, not the host -- see DESIGN.md) ------------------------------
-    const bool graph_env = getenv("REMD_GRAPH") && atoi(getenv("REMD_GRAPH")) != 0;      // read per call: the parity test switches it
-    static const int prof_sample = getenv("REMD_GRAPH_PROF_BODIES") ? atoi(getenv("REMD_GRAPH_PROF_BODIES")) : 24;
-    const bool graph_ok = graph_env && h->profiling != 2 && h->baro_frequency == 0 && h->cmm_frequency <= 1 && n_steps >= 6 && !base.measure;
-    if (graph_ok) {
-        if (!h->d_ctr) REMD_CHECK(h, hipMalloc(&h->d_ctr, 2 * sizeof(long long)));
-        hipLaunchKernelGGL(ctr_set_kernel, dim3(1), dim3(1), 0, h->stream, h->d_ctr, gstep0, 0ll);
-    }
     // the centre-of-mass motion remover needs sum(m v) over the whole replica between two tokens of a step: either two launches
     // (the first ends with the sum) or one launch with a barrier over the replica's workgroups in device memory ('M' token) --
     // every workgroup of the grid must then be resident at once, hence the bound on the grid
@@ -1091,7 +1059,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     // (the same bound holds for the join polled in the chain's prologue: spinning workgroups of a grid larger than the chip
     // holds at once could keep the direct-space stream's last launches from ever being dispatched)
     const bool device_waits_ok = chain_blocks <= 1024 && !h->no_device_waits;
-    const bool merge_cmm = merge_env && !graph_ok && device_waits_ok && h->profiling != 2;
+    const bool merge_cmm = merge_env && device_waits_ok && h->profiling != 2;
     const long long sync_key = (long long)h->R * 1000003ll + ut.n_units;
     if (merge_cmm && (!h->d_chain_sync || h->chain_sync_key != sync_key)) {      // counters count arrivals of THIS grid shape
         if (h->d_chain_sync) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_chain_sync); h->d_chain_sync = nullptr; }
@@ -1100,22 +1068,17 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         REMD_CHECK(h, hipMemsetAsync(h->d_chain_sync, 0, sizeof(unsigned int) * h->R, h->stream));
         h->chain_sync_epoch = 0;
     }
-    int body = 0;                      // index of the loop body being enqueued (== ctr[1] when its kernels run)
     auto flush = [&](bool accumulate, bool bin_for_pme = false) {      // bin_for_pme: a force evaluation follows this launch directly
         if (cur.n == 0 && !accumulate) return;
         cur.accumulate_momentum = accumulate ? 1 : 0;
         cur.cmm_w = cmm_w;
-        cur.body_idx = body;
         // forces are stale after an R that follows the chain's last V: let the chain clear them (saves a memset)
         bool seenR = false, staleAtEnd = false;
         for (int t = 0; t < cur.n; ++t) { if (cur.tok[t] == 'R') seenR = true; if (cur.tok[t] == 'V') seenR = false; }
         staleAtEnd = seenR;
         cur.zero_force = staleAtEnd ? 1 : 0;
         if (staleAtEnd) zeroed_by_chain = true;
-        chain_prog out = cur;
-        out.use_ctr = graph_ok ? 1 : 0;
-        if (graph_ok) for (int t = 0; t < out.n; ++t) out.step[t] -= gstep0 + body;    // absolute step -> relative to this body's counter
-        launch_chain(h, ut, out, bin_for_pme);
+        launch_chain(h, ut, cur, bin_for_pme);
         cur = base; cur.n = 0;
     };
     auto push = [&](char tok, int oidx, long long step) {
@@ -1190,52 +1153,11 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                 if (shadow) { int rc = evaluate_with_energy(true); if (rc) return rc; }
             }
         }
-        if (graph_ok) hipLaunchKernelGGL(ctr_tick_kernel, dim3(1), dim3(1), 0, h->stream, h->d_ctr);
         return 0;
     };
-    const int first_graph_body = 2 + (h->profiling == 1 ? prof_sample : 0);   // timed launches (HIP events) are sampled eagerly
-    std::string key(tokens.begin(), tokens.end());
-    key += "|" + std::to_string(h->graph_epoch) + "|" + std::to_string(h->R) + "|" + std::to_string((long long)(uintptr_t)h->stream);
-    struct snap { std::string tok; bool fz, fv, zc; int cmm_w; };
-    auto take = [&]() { return snap{std::string(cur.tok, cur.tok + cur.n), h->force_zeroed, h->forces_valid, zeroed_by_chain, cmm_w}; };
-    for (int s = 0; s < n_steps; ++s, ++body) {
-        bool done = false;
-        if (graph_ok && s >= first_graph_body && !remd_nb_resort_due(h)) {
-            remd_launch_join_wait(h);          // an eager body's deferred join: the graph's first chain does not poll for it
-            if (h->step_graph_exec && h->step_graph_key == key) {
-                // replay: one launch; then advance the host-side state exactly as the captured body did
-                REMD_CHECK(h, hipGraphLaunch(h->step_graph_exec, h->stream));
-                for (int t = 0; t < cur.n; ++t) cur.step[t] += 1;
-                if (h->cmm_frequency > 0) cmm_w = 1 - cmm_w;
-                remd_nb_note_evaluation(h);
-                done = true;
-            } else if (h->step_graph_key != key + "!") {
-                const snap before = take();
-                if (h->step_graph_exec) { hipGraphExecDestroy(h->step_graph_exec); h->step_graph_exec = nullptr; }
-                if (h->step_graph) { hipGraphDestroy(h->step_graph); h->step_graph = nullptr; }
-                REMD_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-                h->capturing = true;                 // cross-stream dependencies as events: capture follows them into the second stream
-                const int rc = run_body(s);
-                h->capturing = false;
-                hipGraph_t g = nullptr;
-                const hipError_t e = hipStreamEndCapture(h->stream, &g);
-                if (rc) { if (g) hipGraphDestroy(g); return rc; }
-                if (e != hipSuccess || !g) return remd_fail(h, -2, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-                h->step_graph = g;
-                REMD_CHECK(h, hipGraphInstantiate(&h->step_graph_exec, g, nullptr, nullptr, 0));
-                REMD_CHECK(h, hipGraphLaunch(h->step_graph_exec, h->stream));      // capture recorded the body, this runs it
-                const snap after = take();
-                // reusable only if the body left the host-side state as it found it (steady state of the step program)
-                const bool steady = before.tok == after.tok && before.fz == after.fz && before.fv == after.fv && before.zc == after.zc &&
-                                    (h->cmm_frequency > 0 ? after.cmm_w == 1 - before.cmm_w : after.cmm_w == before.cmm_w);
-                h->step_graph_key = steady ? key : key + "!";                      // "!": do not try again for this program
-                done = true;
-            }
-        }
-        if (!done) {
-            if (!graph_ok) remd_nb_tune_step(h, n_steps - s);
-            int rc = run_body(s); if (rc) return rc;
-        }
+    for (int s = 0; s < n_steps; ++s) {
+        remd_nb_tune_step(h, n_steps - s);
+        int rc = run_body(s); if (rc) return rc;
     }
     flush(false);
     remd_launch_join_wait(h);
@@ -1244,13 +1166,6 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     return 0;
 }
 
-void remd_free_step_graph(remd_ctx* h)
-{
-    if (h->step_graph_exec) { hipGraphExecDestroy(h->step_graph_exec); h->step_graph_exec = nullptr; }
-    if (h->step_graph) { hipGraphDestroy(h->step_graph); h->step_graph = nullptr; }
-    h->step_graph_key.clear();
-    if (h->d_ctr) { hipFree(h->d_ctr); h->d_ctr = nullptr; }
-}
 
 int remd_assign_velocities(remd_ctx* h, int64_t iteration)
 {

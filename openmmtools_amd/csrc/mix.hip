@@ -310,11 +310,11 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         size_t ukl_bytes = (size_t)R * K * sizeof(double);
         if (R > 32767) return remd_fail(h, -3, "swap-all supports at most 32767 replicas");
         // window = 6R attempts (conflict probability between two attempts ~4/R), whole wavefronts, <= 768 threads (measured optimum)
-        static int force_waves = getenv("REMD_MIX_WAVES") ? atoi(getenv("REMD_MIX_WAVES")) : 0;
+        const int force_waves = 0;
         int waves = force_waves > 0 ? force_waves : (4 * R + 63) / 64;
         waves = std::max(1, std::min(16, waves));
-        static int per_r = getenv("REMD_MIX_WINDOW") ? std::max(1, atoi(getenv("REMD_MIX_WINDOW"))) : 6;
-        static int max_waves = getenv("REMD_MIX_MAXWAVES") ? std::max(1, std::min(16, atoi(getenv("REMD_MIX_MAXWAVES")))) : 12;
+        const int per_r = 6;                    // window of 6 R attempts (21.9 ms at R = 128: DESIGN.md 7b)
+        const int max_waves = 12;
         if (force_waves <= 0) waves = std::max(1, std::min(max_waves, (per_r * R + 63) / 64));
         while (waves > 1 && (size_t)R * waves * 8 > 64 * 1024) --waves;      // occupancy masks [R][waves] u64
         const size_t Rp = (size_t)((R + 1) & ~1);
@@ -339,7 +339,7 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         static const bool debug = getenv("REMD_MIX_DEBUG") != nullptr;
         if (debug && !d_dbg) REMD_CHECK(h, hipMalloc(&d_dbg, 8 * sizeof(long long)));
         unsigned int* d_log = nullptr;
-        static const bool use_log = !(getenv("REMD_MIX_LOG") && atoi(getenv("REMD_MIX_LOG")) == 0);
+        const bool use_log = true;              // counters beyond the LDS: attempt log instead of global atomics
         if (!stats_lds && use_log && (size_t)n_attempts * sizeof(unsigned int) <= ((size_t)1 << 30)) {
             if (h->mix_log_n < (size_t)n_attempts) {
                 if (h->d_mix_log) { hipFree(h->d_mix_log); h->d_mix_log = nullptr; h->mix_log_n = 0; }

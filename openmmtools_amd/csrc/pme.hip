@@ -22,17 +22,13 @@
 #define FFT_T 32
 #define PME_FIXED_SCALE 68719476736.0      // 2^36
 
-struct fft_sched { const uint2* tab; int off[8]; int wave_local; };   // see fft_stage_sched
-
-int remd_dftmm_build_table(remd_ctx* h, int n, void** d_table);
-void remd_dftmm_launch_xy(hipStream_t st, int n, int nplanes, int nzc, int nz, float2* spec, const void* table, const float* infl,
-                          const float* gbound, int with_energy, double* energy, int n_eblk, int mode, long long* tdbg = nullptr);
+struct fft_sched { const uint2* tab; int off[8]; };   // see fft_stage_sched
 
 struct pme_state {
     int n[4] = {0, 0, 0, 0};           // mesh dimensions; n[3] = nz / 2 (length of the packed real-to-complex z transform)
     int R = 0;
     size_t npts = 0;
-    int* d_mesh = nullptr;             // [R][nx][ny][nz] 32-bit fixed-point charge mesh; reused as the float potential mesh
+    bool ready = false;                // buffers of the force path are allocated (not the FFT test hook's)
     float2* d_grid = nullptr;          // [R][nz/2+1][nx][ny] half spectrum, kz-major (or the full complex grid of the test hook)
     hipStream_t stream = nullptr;      // stream of the current remd_pme_forces call
     int nzc = 0; size_t nspec = 0; size_t xy_lds = 0; bool xy_fused = false; int xy_threads = 512;
@@ -41,7 +37,6 @@ struct pme_state {
     float* d_bmod[3] = {nullptr, nullptr, nullptr};  // |b(m)|^-2 ... stored as B-spline moduli squared inverse
     int nrad[4] = {0, 0, 0, 0}; int radix[4][8];
     int xs_sw = 0;                      // y-slab width of pme_x_fused_kernel (planes that do not fit the LDS)
-    float* d_gmax = nullptr;           // [R][nz/2+1] largest influence value of a plane (a-priori scale of the matrix-core XY pass)
     float* d_infl = nullptr; int infl_version = -1;   // influence function [R][nz/2+1][nx][ny], rebuilt when a box changes
     bool z_half = false;               // nz even: z transforms run as nz/2-point complex FFTs of packed real pairs
     double* d_energy = nullptr;        // [R][n_eblk]
@@ -53,8 +48,6 @@ struct pme_state {
     // evaluation parity (the spreading pass zeroes the other one), atoms[R][nx][cbin_cap]; cbin_use: this evaluation reads them
     float* d_cbin_q = nullptr;
     int* d_cbin_count = nullptr; float4* d_cbin_atoms = nullptr; int cbin_cap = 0, cbin_parity = 0; bool cbin_use = false;
-    void* d_dftmm = nullptr; bool xy_mfma = false;    // matrix-core XY pass (dft_mfma.hip): LDS image of the DFT matrix
-    bool gather_fused = false;         // the inverse z launch already added the forces (pme_zinv_gather_kernel)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -163,9 +156,7 @@ template <int SIGN, int RX> __device__ __forceinline__ void bfly(float2* v)
 // (stage s, slot b, thread t) at tab[off[s] + b * nthreads + t]: x = first input element | first output element << 16
 // (0xffffffff: idle), y = twiddle step.
 
-// WL (wave-local schedule): every wavefront owns whole lines, so the read -> write hand-over of a stage only involves
-// its own lanes — LDS operations of one wavefront retire in order — and no workgroup barrier is needed inside a pass.
-template <int SIGN, int RX, int PPT, bool WL>
+template <int SIGN, int RX, int PPT>
 __device__ __forceinline__ void fft_stage_sched(float2* buf, const uint2* __restrict__ tab, int in_stride, int out_stride,
                                                 bool twiddle, const float2* __restrict__ tw, int tid, int nthreads)
 {
@@ -194,45 +185,31 @@ __device__ __forceinline__ void fft_stage_sched(float2* buf, const uint2* __rest
             dst[b] = (int)(e[b].x >> 16);
         }
     }
-    if (WL) __builtin_amdgcn_wave_barrier(); else __syncthreads();      // every input of this stage is in registers
+    __syncthreads();                                    // every input of this stage is in registers
 #pragma unroll
     for (int b = 0; b < NB; ++b) if (dst[b] >= 0) {
 #pragma unroll
         for (int r = 0; r < RX; ++r) buf[dst[b] + r * out_stride] = v[b][r];
     }
-    if (WL) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-}
-
-// in-place FFT of nlines lines (element e of line l at buf[l*ls + e*es]); every thread keeps its share of the points in
-// registers across the barrier, so only ONE LDS image of the data is needed
-template <int SIGN, int PPT, bool WL>
-__device__ __forceinline__ void fft_lines_stages(const fft_plan& pl, const fft_sched& sc, float2* buf, int es,
-                                                 const float2* __restrict__ tw, int tid, int nthreads)
-{
-    int Ns = 1;
-    for (int s = 0; s < pl.nrad; ++s) {
-        const int Rx = pl.radix[s];
-        const int in_stride = (pl.n / Rx) * es, out_stride = Ns * es;
-        const uint2* tab = sc.tab + sc.off[s];
-        if (Rx == 4) fft_stage_sched<SIGN, 4, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
-        else if (Rx == 5) fft_stage_sched<SIGN, 5, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
-        else if (Rx == 3) fft_stage_sched<SIGN, 3, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
-        else fft_stage_sched<SIGN, 2, PPT, WL>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
-        Ns *= Rx;
-    }
+    __syncthreads();
 }
 
 // in-place FFT of nlines lines (element e of line l at buf[l*ls + e*es]); every thread keeps its share of the points in
 // registers across the barrier, so only ONE LDS image of the data is needed
 template <int SIGN, int PPT>
 __device__ __forceinline__ void fft_lines_inplace(const fft_plan& pl, const fft_sched& sc, float2* buf, int es,
-                                  const float2* __restrict__ tw, int tid, int nthreads)
+                                                  const float2* __restrict__ tw, int tid, int nthreads)
 {
-    if (sc.wave_local) {
-        fft_lines_stages<SIGN, PPT, true>(pl, sc, buf, es, tw, tid, nthreads);
-        __syncthreads();                                     // the next pass regroups the lines
-    } else {
-        fft_lines_stages<SIGN, PPT, false>(pl, sc, buf, es, tw, tid, nthreads);
+    int Ns = 1;
+    for (int s = 0; s < pl.nrad; ++s) {
+        const int Rx = pl.radix[s];
+        const int in_stride = (pl.n / Rx) * es, out_stride = Ns * es;
+        const uint2* tab = sc.tab + sc.off[s];
+        if (Rx == 4) fft_stage_sched<SIGN, 4, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else if (Rx == 5) fft_stage_sched<SIGN, 5, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else if (Rx == 3) fft_stage_sched<SIGN, 3, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else fft_stage_sched<SIGN, 2, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        Ns *= Rx;
     }
 }
 
@@ -476,71 +453,6 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
     }
 }
 
-// inverse z: half spectrum -> nl real lines (Hermitian completion in LDS), written as float mesh[x][y][z]
-// HALF: Z'[k] = (X[k] + conj X[M-k]) + i conj(W^k) (X[k] - conj X[M-k]), k < M = nz/2; the M-point inverse FFT of Z'
-// holds the real line as pairs (x[2n], x[2n+1]).
-template <int Z_THREADS, bool HALF>
-__global__ __launch_bounds__(Z_THREADS)
-void pme_zinv_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, const float2* __restrict__ spec, float* __restrict__ mesh,
-                     const float2* tw, const float2* tw_half)
-{
-    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int M = pl.n;
-    const int nz = HALF ? 2 * M : M, nzc = nz / 2 + 1, PZ = HALF ? ((M + 1) | 1) : (nz | 1);
-    float2* buf = reinterpret_cast<float2*>(smem);
-    float2* s_tw = buf + nl * PZ;
-    float2* s_twh = s_tw + nz;
-    const int r = blockIdx.y, tid = threadIdx.x;
-    // a mesh row x is covered by ceil(ny / nl) workgroups of nl lines (the last one may hang over the end of the row)
-    const int nbpr = (ny + nl - 1) / nl;
-    const int x = blockIdx.x / nbpr, y0 = (blockIdx.x - x * nbpr) * nl;
-    const int l0 = x * ny + y0;
-    for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
-    if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
-    const float2* S = spec + (size_t)r * nzc * nx * ny;
-    const unsigned mnl = fft_magic((unsigned)nl);
-    for (int idx = tid; idx < nl * nzc; idx += Z_THREADS) {
-        const int kz = fft_div(idx, mnl, nl), b = idx - kz * nl;
-        const float2 v = (y0 + b < ny) ? S[((size_t)kz * nx + x) * ny + y0 + b] : make_float2(0.f, 0.f);
-        buf[b * PZ + kz] = v;                                 // HALF: slot M = nz/2 exists (PZ >= M + 1)
-        if (!HALF && kz > 0 && kz < nz - kz) buf[b * PZ + nz - kz] = make_float2(v.x, -v.y);
-    }
-    __syncthreads();
-    if (HALF) {
-        // in place: the pair (k, M - k) is owned by one thread
-        for (int idx = tid; idx < nl * (M / 2 + 1); idx += Z_THREADS) {
-            const int k = fft_div(idx, mnl, nl), b = idx - k * nl;
-            const float2 Xk = buf[b * PZ + k], Xm = buf[b * PZ + M - k];
-            const float2 A = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);              // X[k] + conj X[M-k]
-            const float2 B = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);              // X[k] - conj X[M-k]
-            const float2 w = s_tw[k];                                             // W^k
-            const float2 t = cmul(make_float2(w.x, -w.y), B);                     // conj(W^k) B
-            buf[b * PZ + k] = make_float2(A.x - t.y, A.y + t.x);                  // A + i t
-            if (k != 0 && k != M - k) {
-                const float2 u = cmul(w, make_float2(B.x, -B.y));                 // W^k conj(B)
-                buf[b * PZ + M - k] = make_float2(A.x - u.y, -A.y + u.x);         // conj(A) + i u
-            }
-        }
-        __syncthreads();
-    }
-    fft_lines_inplace<+1, Z_PPT>(pl, sc, buf, 1, HALF ? s_twh : s_tw, tid, Z_THREADS);
-    float* Mesh = mesh + (size_t)r * nx * ny * nz + (size_t)l0 * nz;
-    const unsigned mM = fft_magic((unsigned)M);
-    if (HALF) {
-        float2* M2 = reinterpret_cast<float2*>(Mesh);          // nz even: the line start is 8-byte aligned
-        for (int idx = tid; idx < nl * M; idx += Z_THREADS) {
-            const int l = fft_div(idx, mM, M);
-            M2[idx] = buf[idx + l * (PZ - M)];                 // (x[2n], x[2n+1])
-        }
-    } else {
-        for (int idx = tid; idx < nl * nz; idx += Z_THREADS) {
-            const int l = fft_div(idx, mM, M);
-            Mesh[idx] = buf[idx + l * (PZ - nz)].x;
-        }
-    }
-}
-
 // inverse z + force gather in one launch.  After the inverse z transforms a workgroup holds the real potential of its mesh
 // row(s) x in LDS; the atoms whose 5-point x stencil touches that row are exactly the ones of bins kx = x .. x+4 (the
 // candidates of the spreading pass), so each of them takes ITS SHARE of the force from this row here -- 25 LDS reads --
@@ -649,11 +561,8 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
 // recomputed (~45 VALU instructions per mesh point incl. an IEEE division and an exp) in every XY pass.
 __global__ __launch_bounds__(256)
 void pme_influence_table_kernel(int nx, int ny, int nz, const float* __restrict__ bmx, const float* __restrict__ bmy,
-                                const float* __restrict__ bmz, const float* __restrict__ box, float alpha, float* __restrict__ infl,
-                                float* __restrict__ gmax /* [R][nzc] largest value of each plane, or NULL */)
+                                const float* __restrict__ bmz, const float* __restrict__ box, float alpha, float* __restrict__ infl)
 {
-    __shared__ float s_gm[4];
-    float gm = 0.f;
     const int kz = blockIdx.x, r = blockIdx.y, nzc = nz / 2 + 1, np = nx * ny;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const double V = (double)Lx * Ly * Lz;
@@ -670,13 +579,6 @@ void pme_influence_table_kernel(int nx, int ny, int nz, const float* __restrict_
         float g = 0.f;
         if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
         G[idx] = g;
-        gm = fmaxf(gm, g);
-    }
-    if (gmax) {
-        for (int off = 32; off > 0; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off));
-        if ((threadIdx.x & 63) == 0) s_gm[threadIdx.x >> 6] = gm;
-        __syncthreads();
-        if (threadIdx.x == 0) gmax[(size_t)r * nzc + kz] = fmaxf(fmaxf(s_gm[0], s_gm[1]), fmaxf(s_gm[2], s_gm[3]));
     }
 }
 
@@ -833,59 +735,6 @@ void fft_pass_kernel(fft_plan pl, float2* __restrict__ grid, size_t rep_stride, 
     }
 }
 
-__global__ __launch_bounds__(128)
-void pme_gather_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __restrict__ pos,
-                       const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                       const float* __restrict__ mesh, long long* __restrict__ force, const int* __restrict__ col_atoms)
-{
-    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (t >= N) return;
-    // atoms in the order of the spreading bins (sorted by mesh column kx): the lanes of a wavefront then read the same
-    // one or two x slabs of the potential mesh (21.6 KB each), which stay in L1 instead of being re-fetched from L2
-    const int i = col_atoms[(size_t)r * Npad + t];
-    const float4 pr = param[i];
-    float q = pr.x;
-    if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
-    if (q == 0.f) return;
-    const float4 x = pos[(size_t)r * Npad + i];
-    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-    float fx = x.x / Lx, fy = x.y / Ly, fz = x.z / Lz;
-    fx -= floorf(fx); fy -= floorf(fy); fz -= floorf(fz);
-    float ux = fx * nx, uy = fy * ny, uz = fz * nz;
-    int kx = (int)ux, ky = (int)uy, kz = (int)uz;
-    float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
-    bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
-    if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
-    const float* M = mesh + (size_t)r * nx * ny * nz;
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll
-    for (int a = 0; a < 5; ++a) {
-        int ix = kx - a; if (ix < 0) ix += nx;
-#pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            int iy = ky - b; if (iy < 0) iy += ny;
-            const size_t row = ((size_t)ix * ny + iy) * nz;
-            float sx = 0.f, sz = 0.f;
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                int iz = kz - c; if (iz < 0) iz += nz;
-                const float phi = M[row + iz];
-                sx += wz[c] * phi; sz += dz[c] * phi;
-            }
-            gx += dx[a] * wy[b] * sx; gy += wx[a] * dy[b] * sx; gz += wx[a] * wy[b] * sz;
-        }
-    }
-    // dE/dx = q * dtheta/du * du/dx, du/dx = n / L
-    const float Fx = -q * gx * nx / Lx, Fy = -q * gy * ny / Ly, Fz = -q * gz * nz / Lz;
-    // integer atomics: the direct-space kernels add to the same accumulators concurrently on another stream
-    unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
-    atomicAdd(&F[i], remd_f2fix(Fx));
-    atomicAdd(&F[Npad + i], remd_f2fix(Fy));
-    atomicAdd(&F[2 * Npad + i], remd_f2fix(Fz));
-}
-
 // fall-back influence-function pass for meshes whose (x,y) plane does not fit the LDS
 __global__ __launch_bounds__(256)
 void pme_influence_kernel(int nx, int ny, int nz, float2* __restrict__ spec, const float* __restrict__ bmx,
@@ -953,16 +802,13 @@ int remd_pme_destroy(remd_ctx* h)
     pme_state* s = (pme_state*)h->pme;
     if (!s) return 0;
     if (s->d_grid) hipFree(s->d_grid);
-    if (s->d_mesh) hipFree(s->d_mesh);
     if (s->d_col_count) hipFree(s->d_col_count); if (s->d_col_start) hipFree(s->d_col_start); if (s->d_cursor) hipFree(s->d_cursor);
     if (s->d_atom_col) hipFree(s->d_atom_col); if (s->d_col_atoms) hipFree(s->d_col_atoms);
     for (int k = 0; k < 4; ++k) if (s->d_tw[k]) hipFree(s->d_tw[k]);
     for (int k = 0; k < 3; ++k) if (s->d_bmod[k]) hipFree(s->d_bmod[k]);
     if (s->d_energy) hipFree(s->d_energy);
     if (s->d_infl) hipFree(s->d_infl);
-    if (s->d_dftmm) hipFree(s->d_dftmm);
     if (s->d_cbin_count) hipFree(s->d_cbin_count); if (s->d_cbin_atoms) hipFree(s->d_cbin_atoms); if (s->d_cbin_q) hipFree(s->d_cbin_q);
-    if (s->d_gmax) hipFree(s->d_gmax);
     for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
     delete s;
     h->pme = nullptr;
@@ -984,55 +830,29 @@ static fft_plan make_plan(pme_state* s, int axis)
 // host mirror of the index arithmetic of one in-place pass (element e of line l at l*ls + e*es, consecutive threads
 // take consecutive lines): fills the butterfly schedule read by fft_stage_sched
 static int build_sched(remd_ctx* h, pme_state* s, int axis, int nlines, int ls, int es, int nthreads, int ppt,
-                       fft_sched* out, uint2** d_tab, bool want_wave_local = false)
+                       fft_sched* out, uint2** d_tab)
 {
     const int n = s->n[axis];
-    const int nwaves = nthreads / 64;
-    // wave-local mapping: wavefront w owns the contiguous lines [w, w+1) * lines_per_wave; feasible when every wavefront's butterflies fit its slots
-    bool wl = want_wave_local && nwaves >= 1 && getenv("REMD_PME_WAVELOCAL") && atoi(getenv("REMD_PME_WAVELOCAL")) != 0;
-    const int lines_per_wave = (nlines + nwaves - 1) / nwaves;
-    for (int st = 0; st < s->nrad[axis] && wl; ++st) {
-        const int Rx = s->radix[axis][st];
-        if ((long long)lines_per_wave * (n / Rx) > (long long)((ppt + Rx - 1) / Rx) * 64) wl = false;
-    }
-    out->wave_local = wl ? 1 : 0;
     std::vector<uint2> tab;
     int Ns = 1;
     for (int st = 0; st < s->nrad[axis]; ++st) {
         const int Rx = s->radix[axis][st];
         const int NB = (ppt + Rx - 1) / Rx;
         const int nb = n / Rx, total = nlines * nb, tstride = n / (Ns * Rx);
-        if (!wl && (long long)NB * nthreads < total) return remd_fail(h, -3, "PME FFT pass does not fit the workgroup registers");
+        if ((long long)NB * nthreads < total) return remd_fail(h, -3, "PME FFT pass does not fit the workgroup registers");
         out->off[st] = (int)tab.size();
         const size_t base = tab.size();
         tab.resize(base + (size_t)NB * nthreads, make_uint2(0xffffffffu, 0u));
-        auto entry = [&](int l, int j) {
-            const int jq = j / Ns, k = j % Ns;
-            const int src = l * ls + j * es, dst = l * ls + (jq * Ns * Rx + k) * es;
-            return make_uint2((unsigned)src | ((unsigned)dst << 16), (unsigned)(k * tstride));
-        };
         if ((nlines - 1) * ls + (n - 1) * es > 0xffff) return remd_fail(h, -3, "PME plane too large for the FFT schedule");
-        if (wl) {
-            for (int w = 0; w < nwaves; ++w) {
-                std::vector<int> mine;
-                for (int l = w * lines_per_wave; l < std::min(nlines, (w + 1) * lines_per_wave); ++l) mine.push_back(l);
-                const int cnt = (int)mine.size() * nb;
-                if (mine.empty()) continue;
-                for (int k = 0; k < cnt; ++k) {
-                    // consecutive lanes walk the unit-stride direction: lines when ls == 1, butterflies when es == 1
-                    int l, j;
-                    if (ls == 1) { j = k / (int)mine.size(); l = mine[k % mine.size()]; }
-                    else { l = mine[k / nb]; j = k % nb; }
-                    tab[base + (size_t)(k / 64) * nthreads + w * 64 + (k % 64)] = entry(l, j);
-                }
+        for (int b = 0; b < NB; ++b)
+            for (int t = 0; t < nthreads; ++t) {
+                const int idx = t + b * nthreads;
+                if (idx >= total) continue;
+                const int l = idx % nlines, j = idx / nlines;           // consecutive threads take consecutive lines
+                const int jq = j / Ns, k = j % Ns;
+                const int src = l * ls + j * es, dst = l * ls + (jq * Ns * Rx + k) * es;
+                tab[base + (size_t)b * nthreads + t] = make_uint2((unsigned)src | ((unsigned)dst << 16), (unsigned)(k * tstride));
             }
-        } else {
-            for (int b = 0; b < NB; ++b)
-                for (int t = 0; t < nthreads; ++t) {
-                    const int idx = t + b * nthreads;
-                    if (idx < total) tab[base + (size_t)b * nthreads + t] = entry(idx % nlines, idx / nlines);
-                }
-        }
         Ns *= Rx;
     }
     if (*d_tab) { hipFree(*d_tab); *d_tab = nullptr; }
@@ -1055,7 +875,7 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     }
     s->n[3] = s->n[2] / 2;
     s->z_half = (s->n[2] % 2 == 0) && s->n[3] >= 3 && factorize(s->n[3], s->radix[3], s->nrad[3]) &&
-                !(getenv("REMD_PME_ZHALF") && atoi(getenv("REMD_PME_ZHALF")) == 0);
+                true;
     s->R = h->R;
     s->npts = (size_t)s->n[0] * s->n[1] * s->n[2];
     s->nzc = s->n[2] / 2 + 1;
@@ -1063,7 +883,7 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     if (full_complex) {
         REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->npts * s->R));
     } else {
-        REMD_CHECK(h, hipMalloc(&s->d_mesh, sizeof(int) * s->npts * s->R));
+        s->ready = true;
         REMD_CHECK(h, hipMalloc(&s->d_grid, sizeof(float2) * s->nspec * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_start, sizeof(int) * (size_t)(s->n[0] + 1) * s->R));
         REMD_CHECK(h, hipMalloc(&s->d_col_atoms, sizeof(int) * (size_t)h->Npad * s->R));
@@ -1115,30 +935,22 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     {
         const long long np = (long long)s->n[0] * s->n[1];
         long long best_cost = -1; int best_t = 1024;
-        // REMD_PME_WAVELOCAL=1: standalone XY pass 64 -> 60 us (24 x alanine), but no end-to-end gain next to the pair kernels: default off
-        const bool try_wl = getenv("REMD_PME_WAVELOCAL") && atoi(getenv("REMD_PME_WAVELOCAL")) != 0;
-        for (int pass = try_wl ? 0 : 1; pass < 2 && best_cost < 0; ++pass)       // pass 0: wave-local schedules, 1: global
-            // multiples of 256 threads only: the dispatcher reserves ceil(waves / 4) wave slots on EVERY SIMD for a workgroup
-            // (tools/probes/occupancy_probe.hip), so a 6-wavefront workgroup occupies the slots of 8; next to the pair kernel's
-            // resident workgroups 512 threads beat the 384 that waste the fewest butterfly slots (108.3 vs 110.2 ms per 500 steps)
-            for (int t = 256; t <= 1024; t += 256) {
-                if (np > (long long)XY_PPT * t) continue;
-                long long cost = 0; bool ok = true;
-                for (int ax = 0; ax < 2 && ok; ++ax)
-                    for (int st = 0; st < s->nrad[ax]; ++st) {
-                        const int rx = s->radix[ax][st];
-                        long long slots;
-                        if (pass == 0) {
-                            const long long lpw = (s->n[1 - ax] + t / 64 - 1) / (t / 64);     // lines of the busiest wavefront
-                            slots = (lpw * (s->n[ax] / rx) + 63) / 64;
-                        } else slots = (np / rx + t - 1) / t;
-                        if (slots > (XY_PPT + rx - 1) / rx) ok = false;
-                        cost += slots * t * rx;                    // issued lane-points of this stage
-                    }
-                if (ok && (best_cost < 0 || cost < best_cost)) { best_cost = cost; best_t = t; }
-            }
+        // multiples of 256 threads only: the dispatcher reserves ceil(waves / 4) wave slots on EVERY SIMD for a workgroup
+        // (tools/probes/occupancy_probe.hip), so a 6-wavefront workgroup occupies the slots of 8; next to the pair kernel's
+        // resident workgroups 512 threads beat the 384 that waste the fewest butterfly slots (108.3 vs 110.2 ms per 500 steps)
+        for (int t = 256; t <= 1024; t += 256) {
+            if (np > (long long)XY_PPT * t) continue;
+            long long cost = 0; bool ok = true;
+            for (int ax = 0; ax < 2 && ok; ++ax)
+                for (int st = 0; st < s->nrad[ax]; ++st) {
+                    const int rx = s->radix[ax][st];
+                    const long long slots = (np / rx + t - 1) / t;
+                    if (slots > (XY_PPT + rx - 1) / rx) ok = false;
+                    cost += slots * t * rx;                    // issued lane-points of this stage
+                }
+            if (ok && (best_cost < 0 || cost < best_cost)) { best_cost = cost; best_t = t; }
+        }
         s->xy_threads = best_t;
-        if (getenv("REMD_PME_XYT")) s->xy_threads = std::max(256, std::min(1024, atoi(getenv("REMD_PME_XYT"))));
     }
     s->xy_fused = (size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * s->xy_threads && s->xy_lds <= 160 * 1024;
     if (!s->xy_fused && !full_complex) {
@@ -1154,22 +966,16 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
             REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_x_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         }
     }
-    // square planes up to 80 x 80: the XY pass as matrix products on the MFMA pipes (dft_mfma.hip), REMD_PME_XY_MFMA=1.
-    // Opt-in: parity-green and as accurate as the FFT, but 89 us stand-alone against the FFT kernel's 67 (its 154 KB of LDS
-    // allow one workgroup per CU, so the 80 MB of plane traffic are not overlapped with the products)
-    s->xy_mfma = !full_complex && s->n[0] == s->n[1] && s->n[0] <= 80 && s->xy_fused
-                 && getenv("REMD_PME_XY_MFMA") && atoi(getenv("REMD_PME_XY_MFMA")) != 0;
-    if (s->xy_mfma) { int rc = remd_dftmm_build_table(h, s->n[0], &s->d_dftmm); if (rc) return rc; }
     if (s->xy_fused && !full_complex) {
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
         const int PS = s->n[1] | 1;
-        int rc = build_sched(h, s, 1, s->n[0], PS, 1, s->xy_threads, XY_PPT, &s->sch_y, &s->d_sched[1], true);      // along y: lines = x rows
-        if (!rc) rc = build_sched(h, s, 0, s->n[1], 1, PS, s->xy_threads, XY_PPT, &s->sch_x, &s->d_sched[0], true);  // along x: lines = y columns
+        int rc = build_sched(h, s, 1, s->n[0], PS, 1, s->xy_threads, XY_PPT, &s->sch_y, &s->d_sched[1]);      // along y: lines = x rows
+        if (!rc) rc = build_sched(h, s, 0, s->n[1], 1, PS, s->xy_threads, XY_PPT, &s->sch_x, &s->d_sched[0]);  // along x: lines = y columns
         if (rc) return rc;
     }
 #define Z_LDS_ATTR(ZT, HF) \
     REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_spread_zfwd_kernel<ZT, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_kernel<ZT, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_zinv_gather_kernel<ZT, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     Z_LDS_ATTR(512, false) Z_LDS_ATTR(256, false) Z_LDS_ATTR(512, true) Z_LDS_ATTR(256, true)
 #undef Z_LDS_ATTR
     // the fills above ran on the null stream; the handle's stream is non-blocking and does not wait for it
@@ -1196,14 +1002,14 @@ const float4* remd_nb_param(remd_ctx* h);
 int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
 {
     pme_state* s = (pme_state*)h->pme;
-    if (!s || s->R != h->R || !s->d_mesh) { int rc = remd_pme_setup(h); if (rc) return rc; s = (pme_state*)h->pme; }
+    if (!s || s->R != h->R || !s->ready) { int rc = remd_pme_setup(h); if (rc) return rc; s = (pme_state*)h->pme; }
     s->stream = st;
     const int nx = s->n[0], ny = s->n[1], nz = s->n[2];
     const float* rep_lam = remd_nb_rep_lam(h);
     const float4* param = remd_nb_param(h);
     if (part & 1) {
     // bins from the integrator chain (h->cbins_ready: the chain launched just before this evaluation filled buffer cbin_parity)
-    s->cbin_use = h->cbins_ready && s->d_cbin_count && !(getenv("REMD_PME_FUSEGATHER") && atoi(getenv("REMD_PME_FUSEGATHER")) == 0);
+    s->cbin_use = h->cbins_ready && s->d_cbin_count;
     h->cbins_ready = false;
     if (!s->cbin_use)
     {
@@ -1215,19 +1021,14 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
     {
         remd_prof_scope ps(h, "pme_fft", st);
         // lines per workgroup: a divisor of ny whose points fit the registers of the workgroup
-        static const int zt_env = getenv("REMD_PME_ZT") ? atoi(getenv("REMD_PME_ZT")) : 0;
-        static const int nl_cap = getenv("REMD_PME_NL") ? atoi(getenv("REMD_PME_NL")) : 1 << 30;
         const bool half = s->z_half;
         const int zaxis = half ? 3 : 2;                  // the transform that is run: nz/2 packed points or nz points
         const int M = s->n[zaxis], PZ = half ? ((M + 1) | 1) : (nz | 1);
         // 256 threads when a whole mesh row still fits their registers (fuller butterfly slots, 8 workgroups per CU;
         // measured 6.75 -> 6.95 it/s on the 75 x 75 x 72 mesh), else 512
-        const int ZT = zt_env == 256 ? 256 : zt_env == 512 ? 512 : ((long long)ny * M <= (long long)Z_PPT * 256 ? 256 : 512);
+        const int ZT = (long long)ny * M <= (long long)Z_PPT * 256 ? 256 : 512;
         int nl = 1;
-        for (int c = 1; c <= ny && c <= nl_cap; ++c) if (ny % c == 0 && c * M <= Z_PPT * ZT) nl = c;
-        // REMD_PME_NLX: any number of lines per workgroup (the last workgroup of a row hangs over its end); fused gather path only
-        static const int nlx = getenv("REMD_PME_NLX") ? atoi(getenv("REMD_PME_NLX")) : 0;
-        if (nlx > 0 && nlx * M <= Z_PPT * ZT && nlx <= ny) nl = nlx;
+        for (int c = 1; c <= ny; ++c) if (ny % c == 0 && c * M <= Z_PPT * ZT) nl = c;
         const size_t zlds = sizeof(float2) * ((size_t)nl * PZ + nz + (half ? M : 0));
         const dim3 zgrid(nx * ((ny + nl - 1) / nl), s->R);
         if (s->sch_nl != nl || s->sch_zt != ZT) {
@@ -1251,18 +1052,13 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
                    s->d_tw[2], s->d_tw[3], bin_cap, bin_zero, fflag, fseq, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr);
         if (s->xy_fused || s->xs_sw > 0) {
             if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
-            if (!s->d_gmax) REMD_CHECK(h, hipMalloc(&s->d_gmax, sizeof(float) * s->nzc * s->R));
             if (s->infl_version != h->box_version) {
                 hipLaunchKernelGGL(pme_influence_table_kernel, dim3(s->nzc, s->R), dim3(256), 0, st, nx, ny, nz, s->d_bmod[0], s->d_bmod[1],
-                                   s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl, s->d_gmax);
+                                   s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl);
                 s->infl_version = h->box_version;
             }
         }
-        if (s->xy_mfma) {
-            remd_prof_scope pxy(h, "pme_xy", st);
-            remd_dftmm_launch_xy(st, nx, s->nzc * s->R, s->nzc, nz, s->d_grid, s->d_dftmm, s->d_infl, s->d_gmax, with_energy ? 1 : 0, s->d_energy,
-                                 s->n_eblk, 0);
-        } else if (s->xy_fused) {
+        if (s->xy_fused) {
             remd_prof_scope pxy(h, "pme_xy", st);
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
@@ -1284,26 +1080,17 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         }
-        static const bool fuse_gather = !(getenv("REMD_PME_FUSEGATHER") && atoi(getenv("REMD_PME_FUSEGATHER")) == 0);
-        s->gather_fused = fuse_gather;
-        if (fuse_gather) {
-            remd_prof_scope pzg(h, "pme_zinv_gather", st);
-            DISPATCH_Z(pme_zinv_gather_kernel, s->d_grid, s->d_tw[2], s->d_tw[3], h->Npad, h->d_pos, param, h->d_box, rep_lam,
-                       bin_cs, bin_ca, h->d_force, bin_cap, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr);
-            if (s->cbin_use) s->cbin_parity ^= 1;          // the next chain fills the buffer this evaluation has just zeroed
-        } else {
-            DISPATCH_Z(pme_zinv_kernel, s->d_grid, reinterpret_cast<float*>(s->d_mesh), s->d_tw[2], s->d_tw[3]);
+        {
+        remd_prof_scope pzg(h, "pme_zinv_gather", st);
+        DISPATCH_Z(pme_zinv_gather_kernel, s->d_grid, s->d_tw[2], s->d_tw[3], h->Npad, h->d_pos, param, h->d_box, rep_lam,
+                   bin_cs, bin_ca, h->d_force, bin_cap, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr);
+        if (s->cbin_use) s->cbin_parity ^= 1;          // the next chain fills the buffer this evaluation has just zeroed
         }
 #undef DISPATCH_Z
 #undef LAUNCH_Z
     }
     }   // part 1
     if (!(part & 2)) { REMD_CHECK(h, hipGetLastError()); return 0; }
-    if (!s->gather_fused) {
-        remd_prof_scope ps(h, "pme_gather", st);
-        hipLaunchKernelGGL(pme_gather_kernel, dim3((h->N + 127) / 128, h->R), dim3(128), 0, st, h->N, h->Npad, nx, ny, nz,
-                           h->d_pos, param, h->d_box, rep_lam, reinterpret_cast<const float*>(s->d_mesh), h->d_force, s->d_col_atoms);
-    }
     if (with_energy)
         hipLaunchKernelGGL(pme_energy_reduce_kernel, dim3(h->R), dim3(64), 0, st, s->n_eblk, s->d_energy, h->d_epart,
                            h->n_epart, 6 /*EP_PME*/);
@@ -1317,8 +1104,7 @@ remd_chain_bins remd_pme_chain_bins(remd_ctx* h)
 {
     remd_chain_bins b;
     pme_state* s = (pme_state*)h->pme;
-    static const bool fuse_gather = !(getenv("REMD_PME_FUSEGATHER") && atoi(getenv("REMD_PME_FUSEGATHER")) == 0);
-    if (!s || !s->d_cbin_count || s->R != h->R || !fuse_gather || !h->pme_concurrent || h->no_chain_bins) return b;
+    if (!s || !s->d_cbin_count || s->R != h->R || !h->pme_concurrent || h->no_chain_bins) return b;
     b.nx = s->n[0]; b.cap = s->cbin_cap; b.count = s->d_cbin_count + (size_t)s->cbin_parity * s->R * s->n[0]; b.atoms = s->d_cbin_atoms;
     b.box = h->d_box; b.err = h->d_sync + 2;
     // charges ride in the bins only when they do not depend on the replica's state: the chain runs before the evaluation

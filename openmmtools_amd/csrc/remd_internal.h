@@ -146,11 +146,6 @@ struct remd_ctx {
     bool forces_valid = false;
     bool force_zeroed = false;         // the last integrator chain already cleared d_force (skip the memset)
 
-    // ---- step counters on the device + the captured MD step (integrate.hip: remd_run_steps) ---------
-    long long* d_ctr = nullptr;        // [0] global step index of the current loop body, [1] body index inside the current run
-    hipGraph_t step_graph = nullptr; hipGraphExec_t step_graph_exec = nullptr; std::string step_graph_key;
-    unsigned long long graph_epoch = 0;   // bumped by everything that changes buffers / programs a captured step refers to
-
     // ---- PME ------------------------------------------------------------------------
     void* pme = nullptr;               // opaque (pme.hip)
 
@@ -164,8 +159,8 @@ struct remd_ctx {
     // fork / join of the two streams by flags in device memory ([0] fork, [1] join, [2] a spin ran out): the first mesh kernel
     // publishes the fork, a one-wavefront kernel at the head of the second stream waits for it, and the mirror image at the
     // join -- an event record / wait costs ~6 us of command-processor latency on the critical path, twice per step.
-    // REMD_SYNC_EVENTS=1 (and graph capture, which needs events to see the second stream) keep the events.
-    unsigned int* d_sync = nullptr; unsigned int sync_seq = 0; unsigned int fork_seq_pending = 0; bool sync_events = false, capturing = false;
+    // REMD_SYNC_EVENTS=1 keeps the events (also the fall-back of a handle whose polled wait ran out, api.hip).
+    unsigned int* d_sync = nullptr; unsigned int sync_seq = 0; unsigned int fork_seq_pending = 0; bool sync_events = false;
     // remd_run_steps: the launch that follows a force evaluation on the main stream is always an integrator chain, so the
     // join is polled in that kernel's prologue (join_deferred = sequence number to wait for) instead of a kernel of its own
     bool defer_join_ok = false; unsigned int join_deferred = 0;
@@ -175,7 +170,6 @@ struct remd_ctx {
     unsigned long long* d_chain_own = nullptr;   // [2] profiling: sum of (end - flag seen) wall-clock ticks of workgroup (0, 0), launches
     unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
-    hipStream_t stream3 = nullptr; bool listed_on_s3 = false;    // third stream: the listed terms of a force-only evaluation (joins through d_sync[3])
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true; bool pme_concurrent = false;
     double t_prop = 0, t_energy = 0, t_mix = 0;
     int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes
@@ -246,10 +240,10 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
 int remd_assign_velocities(remd_ctx* h, int64_t iteration);
 int remd_kinetic_energy(remd_ctx* h);
 int remd_work_buffers(remd_ctx* h);                    // heat / shadow-work accumulators and the '{' snapshot of the local replicas
-void remd_free_step_graph(remd_ctx* h);
 
 // ---- forces.hip -------------------------------------------------------------------------
-int remd_barostat_attempt(remd_ctx* h);
+int remd_barostat_attempt(remd_ctx* h);                      // barostat.hip
+int remd_nb_molecules(remd_ctx* h, const int** first, const int** size);   // molecule table of the nonbonded setup (device); 0: none
 int remd_minimize_impl(remd_ctx* h, double tolerance, int max_iterations, int32_t* converged, int32_t* n_iterations);
 void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluation re-sorts the molecules
 int remd_compute_forces(remd_ctx* h, bool with_energy);   // fills d_force (and d_potential when with_energy)

@@ -1520,30 +1520,6 @@ int remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inve
 }
 
 /* same contract as the matrix-core XY pass of the device library (csrc/dft_mfma.hip), as plain f64 FFTs */
-int remd_test_xy_mfma(remd_handle h, int n, int nplanes, float* data, int mode)
-{
-    if (!h || !data || n <= 0 || nplanes <= 0) return fail(h, -1, "remd_test_xy_mfma: bad arguments");
-    FFT1D fft(n);
-    std::vector<cplx> a((size_t)n * n), lin(n), lout(n);
-    for (int p = 0; p < nplanes; ++p) {
-        float* d = data + (size_t)p * n * n * 2;
-        for (size_t i = 0; i < a.size(); ++i) a[i] = cplx(d[2 * i], d[2 * i + 1]);
-        for (int pass = 0; pass < (mode == 1 ? 1 : 2); ++pass) {
-            const bool inv = pass == 1;
-            for (int x = 0; x < n; ++x) {                      // along y
-                fft.transform(a.data() + (size_t)x * n, lout.data(), inv);
-                for (int k = 0; k < n; ++k) a[(size_t)x * n + k] = lout[k];
-            }
-            for (int y = 0; y < n; ++y) {                      // along x
-                for (int k = 0; k < n; ++k) lin[k] = a[(size_t)k * n + y];
-                fft.transform(lin.data(), lout.data(), inv);
-                for (int k = 0; k < n; ++k) a[(size_t)k * n + y] = lout[k];
-            }
-        }
-        for (size_t i = 0; i < a.size(); ++i) { d[2 * i] = (float)a[i].real(); d[2 * i + 1] = (float)a[i].imag(); }
-    }
-    return 0;
-}
 
 int remd_last_timing(remd_handle h, double* p, double* e, double* m)
 {

@@ -62,18 +62,6 @@ def test_cpu_fft3d_matches_numpy(cpu_engine_factory, shape):
     assert np.abs(back - a).max() < 1e-6 * np.abs(a).max()
 
 
-def test_cpu_xy_plane_hook_matches_numpy(cpu_engine_factory):
-    """remd_test_xy_mfma on the CPU library: the contract of the device's matrix-core XY pass as plain f64 FFTs."""
-    eng = cpu_engine_factory()
-    rng = np.random.default_rng(9)
-    a = (rng.normal(size=(3, 30, 30)) + 1j * rng.normal(size=(3, 30, 30))).astype(np.complex64)
-    got = eng.test_xy_mfma(a, mode=1)
-    ref = np.fft.fft2(a.astype(np.complex128), axes=(1, 2))
-    assert np.abs(got - ref).max() < 3e-7 * np.abs(ref).max()
-    back = eng.test_xy_mfma(a, mode=0) / 900.0
-    assert np.abs(back - a).max() < 1e-6 * np.abs(a).max()
-
-
 def test_cpu_lj_fluid_energy_forces_and_alchemical_rows(cpu_engine_factory):
     lj = ts.LennardJonesFluid(nparticles=512)
     region = alchemy.AlchemicalRegion(alchemical_atoms=range(10))

@@ -1,5 +1,5 @@
 """Experiment: several handles (replica groups) on one GPU driven step by step from ONE host thread, so that the latency-bound
-phases of one group overlap the force kernels of another.  usage: REMD_STEP_NOSYNC=1 python tools/interleave_check.py <n_groups> [R]"""
+phases of one group overlap the force kernels of another.  usage: python tools/interleave_check.py <n_groups> [R]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -20,4 +20,4 @@ for R in Rs:
         eng.mix_host('swap-all', it, u, labels)
     n, ms = eng.profile_get('mix_swap_all')
     _, nacc, nprop, _ = eng.mix_host('swap-all', 99, u, labels)
-    print('waves', os.environ.get('REMD_MIX_WAVES', 'auto'), 'R', R, 'attempts', R ** 3, 'ms/call', ms / n, 'ns/attempt', 1e6 * ms / n / R ** 3, 'acceptance', float(nacc.sum()) / max(1.0, float(nprop.sum())))
+    print('R', R, 'attempts', R ** 3, 'ms/call', ms / n, 'ns/attempt', 1e6 * ms / n / R ** 3, 'acceptance', float(nacc.sum()) / max(1.0, float(nprop.sum())))

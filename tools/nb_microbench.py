@@ -23,5 +23,5 @@ for cutoff in (0.2, 0.6, 1.0):
         eng.lib.remd_get_forces  # noqa
         eng.get_forces()
     out = {k: eng.profile_get(k) for k in ('nonbonded', 'nb_gather', 'nb_sort', 'pme_fft', 'pme_bin', 'pme_gather')}
-    print('cutoff', cutoff, 'sort', os.environ.get('REMD_NB_SORT', '1'), {k: round(1e3 * v[1] / max(1, v[0]), 1) for k, v in out.items()})
+    print('cutoff', cutoff, {k: round(1e3 * v[1] / max(1, v[0]), 1) for k, v in out.items()})
     eng.close()

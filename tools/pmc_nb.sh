@@ -1,15 +1,15 @@
 #!/bin/bash
 export TMPDIR=/tmp
 ROOT=$(pwd)
-for n3l in 1 0; do
+for tiles in "" "REMD_NB_TILES=1"; do      # cluster-pair lists, then the 64-atom tile kernel (the fall-back)
 dbs=""
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES"; do
   i=$((i+1))
-  (cd /tmp && rm -rf /tmp/pmc_$i && env REMD_OVERLAP=0 REMD_NB_N3L=$n3l rocprofv3 --pmc $set -d /tmp/pmc_$i -o p -- python $ROOT/tools/small_r_profile.py 24 > /dev/null 2>&1)
+  (cd /tmp && rm -rf /tmp/pmc_$i && env REMD_OVERLAP=0 $tiles rocprofv3 --pmc $set -d /tmp/pmc_$i -o p -- python $ROOT/tools/small_r_profile.py 24 > /dev/null 2>&1)
   dbs="$dbs $(find /tmp/pmc_$i -name '*.db' | head -1)"
 done
-echo "== N3L=$n3l"
+echo "== ${tiles:-cluster-pair lists}"
 python - $dbs <<'PY'
 import sqlite3, sys
 tab = {}

@@ -1,6 +1,6 @@
 """GPU microbenchmark of the direct-space pair kernels on a fixed configuration (24 x alanine dipeptide in water):
 time per force evaluation of the 'nonbonded' / 'nonbonded_lj' profile classes for a list of environment variants.
-usage: python tools/sci_microbench.py "REMD_NB_N3L=0" "REMD_NB_N3L=1 REMD_NB_SCISPLIT=8" ...  (diagnostic)"""
+usage: python tools/sci_microbench.py "" "REMD_NB_TILES=1" "REMD_NB_PERSIST_GRID=576" ...  (diagnostic)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
