@@ -242,6 +242,29 @@ def test_alanine_short_trajectory(hip_engine_factory, alanine):
     assert np.allclose(U_dev, U_ora, rtol=2e-4)
 
 
+@pytest.mark.parametrize('grid', [(48, 60, 64), (80, 90, 96), (54, 81, 100), (64, 50, 40), (45, 120, 36), (32, 72, 128), (125, 128, 108)])
+def test_pme_mesh_sizes_cover_every_fft_stage_radix(hip_engine_factory, grid):
+    """The LDS-resident mesh passes run mixed-radix stages chosen per mesh size (pme.hip: factorize_nested): radix 2..5
+    butterflies and the nested 6, 8, 9, 10, 12, 15, 16 ones, along y and x in the plane pass and along z (packed real
+    pairs, nz / 2 points) in the spreading / gathering passes; planes that outgrow one workgroup take the slab path.  The
+    mesh sizes here put every radix into a first (no twiddles) and a later stage; energy and forces of the alanine dipeptide
+    box against the f64 oracle on the SAME mesh (the mesh only has to be at least as fine as the Ewald tolerance asks)."""
+    al = ts.AlanineDipeptideExplicit()
+    eng = hip_engine_factory()
+    desc = system_to_desc(al.system)
+    desc['pme_grid'] = np.array(grid, dtype=np.int32)
+    eng.set_system(desc)
+    eng.set_states(np.full(1, 1.0 / (KB * 300.0)))
+    eng.set_integrator('V R O R V', 0.001, 1.0, 1, True, 1e-8)
+    box = np.diag(al.system.getDefaultPeriodicBoxVectors())[None]
+    eng.set_replicas(1, 0, al.positions[None], None, box, np.arange(1))
+    U = eng.compute_energies(want_potential=True)[1]
+    f = eng.get_forces()
+    e_ref, f_ref = ForceFieldOracle(desc).energy_forces(al.positions, box[0])
+    assert np.isclose(U[0], e_ref, rtol=1e-5), (U[0], e_ref)
+    assert np.sqrt(((f[0] - f_ref) ** 2).sum(axis=1).mean()) < 0.5
+
+
 @pytest.mark.parametrize('system_cls,R', [(ts.HostGuestExplicit, 2), (ts.DHFRExplicit, 1)])
 def test_large_systems_energy_forces_and_propagation(hip_engine_factory, system_cls, R):
     """BASELINE config 4 / 5 systems (CB7:B2 host-guest, 4491 atoms, 96^3 mesh; DHFR, 23558 atoms, 144^3 mesh):

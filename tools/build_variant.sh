@@ -8,6 +8,6 @@ make -s
 base=${src%.hip}
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-value -Wno-unused-result "$@" -c $src -o /tmp/${base}_$name.o
 objs=""
-for o in api.o mix.o integrate.o forces.o pme.o dft_mfma.o roofs.o; do if [ "$o" = "$base.o" ]; then objs="$objs /tmp/${base}_$name.o"; else objs="$objs $o"; fi; done
+for o in $(sed -n "s/^SRCS = //p" Makefile | sed "s/\.hip/.o/g"); do if [ "$o" = "$base.o" ]; then objs="$objs /tmp/${base}_$name.o"; else objs="$objs $o"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../libremd_hip_$name.so
 echo built libremd_hip_$name.so
