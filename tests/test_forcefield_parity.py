@@ -243,12 +243,12 @@ def test_alanine_short_trajectory(hip_engine_factory, alanine):
 
 
 @pytest.mark.parametrize('grid', [(48, 60, 64), (80, 90, 96), (54, 81, 100), (64, 50, 40), (45, 120, 36), (32, 72, 128), (125, 128, 108)])
-def test_pme_mesh_sizes_cover_every_fft_stage_radix(hip_engine_factory, grid):
-    """The LDS-resident mesh passes run mixed-radix stages chosen per mesh size (pme.hip: factorize_nested): radix 2..5
-    butterflies and the nested 6, 8, 9, 10, 12, 15, 16 ones, along y and x in the plane pass and along z (packed real
-    pairs, nz / 2 points) in the spreading / gathering passes; planes that outgrow one workgroup take the slab path.  The
-    mesh sizes here put every radix into a first (no twiddles) and a later stage; energy and forces of the alanine dipeptide
-    box against the f64 oracle on the SAME mesh (the mesh only has to be at least as fine as the Ewald tolerance asks)."""
+def test_pme_mesh_sizes_through_the_force_path(hip_engine_factory, grid):
+    """The LDS-resident mesh passes run mixed-radix stages (radix 4, 2, 3, 5 in that order, pme.hip: factorize) along y and
+    x in the plane pass and along z (packed real pairs, nz / 2 points) in the spreading / gathering passes; planes that
+    outgrow one workgroup take the slab path (125 x 128).  Mesh sizes with every radix in a first (no twiddles) and a later
+    stage, odd and even nz: energy and forces of the alanine dipeptide box against the f64 oracle on the SAME mesh (the
+    mesh only has to be at least as fine as the Ewald tolerance asks, so any of these is a legal choice)."""
     al = ts.AlanineDipeptideExplicit()
     eng = hip_engine_factory()
     desc = system_to_desc(al.system)
