@@ -181,8 +181,14 @@ class HipEngine:
         if rc != 0:
             raise RuntimeError('remd_create failed (%d): %s' % (rc, self.lib.remd_last_error(None).decode()))
         self.device = device
+        self._ctor = (device, stream, lib_path)
         self.N = self.K = self.R = self.R_global = self.r_begin = 0
         self._keep = None
+
+    def spawn(self):
+        """Another handle of the same library on the same device and stream (one per group of compatible states:
+        multistate/_engine_pool.py)."""
+        return type(self)(*self._ctor)
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:

@@ -492,15 +492,23 @@ class MultiStateSampler:
         if self._engine is None:
             from .._engine import HipEngine
             self._engine = HipEngine()          # raises if libremd_hip.so / a GPU is missing: no CPU fallback
-        eng = self._engine
         all_states = list(self._thermodynamic_states) + list(self._unsampled_states)
         ref = all_states[0]
-        for s in all_states[1:]:
-            if not s.is_state_compatible(ref):
-                raise NotImplementedError('all thermodynamic states must share one System (differing only in '
-                                          'temperature and lambda parameters)')
         box0 = self._sampler_states[0].box_edges if ref.is_periodic else None
-        desc = system_to_desc(ref.system, box=box0)
+        # states.py:186-217: states of one standard System share a handle; several Systems => one handle per group behind the
+        # same interface (_engine_pool.py), as the reference keeps one Context per compatible group (multistatesampler.py:1470-1490)
+        from ..states import group_by_compatibility
+        groups, group_indices = group_by_compatibility(all_states)
+        if len(groups) > 1:
+            if any(getattr(g[0].system, 'alchemical_region', None) is not None for g in groups):
+                raise NotImplementedError('alchemical states in more than one compatibility group')
+            from ._engine_pool import EnginePool
+            if not isinstance(self._engine, EnginePool):
+                self._engine = EnginePool(self._engine, group_indices)
+            desc = [system_to_desc(g[0].system, box=box0) for g in groups]
+        else:
+            desc = system_to_desc(ref.system, box=box0)
+        eng = self._engine
         eng.set_system(desc)
         beta = np.array([s.beta for s in all_states])
         lam_s = np.array([s.lambda_sterics for s in all_states], dtype=np.float64)

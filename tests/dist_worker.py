@@ -16,7 +16,18 @@ def build(sampler_kind, engine, comm, n_iter, storage=None):
     ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
     move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
                                               n_steps=25, reassign_velocities=True, splitting='V R O R V')
-    if sampler_kind == 'pt':
+    if sampler_kind == 'groups':
+        # four oscillators of different spring constants = four Systems = four compatibility groups (tests/test_compat_groups.py)
+        from openmmtools_amd.multistate import ReplicaExchangeSampler
+        from openmmtools_amd.constants import kB
+        sts = []
+        for i in range(4):
+            K = kB * 300.0 / (0.1 * (1.2 + 0.2 * i)) ** 2
+            sts.append(states.ThermodynamicState(testsystems.HarmonicOscillator(
+                K=K * unit.kilojoules_per_mole / unit.nanometer ** 2, mass=12.0 * unit.amu).system, 300.0))
+        s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm)
+        s.create(sts, [ss], storage=storage)
+    elif sampler_kind == 'pt':
         s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm,
                                      online_analysis_interval=3)       # MBAR on rank 0 at iterations 3 and 6, error broadcast
         s.create(ts, [ss], storage=storage, min_temperature=300.0, max_temperature=600.0, n_temperatures=5)
@@ -40,7 +51,7 @@ def run(sampler_kind, comm, n_iter=6, storage_dir=None):
         s.run(1)
         history.append((s.replica_thermodynamic_states.copy(), s.energy_thermodynamic_states.copy(),
                         s._n_accepted_matrix.copy(), s._n_proposed_matrix.copy()))
-        analysis.append(np.append(s._last_mbar_f_k, s._last_err_free_energy))
+        analysis.append(np.append(s._last_mbar_f_k, s._last_err_free_energy) if sampler_kind != 'groups' else np.zeros(1))
     x = np.stack([st.positions for st in s.sampler_states])
     run.last_analysis = np.stack(analysis)          # [iteration, K + 1]: online f_k and the current error estimate
     return history, x, (s._r_begin, s._r_count)

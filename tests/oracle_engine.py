@@ -14,6 +14,9 @@ class OracleEngine:
         self.system_factory = system_factory or mo.OracleSystem
         self.seed_value = 0
 
+    def spawn(self):
+        return type(self)(self.system_factory)
+
     def set_system(self, desc):
         self.desc = desc
         self.sys = self.system_factory(desc)

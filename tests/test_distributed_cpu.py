@@ -58,6 +58,31 @@ def test_sharded_run_equals_single_process(tmp_path, kind):
     assert np.array_equal(a.read_replica_thermodynamic_states(), b.read_replica_thermodynamic_states())
 
 
+def test_sharded_run_with_several_compatibility_groups(tmp_path):
+    """States on different Systems (one engine handle per group on every rank, multistate/_engine_pool.py) under two ranks:
+    every rank holds the same gathered energy matrix and labels, swaps happen, and the stored energies are those of the stored
+    positions in every state's own System (u = beta K_k |x|^2 / 2).  (The Langevin noise of a group's batch is keyed by group and
+    rank offset, so this run is reproducible but not the single-process trajectory.)"""
+    from openmmtools_amd.constants import kB
+    port = 29850 + (os.getpid() % 100)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(HERE, 'dist_worker.py'), 'groups', str(tmp_path)]
+    res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS='1'), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    ranks = [np.load(os.path.join(tmp_path, 'rank%d.npz' % r)) for r in range(2)]
+    assert np.array_equal(ranks[0]['labels'], ranks[1]['labels']) and np.array_equal(ranks[0]['ukl'], ranks[1]['ukl'])
+    assert np.array_equal(ranks[0]['nacc'], ranks[1]['nacc']) and ranks[0]['nacc'].sum() > 0
+    assert all(sorted(l) == [0, 1, 2, 3] for l in ranks[0]['labels'])
+    from openmmtools_amd.multistate import MultiStateReporter
+    rep = MultiStateReporter(os.path.join(tmp_path, 'store'), open_mode='r')
+    K = np.array([kB * 300.0 / (0.1 * (1.2 + 0.2 * i)) ** 2 for i in range(4)])
+    e = rep.read_energies()[0]
+    for it in (2, 4, 6):
+        x = np.stack([s.positions for s in rep.read_sampler_states(it)])[:, 0, :]
+        assert np.allclose(e[it], 0.5 * (x ** 2).sum(axis=1)[:, None] * K[None, :] / (kB * 300.0), rtol=2e-5, atol=1e-7)
+    assert np.array_equal(e[6], ranks[0]['ukl'][-1])
+
+
 def test_existing_storage_is_refused_on_every_rank(tmp_path):
     """the 'storage already exists' error used to be raised on rank 0 only; the other ranks went on into the
     collectives of create() and hung.  The check is broadcast now: both ranks refuse (and the job ends)."""
