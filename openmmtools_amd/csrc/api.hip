@@ -550,6 +550,11 @@ static int mix_common(remd_ctx* h, int scheme, int64_t iteration, int R, int K, 
     hipEventRecord(h->ev1, h->stream);
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
     float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_mix = ms;
+    if (scheme == REMD_MIX_SWAP_ALL && n_accepted && n_proposed) {
+        double a = 0.0, p = 0.0;
+        for (size_t q = 0; q < (size_t)K * K; ++q) { a += (double)n_accepted[q]; p += (double)n_proposed[q]; }
+        if (p > 0.0) h->mix_acc_rate = a / p;
+    }
     return 0;
 }
 

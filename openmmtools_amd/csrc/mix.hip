@@ -195,6 +195,128 @@ void mix_swap_all_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
         for (int t = tid; t < K * K; t += W) { g_nprop[t] = s_nprop[t]; g_nacc[t] = s_nacc[t]; }
 }
 
+// ---- swap-all as a dataflow ---------------------------------------------------------------------------------------
+// The same window of consecutive attempts, but no speculation: an attempt runs when every earlier attempt of the window
+// that touches one of its two replica slots has run.  Per slot ONE 64-bit LDS word holds (label, number of the window's
+// attempts on this slot already executed); an attempt knows its ordinal in both slots' chains (occupancy masks, as above),
+// polls the two words (one ds_read_b64 each: count and label arrive together), and when both counts equal its ordinals the
+// labels it read are exactly those the sequential loop would see.  It decides, then publishes (new label, ordinal + 1) for
+// both slots with one 64-bit store each.  Wavefronts run asynchronously inside a window (no barrier per dependency level):
+// the cost of a level is two LDS round trips and the f64 arithmetic of one decision, whatever the acceptance rate -- the
+// speculative kernel above needs one workgroup sweep per level of CHANGED decisions, which is cheap at parallel-tempering
+// acceptance (few %) and 5-10x slower at the 40-50 % of an alchemical ladder.  Lower-numbered attempts never wait on
+// higher-numbered ones, every wavefront of the workgroup is resident, so the polling cannot deadlock.
+__device__ __forceinline__ unsigned long long mix_slot_load(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void mix_slot_store(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <bool UKL_LDS>
+__global__ __launch_bounds__(1024)
+void mix_swap_all_dataflow_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
+                                  const double* __restrict__ g_ukl, int64_t* __restrict__ g_labels,
+                                  unsigned long long* __restrict__ g_nacc, unsigned long long* __restrict__ g_nprop,
+                                  int64_t n_attempts, int stats_in_lds, long long* __restrict__ g_dbg, unsigned int* __restrict__ g_log)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, W = blockDim.x, nw = W >> 6;
+    long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t0 = clock64(), w0 = wall_clock64();
+    double* s_u = reinterpret_cast<double*>(smem);
+    unsigned long long* s_touch = reinterpret_cast<unsigned long long*>(smem + (UKL_LDS ? (size_t)R * K * sizeof(double) : 0));   // [R][nw]
+    unsigned long long* s_slot = s_touch + (size_t)R * nw;                       // [R] label | executed attempts of the window << 32
+    unsigned* s_nprop = reinterpret_cast<unsigned*>(s_slot + R);                 // [K*K] when stats_in_lds
+    unsigned* s_nacc = s_nprop + K * K;
+
+    if (UKL_LDS)
+        for (int t = tid; t < R * K; t += W) s_u[t] = g_ukl[(size_t)(t / K) * ld + (t % K)];
+    for (int t = tid; t < R; t += W) s_slot[t] = (unsigned long long)(unsigned)g_labels[t];
+    for (int t = tid; t < R * nw; t += W) s_touch[t] = 0ull;
+    if (stats_in_lds) for (int t = tid; t < 2 * K * K; t += W) s_nprop[t] = 0u;
+    __syncthreads();
+    const int ldu = UKL_LDS ? K : ld;
+    MIX_TICK(0);
+    for (int64_t base = 0; base < n_attempts; base += W) {
+        const int64_t k = base + tid;
+        const bool active = k < n_attempts;
+        philox4 w = remd_philox(seed, REMD_STREAM_SWAP_ALL, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), (uint64_t)iteration);
+        const int i = (int)remd_mulhi32(w.w[0], (uint32_t)R);     // randint(R), replicaexchange.py:324
+        const int j = (int)remd_mulhi32(w.w[1], (uint32_t)R);     // :325
+        const double u = remd_u53(w.w[2], w.w[3]);
+        if (active) {
+            atomicOr(&s_touch[(size_t)i * nw + (tid >> 6)], 1ull << (tid & 63));
+            atomicOr(&s_touch[(size_t)j * nw + (tid >> 6)], 1ull << (tid & 63));
+        }
+        mix_barrier();
+        unsigned ord_i = 0, ord_j = 0;
+        if (active) {
+            const unsigned long long* ti = s_touch + (size_t)i * nw;
+            const unsigned long long* tj = s_touch + (size_t)j * nw;
+            const int wi = tid >> 6;
+            const unsigned long long low = (1ull << (tid & 63)) - 1ull;
+            for (int q = 0; q < wi; ++q) { ord_i += __popcll(ti[q]); ord_j += __popcll(tj[q]); }
+            ord_i += __popcll(ti[wi] & low); ord_j += __popcll(tj[wi] & low);
+        }
+        MIX_TICK(1);
+        // u < exp(log_p) is decided by log_p - log(u) wherever that is not a borderline case (|difference| > 1e-9, far above
+        // the error of either function); the borderline falls back to the deterministic exp the oracle uses, so the decision
+        // is the oracle's bit for bit while the 18 dependent f64 operations of that exp stay off the dependency chain
+        const double lu = log(u);
+        const double* row_i = (UKL_LDS ? s_u : g_ukl) + (size_t)i * ldu;
+        const double* row_j = (UKL_LDS ? s_u : g_ukl) + (size_t)j * ldu;
+        const unsigned long long hi_i = (unsigned long long)(ord_i + 1u) << 32, hi_j = (unsigned long long)(ord_j + 1u) << 32;
+        unsigned long long* slot_i = s_slot + i;
+        unsigned long long* slot_j = s_slot + j;
+        bool pending = active, acc = false;
+        unsigned si = 0, sj = 0;
+        while (__ballot(pending)) {
+            if (pending) {
+                const unsigned long long vi = mix_slot_load(slot_i), vj = mix_slot_load(slot_j);
+                if ((unsigned)(vi >> 32) == ord_i && (unsigned)(vj >> 32) == ord_j) {
+                    si = (unsigned)vi; sj = (unsigned)vj;                                              // :328-329
+                    // replicaexchange.py:332-336, same association as mix_logp: (-(e_ij + e_ji) + e_ii) + e_jj
+                    const double e_ij = row_i[sj], e_ji = row_j[si], e_ii = row_i[si], e_jj = row_j[sj];
+                    const double log_p = __dadd_rn(__dadd_rn(-__dadd_rn(e_ij, e_ji), e_ii), e_jj);
+                    const double d = log_p - lu;
+                    if (log_p >= 0.0) acc = true;                                                      // :343
+                    else if (log_p > -690.0 && d > 1e-9 && d < 1e300) acc = true;                      // (d = inf: u = 0, exact path)
+                    else if (log_p > -690.0 && d < -1e-9) acc = false;
+                    else acc = u < remd_exp_det(log_p);
+                    mix_slot_store(slot_i, (unsigned long long)(acc ? sj : si) | hi_i);                // :345-346 (i == j: si == sj)
+                    if (i != j) mix_slot_store(slot_j, (unsigned long long)(acc ? si : sj) | hi_j);
+                    pending = false;
+                }
+            }
+            dbg[5] += 1;
+        }
+        if (active) {                                    // counts (:339-340, :348-349), off the dependency chain
+            if (stats_in_lds) {
+                atomicAdd(&s_nprop[si * K + sj], 1u); atomicAdd(&s_nprop[sj * K + si], 1u);
+                if (acc) { atomicAdd(&s_nacc[si * K + sj], 1u); atomicAdd(&s_nacc[sj * K + si], 1u); }
+            } else if (g_log) {
+                g_log[k] = (unsigned)si | ((unsigned)sj << 15) | (acc ? (1u << 30) : 0u) | (1u << 31);
+            } else {
+                atomicAdd(&g_nprop[(size_t)si * K + sj], 1ull); atomicAdd(&g_nprop[(size_t)sj * K + si], 1ull);
+                if (acc) { atomicAdd(&g_nacc[(size_t)si * K + sj], 1ull); atomicAdd(&g_nacc[(size_t)sj * K + si], 1ull); }
+            }
+        }
+        MIX_TICK(2);
+        mix_barrier();                                   // every attempt of the window has run
+        for (int t = tid; t < R * nw; t += W) s_touch[t] = 0ull;
+        for (int t = tid; t < R; t += W) s_slot[t] &= 0xffffffffull;          // keep the labels, restart the counts
+        mix_barrier();
+        MIX_TICK(3);
+    }
+    if (g_dbg && tid == 0) { for (int q = 0; q < 8; ++q) g_dbg[q] = dbg[q]; g_dbg[6] = wall_clock64() - w0; }
+    for (int t = tid; t < R; t += W) g_labels[t] = (int64_t)(unsigned)s_slot[t];
+    if (stats_in_lds)
+        for (int t = tid; t < K * K; t += W) { g_nprop[t] = s_nprop[t]; g_nacc[t] = s_nacc[t]; }
+}
+
 // replicaexchange.py:366-380 — neighbouring STATE pairs (s, s+1), s = offset, offset+2, ...
 __global__ __launch_bounds__(256)
 void mix_swap_neighbors_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
@@ -313,7 +435,7 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         const int force_waves = 0;
         int waves = force_waves > 0 ? force_waves : (4 * R + 63) / 64;
         waves = std::max(1, std::min(16, waves));
-        const int per_r = 6;                    // window of 6 R attempts (21.9 ms at R = 128: DESIGN.md 7b)
+        const int per_r = 6;                    // window of 6 R attempts (21.9 ms at R = 128: DESIGN.md 7b; the dataflow kernel: 43.9 ms, 45.5 at 4 R, 52 at 2 R)
         const int max_waves = 12;
         if (force_waves <= 0) waves = std::max(1, std::min(max_waves, (per_r * R + 63) / 64));
         while (waves > 1 && (size_t)R * waves * 8 > 64 * 1024) --waves;      // occupancy masks [R][waves] u64
@@ -332,7 +454,15 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         size_t lds = (in_lds ? ukl_bytes : 0) + work_bytes + (stats_lds ? stat_bytes : 0);
         lds = (lds + 15) & ~(size_t)15;
         if (lds > 160 * 1024) return remd_fail(h, -3, "swap-all working set does not fit in LDS");
-        auto kern = in_lds ? mix_swap_all_kernel<true> : mix_swap_all_kernel<false>;
+        // which kernel: both give the sequential loop's result bit for bit.  Speculative windows are 2-6x faster while few
+        // attempts are accepted (parallel tempering: 6 % -> 22 ms at R = 128 against 43), the dataflow kernel does not care
+        // (43 ms) where speculation degrades (45 % on an alchemical ladder -> 116 ms); the acceptance of the handle's previous
+        // swap-all call decides, crossover measured at 15-20 % for R = 16 ... 128 (profiles/r03_g_mix_kernels.txt).
+        // REMD_MIX_FLOW = 0 / 1 pins the kernel (parity tests).
+        const char* flow_env = getenv("REMD_MIX_FLOW");
+        const int flow = flow_env ? atoi(flow_env) : (h->mix_acc_rate > 0.17 ? 1 : 0);
+        auto kern = flow ? (in_lds ? mix_swap_all_dataflow_kernel<true> : mix_swap_all_dataflow_kernel<false>)
+                         : (in_lds ? mix_swap_all_kernel<true> : mix_swap_all_kernel<false>);
         REMD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         remd_prof_scope ps(h, "mix_swap_all");
         static long long* d_dbg = nullptr;

@@ -127,7 +127,8 @@ struct remd_ctx {
     float* d_box_old = nullptr; float4* d_baro_x0 = nullptr; long long* d_baro_f0 = nullptr; double* d_baro_U0 = nullptr; int* d_baro_acc = nullptr;
     int box_version = 0;               // bumped whenever the box edges on the device change (PME influence table)
     int n_restart_attempts = 0;        // mcmc.py:706-759
-    unsigned int* d_mix_log = nullptr; size_t mix_log_n = 0;      // swap-all attempt log (si, sj, accepted) when the counters do not fit in LDS
+    unsigned int* d_mix_log = nullptr; size_t mix_log_n = 0;      // swap-all attempt log (si, sj, accepted) when the counters do not fit
+    double mix_acc_rate = -1.0;        // accepted / proposed of the previous swap-all call (picks the kernel of the next: mix.hip) in LDS
     float4* d_snap_pos = nullptr; float4* d_snap_vel = nullptr;   // pre-propagate state (restart attempts)
     float4* d_fin_pos = nullptr; float4* d_fin_vel = nullptr;     // first successful result of every replica
     float* d_snap_box = nullptr; float* d_fin_box = nullptr;      // boxes move under the barostat: same treatment

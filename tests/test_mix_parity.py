@@ -8,6 +8,17 @@ pytestmark = pytest.mark.gpu
 SEED = 0xC0FFEE
 
 
+@pytest.fixture(params=['speculative', 'dataflow', 'by-acceptance'], autouse=True)
+def swap_all_kernel(request, monkeypatch):
+    """swap-all has two kernels with the same (sequential) result: speculative windows and the dataflow over per-slot
+    tickets; a handle picks by the acceptance of its previous call, REMD_MIX_FLOW pins one (mix.hip: remd_mix_launch)."""
+    if request.param == 'by-acceptance':
+        monkeypatch.delenv('REMD_MIX_FLOW', raising=False)
+    else:
+        monkeypatch.setenv('REMD_MIX_FLOW', '0' if request.param == 'speculative' else '1')
+    return request.param
+
+
 def _ukl(R, K, scale, rng):
     # PT-like structure (outer product) plus noise so that acceptance is neither 0 nor 1
     return np.outer(rng.normal(scale=scale, size=R), np.linspace(0.5, 1.5, K)) + rng.normal(scale=0.5, size=(R, K))
