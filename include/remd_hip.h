@@ -149,6 +149,16 @@ int  remd_set_work_measurement(remd_handle h, int measure_heat, int measure_shad
 int  remd_get_work(remd_handle h, double* heat, double* shadow_work, int64_t* n_accepted, int64_t* n_trials);
 int  remd_reset_work(remd_handle h);
 
+/* Multiple-time-step splittings of LangevinIntegrator ("V0 V1 R R O R R V1 R R O R R V1 V0", integrators.py:1036-1053):
+   a V<g> substep kicks with the forces of force group g only and dt / (number of V<g> tokens) (:1437-1438); with one
+   distinct group, or none, every V uses all forces (:1440).  groups[6] = force group (Force.getForceGroup(); for the
+   reciprocal part NonbondedForce.getReciprocalSpaceForceGroup(), -1 there meaning "as the direct part") of, in order:
+   the external force, bonds, angles, torsions, NonbondedForce direct space (with its exceptions and the Ewald exclusion
+   correction), PME reciprocal space.  Default: all 0.  Groups 0 ... 3 may appear in a multiple-time-step splitting;
+   every force class must then sit in a group the splitting names.  libremd_cpu.so stores the groups and refuses
+   multiple-time-step splittings (-3).                                                                              */
+int  remd_set_force_groups(remd_handle h, const int32_t* groups);
+
 /* BaseIntegratorMove.n_restart_attempts (mcmc.py:668-776, retry loop :706-759): when a replica
    holds a NaN after remd_propagate's MD steps, its pre-propagate positions/velocities are
    restored and the move is repeated (fresh noise: the Philox counters carry the attempt

@@ -44,7 +44,7 @@ EXPORTS = [
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
-    'remd_set_restart_attempts', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
+    'remd_set_restart_attempts', 'remd_set_force_groups', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
     'remd_set_energy_const_volume', 'remd_roof_microbench',
 ]
@@ -79,6 +79,7 @@ def load_library(path=None):
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
+    lib.remd_set_force_groups.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.remd_set_work_measurement.argtypes = [vp, C.c_int, C.c_int]
     lib.remd_get_work.argtypes = [vp, c_double_p, c_double_p, c_int64_p, c_int64_p]
     lib.remd_reset_work.argtypes = [vp]
@@ -210,6 +211,8 @@ class HipEngine:
         s, keep = build_desc(desc_dict)
         self._check(self.lib.remd_set_system(self.h, C.byref(s)), 'remd_set_system')
         self.N = int(desc_dict['n_atoms'])
+        if 'force_groups' in desc_dict:                  # Force.getForceGroup() of the force classes (V<g> substeps)
+            self.set_force_groups(desc_dict['force_groups'])
 
     def set_states(self, beta, lambda_sterics=None, lambda_electrostatics=None, energy_const=None):
         beta = np.ascontiguousarray(beta, dtype=np.float64)
@@ -237,6 +240,11 @@ class HipEngine:
 
     def reset_work(self):
         self._check(self.lib.remd_reset_work(self.h), 'remd_reset_work')
+
+    def set_force_groups(self, groups):
+        """Force groups of (external, bonds, angles, torsions, nonbonded direct, PME reciprocal) for V<g> substeps."""
+        g = (C.c_int32 * 6)(*[int(x) for x in groups])
+        self._check(self.lib.remd_set_force_groups(self.h, g), 'remd_set_force_groups')
 
     def set_restart_attempts(self, n):
         """mcmc.py:706-759: retries of a move whose result holds a NaN (restored start state, fresh noise)."""

@@ -100,6 +100,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_alch_atoms);
     dfree(h->d_beta); dfree(h->d_lam_s); dfree(h->d_lam_e); dfree(h->d_econst);
     dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_pos_ref); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels);
+    for (int g = 0; g < 4; ++g) dfree(h->d_force_g[g]);
     dfree(h->d_ukl); dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
     dfree(h->d_pressure); dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
     dfree(h->d_mix_log);
@@ -123,6 +124,7 @@ int remd_seed(remd_handle h, uint64_t seed) { if (!h) return -1; h->seed = seed;
 
 int remd_set_system(remd_handle h, const remd_system_desc* d)
 {
+    if (h) for (int c = 0; c < 6; ++c) h->fgroup[c] = 0;           // until remd_set_force_groups says otherwise
     if (!h || !d) return remd_fail(h, -1, "remd_set_system: NULL argument");
     if (d->n_atoms <= 0 || !d->mass) return remd_fail(h, -1, "remd_set_system: n_atoms/mass missing");
     hipSetDevice(h->device);
@@ -179,11 +181,21 @@ int remd_set_integrator(remd_handle h, const char* splitting, double dt, double 
 {
     if (!h) return -1;
     if (!(dt > 0) || n_steps < 0 || gamma < 0) return remd_fail(h, -1, "remd_set_integrator: bad parameters");
-    int rc = remd_parse_splitting(h, splitting, h->tokens, h->nV, h->nR, h->nO);
+    int rc = remd_parse_splitting(h, splitting, h->tokens, h->nV, h->nR, h->nO, h->nVg);
     if (rc) return rc;
     h->splitting = splitting; h->dt = dt; h->gamma = gamma; h->n_steps = n_steps; h->reassign = reassign;
     h->constraint_tol = tol > 0 ? tol : 1e-8;
     h->has_integrator = true;
+    return 0;
+}
+
+int remd_set_force_groups(remd_handle h, const int32_t* groups)
+{
+    if (!h || !groups) return remd_fail(h, -1, "remd_set_force_groups: bad arguments");
+    for (int c = 0; c < 6; ++c) {
+        if (groups[c] < 0 || groups[c] > 31) return remd_fail(h, -1, "remd_set_force_groups: force groups are 0 ... 31");
+        h->fgroup[c] = groups[c];
+    }
     return 0;
 }
 
@@ -210,6 +222,8 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     const size_t n = (size_t)R_local * h->Npad;
     if (realloc) {
         dfree(h->d_pos); dfree(h->d_vel); dfree(h->d_force); dfree(h->d_box); dfree(h->d_labels); dfree(h->d_ukl);
+        for (int g = 0; g < 4; ++g) dfree(h->d_force_g[g]);
+        h->force_g_n = 0;
         // per-replica scratch of the barostat and of the restart attempts is sized by R_local as well
         dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
         dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);

@@ -1770,8 +1770,14 @@ int remd_nb_resident_info(remd_ctx* h, int* ok, int* method, int* has_alch, nb_p
     return 0;
 }
 
-int remd_compute_forces(remd_ctx* h, bool with_energy)
+int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
 {
+    // class_mask: which force classes act (REMD_FG_* bits; everything unless a multiple-time-step splitting asks for the forces
+    // of one force group, integrate.hip).  Energies are only defined for the full set.
+    if (with_energy && (class_mask & 63u) != 63u) return remd_fail(h, -1, "energies need every force class");
+    const bool do_ext = (class_mask >> REMD_FG_EXTERNAL) & 1u, do_bond = (class_mask >> REMD_FG_BOND) & 1u;
+    const bool do_angle = (class_mask >> REMD_FG_ANGLE) & 1u, do_torsion = (class_mask >> REMD_FG_TORSION) & 1u;
+    const bool do_nb = (class_mask >> REMD_FG_NONBONDED) & 1u, do_recip = (class_mask >> REMD_FG_RECIPROCAL) & 1u;
     if (!h->force_zeroed)
         REMD_CHECK(h, hipMemsetAsync(h->d_force, 0, sizeof(long long) * 3 * (size_t)h->Npad * h->R, h->stream));
     h->force_zeroed = false;
@@ -1779,7 +1785,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         REMD_CHECK(h, hipMemsetAsync(h->d_epart, 0, sizeof(double) * (size_t)h->n_epart * h->R, h->stream));
     const int R = h->R;
 #define LAUNCH_E(kern, ...) do { if (with_energy) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
-    if (h->n_ext > 0) {
+    if (h->n_ext > 0 && do_ext) {
         remd_prof_scope ps(h, "ext_force");
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
                  h->ext_U0, h->Npad, h->d_pos, h->d_force, h->d_epart, h->n_epart);
@@ -1797,7 +1803,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         nb_tables& t0 = g_nb[h];
         int rc0 = update_replica_lambdas(h, t0);
         if (rc0) return rc0;
-        if (t0.method == NB_EWALD && h->overlap && h->stream2) {
+        if (t0.method == NB_EWALD && h->overlap && h->stream2 && do_nb && do_recip) {
             if (!h->sync_events) {
                 // the first mesh launch (binning kernel, or the spreading pass when the chain binned the atoms) stores the
                 // fork flag; a one-wavefront kernel at the head of the second stream polls it
@@ -1834,12 +1840,12 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
     // spreading pass: 118.9 -> 116.8 ms per 500 steps)
     auto launch_listed = [&]() {
         listed_tables T{};
-        T.n_bonds = h->n_bonds; T.n_angles = h->n_angles; T.n_torsions = h->n_torsions;
+        T.n_bonds = do_bond ? h->n_bonds : 0; T.n_angles = do_angle ? h->n_angles : 0; T.n_torsions = do_torsion ? h->n_torsions : 0;
         T.bond_atoms = h->d_bond_atoms; T.bond_params = h->d_bond_params;
         T.angle_atoms = h->d_angle_atoms; T.angle_params = h->d_angle_params;
         T.torsion_atoms = h->d_torsion_atoms; T.torsion_params = h->d_torsion_params;
         nb_tables* it = g_nb.find(h);
-        if (it && h->nb_method != REMD_NB_NONE) {
+        if (it && h->nb_method != REMD_NB_NONE && do_nb) {
             nb_tables& t = *it;
             T.n_exc = t.n_exc; T.exc_atoms = t.d_exc_atoms; T.exc_params = t.d_exc_params;
             T.n_excl = t.n_excl; T.excl_atoms = t.d_excl_atoms; T.excl_qq = t.d_excl_qq;
@@ -1857,9 +1863,9 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
         if (merged) launch_listed();
     } else {
         nb_tables& t = g_nb[h];
-        int rc = ensure_sorted(h, t);
+        int rc = do_nb ? ensure_sorted(h, t) : 0;
         if (rc) return rc;
-        {
+        if (do_nb) {
             remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {
                 if (t.method == NB_LJ_ONLY) launch_nb<NB_LJ_ONLY, true>(h, t);
@@ -1900,7 +1906,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy)
                 }
                 rc = remd_pme_forces(h, with_energy, h->stream, 2); if (rc) return rc;        // (the energy reduction of the mesh part)
             }
-            else { rc = remd_pme_forces(h, with_energy, h->stream); if (rc) return rc; }
+            else if (do_recip) { rc = remd_pme_forces(h, with_energy, h->stream); if (rc) return rc; }
         }
         if (with_energy)
             hipLaunchKernelGGL(const_energy_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, t.disp_coeff, t.self_nn, t.self_aa,

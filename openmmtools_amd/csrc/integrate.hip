@@ -15,6 +15,7 @@
 // rank are covered by one launch (blockIdx.y = replica).
 #include "remd_internal.h"
 #include "rng.h"
+#include <set>
 #include "pair_math.h"
 
 #define UNIT_FREE   0
@@ -28,6 +29,8 @@ struct chain_prog {
     int o_index[MAX_TOK];  // for 'O': index of this O inside the step program
     long long step[MAX_TOK]; // global step index of each token (a chain may hold tokens left pending by the previous step)
     float hV, hR;          // dt/n_V, dt/n_R
+    float hVg[4];          // multiple-time-step splittings: dt / (V tokens of force group g); tokens '0'..'3'
+    const long long* Fg[4]; // forces of force group g ([R][3][Npad] fixed point, like the all-forces accumulator)
     float a, b;            // OU coefficients
     int nO;
     int accumulate_momentum;  // after the chain, add sum(m v) into cmm buffer cmm_w
@@ -268,7 +271,8 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
     }
     for (int t = t0; t < t1; ++t) {
         const char tok = prog.tok[t];
-        const float ke0 = ((prog.measure & 1) && tok == 'O') || ((prog.measure & 2) && (tok == 'V' || tok == 'R')) ? unit_ke() : 0.f;
+        const bool is_v = tok == 'V' || (tok >= '0' && tok <= '3');
+        const float ke0 = ((prog.measure & 1) && tok == 'O') || ((prog.measure & 2) && (is_v || tok == 'R')) ? unit_ke() : 0.f;
         if (tok == '{') {
             // Metropolization starts: remember x and v (integrators.py:1539-1542)
 #pragma unroll
@@ -276,13 +280,16 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                 Xold[idx[k]] = make_float4(x[k].x, x[k].y, x[k].z, 0.f);
                 Vold[idx[k]] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
             }
-        } else if (tok == 'V') {
+        } else if (tok == 'V' || (tok >= '0' && tok <= '3')) {
+            // all forces, or the forces of one force group with that group's share of the time step (integrators.py:1437-1440)
+            const long long* Ft = tok == 'V' ? F : prog.Fg[tok - '0'] + (size_t)r * 3 * Npad;
+            const float hv = tok == 'V' ? prog.hV : prog.hVg[tok - '0'];
 #pragma unroll
             for (int k = 0; k < NAT; ++k) {
-                const float s = prog.hV * im[k] * (1.0f / 4294967296.0f);
-                v[k].x += s * (float)F[idx[k]];
-                v[k].y += s * (float)F[Npad + idx[k]];
-                v[k].z += s * (float)F[2 * Npad + idx[k]];
+                const float s = hv * im[k] * (1.0f / 4294967296.0f);
+                v[k].x += s * (float)Ft[idx[k]];
+                v[k].y += s * (float)Ft[Npad + idx[k]];
+                v[k].z += s * (float)Ft[2 * Npad + idx[k]];
             }
             constrain_v<TYPE, NAT>(sc, im, tol, v, x);
         } else if (tok == 'R') {
@@ -329,7 +336,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
             for (int k = 0; k < NAT; ++k) { v[k].x -= sx; v[k].y -= sy; v[k].z -= sz; }
         }
         if ((prog.measure & 1) && tok == 'O') S.heat += unit_ke() - ke0;                           // :1448-1460
-        if ((prog.measure & 2) && (tok == 'V' || tok == 'R')) S.shadow += unit_ke() - ke0;         // :1409-1446 (kinetic part)
+        if ((prog.measure & 2) && (is_v || tok == 'R')) S.shadow += unit_ke() - ke0;                // :1409-1446 (kinetic part)
     }
     float3 mom = f3(0, 0, 0);
     if (!last) return mom;
@@ -627,12 +634,15 @@ void remd_free_constraints(remd_ctx* h)
     g_units.erase(h);
 }
 
-int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO)
+int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO, int* nVg)
 {
-    // integrators.py:1474-1537: space-separated, case-insensitive V/R/O tokens.  Force-group
-    // suffixes (V0, V1: multiple-time-step) and Metropolization braces are not supported.
+    // integrators.py:1474-1537: space-separated, case-insensitive V/R/O tokens, Metropolization braces, and force-group
+    // suffixes V0, V1, ...: with more than one distinct group the splitting is a multiple-time-step one, every V must name its
+    // group (:1527-1529) and takes dt / (occurrences of that group) with that group's forces only (:1437-1438); with one group
+    // (or none) every V uses all forces and dt / (number of V tokens) (:1440, :1535)
     tokens.clear(); nV = nR = nO = 0;
     std::string s(splitting ? splitting : "");
+    std::vector<int> vgroup;             // per V token: group index or -1 (no suffix)
     size_t i = 0;
     while (i < s.size()) {
         while (i < s.size() && s[i] == ' ') ++i;
@@ -640,12 +650,36 @@ int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& 
         size_t j = i; while (j < s.size() && s[j] != ' ') ++j;
         std::string tok = s.substr(i, j - i);
         for (auto& c : tok) c = (char)toupper(c);
-        if (tok == "V" || tok == "V0") { tokens.push_back('V'); nV++; }
+        if (tok[0] == 'V' && tok.find_first_not_of("0123456789", 1) == std::string::npos) {
+            int g = -1;
+            if (tok.size() > 1) {
+                if (tok.size() > 3) return remd_fail(h, -3, "force group of '" + tok + "' out of range");
+                g = atoi(tok.c_str() + 1);
+                if (g > 31) return remd_fail(h, -3, "OpenMM only allows up to 32 force groups (integrators.py:1346-1347)");
+            }
+            tokens.push_back('V'); vgroup.push_back(g); nV++;
+        }
         else if (tok == "R") { tokens.push_back('R'); nR++; }
         else if (tok == "O") { tokens.push_back('O'); nO++; }
         else if (tok == "{" || tok == "}") tokens.push_back(tok[0]);      // Metropolization of the substeps in between (:1539-1557)
-        else return remd_fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V R O { })");
+        else return remd_fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V V<group> R O { })");
         i = j;
+    }
+    {
+        std::set<int> groups;
+        for (int g : vgroup) if (g >= 0) groups.insert(g);
+        int counts[4] = {0, 0, 0, 0};
+        if (groups.size() > 1) {
+            if (!nVg) return remd_fail(h, -3, "multiple-time-step splittings are set with remd_set_integrator");
+            size_t v = 0;
+            for (auto& c : tokens) if (c == 'V') {
+                const int g = vgroup[v++];
+                if (g < 0) return remd_fail(h, -3, "a multiple-time-step splitting must name the force group of every V (integrators.py:1527-1529)");
+                if (g > 3) return remd_fail(h, -3, "force groups above 3 are not supported in multiple-time-step splittings");
+                c = (char)('0' + g); counts[g]++;
+            }
+        }
+        if (nVg) for (int g = 0; g < 4; ++g) nVg[g] = counts[g];
     }
     if (tokens.empty()) return remd_fail(h, -3, "empty splitting string");
     if (nR == 0 || nV == 0) return remd_fail(h, -3, "splitting needs at least one R and one V (integrators.py:1376-1385)");
@@ -1041,6 +1075,31 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     base.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO));       // :1146
     base.nO = nO > 0 ? nO : 1;
     base.cmm_r = -1; base.cmm_w = 0; base.zero_force = 0;
+    // multiple-time-step program: one force array per force group that the splitting names, evaluated when a V of the group
+    // comes up and the positions have changed since its last evaluation
+    bool mts = false;
+    for (char c : tokens) mts |= (c >= '0' && c <= '3');
+    unsigned group_mask[4] = {0u, 0u, 0u, 0u};
+    bool group_valid[4] = {false, false, false, false};
+    if (mts) {
+        const size_t nf = (size_t)h->R * 3 * h->Npad;
+        for (int g = 0; g < 4; ++g) {
+            base.hVg[g] = h->nVg[g] > 0 ? (float)(h->dt / h->nVg[g]) : 0.f;
+            for (int c = 0; c < 6; ++c) if (h->fgroup[c] == g) group_mask[g] |= 1u << c;
+            if (h->nVg[g] > 0 && (!h->d_force_g[g] || h->force_g_n != nf)) {
+                if (h->d_force_g[g]) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_force_g[g]); h->d_force_g[g] = nullptr; }
+                REMD_CHECK(h, hipMalloc(&h->d_force_g[g], sizeof(long long) * nf));
+            }
+            base.Fg[g] = h->d_force_g[g];
+        }
+        h->force_g_n = nf;
+        unsigned named = 0u, all = 0u;
+        for (int g = 0; g < 4; ++g) { if (h->nVg[g] > 0) named |= group_mask[g]; all |= group_mask[g]; }
+        for (int c = 0; c < 6; ++c)
+            if (h->fgroup[c] > 3 || !(named & (1u << c)))
+                return remd_fail(h, -3, "multiple-time-step splitting: a force class sits in a force group that no V of the splitting names "
+                                        "(its forces would never act); groups 0-3 are supported");
+    }
     int n_braces = 0;
     for (char c : tokens) n_braces += (c == '}');
     const bool shadow = h->measure_shadow || n_braces > 0;              // a Metropolized program measures shadow work (:1117-1119)
@@ -1075,7 +1134,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         // forces are stale after an R that follows the chain's last V: let the chain clear them (saves a memset)
         bool seenR = false, staleAtEnd = false;
         for (int t = 0; t < cur.n; ++t) { if (cur.tok[t] == 'R') seenR = true; if (cur.tok[t] == 'V') seenR = false; }
-        staleAtEnd = seenR;
+        staleAtEnd = seenR && !mts;          // (the per-group arrays of a multiple-time-step program are cleared before their evaluation)
         cur.zero_force = staleAtEnd ? 1 : 0;
         if (staleAtEnd) zeroed_by_chain = true;
         launch_chain(h, ut, cur, bin_for_pme);
@@ -1112,6 +1171,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             zeroed_by_chain = false;
             int rc = remd_barostat_attempt(h);
             if (rc) return rc;
+            for (bool& gv : group_valid) gv = false;
         }
         int oidx = 0, brace = 0;
         auto evaluate_with_energy = [&](bool accumulate) -> int {
@@ -1134,9 +1194,26 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                 hipLaunchKernelGGL(metropolis_restore_kernel, dim3((h->N + 255) / 256, h->R), dim3(256), 0, h->stream, h->N, h->Npad, h->d_accept,
                                    h->d_pos, h->d_vel, h->d_xold, h->d_vold);
                 h->forces_valid = false; pe_valid = false;         // rejected replicas are back at their old positions
+                for (bool& gv : group_valid) gv = false;
                 continue;
             }
             if (tok == 'R' && shadow && !pe_valid) { int rc = evaluate_with_energy(false); if (rc) return rc; }
+            if (tok >= '0' && tok <= '3' && !group_valid[tok - '0']) {
+                // forces of this force group at the current positions, into the group's own array
+                const int g = tok - '0';
+                const bool has_mesh = (group_mask[g] >> REMD_FG_RECIPROCAL) & 1u;
+                flush(false, has_mesh);
+                long long* all_forces = h->d_force;
+                h->d_force = h->d_force_g[g];
+                h->force_zeroed = false; zeroed_by_chain = false;
+                h->defer_join_ok = device_waits_ok;
+                int rc = remd_compute_forces(h, false, group_mask[g]);
+                h->defer_join_ok = false;
+                h->d_force = all_forces;
+                h->forces_valid = false; h->force_zeroed = false;      // (the all-forces accumulator was not touched)
+                if (rc) return rc;
+                group_valid[g] = true;
+            }
             if (tok == 'V' && !h->forces_valid) {
                 flush(false, true);
                 h->force_zeroed = zeroed_by_chain;
@@ -1150,6 +1227,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             if (tok == 'O') oidx++;
             if (tok == 'R') {
                 h->forces_valid = false;
+                for (bool& gv : group_valid) gv = false;
                 if (shadow) { int rc = evaluate_with_energy(true); if (rc) return rc; }
             }
         }

@@ -105,6 +105,11 @@ struct remd_ctx {
     std::string splitting = "V R O R V";
     std::vector<char> tokens;          // parsed 'V','R','O'
     int nV = 0, nR = 0, nO = 0;
+    // multiple-time-step splittings (V0 V1 ..., integrators.py:1425-1442): tokens '0'..'3' = V of that force group;
+    // nVg[g] = occurrences per step, fgroup[c] = force group of class c (REMD_FG_*), d_force_g[g] = that group's forces
+    int nVg[4] = {0, 0, 0, 0};
+    int fgroup[6] = {0, 0, 0, 0, 0, 0};
+    long long* d_force_g[4] = {nullptr, nullptr, nullptr, nullptr}; size_t force_g_n = 0;
     double dt = 0.001, gamma = 1.0, constraint_tol = 1e-8;
     int n_steps = 1; int reassign = 1;
     bool has_integrator = false;
@@ -235,7 +240,7 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
                     const double* d_logw, double* d_logP, int64_t n_attempts);
 
 // ---- integrate.hip ----------------------------------------------------------------------
-int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO);
+int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO, int* nVg = nullptr);
 int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
                    int64_t iteration, int64_t first_step, int n_steps);
 int remd_assign_velocities(remd_ctx* h, int64_t iteration);
@@ -247,7 +252,14 @@ int remd_barostat_attempt(remd_ctx* h);                      // barostat.hip
 int remd_nb_molecules(remd_ctx* h, const int** first, const int** size);   // molecule table of the nonbonded setup (device); 0: none
 int remd_minimize_impl(remd_ctx* h, double tolerance, int max_iterations, int32_t* converged, int32_t* n_iterations);
 void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluation re-sorts the molecules
-int remd_compute_forces(remd_ctx* h, bool with_energy);   // fills d_force (and d_potential when with_energy)
+// force classes (bits of the mask of remd_compute_forces, indices of remd_ctx::fgroup)
+#define REMD_FG_EXTERNAL 0
+#define REMD_FG_BOND 1
+#define REMD_FG_ANGLE 2
+#define REMD_FG_TORSION 3
+#define REMD_FG_NONBONDED 4      /* direct space, exceptions, Ewald exclusion correction */
+#define REMD_FG_RECIPROCAL 5
+int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask = ~0u);   // fills d_force (and d_potential when with_energy)
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d);
 int remd_build_constraints(remd_ctx* h, const remd_system_desc* d);
 

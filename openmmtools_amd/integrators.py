@@ -112,8 +112,11 @@ class LangevinIntegrator:
         counts = {s: sum(1 for t in steps if t[0] == s) for s in 'ORV{}'}
         groups = set(t[1:] for t in steps if t[0] == 'V' and len(t) > 1)
         mts = len(groups) > 1
-        if mts:
-            raise NotImplementedError('multiple-time-step splittings (V0 V1 ...) are not implemented')
+        if mts:                                             # integrators.py:1524-1533
+            for t in steps:
+                if t[0] == 'V' and len(t) == 1:
+                    raise ValueError('a multiple-time-step splitting must name the force group of every V step')
+            return counts, mts, {g: sum(1 for t in steps if t[0] == 'V' and t[1:] == g) for g in groups}
         return counts, mts, {'0': counts['V']}
 
 

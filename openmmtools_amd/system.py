@@ -88,6 +88,14 @@ class NonbondedForce(Force):
         self._rf_dielectric = 78.3
         self._ewald_tol = 5e-4
         self._pme_params = None
+        self._recip_group = -1
+
+    def getReciprocalSpaceForceGroup(self):
+        return self._recip_group
+
+    def setReciprocalSpaceForceGroup(self, g):
+        """-1 (default): the reciprocal-space part acts in the force group of the force itself."""
+        self._recip_group = int(g)
 
     def addParticle(self, charge, sigma, epsilon):
         self.particles.append((float(charge), float(sigma), float(epsilon)))
@@ -345,6 +353,22 @@ def system_to_desc(system, box=None):
     bonds, angles, torsions = [], [], []
     nb = None
     cmm = 0
+    # force groups of (external, bonds, angles, torsions, nonbonded direct, PME reciprocal): remd_set_force_groups
+    fg = [0, 0, 0, 0, 0, 0]
+    for f in system.forces:
+        g = f.getForceGroup() if hasattr(f, 'getForceGroup') else 0
+        if isinstance(f, CustomExternalForce):
+            fg[0] = g
+        elif isinstance(f, HarmonicBondForce):
+            fg[1] = g
+        elif isinstance(f, HarmonicAngleForce):
+            fg[2] = g
+        elif isinstance(f, PeriodicTorsionForce):
+            fg[3] = g
+        elif isinstance(f, NonbondedForce):
+            fg[4] = g
+            fg[5] = g if f.getReciprocalSpaceForceGroup() < 0 else f.getReciprocalSpaceForceGroup()
+    d['force_groups'] = np.array(fg, dtype=np.int32)
     for f in system.forces:
         if isinstance(f, CustomExternalForce):
             d['n_ext'] = len(f.particles)

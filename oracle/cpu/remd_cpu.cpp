@@ -792,6 +792,7 @@ static int fail(remd_ctx* h, int code, const std::string& msg)
 static int parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO)
 {
     tokens.clear(); nV = nR = nO = 0;
+    int group = -1; bool mts = false;
     std::string s(splitting ? splitting : "");
     size_t i = 0;
     while (i < s.size()) {
@@ -800,13 +801,18 @@ static int parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>
         size_t j = i; while (j < s.size() && s[j] != ' ') ++j;
         std::string tok = s.substr(i, j - i);
         for (auto& c : tok) c = (char)toupper(c);
-        if (tok == "V" || tok == "V0") { tokens.push_back('V'); nV++; }
+        if (tok[0] == 'V' && tok.find_first_not_of("0123456789", 1) == std::string::npos) {
+            // one distinct force group (or none): every V uses all forces (integrators.py:1518-1535)
+            if (tok.size() > 1) { const int g = atoi(tok.c_str() + 1); if (group >= 0 && g != group) mts = true; group = g; }
+            tokens.push_back('V'); nV++;
+        }
         else if (tok == "R") { tokens.push_back('R'); nR++; }
         else if (tok == "O") { tokens.push_back('O'); nO++; }
         else if (tok == "{" || tok == "}") tokens.push_back(tok[0]);
-        else return fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V R O { })");
+        else return fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V V<group> R O { })");
         i = j;
     }
+    if (mts) return fail(h, -3, "multiple-time-step splittings (several force groups) are not implemented in the CPU library");
     if (tokens.empty()) return fail(h, -3, "empty splitting string");
     if (nR == 0 || nV == 0) return fail(h, -3, "splitting needs at least one R and one V (integrators.py:1376-1385)");
     int depth = 0;
@@ -1249,6 +1255,13 @@ int remd_get_work(remd_handle h, double* heat, double* shadow_work, int64_t* n_a
     }
     return 0;
 }
+int remd_set_force_groups(remd_handle h, const int32_t* groups)
+{
+    if (!h || !groups) return fail(h, -1, "remd_set_force_groups: bad arguments");
+    for (int c = 0; c < 6; ++c) if (groups[c] < 0 || groups[c] > 31) return fail(h, -1, "remd_set_force_groups: force groups are 0 ... 31");
+    return 0;       // (multiple-time-step splittings are refused when they are parsed)
+}
+
 int remd_set_restart_attempts(remd_handle h, int n)
 {
     if (!h || n < 0) return fail(h, -1, "remd_set_restart_attempts: bad arguments");

@@ -144,23 +144,23 @@ class ForceFieldOracle(OracleSystem):
         return 1.0 - 10.0 * x ** 3 + 15.0 * x ** 4 - 6.0 * x ** 5
 
     # ---- energy terms (torch) --------------------------------------------------------------------
-    def _bonded(self, x):
+    def _bonded(self, x, only=None):
         d = self.d
         e = x.new_zeros(())
         ba = np.asarray(d['bond_atoms']).reshape(-1, 2)
-        if len(ba):
+        if len(ba) and (only is None or 1 in only):
             bp = torch.tensor(np.asarray(d['bond_params'], dtype=np.float64).reshape(-1, 2))
             r = (x[ba[:, 1]] - x[ba[:, 0]]).norm(dim=1)
             e = e + (0.5 * bp[:, 1] * (r - bp[:, 0]) ** 2).sum()
         aa = np.asarray(d['angle_atoms']).reshape(-1, 3)
-        if len(aa):
+        if len(aa) and (only is None or 2 in only):
             ap = torch.tensor(np.asarray(d['angle_params'], dtype=np.float64).reshape(-1, 2))
             v0, v1 = x[aa[:, 0]] - x[aa[:, 1]], x[aa[:, 2]] - x[aa[:, 1]]
             cos = (v0 * v1).sum(1) / (v0.norm(dim=1) * v1.norm(dim=1))
             th = torch.acos(torch.clamp(cos, -1.0, 1.0))
             e = e + (0.5 * ap[:, 1] * (th - ap[:, 0]) ** 2).sum()
         ta = np.asarray(d['torsion_atoms']).reshape(-1, 4)
-        if len(ta):
+        if len(ta) and (only is None or 3 in only):
             tp = torch.tensor(np.asarray(d['torsion_params'], dtype=np.float64).reshape(-1, 3))
             b1, b2, b3 = x[ta[:, 1]] - x[ta[:, 0]], x[ta[:, 2]] - x[ta[:, 1]], x[ta[:, 3]] - x[ta[:, 2]]
             m, n = torch.linalg.cross(b1, b2), torch.linalg.cross(b2, b3)
@@ -240,32 +240,37 @@ class ForceFieldOracle(OracleSystem):
                         torch.zeros_like(msq))
         return 0.5 * (G * (S.real ** 2 + S.imag ** 2)).sum()
 
-    def energy_torch(self, x, box, lam_s=1.0, lam_e=1.0, include_na=True):
+    def energy_torch(self, x, box, lam_s=1.0, lam_e=1.0, include_na=True, classes=None):
+        """classes: None (everything) or a set of force-class indices in the order of remd_set_force_groups (0 external,
+        1 bonds, 2 angles, 3 torsions, 4 nonbonded direct space + exceptions + exclusion correction + dispersion constant,
+        5 PME reciprocal space + self terms) -- the forces of one force group of a multiple-time-step splitting."""
         d = self.d
+        on = (lambda c: True) if classes is None else (lambda c: c in classes)
         e = x.new_zeros(())
-        if d['n_ext'] > 0:
+        if d['n_ext'] > 0 and on(0):
             idx = np.asarray(d['ext_atoms'])
             dx = x[idx] - torch.tensor([d['ext_x0'], 0.0, 0.0])
             e = e + 0.5 * d['ext_K'] * (dx * dx).sum() + d['ext_U0'] * len(idx)
-        e = e + self._bonded(x)
+        e = e + (self._bonded(x) if classes is None else self._bonded(x, only=classes))
         if self.method:
             box_t = torch.tensor(np.asarray(box, dtype=np.float64))
-            pairs = self._pairs(x.detach().numpy(), np.asarray(box, dtype=np.float64))
-            if len(pairs):
-                e = e + self._pair_terms(x, box_t, pairs, lam_s, lam_e, include_na=include_na)
-            e = e + self._exceptions(x, box_t, lam_e)
             V = float(np.prod(box))
-            e = e + self.disp_coeff / V
-            if self.method == 2 and self.has_charge:
+            if on(4):
+                pairs = self._pairs(x.detach().numpy(), np.asarray(box, dtype=np.float64))
+                if len(pairs):
+                    e = e + self._pair_terms(x, box_t, pairs, lam_s, lam_e, include_na=include_na)
+                e = e + self._exceptions(x, box_t, lam_e)
+                e = e + self.disp_coeff / V
+            if self.method == 2 and self.has_charge and on(5):
                 q = torch.where(self.alch_t, self.q * lam_e, self.q)
                 e = e + self.pme_reciprocal(x, box_t, q)
                 e = e - ONE_4PI_EPS0 * self.alpha / math.sqrt(math.pi) * (q * q).sum()
                 e = e - ONE_4PI_EPS0 * math.pi * q.sum() ** 2 / (2.0 * self.alpha ** 2 * V)
         return e
 
-    def energy_forces(self, x, box=None, lambda_sterics=1.0, lambda_electrostatics=1.0, forces=True):
+    def energy_forces(self, x, box=None, lambda_sterics=1.0, lambda_electrostatics=1.0, forces=True, classes=None):
         xt = torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=forces)
-        e = self.energy_torch(xt, box, lambda_sterics, lambda_electrostatics)
+        e = self.energy_torch(xt, box, lambda_sterics, lambda_electrostatics, classes=classes)
         if not forces:
             return float(e.detach()), None
         if e.requires_grad:

@@ -120,8 +120,10 @@ class OracleSystem:
             f[idx] = -K * dx
         return e, f
 
-    def energy_forces(self, x, box=None, lambda_sterics=1.0, lambda_electrostatics=1.0, forces=True):
+    def energy_forces(self, x, box=None, lambda_sterics=1.0, lambda_electrostatics=1.0, forces=True, classes=None):
         e, f = self.ext(x)
+        if classes is not None and 0 not in classes:            # (force class 0 = the external force: remd_set_force_groups)
+            e, f = 0.0, np.zeros_like(x)
         for term in getattr(self, 'extra_terms', []):
             et, ft = term(x, box, lambda_sterics, lambda_electrostatics)
             e += et
@@ -211,6 +213,13 @@ class OracleLangevin:
         self.s = system
         self.tokens = splitting.upper().split()
         self.nV = sum(t[0] == 'V' for t in self.tokens)
+        # integrators.py:1507-1535: more than one distinct force group named => multiple-time-step: V<g> kicks with the forces of
+        # group g and dt / (number of V<g>); otherwise every V uses all forces and dt / (number of V)
+        groups = sorted(set(t[1:] for t in self.tokens if t[0] == 'V' and len(t) > 1))
+        self.mts = len(groups) > 1
+        self.nVg = {g: sum(t == 'V' + g for t in self.tokens) for g in groups} if self.mts else {}
+        fg = np.asarray(system.d.get('force_groups', np.zeros(6, dtype=np.int32))) if hasattr(system, 'd') else np.zeros(6, dtype=np.int32)
+        self.group_classes = {g: set(c for c in range(6) if int(fg[c]) == int(g)) for g in groups}
         self.nR = self.tokens.count('R')
         self.nO = self.tokens.count('O')
         self.dt, self.gamma, self.n_steps, self.seed = float(timestep), float(collision_rate), int(n_steps), int(seed)
@@ -274,6 +283,15 @@ class OracleLangevin:
                         f = None
                     work['shadow_work'] = 0.0
                     brace += 1
+                elif tok[0] == 'V' and self.mts:
+                    g = tok[1:]
+                    fgrp = s.energy_forces(x, box, lambda_sterics, lambda_electrostatics, classes=self.group_classes[g])[1]
+                    ke0 = ke(v) if work is not None else 0.0
+                    v = v + (self.dt / self.nVg[g]) * fgrp * invm[:, None]          # :1437-1438
+                    if s.constraints:
+                        v = rattle(s.constraints, invm, x, v)
+                    if work is not None:
+                        work['shadow_work'] += ke(v) - ke0
                 elif tok[0] == 'V':
                     if f is None:
                         f = s.energy_forces(x, box, lambda_sterics, lambda_electrostatics)[1]

@@ -93,7 +93,7 @@ def _resume_and_extend(engine, tmp_path):
     e, nb, eu = rep.read_energies()
     ref = MultiStateReporter(STORE, open_mode='r')
     assert e.shape == (4, 1, 20) and np.array_equal(e[:3], ref.read_energies()[0])
-    again = MultiStateSampler.from_storage(str(tmp_path / 'continued.nc'), engine=type(engine)(**engine._ctor) if hasattr(engine, '_ctor') else engine)
+    again = MultiStateSampler.from_storage(str(tmp_path / 'continued.nc'), engine=engine.spawn() if hasattr(engine, 'spawn') else engine)
     assert again.iteration == 3
     v = again.sampler_states[0].velocities
     assert v is not None and np.abs(v).max() > 0                            # velocities are part of a checkpoint now
