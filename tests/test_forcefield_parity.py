@@ -283,6 +283,7 @@ def test_large_systems_energy_forces_and_propagation(hip_engine_factory, system_
         assert np.isclose(U[r], e_ref, rtol=1e-5), (U[r], e_ref)
         rmse = np.sqrt(((f[r] - f_ref) ** 2).sum(axis=1).mean())
         assert rmse < 2.5, rmse
+        assert np.abs(f[r] - f_ref).max() < 2e-3 * np.abs(f_ref).max(), np.abs(f[r] - f_ref).max()      # per atom, not only on average
     assert not eng.propagate(1).any()
     xg, vg, _, _ = eng.get_replicas()
     cons = mo.OracleSystem(desc).constraints
@@ -501,3 +502,61 @@ def test_config5_dhfr_128_state_sams_row_and_jump(hip_engine_factory):
     assert np.array_equal(got[0], ref[0])
     assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
     assert np.allclose(got[3], ref[3], rtol=0, atol=1e-9)      # log P of O(1e5)-sized arguments: 1e-9 absolute
+
+
+def test_config5_dhfr_hamiltonian_ladder_columns(hip_engine_factory):
+    """BASELINE config 5 as north_star words it -- DHFR with 128 HAMILTONIAN replicas: an alchemical ladder (ten solvent
+    molecules decoupled: lambda_electrostatics 1 -> 0 over 64 states, then lambda_sterics 1 -> 0 over 64) on the 23 558-atom
+    system.  The device fits U(lambda_e) from three mesh passes and evaluates the soft-core pairs of all lambda_s in one pass;
+    five columns spread over the ladder against the oracle, which recomputes each state from scratch
+    (reduced_potential_at_states, states.py:911-992), and neighbouring columns differ by a few kT."""
+    dh = ts.DHFRExplicit()
+    n = dh.system.getNumParticles()
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(n - 30, n))          # the last ten waters
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(dh.system, region)
+    K = 128
+    lam_e = np.concatenate([np.linspace(1.0, 0.0, 64), np.zeros(64)])
+    lam_s = np.concatenate([np.ones(64), np.linspace(1.0, 0.0, 64)])
+    nb = [f for f in system.getForces() if hasattr(f, 'particles') and hasattr(f, 'exceptions')][0]
+    V = np.prod(np.diag(system.getDefaultPeriodicBoxVectors()))
+    econst = alchemy.alchemical_long_range_constants(system, nb, lam_s, V)
+    eng = hip_engine_factory()
+    desc = system_to_desc(system)
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 300.0)
+    eng.set_states(np.full(K, beta), lam_s, lam_e, econst)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 5, True, 1e-8)
+    eng.seed(SEED)
+    box = np.diag(system.getDefaultPeriodicBoxVectors())[None]
+    eng.set_replicas(1, 0, dh.positions[None], None, box, np.array([40], dtype=np.int64))
+    rows = eng.compute_energies()
+    assert rows.shape == (1, K) and np.isfinite(rows).all()
+    ff = ForceFieldOracle(desc)
+    xd = eng.get_replicas()[0][0]
+    for k in (0, 31, 63, 96, 127):
+        e_ref = ff.energy_forces(xd, box[0], lambda_sterics=lam_s[k], lambda_electrostatics=lam_e[k], forces=False)[0] + econst[k]
+        assert np.isclose(rows[0, k], beta * e_ref, rtol=1e-5), (k, rows[0, k], beta * e_ref)
+    assert np.abs(np.diff(rows[0])).max() < 10.0                 # ten waters discharged over 64 states: 6.3 kT per rung
+
+
+def test_energy_drift_bounds_the_fixed_iteration_constraint_solver(hip_engine_factory):
+    """The device solves X-H clusters with a fixed three Newton iterations and rigid waters analytically, whatever
+    constraint_tolerance says (include/remd_hip.h).  What that means for the dynamics, in the terms that matter: velocity
+    Verlet ('V R V', no thermostat) on alanine dipeptide in water at 1 fs conserves K + U to a small fraction of kT per
+    degree of freedom over 0.4 ps -- the bar OpenMM's own constraint tolerance (1e-5 by default there) is held to."""
+    al = ts.AlanineDipeptideExplicit()
+    eng = hip_engine_factory()
+    _engine_for(eng, al.system, al.positions, R=1, splitting='V R V', dt=0.001, n_steps=100)
+    eng.minimize(tolerance=50.0, max_iterations=200)
+    eng.set_integrator('V R O R V', 0.001, 5.0, 200, True, 1e-8)
+    eng.propagate(0)                                                  # thermalise for 0.2 ps
+    eng.set_integrator('V R V', 0.001, 0.0, 100, False, 1e-8)
+    energies = []
+    for it in range(5):
+        kinetic = eng.get_replicas(positions=False, velocities=False, kinetic=True)[3]
+        energies.append(float(kinetic[0] + eng.compute_energies(want_potential=True)[1][0]))
+        if it < 4:
+            eng.propagate(it + 1)
+    ndof = 3 * 2269 - 2259 - 3
+    drift = (np.array(energies) - energies[0]) / (ndof * KB * 300.0)
+    assert np.abs(drift).max() < 2e-3, drift                          # kT per degree of freedom over 0.4 ps
