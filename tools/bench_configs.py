@@ -37,7 +37,7 @@ def run(name, sampler, n_iter, warm=1):
 
 
 def main():
-    which = sys.argv[1:] or ['2', '4', '5']
+    which = sys.argv[1:] or ['2', '4', '5', '5h']
     def move(dt_fs, split):
         return mcmc.LangevinSplittingDynamicsMove(timestep=dt_fs * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
                                                   n_steps=500, reassign_velocities=True, splitting=split)
@@ -65,6 +65,17 @@ def main():
         ss = states.SamplerState(dh.positions, box_vectors=dh.system.getDefaultPeriodicBoxVectors())
         s.create(ths, [ss] * 16)
         run('5 (1-GPU share): DHFRExplicit 23558 atoms, 16 replicas x 128 temperature states, SAMS global jump, g-BAOAB 2 fs x 500', s, 2)
+    if '5h' in which:
+        # the same share with north_star's wording: 128 HAMILTONIAN replicas = an alchemical ladder (ten solvent molecules decoupled)
+        dh = testsystems.DHFRExplicit()
+        n = dh.system.getNumParticles()
+        lam_e = np.concatenate([np.linspace(1.0, 0.0, 64), np.zeros(64)])
+        lam_s = np.concatenate([np.ones(64), np.linspace(1.0, 0.0, 64)])
+        ths = alchemical_states(dh.system, range(n - 30, n), lam_e, lam_s)
+        s = SAMSSampler(mcmc_moves=move(2.0, 'V R R O R R V'), number_of_iterations=10 ** 9, engine=HipEngine(), seed=1)
+        ss = states.SamplerState(dh.positions, box_vectors=dh.system.getDefaultPeriodicBoxVectors())
+        s.create(ths, [ss] * 16)
+        run('5h (1-GPU share): DHFRExplicit 23558 atoms, 16 replicas x 128 alchemical states, SAMS global jump, g-BAOAB 2 fs x 500', s, 2)
 
 
 if __name__ == '__main__':
