@@ -80,10 +80,15 @@ class ReferenceStoreReader:
         self._c = _hdf5.File(self._cpath) if os.path.isfile(self._cpath) else None
         ci = self._a.attr('CheckpointInterval')
         self._checkpoint_interval = int(np.asarray(ci).reshape(-1)[0]) if ci is not None else 1
-        self.title = self._a.attr('title')
 
     filepath = property(lambda self: self._path)
+    title = property(lambda self: self._a.attr('title'))
     checkpoint_interval = property(lambda self: self._checkpoint_interval)
+
+    def read_seed(self):
+        """The Philox seed of a store this package wrote (global attribute; None for the reference's own files)."""
+        v = self._a.attr('openmmtools_amd_seed')
+        return None if v is None else int(np.asarray(v).reshape(-1)[0])
 
     def close(self):
         self._a.close()
@@ -96,7 +101,10 @@ class ReferenceStoreReader:
         path = '/' + path.strip('/')
         if self._a.is_group(path):
             groups, datasets = self._a.keys(path)
-            return {k: self.read_dict(path + '/' + k) for k in groups + datasets}
+            data = {k: self.read_dict(path + '/' + k) for k in groups + datasets}
+            if path == '/metadata':
+                data['title'] = self.title
+            return data
         if path not in self._a:
             head, key = path.rsplit('/', 1)
             if not head:
@@ -146,12 +154,16 @@ class ReferenceStoreReader:
 
     def read_online_data_if_present(self, iteration):
         out = {}
-        for key in ('logZ', 'log_weights'):
+        for key in ('logZ', 'log_weights', 'stage', 't0', 'state_histogram'):
             for path in ('/online_analysis/' + key + '_history', '/online_analysis/' + key):
                 if path in self._a:
                     a = self._a.read(path)
                     out[key] = a[iteration] if a.ndim == 2 and a.shape[0] > iteration else a
                     break
+        if 'stage' in out and 't0' in out:                          # sams.py:374-393: what a SAMS sampler restores
+            out['sams_state'] = dict(stage=int(np.asarray(out.pop('stage')).reshape(-1)[0]), t0=int(np.asarray(out.pop('t0')).reshape(-1)[0]),
+                                     histogram=None if 'state_histogram' not in out else np.asarray(out.pop('state_histogram')).astype(np.int64),
+                                     iteration=int(iteration))
         return out or None
 
     def read_online_analysis_data(self, iteration, *keys):
@@ -235,3 +247,300 @@ class ReferenceStoreReader:
         for r in range(x.shape[0]):
             out.append(states.SamplerState(x[r], velocities=v[r], box_vectors=None if box is None else box[r]))
         return out
+
+
+# =====================================================================================================================
+# Writing the same layout (multistatereporter.py:280-460, 476-690, 865-1115, 1597-1737, 1817-1880)
+# =====================================================================================================================
+
+class _Quantity:
+    """A number with the unit name the reference's YAML carries ('!Quantity {unit, value}')."""
+
+    def __init__(self, value, unit):
+        self.value, self.unit = value, unit
+
+
+def _yaml_dump(data):
+    import yaml
+
+    class Dumper(yaml.SafeDumper):
+        pass
+
+    def quantity(dumper, q):
+        v = q.value.tolist() if isinstance(q.value, np.ndarray) else float(q.value)
+        return dumper.represent_mapping('!Quantity', {'unit': q.unit, 'value': v})
+
+    Dumper.add_representer(_Quantity, quantity)
+    Dumper.add_representer(np.float64, lambda d, x: d.represent_float(float(x)))
+    Dumper.add_representer(np.int64, lambda d, x: d.represent_int(int(x)))
+    Dumper.add_representer(np.bool_, lambda d, x: d.represent_bool(bool(x)))
+    return yaml.dump(data, Dumper=Dumper)
+
+
+PROGRAM = 'openmmtools_amd'
+_STANDARD_TEMPERATURE = 273.0              # states.py:224-226: what the standard System's barostat carries
+_STANDARD_PRESSURE_BAR = 1.0
+
+
+class ReferenceStoreWriter:
+    """The write half: the variables, dimensions, attributes and serialized objects the reference's MultiStateReporter
+    creates through netCDF4-python, created through libhdf5 (``_netcdf4_write``).  What can be written is what
+    ``ReferenceStoreReader`` understands: plain ThermodynamicStates (temperature, pressure) on Systems of the hot-path
+    forces, Langevin moves, the samplers' options; anything else raises NotImplementedError naming it."""
+
+    def __init__(self, analysis_path, checkpoint_path, mode, checkpoint_interval, title=None):
+        from . import _netcdf4_write as nw
+        self._nw = nw
+        self._path, self._cpath = str(analysis_path), str(checkpoint_path)
+        self._interval = int(checkpoint_interval)
+        fresh = mode == 'w' or not os.path.isfile(self._path)
+        self._a = nw.NetCDF4File(self._path, 'w' if fresh else 'a')
+        self._c = nw.NetCDF4File(self._cpath, 'w' if fresh or not os.path.isfile(self._cpath) else 'a')
+        if fresh:
+            import time
+            import uuid
+            uid = str(uuid.uuid4())
+            title = title or 'Multi-state sampler simulation created using %s on %s' % (PROGRAM, time.asctime())
+            for f, used in ((self._a, 'analysis'), (self._c, 'checkpoint')):        # :432-460 _initialize_storage_file
+                f.create_dimension('/scalar', 1)
+                f.create_dimension('/iteration', None)
+                f.create_dimension('/spatial', 3)
+                f.set_attr('/', 'program', PROGRAM)
+                f.set_attr('/', 'programVersion', '0.3')
+                f.set_attr('/', 'Conventions', 'ReplicaExchange')
+                f.set_attr('/', 'ConventionVersion', '0.2')
+                f.set_attr('/', 'DataUsedFor', used)
+                f.set_attr('/', 'CheckpointInterval', np.array([self._interval], dtype=np.int64))
+                f.set_attr('/', 'UUID', uid)                                        # :346-361: the two files carry one UUID
+                f.set_attr('/', 'title', title)
+                f.create_variable('/last_iteration', 'i8', ('scalar',))
+                f.write('/last_iteration', [0])
+        else:
+            ci = self._a.attr('CheckpointInterval')
+            if ci is not None:
+                self._interval = int(np.asarray(ci).reshape(-1)[0])
+
+    @staticmethod
+    def written_here(path):
+        """Only stores this writer made are extended in place; one written by the reference is read and continued elsewhere."""
+        try:
+            with _hdf5.File(str(path)) as f:
+                return str(f.attr('program', default='')).startswith(PROGRAM)
+        except Exception:
+            return False
+
+    def reader(self):
+        r = ReferenceStoreReader.__new__(ReferenceStoreReader)
+        r._path, r._cpath, r._a, r._c = self._path, self._cpath, self._a, self._c
+        r._checkpoint_interval = self._interval
+        return r
+
+    def sync(self):
+        self._a.flush()
+        self._c.flush()
+
+    def close(self):
+        self._a.close()
+        self._c.close()
+
+    # ---- dictionaries (:1817-1880) -----------------------------------------------------------------------------
+    def _write_text(self, f, path, text, fixed):
+        group = path.rsplit('/', 1)[0]
+        if group:
+            f.create_group(group)
+        if fixed:
+            dim = '/fixedL%d' % len(text)
+            if path not in f:
+                f.create_dimension(dim, len(text))
+                f.create_variable(path, 'S1', (dim[1:],))
+            elif f.shape(path)[0] != len(text):
+                raise IOError('%s: a fixed-length dictionary cannot change its length' % path)
+            f.write(path, text)
+        else:
+            if path not in f:
+                f.create_variable(path, 'str', ('scalar',))
+            f.write(path, text)
+
+    def write_dict(self, name, data):
+        data = dict(data) if data is not None else {}
+        if name == 'options' and 'kwargs' in data and 'cls' in data:
+            # the reference restores with cls(**options) (multistatesampler.py:948-950): only its constructor's keywords may
+            # appear; this package's extras (sampler class, Philox seed) go to global attributes
+            self._a.set_attr('/', 'openmmtools_amd_sampler', '%s.%s' % (data.get('module', ''), data['cls']))
+            if data.get('seed') is not None:
+                self._a.set_attr('/', 'openmmtools_amd_seed', np.array([int(data['seed'])], dtype=np.int64))
+            flat = dict(number_of_iterations=data.get('number_of_iterations'))
+            flat.update(data['kwargs'])
+            data = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in flat.items()}
+        if name == 'metadata':
+            # :1127-1139: the title is a global attribute, the rest is stored nested (a group per dictionary, a fixed-length
+            # character variable per value) so that one entry can be read without the rest
+            if data.get('title') is not None:
+                self._a.set_attr('/', 'title', str(data.pop('title')))
+            else:
+                data.pop('title', None)
+            self._write_nested('/metadata', data)
+            return
+        self._write_text(self._a, '/' + name.strip('/'), _yaml_dump(data), fixed=False)
+
+    def _write_nested(self, path, value):
+        if isinstance(value, dict) and len(value) > 0:
+            for k, v in value.items():
+                if not isinstance(k, str):
+                    raise ValueError('Cannot store dict in nested form with non-string keys.')          # :1854-1856
+                self._write_nested(path + '/' + k, v)
+            return
+        self._write_text(self._a, path, _yaml_dump(value), fixed=True)
+
+    # ---- states (:612-668) -------------------------------------------------------------------------------------
+    def write_thermodynamic_states(self, thermodynamic_states, unsampled_states):
+        from .. import system_xml
+        import zlib
+        first_of = []                                   # (state, 'kind/index') of the first state of every compatible group
+        for kind, states in (('thermodynamic_states', thermodynamic_states), ('unsampled_states', unsampled_states)):
+            for k, s in enumerate(states):
+                if type(s).__name__ != 'ThermodynamicState':
+                    raise NotImplementedError('%s in the reference\'s store layout (plain ThermodynamicStates only)' % type(s).__name__)
+                d = {'_serialized__class_name': 'ThermodynamicState', '_serialized__module_name': 'openmmtools.states',
+                     'temperature': _Quantity(float(s.temperature), 'kelvin'), 'surface_tension': None,
+                     'pressure': None if s.pressure is None else _Quantity(float(s.pressure) / _UNIT_TO_MD['bar'], 'bar')}
+                ref = next((name for other, name in first_of if s.is_state_compatible(other)), None)
+                if ref is None:
+                    xml = system_xml.to_xml(s.system, pressure=None if s.pressure is None else _STANDARD_PRESSURE_BAR * _UNIT_TO_MD['bar'],
+                                            temperature=_STANDARD_TEMPERATURE)
+                    d['standard_system'] = zlib.compress(xml.encode())
+                    first_of.append((s, '%s/%d' % (kind, k)))
+                else:
+                    d['_Reporter__compatible_state'] = ref
+                self._write_text(self._a, '/%s/state%d' % (kind, k), _yaml_dump(d), fixed=True)
+
+    def write_mcmc_moves(self, mcmc_moves):
+        """:813-815 (one variable per state's move, rewritten every iteration by the reference; the recipes here are fixed)."""
+        for k, m in enumerate(mcmc_moves):
+            name = type(m).__name__
+            if name not in ('LangevinSplittingDynamicsMove', 'LangevinDynamicsMove'):
+                raise NotImplementedError('MCMC move %s in the reference\'s store layout' % name)
+            d = {'_serialized__class_name': name, '_serialized__module_name': 'openmmtools.mcmc',
+                 'timestep': _Quantity(float(m.timestep) * 1e3, 'femtosecond'),
+                 'collision_rate': _Quantity(float(m.collision_rate), '/picosecond'),
+                 'n_steps': int(m.n_steps), 'reassign_velocities': bool(m.reassign_velocities),
+                 'constraint_tolerance': float(getattr(m, 'constraint_tolerance', 1e-8)),
+                 'n_restart_attempts': int(getattr(m, 'n_restart_attempts', 4))}
+            if name == 'LangevinSplittingDynamicsMove':
+                d.update(splitting=str(m.splitting), measure_heat=bool(getattr(m, 'measure_heat', False)),
+                         measure_shadow_work=bool(getattr(m, 'measure_shadow_work', False)))
+            path = '/mcmc_moves/move%d' % k
+            text = _yaml_dump(d)
+            if path in self._a and str(np.asarray(self._a.read(path)).reshape(-1)[0]) == text:
+                continue
+            self._write_text(self._a, path, text, fixed=False)
+
+    # ---- per-iteration variables (:775-1018) -------------------------------------------------------------------
+    def _record_variable(self, f, path, kind, dims, sizes, attrs=()):
+        if path in f:
+            return
+        group = path.rsplit('/', 1)[0]
+        if group:
+            f.create_group(group)
+        for d, n in zip(dims, sizes):
+            where = (group + '/' + d) if (group and d.startswith('dim_size')) else '/' + d
+            if n is not None and not f.has_dimension(where):
+                f.create_dimension(where, n)
+        f.create_variable(path, kind, dims)
+        for k, v in attrs:
+            f.set_attr(path, k, v)
+
+    def write_replica_thermodynamic_states(self, state_indices, iteration):
+        s = np.asarray(state_indices)
+        self._record_variable(self._a, '/states', 'i4', ('iteration', 'replica'), (None, len(s)),
+                              (('units', 'none'), ('long_name', "states[iteration][replica] is the thermodynamic state index (0..n_states-1) "
+                                                                "of replica 'replica' of iteration 'iteration'.")))
+        self._a.write('/states', s, record=int(iteration))
+
+    def write_energies(self, energy_thermodynamic_states, energy_neighborhoods, energy_unsampled_states, iteration):
+        e = np.asarray(energy_thermodynamic_states)
+        R, K = e.shape
+        self._record_variable(self._a, '/energies', 'f8', ('iteration', 'replica', 'state'), (None, R, K),
+                              (('units', 'kT'), ('long_name', "energies[iteration][replica][state] is the reduced (unitless) energy of "
+                                                             "replica 'replica' from iteration 'iteration' evaluated at the thermodynamic state 'state'.")))
+        self._record_variable(self._a, '/neighborhoods', 'i1', ('iteration', 'replica', 'state'), (None, R, K),
+                              (('_FillValue', np.array([1], dtype=np.int8)),            # :901: old files read as "all states"
+                               ('long_name', "neighborhoods[iteration][replica][state] is 1 if this energy was computed during this iteration.")))
+        self._a.write('/energies', e, record=int(iteration))
+        self._a.write('/neighborhoods', np.asarray(energy_neighborhoods), record=int(iteration))
+        eu = np.asarray(energy_unsampled_states)
+        if eu.size:
+            self._record_variable(self._a, '/unsampled_energies', 'f8', ('iteration', 'replica', 'unsampled'), (None, R, eu.shape[1]),
+                                  (('units', 'kT'), ('long_name', "unsampled_energies[iteration][replica][state] is the reduced (unitless) energy of replica "
+                                                                 "'replica' from iteration 'iteration' evaluated at unsampled thermodynamic state 'state'.")))
+            self._a.write('/unsampled_energies', eu, record=int(iteration))
+
+    def write_mixing_statistics(self, n_accepted_matrix, n_proposed_matrix, iteration):
+        a = np.asarray(n_accepted_matrix)
+        for name, m, what in (('accepted', a, 'accepted'), ('proposed', np.asarray(n_proposed_matrix), 'proposed')):
+            self._record_variable(self._a, '/' + name, 'i4', ('iteration', 'state', 'state'), (None, a.shape[0], a.shape[0]),
+                                  (('units', 'none'), ('long_name', "%s[iteration][i][j] is the number of %s transitions between states i and j "
+                                                                    "from iteration 'iteration-1'." % (name, what))))
+            self._a.write('/' + name, m, record=int(iteration))
+
+    def write_timestamp(self, iteration):
+        import time
+        self._record_variable(self._a, '/timestamp', 'str', ('iteration',), (None,))
+        self._a.write('/timestamp', time.ctime(), record=int(iteration))
+
+    def write_last_iteration(self, iteration):
+        self._a.write('/last_iteration', [int(iteration)])
+        self._c.write('/last_iteration', [int(iteration)])
+        self.sync()
+
+    def write_online_analysis(self, iteration, **kwargs):
+        """:1167-1252: numeric arrays under online_analysis/: '<name>' (latest) and '<name>_history' (per iteration)."""
+        kwargs = dict(kwargs)
+        sams = kwargs.pop('sams_state', None)
+        if isinstance(sams, dict):
+            # sams.py:615-620: stage and t0 are stored beside logZ; the state histogram (recomputed from the stored states by the
+            # reference, :437-451) is kept as well so that a resume here does not have to re-read every iteration
+            kwargs.update(stage=sams['stage'], t0=sams['t0'], state_histogram=sams['histogram'])
+        for name, v in kwargs.items():
+            if v is None:
+                continue
+            try:
+                arr = np.atleast_1d(np.asarray(v, dtype=np.float64))
+            except (TypeError, ValueError):
+                continue
+            if arr.ndim != 1:
+                continue
+            dim = 'dim_size%d' % arr.size
+            self._record_variable(self._a, '/online_analysis/' + name, 'f8', (dim,), (arr.size,))
+            self._record_variable(self._a, '/online_analysis/%s_history' % name, 'f8', ('iteration', dim), (None, arr.size))
+            self._a.write('/online_analysis/' + name, arr)
+            self._a.write('/online_analysis/%s_history' % name, arr, record=int(iteration))
+
+    # ---- checkpoints (:1597-1737) ------------------------------------------------------------------------------
+    def write_sampler_states(self, sampler_states, iteration):
+        if iteration % self._interval != 0:
+            return False
+        frame = int(iteration) // self._interval
+        x = np.stack([np.asarray(s.positions, dtype=np.float64) for s in sampler_states])
+        R, N = x.shape[0], x.shape[1]
+        v = np.stack([np.zeros((N, 3)) if s.velocities is None else np.asarray(s.velocities, dtype=np.float64) for s in sampler_states])
+        c = self._c
+        self._record_variable(c, '/positions', 'f4', ('iteration', 'replica', 'atom', 'spatial'), (None, R, N, 3),
+                              (('units', 'nm'), ('long_name', "positions[iteration][replica][atom][spatial] is position of coordinate 'spatial' "
+                                                             "of atom 'atom' from replica 'replica' for iteration 'iteration'.")))
+        self._record_variable(c, '/velocities', 'f4', ('iteration', 'replica', 'atom', 'spatial'), (None, R, N, 3),
+                              (('units', 'nm / ps'), ('long_name', "velocities[iteration][replica][atom][spatial] is velocity of coordinate 'spatial' "
+                                                                  "of atom 'atom' from replica 'replica' for iteration 'iteration'.")))
+        c.write('/positions', x, record=frame)
+        c.write('/velocities', v, record=frame)
+        if all(s.box_vectors is not None for s in sampler_states):
+            box = np.stack([np.asarray(s.box_vectors, dtype=np.float64).reshape(3, 3) for s in sampler_states])
+            self._record_variable(c, '/box_vectors', 'f4', ('iteration', 'replica', 'spatial', 'spatial'), (None, R, 3, 3),
+                                  (('units', 'nm'), ('long_name', "box_vectors[iteration][replica][i][j] is dimension j of box vector i for replica "
+                                                                 "'replica' from iteration 'iteration-1'.")))
+            self._record_variable(c, '/volumes', 'f8', ('iteration', 'replica'), (None, R),
+                                  (('units', 'nm**3'), ('long_name', "volume[iteration][replica] is the box volume for replica 'replica' "
+                                                                    "from iteration 'iteration-1'.")))
+            c.write('/box_vectors', box, record=frame)
+            c.write('/volumes', np.abs(np.linalg.det(box)), record=frame)
+        return True

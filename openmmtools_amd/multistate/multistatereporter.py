@@ -113,7 +113,8 @@ class MultiStateReporter:
         self._files = {}
         self._meta = None
         self._open_mode = None
-        self._ref = None                  # a ReferenceStoreReader when `storage` is a netCDF4 file written by the reference
+        self._ref = None                  # a ReferenceStoreReader when `storage` is a netCDF4 file (the reference's layout)
+        self._ncw = None                  # a ReferenceStoreWriter when this reporter WRITES that layout (storage path ends in .nc)
         if open_mode is not None:
             self.open(open_mode)
 
@@ -140,10 +141,25 @@ class MultiStateReporter:
     def open(self, mode='r'):
         if mode not in ('r', 'w', 'a'):
             raise ValueError("open mode must be 'r', 'w' or 'a'")
-        from ._reference_store import is_reference_store, ReferenceStoreReader
+        from ._reference_store import is_reference_store, ReferenceStoreReader, ReferenceStoreWriter
+        nc_path = self._storage_analysis.endswith('.nc')
+        if nc_path and mode in ('w', 'a') and (not is_reference_store(self._storage_analysis)
+                                               or ReferenceStoreWriter.written_here(self._storage_analysis)):
+            # the reference's own layout (netCDF4 = HDF5 through libhdf5): <name>.nc and <name>_checkpoint.nc, multistatereporter.py:176-199;
+            # readable by the reference's reporter and analyzers.  Only files this package wrote are truncated or extended.
+            stem = self._storage_analysis[:-3]
+            ckpt = self._storage_checkpoint if self._storage_checkpoint.endswith('.nc') else stem + '_checkpoint.nc'
+            for d in (os.path.dirname(os.path.abspath(self._storage_analysis)), os.path.dirname(os.path.abspath(ckpt))):
+                os.makedirs(d, exist_ok=True)
+            self._ncw = ReferenceStoreWriter(self._storage_analysis, ckpt, mode, self._checkpoint_interval)
+            self._ref = self._ncw.reader()
+            self._checkpoint_interval = self._ref.checkpoint_interval
+            self._open_mode = mode
+            self._meta = dict(format='netcdf4')
+            return
         if is_reference_store(self._storage_analysis):
             # a store written by the reference itself (netCDF4): readable through libhdf5, never written (multistatereporter.py
-            # of the reference owns that format); a simulation resumed from it reports into a store of this package's own
+            # of the reference owns that file); a simulation resumed from it reports into a store of its own
             if mode == 'w':
                 raise IOError('{} is a netCDF4 store written by the reference: it can be read and resumed from, not overwritten'.format(self._storage_analysis))
             ckpt = self._storage_checkpoint if os.path.isfile(self._storage_checkpoint) else None
@@ -183,13 +199,20 @@ class MultiStateReporter:
         return cls._OWNED_NAMES.match(filename) is not None
 
     def close(self):
+        if self._ncw is not None:
+            self._ncw.close()
+            self._ncw = self._ref = None
+        elif self._ref is not None:
+            self._ref.close()
+            self._ref = None
         self._open_mode = None
 
     def sync(self):
-        pass                                   # every write is flushed when its file is closed
+        if self._ncw is not None:
+            self._ncw.sync()                   # (the record files are flushed when each write closes its file)
 
     def _require_write(self):
-        if self._ref is not None:
+        if self._ref is not None and self._ncw is None:
             raise IOError('a store written by the reference is read-only here')
         if self._open_mode not in ('w', 'a'):
             raise IOError('storage is not open for writing')
@@ -217,6 +240,8 @@ class MultiStateReporter:
     def initialize(self, n_replicas, n_states, n_unsampled, n_atoms):
         """Dimensions of the record variables (the reference creates them lazily on first write)."""
         self._require_write()
+        if self._ncw is not None:
+            return                             # (netCDF variables are created with their first record, like the reference's)
         self._meta = dict(n_replicas=int(n_replicas), n_states=int(n_states), n_unsampled=int(n_unsampled),
                           n_atoms=int(n_atoms), checkpoint_interval=self._checkpoint_interval,
                           format='openmmtools_amd-records-1', created=time.time())
@@ -235,6 +260,9 @@ class MultiStateReporter:
             return _RestrictedUnpickler(fh).load()
 
     def write_thermodynamic_states(self, thermodynamic_states, unsampled_states):
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_thermodynamic_states(thermodynamic_states, unsampled_states)
         self._write_object('thermodynamic_states', (list(thermodynamic_states), list(unsampled_states)))
 
     @_reference_read
@@ -242,6 +270,9 @@ class MultiStateReporter:
         return self._read_object('thermodynamic_states')
 
     def write_mcmc_moves(self, mcmc_moves):
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_mcmc_moves(mcmc_moves)
         self._write_object('mcmc_moves', list(mcmc_moves))
 
     @_reference_read
@@ -249,6 +280,9 @@ class MultiStateReporter:
         return self._read_object('mcmc_moves')
 
     def write_dict(self, name, data):
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_dict(name, data)
         self._write_object(name, dict(data))
 
     @_reference_read
@@ -258,6 +292,9 @@ class MultiStateReporter:
     # ---- per-iteration analysis data -----------------------------------------------------------------------
     def write_energies(self, energy_thermodynamic_states, energy_neighborhoods, energy_unsampled_states, iteration):
         """:865-929."""
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_energies(energy_thermodynamic_states, energy_neighborhoods, energy_unsampled_states, iteration)
         self._require_write()
         self._files['energies'].write(iteration, energy_thermodynamic_states)
         self._files['neighborhoods'].write(iteration, energy_neighborhoods)
@@ -273,6 +310,9 @@ class MultiStateReporter:
 
     def write_replica_thermodynamic_states(self, state_indices, iteration):
         """:797-815."""
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_replica_thermodynamic_states(state_indices, iteration)
         self._require_write()
         self._files['states'].write(iteration, state_indices)
 
@@ -283,6 +323,9 @@ class MultiStateReporter:
 
     def write_mixing_statistics(self, n_accepted_matrix, n_proposed_matrix, iteration):
         """:957-999 (stored as i4, like the reference)."""
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_mixing_statistics(n_accepted_matrix, n_proposed_matrix, iteration)
         self._require_write()
         self._files['accepted'].write(iteration, n_accepted_matrix)
         self._files['proposed'].write(iteration, n_proposed_matrix)
@@ -294,6 +337,9 @@ class MultiStateReporter:
 
     def write_timestamp(self, iteration):
         """:1001-1018."""
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_timestamp(iteration)
         self._require_write()
         self._files['timestamp'].write(iteration, time.time())
 
@@ -303,6 +349,9 @@ class MultiStateReporter:
 
     def write_online_data_dynamic_and_static(self, iteration, **kwargs):
         """:1167-1252 (the variables SAMS writes: logZ, log_weights)."""
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_online_analysis(iteration, **kwargs)
         self._require_write()
         for k, v in kwargs.items():
             if k in self._files and v is not None:
@@ -356,6 +405,9 @@ class MultiStateReporter:
 
     def write_last_iteration(self, iteration):
         """:1072-1092: marks the last iteration all of whose data is on disk."""
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_last_iteration(iteration)
         self._require_write()
         tmp = os.path.join(self._storage_analysis, 'last_iteration.json.tmp')
         with open(tmp, 'w') as fh:
@@ -387,6 +439,9 @@ class MultiStateReporter:
 
     def write_sampler_states(self, sampler_states, iteration):
         """:1094-1115: only on checkpoint iterations; positions / velocities as f4 (:1621-1632), box f4."""
+        if self._ncw is not None:
+            self._require_write()
+            return self._ncw.write_sampler_states(sampler_states, iteration)
         self._require_write()
         if iteration % self._checkpoint_interval != 0:
             return False

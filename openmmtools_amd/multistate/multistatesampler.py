@@ -309,8 +309,11 @@ class MultiStateSampler:
         dropped = sorted(k for k in opts if k not in accepted)
         if dropped:
             logger.warning('options of the reference store not understood by %s and ignored: %s', cls.__name__, dropped)
+        kwargs.pop('seed', None)
         moves = rep.read_mcmc_moves()
         n_iter = opts.get('number_of_iterations', 1)
+        if seed is None and getattr(rep, '_ref', None) is not None:
+            seed = rep._ref.read_seed()              # a store of the reference's layout written by this package carries its seed
         s = cls(mcmc_moves=moves, number_of_iterations=float('inf') if n_iter is None else n_iter, engine=engine,
                 seed=0xC0FFEE if seed is None else seed, comm=comm, **kwargs)
         thermo, unsampled = rep.read_thermodynamic_states()
@@ -332,6 +335,14 @@ class MultiStateSampler:
         s._reporter = None
         s._initialize_engine()
         s._mix_from_stored_energies = True
+        if continue_in is None:
+            from ._reference_store import ReferenceStoreWriter
+            if ReferenceStoreWriter.written_here(rep.filepath):
+                # this package's own store in the reference's layout: extended in place (rank 0 writes)
+                rep.close()
+                if s._comm.rank == 0:
+                    rep.open('a')
+                s._reporter = rep
         if continue_in is not None:
             new = MultiStateReporter(continue_in) if isinstance(continue_in, (str, bytes, os.PathLike)) else continue_in
             if s._comm.broadcast_object(bool(new.storage_exists()) if s._comm.rank == 0 else None):

@@ -64,7 +64,8 @@ class SAMSSampler(ReplicaExchangeSampler):
         st = data.get('sams_state')
         if st and st.get('iteration') == self._iteration:
             self._stage, self._t0 = st['stage'], st['t0']
-            self._cached_state_histogram = np.array(st['histogram'])
+            if st.get('histogram') is not None:
+                self._cached_state_histogram = np.array(st['histogram'])
 
     def _initialize_stage(self):
         """sams.py:291-296."""

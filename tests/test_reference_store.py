@@ -86,13 +86,18 @@ def _resume_and_extend(engine, tmp_path):
     # u drops by a few hundred kT of the ~2270 kT equipartition would take, and stays the same order
     assert -0.15 < sampler.energy_thermodynamic_states[0, 0] / e_before[0, 0] - 1.0 < 0.15
     assert sampler.energy_thermodynamic_states[0, 0] < e_before[0, 0]
-    # "delete reporters and load again": the continuation is a store of this package's format holding the whole history
+    # "delete reporters and load again": the continuation ('.nc' => again the reference's layout, written by this package) holds
+    # the whole history
+    sampler._reporter.close()
     del sampler
     rep = MultiStateReporter(str(tmp_path / 'continued.nc'), open_mode='r')
-    assert not rep.is_reference_store and rep.read_last_iteration() == 3
+    assert rep.is_reference_store and rep.read_last_iteration() == 3
+    with _hdf5.File(str(tmp_path / 'continued_checkpoint.nc')) as ck:
+        assert 'velocities' in ck.keys('/')[1]                               # stores written today carry them (:1795-1806)
     e, nb, eu = rep.read_energies()
     ref = MultiStateReporter(STORE, open_mode='r')
     assert e.shape == (4, 1, 20) and np.array_equal(e[:3], ref.read_energies()[0])
+    rep.close()
     again = MultiStateSampler.from_storage(str(tmp_path / 'continued.nc'), engine=engine.spawn() if hasattr(engine, 'spawn') else engine)
     assert again.iteration == 3
     v = again.sampler_states[0].velocities
@@ -122,3 +127,208 @@ def test_a_mixing_sampler_class_resumes_the_same_store(tmp_path):
 def test_resume_velocities_from_legacy_storage_on_the_device(hip_engine_factory, tmp_path):
     e = _resume_and_extend(hip_engine_factory(), tmp_path)
     assert np.isfinite(e).all()
+
+
+# ---- writing the same layout -----------------------------------------------------------------------------------------
+
+def _h5_structure(path):
+    """{object path: (datatype, dataspace, [dimension names], {attribute names})} from `h5dump -H -A`."""
+    import re
+    import shutil
+    import subprocess
+    h5dump = shutil.which('h5dump') or '/opt/conda/bin/h5dump'
+    if not os.path.exists(h5dump):
+        pytest.skip('no h5dump on this machine')
+    text = subprocess.run([h5dump, '-H', '-A', path], capture_output=True, text=True, check=True).stdout
+    out, stack, cur, in_attr, attr_depth = {}, [], None, None, 0
+    lines = text.splitlines()
+    depth_of = []
+    for i, line in enumerate(lines):
+        s = line.strip()
+        m = re.match(r'(GROUP|DATASET) "([^"]*)" \{', s)
+        if m and in_attr is None:
+            name = m.group(2)
+            stack.append(name if name != '/' else '')
+            depth_of.append(line.index(s[0]))
+            if m.group(1) == 'DATASET':
+                cur = '/'.join(stack)
+                out[cur] = dict(type=None, space=None, dims=[], attrs=set())
+            continue
+        m = re.match(r'ATTRIBUTE "([^"]*)" \{', s)
+        if m and in_attr is None:
+            in_attr, attr_depth = m.group(1), line.index(s[0])
+            owner = '/'.join(stack)
+            out.setdefault(owner or '/', dict(type=None, space=None, dims=[], attrs=set()))['attrs'].add(in_attr)
+            continue
+        if in_attr is not None:
+            if in_attr == 'DIMENSION_LIST':
+                out['/'.join(stack)]['dims'] += re.findall(r'DATASET \d+ (/\S+)', s)
+            if s == '}' and line.index('}') == attr_depth:
+                in_attr = None
+            continue
+        if s.startswith('DATATYPE') and cur == '/'.join(stack) and out[cur]['type'] is None:
+            extra = [x.strip() for x in lines[i + 1:i + 6] if 'STRSIZE' in x or 'CSET' in x] if 'H5T_STRING' in s else []
+            extra = [x if 'STRSIZE' not in x or 'VARIABLE' in x else 'STRSIZE n;' for x in extra]      # (fixed lengths differ by content)
+            out[cur]['type'] = ' '.join((s + ' ' + ' '.join(extra)).split())
+        if s.startswith('DATASPACE') and cur == '/'.join(stack) and out[cur]['space'] is None:
+            out[cur]['space'] = s
+        if s == '}' and stack and line.index('}') == depth_of[-1]:
+            stack.pop()
+            depth_of.pop()
+            cur = None
+    return out
+
+
+def _pt_run(tmp_path, n_iterations, name='run.nc', interval=2, metadata=None):
+    import sys
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from openmmtools_amd import testsystems, mcmc, unit
+    from openmmtools_amd.multistate import ParallelTemperingSampler
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions + 0.01, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=5.0 / unit.picosecond, n_steps=10,
+                                              reassign_velocities=True, splitting='V R O R V')
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iterations, engine=OracleEngine(), seed=5)
+    rep = MultiStateReporter(str(tmp_path / name), checkpoint_interval=interval)
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=400.0, n_temperatures=3,
+             unsampled_thermodynamic_states=[states.ThermodynamicState(ho.system, 500.0 * unit.kelvin)],
+             metadata=metadata)
+    return s, rep
+
+
+def test_a_run_reported_into_an_nc_path_is_a_store_of_the_references_layout(tmp_path):
+    """storage = '<name>.nc': the analysis file and '<name>_checkpoint.nc' are netCDF-4 (HDF5) files with the reference's
+    variables (multistatereporter.py:476-1115, 1597-1737); everything read back through the reader that reads the reference's own
+    files equals what the sampler held."""
+    s, rep = _pt_run(tmp_path, 4, metadata=dict(title='oscillators on a ladder', phase=dict(name='test', index=3)))
+    history = []
+    for _ in range(4):
+        s.run(1)
+        history.append((s.energy_thermodynamic_states.copy(), s._energy_unsampled_states.copy(), s.replica_thermodynamic_states.copy(),
+                        s._n_accepted_matrix.copy(), s._n_proposed_matrix.copy(), np.stack([st.positions for st in s.sampler_states])))
+    assert sorted(os.listdir(tmp_path)) == ['run.nc', 'run_checkpoint.nc']
+    r = MultiStateReporter(str(tmp_path / 'run.nc'), open_mode='r')
+    assert r.is_reference_store and r.checkpoint_interval == 2
+    assert r.read_last_iteration(last_checkpoint=False) == 4 and r.read_checkpoint_iterations() == [0, 2, 4]
+    e, nb, eu = r.read_energies()
+    st = r.read_replica_thermodynamic_states()
+    acc, prop = r.read_mixing_statistics()
+    assert e.shape == (5, 3, 3) and eu.shape == (5, 3, 1) and nb.dtype == np.int8 and nb.all()
+    for it, (E, EU, L, A, P, X) in enumerate(history, start=1):
+        assert np.array_equal(e[it], E) and np.array_equal(eu[it], EU) and np.array_equal(st[it], L)
+        assert np.array_equal(acc[it], A) and np.array_equal(prop[it], P)
+        if it % 2 == 0:
+            got = np.stack([q.positions for q in r.read_sampler_states(it)])
+            assert np.array_equal(got, X.astype(np.float32).astype(np.float64))          # f4 on disk (:1621-1632)
+    assert r.read_sampler_states(3) is None
+    thermo, unsampled = r.read_thermodynamic_states()
+    assert [round(t.temperature, 6) for t in thermo] == [300.0, round(np.sqrt(300.0 * 400.0), 6), 400.0] and unsampled[0].temperature == 500.0
+    assert thermo[1].system is thermo[0].system and unsampled[0].system is thermo[0].system      # '_Reporter__compatible_state'
+    opts = r.read_dict('options')                     # what the reference's from_storage passes to cls(**options) (:948-950)
+    assert opts == dict(locality=None, number_of_iterations=4, online_analysis_interval=200, online_analysis_minimum_iterations=200,
+                        online_analysis_target_error=0.0, replica_mixing_scheme='swap-all')
+    assert r._ref.read_seed() == 5 and r.read_mcmc_moves()[0].n_steps == 10 and len(r.read_timestamp()) == 5
+    # :1127-1139: the title is the file's global attribute, the rest of the metadata is stored nested
+    assert r.read_dict('metadata') == dict(title='oscillators on a ladder', phase=dict(name='test', index=3))
+    assert r.read_dict('metadata/phase/index') == 3
+
+
+def test_written_store_has_the_object_structure_of_a_store_the_reference_wrote(tmp_path):
+    """Same HDF5 objects as netCDF4-python produced for the reference (h5dump -H of the shipped legacy store): dimension
+    scales (IEEE_F32BE, CLASS / NAME / _Netcdf4Dimid), the record dimension unlimited, every variable with the same type, the
+    same attached dimensions in the same order and the same kind of attributes; string variables as the reference stores them
+    (fixed-length characters for the states, variable-length UTF-8 for options / moves / timestamps)."""
+    s, rep = _pt_run(tmp_path, 2, interval=1)
+    s.run()
+    rep.close()
+    ours, theirs = _h5_structure(str(tmp_path / 'run.nc')), _h5_structure(STORE)
+    for dim in ('/scalar', '/iteration', '/spatial', '/replica', '/state'):
+        assert ours[dim]['type'] == theirs[dim]['type'] == 'DATATYPE H5T_IEEE_F32BE'
+        assert {'CLASS', 'NAME', '_Netcdf4Dimid'} <= ours[dim]['attrs'] and {'CLASS', 'NAME', '_Netcdf4Dimid'} <= theirs[dim]['attrs']
+    assert 'H5S_UNLIMITED' in ours['/iteration']['space'] and 'H5S_UNLIMITED' in theirs['/iteration']['space']
+    for var in ('/energies', '/neighborhoods', '/states', '/accepted', '/proposed', '/timestamp', '/last_iteration', '/options', '/metadata',
+                '/thermodynamic_states/state0', '/thermodynamic_states/state1', '/mcmc_moves/move0'):
+        a, b = ours[var], theirs[var]
+        assert a['type'] == b['type'], (var, a['type'], b['type'])
+        da = [d if not d.startswith('/fixedL') else '/fixedL' for d in a['dims']]
+        db = [d if not d.startswith('/fixedL') else '/fixedL' for d in b['dims']]
+        assert da == db, (var, a['dims'], b['dims'])
+        assert {'DIMENSION_LIST', '_Netcdf4Coordinates'} <= a['attrs']
+        assert b['attrs'] - {'_Netcdf4Coordinates'} <= a['attrs'], (var, b['attrs'] - a['attrs'])
+    for attr in ('Conventions', 'ConventionVersion', 'DataUsedFor', 'CheckpointInterval', 'UUID', 'title', 'program', '_NCProperties'):
+        assert attr in ours['/']['attrs'] and attr in theirs['/']['attrs']
+    ck_ours, ck_theirs = _h5_structure(str(tmp_path / 'run_checkpoint.nc')), _h5_structure(CHECKPOINT)
+    for var in ('/positions', '/box_vectors', '/volumes'):
+        assert ck_ours[var]['type'] == ck_theirs[var]['type'] and ck_ours[var]['dims'] == ck_theirs[var]['dims'], var
+    assert '/velocities' in ck_ours                       # (the shipped file predates 0.21.3 and has none, :1795-1806)
+
+
+def test_resume_in_place_continues_the_same_run(tmp_path):
+    a, _ = _pt_run(tmp_path, 6, name='a.nc')
+    a.run()
+    b, repb = _pt_run(tmp_path, 4, name='b.nc')
+    b.run()
+    repb.close()
+    del b
+    import sys
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from openmmtools_amd.multistate import ParallelTemperingSampler
+    r = ParallelTemperingSampler.from_storage(str(tmp_path / 'b.nc'), engine=OracleEngine())
+    assert r.iteration == 4 and r._seed == 5
+    r.extend(2)
+    assert r.iteration == 6 and list(r.replica_thermodynamic_states) == list(a.replica_thermodynamic_states)
+    ea = MultiStateReporter(str(tmp_path / 'a.nc'), open_mode='r').read_energies()[0]
+    r._reporter.close()
+    eb = MultiStateReporter(str(tmp_path / 'b.nc'), open_mode='r').read_energies()[0]
+    assert ea.shape == eb.shape == (7, 3, 3)
+    assert np.array_equal(ea[:5], eb[:5]) and np.allclose(ea[5:], eb[5:], rtol=2e-5, atol=1e-6)     # restart from f4 checkpoints
+
+
+def test_the_references_own_files_are_never_written(tmp_path):
+    import shutil
+    shutil.copy(STORE, tmp_path / 'ref.nc')
+    shutil.copy(CHECKPOINT, tmp_path / 'ref_checkpoint.nc')
+    before = open(tmp_path / 'ref.nc', 'rb').read()
+    with pytest.raises(IOError, match='written by the reference'):
+        MultiStateReporter(str(tmp_path / 'ref.nc'), open_mode='w')
+    rep = MultiStateReporter(str(tmp_path / 'ref.nc'), open_mode='a')          # opens, read-only
+    with pytest.raises(IOError, match='read-only'):
+        rep.write_last_iteration(7)
+    rep.close()
+    assert open(tmp_path / 'ref.nc', 'rb').read() == before
+
+
+def test_sams_stage_bookkeeping_survives_a_resume_from_the_nc_layout(tmp_path):
+    """sams.py:374-393, 615-620: logZ, stage and t0 live under online_analysis/ (latest value and per-iteration history)."""
+    import sys
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from openmmtools_amd import testsystems, mcmc, unit
+    from openmmtools_amd.multistate import SAMSSampler
+    ho = testsystems.HarmonicOscillator()
+    sts = [states.ThermodynamicState(ho.system, T * unit.kelvin) for T in np.linspace(300.0, 500.0, 5)]
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=5.0 / unit.picosecond, n_steps=10,
+                                              reassign_velocities=True, splitting='V R O R V')
+
+    def make(name, n):
+        s = SAMSSampler(mcmc_moves=move, number_of_iterations=n, engine=OracleEngine(), seed=3, flatness_criteria='minimum-visits')
+        s.create(sts, [ss] * 2, storage=MultiStateReporter(str(tmp_path / name), checkpoint_interval=2))
+        return s
+    a = make('a.nc', 8)
+    a.run()
+    b = make('b.nc', 4)
+    b.run()
+    b._reporter.close()
+    r = SAMSSampler.from_storage(str(tmp_path / 'b.nc'), engine=OracleEngine())
+    assert r.iteration == 4 and r._stage == b._stage and r._t0 == b._t0 and np.array_equal(r._logZ, b._logZ)
+    assert np.array_equal(r._cached_state_histogram, b._cached_state_histogram)
+    r.extend(4)
+    assert list(r.replica_thermodynamic_states) == list(a.replica_thermodynamic_states)
+    assert np.allclose(r._logZ, a._logZ, rtol=1e-6, atol=1e-6)             # (positions restart from f4 checkpoints)
+    with _hdf5.File(str(tmp_path / 'b.nc')) as f:
+        assert set(f.keys('/online_analysis')[1]) >= {'logZ', 'logZ_history', 'log_weights_history', 'stage', 't0'}
+        assert f.read('/online_analysis/logZ_history').shape == (9, 5)

@@ -18,7 +18,7 @@ def _pt(tmp_path, n_iter, interval=2, storage=True):
     ho = testsystems.HarmonicOscillator()
     ts = states.ThermodynamicState(ho.system, 300.0)
     ss = states.SamplerState(ho.positions)
-    rep = MultiStateReporter(str(tmp_path / 'pt.nc'), checkpoint_interval=interval) if storage else None
+    rep = MultiStateReporter(str(tmp_path / 'pt_store'), checkpoint_interval=interval) if storage else None
     s = ParallelTemperingSampler(mcmc_moves=_move(), number_of_iterations=n_iter, engine=OracleEngine(), seed=11)
     s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=600.0, n_temperatures=4)
     return s, rep
@@ -31,7 +31,7 @@ def test_every_iteration_is_stored_with_reference_dtypes(tmp_path):
         s.run(1)
         seen.append((s.energy_thermodynamic_states.copy(), s.replica_thermodynamic_states.copy(),
                      s._n_accepted_matrix.copy(), s._n_proposed_matrix.copy()))
-    r = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r')
+    r = MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='r')
     e, nb, eu = r.read_energies()
     assert e.shape == (6, 4, 4) and e.dtype == np.dtype('<f8') and nb.dtype == np.dtype('i1') and eu.shape == (6, 4, 0)
     st = r.read_replica_thermodynamic_states()
@@ -53,7 +53,7 @@ def test_checkpoint_positions_are_float32_of_the_sampler_state(tmp_path):
     s, rep = _pt(tmp_path, 2, interval=1)
     s.run()
     x = np.stack([st.positions for st in s.sampler_states])
-    cp = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_sampler_states(2)
+    cp = MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='r').read_sampler_states(2)
     xs = np.stack([c.positions for c in cp])
     assert np.array_equal(xs, x.astype(np.float32).astype(np.float64))
     assert not np.array_equal(xs, x)                               # f4 on disk (multistatereporter.py:1621-1632)
@@ -66,27 +66,27 @@ def test_resume_from_storage_continues_the_same_markov_chain(tmp_path):
     s, rep = _pt(tmp_path, 6, interval=2)
     s.run(4)                                                       # iterations 1..4, checkpoint at 4
     del s
-    r = ParallelTemperingSampler.from_storage(str(tmp_path / 'pt.nc'), engine=OracleEngine())
+    r = ParallelTemperingSampler.from_storage(str(tmp_path / 'pt_store'), engine=OracleEngine())
     assert r.iteration == 4 and r.number_of_iterations == 6 and type(r) is ParallelTemperingSampler
     assert np.array_equal(r.replica_thermodynamic_states,
-                          MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_replica_thermodynamic_states(4))
+                          MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='r').read_replica_thermodynamic_states(4))
     r.run()
     assert r.iteration == 6 and r.is_completed
-    rd = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r')
+    rd = MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='r')
     e, _, _ = rd.read_energies()
     assert e.shape[0] == 7 and rd.read_last_iteration(last_checkpoint=False) == 6
     # the resumed chain is a deterministic function of the checkpoint: a second resume reproduces it bit for bit
     import shutil
-    shutil.copytree(str(tmp_path / 'pt.nc'), str(tmp_path / 'copy.nc'))
-    shutil.copytree(str(tmp_path / 'pt_checkpoint'), str(tmp_path / 'copy_checkpoint'))
-    rc = MultiStateReporter(str(tmp_path / 'copy.nc'), open_mode='a')
+    shutil.copytree(str(tmp_path / 'pt_store'), str(tmp_path / 'copy_store'))
+    shutil.copytree(str(tmp_path / 'pt_store_checkpoint'), str(tmp_path / 'copy_store_checkpoint'))
+    rc = MultiStateReporter(str(tmp_path / 'copy_store'), open_mode='a')
     rc.write_last_iteration(4)
     r2 = ParallelTemperingSampler.from_storage(rc, engine=OracleEngine())
     r2.run()
-    e2, _, _ = MultiStateReporter(str(tmp_path / 'copy.nc'), open_mode='r').read_energies()
+    e2, _, _ = MultiStateReporter(str(tmp_path / 'copy_store'), open_mode='r').read_energies()
     assert np.array_equal(e2[5:], e[5:])
     with pytest.raises(TypeError):
-        SAMSSampler.from_storage(str(tmp_path / 'pt.nc'), engine=OracleEngine())
+        SAMSSampler.from_storage(str(tmp_path / 'pt_store'), engine=OracleEngine())
 
 
 def test_sams_online_data_and_resume(tmp_path):
@@ -130,20 +130,20 @@ def test_create_equilibrate_run_resume_keeps_iteration_zero(tmp_path):
     """multistatesampler.py:588-609, 738-753: iteration 0 is reported at create() and its energies are rewritten by the
     first run() whatever happened in between; a resume before the next checkpoint must find the initial permutation."""
     s, rep = _pt(tmp_path, 4, interval=10)
-    r0 = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r')
+    r0 = MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='r')
     assert r0.read_last_iteration(last_checkpoint=False) == 0            # on disk right after create()
     assert r0.read_replica_thermodynamic_states(0).tolist() == [0, 1, 2, 3]
     s.equilibrate(2)
     labels_after_equil = s.replica_thermodynamic_states.copy()
     s.run(3)                                                             # no checkpoint after iteration 0 (interval 10)
-    rd = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r')
+    rd = MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='r')
     e, nb, _ = rd.read_energies()
     assert np.all(nb[0] == 1) and np.isfinite(e[0]).all() and np.abs(e[0]).sum() > 0
     assert np.array_equal(rd.read_replica_thermodynamic_states(0), labels_after_equil)
     x0 = np.stack([c.positions for c in rd.read_sampler_states(0)])
     assert np.abs(x0).sum() > 0                                          # the equilibrated positions, not the initial zeros
     del s
-    r = ParallelTemperingSampler.from_storage(str(tmp_path / 'pt.nc'), engine=OracleEngine())
+    r = ParallelTemperingSampler.from_storage(str(tmp_path / 'pt_store'), engine=OracleEngine())
     assert r.iteration == 0
     assert np.array_equal(r.replica_thermodynamic_states, labels_after_equil)
     assert sorted(r.replica_thermodynamic_states.tolist()) == [0, 1, 2, 3]
@@ -173,10 +173,10 @@ def test_storage_objects_are_unpickled_with_a_whitelist(tmp_path):
     import pickle, subprocess
     s, rep = _pt(tmp_path, 2)
     s.run(1)
-    with open(str(tmp_path / 'pt.nc' / 'metadata.pkl'), 'wb') as fh:
+    with open(str(tmp_path / 'pt_store' / 'metadata.pkl'), 'wb') as fh:
         pickle.dump(subprocess.Popen, fh)                               # a class reference the format never stores
     with pytest.raises(pickle.UnpicklingError):
-        MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_dict('metadata')
+        MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='r').read_dict('metadata')
     # from protocol 4 on STACK_GLOBAL hands find_class a dotted name that getattr walks ('os.system' through any
     # module of this package that imports os); and a whole-numpy whitelist admits exec gadgets
     marker = tmp_path / 'pwned'
@@ -197,14 +197,14 @@ def test_storage_objects_are_unpickled_with_a_whitelist(tmp_path):
         stack_global('builtins', 'eval', '1'),
     ]
     for payload in payloads:
-        with open(str(tmp_path / 'pt.nc' / 'metadata.pkl'), 'wb') as fh:
+        with open(str(tmp_path / 'pt_store' / 'metadata.pkl'), 'wb') as fh:
             fh.write(payload)
         with pytest.raises(pickle.UnpicklingError):
-            MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='r').read_dict('metadata')
+            MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='r').read_dict('metadata')
     assert not marker.exists()
     # what the format does store still loads: this package's classes, numpy arrays and scalars, builtin containers
     import numpy as np
-    rep2 = MultiStateReporter(str(tmp_path / 'pt.nc'), open_mode='a')
+    rep2 = MultiStateReporter(str(tmp_path / 'pt_store'), open_mode='a')
     rep2.write_dict('metadata', dict(a=np.arange(3.0), b=np.float64(2.5), c=[1, (2, 3)], d={'x': None}))
     back = rep2.read_dict('metadata')
     assert np.array_equal(back['a'], np.arange(3.0)) and back['b'] == 2.5 and back['c'] == [1, (2, 3)]
@@ -222,12 +222,12 @@ def test_a_users_subclass_resumes_through_its_own_from_storage(tmp_path):
     ho = testsystems.HarmonicOscillator()
     ts_ = states.ThermodynamicState(ho.system, 300.0)
     ss = states.SamplerState(ho.positions)
-    rep = MultiStateReporter(str(tmp_path / 'u.nc'), checkpoint_interval=1)
+    rep = MultiStateReporter(str(tmp_path / 'u_store'), checkpoint_interval=1)
     s = _UserSampler(mcmc_moves=_move(), number_of_iterations=4, engine=OracleEngine(), seed=11)
     s.create(ts_, [ss], storage=rep, min_temperature=300.0, max_temperature=600.0, n_temperatures=3)
     s.run(2)
-    r = _UserSampler.from_storage(str(tmp_path / 'u.nc'), engine=OracleEngine())
+    r = _UserSampler.from_storage(str(tmp_path / 'u_store'), engine=OracleEngine())
     assert type(r) is _UserSampler and r.iteration == 2
     r.run(1)
     with pytest.raises(TypeError, match='resume with that class'):
-        ParallelTemperingSampler.from_storage(str(tmp_path / 'u.nc'), engine=OracleEngine())
+        ParallelTemperingSampler.from_storage(str(tmp_path / 'u_store'), engine=OracleEngine())
