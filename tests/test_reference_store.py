@@ -193,7 +193,7 @@ def _pt_run(tmp_path, n_iterations, name='run.nc', interval=2, metadata=None):
     s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iterations, engine=OracleEngine(), seed=5)
     rep = MultiStateReporter(str(tmp_path / name), checkpoint_interval=interval)
     s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=400.0, n_temperatures=3,
-             unsampled_thermodynamic_states=[states.ThermodynamicState(ho.system, 500.0 * unit.kelvin)],
+             unsampled_thermodynamic_states=[states.ThermodynamicState(ho.system, T * unit.kelvin) for T in (250.0, 500.0)],
              metadata=metadata)
     return s, rep
 
@@ -215,7 +215,7 @@ def test_a_run_reported_into_an_nc_path_is_a_store_of_the_references_layout(tmp_
     e, nb, eu = r.read_energies()
     st = r.read_replica_thermodynamic_states()
     acc, prop = r.read_mixing_statistics()
-    assert e.shape == (5, 3, 3) and eu.shape == (5, 3, 1) and nb.dtype == np.int8 and nb.all()
+    assert e.shape == (5, 3, 3) and eu.shape == (5, 3, 2) and nb.dtype == np.int8 and nb.all()
     for it, (E, EU, L, A, P, X) in enumerate(history, start=1):
         assert np.array_equal(e[it], E) and np.array_equal(eu[it], EU) and np.array_equal(st[it], L)
         assert np.array_equal(acc[it], A) and np.array_equal(prop[it], P)
@@ -224,7 +224,7 @@ def test_a_run_reported_into_an_nc_path_is_a_store_of_the_references_layout(tmp_
             assert np.array_equal(got, X.astype(np.float32).astype(np.float64))          # f4 on disk (:1621-1632)
     assert r.read_sampler_states(3) is None
     thermo, unsampled = r.read_thermodynamic_states()
-    assert [round(t.temperature, 6) for t in thermo] == [300.0, round(np.sqrt(300.0 * 400.0), 6), 400.0] and unsampled[0].temperature == 500.0
+    assert [round(t.temperature, 6) for t in thermo] == [300.0, round(np.sqrt(300.0 * 400.0), 6), 400.0] and [u.temperature for u in unsampled] == [250.0, 500.0]
     assert thermo[1].system is thermo[0].system and unsampled[0].system is thermo[0].system      # '_Reporter__compatible_state'
     opts = r.read_dict('options')                     # what the reference's from_storage passes to cls(**options) (:948-950)
     assert opts == dict(locality=None, number_of_iterations=4, online_analysis_interval=200, online_analysis_minimum_iterations=200,
@@ -332,3 +332,20 @@ def test_sams_stage_bookkeeping_survives_a_resume_from_the_nc_layout(tmp_path):
     with _hdf5.File(str(tmp_path / 'b.nc')) as f:
         assert set(f.keys('/online_analysis')[1]) >= {'logZ', 'logZ_history', 'log_weights_history', 'stage', 't0'}
         assert f.read('/online_analysis/logZ_history').shape == (9, 5)
+
+
+def test_analyzer_works_on_the_nc_layout(tmp_path):
+    """The analyzer reads energies / states / options through the reporter interface: the free energy between the ladder's end
+    states from a store in the reference's layout equals the one from the record container of the same run, and sits within
+    6 sigma of -3/2 ln(T_hi / T_lo)."""
+    from openmmtools_amd.multistate import analysis as an
+    out = []
+    for name in ('run.nc', 'run_records'):
+        s, rep = _pt_run(tmp_path, 150, name=name, interval=50)
+        s.run()
+        D, dD = an.MultiStateSamplerAnalyzer(rep).get_free_energy()
+        out.append((D, dD))
+    (Da, dDa), (Db, dDb) = out
+    assert np.allclose(Da, Db, rtol=0, atol=1e-12) and np.allclose(dDa, dDb, rtol=0, atol=1e-12)
+    exact = -1.5 * np.log(500.0 / 250.0)                 # between the two unsampled end states (multistateanalyzer.py:1517-1536)
+    assert Da.shape == (5, 5) and abs(Da[0, -1] - exact) < 6.0 * dDa[0, -1] + 0.05
