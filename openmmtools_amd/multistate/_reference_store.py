@@ -321,6 +321,17 @@ class ReferenceStoreWriter:
                 self._interval = int(np.asarray(ci).reshape(-1)[0])
 
     @staticmethod
+    def can_store(thermodynamic_states, unsampled_states, mcmc_moves):
+        """None when this layout can hold the objects, else what it cannot (compound alchemical states, other moves)."""
+        for s in list(thermodynamic_states) + list(unsampled_states):
+            if type(s).__name__ != 'ThermodynamicState':
+                return type(s).__name__
+        for m in mcmc_moves:
+            if type(m).__name__ not in ('LangevinSplittingDynamicsMove', 'LangevinDynamicsMove'):
+                return type(m).__name__
+        return None
+
+    @staticmethod
     def written_here(path):
         """Only stores this writer made are extended in place; one written by the reference is read and continued elsewhere."""
         try:

@@ -15,12 +15,16 @@ on resume) plus one ``.npz`` per checkpoint; variable names, dtypes and shapes a
 caller's rank 0 writes (the reference: ``@mpiplus.on_single_node(0)``).
 """
 import json
+import logging
 import os
 import pickle
 import re
 import time
 
 import numpy as np
+
+
+logger = logging.getLogger(__name__)
 
 
 class _RecordFile:
@@ -104,7 +108,7 @@ class MultiStateReporter:
     ``<name>_checkpoint.nc``, :176-199)."""
 
     def __init__(self, storage, open_mode=None, checkpoint_interval=50, checkpoint_storage=None,
-                 analysis_particle_indices=()):
+                 analysis_particle_indices=(), layout='auto'):
         self._storage_analysis = str(storage)
         stem = self._storage_analysis[:-3] if self._storage_analysis.endswith('.nc') else self._storage_analysis
         self._storage_checkpoint = str(checkpoint_storage) if checkpoint_storage else stem + '_checkpoint'
@@ -115,6 +119,11 @@ class MultiStateReporter:
         self._open_mode = None
         self._ref = None                  # a ReferenceStoreReader when `storage` is a netCDF4 file (the reference's layout)
         self._ncw = None                  # a ReferenceStoreWriter when this reporter WRITES that layout (storage path ends in .nc)
+        # 'auto': the reference's netCDF4 layout for paths ending in .nc when libhdf5 is there, else the record container;
+        # 'records' / 'netcdf4' force one (the sampler picks 'records' for states the netCDF4 layout cannot hold)
+        if layout not in ('auto', 'records', 'netcdf4'):
+            raise ValueError("layout must be 'auto', 'records' or 'netcdf4'")
+        self.layout = layout
         if open_mode is not None:
             self.open(open_mode)
 
@@ -142,7 +151,14 @@ class MultiStateReporter:
         if mode not in ('r', 'w', 'a'):
             raise ValueError("open mode must be 'r', 'w' or 'a'")
         from ._reference_store import is_reference_store, ReferenceStoreReader, ReferenceStoreWriter
-        nc_path = self._storage_analysis.endswith('.nc')
+        nc_path = self._storage_analysis.endswith('.nc') and self.layout != 'records' and not os.path.isdir(self._storage_analysis)
+        if self.layout == 'netcdf4' and not self._storage_analysis.endswith('.nc'):
+            raise ValueError("the netCDF4 layout needs a storage path ending in '.nc'")
+        if nc_path and mode in ('w', 'a') and self.layout == 'auto':
+            from . import _netcdf4_write
+            if not _netcdf4_write.available():
+                logger.warning('no libhdf5 / libhdf5_hl: %s is written as a record-file container, not as netCDF4', self._storage_analysis)
+                nc_path = False
         if nc_path and mode in ('w', 'a') and (not is_reference_store(self._storage_analysis)
                                                or ReferenceStoreWriter.written_here(self._storage_analysis)):
             # the reference's own layout (netCDF4 = HDF5 through libhdf5): <name>.nc and <name>_checkpoint.nc, multistatereporter.py:176-199;

@@ -218,6 +218,13 @@ class MultiStateSampler:
         if self._comm.rank != 0:
             return
         if not rep.is_open() or rep._open_mode == 'r':
+            if getattr(rep, 'layout', None) == 'auto' and str(rep.filepath).endswith('.nc'):
+                from ._reference_store import ReferenceStoreWriter
+                what = ReferenceStoreWriter.can_store(self._thermodynamic_states, self._unsampled_states, self._mcmc_moves)
+                if what is not None:
+                    logger.warning('%s cannot be held by the reference\'s netCDF4 layout: %s is written as a record-file container',
+                                   what, rep.filepath)
+                    rep.layout = 'records'
             rep.open('w')
         rep.initialize(self.n_replicas, self.n_states, len(self._unsampled_states), self._thermodynamic_states[0].n_particles)
         rep.write_thermodynamic_states(self._thermodynamic_states, self._unsampled_states)

@@ -349,3 +349,31 @@ def test_analyzer_works_on_the_nc_layout(tmp_path):
     assert np.allclose(Da, Db, rtol=0, atol=1e-12) and np.allclose(dDa, dDb, rtol=0, atol=1e-12)
     exact = -1.5 * np.log(500.0 / 250.0)                 # between the two unsampled end states (multistateanalyzer.py:1517-1536)
     assert Da.shape == (5, 5) and abs(Da[0, -1] - exact) < 6.0 * dDa[0, -1] + 0.05
+
+
+def test_states_the_layout_cannot_hold_fall_back_to_the_record_container(tmp_path, caplog):
+    """Compound (alchemical) states have no counterpart in what this package writes of the netCDF4 layout: the same '.nc' path
+    then becomes a record-file container (a directory), with a warning; layout='records' asks for that explicitly."""
+    import logging
+    import sys
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from oracle.forcefield import ForceFieldOracle
+    from openmmtools_amd import testsystems, mcmc, unit, alchemy
+    lj = testsystems.LennardJonesFluid(nparticles=64)
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(4))
+    asys = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, region)
+    ths = [states.CompoundThermodynamicState(states.ThermodynamicState(asys, 120.0 * unit.kelvin),
+                                             [states.AlchemicalState(lambda_sterics=l, lambda_electrostatics=1.0)]) for l in (1.0, 0.5)]
+    ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=2, reassign_velocities=True, splitting='V R O R V')
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=1, engine=OracleEngine(ForceFieldOracle), seed=1)
+    with caplog.at_level(logging.WARNING):
+        s.create(ths, [ss], storage=str(tmp_path / 'alch.nc'))
+    assert any('record-file container' in r.getMessage() for r in caplog.records)
+    s.run()
+    assert os.path.isdir(tmp_path / 'alch.nc') and os.path.exists(tmp_path / 'alch.nc' / 'meta.json')
+    r = MultiStateReporter(str(tmp_path / 'alch.nc'), open_mode='r')
+    assert not r.is_reference_store and r.read_energies()[0].shape == (2, 2, 2)
+    forced = MultiStateReporter(str(tmp_path / 'plain.nc'), open_mode='w', layout='records')
+    assert os.path.isdir(tmp_path / 'plain.nc') and not forced.is_reference_store
