@@ -136,3 +136,11 @@ class GeodesicBAOABIntegrator(LangevinIntegrator):
     def __init__(self, *args, K_r=2, **kwargs):
         kwargs['splitting'] = " ".join(["V"] + ["R"] * K_r + ["O"] + ["R"] * K_r + ["V"])   # :2237-2238
         super().__init__(*args, **kwargs)
+
+
+class GHMCIntegrator(LangevinIntegrator):
+    """integrators.py:2242-2289: generalized hybrid Monte Carlo = the Metropolized splitting "O { V R V } O"."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs['splitting'] = "O { V R V } O"   # integrators.py:2286
+        super().__init__(*args, **kwargs)

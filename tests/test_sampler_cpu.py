@@ -110,6 +110,8 @@ def test_integrator_splitting_parsing():
     with pytest.raises(ValueError):
         integrators.LangevinIntegrator(splitting='V R X')
     g = integrators.GeodesicBAOABIntegrator(K_r=2)
+    ghmc = integrators.GHMCIntegrator()                                   # integrators.py:2242-2289
+    assert ghmc._splitting == 'O { V R V } O' and ghmc.is_metropolized and ghmc.measure_shadow_work
     assert g.splitting == 'V R R O R R V'
     assert integrators.BAOABIntegrator().splitting == 'V R O R V'
     assert integrators.VVVRIntegrator().splitting == 'O V R V O'
