@@ -12,7 +12,7 @@ int remd_nb_required_epart(remd_ctx* h);
 void remd_free_nonbonded(remd_ctx* h);
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
 void remd_nb_tune_resolve(remd_ctx* h);
-static int remd_check_device_flags(remd_ctx* h, const char* where);
+static int remd_check_device_flags(remd_ctx* h, const char* where, bool may_retry = false);
 void remd_free_constraints(remd_ctx* h);
 
 static std::mutex g_err_mutex;
@@ -268,7 +268,10 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     REMD_CHECK(h, hipMemcpy(h->d_box, hb.data(), sizeof(float) * 4 * R_local, hipMemcpyHostToDevice));
     h->box_version++;
     h->forces_valid = false; h->force_zeroed = false;
-    if (h->nb_method == REMD_NB_PME) { int rc = remd_pme_setup(h); if (rc) return rc; }
+    h->cbins_ready = false;              // (bins a chain filled for positions that are gone)
+    // (the mesh buffers follow the replica count; a call that only replaces coordinates keeps them -- one handle per compatibility
+    // group re-enters here every iteration, multistate/_engine_pool.py)
+    if (h->nb_method == REMD_NB_PME && (realloc || !h->pme)) { int rc = remd_pme_setup(h); if (rc) return rc; }
     return remd_set_labels(h, labels);
 }
 
@@ -515,17 +518,21 @@ int remd_compute_energies(remd_handle h, double* d_ukl_rows, double* ukl_host, d
 {
     if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return remd_fail(h, -1, "remd_compute_energies: not set up");
     hipSetDevice(h->device);
-    hipEventRecord(h->ev0, h->stream);
-    int rc;
-    if ((rc = remd_compute_forces(h, true))) return rc;
-    double* rows = d_ukl_rows ? d_ukl_rows : h->d_ukl + (size_t)h->r_begin * h->K;
-    if ((rc = remd_assemble_ukl(h, rows))) return rc;
-    hipEventRecord(h->ev1, h->stream);
-    if (ukl_host) REMD_CHECK(h, hipMemcpyAsync(ukl_host, rows, sizeof(double) * (size_t)h->R * h->K, hipMemcpyDeviceToHost, h->stream));
-    if (potential_host) REMD_CHECK(h, hipMemcpyAsync(potential_host, h->d_potential, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
-    REMD_CHECK(h, hipStreamSynchronize(h->stream));
-    float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_energy = ms;
-    return remd_check_device_flags(h, "remd_compute_energies");
+    for (int attempt = 0;; ++attempt) {
+        hipEventRecord(h->ev0, h->stream);
+        int rc;
+        h->forces_valid = false;
+        if ((rc = remd_compute_forces(h, true))) return rc;
+        double* rows = d_ukl_rows ? d_ukl_rows : h->d_ukl + (size_t)h->r_begin * h->K;
+        if ((rc = remd_assemble_ukl(h, rows))) return rc;
+        hipEventRecord(h->ev1, h->stream);
+        if (ukl_host) REMD_CHECK(h, hipMemcpyAsync(ukl_host, rows, sizeof(double) * (size_t)h->R * h->K, hipMemcpyDeviceToHost, h->stream));
+        if (potential_host) REMD_CHECK(h, hipMemcpyAsync(potential_host, h->d_potential, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
+        REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_energy = ms;
+        rc = remd_check_device_flags(h, "remd_compute_energies", attempt == 0);
+        if (rc != 1) return rc;                          // 1: the failed mechanism is off now, evaluate again
+    }
 }
 
 static int ensure_mix_buffers(remd_ctx* h, int R, int K)
@@ -648,24 +655,31 @@ int remd_get_forces(remd_handle h, double* f)
 {
     if (!h || h->R <= 0 || !f) return remd_fail(h, -1, "remd_get_forces: bad arguments");
     hipSetDevice(h->device);
-    int rc = remd_compute_forces(h, false); if (rc) return rc;
-    const size_t n = (size_t)h->R * 3 * h->Npad;
-    std::vector<long long> buf(n);
-    REMD_CHECK(h, hipMemcpyAsync(buf.data(), h->d_force, sizeof(long long) * n, hipMemcpyDeviceToHost, h->stream));
-    REMD_CHECK(h, hipStreamSynchronize(h->stream));
-    for (int r = 0; r < h->R; ++r) for (int i = 0; i < h->N; ++i) for (int k = 0; k < 3; ++k)
-        f[((size_t)r * h->N + i) * 3 + k] = (double)buf[((size_t)r * 3 + k) * h->Npad + i] / REMD_FORCE_SCALE;
-    return remd_check_device_flags(h, "remd_get_forces");
+    for (int attempt = 0;; ++attempt) {
+        h->forces_valid = false;
+        int rc = remd_compute_forces(h, false); if (rc) return rc;
+        const size_t n = (size_t)h->R * 3 * h->Npad;
+        std::vector<long long> buf(n);
+        REMD_CHECK(h, hipMemcpyAsync(buf.data(), h->d_force, sizeof(long long) * n, hipMemcpyDeviceToHost, h->stream));
+        REMD_CHECK(h, hipStreamSynchronize(h->stream));
+        for (int r = 0; r < h->R; ++r) for (int i = 0; i < h->N; ++i) for (int k = 0; k < 3; ++k)
+            f[((size_t)r * h->N + i) * 3 + k] = (double)buf[((size_t)r * 3 + k) * h->Npad + i] / REMD_FORCE_SCALE;
+        rc = remd_check_device_flags(h, "remd_get_forces", attempt == 0);
+        if (rc != 1) return rc;
+    }
 }
 
 // the device reports what it cannot raise: a cross-stream poll or the chain's barrier that ran out, an overfull PME bin
 // (d_sync[2], sticky).  Called behind the stream synchronisation of every entry point that evaluates forces.
-static int remd_check_device_flags(remd_ctx* h, const char* where)
+static int remd_check_device_flags(remd_ctx* h, const char* where, bool may_retry)
 {
+    // may_retry: the caller's work changed nothing but its outputs (an energy / force evaluation): after the failed mechanism is
+    // switched off it is simply run again (return 1); otherwise the flag is an error
     unsigned int f = 0;
     REMD_CHECK(h, hipMemcpy(&f, h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost));
-    if (f) return remd_recover_device_flag(h, f, where, false);
-    return 0;
+    if (!f) return 0;
+    const int rc = remd_recover_device_flag(h, f, where, may_retry);
+    return rc ? rc : 1;
 }
 
 int remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inverse)
