@@ -232,6 +232,13 @@ class ReferenceStoreReader:
         """:670-705, 1739-1815: the checkpoint frame of ``iteration`` (None off the checkpoint interval); zero velocities where
         the file carries none."""
         from .. import states
+        if analysis_particles_only:
+            # :696-705: the subset the analysis file carries for every iteration
+            if '/positions' not in self._a:
+                raise ValueError('No particles were flagged for special analysis! No such trajectory would have been written!')
+            x = self._a.read('/positions')[iteration].astype(np.float64)
+            v = self._a.read('/velocities')[iteration].astype(np.float64) if '/velocities' in self._a else np.zeros_like(x)
+            return [states.SamplerState(x[r], velocities=v[r]) for r in range(x.shape[0])]
         if self._c is None:
             raise IOError('checkpoint file %s is missing' % self._cpath)
         if iteration % self._checkpoint_interval != 0:
@@ -288,7 +295,7 @@ class ReferenceStoreWriter:
     ``ReferenceStoreReader`` understands: plain ThermodynamicStates (temperature, pressure) on Systems of the hot-path
     forces, Langevin moves, the samplers' options; anything else raises NotImplementedError naming it."""
 
-    def __init__(self, analysis_path, checkpoint_path, mode, checkpoint_interval, title=None):
+    def __init__(self, analysis_path, checkpoint_path, mode, checkpoint_interval, title=None, analysis_particle_indices=()):
         from . import _netcdf4_write as nw
         self._nw = nw
         self._path, self._cpath = str(analysis_path), str(checkpoint_path)
@@ -313,12 +320,26 @@ class ReferenceStoreWriter:
                 f.set_attr('/', 'CheckpointInterval', np.array([self._interval], dtype=np.int64))
                 f.set_attr('/', 'UUID', uid)                                        # :346-361: the two files carry one UUID
                 f.set_attr('/', 'title', title)
+                f.set_attr('/', 'PositionInterval', np.array([1], dtype=np.int64))       # :450-451
+                f.set_attr('/', 'VelocityInterval', np.array([1], dtype=np.int64))
                 f.create_variable('/last_iteration', 'i8', ('scalar',))
                 f.write('/last_iteration', [0])
+            # :369-381: the reference's open() creates this variable when it is missing -- which fails on a file opened for
+            # reading, so it has to be there from the start (no analysis particles = an unlimited dimension of length 0)
+            idx = np.asarray(sorted(int(i) for i in analysis_particle_indices), dtype=np.int64)
+            self._a.create_dimension('/analysis_particles', len(idx) if len(idx) else None)
+            self._a.create_variable('/analysis_particle_indices', 'i8', ('analysis_particles',))
+            self._a.set_attr('/analysis_particle_indices', 'long_name', 'analysis_particle_indices[analysis_particles] is the indices of the '
+                             'particles with extra information stored about them in theanalysis file.')
+            if len(idx):
+                self._a.write('/analysis_particle_indices', idx)
+            self._analysis_particles = tuple(idx.tolist())
         else:
             ci = self._a.attr('CheckpointInterval')
             if ci is not None:
                 self._interval = int(np.asarray(ci).reshape(-1)[0])
+            self._analysis_particles = tuple(int(i) for i in np.asarray(self._a.read('/analysis_particle_indices')).reshape(-1)) \
+                if '/analysis_particle_indices' in self._a else ()
 
     @staticmethod
     def can_store(thermodynamic_states, unsampled_states, mcmc_moves):
@@ -529,6 +550,17 @@ class ReferenceStoreWriter:
 
     # ---- checkpoints (:1597-1737) ------------------------------------------------------------------------------
     def write_sampler_states(self, sampler_states, iteration):
+        if self._analysis_particles:
+            # :722-741: the chosen particles go to the ANALYSIS file every iteration (one frame per iteration there)
+            sel = list(self._analysis_particles)
+            xs = np.stack([np.asarray(s.positions, dtype=np.float64)[sel] for s in sampler_states])
+            vs = np.stack([np.zeros((len(sel), 3)) if s.velocities is None else np.asarray(s.velocities, dtype=np.float64)[sel] for s in sampler_states])
+            R = xs.shape[0]
+            a = self._a
+            self._record_variable(a, '/positions', 'f4', ('iteration', 'replica', 'analysis_particles', 'spatial'), (None, R, None, 3), (('units', 'nm'),))
+            self._record_variable(a, '/velocities', 'f4', ('iteration', 'replica', 'analysis_particles', 'spatial'), (None, R, None, 3), (('units', 'nm / ps'),))
+            a.write('/positions', xs, record=int(iteration))
+            a.write('/velocities', vs, record=int(iteration))
         if iteration % self._interval != 0:
             return False
         frame = int(iteration) // self._interval

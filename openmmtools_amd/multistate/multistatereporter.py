@@ -167,7 +167,8 @@ class MultiStateReporter:
             ckpt = self._storage_checkpoint if self._storage_checkpoint.endswith('.nc') else stem + '_checkpoint.nc'
             for d in (os.path.dirname(os.path.abspath(self._storage_analysis)), os.path.dirname(os.path.abspath(ckpt))):
                 os.makedirs(d, exist_ok=True)
-            self._ncw = ReferenceStoreWriter(self._storage_analysis, ckpt, mode, self._checkpoint_interval)
+            self._ncw = ReferenceStoreWriter(self._storage_analysis, ckpt, mode, self._checkpoint_interval,
+                                             analysis_particle_indices=self._analysis_particle_indices)
             self._ref = self._ncw.reader()
             self._checkpoint_interval = self._ref.checkpoint_interval
             self._open_mode = mode
@@ -486,15 +487,18 @@ class MultiStateReporter:
 
     # ---- the sampler's hook: what MultiStateSampler._report_iteration does (multistatesampler.py:1189-1222) --
     def write_iteration(self, sampler):
+        # positions are needed on checkpoint iterations -- and at every iteration when particles are flagged for the analysis file
+        # (multistatereporter.py:722-741; the netCDF4 layout only)
+        every = bool(self._analysis_particle_indices) and str(self._storage_analysis).endswith('.nc') and self.layout != 'records'
         if getattr(sampler, '_comm', None) is not None and sampler._comm.rank != 0:
-            if sampler._iteration % self._checkpoint_interval == 0:
+            if every or sampler._iteration % self._checkpoint_interval == 0:
                 sampler._gather_sampler_states()          # collective: every rank takes part
             return
         it = sampler._iteration
         if self._meta is None:
             self.initialize(sampler.n_replicas, sampler.n_states, len(sampler._unsampled_states),
                             sampler._thermodynamic_states[0].n_particles)
-        if it % self._checkpoint_interval == 0:
+        if every or it % self._checkpoint_interval == 0:
             sampler._gather_sampler_states()
             self.write_sampler_states(sampler._sampler_states, it)                                  # :1217
         self.write_replica_thermodynamic_states(sampler._replica_thermodynamic_states, it)          # :1218

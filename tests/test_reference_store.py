@@ -377,3 +377,38 @@ def test_states_the_layout_cannot_hold_fall_back_to_the_record_container(tmp_pat
     assert not r.is_reference_store and r.read_energies()[0].shape == (2, 2, 2)
     forced = MultiStateReporter(str(tmp_path / 'plain.nc'), open_mode='w', layout='records')
     assert os.path.isdir(tmp_path / 'plain.nc') and not forced.is_reference_store
+
+
+def test_analysis_particles_are_stored_every_iteration_in_the_analysis_file(tmp_path):
+    """multistatereporter.py:369-388, 722-741: 'analysis_particle_indices' is a variable of every store (the reference's open()
+    would otherwise try to create it, which fails on a file opened for reading); the flagged particles' positions and velocities go
+    to the analysis file at EVERY iteration, the full frames to the checkpoint file on the checkpoint interval only."""
+    import sys
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from oracle.forcefield import ForceFieldOracle
+    from openmmtools_amd import testsystems, mcmc, unit
+    from openmmtools_amd.multistate import ParallelTemperingSampler
+    lj = testsystems.LennardJonesFluid(nparticles=27)
+    ts = states.ThermodynamicState(lj.system, 120.0 * unit.kelvin)
+    ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=3, reassign_velocities=True, splitting='V R O R V')
+    rep = MultiStateReporter(str(tmp_path / 'p.nc'), checkpoint_interval=2, analysis_particle_indices=(3, 5, 11))
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=3, engine=OracleEngine(ForceFieldOracle), seed=2)
+    s.create(ts, [ss], storage=rep, min_temperature=120.0, max_temperature=150.0, n_temperatures=2)
+    s.run()
+    x = np.stack([st.positions for st in s.sampler_states])
+    rep.close()
+    with _hdf5.File(str(tmp_path / 'p.nc')) as f:
+        assert list(f.read('/analysis_particle_indices')) == [3, 5, 11]
+        assert f.read('/positions').shape == (4, 2, 3, 3) and f.read('/velocities').shape == (4, 2, 3, 3)
+    with _hdf5.File(str(tmp_path / 'p_checkpoint.nc')) as f:
+        assert f.read('/positions').shape == (2, 2, 27, 3)                      # iterations 0 and 2
+    r = MultiStateReporter(str(tmp_path / 'p.nc'), open_mode='r')
+    sub = r.read_sampler_states(3, analysis_particles_only=True)
+    assert np.array_equal(np.stack([q.positions for q in sub]), x[:, [3, 5, 11]].astype(np.float32).astype(np.float64))
+    assert r.read_sampler_states(3) is None
+    plain = MultiStateReporter(str(tmp_path / 'run.nc'), open_mode='w')
+    plain.close()
+    with _hdf5.File(str(tmp_path / 'run.nc')) as f:                             # none flagged: the variable exists, empty
+        assert f.shape('/analysis_particle_indices') == (0,)
