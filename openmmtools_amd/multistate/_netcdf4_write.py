@@ -95,6 +95,12 @@ def _g(name):
     return _hid.in_dll(_lib, name).value
 
 
+def _ck(rc, what):
+    if rc < 0:
+        raise IOError('HDF5: %s failed' % what)
+    return rc
+
+
 class NetCDF4File(_hdf5.File):
     """A netCDF-4 file opened for writing ('w': create / truncate, 'a': extend an existing one).  Dimensions and variables are
     addressed by '/'-separated paths; a variable's dimensions are looked up in its own group, then in the root."""
@@ -160,7 +166,7 @@ class NetCDF4File(_hdf5.File):
         return self._open[path]
 
     def flush(self):
-        self._lib.H5Fflush(self._fid, 1)       # H5F_SCOPE_GLOBAL
+        _ck(self._lib.H5Fflush(self._fid, 1), 'H5Fflush')       # H5F_SCOPE_GLOBAL
 
     def close(self):
         for did in self._open.values():
@@ -205,7 +211,7 @@ class NetCDF4File(_hdf5.File):
         lib.H5Sclose(sid)
         if did < 0:
             raise IOError('cannot create dimension %s' % path)
-        self._hl.H5DSset_scale(did, ('This is a netCDF dimension but not a netCDF variable.%10d' % n).encode())
+        _ck(self._hl.H5DSset_scale(did, ('This is a netCDF dimension but not a netCDF variable.%10d' % n).encode()), 'H5DSset_scale(%s)' % path)
         self._open[path] = did
         dimid = len(self._dims)
         self._dims[path] = (None if size is None else n, dimid)
@@ -244,7 +250,7 @@ class NetCDF4File(_hdf5.File):
         if did < 0:
             raise IOError('cannot create variable %s' % path)
         for k, d in enumerate(dpaths):
-            self._hl.H5DSattach_scale(did, self._dataset(d), k)
+            _ck(self._hl.H5DSattach_scale(did, self._dataset(d), k), 'H5DSattach_scale(%s, %s)' % (path, d))
         self._set_numeric_attr(did, '_Netcdf4Coordinates', np.array([self._dims[d][1] for d in dpaths], dtype=np.int32))
         self._open[path] = did
         self._vars[path] = (kind, dpaths)
@@ -290,14 +296,14 @@ class NetCDF4File(_hdf5.File):
         if record is not None:
             if record >= cur[0]:
                 cur[0] = record + 1
-                lib.H5Dset_extent(did, (_hsize * len(cur))(*cur))
+                _ck(lib.H5Dset_extent(did, (_hsize * len(cur))(*cur)), 'H5Dset_extent(%s)' % path)
             start = [int(record)] + [0] * (len(cur) - 1)
             count = [1] + cur[1:]
         else:
             start, count = [0] * len(cur), cur
         fsp = lib.H5Dget_space(did)
         n = len(cur)
-        lib.H5Sselect_hyperslab(fsp, 0, (_hsize * n)(*start), None, (_hsize * n)(*count), None)
+        _ck(lib.H5Sselect_hyperslab(fsp, 0, (_hsize * n)(*start), None, (_hsize * n)(*count), None), 'H5Sselect_hyperslab(%s)' % path)
         msp = lib.H5Screate_simple(n, (_hsize * n)(*count), None)
         try:
             if kind == 'str':
@@ -337,8 +343,8 @@ class NetCDF4File(_hdf5.File):
         if lib.H5Aexists(oid, name.encode()) > 0:
             lib.H5Adelete(oid, name.encode())
         sid = lib.H5Screate(0) if scalar else lib.H5Screate_simple(1, (_hsize * 1)(max(1, arr.size)), None)
-        aid = lib.H5Acreate2(oid, name.encode(), _g(_FILE_TYPES[kind]), sid, 0, 0)
-        lib.H5Awrite(aid, _g(_MEM_TYPES[kind][0]), arr.ctypes.data_as(ctypes.c_void_p))
+        aid = _ck(lib.H5Acreate2(oid, name.encode(), _g(_FILE_TYPES[kind]), sid, 0, 0), 'H5Acreate2(%s)' % name)
+        _ck(lib.H5Awrite(aid, _g(_MEM_TYPES[kind][0]), arr.ctypes.data_as(ctypes.c_void_p)), 'H5Awrite(%s)' % name)
         lib.H5Aclose(aid)
         lib.H5Sclose(sid)
 
@@ -356,8 +362,8 @@ class NetCDF4File(_hdf5.File):
                 t = lib.H5Tcopy(_g('H5T_C_S1_g'))
                 lib.H5Tset_size(t, len(raw))
                 sid = lib.H5Screate(0)
-                aid = lib.H5Acreate2(oid, name.encode(), t, sid, 0, 0)
-                lib.H5Awrite(aid, t, ctypes.c_char_p(raw))
+                aid = _ck(lib.H5Acreate2(oid, name.encode(), t, sid, 0, 0), 'H5Acreate2(%s)' % name)
+                _ck(lib.H5Awrite(aid, t, ctypes.c_char_p(raw)), 'H5Awrite(%s)' % name)
                 lib.H5Aclose(aid)
                 lib.H5Sclose(sid)
                 lib.H5Tclose(t)
