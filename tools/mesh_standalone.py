@@ -1,5 +1,6 @@
 """Stand-alone durations of the mesh launches (spread + z forward | XY plane pass | z inverse + gather) and of the pair kernel on
-the headline system: force evaluations only, stream overlap off, per-scope events.  usage: [AB_LIB=...] python tools/mesh_standalone.py [R]"""
+the headline system (or DHFR): force evaluations only, stream overlap off, per-scope events.
+usage: [AB_LIB=...] python tools/mesh_standalone.py [R] [dhfr]"""
 import os, sys
 os.environ.setdefault('REMD_OVERLAP', '0')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,7 @@ from openmmtools_amd import testsystems as ts
 from openmmtools_amd.system import system_to_desc
 from openmmtools_amd._engine import HipEngine
 KB = 0.008314462618153242
-al = ts.AlanineDipeptideExplicit()
+al = ts.DHFRExplicit() if (len(sys.argv) > 2 and sys.argv[2] == 'dhfr') else ts.AlanineDipeptideExplicit()
 box = np.diag(al.system.getDefaultPeriodicBoxVectors())
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 eng = HipEngine(lib_path=os.environ.get('AB_LIB') or None)
