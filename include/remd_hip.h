@@ -221,6 +221,29 @@ int  remd_compute_energies(remd_handle h, double* d_ukl_rows, double* ukl_host,
    through torch.distributed on an aliasing tensor).                                     */
 int  remd_ukl_device_ptr(remd_handle h, double** d_ukl);
 
+/* ---- sharding without a Python host: RCCL behind the C ABI --------------------------- */
+/* The reference distributes replicas over MPI ranks with mpiplus (multistatesampler.py:1296-1311, 1448-1449: every rank
+   propagates / evaluates its replicas, results are gathered) and broadcasts the mixed labels (replicaexchange.py:255).
+   Here: one process per GPU, the host gives every rank a contiguous block of replicas (remd_set_replicas), and the ONE
+   data-path collective -- every rank's rows of u_kl to every rank -- runs on RCCL over xGMI inside the library, on the
+   handle's stream; remd_mix on the handle's own matrix is then the same deterministic computation on every rank, so no
+   label broadcast is needed.  A torch.distributed host may instead gather through remd_ukl_device_ptr (multistate/comm.py).
+     remd_comm_unique_id   rank 0: 128 opaque bytes (ncclUniqueId) the host passes to the other ranks by its own means
+                           (MPI_Bcast, a file, a socket)
+     remd_comm_init        collective over all `world` ranks: joins the communicator on the handle's device
+     remd_comm_all_gather_energies
+                           collective: after remd_compute_energies(h, NULL, ...) wrote the local rows into the handle's
+                           own [R_global][K] matrix, fills in every other rank's rows (blocks may differ in size; they
+                           must tile 0..R_global-1 in rank order).  Asynchronous on the handle's stream; world 1 or an
+                           unsharded handle: nothing to do.
+     remd_comm_finalize    leaves the communicator (remd_destroy does it too)
+   librccl is opened at run time by the first of these calls (REMD_RCCL_LIB overrides the name), never linked.            */
+#define REMD_COMM_ID_BYTES 128
+int  remd_comm_unique_id(void* id /*[REMD_COMM_ID_BYTES]*/);
+int  remd_comm_init(remd_handle h, int rank, int world, const void* id /*[REMD_COMM_ID_BYTES]*/);
+int  remd_comm_all_gather_energies(remd_handle h);
+int  remd_comm_finalize(remd_handle h);
+
 /* Replaces ReplicaExchangeSampler._mix_replicas (replicaexchange.py:255-292),
    _mix_all_replicas_numba (:294-349), _mix_neighboring_replicas (:366-380) and
    SAMSSampler._global_jump (sams.py:477-501).

@@ -47,6 +47,7 @@ EXPORTS = [
     'remd_set_restart_attempts', 'remd_set_force_groups', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
     'remd_set_energy_const_volume', 'remd_roof_microbench',
+    'remd_comm_unique_id', 'remd_comm_init', 'remd_comm_all_gather_energies', 'remd_comm_finalize',
 ]
 
 _lib = None
@@ -245,6 +246,26 @@ class HipEngine:
         """Force groups of (external, bonds, angles, torsions, nonbonded direct, PME reciprocal) for V<g> substeps."""
         g = (C.c_int32 * 6)(*[int(x) for x in groups])
         self._check(self.lib.remd_set_force_groups(self.h, g), 'remd_set_force_groups')
+
+    # ---- sharding through RCCL inside the library (include/remd_hip.h; a torch.distributed host may use multistate/comm.py) ----
+    def comm_unique_id(self):
+        """Rank 0: the 128 opaque bytes every other rank needs for ``comm_init`` (passed on by the host's own channel)."""
+        buf = (C.c_ubyte * 128)()
+        self._check(self.lib.remd_comm_unique_id(buf), 'remd_comm_unique_id')
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError('the communicator id is 128 bytes')
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.remd_comm_init(self.h, int(rank), int(world), buf), 'remd_comm_init')
+
+    def comm_all_gather_energies(self):
+        """After ``compute_energies`` into the handle's own matrix: every other rank's rows, on the handle's stream."""
+        self._check(self.lib.remd_comm_all_gather_energies(self.h), 'remd_comm_all_gather_energies')
+
+    def comm_finalize(self):
+        self._check(self.lib.remd_comm_finalize(self.h), 'remd_comm_finalize')
 
     def set_restart_attempts(self, n):
         """mcmc.py:706-759: retries of a move whose result holds a NaN (restored start state, fresh noise)."""

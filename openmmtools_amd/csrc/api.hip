@@ -90,6 +90,7 @@ int remd_destroy(remd_handle h)
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    remd_comm_release(h);
     remd_pme_destroy(h);
     remd_free_constraints(h);
     remd_free_nonbonded(h);
@@ -269,6 +270,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     h->box_version++;
     h->forces_valid = false; h->force_zeroed = false;
     h->cbins_ready = false;              // (bins a chain filled for positions that are gone)
+    h->comm_part_current = false;       // (the ranks exchange their blocks again at the next all-gather)
     // (the mesh buffers follow the replica count; a call that only replaces coordinates keeps them -- one handle per compatibility
     // group re-enters here every iteration, multistate/_engine_pool.py)
     if (h->nb_method == REMD_NB_PME && (realloc || !h->pme)) { int rc = remd_pme_setup(h); if (rc) return rc; }

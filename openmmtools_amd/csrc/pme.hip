@@ -369,7 +369,6 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
     // a mesh row x is covered by ceil(ny / nl) workgroups of nl lines (the last one may hang over the end of the row)
     const int nbpr = (ny + nl - 1) / nl;
     const int x = blockIdx.x / nbpr, y0 = (blockIdx.x - x * nbpr) * nl;
-    const int l0 = x * ny + y0;
     for (int idx = tid; idx < nl * nz; idx += Z_THREADS) acc[idx] = 0;
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
@@ -479,7 +478,6 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
     // a mesh row x is covered by ceil(ny / nl) workgroups of nl lines (the last one may hang over the end of the row)
     const int nbpr = (ny + nl - 1) / nl;
     const int x = blockIdx.x / nbpr, y0 = (blockIdx.x - x * nbpr) * nl;
-    const int l0 = x * ny + y0;
     for (int idx = tid; idx < nz; idx += Z_THREADS) s_tw[idx] = tw[idx];
     if (HALF) for (int idx = tid; idx < M; idx += Z_THREADS) s_twh[idx] = tw_half[idx];
     const float2* S = spec + (size_t)r * nzc * nx * ny;

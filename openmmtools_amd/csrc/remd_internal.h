@@ -177,6 +177,10 @@ struct remd_ctx {
     unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true; bool pme_concurrent = false;
+    // sharding without a Python host (comm.hip): an RCCL communicator over the ranks of one replica-exchange run
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;
+    std::vector<long long> comm_begin, comm_count;   // every rank's block of replicas, exchanged when the local block changes
+    long long* d_comm_part = nullptr; bool comm_part_current = false;
     double t_prop = 0, t_energy = 0, t_mix = 0;
     int profiling = 0;                 // 0 off, 1 filtered class only, 2 all classes
     std::string prof_filter = "nonbonded";
@@ -192,6 +196,7 @@ struct remd_ctx {
 
 void remd_set_global_error(const std::string& s);
 int remd_fail(remd_ctx* h, int code, const std::string& msg);
+void remd_comm_release(remd_ctx* h);      // comm.hip
 
 // profiling wrapper: brackets a launch with HIP events recorded on the handle's stream.  Nothing is
 // synchronised at launch time; the pairs are resolved in remd_profile_get().  Level 1 records only

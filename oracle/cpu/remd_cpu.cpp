@@ -1262,6 +1262,27 @@ int remd_set_force_groups(remd_handle h, const int32_t* groups)
     return 0;       // (multiple-time-step splittings are refused when they are parsed)
 }
 
+// Sharding collectives (include/remd_hip.h): the CPU library is the single-process checker -- it joins a world of one.
+int remd_comm_unique_id(void* id)
+{
+    if (!id) return fail(nullptr, -1, "remd_comm_unique_id: null pointer");
+    memset(id, 0, REMD_COMM_ID_BYTES);
+    return 0;
+}
+int remd_comm_init(remd_handle h, int rank, int world, const void* id)
+{
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) return fail(h, -1, "remd_comm_init: bad arguments");
+    if (world != 1) return fail(h, -1, "remd_comm_init: several ranks are not implemented in the CPU library");
+    return 0;
+}
+int remd_comm_all_gather_energies(remd_handle h)
+{
+    if (!h) return fail(h, -1, "remd_comm_all_gather_energies: null handle");
+    if (h->R != h->R_global) return fail(h, -1, "remd_comm_all_gather_energies: replicas are sharded but the CPU library has no communicator");
+    return 0;
+}
+int remd_comm_finalize(remd_handle) { return 0; }
+
 int remd_set_restart_attempts(remd_handle h, int n)
 {
     if (!h || n < 0) return fail(h, -1, "remd_set_restart_attempts: bad arguments");
