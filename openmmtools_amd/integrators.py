@@ -141,6 +141,8 @@ class GeodesicBAOABIntegrator(LangevinIntegrator):
 class GHMCIntegrator(LangevinIntegrator):
     """integrators.py:2242-2289: generalized hybrid Monte Carlo = the Metropolized splitting "O { V R V } O"."""
 
+    SPLITTING = "O { V R V } O"                 # integrators.py:2286
+
     def __init__(self, *args, **kwargs):
-        kwargs['splitting'] = "O { V R V } O"   # integrators.py:2286
+        kwargs['splitting'] = self.SPLITTING
         super().__init__(*args, **kwargs)

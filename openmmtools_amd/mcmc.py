@@ -1,7 +1,7 @@
 """Langevin MCMC moves as the sampler's propagation recipe.
 
 Mirrors openmmtools/mcmc.py: SequenceMove (:350-440), BaseIntegratorMove (:603-807), LangevinDynamicsMove (:1066-1172),
-LangevinSplittingDynamicsMove (:1180-1316), MonteCarloBarostatMove (:1597-1700).  In the reference ``apply`` pushes one replica
+LangevinSplittingDynamicsMove (:1180-1316), GHMCMove (:1323-1490), MonteCarloBarostatMove (:1597-1700).  In the reference ``apply`` pushes one replica
 through an OpenMM Context (:668-776); here a move only carries the parameters and the
 multistate sampler propagates *all* replicas in one batched device call
 (_engine.HipEngine.propagate -> remd_propagate).
@@ -118,6 +118,76 @@ class LangevinDynamicsMove(LangevinSplittingDynamicsMove):
         super().__init__(timestep=timestep, collision_rate=collision_rate, n_steps=n_steps,
                          reassign_velocities=reassign_velocities, splitting="V R O R V",
                          constraint_tolerance=constraint_tolerance, **kwargs)
+
+
+class GHMCMove(LangevinSplittingDynamicsMove):
+    """mcmc.py:1323-1490: generalized hybrid Monte Carlo -- ``n_steps`` of GHMCIntegrator, i.e. the Metropolized splitting
+    "O { V R V } O" (integrators.py:2286), whose accepted / attempted steps the move accumulates (the reference reads the
+    integrator's ``naccept`` / ``ntrials`` after the integration, :1478-1489; here the engine's per-replica counters,
+    remd_get_work, are credited to the move of the state a replica was propagated in)."""
+
+    def __init__(self, timestep=1.0 * unit.femtosecond, collision_rate=20.0 / unit.picoseconds, n_steps=1000, **kwargs):
+        super().__init__(timestep=timestep, collision_rate=collision_rate, n_steps=n_steps,
+                         splitting=integrators.GHMCIntegrator.SPLITTING, **kwargs)
+        self.n_accepted = 0      # :1399-1400
+        self.n_proposed = 0
+
+    @property
+    def fraction_accepted(self):
+        """:1403-1412: accepted over attempted steps, NaN before the first one."""
+        if self.n_proposed == 0:
+            return float('nan')
+        return float(self.n_accepted) / self.n_proposed
+
+    @property
+    def statistics(self):
+        return dict(n_accepted=self.n_accepted, n_proposed=self.n_proposed)
+
+    @statistics.setter
+    def statistics(self, value):
+        self.n_accepted = int(value.get('n_accepted', 0))
+        self.n_proposed = int(value.get('n_proposed', 0))
+
+    def reset_statistics(self):
+        self.n_accepted = 0
+        self.n_proposed = 0
+
+    def _get_integrator(self, thermodynamic_state):
+        """:1469-1474."""
+        return integrators.GHMCIntegrator(temperature=thermodynamic_state.temperature, collision_rate=self.collision_rate,
+                                          timestep=self.timestep, constraint_tolerance=self.constraint_tolerance)
+
+
+class HMCMove(LangevinSplittingDynamicsMove):
+    """mcmc.py:1493-1590: hybrid Monte Carlo -- velocities from the Maxwell-Boltzmann distribution, ``n_steps`` velocity Verlet
+    steps, one Metropolis test on the change of total energy (HMCIntegrator, integrators.py:885-1010).  As a program of the
+    Langevin engine that is ONE step of the splitting
+
+        O { V R V  V R V  ...  V R V }            (n_steps groups)
+
+    at timestep n_steps * dt with an infinite collision rate: O then draws v = sqrt(kT/m) xi, every V is the half kick dt/2
+    (2 n_steps of them share the step), every R the drift dt, and the braces accept or restore the start of the trajectory.
+    Like the reference, ``apply`` runs the integrator ``n_steps`` times (mcmc.py:719 steps the HMCIntegrator(nsteps=n_steps)
+    n_steps times): n_steps trajectories of n_steps steps per iteration."""
+
+    RESAMPLE = 1.0e12          # 1/ps: exp(-RESAMPLE * dt) is exactly 0 for any dt the integrators accept
+
+    def __init__(self, timestep=1.0 * unit.femtosecond, n_steps=1000, **kwargs):
+        n = int(n_steps)
+        if n < 1:
+            raise ValueError('HMCMove needs at least one step per trajectory')
+        super().__init__(timestep=timestep, collision_rate=self.RESAMPLE, n_steps=n,
+                         splitting='O {' + ' V R V' * n + ' }', **kwargs)
+
+    @property
+    def engine_timestep(self):
+        """ps per pass of the splitting (``timestep`` keeps the reference's meaning: the velocity Verlet step)."""
+        return self.timestep * self.n_steps
+
+    def _get_integrator(self, thermodynamic_state):
+        return integrators.LangevinIntegrator(temperature=thermodynamic_state.temperature, collision_rate=self.collision_rate,
+                                              timestep=self.engine_timestep, splitting=self.splitting,
+                                              constraint_tolerance=self.constraint_tolerance)
 
 
 class MonteCarloBarostatMove(BaseIntegratorMove):

@@ -458,14 +458,13 @@ class MultiStateSampler:
 
     def _engine_program(self):
         """The per-iteration recipe of every replica: the flattened move sequence of state 0, which all states must share
-        (one batched launch covers every replica).  At most one Langevin move (the engine holds one integrator program)."""
+        (one batched launch covers every replica).  The engine holds one integrator program at a time: a sequence with several
+        integrator moves (tests/test_mcmc.py:283 SequenceMove([LangevinDynamicsMove, GHMCMove])) reprograms it between them."""
         prog = self._flatten(self._mcmc_moves[0])
         keys = [self._move_key(m) for m in prog]
         for other in self._mcmc_moves[1:]:
             if [self._move_key(m) for m in self._flatten(other)] != keys:
                 raise NotImplementedError('per-state MCMC moves must be identical for batched propagation')
-        if sum(1 for k in keys if k[0] == 'langevin') > 1:
-            raise NotImplementedError('more than one Langevin move per iteration')
         return prog
 
     def _engine_move(self):
@@ -475,8 +474,8 @@ class MultiStateSampler:
                 return m
         return None
 
-    def _program_engine_move(self):
-        move = self._engine_move()
+    def _program_engine_move(self, move=None):
+        move = self._engine_move() if move is None else move
         eng = self._engine
         if move is not None:
             has_constraints = self._thermodynamic_states[0].system.getNumConstraints() > 0
@@ -486,7 +485,7 @@ class MultiStateSampler:
                                'X-H clusters with a fixed three Newton iterations and rigid waters analytically, whatever the '
                                'tolerance', move.constraint_tolerance)
                 self._warned_tolerance = True
-            eng.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps,
+            eng.set_integrator(move.splitting, getattr(move, 'engine_timestep', move.timestep), move.collision_rate, move.n_steps,
                                move.reassign_velocities, move.constraint_tolerance)
             eng.set_restart_attempts(getattr(move, 'n_restart_attempts', 0))      # mcmc.py:706-759
             if hasattr(eng, 'set_work_measurement'):                              # mcmc.py:1308-1316: the move's flags reach the integrator
@@ -805,20 +804,46 @@ class MultiStateSampler:
         """multistatesampler.py:1287-1337 for every local replica in one device call."""
         it = self._iteration if rng_iteration is None else rng_iteration
         self._engine.set_labels(self._replica_thermodynamic_states)
-        for move in self._engine_program():                      # SequenceMove: in order, once per iteration (mcmc.py:406-424)
+        program = self._engine_program()                           # SequenceMove: in order, once per iteration (mcmc.py:406-424)
+        integrations = [m for m in program if isinstance(m, mcmc.LangevinSplittingDynamicsMove)]
+        for position, move in enumerate(program):
             if isinstance(move, mcmc.MonteCarloBarostatMove):
                 if not getattr(self, '_npt', False):
                     raise RuntimeError('Requested a MonteCarloBarostat move on a system at constant volume')   # mcmc.py:1673-1676
                 self._engine.barostat_attempts(move.n_attempts)
                 self._sampler_states_stale = True
                 continue
-            flags = self._engine.propagate(it)
+            key = it
+            if len(integrations) > 1:
+                # one integrator program at a time: load this move's; its noise is keyed by (iteration, place in the sequence)
+                self._program_engine_move(move)
+                nth = [m is move for m in integrations].index(True)
+                key = it * len(integrations) + (nth if it >= 0 else -nth)
+            counted = isinstance(move, mcmc.GHMCMove) and hasattr(self._engine, 'get_work')
+            before = self._engine.get_work() if counted else None
+            flags = self._engine.propagate(key)
             self._sampler_states_stale = True
             if np.any(flags):
                 self._dump_nan_errors(np.nonzero(flags)[0], move)
+            if counted:
+                self._credit_metropolized_steps(position, before, self._engine.get_work())
         for state_move in self._mcmc_moves:
             for move in self._flatten(state_move):
-                move.statistics = dict(n_attempts=move.statistics.get('n_attempts', 0) + 1)
+                if not isinstance(move, mcmc.GHMCMove):
+                    move.statistics = dict(n_attempts=move.statistics.get('n_attempts', 0) + 1)
+
+    def _credit_metropolized_steps(self, position, before, after):
+        """mcmc.py:1478-1489: a GHMCMove accumulates the accepted / attempted steps of the integrations it drove.  The engine
+        counts per replica; the steps of this integration go to the move (at ``position`` of the flattened sequence) of the
+        state each local replica was propagated in.  Under several ranks every rank credits its own replicas, as the
+        reference's worker-side move objects do."""
+        acc = np.asarray(after['n_accepted'], np.int64) - np.asarray(before['n_accepted'], np.int64)
+        tri = np.asarray(after['n_trials'], np.int64) - np.asarray(before['n_trials'], np.int64)
+        local_states = np.asarray(self._replica_thermodynamic_states)[self._r_begin:self._r_begin + len(acc)]
+        for r, state in enumerate(local_states):
+            move = self._flatten(self._mcmc_moves[int(state)])[position]
+            move.n_accepted += int(acc[r])
+            move.n_proposed += int(tri[r])
 
     def _dump_nan_errors(self, bad_local, move):
         """multistatesampler.py:1324-1334: save the NaN-ing replica (state, System, move) under ``nan-error-logs/`` next to

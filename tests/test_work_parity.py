@@ -155,3 +155,156 @@ def test_device_shadow_work_with_constraints_and_mesh(hip_engine_factory):
     ke = 0.5 * 4548 * KB * 330.0
     assert np.allclose(w['heat'], wo['heat'], rtol=1e-3, atol=1e-4 * ke)
     assert np.allclose(w['shadow_work'], wo['shadow_work'], rtol=1e-3, atol=1e-4 * ke), (w['shadow_work'], wo['shadow_work'])
+
+
+# ---- GHMCMove through the samplers (mcmc.py:1323-1490) -----------------------------------------------------------------------
+def _ghmc_sampler(engine, n_iterations=4, timestep=4.0, n_steps=10, T=(100.0, 140.0, 200.0)):
+    from openmmtools_amd import states, unit
+    from openmmtools_amd.multistate import ReplicaExchangeSampler
+    lj = ts.LennardJonesFluid(nparticles=216)
+    move = mcmc.GHMCMove(timestep=timestep * unit.femtosecond, collision_rate=20.0 / unit.picosecond, n_steps=n_steps)
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=n_iterations, engine=engine, seed=21, online_analysis_interval=None)
+    thermo = [states.ThermodynamicState(lj.system, t * unit.kelvin) for t in T]
+    s.create(thermo, [states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())], storage=None)
+    return s
+
+
+def test_ghmc_move_mirrors_the_reference_class():
+    m = mcmc.GHMCMove()
+    assert m.splitting == 'O { V R V } O' and m.n_steps == 1000 and abs(m.collision_rate - 20.0) < 1e-12      # mcmc.py:1392-1400, integrators.py:2286
+    assert np.isnan(m.fraction_accepted) and m.statistics == dict(n_accepted=0, n_proposed=0)
+    m.statistics = dict(n_accepted=3, n_proposed=4)
+    assert m.fraction_accepted == 0.75
+    m.reset_statistics()
+    assert m.n_proposed == 0
+    integ = m._get_integrator(type('S', (), {'temperature': 300.0})())
+    assert integ.is_metropolized and type(integ).__name__ == 'GHMCIntegrator'
+
+
+def test_ghmc_move_statistics_accumulate_per_state_on_the_oracle_engine():
+    """Every iteration proposes n_steps steps per replica; the steps are credited to the move of the state the replica was in, so
+    the moves' n_proposed add up to iterations x replicas x n_steps and the hot state accepts at least as often as the cold one
+    is NOT implied (larger kicks) -- only that both outcomes occurred and fractions are probabilities."""
+    s = _ghmc_sampler(OracleEngine(system_factory=ForceFieldOracle), n_iterations=3)
+    s.run()
+    moves = s._mcmc_moves
+    assert all(isinstance(m, mcmc.GHMCMove) for m in moves)
+    assert sum(m.n_proposed for m in moves) == 3 * 3 * 10
+    assert all(m.n_proposed % 10 == 0 for m in moves)
+    acc = sum(m.n_accepted for m in moves)
+    assert 0 < acc < 90
+    assert all(0.0 <= m.fraction_accepted <= 1.0 for m in moves if m.n_proposed)
+    s.extend(1)                                            # counters are differences per iteration, not cumulative re-reads
+    assert sum(m.n_proposed for m in moves) == 4 * 3 * 10
+
+
+@pytest.mark.gpu
+def test_ghmc_move_on_the_device_follows_the_oracle_engine(hip_engine_factory):
+    """The same GHMC replica-exchange run on the device and on the f64 oracle engine: 2 fs steps in the unminimised fluid put
+    the acceptance well inside (0, 1); labels agree, and the credited steps agree up to the fp32 Metropolis borderline cases."""
+    runs = []
+    for eng in (hip_engine_factory(), OracleEngine(system_factory=ForceFieldOracle)):
+        s = _ghmc_sampler(eng, n_iterations=3, timestep=2.0, n_steps=8)
+        s.run()
+        runs.append((list(s.replica_thermodynamic_states), [(m.n_accepted, m.n_proposed) for m in s._mcmc_moves]))
+    (la, sa), (lb, sb) = runs
+    assert [p for _, p in sa] == [p for _, p in sb] and sum(p for _, p in sa) == 3 * 3 * 8
+    assert abs(sum(a for a, _ in sa) - sum(a for a, _ in sb)) <= 3
+    assert 0 < sum(a for a, _ in sa) < 72
+
+
+# ---- HMCMove and sequences of integrator moves (mcmc.py:1493-1590, 350-440; tests/test_mcmc.py:283) -----------------------------
+def test_hmc_move_is_one_metropolized_trajectory_per_integrator_step():
+    """One pass of 'O { (V R V)^n }' at n dt with full velocity resampling against a hand-written HMC step on the oracle's
+    forces: same start, same noise => the proposal's end point is velocity Verlet from v = sigma xi, and the recorded trial is
+    accepted exactly when exp(-(E_new - E_old) / kT) beats the uniform draw the engine used (here: energy is conserved to
+    ~1e-3 kT by 1 fs steps in the relaxed fluid, so every trajectory is accepted and positions move)."""
+    from openmmtools_amd import unit
+    m = mcmc.HMCMove(timestep=1.0 * unit.femtosecond, n_steps=6)
+    assert m.splitting == 'O {' + ' V R V' * 6 + ' }' and abs(m.timestep - 0.001) < 1e-15 and abs(m.engine_timestep - 0.006) < 1e-15
+    integ = m._get_integrator(type('S', (), {'temperature': 300.0})())
+    assert integ.is_metropolized
+    system, positions = _lj()
+    ora = OracleEngine(system_factory=ForceFieldOracle)
+    _setup(ora, system, positions, m.splitting, m.engine_timestep, 1, R=2, T=(100.0, 120.0))
+    ora.set_integrator(m.splitting, m.engine_timestep, m.collision_rate, 1, False, 1e-8)
+    from oracle import md_oracle as mo
+    box, x_start = ora.box.copy(), ora.x.copy()
+    ora.propagate(0)
+    v_end, x_end = ora.v.copy(), ora.x.copy()
+    w = ora.get_work()
+    assert np.all(w['n_trials'] == 1)
+    # replay: the velocities the O substep drew are not observable afterwards, so integrate BACKWARDS from the accepted end point
+    # (velocity Verlet is time reversible): six reversed steps must land on the start positions
+    for r in range(2):
+        if not w['n_accepted'][r]:
+            continue
+        x, v = x_end[r].copy(), -v_end[r].copy()
+        mass = np.asarray(ora.sys.mass)[:, None]
+        f = ora.sys.energy_forces(x, box[r])[1]
+        for _ in range(6):
+            v = v + 0.5 * 0.001 * f / mass
+            x = x + 0.001 * v
+            f = ora.sys.energy_forces(x, box[r])[1]
+            v = v + 0.5 * 0.001 * f / mass
+        assert np.abs(x - x_start[r]).max() < 1e-9
+    assert w['n_accepted'].sum() >= 1
+
+
+def test_a_sequence_of_two_integrator_moves_reprograms_the_engine_between_them():
+    """tests/test_mcmc.py:283: SequenceMove([LangevinDynamicsMove, GHMCMove]).  Both integrations run every iteration (the GHMC
+    steps are counted, so its program was the one loaded when it ran), with distinct noise keys."""
+    from openmmtools_amd import states, unit
+    from openmmtools_amd.multistate import ReplicaExchangeSampler
+    lj = ts.LennardJonesFluid(nparticles=216)
+    seq = mcmc.SequenceMove([mcmc.LangevinDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=5),
+                             mcmc.GHMCMove(timestep=2.0 * unit.femtosecond, n_steps=5)])
+    calls = []
+
+    class Spy(OracleEngine):
+        def set_integrator(self, splitting, *a):
+            calls.append(('program', splitting))
+            return super().set_integrator(splitting, *a)
+
+        def propagate(self, key):
+            calls.append(('propagate', key))
+            return super().propagate(key)
+    s = ReplicaExchangeSampler(mcmc_moves=seq, number_of_iterations=2, engine=Spy(system_factory=ForceFieldOracle), seed=4,
+                               online_analysis_interval=None)
+    thermo = [states.ThermodynamicState(lj.system, t * unit.kelvin) for t in (100.0, 130.0)]
+    s.create(thermo, [states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())], storage=None)
+    del calls[:]
+    s.run()
+    assert calls == [('program', 'V R O R V'), ('propagate', 2), ('program', 'O { V R V } O'), ('propagate', 3),
+                     ('program', 'V R O R V'), ('propagate', 4), ('program', 'O { V R V } O'), ('propagate', 5)]
+    ghmc = [m.move_list[1] for m in s._mcmc_moves]
+    assert sum(g.n_proposed for g in ghmc) == 2 * 2 * 5
+    assert all(m.move_list[0].statistics == dict(n_attempts=2) for m in s._mcmc_moves)
+
+
+def _hmc_case(make_engine):
+    """Three HMC trajectories of 12 steps (37 tokens per pass: longer than one launch chain holds) against the oracle."""
+    from openmmtools_amd import unit
+    m = mcmc.HMCMove(timestep=1.0 * unit.femtosecond, n_steps=12)
+    system, positions = _lj()
+    eng, ora = make_engine(), OracleEngine(system_factory=ForceFieldOracle)
+    for e in (eng, ora):
+        _setup(e, system, positions, m.splitting, m.engine_timestep, 3, measure=(False, False))
+        e.set_integrator(m.splitting, m.engine_timestep, m.collision_rate, 3, False, 1e-8)
+    assert not np.any(eng.propagate(1))
+    ora.propagate(1)
+    w, wo = eng.get_work(), ora.get_work()
+    assert np.all(wo['n_trials'] == 3) and np.array_equal(w['n_trials'], wo['n_trials']) and np.array_equal(w['n_accepted'], wo['n_accepted'])
+    assert wo['n_accepted'].sum() >= 6
+    xg, vg = eng.get_replicas()[:2]
+    assert np.abs(xg - ora.x).max() < 5e-5 and np.abs(vg - ora.v).max() < 5e-4
+    assert np.abs(ora.x - positions[None]).max() > 1e-3
+
+
+def test_cpu_library_hmc_trajectories_follow_the_oracle(cpu_engine):
+    _hmc_case(cpu_engine)
+
+
+@pytest.mark.gpu
+def test_device_hmc_trajectories_follow_the_oracle(hip_engine_factory):
+    _hmc_case(hip_engine_factory)
