@@ -817,7 +817,7 @@ class MultiStateSampler:
             if len(integrations) > 1:
                 # one integrator program at a time: load this move's; its noise is keyed by (iteration, place in the sequence)
                 self._program_engine_move(move)
-                nth = [m is move for m in integrations].index(True)
+                nth = sum(1 for m in program[:position] if isinstance(m, mcmc.LangevinSplittingDynamicsMove))
                 key = it * len(integrations) + (nth if it >= 0 else -nth)
             counted = isinstance(move, mcmc.GHMCMove) and hasattr(self._engine, 'get_work')
             before = self._engine.get_work() if counted else None

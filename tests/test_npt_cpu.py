@@ -133,9 +133,12 @@ def test_monte_carlo_barostat_move_in_a_sequence_move():
     s3.create(nvt, [ss], min_temperature=120.0, max_temperature=150.0, n_temperatures=2)
     with pytest.raises(RuntimeError, match='MonteCarloBarostat'):
         s3.run()
-    with pytest.raises(NotImplementedError):
-        ParallelTemperingSampler(mcmc_moves=mcmc.SequenceMove([langevin, langevin]), engine=OracleEngine(ForceFieldOracle)
-                                 ).create(ts, [ss], min_temperature=120.0, max_temperature=150.0, n_temperatures=2)
+    # two integrator moves in one sequence (tests/test_mcmc.py:283): the engine is reprogrammed between them
+    s4 = ParallelTemperingSampler(mcmc_moves=mcmc.SequenceMove([langevin, langevin]), engine=OracleEngine(ForceFieldOracle),
+                                  number_of_iterations=1)
+    s4.create(ts, [ss], min_temperature=120.0, max_temperature=150.0, n_temperatures=2)
+    s4.run()
+    assert s4.iteration == 1
 
 
 def test_sequence_move_survives_storage_and_resume(tmp_path):
