@@ -1,7 +1,8 @@
 """Langevin MCMC moves as the sampler's propagation recipe.
 
 Mirrors openmmtools/mcmc.py: SequenceMove (:350-440), BaseIntegratorMove (:603-807), LangevinDynamicsMove (:1066-1172),
-LangevinSplittingDynamicsMove (:1180-1316), GHMCMove (:1323-1490), MonteCarloBarostatMove (:1597-1700).  In the reference ``apply`` pushes one replica
+LangevinSplittingDynamicsMove (:1180-1316), GHMCMove (:1323-1490), HMCMove (:1493-1590), MonteCarloBarostatMove (:1597-1700), MetropolizedMove (:810-975),
+MCDisplacementMove (:1704-1770), MCRotationMove (:1777-1910).  In the reference ``apply`` pushes one replica
 through an OpenMM Context (:668-776); here a move only carries the parameters and the
 multistate sampler propagates *all* replicas in one batched device call
 (_engine.HipEngine.propagate -> remd_propagate).
@@ -204,3 +205,98 @@ class MonteCarloBarostatMove(BaseIntegratorMove):
     @n_attempts.setter
     def n_attempts(self, value):
         self.n_steps = int(value)
+
+
+class MetropolizedMove(MCMCMove):
+    """mcmc.py:810-975: propose new positions for a subset of atoms, accept with min(1, exp(-delta u)) on the reduced potential
+    of the replica's own state, restore otherwise.  The reference pushes one replica through a Context twice; the sampler
+    here does it for all local replicas at once (positions of every replica proposed on the host, two batched energy
+    evaluations on the device; multistatesampler._apply_metropolized_move).  Subclasses implement ``_propose_positions``."""
+
+    def __init__(self, atom_subset=None, **kwargs):
+        self.n_accepted = 0
+        self.n_proposed = 0
+        self.atom_subset = atom_subset
+
+    @property
+    def statistics(self):
+        return dict(n_accepted=self.n_accepted, n_proposed=self.n_proposed)
+
+    @statistics.setter
+    def statistics(self, value):
+        self.n_accepted = int(value.get('n_accepted', 0))
+        self.n_proposed = int(value.get('n_proposed', 0))
+
+    def _subset(self):
+        """:873-879: all atoms by default; a one-element list becomes a slice so that the proposal sees an (1, 3) array."""
+        import numpy as np
+        if self.atom_subset is None:
+            return slice(None)
+        if not isinstance(self.atom_subset, slice) and len(self.atom_subset) == 1:
+            return slice(int(self.atom_subset[0]), int(self.atom_subset[0]) + 1)
+        return self.atom_subset if isinstance(self.atom_subset, slice) else np.asarray(self.atom_subset, dtype=np.int64)
+
+    def _propose_positions(self, positions, rng=None):
+        raise NotImplementedError('MetropolizedMove subclasses propose the new positions')
+
+
+def _uniform_source(rng):
+    import numpy as np
+    return np.random if rng is None else rng
+
+
+class MCDisplacementMove(MetropolizedMove):
+    """mcmc.py:1704-1770: rigid translation of the subset by a normal vector of standard deviation ``displacement_sigma``."""
+
+    def __init__(self, displacement_sigma=1.0 * unit.nanometer, **kwargs):
+        super().__init__(**kwargs)
+        self.displacement_sigma = float(unit.to_md(displacement_sigma))      # nm
+
+    @staticmethod
+    def displace_positions(positions, displacement_sigma=1.0 * unit.nanometer, rng=None):
+        """:1744-1765 (positions in nm; ``rng``: a numpy Generator, default the global numpy stream as in the reference)."""
+        import numpy as np
+        src = _uniform_source(rng)
+        vector = (src.standard_normal(3) if rng is not None else src.randn(3)) * float(unit.to_md(displacement_sigma))
+        return np.asarray(positions, dtype=np.float64) + vector
+
+    def _propose_positions(self, positions, rng=None):
+        return self.displace_positions(positions, self.displacement_sigma, rng)
+
+
+class MCRotationMove(MetropolizedMove):
+    """mcmc.py:1777-1910: uniform random rotation of the subset about its centre of geometry (Shoemake's quaternions)."""
+
+    @classmethod
+    def rotate_positions(cls, positions, rng=None):
+        import numpy as np
+        x = np.asarray(positions, dtype=np.float64)
+        centre = x.mean(0)                                                   # :1822
+        return (cls.generate_random_rotation_matrix(rng) @ (x - centre).T).T + centre
+
+    @classmethod
+    def generate_random_rotation_matrix(cls, rng=None):
+        return cls._rotation_matrix_from_quaternion(cls._generate_uniform_quaternion(rng))
+
+    @staticmethod
+    def _rotation_matrix_from_quaternion(q):
+        """:1842-1880: the quaternion need not be normalised (zero norm gives the identity)."""
+        import numpy as np
+        w, x, y, z = (float(c) for c in q)
+        n = w * w + x * x + y * y + z * z
+        s = 2.0 / n if n > 0.0 else 0.0
+        return np.array([[1.0 - s * (y * y + z * z), s * (x * y - w * z), s * (x * z + w * y)],
+                         [s * (x * y + w * z), 1.0 - s * (x * x + z * z), s * (y * z - w * x)],
+                         [s * (x * z - w * y), s * (y * z + w * x), 1.0 - s * (x * x + y * y)]])
+
+    @staticmethod
+    def _generate_uniform_quaternion(rng=None):
+        """:1882-1906."""
+        import numpy as np
+        src = _uniform_source(rng)
+        u = src.random(3) if rng is not None else src.rand(3)
+        return np.array([np.sqrt(1 - u[0]) * np.sin(2 * np.pi * u[1]), np.sqrt(1 - u[0]) * np.cos(2 * np.pi * u[1]),
+                         np.sqrt(u[0]) * np.sin(2 * np.pi * u[2]), np.sqrt(u[0]) * np.cos(2 * np.pi * u[2])])
+
+    def _propose_positions(self, positions, rng=None):
+        return self.rotate_positions(positions, rng)

@@ -450,11 +450,15 @@ class MultiStateSampler:
     def _move_key(m):
         if isinstance(m, mcmc.MonteCarloBarostatMove):
             return ('barostat', m.n_attempts)
+        if isinstance(m, mcmc.MetropolizedMove):
+            sub = m.atom_subset
+            sub = None if sub is None else ((sub.start, sub.stop, sub.step) if isinstance(sub, slice) else tuple(int(i) for i in sub))
+            return ('metropolized', type(m).__name__, sub, getattr(m, 'displacement_sigma', None))
         if isinstance(m, mcmc.LangevinSplittingDynamicsMove):
             return ('langevin', m.timestep, m.collision_rate, m.n_steps, m.reassign_velocities, m.splitting,
                     getattr(m, 'measure_heat', False), getattr(m, 'measure_shadow_work', False))
-        raise NotImplementedError('the device engine propagates with Langevin(Splitting)DynamicsMove and '
-                                  'MonteCarloBarostatMove (alone or in a SequenceMove) only')
+        raise NotImplementedError('the device engine propagates with Langevin(Splitting)DynamicsMove, GHMCMove, HMCMove, '
+                                  'MonteCarloBarostatMove and the Metropolized displacement / rotation moves (alone or in a SequenceMove) only')
 
     def _engine_program(self):
         """The per-iteration recipe of every replica: the flattened move sequence of state 0, which all states must share
@@ -813,6 +817,10 @@ class MultiStateSampler:
                 self._engine.barostat_attempts(move.n_attempts)
                 self._sampler_states_stale = True
                 continue
+            if isinstance(move, mcmc.MetropolizedMove):
+                self._apply_metropolized_move(position, move, it)
+                self._sampler_states_stale = True
+                continue
             key = it
             if len(integrations) > 1:
                 # one integrator program at a time: load this move's; its noise is keyed by (iteration, place in the sequence)
@@ -829,8 +837,45 @@ class MultiStateSampler:
                 self._credit_metropolized_steps(position, before, self._engine.get_work())
         for state_move in self._mcmc_moves:
             for move in self._flatten(state_move):
-                if not isinstance(move, mcmc.GHMCMove):
+                if not isinstance(move, (mcmc.GHMCMove, mcmc.MetropolizedMove)):
                     move.statistics = dict(n_attempts=move.statistics.get('n_attempts', 0) + 1)
+
+    def _apply_metropolized_move(self, position, move, it):
+        """mcmc.py:843-905 for every local replica at once: potential of the current positions, proposal for the move's atom
+        subset, potential of the proposed positions (two batched device evaluations at each replica's own state), Metropolis
+        test on beta * delta U (a rigid move of a subset leaves the volume, hence the p V term, unchanged).  Proposals and the
+        acceptance draws come from one numpy Philox stream per (seed, iteration, place in the sequence, global replica): a
+        run is reproducible and independent of how replicas are sharded (the reference draws from numpy's global stream)."""
+        eng = self._engine
+        x, v, u_old, _ = eng.get_replicas(positions=True, velocities=True, potential=True)
+        n_local = x.shape[0]
+        try:
+            box = np.asarray(eng.get_boxes(), dtype=np.float64).reshape(n_local, 3)
+        except Exception:
+            box = np.zeros((n_local, 3))
+        subset = move._subset()
+        proposed = x.copy()
+        rngs = []
+        for r in range(n_local):
+            words = [self._seed & 0xFFFFFFFFFFFFFFFF, int(it) & 0xFFFFFFFFFFFFFFFF, int(position), int(self._r_begin + r), 0x4D43]
+            rng = np.random.Generator(np.random.Philox(np.random.SeedSequence(words)))
+            rngs.append(rng)
+            proposed[r][subset] = move._propose_positions(x[r][subset], rng)
+        labels = self._replica_thermodynamic_states
+        eng.set_replicas(self.n_replicas, self._r_begin, proposed, v, box, labels)
+        u_new = eng.get_replicas(positions=False, velocities=False, potential=True)[2]
+        states = np.asarray(labels)[self._r_begin:self._r_begin + n_local]
+        beta = np.array([self._thermodynamic_states[int(k)].beta for k in states])
+        delta = beta * (np.asarray(u_new) - np.asarray(u_old))
+        accept = np.zeros(n_local, dtype=bool)
+        for r in range(n_local):
+            accept[r] = (not np.isnan(u_new[r])) and (delta[r] <= 0.0 or rngs[r].random() < np.exp(-delta[r]))     # :893-895
+            mv = self._flatten(self._mcmc_moves[int(states[r])])[position]
+            mv.n_accepted += int(accept[r])
+            mv.n_proposed += 1
+        if not np.all(accept):
+            proposed[~accept] = x[~accept]                                    # :897-898: restore the rejected replicas
+            eng.set_replicas(self.n_replicas, self._r_begin, proposed, v, box, labels)
 
     def _credit_metropolized_steps(self, position, before, after):
         """mcmc.py:1478-1489: a GHMCMove accumulates the accepted / attempted steps of the integrations it drove.  The engine

@@ -1,0 +1,138 @@
+"""The Metropolized Monte Carlo moves of the reference (mcmc.py:810-975 MetropolizedMove, :1704-1770 MCDisplacementMove,
+:1777-1910 MCRotationMove) applied to all local replicas at once (multistatesampler._apply_metropolized_move): proposals on the
+host, two batched energy evaluations on the engine, exp(-beta dU) acceptance."""
+import copy
+import numpy as np
+import pytest
+from openmmtools_amd import testsystems, states, mcmc, unit
+from openmmtools_amd.constants import kB
+from openmmtools_amd.multistate import MultiStateSampler, ReplicaExchangeSampler
+from oracle.forcefield import ForceFieldOracle
+from oracle_engine import OracleEngine
+
+
+def test_proposals_are_rigid_and_reproducible():
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(7, 3))
+    moved = mcmc.MCDisplacementMove.displace_positions(x, 0.2 * unit.nanometer, np.random.default_rng(1))
+    assert np.allclose(moved - x, (moved - x)[0]) and 0.0 < np.linalg.norm((moved - x)[0]) < 2.0      # one vector for the whole subset
+    assert np.array_equal(moved, mcmc.MCDisplacementMove.displace_positions(x, 0.2, np.random.default_rng(1)))
+    for seed in range(5):
+        Q = mcmc.MCRotationMove.generate_random_rotation_matrix(np.random.default_rng(seed))
+        assert np.allclose(Q @ Q.T, np.eye(3), atol=1e-13) and abs(np.linalg.det(Q) - 1.0) < 1e-13
+    assert np.array_equal(mcmc.MCRotationMove._rotation_matrix_from_quaternion(np.zeros(4)), np.eye(3))    # mcmc.py:1862-1865
+    r = mcmc.MCRotationMove.rotate_positions(x, np.random.default_rng(2))
+    assert np.allclose(r.mean(0), x.mean(0)) and not np.allclose(r, x)
+    d = lambda a: np.linalg.norm(a[:, None] - a[None], axis=-1)
+    assert np.allclose(d(r), d(x))
+    np.random.seed(7)                                          # default stream: numpy's global one, as in the reference
+    a = mcmc.MCRotationMove.rotate_positions(x)
+    np.random.seed(7)
+    assert np.array_equal(a, mcmc.MCRotationMove.rotate_positions(x))
+    m = mcmc.MCDisplacementMove(displacement_sigma=2.0 * unit.angstrom, atom_subset=[4])
+    assert abs(m.displacement_sigma - 0.2) < 1e-15 and m._subset() == slice(4, 5) and m.statistics == dict(n_accepted=0, n_proposed=0)
+
+
+def _oscillator_sampler(engine, n_iterations, temperatures=(200.0, 300.0, 450.0), sigma=0.08, with_langevin=False):
+    ho = testsystems.HarmonicOscillator(K=100.0 * unit.kilojoules_per_mole / unit.nanometer ** 2, mass=12.0 * unit.amu)
+    thermo = [states.ThermodynamicState(ho.system, t * unit.kelvin) for t in temperatures]
+    moves = [mcmc.MCDisplacementMove(displacement_sigma=sigma * unit.nanometer)]
+    if with_langevin:
+        moves.append(mcmc.LangevinDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=10.0 / unit.picosecond, n_steps=5))
+    move = mcmc.SequenceMove(moves) if len(moves) > 1 else moves[0]
+    s = MultiStateSampler(mcmc_moves=move, number_of_iterations=n_iterations, engine=engine, seed=13, online_analysis_interval=None)
+    ss = states.SamplerState(np.zeros((1, 3)), box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    s.create(thermo, [copy.deepcopy(ss) for _ in temperatures], storage=None)
+    return s
+
+
+def test_displacement_moves_sample_the_boltzmann_distribution_of_each_state():
+    """A particle in a 3-D harmonic well moved ONLY by MCDisplacementMove: <x^2> per axis = kT / K at each of three temperatures
+    (no mixing, so replica r stays in state r); acceptance between 0 and 1 and lower for the colder, narrower states."""
+    n = 1500
+    s = _oscillator_sampler(OracleEngine(), n)
+    x2 = np.zeros(3)
+    for it in range(n):
+        s.run(1)
+        x = np.stack([st.positions for st in s.sampler_states])[:, 0, :]
+        if it >= 100:
+            x2 += (x ** 2).sum(axis=1) / 3.0
+    want = kB * np.array([200.0, 300.0, 450.0]) / 100.0
+    got = x2 / (n - 100)
+    assert np.all(np.abs(got / want - 1.0) < 0.15), got / want
+    moves = s._mcmc_moves
+    assert all(m.n_proposed == n for m in moves)
+    frac = [m.n_accepted / m.n_proposed for m in moves]
+    assert 0.2 < frac[0] < frac[1] < frac[2] < 0.95, frac
+
+
+def test_rejected_replicas_keep_their_positions_and_accepted_ones_move_rigidly():
+    """Alanine dipeptide in water, the dipeptide (atoms 0..21) rotated / displaced as a body: a rejected replica's coordinates
+    are untouched to the last bit; an accepted one differs only in the subset, by a rigid motion."""
+    al = testsystems.AlanineDipeptideExplicit()
+    subset = list(range(22))
+    seq = mcmc.SequenceMove([mcmc.MCDisplacementMove(displacement_sigma=0.01 * unit.nanometer, atom_subset=subset),
+                             mcmc.MCRotationMove(atom_subset=subset)])
+    s = ReplicaExchangeSampler(mcmc_moves=seq, number_of_iterations=1, engine=OracleEngine(system_factory=ForceFieldOracle), seed=2,
+                               online_analysis_interval=None)
+    thermo = [states.ThermodynamicState(al.system, t * unit.kelvin) for t in (300.0, 320.0, 340.0)]
+    s.create(thermo, [states.SamplerState(al.positions, box_vectors=al.system.getDefaultPeriodicBoxVectors())], storage=None)
+    x0 = np.stack([st.positions for st in s.sampler_states])
+    s.run()
+    x1 = np.stack([st.positions for st in s.sampler_states])
+    disp = [m.move_list[0] for m in s._mcmc_moves]
+    rot = [m.move_list[1] for m in s._mcmc_moves]
+    assert sum(m.n_proposed for m in disp) == 3 and sum(m.n_proposed for m in rot) == 3
+    assert sum(m.n_accepted for m in rot) == 0                 # a random rotation of the solute inside its water shell clashes
+    assert sum(m.n_accepted for m in disp) >= 1                # a 0.01 nm nudge is mostly accepted
+    for r in range(3):
+        assert np.array_equal(x1[r][22:], x0[r][22:])
+        shift = x1[r][:22] - x0[r][:22]
+        assert np.allclose(shift, shift[0], atol=1e-12)
+    assert any(np.abs(x1[r][:22] - x0[r][:22]).max() > 1e-4 for r in range(3))
+
+
+def test_moves_with_different_parameters_per_state_are_refused():
+    ho = testsystems.HarmonicOscillator()
+    thermo = [states.ThermodynamicState(ho.system, t * unit.kelvin) for t in (250.0, 300.0)]
+    moves = [mcmc.MCDisplacementMove(displacement_sigma=s * unit.nanometer) for s in (0.1, 0.2)]
+    s = MultiStateSampler(mcmc_moves=moves, number_of_iterations=1, engine=OracleEngine(), seed=1)
+    ss = states.SamplerState(np.zeros((1, 3)), box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    with pytest.raises(NotImplementedError, match='identical'):
+        s.create(thermo, [ss, copy.deepcopy(ss)], storage=None)
+        s.run()
+
+
+@pytest.mark.gpu
+def test_device_and_oracle_engines_take_the_same_decisions(hip_engine_factory):
+    """The same displacement + Langevin sequence on the device and on the f64 oracle engine: the host draws are identical, the
+    energies agree to fp32, so the per-state acceptance counts agree (up to rare borderline cases) and both sample the well."""
+    counts = []
+    for eng in (hip_engine_factory(), OracleEngine()):
+        s = _oscillator_sampler(eng, 60, with_langevin=True)
+        s.run()
+        counts.append([(m.move_list[0].n_accepted, m.move_list[0].n_proposed) for m in s._mcmc_moves])
+        x = np.stack([st.positions for st in s.sampler_states])
+        assert np.all(np.abs(x) < 1.5)
+    assert [p for _, p in counts[0]] == [60, 60, 60] == [p for _, p in counts[1]]
+    assert all(abs(a - b) <= 6 for (a, _), (b, _) in zip(*counts))
+    assert all(0 < a < 60 for a, _ in counts[0])
+
+
+@pytest.mark.gpu
+def test_device_rejections_restore_the_solute_exactly(hip_engine_factory):
+    al = testsystems.AlanineDipeptideExplicit()
+    subset = list(range(22))
+    seq = mcmc.SequenceMove([mcmc.MCRotationMove(atom_subset=subset),
+                             mcmc.MCDisplacementMove(displacement_sigma=0.005 * unit.nanometer, atom_subset=subset)])
+    s = ReplicaExchangeSampler(mcmc_moves=seq, number_of_iterations=2, engine=hip_engine_factory(), seed=2, online_analysis_interval=None)
+    thermo = [states.ThermodynamicState(al.system, t * unit.kelvin) for t in (300.0, 320.0, 340.0)]
+    s.create(thermo, [states.SamplerState(al.positions, box_vectors=al.system.getDefaultPeriodicBoxVectors())], storage=None)
+    x0 = np.stack([st.positions for st in s.sampler_states]).astype(np.float32)
+    s.run()
+    x1 = np.stack([st.positions for st in s.sampler_states]).astype(np.float32)
+    rot = [m.move_list[0] for m in s._mcmc_moves]
+    disp = [m.move_list[1] for m in s._mcmc_moves]
+    assert sum(m.n_proposed for m in rot) == 6 and sum(m.n_accepted for m in rot) == 0
+    assert sum(m.n_proposed for m in disp) == 6 and sum(m.n_accepted for m in disp) >= 1
+    assert np.array_equal(x1[:, 22:], x0[:, 22:])              # water never moves: no dynamics in this sequence
