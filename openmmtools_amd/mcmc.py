@@ -121,6 +121,28 @@ class LangevinDynamicsMove(LangevinSplittingDynamicsMove):
                          constraint_tolerance=constraint_tolerance, **kwargs)
 
 
+class IntegratorMove(LangevinSplittingDynamicsMove):
+    """mcmc.py:977-1020: ``n_steps`` of a caller-supplied integrator.  The engine runs Langevin splittings, so the integrator
+    must be one of ``openmmtools_amd.integrators`` (LangevinIntegrator and its named splittings); its temperature is replaced
+    by the thermodynamic state's when the move is applied, as the reference's thermostated integrators are (:676-680)."""
+
+    def __init__(self, integrator, n_steps, **kwargs):
+        if not isinstance(integrator, integrators.LangevinIntegrator):
+            raise NotImplementedError('IntegratorMove runs the Langevin-splitting integrators of openmmtools_amd.integrators; got %s'
+                                      % type(integrator).__name__)
+        super().__init__(timestep=integrator.getStepSize(), collision_rate=integrator._gamma, n_steps=n_steps,
+                         splitting=integrator.splitting, constraint_tolerance=integrator.getConstraintTolerance(),
+                         measure_shadow_work=integrator._measure_shadow_work and not integrator.is_metropolized,
+                         measure_heat=integrator.measure_heat, **kwargs)
+        self.integrator = integrator
+
+    def _get_integrator(self, thermodynamic_state):
+        import copy
+        integ = copy.deepcopy(self.integrator)                 # :1003-1009: a copy per application
+        integ.setTemperature(thermodynamic_state.temperature)
+        return integ
+
+
 class GHMCMove(LangevinSplittingDynamicsMove):
     """mcmc.py:1323-1490: generalized hybrid Monte Carlo -- ``n_steps`` of GHMCIntegrator, i.e. the Metropolized splitting
     "O { V R V } O" (integrators.py:2286), whose accepted / attempted steps the move accumulates (the reference reads the

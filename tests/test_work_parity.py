@@ -308,3 +308,17 @@ def test_cpu_library_hmc_trajectories_follow_the_oracle(cpu_engine):
 @pytest.mark.gpu
 def test_device_hmc_trajectories_follow_the_oracle(hip_engine_factory):
     _hmc_case(hip_engine_factory)
+
+
+def test_integrator_move_wraps_the_named_langevin_integrators():
+    """mcmc.py:977-1020: IntegratorMove(integrator, n_steps) carries the integrator's program to the engine."""
+    from openmmtools_amd import integrators, unit
+    integ = integrators.BAOABIntegrator(temperature=250.0 * unit.kelvin, collision_rate=3.0 / unit.picosecond, timestep=1.5 * unit.femtosecond)
+    m = mcmc.IntegratorMove(integ, n_steps=7)
+    assert (m.splitting, m.n_steps) == (integ.splitting, 7) and abs(m.timestep - 0.0015) < 1e-15 and abs(m.collision_rate - 3.0) < 1e-12
+    applied = m._get_integrator(type('S', (), {'temperature': 310.0})())
+    assert applied is not integ and applied.getTemperature() == 310.0 and integ.getTemperature() == 250.0
+    with pytest.raises(NotImplementedError):
+        mcmc.IntegratorMove(object(), n_steps=1)
+    from openmmtools_amd.multistate import MultiStateSampler
+    assert MultiStateSampler._move_key(m)[0] == 'langevin'
