@@ -14,6 +14,42 @@ class MCMCMove:
     pass
 
 
+class MCMCSampler:
+    """mcmc.py:216-347: one thermodynamic state, one configuration, one move applied ``n_iterations`` times.  The reference calls
+    ``move.apply`` in a loop; here the same engine that propagates the replicas of a multistate sampler runs it as a
+    one-replica, one-state ensemble (no mixing, nothing stored), so every move the engine knows is available unchanged."""
+
+    def __init__(self, thermodynamic_state, sampler_state, move, engine=None, seed=0xC0FFEE):
+        import copy
+        self.thermodynamic_state = copy.deepcopy(thermodynamic_state)       # :247-249
+        self.sampler_state = copy.deepcopy(sampler_state)
+        self.move = move
+        self._engine, self._seed, self._driver = engine, seed, None
+
+    def _ensemble(self):
+        if self._driver is None:
+            from .multistate import MultiStateSampler
+            d = MultiStateSampler(mcmc_moves=[self.move], number_of_iterations=0, engine=self._engine, seed=self._seed,
+                                  online_analysis_interval=None)
+            d.create([self.thermodynamic_state], [self.sampler_state], storage=None)
+            d._mcmc_moves = [self.move]                                      # the caller's object collects the statistics
+            d._program_engine_move()
+            self._driver = d
+        return self._driver
+
+    def run(self, n_iterations=1):
+        """:251-266."""
+        d = self._ensemble()
+        d.extend(int(n_iterations))
+        self.sampler_state = d.sampler_states[0]
+
+    def minimize(self, tolerance=1.0 * unit.kilocalories_per_mole / unit.angstroms, max_iterations=100):
+        """:268-300 (the engine's FIRE minimiser, as MultiStateSampler.minimize)."""
+        d = self._ensemble()
+        d.minimize(tolerance=tolerance, max_iterations=max_iterations)
+        self.sampler_state = d.sampler_states[0]
+
+
 class SequenceMove(MCMCMove):
     """mcmc.py:350-440: the moves are applied in order, once per iteration."""
 

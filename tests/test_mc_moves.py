@@ -136,3 +136,27 @@ def test_device_rejections_restore_the_solute_exactly(hip_engine_factory):
     assert sum(m.n_proposed for m in rot) == 6 and sum(m.n_accepted for m in rot) == 0
     assert sum(m.n_proposed for m in disp) == 6 and sum(m.n_accepted for m in disp) >= 1
     assert np.array_equal(x1[:, 22:], x0[:, 22:])              # water never moves: no dynamics in this sequence
+
+
+def test_mcmc_sampler_runs_one_configuration_through_the_engine():
+    """mcmc.py:216-347 MCMCSampler(thermodynamic_state, sampler_state, move).run(n): the harmonic well sampled by a
+    displacement + Langevin sequence; the caller's move objects collect the statistics; minimize() goes downhill."""
+    ho = testsystems.HarmonicOscillator(K=100.0 * unit.kilojoules_per_mole / unit.nanometer ** 2, mass=12.0 * unit.amu)
+    ts_ = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(np.full((1, 3), 0.3), box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    disp = mcmc.MCDisplacementMove(displacement_sigma=0.1 * unit.nanometer)
+    move = mcmc.SequenceMove([disp, mcmc.LangevinDynamicsMove(timestep=2.0 * unit.femtosecond, n_steps=10)])
+    sampler = mcmc.MCMCSampler(ts_, ss, move, engine=OracleEngine(), seed=8)
+    assert sampler.sampler_state is not ss
+    x2 = 0.0
+    for it in range(300):
+        sampler.run(1)
+        x2 += (sampler.sampler_state.positions ** 2).sum() / 3.0
+    assert abs(x2 / 300 / (kB * 300.0 / 100.0) - 1.0) < 0.35
+    assert disp.n_proposed == 300 and 0 < disp.n_accepted < 300
+    sampler.run(5)
+    assert disp.n_proposed == 305
+    far = mcmc.MCMCSampler(ts_, states.SamplerState(np.full((1, 3), 0.8), box_vectors=ho.system.getDefaultPeriodicBoxVectors()),
+                           mcmc.LangevinDynamicsMove(n_steps=1), engine=OracleEngine(), seed=1)
+    far.minimize(tolerance=0.5 * unit.kilojoules_per_mole / unit.nanometer, max_iterations=3000)
+    assert np.abs(far.sampler_state.positions).max() < 0.05
