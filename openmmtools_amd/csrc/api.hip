@@ -267,6 +267,8 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     REMD_CHECK(h, hipMemcpy(h->d_pos, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     REMD_CHECK(h, hipMemcpy(h->d_vel, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     REMD_CHECK(h, hipMemcpy(h->d_box, hb.data(), sizeof(float) * 4 * R_local, hipMemcpyHostToDevice));
+    h->box_uniform = true;
+    for (int r = 1; r < R_local; ++r) for (int k = 0; k < 3; ++k) if (hb[4 * r + k] != hb[k]) h->box_uniform = false;
     h->box_version++;
     h->forces_valid = false; h->force_zeroed = false;
     h->cbins_ready = false;              // (bins a chain filled for positions that are gone)

@@ -115,6 +115,7 @@ int remd_barostat_attempt(remd_ctx* h)
                        h->d_box_old, h->d_baro);
     hipLaunchKernelGGL(baro_scale_kernel, dim3((n_groups + 255) / 256, R), dim3(256), 0, h->stream, n_groups, grp_first,
                        grp_size, Npad, h->d_pos, h->d_box_old, h->d_baro);
+    h->box_uniform = false;                  // (every replica draws its own volume)
     h->box_version++;
     h->force_zeroed = false;
     if ((rc = remd_compute_forces(h, true))) return rc;                         // U' and forces of the scaled configuration

@@ -1093,8 +1093,8 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             base.Fg[g] = h->d_force_g[g];
         }
         h->force_g_n = nf;
-        unsigned named = 0u, all = 0u;
-        for (int g = 0; g < 4; ++g) { if (h->nVg[g] > 0) named |= group_mask[g]; all |= group_mask[g]; }
+        unsigned named = 0u;
+        for (int g = 0; g < 4; ++g) if (h->nVg[g] > 0) named |= group_mask[g];
         for (int c = 0; c < 6; ++c)
             if (h->fgroup[c] > 3 || !(named & (1u << c)))
                 return remd_fail(h, -3, "multiple-time-step splitting: a force class sits in a force group that no V of the splitting names "

@@ -39,6 +39,7 @@ struct pme_state {
     int xs_sw = 0;                      // y-slab width of pme_x_fused_kernel (planes that do not fit the LDS)
     int ys_sh = 0;                      // x-slab height of pme_y_slab_kernel (the y passes of those planes)
     float* d_infl = nullptr; int infl_version = -1;   // influence function [R][nz/2+1][nx][ny], rebuilt when a box changes
+    int infl_rep = 0;                                 // planes between two replicas' tables (0: all boxes equal, one table)
     bool z_half = false;               // nz even: z transforms run as nz/2-point complex FFTs of packed real pairs
     double* d_energy = nullptr;        // [R][n_eblk]
     int n_eblk = 0;
@@ -590,7 +591,7 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
                          const float2* twx, const float2* twy,
                          const float* __restrict__ bmx, const float* __restrict__ bmy, const float* __restrict__ bmz,
                          const float* __restrict__ box, float alpha, int with_energy, double* __restrict__ energy, int n_eblk,
-                         const float* __restrict__ infl)
+                         const float* __restrict__ infl, int infl_rep)
 {
     __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -616,7 +617,7 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
     fft_lines_inplace<-1, XY_PPT>(plx, scx, buf, PS, twx, tid, XY_THREADS);     // along x
     {
         const float wz = (kz == 0 || 2 * kz == nz) ? 1.f : 2.f;     // Hermitian half: weight of the mirrored plane
-        const float* __restrict__ G = infl + ((size_t)r * nzc + kz) * np;
+        const float* __restrict__ G = infl + ((size_t)r * infl_rep + kz) * np;
         double e_acc = 0.0;
         for (int idx = tid; idx < np; idx += XY_THREADS) {
             const int kx = fft_div(idx, mny, ny);
@@ -648,7 +649,7 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
 #define XS_THREADS 256
 __global__ __launch_bounds__(XS_THREADS)
 void pme_x_fused_kernel(fft_plan plx, fft_sched scx, int ny, int nz, int sw, float2* __restrict__ spec, const float2* twx,
-                        int with_energy, double* __restrict__ energy, int n_eblk, const float* __restrict__ infl)
+                        int with_energy, double* __restrict__ energy, int n_eblk, const float* __restrict__ infl, int infl_rep)
 {
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -659,7 +660,7 @@ void pme_x_fused_kernel(fft_plan plx, fft_sched scx, int ny, int nz, int sw, flo
     const int kz = blockIdx.x / nslab, slab = blockIdx.x - kz * nslab, r = blockIdx.y, tid = threadIdx.x;
     const int y0 = slab * sw;
     float2* P = spec + ((size_t)r * nzc + kz) * nx * ny;
-    const float* __restrict__ G = infl + ((size_t)r * nzc + kz) * nx * ny;
+    const float* __restrict__ G = infl + ((size_t)r * infl_rep + kz) * nx * ny;
     const unsigned msw = fft_magic((unsigned)sw);
     for (int idx = tid; idx < nx * sw; idx += XS_THREADS) { const int x = fft_div(idx, msw, sw), yy = idx - x * sw; buf[x * PS + yy] = P[x * ny + y0 + yy]; }
     for (int idx = tid; idx < nx; idx += XS_THREADS) s_twx[idx] = twx[idx];
@@ -1083,16 +1084,18 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         if (s->xy_fused || s->xs_sw > 0) {
             if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
             if (s->infl_version != h->box_version) {
-                hipLaunchKernelGGL(pme_influence_table_kernel, dim3(s->nzc, s->R), dim3(256), 0, st, nx, ny, nz, s->d_bmod[0], s->d_bmod[1],
+                // one table serves every replica while all boxes are the same (constant volume): 1 / R of the table traffic
+                hipLaunchKernelGGL(pme_influence_table_kernel, dim3(s->nzc, h->box_uniform ? 1 : s->R), dim3(256), 0, st, nx, ny, nz, s->d_bmod[0], s->d_bmod[1],
                                    s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl);
                 s->infl_version = h->box_version;
+                s->infl_rep = h->box_uniform ? 0 : s->nzc;
             }
         }
         if (s->xy_fused) {
             remd_prof_scope pxy(h, "pme_xy", st);
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
-                               (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl);
+                               (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl, s->infl_rep);
         } else if (s->xs_sw > 0) {
             // spec layout [kz][x][y]: y passes on contiguous lines, then the fused x pass on LDS-resident y slabs
             const size_t ylds = sizeof(float2) * ((size_t)s->ys_sh * (ny | 1) + ny + 2);
@@ -1104,7 +1107,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
             const int PS = s->xs_sw | 1;
             const size_t lds = sizeof(float2) * ((size_t)nx * PS + nx + 2) + 64;
             hipLaunchKernelGGL(pme_x_fused_kernel, dim3(s->nzc * (ny / s->xs_sw), s->R), dim3(XS_THREADS), lds, st, make_plan(s, 0), s->sch_x,
-                               ny, nz, s->xs_sw, s->d_grid, s->d_tw[0], with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl);
+                               ny, nz, s->xs_sw, s->d_grid, s->d_tw[0], with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl, s->infl_rep);
             if (s->ys_sh > 0)
                 hipLaunchKernelGGL(pme_y_slab_kernel<+1>, dim3(s->nzc * (nx / s->ys_sh), s->R), dim3(XS_THREADS), ylds, st, make_plan(s, 1), s->sch_y,
                                    nx, nz, s->ys_sh, s->d_grid, s->d_tw[1]);

@@ -130,6 +130,7 @@ struct remd_ctx {
     double* d_pressure = nullptr;      // [K] kJ/mol/nm^3 (bar * N_A * 1e-25)
     double* d_baro = nullptr;          // [R][8]: volumeScale, attempted, accepted (adaptation window), total attempted, total accepted, dV, newV, oldV
     float* d_box_old = nullptr; float4* d_baro_x0 = nullptr; long long* d_baro_f0 = nullptr; double* d_baro_U0 = nullptr; int* d_baro_acc = nullptr;
+    bool box_uniform = false;          // every local replica has the same box (set_replicas; a barostat move clears it)
     int box_version = 0;               // bumped whenever the box edges on the device change (PME influence table)
     int n_restart_attempts = 0;        // mcmc.py:706-759
     unsigned int* d_mix_log = nullptr; size_t mix_log_n = 0;      // swap-all attempt log (si, sj, accepted) when the counters do not fit
