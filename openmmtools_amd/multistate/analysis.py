@@ -110,12 +110,54 @@ def get_equilibration_data_per_sample(timeseries_to_analyze, fast=True, max_subs
     counter = np.arange(max_subset)
     i_t = np.floor(counter * time_size / max_subset).astype(int)
     for i, t in enumerate(i_t):
-        try:
-            g_i[i] = statistical_inefficiency(series[t:], fast=fast)
-        except Exception:
-            g_i[i] = (time_size - t + 1)
+        g_i[i] = statistical_inefficiency(series[t:], fast=fast)       # (:176-181: an error here is raised, not papered over)
         n_effective_i[i] = (time_size - t + 1) / g_i[i]
-    return i_t, g_i, n_effective_i
+    return i_t[1:], g_i[1:], n_effective_i[1:]                          # :190: the origin t = 0 is not a candidate
+
+
+def get_decorrelation_time(timeseries_to_analyze):
+    """multistate/utils.py:98-104."""
+    return statistical_inefficiency(timeseries_to_analyze)
+
+
+def get_equilibration_data(timeseries_to_analyze, fast=True, max_subset=1000):
+    """multistate/utils.py:195-235 (kept by the reference for old callers): (n_equilibration, g_t, n_effective_max)."""
+    i_t, g_i, n_effective_i = get_equilibration_data_per_sample(timeseries_to_analyze, fast=fast, max_subset=max_subset)
+    i_max = n_effective_i.argmax()
+    return i_t[i_max], g_i[i_max], n_effective_i.max()
+
+
+def remove_unequilibrated_data(data, number_equilibrated, axis):
+    """multistate/utils.py:238-266: drop the first ``number_equilibrated`` entries along ``axis``."""
+    cast = np.asarray(data)
+    slc = [slice(None)] * cast.ndim
+    slc[axis] = slice(number_equilibrated, None)
+    return cast[tuple(slc)]
+
+
+def subsample_data_along_axis(data, subsample_rate, axis):
+    """multistate/utils.py:269-300: every ``subsample_rate``-th entry (rounded as subsample_correlated_data does) along ``axis``."""
+    cast = np.asarray(data)
+    indices = subsample_correlated_data(np.zeros(cast.shape[axis]), g=subsample_rate)
+    return np.take(cast, indices, axis=axis)
+
+
+def generate_phase_name(current_name, name_list):
+    """multistate/utils.py:60-95: a name not yet in ``name_list`` ('phase0', 'phase1', ... or the given name + counter)."""
+    counter = 0
+    if current_name is None:
+        name = 'phase%d' % counter
+        while name in name_list:
+            counter += 1
+            name = 'phase%d' % counter
+        return name
+    if current_name in name_list:
+        name = current_name + str(counter)
+        while name in name_list:
+            counter += 1
+            name = current_name + str(counter)
+        return name
+    return current_name
 
 
 # ---- MBAR --------------------------------------------------------------------------------------------------------
@@ -461,3 +503,16 @@ class MultiStateSamplerAnalyzer:
     def get_free_energy(self):
         """(Delta_f_ij, dDelta_f_ij) in kT between all (unsampled + sampled) states (:1958-2003)."""
         return self.mbar.compute_free_energy_differences()
+
+
+
+class ReplicaExchangeAnalyzer(MultiStateSamplerAnalyzer):
+    """replicaexchange.py:427-439."""
+
+
+class ParallelTemperingAnalyzer(ReplicaExchangeAnalyzer):
+    """paralleltempering.py:240-252."""
+
+
+class SAMSAnalyzer(MultiStateSamplerAnalyzer):
+    """sams.py:694-704."""

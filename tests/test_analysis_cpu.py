@@ -32,12 +32,32 @@ def test_subsampling_and_equilibration_detection():
     rng = np.random.default_rng(2)
     u = rng.normal(size=600) + 30.0 * np.exp(-np.arange(600) / 15.0)
     i_t, g_i, n_eff = an.get_equilibration_data_per_sample(u, max_subset=100)
-    assert len(i_t) == len(g_i) == len(n_eff) == 100
+    assert len(i_t) == len(g_i) == len(n_eff) == 99 and i_t[0] == 6            # multistate/utils.py:190: the origin t = 0 is dropped
     t0 = i_t[n_eff.argmax()]
     assert 30 <= t0 <= 200
     # constant series: the special trap of multistate/utils.py:170-174
     i_t, g_i, n_eff = an.get_equilibration_data_per_sample(np.ones(5))
     assert list(g_i) == [1, 1, 1, 1] and list(n_eff) == [5, 4, 3, 2]
+
+
+def test_time_series_helpers_of_multistate_utils():
+    """multistate/utils.py:60-300, importable from both places the reference exposes them."""
+    from openmmtools_amd import multistate
+    from openmmtools_amd.multistate import utils as mu
+    assert mu.get_equilibration_data is an.get_equilibration_data and multistate.remove_unequilibrated_data is an.remove_unequilibrated_data
+    rng = np.random.default_rng(2)
+    u = rng.normal(size=600) + 30.0 * np.exp(-np.arange(600) / 15.0)
+    n_eq, g_t, n_eff = an.get_equilibration_data(u, max_subset=100)
+    i_t, g_i, n_i = an.get_equilibration_data_per_sample(u, max_subset=100)
+    assert (n_eq, g_t, n_eff) == (i_t[n_i.argmax()], g_i[n_i.argmax()], n_i.max())
+    assert an.get_decorrelation_time(u[200:]) == an.statistical_inefficiency(u[200:])
+    data = np.arange(24).reshape(2, 12)
+    assert an.remove_unequilibrated_data(data, 5, axis=1).shape == (2, 7) and an.remove_unequilibrated_data(data, 1, axis=0).shape == (1, 12)
+    assert np.array_equal(an.subsample_data_along_axis(data, 2.5, axis=1), data[:, [0, 2, 5, 8, 10]])
+    assert an.generate_phase_name(None, ['phase0', 'phase1']) == 'phase2'
+    assert an.generate_phase_name('complex', ['complex', 'complex0']) == 'complex1' and an.generate_phase_name('solvent', ['complex']) == 'solvent'
+    assert issubclass(multistate.ParallelTemperingAnalyzer, multistate.ReplicaExchangeAnalyzer)
+    assert issubclass(multistate.SAMSAnalyzer, multistate.MultiStateSamplerAnalyzer)
 
 
 def _harmonic_samples(sigmas, sampled, n_per_state, rng):
