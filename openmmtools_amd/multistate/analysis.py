@@ -353,6 +353,87 @@ class MultiStateSamplerAnalyzer:
         self._kwargs = dict(analysis_kwargs or {})
         self._equilibration_data = None
         self._mbar = None
+        self.name = None                       # :611-617: the phase name used when analyzers are combined
+        self.reference_states = (0, -1)         # :633-643: the two states a phase's free energy is reported between
+        self._sign = '+'
+
+    # ---- the PhaseAnalyzer surface (multistateanalyzer.py:446-1134) ----------------------------------------------
+    observables = ('free_energy', 'entropy', 'enthalpy')     # default registry (:304-340): two-state observables, errors in quadrature
+
+    @property
+    def reporter(self):
+        return self._reporter
+
+    @property
+    def n_iterations(self):
+        """:646-652: the last completely written iteration (capped by ``max_n_iterations``)."""
+        last = self._reporter.read_last_iteration(last_checkpoint=False)
+        return last if self._max_n_iterations is None else min(last, self._max_n_iterations)
+
+    @property
+    def n_replicas(self):
+        return int(self._read_energies()[0].shape[0])
+
+    @property
+    def n_states(self):
+        return int(self._read_energies()[0].shape[1])
+
+    @property
+    def kT(self):
+        """:684-693: kT of the first stored thermodynamic state, kJ/mol."""
+        from .. import constants
+        st = self._reporter.read_thermodynamic_states()[0][0]
+        return constants.kB * float(st.temperature)
+
+    def read_energies(self):
+        """:831-896: (sampled [replica, state, iteration], unsampled, neighborhoods, replica state indices [replica, iteration])."""
+        return self._read_energies()
+
+    def clear(self):
+        """:596-608 / :1230-1241: forget everything derived from the storage."""
+        self._equilibration_data = None
+        self._mbar = None
+
+    @property
+    def effective_length(self):
+        """:2207-2221: number of uncorrelated production samples."""
+        e, _, _, states = self._read_energies()
+        return self._get_equilibration_data(e, states)[2]
+
+    def show_mixing_statistics(self, cutoff=0.05, number_equilibrated=None):
+        """:1305-1351: log the state-to-state transition matrix (entries below ``cutoff`` blank) and what its second
+        eigenvalue says about the equilibration of the state walk; returns the text."""
+        import logging
+        stats = self.generate_mixing_statistics(number_equilibrated=number_equilibrated)
+        t_ij, mu = stats.transition_matrix, stats.eigenvalues
+        n = t_ij.shape[0]
+        lines = ['Cumulative symmetrized state mixing transition matrix:', '%6s' % '' + ''.join('%6d' % j for j in range(n))]
+        for i in range(n):
+            lines.append('%-6d' % i + ''.join(('%6.3f' % p) if p >= cutoff else '%6s' % '' for p in t_ij[i]))
+        if mu[1] >= 1:
+            lines.append('Perron eigenvalue is unity; Markov chain is decomposable.')
+        elif mu[1] <= 0:
+            lines.append('Perron eigenvalue is %9.5f; state equilibration timescale is less than one iteration.' % mu[1].real)
+        else:
+            lines.append('Perron eigenvalue is %9.5f; state equilibration timescale is ~ %.1f iterations' % (mu[1].real, 1.0 / (1.0 - mu[1].real)))
+        text = '\n'.join(lines)
+        logging.getLogger(__name__).info(text)
+        return text
+
+    def _combine(self, other, operator):
+        mine = dict(phases=[self], names=[generate_phase_name(self.name, [])], signs=[self._sign])
+        self._sign = '+'
+        return MultiPhaseAnalyzer(mine)._combine_phases(other, operator)
+
+    def __add__(self, other):
+        return self._combine(other, '+')
+
+    def __sub__(self, other):
+        return self._combine(other, '-')
+
+    def __neg__(self):
+        self._sign = '-' if self._sign == '+' else '+'           # :1128-1134
+        return self
 
     def _read_energies(self):
         """[replica, state, iteration] arrays like the reference's ``_read_energies`` (:1353-1412)."""
@@ -516,3 +597,70 @@ class ParallelTemperingAnalyzer(ReplicaExchangeAnalyzer):
 
 class SAMSAnalyzer(MultiStateSamplerAnalyzer):
     """sams.py:694-704."""
+
+
+class MultiPhaseAnalyzer:
+    """multistateanalyzer.py:2224-2570: several phases combined with signs (``complex - solvent``); an observable of the
+    combination is the signed sum of each phase's value between its ``reference_states``, errors added in quadrature (the
+    default registry's free_energy / entropy / enthalpy, :304-340)."""
+
+    def __init__(self, phases):
+        self._phases, self._names, self._signs = list(phases['phases']), list(phases['names']), list(phases['signs'])
+        shared = [o for o in MultiStateSamplerAnalyzer.observables if all(o in getattr(p, 'observables', ()) for p in self._phases)]
+        if not shared:
+            raise RuntimeError('There are no shared computable observable between the phases, combining them will do nothing.')
+        self._observables = tuple(shared)
+        for name in shared:
+            setattr(self, 'get_' + name, (lambda n: (lambda: self._compute_observable(n)))(name))
+
+    observables = property(lambda self: self._observables)
+    phases = property(lambda self: self._phases)
+    names = property(lambda self: self._names)
+    signs = property(lambda self: self._signs)
+
+    def clear(self):
+        for phase in self._phases:
+            phase.clear()
+
+    def _combine_phases(self, other, operator='+'):
+        phases, names, signs = list(self._phases), list(self._names), list(self._signs)
+        flip = lambda sign: '-' if ((operator == '-') != (sign == '-')) else '+'
+        if isinstance(other, MultiPhaseAnalyzer):
+            for phase, name, sign in zip(other.phases, other.names, other.signs):
+                names.append(generate_phase_name(name, [n for n in other.names if n != name] + names))
+                signs.append(flip(sign))
+                phases.append(phase)
+        elif isinstance(other, MultiStateSamplerAnalyzer):
+            names.append(generate_phase_name(other.name, names))
+            signs.append(flip(other._sign))
+            other._sign = '+'
+            phases.append(other)
+        else:
+            raise TypeError("cannot %s 'MultiPhaseAnalyzer' and '%s' objects" % ('add' if operator == '+' else 'subtract', type(other)))
+        return MultiPhaseAnalyzer(dict(phases=phases, names=names, signs=signs))
+
+    def __add__(self, other):
+        return self._combine_phases(other, '+')
+
+    def __sub__(self, other):
+        return self._combine_phases(other, '-')
+
+    def __neg__(self):
+        import copy
+        out = copy.copy(self)
+        out._signs = ['-' if s == '+' else '+' for s in self._signs]
+        return out
+
+    def __str__(self):
+        return 'MultiPhaseAnalyzer <' + ' '.join('%s%s' % (s, n) for s, n in zip(self._signs, self._names)) + '>'
+
+    def _compute_observable(self, name):
+        value, error = 0.0, 0.0
+        for phase, sign in zip(self._phases, self._signs):
+            v, e = getattr(phase, 'get_' + name)()
+            if not isinstance(phase, MultiPhaseAnalyzer):
+                i, j = phase.reference_states
+                v, e = v[i, j], e[i, j]
+            value = value + v if sign == '+' else value - v
+            error = (error ** 2 + e ** 2) ** 0.5
+        return value, error

@@ -333,3 +333,43 @@ def test_mbar_enthalpy_and_entropy_of_harmonic_oscillators():
     assert 0.5 < np.mean(dds) / np.std(ds, ddof=1) < 2.0
     # identity Delta_s = Delta_u - Delta_f holds for the estimates themselves
     assert np.allclose(r['Delta_s'], r['Delta_u'] - r['Delta_f'], atol=1e-12)
+
+
+def test_phase_surface_and_the_combination_of_phases(tmp_path):
+    """multistateanalyzer.py:446-1134 (PhaseAnalyzer properties), :2224-2570 (MultiPhaseAnalyzer): ``a - b`` reports the signed
+    sum of the phases' free energies between their reference states with the errors added in quadrature."""
+    from openmmtools_amd.constants import kB
+    runs = []
+    for name in ('complex', 'solvent'):
+        (tmp_path / name).mkdir()
+        s, rep = _pt_sampler(tmp_path / name, 120, online_analysis_interval=None)
+        s.run()
+        a = an.MultiStateSamplerAnalyzer(rep)
+        a.name = name
+        runs.append(a)
+    a, b = runs
+    assert a.n_iterations == 120 and a.n_replicas == a.n_states and abs(a.kT - kB * 300.0) < 1e-9 and a.reporter is not None
+    e, eu, nb, st = a.read_energies()
+    assert e.shape == (a.n_replicas, a.n_states, 121) and st.shape == (a.n_replicas, 121)
+    assert a.effective_length > 5
+    text = a.show_mixing_statistics(cutoff=0.01)
+    assert 'Perron eigenvalue' in text and 'transition matrix' in text
+    fa, da = a.get_free_energy()
+    fb, db = b.get_free_energy()
+    diff = a - b
+    assert isinstance(diff, an.MultiPhaseAnalyzer) and diff.names == ['complex', 'solvent'] and diff.signs == ['+', '-']
+    v, err = diff.get_free_energy()
+    assert abs(v - (fa[0, -1] - fb[0, -1])) < 1e-12 and abs(err - np.hypot(da[0, -1], db[0, -1])) < 1e-12
+    total = a + b
+    assert total.signs == ['+', '+'] and abs(total.get_free_energy()[0] - (fa[0, -1] + fb[0, -1])) < 1e-12
+    three = diff - a                                            # a name that is taken gets a counter (multistate/utils.py:60-95)
+    assert three.names == ['complex', 'solvent', 'complex0'] and three.signs == ['+', '-', '-']
+    assert abs(three.get_free_energy()[0] + fb[0, -1]) < 1e-12
+    neg = -diff
+    assert neg.signs == ['-', '+'] and abs(neg.get_enthalpy()[0] + diff.get_enthalpy()[0]) < 1e-12
+    a.reference_states = (0, 1)
+    assert abs((a - b).get_free_energy()[0] - (fa[0, 1] - fb[0, -1])) < 1e-12
+    a.clear()
+    assert a._mbar is None
+    with pytest.raises(TypeError):
+        diff + 3
