@@ -14,16 +14,73 @@ from . import constants
 from .unit import to_md
 
 
+class ThermodynamicsError(Exception):
+    """states.py:272-337."""
+
+
+class SamplerStateError(Exception):
+    """states.py:340-382."""
+
+
+def create_thermodynamic_state_protocol(system, protocol, constants=None, composable_states=None):
+    """states.py:39-141: one state per entry of the protocol -- ``protocol`` maps attribute names (temperature, pressure,
+    lambda_sterics, ...) to equally long value lists, ``constants`` to values shared by every state; ``system`` is a System
+    (then a temperature must be among them) or a ThermodynamicState; ``composable_states`` wrap it into a
+    CompoundThermodynamicState first."""
+    protocol = dict(protocol)
+    if len(protocol) == 0:
+        raise ValueError('No protocol has been specified.')
+    lengths = {len(v) for v in protocol.values()}
+    if len(lengths) != 1:
+        raise ValueError('The protocol parameter values have different lengths!\n{}'.format(protocol))
+    n = lengths.pop()
+    constants_ = dict(constants or {})
+    if set(constants_) & set(protocol):
+        raise ValueError('Some parameters have been specified both in constants and protocol.')
+    for key, value in constants_.items():
+        protocol[key] = [value] * n
+    if isinstance(system, ThermodynamicState):
+        thermo_state = system
+    else:
+        if 'temperature' in constants_:
+            temperature = constants_['temperature']
+        elif 'temperature' in protocol:
+            temperature = protocol['temperature'][0]
+        else:
+            raise ValueError('If a System is passed the list of constants must specify the temperature.')
+        thermo_state = ThermodynamicState(system, temperature=temperature)
+    if composable_states is not None:
+        if not isinstance(composable_states, (list, tuple)):
+            composable_states = [composable_states]
+        thermo_state = CompoundThermodynamicState(thermo_state, composable_states)
+    out = [copy.deepcopy(thermo_state) for _ in range(n)]
+    for k, state in enumerate(out):
+        for key, values in protocol.items():
+            if not hasattr(state, key):
+                raise AttributeError('{} object does not have protocol attribute {}'.format(type(state), key))
+            setattr(state, key, values[k])
+    return out
+
+
 class ThermodynamicState:
     def __init__(self, system, temperature, pressure=None):
         self._system = system
         self.temperature = temperature
         # NPT: the reference adds an openmm.MonteCarloBarostat (frequency 25) to the System (states.py:1177-1181); here the
         # pressure (kJ/mol/nm^3, i.e. `p * unit.bar`) and the frequency are handed to the engine's barostat
-        self.pressure = None if pressure is None else float(to_md(pressure))     # Quantity -> kJ/mol/nm^3 (md units)
+        self.pressure = pressure                                                 # Quantity -> kJ/mol/nm^3 (md units)
         self.barostat_frequency = 25
-        if pressure is not None and not system.usesPeriodicBoundaryConditions():
+
+    @property
+    def pressure(self):
+        return self._pressure
+
+    @pressure.setter
+    def pressure(self, value):
+        """states.py:680-703."""
+        if value is not None and not self._system.usesPeriodicBoundaryConditions():
             raise ValueError('pressure is specified but the system is not periodic')          # states.py:1156-1158
+        self._pressure = None if value is None else float(to_md(value))
 
     @property
     def system(self):
@@ -157,6 +214,17 @@ class SamplerState:
     @property
     def n_particles(self):
         return self.positions.shape[0]
+
+    @property
+    def total_energy(self):
+        """states.py:2170-2174: potential + kinetic energy when both are cached, else None."""
+        if self.potential_energy is None or self.kinetic_energy is None:
+            return None
+        return self.potential_energy + self.kinetic_energy
+
+    def has_nan(self):
+        """states.py:2281-2293: any NaN among the positions (what the reference checks) or the velocities."""
+        return bool(np.isnan(self.positions).any() or (self.velocities is not None and np.isnan(self.velocities).any()))
 
     @property
     def volume(self):

@@ -1,0 +1,51 @@
+"""states.create_thermodynamic_state_protocol (states.py:39-141) and the small SamplerState helpers."""
+import numpy as np
+import pytest
+from openmmtools_amd import testsystems, states, unit, alchemy
+
+
+def test_protocol_over_temperature_and_pressure():
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    out = states.create_thermodynamic_state_protocol(lj.system, dict(temperature=[100.0 * unit.kelvin, 120.0, 150.0]),
+                                                     constants=dict(pressure=1.0 * unit.bar))
+    assert [s.temperature for s in out] == [100.0, 120.0, 150.0]
+    assert all(abs(s.pressure - 1.0 * unit.bar) < 1e-15 for s in out) and out[0] is not out[1]
+    with pytest.raises(ValueError, match='No protocol'):
+        states.create_thermodynamic_state_protocol(lj.system, {})
+    with pytest.raises(ValueError, match='different lengths'):
+        states.create_thermodynamic_state_protocol(lj.system, dict(temperature=[1.0, 2.0], pressure=[1.0]))
+    with pytest.raises(ValueError, match='both in constants and protocol'):
+        states.create_thermodynamic_state_protocol(lj.system, dict(temperature=[1.0]), constants=dict(temperature=2.0))
+    with pytest.raises(ValueError, match='must specify the temperature'):
+        states.create_thermodynamic_state_protocol(lj.system, dict(pressure=[1.0]))
+    with pytest.raises(AttributeError, match='does not have protocol attribute'):
+        states.create_thermodynamic_state_protocol(lj.system, dict(temperature=[100.0], lambda_bonds=[1.0]))
+
+
+def test_protocol_over_alchemical_parameters():
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    asys = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, alchemy.AlchemicalRegion(alchemical_atoms=range(4)))
+    base = states.ThermodynamicState(asys, 120.0 * unit.kelvin)
+    out = states.create_thermodynamic_state_protocol(base, dict(lambda_sterics=[1.0, 0.5, 0.0], lambda_electrostatics=[1.0, 1.0, 1.0]),
+                                                     composable_states=states.AlchemicalState.from_system(asys))
+    assert [s.lambda_sterics for s in out] == [1.0, 0.5, 0.0] and all(isinstance(s, states.CompoundThermodynamicState) for s in out)
+    assert all(s.temperature == 120.0 for s in out)
+    out[0].lambda_sterics = 0.25
+    assert out[1].lambda_sterics == 0.5                         # independent copies
+
+
+def test_sampler_state_helpers_and_pressure_rules():
+    ho = testsystems.HarmonicOscillator()
+    ss = states.SamplerState(np.zeros((1, 3)), velocities=np.ones((1, 3)))
+    assert ss.total_energy is None and not ss.has_nan()
+    ss.potential_energy, ss.kinetic_energy = 2.0, 3.5
+    assert ss.total_energy == 5.5
+    ss.velocities[0, 1] = np.nan
+    assert ss.has_nan()
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    st = states.ThermodynamicState(lj.system, 100.0)
+    st.pressure = 2.0 * unit.bar
+    assert abs(st.pressure - 2.0 * unit.bar) < 1e-15
+    st.pressure = None
+    assert st.pressure is None
+    assert issubclass(states.ThermodynamicsError, Exception) and issubclass(states.SamplerStateError, Exception)
