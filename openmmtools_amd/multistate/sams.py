@@ -28,7 +28,7 @@ class SAMSSampler(ReplicaExchangeSampler):
         if weight_update_method not in ('optimal', 'rao-blackwellized'):
             raise ValueError('unknown weight_update_method')
         if adapt_target_probabilities:
-            raise NotImplementedError('adapt_target_probabilities')
+            raise ValueError("Unknown update scheme '{}'. Supported values are {}.".format(adapt_target_probabilities, [False]))   # sams.py:273-278
         self.log_target_probabilities = log_target_probabilities
         self.state_update_scheme = state_update_scheme
         self.locality = None                      # global-jump forces global neighbourhoods (:338-339)
