@@ -27,6 +27,16 @@ def build(sampler_kind, engine, comm, n_iter, storage=None):
                 K=K * unit.kilojoules_per_mole / unit.nanometer ** 2, mass=12.0 * unit.amu).system, 300.0))
         s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm)
         s.create(sts, [ss], storage=storage)
+    elif sampler_kind == 'mc':
+        # a Metropolized displacement, a GHMC integration and a Langevin integration per iteration (mcmc.py:810-975, 1323-1490):
+        # host proposals keyed by the GLOBAL replica, the engine reprogrammed between the two integrator moves
+        from openmmtools_amd.multistate import ReplicaExchangeSampler
+        seq = mcmc.SequenceMove([mcmc.MCDisplacementMove(displacement_sigma=0.05 * unit.nanometer),
+                                 mcmc.GHMCMove(timestep=2.0 * unit.femtosecond, n_steps=6), move])
+        sts = [states.ThermodynamicState(ho.system, T) for T in np.linspace(300.0, 450.0, 5)]
+        s = ReplicaExchangeSampler(mcmc_moves=seq, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm,
+                                   online_analysis_interval=None)
+        s.create(sts, [ss], storage=storage)
     elif sampler_kind == 'pt':
         s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=engine, seed=77, comm=comm,
                                      online_analysis_interval=3)       # MBAR on rank 0 at iterations 3 and 6, error broadcast
@@ -51,7 +61,7 @@ def run(sampler_kind, comm, n_iter=6, storage_dir=None):
         s.run(1)
         history.append((s.replica_thermodynamic_states.copy(), s.energy_thermodynamic_states.copy(),
                         s._n_accepted_matrix.copy(), s._n_proposed_matrix.copy()))
-        analysis.append(np.append(s._last_mbar_f_k, s._last_err_free_energy) if sampler_kind != 'groups' else np.zeros(1))
+        analysis.append(np.append(s._last_mbar_f_k, s._last_err_free_energy) if sampler_kind not in ('groups', 'mc') else np.zeros(1))
     x = np.stack([st.positions for st in s.sampler_states])
     run.last_analysis = np.stack(analysis)          # [iteration, K + 1]: online f_k and the current error estimate
     return history, x, (s._r_begin, s._r_count)
