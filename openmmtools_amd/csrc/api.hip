@@ -77,7 +77,7 @@ int remd_create(remd_handle* out, int device, void* stream)
       hipEventCreateWithFlags(&h->ev_fork, evf); hipEventCreateWithFlags(&h->ev_join, evf); }
     { const char* env = getenv("REMD_OVERLAP"); h->overlap = !(env && atoi(env) == 0); }
     h->sync_events = getenv("REMD_SYNC_EVENTS") && atoi(getenv("REMD_SYNC_EVENTS")) != 0;
-    if (hipMalloc(&h->d_chain_own, 2 * sizeof(unsigned long long)) == hipSuccess) hipMemset(h->d_chain_own, 0, 2 * sizeof(unsigned long long));
+    if (hipMalloc(&h->d_chain_own, 40 * sizeof(unsigned long long)) == hipSuccess) hipMemset(h->d_chain_own, 0, 40 * sizeof(unsigned long long));
     if (hipMalloc(&h->d_sync, 4 * sizeof(unsigned int)) != hipSuccess || hipMemset(h->d_sync, 0, 4 * sizeof(unsigned int)) != hipSuccess) {
         delete h; return remd_fail(nullptr, -2, "remd_create: hipMalloc failed");
     }
@@ -736,7 +736,7 @@ int remd_profile_reset(remd_handle h)
 {
     if (!h) return -1;
     resolve_profile(h); h->prof.clear();
-    if (h->d_chain_own) { hipStreamSynchronize(h->stream); hipMemset(h->d_chain_own, 0, 2 * sizeof(unsigned long long)); }
+    if (h->d_chain_own) { hipStreamSynchronize(h->stream); hipMemset(h->d_chain_own, 0, 40 * sizeof(unsigned long long)); }
     return 0;
 }
 int remd_profile_get(remd_handle h, const char* name, int64_t* n, double* ms)
@@ -749,6 +749,16 @@ int remd_profile_get(remd_handle h, const char* name, int64_t* n, double* ms)
         if (h->d_chain_own) { hipStreamSynchronize(h->stream); hipMemcpy(v, h->d_chain_own, sizeof(v), hipMemcpyDeviceToHost); }
         if (n) *n = (int64_t)v[1];
         if (ms) *ms = (double)v[0] * 1e-5;
+        return 0;
+    }
+    if (std::string(name).rfind("integrate_chain_seg", 0) == 0) {
+        // per-segment stamps of workgroup (0, 0) (a library built with -DCHAIN_STAMPS, tools/chain_segments.py): slot k of
+        // [prologue, token 0 .. token 31 (an 'M' barrier counts as its own token), epilogue stores + binning]
+        const int k = atoi(name + 19);
+        unsigned long long v[40] = {};
+        if (h->d_chain_own && k >= 0 && k < 38) { hipStreamSynchronize(h->stream); hipMemcpy(v, h->d_chain_own, sizeof(v), hipMemcpyDeviceToHost); }
+        if (n) *n = (int64_t)v[1];
+        if (ms) *ms = (double)v[2 + (k < 0 || k >= 38 ? 0 : k)] * 1e-5;
         return 0;
     }
     auto it = h->prof.find(name);

@@ -42,7 +42,11 @@ struct chain_prog {
 };
 
 // state of one constraint unit between the segments of a chain (registers)
-struct unit_regs { float3 x[4], v[4]; float im[4]; float heat, shadow; };
+struct unit_regs { float3 x[4], v[4]; float im[4]; float heat, shadow;
+#ifdef CHAIN_STAMPS
+    unsigned long long* stamps; unsigned long long t_last;     // tools/chain_segments.py: per-token wall-clock of workgroup (0, 0)
+#endif
+};
 
 struct settle_const { float mO, mH, ra, rb, rc, dOH, dHH; };
 
@@ -335,6 +339,9 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
 #pragma unroll
             for (int k = 0; k < NAT; ++k) { v[k].x -= sx; v[k].y -= sy; v[k].z -= sz; }
         }
+#ifdef CHAIN_STAMPS
+        if (S.stamps) { const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + min(t, 33)], now - S.t_last); S.t_last = now; }
+#endif
         if ((prog.measure & 1) && tok == 'O') S.heat += unit_ke() - ke0;                           // :1448-1460
         if ((prog.measure & 2) && (is_v || tok == 'R')) S.shadow += unit_ke() - ke0;                // :1409-1446 (kinetic part)
     }
@@ -361,6 +368,9 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
             } else atomicExch(bins.err, 2u);
         }
     }
+#ifdef CHAIN_STAMPS
+    if (S.stamps) { const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[35], now - S.t_last); S.t_last = now; }
+#endif
     return mom;
 }
 
@@ -414,6 +424,10 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
     const uint32_t rg = (uint32_t)(r_begin + r);
     const long long* cr = cmm + ((size_t)max(cmm_r_eff, 0) * gridDim.y + r) * 4;
     unit_regs S;
+#ifdef CHAIN_STAMPS
+    S.stamps = (own_time && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? own_time + 2 : nullptr;
+    S.t_last = own_t0;
+#endif
     // segments of the token program, split at 'M' (momentum sum + barrier over the replica's workgroups)
     for (int t0 = 0;;) {
         int t1 = t0;
@@ -458,6 +472,9 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                 }
             }
             __syncthreads();
+#ifdef CHAIN_STAMPS
+            if (S.stamps) { const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + min(t1, 33)], now - S.t_last); S.t_last = now; }
+#endif
         }
         t0 = t1 + 1;
     }
