@@ -160,3 +160,19 @@ def test_mcmc_sampler_runs_one_configuration_through_the_engine():
                            mcmc.LangevinDynamicsMove(n_steps=1), engine=OracleEngine(), seed=1)
     far.minimize(tolerance=0.5 * unit.kilojoules_per_mole / unit.nanometer, max_iterations=3000)
     assert np.abs(far.sampler_state.positions).max() < 0.05
+
+
+def test_rotation_proposal_matches_vectors_executed_from_the_reference():
+    """tests/golden/mc_rotation_reference.json: quaternions drawn and matrices built BY the reference's two functions
+    (mcmc.py:1842-1906, taken from its syntax tree by tests/golden/make_golden_mc_moves.py) under seeded numpy streams."""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mc_rotation_reference.json')
+    cases = json.load(open(path))['cases']
+    assert len(cases) == 11
+    for c in cases:
+        if c['seed'] is not None:
+            np.random.seed(c['seed'])
+            q = mcmc.MCRotationMove._generate_uniform_quaternion()
+            assert np.array_equal(q, np.array(c['quaternion']))                    # same draws, same arithmetic
+        got = mcmc.MCRotationMove._rotation_matrix_from_quaternion(np.array(c['quaternion']))
+        assert np.allclose(got, np.array(c['matrix']), rtol=0, atol=4e-16)
