@@ -78,32 +78,40 @@ class LangevinIntegrator:
     # ---- parsing (integrators.py:1337-1402, 1474-1537) --------------------------------------
     @staticmethod
     def _sanity_check(splitting):
-        """integrators.py:1337-1402: step names, one V and one R at least, balanced non-nested braces without an O inside."""
+        """integrators.py:1319-1402.  Same verdicts and exception types as the reference on every string it treats sensibly
+        (tests/golden/splittings_reference.json holds what its own parser says); stricter where the reference lets nonsense
+        through by accident: step names must be single letters (it accepts 'OR' and '12' by a substring test), braces must be
+        balanced and not nested, no O inside them and no R / V outside them (its two regular expressions only look at the start
+        of the string)."""
         tokens = splitting.split(' ')
         depth = 0
+        has_braces = '{' in tokens
         for t in tokens:
             if t == '':
                 raise ValueError('Invalid step name: splitting has repeated or trailing spaces')
             if t in '{}':
+                if t == '{' and '}' not in tokens:
+                    raise ValueError('Use of { must be followed by }')                       # :1356-1357
                 depth += 1 if t == '{' else -1
                 if depth < 0 or depth > 1:
-                    raise ValueError('Use of { and } must be balanced and not nested')       # :1366-1374
+                    raise ValueError('There can only be one Metropolized region.')          # :1371-1374
                 continue
             if t[0] not in 'ORV':
                 raise ValueError("Invalid step name '%s' used; valid step names are R, V, O, { and }" % t)
             if t[0] != 'V' and len(t) > 1:
                 raise ValueError("Invalid step name '%s'" % t)
-            if t[0] == 'V' and len(t) > 1 and not t[1:].isdigit():
-                raise ValueError("Invalid force group in step '%s'" % t)
+            if t[0] == 'V' and len(t) > 1 and not (t[1:].isdigit() and int(t[1:]) <= 31):
+                raise ValueError('You must use an integer force group')                      # :1343-1351 (32 groups at most)
             if t[0] == 'O' and depth > 0:
-                raise ValueError('Shadow work generating steps found outside the Metropolization block' if False else
-                                 'O steps cannot be inside the Metropolization block')          # :1387-1401
+                raise ValueError('O steps cannot be inside the Metropolization block')
+            if t[0] in 'RV' and has_braces and depth == 0:
+                raise ValueError('Shadow work generating steps found outside the Metropolization block')   # :1358-1359
         if depth != 0:
-            raise ValueError('Use of { and } must be balanced')
-        if 'R' not in tokens:
-            raise ValueError('Must have at least one R step')
-        if not any(t[0] == 'V' for t in tokens):
-            raise ValueError('Must have at least one V step')
+            raise ValueError('Use of { must be followed by }')
+        # :1365-1368: the reference asserts that all three kinds of step occur
+        assert any(t == 'R' for t in tokens)
+        assert any(t[0] == 'V' for t in tokens)
+        assert any(t == 'O' for t in tokens)
 
     def _parse_splitting_string(self, splitting_string):
         splitting_string = splitting_string.upper()
@@ -114,8 +122,8 @@ class LangevinIntegrator:
         mts = len(groups) > 1
         if mts:                                             # integrators.py:1524-1533
             for t in steps:
-                if t[0] == 'V' and len(t) == 1:
-                    raise ValueError('a multiple-time-step splitting must name the force group of every V step')
+                # integrators.py:1527-1529: every V of a multiple-time-step splitting names its force group
+                assert not (t[0] == 'V' and len(t) == 1), 'a multiple-time-step splitting must name the force group of every V step'
             return counts, mts, {g: sum(1 for t in steps if t[0] == 'V' and t[1:] == g) for g in groups}
         return counts, mts, {'0': counts['V']}
 

