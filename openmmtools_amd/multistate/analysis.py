@@ -389,6 +389,15 @@ class MultiStateSamplerAnalyzer:
         """:831-896: (sampled [replica, state, iteration], unsampled, neighborhoods, replica state indices [replica, iteration])."""
         return self._read_energies()
 
+    @staticmethod
+    def reformat_energies_for_mbar(u_kln, n_k=None):
+        """:993-1040: energies [sampled state k, evaluated state l, sample n] -> the [l, all samples] layout MBAR takes, the first
+        ``n_k[k]`` samples of every k laid side by side in the order of k."""
+        u_kln = np.asarray(u_kln)
+        k, l, n = u_kln.shape
+        n_k = np.full(k, n, dtype=np.int64) if n_k is None else np.asarray(n_k, dtype=np.int64)
+        return np.concatenate([u_kln[i, :, :n_k[i]] for i in range(k)], axis=1).astype(np.float64) if k else np.zeros([l, 0])
+
     def clear(self):
         """:596-608 / :1230-1241: forget everything derived from the storage."""
         self._equilibration_data = None

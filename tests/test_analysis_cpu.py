@@ -373,3 +373,15 @@ def test_phase_surface_and_the_combination_of_phases(tmp_path):
     assert a._mbar is None
     with pytest.raises(TypeError):
         diff + 3
+
+
+def test_helpers_match_vectors_executed_from_the_reference():
+    """tests/golden/analysis_reference.json (tests/golden/make_golden_analysis.py): reformat_energies_for_mbar and
+    generate_phase_name run from the reference's own source."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'analysis_reference.json')))
+    u = np.array(g['u_kln'])
+    assert np.array_equal(an.MultiStateSamplerAnalyzer.reformat_energies_for_mbar(u), np.array(g['full']))
+    assert np.array_equal(an.MultiStateSamplerAnalyzer.reformat_energies_for_mbar(u, g['ragged_n_k']), np.array(g['ragged']))
+    for current, taken, want in g['names']:
+        assert an.generate_phase_name(current, taken) == want
