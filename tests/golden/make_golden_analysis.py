@@ -1,6 +1,7 @@
 """Reference-executed vectors for the pure-numpy / pure-Python helpers of the analysis layer:
     multistateanalyzer.py:993-1040  PhaseAnalyzer.reformat_energies_for_mbar
     multistate/utils.py:60-95       generate_phase_name
+    multistatesampler.py:1117-1143  MultiStateSampler._default_initial_thermodynamic_states
 taken from the syntax trees of the files under /root/reference (decorators and annotations dropped), run here.
 Output: tests/golden/analysis_reference.json.     usage: python tests/golden/make_golden_analysis.py"""
 import ast
@@ -28,6 +29,7 @@ def take(path, name, cls=None):
 if __name__ == '__main__':
     reformat = take(os.path.join(REF, 'multistateanalyzer.py'), 'reformat_energies_for_mbar', cls='PhaseAnalyzer')
     phase_name = take(os.path.join(REF, 'utils.py'), 'generate_phase_name')
+    assign = take(os.path.join(REF, 'multistatesampler.py'), '_default_initial_thermodynamic_states', cls='MultiStateSampler')
     rng = np.random.default_rng(11)
     u = rng.normal(size=(3, 4, 5))
     cases = dict(
@@ -35,6 +37,7 @@ if __name__ == '__main__':
         full=reformat(u).tolist(),
         ragged_n_k=[5, 2, 0],
         ragged=reformat(u, np.array([5, 2, 0])).tolist(),
+        initial_states=[[k, r, [int(i) for i in assign(None, list(range(k)), list(range(r)))]] for k in range(1, 8) for r in range(1, 10)],
         names=[[cur, lst, phase_name(cur, lst)] for cur, lst in (
             (None, []), (None, ['phase0']), (None, ['phase0', 'phase1', 'x']), ('complex', []), ('complex', ['complex']),
             ('complex', ['complex', 'complex0', 'complex1']), ('solvent', ['complex']))])

@@ -24,6 +24,13 @@ def test_default_initial_thermodynamic_states_rules():
     assert list(f(range(5), range(3))) == [0, 2, 4]
     assert list(f(range(2), range(5))) == [0, 1, 0, 1, 0]
     assert list(f(range(3), range(5))) == [0, 1, 2, 0, 2]
+    # every (n_states, n_replicas) up to (7, 9) as the reference's own classmethod assigns them (executed from its source by
+    # tests/golden/make_golden_analysis.py)
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'analysis_reference.json')))
+    assert len(g['initial_states']) == 63
+    for k, r, want in g['initial_states']:
+        assert list(f(range(k), range(r))) == want, (k, r)
 
 
 def test_parallel_tempering_temperatures_are_logspace():
