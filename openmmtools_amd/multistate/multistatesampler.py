@@ -89,6 +89,13 @@ class MultiStateSampler:
     def mcmc_moves(self):
         return copy.deepcopy(self._mcmc_moves)
 
+    @mcmc_moves.setter
+    def mcmc_moves(self, new_value):
+        """:398-408: only before create() (a single move becomes one per state there)."""
+        if self._thermodynamic_states is not None:
+            raise RuntimeError('Cannot modify MCMCMoves after creation.')
+        self._mcmc_moves = copy.deepcopy(new_value)
+
     @property
     def thermodynamic_states(self):
         return self._thermodynamic_states
@@ -97,6 +104,51 @@ class MultiStateSampler:
     def sampler_states(self):
         self._sync_sampler_states()
         return self._sampler_states
+
+    @sampler_states.setter
+    def sampler_states(self, value):
+        """:417-429: new configurations between create() and run(); they go to the engine and to the storage."""
+        if self._iteration != 0:
+            raise RuntimeError('Sampler states can be assigned only between create() and run().')
+        if len(value) != self.n_replicas:
+            raise ValueError('Passed {} sampler states for {} replicas'.format(len(value), self.n_replicas))
+        self._sampler_states = copy.deepcopy(list(value))
+        self._sampler_states_stale = False
+        sl = slice(self._r_begin, self._r_begin + self._r_count)
+        x = np.stack([s.positions for s in self._sampler_states[sl]])
+        have_v = all(s.velocities is not None for s in self._sampler_states[sl])
+        v = np.stack([s.velocities for s in self._sampler_states[sl]]) if have_v else None
+        if self._thermodynamic_states[0].is_periodic:
+            box = np.stack([s.box_edges for s in self._sampler_states[sl]])
+        else:
+            box = np.zeros((self._r_count, 3))
+        self._engine.set_replicas(self.n_replicas, self._r_begin, x, v, box, self._replica_thermodynamic_states)
+        self._compute_energies()                       # the stored energies of iteration 0 belong to the configurations in place
+        if self._reporter is not None and self._comm.rank == 0:
+            self._reporter.write_sampler_states(self._sampler_states, self._iteration)
+            self._reporter.write_energies(self._energy_thermodynamic_states, self._neighborhoods, self._energy_unsampled_states, self._iteration)
+
+    @classmethod
+    def default_options(cls):
+        """:1224-1237: the keyword defaults of __init__ along the class hierarchy (without ``mcmc_moves``)."""
+        import inspect
+        out = {}
+        for c in inspect.getmro(cls):
+            if c is object:
+                continue
+            spec = inspect.getfullargspec(c.__init__)
+            if spec.defaults:
+                out.update(dict(zip(spec.args[-len(spec.defaults):], spec.defaults)))
+        out.pop('mcmc_moves', None)
+        for private in ('engine', 'comm', 'seed'):      # this package's own constructor arguments, not simulation options
+            out.pop(private, None)
+        return out
+
+    # multistatesampler.py:129-131, 1755-1764: the reference propagates and evaluates energies in two ContextCaches; here one
+    # engine handle per GPU plays both parts (``engine=``).  The attributes exist so that scripts which assign caches keep
+    # running; what is assigned is kept and not used.
+    energy_context_cache = None
+    sampler_context_cache = None
 
     @property
     def replica_thermodynamic_states(self):

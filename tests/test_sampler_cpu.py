@@ -339,3 +339,35 @@ def test_timer_utilities_and_phase_logging(caplog):
     for phrase in ('decorated task took', 'block took', 'Propagating all replicas took', 'Computing energy matrix took',
                    'Mixing of replicas took', 'Iteration 1/1'):
         assert phrase in text, phrase
+
+
+def test_setters_and_default_options_follow_the_reference_rules():
+    """multistatesampler.py:389-429 (mcmc_moves / sampler_states setters), :1224-1237 (default_options)."""
+    ho, ts, ss = _ho_states(3)
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=5)
+    s = ParallelTemperingSampler(number_of_iterations=2, engine=OracleEngine(), seed=3)
+    s.mcmc_moves = move                                           # before create(): allowed
+    assert s.mcmc_moves.n_steps == 5 and s.mcmc_moves is not move
+    s.create(ts, [ss], min_temperature=300.0, max_temperature=400.0, n_temperatures=3)
+    with pytest.raises(RuntimeError, match='Cannot modify MCMCMoves after creation'):
+        s.mcmc_moves = move
+    with pytest.raises(ValueError, match='Passed 2 sampler states for 3 replicas'):
+        s.sampler_states = [ss, ss]
+    moved = [copy.deepcopy(ss) for _ in range(3)]
+    for k, st in enumerate(moved):
+        st.positions = st.positions + 0.05 * (k + 1)
+    s.sampler_states = moved
+    assert np.allclose(s.sampler_states[2].positions, ss.positions + 0.15)
+    x = s._engine.get_replicas()[0]
+    assert np.allclose(x[1], ss.positions + 0.10)                 # the engine holds the new configurations
+    u = s.energy_thermodynamic_states
+    K = ho.K if hasattr(ho, 'K') else None
+    assert u[0, 0] < u[1, 0] < u[2, 0]                            # energies were re-evaluated for them
+    s.run()
+    with pytest.raises(RuntimeError, match='only between create\\(\\) and run\\(\\)'):
+        s.sampler_states = moved
+    d = ReplicaExchangeSampler.default_options()
+    assert d['number_of_iterations'] == 1 and d['replica_mixing_scheme'] == 'swap-all' and 'mcmc_moves' not in d
+    assert 'online_analysis_interval' in d and 'engine' not in d
+    assert SAMSSampler.default_options()['state_update_scheme'] == 'global-jump'
+    s.energy_context_cache = object()                              # accepted and unused (the engine is the context pool)
