@@ -564,7 +564,10 @@ class MultiStateSampler:
     def _initialize_engine(self):
         if self._engine is None:
             from .._engine import HipEngine
-            self._engine = HipEngine()          # raises if libremd_hip.so / a GPU is missing: no CPU fallback
+            # raises if libremd_hip.so / a GPU is missing: no CPU fallback.  A ContextCache assigned the reference's way
+            # (sampler_context_cache, multistatesampler.py:174-175) still chooses the device
+            cc = self.sampler_context_cache
+            self._engine = HipEngine(device=cc.device_index) if hasattr(cc, 'device_index') else HipEngine()
         all_states = list(self._thermodynamic_states) + list(self._unsampled_states)
         ref = all_states[0]
         box0 = self._sampler_states[0].box_edges if ref.is_periodic else None

@@ -49,3 +49,20 @@ def test_sampler_state_helpers_and_pressure_rules():
     st.pressure = None
     assert st.pressure is None
     assert issubclass(states.ThermodynamicsError, Exception) and issubclass(states.SamplerStateError, Exception)
+
+
+def test_context_cache_stand_in_keeps_the_configuration_surface():
+    """openmmtools/cache.py:200-560: capacity / time_to_live / platform are kept; DeviceIndex names the engine's GPU."""
+    import pickle
+    from openmmtools_amd import cache
+    assert len(cache.global_context_cache) == 0 and cache.global_context_cache.capacity is None
+    cache.global_context_cache.platform = 'HIP'
+    assert cache.global_context_cache.platform == 'HIP'
+    cc = cache.ContextCache(capacity=None, time_to_live=None, platform='HIP', platform_properties={'DeviceIndex': '3'})
+    assert cc.device_index == 3 and cache.ContextCache().device_index == 0
+    with pytest.raises(ValueError, match='you need to also specify the platform'):
+        cache.ContextCache(platform_properties={'DeviceIndex': '1'})
+    back = pickle.loads(pickle.dumps(cc))
+    assert back.device_index == 3 and back.capacity is None
+    assert cache.DummyContextCache().capacity == 0
+    cc.empty()
