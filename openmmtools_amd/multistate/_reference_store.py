@@ -78,8 +78,21 @@ class ReferenceStoreReader:
         self._cpath = str(checkpoint_path) if checkpoint_path else stem + '_checkpoint.nc'
         self._a = _hdf5.File(self._path)
         self._c = _hdf5.File(self._cpath) if os.path.isfile(self._cpath) else None
+        self._check_uuid()
         ci = self._a.attr('CheckpointInterval')
         self._checkpoint_interval = int(np.asarray(ci).reshape(-1)[0]) if ci is not None else 1
+
+    def _check_uuid(self):
+        """multistatereporter.py:318-354: the checkpoint file must carry the analysis file's UUID (a checkpoint of another
+        simulation next to this analysis file is refused)."""
+        if self._c is None:
+            return
+        ua, uc = self._a.attr('UUID'), self._c.attr('UUID')
+        if ua is not None and uc is not None and str(np.asarray(ua).reshape(-1)[0]) != str(np.asarray(uc).reshape(-1)[0]):
+            a, c = str(np.asarray(ua).reshape(-1)[0]), str(np.asarray(uc).reshape(-1)[0])
+            self.close()
+            raise OSError('Checkpoint UUID does not match analysis UUID! This checkpoint file came from another simulation!\n'
+                          'Analysis UUID: {}; Checkpoint UUID: {}'.format(a, c))
 
     filepath = property(lambda self: self._path)
     title = property(lambda self: self._a.attr('title'))
@@ -303,6 +316,8 @@ class ReferenceStoreWriter:
         fresh = mode == 'w' or not os.path.isfile(self._path)
         self._a = nw.NetCDF4File(self._path, 'w' if fresh else 'a')
         self._c = nw.NetCDF4File(self._cpath, 'w' if fresh or not os.path.isfile(self._cpath) else 'a')
+        if not fresh:
+            self.reader()._check_uuid()            # multistatereporter.py:343-354: a checkpoint of another simulation is refused
         if fresh:
             import time
             import uuid

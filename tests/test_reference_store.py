@@ -412,3 +412,24 @@ def test_analysis_particles_are_stored_every_iteration_in_the_analysis_file(tmp_
     plain.close()
     with _hdf5.File(str(tmp_path / 'run.nc')) as f:                             # none flagged: the variable exists, empty
         assert f.shape('/analysis_particle_indices') == (0,)
+
+
+def test_a_checkpoint_file_of_another_simulation_is_refused(tmp_path):
+    """tests/test_sampling.py:2143-2171 / multistatereporter.py:318-354: the analysis and checkpoint files of one store carry one
+    UUID; pairing an analysis file with the checkpoint file of another run raises IOError, for reading and for appending."""
+    from openmmtools_amd.multistate import _hdf5
+    sa, ra = _pt_run(tmp_path, 2, name='a.nc')
+    sa.run()
+    sb, rb = _pt_run(tmp_path, 2, name='b.nc')
+    sb.run()
+    ra.close(), rb.close()
+    with _hdf5.File(str(tmp_path / 'a.nc')) as fa, _hdf5.File(str(tmp_path / 'a_checkpoint.nc')) as fc, \
+            _hdf5.File(str(tmp_path / 'b_checkpoint.nc')) as fo:
+        uid = lambda f: str(np.asarray(f.attr('UUID')).reshape(-1)[0])
+        assert uid(fa) == uid(fc) != uid(fo)
+    ok = MultiStateReporter(str(tmp_path / 'a.nc'), open_mode='r')
+    assert ok.read_last_iteration(last_checkpoint=False) == 2
+    ok.close()
+    for mode in ('r', 'a'):
+        with pytest.raises(IOError, match='Checkpoint UUID does not match analysis UUID'):
+            MultiStateReporter(str(tmp_path / 'a.nc'), checkpoint_storage=str(tmp_path / 'b_checkpoint.nc'), open_mode=mode)
