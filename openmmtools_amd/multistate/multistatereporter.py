@@ -317,9 +317,17 @@ class MultiStateReporter:
         self._files['neighborhoods'].write(iteration, energy_neighborhoods)
         self._files['unsampled_energies'].write(iteration, energy_unsampled_states)
 
+    def _map_iteration_to_good(self, iteration):
+        """:1517-1541: an index or slice over the iterations that were written COMPLETELY (0 .. last_iteration): negative
+        indices count back from the last good iteration, slices stop there, an index beyond it raises IndexError -- records a
+        crashed or abandoned continuation left behind the last good iteration are never served."""
+        last_good = self.read_last_iteration(last_checkpoint=False)
+        return np.arange((last_good if last_good is not None else -1) + 1, dtype=int)[iteration]
+
     @_reference_read
     def read_energies(self, iteration=slice(None)):
         """:817-863 -> (energy_thermodynamic_states, neighborhoods, energy_unsampled_states)."""
+        iteration = self._map_iteration_to_good(iteration)
         e = self._files['energies'].read(iteration)
         fu = self._files['unsampled_energies']
         eu = fu.read(iteration) if fu.nbytes else np.zeros(e.shape[:-1] + (0,), fu.dtype)    # no unsampled states: empty records
@@ -336,7 +344,7 @@ class MultiStateReporter:
     @_reference_read
     def read_replica_thermodynamic_states(self, iteration=slice(None)):
         """:775-795."""
-        return self._files['states'].read(iteration).astype(np.int64)
+        return self._files['states'].read(self._map_iteration_to_good(iteration)).astype(np.int64)
 
     def write_mixing_statistics(self, n_accepted_matrix, n_proposed_matrix, iteration):
         """:957-999 (stored as i4, like the reference)."""
@@ -350,6 +358,7 @@ class MultiStateReporter:
     @_reference_read
     def read_mixing_statistics(self, iteration=slice(None)):
         """:931-955."""
+        iteration = self._map_iteration_to_good(iteration)
         return self._files['accepted'].read(iteration), self._files['proposed'].read(iteration)
 
     def write_timestamp(self, iteration):
@@ -362,7 +371,7 @@ class MultiStateReporter:
 
     @_reference_read
     def read_timestamp(self, iteration=slice(None)):
-        return self._files['timestamp'].read(iteration)
+        return self._files['timestamp'].read(self._map_iteration_to_good(iteration))
 
     def write_online_data_dynamic_and_static(self, iteration, **kwargs):
         """:1167-1252 (the variables SAMS writes: logZ, log_weights)."""

@@ -231,3 +231,37 @@ def test_a_users_subclass_resumes_through_its_own_from_storage(tmp_path):
     r.run(1)
     with pytest.raises(TypeError, match='resume with that class'):
         ParallelTemperingSampler.from_storage(str(tmp_path / 'u_store'), engine=OracleEngine())
+
+
+@pytest.mark.parametrize('name', ['store', 'store.nc'])
+def test_last_iteration_functions(tmp_path, name):
+    """tests/test_sampling.py:2080-2128 on both layouts: after the last good iteration is set back to 4 of 10, reads by index,
+    negative index, slice and reversed slice are relative to iteration 4, and an index beyond it raises IndexError."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    from openmmtools_amd import testsystems, states, mcmc, unit
+    from openmmtools_amd.multistate import ParallelTemperingSampler, MultiStateReporter
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=1)
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=10, engine=OracleEngine(), seed=2, online_analysis_interval=None)
+    rep = MultiStateReporter(str(tmp_path / name), checkpoint_interval=2)
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=400.0, n_temperatures=3)
+    s.run()
+    rep.close()
+    rep = MultiStateReporter(str(tmp_path / name), open_mode='a', checkpoint_interval=2)
+    all_energies = rep.read_energies()[0]
+    all_states = rep.read_replica_thermodynamic_states()
+    assert all_energies.shape[0] == 11
+    rep.write_last_iteration(4)                                  # "break the checkpoint" (:2108-2110)
+    rep.close()
+    rep = MultiStateReporter(str(tmp_path / name), open_mode='r', checkpoint_interval=2)
+    assert np.all(rep.read_energies(1)[0] == all_energies[1])
+    assert np.all(rep.read_energies(-1)[0] == all_energies[4])
+    assert np.all(rep.read_energies()[0] == all_energies[:5])
+    assert np.all(rep.read_energies(slice(-1, None, -1))[0] == all_energies[4::-1])
+    assert np.all(rep.read_replica_thermodynamic_states(-1) == all_states[4]) and rep.read_mixing_statistics()[0].shape[0] == 5
+    with pytest.raises(IndexError):
+        rep.read_energies(7)
