@@ -249,8 +249,18 @@ class ReferenceStoreReader:
             # :696-705: the subset the analysis file carries for every iteration
             if '/positions' not in self._a:
                 raise ValueError('No particles were flagged for special analysis! No such trajectory would have been written!')
-            x = self._a.read('/positions')[iteration].astype(np.float64)
-            v = self._a.read('/velocities')[iteration].astype(np.float64) if '/velocities' in self._a else np.zeros_like(x)
+            def frame(name, like=None):
+                # frames an interval skipped (or that lie behind the last one written) read as zeros, like netCDF's masked fill
+                data = self._a.read(name) if name in self._a else None
+                if data is None or iteration >= data.shape[0]:
+                    return np.zeros(like.shape if like is not None else (0, 0, 3))
+                out = np.array(data[iteration], dtype=np.float64)
+                out[~np.isfinite(out) | (np.abs(out) > 1e30)] = 0.0
+                return out
+            x = frame('/positions')
+            v = frame('/velocities', like=x)
+            if x.size == 0 and v.size:
+                x = np.zeros_like(v)
             return [states.SamplerState(x[r], velocities=v[r]) for r in range(x.shape[0])]
         if self._c is None:
             raise IOError('checkpoint file %s is missing' % self._cpath)
@@ -308,11 +318,13 @@ class ReferenceStoreWriter:
     ``ReferenceStoreReader`` understands: plain ThermodynamicStates (temperature, pressure) on Systems of the hot-path
     forces, Langevin moves, the samplers' options; anything else raises NotImplementedError naming it."""
 
-    def __init__(self, analysis_path, checkpoint_path, mode, checkpoint_interval, title=None, analysis_particle_indices=()):
+    def __init__(self, analysis_path, checkpoint_path, mode, checkpoint_interval, title=None, analysis_particle_indices=(),
+                 position_interval=1, velocity_interval=1):
         from . import _netcdf4_write as nw
         self._nw = nw
         self._path, self._cpath = str(analysis_path), str(checkpoint_path)
         self._interval = int(checkpoint_interval)
+        self._position_interval, self._velocity_interval = int(position_interval), int(velocity_interval)
         fresh = mode == 'w' or not os.path.isfile(self._path)
         self._a = nw.NetCDF4File(self._path, 'w' if fresh else 'a')
         self._c = nw.NetCDF4File(self._cpath, 'w' if fresh or not os.path.isfile(self._cpath) else 'a')
@@ -335,8 +347,8 @@ class ReferenceStoreWriter:
                 f.set_attr('/', 'CheckpointInterval', np.array([self._interval], dtype=np.int64))
                 f.set_attr('/', 'UUID', uid)                                        # :346-361: the two files carry one UUID
                 f.set_attr('/', 'title', title)
-                f.set_attr('/', 'PositionInterval', np.array([1], dtype=np.int64))       # :450-451
-                f.set_attr('/', 'VelocityInterval', np.array([1], dtype=np.int64))
+                f.set_attr('/', 'PositionInterval', np.array([self._position_interval], dtype=np.int64))       # :450-451
+                f.set_attr('/', 'VelocityInterval', np.array([self._velocity_interval], dtype=np.int64))
                 f.create_variable('/last_iteration', 'i8', ('scalar',))
                 f.write('/last_iteration', [0])
             # :369-381: the reference's open() creates this variable when it is missing -- which fails on a file opened for
@@ -574,8 +586,12 @@ class ReferenceStoreWriter:
             a = self._a
             self._record_variable(a, '/positions', 'f4', ('iteration', 'replica', 'analysis_particles', 'spatial'), (None, R, None, 3), (('units', 'nm'),))
             self._record_variable(a, '/velocities', 'f4', ('iteration', 'replica', 'analysis_particles', 'spatial'), (None, R, None, 3), (('units', 'nm / ps'),))
-            a.write('/positions', xs, record=int(iteration))
-            a.write('/velocities', vs, record=int(iteration))
+            # :1686-1692: frames of the analysis trajectory only every position_interval / velocity_interval iterations (0: never);
+            # the iterations in between stay at the fill value, as records netCDF never wrote do
+            if self._position_interval != 0 and int(iteration) % self._position_interval == 0:
+                a.write('/positions', xs, record=int(iteration))
+            if self._velocity_interval != 0 and int(iteration) % self._velocity_interval == 0:
+                a.write('/velocities', vs, record=int(iteration))
         if iteration % self._interval != 0:
             return False
         frame = int(iteration) // self._interval

@@ -108,12 +108,15 @@ class MultiStateReporter:
     ``<name>_checkpoint.nc``, :176-199)."""
 
     def __init__(self, storage, open_mode=None, checkpoint_interval=50, checkpoint_storage=None,
-                 analysis_particle_indices=(), layout='auto'):
+                 analysis_particle_indices=(), position_interval=1, velocity_interval=1, layout='auto'):
         self._storage_analysis = str(storage)
         stem = self._storage_analysis[:-3] if self._storage_analysis.endswith('.nc') else self._storage_analysis
         self._storage_checkpoint = str(checkpoint_storage) if checkpoint_storage else stem + '_checkpoint'
         self._checkpoint_interval = int(checkpoint_interval)
         self._analysis_particle_indices = tuple(int(i) for i in analysis_particle_indices)
+        # multistatereporter.py:133-134, 1686-1692: how often the analysis file gets the flagged particles' positions / velocities
+        # (0: never); checkpoints always carry both
+        self._position_interval, self._velocity_interval = int(position_interval), int(velocity_interval)
         self._files = {}
         self._meta = None
         self._open_mode = None
@@ -135,6 +138,16 @@ class MultiStateReporter:
     @property
     def checkpoint_interval(self):
         return self._checkpoint_interval
+
+    @property
+    def position_interval(self):
+        """:228-230."""
+        return self._position_interval
+
+    @property
+    def velocity_interval(self):
+        """:233-235."""
+        return self._velocity_interval
 
     def storage_exists(self):
         from ._reference_store import is_reference_store
@@ -168,7 +181,8 @@ class MultiStateReporter:
             for d in (os.path.dirname(os.path.abspath(self._storage_analysis)), os.path.dirname(os.path.abspath(ckpt))):
                 os.makedirs(d, exist_ok=True)
             self._ncw = ReferenceStoreWriter(self._storage_analysis, ckpt, mode, self._checkpoint_interval,
-                                             analysis_particle_indices=self._analysis_particle_indices)
+                                             analysis_particle_indices=self._analysis_particle_indices,
+                                             position_interval=self._position_interval, velocity_interval=self._velocity_interval)
             self._ref = self._ncw.reader()
             self._checkpoint_interval = self._ref.checkpoint_interval
             self._open_mode = mode

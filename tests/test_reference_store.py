@@ -433,3 +433,34 @@ def test_a_checkpoint_file_of_another_simulation_is_refused(tmp_path):
     for mode in ('r', 'a'):
         with pytest.raises(IOError, match='Checkpoint UUID does not match analysis UUID'):
             MultiStateReporter(str(tmp_path / 'a.nc'), checkpoint_storage=str(tmp_path / 'b_checkpoint.nc'), open_mode=mode)
+
+
+@pytest.mark.parametrize('position_interval,velocity_interval', [(2, 2), (1, 0)])
+def test_position_and_velocity_intervals_of_the_analysis_trajectory(tmp_path, position_interval, velocity_interval):
+    """tests/test_sampling.py:700-775 (multistatereporter.py:1686-1692): the flagged particles' positions / velocities reach the
+    analysis file only every position_interval / velocity_interval iterations (0: never); skipped frames read as zeros;
+    checkpoints always carry everything."""
+    from openmmtools_amd.multistate import _hdf5
+    rng = np.random.default_rng(4)
+    rep = MultiStateReporter(str(tmp_path / 't.nc'), open_mode='w', checkpoint_interval=2, analysis_particle_indices=(1, 2),
+                             position_interval=position_interval, velocity_interval=velocity_interval)
+    assert (rep.position_interval, rep.velocity_interval) == (position_interval, velocity_interval)
+    sampler_states = [states.SamplerState(rng.normal(size=(5, 3)), velocities=rng.normal(size=(5, 3))) for _ in range(2)]
+    for it in range(3):
+        rep.write_sampler_states(sampler_states, it)
+        rep.write_last_iteration(it)
+    rep.close()
+    with _hdf5.File(str(tmp_path / 't.nc')) as f:
+        assert int(np.asarray(f.attr('PositionInterval')).reshape(-1)[0]) == position_interval
+        assert int(np.asarray(f.attr('VelocityInterval')).reshape(-1)[0]) == velocity_interval
+    r = MultiStateReporter(str(tmp_path / 't.nc'), open_mode='r')
+    f4 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    for it in range(3):
+        got = r.read_sampler_states(it, analysis_particles_only=True)
+        for st, back in zip(sampler_states, got):
+            want_x = f4(st.positions[[1, 2]]) if position_interval and it % position_interval == 0 else np.zeros((2, 3))
+            want_v = f4(st.velocities[[1, 2]]) if velocity_interval and it % velocity_interval == 0 else np.zeros((2, 3))
+            assert np.array_equal(back.positions, want_x), (it, back.positions)
+            assert np.array_equal(back.velocities, want_v), it
+    full = r.read_sampler_states(2)                                        # the checkpoint frame: all particles, both arrays
+    assert np.array_equal(full[1].positions, f4(sampler_states[1].positions)) and np.array_equal(full[1].velocities, f4(sampler_states[1].velocities))
