@@ -98,6 +98,12 @@ class ReferenceStoreReader:
     title = property(lambda self: self._a.attr('title'))
     checkpoint_interval = property(lambda self: self._checkpoint_interval)
 
+    def analysis_particle_indices(self):
+        """The stored indices (an empty tuple when none were flagged), None for a file that predates the variable."""
+        if '/analysis_particle_indices' not in self._a:
+            return None
+        return tuple(int(i) for i in np.asarray(self._a.read('/analysis_particle_indices')).reshape(-1))
+
     def read_seed(self):
         """The Philox seed of a store this package wrote (global attribute; None for the reference's own files)."""
         v = self._a.attr('openmmtools_amd_seed')

@@ -140,6 +140,16 @@ class MultiStateReporter:
         return self._checkpoint_interval
 
     @property
+    def analysis_particle_indices(self):
+        """:214-225 and tests/test_sampling.py:816-866: what an open store already holds takes priority over the constructor's
+        argument (the netCDF4 layout stores the indices; the record container keeps no per-particle trajectory)."""
+        if self._ref is not None:
+            stored = self._ref.analysis_particle_indices()
+            if stored is not None:
+                return stored
+        return self._analysis_particle_indices
+
+    @property
     def position_interval(self):
         """:228-230."""
         return self._position_interval

@@ -464,3 +464,15 @@ def test_position_and_velocity_intervals_of_the_analysis_trajectory(tmp_path, po
             assert np.array_equal(back.velocities, want_v), it
     full = r.read_sampler_states(2)                                        # the checkpoint frame: all particles, both arrays
     assert np.array_equal(full[1].positions, f4(sampler_states[1].positions)) and np.array_equal(full[1].velocities, f4(sampler_states[1].velocities))
+
+
+def test_stored_analysis_particles_take_priority_over_the_argument(tmp_path):
+    """tests/test_sampling.py:816-866."""
+    blank = str(tmp_path / 'temp_dir' / 'blank_analysis.nc')
+    MultiStateReporter(blank, open_mode='w', analysis_particle_indices=()).close()
+    assert MultiStateReporter(blank, open_mode='r', analysis_particle_indices=(0, 1)).analysis_particle_indices == ()
+    set1 = str(tmp_path / 'temp_dir' / 'set1_analysis.nc')
+    MultiStateReporter(set1, open_mode='w', analysis_particle_indices=(0, 1)).close()
+    assert MultiStateReporter(set1, open_mode='r', analysis_particle_indices=()).analysis_particle_indices == (0, 1)
+    assert MultiStateReporter(set1, open_mode='r', analysis_particle_indices=(0, 2)).analysis_particle_indices == (0, 1)
+    assert MultiStateReporter(str(tmp_path / 'unopened.nc'), analysis_particle_indices=(4,)).analysis_particle_indices == (4,)
