@@ -306,7 +306,12 @@ def _yaml_dump(data):
         v = q.value.tolist() if isinstance(q.value, np.ndarray) else float(q.value)
         return dumper.represent_mapping('!Quantity', {'unit': q.unit, 'value': v})
 
+    def ndarray(dumper, a):
+        # multistatereporter.py:1932-1939: dtype, shape and the values as nested lists under the !ndarray tag
+        return dumper.represent_mapping('!ndarray', {'type': str(a.dtype), 'shape': list(a.shape), 'values': a.tolist()})
+
     Dumper.add_representer(_Quantity, quantity)
+    Dumper.add_representer(np.ndarray, ndarray)
     Dumper.add_representer(np.float64, lambda d, x: d.represent_float(float(x)))
     Dumper.add_representer(np.int64, lambda d, x: d.represent_int(int(x)))
     Dumper.add_representer(np.bool_, lambda d, x: d.represent_bool(bool(x)))
@@ -426,8 +431,13 @@ class ReferenceStoreWriter:
                 f.create_variable(path, 'str', ('scalar',))
             f.write(path, text)
 
-    def write_dict(self, name, data):
+    def write_dict(self, name, data, nested=False, fixed_dimension=False):
+        """:1817-1880 _write_dict: one YAML string variable, or (``nested``) a group per dictionary and a variable per value;
+        ``fixed_dimension`` stores the text as a character array of its own length instead of a variable-length string."""
         data = dict(data) if data is not None else {}
+        if nested and name not in ('options', 'metadata'):
+            self._write_nested('/' + name.strip('/'), data, fixed=bool(fixed_dimension))
+            return
         if name == 'options' and 'kwargs' in data and 'cls' in data:
             # the reference restores with cls(**options) (multistatesampler.py:948-950): only its constructor's keywords may
             # appear; this package's extras (sampler class, Philox seed) go to global attributes
@@ -446,16 +456,16 @@ class ReferenceStoreWriter:
                 data.pop('title', None)
             self._write_nested('/metadata', data)
             return
-        self._write_text(self._a, '/' + name.strip('/'), _yaml_dump(data), fixed=False)
+        self._write_text(self._a, '/' + name.strip('/'), _yaml_dump(data), fixed=bool(fixed_dimension))
 
-    def _write_nested(self, path, value):
+    def _write_nested(self, path, value, fixed=True):
         if isinstance(value, dict) and len(value) > 0:
             for k, v in value.items():
                 if not isinstance(k, str):
                     raise ValueError('Cannot store dict in nested form with non-string keys.')          # :1854-1856
-                self._write_nested(path + '/' + k, v)
+                self._write_nested(path + '/' + k, v, fixed)
             return
-        self._write_text(self._a, path, _yaml_dump(value), fixed=True)
+        self._write_text(self._a, path, _yaml_dump(value), fixed=fixed)
 
     # ---- states (:612-668) -------------------------------------------------------------------------------------
     def write_thermodynamic_states(self, thermodynamic_states, unsampled_states):

@@ -320,15 +320,24 @@ class MultiStateReporter:
     def read_mcmc_moves(self):
         return self._read_object('mcmc_moves')
 
-    def write_dict(self, name, data):
+    def write_dict(self, name, data, nested=False, fixed_dimension=False):
+        """:1094-1115, 1817-1880 (``nested`` / ``fixed_dimension`` choose among the netCDF4 layout's three representations; the
+        record container has one)."""
         if self._ncw is not None:
             self._require_write()
-            return self._ncw.write_dict(name, data)
+            return self._ncw.write_dict(name, data, nested=nested, fixed_dimension=fixed_dimension)
         self._write_object(name, dict(data))
+
+    _write_dict = write_dict                      # the reference's tests call the private name
 
     @_reference_read
     def read_dict(self, name):
-        return self._read_object(name)
+        """:1117-1165: a stored dictionary, or with 'name/key/subkey' one entry of it."""
+        head, *keys = name.strip('/').split('/')
+        value = self._read_object(head)
+        for k in keys:
+            value = value[k]
+        return value
 
     # ---- per-iteration analysis data -----------------------------------------------------------------------
     def write_energies(self, energy_thermodynamic_states, energy_neighborhoods, energy_unsampled_states, iteration):

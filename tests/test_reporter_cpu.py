@@ -265,3 +265,39 @@ def test_last_iteration_functions(tmp_path, name):
     assert np.all(rep.read_replica_thermodynamic_states(-1) == all_states[4]) and rep.read_mixing_statistics()[0].shape[0] == 5
     with pytest.raises(IndexError):
         rep.read_energies(7)
+
+
+@pytest.mark.parametrize('storage', ['dicts', 'dicts.nc'])
+def test_store_dict(tmp_path, storage):
+    """tests/test_sampling.py:934-1001 (multistatereporter.py:1094-1165, 1817-1880) on both layouts: booleans, strings, numbers,
+    lists, (nested) numpy arrays and nested dictionaries come back equal from the single-string, the nested and the
+    fixed-dimension representation; an entry can be read by its path; a rewrite with the same structure updates in place."""
+    from openmmtools_amd.multistate import MultiStateReporter
+    data = {'mybool': False, 'mystring': 'test', 'myinteger': 3, 'myfloat': 4.0, 'mylist': [0, 1, 2, 3],
+            'mynumpyarray': np.array([2.0, 3, 4]), 'mynestednumpyarray': np.array([[1, 2, 3], [4.0, 5, 6]]),
+            'mynesteddict': {'field1': 'string', 'field2': {'field21': 3.0, 'field22': True}}}
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return isinstance(b, dict) and sorted(a) == sorted(b) and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, np.ndarray):
+            return isinstance(b, np.ndarray) and a.dtype == b.dtype and np.array_equal(a, b)
+        return type(a) is type(b) and a == b
+    rep = MultiStateReporter(str(tmp_path / storage), open_mode='w')
+    if not storage.endswith('.nc'):
+        rep.initialize(1, 1, 0, 1)
+    for name, kwargs in (('testdict', {}), ('nested', dict(nested=True)), ('fixed', dict(fixed_dimension=True))):
+        rep._write_dict(name, data, **kwargs)
+        assert same(data, rep.read_dict(name)), name
+        assert same(data['mynesteddict']['field2'], rep.read_dict(name + '/mynesteddict/field2'))
+        if name != 'fixed':                                   # (a fixed-length text cannot change its length)
+            changed = dict(data, mybool=True, mystring='substituted')
+            rep._write_dict(name, changed, **kwargs)
+            back = rep.read_dict(name)
+            assert back['mybool'] is True and back['mystring'] == 'substituted'
+    rep.close()
+    if storage.endswith('.nc'):
+        from openmmtools_amd.multistate import _hdf5
+        with _hdf5.File(str(tmp_path / storage)) as f:         # :990-996: groups and variables of the nested form, one variable otherwise
+            assert f.is_group('/nested') and f.is_group('/nested/mynesteddict') and '/nested/mylist' in f
+            assert '/testdict' in f and not f.is_group('/testdict')
