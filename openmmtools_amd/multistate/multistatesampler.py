@@ -284,6 +284,25 @@ class MultiStateSampler:
         rep.write_dict('options', self._options())
         rep.write_dict('metadata', self._metadata)
 
+    # multistatesampler.py:440-517 _StoredProperty: options that are kept in sync with the storage -- assigning one on a created
+    # sampler rewrites the stored 'options' (so that a resume sees the new number of iterations, analysis interval ...)
+    _STORED_OPTIONS = frozenset(['number_of_iterations', 'online_analysis_interval', 'online_analysis_target_error',
+                                 'online_analysis_minimum_iterations', 'locality', 'replica_mixing_scheme', 'log_target_probabilities',
+                                 'state_update_scheme', 'update_stages', 'flatness_criteria', 'flatness_threshold',
+                                 'weight_update_method', 'gamma0', 'logZ_guess'])
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name in self._STORED_OPTIONS:
+            d = self.__dict__
+            rep = d.get('_reporter')
+            if rep is not None and d.get('_thermodynamic_states') is not None and getattr(rep, '_open_mode', None) in ('w', 'a') \
+                    and d.get('_comm') is not None and d['_comm'].rank == 0 and not d.get('_restoring', False):
+                try:
+                    rep.write_dict('options', self._options())
+                except AttributeError:
+                    pass                                  # (an option assigned while the constructor is still running)
+
     def _options(self):
         """What from_storage needs to rebuild the sampler (multistatesampler.py:1145-1167 _store_options)."""
         kwargs = dict(locality=self.locality, online_analysis_interval=self.online_analysis_interval,
