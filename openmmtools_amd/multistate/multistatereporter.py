@@ -111,7 +111,9 @@ class MultiStateReporter:
                  analysis_particle_indices=(), position_interval=1, velocity_interval=1, layout='auto'):
         self._storage_analysis = str(storage)
         stem = self._storage_analysis[:-3] if self._storage_analysis.endswith('.nc') else self._storage_analysis
-        self._storage_checkpoint = str(checkpoint_storage) if checkpoint_storage else stem + '_checkpoint'
+        # multistatereporter.py:141-149: a checkpoint name is relative to the analysis file's directory (an absolute path stays)
+        self._storage_checkpoint = (os.path.join(os.path.dirname(self._storage_analysis), str(checkpoint_storage)) if checkpoint_storage
+                                    else stem + '_checkpoint')
         self._checkpoint_interval = int(checkpoint_interval)
         self._analysis_particle_indices = tuple(int(i) for i in analysis_particle_indices)
         # multistatereporter.py:133-134, 1686-1692: how often the analysis file gets the flagged particles' positions / velocities

@@ -476,3 +476,34 @@ def test_stored_analysis_particles_take_priority_over_the_argument(tmp_path):
     assert MultiStateReporter(set1, open_mode='r', analysis_particle_indices=()).analysis_particle_indices == (0, 1)
     assert MultiStateReporter(set1, open_mode='r', analysis_particle_indices=(0, 2)).analysis_particle_indices == (0, 1)
     assert MultiStateReporter(str(tmp_path / 'unopened.nc'), analysis_particle_indices=(4,)).analysis_particle_indices == (4,)
+
+
+def test_separate_checkpoint_file_and_opening_without_it(tmp_path):
+    """tests/test_sampling.py:2130-2184: a checkpoint file NAME lives next to the analysis file; the analysis file opens for
+    reading when the named checkpoint file is not there; a sampler created from a path string and one resumed from a reporter
+    object see the same energies (:2186-2211)."""
+    path = str(tmp_path / 'sub' / 'run.nc')
+    rep = MultiStateReporter(path, checkpoint_storage='checkpoint_file.nc', open_mode='w')
+    rep.close()
+    assert os.path.isfile(path) and os.path.isfile(str(tmp_path / 'sub' / 'checkpoint_file.nc'))
+    r = MultiStateReporter(path, checkpoint_storage='checkpoint_mod.nc', open_mode='r')       # no such checkpoint file: still opens
+    assert r.read_last_iteration(last_checkpoint=False) == 0
+    r.close()
+    import sys
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from openmmtools_amd import testsystems, mcmc, unit
+    from openmmtools_amd.multistate import ParallelTemperingSampler
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    s = ParallelTemperingSampler(mcmc_moves=mcmc.LangevinDynamicsMove(n_steps=1), number_of_iterations=5, engine=OracleEngine(), seed=1)
+    by_string = str(tmp_path / 'string.nc')
+    s.create(ts, [ss], storage=by_string, min_temperature=300.0, max_temperature=400.0, n_temperatures=3)
+    s.run()
+    e_string = s._reporter.read_energies()[0]
+    s._reporter.close()
+    del s
+    resumed = ParallelTemperingSampler.from_storage(MultiStateReporter(by_string), engine=OracleEngine())
+    assert np.array_equal(resumed._reporter.read_energies()[0], e_string)
+    assert resumed.iteration == 0                      # the last CHECKPOINT (interval 50): where the reference resumes, too
