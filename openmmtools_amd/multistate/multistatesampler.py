@@ -284,6 +284,8 @@ class MultiStateSampler:
         rep.write_dict('options', self._options())
         rep.write_dict('metadata', self._metadata)
 
+    _TITLE_TEMPLATE = 'Multi-state sampler simulation created using MultiStateSampler class of openmmtools_amd.multistate on {}'   # :534
+
     # multistatesampler.py:440-517 _StoredProperty: options that are kept in sync with the storage -- assigning one on a created
     # sampler rewrites the stored 'options' (so that a resume sees the new number of iterations, analysis interval ...)
     _STORED_OPTIONS = frozenset(['number_of_iterations', 'online_analysis_interval', 'online_analysis_target_error',
@@ -483,7 +485,10 @@ class MultiStateSampler:
                 if state.n_particles != n_particles:
                     raise ValueError('All ThermodynamicStates and SamplerStates must have the same number '
                                      'of particles')
+        # multistatesampler.py:870-877: a default title unless the caller's metadata carries one
         self._metadata = dict(metadata) if metadata else {}
+        if 'title' not in self._metadata:
+            self._metadata['title'] = self._TITLE_TEMPLATE.format(time.asctime(time.localtime()))
         self._thermodynamic_states = copy.deepcopy(list(thermodynamic_states))
         self._unsampled_states = copy.deepcopy(list(unsampled_thermodynamic_states or []))
         self._sampler_states = [copy.deepcopy(s) for s in sampler_states]

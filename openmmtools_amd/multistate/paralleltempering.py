@@ -12,6 +12,8 @@ from .replicaexchange import ReplicaExchangeSampler
 
 
 class ParallelTemperingSampler(ReplicaExchangeSampler):
+    _TITLE_TEMPLATE = 'Parallel tempering simulation created using ParallelTempering class of openmmtools_amd.multistate on {}'
+
     def create(self, thermodynamic_state, sampler_states, storage=None, min_temperature=None, max_temperature=None,
                n_temperatures=None, temperatures=None, **kwargs):
         if not isinstance(thermodynamic_state, states.ThermodynamicState):

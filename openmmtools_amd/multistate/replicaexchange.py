@@ -12,6 +12,8 @@ from ..utils import time_it
 
 
 class ReplicaExchangeSampler(MultiStateSampler):
+    _TITLE_TEMPLATE = 'Replica-exchange sampler simulation created using ReplicaExchangeSampler class of openmmtools_amd.multistate on {}'
+
     def __init__(self, replica_mixing_scheme='swap-all', **kwargs):
         super().__init__(**kwargs)
         self.replica_mixing_scheme = replica_mixing_scheme

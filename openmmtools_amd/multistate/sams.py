@@ -13,6 +13,8 @@ from .multistatesampler import MultiStateSampler
 
 
 class SAMSSampler(ReplicaExchangeSampler):
+    _TITLE_TEMPLATE = 'Self-adjusted mixture sampling (SAMS) simulation using SAMSSampler class of openmmtools_amd.multistate on {}'
+
     def __init__(self, number_of_iterations=1, log_target_probabilities=None, state_update_scheme='global-jump',
                  locality=5, update_stages='two-stage', flatness_criteria='logZ-flatness', flatness_threshold=0.2,
                  weight_update_method='rao-blackwellized', adapt_target_probabilities=False, gamma0=1.0,

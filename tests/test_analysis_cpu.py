@@ -220,7 +220,8 @@ def test_extend_read_status_and_stored_options(tmp_path):
     """multistatesampler.py:307-358 (read_status), :806-822 (extend), :1145-1167 (stored options)."""
     (tmp_path / 'a').mkdir(); (tmp_path / 'b').mkdir()
     s, rep = _pt_sampler(tmp_path / 'a', 2, online_analysis_interval=1)
-    assert s.is_periodic is False and repr(s) == '<instance of ParallelTemperingSampler>' and s.metadata == {}
+    assert s.is_periodic is False and repr(s) == '<instance of ParallelTemperingSampler>' and list(s.metadata) == ['title']            # multistatesampler.py:870-877: the default title
+    assert s.metadata['title'].startswith('Parallel tempering simulation created using ParallelTempering class')
     s.run()
     assert s.iteration == 2 and s.is_completed
     st = ParallelTemperingSampler.read_status(rep)
