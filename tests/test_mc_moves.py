@@ -176,3 +176,55 @@ def test_rotation_proposal_matches_vectors_executed_from_the_reference():
             assert np.array_equal(q, np.array(c['quaternion']))                    # same draws, same arithmetic
         got = mcmc.MCRotationMove._rotation_matrix_from_quaternion(np.array(c['quaternion']))
         assert np.allclose(got, np.array(c['matrix']), rtol=0, atol=4e-16)
+
+
+def _lj_ladder():
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    thermo = [states.ThermodynamicState(lj.system, t * unit.kelvin) for t in (100.0, 120.0, 140.0)]
+    ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+    return lj, thermo, ss
+
+
+def test_run_extend_with_the_references_move_sequence(tmp_path):
+    """tests/test_sampling.py:1930-1995: SequenceMove([LangevinDynamicsMove, MCRotationMove, GHMCMove]); run() stops at
+    number_of_iterations, extend() goes past it; every state's moves were applied as often as a replica visited the state, in
+    memory and in the moves the storage holds."""
+    from openmmtools_amd.multistate import MultiStateReporter
+    lj, thermo, ss = _lj_ladder()
+    moves = mcmc.SequenceMove([mcmc.LangevinDynamicsMove(n_steps=1), mcmc.MCRotationMove(atom_subset=list(range(4))), mcmc.GHMCMove(n_steps=1)])
+    s = ReplicaExchangeSampler(mcmc_moves=moves, number_of_iterations=2, engine=OracleEngine(system_factory=ForceFieldOracle), seed=6)
+    rep = MultiStateReporter(str(tmp_path / 'store'), checkpoint_interval=1)
+    s.create(thermo, [ss], storage=rep)
+    assert not s.is_completed
+    s.run(n_iterations=3)
+    assert s.iteration == 2 and s.is_completed
+    s.extend(n_iterations=2)
+    assert s.iteration == 4
+    visited = list(rep.read_replica_thermodynamic_states()[1:].flat)
+    for k, seq in enumerate(s._mcmc_moves):
+        for move_id in (1, 2):
+            assert seq.move_list[move_id].n_proposed == visited.count(k), (k, move_id)
+    rep.close()
+    stored = MultiStateReporter(str(tmp_path / 'store'), open_mode='r').read_mcmc_moves()
+    for k, seq in enumerate(stored):
+        for move_id in (1, 2):
+            assert seq.move_list[move_id].n_proposed == visited.count(k)
+
+
+def test_equilibrate_with_temporary_moves(tmp_path):
+    """tests/test_sampling.py:1878-1928: a GHMC sampler equilibrated with a Langevin move: the production moves are back
+    afterwards, the iteration is still 0 and the storage holds the equilibrated positions."""
+    from openmmtools_amd.multistate import MultiStateReporter
+    lj, thermo, ss = _lj_ladder()
+    s = ReplicaExchangeSampler(mcmc_moves=mcmc.GHMCMove(n_steps=2), engine=OracleEngine(system_factory=ForceFieldOracle), seed=6)
+    rep = MultiStateReporter(str(tmp_path / 'store'), checkpoint_interval=1)
+    s.create(thermo, [ss], storage=rep)
+    s.equilibrate(n_iterations=3, mcmc_moves=mcmc.LangevinDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=1))
+    assert all(isinstance(m, mcmc.GHMCMove) for m in s._mcmc_moves) and s.iteration == 0
+    assert s._engine.integ_args[0] == 'O { V R V } O'                                   # the production program is loaded again
+    now = np.stack([st.positions for st in s.sampler_states])
+    assert np.abs(now - lj.positions[None]).max() > 1e-5
+    rep.close()
+    stored = MultiStateReporter(str(tmp_path / 'store'), open_mode='r').read_sampler_states(iteration=0)
+    for st in stored:
+        assert any(np.allclose(st.positions, x, atol=1e-6) for x in now)
