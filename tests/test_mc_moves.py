@@ -228,3 +228,25 @@ def test_equilibrate_with_temporary_moves(tmp_path):
     stored = MultiStateReporter(str(tmp_path / 'store'), open_mode='r').read_sampler_states(iteration=0)
     for st in stored:
         assert any(np.allclose(st.positions, x, atol=1e-6) for x in now)
+
+
+def test_resume_positions_and_velocities_with_the_references_move_sequence(tmp_path):
+    """tests/test_sampling.py:2032-2078: a sampler with the Langevin + MCRotation + GHMC sequence resumed from its storage holds
+    the positions and velocities it had (to the f4 the checkpoint stores), and its moves come back with their statistics."""
+    from openmmtools_amd.multistate import MultiStateReporter
+    lj, thermo, ss = _lj_ladder()
+    moves = mcmc.SequenceMove([mcmc.LangevinDynamicsMove(n_steps=1), mcmc.MCRotationMove(atom_subset=list(range(4))), mcmc.GHMCMove(n_steps=1)])
+    s = ReplicaExchangeSampler(mcmc_moves=moves, number_of_iterations=3, engine=OracleEngine(system_factory=ForceFieldOracle), seed=6)
+    rep = MultiStateReporter(str(tmp_path / 'store'), checkpoint_interval=1)
+    s.create(thermo, [ss], storage=rep)
+    s.run(n_iterations=3)
+    original = s.sampler_states
+    proposed = [m.move_list[2].n_proposed for m in s._mcmc_moves]
+    del s
+    rep.close()
+    back = ReplicaExchangeSampler.from_storage(rep, engine=OracleEngine(system_factory=ForceFieldOracle))
+    assert back.iteration == 3
+    for a, b in zip(original, back.sampler_states):
+        assert np.allclose(a.positions, b.positions, atol=1e-6) and np.allclose(a.velocities, b.velocities, atol=1e-5)
+    assert [m.move_list[2].n_proposed for m in back._mcmc_moves] == proposed
+    assert isinstance(back._mcmc_moves[0].move_list[1], mcmc.MCRotationMove)
