@@ -147,8 +147,23 @@ class MultiStateSampler:
     # multistatesampler.py:129-131, 1755-1764: the reference propagates and evaluates energies in two ContextCaches; here one
     # engine handle per GPU plays both parts (``engine=``).  The attributes exist so that scripts which assign caches keep
     # running; what is assigned is kept and not used.
-    energy_context_cache = None
-    sampler_context_cache = None
+    @property
+    def energy_context_cache(self):
+        from .. import cache
+        return self.__dict__.get('_energy_context_cache') or cache.global_context_cache       # :1763-1764: the global cache by default
+
+    @energy_context_cache.setter
+    def energy_context_cache(self, value):
+        self.__dict__['_energy_context_cache'] = value
+
+    @property
+    def sampler_context_cache(self):
+        from .. import cache
+        return self.__dict__.get('_sampler_context_cache') or cache.global_context_cache
+
+    @sampler_context_cache.setter
+    def sampler_context_cache(self, value):
+        self.__dict__['_sampler_context_cache'] = value
 
     @property
     def replica_thermodynamic_states(self):

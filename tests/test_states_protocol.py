@@ -66,3 +66,8 @@ def test_context_cache_stand_in_keeps_the_configuration_surface():
     assert back.device_index == 3 and back.capacity is None
     assert cache.DummyContextCache().capacity == 0
     cc.empty()
+    from openmmtools_amd.multistate import MultiStateSampler
+    sampler = MultiStateSampler()                              # tests/test_sampling.py:2328-2334
+    assert sampler.sampler_context_cache is cache.global_context_cache and sampler.energy_context_cache is cache.global_context_cache
+    sampler.sampler_context_cache = cc
+    assert sampler.sampler_context_cache is cc and sampler.energy_context_cache is cache.global_context_cache
