@@ -150,7 +150,8 @@ class MultiStateSampler:
     @property
     def energy_context_cache(self):
         from .. import cache
-        return self.__dict__.get('_energy_context_cache') or cache.global_context_cache       # :1763-1764: the global cache by default
+        own = self.__dict__.get('_energy_context_cache')             # (a cache is falsy while empty: compare with None)
+        return cache.global_context_cache if own is None else own     # :1763-1764: the global cache by default
 
     @energy_context_cache.setter
     def energy_context_cache(self, value):
@@ -159,7 +160,8 @@ class MultiStateSampler:
     @property
     def sampler_context_cache(self):
         from .. import cache
-        return self.__dict__.get('_sampler_context_cache') or cache.global_context_cache
+        own = self.__dict__.get('_sampler_context_cache')
+        return cache.global_context_cache if own is None else own
 
     @sampler_context_cache.setter
     def sampler_context_cache(self, value):
