@@ -11,7 +11,43 @@ from . import unit, integrators
 
 
 class MCMCMove:
-    pass
+    """mcmc.py:143-213.  A move carries parameters (and statistics); the multistate samplers apply it to all their replicas in one
+    batched engine call.  ``apply`` keeps the reference's single-configuration entry point (:155-170): the configuration goes
+    through the same engine as a one-replica ensemble and ``sampler_state`` is updated in place."""
+
+    def apply(self, thermodynamic_state, sampler_state, context_cache=None, engine=None):
+        """``context_cache`` is accepted for call compatibility (a cache with ``make_engine`` chooses the device);
+        ``engine``: the engine object to run on (default: a HipEngine on the GPU -- there is no CPU fallback)."""
+        import numpy as np
+        if engine is None and context_cache is not None and hasattr(context_cache, 'make_engine'):
+            engine = context_cache.make_engine()
+        key = (id(thermodynamic_state), id(engine) if engine is not None else None, sampler_state.n_particles)
+        held = self.__dict__.get('_apply_driver')
+        if held is None or held[0] != key:
+            driver = MCMCSampler(thermodynamic_state, sampler_state, self, engine=engine)
+            driver._ensemble()
+            self.__dict__['_apply_driver'] = held = (key, driver, thermodynamic_state)        # (keeps the state alive: ids stay unique)
+        else:
+            driver = held[1]
+            d = driver._ensemble()
+            box = sampler_state.box_edges if thermodynamic_state.is_periodic else np.zeros(3)
+            d._engine.set_replicas(1, 0, sampler_state.positions[None], None if sampler_state.velocities is None else sampler_state.velocities[None],
+                                   np.asarray(box, dtype=np.float64)[None], d._replica_thermodynamic_states)
+            d._sampler_states_stale = True
+        driver.run(1)
+        new = driver.sampler_state
+        sampler_state.positions = new.positions.copy()
+        sampler_state.velocities = None if new.velocities is None else new.velocities.copy()
+        if new.box_vectors is not None:
+            sampler_state.box_vectors = new.box_vectors.copy()
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_apply_driver', None)            # the engine behind ``apply`` is not part of the move
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
 
 
 class MCMCSampler:

@@ -250,3 +250,51 @@ def test_resume_positions_and_velocities_with_the_references_move_sequence(tmp_p
         assert np.allclose(a.positions, b.positions, atol=1e-6) and np.allclose(a.velocities, b.velocities, atol=1e-5)
     assert [m.move_list[2].n_proposed for m in back._mcmc_moves] == proposed
     assert isinstance(back._mcmc_moves[0].move_list[1], mcmc.MCRotationMove)
+
+
+def test_metropolized_moves_through_apply():
+    """tests/test_mcmc.py:544-580: every MetropolizedMove subclass applied to one configuration with ``move.apply`` until both an
+    acceptance and a rejection occurred; accepted moves change the positions, rejected ones leave them untouched to the bit.
+    (The reference rotates alanine dipeptide in vacuum; here: the solvated dipeptide nudged as a body, and three neighbouring
+    atoms of a dilute Lennard-Jones fluid rotated about their centre -- a single atom would rotate onto itself.)"""
+    al = testsystems.AlanineDipeptideExplicit()
+    lj = testsystems.LennardJonesFluid(nparticles=216, reduced_density=0.3)
+    near = [int(i) for i in np.argsort(np.linalg.norm(lj.positions - lj.positions[0], axis=1))[:3]]
+    cases = {mcmc.MCDisplacementMove: (al, 300.0, dict(atom_subset=list(range(22)), displacement_sigma=0.02 * unit.nanometer)),
+             mcmc.MCRotationMove: (lj, 120.0, dict(atom_subset=near))}
+    assert set(cases) == set(mcmc.MetropolizedMove.__subclasses__())
+    for move_class, (system, temperature, kwargs) in cases.items():
+        thermo = states.ThermodynamicState(system.system, temperature * unit.kelvin)
+        engine = OracleEngine(system_factory=ForceFieldOracle)
+        move = move_class(**kwargs)
+        ss = states.SamplerState(system.positions, box_vectors=system.system.getDefaultPeriodicBoxVectors())
+        for _ in range(60):
+            before, accepted = ss.positions.copy(), move.n_accepted
+            move.apply(thermo, ss, engine=engine)
+            if move.n_accepted > accepted:
+                assert not np.allclose(before, ss.positions)
+            else:
+                assert np.array_equal(before, ss.positions)
+            if 0 < move.n_accepted < move.n_proposed:
+                break
+        assert 0 < move.n_accepted < move.n_proposed, 'Could not generate an accepted and rejected move for class ' + move_class.__name__
+
+
+def test_langevin_splitting_move_through_the_mcmc_sampler_and_apply():
+    """tests/test_mcmc.py:583-593: the three splittings of the reference's test run through MCMCSampler; ``move.apply`` updates
+    the sampler state in place and a pickled move does not drag its engine along."""
+    import pickle
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    thermo = states.ThermodynamicState(lj.system, 120.0 * unit.kelvin)
+    for splitting in ('V R O R V', 'V R R R O R R R V', 'O { V R V } O'):
+        ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+        move = mcmc.LangevinSplittingDynamicsMove(splitting=splitting, n_steps=3, timestep=1.0 * unit.femtosecond)
+        sampler = mcmc.MCMCSampler(thermo, ss, move=move, engine=OracleEngine(system_factory=ForceFieldOracle))
+        sampler.run(1)
+        assert not np.allclose(sampler.sampler_state.positions, lj.positions)
+        move.apply(thermo, ss, engine=OracleEngine(system_factory=ForceFieldOracle))
+        assert not np.allclose(ss.positions, lj.positions) and ss.velocities is not None
+        first = ss.positions.copy()
+        move.apply(thermo, ss, engine=None if False else move.__dict__['_apply_driver'][1]._engine)      # same engine: the cached driver
+        assert not np.allclose(ss.positions, first)
+        assert '_apply_driver' not in pickle.loads(pickle.dumps(move)).__dict__
