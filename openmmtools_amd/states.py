@@ -222,6 +222,23 @@ class SamplerState:
             return None
         return self.potential_energy + self.kinetic_energy
 
+    @property
+    def area_xy(self):
+        """states.py:2180-2184: area of the box in the xy plane (None without a box)."""
+        if self.box_vectors is None:
+            return None
+        return float(abs(np.cross(self.box_vectors[0], self.box_vectors[1])[2]))
+
+    def __getitem__(self, item):
+        """states.py:2296-2325: the sampler state of a subset of particles (an index, a slice or a sequence of indices): copies
+        of their positions and velocities, the same box, no energies (undefined for a subset)."""
+        if np.issubdtype(type(item), np.integer):
+            item = [int(item)]
+        sub = SamplerState(np.array(self.positions[item], dtype=np.float64),
+                           velocities=None if self.velocities is None else np.array(self.velocities[item], dtype=np.float64),
+                           box_vectors=None if self.box_vectors is None else self.box_vectors.copy())
+        return sub
+
     def has_nan(self):
         """states.py:2281-2293: any NaN among the positions (what the reference checks) or the velocities."""
         return bool(np.isnan(self.positions).any() or (self.velocities is not None and np.isnan(self.velocities).any()))

@@ -71,3 +71,20 @@ def test_context_cache_stand_in_keeps_the_configuration_surface():
     assert sampler.sampler_context_cache is cache.global_context_cache and sampler.energy_context_cache is cache.global_context_cache
     sampler.sampler_context_cache = cc
     assert sampler.sampler_context_cache is cc and sampler.energy_context_cache is cache.global_context_cache
+
+
+def test_sampler_state_subsets():
+    """states.py:2296-2325 (tests/test_states.py __getitem__ cases): an index, a slice and an index list give independent copies
+    with the same box and no energies."""
+    rng = np.random.default_rng(0)
+    box = np.diag([2.0, 3.0, 4.0])
+    ss = states.SamplerState(rng.normal(size=(6, 3)), velocities=rng.normal(size=(6, 3)), box_vectors=box)
+    ss.potential_energy = 1.0
+    one, sl, pick = ss[2], ss[1:4], ss[[0, 5]]
+    assert one.n_particles == 1 and np.array_equal(one.positions[0], ss.positions[2]) and np.array_equal(one.velocities[0], ss.velocities[2])
+    assert sl.n_particles == 3 and np.array_equal(sl.positions, ss.positions[1:4])
+    assert pick.n_particles == 2 and np.array_equal(pick.velocities, ss.velocities[[0, 5]])
+    assert np.array_equal(sl.box_vectors, box) and sl.potential_energy is None and abs(ss.area_xy - 6.0) < 1e-15
+    sl.positions[0, 0] += 1.0
+    assert ss.positions[1, 0] != sl.positions[0, 0]
+    assert states.SamplerState(np.zeros((2, 3)))[0].velocities is None and states.SamplerState(np.zeros((2, 3))).area_xy is None
