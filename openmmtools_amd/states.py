@@ -267,6 +267,22 @@ class SamplerState:
         self.__dict__.update(s)
 
 
+def reduced_potential_at_states(sampler_state, thermodynamic_states, context_cache=None, engine=None):
+    """states.py:144-183: the reduced potentials of ONE configuration at a list of thermodynamic states (grouped by compatible
+    System: one set of device tables per group, every state of a group from one evaluation where only the temperature or
+    lambda differs).  The engine's u_kl row for a single replica: ``engine`` is the engine object to use (default: a HipEngine
+    on the GPU; ``context_cache.make_engine()`` when a cache is given)."""
+    from .multistate import MultiStateSampler
+    from . import mcmc
+    if engine is None and context_cache is not None and hasattr(context_cache, 'make_engine'):
+        engine = context_cache.make_engine()
+    row = MultiStateSampler(mcmc_moves=mcmc.LangevinDynamicsMove(n_steps=1), number_of_iterations=0, engine=engine,
+                            online_analysis_interval=None)
+    row.create(list(thermodynamic_states), [sampler_state], storage=None)
+    row._compute_energies()
+    return np.array(row.energy_thermodynamic_states[0], dtype=np.float64)
+
+
 def group_by_compatibility(states):
     """states.py:186-217."""
     groups, indices = [], []

@@ -88,3 +88,23 @@ def test_sampler_state_subsets():
     sl.positions[0, 0] += 1.0
     assert ss.positions[1, 0] != sl.positions[0, 0]
     assert states.SamplerState(np.zeros((2, 3)))[0].velocities is None and states.SamplerState(np.zeros((2, 3))).area_xy is None
+
+
+def test_reduced_potential_at_states_is_the_energy_row_of_one_configuration():
+    """states.py:144-183 (tests/test_states.py reduced_potential_at_states): temperatures on one System, and states on two
+    Systems (two compatibility groups), against beta * U of the f64 oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    from oracle.forcefield import ForceFieldOracle
+    from openmmtools_amd.system import system_to_desc
+    from openmmtools_amd.constants import kB
+    a = testsystems.LennardJonesFluid(nparticles=216)
+    b = testsystems.LennardJonesFluid(nparticles=216, epsilon=0.2 * unit.kilocalories_per_mole)
+    ss = states.SamplerState(a.positions, box_vectors=a.system.getDefaultPeriodicBoxVectors())
+    thermo = [states.ThermodynamicState(a.system, 100.0), states.ThermodynamicState(a.system, 150.0), states.ThermodynamicState(b.system, 100.0)]
+    u = states.reduced_potential_at_states(ss, thermo, engine=OracleEngine(system_factory=ForceFieldOracle))
+    box = np.diag(a.system.getDefaultPeriodicBoxVectors())
+    Ua = ForceFieldOracle(system_to_desc(a.system)).energy_forces(a.positions, box)[0]
+    Ub = ForceFieldOracle(system_to_desc(b.system)).energy_forces(a.positions, box)[0]
+    assert np.allclose(u, [Ua / (kB * 100.0), Ua / (kB * 150.0), Ub / (kB * 100.0)], rtol=1e-10)
