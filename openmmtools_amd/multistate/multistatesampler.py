@@ -945,9 +945,9 @@ class MultiStateSampler:
         eng = self._engine
         x, v, u_old, _ = eng.get_replicas(positions=True, velocities=True, potential=True)
         n_local = x.shape[0]
-        try:
+        if self._thermodynamic_states[0].is_periodic:
             box = np.asarray(eng.get_boxes(), dtype=np.float64).reshape(n_local, 3)
-        except Exception:
+        else:
             box = np.zeros((n_local, 3))
         subset = move._subset()
         proposed = x.copy()
