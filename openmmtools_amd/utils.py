@@ -70,3 +70,44 @@ def with_timer(task_name):
                 return func(*args, **kwargs)
         return wrapper
     return decorate
+
+
+# ---- serialization (openmmtools/utils/utils.py:606-690) -------------------------------------------------------------------------
+_SERIALIZED_MANGLED_PREFIX = '_serialized__'
+
+
+def serialize(instance, **kwargs):
+    """The dictionary of ``instance.__getstate__(**kwargs)`` plus the module and class names it is rebuilt from (:611-646)."""
+    try:
+        serialization = dict(instance.__getstate__(**kwargs))
+    except AttributeError:
+        raise ValueError('Cannot serialize class {} without a __getstate__ method'.format(instance.__class__.__name__))
+    serialization[_SERIALIZED_MANGLED_PREFIX + 'module_name'] = instance.__module__
+    serialization[_SERIALIZED_MANGLED_PREFIX + 'class_name'] = instance.__class__.__name__
+    return serialization
+
+
+def deserialize(serialization):
+    """The instance a ``serialize`` dictionary describes: its class is looked up by name (classes of this package only) and
+    filled through ``__setstate__`` without running ``__init__`` (:649-686)."""
+    import importlib
+    serialization = dict(serialization)
+    names = []
+    for key in ('module_name', 'class_name'):
+        try:
+            names.append(serialization.pop(_SERIALIZED_MANGLED_PREFIX + key))
+        except KeyError:
+            raise ValueError('Cannot find {} in the serialization. Was the original object serialized with '
+                             'openmmtools.utils.serialize()?'.format(key))
+    module_name, class_name = names
+    if module_name.startswith('openmmtools.'):                       # a dictionary written by the reference: same class, this package
+        module_name = 'openmmtools_amd.' + module_name[len('openmmtools.'):]
+    if not (module_name == 'openmmtools_amd' or module_name.startswith('openmmtools_amd.')):
+        raise ValueError('refusing to deserialize a class outside this package: {}.{}'.format(module_name, class_name))
+    cls = getattr(importlib.import_module(module_name), class_name)
+    instance = cls.__new__(cls)
+    try:
+        instance.__setstate__(serialization)
+    except AttributeError:
+        raise ValueError('Cannot deserialize class {} without a __setstate__ method'.format(class_name))
+    return instance

@@ -298,3 +298,24 @@ def test_langevin_splitting_move_through_the_mcmc_sampler_and_apply():
         move.apply(thermo, ss, engine=None if False else move.__dict__['_apply_driver'][1]._engine)      # same engine: the cached driver
         assert not np.allclose(ss.positions, first)
         assert '_apply_driver' not in pickle.loads(pickle.dumps(move)).__dict__
+
+
+def test_moves_serialization():
+    """tests/test_mcmc.py:463-484: every move survives utils.serialize / utils.deserialize with an identical pickle."""
+    import pickle
+    from openmmtools_amd import utils, integrators, cache
+    cases = [mcmc.IntegratorMove(integrators.BAOABIntegrator(timestep=1.0 * unit.femtosecond), n_steps=10),
+             mcmc.LangevinDynamicsMove(), mcmc.LangevinSplittingDynamicsMove(), mcmc.GHMCMove(), mcmc.HMCMove(n_steps=5),
+             mcmc.MonteCarloBarostatMove(), mcmc.MCDisplacementMove(atom_subset=[1, 2]), mcmc.MCRotationMove(),
+             mcmc.SequenceMove(move_list=[mcmc.LangevinDynamicsMove(), mcmc.GHMCMove()])]
+    for move in cases:
+        ser = utils.serialize(move)
+        assert ser['_serialized__class_name'] == type(move).__name__ and ser['_serialized__module_name'] == 'openmmtools_amd.mcmc'
+        back = utils.deserialize(ser)
+        assert type(back) is type(move) and pickle.dumps(back) == pickle.dumps(move)
+    with pytest.raises(ValueError, match='Cannot find module_name'):
+        utils.deserialize(dict(n_steps=3))
+    with pytest.raises(ValueError, match='outside this package'):
+        utils.deserialize({'_serialized__module_name': 'os', '_serialized__class_name': 'system'})
+    ref_style = dict(utils.serialize(mcmc.GHMCMove()), _serialized__module_name='openmmtools.mcmc')       # written by the reference
+    assert isinstance(utils.deserialize(ref_style), mcmc.GHMCMove)
