@@ -75,6 +75,10 @@ class MCMCSampler:
 
     def run(self, n_iterations=1):
         """:251-266."""
+        if isinstance(self.move, WeightedMove):                              # a choice per application: the move's own apply
+            for _ in range(int(n_iterations)):
+                self.move.apply(self.thermodynamic_state, self.sampler_state, engine=self._engine)
+            return
         d = self._ensemble()
         d.extend(int(n_iterations))
         self.sampler_state = d.sampler_states[0]
@@ -107,6 +111,40 @@ class SequenceMove(MCMCMove):
 
     def __len__(self):
         return len(self.move_list)
+
+
+class WeightedMove(MCMCMove):
+    """mcmc.py:439-535: one move of a set per application, picked with probability equal to its weight (numpy's global stream,
+    as in the reference).  The choice is made per configuration, so it runs through ``apply`` / ``MCMCSampler``; a multistate
+    sampler propagates all replicas with ONE program per launch and refuses it (``SequenceMove`` is the batched composition)."""
+
+    def __init__(self, move_set, **kwargs):
+        self.move_set = list(move_set)
+
+    @property
+    def statistics(self):
+        return [getattr(move, 'statistics', {}) for move, _ in self.move_set]
+
+    @statistics.setter
+    def statistics(self, value):
+        for (move, _), v in zip(self.move_set, value):
+            if hasattr(move, 'statistics'):
+                move.statistics = v
+
+    def apply(self, thermodynamic_state, sampler_state, context_cache=None, engine=None):
+        import numpy as np
+        moves, weights = zip(*self.move_set)
+        move = moves[int(np.random.choice(len(moves), p=np.asarray(weights, dtype=np.float64)))]     # :516-517
+        move.apply(thermodynamic_state, sampler_state, context_cache=context_cache, engine=engine)
+
+    def __iter__(self):
+        return iter(self.move_set)
+
+    def __len__(self):
+        return len(self.move_set)
+
+    def __str__(self):
+        return str(self.move_set)
 
 
 class IntegratorMoveError(Exception):

@@ -319,3 +319,24 @@ def test_moves_serialization():
         utils.deserialize({'_serialized__module_name': 'os', '_serialized__class_name': 'system'})
     ref_style = dict(utils.serialize(mcmc.GHMCMove()), _serialized__module_name='openmmtools.mcmc')       # written by the reference
     assert isinstance(utils.deserialize(ref_style), mcmc.GHMCMove)
+
+
+def test_weighted_move_picks_by_weight_per_application():
+    """mcmc.py:439-535 (its docstring example through MCMCSampler): over many applications both moves of the set are used in
+    proportion to their weights; a multistate sampler refuses the per-configuration choice."""
+    ho = testsystems.HarmonicOscillator(K=100.0 * unit.kilojoules_per_mole / unit.nanometer ** 2, mass=12.0 * unit.amu)
+    thermo = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(np.full((1, 3), 0.1), box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    a = mcmc.MCDisplacementMove(displacement_sigma=0.05 * unit.nanometer)
+    b = mcmc.GHMCMove(timestep=2.0 * unit.femtosecond, n_steps=2)
+    move = mcmc.WeightedMove([(a, 0.75), (b, 0.25)])
+    np.random.seed(3)
+    sampler = mcmc.MCMCSampler(thermo, ss, move=move, engine=OracleEngine())
+    sampler.run(n_iterations=80)
+    assert a.n_proposed + b.n_proposed // 2 == 80 and 45 <= a.n_proposed <= 72
+    assert not np.allclose(sampler.sampler_state.positions, 0.1)
+    assert move.statistics == [a.statistics, b.statistics] and len(move) == 2
+    s = MultiStateSampler(mcmc_moves=move, engine=OracleEngine(), seed=1)
+    with pytest.raises(NotImplementedError):
+        s.create([thermo], [ss], storage=None)
+        s.run()
