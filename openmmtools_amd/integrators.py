@@ -77,7 +77,7 @@ class LangevinIntegrator:
 
     # ---- parsing (integrators.py:1337-1402, 1474-1537) --------------------------------------
     @staticmethod
-    def _sanity_check(splitting):
+    def _sanity_check(splitting, require_O=True):
         """integrators.py:1319-1402.  Same verdicts and exception types as the reference on every string it treats sensibly
         (tests/golden/splittings_reference.json holds what its own parser says); stricter where the reference lets nonsense
         through by accident: step names must be single letters (it accepts 'OR' and '12' by a substring test), braces must be
@@ -111,11 +111,11 @@ class LangevinIntegrator:
         # :1365-1368: the reference asserts that all three kinds of step occur
         assert any(t == 'R' for t in tokens)
         assert any(t[0] == 'V' for t in tokens)
-        assert any(t == 'O' for t in tokens)
+        assert any(t == 'O' for t in tokens) or not require_O
 
     def _parse_splitting_string(self, splitting_string):
         splitting_string = splitting_string.upper()
-        self._sanity_check(splitting_string)
+        self._sanity_check(splitting_string, require_O=getattr(self, '_REQUIRE_O', True))
         steps = splitting_string.split(' ')
         counts = {s: sum(1 for t in steps if t[0] == s) for s in 'ORV{}'}
         groups = set(t[1:] for t in steps if t[0] == 'V' and len(t) > 1)
@@ -154,3 +154,37 @@ class GHMCIntegrator(LangevinIntegrator):
     def __init__(self, *args, **kwargs):
         kwargs['splitting'] = self.SPLITTING
         super().__init__(*args, **kwargs)
+
+
+class VelocityVerletIntegrator(LangevinIntegrator):
+    """integrators.py:456-498: velocity Verlet with constraints -- the deterministic splitting "V R V" (no thermostat step: the
+    collision rate is zero and the temperature unused)."""
+
+    _REQUIRE_O = False
+
+    def __init__(self, timestep=1.0 * unit.femtoseconds, **kwargs):
+        kwargs.pop('splitting', None)
+        super().__init__(temperature=kwargs.pop('temperature', 298.0 * unit.kelvin), collision_rate=0.0, timestep=timestep,
+                         splitting='V R V', **kwargs)
+
+
+class HMCIntegrator(LangevinIntegrator):
+    """integrators.py:885-1010: hybrid Monte Carlo -- velocities redrawn from the Maxwell-Boltzmann distribution, ``nsteps``
+    velocity Verlet steps, one Metropolis test: one pass of "O { (V R V)^nsteps }" at nsteps * timestep with the collision
+    rate at which the O step forgets the old velocities completely (mcmc.HMCMove runs the same program)."""
+
+    def __init__(self, temperature=298.0 * unit.kelvin, nsteps=10, timestep=1.0 * unit.femtoseconds, **kwargs):
+        n = int(nsteps)
+        if n < 1:
+            raise ValueError('HMCIntegrator needs at least one step per trajectory')
+        kwargs.pop('splitting', None)
+        kwargs.pop('collision_rate', None)
+        self.nsteps = n
+        self.hmc_timestep = float(unit.to_md(timestep)) if hasattr(unit, 'to_md') else float(timestep)
+        super().__init__(temperature=temperature, collision_rate=1.0e12, timestep=self.hmc_timestep * n,
+                         splitting='O {' + ' V R V' * n + ' }', **kwargs)
+
+    @property
+    def acceptance_rate(self):
+        """:1003-1006 reads the integrator's counters; here they live on the engine (remd_get_work)."""
+        raise AttributeError('acceptance statistics are per replica on the engine: engine.get_work()')

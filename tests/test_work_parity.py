@@ -322,3 +322,32 @@ def test_integrator_move_wraps_the_named_langevin_integrators():
         mcmc.IntegratorMove(object(), n_steps=1)
     from openmmtools_amd.multistate import MultiStateSampler
     assert MultiStateSampler._move_key(m)[0] == 'langevin'
+
+
+def test_velocity_verlet_and_hmc_integrators_as_moves():
+    """integrators.py:456-498, 885-1010 through IntegratorMove: velocity Verlet conserves the total energy of the relaxed fluid to
+    O(dt^2) and reverses exactly; the HMC integrator is the program HMCMove runs."""
+    from openmmtools_amd import integrators, unit
+    vv = integrators.VelocityVerletIntegrator(timestep=1.0 * unit.femtosecond)
+    assert vv.splitting == 'V R V' and vv.collision_rate == 0.0
+    with pytest.raises(AssertionError):
+        integrators.LangevinIntegrator(splitting='V R V')                  # the Langevin class itself needs an O (integrators.py:1368)
+    hmc = integrators.HMCIntegrator(temperature=120.0 * unit.kelvin, nsteps=4, timestep=1.0 * unit.femtosecond)
+    ref = mcmc.HMCMove(timestep=1.0 * unit.femtosecond, n_steps=4)
+    assert hmc.splitting == ref.splitting and abs(hmc.getStepSize() - ref.engine_timestep) < 1e-15 and hmc.is_metropolized
+    move = mcmc.IntegratorMove(vv, n_steps=20)
+    system, positions = _lj()
+    ora = OracleEngine(system_factory=ForceFieldOracle)
+    _setup(ora, system, positions, move.splitting, move.timestep, move.n_steps, R=1, measure=(False, False), T=(120.0,))
+    ora.set_integrator(move.splitting, move.timestep, move.collision_rate, move.n_steps, False, 1e-8)
+    from oracle import md_oracle as mo
+    rng = np.random.default_rng(1)
+    ora.v = 0.2 * rng.normal(size=ora.x.shape)
+    e0 = ora.sys.potential(ora.x[0], ora.box[0]) + mo.kinetic_energy(ora.sys.mass, ora.v[0])
+    x0 = ora.x.copy()
+    ora.propagate(0)
+    e1 = ora.sys.potential(ora.x[0], ora.box[0]) + mo.kinetic_energy(ora.sys.mass, ora.v[0])
+    assert abs(e1 - e0) < 2e-2 * abs(mo.kinetic_energy(ora.sys.mass, ora.v[0])) and np.abs(ora.x - x0).max() > 1e-3
+    ora.v = -ora.v
+    ora.propagate(1)
+    assert np.abs(ora.x - x0).max() < 1e-9                              # time reversible: no noise anywhere in the program
