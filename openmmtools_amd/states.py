@@ -158,9 +158,24 @@ class ThermodynamicState:
 class AlchemicalState:
     """lambda_sterics / lambda_electrostatics carrier (alchemy.py:86-410, only these two)."""
 
-    def __init__(self, lambda_sterics=1.0, lambda_electrostatics=1.0):
+    def __init__(self, lambda_sterics=1.0, lambda_electrostatics=1.0, lambda_bonds=1.0, lambda_angles=1.0, lambda_torsions=1.0):
         self.lambda_sterics = float(lambda_sterics)
         self.lambda_electrostatics = float(lambda_electrostatics)
+        # alchemy.py:196-199: the factory here does not soften bonded terms (alchemical_bonds / angles / torsions), so these
+        # three parameters exist for call compatibility and must stay at the interacting value
+        for name, value in (('lambda_bonds', lambda_bonds), ('lambda_angles', lambda_angles), ('lambda_torsions', lambda_torsions)):
+            if value is not None and float(value) != 1.0:
+                raise NotImplementedError('%s != 1: alchemically modified bonded terms are not built' % name)
+
+    lambda_bonds = lambda_angles = lambda_torsions = 1.0
+
+    def set_alchemical_parameters(self, new_value):
+        """alchemy.py:247-262: every alchemical parameter this state controls to ``new_value``."""
+        v = float(new_value)
+        if not 0.0 <= v <= 1.0:
+            raise ValueError('alchemical parameters lie in [0, 1]')
+        self.lambda_sterics = v
+        self.lambda_electrostatics = v
 
     @classmethod
     def from_system(cls, system):

@@ -108,3 +108,15 @@ def test_reduced_potential_at_states_is_the_energy_row_of_one_configuration():
     Ua = ForceFieldOracle(system_to_desc(a.system)).energy_forces(a.positions, box)[0]
     Ub = ForceFieldOracle(system_to_desc(b.system)).energy_forces(a.positions, box)[0]
     assert np.allclose(u, [Ua / (kB * 100.0), Ua / (kB * 150.0), Ub / (kB * 100.0)], rtol=1e-10)
+
+
+def test_alchemical_state_surface():
+    """alchemy.py:86-262: the two parameters the engine scales, the bonded ones pinned at 1, set_alchemical_parameters."""
+    a = states.AlchemicalState(lambda_sterics=0.5, lambda_electrostatics=0.25, lambda_bonds=1.0)
+    assert (a.lambda_sterics, a.lambda_electrostatics, a.lambda_bonds, a.lambda_torsions) == (0.5, 0.25, 1.0, 1.0)
+    a.set_alchemical_parameters(0.0)
+    assert a.lambda_sterics == 0.0 and a.lambda_electrostatics == 0.0
+    with pytest.raises(NotImplementedError):
+        states.AlchemicalState(lambda_torsions=0.5)
+    with pytest.raises(ValueError):
+        a.set_alchemical_parameters(1.5)
