@@ -62,6 +62,22 @@ def create_thermodynamic_state_protocol(system, protocol, constants=None, compos
     return out
 
 
+class MonteCarloBarostatSettings:
+    """The accessors of openmm.MonteCarloBarostat the reference's code and tests read from ``ThermodynamicState.barostat``."""
+
+    def __init__(self, pressure, temperature, frequency):
+        self._pressure, self._temperature, self._frequency = float(pressure), float(temperature), int(frequency)
+
+    def getDefaultPressure(self):
+        return self._pressure                     # kJ/mol/nm^3 (``pressure / unit.bar`` gives bar)
+
+    def getDefaultTemperature(self):
+        return self._temperature
+
+    def getFrequency(self):
+        return self._frequency
+
+
 class ThermodynamicState:
     def __init__(self, system, temperature, pressure=None):
         self._system = system
@@ -81,6 +97,14 @@ class ThermodynamicState:
         if value is not None and not self._system.usesPeriodicBoundaryConditions():
             raise ValueError('pressure is specified but the system is not periodic')          # states.py:1156-1158
         self._pressure = None if value is None else float(to_md(value))
+
+    @property
+    def barostat(self):
+        """states.py:705-727: what the reference returns as a copy of the System's MonteCarloBarostat -- here the three numbers it
+        carries (pressure of this state, its temperature, the attempt frequency); None at constant volume."""
+        if self._pressure is None:
+            return None
+        return MonteCarloBarostatSettings(self._pressure, self._temperature, self.barostat_frequency)
 
     @property
     def system(self):

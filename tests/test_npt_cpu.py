@@ -169,3 +169,20 @@ def test_sequence_move_survives_storage_and_resume(tmp_path):
     # resumed run is a valid continuation, not a bit-identical one; volumes stay close to the uninterrupted run
     va = np.array([st.volume for st in full.sampler_states]); vb = np.array([st.volume for st in resumed.sampler_states])
     assert np.all(np.abs(vb / va - 1.0) < 0.1)
+
+
+def test_barostat_move_frequency():
+    """tests/test_mcmc.py:251-275: MonteCarloBarostatMove.apply on one configuration leaves the state's barostat frequency (25,
+    not 1) as it was, and changes the box."""
+    from openmmtools_amd import testsystems, states, mcmc, unit
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+    thermo = states.ThermodynamicState(lj.system, 120.0 * unit.kelvin, 1.0 * unit.atmosphere)
+    assert states.ThermodynamicState(lj.system, 120.0 * unit.kelvin).barostat is None
+    old_frequency = thermo.barostat.getFrequency()
+    assert old_frequency != 1 and abs(thermo.barostat.getDefaultPressure() - 1.0 * unit.atmosphere) < 1e-15
+    move = mcmc.MonteCarloBarostatMove(n_attempts=5)
+    v0 = ss.volume
+    move.apply(thermo, ss, engine=OracleEngine(ForceFieldOracle))
+    assert thermo.barostat.getFrequency() == old_frequency
+    assert ss.volume != v0
