@@ -340,3 +340,29 @@ def test_weighted_move_picks_by_weight_per_application():
     with pytest.raises(NotImplementedError):
         s.create([thermo], [ss], storage=None)
         s.run()
+
+
+@pytest.mark.parametrize('case', ['ghmc', 'weighted'])
+def test_mcmc_expectations_on_the_harmonic_oscillator(case):
+    """tests/test_mcmc.py:33-49, 97-250 with its move parameters: GHMCMove(10 fs x 100) and WeightedMove([GHMC, HMC(10 fs x 10)])
+    on testsystems.HarmonicOscillator at 298 K through MCMCSampler; <U> = 3/2 kT within 6 standard errors (statistical
+    inefficiency from the series), as the reference tests it."""
+    from openmmtools_amd.multistate import analysis as an
+    ho = testsystems.HarmonicOscillator()
+    ghmc = mcmc.GHMCMove(timestep=10.0 * unit.femtoseconds, n_steps=100)
+    move = ghmc if case == 'ghmc' else mcmc.WeightedMove([(ghmc, 0.5), (mcmc.HMCMove(timestep=10.0 * unit.femtosecond, n_steps=10), 0.5)])
+    thermo = states.ThermodynamicState(ho.system, 298.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    np.random.seed(0)
+    sampler = mcmc.MCMCSampler(thermo, ss, move=move, engine=OracleEngine(), seed=4)
+    from openmmtools_amd.system import system_to_desc
+    K = float(np.asarray(system_to_desc(ho.system)['ext_K']).reshape(-1)[0])          # kJ/mol/nm^2 (testsystems.py:779-786)
+    n = 200
+    u = np.zeros(n)
+    for it in range(n):
+        sampler.run(1)
+        u[it] = 0.5 * K * float((sampler.sampler_state.positions[0] ** 2).sum()) / thermo.kT
+    g = an.statistical_inefficiency(u[20:])
+    err = u[20:].std() / np.sqrt(len(u[20:]) / g)
+    assert abs(u[20:].mean() - 1.5) < 6.0 * err, (u[20:].mean(), err, g)
+    assert 0.3 < ghmc.fraction_accepted <= 1.0
