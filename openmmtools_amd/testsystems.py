@@ -132,6 +132,31 @@ class LennardJonesFluid(TestSystem):
         self.ndof = 3 * nparticles
 
 
+class IdealGas(TestSystem):
+    """testsystems.py:2631-2735: non-interacting particles in a periodic box of volume N kT / p with a null periodic
+    NonbondedForce (so that a barostat can act): <V> = (N + 1) kT / p under the Monte Carlo barostat, <U> = 0."""
+
+    def __init__(self, nparticles=216, mass=39.9 * unit.amu, temperature=298.0 * unit.kelvin, pressure=1.0 * unit.atmosphere,
+                 volume=None, **kwargs):
+        super().__init__(**kwargs)
+        from . import constants
+        if volume is None:
+            volume = nparticles * constants.kB * float(unit.to_md(temperature)) / float(unit.to_md(pressure))      # nm^3, :2664-2665
+        length = float(unit.to_md(volume)) ** (1.0 / 3.0)
+        system = System()
+        system.setDefaultPeriodicBoxVectors([length, 0, 0], [0, length, 0], [0, 0, length])
+        nb = NonbondedForce()
+        nb.setNonbondedMethod(NonbondedForce.CutoffPeriodic)                # :2678-2682: charge 0, sigma 1 nm, epsilon 0
+        nb.setCutoffDistance(min(1.0, 0.45 * length))
+        nb.setUseDispersionCorrection(False)
+        for _ in range(nparticles):
+            system.addParticle(mass)
+            nb.addParticle(0.0, 1.0, 0.0)
+        system.addForce(nb)
+        self.system, self.positions = system, subrandom_particle_positions(nparticles, system.getDefaultPeriodicBoxVectors())
+        self.ndof = 3 * nparticles
+
+
 def _load_npz_system(name):
     path = os.path.join(_DATA, name + '.npz')
     if not os.path.exists(path):

@@ -186,3 +186,32 @@ def test_barostat_move_frequency():
     move.apply(thermo, ss, engine=OracleEngine(ForceFieldOracle))
     assert thermo.barostat.getFrequency() == old_frequency
     assert ss.volume != v0
+
+
+def test_ideal_gas_with_the_references_hmc_plus_barostat_sequence():
+    """tests/test_mcmc.py:56-66 + 97-250: testsystems.IdealGas under SequenceMove([HMCMove(10 fs x 10), MonteCarloBarostatMove()])
+    at 298 K, 1 atm through MCMCSampler: the potential energy is zero, every HMC trajectory is accepted (free flight conserves
+    the energy) and <V> = (N + 1) kT / p within 6 standard errors."""
+    from openmmtools_amd import testsystems, states, mcmc, unit
+    from openmmtools_amd.constants import kB
+    from openmmtools_amd.multistate import analysis as an
+    gas = testsystems.IdealGas(nparticles=64)
+    p = 1.0 * unit.atmosphere
+    thermo = states.ThermodynamicState(gas.system, 298.0 * unit.kelvin, p)
+    ss = states.SamplerState(gas.positions, box_vectors=gas.system.getDefaultPeriodicBoxVectors())
+    assert abs(ss.volume - 64 * kB * 298.0 / p) < 1e-9 * ss.volume
+    hmc = mcmc.HMCMove(timestep=10.0 * unit.femtosecond, n_steps=10)
+    move = mcmc.SequenceMove([hmc, mcmc.MonteCarloBarostatMove()])
+    sampler = mcmc.MCMCSampler(thermo, ss, move=move, engine=OracleEngine(ForceFieldOracle), seed=9)
+    n = 160
+    vol = np.zeros(n)
+    for it in range(n):
+        sampler.run(1)
+        vol[it] = sampler.sampler_state.volume
+    v = vol[40:]
+    g = an.statistical_inefficiency(v)
+    err = v.std() / np.sqrt(len(v) / g)
+    expect = 65 * kB * 298.0 / p
+    assert abs(v.mean() - expect) < 6.0 * err, (v.mean() / expect, err / expect, g)
+    w = sampler._driver._engine.get_work()
+    assert int(w['n_trials'][0]) == n * 10 and int(w['n_accepted'][0]) == n * 10
