@@ -7,6 +7,7 @@ through an OpenMM Context (:668-776); here a move only carries the parameters an
 multistate sampler propagates *all* replicas in one batched device call
 (_engine.HipEngine.propagate -> remd_propagate).
 """
+import numpy as np
 from . import unit, integrators
 
 
@@ -36,6 +37,7 @@ class MCMCMove:
             d._sampler_states_stale = True
         driver.run(1)
         new = driver.sampler_state
+        sampler_state.potential_energy, sampler_state.kinetic_energy = new.potential_energy, new.kinetic_energy
         sampler_state.positions = new.positions.copy()
         sampler_state.velocities = None if new.velocities is None else new.velocities.copy()
         if new.box_vectors is not None:
@@ -82,6 +84,10 @@ class MCMCSampler:
         d = self._ensemble()
         d.extend(int(n_iterations))
         self.sampler_state = d.sampler_states[0]
+        # states.py:2431-2490 update_from_context: the sampler state leaves a move with its energies (kJ/mol)
+        _, _, u, k = d._engine.get_replicas(positions=False, velocities=False, potential=True, kinetic=True)
+        self.sampler_state.potential_energy = float(np.asarray(u).reshape(-1)[0])
+        self.sampler_state.kinetic_energy = float(np.asarray(k).reshape(-1)[0])
 
     def minimize(self, tolerance=1.0 * unit.kilocalories_per_mole / unit.angstroms, max_iterations=100):
         """:268-300 (the engine's FIRE minimiser, as MultiStateSampler.minimize)."""

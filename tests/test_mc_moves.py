@@ -366,3 +366,21 @@ def test_mcmc_expectations_on_the_harmonic_oscillator(case):
     err = u[20:].std() / np.sqrt(len(u[20:]) / g)
     assert abs(u[20:].mean() - 1.5) < 6.0 * err, (u[20:].mean(), err, g)
     assert 0.3 < ghmc.fraction_accepted <= 1.0
+
+
+def test_sampler_state_leaves_a_move_with_its_energies():
+    """states.py:2431-2490 / tests/test_mcmc.py:140-147: after MCMCSampler.run and move.apply the sampler state carries the
+    potential and kinetic energy of its configuration."""
+    from oracle import md_oracle as mo
+    lj, thermo, ss = _lj_ladder()
+    move = mcmc.LangevinDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=3)
+    eng = OracleEngine(system_factory=ForceFieldOracle)
+    sampler = mcmc.MCMCSampler(thermo[0], ss, move=move, engine=eng)
+    sampler.run(2)
+    st = sampler.sampler_state
+    box = np.diag(lj.system.getDefaultPeriodicBoxVectors())
+    assert abs(st.potential_energy - eng.sys.potential(st.positions, box)) < 1e-9
+    assert abs(st.kinetic_energy - mo.kinetic_energy(eng.sys.mass, st.velocities)) < 1e-9 and st.total_energy is not None
+    fresh = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+    move.apply(thermo[0], fresh, engine=OracleEngine(system_factory=ForceFieldOracle))
+    assert fresh.potential_energy is not None and fresh.kinetic_energy > 0.0
