@@ -384,3 +384,22 @@ def test_sampler_state_leaves_a_move_with_its_energies():
     fresh = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
     move.apply(thermo[0], fresh, engine=OracleEngine(system_factory=ForceFieldOracle))
     assert fresh.potential_energy is not None and fresh.kinetic_energy > 0.0
+
+
+@pytest.mark.gpu
+def test_mcmc_sampler_and_energy_row_on_the_device(hip_engine_factory):
+    """MCMCSampler (Metropolized displacement + GHMC sequence; energies on the sampler state) and
+    states.reduced_potential_at_states through the device engine (also runnable as tools/gpu_check_mcmc_sampler.py)."""
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    thermo = states.ThermodynamicState(lj.system, 120.0 * unit.kelvin)
+    ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
+    seq = mcmc.SequenceMove([mcmc.MCDisplacementMove(displacement_sigma=0.01 * unit.nanometer, atom_subset=[0, 1]),
+                             mcmc.GHMCMove(timestep=2.0 * unit.femtosecond, n_steps=5)])
+    s = mcmc.MCMCSampler(thermo, ss, move=seq, engine=hip_engine_factory())
+    s.run(3)
+    st = s.sampler_state
+    assert np.isfinite(st.potential_energy) and st.kinetic_energy > 0 and seq.move_list[1].n_proposed == 15 and seq.move_list[0].n_proposed == 3
+    ref = ForceFieldOracle(__import__('openmmtools_amd.system', fromlist=['system_to_desc']).system_to_desc(lj.system))
+    assert abs(st.potential_energy - ref.energy_forces(st.positions, np.diag(lj.system.getDefaultPeriodicBoxVectors()))[0]) < 1e-4 * abs(st.potential_energy) + 1e-3
+    u = states.reduced_potential_at_states(ss, [thermo, states.ThermodynamicState(lj.system, 150.0 * unit.kelvin)], engine=hip_engine_factory())
+    assert abs(u[0] / u[1] - 150.0 / 120.0) < 1e-6
