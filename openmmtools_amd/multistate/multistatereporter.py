@@ -352,6 +352,11 @@ class MultiStateReporter:
         self._files['neighborhoods'].write(iteration, energy_neighborhoods)
         self._files['unsampled_energies'].write(iteration, energy_unsampled_states)
 
+    def _calculate_checkpoint_iteration(self, iteration):
+        """:1504-1515: the frame of ``iteration`` in the checkpoint store, None off the checkpoint interval."""
+        index, remainder = divmod(int(iteration), self._checkpoint_interval)
+        return int(index) if remainder == 0 else None
+
     def _map_iteration_to_good(self, iteration):
         """:1517-1541: an index or slice over the iterations that were written COMPLETELY (0 .. last_iteration): negative
         indices count back from the last good iteration, slices stop there, an index beyond it raises IndexError -- records a

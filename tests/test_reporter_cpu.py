@@ -331,3 +331,32 @@ def test_stored_properties_stay_in_sync_with_the_storage(tmp_path, storage):
     flat = opts if 'kwargs' not in opts else dict(opts['kwargs'], number_of_iterations=opts['number_of_iterations'])
     assert flat['number_of_iterations'] == float('inf') and flat['online_analysis_interval'] == 7
     assert np.allclose(back.read_sampler_states(0)[0].positions, original + 0.1, atol=1e-6)
+
+
+@pytest.mark.parametrize('storage', ['ckpt', 'ckpt.nc'])
+def test_checkpointing_writes_on_the_interval_only(tmp_path, storage):
+    """tests/test_sampling.py:1997-2030: energies exist for every iteration, sampler states only on the checkpoint interval."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    from openmmtools_amd import testsystems, states, mcmc, unit, integrators
+    from openmmtools_amd.multistate import ParallelTemperingSampler, MultiStateReporter
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.IntegratorMove(integrators.VelocityVerletIntegrator(1.0 * unit.femtosecond), n_steps=1)    # the reference's VerletIntegrator move
+    rep = MultiStateReporter(str(tmp_path / storage), checkpoint_interval=2)
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=3, engine=OracleEngine(), seed=2, online_analysis_interval=None)
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=400.0, n_temperatures=3)
+    s.run()
+    rep.close()
+    rep = MultiStateReporter(str(tmp_path / storage), open_mode='r', checkpoint_interval=2)
+    for i in range(3):
+        energies = rep.read_energies(i)[0]
+        got = rep.read_sampler_states(i)
+        assert type(energies) is np.ndarray and energies.shape == (3, 3)
+        if rep._calculate_checkpoint_iteration(i) is not None:
+            assert got[0].positions.shape == (1, 3)
+        else:
+            assert got is None
+    assert [rep._calculate_checkpoint_iteration(i) for i in range(5)] == [0, None, 1, None, 2]
