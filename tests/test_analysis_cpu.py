@@ -386,3 +386,23 @@ def test_helpers_match_vectors_executed_from_the_reference():
     assert np.array_equal(an.MultiStateSamplerAnalyzer.reformat_energies_for_mbar(u, g['ragged_n_k']), np.array(g['ragged']))
     for current, taken, want in g['names']:
         assert an.generate_phase_name(current, taken) == want
+
+
+def test_online_analysis_works_like_the_references_test(tmp_path):
+    """tests/test_sampling.py:2213-2295 with its parameters (10 iterations, analysis every 2, at least 3 iterations, the
+    Verlet-integrator move): what the sampler holds after run() is what _read_last_free_energy reads back from the storage."""
+    from openmmtools_amd import integrators
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions + 0.01, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.SequenceMove([mcmc.IntegratorMove(integrators.VelocityVerletIntegrator(1.0 * unit.femtosecond), n_steps=1),
+                              mcmc.LangevinDynamicsMove(timestep=2.0 * unit.femtosecond, n_steps=20, reassign_velocities=True)])
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=10, online_analysis_interval=2, online_analysis_minimum_iterations=3,
+                                 engine=OracleEngine(), seed=12)
+    rep = MultiStateReporter(str(tmp_path / 'store'), checkpoint_interval=2)
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=600.0, n_temperatures=3)
+    s.run()
+    f_k, (free_energy, err) = ParallelTemperingSampler._read_last_free_energy(s._reporter, s.iteration)
+    assert len(s._last_mbar_f_k) == 3 and not np.all(s._last_mbar_f_k == 0)
+    assert np.all(s._last_mbar_f_k == f_k) and free_energy is not None
+    assert s._last_err_free_energy != 0 and s._last_err_free_energy == err
