@@ -1,6 +1,7 @@
 """Online / offline free-energy analysis: the numpy restatement of the pymbar algorithms the
 reference's analyzer uses (openmmtools_amd/multistate/analysis.py), pinned against analytical results, and the
 sampler plumbing of multistatesampler.py:1519-1735 (tests/test_sampling.py:100-300, 2213-2325 are the models)."""
+import os
 import numpy as np
 import pytest
 from openmmtools_amd import testsystems, states, mcmc, unit
@@ -406,3 +407,44 @@ def test_online_analysis_works_like_the_references_test(tmp_path):
     assert len(s._last_mbar_f_k) == 3 and not np.all(s._last_mbar_f_k == 0)
     assert np.all(s._last_mbar_f_k == f_k) and free_energy is not None
     assert s._last_err_free_energy != 0 and s._last_err_free_energy == err
+
+
+def _yaml_sampler(tmp_path, n_iterations, online_interval, checkpoint_interval, name='store.nc'):
+    from openmmtools_amd import integrators
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions + 0.01, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinDynamicsMove(timestep=2.0 * unit.femtosecond, n_steps=5, reassign_velocities=True)
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=n_iterations, online_analysis_interval=online_interval,
+                                 engine=OracleEngine(), seed=12)
+    rep = MultiStateReporter(str(tmp_path / name), checkpoint_interval=checkpoint_interval)
+    s.create(ts, [ss], storage=rep, min_temperature=300.0, max_temperature=600.0, n_temperatures=3)
+    return s, rep, str(tmp_path / (os.path.splitext(name)[0] + '_real_time_analysis.yaml'))
+
+
+def test_real_time_analysis_yaml_has_one_entry_per_analysis(tmp_path):
+    """tests/test_sampling.py:2385-2426: 13 iterations, analysis every 3 => int(13 / 3) entries in <name>_real_time_analysis.yaml."""
+    import yaml
+    s, rep, path = _yaml_sampler(tmp_path, 13, 3, 3)
+    s.run()
+    assert len(yaml.safe_load(open(path))) == int(13 / 3)
+
+
+@pytest.mark.parametrize('n_iterations,online_interval,checkpoint_interval,iterations_first_run',
+                         [(15, 3, 5, 11), (15, 3, 5, 3), (10, 2, 2, 3), (10, 2, 2, 4), (10, 2, 2, 2)])
+def test_real_time_analysis_yaml_after_a_restore(tmp_path, n_iterations, online_interval, checkpoint_interval, iterations_first_run):
+    """tests/test_sampling.py:2428-2500 with its five cases: the entries of the first run, then (after from_storage resumes at the
+    last checkpoint and repeats the iterations behind it) the total the reference expects."""
+    import yaml
+    first = iterations_first_run // online_interval
+    checkpoints = iterations_first_run // checkpoint_interval
+    extra = first - checkpoint_interval * checkpoints // online_interval
+    total = n_iterations // online_interval + extra
+    s, rep, path = _yaml_sampler(tmp_path, n_iterations, online_interval, checkpoint_interval)
+    s.run(n_iterations=iterations_first_run)
+    got = yaml.safe_load(open(path)) if os.path.exists(path) else []
+    assert len(got or []) == first
+    del s
+    back = ParallelTemperingSampler.from_storage(rep, engine=OracleEngine())
+    back.run()
+    assert len(yaml.safe_load(open(path))) == total
