@@ -267,7 +267,12 @@ class ReferenceStoreReader:
             v = frame('/velocities', like=x)
             if x.size == 0 and v.size:
                 x = np.zeros_like(v)
-            return [states.SamplerState(x[r], velocities=v[r]) for r in range(x.shape[0])]
+            box = None
+            if '/box_vectors' in self._a:
+                data = self._a.read('/box_vectors')
+                if iteration < data.shape[0] and np.abs(data[iteration]).max() > 0 and np.abs(data[iteration]).max() < 1e30:
+                    box = np.array(data[iteration], dtype=np.float64)
+            return [states.SamplerState(x[r], velocities=v[r], box_vectors=None if box is None else box[r]) for r in range(x.shape[0])]
         if self._c is None:
             raise IOError('checkpoint file %s is missing' % self._cpath)
         if iteration % self._checkpoint_interval != 0:
@@ -606,6 +611,12 @@ class ReferenceStoreWriter:
             # the iterations in between stay at the fill value, as records netCDF never wrote do
             if self._position_interval != 0 and int(iteration) % self._position_interval == 0:
                 a.write('/positions', xs, record=int(iteration))
+                if all(s.box_vectors is not None for s in sampler_states):                      # :1720-1731: boxes go with positions
+                    box = np.stack([np.asarray(s.box_vectors, dtype=np.float64).reshape(3, 3) for s in sampler_states])
+                    self._record_variable(a, '/box_vectors', 'f4', ('iteration', 'replica', 'spatial', 'spatial'), (None, R, 3, 3), (('units', 'nm'),))
+                    self._record_variable(a, '/volumes', 'f8', ('iteration', 'replica'), (None, R), (('units', 'nm**3'),))
+                    a.write('/box_vectors', box, record=int(iteration))
+                    a.write('/volumes', np.abs(np.linalg.det(box)), record=int(iteration))
             if self._velocity_interval != 0 and int(iteration) % self._velocity_interval == 0:
                 a.write('/velocities', vs, record=int(iteration))
         if iteration % self._interval != 0:

@@ -507,3 +507,30 @@ def test_separate_checkpoint_file_and_opening_without_it(tmp_path):
     resumed = ParallelTemperingSampler.from_storage(MultiStateReporter(by_string), engine=OracleEngine())
     assert np.array_equal(resumed._reporter.read_energies()[0], e_string)
     assert resumed.iteration == 0                      # the last CHECKPOINT (interval 50): where the reference resumes, too
+
+
+def test_write_sampler_states_like_the_references_test(tmp_path):
+    """tests/test_sampling.py:636-698: checkpoints hold all particles on the interval (zero velocities when a state has none),
+    the analysis file holds the flagged particles -- with their box -- every iteration, and the two agree where both exist."""
+    from openmmtools_amd import testsystems
+    al = testsystems.AlanineDipeptideExplicit()
+    box = al.system.getDefaultPeriodicBoxVectors()
+    rep = MultiStateReporter(str(tmp_path / 'w.nc'), open_mode='w', checkpoint_interval=2, analysis_particle_indices=(1, 2))
+    sampler_states = [states.SamplerState(al.positions, box_vectors=box) for _ in range(2)]
+    for it in range(3):
+        rep.write_sampler_states(sampler_states, it)
+        rep.write_last_iteration(it)
+    rep.close()
+    rep = MultiStateReporter(str(tmp_path / 'w.nc'), open_mode='r')
+    for st, back in zip(sampler_states, rep.read_sampler_states(iteration=0)):
+        assert np.allclose(st.positions, back.positions, atol=1e-6) and np.allclose(back.velocities, 0.0)
+        assert np.allclose(np.asarray(box), back.box_vectors, atol=1e-6)
+    analysis = rep.read_sampler_states(iteration=1, analysis_particles_only=True)
+    assert type(analysis) is list and rep.read_sampler_states(iteration=1) is None
+    for st in analysis:
+        assert st.positions.shape == (2, 3) and st.velocities.shape == (2, 3)
+    analysis, checkpoint = rep.read_sampler_states(iteration=2, analysis_particles_only=True), rep.read_sampler_states(iteration=2)
+    assert len(analysis) == len(checkpoint) == 2
+    for a, c in zip(analysis, checkpoint):
+        assert np.allclose(a.positions, c.positions[[1, 2], :]) and np.allclose(a.velocities, c.velocities[[1, 2], :])
+        assert np.allclose(a.box_vectors, c.box_vectors)
