@@ -534,3 +534,25 @@ def test_write_sampler_states_like_the_references_test(tmp_path):
     for a, c in zip(analysis, checkpoint):
         assert np.allclose(a.positions, c.positions[[1, 2], :]) and np.allclose(a.velocities, c.velocities[[1, 2], :])
         assert np.allclose(a.box_vectors, c.box_vectors)
+
+
+def test_store_roundtrips_of_the_references_reporter_tests(tmp_path):
+    """tests/test_sampling.py:868-931, 1003-1021 on a bare reporter (netCDF4 layout, nothing else written before): state indices,
+    energies with neighbourhoods and unsampled columns, mixing statistics -- written and read at once."""
+    rep = MultiStateReporter(str(tmp_path / 'bare.nc'), open_mode='w')
+    for i, replica_states in enumerate([[2, 1, 0, 3], np.array([3, 1, 0, 2])]):
+        rep.write_replica_thermodynamic_states(replica_states, iteration=i)
+        rep.write_last_iteration(i)
+        assert np.all(np.asarray(replica_states) == rep.read_replica_thermodynamic_states(iteration=i))
+    rep.close()
+    rep = MultiStateReporter(str(tmp_path / 'bare2.nc'), open_mode='w')
+    e = np.array([[0, 2, 3], [1, 2, 0], [1, 2, 3]])
+    nb = np.array([[0, 1, 1], [1, 1, 0], [1, 1, 3]])
+    eu = np.array([[1, 2], [2, 3.0], [3, 9.0]])
+    rep.write_energies(e, nb, eu, iteration=0)
+    got = rep.read_energies(iteration=0)
+    assert np.all(e == got[0]) and np.all(nb == got[1]) and np.all(eu == got[2])
+    acc, prop = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]]), np.array([[3, 3, 3], [6, 6, 6], [9, 9, 9]])
+    rep.write_mixing_statistics(acc, prop, iteration=0)
+    back = rep.read_mixing_statistics(iteration=0)
+    assert np.all(acc == back[0]) and np.all(prop == back[1])
