@@ -556,3 +556,38 @@ def test_store_roundtrips_of_the_references_reporter_tests(tmp_path):
     rep.write_mixing_statistics(acc, prop, iteration=0)
     back = rep.read_mixing_statistics(iteration=0)
     assert np.all(acc == back[0]) and np.all(prop == back[1])
+
+
+def test_store_thermodynamic_states_one_full_serialization_per_compatible_group(tmp_path):
+    """tests/test_sampling.py:513-634 (its plain-state part): states of one System are stored once, the others point at the first
+    through '_Reporter__compatible_state' -- also from the unsampled group into the sampled one; all come back equal."""
+    from openmmtools_amd import testsystems, unit
+    from openmmtools_amd.multistate import _hdf5
+    from openmmtools_amd.multistate._reference_store import _yaml_load
+    lj = testsystems.LennardJonesFluid(nparticles=216).system
+    other = testsystems.LennardJonesFluid(nparticles=216, epsilon=0.2 * unit.kilocalories_per_mole).system
+    nvt = states.ThermodynamicState(lj, 300.0 * unit.kelvin)
+    nvt_compatible = states.ThermodynamicState(lj, 320.0 * unit.kelvin)
+    npt = states.ThermodynamicState(lj, 300.0 * unit.kelvin, 1.0 * unit.atmosphere)
+    thermo = [nvt, nvt_compatible, npt]
+    unsampled = [states.ThermodynamicState(other, 300.0 * unit.kelvin), states.ThermodynamicState(other, 300.0 * unit.kelvin),
+                 states.ThermodynamicState(lj, 300.0 * unit.kelvin)]
+    rep = MultiStateReporter(str(tmp_path / 'ts.nc'), open_mode='w')
+    rep.write_thermodynamic_states(thermo, unsampled)
+    back, back_unsampled = rep.read_thermodynamic_states()
+    for a, b in zip(thermo + unsampled, back + back_unsampled):
+        assert a.temperature == b.temperature and (a.pressure is None) == (b.pressure is None) and a.is_state_compatible(b)
+        if a.pressure is not None:
+            assert abs(a.pressure - b.pressure) < 1e-12 * a.pressure
+    rep.close()
+    with _hdf5.File(str(tmp_path / 'ts.nc')) as f:
+        def stored(path):
+            raw = f.read(path)
+            text = raw.tobytes().decode() if getattr(raw, 'dtype', None) is not None and raw.dtype.kind == 'S' else str(np.asarray(raw).reshape(-1)[0])
+            return _yaml_load(text)
+        s = [stored('/thermodynamic_states/state%d' % k) for k in range(3)]
+        u = [stored('/unsampled_states/state%d' % k) for k in range(3)]
+    assert 'standard_system' in s[0] and 'standard_system' not in s[1] and s[1]['_Reporter__compatible_state'] == 'thermodynamic_states/0'
+    assert 'standard_system' in s[2]                                          # NPT: another ensemble, its own serialization
+    assert 'standard_system' in u[0] and u[1]['_Reporter__compatible_state'] == 'unsampled_states/0'
+    assert u[2]['_Reporter__compatible_state'] == 'thermodynamic_states/0'
