@@ -403,3 +403,30 @@ def test_mcmc_sampler_and_energy_row_on_the_device(hip_engine_factory):
     assert abs(st.potential_energy - ref.energy_forces(st.positions, np.diag(lj.system.getDefaultPeriodicBoxVectors()))[0]) < 1e-4 * abs(st.potential_energy) + 1e-3
     u = states.reduced_potential_at_states(ss, [thermo, states.ThermodynamicState(lj.system, 150.0 * unit.kelvin)], engine=hip_engine_factory())
     assert abs(u[0] / u[1] - 150.0 / 120.0) < 1e-6
+
+
+def test_propagate_replicas_and_compute_energies_do_not_mix_up_replicas():
+    """tests/test_sampling.py:1607-1718: configurations that are translated copies stay translated copies after one velocity
+    Verlet femtosecond of _propagate_replicas, and _compute_energies equals the energies computed one state and one
+    configuration at a time (states.reduced_potential_at_states), unsampled columns included."""
+    from openmmtools_amd import integrators
+    from openmmtools_amd.multistate import MultiStateSampler
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    box = lj.system.getDefaultPeriodicBoxVectors()
+    L = float(np.diag(box)[0])
+    thermo = [states.ThermodynamicState(lj.system, (300.0 + 10.0 * i) * unit.kelvin) for i in range(3)]
+    unsampled = [states.ThermodynamicState(lj.system, 500.0 * unit.kelvin)]
+    sampler_states = [states.SamplerState(lj.positions + 0.1 * i * L, box_vectors=box) for i in range(3)]     # periodic images apart
+    diffs = [np.average(sampler_states[i].positions - sampler_states[i + 1].positions) for i in range(2)]
+    assert not np.allclose(diffs, 0.0)
+    move = mcmc.IntegratorMove(integrators.VelocityVerletIntegrator(1.0 * unit.femtosecond), n_steps=1)
+    s = MultiStateSampler(mcmc_moves=move, engine=OracleEngine(system_factory=ForceFieldOracle), seed=1)
+    s.create(thermo, sampler_states, storage=None, unsampled_thermodynamic_states=unsampled)
+    s._propagate_replicas()
+    new = s.sampler_states
+    assert np.allclose(diffs, [np.average(new[i].positions - new[i + 1].positions) for i in range(2)], rtol=1e-4)
+    s._compute_energies()
+    for r in range(3):
+        row = states.reduced_potential_at_states(new[r], thermo + unsampled, engine=OracleEngine(system_factory=ForceFieldOracle))
+        assert np.allclose(s._energy_thermodynamic_states[r], row[:3], rtol=1e-10)
+        assert np.allclose(s._energy_unsampled_states[r], row[3:], rtol=1e-10)
