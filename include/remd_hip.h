@@ -110,6 +110,15 @@ int  remd_version(void);
 /* ---- set-up (reference: MultiStateSampler._pre_write_create, multistatesampler.py:836-926) */
 int  remd_set_system(remd_handle h, const remd_system_desc* desc);
 
+/* Ewald split of a PME system, to be called BEFORE remd_set_system (0 = none, the default): the direct-space erfc sum runs to
+   coulomb_cutoff_nm >= desc->cutoff while every Lennard-Jones term keeps desc->cutoff and its switching function, and the
+   host passes the ewald_alpha / pme_grid that belong to that range in the descriptor (OpenMM's rule applied to the Coulomb
+   range: alpha = sqrt(-ln 2 tol) / r, mesh >= 2 alpha L / (3 tol^(1/5)); reference: the formula quoted at
+   alchemy/alchemy.py:1528-1532, openmmtools_amd/system.py:ewald_parameters).  The Ewald sum does not depend on where it is
+   split, so potentials and forces agree with the reference split to the Ewald error tolerance on both sides; what changes is
+   how much work the pair kernel and the mesh get (a longer range buys a smaller mesh).  Ignored by non-PME methods.        */
+int  remd_set_coulomb_cutoff(remd_handle h, double coulomb_cutoff_nm);
+
 /* K thermodynamic states: beta [1/(kJ/mol)], lambda_sterics, lambda_electrostatics, and an
    additive potential-energy constant per state in kJ/mol (e.g. the lambda-dependent
    long-range correction of the alchemical CustomNonbondedForce).  Arrays may be NULL
@@ -280,6 +289,12 @@ int  remd_sync(remd_handle h);
 /* test hook: in-place unnormalised 3-D complex FFT of a host array [nx][ny][nz][2] on the
    in-tree mixed-radix FFT that the PME reciprocal pass uses                             */
 int  remd_test_fft3d(remd_handle h, int nx, int ny, int nz, float* data, int inverse);
+
+/* test hook (host arithmetic only, no device needed): minus_G[k] = -G(u[k]) of the force-only Ewald direct-space kernels,
+   F_i = q_i q_j (-G(r^2)) (x_j - x_i) k_e, G(u) = (erfc(alpha r)/r + 2 alpha/sqrt(pi) exp(-alpha^2 u))/u, as libremd_hip.so
+   evaluates it: from the cubic table in r^2 the pair kernels stage in LDS, in the same f32 operations (csrc/coulomb_table.h).
+   libremd_cpu.so answers with the f64 closed form.  u in [2^-8, coulomb_cutoff^2] nm^2.                                 */
+int  remd_test_coulomb_table(double alpha, double coulomb_cutoff_nm, int n, const float* u, float* minus_G);
 
 /* timing of the last remd_propagate / compute_energies / mix on the handle's stream,
    measured with hipEvents (ms)                                                           */

@@ -39,18 +39,21 @@ class RemdSystemDesc(C.Structure):
 
 
 EXPORTS = [
-    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_states',
+    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_states',
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_set_force_groups', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
-    'remd_set_energy_const_volume', 'remd_roof_microbench',
+    'remd_set_energy_const_volume', 'remd_roof_microbench', 'remd_test_coulomb_table',
     'remd_comm_unique_id', 'remd_comm_init', 'remd_comm_all_gather_energies', 'remd_comm_finalize',
 ]
 
 _lib = None
+
+# the split of the Ewald sum a HipEngine asks the host classes for when nothing else is said (see HipEngine.__init__)
+DEFAULT_EWALD_SPLIT = os.environ.get('REMD_EWALD_SPLIT', 'reference')
 
 
 def load_library(path=None):
@@ -77,6 +80,7 @@ def load_library(path=None):
     lib.remd_last_error.restype = C.c_char_p
     lib.remd_version.argtypes = []
     lib.remd_set_system.argtypes = [vp, C.POINTER(RemdSystemDesc)]
+    lib.remd_set_coulomb_cutoff.argtypes = [vp, C.c_double]
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
@@ -112,6 +116,7 @@ def load_library(path=None):
     lib.remd_profile_reset.argtypes = [vp]
     lib.remd_profile_filter.argtypes = [vp, C.c_char_p]
     lib.remd_roof_microbench.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+    lib.remd_test_coulomb_table.argtypes = [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     for name in EXPORTS:
         if name not in ('remd_last_error',):
             getattr(lib, name).restype = C.c_int
@@ -176,14 +181,18 @@ class HipEngine:
 
     is_device = True
 
-    def __init__(self, device=0, stream=None, lib_path=None):
+    def __init__(self, device=0, stream=None, lib_path=None, ewald_split=DEFAULT_EWALD_SPLIT):
+        """ewald_split: how the host classes split the Ewald sum of a PME System for this engine (system.system_to_desc):
+        'reference' = OpenMM's rule on the NonbondedForce cutoff, 'auto' = a longer Coulomb range that buys a plane-friendly
+        mesh (system.rebalanced_coulomb_cutoff), or a Coulomb range in nm.  Potentials agree to the Ewald tolerance either way."""
+        self.ewald_split = ewald_split
         self.lib = load_library(lib_path)
         self.h = C.c_void_p()
         rc = self.lib.remd_create(C.byref(self.h), int(device), C.c_void_p(stream) if stream else None)
         if rc != 0:
             raise RuntimeError('remd_create failed (%d): %s' % (rc, self.lib.remd_last_error(None).decode()))
         self.device = device
-        self._ctor = (device, stream, lib_path)
+        self._ctor = (device, stream, lib_path, ewald_split)
         self.N = self.K = self.R = self.R_global = self.r_begin = 0
         self._keep = None
 
@@ -210,6 +219,8 @@ class HipEngine:
     # ---- set-up ---------------------------------------------------------------------
     def set_system(self, desc_dict):
         s, keep = build_desc(desc_dict)
+        # Ewald split (system.system_to_desc(ewald_split=...)): range of the direct-space Coulomb sum, 0 = the cutoff
+        self._check(self.lib.remd_set_coulomb_cutoff(self.h, float(desc_dict.get('coulomb_cutoff', 0.0))), 'remd_set_coulomb_cutoff')
         self._check(self.lib.remd_set_system(self.h, C.byref(s)), 'remd_set_system')
         self.N = int(desc_dict['n_atoms'])
         if 'force_groups' in desc_dict:                  # Force.getForceGroup() of the force classes (V<g> substeps)

@@ -1,6 +1,7 @@
 // C ABI of libremd_hip.so (see include/remd_hip.h for the contract and reference citations).
 #include <chrono>
 #include "remd_internal.h"
+#include "coulomb_table.h"
 #include <cstring>
 #include <cmath>
 #include <mutex>
@@ -59,6 +60,27 @@ int remd_create(remd_handle* out, int device, void* stream)
     remd_ctx* h = new remd_ctx();
     h->device = device;
     h->stream = (hipStream_t)stream;
+    // Spatial partition of the chip between the two streams of a force evaluation (experiment, profiles/r04_cumask_sweep.txt):
+    // REMD_CU_PAIR = n restricts the direct-space stream to n of the 256 CUs, REMD_CU_MESH = m the handle's own main stream
+    // (only when the caller passed none) to m CUs taken from the other end.  REMD_CU_LAYOUT: 0 = mask bit b is CU b as the
+    // runtime numbers them (KFD deals consecutive bits round-robin to the 8 XCDs), 1 = bit b is CU (b % 32) of XCD (b / 32).
+    auto cu_mask = [](int n, bool from_top, uint32_t* m) {
+        const int layout = getenv("REMD_CU_LAYOUT") ? atoi(getenv("REMD_CU_LAYOUT")) : 0;
+        for (int w = 0; w < 8; ++w) m[w] = 0u;
+        n = std::max(8, std::min(256, n));
+        for (int k = 0; k < n; ++k) {
+            int b;
+            if (layout == 0) b = from_top ? 255 - k : k;
+            else { const int xcd = k % 8, cu = k / 8; b = xcd * 32 + (from_top ? 31 - cu : cu); }
+            m[b >> 5] |= 1u << (b & 31);
+        }
+    };
+    const int cu_pair = getenv("REMD_CU_PAIR") ? atoi(getenv("REMD_CU_PAIR")) : 0;
+    const int cu_mesh = getenv("REMD_CU_MESH") ? atoi(getenv("REMD_CU_MESH")) : 0;
+    if (!h->stream && cu_mesh > 0) {
+        uint32_t m[8]; cu_mask(cu_mesh, false, m);
+        if (hipExtStreamCreateWithCUMask(&h->stream, 8, m) == hipSuccess) h->owns_stream = true; else { h->stream = nullptr; (void)hipGetLastError(); }
+    }
     if (!h->stream) {
         // NULL: a private non-blocking stream (the legacy default stream cannot be captured into a graph, and every entry point
         // that hands results to the caller synchronises before it returns, so nothing relies on default-stream ordering)
@@ -70,7 +92,11 @@ int remd_create(remd_handle* out, int device, void* stream)
         // second stream: carries the direct-space kernels while the (longer) reciprocal-space chain stays on the main one
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess)
+        if (cu_pair > 0) {
+            uint32_t m[8]; cu_mask(cu_pair, true, m);
+            if (hipExtStreamCreateWithCUMask(&h->stream2, 8, m) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); }
+        }
+        if (!h->stream2 && hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess)
             hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
     }
     { const unsigned evf = hipEventReleaseToDevice | hipEventDisableTiming;   // device-scope release: no system-scope cache write-back per fork / join
@@ -122,6 +148,24 @@ int remd_destroy(remd_handle h)
 }
 
 int remd_seed(remd_handle h, uint64_t seed) { if (!h) return -1; h->seed = seed; return 0; }
+
+int remd_test_coulomb_table(double alpha, double coulomb_cutoff_nm, int n, const float* u, float* minus_G)
+{
+    if (!(alpha > 0) || !(coulomb_cutoff_nm > 0) || n < 0 || !u || !minus_G) return remd_fail(nullptr, -1, "remd_test_coulomb_table: bad arguments");
+    const coulomb_table_host T = ctab_build(alpha, coulomb_cutoff_nm * coulomb_cutoff_nm);
+    for (int k = 0; k < n; ++k) {
+        const float uc = std::min(std::max(u[k], T.umin), (float)(coulomb_cutoff_nm * coulomb_cutoff_nm));   // the kernel's v_med3_f32
+        minus_G[k] = ctab_eval_host(T, uc);
+    }
+    return 0;
+}
+
+int remd_set_coulomb_cutoff(remd_handle h, double coulomb_cutoff_nm)
+{
+    if (!h || !(coulomb_cutoff_nm >= 0.0)) return remd_fail(h, -1, "remd_set_coulomb_cutoff: bad arguments");
+    h->coulomb_cutoff = coulomb_cutoff_nm;      // consumed by the next remd_set_system
+    return 0;
+}
 
 int remd_set_system(remd_handle h, const remd_system_desc* d)
 {
@@ -258,6 +302,9 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     // padding atoms are parked far apart so that they never interact
     for (int r = 0; r < R_local; ++r)
         for (int i = h->N; i < h->Npad; ++i) hp[(size_t)r * h->Npad + i] = make_float4(1e6f + 10.f * i, 1e6f, 1e6f, 0.f);
+    if (h->nb_method != REMD_NB_NONE && box)
+        for (int r = 0; r < R_local; ++r) for (int k = 0; k < 3; ++k)
+            if (box[3 * r + k] < 2.0 * h->cutoff) return remd_fail(h, -1, "remd_set_replicas: box smaller than twice the cutoff");
     std::vector<float> hb(4 * (size_t)R_local, 0.f);
     h->box_host.assign(3 * (size_t)R_local, 0.0);
     for (int r = 0; r < R_local; ++r) for (int k = 0; k < 3; ++k) {

@@ -97,6 +97,8 @@ struct nb_tables {
     std::vector<tune_seg> tune_segs; int tune_state = 0 /* 0 measuring, 1 awaiting resolve, 2 done */, tune_left = 0, tune_next = 0;
     int nb_grid = 0;                      // current choice (workgroups; 0 = one per item)
     float sort_cell = 0.45f;              // Morton cell edge (nm) of the molecule sort
+    // Ewald direct-space force table of the force-only pair kernels (coulomb_table.h); REMD_NB_TABLE=0: Abramowitz & Stegun erfc
+    float4* d_ctab = nullptr; bool use_table = false;
 };
 static handle_table<nb_tables> g_nb;
 
@@ -681,13 +683,15 @@ void build_sci_list_kernel(int ncl, int cap, float rc2, const float4* __restrict
 }
 
 struct sci_list_args { int ncl, cap; const float4* cl_c; const float4* cl_h; const float4* tile_c; const float4* tile_h; unsigned int* list; int* count; };
+// (rc2_a / rc2_b: the main system of an Ewald method lists to the Coulomb range nb_params::rcc2, the LJ sub-system to the
+// NonbondedForce cutoff)
 __global__ __launch_bounds__(64)
-void build_sci_list2_kernel(int nt_a, sci_list_args a, sci_list_args b, float rc2, const float* __restrict__ box)
+void build_sci_list2_kernel(int nt_a, sci_list_args a, sci_list_args b, float rc2_a, float rc2_b, const float* __restrict__ box)
 {
     const bool second = (int)blockIdx.x >= nt_a;
     const sci_list_args& g = second ? b : a;
-    build_sci_list_body(second ? blockIdx.x - nt_a : blockIdx.x, blockIdx.y, threadIdx.x, g.ncl, g.cap, rc2, g.cl_c, g.cl_h, g.tile_c, g.tile_h,
-                        box, g.list, g.count);
+    build_sci_list_body(second ? blockIdx.x - nt_a : blockIdx.x, blockIdx.y, threadIdx.x, g.ncl, g.cap, second ? rc2_b : rc2_a, g.cl_c, g.cl_h,
+                        g.tile_c, g.tile_h, box, g.list, g.count);
 }
 
 // all-reduce over the lanes that differ in bit 3 / 4 / 5 of the lane id without the LDS crossbar (ds_bpermute: address
@@ -732,11 +736,15 @@ struct sci_args {
     const float4* spos; const float4* sparam; const unsigned long long* excl; const unsigned int* list; const int* count;
     long long* force;
 };
-template <int METHOD, bool ENERGY, bool ALCH, int NW>
+#define SCI_EWALD(M) ((M) == NB_EWALD || (M) == NB_EWALD_NOLJ)
+template <int METHOD, bool ENERGY, bool ALCH, int NW, bool TABLE = false>
 __device__ __forceinline__
 void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const float* __restrict__ box,
-                        const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R)
+                        const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R,
+                        const float4* ctab = nullptr)
 {
+    constexpr bool TAB = TABLE && !ENERGY && SCI_EWALD(METHOD);
+    const float rcut2 = SCI_EWALD(METHOD) ? p.rcc2 : p.rc2;     // Coulomb range of the Ewald split / NonbondedForce cutoff
     const int N = a.N, Npad = a.Npad, ncl = a.ncl, cap = a.cap, W = a.W, Npad_force = a.Npad_force, ep_off = a.ep_off, nsplit = a.nsplit;
     const float4* __restrict__ spos = a.spos; const float4* __restrict__ sparam = a.sparam;
     const unsigned long long* __restrict__ excl = a.excl; const unsigned int* __restrict__ list = a.list;
@@ -810,8 +818,9 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
                 const float r2 = dx * dx + dy * dy + dz * dz;
                 // which lane pairs count is wave-uniform data (cutoff ballot, exclusion word, padding masks): scalar unit
-                unsigned long long in = __builtin_amdgcn_ballot_w64(r2 < p.rc2);
-                const float r2c = min_sv(p.rc2, r2);             // lanes beyond the cutoff evaluate at the cutoff
+                unsigned long long in = __builtin_amdgcn_ballot_w64(r2 < rcut2);
+                // lanes beyond the cutoff evaluate at the cutoff (the table also has a lower end)
+                const float r2c = TAB ? __builtin_amdgcn_fmed3f(r2, p.ctab_umin, rcut2) : min_sv(rcut2, r2);
                 const int dj = jc - ic;
                 if (dj < W) {                                    // wave-uniform: exclusions (and the diagonal) live here
                     unsigned long long m;
@@ -831,7 +840,7 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 touched = true;
                 float fr, ee;
                 // evaluated for every lane (excluded pairs, even r2 = 0, produce garbage that the select below discards)
-                pair_interaction<METHOD, ALCH, !ENERGY>(p, r2c, pi[s], pj, lam_a, sc, fr, ENERGY, ee);
+                pair_interaction<METHOD, ALCH, !ENERGY, TAB>(p, r2c, pi[s], pj, lam_a, sc, fr, ENERGY, ee, ctab);
                 fr = keep_where(in, fr);
                 const float tx = fr * dx, ty = fr * dy, tz = fr * dz;
                 fix[s] += tx; fiy[s] += ty; fiz[s] += tz;
@@ -889,26 +898,41 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
 
 // 4 wavefronts per SIMD (<= 128 VGPRs) for the hot variants; the rarely used ones that would spill keep 3
 #define SCI_RELAXED(M) (M == NB_RF || M == NB_EWALD || (M == NB_LJ_ONLY && ALCH))
-template <int METHOD, bool ENERGY, bool ALCH, int NW>
+// the Ewald force table (coulomb_table.h) of a force-only launch: global -> LDS, once per workgroup
+extern __shared__ __attribute__((aligned(16))) float4 s_ctab[];
+__device__ __forceinline__ void stage_coulomb_table(const nb_params& p, const float4* __restrict__ ctab_g, int nthreads)
+{
+    for (int k = threadIdx.x; k < p.ctab_n; k += nthreads) s_ctab[k] = ctab_g[k];
+    __syncthreads();
+}
+
+template <int METHOD, bool ENERGY, bool ALCH, int NW, bool TABLE>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SCI_RELAXED(METHOD) ? 2 : 4, SCI_RELAXED(METHOD) ? 3 : 4)))
 void nonbonded_sci_kernel(nb_params p, sci_args a, const float* __restrict__ box, const float* __restrict__ rep_lam,
-                          double* __restrict__ epart, int n_epart, int R)
+                          double* __restrict__ epart, int n_epart, int R, const float4* __restrict__ ctab_g)
 {
-    nonbonded_sci_body<METHOD, ENERGY, ALCH, NW>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R);
+    constexpr bool TAB = TABLE && !ENERGY && SCI_EWALD(METHOD);
+    if (TAB) stage_coulomb_table(p, ctab_g, 64 * NW);
+    nonbonded_sci_body<METHOD, ENERGY, ALCH, NW, TAB>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R, s_ctab - p.ctab_key0);
 }
 
 // main (Coulomb-only) system and LJ sub-system in one launch: the short LJ work items fill the tail of the main ones
-template <int METHOD_A, int METHOD_B, bool ENERGY, bool ALCH, int NW>
+template <int METHOD_A, int METHOD_B, bool ENERGY, bool ALCH, int NW, bool TABLE>
 __global__ __launch_bounds__(64 * NW)
 __attribute__((amdgpu_waves_per_eu((SCI_RELAXED(METHOD_A) || SCI_RELAXED(METHOD_B)) ? 2 : 4, (SCI_RELAXED(METHOD_A) || SCI_RELAXED(METHOD_B)) ? 3 : 4)))
 void nonbonded_sci2_kernel(nb_params p, sci_args a, sci_args b, int n_items_a, int n_items, unsigned int* queue, const float* __restrict__ box,
-                           const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R)
+                           const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R, const float4* __restrict__ ctab_g)
 {
+    constexpr bool TAB = TABLE && !ENERGY && SCI_EWALD(METHOD_A);
     if (!queue) {
-        if ((int)blockIdx.x < n_items_a) nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R);
+        if ((int)blockIdx.x < n_items_a) {
+            if (TAB) stage_coulomb_table(p, ctab_g, 64 * NW);
+            nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW, TAB>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R, s_ctab - p.ctab_key0);
+        }
         else nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW>(p, b, blockIdx.x - n_items_a, box, rep_lam, epart, n_epart, R);
         return;
     }
+    if (TAB) stage_coulomb_table(p, ctab_g, 64 * NW);
     // gridDim.x < n_items: a resident set of workgroups pulls items from two queues (Coulomb items first, then the short LJ
     // items).  The grid size bounds the share of a CU's wave slots and registers this kernel holds while the mesh kernels of
     // the other stream want them: with one workgroup per item the XY pass got 30 % of its work done next to this kernel and
@@ -920,7 +944,7 @@ void nonbonded_sci2_kernel(nb_params p, sci_args a, sci_args b, int n_items_a, i
         __syncthreads();
         const int item = s_item;
         if (item >= n_items_a) break;
-        nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW>(p, a, item, box, rep_lam, epart, n_epart, R);
+        nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW, TAB>(p, a, item, box, rep_lam, epart, n_epart, R, s_ctab - p.ctab_key0);
         __syncthreads();                 // s_item and the merge buffer are reused
     }
     __syncthreads();
@@ -983,6 +1007,7 @@ void nonbonded_kernel(nb_params p, int N, int Npad, const float4* __restrict__ p
     if (cull) { ci = tile_c[(size_t)r * ntile + itile]; hi = tile_h[(size_t)r * ntile + itile]; }
     float fx = 0.f, fy = 0.f, fz = 0.f;
     double e = 0.0;
+    const float rcut2 = SCI_EWALD(METHOD) ? p.rcc2 : p.rc2;
     for (int cb = jbeg; cb < jend; cb += NB_CHUNK) {
         __syncthreads();                                     // previous chunk fully consumed
         {
@@ -1002,7 +1027,7 @@ void nonbonded_kernel(nb_params p, int N, int Npad, const float4* __restrict__ p
                 float bx = cj.x - ci.x, by = cj.y - ci.y, bz = cj.z - ci.z;
                 bx -= Lx * rintf(bx * iLx); by -= Ly * rintf(by * iLy); bz -= Lz * rintf(bz * iLz);
                 bx = fmaxf(0.f, fabsf(bx) - hi.x - hj.x); by = fmaxf(0.f, fabsf(by) - hi.y - hj.y); bz = fmaxf(0.f, fabsf(bz) - hi.z - hj.z);
-                if (bx * bx + by * by + bz * bz > p.rc2) continue;
+                if (bx * bx + by * by + bz * bz > rcut2) continue;
             }
 #pragma unroll 4
             for (int u = 0; u < tn; ++u) {
@@ -1012,7 +1037,7 @@ void nonbonded_kernel(nb_params p, int N, int Npad, const float4* __restrict__ p
                 float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
                 dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
                 const float r2 = dx * dx + dy * dy + dz * dz;
-                bool in = active && (r2 < p.rc2);
+                bool in = active && (r2 < rcut2);
                 if (near) {
                     const int d = j - i + half;
                     if (d >= 0 && d < 2 * half) in = in && !((mk[d >> 6] >> (d & 63)) & 1ull);
@@ -1230,7 +1255,7 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h);
     dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
-    dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue);
+    dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue); dfree(t.d_ctab);
     for (auto& sg : t.tune_segs) { if (sg.a) hipEventDestroy(sg.a); if (sg.b) hipEventDestroy(sg.b); }
     g_nb.erase(h);
 }
@@ -1379,11 +1404,28 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     p.crf = (float)(3.0 * eps_s / (2.0 * eps_s + 1.0) / d->cutoff);
     p.alpha = (float)d->ewald_alpha; p.two_alpha_sqrtpi = (float)(2.0 * d->ewald_alpha / sqrt(M_PI));
     p.excl_words = words;
+    // Ewald split (remd_set_coulomb_cutoff): the erfc tail may be summed beyond the NonbondedForce cutoff, with the alpha and
+    // the mesh of the descriptor chosen for that range by the host; Lennard-Jones terms keep d->cutoff and its switch
+    p.rcc2 = p.rc2;
+    if (t.method == NB_EWALD && h->coulomb_cutoff > 0.0) {
+        if (h->coulomb_cutoff < d->cutoff) return remd_fail(h, -1, "the Coulomb cutoff of remd_set_coulomb_cutoff is shorter than the NonbondedForce cutoff");
+        p.rcc2 = (float)(h->coulomb_cutoff * h->coulomb_cutoff);
+    }
+    p.ctab_key0 = 0; p.ctab_n = 0; p.ctab_umin = 0.f;
+    t.use_table = false;
+    if (t.method == NB_EWALD && !(getenv("REMD_NB_TABLE") && atoi(getenv("REMD_NB_TABLE")) == 0)) {
+        const coulomb_table_host T = ctab_build(d->ewald_alpha, (double)p.rcc2);
+        std::vector<float4> tab(T.n);
+        for (int k = 0; k < T.n; ++k) tab[k] = make_float4(T.c[4 * k], T.c[4 * k + 1], T.c[4 * k + 2], T.c[4 * k + 3]);
+        if ((rc = upload(h, t.d_ctab, tab))) return rc;
+        p.ctab_key0 = T.key0; p.ctab_n = T.n; p.ctab_umin = T.umin;
+        t.use_table = true;
+    }
     const int ntile = (N + 63) / 64;
     {
         p.n_jsplit = std::max(1, std::min(std::min(ntile, 16), 4));
     }
-    h->cutoff = d->cutoff; h->switch_dist = d->switch_distance; h->ewald_alpha = d->ewald_alpha;
+    h->cutoff = std::max(d->cutoff, (double)sqrtf(p.rcc2)); h->switch_dist = d->switch_distance; h->ewald_alpha = d->ewald_alpha;
     for (int k = 0; k < 3; ++k) h->grid[k] = d->pme_grid[k];
 
     // groups: connected components of exclusions + constraints, made contiguous in index space
@@ -1494,7 +1536,8 @@ static int update_replica_lambdas(remd_ctx* h, nb_tables& t)
 static void launch_list_build(remd_ctx* h, nb_tables& t, bool lj)
 {
     const int ncl = lj ? t.NLpad / 8 : ((h->N + 63) / 64) * 8;
-    hipLaunchKernelGGL(build_sci_list_kernel, dim3(ncl / 8, h->R), dim3(64), 0, h->stream, ncl, lj ? t.lj_cap : t.cl_cap, t.p.rc2,
+    hipLaunchKernelGGL(build_sci_list_kernel, dim3(ncl / 8, h->R), dim3(64), 0, h->stream, ncl, lj ? t.lj_cap : t.cl_cap,
+                       (!lj && t.method == NB_EWALD) ? t.p.rcc2 : t.p.rc2,
                        lj ? t.d_lj_cl_c : t.d_cl_c, lj ? t.d_lj_cl_h : t.d_cl_h, lj ? t.d_lj_tile_c : t.d_tile_c, lj ? t.d_lj_tile_h : t.d_tile_h,
                        h->d_box, lj ? t.d_lj_sci_list : t.d_sci_list, lj ? t.d_lj_sci_count : t.d_sci_count);
 }
@@ -1587,7 +1630,8 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
         sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
         sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};
-        hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb, t.p.rc2, h->d_box);
+        hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb,
+                           t.method == NB_EWALD ? t.p.rcc2 : t.p.rc2, t.p.rc2, h->d_box);
     } else {
         hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, h->Npad, t.d_order, h->d_pos, h->d_box,
                            t.d_spos, t.d_tile_c, t.d_tile_h, cl ? t.d_cl_c : (float4*)nullptr, cl ? t.d_cl_h : (float4*)nullptr);
@@ -1637,17 +1681,24 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
             static const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
             const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
             const int grid = (h->pme_concurrent && persist_grid > 0) ? std::min(items, persist_grid) : items;
-#define LAUNCH_SCI2(ALCHF) hipLaunchKernelGGL((nonbonded_sci2_kernel<MAIN, NB_LJ_ONLY, ENERGY, ALCHF, SCI_NW>), dim3(grid), dim3(64 * SCI_NW), 0, \
-            h->stream, t.p, sa, sb, items_a, items, grid < items ? t.d_queue : (unsigned int*)nullptr, h->d_box, rl, h->d_epart, h->n_epart, h->R)
-            if (t.has_alch) LAUNCH_SCI2(true); else LAUNCH_SCI2(false);
+            const bool tab = t.use_table && !ENERGY && SCI_EWALD(MAIN);
+            const size_t tab_lds = tab ? sizeof(float4) * (size_t)t.p.ctab_n : 0;
+#define LAUNCH_SCI2(ALCHF, TABF) hipLaunchKernelGGL((nonbonded_sci2_kernel<MAIN, NB_LJ_ONLY, ENERGY, ALCHF, SCI_NW, TABF>), dim3(grid), dim3(64 * SCI_NW), \
+            tab_lds, h->stream, t.p, sa, sb, items_a, items, grid < items ? t.d_queue : (unsigned int*)nullptr, h->d_box, rl, h->d_epart, h->n_epart, h->R, \
+            (const float4*)t.d_ctab)
+            if (t.has_alch) { if (tab) LAUNCH_SCI2(true, true); else LAUNCH_SCI2(true, false); }
+            else { if (tab) LAUNCH_SCI2(false, true); else LAUNCH_SCI2(false, false); }
 #undef LAUNCH_SCI2
             hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
                                t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
             return;
         }
-#define LAUNCH_SCI(ALCHF) hipLaunchKernelGGL((nonbonded_sci_kernel<METHOD, ENERGY, ALCHF, SCI_NW>), dim3(items_a), dim3(64 * SCI_NW), 0, h->stream, t.p, sa, \
-            h->d_box, rl, h->d_epart, h->n_epart, h->R)
-        if (t.has_alch) LAUNCH_SCI(true); else LAUNCH_SCI(false);
+        const bool tab1 = t.use_table && !ENERGY && SCI_EWALD(METHOD);
+        const size_t tab1_lds = tab1 ? sizeof(float4) * (size_t)t.p.ctab_n : 0;
+#define LAUNCH_SCI(ALCHF, TABF) hipLaunchKernelGGL((nonbonded_sci_kernel<METHOD, ENERGY, ALCHF, SCI_NW, TABF>), dim3(items_a), dim3(64 * SCI_NW), tab1_lds, \
+            h->stream, t.p, sa, h->d_box, rl, h->d_epart, h->n_epart, h->R, (const float4*)t.d_ctab)
+        if (t.has_alch) { if (tab1) LAUNCH_SCI(true, true); else LAUNCH_SCI(true, false); }
+        else { if (tab1) LAUNCH_SCI(false, true); else LAUNCH_SCI(false, false); }
 #undef LAUNCH_SCI
         hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.d_order,
                            t.d_sforce, 0, (const int*)nullptr, (long long*)nullptr, h->d_force, h->Npad);

@@ -4,6 +4,7 @@
 // alchemical soft-core of alchemy.py:1383-1388; f64 restatement: oracle/forcefield.py.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "coulomb_table.h"
 
 #define NB_LJ_ONLY 0
 #define NB_RF      1
@@ -18,6 +19,11 @@ struct nb_params {
     float alpha, two_alpha_sqrtpi;    // Ewald
     int excl_words;                   // 64-bit words of the exclusion window per atom
     int n_jsplit;
+    // Ewald split chosen by the host (remd_set_coulomb_cutoff): the erfc tail is summed to rcc >= rc while the Lennard-Jones
+    // terms keep the NonbondedForce cutoff rc and its switch; rcc2 = rc2 unless the host asked for a longer Coulomb range
+    float rcc2;
+    // force-only Coulomb kernel from a table in r^2 (coulomb_table.h): first bin's key, number of bins, clamp of r^2
+    int ctab_key0, ctab_n; float ctab_umin;
 };
 
 
@@ -34,9 +40,13 @@ __device__ __forceinline__ void switch_fn(const nb_params& p, float r, float& U,
 }
 
 // returns energy, writes dU/dr / r  (so that F_i = fr * (xj - xi))
-template <int METHOD, bool ALCH, bool FAST_ERFC>
+// FAST_ERFC (force-only evaluations): the Ewald direct-space force comes from the cubic table `ctab` (LDS, coulomb_table.h)
+// when one is given (TABLE; `ctab` = the table's LDS address minus its first key, so that the key of r^2 indexes it directly),
+// from the Abramowitz & Stegun erfc otherwise; energy evaluations use erfcf.
+template <int METHOD, bool ALCH, bool FAST_ERFC, bool TABLE = false>
 __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, float4 pi, float4 pj,
-                                                  float lam_a, float sc, float& fr, bool energy_skip_na, float& e_out)
+                                                  float lam_a, float sc, float& fr, bool energy_skip_na, float& e_out,
+                                                  const float4* ctab = nullptr)
 {
     // hardware v_rsq_f32 / v_rcp_f32 (1 ulp) instead of the libm wrappers: r2 is never denormal here and the
     // denormal/IEEE-division guards cost a sixth of this VALU-bound loop
@@ -45,7 +55,8 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
     const float sig = pi.y + pj.y, eps4 = pi.z * pj.z;
     float U = 0.f, dUdr = 0.f;
     bool na = false;
-    if (METHOD <= NB_EWALD && eps4 != 0.f) {
+    // (an unsplit Ewald kernel that sums the Coulomb tail beyond the Lennard-Jones cutoff: LJ stops at rc)
+    if (METHOD <= NB_EWALD && eps4 != 0.f && (METHOD != NB_EWALD || r2 < p.rc2)) {
         if (ALCH && (pi.w != pj.w)) {
             // soft-core (alchemy.py:1383-1388 with softcore_c = 6): x = 1/(alpha(1-l)^b + (r/sigma)^6)
             na = true;
@@ -62,10 +73,17 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
         }
         switch_fn(p, r, U, dUdr);
     }
-    float Uc = 0.f, dUc = 0.f;
+    float Uc = 0.f, dUc = 0.f, frc = 0.f;
     if (METHOD != NB_LJ_ONLY) {
         const float qq = pi.x * pj.x;
-        if (METHOD == NB_EWALD || METHOD == NB_EWALD_NOLJ) {
+        if ((METHOD == NB_EWALD || METHOD == NB_EWALD_NOLJ) && TABLE) {
+            // coulomb_table.h: key = exponent and leading mantissa bits of r^2, cubic in the remaining mantissa bits;
+            // the table holds -G, so that frc = dUc/dr / r
+            const unsigned int bits = __float_as_uint(r2);
+            const float tf = (float)(bits & CTAB_MASK);
+            const float4 c = ctab[bits >> CTAB_SHIFT];      // (ctab is biased by the first bin's key: one shift-add per address)
+            frc = qq * fmaf(tf, fmaf(tf, fmaf(tf, c.w, c.z), c.y), c.x);
+        } else if (METHOD == NB_EWALD || METHOD == NB_EWALD_NOLJ) {
             const float ar = p.alpha * r;
             const float ex = __expf(-ar * ar);
             float erfc_ar;
@@ -84,7 +102,8 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
         }
     }
     // (x + 0.f cannot be folded without nsz: name the sum the variant has)
-    fr = (METHOD == NB_LJ_ONLY ? dUdr : METHOD > NB_EWALD ? dUc : dUdr + dUc) * inv_r;
+    if (TABLE && (METHOD == NB_EWALD || METHOD == NB_EWALD_NOLJ)) fr = (METHOD == NB_EWALD_NOLJ) ? frc : dUdr * inv_r + frc;
+    else fr = (METHOD == NB_LJ_ONLY ? dUdr : METHOD > NB_EWALD ? dUc : dUdr + dUc) * inv_r;
     e_out = ((ALCH && na && energy_skip_na) ? 0.f : U) + Uc;
     return e_out;
 }

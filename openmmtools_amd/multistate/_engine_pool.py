@@ -46,6 +46,7 @@ class EnginePool:
         for g, idx in enumerate(self._groups):
             for l, k in enumerate(idx):
                 self._group_of_state[k], self._local_index[k] = g, l
+        self.ewald_split = getattr(first_engine, 'ewald_split', None)
         self._energy = [first_engine] + [self._spawn() for _ in range(self.G - 1)]     # all local replicas, u_kl columns
         self._prop = [None] * self.G                                                   # made when a group first holds a replica
         self._setup = []                                                               # calls replayed on a late propagation handle

@@ -612,6 +612,7 @@ class MultiStateSampler:
         all_states = list(self._thermodynamic_states) + list(self._unsampled_states)
         ref = all_states[0]
         box0 = self._sampler_states[0].box_edges if ref.is_periodic else None
+        split = getattr(self._engine, 'ewald_split', None)        # the engine's preferred split of the Ewald sum (PME systems)
         # states.py:186-217: states of one standard System share a handle; several Systems => one handle per group behind the
         # same interface (_engine_pool.py), as the reference keeps one Context per compatible group (multistatesampler.py:1470-1490)
         from ..states import group_by_compatibility
@@ -622,9 +623,9 @@ class MultiStateSampler:
             from ._engine_pool import EnginePool
             if not isinstance(self._engine, EnginePool):
                 self._engine = EnginePool(self._engine, group_indices)
-            desc = [system_to_desc(g[0].system, box=box0) for g in groups]
+            desc = [system_to_desc(g[0].system, box=box0, ewald_split=split) for g in groups]
         else:
-            desc = system_to_desc(ref.system, box=box0)
+            desc = system_to_desc(ref.system, box=box0, ewald_split=split)
         eng = self._engine
         eng.set_system(desc)
         beta = np.array([s.beta for s in all_states])

@@ -301,6 +301,34 @@ def ewald_parameters(cutoff, tolerance, box):
     return alpha, grid
 
 
+def rebalanced_coulomb_cutoff(cutoff, tolerance, box, max_extension=1.25):
+    """Range of the Ewald direct-space sum that the device engine prefers for this box (``ewald_split='auto'``), or ``cutoff``.
+
+    The Ewald sum does not depend on where it is split; OpenMM ties the split to the NonbondedForce cutoff
+    (alpha = sqrt(-ln 2 tol) / r_c, the rule quoted at alchemy.py:1528-1532), which for AlanineDipeptideExplicit means a
+    75 x 75 x 72 mesh.  On the MI355X the mesh chain (spread -> planes -> gather) is the critical path of an MD step and the
+    plane pass quantises badly: an nx x ny plane of complex f32 must fit the LDS several times per CU, and power-of-two lines
+    need a third fewer butterfly stages.  So the Coulomb range is stretched, by at most ``max_extension``, to the shortest
+    range >= cutoff for which the SAME tolerance rule asks for a mesh whose largest edge is one of the plane-friendly sizes
+    below; Lennard-Jones terms keep ``cutoff``.  Measured on 24 x alanine dipeptide: profiles/r04_ewald_split_sweep.txt.
+    """
+    friendly = (32, 40, 48, 64, 80, 96, 128)
+    root = math.sqrt(-math.log(2.0 * tolerance))
+    lmax = max(float(L) for L in box)
+    lmin = min(float(L) for L in box)
+    n_ref = max(ewald_parameters(cutoff, tolerance, box)[1])
+    best = cutoff
+    for n in friendly:
+        if n >= n_ref:
+            break
+        # largest alpha whose rule mesh is <= n on the longest edge, a hair inside the ceil()
+        alpha = (n - 1e-6) * 3.0 * tolerance ** 0.2 / (2.0 * lmax)
+        rcc = root / alpha
+        if cutoff < rcc <= max_extension * cutoff and 2.0 * rcc < lmin:
+            best = rcc
+    return best
+
+
 def _classify_constraints(system):
     """Split distance constraints into rigid 3-site waters (SETTLE) and X-H star clusters (SHAKE)."""
     n = system.getNumParticles()
@@ -345,8 +373,13 @@ def _classify_constraints(system):
     return settle, shake, shake_d
 
 
-def system_to_desc(system, box=None):
-    """Flatten a System into the arrays of remd_system_desc (include/remd_hip.h)."""
+def system_to_desc(system, box=None, ewald_split=None):
+    """Flatten a System into the arrays of remd_system_desc (include/remd_hip.h).
+
+    ewald_split: None / 'reference' = OpenMM's rule (alpha and mesh from the NonbondedForce cutoff); 'auto' = the Coulomb range
+    of ``rebalanced_coulomb_cutoff``; a number = that Coulomb range in nm.  With a range beyond the cutoff the descriptor
+    carries ``coulomb_cutoff`` (-> remd_set_coulomb_cutoff) and the alpha / mesh that the same tolerance rule gives for it.
+    """
     n = system.getNumParticles()
     d = dict(n_atoms=n, mass=np.array(system.masses, dtype=np.float64))
     d.update(n_ext=0, ext_atoms=np.zeros(0, np.int32), ext_K=0.0, ext_x0=0.0, ext_U0=0.0)
@@ -425,9 +458,19 @@ def system_to_desc(system, box=None):
                 d['ewald_alpha'] = nb._pme_params[0]
                 d['pme_grid'] = np.array(nb._pme_params[1:], dtype=np.int32)
             else:
-                alpha, grid = ewald_parameters(d['cutoff'], nb.getEwaldErrorTolerance(), box)
+                tol = nb.getEwaldErrorTolerance()
+                rcc = d['cutoff']
+                if ewald_split == 'auto':
+                    rcc = rebalanced_coulomb_cutoff(d['cutoff'], tol, box)
+                elif ewald_split not in (None, 'reference'):
+                    rcc = float(ewald_split)
+                    if rcc < d['cutoff']:
+                        raise ValueError('ewald_split: the Coulomb range cannot be shorter than the nonbonded cutoff')
+                alpha, grid = ewald_parameters(rcc, tol, box)
                 d['ewald_alpha'] = alpha
                 d['pme_grid'] = np.array(grid, dtype=np.int32)
+                if rcc > d['cutoff']:
+                    d['coulomb_cutoff'] = rcc
     settle, shake, shake_d = _classify_constraints(system)
     d['settle_atoms'] = np.array([s[:3] for s in settle], dtype=np.int32).reshape(-1, 3)
     d['settle_dOH'] = settle[0][3] if settle else 0.0

@@ -182,6 +182,7 @@ struct System {
     std::vector<int> bond_atoms, angle_atoms, torsion_atoms, exc_atoms;
     std::vector<double> bond_params, angle_params, torsion_params, exc_params;
     int method = 0; double rc = 0, rs = -1, rf_eps = 78.3, alpha = 0; int grid[3] = {0, 0, 0}; int use_disp = 0;
+    double rcc = 0;       // range of the Ewald direct-space sum (remd_set_coulomb_cutoff); = rc unless the host split the sum elsewhere
     std::vector<double> q, sig, eps;
     std::vector<char> alch;
     bool has_charge = false, has_alch = false;
@@ -277,7 +278,7 @@ inline double min_image(double d, double L) { return d - L * nearbyint(d / L); }
 void build_list(const System& s, Replica& r)
 {
     const int N = s.N;
-    const double rl = s.rc + SKIN, rl2 = rl * rl;
+    const double rl = std::max(s.rc, s.rcc) + SKIN, rl2 = rl * rl;
     r.pair_i.clear(); r.pair_j.clear();
     r.x_list = r.x; for (int k = 0; k < 3; ++k) r.box_list[k] = r.box[k];
     int nc[3]; double cs[3];
@@ -547,7 +548,7 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
         double tt0 = g_time ? now_ms() : 0;
         ensure_list(s, r);
         if (g_time) { const double t1 = now_ms(); g_timers.list += t1 - tt0; tt0 = t1; }
-        const double rc2 = s.rc * s.rc;
+        const double rc2 = s.rc * s.rc, rcc2 = std::max(s.rc, s.rcc) * std::max(s.rc, s.rcc);
         const double krf = (s.rf_eps - 1.0) / (2.0 * s.rf_eps + 1.0) / (s.rc * s.rc * s.rc), crf = 3.0 * s.rf_eps / (2.0 * s.rf_eps + 1.0) / s.rc;
         const double two_a_sqrtpi = 2.0 * s.alpha / sqrt(PI);
         const bool sw = s.rs >= 0 && s.rs < s.rc;
@@ -558,10 +559,10 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
             const int i = r.pair_i[p], j = r.pair_j[p];
             double d[3]; delta(i, j, d);
             const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            if (r2 >= rc2) continue;
+            if (r2 >= rcc2) continue;
             const double rr = sqrt(r2);
             double fr = 0.0;                                       // -dE/dr / r  (force on j = fr * d)
-            const double ep = sqrt(s.eps[i] * s.eps[j]);
+            const double ep = (r2 < rc2) ? sqrt(s.eps[i] * s.eps[j]) : 0.0;      // Lennard-Jones stops at the NonbondedForce cutoff
             const bool na = s.has_alch && (s.alch[i] != s.alch[j]);
             if (ep != 0.0 && ((na && (parts & PART_SOFTCORE)) || (!na && (parts & PART_STERICS)))) {
                 const double sg = 0.5 * (s.sig[i] + s.sig[j]);
@@ -768,6 +769,7 @@ struct remd_ctx {
     std::vector<double> pressure; int baro_frequency = 0; long long baro_steps = 0, baro_attempts = 0;
     std::vector<char> tokens; int nV = 0, nR = 0, nO = 0;
     double dt = 0, gamma = 0; int n_steps = 0, reassign = 0, n_restart_attempts = 0;
+    double coulomb_cutoff = 0;
     int measure_heat = 0, measure_shadow = 0;
     int R = 0, R_global = 0, r_begin = 0;
     std::vector<Replica> reps;
@@ -1136,6 +1138,11 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
     s.angle_atoms.assign(d->angle_atoms, d->angle_atoms + 3 * (size_t)d->n_angles); s.angle_params.assign(d->angle_params, d->angle_params + 2 * (size_t)d->n_angles);
     s.torsion_atoms.assign(d->torsion_atoms, d->torsion_atoms + 4 * (size_t)d->n_torsions); s.torsion_params.assign(d->torsion_params, d->torsion_params + 3 * (size_t)d->n_torsions);
     s.method = d->nb_method; s.rc = d->cutoff; s.rs = d->switch_distance > 0 ? d->switch_distance : -1.0;
+    s.rcc = s.rc;
+    if (s.method == REMD_NB_PME && h->coulomb_cutoff > 0.0) {
+        if (h->coulomb_cutoff < s.rc) return fail(h, -1, "the Coulomb cutoff of remd_set_coulomb_cutoff is shorter than the NonbondedForce cutoff");
+        s.rcc = h->coulomb_cutoff;
+    }
     s.rf_eps = d->rf_dielectric; s.alpha = d->ewald_alpha; s.use_disp = d->use_dispersion_correction;
     for (int k = 0; k < 3; ++k) s.grid[k] = d->pme_grid[k];
     s.q.assign(N, 0.0); s.sig.assign(N, 1.0); s.eps.assign(N, 0.0); s.alch.assign(N, 0);
@@ -1283,6 +1290,24 @@ int remd_comm_all_gather_energies(remd_handle h)
 }
 int remd_comm_finalize(remd_handle) { return 0; }
 
+int remd_test_coulomb_table(double alpha, double coulomb_cutoff_nm, int n, const float* u, float* minus_G)
+{
+    // the closed form the device's table interpolates (include/remd_hip.h), f64
+    if (!(alpha > 0) || !(coulomb_cutoff_nm > 0) || n < 0 || !u || !minus_G) return fail(nullptr, -1, "remd_test_coulomb_table: bad arguments");
+    for (int k = 0; k < n; ++k) {
+        const double uu = u[k], r = sqrt(uu);
+        minus_G[k] = (float)(-(erfc(alpha * r) / r + 2.0 * alpha / sqrt(PI) * exp(-alpha * alpha * uu)) / uu);
+    }
+    return 0;
+}
+
+int remd_set_coulomb_cutoff(remd_handle h, double coulomb_cutoff_nm)
+{
+    if (!h || !(coulomb_cutoff_nm >= 0.0)) return fail(h, -1, "remd_set_coulomb_cutoff: bad arguments");
+    h->coulomb_cutoff = coulomb_cutoff_nm;        // consumed by the next remd_set_system (include/remd_hip.h)
+    return 0;
+}
+
 int remd_set_restart_attempts(remd_handle h, int n)
 {
     if (!h || n < 0) return fail(h, -1, "remd_set_restart_attempts: bad arguments");
@@ -1367,7 +1392,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         rep.f.assign(3 * (size_t)N, 0.0);
         for (int k = 0; k < 3; ++k) rep.box[k] = box ? box[3 * r + k] : 0.0;
         if (h->sys.method && !(rep.box[0] > 0 && rep.box[1] > 0 && rep.box[2] > 0)) return fail(h, -1, "remd_set_replicas: periodic system needs a box");
-        if (h->sys.method) for (int k = 0; k < 3; ++k) if (rep.box[k] < 2.0 * h->sys.rc) return fail(h, -1, "remd_set_replicas: box smaller than twice the cutoff");
+        if (h->sys.method) for (int k = 0; k < 3; ++k) if (rep.box[k] < 2.0 * std::max(h->sys.rc, h->sys.rcc)) return fail(h, -1, "remd_set_replicas: box smaller than twice the cutoff");
     }
     h->ukl.assign((size_t)R_global * std::max(0, h->K), 0.0);
     h->potential.assign(R_local, 0.0);

@@ -111,6 +111,8 @@ class ForceFieldOracle(OracleSystem):
         self.exc_params = np.asarray(d['exception_params'], dtype=np.float64).reshape(-1, 3)
         self.method = int(d['nb_method'])
         self.rc = float(d['cutoff'])
+        # Ewald split (include/remd_hip.h remd_set_coulomb_cutoff): the erfc sum may run beyond the Lennard-Jones cutoff
+        self.rcc = max(self.rc, float(d.get('coulomb_cutoff', 0.0))) if int(d['nb_method']) == 2 else self.rc
         self.rs = float(d['switch_distance']) if d['switch_distance'] > 0 else None
         self.alpha = float(d['ewald_alpha'])
         self.grid = [int(g) for g in d['pme_grid']]
@@ -126,7 +128,7 @@ class ForceFieldOracle(OracleSystem):
         xw = np.mod(x, box)
         xw = np.where(xw >= box, 0.0, xw)
         tree = cKDTree(xw, boxsize=box)
-        pairs = tree.query_pairs(self.rc, output_type='ndarray')
+        pairs = tree.query_pairs(self.rcc, output_type='ndarray')
         if len(self.excluded):
             key = pairs[:, 0].astype(np.int64) * self.N + pairs[:, 1]
             ex = np.array([a * self.N + b for a, b in self.excluded], dtype=np.int64)
@@ -181,6 +183,8 @@ class ForceFieldOracle(OracleSystem):
         xsc = (sig / reff) ** 6
         sc = (lam_s ** a) * 4.0 * eps * xsc * (xsc - 1.0)
         S = self._switch(r)
+        if self.rcc > self.rc:                       # pairs of the Coulomb-only shell carry no Lennard-Jones term
+            S = torch.where(r < self.rc, S, torch.zeros_like(S))
         if only_na:
             return (torch.where(na, sc, torch.zeros_like(sc)) * S).sum()
         sterics = torch.where(na, sc if include_na else torch.zeros_like(sc), lj) * S

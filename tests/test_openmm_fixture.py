@@ -171,3 +171,80 @@ def test_hip_engine_from_amber_files_reproduces_openmm_too(hip_engine_factory, f
     own = dict(fixture, desc=system_to_desc(ts.AlanineDipeptideExplicit().system))
     rows, u_openmm = _engine_rows(eng, own)
     assert np.abs(rows / u_openmm - 1.0).max() < 1e-5
+
+
+# ---- the Ewald sum split elsewhere (remd_set_coulomb_cutoff): still OpenMM's numbers ------------------------------------------
+# The engine may sum the erfc tail beyond the NonbondedForce cutoff and use the smaller mesh the same tolerance rule then asks
+# for (system.system_to_desc(ewald_split=...), include/remd_hip.h); Lennard-Jones terms keep the 1.0 nm cutoff and the switch.
+# 'auto' is what HipEngine asks for on this system (Coulomb range 1.126 nm, alpha 2.921 / nm, 64 x 64 x 64 instead of
+# 75 x 75 x 72); 1.21 nm gives 60 x 60 x 60.
+SPLITS = ['auto', 1.21]
+
+
+def _split_fixture(fixture, split):
+    d = system_to_desc(fixture['system'], ewald_split=split)
+    assert d['coulomb_cutoff'] > d['cutoff'] == 1.0 and max(d['pme_grid']) < 75
+    return dict(fixture, desc=d)
+
+
+def test_auto_split_of_the_headline_system_is_the_64_mesh(fixture):
+    d = system_to_desc(fixture['system'], ewald_split='auto')
+    assert list(d['pme_grid']) == [64, 64, 64]
+    assert d['coulomb_cutoff'] == pytest.approx(1.126, abs=1e-3)
+    assert d['ewald_alpha'] * d['coulomb_cutoff'] == pytest.approx(fixture['desc']['ewald_alpha'] * 1.0, rel=1e-12)   # same tolerance
+    ref = system_to_desc(fixture['system'], ewald_split='reference')
+    assert 'coulomb_cutoff' not in ref and list(ref['pme_grid']) == [75, 75, 72]
+
+
+@pytest.mark.parametrize('split', SPLITS)
+def test_oracle_reproduces_openmm_at_another_ewald_split(fixture, split):
+    x, box, beta, u_openmm = _frames(fixture)
+    ff = ForceFieldOracle(_split_fixture(fixture, split)['desc'])
+    worst = 0.0
+    for it in range(3):
+        u = ff.potential(x[it], box[it]) * beta
+        worst = max(worst, np.abs(u / u_openmm[it] - 1.0).max())
+    assert worst < 5e-6, worst
+
+
+@pytest.mark.parametrize('split', SPLITS)
+def test_cpu_library_reproduces_openmm_at_another_ewald_split(fixture, split):
+    if not os.path.exists(CPU_LIB):
+        oracle.build()
+    eng = HipEngine(lib_path=CPU_LIB)
+    try:
+        rows, u_openmm = _engine_rows(eng, _split_fixture(fixture, split))
+    finally:
+        eng.close()
+    assert np.abs(rows / u_openmm - 1.0).max() < 5e-6, np.abs(rows / u_openmm - 1.0).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('split', SPLITS)
+def test_hip_engine_reproduces_openmm_at_another_ewald_split(hip_engine_factory, fixture, split):
+    """The 1e-5 contract against OpenMM's u_kl with the mesh chain given less work."""
+    eng = hip_engine_factory()
+    rows, u_openmm = _engine_rows(eng, _split_fixture(fixture, split))
+    err = np.abs(rows / u_openmm - 1.0).max()
+    assert err < 1e-5, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('split', SPLITS)
+def test_hip_forces_at_another_ewald_split_match_the_reference_split(hip_engine_factory, fixture, split):
+    """Forces of the rebalanced split against the f64 oracle AT THE REFERENCE SPLIT (75 x 75 x 72): RMSE far inside the
+    reference's cross-platform bar of 0.06 kcal/mol/A = 25.1 kJ/mol/nm (scripts/test_openmm_platforms.py:154-155), and
+    no worse than the device's own reference-split forces by more than the Ewald tolerance allows."""
+    x, box, beta, _ = _frames(fixture)
+    ff = ForceFieldOracle(fixture['desc'])
+    f_ref = ff.energy_forces(x[0], box[0])[1]
+    out = {}
+    for name, fx in (('reference', fixture), ('split', _split_fixture(fixture, split))):
+        eng = hip_engine_factory()
+        _engine_rows(eng, fx)
+        out[name] = eng.get_forces()[0]
+    scale = np.sqrt((f_ref ** 2).sum(axis=1).mean())
+    rmse = {k: np.sqrt(((v - f_ref) ** 2).sum(axis=1).mean()) for k, v in out.items()}
+    assert rmse['split'] < 0.02 * 25.1, rmse                     # kJ/mol/nm: 2 % of the reference's bar
+    assert rmse['split'] / scale < 2e-4, (rmse, scale)           # and small against the forces themselves (~1e3 kJ/mol/nm)
+    assert rmse['split'] < 3.0 * rmse['reference'] + 0.05, rmse
