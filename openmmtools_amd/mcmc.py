@@ -22,7 +22,11 @@ class MCMCMove:
         import numpy as np
         if engine is None and context_cache is not None and hasattr(context_cache, 'make_engine'):
             engine = context_cache.make_engine()
-        key = (id(thermodynamic_state), id(engine) if engine is not None else None, sampler_state.n_particles)
+        # the reference rebuilds the integrator and re-applies the state on every apply (mcmc.py:692-700): a state or a move
+        # mutated between two calls (temperature, pressure, lambda, n_steps, timestep ...) must not meet a stale driver, so
+        # their parameters are part of the key and a mismatch builds a new one
+        key = (id(thermodynamic_state), id(engine) if engine is not None else None, sampler_state.n_particles,
+               _parameter_fingerprint(thermodynamic_state), _parameter_fingerprint(self))
         held = self.__dict__.get('_apply_driver')
         if held is None or held[0] != key:
             driver = MCMCSampler(thermodynamic_state, sampler_state, self, engine=engine)
@@ -52,13 +56,36 @@ class MCMCMove:
         self.__dict__.update(state)
 
 
+def _parameter_fingerprint(obj, _depth=0):
+    """Hashable digest of the parameters an engine was programmed with (numbers, strings, flags; nested moves / composable
+    states followed; systems by their content hash; statistics and caches skipped)."""
+    if _depth > 4:
+        return None
+    if isinstance(obj, (int, float, str, bool, type(None))):
+        return obj
+    if isinstance(obj, np.ndarray):
+        return ('nd', obj.shape, obj.tobytes() if obj.size <= 64 else hash(obj.tobytes()))
+    if isinstance(obj, (list, tuple)):
+        return tuple(_parameter_fingerprint(o, _depth + 1) for o in obj)
+    if hasattr(obj, 'fingerprint') and callable(obj.fingerprint):            # System
+        return ('system', id(obj), obj.getNumParticles() if hasattr(obj, 'getNumParticles') else 0)
+    d = getattr(obj, '__dict__', None)
+    if d is None:
+        return repr(obj)
+    skip = ('_apply_driver', 'statistics', 'n_accepted', 'n_proposed', 'n_attempted', '_standard_system_hash')
+    return (type(obj).__name__,) + tuple((k, _parameter_fingerprint(v, _depth + 1)) for k, v in sorted(d.items())
+                                         if k not in skip and not k.startswith('_cache'))
+
+
 class MCMCSampler:
     """mcmc.py:216-347: one thermodynamic state, one configuration, one move applied ``n_iterations`` times.  The reference calls
     ``move.apply`` in a loop; here the same engine that propagates the replicas of a multistate sampler runs it as a
     one-replica, one-state ensemble (no mixing, nothing stored), so every move the engine knows is available unchanged."""
 
-    def __init__(self, thermodynamic_state, sampler_state, move, engine=None, seed=0xC0FFEE):
+    def __init__(self, thermodynamic_state, sampler_state, move, engine=None, seed=None):
         import copy
+        if seed is None:              # independent runs draw independent noise, like the reference's global streams (ADVICE r3)
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) << 16 | int(np.random.randint(0, 2 ** 16))
         self.thermodynamic_state = copy.deepcopy(thermodynamic_state)       # :247-249
         self.sampler_state = copy.deepcopy(sampler_state)
         self.move = move

@@ -148,6 +148,17 @@ class ThermodynamicState:
     lambda_sterics = 1.0
     lambda_electrostatics = 1.0
 
+    def __setstate__(self, state):
+        """States pickled before ``pressure`` / ``temperature`` became properties (storage format 'openmmtools_amd-records-1'
+        of earlier revisions) carry the plain attribute names: map them onto the backing fields so that old stores resume."""
+        state = dict(state)
+        for old, new in (('pressure', '_pressure'), ('temperature', '_temperature'), ('system', '_system')):
+            if old in state and new not in state:
+                state[new] = state.pop(old)
+        state.setdefault('_pressure', None)
+        state.setdefault('barostat_frequency', 25)
+        self.__dict__.update(state)
+
     @staticmethod
     def _compute_reduced_potential(potential_energy, temperature, volume=None, pressure=None):
         """states.py:1908-1917: u = beta (U + p V); energies per mole, so N_A is already folded in."""

@@ -430,3 +430,33 @@ def test_propagate_replicas_and_compute_energies_do_not_mix_up_replicas():
         row = states.reduced_potential_at_states(new[r], thermo + unsampled, engine=OracleEngine(system_factory=ForceFieldOracle))
         assert np.allclose(s._energy_thermodynamic_states[r], row[:3], rtol=1e-10)
         assert np.allclose(s._energy_unsampled_states[r], row[3:], rtol=1e-10)
+
+
+def test_apply_sees_a_state_or_move_mutated_between_calls():
+    """``apply`` caches its one-replica driver; the reference rebuilds the integrator and re-applies the state on
+    every call (mcmc.py:692-700), so a temperature or n_steps changed between two calls must reach the engine."""
+    ho = testsystems.HarmonicOscillator()
+    thermo = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinDynamicsMove(n_steps=2, timestep=1.0 * unit.femtosecond)
+    engine = OracleEngine()
+    move.apply(thermo, ss, engine=engine)
+    assert engine.beta[0] == pytest.approx(thermo.beta) and engine.integ_args[3] == 2
+    thermo.temperature = 600.0 * unit.kelvin
+    move.n_steps = 5
+    move.apply(thermo, ss, engine=engine)
+    assert engine.beta[0] == pytest.approx(1.0 / (kB * 600.0)) and engine.integ_args[3] == 5
+    first = move.__dict__['_apply_driver'][1]
+    move.apply(thermo, ss, engine=engine)                      # nothing changed: the cached driver is kept
+    assert move.__dict__['_apply_driver'][1] is first
+
+
+def test_thermodynamic_state_pickled_before_pressure_was_a_property_still_loads():
+    """stores of earlier revisions carry 'pressure' / 'temperature' as plain attributes."""
+    lj = testsystems.LennardJonesFluid(nparticles=64)
+    t = states.ThermodynamicState(lj.system, 120.0 * unit.kelvin, pressure=1.0 * unit.bar)
+    legacy = dict(t.__dict__)
+    legacy['pressure'] = legacy.pop('_pressure')
+    old = states.ThermodynamicState.__new__(states.ThermodynamicState)
+    old.__setstate__(legacy)
+    assert old.pressure == t.pressure and old.barostat is not None and old.temperature == 120.0
