@@ -41,7 +41,6 @@ SEED = 0xC0FFEE
 FLOP_PER_ATOM_NONBONDED = 1.0e4
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector peak = f32-input MFMA peak
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PME_MESH = (75, 75, 72)           # AlanineDipeptideExplicit at ewaldErrorTolerance 1e-5 (system.ewald_parameters)
 
 
 def pmc_traffic_bytes(kernel):
@@ -168,6 +167,14 @@ def main():
         raise SystemExit('--replicas-total must be at least the number of ranks')
     sampler, ts = build_sampler(n_replicas, engine, comm, args.md_steps)
     n_local = sampler._r_count                  # replicas on this rank (block partition, comm.py)
+    # the Ewald split the engine runs (HipEngine.ewald_split -> system.system_to_desc): Coulomb range, alpha, mesh
+    from openmmtools_amd.system import system_to_desc
+    _d = system_to_desc(ts.system, ewald_split=engine.ewald_split)
+    ewald = dict(split=str(engine.ewald_split), lj_cutoff_nm=float(_d['cutoff']), coulomb_cutoff_nm=float(_d.get('coulomb_cutoff', _d['cutoff'])),
+                 alpha_per_nm=float(_d['ewald_alpha']), pme_grid=[int(g) for g in _d['pme_grid']], ewald_error_tolerance=1e-5,
+                 note="'auto': the direct-space erfc sum runs beyond the 1.0 nm Lennard-Jones cutoff and the mesh shrinks by the same "
+                      "tolerance rule (reference split: alpha 3.289 / nm, 75 x 75 x 72); u_kl parity against OpenMM's own numbers at this "
+                      "split: tests/test_openmm_fixture.py")
     n_atoms = ts.system.getNumParticles()
 
     def sync():
@@ -217,7 +224,7 @@ def main():
         if n_xy > 0:
             # algorithmic bytes (SURVEY 8(d) "grid traffic 8 B x G per pass"): the half spectrum [nz/2+1][nx][ny] complex f32 of
             # every replica is read once and written once by the plane-resident XY pass
-            nx, ny, nz = PME_MESH
+            nx, ny, nz = ewald['pme_grid']
             nbytes = 2.0 * 8.0 * (nz // 2 + 1) * nx * ny * n_local
             avg_ms = ms_xy / n_xy
             achieved = nbytes / (avg_ms * 1e-3) / 1e9
@@ -271,7 +278,7 @@ def main():
                                         % args.md_steps,
                                replicas_per_gpu=(n_replicas / float(world)), replicas_total=n_replicas, md_steps=args.md_steps,
                                mode=('strong: one %d-replica ensemble' % n_replicas) if strong else 'weak: 24 replicas per GPU',
-                               parallelism='replica-sharded x%d' % world, seed=SEED),
+                               parallelism='replica-sharded x%d' % world, seed=SEED, ewald=ewald),
                    timing=timing_of_timed_region, roofline=roof, roofline_secondary=roof2, roofline_integrator=roof_ch)
         try:
             # achievable roofs of THIS box (STREAM triad past the Infinity Cache, FMA chains), SURVEY 8(d)

@@ -52,8 +52,10 @@ EXPORTS = [
 
 _lib = None
 
-# the split of the Ewald sum a HipEngine asks the host classes for when nothing else is said (see HipEngine.__init__)
-DEFAULT_EWALD_SPLIT = os.environ.get('REMD_EWALD_SPLIT', 'reference')
+# the split of the Ewald sum a HipEngine on the device asks the host classes for when nothing else is said (HipEngine.__init__):
+# 'auto' = system.rebalanced_coulomb_cutoff.  Measured on the three PME systems of BASELINE.json (profiles/r04_a_ewald_split_sweep.txt,
+# ms per 500 MD steps, reference -> auto): 24 x alanine dipeptide 104.5 -> 95.0, 8 x host-guest 99.7 -> 91.4, 16 x DHFR 836 -> 790.
+DEFAULT_EWALD_SPLIT = os.environ.get('REMD_EWALD_SPLIT', 'auto')
 
 
 def load_library(path=None):
@@ -181,10 +183,14 @@ class HipEngine:
 
     is_device = True
 
-    def __init__(self, device=0, stream=None, lib_path=None, ewald_split=DEFAULT_EWALD_SPLIT):
+    def __init__(self, device=0, stream=None, lib_path=None, ewald_split=None):
         """ewald_split: how the host classes split the Ewald sum of a PME System for this engine (system.system_to_desc):
         'reference' = OpenMM's rule on the NonbondedForce cutoff, 'auto' = a longer Coulomb range that buys a plane-friendly
-        mesh (system.rebalanced_coulomb_cutoff), or a Coulomb range in nm.  Potentials agree to the Ewald tolerance either way."""
+        mesh (system.rebalanced_coulomb_cutoff), or a Coulomb range in nm.  Potentials agree to the Ewald tolerance either way.
+        None: DEFAULT_EWALD_SPLIT on the device library; 'reference' for another build of the ABI (lib_path: the CPU baseline keeps
+        the reference's own split)."""
+        if ewald_split is None:
+            ewald_split = DEFAULT_EWALD_SPLIT if lib_path is None else 'reference'
         self.ewald_split = ewald_split
         self.lib = load_library(lib_path)
         self.h = C.c_void_p()

@@ -11,6 +11,7 @@ System into the arrays behind ``remd_system_desc`` (include/remd_hip.h).  A real
 """
 import hashlib
 import math
+import os
 import numpy as np
 
 
@@ -380,6 +381,8 @@ def system_to_desc(system, box=None, ewald_split=None):
     of ``rebalanced_coulomb_cutoff``; a number = that Coulomb range in nm.  With a range beyond the cutoff the descriptor
     carries ``coulomb_cutoff`` (-> remd_set_coulomb_cutoff) and the alpha / mesh that the same tolerance rule gives for it.
     """
+    if ewald_split is None:
+        ewald_split = os.environ.get('REMD_TOOLS_EWALD_SPLIT')        # diagnostic tools only (tools/*.py build descriptors directly)
     n = system.getNumParticles()
     d = dict(n_atoms=n, mass=np.array(system.masses, dtype=np.float64))
     d.update(n_ext=0, ext_atoms=np.zeros(0, np.int32), ext_K=0.0, ext_x0=0.0, ext_U0=0.0)
