@@ -11,6 +11,7 @@ int remd_check_finite(remd_ctx* h);
 int remd_assemble_ukl(remd_ctx* h, double* d_rows);
 int remd_nb_required_epart(remd_ctx* h);
 void remd_free_nonbonded(remd_ctx* h);
+void remd_mix_release(remd_ctx* h);          // mix.hip
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
 void remd_nb_tune_resolve(remd_ctx* h);
 static int remd_check_device_flags(remd_ctx* h, const char* where, bool may_retry = false);
@@ -120,6 +121,7 @@ int remd_destroy(remd_handle h)
     remd_pme_destroy(h);
     remd_free_constraints(h);
     remd_free_nonbonded(h);
+    remd_mix_release(h);
     dfree(h->d_invmass); dfree(h->d_mass); dfree(h->d_ext_atoms);
     dfree(h->d_bond_atoms); dfree(h->d_bond_params); dfree(h->d_angle_atoms); dfree(h->d_angle_params);
     dfree(h->d_torsion_atoms); dfree(h->d_torsion_params);

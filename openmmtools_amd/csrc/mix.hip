@@ -317,6 +317,193 @@ void mix_swap_all_dataflow_kernel(uint64_t seed, int64_t iteration, int R, int K
         for (int t = tid; t < K * K; t += W) { g_nprop[t] = s_nprop[t]; g_nacc[t] = s_nacc[t]; }
 }
 
+// ---- swap-all, label-independent part hoisted (round 4) ---------------------------------------------------------------
+// Everything a window of attempts needs except the labels is a function of (seed, iteration, attempt index) alone: the
+// Philox draws (i, j, u), the attempts' ordinals in their two slots' chains, where a window has to be cut because a slot
+// would collect more than MIX_CHAIN attempts, and how many attempts each slot sees.  mix_prep_kernel computes that for
+// ALL windows at once on the whole chip (one workgroup per window of W attempts) and leaves one 16-byte record per
+// attempt; the serial workgroup (mix_swap_all_pre_kernel) is left with what really is sequential: building the chain
+// table of a window from the records (two LDS stores per attempt), the speculative sweeps, and the label update.
+// Acceptance is decided by log_p - log u away from the borderline, exactly as the dataflow kernel does (the uniform is
+// regenerated from its Philox counter for the rare borderline attempt), and every attempt's (s_i, s_j, accepted) goes to
+// the attempt log from which mix_stats_from_log_kernel builds the count matrices on the whole chip.
+// A window of W attempts is processed as 1 ... MIXP pieces (cut where a slot's chain is full; more than one piece per
+// window is rare: P(Poisson(12) >= 32) ~ 1e-6 per slot and window); a window that would need more than MIXP pieces raises
+// g_err and the host runs the one-kernel path instead.
+#define MIXP 4
+struct mix_rec { unsigned ij, ords, lu_lo, lu_hi; };       // i | j << 16 ; ord_i | ord_j << 8 ; log(u) as two words
+
+__global__ __launch_bounds__(1024)
+void mix_prep_kernel(uint64_t seed, int64_t iteration, int R, int64_t n_attempts, uint4* __restrict__ g_rec,
+                     unsigned* __restrict__ g_piece /*[n_win][MIXP]: start | len << 16*/, unsigned* __restrict__ g_npiece,
+                     unsigned char* __restrict__ g_cnt /*[n_win][MIXP][Rpad]*/, int Rpad, unsigned* __restrict__ g_err)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, W = blockDim.x, nw = W >> 6;
+    unsigned long long* s_touch = reinterpret_cast<unsigned long long*>(smem);      // [R][nw]
+    __shared__ int s_cut;
+    const int64_t win = blockIdx.x;
+    const int64_t k = win * W + tid;
+    const bool active = k < n_attempts;
+    const int n_in = (int)min((int64_t)W, n_attempts - win * W);
+    philox4 w = remd_philox(seed, REMD_STREAM_SWAP_ALL, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), (uint64_t)iteration);
+    const int i = (int)remd_mulhi32(w.w[0], (uint32_t)R);     // randint(R), replicaexchange.py:324
+    const int j = (int)remd_mulhi32(w.w[1], (uint32_t)R);     // :325
+    const double lu = log(remd_u53(w.w[2], w.w[3]));           // u = 0: -inf (the serial kernel takes the exact path)
+    int start = 0, np = 0;
+    while (start < n_in) {
+        for (int t = tid; t < R * nw; t += W) s_touch[t] = 0ull;
+        if (tid == 0) s_cut = n_in;
+        __syncthreads();
+        const bool in_piece = active && tid >= start;
+        if (in_piece) {
+            atomicOr(&s_touch[(size_t)i * nw + (tid >> 6)], 1ull << (tid & 63));
+            atomicOr(&s_touch[(size_t)j * nw + (tid >> 6)], 1ull << (tid & 63));
+        }
+        __syncthreads();
+        int ord_i = 0, ord_j = 0;
+        if (in_piece) {
+            const unsigned long long* ti = s_touch + (size_t)i * nw;
+            const unsigned long long* tj = s_touch + (size_t)j * nw;
+            const int wi = tid >> 6;
+            const unsigned long long low = (1ull << (tid & 63)) - 1ull;
+            for (int q = 0; q < wi; ++q) { ord_i += __popcll(ti[q]); ord_j += __popcll(tj[q]); }
+            ord_i += __popcll(ti[wi] & low); ord_j += __popcll(tj[wi] & low);
+            if (ord_i >= MIX_CHAIN || ord_j >= MIX_CHAIN) atomicMin(&s_cut, tid);
+        }
+        __syncthreads();
+        const int cut = s_cut;                   // > start: the first attempt of a piece has ordinal 0 in both chains
+        if (np < MIXP) {
+            if (in_piece && tid < cut)
+                g_rec[k] = make_uint4((unsigned)i | ((unsigned)j << 16), (unsigned)ord_i | ((unsigned)ord_j << 8),
+                                      (unsigned)__double2loint(lu), (unsigned)__double2hiint(lu));
+            // attempts of this piece per slot (= the chain position behind its last one)
+            for (int r = tid; r < R; r += W) {
+                int n = 0;
+                const unsigned long long* tr = s_touch + (size_t)r * nw;
+                const int wc = cut >> 6;
+                for (int q = 0; q < wc; ++q) n += __popcll(tr[q]);
+                if (cut & 63) n += __popcll(tr[wc] & ((1ull << (cut & 63)) - 1ull));
+                g_cnt[((size_t)win * MIXP + np) * Rpad + r] = (unsigned char)n;
+            }
+            if (tid == 0) g_piece[win * MIXP + np] = (unsigned)start | ((unsigned)(cut - start) << 16);
+        } else if (tid == 0) atomicExch(g_err, 1u);
+        ++np;
+        start = cut;
+        __syncthreads();
+    }
+    if (tid == 0) g_npiece[win] = (unsigned)min(np, MIXP);
+}
+
+template <bool UKL_LDS>
+__global__ __launch_bounds__(1024)
+void mix_swap_all_pre_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld, const double* __restrict__ g_ukl,
+                             int64_t* __restrict__ g_labels, int64_t n_attempts, const uint4* __restrict__ g_rec,
+                             const unsigned* __restrict__ g_piece, const unsigned* __restrict__ g_npiece,
+                             const unsigned char* __restrict__ g_cnt, int Rpad_cnt, unsigned int* __restrict__ g_log,
+                             long long* __restrict__ g_dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, W = blockDim.x;
+    long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t0 = clock64(), w0 = wall_clock64();
+    const int Rpad = (R + 1) & ~1;
+    double* s_u = reinterpret_cast<double*>(smem);
+    unsigned* s_chain = reinterpret_cast<unsigned*>(smem + (UKL_LDS ? (size_t)R * K * sizeof(double) : 0));   // [R][32]
+    unsigned* s_accb = s_chain + (size_t)R * MIX_CHAIN;                          // [R]
+    int* s_lab = reinterpret_cast<int*>(s_accb + Rpad);                          // [2][Rpad]
+    int* s_flag = s_lab + 2 * Rpad;                                              // [0..2] rotating "a decision changed" flags
+    if (UKL_LDS)
+        for (int t = tid; t < R * K; t += W) s_u[t] = g_ukl[(size_t)(t / K) * ld + (t % K)];
+    for (int t = tid; t < R; t += W) s_lab[t] = (int)g_labels[t];
+    if (tid < 4) s_flag[tid] = 0;
+    __syncthreads();
+    const int ldu = UKL_LDS ? K : ld;
+    const double* U = UKL_LDS ? s_u : g_ukl;
+    const int64_t n_win = (n_attempts + W - 1) / W;
+    int sweep = 0, cur_lab = 0;
+    MIX_TICK(0);
+    // records of the next window's first piece travel while this window is decided
+    unsigned pc_next = n_win > 0 ? g_piece[0] : 0u, np_next = n_win > 0 ? g_npiece[0] : 0u;
+    uint4 rec_next = make_uint4(0u, 0u, 0u, 0u);
+    if (n_win > 0 && tid < (int)(pc_next >> 16)) rec_next = g_rec[tid];
+    for (int64_t win = 0; win < n_win; ++win) {
+        const unsigned np = np_next;
+        unsigned pc = pc_next;
+        uint4 rec = rec_next;
+        if (win + 1 < n_win) {
+            pc_next = g_piece[(win + 1) * MIXP]; np_next = g_npiece[win + 1];
+            if (tid < (int)(pc_next >> 16)) rec_next = g_rec[(win + 1) * W + tid];
+        }
+        for (unsigned p = 0; p < np; ++p) {
+            if (p > 0) {
+                pc = g_piece[win * MIXP + p];
+                if (tid < (int)(pc >> 16)) rec = g_rec[win * W + (pc & 0xffffu) + tid];
+            }
+            const int len = (int)(pc >> 16);
+            const int64_t k = win * W + (int)(pc & 0xffffu) + tid;
+            const bool live = tid < len;
+            const int i = (int)(rec.x & 0xffffu), j = (int)(rec.x >> 16);
+            const int ord_i = (int)(rec.y & 0xffu), ord_j = (int)((rec.y >> 8) & 0xffu);
+            const double lu = __hiloint2double((int)rec.w, (int)rec.z);
+            const int* lab0 = s_lab + cur_lab * Rpad;
+            int* lab1 = s_lab + (cur_lab ^ 1) * Rpad;
+            for (int r = tid; r < R; r += W) s_accb[r] = 0u;
+            if (live && i != j) {
+                s_chain[i * MIX_CHAIN + ord_i] = (unsigned)j | ((unsigned)ord_j << 16);
+                s_chain[j * MIX_CHAIN + ord_j] = (unsigned)i | ((unsigned)ord_i << 16);
+            }
+            mix_barrier();
+            MIX_TICK(1);
+            bool acc = false;
+            int a_seen = -1, b_seen = -1, si = 0, sj = 0;
+            for (;; ++sweep) {
+                if (live) {
+                    const unsigned ma = s_accb[i] & mix_below(ord_i), mb = s_accb[j] & mix_below(ord_j);
+                    const int a = mix_origin(s_accb, s_chain, i, ma);
+                    const int b = mix_origin(s_accb, s_chain, j, mb);
+                    if (a != a_seen || b != b_seen) {
+                        a_seen = a; b_seen = b;
+                        si = lab0[a]; sj = lab0[b];                                          // :328-329
+                        const double log_p = mix_logp(U, ldu, i, j, si, sj);                 // :332-336
+                        const double d = log_p - lu;
+                        bool nacc;
+                        if (log_p >= 0.0) nacc = true;                                       // :343
+                        else if (!(log_p > -700.0)) nacc = false;                            // remd_exp_det gives 0: u < 0 never holds
+                        else if (d > 1e-9 && d < 1e300) nacc = true;                         // (d = inf: u = 0, exact path)
+                        else if (d < -1e-9) nacc = false;
+                        else {
+                            const philox4 w = remd_philox(seed, REMD_STREAM_SWAP_ALL, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), (uint64_t)iteration);
+                            nacc = remd_u53(w.w[2], w.w[3]) < remd_exp_det(log_p);
+                        }
+                        if (nacc != acc) {
+                            acc = nacc;
+                            if (i != j) {
+                                atomicXor(&s_accb[i], 1u << ord_i); atomicXor(&s_accb[j], 1u << ord_j);
+                                s_flag[sweep % 3] = 1;
+                            }
+                        }
+                    }
+                }
+                if (tid == 0) s_flag[(sweep + 1) % 3] = 0;
+                mix_barrier();
+                dbg[5] += 1;
+                if (!s_flag[sweep % 3]) { ++sweep; break; }
+            }
+            MIX_TICK(2);
+            if (live) g_log[k] = (unsigned)si | ((unsigned)sj << 15) | (acc ? (1u << 30) : 0u) | (1u << 31);
+            const unsigned char* cnt = g_cnt + ((size_t)win * MIXP + p) * Rpad_cnt;
+            for (int r = tid; r < R; r += W)
+                lab1[r] = lab0[mix_origin(s_accb, s_chain, r, s_accb[r] & mix_below((int)cnt[r]))];
+            cur_lab ^= 1;
+            mix_barrier();
+            MIX_TICK(3);
+        }
+    }
+    if (g_dbg && tid == 0) { for (int q = 0; q < 8; ++q) g_dbg[q] = dbg[q]; g_dbg[6] = wall_clock64() - w0; }
+    for (int t = tid; t < R; t += W) g_labels[t] = (int64_t)s_lab[cur_lab * Rpad + t];
+}
+
 // replicaexchange.py:366-380 — neighbouring STATE pairs (s, s+1), s = offset, offset+2, ...
 __global__ __launch_bounds__(256)
 void mix_swap_neighbors_kernel(uint64_t seed, int64_t iteration, int R, int K, int ld,
@@ -417,6 +604,17 @@ void mix_stats_from_log_kernel(int64_t n_attempts, const unsigned int* __restric
     }
 }
 
+// buffers of the hoisted swap-all path, per handle (grow-only)
+struct mix_pre_buffers {
+    uint4* rec = nullptr; size_t rec_n = 0;
+    unsigned* piece = nullptr; unsigned* npiece = nullptr; size_t win_n = 0;
+    unsigned char* cnt = nullptr; size_t cnt_n = 0;
+    unsigned* err = nullptr;
+    ~mix_pre_buffers() { hipFree(rec); hipFree(piece); hipFree(npiece); hipFree(cnt); hipFree(err); }
+};
+static handle_table<mix_pre_buffers> g_mix_pre;
+void remd_mix_release(remd_ctx* h) { g_mix_pre.erase(h); }
+
 int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, int ld, const double* d_ukl,
                     int64_t* d_labels, unsigned long long* d_nacc, unsigned long long* d_nprop,
                     const double* d_logw, double* d_logP, int64_t n_attempts)
@@ -461,13 +659,65 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         // REMD_MIX_FLOW = 0 / 1 pins the kernel (parity tests).
         const char* flow_env = getenv("REMD_MIX_FLOW");
         const int flow = flow_env ? atoi(flow_env) : (h->mix_acc_rate > 0.17 ? 1 : 0);
+        static const bool debug = getenv("REMD_MIX_DEBUG") != nullptr;
+        static long long* d_dbg = nullptr;
+        if (debug && !d_dbg) REMD_CHECK(h, hipMalloc(&d_dbg, 8 * sizeof(long long)));
+        // speculative windows with the label-independent part hoisted into a whole-chip kernel (mix_prep_kernel); REMD_MIX_PRE=0
+        // keeps everything in the one serial workgroup (parity tests run both)
+        const bool pre_off = getenv("REMD_MIX_PRE") && atoi(getenv("REMD_MIX_PRE")) == 0;
+        if (!flow && !pre_off && (size_t)n_attempts * sizeof(unsigned int) <= ((size_t)1 << 30)) {
+            const int W = 64 * waves;
+            const int64_t n_win = (n_attempts + W - 1) / W;
+            const int Rp4 = (R + 3) & ~3;
+            mix_pre_buffers& B = g_mix_pre[h];
+            if (B.rec_n < (size_t)n_win * W) { hipFree(B.rec); B.rec = nullptr; REMD_CHECK(h, hipMalloc(&B.rec, sizeof(uint4) * (size_t)n_win * W)); B.rec_n = (size_t)n_win * W; }
+            if (B.win_n < (size_t)n_win) {
+                hipFree(B.piece); hipFree(B.npiece); B.piece = B.npiece = nullptr;
+                REMD_CHECK(h, hipMalloc(&B.piece, sizeof(unsigned) * (size_t)n_win * MIXP));
+                REMD_CHECK(h, hipMalloc(&B.npiece, sizeof(unsigned) * (size_t)n_win));
+                B.win_n = (size_t)n_win;
+            }
+            if (B.cnt_n < (size_t)n_win * MIXP * Rp4) { hipFree(B.cnt); B.cnt = nullptr; REMD_CHECK(h, hipMalloc(&B.cnt, (size_t)n_win * MIXP * Rp4)); B.cnt_n = (size_t)n_win * MIXP * Rp4; }
+            if (!B.err) REMD_CHECK(h, hipMalloc(&B.err, sizeof(unsigned)));
+            if (h->mix_log_n < (size_t)n_attempts) {
+                if (h->d_mix_log) { hipFree(h->d_mix_log); h->d_mix_log = nullptr; h->mix_log_n = 0; }
+                REMD_CHECK(h, hipMalloc(&h->d_mix_log, sizeof(unsigned int) * (size_t)n_attempts));
+                h->mix_log_n = (size_t)n_attempts;
+            }
+            remd_prof_scope ps(h, "mix_swap_all");
+            REMD_CHECK(h, hipMemsetAsync(B.err, 0, sizeof(unsigned), h->stream));
+            hipLaunchKernelGGL(mix_prep_kernel, dim3((unsigned)n_win), dim3(W), sizeof(unsigned long long) * (size_t)R * waves, h->stream,
+                               h->seed, iteration, R, n_attempts, B.rec, B.piece, B.npiece, B.cnt, Rp4, B.err);
+            unsigned err = 0;
+            REMD_CHECK(h, hipMemcpyAsync(&err, B.err, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+            REMD_CHECK(h, hipStreamSynchronize(h->stream));
+            if (!err) {
+                const size_t pre_work = 4 * (size_t)R * MIX_CHAIN + 4 * Rp + 8 * Rp + 16;
+                const int pre_in_lds = ukl_bytes + pre_work <= 156 * 1024;
+                size_t pre_lds = ((pre_in_lds ? ukl_bytes : 0) + pre_work + 15) & ~(size_t)15;
+                auto pk = pre_in_lds ? mix_swap_all_pre_kernel<true> : mix_swap_all_pre_kernel<false>;
+                REMD_CHECK(h, hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
+                hipLaunchKernelGGL(pk, dim3(1), dim3(W), pre_lds, h->stream, h->seed, iteration, R, K, ld, d_ukl, d_labels, n_attempts,
+                                   (const uint4*)B.rec, (const unsigned*)B.piece, (const unsigned*)B.npiece, (const unsigned char*)B.cnt, Rp4,
+                                   h->d_mix_log, d_dbg);
+                hipLaunchKernelGGL(mix_stats_from_log_kernel, dim3((unsigned)std::min<int64_t>(4096, (n_attempts + 255) / 256)), dim3(256), 0, h->stream,
+                                   n_attempts, h->d_mix_log, K, d_nacc, d_nprop);
+                if (debug) {
+                    long long hd[8];
+                    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+                    REMD_CHECK(h, hipMemcpy(hd, d_dbg, sizeof(hd), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[mix-pre] R=%d W=%d lds=%zu ukl_lds=%d cycles: setup %lld chain-build %lld sweeps %lld finalize %lld n_sweeps %lld "
+                            "wall(100MHz ticks) %lld\n", R, W, pre_lds, pre_in_lds, hd[0], hd[1], hd[2], hd[3], hd[5], hd[6]);
+                }
+                REMD_CHECK(h, hipGetLastError());
+                return 0;
+            }
+            // (a window needed more than MIXP pieces: fall through to the one-kernel path, which cuts windows as it goes)
+        }
         auto kern = flow ? (in_lds ? mix_swap_all_dataflow_kernel<true> : mix_swap_all_dataflow_kernel<false>)
                          : (in_lds ? mix_swap_all_kernel<true> : mix_swap_all_kernel<false>);
         REMD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         remd_prof_scope ps(h, "mix_swap_all");
-        static long long* d_dbg = nullptr;
-        static const bool debug = getenv("REMD_MIX_DEBUG") != nullptr;
-        if (debug && !d_dbg) REMD_CHECK(h, hipMalloc(&d_dbg, 8 * sizeof(long long)));
         unsigned int* d_log = nullptr;
         const bool use_log = true;              // counters beyond the LDS: attempt log instead of global atomics
         if (!stats_lds && use_log && (size_t)n_attempts * sizeof(unsigned int) <= ((size_t)1 << 30)) {

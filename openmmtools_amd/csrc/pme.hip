@@ -956,12 +956,13 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
     // run 1125 radix-5 and 1875 radix-3 butterflies in 3 and 5 full slots; 512 threads would idle a quarter of them)
     {
         const long long np = (long long)s->n[0] * s->n[1];
-        long long best_cost = -1; int best_t = 1024;
+        long long best_cost = -1; int best_t = 0;
         // multiples of 256 threads only: the dispatcher reserves ceil(waves / 4) wave slots on EVERY SIMD for a workgroup
         // (tools/probes/occupancy_probe.hip), so a 6-wavefront workgroup occupies the slots of 8; next to the pair kernel's
         // resident workgroups 512 threads beat the 384 that waste the fewest butterfly slots (108.3 vs 110.2 ms per 500 steps)
         for (int t = 256; t <= 1024; t += 256) {
-            if (np > (long long)XY_PPT * t) continue;
+            // (what bounds a stage is its butterfly slots per thread, ceil(XY_PPT / radix) of them: a 128 x 128 plane is 16 points
+            // per thread of a 1024-thread workgroup = 4 radix-4 slots, although 16 > XY_PPT)
             long long cost = 0; bool ok = true;
             for (int ax = 0; ax < 2 && ok; ++ax)
                 for (int st = 0; st < s->nrad[ax]; ++st) {
@@ -972,9 +973,9 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
                 }
             if (ok && (best_cost < 0 || cost < best_cost)) { best_cost = cost; best_t = t; }
         }
-        s->xy_threads = best_t;
+        s->xy_threads = best_t > 0 ? best_t : 1024;
+        s->xy_fused = best_t > 0 && s->xy_lds <= 160 * 1024;
     }
-    s->xy_fused = (size_t)s->n[0] * s->n[1] <= (size_t)XY_PPT * s->xy_threads && s->xy_lds <= 160 * 1024;
     if (!s->xy_fused && !full_complex) {
         // widest divisor of ny whose slab fits the registers of 256 threads and ~40 KB of LDS
         for (int c = 1; c <= s->n[1]; ++c)

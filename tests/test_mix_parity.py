@@ -8,14 +8,19 @@ pytestmark = pytest.mark.gpu
 SEED = 0xC0FFEE
 
 
-@pytest.fixture(params=['speculative', 'dataflow', 'by-acceptance'], autouse=True)
+@pytest.fixture(params=['speculative', 'speculative-one-kernel', 'dataflow', 'by-acceptance'], autouse=True)
 def swap_all_kernel(request, monkeypatch):
     """swap-all has two kernels with the same (sequential) result: speculative windows and the dataflow over per-slot
-    tickets; a handle picks by the acceptance of its previous call, REMD_MIX_FLOW pins one (mix.hip: remd_mix_launch)."""
+    tickets; a handle picks by the acceptance of its previous call, REMD_MIX_FLOW pins one (mix.hip: remd_mix_launch).
+    The speculative one runs with its label-independent part hoisted into a whole-chip kernel (round 4, the default) or
+    entirely inside the serial workgroup (REMD_MIX_PRE=0)."""
+    monkeypatch.delenv('REMD_MIX_PRE', raising=False)
     if request.param == 'by-acceptance':
         monkeypatch.delenv('REMD_MIX_FLOW', raising=False)
     else:
-        monkeypatch.setenv('REMD_MIX_FLOW', '0' if request.param == 'speculative' else '1')
+        monkeypatch.setenv('REMD_MIX_FLOW', '1' if request.param == 'dataflow' else '0')
+        if request.param == 'speculative-one-kernel':
+            monkeypatch.setenv('REMD_MIX_PRE', '0')
     return request.param
 
 
