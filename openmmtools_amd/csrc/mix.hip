@@ -665,7 +665,7 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         // speculative windows with the label-independent part hoisted into a whole-chip kernel (mix_prep_kernel); REMD_MIX_PRE=0
         // keeps everything in the one serial workgroup (parity tests run both)
         const bool pre_off = getenv("REMD_MIX_PRE") && atoi(getenv("REMD_MIX_PRE")) == 0;
-        if (!flow && !pre_off && (size_t)n_attempts * sizeof(unsigned int) <= ((size_t)1 << 30)) {
+        if (!flow && !pre_off && n_attempts > 0 && (size_t)n_attempts * sizeof(unsigned int) <= ((size_t)1 << 30)) {
             const int W = 64 * waves;
             const int64_t n_win = (n_attempts + W - 1) / W;
             const int Rp4 = (R + 3) & ~3;

@@ -81,6 +81,22 @@ __device__ __forceinline__ void bfly4(float2* v)
     const float2 id = make_float2(-SIGN * d.y, SIGN * d.x);   // SIGN * i * d
     v[0] = cadd(a, c); v[2] = csub(a, c); v[1] = cadd(b, id); v[3] = csub(b, id);
 }
+// radix 8 = two radix-4 butterflies on the even / odd inputs + the eighth roots of unity (round 4: power-of-two meshes of the
+// rebalanced Ewald split, 64 = 8 x 8 is two LDS stages per line instead of three)
+template <int SIGN>
+__device__ __forceinline__ void bfly8(float2* v)
+{
+    float2 e[4] = { v[0], v[2], v[4], v[6] }, o[4] = { v[1], v[3], v[5], v[7] };
+    bfly4<SIGN>(e); bfly4<SIGN>(o);
+    const float h = 0.70710678118654752f;
+    const float2 o1 = make_float2((o[1].x - SIGN * o[1].y) * h, (o[1].y + SIGN * o[1].x) * h);      // * (1 + SIGN i) / sqrt 2
+    const float2 o2 = make_float2(-SIGN * o[2].y, SIGN * o[2].x);                                   // * SIGN i
+    const float2 o3 = make_float2((-o[3].x - SIGN * o[3].y) * h, (-o[3].y + SIGN * o[3].x) * h);    // * (-1 + SIGN i) / sqrt 2
+    v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+    v[1] = cadd(e[1], o1);   v[5] = csub(e[1], o1);
+    v[2] = cadd(e[2], o2);   v[6] = csub(e[2], o2);
+    v[3] = cadd(e[3], o3);   v[7] = csub(e[3], o3);
+}
 template <int SIGN>
 __device__ __forceinline__ void bfly5(float2* v)
 {
@@ -122,9 +138,9 @@ __device__ float2* fft_lines_lds(const fft_plan& pl, float2* src, float2* dst, i
             const int k = j - jq * Ns;
             const int tstep = k * tstride;                  // tstep * r < n for every r < Rx: no modulo needed
             const float2* S = src + l * ls;
-            float2 v[5];
+            float2 v[8];
 #pragma unroll
-            for (int r = 0; r < 5; ++r) if (r < Rx) {
+            for (int r = 0; r < 8; ++r) if (r < Rx) {
                 v[r] = S[(j + r * nb) * es];
                 if (s > 0 && r > 0) {                       // first stage (Ns = 1) and r = 0: twiddle = 1
                     float2 w = tw[tstep * r];
@@ -132,11 +148,11 @@ __device__ float2* fft_lines_lds(const fft_plan& pl, float2* src, float2* dst, i
                     v[r] = cmul(v[r], w);
                 }
             }
-            if (Rx == 2) bfly2<SIGN>(v); else if (Rx == 3) bfly3<SIGN>(v); else if (Rx == 4) bfly4<SIGN>(v); else bfly5<SIGN>(v);
+            if (Rx == 2) bfly2<SIGN>(v); else if (Rx == 3) bfly3<SIGN>(v); else if (Rx == 4) bfly4<SIGN>(v); else if (Rx == 8) bfly8<SIGN>(v); else bfly5<SIGN>(v);
             const int d0 = jq * Ns * Rx + k;
             float2* D = dst + l * ls;
 #pragma unroll
-            for (int r = 0; r < 5; ++r) if (r < Rx) D[(d0 + r * Ns) * es] = v[r];
+            for (int r = 0; r < 8; ++r) if (r < Rx) D[(d0 + r * Ns) * es] = v[r];
         }
         __syncthreads();
         float2* tmp = src; src = dst; dst = tmp;
@@ -149,7 +165,7 @@ __device__ float2* fft_lines_lds(const fft_plan& pl, float2* src, float2* dst, i
 // LDS image of the data is needed (half the footprint of the ping-pong version => more workgroups per CU).
 template <int SIGN, int RX> __device__ __forceinline__ void bfly(float2* v)
 {
-    if (RX == 2) bfly2<SIGN>(v); else if (RX == 3) bfly3<SIGN>(v); else if (RX == 4) bfly4<SIGN>(v); else bfly5<SIGN>(v);
+    if (RX == 2) bfly2<SIGN>(v); else if (RX == 3) bfly3<SIGN>(v); else if (RX == 4) bfly4<SIGN>(v); else if (RX == 8) bfly8<SIGN>(v); else bfly5<SIGN>(v);
 }
 
 // Butterfly schedule of one in-place pass, precomputed on the host (build_sched): the index arithmetic of a
@@ -207,7 +223,8 @@ __device__ __forceinline__ void fft_lines_inplace(const fft_plan& pl, const fft_
         const int Rx = pl.radix[s];
         const int in_stride = (pl.n / Rx) * es, out_stride = Ns * es;
         const uint2* tab = sc.tab + sc.off[s];
-        if (Rx == 4) fft_stage_sched<SIGN, 4, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        if (Rx == 8) fft_stage_sched<SIGN, 8, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
+        else if (Rx == 4) fft_stage_sched<SIGN, 4, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
         else if (Rx == 5) fft_stage_sched<SIGN, 5, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
         else if (Rx == 3) fft_stage_sched<SIGN, 3, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
         else fft_stage_sched<SIGN, 2, PPT>(buf, tab, in_stride, out_stride, s > 0, tw, tid, nthreads);
@@ -806,8 +823,18 @@ static bool factorize(int n, int* radix, int& nrad)
 {
     nrad = 0;
     int m = n;
-    while (m % 4 == 0) { radix[nrad++] = 4; m /= 4; }
-    while (m % 2 == 0) { radix[nrad++] = 2; m /= 2; }
+    // the power of two 2^e in ceil(e / 3) stages of radix 8 / 4 / 2, bits spread evenly (16 = 4 x 4, 32 = 8 x 4, 64 = 8 x 8,
+    // 128 = 8 x 4 x 4): every stage is a pass over the LDS image and two workgroup barriers.  REMD_PME_RADIX8=0: 4s and 2s only.
+    static const bool radix8 = !(getenv("REMD_PME_RADIX8") && atoi(getenv("REMD_PME_RADIX8")) == 0);
+    int e = 0;
+    while (m % 2 == 0) { ++e; m /= 2; }
+    if (radix8) {
+        const int st = (e + 2) / 3;
+        for (int k = 0, left = e; k < st; ++k) { const int b = (left + (st - k) - 1) / (st - k); radix[nrad++] = 1 << b; left -= b; }
+    } else {
+        while (e >= 2) { radix[nrad++] = 4; e -= 2; }
+        if (e) radix[nrad++] = 2;
+    }
     while (m % 3 == 0) { radix[nrad++] = 3; m /= 3; }
     while (m % 5 == 0) { radix[nrad++] = 5; m /= 5; }
     return m == 1 && nrad <= 8;
@@ -972,6 +999,13 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
                     cost += slots * t * rx;                    // issued lane-points of this stage
                 }
             if (ok && (best_cost < 0 || cost < best_cost)) { best_cost = cost; best_t = t; }
+        }
+        if (getenv("REMD_PME_XYT")) {            // experiment hook: workgroup size of the plane pass (must leave <= ceil(XY_PPT / radix) slots per thread)
+            const int t = atoi(getenv("REMD_PME_XYT"));
+            bool ok = t >= 64 && t <= 1024 && t % 64 == 0;
+            for (int ax = 0; ax < 2 && ok; ++ax)
+                for (int st = 0; st < s->nrad[ax]; ++st) { const int rx = s->radix[ax][st]; if ((np / rx + t - 1) / t > (XY_PPT + rx - 1) / rx) ok = false; }
+            if (ok) best_t = t;
         }
         s->xy_threads = best_t > 0 ? best_t : 1024;
         s->xy_fused = best_t > 0 && s->xy_lds <= 160 * 1024;
