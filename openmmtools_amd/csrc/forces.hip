@@ -501,11 +501,14 @@ __device__ __forceinline__
 void gather_positions_body(int tile, int nt, int r, int lane, int Npad, int Npad_pos, const int* __restrict__ order,
                            const float4* __restrict__ pos, const float* __restrict__ box, float4* __restrict__ spos,
                            float4* __restrict__ tile_c, float4* __restrict__ tile_h, float4* __restrict__ cl_c,
-                           float4* __restrict__ cl_h)
+                           float4* __restrict__ cl_h, const float4* __restrict__ sparam = nullptr)
 {
     const int k = tile * 64 + lane;
     const int o = order[(size_t)r * Npad + k];
-    const float4 x = (o >= 0) ? pos[(size_t)r * Npad_pos + o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 x = (o >= 0) ? pos[(size_t)r * Npad_pos + o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // .w = the atom's charge (q sqrt(k_e), sorted parameter table): the Coulomb-only pair kernel then needs ONE 16-byte load per
+    // atom instead of two, which also frees the registers for a second entry of prefetch
+    if (sparam) x.w = sparam[(size_t)r * Npad + k].x;
     spos[(size_t)r * Npad + k] = x;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const float x0 = __shfl(x.x, 0), y0 = __shfl(x.y, 0), z0 = __shfl(x.z, 0);   // lane 0 of a tile is always a real atom
@@ -557,7 +560,7 @@ void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ ord
 }
 
 // main system (first nt_a tiles of the grid) and LJ sub-system in one launch: one dependent launch less per evaluation
-struct gather_args { int Npad; const int* order; float4* spos; float4* tile_c; float4* tile_h; float4* cl_c; float4* cl_h; };
+struct gather_args { int Npad; const int* order; float4* spos; float4* tile_c; float4* tile_h; float4* cl_c; float4* cl_h; const float4* sparam; };
 __global__ __launch_bounds__(64)
 void gather_positions2_kernel(int nt_a, gather_args a, gather_args b, int Npad_pos, const float4* __restrict__ pos,
                               const float* __restrict__ box)
@@ -565,7 +568,7 @@ void gather_positions2_kernel(int nt_a, gather_args a, gather_args b, int Npad_p
     const bool second = (int)blockIdx.x >= nt_a;
     const gather_args& g = second ? b : a;
     gather_positions_body(second ? blockIdx.x - nt_a : blockIdx.x, second ? gridDim.x - nt_a : nt_a, blockIdx.y, threadIdx.x, g.Npad, Npad_pos,
-                          g.order, pos, box, g.spos, g.tile_c, g.tile_h, g.cl_c, g.cl_h);
+                          g.order, pos, box, g.spos, g.tile_c, g.tile_h, g.cl_c, g.cl_h, g.sparam);
 }
 
 // ---- Newton's-third-law path: super-cluster ("sci") lists -----------------------------------------------------------
@@ -769,12 +772,15 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
     if (NW == 1 && n <= 0) return;
     const unsigned int* L = list + ((size_t)r * ntile + T) * cap + zsl;
 
+    // Coulomb-only main kernel of a split system: the charge rides in spos.w (gather_positions_body), no parameter loads
+    constexpr bool PACKQ = (METHOD == NB_EWALD_NOLJ || METHOD == NB_RF_NOLJ) && !ALCH;
     float4 xi[8], pi[8];
     float fix[8], fiy[8], fiz[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int i = (T * 8 + s) * 8 + ii;
-        xi[s] = P[i]; pi[s] = prm[i];
+        xi[s] = P[i];
+        if (PACKQ) pi[s] = make_float4(xi[s].w, 0.f, 0.f, 0.f); else pi[s] = prm[i];
         if (ALCH && pi[s].w != 0.f) pi[s].x *= lam_e;
         fix[s] = fiy[s] = fiz[s] = 0.f;
     }
@@ -795,17 +801,26 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
         const int cnt = min(64, n - base);                       // list entries in this 64-chunk
         const unsigned int my_ent = (lane < cnt) ? L[(size_t)(base + lane) * nsplit] : 0u;
         int jn = (int)(__builtin_amdgcn_readlane(my_ent, 0) & 0xffffu);
-        float4 gx = P[jn * 8 + jj], gp = prm[jn * 8 + jj];
+        float4 gx = P[jn * 8 + jj], gp = PACKQ ? gx : prm[jn * 8 + jj];
+        float4 gx2 = gx;                                         // PACKQ: the entry after the next one
+        if (PACKQ) { jn = (int)(__builtin_amdgcn_readlane(my_ent, min(1, cnt - 1)) & 0xffffu); gx2 = P[jn * 8 + jj]; }
         for (int k = 0; k < cnt; ++k) {
             const unsigned int ent = __builtin_amdgcn_readlane(my_ent, k);
             const int jc = (int)(ent & 0xffffu);
             const unsigned int imask = ent >> 16;
             const float4 xj = gx;
-            float4 pj = gp;
+            float4 pj = PACKQ ? make_float4(gx.w, 0.f, 0.f, 0.f) : gp;
             // prefetch the next entry's j atoms behind this entry's arithmetic (unconditional: the last entry of a chunk
-            // re-reads itself, which keeps the loop free of a branch the register allocator would pin copies to)
-            jn = (int)(__builtin_amdgcn_readlane(my_ent, min(k + 1, cnt - 1)) & 0xffffu);
-            gx = P[jn * 8 + jj]; gp = prm[jn * 8 + jj];
+            // re-reads itself, which keeps the loop free of a branch the register allocator would pin copies to); the packed
+            // Coulomb-only kernel keeps two entries in flight
+            if (PACKQ) {
+                gx = gx2;
+                jn = (int)(__builtin_amdgcn_readlane(my_ent, min(k + 2, cnt - 1)) & 0xffffu);
+                gx2 = P[jn * 8 + jj];
+            } else {
+                jn = (int)(__builtin_amdgcn_readlane(my_ent, min(k + 1, cnt - 1)) & 0xffffu);
+                gx = P[jn * 8 + jj]; gp = prm[jn * 8 + jj];
+            }
             if (ALCH && pj.w != 0.f) pj.x *= lam_e;
             const int j = jc * 8 + jj;
             float fjx = 0.f, fjy = 0.f, fjz = 0.f;
@@ -821,6 +836,15 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 unsigned long long in = __builtin_amdgcn_ballot_w64(r2 < rcut2);
                 // lanes beyond the cutoff evaluate at the cutoff (the table also has a lower end)
                 const float r2c = TAB ? __builtin_amdgcn_fmed3f(r2, p.ctab_umin, rcut2) : min_sv(rcut2, r2);
+                // Coulomb-only kernel from the table: the LDS read is issued here, in front of the scalar mask chain and its
+                // branches, so that its round trip overlaps them instead of stalling the polynomial that consumes it
+                constexpr bool EARLY = TAB && METHOD == NB_EWALD_NOLJ && !ALCH;
+                float4 tc = make_float4(0.f, 0.f, 0.f, 0.f); float ttf = 0.f;
+                if (EARLY) {
+                    const unsigned int bits = __float_as_uint(r2c);
+                    tc = ctab[bits >> CTAB_SHIFT];
+                    ttf = (float)(bits & CTAB_MASK);
+                }
                 const int dj = jc - ic;
                 if (dj < W) {                                    // wave-uniform: exclusions (and the diagonal) live here
                     unsigned long long m;
@@ -840,7 +864,8 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 touched = true;
                 float fr, ee;
                 // evaluated for every lane (excluded pairs, even r2 = 0, produce garbage that the select below discards)
-                pair_interaction<METHOD, ALCH, !ENERGY, TAB>(p, r2c, pi[s], pj, lam_a, sc, fr, ENERGY, ee, ctab);
+                if (EARLY) { fr = (pi[s].x * pj.x) * fmaf(ttf, fmaf(ttf, fmaf(ttf, tc.w, tc.z), tc.y), tc.x); ee = 0.f; }
+                else pair_interaction<METHOD, ALCH, !ENERGY, TAB>(p, r2c, pi[s], pj, lam_a, sc, fr, ENERGY, ee, ctab);
                 fr = keep_where(in, fr);
                 const float tx = fr * dx, ty = fr * dy, tz = fr * dz;
                 fix[s] += tx; fiy[s] += ty; fiz[s] += tz;
@@ -1625,8 +1650,8 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
     if (split) {
         // main system + LJ sub-system in one gather launch and one list launch
         const int ntile_lj = t.NLpad / 64;
-        gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h};
-        gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h};
+        gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h, t.d_sparam};
+        gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h, nullptr};
         hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
         sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
         sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};

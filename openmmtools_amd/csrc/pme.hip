@@ -987,7 +987,10 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         // multiples of 256 threads only: the dispatcher reserves ceil(waves / 4) wave slots on EVERY SIMD for a workgroup
         // (tools/probes/occupancy_probe.hip), so a 6-wavefront workgroup occupies the slots of 8; next to the pair kernel's
         // resident workgroups 512 threads beat the 384 that waste the fewest butterfly slots (108.3 vs 110.2 ms per 500 steps)
-        for (int t = 256; t <= 1024; t += 256) {
+        // (ties go to 512 threads: 64 x 64 planes measured 92.7 ms per 500 steps with 512 against 94.9 with 256 and the same issued lane-points)
+        const int xy_cands[4] = {512, 256, 768, 1024};
+        for (int tc = 0; tc < 4; ++tc) {
+            const int t = xy_cands[tc];
             // (what bounds a stage is its butterfly slots per thread, ceil(XY_PPT / radix) of them: a 128 x 128 plane is 16 points
             // per thread of a 1024-thread workgroup = 4 radix-4 slots, although 16 > XY_PPT)
             long long cost = 0; bool ok = true;
