@@ -601,12 +601,27 @@ void scatter_sorted_forces_body(int Npad_a, const int* __restrict__ order_a, lon
     }
 }
 
+// join_flag != NULL: this is the last launch of the direct-space stream of a forked evaluation, and the last workgroup to finish
+// publishes "forces complete" (remd_ctx::d_sync[1]) itself -- one dependent launch (remd_signal_kernel) less on what has become
+// the critical path of a step (profiles/r04_e_timeline.txt)
 __global__ __launch_bounds__(256)
 void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, long long* __restrict__ sforce_a,
                                   int Npad_b, const int* __restrict__ order_b, long long* __restrict__ sforce_b,
-                                  long long* __restrict__ force, int Npad_force)
+                                  long long* __restrict__ force, int Npad_force,
+                                  unsigned int* __restrict__ join_flag = nullptr, unsigned int join_seq = 0u, unsigned int* __restrict__ arrivals = nullptr)
 {
     scatter_sorted_forces_body(Npad_a, order_a, sforce_a, Npad_b, order_b, sforce_b, force, Npad_force, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+    if (join_flag) {
+        __threadfence();                                 // this thread's force atomics are visible device-wide
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int n = gridDim.x * gridDim.y;
+            if (atomicAdd(arrivals, 1u) == n - 1u) {
+                atomicExch(arrivals, 0u);
+                __hip_atomic_store(join_flag, join_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(64)
@@ -740,6 +755,16 @@ struct sci_args {
     long long* force;
 };
 #define SCI_EWALD(M) ((M) == NB_EWALD || (M) == NB_EWALD_NOLJ)
+// A/B switches of the round-4 pair-kernel changes (tools/build_variant.sh -DSCI_...=0)
+#ifndef SCI_EARLY_TABLE
+#define SCI_EARLY_TABLE 1
+#endif
+#ifndef SCI_PREFETCH2
+#define SCI_PREFETCH2 1
+#endif
+#ifndef SCI_PACKQ
+#define SCI_PACKQ 1
+#endif
 template <int METHOD, bool ENERGY, bool ALCH, int NW, bool TABLE = false>
 __device__ __forceinline__
 void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const float* __restrict__ box,
@@ -773,7 +798,8 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
     const unsigned int* L = list + ((size_t)r * ntile + T) * cap + zsl;
 
     // Coulomb-only main kernel of a split system: the charge rides in spos.w (gather_positions_body), no parameter loads
-    constexpr bool PACKQ = (METHOD == NB_EWALD_NOLJ || METHOD == NB_RF_NOLJ) && !ALCH;
+    constexpr bool PACKQ = SCI_PACKQ && (METHOD == NB_EWALD_NOLJ || METHOD == NB_RF_NOLJ) && !ALCH;
+    constexpr bool PF2 = PACKQ && SCI_PREFETCH2;
     float4 xi[8], pi[8];
     float fix[8], fiy[8], fiz[8];
 #pragma unroll
@@ -803,7 +829,7 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
         int jn = (int)(__builtin_amdgcn_readlane(my_ent, 0) & 0xffffu);
         float4 gx = P[jn * 8 + jj], gp = PACKQ ? gx : prm[jn * 8 + jj];
         float4 gx2 = gx;                                         // PACKQ: the entry after the next one
-        if (PACKQ) { jn = (int)(__builtin_amdgcn_readlane(my_ent, min(1, cnt - 1)) & 0xffffu); gx2 = P[jn * 8 + jj]; }
+        if (PF2) { jn = (int)(__builtin_amdgcn_readlane(my_ent, min(1, cnt - 1)) & 0xffffu); gx2 = P[jn * 8 + jj]; }
         for (int k = 0; k < cnt; ++k) {
             const unsigned int ent = __builtin_amdgcn_readlane(my_ent, k);
             const int jc = (int)(ent & 0xffffu);
@@ -813,13 +839,13 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
             // prefetch the next entry's j atoms behind this entry's arithmetic (unconditional: the last entry of a chunk
             // re-reads itself, which keeps the loop free of a branch the register allocator would pin copies to); the packed
             // Coulomb-only kernel keeps two entries in flight
-            if (PACKQ) {
+            if (PF2) {
                 gx = gx2;
                 jn = (int)(__builtin_amdgcn_readlane(my_ent, min(k + 2, cnt - 1)) & 0xffffu);
                 gx2 = P[jn * 8 + jj];
             } else {
                 jn = (int)(__builtin_amdgcn_readlane(my_ent, min(k + 1, cnt - 1)) & 0xffffu);
-                gx = P[jn * 8 + jj]; gp = prm[jn * 8 + jj];
+                gx = P[jn * 8 + jj]; if (!PACKQ) gp = prm[jn * 8 + jj];
             }
             if (ALCH && pj.w != 0.f) pj.x *= lam_e;
             const int j = jc * 8 + jj;
@@ -838,7 +864,7 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 const float r2c = TAB ? __builtin_amdgcn_fmed3f(r2, p.ctab_umin, rcut2) : min_sv(rcut2, r2);
                 // Coulomb-only kernel from the table: the LDS read is issued here, in front of the scalar mask chain and its
                 // branches, so that its round trip overlaps them instead of stalling the polynomial that consumes it
-                constexpr bool EARLY = TAB && METHOD == NB_EWALD_NOLJ && !ALCH;
+                constexpr bool EARLY = SCI_EARLY_TABLE && TAB && METHOD == NB_EWALD_NOLJ && !ALCH;
                 float4 tc = make_float4(0.f, 0.f, 0.f, 0.f); float ttf = 0.f;
                 if (EARLY) {
                     const unsigned int bits = __float_as_uint(r2c);
@@ -1715,7 +1741,9 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
             else { if (tab) LAUNCH_SCI2(false, true); else LAUNCH_SCI2(false, false); }
 #undef LAUNCH_SCI2
             hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
-                               t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
+                               t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad,
+                               h->join_sig_pending ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_sig_pending, h->d_sync + 3);
+            h->join_sig_pending = 0;
             return;
         }
         const bool tab1 = t.use_table && !ENERGY && SCI_EWALD(METHOD);
@@ -1914,7 +1942,13 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
     }
     // listed terms of a force-only evaluation: ONE launch, behind the pair kernel (it then starts 20 us earlier, next to the
     // spreading pass: 118.9 -> 116.8 ms per 500 steps)
-    auto launch_listed = [&]() {
+    // forked force-only evaluations: the listed terms go to the MAIN stream behind the mesh launches (they only need the positions
+    // and add with the same integer atomics), and the scatter of the pair kernel publishes the join: since the Ewald split was
+    // rebalanced the direct-space stream is the critical path of a step, and this takes two dependent launches (13 + 5 us) off
+    // it.  REMD_LISTED_MAIN=0: behind the pair kernel on the direct-space stream, as in round 3.
+    static const bool listed_main_env = !(getenv("REMD_LISTED_MAIN") && atoi(getenv("REMD_LISTED_MAIN")) == 0);
+    const bool listed_main = listed_main_env && forked && !with_energy && !h->sync_events;
+    auto launch_listed = [&](hipStream_t lst) {
         listed_tables T{};
         T.n_bonds = do_bond ? h->n_bonds : 0; T.n_angles = do_angle ? h->n_angles : 0; T.n_torsions = do_torsion ? h->n_torsions : 0;
         T.bond_atoms = h->d_bond_atoms; T.bond_params = h->d_bond_params;
@@ -1931,16 +1965,22 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         const int total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
         if (total > 0) {
             remd_prof_scope ps(h, "bonded");
-            hipLaunchKernelGGL(listed_forces_kernel, dim3((total + 255) / 256, R), dim3(256), 0, h->stream, T, h->Npad, h->d_pos,
+            hipLaunchKernelGGL(listed_forces_kernel, dim3((total + 255) / 256, R), dim3(256), 0, lst, T, h->Npad, h->d_pos,
                                h->d_box, h->d_force);
         }
     };
     if (h->nb_method == REMD_NB_NONE) {
-        if (merged) launch_listed();
+        if (merged) launch_listed(h->stream);
     } else {
         nb_tables& t = g_nb[h];
         int rc = do_nb ? ensure_sorted(h, t) : 0;
         if (rc) return rc;
+        // (after the swap h->stream2 is the main stream: the listed terms queue up behind the mesh launches already enqueued there)
+        if (merged && listed_main) launch_listed(h->stream2);
+        // the pair kernel's scatter is then the direct-space stream's last launch and signals the join itself (split systems only:
+        // launch_nb consumes join_sig_pending where it launches that scatter)
+        const bool scatter_joins = listed_main && do_nb && t.sorting && t.clusters && t.lj_split && t.d_lj_sci_list && t.d_sci_list;
+        if (scatter_joins) h->join_sig_pending = h->sync_seq;
         if (do_nb) {
             remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {
@@ -1953,7 +1993,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
                 else launch_nb<NB_EWALD, false>(h, t);
             }
         }
-        if (merged) launch_listed();
+        if (merged && !listed_main) launch_listed(h->stream);
         if (!merged && t.n_exc > 0) {
             remd_prof_scope ps(h, "exceptions");
             LAUNCH_E(exception_kernel, dim3(R), dim3(256), 0, h->stream, t.n_exc, t.d_exc_atoms, t.d_exc_params, t.d_exc_alch,
@@ -1969,7 +2009,8 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         if (t.method == NB_EWALD) {
             if (forked) {                                                       // join
                 if (!h->sync_events) {
-                    hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
+                    if (scatter_joins && h->join_sig_pending == 0) { /* the scatter published the join */ }
+                    else { h->join_sig_pending = 0; hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq); }
                     std::swap(h->stream, h->stream2); swapped = false;
                     // inside remd_run_steps the launch that follows on the main stream is an integrator chain: it polls the
                     // flag in its prologue (no kernel of its own for the wait)

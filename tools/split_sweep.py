@@ -19,10 +19,10 @@ standalone = len(sys.argv) > 4 and sys.argv[4] == 'standalone'
 al = {'alanine': ts.AlanineDipeptideExplicit, 'hostguest': ts.HostGuestExplicit, 'dhfr': ts.DHFRExplicit}[name]()
 box = np.diag(al.system.getDefaultPeriodicBoxVectors())
 d = system_to_desc(al.system, ewald_split=split)
-eng = HipEngine()
+eng = HipEngine(lib_path=os.environ.get('AB_LIB') or None)      # AB_LIB: a variant build (tools/build_variant.sh)
 eng.set_system(d); eng.set_states(1 / (KB * np.geomspace(300.0, 600.0, R)))
 tag = 'split %-9s rcoul %.3f mesh %s  env {%s}' % (sys.argv[1] if len(sys.argv) > 1 else 'reference', d.get('coulomb_cutoff', d['cutoff']), list(d['pme_grid']),
-      ' '.join('%s=%s' % (k[5:], v) for k, v in sorted(os.environ.items()) if k.startswith('REMD_')))
+      ' '.join('%s=%s' % (k[5:], v) for k, v in sorted(os.environ.items()) if k.startswith('REMD_')) + (' lib=' + os.path.basename(os.environ['AB_LIB']) if os.environ.get('AB_LIB') else ''))
 if standalone:
     eng.set_integrator('V R O R V', 0.001, 1.0, 1, True, 1e-8)
     eng.set_replicas(R, 0, np.tile(al.positions, (R, 1, 1)), None, np.tile(box, (R, 1)), np.arange(R))
