@@ -601,27 +601,12 @@ void scatter_sorted_forces_body(int Npad_a, const int* __restrict__ order_a, lon
     }
 }
 
-// join_flag != NULL: this is the last launch of the direct-space stream of a forked evaluation, and the last workgroup to finish
-// publishes "forces complete" (remd_ctx::d_sync[1]) itself -- one dependent launch (remd_signal_kernel) less on what has become
-// the critical path of a step (profiles/r04_e_timeline.txt)
 __global__ __launch_bounds__(256)
 void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, long long* __restrict__ sforce_a,
                                   int Npad_b, const int* __restrict__ order_b, long long* __restrict__ sforce_b,
-                                  long long* __restrict__ force, int Npad_force,
-                                  unsigned int* __restrict__ join_flag = nullptr, unsigned int join_seq = 0u, unsigned int* __restrict__ arrivals = nullptr)
+                                  long long* __restrict__ force, int Npad_force)
 {
     scatter_sorted_forces_body(Npad_a, order_a, sforce_a, Npad_b, order_b, sforce_b, force, Npad_force, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
-    if (join_flag) {
-        __threadfence();                                 // this thread's force atomics are visible device-wide
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int n = gridDim.x * gridDim.y;
-            if (atomicAdd(arrivals, 1u) == n - 1u) {
-                atomicExch(arrivals, 0u);
-                __hip_atomic_store(join_flag, join_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
 }
 
 __global__ __launch_bounds__(64)
@@ -1678,11 +1663,13 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         const int ntile_lj = t.NLpad / 64;
         gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h, t.d_sparam};
         gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h, nullptr};
-        hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
         sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
         sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};
-        hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb,
-                           t.method == NB_EWALD ? t.p.rcc2 : t.p.rc2, t.p.rc2, h->d_box);
+        const float rc2_main = t.method == NB_EWALD ? t.p.rcc2 : t.p.rc2;
+        // (one launch for both with an arrival-counter barrier between the phases was measured in round 4: the polling wavefronts
+        // slow the arrivals and the spreading pass beside them, 90 us instead of 11.6 + 12.7 -- profiles/r04_h_rejected.txt)
+        hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
+        hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb, rc2_main, t.p.rc2, h->d_box);
     } else {
         hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, h->Npad, t.d_order, h->d_pos, h->d_box,
                            t.d_spos, t.d_tile_c, t.d_tile_h, cl ? t.d_cl_c : (float4*)nullptr, cl ? t.d_cl_h : (float4*)nullptr);
@@ -1741,9 +1728,7 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
             else { if (tab) LAUNCH_SCI2(false, true); else LAUNCH_SCI2(false, false); }
 #undef LAUNCH_SCI2
             hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
-                               t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad,
-                               h->join_sig_pending ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_sig_pending, h->d_sync + 3);
-            h->join_sig_pending = 0;
+                               t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
             return;
         }
         const bool tab1 = t.use_table && !ENERGY && SCI_EWALD(METHOD);
@@ -1943,9 +1928,9 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
     // listed terms of a force-only evaluation: ONE launch, behind the pair kernel (it then starts 20 us earlier, next to the
     // spreading pass: 118.9 -> 116.8 ms per 500 steps)
     // forked force-only evaluations: the listed terms go to the MAIN stream behind the mesh launches (they only need the positions
-    // and add with the same integer atomics), and the scatter of the pair kernel publishes the join: since the Ewald split was
-    // rebalanced the direct-space stream is the critical path of a step, and this takes two dependent launches (13 + 5 us) off
-    // it.  REMD_LISTED_MAIN=0: behind the pair kernel on the direct-space stream, as in round 3.
+    // and add with the same integer atomics): since the Ewald split was rebalanced the direct-space stream is the critical path of
+    // a step, and this takes a dependent 13 us launch off it (93.3 -> 89.5 ms per 500 steps).  REMD_LISTED_MAIN=0: behind the pair
+    // kernel on the direct-space stream, as in round 3.
     static const bool listed_main_env = !(getenv("REMD_LISTED_MAIN") && atoi(getenv("REMD_LISTED_MAIN")) == 0);
     const bool listed_main = listed_main_env && forked && !with_energy && !h->sync_events;
     auto launch_listed = [&](hipStream_t lst) {
@@ -1977,10 +1962,6 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         if (rc) return rc;
         // (after the swap h->stream2 is the main stream: the listed terms queue up behind the mesh launches already enqueued there)
         if (merged && listed_main) launch_listed(h->stream2);
-        // the pair kernel's scatter is then the direct-space stream's last launch and signals the join itself (split systems only:
-        // launch_nb consumes join_sig_pending where it launches that scatter)
-        const bool scatter_joins = listed_main && do_nb && t.sorting && t.clusters && t.lj_split && t.d_lj_sci_list && t.d_sci_list;
-        if (scatter_joins) h->join_sig_pending = h->sync_seq;
         if (do_nb) {
             remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {
@@ -2009,8 +1990,9 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         if (t.method == NB_EWALD) {
             if (forked) {                                                       // join
                 if (!h->sync_events) {
-                    if (scatter_joins && h->join_sig_pending == 0) { /* the scatter published the join */ }
-                    else { h->join_sig_pending = 0; hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq); }
+                    // (the scatter's last workgroup publishing the join instead of this launch: its arrival counter costs more than the
+                    // launch it saves, 14 us against 5.2 + 5.6 with two-level counters -- profiles/r04_h_rejected.txt)
+                    hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);
                     std::swap(h->stream, h->stream2); swapped = false;
                     // inside remd_run_steps the launch that follows on the main stream is an integrator chain: it polls the
                     // flag in its prologue (no kernel of its own for the wait)
