@@ -93,7 +93,8 @@ struct nb_tables {
     // the two streams that depends on the system (24 x alanine dipeptide: 2 per CU is 4 % faster than one per item, 8 x
     // host-guest: 7 % slower), so it is measured: during the first long remd_run_steps the candidates take turns over
     // segments of TUNE_SEG real MD steps timed with events; results are bit-identical under every choice (fixed-point sums).
-    struct tune_seg { int cand; hipEvent_t a, b; };
+    struct tune_seg { int cand; hipEvent_t a, b; };       // cand: index into g_tune_cands
+    int nb_prio = 0;                      // current choice: 1 = the pair kernel runs at raised wave priority and the mesh kernels do not
     std::vector<tune_seg> tune_segs; int tune_state = 0 /* 0 measuring, 1 awaiting resolve, 2 done */, tune_left = 0, tune_next = 0;
     int nb_grid = 0;                      // current choice (workgroups; 0 = one per item)
     float sort_cell = 0.45f;              // Morton cell edge (nm) of the molecule sort
@@ -960,6 +961,7 @@ void nonbonded_sci2_kernel(nb_params p, sci_args a, sci_args b, int n_items_a, i
                            const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R, const float4* __restrict__ ctab_g)
 {
     constexpr bool TAB = TABLE && !ENERGY && SCI_EWALD(METHOD_A);
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     if (!queue) {
         if ((int)blockIdx.x < n_items_a) {
             if (TAB) stage_coulomb_table(p, ctab_g, 64 * NW);
@@ -1783,7 +1785,11 @@ int remd_nb_required_epart(remd_ctx* h)
 
 #define TUNE_SEG 40                       // one re-sort of the spatial order per segment (resort_interval)
 #define TUNE_NC 6
-static const int g_tune_cands[TUNE_NC] = {0, 768, 704, 640, 576, 512};      // workgroups: one per item, 3 ... 2 per CU (256 CUs) in steps of 1/4
+// candidates: resident workgroups of the pair kernel (0 = one per item; 3 ... 2 per CU of the 256 CUs) and which stream's kernels
+// run at raised wave priority (1: the pair kernel, 0: the mesh kernels).  Round 4: with the rebalanced Ewald split the
+// direct-space stream is the critical path on the headline system and (0, pair priority) wins: 87.6 against 90.0 ms per 500 steps.
+struct tune_cand { int grid, prio_pair; };
+static const tune_cand g_tune_cands[TUNE_NC] = {{0, 1}, {0, 0}, {768, 0}, {640, 0}, {576, 0}, {512, 0}};
 // called at the top of every eagerly launched MD step of remd_run_steps
 void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call)
 {
@@ -1800,10 +1806,10 @@ void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call)
         }
         if (t.tune_next == 2 * TUNE_NC) { t.tune_state = 1; t.nb_grid = 0; return; }      // two rounds of the candidates measured
         if (steps_left_in_call < TUNE_SEG) { t.nb_grid = 0; return; }           // resume in a later call
-        nb_tables::tune_seg sg{g_tune_cands[t.tune_next % TUNE_NC], nullptr, nullptr};
+        nb_tables::tune_seg sg{t.tune_next % TUNE_NC, nullptr, nullptr};
         hipEventCreate(&sg.a); hipEventRecord(sg.a, h->stream);                // (each segment owns its pair of events)
         t.tune_segs.push_back(sg);
-        t.nb_grid = sg.cand;
+        t.nb_grid = g_tune_cands[sg.cand].grid; t.nb_prio = g_tune_cands[sg.cand].prio_pair;
         t.tune_next++;
         t.tune_left = TUNE_SEG;
     }
@@ -1820,19 +1826,19 @@ void remd_nb_tune_resolve(remd_ctx* h)
     for (auto& sg : t.tune_segs) {
         float e = 0.f;
         if (!sg.a || !sg.b || hipEventElapsedTime(&e, sg.a, sg.b) != hipSuccess) { ok = false; (void)hipGetLastError(); }
-        for (int c = 0; c < TUNE_NC; ++c) if (g_tune_cands[c] == sg.cand) ms[c] += e;
+        ms[sg.cand] += e;
         if (sg.a) hipEventDestroy(sg.a);
         if (sg.b) hipEventDestroy(sg.b);
     }
     t.tune_segs.clear();
     int best = 0;
     for (int c = 1; c < TUNE_NC; ++c) if (ok && ms[c] < ms[best] * 0.995) best = c;     // ties go to the earlier candidate
-    t.nb_grid = ok ? g_tune_cands[best] : 0;
+    t.nb_grid = ok ? g_tune_cands[best].grid : 0; t.nb_prio = ok ? g_tune_cands[best].prio_pair : 0;
     t.tune_state = 2;
     if (getenv("REMD_NB_TUNE_VERBOSE"))
     {
         fprintf(stderr, "[remd] pair-kernel residency, ms per %d steps:", 2 * TUNE_SEG);
-        for (int c = 0; c < TUNE_NC; ++c) fprintf(stderr, " %d: %.2f", g_tune_cands[c], ms[c]);
+        for (int c = 0; c < TUNE_NC; ++c) fprintf(stderr, " %d%s: %.2f", g_tune_cands[c].grid, g_tune_cands[c].prio_pair ? "p" : "", ms[c]);
         fprintf(stderr, " -> %d workgroups\n", t.nb_grid);
     }
 }
@@ -1893,6 +1899,10 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         int rc0 = update_replica_lambdas(h, t0);
         if (rc0) return rc0;
         if (t0.method == NB_EWALD && h->overlap && h->stream2 && do_nb && do_recip) {
+            // which stream's kernels run at raised wave priority: chosen together with the pair kernel's residency (remd_nb_tune_step)
+            static const int prio_env = getenv("REMD_NB_PRIO") ? atoi(getenv("REMD_NB_PRIO")) : -1;
+            t0.p.prio = prio_env >= 0 ? (prio_env ? 1 : 0) : t0.nb_prio;
+            h->mesh_prio_hi = !t0.p.prio;
             if (!h->sync_events) {
                 // the first mesh launch (binning kernel, or the spreading pass when the chain binned the atoms) stores the
                 // fork flag; a one-wavefront kernel at the head of the second stream polls it
@@ -1909,6 +1919,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         }
     }
     h->pme_concurrent = forked;
+    if (!forked) { h->mesh_prio_hi = true; if (h->nb_method != REMD_NB_NONE) g_nb[h].p.prio = 0; }
     const bool merged = !with_energy;      // force-only evaluations: every listed term in one launch
     if (!merged && h->n_bonds > 0) {
         remd_prof_scope ps(h, "bonded");
@@ -1932,7 +1943,9 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
     // a step, and this takes a dependent 13 us launch off it (93.3 -> 89.5 ms per 500 steps).  REMD_LISTED_MAIN=0: behind the pair
     // kernel on the direct-space stream, as in round 3.
     static const bool listed_main_env = !(getenv("REMD_LISTED_MAIN") && atoi(getenv("REMD_LISTED_MAIN")) == 0);
-    const bool listed_main = listed_main_env && forked && !with_energy && !h->sync_events;
+    // (only in the mode in which the direct-space stream is the critical one, chosen by the tuner together with the wave priority:
+    // on a system whose mesh chain is the longer branch the extra launch on the main stream costs what it saves here)
+    const bool listed_main = listed_main_env && forked && !with_energy && !h->sync_events && h->nb_method != REMD_NB_NONE && g_nb[h].p.prio != 0;
     auto launch_listed = [&](hipStream_t lst) {
         listed_tables T{};
         T.n_bonds = do_bond ? h->n_bonds : 0; T.n_angles = do_angle ? h->n_angles : 0; T.n_torsions = do_torsion ? h->n_torsions : 0;

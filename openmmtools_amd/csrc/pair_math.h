@@ -24,6 +24,7 @@ struct nb_params {
     float rcc2;
     // force-only Coulomb kernel from a table in r^2 (coulomb_table.h): first bin's key, number of bins, clamp of r^2
     int ctab_key0, ctab_n; float ctab_umin;
+    int prio;                         // pair kernel at raised wave priority (the direct-space stream is the critical path)
 };
 
 

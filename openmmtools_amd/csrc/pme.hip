@@ -17,6 +17,9 @@
 #include <vector>
 #include <type_traits>
 
+#ifndef PME_PRIO
+#define PME_PRIO 3          // wave priority of the mesh kernels (A/B: tools/build_variant.sh -DPME_PRIO=0)
+#endif
 #define PME_ORDER 5
 #define FFT_B 8
 #define FFT_T 32
@@ -25,6 +28,7 @@
 struct fft_sched { const uint2* tab; int off[8]; };   // see fft_stage_sched
 
 struct pme_state {
+    bool prio_hi = true;                  // mesh kernels at raised wave priority (remd_pme_forces copies remd_ctx::mesh_prio_hi)
     int n[4] = {0, 0, 0, 0};           // mesh dimensions; n[3] = nz / 2 (length of the packed real-to-complex z transform)
     int R = 0;
     size_t npts = 0;
@@ -57,7 +61,7 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
 // mnb[s] / mNs[s]: ceil(2^32 / d) for d = n/radix[s] and d = Ns(s): exact unsigned division of indices < 2^16
-struct fft_plan { int n; int nrad; int radix[8]; unsigned mnb[8]; unsigned mNs[8]; };
+struct fft_plan { int n; int nrad; int radix[8]; unsigned mnb[8]; unsigned mNs[8]; int prio; /* raise the wave priority: the mesh chain is the critical path */ };
 __host__ __device__ __forceinline__ unsigned fft_magic(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
 __device__ __forceinline__ int fft_div(int x, unsigned magic, int d) { return d == 1 ? x : (int)__umulhi((unsigned)x, magic); }
 
@@ -329,7 +333,7 @@ void pme_bin_kernel(int N, int Npad, int nx, int ny, int nz, const float4* __res
     // this launch sits directly behind the integrator on the main stream: its start publishes "positions are final" to the
     // direct-space kernels polling on the second stream (remd_ctx::d_sync)
     if (fork_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(fork_flag, fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
+    __builtin_amdgcn_s_setprio(PME_PRIO);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     __shared__ int s_cnt[257], s_start[257], s_cur[256];
     const int r = blockIdx.x, tid = threadIdx.x;
     for (int k = tid; k <= nx; k += 1024) s_cnt[k] = 0;
@@ -375,7 +379,7 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
                             int bin_cap, int* __restrict__ zero_count, unsigned int* fork_flag, unsigned int fork_seq,
                             const float* __restrict__ bin_q)
 {
-    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
+    if (pl.prio) __builtin_amdgcn_s_setprio(PME_PRIO);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = pl.n;                                     // length of the FFT that is run
     const int nz = HALF ? 2 * M : M, nzc = nz / 2 + 1, PZ = HALF ? ((M + 1) | 1) : (nz | 1);
@@ -485,7 +489,7 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms, long long* __restrict__ force,
                             int bin_cap, const float* __restrict__ bin_q)
 {
-    __builtin_amdgcn_s_setprio(3);
+    if (pl.prio) __builtin_amdgcn_s_setprio(PME_PRIO);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = pl.n;
     const int nz = HALF ? 2 * M : M, nzc = nz / 2 + 1, PZ = HALF ? ((M + 1) | 1) : (nz | 1);
@@ -610,7 +614,7 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
                          const float* __restrict__ box, float alpha, int with_energy, double* __restrict__ energy, int n_eblk,
                          const float* __restrict__ infl, int infl_rep)
 {
-    __builtin_amdgcn_s_setprio(3);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
+    if (plx.prio) __builtin_amdgcn_s_setprio(PME_PRIO);    // the critical path of the two streams wins issue arbitration (forces.hip: the tuner)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nx = plx.n, ny = ply.n, nzc = nz / 2 + 1;
     const int np = nx * ny;
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(XS_THREADS)
 void pme_x_fused_kernel(fft_plan plx, fft_sched scx, int ny, int nz, int sw, float2* __restrict__ spec, const float2* twx,
                         int with_energy, double* __restrict__ energy, int n_eblk, const float* __restrict__ infl, int infl_rep)
 {
-    __builtin_amdgcn_s_setprio(3);
+    if (plx.prio) __builtin_amdgcn_s_setprio(PME_PRIO);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nx = plx.n, nzc = nz / 2 + 1, nslab = ny / sw, PS = sw | 1;
     float2* buf = reinterpret_cast<float2*>(smem);           // [nx][PS]
@@ -714,7 +718,7 @@ template <int SIGN>
 __global__ __launch_bounds__(XS_THREADS)
 void pme_y_slab_kernel(fft_plan ply, fft_sched scy, int nx, int nz, int sh, float2* __restrict__ spec, const float2* twy)
 {
-    __builtin_amdgcn_s_setprio(3);
+    if (ply.prio) __builtin_amdgcn_s_setprio(PME_PRIO);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ny = ply.n, nzc = nz / 2 + 1, nslab = nx / sh, PS = ny | 1;
     float2* buf = reinterpret_cast<float2*>(smem);           // [sh][PS]
@@ -866,7 +870,7 @@ int remd_pme_destroy(remd_ctx* h)
 
 static fft_plan make_plan(pme_state* s, int axis)
 {
-    fft_plan pl; pl.n = s->n[axis]; pl.nrad = s->nrad[axis];
+    fft_plan pl; pl.n = s->n[axis]; pl.nrad = s->nrad[axis]; pl.prio = s->prio_hi ? 1 : 0;
     int Ns = 1;
     for (int k = 0; k < 8; ++k) {
         pl.radix[k] = s->radix[axis][k];
@@ -1073,6 +1077,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
     pme_state* s = (pme_state*)h->pme;
     if (!s || s->R != h->R || !s->ready) { int rc = remd_pme_setup(h); if (rc) return rc; s = (pme_state*)h->pme; }
     s->stream = st;
+    s->prio_hi = h->mesh_prio_hi;
     const int nx = s->n[0], ny = s->n[1], nz = s->n[2];
     const float* rep_lam = remd_nb_rep_lam(h);
     const float4* param = remd_nb_param(h);

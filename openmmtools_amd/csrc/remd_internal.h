@@ -172,6 +172,7 @@ struct remd_ctx {
     // remd_run_steps: the launch that follows a force evaluation on the main stream is always an integrator chain, so the
     // join is polled in that kernel's prologue (join_deferred = sequence number to wait for) instead of a kernel of its own
     bool defer_join_ok = false; unsigned int join_deferred = 0;
+    bool mesh_prio_hi = true;          // which of the two streams' kernels run at raised wave priority (forces.hip: chosen with the pair-kernel residency)
     // set when a wait polled on the device ran out / a capped PME bin overflowed: the handle falls back to events, two chain
     // launches and the binning launch (api.hip: remd_recover_device_flag) instead of staying dead behind a sticky flag
     bool no_device_waits = false, no_chain_bins = false, no_resident = false;
