@@ -633,7 +633,8 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         const int force_waves = 0;
         int waves = force_waves > 0 ? force_waves : (4 * R + 63) / 64;
         waves = std::max(1, std::min(16, waves));
-        const int per_r = 6;                    // window of 6 R attempts (21.9 ms at R = 128: DESIGN.md 7b; the dataflow kernel: 43.9 ms, 45.5 at 4 R, 52 at 2 R)
+        // window of 6 R attempts (21.9 ms at R = 128: DESIGN.md 7b; the dataflow kernel: 43.9 ms, 45.5 at 4 R, 52 at 2 R); REMD_MIX_PERR: experiments
+        const int per_r = getenv("REMD_MIX_PERR") ? std::max(1, atoi(getenv("REMD_MIX_PERR"))) : 6;
         const int max_waves = 12;
         if (force_waves <= 0) waves = std::max(1, std::min(max_waves, (per_r * R + 63) / 64));
         while (waves > 1 && (size_t)R * waves * 8 > 64 * 1024) --waves;      // occupancy masks [R][waves] u64
