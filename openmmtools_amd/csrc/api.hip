@@ -12,6 +12,7 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows);
 int remd_nb_required_epart(remd_ctx* h);
 void remd_free_nonbonded(remd_ctx* h);
 void remd_mix_release(remd_ctx* h);          // mix.hip
+void remd_nb_reset_accumulators(remd_ctx* h); // forces.hip
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
 void remd_nb_tune_resolve(remd_ctx* h);
 static int remd_check_device_flags(remd_ctx* h, const char* where, bool may_retry = false);
@@ -382,6 +383,7 @@ int remd_recover_device_flag(remd_ctx* h, unsigned int f, const char* where, boo
     REMD_CHECK(h, hipMemset(h->d_sync + 2, 0, sizeof(unsigned int)));
     h->join_deferred = 0; h->cbins_ready = false;
     remd_nb_invalidate_sort(h);
+    remd_nb_reset_accumulators(h);
     std::string what;
     if (f == 2) { h->no_chain_bins = true; what = "more atoms in one PME mesh column than the chain-binned layout holds; using the binning launch from now on"; }
     else if (f == 3) { h->no_device_waits = true; what = "the integrator chain's momentum barrier ran out; using two chain launches from now on"; }

@@ -100,6 +100,7 @@ struct nb_tables {
     float sort_cell = 0.45f;              // Morton cell edge (nm) of the molecule sort
     // Ewald direct-space force table of the force-only pair kernels (coulomb_table.h); REMD_NB_TABLE=0: Abramowitz & Stegun erfc
     float4* d_ctab = nullptr; bool use_table = false;
+    unsigned int* d_pair_done = nullptr; unsigned int pair_done_target = 0;      // remd_fold_args: the scatter launch's done counter
 };
 static handle_table<nb_tables> g_nb;
 
@@ -117,6 +118,13 @@ __global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq
 }
 void remd_launch_join_wait(remd_ctx* h)      // a deferred join nobody consumed: wait for it now
 {
+    if (h->fold_pending) {
+        // no chain took it (remd_fold_args): the scatter is the direct-space stream's last launch -- an event is enough here
+        // (end of a propagation, once per call)
+        hipEventRecord(h->ev_join, h->stream2);
+        hipStreamWaitEvent(h->stream, h->ev_join, 0);
+        h->fold_pending = false;
+    }
     if (!h->join_deferred) return;
     hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->join_deferred, h->d_sync + 2);
     h->join_deferred = 0;
@@ -605,9 +613,13 @@ void scatter_sorted_forces_body(int Npad_a, const int* __restrict__ order_a, lon
 __global__ __launch_bounds__(256)
 void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, long long* __restrict__ sforce_a,
                                   int Npad_b, const int* __restrict__ order_b, long long* __restrict__ sforce_b,
-                                  long long* __restrict__ force, int Npad_force)
+                                  long long* __restrict__ force, int Npad_force, unsigned int* __restrict__ done = nullptr)
 {
     scatter_sorted_forces_body(Npad_a, order_a, sforce_a, Npad_b, order_b, sforce_b, force, Npad_force, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+    // remd_fold_args: the barrier waits for the workgroup's outstanding force atomics -- device-scope read-modify-writes, performed at
+    // the memory side and visible to every XCD once acknowledged -- so the arrival needs NO release fence: a device-scope release
+    // writes back the whole L2 of the XCD it runs on, and 312 of them made this launch 28 us instead of 6 (profiles/r04_p_*)
+    if (done) { __syncthreads(); if (threadIdx.x == 0) __hip_atomic_fetch_add(done + 16 * blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 __global__ __launch_bounds__(64)
@@ -1293,7 +1305,7 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h);
     dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
-    dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue); dfree(t.d_ctab);
+    dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue); dfree(t.d_ctab); dfree(t.d_pair_done);
     for (auto& sg : t.tune_segs) { if (sg.a) hipEventDestroy(sg.a); if (sg.b) hipEventDestroy(sg.b); }
     g_nb.erase(h);
 }
@@ -1495,6 +1507,8 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         // 106.55 ms per 500 steps on the headline config), 12 elsewhere (LJ fluid, one workgroup per item: 66.6 vs 63.3 it/s).
         // Fixed per system, never per launch mode: the slices' fp32 partial sums enter the forces bit-wise.
         t.sci_split = (t.method == NB_EWALD && h->overlap && h->stream2) ? 8 : 12;
+        if (getenv("REMD_NB_SPLIT")) t.sci_split = std::max(4, atoi(getenv("REMD_NB_SPLIT")));      // experiment hook
+        if (getenv("REMD_NB_RESORT")) t.resort_interval = std::max(1, atoi(getenv("REMD_NB_RESORT")));
     }
 
     // LJ-active sub-system: worthwhile when charges exist and most atoms carry no LJ (TIP3P hydrogens)
@@ -1596,6 +1610,10 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         REMD_CHECK(h, hipMalloc(&t.d_smask, sizeof(unsigned long long) * n * t.p.excl_words));
         REMD_CHECK(h, hipMalloc(&t.d_tile_c, sizeof(float4) * (size_t)h->R * ntile));
         REMD_CHECK(h, hipMalloc(&t.d_tile_h, sizeof(float4) * (size_t)h->R * ntile));
+        dfree(t.d_pair_done);
+        REMD_CHECK(h, hipMalloc(&t.d_pair_done, sizeof(unsigned int) * 16 * h->R));       // one arrival counter per replica, 64 bytes apart
+        REMD_CHECK(h, hipMemsetAsync(t.d_pair_done, 0, sizeof(unsigned int) * 16 * h->R, h->stream));
+        t.pair_done_target = 0;
         dfree(t.d_cl_c); dfree(t.d_cl_h);
         dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_sforce); dfree(t.d_lj_sforce);
         dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
@@ -1721,6 +1739,10 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
             static const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
             const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
             const int grid = (h->pme_concurrent && persist_grid > 0) ? std::min(items, persist_grid) : items;
+            // requested by remd_compute_forces (h->fold_pending): the scatter's workgroups count themselves done for the integrator
+            // chain to poll (remd_fold_args) -- no signal launch behind it
+            const bool fold = h->fold_pending && !ENERGY && t.d_pair_done;
+            if (h->fold_pending && !fold) h->fold_pending = false;
             const bool tab = t.use_table && !ENERGY && SCI_EWALD(MAIN);
             const size_t tab_lds = tab ? sizeof(float4) * (size_t)t.p.ctab_n : 0;
 #define LAUNCH_SCI2(ALCHF, TABF) hipLaunchKernelGGL((nonbonded_sci2_kernel<MAIN, NB_LJ_ONLY, ENERGY, ALCHF, SCI_NW, TABF>), dim3(grid), dim3(64 * SCI_NW), \
@@ -1729,8 +1751,13 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
             if (t.has_alch) { if (tab) LAUNCH_SCI2(true, true); else LAUNCH_SCI2(true, false); }
             else { if (tab) LAUNCH_SCI2(false, true); else LAUNCH_SCI2(false, false); }
 #undef LAUNCH_SCI2
-            hipLaunchKernelGGL(scatter_sorted_forces_kernel, dim3((h->Npad + t.NLpad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad,
-                               t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad);
+            const dim3 sgrid((h->Npad + t.NLpad + 255) / 256, h->R);
+            if (fold) {
+                t.pair_done_target += sgrid.x;           // per replica
+                h->fold.done = t.d_pair_done; h->fold.target = t.pair_done_target;
+            }
+            hipLaunchKernelGGL(scatter_sorted_forces_kernel, sgrid, dim3(256), 0, h->stream, h->Npad,
+                               t.d_order, t.d_sforce, t.NLpad, t.d_lj_order, t.d_lj_sforce, h->d_force, h->Npad, fold ? t.d_pair_done : (unsigned int*)nullptr);
             return;
         }
         const bool tab1 = t.use_table && !ENERGY && SCI_EWALD(METHOD);
@@ -1760,6 +1787,16 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
                            prm, mk, ord, t.d_tile_c, t.d_tile_h, h->d_box, (const float*)nullptr, t.d_partial, h->d_epart, h->n_epart, ntile);
     hipLaunchKernelGGL(nb_reduce_kernel, dim3((h->N + 255) / 256, h->R), dim3(256), 0, h->stream, h->N, h->Npad, t.p.n_jsplit,
                        t.d_partial, h->d_force);
+}
+
+// after a device-side fault: partial sums a discarded evaluation left in the sorted accumulators must not reach the next one
+void remd_nb_reset_accumulators(remd_ctx* h)
+{
+    nb_tables* t = g_nb.find(h);
+    h->fold_pending = false;
+    if (!t || h->R <= 0) return;
+    if (t->d_sforce) hipMemsetAsync(t->d_sforce, 0, sizeof(long long) * 3 * (size_t)h->R * h->Npad, h->stream);
+    if (t->d_lj_sforce) hipMemsetAsync(t->d_lj_sforce, 0, sizeof(long long) * 3 * (size_t)h->R * t->NLpad, h->stream);
 }
 
 int remd_nb_molecules(remd_ctx* h, const int** first, const int** size)
@@ -1975,6 +2012,13 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         if (rc) return rc;
         // (after the swap h->stream2 is the main stream: the listed terms queue up behind the mesh launches already enqueued there)
         if (merged && listed_main) launch_listed(h->stream2);
+        // let the integrator chain that consumes this evaluation poll the scatter's done counter (remd_fold_args) instead of a flag
+        // from a signal launch: only where that chain is certain to be the next launch on the main stream (remd_run_steps, plain
+        // single-group programs) and in the mode in which the direct-space stream is the critical one; REMD_NB_FOLD=0: signal launch
+        static const bool fold_env = !(getenv("REMD_NB_FOLD") && atoi(getenv("REMD_NB_FOLD")) == 0);
+        h->fold_pending = fold_env && listed_main && merged && h->defer_join_ok && do_nb && (class_mask & 63u) == 63u && t.sorting && t.clusters &&
+                          t.lj_split && t.d_lj_sci_list && t.d_sci_list && h->profiling != 2;
+        h->fold.done = nullptr;                  // (launch_nb fills remd_fold_args where it takes the request)
         if (do_nb) {
             remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {
@@ -1987,6 +2031,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
                 else launch_nb<NB_EWALD, false>(h, t);
             }
         }
+        h->fold_pending = h->fold_pending && h->fold.done != nullptr;
         if (merged && !listed_main) launch_listed(h->stream);
         if (!merged && t.n_exc > 0) {
             remd_prof_scope ps(h, "exceptions");
@@ -2002,7 +2047,10 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         }
         if (t.method == NB_EWALD) {
             if (forked) {                                                       // join
-                if (!h->sync_events) {
+                if (h->fold_pending) {
+                    // nothing left to launch on the direct-space stream: the chain polls the scatter's done counter
+                    std::swap(h->stream, h->stream2); swapped = false;
+                } else if (!h->sync_events) {
                     // (the scatter's last workgroup publishing the join instead of this launch: its arrival counter costs more than the
                     // launch it saves, 14 us against 5.2 + 5.6 with two-level counters -- profiles/r04_h_rejected.txt)
                     hipLaunchKernelGGL(remd_signal_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 1, h->sync_seq);

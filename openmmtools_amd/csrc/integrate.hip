@@ -384,8 +384,25 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
                             unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
                             unsigned int* chain_sync, unsigned int* chain_sync_err,
-                            unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold)
+                            unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold,
+                            remd_fold_args fold)
 {
+    if (fold.done) {
+        // remd_fold_args: wait until every workgroup of the direct-space stream's last launch has counted itself done (their force
+        // atomics are complete by then)
+        // one counter per replica, each on its own cache line (done[16 r]): a replica's chain workgroups need that replica's forces
+        // only, and a few hundred arrivals on ONE address serialise at the memory side (~35 ns each: profiles/r04_p_*)
+        if (threadIdx.x == 0) {
+            const unsigned int* word = fold.done + 16 * blockIdx.y;
+            long long n = 0;
+            while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fold.target) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++n > (1ll << 25)) { atomicExch(chain_sync_err, 1u); break; }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     if (join_flag) {
         // the forces of the direct-space stream: poll its "done" flag here instead of behind a cross-stream event (remd_ctx::d_sync)
         if (threadIdx.x == 0) {
@@ -722,8 +739,8 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0),
                        h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2,
                        (h->profiling == 2 || (h->profiling == 1 && h->prof_filter.find("integrate_chain") != std::string::npos)) ? h->d_chain_own : (unsigned long long*)nullptr,
-                       h->d_work, h->d_xold, h->d_vold);
-    h->join_deferred = 0;
+                       h->d_work, h->d_xold, h->d_vold, h->fold_pending ? h->fold : remd_fold_args());
+    h->join_deferred = 0; h->fold_pending = false;
     if (bins.count) h->cbins_ready = true;
 }
 

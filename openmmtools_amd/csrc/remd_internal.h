@@ -49,6 +49,16 @@ __device__ __forceinline__ unsigned long long remd_f2fix(float f)
     return f < 0.f ? 0ull - v : v;
 }
 
+// The join of the two streams without a launch of its own (round 4): the direct-space stream's last launch (the scatter of the
+// pair kernel's sorted accumulators) has every workgroup count itself done with one atomic that nobody waits for, and the
+// integrator chain's prologue polls that count instead of a flag published by a one-wavefront launch behind the scatter (5.6 us
+// on what has become the critical path of a step).  Measured on the way and rejected: the scatter's LAST workgroup publishing the
+// flag (it has to wait for its arrival atomic: 14 - 28 us), and the chain folding the sorted accumulators itself (no scatter
+// launch at all, but +9 us in the one launch of a step that nothing overlaps): profiles/r04_h_rejected.txt, r04_p_fold_rejected.txt.
+struct remd_fold_args {
+    const unsigned int* done = nullptr; unsigned int target = 0;     // scatter workgroups finished (cumulative over launches)
+};
+
 struct remd_profile_entry { int64_t n = 0; double ms = 0.0; };
 
 struct remd_ctx {
@@ -172,6 +182,7 @@ struct remd_ctx {
     // remd_run_steps: the launch that follows a force evaluation on the main stream is always an integrator chain, so the
     // join is polled in that kernel's prologue (join_deferred = sequence number to wait for) instead of a kernel of its own
     bool defer_join_ok = false; unsigned int join_deferred = 0;
+    remd_fold_args fold; bool fold_pending = false;      // the next chain launch polls the scatter's done counter instead of a join flag (forces.hip)
     bool mesh_prio_hi = true;          // which of the two streams' kernels run at raised wave priority (forces.hip: chosen with the pair-kernel residency)
     // set when a wait polled on the device ran out / a capped PME bin overflowed: the handle falls back to events, two chain
     // launches and the binning launch (api.hip: remd_recover_device_flag) instead of staying dead behind a sticky flag
