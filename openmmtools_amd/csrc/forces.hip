@@ -1686,8 +1686,10 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
         sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};
         const float rc2_main = t.method == NB_EWALD ? t.p.rcc2 : t.p.rc2;
-        // (one launch for both with an arrival-counter barrier between the phases was measured in round 4: the polling wavefronts
-        // slow the arrivals and the spreading pass beside them, 90 us instead of 11.6 + 12.7 -- profiles/r04_h_rejected.txt)
+        // (one launch for both with an arrival-counter barrier between the phases was measured twice in round 4: with a release fence
+        // before the arrival -- a device-scope release writes back the XCD's whole L2 -- 90 us instead of 11.6 + 12.7; with the boxes
+        // as write-through device-scope stores and no fence 23.3 us, what the two launches take: profiles/r04_h_rejected.txt,
+        // profiles/r04_r_fused_list_v2.txt)
         hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
         hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb, rc2_main, t.p.rc2, h->d_box);
     } else {
