@@ -60,6 +60,16 @@ def pmc_traffic_bytes(kernel):
     return None
 
 
+def pmc_traffic_source():
+    """Where roofline.traffic comes from: it is NOT measured inside this run (counter passes serialise the kernels); the table
+    was collected with tools/collect_profiles.sh on the commit named in profiles/pmc_traffic_latest.source."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.source')) as fh:
+            return fh.read().strip()
+    except Exception:
+        return 'profiles/pmc_traffic_latest.json (collection commit not recorded)' 
+
+
 def build_sampler(n_replicas, engine, comm, md_steps):
     from openmmtools_amd import testsystems, states, mcmc, unit
     from openmmtools_amd.multistate import ParallelTemperingSampler
@@ -215,12 +225,14 @@ def main():
             roof_nb = dict(kernel='nonbonded_sci2_kernel', bound='mfma', achieved=achieved, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
                            frac=achieved / FP32_PEAK_TFLOPS, traffic=pmc_traffic_bytes('nonbonded_sci2_kernel'),
                            launches=n_launch, avg_launch_ms=avg_ms, total_ms=ms + ms_lj,
-                           note='fp32 VALU kernel; peak = FP32 vector rate = f32-input MFMA rate (157.3 TFLOP/s); '
-                                'algorithmic work = 10 kflop/atom (SURVEY 8(d)); one launch evaluates the Coulomb system and the LJ '
-                                'sub-system (every pair once: Newton\'s third law on per-tile union lists); the timed scope also '
-                                'holds the 7 us sorted-slot force scatter.  The duration is the one next to the mesh kernels of the '
-                                'other stream: the launch keeps a tuned number of workgroups resident (2 per CU here) so that the XY '
-                                'pass is not starved, which stretches this launch and shortens the step (stand-alone: 0.075 ms)')
+                           traffic_source=pmc_traffic_source(),
+                           note='fp32 VALU kernel (no MFMA: "mfma" is the contract\'s name for the compute roof); peak = FP32 vector rate = '
+                                'f32-input MFMA rate (157.3 TFLOP/s); algorithmic work = 10 kflop/atom (SURVEY 8(d): ~210 pairs per atom '
+                                'inside the reference\'s 1.0 nm cutoff x ~48 flop -- the rebalanced Ewald split evaluates 1.43x as many '
+                                'Coulomb pairs, from a force table, which is NOT counted); one launch evaluates the Coulomb system and the '
+                                'LJ sub-system (every pair once: Newton\'s third law on per-tile union lists); the timed scope also holds '
+                                'the sorted-slot force scatter.  The duration is the one next to the mesh kernels of the other stream '
+                                '(stand-alone: 0.081 ms); traffic is an offline PMC figure, see traffic_source')
         if n_xy > 0:
             # algorithmic bytes (SURVEY 8(d) "grid traffic 8 B x G per pass"): the half spectrum [nz/2+1][nx][ny] complex f32 of
             # every replica is read once and written once by the plane-resident XY pass

@@ -7,7 +7,7 @@ import json
 import sys
 
 R, N, NPAD = 24, 2269, 2304
-NX, NY, NZ = 75, 75, 72
+NX, NY, NZ = [int(v) for v in (sys.argv[sys.argv.index("--mesh") + 1].split("x") if "--mesh" in sys.argv else ("64", "64", "64"))]   # round 4: the rebalanced split
 HALF = (NZ // 2 + 1) * NX * NY * R            # complex points of the half spectrum, all replicas
 REAL = NX * NY * NZ * R
 # algorithmic bytes per launch (what the kernel must move at least once) and the SURVEY 8(d) row they come from
@@ -15,7 +15,7 @@ ALGO = {
     'integrate_chain_kernel': (64.0 * N * R, 'fused V/R/O bound: read x, v, f, 1/m; write x, v = 64 B/atom'),
     'pme_spread_zfwd': (16.0 * N * R + 8.0 * HALF, 'read x, q per atom; write the half spectrum (8 B/point)'),
     'pme_xy_fused_kernel': (16.0 * HALF + 4.0 * HALF, 'read + write the half spectrum, read the influence table'),
-    'pme_zinv': (8.0 * HALF + 4.0 * REAL, 'read the half spectrum, write the real potential mesh'),
+    'pme_zinv': (8.0 * HALF + 40.0 * N * R, 'read the half spectrum; x, q in, 24 B/atom of force atomics out (the potential mesh stays in LDS)'),
     'pme_gather_kernel': (4.0 * REAL + 40.0 * N * R, 'read the potential mesh once; x, q in, 24 B/atom of force atomics out'),
     'nonbonded_sci2_kernel': (28.0 * N * R, 'x, q, sigma, eps in; f out = 28 B/atom (the kernel is FP32-VALU bound, 10 kflop/atom)'),
     'scatter_sorted_forces_kernel': (2 * 24.0 * NPAD * R, 'read the sorted accumulator, add into the per-atom accumulator'),
