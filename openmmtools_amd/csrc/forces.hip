@@ -36,6 +36,7 @@
 #define EP_NB0      8      // first nonbonded block slot
 
 #include "pair_math.h"
+#include "listed_terms.h"
 
 #define MAX_EXCL_WORDS 8
 
@@ -134,14 +135,6 @@ __global__ void remd_signal_kernel(unsigned int* flag, unsigned int seq)
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void add_force(long long* __restrict__ F, int Npad, int i, float fx, float fy, float fz)
-{
-    unsigned long long* U = reinterpret_cast<unsigned long long*>(F);
-    atomicAdd(&U[i],            remd_f2fix(fx));
-    atomicAdd(&U[Npad + i],     remd_f2fix(fy));
-    atomicAdd(&U[2 * Npad + i], remd_f2fix(fz));
-}
-
 __device__ __forceinline__ double wave_sum(double e)
 {
     for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
@@ -178,16 +171,7 @@ void ext_force_kernel(int n_ext, const int* __restrict__ ext_atoms, float K, flo
     }
 }
 
-// ---- bonded terms -----------------------------------------------------------------------------
-__device__ __forceinline__ float3 ld3(const float4* P, int i) { const float4 p = P[i]; return make_float3(p.x, p.y, p.z); }
-__device__ __forceinline__ float3 sub3(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ float3 scl3(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float3 add3(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ float dotf(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float3 crs3(float3 a, float3 b) {
-    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-
+// ---- bonded terms (float3 helpers: listed_terms.h) ------------------------------------------------
 template <bool ENERGY>
 __global__ __launch_bounds__(256)
 void bond_kernel(int n, const int* __restrict__ atoms, const float* __restrict__ params, int Npad,
@@ -281,105 +265,6 @@ void torsion_kernel(int n, const int* __restrict__ atoms, const float* __restric
         if (ENERGY) e += (double)k * (1.0 + (double)cosf(arg));
     }
     if (ENERGY) { e = block_sum_256(e, s_part); if (threadIdx.x == 0) epart[(size_t)r * n_epart + EP_TORSION] = e; }
-}
-
-// All short "listed" terms of one force evaluation in a single launch (force-only path): harmonic bonds, angles,
-// periodic torsions, non-zero exceptions and the Ewald exclusion correction.  One term per thread.
-struct listed_tables {
-    int n_bonds, n_angles, n_torsions, n_exc, n_excl;
-    const int *bond_atoms, *angle_atoms, *torsion_atoms, *exc_atoms, *excl_atoms;
-    const float *bond_params, *angle_params, *torsion_params, *exc_params, *excl_qq;
-    const int *exc_alch, *excl_alch; const float* rep_lam;
-    float alpha, two_alpha_sqrtpi;
-};
-
-__device__ __forceinline__
-void listed_forces_body(const listed_tables& T, int Npad, const float4* __restrict__ pos, const float* __restrict__ box,
-                        long long* __restrict__ force, int t, int r)
-{
-    const float4* P = pos + (size_t)r * Npad;
-    long long* F = force + (size_t)r * 3 * Npad;
-    if (t < T.n_bonds) {
-        const int i = T.bond_atoms[2 * t], j = T.bond_atoms[2 * t + 1];
-        const float r0 = T.bond_params[2 * t], k = T.bond_params[2 * t + 1];
-        const float3 d = sub3(ld3(P, j), ld3(P, i));
-        const float len = sqrtf(dotf(d, d));
-        const float fs = k * (len - r0) / len;
-        add_force(F, Npad, i, fs * d.x, fs * d.y, fs * d.z);
-        add_force(F, Npad, j, -fs * d.x, -fs * d.y, -fs * d.z);
-        return;
-    }
-    t -= T.n_bonds;
-    if (t < T.n_angles) {
-        const int a = T.angle_atoms[3 * t], b = T.angle_atoms[3 * t + 1], c = T.angle_atoms[3 * t + 2];
-        const float th0 = T.angle_params[2 * t], k = T.angle_params[2 * t + 1];
-        const float3 v0 = sub3(ld3(P, a), ld3(P, b)), v1 = sub3(ld3(P, c), ld3(P, b));
-        const float3 cp = crs3(v0, v1);
-        const float rp = fmaxf(sqrtf(dotf(cp, cp)), 1e-6f);
-        const float r20 = dotf(v0, v0), r21 = dotf(v1, v1);
-        const float cosine = fminf(fmaxf(dotf(v0, v1) * rsqrtf(r20 * r21), -1.f), 1.f);
-        const float dEdth = k * (acosf(cosine) - th0);
-        const float3 fa = scl3(crs3(v0, cp), -dEdth / (r20 * rp));
-        const float3 fc = scl3(crs3(cp, v1), -dEdth / (r21 * rp));
-        add_force(F, Npad, a, fa.x, fa.y, fa.z);
-        add_force(F, Npad, c, fc.x, fc.y, fc.z);
-        add_force(F, Npad, b, -(fa.x + fc.x), -(fa.y + fc.y), -(fa.z + fc.z));
-        return;
-    }
-    t -= T.n_angles;
-    if (t < T.n_torsions) {
-        const int a1 = T.torsion_atoms[4 * t], a2 = T.torsion_atoms[4 * t + 1], a3 = T.torsion_atoms[4 * t + 2], a4 = T.torsion_atoms[4 * t + 3];
-        const float per = T.torsion_params[3 * t], phase = T.torsion_params[3 * t + 1], k = T.torsion_params[3 * t + 2];
-        const float3 p1 = ld3(P, a1), p2 = ld3(P, a2), p3 = ld3(P, a3), p4 = ld3(P, a4);
-        const float3 b1 = sub3(p2, p1), b2 = sub3(p3, p2), b3 = sub3(p4, p3);
-        const float3 m = crs3(b1, b2), nn = crs3(b2, b3);
-        const float m2 = fmaxf(dotf(m, m), 1e-12f), n2 = fmaxf(dotf(nn, nn), 1e-12f);
-        const float lb2 = sqrtf(dotf(b2, b2));
-        const float phi = atan2f(lb2 * dotf(b1, nn), dotf(m, nn));
-        const float dEdphi = -k * per * sinf(per * phi - phase);
-        const float3 g1 = scl3(m, -lb2 / m2);
-        const float3 g4 = scl3(nn, lb2 / n2);
-        const float s12 = dotf(b1, b2) / (lb2 * lb2), s32 = dotf(b3, b2) / (lb2 * lb2);
-        const float3 g2 = add3(scl3(g1, -(1.f + s12)), scl3(g4, s32));
-        const float3 g3 = add3(scl3(g4, -(1.f + s32)), scl3(g1, s12));
-        add_force(F, Npad, a1, -dEdphi * g1.x, -dEdphi * g1.y, -dEdphi * g1.z);
-        add_force(F, Npad, a2, -dEdphi * g2.x, -dEdphi * g2.y, -dEdphi * g2.z);
-        add_force(F, Npad, a3, -dEdphi * g3.x, -dEdphi * g3.y, -dEdphi * g3.z);
-        add_force(F, Npad, a4, -dEdphi * g4.x, -dEdphi * g4.y, -dEdphi * g4.z);
-        return;
-    }
-    t -= T.n_torsions;
-    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-    if (t < T.n_exc) {
-        const int i = T.exc_atoms[2 * t], j = T.exc_atoms[2 * t + 1];
-        float qq = T.exc_params[3 * t];
-        const float sig = T.exc_params[3 * t + 1], eps = T.exc_params[3 * t + 2];
-        if (T.rep_lam && T.exc_alch[t] > 0) qq *= T.rep_lam[4 * r + 2];      // alchemy.py:1964-1966 exception offset
-        float3 d = sub3(ld3(P, j), ld3(P, i));
-        if (Lx > 0.f) { d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz); }
-        const float r2 = dotf(d, d);
-        const float inv_r = rsqrtf(r2);
-        const float s2 = sig * sig * inv_r * inv_r, s6 = s2 * s2 * s2;
-        const float fr = (4.f * eps * s6 * (6.f - 12.f * s6) * inv_r - qq * inv_r * inv_r) * inv_r;
-        add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
-        add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
-        return;
-    }
-    t -= T.n_exc;
-    if (t < T.n_excl) {
-        const int i = T.excl_atoms[2 * t], j = T.excl_atoms[2 * t + 1];
-        float qq = T.excl_qq[t];
-        if (T.rep_lam) { const float le = T.rep_lam[4 * r + 2]; const int na = T.excl_alch[t]; qq *= (na == 2) ? le * le : (na == 1) ? le : 1.f; }
-        float3 d = sub3(ld3(P, j), ld3(P, i));
-        d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz);
-        const float r2 = dotf(d, d);
-        const float inv_r = rsqrtf(r2);
-        const float ar = T.alpha * r2 * inv_r;
-        const float erf_ar = erff(ar);
-        const float fr = -qq * (T.two_alpha_sqrtpi * __expf(-ar * ar) * inv_r - erf_ar * inv_r * inv_r) * inv_r;
-        add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
-        add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
-    }
 }
 
 __global__ __launch_bounds__(256)
@@ -1933,6 +1818,26 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
     // flag in one launch.
     bool forked = false, swapped = false;
     struct unswap { remd_ctx* h; bool* on; ~unswap() { if (*on) std::swap(h->stream, h->stream2); } } guard{h, &swapped};
+    auto listed_terms = [&](int& total) {
+        listed_tables T{};
+        T.n_bonds = do_bond ? h->n_bonds : 0; T.n_angles = do_angle ? h->n_angles : 0; T.n_torsions = do_torsion ? h->n_torsions : 0;
+        T.bond_atoms = h->d_bond_atoms; T.bond_params = h->d_bond_params;
+        T.angle_atoms = h->d_angle_atoms; T.angle_params = h->d_angle_params;
+        T.torsion_atoms = h->d_torsion_atoms; T.torsion_params = h->d_torsion_params;
+        nb_tables* it = g_nb.find(h);
+        if (it && h->nb_method != REMD_NB_NONE && do_nb) {
+            nb_tables& t = *it;
+            T.n_exc = t.n_exc; T.exc_atoms = t.d_exc_atoms; T.exc_params = t.d_exc_params;
+            T.n_excl = t.n_excl; T.excl_atoms = t.d_excl_atoms; T.excl_qq = t.d_excl_qq;
+            T.alpha = t.p.alpha; T.two_alpha_sqrtpi = t.p.two_alpha_sqrtpi;
+            T.exc_alch = t.d_exc_alch; T.excl_alch = t.d_excl_alch; T.rep_lam = t.has_alch ? t.d_rep_lam : nullptr;
+        }
+        total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
+        return T;
+    };
+    static const bool listed_main_env = !(getenv("REMD_LISTED_MAIN") && atoi(getenv("REMD_LISTED_MAIN")) == 0);
+    static const bool listed_ride_env = !(getenv("REMD_LISTED_RIDE") && atoi(getenv("REMD_LISTED_RIDE")) == 0);
+    bool listed_rode = false;
     if (h->nb_method != REMD_NB_NONE) {      // per-replica lambdas must be current before ANY kernel reads them
         nb_tables& t0 = g_nb[h];
         int rc0 = update_replica_lambdas(h, t0);
@@ -1950,6 +1855,15 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
             } else {
                 hipEventRecord(h->ev_fork, h->stream);
                 hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
+            }
+            // direct-space stream critical (t0.p.prio): the listed terms of a force-only evaluation leave it -- as extra workgroups of
+            // the spreading launch (REMD_LISTED_RIDE=0: as a launch of their own behind the mesh launches)
+            h->mesh_listed_total = 0;
+            if (listed_main_env && listed_ride_env && !with_energy && !h->sync_events && t0.p.prio != 0) {
+                int total = 0;
+                h->mesh_listed = listed_terms(total);
+                h->mesh_listed_total = total;
+                listed_rode = total > 0;
             }
             rc0 = remd_pme_forces(h, with_energy, h->stream, 1);        // everything up to the inverse z transform + gather
             if (rc0) return rc0;
@@ -1981,25 +1895,13 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
     // and add with the same integer atomics): since the Ewald split was rebalanced the direct-space stream is the critical path of
     // a step, and this takes a dependent 13 us launch off it (93.3 -> 89.5 ms per 500 steps).  REMD_LISTED_MAIN=0: behind the pair
     // kernel on the direct-space stream, as in round 3.
-    static const bool listed_main_env = !(getenv("REMD_LISTED_MAIN") && atoi(getenv("REMD_LISTED_MAIN")) == 0);
     // (only in the mode in which the direct-space stream is the critical one, chosen by the tuner together with the wave priority:
-    // on a system whose mesh chain is the longer branch the extra launch on the main stream costs what it saves here)
+    // on a system whose mesh chain is the longer branch the extra work on the main stream costs what it saves here)
     const bool listed_main = listed_main_env && forked && !with_energy && !h->sync_events && h->nb_method != REMD_NB_NONE && g_nb[h].p.prio != 0;
     auto launch_listed = [&](hipStream_t lst) {
-        listed_tables T{};
-        T.n_bonds = do_bond ? h->n_bonds : 0; T.n_angles = do_angle ? h->n_angles : 0; T.n_torsions = do_torsion ? h->n_torsions : 0;
-        T.bond_atoms = h->d_bond_atoms; T.bond_params = h->d_bond_params;
-        T.angle_atoms = h->d_angle_atoms; T.angle_params = h->d_angle_params;
-        T.torsion_atoms = h->d_torsion_atoms; T.torsion_params = h->d_torsion_params;
-        nb_tables* it = g_nb.find(h);
-        if (it && h->nb_method != REMD_NB_NONE && do_nb) {
-            nb_tables& t = *it;
-            T.n_exc = t.n_exc; T.exc_atoms = t.d_exc_atoms; T.exc_params = t.d_exc_params;
-            T.n_excl = t.n_excl; T.excl_atoms = t.d_excl_atoms; T.excl_qq = t.d_excl_qq;
-            T.alpha = t.p.alpha; T.two_alpha_sqrtpi = t.p.two_alpha_sqrtpi;
-            T.exc_alch = t.d_exc_alch; T.excl_alch = t.d_excl_alch; T.rep_lam = t.has_alch ? t.d_rep_lam : nullptr;
-        }
-        const int total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
+        if (listed_rode) return;                      // they rode in the spreading launch
+        int total = 0;
+        const listed_tables T = listed_terms(total);
         if (total > 0) {
             remd_prof_scope ps(h, "bonded");
             hipLaunchKernelGGL(listed_forces_kernel, dim3((total + 255) / 256, R), dim3(256), 0, lst, T, h->Npad, h->d_pos,

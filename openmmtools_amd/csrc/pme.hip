@@ -13,6 +13,7 @@
 // (ewaldErrorTolerance 1e-5, cutoff 1 nm).  f64 restatement: oracle/md_oracle.py (pme_reciprocal),
 // itself pinned against direct Ewald summation.
 #include "remd_internal.h"
+#include "listed_terms.h"
 #include <cmath>
 #include <vector>
 #include <type_traits>
@@ -377,8 +378,13 @@ void pme_spread_zfwd_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, i
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms,
                             float2* __restrict__ spec, const float2* tw, const float2* tw_half,
                             int bin_cap, int* __restrict__ zero_count, unsigned int* fork_flag, unsigned int fork_seq,
-                            const float* __restrict__ bin_q)
+                            const float* __restrict__ bin_q, listed_tables LT, int n_mesh_blocks, long long* __restrict__ force)
 {
+    if ((int)blockIdx.x >= n_mesh_blocks) {
+        // workgroups behind the mesh rows: the listed terms of this force evaluation (listed_terms.h), one term per thread
+        listed_forces_body(LT, Npad, pos, box, force, ((int)blockIdx.x - n_mesh_blocks) * Z_THREADS + (int)threadIdx.x, blockIdx.y);
+        return;
+    }
     if (pl.prio) __builtin_amdgcn_s_setprio(PME_PRIO);    // latency-bound pipeline sharing the CUs with the VALU-bound direct-space kernels: win issue arbitration
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = pl.n;                                     // length of the FFT that is run
@@ -1122,8 +1128,17 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         unsigned int* fflag = (s->cbin_use && h->fork_seq_pending) ? h->d_sync : (unsigned int*)nullptr;
         const unsigned int fseq = h->fork_seq_pending;
         if (s->cbin_use) { h->fork_seq_pending = 0; }
-        DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, bin_cs, bin_ca, s->d_grid,
-                   s->d_tw[2], s->d_tw[3], bin_cap, bin_zero, fflag, fseq, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr);
+        // listed terms riding in this launch (forces.hip decides: remd_ctx::mesh_listed_total)
+        const int n_mesh_blocks = (int)zgrid.x;
+        const int n_listed_blocks = h->mesh_listed_total > 0 ? (h->mesh_listed_total + ZT - 1) / ZT : 0;
+        {
+            const dim3 zgrid_keep = zgrid;
+            const dim3 zgrid(zgrid_keep.x + n_listed_blocks, zgrid_keep.y);
+            DISPATCH_Z(pme_spread_zfwd_kernel, h->Npad, h->d_pos, param, h->d_box, rep_lam, bin_cs, bin_ca, s->d_grid,
+                       s->d_tw[2], s->d_tw[3], bin_cap, bin_zero, fflag, fseq, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr,
+                       h->mesh_listed, n_mesh_blocks, h->d_force);
+        }
+        h->mesh_listed_total = 0;
         if (s->xy_fused || s->xs_sw > 0) {
             if (!s->d_infl) REMD_CHECK(h, hipMalloc(&s->d_infl, sizeof(float) * s->nspec * s->R));
             if (s->infl_version != h->box_version) {

@@ -59,6 +59,14 @@ struct remd_fold_args {
     const unsigned int* done = nullptr; unsigned int target = 0;     // scatter workgroups finished (cumulative over launches)
 };
 
+struct listed_tables {
+    int n_bonds, n_angles, n_torsions, n_exc, n_excl;
+    const int *bond_atoms, *angle_atoms, *torsion_atoms, *exc_atoms, *excl_atoms;
+    const float *bond_params, *angle_params, *torsion_params, *exc_params, *excl_qq;
+    const int *exc_alch, *excl_alch; const float* rep_lam;
+    float alpha, two_alpha_sqrtpi;
+};
+
 struct remd_profile_entry { int64_t n = 0; double ms = 0.0; };
 
 struct remd_ctx {
@@ -182,6 +190,7 @@ struct remd_ctx {
     // remd_run_steps: the launch that follows a force evaluation on the main stream is always an integrator chain, so the
     // join is polled in that kernel's prologue (join_deferred = sequence number to wait for) instead of a kernel of its own
     bool defer_join_ok = false; unsigned int join_deferred = 0;
+    listed_tables mesh_listed{}; int mesh_listed_total = 0;   // listed terms to ride in the next spreading launch (0: none)
     remd_fold_args fold; bool fold_pending = false;      // the next chain launch polls the scatter's done counter instead of a join flag (forces.hip)
     bool mesh_prio_hi = true;          // which of the two streams' kernels run at raised wave priority (forces.hip: chosen with the pair-kernel residency)
     // set when a wait polled on the device ran out / a capped PME bin overflowed: the handle falls back to events, two chain
