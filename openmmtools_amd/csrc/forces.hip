@@ -1623,7 +1623,7 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
             sci_args sb{t.NL, t.NLpad, t.NLpad / 8, t.lj_cap, t.lj_excl_W, t.NLpad, ncl * 4, ssplit, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl,
                         t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce};
             const int items = items_a + (t.NLpad / 64) * h->R * (ssplit / SCI_NW);
-            static const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
+            const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
             const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
             const int grid = (h->pme_concurrent && persist_grid > 0) ? std::min(items, persist_grid) : items;
             // requested by remd_compute_forces (h->fold_pending): the scatter's workgroups count themselves done for the integrator
@@ -1720,7 +1720,7 @@ void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call)
     nb_tables* tp = g_nb.find(h);
     if (!tp || h->nb_method == REMD_NB_NONE) return;
     nb_tables& t = *tp;
-    static const bool fixed = getenv("REMD_NB_PERSIST_GRID") != nullptr;
+    const bool fixed = getenv("REMD_NB_PERSIST_GRID") != nullptr;
     if (fixed || t.tune_state != 0 || !h->pme_concurrent || h->profiling == 2) return;
     if (t.tune_left == 0) {
         hipEvent_t boundary = nullptr;
@@ -1835,8 +1835,8 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
         return T;
     };
-    static const bool listed_main_env = !(getenv("REMD_LISTED_MAIN") && atoi(getenv("REMD_LISTED_MAIN")) == 0);
-    static const bool listed_ride_env = !(getenv("REMD_LISTED_RIDE") && atoi(getenv("REMD_LISTED_RIDE")) == 0);
+    const bool listed_main_env = !(getenv("REMD_LISTED_MAIN") && atoi(getenv("REMD_LISTED_MAIN")) == 0);
+    const bool listed_ride_env = !(getenv("REMD_LISTED_RIDE") && atoi(getenv("REMD_LISTED_RIDE")) == 0);
     bool listed_rode = false;
     if (h->nb_method != REMD_NB_NONE) {      // per-replica lambdas must be current before ANY kernel reads them
         nb_tables& t0 = g_nb[h];
@@ -1844,7 +1844,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         if (rc0) return rc0;
         if (t0.method == NB_EWALD && h->overlap && h->stream2 && do_nb && do_recip) {
             // which stream's kernels run at raised wave priority: chosen together with the pair kernel's residency (remd_nb_tune_step)
-            static const int prio_env = getenv("REMD_NB_PRIO") ? atoi(getenv("REMD_NB_PRIO")) : -1;
+            const int prio_env = getenv("REMD_NB_PRIO") ? atoi(getenv("REMD_NB_PRIO")) : -1;
             t0.p.prio = prio_env >= 0 ? (prio_env ? 1 : 0) : t0.nb_prio;
             h->mesh_prio_hi = !t0.p.prio;
             if (!h->sync_events) {
@@ -1919,7 +1919,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         // let the integrator chain that consumes this evaluation poll the scatter's done counter (remd_fold_args) instead of a flag
         // from a signal launch: only where that chain is certain to be the next launch on the main stream (remd_run_steps, plain
         // single-group programs) and in the mode in which the direct-space stream is the critical one; REMD_NB_FOLD=0: signal launch
-        static const bool fold_env = !(getenv("REMD_NB_FOLD") && atoi(getenv("REMD_NB_FOLD")) == 0);
+        const bool fold_env = !(getenv("REMD_NB_FOLD") && atoi(getenv("REMD_NB_FOLD")) == 0);
         h->fold_pending = fold_env && listed_main && merged && h->defer_join_ok && do_nb && (class_mask & 63u) == 63u && t.sorting && t.clusters &&
                           t.lj_split && t.d_lj_sci_list && t.d_sci_list && h->profiling != 2;
         h->fold.done = nullptr;                  // (launch_nb fills remd_fold_args where it takes the request)

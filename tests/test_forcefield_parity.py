@@ -28,8 +28,8 @@ def test_fft3d_matches_numpy(hip_engine_factory, shape):
 
 
 def _engine_for(eng, system, positions, R=2, temperature=300.0, lam_s=None, jitter=0.0, splitting='V R O R V',
-                dt=0.001, n_steps=5, labels=None, econst=None):
-    desc = system_to_desc(system)
+                dt=0.001, n_steps=5, labels=None, econst=None, desc=None):
+    desc = system_to_desc(system) if desc is None else desc
     eng.set_system(desc)
     K = R if lam_s is None else len(lam_s)
     eng.set_states(np.full(K, 1.0 / (KB * temperature)), lam_s, None, econst)
@@ -398,6 +398,36 @@ def test_resident_pair_workgroups_do_not_change_a_bit(hip_engine_factory, monkey
         monkeypatch.setenv('REMD_NB_PERSIST_GRID', grid)
         eng = hip_engine_factory()
         _engine_for(eng, al.system, al.positions, R=3, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=25)
+        f = eng.get_forces()
+        eng.propagate(0)
+        x, v = eng.get_replicas()[:2]
+        out.append((f, x, v))
+    for f, x, v in out[1:]:
+        assert np.array_equal(f, out[0][0]) and np.array_equal(x, out[0][1]) and np.array_equal(v, out[0][2])
+
+
+def test_stream_modes_of_a_force_evaluation_do_not_change_a_bit(hip_engine_factory, monkeypatch):
+    """Round 4: which stream is treated as the critical one is a run-time choice (tuner candidate '0p'): the pair kernel at raised
+    wave priority, the listed terms on the mesh stream -- as a launch of their own or as extra workgroups of the spreading launch --
+    and the join by the scatter's per-replica done counters instead of a signal launch.  Every contribution is an integer atomic
+    add into the same accumulators, so forces, positions and velocities are bit-identical under every combination, at the
+    rebalanced Ewald split as well."""
+    al = ts.AlanineDipeptideExplicit()
+    desc = system_to_desc(al.system, ewald_split='auto')
+    modes = [dict(REMD_NB_PRIO='0', REMD_NB_PERSIST_GRID='0'),
+             dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0'),
+             dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_LISTED_RIDE='0'),
+             dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_NB_FOLD='0'),
+             dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_LISTED_MAIN='0'),
+             dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='640')]
+    out = []
+    for mode in modes:
+        for k in ('REMD_NB_PRIO', 'REMD_NB_PERSIST_GRID', 'REMD_LISTED_RIDE', 'REMD_NB_FOLD', 'REMD_LISTED_MAIN'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in mode.items():
+            monkeypatch.setenv(k, v)
+        eng = hip_engine_factory()
+        _engine_for(eng, al.system, al.positions, R=3, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=25, desc=desc)
         f = eng.get_forces()
         eng.propagate(0)
         x, v = eng.get_replicas()[:2]
