@@ -494,6 +494,47 @@ def test_config4_all_64_alchemical_states_ukl(hip_engine_factory):
         assert np.abs(d_dev - d_ref).max() < 0.05, np.abs(d_dev - d_ref).max()
 
 
+def test_config4_alchemical_ukl_at_the_rebalanced_ewald_split(hip_engine_factory):
+    """Round 4: what HipEngine asks for by default on config 4 (Coulomb range 1.091 nm, 80 x 80 x 80 instead of 90 x 90 x 90; the
+    soft-core and Lennard-Jones terms keep the 1.0 nm cutoff): a 12-state sample of the 64-state ladder against the f64 oracle at
+    the SAME split, and the device rows against the device rows at OpenMM's split (the Ewald sum does not depend on the split: both
+    sides' Ewald tolerance bounds the difference), incl. the exact-PME lambda_electrostatics polynomial and forces."""
+    hg = ts.HostGuestExplicit()
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156))
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(hg.system, region)
+    lam_e = np.concatenate([np.linspace(1.0, 0.0, 6), np.zeros(6)])
+    lam_s = np.concatenate([np.ones(6), np.linspace(1.0, 0.0, 6)])
+    K = 12
+    nb = [f for f in system.getForces() if hasattr(f, 'particles') and hasattr(f, 'exceptions')][0]
+    V = np.prod(np.diag(system.getDefaultPeriodicBoxVectors()))
+    econst = alchemy.alchemical_long_range_constants(system, nb, lam_s, V)
+    beta = 1.0 / (KB * 300.0)
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (2, 1))
+    x = np.stack([hg.positions, hg.positions + 0.001 * np.random.default_rng(0).normal(size=hg.positions.shape)])
+    rows, forces = {}, {}
+    for split in ('reference', 'auto'):
+        desc = system_to_desc(system, ewald_split=split)
+        assert (max(desc['pme_grid']) == 80 and desc['coulomb_cutoff'] > 1.05) if split == 'auto' else 'coulomb_cutoff' not in desc
+        eng = hip_engine_factory()
+        eng.set_system(desc)
+        eng.set_states(np.full(K, beta), lam_s, lam_e, econst)
+        eng.set_integrator('V R R O R R V', 0.002, 1.0, 5, True, 1e-8)
+        eng.seed(SEED)
+        eng.set_replicas(2, 0, x, None, box, np.array([2, 9]))
+        rows[split] = eng.compute_energies()
+        forces[split] = eng.get_forces()
+        if split == 'auto':
+            xd = eng.get_replicas()[0]
+            ff = ForceFieldOracle(desc)
+            for r in range(2):
+                ref = beta * (ff.state_energies(xd[r], box[r], lam_s, lam_e) + econst)
+                assert np.allclose(rows[split][r], ref, rtol=1e-5), np.abs(rows[split][r] / ref - 1).max()
+                assert np.abs(np.diff(rows[split][r]) - np.diff(ref)).max() < 0.05
+    assert np.allclose(rows['auto'], rows['reference'], rtol=1e-5), np.abs(rows['auto'] / rows['reference'] - 1).max()
+    rmse = np.sqrt(((forces['auto'] - forces['reference']) ** 2).sum(axis=2).mean())
+    assert rmse < 0.5, rmse                                    # kJ/mol/nm; the reference's cross-platform bar is 25.1
+
+
 def test_config5_dhfr_128_state_sams_row_and_jump(hip_engine_factory):
     """BASELINE config 5 AT ITS STATED SHAPE: DHFR (23 558 atoms) with a 128-state ladder (temperatures, BASELINE.md
     section 4 leaves the ladder to us: geomspace 300-400 K) and the SAMS global jump.  Two replicas: the 128-column u_kl
