@@ -314,6 +314,9 @@ int  remd_profile_reset(remd_handle h);
    (GB/s), independent v_fma_f32 chains and v_pk_fma_f32 chains (TFLOP/s).  Any pointer may be NULL.  bench.py reports
    them beside the spec peaks; the reference has no counterpart.                                                          */
 int  remd_roof_microbench(remd_handle h, double* stream_gb_per_s, double* fma_tflop_per_s, double* pk_fma_tflop_per_s);
+/* the shader clock (GHz) the chip sustains under that FMA load (cycle counter against the constant 100 MHz wall clock inside one
+   wavefront of the microbenchmark): the spec peak of 157.3 TFLOP/s is quoted at 2.4 GHz.  libremd_cpu.so: -3.               */
+int  remd_roof_clock_ghz(remd_handle h, double* ghz_under_fma_load);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,7 @@ EXPORTS = [
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_set_force_groups', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
-    'remd_set_energy_const_volume', 'remd_roof_microbench', 'remd_test_coulomb_table',
+    'remd_set_energy_const_volume', 'remd_roof_microbench', 'remd_roof_clock_ghz', 'remd_test_coulomb_table',
     'remd_comm_unique_id', 'remd_comm_init', 'remd_comm_all_gather_energies', 'remd_comm_finalize',
 ]
 
@@ -118,6 +118,7 @@ def load_library(path=None):
     lib.remd_profile_reset.argtypes = [vp]
     lib.remd_profile_filter.argtypes = [vp, C.c_char_p]
     lib.remd_roof_microbench.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+    lib.remd_roof_clock_ghz.argtypes = [vp, c_double_p]
     lib.remd_test_coulomb_table.argtypes = [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     for name in EXPORTS:
         if name not in ('remd_last_error',):
@@ -431,7 +432,13 @@ class HipEngine:
         """Achievable roofs of this box: STREAM triad GB/s, v_fma_f32 and v_pk_fma_f32 TFLOP/s (include/remd_hip.h)."""
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         self._check(self.lib.remd_roof_microbench(self.h, C.byref(a), C.byref(b), C.byref(c)), 'remd_roof_microbench')
-        return dict(stream_triad_gb_per_s=a.value, fma_f32_tflop_per_s=b.value, pk_fma_f32_tflop_per_s=c.value)
+        out = dict(stream_triad_gb_per_s=a.value, fma_f32_tflop_per_s=b.value, pk_fma_f32_tflop_per_s=c.value)
+        g = C.c_double()
+        if self.lib.remd_roof_clock_ghz(self.h, C.byref(g)) == 0 and g.value > 0:
+            # 157.3 TFLOP/s = 256 CUs x 4 SIMDs x 32 lanes x 2 flop at 2.4 GHz: what the same issue rate gives at the measured clock
+            out['shader_clock_ghz_under_fma_load'] = g.value
+            out['fma_f32_peak_at_that_clock_tflop_per_s'] = 157.3 * g.value / 2.4
+        return out
 
     def profile_enable(self, on=1, kernel_class=None):
         if kernel_class is not None:

@@ -17,8 +17,12 @@ void roof_triad_kernel(const float4* __restrict__ a, const float4* __restrict__ 
 
 // 16 independent v_fma_f32 chains per lane (enough to cover the dependent-issue latency at 4 waves per SIMD)
 __global__ __launch_bounds__(256)
-void roof_fma_kernel(float* __restrict__ out, int iters, float seed)
+void roof_fma_kernel(float* __restrict__ out, int iters, float seed, unsigned long long* __restrict__ clk = nullptr)
 {
+    // clk: shader cycles (s_memtime) and 100 MHz wall-clock ticks spent by wavefront 0 inside the FMA loop: the clock the chip
+    // sustains under this load (the 157.3 TFLOP/s vector peak is quoted at 2.4 GHz)
+    const bool stamp = clk && blockIdx.x == 0 && threadIdx.x == 0;
+    const unsigned long long c0 = stamp ? clock64() : 0ull, w0 = stamp ? wall_clock64() : 0ull;
     float a[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = seed + 0.001f * (float)(threadIdx.x + k);
@@ -31,6 +35,7 @@ void roof_fma_kernel(float* __restrict__ out, int iters, float seed)
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += a[k];
     if (s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;      // never true: keeps the chains alive
+    if (stamp) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
 // the same with v_pk_fma_f32 (two f32 FMAs per lane per instruction): the form the 157.3 TFLOP/s vector peak counts
@@ -77,9 +82,9 @@ extern "C" int remd_roof_microbench(remd_handle h, double* stream_gb_per_s, doub
     const int blocks = 256 * 8, iters = 8192;
     REMD_CHECK(h, hipMalloc(&out, sizeof(float) * blocks * 256));
     if (fma_tflop_per_s) {
-        hipLaunchKernelGGL(roof_fma_kernel, dim3(blocks), dim3(256), 0, h->stream, out, 64, 1.0f);
+        hipLaunchKernelGGL(roof_fma_kernel, dim3(blocks), dim3(256), 0, h->stream, out, 64, 1.0f, (unsigned long long*)nullptr);
         hipEventRecord(e0, h->stream);
-        hipLaunchKernelGGL(roof_fma_kernel, dim3(blocks), dim3(256), 0, h->stream, out, iters, 1.0f);
+        hipLaunchKernelGGL(roof_fma_kernel, dim3(blocks), dim3(256), 0, h->stream, out, iters, 1.0f, (unsigned long long*)nullptr);
         hipEventRecord(e1, h->stream);
         REMD_CHECK(h, hipEventSynchronize(e1));
         hipEventElapsedTime(&ms, e0, e1);
@@ -96,5 +101,25 @@ extern "C" int remd_roof_microbench(remd_handle h, double* stream_gb_per_s, doub
     }
     hipFree(out);
     hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
+
+// The shader clock under sustained v_fma_f32 load (one full-occupancy launch of roof_fma_kernel, cycles / wall time of one
+// wavefront): explains measured_roofs.fma_f32 against the 157.3 TFLOP/s spec, which assumes 2.4 GHz.
+extern "C" int remd_roof_clock_ghz(remd_handle h, double* ghz_under_fma_load)
+{
+    if (!h || !ghz_under_fma_load) return -1;
+    hipSetDevice(h->device);
+    float* out = nullptr; unsigned long long* clk = nullptr;
+    const int blocks = 256 * 8, iters = 8192;
+    REMD_CHECK(h, hipMalloc(&out, sizeof(float) * blocks * 256));
+    REMD_CHECK(h, hipMalloc(&clk, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(roof_fma_kernel, dim3(blocks), dim3(256), 0, h->stream, out, 64, 1.0f, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(roof_fma_kernel, dim3(blocks), dim3(256), 0, h->stream, out, iters, 1.0f, clk);
+    unsigned long long hc[2] = {0, 0};
+    REMD_CHECK(h, hipMemcpyAsync(hc, clk, sizeof(hc), hipMemcpyDeviceToHost, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    hipFree(out); hipFree(clk);
+    *ghz_under_fma_load = hc[1] > 0 ? (double)hc[0] / ((double)hc[1] * 10.0) : 0.0;     // cycles / (ticks * 10 ns) in GHz
     return 0;
 }
