@@ -208,6 +208,14 @@ int  remd_minimize(remd_handle h, double tolerance_kj_per_mol_nm, int max_iterat
 int  remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local,
                        const double* x, const double* v, const double* box,
                        const int64_t* labels);
+
+/* What keys the random streams of the local replicas (velocity reassignment, Ornstein-Uhlenbeck noise, Metropolis and barostat
+   draws): by default the global replica index r_begin + r of remd_set_replicas, which makes a trajectory independent of how the
+   ensemble is sharded.  A host that gives one handle a NON-CONTIGUOUS subset of the ensemble (one handle per compatibility group of
+   states: states.py:186-217, multistatesampler.py:1296-1320 propagates a replica in the Context of its own state's System) passes the
+   subset's global indices here, after remd_set_replicas (which resets them); NULL restores the default.                       */
+int  remd_set_replica_ids(remd_handle h, const int64_t* global_replica_index /* [R_local] or NULL */);
+
 int  remd_set_labels(remd_handle h, const int64_t* labels /*[R_global]*/);
 int  remd_seed(remd_handle h, uint64_t seed);
 

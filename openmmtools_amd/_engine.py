@@ -40,7 +40,7 @@ class RemdSystemDesc(C.Structure):
 
 EXPORTS = [
     'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_states',
-    'remd_set_integrator', 'remd_set_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
+    'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
@@ -97,6 +97,7 @@ def load_library(path=None):
     lib.remd_get_barostat_stats.argtypes = [vp, c_double_p, c_int64_p, c_int64_p]
     lib.remd_barostat_attempts.argtypes = [vp, C.c_int]
     lib.remd_set_replicas.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]
+    lib.remd_set_replica_ids.argtypes = [vp, c_int64_p]
     lib.remd_set_labels.argtypes = [vp, c_int64_p]
     lib.remd_seed.argtypes = [vp, C.c_uint64]
     lib.remd_propagate.argtypes = [vp, C.c_int64, c_int32_p]
@@ -335,6 +336,14 @@ class HipEngine:
         self._check(self.lib.remd_set_replicas(self.h, int(R_global), int(r_begin), R_local, _dp(x), _dp(v),
                                                _dp(box), _lp(labels)), 'remd_set_replicas')
         self.R, self.R_global, self.r_begin = R_local, int(R_global), int(r_begin)
+
+    def set_replica_ids(self, ids):
+        """Global replica indices that key the local replicas' random streams (a handle holding a non-contiguous subset of the
+        ensemble: multistate/_engine_pool.py); None restores r_begin + r.  Call after set_replicas."""
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        if ids is not None and ids.shape != (self.R,):
+            raise ValueError('one id per local replica')
+        self._check(self.lib.remd_set_replica_ids(self.h, _lp(ids)), 'remd_set_replica_ids')
 
     def set_labels(self, labels):
         labels = np.ascontiguousarray(labels, dtype=np.int64)

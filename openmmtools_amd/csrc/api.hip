@@ -133,7 +133,7 @@ int remd_destroy(remd_handle h)
     for (int g = 0; g < 4; ++g) dfree(h->d_force_g[g]);
     dfree(h->d_ukl); dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
     dfree(h->d_pressure); dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
-    dfree(h->d_mix_log);
+    dfree(h->d_mix_log); dfree(h->d_noise_id);
     dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
@@ -247,6 +247,22 @@ int remd_set_force_groups(remd_handle h, const int32_t* groups)
     return 0;
 }
 
+int remd_set_replica_ids(remd_handle h, const int64_t* ids)
+{
+    if (!h || h->R <= 0) return remd_fail(h, -1, "remd_set_replica_ids: call remd_set_replicas first");
+    hipSetDevice(h->device);
+    if (h->d_noise_id) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_noise_id); h->d_noise_id = nullptr; }
+    if (!ids) return 0;                                   // back to the block's own global indices
+    std::vector<unsigned int> v(h->R);
+    for (int r = 0; r < h->R; ++r) {
+        if (ids[r] < 0 || ids[r] > 0xffffffffll) return remd_fail(h, -1, "remd_set_replica_ids: ids must fit 32 bits");
+        v[r] = (unsigned int)ids[r];
+    }
+    REMD_CHECK(h, hipMalloc(&h->d_noise_id, sizeof(unsigned int) * h->R));
+    REMD_CHECK(h, hipMemcpy(h->d_noise_id, v.data(), sizeof(unsigned int) * h->R, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int remd_set_labels(remd_handle h, const int64_t* labels)
 {
     if (!h || !labels || h->R_global <= 0) return remd_fail(h, -1, "remd_set_labels: replicas not set");
@@ -266,6 +282,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         return remd_fail(h, -1, "remd_set_replicas: bad arguments");
     hipSetDevice(h->device);
     const bool realloc = (R_local != h->R) || (R_global != h->R_global) || !h->d_pos;
+    if (h->d_noise_id) { hipStreamSynchronize(h->stream); hipFree(h->d_noise_id); h->d_noise_id = nullptr; }     // ids belong to one set of replicas
     h->R_global = R_global; h->r_begin = r_begin; h->R = R_local;
     const size_t n = (size_t)R_local * h->Npad;
     if (realloc) {

@@ -10,7 +10,7 @@
 // u' > exp(-w / kT);  after >= 10 attempts volumeScale /= 1.1 below 25 % acceptance, *= 1.1 (capped at 0.3 V) above 75 %.
 // All local replicas attempt at once, each with its own state's p and kT and its own Philox draws.
 __global__ void baro_draw_kernel(int R, int r_begin, uint64_t seed, long long attempt, float* __restrict__ box,
-                                 float* __restrict__ box_old, double* __restrict__ st)
+                                 float* __restrict__ box_old, double* __restrict__ st, const unsigned int* __restrict__ noise_id)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
@@ -18,7 +18,7 @@ __global__ void baro_draw_kernel(int R, int r_begin, uint64_t seed, long long at
     const double Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const double V = Lx * Ly * Lz;
     if (S[0] <= 0.0) S[0] = 0.01 * V;                                   // initial volumeScale (MonteCarloBarostatImpl::initialize)
-    const philox4 w = remd_philox(seed, REMD_STREAM_BAROSTAT, 0u, (uint32_t)(r_begin + r), (uint64_t)attempt);
+    const philox4 w = remd_philox(seed, REMD_STREAM_BAROSTAT, 0u, noise_id ? noise_id[r] : (uint32_t)(r_begin + r), (uint64_t)attempt);
     const double dV = S[0] * 2.0 * (remd_u53(w.w[2], w.w[3]) - 0.5);
     const double newV = V + dV;
     const double scale = cbrt(newV / V);
@@ -53,7 +53,7 @@ __global__ void baro_decide_kernel(int R, int r_begin, uint64_t seed, long long 
                                    const double* __restrict__ beta, const double* __restrict__ pressure,
                                    const double* __restrict__ econst, double econst_vref,
                                    float* __restrict__ box, const float* __restrict__ box_old, double* __restrict__ st,
-                                   int* __restrict__ accepted)
+                                   int* __restrict__ accepted, const unsigned int* __restrict__ noise_id)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
@@ -63,7 +63,7 @@ __global__ void baro_decide_kernel(int R, int r_begin, uint64_t seed, long long 
     // + the current state's long-range constant ~ 1/V (alchemical sterics correction), which d_potential does not carry
     const double dlr = (econst_vref > 0.0) ? econst[k] * econst_vref * (1.0 / S[6] - 1.0 / S[7]) : 0.0;
     const double w = U_new[r] - U_old[r] + dlr + pressure[k] * S[5] - (double)n_mol * kT * log(S[6] / S[7]);
-    const philox4 q = remd_philox(seed, REMD_STREAM_BAROSTAT, 1u, (uint32_t)(r_begin + r), (uint64_t)attempt);
+    const philox4 q = remd_philox(seed, REMD_STREAM_BAROSTAT, 1u, noise_id ? noise_id[r] : (uint32_t)(r_begin + r), (uint64_t)attempt);
     const bool reject = !(w <= 0.0) && !(remd_u53(q.w[2], q.w[3]) <= exp(-w / kT));     // NaN energies reject
     accepted[r] = reject ? 0 : 1;
     if (reject) { box[4 * r] = box_old[4 * r]; box[4 * r + 1] = box_old[4 * r + 1]; box[4 * r + 2] = box_old[4 * r + 2]; }
@@ -112,7 +112,7 @@ int remd_barostat_attempt(remd_ctx* h)
     REMD_CHECK(h, hipMemcpyAsync(h->d_baro_x0, h->d_pos, sizeof(float4) * (size_t)R * Npad, hipMemcpyDeviceToDevice, h->stream));
     const long long attempt = h->baro_attempts++;
     hipLaunchKernelGGL(baro_draw_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, h->r_begin, h->seed, attempt, h->d_box,
-                       h->d_box_old, h->d_baro);
+                       h->d_box_old, h->d_baro, h->d_noise_id);
     hipLaunchKernelGGL(baro_scale_kernel, dim3((n_groups + 255) / 256, R), dim3(256), 0, h->stream, n_groups, grp_first,
                        grp_size, Npad, h->d_pos, h->d_box_old, h->d_baro);
     h->box_uniform = false;                  // (every replica draws its own volume)
@@ -121,7 +121,7 @@ int remd_barostat_attempt(remd_ctx* h)
     if ((rc = remd_compute_forces(h, true))) return rc;                         // U' and forces of the scaled configuration
     hipLaunchKernelGGL(baro_decide_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, h->r_begin, h->seed, attempt, n_groups,
                        h->d_baro_U0, h->d_potential, h->d_labels, h->d_beta, h->d_pressure, h->d_econst, h->econst_vref, h->d_box, h->d_box_old, h->d_baro,
-                       h->d_baro_acc);
+                       h->d_baro_acc, h->d_noise_id);
     hipLaunchKernelGGL(baro_restore_kernel, dim3((h->N + 255) / 256, R), dim3(256), 0, h->stream, h->N, Npad, h->d_baro_acc, h->d_pos,
                        h->d_baro_x0, h->d_force, h->d_baro_f0, h->d_potential, h->d_baro_U0);
     h->box_version++;

@@ -385,7 +385,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
                             unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
                             unsigned int* chain_sync, unsigned int* chain_sync_err,
                             unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold,
-                            remd_fold_args fold)
+                            remd_fold_args fold, const unsigned int* __restrict__ noise_id)
 {
     if (fold.done) {
         // remd_fold_args: wait until every workgroup of the direct-space stream's last launch has counted itself done (their force
@@ -438,7 +438,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
     const long long* F = force + (size_t)r * 3 * Npad;
     long long* Fw = force + (size_t)r * 3 * Npad;
     const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
-    const uint32_t rg = (uint32_t)(r_begin + r);
+    const uint32_t rg = noise_id ? noise_id[r] : (uint32_t)(r_begin + r);
     const long long* cr = cmm + ((size_t)max(cmm_r_eff, 0) * gridDim.y + r) * 4;
     unit_regs S;
 #ifdef CHAIN_STAMPS
@@ -550,7 +550,8 @@ void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
                               const unsigned char* __restrict__ unit_type, settle_const sc, float tol,
                               int Npad, const float4* __restrict__ pos, float4* __restrict__ vel,
                               const float* __restrict__ invmass, const int64_t* __restrict__ labels,
-                              const double* __restrict__ beta, int r_begin, uint64_t seed, int64_t iteration)
+                              const double* __restrict__ beta, int r_begin, uint64_t seed, int64_t iteration,
+                              const unsigned int* __restrict__ noise_id)
 {
     const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
@@ -562,7 +563,7 @@ void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
     const float4* P = pos + (size_t)r * Npad;
     float4* V = vel + (size_t)r * Npad;
     const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
-    const uint32_t rg = (uint32_t)(r_begin + r);
+    const uint32_t rg = noise_id ? noise_id[r] : (uint32_t)(r_begin + r);
     if (type == UNIT_SETTLE) assign_unit<UNIT_SETTLE, 3>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
     else if (type == UNIT_FREE) assign_unit<UNIT_FREE, 1>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
     else if (a4.z < 0) assign_unit<UNIT_SHAKE, 2>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
@@ -739,7 +740,7 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0),
                        h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2,
                        (h->profiling == 2 || (h->profiling == 1 && h->prof_filter.find("integrate_chain") != std::string::npos)) ? h->d_chain_own : (unsigned long long*)nullptr,
-                       h->d_work, h->d_xold, h->d_vold, h->fold_pending ? h->fold : remd_fold_args());
+                       h->d_work, h->d_xold, h->d_vold, h->fold_pending ? h->fold : remd_fold_args(), h->d_noise_id);
     h->join_deferred = 0; h->fold_pending = false;
     if (bins.count) h->cbins_ready = true;
 }
@@ -759,12 +760,13 @@ __global__ void work_pe_kernel(int R, const double* __restrict__ U, double* __re
 }
 // '}' (:1544-1557): accept = step(exp(-shadow_work / kT) - uniform); trials++; on rejection x = xold, v = -vold; shadow_work = 0
 __global__ void metropolis_kernel(int R, int r_begin, uint64_t seed, long long gstep, int brace, const int64_t* __restrict__ labels,
-                                  const double* __restrict__ beta, long long* __restrict__ work, int* __restrict__ accept)
+                                  const double* __restrict__ beta, long long* __restrict__ work, int* __restrict__ accept,
+                                  const unsigned int* __restrict__ noise_id)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const double sw = (double)work[4 * r + 1] / WORK_SCALE;
-    const philox4 w = remd_philox(seed, REMD_STREAM_METROPOLIS, (uint32_t)brace, (uint32_t)(r_begin + r), (uint64_t)gstep);
+    const philox4 w = remd_philox(seed, REMD_STREAM_METROPOLIS, (uint32_t)brace, noise_id ? noise_id[r] : (uint32_t)(r_begin + r), (uint64_t)gstep);
     const double u = remd_u53(w.w[2], w.w[3]);
     const int acc = (exp(-sw * beta[labels[r_begin + r]]) - u >= 0.0) ? 1 : 0;
     accept[r] = acc;
@@ -824,7 +826,7 @@ struct resident_sys {
     nb_params p;
     float skin, ext_K, ext_x0, inv_total_mass;
     const float4* param; const float* rep_lam; const int* ext_atoms; const float* invmass; const float* box;
-    const int64_t* labels; const double* beta; int r_begin; uint64_t seed;
+    const int64_t* labels; const double* beta; int r_begin; uint64_t seed; const unsigned int* noise_id;
     unsigned int* err;
 };
 
@@ -892,7 +894,7 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
     float lam_a = 1.f, sc = 0.f;
     if (ALCH) { lam_a = S.rep_lam[4 * r]; sc = S.rep_lam[4 * r + 1]; }
     const float kT = frcp((float)S.beta[S.labels[S.r_begin + r]]);
-    const uint32_t rg = (uint32_t)(S.r_begin + r);
+    const uint32_t rg = S.noise_id ? S.noise_id[r] : (uint32_t)(S.r_begin + r);
     const float rl = S.p.rc + S.skin, rl2 = rl * rl, half_skin2 = 0.25f * S.skin * S.skin;
     bool have_list = false, forces_valid = false;
     int n_eval = 0;
@@ -1050,7 +1052,7 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
     if (method >= 0 && !(0.5 * lmin > p.rc)) return 0;
     S.ext_K = (float)h->ext_K; S.ext_x0 = (float)h->ext_x0; S.inv_total_mass = (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0);
     S.param = param; S.rep_lam = rep_lam; S.ext_atoms = h->d_ext_atoms; S.invmass = h->d_invmass; S.box = h->d_box;
-    S.labels = h->d_labels; S.beta = h->d_beta; S.r_begin = h->r_begin; S.seed = h->seed; S.err = h->d_sync + 2;
+    S.labels = h->d_labels; S.beta = h->d_beta; S.r_begin = h->r_begin; S.seed = h->seed; S.err = h->d_sync + 2; S.noise_id = h->d_noise_id;
     const int T = std::max(64, (h->N + 63) / 64 * 64);
     // pair-list capacity from the LDS that is left: positions + parameters (32 B per thread), partial sums / flags, force accumulators
     const size_t fixed = (size_t)T * 32 + 64 * sizeof(float) + (size_t)T * 12 + 8 + (size_t)T * 24;
@@ -1224,7 +1226,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             if (tok == '}') {
                 flush(false);
                 hipLaunchKernelGGL(metropolis_kernel, dim3((h->R + 63) / 64), dim3(64), 0, h->stream, h->R, h->r_begin, h->seed, gstep, brace++,
-                                   h->d_labels, h->d_beta, h->d_work, h->d_accept);
+                                   h->d_labels, h->d_beta, h->d_work, h->d_accept, h->d_noise_id);
                 hipLaunchKernelGGL(metropolis_restore_kernel, dim3((h->N + 255) / 256, h->R), dim3(256), 0, h->stream, h->N, h->Npad, h->d_accept,
                                    h->d_pos, h->d_vel, h->d_xold, h->d_vold);
                 h->forces_valid = false; pe_valid = false;         // rejected replicas are back at their old positions
@@ -1286,7 +1288,7 @@ int remd_assign_velocities(remd_ctx* h, int64_t iteration)
     dim3 grid((ut.n_units + 255) / 256, h->R);
     hipLaunchKernelGGL(assign_velocities_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc,
                        (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_invmass, h->d_labels,
-                       h->d_beta, h->r_begin, h->seed, iteration);
+                       h->d_beta, h->r_begin, h->seed, iteration, h->d_noise_id);
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }

@@ -141,6 +141,9 @@ struct remd_ctx {
 
     // ---- replicas -------------------------------------------------------------------
     int R_global = 0, r_begin = 0, R = 0;     // R = local replicas
+    // remd_set_replica_ids: what keys the local replicas' random streams instead of r_begin + r (a handle that holds a
+    // non-contiguous subset of an ensemble, multistate/_engine_pool.py); NULL: the block's own global indices
+    unsigned int* d_noise_id = nullptr;
     float4* d_pos = nullptr;           // [R][Npad] xyz + pad
     float4* d_vel = nullptr;           // [R][Npad] xyz + pad
     // Monte Carlo barostat (OpenMM MonteCarloBarostat as the reference's NPT ThermodynamicState adds it, states.py:1177-1181)

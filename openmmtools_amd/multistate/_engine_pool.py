@@ -12,23 +12,13 @@ matrix (:1470-1490).  Here a group is an engine handle with its own System table
     mixing        any handle: the swap kernels only see the energy matrix
 
 The master copy of positions / velocities / boxes lives on the host between the calls (a few MB per iteration), which is
-what the reference does with its SamplerStates.  Langevin noise: a group's propagation handle is seeded with a hash of (seed,
-group, first local replica), so streams never coincide between groups or ranks; a run is reproducible for a fixed seed and
-rank count (with ONE group the sampler talks to its engine directly and trajectories are independent of the rank count).
+what the reference does with its SamplerStates.  Random streams: every handle carries the ensemble's seed and a group's share of
+the local replicas is keyed by the replicas' GLOBAL indices (``set_replica_ids`` -> remd_set_replica_ids), exactly as a
+single-group run keys its block by r_begin + r: velocities, Langevin noise and Metropolis draws of a replica do not depend on
+which handle runs it, so a multi-group run is independent of the rank count too (tests/test_compat_groups.py; round 4 -- before,
+handles were seeded per (seed, group, rank offset)).  The Monte Carlo barostat's attempt counter is per handle and still is not.
 """
 import numpy as np
-
-
-def _mix64(*words):
-    """SplitMix64 finaliser over a sequence of integers: a seed per (seed, group, rank offset)."""
-    z = 0x9E3779B97F4A7C15
-    for w in words:
-        z = (z ^ (int(w) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
-        z = (z + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-        z = z ^ (z >> 31)
-    return z
 
 
 class EnginePool:
@@ -102,7 +92,7 @@ class EnginePool:
         for g in range(self.G):
             self._energy[g].seed(seed)                     # (mixing draws from the first handle: the sampler's own stream)
             if self._prop[g] is not None:
-                self._prop[g].seed(_mix64(self._seed, g, getattr(self, 'r_begin', 0)))
+                self._prop[g].seed(self._seed)
 
     def _propagator(self, g):
         if self._prop[g] is None:
@@ -110,7 +100,7 @@ class EnginePool:
             for name, args in self._setup:
                 if hasattr(eng, name):
                     getattr(eng, name)(*args(g))
-            eng.seed(_mix64(self._seed, g, self.r_begin))
+            eng.seed(self._seed)
             self._prop[g] = eng
         return self._prop[g]
 
@@ -123,9 +113,6 @@ class EnginePool:
         self._box = np.array(box, dtype=np.float64).reshape(self.R, 3)
         self._energy_current = False
         self.set_labels(labels)
-        for g in range(self.G):
-            if self._prop[g] is not None:
-                self._prop[g].seed(_mix64(self._seed, g, self.r_begin))
 
     def set_labels(self, labels):
         self._labels = np.array(labels, dtype=np.int64)
@@ -152,6 +139,8 @@ class EnginePool:
                 continue
             eng = self._propagator(g)
             eng.set_replicas(len(idx), 0, self._x[idx], self._v[idx], self._box[idx], loc[idx])
+            if hasattr(eng, 'set_replica_ids'):
+                eng.set_replica_ids(self.r_begin + idx)              # noise keyed by the global replica index, whatever the grouping
             out[g] = (idx, call(eng))
             x, v, _, _ = eng.get_replicas()
             self._x[idx], self._v[idx] = x, v

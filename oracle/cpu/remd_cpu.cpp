@@ -770,6 +770,7 @@ struct remd_ctx {
     std::vector<char> tokens; int nV = 0, nR = 0, nO = 0;
     double dt = 0, gamma = 0; int n_steps = 0, reassign = 0, n_restart_attempts = 0;
     double coulomb_cutoff = 0;
+    std::vector<uint32_t> noise_ids;   // remd_set_replica_ids: keys of the local replicas' random streams (empty: r_begin + r)
     int measure_heat = 0, measure_shadow = 0;
     int R = 0, R_global = 0, r_begin = 0;
     std::vector<Replica> reps;
@@ -849,6 +850,8 @@ static void ensure_forces(remd_ctx* h, int r)
 
 static void barostat_attempt(remd_ctx* h, int r, long long attempt);
 
+static inline uint32_t noise_key(const remd_ctx* h, int r) { return h->noise_ids.empty() ? (uint32_t)(h->r_begin + r) : h->noise_ids[r]; }
+
 // integrators.py:1309-1317, 1404-1460 for one replica (cf. oracle/md_oracle.py:OracleLangevin.run)
 static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int nV, int nR, int nO, int64_t iteration,
                       int64_t first_step, int n_steps, bool with_barostat = false)
@@ -889,7 +892,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                 xold = rep.x; vold = rep.v;
             } else if (tok == '}') {                                                                                     // :1544-1557
                 uint32_t w[4];
-                oracle_draw(h->seed, 7u, (uint32_t)brace, (uint32_t)rg, (uint64_t)gstep, w);
+                oracle_draw(h->seed, 7u, (uint32_t)brace, noise_key(h, r), (uint64_t)gstep, w);
                 const double u = (double)(((uint64_t)w[2] << 21) | (uint64_t)(w[3] >> 11)) / 9007199254740992.0;
                 rep.n_trials++;
                 if (!(exp(-rep.shadow / kT) - u >= 0.0)) {
@@ -921,7 +924,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                 const double ke0 = m_heat ? ke() : 0.0;
                 const uint64_t cnt = (uint64_t)gstep * (uint64_t)std::max(1, nO) + (uint64_t)oidx;
                 for (int i = 0; i < N; ++i) {
-                    double g[3]; gaussians3(h->seed, 5u, i, rg, cnt, g);
+                    double g[3]; gaussians3(h->seed, 5u, i, (int)noise_key(h, r), cnt, g);
                     const double sg = b * sqrt(kT * s.invm[i]);
                     for (int k = 0; k < 3; ++k) v[3 * i + k] = a * v[3 * i + k] + sg * g[k];                             // :1455
                 }
@@ -940,7 +943,7 @@ static void assign_velocities(remd_ctx* h, int r, int64_t iteration)
     const int rg = h->r_begin + r;
     const double kT = 1.0 / h->beta[h->labels[rg]];
     for (int i = 0; i < s.N; ++i) {                                       // mcmc.py:710-711
-        double g[3]; gaussians3(h->seed, 4u, i, rg, (uint64_t)iteration, g);
+        double g[3]; gaussians3(h->seed, 4u, i, (int)noise_key(h, r), (uint64_t)iteration, g);
         const double sg = sqrt(kT * s.invm[i]);
         for (int k = 0; k < 3; ++k) rep.v[3 * i + k] = sg * g[k];
     }
@@ -1009,7 +1012,7 @@ static void barostat_attempt(remd_ctx* h, int r, long long attempt)
     const double V = rep.box[0] * rep.box[1] * rep.box[2];
     if (rep.baro[0] <= 0.0) rep.baro[0] = 0.01 * V;
     uint32_t w[4];
-    oracle_draw(h->seed, 6u, 0u, (uint32_t)rg, (uint64_t)attempt, w);
+    oracle_draw(h->seed, 6u, 0u, noise_key(h, r), (uint64_t)attempt, w);
     auto u53 = [](uint32_t hi, uint32_t lo) { return (double)(((uint64_t)hi << 21) | (uint64_t)(lo >> 11)) / 9007199254740992.0; };
     const double dV = rep.baro[0] * 2.0 * (u53(w[2], w[3]) - 0.5);
     const double newV = V + dV, scale = cbrt(newV / V);
@@ -1029,7 +1032,7 @@ static void barostat_attempt(remd_ctx* h, int r, long long attempt)
     rep.list_valid = false;
     const double U1 = evaluate(s, rep, h->lam_s[k], h->lam_e[k], nullptr, fft).total();
     const double wgt = U1 - U0 + c_lr * (1.0 / newV - 1.0 / V) + p * dV - (double)s.molecules.size() * kT * log(newV / V);
-    oracle_draw(h->seed, 6u, 1u, (uint32_t)rg, (uint64_t)attempt, w);
+    oracle_draw(h->seed, 6u, 1u, noise_key(h, r), (uint64_t)attempt, w);
     const bool reject = !(wgt <= 0.0) && !(u53(w[2], w[3]) <= exp(-wgt / kT));
     if (reject) { rep.x = x0; for (int q = 0; q < 3; ++q) rep.box[q] = box0[q]; rep.list_valid = false; }
     else { rep.baro[2] += 1; rep.baro[4] += 1; }
@@ -1301,6 +1304,18 @@ int remd_test_coulomb_table(double alpha, double coulomb_cutoff_nm, int n, const
     return 0;
 }
 
+int remd_set_replica_ids(remd_handle h, const int64_t* ids)
+{
+    if (!h || h->reps.empty()) return fail(h, -1, "remd_set_replica_ids: call remd_set_replicas first");
+    h->noise_ids.clear();
+    if (!ids) return 0;
+    for (size_t r = 0; r < h->reps.size(); ++r) {
+        if (ids[r] < 0 || ids[r] > 0xffffffffll) { h->noise_ids.clear(); return fail(h, -1, "remd_set_replica_ids: ids must fit 32 bits"); }
+        h->noise_ids.push_back((uint32_t)ids[r]);
+    }
+    return 0;
+}
+
 int remd_set_coulomb_cutoff(remd_handle h, double coulomb_cutoff_nm)
 {
     if (!h || !(coulomb_cutoff_nm >= 0.0)) return fail(h, -1, "remd_set_coulomb_cutoff: bad arguments");
@@ -1384,6 +1399,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         return fail(h, -1, "remd_set_replicas: bad arguments");
     const int N = h->sys.N;
     h->R_global = R_global; h->r_begin = r_begin; h->R = R_local;
+    h->noise_ids.clear();                   // (ids belong to one set of replicas)
     h->reps.assign(R_local, Replica());
     for (int r = 0; r < R_local; ++r) {
         Replica& rep = h->reps[r];

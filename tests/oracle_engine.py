@@ -80,6 +80,14 @@ class OracleEngine:
         self.v = np.zeros_like(self.x) if v is None else np.array(v, dtype=np.float64)
         self.box = np.array(box, dtype=np.float64).reshape(self.R, 3)
         self.labels = np.array(labels, dtype=np.int64)
+        self.noise_ids = None                     # (ids belong to one set of replicas: include/remd_hip.h remd_set_replica_ids)
+
+    def set_replica_ids(self, ids):
+        self.noise_ids = None if ids is None else np.array(ids, dtype=np.int64)
+
+    def _nk(self, r):
+        ids = getattr(self, 'noise_ids', None)
+        return int(self.r_begin + r) if ids is None else int(ids[r])
 
     def set_labels(self, labels):
         self.labels = np.array(labels, dtype=np.int64)
@@ -106,7 +114,7 @@ class OracleEngine:
             # number rides in the high bits of the iteration counter, as in remd_propagate)
             for attempt in range(getattr(self, 'n_restart_attempts', 0) + 1):
                 it = iteration + (attempt << 40)
-                v = integ.assign_velocities(x0, kT, rg, it) if self.reassign else v0
+                v = integ.assign_velocities(x0, kT, self._nk(r), it) if self.reassign else v0
                 self._work_of(integ, r)
                 if getattr(self, 'pressure', None) is not None:
                     if self._baro is None:
@@ -115,10 +123,10 @@ class OracleEngine:
                     baro = dict(obj=self._baro, pressure=self.pressure[k], frequency=self.baro_frequency,
                                 steps_done=self._baro_steps, attempts_done=self._baro_attempts,
                                 long_range=(self.econst[k] * vref) if vref > 0 else 0.0)
-                    self.x[r], self.v[r], self.box[r] = integ.run(x0, v, self._box(r), kT, rg, it, lambda_sterics=self.lam_s[k],
+                    self.x[r], self.v[r], self.box[r] = integ.run(x0, v, self._box(r), kT, self._nk(r), it, lambda_sterics=self.lam_s[k],
                                                                   lambda_electrostatics=self.lam_e[k], barostat=baro)
                 else:
-                    self.x[r], self.v[r] = integ.run(x0, v, self._box(r), kT, rg, it,
+                    self.x[r], self.v[r] = integ.run(x0, v, self._box(r), kT, self._nk(r), it,
                                                      lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
                 flags[r] = 0 if (np.isfinite(self.x[r]).all() and np.isfinite(self.v[r]).all()) else 1
                 if not flags[r]:
@@ -141,7 +149,7 @@ class OracleEngine:
                 rg = self.r_begin + r
                 k = self.labels[rg]
                 lr = (self.econst[k] * vref) if vref > 0 else 0.0
-                self.x[r], self.box[r], _ = self._baro.attempt(self.x[r], self._box(r), 1.0 / self.beta[k], self.pressure[k], rg,
+                self.x[r], self.box[r], _ = self._baro.attempt(self.x[r], self._box(r), 1.0 / self.beta[k], self.pressure[k], self._nk(r),
                                                                self._baro_attempts, long_range=lr,
                                                                lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
             self._baro_attempts += 1
@@ -164,7 +172,7 @@ class OracleEngine:
             rg = self.r_begin + r
             k = self.labels[rg]
             self._work_of(integ, r, [c for c in splitting.upper() if c != ' '])
-            self.x[r], self.v[r] = integ.run(self.x[r], self.v[r], self._box(r), 1.0 / self.beta[k], rg, iteration,
+            self.x[r], self.v[r] = integ.run(self.x[r], self.v[r], self._box(r), 1.0 / self.beta[k], self._nk(r), iteration,
                                              first_step=first_step, n_steps=n_steps,
                                              tokens=[c for c in splitting.upper() if c != ' '],
                                              lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])

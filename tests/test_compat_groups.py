@@ -52,11 +52,16 @@ def test_energy_matrix_and_propagation_follow_each_states_own_system():
     replica is propagated by the System of its current state: without mixing (MultiStateSampler) its positions spread with
     that state's sigma."""
     sampled, unsampled, ss, f_i, K_i = _oscillators()
-    s = MultiStateSampler(mcmc_moves=_move(40), number_of_iterations=120, engine=OracleEngine(), seed=7)
+    # collision rate 5 / ps here (near critical damping for these wells: positions decorrelate within ~0.5 ps; the 20 / ps of the
+    # other tests is overdamped, relaxation time gamma / omega^2 up to 4 ps, and would leave a handful of independent samples)
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=4.0 * unit.femtosecond, collision_rate=5.0 / unit.picosecond, n_steps=120,
+                                              reassign_velocities=True, splitting='V R O R V')
+    n_iter = 240
+    s = MultiStateSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=OracleEngine(), seed=7)
     import copy
     s.create(sampled, [copy.deepcopy(ss) for _ in range(5)], storage=None, unsampled_thermodynamic_states=unsampled)
     x2 = np.zeros(5)
-    for it in range(120):
+    for it in range(n_iter):
         s.run(1)
         x = np.stack([st.positions for st in s.sampler_states])[:, 0, :]
         r2 = (x ** 2).sum(axis=1)
@@ -65,7 +70,9 @@ def test_energy_matrix_and_propagation_follow_each_states_own_system():
         x2 += r2 / 3.0
     sigma2 = KT / K_i[1:-1]
     assert list(s.replica_thermodynamic_states) == [0, 1, 2, 3, 4]
-    assert np.all(np.abs(x2 / 120 / sigma2 - 1.0) < 0.35), x2 / 120 / sigma2       # 360 samples per state: ~8 % standard error
+    # 115 ps per replica; measured autocorrelation time of |x|^2 ~ 1 ps (velocities are redrawn every 0.48 ps): ~100 independent
+    # samples of a chi^2_3 variable, ~8 % standard error of the variance -- the bound is four of them
+    assert np.all(np.abs(x2 / n_iter / sigma2 - 1.0) < 0.35), x2 / n_iter / sigma2
 
 
 @pytest.mark.parametrize('cls', [ReplicaExchangeSampler, SAMSSampler])
@@ -173,3 +180,41 @@ def test_lj_fluids_of_different_well_depths_exchange_on_the_device(hip_engine_fa
         ref = np.array([[beta * o.energy_forces(x[r], box)[0] for o in oracles] for r in range(3)])
         assert np.allclose(s.energy_thermodynamic_states, ref, rtol=1e-5, atol=1e-4), np.abs(s.energy_thermodynamic_states - ref).max()
     assert len(seen) > 1                                             # neighbouring well depths overlap: swaps are accepted
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('system_name', ['LennardJonesFluid', 'AlanineDipeptideExplicit'])
+def test_a_handle_holding_a_subset_keyed_by_global_indices_reproduces_those_replicas(hip_engine_factory, system_name):
+    """remd_set_replica_ids (round 4): velocity reassignment and Langevin noise are keyed by what the host says a replica's global
+    index is, so a handle that holds replicas {1, 3} of a four-replica ensemble (one handle per compatibility group,
+    _engine_pool.py) moves them exactly as the handle that holds all four does -- on the resident small-system kernel (LJ fluid)
+    and on the integrator chain (alanine dipeptide, constraints + PME)."""
+    from openmmtools_amd.system import system_to_desc
+    tsys = testsystems.LennardJonesFluid(nparticles=216) if system_name == 'LennardJonesFluid' else testsystems.AlanineDipeptideExplicit()
+    desc = system_to_desc(tsys.system)
+    box = np.diag(tsys.system.getDefaultPeriodicBoxVectors())
+    rng = np.random.default_rng(5)
+    x = np.stack([tsys.positions + 0.002 * rng.normal(size=tsys.positions.shape) for _ in range(4)])
+    beta = 1.0 / (kB * np.array([300.0, 330.0, 360.0, 400.0]))
+    out = {}
+    for name, sel in (('all', [0, 1, 2, 3]), ('subset', [1, 3])):
+        eng = hip_engine_factory()
+        eng.set_system(desc)
+        eng.set_states(beta)
+        eng.set_integrator('V R O R V', 0.002 if system_name != 'LennardJonesFluid' else 0.001, 1.0, 20, True, 1e-8)
+        eng.seed(11)
+        eng.set_replicas(len(sel), 0, x[sel], None, np.tile(box, (len(sel), 1)), np.array(sel, dtype=np.int64))   # labels = own temperature
+        if name == 'subset':
+            eng.set_replica_ids(sel)
+        eng.propagate(3)
+        out[name] = eng.get_replicas()[:2]
+    for k in range(2):
+        assert np.array_equal(out['subset'][k], out['all'][k][[1, 3]])
+    # and without the ids the subset is keyed 0, 1: another trajectory
+    eng = hip_engine_factory()
+    eng.set_system(desc); eng.set_states(beta)
+    eng.set_integrator('V R O R V', 0.002 if system_name != 'LennardJonesFluid' else 0.001, 1.0, 20, True, 1e-8)
+    eng.seed(11)
+    eng.set_replicas(2, 0, x[[1, 3]], None, np.tile(box, (2, 1)), np.array([1, 3], dtype=np.int64))
+    eng.propagate(3)
+    assert not np.array_equal(eng.get_replicas()[0], out['subset'][0])

@@ -61,9 +61,14 @@ def test_sharded_run_equals_single_process(tmp_path, kind):
 def test_sharded_run_with_several_compatibility_groups(tmp_path):
     """States on different Systems (one engine handle per group on every rank, multistate/_engine_pool.py) under two ranks:
     every rank holds the same gathered energy matrix and labels, swaps happen, and the stored energies are those of the stored
-    positions in every state's own System (u = beta K_k |x|^2 / 2).  (The Langevin noise of a group's batch is keyed by group and
-    rank offset, so this run is reproducible but not the single-process trajectory.)"""
+    positions in every state's own System (u = beta K_k |x|^2 / 2).  Round 4: a group's batch is keyed by the replicas' GLOBAL
+    indices (remd_set_replica_ids), so the two-rank run IS the single-process trajectory -- labels, energy matrix, counts and
+    positions bit for bit -- like a single-group run."""
     from openmmtools_amd.constants import kB
+    import dist_worker
+    from openmmtools_amd.multistate.comm import SingleProcessComm
+    os.makedirs(tmp_path / 'single')
+    ref_hist, ref_x, _ = dist_worker.run('groups', SingleProcessComm(), storage_dir=str(tmp_path / 'single'))
     port = 29850 + (os.getpid() % 100)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(HERE, 'dist_worker.py'), 'groups', str(tmp_path)]
@@ -73,6 +78,10 @@ def test_sharded_run_with_several_compatibility_groups(tmp_path):
     assert np.array_equal(ranks[0]['labels'], ranks[1]['labels']) and np.array_equal(ranks[0]['ukl'], ranks[1]['ukl'])
     assert np.array_equal(ranks[0]['nacc'], ranks[1]['nacc']) and ranks[0]['nacc'].sum() > 0
     assert all(sorted(l) == [0, 1, 2, 3] for l in ranks[0]['labels'])
+    for it, (labels, ukl, nacc, nprop) in enumerate(ref_hist):           # rank-count invariance
+        assert np.array_equal(ranks[0]['labels'][it], labels) and np.array_equal(ranks[0]['ukl'][it], ukl)
+        assert np.array_equal(ranks[0]['nacc'][it], nacc) and np.array_equal(ranks[0]['nprop'][it], nprop)
+    assert np.array_equal(np.concatenate([z['x_local'] for z in ranks]), ref_x)
     from openmmtools_amd.multistate import MultiStateReporter
     rep = MultiStateReporter(os.path.join(tmp_path, 'store'), open_mode='r')
     K = np.array([kB * 300.0 / (0.1 * (1.2 + 0.2 * i)) ** 2 for i in range(4)])
