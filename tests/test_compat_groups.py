@@ -165,7 +165,7 @@ def test_lj_fluids_of_different_well_depths_exchange_on_the_device(hip_engine_fa
     ss = states.SamplerState(fluids[0].positions, box_vectors=fluids[0].system.getDefaultPeriodicBoxVectors())
     move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=5.0 / unit.picosecond, n_steps=20,
                                               reassign_velocities=True, splitting='V R O R V')
-    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=8, engine=hip_engine_factory(), seed=9)
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=32, engine=hip_engine_factory(), seed=9)
     s.create(thermo, [ss], storage=None)
     s.minimize(max_iterations=60)
     assert isinstance(s._engine, EnginePool) and s._engine.G == 3
@@ -173,9 +173,11 @@ def test_lj_fluids_of_different_well_depths_exchange_on_the_device(hip_engine_fa
     box = np.diag(fluids[0].system.getDefaultPeriodicBoxVectors())
     beta = 1.0 / (kB * 120.0)
     seen = set()
-    for it in range(8):
+    for it in range(32):                                                  # (a statistical statement: enough iterations for a swap whatever the noise)
         s.run(1)
         seen.add(tuple(s.replica_thermodynamic_states))
+        if it >= 8 and len(seen) > 1:
+            break
         x = np.stack([st.positions for st in s.sampler_states])
         ref = np.array([[beta * o.energy_forces(x[r], box)[0] for o in oracles] for r in range(3)])
         assert np.allclose(s.energy_thermodynamic_states, ref, rtol=1e-5, atol=1e-4), np.abs(s.energy_thermodynamic_states - ref).max()
