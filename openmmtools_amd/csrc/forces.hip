@@ -68,6 +68,7 @@ struct nb_tables {
     int n_groups = 0; int* d_grp_first = nullptr; int* d_grp_size = nullptr;
     int* d_order = nullptr;               // [R][Npad] sorted slot -> atom (-1: padding)
     float4* d_spos = nullptr;             // [R][Npad] positions in sorted order (refreshed every evaluation)
+    float4* d_sposi = nullptr;            // [R][Npad] the same as 32-bit box fractions (bit patterns in x, y, z) + charge in w
     float4* d_sparam = nullptr;           // [R][Npad]
     unsigned long long* d_smask = nullptr;// [R][Npad][excl_words]
     float4* d_tile_c = nullptr; float4* d_tile_h = nullptr;   // [R][ntile] bounding-box centre / half extent
@@ -395,7 +396,7 @@ __device__ __forceinline__
 void gather_positions_body(int tile, int nt, int r, int lane, int Npad, int Npad_pos, const int* __restrict__ order,
                            const float4* __restrict__ pos, const float* __restrict__ box, float4* __restrict__ spos,
                            float4* __restrict__ tile_c, float4* __restrict__ tile_h, float4* __restrict__ cl_c,
-                           float4* __restrict__ cl_h, const float4* __restrict__ sparam = nullptr)
+                           float4* __restrict__ cl_h, const float4* __restrict__ sparam = nullptr, float4* __restrict__ sposi = nullptr)
 {
     const int k = tile * 64 + lane;
     const int o = order[(size_t)r * Npad + k];
@@ -405,6 +406,14 @@ void gather_positions_body(int tile, int nt, int r, int lane, int Npad, int Npad
     if (sparam) x.w = sparam[(size_t)r * Npad + k].x;
     spos[(size_t)r * Npad + k] = x;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    if (sposi) {
+        // the same atom as 32-bit fractions of the box edges: a difference of two such integers wraps modulo 2^32, which IS the
+        // minimum image (three subtractions instead of subtract / multiply / round / fused multiply-add per component in the
+        // Coulomb-only pair loop); 2^-32 of an edge is far below the f32 resolution of the positions themselves
+        auto frac = [](float v, float L) { float f = v / L; f -= floorf(f); return (unsigned int)(f * 4294967296.f); };
+        const unsigned int fx = frac(x.x, Lx), fy = frac(x.y, Ly), fz = frac(x.z, Lz);
+        sposi[(size_t)r * Npad + k] = make_float4(__uint_as_float(fx), __uint_as_float(fy), __uint_as_float(fz), x.w);
+    }
     const float x0 = __shfl(x.x, 0), y0 = __shfl(x.y, 0), z0 = __shfl(x.z, 0);   // lane 0 of a tile is always a real atom
     float dx = x.x - x0, dy = x.y - y0, dz = x.z - z0;
     dx -= Lx * rintf(dx / Lx); dy -= Ly * rintf(dy / Ly); dz -= Lz * rintf(dz / Lz);
@@ -454,7 +463,7 @@ void gather_positions_kernel(int Npad, int Npad_pos, const int* __restrict__ ord
 }
 
 // main system (first nt_a tiles of the grid) and LJ sub-system in one launch: one dependent launch less per evaluation
-struct gather_args { int Npad; const int* order; float4* spos; float4* tile_c; float4* tile_h; float4* cl_c; float4* cl_h; const float4* sparam; };
+struct gather_args { int Npad; const int* order; float4* spos; float4* tile_c; float4* tile_h; float4* cl_c; float4* cl_h; const float4* sparam; float4* sposi; };
 __global__ __launch_bounds__(64)
 void gather_positions2_kernel(int nt_a, gather_args a, gather_args b, int Npad_pos, const float4* __restrict__ pos,
                               const float* __restrict__ box)
@@ -462,7 +471,7 @@ void gather_positions2_kernel(int nt_a, gather_args a, gather_args b, int Npad_p
     const bool second = (int)blockIdx.x >= nt_a;
     const gather_args& g = second ? b : a;
     gather_positions_body(second ? blockIdx.x - nt_a : blockIdx.x, second ? gridDim.x - nt_a : nt_a, blockIdx.y, threadIdx.x, g.Npad, Npad_pos,
-                          g.order, pos, box, g.spos, g.tile_c, g.tile_h, g.cl_c, g.cl_h, g.sparam);
+                          g.order, pos, box, g.spos, g.tile_c, g.tile_h, g.cl_c, g.cl_h, g.sparam, g.sposi);
 }
 
 // ---- Newton's-third-law path: super-cluster ("sci") lists -----------------------------------------------------------
@@ -636,6 +645,7 @@ struct sci_args {
     int N, Npad, ncl, cap, W, Npad_force, ep_off, nsplit;
     const float4* spos; const float4* sparam; const unsigned long long* excl; const unsigned int* list; const int* count;
     long long* force;
+    const float4* sposi;        // positions as 32-bit box fractions + charge (gather_positions_body), or NULL
 };
 #define SCI_EWALD(M) ((M) == NB_EWALD || (M) == NB_EWALD_NOLJ)
 // A/B switches of the round-4 pair-kernel changes (tools/build_variant.sh -DSCI_...=0)
@@ -647,6 +657,9 @@ struct sci_args {
 #endif
 #ifndef SCI_PACKQ
 #define SCI_PACKQ 1
+#endif
+#ifndef SCI_INTCOORD
+#define SCI_INTCOORD 1
 #endif
 template <int METHOD, bool ENERGY, bool ALCH, int NW, bool TABLE = false>
 __device__ __forceinline__
@@ -664,10 +677,13 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
     const int ntile = ncl >> 3;
     const int T = item % ntile, r = (item / ntile) % R, zsl = (item / (ntile * R)) * NW + wv;
     const int ii = lane >> 3, jj = lane & 7;
-    const float4* __restrict__ P = spos + (size_t)r * Npad;
+    // force-only Coulomb-only kernel: positions as integer box fractions (sci_args::sposi), minimum image by wrap-around
+    constexpr bool INTC = SCI_INTCOORD && SCI_PACKQ && !ENERGY && !ALCH && (METHOD == NB_EWALD_NOLJ || METHOD == NB_RF_NOLJ);
+    const float4* __restrict__ P = (INTC ? a.sposi : spos) + (size_t)r * Npad;      // (the split launch always passes sposi)
     const float4* __restrict__ prm = sparam + (size_t)r * Npad;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const float iLx = 1.f / Lx, iLy = 1.f / Ly, iLz = 1.f / Lz;
+    const float sLx = Lx * (1.f / 4294967296.f), sLy = Ly * (1.f / 4294967296.f), sLz = Lz * (1.f / 4294967296.f);
     float lam_a = 1.f, sc = 0.f, lam_e = 1.f;
     if (ALCH) { lam_a = rep_lam[4 * r]; sc = rep_lam[4 * r + 1]; lam_e = rep_lam[4 * r + 2]; }
     const int c_last = (N - 1) >> 3;                         // the only cluster that can mix real and padding atoms
@@ -738,8 +754,15 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
             for (int s = 0; s < 8; ++s) {
                 if (!((imask >> s) & 1u)) continue;              // wave-uniform
                 const int ic = T * 8 + s;
-                float dx = xj.x - xi[s].x, dy = xj.y - xi[s].y, dz = xj.z - xi[s].z;
-                dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
+                float dx, dy, dz;
+                if (INTC) {
+                    dx = (float)(int)(__float_as_uint(xj.x) - __float_as_uint(xi[s].x)) * sLx;
+                    dy = (float)(int)(__float_as_uint(xj.y) - __float_as_uint(xi[s].y)) * sLy;
+                    dz = (float)(int)(__float_as_uint(xj.z) - __float_as_uint(xi[s].z)) * sLz;
+                } else {
+                    dx = xj.x - xi[s].x; dy = xj.y - xi[s].y; dz = xj.z - xi[s].z;
+                    dx -= Lx * rintf(dx * iLx); dy -= Ly * rintf(dy * iLy); dz -= Lz * rintf(dz * iLz);
+                }
                 const float r2 = dx * dx + dy * dy + dz * dz;
                 // which lane pairs count is wave-uniform data (cutoff ballot, exclusion word, padding masks): scalar unit
                 unsigned long long in = __builtin_amdgcn_ballot_w64(r2 < rcut2);
@@ -1185,7 +1208,7 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_param); dfree(t.d_mask); dfree(t.d_exc_atoms); dfree(t.d_exc_params); dfree(t.d_excl_atoms); dfree(t.d_excl_qq);
     dfree(t.d_exc_alch); dfree(t.d_excl_alch); dfree(t.d_probe);
     dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
-    dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sparam); dfree(t.d_smask);
+    dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sposi); dfree(t.d_sparam); dfree(t.d_smask);
     dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h);
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h);
@@ -1491,6 +1514,8 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         const size_t n = (size_t)h->R * h->Npad;
         REMD_CHECK(h, hipMalloc(&t.d_order, sizeof(int) * n));
         REMD_CHECK(h, hipMalloc(&t.d_spos, sizeof(float4) * n));
+        dfree(t.d_sposi);
+        REMD_CHECK(h, hipMalloc(&t.d_sposi, sizeof(float4) * n));
         REMD_CHECK(h, hipMalloc(&t.d_sparam, sizeof(float4) * n));
         REMD_CHECK(h, hipMalloc(&t.d_smask, sizeof(unsigned long long) * n * t.p.excl_words));
         REMD_CHECK(h, hipMalloc(&t.d_tile_c, sizeof(float4) * (size_t)h->R * ntile));
@@ -1566,8 +1591,8 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
     if (split) {
         // main system + LJ sub-system in one gather launch and one list launch
         const int ntile_lj = t.NLpad / 64;
-        gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h, t.d_sparam};
-        gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h, nullptr};
+        gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h, t.d_sparam, t.d_sposi};
+        gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h, nullptr, nullptr};
         sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
         sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};
         const float rc2_main = t.method == NB_EWALD ? t.p.rcc2 : t.p.rc2;
@@ -1615,13 +1640,14 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
         const bool split = t.lj_split && t.d_lj_sci_list && (METHOD == NB_EWALD || METHOD == NB_RF);
         constexpr int MAIN = (METHOD == NB_EWALD) ? NB_EWALD_NOLJ : (METHOD == NB_RF) ? NB_RF_NOLJ : METHOD;
         const int ssplit = std::max(SCI_NW, std::min(16, t.sci_split / SCI_NW * SCI_NW));
-        sci_args sa{h->N, h->Npad, ncl, t.cl_cap, t.excl_W, h->Npad, 0, ssplit, t.d_spos, t.d_sparam, t.d_excl, t.d_sci_list, t.d_sci_count, t.d_sforce};
+        sci_args sa{h->N, h->Npad, ncl, t.cl_cap, t.excl_W, h->Npad, 0, ssplit, t.d_spos, t.d_sparam, t.d_excl, t.d_sci_list, t.d_sci_count, t.d_sforce,
+                    t.d_sposi};
         const int items_a = ntile * h->R * (ssplit / SCI_NW);
         if (split) {
             // one launch for both systems, one scatter for both sorted accumulators; the launch is either one workgroup per
             // work item or a resident set pulling items from a queue (t.nb_grid, chosen by timing: remd_nb_tune_step)
             sci_args sb{t.NL, t.NLpad, t.NLpad / 8, t.lj_cap, t.lj_excl_W, t.NLpad, ncl * 4, ssplit, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl,
-                        t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce};
+                        t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce, nullptr};
             const int items = items_a + (t.NLpad / 64) * h->R * (ssplit / SCI_NW);
             const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
             const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
