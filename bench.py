@@ -232,7 +232,7 @@ def main():
                                 'Coulomb pairs, from a force table, which is NOT counted); one launch evaluates the Coulomb system and the '
                                 'LJ sub-system (every pair once: Newton\'s third law on per-tile union lists); the timed scope also holds '
                                 'the sorted-slot force scatter.  The duration is the one next to the mesh kernels of the other stream '
-                                '(stand-alone: 0.081 ms); traffic is an offline PMC figure, see traffic_source')
+                                '(stand-alone: 0.076 ms); traffic is an offline PMC figure, see traffic_source')
         if n_xy > 0:
             # algorithmic bytes (SURVEY 8(d) "grid traffic 8 B x G per pass"): the half spectrum [nz/2+1][nx][ny] complex f32 of
             # every replica is read once and written once by the plane-resident XY pass

@@ -69,6 +69,7 @@ struct nb_tables {
     int* d_order = nullptr;               // [R][Npad] sorted slot -> atom (-1: padding)
     float4* d_spos = nullptr;             // [R][Npad] positions in sorted order (refreshed every evaluation)
     float4* d_sposi = nullptr;            // [R][Npad] the same as 32-bit box fractions (bit patterns in x, y, z) + charge in w
+    float4* d_lj_sposi = nullptr;         // [R][NLpad] the LJ sub-system's
     float4* d_sparam = nullptr;           // [R][Npad]
     unsigned long long* d_smask = nullptr;// [R][Npad][excl_words]
     float4* d_tile_c = nullptr; float4* d_tile_h = nullptr;   // [R][ntile] bounding-box centre / half extent
@@ -661,7 +662,7 @@ struct sci_args {
 #ifndef SCI_INTCOORD
 #define SCI_INTCOORD 1
 #endif
-template <int METHOD, bool ENERGY, bool ALCH, int NW, bool TABLE = false>
+template <int METHOD, bool ENERGY, bool ALCH, int NW, bool TABLE = false, bool INTPOS = false>
 __device__ __forceinline__
 void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const float* __restrict__ box,
                         const float* __restrict__ rep_lam, double* __restrict__ epart, int n_epart, int R,
@@ -678,7 +679,8 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
     const int T = item % ntile, r = (item / ntile) % R, zsl = (item / (ntile * R)) * NW + wv;
     const int ii = lane >> 3, jj = lane & 7;
     // force-only Coulomb-only kernel: positions as integer box fractions (sci_args::sposi), minimum image by wrap-around
-    constexpr bool INTC = SCI_INTCOORD && SCI_PACKQ && !ENERGY && !ALCH && (METHOD == NB_EWALD_NOLJ || METHOD == NB_RF_NOLJ);
+    // (INTPOS: the caller also has integer positions for a system that keeps its parameter loads -- the LJ sub-system of a split launch)
+    constexpr bool INTC = SCI_INTCOORD && !ENERGY && ((SCI_PACKQ && !ALCH && (METHOD == NB_EWALD_NOLJ || METHOD == NB_RF_NOLJ)) || INTPOS);
     const float4* __restrict__ P = (INTC ? a.sposi : spos) + (size_t)r * Npad;      // (the split launch always passes sposi)
     const float4* __restrict__ prm = sparam + (size_t)r * Npad;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
@@ -887,7 +889,7 @@ void nonbonded_sci2_kernel(nb_params p, sci_args a, sci_args b, int n_items_a, i
             if (TAB) stage_coulomb_table(p, ctab_g, 64 * NW);
             nonbonded_sci_body<METHOD_A, ENERGY, ALCH, NW, TAB>(p, a, blockIdx.x, box, rep_lam, epart, n_epart, R, s_ctab - p.ctab_key0);
         }
-        else nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW>(p, b, blockIdx.x - n_items_a, box, rep_lam, epart, n_epart, R);
+        else nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW, false, true>(p, b, blockIdx.x - n_items_a, box, rep_lam, epart, n_epart, R);
         return;
     }
     if (TAB) stage_coulomb_table(p, ctab_g, 64 * NW);
@@ -911,7 +913,7 @@ void nonbonded_sci2_kernel(nb_params p, sci_args a, sci_args b, int n_items_a, i
         __syncthreads();
         const int item = s_item;
         if (item >= n_items - n_items_a) break;
-        nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW>(p, b, item, box, rep_lam, epart, n_epart, R);
+        nonbonded_sci_body<METHOD_B, ENERGY, ALCH, NW, false, true>(p, b, item, box, rep_lam, epart, n_epart, R);
         __syncthreads();
     }
     // the last workgroup to leave rewinds the queues for the next launch (everybody has seen them run dry by then)
@@ -1208,7 +1210,7 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_param); dfree(t.d_mask); dfree(t.d_exc_atoms); dfree(t.d_exc_params); dfree(t.d_excl_atoms); dfree(t.d_excl_qq);
     dfree(t.d_exc_alch); dfree(t.d_excl_alch); dfree(t.d_probe);
     dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
-    dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sposi); dfree(t.d_sparam); dfree(t.d_smask);
+    dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sposi); dfree(t.d_lj_sposi); dfree(t.d_sparam); dfree(t.d_smask);
     dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h);
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h);
@@ -1551,6 +1553,8 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
             t.lj_cap = std::min(ncl_lj, 4096);
             REMD_CHECK(h, hipMalloc(&t.d_lj_order, sizeof(int) * nl));
             REMD_CHECK(h, hipMalloc(&t.d_lj_spos, sizeof(float4) * nl));
+            dfree(t.d_lj_sposi);
+            REMD_CHECK(h, hipMalloc(&t.d_lj_sposi, sizeof(float4) * nl));
             REMD_CHECK(h, hipMalloc(&t.d_lj_sparam, sizeof(float4) * nl));
             REMD_CHECK(h, hipMalloc(&t.d_lj_smask, sizeof(unsigned long long) * nl * t.lj_words));
             REMD_CHECK(h, hipMalloc(&t.d_lj_tile_c, sizeof(float4) * (size_t)h->R * (t.NLpad / 64)));
@@ -1592,7 +1596,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         // main system + LJ sub-system in one gather launch and one list launch
         const int ntile_lj = t.NLpad / 64;
         gather_args ga{h->Npad, t.d_order, t.d_spos, t.d_tile_c, t.d_tile_h, t.d_cl_c, t.d_cl_h, t.d_sparam, t.d_sposi};
-        gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h, nullptr, nullptr};
+        gather_args gb{t.NLpad, t.d_lj_order, t.d_lj_spos, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_cl_c, t.d_lj_cl_h, nullptr, t.d_lj_sposi};
         sci_list_args la{ntile * 8, t.cl_cap, t.d_cl_c, t.d_cl_h, t.d_tile_c, t.d_tile_h, t.d_sci_list, t.d_sci_count};
         sci_list_args lb{t.NLpad / 8, t.lj_cap, t.d_lj_cl_c, t.d_lj_cl_h, t.d_lj_tile_c, t.d_lj_tile_h, t.d_lj_sci_list, t.d_lj_sci_count};
         const float rc2_main = t.method == NB_EWALD ? t.p.rcc2 : t.p.rc2;
@@ -1647,7 +1651,7 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
             // one launch for both systems, one scatter for both sorted accumulators; the launch is either one workgroup per
             // work item or a resident set pulling items from a queue (t.nb_grid, chosen by timing: remd_nb_tune_step)
             sci_args sb{t.NL, t.NLpad, t.NLpad / 8, t.lj_cap, t.lj_excl_W, t.NLpad, ncl * 4, ssplit, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl,
-                        t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce, nullptr};
+                        t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce, t.d_lj_sposi};
             const int items = items_a + (t.NLpad / 64) * h->R * (ssplit / SCI_NW);
             const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
             const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
