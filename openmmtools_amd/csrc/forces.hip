@@ -104,6 +104,7 @@ struct nb_tables {
     // Ewald direct-space force table of the force-only pair kernels (coulomb_table.h); REMD_NB_TABLE=0: Abramowitz & Stegun erfc
     float4* d_ctab = nullptr; bool use_table = false;
     unsigned int* d_pair_done = nullptr; unsigned int pair_done_target = 0;      // remd_fold_args: the scatter launch's done counter
+    int* d_sort_scratch = nullptr; size_t sort_scratch_n = 0;                    // sort_groups_large_kernel (more than 8191 molecules)
 };
 static handle_table<nb_tables> g_nb;
 
@@ -286,30 +287,31 @@ __device__ __forceinline__ unsigned morton3(unsigned x, unsigned y, unsigned z)
 }
 
 // one workgroup per replica: rank the groups by (Morton cell of the group's first atom, group index), then
-// lay their atoms out contiguously.  Keys are unique, so the order is deterministic.
-__global__ __launch_bounds__(1024)
-void sort_groups_kernel(int G, int N, int Npad, const int* __restrict__ grp_first, const int* __restrict__ grp_size,
-                        const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order)
+// lay their atoms out contiguously.  Keys are unique, so the order is deterministic.  The work arrays (key, first atom / size /
+// offset by rank: 16 - 20 bytes per group) live in LDS up to 8191 groups (sort_groups_kernel) and in a global scratch buffer
+// beyond (sort_groups_large_kernel, 64-bit keys; round 4: systems of more than 8191 molecules used to leave the cluster-pair
+// path for the tile kernel).  The ranking is G comparisons per group -- every 40 evaluations, a few hundred microseconds for
+// 30 k molecules.
+template <typename KEY>
+__device__ __forceinline__
+void sort_groups_body(int G, int N, int Npad, const int* __restrict__ grp_first, const int* __restrict__ grp_size,
+                      const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order,
+                      KEY* key, int* r_first, int* r_size, int* r_off, int* s_part)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned* key = reinterpret_cast<unsigned*>(smem);       // [G]
-    int* r_first = reinterpret_cast<int*>(key + G);          // [G] by rank
-    int* r_size = r_first + G;                               // [G] by rank
-    int* r_off = r_size + G;                                 // [G] by rank (exclusive scan)
-    __shared__ int s_part[1024];
     const int r = blockIdx.x, tid = threadIdx.x;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     const int ncx = max(1, min(63, (int)(Lx / cell))), ncy = max(1, min(63, (int)(Ly / cell))), ncz = max(1, min(63, (int)(Lz / cell)));
+    constexpr int GBITS = sizeof(KEY) == 8 ? 32 : 13;
     for (int g = tid; g < G; g += 1024) {
         const float4 x = pos[(size_t)r * Npad + grp_first[g]];
         float fx = x.x / Lx, fy = x.y / Ly, fz = x.z / Lz;
         fx -= floorf(fx); fy -= floorf(fy); fz -= floorf(fz);
         const unsigned cx = min(ncx - 1, (int)(fx * ncx)), cy = min(ncy - 1, (int)(fy * ncy)), cz = min(ncz - 1, (int)(fz * ncz));
-        key[g] = (morton3(cx, cy, cz) << 13) | (unsigned)g;
+        key[g] = ((KEY)morton3(cx, cy, cz) << GBITS) | (KEY)(unsigned)g;
     }
     __syncthreads();
     for (int g = tid; g < G; g += 1024) {
-        const unsigned k = key[g];
+        const KEY k = key[g];
         int rank = 0;
         for (int o = 0; o < G; ++o) rank += (key[o] < k) ? 1 : 0;
         r_first[rank] = grp_first[g];
@@ -337,6 +339,30 @@ void sort_groups_kernel(int G, int N, int Npad, const int* __restrict__ grp_firs
         for (int a = 0; a < n; ++a) O[st + a] = f + a;
     }
     for (int k = N + tid; k < Npad; k += 1024) O[k] = -1;
+}
+
+__global__ __launch_bounds__(1024)
+void sort_groups_kernel(int G, int N, int Npad, const int* __restrict__ grp_first, const int* __restrict__ grp_size,
+                        const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* key = reinterpret_cast<unsigned*>(smem);       // [G]
+    int* r_first = reinterpret_cast<int*>(key + G);          // [G] by rank
+    __shared__ int s_part[1024];
+    sort_groups_body<unsigned>(G, N, Npad, grp_first, grp_size, pos, box, cell, order, key, r_first, r_first + G, r_first + 2 * G, s_part);
+}
+
+// scratch: [R][5 G] ints (the 64-bit keys first)
+__global__ __launch_bounds__(1024)
+void sort_groups_large_kernel(int G, int N, int Npad, const int* __restrict__ grp_first, const int* __restrict__ grp_size,
+                              const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order,
+                              int* __restrict__ scratch)
+{
+    __shared__ int s_part[1024];
+    int* base = scratch + (size_t)blockIdx.x * 5 * G;
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(base);
+    int* r_first = base + 2 * G;
+    sort_groups_body<unsigned long long>(G, N, Npad, grp_first, grp_size, pos, box, cell, order, key, r_first, r_first + G, r_first + 2 * G, s_part);
 }
 
 __global__ __launch_bounds__(256)
@@ -1215,7 +1241,7 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h);
     dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
-    dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue); dfree(t.d_ctab); dfree(t.d_pair_done);
+    dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue); dfree(t.d_ctab); dfree(t.d_pair_done); dfree(t.d_sort_scratch);
     for (auto& sg : t.tune_segs) { if (sg.a) hipEventDestroy(sg.a); if (sg.b) hipEventDestroy(sg.b); }
     g_nb.erase(h);
 }
@@ -1508,7 +1534,7 @@ static void launch_list_build(remd_ctx* h, nb_tables& t, bool lj)
 // lists (every evaluation) of the cluster-pair path
 static int ensure_sorted(remd_ctx* h, nb_tables& t)
 {
-    if (!t.sorting || t.n_groups <= 0 || t.n_groups >= 8192) return 0;
+    if (!t.sorting || t.n_groups <= 0) return 0;
     const int ntile = (h->N + 63) / 64;
     const bool cl = t.clusters && ntile * 8 < 65536;
     if (t.sort_R != h->R) {
@@ -1573,9 +1599,20 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
     const bool split = cl && t.lj_split;
     if (t.evals_since_sort >= t.resort_interval) {
         remd_prof_scope ps(h, "nb_sort");
-        const size_t lds = sizeof(int) * 4 * (size_t)t.n_groups;
-        hipLaunchKernelGGL(sort_groups_kernel, dim3(h->R), dim3(1024), lds, h->stream, t.n_groups, h->N, h->Npad, t.d_grp_first,
-                           t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order);
+        if (t.n_groups < 8192) {
+            const size_t lds = sizeof(int) * 4 * (size_t)t.n_groups;
+            hipLaunchKernelGGL(sort_groups_kernel, dim3(h->R), dim3(1024), lds, h->stream, t.n_groups, h->N, h->Npad, t.d_grp_first,
+                               t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order);
+        } else {
+            const size_t need = (size_t)h->R * 5 * t.n_groups;
+            if (t.sort_scratch_n < need) {
+                dfree(t.d_sort_scratch);
+                REMD_CHECK(h, hipMalloc(&t.d_sort_scratch, sizeof(int) * need));
+                t.sort_scratch_n = need;
+            }
+            hipLaunchKernelGGL(sort_groups_large_kernel, dim3(h->R), dim3(1024), 0, h->stream, t.n_groups, h->N, h->Npad, t.d_grp_first,
+                               t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order, t.d_sort_scratch);
+        }
         hipLaunchKernelGGL(gather_params_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.p.excl_words,
                            t.d_order, t.d_param, t.d_mask, t.d_sparam, t.d_smask);
         if (split)
@@ -1638,7 +1675,7 @@ template <int METHOD, bool ENERGY>
 static void launch_nb(remd_ctx* h, nb_tables& t)
 {
     const int ntile = (h->N + 63) / 64;
-    if (t.sorting && t.clusters && t.d_order && t.d_sci_list && t.n_groups > 0 && t.n_groups < 8192 && ntile * 8 < 65536) {
+    if (t.sorting && t.clusters && t.d_order && t.d_sci_list && t.n_groups > 0 && ntile * 8 < 65536) {
         const int ncl = ntile * 8;
         const float* rl = t.has_alch ? t.d_rep_lam : (const float*)nullptr;
         const bool split = t.lj_split && t.d_lj_sci_list && (METHOD == NB_EWALD || METHOD == NB_RF);
@@ -1691,7 +1728,7 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
     dim3 grid((ntile + NB_WAVES - 1) / NB_WAVES, t.p.n_jsplit, h->R);
     const size_t need = (size_t)h->R * t.p.n_jsplit * h->Npad;
     if (t.partial_n < need) { dfree(t.d_partial); if (hipMalloc(&t.d_partial, sizeof(float4) * need) != hipSuccess) return; t.partial_n = need; }
-    const bool sorted = t.sorting && t.d_order && t.n_groups > 0 && t.n_groups < 8192;
+    const bool sorted = t.sorting && t.d_order && t.n_groups > 0;
     const float4* P = sorted ? t.d_spos : h->d_pos;
     const float4* prm = sorted ? t.d_sparam : t.d_param;
     const unsigned long long* mk = sorted ? t.d_smask : t.d_mask;

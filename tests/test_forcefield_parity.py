@@ -456,6 +456,32 @@ def test_cluster_pair_lists_match_the_tile_kernel(hip_engine_factory, monkeypatc
     assert np.allclose(u1, u0, rtol=2e-8, atol=1e-6)
 
 
+def test_more_than_8191_molecules_stay_on_the_cluster_path(hip_engine_factory, monkeypatch):
+    """Round 4: the molecule sort kept its work arrays in LDS, which capped the cluster-pair path at 8191 molecules (larger
+    systems fell to the tile kernel).  Past that the same ranking runs on a global scratch buffer with 64-bit keys
+    (sort_groups_large_kernel).  10 000 single-atom molecules (a dense LJ fluid): the cluster path against the oracle and
+    against the tile kernel on the same coordinates."""
+    lj = ts.LennardJonesFluid(nparticles=10000, reduced_density=0.5)
+    L = np.diag(lj.system.getDefaultPeriodicBoxVectors())
+    g = np.stack(np.meshgrid(*[np.arange(22)] * 3, indexing='ij'), axis=-1).reshape(-1, 3)
+    pos = (np.random.default_rng(5).permutation(g)[:10000] + 0.5) * (L / 22)          # jittered lattice sites, in no spatial order
+    res = []
+    for tiles in (False, True):
+        if tiles:
+            monkeypatch.setenv('REMD_NB_TILES', '1')
+        eng = hip_engine_factory()
+        desc, x, box = _engine_for(eng, lj.system, pos, R=2, jitter=0.02)
+        U = eng.compute_energies(want_potential=True)[1]
+        res.append((eng.get_forces(), U, eng.get_replicas()[0]))
+    (f1, u1, xd), (f0, u0, _) = res
+    assert np.abs(f1 - f0).max() < 2e-5 * np.abs(f0).max()
+    assert np.allclose(u1, u0, rtol=2e-7)
+    ff = ForceFieldOracle(desc)
+    e_ref, f_ref = ff.energy_forces(xd[1], box[1])
+    assert np.isclose(u1[1], e_ref, rtol=1e-5), (u1[1], e_ref)
+    assert np.abs(f1[1] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
+
+
 def test_config4_all_64_alchemical_states_ukl(hip_engine_factory):
     """BASELINE config 4 AT ITS STATED SIZE: CB7:B2 with the full 64-state ladder (lambda_electrostatics 1 -> 0 over 32
     states, then lambda_sterics 1 -> 0 over 32) — every column of two replicas' u_kl rows against
