@@ -1,0 +1,341 @@
+"""The alchemically modified System as OpenMM XML: what the reference's AbsoluteAlchemicalFactory would have built, written
+from and read back into this package's *marked* System (``system.alchemical_region``, alchemy.py here).
+
+The reference stores a CompoundThermodynamicState's System as ``XmlSerializer.serialize`` of the factory's output
+(states.py:1257-1280, multistatereporter.py:612-668); to put configs 2 and 4 into the reference's netCDF4 layout, the store
+writer therefore needs that force set (alchemy/alchemy.py of the reference, defaults of :626-635: exact PME treatment,
+split_alchemical_forces, no consistent exceptions, switched reaction field):
+
+    order        forces the factory does not touch, in place; then the re-added bonded forces (and the NonbondedForce when
+                 electrostatics is not handled by offsets) :711-741, 1052-1061; then by sorted lambda name :1075-1083 --
+                 'lambda_electrostatics' (force group = lowest free) and 'lambda_sterics' (next free); the unshifted
+                 reaction-field force last :744-749 (forcefactories.py:76-84, forces.py:1110-1196)
+    NonbondedForce   alchemical atoms lose charge and epsilon, exceptions that touch them lose chargeprod and epsilon
+                 :1903-1911, 2000-2006; Ewald methods: global parameter lambda_electrostatics + one particle offset (q) per
+                 alchemical atom :1675-1680, 1896-1899 and one exception offset per charged exception :1978-1982;
+                 sigma = 0 becomes 1 angstrom :1640-1661
+    sterics      CustomNonbondedForce non-alchemical/alchemical (lambda_sterics, interaction group (N, A)) and
+                 alchemical/alchemical (group (A, A); lambda fixed to 1 in the expression unless annihilate_sterics)
+                 :1767-1797, 1913-1919, expressions :1355-1390; CustomBondForces for the Lennard-Jones part of exceptions
+                 with one / two alchemical atoms :1836-1851, 1985-1998
+    electrostatics   (non-Ewald methods only) the same four forces with the reaction-field expression :1392-1508, 1799-1830
+    softcore_*   eight global parameters on every custom force :2009-2025
+
+The XML element layout of CustomNonbondedForce / CustomBondForce / NonbondedForce offsets restates OpenMM's
+CustomNonbondedForceProxy, CustomBondForceProxy and NonbondedForceProxy -- **external knowledge, unpinned**: neither OpenMM
+nor any document it wrote with these forces exists in /root/reference or here (system_xml.py's plain forces are pinned by
+the System inside the reference's alanine store).  What is pinned: write -> read returns the System description the engine
+was given (tests/test_alchemical_store_cpu.py), so a store written here resumes here.
+
+Outside what this package's factory builds (and so refused, with the name of what is missing): several regions, alchemical
+bonds / angles / torsions, soft-core electrostatics, 'coulomb' / 'direct-space' PME treatments, charged systems under the
+reaction-field methods (the engine evaluates OpenMM's shifted reaction field, the factory an unshifted switched one).
+"""
+import xml.etree.ElementTree as ET
+
+from .constants import ONE_4PI_EPS0
+from .system import NonbondedForce, HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce
+
+_REMODELLED = (HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce)      # :711-726 have a creator
+_SOFTCORE = ('softcore_alpha', 'softcore_beta', 'softcore_a', 'softcore_b', 'softcore_c', 'softcore_d', 'softcore_e', 'softcore_f')
+_MIX_STERICS = 'epsilon = sqrt(epsilon1*epsilon2);sigma = 0.5*(sigma1 + sigma2);'
+_MIX_ELECTROSTATICS = 'chargeprod = charge1*charge2;sigma = 0.5*(sigma1 + sigma2);'
+_RF_HEAD = 'ONE_4PI_EPS0*chargeprod*(r^(-1) + k_rf*r^2);'
+
+
+def _f(x):
+    return repr(float(x))
+
+
+def sterics_exception_expression(lam='lambda_sterics'):
+    """:1374-1380 -- the soft-core Lennard-Jones of one pair with effective sigma / epsilon."""
+    return ('U_sterics;'
+            'U_sterics = ((%s)^softcore_a)*4*epsilon*x*(x-1.0);'
+            'x = (sigma/reff_sterics)^6;'
+            'reff_sterics = sigma*((softcore_alpha*(1.0-(%s))^softcore_b + (r/sigma)^softcore_c))^(1/softcore_c);' % (lam, lam))
+
+
+def electrostatics_expressions(nb, lam='lambda_electrostatics'):
+    """:1392-1471 for the methods that reach it here (NoCutoff, reaction field): (pair expression, exception expression)."""
+    prefix = 'U_electrostatics;U_electrostatics=((%s)^softcore_d)*ONE_4PI_EPS0*chargeprod' % lam
+    suffix = ('reff_electrostatics = sigma*((softcore_beta*(1.0-(%s))^softcore_e + (r/sigma)^softcore_f))^(1/softcore_f);'
+              'ONE_4PI_EPS0 = %s;' % (lam, ONE_4PI_EPS0))
+    coulomb = '/reff_electrostatics;'
+    if nb.getNonbondedMethod() == NonbondedForce.NoCutoff:
+        method = coulomb
+    else:                                                                    # :1473-1508, 'switched': c_rf = 0
+        eps, rc = nb.getReactionFieldDielectric(), nb.getCutoffDistance()
+        method = ('*(reff_electrostatics^(-1) + k_rf*reff_electrostatics^2 - c_rf);k_rf = %s;c_rf = %s;'
+                  % (rc ** -3 * ((eps - 1) / (2 * eps + 1)), 0.0))
+    return prefix + method + suffix + _MIX_ELECTROSTATICS, prefix + coulomb + suffix
+
+
+def _emit_custom(forces, kind, group, energy, per_name, per_params, lam_globals, region, **attrs):
+    e = ET.SubElement(forces, 'Force', dict(forceGroup=str(group), name=kind, type=kind, energy=energy, version='3', **attrs))
+    b = ET.SubElement(e, per_name)
+    for n in per_params:
+        ET.SubElement(b, 'Parameter', dict(name=n))
+    g = ET.SubElement(e, 'GlobalParameters')
+    values = dict(softcore_alpha=region.softcore_alpha, softcore_beta=0.0, softcore_a=region.softcore_a, softcore_b=region.softcore_b,
+                  softcore_c=region.softcore_c, softcore_d=1.0, softcore_e=1.0, softcore_f=2.0)
+    for n in lam_globals:
+        ET.SubElement(g, 'Parameter', dict(default=_f(1.0), name=n))
+    for n in _SOFTCORE:
+        ET.SubElement(g, 'Parameter', dict(default=_f(values[n]), name=n))
+    return e
+
+
+def _emit_custom_nonbonded(forces, group, energy, per_params, lam_globals, region, nb, particles, exclusions, set1, set2,
+                           use_switch, switch_distance, lrc, with_softcore=True):
+    periodic = nb.usesPeriodicBoundaryConditions()
+    attrs = dict(method=str(2 if periodic else nb.getNonbondedMethod()), cutoff=_f(nb.getCutoffDistance()),
+                 useSwitchingFunction=str(int(use_switch)), switchingDistance=_f(switch_distance), useLongRangeCorrection=str(int(lrc)))
+    if with_softcore:
+        e = _emit_custom(forces, 'CustomNonbondedForce', group, energy, 'PerParticleParameters', per_params, lam_globals, region, **attrs)
+    else:
+        e = ET.SubElement(forces, 'Force', dict(forceGroup=str(group), name='CustomNonbondedForce', type='CustomNonbondedForce',
+                                                energy=energy, version='3', **attrs))
+        b = ET.SubElement(e, 'PerParticleParameters')
+        for n in per_params:
+            ET.SubElement(b, 'Parameter', dict(name=n))
+        ET.SubElement(e, 'GlobalParameters')
+    ET.SubElement(e, 'ComputedValues'); ET.SubElement(e, 'EnergyParameterDerivatives')
+    b = ET.SubElement(e, 'Particles')
+    for p in particles:
+        ET.SubElement(b, 'Particle', {'param%d' % (k + 1): _f(v) for k, v in enumerate(p)})
+    b = ET.SubElement(e, 'Exclusions')
+    for (i, j) in exclusions:
+        ET.SubElement(b, 'Exclusion', dict(p1=str(i), p2=str(j)))
+    ET.SubElement(e, 'Functions')
+    groups = ET.SubElement(e, 'InteractionGroups')
+    if set1 is not None:
+        grp = ET.SubElement(groups, 'InteractionGroup')
+        for tag, members in (('Set1', set1), ('Set2', set2)):
+            s = ET.SubElement(grp, tag)
+            for idx in sorted(members):
+                ET.SubElement(s, 'Particle', dict(index=str(idx)))
+    return e
+
+
+def _emit_custom_bond(forces, group, energy, per_params, lam_globals, region, bonds):
+    e = _emit_custom(forces, 'CustomBondForce', group, energy, 'PerBondParameters', per_params, lam_globals, region, usesPeriodic='0')
+    ET.SubElement(e, 'EnergyParameterDerivatives')
+    b = ET.SubElement(e, 'Bonds')
+    for (i, j, params) in bonds:
+        ET.SubElement(b, 'Bond', dict({'param%d' % (k + 1): _f(v) for k, v in enumerate(params)}, p1=str(i), p2=str(j)))
+    return e
+
+
+def emit_alchemical_forces(forces, system, emit_plain):
+    """Append the factory's force set for the marked ``system`` to the <Forces> element.  ``emit_plain(force, **overrides)`` is
+    system_xml's emitter of one unmodified force."""
+    region = system.alchemical_region
+    all_forces = system.getForces()
+    nbs = [f for f in all_forces if isinstance(f, NonbondedForce)]
+    if len(nbs) != 1:
+        raise NotImplementedError('an alchemical System with %d NonbondedForces' % len(nbs))
+    nb = nbs[0]
+    A = set(region.alchemical_atoms)
+    N = set(range(nb.getNumParticles())) - A
+    ewald = nb.getNonbondedMethod() in (NonbondedForce.Ewald, NonbondedForce.PME)
+    if not ewald and any(q != 0.0 for (q, _, _) in nb.particles) and nb.getNonbondedMethod() != NonbondedForce.NoCutoff:
+        raise NotImplementedError('charged alchemical System under a reaction-field method (the factory switches to an unshifted '
+                                  'reaction field, forcefactories.py:76-84; the engine evaluates the shifted one)')
+    if ewald and not region.annihilate_electrostatics:
+        raise NotImplementedError('decoupled electrostatics with the exact PME treatment (alchemy.py:1617-1623 refuses it too)')
+
+    # ---- the NonbondedForce that keeps the non-alchemical interactions ----------------------------------------------
+    sig1 = lambda s: 0.1 if s == 0.0 else s                                                  # :1640-1661
+    particles = [(q, sig1(s), e) for (q, s, e) in nb.particles]
+    exceptions = [(i, j, qq, sig1(s), e) for (i, j, qq, s, e) in nb.exceptions]
+    kept_particles = [(0.0, s, 0.0) if k in A else (q, s, e) for k, (q, s, e) in enumerate(particles)]
+    kept_exceptions, particle_offsets, exception_offsets = [], [], []
+    na_lj, aa_lj, na_qq, aa_qq = [], [], [], []
+    for k, (q, s, e) in enumerate(particles):
+        if ewald and k in A:
+            particle_offsets.append(('lambda_electrostatics', k, q, 0.0, 0.0))
+    for n, (i, j, qq, s, e) in enumerate(exceptions):
+        n_alch = (i in A) + (j in A)
+        if n_alch == 0:
+            kept_exceptions.append((i, j, qq, s, e))
+            continue
+        if ewald and qq != 0.0:
+            exception_offsets.append(('lambda_electrostatics', n, qq, 0.0, 0.0))
+        if e != 0.0:
+            (aa_lj if n_alch == 2 else na_lj).append((i, j, (s, e)))
+        if qq != 0.0 and not ewald:
+            (aa_qq if n_alch == 2 else na_qq).append((i, j, (qq, s)))
+        kept_exceptions.append((i, j, 0.0, s, 0.0))
+    exclusions = [(i, j) for (i, j, _, _, _) in exceptions]
+
+    # ---- order and force groups (:1052-1083) ------------------------------------------------------------------------
+    untouched = [f for f in all_forces if not isinstance(f, _REMODELLED)]
+    readded = [f for f in all_forces if isinstance(f, _REMODELLED) and (not isinstance(f, NonbondedForce) or not ewald)]
+    used = {f.getForceGroup() for f in untouched + readded}
+    free = sorted(set(range(32)) - used)
+    if len(free) < 2:
+        raise NotImplementedError('no free force groups for the alchemical forces (alchemy.py:1068-1072 raises here too)')
+    g_elec, g_ster = free[0], free[1]
+
+    if nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic:             # forcefactories.py:82-84: charges move to the last force
+        kept_particles = [(0.0, s, e) for (q, s, e) in kept_particles]
+
+    def emit_nb(group):
+        emit_plain(nb, particles=kept_particles, exceptions=kept_exceptions, force_group=group,
+                   global_parameters=[('lambda_electrostatics', 1.0)] if ewald else [],
+                   particle_offsets=particle_offsets, exception_offsets=exception_offsets)
+
+    for f in untouched:
+        emit_plain(f)
+    for f in readded:
+        if isinstance(f, NonbondedForce):
+            emit_nb(f.getForceGroup())
+        else:
+            emit_plain(f)
+
+    lrc = nb.getUseDispersionCorrection() and getattr(system, 'alchemical_lrc', True)
+    cnb = dict(region=region, nb=nb, exclusions=exclusions)
+    if not ewald:                                                            # 'lambda_electrostatics' sorts first
+        pair_expr, exc_expr = electrostatics_expressions(nb)
+        fixed = '' if region.annihilate_electrostatics else 'lambda_electrostatics=1.0;'
+        charges = [(q, s) for (q, s, e) in particles]
+        switched = nb.getNonbondedMethod() in (NonbondedForce.CutoffPeriodic, NonbondedForce.CutoffNonPeriodic)
+        switch_width = getattr(system, 'alchemical_switch_width', 0.1)
+        common = dict(use_switch=switched, switch_distance=nb.getCutoffDistance() - switch_width, lrc=False, **cnb)
+        _emit_custom_nonbonded(forces, g_elec, pair_expr, ('charge', 'sigma'), ('lambda_electrostatics',), particles=charges,
+                               set1=N, set2=A, **common)
+        _emit_custom_nonbonded(forces, g_elec, pair_expr + fixed, ('charge', 'sigma'), () if fixed else ('lambda_electrostatics',),
+                               particles=charges, set1=A, set2=A, **common)
+        _emit_custom_bond(forces, g_elec, exc_expr, ('chargeprod', 'sigma'), ('lambda_electrostatics',), region, na_qq)
+        _emit_custom_bond(forces, g_elec, exc_expr + fixed, ('chargeprod', 'sigma'), () if fixed else ('lambda_electrostatics',), region, aa_qq)
+    else:
+        emit_nb(g_elec)
+    exc_expr = sterics_exception_expression()
+    pair_expr = exc_expr + _MIX_STERICS
+    fixed = '' if region.annihilate_sterics else 'lambda_sterics=1.0;'
+    lj = [(s, e) for (q, s, e) in particles]
+    common = dict(use_switch=nb.getUseSwitchingFunction(), switch_distance=nb.getSwitchingDistance(), lrc=lrc, **cnb)
+    _emit_custom_nonbonded(forces, g_ster, pair_expr, ('sigma', 'epsilon'), ('lambda_sterics',), particles=lj, set1=N, set2=A, **common)
+    _emit_custom_nonbonded(forces, g_ster, pair_expr + fixed, ('sigma', 'epsilon'), () if fixed else ('lambda_sterics',),
+                           particles=lj, set1=A, set2=A, **common)
+    _emit_custom_bond(forces, g_ster, exc_expr, ('sigma', 'epsilon'), ('lambda_sterics',), region, na_lj)
+    _emit_custom_bond(forces, g_ster, exc_expr + fixed, ('sigma', 'epsilon'), () if fixed else ('lambda_sterics',), region, aa_lj)
+    if nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic:             # forcefactories.py:76-84 (charges: all zero here)
+        eps, rc = nb.getReactionFieldDielectric(), nb.getCutoffDistance()
+        energy = _RF_HEAD + 'chargeprod = charge1*charge2;k_rf = %f;ONE_4PI_EPS0 = %f;' % (rc ** -3 * (eps - 1.0) / (2.0 * eps + 1.0), ONE_4PI_EPS0)
+        switch_width = getattr(system, 'alchemical_switch_width', 0.1)
+        _emit_custom_nonbonded(forces, 0, energy, ('charge',), (), region, nb, [(q,) for (q, s, e) in particles], exclusions, None, None,
+                               True, rc - switch_width, False, with_softcore=False)
+
+
+# ---- reader -------------------------------------------------------------------------------------------------------
+def _params(elem):
+    out, k = [], 1
+    while elem.get('param%d' % k) is not None:
+        out.append(float(elem.get('param%d' % k)))
+        k += 1
+    return out
+
+
+def _kids(e, tag):
+    b = e.find(tag)
+    return [] if b is None else list(b)
+
+
+def parse_custom(e):
+    """A CustomNonbondedForce / CustomBondForce element as a plain dictionary."""
+    d = dict(type=e.get('type'), energy=e.get('energy', ''), group=int(e.get('forceGroup', '0')), attrs=dict(e.attrib),
+             globals={g.get('name'): float(g.get('default')) for g in _kids(e, 'GlobalParameters')})
+    if d['type'] == 'CustomNonbondedForce':
+        d['per'] = [p.get('name') for p in _kids(e, 'PerParticleParameters')]
+        d['particles'] = [_params(p) for p in _kids(e, 'Particles')]
+        d['groups'] = [tuple(sorted(int(p.get('index')) for p in _kids(g, tag)) for tag in ('Set1', 'Set2'))
+                       for g in _kids(e, 'InteractionGroups')]
+    else:
+        d['per'] = [p.get('name') for p in _kids(e, 'PerBondParameters')]
+        d['bonds'] = [(int(b.get('p1')), int(b.get('p2')), _params(b)) for b in _kids(e, 'Bonds')]
+    return d
+
+
+def is_alchemical_document(nb_offsets, customs):
+    return bool(nb_offsets) or any('softcore_alpha' in c['globals'] for c in customs)
+
+
+def rebuild_marked_system(system, nb, global_parameters, particle_offsets, exception_offsets, customs):
+    """Undo the factory on a parsed document: give the NonbondedForce back the alchemical atoms' charges, Lennard-Jones
+    parameters and exceptions, drop the custom forces, and mark the region on ``system``.  ``nb`` is the parsed (kept)
+    NonbondedForce, the offsets are (parameter, index, q, sig, eps) tuples, ``customs`` the parse_custom dictionaries."""
+    from .alchemy import AlchemicalRegion
+    compact = lambda s: s.replace(' ', '')
+    sterics = [c for c in customs if 'U_sterics' in c['energy']]
+    electro = [c for c in customs if 'U_electrostatics' in c['energy']]
+    rf = [c for c in customs if compact(c['energy']).startswith(compact(_RF_HEAD)) and c['type'] == 'CustomNonbondedForce']
+    other = [c for c in customs if c not in sterics + electro + rf]
+    if other:
+        raise NotImplementedError('custom force outside the alchemical factory\'s set: %s' % other[0]['energy'][:60])
+    for name in list(global_parameters) + [p[0] for p in particle_offsets + exception_offsets]:
+        if name != 'lambda_electrostatics':
+            raise NotImplementedError('NonbondedForce offset parameter %r (one unnamed alchemical region only)' % name)
+    for c in sterics + electro:
+        for g in c['globals']:
+            if g not in _SOFTCORE + ('lambda_sterics', 'lambda_electrostatics'):
+                raise NotImplementedError('alchemical parameter %r (one unnamed region, no bonded lambdas)' % g)
+    cnb_s = [c for c in sterics if c['type'] == 'CustomNonbondedForce']
+    na = [c for c in cnb_s if 'lambda_sterics' in c['globals'] and c['groups'] and c['groups'][0][0] != c['groups'][0][1]]
+    aa = [c for c in cnb_s if c['groups'] and c['groups'][0][0] == c['groups'][0][1]]
+    if len(na) != 1 or len(aa) != 1 or len(cnb_s) != 2:
+        raise NotImplementedError('sterics CustomNonbondedForces of more than one alchemical region')
+    na, aa = na[0], aa[0]
+    A = list(aa['groups'][0][0])
+    if sorted(na['groups'][0][1]) != sorted(A):
+        raise NotImplementedError('interaction groups of the two sterics forces disagree on the alchemical atoms')
+    if 'lambda_sterics' in aa['globals']:
+        raise NotImplementedError('annihilate_sterics=True')
+    if compact(sterics_exception_expression() + _MIX_STERICS) != compact(na['energy']):
+        raise NotImplementedError('sterics expression other than the factory\'s soft-core Lennard-Jones: %s' % na['energy'][:80])
+    g = na['globals']
+    if (g.get('softcore_beta', 0.0), g.get('softcore_d', 1.0), g.get('softcore_e', 1.0), g.get('softcore_f', 2.0)) != (0.0, 1.0, 1.0, 2.0):
+        raise NotImplementedError('soft-core electrostatics')
+    cnb_e = [c for c in electro if c['type'] == 'CustomNonbondedForce']
+    annihilate_electrostatics = True
+    for c in cnb_e:
+        if c['groups'] and c['groups'][0][0] == c['groups'][0][1] and 'lambda_electrostatics' not in c['globals']:
+            annihilate_electrostatics = False
+    region = AlchemicalRegion(alchemical_atoms=A, annihilate_electrostatics=annihilate_electrostatics,
+                              softcore_alpha=g['softcore_alpha'], softcore_a=g['softcore_a'], softcore_b=g['softcore_b'], softcore_c=g['softcore_c'])
+    Aset = set(A)
+    # particles
+    charge = {p[1]: p[2] for p in particle_offsets}
+    if cnb_e:
+        for k in A:
+            charge[k] = cnb_e[0]['particles'][k][0]
+    for k in A:
+        sig, eps = na['particles'][k]
+        nb.setParticleParameters(k, charge.get(k, 0.0), sig, eps)
+    if rf:                                                                   # the factory moved ALL charges there
+        for k, p in enumerate(rf[0]['particles']):
+            if k not in Aset:
+                q, s, e = nb.getParticleParameters(k)
+                nb.setParticleParameters(k, p[0], s, e)
+    # exceptions
+    qq_of = {p[1]: p[2] for p in exception_offsets}
+    lj_of, qq_bond = {}, {}
+    for c in sterics:
+        if c['type'] == 'CustomBondForce':
+            for (i, j, p) in c['bonds']:
+                lj_of[frozenset((i, j))] = (p[0], p[1])
+    for c in electro:
+        if c['type'] == 'CustomBondForce':
+            for (i, j, p) in c['bonds']:
+                qq_bond[frozenset((i, j))] = p[0]
+    for n, (i, j, qq, s, e) in enumerate(list(nb.exceptions)):
+        if i in Aset or j in Aset:
+            key = frozenset((i, j))
+            sig, eps = lj_of.get(key, (s, 0.0))
+            nb.exceptions[n] = (i, j, qq_of.get(n, qq_bond.get(key, 0.0)), sig, eps)
+    system.alchemical_region = region
+    use_lrc = na['attrs'].get('useLongRangeCorrection', '0') not in ('0', 'false')
+    system.alchemical_lrc = use_lrc or not nb.getUseDispersionCorrection()
+    if particle_offsets or global_parameters:                                # the factory put it into the lambda_electrostatics group
+        nb.setForceGroup(0)
+    return system

@@ -17,8 +17,9 @@ __getstate__; quantities as '!Quantity {unit, value}'; a ThermodynamicState's Sy
 'standard_system', shared between compatible states through '_Reporter__compatible_state' :552-610.
 
 What is understood: ThermodynamicState (temperature, pressure) on a System of the forces openmmtools_amd/system_xml.py reads,
+CompoundThermodynamicState with one AlchemicalState (round 4: the System as the alchemical factory builds it, _alchemical_xml.py),
 LangevinSplittingDynamicsMove / LangevinDynamicsMove, MultiStateSampler / ReplicaExchangeSampler / ParallelTemperingSampler /
-SAMSSampler options.  Anything else (compound alchemical states, other moves) raises NotImplementedError naming it.  The HDF5
+SAMSSampler options.  Anything else (other composable states, other moves) raises NotImplementedError naming it.  The HDF5
 library is loaded through ctypes (``_hdf5``); without it the store cannot be opened (ImportError says so).
 """
 import os
@@ -208,10 +209,10 @@ class ReferenceStoreReader:
                 continue
             n = len(self._a.keys('/' + kind)[1])
             for k in range(n):
-                d = self.read_dict('%s/state%d' % (kind, k))
-                if 'thermodynamic_state' in d:
-                    raise NotImplementedError('compound thermodynamic states (%s) in a reference store' %
-                                              ', '.join(str(c.get('_serialized__class_name')) for c in d.get('composable_states', [])))
+                outer = self.read_dict('%s/state%d' % (kind, k))
+                d = outer
+                while 'thermodynamic_state' in d:                    # CompoundThermodynamicState.__getstate__, states.py:2956-2971
+                    d = d['thermodynamic_state']
                 if d.get('_serialized__class_name') != 'ThermodynamicState':
                     raise NotImplementedError('state class %r in a reference store' % d.get('_serialized__class_name'))
                 ref = d.get('_Reporter__compatible_state')
@@ -221,8 +222,21 @@ class ReferenceStoreReader:
                     systems['%s/%d' % (kind, k)] = system
                 else:
                     system = systems[ref]
-                out[kind].append(states.ThermodynamicState(system, float(d['temperature']),
-                                                           pressure=None if d.get('pressure') is None else float(d['pressure'])))
+                state = states.ThermodynamicState(system, float(d['temperature']),
+                                                  pressure=None if d.get('pressure') is None else float(d['pressure']))
+                if outer is not d:
+                    composable = outer.get('composable_states', [])
+                    names = [str(c.get('_serialized__class_name')) for c in composable]
+                    if names != ['AlchemicalState']:
+                        raise NotImplementedError('compound thermodynamic states (%s) in a reference store' % ', '.join(names))
+                    c = composable[0]
+                    if c.get('parameters_name_suffix') is not None or c.get('function_variables'):
+                        raise NotImplementedError('AlchemicalState with a parameter suffix or alchemical functions')
+                    par = {n: v for n, v in c['parameters'].items() if v is not None}     # None: not defined on the System (alchemy.py:94-99)
+                    if any(isinstance(v, str) for v in par.values()):
+                        raise NotImplementedError('AlchemicalState parameters given as functions')
+                    state = states.CompoundThermodynamicState(state, [states.AlchemicalState(**par)])
+                out[kind].append(state)
         return out['thermodynamic_states'], out['unsampled_states']
 
     def read_mcmc_moves(self):
@@ -386,10 +400,19 @@ class ReferenceStoreWriter:
 
     @staticmethod
     def can_store(thermodynamic_states, unsampled_states, mcmc_moves):
-        """None when this layout can hold the objects, else what it cannot (compound alchemical states, other moves)."""
+        """None when this layout can hold the objects, else what it cannot (other state classes, other moves, alchemical Systems
+        outside the factory's defaults)."""
+        from .. import system_xml
+        seen = set()
         for s in list(thermodynamic_states) + list(unsampled_states):
-            if type(s).__name__ != 'ThermodynamicState':
+            if type(s).__name__ not in ('ThermodynamicState', 'CompoundThermodynamicState'):
                 return type(s).__name__
+            if getattr(s.system, 'alchemical_region', None) is not None and id(s.system) not in seen:
+                seen.add(id(s.system))
+                try:                                        # the factory's force set for this System (_alchemical_xml.py) or why not
+                    system_xml.to_xml(s.system)
+                except NotImplementedError as err:
+                    return 'alchemical System: %s' % err
         for m in mcmc_moves:
             if type(m).__name__ not in ('LangevinSplittingDynamicsMove', 'LangevinDynamicsMove'):
                 return type(m).__name__
@@ -479,8 +502,9 @@ class ReferenceStoreWriter:
         first_of = []                                   # (state, 'kind/index') of the first state of every compatible group
         for kind, states in (('thermodynamic_states', thermodynamic_states), ('unsampled_states', unsampled_states)):
             for k, s in enumerate(states):
-                if type(s).__name__ != 'ThermodynamicState':
-                    raise NotImplementedError('%s in the reference\'s store layout (plain ThermodynamicStates only)' % type(s).__name__)
+                name = type(s).__name__
+                if name not in ('ThermodynamicState', 'CompoundThermodynamicState'):
+                    raise NotImplementedError('%s in the reference\'s store layout' % name)
                 d = {'_serialized__class_name': 'ThermodynamicState', '_serialized__module_name': 'openmmtools.states',
                      'temperature': _Quantity(float(s.temperature), 'kelvin'), 'surface_tension': None,
                      'pressure': None if s.pressure is None else _Quantity(float(s.pressure) / _UNIT_TO_MD['bar'], 'bar')}
@@ -492,6 +516,15 @@ class ReferenceStoreWriter:
                     first_of.append((s, '%s/%d' % (kind, k)))
                 else:
                     d['_Reporter__compatible_state'] = ref
+                if name == 'CompoundThermodynamicState':
+                    # states.py:2956-2971 around the plain state; the AlchemicalState as GlobalParameterState.__getstate__
+                    # writes it (:3879-3898): the lambdas the System defines, None for the ones it does not (alchemy.py:94-99)
+                    alch = {'_serialized__class_name': 'AlchemicalState', '_serialized__module_name': 'openmmtools.alchemy.alchemy',
+                            'parameters': {'lambda_sterics': float(s.lambda_sterics), 'lambda_electrostatics': float(s.lambda_electrostatics),
+                                           'lambda_bonds': None, 'lambda_angles': None, 'lambda_torsions': None},
+                            'function_variables': {}, 'parameters_name_suffix': None}
+                    d = {'_serialized__class_name': 'CompoundThermodynamicState', '_serialized__module_name': 'openmmtools.states',
+                         'thermodynamic_state': d, 'composable_states': [alch]}
                 self._write_text(self._a, '/%s/state%d' % (kind, k), _yaml_dump(d), fixed=True)
 
     def write_mcmc_moves(self, mcmc_moves):

@@ -13,8 +13,10 @@ AlanineDipeptideExplicit stored in the reference's data/reporter-examples/alanin
 (tests/golden/openmm_alanine_fixture.npz, tests/test_openmm_fixture.py) parses to exactly the description this
 package builds from the Amber files.
 
-Forces outside the hot path's scope (GBSA, CustomNonbonded, CustomBond, ... and NonbondedForce parameter offsets /
-non-default PME) raise ``NotImplementedError`` naming the force, like ``system_to_desc`` does.
+Round 4: a System marked by ``alchemy.AbsoluteAlchemicalFactory`` is written as the force set the reference's factory builds
+(NonbondedForce offsets, soft-core CustomNonbondedForces / CustomBondForces: ``_alchemical_xml.py``) and such a document is
+read back into a marked System.  Other forces outside the hot path's scope (GBSA, Custom*Force with any other expression,
+other NonbondedForce parameter offsets) raise ``NotImplementedError`` naming the force, like ``system_to_desc`` does.
 """
 import xml.etree.ElementTree as ET
 
@@ -27,6 +29,67 @@ def _f(x):
 
 
 # ---- writer ------------------------------------------------------------------------------------------------------
+def _emit_force(forces, f, force_group=None, particles=None, exceptions=None, global_parameters=(), particle_offsets=(),
+                exception_offsets=()):
+    """One force of the System shim as a <Force> element.  The keyword arguments are the NonbondedForce of an alchemically
+    modified System (_alchemical_xml.py): replaced particle / exception tables, the global parameter and its offsets."""
+    name = type(f).__name__
+    common = dict(forceGroup=str(f.getForceGroup() if force_group is None else force_group), name=name, type=name)
+    if isinstance(f, HarmonicBondForce):
+        e = ET.SubElement(forces, 'Force', dict(common, usesPeriodic='0', version='2'))
+        b = ET.SubElement(e, 'Bonds')
+        for (i, j, d, k) in f.bonds:
+            ET.SubElement(b, 'Bond', dict(d=_f(d), k=_f(k), p1=str(i), p2=str(j)))
+    elif isinstance(f, HarmonicAngleForce):
+        e = ET.SubElement(forces, 'Force', dict(common, usesPeriodic='0', version='2'))
+        b = ET.SubElement(e, 'Angles')
+        for (i, j, k, a, kf) in f.angles:
+            ET.SubElement(b, 'Angle', dict(a=_f(a), k=_f(kf), p1=str(i), p2=str(j), p3=str(k)))
+    elif isinstance(f, PeriodicTorsionForce):
+        e = ET.SubElement(forces, 'Force', dict(common, usesPeriodic='0', version='2'))
+        b = ET.SubElement(e, 'Torsions')
+        for (i, j, k, l, per, ph, kf) in f.torsions:
+            ET.SubElement(b, 'Torsion', dict(k=_f(kf), p1=str(i), p2=str(j), p3=str(k), p4=str(l),
+                                             periodicity=str(int(per)), phase=_f(ph)))
+    elif isinstance(f, NonbondedForce):
+        alpha, nx, ny, nz = f._pme_params if f._pme_params else (0.0, 0, 0, 0)
+        e = ET.SubElement(forces, 'Force', dict(
+            common, alpha=_f(alpha), cutoff=_f(f.getCutoffDistance()),
+            dispersionCorrection=str(int(f.getUseDispersionCorrection())), ewaldTolerance=_f(f.getEwaldErrorTolerance()),
+            exceptionsUsePeriodic='0', includeDirectSpace='1', ljAlpha='0', ljnx='0', ljny='0', ljnz='0',
+            method=str(f.getNonbondedMethod()), nx=str(nx), ny=str(ny), nz=str(nz), recipForceGroup='-1',
+            rfDielectric=_f(f.getReactionFieldDielectric()), switchingDistance=_f(f.getSwitchingDistance()),
+            useSwitchingFunction=str(int(f.getUseSwitchingFunction())), version='4'))
+        g = ET.SubElement(e, 'GlobalParameters')
+        for (pname, default) in global_parameters:
+            ET.SubElement(g, 'Parameter', dict(default=_f(default), name=pname))
+        g = ET.SubElement(e, 'ParticleOffsets')
+        for (pname, idx, q, sig, eps) in particle_offsets:
+            ET.SubElement(g, 'Offset', dict(eps=_f(eps), parameter=pname, particle=str(idx), q=_f(q), sig=_f(sig)))
+        g = ET.SubElement(e, 'ExceptionOffsets')
+        for (pname, idx, q, sig, eps) in exception_offsets:
+            ET.SubElement(g, 'Offset', dict(eps=_f(eps), exception=str(idx), parameter=pname, q=_f(q), sig=_f(sig)))
+        b = ET.SubElement(e, 'Particles')
+        for (q, sig, eps) in (f.particles if particles is None else particles):
+            ET.SubElement(b, 'Particle', dict(eps=_f(eps), q=_f(q), sig=_f(sig)))
+        b = ET.SubElement(e, 'Exceptions')
+        for (i, j, qq, sig, eps) in (f.exceptions if exceptions is None else exceptions):
+            ET.SubElement(b, 'Exception', dict(eps=_f(eps), p1=str(i), p2=str(j), q=_f(qq), sig=_f(sig)))
+    elif isinstance(f, CustomExternalForce):
+        e = ET.SubElement(forces, 'Force', dict(common, energy=f.energy_expression, version='1'))
+        ET.SubElement(e, 'PerParticleParameters')
+        g = ET.SubElement(e, 'GlobalParameters')
+        for k, v in f.globals.items():
+            ET.SubElement(g, 'Parameter', dict(default=_f(v), name=k))
+        b = ET.SubElement(e, 'Particles')
+        for idx in f.particles:
+            ET.SubElement(b, 'Particle', dict(index=str(idx)))
+    elif isinstance(f, CMMotionRemover):
+        ET.SubElement(forces, 'Force', dict(common, frequency=str(f.getFrequency()), version='1'))
+    else:
+        raise NotImplementedError('unsupported force %r' % name)
+
+
 def to_xml(system, pressure=None, temperature=None, barostat_frequency=25):
     """Serialise ``system`` (and, when ``pressure`` is given, a MonteCarloBarostat force in bar / kelvin, which is how
     the reference carries the pressure of an NPT ThermodynamicState, states.py:1020-1068)."""
@@ -42,54 +105,13 @@ def to_xml(system, pressure=None, temperature=None, barostat_frequency=25):
         p, q, d = system.getConstraintParameters(i)
         ET.SubElement(cons, 'Constraint', dict(d=_f(d), p1=str(p), p2=str(q)))
     forces = ET.SubElement(root, 'Forces')
-    for f in system.getForces():
-        name = type(f).__name__
-        common = dict(forceGroup=str(f.getForceGroup()), name=name, type=name)
-        if isinstance(f, HarmonicBondForce):
-            e = ET.SubElement(forces, 'Force', dict(common, usesPeriodic='0', version='2'))
-            b = ET.SubElement(e, 'Bonds')
-            for (i, j, d, k) in f.bonds:
-                ET.SubElement(b, 'Bond', dict(d=_f(d), k=_f(k), p1=str(i), p2=str(j)))
-        elif isinstance(f, HarmonicAngleForce):
-            e = ET.SubElement(forces, 'Force', dict(common, usesPeriodic='0', version='2'))
-            b = ET.SubElement(e, 'Angles')
-            for (i, j, k, a, kf) in f.angles:
-                ET.SubElement(b, 'Angle', dict(a=_f(a), k=_f(kf), p1=str(i), p2=str(j), p3=str(k)))
-        elif isinstance(f, PeriodicTorsionForce):
-            e = ET.SubElement(forces, 'Force', dict(common, usesPeriodic='0', version='2'))
-            b = ET.SubElement(e, 'Torsions')
-            for (i, j, k, l, per, ph, kf) in f.torsions:
-                ET.SubElement(b, 'Torsion', dict(k=_f(kf), p1=str(i), p2=str(j), p3=str(k), p4=str(l),
-                                                 periodicity=str(int(per)), phase=_f(ph)))
-        elif isinstance(f, NonbondedForce):
-            alpha, nx, ny, nz = f._pme_params if f._pme_params else (0.0, 0, 0, 0)
-            e = ET.SubElement(forces, 'Force', dict(
-                common, alpha=_f(alpha), cutoff=_f(f.getCutoffDistance()),
-                dispersionCorrection=str(int(f.getUseDispersionCorrection())), ewaldTolerance=_f(f.getEwaldErrorTolerance()),
-                exceptionsUsePeriodic='0', includeDirectSpace='1', ljAlpha='0', ljnx='0', ljny='0', ljnz='0',
-                method=str(f.getNonbondedMethod()), nx=str(nx), ny=str(ny), nz=str(nz), recipForceGroup='-1',
-                rfDielectric=_f(f.getReactionFieldDielectric()), switchingDistance=_f(f.getSwitchingDistance()),
-                useSwitchingFunction=str(int(f.getUseSwitchingFunction())), version='4'))
-            ET.SubElement(e, 'GlobalParameters'); ET.SubElement(e, 'ParticleOffsets'); ET.SubElement(e, 'ExceptionOffsets')
-            b = ET.SubElement(e, 'Particles')
-            for (q, sig, eps) in f.particles:
-                ET.SubElement(b, 'Particle', dict(eps=_f(eps), q=_f(q), sig=_f(sig)))
-            b = ET.SubElement(e, 'Exceptions')
-            for (i, j, qq, sig, eps) in f.exceptions:
-                ET.SubElement(b, 'Exception', dict(eps=_f(eps), p1=str(i), p2=str(j), q=_f(qq), sig=_f(sig)))
-        elif isinstance(f, CustomExternalForce):
-            e = ET.SubElement(forces, 'Force', dict(common, energy=f.energy_expression, version='1'))
-            ET.SubElement(e, 'PerParticleParameters')
-            g = ET.SubElement(e, 'GlobalParameters')
-            for k, v in f.globals.items():
-                ET.SubElement(g, 'Parameter', dict(default=_f(v), name=k))
-            b = ET.SubElement(e, 'Particles')
-            for idx in f.particles:
-                ET.SubElement(b, 'Particle', dict(index=str(idx)))
-        elif isinstance(f, CMMotionRemover):
-            ET.SubElement(forces, 'Force', dict(common, frequency=str(f.getFrequency()), version='1'))
-        else:
-            raise NotImplementedError('unsupported force %r' % name)
+    if getattr(system, 'alchemical_region', None) is not None:
+        # a System marked by alchemy.AbsoluteAlchemicalFactory is written as the force set the reference's factory builds
+        from . import _alchemical_xml
+        _alchemical_xml.emit_alchemical_forces(forces, system, lambda f, **kw: _emit_force(forces, f, **kw))
+    else:
+        for f in system.getForces():
+            _emit_force(forces, f)
     if pressure is not None:
         ET.SubElement(forces, 'Force', dict(forceGroup='0', name='MonteCarloBarostat', type='MonteCarloBarostat',
                                             pressure=_f(pressure), temperature=_f(temperature if temperature is not None else 300.0),
@@ -131,6 +153,7 @@ def from_xml(text_or_path):
     for c in _children(root, 'Constraints', 'Constraint'):
         s.addConstraint(int(c.get('p1')), int(c.get('p2')), float(c.get('d')))
     barostat = None
+    customs, alch_nb, nb_force = [], None, None
     for e in _children(root, 'Forces', 'Force'):
         kind = e.get('type')
         if kind == 'HarmonicBondForce':
@@ -147,10 +170,16 @@ def from_xml(text_or_path):
                 f.addTorsion(int(b.get('p1')), int(b.get('p2')), int(b.get('p3')), int(b.get('p4')),
                              int(b.get('periodicity')), float(b.get('phase')), float(b.get('k')))
         elif kind == 'NonbondedForce':
-            for block in ('GlobalParameters', 'ParticleOffsets', 'ExceptionOffsets'):
-                if _nonempty(e, block):
-                    raise NotImplementedError('NonbondedForce %s (parameter offsets) are not supported' % block)
+            # parameter offsets: understood as the alchemical factory's lambda_electrostatics (checked after the loop)
+            nb_globals = {g.get('name'): float(g.get('default')) for g in _children(e, 'GlobalParameters', 'Parameter')}
+            offsets = [[(o.get('parameter'), int(o.get(key)), float(o.get('q')), float(o.get('sig')), float(o.get('eps')))
+                        for o in _children(e, block, 'Offset')] for block, key in (('ParticleOffsets', 'particle'), ('ExceptionOffsets', 'exception'))]
+            if nb_globals or offsets[0] or offsets[1]:
+                if alch_nb is not None:
+                    raise NotImplementedError('parameter offsets on more than one NonbondedForce')
+                alch_nb = (nb_globals, offsets[0], offsets[1])
             f = NonbondedForce()
+            nb_force = f
             f.setNonbondedMethod(int(e.get('method')))
             f.setCutoffDistance(float(e.get('cutoff')))
             f.setUseSwitchingFunction(bool(int(e.get('useSwitchingFunction', '0'))))
@@ -165,6 +194,10 @@ def from_xml(text_or_path):
                 f.addParticle(float(b.get('q')), float(b.get('sig')), float(b.get('eps')))
             for b in _children(e, 'Exceptions', 'Exception'):
                 f.addException(int(b.get('p1')), int(b.get('p2')), float(b.get('q')), float(b.get('sig')), float(b.get('eps')))
+        elif kind in ('CustomNonbondedForce', 'CustomBondForce'):
+            from . import _alchemical_xml
+            customs.append(_alchemical_xml.parse_custom(e))        # only as the pieces of an alchemically modified System
+            continue
         elif kind == 'CustomExternalForce':
             if _nonempty(e, 'PerParticleParameters'):
                 raise NotImplementedError('CustomExternalForce with per-particle parameters')
@@ -188,4 +221,10 @@ def from_xml(text_or_path):
             raise NotImplementedError('unsupported OpenMM force %s' % kind)
         f.setForceGroup(int(e.get('forceGroup', '0')))
         s.addForce(f)
+    if customs or alch_nb is not None:
+        from . import _alchemical_xml
+        if nb_force is None:
+            raise NotImplementedError('custom forces without a NonbondedForce (%s)' % customs[0]['type'])
+        g, po, eo = alch_nb if alch_nb is not None else ({}, [], [])
+        _alchemical_xml.rebuild_marked_system(s, nb_force, g, po, eo, customs)
     return s, barostat

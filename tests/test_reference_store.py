@@ -351,26 +351,24 @@ def test_analyzer_works_on_the_nc_layout(tmp_path):
     assert Da.shape == (5, 5) and abs(Da[0, -1] - exact) < 6.0 * dDa[0, -1] + 0.05
 
 
-def test_states_the_layout_cannot_hold_fall_back_to_the_record_container(tmp_path, caplog):
-    """Compound (alchemical) states have no counterpart in what this package writes of the netCDF4 layout: the same '.nc' path
-    then becomes a record-file container (a directory), with a warning; layout='records' asks for that explicitly."""
+def test_moves_the_layout_cannot_hold_fall_back_to_the_record_container(tmp_path, caplog):
+    """What this package does not write of the netCDF4 layout (moves other than the Langevin ones; round 4 added compound
+    alchemical states, tests/test_alchemical_store_cpu.py): the same '.nc' path then becomes a record-file container (a
+    directory), with a warning; layout='records' asks for that explicitly."""
     import logging
     import sys
     sys.path.insert(0, HERE)
     from oracle_engine import OracleEngine
     from oracle.forcefield import ForceFieldOracle
-    from openmmtools_amd import testsystems, mcmc, unit, alchemy
+    from openmmtools_amd import testsystems, mcmc, unit
     lj = testsystems.LennardJonesFluid(nparticles=64)
-    region = alchemy.AlchemicalRegion(alchemical_atoms=range(4))
-    asys = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, region)
-    ths = [states.CompoundThermodynamicState(states.ThermodynamicState(asys, 120.0 * unit.kelvin),
-                                             [states.AlchemicalState(lambda_sterics=l, lambda_electrostatics=1.0)]) for l in (1.0, 0.5)]
+    ths = [states.ThermodynamicState(lj.system, t * unit.kelvin) for t in (120.0, 130.0)]
     ss = states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())
-    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=2, reassign_velocities=True, splitting='V R O R V')
+    move = mcmc.GHMCMove(timestep=1.0 * unit.femtosecond, n_steps=2)
     s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=1, engine=OracleEngine(ForceFieldOracle), seed=1)
     with caplog.at_level(logging.WARNING):
         s.create(ths, [ss], storage=str(tmp_path / 'alch.nc'))
-    assert any('record-file container' in r.getMessage() for r in caplog.records)
+    assert any('GHMCMove' in r.getMessage() and 'record-file container' in r.getMessage() for r in caplog.records)
     s.run()
     assert os.path.isdir(tmp_path / 'alch.nc') and os.path.exists(tmp_path / 'alch.nc' / 'meta.json')
     r = MultiStateReporter(str(tmp_path / 'alch.nc'), open_mode='r')
