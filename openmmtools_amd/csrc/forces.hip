@@ -57,6 +57,7 @@ struct nb_tables {
     std::vector<double> state_lam_a, state_sc;   // per state, for the alchemical u_kl kernel
     double* d_state_lam = nullptr;        // [K][2]
     double* d_alch_ukl = nullptr;         // [R][K]
+    int* d_own = nullptr;                 // [R] the replicas' own states (column of d_alch_ukl that d_potential already holds)
     int alch_R = 0, alch_K = 0;
     double disp_coeff = 0.0;              // E_disp = disp_coeff / V
     double self_energy = 0.0;             // Ewald self term, kJ/mol
@@ -825,7 +826,7 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 float fr, ee;
                 // evaluated for every lane (excluded pairs, even r2 = 0, produce garbage that the select below discards)
                 if (EARLY) { fr = (pi[s].x * pj.x) * fmaf(ttf, fmaf(ttf, fmaf(ttf, tc.w, tc.z), tc.y), tc.x); ee = 0.f; }
-                else pair_interaction<METHOD, ALCH, !ENERGY, TAB>(p, r2c, pi[s], pj, lam_a, sc, fr, ENERGY, ee, ctab);
+                else pair_interaction<METHOD, ALCH, !ENERGY, TAB>(p, r2c, pi[s], pj, lam_a, sc, fr, false, ee, ctab);
                 fr = keep_where(in, fr);
                 const float tx = fr * dx, ty = fr * dy, tz = fr * dz;
                 fix[s] += tx; fiy[s] += ty; fiz[s] += tz;
@@ -1031,7 +1032,7 @@ void nonbonded_kernel(nb_params p, int N, int Npad, const float4* __restrict__ p
                 if (in) {
                     if (ALCH && pj.w != 0.f) pj.x *= lam_e;
                     float fr, ee;
-                    pair_interaction<METHOD, ALCH, !ENERGY>(p, r2, pi, pj, lam_a, sc, fr, ENERGY, ee);
+                    pair_interaction<METHOD, ALCH, !ENERGY>(p, r2, pi, pj, lam_a, sc, fr, false, ee);
                     fx += fr * dx; fy += fr * dy; fz += fr * dz;
                     if (ENERGY) e += 0.5 * (double)ee;
                 }
@@ -1197,11 +1198,14 @@ void reduce_energy_kernel(int n_epart, const double* __restrict__ epart, double*
 }
 
 // u_kl rows (states.py:1908-1917 with pressure=None; paralleltempering.py:206-215):
-//   u[r][l] = beta_l * (U_r + E_alch[r][l] + econst_l)
+//   u[r][l] = beta_l * (U_r + E_alch[r][l] - E_alch[r][own_r] + econst_l)
+//   U_r is the potential at the replica's OWN state (round 4: it used to leave the lambda_sterics-controlled pairs out, which
+//   made it useless as "the potential energy of the replica": the barostat's and GHMC's Metropolis tests and the work
+//   accumulators difference it); E_alch[r][l] are those pairs re-evaluated at every state's lambda_sterics.
 //   NPT states add p_l V_r (states.py:1913-1914)
 __global__ void assemble_ukl_kernel(int R, int K, const double* __restrict__ potential,
                                     const double* __restrict__ beta, const double* __restrict__ econst,
-                                    const double* __restrict__ alch /*[R][K] or null*/,
+                                    const double* __restrict__ alch /*[R][K] or null*/, const int* __restrict__ own /*[R]*/,
                                     const double* __restrict__ pressure /*[K] or null*/, const float* __restrict__ box,
                                     double econst_vref, double* __restrict__ ukl_rows)
 {
@@ -1211,7 +1215,7 @@ __global__ void assemble_ukl_kernel(int R, int K, const double* __restrict__ pot
     const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
     // the per-state constants are long-range corrections ~ 1/V quoted at the volume econst_vref (0: volume independent)
     double U = potential[r] + econst[l] * ((econst_vref > 0.0 && V > 0.0) ? econst_vref / V : 1.0);
-    if (alch) U += alch[t];
+    if (alch) U += alch[t] - alch[(size_t)r * K + own[r]];
     if (pressure) U += pressure[l] * V;
     ukl_rows[t] = beta[l] * U;
 }
@@ -1235,7 +1239,7 @@ void remd_free_nonbonded(remd_ctx* h)
     nb_tables& t = *it;
     dfree(t.d_param); dfree(t.d_mask); dfree(t.d_exc_atoms); dfree(t.d_exc_params); dfree(t.d_excl_atoms); dfree(t.d_excl_qq);
     dfree(t.d_exc_alch); dfree(t.d_excl_alch); dfree(t.d_probe);
-    dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl);
+    dfree(t.d_rep_lam); dfree(t.d_state_lam); dfree(t.d_alch_ukl); dfree(t.d_own);
     dfree(t.d_grp_first); dfree(t.d_grp_size); dfree(t.d_order); dfree(t.d_spos); dfree(t.d_sposi); dfree(t.d_lj_sposi); dfree(t.d_sparam); dfree(t.d_smask);
     dfree(t.d_tile_c); dfree(t.d_tile_h); dfree(t.d_partial); dfree(t.d_cl_c); dfree(t.d_cl_h);
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
@@ -2056,7 +2060,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
 // linearly, so U(lambda_e) = a + b l + c l^2 EXACTLY; three energy passes at l = 0, 1/2, 1 determine a, b, c per replica.
 __global__ void assemble_ukl_poly_kernel(int R, int K, const double* __restrict__ probe /*[3][R]*/,
                                          const double* __restrict__ beta, const double* __restrict__ econst,
-                                         const double* __restrict__ lam_e, const double* __restrict__ alch,
+                                         const double* __restrict__ lam_e, const double* __restrict__ alch, const int* __restrict__ own,
                                          const double* __restrict__ pressure /*[K] or null*/, const float* __restrict__ box,
                                          double econst_vref, double* __restrict__ ukl_rows)
 {
@@ -2069,7 +2073,7 @@ __global__ void assemble_ukl_poly_kernel(int R, int K, const double* __restrict_
     const double le = lam_e[l];
     const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
     double U = P0 + b * le + c * le * le + econst[l] * ((econst_vref > 0.0 && V > 0.0) ? econst_vref / V : 1.0);
-    if (alch) U += alch[t];
+    if (alch) U += alch[t] - alch[(size_t)r * K + own[r]];
     if (pressure) U += pressure[l] * V;
     ukl_rows[t] = beta[l] * U;
 }
@@ -2083,9 +2087,10 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
     if (it && it->has_alch && h->nb_method != REMD_NB_NONE) {
         nb_tables& t = *it;
         if (t.alch_R != h->R || t.alch_K != h->K) {
-            dfree(t.d_alch_ukl); dfree(t.d_state_lam);
+            dfree(t.d_alch_ukl); dfree(t.d_state_lam); dfree(t.d_own);
             REMD_CHECK(h, hipMalloc(&t.d_alch_ukl, sizeof(double) * (size_t)n));
             REMD_CHECK(h, hipMalloc(&t.d_state_lam, sizeof(double) * 2 * h->K));
+            REMD_CHECK(h, hipMalloc(&t.d_own, sizeof(int) * h->R));
             t.alch_R = h->R; t.alch_K = h->K;
         }
         std::vector<double> sl(2 * (size_t)h->K);
@@ -2093,7 +2098,10 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
             sl[2 * k] = pow(h->lam_s[k], h->sc_a);
             sl[2 * k + 1] = h->sc_alpha * pow(1.0 - h->lam_s[k], h->sc_b);
         }
+        std::vector<int> own(h->R);
+        for (int r = 0; r < h->R; ++r) own[r] = h->labels.empty() ? 0 : (int)h->labels[h->r_begin + r];
         REMD_CHECK(h, hipMemcpyAsync(t.d_state_lam, sl.data(), sizeof(double) * sl.size(), hipMemcpyHostToDevice, h->stream));
+        REMD_CHECK(h, hipMemcpyAsync(t.d_own, own.data(), sizeof(int) * own.size(), hipMemcpyHostToDevice, h->stream));
         REMD_CHECK(h, hipStreamSynchronize(h->stream));
         {
             remd_prof_scope ps(h, "alch_ukl");
@@ -2117,14 +2125,14 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
             }
             h->forces_valid = false;        // the last pass used a probe lambda, not the replicas' own
             hipLaunchKernelGGL(assemble_ukl_poly_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K, t.d_probe,
-                               h->d_beta, h->d_econst, h->d_lam_e, alch, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr,
+                               h->d_beta, h->d_econst, h->d_lam_e, alch, t.d_own, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr,
                                h->d_box, h->econst_vref, d_rows);
             REMD_CHECK(h, hipGetLastError());
             return 0;
         }
     }
     hipLaunchKernelGGL(assemble_ukl_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K,
-                       h->d_potential, h->d_beta, h->d_econst, alch, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr, h->d_box, h->econst_vref, d_rows);
+                       h->d_potential, h->d_beta, h->d_econst, alch, alch ? it->d_own : (const int*)nullptr, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr, h->d_box, h->econst_vref, d_rows);
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }

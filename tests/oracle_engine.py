@@ -178,7 +178,15 @@ class OracleEngine:
                                              lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
 
     def potentials(self):
-        return np.array([self.sys.potential(self.x[r], self._box(r)) for r in range(self.R)])
+        """The potential energy of each replica in its OWN thermodynamic state (what the reference's SamplerState carries)."""
+        out = []
+        for r in range(self.R):
+            k = self.labels[self.r_begin + r]
+            lam = {}
+            if hasattr(self.sys, 'state_energies'):
+                lam = dict(lambda_sterics=self.lam_s[k], lambda_electrostatics=self.lam_e[k])
+            out.append(self.sys.potential(self.x[r], self._box(r), **lam))
+        return np.array(out)
 
     def compute_energies(self, d_rows=None, want_host=True, want_potential=False):
         U = self.potentials()

@@ -72,12 +72,14 @@ def test_lj_fluid_alchemical_ukl(hip_engine_factory):
     desc, x, box = _engine_for(eng, system, lj.positions, R=3, lam_s=lam, jitter=0.01, labels=[0, 7, 15],
                                econst=econst)
     ff = ForceFieldOracle(desc)
-    rows = eng.compute_energies()
+    rows, U = eng.compute_energies(want_potential=True)
     xd = eng.get_replicas()[0]
     beta = 1.0 / (KB * 300.0)
     for r in range(3):
         ref = beta * (ff.state_energies(xd[r], box[r], lam, np.ones(16)) + econst)
         assert np.allclose(rows[r], ref, rtol=1e-5), np.abs(rows[r] / ref - 1).max()
+        # the per-replica potential is the energy in the replica's own state (without the state's long-range constant)
+        assert np.isclose(U[r], ff.energy_forces(xd[r], box[r], lambda_sterics=lam[[0, 7, 15][r]], forces=False)[0], rtol=1e-5)
     # forces at each replica's own lambda
     f = eng.get_forces()
     for r, k in enumerate([0, 7, 15]):

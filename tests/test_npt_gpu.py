@@ -164,6 +164,47 @@ def test_npt_with_alchemical_states_tracks_the_oracle(hip_engine_factory):
     assert np.allclose(dev.compute_energies(), ora.compute_energies(), rtol=1e-5, atol=2e-4)
 
 
+def test_barostat_acceptance_sees_the_lambda_controlled_pairs(hip_engine_factory):
+    """The volume move's Metropolis test differences the potential of the replica's OWN state (MonteCarloBarostat on the
+    alchemical System's Context in the reference).  Until round 4 the device's per-replica potential left the
+    lambda_sterics-controlled pairs out (they only entered the u_kl rows), so the barostat of an alchemical NPT run did not
+    feel the guest / solvent Lennard-Jones energy.  Dense start (close alchemical / solvent contacts: that energy changes by
+    many kT under a volume move): 16 attempts per replica decide as the f64 oracle does, and the potential is the oracle's
+    full energy at each replica's lambda."""
+    from openmmtools_amd import alchemy
+    lj = ts.LennardJonesFluid(nparticles=216, reduced_density=0.7)
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, alchemy.AlchemicalRegion(alchemical_atoms=range(10)))
+    lam = np.array([1.0, 0.8, 0.4, 0.0])
+    R = len(lam)
+    x = np.tile(lj.positions, (R, 1, 1))
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (R, 1))
+    desc = system_to_desc(system)
+    engines = []
+    for eng in (hip_engine_factory(), OracleEngine(ForceFieldOracle)):
+        eng.set_system(desc)
+        eng.set_states(np.full(R, 1.0 / (KB * 120.0)), lam, None, None)
+        eng.set_integrator('V R O R V', 0.001, 1.0, 5, True, 1e-8)
+        eng.set_barostat(np.full(R, 40.0 * unit.bar), 25)
+        eng.seed(4)
+        eng.set_replicas(R, 0, x, None, box, np.arange(R))
+        engines.append(eng)
+    dev, ora = engines
+    ff = ForceFieldOracle(desc)
+    U = dev.compute_energies(want_potential=True)[1]
+    full = np.array([ff.energy_forces(x[r], box[r], lambda_sterics=lam[r], forces=False)[0] for r in range(R)])
+    assert np.allclose(U, full, rtol=1e-5), (U, full)
+    assert abs(full[0] - full[-1]) > 50.0                 # the lambda-controlled pairs matter here
+    assert np.allclose(dev.get_replicas(potential=True)[2], full, rtol=1e-5)
+    volumes = []
+    for _ in range(4):
+        dev.barostat_attempts(4)
+        ora.barostat_attempts(4)
+        volumes.append((np.prod(dev.get_boxes(), axis=1), np.prod(ora.get_boxes(), axis=1)))
+    for vd, vo in volumes:
+        assert np.allclose(vd, vo, rtol=3e-5), volumes
+    assert len({tuple(np.round(vd, 9)) for vd, _ in volumes}) > 1          # moves were accepted along the way
+
+
 def test_hostguest_npt_alchemical_production_mode(hip_engine_factory):
     """CB7:B2 host-guest, lambda_electrostatics + lambda_sterics states, NPT at 1 bar (the production free-energy ensemble):
     50 g-BAOAB steps with two volume moves per replica on the device, then u_kl = beta_l (U(l) + c_l V0/V + p V) against
