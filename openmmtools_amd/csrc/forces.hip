@@ -1087,9 +1087,16 @@ void exception_kernel(int n, const int* __restrict__ atoms, const float* __restr
         if (Lx > 0.f) { d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz); }
         const float r2 = dotf(d, d);
         const float inv_r = rsqrtf(r2);
-        const float s2 = sig * sig * inv_r * inv_r, s6 = s2 * s2 * s2;
-        const float U = 4.f * eps * s6 * (s6 - 1.f) + qq * inv_r;
-        const float dUdr = 4.f * eps * s6 * (6.f - 12.f * s6) * inv_r - qq * inv_r * inv_r;
+        float Ulj, dUlj;
+        if (rep_lam && alch[t] == 1 && eps != 0.f) {             // soft-core: listed_terms.h
+            const float2 sc = softcore_exception(rep_lam[4 * r], rep_lam[4 * r + 1], sig, eps, r2, inv_r);
+            Ulj = sc.x; dUlj = sc.y;
+        } else {
+            const float s2 = sig * sig * inv_r * inv_r, s6 = s2 * s2 * s2;
+            Ulj = 4.f * eps * s6 * (s6 - 1.f); dUlj = 4.f * eps * s6 * (6.f - 12.f * s6) * inv_r;
+        }
+        const float U = Ulj + qq * inv_r;
+        const float dUdr = dUlj - qq * inv_r * inv_r;
         const float fr = dUdr * inv_r;
         add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
         add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
@@ -1153,7 +1160,9 @@ __global__ void const_energy_kernel(int R, double disp_coeff, double self_nn, do
 __global__ __launch_bounds__(256)
 void alch_ukl_kernel(nb_params p, int N, int Npad, int n_alch, const int* __restrict__ alch_atoms,
                      const float4* __restrict__ pos, const float4* __restrict__ param, const float* __restrict__ box,
-                     int K, const double* __restrict__ state_lam /*[K][2]*/, double* __restrict__ out /*[R][K]*/)
+                     int K, const double* __restrict__ state_lam /*[K][2]*/, double* __restrict__ out /*[R][K]*/,
+                     int n_exc, const int* __restrict__ exc_atoms, const float* __restrict__ exc_params, const int* __restrict__ exc_alch,
+                     const unsigned long long* __restrict__ mask /*[Npad][excl_words], atom order*/)
 {
     __shared__ double s_part[4];
     const int k = blockIdx.x, r = blockIdx.y;
@@ -1166,6 +1175,9 @@ void alch_ukl_kernel(nb_params p, int N, int Npad, int n_alch, const int* __rest
         const int a = alch_atoms[t / N], j = t % N;
         const float4 pj = param[j];
         if (pj.w != 0.f) continue;                       // alchemical/alchemical pairs are not lambda-controlled
+        // excluded pairs (a region that cuts a molecule has bonded neighbours on both sides; their exceptions follow below)
+        const int dd = j - a + 32 * p.excl_words;
+        if (dd >= 0 && dd < 64 * p.excl_words && ((mask[(size_t)a * p.excl_words + (dd >> 6)] >> (dd & 63)) & 1ull)) continue;
         const float4 pa = param[a];
         const float4 xa = P[a], xj = P[j];
         float dx = xj.x - xa.x, dy = xj.y - xa.y, dz = xj.z - xa.z;
@@ -1181,6 +1193,16 @@ void alch_ukl_kernel(nb_params p, int N, int Npad, int n_alch, const int* __rest
         float U = lam_a * eps4 * x * (x - 1.f), dU = 0.f;
         switch_fn(p, rr, U, dU);
         e += (double)U;
+    }
+    // exceptions with one alchemical atom: the same soft-core, no cutoff, no switch (listed_terms.h)
+    for (int t = threadIdx.x; t < n_exc; t += 256) {
+        const float eps = exc_params[3 * t + 2];
+        if (exc_alch[t] != 1 || eps == 0.f) continue;
+        const float4 xa = P[exc_atoms[2 * t]], xj = P[exc_atoms[2 * t + 1]];
+        float dx = xj.x - xa.x, dy = xj.y - xa.y, dz = xj.z - xa.z;
+        if (Lx > 0.f) { dx -= Lx * rintf(dx / Lx); dy -= Ly * rintf(dy / Ly); dz -= Lz * rintf(dz / Lz); }
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        e += (double)softcore_exception(lam_a, sc, exc_params[3 * t + 1], eps, r2, rsqrtf(r2)).x;
     }
     e = block_sum_256(e, s_part);
     if (threadIdx.x == 0) out[(size_t)r * K + k] = e;
@@ -1366,9 +1388,8 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         if (qq != 0.0 || ep != 0.0) {
             // alchemy.py:1964-1990: electrostatic exceptions touching the region scale with lambda_electrostatics;
             // alchemical/alchemical sterics exceptions stay at full strength (annihilate_sterics=False); a sterics
-            // exception between an alchemical and a non-alchemical atom would need the soft-core CustomBondForce.
-            if ((t.is_alch[i] != t.is_alch[j]) && ep != 0.0)
-                return remd_fail(h, -3, "sterics exceptions between alchemical and non-alchemical atoms are not implemented");
+            // exception between an alchemical and a non-alchemical atom is soft-core (round 4: softcore_exception,
+            // listed_terms.h; the factory's CustomBondForce, alchemy.py:1836-1851) -- softcore_c = 6 like the pair kernel.
             exc_alch.push_back((int)t.is_alch[i] + (int)t.is_alch[j]);
             exc_atoms.push_back(i); exc_atoms.push_back(j);
             exc_params.push_back((float)(qq * REMD_ONE_4PI_EPS0)); exc_params.push_back((float)sg); exc_params.push_back((float)ep);
@@ -2062,7 +2083,7 @@ __global__ void assemble_ukl_poly_kernel(int R, int K, const double* __restrict_
                                          const double* __restrict__ beta, const double* __restrict__ econst,
                                          const double* __restrict__ lam_e, const double* __restrict__ alch, const int* __restrict__ own,
                                          const double* __restrict__ pressure /*[K] or null*/, const float* __restrict__ box,
-                                         double econst_vref, double* __restrict__ ukl_rows)
+                                         double econst_vref, double* __restrict__ ukl_rows, double* __restrict__ potential)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R * K) return;
@@ -2072,6 +2093,9 @@ __global__ void assemble_ukl_poly_kernel(int R, int K, const double* __restrict_
     const double b = (P1 - P0) - c;
     const double le = lam_e[l];
     const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
+    // the probes ran at the replica's own lambda_sterics: at its own lambda_electrostatics the polynomial is the potential of
+    // the replica's state (d_potential holds the last probe until here)
+    if (l == own[r]) potential[r] = P0 + b * le + c * le * le;
     double U = P0 + b * le + c * le * le + econst[l] * ((econst_vref > 0.0 && V > 0.0) ? econst_vref / V : 1.0);
     if (alch) U += alch[t] - alch[(size_t)r * K + own[r]];
     if (pressure) U += pressure[l] * V;
@@ -2106,7 +2130,8 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
         {
             remd_prof_scope ps(h, "alch_ukl");
             hipLaunchKernelGGL(alch_ukl_kernel, dim3(h->K, h->R), dim3(256), 0, h->stream, t.p, h->N, h->Npad, h->n_alch,
-                               h->d_alch_atoms, h->d_pos, t.d_param, h->d_box, h->K, t.d_state_lam, t.d_alch_ukl);
+                               h->d_alch_atoms, h->d_pos, t.d_param, h->d_box, h->K, t.d_state_lam, t.d_alch_ukl,
+                               t.n_exc, t.d_exc_atoms, t.d_exc_params, t.d_exc_alch, t.d_mask);
         }
         alch = t.d_alch_ukl;
         // lambda_electrostatics states need the polynomial only when alchemical atoms carry charge
@@ -2126,7 +2151,7 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
             h->forces_valid = false;        // the last pass used a probe lambda, not the replicas' own
             hipLaunchKernelGGL(assemble_ukl_poly_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K, t.d_probe,
                                h->d_beta, h->d_econst, h->d_lam_e, alch, t.d_own, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr,
-                               h->d_box, h->econst_vref, d_rows);
+                               h->d_box, h->econst_vref, d_rows, h->d_potential);
             REMD_CHECK(h, hipGetLastError());
             return 0;
         }

@@ -26,9 +26,23 @@ __device__ __forceinline__ float3 crs3(float3 a, float3 b) {
 }
 
 
+
+// Lennard-Jones part of an exception between an alchemical and a non-alchemical atom: the factory moves it to a
+// lambda_sterics-controlled CustomBondForce with the soft-core expression of the pair interactions, no cutoff, no switch
+// (alchemy.py:1836-1851, 1985-1998, expression :1374-1380 with softcore_c = 6).  lam_a = lambda^a, sc = alpha (1 - lambda)^b.
+// Returns (U, dU/dr).
+__device__ __forceinline__ float2 softcore_exception(float lam_a, float sc, float sig, float eps, float r2, float inv_r)
+{
+    const float is2 = 1.f / (sig * sig);
+    const float t = r2 * r2 * r2 * is2 * is2 * is2;
+    const float x = 1.f / (sc + t);
+    const float e4 = 4.f * eps * lam_a;
+    return make_float2(e4 * x * (x - 1.f), e4 * (2.f * x - 1.f) * (-x * x * 6.f * t * inv_r));
+}
+
+
 // All short "listed" terms of one force evaluation in a single launch (force-only path): harmonic bonds, angles,
 // periodic torsions, non-zero exceptions and the Ewald exclusion correction.  One term per thread.
-
 __device__ __forceinline__
 void listed_forces_body(const listed_tables& T, int Npad, const float4* __restrict__ pos, const float* __restrict__ box,
                         long long* __restrict__ force, int t, int r)
@@ -95,8 +109,14 @@ void listed_forces_body(const listed_tables& T, int Npad, const float4* __restri
         if (Lx > 0.f) { d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz); }
         const float r2 = dotf(d, d);
         const float inv_r = rsqrtf(r2);
-        const float s2 = sig * sig * inv_r * inv_r, s6 = s2 * s2 * s2;
-        const float fr = (4.f * eps * s6 * (6.f - 12.f * s6) * inv_r - qq * inv_r * inv_r) * inv_r;
+        float dUlj;
+        if (T.rep_lam && T.exc_alch[t] == 1 && eps != 0.f) {
+            dUlj = softcore_exception(T.rep_lam[4 * r], T.rep_lam[4 * r + 1], sig, eps, r2, inv_r).y;
+        } else {
+            const float s2 = sig * sig * inv_r * inv_r, s6 = s2 * s2 * s2;
+            dUlj = 4.f * eps * s6 * (6.f - 12.f * s6) * inv_r;
+        }
+        const float fr = (dUlj - qq * inv_r * inv_r) * inv_r;
         add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
         add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
         return;

@@ -606,16 +606,29 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
         if (g_time) g_timers.pairs += now_ms() - tt0;
     }
     // ---- exceptions (no cutoff) and the Ewald correction of every excluded pair ------------------------------------------
-    if (parts & (PART_STERICS | PART_ELEC)) {
+    if (parts & (PART_STERICS | PART_SOFTCORE | PART_ELEC)) {
         const size_t ne = s.exc_atoms.size() / 2;
         const double two_a_sqrtpi = 2.0 * s.alpha / sqrt(PI);
+        const double la = pow(lam_s, s.sc_a), lb = s.sc_alpha * pow(1.0 - lam_s, s.sc_b);
         for (size_t e = 0; e < ne; ++e) {
             const int i = s.exc_atoms[2 * e], j = s.exc_atoms[2 * e + 1];
             const double qq0 = s.exc_params[3 * e], sg = s.exc_params[3 * e + 1], ep = s.exc_params[3 * e + 2];
             double d[3]; delta(i, j, d);
             const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], rr = sqrt(r2);
             double fr = 0.0;
-            if ((parts & PART_STERICS) && ep != 0.0) {
+            // the Lennard-Jones part of an exception between an alchemical and a non-alchemical atom is soft-core and
+            // lambda_sterics-controlled like the pair interaction, without cutoff or switch (CustomBondForce of alchemy.py:1836-1851,
+            // 1985-1998); alchemical/alchemical exceptions keep lambda = 1 (annihilate_sterics = False)
+            const bool na = s.has_alch && (s.alch[i] != s.alch[j]);
+            if (ep != 0.0 && na && (parts & PART_SOFTCORE)) {
+                const double rs_c = pow(rr / sg, s.sc_c);
+                const double base = lb + rs_c;
+                const double xs = pow(base, -6.0 / s.sc_c);
+                E.c[4] += la * 4.0 * ep * xs * (xs - 1.0);
+                const double dxdr = (-6.0 / s.sc_c) * pow(base, -6.0 / s.sc_c - 1.0) * s.sc_c * rs_c / rr;
+                fr -= la * 4.0 * ep * (2.0 * xs - 1.0) * dxdr / rr;
+            }
+            if ((parts & PART_STERICS) && ep != 0.0 && !na) {
                 const double s2 = sg * sg / r2, s6 = s2 * s2 * s2;
                 E.c[4] += 4.0 * ep * s6 * (s6 - 1.0);
                 fr += 4.0 * ep * (12.0 * s6 * s6 - 6.0 * s6) / r2;

@@ -22,7 +22,9 @@ vendored under /root/reference, so absolute parity with it is UNPINNED; see md_o
     (alchemy/alchemy.py:1383-1388): U = l^a 4 eps x (x-1), x = (s/r_eff)^6,
     r_eff = s (alpha (1-l)^b + (r/s)^c)^(1/c); alchemical/alchemical pairs keep full LJ
     (annihilate_sterics=False, alchemy.py:421); alchemical charges scale with
-    lambda_electrostatics (exact PME treatment, alchemy.py:1675-1680).
+    lambda_electrostatics (exact PME treatment, alchemy.py:1675-1680); the Lennard-Jones part of an
+    exception with ONE alchemical atom is soft-core and lambda_sterics-controlled too, without cutoff
+    or switch (CustomBondForce, alchemy.py:1836-1851, 1985-1998).
 """
 import math
 import numpy as np
@@ -201,7 +203,7 @@ class ForceFieldOracle(OracleSystem):
                 e = e + (qq * (1.0 / r + krf * r * r - crf)).sum()
         return e
 
-    def _exceptions(self, x, box_t, lam_e):
+    def _exceptions(self, x, box_t, lam_e, lam_s=1.0, include_na=True, only_na=False):
         e = x.new_zeros(())
         if len(self.exc_atoms) == 0:
             return e
@@ -213,11 +215,23 @@ class ForceFieldOracle(OracleSystem):
         r = dv.norm(dim=1)
         nz = (p[:, 0] != 0) | (p[:, 2] != 0)
         sr6 = torch.where(nz, (p[:, 1] / r) ** 6, torch.zeros_like(r))
+        lj = 4.0 * p[:, 2] * sr6 * (sr6 - 1.0)
+        # Lennard-Jones exceptions between an alchemical and a non-alchemical atom: soft-core, lambda_sterics-controlled,
+        # no cutoff and no switch (the factory's CustomBondForce, alchemy.py:1836-1851, 1985-1998, expression :1374-1380)
+        na = torch.tensor(self.is_alch[i] != self.is_alch[j]) & (p[:, 2] != 0)
+        alpha_sc, a, b, c = self.sc
+        sig = torch.where(na, p[:, 1], torch.ones_like(r))
+        reff = sig * (alpha_sc * (1.0 - lam_s) ** b + (r / sig) ** c) ** (1.0 / c)
+        xsc = (sig / reff) ** 6
+        sc = (lam_s ** a) * 4.0 * p[:, 2] * xsc * (xsc - 1.0)
+        if only_na:
+            return torch.where(na, sc, torch.zeros_like(sc)).sum()
+        e = e + torch.where(na, sc if include_na else torch.zeros_like(sc), lj).sum()
         # exact PME treatment: electrostatic exceptions touching the alchemical region scale with lambda_electrostatics
         # (exception parameter offset, alchemy.py:1964-1966)
         any_alch = torch.tensor(self.is_alch[i] | self.is_alch[j])
         qq = torch.where(any_alch, p[:, 0] * lam_e, p[:, 0])
-        e = e + (torch.where(nz, ONE_4PI_EPS0 * qq / r, torch.zeros_like(r)) + 4.0 * p[:, 2] * sr6 * (sr6 - 1.0)).sum()
+        e = e + torch.where(nz, ONE_4PI_EPS0 * qq / r, torch.zeros_like(r)).sum()
         if self.method == 2 and self.has_charge:
             q = torch.where(self.alch_t, self.q * lam_e, self.q)
             e = e - (ONE_4PI_EPS0 * q[i] * q[j] * torch.erf(self.alpha * r) / r).sum()
@@ -263,7 +277,7 @@ class ForceFieldOracle(OracleSystem):
                 pairs = self._pairs(x.detach().numpy(), np.asarray(box, dtype=np.float64))
                 if len(pairs):
                     e = e + self._pair_terms(x, box_t, pairs, lam_s, lam_e, include_na=include_na)
-                e = e + self._exceptions(x, box_t, lam_e)
+                e = e + self._exceptions(x, box_t, lam_e, lam_s, include_na=include_na)
                 e = e + self.disp_coeff / V
             if self.method == 2 and self.has_charge and on(5):
                 q = torch.where(self.alch_t, self.q * lam_e, self.q)
@@ -295,7 +309,8 @@ class ForceFieldOracle(OracleSystem):
         base = float(self.energy_torch(xt, box, 1.0, 1.0, include_na=False))
         box_t = torch.tensor(np.asarray(box, dtype=np.float64))
         pairs = self._pairs(np.asarray(x, dtype=np.float64), np.asarray(box, dtype=np.float64))
-        return np.array([base + float(self._pair_terms(xt, box_t, pairs, ls, 1.0, only_na=True)) for ls in lam_s])
+        return np.array([base + float(self._pair_terms(xt, box_t, pairs, ls, 1.0, only_na=True))
+                         + float(self._exceptions(xt, box_t, 1.0, ls, only_na=True)) for ls in lam_s])
 
 
 def ewald_direct_sum(x, q, box, alpha, rc_real=None, kmax=12):

@@ -222,7 +222,7 @@ def _document_energy(xml, x, box, lambdas):
     return total + ForceFieldOracle(system_to_desc(plain)).energy_forces(x, box, forces=False)[0]
 
 
-@pytest.mark.parametrize('name', ['lj-reaction-field', 'alanine-pme', 'host-guest-pme'])
+@pytest.mark.parametrize('name', ['lj-reaction-field', 'alanine-pme', 'alanine-cut-pme', 'host-guest-pme'])
 def test_the_document_means_the_hamiltonian_the_engine_evaluates(name):
     if name == 'lj-reaction-field':
         t = testsystems.LennardJonesFluid(nparticles=216, reduced_density=0.6, dispersion_correction=False)
@@ -230,6 +230,9 @@ def test_the_document_means_the_hamiltonian_the_engine_evaluates(name):
     elif name == 'alanine-pme':
         t = testsystems.AlanineDipeptideExplicit(use_dispersion_correction=False)
         atoms = range(22)
+    elif name == 'alanine-cut-pme':          # the region cuts the solute: 16 soft-core exception bonds, 12 alchemical/alchemical ones
+        t = testsystems.AlanineDipeptideExplicit(use_dispersion_correction=False)
+        atoms = range(10)
     else:
         t = testsystems.HostGuestExplicit(use_dispersion_correction=False)
         atoms = range(126, 156)
@@ -245,12 +248,14 @@ def test_the_document_means_the_hamiltonian_the_engine_evaluates(name):
 
 
 # ---- round trip and the store -------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('case', ['lj', 'alanine', 'host-guest', 'softcore'])
+@pytest.mark.parametrize('case', ['lj', 'alanine', 'alanine-cut', 'host-guest', 'softcore'])
 def test_write_then_read_returns_the_marked_system(case):
     if case == 'lj':
         marked = _alchemical(testsystems.LennardJonesFluid(nparticles=64), range(4))
     elif case == 'alanine':
         marked = _alchemical(testsystems.AlanineDipeptideExplicit(), range(22))
+    elif case == 'alanine-cut':
+        marked = _alchemical(testsystems.AlanineDipeptideExplicit(), range(10))
     elif case == 'host-guest':
         marked = _alchemical(testsystems.HostGuestExplicit(), range(126, 156))
     else:

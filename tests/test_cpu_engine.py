@@ -151,6 +151,31 @@ def test_cpu_hostguest_lambda_rows(cpu_engine_factory):
     assert np.abs(f[0] - f_ref).max() < 1e-7 * np.abs(f_ref).max()
 
 
+def test_cpu_softcore_exceptions_of_a_region_that_cuts_a_molecule(cpu_engine_factory, alanine):
+    """Round 4: 1-4 exceptions between an alchemical and a non-alchemical atom carry soft-core, lambda_sterics-controlled
+    Lennard-Jones (the factory's CustomBondForce, alchemy.py:1836-1851, 1985-1998); earlier rounds left them at full strength.
+    Alanine dipeptide with only its first 10 atoms alchemical: 16 such exceptions.  u_kl rows, the own-state potential and the
+    forces of the C++ port against the torch oracle (which tests/test_alchemical_store_cpu.py pins against the reference's
+    energy expression)."""
+    alanine = alanine[0]
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(alanine.system, alchemy.AlchemicalRegion(alchemical_atoms=range(10)))
+    lam_e = np.array([1.0, 0.5, 0.0, 0.0, 0.0])
+    lam_s = np.array([1.0, 1.0, 1.0, 0.45, 0.0])
+    eng = cpu_engine_factory()
+    desc, x, box = _setup(eng, system, alanine.positions, R=1, lam_s=lam_s, lam_e=lam_e, labels=[3])
+    ff = ForceFieldOracle(desc)
+    nb_exc = [(i, j) for (i, j), p in zip(desc['exception_atoms'], desc['exception_params']) if p[2] != 0 and (i < 10) != (j < 10)]
+    assert len(nb_exc) == 16
+    rows, U = eng.compute_energies(want_potential=True)
+    ref = ff.state_energies(x[0], box[0], lam_s, lam_e)
+    assert np.allclose(rows[0], ref / (KB * 300.0), rtol=1e-9), np.abs(rows[0] * KB * 300.0 / ref - 1).max()
+    assert np.isclose(U[0], ref[3], rtol=1e-9)
+    assert abs(ref[3] - ff.energy_forces(x[0], box[0], lambda_sterics=1.0, lambda_electrostatics=0.0, forces=False)[0]) > 1.0   # lambda matters
+    f = eng.get_forces()
+    f_ref = ff.energy_forces(x[0], box[0], lambda_sterics=0.45, lambda_electrostatics=0.0)[1]
+    assert np.abs(f[0] - f_ref).max() < 1e-7 * np.abs(f_ref).max()
+
+
 def test_cpu_sampler_equals_python_oracle_engine(cpu_engine_factory):
     """The whole iteration (mix -> propagate -> u_kl) of ParallelTemperingSampler through the ABI on the CPU library equals
     the run on the Python OracleEngine: labels and count matrices exactly, energies to round-off."""

@@ -484,6 +484,41 @@ def test_more_than_8191_molecules_stay_on_the_cluster_path(hip_engine_factory, m
     assert np.abs(f1[1] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
 
 
+def test_softcore_exceptions_of_a_region_that_cuts_a_molecule(hip_engine_factory):
+    """Round 4: the Lennard-Jones part of a 1-4 exception between an alchemical and a non-alchemical atom is soft-core and
+    lambda_sterics-controlled (the factory's CustomBondForce, alchemy.py:1836-1851, 1985-1998).  Alanine dipeptide with its
+    first 10 atoms alchemical (16 such exceptions): u_kl over a (lambda_e, lambda_s) ladder, the own-state potential and the
+    forces at each replica's lambda against the f64 oracle."""
+    al = ts.AlanineDipeptideExplicit()
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, alchemy.AlchemicalRegion(alchemical_atoms=range(10)))
+    lam_e = np.array([1.0, 0.5, 0.0, 0.0, 0.0, 0.0])
+    lam_s = np.array([1.0, 1.0, 1.0, 0.7, 0.3, 0.0])
+    nb = [f for f in system.getForces() if hasattr(f, 'particles') and hasattr(f, 'exceptions')][0]
+    V = np.prod(np.diag(system.getDefaultPeriodicBoxVectors()))
+    econst = alchemy.alchemical_long_range_constants(system, nb, lam_s, V)
+    eng = hip_engine_factory()
+    desc = system_to_desc(system)
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 300.0)
+    eng.set_states(np.full(6, beta), lam_s, lam_e, econst)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 5, True, 1e-8)
+    eng.seed(SEED)
+    labels = np.array([0, 3, 4])
+    x = np.stack([al.positions + 0.001 * r * np.random.default_rng(r).normal(size=al.positions.shape) for r in range(3)])
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (3, 1))
+    eng.set_replicas(3, 0, x, None, box, labels)
+    ff = ForceFieldOracle(desc)
+    rows, U = eng.compute_energies(want_potential=True)
+    xd = eng.get_replicas()[0]
+    f = eng.get_forces()
+    for r, k in enumerate(labels):
+        ref = ff.state_energies(xd[r], box[r], lam_s, lam_e)
+        assert np.allclose(rows[r], beta * (ref + econst), rtol=1e-5), np.abs(rows[r] / (beta * (ref + econst)) - 1).max()
+        assert np.isclose(U[r], ref[k], rtol=1e-5)
+        f_ref = ff.energy_forces(xd[r], box[r], lambda_sterics=lam_s[k], lambda_electrostatics=lam_e[k])[1]
+        assert np.abs(f[r] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
+
+
 def test_config4_all_64_alchemical_states_ukl(hip_engine_factory):
     """BASELINE config 4 AT ITS STATED SIZE: CB7:B2 with the full 64-state ladder (lambda_electrostatics 1 -> 0 over 32
     states, then lambda_sterics 1 -> 0 over 32) — every column of two replicas' u_kl rows against
