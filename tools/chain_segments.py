@@ -10,11 +10,11 @@ from openmmtools_amd._engine import HipEngine
 KB = 0.008314462618153242
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 splitting = sys.argv[2] if len(sys.argv) > 2 else 'V R R O R R V'
-al = ts.AlanineDipeptideExplicit()
+al = ts.DHFRExplicit() if os.environ.get('SEG_SYSTEM') == 'dhfr' else ts.AlanineDipeptideExplicit()
 box = np.diag(al.system.getDefaultPeriodicBoxVectors())
 eng = HipEngine(lib_path=os.environ.get('AB_LIB') or None)
-eng.set_system(system_to_desc(al.system)); eng.set_states(1 / (KB * np.linspace(300.0, 600.0, R)))
-eng.set_integrator(splitting, 0.002, 5.0, 500, True, 1e-8)
+eng.set_system(system_to_desc(al.system, ewald_split='auto')); eng.set_states(1 / (KB * np.linspace(300.0, 600.0, R)))
+eng.set_integrator(splitting, 0.002, 5.0, int(os.environ.get('SEG_STEPS', '500')), True, 1e-8)
 eng.seed(1)
 eng.set_replicas(R, 0, np.tile(al.positions, (R, 1, 1)), None, np.tile(box, (R, 1)), np.arange(R))
 eng.propagate(0)
