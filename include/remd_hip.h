@@ -202,7 +202,8 @@ int  remd_minimize(remd_handle h, double tolerance_kj_per_mol_nm, int max_iterat
                    int32_t* converged, int32_t* n_iterations);
 
 /* Replicas r_begin .. r_begin+R_local-1 of R_global live on this handle.
-   x, v: [R_local][N][3] (v may be NULL -> zero); box: [R_local][3] orthorhombic edge
+   x, v: [R_local][N][3] (v may be NULL -> zero; x may be NULL when the coordinates follow through
+   remd_copy_replicas: the call then only sizes the handle); box: [R_local][3] orthorhombic edge
    lengths; labels: [R_global] state index of every replica.
    Reference: SamplerState.apply_to_context (states.py:2257-2279).                       */
 int  remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local,
@@ -215,6 +216,15 @@ int  remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local,
    states: states.py:186-217, multistatesampler.py:1296-1320 propagates a replica in the Context of its own state's System) passes the
    subset's global indices here, after remd_set_replicas (which resets them); NULL restores the default.                       */
 int  remd_set_replica_ids(remd_handle h, const int64_t* global_replica_index /* [R_local] or NULL */);
+
+/* Device-to-device transfer of replicas between two handles on the same device that hold the same particles (one handle per
+   compatibility group of states: the reference propagates a replica in the Context of its own state's System,
+   multistatesampler.py:1296-1320, and evaluates every configuration in one Context per group, :1470-1490 -- the coordinates it moves
+   between Contexts through SamplerState.apply_to_context, states.py:2257-2279, stay on the device here): positions, velocities
+   and box edges of src's local replicas src_slot[k] replace those of dst's local replicas dst_slot[k], k < n.  what: bit 0
+   positions, bit 1 velocities, bit 2 boxes.  dst is sized by remd_set_replicas first (x = NULL there: "coordinates follow").
+   Returns after the copy is complete; dst re-sorts its molecules at the next force evaluation. */
+int  remd_copy_replicas(remd_handle dst, const int32_t* dst_slot, remd_handle src, const int32_t* src_slot, int32_t n, int32_t what);
 
 int  remd_set_labels(remd_handle h, const int64_t* labels /*[R_global]*/);
 int  remd_seed(remd_handle h, uint64_t seed);

@@ -40,7 +40,7 @@ class RemdSystemDesc(C.Structure):
 
 EXPORTS = [
     'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_states',
-    'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_set_labels', 'remd_seed', 'remd_propagate',
+    'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_copy_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
@@ -98,6 +98,7 @@ def load_library(path=None):
     lib.remd_barostat_attempts.argtypes = [vp, C.c_int]
     lib.remd_set_replicas.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int64_p]
     lib.remd_set_replica_ids.argtypes = [vp, c_int64_p]
+    lib.remd_copy_replicas.argtypes = [vp, c_int32_p, vp, c_int32_p, C.c_int32, C.c_int32]
     lib.remd_set_labels.argtypes = [vp, c_int64_p]
     lib.remd_seed.argtypes = [vp, C.c_uint64]
     lib.remd_propagate.argtypes = [vp, C.c_int64, c_int32_p]
@@ -327,15 +328,29 @@ class HipEngine:
         return conv, n.value
 
     def set_replicas(self, R_global, r_begin, x, v, box, labels):
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        R_local = x.shape[0]
+        """x = None sizes the handle for len(box) replicas whose coordinates follow through copy_replicas."""
+        box = np.ascontiguousarray(box, dtype=np.float64)
+        R_local = box.reshape(-1, 3).shape[0] if x is None else np.shape(x)[0]
+        x = None if x is None else np.ascontiguousarray(x, dtype=np.float64)
         v = None if v is None else np.ascontiguousarray(v, dtype=np.float64)
-        box = np.ascontiguousarray(box, dtype=np.float64).reshape(R_local, 3)
+        box = box.reshape(R_local, 3)
         labels = np.ascontiguousarray(labels, dtype=np.int64)
-        assert x.shape == (R_local, self.N, 3) and labels.shape == (R_global,)
+        assert (x is None or x.shape == (R_local, self.N, 3)) and labels.shape == (R_global,)
         self._check(self.lib.remd_set_replicas(self.h, int(R_global), int(r_begin), R_local, _dp(x), _dp(v),
                                                _dp(box), _lp(labels)), 'remd_set_replicas')
         self.R, self.R_global, self.r_begin = R_local, int(R_global), int(r_begin)
+
+    POSITIONS, VELOCITIES, BOXES = 1, 2, 4
+
+    def copy_replicas(self, slots, source, source_slots, what=7):
+        """Positions / velocities / boxes (bits 1 / 2 / 4 of ``what``) of ``source``'s local replicas ``source_slots`` into this
+        handle's local replicas ``slots``, device to device (remd_copy_replicas; one handle per compatibility group)."""
+        d = np.ascontiguousarray(slots, dtype=np.int32)
+        s = np.ascontiguousarray(source_slots, dtype=np.int32)
+        if d.shape != s.shape or d.ndim != 1:
+            raise ValueError('one source slot per destination slot')
+        self._check(self.lib.remd_copy_replicas(self.h, d.ctypes.data_as(c_int32_p), source.h, s.ctypes.data_as(c_int32_p),
+                                                int(len(d)), int(what)), 'remd_copy_replicas')
 
     def set_replica_ids(self, ids):
         """Global replica indices that key the local replicas' random streams (a handle holding a non-contiguous subset of the

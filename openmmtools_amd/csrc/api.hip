@@ -13,6 +13,7 @@ int remd_nb_required_epart(remd_ctx* h);
 void remd_free_nonbonded(remd_ctx* h);
 void remd_mix_release(remd_ctx* h);          // mix.hip
 void remd_nb_reset_accumulators(remd_ctx* h); // forces.hip
+void remd_nb_invalidate_sort(remd_ctx* h);    // forces.hip
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
 void remd_nb_tune_resolve(remd_ctx* h);
 static int remd_check_device_flags(remd_ctx* h, const char* where, bool may_retry = false);
@@ -278,7 +279,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
                       const double* box, const int64_t* labels)
 {
     if (!h || !h->has_system) return remd_fail(h, -1, "remd_set_replicas: call remd_set_system first");
-    if (R_global <= 0 || R_local <= 0 || r_begin < 0 || r_begin + R_local > R_global || !x || !labels)
+    if (R_global <= 0 || R_local <= 0 || r_begin < 0 || r_begin + R_local > R_global || !labels)
         return remd_fail(h, -1, "remd_set_replicas: bad arguments");
     hipSetDevice(h->device);
     const bool realloc = (R_local != h->R) || (R_global != h->R_global) || !h->d_pos;
@@ -310,9 +311,11 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         }
     }
     std::vector<float4> hp(n, make_float4(0, 0, 0, 0)), hv(n, make_float4(0, 0, 0, 0));
+    // (x = NULL: the coordinates follow through remd_copy_replicas; until then every replica holds atoms on a coarse lattice)
     for (int r = 0; r < R_local; ++r)
         for (int i = 0; i < h->N; ++i) {
-            const double* p = x + ((size_t)r * h->N + i) * 3;
+            const double lattice[3] = { 0.3 * (i % 64), 0.3 * ((i / 64) % 64), 0.3 * (i / 4096) };
+            const double* p = x ? x + ((size_t)r * h->N + i) * 3 : lattice;
             hp[(size_t)r * h->Npad + i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
             if (v) {
                 const double* w = v + ((size_t)r * h->N + i) * 3;
@@ -340,10 +343,82 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     h->forces_valid = false; h->force_zeroed = false;
     h->cbins_ready = false;              // (bins a chain filled for positions that are gone)
     h->comm_part_current = false;       // (the ranks exchange their blocks again at the next all-gather)
+    remd_nb_invalidate_sort(h);         // (a molecule order made for other coordinates overflows the cluster lists)
     // (the mesh buffers follow the replica count; a call that only replaces coordinates keeps them -- one handle per compatibility
     // group re-enters here every iteration, multistate/_engine_pool.py)
     if (h->nb_method == REMD_NB_PME && (realloc || !h->pme)) { int rc = remd_pme_setup(h); if (rc) return rc; }
     return remd_set_labels(h, labels);
+}
+
+// rows of [R][Npad] float4 arrays from one handle's slots to another's
+__global__ __launch_bounds__(256)
+void copy_replica_rows_kernel(int Npad, const int* __restrict__ slots /*[2][n]: dst, src*/, int n, float4* __restrict__ dst_pos,
+                              const float4* __restrict__ src_pos, float4* __restrict__ dst_vel, const float4* __restrict__ src_vel,
+                              float* __restrict__ dst_box, const float* __restrict__ src_box)
+{
+    const int k = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = slots[k], s = slots[n + k];
+    if (i < Npad) {
+        if (dst_pos) dst_pos[(size_t)d * Npad + i] = src_pos[(size_t)s * Npad + i];
+        if (dst_vel) dst_vel[(size_t)d * Npad + i] = src_vel[(size_t)s * Npad + i];
+    }
+    if (dst_box && i < 4) dst_box[4 * d + i] = src_box[4 * s + i];
+}
+
+int remd_copy_replicas(remd_handle dst, const int32_t* dst_slot, remd_handle src, const int32_t* src_slot, int32_t n, int32_t what)
+{
+    if (!dst || !src || !dst->has_system || !src->has_system || !dst->d_pos || !src->d_pos)
+        return remd_fail(dst, -1, "remd_copy_replicas: both handles need a system and replicas (remd_set_replicas)");
+    if (n < 0 || (n > 0 && (!dst_slot || !src_slot)) || (what & ~7) || !(what & 7)) return remd_fail(dst, -1, "remd_copy_replicas: bad arguments");
+    if (dst->device != src->device) return remd_fail(dst, -3, "remd_copy_replicas: the handles live on different devices");
+    if (dst->N != src->N || dst->Npad != src->Npad) return remd_fail(dst, -1, "remd_copy_replicas: the handles hold different particle counts");
+    if (dst == src) return remd_fail(dst, -1, "remd_copy_replicas: source and destination are the same handle");
+    if (n == 0) return 0;
+    std::vector<int> slots(2 * (size_t)n);
+    std::vector<char> seen(dst->R, 0);
+    for (int k = 0; k < n; ++k) {
+        if (dst_slot[k] < 0 || dst_slot[k] >= dst->R || src_slot[k] < 0 || src_slot[k] >= src->R) return remd_fail(dst, -1, "remd_copy_replicas: slot out of range");
+        if (seen[dst_slot[k]]++) return remd_fail(dst, -1, "remd_copy_replicas: a destination slot is named twice");
+        slots[k] = dst_slot[k]; slots[n + k] = src_slot[k];
+    }
+    hipSetDevice(dst->device);
+    REMD_CHECK(dst, hipStreamSynchronize(src->stream));              // what the source computed last is complete
+    int* d_slots = nullptr;
+    REMD_CHECK(dst, hipMalloc(&d_slots, sizeof(int) * slots.size()));
+    REMD_CHECK(dst, hipMemcpyAsync(d_slots, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, dst->stream));
+    const bool pos = what & 1, vel = what & 2, box = what & 4;
+    hipLaunchKernelGGL(copy_replica_rows_kernel, dim3((dst->Npad + 255) / 256, n), dim3(256), 0, dst->stream, dst->Npad, d_slots, n,
+                       pos ? dst->d_pos : (float4*)nullptr, src->d_pos, vel ? dst->d_vel : (float4*)nullptr, src->d_vel,
+                       box ? dst->d_box : (float*)nullptr, src->d_box);
+    REMD_CHECK(dst, hipGetLastError());
+    if (box) {
+        std::vector<float> hb(4 * (size_t)dst->R);
+        REMD_CHECK(dst, hipMemcpyAsync(hb.data(), dst->d_box, sizeof(float) * hb.size(), hipMemcpyDeviceToHost, dst->stream));
+        REMD_CHECK(dst, hipStreamSynchronize(dst->stream));
+        bool changed = dst->box_host.size() != 3 * (size_t)dst->R;
+        dst->box_host.resize(3 * (size_t)dst->R, 0.0);
+        for (int r = 0; r < dst->R; ++r) for (int k = 0; k < 3; ++k) {
+            // (the mirror keeps the doubles a remd_set_replicas gave where the device value still is their rounding)
+            if ((float)dst->box_host[3 * r + k] != hb[4 * r + k]) { dst->box_host[3 * r + k] = hb[4 * r + k]; changed = true; }
+        }
+        if (dst->nb_method != REMD_NB_NONE)
+            for (int r = 0; r < dst->R; ++r) for (int k = 0; k < 3; ++k)
+                if (dst->box_host[3 * r + k] < 2.0 * dst->cutoff) { hipFree(d_slots); return remd_fail(dst, -1, "remd_copy_replicas: box smaller than twice the cutoff"); }
+        if (changed) {
+            dst->box_uniform = true;
+            for (int r = 1; r < dst->R; ++r) for (int k = 0; k < 3; ++k) if (hb[4 * r + k] != hb[k]) dst->box_uniform = false;
+            dst->box_version++;
+        }
+    }
+    REMD_CHECK(dst, hipStreamSynchronize(dst->stream));
+    hipFree(d_slots);
+    if (pos || box) {
+        dst->forces_valid = false; dst->force_zeroed = false;
+        dst->cbins_ready = false;
+        dst->comm_part_current = false;
+        remd_nb_invalidate_sort(dst);
+    }
+    return 0;
 }
 
 int remd_set_work_measurement(remd_handle h, int measure_heat, int measure_shadow_work)

@@ -6,13 +6,15 @@ state's System (multistatesampler.py:1296-1320) and its configuration is evaluat
 matrix (:1470-1490).  Here a group is an engine handle with its own System tables on the device:
 
     propagation   the local replicas are partitioned by the group of their current state; each group's handle receives its
-                  share as one batch (``set_replicas`` of the subset, ``propagate``, ``get_replicas``) -- batches, not one
-                  launch chain per replica; a group without replicas in an iteration is skipped
+                  share as one batch, propagates it and hands it back -- batches, not one launch chain per replica; a group
+                  without replicas in an iteration is skipped
     u_kl          a second handle per group holds ALL local replicas and fills the columns of the group's states
     mixing        any handle: the swap kernels only see the energy matrix
 
-The master copy of positions / velocities / boxes lives on the host between the calls (a few MB per iteration), which is
-what the reference does with its SamplerStates.  Random streams: every handle carries the ensemble's seed and a group's share of
+Round 4: the master copy of positions / velocities / boxes lives ON THE DEVICE, in the first group's all-replica handle; shares
+go to the propagation handles and back, and the full set to the other groups' energy handles, through ``copy_replicas``
+(remd_copy_replicas: device-to-device rows, no host staging; the reference moves them between Contexts through
+SamplerState.apply_to_context).  The host sees coordinates only in ``set_replicas`` / ``get_replicas``.  Random streams: every handle carries the ensemble's seed and a group's share of
 the local replicas is keyed by the replicas' GLOBAL indices (``set_replica_ids`` -> remd_set_replica_ids), exactly as a
 single-group run keys its block by r_begin + r: velocities, Langevin noise and Metropolis draws of a replica do not depend on
 which handle runs it, so a multi-group run is independent of the rank count too (tests/test_compat_groups.py; round 4 -- before,
@@ -22,7 +24,7 @@ import numpy as np
 
 
 class EnginePool:
-    is_device = False          # rows and labels pass through the host (the sampler takes its host all-gather path)
+    is_device = False          # rows and labels pass through the host (the sampler takes its host all-gather path); coordinates do not
 
     def __init__(self, first_engine, state_groups):
         """first_engine: an engine of the kind to pool (its ``spawn()`` or its class makes the others).
@@ -107,12 +109,18 @@ class EnginePool:
     # ---- replicas: master copy on the host ---------------------------------------------------------------------------
     def set_replicas(self, R_global, r_begin, x, v, box, labels):
         self.R_global, self.r_begin = int(R_global), int(r_begin)
-        self._x = np.array(x, dtype=np.float64)
-        self.R = self._x.shape[0]
-        self._v = np.zeros_like(self._x) if v is None else np.array(v, dtype=np.float64)
-        self._box = np.array(box, dtype=np.float64).reshape(self.R, 3)
-        self._energy_current = False
+        x = np.asarray(x, dtype=np.float64)
+        self.R = x.shape[0]
+        box = np.array(box, dtype=np.float64).reshape(self.R, 3)
+        zero = np.zeros(self.R, dtype=np.int64)
+        self._master.set_replicas(self.R, 0, x, v, box, zero)           # the master copy (labels of a handle are group-local)
+        for eng in self._energy[1:]:
+            eng.set_replicas(self.R, 0, None, None, box, zero)          # sized here, filled by copy_replicas before each use
         self.set_labels(labels)
+
+    @property
+    def _master(self):
+        return self._energy[0]
 
     def set_labels(self, labels):
         self._labels = np.array(labels, dtype=np.int64)
@@ -120,10 +128,11 @@ class EnginePool:
     def get_replicas(self, positions=True, velocities=True, potential=False, kinetic=False):
         if potential or kinetic:
             raise NotImplementedError('per-replica energies are not kept across compatibility groups')
-        return (self._x.copy() if positions else None), (self._v.copy() if velocities else None), None, None
+        x, v, _, _ = self._master.get_replicas(positions, velocities)
+        return x, v, None, None
 
     def get_boxes(self):
-        return self._box.copy()
+        return self._master.get_boxes()
 
     def _local_groups(self):
         mine = self._labels[self.r_begin:self.r_begin + self.R]
@@ -133,20 +142,20 @@ class EnginePool:
         """Run ``call(engine) -> per-replica result or None`` on each group's share of the local replicas."""
         grp, loc = self._local_groups()
         out = {}
+        boxes = None
         for g in range(self.G):
             idx = np.nonzero(grp == g)[0]
             if len(idx) == 0:
                 continue
             eng = self._propagator(g)
-            eng.set_replicas(len(idx), 0, self._x[idx], self._v[idx], self._box[idx], loc[idx])
-            if hasattr(eng, 'set_replica_ids'):
-                eng.set_replica_ids(self.r_begin + idx)              # noise keyed by the global replica index, whatever the grouping
+            slots = np.arange(len(idx))
+            if boxes is None:
+                boxes = self._master.get_boxes()                     # (3 numbers per replica: only to size the handle)
+            eng.set_replicas(len(idx), 0, None, None, boxes[idx], loc[idx])
+            eng.copy_replicas(slots, self._master, idx, 7)           # positions, velocities, boxes: device to device
+            eng.set_replica_ids(self.r_begin + idx)                  # noise keyed by the global replica index, whatever the grouping
             out[g] = (idx, call(eng))
-            x, v, _, _ = eng.get_replicas()
-            self._x[idx], self._v[idx] = x, v
-            if periodic_boxes:
-                self._box[idx] = eng.get_boxes()
-        self._energy_current = False
+            self._master.copy_replicas(idx, eng, slots, 7 if periodic_boxes else 3)
         return out
 
     def propagate(self, iteration):
@@ -177,9 +186,11 @@ class EnginePool:
         if d_rows is not None or want_potential:
             raise NotImplementedError('the pooled engines return host rows only')
         rows = np.empty((self.R, self.K), dtype=np.float64)
+        every = np.arange(self.R)
         for g in range(self.G):
             eng = self._energy[g]
-            eng.set_replicas(self.R, 0, self._x, self._v, self._box, np.zeros(self.R, dtype=np.int64))
+            if g > 0:
+                eng.copy_replicas(every, self._master, every, 5)     # positions and boxes of all local replicas
             rows[:, self._groups[g]] = eng.compute_energies()
         self._rows = rows
         return rows

@@ -1408,7 +1408,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
                       const int64_t* labels)
 {
     if (!h || !h->has_system) return fail(h, -1, "remd_set_replicas: call remd_set_system first");
-    if (R_global <= 0 || R_local <= 0 || r_begin < 0 || r_begin + R_local > R_global || !x || !labels)
+    if (R_global <= 0 || R_local <= 0 || r_begin < 0 || r_begin + R_local > R_global || !labels)
         return fail(h, -1, "remd_set_replicas: bad arguments");
     const int N = h->sys.N;
     h->R_global = R_global; h->r_begin = r_begin; h->R = R_local;
@@ -1416,7 +1416,8 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     h->reps.assign(R_local, Replica());
     for (int r = 0; r < R_local; ++r) {
         Replica& rep = h->reps[r];
-        rep.x.assign(x + (size_t)r * 3 * N, x + (size_t)(r + 1) * 3 * N);
+        if (x) rep.x.assign(x + (size_t)r * 3 * N, x + (size_t)(r + 1) * 3 * N);
+        else { rep.x.resize(3 * (size_t)N); for (int i = 0; i < N; ++i) { rep.x[3 * i] = 0.3 * (i % 64); rep.x[3 * i + 1] = 0.3 * ((i / 64) % 64); rep.x[3 * i + 2] = 0.3 * (i / 4096); } }   // coordinates follow: remd_copy_replicas
         if (v) rep.v.assign(v + (size_t)r * 3 * N, v + (size_t)(r + 1) * 3 * N); else rep.v.assign(3 * (size_t)N, 0.0);
         rep.f.assign(3 * (size_t)N, 0.0);
         for (int k = 0; k < 3; ++k) rep.box[k] = box ? box[3 * r + k] : 0.0;
@@ -1427,6 +1428,32 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     h->potential.assign(R_local, 0.0);
     h->labels.clear();
     return remd_set_labels(h, labels);
+}
+
+int remd_copy_replicas(remd_handle dst, const int32_t* dst_slot, remd_handle src, const int32_t* src_slot, int32_t n, int32_t what)
+{
+    if (!dst || !src || !dst->has_system || !src->has_system || dst->R <= 0 || src->R <= 0)
+        return fail(dst, -1, "remd_copy_replicas: both handles need a system and replicas (remd_set_replicas)");
+    if (n < 0 || (n > 0 && (!dst_slot || !src_slot)) || (what & ~7) || !(what & 7)) return fail(dst, -1, "remd_copy_replicas: bad arguments");
+    if (dst->sys.N != src->sys.N) return fail(dst, -1, "remd_copy_replicas: the handles hold different particle counts");
+    if (dst == src) return fail(dst, -1, "remd_copy_replicas: source and destination are the same handle");
+    std::vector<char> seen(dst->R, 0);
+    for (int k = 0; k < n; ++k) {
+        if (dst_slot[k] < 0 || dst_slot[k] >= dst->R || src_slot[k] < 0 || src_slot[k] >= src->R) return fail(dst, -1, "remd_copy_replicas: slot out of range");
+        if (seen[dst_slot[k]]++) return fail(dst, -1, "remd_copy_replicas: a destination slot is named twice");
+    }
+    for (int k = 0; k < n; ++k) {
+        Replica& d = dst->reps[dst_slot[k]];
+        const Replica& s = src->reps[src_slot[k]];
+        if (what & 1) d.x = s.x;
+        if (what & 2) d.v = s.v;
+        if (what & 4) {
+            for (int q = 0; q < 3; ++q) d.box[q] = s.box[q];
+            if (dst->sys.method) for (int q = 0; q < 3; ++q) if (d.box[q] < 2.0 * std::max(dst->sys.rc, dst->sys.rcc)) return fail(dst, -1, "remd_copy_replicas: box smaller than twice the cutoff");
+        }
+        if (what & 5) { d.f_valid = false; d.list_valid = false; }
+    }
+    return 0;
 }
 
 int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)

@@ -75,15 +75,26 @@ class OracleEngine:
 
     def set_replicas(self, R_global, r_begin, x, v, box, labels):
         self.R_global, self.r_begin = R_global, r_begin
-        self.x = np.array(x, dtype=np.float64)
+        self.box = np.array(box, dtype=np.float64).reshape(-1, 3)
+        # (x = None: the handle is only sized, coordinates follow through copy_replicas -- include/remd_hip.h)
+        self.x = np.zeros((len(self.box), self.N, 3)) if x is None else np.array(x, dtype=np.float64)
         self.R = self.x.shape[0]
         self.v = np.zeros_like(self.x) if v is None else np.array(v, dtype=np.float64)
-        self.box = np.array(box, dtype=np.float64).reshape(self.R, 3)
         self.labels = np.array(labels, dtype=np.int64)
         self.noise_ids = None                     # (ids belong to one set of replicas: include/remd_hip.h remd_set_replica_ids)
 
     def set_replica_ids(self, ids):
         self.noise_ids = None if ids is None else np.array(ids, dtype=np.int64)
+
+    def copy_replicas(self, slots, source, source_slots, what=7):
+        """remd_copy_replicas: positions (1), velocities (2), boxes (4) of ``source``'s slots into this engine's slots."""
+        d, s = np.asarray(slots, dtype=np.int64), np.asarray(source_slots, dtype=np.int64)
+        if what & 1:
+            self.x[d] = source.x[s]
+        if what & 2:
+            self.v[d] = source.v[s]
+        if what & 4:
+            self.box[d] = source.box[s]
 
     def _nk(self, r):
         ids = getattr(self, 'noise_ids', None)

@@ -220,3 +220,40 @@ def test_a_handle_holding_a_subset_keyed_by_global_indices_reproduces_those_repl
     eng.set_replicas(2, 0, x[[1, 3]], None, np.tile(box, (2, 1)), np.array([1, 3], dtype=np.int64))
     eng.propagate(3)
     assert not np.array_equal(eng.get_replicas()[0], out['subset'][0])
+
+
+@pytest.mark.gpu
+def test_copy_replicas_between_device_handles(hip_engine_factory):
+    """remd_copy_replicas: a handle sized with x = NULL and filled device-to-device evaluates and propagates bit for bit like a
+    handle that was given the same coordinates from the host (solvated dipeptide: molecule sort, cluster lists, mesh)."""
+    from openmmtools_amd import testsystems
+    from openmmtools_amd.system import system_to_desc
+    al = testsystems.AlanineDipeptideExplicit()
+    desc = system_to_desc(al.system, ewald_split='auto')
+    box = np.tile(np.diag(al.system.getDefaultPeriodicBoxVectors()), (4, 1))
+    rng = np.random.default_rng(2)
+    x = np.stack([al.positions + 0.002 * rng.normal(size=al.positions.shape) for _ in range(4)])
+    v = 0.3 * rng.normal(size=x.shape)
+    a, b, c = hip_engine_factory(), hip_engine_factory(), hip_engine_factory()
+    for eng in (a, b, c):
+        eng.set_system(desc)
+        eng.set_states(np.full(4, 1.0 / (0.008314462618153242 * 300.0)))
+        eng.set_integrator('V R O R V', 0.002, 1.0, 10, False, 1e-8)
+        eng.seed(9)
+    a.set_replicas(4, 0, x, v, box, np.arange(4))
+    a.compute_energies()                                   # (the source has work in flight on its own stream)
+    b.set_replicas(2, 0, None, None, box[:2], np.arange(2))
+    b.copy_replicas([1, 0], a, [3, 1], 7)
+    xa, va, _, _ = a.get_replicas()
+    xb, vb, _, _ = b.get_replicas()
+    assert np.array_equal(xb, xa[[1, 3]]) and np.array_equal(vb, va[[1, 3]])
+    c.set_replicas(2, 0, xa[[1, 3]], va[[1, 3]], box[:2], np.arange(2))
+    for eng in (b, c):
+        eng.set_replica_ids([1, 3])
+    assert np.array_equal(b.compute_energies(), c.compute_energies()) and np.array_equal(b.get_forces(), c.get_forces())
+    assert not b.propagate(0).any() and not c.propagate(0).any()
+    for got, ref in zip(b.get_replicas()[:2], c.get_replicas()[:2]):
+        assert np.array_equal(got, ref)
+    a.copy_replicas([3, 1], b, [0, 1], 3)                  # and back into the master
+    xa2 = a.get_replicas()[0]
+    assert np.array_equal(xa2[[3, 1]], b.get_replicas()[0]) and np.array_equal(xa2[[0, 2]], xa[[0, 2]])

@@ -176,6 +176,36 @@ def test_cpu_softcore_exceptions_of_a_region_that_cuts_a_molecule(cpu_engine_fac
     assert np.abs(f[0] - f_ref).max() < 1e-7 * np.abs(f_ref).max()
 
 
+def test_cpu_copy_replicas_between_handles(cpu_engine_factory):
+    """remd_copy_replicas (one handle per compatibility group, multistate/_engine_pool.py): rows go from one handle's slots to
+    another's without the host; a handle sized with x = NULL and filled that way evaluates like one given the coordinates."""
+    lj = ts.LennardJonesFluid(nparticles=64)
+    a, b, c = cpu_engine_factory(), cpu_engine_factory(), cpu_engine_factory()
+    desc, x, box = _setup(a, lj.system, lj.positions, R=4, jitter=0.01)
+    v = np.random.default_rng(1).normal(size=x.shape)
+    box = box * np.array([1.0, 1.01, 1.02, 1.03])[:, None]
+    a.set_replicas(4, 0, x, v, box, np.arange(4))
+    for eng in (b, c):
+        eng.set_system(desc)
+        eng.set_states(np.full(4, 1.0 / (KB * 300.0)))
+        eng.set_integrator('V R O R V', 0.001, 1.0, 5, True, 1e-8)
+        eng.seed(SEED)
+    b.set_replicas(2, 0, None, None, box[:2], np.arange(2))             # sized only
+    b.copy_replicas([1, 0], a, [3, 1], 7)
+    xb, vb, _, _ = b.get_replicas()
+    assert np.array_equal(xb, x[[1, 3]]) and np.array_equal(vb, v[[1, 3]]) and np.array_equal(b.get_boxes(), box[[1, 3]])
+    c.set_replicas(2, 0, x[[1, 3]], v[[1, 3]], box[[1, 3]], np.arange(2))
+    assert np.array_equal(b.compute_energies(), c.compute_energies()) and np.array_equal(b.get_forces(), c.get_forces())
+    b.copy_replicas([0], a, [0], 1)                                     # positions only
+    xb2, vb2, _, _ = b.get_replicas()
+    assert np.array_equal(xb2[0], x[0]) and np.array_equal(vb2, vb) and np.array_equal(b.get_boxes(), box[[1, 3]])
+    for bad in (([0, 0], [1, 2]), ([2], [0]), ([0], [4])):
+        with pytest.raises(RuntimeError, match='remd_copy_replicas'):
+            b.copy_replicas(bad[0], a, bad[1], 7)
+    with pytest.raises(RuntimeError, match='same handle'):
+        a.copy_replicas([0], a, [1], 7)
+
+
 def test_cpu_sampler_equals_python_oracle_engine(cpu_engine_factory):
     """The whole iteration (mix -> propagate -> u_kl) of ParallelTemperingSampler through the ABI on the CPU library equals
     the run on the Python OracleEngine: labels and count matrices exactly, energies to round-off."""
