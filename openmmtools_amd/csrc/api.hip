@@ -136,6 +136,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_pressure); dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
     dfree(h->d_mix_log); dfree(h->d_noise_id);
     dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
+    dfree(h->d_snap_work);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
@@ -293,6 +294,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
         // per-replica scratch of the barostat and of the restart attempts is sized by R_local as well
         dfree(h->d_baro); dfree(h->d_box_old); dfree(h->d_baro_x0); dfree(h->d_baro_f0); dfree(h->d_baro_U0); dfree(h->d_baro_acc);
         dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
+        dfree(h->d_snap_work);
         dfree(h->d_potential); dfree(h->d_epart); dfree(h->d_kinetic); dfree(h->d_nan); dfree(h->d_cmm);
         REMD_CHECK(h, hipMalloc(&h->d_pos, sizeof(float4) * n));
         REMD_CHECK(h, hipMalloc(&h->d_vel, sizeof(float4) * n));
@@ -511,6 +513,13 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         REMD_CHECK(h, hipMemcpyAsync(h->d_snap_pos, h->d_pos, bytes, hipMemcpyDeviceToDevice, h->stream));
         REMD_CHECK(h, hipMemcpyAsync(h->d_snap_vel, h->d_vel, bytes, hipMemcpyDeviceToDevice, h->stream));
     }
+    // heat / shadow work / Metropolis counters (remd_get_work) of an attempt that is thrown away must not stay accumulated
+    // (ADVICE r3): they are snapshotted and restored like the coordinates.  [0 .. 4R): at the start, [4R .. 8R): per replica at success
+    const size_t wbytes = sizeof(long long) * 4 * h->R;
+    const bool had_work = h->d_work != nullptr && h->work_R == h->R;
+    if (!h->d_snap_work) REMD_CHECK(h, hipMalloc(&h->d_snap_work, 2 * wbytes));
+    if (had_work) REMD_CHECK(h, hipMemcpyAsync(h->d_snap_work, h->d_work, wbytes, hipMemcpyDeviceToDevice, h->stream));
+    else REMD_CHECK(h, hipMemsetAsync(h->d_snap_work, 0, wbytes, h->stream));
     std::vector<int> flags(h->R, 0);
     std::vector<char> pending(h->R, 1);
     for (int a = 0;; ++a) {
@@ -534,6 +543,7 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
             REMD_CHECK(h, hipMemcpyAsync(h->d_pos, h->d_snap_pos, bytes, hipMemcpyDeviceToDevice, h->stream));
             REMD_CHECK(h, hipMemcpyAsync(h->d_vel, h->d_snap_vel, bytes, hipMemcpyDeviceToDevice, h->stream));
             REMD_CHECK(h, hipMemcpyAsync(h->d_box, h->d_snap_box, sizeof(float) * 4 * h->R, hipMemcpyDeviceToDevice, h->stream));
+            if (h->d_work) REMD_CHECK(h, hipMemcpyAsync(h->d_work, h->d_snap_work, wbytes, hipMemcpyDeviceToDevice, h->stream));
             h->box_version++;
             h->forces_valid = false; h->force_zeroed = false;
             --a;
@@ -548,6 +558,7 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
             REMD_CHECK(h, hipMemcpyAsync(h->d_fin_pos + r * seg, h->d_pos + r * seg, sizeof(float4) * seg, hipMemcpyDeviceToDevice, h->stream));
             REMD_CHECK(h, hipMemcpyAsync(h->d_fin_vel + r * seg, h->d_vel + r * seg, sizeof(float4) * seg, hipMemcpyDeviceToDevice, h->stream));
             REMD_CHECK(h, hipMemcpyAsync(h->d_fin_box + 4 * r, h->d_box + 4 * r, sizeof(float) * 4, hipMemcpyDeviceToDevice, h->stream));
+            if (h->d_work) REMD_CHECK(h, hipMemcpyAsync(h->d_snap_work + 4 * (h->R + r), h->d_work + 4 * r, sizeof(long long) * 4, hipMemcpyDeviceToDevice, h->stream));
             if (!flags[r]) pending[r] = 0;
         }
         const float4* src_p = last ? h->d_fin_pos : h->d_snap_pos;
@@ -555,6 +566,7 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         REMD_CHECK(h, hipMemcpyAsync(h->d_pos, src_p, bytes, hipMemcpyDeviceToDevice, h->stream));
         REMD_CHECK(h, hipMemcpyAsync(h->d_vel, src_v, bytes, hipMemcpyDeviceToDevice, h->stream));
         REMD_CHECK(h, hipMemcpyAsync(h->d_box, last ? h->d_fin_box : h->d_snap_box, sizeof(float) * 4 * h->R, hipMemcpyDeviceToDevice, h->stream));
+        if (h->d_work) REMD_CHECK(h, hipMemcpyAsync(h->d_work, h->d_snap_work + (last ? 4 * h->R : 0), wbytes, hipMemcpyDeviceToDevice, h->stream));
         h->box_version++;
         h->forces_valid = false; h->force_zeroed = false;
         if (last) { for (int r = 0; r < h->R; ++r) flags[r] = pending[r] ? 1 : 0; break; }

@@ -134,6 +134,7 @@ struct remd_ctx {
     bool has_integrator = false;
     // heat / shadow work / Metropolization (integrators.py:1175-1204, 1404-1460, 1539-1557)
     int measure_heat = 0, measure_shadow = 0;                   // (a splitting with '{' '}' measures shadow work whatever the flag says)
+    long long* d_snap_work = nullptr;  // [2][R][4] remd_propagate: d_work at the start of the call / of each replica's successful attempt
     long long* d_work = nullptr;       // [R][4] fixed point 2^-24 kJ/mol: heat, shadow work; integers: Metropolis trials, rejections
     double* d_pe_prev = nullptr;       // [R] potential energy at the positions the last energy evaluation saw
     float4* d_xold = nullptr; float4* d_vold = nullptr; int* d_accept = nullptr;   // '{' snapshot, per-replica decision of '}'

@@ -116,6 +116,7 @@ class EnginePool:
         self._master.set_replicas(self.R, 0, x, v, box, zero)           # the master copy (labels of a handle are group-local)
         for eng in self._energy[1:]:
             eng.set_replicas(self.R, 0, None, None, box, zero)          # sized here, filled by copy_replicas before each use
+        self.reset_work()
         self.set_labels(labels)
 
     @property
@@ -154,7 +155,13 @@ class EnginePool:
             eng.set_replicas(len(idx), 0, None, None, boxes[idx], loc[idx])
             eng.copy_replicas(slots, self._master, idx, 7)           # positions, velocities, boxes: device to device
             eng.set_replica_ids(self.r_begin + idx)                  # noise keyed by the global replica index, whatever the grouping
+            if hasattr(eng, 'reset_work'):
+                eng.reset_work()                                     # (a handle's accumulators are per slot; the pool's per replica)
             out[g] = (idx, call(eng))
+            if hasattr(eng, 'get_work'):
+                w = eng.get_work()
+                for key in self._work:
+                    self._work[key][idx] += w[key]
             self._master.copy_replicas(idx, eng, slots, 7 if periodic_boxes else 3)
         return out
 
@@ -206,7 +213,12 @@ class EnginePool:
         return self._first.mix_host(scheme, iteration, np.ascontiguousarray(self._rows[:, :K]), labels, log_weights=log_weights)
 
     def get_work(self):
-        raise NotImplementedError('heat / shadow work across compatibility groups')
+        """Heat, shadow work and Metropolis counters per local replica, summed over the handles that propagated it."""
+        return {k: v.copy() for k, v in self._work.items()}
+
+    def reset_work(self):
+        self._work = dict(heat=np.zeros(self.R), shadow_work=np.zeros(self.R), n_accepted=np.zeros(self.R, np.int64),
+                          n_trials=np.zeros(self.R, np.int64))
 
     def close(self):
         for eng in self._energy + self._prop:

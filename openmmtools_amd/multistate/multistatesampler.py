@@ -920,10 +920,15 @@ class MultiStateSampler:
                 continue
             key = it
             if len(integrations) > 1:
-                # one integrator program at a time: load this move's; its noise is keyed by (iteration, place in the sequence)
+                # one integrator program at a time: load this move's; its noise is keyed by (iteration, place in the sequence).
+                # The place rides in bits 34.. of the iteration (below the restart attempts' bit 40): the engine numbers the
+                # steps of a propagation key * n_steps + step with the CURRENT move's n_steps, so a key scaled by the number of
+                # moves let the step ranges of moves with different n_steps overlap
                 self._program_engine_move(move)
                 nth = sum(1 for m in program[:position] if isinstance(m, mcmc.LangevinSplittingDynamicsMove))
-                key = it * len(integrations) + (nth if it >= 0 else -nth)
+                if nth >= 64:
+                    raise NotImplementedError('more than 64 integrator moves in one SequenceMove')
+                key = it + (nth << 34) * (1 if it >= 0 else -1)
             counted = isinstance(move, mcmc.GHMCMove) and hasattr(self._engine, 'get_work')
             before = self._engine.get_work() if counted else None
             flags = self._engine.propagate(key)

@@ -121,6 +121,21 @@ def test_resume_keeps_the_groups(tmp_path):
     assert np.allclose(ea[4:], eb[4:], rtol=2e-5, atol=1e-6)               # the resumed part restarts from f4 checkpoints
 
 
+def test_ghmc_statistics_are_kept_per_replica_across_the_group_handles():
+    """GHMCMove over several compatibility groups: the Metropolis counters live per slot of each group's handle, the
+    pool sums what each replica collected wherever it was propagated, and the sampler credits the moves of the states."""
+    sampled, unsampled, ss, f_i, K_i = _oscillators(3)
+    move = mcmc.GHMCMove(timestep=4.0 * unit.femtosecond, collision_rate=20.0 / unit.picosecond, n_steps=10)
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=6, engine=OracleEngine(), seed=3)
+    s.create(sampled, [ss], storage=None)
+    assert isinstance(s._engine, EnginePool) and s._engine.G == 3
+    s.run()
+    w = s._engine.get_work()
+    assert w['n_trials'].tolist() == [60, 60, 60] and np.all(w['n_accepted'] <= w['n_trials']) and w['n_accepted'].sum() > 0
+    moves = s.mcmc_moves
+    assert sum(m.n_proposed for m in moves) == 180 and sum(m.n_accepted for m in moves) == int(w['n_accepted'].sum())
+
+
 def test_particle_counts_must_agree():
     ho, two = testsystems.HarmonicOscillator(), testsystems.HarmonicOscillator()
     two.system.addParticle(12.0 * unit.amu)
