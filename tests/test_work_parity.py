@@ -275,8 +275,10 @@ def test_a_sequence_of_two_integrator_moves_reprograms_the_engine_between_them()
     s.create(thermo, [states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())], storage=None)
     del calls[:]
     s.run()
-    assert calls == [('program', 'V R O R V'), ('propagate', 2), ('program', 'O { V R V } O'), ('propagate', 3),
-                     ('program', 'V R O R V'), ('propagate', 4), ('program', 'O { V R V } O'), ('propagate', 5)]
+    # the place in the sequence rides in bit 34 of the key: the engine numbers a propagation's steps key * n_steps + step, so keys
+    # that differ by less than that would let moves of different n_steps share noise counters
+    assert calls == [('program', 'V R O R V'), ('propagate', 1), ('program', 'O { V R V } O'), ('propagate', 1 + (1 << 34)),
+                     ('program', 'V R O R V'), ('propagate', 2), ('program', 'O { V R V } O'), ('propagate', 2 + (1 << 34))]
     ghmc = [m.move_list[1] for m in s._mcmc_moves]
     assert sum(g.n_proposed for g in ghmc) == 2 * 2 * 5
     assert all(m.move_list[0].statistics == dict(n_attempts=2) for m in s._mcmc_moves)
