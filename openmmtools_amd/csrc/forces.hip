@@ -657,6 +657,12 @@ __device__ __forceinline__ float keep_where(unsigned long long m, float v)
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(m));
     return o;
 }
+__device__ __forceinline__ float max_sv(float s_uniform, float v)
+{
+    float o;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(o) : "s"(s_uniform), "v"(v));
+    return o;
+}
 __device__ __forceinline__ float min_sv(float s_uniform, float v)
 {
     float o;
@@ -689,6 +695,15 @@ struct sci_args {
 #ifndef SCI_INTCOORD
 #define SCI_INTCOORD 1
 #endif
+// x / y components of the separation and of both force accumulators as register pairs: one v_pk_fma_f32 each instead of a packed
+// multiply and two adds
+#ifndef SCI_PKACC
+#define SCI_PKACC 1
+#endif
+#ifndef SCI_TABIDX
+#define SCI_TABIDX 1
+#endif
+typedef float sci_v2f __attribute__((ext_vector_type(2)));
 template <int METHOD, bool ENERGY, bool ALCH, int NW, bool TABLE = false, bool INTPOS = false>
 __device__ __forceinline__
 void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const float* __restrict__ box,
@@ -730,8 +745,10 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
     constexpr bool PF2 = PACKQ && SCI_PREFETCH2;
     float4 xi[8], pi[8];
     float fix[8], fiy[8], fiz[8];
+    sci_v2f fixy[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
+        fixy[s] = sci_v2f{ 0.f, 0.f };
         const int i = (T * 8 + s) * 8 + ii;
         xi[s] = P[i];
         if (PACKQ) pi[s] = make_float4(xi[s].w, 0.f, 0.f, 0.f); else pi[s] = prm[i];
@@ -778,6 +795,7 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
             if (ALCH && pj.w != 0.f) pj.x *= lam_e;
             const int j = jc * 8 + jj;
             float fjx = 0.f, fjy = 0.f, fjz = 0.f;
+            sci_v2f fjxy = { 0.f, 0.f };
             bool touched = false;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
@@ -796,14 +814,24 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 // which lane pairs count is wave-uniform data (cutoff ballot, exclusion word, padding masks): scalar unit
                 unsigned long long in = __builtin_amdgcn_ballot_w64(r2 < rcut2);
                 // lanes beyond the cutoff evaluate at the cutoff (the table also has a lower end)
-                const float r2c = TAB ? __builtin_amdgcn_fmed3f(r2, p.ctab_umin, rcut2) : min_sv(rcut2, r2);
+                // (SCI_TABIDX, the early-table kernel: only the lower end is clamped.  Lanes beyond the cutoff are discarded by the
+                // select below whatever they read, and an LDS address past the workgroup's allocation reads as zero)
+                constexpr bool EARLY = SCI_EARLY_TABLE && TAB && METHOD == NB_EWALD_NOLJ && !ALCH;
+                const float r2c = (EARLY && SCI_TABIDX) ? max_sv(p.ctab_umin, r2)
+                                : TAB ? __builtin_amdgcn_fmed3f(r2, p.ctab_umin, rcut2) : min_sv(rcut2, r2);
                 // Coulomb-only kernel from the table: the LDS read is issued here, in front of the scalar mask chain and its
                 // branches, so that its round trip overlaps them instead of stalling the polynomial that consumes it
-                constexpr bool EARLY = SCI_EARLY_TABLE && TAB && METHOD == NB_EWALD_NOLJ && !ALCH;
                 float4 tc = make_float4(0.f, 0.f, 0.f, 0.f); float ttf = 0.f;
                 if (EARLY) {
                     const unsigned int bits = __float_as_uint(r2c);
-                    tc = ctab[bits >> CTAB_SHIFT];
+                    if (SCI_TABIDX) {
+                        // key = bits [18, 32) as a bit-field extract, address = key * 16 + base as one shift-add (the plain
+                        // expression compiles to shift, mask, add)
+                        const unsigned int key = __builtin_amdgcn_ubfe(bits, CTAB_SHIFT, 32 - CTAB_SHIFT);
+                        tc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ctab) + (key << 4));
+                    } else {
+                        tc = ctab[bits >> CTAB_SHIFT];
+                    }
                     ttf = (float)(bits & CTAB_MASK);
                 }
                 const int dj = jc - ic;
@@ -828,11 +856,20 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 if (EARLY) { fr = (pi[s].x * pj.x) * fmaf(ttf, fmaf(ttf, fmaf(ttf, tc.w, tc.z), tc.y), tc.x); ee = 0.f; }
                 else pair_interaction<METHOD, ALCH, !ENERGY, TAB>(p, r2c, pi[s], pj, lam_a, sc, fr, false, ee, ctab);
                 fr = keep_where(in, fr);
-                const float tx = fr * dx, ty = fr * dy, tz = fr * dz;
-                fix[s] += tx; fiy[s] += ty; fiz[s] += tz;
-                fjx -= tx; fjy -= ty; fjz -= tz;
+                if (SCI_PKACC) {
+                    const sci_v2f dxy = { dx, dy }, fr2 = { fr, fr };
+                    fixy[s] = __builtin_elementwise_fma(dxy, fr2, fixy[s]);
+                    fjxy = __builtin_elementwise_fma(-dxy, fr2, fjxy);
+                    fiz[s] = fmaf(dz, fr, fiz[s]);
+                    fjz = fmaf(-dz, fr, fjz);
+                } else {
+                    const float tx = fr * dx, ty = fr * dy, tz = fr * dz;
+                    fix[s] += tx; fiy[s] += ty; fiz[s] += tz;
+                    fjx -= tx; fjy -= ty; fjz -= tz;
+                }
                 if (ENERGY) e += ((in >> lane) & 1ull) ? (double)ee : 0.0;
             }
+            if (SCI_PKACC) { fjx = fjxy.x; fjy = fjxy.y; }
             if (touched) {
                 // reaction on the j atoms: all-reduce over the 8 ii lanes (every lane ends up with the total of its jj)
                 fjx = allsum_x8(fjx); fjy = allsum_x8(fjy); fjz = allsum_x8(fjz);
@@ -864,6 +901,10 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
         const float send = (jj & 1) ? b[0] : b[1], keep = (jj & 1) ? b[1] : b[0];
         return keep + __shfl_xor(send, 1);
     };
+    if (SCI_PKACC) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { fix[s] = fixy[s].x; fiy[s] = fixy[s].y; }
+    }
     float fx = reduce_scatter(fix), fy = reduce_scatter(fiy), fz = reduce_scatter(fiz);
     if (NW > 1) {
         __shared__ float s_f[NW][3][64];

@@ -455,7 +455,7 @@ def test_cluster_pair_lists_match_the_tile_kernel(hip_engine_factory, monkeypatc
         res.append((eng.get_forces(), U))
     (f1, u1), (f0, u0) = res
     assert np.abs(f1 - f0).max() < 2e-5 * np.abs(f0).max()
-    assert np.allclose(u1, u0, rtol=2e-8, atol=1e-6)
+    assert np.allclose(u1, u0, rtol=1e-7, atol=1e-6)          # (fp32 partial sums per lane in both kernels, summed in f64)
 
 
 def test_more_than_8191_molecules_stay_on_the_cluster_path(hip_engine_factory, monkeypatch):
