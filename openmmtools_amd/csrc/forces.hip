@@ -817,22 +817,27 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 // (SCI_TABIDX, the early-table kernel: only the lower end is clamped.  Lanes beyond the cutoff are discarded by the
                 // select below whatever they read, and an LDS address past the workgroup's allocation reads as zero)
                 constexpr bool EARLY = SCI_EARLY_TABLE && TAB && METHOD == NB_EWALD_NOLJ && !ALCH;
-                const float r2c = (EARLY && SCI_TABIDX) ? max_sv(p.ctab_umin, r2)
-                                : TAB ? __builtin_amdgcn_fmed3f(r2, p.ctab_umin, rcut2) : min_sv(rcut2, r2);
+                float r2c = (EARLY && SCI_TABIDX) ? r2
+                          : TAB ? __builtin_amdgcn_fmed3f(r2, p.ctab_umin, rcut2) : min_sv(rcut2, r2);
                 // Coulomb-only kernel from the table: the LDS read is issued here, in front of the scalar mask chain and its
                 // branches, so that its round trip overlaps them instead of stalling the polynomial that consumes it
                 float4 tc = make_float4(0.f, 0.f, 0.f, 0.f); float ttf = 0.f;
                 if (EARLY) {
-                    const unsigned int bits = __float_as_uint(r2c);
                     if (SCI_TABIDX) {
-                        // key = bits [18, 32) as a bit-field extract, address = key * 16 + base as one shift-add (the plain
-                        // expression compiles to shift, mask, add)
-                        const unsigned int key = __builtin_amdgcn_ubfe(bits, CTAB_SHIFT, 32 - CTAB_SHIFT);
-                        tc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ctab) + (key << 4));
+                        // lower clamp, key = bits [18, 32) as a bit-field extract, LDS address = key * 16 + base as one shift-add:
+                        // three instructions (the plain expression: a register copy of the bound, max, shift, mask, add)
+                        typedef float sci_v4f __attribute__((ext_vector_type(4)));
+                        typedef __attribute__((address_space(3))) const sci_v4f lds_v4f;
+                        const unsigned int lds_base = (unsigned int)(__UINTPTR_TYPE__)(lds_v4f*)ctab;
+                        unsigned int addr;
+                        asm("v_max_f32_e32 %0, %2, %3\n\tv_bfe_u32 %1, %0, %5, %6\n\tv_lshl_add_u32 %1, %1, 4, %4"
+                            : "=&v"(r2c), "=&v"(addr) : "s"(p.ctab_umin), "v"(r2), "s"(lds_base), "n"(CTAB_SHIFT), "n"(32 - CTAB_SHIFT));
+                        const sci_v4f c4 = *(lds_v4f*)(__UINTPTR_TYPE__)addr;
+                        tc = make_float4(c4.x, c4.y, c4.z, c4.w);
                     } else {
-                        tc = ctab[bits >> CTAB_SHIFT];
+                        tc = ctab[__float_as_uint(r2c) >> CTAB_SHIFT];
                     }
-                    ttf = (float)(bits & CTAB_MASK);
+                    ttf = (float)(__float_as_uint(r2c) & CTAB_MASK);
                 }
                 const int dj = jc - ic;
                 if (dj < W) {                                    // wave-uniform: exclusions (and the diagonal) live here
