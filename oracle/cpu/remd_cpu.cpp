@@ -1468,9 +1468,14 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
         Replica& rep = h->reps[r];
         const std::vector<double> x0 = rep.x, v0 = rep.v;
         const double box0[3] = {rep.box[0], rep.box[1], rep.box[2]};
+        const double heat0 = rep.heat, shadow0 = rep.shadow; const long long trials0 = rep.n_trials, rejected0 = rep.n_rejected;
         for (int a = 0; a <= h->n_restart_attempts; ++a) {             // mcmc.py:706-759
             const int64_t it = iteration + ((int64_t)a << 40);
-            if (a > 0) { rep.x = x0; rep.v = v0; for (int q = 0; q < 3; ++q) rep.box[q] = box0[q]; rep.f_valid = false; rep.list_valid = false; }
+            if (a > 0) {
+                rep.x = x0; rep.v = v0; for (int q = 0; q < 3; ++q) rep.box[q] = box0[q]; rep.f_valid = false; rep.list_valid = false;
+                // (what a discarded attempt accumulated for remd_get_work goes with it)
+                rep.heat = heat0; rep.shadow = shadow0; rep.n_trials = trials0; rep.n_rejected = rejected0;
+            }
             if (h->reassign) assign_velocities(h, r, it);
             run_steps(h, r, h->tokens, h->nV, h->nR, h->nO, it, 0, h->n_steps, true);
             flags[r] = finite_state(rep) ? 0 : 1;

@@ -127,6 +127,11 @@ class OracleEngine:
                 it = iteration + (attempt << 40)
                 v = integ.assign_velocities(x0, kT, self._nk(r), it) if self.reassign else v0
                 self._work_of(integ, r)
+                if integ.work is not None:                # (what a discarded attempt accumulated for get_work goes with it)
+                    if attempt == 0:
+                        work0 = dict(integ.work)
+                    else:
+                        integ.work.update(work0)
                 if getattr(self, 'pressure', None) is not None:
                     if self._baro is None:
                         self._baro = mo.OracleBarostat(self.sys, self.seed_value, mo.molecules_from_desc(self.sys.d))
