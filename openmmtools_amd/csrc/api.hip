@@ -385,8 +385,9 @@ int remd_copy_replicas(remd_handle dst, const int32_t* dst_slot, remd_handle src
     }
     hipSetDevice(dst->device);
     REMD_CHECK(dst, hipStreamSynchronize(src->stream));              // what the source computed last is complete
-    int* d_slots = nullptr;
-    REMD_CHECK(dst, hipMalloc(&d_slots, sizeof(int) * slots.size()));
+    struct scratch { int* p = nullptr; ~scratch() { if (p) hipFree(p); } } slots_dev;      // (freed on every return path)
+    REMD_CHECK(dst, hipMalloc(&slots_dev.p, sizeof(int) * slots.size()));
+    int* d_slots = slots_dev.p;
     REMD_CHECK(dst, hipMemcpyAsync(d_slots, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, dst->stream));
     const bool pos = what & 1, vel = what & 2, box = what & 4;
     hipLaunchKernelGGL(copy_replica_rows_kernel, dim3((dst->Npad + 255) / 256, n), dim3(256), 0, dst->stream, dst->Npad, d_slots, n,
@@ -405,7 +406,7 @@ int remd_copy_replicas(remd_handle dst, const int32_t* dst_slot, remd_handle src
         }
         if (dst->nb_method != REMD_NB_NONE)
             for (int r = 0; r < dst->R; ++r) for (int k = 0; k < 3; ++k)
-                if (dst->box_host[3 * r + k] < 2.0 * dst->cutoff) { hipFree(d_slots); return remd_fail(dst, -1, "remd_copy_replicas: box smaller than twice the cutoff"); }
+                if (dst->box_host[3 * r + k] < 2.0 * dst->cutoff) return remd_fail(dst, -1, "remd_copy_replicas: box smaller than twice the cutoff");
         if (changed) {
             dst->box_uniform = true;
             for (int r = 1; r < dst->R; ++r) for (int k = 0; k < 3; ++k) if (hb[4 * r + k] != hb[k]) dst->box_uniform = false;
@@ -413,7 +414,6 @@ int remd_copy_replicas(remd_handle dst, const int32_t* dst_slot, remd_handle src
         }
     }
     REMD_CHECK(dst, hipStreamSynchronize(dst->stream));
-    hipFree(d_slots);
     if (pos || box) {
         dst->forces_valid = false; dst->force_zeroed = false;
         dst->cbins_ready = false;
