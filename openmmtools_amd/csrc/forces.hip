@@ -544,12 +544,29 @@ void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, l
     if (done) { __syncthreads(); if (threadIdx.x == 0) __hip_atomic_fetch_add(done + 16 * blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
+// lane <-> (i atom ii, j atom jj) of a cluster pair in the sci kernels.  SCI_LANES_IJ = 1 (round 4): ii in the LOW three lane
+// bits, so the per-entry all-reduce of the reaction forces over the 8 i atoms is three DPP adds inside groups of 8 lanes
+// (quad permutes + half-row mirror) instead of a row rotation and two cross-row swaps per component (27 -> 9 instructions per
+// list entry); the exclusion words are ballots in the same lane order (build_excl_kernel).
+#ifndef SCI_LANES_IJ
+#define SCI_LANES_IJ 1
+#endif
+#if SCI_LANES_IJ
+#define SCI_LANE_II(lane) ((lane) & 7)
+#define SCI_LANE_JJ(lane) ((lane) >> 3)
+#define SCI_LANE_OF(ii, jj) ((jj) * 8 + (ii))
+#else
+#define SCI_LANE_II(lane) ((lane) >> 3)
+#define SCI_LANE_JJ(lane) ((lane) & 7)
+#define SCI_LANE_OF(ii, jj) ((ii) * 8 + (jj))
+#endif
+
 __global__ __launch_bounds__(64)
 void build_excl_kernel(int Npad, int ncl, int W, int words, const unsigned long long* __restrict__ smask,
                        unsigned long long* __restrict__ excl)
 {
     const int ic = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
-    const int ii = lane >> 3, jj = lane & 7;
+    const int ii = SCI_LANE_II(lane), jj = SCI_LANE_JJ(lane);          // bit = the pair kernel's lane of (i atom, j atom)
     const int half = 32 * words;
     const int i = ic * 8 + ii;
     for (int dj = 0; dj < W; ++dj) {
@@ -638,6 +655,14 @@ __device__ __forceinline__ float allsum_x8(float v)
 {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
 }
+// all-reduce inside every group of 8 consecutive lanes: two quad permutes and the half-row mirror (DPP, no cross-row traffic)
+__device__ __forceinline__ float allsum_low8(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return v;
+}
 __device__ __forceinline__ float allsum_x16(float v)
 {
     float a = v, b = v;        // odd rows of a <-> even rows of b
@@ -670,7 +695,7 @@ __device__ __forceinline__ float min_sv(float s_uniform, float v)
     return o;
 }
 
-// lane = (ii = lane >> 3, jj = lane & 7): the lane holds atom ii of all 8 i clusters of its tile in registers and, per
+// lane = (ii, jj) by SCI_LANE_II / SCI_LANE_JJ above: the lane holds atom ii of all 8 i clusters of its tile in registers and, per
 // list entry, atom jj of the j cluster.
 #define SCI_NW 4
 // NW wavefronts per workgroup take consecutive slices of one tile's list and merge their i forces through LDS (fixed
@@ -719,7 +744,7 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntile = ncl >> 3;
     const int T = item % ntile, r = (item / ntile) % R, zsl = (item / (ntile * R)) * NW + wv;
-    const int ii = lane >> 3, jj = lane & 7;
+    const int ii = SCI_LANE_II(lane), jj = SCI_LANE_JJ(lane);
     // force-only Coulomb-only kernel: positions as integer box fractions (sci_args::sposi), minimum image by wrap-around
     // (INTPOS: the caller also has integer positions for a system that keeps its parameter loads -- the LJ sub-system of a split launch)
     constexpr bool INTC = SCI_INTCOORD && !ENERGY && ((SCI_PACKQ && !ALCH && (METHOD == NB_EWALD_NOLJ || METHOD == NB_RF_NOLJ)) || INTPOS);
@@ -843,8 +868,8 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
                 if (dj < W) {                                    // wave-uniform: exclusions (and the diagonal) live here
                     unsigned long long m;
                     // (readlane returns int: without the unsigned cast bit 31 of the low word would smear over lanes 32..63)
-                    if (W <= 8) m = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(ex_lo, s * 8 + dj)
-                                  | ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(ex_hi, s * 8 + dj) << 32);
+                    if (W <= 8) m = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(ex_lo, SCI_LANE_OF(s, dj))
+                                  | ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(ex_hi, SCI_LANE_OF(s, dj)) << 32);
                     else {
                         const unsigned long long mv = excl[((size_t)r * ncl + ic) * W + dj];
                         m = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)mv)
@@ -877,9 +902,13 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
             if (SCI_PKACC) { fjx = fjxy.x; fjy = fjxy.y; }
             if (touched) {
                 // reaction on the j atoms: all-reduce over the 8 ii lanes (every lane ends up with the total of its jj)
-                fjx = allsum_x8(fjx); fjy = allsum_x8(fjy); fjz = allsum_x8(fjz);
-                fjx = allsum_x16(fjx); fjy = allsum_x16(fjy); fjz = allsum_x16(fjz);
-                fjx = allsum_x32(fjx); fjy = allsum_x32(fjy); fjz = allsum_x32(fjz);
+                if (SCI_LANES_IJ) {
+                    fjx = allsum_low8(fjx); fjy = allsum_low8(fjy); fjz = allsum_low8(fjz);
+                } else {
+                    fjx = allsum_x8(fjx); fjy = allsum_x8(fjy); fjz = allsum_x8(fjz);
+                    fjx = allsum_x16(fjx); fjy = allsum_x16(fjy); fjz = allsum_x16(fjz);
+                    fjx = allsum_x32(fjx); fjy = allsum_x32(fjy); fjz = allsum_x32(fjz);
+                }
             }
             const int eb = k & 7;
             if (ii == eb) { qfx = fjx; qfy = fjy; qfz = fjz; qj = j; }
@@ -896,15 +925,15 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float send = (jj & 4) ? v[q] : v[q + 4], keep = (jj & 4) ? v[q + 4] : v[q];
-            a[q] = keep + __shfl_xor(send, 4);
+            a[q] = keep + __shfl_xor(send, SCI_LANES_IJ ? 32 : 4);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const float send = (jj & 2) ? a[q] : a[q + 2], keep = (jj & 2) ? a[q + 2] : a[q];
-            b[q] = keep + __shfl_xor(send, 2);
+            b[q] = keep + __shfl_xor(send, SCI_LANES_IJ ? 16 : 2);
         }
         const float send = (jj & 1) ? b[0] : b[1], keep = (jj & 1) ? b[1] : b[0];
-        return keep + __shfl_xor(send, 1);
+        return keep + __shfl_xor(send, SCI_LANES_IJ ? 8 : 1);
     };
     if (SCI_PKACC) {
 #pragma unroll

@@ -1,5 +1,5 @@
 #!/bin/bash
-# pair kernel: clamp + table address as three instructions (A = tree, B = libremd_hip_base.so with -DSCI_TABIDX=0: med3 + shift/mask/add)
+# pair kernel: i atoms in the low lane bits (A = tree, B = libremd_hip_base.so with -DSCI_LANES_IJ=0)
 export TMPDIR=/tmp
 B=$PWD/openmmtools_amd/libremd_hip_base.so
 timeout 600 python -m pytest tests/test_forcefield_parity.py tests/test_openmm_fixture.py tests/test_coulomb_table.py -m gpu -x -q 2>&1 | tail -3
