@@ -217,6 +217,12 @@ int  remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local,
    subset's global indices here, after remd_set_replicas (which resets them); NULL restores the default.                       */
 int  remd_set_replica_ids(remd_handle h, const int64_t* global_replica_index /* [R_local] or NULL */);
 
+/* Options of the alchemical region that the descriptor does not carry; call before remd_set_system.  annihilate_sterics
+   (AlchemicalRegion.annihilate_sterics, alchemy.py:421, 1767-1779, 1841-1846): the Lennard-Jones interactions BETWEEN alchemical
+   atoms (pairs and exceptions) are soft-core and lambda_sterics-controlled like those with the environment; 0 (default): they
+   stay at full strength ("decoupling").                                                                                       */
+int  remd_set_alchemical_options(remd_handle h, int annihilate_sterics);
+
 /* Device-to-device transfer of replicas between two handles on the same device that hold the same particles (one handle per
    compatibility group of states: the reference propagates a replica in the Context of its own state's System,
    multistatesampler.py:1296-1320, and evaluates every configuration in one Context per group, :1470-1490 -- the coordinates it moves

@@ -289,8 +289,7 @@ def rebuild_marked_system(system, nb, global_parameters, particle_offsets, excep
     A = list(aa['groups'][0][0])
     if sorted(na['groups'][0][1]) != sorted(A):
         raise NotImplementedError('interaction groups of the two sterics forces disagree on the alchemical atoms')
-    if 'lambda_sterics' in aa['globals']:
-        raise NotImplementedError('annihilate_sterics=True')
+    annihilate_sterics = 'lambda_sterics' in aa['globals']
     if compact(sterics_exception_expression() + _MIX_STERICS) != compact(na['energy']):
         raise NotImplementedError('sterics expression other than the factory\'s soft-core Lennard-Jones: %s' % na['energy'][:80])
     g = na['globals']
@@ -301,7 +300,7 @@ def rebuild_marked_system(system, nb, global_parameters, particle_offsets, excep
     for c in cnb_e:
         if c['groups'] and c['groups'][0][0] == c['groups'][0][1] and 'lambda_electrostatics' not in c['globals']:
             annihilate_electrostatics = False
-    region = AlchemicalRegion(alchemical_atoms=A, annihilate_electrostatics=annihilate_electrostatics,
+    region = AlchemicalRegion(alchemical_atoms=A, annihilate_electrostatics=annihilate_electrostatics, annihilate_sterics=annihilate_sterics,
                               softcore_alpha=g['softcore_alpha'], softcore_a=g['softcore_a'], softcore_b=g['softcore_b'], softcore_c=g['softcore_c'])
     Aset = set(A)
     # particles

@@ -39,7 +39,7 @@ class RemdSystemDesc(C.Structure):
 
 
 EXPORTS = [
-    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_states',
+    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_alchemical_options', 'remd_set_states',
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_copy_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
@@ -83,6 +83,7 @@ def load_library(path=None):
     lib.remd_version.argtypes = []
     lib.remd_set_system.argtypes = [vp, C.POINTER(RemdSystemDesc)]
     lib.remd_set_coulomb_cutoff.argtypes = [vp, C.c_double]
+    lib.remd_set_alchemical_options.argtypes = [vp, C.c_int]
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
@@ -230,6 +231,7 @@ class HipEngine:
         s, keep = build_desc(desc_dict)
         # Ewald split (system.system_to_desc(ewald_split=...)): range of the direct-space Coulomb sum, 0 = the cutoff
         self._check(self.lib.remd_set_coulomb_cutoff(self.h, float(desc_dict.get('coulomb_cutoff', 0.0))), 'remd_set_coulomb_cutoff')
+        self._check(self.lib.remd_set_alchemical_options(self.h, int(bool(desc_dict.get('annihilate_sterics', False)))), 'remd_set_alchemical_options')
         self._check(self.lib.remd_set_system(self.h, C.byref(s)), 'remd_set_system')
         self.N = int(desc_dict['n_atoms'])
         if 'force_groups' in desc_dict:                  # Force.getForceGroup() of the force classes (V<g> substeps)

@@ -25,8 +25,6 @@ class AlchemicalRegion:
                  softcore_d=1, softcore_e=1, softcore_f=2, name=None):
         if not alchemical_atoms:
             raise ValueError('alchemical_atoms must be a non-empty list')
-        if annihilate_sterics:
-            raise NotImplementedError('annihilate_sterics=True')
         if (softcore_beta, softcore_d, softcore_e) != (0.0, 1, 1):
             raise NotImplementedError('softcore electrostatics (only the exact PME treatment is implemented)')
         self.alchemical_atoms = sorted(int(a) for a in alchemical_atoms)
@@ -106,7 +104,8 @@ def alchemical_long_range_constants(system, nonbonded_force, lambdas_sterics, vo
                 eps = math.sqrt(ea * en)
                 if eps > 0:
                     tot += na * nn * _tail_integral(0.5 * (sa + sn), eps, lam, region, rc, rs)
-        # alchemical/alchemical force: lambda fixed to 1 (annihilate_sterics=False)
+        # alchemical/alchemical force: lambda fixed to 1 unless annihilate_sterics (alchemy.py:1767-1779)
+        lam_aa = lam if region.annihilate_sterics else 1.0
         keys = list(cls_a.items())
         for x in range(len(keys)):
             for y in range(x, len(keys)):
@@ -115,6 +114,6 @@ def alchemical_long_range_constants(system, nonbonded_force, lambdas_sterics, vo
                 count = n1 * (n1 - 1) / 2.0 if x == y else n1 * n2
                 eps = math.sqrt(e1 * e2)
                 if eps > 0 and count > 0:
-                    tot += count * _tail_integral(0.5 * (s1 + s2), eps, 1.0, region, rc, rs)
+                    tot += count * _tail_integral(0.5 * (s1 + s2), eps, lam_aa, region, rc, rs)
         out[k] = norm * tot
     return out

@@ -165,6 +165,13 @@ int remd_test_coulomb_table(double alpha, double coulomb_cutoff_nm, int n, const
     return 0;
 }
 
+int remd_set_alchemical_options(remd_handle h, int annihilate_sterics)
+{
+    if (!h || (annihilate_sterics != 0 && annihilate_sterics != 1)) return remd_fail(h, -1, "remd_set_alchemical_options: bad arguments");
+    h->annihilate_sterics = annihilate_sterics;      // consumed by the next remd_set_system
+    return 0;
+}
+
 int remd_set_coulomb_cutoff(remd_handle h, double coulomb_cutoff_nm)
 {
     if (!h || !(coulomb_cutoff_nm >= 0.0)) return remd_fail(h, -1, "remd_set_coulomb_cutoff: bad arguments");

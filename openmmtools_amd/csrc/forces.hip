@@ -1249,7 +1249,8 @@ void alch_ukl_kernel(nb_params p, int N, int Npad, int n_alch, const int* __rest
     for (int t = threadIdx.x; t < total; t += 256) {
         const int a = alch_atoms[t / N], j = t % N;
         const float4 pj = param[j];
-        if (pj.w != 0.f) continue;                       // alchemical/alchemical pairs are not lambda-controlled
+        // alchemical/alchemical pairs are lambda-controlled only under annihilate_sterics (w = 2); each of them once
+        if (pj.w != 0.f && (pj.w < 1.5f || j <= a)) continue;
         // excluded pairs (a region that cuts a molecule has bonded neighbours on both sides; their exceptions follow below)
         const int dd = j - a + 32 * p.excl_words;
         if (dd >= 0 && dd < 64 * p.excl_words && ((mask[(size_t)a * p.excl_words + (dd >> 6)] >> (dd & 63)) & 1ull)) continue;
@@ -1440,7 +1441,7 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     std::vector<float4> prm(h->Npad, make_float4(0, 0, 0, 0));
     for (int i = 0; i < N; ++i)
         prm[i] = make_float4((float)(d->charge[i] * sqk), (float)(0.5 * d->sigma[i]), (float)(2.0 * sqrt(d->epsilon[i])),
-                             t.is_alch[i] ? 1.f : 0.f);
+                             t.is_alch[i] ? (h->annihilate_sterics ? 2.f : 1.f) : 0.f);
     int rc;
     if ((rc = upload(h, t.d_param, prm))) return rc;
     // exclusion window
@@ -1465,7 +1466,9 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
             // alchemical/alchemical sterics exceptions stay at full strength (annihilate_sterics=False); a sterics
             // exception between an alchemical and a non-alchemical atom is soft-core (round 4: softcore_exception,
             // listed_terms.h; the factory's CustomBondForce, alchemy.py:1836-1851) -- softcore_c = 6 like the pair kernel.
-            exc_alch.push_back((int)t.is_alch[i] + (int)t.is_alch[j]);
+            // (1 marks the soft-core Lennard-Jones exceptions: one alchemical atom, or two under annihilate_sterics -- the
+            // alchemical/alchemical CustomBondForce is lambda-controlled then, alchemy.py:1841-1846; any value > 0 scales the charges)
+            exc_alch.push_back((t.is_alch[i] && t.is_alch[j] && h->annihilate_sterics) ? 1 : (int)t.is_alch[i] + (int)t.is_alch[j]);
             exc_atoms.push_back(i); exc_atoms.push_back(j);
             exc_params.push_back((float)(qq * REMD_ONE_4PI_EPS0)); exc_params.push_back((float)sg); exc_params.push_back((float)ep);
         }

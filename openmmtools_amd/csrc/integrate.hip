@@ -844,7 +844,7 @@ __device__ __forceinline__ float resident_pair(const nb_params& p, float r2, flo
 {
     const float inv_r = __builtin_amdgcn_rsqf(r2), r = r2 * inv_r;
     const float sig = pi.y + pj.y, eps4 = pi.z * pj.z;
-    const bool soft = ALCH && (pi.w != pj.w);
+    const bool soft = ALCH && ((pi.w != pj.w) || pi.w > 1.5f);      // (w = 2: annihilate_sterics, pair_math.h)
     const float lam = soft ? lam_a : 1.f, s0 = soft ? sc : 0.f;
     const float is2 = __builtin_amdgcn_rcpf(sig * sig);
     const float q2 = r2 * is2, t = q2 * q2 * q2;

@@ -58,7 +58,9 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
     bool na = false;
     // (an unsplit Ewald kernel that sums the Coulomb tail beyond the Lennard-Jones cutoff: LJ stops at rc)
     if (METHOD <= NB_EWALD && eps4 != 0.f && (METHOD != NB_EWALD || r2 < p.rc2)) {
-        if (ALCH && (pi.w != pj.w)) {
+        // (param.w: 0 non-alchemical, 1 alchemical, 2 alchemical with annihilate_sterics -- then alchemical/alchemical pairs are
+        // lambda-controlled too, alchemy.py:1767-1779)
+        if (ALCH && ((pi.w != pj.w) || pi.w > 1.5f)) {
             // soft-core (alchemy.py:1383-1388 with softcore_c = 6): x = 1/(alpha(1-l)^b + (r/sigma)^6)
             na = true;
             const float is2 = 1.f / (sig * sig);

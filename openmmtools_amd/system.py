@@ -488,9 +488,11 @@ def system_to_desc(system, box=None, ewald_split=None):
     if region is not None:
         d['alch_atoms'] = np.array(sorted(region.alchemical_atoms), dtype=np.int32)
         d['softcore'] = (region.softcore_alpha, region.softcore_a, region.softcore_b, region.softcore_c)
+        d['annihilate_sterics'] = bool(region.annihilate_sterics)          # -> remd_set_alchemical_options
     else:
         d['alch_atoms'] = np.zeros(0, np.int32)
         d['softcore'] = (0.5, 1.0, 1.0, 6.0)
+        d['annihilate_sterics'] = False
     return d
 
 

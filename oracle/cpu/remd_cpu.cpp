@@ -182,6 +182,7 @@ struct System {
     std::vector<int> bond_atoms, angle_atoms, torsion_atoms, exc_atoms;
     std::vector<double> bond_params, angle_params, torsion_params, exc_params;
     int method = 0; double rc = 0, rs = -1, rf_eps = 78.3, alpha = 0; int grid[3] = {0, 0, 0}; int use_disp = 0;
+    bool annihilate = false;  // AlchemicalRegion.annihilate_sterics (remd_set_alchemical_options)
     double rcc = 0;       // range of the Ewald direct-space sum (remd_set_coulomb_cutoff); = rc unless the host split the sum elsewhere
     std::vector<double> q, sig, eps;
     std::vector<char> alch;
@@ -563,7 +564,8 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
             const double rr = sqrt(r2);
             double fr = 0.0;                                       // -dE/dr / r  (force on j = fr * d)
             const double ep = (r2 < rc2) ? sqrt(s.eps[i] * s.eps[j]) : 0.0;      // Lennard-Jones stops at the NonbondedForce cutoff
-            const bool na = s.has_alch && (s.alch[i] != s.alch[j]);
+            // (soft-core, lambda_sterics-controlled: alchemical with non-alchemical; under annihilate_sterics also alchemical with alchemical)
+            const bool na = s.has_alch && ((s.alch[i] != s.alch[j]) || (s.annihilate && s.alch[i] && s.alch[j]));
             if (ep != 0.0 && ((na && (parts & PART_SOFTCORE)) || (!na && (parts & PART_STERICS)))) {
                 const double sg = 0.5 * (s.sig[i] + s.sig[j]);
                 double e, dedr;
@@ -619,7 +621,8 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
             // the Lennard-Jones part of an exception between an alchemical and a non-alchemical atom is soft-core and
             // lambda_sterics-controlled like the pair interaction, without cutoff or switch (CustomBondForce of alchemy.py:1836-1851,
             // 1985-1998); alchemical/alchemical exceptions keep lambda = 1 (annihilate_sterics = False)
-            const bool na = s.has_alch && (s.alch[i] != s.alch[j]);
+            // (soft-core, lambda_sterics-controlled: alchemical with non-alchemical; under annihilate_sterics also alchemical with alchemical)
+            const bool na = s.has_alch && ((s.alch[i] != s.alch[j]) || (s.annihilate && s.alch[i] && s.alch[j]));
             if (ep != 0.0 && na && (parts & PART_SOFTCORE)) {
                 const double rs_c = pow(rr / sg, s.sc_c);
                 const double base = lb + rs_c;
@@ -783,6 +786,7 @@ struct remd_ctx {
     std::vector<char> tokens; int nV = 0, nR = 0, nO = 0;
     double dt = 0, gamma = 0; int n_steps = 0, reassign = 0, n_restart_attempts = 0;
     double coulomb_cutoff = 0;
+    int annihilate_sterics = 0;
     std::vector<uint32_t> noise_ids;   // remd_set_replica_ids: keys of the local replicas' random streams (empty: r_begin + r)
     int measure_heat = 0, measure_shadow = 0;
     int R = 0, R_global = 0, r_begin = 0;
@@ -1159,6 +1163,7 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
         if (h->coulomb_cutoff < s.rc) return fail(h, -1, "the Coulomb cutoff of remd_set_coulomb_cutoff is shorter than the NonbondedForce cutoff");
         s.rcc = h->coulomb_cutoff;
     }
+    s.annihilate = h->annihilate_sterics != 0;
     s.rf_eps = d->rf_dielectric; s.alpha = d->ewald_alpha; s.use_disp = d->use_dispersion_correction;
     for (int k = 0; k < 3; ++k) s.grid[k] = d->pme_grid[k];
     s.q.assign(N, 0.0); s.sig.assign(N, 1.0); s.eps.assign(N, 0.0); s.alch.assign(N, 0);
@@ -1326,6 +1331,13 @@ int remd_set_replica_ids(remd_handle h, const int64_t* ids)
         if (ids[r] < 0 || ids[r] > 0xffffffffll) { h->noise_ids.clear(); return fail(h, -1, "remd_set_replica_ids: ids must fit 32 bits"); }
         h->noise_ids.push_back((uint32_t)ids[r]);
     }
+    return 0;
+}
+
+int remd_set_alchemical_options(remd_handle h, int annihilate_sterics)
+{
+    if (!h || (annihilate_sterics != 0 && annihilate_sterics != 1)) return fail(h, -1, "remd_set_alchemical_options: bad arguments");
+    h->annihilate_sterics = annihilate_sterics;   // consumed by the next remd_set_system (include/remd_hip.h)
     return 0;
 }
 

@@ -107,6 +107,7 @@ class ForceFieldOracle(OracleSystem):
         self.is_alch = np.zeros(self.N, dtype=bool)
         self.is_alch[np.asarray(d['alch_atoms'], dtype=int)] = True
         self.alch_t = torch.tensor(self.is_alch)
+        self.annihilate = bool(d.get('annihilate_sterics', False))          # remd_set_alchemical_options
         exc = np.asarray(d['exception_atoms']).reshape(-1, 2)
         self.excluded = set((min(i, j), max(i, j)) for i, j in exc)
         self.exc_atoms = exc
@@ -179,6 +180,8 @@ class ForceFieldOracle(OracleSystem):
         sig = 0.5 * (self.sig[i] + self.sig[j])
         eps = torch.sqrt(self.eps[i] * self.eps[j])
         na = self.alch_t[i] != self.alch_t[j]
+        if self.annihilate:                          # alchemy.py:1767-1779: alchemical/alchemical pairs are lambda-controlled too
+            na = na | (self.alch_t[i] & self.alch_t[j])
         alpha_sc, a, b, c = self.sc
         lj = 4.0 * eps * ((sig / r) ** 12 - (sig / r) ** 6)
         reff = sig * (alpha_sc * (1.0 - lam_s) ** b + (r / sig) ** c) ** (1.0 / c)
@@ -218,7 +221,7 @@ class ForceFieldOracle(OracleSystem):
         lj = 4.0 * p[:, 2] * sr6 * (sr6 - 1.0)
         # Lennard-Jones exceptions between an alchemical and a non-alchemical atom: soft-core, lambda_sterics-controlled,
         # no cutoff and no switch (the factory's CustomBondForce, alchemy.py:1836-1851, 1985-1998, expression :1374-1380)
-        na = torch.tensor(self.is_alch[i] != self.is_alch[j]) & (p[:, 2] != 0)
+        na = torch.tensor((self.is_alch[i] != self.is_alch[j]) | (self.annihilate & self.is_alch[i] & self.is_alch[j])) & (p[:, 2] != 0)
         alpha_sc, a, b, c = self.sc
         sig = torch.where(na, p[:, 1], torch.ones_like(r))
         reff = sig * (alpha_sc * (1.0 - lam_s) ** b + (r / sig) ** c) ** (1.0 / c)

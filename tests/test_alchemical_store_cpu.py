@@ -222,7 +222,7 @@ def _document_energy(xml, x, box, lambdas):
     return total + ForceFieldOracle(system_to_desc(plain)).energy_forces(x, box, forces=False)[0]
 
 
-@pytest.mark.parametrize('name', ['lj-reaction-field', 'alanine-pme', 'alanine-cut-pme', 'host-guest-pme'])
+@pytest.mark.parametrize('name', ['lj-reaction-field', 'alanine-pme', 'alanine-cut-pme', 'host-guest-pme', 'host-guest-annihilate'])
 def test_the_document_means_the_hamiltonian_the_engine_evaluates(name):
     if name == 'lj-reaction-field':
         t = testsystems.LennardJonesFluid(nparticles=216, reduced_density=0.6, dispersion_correction=False)
@@ -236,11 +236,19 @@ def test_the_document_means_the_hamiltonian_the_engine_evaluates(name):
     else:
         t = testsystems.HostGuestExplicit(use_dispersion_correction=False)
         atoms = range(126, 156)
-    marked = _alchemical(t, atoms)
+    # annihilate_sterics: the guest's own Lennard-Jones pairs and 1-4 exceptions are lambda-controlled too (alchemy.py:1767-1779, 1841-1846)
+    marked = _alchemical(t, atoms, annihilate_sterics=(name == 'host-guest-annihilate'))
     xml = system_xml.to_xml(marked)
+    if name == 'host-guest-annihilate':
+        aa = [e for e in _forces(xml) if e.get('type') == 'CustomNonbondedForce'][1]
+        assert 'lambda_sterics' in _globals(aa) and not aa.get('energy').endswith('lambda_sterics=1.0;')
     box = np.diag(t.system.getDefaultPeriodicBoxVectors())
     x = t.positions + 0.002 * np.random.default_rng(1).normal(size=t.positions.shape)
     oracle = ForceFieldOracle(system_to_desc(marked))
+    if name == 'host-guest-annihilate':
+        decoupled = ForceFieldOracle(system_to_desc(_alchemical(t, atoms)))
+        assert abs(oracle.energy_forces(x, box, lambda_sterics=0.0, forces=False)[0]
+                   - decoupled.energy_forces(x, box, lambda_sterics=0.0, forces=False)[0]) > 10.0          # kJ/mol: the guest's own LJ
     for lam_s, lam_e in ((1.0, 1.0), (1.0, 0.35), (0.6, 0.0), (0.0, 0.0)):
         ref = oracle.energy_forces(x, box, lambda_sterics=lam_s, lambda_electrostatics=lam_e, forces=False)[0]
         got = _document_energy(xml, x, box, dict(lambda_sterics=lam_s, lambda_electrostatics=lam_e))
@@ -248,7 +256,7 @@ def test_the_document_means_the_hamiltonian_the_engine_evaluates(name):
 
 
 # ---- round trip and the store -------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('case', ['lj', 'alanine', 'alanine-cut', 'host-guest', 'softcore'])
+@pytest.mark.parametrize('case', ['lj', 'alanine', 'alanine-cut', 'host-guest', 'host-guest-annihilate', 'softcore'])
 def test_write_then_read_returns_the_marked_system(case):
     if case == 'lj':
         marked = _alchemical(testsystems.LennardJonesFluid(nparticles=64), range(4))
@@ -258,6 +266,8 @@ def test_write_then_read_returns_the_marked_system(case):
         marked = _alchemical(testsystems.AlanineDipeptideExplicit(), range(10))
     elif case == 'host-guest':
         marked = _alchemical(testsystems.HostGuestExplicit(), range(126, 156))
+    elif case == 'host-guest-annihilate':
+        marked = _alchemical(testsystems.HostGuestExplicit(), range(126, 156), annihilate_sterics=True)
     else:
         marked = _alchemical(testsystems.LennardJonesFluid(nparticles=64), [3, 9, 11], softcore_alpha=0.3, softcore_a=2, softcore_b=2, softcore_c=6)
         marked.alchemical_lrc = False
@@ -265,7 +275,7 @@ def test_write_then_read_returns_the_marked_system(case):
     assert barostat is None and back.alchemical_region.alchemical_atoms == marked.alchemical_region.alchemical_atoms
     r0, r1 = marked.alchemical_region, back.alchemical_region
     assert (r0.softcore_alpha, r0.softcore_a, r0.softcore_b, r0.softcore_c) == (r1.softcore_alpha, r1.softcore_a, r1.softcore_b, r1.softcore_c)
-    assert back.alchemical_lrc == marked.alchemical_lrc
+    assert back.alchemical_lrc == marked.alchemical_lrc and r1.annihilate_sterics == r0.annihilate_sterics
     d0, d1 = system_to_desc(marked), system_to_desc(back)
     assert sorted(d0) == sorted(d1)
     for k in d0:

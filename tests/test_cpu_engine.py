@@ -151,6 +151,32 @@ def test_cpu_hostguest_lambda_rows(cpu_engine_factory):
     assert np.abs(f[0] - f_ref).max() < 1e-7 * np.abs(f_ref).max()
 
 
+def test_cpu_annihilated_sterics(cpu_engine_factory):
+    """AlchemicalRegion(annihilate_sterics=True) (alchemy.py:421, 1767-1779, 1841-1846; remd_set_alchemical_options): the
+    Lennard-Jones pairs and 1-4 exceptions INSIDE the alchemical region are soft-core and lambda-controlled too.  CB7:B2 guest:
+    u_kl rows, own-state potential and forces of the C++ port against the torch oracle (pinned to the reference's expressions by
+    the document interpreter of tests/test_alchemical_store_cpu.py)."""
+    hg = ts.HostGuestExplicit()
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(
+        hg.system, alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156), annihilate_sterics=True))
+    lam_e = np.array([1.0, 0.3, 0.0, 0.0, 0.0])
+    lam_s = np.array([1.0, 1.0, 1.0, 0.4, 0.0])
+    eng = cpu_engine_factory()
+    desc, x, box = _setup(eng, system, hg.positions, R=1, lam_s=lam_s, lam_e=lam_e, labels=[3])
+    assert desc['annihilate_sterics'] is True
+    ff = ForceFieldOracle(desc)
+    rows, U = eng.compute_energies(want_potential=True)
+    ref = ff.state_energies(x[0], box[0], lam_s, lam_e)
+    assert np.allclose(rows[0], ref / (KB * 300.0), rtol=1e-9), np.abs(rows[0] * KB * 300.0 / ref - 1).max()
+    assert np.isclose(U[0], ref[3], rtol=1e-9)
+    decoupled = ForceFieldOracle(system_to_desc(alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(
+        hg.system, alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156)))))
+    assert abs(ref[4] - decoupled.state_energies(x[0], box[0], lam_s, lam_e)[4]) > 10.0
+    f = eng.get_forces()
+    f_ref = ff.energy_forces(x[0], box[0], lambda_sterics=0.4, lambda_electrostatics=0.0)[1]
+    assert np.abs(f[0] - f_ref).max() < 1e-7 * np.abs(f_ref).max()
+
+
 def test_cpu_softcore_exceptions_of_a_region_that_cuts_a_molecule(cpu_engine_factory, alanine):
     """Round 4: 1-4 exceptions between an alchemical and a non-alchemical atom carry soft-core, lambda_sterics-controlled
     Lennard-Jones (the factory's CustomBondForce, alchemy.py:1836-1851, 1985-1998); earlier rounds left them at full strength.

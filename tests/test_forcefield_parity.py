@@ -58,10 +58,12 @@ def test_lj_fluid_energy_and_forces(hip_engine_factory):
         assert np.isclose(rows[r, 0], e_ref / (KB * 300.0), rtol=1e-5)
 
 
-def test_lj_fluid_alchemical_ukl(hip_engine_factory):
-    """16 lambda_sterics states on atoms 0-9 (tests/test_alchemy.py:1864-1866): u_kl rows from one pass."""
+@pytest.mark.parametrize('annihilate', [False, True])
+def test_lj_fluid_alchemical_ukl(hip_engine_factory, annihilate):
+    """16 lambda_sterics states on atoms 0-9 (tests/test_alchemy.py:1864-1866): u_kl rows from one pass; with annihilate_sterics
+    the pairs among the ten atoms are lambda-controlled too."""
     lj = ts.LennardJonesFluid(nparticles=512)
-    region = alchemy.AlchemicalRegion(alchemical_atoms=range(10))
+    region = alchemy.AlchemicalRegion(alchemical_atoms=range(10), annihilate_sterics=annihilate)
     system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, region)
     lam = np.linspace(1.0, 0.0, 16)
     nb = [f for f in system.getForces() if hasattr(f, 'particles') and hasattr(f, 'exceptions')][0]
@@ -517,6 +519,46 @@ def test_softcore_exceptions_of_a_region_that_cuts_a_molecule(hip_engine_factory
         assert np.isclose(U[r], ref[k], rtol=1e-5)
         f_ref = ff.energy_forces(xd[r], box[r], lambda_sterics=lam_s[k], lambda_electrostatics=lam_e[k])[1]
         assert np.abs(f[r] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
+
+
+def test_annihilated_sterics(hip_engine_factory):
+    """AlchemicalRegion(annihilate_sterics=True) (alchemy.py:421, 1767-1779, 1841-1846; remd_set_alchemical_options): the
+    Lennard-Jones pairs and 1-4 exceptions inside the alchemical region are soft-core and lambda_sterics-controlled like those
+    with the environment.  CB7:B2 with the guest annihilated: u_kl over a (lambda_e, lambda_s) ladder, the own-state potential and
+    the forces at each replica's lambda against the f64 oracle; the same ladder under decoupling differs by tens of kJ/mol."""
+    hg = ts.HostGuestExplicit()
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(
+        hg.system, alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156), annihilate_sterics=True))
+    lam_e = np.array([1.0, 0.5, 0.0, 0.0, 0.0, 0.0])
+    lam_s = np.array([1.0, 1.0, 1.0, 0.7, 0.3, 0.0])
+    nb = [f for f in system.getForces() if hasattr(f, 'particles') and hasattr(f, 'exceptions')][0]
+    V = np.prod(np.diag(system.getDefaultPeriodicBoxVectors()))
+    econst = alchemy.alchemical_long_range_constants(system, nb, lam_s, V)
+    eng = hip_engine_factory()
+    desc = system_to_desc(system)
+    assert desc['annihilate_sterics'] is True
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 300.0)
+    eng.set_states(np.full(6, beta), lam_s, lam_e, econst)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 5, True, 1e-8)
+    eng.seed(SEED)
+    labels = np.array([1, 3, 5])
+    x = np.stack([hg.positions + 0.001 * r * np.random.default_rng(r).normal(size=hg.positions.shape) for r in range(3)])
+    box = np.tile(np.diag(system.getDefaultPeriodicBoxVectors()), (3, 1))
+    eng.set_replicas(3, 0, x, None, box, labels)
+    ff = ForceFieldOracle(desc)
+    rows, U = eng.compute_energies(want_potential=True)
+    xd = eng.get_replicas()[0]
+    f = eng.get_forces()
+    for r, k in enumerate(labels):
+        ref = ff.state_energies(xd[r], box[r], lam_s, lam_e)
+        assert np.allclose(rows[r], beta * (ref + econst), rtol=1e-5), np.abs(rows[r] / (beta * (ref + econst)) - 1).max()
+        assert np.isclose(U[r], ref[k], rtol=1e-5)
+        f_ref = ff.energy_forces(xd[r], box[r], lambda_sterics=lam_s[k], lambda_electrostatics=lam_e[k])[1]
+        assert np.abs(f[r] - f_ref).max() < 2e-4 * np.abs(f_ref).max()
+    decoupled = ForceFieldOracle(system_to_desc(alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(
+        hg.system, alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156)))))
+    assert abs(ff.state_energies(xd[0], box[0], lam_s, lam_e)[5] - decoupled.state_energies(xd[0], box[0], lam_s, lam_e)[5]) > 10.0
 
 
 def test_config4_all_64_alchemical_states_ukl(hip_engine_factory):
