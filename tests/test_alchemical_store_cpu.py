@@ -352,3 +352,52 @@ def test_alchemical_states_go_into_the_netcdf4_layout_and_resume(tmp_path, caplo
     eb = MultiStateReporter(str(tmp_path / 'full.nc'), open_mode='r').read_energies()[0]
     assert ea.shape == eb.shape == (6, 3, 3) and np.array_equal(ea[:4], e_first[:4])
     assert np.array_equal(ea[:4], eb[:4]) and np.allclose(ea[4:], eb[4:], rtol=2e-5, atol=1e-6)        # restart from f4 checkpoints
+
+
+def test_a_document_in_the_dress_of_an_older_openmm_is_read():
+    """The reader is tolerant of what differs between OpenMM releases (no `name` attribute and version 1 / 2 forces in 7.x, no
+    ComputedValues / EnergyParameterDerivatives blocks, `true` / `false` is not used by OpenMM but harmless, attribute order free):
+    a hand-written alchemical System of two alchemical and two environment atoms, with one soft-core exception, parses into the
+    marked System it describes."""
+    from openmmtools_amd import _alchemical_xml as ax
+    pair = ax.sterics_exception_expression() + 'epsilon = sqrt(epsilon1*epsilon2);sigma = 0.5*(sigma1 + sigma2);'
+    soft = ''.join('<Parameter default="%s" name="%s"/>' % (v, n) for n, v in
+                   (('softcore_alpha', 0.5), ('softcore_beta', 0.0), ('softcore_a', 1.0), ('softcore_b', 1.0), ('softcore_c', 6.0),
+                    ('softcore_d', 1.0), ('softcore_e', 1.0), ('softcore_f', 2.0)))
+    particles = ''.join('<Particle param1="%s" param2="%s"/>' % p for p in ((0.3, 0.5), (0.25, 0.0), (0.32, 0.6), (0.31, 0.4)))
+    cnb = lambda lam, s1, s2, energy: (
+        '<Force cutoff="1" energy="%s" forceGroup="2" method="2" switchingDistance="0.9" type="CustomNonbondedForce" useLongRangeCorrection="1" '
+        'useSwitchingFunction="1" version="2"><PerParticleParameters><Parameter name="sigma"/><Parameter name="epsilon"/></PerParticleParameters>'
+        '<GlobalParameters>%s%s</GlobalParameters><Particles>%s</Particles><Exclusions><Exclusion p1="1" p2="2"/></Exclusions><Functions/>'
+        '<InteractionGroups><InteractionGroup><Set1>%s</Set1><Set2>%s</Set2></InteractionGroup></InteractionGroups></Force>'
+        % (energy, lam, soft, particles, ''.join('<Particle index="%d"/>' % i for i in s1), ''.join('<Particle index="%d"/>' % i for i in s2)))
+    lam = '<Parameter default="1" name="lambda_sterics"/>'
+    bond = lambda lam, energy, bonds: (
+        '<Force energy="%s" forceGroup="2" type="CustomBondForce" usesPeriodic="0" version="1"><PerBondParameters><Parameter name="sigma"/>'
+        '<Parameter name="epsilon"/></PerBondParameters><GlobalParameters>%s%s</GlobalParameters><Bonds>%s</Bonds></Force>' % (energy, lam, soft, bonds))
+    doc = ('<?xml version="1.0" ?><System openmmVersion="7.7" type="System" version="1">'
+           '<PeriodicBoxVectors><A x="3" y="0" z="0"/><B x="0" y="3" z="0"/><C x="0" y="0" z="3"/></PeriodicBoxVectors>'
+           '<Particles><Particle mass="12"/><Particle mass="1"/><Particle mass="16"/><Particle mass="14"/></Particles><Constraints/><Forces>'
+           '<Force alpha="0" cutoff="1" dispersionCorrection="1" ewaldTolerance=".0005" forceGroup="1" method="4" nx="0" ny="0" nz="0" '
+           'recipForceGroup="-1" rfDielectric="78.3" switchingDistance="0.9" type="NonbondedForce" useSwitchingFunction="1" version="3">'
+           '<GlobalParameters><Parameter default="1" name="lambda_electrostatics"/></GlobalParameters>'
+           '<ParticleOffsets><Offset eps="0" parameter="lambda_electrostatics" particle="0" q="-0.2" sig="0"/>'
+           '<Offset eps="0" parameter="lambda_electrostatics" particle="1" q="0.2" sig="0"/></ParticleOffsets>'
+           '<ExceptionOffsets><Offset eps="0" exception="0" parameter="lambda_electrostatics" q="-0.01" sig="0"/></ExceptionOffsets>'
+           '<Particles><Particle eps="0" q="0" sig=".3"/><Particle eps="0" q="0" sig=".25"/><Particle eps=".6" q="-.4" sig=".32"/>'
+           '<Particle eps=".4" q=".4" sig=".31"/></Particles><Exceptions><Exception eps="0" p1="1" p2="2" q="0" sig=".285"/></Exceptions></Force>'
+           + cnb(lam, (2, 3), (0, 1), pair) + cnb('', (0, 1), (0, 1), pair + 'lambda_sterics=1.0;')
+           + bond(lam, ax.sterics_exception_expression(), '<Bond p1="1" p2="2" param1=".285" param2=".05"/>')
+           + bond('', ax.sterics_exception_expression() + 'lambda_sterics=1.0;', '')
+           + '</Forces></System>')
+    system, barostat = system_xml.from_xml(doc)
+    assert barostat is None and system.alchemical_region.alchemical_atoms == [0, 1] and not system.alchemical_region.annihilate_sterics
+    assert system.alchemical_lrc is True
+    nb = [f for f in system.getForces() if hasattr(f, 'exceptions')][0]
+    assert nb.particles == [(-0.2, 0.3, 0.5), (0.2, 0.25, 0.0), (-0.4, 0.32, 0.6), (0.4, 0.31, 0.4)]
+    assert nb.exceptions == [(1, 2, -0.01, 0.285, 0.05)] and nb.getForceGroup() == 0
+    d = system_to_desc(system)
+    assert list(d['alch_atoms']) == [0, 1] and d['annihilate_sterics'] is False and d['nb_method'] == 2
+    # and what is written from it reads back the same
+    again, _ = system_xml.from_xml(system_xml.to_xml(system))
+    assert again.fingerprint() == system.fingerprint()
