@@ -151,3 +151,25 @@ def test_golden_mixing_vectors():
         lab, nacc, nprop, _ = oracle.mix('swap-all', c['seed'], c['iteration'], u, np.array(c['labels_in'], dtype=np.int64))
         assert lab.tolist() == c['labels_out']
         assert nacc.tolist() == c['n_accepted'] and nprop.tolist() == c['n_proposed']
+
+
+@pytest.mark.parametrize('schedule', ['random', 'round-robin', 'reverse'])
+def test_rendezvous_formulation_of_swap_all_is_the_sequential_loop(schedule):
+    """A lead for a device kernel (tools/experiments/mix_rendezvous_model.py): one agent per replica walks its own
+    chain of attempts, the lower-indexed agent of a pair decides an attempt once both heads point at it.  Whatever the order the
+    agents are stepped in, the labels and the count matrices are those of the sequential oracle, bit for bit (self-swaps and
+    repeated pairs included), and the execution never deadlocks."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools', 'experiments'))
+    from mix_rendezvous_model import swap_all_rendezvous
+    for R, n, seed in ((5, 400, 1), (12, 3000, 2), (33, 6000, 3)):
+        rng = np.random.default_rng(seed)
+        u_kl = rng.normal(size=(R, R)) * (0.2 if seed == 1 else 3.0)          # high and low acceptance
+        ii, jj, uu = rng.integers(0, R, n).astype(np.int32), rng.integers(0, R, n).astype(np.int32), rng.random(n)
+        labels0 = rng.permutation(R).astype(np.int64)
+        ref_labels, ref_acc, ref_prop = oracle.mix_sequence(u_kl, labels0, ii, jj, uu)
+        accept = lambda log_p, u: log_p >= 0.0 or u < oracle.exp_det(log_p)
+        labels, n_acc, n_prop, rounds = swap_all_rendezvous(u_kl, labels0, ii, jj, uu, accept, schedule=schedule, seed=seed)
+        assert np.array_equal(labels, ref_labels) and np.array_equal(n_acc, ref_acc) and np.array_equal(n_prop, ref_prop)
+        assert 0 < rounds <= 2 * n + R
