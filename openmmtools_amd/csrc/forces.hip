@@ -538,10 +538,16 @@ void scatter_sorted_forces_kernel(int Npad_a, const int* __restrict__ order_a, l
                                   long long* __restrict__ force, int Npad_force, unsigned int* __restrict__ done = nullptr)
 {
     scatter_sorted_forces_body(Npad_a, order_a, sforce_a, Npad_b, order_b, sforce_b, force, Npad_force, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
-    // remd_fold_args: the barrier waits for the workgroup's outstanding force atomics -- device-scope read-modify-writes, performed at
-    // the memory side and visible to every XCD once acknowledged -- so the arrival needs NO release fence: a device-scope release
-    // writes back the whole L2 of the XCD it runs on, and 312 of them made this launch 28 us instead of 6 (profiles/r04_p_*)
-    if (done) { __syncthreads(); if (threadIdx.x == 0) __hip_atomic_fetch_add(done + 16 * blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // remd_fold_args: every thread drains its OWN force atomics (s_waitcnt vmcnt(0): the compiler puts no wait in front of the
+    // barrier -- the fence of __syncthreads is workgroup scope and gfx950 has a back-off barrier), then the barrier, then
+    // the arrival.  The force sums are device-scope read-modify-writes, performed at the memory side and visible to every XCD once
+    // acknowledged, so the arrival needs NO release fence: a device-scope release writes back the whole L2 of the XCD it runs on,
+    // and 312 of them made this launch 28 us instead of 6 (profiles/r04_p_*)
+    if (done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(done + 16 * blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // lane <-> (i atom ii, j atom jj) of a cluster pair in the sci kernels.  SCI_LANES_IJ = 1 (round 4): ii in the LOW three lane
