@@ -482,6 +482,10 @@ int remd_recover_device_flag(remd_ctx* h, unsigned int f, const char* where, boo
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
     if (h->stream2) REMD_CHECK(h, hipStreamSynchronize(h->stream2));
     REMD_CHECK(h, hipMemset(h->d_sync + 2, 0, sizeof(unsigned int)));
+    if (f == 6)        // (nothing to switch off: the run cannot continue at this cutoff; the move itself was rejected and restored)
+        return remd_fail(h, -2, std::string(where) + ": the Monte Carlo barostat proposed a periodic box smaller than twice the nonbonded cutoff "
+                                "(for a PME System: the Coulomb range of the Ewald split, remd_set_coulomb_cutoff) -- the box has shrunk too far "
+                                "for this cutoff (OpenMM: \"The periodic box size has decreased to less than twice the nonbonded cutoff\")");
     h->join_deferred = 0; h->cbins_ready = false;
     remd_nb_invalidate_sort(h);
     remd_nb_reset_accumulators(h);

@@ -53,7 +53,8 @@ __global__ void baro_decide_kernel(int R, int r_begin, uint64_t seed, long long 
                                    const double* __restrict__ beta, const double* __restrict__ pressure,
                                    const double* __restrict__ econst, double econst_vref,
                                    float* __restrict__ box, const float* __restrict__ box_old, double* __restrict__ st,
-                                   int* __restrict__ accepted, const unsigned int* __restrict__ noise_id)
+                                   int* __restrict__ accepted, const unsigned int* __restrict__ noise_id,
+                                   float min_edge, unsigned int* __restrict__ err)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
@@ -64,7 +65,11 @@ __global__ void baro_decide_kernel(int R, int r_begin, uint64_t seed, long long 
     const double dlr = (econst_vref > 0.0) ? econst[k] * econst_vref * (1.0 / S[6] - 1.0 / S[7]) : 0.0;
     const double w = U_new[r] - U_old[r] + dlr + pressure[k] * S[5] - (double)n_mol * kT * log(S[6] / S[7]);
     const philox4 q = remd_philox(seed, REMD_STREAM_BAROSTAT, 1u, noise_id ? noise_id[r] : (uint32_t)(r_begin + r), (uint64_t)attempt);
-    const bool reject = !(w <= 0.0) && !(remd_u53(q.w[2], q.w[3]) <= exp(-w / kT));     // NaN energies reject
+    bool reject = !(w <= 0.0) && !(remd_u53(q.w[2], q.w[3]) <= exp(-w / kT));           // NaN energies reject
+    // a trial box with an edge below twice the longer cutoff (the Coulomb range of the Ewald split may exceed the NonbondedForce
+    // cutoff) was evaluated with a broken minimum image: never accept it, and say so -- OpenMM raises "The periodic box size has
+    // decreased to less than twice the nonbonded cutoff" here (sticky device flag 6: api.hip turns it into the error)
+    if (fminf(box[4 * r], fminf(box[4 * r + 1], box[4 * r + 2])) < min_edge) { reject = true; atomicExch(err, 6u); }
     accepted[r] = reject ? 0 : 1;
     if (reject) { box[4 * r] = box_old[4 * r]; box[4 * r + 1] = box_old[4 * r + 1]; box[4 * r + 2] = box_old[4 * r + 2]; }
     else { S[2] += 1.0; S[4] += 1.0; }
@@ -121,7 +126,7 @@ int remd_barostat_attempt(remd_ctx* h)
     if ((rc = remd_compute_forces(h, true))) return rc;                         // U' and forces of the scaled configuration
     hipLaunchKernelGGL(baro_decide_kernel, dim3((R + 63) / 64), dim3(64), 0, h->stream, R, h->r_begin, h->seed, attempt, n_groups,
                        h->d_baro_U0, h->d_potential, h->d_labels, h->d_beta, h->d_pressure, h->d_econst, h->econst_vref, h->d_box, h->d_box_old, h->d_baro,
-                       h->d_baro_acc, h->d_noise_id);
+                       h->d_baro_acc, h->d_noise_id, (float)(2.0 * std::max(h->cutoff, h->coulomb_cutoff)), h->d_sync + 2);
     hipLaunchKernelGGL(baro_restore_kernel, dim3((h->N + 255) / 256, R), dim3(256), 0, h->stream, h->N, Npad, h->d_baro_acc, h->d_pos,
                        h->d_baro_x0, h->d_force, h->d_baro_f0, h->d_potential, h->d_baro_U0);
     h->box_version++;

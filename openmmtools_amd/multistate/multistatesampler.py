@@ -613,6 +613,16 @@ class MultiStateSampler:
         ref = all_states[0]
         box0 = self._sampler_states[0].box_edges if ref.is_periodic else None
         split = getattr(self._engine, 'ewald_split', None)        # the engine's preferred split of the Ewald sum (PME systems)
+        min_edge = None
+        if ref.is_periodic and split == 'auto':
+            # ONE Ewald split (Coulomb range, alpha, mesh) serves the whole ensemble: choose it for the SMALLEST box any replica
+            # starts in, and under a barostat leave the volume room to fluctuate -- the stretched Coulomb range must stay below
+            # half the box edge of every replica at every step (the engine refuses a smaller box: remd_set_replicas, and the
+            # Monte Carlo barostat raises when a trial box gets there, as OpenMM does) -- ADVICE r4
+            edges = np.array([np.asarray(ss.box_edges, dtype=np.float64) for ss in self._sampler_states if ss.box_edges is not None])
+            min_edge = float(edges.min()) if len(edges) else float(np.min(box0))
+            if any(s.pressure is not None for s in all_states):
+                min_edge /= 1.1
         # states.py:186-217: states of one standard System share a handle; several Systems => one handle per group behind the
         # same interface (_engine_pool.py), as the reference keeps one Context per compatible group (multistatesampler.py:1470-1490)
         from ..states import group_by_compatibility
@@ -623,9 +633,9 @@ class MultiStateSampler:
             from ._engine_pool import EnginePool
             if not isinstance(self._engine, EnginePool):
                 self._engine = EnginePool(self._engine, group_indices)
-            desc = [system_to_desc(g[0].system, box=box0, ewald_split=split) for g in groups]
+            desc = [system_to_desc(g[0].system, box=box0, ewald_split=split, min_edge=min_edge) for g in groups]
         else:
-            desc = system_to_desc(ref.system, box=box0, ewald_split=split)
+            desc = system_to_desc(ref.system, box=box0, ewald_split=split, min_edge=min_edge)
         eng = self._engine
         eng.set_system(desc)
         beta = np.array([s.beta for s in all_states])

@@ -302,7 +302,7 @@ def ewald_parameters(cutoff, tolerance, box):
     return alpha, grid
 
 
-def rebalanced_coulomb_cutoff(cutoff, tolerance, box, max_extension=1.25):
+def rebalanced_coulomb_cutoff(cutoff, tolerance, box, max_extension=1.25, min_edge=None):
     """Range of the Ewald direct-space sum that the device engine prefers for this box (``ewald_split='auto'``), or ``cutoff``.
 
     The Ewald sum does not depend on where it is split; OpenMM ties the split to the NonbondedForce cutoff
@@ -316,7 +316,9 @@ def rebalanced_coulomb_cutoff(cutoff, tolerance, box, max_extension=1.25):
     friendly = (32, 40, 48, 64, 80, 96, 128)
     root = math.sqrt(-math.log(2.0 * tolerance))
     lmax = max(float(L) for L in box)
-    lmin = min(float(L) for L in box)
+    # (min_edge: the shortest box edge the run may see -- the smallest starting box of an ensemble, less a margin under a barostat;
+    # twice the stretched range must stay below it)
+    lmin = min(float(L) for L in box) if min_edge is None else min(float(min_edge), min(float(L) for L in box))
     n_ref = max(ewald_parameters(cutoff, tolerance, box)[1])
     best = cutoff
     for n in friendly:
@@ -374,7 +376,7 @@ def _classify_constraints(system):
     return settle, shake, shake_d
 
 
-def system_to_desc(system, box=None, ewald_split=None):
+def system_to_desc(system, box=None, ewald_split=None, min_edge=None):
     """Flatten a System into the arrays of remd_system_desc (include/remd_hip.h).
 
     ewald_split: None / 'reference' = OpenMM's rule (alpha and mesh from the NonbondedForce cutoff); 'auto' = the Coulomb range
@@ -464,7 +466,7 @@ def system_to_desc(system, box=None, ewald_split=None):
                 tol = nb.getEwaldErrorTolerance()
                 rcc = d['cutoff']
                 if ewald_split == 'auto':
-                    rcc = rebalanced_coulomb_cutoff(d['cutoff'], tol, box)
+                    rcc = rebalanced_coulomb_cutoff(d['cutoff'], tol, box, min_edge=min_edge)
                 elif ewald_split not in (None, 'reference'):
                     rcc = float(ewald_split)
                     if rcc < d['cutoff']:
