@@ -17,6 +17,7 @@ void remd_nb_invalidate_sort(remd_ctx* h);    // forces.hip
 int remd_test_fft3d_impl(remd_ctx* h, int nx, int ny, int nz, float* data, int inverse);
 void remd_nb_tune_resolve(remd_ctx* h);
 static int remd_check_device_flags(remd_ctx* h, const char* where, bool may_retry = false);
+const unsigned* remd_mix_pending_flag(remd_ctx* h);      // mix.hip
 void remd_free_constraints(remd_ctx* h);
 
 static std::mutex g_err_mutex;
@@ -289,6 +290,10 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     if (!h || !h->has_system) return remd_fail(h, -1, "remd_set_replicas: call remd_set_system first");
     if (R_global <= 0 || R_local <= 0 || r_begin < 0 || r_begin + R_local > R_global || !labels)
         return remd_fail(h, -1, "remd_set_replicas: bad arguments");
+    // (validated before anything of the handle changes: a refused call leaves it as it was)
+    if (h->nb_method != REMD_NB_NONE && box)
+        for (int r = 0; r < R_local; ++r) for (int k = 0; k < 3; ++k)
+            if (!(box[3 * r + k] >= 2.0 * h->cutoff)) return remd_fail(h, -1, "remd_set_replicas: box smaller than twice the cutoff");
     hipSetDevice(h->device);
     const bool realloc = (R_local != h->R) || (R_global != h->R_global) || !h->d_pos;
     if (h->d_noise_id) { hipStreamSynchronize(h->stream); hipFree(h->d_noise_id); h->d_noise_id = nullptr; }     // ids belong to one set of replicas
@@ -334,9 +339,6 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     // padding atoms are parked far apart so that they never interact
     for (int r = 0; r < R_local; ++r)
         for (int i = h->N; i < h->Npad; ++i) hp[(size_t)r * h->Npad + i] = make_float4(1e6f + 10.f * i, 1e6f, 1e6f, 0.f);
-    if (h->nb_method != REMD_NB_NONE && box)
-        for (int r = 0; r < R_local; ++r) for (int k = 0; k < 3; ++k)
-            if (box[3 * r + k] < 2.0 * h->cutoff) return remd_fail(h, -1, "remd_set_replicas: box smaller than twice the cutoff");
     std::vector<float> hb(4 * (size_t)R_local, 0.f);
     h->box_host.assign(3 * (size_t)R_local, 0.0);
     for (int r = 0; r < R_local; ++r) for (int k = 0; k < 3; ++k) {
@@ -729,10 +731,16 @@ static int mix_common(remd_ctx* h, int scheme, int64_t iteration, int R, int K, 
 {
     int rc;
     hipEventRecord(h->ev0, h->stream);
-    REMD_CHECK(h, hipMemcpyAsync(d_labels, labels, sizeof(int64_t) * R, hipMemcpyHostToDevice, h->stream));
+    const std::vector<int64_t> labels_in(labels, labels + R);
+  again:
+    REMD_CHECK(h, hipMemcpyAsync(d_labels, labels_in.data(), sizeof(int64_t) * R, hipMemcpyHostToDevice, h->stream));
     if (log_weights) REMD_CHECK(h, hipMemcpyAsync(h->d_logw, log_weights, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
     if ((rc = remd_mix_launch(h, scheme, iteration, R, K, ld, d_ukl, d_labels, h->d_nacc, h->d_nprop,
-                              log_weights ? h->d_logw : nullptr, h->d_logP, n_attempts))) return rc;
+                              log_weights ? h->d_logw : nullptr, h->d_logP, n_attempts))) { h->mix_no_pre = false; return rc; }
+    // the hoisted swap-all path leaves its overflow flag on the device: read here, with the results (one synchronisation per call)
+    unsigned pre_overflow = 0;
+    if (const unsigned* flag = remd_mix_pending_flag(h))
+        REMD_CHECK(h, hipMemcpyAsync(&pre_overflow, flag, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     REMD_CHECK(h, hipMemcpyAsync(labels, d_labels, sizeof(int64_t) * R, hipMemcpyDeviceToHost, h->stream));
     if (n_accepted) REMD_CHECK(h, hipMemcpyAsync(n_accepted, h->d_nacc, sizeof(int64_t) * (size_t)K * K, hipMemcpyDeviceToHost, h->stream));
     if (n_proposed) REMD_CHECK(h, hipMemcpyAsync(n_proposed, h->d_nprop, sizeof(int64_t) * (size_t)K * K, hipMemcpyDeviceToHost, h->stream));
@@ -740,6 +748,11 @@ static int mix_common(remd_ctx* h, int scheme, int64_t iteration, int R, int K, 
         REMD_CHECK(h, hipMemcpyAsync(sams_log_P, h->d_logP, sizeof(double) * (size_t)R * K, hipMemcpyDeviceToHost, h->stream));
     hipEventRecord(h->ev1, h->stream);
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    if (pre_overflow && !h->mix_no_pre) {        // (nothing was touched: the serial kernel and the statistics return at once on the flag)
+        h->mix_no_pre = true;
+        goto again;
+    }
+    h->mix_no_pre = false;
     float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_mix = ms;
     if (scheme == REMD_MIX_SWAP_ALL && n_accepted && n_proposed) {
         double a = 0.0, p = 0.0;

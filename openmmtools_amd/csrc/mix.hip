@@ -401,9 +401,12 @@ void mix_swap_all_pre_kernel(uint64_t seed, int64_t iteration, int R, int K, int
                              int64_t* __restrict__ g_labels, int64_t n_attempts, const uint4* __restrict__ g_rec,
                              const unsigned* __restrict__ g_piece, const unsigned* __restrict__ g_npiece,
                              const unsigned char* __restrict__ g_cnt, int Rpad_cnt, unsigned int* __restrict__ g_log,
-                             long long* __restrict__ g_dbg)
+                             long long* __restrict__ g_dbg, const unsigned* __restrict__ g_err)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (a window of mix_prep_kernel needed more than MIXP pieces: nothing is touched here, the host runs the one-kernel path when it
+    // reads the flag at the end of the call -- no host round trip between the two launches)
+    if (*g_err) return;
     const int tid = threadIdx.x, W = blockDim.x;
     long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t0 = clock64(), w0 = wall_clock64();
@@ -593,8 +596,10 @@ void sams_global_jump_kernel(uint64_t seed, int64_t iteration, int R, int K, int
 // proposed / accepted state-pair counts (replicaexchange.py:339-340, 348-349) from the attempt log of mix_swap_all_kernel
 __global__ __launch_bounds__(256)
 void mix_stats_from_log_kernel(int64_t n_attempts, const unsigned int* __restrict__ log, int K,
-                               unsigned long long* __restrict__ g_nacc, unsigned long long* __restrict__ g_nprop)
+                               unsigned long long* __restrict__ g_nacc, unsigned long long* __restrict__ g_nprop,
+                               const unsigned* __restrict__ g_err = nullptr)
 {
+    if (g_err && *g_err) return;
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n_attempts; k += (int64_t)gridDim.x * 256) {
         const unsigned int e = log[k];
         if (!(e >> 31)) continue;
@@ -610,10 +615,18 @@ struct mix_pre_buffers {
     unsigned* piece = nullptr; unsigned* npiece = nullptr; size_t win_n = 0;
     unsigned char* cnt = nullptr; size_t cnt_n = 0;
     unsigned* err = nullptr;
-    ~mix_pre_buffers() { hipFree(rec); hipFree(piece); hipFree(npiece); hipFree(cnt); hipFree(err); }
+    long long* dbg = nullptr;             // REMD_MIX_DEBUG phase counters (per handle: handles may live on different devices)
+    ~mix_pre_buffers() { hipFree(rec); hipFree(piece); hipFree(npiece); hipFree(cnt); hipFree(err); hipFree(dbg); }
 };
 static handle_table<mix_pre_buffers> g_mix_pre;
 void remd_mix_release(remd_ctx* h) { g_mix_pre.erase(h); }
+// the overflow flag of the hoisted swap-all path launched last (device pointer; NULL: that path did not run): api.hip reads it with
+// the results, at the call's one synchronisation, and repeats the call on the one-kernel path when it is raised
+const unsigned* remd_mix_pending_flag(remd_ctx* h)
+{
+    mix_pre_buffers* B = g_mix_pre.find(h);
+    return (B && h->mix_pre_launched) ? B->err : nullptr;
+}
 
 int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, int ld, const double* d_ukl,
                     int64_t* d_labels, unsigned long long* d_nacc, unsigned long long* d_nprop,
@@ -661,12 +674,17 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
         const char* flow_env = getenv("REMD_MIX_FLOW");
         const int flow = flow_env ? atoi(flow_env) : (h->mix_acc_rate > 0.17 ? 1 : 0);
         static const bool debug = getenv("REMD_MIX_DEBUG") != nullptr;
-        static long long* d_dbg = nullptr;
-        if (debug && !d_dbg) REMD_CHECK(h, hipMalloc(&d_dbg, 8 * sizeof(long long)));
+        long long* d_dbg = nullptr;
+        if (debug) {
+            mix_pre_buffers& Bd = g_mix_pre[h];
+            if (!Bd.dbg) REMD_CHECK(h, hipMalloc(&Bd.dbg, 8 * sizeof(long long)));
+            d_dbg = Bd.dbg;
+        }
+        h->mix_pre_launched = false;
         // speculative windows with the label-independent part hoisted into a whole-chip kernel (mix_prep_kernel); REMD_MIX_PRE=0
         // keeps everything in the one serial workgroup (parity tests run both)
         const bool pre_off = getenv("REMD_MIX_PRE") && atoi(getenv("REMD_MIX_PRE")) == 0;
-        if (!flow && !pre_off && n_attempts > 0 && (size_t)n_attempts * sizeof(unsigned int) <= ((size_t)1 << 30)) {
+        if (!flow && !pre_off && !h->mix_no_pre && n_attempts > 0 && (size_t)n_attempts * sizeof(unsigned int) <= ((size_t)1 << 30)) {
             const int W = 64 * waves;
             const int64_t n_win = (n_attempts + W - 1) / W;
             const int Rp4 = (R + 3) & ~3;
@@ -689,10 +707,7 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
             REMD_CHECK(h, hipMemsetAsync(B.err, 0, sizeof(unsigned), h->stream));
             hipLaunchKernelGGL(mix_prep_kernel, dim3((unsigned)n_win), dim3(W), sizeof(unsigned long long) * (size_t)R * waves, h->stream,
                                h->seed, iteration, R, n_attempts, B.rec, B.piece, B.npiece, B.cnt, Rp4, B.err);
-            unsigned err = 0;
-            REMD_CHECK(h, hipMemcpyAsync(&err, B.err, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-            REMD_CHECK(h, hipStreamSynchronize(h->stream));
-            if (!err) {
+            {
                 const size_t pre_work = 4 * (size_t)R * MIX_CHAIN + 4 * Rp + 8 * Rp + 16;
                 const int pre_in_lds = ukl_bytes + pre_work <= 156 * 1024;
                 size_t pre_lds = ((pre_in_lds ? ukl_bytes : 0) + pre_work + 15) & ~(size_t)15;
@@ -700,9 +715,10 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
                 REMD_CHECK(h, hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
                 hipLaunchKernelGGL(pk, dim3(1), dim3(W), pre_lds, h->stream, h->seed, iteration, R, K, ld, d_ukl, d_labels, n_attempts,
                                    (const uint4*)B.rec, (const unsigned*)B.piece, (const unsigned*)B.npiece, (const unsigned char*)B.cnt, Rp4,
-                                   h->d_mix_log, d_dbg);
+                                   h->d_mix_log, d_dbg, (const unsigned*)B.err);
                 hipLaunchKernelGGL(mix_stats_from_log_kernel, dim3((unsigned)std::min<int64_t>(4096, (n_attempts + 255) / 256)), dim3(256), 0, h->stream,
-                                   n_attempts, h->d_mix_log, K, d_nacc, d_nprop);
+                                   n_attempts, h->d_mix_log, K, d_nacc, d_nprop, (const unsigned*)B.err);
+                h->mix_pre_launched = true;
                 if (debug) {
                     long long hd[8];
                     REMD_CHECK(h, hipStreamSynchronize(h->stream));
@@ -713,7 +729,6 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
                 REMD_CHECK(h, hipGetLastError());
                 return 0;
             }
-            // (a window needed more than MIXP pieces: fall through to the one-kernel path, which cuts windows as it goes)
         }
         auto kern = flow ? (in_lds ? mix_swap_all_dataflow_kernel<true> : mix_swap_all_dataflow_kernel<false>)
                          : (in_lds ? mix_swap_all_kernel<true> : mix_swap_all_kernel<false>);

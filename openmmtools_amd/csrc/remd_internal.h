@@ -158,6 +158,7 @@ struct remd_ctx {
     int box_version = 0;               // bumped whenever the box edges on the device change (PME influence table)
     int n_restart_attempts = 0;        // mcmc.py:706-759
     unsigned int* d_mix_log = nullptr; size_t mix_log_n = 0;      // swap-all attempt log (si, sj, accepted) when the counters do not fit
+    bool mix_pre_launched = false, mix_no_pre = false;   // swap-all: the hoisted path ran last (its overflow flag is pending) / is off for the repeat
     double mix_acc_rate = -1.0;        // accepted / proposed of the previous swap-all call (picks the kernel of the next: mix.hip) in LDS
     float4* d_snap_pos = nullptr; float4* d_snap_vel = nullptr;   // pre-propagate state (restart attempts)
     float4* d_fin_pos = nullptr; float4* d_fin_vel = nullptr;     // first successful result of every replica

@@ -67,8 +67,8 @@ def _parameter_fingerprint(obj, _depth=0):
         return ('nd', obj.shape, obj.tobytes() if obj.size <= 64 else hash(obj.tobytes()))
     if isinstance(obj, (list, tuple)):
         return tuple(_parameter_fingerprint(o, _depth + 1) for o in obj)
-    if hasattr(obj, 'fingerprint') and callable(obj.fingerprint):            # System
-        return ('system', id(obj), obj.getNumParticles() if hasattr(obj, 'getNumParticles') else 0)
+    if hasattr(obj, 'fingerprint') and callable(obj.fingerprint):            # System: by CONTENT (one mutated in place must not meet
+        return ('system', obj.fingerprint())                                  # the driver programmed with its old parameters)
     d = getattr(obj, '__dict__', None)
     if d is None:
         return repr(obj)
