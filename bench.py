@@ -19,6 +19,13 @@ collective is the RCCL all-gather of u_kl rows.  `value` counts 24-replica-itera
                            T = 128: the north_star efficiency target, "1->8 GPUs at 128 replicas").
                           `value` keeps the same unit (T / 24 * iterations / s), `scaling` = "strong".
 
+shapes: besides the main line's `value`, the same JSON line carries `"shapes"`: the other ensemble shapes the scaling question is
+asked on, each measured in this very run on the same N ranks (a few iterations each; `--no-shapes` skips them):
+    strong24_alanine       one 24-replica ensemble over the N GPUs  (BASELINE.json's metric as written; = the main line at N = 1)
+    strong128_alanine      one 128-replica alanine ensemble over the N GPUs (north_star's "1 -> 8 GPUs at 128 replicas")
+    config5_dhfr128_sams   DHFR x 128 temperature states, SAMS global jump, over the N GPUs (BASELINE config 5: mixing is R x K)
+each with its own value, ms per iteration, the slowest rank's mix / propagate / u_kl / all-gather ms and the world size it saw.
+
 cpu_baseline: the same iteration through the same C ABI on oracle/_build/libremd_cpu.so (f64, OpenMP over
 replicas, all host cores), timed on a bounded sample (fewer MD steps per iteration, scaled to 500).
 """
@@ -86,7 +93,7 @@ def build_sampler(n_replicas, engine, comm, md_steps):
     return sampler, ts
 
 
-def cpu_baseline(n_replicas=REPLICAS_PER_GPU, budget_s=15.0):
+def cpu_baseline(n_replicas=REPLICAS_PER_GPU, budget_s=12.0, all_cores=True):
     """The CPU baseline BASELINE.md section 3 names: the same mix -> propagate -> u_kl iteration of the same 24-replica
     parallel-tempering ensemble, through the same C ABI (include/remd_hip.h) implemented on the CPU by
     oracle/_build/libremd_cpu.so (f64, cell/Verlet-list direct space, smooth PME with an in-tree FFT, SETTLE/SHAKE,
@@ -122,7 +129,31 @@ def cpu_baseline(n_replicas=REPLICAS_PER_GPU, budget_s=15.0):
     t_mix, t_prop, t_en = float(td['mixing_seconds']), float(td['propagation_seconds']), float(td['energy_seconds'])
     per_iter = t_mix + t_prop * (MD_STEPS / float(k)) + t_en
     eng.close()
-    return dict(value=1.0 / per_iter, unit='iterations/s', cores=min(threads, n_replicas), kind='port',
+    # SURVEY 8(d) asks for ALL host cores.  The port parallelises over replicas (one per thread: the shape of the reference's mpiplus
+    # distribution), so the box is full when the ensemble has as many replicas as it has hardware threads: a second bounded sample
+    # times such an ensemble and reports it in the metric's 24-replica units -- what these host cores deliver on this workload
+    full = None
+    if all_cores and threads > n_replicas:
+        try:
+            r_all = int(threads)
+            eng2 = HipEngine(lib_path=lib_path)
+            eng2.is_device = False
+            k2 = max(2, k // 2)
+            s2, _ = build_sampler(r_all, eng2, None, k2)
+            s2.run(1)
+            t0 = time.perf_counter()
+            s2.run(1)
+            sample2 = time.perf_counter() - t0
+            td2 = s2._timing_data
+            per_iter2 = float(td2['mixing_seconds']) + float(td2['propagation_seconds']) * (MD_STEPS / float(k2)) + float(td2['energy_seconds'])
+            eng2.close()
+            full = dict(kind='port-f64-all-threads', value=(r_all / float(n_replicas)) / per_iter2, unit='iterations/s in 24-replica units',
+                        replicas=r_all, cores=r_all, seconds_per_iteration_of_that_ensemble=per_iter2,
+                        sample='one iteration of a %d-replica ensemble (one replica per hardware thread) with %d of %d MD steps, %.1f s measured'
+                               % (r_all, k2, MD_STEPS, sample2))
+        except Exception as exc:
+            full = dict(error='%s: %s' % (type(exc).__name__, exc))
+    return dict(value=1.0 / per_iter, unit='iterations/s', cores=min(threads, n_replicas), kind='port', all_host_threads=full,
                 threads_available=threads, seconds_per_iteration=per_iter,
                 sample='one full mix -> propagate -> u_kl iteration of the %d-replica AlanineDipeptideExplicit ensemble on '
                        'libremd_cpu.so (same C ABI, f64, OpenMP over replicas) with %d of %d MD steps (%.1f s measured; '
@@ -133,6 +164,68 @@ def cpu_baseline(n_replicas=REPLICAS_PER_GPU, budget_s=15.0):
                        (n_replicas, k, MD_STEPS, sample_s, MD_STEPS / float(k), t_mix, t_en, probe, min(threads, n_replicas), threads))
 
 
+def build_dhfr_sams(n_replicas, engine, comm, md_steps):
+    """BASELINE config 5: testsystems.DHFRExplicit (23 558 atoms), 128 states on a temperature ladder, SAMSSampler with the global
+    jump (sams.py:477-501), g-BAOAB 2 fs."""
+    from openmmtools_amd import testsystems, states, mcmc, unit
+    from openmmtools_amd.multistate import SAMSSampler
+    dh = testsystems.DHFRExplicit()
+    ths = [states.ThermodynamicState(dh.system, t) for t in np.geomspace(300.0, 400.0, n_replicas)]
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond, n_steps=md_steps,
+                                              reassign_velocities=True, splitting='V R R O R R V')
+    s = SAMSSampler(mcmc_moves=move, number_of_iterations=10 ** 9, engine=engine, seed=SEED, comm=comm)
+    s.create(ths, [states.SamplerState(dh.positions, box_vectors=dh.system.getDefaultPeriodicBoxVectors())] * n_replicas)
+    return s
+
+
+def run_shapes(args, world, rank, local_rank, comm, sync, stream, budget_s=240.0):
+    """The other ensemble shapes on the same ranks (every rank calls this: the samplers hold collectives).  Returns the dict for the
+    JSON line on rank 0.  A shape that fails is reported with its error instead of taking the main line down."""
+    import torch
+    from openmmtools_amd._engine import HipEngine
+    t_start = time.perf_counter()
+    out = {}
+    specs = [('strong24_alanine', 24, 'alanine', 3, 1), ('strong128_alanine', 128, 'alanine', 3, 1),
+             ('config5_dhfr128_sams', 128, 'dhfr', 1 if world == 1 else 2, 1)]
+    for name, R, kind, n_it, n_warm in specs:
+        if R < world or (name == 'strong24_alanine' and world == 1):
+            continue
+        if time.perf_counter() - t_start > budget_s:
+            out[name] = dict(skipped='time budget of the extra shapes used up')
+            continue
+        try:
+            engine = HipEngine(device=local_rank, stream=stream)
+            sampler = build_sampler(R, engine, comm, args.md_steps)[0] if kind == 'alanine' else build_dhfr_sams(R, engine, comm, args.md_steps)
+            sampler.run(n_warm)
+            sync()
+            t0 = time.perf_counter()
+            sampler.run(n_it)
+            sync()
+            elapsed = time.perf_counter() - t0
+            td = sampler._timing_data
+            parts = [float(td.get(k, 0.0)) for k in ('mixing_seconds', 'propagation_seconds', 'energy_seconds', 'allgather_seconds')]
+            if world > 1:
+                import torch.distributed as dist
+                dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+                t = torch.tensor([elapsed] + parts, dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed, parts = float(t[0].item()), [float(v) for v in t[1:].tolist()]
+            it_per_s = n_it / elapsed
+            out[name] = dict(value=it_per_s * (R / float(REPLICAS_PER_GPU)) if kind == 'alanine' else it_per_s,
+                             unit='iterations/s in 24-replica units (R / 24 x ensemble iterations/s)' if kind == 'alanine'
+                                  else 'iterations/s of the 128-replica ensemble',
+                             scaling='strong', replicas_total=R, replicas_on_rank0=int(sampler._r_count), n_gpus=world, world_size_seen=world,
+                             backend=(os.environ.get('REMD_BENCH_BACKEND', 'nccl') if world > 1 else 'none'),
+                             iterations=n_it, warmup=n_warm, md_steps=args.md_steps, ms_per_iteration=1e3 * elapsed / n_it,
+                             slowest_rank_last_iteration_ms=dict(mix=1e3 * parts[0], propagate=1e3 * parts[1], ukl=1e3 * parts[2],
+                                                                 allgather=1e3 * parts[3]),
+                             mix=('swap-all, R^3 attempts, replicated on every rank' if kind == 'alanine' else 'SAMS global jump, R x K'))
+            engine.close()
+        except Exception as exc:                       # never fail the main line for an extra shape
+            out[name] = dict(error='%s: %s' % (type(exc).__name__, exc))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -140,6 +233,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--md-steps', type=int, default=MD_STEPS, help='MD steps per iteration (500 = BASELINE)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-shapes', action='store_true', help='skip the extra ensemble shapes (strong-24 / strong-128 / config 5)')
     ap.add_argument('--replicas-total', type=int, default=0,
                     help='strong scaling: one ensemble of this many replicas sharded over the ranks (24 = the BASELINE '
                          'metric as written, 128 = the north_star efficiency target); 0 = weak scaling, 24 per GPU')
@@ -209,6 +303,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # the other ensemble shapes, on the same ranks (collective: every rank takes part); the main engine stays open for the roofline extras
+    shapes = None
+    if not args.no_shapes and args.replicas_total == 0:
+        shapes = run_shapes(args, world, rank, local_rank, comm, sync, stream)
 
     if rank == 0:
         it_per_s = args.steps / elapsed
@@ -291,7 +390,7 @@ def main():
                                replicas_per_gpu=(n_replicas / float(world)), replicas_total=n_replicas, md_steps=args.md_steps,
                                mode=('strong: one %d-replica ensemble' % n_replicas) if strong else 'weak: 24 replicas per GPU',
                                parallelism='replica-sharded x%d' % world, seed=SEED, ewald=ewald),
-                   timing=timing_of_timed_region, roofline=roof, roofline_secondary=roof2, roofline_integrator=roof_ch)
+                   timing=timing_of_timed_region, roofline=roof, roofline_secondary=roof2, roofline_integrator=roof_ch, shapes=shapes)
         try:
             # achievable roofs of THIS box (STREAM triad past the Infinity Cache, FMA chains), SURVEY 8(d)
             out['measured_roofs'] = engine.roof_microbench()

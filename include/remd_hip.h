@@ -341,6 +341,10 @@ int  remd_roof_microbench(remd_handle h, double* stream_gb_per_s, double* fma_tf
 /* the shader clock (GHz) the chip sustains under that FMA load (cycle counter against the constant 100 MHz wall clock inside one
    wavefront of the microbenchmark): the spec peak of 157.3 TFLOP/s is quoted at 2.4 GHz.  libremd_cpu.so: -3.               */
 int  remd_roof_clock_ghz(remd_handle h, double* ghz_under_fma_load);
+/* Issue floor of the direct-space pair kernel (diagnostic, roofs.hip): a replay of its cluster-pair step -- 27 VALU instructions and
+ * one 16-byte LDS read, operands in registers -- at `waves_per_simd` (1 ... 8) resident wavefronts per SIMD with `chains` (1 or 2)
+ * independent steps in flight per wavefront; returns shader cycles per step per SIMD at the clock `ghz` and the launch's time. */
+int  remd_roof_pair_step(remd_handle h, int waves_per_simd, int chains, double ghz, double* cycles_per_step_per_simd, double* us_total);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,7 @@ EXPORTS = [
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_set_force_groups', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
-    'remd_set_energy_const_volume', 'remd_roof_microbench', 'remd_roof_clock_ghz', 'remd_test_coulomb_table',
+    'remd_set_energy_const_volume', 'remd_roof_microbench', 'remd_roof_clock_ghz', 'remd_roof_pair_step', 'remd_test_coulomb_table',
     'remd_comm_unique_id', 'remd_comm_init', 'remd_comm_all_gather_energies', 'remd_comm_finalize',
 ]
 
@@ -122,6 +122,7 @@ def load_library(path=None):
     lib.remd_profile_filter.argtypes = [vp, C.c_char_p]
     lib.remd_roof_microbench.argtypes = [vp, c_double_p, c_double_p, c_double_p]
     lib.remd_roof_clock_ghz.argtypes = [vp, c_double_p]
+    lib.remd_roof_pair_step.argtypes = [vp, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p]
     lib.remd_test_coulomb_table.argtypes = [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     for name in EXPORTS:
         if name not in ('remd_last_error',):
@@ -465,6 +466,12 @@ class HipEngine:
             out['shader_clock_ghz_under_fma_load'] = g.value
             out['fma_f32_peak_at_that_clock_tflop_per_s'] = 157.3 * g.value / 2.4
         return out
+
+    def roof_pair_step(self, waves_per_simd, chains=1, ghz=2.4):
+        """(cycles per cluster-pair step per SIMD at `ghz`, microseconds of the launch): the pair kernel's step replayed from registers."""
+        c, us = C.c_double(), C.c_double()
+        self._check(self.lib.remd_roof_pair_step(self.h, int(waves_per_simd), int(chains), float(ghz), C.byref(c), C.byref(us)), 'remd_roof_pair_step')
+        return c.value, us.value
 
     def profile_enable(self, on=1, kernel_class=None):
         if kernel_class is not None:

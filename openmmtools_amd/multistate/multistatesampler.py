@@ -1070,11 +1070,15 @@ class MultiStateSampler:
                 self._device_rows = torch.empty((self._r_count, Kt), dtype=torch.float64, device=dev)
                 self._device_ukl = torch.empty((self.n_replicas, Kt), dtype=torch.float64, device=dev)
             eng.compute_energies(d_rows=self._device_rows.data_ptr(), want_host=False)
+            t_gather = time.time()                          # (compute_energies returns synchronised: what follows is the collective)
             self._comm.all_gather_rows(self._device_rows, self.n_replicas, out=self._device_ukl)
             torch.cuda.synchronize(self._device_ukl.device)
+            self._timing_data['allgather_seconds'] = time.time() - t_gather
             return self._device_ukl.cpu().numpy()
         rows = torch.from_numpy(np.ascontiguousarray(eng.compute_energies()))
+        t_gather = time.time()
         full = self._comm.all_gather_rows(rows, self.n_replicas)
+        self._timing_data['allgather_seconds'] = time.time() - t_gather
         self._host_ukl_full = full.numpy()
         return self._host_ukl_full
 

@@ -1671,6 +1671,7 @@ int remd_roof_microbench(remd_handle h, double* a, double* b, double* c)
     return fail(h, -3, "libremd_cpu: the roof microbenchmarks are GPU measurements (not implemented on the CPU)");
 }
 int remd_roof_clock_ghz(remd_handle h, double*) { return fail(h, -3, "remd_roof_clock_ghz: GPU-only microbenchmark"); }
+int remd_roof_pair_step(remd_handle h, int, int, double, double*, double*) { return fail(h, -3, "remd_roof_pair_step: GPU-only microbenchmark"); }
 
 /* CPU-library extension used by bench.py's cpu_baseline leg: threads OpenMP will use over replicas */
 int remd_cpu_num_threads(void)
