@@ -2041,12 +2041,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
                 h->mesh_listed_total = total;
                 listed_rode = total > 0;
             }
-            // (the plane pass publishes "started" for the pair kernel to wait for: only where a fused plane pass exists it is consumed)
-            const bool pair_after_xy = !h->sync_events && (getenv("REMD_PAIR_AFTER_XY") ? atoi(getenv("REMD_PAIR_AFTER_XY")) != 0 : h->pair_after_xy > 0);
-            h->xy_started_seq = pair_after_xy ? h->sync_seq : 0u;
             rc0 = remd_pme_forces(h, with_energy, h->stream, 1);        // everything up to the inverse z transform + gather
-            h->pair_wait_seq = (pair_after_xy && h->xy_started_seq == 0u) ? h->sync_seq : 0u;     // (consumed = a fused plane pass was launched)
-            h->xy_started_seq = 0u;
             if (rc0) return rc0;
             std::swap(h->stream, h->stream2);
             swapped = true; forked = true;
@@ -2104,10 +2099,6 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         h->fold_pending = fold_env && listed_main && merged && h->defer_join_ok && do_nb && (class_mask & 63u) == 63u && t.sorting && t.clusters &&
                           t.lj_split && t.d_lj_sci_list && t.d_sci_list && h->profiling != 2;
         h->fold.done = nullptr;                  // (launch_nb fills remd_fold_args where it takes the request)
-        if (do_nb && forked && h->pair_wait_seq) {
-            hipLaunchKernelGGL(remd_spin_wait_kernel, dim3(1), dim3(64), 0, h->stream, h->d_sync + 3, h->pair_wait_seq, h->d_sync + 2);
-            h->pair_wait_seq = 0u;
-        }
         if (do_nb) {
             remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {

@@ -618,14 +618,9 @@ void pme_xy_fused_kernel(fft_plan plx, fft_plan ply, fft_sched scx, fft_sched sc
                          const float2* twx, const float2* twy,
                          const float* __restrict__ bmx, const float* __restrict__ bmy, const float* __restrict__ bmz,
                          const float* __restrict__ box, float alpha, int with_energy, double* __restrict__ energy, int n_eblk,
-                         const float* __restrict__ infl, int infl_rep, unsigned int* started_flag, unsigned int started_seq)
+                         const float* __restrict__ infl, int infl_rep)
 {
     if (plx.prio) __builtin_amdgcn_s_setprio(PME_PRIO);    // the critical path of the two streams wins issue arbitration (forces.hip: the tuner)
-    // remd_ctx::pair_after_xy: the direct-space stream holds its pair kernel back until this pass has STARTED (d_sync[3]): plane
-    // workgroups dispatched behind an already resident pair kernel starve -- a plane workgroup needs several pair workgroups of one
-    // CU to retire together, and each retiring one is replaced by the next pair workgroup first (profiles/r05_2_*)
-    if (started_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-        __hip_atomic_store(started_flag, started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nx = plx.n, ny = ply.n, nzc = nz / 2 + 1;
     const int np = nx * ny;
@@ -1158,9 +1153,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
             remd_prof_scope pxy(h, "pme_xy", st);
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
-                               (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl, s->infl_rep,
-                               h->xy_started_seq ? h->d_sync + 3 : (unsigned int*)nullptr, h->xy_started_seq);
-            h->xy_started_seq = 0;
+                               (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl, s->infl_rep);
         } else if (s->xs_sw > 0) {
             // spec layout [kz][x][y]: y passes on contiguous lines, then the fused x pass on LDS-resident y slabs
             const size_t ylds = sizeof(float2) * ((size_t)s->ys_sh * (ny | 1) + ny + 2);

@@ -196,8 +196,6 @@ struct remd_ctx {
     // remd_run_steps: the launch that follows a force evaluation on the main stream is always an integrator chain, so the
     // join is polled in that kernel's prologue (join_deferred = sequence number to wait for) instead of a kernel of its own
     bool defer_join_ok = false; unsigned int join_deferred = 0;
-    // REMD_PAIR_AFTER_XY: the pair kernel waits (a second one-wavefront poll, d_sync[3]) until the mesh stream's plane pass has started
-    unsigned int xy_started_seq = 0, pair_wait_seq = 0; int pair_after_xy = -1;
     listed_tables mesh_listed{}; int mesh_listed_total = 0;   // listed terms to ride in the next spreading launch (0: none)
     remd_fold_args fold; bool fold_pending = false;      // the next chain launch polls the scatter's done counter instead of a join flag (forces.hip)
     bool mesh_prio_hi = true;          // which of the two streams' kernels run at raised wave priority (forces.hip: chosen with the pair-kernel residency)
