@@ -105,6 +105,7 @@ struct nb_tables {
     // Ewald direct-space force table of the force-only pair kernels (coulomb_table.h); REMD_NB_TABLE=0: Abramowitz & Stegun erfc
     float4* d_ctab = nullptr; bool use_table = false;
     unsigned int* d_pair_done = nullptr; unsigned int pair_done_target = 0;      // remd_fold_args: the scatter launch's done counter
+    int* d_tile_of_rank = nullptr;        // [R][ntile] the main system's tiles by descending list length, refreshed with the molecule order
     int* d_sort_scratch = nullptr; size_t sort_scratch_n = 0;                    // sort_groups_large_kernel (more than 8191 molecules)
 };
 static handle_table<nb_tables> g_nb;
@@ -635,6 +636,20 @@ void build_sci_list_body(int T, int r, int lane, int ncl, int cap, float rc2, co
     if (lane == 0) count[(size_t)r * ntile + T] = n;      // n > cap is detected on the host side (fallback)
 }
 
+// tiles of every replica by descending list length (ties: ascending tile index): tile_of_rank[r][k] = the tile with the k-th longest list
+__global__ __launch_bounds__(256)
+void rank_tiles_kernel(int ntile, const int* __restrict__ count, int* __restrict__ tile_of_rank)
+{
+    const int r = blockIdx.y;
+    const int* c = count + (size_t)r * ntile;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < ntile; t += gridDim.x * 256) {
+        const int mine = c[t];
+        int rank = 0;
+        for (int q = 0; q < ntile; ++q) { const int o = c[q]; rank += (o > mine || (o == mine && q < t)) ? 1 : 0; }
+        tile_of_rank[(size_t)r * ntile + rank] = t;
+    }
+}
+
 __global__ __launch_bounds__(64)
 void build_sci_list_kernel(int ncl, int cap, float rc2, const float4* __restrict__ cl_c, const float4* __restrict__ cl_h,
                            const float4* __restrict__ tile_c, const float4* __restrict__ tile_h,
@@ -711,6 +726,7 @@ struct sci_args {
     const float4* spos; const float4* sparam; const unsigned long long* excl; const unsigned int* list; const int* count;
     long long* force;
     const float4* sposi;        // positions as 32-bit box fractions + charge (gather_positions_body), or NULL
+    const int* tile_of_rank;    // [R][ntile] tiles of a replica by descending list length (rank_tiles_kernel), or NULL: item order = tile order
 };
 #define SCI_EWALD(M) ((M) == NB_EWALD || (M) == NB_EWALD_NOLJ)
 // A/B switches of the round-4 pair-kernel changes (tools/build_variant.sh -DSCI_...=0)
@@ -749,7 +765,18 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
     const int* __restrict__ count = a.count; long long* __restrict__ force = a.force;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntile = ncl >> 3;
-    const int T = item % ntile, r = (item / ntile) % R, zsl = (item / (ntile * R)) * NW + wv;
+    // work items are dispatched in index order and a tile's list is up to twice the average length: with the tiles in list-length
+    // order (longest first, all replicas' longest before anybody's second) the long items start at the front of the launch and the
+    // short ones fill its tail, instead of a long item that starts in the last round setting the duration of the launch
+    int T, r, zsl;
+    if (a.tile_of_rank) {
+        const int nzg = nsplit / NW, per_rank = R * nzg;
+        const int k = item / per_rank, rem = item - k * per_rank;
+        r = rem / nzg; zsl = (rem - r * nzg) * NW + wv;
+        T = a.tile_of_rank[(size_t)r * ntile + k];
+    } else {
+        T = item % ntile; r = (item / ntile) % R; zsl = (item / (ntile * R)) * NW + wv;
+    }
     const int ii = SCI_LANE_II(lane), jj = SCI_LANE_JJ(lane);
     // force-only Coulomb-only kernel: positions as integer box fractions (sci_args::sposi), minimum image by wrap-around
     // (INTPOS: the caller also has integer positions for a system that keeps its parameter loads -- the LJ sub-system of a split launch)
@@ -1349,6 +1376,7 @@ void remd_free_nonbonded(remd_ctx* h)
     dfree(t.d_lj_ord); dfree(t.d_lj_mask); dfree(t.d_lj_order); dfree(t.d_lj_spos); dfree(t.d_lj_sparam); dfree(t.d_lj_smask);
     dfree(t.d_lj_tile_c); dfree(t.d_lj_tile_h); dfree(t.d_lj_cl_c); dfree(t.d_lj_cl_h);
     dfree(t.d_sci_list); dfree(t.d_sci_count); dfree(t.d_excl); dfree(t.d_lj_sci_list); dfree(t.d_lj_sci_count); dfree(t.d_lj_excl);
+    dfree(t.d_tile_of_rank);
     dfree(t.d_sforce); dfree(t.d_lj_sforce); dfree(t.d_queue); dfree(t.d_ctab); dfree(t.d_pair_done); dfree(t.d_sort_scratch);
     for (auto& sg : t.tune_segs) { if (sg.a) hipEventDestroy(sg.a); if (sg.b) hipEventDestroy(sg.b); }
     g_nb.erase(h);
@@ -1672,6 +1700,8 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
             t.excl_W = 4 * t.p.excl_words + 1;
             REMD_CHECK(h, hipMalloc(&t.d_sci_list, sizeof(unsigned int) * (size_t)h->R * ntile * t.cl_cap));
             REMD_CHECK(h, hipMalloc(&t.d_sci_count, sizeof(int) * (size_t)h->R * ntile));
+            dfree(t.d_tile_of_rank);
+            REMD_CHECK(h, hipMalloc(&t.d_tile_of_rank, sizeof(int) * (size_t)h->R * ntile));
             REMD_CHECK(h, hipMalloc(&t.d_excl, sizeof(unsigned long long) * (size_t)h->R * ncl * t.excl_W));
             REMD_CHECK(h, hipMalloc(&t.d_sforce, sizeof(long long) * n * 3));
             REMD_CHECK(h, hipMemsetAsync(t.d_sforce, 0, sizeof(long long) * n * 3, h->stream));
@@ -1752,6 +1782,10 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         // profiles/r04_r_fused_list_v2.txt)
         hipLaunchKernelGGL(gather_positions2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, ga, gb, h->Npad, h->d_pos, h->d_box);
         hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb, rc2_main, t.p.rc2, h->d_box);
+        // (the list lengths of the evaluation that re-sorted the molecules order the work items until the next re-sort: the geometry
+        // of a tile changes slowly; REMD_NB_RANK=0: tile order)
+        if (t.evals_since_sort == 1 && t.d_tile_of_rank)
+            hipLaunchKernelGGL(rank_tiles_kernel, dim3((ntile + 255) / 256, h->R), dim3(256), 0, h->stream, ntile, t.d_sci_count, t.d_tile_of_rank);
     } else {
         hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, h->Npad, t.d_order, h->d_pos, h->d_box,
                            t.d_spos, t.d_tile_c, t.d_tile_h, cl ? t.d_cl_c : (float4*)nullptr, cl ? t.d_cl_h : (float4*)nullptr);
@@ -1790,14 +1824,18 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
         const bool split = t.lj_split && t.d_lj_sci_list && (METHOD == NB_EWALD || METHOD == NB_RF);
         constexpr int MAIN = (METHOD == NB_EWALD) ? NB_EWALD_NOLJ : (METHOD == NB_RF) ? NB_RF_NOLJ : METHOD;
         const int ssplit = std::max(SCI_NW, std::min(16, t.sci_split / SCI_NW * SCI_NW));
+        // (measured, profiles/r05_7_*: -1.2 % of a step on 8 x host-guest (71 tiles) and 16 x DHFR (369 tiles), +1 % on 24 x alanine dipeptide
+        // (36 tiles: its launch is two rounds of the chip whatever the order) -- so from 64 tiles on; REMD_NB_RANK = 0 / 1 pins it)
+        static const int rank_env = getenv("REMD_NB_RANK") ? atoi(getenv("REMD_NB_RANK")) : -1;
+        const bool ranked = (rank_env < 0 ? ntile >= 64 : rank_env != 0) && t.lj_split && t.d_lj_sci_list && t.d_tile_of_rank && (METHOD == NB_EWALD || METHOD == NB_RF);
         sci_args sa{h->N, h->Npad, ncl, t.cl_cap, t.excl_W, h->Npad, 0, ssplit, t.d_spos, t.d_sparam, t.d_excl, t.d_sci_list, t.d_sci_count, t.d_sforce,
-                    t.d_sposi};
+                    t.d_sposi, ranked ? t.d_tile_of_rank : (const int*)nullptr};
         const int items_a = ntile * h->R * (ssplit / SCI_NW);
         if (split) {
             // one launch for both systems, one scatter for both sorted accumulators; the launch is either one workgroup per
             // work item or a resident set pulling items from a queue (t.nb_grid, chosen by timing: remd_nb_tune_step)
             sci_args sb{t.NL, t.NLpad, t.NLpad / 8, t.lj_cap, t.lj_excl_W, t.NLpad, ncl * 4, ssplit, t.d_lj_spos, t.d_lj_sparam, t.d_lj_excl,
-                        t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce, t.d_lj_sposi};
+                        t.d_lj_sci_list, t.d_lj_sci_count, t.d_lj_sforce, t.d_lj_sposi, nullptr};
             const int items = items_a + (t.NLpad / 64) * h->R * (ssplit / SCI_NW);
             const int env_grid = getenv("REMD_NB_PERSIST_GRID") ? atoi(getenv("REMD_NB_PERSIST_GRID")) : -1;
             const int persist_grid = env_grid >= 0 ? env_grid : t.nb_grid;
