@@ -750,6 +750,9 @@ struct sci_args {
 #ifndef SCI_TABIDX
 #define SCI_TABIDX 1
 #endif
+#ifndef SCI_DPP_ASM
+#define SCI_DPP_ASM 1
+#endif
 typedef float sci_v2f __attribute__((ext_vector_type(2)));
 template <int METHOD, bool ENERGY, bool ALCH, int NW, bool TABLE = false, bool INTPOS = false>
 __device__ __forceinline__
@@ -935,7 +938,24 @@ void nonbonded_sci_body(const nb_params& p, const sci_args& a, int item, const f
             if (SCI_PKACC) { fjx = fjxy.x; fjy = fjxy.y; }
             if (touched) {
                 // reaction on the j atoms: all-reduce over the 8 ii lanes (every lane ends up with the total of its jj)
-                if (SCI_LANES_IJ) {
+                if (SCI_LANES_IJ && SCI_DPP_ASM) {
+                    // three DPP adds per component inside groups of 8 lanes, written out: left to the compiler the x / y pair stays a
+                    // packed value (register copies + v_mov_b32_dpp + v_pk_add_f32: ~21 instructions per entry instead of these 9).
+                    // (a DPP operand must not be read within two instructions of the VALU write that produced it: the leading s_nop
+                    // covers the accumulators written just before, and inside the block every value is read two instructions after
+                    // its own update)
+                    asm("s_nop 1\n\t"
+                        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf"
+                        : "+v"(fjx), "+v"(fjy), "+v"(fjz));
+                } else if (SCI_LANES_IJ) {
                     fjx = allsum_low8(fjx); fjy = allsum_low8(fjy); fjz = allsum_low8(fjz);
                 } else {
                     fjx = allsum_x8(fjx); fjy = allsum_x8(fjy); fjz = allsum_x8(fjz);
