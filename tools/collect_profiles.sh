@@ -2,17 +2,20 @@
 # usage (on the GPU box, repo root): tools/collect_profiles.sh <tag>
 # Produces under gpurun_out/<tag>/: the default bench line, the rocprofv3 kernel-trace stats of the same command, and
 # the HBM-side traffic counters (separate --pmc passes, never combined with other traces).
+# (round 5: the profiled command is the default one WITHOUT the extra ensemble shapes and the CPU leg -- `--no-shapes --no-cpu-baseline` --
+# so that a kernel's average is the headline configuration's; roofline.avg_launch_ms of the bench line is measured inside the timed
+# region of the headline configuration whatever runs afterwards)
 tag=${1:-r01_x}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 out=$ROOT/gpurun_out/$tag
 mkdir -p $out
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
-(cd /tmp && rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $ROOT/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> /dev/null)
+(cd /tmp && rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $ROOT/bench.py --no-cpu-baseline --no-shapes > $out/bench_under_rocprof.json 2> /dev/null)
 python tools/rocpd_stats.py $(find /tmp/prof_kt -name "*.db" | head -1) $out/kernel_stats.md > /dev/null
 dbs=""
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rm -rf /tmp/prof_$c && rocprofv3 --pmc $c -d /tmp/prof_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 0 --md-steps 50 --no-cpu-baseline > /dev/null 2>&1)
+  (cd /tmp && rm -rf /tmp/prof_$c && rocprofv3 --pmc $c -d /tmp/prof_$c -o pmc -- python $ROOT/bench.py --steps 1 --warmup 0 --md-steps 50 --no-cpu-baseline --no-shapes > /dev/null 2>&1)
   dbs="$dbs $(find /tmp/prof_$c -name "*.db" | head -1)"
 done
 python tools/rocpd_pmc.py $dbs --md $out/pmc_traffic.md --json $out/pmc_traffic.json > /dev/null
