@@ -150,9 +150,15 @@ class EnginePool:
                 continue
             eng = self._propagator(g)
             slots = np.arange(len(idx))
-            if boxes is None:
-                boxes = self._master.get_boxes()                     # (3 numbers per replica: only to size the handle)
-            eng.set_replicas(len(idx), 0, None, None, boxes[idx], loc[idx])
+            if getattr(eng, '_pool_size', None) == len(idx) and hasattr(eng, 'set_labels'):
+                # the handle already holds this many replicas: labels only (no host-built lattice, no upload, no re-allocation of
+                # the mesh buffers) -- the coordinates and boxes follow device to device below
+                eng.set_labels(loc[idx])
+            else:
+                if boxes is None:
+                    boxes = self._master.get_boxes()                 # (3 numbers per replica: only to size the handle)
+                eng.set_replicas(len(idx), 0, None, None, boxes[idx], loc[idx])
+                eng._pool_size = len(idx)
             eng.copy_replicas(slots, self._master, idx, 7)           # positions, velocities, boxes: device to device
             eng.set_replica_ids(self.r_begin + idx)                  # noise keyed by the global replica index, whatever the grouping
             if hasattr(eng, 'reset_work'):

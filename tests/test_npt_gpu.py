@@ -275,3 +275,23 @@ def test_barostat_attempts_outside_the_integrator_track_the_oracle(hip_engine_fa
     nvt.set_replicas(R, 0, x, None, np.tile(np.diag(lj.system.getDefaultPeriodicBoxVectors()), (R, 1)), np.arange(R))
     with pytest.raises(RuntimeError):
         nvt.barostat_attempts(1)
+
+
+def test_a_box_below_twice_the_cutoff_is_an_error_not_a_broken_minimum_image(hip_engine_factory):
+    """an ideal gas under a pressure whose equilibrium volume is (1.5 nm)^3 shrinks towards a box of 1.5 nm, the cutoff is
+    1.02 nm.  The Monte Carlo barostat must never ACCEPT a trial box with an edge below twice the cutoff (its energy was evaluated with a
+    broken minimum image) and the propagation that proposed it fails the way OpenMM's does ("... less than twice the nonbonded cutoff");
+    every box the handle ever held stays legal."""
+    N, T = 64, 300.0
+    lj = ts.LennardJonesFluid(nparticles=N, epsilon=0.0)
+    cutoff = 1.02
+    p = (N + 1) * KB * T / 1.5 ** 3
+    R = 4
+    eng = hip_engine_factory()
+    _setup(eng, lj.system, np.tile(lj.positions, (R, 1, 1)), [T] * R, p, 25, dt=0.001)
+    assert np.all(eng.get_boxes() >= 2.0 * cutoff)
+    with pytest.raises(RuntimeError, match='twice the nonbonded cutoff'):
+        for it in range(3000):
+            eng.propagate(it)
+            assert np.all(eng.get_boxes() >= 2.0 * cutoff)
+    assert np.all(eng.get_boxes() >= 2.0 * cutoff)
