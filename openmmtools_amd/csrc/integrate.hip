@@ -298,7 +298,8 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
             constrain_v<TYPE, NAT>(sc, im, tol, v, x);
         } else if (tok == 'R') {
             if (TYPE == UNIT_FREE) {
-                x[0] = x[0] + v[0] * prog.hR;
+#pragma unroll
+                for (int k = 0; k < NAT; ++k) x[k] = x[k] + v[k] * prog.hR;
             } else {
                 // relative coordinates (origin = old position of atom 0) keep fp32 precision
                 float3 p0[NAT], p1[NAT], q[NAT];
@@ -453,7 +454,7 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         if (active) {
 #define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, bins, r, S, t0, t1, first, last, xold ? xold + (size_t)r * Npad : nullptr, vold ? vold + (size_t)r * Npad : nullptr)
             if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
-            else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
+            else if (type == UNIT_FREE) { if (a4.y < 0) RUN(UNIT_FREE, 1); else RUN(UNIT_FREE, 4); }
             else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
             else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
             else RUN(UNIT_SHAKE, 4);
@@ -565,7 +566,8 @@ void assign_velocities_kernel(int n_units, const int4* __restrict__ unit_atoms,
     const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
     const uint32_t rg = noise_id ? noise_id[r] : (uint32_t)(r_begin + r);
     if (type == UNIT_SETTLE) assign_unit<UNIT_SETTLE, 3>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
-    else if (type == UNIT_FREE) assign_unit<UNIT_FREE, 1>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
+    else if (type == UNIT_FREE) { if (a4.y < 0) assign_unit<UNIT_FREE, 1>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
+                                  else assign_unit<UNIT_FREE, 4>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration); }
     else if (a4.z < 0) assign_unit<UNIT_SHAKE, 2>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
     else if (a4.w < 0) assign_unit<UNIT_SHAKE, 3>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
     else assign_unit<UNIT_SHAKE, 4>(idx, sc, tol, P, V, invmass, kT, rg, seed, iteration);
@@ -634,9 +636,21 @@ int remd_build_constraints(remd_ctx* h, const remd_system_desc* d)
         while (atoms.size() % 64) { atoms.push_back(make_int4(-1, -1, -1, -1)); type.push_back(ty); dist.push_back(0); dist.push_back(0); dist.push_back(0); }
     };
     pad64(UNIT_SHAKE);
-    for (int i = 0; i < N; ++i) if (!used[i]) {
-        atoms.push_back(make_int4(i, -1, -1, -1)); type.push_back(UNIT_FREE);
-        dist.push_back(0); dist.push_back(0); dist.push_back(0);
+    // unconstrained atoms: FOUR to a unit while they last, the remainder one each (a unit = a thread; on DHFR -- 7023 waters, 790 X-H
+    // clusters, 464 free atoms -- single-atom units made 8336 units = 33 workgroups per replica, and at one workgroup per CU (this
+    // kernel's registers) 16 x 33 = 528 workgroups are THREE rounds of the chip; four to a unit: 7988 units = 32 workgroups, 512 = two rounds)
+    {
+        std::vector<int> fr;
+        for (int i = 0; i < N; ++i) if (!used[i]) fr.push_back(i);
+        size_t q = 0;
+        for (; q + 4 <= fr.size(); q += 4) {
+            atoms.push_back(make_int4(fr[q], fr[q + 1], fr[q + 2], fr[q + 3])); type.push_back(UNIT_FREE);
+            dist.push_back(0); dist.push_back(0); dist.push_back(0);
+        }
+        for (; q < fr.size(); ++q) {
+            atoms.push_back(make_int4(fr[q], -1, -1, -1)); type.push_back(UNIT_FREE);
+            dist.push_back(0); dist.push_back(0); dist.push_back(0);
+        }
     }
     ut.n_units = (int)atoms.size();
     REMD_CHECK(h, hipMalloc(&ut.d_atoms, sizeof(int4) * ut.n_units));
@@ -1343,7 +1357,8 @@ __device__ __forceinline__ void fire_move_unit(const int* idx, const float* dist
         v[k].x += s * (float)fx; v[k].y += s * (float)fy; v[k].z += s * (float)fz;
     }
     if (TYPE == UNIT_FREE) {
-        x[0] = x[0] + v[0] * dt;
+#pragma unroll
+        for (int k = 0; k < NAT; ++k) x[k] = x[k] + v[k] * dt;
     } else {
         float3 p0[NAT], p1[NAT], q[NAT];
 #pragma unroll
@@ -1381,7 +1396,7 @@ void fire_move_kernel(int n_units, const int4* __restrict__ unit_atoms, const un
     const size_t o = (size_t)r * Npad, of = (size_t)r * 3 * Npad;
 #define RUN(TY, NA) fire_move_unit<TY, NA>(idx, dist, sc, tol, Npad, pos + o, vel + o, force + of, x0 + o, v0 + o, f0 + of, invmass, s.dt)
     if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
-    else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
+    else if (type == UNIT_FREE) { if (a4.y < 0) RUN(UNIT_FREE, 1); else RUN(UNIT_FREE, 4); }
     else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
     else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
     else RUN(UNIT_SHAKE, 4);
@@ -1430,7 +1445,7 @@ void fire_finish_kernel(int n_units, const int4* __restrict__ unit_atoms, const 
         const size_t o = (size_t)r * Npad, of = (size_t)r * 3 * Npad;
 #define RUN(TY, NA) fire_finish_unit<TY, NA>(idx, sc, tol, Npad, pos + o, vel + o, force + of, invmass, s.dt, kick != 0, sums)
         if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
-        else if (type == UNIT_FREE) RUN(UNIT_FREE, 1);
+        else if (type == UNIT_FREE) { if (a4.y < 0) RUN(UNIT_FREE, 1); else RUN(UNIT_FREE, 4); }
         else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
         else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
         else RUN(UNIT_SHAKE, 4);
