@@ -375,8 +375,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
     return mom;
 }
 
-__global__ __launch_bounds__(256)
-void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict__ unit_atoms,
+__device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_units, const int4* __restrict__ unit_atoms,
                             const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist,
                             settle_const sc, float tol,
                             int Npad, float4* __restrict__ pos, float4* __restrict__ vel,
@@ -523,6 +522,17 @@ void integrate_chain_kernel(chain_prog prog, int n_units, const int4* __restrict
         atomicAdd(&own_time[1], 1ull);
     }
 }
+
+// Two compilations of the same body.  The integrator's working set under the widest unit type is 256 VGPRs + AGPRs = one wavefront per
+// SIMD, one workgroup per CU; a grid larger than the chip then runs in rounds (DHFR x 16: 512 workgroups).  The second compilation is held
+// to two wavefronts per SIMD (256 registers in all: the four-atom X-H path spills, the water path -- 238 -- does not) and takes such grids
+// in one round.
+#define CHAIN_PARAMS chain_prog prog, int n_units, const int4* __restrict__ unit_atoms, const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist, settle_const sc, float tol, int Npad, float4* __restrict__ pos, float4* __restrict__ vel, long long* force, const float* __restrict__ invmass, const int64_t* __restrict__ labels, const double* __restrict__ beta, int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins, unsigned int* chain_sync, unsigned int* chain_sync_err, unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold, remd_fold_args fold, const unsigned int* __restrict__ noise_id
+#define CHAIN_ARGS prog, n_units, unit_atoms, unit_type, shake_dist, sc, tol, Npad, pos, vel, force, invmass, labels, beta, r_begin, seed, cmm, inv_total_mass, join_flag, join_seq, bins, chain_sync, chain_sync_err, own_time, work, xold, vold, fold, noise_id
+__global__ __launch_bounds__(256)
+void integrate_chain_kernel(CHAIN_PARAMS) { integrate_chain_body(CHAIN_ARGS); }
+__global__ __launch_bounds__(256, 2)
+void integrate_chain2_kernel(CHAIN_PARAMS) { integrate_chain_body(CHAIN_ARGS); }
 
 // Maxwell-Boltzmann velocities (mcmc.py:710-711): v = sqrt(kT/m) xi, then velocity constraints.
 template <int TYPE, int NAT>
@@ -748,7 +758,13 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
     const remd_chain_bins bins = bin_for_pme ? remd_pme_chain_bins(h) : remd_chain_bins();
     remd_prof_scope ps(h, "integrate_chain");
     dim3 grid((ut.n_units + 255) / 256, h->R);
-    hipLaunchKernelGGL(integrate_chain_kernel, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
+    // more workgroups than CUs: the two-per-CU compilation (REMD_CHAIN_TWO=0/1 pins the choice)
+    static const char* two_env = getenv("REMD_CHAIN_TWO");
+    static int n_cu = 0;
+    if (!n_cu) { hipDeviceProp_t prop; n_cu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256; }
+    const bool two = two_env ? atoi(two_env) != 0 : (int)(grid.x * grid.y) > n_cu;
+    auto kern = two ? integrate_chain2_kernel : integrate_chain_kernel;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0),

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from openmmtools_amd._engine import HipEngine
-eng = HipEngine(); eng.seed(0xC0FFEE)
+eng = HipEngine(lib_path=os.environ.get("AB_LIB") or None); eng.seed(0xC0FFEE)
 rng = np.random.default_rng(0)
 kind = os.environ.get('MIX_MATRIX', 'pt')      # 'pt': parallel-tempering-like (few % acceptance); 'hot': ~50 % acceptance
 # MIX_SET_BETA=1: the states' beta on the handle (remd_set_states), as a sampler has them: the rendezvous kernel may then take the
