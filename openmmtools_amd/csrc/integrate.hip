@@ -43,6 +43,7 @@ struct chain_prog {
 
 // state of one constraint unit between the segments of a chain (registers)
 struct unit_regs { float3 x[4], v[4]; float im[4]; float heat, shadow;
+    float cmx, cmy, cmz; int have_cm;        // centre-of-mass velocity from an 'M' token of this launch, for the 'C' that follows it
 #ifdef CHAIN_STAMPS
     unsigned long long* stamps; unsigned long long t_last;     // tools/chain_segments.py: per-token wall-clock of workgroup (0, 0)
 #endif
@@ -334,9 +335,13 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
         } else if (tok == 'C') {
             // CMMotionRemover: v -= P/M with P accumulated by the previous chain or by the 'M' token in front (read at the
             // coherence point: other workgroups added to it by atomics during this launch)
-            const float sx = (float)__hip_atomic_load(&cmm_r[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
-            const float sy = (float)__hip_atomic_load(&cmm_r[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
-            const float sz = (float)__hip_atomic_load(&cmm_r[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
+            float sx, sy, sz;
+            if (S.have_cm) { sx = S.cmx; sy = S.cmy; sz = S.cmz; }
+            else {
+                sx = (float)__hip_atomic_load(&cmm_r[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
+                sy = (float)__hip_atomic_load(&cmm_r[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
+                sz = (float)__hip_atomic_load(&cmm_r[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0f / 4294967296.0f) * inv_total_mass;
+            }
 #pragma unroll
             for (int k = 0; k < NAT; ++k) { v[k].x -= sx; v[k].y -= sy; v[k].z -= sz; }
         }
@@ -383,7 +388,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
                             const int64_t* __restrict__ labels, const double* __restrict__ beta,
                             int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass,
                             unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins,
-                            unsigned int* chain_sync, unsigned int* chain_sync_err,
+                            unsigned long long* chain_slots, unsigned int* chain_sync_err,
                             unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold,
                             remd_fold_args fold, const unsigned int* __restrict__ noise_id)
 {
@@ -441,6 +446,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
     const uint32_t rg = noise_id ? noise_id[r] : (uint32_t)(r_begin + r);
     const long long* cr = cmm + ((size_t)max(cmm_r_eff, 0) * gridDim.y + r) * 4;
     unit_regs S;
+    S.have_cm = 0;
 #ifdef CHAIN_STAMPS
     S.stamps = (own_time && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? own_time + 2 : nullptr;
     S.t_last = own_t0;
@@ -461,8 +467,15 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
         }
         if (last) break;
         {
-            // 'M': sum(m v) of the velocities as they are now into buffer m_buf; every workgroup of this replica arrives at a
-            // counter in device memory and waits for the others (all of them are resident: the launcher checks the grid size)
+            // 'M': sum(m v) of the velocities as they are now, over all workgroups of this replica (all of them are resident: the launcher
+            // checks the grid size).  One exchange through device memory: a workgroup publishes its three fixed-point partial sums as
+            // 64-bit words that carry the epoch of this barrier in their low 16 bits (48-bit payload), in the epoch's parity half of
+            // chain_slots [2][replica][workgroup][3]; every workgroup then reads all words of its replica, spinning on a word until its
+            // tag is this epoch's.  A word is rewritten two epochs later, which its writer cannot reach before every reader has published
+            // the epoch in between, i.e. is done with this one.  (Before: atomics into one accumulator + an arrival counter + a read-back
+            // = three dependent round trips, 5.1 us of the headline step's 27 us chain; the sum is the same integer.)
+            __shared__ long long s_pm[4][3];
+            __shared__ unsigned long long s_tot[3];
             float3 pm = f3(0, 0, 0);
             if (active) {
 #pragma unroll
@@ -472,23 +485,38 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
                 pm.x += __shfl_xor(pm.x, off); pm.y += __shfl_xor(pm.y, off); pm.z += __shfl_xor(pm.z, off);
             }
             if ((threadIdx.x & 63) == 0) {
-                unsigned long long* c = reinterpret_cast<unsigned long long*>(cmm + ((size_t)prog.m_buf * gridDim.y + r) * 4);
-                atomicAdd(&c[0], (unsigned long long)(long long)((double)pm.x * 4294967296.0));
-                atomicAdd(&c[1], (unsigned long long)(long long)((double)pm.y * 4294967296.0));
-                atomicAdd(&c[2], (unsigned long long)(long long)((double)pm.z * 4294967296.0));
+                long long* w = s_pm[threadIdx.x >> 6];
+                w[0] = (long long)((double)pm.x * 4294967296.0); w[1] = (long long)((double)pm.y * 4294967296.0); w[2] = (long long)((double)pm.z * 4294967296.0);
             }
-            __syncthreads();                                    // (s_waitcnt: this workgroup's atomics are acknowledged)
-            if (threadIdx.x == 0) {
-                unsigned int* arrive = chain_sync + r;
-                atomicAdd(arrive, 1u);
-                const unsigned int target = prog.m_epoch * gridDim.x;
-                long long n = 0;
-                while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++n > (1ll << 25)) { atomicExch(chain_sync_err, 3u); break; }
+            if (threadIdx.x < 3) s_tot[threadIdx.x] = 0ull;
+            __syncthreads();
+            const unsigned long long tag = (unsigned long long)(prog.m_epoch & 0xffffu);
+            unsigned long long* slots = chain_slots + ((size_t)(prog.m_epoch & 1u) * gridDim.y + r) * gridDim.x * 3;
+            if (threadIdx.x < 3) {
+                const long long t = s_pm[0][threadIdx.x] + s_pm[1][threadIdx.x] + s_pm[2][threadIdx.x] + s_pm[3][threadIdx.x];
+                if (t >= (1ll << 46) || t < -(1ll << 46)) atomicExch(chain_sync_err, 3u);       // (the host then sums with two launches)
+                __hip_atomic_store(&slots[blockIdx.x * 3 + threadIdx.x], ((unsigned long long)t << 16) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int n_words = 3 * (int)gridDim.x;
+            if (threadIdx.x < 255 && (int)threadIdx.x < n_words) {
+                long long part = 0;
+                for (int q = threadIdx.x; q < n_words; q += 255) {          // (255 = 0 mod 3: a thread stays on one component)
+                    unsigned long long w;
+                    long long n = 0;
+                    while (((w = __hip_atomic_load(&slots[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffull) != tag) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++n > (1ll << 25)) { atomicExch(chain_sync_err, 3u); break; }
+                    }
+                    part += (long long)w >> 16;
                 }
+                atomicAdd(&s_tot[threadIdx.x % 3], (unsigned long long)part);
             }
             __syncthreads();
+            S.cmx = (float)(long long)s_tot[0] * (1.0f / 4294967296.0f) * inv_total_mass;
+            S.cmy = (float)(long long)s_tot[1] * (1.0f / 4294967296.0f) * inv_total_mass;
+            S.cmz = (float)(long long)s_tot[2] * (1.0f / 4294967296.0f) * inv_total_mass;
+            S.have_cm = 1;
+            __syncthreads();                                    // (s_pm / s_tot may be written again by a second 'M' of this launch)
 #ifdef CHAIN_STAMPS
             if (S.stamps) { const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + min(t1, 33)], now - S.t_last); S.t_last = now; }
 #endif
@@ -527,8 +555,8 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
 // SIMD, one workgroup per CU; a grid larger than the chip then runs in rounds (DHFR x 16: 512 workgroups).  The second compilation is held
 // to two wavefronts per SIMD (256 registers in all: the four-atom X-H path spills, the water path -- 238 -- does not) and takes such grids
 // in one round.
-#define CHAIN_PARAMS chain_prog prog, int n_units, const int4* __restrict__ unit_atoms, const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist, settle_const sc, float tol, int Npad, float4* __restrict__ pos, float4* __restrict__ vel, long long* force, const float* __restrict__ invmass, const int64_t* __restrict__ labels, const double* __restrict__ beta, int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins, unsigned int* chain_sync, unsigned int* chain_sync_err, unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold, remd_fold_args fold, const unsigned int* __restrict__ noise_id
-#define CHAIN_ARGS prog, n_units, unit_atoms, unit_type, shake_dist, sc, tol, Npad, pos, vel, force, invmass, labels, beta, r_begin, seed, cmm, inv_total_mass, join_flag, join_seq, bins, chain_sync, chain_sync_err, own_time, work, xold, vold, fold, noise_id
+#define CHAIN_PARAMS chain_prog prog, int n_units, const int4* __restrict__ unit_atoms, const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist, settle_const sc, float tol, int Npad, float4* __restrict__ pos, float4* __restrict__ vel, long long* force, const float* __restrict__ invmass, const int64_t* __restrict__ labels, const double* __restrict__ beta, int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins, unsigned long long* chain_slots, unsigned int* chain_sync_err, unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold, remd_fold_args fold, const unsigned int* __restrict__ noise_id
+#define CHAIN_ARGS prog, n_units, unit_atoms, unit_type, shake_dist, sc, tol, Npad, pos, vel, force, invmass, labels, beta, r_begin, seed, cmm, inv_total_mass, join_flag, join_seq, bins, chain_slots, chain_sync_err, own_time, work, xold, vold, fold, noise_id
 __global__ __launch_bounds__(256)
 void integrate_chain_kernel(CHAIN_PARAMS) { integrate_chain_body(CHAIN_ARGS); }
 __global__ __launch_bounds__(256, 2)
@@ -768,7 +796,7 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0),
-                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2,
+                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, reinterpret_cast<unsigned long long*>(h->d_chain_sync), h->d_sync + 2,
                        (h->profiling == 2 || (h->profiling == 1 && h->prof_filter.find("integrate_chain") != std::string::npos)) ? h->d_chain_own : (unsigned long long*)nullptr,
                        h->d_work, h->d_xold, h->d_vold, h->fold_pending ? h->fold : remd_fold_args(), h->d_noise_id);
     h->join_deferred = 0; h->fold_pending = false;
@@ -1189,8 +1217,9 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
     if (merge_cmm && (!h->d_chain_sync || h->chain_sync_key != sync_key)) {      // counters count arrivals of THIS grid shape
         if (h->d_chain_sync) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_chain_sync); h->d_chain_sync = nullptr; }
         h->chain_sync_key = sync_key;
-        REMD_CHECK(h, hipMalloc(&h->d_chain_sync, sizeof(unsigned int) * h->R));
-        REMD_CHECK(h, hipMemsetAsync(h->d_chain_sync, 0, sizeof(unsigned int) * h->R, h->stream));
+        const size_t slot_bytes = sizeof(unsigned long long) * 2 * (size_t)h->R * (size_t)((ut.n_units + 255) / 256) * 3;   // [2][R][workgroups][3]
+        REMD_CHECK(h, hipMalloc(&h->d_chain_sync, slot_bytes));
+        REMD_CHECK(h, hipMemsetAsync(h->d_chain_sync, 0, slot_bytes, h->stream));
         h->chain_sync_epoch = 0;
     }
     auto flush = [&](bool accumulate, bool bin_for_pme = false) {      // bin_for_pme: a force evaluation follows this launch directly
