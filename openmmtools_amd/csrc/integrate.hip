@@ -41,6 +41,19 @@ struct chain_prog {
     int measure;              // bit 0: heat (kinetic-energy change of the O substeps), bit 1: kinetic part of the shadow work (V, R substeps)
 };
 
+// token t of the program, from registers: a dynamic index into the kernel-argument array is a scalar memory load per token on the
+// chain's critical path (the chain is a handful of wavefronts waiting for one thing after another: profiles/r05_15_chain_segments.txt);
+// the six words are loaded once with the other arguments
+__device__ __forceinline__ char chain_tok(const chain_prog& prog, int t)
+{
+    static_assert(MAX_TOK == 24, "six 32-bit words of tokens");
+    const unsigned int* w = reinterpret_cast<const unsigned int*>(prog.tok);
+    const unsigned int w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5];
+    const int q = t >> 2;
+    const unsigned int x = q == 0 ? w0 : q == 1 ? w1 : q == 2 ? w2 : q == 3 ? w3 : q == 4 ? w4 : w5;
+    return (char)((x >> ((t & 3) * 8)) & 0xffu);
+}
+
 // state of one constraint unit between the segments of a chain (registers)
 struct unit_regs { float3 x[4], v[4]; float im[4]; float heat, shadow;
     float cmx, cmy, cmz; int have_cm;        // centre-of-mass velocity from an 'M' token of this launch, for the 'C' that follows it
@@ -249,7 +262,7 @@ __device__ __forceinline__ float3 gaussian3(uint64_t seed, uint32_t stream, uint
 }
 
 // the whole chain of substeps for one constraint unit, everything in registers
-template <int TYPE, int NAT>
+template <int TYPE, int NAT, bool LOADS>
 __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* idx, const float* dist, const settle_const& sc,
                                           float tol, int Npad, float4* __restrict__ P, float4* __restrict__ V,
                                           const long long* F, long long* Fw, const float* __restrict__ invmass, float kT,
@@ -267,15 +280,20 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
         return ke; };
     if (first) {
         S.heat = 0.f; S.shadow = 0.f;
+        if (LOADS) {
 #pragma unroll
-        for (int k = 0; k < NAT; ++k) {
-            const float4 p = P[idx[k]], w = V[idx[k]];
-            x[k] = f3(p.x, p.y, p.z); v[k] = f3(w.x, w.y, w.z);
-            im[k] = invmass[idx[k]];
+            for (int k = 0; k < NAT; ++k) {
+                const float4 p = P[idx[k]], w = V[idx[k]];
+                x[k] = f3(p.x, p.y, p.z); v[k] = f3(w.x, w.y, w.z);
+                im[k] = invmass[idx[k]];
+            }
         }
+#ifdef CHAIN_STAMPS
+        if (S.stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + 21], now - S.t_last); S.t_last = now; }
+#endif
     }
     for (int t = t0; t < t1; ++t) {
-        const char tok = prog.tok[t];
+        const char tok = chain_tok(prog, t);
         const bool is_v = tok == 'V' || (tok >= '0' && tok <= '3');
         const float ke0 = ((prog.measure & 1) && tok == 'O') || ((prog.measure & 2) && (is_v || tok == 'R')) ? unit_ke() : 0.f;
         if (tok == '{') {
@@ -296,6 +314,9 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                 v[k].y += s * (float)Ft[Npad + idx[k]];
                 v[k].z += s * (float)Ft[2 * Npad + idx[k]];
             }
+#ifdef CHAIN_STAMPS
+            if (S.stamps && t == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + 22], now - S.t_last); S.t_last = now; }
+#endif
             constrain_v<TYPE, NAT>(sc, im, tol, v, x);
         } else if (tok == 'R') {
             if (TYPE == UNIT_FREE) {
@@ -373,6 +394,9 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                 if (bins.q) bins.q[e] = bins.param[idx[k]].x;        // (state-independent charges only, see remd_pme_chain_bins)
             } else atomicExch(bins.err, 2u);
         }
+#ifdef CHAIN_STAMPS
+        if (S.stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + 24 + k], now - S.t_last); S.t_last = now; }
+#endif
     }
 #ifdef CHAIN_STAMPS
     if (S.stamps) { const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[35], now - S.t_last); S.t_last = now; }
@@ -380,6 +404,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
     return mom;
 }
 
+template <bool EARLY>
 __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_units, const int4* __restrict__ unit_atoms,
                             const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist,
                             settle_const sc, float tol,
@@ -392,6 +417,37 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
                             unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold,
                             remd_fold_args fold, const unsigned int* __restrict__ noise_id)
 {
+    // EARLY: what does not depend on the forces travels while this workgroup waits for them (or, when they are complete already, all
+    // at once instead of table -> type -> distances and label -> beta one round trip after the other): the unit table, positions,
+    // velocities, masses, the state's temperature.  Positions and velocities are written by the previous chain launch of this stream
+    // only.  (Not in the two-per-CU compilation: the longer live ranges are 34 more spilled registers there.)
+    const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    int4 a4 = make_int4(-1, -1, -1, -1);
+    int type = UNIT_FREE;
+    float dist[3] = { 0.f, 0.f, 0.f };
+    float kT = 0.f;
+    uint32_t rg = 0u;
+    unit_regs S;
+    S.have_cm = 0;
+    if (EARLY) {
+        if (uidx < n_units) {
+            a4 = unit_atoms[uidx]; type = (int)unit_type[uidx];
+            dist[0] = shake_dist[uidx * 3]; dist[1] = shake_dist[uidx * 3 + 1]; dist[2] = shake_dist[uidx * 3 + 2];
+        }
+        kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
+        rg = noise_id ? noise_id[r] : (uint32_t)(r_begin + r);
+        const int e_idx[4] = { a4.x, a4.y, a4.z, a4.w };
+        const float4* Pe = pos + (size_t)r * Npad;
+        const float4* Ve = vel + (size_t)r * Npad;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (e_idx[k] >= 0) {
+                const float4 p = Pe[e_idx[k]], w = Ve[e_idx[k]];
+                S.x[k] = f3(p.x, p.y, p.z); S.v[k] = f3(w.x, w.y, w.z); S.im[k] = invmass[e_idx[k]];
+            }
+        }
+    }
     if (fold.done) {
         // remd_fold_args: wait until every workgroup of the direct-space stream's last launch has counted itself done (their force
         // atomics are complete by then)
@@ -423,8 +479,6 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
     // profiling: this launch's OWN time, from "forces complete" seen to the end, for workgroup (0, 0) (the launch duration a
     // profiler reports also holds the wait for the direct-space stream in the prologue)
     const unsigned long long own_t0 = own_time ? wall_clock64() : 0ull;
-    const int uidx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
     float3 mom = f3(0, 0, 0);
     const int cmm_r_eff = prog.cmm_r, cmm_w_eff = prog.cmm_w;
     if (uidx == 0 && cmm_r_eff >= 0) {
@@ -432,32 +486,35 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
         long long* o = cmm + ((size_t)(1 - cmm_r_eff) * gridDim.y + r) * 4;
         o[0] = 0; o[1] = 0; o[2] = 0;
     }
-    const int4 a4 = (uidx < n_units) ? unit_atoms[uidx] : make_int4(-1, -1, -1, -1);
+    if (!EARLY) {
+        if (uidx < n_units) a4 = unit_atoms[uidx];
+        if (a4.x >= 0) type = (int)unit_type[uidx];
+        if (a4.x >= 0 && type == UNIT_SHAKE) { dist[0] = shake_dist[uidx * 3]; dist[1] = shake_dist[uidx * 3 + 1]; dist[2] = shake_dist[uidx * 3 + 2]; }
+        kT = frcp((float)beta[labels[r_begin + r]]);
+        rg = noise_id ? noise_id[r] : (uint32_t)(r_begin + r);
+    }
     const bool active = a4.x >= 0;                              // padding units do nothing (but take part in the 'M' barrier)
+    if (!active) type = UNIT_FREE;
     const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
-    const int type = active ? unit_type[uidx] : UNIT_FREE;
-    float dist[3] = { 0.f, 0.f, 0.f };
-    if (active && type == UNIT_SHAKE) { dist[0] = shake_dist[uidx * 3]; dist[1] = shake_dist[uidx * 3 + 1]; dist[2] = shake_dist[uidx * 3 + 2]; }
     float4* P = pos + (size_t)r * Npad;
     float4* V = vel + (size_t)r * Npad;
     const long long* F = force + (size_t)r * 3 * Npad;
     long long* Fw = force + (size_t)r * 3 * Npad;
-    const float kT = frcp((float)beta[labels[r_begin + r]]);       // fp32 state: 1 ulp of kT is below its own rounding
-    const uint32_t rg = noise_id ? noise_id[r] : (uint32_t)(r_begin + r);
     const long long* cr = cmm + ((size_t)max(cmm_r_eff, 0) * gridDim.y + r) * 4;
-    unit_regs S;
-    S.have_cm = 0;
 #ifdef CHAIN_STAMPS
     S.stamps = (own_time && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? own_time + 2 : nullptr;
     S.t_last = own_t0;
 #endif
+#ifdef CHAIN_STAMPS
+    if (S.stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + 20], now - S.t_last); S.t_last = now; }
+#endif
     // segments of the token program, split at 'M' (momentum sum + barrier over the replica's workgroups)
     for (int t0 = 0;;) {
         int t1 = t0;
-        while (t1 < prog.n && prog.tok[t1] != 'M') ++t1;
+        while (t1 < prog.n && chain_tok(prog, t1) != 'M') ++t1;
         const bool first = t0 == 0, last = t1 == prog.n;
         if (active) {
-#define RUN(TY, NA) mom = run_unit<TY, NA>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, bins, r, S, t0, t1, first, last, xold ? xold + (size_t)r * Npad : nullptr, vold ? vold + (size_t)r * Npad : nullptr)
+#define RUN(TY, NA) mom = run_unit<TY, NA, !EARLY>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, bins, r, S, t0, t1, first, last, xold ? xold + (size_t)r * Npad : nullptr, vold ? vold + (size_t)r * Npad : nullptr)
             if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
             else if (type == UNIT_FREE) { if (a4.y < 0) RUN(UNIT_FREE, 1); else RUN(UNIT_FREE, 4); }
             else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
@@ -558,9 +615,9 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
 #define CHAIN_PARAMS chain_prog prog, int n_units, const int4* __restrict__ unit_atoms, const unsigned char* __restrict__ unit_type, const float* __restrict__ shake_dist, settle_const sc, float tol, int Npad, float4* __restrict__ pos, float4* __restrict__ vel, long long* force, const float* __restrict__ invmass, const int64_t* __restrict__ labels, const double* __restrict__ beta, int r_begin, uint64_t seed, long long* __restrict__ cmm, float inv_total_mass, unsigned int* join_flag, unsigned int join_seq, remd_chain_bins bins, unsigned long long* chain_slots, unsigned int* chain_sync_err, unsigned long long* own_time, long long* __restrict__ work, float4* __restrict__ xold, float4* __restrict__ vold, remd_fold_args fold, const unsigned int* __restrict__ noise_id
 #define CHAIN_ARGS prog, n_units, unit_atoms, unit_type, shake_dist, sc, tol, Npad, pos, vel, force, invmass, labels, beta, r_begin, seed, cmm, inv_total_mass, join_flag, join_seq, bins, chain_slots, chain_sync_err, own_time, work, xold, vold, fold, noise_id
 __global__ __launch_bounds__(256)
-void integrate_chain_kernel(CHAIN_PARAMS) { integrate_chain_body(CHAIN_ARGS); }
+void integrate_chain_kernel(CHAIN_PARAMS) { integrate_chain_body<true>(CHAIN_ARGS); }
 __global__ __launch_bounds__(256, 2)
-void integrate_chain2_kernel(CHAIN_PARAMS) { integrate_chain_body(CHAIN_ARGS); }
+void integrate_chain2_kernel(CHAIN_PARAMS) { integrate_chain_body<false>(CHAIN_ARGS); }
 
 // Maxwell-Boltzmann velocities (mcmc.py:710-711): v = sqrt(kT/m) xi, then velocity constraints.
 template <int TYPE, int NAT>
