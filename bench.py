@@ -67,6 +67,22 @@ def pmc_traffic_bytes(kernel):
     return None
 
 
+def pmc_traffic_is_current():
+    """The counters were collected on a build of the pair kernel: profiles/pmc_traffic_latest.source carries the SHA-256 of
+    openmmtools_amd/csrc/forces.hip at collection time.  True / False: the file as it is now has / has not that hash (a changed kernel with
+    an old table would otherwise go unnoticed); None: no hash recorded."""
+    import hashlib, re
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.source')) as fh:
+            m = re.search(r'forces\.hip sha256[: ]+([0-9a-f]{64})', fh.read())
+        if not m:
+            return None
+        with open(os.path.join(ROOT, 'openmmtools_amd', 'csrc', 'forces.hip'), 'rb') as fh:
+            return hashlib.sha256(fh.read()).hexdigest() == m.group(1)
+    except Exception:
+        return None
+
+
 def pmc_traffic_source():
     """Where roofline.traffic comes from: it is NOT measured inside this run (counter passes serialise the kernels); the table
     was collected with tools/collect_profiles.sh on the commit named in profiles/pmc_traffic_latest.source."""
@@ -324,7 +340,7 @@ def main():
             roof_nb = dict(kernel='nonbonded_sci2_kernel', bound='mfma', achieved=achieved, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
                            frac=achieved / FP32_PEAK_TFLOPS, traffic=pmc_traffic_bytes('nonbonded_sci2_kernel'),
                            launches=n_launch, avg_launch_ms=avg_ms, total_ms=ms + ms_lj,
-                           traffic_source=pmc_traffic_source(),
+                           traffic_source=pmc_traffic_source(), traffic_source_is_this_kernel=pmc_traffic_is_current(),
                            note='fp32 VALU kernel (no MFMA: "mfma" is the contract\'s name for the compute roof); peak = FP32 vector rate = '
                                 'f32-input MFMA rate (157.3 TFLOP/s); algorithmic work = 10 kflop/atom (SURVEY 8(d): ~210 pairs per atom '
                                 'inside the reference\'s 1.0 nm cutoff x ~48 flop -- the rebalanced Ewald split evaluates 1.43x as many '
