@@ -22,6 +22,7 @@
 #define UNIT_SETTLE 1
 #define UNIT_SHAKE  2
 #define MAX_TOK 24
+#define CHAIN_BIN_COLS 256       // mesh columns (nx) a chain workgroup can bin in its LDS counters
 
 struct chain_prog {
     int n;                 // tokens in this chain
@@ -505,6 +506,15 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
     S.stamps = (own_time && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? own_time + 2 : nullptr;
     S.t_last = own_t0;
 #endif
+    // mesh-column bins: by the workgroup (below, behind the token program) when the columns fit its LDS counters, else atom by atom
+    // at the end of run_unit
+#ifdef CHAIN_UNIT_BINS
+    const bool wg_bins = false;
+#else
+    const bool wg_bins = bins.count != nullptr && bins.nx <= CHAIN_BIN_COLS;
+#endif
+    remd_chain_bins unit_bins = bins;
+    if (wg_bins) unit_bins.count = nullptr;
 #ifdef CHAIN_STAMPS
     if (S.stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + 20], now - S.t_last); S.t_last = now; }
 #endif
@@ -514,7 +524,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
         while (t1 < prog.n && chain_tok(prog, t1) != 'M') ++t1;
         const bool first = t0 == 0, last = t1 == prog.n;
         if (active) {
-#define RUN(TY, NA) mom = run_unit<TY, NA, !EARLY>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, bins, r, S, t0, t1, first, last, xold ? xold + (size_t)r * Npad : nullptr, vold ? vold + (size_t)r * Npad : nullptr)
+#define RUN(TY, NA) mom = run_unit<TY, NA, !EARLY>(prog, idx, dist, sc, tol, Npad, P, V, F, Fw, invmass, kT, rg, seed, cr, inv_total_mass, unit_bins, r, S, t0, t1, first, last, xold ? xold + (size_t)r * Npad : nullptr, vold ? vold + (size_t)r * Npad : nullptr)
             if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
             else if (type == UNIT_FREE) { if (a4.y < 0) RUN(UNIT_FREE, 1); else RUN(UNIT_FREE, 4); }
             else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
@@ -579,6 +589,50 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
 #endif
         }
         t0 = t1 + 1;
+    }
+    if (wg_bins) {
+        // The final positions of this workgroup's atoms, binned by PME mesh column for the spreading pass that follows (the order inside
+        // a bin is irrelevant: charges and forces are fixed-point sums).  One atomic with a returned slot per ATOM made the end of the chain
+        // three dependent rounds per unit (each behind the stores issued before it: one in-order counter) on ~35 atoms per counter;
+        // here the atoms take ranks in LDS counters, the workgroup reserves one range per occupied column with ONE returning atomic,
+        // and every atom stores at base + rank.
+        __shared__ int s_bin_cnt[CHAIN_BIN_COLS], s_bin_base[CHAIN_BIN_COLS];
+        for (int c = threadIdx.x; c < bins.nx; c += blockDim.x) s_bin_cnt[c] = 0;
+        __syncthreads();
+        int col[4] = { 0, 0, 0, 0 }, rank[4] = { 0, 0, 0, 0 };
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (idx[k] >= 0) {
+                    float u; int kx;
+                    remd_pme_scaled1(S.x[k].x, bins.box[4 * r], bins.nx, u, kx);
+                    if (kx >= bins.nx) kx -= bins.nx;
+                    col[k] = kx; rank[k] = atomicAdd(&s_bin_cnt[kx], 1);
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < bins.nx; c += blockDim.x) {
+            const int n = s_bin_cnt[c];
+            if (n > 0) s_bin_base[c] = atomicAdd(&bins.count[(size_t)r * bins.nx + c], n);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (idx[k] >= 0) {
+                    const int slot = s_bin_base[col[k]] + rank[k];
+                    if (slot < bins.cap) {
+                        const size_t e = ((size_t)r * bins.nx + col[k]) * bins.cap + slot;
+                        bins.atoms[e] = make_float4(S.x[k].x, S.x[k].y, S.x[k].z, __int_as_float(idx[k]));
+                        if (bins.q) bins.q[e] = bins.param[idx[k]].x;        // (state-independent charges only, see remd_pme_chain_bins)
+                    } else atomicExch(bins.err, 2u);
+                }
+            }
+        }
+#ifdef CHAIN_STAMPS
+        if (S.stamps) { const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + 27], now - S.t_last); S.t_last = now; }
+#endif
     }
     if (prog.accumulate_momentum) {
         // wavefront shuffle reduction, one fixed-point atomic per wave (integer => order-independent sum)
