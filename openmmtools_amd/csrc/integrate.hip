@@ -897,11 +897,13 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
     const remd_chain_bins bins = bin_for_pme ? remd_pme_chain_bins(h) : remd_chain_bins();
     remd_prof_scope ps(h, "integrate_chain");
     dim3 grid((ut.n_units + 255) / 256, h->R);
-    // more workgroups than CUs: the two-per-CU compilation (REMD_CHAIN_TWO=0/1 pins the choice)
+    // The two-per-CU compilation is OPT-IN (REMD_CHAIN_TWO=1).  It takes a grid larger than the chip in one round (DHFR x 16: -1.3 % of the
+    // converged step), but its workgroups hold the WHOLE register file of their CUs while they poll for the forces in the prologue, and a
+    // direct-space stream that still has workgroups to place (one workgroup per work item, the scatter) then never gets a slot: the poll runs
+    // out after seconds (seen at the end of round 5 with 128 alanine replicas = 384 workgroups, and as a 4.8 s stall of the tuner's
+    // one-per-item candidate on DHFR).  One workgroup per CU leaves 160 registers per lane for the kernels the chain waits for.
     static const char* two_env = getenv("REMD_CHAIN_TWO");
-    static int n_cu = 0;
-    if (!n_cu) { hipDeviceProp_t prop; n_cu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256; }
-    const bool two = two_env ? atoi(two_env) != 0 : (int)(grid.x * grid.y) > n_cu;
+    const bool two = two_env != nullptr && atoi(two_env) != 0;
     auto kern = two ? integrate_chain2_kernel : integrate_chain_kernel;
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
