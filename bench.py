@@ -194,13 +194,13 @@ def build_dhfr_sams(n_replicas, engine, comm, md_steps):
     return s
 
 
-def run_shapes(args, world, rank, local_rank, comm, sync, stream, budget_s=240.0):
+def run_shapes(args, world, rank, local_rank, comm, sync, stream, budget_s=240.0, out=None):
     """The other ensemble shapes on the same ranks (every rank calls this: the samplers hold collectives).  Returns the dict for the
     JSON line on rank 0.  A shape that fails is reported with its error instead of taking the main line down."""
     import torch
     from openmmtools_amd._engine import HipEngine
     t_start = time.perf_counter()
-    out = {}
+    out = {} if out is None else out       # (caller-owned: the watchdog of main() reports what finished)
     specs = [('strong24_alanine', 24, 'alanine', 3, 1), ('strong128_alanine', 128, 'alanine', 3, 1),
              ('config5_dhfr128_sams', 128, 'dhfr', 1 if world == 1 else 2, 1)]
     for name, R, kind, n_it, n_warm in specs:
@@ -240,6 +240,42 @@ def run_shapes(args, world, rank, local_rank, comm, sync, stream, budget_s=240.0
         except Exception as exc:                       # never fail the main line for an extra shape
             out[name] = dict(error='%s: %s' % (type(exc).__name__, exc))
     return out
+
+
+def finish_line(out, rank, shapes_fn, limit_s, write=None, end_process=None):
+    """Print the ONE JSON line (rank 0), after the extra ensemble shapes if there are any.  The shapes run LAST and under a watchdog: the
+    headline part of `out` is complete when this is called, and an extra shape that stalls (a device-side poll that runs out takes seconds
+    per MD step) must not keep it from being printed.  The watchdog thread runs while the main thread sits in a C call (ctypes releases
+    the GIL); it prints the line with the shapes that did finish and ends the process -- on every rank, each by its own timer.
+    shapes_fn(dict) fills the dict shape by shape (every rank calls it: the samplers hold collectives); None: no extra shapes."""
+    import threading
+    write = write or (lambda text: print(text, flush=True))
+    end_process = end_process or (lambda: os._exit(0))
+    printed = threading.Lock()
+
+    def emit(note=None):
+        if not printed.acquire(blocking=False):
+            return False
+        if rank == 0:
+            if note and out.get('shapes') is not None:
+                out['shapes']['watchdog'] = note
+            write(json.dumps(out, default=float))
+        return True
+
+    if shapes_fn is not None:
+        shapes = {}
+        if rank == 0:
+            out['shapes'] = shapes
+
+        def expired():
+            if emit('the extra shapes did not finish within %.0f s: the line is printed without the rest and the process ends' % limit_s):
+                end_process()
+        dog = threading.Timer(limit_s, expired)
+        dog.daemon = True
+        dog.start()
+        shapes_fn(shapes)
+        dog.cancel()
+    emit()
 
 
 def main():
@@ -320,11 +356,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # the other ensemble shapes, on the same ranks (collective: every rank takes part); the main engine stays open for the roofline extras
-    shapes = None
-    if not args.no_shapes and args.replicas_total == 0:
-        shapes = run_shapes(args, world, rank, local_rank, comm, sync, stream)
-
+    out = None
     if rank == 0:
         it_per_s = args.steps / elapsed
         value = it_per_s * (n_replicas / REPLICAS_PER_GPU)
@@ -406,7 +438,7 @@ def main():
                                replicas_per_gpu=(n_replicas / float(world)), replicas_total=n_replicas, md_steps=args.md_steps,
                                mode=('strong: one %d-replica ensemble' % n_replicas) if strong else 'weak: 24 replicas per GPU',
                                parallelism='replica-sharded x%d' % world, seed=SEED, ewald=ewald),
-                   timing=timing_of_timed_region, roofline=roof, roofline_secondary=roof2, roofline_integrator=roof_ch, shapes=shapes)
+                   timing=timing_of_timed_region, roofline=roof, roofline_secondary=roof2, roofline_integrator=roof_ch, shapes=None)
         try:
             # achievable roofs of THIS box (STREAM triad past the Infinity Cache, FMA chains), SURVEY 8(d)
             out['measured_roofs'] = engine.roof_microbench()
@@ -426,7 +458,12 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out, default=float))
+
+    shapes_fn = None
+    if not args.no_shapes and args.replicas_total == 0:
+        def shapes_fn(shapes):
+            run_shapes(args, world, rank, local_rank, comm, sync, stream, out=shapes)
+    finish_line(out, rank, shapes_fn, float(os.environ.get('REMD_BENCH_SHAPES_LIMIT_S', '420')))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
