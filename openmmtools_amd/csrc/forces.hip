@@ -116,6 +116,9 @@ __global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq
     if (threadIdx.x == 0) {
         long long n = 0;
         while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+            // a fault is raised already (this propagation is run again by the host whatever happens from here): no second wait -- else every
+            // step behind a poll that ran out waits for its own time-out
+            if ((n & 255) == 0 && __hip_atomic_load(spin_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             __builtin_amdgcn_s_sleep(4);
             if (++n > (1ll << 25)) { atomicExch(spin_out, 1u); break; }       // seconds: something upstream died; say so instead of hanging
         }
