@@ -475,7 +475,9 @@ int remd_set_restart_attempts(remd_handle h, int n)
 }
 
 // The device reports what it cannot raise through a sticky word (d_sync[2]): a wait polled on the device that ran out (1), an
-// overfull capped PME bin (2), the integrator chain's momentum barrier (3).  A raised flag is cleared and the mechanism behind it
+// overfull capped PME bin (2), the integrator chain's momentum barrier (3).  The FIRST fault of a call stays in the word (compare-and-swap
+// from 0: what follows a fault is garbage that raises others, e.g. exploded positions overfill a bin after a wait ran out, and the remedy
+// must be the first one's); once it is raised the device-side polls of the same call stop waiting.  A raised flag is cleared and the mechanism behind it
 // switched off for this handle (events instead of polled flags, two chain launches instead of the barrier, the binning launch
 // instead of capped bins), so that the handle keeps working; `retry` says whether the caller runs the work again itself (then
 // this is not an error yet).

@@ -69,7 +69,7 @@ __global__ void baro_decide_kernel(int R, int r_begin, uint64_t seed, long long 
     // a trial box with an edge below twice the longer cutoff (the Coulomb range of the Ewald split may exceed the NonbondedForce
     // cutoff) was evaluated with a broken minimum image: never accept it, and say so -- OpenMM raises "The periodic box size has
     // decreased to less than twice the nonbonded cutoff" here (sticky device flag 6: api.hip turns it into the error)
-    if (fminf(box[4 * r], fminf(box[4 * r + 1], box[4 * r + 2])) < min_edge) { reject = true; atomicExch(err, 6u); }
+    if (fminf(box[4 * r], fminf(box[4 * r + 1], box[4 * r + 2])) < min_edge) { reject = true; atomicCAS(err, 0u, 6u); }
     accepted[r] = reject ? 0 : 1;
     if (reject) { box[4 * r] = box_old[4 * r]; box[4 * r + 1] = box_old[4 * r + 1]; box[4 * r + 2] = box_old[4 * r + 2]; }
     else { S[2] += 1.0; S[4] += 1.0; }

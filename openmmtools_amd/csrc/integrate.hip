@@ -393,7 +393,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                 const size_t e = ((size_t)r * bins.nx + kx) * bins.cap + slot;
                 bins.atoms[e] = make_float4(x[k].x, x[k].y, x[k].z, __int_as_float(idx[k]));
                 if (bins.q) bins.q[e] = bins.param[idx[k]].x;        // (state-independent charges only, see remd_pme_chain_bins)
-            } else atomicExch(bins.err, 2u);
+            } else atomicCAS(bins.err, 0u, 2u);
         }
 #ifdef CHAIN_STAMPS
         if (S.stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now = wall_clock64(); atomicAdd(&S.stamps[1 + 24 + k], now - S.t_last); S.t_last = now; }
@@ -462,7 +462,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
                 // without this every step behind a poll that ran out waits for its own time-out, seconds each)
                 if ((n & 255) == 0 && __hip_atomic_load(chain_sync_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++n > (1ll << 25)) { atomicExch(chain_sync_err, 1u); break; }
+                if (++n > (1ll << 25)) { atomicCAS(chain_sync_err, 0u, 1u); break; }
             }
         }
         __syncthreads();
@@ -475,7 +475,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
             while ((int)(__hip_atomic_load(join_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0) {
                 if ((n & 255) == 0 && __hip_atomic_load(join_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // (as above)
                 __builtin_amdgcn_s_sleep(2);
-                if (++n > (1ll << 25)) { atomicExch(join_flag + 1, 1u); break; }
+                if (++n > (1ll << 25)) { atomicCAS(join_flag + 1, 0u, 1u); break; }
             }
         }
         __syncthreads();
@@ -565,7 +565,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
             unsigned long long* slots = chain_slots + ((size_t)(prog.m_epoch & 1u) * gridDim.y + r) * gridDim.x * 3;
             if (threadIdx.x < 3) {
                 const long long t = s_pm[0][threadIdx.x] + s_pm[1][threadIdx.x] + s_pm[2][threadIdx.x] + s_pm[3][threadIdx.x];
-                if (t >= (1ll << 46) || t < -(1ll << 46)) atomicExch(chain_sync_err, 3u);       // (the host then sums with two launches)
+                if (t >= (1ll << 46) || t < -(1ll << 46)) atomicCAS(chain_sync_err, 0u, 3u);       // (the host then sums with two launches)
                 __hip_atomic_store(&slots[blockIdx.x * 3 + threadIdx.x], ((unsigned long long)t << 16) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const int n_words = 3 * (int)gridDim.x;
@@ -577,7 +577,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
                     while (((w = __hip_atomic_load(&slots[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffull) != tag) {
                         if ((n & 255) == 0 && __hip_atomic_load(chain_sync_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // (as in the prologue)
                         __builtin_amdgcn_s_sleep(1);
-                        if (++n > (1ll << 25)) { atomicExch(chain_sync_err, 3u); break; }
+                        if (++n > (1ll << 25)) { atomicCAS(chain_sync_err, 0u, 3u); break; }
                     }
                     part += (long long)w >> 16;
                 }
@@ -631,7 +631,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
                         const size_t e = ((size_t)r * bins.nx + col[k]) * bins.cap + slot;
                         bins.atoms[e] = make_float4(S.x[k].x, S.x[k].y, S.x[k].z, __int_as_float(idx[k]));
                         if (bins.q) bins.q[e] = bins.param[idx[k]].x;        // (state-independent charges only, see remd_pme_chain_bins)
-                    } else atomicExch(bins.err, 2u);
+                    } else atomicCAS(bins.err, 0u, 2u);
                 }
             }
         }
@@ -1109,7 +1109,7 @@ void resident_md_kernel(resident_prog prog, resident_sys S, float4* __restrict__
                 }
                 have_list = true;
                 __syncthreads();
-                if (tid == 0 && *s_np > S.list_cap) atomicExch(S.err, 4u);
+                if (tid == 0 && *s_np > S.list_cap) atomicCAS(S.err, 0u, 4u);
             }
             {
                 // a thread takes pairs tid, tid + T, ...: the same number for every lane (an atom-per-lane loop runs as long as the
