@@ -23,7 +23,14 @@ eng.propagate(1)
 n, own = eng.profile_get('integrate_chain_own')
 print('launches', n, 'own us per launch', round(1e3 * own / max(n, 1), 2))
 names = ['prologue'] + ['tok%d' % t for t in range(34)] + ['epilogue']
+# round 5: finer stamps in the unused token slots (each drains the wavefront's memory operations first, so they over-count a little)
+names[1 + 20] = 'tok20 (unit table, temperature arrived)'
+names[1 + 21] = 'tok21 (positions, velocities, masses arrived)'
+names[1 + 22] = 'tok22 (forces arrived + first kick)'
+for k in range(3):
+    names[1 + 24 + k] = 'tok%d (stores of atom %d drained)' % (24 + k, k)
+names[1 + 27] = 'tok27 (mesh-column bins by the workgroup)'
 for k, name in enumerate(names):
     _, ms = eng.profile_get('integrate_chain_seg%d' % k)
     if ms > 0:
-        print('%-9s %7.2f us' % (name, 1e3 * ms / max(n, 1)))
+        print('%-48s %7.2f us' % (name, 1e3 * ms / max(n, 1)))
