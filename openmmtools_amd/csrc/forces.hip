@@ -118,7 +118,7 @@ __global__ void remd_spin_wait_kernel(const unsigned int* flag, unsigned int seq
         while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
             // a fault is raised already (this propagation is run again by the host whatever happens from here): no second wait -- else every
             // step behind a poll that ran out waits for its own time-out
-            if ((n & 255) == 0 && __hip_atomic_load(spin_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if ((n & 255) == 255 && __hip_atomic_load(spin_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             __builtin_amdgcn_s_sleep(4);
             if (++n > (1ll << 25)) { atomicCAS(spin_out, 0u, 1u); break; }       // seconds: something upstream died; say so instead of hanging
         }

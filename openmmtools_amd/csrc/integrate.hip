@@ -459,8 +459,9 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
             long long n = 0;
             while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fold.target) < 0) {
                 // (a fault is already raised -- this propagation is run again whatever happens from here: do not wait a second time;
-                // without this every step behind a poll that ran out waits for its own time-out, seconds each)
-                if ((n & 255) == 0 && __hip_atomic_load(chain_sync_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                // without this every step behind a poll that ran out waits for its own time-out, seconds each; looked at every 256th poll
+                // only, from the 256th on: a wait of ordinary length never pays for the extra load)
+                if ((n & 255) == 255 && __hip_atomic_load(chain_sync_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(2);
                 if (++n > (1ll << 25)) { atomicCAS(chain_sync_err, 0u, 1u); break; }
             }
@@ -473,7 +474,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
         if (threadIdx.x == 0) {
             long long n = 0;
             while ((int)(__hip_atomic_load(join_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - join_seq) < 0) {
-                if ((n & 255) == 0 && __hip_atomic_load(join_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // (as above)
+                if ((n & 255) == 255 && __hip_atomic_load(join_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // (as above)
                 __builtin_amdgcn_s_sleep(2);
                 if (++n > (1ll << 25)) { atomicCAS(join_flag + 1, 0u, 1u); break; }
             }
@@ -575,7 +576,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
                     unsigned long long w;
                     long long n = 0;
                     while (((w = __hip_atomic_load(&slots[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffull) != tag) {
-                        if ((n & 255) == 0 && __hip_atomic_load(chain_sync_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // (as in the prologue)
+                        if ((n & 255) == 255 && __hip_atomic_load(chain_sync_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // (as in the prologue)
                         __builtin_amdgcn_s_sleep(1);
                         if (++n > (1ll << 25)) { atomicCAS(chain_sync_err, 0u, 3u); break; }
                     }
