@@ -43,7 +43,11 @@ class AbsoluteAlchemicalFactory:
             raise NotImplementedError("only alchemical_pme_treatment='exact' (the reference default, alchemy.py:628)")
         self.disable_alchemical_dispersion_correction = disable_alchemical_dispersion_correction
 
-    def create_alchemical_system(self, reference_system, alchemical_regions):
+    def create_alchemical_system(self, reference_system, alchemical_regions, alchemical_regions_interactions=frozenset()):
+        """alchemy.py:637-664.  alchemical_regions_interactions names pairs of regions that interact through their own lambdas: it
+        only has a meaning with several regions, which are not built here."""
+        if alchemical_regions_interactions != frozenset():
+            raise NotImplementedError('interactions between several alchemical regions (alchemy.py:661-664)')
         if isinstance(alchemical_regions, (list, tuple)):
             if len(alchemical_regions) != 1:
                 raise NotImplementedError('multiple alchemical regions')

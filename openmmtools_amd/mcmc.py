@@ -102,8 +102,9 @@ class MCMCSampler:
             self._driver = d
         return self._driver
 
-    def run(self, n_iterations=1):
-        """:251-266."""
+    def run(self, n_iterations=1, context_cache=None):
+        """:251-266 (context_cache: the reference's per-call cache of OpenMM Contexts; the engine of this sampler is its counterpart and
+        is chosen at construction -- accepted and not used)."""
         if isinstance(self.move, WeightedMove):                              # a choice per application: the move's own apply
             for _ in range(int(n_iterations)):
                 self.move.apply(self.thermodynamic_state, self.sampler_state, engine=self._engine)
@@ -116,8 +117,8 @@ class MCMCSampler:
         self.sampler_state.potential_energy = float(np.asarray(u).reshape(-1)[0])
         self.sampler_state.kinetic_energy = float(np.asarray(k).reshape(-1)[0])
 
-    def minimize(self, tolerance=1.0 * unit.kilocalories_per_mole / unit.angstroms, max_iterations=100):
-        """:268-300 (the engine's FIRE minimiser, as MultiStateSampler.minimize)."""
+    def minimize(self, tolerance=1.0 * unit.kilocalories_per_mole / unit.angstroms, max_iterations=100, context_cache=None):
+        """:268-300 (the engine's FIRE minimiser, as MultiStateSampler.minimize; context_cache as in run)."""
         d = self._ensemble()
         d.minimize(tolerance=tolerance, max_iterations=max_iterations)
         self.sampler_state = d.sampler_states[0]

@@ -14,12 +14,45 @@ from . import constants
 from .unit import to_md
 
 
-class ThermodynamicsError(Exception):
-    """states.py:272-337."""
+class _CodedError(Exception):
+    """The reference's state errors carry a `code` (class constants, numbered in declaration order) and take their message from a table
+    indexed by it (states.py:300-337, 366-377): user code tests `err.code == ThermodynamicsError.NO_THERMOSTAT`."""
+    _table = ()
+
+    def __init__(self, code, *args):
+        super().__init__(self.error_messages[code].format(*args))
+        self.code = code
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        cls.error_messages = {}
+        for number, (name, message) in enumerate(cls._table):
+            setattr(cls, name, number)
+            cls.error_messages[number] = message
 
 
-class SamplerStateError(Exception):
+class ThermodynamicsError(_CodedError):
+    """states.py:272-337 (names, numbers and messages are the reference's: tests/test_signatures.py holds them to its source)."""
+    _table = (('MULTIPLE_THERMOSTATS', 'System has multiple thermostats.'),
+              ('NO_THERMOSTAT', 'System does not have a thermostat specifying the temperature.'),
+              ('NONE_TEMPERATURE', 'Cannot set temperature of the thermodynamic state to None.'),
+              ('INCONSISTENT_THERMOSTAT', 'System thermostat is inconsistent with thermodynamic state.'),
+              ('MULTIPLE_BAROSTATS', 'System has multiple barostats.'),
+              ('NO_BAROSTAT', 'System does not have a barostat specifying the pressure.'),
+              ('UNSUPPORTED_BAROSTAT', 'Found unsupported barostat {} in system.'),
+              ('UNSUPPORTED_ANISOTROPIC_BAROSTAT', 'MonteCarloAnisotropicBarostat is only supported if the pressure along all scaled axes is the same.'),
+              ('SURFACE_TENSION_NOT_SUPPORTED', 'Surface tension can only be set for states that have a system with a MonteCarloMembraneBarostat.'),
+              ('INCONSISTENT_BAROSTAT', 'System barostat is inconsistent with thermodynamic state.'),
+              ('BAROSTATED_NONPERIODIC', 'Non-periodic systems cannot have a barostat.'),
+              ('INCONSISTENT_INTEGRATOR', 'Integrator is coupled to a heat bath at a different temperature.'),
+              ('INCOMPATIBLE_SAMPLER_STATE', 'The sampler state has a different number of particles.'),
+              ('INCOMPATIBLE_ENSEMBLE', 'Cannot apply to a context in a different thermodynamic ensemble.'))
+
+
+class SamplerStateError(_CodedError):
     """states.py:340-382."""
+    _table = (('INCONSISTENT_VELOCITIES', 'Velocities have different length than positions.'),
+              ('INCONSISTENT_POSITIONS', 'Specified positions with inconsistent number of particles.'))
 
 
 def create_thermodynamic_state_protocol(system, protocol, constants=None, composable_states=None):
@@ -79,8 +112,14 @@ class MonteCarloBarostatSettings:
 
 
 class ThermodynamicState:
-    def __init__(self, system, temperature, pressure=None):
+    def __init__(self, system, temperature=None, pressure=None, surface_tension=None):
+        """states.py:507-508, 1314-1353.  A System here carries no thermostat force a temperature could be read from and no membrane
+        barostat: no temperature is the reference's NO_THERMOSTAT, a surface tension its INCOMPATIBLE_ENSEMBLE."""
         self._system = system
+        if surface_tension is not None:
+            raise ThermodynamicsError(ThermodynamicsError.INCOMPATIBLE_ENSEMBLE)          # states.py:1330-1331
+        if temperature is None:
+            raise ThermodynamicsError(ThermodynamicsError.NO_THERMOSTAT)                  # states.py:1336-1339
         self.temperature = temperature
         # NPT: the reference adds an openmm.MonteCarloBarostat (frequency 25) to the System (states.py:1177-1181); here the
         # pressure (kJ/mol/nm^3, i.e. `p * unit.bar`) and the frequency are handed to the engine's barostat
@@ -95,7 +134,7 @@ class ThermodynamicState:
     def pressure(self, value):
         """states.py:680-703."""
         if value is not None and not self._system.usesPeriodicBoundaryConditions():
-            raise ValueError('pressure is specified but the system is not periodic')          # states.py:1156-1158
+            raise ThermodynamicsError(ThermodynamicsError.BAROSTATED_NONPERIODIC)            # states.py:1764-1766
         self._pressure = None if value is None else float(to_md(value))
 
     @property
@@ -119,6 +158,8 @@ class ThermodynamicState:
 
     @temperature.setter
     def temperature(self, value):
+        if value is None:
+            raise ThermodynamicsError(ThermodynamicsError.NONE_TEMPERATURE)                  # states.py:664-666
         value = float(to_md(value))                    # float kelvin or an openmm.unit.Quantity
         if not value > 0:
             raise ValueError('temperature must be positive')
@@ -255,6 +296,8 @@ class SamplerState:
         # plain arrays in nm / nm ps^-1, or openmm.unit.Quantity of arrays / Vec3 lists (states.py:1975-2010)
         self.positions = np.array(to_md(positions), dtype=np.float64).reshape(-1, 3)
         self.velocities = None if velocities is None else np.array(to_md(velocities), dtype=np.float64).reshape(-1, 3)
+        if self.velocities is not None and self.velocities.shape != self.positions.shape:
+            raise SamplerStateError(SamplerStateError.INCONSISTENT_VELOCITIES)               # states.py:2397-2399
         if box_vectors is not None and not hasattr(box_vectors, 'value_in_unit_system'):
             box_vectors = [to_md(b) for b in box_vectors] if isinstance(box_vectors, (list, tuple)) else box_vectors
         self.box_vectors = None if box_vectors is None else np.array(to_md(box_vectors), dtype=np.float64).reshape(3, 3)

@@ -17,7 +17,7 @@ def test_reduced_potential_npt_algebra():
     ss.potential_energy = -12.5
     expect = (ss.potential_energy + 2.0 * unit.bar * ss.volume) / (0.008314462618 * 300.0)
     assert np.isclose(ts.reduced_potential(ss), expect, rtol=1e-9)
-    with pytest.raises(ValueError):
+    with pytest.raises(states.ThermodynamicsError):       # states.py:1764-1766 BAROSTATED_NONPERIODIC
         states.ThermodynamicState(testsystems.HarmonicOscillator().system, 300.0, pressure=1.0 * unit.bar)
 
 

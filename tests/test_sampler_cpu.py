@@ -129,7 +129,7 @@ def test_reduced_potential_algebra():
     ho, ts, ss = _ho_states(1)
     ss.potential_energy = 12.5
     assert np.isclose(ts.reduced_potential(ss), 12.5 / (0.008314462618153242 * 300.0))
-    with pytest.raises(ValueError):            # states.py:1156-1158: a pressure needs a periodic system (NPT: tests/test_npt_cpu.py)
+    with pytest.raises(states.ThermodynamicsError) as err:     # states.py:1764-1766: a pressure needs a periodic system (NPT: tests/test_npt_cpu.py)
         states.ThermodynamicState(ho.system, 300.0, pressure=1.0 * unit.atmosphere)
 
 

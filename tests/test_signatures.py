@@ -1,0 +1,96 @@
+"""The mirror keeps the reference's public signatures (same names, argument meaning, defaults, error behaviour):
+tests/golden/reference_signatures.json holds `__init__` and the public entry points of every class of the reference's integrators /
+mcmc / states / alchemy / multistate modules, taken out of the syntax tree with every default evaluated in the MD unit system
+(tests/golden/make_golden_signatures.py).  For every class this package mirrors: each argument of the reference exists here under the
+same name (or is swallowed by **kwargs), every default that is a plain value is the same value, and the coded errors of states.py carry
+the reference's names, numbers and messages.  What differs on purpose is listed in ALLOWED with its reason."""
+import importlib
+import inspect
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, 'golden', 'reference_signatures.json')))
+
+# (module, class, method, argument): reason
+ALLOWED = {
+    ('multistate.multistatesampler', 'MultiStateSampler', 'create', 'storage'): 'optional here: storage=None keeps the run in memory (bench.py); the reference requires a reporter',
+    ('multistate.paralleltempering', 'ParallelTemperingSampler', 'create', 'storage'): 'as MultiStateSampler.create',
+}
+# classes of those modules that are not mirrored (out of the hot path's scope)
+NOT_MIRRORED = {
+    'integrators': {'AlchemicalNonequilibriumLangevinIntegrator', 'AndersenVelocityVerletIntegrator', 'DummyIntegrator',
+                    'ExternalPerturbationLangevinIntegrator', 'FIREMinimizationIntegrator', 'GradientDescentMinimizationIntegrator',
+                    'MTSIntegrator', 'MetropolisMonteCarloIntegrator', 'NonequilibriumLangevinIntegrator',
+                    'NoseHooverChainVelocityVerletIntegrator', 'PeriodicNonequilibriumIntegrator', 'ThermostatedIntegrator',
+                    'PrettyPrintableIntegrator', 'RestorableIntegrator'},
+    'states': {'GlobalParameterFunction', 'GlobalParameterState', 'GlobalParameterError', 'IComposableState'},
+}
+
+
+def _cases():
+    for mod, m in sorted(G['modules'].items()):
+        for cls in sorted(m['classes']):
+            yield mod, cls
+
+
+def _same(mine, ref):
+    if isinstance(ref, float) and not isinstance(ref, bool):
+        return isinstance(mine, (int, float)) and not isinstance(mine, bool) and np.isclose(float(mine), ref, rtol=1e-12, atol=0.0)
+    return mine == ref and type(mine) is type(ref)
+
+
+@pytest.mark.parametrize('mod,cls', list(_cases()))
+def test_signature_follows_the_reference(mod, cls):
+    ours = importlib.import_module('openmmtools_amd.' + mod)
+    if not hasattr(ours, cls):
+        assert cls in NOT_MIRRORED.get(mod.split('.')[0], set()) or cls in NOT_MIRRORED.get(mod, set()), (mod, cls, 'neither mirrored nor listed as out of scope')
+        pytest.skip('%s.%s is outside the hot path (not mirrored)' % (mod, cls))
+    C = getattr(ours, cls)
+    for meth, ref in G['modules'][mod]['classes'][cls].items():
+        if meth == 'error_codes':
+            for e in ref:
+                assert getattr(C, e['name']) == e['number'] and C.error_messages[e['number']] == e['message'], (cls, e)
+            err = C(ref[0]['number'])
+            assert err.code == ref[0]['number'] and str(err) == ref[0]['message']
+            continue
+        assert hasattr(C, meth), (mod, cls, meth, 'method missing')
+        sig = inspect.signature(getattr(C, meth))
+        swallows = any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values())
+        for a in ref['arguments']:
+            if (mod, cls, meth, a['name']) in ALLOWED:
+                continue
+            p = sig.parameters.get(a['name'])
+            if p is None:
+                assert swallows, (mod, cls, meth, a['name'], 'argument missing')
+                continue
+            if a.get('required'):
+                assert p.default is inspect.Parameter.empty, (mod, cls, meth, a['name'], 'required in the reference')
+            elif 'value' in a:
+                assert p.default is not inspect.Parameter.empty and _same(p.default, a['value']), (mod, cls, meth, a['name'], p.default, a)
+            else:
+                assert p.default is not inspect.Parameter.empty, (mod, cls, meth, a['name'], 'has a default in the reference: ' + a['source'])
+
+
+def test_state_errors_behave_like_the_references():
+    from openmmtools_amd import states, testsystems, unit
+    ho = testsystems.HarmonicOscillator()
+    with pytest.raises(states.ThermodynamicsError) as e:
+        states.ThermodynamicState(ho.system)                                   # states.py:1336-1339: no thermostat to read it from
+    assert e.value.code == states.ThermodynamicsError.NO_THERMOSTAT
+    with pytest.raises(states.ThermodynamicsError) as e:
+        states.ThermodynamicState(ho.system, 300.0, surface_tension=1.0)       # :1330-1331
+    assert e.value.code == states.ThermodynamicsError.INCOMPATIBLE_ENSEMBLE
+    with pytest.raises(states.ThermodynamicsError) as e:
+        states.ThermodynamicState(ho.system, 300.0, pressure=1.0 * unit.atmosphere)     # :1764-1766
+    assert e.value.code == states.ThermodynamicsError.BAROSTATED_NONPERIODIC and str(e.value) == 'Non-periodic systems cannot have a barostat.'
+    ts = states.ThermodynamicState(ho.system, 300.0)
+    with pytest.raises(states.ThermodynamicsError) as e:
+        ts.temperature = None                                                   # :664-666
+    assert e.value.code == states.ThermodynamicsError.NONE_TEMPERATURE
+    with pytest.raises(states.SamplerStateError) as e:
+        states.SamplerState(np.zeros((3, 3)), velocities=np.zeros((2, 3)))    # :2397-2399
+    assert e.value.code == states.SamplerStateError.INCONSISTENT_VELOCITIES
