@@ -449,6 +449,41 @@ class MultiStateReporter:
             out[k] = self._files[k].read(idx)
         return out
 
+    # ---- small accessors of the reference built on the readers above (they answer from whichever store is open) ----------------
+    @property
+    def n_states(self):
+        """:197-201: number of sampled thermodynamic states (None while closed)."""
+        if not self.is_open():
+            return None
+        return len(self.read_thermodynamic_states()[0])
+
+    @property
+    def n_replicas(self):
+        """:203-207."""
+        if not self.is_open():
+            return None
+        return int(np.asarray(self.read_replica_thermodynamic_states(iteration=0)).shape[-1])
+
+    @property
+    def is_periodic(self):
+        """:209-215: whether the stored configurations carry box vectors."""
+        if not self.is_open():
+            return None
+        return self.read_sampler_states(0)[0].box_vectors is not None
+
+    def read_end_thermodynamic_states(self):
+        """:480-560: the unsampled states if there are any, else the first and the last sampled state."""
+        states_, unsampled = self.read_thermodynamic_states()
+        return list(unsampled) if len(unsampled) > 0 else [states_[0], states_[-1]]
+
+    def read_logZ(self, iteration):
+        """:1203-1220 (SAMS)."""
+        return self.read_online_analysis_data(iteration, 'logZ')['logZ']
+
+    def write_logZ(self, iteration, logZ):
+        """:1222-1234."""
+        self.write_online_data_dynamic_and_static(iteration, logZ=logZ)
+
     def write_current_statistics(self, data):
         """:1353-1375: appends one YAML document per call to ``<storage stem>_real_time_analysis.yaml``."""
         self._require_write()

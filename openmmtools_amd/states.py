@@ -146,6 +146,25 @@ class ThermodynamicState:
         return MonteCarloBarostatSettings(self._pressure, self._temperature, self.barostat_frequency)
 
     @property
+    def surface_tension(self):
+        """states.py:729-748: None -- a surface tension needs a System with a membrane barostat, which this package does not build."""
+        return None
+
+    def get_volume(self, ignore_ensemble=False):
+        """states.py:773-794: volume of the System's default periodic box (nm^3); None when the volume fluctuates (a pressure is set,
+        unless ignore_ensemble) or the System is not periodic."""
+        if self._pressure is not None and not ignore_ensemble:
+            return None
+        if not self._system.usesPeriodicBoundaryConditions():
+            return None
+        return float(abs(np.linalg.det(np.array(self._system.getDefaultPeriodicBoxVectors(), dtype=np.float64).reshape(3, 3))))
+
+    @property
+    def volume(self):
+        """states.py:763-771."""
+        return self.get_volume()
+
+    @property
     def system(self):
         return self._system
 

@@ -589,3 +589,42 @@ def test_store_thermodynamic_states_one_full_serialization_per_compatible_group(
     assert 'standard_system' in s[2]                                          # NPT: another ensemble, its own serialization
     assert 'standard_system' in u[0] and u[1]['_Reporter__compatible_state'] == 'unsampled_states/0'
     assert u[2]['_Reporter__compatible_state'] == 'thermodynamic_states/0'
+
+
+def test_small_accessors_of_the_references_reporter(tmp_path):
+    """multistatereporter.py:197-215 n_states / n_replicas / is_periodic, :480-560 read_end_thermodynamic_states, :1203-1234
+    read_logZ / write_logZ: on the store the reference wrote, on a store of the reference's layout written here, and on the record
+    container."""
+    import sys
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from openmmtools_amd import testsystems, mcmc, unit
+    from openmmtools_amd.multistate import SAMSSampler
+    rep = MultiStateReporter(STORE, open_mode='r')
+    assert (rep.n_states, rep.n_replicas, rep.is_periodic) == (20, 1, True)
+    ends = rep.read_end_thermodynamic_states()                              # no unsampled states: first and last sampled one
+    assert len(ends) == 2 and ends[0].temperature == 300.0 and abs(ends[1].temperature - 600.0) < 1e-9
+    rep.close()
+    assert rep.n_states is None and rep.n_replicas is None and rep.is_periodic is None
+    ho = testsystems.HarmonicOscillator()
+    sts = [states.ThermodynamicState(ho.system, T * unit.kelvin) for T in np.linspace(300.0, 500.0, 5)]
+    unsampled = [states.ThermodynamicState(ho.system, 700.0 * unit.kelvin)]
+    ss = states.SamplerState(ho.positions)
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=5.0 / unit.picosecond, n_steps=5,
+                                              reassign_velocities=True, splitting='V R O R V')
+    for name in ('layout.nc', 'records'):
+        s = SAMSSampler(mcmc_moves=move, number_of_iterations=3, engine=OracleEngine(), seed=3)
+        s.create(sts, [ss] * 2, storage=MultiStateReporter(str(tmp_path / name), checkpoint_interval=1), unsampled_thermodynamic_states=unsampled)
+        s.run()
+        s._reporter.close()
+        r = MultiStateReporter(str(tmp_path / name), open_mode='r')
+        periodic = s.sampler_states[0].box_vectors is not None                 # (what the sampler holds is what is stored)
+        assert (r.n_states, r.n_replicas, r.is_periodic) == (5, 2, periodic), name
+        ends = r.read_end_thermodynamic_states()
+        assert len(ends) == 1 and abs(ends[0].temperature - 700.0) < 1e-9, name
+        assert np.array_equal(np.asarray(r.read_logZ(3)), np.asarray(s._logZ)), name
+        r.close()
+        w = MultiStateReporter(str(tmp_path / name), open_mode='a')
+        w.write_logZ(3, np.arange(5.0))
+        assert np.array_equal(np.asarray(w.read_logZ(3)), np.arange(5.0)), name
+        w.close()

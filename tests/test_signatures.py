@@ -94,3 +94,16 @@ def test_state_errors_behave_like_the_references():
     with pytest.raises(states.SamplerStateError) as e:
         states.SamplerState(np.zeros((3, 3)), velocities=np.zeros((2, 3)))    # :2397-2399
     assert e.value.code == states.SamplerStateError.INCONSISTENT_VELOCITIES
+
+
+def test_thermodynamic_state_volume_follows_the_reference():
+    """states.py:763-794: the default box's volume at constant volume, None under a barostat (unless asked to ignore the ensemble) and
+    for a System without periodic boundary conditions; surface_tension is None without a membrane barostat."""
+    from openmmtools_amd import states, testsystems, unit
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    edges = np.diag(np.array(lj.system.getDefaultPeriodicBoxVectors(), dtype=float).reshape(3, 3))
+    nvt = states.ThermodynamicState(lj.system, 120.0 * unit.kelvin)
+    assert np.isclose(nvt.volume, np.prod(edges), rtol=1e-12) and nvt.get_volume() == nvt.volume and nvt.surface_tension is None
+    npt = states.ThermodynamicState(lj.system, 120.0 * unit.kelvin, 1.0 * unit.atmosphere)
+    assert npt.volume is None and np.isclose(npt.get_volume(ignore_ensemble=True), np.prod(edges), rtol=1e-12)
+    assert states.ThermodynamicState(testsystems.HarmonicOscillator().system, 300.0).volume is None
