@@ -18,6 +18,8 @@ import math
 import numpy as np
 from scipy import integrate
 
+from .states import AlchemicalState, AlchemicalStateError          # alchemy.py:60-62, 90-410: users reach them as alchemy.AlchemicalState
+
 
 class AlchemicalRegion:
     def __init__(self, alchemical_atoms=None, annihilate_electrostatics=True, annihilate_sterics=False,

@@ -161,7 +161,9 @@ class MultiStateReporter:
         """:233-235."""
         return self._velocity_interval
 
-    def storage_exists(self):
+    def storage_exists(self, skip_size=False):
+        """:237-261 (skip_size: the reference's guard against a zero-size netCDF file just created; the stores here are complete once
+        they exist -- accepted, nothing to skip)."""
         from ._reference_store import is_reference_store
         return is_reference_store(self._storage_analysis) or os.path.exists(os.path.join(self._storage_analysis, 'meta.json'))
 
@@ -172,7 +174,11 @@ class MultiStateReporter:
     def is_open(self):
         return self._open_mode is not None
 
-    def open(self, mode='r'):
+    def open(self, mode='r', convention='ReplicaExchange', netcdf_format='NETCDF4'):
+        """:280-340.  convention / netcdf_format: what the reference stamps on / asks of its netCDF file; the stores of the reference's
+        layout written here carry exactly these two defaults, anything else is refused."""
+        if convention != 'ReplicaExchange' or netcdf_format != 'NETCDF4':
+            raise ValueError("only convention='ReplicaExchange' and netcdf_format='NETCDF4' (the reference's defaults) are written")
         if mode not in ('r', 'w', 'a'):
             raise ValueError("open mode must be 'r', 'w' or 'a'")
         from ._reference_store import is_reference_store, ReferenceStoreReader, ReferenceStoreWriter
@@ -322,20 +328,20 @@ class MultiStateReporter:
     def read_mcmc_moves(self):
         return self._read_object('mcmc_moves')
 
-    def write_dict(self, name, data, nested=False, fixed_dimension=False):
+    def write_dict(self, path, data, nested=False, fixed_dimension=False):
         """:1094-1115, 1817-1880 (``nested`` / ``fixed_dimension`` choose among the netCDF4 layout's three representations; the
         record container has one)."""
         if self._ncw is not None:
             self._require_write()
-            return self._ncw.write_dict(name, data, nested=nested, fixed_dimension=fixed_dimension)
-        self._write_object(name, dict(data))
+            return self._ncw.write_dict(path, data, nested=nested, fixed_dimension=fixed_dimension)
+        self._write_object(path, dict(data))
 
     _write_dict = write_dict                      # the reference's tests call the private name
 
     @_reference_read
-    def read_dict(self, name):
+    def read_dict(self, path):
         """:1117-1165: a stored dictionary, or with 'name/key/subkey' one entry of it."""
-        head, *keys = name.strip('/').split('/')
+        head, *keys = path.strip('/').split('/')
         value = self._read_object(head)
         for k in keys:
             value = value[k]

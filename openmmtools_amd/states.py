@@ -168,7 +168,9 @@ class ThermodynamicState:
     def system(self):
         return self._system
 
-    def get_system(self):
+    def get_system(self, remove_thermostat=False, remove_barostat=False):
+        """states.py:836-870.  A System here holds neither a thermostat nor a barostat force (temperature and pressure live on the
+        state and go to the engine), so there is nothing to remove: the two flags are accepted for the caller's sake."""
         return self._system
 
     @property
@@ -228,8 +230,10 @@ class ThermodynamicState:
             reduced = reduced + pressure * volume
         return beta * reduced
 
-    def reduced_potential(self, sampler_state_or_energy):
-        """Reduced potential of a SamplerState with a cached potential energy, or of an energy in kJ/mol."""
+    def reduced_potential(self, context_state):
+        """states.py:932-992.  Reduced potential of a SamplerState with a cached potential energy, or of an energy in kJ/mol (the
+        reference also takes an openmm.Context there, hence the argument's name)."""
+        sampler_state_or_energy = context_state
         if isinstance(sampler_state_or_energy, SamplerState):
             energy = sampler_state_or_energy.potential_energy
             volume = sampler_state_or_energy.volume
@@ -239,8 +243,9 @@ class ThermodynamicState:
             energy, volume = float(sampler_state_or_energy), None
         return self._compute_reduced_potential(energy, self._temperature, volume, self.pressure)
 
-    def is_state_compatible(self, other):
+    def is_state_compatible(self, thermodynamic_state):
         """states.py:994-1050: same standard system and same ensemble."""
+        other = thermodynamic_state
         return (self._system is other._system or self._system.fingerprint() == other._system.fingerprint()) \
             and (self.pressure is None) == (other.pressure is None)
 
@@ -248,6 +253,10 @@ class ThermodynamicState:
         # Systems are treated as immutable once wrapped (the reference deep-copies and re-hashes)
         new = copy.copy(self)
         return new
+
+
+class AlchemicalStateError(ValueError):
+    """alchemy.py:60-62 (a ValueError here as well: what this class raised before it had a name of its own)."""
 
 
 class AlchemicalState:
@@ -272,11 +281,30 @@ class AlchemicalState:
         self.lambda_sterics = v
         self.lambda_electrostatics = v
 
+    _PARAMETERS = ('lambda_sterics', 'lambda_electrostatics')
+
     @classmethod
-    def from_system(cls, system):
+    def from_system(cls, system, *args, **kwargs):
+        """alchemy.py:203-231: the state a System's alchemical parameters stand at (those written by apply_to_system, else the
+        interacting end state the factory creates); a System without an alchemical region has none."""
         if getattr(system, 'alchemical_region', None) is None:
-            raise ValueError('system has no alchemical region')
-        return cls()
+            raise AlchemicalStateError('system has no alchemical region')
+        stored = getattr(system, 'alchemical_parameters', None) or {}
+        return cls(*args, **dict({k: stored.get(k, 1.0) for k in cls._PARAMETERS}, **kwargs))
+
+    def apply_to_system(self, system):
+        """alchemy.py:354-373: the System's own alchemical parameters (what a state read back with from_system starts from) set to
+        this state's.  The engine takes lambdas from the thermodynamic states, not from the System."""
+        if getattr(system, 'alchemical_region', None) is None:
+            raise AlchemicalStateError('system has no alchemical region')
+        system.alchemical_parameters = {k: float(getattr(self, k)) for k in self._PARAMETERS}
+
+    def check_system_consistency(self, system):
+        """alchemy.py:375-393: AlchemicalStateError unless the System's alchemical parameters equal this state's."""
+        other = type(self).from_system(system)
+        for k in self._PARAMETERS:
+            if float(getattr(other, k)) != float(getattr(self, k)):
+                raise AlchemicalStateError('system has %s = %r, the state %r' % (k, getattr(other, k), getattr(self, k)))
 
 
 class CompoundThermodynamicState(ThermodynamicState):

@@ -2,8 +2,8 @@
 reference's names, argument meaning and defaults so that a user's script runs unchanged).
 
 openmm is absent here, so the reference modules cannot be imported; signatures are syntax.  For every class of the reference modules
-listed in MODULES that this package mirrors, this script takes the argument names and default expressions of `__init__` and of the
-public methods listed in METHODS out of the syntax tree, evaluates each default in a namespace with a unit table written out here
+listed in MODULES, this script takes the argument names and default expressions of `__init__` and of every public method (properties
+aside) out of the syntax tree, evaluates each default in a namespace with a unit table written out here
 (MD unit system: nm, ps, amu, kJ/mol, K), numpy and the module's own simple constants, and stores source text + value (when the
 expression evaluates to a plain number / string / bool / None) in tests/golden/reference_signatures.json.
 tests/test_signatures.py compares this package's signatures.     usage: python tests/golden/make_golden_signatures.py"""
@@ -35,6 +35,10 @@ class unit:
     atmospheres = atmosphere = 101325.0 * 6.02214076e23 * 1.0e-30
     elementary_charge = 1.0
     dimensionless = 1.0
+
+
+def _is_property(fn):
+    return any((isinstance(d, ast.Name) and d.id == 'property') or (isinstance(d, ast.Attribute) and d.attr in ('setter', 'getter', 'deleter')) for d in fn.decorator_list)
 
 
 def signature(fn, ns):
@@ -81,7 +85,7 @@ def main():
                 continue
             sigs = {}
             for fn in node.body:
-                if isinstance(fn, ast.FunctionDef) and fn.name in METHODS:
+                if isinstance(fn, ast.FunctionDef) and (fn.name in METHODS or not fn.name.startswith('_')) and not _is_property(fn):
                     sigs[fn.name] = dict(signature(fn, ns), line=fn.lineno)
                     n_sig += 1
             # the coded errors of states.py: the tuple of names unpacked from range(n) and the message table

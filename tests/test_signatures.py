@@ -1,5 +1,5 @@
 """The mirror keeps the reference's public signatures (same names, argument meaning, defaults, error behaviour):
-tests/golden/reference_signatures.json holds `__init__` and the public entry points of every class of the reference's integrators /
+tests/golden/reference_signatures.json holds `__init__` and every public method of every class of the reference's integrators /
 mcmc / states / alchemy / multistate modules, taken out of the syntax tree with every default evaluated in the MD unit system
 (tests/golden/make_golden_signatures.py).  For every class this package mirrors: each argument of the reference exists here under the
 same name (or is swallowed by **kwargs), every default that is a plain value is the same value, and the coded errors of states.py carry
@@ -28,6 +28,25 @@ NOT_MIRRORED = {
                     'NoseHooverChainVelocityVerletIntegrator', 'PeriodicNonequilibriumIntegrator', 'ThermostatedIntegrator',
                     'PrettyPrintableIntegrator', 'RestorableIntegrator'},
     'states': {'GlobalParameterFunction', 'GlobalParameterState', 'GlobalParameterError', 'IComposableState'},
+    'alchemy': {'AlchemicalFunction'},
+}
+
+
+# public methods of mirrored classes that have no counterpart here, and why
+_CONTEXT = 'works on an openmm.Context: the engine handle is the counterpart (SURVEY.md a15), states are handed to it by the sampler'
+NOT_MIRRORED_METHODS = {
+    'ThermodynamicState': {'apply_to_context': _CONTEXT, 'create_context': _CONTEXT, 'is_context_compatible': _CONTEXT,
+                           'reduced_potential_at_states': _CONTEXT + ' (module function states.reduced_potential_at_states is mirrored)',
+                           'set_system': 'a state is built on its System; replacing it means building a new state'},
+    'CompoundThermodynamicState': {'apply_to_context': _CONTEXT, 'is_context_compatible': _CONTEXT, 'set_system': 'as ThermodynamicState'},
+    'SamplerState': {'apply_to_context': _CONTEXT, 'from_context': _CONTEXT, 'is_context_compatible': _CONTEXT, 'update_from_context': _CONTEXT},
+    'LangevinIntegrator': {k: 'reads / resets global variables of an openmm.CustomIntegrator; heat and shadow work are accumulated on the device '
+                              'and reported per replica through the move (mcmc.LangevinSplittingDynamicsMove measure_heat / measure_shadow_work)'
+                           for k in ('get_acceptance_rate', 'get_heat', 'get_shadow_work', 'reset', 'reset_ghmc_statistics', 'reset_heat', 'reset_shadow_work')},
+    'AlchemicalState': dict({'apply_to_context': _CONTEXT},
+                            **{k: 'alchemical variables and functions of them (alchemy.AlchemicalFunction): lambdas are set directly, protocol by protocol'
+                               for k in ('get_alchemical_variable', 'get_function_variable', 'set_alchemical_variable', 'set_function_variable')}),
+    'AbsoluteAlchemicalFactory': {'get_energy_components': 'energy decomposition by force group of an openmm.Context (a diagnostic outside the hot path)'},
 }
 
 
@@ -57,7 +76,9 @@ def test_signature_follows_the_reference(mod, cls):
             err = C(ref[0]['number'])
             assert err.code == ref[0]['number'] and str(err) == ref[0]['message']
             continue
-        assert hasattr(C, meth), (mod, cls, meth, 'method missing')
+        if not hasattr(C, meth):
+            assert meth in NOT_MIRRORED_METHODS.get(cls, ()), (mod, cls, meth, 'method neither mirrored nor listed with a reason')
+            continue
         sig = inspect.signature(getattr(C, meth))
         swallows = any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values())
         for a in ref['arguments']:
@@ -107,3 +128,22 @@ def test_thermodynamic_state_volume_follows_the_reference():
     npt = states.ThermodynamicState(lj.system, 120.0 * unit.kelvin, 1.0 * unit.atmosphere)
     assert npt.volume is None and np.isclose(npt.get_volume(ignore_ensemble=True), np.prod(edges), rtol=1e-12)
     assert states.ThermodynamicState(testsystems.HarmonicOscillator().system, 300.0).volume is None
+
+
+def test_alchemical_state_and_its_system():
+    """alchemy.py:203-231, 354-393: from_system / apply_to_system / check_system_consistency, reachable as alchemy.AlchemicalState."""
+    from openmmtools_amd import alchemy, testsystems
+    assert alchemy.AlchemicalState is importlib.import_module('openmmtools_amd.states').AlchemicalState
+    lj = testsystems.LennardJonesFluid(nparticles=216)
+    with pytest.raises(alchemy.AlchemicalStateError):
+        alchemy.AlchemicalState.from_system(lj.system)                          # no alchemical region
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, alchemy.AlchemicalRegion(alchemical_atoms=[0, 1]))
+    state = alchemy.AlchemicalState.from_system(system)
+    assert (state.lambda_sterics, state.lambda_electrostatics) == (1.0, 1.0)     # the factory's System is fully interacting
+    state.check_system_consistency(system)
+    state.lambda_sterics = 0.25
+    with pytest.raises(alchemy.AlchemicalStateError):
+        state.check_system_consistency(system)
+    state.apply_to_system(system)
+    state.check_system_consistency(system)
+    assert alchemy.AlchemicalState.from_system(system).lambda_sterics == 0.25
