@@ -66,6 +66,29 @@ class Recorder:
     def endBlock(self): self.program.append(['end'])
 
 
+class PlainRecorder(Recorder):
+    """openmm.CustomIntegrator(timestep): what VelocityVerletIntegrator derives from"""
+    def __init__(self, timestep):
+        self.program, self.globals, self.per_dof = [], {}, []
+        self.dt = float(timestep)
+
+
+class mm:
+    CustomIntegrator = PlainRecorder
+
+
+def other_reference_classes(names):
+    """further integrator classes of the module, executed the same way (their bases: ThermostatedIntegrator or mm.CustomIntegrator)"""
+    tree = ast.parse(open(SRC).read())
+    ns = dict(np=np, numpy=np, re=re, unit=unit, logger=None, mm=mm, openmm=mm, ThermostatedIntegrator=Recorder)
+    out = {}
+    for name in names:
+        cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == name)
+        exec(compile(ast.Module(body=[cls], type_ignores=[]), SRC, 'exec'), ns)
+        out[name] = (ns[name], (cls.lineno, cls.end_lineno))
+    return out
+
+
 def reference_class():
     tree = ast.parse(open(SRC).read())
     thermo = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'ThermostatedIntegrator')
@@ -129,7 +152,7 @@ def _expr(text):
     return text.replace('^', '**')
 
 
-def interpret(rec, chain, x, v, n_steps, noise, uniforms):
+def interpret(rec, chain, x, v, n_steps, noise, uniforms, keep=('heat', 'shadow_work', 'naccept', 'ntrials', 'nreject')):
     """OpenMM's CustomIntegrator semantics for the recorded program; returns per-step (x, v) and the globals at the end of each step"""
     N = x.shape[0]
     m = np.asarray(MASSES, dtype=np.float64)[:, None]
@@ -200,7 +223,7 @@ def interpret(rec, chain, x, v, n_steps, noise, uniforms):
                 raise ValueError(op)
             pc += 1
         assert not gauss and not unif, 'noise prepared for this step was not consumed'
-        out.append(dict(x=x.tolist(), v=v.tolist(), **{k: g[k] for k in ('heat', 'shadow_work', 'naccept', 'ntrials', 'nreject') if k in g}))
+        out.append(dict(x=x.tolist(), v=v.tolist(), **{k: g[k] for k in keep if k in g}))
     return out
 
 
@@ -233,6 +256,26 @@ def main():
                                  noise=[[n.tolist() for n in s] for s in noise], uniforms=uniforms, trajectory=traj))
         print('%-22s %2d program lines; a = %.12f b = %.12f; |x| after %d steps %.9f' % (
             splitting, len(rec.program), rec.globals['a'], rec.globals['b'], N_STEPS, float(np.abs(np.array(traj[-1]['x'])).sum())))
+    # velocity Verlet and hybrid Monte Carlo: programs of their own in the reference (integrators.py:456-498, 885-1010); this package runs
+    # them as the splittings 'V R V' and 'O { (V R V)^n }' of the same chain kernel -- the fixture holds what the reference's programs do
+    others = other_reference_classes(['VelocityVerletIntegrator', 'HMCIntegrator'])
+    out['other_integrators'] = []
+    for name, kwargs in (('VelocityVerletIntegrator', dict(timestep=DT)), ('HMCIntegrator', dict(temperature=TEMPERATURE, nsteps=3, timestep=0.002)),
+                         ('HMCIntegrator', dict(temperature=TEMPERATURE, nsteps=2, timestep=0.003))):
+        cls, lines_ = others[name]
+        rec = cls(**kwargs)
+        if 'kT' not in rec.globals:
+            rec.globals['kT'] = KB * TEMPERATURE                        # (velocity Verlet has no temperature; the interpreter wants the name)
+        hmc = name == 'HMCIntegrator'
+        noise = [[md_oracle.gaussians3(SEED, md_oracle.STREAM_OU, np.arange(4), REPLICA, step)] if hmc else [] for step in range(N_STEPS)]
+        uniforms = []
+        for step in range(N_STEPS):
+            w = md_oracle.draw(SEED, md_oracle.STREAM_METROPOLIS, 0, REPLICA, step)
+            uniforms.append([((int(w[2]) << 21) | (int(w[3]) >> 11)) / 9007199254740992.0] if hmc else [])
+        traj = interpret(rec, chain, x0, v0, N_STEPS, noise, uniforms, keep=('naccept', 'ntrials', 'accept', 'Eold', 'Enew'))
+        out['other_integrators'].append(dict(name=name, kwargs=kwargs, source='openmmtools/integrators.py:%d-%d' % lines_, program=rec.program,
+                                             noise=[[n.tolist() for n in s_] for s_ in noise], uniforms=uniforms, trajectory=traj))
+        print('%-26s %-44s %2d program lines; accepted %s' % (name, kwargs, len(rec.program), [int(t['accept']) for t in traj] if hmc else '-'))
     with open(OUT, 'w') as fh:
         json.dump(out, fh, separators=(',', ':'))
     print('wrote', OUT, os.path.getsize(OUT), 'bytes')

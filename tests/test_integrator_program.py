@@ -115,3 +115,31 @@ def test_cpu_port_follows_the_references_program(k):
     if not os.path.exists(CPU_LIB):
         oracle.build()
     check_engine(lambda: HipEngine(lib_path=CPU_LIB), k, 1e-11, 1e-9, 1e-6, mts=False)
+
+
+@pytest.mark.parametrize('k', range(len(G['other_integrators'])))
+def test_velocity_verlet_and_hmc_as_splittings_of_the_same_chain(k):
+    """integrators.py:456-498 VelocityVerletIntegrator and :885-1010 HMCIntegrator are programs of their own in the reference; this
+    package runs them as the splittings 'V R V' and 'O { (V R V)^n }' (openmmtools_amd/integrators.py).  Against the reference's
+    programs executed: positions after every step, the Metropolis decisions, the energy change the test is made on; velocities after
+    every ACCEPTED step.  After a rejected trajectory the reference keeps the velocities the trajectory ended with and this package
+    hands back the negated start velocities (what the reference's own Langevin '}' does) -- both are discarded by the next step's draw."""
+    from openmmtools_amd import integrators
+    c = G['other_integrators'][k]
+    mine = getattr(integrators, c['name'])(**c['kwargs'])
+    desc = system_to_desc(_system())
+    integ = md_oracle.OracleLangevin(ForceFieldOracle(desc), mine.splitting, float(mine.getStepSize()), float(mine._gamma), 1, G["seed"], cmm_frequency=0)
+    hmc = c['name'] == 'HMCIntegrator'
+    if hmc:
+        integ.work = dict(heat=0.0, shadow_work=0.0, n_accepted=0, n_trials=0)
+    x, v = np.array(G['x0']), np.array(G['v0'])
+    kT = G['kB'] * G['temperature']
+    for s, want in enumerate(c['trajectory']):
+        before = dict(integ.work) if hmc else None
+        x, v = integ.run(x, v, None, kT, G['replica'], s, first_step=0, n_steps=1)
+        assert np.allclose(x, want['x'], rtol=0, atol=1e-12), (c['name'], s, np.abs(x - np.array(want['x'])).max())
+        if not hmc or want['accept'] == 1.0:
+            assert np.allclose(v, want['v'], rtol=0, atol=1e-10), (c['name'], s, np.abs(v - np.array(want['v'])).max())
+        if hmc:
+            assert integ.work['n_trials'] == int(want['ntrials']) and integ.work['n_accepted'] == int(want['naccept'])
+            assert (integ.work['n_accepted'] - before['n_accepted']) == int(want['accept'])
