@@ -272,3 +272,22 @@ def test_copy_replicas_between_device_handles(hip_engine_factory):
     a.copy_replicas([3, 1], b, [0, 1], 3)                  # and back into the master
     xa2 = a.get_replicas()[0]
     assert np.array_equal(xa2[[3, 1]], b.get_replicas()[0]) and np.array_equal(xa2[[0, 2]], xa[[0, 2]])
+
+
+def test_group_by_compatibility_is_the_references_function():
+    """states.py:186-217 executed from the reference's source on stand-in states (tests/golden/make_golden_group_by_compatibility.py):
+    same groups, same order, same original indices."""
+    import json
+    import os
+    from openmmtools_amd import states as st
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'group_by_compatibility_reference.json')))
+
+    class State:
+        def __init__(self, kind, index):
+            self.kind, self.index = kind, index
+
+        def is_state_compatible(self, other):
+            return self.kind == other.kind
+    for c in G['cases']:
+        groups, indices = st.group_by_compatibility([State(k, i) for i, k in enumerate(c['kinds'])])
+        assert [[s.index for s in g] for g in groups] == c['groups'] and [list(i) for i in indices] == c['original_indices'], c
