@@ -371,3 +371,62 @@ def test_setters_and_default_options_follow_the_reference_rules():
     assert 'online_analysis_interval' in d and 'engine' not in d
     assert SAMSSampler.default_options()['state_update_scheme'] == 'global-jump'
     s.energy_context_cache = object()                              # accepted and unused (the engine is the context pool)
+
+
+def test_run_loop_calls_its_steps_in_the_references_order():
+    """multistatesampler.py:724-821 run / extend, :1720-1739 _is_completed, :1766-1803 _update_timing EXECUTED from the reference's source
+    on a stand-in whose steps log their names (tests/golden/make_golden_run_loop.py): this package's sampler, with the same steps
+    logged, makes the same calls in the same order -- what iteration 0 does first, how run(n) / extend(n) bound the iterations, when
+    the online analysis's error target ends the run -- and fills the same _timing_data keys with the same arithmetic."""
+    import json
+    import os
+    from oracle_engine import OracleEngine
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'run_loop_reference.json')))
+    steps = ('_compute_energies', '_check_nan_energy', '_mix_replicas', '_propagate_replicas', '_report_iteration', '_update_analysis')
+    ho, ts, ss = _ho_states(1)
+    sts = [states.ThermodynamicState(ho.system, T * unit.kelvin) for T in (300.0, 350.0)]
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=5.0 / unit.picosecond, n_steps=5)
+
+    def make(iteration, n_iter, target=0.0, errors=()):
+        s = MultiStateSampler(mcmc_moves=move, number_of_iterations=n_iter, engine=OracleEngine(), seed=5, online_analysis_interval=None,
+                              online_analysis_target_error=target)
+        s.create(sts, [ss], storage=None)
+        log, errs = [], list(errors)
+        if iteration:
+            s.run(iteration) if iteration <= n_iter else s.extend(iteration)
+        assert s.iteration == iteration
+        for name in steps:
+            def wrapped(*a, _orig=getattr(s, name), _name=name, **kw):
+                log.append(_name)
+                out = _orig(*a, **kw)
+                if _name == '_update_analysis' and errs:
+                    s._last_err_free_energy = errs.pop(0)
+                return out
+            setattr(s, name, wrapped)
+        return s, log
+    calls = {'run(2) from iteration 0 of 5': (lambda: make(0, 5), lambda s: s.run(2)),
+             'run() from iteration 3 of 5': (lambda: make(3, 5), lambda s: s.run()),
+             'run(10) from iteration 4 of 5': (lambda: make(4, 5), lambda s: s.run(10)),
+             'extend(2) at iteration 5 of 5': (lambda: make(5, 5), lambda s: s.extend(2)),
+             'run() of 6 with an error target reached after the 2nd analysis': (lambda: make(0, 6, target=0.5, errors=[0.9, 0.4, 0.1]), lambda s: s.run())}
+    for c in G['cases']:
+        build, call = calls[c['label']]
+        s, log = build()
+        call(s)
+        want = [x for x in c['calls'] if x != 'reporter.write_energies']          # (no reporter in this run: storage=None)
+        assert log == want, (c['label'], log, want)
+        assert s.iteration == c['iteration'] and s.number_of_iterations == c['number_of_iterations'], c['label']
+        assert set(c['timing_keys']) <= set(s._timing_data), (c['label'], sorted(s._timing_data))
+    # the arithmetic of _update_timing on the reference's example (two moves of 500 x 2 fs; 1.5 s for 2 iterations; limit 10)
+    e = G['timing_example']
+    s, _ = make(0, 10)
+    s._mcmc_moves = [mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, n_steps=500)] * 2
+    s._iteration = e['iteration']
+    import time as _time
+    now = _time.time()
+    s._update_timing(now - e['iteration_time'], now, now, now, now - e['partial_total_time'], e['run_initial_iteration'], e['iteration_limit'])
+    for k, v in e['timing_data'].items():
+        if isinstance(v, float):
+            assert np.isclose(s._timing_data[k], v, rtol=2e-2), (k, s._timing_data[k], v)          # (wall clock in between)
+        else:
+            assert s._timing_data[k].split('.')[0] == v.split('.')[0], (k, s._timing_data[k], v)
