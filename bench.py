@@ -273,7 +273,10 @@ def finish_line(out, rank, shapes_fn, limit_s, write=None, end_process=None):
         dog = threading.Timer(limit_s, expired)
         dog.daemon = True
         dog.start()
-        shapes_fn(shapes)
+        try:
+            shapes_fn(shapes)
+        except Exception as exc:                       # (whatever happens in the extras, the line is printed)
+            shapes['error'] = '%s: %s' % (type(exc).__name__, exc)
         dog.cancel()
     emit()
 

@@ -46,3 +46,14 @@ def test_a_stalled_shape_does_not_take_the_line_down():
     line = json.loads(got[0])
     assert line['value'] == 12.0 and line['shapes']['strong128_alanine'] == {'value': 14.0}
     assert 'did not finish' in line['shapes']['watchdog']
+
+
+def test_an_exception_in_the_shapes_is_reported_in_the_line():
+    got = []
+    def shapes(d):
+        d['strong128_alanine'] = dict(value=14.0)
+        raise RuntimeError('device gone')
+    bench.finish_line(_line(), 0, shapes, 5.0, write=got.append, end_process=lambda: got.append('END'))
+    assert len(got) == 1
+    line = json.loads(got[0])
+    assert line['value'] == 12.0 and line['shapes']['strong128_alanine'] == {'value': 14.0} and 'device gone' in line['shapes']['error']
