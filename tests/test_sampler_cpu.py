@@ -430,3 +430,34 @@ def test_run_loop_calls_its_steps_in_the_references_order():
             assert np.isclose(s._timing_data[k], v, rtol=2e-2), (k, s._timing_data[k], v)          # (wall clock in between)
         else:
             assert s._timing_data[k].split('.')[0] == v.split('.')[0], (k, s._timing_data[k], v)
+
+
+def test_compute_energies_refreshes_what_the_references_method_refreshes():
+    """multistatesampler.py:1437-1494 _compute_energies / _compute_replica_energies and :1263-1281 _neighborhood EXECUTED from the
+    reference's source on a stand-in (tests/golden/make_golden_compute_energies.py): under a locality only the entries of a replica's
+    neighbourhood are refreshed, the others keep the value of the iteration before; the neighbourhood mask; the unsampled states'
+    columns.  This package's method on an engine stand-in that returns the same rows."""
+    import json
+    import os
+    from oracle_engine import OracleEngine
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'compute_energies_reference.json')))
+    ho, ts, ss = _ho_states(1)
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, n_steps=2)
+    for c in G['cases']:
+        K, R, U = c['n_states'], c['n_replicas'], c['n_unsampled']
+        sts = [states.ThermodynamicState(ho.system, (300.0 + 10.0 * k) * unit.kelvin) for k in range(K)]
+        uns = [states.ThermodynamicState(ho.system, (500.0 + 10.0 * k) * unit.kelvin) for k in range(U)]
+        s = MultiStateSampler(mcmc_moves=move, number_of_iterations=1, engine=OracleEngine(), seed=5, locality=c['locality'],
+                              online_analysis_interval=None)
+        s.create(sts, [ss] * R, storage=None, unsampled_thermodynamic_states=uns)
+        s._energy_thermodynamic_states[:, :] = 0.0
+        s._energy_unsampled_states[:, :] = 0.0
+        s._neighborhoods[:, :] = 0
+        for call in c['calls']:
+            s._replica_thermodynamic_states = np.array(call['labels'])
+            s._engine.compute_energies = lambda *a, _full=np.array(call['full']), **kw: _full.copy()
+            s._compute_energies()
+            assert np.array_equal(np.asarray(s._energy_thermodynamic_states), np.array(call['energy_thermodynamic_states'])), (c['locality'], call['labels'])
+            assert np.array_equal(np.asarray(s._neighborhoods).astype(int), np.array(call['neighborhoods'])), (c['locality'], call['labels'])
+            if U:
+                assert np.array_equal(np.asarray(s._energy_unsampled_states), np.array(call['energy_unsampled_states']))
