@@ -21,16 +21,13 @@ class SAMSSampler(ReplicaExchangeSampler):
                  logZ_guess=None, **kwargs):
         kwargs.pop('replica_mixing_scheme', None)
         super().__init__(number_of_iterations=number_of_iterations, replica_mixing_scheme=None, **kwargs)
-        if state_update_scheme != 'global-jump':
-            raise ValueError("state_update_scheme must be 'global-jump' (sams.py:241-246)")
-        if update_stages not in ('one-stage', 'two-stage'):
-            raise ValueError('update_stages must be one-stage or two-stage')
-        if flatness_criteria not in ('logZ-flatness', 'minimum-visits', 'histogram-flatness'):
-            raise ValueError('unknown flatness_criteria')
-        if weight_update_method not in ('optimal', 'rao-blackwellized'):
-            raise ValueError('unknown weight_update_method')
-        if adapt_target_probabilities:
-            raise ValueError("Unknown update scheme '{}'. Supported values are {}.".format(adapt_target_probabilities, [False]))   # sams.py:273-278
+        # sams.py:237-278: one validator per option, all with the same sentence (tests/test_sampler_cpu.py holds the texts to the
+        # reference's validators executed from its source)
+        for value, supported in ((state_update_scheme, ['global-jump']), (update_stages, ['one-stage', 'two-stage']),
+                                 (flatness_criteria, ['minimum-visits', 'logZ-flatness', 'histogram-flatness']),
+                                 (weight_update_method, ['optimal', 'rao-blackwellized']), (adapt_target_probabilities, [False])):
+            if value not in supported:
+                raise ValueError("Unknown update scheme '{}'. Supported values are {}.".format(value, supported))
         self.log_target_probabilities = log_target_probabilities
         self.state_update_scheme = state_update_scheme
         self.locality = None                      # global-jump forces global neighbourhoods (:338-339)
@@ -38,6 +35,7 @@ class SAMSSampler(ReplicaExchangeSampler):
         self.flatness_criteria = flatness_criteria
         self.flatness_threshold = flatness_threshold
         self.weight_update_method = weight_update_method
+        self.adapt_target_probabilities = adapt_target_probabilities          # sams.py:287 (only False passes its validator)
         self.gamma0 = gamma0
         self.logZ_guess = logZ_guess
         self._cached_state_histogram = None

@@ -461,3 +461,20 @@ def test_compute_energies_refreshes_what_the_references_method_refreshes():
             assert np.array_equal(np.asarray(s._neighborhoods).astype(int), np.array(call['neighborhoods'])), (c['locality'], call['labels'])
             if U:
                 assert np.array_equal(np.asarray(s._energy_unsampled_states), np.array(call['energy_unsampled_states']))
+
+
+def test_sams_option_validators_are_the_references():
+    """sams.py:237-278 executed from the reference's source (tests/golden/make_golden_sams_validators.py): what each option accepts, and
+    the ValueError text for what it does not."""
+    import json
+    import os
+    from openmmtools_amd.multistate import SAMSSampler
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sams_validators_reference.json')))
+    for option, rows in G['options'].items():
+        for row in rows:
+            if 'error' in row:
+                with pytest.raises(ValueError) as e:
+                    SAMSSampler(**{option: row['value']})
+                assert str(e.value) == row['error'], (option, row, str(e.value))
+            else:
+                assert getattr(SAMSSampler(**{option: row['value']}), option) == row['returns']
