@@ -26,7 +26,7 @@ class AlchemicalRegion:
                  softcore_alpha=0.5, softcore_a=1, softcore_b=1, softcore_c=6, softcore_beta=0.0,
                  softcore_d=1, softcore_e=1, softcore_f=2, name=None):
         if not alchemical_atoms:
-            raise ValueError('alchemical_atoms must be a non-empty list')
+            raise ValueError('The AlchemicalRegion is empty.')                      # alchemy.py:899-900 (raised there when the region is resolved)
         if (softcore_beta, softcore_d, softcore_e) != (0.0, 1, 1):
             raise NotImplementedError('softcore electrostatics (only the exact PME treatment is implemented)')
         self.alchemical_atoms = sorted(int(a) for a in alchemical_atoms)
@@ -41,6 +41,10 @@ class AbsoluteAlchemicalFactory:
     def __init__(self, consistent_exceptions=False, switch_width=0.1, alchemical_pme_treatment='exact',
                  alchemical_rf_treatment='switched', disable_alchemical_dispersion_correction=False,
                  split_alchemical_forces=True):
+        if alchemical_pme_treatment not in ('exact', 'direct-space', 'coulomb'):
+            raise ValueError(f"Unknown alchemical_pme_treatment scheme '{alchemical_pme_treatment}'")     # alchemy.py:1455
+        if alchemical_rf_treatment not in ('switched', 'shifted'):
+            raise ValueError(f"Unknown alchemical_rf_treatment scheme '{alchemical_rf_treatment}'")       # alchemy.py:1501
         if alchemical_pme_treatment != 'exact':
             raise NotImplementedError("only alchemical_pme_treatment='exact' (the reference default, alchemy.py:628)")
         self.disable_alchemical_dispersion_correction = disable_alchemical_dispersion_correction

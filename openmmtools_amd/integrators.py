@@ -93,15 +93,18 @@ class LangevinIntegrator:
                 if t == '{' and '}' not in tokens:
                     raise ValueError('Use of { must be followed by }')                       # :1356-1357
                 depth += 1 if t == '{' else -1
-                if depth < 0 or depth > 1:
+                if depth > 1:
                     raise ValueError('There can only be one Metropolized region.')          # :1371-1374
+                if depth < 0:      # a '}' in front of its '{': the reference's verdict on 'O } V R V { O' (:1358-1359 through :1376-1402)
+                    raise ValueError('Shadow work generating steps found outside the Metropolization block')
                 continue
-            if t[0] not in 'ORV':
-                raise ValueError("Invalid step name '%s' used; valid step names are R, V, O, { and }" % t)
-            if t[0] != 'V' and len(t) > 1:
-                raise ValueError("Invalid step name '%s'" % t)
+            allowed_characters = "0123456789" + "O" + "R" + "{" + "}" + "V"              # :1336-1340: digits + the dispatch table's keys in its order
+            if t[0] not in 'ORV' or (t[0] != 'V' and len(t) > 1):
+                raise ValueError("Invalid step name '{}' used; valid step names are {}".format(t, allowed_characters))   # :1358
             if t[0] == 'V' and len(t) > 1 and not (t[1:].isdigit() and int(t[1:]) <= 31):
-                raise ValueError('You must use an integer force group')                      # :1343-1351 (32 groups at most)
+                # :1343-1350: the reference's "OpenMM only allows up to 32 force groups" is raised inside the try whose except
+                # turns every ValueError into this sentence, so this is what a user sees for V32 as well
+                raise ValueError("You must use an integer force group")
             if t[0] == 'O' and depth > 0:
                 raise ValueError('O steps cannot be inside the Metropolization block')
             if t[0] in 'RV' and has_braces and depth == 0:

@@ -38,6 +38,8 @@ class MultiStateSampler:
                 raise ValueError('online_analysis_target_error must be a float >= 0')
             if type(online_analysis_minimum_iterations) is not int or online_analysis_minimum_iterations < 0:
                 raise ValueError('online_analysis_minimum_iterations must be an integer >= 0')
+        if not (0 <= number_of_iterations <= float('inf')):                              # :469-475 (the text is the reference's, run-on included)
+            raise ValueError('Accepted values for number_of_iterations are' 'non-negative integers and infinity.')
         if mcmc_moves is None:
             # multistatesampler.py:224-227
             self._mcmc_moves = mcmc.LangevinDynamicsMove(timestep=2.0 * unit.femtosecond,
@@ -212,6 +214,8 @@ class MultiStateSampler:
         rep = MultiStateReporter(storage) if isinstance(storage, (str, bytes, os.PathLike)) else storage
         was_open = rep.is_open()
         if not was_open:
+            if not rep.storage_exists():                                        # :1163-1166
+                raise FileNotFoundError('Storage file {} or its subfiles do not exist; cannot read status.'.format(rep.filepath))
             rep.open('r')
         try:
             opts = rep.read_dict('options')
@@ -349,6 +353,8 @@ class MultiStateSampler:
         from .multistatereporter import MultiStateReporter
         rep = MultiStateReporter(storage) if isinstance(storage, (str, bytes, os.PathLike)) else storage
         if not rep.is_open():
+            if not rep.storage_exists():                                        # :1163-1166
+                raise FileNotFoundError('Storage file {} or its subfiles do not exist; cannot read status.'.format(rep.filepath))
             rep.open('a')
         it = rep.read_last_iteration(last_checkpoint=True)
         if it is None:
@@ -920,7 +926,7 @@ class MultiStateSampler:
         for position, move in enumerate(program):
             if isinstance(move, mcmc.MonteCarloBarostatMove):
                 if not getattr(self, '_npt', False):
-                    raise RuntimeError('Requested a MonteCarloBarostat move on a system at constant volume')   # mcmc.py:1673-1676
+                    raise RuntimeError('Requested a MonteCarloBarostat move' ' on a system at constant pressure')   # mcmc.py:1673-1676 (the reference's wording: it means a state without a barostat)
                 self._engine.barostat_attempts(move.n_attempts)
                 self._sampler_states_stale = True
                 continue

@@ -277,7 +277,7 @@ class AlchemicalState:
         """alchemy.py:247-262: every alchemical parameter this state controls to ``new_value``."""
         v = float(new_value)
         if not 0.0 <= v <= 1.0:
-            raise ValueError('alchemical parameters lie in [0, 1]')
+            raise ValueError('{} must be between 0 and 1.'.format('lambda_sterics'))     # alchemy.py:216-218: the first parameter's validator speaks
         self.lambda_sterics = v
         self.lambda_electrostatics = v
 

@@ -43,7 +43,7 @@ if __name__ == '__main__':
             counts, mts, n_v = Stub()._parse_splitting_string(s)
             cases.append(dict(splitting=s, ok=True, counts=counts, mts=mts, n_v=n_v))
         except Exception as exc:                                   # noqa: BLE001 -- the TYPE is the datum
-            cases.append(dict(splitting=s, ok=False, error=type(exc).__name__))
+            cases.append(dict(splitting=s, ok=False, error=type(exc).__name__, message=str(exc)))
     with open(OUT, 'w') as fh:
         json.dump(dict(source='openmmtools/integrators.py:1319-1402, 1474-1537 executed from /root/reference', cases=cases), fh, indent=1)
     for c in cases:

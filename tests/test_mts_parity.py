@@ -147,3 +147,5 @@ def test_host_parser_agrees_with_the_reference_parser_run_on_the_same_strings():
                 integrators.LangevinIntegrator(splitting=s)
             if not c['ok'] and c['error'] in ('ValueError', 'AssertionError'):
                 assert type(err.value).__name__ == c['error'], (s, c['error'], err.value)
+                if c['error'] == 'ValueError':
+                    assert str(err.value) == c['message'], (s, str(err.value), c['message'])          # the sentence too
