@@ -114,6 +114,8 @@ class MultiStateReporter:
         # multistatereporter.py:141-149: a checkpoint name is relative to the analysis file's directory (an absolute path stays)
         self._storage_checkpoint = (os.path.join(os.path.dirname(self._storage_analysis), str(checkpoint_storage)) if checkpoint_storage
                                     else stem + '_checkpoint')
+        if type(checkpoint_interval) != int:                                   # multistatereporter.py:141-142
+            raise ValueError("checkpoint_interval must be an integer!")
         self._checkpoint_interval = int(checkpoint_interval)
         self._analysis_particle_indices = tuple(int(i) for i in analysis_particle_indices)
         # multistatereporter.py:133-134, 1686-1692: how often the analysis file gets the flagged particles' positions / velocities
@@ -217,7 +219,7 @@ class MultiStateReporter:
             self._open_mode = 'r'
             return
         if mode == 'r' and not self.storage_exists():
-            raise IOError('no storage at {}'.format(self._storage_analysis))
+            raise OSError(f"{self._storage_analysis} does not exist")                 # :419
         if mode == 'w':
             # start a fresh store: remove only the files THIS format owns (never the contents of an unrelated directory)
             for d in (self._storage_analysis, self._storage_checkpoint):

@@ -10,7 +10,7 @@ import re
 ROOT = '/root/reference/openmmtools/'
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_error_messages.json')
 FILES = ['multistate/multistatesampler.py', 'multistate/replicaexchange.py', 'multistate/paralleltempering.py', 'multistate/sams.py',
-         'mcmc.py', 'states.py', 'integrators.py', 'alchemy/alchemy.py']
+         'mcmc.py', 'states.py', 'integrators.py', 'alchemy/alchemy.py', 'multistate/multistatereporter.py']
 
 
 def literal(node):

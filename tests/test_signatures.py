@@ -155,7 +155,8 @@ _MIRROR_SOURCES = {
     'multistate/multistatesampler.py': ['multistate/multistatesampler.py', 'multistate/analysis.py'],
     'multistate/replicaexchange.py': ['multistate/replicaexchange.py'], 'multistate/paralleltempering.py': ['multistate/paralleltempering.py'],
     'multistate/sams.py': ['multistate/sams.py'], 'mcmc.py': ['mcmc.py', 'multistate/multistatesampler.py'], 'states.py': ['states.py'],
-    'integrators.py': ['integrators.py'], 'alchemy/alchemy.py': ['alchemy.py', 'states.py', '_alchemical_xml.py']}
+    'integrators.py': ['integrators.py'], 'alchemy/alchemy.py': ['alchemy.py', 'states.py', '_alchemical_xml.py'],
+    'multistate/multistatereporter.py': ['multistate/multistatereporter.py', 'multistate/_reference_store.py', 'multistate/_netcdf4_write.py']}
 # raises of the reference without a counterpart here: (file, line) -> why
 _NO_COUNTERPART = {}
 for _f, _lines, _why in (
@@ -164,6 +165,7 @@ for _f, _lines, _why in (
         ('mcmc.py', (208, 1678), 'ContextCache type check / a barostat class other than MonteCarloBarostat: there is one engine and one barostat'),
         ('states.py', (946, 1176, 2140, 2153, 2166, 2471, 2917, 3309, 3510), 'openmm.Context plumbing, read-only energies of a Context-backed SamplerState, GlobalParameterState machinery'),
         ('integrators.py', (95, 678, 681, 1257, 1279, 1296, 1347, 1777, 1792, 1983, 2345), 'integrators outside the hot path (Nose-Hoover, nonequilibrium, periodic), accessors of CustomIntegrator globals; :1347 is unreachable in the reference (its except turns it into the integer-group sentence)'),
+        ('multistate/multistatereporter.py', (1179, 1266, 1278, 1484, 1569, 1573), 'netCDF bookkeeping of the reference (dimension redeclaration, the online-analysis group): the readers here raise KeyError / IndexError / ValueError per variable, which is what the sampler handles'),
         ('alchemy/alchemy.py', (662, 686, 694, 709, 1070, 1457, 1628, 1630, 1632, 1970, 2073, 2076, 2091, 2094, 2169, 2263), 'several alchemical regions, virtual sites, Amoeba / GB forces, decoupled or soft-core electrostatics: refused here with NotImplementedError naming the option')):
     for _l in _lines:
         _NO_COUNTERPART[(_f, _l)] = _why
@@ -179,7 +181,7 @@ def _templates_of(path):
 
 
 def test_error_messages_are_the_references():
-    """tests/golden/reference_error_messages.json: every raise of the mirrored reference modules with a literal message (88).  Each
+    """tests/golden/reference_error_messages.json: every raise of the mirrored reference modules with a literal message (99).  Each
     template must occur, character for character (placeholders aside), in a raise of the mirror's corresponding module -- unless the
     raise is listed above as having no counterpart here."""
     import importlib.util
@@ -195,5 +197,5 @@ def test_error_messages_are_the_references():
                 continue
             assert row['template'] in mine, (f, row['line'], row['exception'], row['template'])
             n_same += 1
-    assert n_same >= 43
+    assert n_same >= 47
     assert all(any(r['line'] == l for r in E[f]) for (f, l) in _NO_COUNTERPART), 'a listed raise is not in the fixture (line numbers moved?)'
