@@ -95,6 +95,13 @@ def main():
                     names = [e.id for e in stmt.targets[0].elts]
                 if isinstance(stmt, ast.Assign) and getattr(stmt.targets[0], 'id', '') == 'error_messages' and isinstance(stmt.value, ast.Dict):
                     messages = {k.id: v.value for k, v in zip(stmt.value.keys, stmt.value.values)}
+            # public properties and class-level descriptors (the reference's _StoredProperty options): names only
+            props = sorted({n.name for n in node.body if isinstance(n, ast.FunctionDef) and not n.name.startswith('_')
+                            and any(isinstance(d, ast.Name) and d.id == 'property' for d in n.decorator_list)} |
+                           {t.id for n in node.body if isinstance(n, ast.Assign) and isinstance(n.value, ast.Call) for t in n.targets
+                            if isinstance(t, ast.Name) and not t.id.startswith('_')})
+            if props:
+                sigs['properties'] = props
             if names and messages:
                 sigs['error_codes'] = [dict(name=n, number=i, message=messages[n]) for i, n in enumerate(names)]
             if sigs:

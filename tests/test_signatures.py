@@ -71,6 +71,8 @@ def test_signature_follows_the_reference(mod, cls):
         pytest.skip('%s.%s is outside the hot path (not mirrored)' % (mod, cls))
     C = getattr(ours, cls)
     for meth, ref in G['modules'][mod]['classes'][cls].items():
+        if meth == 'properties':
+            continue                                  # (test_public_properties_exist_on_instances)
         if meth == 'error_codes':
             for e in ref:
                 assert getattr(C, e['name']) == e['number'] and C.error_messages[e['number']] == e['message'], (cls, e)
@@ -199,3 +201,45 @@ def test_error_messages_are_the_references():
             n_same += 1
     assert n_same >= 47
     assert all(any(r['line'] == l for r in E[f]) for (f, l) in _NO_COUNTERPART), 'a listed raise is not in the fixture (line numbers moved?)'
+
+
+def test_public_properties_exist_on_instances():
+    """every public property / stored option of a mirrored class (names from the reference's source) is an attribute of an instance here;
+    the ones without a counterpart are listed with the reason"""
+    from openmmtools_amd import states, testsystems, unit, mcmc, integrators, alchemy
+    from openmmtools_amd.multistate import MultiStateSampler, ReplicaExchangeSampler, SAMSSampler, ParallelTemperingSampler, MultiStateReporter
+    ho = testsystems.HarmonicOscillator()
+    ts = states.ThermodynamicState(ho.system, 300.0 * unit.kelvin)
+    instances = {
+        'ThermodynamicState': ts, 'SamplerState': states.SamplerState(ho.positions),
+        'CompoundThermodynamicState': None, 'AlchemicalState': alchemy.AlchemicalState(),
+        'MultiStateSampler': MultiStateSampler(), 'ReplicaExchangeSampler': ReplicaExchangeSampler(), 'SAMSSampler': SAMSSampler(),
+        'ParallelTemperingSampler': ParallelTemperingSampler(), 'MultiStateReporter': MultiStateReporter('/tmp/never-opened-store'),
+        'LangevinIntegrator': integrators.LangevinIntegrator(), 'HMCIntegrator': integrators.HMCIntegrator(),
+        'LangevinDynamicsMove': mcmc.LangevinDynamicsMove(), 'LangevinSplittingDynamicsMove': mcmc.LangevinSplittingDynamicsMove(),
+        'GHMCMove': mcmc.GHMCMove(), 'HMCMove': mcmc.HMCMove(), 'MonteCarloBarostatMove': mcmc.MonteCarloBarostatMove(),
+        'MCDisplacementMove': mcmc.MCDisplacementMove(), 'MCRotationMove': mcmc.MCRotationMove(),
+    }
+    no_counterpart = {
+        ('LangevinIntegrator', 'heat'), ('LangevinIntegrator', 'shadow_work'), ('LangevinIntegrator', 'acceptance_rate'),   # CustomIntegrator globals:
+        ('HMCIntegrator', 'n_accept'), ('HMCIntegrator', 'n_trials'),                                                        # per replica on the engine (get_work)
+        ('MCMCMove', 'context_cache'), ('SamplerState', 'collective_variables'),                                             # openmm.Context side
+    }
+    checked = 0
+    for mod, m in G['modules'].items():
+        ours = importlib.import_module('openmmtools_amd.' + mod)
+        for cls, sigs in m['classes'].items():
+            if not hasattr(ours, cls) or 'properties' not in sigs:
+                continue
+            obj = instances.get(cls) or getattr(ours, cls)
+            for name in sigs['properties']:
+                if (cls, name) in no_counterpart or any((base.__name__, name) in no_counterpart for base in getattr(ours, cls).__mro__):
+                    continue
+                try:
+                    getattr(obj, name)
+                except AttributeError:
+                    raise AssertionError((mod, cls, name))
+                except Exception:
+                    pass                                  # (it is there; a sampler that was not created yet has nothing to answer with)
+                checked += 1
+    assert checked >= 60
