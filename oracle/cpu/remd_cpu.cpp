@@ -468,7 +468,10 @@ double pme_reciprocal(const System& s, Replica& r, const std::vector<double>& qv
 // ------------------------------------------------------------------------------------------------------------------
 enum { PART_BONDED = 1, PART_STERICS = 2, PART_SOFTCORE = 4, PART_ELEC = 8, PART_ALL = 15 };
 
-Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double* f, FFTSet& fft, int parts = PART_ALL)
+// classes: bit c set = force class c of remd_set_force_groups is evaluated (0 external, 1 bonds, 2 angles, 3 torsions, 4 nonbonded direct space +
+// exceptions + exclusion correction + dispersion constant, 5 PME reciprocal space + self terms): the forces of one force group of a
+// multiple-time-step splitting (integrators.py:1425-1442; same convention as oracle/forcefield.py energy_torch)
+Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double* f, FFTSet& fft, int parts = PART_ALL, int classes = 63)
 {
     Energy E;
     const int N = s.N;
@@ -479,14 +482,14 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
         for (int k = 0; k < 3; ++k) { d[k] = x[3 * j + k] - x[3 * i + k]; if (periodic) d[k] = min_image(d[k], r.box[k]); }
     };
     if (parts & PART_BONDED) {
-        if (!s.ext_atoms.empty()) {                                   // testsystems.py:779-786
+        if (!s.ext_atoms.empty() && (classes & 1)) {                  // testsystems.py:779-786
             for (int i : s.ext_atoms) {
                 const double dx[3] = {x[3 * i] - s.ext_x0, x[3 * i + 1], x[3 * i + 2]};
                 E.c[0] += 0.5 * s.ext_K * (dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]) + s.ext_U0;
                 if (f) for (int k = 0; k < 3; ++k) f[3 * i + k] -= s.ext_K * dx[k];
             }
         }
-        for (size_t b = 0; b < s.bond_atoms.size() / 2; ++b) {
+        for (size_t b = 0; (classes & 2) && b < s.bond_atoms.size() / 2; ++b) {
             const int i = s.bond_atoms[2 * b], j = s.bond_atoms[2 * b + 1];
             const double r0 = s.bond_params[2 * b], k = s.bond_params[2 * b + 1];
             double d[3] = {x[3 * j] - x[3 * i], x[3 * j + 1] - x[3 * i + 1], x[3 * j + 2] - x[3 * i + 2]};
@@ -494,7 +497,7 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
             E.c[1] += 0.5 * k * (rr - r0) * (rr - r0);
             if (f) { const double g = k * (rr - r0) / rr; for (int c = 0; c < 3; ++c) { f[3 * i + c] += g * d[c]; f[3 * j + c] -= g * d[c]; } }
         }
-        for (size_t a = 0; a < s.angle_atoms.size() / 3; ++a) {
+        for (size_t a = 0; (classes & 4) && a < s.angle_atoms.size() / 3; ++a) {
             const int i = s.angle_atoms[3 * a], j = s.angle_atoms[3 * a + 1], k = s.angle_atoms[3 * a + 2];
             const double th0 = s.angle_params[2 * a], ka = s.angle_params[2 * a + 1];
             double v0[3], v1[3];
@@ -514,7 +517,7 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
                 }
             }
         }
-        for (size_t t = 0; t < s.torsion_atoms.size() / 4; ++t) {
+        for (size_t t = 0; (classes & 8) && t < s.torsion_atoms.size() / 4; ++t) {
             const int a0 = s.torsion_atoms[4 * t], a1 = s.torsion_atoms[4 * t + 1], a2 = s.torsion_atoms[4 * t + 2], a3 = s.torsion_atoms[4 * t + 3];
             const double per = s.torsion_params[3 * t], phase = s.torsion_params[3 * t + 1], kt = s.torsion_params[3 * t + 2];
             double b1[3], b2[3], b3[3], m[3], n[3];
@@ -545,7 +548,7 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
     const bool elec = (parts & PART_ELEC) && s.has_charge;
     if (elec) { qv.resize(N); for (int i = 0; i < N; ++i) qv[i] = s.alch[i] ? s.q[i] * lam_e : s.q[i]; }
     // ---- pair loop -------------------------------------------------------------------------------------------
-    if (parts & (PART_STERICS | PART_SOFTCORE | PART_ELEC)) {
+    if ((classes & 16) && (parts & (PART_STERICS | PART_SOFTCORE | PART_ELEC))) {
         double tt0 = g_time ? now_ms() : 0;
         ensure_list(s, r);
         if (g_time) { const double t1 = now_ms(); g_timers.list += t1 - tt0; tt0 = t1; }
@@ -608,7 +611,7 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
         if (g_time) g_timers.pairs += now_ms() - tt0;
     }
     // ---- exceptions (no cutoff) and the Ewald correction of every excluded pair ------------------------------------------
-    if (parts & (PART_STERICS | PART_SOFTCORE | PART_ELEC)) {
+    if ((classes & 16) && (parts & (PART_STERICS | PART_SOFTCORE | PART_ELEC))) {
         const size_t ne = s.exc_atoms.size() / 2;
         const double two_a_sqrtpi = 2.0 * s.alpha / sqrt(PI);
         const double la = pow(lam_s, s.sc_a), lb = s.sc_alpha * pow(1.0 - lam_s, s.sc_b);
@@ -654,8 +657,8 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
             if (f && fr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * j + k] += fr * d[k]; f[3 * i + k] -= fr * d[k]; }
         }
     }
-    if (parts & PART_STERICS) E.c[7] += s.disp_coeff / V;
-    if (elec && s.method == REMD_NB_PME) {
+    if ((classes & 16) && (parts & PART_STERICS)) E.c[7] += s.disp_coeff / V;
+    if ((classes & 32) && elec && s.method == REMD_NB_PME) {
         const double tp0 = g_time ? now_ms() : 0;
         E.c[6] += pme_reciprocal(s, r, qv, f, fft);
         if (g_time) g_timers.pme += now_ms() - tp0;
@@ -784,6 +787,8 @@ struct remd_ctx {
     double econst_vref = 0.0;
     std::vector<double> pressure; int baro_frequency = 0; long long baro_steps = 0, baro_attempts = 0;
     std::vector<char> tokens; int nV = 0, nR = 0, nO = 0;
+    int nVg[4] = {0, 0, 0, 0};          // multiple-time-step splittings: V tokens per force group ('0' ... '3' in tokens)
+    int force_groups[6] = {0, 0, 0, 0, 0, 0};   // remd_set_force_groups: group of (external, bonds, angles, torsions, direct, reciprocal)
     double dt = 0, gamma = 0; int n_steps = 0, reassign = 0, n_restart_attempts = 0;
     double coulomb_cutoff = 0;
     int annihilate_sterics = 0;
@@ -809,10 +814,13 @@ static int fail(remd_ctx* h, int code, const std::string& msg)
     return code;
 }
 
-static int parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO)
+static int parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO, int* nVg = nullptr)
 {
+    // integrators.py:1474-1537: V / R / O tokens, Metropolization braces, force-group suffixes V0, V1, ...: with more than one distinct
+    // group the splitting is a multiple-time-step one -- every V must name its group (:1527-1529) and kicks with that group's forces
+    // and dt / (occurrences of that group) (:1437-1438); with one group (or none) every V uses all forces and dt / (number of V)
     tokens.clear(); nV = nR = nO = 0;
-    int group = -1; bool mts = false;
+    std::vector<int> vgroup;
     std::string s(splitting ? splitting : "");
     size_t i = 0;
     while (i < s.size()) {
@@ -822,9 +830,13 @@ static int parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>
         std::string tok = s.substr(i, j - i);
         for (auto& c : tok) c = (char)toupper(c);
         if (tok[0] == 'V' && tok.find_first_not_of("0123456789", 1) == std::string::npos) {
-            // one distinct force group (or none): every V uses all forces (integrators.py:1518-1535)
-            if (tok.size() > 1) { const int g = atoi(tok.c_str() + 1); if (group >= 0 && g != group) mts = true; group = g; }
-            tokens.push_back('V'); nV++;
+            int g = -1;
+            if (tok.size() > 1) {
+                if (tok.size() > 3) return fail(h, -3, "force group of '" + tok + "' out of range");
+                g = atoi(tok.c_str() + 1);
+                if (g > 31) return fail(h, -3, "OpenMM only allows up to 32 force groups (integrators.py:1346-1347)");
+            }
+            tokens.push_back('V'); vgroup.push_back(g); nV++;
         }
         else if (tok == "R") { tokens.push_back('R'); nR++; }
         else if (tok == "O") { tokens.push_back('O'); nO++; }
@@ -832,7 +844,22 @@ static int parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>
         else return fail(h, -3, "unsupported splitting token '" + tok + "' (supported: V V<group> R O { })");
         i = j;
     }
-    if (mts) return fail(h, -3, "multiple-time-step splittings (several force groups) are not implemented in the CPU library");
+    {
+        std::vector<int> distinct;
+        for (int g : vgroup) if (g >= 0 && std::find(distinct.begin(), distinct.end(), g) == distinct.end()) distinct.push_back(g);
+        int counts[4] = {0, 0, 0, 0};
+        if (distinct.size() > 1) {
+            if (!nVg) return fail(h, -3, "multiple-time-step splittings are set with remd_set_integrator");
+            size_t v = 0;
+            for (auto& c : tokens) if (c == 'V') {
+                const int g = vgroup[v++];
+                if (g < 0) return fail(h, -3, "a multiple-time-step splitting must name the force group of every V (integrators.py:1527-1529)");
+                if (g > 3) return fail(h, -3, "force groups above 3 are not supported in multiple-time-step splittings");
+                c = (char)('0' + g); counts[g]++;
+            }
+        }
+        if (nVg) for (int g = 0; g < 4; ++g) nVg[g] = counts[g];
+    }
     if (tokens.empty()) return fail(h, -3, "empty splitting string");
     if (nR == 0 || nV == 0) return fail(h, -3, "splitting needs at least one R and one V (integrators.py:1376-1385)");
     int depth = 0;
@@ -919,6 +946,19 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                 }
                 rep.shadow = 0.0;
                 brace++;
+            } else if (tok >= '0' && tok <= '3') {
+                // kick with the forces of one force group and that group's share of the time step (integrators.py:1437-1438)
+                const int g = tok - '0';
+                int mask = 0;
+                for (int c = 0; c < 6; ++c) if (h->force_groups[c] == g) mask |= 1 << c;
+                const int64_t kk = h->labels[rg];
+                std::vector<double> fg(3 * (size_t)N);
+                evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], fg.data(), thread_fft(h), PART_ALL, mask);
+                const double hg = h->dt / std::max(1, h->nVg[g]);
+                const double ke0 = m_shadow ? ke() : 0.0;
+                for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) v[3 * i + k] += hg * fg[3 * i + k] * s.invm[i];
+                if (cons) rattle(s, x, v);
+                if (m_shadow) rep.shadow += ke() - ke0;
             } else if (tok == 'V') {
                 ensure_forces(h, r);
                 const double* f = rep.f.data();
@@ -1253,7 +1293,7 @@ int remd_set_integrator(remd_handle h, const char* splitting, double dt, double 
     (void)tol;                                     // the f64 solver always iterates to 1e-12
     if (!h) return -1;
     if (!(dt > 0) || n_steps < 0 || gamma < 0) return fail(h, -1, "remd_set_integrator: bad parameters");
-    int rc = parse_splitting(h, splitting, h->tokens, h->nV, h->nR, h->nO);
+    int rc = parse_splitting(h, splitting, h->tokens, h->nV, h->nR, h->nO, h->nVg);
     if (rc) return rc;
     h->dt = dt; h->gamma = gamma; h->n_steps = n_steps; h->reassign = reassign; h->has_integrator = true;
     return 0;
@@ -1287,7 +1327,8 @@ int remd_set_force_groups(remd_handle h, const int32_t* groups)
 {
     if (!h || !groups) return fail(h, -1, "remd_set_force_groups: bad arguments");
     for (int c = 0; c < 6; ++c) if (groups[c] < 0 || groups[c] > 31) return fail(h, -1, "remd_set_force_groups: force groups are 0 ... 31");
-    return 0;       // (multiple-time-step splittings are refused when they are parsed)
+    for (int c = 0; c < 6; ++c) h->force_groups[c] = groups[c];
+    return 0;
 }
 
 // Sharding collectives (include/remd_hip.h): the CPU library is the single-process checker -- it joins a world of one.

@@ -114,7 +114,7 @@ def check_engine(make_engine, k, atol_x, atol_v, rtol_work, mts=True):
 def test_cpu_port_follows_the_references_program(k):
     if not os.path.exists(CPU_LIB):
         oracle.build()
-    check_engine(lambda: HipEngine(lib_path=CPU_LIB), k, 1e-11, 1e-9, 1e-6, mts=False)
+    check_engine(lambda: HipEngine(lib_path=CPU_LIB), k, 1e-11, 1e-9, 1e-6)
 
 
 @pytest.mark.parametrize('k', range(len(G['other_integrators'])))

@@ -113,7 +113,15 @@ def test_a_force_class_in_an_unnamed_group_is_refused(hip_engine_factory):
         eng.propagate(0)
 
 
-def test_cpu_library_refuses_multiple_time_step_splittings():
+@pytest.mark.parametrize('groups,splitting', [
+    (dict(bonded=1, nonbonded=0), SOLVENT_SOLUTE),                                     # the reference's docstring example
+    (dict(bonded=0, nonbonded=1, reciprocal=2), 'V2 V1 V0 R V0 R O R V0 R V0 V1 V2'),   # mesh slowest, bonded fastest
+])
+def test_cpu_library_follows_the_oracle(groups, splitting):
+    """The C++ port (libremd_cpu.so through the C ABI) on the same Philox stream as the f64 oracle: alanine dipeptide in water,
+    3 steps at 2 fs, forces per group from the class mask (listed terms / direct space + exceptions / mesh separately); a V without a
+    group in such a splitting and groups above 3 are refused as on the device.  (The four-atom chain of
+    tests/test_integrator_program.py holds both to the reference's own step program.)"""
     import os
     import oracle
     from openmmtools_amd._engine import HipEngine
@@ -121,11 +129,21 @@ def test_cpu_library_refuses_multiple_time_step_splittings():
     if not os.path.exists(lib):
         oracle.build()
     al = ts.AlanineDipeptideExplicit()
-    eng = HipEngine(lib_path=lib)
-    eng.set_system(system_to_desc(_grouped(al)))
-    with pytest.raises(RuntimeError, match='not implemented in the CPU library'):
-        eng.set_integrator(SOLVENT_SOLUTE, 0.002, 1.0, 2, True, 1e-8)
+    system = _grouped(al, **groups)
+    eng, ora = HipEngine(lib_path=lib), OracleEngine(ForceFieldOracle)
+    for e in (eng, ora):
+        _setup(e, system, al.positions, splitting, n_steps=3)
+    assert not eng.propagate(2).any()
+    ora.propagate(2)
+    xc, vc = eng.get_replicas()[:2]
+    assert np.abs(xc - ora.x).max() < 1e-7                      # nm: two f64 implementations with different constraint solvers / FFTs
+    assert np.sqrt(((vc - ora.v) ** 2).mean()) < 1e-6 * np.sqrt((ora.v ** 2).mean())
+    with pytest.raises(RuntimeError, match='must name the force group of every V'):
+        eng.set_integrator('V0 V R O R V1', 0.002, 1.0, 2, True, 1e-8)
+    with pytest.raises(RuntimeError, match='above 3'):
+        eng.set_integrator('V0 V7 R O R V7 V0', 0.002, 1.0, 2, True, 1e-8)
     eng.set_integrator('V0 R O R V0', 0.002, 1.0, 2, True, 1e-8)                       # one group: plain V
+    eng.close()
 
 
 def test_host_parser_agrees_with_the_reference_parser_run_on_the_same_strings():
