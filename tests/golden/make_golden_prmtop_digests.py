@@ -68,6 +68,26 @@ def digest(top, crd):
     free_angles = [a for a in ang if not water[a[1] // 3]]
     dk, dn, dp = np.array(s['DIHEDRAL_FORCE_CONSTANT']), np.array(s['DIHEDRAL_PERIODICITY']), np.array(s['DIHEDRAL_PHASE'])
     dih = np.concatenate([np.array(s['DIHEDRALS_INC_HYDROGEN']).reshape(-1, 5), np.array(s['DIHEDRALS_WITHOUT_HYDROGEN']).reshape(-1, 5)])
+    # exceptions: every entry of the excluded-atoms list is one; the 1-4 pairs among them (end atoms of the dihedrals whose third and
+    # fourth pointers are not negative: negative third = "1-4 already counted or inside a small ring", negative fourth = improper) keep
+    # q_i q_l / SCEE and the type pair's Lennard-Jones epsilon / SCNB (per dihedral type when the prmtop has the sections, else 1.2 / 2.0)
+    n_exceptions = int(sum(1 for e in s['EXCLUDED_ATOMS_LIST'] if e > 0))
+    scee = np.array(s['SCEE_SCALE_FACTOR']) if 'SCEE_SCALE_FACTOR' in s else np.full(len(dk), 1.2)
+    scnb = np.array(s['SCNB_SCALE_FACTOR']) if 'SCNB_SCALE_FACTOR' in s else np.full(len(dk), 2.0)
+    Aall, Ball, nbidx = np.array(s['LENNARD_JONES_ACOEF']), np.array(s['LENNARD_JONES_BCOEF']), np.array(s['NONBONDED_PARM_INDEX'])
+    seen, q14, e14, s14 = set(), 0.0, 0.0, 0.0
+    for d in dih:
+        if d[2] < 0 or d[3] < 0:
+            continue
+        i, l, ty = d[0] // 3, d[3] // 3, d[4] - 1
+        if (min(i, l), max(i, l)) in seen:
+            continue
+        seen.add((min(i, l), max(i, l)))
+        q14 += q[i] * q[l] / scee[ty]
+        k = nbidx[t[i] * ntypes + t[l]] - 1
+        if Aall[k] > 0 and Ball[k] > 0:
+            e14 += Ball[k] ** 2 / (4.0 * Aall[k]) * KCAL / scnb[ty]
+            s14 += (Aall[k] / Ball[k]) ** (1.0 / 6.0) * ANG
     if open(crd, 'rb').read(3) == b'CDF':                       # Amber NetCDF restart (JAC.inpcrd): scipy's NetCDF-3 reader
         from scipy.io import netcdf_file
         with netcdf_file(crd, 'r', mmap=False) as nc:
@@ -93,6 +113,7 @@ def digest(top, crd):
                 n_dihedrals_nonzero=int(sum(1 for d in dih if dk[d[4] - 1] != 0.0)),
                 dihedral_periodicity_sum_nonzero=float(sum(abs(dn[d[4] - 1]) for d in dih if dk[d[4] - 1] != 0.0)),
                 dihedral_phase_sum_nonzero=float(sum(dp[d[4] - 1] for d in dih if dk[d[4] - 1] != 0.0)),
+                n_exceptions=n_exceptions, n_14=len(seen), charge_product_14_sum=float(q14), epsilon_14_sum=float(e14), sigma_14_sum_where_epsilon_nonzero=float(s14),
                 box=[float(b) for b in box], position_sum=float(pos.sum()), position_abs_sum=float(np.abs(pos).sum()), has_velocities=bool(has_vel),
                 first_atoms=names[:6])
 

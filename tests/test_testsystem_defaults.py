@@ -85,6 +85,11 @@ def test_stored_systems_against_digests_of_the_references_amber_files(cls, name)
     nz = tors[:, 2] != 0.0
     assert int(nz.sum()) == D['n_dihedrals_nonzero'] and np.isclose(tors[:, 2].sum(), D['dihedral_k_sum'], rtol=1e-9)
     assert np.isclose(tors[nz, 0].sum(), D['dihedral_periodicity_sum_nonzero'], rtol=1e-12) and np.isclose(tors[nz, 1].sum(), D['dihedral_phase_sum_nonzero'], rtol=1e-9)
+    exc = np.array([nb.getExceptionParameters(k)[2:] for k in range(nb.getNumExceptions())], dtype=float).reshape(-1, 3)
+    live = (exc[:, 0] != 0.0) | (exc[:, 2] != 0.0)                      # the 1-4 pairs; 1-2 and 1-3 exclusions carry zeros
+    assert len(exc) == D['n_exceptions'] and int(live.sum()) == D['n_14']
+    assert np.isclose(exc[:, 0].sum(), D['charge_product_14_sum'], rtol=1e-9) and np.isclose(exc[:, 2].sum(), D['epsilon_14_sum'], rtol=1e-9)
+    assert np.isclose(exc[exc[:, 2] > 0, 1].sum(), D['sigma_14_sum_where_epsilon_nonzero'], rtol=1e-9)
     box = np.diag(np.array(s.getDefaultPeriodicBoxVectors(), dtype=float).reshape(3, 3))
     assert np.allclose(box, D['box'], rtol=1e-7)
     x = np.asarray(t.positions, dtype=float)
