@@ -151,6 +151,20 @@ def test_cpu_hostguest_lambda_rows(cpu_engine_factory):
     assert np.abs(f[0] - f_ref).max() < 1e-7 * np.abs(f_ref).max()
 
 
+def test_cpu_dhfr_energy_and_forces_two_independent_implementations(cpu_engine_factory):
+    """Config 5's system (DHFR, 23 558 atoms, PME at the reference split) has no reference-held energy: its parameters are pinned to
+    the reference's Amber files (tests/test_testsystem_defaults.py), and its energy and forces are computed here by two implementations
+    that share no code -- the torch autograd oracle (pair search + smooth PME with torch.fft) and the C++ port (cell lists, hand-derived
+    forces, in-tree FFT): 1e-11 relative on the energy, 1e-10 of the largest force.  The device is held to the oracle by the -m gpu tests."""
+    dh = ts.DHFRExplicit()
+    eng = cpu_engine_factory()
+    desc, x, box = _setup(eng, dh.system, dh.positions, R=1)
+    u = float(np.asarray(eng.compute_energies()).ravel()[0]) * (KB * 300.0)
+    e, f = ForceFieldOracle(desc).energy_forces(x[0], box[0])
+    assert abs(u - e) < 1e-11 * abs(e), (u, e)
+    assert np.abs(eng.get_forces()[0] - f).max() < 1e-10 * np.abs(f).max()
+
+
 def test_cpu_annihilated_sterics(cpu_engine_factory):
     """AlchemicalRegion(annihilate_sterics=True) (alchemy.py:421, 1767-1779, 1841-1846; remd_set_alchemical_options): the
     Lennard-Jones pairs and 1-4 exceptions INSIDE the alchemical region are soft-core and lambda-controlled too.  CB7:B2 guest:
