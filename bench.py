@@ -199,14 +199,27 @@ def run_shapes(args, world, rank, local_rank, comm, sync, stream, budget_s=240.0
     JSON line on rank 0.  A shape that fails is reported with its error instead of taking the main line down."""
     import torch
     from openmmtools_amd._engine import HipEngine
+    # rank 0 arrives here tens of seconds after the others (roof microbenchmark, CPU baseline): the clock that decides what is skipped
+    # starts behind a barrier, and the decision itself is collective (ADVICE r5: a rank that skips a shape another rank starts leaves
+    # that shape's collectives unmatched)
+    sync()
     t_start = time.perf_counter()
     out = {} if out is None else out       # (caller-owned: the watchdog of main() reports what finished)
+
+    def elapsed_on_the_slowest_rank():
+        e = time.perf_counter() - t_start
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([e], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
     specs = [('strong24_alanine', 24, 'alanine', 3, 1), ('strong128_alanine', 128, 'alanine', 3, 1),
              ('config5_dhfr128_sams', 128, 'dhfr', 1 if world == 1 else 2, 1)]
     for name, R, kind, n_it, n_warm in specs:
         if R < world or (name == 'strong24_alanine' and world == 1):
             continue
-        if time.perf_counter() - t_start > budget_s:
+        if elapsed_on_the_slowest_rank() > budget_s:
             out[name] = dict(skipped='time budget of the extra shapes used up')
             continue
         try:
@@ -242,12 +255,14 @@ def run_shapes(args, world, rank, local_rank, comm, sync, stream, budget_s=240.0
     return out
 
 
-def finish_line(out, rank, shapes_fn, limit_s, write=None, end_process=None):
+def finish_line(out, rank, shapes_fn, limit_s, write=None, end_process=None, align=None):
     """Print the ONE JSON line (rank 0), after the extra ensemble shapes if there are any.  The shapes run LAST and under a watchdog: the
     headline part of `out` is complete when this is called, and an extra shape that stalls (a device-side poll that runs out takes seconds
     per MD step) must not keep it from being printed.  The watchdog thread runs while the main thread sits in a C call (ctypes releases
     the GIL); it prints the line with the shapes that did finish and ends the process -- on every rank, each by its own timer.
-    shapes_fn(dict) fills the dict shape by shape (every rank calls it: the samplers hold collectives); None: no extra shapes."""
+    shapes_fn(dict) fills the dict shape by shape (every rank calls it: the samplers hold collectives); None: no extra shapes.
+    align: called on every rank right before the timer starts (a barrier), so that no rank's watchdog ends its process while another
+    rank, whose timer started later, is still inside a collective of a shape."""
     import threading
     write = write or (lambda text: print(text, flush=True))
     end_process = end_process or (lambda: os._exit(0))
@@ -270,6 +285,8 @@ def finish_line(out, rank, shapes_fn, limit_s, write=None, end_process=None):
         def expired():
             if emit('the extra shapes did not finish within %.0f s: the line is printed without the rest and the process ends' % limit_s):
                 end_process()
+        if align is not None:
+            align()                                    # (a barrier: every rank's timer then runs from the same moment)
         dog = threading.Timer(limit_s, expired)
         dog.daemon = True
         dog.start()
@@ -466,7 +483,7 @@ def main():
     if not args.no_shapes and args.replicas_total == 0:
         def shapes_fn(shapes):
             run_shapes(args, world, rank, local_rank, comm, sync, stream, out=shapes)
-    finish_line(out, rank, shapes_fn, float(os.environ.get('REMD_BENCH_SHAPES_LIMIT_S', '420')))
+    finish_line(out, rank, shapes_fn, float(os.environ.get('REMD_BENCH_SHAPES_LIMIT_S', '420')), align=sync if world > 1 else None)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

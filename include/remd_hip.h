@@ -242,6 +242,16 @@ int  remd_seed(remd_handle h, uint64_t seed);
    nan_flags: host [R_local] or NULL.                                                     */
 int  remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags);
 
+/* remd_propagate for SEVERAL handles of one device in one call from one host thread (round 6): the handles' MD steps take turns, each
+   handle on its own pair of streams, so that the integrator chain of one group of replicas -- the serial part of an MD step -- runs
+   beside the pair and mesh kernels of another group (replicas are independent between two mixes, multistatesampler.py:1296-1297;
+   the reference propagates them one after another or one per MPI rank).  Per-replica results are those of remd_propagate on each
+   handle, bit for bit.  hs: n handles with the same n_steps; nan_flags: host, the handles' local replicas concatenated, or NULL.
+   While the call runs no workgroup of these handles waits on a CU for another stream (the join of a step is a one-wavefront launch,
+   the centre-of-mass momentum sum two launches): a polling integrator chain holds 320 registers per lane of every CU it sits on.
+   A handle that reports a device-side fault, or a NaN with restart attempts left, is run again alone through remd_propagate.   */
+int  remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* nan_flags);
+
 /* Replaces MultiStateSampler._compute_energies / _compute_replica_energies
    (multistatesampler.py:1436-1494; paralleltempering.py:175-215): rows r_begin.. of the
    reduced-potential matrix.  d_ukl_rows: DEVICE [R_local][K] f64, or NULL to use the

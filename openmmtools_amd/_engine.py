@@ -42,7 +42,7 @@ EXPORTS = [
     'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_alchemical_options', 'remd_set_states',
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_copy_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
-    'remd_get_forces', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
+    'remd_get_forces', 'remd_propagate_many', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_set_force_groups', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
@@ -111,6 +111,7 @@ def load_library(path=None):
                                   c_int64_p, c_double_p, c_double_p, C.c_int64]
     lib.remd_get_replicas.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_get_forces.argtypes = [vp, c_double_p]
+    lib.remd_propagate_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
     lib.remd_step.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64, C.c_int]
     lib.remd_sync.argtypes = [vp]
     lib.remd_get_energy_components.argtypes = [vp, c_double_p]
@@ -375,6 +376,15 @@ class HipEngine:
         flags = np.zeros(self.R, dtype=np.int32)
         self._check(self.lib.remd_propagate(self.h, int(iteration), _ip(flags)), 'remd_propagate')
         return flags
+
+    @staticmethod
+    def propagate_many(engines, iteration):
+        """remd_propagate_many: the engines' MD steps take turns on one device from one host thread; returns the NaN flags per engine"""
+        lib = engines[0].lib
+        hs = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+        flags = np.zeros(sum(e.R for e in engines), dtype=np.int32)
+        engines[0]._check(lib.remd_propagate_many(hs, len(engines), int(iteration), _ip(flags)), 'remd_propagate_many')
+        return np.split(flags, np.cumsum([e.R for e in engines])[:-1])
 
     def compute_energies(self, d_rows=None, want_host=True, want_potential=False):
         """Rows [R_local, K] of u_kl.  d_rows: device pointer (int) or None for the handle's matrix."""

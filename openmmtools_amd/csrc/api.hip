@@ -481,7 +481,7 @@ int remd_set_restart_attempts(remd_handle h, int n)
 // switched off for this handle (events instead of polled flags, two chain launches instead of the barrier, the binning launch
 // instead of capped bins), so that the handle keeps working; `retry` says whether the caller runs the work again itself (then
 // this is not an error yet).
-int remd_recover_device_flag(remd_ctx* h, unsigned int f, const char* where, bool retry)
+static int remd_recover_device_flag(remd_ctx* h, unsigned int f, const char* where, bool retry)
 {
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
     if (h->stream2) REMD_CHECK(h, hipStreamSynchronize(h->stream2));
@@ -590,6 +590,90 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     REMD_CHECK(h, hipStreamSynchronize(h->stream));
     float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_prop = ms;
     if (nan_flags) for (int r = 0; r < h->R; ++r) nan_flags[r] = flags[r];
+    return 0;
+}
+
+// Several handles of one device propagated in ONE call from one host thread, their MD steps taking turns (integrate.hip:
+// remd_run_steps_many): replicas are independent between two mixes (multistatesampler.py:1296-1297), so while one group's integrator
+// chain -- the serial part of a step -- runs, another group's pair and mesh kernels have the chip.  Per-replica results are those of
+// remd_propagate on each handle, bit for bit (fixed-point forces, Philox streams keyed by the global replica).  The normal case is handled
+// here; a handle that reports a device-side fault or a NaN with restart attempts left is put back to its snapshot and run again alone
+// through remd_propagate (whose recovery and restart logic then applies).  nan_flags: the handles' replicas, concatenated.
+int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* nan_flags)
+{
+    if (!hs || n < 1) return remd_fail(nullptr, -1, "remd_propagate_many: no handles");
+    for (int i = 0; i < n; ++i) {
+        remd_ctx* h = hs[i];
+        if (!h || !h->has_system || !h->has_integrator || h->R <= 0 || h->K <= 0)
+            return remd_fail(h, -1, "remd_propagate_many: system/states/integrator/replicas not all set");
+        if (h->device != hs[0]->device) return remd_fail(h, -1, "remd_propagate_many: the handles must live on one device");
+        if (h->n_steps != hs[0]->n_steps) return remd_fail(h, -1, "remd_propagate_many: the handles must run the same number of steps");
+    }
+    if (n == 1) return remd_propagate(hs[0], iteration, nan_flags);
+    hipSetDevice(hs[0]->device);
+    for (int i = 0; i < n; ++i) {
+        remd_ctx* h = hs[i];
+        hipEventRecord(h->ev0, h->stream);
+        const size_t bytes = sizeof(float4) * (size_t)h->Npad * h->R;
+        if (!h->d_snap_pos) {
+            REMD_CHECK(h, hipMalloc(&h->d_snap_pos, bytes)); REMD_CHECK(h, hipMalloc(&h->d_snap_vel, bytes));
+            REMD_CHECK(h, hipMalloc(&h->d_fin_pos, bytes)); REMD_CHECK(h, hipMalloc(&h->d_fin_vel, bytes));
+            REMD_CHECK(h, hipMalloc(&h->d_snap_box, sizeof(float) * 4 * h->R)); REMD_CHECK(h, hipMalloc(&h->d_fin_box, sizeof(float) * 4 * h->R));
+        }
+        REMD_CHECK(h, hipMemcpyAsync(h->d_snap_box, h->d_box, sizeof(float) * 4 * h->R, hipMemcpyDeviceToDevice, h->stream));
+        REMD_CHECK(h, hipMemcpyAsync(h->d_snap_pos, h->d_pos, bytes, hipMemcpyDeviceToDevice, h->stream));
+        REMD_CHECK(h, hipMemcpyAsync(h->d_snap_vel, h->d_vel, bytes, hipMemcpyDeviceToDevice, h->stream));
+        const size_t wbytes = sizeof(long long) * 4 * h->R;
+        if (!h->d_snap_work) REMD_CHECK(h, hipMalloc(&h->d_snap_work, 2 * wbytes));
+        if (h->d_work != nullptr && h->work_R == h->R) REMD_CHECK(h, hipMemcpyAsync(h->d_snap_work, h->d_work, wbytes, hipMemcpyDeviceToDevice, h->stream));
+        else REMD_CHECK(h, hipMemsetAsync(h->d_snap_work, 0, wbytes, h->stream));
+        static const bool lean_env = !(getenv("REMD_MANY_LEAN") && atoi(getenv("REMD_MANY_LEAN")) == 0);
+        h->lean_waits = lean_env;
+    }
+    int rc = 0;
+    for (int i = 0; i < n && !rc; ++i) if (hs[i]->reassign) rc = remd_assign_velocities(hs[i], iteration);
+    if (!rc) rc = remd_run_steps_many(hs, n, iteration, 0, hs[0]->n_steps);
+    std::vector<std::vector<int>> flags((size_t)n);
+    std::vector<unsigned int> spin((size_t)n, 0u);
+    for (int i = 0; i < n && !rc; ++i) {
+        remd_ctx* h = hs[i];
+        if ((rc = remd_check_finite(h))) break;
+        flags[i].assign((size_t)h->R, 0);
+        REMD_CHECK(h, hipMemcpyAsync(flags[i].data(), h->d_nan, sizeof(int) * h->R, hipMemcpyDeviceToHost, h->stream));
+        REMD_CHECK(h, hipMemcpyAsync(&spin[i], h->d_sync + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+        hipEventRecord(h->ev1, h->stream);
+    }
+    for (int i = 0; i < n; ++i) {           // (also after an error: no launch of this call may outlive it)
+        remd_ctx* h = hs[i];
+        h->lean_waits = false;
+        hipStreamSynchronize(h->stream);
+        if (h->stream2) hipStreamSynchronize(h->stream2);
+    }
+    if (rc) return rc;
+    int off = 0;
+    for (int i = 0; i < n; ++i) {
+        remd_ctx* h = hs[i];
+        remd_nb_tune_resolve(h);
+        int n_bad = 0;
+        for (int r = 0; r < h->R; ++r) n_bad += flags[i][r] ? 1 : 0;
+        if (spin[i] || (n_bad > 0 && h->n_restart_attempts > 0)) {
+            // the rare cases go through the single-handle path from the state this call started from
+            const size_t bytes = sizeof(float4) * (size_t)h->Npad * h->R;
+            REMD_CHECK(h, hipMemcpyAsync(h->d_pos, h->d_snap_pos, bytes, hipMemcpyDeviceToDevice, h->stream));
+            REMD_CHECK(h, hipMemcpyAsync(h->d_vel, h->d_snap_vel, bytes, hipMemcpyDeviceToDevice, h->stream));
+            REMD_CHECK(h, hipMemcpyAsync(h->d_box, h->d_snap_box, sizeof(float) * 4 * h->R, hipMemcpyDeviceToDevice, h->stream));
+            if (h->d_work) REMD_CHECK(h, hipMemcpyAsync(h->d_work, h->d_snap_work, sizeof(long long) * 4 * h->R, hipMemcpyDeviceToDevice, h->stream));
+            h->box_version++;
+            h->forces_valid = false; h->force_zeroed = false;
+            if (!spin[i]) { remd_nb_invalidate_sort(h); }
+            int rc1 = remd_propagate(h, iteration, nan_flags ? nan_flags + off : nullptr);
+            if (rc1) return rc1;
+        } else {
+            float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_prop = ms;
+            if (nan_flags) for (int r = 0; r < h->R; ++r) nan_flags[off + r] = flags[i][r];
+        }
+        off += h->R;
+    }
     return 0;
 }
 

@@ -1271,77 +1271,94 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
 void remd_launch_join_wait(remd_ctx* h);
 void remd_nb_tune_step(remd_ctx* h, int steps_left_in_call);
 
-int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
-                   int64_t iteration, int64_t first_step, int n_steps)
-{
-    const unit_tables& ut = g_units[h];
-    if (ut.n_units == 0) return remd_fail(h, -3, "no system set");
+// The state remd_run_steps keeps between the MD steps of one call, as an object: begin() = everything in front of the step loop,
+// step(s) = one MD step's launches, end() = the flush behind the last step.  One handle runs begin / step ... / end by itself
+// (remd_run_steps); round 6: SEVERAL handles of one device take turns step by step from one host thread (remd_run_steps_many: the
+// chain of one group of replicas beside the force kernels of another) -- nothing in here synchronises with the host.
+struct step_runner {
+    remd_ctx* h = nullptr; const unit_tables* ut = nullptr; const std::vector<char>* tokens = nullptr;
+    int64_t first_step = 0; int n_steps = 0;
+    chain_prog base{}, cur{};
+    bool mts = false; unsigned group_mask[4] = {0u, 0u, 0u, 0u}; bool group_valid[4] = {false, false, false, false};
+    bool shadow = false, pe_valid = false, zeroed_by_chain = false, device_waits_ok = false, merge_cmm = false;
+    int cmm_w = 0; long long gstep0 = 0;
+    bool done_by_resident = false;       // the resident small-system kernel took the whole call: step() / end() do nothing
+
+    int begin(remd_ctx* h_, const std::vector<char>& tokens_, int nV, int nR, int nO, int64_t iteration, int64_t first_step_, int n_steps_)
     {
-        const int rr = remd_run_steps_resident(h, tokens, nV, nR, nO, iteration, first_step, n_steps);
-        if (rr != 0) return rr < 0 ? rr : 0;
-    }
-    chain_prog base{};
-    base.hV = (float)(h->dt / (nV > 0 ? nV : 1));
-    base.hR = (float)(h->dt / (nR > 0 ? nR : 1));
-    const double hO = h->dt / (nO > 0 ? nO : 1);                 // integrators.py:1142
-    base.a = (float)exp(-h->gamma * hO);                         // :1143
-    base.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO));       // :1146
-    base.nO = nO > 0 ? nO : 1;
-    base.cmm_r = -1; base.cmm_w = 0; base.zero_force = 0;
-    // multiple-time-step program: one force array per force group that the splitting names, evaluated when a V of the group
-    // comes up and the positions have changed since its last evaluation
-    bool mts = false;
-    for (char c : tokens) mts |= (c >= '0' && c <= '3');
-    unsigned group_mask[4] = {0u, 0u, 0u, 0u};
-    bool group_valid[4] = {false, false, false, false};
-    if (mts) {
-        const size_t nf = (size_t)h->R * 3 * h->Npad;
-        for (int g = 0; g < 4; ++g) {
-            base.hVg[g] = h->nVg[g] > 0 ? (float)(h->dt / h->nVg[g]) : 0.f;
-            for (int c = 0; c < 6; ++c) if (h->fgroup[c] == g) group_mask[g] |= 1u << c;
-            if (h->nVg[g] > 0 && (!h->d_force_g[g] || h->force_g_n != nf)) {
-                if (h->d_force_g[g]) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_force_g[g]); h->d_force_g[g] = nullptr; }
-                REMD_CHECK(h, hipMalloc(&h->d_force_g[g], sizeof(long long) * nf));
-            }
-            base.Fg[g] = h->d_force_g[g];
+        h = h_; tokens = &tokens_; first_step = first_step_; n_steps = n_steps_;
+        ut = &g_units[h];
+        if (ut->n_units == 0) return remd_fail(h, -3, "no system set");
+        {
+            const int rr = remd_run_steps_resident(h, tokens_, nV, nR, nO, iteration, first_step, n_steps);
+            if (rr < 0) return rr;
+            if (rr != 0) { done_by_resident = true; return 0; }
         }
-        h->force_g_n = nf;
-        unsigned named = 0u;
-        for (int g = 0; g < 4; ++g) if (h->nVg[g] > 0) named |= group_mask[g];
-        for (int c = 0; c < 6; ++c)
-            if (h->fgroup[c] > 3 || !(named & (1u << c)))
-                return remd_fail(h, -3, "multiple-time-step splitting: a force class sits in a force group that no V of the splitting names "
-                                        "(its forces would never act); groups 0-3 are supported");
+        base = chain_prog{};
+        base.hV = (float)(h->dt / (nV > 0 ? nV : 1));
+        base.hR = (float)(h->dt / (nR > 0 ? nR : 1));
+        const double hO = h->dt / (nO > 0 ? nO : 1);                 // integrators.py:1142
+        base.a = (float)exp(-h->gamma * hO);                         // :1143
+        base.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO));       // :1146
+        base.nO = nO > 0 ? nO : 1;
+        base.cmm_r = -1; base.cmm_w = 0; base.zero_force = 0;
+        // multiple-time-step program: one force array per force group that the splitting names, evaluated when a V of the group
+        // comes up and the positions have changed since its last evaluation
+        for (char c : tokens_) mts |= (c >= '0' && c <= '3');
+        if (mts) {
+            const size_t nf = (size_t)h->R * 3 * h->Npad;
+            for (int g = 0; g < 4; ++g) {
+                base.hVg[g] = h->nVg[g] > 0 ? (float)(h->dt / h->nVg[g]) : 0.f;
+                for (int c = 0; c < 6; ++c) if (h->fgroup[c] == g) group_mask[g] |= 1u << c;
+                if (h->nVg[g] > 0 && (!h->d_force_g[g] || h->force_g_n != nf)) {
+                    if (h->d_force_g[g]) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_force_g[g]); h->d_force_g[g] = nullptr; }
+                    REMD_CHECK(h, hipMalloc(&h->d_force_g[g], sizeof(long long) * nf));
+                }
+                base.Fg[g] = h->d_force_g[g];
+            }
+            h->force_g_n = nf;
+            unsigned named = 0u;
+            for (int g = 0; g < 4; ++g) if (h->nVg[g] > 0) named |= group_mask[g];
+            for (int c = 0; c < 6; ++c)
+                if (h->fgroup[c] > 3 || !(named & (1u << c)))
+                    return remd_fail(h, -3, "multiple-time-step splitting: a force class sits in a force group that no V of the splitting names "
+                                            "(its forces would never act); groups 0-3 are supported");
+        }
+        int n_braces = 0;
+        for (char c : tokens_) n_braces += (c == '}');
+        shadow = h->measure_shadow || n_braces > 0;                         // a Metropolized program measures shadow work (:1117-1119)
+        base.measure = (h->measure_heat ? 1 : 0) | (shadow ? 2 : 0);
+        if (base.measure) { int rcw = remd_work_buffers(h); if (rcw) return rcw; }
+        pe_valid = false;                  // d_pe_prev holds U at the current positions
+        cur = base; cur.n = 0;
+        cmm_w = 0;                         // accumulator the next momentum sum goes to
+        zeroed_by_chain = false;
+        gstep0 = (long long)iteration * (long long)h->n_steps + first_step;
+        // the centre-of-mass motion remover needs sum(m v) over the whole replica between two tokens of a step: either two launches
+        // (the first ends with the sum) or one launch with a barrier over the replica's workgroups in device memory ('M' token) --
+        // every workgroup of the grid must then be resident at once, hence the bound on the grid
+        const bool merge_env = !(getenv("REMD_CHAIN_MERGE") && atoi(getenv("REMD_CHAIN_MERGE")) == 0);
+        const long long chain_blocks = (long long)((ut->n_units + 255) / 256) * h->R;
+        // (the same bound holds for the join polled in the chain's prologue: spinning workgroups of a grid larger than the chip
+        // holds at once could keep the direct-space stream's last launches from ever being dispatched)
+        device_waits_ok = chain_blocks <= 1024 && !h->no_device_waits;
+        merge_cmm = merge_env && device_waits_ok && h->profiling != 2 && !h->lean_waits;
+        const long long sync_key = (long long)h->R * 1000003ll + ut->n_units;
+        if (merge_cmm && (!h->d_chain_sync || h->chain_sync_key != sync_key)) {      // slots of THIS grid shape
+            if (h->d_chain_sync) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_chain_sync); h->d_chain_sync = nullptr; }
+            h->chain_sync_key = sync_key;
+            const size_t slot_bytes = sizeof(unsigned long long) * 2 * (size_t)h->R * (size_t)((ut->n_units + 255) / 256) * 3;   // [2][R][workgroups][3]
+            REMD_CHECK(h, hipMalloc(&h->d_chain_sync, slot_bytes));
+            REMD_CHECK(h, hipMemsetAsync(h->d_chain_sync, 0, slot_bytes, h->stream));
+            h->chain_sync_epoch = 0;
+        }
+        if (h->cmm_frequency > 0)
+            hipMemsetAsync(h->d_cmm, 0, sizeof(long long) * 4 * 2 * h->R, h->stream);      // both accumulators, once per call
+        return 0;
     }
-    int n_braces = 0;
-    for (char c : tokens) n_braces += (c == '}');
-    const bool shadow = h->measure_shadow || n_braces > 0;              // a Metropolized program measures shadow work (:1117-1119)
-    base.measure = (h->measure_heat ? 1 : 0) | (shadow ? 2 : 0);
-    if (base.measure) { int rcw = remd_work_buffers(h); if (rcw) return rcw; }
-    bool pe_valid = false;             // d_pe_prev holds U at the current positions
-    chain_prog cur = base; cur.n = 0;
-    int cmm_w = 0;                     // accumulator the next momentum sum goes to
-    bool zeroed_by_chain = false;
-    const long long gstep0 = (long long)iteration * (long long)h->n_steps + first_step;
-    // the centre-of-mass motion remover needs sum(m v) over the whole replica between two tokens of a step: either two launches
-    // (the first ends with the sum) or one launch with a barrier over the replica's workgroups in device memory ('M' token) --
-    // every workgroup of the grid must then be resident at once, hence the bound on the grid
-    const bool merge_env = !(getenv("REMD_CHAIN_MERGE") && atoi(getenv("REMD_CHAIN_MERGE")) == 0);
-    const long long chain_blocks = (long long)((ut.n_units + 255) / 256) * h->R;
-    // (the same bound holds for the join polled in the chain's prologue: spinning workgroups of a grid larger than the chip
-    // holds at once could keep the direct-space stream's last launches from ever being dispatched)
-    const bool device_waits_ok = chain_blocks <= 1024 && !h->no_device_waits;
-    const bool merge_cmm = merge_env && device_waits_ok && h->profiling != 2;
-    const long long sync_key = (long long)h->R * 1000003ll + ut.n_units;
-    if (merge_cmm && (!h->d_chain_sync || h->chain_sync_key != sync_key)) {      // counters count arrivals of THIS grid shape
-        if (h->d_chain_sync) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_chain_sync); h->d_chain_sync = nullptr; }
-        h->chain_sync_key = sync_key;
-        const size_t slot_bytes = sizeof(unsigned long long) * 2 * (size_t)h->R * (size_t)((ut.n_units + 255) / 256) * 3;   // [2][R][workgroups][3]
-        REMD_CHECK(h, hipMalloc(&h->d_chain_sync, slot_bytes));
-        REMD_CHECK(h, hipMemsetAsync(h->d_chain_sync, 0, slot_bytes, h->stream));
-        h->chain_sync_epoch = 0;
-    }
-    auto flush = [&](bool accumulate, bool bin_for_pme = false) {      // bin_for_pme: a force evaluation follows this launch directly
+
+    void flush(bool accumulate, bool bin_for_pme = false)      // bin_for_pme: a force evaluation follows this launch directly
+    {
         if (cur.n == 0 && !accumulate) return;
         cur.accumulate_momentum = accumulate ? 1 : 0;
         cur.cmm_w = cmm_w;
@@ -1351,16 +1368,30 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
         staleAtEnd = seenR && !mts;          // (the per-group arrays of a multiple-time-step program are cleared before their evaluation)
         cur.zero_force = staleAtEnd ? 1 : 0;
         if (staleAtEnd) zeroed_by_chain = true;
-        launch_chain(h, ut, cur, bin_for_pme);
+        launch_chain(h, *ut, cur, bin_for_pme);
         cur = base; cur.n = 0;
-    };
-    auto push = [&](char tok, int oidx, long long step) {
+    }
+    void push(char tok, int oidx, long long step)
+    {
         if (cur.n == MAX_TOK) flush(false);
         cur.tok[cur.n] = tok; cur.o_index[cur.n] = oidx; cur.step[cur.n] = step; cur.n++;
-    };
-    if (h->cmm_frequency > 0)
-        hipMemsetAsync(h->d_cmm, 0, sizeof(long long) * 4 * 2 * h->R, h->stream);      // both accumulators, once per call
-    auto run_body = [&](int s) -> int {
+    }
+    int evaluate_with_energy(bool accumulate)
+    {
+        // energies (and forces) at the current positions; accumulate: add U - U_prev to the shadow work (:1420-1423)
+        flush(false);
+        h->force_zeroed = zeroed_by_chain;
+        zeroed_by_chain = false;
+        int rc = remd_compute_forces(h, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(work_pe_kernel, dim3((h->R + 63) / 64), dim3(64), 0, h->stream, h->R, h->d_potential, h->d_pe_prev, h->d_work, accumulate ? 1 : 0);
+        pe_valid = true;
+        return 0;
+    }
+
+    int step(int s)
+    {
+        if (done_by_resident) return 0;
         const long long gstep = gstep0 + s;
         // integrators.py:1313 addUpdateContextState: CMMotionRemover fires at the top of a step
         if (h->cmm_frequency > 0 && ((first_step + s) % h->cmm_frequency) == 0) {
@@ -1388,18 +1419,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             for (bool& gv : group_valid) gv = false;
         }
         int oidx = 0, brace = 0;
-        auto evaluate_with_energy = [&](bool accumulate) -> int {
-            // energies (and forces) at the current positions; accumulate: add U - U_prev to the shadow work (:1420-1423)
-            flush(false);
-            h->force_zeroed = zeroed_by_chain;
-            zeroed_by_chain = false;
-            int rc = remd_compute_forces(h, true);
-            if (rc) return rc;
-            hipLaunchKernelGGL(work_pe_kernel, dim3((h->R + 63) / 64), dim3(64), 0, h->stream, h->R, h->d_potential, h->d_pe_prev, h->d_work, accumulate ? 1 : 0);
-            pe_valid = true;
-            return 0;
-        };
-        for (char tok : tokens) {
+        for (char tok : *tokens) {
             if (tok == '{') { push('{', 0, gstep); continue; }
             if (tok == '}') {
                 flush(false);
@@ -1420,7 +1440,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                 long long* all_forces = h->d_force;
                 h->d_force = h->d_force_g[g];
                 h->force_zeroed = false; zeroed_by_chain = false;
-                h->defer_join_ok = device_waits_ok;
+                h->defer_join_ok = device_waits_ok && !h->lean_waits;
                 int rc = remd_compute_forces(h, false, group_mask[g]);
                 h->defer_join_ok = false;
                 h->d_force = all_forces;
@@ -1432,7 +1452,7 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
                 flush(false, true);
                 h->force_zeroed = zeroed_by_chain;
                 zeroed_by_chain = false;
-                h->defer_join_ok = device_waits_ok;   // the next main-stream launch is the chain holding this V
+                h->defer_join_ok = device_waits_ok && !h->lean_waits;   // the next main-stream launch is the chain holding this V
                 int rc = remd_compute_forces(h, false);
                 h->defer_join_ok = false;
                 if (rc) return rc;
@@ -1446,15 +1466,50 @@ int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR,
             }
         }
         return 0;
-    };
-    for (int s = 0; s < n_steps; ++s) {
-        remd_nb_tune_step(h, n_steps - s);
-        int rc = run_body(s); if (rc) return rc;
     }
-    flush(false);
-    remd_launch_join_wait(h);
-    h->force_zeroed = zeroed_by_chain;
-    REMD_CHECK(h, hipGetLastError());
+
+    int end()
+    {
+        if (done_by_resident) return 0;
+        flush(false);
+        remd_launch_join_wait(h);
+        h->force_zeroed = zeroed_by_chain;
+        REMD_CHECK(h, hipGetLastError());
+        return 0;
+    }
+};
+
+int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
+                   int64_t iteration, int64_t first_step, int n_steps)
+{
+    step_runner sr;
+    int rc = sr.begin(h, tokens, nV, nR, nO, iteration, first_step, n_steps);
+    if (rc) return rc;
+    for (int s = 0; s < n_steps && !sr.done_by_resident; ++s) {
+        remd_nb_tune_step(h, n_steps - s);
+        rc = sr.step(s); if (rc) return rc;
+    }
+    return sr.end();
+}
+
+// Several handles of ONE device, one host thread, the MD steps of the handles taking turns: handle 0's step s, handle 1's step s, ...
+// Each handle keeps its own pair of streams, so the integrator chain of one group of replicas (a few hundred wavefronts waiting for one
+// dependent thing after another) runs beside the pair and mesh kernels of another.  Nothing here waits for the device.
+int remd_run_steps_many(remd_ctx** hs, int n, int64_t iteration, int64_t first_step, int n_steps)
+{
+    std::vector<step_runner> sr((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        hipSetDevice(hs[i]->device);
+        int rc = sr[i].begin(hs[i], hs[i]->tokens, hs[i]->nV, hs[i]->nR, hs[i]->nO, iteration, first_step, n_steps);
+        if (rc) return rc;
+    }
+    for (int s = 0; s < n_steps; ++s)
+        for (int i = 0; i < n; ++i) {
+            if (sr[i].done_by_resident) continue;
+            remd_nb_tune_step(hs[i], n_steps - s);
+            int rc = sr[i].step(s); if (rc) return rc;
+        }
+    for (int i = 0; i < n; ++i) { int rc = sr[i].end(); if (rc) return rc; }
     return 0;
 }
 

@@ -202,6 +202,11 @@ struct remd_ctx {
     // set when a wait polled on the device ran out / a capped PME bin overflowed: the handle falls back to events, two chain
     // launches and the binning launch (api.hip: remd_recover_device_flag) instead of staying dead behind a sticky flag
     bool no_device_waits = false, no_chain_bins = false, no_resident = false;
+    // round 6, several handles propagated step by step from one host thread (remd_propagate_many): no workgroup of this handle may sit
+    // on a CU polling for another stream while it holds registers another handle's kernels need -- the join is a one-wavefront launch
+    // in front of the chain instead of a poll in the chain's prologue (320 registers per lane on every CU it occupies), the momentum
+    // sum two launches instead of a barrier over resident workgroups
+    bool lean_waits = false;
     unsigned long long* d_chain_own = nullptr;   // [2] profiling: sum of (end - flag seen) wall-clock ticks of workgroup (0, 0), launches
     unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
@@ -277,6 +282,7 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
 int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO, int* nVg = nullptr);
 int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
                    int64_t iteration, int64_t first_step, int n_steps);
+int remd_run_steps_many(remd_ctx** hs, int n, int64_t iteration, int64_t first_step, int n_steps);   // the handles' steps taking turns
 int remd_assign_velocities(remd_ctx* h, int64_t iteration);
 int remd_kinetic_energy(remd_ctx* h);
 int remd_work_buffers(remd_ctx* h);                    // heat / shadow-work accumulators and the '{' snapshot of the local replicas

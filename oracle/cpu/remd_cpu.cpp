@@ -1544,6 +1544,20 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     return 0;
 }
 
+// the device library interleaves the handles' MD steps on one GPU; here the handles are simply propagated one after the other (same results)
+int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* nan_flags)
+{
+    if (!hs || n < 1) return -1;
+    int off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) return -1;
+        const int rc = remd_propagate(hs[i], iteration, nan_flags ? nan_flags + off : nullptr);
+        if (rc) return rc;
+        off += hs[i]->R;
+    }
+    return 0;
+}
+
 int remd_step(remd_handle h, const char* splitting, int64_t iteration, int64_t first_step, int n_steps)
 {
     if (!h || !h->has_system || h->R <= 0 || h->K <= 0) return fail(h, -1, "remd_step: not set up");

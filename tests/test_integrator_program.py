@@ -7,8 +7,9 @@ group 0, angles in group 1, no constraints) with the noise this repository's eng
   * the f64 oracle integrator (oracle/md_oracle.py OracleLangevin on oracle/forcefield.py) and
   * the C++ port (libremd_cpu.so, through the C ABI of include/remd_hip.h)
 must reproduce positions and velocities after every step, the heat and shadow work the reference accumulates, and the Metropolis
-decisions -- for ten splitting strings incl. g-BAOAB, multiple-time-step and Metropolized ones.  (The HIP kernels are held to the same
-oracle by the -m gpu parity tests.)  Constraints are OpenMM's (addConstrainPositions / addConstrainVelocities), not the reference's:
+decisions -- for ten splitting strings incl. g-BAOAB, multiple-time-step and Metropolized ones; under -m gpu the HIP integrator chain
+(libremd_hip.so) is compared with the same fixture DIRECTLY at fp32 tolerances (round 6; measured worst deviations 8e-8 nm / 1.4e-5 nm/ps,
+profiles/r06_1_integrator_program.txt).  Constraints are OpenMM's (addConstrainPositions / addConstrainVelocities), not the reference's:
 the fixture has none."""
 import json
 import os
@@ -81,7 +82,7 @@ def test_oracle_integrator_follows_the_references_program(k):
 
 
 def check_engine(make_engine, k, atol_x, atol_v, rtol_work, mts=True):
-    """an engine behind the C ABI against case k of the fixture (also used by tools/gpu_check_integrator_program.py on the device)"""
+    """an engine behind the C ABI against case k of the fixture (the CPU library and, under -m gpu, the device)"""
     c = G['cases'][k]
     if not mts and any(ch.isdigit() for ch in c['splitting']):
         pytest.skip('multiple-time-step splittings are not in the CPU library (it refuses them by name); the oracle and the device have them')
@@ -115,6 +116,15 @@ def test_cpu_port_follows_the_references_program(k):
     if not os.path.exists(CPU_LIB):
         oracle.build()
     check_engine(lambda: HipEngine(lib_path=CPU_LIB), k, 1e-11, 1e-9, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', CASES)
+def test_hip_chain_follows_the_references_program(k):
+    """integrators.py:1404-1460 executed (the fixture) against csrc/integrate.hip through the C ABI: positions and velocities after EVERY
+    step, heat / shadow work, Metropolis decisions.  fp32 state: 5e-7 nm on positions of order 0.1 nm, 5e-5 nm/ps on velocities of order
+    1 nm/ps (measured 8e-8 / 1.4e-5), work to 2e-3 (2^-24 kJ/mol fixed point of fp32 kinetic energies)."""
+    check_engine(lambda: HipEngine(), k, 5e-7, 5e-5, 2e-3)
 
 
 @pytest.mark.parametrize('k', range(len(G['other_integrators'])))
