@@ -130,13 +130,14 @@ int  remd_set_states(remd_handle h, int K, const double* beta,
 
 /* LangevinIntegrator (integrators.py:1071-1158) as used by
    mcmc.LangevinSplittingDynamicsMove (mcmc.py:1280-1316): splitting string of V/R/O tokens.
-   constraint_tolerance (reference default 1e-8, integrators.py:1073): NOT an iteration threshold in libremd_hip.so.  Rigid
-   waters are solved analytically (SETTLE).  X-H star clusters (<= 3 hydrogens on one heavy atom) get a fixed amount of work:
-   positions by three Newton iterations on the K x K system of Lagrange multipliers (quadratic convergence from the
-   unconstrained step: residual at the fp32 round-off of the coordinates, ~1e-6 relative to the bond length, after two),
-   velocities by one exact K x K linear solve.  The value is accepted for interface parity and ignored by both solvers; a
-   request below 1e-6 cannot be met by fp32 coordinates and the host classes say so once.  tests/test_forcefield_parity.py
-   (test_alanine_constraints_and_substeps) bounds the residual.  libremd_cpu.so (f64) iterates to 1e-12.                  */
+   constraint_tolerance (reference default 1e-8, integrators.py:1073): a relative distance error, as OpenMM's.  Rigid waters are
+   solved analytically (SETTLE).  X-H star clusters (<= 3 hydrogens on one heavy atom): positions by Newton iterations on the K x K
+   system of Lagrange multipliers until every bond is within max(constraint_tolerance, 2e-7) -- fp32 coordinates relative to the
+   cluster's central atom hold no more -- with at most 8 updates (remd_get_constraint_stats reports what was needed; quadratic
+   convergence from the unconstrained step: two or three); velocities by one exact K x K linear solve.  A request below 2e-7 is
+   served at 2e-7 and the host classes say so once.  tests/test_forcefield_parity.py
+   (test_constraint_tolerance_sets_the_newton_iterations_of_the_xh_solve, test_alanine_constraints_and_substeps) hold it.
+   libremd_cpu.so (f64) iterates to the tolerance itself.                                                                        */
 int  remd_set_integrator(remd_handle h, const char* splitting, double timestep_ps,
                          double collision_rate_invps, int n_steps,
                          int reassign_velocities, double constraint_tolerance);
@@ -240,6 +241,13 @@ int  remd_seed(remd_handle h, uint64_t seed);
    BaseIntegratorMove.apply (mcmc.py:668-776) for every local replica at once: optional
    Maxwell-Boltzmann velocity reassignment, n_steps of the splitting, NaN flag per replica.
    nan_flags: host [R_local] or NULL.                                                     */
+/* Position constraints of X-H star clusters are solved by Newton iterations on the cluster's multipliers until every bond is within
+   the integrator's constraint_tolerance (a relative distance error, as OpenMM's; integrators.py:1416-1418 addConstrainPositions), but no
+   tighter than 2e-7 -- what fp32 coordinates relative to the cluster's central atom hold -- and with at most 8 updates.  Rigid waters
+   are analytic (SETTLE), velocity constraints one exact K x K solve.  max_newton_iterations: the most updates any position solve of this
+   handle has needed since remd_create; unconverged: 1 when a solve reached the bound without meeting the tolerance.                 */
+int  remd_get_constraint_stats(remd_handle h, int32_t* max_newton_iterations, int32_t* unconverged);
+
 int  remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags);
 
 /* remd_propagate for SEVERAL handles of one device in one call from one host thread (round 6): the handles' MD steps take turns, each

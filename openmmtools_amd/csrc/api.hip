@@ -467,6 +467,18 @@ int remd_get_work(remd_handle h, double* heat, double* shadow_work, int64_t* n_a
     return 0;
 }
 
+int remd_get_constraint_stats(remd_handle h, int32_t* max_newton_iterations, int32_t* unconverged)
+{
+    if (!h || !h->d_sync) return remd_fail(h, -1, "remd_get_constraint_stats: no handle");
+    hipSetDevice(h->device);
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    unsigned int w = 0;
+    REMD_CHECK(h, hipMemcpy(&w, h->d_sync + 3, sizeof(unsigned int), hipMemcpyDeviceToHost));
+    if (max_newton_iterations) *max_newton_iterations = (int32_t)std::min(w, 8u);
+    if (unconverged) *unconverged = w > 8u ? 1 : 0;
+    return 0;
+}
+
 int remd_set_restart_attempts(remd_handle h, int n)
 {
     if (!h || n < 0) return remd_fail(h, -1, "remd_set_restart_attempts: bad arguments");
@@ -632,7 +644,9 @@ int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* 
     }
     int rc = 0;
     for (int i = 0; i < n && !rc; ++i) if (hs[i]->reassign) rc = remd_assign_velocities(hs[i], iteration);
+    const auto t_enq0 = std::chrono::steady_clock::now();
     if (!rc) rc = remd_run_steps_many(hs, n, iteration, 0, hs[0]->n_steps);
+    const auto t_enq1 = std::chrono::steady_clock::now();
     std::vector<std::vector<int>> flags((size_t)n);
     std::vector<unsigned int> spin((size_t)n, 0u);
     for (int i = 0; i < n && !rc; ++i) {
@@ -650,6 +664,10 @@ int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* 
         if (h->stream2) hipStreamSynchronize(h->stream2);
     }
     if (rc) return rc;
+    if (getenv("REMD_MANY_VERBOSE"))
+        fprintf(stderr, "[remd] remd_propagate_many: %d handles, host enqueue of the steps %.2f ms, until the device was done %.2f ms\n", n,
+                1e3 * std::chrono::duration<double>(t_enq1 - t_enq0).count(),
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq0).count());
     int off = 0;
     for (int i = 0; i < n; ++i) {
         remd_ctx* h = hs[i];

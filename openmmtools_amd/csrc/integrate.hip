@@ -57,6 +57,7 @@ __device__ __forceinline__ char chain_tok(const chain_prog& prog, int t)
 
 // state of one constraint unit between the segments of a chain (registers)
 struct unit_regs { float3 x[4], v[4]; float im[4]; float heat, shadow;
+    int shake_it;                            // most Newton updates a position solve of this unit needed in this launch (X-H clusters)
     float cmx, cmy, cmz; int have_cm;        // centre-of-mass velocity from an 'M' token of this launch, for the 'C' that follows it
 #ifdef CHAIN_STAMPS
     unsigned long long* stamps; unsigned long long t_last;     // tools/chain_segments.py: per-token wall-clock of workgroup (0, 0)
@@ -167,11 +168,15 @@ __device__ __forceinline__ void solve_small(const float (&A)[3][3], const float 
 // vectors r0_q with one multiplier per bond; instead of Gauss-Seidel sweeps over the bonds (6-10 sweeps, data dependent,
 // and the one wavefront holding the solute's clusters used to set the duration of the whole integrator launch) the K x K
 // system  |s_q + sum_p B_qp lam_p r0_p|^2 = d_q^2,  B_qp = 1/m_0 + delta_qp / m_q,  is solved by Newton iterations with the
-// exact Jacobian (quadratic convergence: a half step moves bond lengths by < 1 %, so two iterations reach fp32 round-off; three
-// are done), a fixed number of them so that the wave never diverges.
+// exact Jacobian (quadratic convergence: a half step moves bond lengths by < 1 %, so two iterations reach fp32 round-off).
+// Round 6: the iteration runs until every bond of the cluster is within the integrator's constraint tolerance (integrators.py:1416-1418:
+// addConstrainPositions works to getConstraintTolerance(), a RELATIVE distance error) -- | |r|^2 - d^2 | <= 2 tol d^2 -- with tol no
+// smaller than what fp32 lengths can hold (the caller passes max(tol, 2e-7)) and at most SHAKE_MAX_IT updates; before it was a fixed
+// three updates whatever the tolerance.  Returns the number of updates made, SHAKE_MAX_IT + 1 when the bound was reached unconverged.
 // NAT is a compile-time constant so that every array lives in registers (no scratch).
+#define SHAKE_MAX_IT 8
 template <int NAT>
-__device__ __forceinline__ void shake_positions(const float* im, const float* d, float /*tol*/, const float3* p0, float3* p1)
+__device__ __forceinline__ int shake_positions(const float* im, const float* d, float tol, const float3* p0, float3* p1)
 {
     constexpr int K = NAT - 1;
     float3 r0[3], sv[3];
@@ -181,17 +186,21 @@ __device__ __forceinline__ void shake_positions(const float* im, const float* d,
         r0[q] = q < K ? p0[q + 1] - p0[0] : f3(0, 0, 0);
         sv[q] = q < K ? p1[q + 1] - p1[0] : f3(0, 0, 0);
     }
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    const float tol2 = 2.f * tol;
+    int it = 0;
+    for (;; ++it) {
         float3 acc = f3(0, 0, 0);                                   // im0 * sum_p lam_p r0_p (the central atom's share)
 #pragma unroll
         for (int p = 0; p < K; ++p) acc = acc + r0[p] * (lam[p] * im[0]);
         float J[3][3], g[3], dl[3];
+        bool converged = true;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             if (q < K) {
                 const float3 cur = sv[q] + acc + r0[q] * (lam[q] * im[q + 1]);
-                g[q] = d[q] * d[q] - dot3(cur, cur);
+                const float d2 = d[q] * d[q];
+                g[q] = d2 - dot3(cur, cur);
+                converged = converged && fabsf(g[q]) <= tol2 * d2;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) J[q][p] = p < K ? 2.f * dot3(cur, r0[p]) * (im[0] + (p == q ? im[q + 1] : 0.f)) : 0.f;
             } else {
@@ -200,6 +209,8 @@ __device__ __forceinline__ void shake_positions(const float* im, const float* d,
                 for (int p = 0; p < 3; ++p) J[q][p] = p == q ? 1.f : 0.f;
             }
         }
+        if (converged) break;
+        if (it == SHAKE_MAX_IT) { it = SHAKE_MAX_IT + 1; break; }
         solve_small<K>(J, g, dl);
 #pragma unroll
         for (int q = 0; q < K; ++q) lam[q] += dl[q];
@@ -209,6 +220,7 @@ __device__ __forceinline__ void shake_positions(const float* im, const float* d,
         p1[0] = p1[0] - r0[q] * (lam[q] * im[0]);
         p1[q + 1] = p1[q + 1] + r0[q] * (lam[q] * im[q + 1]);
     }
+    return it;
 }
 
 // Velocity constraints of a star cluster: the multipliers solve a K x K LINEAR system exactly (no iteration):
@@ -333,7 +345,7 @@ __device__ __forceinline__ float3 run_unit(const chain_prog& prog, const int* id
                     q[k] = p1[k];
                 }
                 if (TYPE == UNIT_SETTLE) settle_positions(sc, p0, p1);
-                else shake_positions<NAT>(im, dist, tol, p0, p1);
+                else S.shake_it = max(S.shake_it, shake_positions<NAT>(im, dist, tol, p0, p1));
                 const float ih = frcp(prog.hR);
                 const float3 org = x[0];
 #pragma unroll
@@ -430,7 +442,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
     float kT = 0.f;
     uint32_t rg = 0u;
     unit_regs S;
-    S.have_cm = 0;
+    S.have_cm = 0; S.shake_it = 0;
     if (EARLY) {
         if (uidx < n_units) {
             a4 = unit_atoms[uidx]; type = (int)unit_type[uidx];
@@ -662,6 +674,11 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
             if (prog.measure & 2) atomicAdd(&w[1], (unsigned long long)(long long)((double)sw * 16777216.0));
         }
     }
+    // most Newton updates any X-H position solve of this handle has needed (remd_get_constraint_stats): d_sync[3], next to the fault
+    // word.  The word only ever grows and stops changing after the first steps, so a lane looks before it writes (no atomic otherwise).
+    if (type == UNIT_SHAKE && S.shake_it > 0 &&
+        (unsigned int)S.shake_it > __hip_atomic_load(chain_sync_err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(chain_sync_err + 1, (unsigned int)S.shake_it);
     if (own_time && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         atomicAdd(&own_time[0], wall_clock64() - own_t0);
         atomicAdd(&own_time[1], 1ull);
@@ -912,7 +929,7 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
     const bool two = two_env != nullptr && atoi(two_env) != 0;
     auto kern = two ? integrate_chain2_kernel : integrate_chain_kernel;
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, prog, ut.n_units, ut.d_atoms, ut.d_type,
-                       ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_force,
+                       ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, REMD_CONSTRAINT_TOL_FLOOR), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0),
                        h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, reinterpret_cast<unsigned long long*>(h->d_chain_sync), h->d_sync + 2,
@@ -1520,7 +1537,7 @@ int remd_assign_velocities(remd_ctx* h, int64_t iteration)
     remd_prof_scope ps(h, "assign_velocities");
     dim3 grid((ut.n_units + 255) / 256, h->R);
     hipLaunchKernelGGL(assign_velocities_kernel, grid, dim3(256), 0, h->stream, ut.n_units, ut.d_atoms, ut.d_type, ut.sc,
-                       (float)fmax(h->constraint_tol, 1e-6), h->Npad, h->d_pos, h->d_vel, h->d_invmass, h->d_labels,
+                       (float)fmax(h->constraint_tol, REMD_CONSTRAINT_TOL_FLOOR), h->Npad, h->d_pos, h->d_vel, h->d_invmass, h->d_labels,
                        h->d_beta, h->r_begin, h->seed, iteration, h->d_noise_id);
     REMD_CHECK(h, hipGetLastError());
     return 0;
@@ -1583,7 +1600,7 @@ __device__ __forceinline__ void fire_move_unit(const int* idx, const float* dist
 #pragma unroll
         for (int k = 0; k < NAT; ++k) { p0[k] = x[k] - x[0]; p1[k] = p0[k] + v[k] * dt; q[k] = p1[k]; }
         if (TYPE == UNIT_SETTLE) settle_positions(sc, p0, p1);
-        else shake_positions<NAT>(im, dist, tol, p0, p1);
+        else (void)shake_positions<NAT>(im, dist, tol, p0, p1);
         const float ih = frcp(dt);
         const float3 org = x[0];
 #pragma unroll
@@ -1767,7 +1784,7 @@ int remd_minimize_impl(remd_ctx* h, double tolerance, int max_iterations, int32_
     REMD_CHECK(h, hipMemcpyAsync(st, init.data(), sizeof(fire_rep) * init.size(), hipMemcpyHostToDevice, h->stream));
     // "velocities should be set to zero before using this integrator" (integrators.py:2341)
     REMD_CHECK(h, hipMemsetAsync(h->d_vel, 0, sizeof(float4) * (size_t)R * Npad, h->stream));
-    const float tol = (float)fmax(h->constraint_tol, 1e-6);
+    const float tol = (float)fmax(h->constraint_tol, REMD_CONSTRAINT_TOL_FLOOR);
     int cur = 0, rc = 0, it = 0;
     h->forces_valid = false; h->force_zeroed = false;
     if ((rc = remd_compute_forces(h, true))) { cleanup(); return rc; }

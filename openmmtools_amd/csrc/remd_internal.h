@@ -18,6 +18,9 @@ struct remd_error { int code; std::string msg; };
 
 // fixed-point scale of the force accumulators (deterministic integer atomics)
 #define REMD_FORCE_SCALE 4294967296.0   // 2^32
+// what the X-H position solve is held to when the integrator asks for less: relative bond-length error of fp32 coordinates taken
+// relative to the cluster's central atom (a few units in the last place of |r|^2)
+#define REMD_CONSTRAINT_TOL_FLOOR 2e-7
 
 // scaled fractional mesh coordinate u in [0, n) of a position component and its integer part: ONE definition, because the PME
 // spreading pass recomputes the mesh column of an atom that was binned elsewhere (pme_bin_kernel or the integrator chain's

@@ -582,11 +582,11 @@ class MultiStateSampler:
         eng = self._engine
         if move is not None:
             has_constraints = self._thermodynamic_states[0].system.getNumConstraints() > 0
-            if getattr(eng, 'is_device', False) and has_constraints and move.constraint_tolerance < 1e-6 and not getattr(self, '_warned_tolerance', False):
-                # include/remd_hip.h: the fp32 state bounds what the iterative X-H solver can reach (SETTLE waters are analytic)
-                logger.warning('constraint_tolerance %g is below what fp32 coordinates can hold (~1e-6 relative); the device solves '
-                               'X-H clusters with a fixed three Newton iterations and rigid waters analytically, whatever the '
-                               'tolerance', move.constraint_tolerance)
+            if getattr(eng, 'is_device', False) and has_constraints and move.constraint_tolerance < 2e-7 and not getattr(self, '_warned_tolerance', False):
+                # include/remd_hip.h (remd_get_constraint_stats): the fp32 state bounds what the X-H solver can reach (SETTLE waters are analytic)
+                logger.warning('constraint_tolerance %g is below what fp32 coordinates can hold: the device iterates X-H clusters to a '
+                               'relative bond-length error of 2e-7 (at most 8 Newton updates) and solves rigid waters analytically',
+                               move.constraint_tolerance)
                 self._warned_tolerance = True
             eng.set_integrator(move.splitting, getattr(move, 'engine_timestep', move.timestep), move.collision_rate, move.n_steps,
                                move.reassign_velocities, move.constraint_tolerance)

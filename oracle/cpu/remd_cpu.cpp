@@ -1544,6 +1544,15 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     return 0;
 }
 
+// the CPU port's SHAKE / RATTLE iterate in f64 to the tolerance itself; it keeps no statistics
+int remd_get_constraint_stats(remd_handle h, int32_t* max_newton_iterations, int32_t* unconverged)
+{
+    if (!h) return -1;
+    if (max_newton_iterations) *max_newton_iterations = 0;
+    if (unconverged) *unconverged = 0;
+    return 0;
+}
+
 // the device library interleaves the handles' MD steps on one GPU; here the handles are simply propagated one after the other (same results)
 int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* nan_flags)
 {

@@ -715,9 +715,34 @@ def test_config5_dhfr_hamiltonian_ladder_columns(hip_engine_factory):
     assert np.abs(np.diff(rows[0])).max() < 10.0                 # ten waters discharged over 64 states: 6.3 kT per rung
 
 
-def test_energy_drift_bounds_the_fixed_iteration_constraint_solver(hip_engine_factory):
-    """The device solves X-H clusters with a fixed three Newton iterations and rigid waters analytically, whatever
-    constraint_tolerance says (include/remd_hip.h).  What that means for the dynamics, in the terms that matter: velocity
+def test_constraint_tolerance_sets_the_newton_iterations_of_the_xh_solve(hip_engine_factory):
+    """Round 6: the X-H position solve iterates until every bond of a cluster is within constraint_tolerance (relative, as OpenMM's
+    addConstrainPositions that integrators.py:1416-1418 calls), no tighter than 2e-7 and with at most 8 updates, instead of a fixed
+    three.  A loose tolerance stops after fewer updates than a tight one; anything below the fp32 floor is the floor, bit for bit;
+    no solve runs into the bound; bond lengths read back from the stored (absolute, fp32) coordinates are within the tolerance or
+    the ~1e-5 that storing 0.1 nm bonds at 3 nm from the origin costs."""
+    al = ts.AlanineDipeptideExplicit()
+    cons = mo.OracleSystem(system_to_desc(al.system)).constraints
+    res = {}
+    for tol in (1e-3, 2e-7, 1e-8):
+        eng = hip_engine_factory()
+        _engine_for(eng, al.system, al.positions, R=2, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=60)
+        eng.set_integrator('V R R O R R V', 0.002, 1.0, 60, True, tol)
+        eng.propagate(0)
+        x, v = eng.get_replicas()[:2]
+        i, j, d = np.array([c[0] for c in cons]), np.array([c[1] for c in cons]), np.array([c[2] for c in cons])
+        rel = np.abs(np.linalg.norm(x[:, i] - x[:, j], axis=-1) - d) / d
+        res[tol] = (x, v, rel.max(), eng.constraint_stats())
+    for tol, (x, v, worst, (n_it, unconverged)) in res.items():
+        assert not unconverged and 1 <= n_it <= 8, (tol, n_it, unconverged)
+        assert worst < max(1.5 * tol, 2e-5), (tol, worst)
+    assert res[1e-3][3][0] < res[1e-8][3][0], (res[1e-3][3], res[1e-8][3])          # fewer updates at the loose tolerance
+    assert np.array_equal(res[2e-7][0], res[1e-8][0]) and np.array_equal(res[2e-7][1], res[1e-8][1])
+
+
+def test_energy_drift_bounds_the_constraint_solver(hip_engine_factory):
+    """The device solves X-H clusters by Newton iterations to constraint_tolerance (no tighter than 2e-7: the fp32 floor) and rigid
+    waters analytically (include/remd_hip.h).  What that means for the dynamics, in the terms that matter: velocity
     Verlet ('V R V', no thermostat) on alanine dipeptide in water at 1 fs conserves K + U to a small fraction of kT per
     degree of freedom over 0.4 ps -- the bar OpenMM's own constraint tolerance (1e-5 by default there) is held to."""
     al = ts.AlanineDipeptideExplicit()

@@ -68,7 +68,7 @@ def test_headline_ensemble_temperatures_constraints_and_swap_rates(hip_engine_fa
         d = x[:, j] - x[:, i]
         d -= box * np.round(d / box)
         worst = max(worst, float(np.abs(np.linalg.norm(d, axis=1) / d0 - 1.0).max()))
-    assert worst < 2e-5, worst                                    # f32 positions: 1e-7 nm on 0.1 nm, three Newton iterations of the X-H solver
+    assert worst < 2e-5, worst                                    # f32 positions: 1e-7 nm on 0.1 nm, Newton iterations of the X-H solver to 2e-7
     # neighbour swap acceptance against the two-ensemble expectation
     nsig_max = 0.0
     for k in range(R - 1):
