@@ -35,6 +35,10 @@ import os
 import sys
 import time
 
+# (before torch / HIP start: two hardware queues per stream priority keep the process at the chip's four pipes when the engine runs its
+# replicas as two phases -- openmmtools_amd/__init__.py, include/remd_hip.h: remd_set_phases)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -386,12 +390,13 @@ def main():
         n_xy, ms_xy = engine.profile_get('pme_xy')
         roof_nb = roof_xy = None
         if n_launch > 0:
-            flops = FLOP_PER_ATOM_NONBONDED * n_atoms * n_local
+            phases = engine.phases_active() if hasattr(engine, 'phases_active') else 1
+            flops = FLOP_PER_ATOM_NONBONDED * n_atoms * n_local / float(phases)      # a launch covers one phase's share of the replicas
             avg_ms = (ms + ms_lj) / n_launch
             achieved = flops / (avg_ms * 1e-3) / 1e12
             roof_nb = dict(kernel='nonbonded_sci2_kernel', bound='mfma', achieved=achieved, peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
                            frac=achieved / FP32_PEAK_TFLOPS, traffic=pmc_traffic_bytes('nonbonded_sci2_kernel'),
-                           launches=n_launch, avg_launch_ms=avg_ms, total_ms=ms + ms_lj,
+                           launches=n_launch, avg_launch_ms=avg_ms, total_ms=ms + ms_lj, phases=phases, replicas_per_launch=n_local / float(phases),
                            traffic_source=pmc_traffic_source(), traffic_source_is_this_kernel=pmc_traffic_is_current(),
                            note='fp32 VALU kernel (no MFMA: "mfma" is the contract\'s name for the compute roof); peak = FP32 vector rate = '
                                 'f32-input MFMA rate (157.3 TFLOP/s); algorithmic work = 10 kflop/atom (SURVEY 8(d): ~210 pairs per atom '
@@ -404,7 +409,7 @@ def main():
             # algorithmic bytes (SURVEY 8(d) "grid traffic 8 B x G per pass"): the half spectrum [nz/2+1][nx][ny] complex f32 of
             # every replica is read once and written once by the plane-resident XY pass
             nx, ny, nz = ewald['pme_grid']
-            nbytes = 2.0 * 8.0 * (nz // 2 + 1) * nx * ny * n_local
+            nbytes = 2.0 * 8.0 * (nz // 2 + 1) * nx * ny * n_local / float(engine.phases_active() if hasattr(engine, 'phases_active') else 1)
             avg_ms = ms_xy / n_xy
             achieved = nbytes / (avg_ms * 1e-3) / 1e9
             roof_xy = dict(kernel='pme_xy_fused_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
@@ -431,7 +436,7 @@ def main():
             # number uses the launch's OWN time: flag seen -> end, from wall-clock stamps inside the kernel (workgroup (0, 0))
             avg_launch_ms = ms_ch / n_ch
             avg_ms = ms_own / n_own if n_own > 0 else avg_launch_ms
-            achieved = 64.0 * n_atoms * n_local / (avg_ms * 1e-3) / 1e9
+            achieved = 64.0 * n_atoms * n_local / float(engine.phases_active() if hasattr(engine, 'phases_active') else 1) / (avg_ms * 1e-3) / 1e9
             roof_ch = dict(kernel='integrate_chain_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                            frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic_bytes('integrate_chain_kernel'), launches=n_ch,
                            avg_launch_ms=avg_ms, avg_launch_to_end_ms=avg_launch_ms, total_ms=ms_ch,
@@ -457,7 +462,8 @@ def main():
                                         % args.md_steps,
                                replicas_per_gpu=(n_replicas / float(world)), replicas_total=n_replicas, md_steps=args.md_steps,
                                mode=('strong: one %d-replica ensemble' % n_replicas) if strong else 'weak: 24 replicas per GPU',
-                               parallelism='replica-sharded x%d' % world, seed=SEED, ewald=ewald),
+                               parallelism='replica-sharded x%d' % world, seed=SEED, ewald=ewald,
+                               phases_per_gpu=(engine.phases_active() if hasattr(engine, 'phases_active') else 1)),
                    timing=timing_of_timed_region, roofline=roof, roofline_secondary=roof2, roofline_integrator=roof_ch, shapes=None)
         try:
             # achievable roofs of THIS box (STREAM triad past the Infinity Cache, FMA chains), SURVEY 8(d)

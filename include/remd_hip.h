@@ -241,6 +241,20 @@ int  remd_seed(remd_handle h, uint64_t seed);
    BaseIntegratorMove.apply (mcmc.py:668-776) for every local replica at once: optional
    Maxwell-Boltzmann velocity reassignment, n_steps of the splitting, NaN flag per replica.
    nan_flags: host [R_local] or NULL.                                                     */
+/* Phases (round 6): remd_propagate of ONE handle as two blocks of its local replicas whose MD steps take turns on the device -- block
+   A's step s, block B's step s, A's step s + 1, ... enqueued by the calling thread, block A on the handle's own pair of streams, block B
+   on one more pair -- so that the integrator chain of one block (the serial part of an MD step: a few hundred wavefronts waiting for
+   one dependent thing after another) runs beside the pair and mesh kernels of the other.  Replicas are independent between two mixes
+   (multistatesampler.py:1296-1297; the reference propagates them one after the other or one per MPI rank), and every per-replica result
+   is the one-block result bit for bit (fixed-point force sums, Philox streams keyed by the global replica, the same schedule of spatial
+   re-sorts).  n: 0 = by rule (two blocks when the environment variable GPU_MAX_HW_QUEUES is 1 or 2 and the handle holds 16 replicas or
+   more: HIP's default of 4 queues per priority gives the second block's main stream a FIFTH hardware queue, and queues beyond the four
+   pipes of the chip are time-sliced -- two blocks then run 55 % slower than one instead of 10 % faster), 1 = one block, 2 = two blocks.
+   Only PME systems under a plain V / R / O splitting without barostat, work measurement or Metropolization run as phases; everything
+   else, and every other entry point, is unchanged.  remd_get_phases: the number of blocks the last remd_propagate ran as.            */
+int  remd_set_phases(remd_handle h, int32_t n);
+int  remd_get_phases(remd_handle h, int32_t* n);
+
 /* Position constraints of X-H star clusters are solved by Newton iterations on the cluster's multipliers until every bond is within
    the integrator's constraint_tolerance (a relative distance error, as OpenMM's; integrators.py:1416-1418 addConstrainPositions), but no
    tighter than 2e-7 -- what fp32 coordinates relative to the cluster's central atom hold -- and with at most 8 updates.  Rigid waters

@@ -42,7 +42,7 @@ EXPORTS = [
     'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_alchemical_options', 'remd_set_states',
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_copy_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
-    'remd_get_forces', 'remd_propagate_many', 'remd_get_constraint_stats', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
+    'remd_get_forces', 'remd_propagate_many', 'remd_set_phases', 'remd_get_phases', 'remd_get_constraint_stats', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
     'remd_profile_get', 'remd_profile_reset', 'remd_test_fft3d', 'remd_get_energy_components', 'remd_profile_filter',
     'remd_set_restart_attempts', 'remd_set_force_groups', 'remd_set_work_measurement', 'remd_get_work', 'remd_reset_work', 'remd_minimize', 'remd_set_barostat', 'remd_get_boxes', 'remd_get_barostat_stats',
     'remd_barostat_attempts',
@@ -113,6 +113,8 @@ def load_library(path=None):
     lib.remd_get_forces.argtypes = [vp, c_double_p]
     lib.remd_propagate_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
     lib.remd_get_constraint_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.remd_set_phases.argtypes = [vp, C.c_int32]
+    lib.remd_get_phases.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.remd_step.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64, C.c_int]
     lib.remd_sync.argtypes = [vp]
     lib.remd_get_energy_components.argtypes = [vp, c_double_p]
@@ -383,6 +385,17 @@ class HipEngine:
         a, b = C.c_int32(0), C.c_int32(0)
         self._check(self.lib.remd_get_constraint_stats(self.h, C.byref(a), C.byref(b)), 'remd_get_constraint_stats')
         return int(a.value), bool(b.value)
+
+    def set_phases(self, n):
+        """remd_set_phases: 0 = by rule (two blocks of replicas whose MD steps take turns when the process keeps few hardware queues),
+        1 = one block, 2 = two blocks"""
+        self._check(self.lib.remd_set_phases(self.h, int(n)), 'remd_set_phases')
+
+    def phases_active(self):
+        """blocks the last propagate ran as"""
+        n = C.c_int32(1)
+        self._check(self.lib.remd_get_phases(self.h, C.byref(n)), 'remd_get_phases')
+        return int(n.value)
 
     @staticmethod
     def propagate_many(engines, iteration):

@@ -120,6 +120,9 @@ int remd_destroy(remd_handle h)
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    for (remd_ctx* c : h->phase) remd_destroy(c);         // (block 0 borrows this handle's streams: before they go)
+    h->phase.clear();
+    delete h->sysdesc; h->sysdesc = nullptr;
     remd_comm_release(h);
     remd_pme_destroy(h);
     remd_free_constraints(h);
@@ -139,7 +142,7 @@ int remd_destroy(remd_handle h)
     dfree(h->d_snap_pos); dfree(h->d_snap_vel); dfree(h->d_fin_pos); dfree(h->d_fin_vel); dfree(h->d_snap_box); dfree(h->d_fin_box);
     dfree(h->d_snap_work);
     dfree(h->d_nacc); dfree(h->d_nprop); dfree(h->d_logw); dfree(h->d_logP); dfree(h->d_ukl_tmp);
-    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->stream2 && !h->borrowed_stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     if (h->d_sync) hipFree(h->d_sync);
     if (h->d_chain_own) hipFree(h->d_chain_own);
@@ -153,7 +156,7 @@ int remd_destroy(remd_handle h)
     return 0;
 }
 
-int remd_seed(remd_handle h, uint64_t seed) { if (!h) return -1; h->seed = seed; return 0; }
+int remd_seed(remd_handle h, uint64_t seed) { if (!h) return -1; h->seed = seed; h->config_version++; return 0; }
 
 int remd_test_coulomb_table(double alpha, double coulomb_cutoff_nm, int n, const float* u, float* minus_G)
 {
@@ -203,6 +206,7 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
         if ((rc = upload(h, h->d_ext_atoms, ea))) return rc;
     }
     h->cmm_frequency = d->cmm_frequency;
+    if (!h->parent) { if (!h->sysdesc) h->sysdesc = new remd_desc_store(); h->sysdesc->assign(d); h->config_version++; }
     if ((rc = remd_build_constraints(h, d))) return rc;
     if ((rc = remd_build_nonbonded(h, d))) return rc;
     h->has_system = true;
@@ -214,7 +218,7 @@ int remd_set_states(remd_handle h, int K, const double* beta, const double* lam_
 {
     if (!h || K <= 0 || !beta) return remd_fail(h, -1, "remd_set_states: bad arguments");
     hipSetDevice(h->device);
-    h->K = K;
+    h->K = K; h->config_version++;
     h->beta.assign(beta, beta + K);
     h->lam_s.assign(K, 1.0); h->lam_e.assign(K, 1.0); h->econst.assign(K, 0.0);
     if (lam_s) h->lam_s.assign(lam_s, lam_s + K);
@@ -241,6 +245,7 @@ int remd_set_integrator(remd_handle h, const char* splitting, double dt, double 
     if (!(dt > 0) || n_steps < 0 || gamma < 0) return remd_fail(h, -1, "remd_set_integrator: bad parameters");
     int rc = remd_parse_splitting(h, splitting, h->tokens, h->nV, h->nR, h->nO, h->nVg);
     if (rc) return rc;
+    h->config_version++;
     h->splitting = splitting; h->dt = dt; h->gamma = gamma; h->n_steps = n_steps; h->reassign = reassign;
     h->constraint_tol = tol > 0 ? tol : 1e-8;
     h->has_integrator = true;
@@ -254,6 +259,7 @@ int remd_set_force_groups(remd_handle h, const int32_t* groups)
         if (groups[c] < 0 || groups[c] > 31) return remd_fail(h, -1, "remd_set_force_groups: force groups are 0 ... 31");
         h->fgroup[c] = groups[c];
     }
+    h->config_version++;
     return 0;
 }
 
@@ -262,7 +268,9 @@ int remd_set_replica_ids(remd_handle h, const int64_t* ids)
     if (!h || h->R <= 0) return remd_fail(h, -1, "remd_set_replica_ids: call remd_set_replicas first");
     hipSetDevice(h->device);
     if (h->d_noise_id) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_noise_id); h->d_noise_id = nullptr; }
+    h->noise_id_host.clear(); h->config_version++;
     if (!ids) return 0;                                   // back to the block's own global indices
+    h->noise_id_host.assign(ids, ids + h->R);
     std::vector<unsigned int> v(h->R);
     for (int r = 0; r < h->R; ++r) {
         if (ids[r] < 0 || ids[r] > 0xffffffffll) return remd_fail(h, -1, "remd_set_replica_ids: ids must fit 32 bits");
@@ -297,6 +305,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     hipSetDevice(h->device);
     const bool realloc = (R_local != h->R) || (R_global != h->R_global) || !h->d_pos;
     if (h->d_noise_id) { hipStreamSynchronize(h->stream); hipFree(h->d_noise_id); h->d_noise_id = nullptr; }     // ids belong to one set of replicas
+    h->noise_id_host.clear(); h->config_version++;
     h->R_global = R_global; h->r_begin = r_begin; h->R = R_local;
     const size_t n = (size_t)R_local * h->Npad;
     if (realloc) {
@@ -482,7 +491,7 @@ int remd_get_constraint_stats(remd_handle h, int32_t* max_newton_iterations, int
 int remd_set_restart_attempts(remd_handle h, int n)
 {
     if (!h || n < 0) return remd_fail(h, -1, "remd_set_restart_attempts: bad arguments");
-    h->n_restart_attempts = n;
+    h->n_restart_attempts = n; h->config_version++;
     return 0;
 }
 
@@ -518,11 +527,141 @@ static int remd_recover_device_flag(remd_ctx* h, unsigned int f, const char* whe
     return remd_fail(h, -2, std::string(where) + ": " + what);
 }
 
+// ---- phases: one handle's replicas as blocks whose MD steps take turns (remd_internal.h: remd_ctx::phase) -------------------------------
+int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* nan_flags);
+
+int remd_set_phases(remd_handle h, int32_t n)
+{
+    if (!h || n < 0 || n > 2) return remd_fail(h, -1, "remd_set_phases: 0 (by rule), 1 (off) or 2");
+    h->phases_req = n;
+    return 0;
+}
+
+int remd_get_phases(remd_handle h, int32_t* n)
+{
+    if (!h || !n) return -1;
+    *n = h->phases_last;
+    return 0;
+}
+
+// how many blocks the next remd_propagate of this handle runs as
+static int phases_for(remd_ctx* h)
+{
+    if (h->parent) return 1;
+    int want = h->phases_req;
+    if (const char* e = getenv("REMD_PHASES")) want = atoi(e);
+    if (want == 1) return 1;
+    // what the blocks' interleaved steps need (everything else takes the one-block path):
+    //  * a force evaluation that forks into the mesh and the direct-space stream (PME with overlap), a plain single-group V / R / O program
+    //    without work measurement, Metropolization or a barostat (their launches in between are not worth taking turns with);
+    //  * no communicator, no profiling of every class;
+    //  * two blocks that are each worth a launch: 8 replicas or more per block unless asked for explicitly.
+    if (!h->has_system || !h->has_integrator || !h->sysdesc || !h->sysdesc->valid) return 1;
+    if (h->nb_method != REMD_NB_PME || !h->overlap || !h->stream2) return 1;
+    if (h->baro_frequency > 0 || h->measure_heat || h->measure_shadow || h->profiling == 2 || h->comm) return 1;
+    for (char c : h->tokens) if (c != 'V' && c != 'R' && c != 'O') return 1;
+    if (h->R < 2) return 1;
+    if (want == 2) return 2;
+    // by rule: only when the process keeps its streams on few hardware queues.  Measured (profiles/r06_phases_*): two blocks on four
+    // hardware queues (two per priority) run the headline step 10 % faster than one block; with a FIFTH queue in the process (the HIP
+    // default GPU_MAX_HW_QUEUES = 4 gives the second block's main stream one) they run 55 % slower -- queues beyond the four pipes are
+    // time-sliced.  The Python package sets GPU_MAX_HW_QUEUES=2 before the runtime starts; a host that does not gets one block.
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    if (!q || atoi(q) < 1 || atoi(q) > 2) return 1;
+    return h->R >= 16 ? 2 : 1;
+}
+
+static int phase_children(remd_ctx* h, int P)
+{
+    if ((int)h->phase.size() == P && h->phase_config == h->config_version) return 0;
+    for (remd_ctx* c : h->phase) remd_destroy(c);
+    h->phase.clear();
+    for (int p = 0; p < P; ++p) {
+        remd_ctx* c = nullptr;
+        int rc = remd_create(&c, h->device, p == 0 ? (void*)h->stream : nullptr);
+        if (rc) return remd_fail(h, rc, "phases: remd_create of a block failed");
+        h->phase.push_back(c);
+        c->parent = h;
+        if (p == 0) {            // block 0 launches on this handle's own pair of streams (no hardware queue of its own)
+            if (c->stream2) hipStreamDestroy(c->stream2);
+            c->stream2 = h->stream2; c->borrowed_stream2 = true;
+        }
+        c->sync_events = h->sync_events; c->overlap = h->overlap;
+        c->annihilate_sterics = h->annihilate_sterics; c->coulomb_cutoff = h->coulomb_cutoff;
+        if ((rc = remd_set_system(c, &h->sysdesc->d))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+        if ((rc = remd_set_states(c, h->K, h->beta.data(), h->lam_s.data(), h->lam_e.data(), h->econst.data()))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+        if ((rc = remd_set_integrator(c, h->splitting.c_str(), h->dt, h->gamma, h->n_steps, h->reassign, h->constraint_tol))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+        for (int k = 0; k < 6; ++k) c->fgroup[k] = h->fgroup[k];
+        c->seed = h->seed; c->n_restart_attempts = h->n_restart_attempts;
+    }
+    h->phase_config = h->config_version;
+    return 0;
+}
+
+static int remd_propagate_phased(remd_ctx* h, int P, int64_t iteration, int32_t* nan_flags)
+{
+    int rc = phase_children(h, P);
+    if (rc) return rc;
+    hipEventRecord(h->ev0, h->stream);
+    // what this handle's streams still hold (the energy pass and the mix of the iteration before synchronise before they return; a
+    // deferred join of a remd_step does not)
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) REMD_CHECK(h, hipStreamSynchronize(h->stream2));
+    const size_t row = (size_t)h->Npad;
+    std::vector<int> r0((size_t)P + 1, 0);
+    for (int p = 0; p <= P; ++p) r0[p] = (int)((long long)h->R * p / P);
+    for (int p = 0; p < P; ++p) {
+        remd_ctx* c = h->phase[p];
+        const int cnt = r0[p + 1] - r0[p];
+        if (c->R != cnt || c->R_global != h->R_global || c->r_begin != h->r_begin + r0[p] || !c->d_pos) {
+            if ((rc = remd_set_replicas(c, h->R_global, h->r_begin + r0[p], cnt, nullptr, nullptr, h->box_host.data() + 3 * (size_t)r0[p], h->labels.data())))
+                return remd_fail(h, rc, std::string("phases: ") + c->err);
+            if (!h->noise_id_host.empty() && (rc = remd_set_replica_ids(c, h->noise_id_host.data() + r0[p]))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+        } else if ((rc = remd_set_labels(c, h->labels.data()))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+        REMD_CHECK(h, hipMemcpyAsync(c->d_pos, h->d_pos + r0[p] * row, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, c->stream));
+        REMD_CHECK(h, hipMemcpyAsync(c->d_vel, h->d_vel + r0[p] * row, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, c->stream));
+        REMD_CHECK(h, hipMemcpyAsync(c->d_box, h->d_box + 4 * (size_t)r0[p], sizeof(float) * 4 * cnt, hipMemcpyDeviceToDevice, c->stream));
+        // the forces the last evaluation of this handle left (the energy pass of the iteration before) serve the first kick, as they
+        // do without phases: the blocks' trajectories are those of the one-block path bit for bit
+        REMD_CHECK(h, hipMemcpyAsync(c->d_force, h->d_force + 3 * (size_t)r0[p] * row, sizeof(long long) * 3 * row * cnt, hipMemcpyDeviceToDevice, c->stream));
+        c->forces_valid = h->forces_valid; c->force_zeroed = h->force_zeroed;
+        c->cbins_ready = false; c->join_deferred = 0; c->fold_pending = false;
+        c->box_uniform = h->box_uniform;
+        c->profiling = h->profiling; c->prof_filter = h->prof_filter; c->prof_every = h->prof_every;
+        remd_nb_invalidate_sort(c);
+    }
+    std::vector<int32_t> flags((size_t)h->R, 0);
+    rc = remd_propagate_many(h->phase.data(), P, iteration, flags.data());
+    if (rc) return remd_fail(h, rc, std::string("phases: ") + (h->phase[0]->err.empty() ? h->phase[P - 1]->err : h->phase[0]->err));
+    for (int p = 0; p < P; ++p) {
+        remd_ctx* c = h->phase[p];
+        const int cnt = r0[p + 1] - r0[p];
+        REMD_CHECK(h, hipMemcpyAsync(h->d_pos + r0[p] * row, c->d_pos, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, h->stream));
+        REMD_CHECK(h, hipMemcpyAsync(h->d_vel + r0[p] * row, c->d_vel, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->forces_valid = false; h->force_zeroed = false; h->cbins_ready = false; h->join_deferred = 0; h->fold_pending = false;
+    remd_nb_invalidate_sort(h);
+    hipEventRecord(h->ev1, h->stream);
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->t_prop = ms;
+    if (nan_flags) for (int r = 0; r < h->R; ++r) nan_flags[r] = flags[r];
+    return 0;
+}
+
 int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
 {
     if (!h || !h->has_system || !h->has_integrator || h->R <= 0 || h->K <= 0)
         return remd_fail(h, -1, "remd_propagate: system/states/integrator/replicas not all set");
     hipSetDevice(h->device);
+    {
+        const int P = phases_for(h);
+        h->phases_last = P;
+        if (P > 1) return remd_propagate_phased(h, P, iteration, nan_flags);
+    }
+    // every propagation starts its spatial order afresh (the first force evaluation re-sorts, then every resort_interval-th): the
+    // schedule of re-sorts, and with it the fp32 order of summation inside the pair kernel, depends on the step index only -- not on
+    // how many evaluations other calls made in between, nor on whether the replicas run as one block or as phases
+    remd_nb_invalidate_sort(h);
     hipEventRecord(h->ev0, h->stream);
     int rc;
     const int attempts = h->n_restart_attempts;
@@ -639,8 +778,11 @@ int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* 
         if (!h->d_snap_work) REMD_CHECK(h, hipMalloc(&h->d_snap_work, 2 * wbytes));
         if (h->d_work != nullptr && h->work_R == h->R) REMD_CHECK(h, hipMemcpyAsync(h->d_snap_work, h->d_work, wbytes, hipMemcpyDeviceToDevice, h->stream));
         else REMD_CHECK(h, hipMemsetAsync(h->d_snap_work, 0, wbytes, h->stream));
-        static const bool lean_env = !(getenv("REMD_MANY_LEAN") && atoi(getenv("REMD_MANY_LEAN")) == 0);
+        // (REMD_MANY_LEAN=1: no workgroup waits on a CU for another stream -- join by a one-wavefront launch, momentum sum as two
+        // launches; measured slower than the polling chain once the handles' streams sit on four hardware queues: 76.1 against 72.9 ms)
+        static const bool lean_env = getenv("REMD_MANY_LEAN") && atoi(getenv("REMD_MANY_LEAN")) != 0;
         h->lean_waits = lean_env;
+        remd_nb_invalidate_sort(h);          // as remd_propagate: the schedule of spatial re-sorts restarts with every propagation
     }
     int rc = 0;
     for (int i = 0; i < n && !rc; ++i) if (hs[i]->reassign) rc = remd_assign_velocities(hs[i], iteration);
@@ -798,6 +940,9 @@ int remd_compute_energies(remd_handle h, double* d_ukl_rows, double* ukl_host, d
         hipEventRecord(h->ev0, h->stream);
         int rc;
         h->forces_valid = false;
+        // (the spatial order of the energy pass is made for ITS positions: the forces it leaves serve the next propagation's first kick,
+        // and their fp32 order of summation must not depend on what ran on this handle before -- one block or phases, remd_set_phases)
+        remd_nb_invalidate_sort(h);
         if ((rc = remd_compute_forces(h, true))) return rc;
         double* rows = d_ukl_rows ? d_ukl_rows : h->d_ukl + (size_t)h->r_begin * h->K;
         if ((rc = remd_assemble_ukl(h, rows))) return rc;
@@ -1018,6 +1163,7 @@ int remd_profile_filter(remd_handle h, const char* kernel_class) { if (!h || !ke
 int remd_profile_reset(remd_handle h)
 {
     if (!h) return -1;
+    for (remd_ctx* c : h->phase) remd_profile_reset(c);
     resolve_profile(h); h->prof.clear();
     if (h->d_chain_own) { hipStreamSynchronize(h->stream); hipMemset(h->d_chain_own, 0, 40 * sizeof(unsigned long long)); }
     return 0;
@@ -1025,6 +1171,14 @@ int remd_profile_reset(remd_handle h)
 int remd_profile_get(remd_handle h, const char* name, int64_t* n, double* ms)
 {
     if (!h || !name) return -1;
+    if (!h->phase.empty() && h->phases_last > 1) {
+        // the launches of a phased propagation are the blocks': their sums (a launch covers one block's replicas)
+        int64_t nn = 0; double mm = 0.0;
+        for (remd_ctx* c : h->phase) { int64_t a = 0; double b = 0.0; int rc = remd_profile_get(c, name, &a, &b); if (rc) return rc; nn += a; mm += b; }
+        { remd_ctx* self = h; std::vector<remd_ctx*> none; none.swap(self->phase); int64_t a = 0; double b = 0.0; remd_profile_get(self, name, &a, &b); none.swap(self->phase); nn += a; mm += b; }
+        if (n) *n = nn; if (ms) *ms = mm;
+        return 0;
+    }
     resolve_profile(h);
     if (std::string(name) == "integrate_chain_own") {
         // the integrator chain's own time (flag seen -> end, workgroup (0, 0)), from wall-clock stamps taken inside the kernel (100 MHz)

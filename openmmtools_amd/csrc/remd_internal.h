@@ -72,6 +72,31 @@ struct listed_tables {
 
 struct remd_profile_entry { int64_t n = 0; double ms = 0.0; };
 
+// a deep copy of the descriptor of the last remd_set_system: the groups of replicas a handle propagates as phases (api.hip) are set up
+// from it without the host
+struct remd_desc_store {
+    remd_system_desc d{}; bool valid = false;
+    std::vector<double> mass, bond_params, angle_params, torsion_params, charge, sigma, epsilon, exception_params, shake_dist;
+    std::vector<int32_t> ext_atoms, bond_atoms, angle_atoms, torsion_atoms, exception_atoms, settle_atoms, shake_atoms, alch_atoms;
+    void assign(const remd_system_desc* s)
+    {
+        d = *s;
+        auto cpd = [](std::vector<double>& v, const double*& p, size_t n) { if (p && n) { v.assign(p, p + n); p = v.data(); } else { v.clear(); if (!n) p = nullptr; } };
+        auto cpi = [](std::vector<int32_t>& v, const int32_t*& p, size_t n) { if (p && n) { v.assign(p, p + n); p = v.data(); } else { v.clear(); if (!n) p = nullptr; } };
+        const size_t N = (size_t)d.n_atoms;
+        cpd(mass, d.mass, N); cpi(ext_atoms, d.ext_atoms, (size_t)d.n_ext);
+        cpi(bond_atoms, d.bond_atoms, 2 * (size_t)d.n_bonds); cpd(bond_params, d.bond_params, 2 * (size_t)d.n_bonds);
+        cpi(angle_atoms, d.angle_atoms, 3 * (size_t)d.n_angles); cpd(angle_params, d.angle_params, 2 * (size_t)d.n_angles);
+        cpi(torsion_atoms, d.torsion_atoms, 4 * (size_t)d.n_torsions); cpd(torsion_params, d.torsion_params, 3 * (size_t)d.n_torsions);
+        cpd(charge, d.charge, N); cpd(sigma, d.sigma, N); cpd(epsilon, d.epsilon, N);
+        cpi(exception_atoms, d.exception_atoms, 2 * (size_t)d.n_exceptions); cpd(exception_params, d.exception_params, 3 * (size_t)d.n_exceptions);
+        cpi(settle_atoms, d.settle_atoms, 3 * (size_t)d.n_settle);
+        cpi(shake_atoms, d.shake_atoms, 4 * (size_t)d.n_shake); cpd(shake_dist, d.shake_dist, 3 * (size_t)d.n_shake);
+        cpi(alch_atoms, d.alch_atoms, (size_t)d.n_alch);
+        valid = true;
+    }
+};
+
 struct remd_ctx {
     int device = 0;
     hipStream_t stream = nullptr; bool owns_stream = false;
@@ -210,6 +235,18 @@ struct remd_ctx {
     // in front of the chain instead of a poll in the chain's prologue (320 registers per lane on every CU it occupies), the momentum
     // sum two launches instead of a barrier over resident workgroups
     bool lean_waits = false;
+    // ---- phases (round 6): remd_propagate of ONE handle as two groups of replicas whose MD steps take turns ------------------------
+    // The local replicas are split into contiguous blocks, each block propagated by a child context of its own (full tables for its
+    // share of the replicas; block 0 launches on THIS handle's two streams, block 1 on one more pair), the blocks' steps enqueued in
+    // turn from the calling thread (remd_propagate_many): the integrator chain of one block runs beside the pair and mesh kernels
+    // of the other.  Coordinates, velocities and the forces the last evaluation left go to the children device to device in front and
+    // come back behind; everything else (energies, mixing, get / set) stays with this handle.  phases_req: remd_set_phases (0 = by rule).
+    int phases_req = 0; int phases_last = 1;
+    std::vector<remd_ctx*> phase; remd_ctx* parent = nullptr;
+    long long config_version = 0, phase_config = -1;      // children are rebuilt when a setter has run since they were made
+    remd_desc_store* sysdesc = nullptr;
+    std::vector<int64_t> noise_id_host;                   // remd_set_replica_ids, for the children's slices
+    bool borrowed_stream2 = false;     // stream2 belongs to another handle (remd_adopt_streams): not destroyed with this one
     unsigned long long* d_chain_own = nullptr;   // [2] profiling: sum of (end - flag seen) wall-clock ticks of workgroup (0, 0), launches
     unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows

@@ -1544,6 +1544,10 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
     return 0;
 }
 
+// phases are a device matter (which kernels share the chip); the CPU port takes the request and runs one block
+int remd_set_phases(remd_handle h, int32_t n) { return (!h || n < 0 || n > 2) ? -1 : 0; }
+int remd_get_phases(remd_handle h, int32_t* n) { if (!h || !n) return -1; *n = 1; return 0; }
+
 // the CPU port's SHAKE / RATTLE iterate in f64 to the tolerance itself; it keeps no statistics
 int remd_get_constraint_stats(remd_handle h, int32_t* max_newton_iterations, int32_t* unconverged)
 {

@@ -440,6 +440,72 @@ def test_stream_modes_of_a_force_evaluation_do_not_change_a_bit(hip_engine_facto
         assert np.array_equal(f, out[0][0]) and np.array_equal(x, out[0][1]) and np.array_equal(v, out[0][2])
 
 
+def test_phases_of_a_propagation_do_not_change_a_bit(hip_engine_factory):
+    """Round 6: remd_propagate runs a handle's replicas as two blocks whose MD steps take turns on the device (remd_set_phases): the
+    integrator chain of one block beside the pair and mesh kernels of the other.  Replicas are independent between mixes
+    (multistatesampler.py:1296-1297), forces are fixed-point sums, noise is keyed by the global replica, the schedule of spatial
+    re-sorts restarts with every propagation, and the first kick uses the forces the energy pass left in both modes: positions,
+    velocities and the energy matrix after two iterations (with an energy pass and new labels in between, 60 steps each: one
+    re-sort inside) are identical to the one-block run, for an even and a ragged split."""
+    al = ts.AlanineDipeptideExplicit()
+    desc = system_to_desc(al.system, ewald_split='auto')
+    out = []
+    for phases, R in ((1, 5), (2, 5), (1, 4), (2, 4)):
+        eng = hip_engine_factory()
+        eng.set_phases(phases)
+        _engine_for(eng, al.system, al.positions, R=R, jitter=0.002, splitting='V R R O R R V', dt=0.002, n_steps=60, desc=desc)
+        eng.propagate(0)
+        u0 = eng.compute_energies()
+        eng.set_labels(np.arange(R)[::-1].copy())
+        eng.propagate(1)
+        assert eng.phases_active() == phases
+        x, v = eng.get_replicas()[:2]
+        out.append((x, v, u0, eng.compute_energies()))
+    for a, b in ((0, 1), (2, 3)):
+        for q in range(4):
+            assert np.array_equal(out[a][q], out[b][q]), (a, b, q)
+
+
+def test_handles_propagated_concurrently_equal_handles_propagated_one_after_the_other(hip_engine_factory):
+    """profiles/r05_11_group_overlap.txt reported other positions for the 24 replicas as 2 or 3 concurrently propagated
+    handles than as one.  On this tree the same experiment is bit-identical in every mode (profiles/r06_1_concurrent_handles.txt:
+    sequential, two host threads, flags or events, tuner pinned or not); what can differ is a handle whose device-side poll ran out --
+    its propagation is run again from the snapshot with a fresh spatial order (different fp32 summation order), which is what the
+    round-5 tree did under the load of several polling handles.  Here: two handles from two host threads, the same two one after the
+    other, and remd_propagate_many (one thread, steps taking turns) give the same bits."""
+    import threading
+    from openmmtools_amd._engine import HipEngine
+    al = ts.AlanineDipeptideExplicit()
+    desc = system_to_desc(al.system, ewald_split='auto')
+    box = np.diag(al.system.getDefaultPeriodicBoxVectors())
+    R = 6
+    x0 = np.tile(al.positions, (R, 1, 1)) + np.random.default_rng(7).normal(0, 0.002, (R,) + al.positions.shape)
+    beta = 1.0 / (KB * np.geomspace(300.0, 400.0, R))
+    res = {}
+    for mode in ('sequential', 'threads', 'many'):
+        engs = []
+        for a, b in ((0, 3), (3, 6)):
+            e = hip_engine_factory()
+            e.set_phases(1)
+            e.set_system(desc); e.set_states(beta)
+            e.set_integrator('V R R O R R V', 0.002, 1.0, 50, True, 1e-8)
+            e.seed(SEED)
+            e.set_replicas(R, a, x0[a:b], None, np.tile(box, (b - a, 1)), np.arange(R))
+            engs.append(e)
+        for it in range(2):
+            if mode == 'sequential':
+                for e in engs: e.propagate(it)
+            elif mode == 'threads':
+                th = [threading.Thread(target=e.propagate, args=(it,)) for e in engs]
+                for t in th: t.start()
+                for t in th: t.join()
+            else:
+                HipEngine.propagate_many(engs, it)
+        res[mode] = [np.concatenate([e.get_replicas()[q] for e in engs]) for q in (0, 1)]
+    for mode in ('threads', 'many'):
+        assert np.array_equal(res[mode][0], res['sequential'][0]) and np.array_equal(res[mode][1], res['sequential'][1]), mode
+
+
 @pytest.mark.parametrize('system_cls', [ts.AlanineDipeptideExplicit, ts.HostGuestExplicit])
 def test_cluster_pair_lists_match_the_tile_kernel(hip_engine_factory, monkeypatch, system_cls):
     """The direct-space sum runs on per-tile union lists with every cluster pair listed once (Newton's third law, sci

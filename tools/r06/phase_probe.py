@@ -27,6 +27,8 @@ for g in range(G):
     e.seed(11)
     e.set_replicas(R, int(a), x0[a:b], None, np.tile(box, (b - a, 1)), np.arange(R))
     engs.append(e)
+if os.environ.get('GO_PHASES'):
+    for e in engs: e.set_phases(int(os.environ['GO_PHASES']))
 
 def run(it):
     t = time.perf_counter()
@@ -44,8 +46,8 @@ own = [e.last_timing()['propagate_ms'] for e in engs]
 x = np.concatenate([e.get_replicas()[0] for e in engs])
 dig = [hashlib.sha1(np.ascontiguousarray(x[r]).tobytes()).hexdigest()[:8] for r in range(R)]
 print('%s R %d G %d %s steps %d env[%s]: ms %s | device ms %s | digest all %s first %s last %s' % (
-    name, R, G, mode, n_steps, ' '.join('%s=%s' % (k, v) for k, v in sorted(os.environ.items()) if k.startswith('REMD_')),
+    name, R, G, mode, n_steps, ' '.join('%s=%s' % (k, v) for k, v in sorted(os.environ.items()) if k.startswith(('REMD_', 'GPU_MAX', 'GO_PHASES'))),
     ' '.join('%.1f' % m for m in ms), ' '.join('%.1f' % o for o in own),
     hashlib.sha1(x.tobytes()).hexdigest()[:10], dig[0], dig[-1]), flush=True)
 print('  per-replica', ' '.join(dig), flush=True)
-for e in engs: e.close()
+for e in reversed(engs): e.close()
