@@ -145,6 +145,7 @@ int remd_destroy(remd_handle h)
     if (h->stream2 && !h->borrowed_stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     if (h->d_sync) hipFree(h->d_sync);
+    if (h->ev_xy) hipEventDestroy(h->ev_xy);
     if (h->d_chain_own) hipFree(h->d_chain_own);
     if (h->d_work) { hipFree(h->d_work); hipFree(h->d_pe_prev); hipFree(h->d_xold); hipFree(h->d_vold); hipFree(h->d_accept); }
     if (h->d_chain_sync) hipFree(h->d_chain_sync);
@@ -762,6 +763,17 @@ int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* 
     }
     if (n == 1) return remd_propagate(hs[0], iteration, nan_flags);
     hipSetDevice(hs[0]->device);
+    // Two kernels that each hold workgroups at a barrier over sibling workgroups can deadlock each other when they do not both fit the
+    // chip (A's waiting workgroups fill one XCD, B's another, each waiting for siblings the other keeps out: seen as the momentum
+    // barrier running out with 2 x 64 alanine replicas = 2 x 576 chain workgroups).  The integrator chains hold one workgroup per CU,
+    // so the momentum sum is an in-kernel barrier only while ALL the handles' chain workgroups are resident at once; beyond that it is
+    // two launches.  The join polled in the chain's prologue cannot deadlock (the kernels it waits for fit beside the chains) but parks
+    // CUs: kept up to four rounds of the chip in total, as for one handle.
+    long long chain_wgs = 0;
+    for (int i = 0; i < n; ++i) chain_wgs += remd_chain_blocks(hs[i]);
+    int n_cu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, hs[0]->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+    const bool barrier_ok = chain_wgs <= n_cu, polls_ok = chain_wgs <= 4ll * n_cu;
     for (int i = 0; i < n; ++i) {
         remd_ctx* h = hs[i];
         hipEventRecord(h->ev0, h->stream);
@@ -781,7 +793,8 @@ int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* 
         // (REMD_MANY_LEAN=1: no workgroup waits on a CU for another stream -- join by a one-wavefront launch, momentum sum as two
         // launches; measured slower than the polling chain once the handles' streams sit on four hardware queues: 76.1 against 72.9 ms)
         static const bool lean_env = getenv("REMD_MANY_LEAN") && atoi(getenv("REMD_MANY_LEAN")) != 0;
-        h->lean_waits = lean_env;
+        h->lean_waits = lean_env || !polls_ok;
+        h->no_chain_barrier = !barrier_ok;
         remd_nb_invalidate_sort(h);          // as remd_propagate: the schedule of spatial re-sorts restarts with every propagation
     }
     int rc = 0;
@@ -801,7 +814,7 @@ int remd_propagate_many(remd_handle* hs, int32_t n, int64_t iteration, int32_t* 
     }
     for (int i = 0; i < n; ++i) {           // (also after an error: no launch of this call may outlive it)
         remd_ctx* h = hs[i];
-        h->lean_waits = false;
+        h->lean_waits = false; h->no_chain_barrier = false;
         hipStreamSynchronize(h->stream);
         if (h->stream2) hipStreamSynchronize(h->stream2);
     }

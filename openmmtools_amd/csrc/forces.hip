@@ -2102,6 +2102,12 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
                 h->mesh_listed_total = total;
                 listed_rode = total > 0;
             }
+            {
+                static const int env_pax = getenv("REMD_PAIR_AFTER_XY") ? atoi(getenv("REMD_PAIR_AFTER_XY")) : -1;
+                h->pair_after_xy = env_pax > 0 && !with_energy;
+                if (h->pair_after_xy && !h->ev_xy) hipEventCreateWithFlags(&h->ev_xy, hipEventDisableTiming);
+                h->xy_recorded = false;
+            }
             rc0 = remd_pme_forces(h, with_energy, h->stream, 1);        // everything up to the inverse z transform + gather
             if (rc0) return rc0;
             std::swap(h->stream, h->stream2);
@@ -2160,6 +2166,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         h->fold_pending = fold_env && listed_main && merged && h->defer_join_ok && do_nb && (class_mask & 63u) == 63u && t.sorting && t.clusters &&
                           t.lj_split && t.d_lj_sci_list && t.d_sci_list && h->profiling != 2;
         h->fold.done = nullptr;                  // (launch_nb fills remd_fold_args where it takes the request)
+        if (forked && h->pair_after_xy && h->xy_recorded) { hipStreamWaitEvent(h->stream, h->ev_xy, 0); h->xy_recorded = false; }
         if (do_nb) {
             remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {

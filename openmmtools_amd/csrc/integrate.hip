@@ -1359,7 +1359,7 @@ struct step_runner {
         // (the same bound holds for the join polled in the chain's prologue: spinning workgroups of a grid larger than the chip
         // holds at once could keep the direct-space stream's last launches from ever being dispatched)
         device_waits_ok = chain_blocks <= 1024 && !h->no_device_waits;
-        merge_cmm = merge_env && device_waits_ok && h->profiling != 2 && !h->lean_waits;
+        merge_cmm = merge_env && device_waits_ok && h->profiling != 2 && !h->lean_waits && !h->no_chain_barrier;
         const long long sync_key = (long long)h->R * 1000003ll + ut->n_units;
         if (merge_cmm && (!h->d_chain_sync || h->chain_sync_key != sync_key)) {      // slots of THIS grid shape
             if (h->d_chain_sync) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_chain_sync); h->d_chain_sync = nullptr; }
@@ -1495,6 +1495,13 @@ struct step_runner {
         return 0;
     }
 };
+
+// workgroups of one integrator-chain launch of this handle (one per 256 constraint units per replica)
+long long remd_chain_blocks(remd_ctx* h)
+{
+    const unit_tables* ut = g_units.find(h);
+    return ut ? (long long)((ut->n_units + 255) / 256) * h->R : 0;
+}
 
 int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
                    int64_t iteration, int64_t first_step, int n_steps)

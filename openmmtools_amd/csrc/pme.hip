@@ -1154,6 +1154,9 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
                                (float)h->ewald_alpha, with_energy ? 1 : 0, s->d_energy, s->n_eblk, s->d_infl, s->infl_rep);
+            // the pair kernel of this evaluation is held back until the plane pass has ENDED (remd_compute_forces waits for this event on
+            // the direct-space stream): planes that take a CU's whole LDS cannot be placed beside resident pair workgroups
+            if (h->pair_after_xy && h->ev_xy) { hipEventRecord(h->ev_xy, st); h->xy_recorded = true; }
         } else if (s->xs_sw > 0) {
             // spec layout [kz][x][y]: y passes on contiguous lines, then the fused x pass on LDS-resident y slabs
             const size_t ylds = sizeof(float2) * ((size_t)s->ys_sh * (ny | 1) + ny + 2);

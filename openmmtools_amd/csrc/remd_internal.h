@@ -234,7 +234,9 @@ struct remd_ctx {
     // on a CU polling for another stream while it holds registers another handle's kernels need -- the join is a one-wavefront launch
     // in front of the chain instead of a poll in the chain's prologue (320 registers per lane on every CU it occupies), the momentum
     // sum two launches instead of a barrier over resident workgroups
-    bool lean_waits = false;
+    bool lean_waits = false, no_chain_barrier = false;
+    // round 6 (DHFR-size meshes): hold the pair kernel of a forked evaluation until the LDS-resident plane pass has ended
+    bool pair_after_xy = false, xy_recorded = false; hipEvent_t ev_xy = nullptr; size_t xy_lds_bytes = 0;
     // ---- phases (round 6): remd_propagate of ONE handle as two groups of replicas whose MD steps take turns ------------------------
     // The local replicas are split into contiguous blocks, each block propagated by a child context of its own (full tables for its
     // share of the replicas; block 0 launches on THIS handle's two streams, block 1 on one more pair), the blocks' steps enqueued in
@@ -322,7 +324,8 @@ int remd_mix_launch(remd_ctx* h, int scheme, int64_t iteration, int R, int K, in
 int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& tokens, int& nV, int& nR, int& nO, int* nVg = nullptr);
 int remd_run_steps(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
                    int64_t iteration, int64_t first_step, int n_steps);
-int remd_run_steps_many(remd_ctx** hs, int n, int64_t iteration, int64_t first_step, int n_steps);   // the handles' steps taking turns
+int remd_run_steps_many(remd_ctx** hs, int n, int64_t iteration, int64_t first_step, int n_steps);
+long long remd_chain_blocks(remd_ctx* h);            // workgroups of one integrator-chain launch   // the handles' steps taking turns
 int remd_assign_velocities(remd_ctx* h, int64_t iteration);
 int remd_kinetic_energy(remd_ctx* h);
 int remd_work_buffers(remd_ctx* h);                    // heat / shadow-work accumulators and the '{' snapshot of the local replicas
