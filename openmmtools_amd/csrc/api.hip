@@ -88,7 +88,13 @@ int remd_create(remd_handle* out, int device, void* stream)
     if (!h->stream) {
         // NULL: a private non-blocking stream (the legacy default stream cannot be captured into a graph, and every entry point
         // that hands results to the caller synchronises before it returns, so nothing relies on default-stream ordering)
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return remd_fail(nullptr, -2, "hipStreamCreate failed"); }
+        // (REMD_MAIN_PRIO=1: the private main stream at raised queue priority -- experiment hook, profiles/r06_13_stream_priorities.txt)
+        int lo0 = 0, hi0 = 0;
+        hipDeviceGetStreamPriorityRange(&lo0, &hi0);
+        const bool main_hi = getenv("REMD_MAIN_PRIO") && atoi(getenv("REMD_MAIN_PRIO")) != 0;
+        if ((main_hi ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi0) : hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+            delete h; return remd_fail(nullptr, -2, "hipStreamCreate failed");
+        }
         h->owns_stream = true;
     }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
@@ -100,7 +106,8 @@ int remd_create(remd_handle* out, int device, void* stream)
             uint32_t m[8]; cu_mask(cu_pair, true, m);
             if (hipExtStreamCreateWithCUMask(&h->stream2, 8, m) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); }
         }
-        if (!h->stream2 && hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess)
+        const bool direct_lo = getenv("REMD_DIRECT_PRIO") && atoi(getenv("REMD_DIRECT_PRIO")) == 0;      // (experiment hook: normal priority)
+        if (!h->stream2 && (direct_lo || hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess))
             hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
     }
     { const unsigned evf = hipEventReleaseToDevice | hipEventDisableTiming;   // device-scope release: no system-scope cache write-back per fork / join
@@ -518,6 +525,7 @@ static int remd_recover_device_flag(remd_ctx* h, unsigned int f, const char* whe
     std::string what;
     if (f == 2) { h->no_chain_bins = true; what = "more atoms in one PME mesh column than the chain-binned layout holds; using the binning launch from now on"; }
     else if (f == 3) { h->no_device_waits = true; what = "the integrator chain's momentum barrier ran out; using two chain launches from now on"; }
+    else if (f == 7) { h->no_chain_merge = true; what = "a workgroup's partial momentum sum does not fit the 48-bit payload of the chain's exchange words; summing with two chain launches from now on"; }
     else if (f == 4) { h->no_resident = true; what = "more neighbours per atom than the resident small-system kernel's list holds; using the regular launches from now on"; }
     else { h->no_device_waits = true; h->sync_events = true; what = "a wait polled on the device ran out (fork / join flag never arrived); using events from now on"; }
     if (retry) {

@@ -2096,17 +2096,24 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
             // direct-space stream critical (t0.p.prio): the listed terms of a force-only evaluation leave it -- as extra workgroups of
             // the spreading launch (REMD_LISTED_RIDE=0: as a launch of their own behind the mesh launches)
             h->mesh_listed_total = 0;
-            if (listed_main_env && listed_ride_env && !with_energy && !h->sync_events && t0.p.prio != 0) {
+            {
+                // Round 6, measured and left OFF (REMD_PAIR_AFTER_XY=1 switches it on): when the plane pass keeps whole planes in LDS with ONE
+                // workgroup per CU (DHFR: 128 x 128 planes, 134 KB) its workgroups cannot be placed beside resident pair workgroups -- the
+                // pass crawls for the pair kernel's 600 us and then runs its 240 us alone (876 us in all).  Holding the pair kernel back
+                // until the plane pass has ENDED (an event), with gather, lists and the listed terms in front of the wait, gives the plane
+                // pass the chip (381 us beside the listed terms) -- and then the pair kernel and the inverse-z / gather pass stretch each
+                // other to 690 us: 139.9 against 134.8 ms per 100 steps of 16 DHFR replicas, +30 % on host-guest and alanine.  At this
+                // size the step is the SUM of its kernels' stand-alone times whatever the order (profiles/r06_12_dhfr_pair_after_plane_pass.txt).
+                static const int env_pax = getenv("REMD_PAIR_AFTER_XY") ? atoi(getenv("REMD_PAIR_AFTER_XY")) : -1;
+                h->pair_after_xy = !with_energy && (class_mask & 63u) == 63u && env_pax > 0;
+                if (h->pair_after_xy && !h->ev_xy) hipEventCreateWithFlags(&h->ev_xy, hipEventDisableTiming);
+                h->xy_recorded = false;
+            }
+            if (listed_main_env && listed_ride_env && !with_energy && !h->sync_events && t0.p.prio != 0 && !h->pair_after_xy) {
                 int total = 0;
                 h->mesh_listed = listed_terms(total);
                 h->mesh_listed_total = total;
                 listed_rode = total > 0;
-            }
-            {
-                static const int env_pax = getenv("REMD_PAIR_AFTER_XY") ? atoi(getenv("REMD_PAIR_AFTER_XY")) : -1;
-                h->pair_after_xy = env_pax > 0 && !with_energy;
-                if (h->pair_after_xy && !h->ev_xy) hipEventCreateWithFlags(&h->ev_xy, hipEventDisableTiming);
-                h->xy_recorded = false;
             }
             rc0 = remd_pme_forces(h, with_energy, h->stream, 1);        // everything up to the inverse z transform + gather
             if (rc0) return rc0;
@@ -2140,7 +2147,8 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
     // kernel on the direct-space stream, as in round 3.
     // (only in the mode in which the direct-space stream is the critical one, chosen by the tuner together with the wave priority:
     // on a system whose mesh chain is the longer branch the extra work on the main stream costs what it saves here)
-    const bool listed_main = listed_main_env && forked && !with_energy && !h->sync_events && h->nb_method != REMD_NB_NONE && g_nb[h].p.prio != 0;
+    const bool pax = forked && h->pair_after_xy;
+    const bool listed_main = listed_main_env && forked && !with_energy && !h->sync_events && h->nb_method != REMD_NB_NONE && g_nb[h].p.prio != 0 && !pax;
     auto launch_listed = [&](hipStream_t lst) {
         if (listed_rode) return;                      // they rode in the spreading launch
         int total = 0;
@@ -2166,7 +2174,11 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         h->fold_pending = fold_env && listed_main && merged && h->defer_join_ok && do_nb && (class_mask & 63u) == 63u && t.sorting && t.clusters &&
                           t.lj_split && t.d_lj_sci_list && t.d_sci_list && h->profiling != 2;
         h->fold.done = nullptr;                  // (launch_nb fills remd_fold_args where it takes the request)
-        if (forked && h->pair_after_xy && h->xy_recorded) { hipStreamWaitEvent(h->stream, h->ev_xy, 0); h->xy_recorded = false; }
+        bool listed_early = false;
+        if (pax && h->xy_recorded) {
+            if (merged) { launch_listed(h->stream); listed_early = true; }      // beside the spreading and the plane pass
+            hipStreamWaitEvent(h->stream, h->ev_xy, 0); h->xy_recorded = false;
+        }
         if (do_nb) {
             remd_prof_scope ps(h, "nonbonded");
             if (with_energy) {
@@ -2180,7 +2192,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
             }
         }
         h->fold_pending = h->fold_pending && h->fold.done != nullptr;
-        if (merged && !listed_main) launch_listed(h->stream);
+        if (merged && !listed_main && !listed_early) launch_listed(h->stream);
         if (!merged && t.n_exc > 0) {
             remd_prof_scope ps(h, "exceptions");
             LAUNCH_E(exception_kernel, dim3(R), dim3(256), 0, h->stream, t.n_exc, t.d_exc_atoms, t.d_exc_params, t.d_exc_alch,

@@ -37,8 +37,8 @@ struct chain_prog {
     int accumulate_momentum;  // after the chain, add sum(m v) into cmm buffer cmm_w
     int cmm_w, cmm_r;         // double-buffered momentum accumulators: 'C' reads cmm_r and clears the other one
     int zero_force;           // the chain ends with stale forces (an R after its last V): clear them for the next evaluation
-    int m_buf;                // token 'M' (inside a chain): add sum(m v) into momentum buffer m_buf, then wait until every workgroup
-    unsigned int m_epoch;     // of the replica has done so (m_epoch-th barrier of this handle): the 'C' that follows reads the sum
+    int m_buf;                // token 'M' (inside a chain): every workgroup of the replica publishes its partial sum(m v) as epoch-tagged 64-bit
+    unsigned int m_epoch;     // words (m_epoch-th exchange of this handle, d_chain_sync) and reads its siblings': the 'C' behind it has the sum
     int measure;              // bit 0: heat (kinetic-energy change of the O substeps), bit 1: kinetic part of the shadow work (V, R substeps)
 };
 
@@ -578,7 +578,7 @@ __device__ __forceinline__ void integrate_chain_body(chain_prog prog, int n_unit
             unsigned long long* slots = chain_slots + ((size_t)(prog.m_epoch & 1u) * gridDim.y + r) * gridDim.x * 3;
             if (threadIdx.x < 3) {
                 const long long t = s_pm[0][threadIdx.x] + s_pm[1][threadIdx.x] + s_pm[2][threadIdx.x] + s_pm[3][threadIdx.x];
-                if (t >= (1ll << 46) || t < -(1ll << 46)) atomicCAS(chain_sync_err, 0u, 3u);       // (the host then sums with two launches)
+                if (t >= (1ll << 46) || t < -(1ll << 46)) atomicCAS(chain_sync_err, 0u, 7u);       // (a fault of its own: the host then sums with two launches, the polled waits stay)
                 __hip_atomic_store(&slots[blockIdx.x * 3 + threadIdx.x], ((unsigned long long)t << 16) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const int n_words = 3 * (int)gridDim.x;
@@ -932,7 +932,7 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
                        ut.d_dist, ut.sc, (float)fmax(h->constraint_tol, REMD_CONSTRAINT_TOL_FLOOR), h->Npad, h->d_pos, h->d_vel, h->d_force,
                        h->d_invmass, h->d_labels, h->d_beta, h->r_begin, h->seed, h->d_cmm,
                        (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0),
-                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, reinterpret_cast<unsigned long long*>(h->d_chain_sync), h->d_sync + 2,
+                       h->join_deferred ? h->d_sync + 1 : (unsigned int*)nullptr, h->join_deferred, bins, h->d_chain_sync, h->d_sync + 2,
                        (h->profiling == 2 || (h->profiling == 1 && h->prof_filter.find("integrate_chain") != std::string::npos)) ? h->d_chain_own : (unsigned long long*)nullptr,
                        h->d_work, h->d_xold, h->d_vold, h->fold_pending ? h->fold : remd_fold_args(), h->d_noise_id);
     h->join_deferred = 0; h->fold_pending = false;
@@ -1359,13 +1359,13 @@ struct step_runner {
         // (the same bound holds for the join polled in the chain's prologue: spinning workgroups of a grid larger than the chip
         // holds at once could keep the direct-space stream's last launches from ever being dispatched)
         device_waits_ok = chain_blocks <= 1024 && !h->no_device_waits;
-        merge_cmm = merge_env && device_waits_ok && h->profiling != 2 && !h->lean_waits && !h->no_chain_barrier;
+        merge_cmm = merge_env && device_waits_ok && h->profiling != 2 && !h->lean_waits && !h->no_chain_barrier && !h->no_chain_merge;
         const long long sync_key = (long long)h->R * 1000003ll + ut->n_units;
         if (merge_cmm && (!h->d_chain_sync || h->chain_sync_key != sync_key)) {      // slots of THIS grid shape
             if (h->d_chain_sync) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_chain_sync); h->d_chain_sync = nullptr; }
             h->chain_sync_key = sync_key;
             const size_t slot_bytes = sizeof(unsigned long long) * 2 * (size_t)h->R * (size_t)((ut->n_units + 255) / 256) * 3;   // [2][R][workgroups][3]
-            REMD_CHECK(h, hipMalloc(&h->d_chain_sync, slot_bytes));
+            REMD_CHECK(h, hipMalloc((void**)&h->d_chain_sync, slot_bytes));
             REMD_CHECK(h, hipMemsetAsync(h->d_chain_sync, 0, slot_bytes, h->stream));
             h->chain_sync_epoch = 0;
         }

@@ -1022,6 +1022,7 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
         }
         s->xy_threads = best_t > 0 ? best_t : 1024;
         s->xy_fused = best_t > 0 && s->xy_lds <= 160 * 1024;
+        h->xy_lds_bytes = s->xy_fused ? s->xy_lds : 0;
     }
     if (!s->xy_fused && !full_complex) {
         // widest divisor of ny whose slab fits the registers of 256 threads and ~40 KB of LDS

@@ -229,7 +229,7 @@ struct remd_ctx {
     bool mesh_prio_hi = true;          // which of the two streams' kernels run at raised wave priority (forces.hip: chosen with the pair-kernel residency)
     // set when a wait polled on the device ran out / a capped PME bin overflowed: the handle falls back to events, two chain
     // launches and the binning launch (api.hip: remd_recover_device_flag) instead of staying dead behind a sticky flag
-    bool no_device_waits = false, no_chain_bins = false, no_resident = false;
+    bool no_device_waits = false, no_chain_bins = false, no_resident = false, no_chain_merge = false;
     // round 6, several handles propagated step by step from one host thread (remd_propagate_many): no workgroup of this handle may sit
     // on a CU polling for another stream while it holds registers another handle's kernels need -- the join is a one-wavefront launch
     // in front of the chain instead of a poll in the chain's prologue (320 registers per lane on every CU it occupies), the momentum
@@ -250,7 +250,7 @@ struct remd_ctx {
     std::vector<int64_t> noise_id_host;                   // remd_set_replica_ids, for the children's slices
     bool borrowed_stream2 = false;     // stream2 belongs to another handle (remd_adopt_streams): not destroyed with this one
     unsigned long long* d_chain_own = nullptr;   // [2] profiling: sum of (end - flag seen) wall-clock ticks of workgroup (0, 0), launches
-    unsigned int* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // per-replica arrival counters of the 'M' token (integrate.hip)
+    unsigned long long* d_chain_sync = nullptr; unsigned int chain_sync_epoch = 0; long long chain_sync_key = -1;    // [2][R][workgroups][3] epoch-tagged partial momentum sums of the 'M' token (integrate.hip)
     bool cbins_ready = false;          // the chain launched last binned the atoms for the PME pass of the evaluation that follows
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool overlap = true; bool pme_concurrent = false;
     // sharding without a Python host (comm.hip): an RCCL communicator over the ranks of one replica-exchange run

@@ -8,6 +8,12 @@ env GO_ITERS=8 GO_STEPS=100 GO_PHASES=1 $P 16 1 seq dhfr
 env GO_ITERS=8 GO_STEPS=100 GO_PHASES=1 REMD_PAIR_AFTER_XY=1 $P 16 1 seq dhfr
 env GO_ITERS=8 GO_STEPS=100 GO_PHASES=2 $P 16 1 seq dhfr
 env GO_ITERS=8 GO_STEPS=100 GO_PHASES=2 REMD_PAIR_AFTER_XY=1 $P 16 1 seq dhfr
+env GO_ITERS=3 GO_PHASES=1 $P 48 1 seq
+env GO_ITERS=3 GO_PHASES=2 $P 48 1 seq
+env GO_ITERS=2 GO_STEPS=200 GO_PHASES=1 $P 128 1 seq
+env GO_ITERS=2 GO_STEPS=200 GO_PHASES=2 $P 128 1 seq
+env GO_ITERS=2 GO_STEPS=200 GO_PHASES=1 $P 64 1 seq
+env GO_ITERS=2 GO_STEPS=200 GO_PHASES=2 $P 64 1 seq
 } 2>&1 | grep -v "amdgpu.ids\|per-replica" | cut -c1-260 | sed 's/ first .*//' | tee $O/probe.txt
 tl() { tag=$1; shift
   (cd /tmp && rm -rf /tmp/tl_$tag && env "$@" rocprofv3 --kernel-trace -d /tmp/tl_$tag -o kt -- python $ROOT/tools/r06/phase_probe.py ${ARGS} > $O/run_$tag.txt 2>&1)
