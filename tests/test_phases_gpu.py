@@ -1,0 +1,68 @@
+"""GPU: a sampler whose engine propagates its replicas as two phases (include/remd_hip.h: remd_set_phases) is the same sampler.
+
+The reference propagates the replicas one after the other or one per MPI rank (multistate/multistatesampler.py:1296-1297): they are
+independent between two mixes, so HOW the device schedules them must not show in any result.  Here the 16-replica parallel-tempering
+ensemble of AlanineDipeptideExplicit (the bench.py system) runs four iterations -- mix, propagate, energy matrix, with swap-all
+accepting and rejecting on the way -- once as one block and once as two blocks whose MD steps take turns: the labels, the count
+matrices, every reduced potential and every coordinate must be identical, bit for bit."""
+import numpy as np
+import pytest
+from openmmtools_amd import testsystems, states, mcmc, unit
+from openmmtools_amd.multistate import ParallelTemperingSampler
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(engine, phases, R=16, n_iter=4):
+    al = testsystems.AlanineDipeptideExplicit()
+    engine.set_phases(phases)
+    thermo = states.ThermodynamicState(al.system, 300.0 * unit.kelvin)
+    ss = states.SamplerState(al.positions, box_vectors=al.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond, n_steps=60,
+                                              reassign_velocities=True, splitting='V R R O R R V')
+    s = ParallelTemperingSampler(mcmc_moves=move, number_of_iterations=10 ** 9, engine=engine, seed=0xC0FFEE)
+    s.create(thermo, [ss], storage=None, min_temperature=300.0 * unit.kelvin, max_temperature=320.0 * unit.kelvin, n_temperatures=R)
+    out = []
+    for _ in range(n_iter):
+        s.run(1)
+        x, v = engine.get_replicas()[:2]
+        out.append((np.array(s._replica_thermodynamic_states), np.array(s.energy_thermodynamic_states), np.array(s._n_accepted_matrix),
+                    np.array(s._n_proposed_matrix), x, v))
+    return out, engine.phases_active()
+
+
+def test_a_sampler_on_two_phases_is_the_sampler_on_one_block(hip_engine_factory):
+    one, p1 = _run(hip_engine_factory(), 1)
+    two, p2 = _run(hip_engine_factory(), 2)
+    assert (p1, p2) == (1, 2)
+    assert any(not np.array_equal(a[0], np.arange(16)) for a in one), 'the ladder never exchanged: the test would not see a label bug'
+    for it, (a, b) in enumerate(zip(one, two)):
+        for q, name in enumerate(('labels', 'u_kl', 'accepted', 'proposed', 'positions', 'velocities')):
+            assert np.array_equal(a[q], b[q]), (it, name)
+
+
+def test_phases_by_rule_follow_the_hardware_queue_limit(hip_engine_factory, monkeypatch):
+    """By rule (remd_set_phases(0), the default) a handle runs two blocks only when the process keeps its streams on few hardware queues
+    (GPU_MAX_HW_QUEUES <= 2, set by the package before the HIP runtime starts) and holds 16 replicas or more; REMD_PHASES=1 pins one
+    block.  (What the limit buys is in profiles/r06_phases_hw_queues.txt; here only the rule.)"""
+    import os
+    from openmmtools_amd.system import system_to_desc
+    al = testsystems.AlanineDipeptideExplicit()
+    desc = system_to_desc(al.system, ewald_split='auto')
+    box = np.diag(al.system.getDefaultPeriodicBoxVectors())
+
+    def phases_of(R, env):
+        for k in ('GPU_MAX_HW_QUEUES', 'REMD_PHASES'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = hip_engine_factory()
+        eng.set_system(desc); eng.set_states(np.full(R, 1.0 / (0.008314462618153242 * 300.0)))
+        eng.set_integrator('V R R O R R V', 0.002, 1.0, 2, True, 1e-8)
+        eng.set_replicas(R, 0, np.tile(al.positions, (R, 1, 1)), None, np.tile(box, (R, 1)), np.arange(R))
+        eng.propagate(0)
+        return eng.phases_active()
+    assert phases_of(16, {'GPU_MAX_HW_QUEUES': '2'}) == 2
+    assert phases_of(16, {}) == 1 and phases_of(16, {'GPU_MAX_HW_QUEUES': '4'}) == 1
+    assert phases_of(8, {'GPU_MAX_HW_QUEUES': '2'}) == 1
+    assert phases_of(16, {'GPU_MAX_HW_QUEUES': '2', 'REMD_PHASES': '1'}) == 1
