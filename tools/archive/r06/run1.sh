@@ -3,7 +3,7 @@
 # (b) what two 12-replica handles cost without resident pollers; (c) the integrator-program check of round 5 that never ran
 export TMPDIR=/tmp
 O=gpurun_out/r06_1; mkdir -p $O
-P="python tools/r06/phase_probe.py"
+P="python tools/phase_probe.py"
 {
 $P 24 1 seq
 $P 24 2 seq

@@ -2,7 +2,7 @@
 # round 6, call 13: queue priorities of the two blocks' streams (two handles, steps taking turns, 2 hardware queues per priority)
 export TMPDIR=/tmp
 O=gpurun_out/r06_13; mkdir -p $O
-P="python tools/r06/phase_probe.py"
+P="python tools/phase_probe.py"
 {
 env GO_ITERS=4 $P 24 2 many
 env GO_ITERS=4 REMD_MAIN_PRIO=1 REMD_DIRECT_PRIO=0 $P 24 2 many

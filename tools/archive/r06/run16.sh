@@ -1,7 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 O=gpurun_out/r06_16; mkdir -p $O
-P="python tools/r06/phase_probe.py"
+P="python tools/phase_probe.py"
 {
 env GO_ITERS=4 GO_PHASES=2 REMD_CHAIN_PRIO=0 $P 24 1 seq
 env GO_ITERS=4 GO_PHASES=2 REMD_CHAIN_PRIO=1 $P 24 1 seq

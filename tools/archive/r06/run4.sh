@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r06_4; mkdir -p $O
 ./tools/probes/launch_rate 2>&1 | tee $O/launch_rate.txt
-P="python tools/r06/phase_probe.py"
+P="python tools/phase_probe.py"
 {
 REMD_MANY_VERBOSE=1 GO_ITERS=3 REMD_NB_PRIO=1 REMD_NB_PERSIST_GRID=0 $P 24 2 many
 REMD_MANY_VERBOSE=1 GO_ITERS=3 REMD_NB_PRIO=1 REMD_NB_PERSIST_GRID=0 REMD_MANY_LEAN=0 $P 24 2 many

@@ -2,7 +2,7 @@
 # round 6, call 5: are the handles' streams sharing hardware queues?  (HIP maps streams onto GPU_MAX_HW_QUEUES = 4 queues by default)
 export TMPDIR=/tmp
 O=gpurun_out/r06_5; mkdir -p $O
-P="python tools/r06/phase_probe.py"
+P="python tools/phase_probe.py"
 {
 for Q in 2 4 8 16; do
 GPU_MAX_HW_QUEUES=$Q GO_ITERS=3 $P 24 1 seq

@@ -3,7 +3,7 @@
 # about three / four groups, the tuner left alone, the handles sharing ONE pair of streams (no environment needed), other systems
 export TMPDIR=/tmp
 O=gpurun_out/r06_6; mkdir -p $O
-P="python tools/r06/phase_probe.py"
+P="python tools/phase_probe.py"
 F="REMD_MANY_LEAN=0 REMD_NB_PRIO=1 REMD_NB_PERSIST_GRID=0"
 {
 env GO_ITERS=3 $P 24 1 seq

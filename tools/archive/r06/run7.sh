@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r06_7; mkdir -p $O
 timeout 900 python -m pytest tests/test_forcefield_parity.py -m gpu -q -x -k "phases or concurrently or stream_modes or resident_pair or constraint" 2>&1 | tail -6 | tee $O/pytest_phases.txt
-P="python tools/r06/phase_probe.py"
+P="python tools/phase_probe.py"
 {
 env GO_ITERS=4 GO_PHASES=1 $P 24 1 seq
 env GO_ITERS=4 GO_PHASES=2 $P 24 1 seq

@@ -4,9 +4,9 @@ order, 64-atom tiles, an entry (tile, j cluster) per j cluster whose bounding bo
 cluster-pair step per i cluster of the tile whose box is within range of the j cluster's (jc >= ic: every pair once).  Counted:
 steps, lane pairs inside the range, and -- per shell of box-to-box distance -- the steps in which only ONE 4-atom half of the j cluster is
 in range of the i cluster's box (a step that a half-cluster entry would turn into half a step IF it found a partner to share lanes with).
-usage: python tools/r06/pair_lane_utilisation.py"""
+usage: python tools/pair_lane_utilisation.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from openmmtools_amd import testsystems as ts
 

@@ -1,8 +1,8 @@
 """Round-6 probe: G handles of R/G replicas, driven sequentially or from G host threads; prints wall ms per propagate and a digest of
 the final positions per GLOBAL replica so that runs in different processes (different environment switches) can be compared.
-usage: python tools/r06/phase_probe.py R G mode[seq|thr|many] [system] ; env GO_STEPS, GO_ITERS"""
+usage: python tools/phase_probe.py R G mode[seq|thr|many] [system] ; env GO_STEPS, GO_ITERS"""
 import os, sys, time, threading, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from openmmtools_amd import testsystems as ts
 from openmmtools_amd.system import system_to_desc

@@ -1,5 +1,5 @@
 """All kernels of every queue inside a time window of a rocprofv3 --kernel-trace rocpd database (several handles = several pairs of
-queues).  usage: python tools/r06/timeline_window.py <dir> [window us = 700] [anchor = the chain launch this many from the end = 150]"""
+queues).  usage: python tools/timeline_window.py <dir> [window us = 700] [anchor = the chain launch this many from the end = 150]"""
 import glob, sqlite3, sys
 db = sqlite3.connect(glob.glob(sys.argv[1] + '/**/*.db', recursive=True)[0])
 rows = db.execute("select name,start,end,queue_id from kernels order by start").fetchall()
