@@ -1807,7 +1807,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
         hipLaunchKernelGGL(build_sci_list2_kernel, dim3(ntile + ntile_lj, h->R), dim3(64), 0, h->stream, ntile, la, lb, rc2_main, t.p.rc2, h->d_box);
         // (the list lengths of the evaluation that re-sorted the molecules order the work items until the next re-sort: the geometry
         // of a tile changes slowly; REMD_NB_RANK=0: tile order)
-        if (t.evals_since_sort == 1 && t.d_tile_of_rank)
+        if (t.evals_since_sort == 1 && t.d_tile_of_rank && ntile <= 2048)
             hipLaunchKernelGGL(rank_tiles_kernel, dim3((ntile + 255) / 256, h->R), dim3(256), 0, h->stream, ntile, t.d_sci_count, t.d_tile_of_rank);
     } else {
         hipLaunchKernelGGL(gather_positions_kernel, dim3(ntile, h->R), dim3(64), 0, h->stream, h->Npad, h->Npad, t.d_order, h->d_pos, h->d_box,
@@ -1850,7 +1850,9 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
         // (measured, profiles/r05_7_*: -1.2 % of a step on 8 x host-guest (71 tiles) and 16 x DHFR (369 tiles), +1 % on 24 x alanine dipeptide
         // (36 tiles: its launch is two rounds of the chip whatever the order) -- so from 64 tiles on; REMD_NB_RANK = 0 / 1 pins it)
         static const int rank_env = getenv("REMD_NB_RANK") ? atoi(getenv("REMD_NB_RANK")) : -1;
-        const bool ranked = (rank_env < 0 ? ntile >= 64 : rank_env != 0) && t.lj_split && t.d_lj_sci_list && t.d_tile_of_rank && (METHOD == NB_EWALD || METHOD == NB_RF);
+        // (rank_tiles_kernel compares every pair of a replica's tiles: measured up to 369 tiles; capped where the ranking would cost
+        // more than the tail it removes)
+        const bool ranked = (rank_env < 0 ? (ntile >= 64 && ntile <= 2048) : rank_env != 0) && t.lj_split && t.d_lj_sci_list && t.d_tile_of_rank && (METHOD == NB_EWALD || METHOD == NB_RF);
         sci_args sa{h->N, h->Npad, ncl, t.cl_cap, t.excl_W, h->Npad, 0, ssplit, t.d_spos, t.d_sparam, t.d_excl, t.d_sci_list, t.d_sci_count, t.d_sforce,
                     t.d_sposi, ranked ? t.d_tile_of_rank : (const int*)nullptr};
         const int items_a = ntile * h->R * (ssplit / SCI_NW);

@@ -66,6 +66,9 @@ class EnginePool:
         self._descs = list(descs)
         self.N = n.pop()
         self._each('set_system', lambda g: (self._descs[g],))
+        for eng in self._prop:                     # (a handle that got a new System is sized again before its labels-only fast path)
+            if eng is not None:
+                eng._pool_size = None
 
     def set_states(self, beta, lambda_sterics=None, lambda_electrostatics=None, energy_const=None):
         def pick(a, g):

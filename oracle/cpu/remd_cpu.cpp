@@ -916,6 +916,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
     auto ke = [&]() { double e = 0; for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) e += 0.5 * s.mass[i] * v[3 * i + k] * v[3 * i + k]; return e; };
     auto pe = [&]() { const int64_t kk = h->labels[rg]; return evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], nullptr, thread_fft(h)).total(); };
     std::vector<double> xold, vold;
+    std::vector<double> fgroup[4]; bool fgroup_valid[4] = {false, false, false, false};      // forces per force group of a multiple-time-step program
     for (int st = 0; st < n_steps; ++st) {
         const int64_t gstep = iteration * (int64_t)h->n_steps + first_step + st;
         if (s.cmm > 0 && ((first_step + st) % s.cmm) == 0) {              // CMMotionRemover at the top of a step (:1313)
@@ -929,6 +930,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
             const long long attempt = h->baro_attempts + (h->baro_steps + st + 1) / h->baro_frequency - h->baro_steps / h->baro_frequency - 1;
             barostat_attempt(h, r, attempt);
             x = rep.x.data();
+            for (bool& gv : fgroup_valid) gv = false;
         }
         int oidx = 0, brace = 0;
         for (char tok : tokens) {
@@ -943,6 +945,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                     rep.n_rejected++;
                     for (int i = 0; i < 3 * N; ++i) { x[i] = xold[i]; v[i] = -vold[i]; }
                     rep.f_valid = false; rep.list_valid = false;
+                    for (bool& gv : fgroup_valid) gv = false;
                 }
                 rep.shadow = 0.0;
                 brace++;
@@ -952,8 +955,14 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                 int mask = 0;
                 for (int c = 0; c < 6; ++c) if (h->force_groups[c] == g) mask |= 1 << c;
                 const int64_t kk = h->labels[rg];
-                std::vector<double> fg(3 * (size_t)N);
-                evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], fg.data(), thread_fft(h), PART_ALL, mask);
+                // (a group's forces are evaluated when one of its kicks comes up and the positions have moved since its last
+                // evaluation -- as on the device, integrate.hip: group_valid -- not once per token)
+                std::vector<double>& fg = fgroup[g];
+                if (!fgroup_valid[g]) {
+                    fg.assign(3 * (size_t)N, 0.0);
+                    evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], fg.data(), thread_fft(h), PART_ALL, mask);
+                    fgroup_valid[g] = true;
+                }
                 const double hg = h->dt / std::max(1, h->nVg[g]);
                 const double ke0 = m_shadow ? ke() : 0.0;
                 for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) v[3 * i + k] += hg * fg[3 * i + k] * s.invm[i];
@@ -976,6 +985,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                     rattle(s, x, v);                                                                                     // :1418
                 } else for (int i = 0; i < 3 * N; ++i) x[i] += hR * v[i];
                 rep.f_valid = false;
+                for (bool& gv : fgroup_valid) gv = false;
                 if (m_shadow) rep.shadow += ke() + pe() - e0;                                                            // :1420-1423
             } else {
                 const double ke0 = m_heat ? ke() : 0.0;
@@ -1184,6 +1194,7 @@ int remd_seed(remd_handle h, uint64_t seed) { if (!h) return -1; h->seed = seed;
 
 int remd_set_system(remd_handle h, const remd_system_desc* d)
 {
+    if (h) for (int c = 0; c < 6; ++c) h->force_groups[c] = 0;           // until remd_set_force_groups says otherwise (as libremd_hip.so)
     if (!h || !d) return fail(h, -1, "remd_set_system: NULL argument");
     if (d->n_atoms <= 0 || !d->mass) return fail(h, -1, "remd_set_system: n_atoms/mass missing");
     System s;
@@ -1513,6 +1524,17 @@ int remd_propagate(remd_handle h, int64_t iteration, int32_t* nan_flags)
 {
     if (!h || !h->has_system || !h->has_integrator || h->R <= 0 || h->K <= 0)
         return fail(h, -1, "remd_propagate: system/states/integrator/replicas not all set");
+    {
+        // a multiple-time-step program must name the force group of every force class (libremd_hip.so returns the same -3: a class
+        // in a group that no V of the splitting names would silently never act)
+        bool mts = false; unsigned named = 0u;
+        for (int g = 0; g < 4; ++g) if (h->nVg[g] > 0) { mts = true; for (int c = 0; c < 6; ++c) if (h->force_groups[c] == g) named |= 1u << c; }
+        if (mts)
+            for (int c = 0; c < 6; ++c)
+                if (h->force_groups[c] > 3 || !(named & (1u << c)))
+                    return fail(h, -3, "multiple-time-step splitting: a force class sits in a force group that no V of the splitting names "
+                                       "(its forces would never act); groups 0-3 are supported");
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const int R = h->R;
     std::vector<int> flags(R, 0);
