@@ -626,7 +626,17 @@ static int remd_propagate_phased(remd_ctx* h, int P, int64_t iteration, int32_t*
             if ((rc = remd_set_replicas(c, h->R_global, h->r_begin + r0[p], cnt, nullptr, nullptr, h->box_host.data() + 3 * (size_t)r0[p], h->labels.data())))
                 return remd_fail(h, rc, std::string("phases: ") + c->err);
             if (!h->noise_id_host.empty() && (rc = remd_set_replica_ids(c, h->noise_id_host.data() + r0[p]))) return remd_fail(h, rc, std::string("phases: ") + c->err);
-        } else if ((rc = remd_set_labels(c, h->labels.data()))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+            c->seen_parent_box = h->box_version;
+        } else {
+            if ((rc = remd_set_labels(c, h->labels.data()))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+            if (c->seen_parent_box != h->box_version) {
+                // the parent's boxes changed since this block took them (remd_set_replicas / remd_copy_replicas of new boxes): the
+                // block's host mirror and everything keyed by its box_version (the PME influence table) follow
+                for (int r = 0; r < cnt; ++r) for (int k = 0; k < 3; ++k) c->box_host[3 * (size_t)r + k] = h->box_host[3 * (size_t)(r0[p] + r) + k];
+                c->box_version++;
+                c->seen_parent_box = h->box_version;
+            }
+        }
         REMD_CHECK(h, hipMemcpyAsync(c->d_pos, h->d_pos + r0[p] * row, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, c->stream));
         REMD_CHECK(h, hipMemcpyAsync(c->d_vel, h->d_vel + r0[p] * row, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, c->stream));
         REMD_CHECK(h, hipMemcpyAsync(c->d_box, h->d_box + 4 * (size_t)r0[p], sizeof(float) * 4 * cnt, hipMemcpyDeviceToDevice, c->stream));

@@ -66,3 +66,29 @@ def test_phases_by_rule_follow_the_hardware_queue_limit(hip_engine_factory, monk
     assert phases_of(16, {}) == 1 and phases_of(16, {'GPU_MAX_HW_QUEUES': '4'}) == 1
     assert phases_of(8, {'GPU_MAX_HW_QUEUES': '2'}) == 1
     assert phases_of(16, {'GPU_MAX_HW_QUEUES': '2', 'REMD_PHASES': '1'}) == 1
+
+
+def test_new_boxes_reach_the_blocks(hip_engine_factory):
+    """The blocks of a phased handle keep their own box mirrors and PME influence tables: replicas set again with OTHER boxes (same shapes,
+    so the blocks are not re-made) must be propagated in the new boxes -- against the one-block run, bit for bit."""
+    from openmmtools_amd.system import system_to_desc
+    al = testsystems.AlanineDipeptideExplicit()
+    desc = system_to_desc(al.system, ewald_split='auto')
+    box = np.diag(al.system.getDefaultPeriodicBoxVectors())
+    R = 4
+    x0 = np.tile(al.positions, (R, 1, 1))
+    out = []
+    for phases in (1, 2):
+        eng = hip_engine_factory()
+        eng.set_phases(phases)
+        eng.set_system(desc); eng.set_states(np.full(R, 1.0 / (0.008314462618153242 * 300.0)))
+        eng.set_integrator('V R R O R R V', 0.002, 1.0, 20, True, 1e-8)
+        eng.seed(7)
+        eng.set_replicas(R, 0, x0, None, np.tile(box, (R, 1)), np.arange(R))
+        eng.propagate(0)
+        x, v = eng.get_replicas()[:2]
+        eng.set_replicas(R, 0, x * 1.002, v, np.tile(box * 1.002, (R, 1)), np.arange(R))      # an isotropic rescale, as a barostat would make
+        eng.propagate(1)
+        out.append(eng.get_replicas()[:2] + (eng.compute_energies(),))
+    for q in range(3):
+        assert np.array_equal(out[0][q], out[1][q]), q
