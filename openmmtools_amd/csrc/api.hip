@@ -276,7 +276,7 @@ int remd_set_replica_ids(remd_handle h, const int64_t* ids)
     if (!h || h->R <= 0) return remd_fail(h, -1, "remd_set_replica_ids: call remd_set_replicas first");
     hipSetDevice(h->device);
     if (h->d_noise_id) { REMD_CHECK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_noise_id); h->d_noise_id = nullptr; }
-    h->noise_id_host.clear(); h->config_version++;
+    h->noise_id_host.clear(); h->ids_version++;
     if (!ids) return 0;                                   // back to the block's own global indices
     h->noise_id_host.assign(ids, ids + h->R);
     std::vector<unsigned int> v(h->R);
@@ -313,7 +313,7 @@ int remd_set_replicas(remd_handle h, int R_global, int r_begin, int R_local, con
     hipSetDevice(h->device);
     const bool realloc = (R_local != h->R) || (R_global != h->R_global) || !h->d_pos;
     if (h->d_noise_id) { hipStreamSynchronize(h->stream); hipFree(h->d_noise_id); h->d_noise_id = nullptr; }     // ids belong to one set of replicas
-    h->noise_id_host.clear(); h->config_version++;
+    h->noise_id_host.clear(); h->ids_version++;
     h->R_global = R_global; h->r_begin = r_begin; h->R = R_local;
     const size_t n = (size_t)R_local * h->Npad;
     if (realloc) {
@@ -625,8 +625,7 @@ static int remd_propagate_phased(remd_ctx* h, int P, int64_t iteration, int32_t*
         if (c->R != cnt || c->R_global != h->R_global || c->r_begin != h->r_begin + r0[p] || !c->d_pos) {
             if ((rc = remd_set_replicas(c, h->R_global, h->r_begin + r0[p], cnt, nullptr, nullptr, h->box_host.data() + 3 * (size_t)r0[p], h->labels.data())))
                 return remd_fail(h, rc, std::string("phases: ") + c->err);
-            if (!h->noise_id_host.empty() && (rc = remd_set_replica_ids(c, h->noise_id_host.data() + r0[p]))) return remd_fail(h, rc, std::string("phases: ") + c->err);
-            c->seen_parent_box = h->box_version;
+            c->seen_parent_box = h->box_version; c->seen_parent_ids = -1;
         } else {
             if ((rc = remd_set_labels(c, h->labels.data()))) return remd_fail(h, rc, std::string("phases: ") + c->err);
             if (c->seen_parent_box != h->box_version) {
@@ -636,6 +635,10 @@ static int remd_propagate_phased(remd_ctx* h, int P, int64_t iteration, int32_t*
                 c->box_version++;
                 c->seen_parent_box = h->box_version;
             }
+        }
+        if (c->seen_parent_ids != h->ids_version) {      // remd_set_replica_ids of the parent (or none: the block's own global indices)
+            if ((rc = remd_set_replica_ids(c, h->noise_id_host.empty() ? nullptr : h->noise_id_host.data() + r0[p]))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+            c->seen_parent_ids = h->ids_version;
         }
         REMD_CHECK(h, hipMemcpyAsync(c->d_pos, h->d_pos + r0[p] * row, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, c->stream));
         REMD_CHECK(h, hipMemcpyAsync(c->d_vel, h->d_vel + r0[p] * row, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, c->stream));

@@ -244,7 +244,7 @@ struct remd_ctx {
     // of the other.  Coordinates, velocities and the forces the last evaluation left go to the children device to device in front and
     // come back behind; everything else (energies, mixing, get / set) stays with this handle.  phases_req: remd_set_phases (0 = by rule).
     int phases_req = 0; int phases_last = 1;
-    std::vector<remd_ctx*> phase; remd_ctx* parent = nullptr; int seen_parent_box = -1;     // (child: the parent's box_version its boxes were taken at)
+    std::vector<remd_ctx*> phase; remd_ctx* parent = nullptr; int seen_parent_box = -1; long long ids_version = 0, seen_parent_ids = -1;     // (child: the parent's box_version its boxes were taken at)
     long long config_version = 0, phase_config = -1;      // children are rebuilt when a setter has run since they were made
     remd_desc_store* sysdesc = nullptr;
     std::vector<int64_t> noise_id_host;                   // remd_set_replica_ids, for the children's slices
