@@ -21,6 +21,7 @@ done
 python tools/rocpd_pmc.py $dbs --md $out/pmc_traffic.md --json $out/pmc_traffic.json > /dev/null
 # per-kernel roofline table: durations x PMC traffic x algorithmic bytes, against the STREAM triad measured by bench.py
 stream=$(python -c "import json,sys; d=json.load(open('$out/bench_default.json')); print(d.get('measured_roofs',{}).get('stream_triad_gb_per_s',0))" 2>/dev/null)
-python tools/kernel_roofs.py $out/kernel_stats.md $out/pmc_traffic.json --stream ${stream:-6300} > $out/kernel_roofs.md
+rpl=$(python -c "import json,sys; d=json.load(open('$out/bench_default.json')); print(int(d['roofline'].get('replicas_per_launch', 24)))" 2>/dev/null)
+python tools/kernel_roofs.py $out/kernel_stats.md $out/pmc_traffic.json --stream ${stream:-6300} --replicas ${rpl:-24} > $out/kernel_roofs.md
 git rev-parse HEAD > /dev/null 2>&1 || true
 head -c 600 $out/bench_default.json; echo; head -8 $out/kernel_stats.md | cut -c1-150; head -6 $out/pmc_traffic.md | cut -c1-150

@@ -1,12 +1,14 @@
 """Per-kernel roofline table ("report each kernel's own HBM fraction"): joins the rocprofv3 kernel-trace
 summary (average duration per launch) with the PMC traffic table (FETCH_SIZE x 2 + WRITE_SIZE per launch, separate
-passes) and the algorithmic bytes per launch of the headline workload (24 replicas x 2269 atoms, 75 x 75 x 72 mesh).
+passes) and the algorithmic bytes per launch of the headline workload (--replicas per launch x 2269 atoms, 64^3 mesh unless --mesh says otherwise).
 
-usage: python tools/kernel_roofs.py <kernel_stats.md> <pmc_traffic.json> [--stream GBs] > profiles/rNN_x_kernel_roofs.md"""
+usage: python tools/kernel_roofs.py <kernel_stats.md> <pmc_traffic.json> [--stream GBs] [--replicas per launch] > profiles/rNN_x_kernel_roofs.md"""
 import json
 import sys
 
-R, N, NPAD = 24, 2269, 2304
+# (round 6: a launch covers one PHASE's share of the replicas -- remd_set_phases -- : --replicas 12 for the phased headline run)
+R = int(float(sys.argv[sys.argv.index("--replicas") + 1])) if "--replicas" in sys.argv else 24
+N, NPAD = 2269, 2304
 NX, NY, NZ = [int(v) for v in (sys.argv[sys.argv.index("--mesh") + 1].split("x") if "--mesh" in sys.argv else ("64", "64", "64"))]   # round 4: the rebalanced split
 HALF = (NZ // 2 + 1) * NX * NY * R            # complex points of the half spectrum, all replicas
 REAL = NX * NY * NZ * R
