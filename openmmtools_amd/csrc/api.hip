@@ -580,6 +580,51 @@ static int phases_for(remd_ctx* h)
     return h->R >= 16 ? 2 : 1;
 }
 
+// ---- do two streams sit on one hardware queue?  HIP deals streams onto GPU_MAX_HW_QUEUES queues per priority by least use, and a process
+// that holds other streams of that priority (torch's NCCL stream is a raised-priority one) can get block B's stream on the queue block A's
+// is on: the two blocks would then serialise (107 against 73 ms, profiles/r06_phases_hw_queues.txt "shared pair of streams").  Asked of the
+// device: a wavefront that waits 30 us of wall clock on each stream at once -- together they take 30 us on two queues and 60 on one.
+__global__ void remd_wait_wallclock_kernel(unsigned long long ticks_100mhz)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(8);
+}
+static bool streams_share_a_queue(hipStream_t a, hipStream_t b)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) hipEventDestroy(e0); return false; }
+    hipStreamSynchronize(a); hipStreamSynchronize(b);
+    hipLaunchKernelGGL(remd_wait_wallclock_kernel, dim3(1), dim3(64), 0, a, 100ull);       // (first launch of the kernel: code object load)
+    hipStreamSynchronize(a);
+    hipEventRecord(e0, a);
+    hipLaunchKernelGGL(remd_wait_wallclock_kernel, dim3(1), dim3(64), 0, a, 3000ull);      // 30 us
+    hipLaunchKernelGGL(remd_wait_wallclock_kernel, dim3(1), dim3(64), 0, b, 3000ull);
+    hipEventRecord(e1, b);
+    hipStreamSynchronize(a); hipStreamSynchronize(b);
+    float ms = 0.f;
+    const bool ok = hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipGetLastError();
+    return ok && ms > 0.048f;
+}
+// a stream like `like_priority_of` (raised priority or not) that does not share its hardware queue with `other`: a stream made while the
+// unwanted one is still alive lands on the less used queue; three tries, then whatever came last
+static hipStream_t stream_beside(hipStream_t other, bool raised)
+{
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    std::vector<hipStream_t> tried;
+    hipStream_t s = nullptr;
+    for (int k = 0; k < 3; ++k) {
+        s = nullptr;
+        if ((raised ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) { s = nullptr; break; }
+        if (!streams_share_a_queue(other, s)) break;
+        tried.push_back(s);
+    }
+    for (hipStream_t t : tried) if (t != s) hipStreamDestroy(t);
+    return s;
+}
+
 static int phase_children(remd_ctx* h, int P)
 {
     if ((int)h->phase.size() == P && h->phase_config == h->config_version) return 0;
@@ -594,6 +639,18 @@ static int phase_children(remd_ctx* h, int P)
         if (p == 0) {            // block 0 launches on this handle's own pair of streams (no hardware queue of its own)
             if (c->stream2) hipStreamDestroy(c->stream2);
             c->stream2 = h->stream2; c->borrowed_stream2 = true;
+        } else if (!getenv("REMD_CU_PAIR") && !getenv("REMD_CU_MESH")) {
+            // block B's streams must not sit on the hardware queues block A's are on (asked of the device, see above)
+            if (c->stream2 && h->stream2 && streams_share_a_queue(h->stream2, c->stream2)) {
+                hipStream_t s2 = stream_beside(h->stream2, true);
+                if (s2) { hipStreamDestroy(c->stream2); c->stream2 = s2; }
+                if (getenv("REMD_MANY_VERBOSE")) fprintf(stderr, "[remd] phases: block B's direct-space stream shared a hardware queue with block A's; re-made (%s)\n", s2 && !streams_share_a_queue(h->stream2, s2) ? "apart now" : "still shared");
+            }
+            if (c->owns_stream && streams_share_a_queue(h->stream, c->stream)) {
+                hipStream_t s1 = stream_beside(h->stream, getenv("REMD_MAIN_PRIO") && atoi(getenv("REMD_MAIN_PRIO")) != 0);
+                if (s1) { hipStreamDestroy(c->stream); c->stream = s1; }
+                if (getenv("REMD_MANY_VERBOSE")) fprintf(stderr, "[remd] phases: block B's main stream shared a hardware queue with block A's; re-made (%s)\n", s1 && !streams_share_a_queue(h->stream, s1) ? "apart now" : "still shared");
+            }
         }
         c->sync_events = h->sync_events; c->overlap = h->overlap;
         c->annihilate_sterics = h->annihilate_sterics; c->coulomb_cutoff = h->coulomb_cutoff;

@@ -8,6 +8,12 @@ from openmmtools_amd import testsystems as ts
 from openmmtools_amd.system import system_to_desc
 from openmmtools_amd._engine import HipEngine
 KB = 0.008314462618153242
+_extra = []
+if os.environ.get('GO_EXTRA_STREAMS'):          # other raised-priority streams in the process before the engines' (as torch's NCCL stream)
+    import torch
+    _extra = [torch.cuda.Stream(priority=-1) for _ in range(int(os.environ['GO_EXTRA_STREAMS']))]
+    for q in _extra:
+        with torch.cuda.stream(q): torch.zeros(8, device='cuda').sum().item()
 R = int(sys.argv[1]); G = int(sys.argv[2]); mode = sys.argv[3]
 name = sys.argv[4] if len(sys.argv) > 4 else 'alanine'
 al = {'alanine': ts.AlanineDipeptideExplicit, 'hostguest': ts.HostGuestExplicit, 'dhfr': ts.DHFRExplicit}[name]()
@@ -46,7 +52,7 @@ own = [e.last_timing()['propagate_ms'] for e in engs]
 x = np.concatenate([e.get_replicas()[0] for e in engs])
 dig = [hashlib.sha1(np.ascontiguousarray(x[r]).tobytes()).hexdigest()[:8] for r in range(R)]
 print('%s R %d G %d %s steps %d env[%s]: ms %s | device ms %s | digest all %s first %s last %s' % (
-    name, R, G, mode, n_steps, ' '.join('%s=%s' % (k, v) for k, v in sorted(os.environ.items()) if k.startswith(('REMD_', 'GPU_MAX', 'GO_PHASES'))),
+    name, R, G, mode, n_steps, ' '.join('%s=%s' % (k, v) for k, v in sorted(os.environ.items()) if k.startswith(('REMD_', 'GPU_MAX', 'GO_PHASES', 'GO_EXTRA'))),
     ' '.join('%.1f' % m for m in ms), ' '.join('%.1f' % o for o in own),
     hashlib.sha1(x.tobytes()).hexdigest()[:10], dig[0], dig[-1]), flush=True)
 print('  per-replica', ' '.join(dig), flush=True)
