@@ -14,6 +14,7 @@
 // itself pinned against direct Ewald summation.
 #include "remd_internal.h"
 #include "listed_terms.h"
+#include "pme_pow2.h"
 #include <cmath>
 #include <vector>
 #include <type_traits>
@@ -37,6 +38,7 @@ struct pme_state {
     float2* d_grid = nullptr;          // [R][nz/2+1][nx][ny] half spectrum, kz-major (or the full complex grid of the test hook)
     hipStream_t stream = nullptr;      // stream of the current remd_pme_forces call
     int nzc = 0; size_t nspec = 0; size_t xy_lds = 0; bool xy_fused = false; int xy_threads = 512;
+    int xy_pow2 = 0;                   // 64 / 128: the plane pass runs on the register transforms of pme_pow2.h
     int* d_col_count = nullptr; int* d_col_start = nullptr; int* d_cursor = nullptr; int* d_atom_col = nullptr; int* d_col_atoms = nullptr;
     float2* d_tw[4] = {nullptr, nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i k / n)
     float* d_bmod[3] = {nullptr, nullptr, nullptr};  // |b(m)|^-2 ... stored as B-spline moduli squared inverse
@@ -588,7 +590,7 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
 // recomputed (~45 VALU instructions per mesh point incl. an IEEE division and an exp) in every XY pass.
 __global__ __launch_bounds__(256)
 void pme_influence_table_kernel(int nx, int ny, int nz, const float* __restrict__ bmx, const float* __restrict__ bmy,
-                                const float* __restrict__ bmz, const float* __restrict__ box, float alpha, float* __restrict__ infl)
+                                const float* __restrict__ bmz, const float* __restrict__ box, float alpha, float* __restrict__ infl, int perm_r1)
 {
     const int kz = blockIdx.x, r = blockIdx.y, nzc = nz / 2 + 1, np = nx * ny;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
@@ -605,7 +607,14 @@ void pme_influence_table_kernel(int nx, int ny, int nz, const float* __restrict_
         const float msq = mx * mx + my * my + mz * mz;
         float g = 0.f;
         if (msq > 0.f) g = pref * __expf(-fac * msq) / (msq * bmx[kx] * bmy[ky] * bz);
-        G[idx] = g;
+        int dst = idx;
+        if (perm_r1 > 0) {
+            // the order pme_xy_pow2_kernel holds the spectrum in (pme_pow2.h): thread kx * 8 + j, register m * 8 + k2 is
+            // ky = j + 8 m + R1 k2
+            const int j = ky & 7, hi = ky >> 3, mm = perm_r1 >> 3, m = hi % mm, k2 = hi / mm;
+            dst = (m * 8 + k2) * (np / perm_r1) + kx * 8 + j;
+        }
+        G[dst] = g;
     }
 }
 
@@ -1046,7 +1055,19 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
             }
         }
     }
-    if (s->xy_fused && !full_complex) {
+    // square power-of-two planes: the register-resident pass (REMD_PME_POW2=0: the scheduled mixed-radix pass)
+    if (s->xy_fused && !full_complex && s->n[0] == s->n[1] && (s->n[0] == 64 || s->n[0] == 128) &&
+        !(getenv("REMD_PME_POW2") && atoi(getenv("REMD_PME_POW2")) == 0)) {
+        s->xy_pow2 = s->n[0];
+        s->xy_threads = s->n[0] == 64 ? 512 : 1024;
+        s->xy_lds = sizeof(float2) * ((size_t)s->n[0] * (s->n[0] + 8) + s->n[0]) + sizeof(double) * 16;
+        h->xy_lds_bytes = s->xy_lds;
+        REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_pow2_kernel<64, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_pow2_kernel<64, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_pow2_kernel<128, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_pow2_kernel<128, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (s->xy_fused && !full_complex && !s->xy_pow2) {
         REMD_CHECK(h, hipFuncSetAttribute((const void*)pme_xy_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->xy_lds));
         const int PS = s->n[1] | 1;
         int rc = build_sched(h, s, 1, s->n[0], PS, 1, s->xy_threads, XY_PPT, &s->sch_y, &s->d_sched[1]);      // along y: lines = x rows
@@ -1145,12 +1166,20 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
             if (s->infl_version != h->box_version) {
                 // one table serves every replica while all boxes are the same (constant volume): 1 / R of the table traffic
                 hipLaunchKernelGGL(pme_influence_table_kernel, dim3(s->nzc, h->box_uniform ? 1 : s->R), dim3(256), 0, st, nx, ny, nz, s->d_bmod[0], s->d_bmod[1],
-                                   s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl);
+                                   s->d_bmod[2], h->d_box, (float)h->ewald_alpha, s->d_infl, s->xy_pow2 == 64 ? 8 : s->xy_pow2 == 128 ? 16 : 0);
                 s->infl_version = h->box_version;
                 s->infl_rep = h->box_uniform ? 0 : s->nzc;
             }
         }
-        if (s->xy_fused) {
+        if (s->xy_pow2) {
+            remd_prof_scope pxy(h, "pme_xy", st);
+#define LAUNCH_XY_P2(NN, RR, TT, WE) hipLaunchKernelGGL((pme_xy_pow2_kernel<NN, RR, WE>), dim3(s->nzc, s->R), dim3(TT), s->xy_lds, st, nz, s->d_grid, \
+                                   s->d_tw[0], s->d_energy, s->n_eblk, s->d_infl, s->infl_rep, s->prio_hi ? 1 : 0)
+            if (s->xy_pow2 == 64) { if (with_energy) LAUNCH_XY_P2(64, 8, 512, true); else LAUNCH_XY_P2(64, 8, 512, false); }
+            else { if (with_energy) LAUNCH_XY_P2(128, 16, 1024, true); else LAUNCH_XY_P2(128, 16, 1024, false); }
+#undef LAUNCH_XY_P2
+            if (h->pair_after_xy && h->ev_xy) { hipEventRecord(h->ev_xy, st); h->xy_recorded = true; }
+        } else if (s->xy_fused) {
             remd_prof_scope pxy(h, "pme_xy", st);
             hipLaunchKernelGGL(pme_xy_fused_kernel, dim3(s->nzc, s->R), dim3(s->xy_threads), s->xy_lds, st, make_plan(s, 0), make_plan(s, 1),
                                s->sch_x, s->sch_y, nz, s->d_grid, s->d_tw[0], s->d_tw[1], s->d_bmod[0], s->d_bmod[1], s->d_bmod[2], h->d_box,
