@@ -585,6 +585,236 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
     }
 }
 
+// ---- the z passes of power-of-two meshes (nz = 64, 128; nz / 2 = M = 8 * R2 packed points per line) on the register
+// transforms of pme_pow2.h.  A workgroup takes 64 lines (x, y0 .. y0 + 63) on 64 * R2 threads: thread (l = tid mod 64,
+// j = tid / 64) holds elements j + R2 q, q < 8, of line l -- j is uniform over a wavefront, so every twiddle is a scalar
+// load, and every LDS image is [element][line]: consecutive lanes, consecutive addresses, in the accumulators of the
+// spreading, the exchange between the two butterflies, the untangling of the packed transform and the potential the
+// gather reads; the half spectrum leaves and enters in runs of 64 numbers.  Five workgroup barriers behind the spreading
+// (the scheduled pass: two per stage + four).
+template <int M, int R2>
+__global__ __launch_bounds__(64 * R2)
+void pme_spread_zfwd_pow2_kernel(int nx, int ny, int Npad, const float4* __restrict__ pos,
+                                 const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
+                                 const int* __restrict__ col_start, const int* __restrict__ col_atoms,
+                                 float2* __restrict__ spec, const float2* __restrict__ tw, const float2* __restrict__ tw_half,
+                                 int bin_cap, int* __restrict__ zero_count, unsigned int* fork_flag, unsigned int fork_seq,
+                                 const float* __restrict__ bin_q, listed_tables LT, int n_mesh_blocks, long long* __restrict__ force, int prio)
+{
+    constexpr int R1 = 8, NL = 64, ZT = NL * R2, MM = R1 / R2, nz = 2 * M;
+    static_assert(M == R1 * R2 && (R2 == 4 || R2 == 8), "M = 8 * R2");
+    if ((int)blockIdx.x >= n_mesh_blocks) {
+        listed_forces_body(LT, Npad, pos, box, force, ((int)blockIdx.x - n_mesh_blocks) * ZT + (int)threadIdx.x, blockIdx.y);
+        return;
+    }
+    if (prio) __builtin_amdgcn_s_setprio(PME_PRIO);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* B = reinterpret_cast<float2*>(smem);            // [M][NL]
+    int* acc = reinterpret_cast<int*>(smem);                // [nz][NL]: the same bytes
+    const int r = blockIdx.y, tid = threadIdx.x;
+    const int nbpr = ny / NL;
+    const int x = blockIdx.x / nbpr, y0 = (blockIdx.x - x * nbpr) * NL;
+    for (int idx = tid; idx < nz * NL; idx += ZT) acc[idx] = 0;
+    __syncthreads();
+    const int* cs = col_start + (size_t)r * (bin_cap > 0 ? nx : nx + 1);
+    const int* ca = col_atoms + (size_t)r * (bin_cap > 0 ? (size_t)nx * bin_cap * 4 : (size_t)Npad);
+    const float4* P = pos + (size_t)r * Npad;
+    if (zero_count && blockIdx.x == 0) for (int k = tid; k < nx; k += ZT) zero_count[(size_t)r * nx + k] = 0;
+    if (fork_flag && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        __hip_atomic_store(fork_flag, fork_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
+        const int ntot = cnd.ntot;
+        for (int t = tid; t < ntot; t += ZT) {
+            float4 xi; float q;
+            pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi, bin_q ? bin_q + (size_t)r * nx * bin_cap : (const float*)nullptr, param, rep_lam, r, q);
+            if (q == 0.f) continue;
+            float ux, uy, uz; int kx, ky, kz;
+            pme_scaled(xi, box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+            float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
+            bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
+            if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+            int a = kx - x; if (a < 0) a += nx;
+            float wa = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (k == a) wa = wx[k];
+            const float qa = q * wa * PME_MESH_SCALE;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                int iy = ky - b; if (iy < 0) iy += ny;
+                const int lb = iy - y0;
+                if (lb < 0 || lb >= NL) continue;
+                const float qab = qa * wy[b];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const int iz = (kz - c) & (nz - 1);
+                    atomicAdd(&acc[iz * NL + lb], __float2int_rn(qab * wz[c]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int l = tid & (NL - 1);
+    const int j = __builtin_amdgcn_readfirstlane(tid / NL);
+    float2 v[R1], w[R1];
+#pragma unroll
+    for (int q = 0; q < R1; ++q) {
+        const int n = j + R2 * q;               // packed point n = (x[2n], x[2n+1])
+        v[q] = make_float2((float)acc[(2 * n) * NL + l] * (1.0f / PME_MESH_SCALE), (float)acc[(2 * n + 1) * NL + l] * (1.0f / PME_MESH_SCALE));
+    }
+    __syncthreads();
+    p2_dft8<-1>(v);
+#pragma unroll
+    for (int k1 = 1; k1 < R1; ++k1) v[k1] = p2_twid<-1>(v[k1], tw_half[j * k1]);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) B[(k1 * R2 + j) * NL + l] = v[k1];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        const int k1 = j + R2 * m;
+        float2 u[R2];
+#pragma unroll
+        for (int jp = 0; jp < R2; ++jp) u[jp] = B[(k1 * R2 + jp) * NL + l];
+        p2_dft<-1, R2>(u);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) w[m * R2 + k2] = u[k2];      // Z[k1 + R1 k2]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) B[(j + R2 * m + R1 * k2) * NL + l] = w[m * R2 + k2];
+    __syncthreads();
+    // untangle: X[k] = (Z[k] + conj Z[M-k]) / 2 - (i/2) W^k (Z[k] - conj Z[M-k]), W = exp(-2 pi i / nz), Z[M] = Z[0]
+    float2* S = spec + (size_t)r * (M + 1) * nx * ny + (size_t)x * ny + y0;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const int k = j + R2 * m + R1 * k2;
+            const float2 Zk = w[m * R2 + k2], Zm = B[((M - k) & (M - 1)) * NL + l];
+            const float2 E = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
+            const float2 O = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));
+            S[(size_t)k * nx * ny + l] = p2_add(E, p2_mul(tw[k], O));
+            if (k == 0) S[(size_t)M * nx * ny + l] = make_float2(Zk.x - Zk.y, 0.f);     // W^M = -1
+        }
+}
+
+template <int M, int R2>
+__global__ __launch_bounds__(64 * R2) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void pme_zinv_gather_pow2_kernel(int nx, int ny, const float2* __restrict__ spec, const float2* __restrict__ tw,
+                                 const float2* __restrict__ tw_half, int Npad, const float4* __restrict__ pos,
+                                 const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
+                                 const int* __restrict__ col_start, const int* __restrict__ col_atoms, long long* __restrict__ force,
+                                 int bin_cap, const float* __restrict__ bin_q, int prio)
+{
+    constexpr int R1 = 8, NL = 64, ZT = NL * R2, MM = R1 / R2, nz = 2 * M;
+    if (prio) __builtin_amdgcn_s_setprio(PME_PRIO);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* B = reinterpret_cast<float2*>(smem);            // [M + 1][NL]
+    float* phi = reinterpret_cast<float*>(smem);            // [nz][NL]: the real potential of the 64 lines
+    const int r = blockIdx.y, tid = threadIdx.x;
+    const int nbpr = ny / NL;
+    const int x = blockIdx.x / nbpr, y0 = (blockIdx.x - x * nbpr) * NL;
+    const int l = tid & (NL - 1);
+    const int j = __builtin_amdgcn_readfirstlane(tid / NL);
+    const float2* S = spec + (size_t)r * (M + 1) * nx * ny + (size_t)x * ny + y0;
+    float2 v[R1], w[R1];
+#pragma unroll
+    for (int q = 0; q < R1; ++q) w[q] = S[(size_t)(j + R2 * q) * nx * ny + l];     // X[k], k = j + R2 q
+    float2 XM = make_float2(0.f, 0.f);
+    if (j == 0) XM = S[(size_t)M * nx * ny + l];
+    // the first candidate atom of this thread for the gather at the end: its chain of dependent loads (bin -> atom -> charge)
+    // runs under the transform
+    const int* cs = col_start + (size_t)r * (bin_cap > 0 ? nx : nx + 1);
+    const int* ca = col_atoms + (size_t)r * (bin_cap > 0 ? (size_t)nx * bin_cap * 4 : (size_t)Npad);
+    const float4* P = pos + (size_t)r * Npad;
+    const float* bq = bin_q ? bin_q + (size_t)r * nx * bin_cap : (const float*)nullptr;
+    const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
+    const int ntot = cnd.ntot;
+    float4 xi0 = make_float4(0.f, 0.f, 0.f, 0.f); float q0 = 0.f; int i0 = 0;
+    if (tid < ntot) i0 = pme_cand_atom(cnd, ca, tid, bin_cap > 0, P, xi0, bq, param, rep_lam, r, q0);
+#pragma unroll
+    for (int q = 0; q < R1; ++q) B[(j + R2 * q) * NL + l] = w[q];
+    if (j == 0) B[M * NL + l] = XM;
+    __syncthreads();
+    // packed spectrum: Z[k] = A + i conj(W^k) Bv, A = X[k] + conj X[M-k], Bv = X[k] - conj X[M-k]
+#pragma unroll
+    for (int q = 0; q < R1; ++q) {
+        const int k = j + R2 * q;
+        const float2 Xk = w[q], Xm = B[(M - k) * NL + l];
+        const float2 A = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);
+        const float2 Bv = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);
+        const float2 t = p2_twid<+1>(Bv, tw[k]);
+        v[q] = make_float2(A.x - t.y, A.y + t.x);
+    }
+    __syncthreads();
+    p2_dft8<+1>(v);
+#pragma unroll
+    for (int k1 = 1; k1 < R1; ++k1) v[k1] = p2_twid<+1>(v[k1], tw_half[j * k1]);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) B[(k1 * R2 + j) * NL + l] = v[k1];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        const int k1 = j + R2 * m;
+        float2 u[R2];
+#pragma unroll
+        for (int jp = 0; jp < R2; ++jp) u[jp] = B[(k1 * R2 + jp) * NL + l];
+        p2_dft<+1, R2>(u);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) w[m * R2 + k2] = u[k2];      // packed point n = k1 + R1 k2: (phi[2n], phi[2n+1])
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const int n = j + R2 * m + R1 * k2;
+            phi[(2 * n) * NL + l] = w[m * R2 + k2].x;
+            phi[(2 * n + 1) * NL + l] = w[m * R2 + k2].y;
+        }
+    __syncthreads();
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
+    for (int t = tid; t < ntot; t += ZT) {
+        float4 xi = xi0; float q = q0; int i = i0;
+        if (t != tid) i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi, bq, param, rep_lam, r, q);
+        if (q == 0.f) continue;
+        float ux, uy, uz; int kx, ky, kz;
+        pme_scaled(xi, box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
+        float wx[5], wy[5], wz[5], dx[5], dy[5], dz[5];
+        bspline5(ux - kx, wx, dx); bspline5(uy - ky, wy, dy); bspline5(uz - kz, wz, dz);
+        if (kx >= nx) kx -= nx; if (ky >= ny) ky -= ny; if (kz >= nz) kz -= nz;
+        int a = kx - x; if (a < 0) a += nx;
+        float wxa = 0.f, dxa = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (k == a) { wxa = wx[k]; dxa = dx[k]; }
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            int iy = ky - b; if (iy < 0) iy += ny;
+            const int lb = iy - y0;
+            if (lb < 0 || lb >= NL) continue;
+            any = true;
+            float sx = 0.f, sz = 0.f;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const int iz = (kz - c) & (nz - 1);
+                const float p = phi[iz * NL + lb];
+                sx += wz[c] * p; sz += dz[c] * p;
+            }
+            gx += wy[b] * sx; gy += dy[b] * sx; gz += wy[b] * sz;
+        }
+        if (!any) continue;
+        const float Fx = -q * dxa * gx * nx / Lx, Fy = -q * wxa * gy * ny / Ly, Fz = -q * wxa * gz * nz / Lz;
+        atomicAdd(&F[i], remd_f2fix(Fx));
+        atomicAdd(&F[Npad + i], remd_f2fix(Fy));
+        atomicAdd(&F[2 * Npad + i], remd_f2fix(Fz));
+    }
+}
+
 // Influence function G(kx, ky, kz) = exp(-pi^2 m^2 / alpha^2) / (pi V m^2 |b_x b_y b_z|^2) of every replica's box, laid out
 // like the half spectrum.  It only depends on the box, so it is tabulated when a box changes (NVT: once) instead of being
 // recomputed (~45 VALU instructions per mesh point incl. an IEEE division and an exp) in every XY pass.
@@ -1055,9 +1285,9 @@ static int pme_setup_impl(remd_ctx* h, bool full_complex)
             }
         }
     }
-    // square power-of-two planes: the register-resident pass (REMD_PME_POW2=0: the scheduled mixed-radix pass)
+    // square power-of-two planes: the register-resident pass (REMD_PME_POW2=0: the scheduled mixed-radix passes; 1 / 2: plane pass / z passes only)
     if (s->xy_fused && !full_complex && s->n[0] == s->n[1] && (s->n[0] == 64 || s->n[0] == 128) &&
-        !(getenv("REMD_PME_POW2") && atoi(getenv("REMD_PME_POW2")) == 0)) {
+        !(getenv("REMD_PME_POW2") && !(atoi(getenv("REMD_PME_POW2")) & 1))) {                 // bit 0: the plane pass
         s->xy_pow2 = s->n[0];
         s->xy_threads = s->n[0] == 64 ? 512 : 1024;
         s->xy_lds = sizeof(float2) * ((size_t)s->n[0] * (s->n[0] + 8) + s->n[0]) + sizeof(double) * 16;
@@ -1153,6 +1383,18 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         // listed terms riding in this launch (forces.hip decides: remd_ctx::mesh_listed_total)
         const int n_mesh_blocks = (int)zgrid.x;
         const int n_listed_blocks = h->mesh_listed_total > 0 ? (h->mesh_listed_total + ZT - 1) / ZT : 0;
+        // power-of-two z: 64 lines per workgroup on the register transforms (REMD_PME_POW2=0: the scheduled passes)
+        static const bool pow2_env = !(getenv("REMD_PME_POW2") && !(atoi(getenv("REMD_PME_POW2")) & 2));      // bit 1: the z passes
+        const int zp2 = (pow2_env && half && (nz == 64 || nz == 128) && ny % 64 == 0 && nl == 64 && ZT == 64 * (nz / 16)) ? nz : 0;
+        const size_t zlds2 = sizeof(float2) * (size_t)(nz / 2 + 1) * 64;
+        if (zp2) {
+            const dim3 zg(zgrid.x + n_listed_blocks, zgrid.y);
+#define LAUNCH_ZF2(MMM, RR) hipLaunchKernelGGL((pme_spread_zfwd_pow2_kernel<MMM, RR>), zg, dim3(64 * RR), zlds2, st, nx, ny, h->Npad, h->d_pos, param, h->d_box, rep_lam, \
+                       bin_cs, bin_ca, s->d_grid, s->d_tw[2], s->d_tw[3], bin_cap, bin_zero, fflag, fseq, \
+                       (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr, h->mesh_listed, n_mesh_blocks, h->d_force, s->prio_hi ? 1 : 0)
+            if (zp2 == 64) LAUNCH_ZF2(32, 4); else LAUNCH_ZF2(64, 8);
+#undef LAUNCH_ZF2
+        } else
         {
             const dim3 zgrid_keep = zgrid;
             const dim3 zgrid(zgrid_keep.x + n_listed_blocks, zgrid_keep.y);
@@ -1215,6 +1457,13 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         }
         {
         remd_prof_scope pzg(h, "pme_zinv_gather", st);
+        if (zp2) {
+#define LAUNCH_ZI2(MMM, RR) hipLaunchKernelGGL((pme_zinv_gather_pow2_kernel<MMM, RR>), zgrid, dim3(64 * RR), zlds2, st, nx, ny, s->d_grid, s->d_tw[2], s->d_tw[3], \
+                       h->Npad, h->d_pos, param, h->d_box, rep_lam, bin_cs, bin_ca, h->d_force, bin_cap, \
+                       (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr, s->prio_hi ? 1 : 0)
+            if (zp2 == 64) LAUNCH_ZI2(32, 4); else LAUNCH_ZI2(64, 8);
+#undef LAUNCH_ZI2
+        } else
         DISPATCH_Z(pme_zinv_gather_kernel, s->d_grid, s->d_tw[2], s->d_tw[3], h->Npad, h->d_pos, param, h->d_box, rep_lam,
                    bin_cs, bin_ca, h->d_force, bin_cap, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr);
         if (s->cbin_use) s->cbin_parity ^= 1;          // the next chain fills the buffer this evaluation has just zeroed

@@ -247,12 +247,13 @@ def test_alanine_short_trajectory(hip_engine_factory, alanine):
 
 
 @pytest.mark.parametrize('grid', [(48, 60, 64), (80, 90, 96), (54, 81, 100), (64, 50, 40), (45, 120, 36), (32, 72, 128), (125, 128, 108),
-                                  (64, 64, 64), (64, 64, 45), (128, 128, 128), (128, 128, 50)])
+                                  (64, 64, 64), (64, 64, 45), (128, 128, 128), (128, 128, 50), (48, 64, 64), (60, 128, 128), (64, 64, 128), (128, 128, 64)])
 def test_pme_mesh_sizes_through_the_force_path(hip_engine_factory, grid):
     """The LDS-resident mesh passes run mixed-radix stages (radix 4, 2, 3, 5 in that order, pme.hip: factorize) along y and
     x in the plane pass and along z (packed real pairs, nz / 2 points) in the spreading / gathering passes; planes that
     outgrow one workgroup take the slab path (125 x 128); square 64 x 64 and 128 x 128 planes take the register transforms of
-    pme_pow2.h (radix 8 x 8 and 16 x 8, with even and odd nz behind them).  Mesh sizes with every radix in a first (no twiddles) and a later
+    pme_pow2.h (radix 8 x 8 and 16 x 8, with even and odd nz behind them), nz = 64 / 128 with ny a multiple of 64 the register z passes
+    (packed 32- and 64-point transforms), also behind planes of other sizes.  Mesh sizes with every radix in a first (no twiddles) and a later
     stage, odd and even nz: energy and forces of the alanine dipeptide box against the f64 oracle on the SAME mesh (the
     mesh only has to be at least as fine as the Ewald tolerance asks, so any of these is a legal choice)."""
     al = ts.AlanineDipeptideExplicit()
