@@ -136,6 +136,7 @@ int remd_destroy(remd_handle h)
     remd_free_nonbonded(h);
     remd_mix_release(h);
     dfree(h->d_invmass); dfree(h->d_mass); dfree(h->d_ext_atoms);
+    dfree(h->d_aterm); h->n_aterm = 0;
     dfree(h->d_bond_atoms); dfree(h->d_bond_params); dfree(h->d_angle_atoms); dfree(h->d_angle_params);
     dfree(h->d_torsion_atoms); dfree(h->d_torsion_params);
     dfree(h->d_nbparam); dfree(h->d_exclmask); dfree(h->d_exc_atoms); dfree(h->d_exc_params); dfree(h->d_excl_pairs);

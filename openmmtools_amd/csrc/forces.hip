@@ -282,6 +282,7 @@ void listed_forces_kernel(listed_tables T, int Npad, const float4* __restrict__ 
     listed_forces_body(T, Npad, pos, box, force, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
 
+
 // ---- spatial ordering ------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned morton3(unsigned x, unsigned y, unsigned z)
 {
@@ -1446,6 +1447,32 @@ static double dispersion_coefficient(int N, const std::vector<double>& sigma, co
     return 8.0 * N * (double)N * M_PI * (sum1 / (9.0 * pow(rc, 9)) - sum2 / (3.0 * pow(rc, 3)) + sum3);
 }
 
+// the (term, slot) entries of the listed terms in the order of the atoms they act on (listed_terms.h): class << 29 | slot << 27 | term
+static int build_atom_terms(remd_ctx* h, int N, const std::vector<int>& ba, const std::vector<int>& aa, const std::vector<int>& ta,
+                            const std::vector<int>& exc, int n_exc, const std::vector<int>& excl, int n_excl)
+{
+    if (h->d_aterm) { hipFree(h->d_aterm); h->d_aterm = nullptr; }
+    h->n_aterm = 0;
+    const size_t nterm[5] = { ba.size() / 2, aa.size() / 3, ta.size() / 4, (size_t)n_exc, (size_t)n_excl };
+    const std::vector<int>* arr[5] = { &ba, &aa, &ta, &exc, &excl };
+    const int width[5] = { 2, 3, 4, 2, 2 };
+    for (int c = 0; c < 5; ++c) if (nterm[c] >= (1u << 27)) return 0;          // (the term-per-thread launch stays)
+    std::vector<int> start(N + 1, 0);
+    for (int c = 0; c < 5; ++c)
+        for (size_t t = 0; t < nterm[c]; ++t)
+            for (int s = 0; s < width[c]; ++s) start[(*arr[c])[t * width[c] + s] + 1]++;
+    for (int i = 0; i < N; ++i) start[i + 1] += start[i];
+    if (start[N] == 0) return 0;
+    std::vector<unsigned int> ent(start[N]);
+    std::vector<int> cur(start.begin(), start.end() - 1);
+    for (int c = 0; c < 5; ++c)
+        for (size_t t = 0; t < nterm[c]; ++t)
+            for (int s = 0; s < width[c]; ++s)
+                ent[cur[(*arr[c])[t * width[c] + s]]++] = ((unsigned int)c << 29) | ((unsigned int)s << 27) | (unsigned int)t;
+    h->n_aterm = (int)ent.size();
+    return upload(h, h->d_aterm, ent);
+}
+
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
 {
     remd_free_nonbonded(h);
@@ -1471,7 +1498,11 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         for (int k = 0; k < 4 * d->n_torsions; ++k) if (ta[k] < 0 || ta[k] >= d->n_atoms) return remd_fail(h, -3, "torsion atom index out of range");
     }
     h->n_alch = d->n_alch;
-    if (d->nb_method == REMD_NB_NONE) return 0;
+    if (d->nb_method == REMD_NB_NONE) {
+        const std::vector<int> ba(d->bond_atoms, d->bond_atoms + 2 * (size_t)d->n_bonds), aa(d->angle_atoms, d->angle_atoms + 3 * (size_t)d->n_angles),
+                               ta(d->torsion_atoms, d->torsion_atoms + 4 * (size_t)d->n_torsions), none;
+        return build_atom_terms(h, d->n_atoms, ba, aa, ta, none, 0, none, 0);
+    }
     if (d->nb_method != REMD_NB_CUTOFF_PERIODIC && d->nb_method != REMD_NB_PME) return remd_fail(h, -3, "unknown nonbonded method");
     if (!d->charge || !d->sigma || !d->epsilon) return remd_fail(h, -1, "nonbonded parameter arrays missing");
     if (!(d->cutoff > 0)) return remd_fail(h, -1, "cutoff must be positive");
@@ -1540,6 +1571,11 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     if ((rc = upload(h, t.d_exc_atoms, exc_atoms)) || (rc = upload(h, t.d_exc_params, exc_params)) || (rc = upload(h, t.d_exc_alch, exc_alch))) return rc;
     t.n_excl = (t.method == NB_EWALD) ? (int)excl_qq.size() : 0;
     if ((rc = upload(h, t.d_excl_atoms, excl_atoms)) || (rc = upload(h, t.d_excl_qq, excl_qq)) || (rc = upload(h, t.d_excl_alch, excl_alch))) return rc;
+    {
+        const std::vector<int> ba(d->bond_atoms, d->bond_atoms + 2 * (size_t)d->n_bonds), aa(d->angle_atoms, d->angle_atoms + 3 * (size_t)d->n_angles),
+                               ta(d->torsion_atoms, d->torsion_atoms + 4 * (size_t)d->n_torsions);
+        if ((rc = build_atom_terms(h, N, ba, aa, ta, exc_atoms, t.n_exc, excl_atoms, t.n_excl))) return rc;
+    }
 
     nb_params& p = t.p;
     p.rc = (float)d->cutoff; p.rc2 = (float)(d->cutoff * d->cutoff);
@@ -2072,6 +2108,10 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
             T.exc_alch = t.d_exc_alch; T.excl_alch = t.d_excl_alch; T.rep_lam = t.has_alch ? t.d_rep_lam : nullptr;
         }
         total = T.n_bonds + T.n_angles + T.n_torsions + T.n_exc + T.n_excl;
+        // one (term, slot) entry per thread in atom order (REMD_LISTED_ATOMS=0: one term per thread)
+        const bool atoms_env = !(getenv("REMD_LISTED_ATOMS") && atoi(getenv("REMD_LISTED_ATOMS")) == 0);
+        T.n_aterm = 0; T.aterm = nullptr;
+        if (atoms_env && total > 0 && h->d_aterm && h->n_aterm > 0) { T.aterm = h->d_aterm; T.n_aterm = h->n_aterm; total = h->n_aterm; }
         return T;
     };
     const bool listed_main_env = !(getenv("REMD_LISTED_MAIN") && atoi(getenv("REMD_LISTED_MAIN")) == 0);

@@ -775,6 +775,9 @@ void pme_zinv_gather_pow2_kernel(int nx, int ny, const float2* __restrict__ spec
             phi[(2 * n + 1) * NL + l] = w[m * R2 + k2].y;
         }
     __syncthreads();
+#ifdef EXP_ZI_NOGATHER    // knock-out probe: transform only
+    if (phi[tid] != 1.2345e33f) return;
+#endif
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
     for (int t = tid; t < ntot; t += ZT) {
@@ -809,6 +812,9 @@ void pme_zinv_gather_pow2_kernel(int nx, int ny, const float2* __restrict__ spec
         }
         if (!any) continue;
         const float Fx = -q * dxa * gx * nx / Lx, Fy = -q * wxa * gy * ny / Ly, Fz = -q * wxa * gz * nz / Lz;
+#ifdef EXP_ZI_NOATOM      // knock-out probe: the gather without its atomics (results wrong on purpose)
+        if (Fx != 1.2345e33f) continue;
+#endif
         atomicAdd(&F[i], remd_f2fix(Fx));
         atomicAdd(&F[Npad + i], remd_f2fix(Fy));
         atomicAdd(&F[2 * Npad + i], remd_f2fix(Fz));

@@ -68,6 +68,8 @@ struct listed_tables {
     const float *bond_params, *angle_params, *torsion_params, *exc_params, *excl_qq;
     const int *exc_alch, *excl_alch; const float* rep_lam;
     float alpha, two_alpha_sqrtpi;
+    // (term, slot) entries in the order of the atoms they act on (listed_terms.h); aterm NULL: one term per thread
+    int n_aterm; const unsigned int* aterm;
 };
 
 struct remd_profile_entry { int64_t n = 0; double ms = 0.0; };
@@ -115,6 +117,7 @@ struct remd_ctx {
     // bonded
     int n_bonds = 0, n_angles = 0, n_torsions = 0;
     int* d_bond_atoms = nullptr; float* d_bond_params = nullptr;
+    unsigned int* d_aterm = nullptr; int n_aterm = 0;      // (term, slot) entries of the listed terms by atom (forces.hip: build_atom_terms)
     int* d_angle_atoms = nullptr; float* d_angle_params = nullptr;
     int* d_torsion_atoms = nullptr; float* d_torsion_params = nullptr;
     // nonbonded

@@ -416,7 +416,8 @@ def test_resident_pair_workgroups_do_not_change_a_bit(hip_engine_factory, monkey
 def test_stream_modes_of_a_force_evaluation_do_not_change_a_bit(hip_engine_factory, monkeypatch):
     """Round 4: which stream is treated as the critical one is a run-time choice (tuner candidate '0p'): the pair kernel at raised
     wave priority, the listed terms on the mesh stream -- as a launch of their own or as extra workgroups of the spreading launch --
-    and the join by the scatter's per-replica done counters instead of a signal launch.  Every contribution is an integer atomic
+    and the join by the scatter's per-replica done counters instead of a signal launch; round 6: the listed terms one ATOM per thread
+    (the default; REMD_LISTED_ATOMS=0: one term per thread, 6 - 12 atomics each).  Every contribution is an integer atomic
     add into the same accumulators, so forces, positions and velocities are bit-identical under every combination, at the
     rebalanced Ewald split as well."""
     al = ts.AlanineDipeptideExplicit()
@@ -426,10 +427,13 @@ def test_stream_modes_of_a_force_evaluation_do_not_change_a_bit(hip_engine_facto
              dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_LISTED_RIDE='0'),
              dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_NB_FOLD='0'),
              dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_LISTED_MAIN='0'),
+             dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_LISTED_ATOMS='0'),
+             dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_LISTED_ATOMS='0', REMD_LISTED_RIDE='0'),
+             dict(REMD_NB_PRIO='0', REMD_NB_PERSIST_GRID='0', REMD_LISTED_ATOMS='0'),
              dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='640')]
     out = []
     for mode in modes:
-        for k in ('REMD_NB_PRIO', 'REMD_NB_PERSIST_GRID', 'REMD_LISTED_RIDE', 'REMD_NB_FOLD', 'REMD_LISTED_MAIN'):
+        for k in ('REMD_NB_PRIO', 'REMD_NB_PERSIST_GRID', 'REMD_LISTED_RIDE', 'REMD_NB_FOLD', 'REMD_LISTED_MAIN', 'REMD_LISTED_ATOMS'):
             monkeypatch.delenv(k, raising=False)
         for k, v in mode.items():
             monkeypatch.setenv(k, v)

@@ -27,7 +27,7 @@ cuts = np.linspace(0, R, G + 1).round().astype(int)
 engs = []
 for g in range(G):
     a, b = cuts[g], cuts[g + 1]
-    e = HipEngine(ewald_split="auto")
+    e = HipEngine(ewald_split="auto", lib_path=os.environ.get("AB_LIB") or None)
     e.set_system(d); e.set_states(beta)
     e.set_integrator('V R R O R R V', 0.002, 1.0, n_steps, True, 1e-8)
     e.seed(11)
