@@ -56,6 +56,9 @@ struct pme_state {
     // bins filled by the integrator chain's epilogue (no binning launch on the critical path): count[2][R][nx] double buffered by
     // evaluation parity (the spreading pass zeroes the other one), atoms[R][nx][cbin_cap]; cbin_use: this evaluation reads them
     float* d_cbin_q = nullptr;
+    // mesh forces by position in the bins (round 6): the gather's atomics of neighbouring lanes fall on neighbouring addresses, and
+    // pme_unbin_forces_kernel hands every atom its total with ONE scattered triple (the gather used to issue five per atom)
+    unsigned long long* d_fbin = nullptr; size_t fbin_P = 0;
     int* d_cbin_count = nullptr; float4* d_cbin_atoms = nullptr; int cbin_cap = 0, cbin_parity = 0; bool cbin_use = false;
 };
 
@@ -305,11 +308,12 @@ __device__ __forceinline__ pme_cand pme_candidates(const int* __restrict__ cs, i
 // loads independent), compact ones indices into pos[] / param[]
 __device__ __forceinline__ int pme_cand_atom(const pme_cand& c, const int* __restrict__ ca, int t, bool capped,
                                              const float4* __restrict__ P, float4& xi, const float* __restrict__ cq,
-                                             const float4* __restrict__ param, const float* __restrict__ rep_lam, int r, float& q)
+                                             const float4* __restrict__ param, const float* __restrict__ rep_lam, int r, float& q, int* flat = nullptr)
 {
     int base = c.base[0];
 #pragma unroll
     for (int b = 0; b < 4; ++b) if (t >= c.n[b]) { t -= c.n[b]; base = c.base[b + 1]; } else break;
+    if (flat) *flat = base + t;              // position in the bins' storage: consecutive candidates of a bin, consecutive positions
     int i;
     if (capped) {
         xi = reinterpret_cast<const float4*>(ca)[base + t];
@@ -495,7 +499,7 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
                             const float2* tw, const float2* tw_half, int Npad, const float4* __restrict__ pos,
                             const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                             const int* __restrict__ col_start, const int* __restrict__ col_atoms, long long* __restrict__ force,
-                            int bin_cap, const float* __restrict__ bin_q)
+                            int bin_cap, const float* __restrict__ bin_q, unsigned long long* __restrict__ fbin, size_t fbin_P)
 {
     if (pl.prio) __builtin_amdgcn_s_setprio(PME_PRIO);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -546,9 +550,10 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
     unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
     const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
     const int ntot = cnd.ntot;
+    unsigned long long* FB = fbin ? fbin + (size_t)r * 3 * fbin_P : (unsigned long long*)nullptr;
     for (int t = tid; t < ntot; t += Z_THREADS) {
-        float4 xi; float q;
-        const int i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi, bin_q ? bin_q + (size_t)r * nx * bin_cap : (const float*)nullptr, param, rep_lam, r, q);
+        float4 xi; float q; int flat;
+        const int i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi, bin_q ? bin_q + (size_t)r * nx * bin_cap : (const float*)nullptr, param, rep_lam, r, q, &flat);
         if (q == 0.f) continue;
         float ux, uy, uz; int kx, ky, kz;
         pme_scaled(xi, box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
@@ -579,6 +584,12 @@ void pme_zinv_gather_kernel(fft_plan pl, fft_sched sc, int nl, int nx, int ny, c
         if (!any) continue;
         // dE/dx = q * dtheta/du * du/dx, du/dx = n / L
         const float Fx = -q * dxa * gx * nx / Lx, Fy = -q * wxa * gy * ny / Ly, Fz = -q * wxa * gz * nz / Lz;
+        if (FB) {          // by position in the bins: neighbouring lanes, neighbouring addresses (pme_unbin_forces_kernel takes them to the atoms)
+            atomicAdd(&FB[flat], remd_f2fix(Fx));
+            atomicAdd(&FB[fbin_P + flat], remd_f2fix(Fy));
+            atomicAdd(&FB[2 * fbin_P + flat], remd_f2fix(Fz));
+            continue;
+        }
         atomicAdd(&F[i], remd_f2fix(Fx));
         atomicAdd(&F[Npad + i], remd_f2fix(Fy));
         atomicAdd(&F[2 * Npad + i], remd_f2fix(Fz));
@@ -706,7 +717,7 @@ void pme_zinv_gather_pow2_kernel(int nx, int ny, const float2* __restrict__ spec
                                  const float2* __restrict__ tw_half, int Npad, const float4* __restrict__ pos,
                                  const float4* __restrict__ param, const float* __restrict__ box, const float* __restrict__ rep_lam,
                                  const int* __restrict__ col_start, const int* __restrict__ col_atoms, long long* __restrict__ force,
-                                 int bin_cap, const float* __restrict__ bin_q, int prio)
+                                 int bin_cap, const float* __restrict__ bin_q, int prio, unsigned long long* __restrict__ fbin, size_t fbin_P)
 {
     constexpr int R1 = 8, NL = 64, ZT = NL * R2, MM = R1 / R2, nz = 2 * M;
     if (prio) __builtin_amdgcn_s_setprio(PME_PRIO);
@@ -732,8 +743,8 @@ void pme_zinv_gather_pow2_kernel(int nx, int ny, const float2* __restrict__ spec
     const float* bq = bin_q ? bin_q + (size_t)r * nx * bin_cap : (const float*)nullptr;
     const pme_cand cnd = pme_candidates(cs, x, nx, bin_cap);
     const int ntot = cnd.ntot;
-    float4 xi0 = make_float4(0.f, 0.f, 0.f, 0.f); float q0 = 0.f; int i0 = 0;
-    if (tid < ntot) i0 = pme_cand_atom(cnd, ca, tid, bin_cap > 0, P, xi0, bq, param, rep_lam, r, q0);
+    float4 xi0 = make_float4(0.f, 0.f, 0.f, 0.f); float q0 = 0.f; int i0 = 0, flat0 = 0;
+    if (tid < ntot) i0 = pme_cand_atom(cnd, ca, tid, bin_cap > 0, P, xi0, bq, param, rep_lam, r, q0, &flat0);
 #pragma unroll
     for (int q = 0; q < R1; ++q) B[(j + R2 * q) * NL + l] = w[q];
     if (j == 0) B[M * NL + l] = XM;
@@ -780,9 +791,10 @@ void pme_zinv_gather_pow2_kernel(int nx, int ny, const float2* __restrict__ spec
 #endif
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
+    unsigned long long* FB = fbin ? fbin + (size_t)r * 3 * fbin_P : (unsigned long long*)nullptr;
     for (int t = tid; t < ntot; t += ZT) {
-        float4 xi = xi0; float q = q0; int i = i0;
-        if (t != tid) i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi, bq, param, rep_lam, r, q);
+        float4 xi = xi0; float q = q0; int i = i0, flat = flat0;
+        if (t != tid) i = pme_cand_atom(cnd, ca, t, bin_cap > 0, P, xi, bq, param, rep_lam, r, q, &flat);
         if (q == 0.f) continue;
         float ux, uy, uz; int kx, ky, kz;
         pme_scaled(xi, box + 4 * r, nx, ny, nz, ux, uy, uz, kx, ky, kz);
@@ -815,10 +827,41 @@ void pme_zinv_gather_pow2_kernel(int nx, int ny, const float2* __restrict__ spec
 #ifdef EXP_ZI_NOATOM      // knock-out probe: the gather without its atomics (results wrong on purpose)
         if (Fx != 1.2345e33f) continue;
 #endif
+        if (FB) {
+            atomicAdd(&FB[flat], remd_f2fix(Fx));
+            atomicAdd(&FB[fbin_P + flat], remd_f2fix(Fy));
+            atomicAdd(&FB[2 * fbin_P + flat], remd_f2fix(Fz));
+            continue;
+        }
         atomicAdd(&F[i], remd_f2fix(Fx));
         atomicAdd(&F[Npad + i], remd_f2fix(Fy));
         atomicAdd(&F[2 * Npad + i], remd_f2fix(Fz));
     }
+}
+
+// The mesh forces from their positions in the bins to the atoms: one thread per position reads (and zeroes, for the next
+// evaluation) the three sums the gather left there and adds them to the atom's accumulators -- the one scattered atomic triple
+// an atom gets from the mesh.  cap > 0: capped bins (count[nx], float4 entries with the atom index in .w); else the compact
+// array of pme_bin_kernel.  Integer sums: the totals are the ones five scattered triples per atom used to give.
+__global__ __launch_bounds__(256)
+void pme_unbin_forces_kernel(int nx, int cap, int N, int Npad, size_t P, const int* __restrict__ count, const int* __restrict__ atoms,
+                             unsigned long long* __restrict__ fbin, long long* __restrict__ force)
+{
+    const int r = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    int i = -1;
+    if (cap > 0) {
+        if (p < nx * cap) {
+            const int kx = p / cap, sl = p - kx * cap;
+            if (sl < min(count[(size_t)r * nx + kx], cap)) i = __float_as_int(reinterpret_cast<const float4*>(atoms)[(size_t)r * nx * cap + p].w);
+        }
+    } else if (p < N) i = atoms[(size_t)r * Npad + p];
+    if (i < 0) return;
+    unsigned long long* FB = fbin + (size_t)r * 3 * P;
+    const unsigned long long vx = FB[p], vy = FB[P + p], vz = FB[2 * P + p];
+    if ((vx | vy | vz) == 0ull) return;
+    FB[p] = 0ull; FB[P + p] = 0ull; FB[2 * P + p] = 0ull;
+    unsigned long long* F = reinterpret_cast<unsigned long long*>(force + (size_t)r * 3 * Npad);
+    atomicAdd(&F[i], vx); atomicAdd(&F[Npad + i], vy); atomicAdd(&F[2 * Npad + i], vz);
 }
 
 // Influence function G(kx, ky, kz) = exp(-pi^2 m^2 / alpha^2) / (pi V m^2 |b_x b_y b_z|^2) of every replica's box, laid out
@@ -1112,6 +1155,7 @@ int remd_pme_destroy(remd_ctx* h)
     for (int k = 0; k < 3; ++k) if (s->d_bmod[k]) hipFree(s->d_bmod[k]);
     if (s->d_energy) hipFree(s->d_energy);
     if (s->d_infl) hipFree(s->d_infl);
+    if (s->d_fbin) hipFree(s->d_fbin);
     if (s->d_cbin_count) hipFree(s->d_cbin_count); if (s->d_cbin_atoms) hipFree(s->d_cbin_atoms); if (s->d_cbin_q) hipFree(s->d_cbin_q);
     for (int k = 0; k < 3; ++k) if (s->d_sched[k]) hipFree(s->d_sched[k]);
     delete s;
@@ -1461,17 +1505,30 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 0, ny, s->nzc * ny, ny, (size_t)nx * ny, 0);
             launch_pass<+1>(h, s, s->d_grid, s->nspec, 1, 1, s->nzc * nx, s->nzc * nx, 0, 1);
         }
+        // mesh forces by bin position + one hand-over to the atoms (REMD_PME_FBIN=0: five scattered atomic triples per atom)
+        const bool fbin_env = !(getenv("REMD_PME_FBIN") && atoi(getenv("REMD_PME_FBIN")) == 0);
+        if (fbin_env && !s->d_fbin) {
+            s->fbin_P = std::max((size_t)nx * (size_t)std::max(s->cbin_cap, 0), (size_t)h->Npad);
+            REMD_CHECK(h, hipMalloc(&s->d_fbin, sizeof(unsigned long long) * 3 * s->fbin_P * s->R));
+            REMD_CHECK(h, hipMemsetAsync(s->d_fbin, 0, sizeof(unsigned long long) * 3 * s->fbin_P * s->R, st));
+        }
+        unsigned long long* fbin = fbin_env ? s->d_fbin : (unsigned long long*)nullptr;
         {
         remd_prof_scope pzg(h, "pme_zinv_gather", st);
         if (zp2) {
 #define LAUNCH_ZI2(MMM, RR) hipLaunchKernelGGL((pme_zinv_gather_pow2_kernel<MMM, RR>), zgrid, dim3(64 * RR), zlds2, st, nx, ny, s->d_grid, s->d_tw[2], s->d_tw[3], \
                        h->Npad, h->d_pos, param, h->d_box, rep_lam, bin_cs, bin_ca, h->d_force, bin_cap, \
-                       (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr, s->prio_hi ? 1 : 0)
+                       (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr, s->prio_hi ? 1 : 0, fbin, s->fbin_P)
             if (zp2 == 64) LAUNCH_ZI2(32, 4); else LAUNCH_ZI2(64, 8);
 #undef LAUNCH_ZI2
         } else
         DISPATCH_Z(pme_zinv_gather_kernel, s->d_grid, s->d_tw[2], s->d_tw[3], h->Npad, h->d_pos, param, h->d_box, rep_lam,
-                   bin_cs, bin_ca, h->d_force, bin_cap, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr);
+                   bin_cs, bin_ca, h->d_force, bin_cap, (s->cbin_use && !rep_lam) ? s->d_cbin_q : (const float*)nullptr, fbin, s->fbin_P);
+        if (fbin) {
+            const int npos = bin_cap > 0 ? nx * bin_cap : h->N;
+            hipLaunchKernelGGL(pme_unbin_forces_kernel, dim3((npos + 255) / 256, s->R), dim3(256), 0, st, nx, bin_cap, h->N, h->Npad, s->fbin_P,
+                               bin_cs, bin_ca, fbin, h->d_force);
+        }
         if (s->cbin_use) s->cbin_parity ^= 1;          // the next chain fills the buffer this evaluation has just zeroed
         }
 #undef DISPATCH_Z

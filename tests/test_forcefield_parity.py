@@ -417,7 +417,8 @@ def test_stream_modes_of_a_force_evaluation_do_not_change_a_bit(hip_engine_facto
     """Round 4: which stream is treated as the critical one is a run-time choice (tuner candidate '0p'): the pair kernel at raised
     wave priority, the listed terms on the mesh stream -- as a launch of their own or as extra workgroups of the spreading launch --
     and the join by the scatter's per-replica done counters instead of a signal launch; round 6: the listed terms one ATOM per thread
-    (the default; REMD_LISTED_ATOMS=0: one term per thread, 6 - 12 atomics each).  Every contribution is an integer atomic
+    (the default; REMD_LISTED_ATOMS=0: one term per thread, 6 - 12 atomics each), and the mesh forces summed by position in the bins
+    and handed to the atoms once (REMD_PME_FBIN=0: five scattered triples per atom).  Every contribution is an integer atomic
     add into the same accumulators, so forces, positions and velocities are bit-identical under every combination, at the
     rebalanced Ewald split as well."""
     al = ts.AlanineDipeptideExplicit()
@@ -430,10 +431,12 @@ def test_stream_modes_of_a_force_evaluation_do_not_change_a_bit(hip_engine_facto
              dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_LISTED_ATOMS='0'),
              dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_LISTED_ATOMS='0', REMD_LISTED_RIDE='0'),
              dict(REMD_NB_PRIO='0', REMD_NB_PERSIST_GRID='0', REMD_LISTED_ATOMS='0'),
+             dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='0', REMD_PME_FBIN='0'),
+             dict(REMD_NB_PRIO='0', REMD_NB_PERSIST_GRID='0', REMD_PME_FBIN='0', REMD_LISTED_ATOMS='0'),
              dict(REMD_NB_PRIO='1', REMD_NB_PERSIST_GRID='640')]
     out = []
     for mode in modes:
-        for k in ('REMD_NB_PRIO', 'REMD_NB_PERSIST_GRID', 'REMD_LISTED_RIDE', 'REMD_NB_FOLD', 'REMD_LISTED_MAIN', 'REMD_LISTED_ATOMS'):
+        for k in ('REMD_NB_PRIO', 'REMD_NB_PERSIST_GRID', 'REMD_LISTED_RIDE', 'REMD_NB_FOLD', 'REMD_LISTED_MAIN', 'REMD_LISTED_ATOMS', 'REMD_PME_FBIN'):
             monkeypatch.delenv(k, raising=False)
         for k, v in mode.items():
             monkeypatch.setenv(k, v)
