@@ -412,12 +412,14 @@ def main():
             nbytes = 2.0 * 8.0 * (nz // 2 + 1) * nx * ny * n_local / float(engine.phases_active() if hasattr(engine, 'phases_active') else 1)
             avg_ms = ms_xy / n_xy
             achieved = nbytes / (avg_ms * 1e-3) / 1e9
-            roof_xy = dict(kernel='pme_xy_fused_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                           frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic_bytes('pme_xy_fused_kernel'), launches=n_xy,
+            xy_name = 'pme_xy_pow2_kernel' if (nx == ny and nx in (64, 128) and os.environ.get('REMD_PME_POW2', '3') not in ('0', '2')) else 'pme_xy_fused_kernel'
+            roof_xy = dict(kernel=xy_name, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                           frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic_bytes(xy_name), launches=n_xy,
                            avg_launch_ms=avg_ms, total_ms=ms_xy,
-                           note='forward y, forward x, influence function, inverse x, inverse y on an LDS-resident plane: one read + '
-                                'one write of the half spectrum; in practice VALU/LDS-issue bound (mixed-radix butterflies), and it '
-                                'shares the chip with the pair kernel on the other stream')
+                           note='forward x, forward y, influence function, inverse y, inverse x on an LDS-resident plane: one read + '
+                                'one write of the half spectrum (round 6: radix-8 x 8 butterflies in registers on 64 x 64 planes, '
+                                'pme_pow2.h; other sizes: scheduled mixed-radix stages); it shares the chip with the pair kernel on '
+                                'the other stream')
         # the integrator chain against its own roof (fused bound 64 B/atom: read x, v, f, 1/m, write x, v)
         # (timed in one extra, untimed iteration: events around the chain launches sit on the critical path of a step and
         # would slow the timed region by ~6 %)

@@ -1434,7 +1434,7 @@ int remd_pme_forces(remd_ctx* h, bool with_energy, hipStream_t st, int part)
         const int n_mesh_blocks = (int)zgrid.x;
         const int n_listed_blocks = h->mesh_listed_total > 0 ? (h->mesh_listed_total + ZT - 1) / ZT : 0;
         // power-of-two z: 64 lines per workgroup on the register transforms (REMD_PME_POW2=0: the scheduled passes)
-        static const bool pow2_env = !(getenv("REMD_PME_POW2") && !(atoi(getenv("REMD_PME_POW2")) & 2));      // bit 1: the z passes
+        const bool pow2_env = !(getenv("REMD_PME_POW2") && !(atoi(getenv("REMD_PME_POW2")) & 2));      // bit 1: the z passes
         const int zp2 = (pow2_env && half && (nz == 64 || nz == 128) && ny % 64 == 0 && nl == 64 && ZT == 64 * (nz / 16)) ? nz : 0;
         const size_t zlds2 = sizeof(float2) * (size_t)(nz / 2 + 1) * 64;
         if (zp2) {

@@ -272,6 +272,28 @@ def test_pme_mesh_sizes_through_the_force_path(hip_engine_factory, grid):
     assert np.sqrt(((f[0] - f_ref) ** 2).sum(axis=1).mean()) < 0.5
 
 
+@pytest.mark.parametrize('system_cls', [ts.AlanineDipeptideExplicit, ts.DHFRExplicit])
+def test_register_transforms_of_power_of_two_meshes_agree_with_the_scheduled_passes(hip_engine_factory, monkeypatch, system_cls):
+    """Round 6: 64^3 (alanine dipeptide, rebalanced split) and 128^3 (DHFR) meshes run their plane pass and their z passes on
+    butterflies held in registers (pme_pow2.h, REMD_PME_POW2 bits 0 / 1); the scheduled mixed-radix passes (REMD_PME_POW2=0)
+    are another factorisation of the same transforms: energies agree to 1e-7 relative, forces to 2e-4 of the largest force
+    component (fp32 round-off of a different summation order), each combination of the two bits."""
+    tsys = system_cls()
+    desc = system_to_desc(tsys.system, ewald_split='auto')
+    assert tuple(desc['pme_grid']) in ((64, 64, 64), (128, 128, 128))
+    out = {}
+    for mode in ('0', '1', '2', '3'):
+        monkeypatch.setenv('REMD_PME_POW2', mode)
+        eng = hip_engine_factory()
+        _engine_for(eng, tsys.system, tsys.positions, R=1, jitter=0.0, splitting='V R O R V', dt=0.001, n_steps=1, desc=desc)
+        out[mode] = (eng.compute_energies(want_potential=True)[1][0], eng.get_forces()[0])
+    U0, f0 = out['0']
+    for mode in ('1', '2', '3'):
+        U, f = out[mode]
+        assert abs(U - U0) < 1e-7 * abs(U0), (mode, U, U0)
+        assert np.abs(f - f0).max() < 2e-4 * np.abs(f0).max(), (mode, np.abs(f - f0).max())
+
+
 @pytest.mark.parametrize('system_cls,R', [(ts.HostGuestExplicit, 2), (ts.DHFRExplicit, 1)])
 def test_large_systems_energy_forces_and_propagation(hip_engine_factory, system_cls, R):
     """BASELINE config 4 / 5 systems (CB7:B2 host-guest, 4491 atoms, 96^3 mesh; DHFR, 23558 atoms, 144^3 mesh):

@@ -17,12 +17,14 @@ ALGO = {
     'integrate_chain_kernel': (64.0 * N * R, 'fused V/R/O bound: read x, v, f, 1/m; write x, v = 64 B/atom'),
     'pme_spread_zfwd': (16.0 * N * R + 8.0 * HALF, 'read x, q per atom; write the half spectrum (8 B/point)'),
     'pme_xy_fused_kernel': (16.0 * HALF + 4.0 * HALF, 'read + write the half spectrum, read the influence table'),
+    'pme_xy_pow2_kernel': (16.0 * HALF + 4.0 * HALF, 'read + write the half spectrum, read the influence table (register transforms, pme_pow2.h)'),
+    'pme_unbin_forces_kernel': (2 * 24.0 * N * R + 24.0 * N * R, 'read + zero the sums by bin position, add 24 B/atom into the per-atom accumulator'),
     'pme_zinv': (8.0 * HALF + 40.0 * N * R, 'read the half spectrum; x, q in, 24 B/atom of force atomics out (the potential mesh stays in LDS)'),
     'pme_gather_kernel': (4.0 * REAL + 40.0 * N * R, 'read the potential mesh once; x, q in, 24 B/atom of force atomics out'),
     'nonbonded_sci2_kernel': (28.0 * N * R, 'x, q, sigma, eps in; f out = 28 B/atom (the kernel is FP32-VALU bound, 10 kflop/atom)'),
     'scatter_sorted_forces_kernel': (2 * 24.0 * NPAD * R, 'read the sorted accumulator, add into the per-atom accumulator'),
     'gather_positions2_kernel': (2 * 16.0 * NPAD * R + 16.0 * NPAD * R, 'x in, sorted x out (+ cluster boxes)'),
-    'listed_forces_kernel': (0.0, 'latency bound (~2300 terms per replica)'),
+    'listed_forces_kernel': (0.0, 'latency bound (~5000 (term, atom) entries per replica)'),
     'build_sci_list2_kernel': (0.0, 'latency bound'),
     'pme_bin_kernel': (16.0 * N * R + 4.0 * N * R, 'x in, bin lists out'),
 }
