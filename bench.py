@@ -63,7 +63,11 @@ def pmc_traffic_bytes(kernel):
         with open(path) as fh:
             table = json.load(fh)
         # one force evaluation launches the Coulomb and the LJ sub-system instantiation (force-only, non-alchemical)
-        hits = [v for k, v in table.items() if kernel in k and ('<' not in k or ', false, false' in k)]
+        # (force-only, non-alchemical instantiations: the pair kernel's '<3, 0, false, false, ...>', the plane pass's '<64, 8, false>')
+        cand = {k: v for k, v in table.items() if kernel in k}
+        hits = [v for k, v in cand.items() if '<' not in k or ', false, false' in k]
+        if not hits:
+            hits = [v for k, v in cand.items() if k.rstrip().endswith(', false>')]
         if hits:
             return sum(float(v['hbm_mb_corrected']) for v in hits) * 1.0e6
     except Exception:

@@ -44,8 +44,14 @@ def main():
         if not key or calls < 100:
             continue
         algo, why = ALGO[key[0]]
-        pm = [v for k, v in traffic.items() if key[0] in k]
-        pmc_mb = pm[0]['hbm_mb_corrected'] if pm else float('nan')
+        # (several instantiations of a kernel share a name stem -- the energy pass's runs 4 times, the force-only one thousands:
+        # the row belongs to the instantiation this line of the statistics names, i.e. the longest common prefix)
+        def lcp(a, b):
+            n = 0
+            while n < min(len(a), len(b)) and a[n] == b[n]: n += 1
+            return n
+        pm = sorted([(lcp(k.replace('void ', ''), c[0].replace('void ', '')), v) for k, v in traffic.items() if key[0] in k], key=lambda e: e[0])
+        pmc_mb = pm[-1][1]['hbm_mb_corrected'] if pm else float('nan')
         rows.append((name[:46], calls, avg_us, algo / 1e6, pmc_mb, algo / (avg_us * 1e-6) / 1e9, pmc_mb * 1e6 / (avg_us * 1e-6) / 1e9, why))
     print('| kernel | launches | avg us | algorithmic MB / launch | PMC HBM-side MB / launch | algorithmic GB/s | frac of 8 TB/s' +
           (' | frac of measured STREAM (%.0f GB/s)' % stream if stream else '') + ' | PMC GB/s | algorithmic bytes counted |')
