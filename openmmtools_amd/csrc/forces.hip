@@ -101,7 +101,8 @@ struct nb_tables {
     int nb_prio = 0;                      // current choice: 1 = the pair kernel runs at raised wave priority and the mesh kernels do not
     std::vector<tune_seg> tune_segs; int tune_state = 0 /* 0 measuring, 1 awaiting resolve, 2 done */, tune_left = 0, tune_next = 0;
     int nb_grid = 0;                      // current choice (workgroups; 0 = one per item)
-    float sort_cell = 0.45f;              // Morton cell edge (nm) of the molecule sort
+    float sort_cell = 0.45f;              // Morton cell edge (nm) of the molecule sort (sort_hbits = 0)
+    int sort_hbits = 0;                   // > 0: 2^sort_hbits cells per box edge along the Hilbert curve (round 6, the default)
     // Ewald direct-space force table of the force-only pair kernels (coulomb_table.h); REMD_NB_TABLE=0: Abramowitz & Stegun erfc
     float4* d_ctab = nullptr; bool use_table = false;
     unsigned int* d_pair_done = nullptr; unsigned int pair_done_target = 0;      // remd_fold_args: the scatter launch's done counter
@@ -292,7 +293,35 @@ __device__ __forceinline__ unsigned morton3(unsigned x, unsigned y, unsigned z)
     return m;
 }
 
-// one workgroup per replica: rank the groups by (Morton cell of the group's first atom, group index), then
+// index of cell (x, y, z) of a 2^bits cube along the 3-D Hilbert curve (Skilling's transpose algorithm): consecutive indices are
+// face neighbours, so the molecules of a run of the order -- the 8-atom clusters and 64-atom tiles of the pair kernel -- fill
+// compact blobs.  The Z-order curve used until round 6 jumps at every power-of-two boundary: on the headline system its clusters
+// give 27 970 cluster-pair steps per replica where the Hilbert order on 16^3 cells gives 23 389 (tools/models/cluster_order_model.py).
+__device__ __forceinline__ unsigned hilbert3(unsigned x, unsigned y, unsigned z, int bits)
+{
+    unsigned X[3] = { x, y, z };
+    const unsigned M = 1u << (bits - 1);
+    for (unsigned Q = M; Q > 1u; Q >>= 1) {
+        const unsigned P = Q - 1u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned t = 0u;
+    for (unsigned Q = M; Q > 1u; Q >>= 1) if (X[2] & Q) t ^= Q - 1u;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    unsigned k = 0u;
+    for (int b = bits - 1; b >= 0; --b) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) k = (k << 1) | ((X[i] >> b) & 1u);
+    }
+    return k;
+}
+
+// one workgroup per replica: rank the groups by (curve index of the cell of the group's first atom, group index), then
 // lay their atoms out contiguously.  Keys are unique, so the order is deterministic.  The work arrays (key, first atom / size /
 // offset by rank: 16 - 20 bytes per group) live in LDS up to 8191 groups (sort_groups_kernel) and in a global scratch buffer
 // beyond (sort_groups_large_kernel, 64-bit keys; round 4: systems of more than 8191 molecules used to leave the cluster-pair
@@ -302,18 +331,20 @@ template <typename KEY>
 __device__ __forceinline__
 void sort_groups_body(int G, int N, int Npad, const int* __restrict__ grp_first, const int* __restrict__ grp_size,
                       const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order,
-                      KEY* key, int* r_first, int* r_size, int* r_off, int* s_part)
+                      KEY* key, int* r_first, int* r_size, int* r_off, int* s_part, int hbits)
 {
     const int r = blockIdx.x, tid = threadIdx.x;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
-    const int ncx = max(1, min(63, (int)(Lx / cell))), ncy = max(1, min(63, (int)(Ly / cell))), ncz = max(1, min(63, (int)(Lz / cell)));
+    // hbits > 0: 2^hbits cells per edge, ordered along the Hilbert curve; 0: cells of edge `cell` along the Z-order curve (until round 6)
+    const int ncx = hbits > 0 ? (1 << hbits) : max(1, min(63, (int)(Lx / cell))), ncy = hbits > 0 ? (1 << hbits) : max(1, min(63, (int)(Ly / cell))),
+              ncz = hbits > 0 ? (1 << hbits) : max(1, min(63, (int)(Lz / cell)));
     constexpr int GBITS = sizeof(KEY) == 8 ? 32 : 13;
     for (int g = tid; g < G; g += 1024) {
         const float4 x = pos[(size_t)r * Npad + grp_first[g]];
         float fx = x.x / Lx, fy = x.y / Ly, fz = x.z / Lz;
         fx -= floorf(fx); fy -= floorf(fy); fz -= floorf(fz);
         const unsigned cx = min(ncx - 1, (int)(fx * ncx)), cy = min(ncy - 1, (int)(fy * ncy)), cz = min(ncz - 1, (int)(fz * ncz));
-        key[g] = ((KEY)morton3(cx, cy, cz) << GBITS) | (KEY)(unsigned)g;
+        key[g] = ((KEY)(hbits > 0 ? hilbert3(cx, cy, cz, hbits) : morton3(cx, cy, cz)) << GBITS) | (KEY)(unsigned)g;
     }
     __syncthreads();
     for (int g = tid; g < G; g += 1024) {
@@ -349,26 +380,26 @@ void sort_groups_body(int G, int N, int Npad, const int* __restrict__ grp_first,
 
 __global__ __launch_bounds__(1024)
 void sort_groups_kernel(int G, int N, int Npad, const int* __restrict__ grp_first, const int* __restrict__ grp_size,
-                        const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order)
+                        const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order, int hbits)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* key = reinterpret_cast<unsigned*>(smem);       // [G]
     int* r_first = reinterpret_cast<int*>(key + G);          // [G] by rank
     __shared__ int s_part[1024];
-    sort_groups_body<unsigned>(G, N, Npad, grp_first, grp_size, pos, box, cell, order, key, r_first, r_first + G, r_first + 2 * G, s_part);
+    sort_groups_body<unsigned>(G, N, Npad, grp_first, grp_size, pos, box, cell, order, key, r_first, r_first + G, r_first + 2 * G, s_part, hbits);
 }
 
 // scratch: [R][5 G] ints (the 64-bit keys first)
 __global__ __launch_bounds__(1024)
 void sort_groups_large_kernel(int G, int N, int Npad, const int* __restrict__ grp_first, const int* __restrict__ grp_size,
                               const float4* __restrict__ pos, const float* __restrict__ box, float cell, int* __restrict__ order,
-                              int* __restrict__ scratch)
+                              int* __restrict__ scratch, int hbits)
 {
     __shared__ int s_part[1024];
     int* base = scratch + (size_t)blockIdx.x * 5 * G;
     unsigned long long* key = reinterpret_cast<unsigned long long*>(base);
     int* r_first = base + 2 * G;
-    sort_groups_body<unsigned long long>(G, N, Npad, grp_first, grp_size, pos, box, cell, order, key, r_first, r_first + G, r_first + 2 * G, s_part);
+    sort_groups_body<unsigned long long>(G, N, Npad, grp_first, grp_size, pos, box, cell, order, key, r_first, r_first + G, r_first + 2 * G, s_part, hbits);
 }
 
 __global__ __launch_bounds__(256)
@@ -1797,10 +1828,18 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
     const bool split = cl && t.lj_split;
     if (t.evals_since_sort >= t.resort_interval) {
         remd_prof_scope ps(h, "nb_sort");
+        // cells of the molecule order: 2^b per box edge with an edge of ~0.22 nm (b from the longest edge of the first replica's box, as
+        // the host mirrors it; 16 per edge on the headline system, 32 on DHFR), along the Hilbert curve.  REMD_NB_CURVE=morton: the
+        // Z-order curve on cells of 0.45 nm, as until round 6.  A property of the handle: fixed at the first sort.
+        if (t.sort_hbits == 0 && !(getenv("REMD_NB_CURVE") && getenv("REMD_NB_CURVE")[0] == 'm')) {
+            double lmax = 0.0;
+            for (int k = 0; k < 3 && (size_t)k < h->box_host.size(); ++k) lmax = std::max(lmax, h->box_host[k]);
+            t.sort_hbits = lmax > 0.0 ? std::max(1, std::min(6, (int)lround(log2(lmax / 0.22)))) : 4;
+        }
         if (t.n_groups < 8192) {
             const size_t lds = sizeof(int) * 4 * (size_t)t.n_groups;
             hipLaunchKernelGGL(sort_groups_kernel, dim3(h->R), dim3(1024), lds, h->stream, t.n_groups, h->N, h->Npad, t.d_grp_first,
-                               t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order);
+                               t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order, t.sort_hbits);
         } else {
             const size_t need = (size_t)h->R * 5 * t.n_groups;
             if (t.sort_scratch_n < need) {
@@ -1809,7 +1848,7 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
                 t.sort_scratch_n = need;
             }
             hipLaunchKernelGGL(sort_groups_large_kernel, dim3(h->R), dim3(1024), 0, h->stream, t.n_groups, h->N, h->Npad, t.d_grp_first,
-                               t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order, t.d_sort_scratch);
+                               t.d_grp_size, h->d_pos, h->d_box, t.sort_cell, t.d_order, t.d_sort_scratch, t.sort_hbits);
         }
         hipLaunchKernelGGL(gather_params_kernel, dim3((h->Npad + 255) / 256, h->R), dim3(256), 0, h->stream, h->Npad, t.p.excl_words,
                            t.d_order, t.d_param, t.d_mask, t.d_sparam, t.d_smask);
