@@ -115,8 +115,14 @@ __device__ __forceinline__ void p2_line_fft(float2* v, float2* out, float2* line
 // apart (2 PS mod 64 = 16: four consecutive lines of a 32-lane group sit on four disjoint quarters of the banks).
 // infl_perm: the influence function in the order the threads hold the spectrum -- [plane][i * T + tid] for register i
 // (pme_influence_table_kernel with perm_r1 = R1).
+// 128 x 128 planes: 1024 threads = 4 wavefronts per SIMD; compiled for FIVE (<= 96 registers) so that a plane workgroup's 384 registers
+// per SIMD lane and 140 KB of LDS fit beside two resident workgroups of the pair kernel (2 x 64 registers, 2 x 10 KB) -- DHFR's
+// plane pass otherwise enters a CU only when the pair kernel's workgroups have left it (A/B: tools/build_variant.sh -DP2_XY128_WPE=4)
+#ifndef P2_XY128_WPE
+#define P2_XY128_WPE 5
+#endif
 template <int N, int R1, bool with_energy>
-__global__ __launch_bounds__(N * N / R1) __attribute__((amdgpu_waves_per_eu(N == 64 ? 8 : 4, N == 64 ? 8 : 4)))
+__global__ __launch_bounds__(N * N / R1) __attribute__((amdgpu_waves_per_eu(N == 64 ? 8 : P2_XY128_WPE, N == 64 ? 8 : P2_XY128_WPE)))
 void pme_xy_pow2_kernel(int nz, float2* __restrict__ spec, const float2* __restrict__ tw, double* __restrict__ energy,
                         int n_eblk, const float* __restrict__ infl_perm, int infl_rep, int prio)
 {
@@ -189,28 +195,35 @@ void pme_xy_pow2_kernel(int nz, float2* __restrict__ spec, const float2* __restr
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) v[m + MM * k2] = make_float2(w[m * R2 + k2].x * g[m * R2 + k2], w[m * R2 + k2].y * g[m * R2 + k2]);
     }
-    // ---- inverse y: w[m * R2 + k2] = value at y = j + R2 m + R1 k2
-    p2_line_fft<+1, R1, R2>(v, w, line, j, s_tw);
+    // ---- inverse y: w[m * R2 + k2] = value at y = j + R2 m + R1 k2   (ji: the lane's j laundered, see below)
+    int ji = j;
+    asm volatile("" : "+v"(ji));
+    p2_line_fft<+1, R1, R2>(v, w, line, ji, s_tw);
 #pragma unroll
     for (int m = 0; m < MM; ++m)
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) line[j + R2 * m + R1 * k2] = w[m * R2 + k2];
+        for (int k2 = 0; k2 < R2; ++k2) line[ji + R2 * m + R1 * k2] = w[m * R2 + k2];
     __syncthreads();
     if (with_energy && tid == 0) {
         double tot = 0.0;
         for (int q = 0; q < T / 64; ++q) tot += s_e[q];
         energy[(size_t)r * n_eblk + kz] = tot;
     }
+    // (the inverse half computes its LDS addresses afresh from laundered indices: the compiler would otherwise keep the forward half's
+    //  addresses beyond the 64 KB an LDS instruction's offset field reaches alive through the whole pass -- 30 spilled registers on
+    //  the 128 x 128 plane)
+    int x0i = x0, yi = y;
+    asm volatile("" : "+v"(x0i), "+v"(yi));
     // ---- transpose back: thread (y, x0) takes kx = x0 + R2 q
 #pragma unroll
-    for (int q = 0; q < R1; ++q) v[q] = L[(x0 + R2 * q) * PS + y];
+    for (int q = 0; q < R1; ++q) v[q] = L[(x0i + R2 * q) * PS + yi];
     __syncthreads();
     // ---- inverse x
     p2_dft<+1, R1>(v);
 #pragma unroll
     for (int k1 = 1; k1 < R1; ++k1) v[k1] = p2_twid<+1>(v[k1], twx[k1]);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; ++k1) L[(k1 * R2 + x0) * N + y] = v[k1];
+    for (int k1 = 0; k1 < R1; ++k1) L[(k1 * R2 + x0i) * N + yi] = v[k1];
     __syncthreads();
     // (the store addresses are recomputed behind an opaque move: the compiler would otherwise keep the eight 64-bit load
     //  addresses of the first lines alive through the whole pass and spill them)
@@ -219,10 +232,10 @@ void pme_xy_pow2_kernel(int nz, float2* __restrict__ spec, const float2* __restr
     off_out = (off_out / N) * N + (off_out & (N - 1));      // x0 * N + y
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
-        const int k1 = x0 + R2 * m;
+        const int k1 = x0i + R2 * m;
         float2 u[R2];
 #pragma unroll
-        for (int xp = 0; xp < R2; ++xp) u[xp] = L[(k1 * R2 + xp) * N + y];
+        for (int xp = 0; xp < R2; ++xp) u[xp] = L[(k1 * R2 + xp) * N + yi];
         p2_dft<+1, R2>(u);
 #pragma unroll
         for (int k2 = 0; k2 < R2; ++k2) (Po + (R2 * m + R1 * k2) * N)[off_out] = u[k2];
