@@ -1828,13 +1828,14 @@ static int ensure_sorted(remd_ctx* h, nb_tables& t)
     const bool split = cl && t.lj_split;
     if (t.evals_since_sort >= t.resort_interval) {
         remd_prof_scope ps(h, "nb_sort");
-        // cells of the molecule order: 2^b per box edge with an edge of ~0.22 nm (b from the longest edge of the first replica's box, as
-        // the host mirrors it; 16 per edge on the headline system, 32 on DHFR), along the Hilbert curve.  REMD_NB_CURVE=morton: the
+        // cells of the molecule order: 2^b per box edge with an edge of ~0.11 nm (b from the longest edge of the first replica's box, as
+        // the host mirrors it; 32 per edge on the headline system, 64 on DHFR: REMD_NB_HBITS scans, profiles/r06_35_hilbert_cells.txt), along the Hilbert curve.  REMD_NB_CURVE=morton: the
         // Z-order curve on cells of 0.45 nm, as until round 6.  A property of the handle: fixed at the first sort.
         if (t.sort_hbits == 0 && !(getenv("REMD_NB_CURVE") && getenv("REMD_NB_CURVE")[0] == 'm')) {
             double lmax = 0.0;
             for (int k = 0; k < 3 && (size_t)k < h->box_host.size(); ++k) lmax = std::max(lmax, h->box_host[k]);
-            t.sort_hbits = lmax > 0.0 ? std::max(1, std::min(6, (int)lround(log2(lmax / 0.22)))) : 4;
+            t.sort_hbits = lmax > 0.0 ? std::max(1, std::min(6, (int)lround(log2(lmax / 0.11)))) : 4;
+            if (getenv("REMD_NB_HBITS")) t.sort_hbits = std::max(1, std::min(6, atoi(getenv("REMD_NB_HBITS"))));      // experiment hook
         }
         if (t.n_groups < 8192) {
             const size_t lds = sizeof(int) * 4 * (size_t)t.n_groups;
