@@ -1671,6 +1671,10 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         // Fixed per system, never per launch mode: the slices' fp32 partial sums enter the forces bit-wise.
         t.sci_split = (t.method == NB_EWALD && h->overlap && h->stream2) ? 8 : 12;
         if (getenv("REMD_NB_SPLIT")) t.sci_split = std::max(4, atoi(getenv("REMD_NB_SPLIT")));      // experiment hook
+        // the ranking of the sort is G comparisons per molecule on ONE workgroup per replica (0.9 ms on DHFR's 7 k molecules): from 2048
+        // molecules on it runs every 160 evaluations instead of every 40 (the order decays slowly: 0.893 -> 0.868 ms per step on 16 x DHFR,
+        // flat between 80 and 320, profiles/r06_36_resort_interval.txt; the headline system does not notice either way)
+        if (t.n_groups >= 2048) t.resort_interval = 160;
         if (getenv("REMD_NB_RESORT")) t.resort_interval = std::max(1, atoi(getenv("REMD_NB_RESORT")));
     }
 
