@@ -224,6 +224,48 @@ int  remd_set_replica_ids(remd_handle h, const int64_t* global_replica_index /* 
    stay at full strength ("decoupling").                                                                                       */
 int  remd_set_alchemical_options(remd_handle h, int annihilate_sterics);
 
+/* General alchemical regions: what AbsoluteAlchemicalFactory._alchemically_modify_NonbondedForce (alchemy.py:1539-2038) builds when
+   the descriptor's one-region / exact-PME fast path (n_alch, softcore_*) does not cover the request -- several named regions with
+   their own lambda_sterics_<name> / lambda_electrostatics_<name> (alchemy.py:1360-1377, 1412-1421), pairs of regions that interact
+   through the PRODUCT of their lambdas (alchemical_regions_interactions, :1684-1690, 1766-1770), soft-core electrostatics of the
+   'direct-space' and 'coulomb' PME treatments and of the reaction-field treatments (:1392-1537: softcore_beta, d, e, f), any
+   softcore_a / b / c, annihilate_sterics / annihilate_electrostatics per region (:1771-1775, 1800-1803).
+   The force split is the reference's: the descriptor of remd_set_system then describes the NonbondedForce the factory leaves behind
+   (alchemical atoms with charge 0 and epsilon 0, exceptions that touch them zeroed but kept as exclusions: :1903-1911, 2001-2006;
+   n_alch = 0) and THIS call adds the custom forces, evaluated by one launch over the (alchemical atom, atom) pairs per force
+   evaluation (csrc/alch_regions.hip):
+     pairs inside the cutoff, not excluded, classes (environment, region y), (y, y) and (a, b) for interacting regions:
+       U_sterics        = l^a 4 eps x (x - 1),  x = (sigma / reff)^6,  reff = sigma (alpha (1 - l)^b + (r / sigma)^c)^(1/c)        :1383-1388
+       U_electrostatics = l^d k_e q1 q2 g(reff_e),  reff_e = sigma (beta (1 - l)^e + (r / sigma)^f)^(1/f)                        :1425-1430
+       g(x) = erfc(elec_alpha x) / x + elec_krf x^2 - elec_crf                                                               :1434, 1505-1507, 1534-1536
+       sterics switched as the NonbondedForce (desc->switch_distance), electrostatics from elec_switch_distance (< 0: not switched) :1780-1782, 1818-1824
+     l = the region's lambda for (environment, y); for (y, y) the region's lambda if it annihilates, else 1; the product for (a, b);
+     the soft-core constants of a class are those of region y (of b for an interacting pair, as the factory's loop leaves them, :2009-2017);
+     exceptions with an alchemical atom: the same sterics without cutoff or switch, electrostatics l^d k_e qq / reff_e            :1374-1380, 1434, 1456-1461
+   charge / sigma / epsilon and the exceptions passed here are the REFERENCE NonbondedForce's (sigma = 0 already replaced by
+   0.1 nm, :1638-1661).  electrostatics = 0: no electrostatic custom forces (alchemical atoms without charge).
+   Call AFTER remd_set_system (which forgets the regions) and follow remd_set_states by remd_set_region_lambdas.  n_regions = 0 or
+   desc = NULL: none.  A handle with regions runs one block of replicas (no phases) and needs a cutoff method.                   */
+typedef struct remd_alch_regions_desc {
+    int32_t n_atoms;                     /* the system's                                                     */
+    int32_t n_regions;
+    const int32_t* region_of_atom;       /* [n_atoms] 0 = environment, g = region g (1-based)               */
+    const double*  softcore;             /* [n_regions][8] alpha, beta, a, b, c, d, e, f                      */
+    const int32_t* annihilate;           /* [n_regions][2] sterics, electrostatics                           */
+    int32_t n_interactions;
+    const int32_t* interactions;         /* [n_interactions][2] 1-based region indices (a, b)               */
+    const double *charge, *sigma, *epsilon;      /* [n_atoms] reference parameters (e, nm, kJ/mol)          */
+    int32_t n_exceptions;                /* the reference exceptions that touch an alchemical atom           */
+    const int32_t* exception_atoms;      /* [n_exceptions][2]                                                */
+    const double*  exception_params;     /* [n_exceptions][3] chargeprod, sigma, epsilon                     */
+    int32_t electrostatics;              /* 0 / 1                                                            */
+    double elec_alpha, elec_krf, elec_crf, elec_switch_distance;
+} remd_alch_regions_desc;
+int  remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* desc);
+/* lambda_sterics / lambda_electrostatics of every region at every state: [K][n_regions], K as in remd_set_states (call after it).  The
+   energy_const of remd_set_states carries the long-range corrections of the sterics custom forces (alchemy.py:1786-1789).      */
+int  remd_set_region_lambdas(remd_handle h, int K, int n_regions, const double* lambda_sterics, const double* lambda_electrostatics);
+
 /* Device-to-device transfer of replicas between two handles on the same device that hold the same particles (one handle per
    compatibility group of states: the reference propagates a replica in the Context of its own state's System,
    multistatesampler.py:1296-1320, and evaluates every configuration in one Context per group, :1470-1490 -- the coordinates it moves

@@ -38,8 +38,21 @@ class RemdSystemDesc(C.Structure):
     ]
 
 
+class RemdAlchRegionsDesc(C.Structure):
+    """remd_alch_regions_desc of include/remd_hip.h (general alchemical regions)."""
+    _fields_ = [
+        ('n_atoms', C.c_int32), ('n_regions', C.c_int32), ('region_of_atom', c_int32_p), ('softcore', c_double_p), ('annihilate', c_int32_p),
+        ('n_interactions', C.c_int32), ('interactions', c_int32_p),
+        ('charge', c_double_p), ('sigma', c_double_p), ('epsilon', c_double_p),
+        ('n_exceptions', C.c_int32), ('exception_atoms', c_int32_p), ('exception_params', c_double_p),
+        ('electrostatics', C.c_int32),
+        ('elec_alpha', C.c_double), ('elec_krf', C.c_double), ('elec_crf', C.c_double), ('elec_switch_distance', C.c_double),
+    ]
+
+
 EXPORTS = [
-    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_alchemical_options', 'remd_set_states',
+    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_alchemical_options', 'remd_set_alchemical_regions',
+    'remd_set_region_lambdas', 'remd_set_states',
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_copy_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_propagate_many', 'remd_set_phases', 'remd_get_phases', 'remd_get_constraint_stats', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
@@ -84,6 +97,8 @@ def load_library(path=None):
     lib.remd_set_system.argtypes = [vp, C.POINTER(RemdSystemDesc)]
     lib.remd_set_coulomb_cutoff.argtypes = [vp, C.c_double]
     lib.remd_set_alchemical_options.argtypes = [vp, C.c_int]
+    lib.remd_set_alchemical_regions.argtypes = [vp, C.POINTER(RemdAlchRegionsDesc)]
+    lib.remd_set_region_lambdas.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p]
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
@@ -239,6 +254,28 @@ class HipEngine:
         self._check(self.lib.remd_set_alchemical_options(self.h, int(bool(desc_dict.get('annihilate_sterics', False)))), 'remd_set_alchemical_options')
         self._check(self.lib.remd_set_system(self.h, C.byref(s)), 'remd_set_system')
         self.N = int(desc_dict['n_atoms'])
+        self.n_regions = 0
+        regions = desc_dict.get('alch_regions')
+        if regions is not None:                          # general alchemical regions: the factory's custom forces (alchemy.py:1539-2038)
+            keep = []
+
+            def f64(a):
+                keep.append(np.ascontiguousarray(a, dtype=np.float64)); return _dp(keep[-1])
+
+            def i32(a):
+                keep.append(np.ascontiguousarray(a, dtype=np.int32)); return _ip(keep[-1])
+            r = RemdAlchRegionsDesc()
+            r.n_atoms = self.N; r.n_regions = len(regions['softcore'])
+            r.region_of_atom = i32(regions['region_of_atom']); r.softcore = f64(regions['softcore']); r.annihilate = i32(regions['annihilate'])
+            r.n_interactions = len(regions['interactions']); r.interactions = i32(np.asarray(regions['interactions'], dtype=np.int32).reshape(-1, 2))
+            r.charge, r.sigma, r.epsilon = f64(regions['charge']), f64(regions['sigma']), f64(regions['epsilon'])
+            r.n_exceptions = len(regions['exception_atoms']); r.exception_atoms = i32(np.asarray(regions['exception_atoms'], dtype=np.int32).reshape(-1, 2))
+            r.exception_params = f64(np.asarray(regions['exception_params'], dtype=np.float64).reshape(-1, 3))
+            r.electrostatics = int(regions['electrostatics'])
+            r.elec_alpha, r.elec_krf, r.elec_crf = float(regions['elec_alpha']), float(regions['elec_krf']), float(regions['elec_crf'])
+            r.elec_switch_distance = float(regions['elec_switch_distance'])
+            self._check(self.lib.remd_set_alchemical_regions(self.h, C.byref(r)), 'remd_set_alchemical_regions')
+            self.n_regions = int(r.n_regions)
         if 'force_groups' in desc_dict:                  # Force.getForceGroup() of the force classes (V<g> substeps)
             self.set_force_groups(desc_dict['force_groups'])
 
@@ -248,6 +285,12 @@ class HipEngine:
                 for a in (lambda_sterics, lambda_electrostatics, energy_const)]
         self._check(self.lib.remd_set_states(self.h, len(beta), _dp(beta), *[_dp(a) for a in arrs]), 'remd_set_states')
         self.K = len(beta)
+
+    def set_region_lambdas(self, lambda_sterics, lambda_electrostatics):
+        """[K][n_regions] lambdas of general alchemical regions (after set_states)."""
+        ls = np.ascontiguousarray(lambda_sterics, dtype=np.float64).reshape(self.K, -1)
+        le = np.ascontiguousarray(lambda_electrostatics, dtype=np.float64).reshape(self.K, -1)
+        self._check(self.lib.remd_set_region_lambdas(self.h, self.K, ls.shape[1], _dp(ls), _dp(le)), 'remd_set_region_lambdas')
 
     def set_integrator(self, splitting, timestep, collision_rate, n_steps, reassign_velocities=True,
                        constraint_tolerance=1e-8):

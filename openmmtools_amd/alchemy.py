@@ -1,7 +1,7 @@
 """Alchemical regions and the lambda-dependent pieces of the energy that are host set-up.
 
-Mirrors the parts of openmmtools/alchemy/alchemy.py the benchmark configs use:
-  AlchemicalRegion defaults           :417-427 (softcore_alpha 0.5, a = b = 1, c = 6, annihilate_sterics False)
+Mirrors the parts of openmmtools/alchemy/alchemy.py that define WHAT the alchemical Hamiltonian is:
+  AlchemicalRegion defaults           :417-427 (softcore_alpha 0.5, a = b = 1, c = 6, beta 0, d = e = 1, f = 2, annihilate_sterics False)
   AbsoluteAlchemicalFactory           :626-635, create_alchemical_system :637-754
   force split                         :1052-1083, :1539-2038: alchemical atoms lose their LJ in the
                                       NonbondedForce (eps = 0); alchemical/non-alchemical pairs go to a
@@ -9,8 +9,19 @@ Mirrors the parts of openmmtools/alchemy/alchemy.py the benchmark configs use:
                                       alchemical/alchemical pairs keep full LJ (lambda fixed to 1, :1771-1775)
   dispersion correction               disable_alchemical_dispersion_correction=False (:630) => the custom
                                       forces use OpenMM's long-range correction, which depends on lambda.
-The device evaluates the pair sums (csrc/forces.hip: nonbonded_kernel, alch_ukl_kernel); this module only
-marks the region on the System and computes the per-state long-range-correction constants that
+
+Two device paths serve it:
+  * ONE region under the exact PME treatment (or without alchemical charges), softcore_c = 6 -- the benchmark configs -- is folded into
+    the pair kernels (csrc/forces.hip: soft-core flag per atom, charges scaled by lambda_electrostatics, alch_ukl_kernel): the System
+    is marked with ``alchemical_region``;
+  * everything else the factory builds for a NonbondedForce -- several named regions with their own lambdas (:1360-1377),
+    alchemical_regions_interactions (:661-664, 1684-1690), the 'direct-space' / 'coulomb' PME treatments and the reaction-field
+    treatments with soft-core electrostatics (:1392-1537), any softcore exponents, decoupled electrostatics -- runs as the factory's own
+    force split: the System keeps the NonbondedForce the factory leaves behind (alchemical charges and epsilons zeroed) and carries
+    ``alchemical_regions`` + ``alchemical_region_terms`` (the custom forces' parameters) for csrc/alch_regions.hip
+    (remd_set_alchemical_regions).
+Not built: the exact PME treatment with SEVERAL charged regions (per-region charge offsets inside the Ewald sum), alchemically
+softened bonds / angles / torsions, GBSA.  This module also computes the per-state long-range-correction constants that
 MultiStateSampler hands to remd_set_states(energy_const).
 """
 import copy
@@ -27,14 +38,20 @@ class AlchemicalRegion:
                  softcore_d=1, softcore_e=1, softcore_f=2, name=None):
         if not alchemical_atoms:
             raise ValueError('The AlchemicalRegion is empty.')                      # alchemy.py:899-900 (raised there when the region is resolved)
-        if (softcore_beta, softcore_d, softcore_e) != (0.0, 1, 1):
-            raise NotImplementedError('softcore electrostatics (only the exact PME treatment is implemented)')
         self.alchemical_atoms = sorted(int(a) for a in alchemical_atoms)
-        self.annihilate_electrostatics = annihilate_electrostatics
-        self.annihilate_sterics = annihilate_sterics
+        self.annihilate_electrostatics = bool(annihilate_electrostatics)
+        self.annihilate_sterics = bool(annihilate_sterics)
         self.softcore_alpha, self.softcore_a, self.softcore_b, self.softcore_c = (
             float(softcore_alpha), float(softcore_a), float(softcore_b), float(softcore_c))
+        self.softcore_beta, self.softcore_d, self.softcore_e, self.softcore_f = (
+            float(softcore_beta), float(softcore_d), float(softcore_e), float(softcore_f))
         self.name = name
+
+    @property
+    def softcore(self):
+        """alpha, beta, a, b, c, d, e, f: the order of remd_alch_regions_desc.softcore"""
+        return (self.softcore_alpha, self.softcore_beta, self.softcore_a, self.softcore_b, self.softcore_c,
+                self.softcore_d, self.softcore_e, self.softcore_f)
 
 
 class AbsoluteAlchemicalFactory:
@@ -45,26 +62,135 @@ class AbsoluteAlchemicalFactory:
             raise ValueError(f"Unknown alchemical_pme_treatment scheme '{alchemical_pme_treatment}'")     # alchemy.py:1455
         if alchemical_rf_treatment not in ('switched', 'shifted'):
             raise ValueError(f"Unknown alchemical_rf_treatment scheme '{alchemical_rf_treatment}'")       # alchemy.py:1501
-        if alchemical_pme_treatment != 'exact':
-            raise NotImplementedError("only alchemical_pme_treatment='exact' (the reference default, alchemy.py:628)")
+        self.consistent_exceptions = bool(consistent_exceptions)
+        self.switch_width = float(switch_width)
+        self.alchemical_pme_treatment = alchemical_pme_treatment
+        self.alchemical_rf_treatment = alchemical_rf_treatment
         self.disable_alchemical_dispersion_correction = disable_alchemical_dispersion_correction
+        self.split_alchemical_forces = split_alchemical_forces
 
     def create_alchemical_system(self, reference_system, alchemical_regions, alchemical_regions_interactions=frozenset()):
-        """alchemy.py:637-664.  alchemical_regions_interactions names pairs of regions that interact through their own lambdas: it
-        only has a meaning with several regions, which are not built here."""
-        if alchemical_regions_interactions != frozenset():
-            raise NotImplementedError('interactions between several alchemical regions (alchemy.py:661-664)')
-        if isinstance(alchemical_regions, (list, tuple)):
-            if len(alchemical_regions) != 1:
-                raise NotImplementedError('multiple alchemical regions')
-            alchemical_regions = alchemical_regions[0]
+        """alchemy.py:637-754."""
+        from .system import NonbondedForce
+        if isinstance(alchemical_regions, AlchemicalRegion):
+            alchemical_regions = [alchemical_regions]
+        regions = list(alchemical_regions)
+        interactions = sorted(set((min(int(a), int(b)), max(int(a), int(b))) for a, b in alchemical_regions_interactions))
+        if interactions and len(regions) < 2:
+            raise ValueError('alchemical_regions_interactions names pairs of regions: there is only one')
+        for a, b in interactions:
+            if a == b or not (0 <= a < len(regions) and 0 <= b < len(regions)):
+                raise ValueError('alchemical_regions_interactions: (%d, %d) is not a pair of regions' % (a, b))
+        names = [r.name for r in regions]
+        if len(regions) > 1 and (None in names or len(set(names)) != len(names)):
+            raise ValueError('several alchemical regions need distinct names')                          # alchemy.py:666-672
         system = copy.deepcopy(reference_system)
         n = system.getNumParticles()
-        if max(alchemical_regions.alchemical_atoms) >= n:
-            raise ValueError('alchemical atom index out of range')
-        system.alchemical_region = alchemical_regions
+        seen = set()
+        for r in regions:
+            if max(r.alchemical_atoms) >= n:
+                raise ValueError('alchemical atom index out of range')
+            if seen & set(r.alchemical_atoms):
+                raise ValueError('alchemical regions overlap')
+            seen |= set(r.alchemical_atoms)
         system.alchemical_lrc = not self.disable_alchemical_dispersion_correction
+        nbs = [f for f in system.getForces() if isinstance(f, NonbondedForce)]
+        nb = nbs[0] if nbs else None
+        charged = nb is not None and any(nb.particles[i][0] != 0.0 for i in seen) or \
+            (nb is not None and any(e[2] != 0.0 and (e[0] in seen or e[1] in seen) for e in nb.exceptions))
+        is_pme = nb is not None and nb.getNonbondedMethod() == NonbondedForce.PME
+        exact = is_pme and self.alchemical_pme_treatment == 'exact'
+        if exact:                                                                                         # alchemy.py:1616-1625
+            err = ' not supported with exact treatment of Ewald electrostatics.'
+            for r in regions:
+                if not r.annihilate_electrostatics:
+                    raise ValueError('Decoupled electrostatics is' + err)
+                if self.consistent_exceptions:
+                    raise ValueError('Consistent exceptions are' + err)
+                if (r.softcore_beta, r.softcore_d, r.softcore_e) != (0, 1, 1):
+                    raise ValueError('Softcore electrostatics is' + err)
+        r0 = regions[0]
+        fast = (len(regions) == 1 and r0.softcore_c == 6.0 and (exact or not charged))
+        if fast:
+            # the pair kernels' own path: one region, charges scaled inside the Ewald sum or none to scale
+            system.alchemical_region = r0
+            system.alchemical_regions = None
+            return system
+        if nb is None:
+            raise ValueError('alchemical regions need a NonbondedForce')
+        if exact and charged:
+            raise NotImplementedError('the exact PME treatment with several charged alchemical regions (per-region charge offsets inside the '
+                                      'Ewald sum, alchemy.py:1663-1681, 1893-1899) is not built: use alchemical_pme_treatment=\'direct-space\' or \'coulomb\'')
+        if self.consistent_exceptions:
+            raise NotImplementedError('consistent_exceptions=True (alchemy.py:1457-1459)')
+        system.alchemical_region = None
+        system.alchemical_regions = regions
+        system.alchemical_region_terms = self._region_terms(nb, regions, interactions, charged)
         return system
+
+    # ---- the factory's split of a NonbondedForce (alchemy.py:1539-2038) ---------------------------------------------
+    def _region_terms(self, nb, regions, interactions, charged):
+        """Zero the alchemical atoms in ``nb`` (what the factory leaves in the NonbondedForce, :1903-1911, 2001-2006) and return the
+        parameters of the custom forces: the dict system_to_desc passes on as ``alch_regions`` (remd_alch_regions_desc)."""
+        from .system import NonbondedForce
+        n = nb.getNumParticles()
+        region_of = np.zeros(n, dtype=np.int32)
+        for g, r in enumerate(regions):
+            region_of[r.alchemical_atoms] = g + 1
+        p = np.array(nb.particles, dtype=np.float64).reshape(-1, 3)
+        p[p[:, 1] == 0.0, 1] = 0.1                                       # sigma = 0 -> 1 A (:1638-1648)
+        exc_atoms, exc_params = [], []
+        for k, e in enumerate(nb.exceptions):
+            i, j, qq, sig, eps = e
+            if region_of[i] == 0 and region_of[j] == 0:
+                continue
+            if sig == 0.0:
+                sig = 0.1                                                # (:1650-1661)
+            if qq != 0.0 or eps != 0.0:
+                if region_of[i] and region_of[j] and region_of[i] != region_of[j]:
+                    raise ValueError('Cannot have exception that straddles two alchemical regions')       # alchemy.py:1969
+                exc_atoms.append((i, j)); exc_params.append((qq, sig, eps))
+            nb.exceptions[k] = (i, j, 0.0, sig, 0.0)
+        for i in np.nonzero(region_of)[0]:
+            q, sig, eps = nb.particles[i]
+            nb.particles[i] = (0.0, sig if sig != 0.0 else 0.1, 0.0)
+        rc = nb.getCutoffDistance()
+        method = nb.getNonbondedMethod()
+        terms = dict(region_of_atom=region_of, softcore=np.array([r.softcore for r in regions], dtype=np.float64),
+                     annihilate=np.array([[r.annihilate_sterics, r.annihilate_electrostatics] for r in regions], dtype=np.int32),
+                     interactions=np.array([(a + 1, b + 1) for a, b in interactions], dtype=np.int32).reshape(-1, 2),
+                     charge=p[:, 0].copy(), sigma=p[:, 1].copy(), epsilon=p[:, 2].copy(),
+                     exception_atoms=np.array(exc_atoms, dtype=np.int32).reshape(-1, 2),
+                     exception_params=np.array(exc_params, dtype=np.float64).reshape(-1, 3),
+                     electrostatics=int(bool(charged)), elec_alpha=0.0, elec_krf=0.0, elec_crf=0.0, elec_switch_distance=-1.0)
+        if charged:
+            if method == NonbondedForce.PME:
+                if self.alchemical_pme_treatment == 'direct-space':                                      # :1510-1537
+                    alpha = nb._pme_params[0] if nb._pme_params is not None else 0.0
+                    if alpha == 0.0:
+                        alpha = math.sqrt(-math.log(2.0 * nb.getEwaldErrorTolerance())) / rc
+                    terms['elec_alpha'] = float(alpha)
+                else:                                                                                      # 'coulomb': switched plain Coulomb (:1449-1452, 1818-1821)
+                    terms['elec_switch_distance'] = rc - self.switch_width
+            elif method == NonbondedForce.CutoffPeriodic:                                                 # :1473-1508
+                eps_s = nb.getReactionFieldDielectric()
+                terms['elec_krf'] = rc ** -3 * (eps_s - 1.0) / (2.0 * eps_s + 1.0)
+                if self.alchemical_rf_treatment == 'switched':
+                    terms['elec_switch_distance'] = rc - self.switch_width
+                else:
+                    terms['elec_crf'] = (1.0 / rc) * 3.0 * eps_s / (2.0 * eps_s + 1.0)
+            else:
+                raise NotImplementedError('nonbonded method %d (only CutoffPeriodic and PME are supported)' % method)
+        return terms
+
+
+def region_lambda_of_class(kind, ls_a, ls_b, annihilate):
+    """lambda of a class of pairs: (environment, a), (a, a) or (a, b) -- alchemy.py:1766-1779."""
+    if kind == 0:
+        return ls_a
+    if kind == 1:
+        return ls_a if annihilate else 1.0
+    return ls_a * ls_b
 
 
 def _softcore_energy(r, sigma, eps, lam, region):
@@ -87,43 +213,75 @@ def _tail_integral(sigma, eps, lam, region, rc, rs):
     return tail
 
 
+def _classes(sigma, epsilon, atoms):
+    out = {}
+    for i in atoms:
+        out[(sigma[i], epsilon[i])] = out.get((sigma[i], epsilon[i]), 0) + 1
+    return list(out.items())
+
+
+def _group_sum(A, B, same, lam, region, rc, rs, cache):
+    """sum over the pairs of an interaction group (set A x set B; ``same``: A is B, unordered pairs) of the tail integrals"""
+    tot = 0.0
+    for x, ((s1, e1), n1) in enumerate(A):
+        for y, ((s2, e2), n2) in enumerate(B):
+            if same and y < x:
+                continue
+            count = (n1 * (n1 - 1) / 2.0 if x == y else n1 * n2) if same else n1 * n2
+            eps = math.sqrt(e1 * e2)
+            if eps > 0 and count > 0:
+                key = (0.5 * (s1 + s2), eps, lam, id(region))
+                if key not in cache:
+                    cache[key] = _tail_integral(0.5 * (s1 + s2), eps, lam, region, rc, rs)
+                tot += count * cache[key]
+    return tot
+
+
 def alchemical_long_range_constants(system, nonbonded_force, lambdas_sterics, volume):
-    """Per-state long-range correction (kJ/mol) of the two sterics CustomNonbondedForces.
+    """Per-state long-range correction (kJ/mol) of the sterics CustomNonbondedForces.
 
     OpenMM CustomNonbondedForce convention: E = 2 pi N^2 / V * sum_classpairs count * I / (N (N+1)/2),
     with count restricted to the force's interaction group: alchemical x non-alchemical atoms for the
     lambda-controlled force, alchemical pairs (lambda = 1) for the other.
+
+    lambdas_sterics: [K] for a System with ``alchemical_region`` (one region); [K][n_regions] for ``alchemical_regions`` -- then every
+    single region has its two forces and every pair of interacting regions one, controlled by the product of the two lambdas
+    (alchemy.py:1766-1779, 1786-1789, 1916-1922).
     """
-    region = system.alchemical_region
-    if region is None or not getattr(system, 'alchemical_lrc', True) or not nonbonded_force.getUseDispersionCorrection():
-        return np.zeros(len(lambdas_sterics))
+    regions = getattr(system, 'alchemical_regions', None)
+    if regions is None:
+        region = getattr(system, 'alchemical_region', None)
+        if region is None:
+            return np.zeros(len(lambdas_sterics))
+        regions, interactions = [region], []
+        lam = np.asarray(lambdas_sterics, dtype=np.float64).reshape(-1, 1)
+        sigma = [q[1] for q in nonbonded_force.particles]
+        epsilon = [q[2] for q in nonbonded_force.particles]
+    else:
+        terms = system.alchemical_region_terms
+        interactions = [(int(a) - 1, int(b) - 1) for a, b in terms['interactions']]
+        lam = np.asarray(lambdas_sterics, dtype=np.float64).reshape(-1, len(regions))
+        sigma, epsilon = list(terms['sigma']), list(terms['epsilon'])
+    if not getattr(system, 'alchemical_lrc', True) or not nonbonded_force.getUseDispersionCorrection():
+        return np.zeros(len(lam))
     n = system.getNumParticles()
     rc = nonbonded_force.getCutoffDistance()
     rs = nonbonded_force.getSwitchingDistance() if nonbonded_force.getUseSwitchingFunction() else None
-    alch = set(region.alchemical_atoms)
-    cls_a, cls_n = {}, {}
-    for i, (q, s, e) in enumerate(nonbonded_force.particles):
-        d = cls_a if i in alch else cls_n
-        d[(s, e)] = d.get((s, e), 0) + 1
+    alch = set()
+    for r in regions:
+        alch |= set(r.alchemical_atoms)
+    env = _classes(sigma, epsilon, [i for i in range(n) if i not in alch])
+    per_region = [_classes(sigma, epsilon, r.alchemical_atoms) for r in regions]
     norm = 2.0 * math.pi * n * n / (n * (n + 1) / 2.0) / volume
-    out = np.zeros(len(lambdas_sterics))
-    for k, lam in enumerate(lambdas_sterics):
+    out = np.zeros(len(lam))
+    cache = {}
+    for k in range(len(lam)):
         tot = 0.0
-        for (sa, ea), na in cls_a.items():
-            for (sn, en), nn in cls_n.items():
-                eps = math.sqrt(ea * en)
-                if eps > 0:
-                    tot += na * nn * _tail_integral(0.5 * (sa + sn), eps, lam, region, rc, rs)
-        # alchemical/alchemical force: lambda fixed to 1 unless annihilate_sterics (alchemy.py:1767-1779)
-        lam_aa = lam if region.annihilate_sterics else 1.0
-        keys = list(cls_a.items())
-        for x in range(len(keys)):
-            for y in range(x, len(keys)):
-                (s1, e1), n1 = keys[x]
-                (s2, e2), n2 = keys[y]
-                count = n1 * (n1 - 1) / 2.0 if x == y else n1 * n2
-                eps = math.sqrt(e1 * e2)
-                if eps > 0 and count > 0:
-                    tot += count * _tail_integral(0.5 * (s1 + s2), eps, lam_aa, region, rc, rs)
+        for g, region in enumerate(regions):
+            tot += _group_sum(per_region[g], env, False, lam[k, g], region, rc, rs, cache)
+            # alchemical/alchemical force: lambda fixed to 1 unless annihilate_sterics (alchemy.py:1767-1779)
+            tot += _group_sum(per_region[g], per_region[g], True, lam[k, g] if region.annihilate_sterics else 1.0, region, rc, rs, cache)
+        for a, b in interactions:
+            tot += _group_sum(per_region[a], per_region[b], False, lam[k, a] * lam[k, b], regions[b], rc, rs, cache)
         out[k] = norm * tot
     return out

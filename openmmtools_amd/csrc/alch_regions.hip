@@ -1,0 +1,422 @@
+// General alchemical regions (gfx950): the custom forces AbsoluteAlchemicalFactory._alchemically_modify_NonbondedForce builds
+// (alchemy/alchemy.py:1539-2038) when the one-region / exact-PME fast path of forces.hip does not cover the request -- several
+// regions with their own lambdas, pairs of interacting regions, soft-core electrostatics of the 'direct-space' / 'coulomb' PME
+// treatments and of the reaction-field treatments, any soft-core exponents.  include/remd_hip.h (remd_set_alchemical_regions)
+// states the force split and the expressions; the f64 restatement is oracle/alchemical_regions.py.
+//
+// Design: alchemical atoms are few (tens among thousands), so the custom forces are ONE launch over the (alchemical atom, atom)
+// candidates per force evaluation -- n_alch x N distance tests, a bit per candidate for everything static (self, excluded pairs,
+// the second side of an alchemical/alchemical pair, regions that do not interact) -- in front of the fork of a force evaluation.
+// Forces add to the fixed-point accumulators of forces.hip (the alchemical atom's own force is summed over the wavefront first:
+// lanes of one wavefront share it).  Energies: a second kernel with one workgroup per (state, replica) and a fixed order of
+// summation; it serves the potential of a replica's own state (slot EP_REGION of the energy partials) and, over all K states, the
+// region part of u_kl (the `alch` term of assemble_ukl_kernel).
+#include "remd_internal.h"
+#include "listed_terms.h"
+#include <cmath>
+#include <algorithm>
+#include <cstring>
+
+struct region_consts {
+    float rc2, rs, inv_sw;                 // cutoff^2, sterics switch (rs < 0: none), 1 / (rc - rs)
+    float rs_e, inv_sw_e;                  // electrostatics switch (rs_e < 0: none)
+    float alpha_e, two_alpha_sqrtpi_e, krf, crf;
+    int elec, n_cls, n_reg1, words, N, Npad, n_alch, n_exc;
+};
+
+struct region_tables {
+    region_consts c{};
+    int n_regions = 0, K = 0;
+    std::vector<double> softcore; std::vector<int> annihilate;
+    struct cls { int kind, a, b, P; };     // kind 0: (environment, a); 1: (a, a); 2: (a, b) interacting; P = region whose soft-core constants apply
+    std::vector<cls> classes;
+    std::vector<double> ls, le;            // [K][n_regions]
+    int* d_alch = nullptr;                 // [n_alch] atom
+    float4* d_atom = nullptr;              // [N] q sqrt(k_e), sigma / 2, 2 sqrt(eps), region (bits)
+    unsigned int* d_skip = nullptr;        // [n_alch][words] candidates that are never evaluated
+    int* d_cls_of = nullptr;               // [(n + 1)^2] class of a pair of regions
+    int* d_exc_atoms = nullptr; float4* d_exc_par = nullptr;      // exceptions: (k_e qq, sigma, 4 eps, class bits)
+    float4* d_state_cls = nullptr;         // [K][n_cls][2]: (l^a, alpha (1 - l)^b, l^d, beta (1 - l)^e), (c, f, 0, 0)
+    int* d_own = nullptr; std::vector<int> own_host;
+};
+static handle_table<region_tables> g_reg;
+
+static inline float host_int_as_float(int v) { float f; memcpy(&f, &v, sizeof f); return f; }
+template <typename T> static void dfree(T*& p) { if (p) { hipFree(p); p = nullptr; } }
+template <typename T>
+static int upload(remd_ctx* h, T*& dptr, const std::vector<T>& host)
+{
+    dfree(dptr);
+    if (host.empty()) return 0;
+    REMD_CHECK(h, hipMalloc(&dptr, sizeof(T) * host.size()));
+    REMD_CHECK(h, hipMemcpy(dptr, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+__device__ __forceinline__ void region_switch(float rs, float inv_sw, float r, float& U, float& dUdr)
+{
+    if (rs >= 0.f && r > rs) {
+        const float x = (r - rs) * inv_sw;
+        const float S = 1.f + x * x * x * (-10.f + x * (15.f - 6.f * x));
+        const float dS = x * x * (-30.f + x * (60.f - 30.f * x)) * inv_sw;
+        dUdr = S * dUdr + U * dS;
+        U *= S;
+    }
+}
+
+// soft-core Lennard-Jones (alchemy.py:1383-1388): U = l^a eps4 x (x - 1), x = (sigma / reff)^6 = (alpha (1 - l)^b + (r / sigma)^c)^(-6/c)
+__device__ __forceinline__ void region_sterics(float4 A, float4 B, float sig, float eps4, float r, float inv_r, float& U, float& dUdr)
+{
+    const float t = powf(r / sig, B.x);
+    const float base = A.y + t;
+    const float x = powf(base, -6.f / B.x);
+    U = A.x * eps4 * x * (x - 1.f);
+    dUdr = A.x * eps4 * (2.f * x - 1.f) * (-6.f * x / base * t * inv_r);
+}
+
+// soft-core electrostatics (alchemy.py:1425-1430, 1434, 1505-1507, 1534-1536): U = l^d qq g(reff), reff = sigma (beta (1 - l)^e + (r / sigma)^f)^(1/f),
+// g(x) = erfc(alpha x) / x + krf x^2 - crf
+__device__ __forceinline__ void region_electrostatics(float4 A, float4 B, float alpha, float two_alpha_sqrtpi, float krf, float crf,
+                                                      float sig, float qq, float r, float inv_r, float& U, float& dUdr)
+{
+    const float t = powf(r / sig, B.y);
+    const float base = A.w + t;
+    const float reff = sig * powf(base, 1.f / B.y);
+    const float inv = 1.f / reff;
+    float g, dg;
+    if (alpha > 0.f) {
+        const float ar = alpha * reff;
+        const float ec = erfcf(ar);
+        g = ec * inv; dg = -(ec * inv + two_alpha_sqrtpi * expf(-ar * ar)) * inv;
+    } else { g = inv; dg = -inv * inv; }
+    g += krf * reff * reff - crf; dg += 2.f * krf * reff;
+    U = A.z * qq * g;
+    dUdr = A.z * qq * dg * (reff / base * t * inv_r);
+}
+
+// one candidate pair (alchemical atom a, atom j): energy and dU/dr / r; false: nothing to add
+__device__ __forceinline__ bool region_pair(const region_consts& c, const float4* __restrict__ cls_tab, const int* __restrict__ cls_of,
+                                            float4 pa, float4 pj, float3 d, float& U, float& fr)
+{
+    const float r2 = dotf(d, d);
+    if (r2 >= c.rc2) return false;
+    const int k = cls_of[__float_as_int(pa.w) * c.n_reg1 + __float_as_int(pj.w)];
+    const float4 A = cls_tab[2 * k], B = cls_tab[2 * k + 1];
+    const float inv_r = rsqrtf(r2), r = r2 * inv_r;
+    const float sig = pa.y + pj.y, eps4 = pa.z * pj.z, qq = pa.x * pj.x;
+    U = 0.f; float dU = 0.f;
+    if (eps4 != 0.f) {
+        region_sterics(A, B, sig, eps4, r, inv_r, U, dU);
+        region_switch(c.rs, c.inv_sw, r, U, dU);
+    }
+    if (c.elec && qq != 0.f) {
+        float Ue, dUe;
+        region_electrostatics(A, B, c.alpha_e, c.two_alpha_sqrtpi_e, c.krf, c.crf, sig, qq, r, inv_r, Ue, dUe);
+        region_switch(c.rs_e, c.inv_sw_e, r, Ue, dUe);
+        U += Ue; dU += dUe;
+    }
+    fr = dU * inv_r;
+    return true;
+}
+
+// exception t: soft-core sterics without cutoff or switch, electrostatics l^d qq / reff (alchemy.py:1374-1380, 1434, 1456-1461)
+__device__ __forceinline__ void region_exception(const region_consts& c, const float4* __restrict__ cls_tab, float4 par, float3 d, float& U, float& fr)
+{
+    const int k = __float_as_int(par.w);
+    const float4 A = cls_tab[2 * k], B = cls_tab[2 * k + 1];
+    const float r2 = dotf(d, d);
+    const float inv_r = rsqrtf(r2), r = r2 * inv_r;
+    U = 0.f; float dU = 0.f;
+    if (par.z != 0.f) region_sterics(A, B, par.y, par.z, r, inv_r, U, dU);
+    if (c.elec && par.x != 0.f) {
+        float Ue, dUe;
+        region_electrostatics(A, B, 0.f, 0.f, 0.f, 0.f, par.y, par.x, r, inv_r, Ue, dUe);
+        U += Ue; dU += dUe;
+    }
+    fr = dU * inv_r;
+}
+
+__device__ __forceinline__ float3 region_min_image(float3 d, float Lx, float Ly, float Lz)
+{
+    d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz);
+    return d;
+}
+
+// forces: workgroup = (alchemical atom a, chunk of 1024 atoms j); the first workgroups of a replica also take the exceptions
+#define REGION_CHUNK 1024
+__global__ __launch_bounds__(256)
+void region_forces_kernel(region_consts c, const int* __restrict__ alch, const float4* __restrict__ atom, const unsigned int* __restrict__ skip,
+                          const int* __restrict__ cls_of, const float4* __restrict__ state_cls, const int* __restrict__ own,
+                          const int* __restrict__ exc_atoms, const float4* __restrict__ exc_par,
+                          const float4* __restrict__ pos, const float* __restrict__ box, long long* __restrict__ force)
+{
+    const int r = blockIdx.y;
+    const int nchunk = (c.N + REGION_CHUNK - 1) / REGION_CHUNK;
+    const int ia = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const float4* P = pos + (size_t)r * c.Npad;
+    long long* F = force + (size_t)r * 3 * c.Npad;
+    const float4* cls_tab = state_cls + (size_t)own[r] * c.n_cls * 2;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    const int a = alch[ia];
+    const float4 pa = atom[a];
+    const float3 xa = ld3(P, a);
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    const int j1 = min(c.N, (chunk + 1) * REGION_CHUNK);
+    for (int j = chunk * REGION_CHUNK + threadIdx.x; j < j1; j += 256) {
+        if ((skip[(size_t)ia * c.words + (j >> 5)] >> (j & 31)) & 1u) continue;
+        const float3 d = region_min_image(sub3(ld3(P, j), xa), Lx, Ly, Lz);
+        float U, fr;
+        if (!region_pair(c, cls_tab, cls_of, pa, atom[j], d, U, fr)) continue;
+        fx += fr * d.x; fy += fr * d.y; fz += fr * d.z;
+        add_force(F, c.Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
+    }
+    for (int off = 32; off > 0; off >>= 1) { fx += __shfl_xor(fx, off); fy += __shfl_xor(fy, off); fz += __shfl_xor(fz, off); }
+    if ((threadIdx.x & 63) == 0 && (fx != 0.f || fy != 0.f || fz != 0.f)) add_force(F, c.Npad, a, fx, fy, fz);
+    // exceptions: spread over the workgroups of the replica
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < c.n_exc; t += gridDim.x * 256) {
+        const int i = exc_atoms[2 * t], j = exc_atoms[2 * t + 1];
+        float3 d = sub3(ld3(P, j), ld3(P, i));
+        if (Lx > 0.f) d = region_min_image(d, Lx, Ly, Lz);
+        float U, fr;
+        region_exception(c, cls_tab, exc_par[t], d, U, fr);
+        add_force(F, c.Npad, i, fr * d.x, fr * d.y, fr * d.z);
+        add_force(F, c.Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
+    }
+}
+
+// energies: workgroup = (state column, replica); state = own[r] when `own` is given (the replica's potential), else the column
+__global__ __launch_bounds__(256)
+void region_energy_kernel(region_consts c, const int* __restrict__ alch, const float4* __restrict__ atom, const unsigned int* __restrict__ skip,
+                          const int* __restrict__ cls_of, const float4* __restrict__ state_cls, const int* __restrict__ own,
+                          const int* __restrict__ exc_atoms, const float4* __restrict__ exc_par,
+                          const float4* __restrict__ pos, const float* __restrict__ box, double* __restrict__ out, int out_stride, int out_offset)
+{
+    __shared__ double s_part[4];
+    const int r = blockIdx.y;
+    const int state = own ? own[r] : blockIdx.x;
+    const float4* P = pos + (size_t)r * c.Npad;
+    const float4* cls_tab = state_cls + (size_t)state * c.n_cls * 2;
+    const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
+    double e = 0.0;
+    const int total = c.n_alch * c.N;
+    for (int t = threadIdx.x; t < total; t += 256) {
+        const int ia = t / c.N, j = t - ia * c.N;
+        if ((skip[(size_t)ia * c.words + (j >> 5)] >> (j & 31)) & 1u) continue;
+        const int a = alch[ia];
+        const float3 d = region_min_image(sub3(ld3(P, j), ld3(P, a)), Lx, Ly, Lz);
+        float U, fr;
+        if (region_pair(c, cls_tab, cls_of, atom[a], atom[j], d, U, fr)) e += (double)U;
+    }
+    for (int t = threadIdx.x; t < c.n_exc; t += 256) {
+        float3 d = sub3(ld3(P, exc_atoms[2 * t + 1]), ld3(P, exc_atoms[2 * t]));
+        if (Lx > 0.f) d = region_min_image(d, Lx, Ly, Lz);
+        float U, fr;
+        region_exception(c, cls_tab, exc_par[t], d, U, fr);
+        e += (double)U;
+    }
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)r * out_stride + out_offset + (own ? 0 : blockIdx.x)] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+void remd_regions_release(remd_ctx* h)
+{
+    region_tables* t = g_reg.find(h);
+    if (t) {
+        dfree(t->d_alch); dfree(t->d_atom); dfree(t->d_skip); dfree(t->d_cls_of); dfree(t->d_exc_atoms); dfree(t->d_exc_par);
+        dfree(t->d_state_cls); dfree(t->d_own);
+        g_reg.erase(h);
+    }
+    h->n_regions = 0;
+}
+
+int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
+{
+    if (!h) return remd_fail(h, -1, "remd_set_alchemical_regions: NULL handle");
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    remd_regions_release(h);
+    h->config_version++;
+    h->forces_valid = false;
+    if (!d || d->n_regions == 0) return 0;
+    if (!h->has_system || h->parent || !h->sysdesc || !h->sysdesc->valid) return remd_fail(h, -2, "remd_set_alchemical_regions: call remd_set_system first");
+    const int N = h->N, n = d->n_regions;
+    if (d->n_atoms != N) return remd_fail(h, -1, "remd_set_alchemical_regions: n_atoms differs from the system's");
+    if (n < 0 || n > 64 || !d->region_of_atom || !d->softcore || !d->annihilate || !d->charge || !d->sigma || !d->epsilon ||
+        d->n_interactions < 0 || (d->n_interactions > 0 && !d->interactions) || d->n_exceptions < 0 || (d->n_exceptions > 0 && (!d->exception_atoms || !d->exception_params)))
+        return remd_fail(h, -1, "remd_set_alchemical_regions: bad arguments");
+    if (h->nb_method == REMD_NB_NONE) return remd_fail(h, -3, "alchemical regions need a NonbondedForce with a cutoff method");
+    if (h->sysdesc->d.n_alch != 0) return remd_fail(h, -3, "alchemical regions: the descriptor of remd_set_system must be the factory's NonbondedForce (n_alch = 0)");
+    region_tables& t = g_reg[h];
+    t.n_regions = n;
+    t.softcore.assign(d->softcore, d->softcore + 8 * (size_t)n);
+    t.annihilate.assign(d->annihilate, d->annihilate + 2 * (size_t)n);
+    for (int g = 0; g < n; ++g) {
+        const double* s = &t.softcore[8 * (size_t)g];
+        if (!(s[4] > 0) || !(s[7] > 0)) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: softcore_c and softcore_f must be positive"); }
+    }
+    // classes of pairs of regions
+    std::vector<int> cls_of((size_t)(n + 1) * (n + 1), -1);
+    t.classes.clear();
+    for (int g = 1; g <= n; ++g) {
+        cls_of[g] = cls_of[(size_t)g * (n + 1)] = (int)t.classes.size(); t.classes.push_back({0, g, g, g});
+        cls_of[(size_t)g * (n + 1) + g] = (int)t.classes.size(); t.classes.push_back({1, g, g, g});
+    }
+    for (int k = 0; k < d->n_interactions; ++k) {
+        const int a = d->interactions[2 * k], b = d->interactions[2 * k + 1];
+        if (a < 1 || b < 1 || a > n || b > n || a == b) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: bad pair of interacting regions"); }
+        if (cls_of[(size_t)a * (n + 1) + b] >= 0) continue;
+        cls_of[(size_t)a * (n + 1) + b] = cls_of[(size_t)b * (n + 1) + a] = (int)t.classes.size(); t.classes.push_back({2, a, b, b});
+    }
+    // atoms
+    std::vector<int> alch;
+    std::vector<float4> atom(N);
+    const double sqk = sqrt(REMD_ONE_4PI_EPS0);
+    for (int i = 0; i < N; ++i) {
+        const int g = d->region_of_atom[i];
+        if (g < 0 || g > n) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: region index out of range"); }
+        if (g > 0) alch.push_back(i);
+        if (!(d->sigma[i] > 0) && g > 0) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: sigma must be positive (the factory sets 0 to 0.1 nm, alchemy.py:1638-1648)"); }
+        atom[i] = make_float4((float)(d->charge[i] * sqk), (float)(0.5 * d->sigma[i]), (float)(2.0 * sqrt(d->epsilon[i])), host_int_as_float(g));
+    }
+    if (alch.empty()) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: no alchemical atom"); }
+    const int na = (int)alch.size(), words = (N + 31) / 32;
+    std::vector<int> ord(N, -1);
+    for (int k = 0; k < na; ++k) ord[alch[k]] = k;
+    std::vector<unsigned int> skip((size_t)na * words, 0u);
+    auto set_skip = [&](int ia, int j) { skip[(size_t)ia * words + (j >> 5)] |= 1u << (j & 31); };
+    for (int ia = 0; ia < na; ++ia) {
+        const int a = alch[ia], ga = d->region_of_atom[a];
+        for (int j = 0; j < N; ++j) {
+            const int gj = d->region_of_atom[j];
+            // itself; an alchemical/alchemical pair is taken from its lower atom; regions that do not interact
+            if (j == a || (gj > 0 && j < a) || cls_of[(size_t)ga * (n + 1) + gj] < 0) set_skip(ia, j);
+            // environment atoms without sigma cannot enter the mixing rule: they have neither epsilon nor (in the factory's system) a way to interact
+            else if (gj == 0 && !(d->sigma[j] > 0) && (d->epsilon[j] != 0.0 || (d->electrostatics && d->charge[j] != 0.0))) {
+                remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: sigma must be positive (the factory sets 0 to 0.1 nm, alchemy.py:1638-1648)");
+            }
+        }
+    }
+    // every exception of the system is an exclusion of the custom forces (alchemy.py:1944-1947)
+    const remd_system_desc& sd = h->sysdesc->d;
+    for (int e = 0; e < sd.n_exceptions; ++e) {
+        const int i = sd.exception_atoms[2 * e], j = sd.exception_atoms[2 * e + 1];
+        if (ord[i] >= 0) set_skip(ord[i], j);
+        if (ord[j] >= 0) set_skip(ord[j], i);
+    }
+    // the exceptions that became custom bonds
+    std::vector<int> ea; std::vector<float4> ep;
+    for (int e = 0; e < d->n_exceptions; ++e) {
+        const int i = d->exception_atoms[2 * e], j = d->exception_atoms[2 * e + 1];
+        if (i < 0 || j < 0 || i >= N || j >= N || i == j) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: bad exception pair"); }
+        const int gi = d->region_of_atom[i], gj = d->region_of_atom[j];
+        const double qq = d->exception_params[3 * e], sg = d->exception_params[3 * e + 1], eps = d->exception_params[3 * e + 2];
+        if ((gi == 0 && gj == 0) || (eps == 0.0 && (qq == 0.0 || !d->electrostatics))) continue;
+        if (gi > 0 && gj > 0 && gi != gj) { remd_regions_release(h); return remd_fail(h, -3, "an exception that straddles two alchemical regions is not supported"); }
+        if (!(sg > 0)) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: exception sigma must be positive"); }
+        ea.push_back(i); ea.push_back(j);
+        ep.push_back(make_float4((float)(qq * REMD_ONE_4PI_EPS0), (float)sg, (float)(4.0 * eps), host_int_as_float(cls_of[(size_t)gi * (n + 1) + gj])));
+    }
+    region_consts& c = t.c;
+    c.rc2 = (float)(h->cutoff * h->cutoff);
+    c.rs = h->switch_dist >= 0 && h->switch_dist < h->cutoff ? (float)h->switch_dist : -1.f;
+    c.inv_sw = c.rs >= 0.f ? (float)(1.0 / (h->cutoff - h->switch_dist)) : 0.f;
+    c.elec = d->electrostatics ? 1 : 0;
+    c.rs_e = c.elec && d->elec_switch_distance >= 0 && d->elec_switch_distance < h->cutoff ? (float)d->elec_switch_distance : -1.f;
+    c.inv_sw_e = c.rs_e >= 0.f ? (float)(1.0 / (h->cutoff - d->elec_switch_distance)) : 0.f;
+    c.alpha_e = (float)d->elec_alpha; c.two_alpha_sqrtpi_e = (float)(2.0 * d->elec_alpha / sqrt(M_PI));
+    c.krf = (float)d->elec_krf; c.crf = (float)d->elec_crf;
+    c.n_cls = (int)t.classes.size(); c.n_reg1 = n + 1; c.words = words; c.N = N; c.Npad = h->Npad; c.n_alch = na; c.n_exc = (int)ea.size() / 2;
+    int rc;
+    if ((rc = upload(h, t.d_alch, alch)) || (rc = upload(h, t.d_atom, atom)) || (rc = upload(h, t.d_skip, skip)) || (rc = upload(h, t.d_cls_of, cls_of)) ||
+        (rc = upload(h, t.d_exc_atoms, ea)) || (rc = upload(h, t.d_exc_par, ep))) { remd_regions_release(h); return rc; }
+    h->n_regions = n;
+    return 0;
+}
+
+int remd_set_region_lambdas(remd_handle h, int K, int n_regions, const double* ls, const double* le)
+{
+    if (!h) return remd_fail(h, -1, "remd_set_region_lambdas: NULL handle");
+    region_tables* tp = g_reg.find(h);
+    if (!tp || h->n_regions == 0) return remd_fail(h, -2, "remd_set_region_lambdas: no alchemical regions on this handle");
+    region_tables& t = *tp;
+    if (K != h->K || n_regions != t.n_regions || !ls || !le) return remd_fail(h, -1, "remd_set_region_lambdas: K / n_regions differ from remd_set_states / remd_set_alchemical_regions");
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    const int n = t.n_regions, C = t.c.n_cls;
+    for (size_t k = 0; k < (size_t)K * n; ++k)
+        if (!(ls[k] >= 0.0 && ls[k] <= 1.0 && le[k] >= 0.0 && le[k] <= 1.0)) return remd_fail(h, -1, "remd_set_region_lambdas: lambdas must be in [0, 1]");
+    t.ls.assign(ls, ls + (size_t)K * n); t.le.assign(le, le + (size_t)K * n); t.K = K;
+    std::vector<float4> tab((size_t)K * C * 2);
+    for (int k = 0; k < K; ++k)
+        for (int q = 0; q < C; ++q) {
+            const region_tables::cls& cl = t.classes[q];
+            const double* s = &t.softcore[8 * (size_t)(cl.P - 1)];
+            double l_s, l_e;
+            if (cl.kind == 0) { l_s = ls[(size_t)k * n + cl.a - 1]; l_e = le[(size_t)k * n + cl.a - 1]; }
+            else if (cl.kind == 1) {
+                l_s = t.annihilate[2 * (cl.a - 1)] ? ls[(size_t)k * n + cl.a - 1] : 1.0;
+                l_e = t.annihilate[2 * (cl.a - 1) + 1] ? le[(size_t)k * n + cl.a - 1] : 1.0;
+            } else { l_s = ls[(size_t)k * n + cl.a - 1] * ls[(size_t)k * n + cl.b - 1]; l_e = le[(size_t)k * n + cl.a - 1] * le[(size_t)k * n + cl.b - 1]; }
+            tab[((size_t)k * C + q) * 2] = make_float4((float)pow(l_s, s[2]), (float)(s[0] * pow(1.0 - l_s, s[3])),
+                                                       (float)pow(l_e, s[5]), (float)(s[1] * pow(1.0 - l_e, s[6])));
+            tab[((size_t)k * C + q) * 2 + 1] = make_float4((float)s[4], (float)s[7], 0.f, 0.f);
+        }
+    int rc = upload(h, t.d_state_cls, tab);
+    if (rc) return rc;
+    h->config_version++;
+    h->forces_valid = false;
+    return 0;
+}
+
+static int region_own_states(remd_ctx* h, region_tables& t)
+{
+    std::vector<int> own(h->R);
+    for (int r = 0; r < h->R; ++r) own[r] = h->labels.empty() ? 0 : (int)h->labels[h->r_begin + r];
+    for (int r = 0; r < h->R; ++r) if (own[r] < 0 || own[r] >= t.K) return remd_fail(h, -1, "alchemical regions: a replica's state has no region lambdas");
+    if (own == t.own_host && t.d_own) return 0;          // uploaded only when the labels changed
+    if (t.own_host.size() != own.size()) { dfree(t.d_own); REMD_CHECK(h, hipMalloc(&t.d_own, sizeof(int) * own.size())); }
+    REMD_CHECK(h, hipMemcpyAsync(t.d_own, own.data(), sizeof(int) * own.size(), hipMemcpyHostToDevice, h->stream));
+    REMD_CHECK(h, hipStreamSynchronize(h->stream));
+    t.own_host = own;
+    return 0;
+}
+
+// at the head of a force evaluation, on the stream everything else of the evaluation is ordered behind
+int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot)
+{
+    region_tables* tp = g_reg.find(h);
+    if (!tp) return 0;
+    region_tables& t = *tp;
+    if (!t.d_state_cls || t.K != h->K) return remd_fail(h, -2, "alchemical regions: remd_set_region_lambdas has not been called for these states");
+    int rc = region_own_states(h, t);
+    if (rc) return rc;
+    remd_prof_scope ps(h, "alch_regions");
+    const int nchunk = (h->N + REGION_CHUNK - 1) / REGION_CHUNK;
+    hipLaunchKernelGGL(region_forces_kernel, dim3(t.c.n_alch * nchunk, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
+                       t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_force);
+    if (with_energy)
+        hipLaunchKernelGGL(region_energy_kernel, dim3(1, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
+                           t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_epart, h->n_epart, ep_slot);
+    REMD_CHECK(h, hipGetLastError());
+    return 0;
+}
+
+// the region terms at every state's lambdas: out[r][k]; *d_own = the replicas' own states on the device
+int remd_regions_ukl(remd_ctx* h, double* d_out, const int** d_own)
+{
+    region_tables* tp = g_reg.find(h);
+    if (!tp) return remd_fail(h, -2, "alchemical regions: none on this handle");
+    region_tables& t = *tp;
+    if (!t.d_state_cls || t.K != h->K) return remd_fail(h, -2, "alchemical regions: remd_set_region_lambdas has not been called for these states");
+    int rc = region_own_states(h, t);
+    if (rc) return rc;
+    remd_prof_scope ps(h, "alch_ukl");
+    hipLaunchKernelGGL(region_energy_kernel, dim3(h->K, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
+                       t.d_state_cls, (const int*)nullptr, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, d_out, h->K, 0);
+    REMD_CHECK(h, hipGetLastError());
+    *d_own = t.d_own;
+    return 0;
+}

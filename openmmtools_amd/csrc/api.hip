@@ -134,6 +134,7 @@ int remd_destroy(remd_handle h)
     remd_pme_destroy(h);
     remd_free_constraints(h);
     remd_free_nonbonded(h);
+    remd_regions_release(h);
     remd_mix_release(h);
     dfree(h->d_invmass); dfree(h->d_mass); dfree(h->d_ext_atoms);
     dfree(h->d_aterm); h->n_aterm = 0;
@@ -198,6 +199,8 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
     if (!h || !d) return remd_fail(h, -1, "remd_set_system: NULL argument");
     if (d->n_atoms <= 0 || !d->mass) return remd_fail(h, -1, "remd_set_system: n_atoms/mass missing");
     hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    remd_regions_release(h);                    // remd_set_alchemical_regions follows the system it belongs to
     h->N = d->n_atoms;
     h->Npad = (d->n_atoms + 63) / 64 * 64;
     std::vector<float> im(h->Npad, 0.f), m(h->Npad, 0.f);
@@ -567,6 +570,7 @@ static int phases_for(remd_ctx* h)
     //  * no communicator, no profiling of every class;
     //  * two blocks that are each worth a launch: 8 replicas or more per block unless asked for explicitly.
     if (!h->has_system || !h->has_integrator || !h->sysdesc || !h->sysdesc->valid) return 1;
+    if (h->n_regions > 0) return 1;             // general alchemical regions live on this handle only (alch_regions.hip)
     if (h->nb_method != REMD_NB_PME || !h->overlap || !h->stream2) return 1;
     if (h->baro_frequency > 0 || h->measure_heat || h->measure_shadow || h->profiling == 2 || h->comm) return 1;
     for (char c : h->tokens) if (c != 'V' && c != 'R' && c != 'O') return 1;

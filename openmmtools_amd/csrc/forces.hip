@@ -2023,7 +2023,9 @@ const float4* remd_nb_param(remd_ctx* h) { return g_nb[h].d_param; }
 int remd_nb_required_epart(remd_ctx* h)
 {
     const int ntile = (h->Npad + 63) / 64;
-    return EP_NB0 + ntile * 8 * 4 + 8 + ntile * 8 * 4;  // up to 4 slices per main cluster + 4 per LJ-sub-system cluster
+    // up to 4 slices per main cluster + 4 per LJ-sub-system cluster; the LAST slot belongs to the custom forces of general alchemical
+    // regions (alch_regions.hip)
+    return EP_NB0 + ntile * 8 * 4 + 8 + ntile * 8 * 4 + 1;
 }
 
 #define TUNE_SEG 40                       // one re-sort of the spatial order per segment (resort_interval)
@@ -2099,6 +2101,7 @@ int remd_nb_resident_info(remd_ctx* h, int* ok, int* method, int* has_alch, nb_p
 {
     *ok = 0; *method = -1; *has_alch = 0; *param = nullptr; *rep_lam = nullptr;
     if (h->nb_method == REMD_NB_NONE) { *ok = 1; return 0; }              // e.g. the harmonic oscillator: external force only
+    if (h->n_regions > 0) return 0;                                       // general alchemical regions: forces.hip + alch_regions.hip
     nb_tables* t = g_nb.find(h);
     if (!t || t->method != NB_LJ_ONLY || t->n_exc != 0 || t->n_excl != 0 || h->n_exceptions != 0) return 0;
     int rc = update_replica_lambdas(h, *t);
@@ -2123,6 +2126,9 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
         REMD_CHECK(h, hipMemsetAsync(h->d_epart, 0, sizeof(double) * (size_t)h->n_epart * h->R, h->stream));
     const int R = h->R;
 #define LAUNCH_E(kern, ...) do { if (with_energy) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
+    // custom forces of general alchemical regions (alch_regions.hip): part of the direct-space nonbonded class, launched here -- in
+    // front of the fork -- so that both branches of the evaluation are ordered behind them
+    if (h->n_regions > 0 && do_nb) { int rcr = remd_regions_forces(h, with_energy, h->n_epart - 1); if (rcr) return rcr; }
     if (h->n_ext > 0 && do_ext) {
         remd_prof_scope ps(h, "ext_force");
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
@@ -2358,6 +2364,19 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
     const double* alch = nullptr;
     nb_tables* it = g_nb.find(h);
     bool poly = false;
+    const int* d_own_states = nullptr;
+    if (it && h->n_regions > 0 && h->nb_method != REMD_NB_NONE) {
+        // general alchemical regions: the custom forces at every state's lambdas (d_potential holds them at the replicas' own)
+        nb_tables& t = *it;
+        if (t.alch_R != h->R || t.alch_K != h->K) {
+            dfree(t.d_alch_ukl); dfree(t.d_state_lam); dfree(t.d_own);
+            REMD_CHECK(h, hipMalloc(&t.d_alch_ukl, sizeof(double) * (size_t)n));
+            t.alch_R = h->R; t.alch_K = h->K;
+        }
+        int rc = remd_regions_ukl(h, t.d_alch_ukl, &d_own_states);
+        if (rc) return rc;
+        alch = t.d_alch_ukl;
+    } else
     if (it && it->has_alch && h->nb_method != REMD_NB_NONE) {
         nb_tables& t = *it;
         if (t.alch_R != h->R || t.alch_K != h->K) {
@@ -2383,7 +2402,7 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
                                h->d_alch_atoms, h->d_pos, t.d_param, h->d_box, h->K, t.d_state_lam, t.d_alch_ukl,
                                t.n_exc, t.d_exc_atoms, t.d_exc_params, t.d_exc_alch, t.d_mask);
         }
-        alch = t.d_alch_ukl;
+        alch = t.d_alch_ukl; d_own_states = t.d_own;
         // lambda_electrostatics states need the polynomial only when alchemical atoms carry charge
         bool lam_e_varies = false;
         for (int k = 0; k < h->K; ++k) lam_e_varies |= (h->lam_e[k] != h->lam_e[0]) || (h->lam_e[k] != 1.0);
@@ -2407,7 +2426,7 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
         }
     }
     hipLaunchKernelGGL(assemble_ukl_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K,
-                       h->d_potential, h->d_beta, h->d_econst, alch, alch ? it->d_own : (const int*)nullptr, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr, h->d_box, h->econst_vref, d_rows);
+                       h->d_potential, h->d_beta, h->d_econst, alch, alch ? d_own_states : (const int*)nullptr, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr, h->d_box, h->econst_vref, d_rows);
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }

@@ -146,6 +146,7 @@ struct remd_ctx {
     // alchemy
     int n_alch = 0; int* d_alch_atoms = nullptr;
     double sc_alpha = 0.5, sc_a = 1, sc_b = 1, sc_c = 6;
+    int n_regions = 0;                 // remd_set_alchemical_regions: general regions (alch_regions.hip holds the tables)
 
     // ---- states ---------------------------------------------------------------------
     int K = 0;
@@ -345,6 +346,10 @@ void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluati
 #define REMD_FG_TORSION 3
 #define REMD_FG_NONBONDED 4      /* direct space, exceptions, Ewald exclusion correction */
 #define REMD_FG_RECIPROCAL 5
+// alch_regions.hip: custom forces of general alchemical regions
+void remd_regions_release(remd_ctx* h);
+int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot);
+int remd_regions_ukl(remd_ctx* h, double* d_out /*[R][K]*/, const int** d_own);
 int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask = ~0u);   // fills d_force (and d_potential when with_energy)
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d);
 int remd_build_constraints(remd_ctx* h, const remd_system_desc* d);

@@ -600,12 +600,16 @@ class MultiStateSampler:
         from ..system import NonbondedForce
         from ..alchemy import alchemical_long_range_constants
         system = states[0].system
-        if getattr(system, 'alchemical_region', None) is None:
+        regions = getattr(system, 'alchemical_regions', None)
+        if getattr(system, 'alchemical_region', None) is None and regions is None:
             return np.zeros(len(states))
         nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)]
         if not nb or not nb[0].usesPeriodicBoundaryConditions():
             return np.zeros(len(states))
         volume = self._sampler_states[0].volume
+        if regions is not None:               # general regions: one lambda_sterics per region and state
+            lam = [s.region_lambdas([r.name for r in regions])[0] for s in states]
+            return alchemical_long_range_constants(system, nb[0], lam, volume)
         return alchemical_long_range_constants(system, nb[0], [s.lambda_sterics for s in states], volume)
 
     def _initialize_engine(self):
@@ -634,7 +638,7 @@ class MultiStateSampler:
         from ..states import group_by_compatibility
         groups, group_indices = group_by_compatibility(all_states)
         if len(groups) > 1:
-            if any(getattr(g[0].system, 'alchemical_region', None) is not None for g in groups):
+            if any(getattr(g[0].system, 'alchemical_region', None) is not None or getattr(g[0].system, 'alchemical_regions', None) is not None for g in groups):
                 raise NotImplementedError('alchemical states in more than one compatibility group')
             from ._engine_pool import EnginePool
             if not isinstance(self._engine, EnginePool):
@@ -648,6 +652,12 @@ class MultiStateSampler:
         lam_s = np.array([s.lambda_sterics for s in all_states], dtype=np.float64)
         lam_e = np.array([s.lambda_electrostatics for s in all_states], dtype=np.float64)
         eng.set_states(beta, lam_s, lam_e, self._state_energy_constants(all_states))
+        regions = getattr(ref.system, 'alchemical_regions', None)
+        if regions is not None:
+            # general alchemical regions (alchemy.py here; csrc/alch_regions.hip): every region's lambdas at every state
+            names = [r.name for r in regions]
+            lams = [s.region_lambdas(names) for s in all_states]
+            eng.set_region_lambdas(np.array([l[0] for l in lams], dtype=np.float64), np.array([l[1] for l in lams], dtype=np.float64))
         self._program_engine_move()
         pressures = [s.pressure for s in all_states]
         if any(p is not None for p in pressures):

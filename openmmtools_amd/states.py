@@ -210,6 +210,9 @@ class ThermodynamicState:
     lambda_sterics = 1.0
     lambda_electrostatics = 1.0
 
+    def region_lambdas(self, names):
+        return [1.0] * len(names), [1.0] * len(names)
+
     def __setstate__(self, state):
         """States pickled before ``pressure`` / ``temperature`` became properties (storage format 'openmmtools_amd-records-1'
         of earlier revisions) carry the plain attribute names: map them onto the backing fields so that old stores resume."""
@@ -260,9 +263,27 @@ class AlchemicalStateError(ValueError):
 
 
 class AlchemicalState:
-    """lambda_sterics / lambda_electrostatics carrier (alchemy.py:86-410, only these two)."""
+    """lambda_sterics / lambda_electrostatics carrier (alchemy.py:86-410, only these two).  ``parameters_name_suffix`` (states.py:3149-3181,
+    alchemy.py:203-231): the state of the alchemical region of that name -- its parameters are then also reachable as
+    ``lambda_sterics_<suffix>`` / ``lambda_electrostatics_<suffix>``, the names the factory gives the region's global parameters
+    (alchemy.py:1360-1377)."""
 
-    def __init__(self, lambda_sterics=1.0, lambda_electrostatics=1.0, lambda_bonds=1.0, lambda_angles=1.0, lambda_torsions=1.0):
+    _PARAMETERS = ('lambda_sterics', 'lambda_electrostatics')
+
+    def __init__(self, lambda_sterics=1.0, lambda_electrostatics=1.0, lambda_bonds=1.0, lambda_angles=1.0, lambda_torsions=1.0,
+                 parameters_name_suffix=None, **kwargs):
+        object.__setattr__(self, 'parameters_name_suffix', parameters_name_suffix)
+        for key, value in kwargs.items():                       # lambda_sterics_<suffix>=... as the reference's constructor takes them
+            base = self._base_name(key)
+            if base == 'lambda_sterics':
+                lambda_sterics = value
+            elif base == 'lambda_electrostatics':
+                lambda_electrostatics = value
+            elif base in ('lambda_bonds', 'lambda_angles', 'lambda_torsions'):
+                if value is not None and float(value) != 1.0:
+                    raise NotImplementedError('%s != 1: alchemically modified bonded terms are not built' % base)
+            else:
+                raise AlchemicalStateError('Unknown parameters %r' % key)                    # states.py:3170-3172
         self.lambda_sterics = float(lambda_sterics)
         self.lambda_electrostatics = float(lambda_electrostatics)
         # alchemy.py:196-199: the factory here does not soften bonded terms (alchemical_bonds / angles / torsions), so these
@@ -272,6 +293,23 @@ class AlchemicalState:
                 raise NotImplementedError('%s != 1: alchemically modified bonded terms are not built' % name)
 
     lambda_bonds = lambda_angles = lambda_torsions = 1.0
+    parameters_name_suffix = None
+
+    def _base_name(self, name):
+        sfx = self.parameters_name_suffix
+        if sfx is not None and name.endswith('_' + sfx):
+            return name[:-len(sfx) - 1]
+        return name
+
+    def __getattr__(self, name):                      # only reached for names that are not plain attributes
+        base = self._base_name(name) if not name.startswith('__') else name
+        if base != name and base in self._PARAMETERS:
+            return self.__dict__[base]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        base = self._base_name(name)
+        object.__setattr__(self, base if base in self._PARAMETERS else name, float(value) if base in self._PARAMETERS else value)
 
     def set_alchemical_parameters(self, new_value):
         """alchemy.py:247-262: every alchemical parameter this state controls to ``new_value``."""
@@ -281,61 +319,113 @@ class AlchemicalState:
         self.lambda_sterics = v
         self.lambda_electrostatics = v
 
-    _PARAMETERS = ('lambda_sterics', 'lambda_electrostatics')
+    @staticmethod
+    def _has_region(system, suffix):
+        regions = getattr(system, 'alchemical_regions', None)
+        if regions is not None:
+            return any(r.name == suffix for r in regions)
+        region = getattr(system, 'alchemical_region', None)
+        return region is not None and (region.name == suffix or suffix is None or region.name is None)
 
     @classmethod
-    def from_system(cls, system, *args, **kwargs):
+    def from_system(cls, system, *args, parameters_name_suffix=None, **kwargs):
         """alchemy.py:203-231: the state a System's alchemical parameters stand at (those written by apply_to_system, else the
-        interacting end state the factory creates); a System without an alchemical region has none."""
-        if getattr(system, 'alchemical_region', None) is None:
-            raise AlchemicalStateError('system has no alchemical region')
-        stored = getattr(system, 'alchemical_parameters', None) or {}
-        return cls(*args, **dict({k: stored.get(k, 1.0) for k in cls._PARAMETERS}, **kwargs))
+        interacting end state the factory creates); a System without an alchemical region (of that name) has none."""
+        if not cls._has_region(system, parameters_name_suffix):
+            raise AlchemicalStateError('system has no alchemical region' + ('' if parameters_name_suffix is None else ' named %r' % parameters_name_suffix))
+        stored = (getattr(system, 'alchemical_parameters', None) or {}).get(parameters_name_suffix, {})
+        return cls(*args, parameters_name_suffix=parameters_name_suffix, **dict({k: stored.get(k, 1.0) for k in cls._PARAMETERS}, **kwargs))
 
     def apply_to_system(self, system):
         """alchemy.py:354-373: the System's own alchemical parameters (what a state read back with from_system starts from) set to
         this state's.  The engine takes lambdas from the thermodynamic states, not from the System."""
-        if getattr(system, 'alchemical_region', None) is None:
+        if not self._has_region(system, self.parameters_name_suffix):
             raise AlchemicalStateError('system has no alchemical region')
-        system.alchemical_parameters = {k: float(getattr(self, k)) for k in self._PARAMETERS}
+        stored = dict(getattr(system, 'alchemical_parameters', None) or {})
+        stored[self.parameters_name_suffix] = {k: float(getattr(self, k)) for k in self._PARAMETERS}
+        system.alchemical_parameters = stored
 
     def check_system_consistency(self, system):
         """alchemy.py:375-393: AlchemicalStateError unless the System's alchemical parameters equal this state's."""
-        other = type(self).from_system(system)
+        other = type(self).from_system(system, parameters_name_suffix=self.parameters_name_suffix)
         for k in self._PARAMETERS:
             if float(getattr(other, k)) != float(getattr(self, k)):
                 raise AlchemicalStateError('system has %s = %r, the state %r' % (k, getattr(other, k), getattr(self, k)))
 
 
 class CompoundThermodynamicState(ThermodynamicState):
-    """states.py:2524-3046 restricted to one AlchemicalState composable state."""
+    """states.py:2524-3046 restricted to AlchemicalState composable states: one (any suffix), or one per named alchemical region."""
 
     def __init__(self, thermodynamic_state, composable_states):
         super().__init__(thermodynamic_state.system, thermodynamic_state.temperature, thermodynamic_state.pressure)
-        if len(composable_states) != 1 or not isinstance(composable_states[0], AlchemicalState):
-            raise NotImplementedError('only a single AlchemicalState composable state is supported')
-        self._alch = copy.copy(composable_states[0])
+        if len(composable_states) < 1 or not all(isinstance(c, AlchemicalState) for c in composable_states):
+            raise NotImplementedError('only AlchemicalState composable states are supported')
+        suffixes = [c.parameters_name_suffix for c in composable_states]
+        if len(set(suffixes)) != len(suffixes):
+            raise ValueError('composable states control the same parameters')                 # states.py:2574-2590
+        object.__setattr__(self, '_alchs', [copy.copy(c) for c in composable_states])
 
     @property
-    def lambda_sterics(self):
-        return self._alch.lambda_sterics
+    def _alch(self):
+        return self._alchs[0]
 
-    @lambda_sterics.setter
-    def lambda_sterics(self, v):
-        self._alch.lambda_sterics = float(v)
+    def _owner(self, name):
+        """the composable state that answers to the attribute ``name`` (plain or suffixed), or None"""
+        for c in self.__dict__.get('_alchs', ()):
+            sfx = c.parameters_name_suffix
+            if name in AlchemicalState._PARAMETERS and (sfx is None or len(self._alchs) == 1):
+                return c, name
+            if sfx is not None and name.endswith('_' + sfx) and name[:-len(sfx) - 1] in AlchemicalState._PARAMETERS:
+                return c, name[:-len(sfx) - 1]
+        return None
+
+    # (the plain names shadow the end-state class attributes of ThermodynamicState)
+    @property
+    def lambda_sterics(self):
+        hit = self._owner('lambda_sterics')
+        return 1.0 if hit is None else getattr(hit[0], hit[1])
 
     @property
     def lambda_electrostatics(self):
-        return self._alch.lambda_electrostatics
+        hit = self._owner('lambda_electrostatics')
+        return 1.0 if hit is None else getattr(hit[0], hit[1])
 
-    @lambda_electrostatics.setter
-    def lambda_electrostatics(self, v):
-        self._alch.lambda_electrostatics = float(v)
+    def __getattr__(self, name):
+        if not name.startswith('_'):
+            hit = self._owner(name)
+            if hit is not None:
+                return getattr(hit[0], hit[1])
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        hit = None if name.startswith('_') else self._owner(name)
+        if hit is not None:
+            setattr(hit[0], hit[1], float(value))
+        else:
+            object.__setattr__(self, name, value)
+
+    def region_lambdas(self, names):
+        """(lambda_sterics, lambda_electrostatics) of the alchemical regions ``names`` at this state: the composable state with that
+        suffix (a single unsuffixed state answers for a single region)."""
+        ls, le = [], []
+        for nm in names:
+            c = next((c for c in self._alchs if c.parameters_name_suffix == nm), None)
+            if c is None and len(self._alchs) == 1 and len(names) == 1:
+                c = self._alchs[0]
+            ls.append(1.0 if c is None else c.lambda_sterics)
+            le.append(1.0 if c is None else c.lambda_electrostatics)
+        return ls, le
 
     def __deepcopy__(self, memo):
         new = copy.copy(self)
-        new._alch = copy.copy(self._alch)
+        object.__setattr__(new, '_alchs', [copy.copy(c) for c in self._alchs])
         return new
+
+    def __setstate__(self, state):
+        state = dict(state)
+        if '_alch' in state and '_alchs' not in state:           # stores written before several composable states were carried
+            state['_alchs'] = [state.pop('_alch')]
+        super().__setstate__(state)
 
 
 class SamplerState:

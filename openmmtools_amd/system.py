@@ -221,7 +221,8 @@ class System:
         self.forces = []
         self.constraints = []
         self._box = ((2.0, 0.0, 0.0), (0.0, 2.0, 0.0), (0.0, 0.0, 2.0))
-        self.alchemical_region = None     # set by alchemy.AbsoluteAlchemicalFactory
+        self.alchemical_region = None     # set by alchemy.AbsoluteAlchemicalFactory (one region on the pair kernels' own path)
+        self.alchemical_regions = None    # ... general regions: the factory's force split (alchemical_region_terms, csrc/alch_regions.hip)
 
     def addParticle(self, mass):
         self.masses.append(float(mass))
@@ -267,12 +268,17 @@ class System:
 
     def fingerprint(self):
         """Stable hash of the system's content (stand-in for the XML hash, states.py:1492-1495)."""
-        d = system_to_desc(self)
         hsh = hashlib.sha1()
-        for key in sorted(d):
-            v = d[key]
-            hsh.update(key.encode())
-            hsh.update(np.ascontiguousarray(v).tobytes() if isinstance(v, np.ndarray) else repr(v).encode())
+
+        def feed(d):
+            for key in sorted(d):
+                v = d[key]
+                hsh.update(key.encode())
+                if isinstance(v, dict):
+                    feed(v)
+                else:
+                    hsh.update(np.ascontiguousarray(v).tobytes() if isinstance(v, np.ndarray) else repr(v).encode())
+        feed(system_to_desc(self))
         return hsh.hexdigest()
 
 
@@ -495,6 +501,10 @@ def system_to_desc(system, box=None, ewald_split=None, min_edge=None):
         d['alch_atoms'] = np.zeros(0, np.int32)
         d['softcore'] = (0.5, 1.0, 1.0, 6.0)
         d['annihilate_sterics'] = False
+    if getattr(system, 'alchemical_regions', None) is not None:
+        # general regions: this descriptor is the NonbondedForce the factory leaves behind, the custom forces follow through
+        # remd_set_alchemical_regions (alchemy.AbsoluteAlchemicalFactory._region_terms)
+        d['alch_regions'] = dict(system.alchemical_region_terms)
     return d
 
 

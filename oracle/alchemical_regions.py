@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE (oracle): f64 restatement of the custom forces the reference's AbsoluteAlchemicalFactory builds for general
+alchemical regions -- /root/reference/openmmtools/alchemy/alchemy.py:1539-2038 (_alchemically_modify_NonbondedForce) with the energy
+expressions of :1356-1390 (sterics), :1392-1471 (electrostatics), :1473-1508 (reaction field), :1510-1537 (Ewald direct space).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this; the product path (csrc/alch_regions.hip) never does.
+
+Pinned by tests/test_alchemical_regions.py against tests/golden/reference_alchemy_expressions.json: values of the reference's OWN
+expression strings (taken out of its syntax tree by tests/golden/make_golden_alchemy_strings.py) on a grid of distances, charges,
+soft-core constants and lambdas.
+
+``terms`` = the dict openmmtools_amd.alchemy.AbsoluteAlchemicalFactory._region_terms returns (system_to_desc(...)['alch_regions']):
+    region_of_atom [N] (0 = environment), softcore [n][8] = alpha, beta, a, b, c, d, e, f, annihilate [n][2] = sterics, electrostatics,
+    interactions [m][2] (1-based), charge / sigma / epsilon [N] of the REFERENCE NonbondedForce, the exceptions that became custom bonds,
+    electrostatics 0 / 1, elec_alpha, elec_krf, elec_crf, elec_switch_distance.
+Total potential of an alchemical System in that mode = ForceFieldOracle(descriptor of the factory's NonbondedForce + bonded forces)
++ RegionOracle (this file).
+"""
+import numpy as np
+import torch
+
+ONE_4PI_EPS0 = 138.93545764438198
+
+
+class RegionOracle:
+    def __init__(self, terms, cutoff, switch_distance, exclusions):
+        """cutoff / switch_distance (< 0 or None: no switch): the NonbondedForce's; exclusions: every exception pair of the System
+        (the custom nonbonded forces exclude them all, alchemy.py:1944-1947)."""
+        t = terms
+        self.g = np.asarray(t['region_of_atom'], dtype=int)
+        self.N = len(self.g)
+        self.sc = np.asarray(t['softcore'], dtype=np.float64).reshape(-1, 8)
+        self.ann = np.asarray(t['annihilate'], dtype=int).reshape(-1, 2)
+        self.n = len(self.sc)
+        self.inter = [(int(a), int(b)) for a, b in np.asarray(t['interactions'], dtype=int).reshape(-1, 2)]
+        self.q = np.asarray(t['charge'], dtype=np.float64)
+        self.sig = np.asarray(t['sigma'], dtype=np.float64)
+        self.eps = np.asarray(t['epsilon'], dtype=np.float64)
+        self.exc_atoms = np.asarray(t['exception_atoms'], dtype=int).reshape(-1, 2)
+        self.exc_params = np.asarray(t['exception_params'], dtype=np.float64).reshape(-1, 3)
+        self.elec = bool(t['electrostatics'])
+        self.alpha, self.krf, self.crf = float(t['elec_alpha']), float(t['elec_krf']), float(t['elec_crf'])
+        self.rs_e = float(t['elec_switch_distance'])
+        self.rc = float(cutoff)
+        self.rs = -1.0 if switch_distance is None else float(switch_distance)
+        excl = set((min(int(i), int(j)), max(int(i), int(j))) for i, j in exclusions)
+        # the candidate pairs: (alchemical, environment) and alchemical pairs once, of regions that interact, not excluded
+        alch = np.nonzero(self.g)[0]
+        pairs, kinds = [], []
+        for a in alch:
+            for j in range(self.N):
+                if j == a or (self.g[j] > 0 and j < a) or (min(a, j), max(a, j)) in excl:
+                    continue
+                k = self._class(self.g[a], self.g[j])
+                if k is None:
+                    continue
+                pairs.append((a, j)); kinds.append(k)
+        self.pairs = np.array(pairs, dtype=int).reshape(-1, 2)
+        self.kinds = kinds
+        self.exc_kinds = [self._class(self.g[i], self.g[j]) for i, j in self.exc_atoms]
+
+    def _class(self, ga, gb):
+        """(kind, a, b, P): kind 0 (environment, a), 1 (a, a), 2 (a, b) interacting; P = region of the soft-core constants (1-based)"""
+        if ga == 0 or gb == 0:
+            y = max(ga, gb)
+            return (0, y, y, y)
+        if ga == gb:
+            return (1, ga, ga, ga)
+        for a, b in self.inter:
+            if {a, b} == {ga, gb}:
+                return (2, a, b, b)
+        return None
+
+    def _lambdas(self, cls, ls, le):
+        kind, a, b, _ = cls
+        if kind == 0:
+            return ls[a - 1], le[a - 1]
+        if kind == 1:
+            return (ls[a - 1] if self.ann[a - 1, 0] else 1.0), (le[a - 1] if self.ann[a - 1, 1] else 1.0)
+        return ls[a - 1] * ls[b - 1], le[a - 1] * le[b - 1]
+
+    @staticmethod
+    def _switch(r, rs, rc):
+        if rs is None or rs < 0 or rs >= rc:
+            return torch.ones_like(r)
+        x = torch.clamp((r - rs) / (rc - rs), 0.0, 1.0)
+        return 1.0 - 10.0 * x ** 3 + 15.0 * x ** 4 - 6.0 * x ** 5
+
+    def _sterics(self, r, sigma, eps, l, P):
+        alpha, _, a, b, c = self.sc[P - 1][:5]
+        reff = sigma * (alpha * (1.0 - l) ** b + (r / sigma) ** c) ** (1.0 / c)                 # alchemy.py:1388
+        x = (sigma / reff) ** 6
+        return (l ** a) * 4.0 * eps * x * (x - 1.0)                                              # :1385-1386
+
+    def _electrostatics(self, r, sigma, qq, l, P, alpha, krf, crf):
+        beta, d, e, f = self.sc[P - 1][1], self.sc[P - 1][5], self.sc[P - 1][6], self.sc[P - 1][7]
+        reff = sigma * (beta * (1.0 - l) ** e + (r / sigma) ** f) ** (1.0 / f)                  # :1429
+        g = (torch.erfc(alpha * reff) if alpha > 0 else torch.ones_like(reff)) / reff + krf * reff ** 2 - crf      # :1434, 1505-1507, 1534-1536
+        return (l ** d) * ONE_4PI_EPS0 * qq * g                                                  # :1425-1426
+
+    def energy_torch(self, x, box, ls, le):
+        """x: torch [N][3]; box: edge lengths or None; ls / le: lambda_sterics / lambda_electrostatics per region."""
+        e = x.new_zeros(())
+        box_t = None if box is None else torch.tensor(np.asarray(box, dtype=np.float64))
+        if len(self.pairs):
+            i, j = self.pairs[:, 0], self.pairs[:, 1]
+            d = x[j] - x[i]
+            if box_t is not None:
+                d = d - box_t * torch.round(d / box_t)
+            r = d.norm(dim=1)
+            inside = r < self.rc
+            sigma = torch.tensor(0.5 * (self.sig[i] + self.sig[j]))
+            eps = torch.tensor(np.sqrt(self.eps[i] * self.eps[j]))
+            qq = torch.tensor(self.q[i] * self.q[j])
+            for cls in sorted(set(self.kinds)):
+                m = torch.tensor([k == cls for k in self.kinds]) & inside
+                if not bool(m.any()):
+                    continue
+                l_s, l_e = self._lambdas(cls, ls, le)
+                rr = r[m]
+                u = self._sterics(rr, sigma[m], eps[m], l_s, cls[3]) * self._switch(rr, self.rs, self.rc)
+                e = e + torch.where(eps[m] != 0, u, torch.zeros_like(u)).sum()
+                if self.elec:
+                    u = self._electrostatics(rr, sigma[m], qq[m], l_e, cls[3], self.alpha, self.krf, self.crf) * self._switch(rr, self.rs_e, self.rc)
+                    e = e + torch.where(qq[m] != 0, u, torch.zeros_like(u)).sum()
+        for t, (i, j) in enumerate(self.exc_atoms):
+            qq, sg, ep = self.exc_params[t]
+            d = x[j] - x[i]
+            if box_t is not None:
+                d = d - box_t * torch.round(d / box_t)
+            r = d.norm().reshape(1)
+            l_s, l_e = self._lambdas(self.exc_kinds[t], ls, le)
+            sg_t = torch.tensor([sg])
+            if ep != 0.0:
+                e = e + self._sterics(r, sg_t, torch.tensor([ep]), l_s, self.exc_kinds[t][3]).sum()
+            if self.elec and qq != 0.0:
+                e = e + self._electrostatics(r, sg_t, torch.tensor([qq]), l_e, self.exc_kinds[t][3], 0.0, 0.0, 0.0).sum()      # :1434, 1456-1461
+        return e
+
+    def energy_forces(self, x, box, ls, le, forces=True):
+        xt = torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=forces)
+        e = self.energy_torch(xt, box, ls, le)
+        if not forces or not e.requires_grad:
+            return float(e.detach()), np.zeros((self.N, 3))
+        (g,) = torch.autograd.grad(e, xt)
+        return float(e.detach()), -g.numpy()
+
+    def state_energies(self, x, box, LS, LE):
+        """the region terms at every state's lambdas: LS / LE [K][n]"""
+        xt = torch.tensor(np.asarray(x, dtype=np.float64))
+        return np.array([float(self.energy_torch(xt, box, ls, le)) for ls, le in zip(LS, LE)])
+
+
+def total_state_energies(desc, x, box, LS, LE):
+    """Potential of an alchemical System in the general-regions mode at every state: the factory's NonbondedForce + bonded terms
+    (ForceFieldOracle on the descriptor) + the custom forces."""
+    from .forcefield import ForceFieldOracle
+    base = ForceFieldOracle(desc)
+    reg = RegionOracle(desc['alch_regions'], desc['cutoff'], desc['switch_distance'] if desc['switch_distance'] > 0 else None,
+                       np.asarray(desc['exception_atoms']).reshape(-1, 2))
+    e0 = base.potential(x, box)
+    return e0 + reg.state_energies(x, box, LS, LE)
+
+
+def total_energy_forces(desc, x, box, ls, le):
+    from .forcefield import ForceFieldOracle
+    base = ForceFieldOracle(desc)
+    reg = RegionOracle(desc['alch_regions'], desc['cutoff'], desc['switch_distance'] if desc['switch_distance'] > 0 else None,
+                       np.asarray(desc['exception_atoms']).reshape(-1, 2))
+    e0, f0 = base.energy_forces(x, box)
+    e1, f1 = reg.energy_forces(x, box, ls, le)
+    return e0 + e1, f0 + f1

@@ -196,6 +196,16 @@ struct System {
     int n_dof = 0;
     std::vector<std::vector<int>> molecules;      // connected components over exceptions, bonds, constraints (barostat scaling units)
     double settle_ra = 0, settle_rb = 0, settle_rc = 0, settle_dHH = 0, settle_mO = 0, settle_mH = 0;
+    // general alchemical regions (remd_set_alchemical_regions): the custom forces of alchemy.py:1539-2038
+    struct RegionClass { int kind, a, b, P; };   // (environment, a) / (a, a) / (a, b) interacting; P: region of the soft-core constants
+    struct Regions {
+        int n = 0, K = 0;
+        std::vector<int> region_of, alch, annihilate, cls_of, exc_atoms, exc_cls;
+        std::vector<double> softcore, q, sig, eps, exc_params, ls, le;
+        std::vector<RegionClass> classes;
+        std::vector<std::vector<char>> skip;      // per alchemical atom: candidates that are never evaluated
+        bool elec = false; double alpha = 0, krf = 0, crf = 0, rs_e = -1;
+    } reg;
 };
 
 double M_spline(int o, double u) {                // cardinal B-spline of order o at u
@@ -463,6 +473,87 @@ double pme_reciprocal(const System& s, Replica& r, const std::vector<double>& qv
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// custom forces of general alchemical regions at the lambdas of state `state` (include/remd_hip.h: remd_set_alchemical_regions;
+// alchemy.py:1356-1537 expressions, :1539-2038 force split): all (alchemical atom, atom) pairs inside the cutoff + the exceptions
+// ------------------------------------------------------------------------------------------------------------------
+static inline void region_switch(double rs, double rc, double rr, double& e, double& dedr)
+{
+    if (rs >= 0 && rs < rc && rr > rs) {
+        const double t = (rr - rs) / (rc - rs);
+        const double S = 1.0 - 10.0 * t * t * t + 15.0 * t * t * t * t - 6.0 * t * t * t * t * t;
+        const double dS = (-30.0 * t * t + 60.0 * t * t * t - 30.0 * t * t * t * t) / (rc - rs);
+        dedr = dedr * S + e * dS; e *= S;
+    }
+}
+static inline void region_class_lambdas(const System::Regions& g, const System::RegionClass& c, int state, double& l_s, double& l_e)
+{
+    const double* ls = &g.ls[(size_t)state * g.n]; const double* le = &g.le[(size_t)state * g.n];
+    if (c.kind == 0) { l_s = ls[c.a - 1]; l_e = le[c.a - 1]; }
+    else if (c.kind == 1) { l_s = g.annihilate[2 * (c.a - 1)] ? ls[c.a - 1] : 1.0; l_e = g.annihilate[2 * (c.a - 1) + 1] ? le[c.a - 1] : 1.0; }
+    else { l_s = ls[c.a - 1] * ls[c.b - 1]; l_e = le[c.a - 1] * le[c.b - 1]; }
+}
+static inline void region_sterics(const double* sc, double l, double sg, double ep, double rr, double& e, double& dedr)
+{
+    const double a = sc[2], b = sc[3], c = sc[4];
+    const double t = pow(rr / sg, c), base = sc[0] * pow(1.0 - l, b) + t, x = pow(base, -6.0 / c), la = pow(l, a);
+    e = la * 4.0 * ep * x * (x - 1.0);
+    dedr = la * 4.0 * ep * (2.0 * x - 1.0) * (-6.0 * x / base * t / rr);
+}
+static inline void region_elec(const double* sc, double l, double alpha, double krf, double crf, double sg, double qq, double rr, double& e, double& dedr)
+{
+    const double d = sc[5], ee = sc[6], f = sc[7];
+    const double t = pow(rr / sg, f), base = sc[1] * pow(1.0 - l, ee) + t, reff = sg * pow(base, 1.0 / f), ld = pow(l, d);
+    double g, dg;
+    if (alpha > 0) { const double ar = alpha * reff, ec = erfc(ar); g = ec / reff; dg = -(ec / reff + 2.0 * alpha / sqrt(PI) * exp(-ar * ar)) / reff; }
+    else { g = 1.0 / reff; dg = -1.0 / (reff * reff); }
+    g += krf * reff * reff - crf; dg += 2.0 * krf * reff;
+    e = ld * ONE_4PI_EPS0 * qq * g;
+    dedr = ld * ONE_4PI_EPS0 * qq * dg * (reff / base * t / rr);
+}
+double region_energy(const System& s, const Replica& r, int state, double* f)
+{
+    const System::Regions& g = s.reg;
+    if (g.n == 0) return 0.0;
+    const double* x = r.x.data();
+    const double rc2 = s.rc * s.rc;
+    double E = 0.0;
+    for (size_t ia = 0; ia < g.alch.size(); ++ia) {
+        const int a = g.alch[ia];
+        const std::vector<char>& skip = g.skip[ia];
+        for (int j = 0; j < s.N; ++j) {
+            if (skip[j]) continue;
+            double d[3];
+            for (int k = 0; k < 3; ++k) d[k] = min_image(x[3 * j + k] - x[3 * a + k], r.box[k]);
+            const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            if (r2 >= rc2) continue;
+            const System::RegionClass& c = g.classes[g.cls_of[(size_t)g.region_of[a] * (g.n + 1) + g.region_of[j]]];
+            const double* sc = &g.softcore[8 * (size_t)(c.P - 1)];
+            double l_s, l_e; region_class_lambdas(g, c, state, l_s, l_e);
+            const double rr = sqrt(r2), sg = 0.5 * (g.sig[a] + g.sig[j]), ep = sqrt(g.eps[a] * g.eps[j]), qq = g.q[a] * g.q[j];
+            double dedr = 0.0;
+            if (ep != 0.0) { double e, de; region_sterics(sc, l_s, sg, ep, rr, e, de); region_switch(s.rs, s.rc, rr, e, de); E += e; dedr += de; }
+            if (g.elec && qq != 0.0) { double e, de; region_elec(sc, l_e, g.alpha, g.krf, g.crf, sg, qq, rr, e, de); region_switch(g.rs_e, s.rc, rr, e, de); E += e; dedr += de; }
+            if (f && dedr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * a + k] += dedr / rr * d[k]; f[3 * j + k] -= dedr / rr * d[k]; }
+        }
+    }
+    for (size_t e2 = 0; e2 < g.exc_cls.size(); ++e2) {
+        const int i = g.exc_atoms[2 * e2], j = g.exc_atoms[2 * e2 + 1];
+        double d[3];
+        for (int k = 0; k < 3; ++k) { d[k] = x[3 * j + k] - x[3 * i + k]; if (s.method != 0) d[k] = min_image(d[k], r.box[k]); }
+        const double rr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const System::RegionClass& c = g.classes[g.exc_cls[e2]];
+        const double* sc = &g.softcore[8 * (size_t)(c.P - 1)];
+        double l_s, l_e; region_class_lambdas(g, c, state, l_s, l_e);
+        const double qq = g.exc_params[3 * e2], sg = g.exc_params[3 * e2 + 1], ep = g.exc_params[3 * e2 + 2];
+        double dedr = 0.0;
+        if (ep != 0.0) { double e, de; region_sterics(sc, l_s, sg, ep, rr, e, de); E += e; dedr += de; }
+        if (g.elec && qq != 0.0) { double e, de; region_elec(sc, l_e, 0.0, 0.0, 0.0, sg, qq, rr, e, de); E += e; dedr += de; }
+        if (f && dedr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * i + k] += dedr / rr * d[k]; f[3 * j + k] -= dedr / rr * d[k]; }
+    }
+    return E;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // potential energy and forces of one replica at (lambda_sterics, lambda_electrostatics)
 //   parts: which contributions to evaluate (the u_kl assembly re-evaluates only what a lambda changes)
 // ------------------------------------------------------------------------------------------------------------------
@@ -471,7 +562,7 @@ enum { PART_BONDED = 1, PART_STERICS = 2, PART_SOFTCORE = 4, PART_ELEC = 8, PART
 // classes: bit c set = force class c of remd_set_force_groups is evaluated (0 external, 1 bonds, 2 angles, 3 torsions, 4 nonbonded direct space +
 // exceptions + exclusion correction + dispersion constant, 5 PME reciprocal space + self terms): the forces of one force group of a
 // multiple-time-step splitting (integrators.py:1425-1442; same convention as oracle/forcefield.py energy_torch)
-Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double* f, FFTSet& fft, int parts = PART_ALL, int classes = 63)
+Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double* f, FFTSet& fft, int parts = PART_ALL, int classes = 63, int region_state = -1)
 {
     Energy E;
     const int N = s.N;
@@ -658,6 +749,8 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
         }
     }
     if ((classes & 16) && (parts & PART_STERICS)) E.c[7] += s.disp_coeff / V;
+    // custom forces of general alchemical regions, at the lambdas of state region_state (part of the direct-space nonbonded class)
+    if (s.reg.n > 0 && region_state >= 0 && region_state < s.reg.K && (classes & 16) && (parts & PART_SOFTCORE)) E.c[8] += region_energy(s, r, region_state, f);
     if ((classes & 32) && elec && s.method == REMD_NB_PME) {
         const double tp0 = g_time ? now_ms() : 0;
         E.c[6] += pme_reciprocal(s, r, qv, f, fft);
@@ -888,7 +981,7 @@ static void ensure_forces(remd_ctx* h, int r)
     Replica& rep = h->reps[r];
     if (rep.f_valid) return;
     const int64_t k = h->labels[h->r_begin + r];
-    evaluate(h->sys, rep, h->lam_s[k], h->lam_e[k], rep.f.data(), thread_fft(h));
+    evaluate(h->sys, rep, h->lam_s[k], h->lam_e[k], rep.f.data(), thread_fft(h), PART_ALL, 63, (int)k);
     rep.f_valid = true;
 }
 
@@ -914,7 +1007,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
     for (char c : tokens) braces |= (c == '}');
     const bool m_heat = h->measure_heat != 0, m_shadow = h->measure_shadow != 0 || braces;
     auto ke = [&]() { double e = 0; for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) e += 0.5 * s.mass[i] * v[3 * i + k] * v[3 * i + k]; return e; };
-    auto pe = [&]() { const int64_t kk = h->labels[rg]; return evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], nullptr, thread_fft(h)).total(); };
+    auto pe = [&]() { const int64_t kk = h->labels[rg]; return evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], nullptr, thread_fft(h), PART_ALL, 63, (int)kk).total(); };
     std::vector<double> xold, vold;
     std::vector<double> fgroup[4]; bool fgroup_valid[4] = {false, false, false, false};      // forces per force group of a multiple-time-step program
     for (int st = 0; st < n_steps; ++st) {
@@ -960,7 +1053,7 @@ static void run_steps(remd_ctx* h, int r, const std::vector<char>& tokens, int n
                 std::vector<double>& fg = fgroup[g];
                 if (!fgroup_valid[g]) {
                     fg.assign(3 * (size_t)N, 0.0);
-                    evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], fg.data(), thread_fft(h), PART_ALL, mask);
+                    evaluate(s, rep, h->lam_s[kk], h->lam_e[kk], fg.data(), thread_fft(h), PART_ALL, mask, (int)kk);
                     fgroup_valid[g] = true;
                 }
                 const double hg = h->dt / std::max(1, h->nVg[g]);
@@ -1036,6 +1129,17 @@ static double ukl_row(remd_ctx* h, int r, double* row)
     const double cscale = (h->econst_vref > 0 && V > 0) ? h->econst_vref / V : 1.0;
     bool lam_varies = false;
     for (int k = 0; k < K; ++k) if (h->lam_s[k] != h->lam_s[0] || h->lam_e[k] != h->lam_e[0]) lam_varies = true;
+    if (s.reg.n > 0) {
+        // general alchemical regions: everything but the custom forces once, the custom forces at every state's lambdas
+        const double base = evaluate(s, rep, 1.0, 1.0, nullptr, fft).total();
+        double U_own = 0;
+        for (int k = 0; k < K; ++k) {
+            const double U = base + region_energy(s, rep, k, nullptr);
+            row[k] = h->beta[k] * (U + h->econst[k] * cscale + (h->pressure.empty() ? 0.0 : h->pressure[k] * V));
+            if (k == own) U_own = U;
+        }
+        return U_own;
+    }
     if (!s.has_alch || !lam_varies) {
         // one energy per replica serves every state (paralleltempering.py:206-215)
         const double U = evaluate(s, rep, h->lam_s[own], h->lam_e[own], nullptr, fft).total();
@@ -1075,7 +1179,7 @@ static void barostat_attempt(remd_ctx* h, int r, long long attempt)
     const int64_t k = h->labels[rg];
     const double kT = 1.0 / h->beta[k], p = h->pressure[k];
     const double c_lr = h->econst_vref > 0 ? h->econst[k] * h->econst_vref : 0.0;
-    const double U0 = evaluate(s, rep, h->lam_s[k], h->lam_e[k], nullptr, fft).total();
+    const double U0 = evaluate(s, rep, h->lam_s[k], h->lam_e[k], nullptr, fft, PART_ALL, 63, (int)k).total();
     const double V = rep.box[0] * rep.box[1] * rep.box[2];
     if (rep.baro[0] <= 0.0) rep.baro[0] = 0.01 * V;
     uint32_t w[4];
@@ -1097,7 +1201,7 @@ static void barostat_attempt(remd_ctx* h, int r, long long attempt)
     }
     for (int q = 0; q < 3; ++q) rep.box[q] = box0[q] * scale;
     rep.list_valid = false;
-    const double U1 = evaluate(s, rep, h->lam_s[k], h->lam_e[k], nullptr, fft).total();
+    const double U1 = evaluate(s, rep, h->lam_s[k], h->lam_e[k], nullptr, fft, PART_ALL, 63, (int)k).total();
     const double wgt = U1 - U0 + c_lr * (1.0 / newV - 1.0 / V) + p * dV - (double)s.molecules.size() * kT * log(newV / V);
     oracle_draw(h->seed, 6u, 1u, noise_key(h, r), (uint64_t)attempt, w);
     const bool reject = !(wgt <= 0.0) && !(u53(w[2], w[3]) <= exp(-wgt / kT));
@@ -1126,7 +1230,7 @@ static void fire_minimize(remd_ctx* h, int r, double ftol, int max_iterations, i
     double dt = timestep, alpha = alpha0; int n_neg = 0; bool converged = false;
     const double ndof = 3.0 * N;
     const bool cons = !s.clusters.empty();
-    auto ef = [&](const std::vector<double>& y, double* fo) { rep.x = y; rep.list_valid = rep.list_valid; return evaluate(s, rep, h->lam_s[k], h->lam_e[k], fo, fft).total(); };
+    auto ef = [&](const std::vector<double>& y, double* fo) { rep.x = y; rep.list_valid = rep.list_valid; return evaluate(s, rep, h->lam_s[k], h->lam_e[k], fo, fft, PART_ALL, 63, (int)k).total(); };
     double E = ef(x, f.data());
     int it = 0;
     const int limit = max_iterations > 0 ? max_iterations : 200000;
@@ -1390,6 +1494,94 @@ int remd_set_alchemical_options(remd_handle h, int annihilate_sterics)
 {
     if (!h || (annihilate_sterics != 0 && annihilate_sterics != 1)) return fail(h, -1, "remd_set_alchemical_options: bad arguments");
     h->annihilate_sterics = annihilate_sterics;   // consumed by the next remd_set_system (include/remd_hip.h)
+    return 0;
+}
+
+// general alchemical regions (include/remd_hip.h): after remd_set_system, which forgets them
+int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
+{
+    if (!h) return fail(h, -1, "remd_set_alchemical_regions: NULL handle");
+    h->sys.reg = System::Regions();
+    for (auto& r : h->reps) r.f_valid = false;
+    if (!d || d->n_regions == 0) return 0;
+    System& s = h->sys;
+    if (!h->has_system) return fail(h, -2, "remd_set_alchemical_regions: call remd_set_system first");
+    const int N = s.N, n = d->n_regions;
+    if (d->n_atoms != N) return fail(h, -1, "remd_set_alchemical_regions: n_atoms differs from the system's");
+    if (n < 0 || n > 64 || !d->region_of_atom || !d->softcore || !d->annihilate || !d->charge || !d->sigma || !d->epsilon ||
+        d->n_interactions < 0 || (d->n_interactions > 0 && !d->interactions) || d->n_exceptions < 0 || (d->n_exceptions > 0 && (!d->exception_atoms || !d->exception_params)))
+        return fail(h, -1, "remd_set_alchemical_regions: bad arguments");
+    if (s.method == 0) return fail(h, -3, "alchemical regions need a NonbondedForce with a cutoff method");
+    if (s.has_alch) return fail(h, -3, "alchemical regions: the descriptor of remd_set_system must be the factory's NonbondedForce (n_alch = 0)");
+    System::Regions g;
+    g.n = n;
+    g.softcore.assign(d->softcore, d->softcore + 8 * (size_t)n);
+    g.annihilate.assign(d->annihilate, d->annihilate + 2 * (size_t)n);
+    for (int q = 0; q < n; ++q) if (!(g.softcore[8 * (size_t)q + 4] > 0) || !(g.softcore[8 * (size_t)q + 7] > 0)) return fail(h, -1, "alchemical regions: softcore_c and softcore_f must be positive");
+    g.cls_of.assign((size_t)(n + 1) * (n + 1), -1);
+    for (int q = 1; q <= n; ++q) {
+        g.cls_of[q] = g.cls_of[(size_t)q * (n + 1)] = (int)g.classes.size(); g.classes.push_back({0, q, q, q});
+        g.cls_of[(size_t)q * (n + 1) + q] = (int)g.classes.size(); g.classes.push_back({1, q, q, q});
+    }
+    for (int k = 0; k < d->n_interactions; ++k) {
+        const int a = d->interactions[2 * k], b = d->interactions[2 * k + 1];
+        if (a < 1 || b < 1 || a > n || b > n || a == b) return fail(h, -1, "alchemical regions: bad pair of interacting regions");
+        if (g.cls_of[(size_t)a * (n + 1) + b] >= 0) continue;
+        g.cls_of[(size_t)a * (n + 1) + b] = g.cls_of[(size_t)b * (n + 1) + a] = (int)g.classes.size(); g.classes.push_back({2, a, b, b});
+    }
+    g.region_of.assign(d->region_of_atom, d->region_of_atom + N);
+    g.q.assign(d->charge, d->charge + N); g.sig.assign(d->sigma, d->sigma + N); g.eps.assign(d->epsilon, d->epsilon + N);
+    for (int i = 0; i < N; ++i) {
+        if (g.region_of[i] < 0 || g.region_of[i] > n) return fail(h, -1, "alchemical regions: region index out of range");
+        if (g.region_of[i] > 0) { g.alch.push_back(i); if (!(g.sig[i] > 0)) return fail(h, -1, "alchemical regions: sigma must be positive (the factory sets 0 to 0.1 nm, alchemy.py:1638-1648)"); }
+    }
+    if (g.alch.empty()) return fail(h, -1, "alchemical regions: no alchemical atom");
+    std::vector<int> ord(N, -1);
+    for (size_t k = 0; k < g.alch.size(); ++k) ord[g.alch[k]] = (int)k;
+    g.skip.assign(g.alch.size(), std::vector<char>(N, 0));
+    for (size_t ia = 0; ia < g.alch.size(); ++ia) {
+        const int a = g.alch[ia], ga = g.region_of[a];
+        for (int j = 0; j < N; ++j) {
+            const int gj = g.region_of[j];
+            if (j == a || (gj > 0 && j < a) || g.cls_of[(size_t)ga * (n + 1) + gj] < 0) g.skip[ia][j] = 1;
+            else if (gj == 0 && !(g.sig[j] > 0) && (g.eps[j] != 0.0 || (d->electrostatics && g.q[j] != 0.0)))
+                return fail(h, -1, "alchemical regions: sigma must be positive (the factory sets 0 to 0.1 nm, alchemy.py:1638-1648)");
+        }
+    }
+    for (size_t e = 0; e < s.exc_atoms.size() / 2; ++e) {          // every exception of the system is an exclusion of the custom forces (alchemy.py:1944-1947)
+        const int i = s.exc_atoms[2 * e], j = s.exc_atoms[2 * e + 1];
+        if (ord[i] >= 0) g.skip[ord[i]][j] = 1;
+        if (ord[j] >= 0) g.skip[ord[j]][i] = 1;
+    }
+    g.elec = d->electrostatics != 0;
+    for (int e = 0; e < d->n_exceptions; ++e) {
+        const int i = d->exception_atoms[2 * e], j = d->exception_atoms[2 * e + 1];
+        if (i < 0 || j < 0 || i >= N || j >= N || i == j) return fail(h, -1, "alchemical regions: bad exception pair");
+        const int gi = g.region_of[i], gj = g.region_of[j];
+        const double qq = d->exception_params[3 * e], sg = d->exception_params[3 * e + 1], ep = d->exception_params[3 * e + 2];
+        if ((gi == 0 && gj == 0) || (ep == 0.0 && (qq == 0.0 || !g.elec))) continue;
+        if (gi > 0 && gj > 0 && gi != gj) return fail(h, -3, "an exception that straddles two alchemical regions is not supported");
+        if (!(sg > 0)) return fail(h, -1, "alchemical regions: exception sigma must be positive");
+        g.exc_atoms.push_back(i); g.exc_atoms.push_back(j);
+        g.exc_params.push_back(qq); g.exc_params.push_back(sg); g.exc_params.push_back(ep);
+        g.exc_cls.push_back(g.cls_of[(size_t)gi * (n + 1) + gj]);
+    }
+    g.alpha = d->elec_alpha; g.krf = d->elec_krf; g.crf = d->elec_crf;
+    g.rs_e = (g.elec && d->elec_switch_distance >= 0 && d->elec_switch_distance < s.rc) ? d->elec_switch_distance : -1.0;
+    s.reg = std::move(g);
+    return 0;
+}
+
+int remd_set_region_lambdas(remd_handle h, int K, int n_regions, const double* ls, const double* le)
+{
+    if (!h) return fail(h, -1, "remd_set_region_lambdas: NULL handle");
+    System::Regions& g = h->sys.reg;
+    if (g.n == 0) return fail(h, -2, "remd_set_region_lambdas: no alchemical regions on this handle");
+    if (K != h->K || n_regions != g.n || !ls || !le) return fail(h, -1, "remd_set_region_lambdas: K / n_regions differ from remd_set_states / remd_set_alchemical_regions");
+    for (size_t k = 0; k < (size_t)K * g.n; ++k)
+        if (!(ls[k] >= 0.0 && ls[k] <= 1.0 && le[k] >= 0.0 && le[k] <= 1.0)) return fail(h, -1, "remd_set_region_lambdas: lambdas must be in [0, 1]");
+    g.ls.assign(ls, ls + (size_t)K * g.n); g.le.assign(le, le + (size_t)K * g.n); g.K = K;
+    for (auto& r : h->reps) r.f_valid = false;
     return 0;
 }
 
@@ -1690,7 +1882,7 @@ int remd_get_replicas(remd_handle h, double* x, double* v, double* potential, do
 #pragma omp parallel for schedule(dynamic, 1)
         for (int r = 0; r < h->R; ++r) {
             const int64_t k = h->labels[h->r_begin + r];
-            potential[r] = evaluate(h->sys, h->reps[r], h->lam_s[k], h->lam_e[k], nullptr, thread_fft(h)).total();
+            potential[r] = evaluate(h->sys, h->reps[r], h->lam_s[k], h->lam_e[k], nullptr, thread_fft(h), PART_ALL, 63, (int)k).total();
         }
     }
     return 0;
@@ -1711,7 +1903,7 @@ int remd_get_energy_components(remd_handle h, double* out)
 #pragma omp parallel for schedule(dynamic, 1)
     for (int r = 0; r < h->R; ++r) {
         const int64_t k = h->labels[h->r_begin + r];
-        const Energy E = evaluate(h->sys, h->reps[r], h->lam_s[k], h->lam_e[k], nullptr, thread_fft(h));
+        const Energy E = evaluate(h->sys, h->reps[r], h->lam_s[k], h->lam_e[k], nullptr, thread_fft(h), PART_ALL, 63, (int)k);
         for (int c = 0; c < 9; ++c) out[9 * r + c] = E.c[c];
     }
     return 0;
