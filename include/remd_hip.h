@@ -242,8 +242,18 @@ int  remd_set_alchemical_options(remd_handle h, int annihilate_sterics);
      l = the region's lambda for (environment, y); for (y, y) the region's lambda if it annihilates, else 1; the product for (a, b);
      the soft-core constants of a class are those of region y (of b for an interacting pair, as the factory's loop leaves them, :2009-2017);
      exceptions with an alchemical atom: the same sterics without cutoff or switch, electrostatics l^d k_e qq / reff_e            :1374-1380, 1434, 1456-1461
+       (between atoms of two regions: a bond of the lower region's (environment, region) force, as the factory's loop leaves it, :1972-2006)
    charge / sigma / epsilon and the exceptions passed here are the REFERENCE NonbondedForce's (sigma = 0 already replaced by
    0.1 nm, :1638-1661).  electrostatics = 0: no electrostatic custom forces (alchemical atoms without charge).
+   exact_pme = 1 (PME systems; alchemy.py:1663-1681, 1893-1899, 1978-1982: the factory's default treatment): no electrostatic custom
+   forces -- the charge of an atom of region x enters the WHOLE Ewald sum as lambda_electrostatics_x q (the NonbondedForce's parameter
+   offsets), a charged exception that touches region x counts lambda_electrostatics_x qq (the offset of the first region that meets it),
+   and every pair of atoms of two regions that do NOT interact is excluded (:1663-1672).  The descriptor of remd_set_system then has the
+   alchemical charges at 0 as the factory leaves them, `charge` / the exceptions here carry the offsets.  Device: the pair kernels see the
+   environment's charges only; the alchemical atoms' direct-space terms, the Ewald corrections of their excluded pairs and the exceptions
+   come from the custom-forces launch (erfc to the Coulomb range of the handle's Ewald split), the mesh takes the scaled charges; u_kl
+   from (n + 1)(n + 2) / 2 energy passes: the Coulomb energy is a quadratic form in the regions' lambda_electrostatics.
+   Sterics as above (of a pair of interacting regions: none, as the reference's loop leaves them -- tables zeroed, :1886-1911).
    Call AFTER remd_set_system (which forgets the regions) and follow remd_set_states by remd_set_region_lambdas.  n_regions = 0 or
    desc = NULL: none.  A handle with regions runs one block of replicas (no phases) and needs a cutoff method.                   */
 typedef struct remd_alch_regions_desc {
@@ -260,6 +270,7 @@ typedef struct remd_alch_regions_desc {
     const double*  exception_params;     /* [n_exceptions][3] chargeprod, sigma, epsilon                     */
     int32_t electrostatics;              /* 0 / 1                                                            */
     double elec_alpha, elec_krf, elec_crf, elec_switch_distance;
+    int32_t exact_pme;                   /* 1: the exact PME treatment (below); electrostatics / elec_* unused */
 } remd_alch_regions_desc;
 int  remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* desc);
 /* lambda_sterics / lambda_electrostatics of every region at every state: [K][n_regions], K as in remd_set_states (call after it).  The

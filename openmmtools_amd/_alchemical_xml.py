@@ -31,6 +31,8 @@ Outside what this package's factory builds (and so refused, with the name of wha
 bonds / angles / torsions, soft-core electrostatics, 'coulomb' / 'direct-space' PME treatments, charged systems under the
 reaction-field methods (the engine evaluates OpenMM's shifted reaction field, the factory an unshifted switched one).
 """
+import math
+import re
 import xml.etree.ElementTree as ET
 
 from .constants import ONE_4PI_EPS0
@@ -55,18 +57,28 @@ def sterics_exception_expression(lam='lambda_sterics'):
             'reff_sterics = sigma*((softcore_alpha*(1.0-(%s))^softcore_b + (r/sigma)^softcore_c))^(1/softcore_c);' % (lam, lam))
 
 
-def electrostatics_expressions(nb, lam='lambda_electrostatics'):
-    """:1392-1471 for the methods that reach it here (NoCutoff, reaction field): (pair expression, exception expression)."""
+def electrostatics_expressions(nb, lam='lambda_electrostatics', pme_treatment='direct-space', rf_treatment='switched'):
+    """:1392-1471: (pair expression, exception expression) for NoCutoff, the reaction-field treatments (:1473-1508) and the
+    'direct-space' (:1510-1537) / 'coulomb' PME treatments."""
     prefix = 'U_electrostatics;U_electrostatics=((%s)^softcore_d)*ONE_4PI_EPS0*chargeprod' % lam
     suffix = ('reff_electrostatics = sigma*((softcore_beta*(1.0-(%s))^softcore_e + (r/sigma)^softcore_f))^(1/softcore_f);'
               'ONE_4PI_EPS0 = %s;' % (lam, ONE_4PI_EPS0))
     coulomb = '/reff_electrostatics;'
-    if nb.getNonbondedMethod() == NonbondedForce.NoCutoff:
+    m = nb.getNonbondedMethod()
+    if m == NonbondedForce.NoCutoff:
         method = coulomb
-    else:                                                                    # :1473-1508, 'switched': c_rf = 0
+    elif m in (NonbondedForce.CutoffPeriodic, NonbondedForce.CutoffNonPeriodic):        # :1473-1508
         eps, rc = nb.getReactionFieldDielectric(), nb.getCutoffDistance()
+        c_rf = 0.0 if rf_treatment == 'switched' else rc ** (-1) * ((3 * eps) / (2 * eps + 1))
         method = ('*(reff_electrostatics^(-1) + k_rf*reff_electrostatics^2 - c_rf);k_rf = %s;c_rf = %s;'
-                  % (rc ** -3 * ((eps - 1) / (2 * eps + 1)), 0.0))
+                  % (rc ** -3 * ((eps - 1) / (2 * eps + 1)), c_rf))
+    elif pme_treatment == 'direct-space':                                                # :1510-1537
+        alpha = nb._pme_params[0] if nb._pme_params is not None else 0.0
+        if alpha == 0.0:
+            alpha = (1.0 / nb.getCutoffDistance()) * math.sqrt(-math.log(2.0 * nb.getEwaldErrorTolerance()))
+        method = '*erfc(alpha_ewald*reff_electrostatics)/reff_electrostatics;alpha_ewald = %s;' % alpha
+    else:
+        method = coulomb
     return prefix + method + suffix + _MIX_ELECTROSTATICS, prefix + coulomb + suffix
 
 
@@ -76,8 +88,9 @@ def _emit_custom(forces, kind, group, energy, per_name, per_params, lam_globals,
     for n in per_params:
         ET.SubElement(b, 'Parameter', dict(name=n))
     g = ET.SubElement(e, 'GlobalParameters')
-    values = dict(softcore_alpha=region.softcore_alpha, softcore_beta=0.0, softcore_a=region.softcore_a, softcore_b=region.softcore_b,
-                  softcore_c=region.softcore_c, softcore_d=1.0, softcore_e=1.0, softcore_f=2.0)
+    values = dict(softcore_alpha=region.softcore_alpha, softcore_beta=getattr(region, 'softcore_beta', 0.0), softcore_a=region.softcore_a,
+                  softcore_b=region.softcore_b, softcore_c=region.softcore_c, softcore_d=getattr(region, 'softcore_d', 1.0),
+                  softcore_e=getattr(region, 'softcore_e', 1.0), softcore_f=getattr(region, 'softcore_f', 2.0))
     for n in lam_globals:
         ET.SubElement(g, 'Parameter', dict(default=_f(1.0), name=n))
     for n in _SOFTCORE:
@@ -228,6 +241,144 @@ def emit_alchemical_forces(forces, system, emit_plain):
                                True, rc - switch_width, False, with_softcore=False)
 
 
+def emit_region_forces(forces, system, emit_plain):
+    """The force set of a System in the general-regions mode (``system.alchemical_regions``): the reference's loop over
+    single_regions + pair_regions (alchemy.py:1693-2036) restated on plain tables -- INCLUDING its order of reading and zeroing the
+    NonbondedForce's parameters, which decides what the later forces' particle tables hold (:1886-1911, 2001-2006)."""
+    regions = system.alchemical_regions
+    opts = system.alchemical_factory_options
+    terms = system.alchemical_region_terms
+    all_forces = system.getForces()
+    nbs = [f for f in all_forces if isinstance(f, NonbondedForce)]
+    if len(nbs) != 1:
+        raise NotImplementedError('an alchemical System with %d NonbondedForces' % len(nbs))
+    nb = nbs[0]
+    ewald = nb.getNonbondedMethod() in (NonbondedForce.Ewald, NonbondedForce.PME)
+    exact = ewald and opts['alchemical_pme_treatment'] == 'exact'
+    if exact and len(regions) > 1:
+        raise NotImplementedError('a store of several regions under the exact PME treatment (the exclusions between the regions, alchemy.py:1663-1672)')
+    n = nb.getNumParticles()
+    # the reference NonbondedForce again (sigma = 0 already 0.1 nm): the kept force + what the custom forces took
+    cur = [(float(terms['charge'][k]), float(terms['sigma'][k]), float(terms['epsilon'][k])) for k in range(n)]
+    took = {frozenset((int(i), int(j))): tuple(float(v) for v in p) for (i, j), p in zip(terms['exception_atoms'], terms['exception_params'])}
+    exc = [(i, j) + took.get(frozenset((i, j)), (qq, sg, ep)) for (i, j, qq, sg, ep) in nb.exceptions]
+    exclusions = [(i, j) for (i, j, _, _, _) in exc]
+    alch_all = set()
+    for r in regions:
+        alch_all |= set(r.alchemical_atoms)
+    env = set(range(n)) - alch_all
+    suffix = lambda r: '' if r.name is None else '_' + r.name
+    by_lambda, particle_offsets, exception_offsets, nb_globals = {}, [], [], []
+    if exact:
+        nb_globals = [('lambda_electrostatics' + suffix(r), 1.0) for r in regions]
+    singles = [[r] for r in regions]
+    pairs = [[regions[a], regions[b]] for a, b in getattr(system, 'alchemical_regions_interactions', [])]
+    lrc = nb.getUseDispersionCorrection() and getattr(system, 'alchemical_lrc', True)
+    switched_e = (ewald and opts['alchemical_pme_treatment'] == 'coulomb') or \
+        (not ewald and opts['alchemical_rf_treatment'] == 'switched' and nb.getNonbondedMethod() != NonbondedForce.NoCutoff)
+    fixed = lambda names, on: '' if on else ''.join(x + '=1.0;' for x in names)
+    last_key = None
+    for group_regions in singles + pairs:
+        sfx = [suffix(r) for r in group_regions]
+        region = group_regions[-1]                                           # whose softcore_* the forces get (:2009-2025)
+        lam_s = 'lambda_sterics' + sfx[0] if len(sfx) == 1 else 'lambda_sterics%s*lambda_sterics%s' % (sfx[0], sfx[1])
+        lam_e = 'lambda_electrostatics' + sfx[0] if len(sfx) == 1 else 'lambda_electrostatics%s*lambda_electrostatics%s' % (sfx[0], sfx[1])
+        names_s, names_e = ['lambda_sterics' + x for x in sfx], ['lambda_electrostatics' + x for x in sfx]
+        A0, A1 = set(group_regions[0].alchemical_atoms), set(group_regions[-1].alchemical_atoms)
+        lj = [(sg, ep) for (q, sg, ep) in cur]                               # read BEFORE this turn zeroes its region (:1886-1899)
+        charges = [(q, sg) for (q, sg, ep) in cur]
+        if exact and len(sfx) == 1:
+            particle_offsets += [(names_e[0], k, cur[k][0], 0.0, 0.0) for k in sorted(A0)]
+        for k in A0:
+            cur[k] = (0.0, cur[k][1], 0.0)                                   # :1903-1911
+        na_lj, aa_lj, na_qq, aa_qq = [], [], [], []
+        for idx, (i, j, qq, sg, ep) in enumerate(exc):
+            if len(sfx) > 1:
+                both = (i in A0 and j in A1) or (j in A0 and i in A1)
+                one = any_ = False
+            else:
+                both = i in A0 and j in A0
+                any_ = i in A0 or j in A0
+                one = any_ and not both
+                if exact and any_ and qq != 0.0:
+                    exception_offsets.append((names_e[0], idx, qq, 0.0, 0.0))
+            if both:
+                if ep != 0.0:
+                    aa_lj.append((i, j, (sg, ep)))
+                if qq != 0.0 and not exact:
+                    aa_qq.append((i, j, (qq, sg)))
+            elif one:
+                if ep != 0.0:
+                    na_lj.append((i, j, (sg, ep)))
+                if qq != 0.0 and not exact:
+                    na_qq.append((i, j, (qq, sg)))
+            if any_:
+                exc[idx] = (i, j, 0.0, sg, 0.0)                              # :2001-2006
+        ster, elec = [], []
+        exc_expr = sterics_exception_expression(lam_s)
+        pair_expr = exc_expr + _MIX_STERICS
+        common = dict(use_switch=nb.getUseSwitchingFunction(), switch_distance=nb.getSwitchingDistance(), lrc=lrc, region=region, nb=nb,
+                      exclusions=exclusions, particles=lj)
+        if len(sfx) > 1:
+            ster.append(('nb', dict(energy=pair_expr, per_params=('sigma', 'epsilon'), lam_globals=tuple(names_s), set1=A0, set2=A1, **common)))
+            ster.append(('bond', dict(energy=exc_expr, per_params=('sigma', 'epsilon'), lam_globals=tuple(names_s), region=region, bonds=aa_lj)))
+        else:
+            fx = fixed(names_s, region.annihilate_sterics)
+            ster.append(('nb', dict(energy=pair_expr, per_params=('sigma', 'epsilon'), lam_globals=tuple(names_s), set1=env, set2=A0, **common)))
+            ster.append(('nb', dict(energy=pair_expr + fx, per_params=('sigma', 'epsilon'), lam_globals=() if fx else tuple(names_s), set1=A0, set2=A0, **common)))
+            ster.append(('bond', dict(energy=exc_expr, per_params=('sigma', 'epsilon'), lam_globals=tuple(names_s), region=region, bonds=na_lj)))
+            ster.append(('bond', dict(energy=exc_expr + fx, per_params=('sigma', 'epsilon'), lam_globals=() if fx else tuple(names_s), region=region, bonds=aa_lj)))
+        if not exact:
+            e_pair, e_exc = electrostatics_expressions(nb, lam_e, opts['alchemical_pme_treatment'], opts['alchemical_rf_treatment'])
+            common = dict(use_switch=switched_e, switch_distance=nb.getCutoffDistance() - opts['switch_width'], lrc=False, region=region, nb=nb,
+                          exclusions=exclusions, particles=charges)
+            if len(sfx) > 1:
+                elec.append(('nb', dict(energy=e_pair, per_params=('charge', 'sigma'), lam_globals=tuple(names_e), set1=A0, set2=A1, **common)))
+                elec.append(('bond', dict(energy=e_exc, per_params=('chargeprod', 'sigma'), lam_globals=tuple(names_e), region=region, bonds=aa_qq)))
+            else:
+                fx = fixed(names_e, region.annihilate_electrostatics)
+                elec.append(('nb', dict(energy=e_pair, per_params=('charge', 'sigma'), lam_globals=tuple(names_e), set1=env, set2=A0, **common)))
+                elec.append(('nb', dict(energy=e_pair + fx, per_params=('charge', 'sigma'), lam_globals=() if fx else tuple(names_e), set1=A0, set2=A0, **common)))
+                elec.append(('bond', dict(energy=e_exc, per_params=('chargeprod', 'sigma'), lam_globals=tuple(names_e), region=region, bonds=na_qq)))
+                elec.append(('bond', dict(energy=e_exc + fx, per_params=('chargeprod', 'sigma'), lam_globals=() if fx else tuple(names_e), region=region, bonds=aa_qq)))
+        by_lambda.setdefault('lambda_electrostatics' + sfx[0], []).extend(elec)              # :2027-2032
+        by_lambda.setdefault('lambda_sterics' + sfx[0], []).extend(ster)
+        last_key = 'lambda_electrostatics' + sfx[0]
+    # ---- order and force groups (:1052-1083) ------------------------------------------------------------------------
+    untouched = [f for f in all_forces if not isinstance(f, _REMODELLED)]
+    readded = [f for f in all_forces if isinstance(f, _REMODELLED) and (not isinstance(f, NonbondedForce) or not exact)]
+    free = sorted(set(range(32)) - {f.getForceGroup() for f in untouched + readded})
+    if len(free) < len(by_lambda):
+        raise NotImplementedError('no free force groups for the alchemical forces (alchemy.py:1068-1072 raises here too)')
+    rf_replaced = nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic and opts['alchemical_rf_treatment'] == 'switched'
+    kept_particles = [(0.0, sg, ep) for (q, sg, ep) in cur] if rf_replaced else list(cur)   # forcefactories.py:82-84: charges move to the last force
+
+    def emit_nb(group):
+        emit_plain(nb, particles=kept_particles, exceptions=exc, force_group=group, global_parameters=nb_globals,
+                   particle_offsets=particle_offsets, exception_offsets=exception_offsets)
+    for f in untouched:
+        emit_plain(f)
+    for f in readded:
+        if isinstance(f, NonbondedForce):
+            emit_nb(f.getForceGroup())
+        else:
+            emit_plain(f)
+    for key in sorted(by_lambda):
+        group = free.pop(0)
+        for kind, kw in by_lambda[key]:
+            if kind == 'nb':
+                _emit_custom_nonbonded(forces, group, kw.pop('energy'), kw.pop('per_params'), kw.pop('lam_globals'), **kw)
+            else:
+                _emit_custom_bond(forces, group, kw['energy'], kw['per_params'], kw['lam_globals'], kw['region'], kw['bonds'])
+        if exact and key == last_key:
+            emit_nb(group)                                                   # :2034-2035
+    if rf_replaced:
+        eps, rc = nb.getReactionFieldDielectric(), nb.getCutoffDistance()
+        energy = _RF_HEAD + 'chargeprod = charge1*charge2;k_rf = %f;ONE_4PI_EPS0 = %f;' % (rc ** -3 * (eps - 1.0) / (2.0 * eps + 1.0), ONE_4PI_EPS0)
+        _emit_custom_nonbonded(forces, 0, energy, ('charge',), (), regions[-1], nb, [(q,) for (q, sg, ep) in cur], exclusions, None, None,
+                               True, rc - opts['switch_width'], False, with_softcore=False)
+
+
 # ---- reader -------------------------------------------------------------------------------------------------------
 def _params(elem):
     out, k = [], 1
@@ -273,6 +424,13 @@ def rebuild_marked_system(system, nb, global_parameters, particle_offsets, excep
     other = [c for c in customs if c not in sterics + electro + rf]
     if other:
         raise NotImplementedError('custom force outside the alchemical factory\'s set: %s' % other[0]['energy'][:60])
+    for name in list(global_parameters) + [p[0] for p in particle_offsets + exception_offsets]:
+        if not name.startswith('lambda_electrostatics'):
+            raise NotImplementedError('NonbondedForce offset parameter %r (only the alchemical factory\'s lambda_electrostatics[_<region>])' % name)
+    if needs_general_reader(nb, global_parameters, particle_offsets, exception_offsets, customs):
+        # several / named regions, soft-core electrostatics, the 'direct-space' / 'coulomb' PME treatments, a charged region under a
+        # reaction-field method: back to the reference System and through this package's factory
+        return rebuild_general_system(system, nb, global_parameters, particle_offsets, exception_offsets, customs)
     for name in list(global_parameters) + [p[0] for p in particle_offsets + exception_offsets]:
         if name != 'lambda_electrostatics':
             raise NotImplementedError('NonbondedForce offset parameter %r (one unnamed alchemical region only)' % name)
@@ -338,3 +496,142 @@ def rebuild_marked_system(system, nb, global_parameters, particle_offsets, excep
     if particle_offsets or global_parameters:                                # the factory put it into the lambda_electrostatics group
         nb.setForceGroup(0)
     return system
+
+
+# ---- reader of the general force set (several / named regions, soft-core electrostatics, the non-exact PME treatments) -------------
+_LAMBDA_OF = re.compile(r'\(\((.*?)\)\^softcore_[ad]\)')
+
+
+def _lambda_names(c):
+    """the lambda variables of a custom force's expression, e.g. ['lambda_sterics_zero', 'lambda_sterics_one']"""
+    m = _LAMBDA_OF.search(c['energy'].replace(' ', ''))
+    if m is None:
+        raise NotImplementedError('custom force without a lambda^softcore prefactor: %s' % c['energy'][:60])
+    return m.group(1).split('*')
+
+
+def needs_general_reader(nb, global_parameters, particle_offsets, exception_offsets, customs):
+    """True when the document holds more than the one unnamed region under the exact PME treatment / without alchemical charges that
+    rebuild_marked_system undoes itself"""
+    names = set(global_parameters) | {p[0] for p in particle_offsets + exception_offsets}
+    sterics = [c for c in customs if 'U_sterics' in c['energy']]
+    electro = [c for c in customs if 'U_electrostatics' in c['energy']]
+    for c in sterics + electro:
+        names |= set(_lambda_names(c))
+        g = c['globals']
+        if (g.get('softcore_beta', 0.0), g.get('softcore_d', 1.0), g.get('softcore_e', 1.0), g.get('softcore_c', 6.0)) != (0.0, 1.0, 1.0, 6.0):
+            return True
+    if any(n not in ('lambda_sterics', 'lambda_electrostatics') for n in names):
+        return True
+    if len([c for c in sterics if c['type'] == 'CustomNonbondedForce']) != 2:
+        return True
+    ewald = nb.getNonbondedMethod() in (NonbondedForce.Ewald, NonbondedForce.PME)
+    charged = any(p[0] != 0.0 for c in electro if c['type'] == 'CustomNonbondedForce' for p in c['particles'])
+    return bool(electro) and (ewald or charged)
+
+
+def rebuild_general_system(system, nb, global_parameters, particle_offsets, exception_offsets, customs):
+    """Undo the factory on a parsed document of the general force set -- back to (reference NonbondedForce, regions, interacting pairs,
+    factory options) -- and run this package's factory on that (alchemy.AbsoluteAlchemicalFactory.create_alchemical_system): the marked
+    System it returns replaces ``system``."""
+    from .alchemy import AlchemicalRegion, AbsoluteAlchemicalFactory
+    compact = lambda s: s.replace(' ', '')
+    sterics = [c for c in customs if 'U_sterics' in c['energy']]
+    electro = [c for c in customs if 'U_electrostatics' in c['energy']]
+    rf = [c for c in customs if compact(c['energy']).startswith(compact(_RF_HEAD)) and c['type'] == 'CustomNonbondedForce']
+    other = [c for c in customs if c not in sterics + electro + rf]
+    if other:
+        raise NotImplementedError('custom force outside the alchemical factory\'s set: %s' % other[0]['energy'][:60])
+    sfx_of = lambda name: name[len('lambda_sterics'):] if name.startswith('lambda_sterics') else name[len('lambda_electrostatics'):]
+    for c in sterics + electro:
+        c['lam'] = _lambda_names(c)
+        c['sfx'] = [sfx_of(x) for x in c['lam']]
+        for g in c['globals']:
+            if g not in _SOFTCORE and not g.startswith(('lambda_sterics', 'lambda_electrostatics')):
+                raise NotImplementedError('alchemical parameter %r (no bonded lambdas)' % g)
+    is_nb = lambda c: c['type'] == 'CustomNonbondedForce'
+    single_s = [c for c in sterics if is_nb(c) and len(c['sfx']) == 1]
+    na_s = {c['sfx'][0]: c for c in single_s if c['groups'] and c['groups'][0][0] != c['groups'][0][1]}
+    aa_s = {c['sfx'][0]: c for c in single_s if c['groups'] and c['groups'][0][0] == c['groups'][0][1]}
+    if not na_s or set(na_s) != set(aa_s) or len(single_s) != 2 * len(na_s):
+        raise NotImplementedError('sterics CustomNonbondedForces that are not one (environment, region) + one (region, region) force per region')
+    elec_sfx = {sfx_of(x) for x in list(global_parameters) + [p[0] for p in particle_offsets + exception_offsets]} | {x for c in electro for x in c['sfx']}
+    if not elec_sfx <= set(na_s):
+        raise NotImplementedError('lambda_electrostatics%s of a region without sterics forces (regions: %s)' % (sorted(elec_sfx - set(na_s))[0], sorted(na_s)))
+    single_e = [c for c in electro if is_nb(c) and len(c['sfx']) == 1]
+    na_e = {c['sfx'][0]: c for c in single_e if c['groups'] and c['groups'][0][0] != c['groups'][0][1]}
+    aa_e = {c['sfx'][0]: c for c in single_e if c['groups'] and c['groups'][0][0] == c['groups'][0][1]}
+    atoms = {x: sorted(na_s[x]['groups'][0][1]) for x in na_s}
+    owner = {k: x for x, A in atoms.items() for k in A}
+    # bonds by the region whose single forces hold them
+    bonds_s, bonds_e = {}, {}
+    for c in sterics + electro:
+        if not is_nb(c) and len(c['sfx']) == 1:
+            for (i, j, p) in c['bonds']:
+                (bonds_s if c in sterics else bonds_e).setdefault(c['sfx'][0], []).append((i, j, p))
+    # the factory's order of the regions: by name, except that an exception between two regions sits in the EARLIER region's forces
+    order = sorted(na_s)
+    before = set()
+    for x, bl in list(bonds_s.items()) + list(bonds_e.items()):
+        for (i, j, p) in bl:
+            for k in (i, j):
+                if k in owner and owner[k] != x:
+                    before.add((x, owner[k]))
+    for _ in range(len(order) ** 2):
+        bad = next(((a, b) for (a, b) in before if order.index(a) > order.index(b)), None)
+        if bad is None:
+            break
+        order.remove(bad[0]); order.insert(order.index(bad[1]), bad[0])
+    regions = []
+    ewald = nb.getNonbondedMethod() in (NonbondedForce.Ewald, NonbondedForce.PME)
+    exact = ewald and not electro
+    for x in order:
+        g = na_s[x]['globals']
+        fixed_s = compact(aa_s[x]['energy']).endswith('lambda_sterics%s=1.0;' % x)
+        fixed_e = x in aa_e and compact(aa_e[x]['energy']).endswith('lambda_electrostatics%s=1.0;' % x)
+        regions.append(AlchemicalRegion(alchemical_atoms=atoms[x], annihilate_electrostatics=not fixed_e, annihilate_sterics=not fixed_s,
+                                        softcore_alpha=g['softcore_alpha'], softcore_a=g['softcore_a'], softcore_b=g['softcore_b'], softcore_c=g['softcore_c'],
+                                        softcore_beta=g.get('softcore_beta', 0.0), softcore_d=g.get('softcore_d', 1.0), softcore_e=g.get('softcore_e', 1.0),
+                                        softcore_f=g.get('softcore_f', 2.0), name=x[1:] if x else None))
+    interactions = set()
+    for c in sterics:
+        if is_nb(c) and len(c['sfx']) == 2:
+            interactions.add(tuple(sorted((order.index(c['sfx'][0]), order.index(c['sfx'][1])))))
+    # factory options from an electrostatics pair force
+    opts = dict(alchemical_pme_treatment='exact', alchemical_rf_treatment='switched', switch_width=0.1)
+    if na_e:
+        c = next(iter(na_e.values()))
+        e = compact(c['energy'])
+        if 'erfc(alpha_ewald*' in e:
+            opts['alchemical_pme_treatment'] = 'direct-space'
+        elif 'k_rf*reff_electrostatics^2' in e:
+            opts['alchemical_rf_treatment'] = 'switched' if float(re.search(r'c_rf=([^;]+);', e).group(1)) == 0.0 else 'shifted'
+        else:
+            opts['alchemical_pme_treatment'] = 'coulomb'
+        opts['switch_width'] = round(nb.getCutoffDistance() - float(c['attrs'].get('switchingDistance', nb.getCutoffDistance() - 0.1)), 12)
+    # ---- the reference NonbondedForce again ---------------------------------------------------------------------------------
+    charge = {p[1]: p[2] for p in particle_offsets}
+    for x in order:
+        for k in atoms[x]:
+            sig, eps = na_s[x]['particles'][k]                  # a region's own forces were filled before its atoms were zeroed
+            q = na_e[x]['particles'][k][0] if x in na_e else charge.get(k, 0.0)
+            nb.setParticleParameters(k, q, sig, eps)
+    if rf:                                                       # replace_reaction_field moved ALL charges there
+        for k, p in enumerate(rf[0]['particles']):
+            if k not in owner:
+                q, s_, e_ = nb.getParticleParameters(k)
+                nb.setParticleParameters(k, p[0], s_, e_)
+    qq_of = {p[1]: p[2] for p in exception_offsets}
+    lj_of = {frozenset((i, j)): (p[0], p[1]) for bl in bonds_s.values() for (i, j, p) in bl}
+    qq_bond = {frozenset((i, j)): p[0] for bl in bonds_e.values() for (i, j, p) in bl}
+    for n, (i, j, qq, s_, e_) in enumerate(list(nb.exceptions)):
+        if i in owner or j in owner:
+            key = frozenset((i, j))
+            sig, eps = lj_of.get(key, (s_, 0.0))
+            nb.exceptions[n] = (i, j, qq_of.get(n, qq_bond.get(key, 0.0)), sig, eps)
+    first = na_s[order[0]]
+    use_lrc = first['attrs'].get('useLongRangeCorrection', '0') not in ('0', 'false')
+    if particle_offsets or global_parameters:                    # the factory put it into a lambda_electrostatics group
+        nb.setForceGroup(0)
+    factory = AbsoluteAlchemicalFactory(disable_alchemical_dispersion_correction=not (use_lrc or not nb.getUseDispersionCorrection()), **opts)
+    return factory.create_alchemical_system(system, regions, alchemical_regions_interactions=frozenset(interactions))

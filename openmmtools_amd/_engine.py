@@ -47,6 +47,7 @@ class RemdAlchRegionsDesc(C.Structure):
         ('n_exceptions', C.c_int32), ('exception_atoms', c_int32_p), ('exception_params', c_double_p),
         ('electrostatics', C.c_int32),
         ('elec_alpha', C.c_double), ('elec_krf', C.c_double), ('elec_crf', C.c_double), ('elec_switch_distance', C.c_double),
+        ('exact_pme', C.c_int32),
     ]
 
 
@@ -274,6 +275,7 @@ class HipEngine:
             r.electrostatics = int(regions['electrostatics'])
             r.elec_alpha, r.elec_krf, r.elec_crf = float(regions['elec_alpha']), float(regions['elec_krf']), float(regions['elec_crf'])
             r.elec_switch_distance = float(regions['elec_switch_distance'])
+            r.exact_pme = int(regions.get('exact_pme', 0))
             self._check(self.lib.remd_set_alchemical_regions(self.h, C.byref(r)), 'remd_set_alchemical_regions')
             self.n_regions = int(r.n_regions)
         if 'force_groups' in desc_dict:                  # Force.getForceGroup() of the force classes (V<g> substeps)

@@ -123,13 +123,28 @@ class AbsoluteAlchemicalFactory:
                                       'Ewald sum, alchemy.py:1663-1681, 1893-1899) is not built: use alchemical_pme_treatment=\'direct-space\' or \'coulomb\'')
         if self.consistent_exceptions:
             raise NotImplementedError('consistent_exceptions=True (alchemy.py:1457-1459)')
+        if nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic and self.alchemical_rf_treatment == 'switched' and \
+                sum(1 for i, q in enumerate(nb.particles) if q[0] != 0.0 and i not in seen) > 1:
+            # alchemy.py:744-749: the factory then ALSO replaces the reaction field of the environment by an unshifted, switched one
+            # (forcefactories.replace_reaction_field); the pair kernels evaluate OpenMM's shifted reaction field
+            raise NotImplementedError("alchemical_rf_treatment='switched' with a charged environment under a reaction-field method "
+                                      "(forcefactories.py:76-84 replaces the environment's reaction field too): use alchemical_rf_treatment='shifted'")
         system.alchemical_region = None
         system.alchemical_regions = regions
-        system.alchemical_region_terms = self._region_terms(nb, regions, interactions, charged)
+        # alchemical_regions_interactions, as the reference's loop EXECUTES them (alchemy.py:1693, 1886-1911): the forces of a pair of
+        # regions are built after both regions' single turns, from the NonbondedForce in which both regions' atoms (and their
+        # exceptions) have been zeroed already -- their particle tables carry charge 0 and epsilon 0, so they evaluate to zero; only
+        # under the exact PME treatment does the pair matter (no exclusions between the two regions, :1663-1672).  The engine's class
+        # of interacting regions (product of the lambdas, remd_alch_regions_desc.interactions) is therefore not used by this factory;
+        # the pairs are recorded for the store writer (_alchemical_xml.py), which emits those forces as the reference would.
+        system.alchemical_regions_interactions = interactions
+        system.alchemical_factory_options = dict(alchemical_pme_treatment=self.alchemical_pme_treatment,
+                                                 alchemical_rf_treatment=self.alchemical_rf_treatment, switch_width=self.switch_width)
+        system.alchemical_region_terms = self._region_terms(nb, regions, charged)
         return system
 
     # ---- the factory's split of a NonbondedForce (alchemy.py:1539-2038) ---------------------------------------------
-    def _region_terms(self, nb, regions, interactions, charged):
+    def _region_terms(self, nb, regions, charged):
         """Zero the alchemical atoms in ``nb`` (what the factory leaves in the NonbondedForce, :1903-1911, 2001-2006) and return the
         parameters of the custom forces: the dict system_to_desc passes on as ``alch_regions`` (remd_alch_regions_desc)."""
         from .system import NonbondedForce
@@ -147,8 +162,8 @@ class AbsoluteAlchemicalFactory:
             if sig == 0.0:
                 sig = 0.1                                                # (:1650-1661)
             if qq != 0.0 or eps != 0.0:
-                if region_of[i] and region_of[j] and region_of[i] != region_of[j]:
-                    raise ValueError('Cannot have exception that straddles two alchemical regions')       # alchemy.py:1969
+                # (between two regions: the first region's turn takes it as "only one alchemical" and zeroes it, :1972-1976, 1992-2006;
+                # the check of :1966-1969 comes after that and never sees a charge product)
                 exc_atoms.append((i, j)); exc_params.append((qq, sig, eps))
             nb.exceptions[k] = (i, j, 0.0, sig, 0.0)
         for i in np.nonzero(region_of)[0]:
@@ -158,7 +173,7 @@ class AbsoluteAlchemicalFactory:
         method = nb.getNonbondedMethod()
         terms = dict(region_of_atom=region_of, softcore=np.array([r.softcore for r in regions], dtype=np.float64),
                      annihilate=np.array([[r.annihilate_sterics, r.annihilate_electrostatics] for r in regions], dtype=np.int32),
-                     interactions=np.array([(a + 1, b + 1) for a, b in interactions], dtype=np.int32).reshape(-1, 2),
+                     interactions=np.zeros((0, 2), dtype=np.int32),
                      charge=p[:, 0].copy(), sigma=p[:, 1].copy(), epsilon=p[:, 2].copy(),
                      exception_atoms=np.array(exc_atoms, dtype=np.int32).reshape(-1, 2),
                      exception_params=np.array(exc_params, dtype=np.float64).reshape(-1, 3),
@@ -259,7 +274,7 @@ def alchemical_long_range_constants(system, nonbonded_force, lambdas_sterics, vo
         epsilon = [q[2] for q in nonbonded_force.particles]
     else:
         terms = system.alchemical_region_terms
-        interactions = [(int(a) - 1, int(b) - 1) for a, b in terms['interactions']]
+        interactions = [(int(a) - 1, int(b) - 1) for a, b in terms['interactions']]         # (none from this package's factory)
         lam = np.asarray(lambdas_sterics, dtype=np.float64).reshape(-1, len(regions))
         sigma, epsilon = list(terms['sigma']), list(terms['epsilon'])
     if not getattr(system, 'alchemical_lrc', True) or not nonbonded_force.getUseDispersionCorrection():

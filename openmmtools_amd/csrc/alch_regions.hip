@@ -314,10 +314,12 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         const int gi = d->region_of_atom[i], gj = d->region_of_atom[j];
         const double qq = d->exception_params[3 * e], sg = d->exception_params[3 * e + 1], eps = d->exception_params[3 * e + 2];
         if ((gi == 0 && gj == 0) || (eps == 0.0 && (qq == 0.0 || !d->electrostatics))) continue;
-        if (gi > 0 && gj > 0 && gi != gj) { remd_regions_release(h); return remd_fail(h, -3, "an exception that straddles two alchemical regions is not supported"); }
         if (!(sg > 0)) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: exception sigma must be positive"); }
+        // an exception between atoms of two regions belongs to the FIRST region's (environment, region) bond force: the factory's loop meets
+        // it there as "only one alchemical" and zeroes it before the second region's turn (alchemy.py:1972-1976, 1992-2006)
+        const int cl = (gi > 0 && gj > 0 && gi != gj) ? cls_of[std::min(gi, gj)] : cls_of[(size_t)gi * (n + 1) + gj];
         ea.push_back(i); ea.push_back(j);
-        ep.push_back(make_float4((float)(qq * REMD_ONE_4PI_EPS0), (float)sg, (float)(4.0 * eps), host_int_as_float(cls_of[(size_t)gi * (n + 1) + gj])));
+        ep.push_back(make_float4((float)(qq * REMD_ONE_4PI_EPS0), (float)sg, (float)(4.0 * eps), host_int_as_float(cl)));
     }
     region_consts& c = t.c;
     c.rc2 = (float)(h->cutoff * h->cutoff);

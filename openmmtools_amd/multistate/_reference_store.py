@@ -227,15 +227,17 @@ class ReferenceStoreReader:
                 if outer is not d:
                     composable = outer.get('composable_states', [])
                     names = [str(c.get('_serialized__class_name')) for c in composable]
-                    if names != ['AlchemicalState']:
+                    if not names or any(n != 'AlchemicalState' for n in names):
                         raise NotImplementedError('compound thermodynamic states (%s) in a reference store' % ', '.join(names))
-                    c = composable[0]
-                    if c.get('parameters_name_suffix') is not None or c.get('function_variables'):
-                        raise NotImplementedError('AlchemicalState with a parameter suffix or alchemical functions')
-                    par = {n: v for n, v in c['parameters'].items() if v is not None}     # None: not defined on the System (alchemy.py:94-99)
-                    if any(isinstance(v, str) for v in par.values()):
-                        raise NotImplementedError('AlchemicalState parameters given as functions')
-                    state = states.CompoundThermodynamicState(state, [states.AlchemicalState(**par)])
+                    alchs = []
+                    for c in composable:
+                        if c.get('function_variables'):
+                            raise NotImplementedError('AlchemicalState with alchemical functions')
+                        par = {n: v for n, v in c['parameters'].items() if v is not None}     # None: not defined on the System (alchemy.py:94-99)
+                        if any(isinstance(v, str) for v in par.values()):
+                            raise NotImplementedError('AlchemicalState parameters given as functions')
+                        alchs.append(states.AlchemicalState(parameters_name_suffix=c.get('parameters_name_suffix'), **par))
+                    state = states.CompoundThermodynamicState(state, alchs)
                 out[kind].append(state)
         return out['thermodynamic_states'], out['unsampled_states']
 
@@ -407,7 +409,7 @@ class ReferenceStoreWriter:
         for s in list(thermodynamic_states) + list(unsampled_states):
             if type(s).__name__ not in ('ThermodynamicState', 'CompoundThermodynamicState'):
                 return type(s).__name__
-            if getattr(s.system, 'alchemical_region', None) is not None and id(s.system) not in seen:
+            if (getattr(s.system, 'alchemical_region', None) is not None or getattr(s.system, 'alchemical_regions', None) is not None) and id(s.system) not in seen:
                 seen.add(id(s.system))
                 try:                                        # the factory's force set for this System (_alchemical_xml.py) or why not
                     system_xml.to_xml(s.system)
@@ -519,12 +521,13 @@ class ReferenceStoreWriter:
                 if name == 'CompoundThermodynamicState':
                     # states.py:2956-2971 around the plain state; the AlchemicalState as GlobalParameterState.__getstate__
                     # writes it (:3879-3898): the lambdas the System defines, None for the ones it does not (alchemy.py:94-99)
-                    alch = {'_serialized__class_name': 'AlchemicalState', '_serialized__module_name': 'openmmtools.alchemy.alchemy',
-                            'parameters': {'lambda_sterics': float(s.lambda_sterics), 'lambda_electrostatics': float(s.lambda_electrostatics),
-                                           'lambda_bonds': None, 'lambda_angles': None, 'lambda_torsions': None},
-                            'function_variables': {}, 'parameters_name_suffix': None}
+                    # (one entry per composable state: the region's name as parameters_name_suffix, the parameters under their plain names)
+                    alch = [{'_serialized__class_name': 'AlchemicalState', '_serialized__module_name': 'openmmtools.alchemy.alchemy',
+                             'parameters': {'lambda_sterics': float(c.lambda_sterics), 'lambda_electrostatics': float(c.lambda_electrostatics),
+                                            'lambda_bonds': None, 'lambda_angles': None, 'lambda_torsions': None},
+                             'function_variables': {}, 'parameters_name_suffix': c.parameters_name_suffix} for c in s._alchs]
                     d = {'_serialized__class_name': 'CompoundThermodynamicState', '_serialized__module_name': 'openmmtools.states',
-                         'thermodynamic_state': d, 'composable_states': [alch]}
+                         'thermodynamic_state': d, 'composable_states': alch}
                 self._write_text(self._a, '/%s/state%d' % (kind, k), _yaml_dump(d), fixed=True)
 
     def write_mcmc_moves(self, mcmc_moves):

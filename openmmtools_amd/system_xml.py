@@ -105,7 +105,11 @@ def to_xml(system, pressure=None, temperature=None, barostat_frequency=25):
         p, q, d = system.getConstraintParameters(i)
         ET.SubElement(cons, 'Constraint', dict(d=_f(d), p1=str(p), p2=str(q)))
     forces = ET.SubElement(root, 'Forces')
-    if getattr(system, 'alchemical_region', None) is not None:
+    if getattr(system, 'alchemical_regions', None) is not None:
+        # ... in the general-regions mode (several / named regions, soft-core electrostatics, the non-exact PME treatments)
+        from . import _alchemical_xml
+        _alchemical_xml.emit_region_forces(forces, system, lambda f, **kw: _emit_force(forces, f, **kw))
+    elif getattr(system, 'alchemical_region', None) is not None:
         # a System marked by alchemy.AbsoluteAlchemicalFactory is written as the force set the reference's factory builds
         from . import _alchemical_xml
         _alchemical_xml.emit_alchemical_forces(forces, system, lambda f, **kw: _emit_force(forces, f, **kw))
@@ -226,5 +230,5 @@ def from_xml(text_or_path):
         if nb_force is None:
             raise NotImplementedError('custom forces without a NonbondedForce (%s)' % customs[0]['type'])
         g, po, eo = alch_nb if alch_nb is not None else ({}, [], [])
-        _alchemical_xml.rebuild_marked_system(s, nb_force, g, po, eo, customs)
+        s = _alchemical_xml.rebuild_marked_system(s, nb_force, g, po, eo, customs)
     return s, barostat

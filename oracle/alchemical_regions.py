@@ -55,7 +55,10 @@ class RegionOracle:
                 pairs.append((a, j)); kinds.append(k)
         self.pairs = np.array(pairs, dtype=int).reshape(-1, 2)
         self.kinds = kinds
-        self.exc_kinds = [self._class(self.g[i], self.g[j]) for i, j in self.exc_atoms]
+        # (an exception between atoms of two regions is a bond of the FIRST region's (environment, region) force: the factory's loop
+        # meets it there as "only one alchemical" and zeroes it before the second region's turn, alchemy.py:1972-1976, 1992-2006)
+        self.exc_kinds = [self._class(0, min(self.g[i], self.g[j])) if (self.g[i] and self.g[j] and self.g[i] != self.g[j])
+                          else self._class(self.g[i], self.g[j]) for i, j in self.exc_atoms]
 
     def _class(self, ga, gb):
         """(kind, a, b, P): kind 0 (environment, a), 1 (a, a), 2 (a, b) interacting; P = region of the soft-core constants (1-based)"""

@@ -1560,11 +1560,11 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         const int gi = g.region_of[i], gj = g.region_of[j];
         const double qq = d->exception_params[3 * e], sg = d->exception_params[3 * e + 1], ep = d->exception_params[3 * e + 2];
         if ((gi == 0 && gj == 0) || (ep == 0.0 && (qq == 0.0 || !g.elec))) continue;
-        if (gi > 0 && gj > 0 && gi != gj) return fail(h, -3, "an exception that straddles two alchemical regions is not supported");
         if (!(sg > 0)) return fail(h, -1, "alchemical regions: exception sigma must be positive");
         g.exc_atoms.push_back(i); g.exc_atoms.push_back(j);
         g.exc_params.push_back(qq); g.exc_params.push_back(sg); g.exc_params.push_back(ep);
-        g.exc_cls.push_back(g.cls_of[(size_t)gi * (n + 1) + gj]);
+        // (an exception between two regions: the first region's (environment, region) bond force, alchemy.py:1972-1976, 1992-2006)
+        g.exc_cls.push_back((gi > 0 && gj > 0 && gi != gj) ? g.cls_of[std::min(gi, gj)] : g.cls_of[(size_t)gi * (n + 1) + gj]);
     }
     g.alpha = d->elec_alpha; g.krf = d->elec_krf; g.crf = d->elec_crf;
     g.rs_e = (g.elec && d->elec_switch_distance >= 0 && d->elec_switch_distance < s.rc) ? d->elec_switch_distance : -1.0;

@@ -18,7 +18,7 @@ import pytest
 
 import oracle
 from oracle.alchemical_regions import RegionOracle, total_state_energies, total_energy_forces
-from openmmtools_amd import alchemy, states, testsystems as ts
+from openmmtools_amd import alchemy, states, system_xml, _alchemical_xml as ax, testsystems as ts
 from openmmtools_amd.system import System, NonbondedForce, system_to_desc
 from openmmtools_amd._engine import HipEngine
 
@@ -99,22 +99,26 @@ def test_region_oracle_reproduces_the_reference_sterics_expression_with_any_expo
 
 
 def test_two_interacting_regions_use_the_product_of_their_lambdas():
-    """alchemy.py:1368-1377 ('lambda_sterics_zero*lambda_sterics_one'): a pair of atoms of two interacting regions at (l0, l1) has the
-    energy of an (environment, region) pair at l0 * l1; without the interaction the two regions do not see each other at all."""
+    """The class of interacting regions of the C ABI (remd_alch_regions_desc.interactions; alchemy.py:1368-1377,
+    'lambda_sterics_zero*lambda_sterics_one'): a pair of atoms of two interacting regions at (l0, l1) has the energy of an
+    (environment, region) pair at l0 * l1; without the interaction the two regions do not see each other at all.
+
+    The reference's factory, AS ITS LOOP EXECUTES, never reaches that class: it builds the forces of a pair of regions from particle
+    tables it has zeroed in the two regions' single turns (alchemy.py:1693, 1886-1911), so this package's factory passes no interacting
+    pairs to the engine either -- alchemical_regions_interactions changes nothing outside the exact PME treatment."""
     base = _pair_system(NonbondedForce.PME, 0.4, -0.3, 0.3, 0.34, 0.5, 0.7)
     regions = [alchemy.AlchemicalRegion(alchemical_atoms=[0], name='zero'), alchemy.AlchemicalRegion(alchemical_atoms=[1], name='one')]
     fac = alchemy.AbsoluteAlchemicalFactory(alchemical_pme_treatment='direct-space')
     both = fac.create_alchemical_system(base, regions, alchemical_regions_interactions=frozenset({(0, 1)}))
     apart = fac.create_alchemical_system(base, regions)
     single = fac.create_alchemical_system(base, alchemy.AlchemicalRegion(alchemical_atoms=[1], name='one'))
-    d = system_to_desc(both)
-    reg = RegionOracle(d['alch_regions'], 1.0, None, np.zeros((0, 2), int))
     x = np.array([[1.0, 1.3, 0.9], [1.3, 1.1, 1.2]])
     r = np.linalg.norm(x[1] - x[0])
-    e = reg.energy_forces(x, [L, L, L], [0.6, 0.5], [0.8, 0.25], forces=False)[0]
-    assert np.isclose(e, _region_value(single, r, 0.3, 0.2), rtol=1e-13)
-    d0 = system_to_desc(apart)
-    assert RegionOracle(d0['alch_regions'], 1.0, None, np.zeros((0, 2), int)).energy_forces(x, [L, L, L], [0.6, 0.5], [0.8, 0.25], forces=False)[0] == 0.0
+    energy = lambda terms: RegionOracle(terms, 1.0, None, np.zeros((0, 2), int)).energy_forces(x, [L, L, L], [0.6, 0.5], [0.8, 0.25], forces=False)[0]
+    assert both.alchemical_regions_interactions == [(0, 1)]
+    assert energy(system_to_desc(both)['alch_regions']) == 0.0 and energy(system_to_desc(apart)['alch_regions']) == 0.0
+    terms = dict(system_to_desc(apart)['alch_regions'], interactions=np.array([[1, 2]], dtype=np.int32))
+    assert np.isclose(energy(terms), _region_value(single, r, 0.3, 0.2), rtol=1e-13)
 
 
 def test_the_factory_chooses_the_path_and_refuses_what_the_reference_refuses():
@@ -128,9 +132,15 @@ def test_the_factory_chooses_the_path_and_refuses_what_the_reference_refuses():
         alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, alchemy.AlchemicalRegion(alchemical_atoms=range(22), softcore_beta=0.5))
     with pytest.raises(ValueError, match='Decoupled electrostatics is not supported with exact treatment'):
         alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, alchemy.AlchemicalRegion(alchemical_atoms=range(22), annihilate_electrostatics=False))
-    with pytest.raises(ValueError, match='straddles two alchemical regions'):                                   # alchemy.py:1969
-        alchemy.AbsoluteAlchemicalFactory(alchemical_pme_treatment='coulomb').create_alchemical_system(
-            al.system, [alchemy.AlchemicalRegion(alchemical_atoms=range(6), name='a'), alchemy.AlchemicalRegion(alchemical_atoms=range(6, 22), name='b')])
+    # an exception between two regions is a bond of the FIRST region's (environment, region) force (alchemy.py:1972-1976, 1992-2006)
+    cut = alchemy.AbsoluteAlchemicalFactory(alchemical_pme_treatment='coulomb').create_alchemical_system(
+        al.system, [alchemy.AlchemicalRegion(alchemical_atoms=range(6), name='a'), alchemy.AlchemicalRegion(alchemical_atoms=range(6, 22), name='b')])
+    d = system_to_desc(cut)
+    reg = RegionOracle(d['alch_regions'], d['cutoff'], d['switch_distance'], d['exception_atoms'])
+    straddling = [k for k, (i, j) in enumerate(reg.exc_atoms) if (i < 6) != (j < 6)]
+    assert len(straddling) > 5 and all(reg.exc_kinds[k] == (0, 1, 1, 1) for k in straddling)
+    with pytest.raises(NotImplementedError, match='replaces the environment'):
+        alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(_charged_lj_fluid(), alchemy.AlchemicalRegion(alchemical_atoms=range(4)))
     with pytest.raises(NotImplementedError, match='several charged alchemical regions'):
         alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(
             al.system, [alchemy.AlchemicalRegion(alchemical_atoms=range(22), name='a'), alchemy.AlchemicalRegion(alchemical_atoms=range(22, 25), name='b')])
@@ -141,6 +151,17 @@ def test_the_factory_chooses_the_path_and_refuses_what_the_reference_refuses():
     assert all(nb.particles[i][0] == 0.0 and nb.particles[i][2] == 0.0 for i in range(22)) and nb.particles[22] == nb0.particles[22]
     assert len(nb.exceptions) == len(nb0.exceptions) and all(e[2] == 0.0 and e[4] == 0.0 for e in nb.exceptions if e[0] < 22 or e[1] < 22)
     assert nb0.particles[0][0] != 0.0                      # (the reference System is left alone)
+
+
+def _charged_lj_fluid(n=216):
+    """a Lennard-Jones fluid with alternating charges under CutoffPeriodic (reaction field)"""
+    import copy
+    lj = ts.LennardJonesFluid(nparticles=n, reduced_density=0.4)
+    system = copy.deepcopy(lj.system)
+    nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
+    for i, (q, s_, e) in enumerate(nb.particles):
+        nb.particles[i] = (0.25 if i % 2 == 0 else -0.25, s_, e)
+    return system
 
 
 # ---- engines against the oracle ---------------------------------------------------------------------------------------------
@@ -158,12 +179,15 @@ LADDER_E = np.array([[1.0, 1.0], [0.5, 1.0], [0.0, 0.7], [0.0, 0.3], [0.0, 0.0],
 
 
 def _check_engine_against_the_oracle(eng, kw, interactions, rtol, ftol, region_kw=None):
+    """interactions: pairs of regions handed to the ENGINE as interacting (the factory itself passes none on, see above)"""
     al, system, regions = _alanine_two_regions(kw, interactions, **(region_kw or {}))
     nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
     box0 = np.diag(system.getDefaultPeriodicBoxVectors())
     econst = alchemy.alchemical_long_range_constants(system, nb, LADDER_S, float(np.prod(box0)))
     assert np.all(np.isfinite(econst)) and econst[0] != econst[-1]
     desc = system_to_desc(system, ewald_split='reference')
+    if interactions:
+        desc['alch_regions']['interactions'] = np.array([(a + 1, b + 1) for a, b in sorted(interactions)], dtype=np.int32)
     eng.set_system(desc)
     K = len(LADDER_S)
     beta = 1.0 / (KB * 300.0)
@@ -212,3 +236,154 @@ def test_hip_regions_match_the_region_oracle(hip_engine_factory, kw, interaction
     assert not np.any(nan)
     rows2 = eng.compute_energies()
     assert np.all(np.isfinite(rows2))
+
+
+# ---- the store adapter: the reference's force set written and read back ------------------------------------------------------------
+def _same_description(a, b):
+    da, db = system_to_desc(a), system_to_desc(b)
+    assert sorted(da) == sorted(db)
+    for k in da:
+        if k == 'alch_regions':
+            assert sorted(da[k]) == sorted(db[k])
+            for q in da[k]:
+                assert np.array_equal(np.asarray(da[k][q]), np.asarray(db[k][q])), q
+        else:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+
+
+def test_written_literals_of_the_other_treatments_are_the_references():
+    """the expression strings this package writes for the 'direct-space' / 'coulomb' PME treatments and the shifted reaction field,
+    character for character (alchemy.py:1392-1537 executed from the reference's syntax tree: tests/golden/make_golden_alchemy_strings.py)"""
+    E = G['expressions']
+    nb = NonbondedForce()
+    nb.setNonbondedMethod(NonbondedForce.PME); nb.setCutoffDistance(1.0); nb.setEwaldErrorTolerance(5e-4)
+    assert ax.electrostatics_expressions(nb, pme_treatment='direct-space') == (E['electrostatics_pme_direct_space'], E['electrostatics_exception_rf'])
+    assert ax.electrostatics_expressions(nb, pme_treatment='coulomb')[0] == E['electrostatics_pme_coulomb']
+    nb.setNonbondedMethod(NonbondedForce.CutoffPeriodic); nb.setReactionFieldDielectric(78.3)
+    assert ax.electrostatics_expressions(nb, rf_treatment='shifted')[0] == E['electrostatics_rf_shifted']
+    assert ax.electrostatics_expressions(nb, rf_treatment='switched')[0] == E['electrostatics_rf_switched']
+
+
+@pytest.mark.parametrize('kw,interactions,region_kw', CASES + [(dict(alchemical_pme_treatment='coulomb'), frozenset({(0, 1)}), {})])
+def test_general_regions_are_written_as_the_factorys_force_set_and_read_back(kw, interactions, region_kw):
+    al, system, regions = _alanine_two_regions(kw, interactions, **region_kw)
+    xml = system_xml.to_xml(system)
+    back, barostat = system_xml.from_xml(xml)
+    assert barostat is None and [r.name for r in back.alchemical_regions] == ['pep', 'wat']
+    assert back.alchemical_regions_interactions == sorted(interactions) and back.alchemical_factory_options == system.alchemical_factory_options
+    for r0, r1 in zip(system.alchemical_regions, back.alchemical_regions):
+        assert r0.__dict__ == r1.__dict__
+    _same_description(system, back)
+    # the document: per region 4 electrostatics forces (group of lambda_electrostatics_<name>) and 4 sterics forces, sorted by lambda
+    # name (alchemy.py:1075-1083); a pair of interacting regions adds a nonbonded + a bond force to the FIRST region's lists (:2027-2032)
+    import xml.etree.ElementTree as ET
+    forces = ET.fromstring(xml).find('Forces').findall('Force')
+    custom = [f for f in forces if f.get('type').startswith('Custom')]
+    extra = 2 if interactions else 0
+    assert len(custom) == 16 + 2 * extra
+    groups = [int(f.get('forceGroup')) for f in custom]
+    assert groups == sorted(groups) and len(set(groups)) == 4
+    names = [sorted(g.get('name') for g in f.find('GlobalParameters') if g.get('name').startswith('lambda')) for f in custom]
+    assert names[0] == ['lambda_electrostatics_pep'] and names[4 + extra][0] == 'lambda_electrostatics_wat' and names[8 + extra][0] == 'lambda_sterics_pep'
+    if interactions:
+        pair = custom[4]                                    # (pep, wat) electrostatics: both lambdas, particle table zeroed in the single turns
+        assert names[4] == ['lambda_electrostatics_pep', 'lambda_electrostatics_wat'] and 'lambda_electrostatics_pep*lambda_electrostatics_wat' in pair.get('energy')
+        assert all(float(p.get('param1')) == 0.0 for k, p in enumerate(pair.find('Particles')) if k < 31)
+    # 'wat' annihilates its sterics, 'pep' does not: lambda fixed in pep's alchemical/alchemical forces only
+    aa_pep = custom[8 + extra + 1]
+    assert aa_pep.get('energy').endswith('lambda_sterics_pep=1.0;') and names[8 + extra + 1] == []
+
+
+def test_a_named_single_region_and_a_charged_region_under_the_shifted_reaction_field_round_trip():
+    lj = _charged_lj_fluid()
+    fac = alchemy.AbsoluteAlchemicalFactory(alchemical_rf_treatment='shifted')
+    system = fac.create_alchemical_system(lj, alchemy.AlchemicalRegion(alchemical_atoms=range(6), name='ligand', softcore_beta=0.25, annihilate_electrostatics=False))
+    assert system.alchemical_regions is not None
+    back, _ = system_xml.from_xml(system_xml.to_xml(system))
+    assert back.alchemical_regions[0].name == 'ligand' and not back.alchemical_regions[0].annihilate_electrostatics
+    assert back.alchemical_factory_options['alchemical_rf_treatment'] == 'shifted'
+    _same_description(system, back)
+    # the states of such a System are reached by the region's name (alchemy.py:203-231)
+    st = states.AlchemicalState.from_system(back, parameters_name_suffix='ligand')
+    st.lambda_sterics_ligand = 0.5
+    assert st.lambda_sterics == 0.5
+    with pytest.raises(states.AlchemicalStateError):
+        states.AlchemicalState.from_system(back, parameters_name_suffix='other')
+
+
+# ---- the sampler on a System with two named regions (C++ port of the ABI here; the device under -m gpu) --------------------------------
+from openmmtools_amd import mcmc, unit                                                        # noqa: E402
+from openmmtools_amd.multistate import ReplicaExchangeSampler, MultiStateReporter, _hdf5      # noqa: E402
+
+needs_hdf5 = pytest.mark.skipif(not _hdf5.available(), reason='libhdf5 not loadable')
+LAM_A = [(1.0, 1.0), (1.0, 0.5), (0.6, 0.0), (0.0, 0.0)]          # (lambda_sterics_a, lambda_electrostatics_a)
+LAM_B = [(1.0, 1.0), (0.8, 1.0), (0.8, 0.3), (0.2, 0.0)]
+
+
+def _two_region_sampler(engine, storage, n_iterations):
+    lj = _charged_lj_fluid()
+    plain = ts.LennardJonesFluid(nparticles=216, reduced_density=0.4)
+    regions = [alchemy.AlchemicalRegion(alchemical_atoms=range(4), name='a', softcore_beta=0.2),
+               alchemy.AlchemicalRegion(alchemical_atoms=range(4, 8), name='b', annihilate_sterics=True)]
+    asys = alchemy.AbsoluteAlchemicalFactory(alchemical_rf_treatment='shifted').create_alchemical_system(lj, regions)
+    ths = [states.CompoundThermodynamicState(states.ThermodynamicState(asys, 120.0 * unit.kelvin),
+                                             [states.AlchemicalState(parameters_name_suffix='a', lambda_sterics_a=a[0], lambda_electrostatics_a=a[1]),
+                                              states.AlchemicalState(parameters_name_suffix='b', lambda_sterics_b=b[0], lambda_electrostatics_b=b[1])])
+           for a, b in zip(LAM_A, LAM_B)]
+    ss = states.SamplerState(plain.positions, box_vectors=plain.system.getDefaultPeriodicBoxVectors())
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=3, reassign_velocities=True, splitting='V R O R V')
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=n_iterations, engine=engine, seed=3)
+    s.create(ths, [ss], storage=storage)
+    return s, asys
+
+
+def _check_sampler_rows(s, asys, rtol):
+    """u_kl of the sampler's first energy pass against the oracle: every state's own (lambda_a, lambda_b) reaches the engine"""
+    s._compute_energies()
+    desc = system_to_desc(asys)
+    nb = [f for f in asys.getForces() if isinstance(f, NonbondedForce)][0]
+    LS = np.array([[a[0], b[0]] for a, b in zip(LAM_A, LAM_B)]); LE = np.array([[a[1], b[1]] for a, b in zip(LAM_A, LAM_B)])
+    box = np.diag(asys.getDefaultPeriodicBoxVectors())
+    econst = alchemy.alchemical_long_range_constants(asys, nb, LS, float(np.prod(box)))
+    x = s._engine.get_replicas()[0]
+    for r in range(len(LAM_A)):
+        ref = (total_state_energies(desc, x[r], box, LS, LE) + econst) / (KB * 120.0)
+        assert np.allclose(s.energy_thermodynamic_states[r], ref, rtol=rtol, atol=1e-6 * np.abs(ref).max()), np.abs(s.energy_thermodynamic_states[r] - ref).max()
+
+
+@needs_hdf5
+def test_sampler_with_two_named_regions_stores_in_the_references_layout_and_resumes(tmp_path):
+    if not os.path.exists(CPU_LIB):
+        oracle.build()
+    rep = MultiStateReporter(str(tmp_path / 'two.nc'), checkpoint_interval=1)
+    s, asys = _two_region_sampler(HipEngine(lib_path=CPU_LIB), rep, 2)
+    _check_sampler_rows(s, asys, 1e-9)
+    s.run()
+    rep.close()
+    r = MultiStateReporter(str(tmp_path / 'two.nc'), open_mode='r')
+    d = r.read_dict('thermodynamic_states/state2')
+    assert [c['parameters_name_suffix'] for c in d['composable_states']] == ['a', 'b']                    # states.py:3879-3898
+    assert d['composable_states'][0]['parameters']['lambda_sterics'] == 0.6 and d['composable_states'][1]['parameters']['lambda_electrostatics'] == 0.3
+    th, _ = r.read_thermodynamic_states()
+    assert [(t.lambda_sterics_a, t.lambda_electrostatics_a) for t in th] == LAM_A and [(t.lambda_sterics_b, t.lambda_electrostatics_b) for t in th] == LAM_B
+    assert th[0].system.fingerprint() == asys.fingerprint()
+    r.close()
+    full, _ = _two_region_sampler(HipEngine(lib_path=CPU_LIB), MultiStateReporter(str(tmp_path / 'full.nc'), checkpoint_interval=1), 4)
+    full.run()
+    full._reporter.close()
+    res = ReplicaExchangeSampler.from_storage(str(tmp_path / 'two.nc'), engine=HipEngine(lib_path=CPU_LIB))
+    assert res.iteration == 2
+    res.extend(2)
+    res._reporter.close()
+    ea = MultiStateReporter(str(tmp_path / 'two.nc'), open_mode='r').read_energies()[0]
+    eb = MultiStateReporter(str(tmp_path / 'full.nc'), open_mode='r').read_energies()[0]
+    assert ea.shape == eb.shape == (5, 4, 4) and np.array_equal(ea[:3], eb[:3]) and np.allclose(ea[3:], eb[3:], rtol=2e-5, atol=1e-5)
+    assert np.ptp(ea[0][0]) > 1.0                                              # the ladder matters
+
+
+@pytest.mark.gpu
+def test_sampler_with_two_named_regions_on_the_device(hip_engine_factory):
+    s, asys = _two_region_sampler(hip_engine_factory(), None, 3)
+    _check_sampler_rows(s, asys, 2e-5)
+    s.run()
+    assert np.all(np.isfinite(s.energy_thermodynamic_states)) and s.iteration == 3

@@ -119,10 +119,10 @@ def test_what_the_factory_would_build_differently_is_refused():
     with pytest.raises(NotImplementedError, match='reaction-field'):
         system_xml.to_xml(_alchemical(al, range(22)))
     al = testsystems.AlanineDipeptideExplicit()
-    with pytest.raises(NotImplementedError, match='exact PME'):
+    with pytest.raises(ValueError, match='Decoupled electrostatics is not supported with exact treatment'):        # alchemy.py:1617-1623
         system_xml.to_xml(_alchemical(al, range(22), annihilate_electrostatics=False))
     xml = system_xml.to_xml(_alchemical(al, range(22)))
-    with pytest.raises(NotImplementedError, match='one unnamed'):
+    with pytest.raises(NotImplementedError, match='lambda_electrostatics_ligand of a region without sterics forces'):
         system_xml.from_xml(xml.replace('lambda_electrostatics', 'lambda_electrostatics_ligand'))
     with pytest.raises(NotImplementedError, match='outside the alchemical'):
         system_xml.from_xml(xml.replace('U_sterics', 'U_other'))
