@@ -255,13 +255,25 @@ def emit_region_forces(forces, system, emit_plain):
     nb = nbs[0]
     ewald = nb.getNonbondedMethod() in (NonbondedForce.Ewald, NonbondedForce.PME)
     exact = ewald and opts['alchemical_pme_treatment'] == 'exact'
-    if exact and len(regions) > 1:
-        raise NotImplementedError('a store of several regions under the exact PME treatment (the exclusions between the regions, alchemy.py:1663-1672)')
     n = nb.getNumParticles()
     # the reference NonbondedForce again (sigma = 0 already 0.1 nm): the kept force + what the custom forces took
     cur = [(float(terms['charge'][k]), float(terms['sigma'][k]), float(terms['epsilon'][k])) for k in range(n)]
     took = {frozenset((int(i), int(j))): tuple(float(v) for v in p) for (i, j), p in zip(terms['exception_atoms'], terms['exception_params'])}
     exc = [(i, j) + took.get(frozenset((i, j)), (qq, sg, ep)) for (i, j, qq, sg, ep) in nb.exceptions]
+    if exact:                                                                # regions that do not interact exclude each other (:1663-1672)
+        together = set(getattr(system, 'alchemical_regions_interactions', []))
+        have = {frozenset((i, j)): k for k, (i, j, _, _, _) in enumerate(exc)}
+        for x in range(len(regions)):
+            for y in range(x + 1, len(regions)):
+                if (x, y) in together:
+                    continue
+                for a1 in regions[x].alchemical_atoms:
+                    for a2 in regions[y].alchemical_atoms:
+                        k = have.get(frozenset((a1, a2)))
+                        if k is None:
+                            exc.append((a1, a2, 0.0, 1.0, 0.0))
+                        else:
+                            exc[k] = (exc[k][0], exc[k][1], 0.0, 1.0, 0.0)
     exclusions = [(i, j) for (i, j, _, _, _) in exc]
     alch_all = set()
     for r in regions:
@@ -629,6 +641,13 @@ def rebuild_general_system(system, nb, global_parameters, particle_offsets, exce
             key = frozenset((i, j))
             sig, eps = lj_of.get(key, (s_, 0.0))
             nb.exceptions[n] = (i, j, qq_of.get(n, qq_bond.get(key, 0.0)), sig, eps)
+    if exact and len(order) > 1:
+        # the exclusions the factory put between regions that do not interact (:1663-1672) are its own: this package's factory (and the
+        # engine) exclude those pairs without listing them
+        slot = {x: k for k, x in enumerate(order)}
+        nb.exceptions[:] = [e for e in nb.exceptions
+                            if not (e[0] in owner and e[1] in owner and owner[e[0]] != owner[e[1]] and (e[2], e[3], e[4]) == (0.0, 1.0, 0.0)
+                                    and tuple(sorted((slot[owner[e[0]]], slot[owner[e[1]]]))) not in interactions)]
     first = na_s[order[0]]
     use_lrc = first['attrs'].get('useLongRangeCorrection', '0') not in ('0', 'false')
     if particle_offsets or global_parameters:                    # the factory put it into a lambda_electrostatics group

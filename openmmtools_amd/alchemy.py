@@ -20,8 +20,8 @@ Two device paths serve it:
     force split: the System keeps the NonbondedForce the factory leaves behind (alchemical charges and epsilons zeroed) and carries
     ``alchemical_regions`` + ``alchemical_region_terms`` (the custom forces' parameters) for csrc/alch_regions.hip
     (remd_set_alchemical_regions).
-Not built: the exact PME treatment with SEVERAL charged regions (per-region charge offsets inside the Ewald sum), alchemically
-softened bonds / angles / torsions, GBSA.  This module also computes the per-state long-range-correction constants that
+Under the exact PME treatment that path scales every region's charges by its own lambda_electrostatics inside the whole Ewald sum
+(remd_alch_regions_desc.exact_pme).  Not built: alchemically softened bonds / angles / torsions, GBSA.  This module also computes the per-state long-range-correction constants that
 MultiStateSampler hands to remd_set_states(energy_const).
 """
 import copy
@@ -118,9 +118,6 @@ class AbsoluteAlchemicalFactory:
             return system
         if nb is None:
             raise ValueError('alchemical regions need a NonbondedForce')
-        if exact and charged:
-            raise NotImplementedError('the exact PME treatment with several charged alchemical regions (per-region charge offsets inside the '
-                                      'Ewald sum, alchemy.py:1663-1681, 1893-1899) is not built: use alchemical_pme_treatment=\'direct-space\' or \'coulomb\'')
         if self.consistent_exceptions:
             raise NotImplementedError('consistent_exceptions=True (alchemy.py:1457-1459)')
         if nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic and self.alchemical_rf_treatment == 'switched' and \
@@ -140,11 +137,11 @@ class AbsoluteAlchemicalFactory:
         system.alchemical_regions_interactions = interactions
         system.alchemical_factory_options = dict(alchemical_pme_treatment=self.alchemical_pme_treatment,
                                                  alchemical_rf_treatment=self.alchemical_rf_treatment, switch_width=self.switch_width)
-        system.alchemical_region_terms = self._region_terms(nb, regions, charged)
+        system.alchemical_region_terms = self._region_terms(nb, regions, charged, exact, interactions)
         return system
 
     # ---- the factory's split of a NonbondedForce (alchemy.py:1539-2038) ---------------------------------------------
-    def _region_terms(self, nb, regions, charged):
+    def _region_terms(self, nb, regions, charged, exact=False, interactions=()):
         """Zero the alchemical atoms in ``nb`` (what the factory leaves in the NonbondedForce, :1903-1911, 2001-2006) and return the
         parameters of the custom forces: the dict system_to_desc passes on as ``alch_regions`` (remd_alch_regions_desc)."""
         from .system import NonbondedForce
@@ -155,9 +152,16 @@ class AbsoluteAlchemicalFactory:
         p = np.array(nb.particles, dtype=np.float64).reshape(-1, 3)
         p[p[:, 1] == 0.0, 1] = 0.1                                       # sigma = 0 -> 1 A (:1638-1648)
         exc_atoms, exc_params = [], []
+        together = set(interactions)
         for k, e in enumerate(nb.exceptions):
             i, j, qq, sig, eps = e
             if region_of[i] == 0 and region_of[j] == 0:
+                continue
+            if exact and charged and region_of[i] and region_of[j] and region_of[i] != region_of[j] and \
+                    (min(region_of[i], region_of[j]) - 1, max(region_of[i], region_of[j]) - 1) not in together:
+                # exact PME treatment: two regions that do not interact exclude each other BEFORE the loop -- addException(atom1, atom2,
+                # 0.0, 1.0, 0.0, replace=True), alchemy.py:1663-1672 -- which wipes an exception between them
+                nb.exceptions[k] = (i, j, 0.0, 1.0, 0.0)
                 continue
             if sig == 0.0:
                 sig = 0.1                                                # (:1650-1661)
@@ -177,8 +181,15 @@ class AbsoluteAlchemicalFactory:
                      charge=p[:, 0].copy(), sigma=p[:, 1].copy(), epsilon=p[:, 2].copy(),
                      exception_atoms=np.array(exc_atoms, dtype=np.int32).reshape(-1, 2),
                      exception_params=np.array(exc_params, dtype=np.float64).reshape(-1, 3),
-                     electrostatics=int(bool(charged)), elec_alpha=0.0, elec_krf=0.0, elec_crf=0.0, elec_switch_distance=-1.0)
-        if charged:
+                     electrostatics=int(bool(charged)), elec_alpha=0.0, elec_krf=0.0, elec_crf=0.0, elec_switch_distance=-1.0, exact_pme=0)
+        if exact and charged:
+            # the exact PME treatment (alchemy.py:1663-1681, 1893-1899, 1978-1982): no electrostatic custom forces; `charge` and the
+            # exceptions above are the parameter OFFSETS of the NonbondedForce (scaled by the region's lambda_electrostatics inside the
+            # whole Ewald sum), regions that do not interact exclude each other, regions that do see each other's scaled charges
+            terms['exact_pme'] = 1
+            terms['electrostatics'] = 0
+            terms['interactions'] = np.array([(a + 1, b + 1) for a, b in interactions], dtype=np.int32).reshape(-1, 2)
+        elif charged:
             if method == NonbondedForce.PME:
                 if self.alchemical_pme_treatment == 'direct-space':                                      # :1510-1537
                     alpha = nb._pme_params[0] if nb._pme_params is not None else 0.0

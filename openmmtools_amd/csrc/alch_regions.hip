@@ -22,6 +22,10 @@ struct region_consts {
     float rs_e, inv_sw_e;                  // electrostatics switch (rs_e < 0: none)
     float alpha_e, two_alpha_sqrtpi_e, krf, crf;
     int elec, n_cls, n_reg1, words, N, Npad, n_alch, n_exc;
+    // exact PME treatment: the Ewald split of the handle (erfc to rcc), per region the self term, the net charge, the environment's
+    // net charge and the coefficient of the neutralising background (E = coeff Q^2 / V)
+    int exact; float alpha_x, two_alpha_sqrtpi_x, rcc2;
+    double self_x[4], q_x[4], q_env, plasma;
 };
 
 struct region_tables {
@@ -38,6 +42,13 @@ struct region_tables {
     int* d_exc_atoms = nullptr; float4* d_exc_par = nullptr;      // exceptions: (k_e qq, sigma, 4 eps, class bits)
     float4* d_state_cls = nullptr;         // [K][n_cls][2]: (l^a, alpha (1 - l)^b, l^d, beta (1 - l)^e), (c, f, 0, 0)
     int* d_own = nullptr; std::vector<int> own_host;
+    // exact PME treatment (<= 4 charged regions: the slots of one float4 per replica, which the mesh kernels index by the atom's code)
+    unsigned int* d_corr = nullptr;        // [n_alch][words] skipped candidates that still get the Ewald correction -qq erf(alpha r) / r
+    float4* d_param_pme = nullptr;         // [Npad] the mesh kernels' charges: reference charges of the alchemical atoms, w = 8 + region slot
+    float* d_rep_le = nullptr;             // [R][4] lambda_electrostatics of the regions at each replica's state (or the probe's)
+    std::vector<float> rep_le_host;
+    float* d_state_le = nullptr;           // [K][4]
+    bool have_override = false; float le_override[4] = {1.f, 1.f, 1.f, 1.f};
 };
 static handle_table<region_tables> g_reg;
 
@@ -94,35 +105,61 @@ __device__ __forceinline__ void region_electrostatics(float4 A, float4 B, float 
     dUdr = A.z * qq * dg * (reff / base * t * inv_r);
 }
 
+// lambda_electrostatics of the region an atom (or an exception) belongs to, exact PME treatment: slot = region - 1 of the replica's float4
+__device__ __forceinline__ float region_le(const float* __restrict__ le4, int g) { return g > 0 ? le4[g - 1] : 1.f; }
+
 // one candidate pair (alchemical atom a, atom j): energy and dU/dr / r; false: nothing to add
+// exact PME treatment (le4 != NULL): the alchemical atom's direct-space Ewald term with the scaled charges, to the Coulomb range of the split
 __device__ __forceinline__ bool region_pair(const region_consts& c, const float4* __restrict__ cls_tab, const int* __restrict__ cls_of,
-                                            float4 pa, float4 pj, float3 d, float& U, float& fr)
+                                            float4 pa, float4 pj, float3 d, float& U, float& fr, const float* __restrict__ le4 = nullptr)
 {
     const float r2 = dotf(d, d);
-    if (r2 >= c.rc2) return false;
-    const int k = cls_of[__float_as_int(pa.w) * c.n_reg1 + __float_as_int(pj.w)];
-    const float4 A = cls_tab[2 * k], B = cls_tab[2 * k + 1];
+    if (r2 >= (le4 ? fmaxf(c.rc2, c.rcc2) : c.rc2)) return false;
+    const int ga = __float_as_int(pa.w), gj = __float_as_int(pj.w);
+    const int k = cls_of[ga * c.n_reg1 + gj];
     const float inv_r = rsqrtf(r2), r = r2 * inv_r;
     const float sig = pa.y + pj.y, eps4 = pa.z * pj.z, qq = pa.x * pj.x;
     U = 0.f; float dU = 0.f;
-    if (eps4 != 0.f) {
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
+    if (k >= 0) { A = cls_tab[2 * k]; B = cls_tab[2 * k + 1]; }
+    if (k >= 0 && eps4 != 0.f && r2 < c.rc2) {
         region_sterics(A, B, sig, eps4, r, inv_r, U, dU);
         region_switch(c.rs, c.inv_sw, r, U, dU);
     }
-    if (c.elec && qq != 0.f) {
+    if (k >= 0 && c.elec && qq != 0.f) {
         float Ue, dUe;
         region_electrostatics(A, B, c.alpha_e, c.two_alpha_sqrtpi_e, c.krf, c.crf, sig, qq, r, inv_r, Ue, dUe);
         region_switch(c.rs_e, c.inv_sw_e, r, Ue, dUe);
         U += Ue; dU += dUe;
     }
+    if (le4 && qq != 0.f && r2 < c.rcc2) {
+        const float L = region_le(le4, ga) * region_le(le4, gj) * qq;
+        const float ar = c.alpha_x * r, ec = erfcf(ar);
+        U += L * ec * inv_r;
+        dU -= L * (ec * inv_r + c.two_alpha_sqrtpi_x * expf(-ar * ar)) * inv_r;
+    }
     fr = dU * inv_r;
     return true;
 }
 
-// exception t: soft-core sterics without cutoff or switch, electrostatics l^d qq / reff (alchemy.py:1374-1380, 1434, 1456-1461)
-__device__ __forceinline__ void region_exception(const region_consts& c, const float4* __restrict__ cls_tab, float4 par, float3 d, float& U, float& fr)
+// exact PME treatment: the reciprocal sum holds every pair; an excluded one (and a pair of two regions that do not interact,
+// alchemy.py:1663-1672) is taken out again: -qq erf(alpha r) / r with the scaled charges, at any distance
+__device__ __forceinline__ void region_ewald_correction(const region_consts& c, float4 pa, float4 pj, float3 d, const float* __restrict__ le4, float& U, float& fr)
 {
-    const int k = __float_as_int(par.w);
+    const float r2 = dotf(d, d);
+    const float inv_r = rsqrtf(r2), r = r2 * inv_r;
+    const float L = region_le(le4, __float_as_int(pa.w)) * region_le(le4, __float_as_int(pj.w)) * pa.x * pj.x;
+    const float ar = c.alpha_x * r, ef = erff(ar);
+    U = -L * ef * inv_r;
+    fr = -L * (c.two_alpha_sqrtpi_x * expf(-ar * ar) * inv_r - ef * inv_r * inv_r) * inv_r;
+}
+
+// exception t: soft-core sterics without cutoff or switch, electrostatics l^d qq / reff (alchemy.py:1374-1380, 1434, 1456-1461);
+// exact PME treatment: the charge product times the lambda of the region that owns the exception (its parameter offset, :1978-1982)
+__device__ __forceinline__ void region_exception(const region_consts& c, const float4* __restrict__ cls_tab, float4 par, float3 d, float& U, float& fr,
+                                                 const float* __restrict__ le4 = nullptr)
+{
+    const int w = __float_as_int(par.w), k = w & 0xffff;
     const float4 A = cls_tab[2 * k], B = cls_tab[2 * k + 1];
     const float r2 = dotf(d, d);
     const float inv_r = rsqrtf(r2), r = r2 * inv_r;
@@ -132,6 +169,10 @@ __device__ __forceinline__ void region_exception(const region_consts& c, const f
         float Ue, dUe;
         region_electrostatics(A, B, 0.f, 0.f, 0.f, 0.f, par.y, par.x, r, inv_r, Ue, dUe);
         U += Ue; dU += dUe;
+    }
+    if (le4 && par.x != 0.f) {
+        const float L = region_le(le4, w >> 16) * par.x;
+        U += L * inv_r; dU -= L * inv_r * inv_r;
     }
     fr = dU * inv_r;
 }
@@ -148,9 +189,11 @@ __global__ __launch_bounds__(256)
 void region_forces_kernel(region_consts c, const int* __restrict__ alch, const float4* __restrict__ atom, const unsigned int* __restrict__ skip,
                           const int* __restrict__ cls_of, const float4* __restrict__ state_cls, const int* __restrict__ own,
                           const int* __restrict__ exc_atoms, const float4* __restrict__ exc_par,
-                          const float4* __restrict__ pos, const float* __restrict__ box, long long* __restrict__ force)
+                          const float4* __restrict__ pos, const float* __restrict__ box, long long* __restrict__ force,
+                          const unsigned int* __restrict__ corr, const float* __restrict__ rep_le)
 {
     const int r = blockIdx.y;
+    const float* le4 = rep_le ? rep_le + 4 * r : nullptr;
     const int nchunk = (c.N + REGION_CHUNK - 1) / REGION_CHUNK;
     const int ia = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
     const float4* P = pos + (size_t)r * c.Npad;
@@ -163,10 +206,15 @@ void region_forces_kernel(region_consts c, const int* __restrict__ alch, const f
     float fx = 0.f, fy = 0.f, fz = 0.f;
     const int j1 = min(c.N, (chunk + 1) * REGION_CHUNK);
     for (int j = chunk * REGION_CHUNK + threadIdx.x; j < j1; j += 256) {
-        if ((skip[(size_t)ia * c.words + (j >> 5)] >> (j & 31)) & 1u) continue;
+        const size_t word = (size_t)ia * c.words + (j >> 5);
         const float3 d = region_min_image(sub3(ld3(P, j), xa), Lx, Ly, Lz);
         float U, fr;
-        if (!region_pair(c, cls_tab, cls_of, pa, atom[j], d, U, fr)) continue;
+        if ((skip[word] >> (j & 31)) & 1u) {
+            if (!le4 || !((corr[word] >> (j & 31)) & 1u)) continue;
+            const float4 pj = atom[j];
+            if (pa.x * pj.x == 0.f) continue;
+            region_ewald_correction(c, pa, pj, d, le4, U, fr);
+        } else if (!region_pair(c, cls_tab, cls_of, pa, atom[j], d, U, fr, le4)) continue;
         fx += fr * d.x; fy += fr * d.y; fz += fr * d.z;
         add_force(F, c.Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
     }
@@ -178,7 +226,7 @@ void region_forces_kernel(region_consts c, const int* __restrict__ alch, const f
         float3 d = sub3(ld3(P, j), ld3(P, i));
         if (Lx > 0.f) d = region_min_image(d, Lx, Ly, Lz);
         float U, fr;
-        region_exception(c, cls_tab, exc_par[t], d, U, fr);
+        region_exception(c, cls_tab, exc_par[t], d, U, fr, le4);
         add_force(F, c.Npad, i, fr * d.x, fr * d.y, fr * d.z);
         add_force(F, c.Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
     }
@@ -189,10 +237,13 @@ __global__ __launch_bounds__(256)
 void region_energy_kernel(region_consts c, const int* __restrict__ alch, const float4* __restrict__ atom, const unsigned int* __restrict__ skip,
                           const int* __restrict__ cls_of, const float4* __restrict__ state_cls, const int* __restrict__ own,
                           const int* __restrict__ exc_atoms, const float4* __restrict__ exc_par,
-                          const float4* __restrict__ pos, const float* __restrict__ box, double* __restrict__ out, int out_stride, int out_offset)
+                          const float4* __restrict__ pos, const float* __restrict__ box, double* __restrict__ out, int out_stride, int out_offset,
+                          const unsigned int* __restrict__ corr, const float* __restrict__ rep_le)
 {
+    // rep_le (exact PME treatment): the electrostatic terms at the replicas' lambdas ride along; NULL: sterics / custom electrostatics only
     __shared__ double s_part[4];
     const int r = blockIdx.y;
+    const float* le4 = rep_le ? rep_le + 4 * r : nullptr;
     const int state = own ? own[r] : blockIdx.x;
     const float4* P = pos + (size_t)r * c.Npad;
     const float4* cls_tab = state_cls + (size_t)state * c.n_cls * 2;
@@ -201,23 +252,39 @@ void region_energy_kernel(region_consts c, const int* __restrict__ alch, const f
     const int total = c.n_alch * c.N;
     for (int t = threadIdx.x; t < total; t += 256) {
         const int ia = t / c.N, j = t - ia * c.N;
-        if ((skip[(size_t)ia * c.words + (j >> 5)] >> (j & 31)) & 1u) continue;
+        const size_t word = (size_t)ia * c.words + (j >> 5);
+        const bool skipped = (skip[word] >> (j & 31)) & 1u;
+        if (skipped && (!le4 || !((corr[word] >> (j & 31)) & 1u))) continue;
         const int a = alch[ia];
         const float3 d = region_min_image(sub3(ld3(P, j), ld3(P, a)), Lx, Ly, Lz);
         float U, fr;
-        if (region_pair(c, cls_tab, cls_of, atom[a], atom[j], d, U, fr)) e += (double)U;
+        if (skipped) {
+            const float4 pa = atom[a], pj = atom[j];
+            if (pa.x * pj.x != 0.f) { region_ewald_correction(c, pa, pj, d, le4, U, fr); e += (double)U; }
+        } else if (region_pair(c, cls_tab, cls_of, atom[a], atom[j], d, U, fr, le4)) e += (double)U;
     }
     for (int t = threadIdx.x; t < c.n_exc; t += 256) {
         float3 d = sub3(ld3(P, exc_atoms[2 * t + 1]), ld3(P, exc_atoms[2 * t]));
         if (Lx > 0.f) d = region_min_image(d, Lx, Ly, Lz);
         float U, fr;
-        region_exception(c, cls_tab, exc_par[t], d, U, fr);
+        region_exception(c, cls_tab, exc_par[t], d, U, fr, le4);
         e += (double)U;
     }
     for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = e;
     __syncthreads();
-    if (threadIdx.x == 0) out[(size_t)r * out_stride + out_offset + (own ? 0 : blockIdx.x)] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (threadIdx.x == 0) {
+        double tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (le4) {
+            // Ewald self terms of the regions' scaled charges and their part of the neutralising background (the environment's are with
+            // the handle's constants: forces.hip const_energy_kernel)
+            double Q = c.q_env;
+            for (int g = 0; g < 4; ++g) { const double l = (double)le4[g]; tot += l * l * c.self_x[g]; Q += l * c.q_x[g]; }
+            const double V = (double)Lx * (double)Ly * (double)Lz;
+            if (V > 0) tot += c.plasma * (Q * Q - c.q_env * c.q_env) / V;
+        }
+        out[(size_t)r * out_stride + out_offset + (own ? 0 : blockIdx.x)] = tot;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -227,9 +294,10 @@ void remd_regions_release(remd_ctx* h)
     if (t) {
         dfree(t->d_alch); dfree(t->d_atom); dfree(t->d_skip); dfree(t->d_cls_of); dfree(t->d_exc_atoms); dfree(t->d_exc_par);
         dfree(t->d_state_cls); dfree(t->d_own);
+        dfree(t->d_corr); dfree(t->d_param_pme); dfree(t->d_rep_le); dfree(t->d_state_le);
         g_reg.erase(h);
     }
-    h->n_regions = 0;
+    h->n_regions = 0; h->regions_exact = 0;
 }
 
 int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
@@ -264,9 +332,17 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         cls_of[g] = cls_of[(size_t)g * (n + 1)] = (int)t.classes.size(); t.classes.push_back({0, g, g, g});
         cls_of[(size_t)g * (n + 1) + g] = (int)t.classes.size(); t.classes.push_back({1, g, g, g});
     }
+    const bool exact = d->exact_pme != 0;
+    if (exact && (h->nb_method != REMD_NB_PME || n > 4)) {
+        remd_regions_release(h);
+        return remd_fail(h, exact && n > 4 ? -3 : -1, n > 4 ? "alchemical regions: more than four regions under the exact PME treatment are not supported" : "alchemical regions: exact_pme needs a PME system");
+    }
+    std::vector<char> interacting((size_t)(n + 1) * (n + 1), 0);
     for (int k = 0; k < d->n_interactions; ++k) {
         const int a = d->interactions[2 * k], b = d->interactions[2 * k + 1];
         if (a < 1 || b < 1 || a > n || b > n || a == b) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: bad pair of interacting regions"); }
+        interacting[(size_t)a * (n + 1) + b] = interacting[(size_t)b * (n + 1) + a] = 1;
+        if (exact) continue;                // exact PME: the pair sees each other's scaled charges; no sterics (tables zeroed, alchemy.py:1886-1911)
         if (cls_of[(size_t)a * (n + 1) + b] >= 0) continue;
         cls_of[(size_t)a * (n + 1) + b] = cls_of[(size_t)b * (n + 1) + a] = (int)t.classes.size(); t.classes.push_back({2, a, b, b});
     }
@@ -285,14 +361,20 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     const int na = (int)alch.size(), words = (N + 31) / 32;
     std::vector<int> ord(N, -1);
     for (int k = 0; k < na; ++k) ord[alch[k]] = k;
-    std::vector<unsigned int> skip((size_t)na * words, 0u);
+    std::vector<unsigned int> skip((size_t)na * words, 0u), corr(exact ? (size_t)na * words : 0, 0u);
     auto set_skip = [&](int ia, int j) { skip[(size_t)ia * words + (j >> 5)] |= 1u << (j & 31); };
+    // exact PME treatment: an excluded pair's share of the reciprocal sum is taken out by the custom-forces launch (once per pair)
+    auto set_corr = [&](int ia, int j) { if (exact && j != alch[ia] && !(d->region_of_atom[j] > 0 && j < alch[ia])) corr[(size_t)ia * words + (j >> 5)] |= 1u << (j & 31); };
     for (int ia = 0; ia < na; ++ia) {
         const int a = alch[ia], ga = d->region_of_atom[a];
         for (int j = 0; j < N; ++j) {
             const int gj = d->region_of_atom[j];
             // itself; an alchemical/alchemical pair is taken from its lower atom; regions that do not interact
-            if (j == a || (gj > 0 && j < a) || cls_of[(size_t)ga * (n + 1) + gj] < 0) set_skip(ia, j);
+            if (j == a || (gj > 0 && j < a)) set_skip(ia, j);
+            else if (cls_of[(size_t)ga * (n + 1) + gj] < 0) {
+                if (!exact) set_skip(ia, j);
+                else if (!interacting[(size_t)ga * (n + 1) + gj]) { set_skip(ia, j); set_corr(ia, j); }       // alchemy.py:1663-1672
+            }
             // environment atoms without sigma cannot enter the mixing rule: they have neither epsilon nor (in the factory's system) a way to interact
             else if (gj == 0 && !(d->sigma[j] > 0) && (d->epsilon[j] != 0.0 || (d->electrostatics && d->charge[j] != 0.0))) {
                 remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: sigma must be positive (the factory sets 0 to 0.1 nm, alchemy.py:1638-1648)");
@@ -303,8 +385,8 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     const remd_system_desc& sd = h->sysdesc->d;
     for (int e = 0; e < sd.n_exceptions; ++e) {
         const int i = sd.exception_atoms[2 * e], j = sd.exception_atoms[2 * e + 1];
-        if (ord[i] >= 0) set_skip(ord[i], j);
-        if (ord[j] >= 0) set_skip(ord[j], i);
+        if (ord[i] >= 0) { set_skip(ord[i], j); set_corr(ord[i], j); }
+        if (ord[j] >= 0) { set_skip(ord[j], i); set_corr(ord[j], i); }
     }
     // the exceptions that became custom bonds
     std::vector<int> ea; std::vector<float4> ep;
@@ -313,28 +395,55 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         if (i < 0 || j < 0 || i >= N || j >= N || i == j) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: bad exception pair"); }
         const int gi = d->region_of_atom[i], gj = d->region_of_atom[j];
         const double qq = d->exception_params[3 * e], sg = d->exception_params[3 * e + 1], eps = d->exception_params[3 * e + 2];
-        if ((gi == 0 && gj == 0) || (eps == 0.0 && (qq == 0.0 || !d->electrostatics))) continue;
+        if ((gi == 0 && gj == 0) || (eps == 0.0 && (qq == 0.0 || !(d->electrostatics || exact)))) continue;
         if (!(sg > 0)) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: exception sigma must be positive"); }
         // an exception between atoms of two regions belongs to the FIRST region's (environment, region) bond force: the factory's loop meets
         // it there as "only one alchemical" and zeroes it before the second region's turn (alchemy.py:1972-1976, 1992-2006)
         const int cl = (gi > 0 && gj > 0 && gi != gj) ? cls_of[std::min(gi, gj)] : cls_of[(size_t)gi * (n + 1) + gj];
+        const int owner = (gi > 0 && gj > 0) ? std::min(gi, gj) : std::max(gi, gj);       // whose lambda_electrostatics the charge product's offset carries
         ea.push_back(i); ea.push_back(j);
-        ep.push_back(make_float4((float)(qq * REMD_ONE_4PI_EPS0), (float)sg, (float)(4.0 * eps), host_int_as_float(cl)));
+        ep.push_back(make_float4((float)(qq * REMD_ONE_4PI_EPS0), (float)sg, (float)(4.0 * eps), host_int_as_float(cl | (owner << 16))));
     }
     region_consts& c = t.c;
-    c.rc2 = (float)(h->cutoff * h->cutoff);
-    c.rs = h->switch_dist >= 0 && h->switch_dist < h->cutoff ? (float)h->switch_dist : -1.f;
-    c.inv_sw = c.rs >= 0.f ? (float)(1.0 / (h->cutoff - h->switch_dist)) : 0.f;
-    c.elec = d->electrostatics ? 1 : 0;
-    c.rs_e = c.elec && d->elec_switch_distance >= 0 && d->elec_switch_distance < h->cutoff ? (float)d->elec_switch_distance : -1.f;
-    c.inv_sw_e = c.rs_e >= 0.f ? (float)(1.0 / (h->cutoff - d->elec_switch_distance)) : 0.f;
+    // the NonbondedForce's cutoff and switch (h->cutoff is the range of the Ewald direct-space sum, which a rebalanced split stretches)
+    const double rcut = sd.cutoff, rsw = sd.switch_distance;
+    c.rc2 = (float)(rcut * rcut);
+    c.rs = rsw > 0 && rsw < rcut ? (float)rsw : -1.f;
+    c.inv_sw = c.rs >= 0.f ? (float)(1.0 / (rcut - rsw)) : 0.f;
+    c.elec = (d->electrostatics && !exact) ? 1 : 0;
+    c.exact = exact ? 1 : 0;
+    for (int g = 0; g < 4; ++g) c.self_x[g] = c.q_x[g] = 0.0;
+    c.q_env = 0.0; c.plasma = 0.0; c.alpha_x = c.two_alpha_sqrtpi_x = 0.f; c.rcc2 = 0.f;
+    std::vector<float4> param_pme;
+    if (exact) {
+        // the handle's Ewald split (h->cutoff: the range of its direct-space sum)
+        c.alpha_x = (float)h->ewald_alpha; c.two_alpha_sqrtpi_x = (float)(2.0 * h->ewald_alpha / sqrt(M_PI)); c.rcc2 = (float)(h->cutoff * h->cutoff);
+        c.plasma = -REMD_ONE_4PI_EPS0 * M_PI / (2.0 * h->ewald_alpha * h->ewald_alpha);
+        param_pme.assign(h->Npad, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int i = 0; i < N; ++i) {
+            const int g = d->region_of_atom[i];
+            if (g > 0) {
+                c.self_x[g - 1] += -REMD_ONE_4PI_EPS0 * h->ewald_alpha / sqrt(M_PI) * d->charge[i] * d->charge[i];
+                c.q_x[g - 1] += d->charge[i];
+                param_pme[i] = make_float4((float)(d->charge[i] * sqk), 0.f, 0.f, (float)(8 + g - 1));
+            } else {
+                if (sd.charge[i] != d->charge[i]) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: the charges of the environment differ from the system's"); }
+                c.q_env += sd.charge[i];
+                param_pme[i] = make_float4((float)(sd.charge[i] * sqk), 0.f, 0.f, 0.f);
+            }
+            if (g > 0 && sd.charge[i] != 0.0) { remd_regions_release(h); return remd_fail(h, -1, "alchemical regions (exact PME): the system's descriptor must carry the alchemical atoms without charge"); }
+        }
+    }
+    c.rs_e = c.elec && d->elec_switch_distance >= 0 && d->elec_switch_distance < rcut ? (float)d->elec_switch_distance : -1.f;
+    c.inv_sw_e = c.rs_e >= 0.f ? (float)(1.0 / (rcut - d->elec_switch_distance)) : 0.f;
     c.alpha_e = (float)d->elec_alpha; c.two_alpha_sqrtpi_e = (float)(2.0 * d->elec_alpha / sqrt(M_PI));
     c.krf = (float)d->elec_krf; c.crf = (float)d->elec_crf;
     c.n_cls = (int)t.classes.size(); c.n_reg1 = n + 1; c.words = words; c.N = N; c.Npad = h->Npad; c.n_alch = na; c.n_exc = (int)ea.size() / 2;
     int rc;
     if ((rc = upload(h, t.d_alch, alch)) || (rc = upload(h, t.d_atom, atom)) || (rc = upload(h, t.d_skip, skip)) || (rc = upload(h, t.d_cls_of, cls_of)) ||
-        (rc = upload(h, t.d_exc_atoms, ea)) || (rc = upload(h, t.d_exc_par, ep))) { remd_regions_release(h); return rc; }
-    h->n_regions = n;
+        (rc = upload(h, t.d_exc_atoms, ea)) || (rc = upload(h, t.d_exc_par, ep)) || (rc = upload(h, t.d_corr, corr)) ||
+        (rc = upload(h, t.d_param_pme, param_pme))) { remd_regions_release(h); return rc; }
+    h->n_regions = n; h->regions_exact = exact ? 1 : 0;
     return 0;
 }
 
@@ -368,6 +477,10 @@ int remd_set_region_lambdas(remd_handle h, int K, int n_regions, const double* l
         }
     int rc = upload(h, t.d_state_cls, tab);
     if (rc) return rc;
+    std::vector<float> sle((size_t)K * 4, 1.f);
+    for (int k = 0; k < K; ++k) for (int g = 0; g < n && g < 4; ++g) sle[4 * (size_t)k + g] = (float)le[(size_t)k * n + g];
+    if ((rc = upload(h, t.d_state_le, sle))) return rc;
+    t.rep_le_host.clear();
     h->config_version++;
     h->forces_valid = false;
     return 0;
@@ -378,6 +491,18 @@ static int region_own_states(remd_ctx* h, region_tables& t)
     std::vector<int> own(h->R);
     for (int r = 0; r < h->R; ++r) own[r] = h->labels.empty() ? 0 : (int)h->labels[h->r_begin + r];
     for (int r = 0; r < h->R; ++r) if (own[r] < 0 || own[r] >= t.K) return remd_fail(h, -1, "alchemical regions: a replica's state has no region lambdas");
+    if (t.c.exact) {
+        // lambda_electrostatics of the regions per replica: its own state's, or the probe's (u_kl passes)
+        std::vector<float> rl(4 * (size_t)h->R, 1.f);
+        for (int r = 0; r < h->R; ++r) for (int g = 0; g < t.n_regions; ++g)
+            rl[4 * (size_t)r + g] = t.have_override ? t.le_override[g] : (float)t.le[(size_t)own[r] * t.n_regions + g];
+        if (rl != t.rep_le_host || !t.d_rep_le) {
+            if (t.rep_le_host.size() != rl.size() || !t.d_rep_le) { dfree(t.d_rep_le); REMD_CHECK(h, hipMalloc(&t.d_rep_le, sizeof(float) * rl.size())); }
+            REMD_CHECK(h, hipMemcpyAsync(t.d_rep_le, rl.data(), sizeof(float) * rl.size(), hipMemcpyHostToDevice, h->stream));
+            REMD_CHECK(h, hipStreamSynchronize(h->stream));
+            t.rep_le_host = rl;
+        }
+    }
     if (own == t.own_host && t.d_own) return 0;          // uploaded only when the labels changed
     if (t.own_host.size() != own.size()) { dfree(t.d_own); REMD_CHECK(h, hipMalloc(&t.d_own, sizeof(int) * own.size())); }
     REMD_CHECK(h, hipMemcpyAsync(t.d_own, own.data(), sizeof(int) * own.size(), hipMemcpyHostToDevice, h->stream));
@@ -398,10 +523,11 @@ int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot)
     remd_prof_scope ps(h, "alch_regions");
     const int nchunk = (h->N + REGION_CHUNK - 1) / REGION_CHUNK;
     hipLaunchKernelGGL(region_forces_kernel, dim3(t.c.n_alch * nchunk, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
-                       t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_force);
+                       t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_force, t.d_corr, t.c.exact ? t.d_rep_le : (const float*)nullptr);
     if (with_energy)
         hipLaunchKernelGGL(region_energy_kernel, dim3(1, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
-                           t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_epart, h->n_epart, ep_slot);
+                           t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_epart, h->n_epart, ep_slot,
+                           t.d_corr, t.c.exact ? t.d_rep_le : (const float*)nullptr);
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }
@@ -417,8 +543,32 @@ int remd_regions_ukl(remd_ctx* h, double* d_out, const int** d_own)
     if (rc) return rc;
     remd_prof_scope ps(h, "alch_ukl");
     hipLaunchKernelGGL(region_energy_kernel, dim3(h->K, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
-                       t.d_state_cls, (const int*)nullptr, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, d_out, h->K, 0);
+                       t.d_state_cls, (const int*)nullptr, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, d_out, h->K, 0,
+                       t.d_corr, (const float*)nullptr);          // (exact PME treatment: the sterics only; the Coulomb part is the quadratic form of forces.hip)
     REMD_CHECK(h, hipGetLastError());
     *d_own = t.d_own;
+    return 0;
+}
+
+// ---- exact PME treatment: what forces.hip / pme.hip ask ---------------------------------------------------------------------------------
+// the mesh kernels' charge table and per-replica lambdas (NULL: not in this mode); pme.hip indexes the float4 of a replica by the atom's code
+int remd_regions_pme_tables(remd_ctx* h, const float4** param, const float** rep_le)
+{
+    *param = nullptr; *rep_le = nullptr;
+    if (!h->regions_exact) return 0;
+    region_tables* t = g_reg.find(h);
+    if (!t) return 0;
+    *param = t->d_param_pme; *rep_le = t->d_rep_le;
+    return 1;
+}
+// every replica at these lambda_electrostatics (u_kl probes); NULL: back to the replicas' own states.  n = regions.
+int remd_regions_le_override(remd_ctx* h, const float* le, int* n, const float** d_state_le)
+{
+    region_tables* t = g_reg.find(h);
+    if (!t || !t->c.exact) return remd_fail(h, -2, "alchemical regions: not under the exact PME treatment");
+    t->have_override = le != nullptr;
+    for (int g = 0; g < 4; ++g) t->le_override[g] = (le && g < t->n_regions) ? le[g] : 1.f;
+    if (n) *n = t->n_regions;
+    if (d_state_le) *d_state_le = t->d_state_le;
     return 0;
 }

@@ -2015,10 +2015,21 @@ int remd_nb_molecules(remd_ctx* h, const int** first, const int** size)
 
 const float* remd_nb_rep_lam(remd_ctx* h)
 {
+    if (h->regions_exact) {                   // general regions under the exact PME treatment: the regions' lambdas per replica (alch_regions.hip)
+        const float4* prm; const float* le;
+        if (remd_regions_pme_tables(h, &prm, &le)) return le;
+    }
     nb_tables* it = g_nb.find(h);
     return (it && it->has_alch) ? it->d_rep_lam : nullptr;
 }
-const float4* remd_nb_param(remd_ctx* h) { return g_nb[h].d_param; }
+const float4* remd_nb_param(remd_ctx* h)
+{
+    if (h->regions_exact) {                   // ... and the mesh kernels' charges: the alchemical atoms' too (the pair kernels see the environment's only)
+        const float4* prm; const float* le;
+        if (remd_regions_pme_tables(h, &prm, &le)) return prm;
+    }
+    return g_nb[h].d_param;
+}
 
 int remd_nb_required_epart(remd_ctx* h)
 {
@@ -2358,6 +2369,39 @@ __global__ void assemble_ukl_poly_kernel(int R, int K, const double* __restrict_
     ukl_rows[t] = beta[l] * U;
 }
 
+// u_kl with SEVERAL regions' lambda_electrostatics under the exact PME treatment (alch_regions.hip): every Coulomb term is bilinear in the
+// charges and a region's charges scale with its lambda, so U(l_1 .. l_n) = c0 + sum_x (b_x l_x + a_x l_x^2) + sum_{x<y} c_xy l_x l_y EXACTLY;
+// probes: all 0; per region l_x = 1/2 and 1 (others 0); per pair l_x = l_y = 1  ->  (n + 1)(n + 2) / 2 energy passes.
+__global__ void assemble_ukl_quad_kernel(int R, int K, int n, const double* __restrict__ probe /*[P][R]*/,
+                                         const double* __restrict__ beta, const double* __restrict__ econst,
+                                         const float* __restrict__ state_le /*[K][4]*/, const double* __restrict__ alch, const int* __restrict__ own,
+                                         const double* __restrict__ pressure /*[K] or null*/, const float* __restrict__ box,
+                                         double econst_vref, double* __restrict__ ukl_rows, double* __restrict__ potential)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R * K) return;
+    const int r = t / K, l = t % K;
+    const double c0 = probe[r];
+    double lin[4], a[4], b[4], le[4];
+    for (int x = 0; x < n; ++x) {
+        const double Ph = probe[(size_t)(1 + 2 * x) * R + r] - c0, P1 = probe[(size_t)(2 + 2 * x) * R + r] - c0;
+        a[x] = 2.0 * P1 - 4.0 * Ph; b[x] = P1 - a[x]; lin[x] = P1;
+        le[x] = (double)state_le[4 * l + x];
+    }
+    double U = c0;
+    for (int x = 0; x < n; ++x) U += b[x] * le[x] + a[x] * le[x] * le[x];
+    int p = 1 + 2 * n;
+    for (int x = 0; x < n; ++x) for (int y = x + 1; y < n; ++y, ++p)
+        U += (probe[(size_t)p * R + r] - c0 - lin[x] - lin[y]) * le[x] * le[y];
+    const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
+    // the probes ran at the replica's own lambda_sterics: at its own lambda_electrostatics the form is the potential of its state
+    if (l == own[r]) potential[r] = U;
+    U += econst[l] * ((econst_vref > 0.0 && V > 0.0) ? econst_vref / V : 1.0);
+    if (alch) U += alch[t] - alch[(size_t)r * K + own[r]];
+    if (pressure) U += pressure[l] * V;
+    ukl_rows[t] = beta[l] * U;
+}
+
 int remd_assemble_ukl(remd_ctx* h, double* d_rows)
 {
     const int n = h->R * h->K;
@@ -2376,6 +2420,29 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
         int rc = remd_regions_ukl(h, t.d_alch_ukl, &d_own_states);
         if (rc) return rc;
         alch = t.d_alch_ukl;
+        if (h->regions_exact) {
+            int nreg = 0; const float* d_state_le = nullptr;
+            if ((rc = remd_regions_le_override(h, nullptr, &nreg, &d_state_le))) return rc;
+            const int P = (nreg + 1) * (nreg + 2) / 2;
+            if (t.probe_R != h->R * P) { dfree(t.d_probe); REMD_CHECK(h, hipMalloc(&t.d_probe, sizeof(double) * (size_t)P * h->R)); t.probe_R = h->R * P; }
+            std::vector<std::vector<float>> probes;
+            probes.push_back(std::vector<float>(4, 0.f));
+            for (int x = 0; x < nreg; ++x) for (float v : {0.5f, 1.f}) { std::vector<float> q(4, 0.f); q[x] = v; probes.push_back(q); }
+            for (int x = 0; x < nreg; ++x) for (int y = x + 1; y < nreg; ++y) { std::vector<float> q(4, 0.f); q[x] = q[y] = 1.f; probes.push_back(q); }
+            for (int q = 0; q < P; ++q) {
+                if ((rc = remd_regions_le_override(h, probes[q].data(), nullptr, nullptr))) return rc;
+                rc = remd_compute_forces(h, true);
+                if (rc) { remd_regions_le_override(h, nullptr, nullptr, nullptr); return rc; }
+                REMD_CHECK(h, hipMemcpyAsync(t.d_probe + (size_t)q * h->R, h->d_potential, sizeof(double) * h->R, hipMemcpyDeviceToDevice, h->stream));
+            }
+            remd_regions_le_override(h, nullptr, nullptr, nullptr);
+            h->forces_valid = false;        // the last pass used a probe's lambdas, not the replicas' own
+            hipLaunchKernelGGL(assemble_ukl_quad_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->R, h->K, nreg, t.d_probe,
+                               h->d_beta, h->d_econst, d_state_le, alch, d_own_states, h->baro_frequency > 0 ? h->d_pressure : (const double*)nullptr,
+                               h->d_box, h->econst_vref, d_rows, h->d_potential);
+            REMD_CHECK(h, hipGetLastError());
+            return 0;
+        }
     } else
     if (it && it->has_alch && h->nb_method != REMD_NB_NONE) {
         nb_tables& t = *it;

@@ -325,7 +325,9 @@ __device__ __forceinline__ int pme_cand_atom(const pme_cand& c, const int* __res
     }
     const float4 pr = param[i];
     q = pr.x;
-    if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + 2];
+    // the atom's charge scales with lambda_electrostatics: slot 2 of the replica's float4 (one alchemical region, forces.hip), or -- general
+    // regions under the exact PME treatment, alch_regions.hip -- the slot the atom's code 8 + region names
+    if (rep_lam && pr.w != 0.f) q *= rep_lam[4 * r + (pr.w >= 8.f ? (int)pr.w - 8 : 2)];
     return i;
 }
 

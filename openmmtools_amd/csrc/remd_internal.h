@@ -147,6 +147,7 @@ struct remd_ctx {
     int n_alch = 0; int* d_alch_atoms = nullptr;
     double sc_alpha = 0.5, sc_a = 1, sc_b = 1, sc_c = 6;
     int n_regions = 0;                 // remd_set_alchemical_regions: general regions (alch_regions.hip holds the tables)
+    int regions_exact = 0;             // ... under the exact PME treatment (the regions' scaled charges inside the Ewald sum)
 
     // ---- states ---------------------------------------------------------------------
     int K = 0;
@@ -350,6 +351,8 @@ void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluati
 void remd_regions_release(remd_ctx* h);
 int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot);
 int remd_regions_ukl(remd_ctx* h, double* d_out /*[R][K]*/, const int** d_own);
+int remd_regions_pme_tables(remd_ctx* h, const float4** param, const float** rep_le);
+int remd_regions_le_override(remd_ctx* h, const float* le, int* n, const float** d_state_le);
 int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask = ~0u);   // fills d_force (and d_potential when with_energy)
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d);
 int remd_build_constraints(remd_ctx* h, const remd_system_desc* d);

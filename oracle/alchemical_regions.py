@@ -152,22 +152,64 @@ class RegionOracle:
         return np.array([float(self.energy_torch(xt, box, ls, le)) for ls, le in zip(LS, LE)])
 
 
+class _Total:
+    """factory's NonbondedForce + bonded terms (ForceFieldOracle) + custom forces (RegionOracle); under the exact PME treatment
+    (terms['exact_pme'], alchemy.py:1663-1681, 1893-1899, 1978-1982) the NonbondedForce is evaluated WITH its parameter offsets: the
+    reference charges of the alchemical atoms times their region's lambda_electrostatics inside the whole Ewald sum, the charge products
+    of the exceptions that touch a region times the (first) region's lambda, every pair of atoms of two regions that do not interact
+    excluded (:1663-1672); the custom forces are then sterics only (of two interacting regions: none, :1886-1911)."""
+
+    def __init__(self, desc):
+        from .forcefield import ForceFieldOracle
+        terms = desc['alch_regions']
+        self.exact = bool(terms.get('exact_pme', 0))
+        excl = np.asarray(desc['exception_atoms']).reshape(-1, 2)
+        rs = desc['switch_distance'] if desc['switch_distance'] > 0 else None
+        if not self.exact:
+            self.base = ForceFieldOracle(desc)
+            self.reg = RegionOracle(terms, desc['cutoff'], rs, excl)
+            return
+        g = np.asarray(terms['region_of_atom'], dtype=int)
+        self.g = g
+        inter = set(frozenset((int(a), int(b))) for a, b in np.asarray(terms['interactions'], dtype=int).reshape(-1, 2))
+        d = dict(desc)
+        d['charge'] = np.where(g > 0, np.asarray(terms['charge'], dtype=np.float64), np.asarray(desc['charge'], dtype=np.float64))
+        exc_a = [tuple(int(v) for v in e) for e in excl]
+        exc_p = np.array(desc['exception_params'], dtype=np.float64).reshape(-1, 3).copy()
+        took = {frozenset((int(i), int(j))): p for (i, j), p in zip(np.asarray(terms['exception_atoms']).reshape(-1, 2), np.asarray(terms['exception_params']).reshape(-1, 3))}
+        self.exc_region = np.zeros(len(exc_a) , dtype=int)
+        for k, (i, j) in enumerate(exc_a):
+            if frozenset((i, j)) in took:
+                exc_p[k, 0] = took[frozenset((i, j))][0]               # the charge product comes back as an offset; the LJ part stays with the custom bonds
+                self.exc_region[k] = min(v for v in (g[i], g[j]) if v > 0)
+        have = set(frozenset(e) for e in exc_a)
+        extra = [(int(i), int(j)) for i in np.nonzero(g)[0] for j in np.nonzero(g)[0]
+                 if i < j and g[i] != g[j] and frozenset((int(g[i]), int(g[j]))) not in inter and frozenset((int(i), int(j))) not in have]
+        d['exception_atoms'] = np.array(exc_a + extra, dtype=np.int32).reshape(-1, 2)
+        d['exception_params'] = np.vstack([exc_p, np.tile([0.0, 1.0, 0.0], (len(extra), 1))]) if extra else exc_p
+        self.exc_region = np.concatenate([self.exc_region, np.zeros(len(extra), dtype=int)])
+        d.pop('alch_regions')
+        self.base = ForceFieldOracle(d)
+        self.reg = RegionOracle(dict(terms, electrostatics=0, interactions=np.zeros((0, 2), dtype=np.int32)), desc['cutoff'], rs, excl)
+
+    def _set(self, le):
+        if self.exact:
+            lam = np.concatenate([[1.0], np.asarray(le, dtype=np.float64)])
+            self.base.q_scale = torch.tensor(lam[self.g])
+            self.base.exc_scale = torch.tensor(lam[self.exc_region])
+
+    def energy_forces(self, x, box, ls, le, forces=True):
+        self._set(le)
+        e0, f0 = self.base.energy_forces(x, box, forces=forces)
+        e1, f1 = self.reg.energy_forces(x, box, ls, le, forces=forces)
+        return e0 + e1, (f0 + f1 if forces else None)
+
+
 def total_state_energies(desc, x, box, LS, LE):
-    """Potential of an alchemical System in the general-regions mode at every state: the factory's NonbondedForce + bonded terms
-    (ForceFieldOracle on the descriptor) + the custom forces."""
-    from .forcefield import ForceFieldOracle
-    base = ForceFieldOracle(desc)
-    reg = RegionOracle(desc['alch_regions'], desc['cutoff'], desc['switch_distance'] if desc['switch_distance'] > 0 else None,
-                       np.asarray(desc['exception_atoms']).reshape(-1, 2))
-    e0 = base.potential(x, box)
-    return e0 + reg.state_energies(x, box, LS, LE)
+    """Potential of an alchemical System in the general-regions mode at every state"""
+    t = _Total(desc)
+    return np.array([t.energy_forces(x, box, ls, le, forces=False)[0] for ls, le in zip(LS, LE)])
 
 
 def total_energy_forces(desc, x, box, ls, le):
-    from .forcefield import ForceFieldOracle
-    base = ForceFieldOracle(desc)
-    reg = RegionOracle(desc['alch_regions'], desc['cutoff'], desc['switch_distance'] if desc['switch_distance'] > 0 else None,
-                       np.asarray(desc['exception_atoms']).reshape(-1, 2))
-    e0, f0 = base.energy_forces(x, box)
-    e1, f1 = reg.energy_forces(x, box, ls, le)
-    return e0 + e1, f0 + f1
+    return _Total(desc).energy_forces(x, box, ls, le)

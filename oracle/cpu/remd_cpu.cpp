@@ -205,6 +205,10 @@ struct System {
         std::vector<RegionClass> classes;
         std::vector<std::vector<char>> skip;      // per alchemical atom: candidates that are never evaluated
         bool elec = false; double alpha = 0, krf = 0, crf = 0, rs_e = -1;
+        // exact PME treatment (remd_alch_regions_desc.exact_pme): the alchemical atoms' charges (restored in System::q) and the charge
+        // products of the exceptions that touch a region count times the region's lambda_electrostatics inside the whole Ewald sum
+        bool exact = false;
+        std::vector<int> exc_region;              // per exception of the System: region whose lambda scales its charge product (0: none)
     } reg;
 };
 
@@ -637,7 +641,13 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
     // charges at this lambda_electrostatics (exact PME treatment: alchemical charges scale, alchemy.py:1675-1680)
     std::vector<double> qv;
     const bool elec = (parts & PART_ELEC) && s.has_charge;
-    if (elec) { qv.resize(N); for (int i = 0; i < N; ++i) qv[i] = s.alch[i] ? s.q[i] * lam_e : s.q[i]; }
+    const bool exact_regions = s.reg.n > 0 && s.reg.exact && region_state >= 0 && region_state < s.reg.K;
+    const double* reg_le = exact_regions ? &s.reg.le[(size_t)region_state * s.reg.n] : nullptr;
+    if (elec) {
+        qv.resize(N);
+        for (int i = 0; i < N; ++i) qv[i] = s.alch[i] ? s.q[i] * lam_e : s.q[i];
+        if (exact_regions) for (int i = 0; i < N; ++i) if (s.reg.region_of[i] > 0) qv[i] = s.q[i] * reg_le[s.reg.region_of[i] - 1];
+    }
     // ---- pair loop -------------------------------------------------------------------------------------------
     if ((classes & 16) && (parts & (PART_STERICS | PART_SOFTCORE | PART_ELEC))) {
         double tt0 = g_time ? now_ms() : 0;
@@ -733,7 +743,8 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
             if (parts & PART_ELEC) {
                 if (qq0 != 0.0) {
                     // exception charge products that touch the alchemical region scale with lambda_e (alchemy.py:1964-1966)
-                    const double qq = ONE_4PI_EPS0 * ((s.has_alch && (s.alch[i] || s.alch[j])) ? qq0 * lam_e : qq0);
+                    double qq = ONE_4PI_EPS0 * ((s.has_alch && (s.alch[i] || s.alch[j])) ? qq0 * lam_e : qq0);
+                    if (exact_regions && s.reg.exc_region[e] > 0) qq = ONE_4PI_EPS0 * qq0 * reg_le[s.reg.exc_region[e] - 1];      // alchemy.py:1978-1982
                     E.c[4] += qq / rr; fr += qq / (rr * r2);
                 }
                 if (elec && s.method == REMD_NB_PME) {
@@ -1131,10 +1142,11 @@ static double ukl_row(remd_ctx* h, int r, double* row)
     for (int k = 0; k < K; ++k) if (h->lam_s[k] != h->lam_s[0] || h->lam_e[k] != h->lam_e[0]) lam_varies = true;
     if (s.reg.n > 0) {
         // general alchemical regions: everything but the custom forces once, the custom forces at every state's lambdas
-        const double base = evaluate(s, rep, 1.0, 1.0, nullptr, fft).total();
+        const double base = s.reg.exact ? 0.0 : evaluate(s, rep, 1.0, 1.0, nullptr, fft).total();
         double U_own = 0;
         for (int k = 0; k < K; ++k) {
-            const double U = base + region_energy(s, rep, k, nullptr);
+            // (exact PME treatment: the whole Ewald sum depends on the state's lambda_electrostatics -- one evaluation per state)
+            const double U = s.reg.exact ? evaluate(s, rep, 1.0, 1.0, nullptr, fft, PART_ALL, 63, k).total() : base + region_energy(s, rep, k, nullptr);
             row[k] = h->beta[k] * (U + h->econst[k] * cscale + (h->pressure.empty() ? 0.0 : h->pressure[k] * V));
             if (k == own) U_own = U;
         }
@@ -1501,6 +1513,7 @@ int remd_set_alchemical_options(remd_handle h, int annihilate_sterics)
 int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
 {
     if (!h) return fail(h, -1, "remd_set_alchemical_regions: NULL handle");
+    if (h->sys.reg.exact) return fail(h, -2, "remd_set_alchemical_regions: call remd_set_system again first (the exact PME treatment changed the system's tables)");
     h->sys.reg = System::Regions();
     for (auto& r : h->reps) r.f_valid = false;
     if (!d || d->n_regions == 0) return 0;
@@ -1523,12 +1536,16 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         g.cls_of[q] = g.cls_of[(size_t)q * (n + 1)] = (int)g.classes.size(); g.classes.push_back({0, q, q, q});
         g.cls_of[(size_t)q * (n + 1) + q] = (int)g.classes.size(); g.classes.push_back({1, q, q, q});
     }
+    std::vector<char> interacting((size_t)(n + 1) * (n + 1), 0);
     for (int k = 0; k < d->n_interactions; ++k) {
         const int a = d->interactions[2 * k], b = d->interactions[2 * k + 1];
         if (a < 1 || b < 1 || a > n || b > n || a == b) return fail(h, -1, "alchemical regions: bad pair of interacting regions");
+        interacting[(size_t)a * (n + 1) + b] = interacting[(size_t)b * (n + 1) + a] = 1;
+        if (d->exact_pme) continue;                // exact PME: the pair sees each other's scaled charges; no sterics (tables zeroed, alchemy.py:1886-1911)
         if (g.cls_of[(size_t)a * (n + 1) + b] >= 0) continue;
         g.cls_of[(size_t)a * (n + 1) + b] = g.cls_of[(size_t)b * (n + 1) + a] = (int)g.classes.size(); g.classes.push_back({2, a, b, b});
     }
+    if (d->exact_pme && s.method != REMD_NB_PME) return fail(h, -1, "alchemical regions: exact_pme needs a PME system");
     g.region_of.assign(d->region_of_atom, d->region_of_atom + N);
     g.q.assign(d->charge, d->charge + N); g.sig.assign(d->sigma, d->sigma + N); g.eps.assign(d->epsilon, d->epsilon + N);
     for (int i = 0; i < N; ++i) {
@@ -1553,7 +1570,34 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         if (ord[i] >= 0) g.skip[ord[i]][j] = 1;
         if (ord[j] >= 0) g.skip[ord[j]][i] = 1;
     }
-    g.elec = d->electrostatics != 0;
+    g.elec = d->electrostatics != 0 && !d->exact_pme;
+    g.exact = d->exact_pme != 0;
+    if (g.exact) {
+        for (int i = 0; i < N; ++i) if (g.region_of[i] > 0) { s.q[i] = g.q[i]; if (g.q[i] != 0.0) s.has_charge = true; }
+        g.exc_region.assign(s.exc_atoms.size() / 2, 0);
+        std::map<std::pair<int, int>, size_t> where;
+        for (size_t e = 0; e < s.exc_atoms.size() / 2; ++e) where[{std::min(s.exc_atoms[2 * e], s.exc_atoms[2 * e + 1]), std::max(s.exc_atoms[2 * e], s.exc_atoms[2 * e + 1])}] = e;
+        for (int e = 0; e < d->n_exceptions; ++e) {
+            const int i = d->exception_atoms[2 * e], j = d->exception_atoms[2 * e + 1];
+            auto it = where.find({std::min(i, j), std::max(i, j)});
+            if (it == where.end()) return fail(h, -1, "alchemical regions: an exception that the system does not have");
+            const int gi = g.region_of[i], gj = g.region_of[j];
+            if (gi == 0 && gj == 0) continue;
+            s.exc_params[3 * it->second] = d->exception_params[3 * e];            // the charge product comes back as an offset (LJ: custom bonds)
+            g.exc_region[it->second] = (gi > 0 && gj > 0) ? std::min(gi, gj) : std::max(gi, gj);
+        }
+        // regions that do not interact exclude each other (alchemy.py:1663-1672)
+        for (size_t ia = 0; ia < g.alch.size(); ++ia) for (size_t ib = ia + 1; ib < g.alch.size(); ++ib) {
+            const int a = g.alch[ia], b = g.alch[ib], ga = g.region_of[a], gb = g.region_of[b];
+            if (ga == gb || interacting[(size_t)ga * (n + 1) + gb] || where.count({std::min(a, b), std::max(a, b)})) continue;
+            s.exc_atoms.push_back(a); s.exc_atoms.push_back(b);
+            s.exc_params.push_back(0.0); s.exc_params.push_back(1.0); s.exc_params.push_back(0.0);
+            g.exc_region.push_back(0);
+            s.excl[std::min(a, b)].push_back(std::max(a, b));
+        }
+        for (auto& v : s.excl) std::sort(v.begin(), v.end());
+        for (auto& r : h->reps) r.list_valid = false;
+    }
     for (int e = 0; e < d->n_exceptions; ++e) {
         const int i = d->exception_atoms[2 * e], j = d->exception_atoms[2 * e + 1];
         if (i < 0 || j < 0 || i >= N || j >= N || i == j) return fail(h, -1, "alchemical regions: bad exception pair");

@@ -124,6 +124,10 @@ class ForceFieldOracle(OracleSystem):
         self.disp_coeff = dispersion_coefficient(list(np.asarray(d['sigma'])), list(eps_for_disp), self.rc, self.rs) \
             if (self.method and d['use_dispersion_correction']) else 0.0
         self.sc = d.get('softcore', (0.5, 1.0, 1.0, 6.0))
+        # exact PME treatment with several regions (oracle/alchemical_regions.py sets them per state): per-atom factor of the charges,
+        # per-exception factor of the charge products (the NonbondedForce's parameter offsets, alchemy.py:1675-1680, 1893-1899, 1978-1982)
+        self.q_scale = None
+        self.exc_scale = None
         self._bm = [torch.tensor(_bspline_moduli(n)) for n in self.grid] if self.method == 2 else None
 
     # ---- pair list (numpy) ---------------------------------------------------------------------
@@ -195,7 +199,7 @@ class ForceFieldOracle(OracleSystem):
         sterics = torch.where(na, sc if include_na else torch.zeros_like(sc), lj) * S
         e = sterics.sum()
         if self.has_charge:
-            q = torch.where(self.alch_t, self.q * lam_e, self.q)
+            q = torch.where(self.alch_t, self.q * lam_e, self.q) if self.q_scale is None else self.q * self.q_scale
             qq = ONE_4PI_EPS0 * q[i] * q[j]
             if self.method == 2:
                 e = e + (qq * torch.erfc(self.alpha * r) / r).sum()
@@ -233,10 +237,10 @@ class ForceFieldOracle(OracleSystem):
         # exact PME treatment: electrostatic exceptions touching the alchemical region scale with lambda_electrostatics
         # (exception parameter offset, alchemy.py:1964-1966)
         any_alch = torch.tensor(self.is_alch[i] | self.is_alch[j])
-        qq = torch.where(any_alch, p[:, 0] * lam_e, p[:, 0])
+        qq = torch.where(any_alch, p[:, 0] * lam_e, p[:, 0]) if self.exc_scale is None else p[:, 0] * self.exc_scale
         e = e + torch.where(nz, ONE_4PI_EPS0 * qq / r, torch.zeros_like(r)).sum()
         if self.method == 2 and self.has_charge:
-            q = torch.where(self.alch_t, self.q * lam_e, self.q)
+            q = torch.where(self.alch_t, self.q * lam_e, self.q) if self.q_scale is None else self.q * self.q_scale
             e = e - (ONE_4PI_EPS0 * q[i] * q[j] * torch.erf(self.alpha * r) / r).sum()
         return e
 
@@ -283,7 +287,7 @@ class ForceFieldOracle(OracleSystem):
                 e = e + self._exceptions(x, box_t, lam_e, lam_s, include_na=include_na)
                 e = e + self.disp_coeff / V
             if self.method == 2 and self.has_charge and on(5):
-                q = torch.where(self.alch_t, self.q * lam_e, self.q)
+                q = torch.where(self.alch_t, self.q * lam_e, self.q) if self.q_scale is None else self.q * self.q_scale
                 e = e + self.pme_reciprocal(x, box_t, q)
                 e = e - ONE_4PI_EPS0 * self.alpha / math.sqrt(math.pi) * (q * q).sum()
                 e = e - ONE_4PI_EPS0 * math.pi * q.sum() ** 2 / (2.0 * self.alpha ** 2 * V)

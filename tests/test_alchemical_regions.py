@@ -141,9 +141,13 @@ def test_the_factory_chooses_the_path_and_refuses_what_the_reference_refuses():
     assert len(straddling) > 5 and all(reg.exc_kinds[k] == (0, 1, 1, 1) for k in straddling)
     with pytest.raises(NotImplementedError, match='replaces the environment'):
         alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(_charged_lj_fluid(), alchemy.AlchemicalRegion(alchemical_atoms=range(4)))
-    with pytest.raises(NotImplementedError, match='several charged alchemical regions'):
-        alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(
-            al.system, [alchemy.AlchemicalRegion(alchemical_atoms=range(22), name='a'), alchemy.AlchemicalRegion(alchemical_atoms=range(22, 25), name='b')])
+    # several charged regions under the exact PME treatment (the default): the regions' charges as parameter offsets (alchemy.py:1675-1680)
+    ex = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(
+        al.system, [alchemy.AlchemicalRegion(alchemical_atoms=range(22), name='a'), alchemy.AlchemicalRegion(alchemical_atoms=range(22, 25), name='b')],
+        alchemical_regions_interactions=frozenset({(0, 1)}))
+    t = system_to_desc(ex)['alch_regions']
+    assert t['exact_pme'] == 1 and t['electrostatics'] == 0 and t['interactions'].tolist() == [[1, 2]] and t['charge'][0] != 0.0
+    assert system_to_desc(ex)['charge'][0] == 0.0
     # the factory's NonbondedForce: alchemical atoms without charge and epsilon, their exceptions zeroed but kept (alchemy.py:1903-1911, 2001-2006)
     s = alchemy.AbsoluteAlchemicalFactory(alchemical_pme_treatment='coulomb').create_alchemical_system(al.system, alchemy.AlchemicalRegion(alchemical_atoms=range(22), name='a'))
     nb = [f for f in s.getForces() if isinstance(f, NonbondedForce)][0]
@@ -178,14 +182,14 @@ LADDER_S = np.array([[1.0, 1.0], [1.0, 0.6], [0.7, 1.0], [0.35, 0.8], [0.0, 0.5]
 LADDER_E = np.array([[1.0, 1.0], [0.5, 1.0], [0.0, 0.7], [0.0, 0.3], [0.0, 0.0], [0.0, 0.0]])
 
 
-def _check_engine_against_the_oracle(eng, kw, interactions, rtol, ftol, region_kw=None):
+def _check_engine_against_the_oracle(eng, kw, interactions, rtol, ftol, region_kw=None, ewald_split='reference'):
     """interactions: pairs of regions handed to the ENGINE as interacting (the factory itself passes none on, see above)"""
     al, system, regions = _alanine_two_regions(kw, interactions, **(region_kw or {}))
     nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
     box0 = np.diag(system.getDefaultPeriodicBoxVectors())
     econst = alchemy.alchemical_long_range_constants(system, nb, LADDER_S, float(np.prod(box0)))
     assert np.all(np.isfinite(econst)) and econst[0] != econst[-1]
-    desc = system_to_desc(system, ewald_split='reference')
+    desc = system_to_desc(system, ewald_split=ewald_split)
     if interactions:
         desc['alch_regions']['interactions'] = np.array([(a + 1, b + 1) for a, b in sorted(interactions)], dtype=np.int32)
     eng.set_system(desc)
@@ -215,6 +219,10 @@ def _check_engine_against_the_oracle(eng, kw, interactions, rtol, ftol, region_k
 CASES = [
     (dict(alchemical_pme_treatment='direct-space'), frozenset({(0, 1)}), dict(softcore_beta=0.3)),
     (dict(alchemical_pme_treatment='coulomb', switch_width=0.15), frozenset(), dict(softcore_c=4, softcore_a=2, softcore_f=4, softcore_e=2, softcore_beta=0.2)),
+    # the exact PME treatment (the factory's default): every region's charges scaled by its own lambda inside the whole Ewald sum,
+    # regions that do not interact excluded from each other / regions that do see each other's scaled charges (alchemy.py:1663-1681)
+    (dict(), frozenset(), dict(softcore_c=8)),
+    (dict(), frozenset({(0, 1)}), dict()),
 ]
 
 
@@ -230,7 +238,9 @@ def test_cpu_port_matches_the_region_oracle(kw, interactions, region_kw):
 @pytest.mark.parametrize('kw,interactions,region_kw', CASES)
 def test_hip_regions_match_the_region_oracle(hip_engine_factory, kw, interactions, region_kw):
     """csrc/alch_regions.hip: u_kl rows over the ladder, the own-state potential (1e-5) and the forces against the f64 oracle"""
-    eng = _check_engine_against_the_oracle(hip_engine_factory(), kw, interactions, 1e-5, 2e-4, region_kw)
+    # (the device's own split of the Ewald sum: a Coulomb range beyond the cutoff -- the custom forces keep the NonbondedForce's cutoff, the
+    # exact treatment's direct-space terms follow the split)
+    eng = _check_engine_against_the_oracle(hip_engine_factory(), kw, interactions, 1e-5, 2e-4, region_kw, ewald_split='auto')
     # ... and the MD loop runs on it (one block of replicas: phases are off with regions)
     nan = eng.propagate(0)
     assert not np.any(nan)
@@ -280,6 +290,22 @@ def test_general_regions_are_written_as_the_factorys_force_set_and_read_back(kw,
     forces = ET.fromstring(xml).find('Forces').findall('Force')
     custom = [f for f in forces if f.get('type').startswith('Custom')]
     extra = 2 if interactions else 0
+    if kw.get('alchemical_pme_treatment', 'exact') == 'exact':
+        # no electrostatic custom forces: per region a global parameter + particle / exception offsets of the NonbondedForce, which sits in the
+        # group of the LAST lambda_electrostatics the loop touched (alchemy.py:1675-1681, 1893-1899, 2034-2035); regions that do not interact
+        # exclude each other (:1663-1672)
+        assert len(custom) == 8 + extra
+        nbf = [f for f in forces if f.get('type') == 'NonbondedForce'][0]
+        assert sorted(g.get('name') for g in nbf.find('GlobalParameters')) == ['lambda_electrostatics_pep', 'lambda_electrostatics_wat']
+        offs = nbf.find('ParticleOffsets').findall('Offset')
+        assert [int(o.get('particle')) for o in offs] == list(range(31)) and offs[0].get('parameter') == 'lambda_electrostatics_pep' and offs[30].get('parameter') == 'lambda_electrostatics_wat'
+        n_exc = len(nbf.find('Exceptions'))
+        n_ref = len([f for f in al.system.getForces() if isinstance(f, NonbondedForce)][0].exceptions)
+        assert n_exc == n_ref + (0 if interactions else 22 * 9)
+        # lambda names sorted, a force group each (:1075-1083): electrostatics_pep, electrostatics_wat, sterics_pep, sterics_wat; the loop's
+        # last turn is the pair (pep, wat) when the regions interact, else wat
+        assert int(nbf.get('forceGroup')) == int(custom[0].get('forceGroup')) - (2 if interactions else 1)
+        return
     assert len(custom) == 16 + 2 * extra
     groups = [int(f.get('forceGroup')) for f in custom]
     assert groups == sorted(groups) and len(set(groups)) == 4
