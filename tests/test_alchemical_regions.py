@@ -413,3 +413,58 @@ def test_sampler_with_two_named_regions_on_the_device(hip_engine_factory):
     _check_sampler_rows(s, asys, 2e-5)
     s.run()
     assert np.all(np.isfinite(s.energy_thermodynamic_states)) and s.iteration == 3
+
+
+# ---- the reference's own multi-region case (tests/test_alchemy.py:2203-2208, 2216-2252): CB7:B2 with the guest as region 'zero' and
+# atoms 156-159 (a water and the next water's oxygen) as region 'one', under the exact PME treatment and under 'direct-space' -----------
+def _host_guest_two_regions(kw):
+    hg = ts.HostGuestExplicit()
+    regions = [alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156), name='zero'), alchemy.AlchemicalRegion(alchemical_atoms=range(156, 160), name='one')]
+    return hg, alchemy.AbsoluteAlchemicalFactory(**kw).create_alchemical_system(hg.system, regions)
+
+
+HG_S = np.array([[1.0, 1.0], [1.0, 1.0], [0.6, 1.0], [0.0, 0.4]])
+HG_E = np.array([[1.0, 1.0], [0.5, 0.0], [0.0, 0.0], [0.0, 0.0]])
+
+
+def _check_host_guest(eng, kw, rtol, ftol, ewald_split):
+    hg, system = _host_guest_two_regions(kw)
+    nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
+    box0 = np.diag(system.getDefaultPeriodicBoxVectors())
+    econst = alchemy.alchemical_long_range_constants(system, nb, HG_S, float(np.prod(box0)))
+    desc = system_to_desc(system, ewald_split=ewald_split)
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 300.0)
+    eng.set_states(np.full(4, beta), None, None, econst)
+    eng.set_region_lambdas(HG_S, HG_E)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 3, True, 1e-8)
+    eng.seed(11)
+    labels = np.array([1, 3])
+    x = np.stack([hg.positions + 0.001 * (r + 1) * np.random.default_rng(r).normal(size=hg.positions.shape) for r in range(2)])
+    box = np.tile(box0, (2, 1))
+    eng.set_replicas(2, 0, x, None, box, labels)
+    rows, U = eng.compute_energies(want_potential=True)
+    xd = eng.get_replicas()[0]
+    f = eng.get_forces()
+    for r, k in enumerate(labels):
+        ref = total_state_energies(desc, xd[r], box[r], HG_S, HG_E)
+        assert np.ptp(ref) > 50.0
+        assert np.allclose(rows[r], beta * (ref + econst), rtol=rtol), np.abs(rows[r] / (beta * (ref + econst)) - 1).max()
+        assert np.isclose(U[r], ref[k], rtol=rtol)
+        f_ref = total_energy_forces(desc, xd[r], box[r], HG_S[k], HG_E[k])[1]
+        assert np.abs(f[r] - f_ref).max() < ftol * np.abs(f_ref).max(), np.abs(f[r] - f_ref).max() / np.abs(f_ref).max()
+    return eng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [dict(), dict(alchemical_pme_treatment='direct-space')])
+def test_the_references_two_region_host_guest_case_on_the_device(hip_engine_factory, kw):
+    eng = _check_host_guest(hip_engine_factory(), kw, 1e-5, 2e-4, 'auto')
+    assert not np.any(eng.propagate(0))
+    assert np.all(np.isfinite(eng.compute_energies()))
+
+
+def test_the_references_two_region_host_guest_case_on_the_cpu_port():
+    if not os.path.exists(CPU_LIB):
+        oracle.build()
+    _check_host_guest(HipEngine(lib_path=CPU_LIB), dict(), 1e-9, 1e-8, 'reference').close()
