@@ -183,7 +183,12 @@ __device__ __forceinline__ float3 region_min_image(float3 d, float Lx, float Ly,
     return d;
 }
 
-// forces: workgroup = (alchemical atom a, chunk of 1024 atoms j); the first workgroups of a replica also take the exceptions
+// forces: workgroup = (alchemical atom a, chunk of 1024 atoms j); the first workgroups of a replica also take the exceptions.
+// One candidate in ten is inside the cutoff, and a wavefront that holds ONE of them pays the whole soft-core arithmetic (powf, erfc):
+// the candidates are therefore tested first (distance, static bits) and the survivors compacted -- per wavefront by ballot + prefix count,
+// so that the order (and with it every float sum) is fixed -- before 256 threads evaluate them densely: the launch's cost per force
+// evaluation of 8 x CB7:B2 (34 alchemical atoms) fell from 21.6 to 5.6 us under 'direct-space', 13.3 to 8.0 under the exact PME treatment
+// (tools/bench_configs.py 4d / 4r against 4, profiles/r06_40_general_regions_config4.txt).
 #define REGION_CHUNK 1024
 __global__ __launch_bounds__(256)
 void region_forces_kernel(region_consts c, const int* __restrict__ alch, const float4* __restrict__ atom, const unsigned int* __restrict__ skip,
@@ -192,6 +197,8 @@ void region_forces_kernel(region_consts c, const int* __restrict__ alch, const f
                           const float4* __restrict__ pos, const float* __restrict__ box, long long* __restrict__ force,
                           const unsigned int* __restrict__ corr, const float* __restrict__ rep_le)
 {
+    __shared__ int s_list[4][REGION_CHUNK / 4];            // per wavefront: its survivors, j | correction flag << 30
+    __shared__ int s_count[4];
     const int r = blockIdx.y;
     const float* le4 = rep_le ? rep_le + 4 * r : nullptr;
     const int nchunk = (c.N + REGION_CHUNK - 1) / REGION_CHUNK;
@@ -203,23 +210,45 @@ void region_forces_kernel(region_consts c, const int* __restrict__ alch, const f
     const int a = alch[ia];
     const float4 pa = atom[a];
     const float3 xa = ld3(P, a);
-    float fx = 0.f, fy = 0.f, fz = 0.f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float rmax2 = le4 ? fmaxf(c.rc2, c.rcc2) : c.rc2;
     const int j1 = min(c.N, (chunk + 1) * REGION_CHUNK);
-    for (int j = chunk * REGION_CHUNK + threadIdx.x; j < j1; j += 256) {
-        const size_t word = (size_t)ia * c.words + (j >> 5);
+    int n_mine = 0;
+    for (int j0 = chunk * REGION_CHUNK + wave * 64; j0 < j1; j0 += 256) {
+        const int j = j0 + lane;
+        int keep = 0;
+        if (j < j1) {
+            const size_t word = (size_t)ia * c.words + (j >> 5);
+            const bool skipped = (skip[word] >> (j & 31)) & 1u;
+            const bool fix = skipped && le4 && ((corr[word] >> (j & 31)) & 1u);
+            if (!skipped || fix) {
+                const float3 d = region_min_image(sub3(ld3(P, j), xa), Lx, Ly, Lz);
+                if (fix || dotf(d, d) < rmax2) keep = j | (fix ? (1 << 30) : 0) | (1 << 31);
+            }
+        }
+        const unsigned long long m = __ballot(keep != 0);
+        if (keep) s_list[wave][n_mine + __popcll(m & ((1ull << lane) - 1ull))] = keep;
+        n_mine += __popcll(m);
+    }
+    if (lane == 0) s_count[wave] = n_mine;
+    __syncthreads();
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    const int n0 = s_count[0], n1 = n0 + s_count[1], n2 = n1 + s_count[2], n3 = n2 + s_count[3];
+    for (int t = threadIdx.x; t < n3; t += 256) {
+        const int e = t < n0 ? s_list[0][t] : t < n1 ? s_list[1][t - n0] : t < n2 ? s_list[2][t - n1] : s_list[3][t - n2];
+        const int j = e & 0x3fffffff;
         const float3 d = region_min_image(sub3(ld3(P, j), xa), Lx, Ly, Lz);
+        const float4 pj = atom[j];
         float U, fr;
-        if ((skip[word] >> (j & 31)) & 1u) {
-            if (!le4 || !((corr[word] >> (j & 31)) & 1u)) continue;
-            const float4 pj = atom[j];
+        if (e & (1 << 30)) {
             if (pa.x * pj.x == 0.f) continue;
             region_ewald_correction(c, pa, pj, d, le4, U, fr);
-        } else if (!region_pair(c, cls_tab, cls_of, pa, atom[j], d, U, fr, le4)) continue;
+        } else if (!region_pair(c, cls_tab, cls_of, pa, pj, d, U, fr, le4)) continue;
         fx += fr * d.x; fy += fr * d.y; fz += fr * d.z;
         add_force(F, c.Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
     }
     for (int off = 32; off > 0; off >>= 1) { fx += __shfl_xor(fx, off); fy += __shfl_xor(fy, off); fz += __shfl_xor(fz, off); }
-    if ((threadIdx.x & 63) == 0 && (fx != 0.f || fy != 0.f || fz != 0.f)) add_force(F, c.Npad, a, fx, fy, fz);
+    if (lane == 0 && (fx != 0.f || fy != 0.f || fz != 0.f)) add_force(F, c.Npad, a, fx, fy, fz);
     // exceptions: spread over the workgroups of the replica
     for (int t = blockIdx.x * 256 + threadIdx.x; t < c.n_exc; t += gridDim.x * 256) {
         const int i = exc_atoms[2 * t], j = exc_atoms[2 * t + 1];

@@ -57,6 +57,26 @@ def main():
         ss = states.SamplerState(hg.positions, box_vectors=hg.system.getDefaultPeriodicBoxVectors())
         s.create(ths, [ss] * 8)
         run('4 (1-GPU share): HostGuestExplicit, 8 replicas x 64 alchemical states, g-BAOAB 2 fs x 500', s, 3)
+    for tag, kw in (('4r', dict()), ('4d', dict(alchemical_pme_treatment='direct-space'))):
+        if tag not in which:
+            continue
+        # config 4's share on the GENERAL alchemical path (csrc/alch_regions.hip): the guest and the reference's second test region
+        # (atoms 156-159, tests/test_alchemy.py:2203-2208) as two named regions, both on config 4's ladder; '4r': the exact PME treatment
+        # (the regions' scaled charges inside the Ewald sum, u_kl from six energy passes), '4d': 'direct-space' soft-core electrostatics
+        hg = testsystems.HostGuestExplicit()
+        lam_e = np.concatenate([np.linspace(1.0, 0.0, 32), np.zeros(32)])
+        lam_s = np.concatenate([np.ones(32), np.linspace(1.0, 0.0, 32)])
+        regions = [alchemy.AlchemicalRegion(alchemical_atoms=range(126, 156), name='zero'), alchemy.AlchemicalRegion(alchemical_atoms=range(156, 160), name='one')]
+        asys = alchemy.AbsoluteAlchemicalFactory(**kw).create_alchemical_system(hg.system, regions)
+        ths = [states.CompoundThermodynamicState(states.ThermodynamicState(asys, 300.0),
+                                                 [states.AlchemicalState(parameters_name_suffix='zero', lambda_sterics=ls, lambda_electrostatics=le),
+                                                  states.AlchemicalState(parameters_name_suffix='one', lambda_sterics=ls, lambda_electrostatics=le)])
+               for le, ls in zip(lam_e, lam_s)]
+        s = SAMSSampler(mcmc_moves=move(2.0, 'V R R O R R V'), number_of_iterations=10 ** 9, engine=HipEngine(), seed=1)
+        ss = states.SamplerState(hg.positions, box_vectors=hg.system.getDefaultPeriodicBoxVectors())
+        s.create(ths, [ss] * 8)
+        run('%s (1-GPU share, general alchemical regions, %s): HostGuestExplicit, 8 replicas x 64 states of two named regions, g-BAOAB 2 fs x 500'
+            % (tag, kw.get('alchemical_pme_treatment', 'exact PME')), s, 3)
     if '5' in which:
         dh = testsystems.DHFRExplicit()
         T = np.geomspace(300.0, 400.0, 128)
