@@ -468,3 +468,40 @@ def test_the_references_two_region_host_guest_case_on_the_cpu_port():
     if not os.path.exists(CPU_LIB):
         oracle.build()
     _check_host_guest(HipEngine(lib_path=CPU_LIB), dict(), 1e-9, 1e-8, 'reference').close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [dict(), dict(alchemical_pme_treatment='direct-space')])
+def test_general_regions_under_the_monte_carlo_barostat(hip_engine_factory, kw):
+    """NPT states on a System with two regions: the barostat's Metropolis test sees the custom forces (and, under the exact treatment, the
+    volume-dependent background term of the regions' scaled charges); after volume moves the u_kl rows -- custom forces at every state's
+    lambdas, long-range constants scaled by V_ref / V, + beta p V -- still match the oracle on the device's positions and boxes."""
+    al, system, regions = _alanine_two_regions(kw, frozenset())
+    nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
+    box0 = np.diag(system.getDefaultPeriodicBoxVectors())
+    V0 = float(np.prod(box0))
+    econst = alchemy.alchemical_long_range_constants(system, nb, LADDER_S, V0)
+    eng = hip_engine_factory()
+    desc = system_to_desc(system, ewald_split='auto', min_edge=float(box0.min()) / 1.1)
+    eng.set_system(desc)
+    K = len(LADDER_S)
+    beta = 1.0 / (KB * 300.0)
+    p = 1.0 * unit.bar
+    eng.set_states(np.full(K, beta), None, None, econst)
+    eng.set_region_lambdas(LADDER_S, LADDER_E)
+    eng.set_integrator('V R R O R R V', 0.002, 1.0, 50, True, 1e-8)
+    eng.set_barostat(np.full(K, p), 25)
+    eng.set_energy_const_volume(V0)
+    eng.seed(5)
+    labels = np.array([0, 4, 5])             # (states whose sterics are softened only where the charges are off: the others are for energies, not dynamics)
+    x = np.stack([al.positions] * 3)
+    eng.set_replicas(3, 0, x, None, np.tile(box0, (3, 1)), labels)
+    assert not eng.propagate(0).any()
+    boxes = eng.get_boxes()
+    assert np.all(np.prod(boxes, axis=1) != V0)
+    rows = eng.compute_energies()
+    xd = eng.get_replicas()[0]
+    for r in range(3):
+        V = float(np.prod(boxes[r]))
+        ref = total_state_energies(desc, xd[r], boxes[r], LADDER_S, LADDER_E) + econst * V0 / V + p * V
+        assert np.allclose(rows[r], beta * ref, rtol=1e-5), np.abs(rows[r] / (beta * ref) - 1).max()
