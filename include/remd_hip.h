@@ -119,6 +119,13 @@ int  remd_set_system(remd_handle h, const remd_system_desc* desc);
    how much work the pair kernel and the mesh get (a longer range buys a smaller mesh).  Ignored by non-PME methods.        */
 int  remd_set_coulomb_cutoff(remd_handle h, double coulomb_cutoff_nm);
 
+/* Reaction field of a CutoffPeriodic system, to be called BEFORE remd_set_system.  unshifted = 0 (default): OpenMM's NonbondedForce,
+   qq (1/r + k_rf r^2 - c_rf).  unshifted = 1: what the reference's alchemical factory turns the WHOLE system's reaction field into under
+   its default alchemical_rf_treatment='switched' (alchemy.py:744-749 -> forcefactories.replace_reaction_field :76-84 ->
+   forces.UnshiftedReactionFieldForce, forces.py:1110-1150): qq (1/r + k_rf r^2), c_rf = 0, times OpenMM's switching function from
+   cutoff - switch_width_nm to the cutoff (0: truncated); exceptions keep their plain qq / r.  Ignored by PME systems.                */
+int  remd_set_reaction_field(remd_handle h, int unshifted, double switch_width_nm);
+
 /* K thermodynamic states: beta [1/(kJ/mol)], lambda_sterics, lambda_electrostatics, and an
    additive potential-energy constant per state in kJ/mol (e.g. the lambda-dependent
    long-range correction of the alchemical CustomNonbondedForce).  Arrays may be NULL
@@ -271,11 +278,22 @@ typedef struct remd_alch_regions_desc {
     int32_t electrostatics;              /* 0 / 1                                                            */
     double elec_alpha, elec_krf, elec_crf, elec_switch_distance;
     int32_t exact_pme;                   /* 1: the exact PME treatment (below); electrostatics / elec_* unused */
+    /* alchemically softened bonded terms (alchemy.py:1115-1354): U = lambda_{bonds, angles, torsions}_<region> x the reference's harmonic
+       bond (K/2)(r - r0)^2, harmonic angle (K/2)(theta - theta0)^2, periodic torsion k (1 + cos(n phi - phase)); the host takes these terms
+       OUT of the descriptor of remd_set_system (and, as the factory does once any term of a class is alchemical, the terms of that class
+       that connect two regions which do not interact, :1156-1162).  remd_set_region_bonded_lambdas gives their lambdas (default 1).     */
+    int32_t n_bonds;    const int32_t* bond_atoms;    const double* bond_params;    const int32_t* bond_region;      /* [n][2]; [n][2] = r0, K; [n] 1-based */
+    int32_t n_angles;   const int32_t* angle_atoms;   const double* angle_params;   const int32_t* angle_region;     /* [n][3]; [n][2] = theta0, K           */
+    int32_t n_torsions; const int32_t* torsion_atoms; const double* torsion_params; const int32_t* torsion_region;   /* [n][4]; [n][3] = n, phase, k         */
 } remd_alch_regions_desc;
 int  remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* desc);
 /* lambda_sterics / lambda_electrostatics of every region at every state: [K][n_regions], K as in remd_set_states (call after it).  The
    energy_const of remd_set_states carries the long-range corrections of the sterics custom forces (alchemy.py:1786-1789).      */
 int  remd_set_region_lambdas(remd_handle h, int K, int n_regions, const double* lambda_sterics, const double* lambda_electrostatics);
+/* lambda_bonds / lambda_angles / lambda_torsions of every region at every state, [K][n_regions] each (NULL: 1), after
+   remd_set_region_lambdas.  AlchemicalState.lambda_bonds ... (alchemy.py:196-199).                                               */
+int  remd_set_region_bonded_lambdas(remd_handle h, int K, int n_regions, const double* lambda_bonds, const double* lambda_angles,
+                                    const double* lambda_torsions);
 
 /* Device-to-device transfer of replicas between two handles on the same device that hold the same particles (one handle per
    compatibility group of states: the reference propagates a replica in the Context of its own state's System,

@@ -151,9 +151,6 @@ def emit_alchemical_forces(forces, system, emit_plain):
     A = set(region.alchemical_atoms)
     N = set(range(nb.getNumParticles())) - A
     ewald = nb.getNonbondedMethod() in (NonbondedForce.Ewald, NonbondedForce.PME)
-    if not ewald and any(q != 0.0 for (q, _, _) in nb.particles) and nb.getNonbondedMethod() != NonbondedForce.NoCutoff:
-        raise NotImplementedError('charged alchemical System under a reaction-field method (the factory switches to an unshifted '
-                                  'reaction field, forcefactories.py:76-84; the engine evaluates the shifted one)')
     if ewald and not region.annihilate_electrostatics:
         raise NotImplementedError('decoupled electrostatics with the exact PME treatment (alchemy.py:1617-1623 refuses it too)')
 
@@ -190,7 +187,8 @@ def emit_alchemical_forces(forces, system, emit_plain):
         raise NotImplementedError('no free force groups for the alchemical forces (alchemy.py:1068-1072 raises here too)')
     g_elec, g_ster = free[0], free[1]
 
-    if nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic:             # forcefactories.py:82-84: charges move to the last force
+    rf_replaced = nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic and getattr(system, 'rf_unshifted_switch_width', None) is not None
+    if rf_replaced:                                                          # forcefactories.py:82-84: charges move to the last force
         kept_particles = [(0.0, s, e) for (q, s, e) in kept_particles]
 
     def emit_nb(group):
@@ -213,7 +211,7 @@ def emit_alchemical_forces(forces, system, emit_plain):
         fixed = '' if region.annihilate_electrostatics else 'lambda_electrostatics=1.0;'
         charges = [(q, s) for (q, s, e) in particles]
         switched = nb.getNonbondedMethod() in (NonbondedForce.CutoffPeriodic, NonbondedForce.CutoffNonPeriodic)
-        switch_width = getattr(system, 'alchemical_switch_width', 0.1)
+        switch_width = getattr(system, 'rf_unshifted_switch_width', None) or 0.1
         common = dict(use_switch=switched, switch_distance=nb.getCutoffDistance() - switch_width, lrc=False, **cnb)
         _emit_custom_nonbonded(forces, g_elec, pair_expr, ('charge', 'sigma'), ('lambda_electrostatics',), particles=charges,
                                set1=N, set2=A, **common)
@@ -233,12 +231,35 @@ def emit_alchemical_forces(forces, system, emit_plain):
                            particles=lj, set1=A, set2=A, **common)
     _emit_custom_bond(forces, g_ster, exc_expr, ('sigma', 'epsilon'), ('lambda_sterics',), region, na_lj)
     _emit_custom_bond(forces, g_ster, exc_expr + fixed, ('sigma', 'epsilon'), () if fixed else ('lambda_sterics',), region, aa_lj)
-    if nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic:             # forcefactories.py:76-84 (charges: all zero here)
+    if rf_replaced:                                                          # forcefactories.py:76-84: the environment's charges live here
         eps, rc = nb.getReactionFieldDielectric(), nb.getCutoffDistance()
         energy = _RF_HEAD + 'chargeprod = charge1*charge2;k_rf = %f;ONE_4PI_EPS0 = %f;' % (rc ** -3 * (eps - 1.0) / (2.0 * eps + 1.0), ONE_4PI_EPS0)
-        switch_width = getattr(system, 'alchemical_switch_width', 0.1)
+        switch_width = getattr(system, 'rf_unshifted_switch_width', None) or 0.1
         _emit_custom_nonbonded(forces, 0, energy, ('charge',), (), region, nb, [(q,) for (q, s, e) in particles], exclusions, None, None,
                                True, rc - switch_width, False, with_softcore=False)
+
+
+# softened bonded terms: class -> (energy expression with the lambda's name, per-term parameters), alchemy.py:1341, 1261, 1180
+_BONDED_CUSTOM = {'bond': ('%s*(K/2)*(r-r0)^2;', ('r0', 'K')),
+                  'angle': ('%s*(K/2)*(theta-theta0)^2;', ('theta0', 'K')),
+                  'torsion': ('%s*k*(1+cos(periodicity*theta-phase))', ('periodicity', 'phase', 'k'))}
+_BONDED_TAGS = {'bond': ('CustomBondForce', 'PerBondParameters', 'Bonds', 'Bond'), 'angle': ('CustomAngleForce', 'PerAngleParameters', 'Angles', 'Angle'),
+                'torsion': ('CustomTorsionForce', 'PerTorsionParameters', 'Torsions', 'Torsion')}
+
+
+def _emit_custom_bonded(forces, group, kind, energy, per, lam, terms):
+    ftype, per_tag, list_tag, item_tag = _BONDED_TAGS[kind]
+    e = ET.SubElement(forces, 'Force', dict(forceGroup=str(group), name=ftype, type=ftype, energy=energy, version='3', usesPeriodic='0'))
+    b = ET.SubElement(e, per_tag)
+    for n in per:
+        ET.SubElement(b, 'Parameter', dict(name=n))
+    g = ET.SubElement(e, 'GlobalParameters')
+    ET.SubElement(g, 'Parameter', dict(default=_f(1.0), name=lam))
+    ET.SubElement(e, 'EnergyParameterDerivatives')
+    b = ET.SubElement(e, list_tag)
+    for atoms, params in terms:
+        ET.SubElement(b, item_tag, dict({'param%d' % (k + 1): _f(v) for k, v in enumerate(params)}, **{'p%d' % (k + 1): str(a) for k, a in enumerate(atoms)}))
+    return e
 
 
 def emit_region_forces(forces, system, emit_plain):
@@ -356,6 +377,17 @@ def emit_region_forces(forces, system, emit_plain):
         by_lambda.setdefault('lambda_electrostatics' + sfx[0], []).extend(elec)              # :2027-2032
         by_lambda.setdefault('lambda_sterics' + sfx[0], []).extend(ster)
         last_key = 'lambda_electrostatics' + sfx[0]
+    # softened bonded terms: one Custom{Bond,Angle,Torsion}Force per region and class, energy lambda x the reference term (:1170-1197, 1252-1275, 1331-1354)
+    for kind, (expr, per) in _BONDED_CUSTOM.items():
+        atoms = terms.get(kind + '_atoms')
+        if atoms is None or len(atoms) == 0:
+            continue
+        for g, r in enumerate(regions):
+            sel = [k for k in range(len(atoms)) if int(terms[kind + '_region'][k]) == g + 1]
+            if sel:
+                name = 'lambda_%ss%s' % (kind, suffix(r))
+                by_lambda.setdefault(name, []).append(('bonded', dict(kind=kind, energy=expr % name, per=per, lam=name,
+                                                                      terms=[(tuple(int(a) for a in atoms[k]), tuple(float(v) for v in terms[kind + '_params'][k])) for k in sel])))
     # ---- order and force groups (:1052-1083) ------------------------------------------------------------------------
     untouched = [f for f in all_forces if not isinstance(f, _REMODELLED)]
     readded = [f for f in all_forces if isinstance(f, _REMODELLED) and (not isinstance(f, NonbondedForce) or not exact)]
@@ -380,6 +412,8 @@ def emit_region_forces(forces, system, emit_plain):
         for kind, kw in by_lambda[key]:
             if kind == 'nb':
                 _emit_custom_nonbonded(forces, group, kw.pop('energy'), kw.pop('per_params'), kw.pop('lam_globals'), **kw)
+            elif kind == 'bonded':
+                _emit_custom_bonded(forces, group, **kw)
             else:
                 _emit_custom_bond(forces, group, kw['energy'], kw['per_params'], kw['lam_globals'], kw['region'], kw['bonds'])
         if exact and key == last_key:
@@ -414,9 +448,13 @@ def parse_custom(e):
         d['particles'] = [_params(p) for p in _kids(e, 'Particles')]
         d['groups'] = [tuple(sorted(int(p.get('index')) for p in _kids(g, tag)) for tag in ('Set1', 'Set2'))
                        for g in _kids(e, 'InteractionGroups')]
-    else:
+    elif d['type'] == 'CustomBondForce':
         d['per'] = [p.get('name') for p in _kids(e, 'PerBondParameters')]
         d['bonds'] = [(int(b.get('p1')), int(b.get('p2')), _params(b)) for b in _kids(e, 'Bonds')]
+    else:                                                    # CustomAngleForce / CustomTorsionForce: softened bonded terms only
+        width, per_tag, list_tag = (3, 'PerAngleParameters', 'Angles') if d['type'] == 'CustomAngleForce' else (4, 'PerTorsionParameters', 'Torsions')
+        d['per'] = [p.get('name') for p in _kids(e, per_tag)]
+        d['terms'] = [(tuple(int(b.get('p%d' % (k + 1))) for k in range(width)), _params(b)) for b in _kids(e, list_tag)]
     return d
 
 
@@ -433,7 +471,8 @@ def rebuild_marked_system(system, nb, global_parameters, particle_offsets, excep
     sterics = [c for c in customs if 'U_sterics' in c['energy']]
     electro = [c for c in customs if 'U_electrostatics' in c['energy']]
     rf = [c for c in customs if compact(c['energy']).startswith(compact(_RF_HEAD)) and c['type'] == 'CustomNonbondedForce']
-    other = [c for c in customs if c not in sterics + electro + rf]
+    bonded = [c for c in customs if re.match(r'lambda_(bonds|angles|torsions)\w*\*', compact(c['energy']))]
+    other = [c for c in customs if c not in sterics + electro + rf + bonded]
     if other:
         raise NotImplementedError('custom force outside the alchemical factory\'s set: %s' % other[0]['energy'][:60])
     for name in list(global_parameters) + [p[0] for p in particle_offsets + exception_offsets]:
@@ -503,6 +542,8 @@ def rebuild_marked_system(system, nb, global_parameters, particle_offsets, excep
             sig, eps = lj_of.get(key, (s, 0.0))
             nb.exceptions[n] = (i, j, qq_of.get(n, qq_bond.get(key, 0.0)), sig, eps)
     system.alchemical_region = region
+    if rf:
+        system.rf_unshifted_switch_width = round(nb.getCutoffDistance() - float(rf[0]['attrs'].get('switchingDistance', nb.getCutoffDistance() - 0.1)), 12)
     use_lrc = na['attrs'].get('useLongRangeCorrection', '0') not in ('0', 'false')
     system.alchemical_lrc = use_lrc or not nb.getUseDispersionCorrection()
     if particle_offsets or global_parameters:                                # the factory put it into the lambda_electrostatics group
@@ -525,6 +566,8 @@ def _lambda_names(c):
 def needs_general_reader(nb, global_parameters, particle_offsets, exception_offsets, customs):
     """True when the document holds more than the one unnamed region under the exact PME treatment / without alchemical charges that
     rebuild_marked_system undoes itself"""
+    if any(re.match(r'lambda_(bonds|angles|torsions)', c['energy'].replace(' ', '')) for c in customs):
+        return True
     names = set(global_parameters) | {p[0] for p in particle_offsets + exception_offsets}
     sterics = [c for c in customs if 'U_sterics' in c['energy']]
     electro = [c for c in customs if 'U_electrostatics' in c['energy']]
@@ -551,7 +594,8 @@ def rebuild_general_system(system, nb, global_parameters, particle_offsets, exce
     sterics = [c for c in customs if 'U_sterics' in c['energy']]
     electro = [c for c in customs if 'U_electrostatics' in c['energy']]
     rf = [c for c in customs if compact(c['energy']).startswith(compact(_RF_HEAD)) and c['type'] == 'CustomNonbondedForce']
-    other = [c for c in customs if c not in sterics + electro + rf]
+    bonded = [c for c in customs if re.match(r'lambda_(bonds|angles|torsions)\w*\*', compact(c['energy']))]
+    other = [c for c in customs if c not in sterics + electro + rf + bonded]
     if other:
         raise NotImplementedError('custom force outside the alchemical factory\'s set: %s' % other[0]['energy'][:60])
     sfx_of = lambda name: name[len('lambda_sterics'):] if name.startswith('lambda_sterics') else name[len('lambda_electrostatics'):]
@@ -594,6 +638,26 @@ def rebuild_general_system(system, nb, global_parameters, particle_offsets, exce
         if bad is None:
             break
         order.remove(bad[0]); order.insert(order.index(bad[1]), bad[0])
+    # softened bonded terms go back into the plain forces (at the end: the reference's indices are not in the document), their new
+    # indices to the region's alchemical_bonds / angles / torsions
+    from .system import HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce
+    softened = {x: dict(bonds=[], angles=[], torsions=[]) for x in order}
+    for c in bonded:
+        m = re.match(r'lambda_(bonds|angles|torsions)(\w*)\*', compact(c['energy']))
+        kind, x = m.group(1), m.group(2)
+        if x not in softened:
+            raise NotImplementedError('lambda_%s%s of a region without sterics forces (regions: %s)' % (kind, x, sorted(na_s)))
+        cls, attr = {'bonds': (HarmonicBondForce, 'bonds'), 'angles': (HarmonicAngleForce, 'angles'), 'torsions': (PeriodicTorsionForce, 'torsions')}[kind]
+        plain = [f for f in system.getForces() if isinstance(f, cls)]
+        if not plain:
+            plain = [cls()]
+            system.addForce(plain[0])
+        items = [((i, j), p) for (i, j, p) in c['bonds']] if kind == 'bonds' else c['terms']
+        for ats, p in items:
+            if kind == 'torsions':
+                p = (int(p[0]), p[1], p[2])
+            getattr(plain[-1], attr).append(tuple(ats) + tuple(p))
+            softened[x][kind].append(len(getattr(plain[-1], attr)) - 1)
     regions = []
     ewald = nb.getNonbondedMethod() in (NonbondedForce.Ewald, NonbondedForce.PME)
     exact = ewald and not electro
@@ -601,7 +665,8 @@ def rebuild_general_system(system, nb, global_parameters, particle_offsets, exce
         g = na_s[x]['globals']
         fixed_s = compact(aa_s[x]['energy']).endswith('lambda_sterics%s=1.0;' % x)
         fixed_e = x in aa_e and compact(aa_e[x]['energy']).endswith('lambda_electrostatics%s=1.0;' % x)
-        regions.append(AlchemicalRegion(alchemical_atoms=atoms[x], annihilate_electrostatics=not fixed_e, annihilate_sterics=not fixed_s,
+        regions.append(AlchemicalRegion(alchemical_atoms=atoms[x], alchemical_bonds=softened[x]['bonds'] or None, alchemical_angles=softened[x]['angles'] or None,
+                                        alchemical_torsions=softened[x]['torsions'] or None, annihilate_electrostatics=not fixed_e, annihilate_sterics=not fixed_s,
                                         softcore_alpha=g['softcore_alpha'], softcore_a=g['softcore_a'], softcore_b=g['softcore_b'], softcore_c=g['softcore_c'],
                                         softcore_beta=g.get('softcore_beta', 0.0), softcore_d=g.get('softcore_d', 1.0), softcore_e=g.get('softcore_e', 1.0),
                                         softcore_f=g.get('softcore_f', 2.0), name=x[1:] if x else None))
@@ -621,6 +686,11 @@ def rebuild_general_system(system, nb, global_parameters, particle_offsets, exce
         else:
             opts['alchemical_pme_treatment'] = 'coulomb'
         opts['switch_width'] = round(nb.getCutoffDistance() - float(c['attrs'].get('switchingDistance', nb.getCutoffDistance() - 0.1)), 12)
+    if rf:
+        opts['alchemical_rf_treatment'] = 'switched'
+        opts['switch_width'] = round(nb.getCutoffDistance() - float(rf[0]['attrs'].get('switchingDistance', nb.getCutoffDistance() - 0.1)), 12)
+    elif nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic and not na_e:
+        opts['alchemical_rf_treatment'] = 'shifted'              # no replaced reaction field in the document
     # ---- the reference NonbondedForce again ---------------------------------------------------------------------------------
     charge = {p[1]: p[2] for p in particle_offsets}
     for x in order:

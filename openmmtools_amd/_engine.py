@@ -48,12 +48,15 @@ class RemdAlchRegionsDesc(C.Structure):
         ('electrostatics', C.c_int32),
         ('elec_alpha', C.c_double), ('elec_krf', C.c_double), ('elec_crf', C.c_double), ('elec_switch_distance', C.c_double),
         ('exact_pme', C.c_int32),
+        ('n_bonds', C.c_int32), ('bond_atoms', c_int32_p), ('bond_params', c_double_p), ('bond_region', c_int32_p),
+        ('n_angles', C.c_int32), ('angle_atoms', c_int32_p), ('angle_params', c_double_p), ('angle_region', c_int32_p),
+        ('n_torsions', C.c_int32), ('torsion_atoms', c_int32_p), ('torsion_params', c_double_p), ('torsion_region', c_int32_p),
     ]
 
 
 EXPORTS = [
-    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_alchemical_options', 'remd_set_alchemical_regions',
-    'remd_set_region_lambdas', 'remd_set_states',
+    'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_reaction_field', 'remd_set_alchemical_options', 'remd_set_alchemical_regions',
+    'remd_set_region_lambdas', 'remd_set_region_bonded_lambdas', 'remd_set_states',
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_copy_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_propagate_many', 'remd_set_phases', 'remd_get_phases', 'remd_get_constraint_stats', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
@@ -97,9 +100,11 @@ def load_library(path=None):
     lib.remd_version.argtypes = []
     lib.remd_set_system.argtypes = [vp, C.POINTER(RemdSystemDesc)]
     lib.remd_set_coulomb_cutoff.argtypes = [vp, C.c_double]
+    lib.remd_set_reaction_field.argtypes = [vp, C.c_int, C.c_double]
     lib.remd_set_alchemical_options.argtypes = [vp, C.c_int]
     lib.remd_set_alchemical_regions.argtypes = [vp, C.POINTER(RemdAlchRegionsDesc)]
     lib.remd_set_region_lambdas.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p]
+    lib.remd_set_region_bonded_lambdas.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
@@ -252,6 +257,9 @@ class HipEngine:
         s, keep = build_desc(desc_dict)
         # Ewald split (system.system_to_desc(ewald_split=...)): range of the direct-space Coulomb sum, 0 = the cutoff
         self._check(self.lib.remd_set_coulomb_cutoff(self.h, float(desc_dict.get('coulomb_cutoff', 0.0))), 'remd_set_coulomb_cutoff')
+        # reaction field as the alchemical factory re-writes it (alchemical_rf_treatment='switched'): c_rf = 0 + switch
+        rfw = desc_dict.get('rf_unshifted_switch_width')
+        self._check(self.lib.remd_set_reaction_field(self.h, int(rfw is not None), float(rfw or 0.0)), 'remd_set_reaction_field')
         self._check(self.lib.remd_set_alchemical_options(self.h, int(bool(desc_dict.get('annihilate_sterics', False)))), 'remd_set_alchemical_options')
         self._check(self.lib.remd_set_system(self.h, C.byref(s)), 'remd_set_system')
         self.N = int(desc_dict['n_atoms'])
@@ -276,6 +284,12 @@ class HipEngine:
             r.elec_alpha, r.elec_krf, r.elec_crf = float(regions['elec_alpha']), float(regions['elec_krf']), float(regions['elec_crf'])
             r.elec_switch_distance = float(regions['elec_switch_distance'])
             r.exact_pme = int(regions.get('exact_pme', 0))
+            for kind, width, npar in (('bond', 2, 2), ('angle', 3, 2), ('torsion', 4, 3)):
+                atoms = np.asarray(regions.get(kind + '_atoms', np.zeros((0, width))), dtype=np.int32).reshape(-1, width)
+                setattr(r, 'n_%ss' % kind, len(atoms))
+                setattr(r, kind + '_atoms', i32(atoms))
+                setattr(r, kind + '_params', f64(np.asarray(regions.get(kind + '_params', np.zeros((0, npar))), dtype=np.float64).reshape(-1, npar)))
+                setattr(r, kind + '_region', i32(np.asarray(regions.get(kind + '_region', np.zeros(0)), dtype=np.int32)))
             self._check(self.lib.remd_set_alchemical_regions(self.h, C.byref(r)), 'remd_set_alchemical_regions')
             self.n_regions = int(r.n_regions)
         if 'force_groups' in desc_dict:                  # Force.getForceGroup() of the force classes (V<g> substeps)
@@ -293,6 +307,12 @@ class HipEngine:
         ls = np.ascontiguousarray(lambda_sterics, dtype=np.float64).reshape(self.K, -1)
         le = np.ascontiguousarray(lambda_electrostatics, dtype=np.float64).reshape(self.K, -1)
         self._check(self.lib.remd_set_region_lambdas(self.h, self.K, ls.shape[1], _dp(ls), _dp(le)), 'remd_set_region_lambdas')
+
+    def set_region_bonded_lambdas(self, lambda_bonds=None, lambda_angles=None, lambda_torsions=None):
+        """[K][n_regions] lambdas of the alchemically softened bonded terms (after set_region_lambdas; None: 1)."""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(self.K, -1) for a in (lambda_bonds, lambda_angles, lambda_torsions)]
+        n = next((a.shape[1] for a in arrs if a is not None), self.n_regions)
+        self._check(self.lib.remd_set_region_bonded_lambdas(self.h, self.K, n, *[_dp(a) for a in arrs]), 'remd_set_region_bonded_lambdas')
 
     def set_integrator(self, splitting, timestep, collision_rate, n_steps, reassign_velocities=True,
                        constraint_tolerance=1e-8):

@@ -33,12 +33,19 @@ from .states import AlchemicalState, AlchemicalStateError          # alchemy.py:
 
 
 class AlchemicalRegion:
-    def __init__(self, alchemical_atoms=None, annihilate_electrostatics=True, annihilate_sterics=False,
+    """alchemy.py:416-600 (a namedtuple there; same fields, same order, same defaults).  alchemical_bonds / angles / torsions: None (no
+    softened bonded terms), True (every bond / angle / proper torsion that involves an alchemical atom, :940-1050) or the indices of the
+    terms in the System's HarmonicBondForce / HarmonicAngleForce / PeriodicTorsionForce."""
+
+    def __init__(self, alchemical_atoms=None, alchemical_bonds=None, alchemical_angles=None, alchemical_torsions=None,
+                 annihilate_electrostatics=True, annihilate_sterics=False,
                  softcore_alpha=0.5, softcore_a=1, softcore_b=1, softcore_c=6, softcore_beta=0.0,
                  softcore_d=1, softcore_e=1, softcore_f=2, name=None):
         if not alchemical_atoms:
             raise ValueError('The AlchemicalRegion is empty.')                      # alchemy.py:899-900 (raised there when the region is resolved)
         self.alchemical_atoms = sorted(int(a) for a in alchemical_atoms)
+        self.alchemical_bonds, self.alchemical_angles, self.alchemical_torsions = (
+            (t if (t is None or t is True or t is False) else sorted(int(k) for k in t)) for t in (alchemical_bonds, alchemical_angles, alchemical_torsions))
         self.annihilate_electrostatics = bool(annihilate_electrostatics)
         self.annihilate_sterics = bool(annihilate_sterics)
         self.softcore_alpha, self.softcore_a, self.softcore_b, self.softcore_c = (
@@ -96,6 +103,10 @@ class AbsoluteAlchemicalFactory:
         system.alchemical_lrc = not self.disable_alchemical_dispersion_correction
         nbs = [f for f in system.getForces() if isinstance(f, NonbondedForce)]
         nb = nbs[0] if nbs else None
+        if nb is not None and nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic and self.alchemical_rf_treatment == 'switched':
+            # alchemy.py:744-749: the factory then replaces the reaction field of the WHOLE system by an unshifted, switched one
+            # (forcefactories.replace_reaction_field :76-84, forces.UnshiftedReactionFieldForce): remd_set_reaction_field
+            system.rf_unshifted_switch_width = self.switch_width
         charged = nb is not None and any(nb.particles[i][0] != 0.0 for i in seen) or \
             (nb is not None and any(e[2] != 0.0 and (e[0] in seen or e[1] in seen) for e in nb.exceptions))
         is_pme = nb is not None and nb.getNonbondedMethod() == NonbondedForce.PME
@@ -110,7 +121,8 @@ class AbsoluteAlchemicalFactory:
                 if (r.softcore_beta, r.softcore_d, r.softcore_e) != (0, 1, 1):
                     raise ValueError('Softcore electrostatics is' + err)
         r0 = regions[0]
-        fast = (len(regions) == 1 and r0.softcore_c == 6.0 and (exact or not charged))
+        bonded = self._softened_bonded_terms(system, regions, interactions)           # takes them out of the System's bonded forces
+        fast = (len(regions) == 1 and r0.softcore_c == 6.0 and (exact or not charged) and bonded is None)
         if fast:
             # the pair kernels' own path: one region, charges scaled inside the Ewald sum or none to scale
             system.alchemical_region = r0
@@ -120,12 +132,6 @@ class AbsoluteAlchemicalFactory:
             raise ValueError('alchemical regions need a NonbondedForce')
         if self.consistent_exceptions:
             raise NotImplementedError('consistent_exceptions=True (alchemy.py:1457-1459)')
-        if nb.getNonbondedMethod() == NonbondedForce.CutoffPeriodic and self.alchemical_rf_treatment == 'switched' and \
-                sum(1 for i, q in enumerate(nb.particles) if q[0] != 0.0 and i not in seen) > 1:
-            # alchemy.py:744-749: the factory then ALSO replaces the reaction field of the environment by an unshifted, switched one
-            # (forcefactories.replace_reaction_field); the pair kernels evaluate OpenMM's shifted reaction field
-            raise NotImplementedError("alchemical_rf_treatment='switched' with a charged environment under a reaction-field method "
-                                      "(forcefactories.py:76-84 replaces the environment's reaction field too): use alchemical_rf_treatment='shifted'")
         system.alchemical_region = None
         system.alchemical_regions = regions
         # alchemical_regions_interactions, as the reference's loop EXECUTES them (alchemy.py:1693, 1886-1911): the forces of a pair of
@@ -138,7 +144,65 @@ class AbsoluteAlchemicalFactory:
         system.alchemical_factory_options = dict(alchemical_pme_treatment=self.alchemical_pme_treatment,
                                                  alchemical_rf_treatment=self.alchemical_rf_treatment, switch_width=self.switch_width)
         system.alchemical_region_terms = self._region_terms(nb, regions, charged, exact, interactions)
+        if bonded is not None:
+            system.alchemical_region_terms.update(bonded)
         return system
+
+    # ---- softened bonds / angles / torsions (alchemy.py:940-1050 what True means, :1115-1354 the forces) -------------------------
+    @staticmethod
+    def _softened_bonded_terms(system, regions, interactions):
+        from .system import HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce
+        if all(not getattr(r, 'alchemical_' + k) for r in regions for k in ('bonds', 'angles', 'torsions')):
+            return None
+        n = system.getNumParticles()
+        bonded_to = [set() for _ in range(n)]                               # _tabulate_bonds: bonds and constraints
+        for f in system.getForces():
+            if isinstance(f, HarmonicBondForce):
+                for b in f.bonds:
+                    bonded_to[b[0]].add(b[1]); bonded_to[b[1]].add(b[0])
+        for k in range(system.getNumConstraints()):
+            i, j, _ = system.getConstraintParameters(k)
+            bonded_to[i].add(j); bonded_to[j].add(i)
+        region_of = {}
+        for g, r in enumerate(regions):
+            for a in r.alchemical_atoms:
+                region_of[a] = g
+        together = set(interactions)
+
+        def straddling(atoms):                                             # _are_straddling_noninteracting_regions (:1086-1112)
+            gs = sorted({region_of[a] for a in atoms if a in region_of})
+            return len(gs) > 1 and (gs[0], gs[1]) not in together
+        out = {}
+        for kind, cls, attr, width in (('bond', HarmonicBondForce, 'bonds', 2), ('angle', HarmonicAngleForce, 'angles', 3), ('torsion', PeriodicTorsionForce, 'torsions', 4)):
+            forces = [f for f in system.getForces() if isinstance(f, cls)]
+            chosen = {}
+            for g, r in enumerate(regions):
+                want = getattr(r, 'alchemical_' + kind + 's')
+                if not want:
+                    continue
+                if not forces:
+                    raise ValueError('alchemical_%ss without a %s in the system' % (kind, cls.__name__))
+                terms = getattr(forces[-1], attr)
+                if want is True:
+                    A = set(r.alchemical_atoms)
+                    want = [k for k, t in enumerate(terms) if A & set(t[:width]) and
+                            (kind != 'torsion' or all(t[q + 1] in bonded_to[t[q]] for q in range(3)))]           # proper torsions only (:970-990)
+                bad = [k for k in want if not 0 <= k < len(terms)]
+                if bad:
+                    raise ValueError('Indices {} in {} cannot be found in the system'.format(set(bad), 'alchemical_%ss' % kind))    # alchemy.py:886-889
+                for k in want:
+                    chosen[k] = g + 1                                   # (a term two regions claim: the later region's force holds it last)
+            if not chosen:
+                continue
+            f = forces[-1]
+            terms = getattr(f, attr)
+            out[kind + '_atoms'] = np.array([terms[k][:width] for k in sorted(chosen)], dtype=np.int32).reshape(-1, width)
+            out[kind + '_params'] = np.array([terms[k][width:] for k in sorted(chosen)], dtype=np.float64)
+            out[kind + '_region'] = np.array([chosen[k] for k in sorted(chosen)], dtype=np.int32)
+            out[kind + '_index'] = np.array(sorted(chosen), dtype=np.int32)
+            # what stays in the plain force: not softened, and not connecting two regions that do not interact (:1156-1162)
+            setattr(f, attr, [t for k, t in enumerate(terms) if k not in chosen and not straddling(t[:width])])
+        return out or None
 
     # ---- the factory's split of a NonbondedForce (alchemy.py:1539-2038) ---------------------------------------------
     def _region_terms(self, nb, regions, charged, exact=False, interactions=()):

@@ -24,6 +24,7 @@ struct region_consts {
     int elec, n_cls, n_reg1, words, N, Npad, n_alch, n_exc;
     // exact PME treatment: the Ewald split of the handle (erfc to rcc), per region the self term, the net charge, the environment's
     // net charge and the coefficient of the neutralising background (E = coeff Q^2 / V)
+    int n_bonds, n_angles, n_torsions;     // alchemically softened bonded terms (lambda_bonds / lambda_angles / lambda_torsions of their region)
     int exact; float alpha_x, two_alpha_sqrtpi_x, rcc2;
     double self_x[4], q_x[4], q_env, plasma;
 };
@@ -42,6 +43,10 @@ struct region_tables {
     int* d_exc_atoms = nullptr; float4* d_exc_par = nullptr;      // exceptions: (k_e qq, sigma, 4 eps, class bits)
     float4* d_state_cls = nullptr;         // [K][n_cls][2]: (l^a, alpha (1 - l)^b, l^d, beta (1 - l)^e), (c, f, 0, 0)
     int* d_own = nullptr; std::vector<int> own_host;
+    // softened bonded terms: atoms, parameters (the last entry of a term = its region as float bits), per state the regions' lambdas
+    int* d_bonded_atoms = nullptr; float* d_bonded_par = nullptr;      // bonds [n][2] + angles [n][3] + torsions [n][4]; [n][3] + [n][3] + [n][4]
+    float* d_state_bl = nullptr;           // [K][3][n_regions]
+    std::vector<double> bl;                // host: [3][K][n_regions]
     // exact PME treatment (<= 4 charged regions: the slots of one float4 per replica, which the mesh kernels index by the atom's code)
     unsigned int* d_corr = nullptr;        // [n_alch][words] skipped candidates that still get the Ewald correction -qq erf(alpha r) / r
     float4* d_param_pme = nullptr;         // [Npad] the mesh kernels' charges: reference charges of the alchemical atoms, w = 8 + region slot
@@ -183,6 +188,71 @@ __device__ __forceinline__ float3 region_min_image(float3 d, float Lx, float Ly,
     return d;
 }
 
+// ---- softened bonded terms: lambda x the reference's harmonic bond / harmonic angle / periodic torsion (alchemy.py:1180, 1261, 1341) -------------
+struct region_bonded { const int* atoms; const float* par; const float* lam; int n_regions; };
+// term t of the three classes laid end to end; returns lambda x energy, adds lambda x force when F is given
+__device__ __forceinline__ float region_bonded_term(const region_consts& c, const region_bonded& B, int t, const float4* __restrict__ P,
+                                                    long long* __restrict__ F)
+{
+    if (t < c.n_bonds) {
+        const int i = B.atoms[2 * t], j = B.atoms[2 * t + 1];
+        const float r0 = B.par[3 * t], k = B.par[3 * t + 1];
+        const float lam = B.lam[__float_as_int(B.par[3 * t + 2]) - 1];
+        const float3 d = sub3(ld3(P, j), ld3(P, i));
+        const float len = sqrtf(dotf(d, d));
+        if (F) {
+            const float fs = lam * k * (len - r0) / len;
+            add_force(F, c.Npad, i, fs * d.x, fs * d.y, fs * d.z);
+            add_force(F, c.Npad, j, -fs * d.x, -fs * d.y, -fs * d.z);
+        }
+        return lam * 0.5f * k * (len - r0) * (len - r0);
+    }
+    t -= c.n_bonds;
+    const int* A = B.atoms + 2 * c.n_bonds;
+    const float* Q = B.par + 3 * c.n_bonds;
+    if (t < c.n_angles) {
+        const int a = A[3 * t], b = A[3 * t + 1], cc = A[3 * t + 2];
+        const float th0 = Q[3 * t], k = Q[3 * t + 1];
+        const float lam = B.lam[B.n_regions + __float_as_int(Q[3 * t + 2]) - 1];
+        const float3 v0 = sub3(ld3(P, a), ld3(P, b)), v1 = sub3(ld3(P, cc), ld3(P, b));
+        const float3 cp = crs3(v0, v1);
+        const float rp = fmaxf(sqrtf(dotf(cp, cp)), 1e-6f);
+        const float r20 = dotf(v0, v0), r21 = dotf(v1, v1);
+        const float cosine = fminf(fmaxf(dotf(v0, v1) * rsqrtf(r20 * r21), -1.f), 1.f);
+        const float dth = acosf(cosine) - th0;
+        if (F) {
+            const float dEdth = lam * k * dth;
+            const float3 fa = scl3(crs3(v0, cp), -dEdth / (r20 * rp)), fc = scl3(crs3(cp, v1), -dEdth / (r21 * rp));
+            add_force(F, c.Npad, a, fa.x, fa.y, fa.z);
+            add_force(F, c.Npad, cc, fc.x, fc.y, fc.z);
+            add_force(F, c.Npad, b, -(fa.x + fc.x), -(fa.y + fc.y), -(fa.z + fc.z));
+        }
+        return lam * 0.5f * k * dth * dth;
+    }
+    t -= c.n_angles;
+    A += 3 * c.n_angles; Q += 3 * c.n_angles;
+    const int a1 = A[4 * t], a2 = A[4 * t + 1], a3 = A[4 * t + 2], a4 = A[4 * t + 3];
+    const float per = Q[4 * t], phase = Q[4 * t + 1], k = Q[4 * t + 2];
+    const float lam = B.lam[2 * B.n_regions + __float_as_int(Q[4 * t + 3]) - 1];
+    const float3 b1 = sub3(ld3(P, a2), ld3(P, a1)), b2 = sub3(ld3(P, a3), ld3(P, a2)), b3 = sub3(ld3(P, a4), ld3(P, a3));
+    const float3 m = crs3(b1, b2), nn = crs3(b2, b3);
+    const float m2 = fmaxf(dotf(m, m), 1e-12f), n2 = fmaxf(dotf(nn, nn), 1e-12f);
+    const float lb2 = sqrtf(dotf(b2, b2));
+    const float phi = atan2f(lb2 * dotf(b1, nn), dotf(m, nn));
+    const float arg = per * phi - phase;
+    if (F) {
+        const float dEdphi = -lam * k * per * sinf(arg);
+        const float3 g1 = scl3(m, -lb2 / m2), g4 = scl3(nn, lb2 / n2);
+        const float s12 = dotf(b1, b2) / (lb2 * lb2), s32 = dotf(b3, b2) / (lb2 * lb2);
+        const float3 g2 = add3(scl3(g1, -(1.f + s12)), scl3(g4, s32)), g3 = add3(scl3(g4, -(1.f + s32)), scl3(g1, s12));
+        add_force(F, c.Npad, a1, -dEdphi * g1.x, -dEdphi * g1.y, -dEdphi * g1.z);
+        add_force(F, c.Npad, a2, -dEdphi * g2.x, -dEdphi * g2.y, -dEdphi * g2.z);
+        add_force(F, c.Npad, a3, -dEdphi * g3.x, -dEdphi * g3.y, -dEdphi * g3.z);
+        add_force(F, c.Npad, a4, -dEdphi * g4.x, -dEdphi * g4.y, -dEdphi * g4.z);
+    }
+    return lam * k * (1.f + cosf(arg));
+}
+
 // forces: workgroup = (alchemical atom a, chunk of 1024 atoms j); the first workgroups of a replica also take the exceptions.
 // One candidate in ten is inside the cutoff, and a wavefront that holds ONE of them pays the whole soft-core arithmetic (powf, erfc):
 // the candidates are therefore tested first (distance, static bits) and the survivors compacted -- per wavefront by ballot + prefix count,
@@ -195,7 +265,7 @@ void region_forces_kernel(region_consts c, const int* __restrict__ alch, const f
                           const int* __restrict__ cls_of, const float4* __restrict__ state_cls, const int* __restrict__ own,
                           const int* __restrict__ exc_atoms, const float4* __restrict__ exc_par,
                           const float4* __restrict__ pos, const float* __restrict__ box, long long* __restrict__ force,
-                          const unsigned int* __restrict__ corr, const float* __restrict__ rep_le)
+                          const unsigned int* __restrict__ corr, const float* __restrict__ rep_le, region_bonded bonded)
 {
     __shared__ int s_list[4][REGION_CHUNK / 4];            // per wavefront: its survivors, j | correction flag << 30
     __shared__ int s_count[4];
@@ -259,6 +329,10 @@ void region_forces_kernel(region_consts c, const int* __restrict__ alch, const f
         add_force(F, c.Npad, i, fr * d.x, fr * d.y, fr * d.z);
         add_force(F, c.Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
     }
+    // softened bonded terms, likewise
+    bonded.lam += (size_t)own[r] * 3 * bonded.n_regions;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < c.n_bonds + c.n_angles + c.n_torsions; t += gridDim.x * 256)
+        region_bonded_term(c, bonded, t, P, F);
 }
 
 // energies: workgroup = (state column, replica); state = own[r] when `own` is given (the replica's potential), else the column
@@ -267,7 +341,7 @@ void region_energy_kernel(region_consts c, const int* __restrict__ alch, const f
                           const int* __restrict__ cls_of, const float4* __restrict__ state_cls, const int* __restrict__ own,
                           const int* __restrict__ exc_atoms, const float4* __restrict__ exc_par,
                           const float4* __restrict__ pos, const float* __restrict__ box, double* __restrict__ out, int out_stride, int out_offset,
-                          const unsigned int* __restrict__ corr, const float* __restrict__ rep_le)
+                          const unsigned int* __restrict__ corr, const float* __restrict__ rep_le, region_bonded bonded)
 {
     // rep_le (exact PME treatment): the electrostatic terms at the replicas' lambdas ride along; NULL: sterics / custom electrostatics only
     __shared__ double s_part[4];
@@ -299,6 +373,8 @@ void region_energy_kernel(region_consts c, const int* __restrict__ alch, const f
         region_exception(c, cls_tab, exc_par[t], d, U, fr, le4);
         e += (double)U;
     }
+    bonded.lam += (size_t)state * 3 * bonded.n_regions;
+    for (int t = threadIdx.x; t < c.n_bonds + c.n_angles + c.n_torsions; t += 256) e += (double)region_bonded_term(c, bonded, t, P, nullptr);
     for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = e;
     __syncthreads();
@@ -324,6 +400,7 @@ void remd_regions_release(remd_ctx* h)
         dfree(t->d_alch); dfree(t->d_atom); dfree(t->d_skip); dfree(t->d_cls_of); dfree(t->d_exc_atoms); dfree(t->d_exc_par);
         dfree(t->d_state_cls); dfree(t->d_own);
         dfree(t->d_corr); dfree(t->d_param_pme); dfree(t->d_rep_le); dfree(t->d_state_le);
+        dfree(t->d_bonded_atoms); dfree(t->d_bonded_par); dfree(t->d_state_bl);
         g_reg.erase(h);
     }
     h->n_regions = 0; h->regions_exact = 0;
@@ -472,6 +549,28 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     if ((rc = upload(h, t.d_alch, alch)) || (rc = upload(h, t.d_atom, atom)) || (rc = upload(h, t.d_skip, skip)) || (rc = upload(h, t.d_cls_of, cls_of)) ||
         (rc = upload(h, t.d_exc_atoms, ea)) || (rc = upload(h, t.d_exc_par, ep)) || (rc = upload(h, t.d_corr, corr)) ||
         (rc = upload(h, t.d_param_pme, param_pme))) { remd_regions_release(h); return rc; }
+    {   // softened bonded terms
+        if (d->n_bonds < 0 || d->n_angles < 0 || d->n_torsions < 0 || (d->n_bonds > 0 && (!d->bond_atoms || !d->bond_params || !d->bond_region)) ||
+            (d->n_angles > 0 && (!d->angle_atoms || !d->angle_params || !d->angle_region)) || (d->n_torsions > 0 && (!d->torsion_atoms || !d->torsion_params || !d->torsion_region))) {
+            remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: bad softened bonded terms");
+        }
+        std::vector<int> ba; std::vector<float> bp;
+        auto take = [&](int cnt, int width, int npar, const int32_t* atoms, const double* par, const int32_t* reg) -> bool {
+            for (int k = 0; k < cnt; ++k) {
+                for (int q = 0; q < width; ++q) { const int a = atoms[width * k + q]; if (a < 0 || a >= N) return false; ba.push_back(a); }
+                for (int q = 0; q < npar; ++q) bp.push_back((float)par[npar * k + q]);
+                if (reg[k] < 1 || reg[k] > n) return false;
+                bp.push_back(host_int_as_float(reg[k]));
+            }
+            return true;
+        };
+        if (!take(d->n_bonds, 2, 2, d->bond_atoms, d->bond_params, d->bond_region) || !take(d->n_angles, 3, 2, d->angle_atoms, d->angle_params, d->angle_region) ||
+            !take(d->n_torsions, 4, 3, d->torsion_atoms, d->torsion_params, d->torsion_region)) {
+            remd_regions_release(h); return remd_fail(h, -1, "alchemical regions: softened bonded term with a bad atom or region");
+        }
+        c.n_bonds = d->n_bonds; c.n_angles = d->n_angles; c.n_torsions = d->n_torsions;
+        if ((rc = upload(h, t.d_bonded_atoms, ba)) || (rc = upload(h, t.d_bonded_par, bp))) { remd_regions_release(h); return rc; }
+    }
     h->n_regions = n; h->regions_exact = exact ? 1 : 0;
     return 0;
 }
@@ -510,6 +609,35 @@ int remd_set_region_lambdas(remd_handle h, int K, int n_regions, const double* l
     for (int k = 0; k < K; ++k) for (int g = 0; g < n && g < 4; ++g) sle[4 * (size_t)k + g] = (float)le[(size_t)k * n + g];
     if ((rc = upload(h, t.d_state_le, sle))) return rc;
     t.rep_le_host.clear();
+    t.bl.assign(3 * (size_t)K * n, 1.0);                      // until remd_set_region_bonded_lambdas says otherwise
+    {
+        std::vector<float> one(3 * (size_t)K * n, 1.f);
+        if ((rc = upload(h, t.d_state_bl, one))) return rc;
+    }
+    h->config_version++;
+    h->forces_valid = false;
+    return 0;
+}
+
+int remd_set_region_bonded_lambdas(remd_handle h, int K, int n_regions, const double* lb, const double* la, const double* lt)
+{
+    if (!h) return remd_fail(h, -1, "remd_set_region_bonded_lambdas: NULL handle");
+    region_tables* tp = g_reg.find(h);
+    if (!tp || h->n_regions == 0) return remd_fail(h, -2, "remd_set_region_bonded_lambdas: no alchemical regions on this handle");
+    region_tables& t = *tp;
+    if (K != h->K || K != t.K || n_regions != t.n_regions) return remd_fail(h, -1, "remd_set_region_bonded_lambdas: call remd_set_region_lambdas first (same K, n_regions)");
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    const int n = t.n_regions;
+    const double* src[3] = {lb, la, lt};
+    std::vector<float> tab(3 * (size_t)K * n, 1.f);           // [K][3][n]
+    for (int q = 0; q < 3; ++q) for (int k = 0; k < K; ++k) for (int g = 0; g < n; ++g) {
+        const double v = src[q] ? src[q][(size_t)k * n + g] : 1.0;
+        if (!(v >= 0.0 && v <= 1.0)) return remd_fail(h, -1, "remd_set_region_bonded_lambdas: lambdas must be in [0, 1]");
+        tab[((size_t)k * 3 + q) * n + g] = (float)v;
+    }
+    int rc = upload(h, t.d_state_bl, tab);
+    if (rc) return rc;
     h->config_version++;
     h->forces_valid = false;
     return 0;
@@ -552,11 +680,11 @@ int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot)
     remd_prof_scope ps(h, "alch_regions");
     const int nchunk = (h->N + REGION_CHUNK - 1) / REGION_CHUNK;
     hipLaunchKernelGGL(region_forces_kernel, dim3(t.c.n_alch * nchunk, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
-                       t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_force, t.d_corr, t.c.exact ? t.d_rep_le : (const float*)nullptr);
+                       t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_force, t.d_corr, t.c.exact ? t.d_rep_le : (const float*)nullptr, region_bonded{t.d_bonded_atoms, t.d_bonded_par, t.d_state_bl, t.n_regions});
     if (with_energy)
         hipLaunchKernelGGL(region_energy_kernel, dim3(1, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
                            t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_epart, h->n_epart, ep_slot,
-                           t.d_corr, t.c.exact ? t.d_rep_le : (const float*)nullptr);
+                           t.d_corr, t.c.exact ? t.d_rep_le : (const float*)nullptr, region_bonded{t.d_bonded_atoms, t.d_bonded_par, t.d_state_bl, t.n_regions});
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }
@@ -573,7 +701,7 @@ int remd_regions_ukl(remd_ctx* h, double* d_out, const int** d_own)
     remd_prof_scope ps(h, "alch_ukl");
     hipLaunchKernelGGL(region_energy_kernel, dim3(h->K, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
                        t.d_state_cls, (const int*)nullptr, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, d_out, h->K, 0,
-                       t.d_corr, (const float*)nullptr);          // (exact PME treatment: the sterics only; the Coulomb part is the quadratic form of forces.hip)
+                       t.d_corr, (const float*)nullptr, region_bonded{t.d_bonded_atoms, t.d_bonded_par, t.d_state_bl, t.n_regions});          // (exact PME treatment: the sterics only; the Coulomb part is the quadratic form of forces.hip)
     REMD_CHECK(h, hipGetLastError());
     *d_own = t.d_own;
     return 0;

@@ -186,6 +186,13 @@ int remd_set_alchemical_options(remd_handle h, int annihilate_sterics)
     return 0;
 }
 
+int remd_set_reaction_field(remd_handle h, int unshifted, double switch_width_nm)
+{
+    if (!h || (unshifted != 0 && unshifted != 1) || !(switch_width_nm >= 0.0)) return remd_fail(h, -1, "remd_set_reaction_field: bad arguments");
+    h->rf_unshifted = unshifted; h->rf_switch_width = switch_width_nm;      // consumed by the next remd_set_system
+    return 0;
+}
+
 int remd_set_coulomb_cutoff(remd_handle h, double coulomb_cutoff_nm)
 {
     if (!h || !(coulomb_cutoff_nm >= 0.0)) return remd_fail(h, -1, "remd_set_coulomb_cutoff: bad arguments");
@@ -658,7 +665,7 @@ static int phase_children(remd_ctx* h, int P)
             }
         }
         c->sync_events = h->sync_events; c->overlap = h->overlap;
-        c->annihilate_sterics = h->annihilate_sterics; c->coulomb_cutoff = h->coulomb_cutoff;
+        c->annihilate_sterics = h->annihilate_sterics; c->coulomb_cutoff = h->coulomb_cutoff; c->rf_unshifted = h->rf_unshifted; c->rf_switch_width = h->rf_switch_width;
         if ((rc = remd_set_system(c, &h->sysdesc->d))) return remd_fail(h, rc, std::string("phases: ") + c->err);
         if ((rc = remd_set_states(c, h->K, h->beta.data(), h->lam_s.data(), h->lam_e.data(), h->econst.data()))) return remd_fail(h, rc, std::string("phases: ") + c->err);
         if ((rc = remd_set_integrator(c, h->splitting.c_str(), h->dt, h->gamma, h->n_steps, h->reassign, h->constraint_tol))) return remd_fail(h, rc, std::string("phases: ") + c->err);

@@ -1615,6 +1615,11 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
     const double eps_s = d->rf_dielectric;
     p.krf = (float)((eps_s - 1.0) / (2.0 * eps_s + 1.0) / pow(d->cutoff, 3));
     p.crf = (float)(3.0 * eps_s / (2.0 * eps_s + 1.0) / d->cutoff);
+    p.rs_c = -1.f; p.inv_sw_c = 0.f;
+    if (h->rf_unshifted) {                  // remd_set_reaction_field: UnshiftedReactionFieldForce (forces.py:1110-1150)
+        p.crf = 0.f;
+        if (h->rf_switch_width > 0.0 && h->rf_switch_width < d->cutoff) { p.rs_c = (float)(d->cutoff - h->rf_switch_width); p.inv_sw_c = (float)(1.0 / h->rf_switch_width); }
+    }
     p.alpha = (float)d->ewald_alpha; p.two_alpha_sqrtpi = (float)(2.0 * d->ewald_alpha / sqrt(M_PI));
     p.excl_words = words;
     // Ewald split (remd_set_coulomb_cutoff): the erfc tail may be summed beyond the NonbondedForce cutoff, with the alpha and

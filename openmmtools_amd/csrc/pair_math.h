@@ -25,6 +25,9 @@ struct nb_params {
     // force-only Coulomb kernel from a table in r^2 (coulomb_table.h): first bin's key, number of bins, clamp of r^2
     int ctab_key0, ctab_n; float ctab_umin;
     int prio;                         // pair kernel at raised wave priority (the direct-space stream is the critical path)
+    // reaction field as the reference's alchemical factory re-writes it (remd_set_reaction_field; forcefactories.py:76-84, forces.py:1110-1150):
+    // c_rf = 0 and the pair term switched from rs_c to the cutoff; rs_c < 0: OpenMM's shifted reaction field
+    float rs_c, inv_sw_c;
 };
 
 
@@ -102,6 +105,12 @@ __device__ __forceinline__ float pair_interaction(const nb_params& p, float r2, 
         } else {
             Uc = qq * (inv_r + p.krf * r2 - p.crf);
             dUc = qq * (2.f * p.krf * r - inv_r * inv_r);
+            if (p.rs_c >= 0.f && r > p.rs_c) {
+                const float x = (r - p.rs_c) * p.inv_sw_c;
+                const float S = 1.f + x * x * x * (-10.f + x * (15.f - 6.f * x));
+                dUc = S * dUc + Uc * (x * x * (-30.f + x * (60.f - 30.f * x)) * p.inv_sw_c);
+                Uc *= S;
+            }
         }
     }
     // (x + 0.f cannot be folded without nsz: name the sum the variant has)

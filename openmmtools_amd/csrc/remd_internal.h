@@ -124,6 +124,7 @@ struct remd_ctx {
     int nb_method = REMD_NB_NONE;
     double cutoff = 0, switch_dist = -1, rf_dielectric = 78.3, ewald_alpha = 0;
     int annihilate_sterics = 0;        // remd_set_alchemical_options: alchemical/alchemical sterics are lambda-controlled too
+    int rf_unshifted = 0; double rf_switch_width = 0;   // remd_set_reaction_field: c_rf = 0, pair term switched over the last rf_switch_width nm
     double coulomb_cutoff = 0;         // remd_set_coulomb_cutoff: range of the Ewald direct-space sum (0: the NonbondedForce cutoff)
     int grid[3] = {0, 0, 0};
     int use_disp = 0;

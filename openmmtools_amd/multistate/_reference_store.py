@@ -524,7 +524,7 @@ class ReferenceStoreWriter:
                     # (one entry per composable state: the region's name as parameters_name_suffix, the parameters under their plain names)
                     alch = [{'_serialized__class_name': 'AlchemicalState', '_serialized__module_name': 'openmmtools.alchemy.alchemy',
                              'parameters': {'lambda_sterics': float(c.lambda_sterics), 'lambda_electrostatics': float(c.lambda_electrostatics),
-                                            'lambda_bonds': None, 'lambda_angles': None, 'lambda_torsions': None},
+                                            **{k: (float(getattr(c, k)) if k in c._defined else None) for k in ('lambda_bonds', 'lambda_angles', 'lambda_torsions')}},
                              'function_variables': {}, 'parameters_name_suffix': c.parameters_name_suffix} for c in s._alchs]
                     d = {'_serialized__class_name': 'CompoundThermodynamicState', '_serialized__module_name': 'openmmtools.states',
                          'thermodynamic_state': d, 'composable_states': alch}

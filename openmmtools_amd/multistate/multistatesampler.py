@@ -658,6 +658,12 @@ class MultiStateSampler:
             names = [r.name for r in regions]
             lams = [s.region_lambdas(names) for s in all_states]
             eng.set_region_lambdas(np.array([l[0] for l in lams], dtype=np.float64), np.array([l[1] for l in lams], dtype=np.float64))
+            bonded = np.array([s.region_bonded_lambdas(names) for s in all_states], dtype=np.float64)           # [K][3][n]
+            if np.any(bonded != 1.0):
+                eng.set_region_bonded_lambdas(bonded[:, 0], bonded[:, 1], bonded[:, 2])
+        elif any(getattr(s, k, 1.0) != 1.0 for s in all_states for k in ('lambda_bonds', 'lambda_angles', 'lambda_torsions')):
+            raise NotImplementedError('lambda_bonds / lambda_angles / lambda_torsions act on the bonded terms an AlchemicalRegion names '
+                                      '(alchemical_bonds=..., alchemical_angles=..., alchemical_torsions=...): this System has none')
         self._program_engine_move()
         pressures = [s.pressure for s in all_states]
         if any(p is not None for p in pressures):

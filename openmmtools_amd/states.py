@@ -213,6 +213,9 @@ class ThermodynamicState:
     def region_lambdas(self, names):
         return [1.0] * len(names), [1.0] * len(names)
 
+    def region_bonded_lambdas(self, names):
+        return [1.0] * len(names), [1.0] * len(names), [1.0] * len(names)
+
     def __setstate__(self, state):
         """States pickled before ``pressure`` / ``temperature`` became properties (storage format 'openmmtools_amd-records-1'
         of earlier revisions) carry the plain attribute names: map them onto the backing fields so that old stores resume."""
@@ -268,32 +271,31 @@ class AlchemicalState:
     ``lambda_sterics_<suffix>`` / ``lambda_electrostatics_<suffix>``, the names the factory gives the region's global parameters
     (alchemy.py:1360-1377)."""
 
-    _PARAMETERS = ('lambda_sterics', 'lambda_electrostatics')
+    _PARAMETERS = ('lambda_sterics', 'lambda_electrostatics', 'lambda_bonds', 'lambda_angles', 'lambda_torsions')
 
     def __init__(self, lambda_sterics=1.0, lambda_electrostatics=1.0, lambda_bonds=1.0, lambda_angles=1.0, lambda_torsions=1.0,
                  parameters_name_suffix=None, **kwargs):
         object.__setattr__(self, 'parameters_name_suffix', parameters_name_suffix)
+        values = dict(lambda_sterics=lambda_sterics, lambda_electrostatics=lambda_electrostatics, lambda_bonds=lambda_bonds,
+                      lambda_angles=lambda_angles, lambda_torsions=lambda_torsions)
         for key, value in kwargs.items():                       # lambda_sterics_<suffix>=... as the reference's constructor takes them
             base = self._base_name(key)
-            if base == 'lambda_sterics':
-                lambda_sterics = value
-            elif base == 'lambda_electrostatics':
-                lambda_electrostatics = value
-            elif base in ('lambda_bonds', 'lambda_angles', 'lambda_torsions'):
-                if value is not None and float(value) != 1.0:
-                    raise NotImplementedError('%s != 1: alchemically modified bonded terms are not built' % base)
-            else:
+            if base not in self._PARAMETERS:
                 raise AlchemicalStateError('Unknown parameters %r' % key)                    # states.py:3170-3172
-        self.lambda_sterics = float(lambda_sterics)
-        self.lambda_electrostatics = float(lambda_electrostatics)
-        # alchemy.py:196-199: the factory here does not soften bonded terms (alchemical_bonds / angles / torsions), so these
-        # three parameters exist for call compatibility and must stay at the interacting value
-        for name, value in (('lambda_bonds', lambda_bonds), ('lambda_angles', lambda_angles), ('lambda_torsions', lambda_torsions)):
-            if value is not None and float(value) != 1.0:
-                raise NotImplementedError('%s != 1: alchemically modified bonded terms are not built' % name)
+            values[base] = value
+        # lambda_bonds / angles / torsions act on the bonded terms a region names (AlchemicalRegion.alchemical_bonds ..., alchemy.py:196-199);
+        # None = "the System does not define it" (alchemy.py:94-99) is the interacting value here
+        for name, value in values.items():
+            setattr(self, name, 1.0 if value is None else float(value))
+        # the bonded parameters this state was GIVEN (the reference keeps the others at None = "not defined", alchemy.py:94-99, and
+        # set_alchemical_parameters leaves those alone, :247-262)
+        given = {self._base_name(k) for k in kwargs}
+        object.__setattr__(self, '_defined', {k for k in ('lambda_bonds', 'lambda_angles', 'lambda_torsions')
+                                              if k in given or (values[k] is not None and float(values[k]) != 1.0)})
 
-    lambda_bonds = lambda_angles = lambda_torsions = 1.0
     parameters_name_suffix = None
+    lambda_bonds = lambda_angles = lambda_torsions = 1.0          # (states pickled before these were carried)
+    _defined = frozenset()
 
     def _base_name(self, name):
         sfx = self.parameters_name_suffix
@@ -318,6 +320,8 @@ class AlchemicalState:
             raise ValueError('{} must be between 0 and 1.'.format('lambda_sterics'))     # alchemy.py:216-218: the first parameter's validator speaks
         self.lambda_sterics = v
         self.lambda_electrostatics = v
+        for k in sorted(self.__dict__.get('_defined', ())):
+            setattr(self, k, v)
 
     @staticmethod
     def _has_region(system, suffix):
@@ -334,7 +338,13 @@ class AlchemicalState:
         if not cls._has_region(system, parameters_name_suffix):
             raise AlchemicalStateError('system has no alchemical region' + ('' if parameters_name_suffix is None else ' named %r' % parameters_name_suffix))
         stored = (getattr(system, 'alchemical_parameters', None) or {}).get(parameters_name_suffix, {})
-        return cls(*args, parameters_name_suffix=parameters_name_suffix, **dict({k: stored.get(k, 1.0) for k in cls._PARAMETERS}, **kwargs))
+        state = cls(*args, parameters_name_suffix=parameters_name_suffix, **dict({k: stored.get(k, 1.0) for k in cls._PARAMETERS}, **kwargs))
+        # lambda_bonds / angles / torsions are defined where the region names softened terms (alchemy.py:1170-1197, 1252-1275, 1331-1354)
+        regions = getattr(system, 'alchemical_regions', None) or [getattr(system, 'alchemical_region', None)]
+        for r in regions:
+            if r is not None and (r.name == parameters_name_suffix or len(regions) == 1):
+                state._defined.update('lambda_' + k for k in ('bonds', 'angles', 'torsions') if getattr(r, 'alchemical_' + k, None))
+        return state
 
     def apply_to_system(self, system):
         """alchemy.py:354-373: the System's own alchemical parameters (what a state read back with from_system starts from) set to
@@ -404,17 +414,22 @@ class CompoundThermodynamicState(ThermodynamicState):
         else:
             object.__setattr__(self, name, value)
 
+    def _state_of_region(self, nm, n_names):
+        c = next((c for c in self._alchs if c.parameters_name_suffix == nm), None)
+        if c is None and len(self._alchs) == 1 and n_names == 1:
+            c = self._alchs[0]
+        return c
+
     def region_lambdas(self, names):
         """(lambda_sterics, lambda_electrostatics) of the alchemical regions ``names`` at this state: the composable state with that
         suffix (a single unsuffixed state answers for a single region)."""
-        ls, le = [], []
-        for nm in names:
-            c = next((c for c in self._alchs if c.parameters_name_suffix == nm), None)
-            if c is None and len(self._alchs) == 1 and len(names) == 1:
-                c = self._alchs[0]
-            ls.append(1.0 if c is None else c.lambda_sterics)
-            le.append(1.0 if c is None else c.lambda_electrostatics)
-        return ls, le
+        cs = [self._state_of_region(nm, len(names)) for nm in names]
+        return [1.0 if c is None else c.lambda_sterics for c in cs], [1.0 if c is None else c.lambda_electrostatics for c in cs]
+
+    def region_bonded_lambdas(self, names):
+        """(lambda_bonds, lambda_angles, lambda_torsions) of the regions ``names``"""
+        cs = [self._state_of_region(nm, len(names)) for nm in names]
+        return tuple([1.0 if c is None else getattr(c, k) for c in cs] for k in ('lambda_bonds', 'lambda_angles', 'lambda_torsions'))
 
     def __deepcopy__(self, memo):
         new = copy.copy(self)

@@ -501,6 +501,9 @@ def system_to_desc(system, box=None, ewald_split=None, min_edge=None):
         d['alch_atoms'] = np.zeros(0, np.int32)
         d['softcore'] = (0.5, 1.0, 1.0, 6.0)
         d['annihilate_sterics'] = False
+    if getattr(system, 'rf_unshifted_switch_width', None) is not None and d['nb_method'] == 1:
+        # the reaction field as the alchemical factory re-writes it for the WHOLE system (alchemical_rf_treatment='switched'): remd_set_reaction_field
+        d['rf_unshifted_switch_width'] = float(system.rf_unshifted_switch_width)
     if getattr(system, 'alchemical_regions', None) is not None:
         # general regions: this descriptor is the NonbondedForce the factory leaves behind, the custom forces follow through
         # remd_set_alchemical_regions (alchemy.AbsoluteAlchemicalFactory._region_terms)

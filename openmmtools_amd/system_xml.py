@@ -198,7 +198,7 @@ def from_xml(text_or_path):
                 f.addParticle(float(b.get('q')), float(b.get('sig')), float(b.get('eps')))
             for b in _children(e, 'Exceptions', 'Exception'):
                 f.addException(int(b.get('p1')), int(b.get('p2')), float(b.get('q')), float(b.get('sig')), float(b.get('eps')))
-        elif kind in ('CustomNonbondedForce', 'CustomBondForce'):
+        elif kind in ('CustomNonbondedForce', 'CustomBondForce', 'CustomAngleForce', 'CustomTorsionForce'):
             from . import _alchemical_xml
             customs.append(_alchemical_xml.parse_custom(e))        # only as the pieces of an alchemically modified System
             continue

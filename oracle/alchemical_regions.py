@@ -25,6 +25,7 @@ class RegionOracle:
         """cutoff / switch_distance (< 0 or None: no switch): the NonbondedForce's; exclusions: every exception pair of the System
         (the custom nonbonded forces exclude them all, alchemy.py:1944-1947)."""
         t = terms
+        self.terms = terms
         self.g = np.asarray(t['region_of_atom'], dtype=int)
         self.N = len(self.g)
         self.sc = np.asarray(t['softcore'], dtype=np.float64).reshape(-1, 8)
@@ -138,9 +139,36 @@ class RegionOracle:
                 e = e + self._electrostatics(r, sg_t, torch.tensor([qq]), l_e, self.exc_kinds[t][3], 0.0, 0.0, 0.0).sum()      # :1434, 1456-1461
         return e
 
-    def energy_forces(self, x, box, ls, le, forces=True):
+    def bonded_torch(self, x, lb, la, lt):
+        """softened bonded terms: lambda_{bonds, angles, torsions} of the term's region x the reference's harmonic bond / harmonic angle /
+        periodic torsion (alchemy.py:1341 'lambda_bonds*(K/2)*(r-r0)^2', :1261 'lambda_angles*(K/2)*(theta-theta0)^2',
+        :1180 'lambda_torsions*k*(1+cos(periodicity*theta-phase))'); lb / la / lt: per region, None = 1"""
+        t = self.terms
+        e = x.new_zeros(())
+        lam = lambda v, reg: torch.ones(len(reg), dtype=torch.float64) if v is None else torch.tensor(np.asarray(v, dtype=np.float64)[np.asarray(reg, dtype=int) - 1])
+        ba = np.asarray(t.get('bond_atoms', np.zeros((0, 2))), dtype=int).reshape(-1, 2)
+        if len(ba):
+            bp = torch.tensor(np.asarray(t['bond_params'], dtype=np.float64).reshape(-1, 2))
+            r = (x[ba[:, 1]] - x[ba[:, 0]]).norm(dim=1)
+            e = e + (lam(lb, t['bond_region']) * 0.5 * bp[:, 1] * (r - bp[:, 0]) ** 2).sum()
+        aa = np.asarray(t.get('angle_atoms', np.zeros((0, 3))), dtype=int).reshape(-1, 3)
+        if len(aa):
+            ap = torch.tensor(np.asarray(t['angle_params'], dtype=np.float64).reshape(-1, 2))
+            v0, v1 = x[aa[:, 0]] - x[aa[:, 1]], x[aa[:, 2]] - x[aa[:, 1]]
+            th = torch.acos(torch.clamp((v0 * v1).sum(1) / (v0.norm(dim=1) * v1.norm(dim=1)), -1.0, 1.0))
+            e = e + (lam(la, t['angle_region']) * 0.5 * ap[:, 1] * (th - ap[:, 0]) ** 2).sum()
+        ta = np.asarray(t.get('torsion_atoms', np.zeros((0, 4))), dtype=int).reshape(-1, 4)
+        if len(ta):
+            tp = torch.tensor(np.asarray(t['torsion_params'], dtype=np.float64).reshape(-1, 3))
+            b1, b2, b3 = x[ta[:, 1]] - x[ta[:, 0]], x[ta[:, 2]] - x[ta[:, 1]], x[ta[:, 3]] - x[ta[:, 2]]
+            m, n = torch.linalg.cross(b1, b2), torch.linalg.cross(b2, b3)
+            phi = torch.atan2(b2.norm(dim=1) * (b1 * n).sum(1), (m * n).sum(1))
+            e = e + (lam(lt, t['torsion_region']) * tp[:, 2] * (1.0 + torch.cos(tp[:, 0] * phi - tp[:, 1]))).sum()
+        return e
+
+    def energy_forces(self, x, box, ls, le, forces=True, bonded=(None, None, None)):
         xt = torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=forces)
-        e = self.energy_torch(xt, box, ls, le)
+        e = self.energy_torch(xt, box, ls, le) + self.bonded_torch(xt, *bonded)
         if not forces or not e.requires_grad:
             return float(e.detach()), np.zeros((self.N, 3))
         (g,) = torch.autograd.grad(e, xt)
@@ -198,18 +226,19 @@ class _Total:
             self.base.q_scale = torch.tensor(lam[self.g])
             self.base.exc_scale = torch.tensor(lam[self.exc_region])
 
-    def energy_forces(self, x, box, ls, le, forces=True):
+    def energy_forces(self, x, box, ls, le, forces=True, bonded=(None, None, None)):
         self._set(le)
         e0, f0 = self.base.energy_forces(x, box, forces=forces)
-        e1, f1 = self.reg.energy_forces(x, box, ls, le, forces=forces)
+        e1, f1 = self.reg.energy_forces(x, box, ls, le, forces=forces, bonded=bonded)
         return e0 + e1, (f0 + f1 if forces else None)
 
 
-def total_state_energies(desc, x, box, LS, LE):
-    """Potential of an alchemical System in the general-regions mode at every state"""
+def total_state_energies(desc, x, box, LS, LE, BONDED=None):
+    """Potential of an alchemical System in the general-regions mode at every state; BONDED: [K][3][n] lambda_bonds / angles / torsions"""
     t = _Total(desc)
-    return np.array([t.energy_forces(x, box, ls, le, forces=False)[0] for ls, le in zip(LS, LE)])
+    return np.array([t.energy_forces(x, box, ls, le, forces=False, bonded=(None, None, None) if BONDED is None else tuple(BONDED[k]))[0]
+                     for k, (ls, le) in enumerate(zip(LS, LE))])
 
 
-def total_energy_forces(desc, x, box, ls, le):
-    return _Total(desc).energy_forces(x, box, ls, le)
+def total_energy_forces(desc, x, box, ls, le, bonded=(None, None, None)):
+    return _Total(desc).energy_forces(x, box, ls, le, bonded=bonded)

@@ -183,6 +183,7 @@ struct System {
     std::vector<double> bond_params, angle_params, torsion_params, exc_params;
     int method = 0; double rc = 0, rs = -1, rf_eps = 78.3, alpha = 0; int grid[3] = {0, 0, 0}; int use_disp = 0;
     bool annihilate = false;  // AlchemicalRegion.annihilate_sterics (remd_set_alchemical_options)
+    bool rf_unshifted = false; double rf_switch_width = 0;   // remd_set_reaction_field: c_rf = 0, pair term switched (forces.py:1110-1150)
     double rcc = 0;       // range of the Ewald direct-space sum (remd_set_coulomb_cutoff); = rc unless the host split the sum elsewhere
     std::vector<double> q, sig, eps;
     std::vector<char> alch;
@@ -207,6 +208,9 @@ struct System {
         bool elec = false; double alpha = 0, krf = 0, crf = 0, rs_e = -1;
         // exact PME treatment (remd_alch_regions_desc.exact_pme): the alchemical atoms' charges (restored in System::q) and the charge
         // products of the exceptions that touch a region count times the region's lambda_electrostatics inside the whole Ewald sum
+        // softened bonded terms (lambda_bonds / lambda_angles / lambda_torsions of their region): atoms, parameters, region (1-based)
+        std::vector<int> bond_atoms, angle_atoms, torsion_atoms, bond_region, angle_region, torsion_region;
+        std::vector<double> bond_params, angle_params, torsion_params, bl;      // bl: [K][3][n]
         bool exact = false;
         std::vector<int> exc_region;              // per exception of the System: region whose lambda scales its charge product (0: none)
     } reg;
@@ -554,6 +558,57 @@ double region_energy(const System& s, const Replica& r, int state, double* f)
         if (g.elec && qq != 0.0) { double e, de; region_elec(sc, l_e, 0.0, 0.0, 0.0, sg, qq, rr, e, de); E += e; dedr += de; }
         if (f && dedr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * i + k] += dedr / rr * d[k]; f[3 * j + k] -= dedr / rr * d[k]; }
     }
+    // softened bonded terms: lambda x harmonic bond / harmonic angle / periodic torsion (alchemy.py:1180, 1261, 1341); central differences
+    // of the energy would do for a checker, but the analytic forces are short
+    const double* bl = g.bl.empty() ? nullptr : &g.bl[(size_t)state * 3 * g.n];
+    auto lam_of = [&](int kind, int region) { return bl ? bl[(size_t)kind * g.n + region - 1] : 1.0; };
+    for (size_t b = 0; b < g.bond_region.size(); ++b) {
+        const int i = g.bond_atoms[2 * b], j = g.bond_atoms[2 * b + 1];
+        const double r0 = g.bond_params[2 * b], k = g.bond_params[2 * b + 1], lam = lam_of(0, g.bond_region[b]);
+        double d[3] = {x[3 * j] - x[3 * i], x[3 * j + 1] - x[3 * i + 1], x[3 * j + 2] - x[3 * i + 2]};
+        const double rr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        E += lam * 0.5 * k * (rr - r0) * (rr - r0);
+        if (f) { const double gg = lam * k * (rr - r0) / rr; for (int c = 0; c < 3; ++c) { f[3 * i + c] += gg * d[c]; f[3 * j + c] -= gg * d[c]; } }
+    }
+    for (size_t a = 0; a < g.angle_region.size(); ++a) {
+        const int i = g.angle_atoms[3 * a], j = g.angle_atoms[3 * a + 1], k = g.angle_atoms[3 * a + 2];
+        const double th0 = g.angle_params[2 * a], ka = g.angle_params[2 * a + 1], lam = lam_of(1, g.angle_region[a]);
+        double v0[3], v1[3];
+        for (int c = 0; c < 3; ++c) { v0[c] = x[3 * i + c] - x[3 * j + c]; v1[c] = x[3 * k + c] - x[3 * j + c]; }
+        const double n0 = sqrt(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]), n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
+        double cs = (v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2]) / (n0 * n1);
+        cs = std::max(-1.0, std::min(1.0, cs));
+        const double th = acos(cs);
+        E += lam * 0.5 * ka * (th - th0) * (th - th0);
+        if (f) {
+            const double sn = sqrt(std::max(1e-30, 1.0 - cs * cs)), dEdth = lam * ka * (th - th0);
+            for (int c = 0; c < 3; ++c) {
+                const double gi = -(v1[c] / n1 - cs * v0[c] / n0) / (n0 * sn), gk = -(v0[c] / n0 - cs * v1[c] / n1) / (n1 * sn);
+                f[3 * i + c] -= dEdth * gi; f[3 * k + c] -= dEdth * gk; f[3 * j + c] += dEdth * (gi + gk);
+            }
+        }
+    }
+    for (size_t t = 0; t < g.torsion_region.size(); ++t) {
+        const int a0 = g.torsion_atoms[4 * t], a1 = g.torsion_atoms[4 * t + 1], a2 = g.torsion_atoms[4 * t + 2], a3 = g.torsion_atoms[4 * t + 3];
+        const double per = g.torsion_params[3 * t], phase = g.torsion_params[3 * t + 1], kt = g.torsion_params[3 * t + 2], lam = lam_of(2, g.torsion_region[t]);
+        double b1[3], b2[3], b3[3], m[3], nn[3];
+        for (int c = 0; c < 3; ++c) { b1[c] = x[3 * a1 + c] - x[3 * a0 + c]; b2[c] = x[3 * a2 + c] - x[3 * a1 + c]; b3[c] = x[3 * a3 + c] - x[3 * a2 + c]; }
+        m[0] = b1[1] * b2[2] - b1[2] * b2[1]; m[1] = b1[2] * b2[0] - b1[0] * b2[2]; m[2] = b1[0] * b2[1] - b1[1] * b2[0];
+        nn[0] = b2[1] * b3[2] - b2[2] * b3[1]; nn[1] = b2[2] * b3[0] - b2[0] * b3[2]; nn[2] = b2[0] * b3[1] - b2[1] * b3[0];
+        const double b2n = sqrt(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]);
+        const double phi = atan2(b2n * (b1[0] * nn[0] + b1[1] * nn[1] + b1[2] * nn[2]), m[0] * nn[0] + m[1] * nn[1] + m[2] * nn[2]);
+        E += lam * kt * (1.0 + cos(per * phi - phase));
+        if (f) {
+            const double dEdphi = -lam * kt * per * sin(per * phi - phase);
+            const double m2 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2], n2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
+            const double b1b2 = b1[0] * b2[0] + b1[1] * b2[1] + b1[2] * b2[2], b3b2 = b3[0] * b2[0] + b3[1] * b2[1] + b3[2] * b2[2];
+            for (int c = 0; c < 3; ++c) {
+                const double g0 = -b2n / m2 * m[c], g3 = b2n / n2 * nn[c];
+                const double g1 = (-1.0 - b1b2 / (b2n * b2n)) * g0 + (b3b2 / (b2n * b2n)) * g3, g2 = -(g0 + g1 + g3);
+                f[3 * a0 + c] -= dEdphi * g0; f[3 * a1 + c] -= dEdphi * g1; f[3 * a2 + c] -= dEdphi * g2; f[3 * a3 + c] -= dEdphi * g3;
+            }
+        }
+    }
     return E;
 }
 
@@ -654,7 +709,8 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
         ensure_list(s, r);
         if (g_time) { const double t1 = now_ms(); g_timers.list += t1 - tt0; tt0 = t1; }
         const double rc2 = s.rc * s.rc, rcc2 = std::max(s.rc, s.rcc) * std::max(s.rc, s.rcc);
-        const double krf = (s.rf_eps - 1.0) / (2.0 * s.rf_eps + 1.0) / (s.rc * s.rc * s.rc), crf = 3.0 * s.rf_eps / (2.0 * s.rf_eps + 1.0) / s.rc;
+        const double krf = (s.rf_eps - 1.0) / (2.0 * s.rf_eps + 1.0) / (s.rc * s.rc * s.rc), crf = s.rf_unshifted ? 0.0 : 3.0 * s.rf_eps / (2.0 * s.rf_eps + 1.0) / s.rc;
+        const double rs_c = (s.rf_unshifted && s.rf_switch_width > 0 && s.rf_switch_width < s.rc) ? s.rc - s.rf_switch_width : -1.0;
         const double two_a_sqrtpi = 2.0 * s.alpha / sqrt(PI);
         const bool sw = s.rs >= 0 && s.rs < s.rc;
         const double one_m_l = 1.0 - lam_s, la = pow(lam_s, s.sc_a), lb = s.sc_alpha * pow(one_m_l, s.sc_b);
@@ -701,8 +757,9 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
                         e_el += qq * ec / rr;
                         fr += qq * (ec / rr + two_a_sqrtpi * exp(-ar * ar)) / r2;
                     } else {
-                        e_el += qq * (1.0 / rr + krf * r2 - crf);
-                        fr += qq * (1.0 / (rr * r2) - 2.0 * krf);
+                        double e = qq * (1.0 / rr + krf * r2 - crf), dedr = qq * (2.0 * krf * rr - 1.0 / r2);
+                        region_switch(rs_c, s.rc, rr, e, dedr);
+                        e_el += e; fr -= dedr / rr;
                     }
                 }
             }
@@ -896,6 +953,7 @@ struct remd_ctx {
     double dt = 0, gamma = 0; int n_steps = 0, reassign = 0, n_restart_attempts = 0;
     double coulomb_cutoff = 0;
     int annihilate_sterics = 0;
+    int rf_unshifted = 0; double rf_switch_width = 0;
     std::vector<uint32_t> noise_ids;   // remd_set_replica_ids: keys of the local replicas' random streams (empty: r_begin + r)
     int measure_heat = 0, measure_shadow = 0;
     int R = 0, R_global = 0, r_begin = 0;
@@ -1331,6 +1389,7 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
         s.rcc = h->coulomb_cutoff;
     }
     s.annihilate = h->annihilate_sterics != 0;
+    s.rf_unshifted = h->rf_unshifted != 0; s.rf_switch_width = h->rf_switch_width;
     s.rf_eps = d->rf_dielectric; s.alpha = d->ewald_alpha; s.use_disp = d->use_dispersion_correction;
     for (int k = 0; k < 3; ++k) s.grid[k] = d->pme_grid[k];
     s.q.assign(N, 0.0); s.sig.assign(N, 1.0); s.eps.assign(N, 0.0); s.alch.assign(N, 0);
@@ -1610,6 +1669,23 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         // (an exception between two regions: the first region's (environment, region) bond force, alchemy.py:1972-1976, 1992-2006)
         g.exc_cls.push_back((gi > 0 && gj > 0 && gi != gj) ? g.cls_of[std::min(gi, gj)] : g.cls_of[(size_t)gi * (n + 1) + gj]);
     }
+    {
+        auto bad = [&](int cnt, int width, const int32_t* atoms, const int32_t* reg) {
+            for (int k = 0; k < cnt; ++k) { if (reg[k] < 1 || reg[k] > n) return true; for (int q = 0; q < width; ++q) if (atoms[width * k + q] < 0 || atoms[width * k + q] >= N) return true; }
+            return false;
+        };
+        if (d->n_bonds < 0 || d->n_angles < 0 || d->n_torsions < 0 || (d->n_bonds > 0 && (!d->bond_atoms || !d->bond_params || !d->bond_region)) ||
+            (d->n_angles > 0 && (!d->angle_atoms || !d->angle_params || !d->angle_region)) || (d->n_torsions > 0 && (!d->torsion_atoms || !d->torsion_params || !d->torsion_region)))
+            return fail(h, -1, "alchemical regions: bad softened bonded terms");
+        if (bad(d->n_bonds, 2, d->bond_atoms, d->bond_region) || bad(d->n_angles, 3, d->angle_atoms, d->angle_region) || bad(d->n_torsions, 4, d->torsion_atoms, d->torsion_region))
+            return fail(h, -1, "alchemical regions: softened bonded term with a bad atom or region");
+        g.bond_atoms.assign(d->bond_atoms, d->bond_atoms + 2 * (size_t)d->n_bonds); g.bond_params.assign(d->bond_params, d->bond_params + 2 * (size_t)d->n_bonds);
+        g.bond_region.assign(d->bond_region, d->bond_region + d->n_bonds);
+        g.angle_atoms.assign(d->angle_atoms, d->angle_atoms + 3 * (size_t)d->n_angles); g.angle_params.assign(d->angle_params, d->angle_params + 2 * (size_t)d->n_angles);
+        g.angle_region.assign(d->angle_region, d->angle_region + d->n_angles);
+        g.torsion_atoms.assign(d->torsion_atoms, d->torsion_atoms + 4 * (size_t)d->n_torsions); g.torsion_params.assign(d->torsion_params, d->torsion_params + 3 * (size_t)d->n_torsions);
+        g.torsion_region.assign(d->torsion_region, d->torsion_region + d->n_torsions);
+    }
     g.alpha = d->elec_alpha; g.krf = d->elec_krf; g.crf = d->elec_crf;
     g.rs_e = (g.elec && d->elec_switch_distance >= 0 && d->elec_switch_distance < s.rc) ? d->elec_switch_distance : -1.0;
     s.reg = std::move(g);
@@ -1625,7 +1701,32 @@ int remd_set_region_lambdas(remd_handle h, int K, int n_regions, const double* l
     for (size_t k = 0; k < (size_t)K * g.n; ++k)
         if (!(ls[k] >= 0.0 && ls[k] <= 1.0 && le[k] >= 0.0 && le[k] <= 1.0)) return fail(h, -1, "remd_set_region_lambdas: lambdas must be in [0, 1]");
     g.ls.assign(ls, ls + (size_t)K * g.n); g.le.assign(le, le + (size_t)K * g.n); g.K = K;
+    g.bl.clear();                                             // until remd_set_region_bonded_lambdas says otherwise: 1
     for (auto& r : h->reps) r.f_valid = false;
+    return 0;
+}
+
+int remd_set_region_bonded_lambdas(remd_handle h, int K, int n_regions, const double* lb, const double* la, const double* lt)
+{
+    if (!h) return fail(h, -1, "remd_set_region_bonded_lambdas: NULL handle");
+    System::Regions& g = h->sys.reg;
+    if (g.n == 0) return fail(h, -2, "remd_set_region_bonded_lambdas: no alchemical regions on this handle");
+    if (K != h->K || K != g.K || n_regions != g.n) return fail(h, -1, "remd_set_region_bonded_lambdas: call remd_set_region_lambdas first (same K, n_regions)");
+    const double* src[3] = {lb, la, lt};
+    g.bl.assign(3 * (size_t)K * g.n, 1.0);
+    for (int q = 0; q < 3; ++q) for (int k = 0; k < K; ++k) for (int r = 0; r < g.n; ++r) {
+        const double v = src[q] ? src[q][(size_t)k * g.n + r] : 1.0;
+        if (!(v >= 0.0 && v <= 1.0)) return fail(h, -1, "remd_set_region_bonded_lambdas: lambdas must be in [0, 1]");
+        g.bl[((size_t)k * 3 + q) * g.n + r] = v;
+    }
+    for (auto& r : h->reps) r.f_valid = false;
+    return 0;
+}
+
+int remd_set_reaction_field(remd_handle h, int unshifted, double switch_width_nm)
+{
+    if (!h || (unshifted != 0 && unshifted != 1) || !(switch_width_nm >= 0.0)) return fail(h, -1, "remd_set_reaction_field: bad arguments");
+    h->rf_unshifted = unshifted; h->rf_switch_width = switch_width_nm;      // consumed by the next remd_set_system (include/remd_hip.h)
     return 0;
 }
 

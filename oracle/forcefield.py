@@ -207,7 +207,14 @@ class ForceFieldOracle(OracleSystem):
                 eps_s = self.d['rf_dielectric']
                 krf = (eps_s - 1.0) / (2.0 * eps_s + 1.0) / self.rc ** 3
                 crf = 3.0 * eps_s / (2.0 * eps_s + 1.0) / self.rc
-                e = e + (qq * (1.0 / r + krf * r * r - crf)).sum()
+                w = self.d.get('rf_unshifted_switch_width')
+                if w is None:
+                    e = e + (qq * (1.0 / r + krf * r * r - crf)).sum()
+                else:
+                    # the reference's UnshiftedReactionFieldForce (forces.py:1110-1150; what its alchemical factory turns the whole system's
+                    # reaction field into, alchemy.py:744-749): c_rf = 0, switched from cutoff - switch_width
+                    xs = torch.clamp((r - (self.rc - w)) / w, 0.0, 1.0) if w > 0 else torch.zeros_like(r)
+                    e = e + (qq * (1.0 / r + krf * r * r) * (1.0 - 10.0 * xs ** 3 + 15.0 * xs ** 4 - 6.0 * xs ** 5)).sum()
         return e
 
     def _exceptions(self, x, box_t, lam_e, lam_s=1.0, include_na=True, only_na=False):

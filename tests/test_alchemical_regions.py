@@ -139,8 +139,11 @@ def test_the_factory_chooses_the_path_and_refuses_what_the_reference_refuses():
     reg = RegionOracle(d['alch_regions'], d['cutoff'], d['switch_distance'], d['exception_atoms'])
     straddling = [k for k, (i, j) in enumerate(reg.exc_atoms) if (i < 6) != (j < 6)]
     assert len(straddling) > 5 and all(reg.exc_kinds[k] == (0, 1, 1, 1) for k in straddling)
-    with pytest.raises(NotImplementedError, match='replaces the environment'):
-        alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(_charged_lj_fluid(), alchemy.AlchemicalRegion(alchemical_atoms=range(4)))
+    # the default reaction-field treatment re-writes the WHOLE system's reaction field (alchemy.py:744-749): carried to the engine
+    rfs = alchemy.AbsoluteAlchemicalFactory(switch_width=0.12).create_alchemical_system(_charged_lj_fluid(), alchemy.AlchemicalRegion(alchemical_atoms=range(4)))
+    assert rfs.alchemical_regions is not None and system_to_desc(rfs)['rf_unshifted_switch_width'] == 0.12
+    assert 'rf_unshifted_switch_width' not in system_to_desc(alchemy.AbsoluteAlchemicalFactory(alchemical_rf_treatment='shifted').create_alchemical_system(
+        _charged_lj_fluid(), alchemy.AlchemicalRegion(alchemical_atoms=range(4))))
     # several charged regions under the exact PME treatment (the default): the regions' charges as parameter offsets (alchemy.py:1675-1680)
     ex = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(
         al.system, [alchemy.AlchemicalRegion(alchemical_atoms=range(22), name='a'), alchemy.AlchemicalRegion(alchemical_atoms=range(22, 25), name='b')],
@@ -197,6 +200,15 @@ def _check_engine_against_the_oracle(eng, kw, interactions, rtol, ftol, region_k
     beta = 1.0 / (KB * 300.0)
     eng.set_states(np.full(K, beta), None, None, econst)
     eng.set_region_lambdas(LADDER_S, LADDER_E)
+    terms = desc['alch_regions']
+    BONDED = None
+    if any(len(terms.get(k + '_atoms', ())) for k in ('bond', 'angle', 'torsion')):
+        # softened bonded terms of the dipeptide (alchemy.py:1115-1354): their own ladders
+        assert len(terms['torsion_atoms']) > 10 and len(terms['angle_atoms']) > 10 and len(terms['bond_atoms']) == 3
+        assert len(system_to_desc(al.system)['torsion_atoms']) == len(desc['torsion_atoms']) + len(terms['torsion_atoms'])
+        BONDED = np.ones((K, 3, 2))
+        BONDED[:, 0, 0] = [1.0, 0.9, 0.7, 0.5, 0.2, 0.0]; BONDED[:, 1, 0] = [1.0, 1.0, 0.8, 0.6, 0.3, 0.1]; BONDED[:, 2, 0] = [1.0, 0.5, 0.5, 0.25, 0.0, 0.0]
+        eng.set_region_bonded_lambdas(BONDED[:, 0], BONDED[:, 1], BONDED[:, 2])
     eng.set_integrator('V R R O R R V', 0.002, 1.0, 5, True, 1e-8)
     eng.seed(7)
     labels = np.array([0, 3, 4])
@@ -207,11 +219,11 @@ def _check_engine_against_the_oracle(eng, kw, interactions, rtol, ftol, region_k
     xd = eng.get_replicas()[0]
     f = eng.get_forces()
     for r, k in enumerate(labels):
-        ref = total_state_energies(desc, xd[r], box[r], LADDER_S, LADDER_E)
+        ref = total_state_energies(desc, xd[r], box[r], LADDER_S, LADDER_E, BONDED)
         assert np.ptp(ref) > 10.0                                     # the ladder matters: tens of kJ/mol between its ends
         assert np.allclose(rows[r], beta * (ref + econst), rtol=rtol), np.abs(rows[r] / (beta * (ref + econst)) - 1).max()
         assert np.isclose(U[r], ref[k], rtol=rtol)
-        f_ref = total_energy_forces(desc, xd[r], box[r], LADDER_S[k], LADDER_E[k])[1]
+        f_ref = total_energy_forces(desc, xd[r], box[r], LADDER_S[k], LADDER_E[k], (None, None, None) if BONDED is None else tuple(BONDED[k]))[1]
         assert np.abs(f[r] - f_ref).max() < ftol * np.abs(f_ref).max(), np.abs(f[r] - f_ref).max() / np.abs(f_ref).max()
     return eng
 
@@ -223,6 +235,9 @@ CASES = [
     # regions that do not interact excluded from each other / regions that do see each other's scaled charges (alchemy.py:1663-1681)
     (dict(), frozenset(), dict(softcore_c=8)),
     (dict(), frozenset({(0, 1)}), dict()),
+    # softened bonded terms: every angle and proper torsion of the dipeptide and three of its bonds under lambda_angles_pep / lambda_torsions_pep /
+    # lambda_bonds_pep (alchemy.py:1115-1354)
+    (dict(), frozenset(), dict(alchemical_torsions=True, alchemical_angles=True, alchemical_bonds=[0, 2, 5])),
 ]
 
 
@@ -256,7 +271,8 @@ def _same_description(a, b):
         if k == 'alch_regions':
             assert sorted(da[k]) == sorted(db[k])
             for q in da[k]:
-                assert np.array_equal(np.asarray(da[k][q]), np.asarray(db[k][q])), q
+                if not q.endswith('_index'):                   # (where a softened term sat in the reference's force)
+                    assert np.array_equal(np.asarray(da[k][q]), np.asarray(db[k][q])), q
         else:
             assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
 
@@ -281,14 +297,27 @@ def test_general_regions_are_written_as_the_factorys_force_set_and_read_back(kw,
     back, barostat = system_xml.from_xml(xml)
     assert barostat is None and [r.name for r in back.alchemical_regions] == ['pep', 'wat']
     assert back.alchemical_regions_interactions == sorted(interactions) and back.alchemical_factory_options == system.alchemical_factory_options
+    softened = ('alchemical_bonds', 'alchemical_angles', 'alchemical_torsions')
     for r0, r1 in zip(system.alchemical_regions, back.alchemical_regions):
-        assert r0.__dict__ == r1.__dict__
+        # (softened bonded terms come back as indices into the re-assembled plain forces: the reference's own indices are not in the document)
+        assert {k: v for k, v in r0.__dict__.items() if k not in softened} == {k: v for k, v in r1.__dict__.items() if k not in softened}
+        assert all(bool(getattr(r0, k)) == bool(getattr(r1, k)) for k in softened)
     _same_description(system, back)
     # the document: per region 4 electrostatics forces (group of lambda_electrostatics_<name>) and 4 sterics forces, sorted by lambda
     # name (alchemy.py:1075-1083); a pair of interacting regions adds a nonbonded + a bond force to the FIRST region's lists (:2027-2032)
     import xml.etree.ElementTree as ET
     forces = ET.fromstring(xml).find('Forces').findall('Force')
     custom = [f for f in forces if f.get('type').startswith('Custom')]
+    if region_kw.get('alchemical_torsions'):
+        # softened bonded terms: one Custom{Angle,Bond,Torsion}Force of the region, energy lambda x the reference term, its lambda the only
+        # global parameter; lambda names sorted: angles < bonds < electrostatics < sterics < torsions (alchemy.py:1075-1083, 1170-1197, 1252-1275, 1331-1354)
+        assert [f.get('type') for f in custom[:2]] == ['CustomAngleForce', 'CustomBondForce'] and custom[-1].get('type') == 'CustomTorsionForce'
+        assert custom[0].get('energy') == 'lambda_angles_pep*(K/2)*(theta-theta0)^2;' and custom[1].get('energy') == 'lambda_bonds_pep*(K/2)*(r-r0)^2;'
+        assert custom[-1].get('energy') == 'lambda_torsions_pep*k*(1+cos(periodicity*theta-phase))'
+        assert [g.get('name') for g in custom[-1].find('GlobalParameters')] == ['lambda_torsions_pep'] and len(custom[1].find('Bonds')) == 3
+        groups = [int(f.get('forceGroup')) for f in custom]
+        assert groups == sorted(groups)
+        custom = custom[2:-1]
     extra = 2 if interactions else 0
     if kw.get('alchemical_pme_treatment', 'exact') == 'exact':
         # no electrostatic custom forces: per region a global parameter + particle / exception offsets of the NonbondedForce, which sits in the
@@ -505,3 +534,53 @@ def test_general_regions_under_the_monte_carlo_barostat(hip_engine_factory, kw):
         V = float(np.prod(boxes[r]))
         ref = total_state_energies(desc, xd[r], boxes[r], LADDER_S, LADDER_E) + econst * V0 / V + p * V
         assert np.allclose(rows[r], beta * ref, rtol=1e-5), np.abs(rows[r] / (beta * ref) - 1).max()
+
+
+# ---- the factory's default reaction-field treatment: the whole system on an unshifted, switched reaction field -----------------------------
+def _check_switched_reaction_field(eng, rtol, ftol):
+    """alchemical_rf_treatment='switched' (the default) on a charged fluid: the alchemical atoms' soft-core reaction field with c_rf = 0 and a
+    switch (alchemy.py:1473-1508, 1818-1824) AND the environment's pair term re-written the same way (alchemy.py:744-749 ->
+    forcefactories.py:76-84 -> forces.UnshiftedReactionFieldForce, forces.py:1110-1150: remd_set_reaction_field)"""
+    lj = _charged_lj_fluid()
+    plain = ts.LennardJonesFluid(nparticles=216, reduced_density=0.4)
+    system = alchemy.AbsoluteAlchemicalFactory(switch_width=0.15).create_alchemical_system(
+        lj, alchemy.AlchemicalRegion(alchemical_atoms=range(6), name='lig', softcore_beta=0.3))
+    desc = system_to_desc(system)
+    assert desc['rf_unshifted_switch_width'] == 0.15 and desc['alch_regions']['elec_crf'] == 0.0 and np.isclose(desc['alch_regions']['elec_switch_distance'], desc['cutoff'] - 0.15)
+    nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
+    box0 = np.diag(system.getDefaultPeriodicBoxVectors())
+    LS = np.array([[1.0], [0.7], [0.2], [0.0]]); LE = np.array([[1.0], [0.4], [0.0], [0.0]])
+    econst = alchemy.alchemical_long_range_constants(system, nb, LS, float(np.prod(box0)))
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 120.0)
+    eng.set_states(np.full(4, beta), None, None, econst)
+    eng.set_region_lambdas(LS, LE)
+    eng.set_integrator('V R O R V', 0.001, 1.0, 5, True, 1e-8)
+    eng.seed(3)
+    labels = np.array([0, 2])
+    x = np.stack([plain.positions + 0.002 * (r + 1) * np.random.default_rng(r).normal(size=plain.positions.shape) for r in range(2)])
+    box = np.tile(box0, (2, 1))
+    eng.set_replicas(2, 0, x, None, box, labels)
+    rows, U = eng.compute_energies(want_potential=True)
+    xd = eng.get_replicas()[0]
+    f = eng.get_forces()
+    shifted = dict(desc); shifted.pop('rf_unshifted_switch_width')
+    for r, k in enumerate(labels):
+        ref = total_state_energies(desc, xd[r], box[r], LS, LE)
+        assert np.allclose(rows[r], beta * (ref + econst), rtol=rtol, atol=rtol * np.abs(beta * ref).max()), np.abs(rows[r] - beta * (ref + econst)).max()
+        assert abs(total_state_energies(shifted, xd[r], box[r], LS, LE)[0] - ref[0]) > 1.0          # OpenMM's shifted field is another Hamiltonian
+        f_ref = total_energy_forces(desc, xd[r], box[r], LS[k], LE[k])[1]
+        assert np.abs(f[r] - f_ref).max() < ftol * np.abs(f_ref).max()
+    return eng
+
+
+def test_switched_reaction_field_of_the_whole_system_on_the_cpu_port():
+    if not os.path.exists(CPU_LIB):
+        oracle.build()
+    _check_switched_reaction_field(HipEngine(lib_path=CPU_LIB), 1e-9, 1e-8).close()
+
+
+@pytest.mark.gpu
+def test_switched_reaction_field_of_the_whole_system_on_the_device(hip_engine_factory):
+    eng = _check_switched_reaction_field(hip_engine_factory(), 2e-5, 2e-4)
+    assert not np.any(eng.propagate(0))

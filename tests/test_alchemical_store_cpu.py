@@ -116,8 +116,12 @@ def test_reaction_field_system_gets_the_electrostatics_forces_and_the_unshifted_
 
 def test_what_the_factory_would_build_differently_is_refused():
     al = testsystems.AlanineDipeptideExplicit(nonbondedMethod='CutoffPeriodic')
-    with pytest.raises(NotImplementedError, match='reaction-field'):
-        system_xml.to_xml(_alchemical(al, range(22)))
+    # (round 6: a charged region under a reaction-field method is written -- the general force set, the environment's charges in the unshifted
+    # reaction-field force, forcefactories.py:76-84 -- and read back)
+    rf = _alchemical(al, range(22))
+    back, _ = system_xml.from_xml(system_xml.to_xml(rf))
+    assert back.alchemical_regions is not None and back.rf_unshifted_switch_width == rf.rf_unshifted_switch_width == 0.1
+    assert back.fingerprint() == rf.fingerprint()
     al = testsystems.AlanineDipeptideExplicit()
     with pytest.raises(ValueError, match='Decoupled electrostatics is not supported with exact treatment'):        # alchemy.py:1617-1623
         system_xml.to_xml(_alchemical(al, range(22), annihilate_electrostatics=False))

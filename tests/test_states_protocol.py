@@ -111,12 +111,26 @@ def test_reduced_potential_at_states_is_the_energy_row_of_one_configuration():
 
 
 def test_alchemical_state_surface():
-    """alchemy.py:86-262: the two parameters the engine scales, the bonded ones pinned at 1, set_alchemical_parameters."""
+    """alchemy.py:86-262: the five parameters; set_alchemical_parameters moves the ones this state DEFINES (the bonded ones only where they
+    were given, alchemy.py:94-99, 247-262); bonded lambdas on a System that names no softened terms are refused when the engine is set up."""
     a = states.AlchemicalState(lambda_sterics=0.5, lambda_electrostatics=0.25, lambda_bonds=1.0)
     assert (a.lambda_sterics, a.lambda_electrostatics, a.lambda_bonds, a.lambda_torsions) == (0.5, 0.25, 1.0, 1.0)
     a.set_alchemical_parameters(0.0)
-    assert a.lambda_sterics == 0.0 and a.lambda_electrostatics == 0.0
-    with pytest.raises(NotImplementedError):
-        states.AlchemicalState(lambda_torsions=0.5)
+    assert a.lambda_sterics == 0.0 and a.lambda_electrostatics == 0.0 and a.lambda_bonds == 1.0 and a.lambda_torsions == 1.0
+    b = states.AlchemicalState(lambda_torsions=0.5)
+    b.set_alchemical_parameters(0.25)
+    assert (b.lambda_sterics, b.lambda_torsions, b.lambda_angles) == (0.25, 0.25, 1.0)
     with pytest.raises(ValueError):
         a.set_alchemical_parameters(1.5)
+    from openmmtools_amd import alchemy, mcmc
+    from openmmtools_amd.multistate import MultiStateSampler
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    from oracle.forcefield import ForceFieldOracle
+    lj = testsystems.LennardJonesFluid(nparticles=64)
+    asys = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj.system, alchemy.AlchemicalRegion(alchemical_atoms=range(4)))
+    th = [states.CompoundThermodynamicState(states.ThermodynamicState(asys, 120.0), [states.AlchemicalState(lambda_torsions=0.5)])]
+    s = MultiStateSampler(mcmc_moves=mcmc.LangevinDynamicsMove(n_steps=1), number_of_iterations=1, engine=OracleEngine(ForceFieldOracle))
+    with pytest.raises(NotImplementedError, match='lambda_bonds / lambda_angles / lambda_torsions'):
+        s.create(th, [states.SamplerState(lj.positions, box_vectors=lj.system.getDefaultPeriodicBoxVectors())], storage=None)
