@@ -285,6 +285,8 @@ typedef struct remd_alch_regions_desc {
     int32_t n_bonds;    const int32_t* bond_atoms;    const double* bond_params;    const int32_t* bond_region;      /* [n][2]; [n][2] = r0, K; [n] 1-based */
     int32_t n_angles;   const int32_t* angle_atoms;   const double* angle_params;   const int32_t* angle_region;     /* [n][3]; [n][2] = theta0, K           */
     int32_t n_torsions; const int32_t* torsion_atoms; const double* torsion_params; const int32_t* torsion_region;   /* [n][4]; [n][3] = n, phase, k         */
+    int32_t consistent_exceptions;       /* AbsoluteAlchemicalFactory(consistent_exceptions=True), alchemy.py:1456-1461: the electrostatics of the
+                                            exceptions use g of the pairs (elec_alpha / elec_krf / elec_crf; no cutoff, no switch) instead of 1 / reff */
 } remd_alch_regions_desc;
 int  remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* desc);
 /* lambda_sterics / lambda_electrostatics of every region at every state: [K][n_regions], K as in remd_set_states (call after it).  The

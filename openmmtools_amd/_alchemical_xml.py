@@ -57,7 +57,7 @@ def sterics_exception_expression(lam='lambda_sterics'):
             'reff_sterics = sigma*((softcore_alpha*(1.0-(%s))^softcore_b + (r/sigma)^softcore_c))^(1/softcore_c);' % (lam, lam))
 
 
-def electrostatics_expressions(nb, lam='lambda_electrostatics', pme_treatment='direct-space', rf_treatment='switched'):
+def electrostatics_expressions(nb, lam='lambda_electrostatics', pme_treatment='direct-space', rf_treatment='switched', consistent_exceptions=False):
     """:1392-1471: (pair expression, exception expression) for NoCutoff, the reaction-field treatments (:1473-1508) and the
     'direct-space' (:1510-1537) / 'coulomb' PME treatments."""
     prefix = 'U_electrostatics;U_electrostatics=((%s)^softcore_d)*ONE_4PI_EPS0*chargeprod' % lam
@@ -79,7 +79,7 @@ def electrostatics_expressions(nb, lam='lambda_electrostatics', pme_treatment='d
         method = '*erfc(alpha_ewald*reff_electrostatics)/reff_electrostatics;alpha_ewald = %s;' % alpha
     else:
         method = coulomb
-    return prefix + method + suffix + _MIX_ELECTROSTATICS, prefix + coulomb + suffix
+    return prefix + method + suffix + _MIX_ELECTROSTATICS, prefix + (method if consistent_exceptions else coulomb) + suffix       # :1456-1461
 
 
 def _emit_custom(forces, kind, group, energy, per_name, per_params, lam_globals, region, **attrs):
@@ -362,7 +362,7 @@ def emit_region_forces(forces, system, emit_plain):
             ster.append(('bond', dict(energy=exc_expr, per_params=('sigma', 'epsilon'), lam_globals=tuple(names_s), region=region, bonds=na_lj)))
             ster.append(('bond', dict(energy=exc_expr + fx, per_params=('sigma', 'epsilon'), lam_globals=() if fx else tuple(names_s), region=region, bonds=aa_lj)))
         if not exact:
-            e_pair, e_exc = electrostatics_expressions(nb, lam_e, opts['alchemical_pme_treatment'], opts['alchemical_rf_treatment'])
+            e_pair, e_exc = electrostatics_expressions(nb, lam_e, opts['alchemical_pme_treatment'], opts['alchemical_rf_treatment'], opts.get('consistent_exceptions', False))
             common = dict(use_switch=switched_e, switch_distance=nb.getCutoffDistance() - opts['switch_width'], lrc=False, region=region, nb=nb,
                           exclusions=exclusions, particles=charges)
             if len(sfx) > 1:
@@ -675,7 +675,7 @@ def rebuild_general_system(system, nb, global_parameters, particle_offsets, exce
         if is_nb(c) and len(c['sfx']) == 2:
             interactions.add(tuple(sorted((order.index(c['sfx'][0]), order.index(c['sfx'][1])))))
     # factory options from an electrostatics pair force
-    opts = dict(alchemical_pme_treatment='exact', alchemical_rf_treatment='switched', switch_width=0.1)
+    opts = dict(alchemical_pme_treatment='exact', alchemical_rf_treatment='switched', switch_width=0.1, consistent_exceptions=False)
     if na_e:
         c = next(iter(na_e.values()))
         e = compact(c['energy'])
@@ -686,6 +686,8 @@ def rebuild_general_system(system, nb, global_parameters, particle_offsets, exce
         else:
             opts['alchemical_pme_treatment'] = 'coulomb'
         opts['switch_width'] = round(nb.getCutoffDistance() - float(c['attrs'].get('switchingDistance', nb.getCutoffDistance() - 0.1)), 12)
+        eb = next((compact(b['energy']) for b in electro if not is_nb(b)), '')
+        opts['consistent_exceptions'] = 'erfc(alpha_ewald*' in eb or 'k_rf*reff_electrostatics^2' in eb
     if rf:
         opts['alchemical_rf_treatment'] = 'switched'
         opts['switch_width'] = round(nb.getCutoffDistance() - float(rf[0]['attrs'].get('switchingDistance', nb.getCutoffDistance() - 0.1)), 12)

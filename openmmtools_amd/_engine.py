@@ -51,6 +51,7 @@ class RemdAlchRegionsDesc(C.Structure):
         ('n_bonds', C.c_int32), ('bond_atoms', c_int32_p), ('bond_params', c_double_p), ('bond_region', c_int32_p),
         ('n_angles', C.c_int32), ('angle_atoms', c_int32_p), ('angle_params', c_double_p), ('angle_region', c_int32_p),
         ('n_torsions', C.c_int32), ('torsion_atoms', c_int32_p), ('torsion_params', c_double_p), ('torsion_region', c_int32_p),
+        ('consistent_exceptions', C.c_int32),
     ]
 
 
@@ -284,6 +285,7 @@ class HipEngine:
             r.elec_alpha, r.elec_krf, r.elec_crf = float(regions['elec_alpha']), float(regions['elec_krf']), float(regions['elec_crf'])
             r.elec_switch_distance = float(regions['elec_switch_distance'])
             r.exact_pme = int(regions.get('exact_pme', 0))
+            r.consistent_exceptions = int(regions.get('consistent_exceptions', 0))
             for kind, width, npar in (('bond', 2, 2), ('angle', 3, 2), ('torsion', 4, 3)):
                 atoms = np.asarray(regions.get(kind + '_atoms', np.zeros((0, width))), dtype=np.int32).reshape(-1, width)
                 setattr(r, 'n_%ss' % kind, len(atoms))

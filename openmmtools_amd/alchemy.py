@@ -130,8 +130,6 @@ class AbsoluteAlchemicalFactory:
             return system
         if nb is None:
             raise ValueError('alchemical regions need a NonbondedForce')
-        if self.consistent_exceptions:
-            raise NotImplementedError('consistent_exceptions=True (alchemy.py:1457-1459)')
         system.alchemical_region = None
         system.alchemical_regions = regions
         # alchemical_regions_interactions, as the reference's loop EXECUTES them (alchemy.py:1693, 1886-1911): the forces of a pair of
@@ -141,11 +139,12 @@ class AbsoluteAlchemicalFactory:
         # of interacting regions (product of the lambdas, remd_alch_regions_desc.interactions) is therefore not used by this factory;
         # the pairs are recorded for the store writer (_alchemical_xml.py), which emits those forces as the reference would.
         system.alchemical_regions_interactions = interactions
-        system.alchemical_factory_options = dict(alchemical_pme_treatment=self.alchemical_pme_treatment,
-                                                 alchemical_rf_treatment=self.alchemical_rf_treatment, switch_width=self.switch_width)
+        system.alchemical_factory_options = dict(alchemical_pme_treatment=self.alchemical_pme_treatment, alchemical_rf_treatment=self.alchemical_rf_treatment,
+                                                 switch_width=self.switch_width, consistent_exceptions=self.consistent_exceptions)
         system.alchemical_region_terms = self._region_terms(nb, regions, charged, exact, interactions)
         if bonded is not None:
             system.alchemical_region_terms.update(bonded)
+        system.alchemical_region_terms['consistent_exceptions'] = int(self.consistent_exceptions)          # alchemy.py:1456-1461
         return system
 
     # ---- softened bonds / angles / torsions (alchemy.py:940-1050 what True means, :1115-1354 the forces) -------------------------

@@ -24,6 +24,7 @@ struct region_consts {
     int elec, n_cls, n_reg1, words, N, Npad, n_alch, n_exc;
     // exact PME treatment: the Ewald split of the handle (erfc to rcc), per region the self term, the net charge, the environment's
     // net charge and the coefficient of the neutralising background (E = coeff Q^2 / V)
+    int consistent_exc;                    // the exceptions' electrostatics with the pairs' g (consistent_exceptions)
     int n_bonds, n_angles, n_torsions;     // alchemically softened bonded terms (lambda_bonds / lambda_angles / lambda_torsions of their region)
     int exact; float alpha_x, two_alpha_sqrtpi_x, rcc2;
     double self_x[4], q_x[4], q_env, plasma;
@@ -172,7 +173,8 @@ __device__ __forceinline__ void region_exception(const region_consts& c, const f
     if (par.z != 0.f) region_sterics(A, B, par.y, par.z, r, inv_r, U, dU);
     if (c.elec && par.x != 0.f) {
         float Ue, dUe;
-        region_electrostatics(A, B, 0.f, 0.f, 0.f, 0.f, par.y, par.x, r, inv_r, Ue, dUe);
+        if (c.consistent_exc) region_electrostatics(A, B, c.alpha_e, c.two_alpha_sqrtpi_e, c.krf, c.crf, par.y, par.x, r, inv_r, Ue, dUe);
+        else region_electrostatics(A, B, 0.f, 0.f, 0.f, 0.f, par.y, par.x, r, inv_r, Ue, dUe);
         U += Ue; dU += dUe;
     }
     if (le4 && par.x != 0.f) {
@@ -518,6 +520,7 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     c.inv_sw = c.rs >= 0.f ? (float)(1.0 / (rcut - rsw)) : 0.f;
     c.elec = (d->electrostatics && !exact) ? 1 : 0;
     c.exact = exact ? 1 : 0;
+    c.consistent_exc = (d->consistent_exceptions && c.elec) ? 1 : 0;
     for (int g = 0; g < 4; ++g) c.self_x[g] = c.q_x[g] = 0.0;
     c.q_env = 0.0; c.plasma = 0.0; c.alpha_x = c.two_alpha_sqrtpi_x = 0.f; c.rcc2 = 0.f;
     std::vector<float4> param_pme;

@@ -136,7 +136,8 @@ class RegionOracle:
             if ep != 0.0:
                 e = e + self._sterics(r, sg_t, torch.tensor([ep]), l_s, self.exc_kinds[t][3]).sum()
             if self.elec and qq != 0.0:
-                e = e + self._electrostatics(r, sg_t, torch.tensor([qq]), l_e, self.exc_kinds[t][3], 0.0, 0.0, 0.0).sum()      # :1434, 1456-1461
+                a_, k_, c_ = (self.alpha, self.krf, self.crf) if self.terms.get('consistent_exceptions', 0) else (0.0, 0.0, 0.0)
+                e = e + self._electrostatics(r, sg_t, torch.tensor([qq]), l_e, self.exc_kinds[t][3], a_, k_, c_).sum()      # :1434, 1456-1461
         return e
 
     def bonded_torch(self, x, lb, la, lt):

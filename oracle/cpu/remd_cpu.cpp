@@ -206,6 +206,7 @@ struct System {
         std::vector<RegionClass> classes;
         std::vector<std::vector<char>> skip;      // per alchemical atom: candidates that are never evaluated
         bool elec = false; double alpha = 0, krf = 0, crf = 0, rs_e = -1;
+        bool consistent_exc = false;              // the exceptions' electrostatics with the pairs' expression (alchemy.py:1456-1461)
         // exact PME treatment (remd_alch_regions_desc.exact_pme): the alchemical atoms' charges (restored in System::q) and the charge
         // products of the exceptions that touch a region count times the region's lambda_electrostatics inside the whole Ewald sum
         // softened bonded terms (lambda_bonds / lambda_angles / lambda_torsions of their region): atoms, parameters, region (1-based)
@@ -555,7 +556,11 @@ double region_energy(const System& s, const Replica& r, int state, double* f)
         const double qq = g.exc_params[3 * e2], sg = g.exc_params[3 * e2 + 1], ep = g.exc_params[3 * e2 + 2];
         double dedr = 0.0;
         if (ep != 0.0) { double e, de; region_sterics(sc, l_s, sg, ep, rr, e, de); E += e; dedr += de; }
-        if (g.elec && qq != 0.0) { double e, de; region_elec(sc, l_e, 0.0, 0.0, 0.0, sg, qq, rr, e, de); E += e; dedr += de; }
+        if (g.elec && qq != 0.0) {
+            double e, de;
+            if (g.consistent_exc) region_elec(sc, l_e, g.alpha, g.krf, g.crf, sg, qq, rr, e, de); else region_elec(sc, l_e, 0.0, 0.0, 0.0, sg, qq, rr, e, de);
+            E += e; dedr += de;
+        }
         if (f && dedr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * i + k] += dedr / rr * d[k]; f[3 * j + k] -= dedr / rr * d[k]; }
     }
     // softened bonded terms: lambda x harmonic bond / harmonic angle / periodic torsion (alchemy.py:1180, 1261, 1341); central differences
@@ -1631,6 +1636,7 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     }
     g.elec = d->electrostatics != 0 && !d->exact_pme;
     g.exact = d->exact_pme != 0;
+    g.consistent_exc = d->consistent_exceptions != 0 && g.elec;
     if (g.exact) {
         for (int i = 0; i < N; ++i) if (g.region_of[i] > 0) { s.q[i] = g.q[i]; if (g.q[i] != 0.0) s.has_charge = true; }
         g.exc_region.assign(s.exc_atoms.size() / 2, 0);

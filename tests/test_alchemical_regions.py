@@ -235,6 +235,8 @@ CASES = [
     # regions that do not interact excluded from each other / regions that do see each other's scaled charges (alchemy.py:1663-1681)
     (dict(), frozenset(), dict(softcore_c=8)),
     (dict(), frozenset({(0, 1)}), dict()),
+    # consistent_exceptions=True (alchemy.py:1456-1461): the exceptions' electrostatics with the pairs' erfc(alpha r_eff) / r_eff
+    (dict(alchemical_pme_treatment='direct-space', consistent_exceptions=True), frozenset(), dict(softcore_beta=0.25)),
     # softened bonded terms: every angle and proper torsion of the dipeptide and three of its bonds under lambda_angles_pep / lambda_torsions_pep /
     # lambda_bonds_pep (alchemy.py:1115-1354)
     (dict(), frozenset(), dict(alchemical_torsions=True, alchemical_angles=True, alchemical_bonds=[0, 2, 5])),
@@ -288,6 +290,7 @@ def test_written_literals_of_the_other_treatments_are_the_references():
     nb.setNonbondedMethod(NonbondedForce.CutoffPeriodic); nb.setReactionFieldDielectric(78.3)
     assert ax.electrostatics_expressions(nb, rf_treatment='shifted')[0] == E['electrostatics_rf_shifted']
     assert ax.electrostatics_expressions(nb, rf_treatment='switched')[0] == E['electrostatics_rf_switched']
+    assert ax.electrostatics_expressions(nb, rf_treatment='switched', consistent_exceptions=True)[1] == E['electrostatics_exception_rf_consistent']
 
 
 @pytest.mark.parametrize('kw,interactions,region_kw', CASES + [(dict(alchemical_pme_treatment='coulomb'), frozenset({(0, 1)}), {})])
