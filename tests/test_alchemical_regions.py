@@ -293,6 +293,26 @@ def test_written_literals_of_the_other_treatments_are_the_references():
     assert ax.electrostatics_expressions(nb, rf_treatment='switched', consistent_exceptions=True)[1] == E['electrostatics_exception_rf_consistent']
 
 
+def test_written_literals_of_the_bonded_custom_forces_and_the_unshifted_reaction_field_are_the_references():
+    """tests/golden/reference_bonded_expressions.json (make_golden_bonded_strings.py: the f-strings of alchemy.py:1115-1354 and the pieces of
+    forces.UnshiftedReactionFieldForce's energy expression, forces.py:1128-1152, out of the reference's syntax tree)"""
+    B = json.load(open(os.path.join(HERE, 'golden', 'reference_bonded_expressions.json')))
+    for kind, (expr, per) in ax._BONDED_CUSTOM.items():
+        ref = B['bonded'][kind]
+        assert expr % 'LAMBDA' == ref['energy'] and list(per) == ref['per_term_parameters'] and ref['lambda_base_name'] == 'lambda_%ss' % kind
+    pieces = B['unshifted_reaction_field']['energy_pieces']
+    assert ax._RF_HEAD == pieces[0] and pieces[1] == 'chargeprod = charge1*charge2;' and B['unshifted_reaction_field']['per_particle_parameters'] == ['charge']
+    # the document this package writes: the same pieces, k_rf and ONE_4PI_EPS0 formatted ':f' as the reference does
+    lj = _charged_lj_fluid()
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(lj, alchemy.AlchemicalRegion(alchemical_atoms=range(4)))
+    import xml.etree.ElementTree as ET
+    rf = ET.fromstring(system_xml.to_xml(system)).find('Forces').findall('Force')[-1]
+    nb = [f for f in lj.getForces() if isinstance(f, NonbondedForce)][0]
+    k_rf = nb.getCutoffDistance() ** -3 * (78.3 - 1.0) / (2.0 * 78.3 + 1.0)
+    assert rf.get('energy') == pieces[0] + pieces[1] + 'k_rf = %f;' % k_rf + 'ONE_4PI_EPS0 = %f;' % G['ONE_4PI_EPS0']
+    assert [p.get('name') for p in rf.find('PerParticleParameters')] == ['charge'] and rf.get('useSwitchingFunction') == '1'
+
+
 @pytest.mark.parametrize('kw,interactions,region_kw', CASES + [(dict(alchemical_pme_treatment='coulomb'), frozenset({(0, 1)}), {})])
 def test_general_regions_are_written_as_the_factorys_force_set_and_read_back(kw, interactions, region_kw):
     al, system, regions = _alanine_two_regions(kw, interactions, **region_kw)
