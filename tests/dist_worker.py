@@ -16,6 +16,14 @@ def build(sampler_kind, engine, comm, n_iter, storage=None):
     ss = states.SamplerState(ho.positions, box_vectors=ho.system.getDefaultPeriodicBoxVectors())
     move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, collision_rate=1.0 / unit.picosecond,
                                               n_steps=25, reassign_velocities=True, splitting='V R O R V')
+    if sampler_kind == 'regions':
+        # general alchemical regions (tests/test_alchemical_regions.py): four states of two named regions on a charged fluid, the engine =
+        # the C++ build of the C ABI; the regions' tables live per handle, the replicas' own states follow the GLOBAL labels
+        from test_alchemical_regions import _two_region_sampler
+        from openmmtools_amd.multistate import ReplicaExchangeSampler
+        s, _ = _two_region_sampler(engine, storage, n_iter, comm=comm)
+        s.verify_labels = True
+        return s
     if sampler_kind == 'groups':
         # four oscillators of different spring constants = four Systems = four compatibility groups (tests/test_compat_groups.py)
         from openmmtools_amd.multistate import ReplicaExchangeSampler
@@ -54,14 +62,22 @@ def run(sampler_kind, comm, n_iter=6, storage_dir=None):
     from oracle_engine import OracleEngine
     from openmmtools_amd.multistate import MultiStateReporter
     storage = MultiStateReporter(os.path.join(storage_dir, 'store'), checkpoint_interval=2) if storage_dir else None
-    s = build(sampler_kind, OracleEngine(), comm, n_iter, storage)
+    if sampler_kind == 'regions':
+        import oracle
+        from openmmtools_amd._engine import HipEngine
+        class CpuBuild(HipEngine):            # the C++ build of the ABI: rows come back on the host (gloo all-gather of host rows)
+            is_device = False
+        engine = CpuBuild(lib_path=os.path.join(os.path.dirname(os.path.abspath(oracle.__file__)), '_build', 'libremd_cpu.so'))
+    else:
+        engine = OracleEngine()
+    s = build(sampler_kind, engine, comm, n_iter, storage)
     history = []
     analysis = []
     for _ in range(n_iter):
         s.run(1)
         history.append((s.replica_thermodynamic_states.copy(), s.energy_thermodynamic_states.copy(),
                         s._n_accepted_matrix.copy(), s._n_proposed_matrix.copy()))
-        analysis.append(np.append(s._last_mbar_f_k, s._last_err_free_energy) if sampler_kind not in ('groups', 'mc') else np.zeros(1))
+        analysis.append(np.append(s._last_mbar_f_k, s._last_err_free_energy) if sampler_kind not in ('groups', 'mc', 'regions') else np.zeros(1))
     x = np.stack([st.positions for st in s.sampler_states])
     run.last_analysis = np.stack(analysis)          # [iteration, K + 1]: online f_k and the current error estimate
     return history, x, (s._r_begin, s._r_count)

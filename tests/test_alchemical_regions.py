@@ -398,7 +398,7 @@ LAM_A = [(1.0, 1.0), (1.0, 0.5), (0.6, 0.0), (0.0, 0.0)]          # (lambda_ster
 LAM_B = [(1.0, 1.0), (0.8, 1.0), (0.8, 0.3), (0.2, 0.0)]
 
 
-def _two_region_sampler(engine, storage, n_iterations):
+def _two_region_sampler(engine, storage, n_iterations, comm=None):
     lj = _charged_lj_fluid()
     plain = ts.LennardJonesFluid(nparticles=216, reduced_density=0.4)
     regions = [alchemy.AlchemicalRegion(alchemical_atoms=range(4), name='a', softcore_beta=0.2),
@@ -410,7 +410,8 @@ def _two_region_sampler(engine, storage, n_iterations):
            for a, b in zip(LAM_A, LAM_B)]
     ss = states.SamplerState(plain.positions, box_vectors=plain.system.getDefaultPeriodicBoxVectors())
     move = mcmc.LangevinSplittingDynamicsMove(timestep=1.0 * unit.femtosecond, n_steps=3, reassign_velocities=True, splitting='V R O R V')
-    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=n_iterations, engine=engine, seed=3)
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=n_iterations, engine=engine, seed=3, online_analysis_interval=None,
+                               **({} if comm is None else dict(comm=comm)))
     s.create(ths, [ss], storage=storage)
     return s, asys
 

@@ -18,14 +18,14 @@ def test_block_partition():
     assert block_partition(3, 4) == ([0, 1, 2, 3], [1, 1, 1, 0])
 
 
-@pytest.mark.parametrize('kind', ['pt', 'sams', 'mc'])
+@pytest.mark.parametrize('kind', ['pt', 'sams', 'mc', 'regions'])
 def test_sharded_run_equals_single_process(tmp_path, kind):
     import dist_worker
     from openmmtools_amd.multistate.comm import SingleProcessComm
     os.makedirs(tmp_path / 'single')
     ref_hist, ref_x, _ = dist_worker.run(kind, SingleProcessComm(), storage_dir=str(tmp_path / 'single'))
     ref_analysis = dist_worker.run.last_analysis.copy()
-    port = 29600 + (os.getpid() % 200) + ['pt', 'sams', 'mc'].index(kind)
+    port = 29600 + (os.getpid() % 200) + ['pt', 'sams', 'mc', 'regions'].index(kind)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(HERE, 'dist_worker.py'), kind,
            str(tmp_path)]
