@@ -39,6 +39,7 @@ typedef struct remd_ctx* remd_handle;
 #define REMD_NB_NONE            0
 #define REMD_NB_CUTOFF_PERIODIC 1   /* reaction field */
 #define REMD_NB_PME             2
+#define REMD_NB_NOCUTOFF        3   /* every pair, no box: the vacuum test systems (csrc/nocutoff.hip); cutoff, switch, dispersion correction unused */
 
 /* mixing schemes (replicaexchange.py:265-283, sams.py:410-417) */
 #define REMD_MIX_NONE           0

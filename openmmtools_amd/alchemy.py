@@ -122,7 +122,8 @@ class AbsoluteAlchemicalFactory:
                     raise ValueError('Softcore electrostatics is' + err)
         r0 = regions[0]
         bonded = self._softened_bonded_terms(system, regions, interactions)           # takes them out of the System's bonded forces
-        fast = (len(regions) == 1 and r0.softcore_c == 6.0 and (exact or not charged) and bonded is None)
+        fast = (len(regions) == 1 and r0.softcore_c == 6.0 and (exact or not charged) and bonded is None and
+                nb is not None and nb.getNonbondedMethod() != NonbondedForce.NoCutoff)      # (that path lives in the cutoff-based pair kernels)
         if fast:
             # the pair kernels' own path: one region, charges scaled inside the Ewald sum or none to scale
             system.alchemical_region = r0
@@ -268,8 +269,8 @@ class AbsoluteAlchemicalFactory:
                     terms['elec_switch_distance'] = rc - self.switch_width
                 else:
                     terms['elec_crf'] = (1.0 / rc) * 3.0 * eps_s / (2.0 * eps_s + 1.0)
-            else:
-                raise NotImplementedError('nonbonded method %d (only CutoffPeriodic and PME are supported)' % method)
+            elif method != NonbondedForce.NoCutoff:                                                       # NoCutoff: plain l^d qq / r_eff, no switch (:1434-1447)
+                raise NotImplementedError('nonbonded method %d (only NoCutoff, CutoffPeriodic and PME are supported)' % method)
         return terms
 
 

@@ -186,7 +186,7 @@ __device__ __forceinline__ void region_exception(const region_consts& c, const f
 
 __device__ __forceinline__ float3 region_min_image(float3 d, float Lx, float Ly, float Lz)
 {
-    d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz);
+    if (Lx > 0.f) { d.x -= Lx * rintf(d.x / Lx); d.y -= Ly * rintf(d.y / Ly); d.z -= Lz * rintf(d.z / Lz); }      // (no box: a NoCutoff system)
     return d;
 }
 
@@ -423,7 +423,7 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     if (n < 0 || n > 64 || !d->region_of_atom || !d->softcore || !d->annihilate || !d->charge || !d->sigma || !d->epsilon ||
         d->n_interactions < 0 || (d->n_interactions > 0 && !d->interactions) || d->n_exceptions < 0 || (d->n_exceptions > 0 && (!d->exception_atoms || !d->exception_params)))
         return remd_fail(h, -1, "remd_set_alchemical_regions: bad arguments");
-    if (h->nb_method == REMD_NB_NONE) return remd_fail(h, -3, "alchemical regions need a NonbondedForce with a cutoff method");
+    if (h->nb_method == REMD_NB_NONE && !h->nocutoff) return remd_fail(h, -3, "alchemical regions need a NonbondedForce");
     if (h->sysdesc->d.n_alch != 0) return remd_fail(h, -3, "alchemical regions: the descriptor of remd_set_system must be the factory's NonbondedForce (n_alch = 0)");
     region_tables& t = g_reg[h];
     t.n_regions = n;
@@ -514,8 +514,9 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     }
     region_consts& c = t.c;
     // the NonbondedForce's cutoff and switch (h->cutoff is the range of the Ewald direct-space sum, which a rebalanced split stretches)
-    const double rcut = sd.cutoff, rsw = sd.switch_distance;
-    c.rc2 = (float)(rcut * rcut);
+    // (NoCutoff: every pair, no switch -- the custom forces copy the NonbondedForce's method, alchemy.py:1793-1796)
+    const double rcut = h->nocutoff ? 1e18 : sd.cutoff, rsw = h->nocutoff ? -1.0 : sd.switch_distance;
+    c.rc2 = (float)std::min(rcut * rcut, 3e38);
     c.rs = rsw > 0 && rsw < rcut ? (float)rsw : -1.f;
     c.inv_sw = c.rs >= 0.f ? (float)(1.0 / (rcut - rsw)) : 0.f;
     c.elec = (d->electrostatics && !exact) ? 1 : 0;

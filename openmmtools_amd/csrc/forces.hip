@@ -1507,7 +1507,9 @@ static int build_atom_terms(remd_ctx* h, int N, const std::vector<int>& ba, cons
 int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
 {
     remd_free_nonbonded(h);
-    h->nb_method = d->nb_method;
+    remd_nocutoff_release(h);
+    // NoCutoff (vacuum systems): the direct sum of nocutoff.hip; everything else treats the handle as one without a cutoff-based nonbonded force
+    h->nb_method = d->nb_method == REMD_NB_NOCUTOFF ? REMD_NB_NONE : d->nb_method;
     // bonded tables live in the context
     {
         std::vector<int> ba(d->bond_atoms, d->bond_atoms + 2 * (size_t)d->n_bonds);
@@ -1529,10 +1531,13 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         for (int k = 0; k < 4 * d->n_torsions; ++k) if (ta[k] < 0 || ta[k] >= d->n_atoms) return remd_fail(h, -3, "torsion atom index out of range");
     }
     h->n_alch = d->n_alch;
-    if (d->nb_method == REMD_NB_NONE) {
+    if (d->nb_method == REMD_NB_NONE || d->nb_method == REMD_NB_NOCUTOFF) {
         const std::vector<int> ba(d->bond_atoms, d->bond_atoms + 2 * (size_t)d->n_bonds), aa(d->angle_atoms, d->angle_atoms + 3 * (size_t)d->n_angles),
                                ta(d->torsion_atoms, d->torsion_atoms + 4 * (size_t)d->n_torsions), none;
-        return build_atom_terms(h, d->n_atoms, ba, aa, ta, none, 0, none, 0);
+        int rc0 = build_atom_terms(h, d->n_atoms, ba, aa, ta, none, 0, none, 0);
+        if (rc0 || d->nb_method == REMD_NB_NONE) return rc0;
+        if (d->n_alch > 0) return remd_fail(h, -3, "NoCutoff: alchemical atoms go through remd_set_alchemical_regions (the descriptor's one-region path needs a cutoff method)");
+        return remd_nocutoff_build(h, d);
     }
     if (d->nb_method != REMD_NB_CUTOFF_PERIODIC && d->nb_method != REMD_NB_PME) return remd_fail(h, -3, "unknown nonbonded method");
     if (!d->charge || !d->sigma || !d->epsilon) return remd_fail(h, -1, "nonbonded parameter arrays missing");
@@ -2116,7 +2121,7 @@ void remd_nb_invalidate_sort(remd_ctx* h)
 int remd_nb_resident_info(remd_ctx* h, int* ok, int* method, int* has_alch, nb_params* p, const float4** param, const float** rep_lam)
 {
     *ok = 0; *method = -1; *has_alch = 0; *param = nullptr; *rep_lam = nullptr;
-    if (h->nb_method == REMD_NB_NONE) { *ok = 1; return 0; }              // e.g. the harmonic oscillator: external force only
+    if (h->nb_method == REMD_NB_NONE) { *ok = h->nocutoff ? 0 : 1; return 0; }      // e.g. the harmonic oscillator: external force only (a NoCutoff system: forces.hip + nocutoff.hip)
     if (h->n_regions > 0) return 0;                                       // general alchemical regions: forces.hip + alch_regions.hip
     nb_tables* t = g_nb.find(h);
     if (!t || t->method != NB_LJ_ONLY || t->n_exc != 0 || t->n_excl != 0 || h->n_exceptions != 0) return 0;
@@ -2145,6 +2150,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
     // custom forces of general alchemical regions (alch_regions.hip): part of the direct-space nonbonded class, launched here -- in
     // front of the fork -- so that both branches of the evaluation are ordered behind them
     if (h->n_regions > 0 && do_nb) { int rcr = remd_regions_forces(h, with_energy, h->n_epart - 1); if (rcr) return rcr; }
+    if (h->nocutoff && do_nb) { int rcn = remd_nocutoff_forces(h, with_energy, EP_NB0); if (rcn) return rcn; }
     if (h->n_ext > 0 && do_ext) {
         remd_prof_scope ps(h, "ext_force");
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
@@ -2414,9 +2420,10 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
     nb_tables* it = g_nb.find(h);
     bool poly = false;
     const int* d_own_states = nullptr;
-    if (it && h->n_regions > 0 && h->nb_method != REMD_NB_NONE) {
+    if (h->n_regions > 0 && (h->nb_method != REMD_NB_NONE || h->nocutoff)) {
         // general alchemical regions: the custom forces at every state's lambdas (d_potential holds them at the replicas' own)
-        nb_tables& t = *it;
+        nb_tables& t = g_nb[h];
+        it = &t;
         if (t.alch_R != h->R || t.alch_K != h->K) {
             dfree(t.d_alch_ukl); dfree(t.d_state_lam); dfree(t.d_own);
             REMD_CHECK(h, hipMalloc(&t.d_alch_ukl, sizeof(double) * (size_t)n));

@@ -122,6 +122,7 @@ struct remd_ctx {
     int* d_torsion_atoms = nullptr; float* d_torsion_params = nullptr;
     // nonbonded
     int nb_method = REMD_NB_NONE;
+    int nocutoff = 0;                  // the descriptor asked for REMD_NB_NOCUTOFF: nb_method stays REMD_NB_NONE for the rest of the engine, nocutoff.hip adds the direct sum
     double cutoff = 0, switch_dist = -1, rf_dielectric = 78.3, ewald_alpha = 0;
     int annihilate_sterics = 0;        // remd_set_alchemical_options: alchemical/alchemical sterics are lambda-controlled too
     int rf_unshifted = 0; double rf_switch_width = 0;   // remd_set_reaction_field: c_rf = 0, pair term switched over the last rf_switch_width nm
@@ -348,6 +349,10 @@ void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluati
 #define REMD_FG_TORSION 3
 #define REMD_FG_NONBONDED 4      /* direct space, exceptions, Ewald exclusion correction */
 #define REMD_FG_RECIPROCAL 5
+// nocutoff.hip: NonbondedForce with NoCutoff (vacuum systems)
+void remd_nocutoff_release(remd_ctx* h);
+int remd_nocutoff_build(remd_ctx* h, const remd_system_desc* d);
+int remd_nocutoff_forces(remd_ctx* h, bool with_energy, int ep_slot);
 // alch_regions.hip: custom forces of general alchemical regions
 void remd_regions_release(remd_ctx* h);
 int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot);

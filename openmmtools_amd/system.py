@@ -452,12 +452,15 @@ def system_to_desc(system, box=None, ewald_split=None, min_edge=None):
             d['nb_method'] = 1
         elif method == NonbondedForce.PME:
             d['nb_method'] = 2
+        elif method == NonbondedForce.NoCutoff:
+            d['nb_method'] = 3                      # REMD_NB_NOCUTOFF: every pair, no box (the vacuum test systems; csrc/nocutoff.hip)
         else:
-            raise NotImplementedError('nonbonded method %d (only CutoffPeriodic and PME are supported)' % method)
-        d['cutoff'] = nb.getCutoffDistance()
-        d['switch_distance'] = nb.getSwitchingDistance() if nb.getUseSwitchingFunction() else -1.0
+            raise NotImplementedError('nonbonded method %d (only NoCutoff, CutoffPeriodic and PME are supported)' % method)
+        nocut = d['nb_method'] == 3                 # OpenMM ignores cutoff, switching function and dispersion correction without a cutoff
+        d['cutoff'] = 0.0 if nocut else nb.getCutoffDistance()
+        d['switch_distance'] = nb.getSwitchingDistance() if (nb.getUseSwitchingFunction() and not nocut) else -1.0
         d['rf_dielectric'] = nb.getReactionFieldDielectric()
-        d['use_dispersion_correction'] = int(nb.getUseDispersionCorrection())
+        d['use_dispersion_correction'] = int(nb.getUseDispersionCorrection() and not nocut)
         p = np.array(nb.particles, dtype=np.float64).reshape(-1, 3)
         d['charge'], d['sigma'], d['epsilon'] = p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy()
         d['exception_atoms'] = np.array([e[:2] for e in nb.exceptions], dtype=np.int32).reshape(-1, 2)

@@ -218,6 +218,20 @@ class AlanineDipeptideExplicit(_AmberExplicit):
     _name = 'alanine-dipeptide-explicit'
 
 
+class AlanineDipeptideVacuum(TestSystem):
+    """testsystems.py:3352-3388: ACE-ALA-NME (22 atoms) without solvent -- prmtop.createSystem(implicitSolvent=None, constraints=HBonds,
+    nonbondedCutoff=None): NonbondedForce with NoCutoff, no periodic box, CMMotionRemover."""
+
+    def __init__(self, constraints='HBonds', hydrogenMass=None, **kwargs):
+        super().__init__(**kwargs)
+        if constraints != 'HBonds' or hydrogenMass is not None:
+            raise NotImplementedError('only constraints=HBonds, no HMR (the testsystem defaults)')
+        system, nb, positions, velocities, z = _load_npz_system('alanine-dipeptide-vacuum')
+        nb.setNonbondedMethod(NonbondedForce.NoCutoff)
+        self.system, self.positions, self.velocities = system, positions, None
+        self.residue_names = [str(s) for s in z['residue_names']] if 'residue_names' in z.files else None
+
+
 class HostGuestExplicit(_AmberExplicit):
     """testsystems.py:3789-3857: CB7 + B2 guest + 1445 TIP3P waters, 4491 atoms."""
     _name = 'cb7-b2-explicit'

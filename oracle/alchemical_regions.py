@@ -40,7 +40,7 @@ class RegionOracle:
         self.elec = bool(t['electrostatics'])
         self.alpha, self.krf, self.crf = float(t['elec_alpha']), float(t['elec_krf']), float(t['elec_crf'])
         self.rs_e = float(t['elec_switch_distance'])
-        self.rc = float(cutoff)
+        self.rc = float(cutoff) if cutoff and cutoff > 0 else float('inf')           # (0: a NoCutoff system)
         self.rs = -1.0 if switch_distance is None else float(switch_distance)
         excl = set((min(int(i), int(j)), max(int(i), int(j))) for i, j in exclusions)
         # the candidate pairs: (alchemical, environment) and alchemical pairs once, of regions that interact, not excluded

@@ -183,6 +183,7 @@ struct System {
     std::vector<double> bond_params, angle_params, torsion_params, exc_params;
     int method = 0; double rc = 0, rs = -1, rf_eps = 78.3, alpha = 0; int grid[3] = {0, 0, 0}; int use_disp = 0;
     bool annihilate = false;  // AlchemicalRegion.annihilate_sterics (remd_set_alchemical_options)
+    bool nocut = false;       // NonbondedForce.NoCutoff (REMD_NB_NOCUTOFF): every pair, no box; `method` stays 0 (nothing periodic)
     bool rf_unshifted = false; double rf_switch_width = 0;   // remd_set_reaction_field: c_rf = 0, pair term switched (forces.py:1110-1150)
     double rcc = 0;       // range of the Ewald direct-space sum (remd_set_coulomb_cutoff); = rc unless the host split the sum elsewhere
     std::vector<double> q, sig, eps;
@@ -532,7 +533,7 @@ double region_energy(const System& s, const Replica& r, int state, double* f)
         for (int j = 0; j < s.N; ++j) {
             if (skip[j]) continue;
             double d[3];
-            for (int k = 0; k < 3; ++k) d[k] = min_image(x[3 * j + k] - x[3 * a + k], r.box[k]);
+            for (int k = 0; k < 3; ++k) { d[k] = x[3 * j + k] - x[3 * a + k]; if (s.method != 0) d[k] = min_image(d[k], r.box[k]); }
             const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
             if (r2 >= rc2) continue;
             const System::RegionClass& c = g.classes[g.cls_of[(size_t)g.region_of[a] * (g.n + 1) + g.region_of[j]]];
@@ -695,6 +696,43 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
                 }
             }
         }
+    }
+    if (s.nocut) {
+        // NoCutoff: every pair that is not an exception, plain Lennard-Jones + Coulomb; the exceptions with their own parameters
+        if ((classes & 16) && (parts & (PART_STERICS | PART_ELEC))) {
+            double e_nb = 0;
+            for (int i = 0; i < N; ++i) {
+                const std::vector<int>& ex = s.excl[i];
+                for (int j = i + 1; j < N; ++j) {
+                    if (std::binary_search(ex.begin(), ex.end(), j)) continue;
+                    double d[3]; delta(i, j, d);
+                    const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], rr = sqrt(r2);
+                    double fr = 0.0;
+                    const double ep = sqrt(s.eps[i] * s.eps[j]);
+                    if (ep != 0.0 && (parts & PART_STERICS)) {
+                        const double sg = 0.5 * (s.sig[i] + s.sig[j]), s2 = sg * sg / r2, s6 = s2 * s2 * s2;
+                        e_nb += 4.0 * ep * (s6 * s6 - s6); fr += 4.0 * ep * (12.0 * s6 * s6 - 6.0 * s6) / r2;
+                    }
+                    const double qq = ONE_4PI_EPS0 * s.q[i] * s.q[j];
+                    if (qq != 0.0 && (parts & PART_ELEC)) { e_nb += qq / rr; fr += qq / (rr * r2); }
+                    if (f && fr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * j + k] += fr * d[k]; f[3 * i + k] -= fr * d[k]; }
+                }
+            }
+            E.c[8] += e_nb;
+            for (size_t e = 0; e < s.exc_atoms.size() / 2; ++e) {
+                const int i = s.exc_atoms[2 * e], j = s.exc_atoms[2 * e + 1];
+                const double qq = ONE_4PI_EPS0 * s.exc_params[3 * e], sg = s.exc_params[3 * e + 1], ep = s.exc_params[3 * e + 2];
+                if (qq == 0.0 && ep == 0.0) continue;
+                double d[3]; delta(i, j, d);
+                const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], rr = sqrt(r2);
+                double fr = 0.0;
+                if (ep != 0.0 && (parts & PART_STERICS)) { const double s2 = sg * sg / r2, s6 = s2 * s2 * s2; E.c[4] += 4.0 * ep * s6 * (s6 - 1.0); fr += 4.0 * ep * (12.0 * s6 * s6 - 6.0 * s6) / r2; }
+                if (qq != 0.0 && (parts & PART_ELEC)) { E.c[4] += qq / rr; fr += qq / (rr * r2); }
+                if (f && fr != 0.0) for (int k = 0; k < 3; ++k) { f[3 * j + k] += fr * d[k]; f[3 * i + k] -= fr * d[k]; }
+            }
+        }
+        if (s.reg.n > 0 && region_state >= 0 && region_state < s.reg.K && (classes & 16) && (parts & PART_SOFTCORE)) E.c[8] += region_energy(s, r, region_state, f);
+        return E;
     }
     if (!periodic) return E;
     const double V = r.box[0] * r.box[1] * r.box[2];
@@ -1388,6 +1426,7 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
     s.angle_atoms.assign(d->angle_atoms, d->angle_atoms + 3 * (size_t)d->n_angles); s.angle_params.assign(d->angle_params, d->angle_params + 2 * (size_t)d->n_angles);
     s.torsion_atoms.assign(d->torsion_atoms, d->torsion_atoms + 4 * (size_t)d->n_torsions); s.torsion_params.assign(d->torsion_params, d->torsion_params + 3 * (size_t)d->n_torsions);
     s.method = d->nb_method; s.rc = d->cutoff; s.rs = d->switch_distance > 0 ? d->switch_distance : -1.0;
+    if (d->nb_method == REMD_NB_NOCUTOFF) { s.nocut = true; s.method = 0; s.rc = 1e18; s.rs = -1.0; }
     s.rcc = s.rc;
     if (s.method == REMD_NB_PME && h->coulomb_cutoff > 0.0) {
         if (h->coulomb_cutoff < s.rc) return fail(h, -1, "the Coulomb cutoff of remd_set_coulomb_cutoff is shorter than the NonbondedForce cutoff");
@@ -1398,11 +1437,12 @@ int remd_set_system(remd_handle h, const remd_system_desc* d)
     s.rf_eps = d->rf_dielectric; s.alpha = d->ewald_alpha; s.use_disp = d->use_dispersion_correction;
     for (int k = 0; k < 3; ++k) s.grid[k] = d->pme_grid[k];
     s.q.assign(N, 0.0); s.sig.assign(N, 1.0); s.eps.assign(N, 0.0); s.alch.assign(N, 0);
-    if (s.method) {
+    if (s.method || s.nocut) {
         if (!d->charge || !d->sigma || !d->epsilon) return fail(h, -1, "remd_set_system: nonbonded parameters missing");
         s.q.assign(d->charge, d->charge + N); s.sig.assign(d->sigma, d->sigma + N); s.eps.assign(d->epsilon, d->epsilon + N);
     }
     for (double q : s.q) if (q != 0.0) s.has_charge = true;
+    if (s.nocut && d->n_alch > 0) return fail(h, -3, "NoCutoff: alchemical atoms go through remd_set_alchemical_regions (the descriptor's one-region path needs a cutoff method)");
     for (int a = 0; a < d->n_alch; ++a) { s.alch[d->alch_atoms[a]] = 1; s.has_alch = true; }
     s.sc_alpha = d->softcore_alpha; s.sc_a = d->softcore_a; s.sc_b = d->softcore_b; s.sc_c = d->softcore_c;
     s.exc_atoms.assign(d->exception_atoms, d->exception_atoms + 2 * (size_t)d->n_exceptions);
@@ -1588,7 +1628,7 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     if (n < 0 || n > 64 || !d->region_of_atom || !d->softcore || !d->annihilate || !d->charge || !d->sigma || !d->epsilon ||
         d->n_interactions < 0 || (d->n_interactions > 0 && !d->interactions) || d->n_exceptions < 0 || (d->n_exceptions > 0 && (!d->exception_atoms || !d->exception_params)))
         return fail(h, -1, "remd_set_alchemical_regions: bad arguments");
-    if (s.method == 0) return fail(h, -3, "alchemical regions need a NonbondedForce with a cutoff method");
+    if (s.method == 0 && !s.nocut) return fail(h, -3, "alchemical regions need a NonbondedForce");
     if (s.has_alch) return fail(h, -3, "alchemical regions: the descriptor of remd_set_system must be the factory's NonbondedForce (n_alch = 0)");
     System::Regions g;
     g.n = n;

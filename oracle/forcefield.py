@@ -132,6 +132,14 @@ class ForceFieldOracle(OracleSystem):
 
     # ---- pair list (numpy) ---------------------------------------------------------------------
     def _pairs(self, x, box):
+        if self.method == 3:                        # NoCutoff: every pair that is not an exception
+            i, j = np.triu_indices(self.N, k=1)
+            pairs = np.stack([i, j], axis=1)
+            if len(self.excluded):
+                key = pairs[:, 0].astype(np.int64) * self.N + pairs[:, 1]
+                ex = np.array([a * self.N + b for a, b in self.excluded], dtype=np.int64)
+                pairs = pairs[~np.isin(key, ex)]
+            return pairs
         xw = np.mod(x, box)
         xw = np.where(xw >= box, 0.0, xw)
         tree = cKDTree(xw, boxsize=box)
@@ -144,6 +152,8 @@ class ForceFieldOracle(OracleSystem):
 
     @staticmethod
     def _min_image(d, box_t):
+        if box_t is None:
+            return d
         return d - box_t * torch.round(d / box_t)
 
     def _switch(self, r):
@@ -203,6 +213,8 @@ class ForceFieldOracle(OracleSystem):
             qq = ONE_4PI_EPS0 * q[i] * q[j]
             if self.method == 2:
                 e = e + (qq * torch.erfc(self.alpha * r) / r).sum()
+            elif self.method == 3:
+                e = e + (qq / r).sum()
             else:
                 eps_s = self.d['rf_dielectric']
                 krf = (eps_s - 1.0) / (2.0 * eps_s + 1.0) / self.rc ** 3
@@ -284,7 +296,13 @@ class ForceFieldOracle(OracleSystem):
             dx = x[idx] - torch.tensor([d['ext_x0'], 0.0, 0.0])
             e = e + 0.5 * d['ext_K'] * (dx * dx).sum() + d['ext_U0'] * len(idx)
         e = e + (self._bonded(x) if classes is None else self._bonded(x, only=classes))
-        if self.method:
+        if self.method == 3:                        # NoCutoff (vacuum systems): no box, no switch, no dispersion correction
+            if on(4):
+                pairs = self._pairs(x.detach().numpy(), None)
+                if len(pairs):
+                    e = e + self._pair_terms(x, None, pairs, lam_s, lam_e, include_na=include_na)
+                e = e + self._exceptions(x, None, lam_e, lam_s, include_na=include_na)
+        elif self.method:
             box_t = torch.tensor(np.asarray(box, dtype=np.float64))
             V = float(np.prod(box))
             if on(4):

@@ -1,7 +1,7 @@
 """Converts the reference's Amber input files into compact .npz system descriptions.
 
 Run in the build container only (needs /root/reference):  python tools/convert_amber.py
-Outputs openmmtools_amd/data/{alanine-dipeptide-explicit,cb7-b2-explicit,dhfr-explicit}.npz, the inputs of
+Outputs openmmtools_amd/data/{alanine-dipeptide-explicit,cb7-b2-explicit,dhfr-explicit,alanine-dipeptide-vacuum}.npz, the inputs of
 testsystems.AlanineDipeptideExplicit / HostGuestExplicit / DHFRExplicit (reference:
 openmmtools/testsystems.py:3499-3527, 3821-3857, 3895-3923).  The reference's data files are the
 physical input of the benchmark configs; only derived numeric arrays are stored.
@@ -21,6 +21,8 @@ JOBS = [
      'alanine-dipeptide-explicit/alanine-dipeptide.crd'),
     ('cb7-b2-explicit', 'cb7-b2/complex-explicit.prmtop', 'cb7-b2/complex-explicit.inpcrd'),
     ('dhfr-explicit', 'dhfr/JAC.prmtop', 'dhfr/JAC.inpcrd'),
+    # testsystems.AlanineDipeptideVacuum (testsystems.py:3352-3388): the same parameter set without solvent, NoCutoff, no box
+    ('alanine-dipeptide-vacuum', 'alanine-dipeptide-gbsa/alanine-dipeptide.prmtop', 'alanine-dipeptide-gbsa/alanine-dipeptide.crd'),
 ]
 
 for name, top, crd in JOBS:
@@ -28,6 +30,8 @@ for name, top, crd in JOBS:
     system, nb = amber.create_system(prm)
     n = system.getNumParticles()
     pos, vel, box = amber.read_inpcrd(os.path.join(REF, crd), n)
+    if box is None:
+        box = np.zeros(3)
     forces = {type(f).__name__: f for f in system.getForces()}
     bf, af, tf = forces['HarmonicBondForce'], forces['HarmonicAngleForce'], forces['PeriodicTorsionForce']
     p = np.array(nb.particles)
