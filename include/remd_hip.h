@@ -290,6 +290,23 @@ typedef struct remd_alch_regions_desc {
                                             exceptions use g of the pairs (elec_alpha / elec_krf / elec_crf; no cutoff, no switch) instead of 1 / reff */
 } remd_alch_regions_desc;
 int  remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* desc);
+/* GBSA implicit solvent of a NoCutoff system: OpenMM's GBSAOBCForce (OBC2 Born radii, ACE surface term) in the form the reference's
+   alchemical factory gives it (alchemy.py:2144-2225, _alchemically_modify_GBSAOBCForce -- a CustomGBForce whose expression strings are the
+   definition followed here; offset 0.009 nm, tanh(psi - 0.8 psi^2 + 4.85 psi^3), k_e = 138.935485, surface term 28.3919551 (R + 0.14)^2 (R / B)^6):
+     I_i = sum_{j != i} s_j H(r_ij; R_i - offset, scale_j (R_j - offset)),   B_i = 1 / (1 / (R_i - offset) - tanh(...) / R_i),
+     E = sum_i s_i [-k_e tau q_i^2 / (2 B_i) + surface_i] - sum_{i<j} k_e tau s_i q_i s_j q_j / sqrt(r^2 + B_i B_j exp(-r^2 / (4 B_i B_j))),
+   tau = 1 / solute_dielectric - 1 / solvent_dielectric, s_i = lambda_electrostatics on the alchemical particles (of the replica's state: region 1
+   of remd_set_region_lambdas -- the factory supports one region with GBSA, :2168-2171) and 1 elsewhere.  Call AFTER remd_set_system
+   (which forgets it); desc = NULL: none.  u_kl re-evaluates the GB energy at every state's lambda (it is not a polynomial in lambda). */
+typedef struct remd_gbsa_desc {
+    int32_t n_atoms;
+    const double *charge, *radius, *scale;     /* [n_atoms] GBSAOBCForce particle parameters: e, nm, -            */
+    const int32_t* alchemical;                 /* [n_atoms] 0 / 1, or NULL (no alchemical particle)                */
+    double solute_dielectric, solvent_dielectric;
+    int32_t surface_area;                      /* 1: with the ACE surface term (GBSAOBCForce's default)            */
+} remd_gbsa_desc;
+int  remd_set_gbsa(remd_handle h, const remd_gbsa_desc* desc);
+
 /* lambda_sterics / lambda_electrostatics of every region at every state: [K][n_regions], K as in remd_set_states (call after it).  The
    energy_const of remd_set_states carries the long-range corrections of the sterics custom forces (alchemy.py:1786-1789).      */
 int  remd_set_region_lambdas(remd_handle h, int K, int n_regions, const double* lambda_sterics, const double* lambda_electrostatics);

@@ -266,6 +266,9 @@ def emit_region_forces(forces, system, emit_plain):
     """The force set of a System in the general-regions mode (``system.alchemical_regions``): the reference's loop over
     single_regions + pair_regions (alchemy.py:1693-2036) restated on plain tables -- INCLUDING its order of reading and zeroing the
     NonbondedForce's parameters, which decides what the later forces' particle tables hold (:1886-1911, 2001-2006)."""
+    from .system import GBSAOBCForce
+    if any(isinstance(f, GBSAOBCForce) for f in system.getForces()):
+        raise NotImplementedError('an alchemical System with GBSA in a store (the factory\'s CustomGBForce, alchemy.py:2172-2225, is not written)')
     regions = system.alchemical_regions
     opts = system.alchemical_factory_options
     terms = system.alchemical_region_terms

@@ -55,9 +55,15 @@ class RemdAlchRegionsDesc(C.Structure):
     ]
 
 
+class RemdGbsaDesc(C.Structure):
+    """remd_gbsa_desc of include/remd_hip.h (GBSA OBC2 + ACE of a NoCutoff system)."""
+    _fields_ = [('n_atoms', C.c_int32), ('charge', c_double_p), ('radius', c_double_p), ('scale', c_double_p), ('alchemical', c_int32_p),
+                ('solute_dielectric', C.c_double), ('solvent_dielectric', C.c_double), ('surface_area', C.c_int32)]
+
+
 EXPORTS = [
     'remd_create', 'remd_destroy', 'remd_last_error', 'remd_version', 'remd_set_system', 'remd_set_coulomb_cutoff', 'remd_set_reaction_field', 'remd_set_alchemical_options', 'remd_set_alchemical_regions',
-    'remd_set_region_lambdas', 'remd_set_region_bonded_lambdas', 'remd_set_states',
+    'remd_set_region_lambdas', 'remd_set_region_bonded_lambdas', 'remd_set_gbsa', 'remd_set_states',
     'remd_set_integrator', 'remd_set_replicas', 'remd_set_replica_ids', 'remd_copy_replicas', 'remd_set_labels', 'remd_seed', 'remd_propagate',
     'remd_compute_energies', 'remd_ukl_device_ptr', 'remd_mix', 'remd_mix_host', 'remd_get_replicas',
     'remd_get_forces', 'remd_propagate_many', 'remd_set_phases', 'remd_get_phases', 'remd_get_constraint_stats', 'remd_step', 'remd_sync', 'remd_last_timing', 'remd_profile_enable',
@@ -106,6 +112,7 @@ def load_library(path=None):
     lib.remd_set_alchemical_regions.argtypes = [vp, C.POINTER(RemdAlchRegionsDesc)]
     lib.remd_set_region_lambdas.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p]
     lib.remd_set_region_bonded_lambdas.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]
+    lib.remd_set_gbsa.argtypes = [vp, C.POINTER(RemdGbsaDesc)]
     lib.remd_set_states.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.remd_set_integrator.argtypes = [vp, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
     lib.remd_set_restart_attempts.argtypes = [vp, C.c_int]
@@ -294,6 +301,13 @@ class HipEngine:
                 setattr(r, kind + '_region', i32(np.asarray(regions.get(kind + '_region', np.zeros(0)), dtype=np.int32)))
             self._check(self.lib.remd_set_alchemical_regions(self.h, C.byref(r)), 'remd_set_alchemical_regions')
             self.n_regions = int(r.n_regions)
+        gb = desc_dict.get('gbsa')
+        if gb is not None:                               # GBSAOBCForce of an implicit-solvent system (alchemy.py:2144-2225)
+            arrs = [np.ascontiguousarray(gb[k], dtype=np.float64) for k in ('charge', 'radius', 'scale')]
+            alch = np.ascontiguousarray(gb.get('alchemical', np.zeros(self.N)), dtype=np.int32)
+            g = RemdGbsaDesc(self.N, _dp(arrs[0]), _dp(arrs[1]), _dp(arrs[2]), _ip(alch), float(gb['solute_dielectric']), float(gb['solvent_dielectric']),
+                             int(gb.get('surface_area', 1)))
+            self._check(self.lib.remd_set_gbsa(self.h, C.byref(g)), 'remd_set_gbsa')
         if 'force_groups' in desc_dict:                  # Force.getForceGroup() of the force classes (V<g> substeps)
             self.set_force_groups(desc_dict['force_groups'])
 

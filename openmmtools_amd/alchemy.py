@@ -120,6 +120,10 @@ class AbsoluteAlchemicalFactory:
                     raise ValueError('Consistent exceptions are' + err)
                 if (r.softcore_beta, r.softcore_d, r.softcore_e) != (0, 1, 1):
                     raise ValueError('Softcore electrostatics is' + err)
+        from .system import GBSAOBCForce
+        has_gb = any(isinstance(f, GBSAOBCForce) for f in system.getForces())
+        if has_gb and len(regions) > 1:
+            raise NotImplementedError('Multiple regions does not work with GBSAOBCForce')               # alchemy.py:2168-2169
         r0 = regions[0]
         bonded = self._softened_bonded_terms(system, regions, interactions)           # takes them out of the System's bonded forces
         fast = (len(regions) == 1 and r0.softcore_c == 6.0 and (exact or not charged) and bonded is None and

@@ -733,3 +733,12 @@ int remd_regions_le_override(remd_ctx* h, const float* le, int* n, const float**
     if (d_state_le) *d_state_le = t->d_state_le;
     return 0;
 }
+
+// lambda_electrostatics of region `g` (0-based) at state k, as remd_set_region_lambdas gave it (gbsa.hip: the alchemical particles' factor)
+int remd_regions_state_le(remd_ctx* h, int k, int g, double* le)
+{
+    region_tables* t = g_reg.find(h);
+    if (!t || t->K <= 0 || k < 0 || k >= t->K || g < 0 || g >= t->n_regions) return -1;
+    *le = t->le[(size_t)k * t->n_regions + g];
+    return 0;
+}

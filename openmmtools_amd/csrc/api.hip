@@ -135,6 +135,7 @@ int remd_destroy(remd_handle h)
     remd_free_constraints(h);
     remd_free_nonbonded(h);
     remd_nocutoff_release(h);
+    remd_gbsa_release(h);
     remd_regions_release(h);
     remd_mix_release(h);
     dfree(h->d_invmass); dfree(h->d_mass); dfree(h->d_ext_atoms);

@@ -1508,6 +1508,7 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
 {
     remd_free_nonbonded(h);
     remd_nocutoff_release(h);
+    remd_gbsa_release(h);
     // NoCutoff (vacuum systems): the direct sum of nocutoff.hip; everything else treats the handle as one without a cutoff-based nonbonded force
     h->nb_method = d->nb_method == REMD_NB_NOCUTOFF ? REMD_NB_NONE : d->nb_method;
     // bonded tables live in the context
@@ -2151,6 +2152,7 @@ int remd_compute_forces(remd_ctx* h, bool with_energy, unsigned class_mask)
     // front of the fork -- so that both branches of the evaluation are ordered behind them
     if (h->n_regions > 0 && do_nb) { int rcr = remd_regions_forces(h, with_energy, h->n_epart - 1); if (rcr) return rcr; }
     if (h->nocutoff && do_nb) { int rcn = remd_nocutoff_forces(h, with_energy, EP_NB0); if (rcn) return rcn; }
+    if (h->gbsa && do_nb) { int rcg = remd_gbsa_forces(h, with_energy, EP_NB0 + 1); if (rcg) return rcg; }
     if (h->n_ext > 0 && do_ext) {
         remd_prof_scope ps(h, "ext_force");
         LAUNCH_E(ext_force_kernel, dim3(R), dim3(64), 0, h->stream, h->n_ext, h->d_ext_atoms, (float)h->ext_K, (float)h->ext_x0,
@@ -2431,6 +2433,7 @@ int remd_assemble_ukl(remd_ctx* h, double* d_rows)
         }
         int rc = remd_regions_ukl(h, t.d_alch_ukl, &d_own_states);
         if (rc) return rc;
+        if (h->gbsa && (rc = remd_gbsa_ukl(h, t.d_alch_ukl))) return rc;       // implicit solvent with alchemical particles: its energy at every state's lambda
         alch = t.d_alch_ukl;
         if (h->regions_exact) {
             int nreg = 0; const float* d_state_le = nullptr;

@@ -122,6 +122,7 @@ struct remd_ctx {
     int* d_torsion_atoms = nullptr; float* d_torsion_params = nullptr;
     // nonbonded
     int nb_method = REMD_NB_NONE;
+    int gbsa = 0;                      // remd_set_gbsa: GBSA (OBC2 + ACE) of a NoCutoff system (gbsa.hip)
     int nocutoff = 0;                  // the descriptor asked for REMD_NB_NOCUTOFF: nb_method stays REMD_NB_NONE for the rest of the engine, nocutoff.hip adds the direct sum
     double cutoff = 0, switch_dist = -1, rf_dielectric = 78.3, ewald_alpha = 0;
     int annihilate_sterics = 0;        // remd_set_alchemical_options: alchemical/alchemical sterics are lambda-controlled too
@@ -353,6 +354,11 @@ void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluati
 void remd_nocutoff_release(remd_ctx* h);
 int remd_nocutoff_build(remd_ctx* h, const remd_system_desc* d);
 int remd_nocutoff_forces(remd_ctx* h, bool with_energy, int ep_slot);
+// gbsa.hip: implicit solvent of a NoCutoff system
+void remd_gbsa_release(remd_ctx* h);
+int remd_gbsa_forces(remd_ctx* h, bool with_energy, int ep_slot);
+int remd_gbsa_ukl(remd_ctx* h, double* d_alch /*[R][K], added to*/);
+int remd_regions_state_le(remd_ctx* h, int k, int g, double* le);
 // alch_regions.hip: custom forces of general alchemical regions
 void remd_regions_release(remd_ctx* h);
 int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot);

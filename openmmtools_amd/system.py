@@ -206,6 +206,33 @@ class CustomExternalForce(Force):
         return len(self.particles)
 
 
+class GBSAOBCForce(Force):
+    """openmm.GBSAOBCForce: OBC2 Born radii + ACE surface term (the form the reference's alchemical factory spells out, alchemy.py:2144-2225).
+    NoCutoff only."""
+    NoCutoff, CutoffNonPeriodic, CutoffPeriodic = 0, 1, 2
+
+    def __init__(self):
+        super().__init__()
+        self.particles = []                 # (charge, radius nm, scale)
+        self._solvent, self._solute, self._sa, self._method = 78.5, 1.0, 2.25936, 0
+
+    def addParticle(self, charge, radius, scalingFactor):
+        self.particles.append((float(charge), float(radius), float(scalingFactor)))
+        return len(self.particles) - 1
+
+    def getNumParticles(self): return len(self.particles)
+    def getParticleParameters(self, idx): return self.particles[idx]
+    def setParticleParameters(self, idx, charge, radius, scalingFactor): self.particles[idx] = (float(charge), float(radius), float(scalingFactor))
+    def getSolventDielectric(self): return self._solvent
+    def setSolventDielectric(self, v): self._solvent = float(v)
+    def getSoluteDielectric(self): return self._solute
+    def setSoluteDielectric(self, v): self._solute = float(v)
+    def getSurfaceAreaEnergy(self): return self._sa
+    def setSurfaceAreaEnergy(self, v): self._sa = float(v)
+    def getNonbondedMethod(self): return self._method
+    def setNonbondedMethod(self, m): self._method = int(m)
+
+
 class CMMotionRemover(Force):
     def __init__(self, frequency=1):
         super().__init__()
@@ -396,6 +423,7 @@ def system_to_desc(system, box=None, ewald_split=None, min_edge=None):
     d.update(n_ext=0, ext_atoms=np.zeros(0, np.int32), ext_K=0.0, ext_x0=0.0, ext_U0=0.0)
     bonds, angles, torsions = [], [], []
     nb = None
+    gb = None
     cmm = 0
     # force groups of (external, bonds, angles, torsions, nonbonded direct, PME reciprocal): remd_set_force_groups
     fg = [0, 0, 0, 0, 0, 0]
@@ -432,6 +460,8 @@ def system_to_desc(system, box=None, ewald_split=None, min_edge=None):
             nb = f
         elif isinstance(f, CMMotionRemover):
             cmm = f.frequency
+        elif isinstance(f, GBSAOBCForce):
+            gb = f
         else:
             raise NotImplementedError('unsupported force %r' % type(f).__name__)
     d['bond_atoms'] = np.array([b[:2] for b in bonds], dtype=np.int32).reshape(-1, 2)
@@ -504,6 +534,23 @@ def system_to_desc(system, box=None, ewald_split=None, min_edge=None):
         d['alch_atoms'] = np.zeros(0, np.int32)
         d['softcore'] = (0.5, 1.0, 1.0, 6.0)
         d['annihilate_sterics'] = False
+    if gb is not None:
+        # implicit solvent: remd_set_gbsa (csrc/gbsa.hip).  The surface term is the ACE one with OpenMM's default energy (28.3919551 = 4 pi x
+        # 2.25936 kJ/mol/nm^2 in the factory's expression, alchemy.py:2207); 0 switches it off
+        if d['nb_method'] != 3 or gb.getNonbondedMethod() != GBSAOBCForce.NoCutoff:
+            raise NotImplementedError('GBSAOBCForce with a cutoff (only NoCutoff implicit-solvent systems are supported)')
+        if gb.getNumParticles() != n:
+            raise ValueError('GBSAOBCForce has %d particles, system has %d' % (gb.getNumParticles(), n))
+        if gb.getSurfaceAreaEnergy() not in (0.0, 2.25936):
+            raise NotImplementedError('GBSAOBCForce surface area energy %r (OpenMM\'s default 2.25936 kJ/mol/nm^2 or 0)' % gb.getSurfaceAreaEnergy())
+        gp = np.array(gb.particles, dtype=np.float64).reshape(-1, 3)
+        alch = np.zeros(n, dtype=np.int32)
+        regions = getattr(system, 'alchemical_regions', None)
+        if regions is not None:                       # the factory's alchemical GBSA: one region (alchemy.py:2168-2171)
+            alch[regions[0].alchemical_atoms] = 1
+        d['gbsa'] = dict(charge=gp[:, 0].copy(), radius=gp[:, 1].copy(), scale=gp[:, 2].copy(), alchemical=alch,
+                         solute_dielectric=gb.getSoluteDielectric(), solvent_dielectric=gb.getSolventDielectric(),
+                         surface_area=int(gb.getSurfaceAreaEnergy() != 0.0))
     if getattr(system, 'rf_unshifted_switch_width', None) is not None and d['nb_method'] == 1:
         # the reaction field as the alchemical factory re-writes it for the WHOLE system (alchemical_rf_treatment='switched'): remd_set_reaction_field
         d['rf_unshifted_switch_width'] = float(system.rf_unshifted_switch_width)

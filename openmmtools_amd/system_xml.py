@@ -20,7 +20,7 @@ other NonbondedForce parameter offsets) raise ``NotImplementedError`` naming the
 """
 import xml.etree.ElementTree as ET
 
-from .system import (System, HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce,
+from .system import (System, HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce, GBSAOBCForce,
                      CustomExternalForce, CMMotionRemover)
 
 
@@ -86,6 +86,13 @@ def _emit_force(forces, f, force_group=None, particles=None, exceptions=None, gl
             ET.SubElement(b, 'Particle', dict(index=str(idx)))
     elif isinstance(f, CMMotionRemover):
         ET.SubElement(forces, 'Force', dict(common, frequency=str(f.getFrequency()), version='1'))
+    elif isinstance(f, GBSAOBCForce):
+        # OpenMM's GBSAOBCForceProxy (external knowledge, unpinned like the custom forces of _alchemical_xml.py)
+        e = ET.SubElement(forces, 'Force', dict(common, method=str(f.getNonbondedMethod()), cutoff=_f(1.0), soluteDielectric=_f(f.getSoluteDielectric()),
+                                                solventDielectric=_f(f.getSolventDielectric()), surfaceAreaEnergy=_f(f.getSurfaceAreaEnergy()), version='2'))
+        b = ET.SubElement(e, 'Particles')
+        for (q, r, sc) in f.particles:
+            ET.SubElement(b, 'Particle', dict(q=_f(q), r=_f(r), scale=_f(sc)))
     else:
         raise NotImplementedError('unsupported force %r' % name)
 
@@ -212,6 +219,13 @@ def from_xml(text_or_path):
                 f.addParticle(int(b.get('index')), [])
         elif kind == 'CMMotionRemover':
             f = CMMotionRemover(int(e.get('frequency', '1')))
+        elif kind == 'GBSAOBCForce':
+            f = GBSAOBCForce()
+            f.setNonbondedMethod(int(e.get('method', '0')))
+            f.setSoluteDielectric(float(e.get('soluteDielectric', '1'))); f.setSolventDielectric(float(e.get('solventDielectric', '78.5')))
+            f.setSurfaceAreaEnergy(float(e.get('surfaceAreaEnergy', '2.25936')))
+            for b in _children(e, 'Particles', 'Particle'):
+                f.addParticle(float(b.get('q')), float(b.get('r')), float(b.get('scale')))
         elif kind == 'MonteCarloBarostat':
             barostat = dict(pressure=float(e.get('pressure')), temperature=float(e.get('temperature', '300')),
                             frequency=int(e.get('frequency', '25')))

@@ -232,6 +232,25 @@ class AlanineDipeptideVacuum(TestSystem):
         self.residue_names = [str(s) for s in z['residue_names']] if 'residue_names' in z.files else None
 
 
+class AlanineDipeptideImplicit(AlanineDipeptideVacuum):
+    """testsystems.py:3424-3462: the vacuum dipeptide + Generalized-Born implicit solvent.  The reference's default is app.OBC1, which
+    current OpenMM builds as a CustomGBForce from its own expression library (not in the reference's tree); what is built here is
+    ``implicitSolvent='OBC2'`` = openmm.GBSAOBCForce -- the force the reference's alchemical factory spells out term by term
+    (alchemy.py:2144-2225) -- with the topology's own GB radii and screening factors (prmtop RADII / SCREEN, mbondi2), solvent
+    dielectric 78.5, solute dielectric 1, ACE surface term."""
+
+    def __init__(self, implicitSolvent='OBC2', constraints='HBonds', hydrogenMass=None, **kwargs):
+        if implicitSolvent != 'OBC2':
+            raise NotImplementedError("implicitSolvent=%r: only 'OBC2' (openmm.GBSAOBCForce) is built" % (implicitSolvent,))
+        super().__init__(constraints=constraints, hydrogenMass=hydrogenMass, **kwargs)
+        from .system import GBSAOBCForce
+        z = np.load(os.path.join(_DATA, 'alanine-dipeptide-vacuum.npz'))
+        gb = GBSAOBCForce()
+        for q, r, sc in zip(z['charge'], z['gb_radii'], z['gb_screen']):
+            gb.addParticle(q, r, sc)
+        self.system.addForce(gb)
+
+
 class HostGuestExplicit(_AmberExplicit):
     """testsystems.py:3789-3857: CB7 + B2 guest + 1445 TIP3P waters, 4491 atoms."""
     _name = 'cb7-b2-explicit'

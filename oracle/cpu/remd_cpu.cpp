@@ -183,6 +183,8 @@ struct System {
     std::vector<double> bond_params, angle_params, torsion_params, exc_params;
     int method = 0; double rc = 0, rs = -1, rf_eps = 78.3, alpha = 0; int grid[3] = {0, 0, 0}; int use_disp = 0;
     bool annihilate = false;  // AlchemicalRegion.annihilate_sterics (remd_set_alchemical_options)
+    // GBSA (remd_set_gbsa): OBC2 + ACE as the reference's alchemical factory writes it (alchemy.py:2144-2225)
+    struct GB { int n = 0; std::vector<double> q, R, sc; std::vector<char> alch; double tau = 0; bool sasa = true; } gb;
     bool nocut = false;       // NonbondedForce.NoCutoff (REMD_NB_NOCUTOFF): every pair, no box; `method` stays 0 (nothing periodic)
     bool rf_unshifted = false; double rf_switch_width = 0;   // remd_set_reaction_field: c_rf = 0, pair term switched (forces.py:1110-1150)
     double rcc = 0;       // range of the Ewald direct-space sum (remd_set_coulomb_cutoff); = rc unless the host split the sum elsewhere
@@ -619,6 +621,70 @@ double region_energy(const System& s, const Replica& r, int state, double* f)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// GBSA: OBC2 Born radii + ACE surface term, the expressions of alchemy.py:2144-2225; lam = lambda_electrostatics of the alchemical particles
+// ------------------------------------------------------------------------------------------------------------------
+static inline void gb_H(double r, double or1, double sr2, double& H, double& dH)
+{
+    H = dH = 0.0;
+    if (r + sr2 - or1 < 0) return;
+    const double U = r + sr2, D = fabs(r - sr2);
+    const bool moving = D > or1;
+    const double L = moving ? D : or1, dL = moving ? (r > sr2 ? 1.0 : -1.0) : 0.0;
+    const bool inside = sr2 - r - or1 >= 0;
+    const double C = inside ? 2.0 * (1.0 / or1 - 1.0 / L) : 0.0, dC = inside ? 2.0 * dL / (L * L) : 0.0;
+    const double a = 1.0 / (U * U) - 1.0 / (L * L), w = r - sr2 * sr2 / r, lg = log(L / U);
+    H = 0.5 * (1.0 / L - 1.0 / U + 0.25 * w * a + 0.5 * lg / r + C);
+    dH = 0.5 * (-dL / (L * L) + 1.0 / (U * U) + 0.25 * (1.0 + sr2 * sr2 / (r * r)) * a + 0.25 * w * (-2.0 / (U * U * U) + 2.0 * dL / (L * L * L))
+                + 0.5 * ((dL / L - 1.0 / U) / r - lg / (r * r)) + dC);
+}
+double gb_energy(const System& s, const double* x, double lam, double* f)
+{
+    const System::GB& g = s.gb;
+    const int N = g.n;
+    const double KE = 138.935485, OFF = 0.009, SA = 28.3919551;
+    std::vector<double> sf(N), orr(N), sr(N), B(N), dBdI(N), dEdB(N, 0.0);
+    for (int i = 0; i < N; ++i) { sf[i] = g.alch[i] ? lam : 1.0; orr[i] = g.R[i] - OFF; sr[i] = g.sc[i] * orr[i]; }
+    auto dist = [&](int i, int j, double d[3]) { for (int k = 0; k < 3; ++k) d[k] = x[3 * j + k] - x[3 * i + k]; return sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); };
+    for (int i = 0; i < N; ++i) {
+        double I = 0;
+        for (int j = 0; j < N; ++j) if (j != i) { double d[3], H, dH; gb_H(dist(i, j, d), orr[i], sr[j], H, dH); I += sf[j] * H; }
+        const double psi = I * orr[i], P = psi - 0.8 * psi * psi + 4.85 * psi * psi * psi, th = tanh(P);
+        B[i] = 1.0 / (1.0 / orr[i] - th / g.R[i]);
+        dBdI[i] = B[i] * B[i] * (1.0 - th * th) * (1.0 - 1.6 * psi + 14.55 * psi * psi) * orr[i] / g.R[i];
+    }
+    double E = 0;
+    for (int i = 0; i < N; ++i) {
+        E += -0.5 * KE * g.tau * sf[i] * g.q[i] * g.q[i] / B[i];
+        dEdB[i] += 0.5 * KE * g.tau * sf[i] * g.q[i] * g.q[i] / (B[i] * B[i]);
+        if (g.sasa) {
+            const double rb = g.R[i] / B[i], rb6 = rb * rb * rb * rb * rb * rb, pre = sf[i] * SA * (g.R[i] + 0.14) * (g.R[i] + 0.14);
+            E += pre * rb6; dEdB[i] += -6.0 * pre * rb6 / B[i];
+        }
+    }
+    for (int i = 0; i < N; ++i) for (int j = i + 1; j < N; ++j) {
+        double d[3]; const double r = dist(i, j, d);
+        const double D = B[i] * B[j], ex = exp(-r * r / (4.0 * D)), f2 = r * r + D * ex, ff = sqrt(f2);
+        const double QQ = KE * g.tau * sf[i] * g.q[i] * sf[j] * g.q[j];
+        E += -QQ / ff;
+        // d(-QQ/f) = QQ / f^2 df;  df/dr = (r - r ex / 4) / f;  df/dD = ex (1 + r^2 / (4 D)) / (2 f)
+        const double dEdf = QQ / f2;
+        const double dfdD = ex * (1.0 + r * r / (4.0 * D)) / (2.0 * ff);
+        dEdB[i] += dEdf * dfdD * B[j]; dEdB[j] += dEdf * dfdD * B[i];
+        if (f) { const double gr = dEdf * (r - 0.25 * r * ex) / ff / r; for (int k = 0; k < 3; ++k) { f[3 * i + k] += gr * d[k]; f[3 * j + k] -= gr * d[k]; } }
+    }
+    if (f) {
+        // the chain through the Born radii: dE/dB_i dB_i/dI_i s_j H'(r; or_i, sr_j) on the pair (i, j), from both sides
+        for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) if (j != i) {
+            double d[3], H, dH; const double r = dist(i, j, d);
+            gb_H(r, orr[i], sr[j], H, dH);
+            const double gr = dEdB[i] * dBdI[i] * sf[j] * dH / r;          // dE/dr of this contribution, over r
+            for (int k = 0; k < 3; ++k) { f[3 * i + k] += gr * d[k]; f[3 * j + k] -= gr * d[k]; }
+        }
+    }
+    return E;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // potential energy and forces of one replica at (lambda_sterics, lambda_electrostatics)
 //   parts: which contributions to evaluate (the u_kl assembly re-evaluates only what a lambda changes)
 // ------------------------------------------------------------------------------------------------------------------
@@ -732,6 +798,11 @@ Energy evaluate(const System& s, Replica& r, double lam_s, double lam_e, double*
             }
         }
         if (s.reg.n > 0 && region_state >= 0 && region_state < s.reg.K && (classes & 16) && (parts & PART_SOFTCORE)) E.c[8] += region_energy(s, r, region_state, f);
+        if (s.gb.n > 0 && (classes & 16) && (parts & PART_ELEC)) {
+            // lambda_electrostatics of the alchemical particles: region 1 of the state (the factory's GBSA knows one region, alchemy.py:2168-2171)
+            const double lam_gb = (s.reg.n > 0 && region_state >= 0 && region_state < s.reg.K) ? s.reg.le[(size_t)region_state * s.reg.n] : lam_e;
+            E.c[8] += gb_energy(s, x, lam_gb, f);
+        }
         return E;
     }
     if (!periodic) return E;
@@ -1243,11 +1314,12 @@ static double ukl_row(remd_ctx* h, int r, double* row)
     for (int k = 0; k < K; ++k) if (h->lam_s[k] != h->lam_s[0] || h->lam_e[k] != h->lam_e[0]) lam_varies = true;
     if (s.reg.n > 0) {
         // general alchemical regions: everything but the custom forces once, the custom forces at every state's lambdas
-        const double base = s.reg.exact ? 0.0 : evaluate(s, rep, 1.0, 1.0, nullptr, fft).total();
+        const bool whole = s.reg.exact || s.gb.n > 0;          // (GBSA: not a polynomial in lambda -- one evaluation per state too)
+        const double base = whole ? 0.0 : evaluate(s, rep, 1.0, 1.0, nullptr, fft).total();
         double U_own = 0;
         for (int k = 0; k < K; ++k) {
             // (exact PME treatment: the whole Ewald sum depends on the state's lambda_electrostatics -- one evaluation per state)
-            const double U = s.reg.exact ? evaluate(s, rep, 1.0, 1.0, nullptr, fft, PART_ALL, 63, k).total() : base + region_energy(s, rep, k, nullptr);
+            const double U = whole ? evaluate(s, rep, 1.0, 1.0, nullptr, fft, PART_ALL, 63, k).total() : base + region_energy(s, rep, k, nullptr);
             row[k] = h->beta[k] * (U + h->econst[k] * cscale + (h->pressure.empty() ? 0.0 : h->pressure[k] * V));
             if (k == own) U_own = U;
         }
@@ -1766,6 +1838,25 @@ int remd_set_region_bonded_lambdas(remd_handle h, int K, int n_regions, const do
         g.bl[((size_t)k * 3 + q) * g.n + r] = v;
     }
     for (auto& r : h->reps) r.f_valid = false;
+    return 0;
+}
+
+int remd_set_gbsa(remd_handle h, const remd_gbsa_desc* d)
+{
+    if (!h) return fail(h, -1, "remd_set_gbsa: NULL handle");
+    h->sys.gb = System::GB();
+    for (auto& r : h->reps) r.f_valid = false;
+    if (!d) return 0;
+    if (!h->has_system || !h->sys.nocut) return fail(h, -3, "remd_set_gbsa: GBSA needs a system with a NoCutoff NonbondedForce (call remd_set_system first)");
+    if (d->n_atoms != h->sys.N || !d->charge || !d->radius || !d->scale || !(d->solute_dielectric > 0) || !(d->solvent_dielectric > 0)) return fail(h, -1, "remd_set_gbsa: bad arguments");
+    System::GB g;
+    g.n = d->n_atoms;
+    g.q.assign(d->charge, d->charge + g.n); g.R.assign(d->radius, d->radius + g.n); g.sc.assign(d->scale, d->scale + g.n);
+    g.alch.assign(g.n, 0);
+    for (int i = 0; i < g.n; ++i) { if (!(g.R[i] > 0.009)) return fail(h, -1, "remd_set_gbsa: radii must exceed the offset 0.009 nm"); if (d->alchemical && d->alchemical[i]) g.alch[i] = 1; }
+    g.tau = 1.0 / d->solute_dielectric - 1.0 / d->solvent_dielectric;
+    g.sasa = d->surface_area != 0;
+    h->sys.gb = std::move(g);
     return 0;
 }
 

@@ -1,0 +1,138 @@
+"""GBSA implicit solvent (OBC2 + ACE) of NoCutoff systems: openmm.GBSAOBCForce in the form the reference's alchemical factory spells out
+(/root/reference/openmmtools/alchemy/alchemy.py:2144-2225, _alchemically_modify_GBSAOBCForce), alchemical and not.
+
+  * oracle/gbsa.py (f64) reproduces the VALUES of the reference's own CustomGBForce expression strings -- computed values I, B and the energy --
+    on random small systems at three lambda (tests/golden/reference_gbsa.json, made by tests/golden/make_golden_gbsa.py from the reference's
+    syntax tree + an interpreter of the CustomGBForce semantics);
+  * the C++ build of the ABI (analytic forces through the Born radii) and -- under -m gpu -- the HIP kernels (csrc/gbsa.hip) against that
+    oracle (autograd forces) on the implicit-solvent dipeptide: potential, u_kl over a lambda ladder, forces, a short propagation.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.forcefield import ForceFieldOracle
+from oracle.gbsa import gbsa_energy_torch, gbsa_energy_forces
+from oracle.alchemical_regions import total_state_energies, total_energy_forces
+from openmmtools_amd import alchemy, states, mcmc, unit, system_xml, testsystems as ts
+from openmmtools_amd.system import system_to_desc, GBSAOBCForce
+from openmmtools_amd._engine import HipEngine
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, 'golden', 'reference_gbsa.json')))
+KB = 0.008314462618153242
+CPU_LIB = os.path.join(os.path.dirname(os.path.abspath(oracle.__file__)), '_build', 'libremd_cpu.so')
+
+
+def test_oracle_reproduces_the_references_custom_gb_expressions():
+    assert len(G['cases']) == 6 and [c[0] for c in G['computed_values']] == ['I', 'B'] and len(G['energy_terms']) == 3
+    for c in G['cases']:
+        e, I, B = gbsa_energy_torch(torch.tensor(c['x'], dtype=torch.float64), c['charge'], c['radius'], c['scale'], c['alchemical'],
+                                    c['lambda_electrostatics'], c['soluteDielectric'], c['solventDielectric'], return_parts=True)
+        assert np.isclose(float(e), c['energy'], rtol=1e-13) and np.allclose(I.numpy(), c['I'], rtol=1e-13) and np.allclose(B.numpy(), c['B'], rtol=1e-13)
+    assert G['globals_in_the_function'] == {'lambda_electrostatics': 1.0, 'offset': 0.009}
+
+
+def _gb_total(desc, x, le, forces=True):
+    d0 = dict(desc)
+    gb = d0.pop('gbsa')
+    e1, f1 = gbsa_energy_forces(x, gb['charge'], gb['radius'], gb['scale'], gb['alchemical'], le, gb['solute_dielectric'], gb['solvent_dielectric'],
+                                sasa=bool(gb['surface_area']), forces=forces)
+    return d0, e1, f1
+
+
+def _check_plain(eng, rtol, ftol):
+    al = ts.AlanineDipeptideImplicit()
+    assert sum(isinstance(f, GBSAOBCForce) for f in al.system.getForces()) == 1
+    desc = system_to_desc(al.system)
+    assert desc['nb_method'] == 3 and desc['gbsa']['surface_area'] == 1 and np.all(desc['gbsa']['alchemical'] == 0)
+    eng.set_system(desc)
+    T = np.array([300.0, 350.0])
+    eng.set_states(1.0 / (KB * T))
+    eng.set_integrator('V R O R V', 0.002, 1.0, 25, True, 1e-8)
+    eng.seed(6)
+    x = np.stack([al.positions + 0.003 * (r + 1) * np.random.default_rng(r).normal(size=al.positions.shape) for r in range(2)])
+    eng.set_replicas(2, 0, x, None, np.zeros((2, 3)), np.arange(2))
+    rows, U = eng.compute_energies(want_potential=True)
+    xd = eng.get_replicas()[0]
+    f = eng.get_forces()
+    for r in range(2):
+        d0, e1, f1 = _gb_total(desc, xd[r], 1.0)
+        e0, f0 = ForceFieldOracle(d0).energy_forces(xd[r], None)
+        assert e1 < -20.0                                            # tens of kJ/mol of solvation
+        assert np.isclose(U[r], e0 + e1, rtol=rtol, atol=rtol * 100.0), (U[r], e0 + e1)
+        assert np.allclose(rows[r], (e0 + e1) / (KB * T), rtol=rtol, atol=rtol * 100.0)
+        assert np.abs(f[r] - (f0 + f1)).max() < ftol * np.abs(f0 + f1).max()
+    assert not np.any(eng.propagate(0))
+    assert np.all(np.isfinite(eng.compute_energies()))
+    return eng
+
+
+LS = np.array([[1.0], [1.0], [0.5], [0.0]])
+LE = np.array([[1.0], [0.4], [0.0], [0.0]])
+
+
+def _check_alchemical(eng, rtol, ftol):
+    """the factory on an implicit-solvent System: the NonbondedForce's custom forces (general-regions path, NoCutoff) and the GB terms with
+    lambda_electrostatics on the alchemical particles (alchemy.py:2195-2210)"""
+    al = ts.AlanineDipeptideImplicit()
+    system = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, alchemy.AlchemicalRegion(alchemical_atoms=range(6)))
+    desc = system_to_desc(system)
+    assert desc['gbsa']['alchemical'].tolist() == [1] * 6 + [0] * 16 and desc['alch_regions']['electrostatics'] == 1
+    eng.set_system(desc)
+    beta = 1.0 / (KB * 300.0)
+    eng.set_states(np.full(4, beta))
+    eng.set_region_lambdas(LS, LE)
+    eng.set_integrator('V R O R V', 0.002, 1.0, 10, True, 1e-8)
+    eng.seed(8)
+    labels = np.array([1, 2, 3])
+    x = np.stack([al.positions + 0.003 * (r + 1) * np.random.default_rng(r).normal(size=al.positions.shape) for r in range(3)])
+    eng.set_replicas(3, 0, x, None, np.zeros((3, 3)), labels)
+    rows, U = eng.compute_energies(want_potential=True)
+    xd = eng.get_replicas()[0]
+    f = eng.get_forces()
+    for r, k in enumerate(labels):
+        d0 = dict(desc); d0.pop('gbsa')
+        ref = total_state_energies(d0, xd[r], None, LS, LE) + np.array([_gb_total(desc, xd[r], LE[q, 0], forces=False)[1] for q in range(4)])
+        assert np.ptp(ref) > 10.0
+        assert np.allclose(rows[r], beta * ref, rtol=rtol, atol=rtol * np.abs(beta * ref).max()), np.abs(rows[r] - beta * ref).max()
+        assert np.isclose(U[r], ref[k], rtol=rtol, atol=rtol * np.abs(ref).max())
+        f_ref = total_energy_forces(d0, xd[r], None, LS[k], LE[k])[1] + _gb_total(desc, xd[r], LE[k, 0])[2]
+        assert np.abs(f[r] - f_ref).max() < ftol * np.abs(f_ref).max()
+    assert not np.any(eng.propagate(0))
+    return eng
+
+
+def test_cpu_port_evaluates_the_implicit_solvent_dipeptide_like_the_oracle():
+    if not os.path.exists(CPU_LIB):
+        oracle.build()
+    _check_plain(HipEngine(lib_path=CPU_LIB), 1e-10, 1e-9).close()
+    _check_alchemical(HipEngine(lib_path=CPU_LIB), 1e-10, 1e-9).close()
+
+
+@pytest.mark.gpu
+def test_hip_evaluates_the_implicit_solvent_dipeptide_like_the_oracle(hip_engine_factory):
+    _check_plain(hip_engine_factory(), 5e-6, 2e-4)
+
+
+@pytest.mark.gpu
+def test_hip_alchemical_implicit_solvent_dipeptide(hip_engine_factory):
+    _check_alchemical(hip_engine_factory(), 1e-5, 2e-4)
+
+
+def test_gbsa_force_in_a_system_document_and_what_is_refused():
+    al = ts.AlanineDipeptideImplicit()
+    back, _ = system_xml.from_xml(system_xml.to_xml(al.system))
+    assert back.fingerprint() == al.system.fingerprint()
+    with pytest.raises(NotImplementedError, match='OBC2'):
+        ts.AlanineDipeptideImplicit(implicitSolvent='OBC1')
+    two = [alchemy.AlchemicalRegion(alchemical_atoms=range(6), name='a'), alchemy.AlchemicalRegion(alchemical_atoms=range(6, 16), name='b')]
+    with pytest.raises(NotImplementedError, match='Multiple regions does not work with GBSAOBCForce'):          # alchemy.py:2168-2169
+        alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, two)
+    marked = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, alchemy.AlchemicalRegion(alchemical_atoms=range(6)))
+    with pytest.raises(NotImplementedError, match='CustomGBForce'):
+        system_xml.to_xml(marked)

@@ -107,8 +107,8 @@ def test_reads_a_document_in_openmm_layout(tmp_path):
 
 
 def test_unsupported_content_is_refused_by_name():
-    with pytest.raises(NotImplementedError, match='GBSAOBCForce'):
-        system_xml.from_xml('<System><Particles/><Forces><Force type="GBSAOBCForce"/></Forces></System>')
+    with pytest.raises(NotImplementedError, match='CustomGBForce'):
+        system_xml.from_xml('<System><Particles/><Forces><Force type="CustomGBForce"/></Forces></System>')
     # offsets are understood as the alchemical factory's lambda_electrostatics only (_alchemical_xml.py)
     with pytest.raises(NotImplementedError, match="offset parameter 'l'"):
         system_xml.from_xml('<System><Forces><Force type="NonbondedForce" method="0" cutoff="1"><ParticleOffsets>'

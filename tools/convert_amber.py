@@ -53,6 +53,11 @@ for name, top, crd in JOBS:
     )
     if vel is not None:
         out['velocities'] = vel
+    if 'RADII' in prm and 'SCREEN' in prm:
+        # Generalized-Born radii (nm) and screening factors of the topology (prmtop RADIUS_SET): what prmtop.createSystem(implicitSolvent=...) hands
+        # GBSAOBCForce.addParticle(charge, radius, scale)
+        out['gb_radii'] = np.array(prm['RADII'][:n], dtype=np.float64) * 0.1
+        out['gb_screen'] = np.array(prm['SCREEN'][:n], dtype=np.float64)
     path = os.path.join(ROOT, 'openmmtools_amd', 'data', name + '.npz')
     np.savez_compressed(path, **out)
     print(name, 'atoms', n, 'bonds', len(bf.bonds), 'angles', len(af.angles), 'torsions', len(tf.torsions),
