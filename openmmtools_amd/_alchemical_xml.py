@@ -262,13 +262,86 @@ def _emit_custom_bonded(forces, group, kind, energy, per, lam, terms):
     return e
 
 
+# ---- alchemical GBSA: the CustomGBForce the factory builds from a GBSAOBCForce (alchemy.py:2172-2225), its strings verbatim -----------------
+_GB_I = ("(lambda_electrostatics*alchemical2 + (1-alchemical2))*step(r+sr2-or1)*0.5*(1/L-1/U+0.25*(r-sr2^2/r)*(1/(U^2)-1/(L^2))+0.5*log(L/U)/r+C);"
+         "U=r+sr2;"
+         "C=2*(1/or1-1/L)*step(sr2-r-or1);"
+         "L=max(or1, D);"
+         "D=abs(r-sr2);"
+         "sr2 = scale2*or2;"
+         "or1 = radius1-offset; or2 = radius2-offset")
+_GB_B = ("1/(1/or-tanh(psi-0.8*psi^2+4.85*psi^3)/radius);"
+         "psi=I*or; or=radius-offset")
+_GB_SELF = "-0.5*138.935485*(1/soluteDielectric-1/solventDielectric)*(lambda_electrostatics*alchemical+(1-alchemical))*charge^2/B"
+_GB_SURFACE = "(lambda_electrostatics*alchemical+(1-alchemical))*28.3919551*(radius+0.14)^2*(radius/B)^6"
+_GB_PAIR = ("-138.935485*(1/soluteDielectric-1/solventDielectric)*(lambda_electrostatics*alchemical1+(1-alchemical1))*charge1*(lambda_electrostatics*alchemical2+(1-alchemical2))*charge2/f;"
+            "f=sqrt(r^2+B1*B2*exp(-r^2/(4*B1*B2)))")
+# OpenMM's CustomGBForce::ComputationType
+_GB_SINGLE, _GB_PAIR_NOEXCL = 0, 2
+
+
+def _emit_custom_gb(forces, group, gb, alchemical_atoms):
+    """CustomGBForce element (OpenMM's CustomGBForceProxy layout: external knowledge, unpinned like the other custom forces here)"""
+    e = ET.SubElement(forces, 'Force', dict(forceGroup=str(group), name='CustomGBForce', type='CustomGBForce', method=str(gb.getNonbondedMethod()),
+                                            cutoff=_f(1.0), version='2'))
+    b = ET.SubElement(e, 'PerParticleParameters')
+    for n in ('charge', 'radius', 'scale', 'alchemical'):
+        ET.SubElement(b, 'Parameter', dict(name=n))
+    g = ET.SubElement(e, 'GlobalParameters')
+    for n, v in (('lambda_electrostatics', 1.0), ('solventDielectric', gb.getSolventDielectric()), ('soluteDielectric', gb.getSoluteDielectric()), ('offset', 0.009)):
+        ET.SubElement(g, 'Parameter', dict(default=_f(v), name=n))
+    ET.SubElement(e, 'EnergyParameterDerivatives')
+    b = ET.SubElement(e, 'Particles')
+    A = set(alchemical_atoms)
+    for k, (q, r, sc) in enumerate(gb.particles):
+        ET.SubElement(b, 'Particle', dict(param1=_f(q), param2=_f(r), param3=_f(sc), param4=_f(1.0 if k in A else 0.0)))
+    ET.SubElement(e, 'Exclusions'); ET.SubElement(e, 'Functions')
+    b = ET.SubElement(e, 'ComputedValues')
+    ET.SubElement(b, 'Value', dict(name='I', expression=_GB_I, type=str(_GB_PAIR_NOEXCL)))
+    ET.SubElement(b, 'Value', dict(name='B', expression=_GB_B, type=str(_GB_SINGLE)))
+    b = ET.SubElement(e, 'EnergyTerms')
+    ET.SubElement(b, 'Term', dict(expression=_GB_SELF, type=str(_GB_SINGLE)))
+    if gb.getSurfaceAreaEnergy() != 0.0:
+        ET.SubElement(b, 'Term', dict(expression=_GB_SURFACE, type=str(_GB_SINGLE)))
+    ET.SubElement(b, 'Term', dict(expression=_GB_PAIR, type=str(_GB_PAIR_NOEXCL)))
+    return e
+
+
+def parse_custom_gb(e):
+    return dict(type='CustomGBForce', energy='', group=int(e.get('forceGroup', '0')), attrs=dict(e.attrib),
+                globals={g.get('name'): float(g.get('default')) for g in _kids(e, 'GlobalParameters')},
+                per=[p.get('name') for p in _kids(e, 'PerParticleParameters')], particles=[_params(p) for p in _kids(e, 'Particles')],
+                values=[(v.get('name'), v.get('expression'), int(v.get('type'))) for v in _kids(e, 'ComputedValues')],
+                terms=[(t.get('expression'), int(t.get('type'))) for t in _kids(e, 'EnergyTerms')])
+
+
+def gbsa_from_custom_gb(c):
+    """the GBSAOBCForce a parsed alchemical CustomGBForce came from + its alchemical atoms (only the factory's own expressions are understood)"""
+    from .system import GBSAOBCForce
+    compact = lambda s: s.replace(' ', '')
+    if c['per'] != ['charge', 'radius', 'scale', 'alchemical'] or [compact(v[1]) for v in c['values']] != [compact(_GB_I), compact(_GB_B)]:
+        raise NotImplementedError('CustomGBForce other than the alchemical factory\'s GBSA (OBC2): %s' % (c['values'][0][1][:60] if c['values'] else '-'))
+    terms = [compact(t[0]) for t in c['terms']]
+    if terms not in ([compact(_GB_SELF), compact(_GB_SURFACE), compact(_GB_PAIR)], [compact(_GB_SELF), compact(_GB_PAIR)]):
+        raise NotImplementedError('CustomGBForce energy terms other than the alchemical factory\'s GBSA')
+    gb = GBSAOBCForce()
+    gb.setNonbondedMethod(int(c['attrs'].get('method', '0')))
+    gb.setSolventDielectric(c['globals'].get('solventDielectric', 78.5)); gb.setSoluteDielectric(c['globals'].get('soluteDielectric', 1.0))
+    gb.setSurfaceAreaEnergy(2.25936 if len(terms) == 3 else 0.0)
+    atoms = []
+    for k, p in enumerate(c['particles']):
+        gb.addParticle(p[0], p[1], p[2])
+        if p[3] != 0.0:
+            atoms.append(k)
+    return gb, atoms
+
+
 def emit_region_forces(forces, system, emit_plain):
     """The force set of a System in the general-regions mode (``system.alchemical_regions``): the reference's loop over
     single_regions + pair_regions (alchemy.py:1693-2036) restated on plain tables -- INCLUDING its order of reading and zeroing the
     NonbondedForce's parameters, which decides what the later forces' particle tables hold (:1886-1911, 2001-2006)."""
     from .system import GBSAOBCForce
-    if any(isinstance(f, GBSAOBCForce) for f in system.getForces()):
-        raise NotImplementedError('an alchemical System with GBSA in a store (the factory\'s CustomGBForce, alchemy.py:2172-2225, is not written)')
+    gbs = [f for f in system.getForces() if isinstance(f, GBSAOBCForce)]
     regions = system.alchemical_regions
     opts = system.alchemical_factory_options
     terms = system.alchemical_region_terms
@@ -392,7 +465,9 @@ def emit_region_forces(forces, system, emit_plain):
                 by_lambda.setdefault(name, []).append(('bonded', dict(kind=kind, energy=expr % name, per=per, lam=name,
                                                                       terms=[(tuple(int(a) for a in atoms[k]), tuple(float(v) for v in terms[kind + '_params'][k])) for k in sel])))
     # ---- order and force groups (:1052-1083) ------------------------------------------------------------------------
-    untouched = [f for f in all_forces if not isinstance(f, _REMODELLED)]
+    for gb in gbs:                                                           # the factory's CustomGBForce joins the lambda_electrostatics forces (:2225)
+        by_lambda.setdefault('lambda_electrostatics' + suffix(regions[0]), []).append(('gb', dict(gb=gb, alchemical_atoms=regions[0].alchemical_atoms)))
+    untouched = [f for f in all_forces if not isinstance(f, _REMODELLED) and not isinstance(f, GBSAOBCForce)]
     readded = [f for f in all_forces if isinstance(f, _REMODELLED) and (not isinstance(f, NonbondedForce) or not exact)]
     free = sorted(set(range(32)) - {f.getForceGroup() for f in untouched + readded})
     if len(free) < len(by_lambda):
@@ -417,6 +492,8 @@ def emit_region_forces(forces, system, emit_plain):
                 _emit_custom_nonbonded(forces, group, kw.pop('energy'), kw.pop('per_params'), kw.pop('lam_globals'), **kw)
             elif kind == 'bonded':
                 _emit_custom_bonded(forces, group, **kw)
+            elif kind == 'gb':
+                _emit_custom_gb(forces, group, **kw)
             else:
                 _emit_custom_bond(forces, group, kw['energy'], kw['per_params'], kw['lam_globals'], kw['region'], kw['bonds'])
         if exact and key == last_key:
@@ -475,7 +552,7 @@ def rebuild_marked_system(system, nb, global_parameters, particle_offsets, excep
     electro = [c for c in customs if 'U_electrostatics' in c['energy']]
     rf = [c for c in customs if compact(c['energy']).startswith(compact(_RF_HEAD)) and c['type'] == 'CustomNonbondedForce']
     bonded = [c for c in customs if re.match(r'lambda_(bonds|angles|torsions)\w*\*', compact(c['energy']))]
-    other = [c for c in customs if c not in sterics + electro + rf + bonded]
+    other = [c for c in customs if c not in sterics + electro + rf + bonded and c['type'] != 'CustomGBForce']
     if other:
         raise NotImplementedError('custom force outside the alchemical factory\'s set: %s' % other[0]['energy'][:60])
     for name in list(global_parameters) + [p[0] for p in particle_offsets + exception_offsets]:
@@ -569,6 +646,8 @@ def _lambda_names(c):
 def needs_general_reader(nb, global_parameters, particle_offsets, exception_offsets, customs):
     """True when the document holds more than the one unnamed region under the exact PME treatment / without alchemical charges that
     rebuild_marked_system undoes itself"""
+    if any(c['type'] == 'CustomGBForce' for c in customs) or nb.getNonbondedMethod() == NonbondedForce.NoCutoff:
+        return True
     if any(re.match(r'lambda_(bonds|angles|torsions)', c['energy'].replace(' ', '')) for c in customs):
         return True
     names = set(global_parameters) | {p[0] for p in particle_offsets + exception_offsets}
@@ -594,6 +673,10 @@ def rebuild_general_system(system, nb, global_parameters, particle_offsets, exce
     System it returns replaces ``system``."""
     from .alchemy import AlchemicalRegion, AbsoluteAlchemicalFactory
     compact = lambda s: s.replace(' ', '')
+    for c in [c for c in customs if c['type'] == 'CustomGBForce']:            # the alchemical GBSA: back to the GBSAOBCForce it came from
+        gb, gb_atoms = gbsa_from_custom_gb(c)
+        system.addForce(gb)
+    customs = [c for c in customs if c['type'] != 'CustomGBForce']
     sterics = [c for c in customs if 'U_sterics' in c['energy']]
     electro = [c for c in customs if 'U_electrostatics' in c['energy']]
     rf = [c for c in customs if compact(c['energy']).startswith(compact(_RF_HEAD)) and c['type'] == 'CustomNonbondedForce']

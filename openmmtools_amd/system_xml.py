@@ -209,6 +209,10 @@ def from_xml(text_or_path):
             from . import _alchemical_xml
             customs.append(_alchemical_xml.parse_custom(e))        # only as the pieces of an alchemically modified System
             continue
+        elif kind == 'CustomGBForce' and e.find('ComputedValues') is not None:
+            from . import _alchemical_xml
+            customs.append(_alchemical_xml.parse_custom_gb(e))     # the alchemical factory's GBSA (alchemy.py:2172-2225)
+            continue
         elif kind == 'CustomExternalForce':
             if _nonempty(e, 'PerParticleParameters'):
                 raise NotImplementedError('CustomExternalForce with per-particle parameters')

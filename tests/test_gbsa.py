@@ -133,6 +133,17 @@ def test_gbsa_force_in_a_system_document_and_what_is_refused():
     two = [alchemy.AlchemicalRegion(alchemical_atoms=range(6), name='a'), alchemy.AlchemicalRegion(alchemical_atoms=range(6, 16), name='b')]
     with pytest.raises(NotImplementedError, match='Multiple regions does not work with GBSAOBCForce'):          # alchemy.py:2168-2169
         alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, two)
+    # the alchemical System: the factory's CustomGBForce with the reference's strings, verbatim, in the lambda_electrostatics force group
+    from openmmtools_amd import _alchemical_xml as ax
+    assert [ax._GB_I, ax._GB_B] == [v[1] for v in G['computed_values']] and [ax._GB_SELF, ax._GB_SURFACE, ax._GB_PAIR] == [t[0] for t in G['energy_terms']]
+    assert [v[2] for v in G['computed_values']] == ['ParticlePairNoExclusions', 'SingleParticle']
     marked = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, alchemy.AlchemicalRegion(alchemical_atoms=range(6)))
-    with pytest.raises(NotImplementedError, match='CustomGBForce'):
-        system_xml.to_xml(marked)
+    xml = system_xml.to_xml(marked)
+    import xml.etree.ElementTree as ET
+    forces = ET.fromstring(xml).find('Forces').findall('Force')
+    cgb = [f for f in forces if f.get('type') == 'CustomGBForce']
+    assert len(cgb) == 1 and not [f for f in forces if f.get('type') == 'GBSAOBCForce']
+    elec_group = [f.get('forceGroup') for f in forces if 'U_electrostatics' in f.get('energy', '')]
+    assert cgb[0].get('forceGroup') == elec_group[0] and [p.get('param4') for p in cgb[0].find('Particles')][:7] == ['1.0'] * 6 + ['0.0']
+    back, _ = system_xml.from_xml(xml)
+    assert back.fingerprint() == marked.fingerprint()
