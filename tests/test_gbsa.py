@@ -147,3 +147,45 @@ def test_gbsa_force_in_a_system_document_and_what_is_refused():
     assert cgb[0].get('forceGroup') == elec_group[0] and [p.get('param4') for p in cgb[0].find('Particles')][:7] == ['1.0'] * 6 + ['0.0']
     back, _ = system_xml.from_xml(xml)
     assert back.fingerprint() == marked.fingerprint()
+
+
+def _alchemical_implicit_sampler(engine, n_iterations):
+    from openmmtools_amd.multistate import ReplicaExchangeSampler
+    al = ts.AlanineDipeptideImplicit()
+    asys = alchemy.AbsoluteAlchemicalFactory().create_alchemical_system(al.system, alchemy.AlchemicalRegion(alchemical_atoms=range(6)))
+    ths = [states.CompoundThermodynamicState(states.ThermodynamicState(asys, 300.0 * unit.kelvin),
+                                             [states.AlchemicalState(lambda_sterics=float(ls), lambda_electrostatics=float(le))]) for ls, le in zip(LS[:, 0], LE[:, 0])]
+    move = mcmc.LangevinSplittingDynamicsMove(timestep=2.0 * unit.femtosecond, n_steps=10, reassign_velocities=True, splitting='V R O R V')
+    s = ReplicaExchangeSampler(mcmc_moves=move, number_of_iterations=n_iterations, engine=engine, seed=12, online_analysis_interval=None)
+    s.create(ths, [states.SamplerState(al.positions)], storage=None)
+    return s, asys
+
+
+def _check_sampler(s, asys, rtol):
+    s._compute_energies()
+    desc = system_to_desc(asys)
+    x = s._engine.get_replicas()[0]
+    d0 = dict(desc); d0.pop('gbsa')
+    for r in range(4):
+        ref = total_state_energies(d0, x[r], None, LS, LE) + np.array([_gb_total(desc, x[r], LE[q, 0], forces=False)[1] for q in range(4)])
+        ref = ref / (KB * 300.0)
+        assert np.allclose(s.energy_thermodynamic_states[r], ref, rtol=rtol, atol=rtol * np.abs(ref).max())
+    s.run()
+    assert np.all(np.isfinite(s.energy_thermodynamic_states))
+
+
+def test_replica_exchange_over_an_alchemical_ladder_in_implicit_solvent_on_the_cpu_port():
+    """the sampler end to end on an alchemical GBSA System: one unsuffixed AlchemicalState per state reaches the custom forces AND the GB
+    terms (region 1's lambda_electrostatics), u_kl of the first energy pass against the oracle, then iterations with swaps"""
+    if not os.path.exists(CPU_LIB):
+        oracle.build()
+    s, asys = _alchemical_implicit_sampler(HipEngine(lib_path=CPU_LIB), 3)
+    _check_sampler(s, asys, 1e-9)
+    assert s.iteration == 3
+
+
+@pytest.mark.gpu
+def test_replica_exchange_over_an_alchemical_ladder_in_implicit_solvent_on_the_device(hip_engine_factory):
+    s, asys = _alchemical_implicit_sampler(hip_engine_factory(), 4)
+    _check_sampler(s, asys, 2e-5)
+    assert s.iteration == 4
