@@ -608,3 +608,35 @@ def test_switched_reaction_field_of_the_whole_system_on_the_cpu_port():
 def test_switched_reaction_field_of_the_whole_system_on_the_device(hip_engine_factory):
     eng = _check_switched_reaction_field(hip_engine_factory(), 2e-5, 2e-4)
     assert not np.any(eng.propagate(0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [dict(), dict(alchemical_pme_treatment='direct-space')])
+def test_velocity_verlet_conserves_energy_on_a_system_with_regions(hip_engine_factory, kw):
+    """forces and energies of the custom-forces launch belong together dynamically: 'V R V' (no thermostat) at 1 fs on solvated alanine
+    dipeptide with two regions at intermediate lambdas conserves K + U to a small fraction of kT per degree of freedom over 0.4 ps (the bar of
+    test_energy_drift_bounds_the_constraint_solver on the plain system)"""
+    al, system, regions = _alanine_two_regions(kw, frozenset(), softcore_beta=0.0 if not kw else 0.25)
+    nb = [f for f in system.getForces() if isinstance(f, NonbondedForce)][0]
+    box0 = np.diag(system.getDefaultPeriodicBoxVectors())
+    eng = hip_engine_factory()
+    eng.set_system(system_to_desc(system, ewald_split='auto'))
+    LS1, LE1 = np.array([[0.8, 0.7]]), np.array([[0.0, 0.0]]) if kw else np.array([[0.4, 0.0]])
+    eng.set_states(np.array([1.0 / (KB * 300.0)]), None, None, alchemy.alchemical_long_range_constants(system, nb, LS1, float(np.prod(box0))))
+    eng.set_region_lambdas(LS1, LE1)
+    eng.seed(13)
+    eng.set_integrator('V R V', 0.001, 0.0, 100, False, 1e-8)
+    eng.set_replicas(1, 0, al.positions[None], None, box0[None], np.zeros(1, dtype=int))
+    eng.minimize(tolerance=50.0, max_iterations=200)
+    eng.set_integrator('V R O R V', 0.001, 5.0, 200, True, 1e-8)
+    assert not eng.propagate(0).any()
+    eng.set_integrator('V R V', 0.001, 0.0, 100, False, 1e-8)
+    energies = []
+    for it in range(5):
+        kinetic = eng.get_replicas(positions=False, velocities=False, kinetic=True)[3]
+        energies.append(float(kinetic[0] + eng.compute_energies(want_potential=True)[1][0]))
+        if it < 4:
+            assert not eng.propagate(it + 1).any()
+    ndof = 3 * 2269 - 2259 - 3
+    drift = (np.array(energies) - energies[0]) / (ndof * KB * 300.0)
+    assert np.abs(drift).max() < 2e-3, drift

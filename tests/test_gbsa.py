@@ -189,3 +189,27 @@ def test_replica_exchange_over_an_alchemical_ladder_in_implicit_solvent_on_the_d
     s, asys = _alchemical_implicit_sampler(hip_engine_factory(), 4)
     _check_sampler(s, asys, 2e-5)
     assert s.iteration == 4
+
+
+@pytest.mark.gpu
+def test_velocity_verlet_conserves_energy_in_implicit_solvent(hip_engine_factory):
+    """the three GB launches' forces belong to the GB energy dynamically: 'V R V' at 1 fs on the implicit-solvent dipeptide conserves K + U
+    to a small fraction of kT per degree of freedom over 2 ps"""
+    al = ts.AlanineDipeptideImplicit()
+    eng = hip_engine_factory()
+    eng.set_system(system_to_desc(al.system))
+    eng.set_states(np.array([1.0 / (KB * 300.0)]))
+    eng.seed(3)
+    eng.set_integrator('V R O R V', 0.001, 5.0, 500, True, 1e-8)
+    eng.set_replicas(1, 0, al.positions[None], None, np.zeros((1, 3)), np.zeros(1, dtype=int))
+    assert not eng.propagate(0).any()
+    eng.set_integrator('V R V', 0.001, 0.0, 500, False, 1e-8)
+    energies = []
+    for it in range(5):
+        kinetic = eng.get_replicas(positions=False, velocities=False, kinetic=True)[3]
+        energies.append(float(kinetic[0] + eng.compute_energies(want_potential=True)[1][0]))
+        if it < 4:
+            assert not eng.propagate(it + 1).any()
+    ndof = 3 * 22 - 12 - 3
+    drift = (np.array(energies) - energies[0]) / (ndof * KB * 300.0)
+    assert np.abs(drift).max() < 5e-3, drift
