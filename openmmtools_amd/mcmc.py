@@ -255,8 +255,12 @@ class LangevinSplittingDynamicsMove(BaseIntegratorMove):
 
 
 class LangevinDynamicsMove(LangevinSplittingDynamicsMove):
-    """mcmc.py:1066-1172.  The reference uses openmm.LangevinMiddleIntegrator (:1169), i.e. the
-    BAOAB-equivalent "V R O R V" leapfrog-middle scheme; here it is run as that splitting."""
+    """mcmc.py:1066-1172.  The reference uses openmm.LangevinMiddleIntegrator (:1169): per step a FULL kick, half a drift, the
+    Ornstein-Uhlenbeck update, half a drift -- "V R O R" with velocities kept half a step behind (leapfrog).  Run here as "V R O R V":
+    two adjacent half kicks see the same positions, so they merge into the middle scheme's full kick -- the positions of the two programs
+    are IDENTICAL step by step for the same noise, and the velocities differ by the half kick v(t) = v_leapfrog + dt F(x_t) / 2m, i.e.
+    the engine holds the on-step velocity (the one OpenMM's kinetic energy of a leapfrog integrator is evaluated at).
+    tests/test_mc_moves.py::test_langevin_dynamics_move_is_the_leapfrog_middle_scheme holds both statements at 1e-15."""
 
     def __init__(self, timestep=1.0 * unit.femtosecond, collision_rate=10.0 / unit.picoseconds,
                  n_steps=1000, reassign_velocities=False, constraint_tolerance=1e-8, **kwargs):

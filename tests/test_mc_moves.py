@@ -460,3 +460,42 @@ def test_thermodynamic_state_pickled_before_pressure_was_a_property_still_loads(
     old = states.ThermodynamicState.__new__(states.ThermodynamicState)
     old.__setstate__(legacy)
     assert old.pressure == t.pressure and old.barostat is not None and old.temperature == 120.0
+
+
+def test_langevin_dynamics_move_is_the_leapfrog_middle_scheme():
+    """mcmc.py:1167-1172: LangevinDynamicsMove = openmm.LangevinMiddleIntegrator (full kick, half drift, O, half drift; velocities half a
+    step behind).  The package runs it as 'V R O R V'.  Same program: 'V R O R' (ONE V token = a full kick) started from the leapfrog
+    velocity v0 - dt F(x0) / 2m reproduces the positions of 'V R O R V' started from v0 exactly, and its velocities are the on-step ones
+    minus the half kick."""
+    import os
+    import oracle
+    from openmmtools_amd import testsystems
+    from openmmtools_amd.system import system_to_desc
+    from openmmtools_amd._engine import HipEngine
+    lib = os.path.join(os.path.dirname(os.path.abspath(oracle.__file__)), '_build', 'libremd_cpu.so')
+    if not os.path.exists(lib):
+        oracle.build()
+    lj = testsystems.LennardJonesFluid(nparticles=64)
+    desc = system_to_desc(lj.system)
+    box = np.diag(lj.system.getDefaultPeriodicBoxVectors())
+    x0 = lj.positions[None].copy()
+    v0 = 0.3 * np.random.default_rng(0).normal(size=x0.shape)
+    dt, m = 0.002, desc['mass'][0]
+
+    def run(splitting, v):
+        eng = HipEngine(lib_path=lib)
+        eng.set_system(desc)
+        eng.set_states(np.array([1.0 / (0.008314462618153242 * 120.0)]))
+        eng.set_integrator(splitting, dt, 5.0, 50, False, 1e-8)
+        eng.seed(42)
+        eng.set_replicas(1, 0, x0, v, box[None], np.array([0]))
+        f_start = eng.get_forces()
+        eng.propagate(0)
+        x, vel = eng.get_replicas()[:2]
+        f_end = eng.get_forces()
+        eng.close()
+        return x, vel, f_start, f_end
+    xa, va, f0, _ = run('V R O R V', v0)
+    xb, vb, _, f1 = run('V R O R', v0 - 0.5 * dt * f0 / m)
+    assert np.abs(xa - xb).max() < 1e-13 and np.abs(xa - x0).max() > 1e-3
+    assert np.abs(va - (vb + 0.5 * dt * f1 / m)).max() < 1e-13
