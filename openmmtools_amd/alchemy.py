@@ -21,8 +21,10 @@ Two device paths serve it:
     ``alchemical_regions`` + ``alchemical_region_terms`` (the custom forces' parameters) for csrc/alch_regions.hip
     (remd_set_alchemical_regions).
 Under the exact PME treatment that path scales every region's charges by its own lambda_electrostatics inside the whole Ewald sum
-(remd_alch_regions_desc.exact_pme).  Not built: alchemically softened bonds / angles / torsions, GBSA.  This module also computes the per-state long-range-correction constants that
-MultiStateSampler hands to remd_set_states(energy_const).
+(remd_alch_regions_desc.exact_pme).  It also carries the softened bonds / angles / torsions of a region (:1115-1354; lambda_bonds ...),
+the vacuum systems (NonbondedForce.NoCutoff: csrc/nocutoff.hip) and, with a GBSAOBCForce in the System, the alchemical GBSA of
+:2144-2225 (csrc/gbsa.hip; one region, as in the reference).  Not built: AMOEBA, GB models other than OBC2, GBSA with a cutoff.
+This module also computes the per-state long-range-correction constants that MultiStateSampler hands to remd_set_states(energy_const).
 """
 import copy
 import math
