@@ -232,6 +232,18 @@ class AlanineDipeptideVacuum(TestSystem):
         self.residue_names = [str(s) for s in z['residue_names']] if 'residue_names' in z.files else None
 
 
+class HostGuestVacuum(TestSystem):
+    """testsystems.py:3660-3712: CB7 host + B2 guest (156 atoms) without solvent -- prmtop.createSystem(implicitSolvent=None,
+    constraints=HBonds, nonbondedMethod=NoCutoff)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        system, nb, positions, velocities, z = _load_npz_system('cb7-b2-vacuum')
+        nb.setNonbondedMethod(NonbondedForce.NoCutoff)
+        self.system, self.positions, self.velocities = system, positions, None
+        self.residue_names = [str(s) for s in z['residue_names']] if 'residue_names' in z.files else None
+
+
 class AlanineDipeptideImplicit(AlanineDipeptideVacuum):
     """testsystems.py:3424-3462: the vacuum dipeptide + Generalized-Born implicit solvent.  The reference's default is app.OBC1, which
     current OpenMM builds as a CustomGBForce from its own expression library (not in the reference's tree); what is built here is

@@ -69,11 +69,18 @@ def _check_plain(eng, system, x0, rtol, ftol, R=2):
     return desc
 
 
-@pytest.mark.parametrize('which', ['alanine', 'cluster'])
+def _system(which):
+    if which == 'cluster':
+        return _cluster()
+    a = ts.AlanineDipeptideVacuum() if which == 'alanine' else ts.HostGuestVacuum()          # testsystems.py:3352-3388, 3660-3712
+    return a.system, a.positions
+
+
+@pytest.mark.parametrize('which', ['alanine', 'cluster', 'hostguest'])
 def test_cpu_port_evaluates_nocutoff_systems_like_the_oracle(which):
     if not os.path.exists(CPU_LIB):
         oracle.build()
-    system, x = (lambda a: (a.system, a.positions))(ts.AlanineDipeptideVacuum()) if which == 'alanine' else _cluster()
+    system, x = _system(which)
     eng = HipEngine(lib_path=CPU_LIB)
     _check_plain(eng, system, x, 1e-10, 1e-9)
     assert not np.any(eng.propagate(0))
@@ -81,9 +88,9 @@ def test_cpu_port_evaluates_nocutoff_systems_like_the_oracle(which):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('which', ['alanine', 'cluster'])
+@pytest.mark.parametrize('which', ['alanine', 'cluster', 'hostguest'])
 def test_hip_evaluates_nocutoff_systems_like_the_oracle(hip_engine_factory, which):
-    system, x = (lambda a: (a.system, a.positions))(ts.AlanineDipeptideVacuum()) if which == 'alanine' else _cluster()
+    system, x = _system(which)
     eng = hip_engine_factory()
     _check_plain(eng, system, x, 2e-6, 1e-4)
     assert not np.any(eng.propagate(0))

@@ -1,7 +1,7 @@
 """Converts the reference's Amber input files into compact .npz system descriptions.
 
 Run in the build container only (needs /root/reference):  python tools/convert_amber.py
-Outputs openmmtools_amd/data/{alanine-dipeptide-explicit,cb7-b2-explicit,dhfr-explicit,alanine-dipeptide-vacuum}.npz, the inputs of
+Outputs openmmtools_amd/data/{alanine-dipeptide-explicit,cb7-b2-explicit,dhfr-explicit,alanine-dipeptide-vacuum,cb7-b2-vacuum}.npz, the inputs of
 testsystems.AlanineDipeptideExplicit / HostGuestExplicit / DHFRExplicit (reference:
 openmmtools/testsystems.py:3499-3527, 3821-3857, 3895-3923).  The reference's data files are the
 physical input of the benchmark configs; only derived numeric arrays are stored.
@@ -23,6 +23,8 @@ JOBS = [
     ('dhfr-explicit', 'dhfr/JAC.prmtop', 'dhfr/JAC.inpcrd'),
     # testsystems.AlanineDipeptideVacuum (testsystems.py:3352-3388): the same parameter set without solvent, NoCutoff, no box
     ('alanine-dipeptide-vacuum', 'alanine-dipeptide-gbsa/alanine-dipeptide.prmtop', 'alanine-dipeptide-gbsa/alanine-dipeptide.crd'),
+    # testsystems.HostGuestVacuum (testsystems.py:3660-3712): CB7:B2 without solvent
+    ('cb7-b2-vacuum', 'cb7-b2/complex-vacuum.prmtop', 'cb7-b2/complex-vacuum.inpcrd'),
 ]
 
 for name, top, crd in JOBS:
