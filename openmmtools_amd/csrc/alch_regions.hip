@@ -44,6 +44,7 @@ struct region_tables {
     int* d_exc_atoms = nullptr; float4* d_exc_par = nullptr;      // exceptions: (k_e qq, sigma, 4 eps, class bits)
     float4* d_state_cls = nullptr;         // [K][n_cls][2]: (l^a, alpha (1 - l)^b, l^d, beta (1 - l)^e), (c, f, 0, 0)
     int* d_own = nullptr; std::vector<int> own_host;
+    double* d_epart = nullptr; size_t epart_n = 0;          // [R][columns][n_alch] energy partials
     // softened bonded terms: atoms, parameters (the last entry of a term = its region as float bits), per state the regions' lambdas
     int* d_bonded_atoms = nullptr; float* d_bonded_par = nullptr;      // bonds [n][2] + angles [n][3] + torsions [n][4]; [n][3] + [n][3] + [n][4]
     float* d_state_bl = nullptr;           // [K][3][n_regions]
@@ -337,60 +338,77 @@ void region_forces_kernel(region_consts c, const int* __restrict__ alch, const f
         region_bonded_term(c, bonded, t, P, F);
 }
 
-// energies: workgroup = (state column, replica); state = own[r] when `own` is given (the replica's potential), else the column
+// energies: workgroup = (alchemical atom, state column, replica) -- its candidates, and for the first atom's workgroup also the exceptions and
+// the softened bonded terms -- writes one f64 partial; region_energy_sum_kernel adds a (column, replica)'s partials in a fixed order.  state =
+// own[r] when `own` is given (the replica's potential), else the column.  (One workgroup per (column, replica) looping over all n_alch x N
+// candidates took 0.9 - 1.4 ms on CB7:B2: eight workgroups on the chip in the own-state launches; rocprofv3, profiles/r06_42.)
 __global__ __launch_bounds__(256)
 void region_energy_kernel(region_consts c, const int* __restrict__ alch, const float4* __restrict__ atom, const unsigned int* __restrict__ skip,
                           const int* __restrict__ cls_of, const float4* __restrict__ state_cls, const int* __restrict__ own,
                           const int* __restrict__ exc_atoms, const float4* __restrict__ exc_par,
-                          const float4* __restrict__ pos, const float* __restrict__ box, double* __restrict__ out, int out_stride, int out_offset,
+                          const float4* __restrict__ pos, const float* __restrict__ box, double* __restrict__ part /*[R][cols][n_alch]*/,
                           const unsigned int* __restrict__ corr, const float* __restrict__ rep_le, region_bonded bonded)
 {
     // rep_le (exact PME treatment): the electrostatic terms at the replicas' lambdas ride along; NULL: sterics / custom electrostatics only
     __shared__ double s_part[4];
-    const int r = blockIdx.y;
+    const int ia = blockIdx.x, col = blockIdx.y, r = blockIdx.z;
     const float* le4 = rep_le ? rep_le + 4 * r : nullptr;
-    const int state = own ? own[r] : blockIdx.x;
+    const int state = own ? own[r] : col;
     const float4* P = pos + (size_t)r * c.Npad;
     const float4* cls_tab = state_cls + (size_t)state * c.n_cls * 2;
     const float Lx = box[4 * r], Ly = box[4 * r + 1], Lz = box[4 * r + 2];
     double e = 0.0;
-    const int total = c.n_alch * c.N;
-    for (int t = threadIdx.x; t < total; t += 256) {
-        const int ia = t / c.N, j = t - ia * c.N;
+    const int a = alch[ia];
+    const float4 pa = atom[a];
+    const float3 xa = ld3(P, a);
+    for (int j = threadIdx.x; j < c.N; j += 256) {
         const size_t word = (size_t)ia * c.words + (j >> 5);
         const bool skipped = (skip[word] >> (j & 31)) & 1u;
         if (skipped && (!le4 || !((corr[word] >> (j & 31)) & 1u))) continue;
-        const int a = alch[ia];
-        const float3 d = region_min_image(sub3(ld3(P, j), ld3(P, a)), Lx, Ly, Lz);
+        const float3 d = region_min_image(sub3(ld3(P, j), xa), Lx, Ly, Lz);
         float U, fr;
         if (skipped) {
-            const float4 pa = atom[a], pj = atom[j];
+            const float4 pj = atom[j];
             if (pa.x * pj.x != 0.f) { region_ewald_correction(c, pa, pj, d, le4, U, fr); e += (double)U; }
-        } else if (region_pair(c, cls_tab, cls_of, atom[a], atom[j], d, U, fr, le4)) e += (double)U;
+        } else if (region_pair(c, cls_tab, cls_of, pa, atom[j], d, U, fr, le4)) e += (double)U;
     }
-    for (int t = threadIdx.x; t < c.n_exc; t += 256) {
-        float3 d = sub3(ld3(P, exc_atoms[2 * t + 1]), ld3(P, exc_atoms[2 * t]));
-        if (Lx > 0.f) d = region_min_image(d, Lx, Ly, Lz);
-        float U, fr;
-        region_exception(c, cls_tab, exc_par[t], d, U, fr, le4);
-        e += (double)U;
+    if (ia == 0) {
+        for (int t = threadIdx.x; t < c.n_exc; t += 256) {
+            float3 d = sub3(ld3(P, exc_atoms[2 * t + 1]), ld3(P, exc_atoms[2 * t]));
+            if (Lx > 0.f) d = region_min_image(d, Lx, Ly, Lz);
+            float U, fr;
+            region_exception(c, cls_tab, exc_par[t], d, U, fr, le4);
+            e += (double)U;
+        }
+        bonded.lam += (size_t)state * 3 * bonded.n_regions;
+        for (int t = threadIdx.x; t < c.n_bonds + c.n_angles + c.n_torsions; t += 256) e += (double)region_bonded_term(c, bonded, t, P, nullptr);
     }
-    bonded.lam += (size_t)state * 3 * bonded.n_regions;
-    for (int t = threadIdx.x; t < c.n_bonds + c.n_angles + c.n_torsions; t += 256) e += (double)region_bonded_term(c, bonded, t, P, nullptr);
     for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = e;
     __syncthreads();
+    if (threadIdx.x == 0) part[((size_t)r * gridDim.y + col) * c.n_alch + ia] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(64)
+void region_energy_sum_kernel(region_consts c, int cols, const double* __restrict__ part, const float* __restrict__ rep_le, const float* __restrict__ box,
+                              double* __restrict__ out, int out_stride, int out_offset)
+{
+    const int col = blockIdx.x, r = blockIdx.y;
+    const double* p = part + ((size_t)r * cols + col) * c.n_alch;
+    double e = 0.0;
+    for (int t = threadIdx.x; t < c.n_alch; t += 64) e += p[t];
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
     if (threadIdx.x == 0) {
-        double tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        if (le4) {
+        if (rep_le) {
             // Ewald self terms of the regions' scaled charges and their part of the neutralising background (the environment's are with
             // the handle's constants: forces.hip const_energy_kernel)
+            const float* le4 = rep_le + 4 * r;
             double Q = c.q_env;
-            for (int g = 0; g < 4; ++g) { const double l = (double)le4[g]; tot += l * l * c.self_x[g]; Q += l * c.q_x[g]; }
-            const double V = (double)Lx * (double)Ly * (double)Lz;
-            if (V > 0) tot += c.plasma * (Q * Q - c.q_env * c.q_env) / V;
+            for (int g = 0; g < 4; ++g) { const double l = (double)le4[g]; e += l * l * c.self_x[g]; Q += l * c.q_x[g]; }
+            const double V = (double)box[4 * r] * (double)box[4 * r + 1] * (double)box[4 * r + 2];
+            if (V > 0) e += c.plasma * (Q * Q - c.q_env * c.q_env) / V;
         }
-        out[(size_t)r * out_stride + out_offset + (own ? 0 : blockIdx.x)] = tot;
+        out[(size_t)r * out_stride + out_offset + col] = e;
     }
 }
 
@@ -400,7 +418,7 @@ void remd_regions_release(remd_ctx* h)
     region_tables* t = g_reg.find(h);
     if (t) {
         dfree(t->d_alch); dfree(t->d_atom); dfree(t->d_skip); dfree(t->d_cls_of); dfree(t->d_exc_atoms); dfree(t->d_exc_par);
-        dfree(t->d_state_cls); dfree(t->d_own);
+        dfree(t->d_state_cls); dfree(t->d_own); dfree(t->d_epart);
         dfree(t->d_corr); dfree(t->d_param_pme); dfree(t->d_rep_le); dfree(t->d_state_le);
         dfree(t->d_bonded_atoms); dfree(t->d_bonded_par); dfree(t->d_state_bl);
         g_reg.erase(h);
@@ -672,6 +690,17 @@ static int region_own_states(remd_ctx* h, region_tables& t)
     return 0;
 }
 
+static int region_energy_launch(remd_ctx* h, region_tables& t, int cols, const int* d_own, const float* d_rep_le, double* d_out, int out_stride, int out_offset)
+{
+    const size_t need = (size_t)h->R * cols * t.c.n_alch;
+    if (need > t.epart_n) { dfree(t.d_epart); REMD_CHECK(h, hipMalloc(&t.d_epart, sizeof(double) * need)); t.epart_n = need; }
+    const region_bonded rb{t.d_bonded_atoms, t.d_bonded_par, t.d_state_bl, t.n_regions};
+    hipLaunchKernelGGL(region_energy_kernel, dim3(t.c.n_alch, cols, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
+                       t.d_state_cls, d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, t.d_epart, t.d_corr, d_rep_le, rb);
+    hipLaunchKernelGGL(region_energy_sum_kernel, dim3(cols, h->R), dim3(64), 0, h->stream, t.c, cols, t.d_epart, d_rep_le, h->d_box, d_out, out_stride, out_offset);
+    return 0;
+}
+
 // at the head of a force evaluation, on the stream everything else of the evaluation is ordered behind
 int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot)
 {
@@ -685,10 +714,9 @@ int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot)
     const int nchunk = (h->N + REGION_CHUNK - 1) / REGION_CHUNK;
     hipLaunchKernelGGL(region_forces_kernel, dim3(t.c.n_alch * nchunk, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
                        t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_force, t.d_corr, t.c.exact ? t.d_rep_le : (const float*)nullptr, region_bonded{t.d_bonded_atoms, t.d_bonded_par, t.d_state_bl, t.n_regions});
-    if (with_energy)
-        hipLaunchKernelGGL(region_energy_kernel, dim3(1, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
-                           t.d_state_cls, t.d_own, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, h->d_epart, h->n_epart, ep_slot,
-                           t.d_corr, t.c.exact ? t.d_rep_le : (const float*)nullptr, region_bonded{t.d_bonded_atoms, t.d_bonded_par, t.d_state_bl, t.n_regions});
+    if (with_energy) {
+        if ((rc = region_energy_launch(h, t, 1, t.d_own, t.c.exact ? t.d_rep_le : (const float*)nullptr, h->d_epart, h->n_epart, ep_slot))) return rc;
+    }
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }
@@ -703,9 +731,8 @@ int remd_regions_ukl(remd_ctx* h, double* d_out, const int** d_own)
     int rc = region_own_states(h, t);
     if (rc) return rc;
     remd_prof_scope ps(h, "alch_ukl");
-    hipLaunchKernelGGL(region_energy_kernel, dim3(h->K, h->R), dim3(256), 0, h->stream, t.c, t.d_alch, t.d_atom, t.d_skip, t.d_cls_of,
-                       t.d_state_cls, (const int*)nullptr, t.d_exc_atoms, t.d_exc_par, h->d_pos, h->d_box, d_out, h->K, 0,
-                       t.d_corr, (const float*)nullptr, region_bonded{t.d_bonded_atoms, t.d_bonded_par, t.d_state_bl, t.n_regions});          // (exact PME treatment: the sterics only; the Coulomb part is the quadratic form of forces.hip)
+    // (exact PME treatment: the sterics only; the Coulomb part is the quadratic form of forces.hip)
+    if ((rc = region_energy_launch(h, t, h->K, (const int*)nullptr, (const float*)nullptr, d_out, h->K, 0))) return rc;
     REMD_CHECK(h, hipGetLastError());
     *d_own = t.d_own;
     return 0;
