@@ -17,6 +17,8 @@
 #include "rng.h"
 #include <set>
 #include "pair_math.h"
+#include "listed_terms.h"
+#include "nocutoff_pair.h"
 
 #define UNIT_FREE   0
 #define UNIT_SETTLE 1
@@ -1279,6 +1281,281 @@ static int remd_run_steps_resident(remd_ctx* h, const std::vector<char>& tokens,
     return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident small-molecule MD (round 6): the reference's vacuum test systems (AlanineDipeptideVacuum 22 atoms, HostGuestVacuum 156,
+// TolueneVacuum 15; testsystems.py:3352-3388) are three dependent launches per MD step on the regular path -- NoCutoff pair sum, listed
+// terms, integrator chain -- of which the chain alone is 25 us of fixed latency for 22 atoms (rocprofv3, profiles/r06_43): 39 us per step
+// whatever the size.  As for the Lennard-Jones fluids above, ONE launch per propagation: a workgroup owns a replica; a thread owns a
+// constraint unit (x, v, 1/m of its <= 4 atoms in registers for all n_steps, the unit arithmetic of the chain kernel: X-H clusters,
+// rigid waters, free atoms) AND, for the pair sum, an atom; positions, pair parameters and the fixed-point force accumulators live in LDS.
+// A force evaluation is: units publish their positions and clear their atoms' accumulators | barrier | every atom sums its partners in
+// ascending order (nocutoff_pair.h: the arithmetic and the order of nocutoff_kernel), exceptions, listed terms (listed_forces_body, the
+// accumulators being an LDS address) | barrier.  Every contribution is converted to fixed point exactly as on the regular path and integer
+// sums do not depend on their order; with the same Philox streams and the same centre-of-mass sum (per-wavefront fp32 partial sums in
+// unit order, then integers) the trajectory follows the regular path to fp32 rounding (one step: velocities within 1 ulp, positions equal;
+// the compiler contracts the long expressions of the two kernels differently; tools/experiments/resident_mol_diff.py), like the
+// Lennard-Jones kernel above (tests/test_nocutoff.py::test_resident_small_molecule_kernel_follows_the_regular_launches).
+// Measured (profiles/r06_43_small_molecule_systems.txt): 24 x AlanineDipeptideVacuum 39 -> 23 us per MD step; a step is then the latency
+// of its seven tokens at one wavefront per SIMD (~1 us each, X-H Newton iterations) + one evaluation.  From ~100 atoms on one workgroup
+// per replica loses against the regular launches, which spread the listed terms over the chip (CB7:B2 in vacuum, 156 atoms: 72 against
+// 61 us per step) -- the kernel takes systems of up to RESIDENT_MOL_MAX_ATOMS atoms.
+struct resident_mol_sys {
+    int N, Npad, n_units, words, n_exc;
+    const float4* nb_param; const unsigned int* excl; const int* exc_atoms; const float4* exc_par;
+    const int4* unit_atoms; const unsigned char* unit_type; const float* shake_dist; settle_const sc; float tol;
+    const float* invmass; const int64_t* labels; const double* beta; int r_begin; uint64_t seed; const unsigned int* noise_id;
+    float inv_total_mass; unsigned int* shake_stat;
+    listed_tables L; int n_listed;
+};
+
+// one token of the step program on the registers of a unit: the V / R / O branches of run_unit, expression for expression
+__device__ __forceinline__ char resident_tok(const resident_prog& prog, int t)
+{
+    static_assert(MAX_TOK == 24, "six 32-bit words of tokens");
+    const unsigned int* w = reinterpret_cast<const unsigned int*>(prog.tok);
+    const unsigned int w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5];
+    const int q = t >> 2;
+    const unsigned int x = q == 0 ? w0 : q == 1 ? w1 : q == 2 ? w2 : q == 3 ? w3 : q == 4 ? w4 : w5;
+    return (char)((x >> ((t & 3) * 8)) & 0xffu);
+}
+
+template <int TYPE, int NAT>
+__device__ __forceinline__ void resident_mol_token(char tok, const resident_prog& prog, int o_index, long long gstep, const int* idx, const float* dist,
+                                                   const settle_const& sc, float tol, const long long* F, int Fs, float kT, uint32_t rg, uint64_t seed,
+                                                   unit_regs& S)
+{
+    float3 (&x)[4] = S.x; float3 (&v)[4] = S.v;
+    float (&im)[4] = S.im;
+    if (tok == 'V') {
+        const float hv = prog.hV;
+#pragma unroll
+        for (int k = 0; k < NAT; ++k) {
+            const float s = hv * im[k] * (1.0f / 4294967296.0f);
+            v[k].x += s * (float)F[idx[k]];
+            v[k].y += s * (float)F[Fs + idx[k]];
+            v[k].z += s * (float)F[2 * Fs + idx[k]];
+        }
+        constrain_v<TYPE, NAT>(sc, im, tol, v, x);
+    } else if (tok == 'R') {
+        if (TYPE == UNIT_FREE) {
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) x[k] = x[k] + v[k] * prog.hR;
+        } else {
+            float3 p0[NAT], p1[NAT], q[NAT];
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) {
+                p0[k] = x[k] - x[0];
+                p1[k] = p0[k] + v[k] * prog.hR;
+                q[k] = p1[k];
+            }
+            if (TYPE == UNIT_SETTLE) settle_positions(sc, p0, p1);
+            else S.shake_it = max(S.shake_it, shake_positions<NAT>(im, dist, tol, p0, p1));
+            const float ih = frcp(prog.hR);
+            const float3 org = x[0];
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) {
+                v[k] = v[k] + (p1[k] - q[k]) * ih;
+                x[k] = org + p1[k];
+            }
+            constrain_v<TYPE, NAT>(sc, im, tol, v, x);
+        }
+    } else if (tok == 'O') {
+        const uint64_t cnt = (uint64_t)gstep * (uint64_t)prog.nO + (uint64_t)o_index;
+#pragma unroll
+        for (int k = 0; k < NAT; ++k) {
+            const float3 xi = gaussian3(seed, REMD_STREAM_OU, (uint32_t)idx[k], rg, cnt);
+            const float sig = prog.b * fsqrt(kT * im[k]);
+            v[k].x = prog.a * v[k].x + sig * xi.x;
+            v[k].y = prog.a * v[k].y + sig * xi.y;
+            v[k].z = prog.a * v[k].z + sig * xi.z;
+        }
+        constrain_v<TYPE, NAT>(sc, im, tol, v, x);
+    }
+}
+
+#define RESIDENT_MOL_T 256
+#define RESIDENT_MOL_MAX_ATOMS 64
+__global__ __launch_bounds__(RESIDENT_MOL_T)
+void resident_mol_kernel(resident_prog prog, resident_mol_sys S, float4* __restrict__ pos, float4* __restrict__ vel)
+{
+    __shared__ float4 s_pos[RESIDENT_MOL_T], s_par[RESIDENT_MOL_T];
+    __shared__ long long s_F[3 * RESIDENT_MOL_T];
+    __shared__ long long s_pm[RESIDENT_MOL_T / 64][3];
+    constexpr int Fs = RESIDENT_MOL_T;
+    const int tid = threadIdx.x, r = blockIdx.x, N = S.N;
+    float4* P = pos + (size_t)r * S.Npad;
+    float4* V = vel + (size_t)r * S.Npad;
+    int4 a4 = make_int4(-1, -1, -1, -1);
+    int type = UNIT_FREE;
+    float dist[3] = { 0.f, 0.f, 0.f };
+    if (tid < S.n_units) {
+        a4 = S.unit_atoms[tid]; type = (int)S.unit_type[tid];
+        dist[0] = S.shake_dist[tid * 3]; dist[1] = S.shake_dist[tid * 3 + 1]; dist[2] = S.shake_dist[tid * 3 + 2];
+    }
+    const bool active = a4.x >= 0;
+    if (!active) type = UNIT_FREE;
+    const int idx[4] = { a4.x, a4.y, a4.z, a4.w };
+    unit_regs U;
+    U.have_cm = 0; U.shake_it = 0; U.heat = 0.f; U.shadow = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        U.x[k] = f3(0, 0, 0); U.v[k] = f3(0, 0, 0); U.im[k] = 0.f;
+        if (idx[k] >= 0) {
+            const float4 p = P[idx[k]], w = V[idx[k]];
+            U.x[k] = f3(p.x, p.y, p.z); U.v[k] = f3(w.x, w.y, w.z); U.im[k] = S.invmass[idx[k]];
+        }
+    }
+    s_par[tid] = tid < N ? S.nb_param[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s_pos[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float kT = frcp((float)S.beta[S.labels[S.r_begin + r]]);
+    const uint32_t rg = S.noise_id ? S.noise_id[r] : (uint32_t)(S.r_begin + r);
+    bool forces_valid = false;
+    __syncthreads();
+
+    auto evaluate = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (idx[k] >= 0) {
+                s_pos[idx[k]] = make_float4(U.x[k].x, U.x[k].y, U.x[k].z, 0.f);
+                s_F[idx[k]] = 0; s_F[Fs + idx[k]] = 0; s_F[2 * Fs + idx[k]] = 0;
+            }
+        }
+        __syncthreads();
+        if (tid < N) {
+            const float4 xi = s_pos[tid], pi = s_par[tid];
+            float fx = 0.f, fy = 0.f, fz = 0.f;
+            double e = 0.0;
+            const unsigned int* mrow = S.excl + (size_t)tid * S.words;
+            for (int j0 = 0; j0 < N; j0 += 32) {
+                const unsigned int m = mrow[j0 >> 5];
+                const int jn = min(32, N - j0);
+                for (int k = 0; k < jn; ++k) {
+                    const int j = j0 + k;
+                    if (j == tid || ((m >> k) & 1u)) continue;
+                    nocutoff_pair<false>(xi, pi, s_pos[j], s_par[j], fx, fy, fz, e);
+                }
+            }
+            add_force(s_F, Fs, tid, fx, fy, fz);
+        }
+        for (int t = tid; t < S.n_exc; t += RESIDENT_MOL_T) {
+            const int i = S.exc_atoms[2 * t], j = S.exc_atoms[2 * t + 1];
+            const float4 par = S.exc_par[t];
+            const float3 d = sub3(ld3(s_pos, j), ld3(s_pos, i));
+            double e = 0.0;
+            const float fr = nocutoff_exception<false>(par, d, e);
+            add_force(s_F, Fs, i, fr * d.x, fr * d.y, fr * d.z);
+            add_force(s_F, Fs, j, -fr * d.x, -fr * d.y, -fr * d.z);
+        }
+        // (every lane of a wavefront takes part in listed_forces_body's reduction over the lanes of one atom)
+        for (int base = 0; base < S.n_listed; base += RESIDENT_MOL_T)
+            listed_forces_body(S.L, Fs, s_pos, (const float*)nullptr, s_F, base + tid, 0);
+        __syncthreads();
+        forces_valid = true;
+    };
+
+    for (int s = 0; s < prog.n_steps; ++s) {
+        const long long gstep = prog.gstep0 + s;
+        if (prog.cmm_frequency > 0 && ((prog.first_step + s) % prog.cmm_frequency) == 0) {
+            // CMMotionRemover at the top of a step (integrators.py:1313): the sum of the chain kernel -- fp32 over a unit's atoms and the
+            // units of a wavefront, then fixed point
+            float3 pm = f3(0, 0, 0);
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (idx[k] >= 0) pm = pm + U.v[k] * frcp(U.im[k]);
+            }
+            for (int off = 32; off > 0; off >>= 1) { pm.x += __shfl_xor(pm.x, off); pm.y += __shfl_xor(pm.y, off); pm.z += __shfl_xor(pm.z, off); }
+            if ((tid & 63) == 0) {
+                long long* w = s_pm[tid >> 6];
+                w[0] = (long long)((double)pm.x * 4294967296.0); w[1] = (long long)((double)pm.y * 4294967296.0); w[2] = (long long)((double)pm.z * 4294967296.0);
+            }
+            __syncthreads();
+            long long tot[3] = { 0, 0, 0 };
+            for (int w = 0; w < RESIDENT_MOL_T / 64; ++w) { tot[0] += s_pm[w][0]; tot[1] += s_pm[w][1]; tot[2] += s_pm[w][2]; }
+            __syncthreads();
+            const float sx = (float)tot[0] * (1.0f / 4294967296.0f) * S.inv_total_mass;
+            const float sy = (float)tot[1] * (1.0f / 4294967296.0f) * S.inv_total_mass;
+            const float sz = (float)tot[2] * (1.0f / 4294967296.0f) * S.inv_total_mass;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { U.v[k].x -= sx; U.v[k].y -= sy; U.v[k].z -= sz; }
+        }
+        int o_index = 0;
+        for (int t = 0; t < prog.n; ++t) {
+            // (the token from six registers loaded with the kernel arguments, the O counter kept here: a dynamic index into the argument
+            //  arrays is a scalar memory load per token on a path that is all latency, see chain_tok)
+            const char tok = resident_tok(prog, t);
+            if (tok == 'V' && !forces_valid) evaluate();
+            if (tok == 'R') forces_valid = false;
+            const int o_now = o_index;
+            if (tok == 'O') ++o_index;
+            if (active) {
+#define RUN(TY, NA) resident_mol_token<TY, NA>(tok, prog, o_now, gstep, idx, dist, S.sc, S.tol, s_F, Fs, kT, rg, S.seed, U)
+                if (type == UNIT_SETTLE) RUN(UNIT_SETTLE, 3);
+                else if (type == UNIT_FREE) { if (a4.y < 0) RUN(UNIT_FREE, 1); else RUN(UNIT_FREE, 4); }
+                else if (a4.z < 0) RUN(UNIT_SHAKE, 2);
+                else if (a4.w < 0) RUN(UNIT_SHAKE, 3);
+                else RUN(UNIT_SHAKE, 4);
+#undef RUN
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (idx[k] >= 0) {
+            P[idx[k]] = make_float4(U.x[k].x, U.x[k].y, U.x[k].z, 0.f);
+            V[idx[k]] = make_float4(U.v[k].x, U.v[k].y, U.v[k].z, 0.f);
+        }
+    }
+    if (type == UNIT_SHAKE && U.shake_it > 0 &&
+        (unsigned int)U.shake_it > __hip_atomic_load(S.shake_stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(S.shake_stat, (unsigned int)U.shake_it);
+}
+
+// returns 1 when the propagation was run by the resident small-molecule kernel, 0 when the system / request is not one it covers
+static int remd_run_steps_resident_mol(remd_ctx* h, const std::vector<char>& tokens, int nV, int nR, int nO,
+                                       int64_t iteration, int64_t first_step, int n_steps)
+{
+    const bool enabled = !(getenv("REMD_RESIDENT") && atoi(getenv("REMD_RESIDENT")) == 0);      // read per call: the parity tests switch it
+    if (!enabled || h->no_resident) return 0;
+    if (!h->nocutoff || h->gbsa || h->n_regions > 0 || h->nb_method != REMD_NB_NONE || h->n_ext > 0) return 0;
+    const unit_tables& ut = g_units[h];
+    if (h->N > RESIDENT_MOL_MAX_ATOMS || ut.n_units > RESIDENT_MOL_T || ut.n_units < 1) return 0;
+    if (getenv("REMD_RESIDENT_MOL") && atoi(getenv("REMD_RESIDENT_MOL")) == 0) return 0;
+    if (h->baro_frequency > 0 || h->profiling == 2 || (int)tokens.size() > MAX_TOK || n_steps < 1) return 0;
+    if (h->measure_heat || h->measure_shadow) return 0;
+    for (char c : tokens) if (c != 'V' && c != 'R' && c != 'O') return 0;
+    resident_mol_sys S{};
+    S.N = h->N; S.Npad = h->Npad; S.n_units = ut.n_units;
+    if (remd_nocutoff_info(h, &S.nb_param, &S.excl, &S.words, &S.n_exc, &S.exc_atoms, &S.exc_par)) return 0;
+    S.unit_atoms = ut.d_atoms; S.unit_type = ut.d_type; S.shake_dist = ut.d_dist; S.sc = ut.sc;
+    S.tol = (float)fmax(h->constraint_tol, REMD_CONSTRAINT_TOL_FLOOR);
+    S.invmass = h->d_invmass; S.labels = h->d_labels; S.beta = h->d_beta; S.r_begin = h->r_begin; S.seed = h->seed; S.noise_id = h->d_noise_id;
+    S.inv_total_mass = (float)(h->total_mass > 0 ? 1.0 / h->total_mass : 0.0);
+    S.shake_stat = h->d_sync + 3;
+    listed_tables L{};
+    L.n_bonds = h->n_bonds; L.n_angles = h->n_angles; L.n_torsions = h->n_torsions;
+    L.bond_atoms = h->d_bond_atoms; L.bond_params = h->d_bond_params;
+    L.angle_atoms = h->d_angle_atoms; L.angle_params = h->d_angle_params;
+    L.torsion_atoms = h->d_torsion_atoms; L.torsion_params = h->d_torsion_params;
+    S.n_listed = L.n_bonds + L.n_angles + L.n_torsions;
+    if (S.n_listed > 0 && h->d_aterm && h->n_aterm > 0) { L.aterm = h->d_aterm; L.n_aterm = h->n_aterm; S.n_listed = h->n_aterm; }
+    S.L = L;
+    resident_prog prog{};
+    prog.n = (int)tokens.size();
+    int oidx = 0;
+    for (int t = 0; t < prog.n; ++t) { prog.tok[t] = tokens[t]; prog.o_index[t] = tokens[t] == 'O' ? oidx++ : 0; }
+    prog.hV = (float)(h->dt / (nV > 0 ? nV : 1)); prog.hR = (float)(h->dt / (nR > 0 ? nR : 1));
+    const double hO = h->dt / (nO > 0 ? nO : 1);
+    prog.a = (float)exp(-h->gamma * hO); prog.b = (float)sqrt(1.0 - exp(-2.0 * h->gamma * hO)); prog.nO = nO > 0 ? nO : 1;
+    prog.n_steps = n_steps; prog.cmm_frequency = h->cmm_frequency;
+    prog.gstep0 = (long long)iteration * (long long)h->n_steps + first_step; prog.first_step = first_step;
+    remd_launch_join_wait(h);
+    remd_prof_scope ps(h, "resident_md");
+    hipLaunchKernelGGL(resident_mol_kernel, dim3(h->R), dim3(RESIDENT_MOL_T), 0, h->stream, prog, S, h->d_pos, h->d_vel);
+    REMD_CHECK(h, hipGetLastError());
+    h->forces_valid = false; h->force_zeroed = false;
+    return 1;
+}
+
 // Runs n_steps of the token program.  Tokens are grouped into chains that need no new
 // force evaluation; a 'V' after an 'R' forces a force evaluation first.
 //
@@ -1310,6 +1587,9 @@ struct step_runner {
             const int rr = remd_run_steps_resident(h, tokens_, nV, nR, nO, iteration, first_step, n_steps);
             if (rr < 0) return rr;
             if (rr != 0) { done_by_resident = true; return 0; }
+            const int rm = remd_run_steps_resident_mol(h, tokens_, nV, nR, nO, iteration, first_step, n_steps);
+            if (rm < 0) return rm;
+            if (rm != 0) { done_by_resident = true; return 0; }
         }
         base = chain_prog{};
         base.hV = (float)(h->dt / (nV > 0 ? nV : 1));

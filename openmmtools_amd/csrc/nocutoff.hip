@@ -11,6 +11,7 @@
 // has always used.
 #include "remd_internal.h"
 #include "listed_terms.h"
+#include "nocutoff_pair.h"
 #include <cmath>
 #include <algorithm>
 
@@ -62,16 +63,7 @@ void nocutoff_kernel(int N, int Npad, int words, const float4* __restrict__ para
             for (int k = 0; k < jn; ++k) {
                 const int j = j0 + k;
                 if (j == i || (((k < 32 ? m0 : m1) >> (k & 31)) & 1u)) continue;
-                const float4 xj = s_x[k], pj = s_p[k];
-                const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
-                const float r2 = dx * dx + dy * dy + dz * dz;
-                const float inv_r = rsqrtf(r2), inv_r2 = inv_r * inv_r;
-                const float sig = pi.y + pj.y, eps4 = pi.z * pj.z, qq = pi.x * pj.x;
-                const float s2 = sig * sig * inv_r2, s6 = s2 * s2 * s2;
-                // U = eps4 s6 (s6 - 1) + qq / r;  fr = dU/dr / r
-                const float fr = eps4 * s6 * (6.f - 12.f * s6) * inv_r2 - qq * inv_r * inv_r2;
-                fx += fr * dx; fy += fr * dy; fz += fr * dz;
-                if (ENERGY) e += 0.5 * ((double)(eps4 * s6 * (s6 - 1.f)) + (double)(qq * inv_r));
+                nocutoff_pair<ENERGY>(xi, pi, s_x[k], s_p[k], fx, fy, fz, e);
             }
         }
         if (live) add_force(F, Npad, i, fx, fy, fz);
@@ -81,12 +73,9 @@ void nocutoff_kernel(int N, int Npad, int words, const float4* __restrict__ para
             const int i = exc_atoms[2 * t], j = exc_atoms[2 * t + 1];
             const float4 par = exc_par[t];
             const float3 d = sub3(ld3(P, j), ld3(P, i));
-            const float r2 = dotf(d, d), inv_r = rsqrtf(r2), inv_r2 = inv_r * inv_r;
-            const float s2 = par.y * par.y * inv_r2, s6 = s2 * s2 * s2;
-            const float fr = par.z * s6 * (6.f - 12.f * s6) * inv_r2 - par.x * inv_r * inv_r2;
+            const float fr = nocutoff_exception<ENERGY>(par, d, e);
             add_force(F, Npad, i, fr * d.x, fr * d.y, fr * d.z);
             add_force(F, Npad, j, -fr * d.x, -fr * d.y, -fr * d.z);
-            if (ENERGY) e += (double)(par.z * s6 * (s6 - 1.f)) + (double)(par.x * inv_r);
         }
     }
     if (ENERGY) {
@@ -142,6 +131,15 @@ int remd_nocutoff_build(remd_ctx* h, const remd_system_desc* d)
     if ((rc = upload(h, t.d_param, prm)) || (rc = upload(h, t.d_excl, ex)) || (rc = upload(h, t.d_exc_atoms, ea)) || (rc = upload(h, t.d_exc_par, ep))) { remd_nocutoff_release(h); return rc; }
     h->nocutoff = 1;
     h->n_exceptions = t.n_exc;
+    return 0;
+}
+
+// the tables, for the resident small-molecule kernel (integrate.hip)
+int remd_nocutoff_info(remd_ctx* h, const float4** param, const unsigned int** excl, int* words, int* n_exc, const int** exc_atoms, const float4** exc_par)
+{
+    nocutoff_tables* t = g_nc.find(h);
+    if (!t) return -1;
+    *param = t->d_param; *excl = t->d_excl; *words = t->words; *n_exc = t->n_exc; *exc_atoms = t->d_exc_atoms; *exc_par = t->d_exc_par;
     return 0;
 }
 

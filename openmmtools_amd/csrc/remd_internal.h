@@ -354,6 +354,7 @@ void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluati
 void remd_nocutoff_release(remd_ctx* h);
 int remd_nocutoff_build(remd_ctx* h, const remd_system_desc* d);
 int remd_nocutoff_forces(remd_ctx* h, bool with_energy, int ep_slot);
+int remd_nocutoff_info(remd_ctx* h, const float4** param, const unsigned int** excl, int* words, int* n_exc, const int** exc_atoms, const float4** exc_par);
 // gbsa.hip: implicit solvent of a NoCutoff system
 void remd_gbsa_release(remd_ctx* h);
 int remd_gbsa_forces(remd_ctx* h, bool with_energy, int ep_slot);

@@ -41,8 +41,8 @@ def _cluster(n=150):
         s.addParticle(39.9)
         nb.addParticle(0.2 if i % 2 == 0 else -0.2, nb0.particles[i][1], nb0.particles[i][2])
     nb.addException(0, 1, 0.0, 0.3, 0.0)
-    nb.addException(5, 70, -0.01, 0.33, 0.4)
-    nb.addException(3, 140, 0.02, 0.3, 0.0)
+    nb.addException(5, min(70, n - 2), -0.01, 0.33, 0.4)
+    nb.addException(3, min(140, n - 1), 0.02, 0.3, 0.0)
     s.addForce(nb)
     return s, x
 
@@ -183,6 +183,51 @@ def test_parallel_tempering_of_the_vacuum_dipeptide_on_the_device(hip_engine_fac
     T = np.array([t.temperature for t in s._thermodynamic_states])
     assert np.allclose(u * T[None, :], (u[:, :1] * T[0]), rtol=1e-12)
     assert np.abs(u[:, 0] * KB * T[0]).max() < 500.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('which,splitting,dt,n_steps', [('alanine', 'V R R O R R V', 0.002, 10), ('alanine', 'V R R O R R V', 0.002, 500),
+                                                        ('alanine', 'O V R V O', 0.001, 100), ('droplet', 'V R O R V', 0.002, 100)])
+def test_resident_small_molecule_kernel_follows_the_regular_launches(hip_engine_factory, monkeypatch, which, splitting, dt, n_steps):
+    """NoCutoff systems of up to 64 atoms are propagated by ONE launch per move (integrate.hip resident_mol_kernel: a workgroup per
+    replica, a constraint unit per thread, positions and fixed-point force accumulators in LDS) instead of three dependent launches per
+    MD step.  Pair sums in the same fp32 order, every contribution converted to fixed point the same way, the same Philox streams and
+    the same centre-of-mass sum: the trajectory follows the regular launches (REMD_RESIDENT=0) to fp32 rounding -- one ulp of a velocity
+    per step at first, amplified by the dynamics afterwards (10 steps: 1e-7 nm; 500 steps of a molecule at 600 K: the same basin,
+    the same energy within a few kT)."""
+    system, x0 = _cluster(60) if which == 'droplet' else _system(which)      # (60 free atoms: no constraint units, no listed terms)
+    desc = system_to_desc(system)
+    out = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('REMD_RESIDENT', flag)
+        eng = hip_engine_factory()
+        eng.set_system(desc)
+        T = np.array([300.0, 450.0, 600.0])
+        eng.set_states(1.0 / (KB * T))
+        eng.set_integrator(splitting, dt, 1.0, n_steps, True, 1e-8)
+        eng.seed(11)
+        x = np.stack([x0 + 0.001 * r * np.random.default_rng(r).normal(size=x0.shape) for r in range(3)])
+        eng.set_replicas(3, 0, x, None, np.zeros((3, 3)), np.array([2, 0, 1]))
+        for it in range(2):
+            assert not eng.propagate(it).any()
+        xa, va = eng.get_replicas()[:2]
+        out.append((xa.copy(), va.copy(), eng.compute_energies(want_potential=True)[1]))
+    (xa, va, ua), (xb, vb, ub) = out
+    assert np.abs(xa - x).max() > (0.2 if n_steps == 500 else 0.01)              # it moved
+    dx, dv = np.abs(xa - xb), np.abs(va - vb)
+    if n_steps <= 10:
+        assert dx.max() < 2e-6 and dv.max() < 2e-4, (dx.max(), dv.max())
+        assert np.allclose(ua, ub, rtol=1e-5, atol=1e-3)
+    elif n_steps <= 100:
+        assert dx.max() < 2e-4 and dv.max() < 2e-2, (dx.max(), dv.max())
+        assert np.allclose(ua, ub, rtol=1e-3, atol=0.05)
+    else:
+        assert np.median(dx) < 5e-3, np.median(dx)
+        assert np.abs(ua - ub).max() < 40.0, (ua, ub)
+    if which == 'alanine':          # X-H bonds at their lengths on both paths
+        for i, j, d in system.constraints:
+            for xx in (xa, xb):
+                assert np.abs(np.linalg.norm(xx[:, i] - xx[:, j], axis=-1) - d).max() < 5e-6 * d + 1e-6
 
 
 def test_alchemical_vacuum_system_through_the_store_adapter():

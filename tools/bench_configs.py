@@ -77,6 +77,15 @@ def main():
         s.create(ths, [ss] * 8)
         run('%s (1-GPU share, general alchemical regions, %s): HostGuestExplicit, 8 replicas x 64 states of two named regions, g-BAOAB 2 fs x 500'
             % (tag, kw.get('alchemical_pme_treatment', 'exact PME')), s, 3)
+    for tag, cls in (('v', 'AlanineDipeptideVacuum'), ('g', 'AlanineDipeptideImplicit'), ('hv', 'HostGuestVacuum')):
+        if tag not in which:
+            continue
+        # the reference's small NoCutoff test systems (csrc/nocutoff.hip, csrc/gbsa.hip): 24 temperatures, the headline's protocol
+        t = getattr(testsystems, cls)()
+        ths = [states.ThermodynamicState(t.system, T) for T in np.geomspace(300.0, 600.0, 24)]
+        s = ReplicaExchangeSampler(mcmc_moves=move(2.0, 'V R R O R R V'), number_of_iterations=10 ** 9, engine=HipEngine(), seed=1)
+        s.create(ths, [states.SamplerState(t.positions)])
+        run('%s: %s (%d atoms, NoCutoff), 24 temperatures, swap-all, g-BAOAB 2 fs x 500' % (tag, cls, t.system.getNumParticles()), s, 5)
     if '5' in which:
         dh = testsystems.DHFRExplicit()
         T = np.geomspace(300.0, 400.0, 128)
