@@ -199,6 +199,135 @@ void gb_reduce_kernel(int n, const double* __restrict__ part, double* __restrict
     if (threadIdx.x == 0) { double* o = out + (size_t)r * stride + offset; *o = add ? *o + e : e; }
 }
 
+// Systems of up to 64 atoms (the implicit-solvent test systems the reference's sampler tests run on: AlanineDipeptideImplicit, 22 atoms):
+// the three kernels above are one wavefront per replica summing N dependent partner terms each -- 10 + 7 + 17 us for 22 atoms
+// (profiles/r06_43).  Here ONE launch, a workgroup of 16 wavefronts per replica: lane = atom i, wavefront w takes the partners
+// j = w, w + 16, w + 32, w + 48, the 16 partial sums of an atom go through LDS and are added in wavefront order (a fixed order: the
+// result does not depend on scheduling); Born radii, dE/dB and c_i stay in LDS between the three passes.
+template <bool ENERGY, bool FORCE>
+__global__ __launch_bounds__(1024)
+void gb_small_kernel(int N, int Npad, float tau, int sasa, const float4* __restrict__ par, const float* __restrict__ lam, const float4* __restrict__ pos,
+                     long long* __restrict__ force, double* __restrict__ out, int out_stride, int out_offset, int add)
+{
+    __shared__ float4 s_x[64];             // x, y, z, or_j
+    __shared__ float4 s_p[64];             // q_j, R_j, sr_j, s_j
+    __shared__ float2 s_born[64];          // B, dB/dI
+    __shared__ float s_c[64];              // dE/dB dB/dI
+    __shared__ float4 s_part[16][64];
+    __shared__ double s_e[16];
+    const int r = blockIdx.x, i = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float4* P = pos + (size_t)r * Npad;
+    const float l = lam[r];
+    if (w == 0) {
+        const float4 x = i < N ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f), p = i < N ? par[i] : make_float4(0.f, 1.f, 0.f, 0.f);
+        const float orj = p.y - GB_OFFSET;
+        s_x[i] = make_float4(x.x, x.y, x.z, orj);
+        s_p[i] = make_float4(p.x, p.y, p.z * orj, p.w != 0.f ? l : 1.f);
+    }
+    __syncthreads();
+    const bool live = i < N;
+    const float4 xi = s_x[i], pi = s_p[i];
+    const float or_i = xi.w, sr_i = pi.z, si = pi.w;
+    // pass 1: I_i -> B_i, dB_i/dI_i
+    {
+        float I = 0.f;
+        if (live)
+            for (int j = w; j < N; j += 16) {
+                if (j == i) continue;
+                const float4 xj = s_x[j], pj = s_p[j];
+                const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+                float H, dH;
+                gb_H(sqrtf(dx * dx + dy * dy + dz * dz), or_i, pj.z, H, dH);
+                I += pj.w * H;
+            }
+        s_part[w][i].x = I;
+    }
+    __syncthreads();
+    if (w == 0 && live) {
+        float I = 0.f;
+        for (int q = 0; q < 16; ++q) I += s_part[q][i].x;
+        const float psi = I * or_i, th = tanhf(psi - 0.8f * psi * psi + 4.85f * psi * psi * psi);
+        const float B = 1.f / (1.f / or_i - th / pi.y);
+        s_born[i] = make_float2(B, B * B * (1.f - th * th) * (1.f - 1.6f * psi + 14.55f * psi * psi) * or_i / pi.y);
+    }
+    __syncthreads();
+    // pass 2: self + surface + pair energies, the pair term's direct force on i, dE/dB_i
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    {
+        const float2 bi = live ? s_born[i] : make_float2(1.f, 0.f);
+        const float Qi = si * pi.x;
+        float dEdB = 0.f;
+        double e = 0.0;
+        if (live && w == 0) {
+            const float self = 0.5f * GB_KE * tau * si * pi.x * pi.x / bi.x;
+            dEdB += self / bi.x;
+            if (ENERGY) e -= (double)self;
+            if (sasa) {
+                const float rb = pi.y / bi.x, rb2 = rb * rb, rb6 = rb2 * rb2 * rb2, pre = si * GB_SA * (pi.y + 0.14f) * (pi.y + 0.14f);
+                dEdB -= 6.f * pre * rb6 / bi.x;
+                if (ENERGY) e += (double)(pre * rb6);
+            }
+        }
+        if (live)
+            for (int j = w; j < N; j += 16) {
+                if (j == i) continue;
+                const float4 xj = s_x[j], pj = s_p[j];
+                const float Bj = s_born[j].x;
+                const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                const float D = bi.x * Bj, ex = __expf(-r2 / (4.f * D)), f2 = r2 + D * ex, inv_f = rsqrtf(f2);
+                const float QQ = GB_KE * tau * Qi * (pj.w * pj.x);
+                const float dEdf = QQ / f2;
+                dEdB += dEdf * ex * (1.f + r2 / (4.f * D)) * 0.5f * inv_f * Bj;
+                if (FORCE) { const float gr = dEdf * (1.f - 0.25f * ex) * inv_f; fx += gr * dx; fy += gr * dy; fz += gr * dz; }
+                if (ENERGY) e -= 0.5 * (double)(QQ * inv_f);
+            }
+        s_part[w][i] = make_float4(fx, fy, fz, dEdB);
+        if (ENERGY) {
+            for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+            if (i == 0) s_e[w] = e;
+        }
+        __syncthreads();
+        if (w == 0) {
+            fx = 0.f; fy = 0.f; fz = 0.f; dEdB = 0.f;
+            for (int q = 0; q < 16; ++q) { const float4 t = s_part[q][i]; fx += t.x; fy += t.y; fz += t.z; dEdB += t.w; }
+            s_c[i] = dEdB * bi.y;
+            if (ENERGY && i == 0) {
+                double tot = 0.0;
+                for (int q = 0; q < 16; ++q) tot += s_e[q];
+                double* o = out + (size_t)r * out_stride + out_offset;
+                *o = add ? *o + tot : tot;
+            }
+        }
+        __syncthreads();
+    }
+    if (!FORCE) return;
+    // pass 3: the force through the Born radii
+    {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (live) {
+            const float ci = s_c[i];
+            for (int j = w; j < N; j += 16) {
+                if (j == i) continue;
+                const float4 xj = s_x[j], pj = s_p[j];
+                const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+                const float rr = sqrtf(dx * dx + dy * dy + dz * dz);
+                float H, dH1, dH2;
+                gb_H(rr, or_i, pj.z, H, dH1);              // B_i depends on j
+                gb_H(rr, xj.w, sr_i, H, dH2);              // B_j depends on i
+                const float gr = (ci * pj.w * dH1 + s_c[j] * si * dH2) / rr;
+                gx += gr * dx; gy += gr * dy; gz += gr * dz;
+            }
+        }
+        s_part[w][i] = make_float4(gx, gy, gz, 0.f);
+        __syncthreads();
+        if (w == 0 && live) {
+            for (int q = 0; q < 16; ++q) { const float4 t = s_part[q][i]; fx += t.x; fy += t.y; fz += t.z; }
+            add_force(force + (size_t)r * 3 * Npad, Npad, i, fx, fy, fz);
+        }
+    }
+}
+
 void remd_gbsa_release(remd_ctx* h)
 {
     gbsa_tables* t = g_gb.find(h);
@@ -268,6 +397,12 @@ static float gb_state_lambda(remd_ctx* h, int k)
     return (float)le;
 }
 
+// the one-launch kernel for up to 64 atoms (REMD_GB_SMALL=0: the three launches, for the A/B and the tests of the large path)
+static bool gb_small(const gbsa_tables& t)
+{
+    return t.N <= 64 && !(getenv("REMD_GB_SMALL") && atoi(getenv("REMD_GB_SMALL")) == 0);
+}
+
 int remd_gbsa_forces(remd_ctx* h, bool with_energy, int ep_slot)
 {
     gbsa_tables* tp = g_gb.find(h);
@@ -279,6 +414,12 @@ int remd_gbsa_forces(remd_ctx* h, bool with_energy, int ep_slot)
     if (t.any_alch) for (int r = 0; r < h->R; ++r) lam[r] = gb_state_lambda(h, h->labels.empty() ? 0 : (int)h->labels[h->r_begin + r]);
     if ((rc = gb_set_lambdas(h, t, lam))) return rc;
     remd_prof_scope ps(h, "gbsa");
+    if (gb_small(t)) {
+        if (with_energy) hipLaunchKernelGGL((gb_small_kernel<true, true>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, h->d_force, h->d_epart, h->n_epart, ep_slot, 0);
+        else hipLaunchKernelGGL((gb_small_kernel<false, true>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, h->d_force, (double*)nullptr, 0, 0, 0);
+        REMD_CHECK(h, hipGetLastError());
+        return 0;
+    }
     const dim3 grid(t.n_tile, h->R);
     hipLaunchKernelGGL(gb_born_kernel, grid, dim3(64), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_born);
     if (with_energy) {
@@ -302,6 +443,10 @@ int remd_gbsa_ukl(remd_ctx* h, double* d_alch)
     const dim3 grid(t.n_tile, h->R);
     for (int k = 0; k < h->K; ++k) {
         if ((rc = gb_set_lambdas(h, t, std::vector<float>(h->R, gb_state_lambda(h, k))))) return rc;
+        if (gb_small(t)) {
+            hipLaunchKernelGGL((gb_small_kernel<true, false>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, (long long*)nullptr, d_alch, h->K, k, 1);
+            continue;
+        }
         hipLaunchKernelGGL(gb_born_kernel, grid, dim3(64), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_born);
         hipLaunchKernelGGL((gb_pair_kernel<true, false>), grid, dim3(64), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c,
                            (long long*)nullptr, t.d_epart, t.n_tile);

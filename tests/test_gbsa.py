@@ -114,13 +114,19 @@ def test_cpu_port_evaluates_the_implicit_solvent_dipeptide_like_the_oracle():
     _check_alchemical(HipEngine(lib_path=CPU_LIB), 1e-10, 1e-9).close()
 
 
+# REMD_GB_SMALL: systems of up to 64 atoms take ONE launch (gb_small_kernel: 16 wavefronts per replica share an atom's partners); '0' keeps
+# them on the three launches of the general path -- both against the oracle
 @pytest.mark.gpu
-def test_hip_evaluates_the_implicit_solvent_dipeptide_like_the_oracle(hip_engine_factory):
+@pytest.mark.parametrize('small', ['1', '0'])
+def test_hip_evaluates_the_implicit_solvent_dipeptide_like_the_oracle(hip_engine_factory, monkeypatch, small):
+    monkeypatch.setenv('REMD_GB_SMALL', small)
     _check_plain(hip_engine_factory(), 5e-6, 2e-4)
 
 
 @pytest.mark.gpu
-def test_hip_alchemical_implicit_solvent_dipeptide(hip_engine_factory):
+@pytest.mark.parametrize('small', ['1', '0'])
+def test_hip_alchemical_implicit_solvent_dipeptide(hip_engine_factory, monkeypatch, small):
+    monkeypatch.setenv('REMD_GB_SMALL', small)
     _check_alchemical(hip_engine_factory(), 1e-5, 2e-4)
 
 
