@@ -4,7 +4,7 @@
 // oracle/forcefield.py (method 3).
 //
 // These systems are small (tens to a few thousand atoms), so the sum is the direct one: workgroup = (tile of 64 atoms i, replica), the j
-// atoms staged through LDS 64 at a time, every pair from both sides (the force on i needs no reduction: one fixed-point atomic triple per
+// atoms staged through LDS 1024 at a time and split over 16 wavefronts, every pair from both sides (the force on i needs no reduction: one fixed-point atomic triple per
 // atom and launch), excluded pairs from an N x N bit matrix.  Energies: a second variant with per-workgroup f64 partials in a fixed order.
 // The rest of the engine sees such a handle as one without a cutoff-based nonbonded force (remd_ctx::nb_method = REMD_NB_NONE,
 // remd_ctx::nocutoff = 1): listed terms, integrator chain, Monte Carlo moves are those of the non-periodic path the harmonic oscillator
@@ -35,14 +35,23 @@ static int upload(remd_ctx* h, T*& dptr, const std::vector<T>& host)
     return 0;
 }
 
+// workgroup = (tile of 64 atoms i, replica), NC_WAVES wavefronts: lane = atom i, wavefront w takes the partners j = w (mod NC_WAVES) of
+// every block of NC_BLOCK atoms staged in LDS; the partial sums of an atom go through LDS and are added in wavefront order (a fixed order:
+// the forces do not depend on scheduling).  (One wavefront per tile looping over all N partners is a chain of N dependent pair terms:
+// 31 us for the 156 atoms of CB7:B2 in vacuum, rocprofv3, profiles/r06_43.)
+#define NC_WAVES 16
+#define NC_BLOCK (64 * NC_WAVES)
 template <bool ENERGY>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(NC_BLOCK)
 void nocutoff_kernel(int N, int Npad, int words, const float4* __restrict__ param, const unsigned int* __restrict__ excl,
                      int n_exc, const int* __restrict__ exc_atoms, const float4* __restrict__ exc_par,
                      const float4* __restrict__ pos, long long* __restrict__ force, double* __restrict__ epart, int n_tile)
 {
-    __shared__ float4 s_x[64], s_p[64];
-    const int r = blockIdx.y, tile = blockIdx.x, lane = threadIdx.x;
+    __shared__ float4 s_x[NC_BLOCK], s_p[NC_BLOCK];
+    __shared__ unsigned int s_m[64][NC_BLOCK / 32 + 1];       // exclusion words of the tile's atoms for the staged block (padded: no bank conflicts)
+    __shared__ float4 s_part[NC_WAVES][64];
+    __shared__ double s_e[NC_WAVES];
+    const int r = blockIdx.y, tile = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float4* P = pos + (size_t)r * Npad;
     long long* F = force + (size_t)r * 3 * Npad;
     double e = 0.0;
@@ -52,24 +61,36 @@ void nocutoff_kernel(int N, int Npad, int words, const float4* __restrict__ para
         const float4 xi = live ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 pi = live ? param[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         float fx = 0.f, fy = 0.f, fz = 0.f;
-        for (int j0 = 0; j0 < N; j0 += 64) {
+        for (int j0 = 0; j0 < N; j0 += NC_BLOCK) {
             __syncthreads();
-            s_x[lane] = (j0 + lane < N) ? P[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-            s_p[lane] = (j0 + lane < N) ? param[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            {
+                const int j = j0 + (int)threadIdx.x;
+                s_x[threadIdx.x] = j < N ? P[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                s_p[threadIdx.x] = j < N ? param[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                // 64 atoms x NC_BLOCK / 32 words: two per thread
+                for (int q = threadIdx.x; q < 64 * (NC_BLOCK / 32); q += NC_BLOCK) {
+                    const int a = q / (NC_BLOCK / 32), wd = q % (NC_BLOCK / 32), ai = tile * 64 + a, gw = (j0 >> 5) + wd;
+                    s_m[a][wd] = (ai < N && gw < words) ? excl[(size_t)ai * words + gw] : 0u;
+                }
+            }
             __syncthreads();
             if (!live) continue;
-            const unsigned int m0 = excl[(size_t)i * words + (j0 >> 5)], m1 = (j0 + 32 < N) ? excl[(size_t)i * words + (j0 >> 5) + 1] : 0u;
-            const int jn = min(64, N - j0);
-            for (int k = 0; k < jn; ++k) {
-                const int j = j0 + k;
-                if (j == i || (((k < 32 ? m0 : m1) >> (k & 31)) & 1u)) continue;
+            const int jn = min(NC_BLOCK, N - j0);
+            for (int k = w; k < jn; k += NC_WAVES) {
+                if (j0 + k == i || ((s_m[lane][k >> 5] >> (k & 31)) & 1u)) continue;
                 nocutoff_pair<ENERGY>(xi, pi, s_x[k], s_p[k], fx, fy, fz, e);
             }
         }
-        if (live) add_force(F, Npad, i, fx, fy, fz);
+        s_part[w][lane] = make_float4(fx, fy, fz, 0.f);
+        __syncthreads();
+        if (w == 0 && live) {
+            fx = 0.f; fy = 0.f; fz = 0.f;
+            for (int q = 0; q < NC_WAVES; ++q) { const float4 t = s_part[q][lane]; fx += t.x; fy += t.y; fz += t.z; }
+            add_force(F, Npad, i, fx, fy, fz);
+        }
     } else {
         // the last workgroup of a replica: the exceptions (plain Coulomb + Lennard-Jones of the exception's own parameters)
-        for (int t = lane; t < n_exc; t += 64) {
+        for (int t = threadIdx.x; t < n_exc; t += NC_BLOCK) {
             const int i = exc_atoms[2 * t], j = exc_atoms[2 * t + 1];
             const float4 par = exc_par[t];
             const float3 d = sub3(ld3(P, j), ld3(P, i));
@@ -80,7 +101,13 @@ void nocutoff_kernel(int N, int Npad, int words, const float4* __restrict__ para
     }
     if (ENERGY) {
         for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
-        if (lane == 0) epart[(size_t)r * (n_tile + 1) + tile] = e;
+        if (lane == 0) s_e[w] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int q = 0; q < NC_WAVES; ++q) tot += s_e[q];
+            epart[(size_t)r * (n_tile + 1) + tile] = tot;
+        }
     }
 }
 
@@ -153,11 +180,11 @@ int remd_nocutoff_forces(remd_ctx* h, bool with_energy, int ep_slot)
     const dim3 grid(t.n_tile + 1, h->R);
     if (with_energy) {
         if (t.epart_R != h->R) { dfree(t.d_epart); REMD_CHECK(h, hipMalloc(&t.d_epart, sizeof(double) * (size_t)h->R * (t.n_tile + 1))); t.epart_R = h->R; }
-        hipLaunchKernelGGL(nocutoff_kernel<true>, grid, dim3(64), 0, h->stream, t.N, h->Npad, t.words, t.d_param, t.d_excl, t.n_exc, t.d_exc_atoms, t.d_exc_par,
+        hipLaunchKernelGGL(nocutoff_kernel<true>, grid, dim3(NC_BLOCK), 0, h->stream, t.N, h->Npad, t.words, t.d_param, t.d_excl, t.n_exc, t.d_exc_atoms, t.d_exc_par,
                            h->d_pos, h->d_force, t.d_epart, t.n_tile);
         hipLaunchKernelGGL(nocutoff_reduce_kernel, dim3(h->R), dim3(64), 0, h->stream, t.n_tile + 1, t.d_epart, h->d_epart, h->n_epart, ep_slot);
     } else {
-        hipLaunchKernelGGL(nocutoff_kernel<false>, grid, dim3(64), 0, h->stream, t.N, h->Npad, t.words, t.d_param, t.d_excl, t.n_exc, t.d_exc_atoms, t.d_exc_par,
+        hipLaunchKernelGGL(nocutoff_kernel<false>, grid, dim3(NC_BLOCK), 0, h->stream, t.N, h->Npad, t.words, t.d_param, t.d_excl, t.n_exc, t.d_exc_atoms, t.d_exc_par,
                            h->d_pos, h->d_force, (double*)nullptr, t.n_tile);
     }
     REMD_CHECK(h, hipGetLastError());

@@ -82,10 +82,11 @@ def main():
             continue
         # the reference's small NoCutoff test systems (csrc/nocutoff.hip, csrc/gbsa.hip): 24 temperatures, the headline's protocol
         t = getattr(testsystems, cls)()
-        ths = [states.ThermodynamicState(t.system, T) for T in np.geomspace(300.0, 600.0, 24)]
+        nt = int(os.environ.get('REMD_BENCH_NT', '24'))           # (swap-all timings at other ensemble sizes: profiles/r06_44)
+        ths = [states.ThermodynamicState(t.system, T) for T in np.geomspace(300.0, 600.0, nt)]
         s = ReplicaExchangeSampler(mcmc_moves=move(2.0, 'V R R O R R V'), number_of_iterations=10 ** 9, engine=HipEngine(), seed=1)
         s.create(ths, [states.SamplerState(t.positions)])
-        run('%s: %s (%d atoms, NoCutoff), 24 temperatures, swap-all, g-BAOAB 2 fs x 500' % (tag, cls, t.system.getNumParticles()), s, 5)
+        run('%s: %s (%d atoms, NoCutoff), %d temperatures, swap-all, g-BAOAB 2 fs x 500' % (tag, cls, t.system.getNumParticles(), nt), s, 5)
     if '5' in which:
         dh = testsystems.DHFRExplicit()
         T = np.geomspace(300.0, 400.0, 128)
