@@ -3,8 +3,8 @@
 // definition followed here; include/remd_hip.h remd_set_gbsa states them).  NoCutoff systems only (the implicit-solvent test systems of
 // the reference: tens to a few thousand atoms).  f64 restatement: oracle/gbsa.py, pinned to the reference's strings.
 //
-// Three launches per force evaluation, each the direct all-pairs sum of nocutoff.hip (workgroup = 64 atoms i of one replica, j through LDS,
-// every pair from both sides so that nothing is reduced across atoms):
+// Three launches per force evaluation, each the direct all-pairs sum of nocutoff.hip (workgroup = 64 atoms i of one replica, 16 wavefronts that
+// split the partners j staged through LDS, every pair from both sides so that nothing is reduced across atoms):
 //   gb_born_kernel    I_i = sum_j s_j H(r_ij; or_i, sr_j)  ->  B_i and dB_i/dI_i
 //   gb_pair_kernel    self + surface + pair energies, the pair term's direct force on i, dE/dB_i  ->  c_i = dE/dB_i dB_i/dI_i
 //   gb_chain_kernel   the force through the Born radii: sum_j [c_i s_j H'(r; or_i, sr_j) + c_j s_i H'(r; or_j, sr_i)] (x_j - x_i) / r
@@ -49,12 +49,19 @@ __device__ __forceinline__ void gb_H(float r, float or1, float sr2, float& H, fl
                  + 0.5f * ((dL * iL - iU) * ir - lg * ir * ir) + dC);
 }
 
-__global__ __launch_bounds__(64)
+// The three kernels: workgroup = (64 atoms i, replica) of GB_WAVES wavefronts; lane = atom i, wavefront w takes the partners
+// j = w (mod GB_WAVES) of every block of GB_BLOCK atoms staged in LDS, an atom's partial sums are added in wavefront order (fixed order).
+// (One wavefront per tile summing N dependent partner terms -- each with a logarithm and a handful of divisions -- was 10 + 7 + 17 us for
+// 22 atoms: profiles/r06_43.)
+#define GB_WAVES 16
+#define GB_BLOCK (64 * GB_WAVES)
+__global__ __launch_bounds__(GB_BLOCK)
 void gb_born_kernel(int N, int Npad, const float4* __restrict__ par, const float* __restrict__ lam, const float4* __restrict__ pos, float2* __restrict__ born)
 {
-    __shared__ float4 s_x[64];             // x, y, z, s_j sr_j packed: w = sr_j, and the scale factor rides in s_s
-    __shared__ float s_s[64];
-    const int r = blockIdx.y, lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+    __shared__ float4 s_x[GB_BLOCK];       // x, y, z, sr_j
+    __shared__ float s_s[GB_BLOCK];        // s_j
+    __shared__ float s_part[GB_WAVES][64];
+    const int r = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
     const float4* P = pos + (size_t)r * Npad;
     const float l = lam[r];
     const bool live = i < N;
@@ -62,17 +69,17 @@ void gb_born_kernel(int N, int Npad, const float4* __restrict__ par, const float
     const float4 pi = live ? par[i] : make_float4(0.f, 1.f, 0.f, 0.f);
     const float or_i = pi.y - GB_OFFSET;
     float I = 0.f;
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    for (int j0 = 0; j0 < N; j0 += GB_BLOCK) {
         __syncthreads();
-        if (j0 + lane < N) {
-            const float4 xj = P[j0 + lane], pj = par[j0 + lane];
-            s_x[lane] = make_float4(xj.x, xj.y, xj.z, pj.z * (pj.y - GB_OFFSET));
-            s_s[lane] = pj.w != 0.f ? l : 1.f;
+        if (j0 + (int)threadIdx.x < N) {
+            const float4 xj = P[j0 + threadIdx.x], pj = par[j0 + threadIdx.x];
+            s_x[threadIdx.x] = make_float4(xj.x, xj.y, xj.z, pj.z * (pj.y - GB_OFFSET));
+            s_s[threadIdx.x] = pj.w != 0.f ? l : 1.f;
         }
         __syncthreads();
         if (!live) continue;
-        const int jn = min(64, N - j0);
-        for (int k = 0; k < jn; ++k) {
+        const int jn = min(GB_BLOCK, N - j0);
+        for (int k = w; k < jn; k += GB_WAVES) {
             if (j0 + k == i) continue;
             const float4 xj = s_x[k];
             const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
@@ -81,7 +88,11 @@ void gb_born_kernel(int N, int Npad, const float4* __restrict__ par, const float
             I += s_s[k] * H;
         }
     }
-    if (live) {
+    s_part[w][lane] = I;
+    __syncthreads();
+    if (w == 0 && live) {
+        I = 0.f;
+        for (int q = 0; q < GB_WAVES; ++q) I += s_part[q][lane];
         const float psi = I * or_i, th = tanhf(psi - 0.8f * psi * psi + 4.85f * psi * psi * psi);
         const float B = 1.f / (1.f / or_i - th / pi.y);
         born[(size_t)r * Npad + i] = make_float2(B, B * B * (1.f - th * th) * (1.f - 1.6f * psi + 14.55f * psi * psi) * or_i / pi.y);
@@ -89,13 +100,15 @@ void gb_born_kernel(int N, int Npad, const float4* __restrict__ par, const float
 }
 
 template <bool ENERGY, bool FORCE>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(GB_BLOCK)
 void gb_pair_kernel(int N, int Npad, float tau, int sasa, const float4* __restrict__ par, const float* __restrict__ lam, const float4* __restrict__ pos,
                     const float2* __restrict__ born, float* __restrict__ cfac, long long* __restrict__ force, double* __restrict__ epart, int n_tile)
 {
-    __shared__ float4 s_x[64];             // x, y, z, B_j
-    __shared__ float s_q[64];              // s_j q_j
-    const int r = blockIdx.y, lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+    __shared__ float4 s_x[GB_BLOCK];       // x, y, z, B_j
+    __shared__ float s_q[GB_BLOCK];        // s_j q_j
+    __shared__ float4 s_part[GB_WAVES][64];
+    __shared__ double s_e[GB_WAVES];
+    const int r = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
     const float4* P = pos + (size_t)r * Npad;
     const float2* BR = born + (size_t)r * Npad;
     const float l = lam[r];
@@ -106,7 +119,7 @@ void gb_pair_kernel(int N, int Npad, float tau, int sasa, const float4* __restri
     const float si = pi.w != 0.f ? l : 1.f, Qi = si * pi.x;
     float fx = 0.f, fy = 0.f, fz = 0.f, dEdB = 0.f;
     double e = 0.0;
-    if (live) {
+    if (live && w == 0) {
         const float self = 0.5f * GB_KE * tau * si * pi.x * pi.x / bi.x;
         dEdB += self / bi.x;
         if (ENERGY) e -= (double)self;
@@ -116,17 +129,17 @@ void gb_pair_kernel(int N, int Npad, float tau, int sasa, const float4* __restri
             if (ENERGY) e += (double)(pre * rb6);
         }
     }
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    for (int j0 = 0; j0 < N; j0 += GB_BLOCK) {
         __syncthreads();
-        if (j0 + lane < N) {
-            const float4 xj = P[j0 + lane], pj = par[j0 + lane];
-            s_x[lane] = make_float4(xj.x, xj.y, xj.z, BR[j0 + lane].x);
-            s_q[lane] = (pj.w != 0.f ? l : 1.f) * pj.x;
+        if (j0 + (int)threadIdx.x < N) {
+            const float4 xj = P[j0 + threadIdx.x], pj = par[j0 + threadIdx.x];
+            s_x[threadIdx.x] = make_float4(xj.x, xj.y, xj.z, BR[j0 + threadIdx.x].x);
+            s_q[threadIdx.x] = (pj.w != 0.f ? l : 1.f) * pj.x;
         }
         __syncthreads();
         if (!live) continue;
-        const int jn = min(64, N - j0);
-        for (int k = 0; k < jn; ++k) {
+        const int jn = min(GB_BLOCK, N - j0);
+        for (int k = w; k < jn; k += GB_WAVES) {
             if (j0 + k == i) continue;
             const float4 xj = s_x[k];
             const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
@@ -139,22 +152,36 @@ void gb_pair_kernel(int N, int Npad, float tau, int sasa, const float4* __restri
             if (ENERGY) e -= 0.5 * (double)(QQ * inv_f);
         }
     }
-    if (live) {
-        if (FORCE) { cfac[(size_t)r * Npad + i] = dEdB * bi.y; add_force(force + (size_t)r * 3 * Npad, Npad, i, fx, fy, fz); }
+    if (FORCE) {
+        s_part[w][lane] = make_float4(fx, fy, fz, dEdB);
+        __syncthreads();
+        if (w == 0 && live) {
+            fx = 0.f; fy = 0.f; fz = 0.f; dEdB = 0.f;
+            for (int q = 0; q < GB_WAVES; ++q) { const float4 t = s_part[q][lane]; fx += t.x; fy += t.y; fz += t.z; dEdB += t.w; }
+            cfac[(size_t)r * Npad + i] = dEdB * bi.y;
+            add_force(force + (size_t)r * 3 * Npad, Npad, i, fx, fy, fz);
+        }
     }
     if (ENERGY) {
         for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
-        if (lane == 0) epart[(size_t)r * n_tile + blockIdx.x] = e;
+        if (lane == 0) s_e[w] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int q = 0; q < GB_WAVES; ++q) tot += s_e[q];
+            epart[(size_t)r * n_tile + blockIdx.x] = tot;
+        }
     }
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(GB_BLOCK)
 void gb_chain_kernel(int N, int Npad, const float4* __restrict__ par, const float* __restrict__ lam, const float4* __restrict__ pos,
                      const float* __restrict__ cfac, long long* __restrict__ force)
 {
-    __shared__ float4 s_x[64];             // x, y, z, or_j
-    __shared__ float4 s_p[64];             // sr_j, s_j, c_j, -
-    const int r = blockIdx.y, lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+    __shared__ float4 s_x[GB_BLOCK];       // x, y, z, or_j
+    __shared__ float4 s_p[GB_BLOCK];       // sr_j, s_j, c_j, -
+    __shared__ float4 s_part[GB_WAVES][64];
+    const int r = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
     const float4* P = pos + (size_t)r * Npad;
     const float* Cf = cfac + (size_t)r * Npad;
     const float l = lam[r];
@@ -163,18 +190,18 @@ void gb_chain_kernel(int N, int Npad, const float4* __restrict__ par, const floa
     const float4 pi = live ? par[i] : make_float4(0.f, 1.f, 0.f, 0.f);
     const float or_i = pi.y - GB_OFFSET, sr_i = pi.z * or_i, si = pi.w != 0.f ? l : 1.f, ci = live ? Cf[i] : 0.f;
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    for (int j0 = 0; j0 < N; j0 += GB_BLOCK) {
         __syncthreads();
-        if (j0 + lane < N) {
-            const float4 xj = P[j0 + lane], pj = par[j0 + lane];
+        if (j0 + (int)threadIdx.x < N) {
+            const float4 xj = P[j0 + threadIdx.x], pj = par[j0 + threadIdx.x];
             const float orj = pj.y - GB_OFFSET;
-            s_x[lane] = make_float4(xj.x, xj.y, xj.z, orj);
-            s_p[lane] = make_float4(pj.z * orj, pj.w != 0.f ? l : 1.f, Cf[j0 + lane], 0.f);
+            s_x[threadIdx.x] = make_float4(xj.x, xj.y, xj.z, orj);
+            s_p[threadIdx.x] = make_float4(pj.z * orj, pj.w != 0.f ? l : 1.f, Cf[j0 + threadIdx.x], 0.f);
         }
         __syncthreads();
         if (!live) continue;
-        const int jn = min(64, N - j0);
-        for (int k = 0; k < jn; ++k) {
+        const int jn = min(GB_BLOCK, N - j0);
+        for (int k = w; k < jn; k += GB_WAVES) {
             if (j0 + k == i) continue;
             const float4 xj = s_x[k], pj = s_p[k];
             const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
@@ -186,7 +213,13 @@ void gb_chain_kernel(int N, int Npad, const float4* __restrict__ par, const floa
             fx += gr * dx; fy += gr * dy; fz += gr * dz;
         }
     }
-    if (live) add_force(force + (size_t)r * 3 * Npad, Npad, i, fx, fy, fz);
+    s_part[w][lane] = make_float4(fx, fy, fz, 0.f);
+    __syncthreads();
+    if (w == 0 && live) {
+        fx = 0.f; fy = 0.f; fz = 0.f;
+        for (int q = 0; q < GB_WAVES; ++q) { const float4 t = s_part[q][lane]; fx += t.x; fy += t.y; fz += t.z; }
+        add_force(force + (size_t)r * 3 * Npad, Npad, i, fx, fy, fz);
+    }
 }
 
 __global__ __launch_bounds__(64)
@@ -421,13 +454,13 @@ int remd_gbsa_forces(remd_ctx* h, bool with_energy, int ep_slot)
         return 0;
     }
     const dim3 grid(t.n_tile, h->R);
-    hipLaunchKernelGGL(gb_born_kernel, grid, dim3(64), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_born);
+    hipLaunchKernelGGL(gb_born_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_born);
     if (with_energy) {
-        hipLaunchKernelGGL((gb_pair_kernel<true, true>), grid, dim3(64), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c, h->d_force, t.d_epart, t.n_tile);
+        hipLaunchKernelGGL((gb_pair_kernel<true, true>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c, h->d_force, t.d_epart, t.n_tile);
         hipLaunchKernelGGL(gb_reduce_kernel, dim3(h->R), dim3(64), 0, h->stream, t.n_tile, t.d_epart, h->d_epart, h->n_epart, ep_slot, 0);
     } else
-        hipLaunchKernelGGL((gb_pair_kernel<false, true>), grid, dim3(64), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c, h->d_force, (double*)nullptr, t.n_tile);
-    hipLaunchKernelGGL(gb_chain_kernel, grid, dim3(64), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_c, h->d_force);
+        hipLaunchKernelGGL((gb_pair_kernel<false, true>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c, h->d_force, (double*)nullptr, t.n_tile);
+    hipLaunchKernelGGL(gb_chain_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_c, h->d_force);
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }
@@ -447,8 +480,8 @@ int remd_gbsa_ukl(remd_ctx* h, double* d_alch)
             hipLaunchKernelGGL((gb_small_kernel<true, false>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, (long long*)nullptr, d_alch, h->K, k, 1);
             continue;
         }
-        hipLaunchKernelGGL(gb_born_kernel, grid, dim3(64), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_born);
-        hipLaunchKernelGGL((gb_pair_kernel<true, false>), grid, dim3(64), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c,
+        hipLaunchKernelGGL(gb_born_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_born);
+        hipLaunchKernelGGL((gb_pair_kernel<true, false>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c,
                            (long long*)nullptr, t.d_epart, t.n_tile);
         hipLaunchKernelGGL(gb_reduce_kernel, dim3(h->R), dim3(64), 0, h->stream, t.n_tile, t.d_epart, d_alch, h->K, k, 1);
     }

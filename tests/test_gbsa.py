@@ -72,6 +72,58 @@ def _check_plain(eng, rtol, ftol):
     return eng
 
 
+def _droplet_in_implicit_solvent(n=150):
+    """a droplet of charged Lennard-Jones particles with GBSA parameters: more than two 64-atom tiles, an alchemical half (the tiled GB
+    kernels and the multi-wavefront NoCutoff sum beyond one tile; the dipeptide has 22 atoms)"""
+    from openmmtools_amd.system import System, NonbondedForce
+    g = np.stack(np.meshgrid(*[np.arange(6)] * 3, indexing='ij'), axis=-1).reshape(-1, 3) * 0.38
+    x = g[np.argsort(np.linalg.norm(g - g.mean(0), axis=1), kind='stable')[:n]].astype(np.float64)
+    s = System()
+    nb = NonbondedForce(); nb.setNonbondedMethod(NonbondedForce.NoCutoff)
+    gb = GBSAOBCForce()
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        s.addParticle(39.9)
+        q = 0.3 if i % 2 == 0 else -0.3
+        nb.addParticle(q, 0.34, 0.5)
+        gb.addParticle(q, 0.15 + 0.05 * rng.random(), 0.7 + 0.2 * rng.random())
+    nb.addException(0, 1, 0.0, 0.3, 0.0)
+    s.addForce(nb); s.addForce(gb)
+    return s, x
+
+
+def _check_droplet(eng, rtol, ftol):
+    system, x0 = _droplet_in_implicit_solvent()
+    desc = system_to_desc(system)
+    eng.set_system(desc)
+    T = np.array([300.0, 350.0])
+    eng.set_states(1.0 / (KB * T))
+    eng.set_integrator('V R O R V', 0.001, 1.0, 10, True, 1e-8)
+    eng.seed(6)
+    x = np.stack([x0 + 0.004 * (r + 1) * np.random.default_rng(r).normal(size=x0.shape) for r in range(2)])
+    eng.set_replicas(2, 0, x, None, np.zeros((2, 3)), np.arange(2))
+    rows, U = eng.compute_energies(want_potential=True)
+    xd = eng.get_replicas()[0]
+    f = eng.get_forces()
+    for r in range(2):
+        d0, e1, f1 = _gb_total(desc, xd[r], 1.0)
+        e0, f0 = ForceFieldOracle(d0).energy_forces(xd[r], None)
+        assert np.isclose(U[r], e0 + e1, rtol=rtol, atol=rtol * 100.0), (U[r], e0 + e1)
+        assert np.abs(f[r] - (f0 + f1)).max() < ftol * np.abs(f0 + f1).max()
+    assert not np.any(eng.propagate(0))
+
+
+def test_cpu_port_evaluates_a_droplet_of_150_atoms_in_implicit_solvent_like_the_oracle():
+    if not os.path.exists(CPU_LIB):
+        pytest.skip('oracle/_build/libremd_cpu.so not built (make -C oracle)')
+    _check_droplet(HipEngine(lib_path=CPU_LIB), 1e-9, 1e-8)
+
+
+@pytest.mark.gpu
+def test_hip_evaluates_a_droplet_of_150_atoms_in_implicit_solvent_like_the_oracle(hip_engine_factory):
+    _check_droplet(hip_engine_factory(), 5e-6, 2e-4)
+
+
 LS = np.array([[1.0], [1.0], [0.5], [0.0]])
 LE = np.array([[1.0], [0.4], [0.0], [0.0]])
 
