@@ -185,9 +185,28 @@ def test_parallel_tempering_of_the_vacuum_dipeptide_on_the_device(hip_engine_fac
     assert np.abs(u[:, 0] * KB * T[0]).max() < 500.0
 
 
+def _water_cluster(n=12):
+    """n rigid TIP3P waters on a lattice without a box (testsystems.WaterCluster's shape: NoCutoff, three constraints per molecule)"""
+    s = System()
+    nb = NonbondedForce(); nb.setNonbondedMethod(NonbondedForce.NoCutoff)
+    dOH, ang = 0.09572, np.deg2rad(104.52)
+    dHH = 2.0 * dOH * np.sin(0.5 * ang)
+    x = []
+    g = np.stack(np.meshgrid(np.arange(3), np.arange(2), np.arange(2), indexing='ij'), axis=-1).reshape(-1, 3)[:n] * 0.31
+    for m in range(n):
+        o = 3 * m
+        for mass, q, sg, ep in ((15.9994, -0.834, 0.3150752406575124, 0.635968), (1.008, 0.417, 1.0, 0.0), (1.008, 0.417, 1.0, 0.0)):
+            s.addParticle(mass); nb.addParticle(q, sg, ep)
+        s.addConstraint(o, o + 1, dOH); s.addConstraint(o, o + 2, dOH); s.addConstraint(o + 1, o + 2, dHH)
+        nb.addException(o, o + 1, 0.0, 1.0, 0.0); nb.addException(o, o + 2, 0.0, 1.0, 0.0); nb.addException(o + 1, o + 2, 0.0, 1.0, 0.0)
+        x += [g[m], g[m] + [dOH, 0.0, 0.0], g[m] + [dOH * np.cos(ang), dOH * np.sin(ang), 0.0]]
+    s.addForce(nb)
+    return s, np.array(x, dtype=np.float64)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('which,splitting,dt,n_steps', [('alanine', 'V R R O R R V', 0.002, 10), ('alanine', 'V R R O R R V', 0.002, 500),
-                                                        ('alanine', 'O V R V O', 0.001, 100), ('droplet', 'V R O R V', 0.002, 100)])
+                                                        ('alanine', 'O V R V O', 0.001, 100), ('droplet', 'V R O R V', 0.002, 100), ('water', 'V R O R V', 0.001, 5), ('water', 'V R R O R R V', 0.002, 10)])
 def test_resident_small_molecule_kernel_follows_the_regular_launches(hip_engine_factory, monkeypatch, which, splitting, dt, n_steps):
     """NoCutoff systems of up to 64 atoms are propagated by ONE launch per move (integrate.hip resident_mol_kernel: a workgroup per
     replica, a constraint unit per thread, positions and fixed-point force accumulators in LDS) instead of three dependent launches per
@@ -195,7 +214,8 @@ def test_resident_small_molecule_kernel_follows_the_regular_launches(hip_engine_
     the same centre-of-mass sum: the trajectory follows the regular launches (REMD_RESIDENT=0) to fp32 rounding -- one ulp of a velocity
     per step at first, amplified by the dynamics afterwards (10 steps: 1e-7 nm; 500 steps of a molecule at 600 K: the same basin,
     the same energy within a few kT)."""
-    system, x0 = _cluster(60) if which == 'droplet' else _system(which)      # (60 free atoms: no constraint units, no listed terms)
+    # (droplet: 60 free atoms, no constraint units, no listed terms; water: twelve rigid molecules, the analytic three-site solve)
+    system, x0 = _cluster(60) if which == 'droplet' else _water_cluster() if which == 'water' else _system(which)
     desc = system_to_desc(system)
     out = []
     for flag in ('1', '0'):
@@ -213,7 +233,7 @@ def test_resident_small_molecule_kernel_follows_the_regular_launches(hip_engine_
         xa, va = eng.get_replicas()[:2]
         out.append((xa.copy(), va.copy(), eng.compute_energies(want_potential=True)[1]))
     (xa, va, ua), (xb, vb, ub) = out
-    assert np.abs(xa - x).max() > (0.2 if n_steps == 500 else 0.01)              # it moved
+    assert np.abs(xa - x).max() > (0.2 if n_steps == 500 else 0.01 if n_steps > 10 else 0.002)              # it moved
     dx, dv = np.abs(xa - xb), np.abs(va - vb)
     if n_steps <= 10:
         assert dx.max() < 2e-6 and dv.max() < 2e-4, (dx.max(), dv.max())
@@ -224,7 +244,7 @@ def test_resident_small_molecule_kernel_follows_the_regular_launches(hip_engine_
     else:
         assert np.median(dx) < 5e-3, np.median(dx)
         assert np.abs(ua - ub).max() < 40.0, (ua, ub)
-    if which == 'alanine':          # X-H bonds at their lengths on both paths
+    if which in ('alanine', 'water'):          # constrained distances at their lengths on both paths
         for i, j, d in system.constraints:
             for xx in (xa, xb):
                 assert np.abs(np.linalg.norm(xx[:, i] - xx[:, j], axis=-1) - d).max() < 5e-6 * d + 1e-6
