@@ -25,7 +25,8 @@ struct gbsa_tables {
     float4* d_par = nullptr;               // [Npad] q, R, scale, alchemical
     float2* d_born = nullptr;              // [R][Npad] B, dB/dI
     float* d_c = nullptr;                  // [R][Npad] dE/dB dB/dI
-    float* d_lam = nullptr; std::vector<float> lam_host;      // [R] lambda_electrostatics of each replica's state (or of the u_kl column)
+    float* d_lam = nullptr; std::vector<float> lam_host;      // [R] lambda_electrostatics of each replica's state
+    float* d_state_lam = nullptr; std::vector<float> state_lam_host;   // [K] of every state (u_kl columns)
     double* d_epart = nullptr; double* d_col = nullptr; int buf_R = 0;
 };
 static handle_table<gbsa_tables> g_gb;
@@ -56,14 +57,14 @@ __device__ __forceinline__ void gb_H(float r, float or1, float sr2, float& H, fl
 #define GB_WAVES 16
 #define GB_BLOCK (64 * GB_WAVES)
 __global__ __launch_bounds__(GB_BLOCK)
-void gb_born_kernel(int N, int Npad, const float4* __restrict__ par, const float* __restrict__ lam, const float4* __restrict__ pos, float2* __restrict__ born)
+void gb_born_kernel(int N, int Npad, const float4* __restrict__ par, const float* __restrict__ lam, int lam_stride, const float4* __restrict__ pos, float2* __restrict__ born)
 {
     __shared__ float4 s_x[GB_BLOCK];       // x, y, z, sr_j
     __shared__ float s_s[GB_BLOCK];        // s_j
     __shared__ float s_part[GB_WAVES][64];
     const int r = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
     const float4* P = pos + (size_t)r * Npad;
-    const float l = lam[r];
+    const float l = lam[(size_t)r * lam_stride];         // (stride 0: every replica at one state's lambda, a u_kl column)
     const bool live = i < N;
     const float4 xi = live ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 pi = live ? par[i] : make_float4(0.f, 1.f, 0.f, 0.f);
@@ -101,7 +102,7 @@ void gb_born_kernel(int N, int Npad, const float4* __restrict__ par, const float
 
 template <bool ENERGY, bool FORCE>
 __global__ __launch_bounds__(GB_BLOCK)
-void gb_pair_kernel(int N, int Npad, float tau, int sasa, const float4* __restrict__ par, const float* __restrict__ lam, const float4* __restrict__ pos,
+void gb_pair_kernel(int N, int Npad, float tau, int sasa, const float4* __restrict__ par, const float* __restrict__ lam, int lam_stride, const float4* __restrict__ pos,
                     const float2* __restrict__ born, float* __restrict__ cfac, long long* __restrict__ force, double* __restrict__ epart, int n_tile)
 {
     __shared__ float4 s_x[GB_BLOCK];       // x, y, z, B_j
@@ -111,7 +112,7 @@ void gb_pair_kernel(int N, int Npad, float tau, int sasa, const float4* __restri
     const int r = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
     const float4* P = pos + (size_t)r * Npad;
     const float2* BR = born + (size_t)r * Npad;
-    const float l = lam[r];
+    const float l = lam[(size_t)r * lam_stride];         // (stride 0: every replica at one state's lambda, a u_kl column)
     const bool live = i < N;
     const float4 xi = live ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 pi = live ? par[i] : make_float4(0.f, 1.f, 0.f, 0.f);
@@ -175,7 +176,7 @@ void gb_pair_kernel(int N, int Npad, float tau, int sasa, const float4* __restri
 }
 
 __global__ __launch_bounds__(GB_BLOCK)
-void gb_chain_kernel(int N, int Npad, const float4* __restrict__ par, const float* __restrict__ lam, const float4* __restrict__ pos,
+void gb_chain_kernel(int N, int Npad, const float4* __restrict__ par, const float* __restrict__ lam, int lam_stride, const float4* __restrict__ pos,
                      const float* __restrict__ cfac, long long* __restrict__ force)
 {
     __shared__ float4 s_x[GB_BLOCK];       // x, y, z, or_j
@@ -184,7 +185,7 @@ void gb_chain_kernel(int N, int Npad, const float4* __restrict__ par, const floa
     const int r = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
     const float4* P = pos + (size_t)r * Npad;
     const float* Cf = cfac + (size_t)r * Npad;
-    const float l = lam[r];
+    const float l = lam[(size_t)r * lam_stride];         // (stride 0: every replica at one state's lambda, a u_kl column)
     const bool live = i < N;
     const float4 xi = live ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 pi = live ? par[i] : make_float4(0.f, 1.f, 0.f, 0.f);
@@ -239,7 +240,7 @@ void gb_reduce_kernel(int n, const double* __restrict__ part, double* __restrict
 // result does not depend on scheduling); Born radii, dE/dB and c_i stay in LDS between the three passes.
 template <bool ENERGY, bool FORCE>
 __global__ __launch_bounds__(1024)
-void gb_small_kernel(int N, int Npad, float tau, int sasa, const float4* __restrict__ par, const float* __restrict__ lam, const float4* __restrict__ pos,
+void gb_small_kernel(int N, int Npad, float tau, int sasa, const float4* __restrict__ par, const float* __restrict__ lam, int lam_stride, const float4* __restrict__ pos,
                      long long* __restrict__ force, double* __restrict__ out, int out_stride, int out_offset, int add)
 {
     __shared__ float4 s_x[64];             // x, y, z, or_j
@@ -250,7 +251,7 @@ void gb_small_kernel(int N, int Npad, float tau, int sasa, const float4* __restr
     __shared__ double s_e[16];
     const int r = blockIdx.x, i = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float4* P = pos + (size_t)r * Npad;
-    const float l = lam[r];
+    const float l = lam[(size_t)r * lam_stride];         // (stride 0: every replica at one state's lambda, a u_kl column)
     if (w == 0) {
         const float4 x = i < N ? P[i] : make_float4(0.f, 0.f, 0.f, 0.f), p = i < N ? par[i] : make_float4(0.f, 1.f, 0.f, 0.f);
         const float orj = p.y - GB_OFFSET;
@@ -365,7 +366,7 @@ void remd_gbsa_release(remd_ctx* h)
 {
     gbsa_tables* t = g_gb.find(h);
     if (t) {
-        dfree(t->d_par); dfree(t->d_born); dfree(t->d_c); dfree(t->d_lam); dfree(t->d_epart); dfree(t->d_col);
+        dfree(t->d_par); dfree(t->d_born); dfree(t->d_c); dfree(t->d_lam); dfree(t->d_state_lam); dfree(t->d_epart); dfree(t->d_col);
         g_gb.erase(h);
     }
     h->gbsa = 0;
@@ -448,19 +449,19 @@ int remd_gbsa_forces(remd_ctx* h, bool with_energy, int ep_slot)
     if ((rc = gb_set_lambdas(h, t, lam))) return rc;
     remd_prof_scope ps(h, "gbsa");
     if (gb_small(t)) {
-        if (with_energy) hipLaunchKernelGGL((gb_small_kernel<true, true>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, h->d_force, h->d_epart, h->n_epart, ep_slot, 0);
-        else hipLaunchKernelGGL((gb_small_kernel<false, true>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, h->d_force, (double*)nullptr, 0, 0, 0);
+        if (with_energy) hipLaunchKernelGGL((gb_small_kernel<true, true>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, 1, h->d_pos, h->d_force, h->d_epart, h->n_epart, ep_slot, 0);
+        else hipLaunchKernelGGL((gb_small_kernel<false, true>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, 1, h->d_pos, h->d_force, (double*)nullptr, 0, 0, 0);
         REMD_CHECK(h, hipGetLastError());
         return 0;
     }
     const dim3 grid(t.n_tile, h->R);
-    hipLaunchKernelGGL(gb_born_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_born);
+    hipLaunchKernelGGL(gb_born_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, 1, h->d_pos, t.d_born);
     if (with_energy) {
-        hipLaunchKernelGGL((gb_pair_kernel<true, true>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c, h->d_force, t.d_epart, t.n_tile);
+        hipLaunchKernelGGL((gb_pair_kernel<true, true>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, 1, h->d_pos, t.d_born, t.d_c, h->d_force, t.d_epart, t.n_tile);
         hipLaunchKernelGGL(gb_reduce_kernel, dim3(h->R), dim3(64), 0, h->stream, t.n_tile, t.d_epart, h->d_epart, h->n_epart, ep_slot, 0);
     } else
-        hipLaunchKernelGGL((gb_pair_kernel<false, true>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c, h->d_force, (double*)nullptr, t.n_tile);
-    hipLaunchKernelGGL(gb_chain_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_c, h->d_force);
+        hipLaunchKernelGGL((gb_pair_kernel<false, true>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, 1, h->d_pos, t.d_born, t.d_c, h->d_force, (double*)nullptr, t.n_tile);
+    hipLaunchKernelGGL(gb_chain_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, 1, h->d_pos, t.d_c, h->d_force);
     REMD_CHECK(h, hipGetLastError());
     return 0;
 }
@@ -474,14 +475,24 @@ int remd_gbsa_ukl(remd_ctx* h, double* d_alch)
     int rc = gb_buffers(h, t);
     if (rc) return rc;
     const dim3 grid(t.n_tile, h->R);
+    // the states' lambdas on the device (uploaded when they change: one synchronisation then, none per column)
+    {
+        std::vector<float> sl(h->K);
+        for (int k = 0; k < h->K; ++k) sl[k] = gb_state_lambda(h, k);
+        if (sl != t.state_lam_host) {
+            if ((int)t.state_lam_host.size() != h->K) { dfree(t.d_state_lam); REMD_CHECK(h, hipMalloc(&t.d_state_lam, sizeof(float) * h->K)); }
+            REMD_CHECK(h, hipMemcpyAsync(t.d_state_lam, sl.data(), sizeof(float) * h->K, hipMemcpyHostToDevice, h->stream));
+            REMD_CHECK(h, hipStreamSynchronize(h->stream));
+            t.state_lam_host = sl;
+        }
+    }
     for (int k = 0; k < h->K; ++k) {
-        if ((rc = gb_set_lambdas(h, t, std::vector<float>(h->R, gb_state_lambda(h, k))))) return rc;
         if (gb_small(t)) {
-            hipLaunchKernelGGL((gb_small_kernel<true, false>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, (long long*)nullptr, d_alch, h->K, k, 1);
+            hipLaunchKernelGGL((gb_small_kernel<true, false>), dim3(h->R), dim3(1024), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_state_lam + k, 0, h->d_pos, (long long*)nullptr, d_alch, h->K, k, 1);
             continue;
         }
-        hipLaunchKernelGGL(gb_born_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_lam, h->d_pos, t.d_born);
-        hipLaunchKernelGGL((gb_pair_kernel<true, false>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_lam, h->d_pos, t.d_born, t.d_c,
+        hipLaunchKernelGGL(gb_born_kernel, grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.d_par, t.d_state_lam + k, 0, h->d_pos, t.d_born);
+        hipLaunchKernelGGL((gb_pair_kernel<true, false>), grid, dim3(GB_BLOCK), 0, h->stream, t.N, h->Npad, t.tau, t.sasa, t.d_par, t.d_state_lam + k, 0, h->d_pos, t.d_born, t.d_c,
                            (long long*)nullptr, t.d_epart, t.n_tile);
         hipLaunchKernelGGL(gb_reduce_kernel, dim3(h->R), dim3(64), 0, h->stream, t.n_tile, t.d_epart, d_alch, h->K, k, 1);
     }
