@@ -1943,7 +1943,9 @@ static void launch_nb(remd_ctx* h, nb_tables& t)
         static const int rank_env = getenv("REMD_NB_RANK") ? atoi(getenv("REMD_NB_RANK")) : -1;
         // (rank_tiles_kernel compares every pair of a replica's tiles: measured up to 369 tiles; capped where the ranking would cost
         // more than the tail it removes)
-        const bool ranked = (rank_env < 0 ? (ntile >= 64 && ntile <= 2048) : rank_env != 0) && t.lj_split && t.d_lj_sci_list && t.d_tile_of_rank && (METHOD == NB_EWALD || METHOD == NB_RF);
+        // (round 6, the blocks of a phased propagation: a block's launch is one round of the chip beside the other block's kernels, and the
+        // longest lists first help there at 36 tiles too: 24 x alanine dipeptide +2.5 %, profiles/r06_45)
+        const bool ranked = (rank_env < 0 ? ((ntile >= 64 || h->parent != nullptr) && ntile <= 2048) : rank_env != 0) && t.lj_split && t.d_lj_sci_list && t.d_tile_of_rank && (METHOD == NB_EWALD || METHOD == NB_RF);
         sci_args sa{h->N, h->Npad, ncl, t.cl_cap, t.excl_W, h->Npad, 0, ssplit, t.d_spos, t.d_sparam, t.d_excl, t.d_sci_list, t.d_sci_count, t.d_sforce,
                     t.d_sposi, ranked ? t.d_tile_of_rank : (const int*)nullptr};
         const int items_a = ntile * h->R * (ssplit / SCI_NW);

@@ -919,7 +919,13 @@ int remd_parse_splitting(remd_ctx* h, const char* splitting, std::vector<char>& 
 remd_chain_bins remd_pme_chain_bins(remd_ctx* h);
 static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& prog, bool bin_for_pme = false)
 {
-    const remd_chain_bins bins = bin_for_pme ? remd_pme_chain_bins(h) : remd_chain_bins();
+    // mesh-column bins from the chain's epilogue: in a handle that runs as ONE block (the binning launch would sit on the step's only
+    // critical path); the blocks of a phased propagation bin with a launch of their own, which runs beside the other block's kernels while
+    // the chain is the serial part of both (24 x alanine dipeptide: 17.5 -> 18.2 it/s; one block of 8 x CB7:B2: 13.2 -> 12.2 the other way;
+    // profiles/r06_45).  REMD_PME_CHAINBIN=0 / 1 pins it (bit-identical either way: the order inside a bin is irrelevant).
+    static const int chainbin_env = getenv("REMD_PME_CHAINBIN") ? atoi(getenv("REMD_PME_CHAINBIN")) : -1;
+    const bool chain_bins = chainbin_env >= 0 ? chainbin_env != 0 : h->parent == nullptr;
+    const remd_chain_bins bins = (bin_for_pme && chain_bins) ? remd_pme_chain_bins(h) : remd_chain_bins();
     remd_prof_scope ps(h, "integrate_chain");
     dim3 grid((ut.n_units + 255) / 256, h->R);
     // The two-per-CU compilation is OPT-IN (REMD_CHAIN_TWO=1).  It takes a grid larger than the chip in one round (DHFR x 16: -1.3 % of the
