@@ -577,7 +577,7 @@ static int phases_for(remd_ctx* h)
     //  * a force evaluation that forks into the mesh and the direct-space stream (PME with overlap), a plain single-group V / R / O program
     //    without work measurement, Metropolization or a barostat (their launches in between are not worth taking turns with);
     //  * no communicator, no profiling of every class;
-    //  * two blocks that are each worth a launch: 8 replicas or more per block unless asked for explicitly.
+    //  * two blocks that are each worth a launch: 3 replicas or more per block unless asked for explicitly.
     if (!h->has_system || !h->has_integrator || !h->sysdesc || !h->sysdesc->valid) return 1;
     if (h->n_regions > 0) return 1;             // general alchemical regions live on this handle only (alch_regions.hip)
     if (h->nb_method != REMD_NB_PME || !h->overlap || !h->stream2) return 1;
@@ -591,7 +591,9 @@ static int phases_for(remd_ctx* h)
     // time-sliced.  The Python package sets GPU_MAX_HW_QUEUES=2 before the runtime starts; a host that does not gets one block.
     const char* q = getenv("GPU_MAX_HW_QUEUES");
     if (!q || atoi(q) < 1 || atoi(q) > 2) return 1;
-    return h->R >= 16 ? 2 : 1;
+    // (two blocks from 6 replicas on: alanine dipeptide R = 4 / 6 / 8 / 12 -> +2 / +7 / +11 / +15 % against one block, R = 2 -> -18 %; 8 x CB7:B2
+    // +2 %; profiles/r06_45.  Until the blocks got their own rules for the mesh-column bins and the work-item order the bound was 16.)
+    return h->R >= 6 ? 2 : 1;
 }
 
 // ---- do two streams sit on one hardware queue?  HIP deals streams onto GPU_MAX_HW_QUEUES queues per priority by least use, and a process

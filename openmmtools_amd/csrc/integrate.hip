@@ -924,7 +924,10 @@ static void launch_chain(remd_ctx* h, const unit_tables& ut, const chain_prog& p
     // the chain is the serial part of both (24 x alanine dipeptide: 17.5 -> 18.2 it/s; one block of 8 x CB7:B2: 13.2 -> 12.2 the other way;
     // profiles/r06_45).  REMD_PME_CHAINBIN=0 / 1 pins it (bit-identical either way: the order inside a bin is irrelevant).
     static const int chainbin_env = getenv("REMD_PME_CHAINBIN") ? atoi(getenv("REMD_PME_CHAINBIN")) : -1;
-    const bool chain_bins = chainbin_env >= 0 ? chainbin_env != 0 : h->parent == nullptr;
+    // (a block whose chain grid is several rounds of the chip -- 64 x DHFR: 2 048 workgroups -- keeps them too: there the epilogue is
+    // amortised over the rounds and the binning launch is the dearer one, 3.38 -> 3.46 s per iteration of 128 x DHFR without this bound)
+    const bool chain_bins = chainbin_env >= 0 ? chainbin_env != 0
+                                              : (h->parent == nullptr || (long long)((ut.n_units + 255) / 256) * h->R > 1024);
     const remd_chain_bins bins = (bin_for_pme && chain_bins) ? remd_pme_chain_bins(h) : remd_chain_bins();
     remd_prof_scope ps(h, "integrate_chain");
     dim3 grid((ut.n_units + 255) / 256, h->R);
