@@ -575,13 +575,15 @@ static int phases_for(remd_ctx* h)
     if (want == 1) return 1;
     // what the blocks' interleaved steps need (everything else takes the one-block path):
     //  * a force evaluation that forks into the mesh and the direct-space stream (PME with overlap), a plain single-group V / R / O program
-    //    without work measurement, Metropolization or a barostat (their launches in between are not worth taking turns with);
+    //    without work measurement or Metropolization (their launches in between are not worth taking turns with); a Monte Carlo barostat is
+    //    each block's own affair (per-replica state and counters travel with the replicas);
     //  * no communicator, no profiling of every class;
     //  * two blocks that are each worth a launch: 3 replicas or more per block unless asked for explicitly.
     if (!h->has_system || !h->has_integrator || !h->sysdesc || !h->sysdesc->valid) return 1;
     if (h->n_regions > 0) return 1;             // general alchemical regions live on this handle only (alch_regions.hip)
     if (h->nb_method != REMD_NB_PME || !h->overlap || !h->stream2) return 1;
-    if (h->baro_frequency > 0 || h->measure_heat || h->measure_shadow || h->profiling == 2 || h->comm) return 1;
+    if (h->measure_heat || h->measure_shadow || h->profiling == 2 || h->comm) return 1;
+    if (h->baro_frequency > 0 && (int)h->pressure_host.size() != h->K) return 1;
     for (char c : h->tokens) if (c != 'V' && c != 'R' && c != 'O') return 1;
     if (h->R < 2) return 1;
     if (want == 2) return 2;
@@ -675,6 +677,10 @@ static int phase_children(remd_ctx* h, int P)
         if ((rc = remd_set_integrator(c, h->splitting.c_str(), h->dt, h->gamma, h->n_steps, h->reassign, h->constraint_tol))) return remd_fail(h, rc, std::string("phases: ") + c->err);
         for (int k = 0; k < 6; ++k) c->fgroup[k] = h->fgroup[k];
         c->seed = h->seed; c->n_restart_attempts = h->n_restart_attempts;
+        if (h->baro_frequency > 0) {
+            if ((rc = remd_set_barostat(c, h->K, h->pressure_host.data(), h->baro_frequency))) return remd_fail(h, rc, std::string("phases: ") + c->err);
+            c->econst_vref = h->econst_vref;
+        }
     }
     h->phase_config = h->config_version;
     return 0;
@@ -721,6 +727,14 @@ static int remd_propagate_phased(remd_ctx* h, int P, int64_t iteration, int32_t*
         REMD_CHECK(h, hipMemcpyAsync(c->d_force, h->d_force + 3 * (size_t)r0[p] * row, sizeof(long long) * 3 * row * cnt, hipMemcpyDeviceToDevice, c->stream));
         c->forces_valid = h->forces_valid; c->force_zeroed = h->force_zeroed;
         c->cbins_ready = false; c->join_deferred = 0; c->fold_pending = false;
+        if (h->baro_frequency > 0) {
+            // the barostat's per-replica state (volume step, adaptation window, totals) and the handle's step / attempt counters travel
+            // with the replicas: the blocks draw and decide what the one-block path draws and decides (Philox by global replica and attempt)
+            if ((rc = remd_barostat_buffers(h)) || (rc = remd_barostat_buffers(c))) return rc;
+            REMD_CHECK(h, hipMemcpyAsync(c->d_baro, h->d_baro + 8 * (size_t)r0[p], sizeof(double) * 8 * cnt, hipMemcpyDeviceToDevice, c->stream));
+            c->baro_steps = h->baro_steps; c->baro_attempts = h->baro_attempts;
+            c->econst_vref = h->econst_vref;
+        }
         c->box_uniform = h->box_uniform;
         c->profiling = h->profiling; c->prof_filter = h->prof_filter; c->prof_every = h->prof_every;
         remd_nb_invalidate_sort(c);
@@ -733,6 +747,14 @@ static int remd_propagate_phased(remd_ctx* h, int P, int64_t iteration, int32_t*
         const int cnt = r0[p + 1] - r0[p];
         REMD_CHECK(h, hipMemcpyAsync(h->d_pos + r0[p] * row, c->d_pos, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, h->stream));
         REMD_CHECK(h, hipMemcpyAsync(h->d_vel + r0[p] * row, c->d_vel, sizeof(float4) * row * cnt, hipMemcpyDeviceToDevice, h->stream));
+        if (h->baro_frequency > 0) {
+            REMD_CHECK(h, hipMemcpyAsync(h->d_box + 4 * (size_t)r0[p], c->d_box, sizeof(float) * 4 * cnt, hipMemcpyDeviceToDevice, h->stream));
+            REMD_CHECK(h, hipMemcpyAsync(h->d_baro + 8 * (size_t)r0[p], c->d_baro, sizeof(double) * 8 * cnt, hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    if (h->baro_frequency > 0) {
+        if (h->phase[0]->baro_attempts != h->baro_attempts) { h->box_uniform = false; h->box_version++; }
+        h->baro_steps = h->phase[0]->baro_steps; h->baro_attempts = h->phase[0]->baro_attempts;
     }
     h->forces_valid = false; h->force_zeroed = false; h->cbins_ready = false; h->join_deferred = 0; h->fold_pending = false;
     remd_nb_invalidate_sort(h);
@@ -948,13 +970,15 @@ int remd_set_barostat(remd_handle h, int K, const double* pressure, int frequenc
 {
     if (!h) return -1;
     hipSetDevice(h->device);
-    if (!pressure || frequency <= 0) { h->baro_frequency = 0; return 0; }
+    if (!pressure || frequency <= 0) { if (h->baro_frequency != 0) h->config_version++; h->baro_frequency = 0; return 0; }
     if (K != h->K) return remd_fail(h, -1, "remd_set_barostat: K differs from remd_set_states");
     std::vector<double> p(pressure, pressure + K);
     for (double v : p) if (!(v == v)) return remd_fail(h, -1, "remd_set_barostat: NaN pressure");
     int rc = upload(h, h->d_pressure, p);
     if (rc) return rc;
+    if (h->baro_frequency != frequency || h->pressure_host != p) h->config_version++;     // (the blocks of a phased propagation follow)
     h->baro_frequency = frequency;
+    h->pressure_host = p;
     return 0;
 }
 

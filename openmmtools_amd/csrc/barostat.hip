@@ -95,11 +95,8 @@ void baro_restore_kernel(int N, int Npad, const int* __restrict__ accepted, floa
     force[of + i] = f0[of + i]; force[of + Npad + i] = f0[of + Npad + i]; force[of + 2 * Npad + i] = f0[of + 2 * Npad + i];
 }
 
-int remd_barostat_attempt(remd_ctx* h)
+int remd_barostat_buffers(remd_ctx* h)
 {
-    const int* grp_first = nullptr; const int* grp_size = nullptr;
-    const int n_groups = remd_nb_molecules(h, &grp_first, &grp_size);
-    if (n_groups <= 0) return remd_fail(h, -3, "barostat: the system has no molecule table (needs a NonbondedForce)");
     const int R = h->R, Npad = h->Npad;
     if (!h->d_baro) {
         REMD_CHECK(h, hipMalloc(&h->d_baro, sizeof(double) * 8 * R)); REMD_CHECK(h, hipMemsetAsync(h->d_baro, 0, sizeof(double) * 8 * R, h->stream));
@@ -109,7 +106,17 @@ int remd_barostat_attempt(remd_ctx* h)
         REMD_CHECK(h, hipMalloc(&h->d_baro_U0, sizeof(double) * R));
         REMD_CHECK(h, hipMalloc(&h->d_baro_acc, sizeof(int) * R));
     }
+    return 0;
+}
+
+int remd_barostat_attempt(remd_ctx* h)
+{
+    const int* grp_first = nullptr; const int* grp_size = nullptr;
+    const int n_groups = remd_nb_molecules(h, &grp_first, &grp_size);
+    if (n_groups <= 0) return remd_fail(h, -3, "barostat: the system has no molecule table (needs a NonbondedForce)");
+    const int R = h->R, Npad = h->Npad;
     int rc;
+    if ((rc = remd_barostat_buffers(h))) return rc;
     h->force_zeroed = false;
     if ((rc = remd_compute_forces(h, true))) return rc;                         // U and forces of the current configuration
     REMD_CHECK(h, hipMemcpyAsync(h->d_baro_U0, h->d_potential, sizeof(double) * R, hipMemcpyDeviceToDevice, h->stream));

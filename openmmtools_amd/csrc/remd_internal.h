@@ -185,7 +185,7 @@ struct remd_ctx {
     float4* d_pos = nullptr;           // [R][Npad] xyz + pad
     float4* d_vel = nullptr;           // [R][Npad] xyz + pad
     // Monte Carlo barostat (OpenMM MonteCarloBarostat as the reference's NPT ThermodynamicState adds it, states.py:1177-1181)
-    int baro_frequency = 0; long long baro_steps = 0, baro_attempts = 0;
+    int baro_frequency = 0; long long baro_steps = 0, baro_attempts = 0; std::vector<double> pressure_host;   // (pressure_host: for the blocks of a phased propagation)
     double econst_vref = 0.0;          // volume at which the per-state energy constants were evaluated (they scale as 1/V); 0: constant
     double* d_pressure = nullptr;      // [K] kJ/mol/nm^3 (bar * N_A * 1e-25)
     double* d_baro = nullptr;          // [R][8]: volumeScale, attempted, accepted (adaptation window), total attempted, total accepted, dV, newV, oldV
@@ -340,6 +340,7 @@ int remd_work_buffers(remd_ctx* h);                    // heat / shadow-work acc
 
 // ---- forces.hip -------------------------------------------------------------------------
 int remd_barostat_attempt(remd_ctx* h);                      // barostat.hip
+int remd_barostat_buffers(remd_ctx* h);                      // (its per-replica state and scratch, allocated on first use)
 int remd_nb_molecules(remd_ctx* h, const int** first, const int** size);   // molecule table of the nonbonded setup (device); 0: none
 int remd_minimize_impl(remd_ctx* h, double tolerance, int max_iterations, int32_t* converged, int32_t* n_iterations);
 void remd_nb_invalidate_sort(remd_ctx* h);            // the next force evaluation re-sorts the molecules

@@ -68,6 +68,40 @@ def test_phases_by_rule_follow_the_hardware_queue_limit(hip_engine_factory, monk
     assert phases_of(16, {'GPU_MAX_HW_QUEUES': '2', 'REMD_PHASES': '1'}) == 1
 
 
+def test_a_monte_carlo_barostat_in_two_phases_is_the_barostat_in_one_block(hip_engine_factory):
+    """NPT states: every block runs the volume moves of its own replicas (per-replica volume step, adaptation window and totals, the
+    handle's step and attempt counters travel with the replicas; the draws are Philox by global replica and attempt).  Positions,
+    velocities, boxes and the barostat's statistics after three propagations of 12 replicas (a move every 5 steps) equal the one-block
+    run bit for bit."""
+    from openmmtools_amd.system import system_to_desc
+    al = testsystems.AlanineDipeptideExplicit()
+    desc = system_to_desc(al.system, ewald_split='auto')
+    box = np.diag(al.system.getDefaultPeriodicBoxVectors())
+    R = 12
+    KB = 0.008314462618153242
+    out = []
+    for phases in (1, 2):
+        eng = hip_engine_factory()
+        eng.set_phases(phases)
+        eng.set_system(desc)
+        T = np.linspace(300.0, 330.0, R)
+        eng.set_states(1.0 / (KB * T))
+        eng.set_barostat(np.full(R, 0.0602214076 * 1.01325), frequency=5)          # 1 atm in kJ/mol/nm^3
+        eng.set_integrator('V R R O R R V', 0.002, 1.0, 30, True, 1e-8)
+        eng.seed(21)
+        eng.set_replicas(R, 0, np.tile(al.positions, (R, 1, 1)), None, np.tile(box, (R, 1)), np.arange(R))
+        for it in range(3):
+            assert not eng.propagate(it).any()
+            u = eng.compute_energies()           # (as a sampler does between two propagations: the forces of the first kick come from here)
+        x, v = eng.get_replicas()[:2]
+        out.append((x.copy(), v.copy(), eng.get_boxes(), eng.barostat_stats(), u, eng.phases_active()))
+    (xa, va, ba, sa, ua, pa), (xb, vb, bb, sb, ub, pb) = out
+    assert (pa, pb) == (1, 2)
+    assert sa[1].min() == 18 and np.any(sa[2] > 0) and not np.allclose(ba, box)       # 3 x 30 / 5 attempts per replica, some accepted, boxes moved
+    assert np.array_equal(ba, bb) and all(np.array_equal(p, q) for p, q in zip(sa, sb))
+    assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(ua, ub)
+
+
 def test_new_boxes_reach_the_blocks(hip_engine_factory):
     """The blocks of a phased handle keep their own box mirrors and PME influence tables: replicas set again with OTHER boxes (same shapes,
     so the blocks are not re-made) must be propagated in the new boxes -- against the one-block run, bit for bit."""

@@ -87,6 +87,13 @@ def main():
         s = ReplicaExchangeSampler(mcmc_moves=move(2.0, 'V R R O R R V'), number_of_iterations=10 ** 9, engine=HipEngine(), seed=1)
         s.create(ths, [states.SamplerState(t.positions)])
         run('%s: %s (%d atoms, NoCutoff), %d temperatures, swap-all, g-BAOAB 2 fs x 500' % (tag, cls, t.system.getNumParticles(), nt), s, 5)
+    if 'n' in which:
+        # the headline ensemble at constant pressure (NPT states: Monte Carlo barostat every 25 steps inside the propagation)
+        al = testsystems.AlanineDipeptideExplicit()
+        ths = [states.ThermodynamicState(al.system, T, pressure=1.0 * unit.atmosphere) for T in np.geomspace(300.0, 600.0, 24)]
+        s = ReplicaExchangeSampler(mcmc_moves=move(2.0, 'V R R O R R V'), number_of_iterations=10 ** 9, engine=HipEngine(), seed=1)
+        s.create(ths, [states.SamplerState(al.positions, box_vectors=al.system.getDefaultPeriodicBoxVectors())])
+        run('n: AlanineDipeptideExplicit, 24 temperatures at 1 atm (Monte Carlo barostat every 25 steps), swap-all, g-BAOAB 2 fs x 500', s, 5)
     if '5' in which:
         dh = testsystems.DHFRExplicit()
         T = np.geomspace(300.0, 400.0, 128)
