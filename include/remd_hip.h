@@ -263,7 +263,7 @@ int  remd_set_alchemical_options(remd_handle h, int annihilate_sterics);
    from (n + 1)(n + 2) / 2 energy passes: the Coulomb energy is a quadratic form in the regions' lambda_electrostatics.
    Sterics as above (of a pair of interacting regions: none, as the reference's loop leaves them -- tables zeroed, :1886-1911).
    Call AFTER remd_set_system (which forgets the regions) and follow remd_set_states by remd_set_region_lambdas.  n_regions = 0 or
-   desc = NULL: none.  A handle with regions runs one block of replicas (no phases).  NoCutoff systems: no box, no cutoff, no switch (the
+   desc = NULL: none.  NoCutoff systems: no box, no cutoff, no switch (the
    custom forces copy the NonbondedForce's method, :1793-1796).                   */
 typedef struct remd_alch_regions_desc {
     int32_t n_atoms;                     /* the system's                                                     */

@@ -56,6 +56,27 @@ struct region_tables {
     std::vector<float> rep_le_host;
     float* d_state_le = nullptr;           // [K][4]
     bool have_override = false; float le_override[4] = {1.f, 1.f, 1.f, 1.f};
+    // a deep copy of the descriptor of remd_set_alchemical_regions: the blocks of a phased propagation (api.hip) are set up from it
+    struct desc_store {
+        remd_alch_regions_desc d{};
+        std::vector<int32_t> region_of_atom, annihilate, interactions, exception_atoms, bond_atoms, bond_region, angle_atoms, angle_region, torsion_atoms, torsion_region;
+        std::vector<double> softcore, charge, sigma, epsilon, exception_params, bond_params, angle_params, torsion_params;
+        void assign(const remd_alch_regions_desc* s)
+        {
+            d = *s;
+            auto cpi = [](std::vector<int32_t>& v, const int32_t*& p, size_t n) { if (p && n) { v.assign(p, p + n); p = v.data(); } else { v.clear(); p = nullptr; } };
+            auto cpd = [](std::vector<double>& v, const double*& p, size_t n) { if (p && n) { v.assign(p, p + n); p = v.data(); } else { v.clear(); p = nullptr; } };
+            const size_t N = (size_t)d.n_atoms, n = (size_t)d.n_regions;
+            cpi(region_of_atom, d.region_of_atom, N); cpd(softcore, d.softcore, 8 * n); cpi(annihilate, d.annihilate, 2 * n);
+            cpi(interactions, d.interactions, 2 * (size_t)d.n_interactions);
+            cpd(charge, d.charge, N); cpd(sigma, d.sigma, N); cpd(epsilon, d.epsilon, N);
+            cpi(exception_atoms, d.exception_atoms, 2 * (size_t)d.n_exceptions); cpd(exception_params, d.exception_params, 3 * (size_t)d.n_exceptions);
+            cpi(bond_atoms, d.bond_atoms, 2 * (size_t)d.n_bonds); cpd(bond_params, d.bond_params, 2 * (size_t)d.n_bonds); cpi(bond_region, d.bond_region, (size_t)d.n_bonds);
+            cpi(angle_atoms, d.angle_atoms, 3 * (size_t)d.n_angles); cpd(angle_params, d.angle_params, 2 * (size_t)d.n_angles); cpi(angle_region, d.angle_region, (size_t)d.n_angles);
+            cpi(torsion_atoms, d.torsion_atoms, 4 * (size_t)d.n_torsions); cpd(torsion_params, d.torsion_params, 3 * (size_t)d.n_torsions); cpi(torsion_region, d.torsion_region, (size_t)d.n_torsions);
+        }
+    } store;
+    bool have_bonded_lambdas = false;
 };
 static handle_table<region_tables> g_reg;
 
@@ -435,14 +456,16 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
     h->config_version++;
     h->forces_valid = false;
     if (!d || d->n_regions == 0) return 0;
-    if (!h->has_system || h->parent || !h->sysdesc || !h->sysdesc->valid) return remd_fail(h, -2, "remd_set_alchemical_regions: call remd_set_system first");
+    // (a block of a phased propagation reads the descriptor its parent keeps: api.hip phase_children)
+    const remd_desc_store* store = h->parent ? h->parent->sysdesc : h->sysdesc;
+    if (!h->has_system || !store || !store->valid) return remd_fail(h, -2, "remd_set_alchemical_regions: call remd_set_system first");
     const int N = h->N, n = d->n_regions;
     if (d->n_atoms != N) return remd_fail(h, -1, "remd_set_alchemical_regions: n_atoms differs from the system's");
     if (n < 0 || n > 64 || !d->region_of_atom || !d->softcore || !d->annihilate || !d->charge || !d->sigma || !d->epsilon ||
         d->n_interactions < 0 || (d->n_interactions > 0 && !d->interactions) || d->n_exceptions < 0 || (d->n_exceptions > 0 && (!d->exception_atoms || !d->exception_params)))
         return remd_fail(h, -1, "remd_set_alchemical_regions: bad arguments");
     if (h->nb_method == REMD_NB_NONE && !h->nocutoff) return remd_fail(h, -3, "alchemical regions need a NonbondedForce");
-    if (h->sysdesc->d.n_alch != 0) return remd_fail(h, -3, "alchemical regions: the descriptor of remd_set_system must be the factory's NonbondedForce (n_alch = 0)");
+    if (store->d.n_alch != 0) return remd_fail(h, -3, "alchemical regions: the descriptor of remd_set_system must be the factory's NonbondedForce (n_alch = 0)");
     region_tables& t = g_reg[h];
     t.n_regions = n;
     t.softcore.assign(d->softcore, d->softcore + 8 * (size_t)n);
@@ -508,7 +531,7 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         }
     }
     // every exception of the system is an exclusion of the custom forces (alchemy.py:1944-1947)
-    const remd_system_desc& sd = h->sysdesc->d;
+    const remd_system_desc& sd = store->d;
     for (int e = 0; e < sd.n_exceptions; ++e) {
         const int i = sd.exception_atoms[2 * e], j = sd.exception_atoms[2 * e + 1];
         if (ord[i] >= 0) { set_skip(ord[i], j); set_corr(ord[i], j); }
@@ -594,6 +617,7 @@ int remd_set_alchemical_regions(remd_handle h, const remd_alch_regions_desc* d)
         if ((rc = upload(h, t.d_bonded_atoms, ba)) || (rc = upload(h, t.d_bonded_par, bp))) { remd_regions_release(h); return rc; }
     }
     h->n_regions = n; h->regions_exact = exact ? 1 : 0;
+    if (!h->parent) t.store.assign(d);
     return 0;
 }
 
@@ -660,8 +684,28 @@ int remd_set_region_bonded_lambdas(remd_handle h, int K, int n_regions, const do
     }
     int rc = upload(h, t.d_state_bl, tab);
     if (rc) return rc;
+    for (int q = 0; q < 3; ++q) for (int k = 0; k < K; ++k) for (int g = 0; g < n; ++g) t.bl[((size_t)q * K + k) * n + g] = (double)tab[((size_t)k * 3 + q) * n + g];
+    t.have_bonded_lambdas = true;
     h->config_version++;
     h->forces_valid = false;
+    return 0;
+}
+
+// the regions of `parent` on one of its blocks (api.hip phase_children): descriptor, the states' lambdas, the bonded lambdas
+int remd_regions_clone(remd_ctx* parent, remd_ctx* child)
+{
+    region_tables* tp = g_reg.find(parent);
+    if (!tp || parent->n_regions == 0) return 0;
+    region_tables& t = *tp;
+    if (t.store.d.n_regions != t.n_regions || t.K != parent->K || t.ls.size() != (size_t)t.K * t.n_regions)
+        return remd_fail(parent, -2, "phases: the handle's alchemical regions are not complete (remd_set_region_lambdas)");
+    int rc = remd_set_alchemical_regions(child, &t.store.d);
+    if (!rc) rc = remd_set_region_lambdas(child, t.K, t.n_regions, t.ls.data(), t.le.data());
+    if (!rc && t.have_bonded_lambdas && t.bl.size() == 3 * (size_t)t.K * t.n_regions) {
+        const size_t m = (size_t)t.K * t.n_regions;
+        rc = remd_set_region_bonded_lambdas(child, t.K, t.n_regions, t.bl.data(), t.bl.data() + m, t.bl.data() + 2 * m);
+    }
+    if (rc) return remd_fail(parent, rc, std::string("phases: ") + child->err);
     return 0;
 }
 

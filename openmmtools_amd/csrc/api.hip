@@ -580,7 +580,6 @@ static int phases_for(remd_ctx* h)
     //  * no communicator, no profiling of every class;
     //  * two blocks that are each worth a launch: 3 replicas or more per block unless asked for explicitly.
     if (!h->has_system || !h->has_integrator || !h->sysdesc || !h->sysdesc->valid) return 1;
-    if (h->n_regions > 0) return 1;             // general alchemical regions live on this handle only (alch_regions.hip)
     if (h->nb_method != REMD_NB_PME || !h->overlap || !h->stream2) return 1;
     if (h->measure_heat || h->measure_shadow || h->profiling == 2 || h->comm) return 1;
     if (h->baro_frequency > 0 && (int)h->pressure_host.size() != h->K) return 1;
@@ -677,6 +676,7 @@ static int phase_children(remd_ctx* h, int P)
         if ((rc = remd_set_integrator(c, h->splitting.c_str(), h->dt, h->gamma, h->n_steps, h->reassign, h->constraint_tol))) return remd_fail(h, rc, std::string("phases: ") + c->err);
         for (int k = 0; k < 6; ++k) c->fgroup[k] = h->fgroup[k];
         c->seed = h->seed; c->n_restart_attempts = h->n_restart_attempts;
+        if (h->n_regions > 0 && (rc = remd_regions_clone(h, c))) return rc;       // general alchemical regions (alch_regions.hip)
         if (h->baro_frequency > 0) {
             if ((rc = remd_set_barostat(c, h->K, h->pressure_host.data(), h->baro_frequency))) return remd_fail(h, rc, std::string("phases: ") + c->err);
             c->econst_vref = h->econst_vref;
