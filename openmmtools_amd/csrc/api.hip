@@ -580,7 +580,12 @@ static int phases_for(remd_ctx* h)
     //  * no communicator, no profiling of every class;
     //  * two blocks that are each worth a launch: 3 replicas or more per block unless asked for explicitly.
     if (!h->has_system || !h->has_integrator || !h->sysdesc || !h->sysdesc->valid) return 1;
-    if (h->nb_method != REMD_NB_PME || !h->overlap || !h->stream2) return 1;
+    // (NoCutoff systems -- a step of three or four dependent small launches on ONE stream -- run as two blocks only when asked to: built and
+    // measured at the end of round 6, bit-identical, and no faster (24 x CB7:B2 in vacuum 52.7 / 53.2 it/s, the implicit-solvent dipeptide
+    // 45.7 / 45.4): with twice the launches per unit of time the HOST's enqueue rate is the limit, ~4.7 us per launch; profiles/r06_45)
+    const bool pme_fork = h->nb_method == REMD_NB_PME && h->overlap && h->stream2;
+    const bool small_launches = h->nocutoff && h->nb_method == REMD_NB_NONE && (h->gbsa || h->n_regions > 0 || h->N > 64);
+    if (!pme_fork && !(small_launches && want == 2)) return 1;
     if (h->measure_heat || h->measure_shadow || h->profiling == 2 || h->comm) return 1;
     if (h->baro_frequency > 0 && (int)h->pressure_host.size() != h->K) return 1;
     for (char c : h->tokens) if (c != 'V' && c != 'R' && c != 'O') return 1;
@@ -676,6 +681,7 @@ static int phase_children(remd_ctx* h, int P)
         if ((rc = remd_set_integrator(c, h->splitting.c_str(), h->dt, h->gamma, h->n_steps, h->reassign, h->constraint_tol))) return remd_fail(h, rc, std::string("phases: ") + c->err);
         for (int k = 0; k < 6; ++k) c->fgroup[k] = h->fgroup[k];
         c->seed = h->seed; c->n_restart_attempts = h->n_restart_attempts;
+        if (h->gbsa && (rc = remd_gbsa_clone(h, c))) return rc;                    // implicit solvent (gbsa.hip)
         if (h->n_regions > 0 && (rc = remd_regions_clone(h, c))) return rc;       // general alchemical regions (alch_regions.hip)
         if (h->baro_frequency > 0) {
             if ((rc = remd_set_barostat(c, h->K, h->pressure_host.data(), h->baro_frequency))) return remd_fail(h, rc, std::string("phases: ") + c->err);

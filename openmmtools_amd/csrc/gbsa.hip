@@ -27,6 +27,8 @@ struct gbsa_tables {
     float* d_c = nullptr;                  // [R][Npad] dE/dB dB/dI
     float* d_lam = nullptr; std::vector<float> lam_host;      // [R] lambda_electrostatics of each replica's state
     float* d_state_lam = nullptr; std::vector<float> state_lam_host;   // [K] of every state (u_kl columns)
+    // a deep copy of the descriptor of remd_set_gbsa: the blocks of a phased propagation (api.hip) are set up from it
+    remd_gbsa_desc store{}; std::vector<double> st_charge, st_radius, st_scale; std::vector<int32_t> st_alch;
     double* d_epart = nullptr; double* d_col = nullptr; int buf_R = 0;
 };
 static handle_table<gbsa_tables> g_gb;
@@ -397,6 +399,22 @@ int remd_set_gbsa(remd_handle h, const remd_gbsa_desc* d)
     REMD_CHECK(h, hipMalloc(&t.d_par, sizeof(float4) * par.size()));
     REMD_CHECK(h, hipMemcpy(t.d_par, par.data(), sizeof(float4) * par.size(), hipMemcpyHostToDevice));
     h->gbsa = 1;
+    if (!h->parent) {
+        t.store = *d;
+        t.st_charge.assign(d->charge, d->charge + h->N); t.st_radius.assign(d->radius, d->radius + h->N); t.st_scale.assign(d->scale, d->scale + h->N);
+        t.store.charge = t.st_charge.data(); t.store.radius = t.st_radius.data(); t.store.scale = t.st_scale.data();
+        if (d->alchemical) { t.st_alch.assign(d->alchemical, d->alchemical + h->N); t.store.alchemical = t.st_alch.data(); } else { t.st_alch.clear(); t.store.alchemical = nullptr; }
+    }
+    return 0;
+}
+
+// the implicit solvent of `parent` on one of its blocks (api.hip phase_children)
+int remd_gbsa_clone(remd_ctx* parent, remd_ctx* child)
+{
+    gbsa_tables* t = g_gb.find(parent);
+    if (!t || !parent->gbsa) return 0;
+    const int rc = remd_set_gbsa(child, &t->store);
+    if (rc) return remd_fail(parent, rc, std::string("phases: ") + child->err);
     return 0;
 }
 

@@ -364,6 +364,7 @@ int remd_regions_state_le(remd_ctx* h, int k, int g, double* le);
 // alch_regions.hip: custom forces of general alchemical regions
 void remd_regions_release(remd_ctx* h);
 int remd_regions_clone(remd_ctx* parent, remd_ctx* child);
+int remd_gbsa_clone(remd_ctx* parent, remd_ctx* child);
 int remd_regions_forces(remd_ctx* h, bool with_energy, int ep_slot);
 int remd_regions_ukl(remd_ctx* h, double* d_out /*[R][K]*/, const int** d_own);
 int remd_regions_pme_tables(remd_ctx* h, const float4** param, const float** rep_le);

@@ -102,6 +102,35 @@ def test_a_monte_carlo_barostat_in_two_phases_is_the_barostat_in_one_block(hip_e
     assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(ua, ub)
 
 
+@pytest.mark.parametrize('which', ['HostGuestVacuum', 'AlanineDipeptideImplicit'])
+def test_nocutoff_systems_in_two_phases_are_the_one_block_run(hip_engine_factory, which):
+    """NoCutoff systems beyond the resident small-molecule kernel (more than 64 atoms, or with GBSA): a step is three to four dependent small
+    launches on one stream; such a handle runs as two blocks on two streams when asked to (remd_set_phases(2); the implicit solvent's
+    descriptor travels to the blocks: remd_gbsa_clone) -- bit-identical to one block, and no faster: the host's enqueue rate is the limit,
+    so the rule keeps these handles in one block."""
+    from openmmtools_amd.system import system_to_desc
+    t = getattr(testsystems, which)()
+    desc = system_to_desc(t.system)
+    R = 8
+    out = []
+    for phases in (1, 2):
+        eng = hip_engine_factory()
+        eng.set_phases(phases)
+        eng.set_system(desc)
+        eng.set_states(1.0 / (0.008314462618153242 * np.linspace(300.0, 400.0, R)))
+        eng.set_integrator('V R R O R R V', 0.002, 1.0, 60, True, 1e-8)
+        eng.seed(5)
+        eng.set_replicas(R, 0, np.tile(t.positions, (R, 1, 1)), None, np.zeros((R, 3)), np.arange(R))
+        for it in range(2):
+            assert not eng.propagate(it).any()
+            u = eng.compute_energies()
+        x, v = eng.get_replicas()[:2]
+        out.append((x.copy(), v.copy(), u.copy(), eng.phases_active()))
+    (xa, va, ua, pa), (xb, vb, ub, pb) = out
+    assert (pa, pb) == (1, 2)
+    assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(ua, ub)
+
+
 def test_new_boxes_reach_the_blocks(hip_engine_factory):
     """The blocks of a phased handle keep their own box mirrors and PME influence tables: replicas set again with OTHER boxes (same shapes,
     so the blocks are not re-made) must be propagated in the new boxes -- against the one-block run, bit for bit."""
