@@ -596,7 +596,9 @@ static int phases_for(remd_ctx* h)
     // default GPU_MAX_HW_QUEUES = 4 gives the second block's main stream one) they run 55 % slower -- queues beyond the four pipes are
     // time-sliced.  The Python package sets GPU_MAX_HW_QUEUES=2 before the runtime starts; a host that does not gets one block.
     const char* q = getenv("GPU_MAX_HW_QUEUES");
-    if (!q || atoi(q) < 1 || atoi(q) > 2) return 1;
+    // (1: the blocks' main streams would share one queue and their direct-space streams the other -- 12.2 it/s on the headline against
+    // 18.7; 3: the four streams still get a queue each, 18.7; profiles/r06_45 call 49)
+    if (!q || atoi(q) < 2 || atoi(q) > 3) return 1;
     // (two blocks from 6 replicas on: alanine dipeptide R = 4 / 6 / 8 / 12 -> +2 / +7 / +11 / +15 % against one block, R = 2 -> -18 %; 8 x CB7:B2
     // +2 %; profiles/r06_45.  Until the blocks got their own rules for the mesh-column bins and the work-item order the bound was 16.)
     return h->R >= 6 ? 2 : 1;

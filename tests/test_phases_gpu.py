@@ -43,7 +43,7 @@ def test_a_sampler_on_two_phases_is_the_sampler_on_one_block(hip_engine_factory)
 
 def test_phases_by_rule_follow_the_hardware_queue_limit(hip_engine_factory, monkeypatch):
     """By rule (remd_set_phases(0), the default) a handle runs two blocks only when the process keeps its streams on few hardware queues
-    (GPU_MAX_HW_QUEUES <= 2, set by the package before the HIP runtime starts) and holds 6 replicas or more; REMD_PHASES=1 pins one
+    (GPU_MAX_HW_QUEUES = 2 (or 3), set by the package before the HIP runtime starts) and holds 6 replicas or more; REMD_PHASES=1 pins one
     block.  (What the limit buys is in profiles/r06_phases_hw_queues.txt; here only the rule.)"""
     import os
     from openmmtools_amd.system import system_to_desc
@@ -63,7 +63,7 @@ def test_phases_by_rule_follow_the_hardware_queue_limit(hip_engine_factory, monk
         eng.propagate(0)
         return eng.phases_active()
     assert phases_of(16, {'GPU_MAX_HW_QUEUES': '2'}) == 2
-    assert phases_of(16, {}) == 1 and phases_of(16, {'GPU_MAX_HW_QUEUES': '4'}) == 1
+    assert phases_of(16, {}) == 1 and phases_of(16, {'GPU_MAX_HW_QUEUES': '4'}) == 1 and phases_of(16, {'GPU_MAX_HW_QUEUES': '1'}) == 1
     assert phases_of(8, {'GPU_MAX_HW_QUEUES': '2'}) == 2 and phases_of(4, {'GPU_MAX_HW_QUEUES': '2'}) == 1
     assert phases_of(16, {'GPU_MAX_HW_QUEUES': '2', 'REMD_PHASES': '1'}) == 1
 
