@@ -1681,6 +1681,12 @@ int remd_build_nonbonded(remd_ctx* h, const remd_system_desc* d)
         // 106.55 ms per 500 steps on the headline config), 12 elsewhere (LJ fluid, one workgroup per item: 66.6 vs 63.3 it/s).
         // Fixed per system, never per launch mode: the slices' fp32 partial sums enter the forces bit-wise.
         t.sci_split = (t.method == NB_EWALD && h->overlap && h->stream2) ? 8 : 12;
+        // (round 6, last scan: systems of 64 tiles or more have work items enough without the finer slicing -- 4 slices: 8 x CB7:B2 (71 tiles)
+        // 13.81 -> 14.65 it/s, 16 x DHFR (369) 2.25 -> 2.31, DHFR on an alchemical ladder 1.92 -> 2.04; the headline system (36 tiles) loses
+        // 10 % with 4; profiles/r06_45.  A property of the system, not of the replica count: blocks and one-block runs stay bit-identical.)
+        // (the plain kernel on CB7:B2 -- the general alchemical path, whose pair kernels see the environment only -- loses 2 % with 4: 13.3 -> 13.0;
+        // so from 64 tiles on for the soft-core variant, from 256 on for the plain one)
+        if (t.method == NB_EWALD && h->overlap && h->stream2 && (h->N + 63) / 64 >= (d->n_alch > 0 ? 64 : 256)) t.sci_split = 4;
         if (getenv("REMD_NB_SPLIT")) t.sci_split = std::max(4, atoi(getenv("REMD_NB_SPLIT")));      // experiment hook
         // the ranking of the sort is G comparisons per molecule on ONE workgroup per replica (0.9 ms on DHFR's 7 k molecules): from 2048
         // molecules on it runs every 160 evaluations instead of every 40 (the order decays slowly: 0.893 -> 0.868 ms per step on 16 x DHFR,
