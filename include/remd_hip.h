@@ -339,7 +339,7 @@ int  remd_seed(remd_handle h, uint64_t seed);
    one dependent thing after another) runs beside the pair and mesh kernels of the other.  Replicas are independent between two mixes
    (multistatesampler.py:1296-1297; the reference propagates them one after the other or one per MPI rank), and every per-replica result
    is the one-block result bit for bit (fixed-point force sums, Philox streams keyed by the global replica, the same schedule of spatial
-   re-sorts).  n: 0 = by rule (two blocks when the environment variable GPU_MAX_HW_QUEUES is 2 or 3 and the handle holds 6 replicas or
+   re-sorts).  n: 0 = by rule (two blocks when the environment variable GPU_MAX_HW_QUEUES is 2 or 3, a propagation is 16 MD steps or more and the handle holds 6 replicas or
    more: HIP's default of 4 queues per priority gives the second block's main stream a FIFTH hardware queue, and queues beyond the four
    pipes of the chip are time-sliced -- two blocks then run 55 % slower than one instead of 10 % faster), 1 = one block, 2 = two blocks.
    Only PME systems under a plain V / R / O splitting without barostat, work measurement or Metropolization run as phases; everything

@@ -601,6 +601,10 @@ static int phases_for(remd_ctx* h)
     if (!q || atoi(q) < 2 || atoi(q) > 3) return 1;
     // (two blocks from 6 replicas on: alanine dipeptide R = 4 / 6 / 8 / 12 -> +2 / +7 / +11 / +15 % against one block, R = 2 -> -18 %; 8 x CB7:B2
     // +2 %; profiles/r06_45.  Until the blocks got their own rules for the mesh-column bins and the work-item order the bound was 16.)
+    // (setting the blocks up for a call -- two stream synchronisations, the replicas copied in and out -- costs ~0.2 ms: short propagations
+    // stay in one block; 24 x alanine dipeptide, ms per call one block / two blocks: 1 step 0.32 / 0.54, 5: 0.87 / 1.06, 20: 3.00 / 2.79,
+    // 50: 6.75 / 5.49; profiles/r06_45 call 59)
+    if (h->n_steps < 16) return 1;
     return h->R >= 6 ? 2 : 1;
 }
 

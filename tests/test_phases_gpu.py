@@ -43,7 +43,7 @@ def test_a_sampler_on_two_phases_is_the_sampler_on_one_block(hip_engine_factory)
 
 def test_phases_by_rule_follow_the_hardware_queue_limit(hip_engine_factory, monkeypatch):
     """By rule (remd_set_phases(0), the default) a handle runs two blocks only when the process keeps its streams on few hardware queues
-    (GPU_MAX_HW_QUEUES = 2 (or 3), set by the package before the HIP runtime starts) and holds 6 replicas or more; REMD_PHASES=1 pins one
+    (GPU_MAX_HW_QUEUES = 2 (or 3), set by the package before the HIP runtime starts) and holds 6 replicas or more for 16 MD steps or more; REMD_PHASES=1 pins one
     block.  (What the limit buys is in profiles/r06_phases_hw_queues.txt; here only the rule.)"""
     import os
     from openmmtools_amd.system import system_to_desc
@@ -51,14 +51,14 @@ def test_phases_by_rule_follow_the_hardware_queue_limit(hip_engine_factory, monk
     desc = system_to_desc(al.system, ewald_split='auto')
     box = np.diag(al.system.getDefaultPeriodicBoxVectors())
 
-    def phases_of(R, env):
+    def phases_of(R, env, n_steps=16):
         for k in ('GPU_MAX_HW_QUEUES', 'REMD_PHASES'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = hip_engine_factory()
         eng.set_system(desc); eng.set_states(np.full(R, 1.0 / (0.008314462618153242 * 300.0)))
-        eng.set_integrator('V R R O R R V', 0.002, 1.0, 2, True, 1e-8)
+        eng.set_integrator('V R R O R R V', 0.002, 1.0, n_steps, True, 1e-8)
         eng.set_replicas(R, 0, np.tile(al.positions, (R, 1, 1)), None, np.tile(box, (R, 1)), np.arange(R))
         eng.propagate(0)
         return eng.phases_active()
@@ -66,6 +66,7 @@ def test_phases_by_rule_follow_the_hardware_queue_limit(hip_engine_factory, monk
     assert phases_of(16, {}) == 1 and phases_of(16, {'GPU_MAX_HW_QUEUES': '4'}) == 1 and phases_of(16, {'GPU_MAX_HW_QUEUES': '1'}) == 1
     assert phases_of(8, {'GPU_MAX_HW_QUEUES': '2'}) == 2 and phases_of(4, {'GPU_MAX_HW_QUEUES': '2'}) == 1
     assert phases_of(16, {'GPU_MAX_HW_QUEUES': '2', 'REMD_PHASES': '1'}) == 1
+    assert phases_of(16, {'GPU_MAX_HW_QUEUES': '2'}, n_steps=8) == 1              # (short propagations: the set-up of the blocks costs more than they save)
 
 
 def test_a_monte_carlo_barostat_in_two_phases_is_the_barostat_in_one_block(hip_engine_factory):
